@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of the YOLOX-s 640x640 training step (forward + SimOTA/loss + backward +
+gradient all-reduce + SGD update), bs=16/GPU, synthetic COCO-shaped data, on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (see BASELINE.json for the metric).  `roofline` describes the dominant
+kernel (the conv_igemm instantiation with the largest total time per step), `cpu_baseline` the oracle
+(CPU fp32 restatement of the reference path) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def synth_batch_device(B, H, W, seed, device, max_labels=100, num_classes=80, max_gt=20):
+    """COCO-shaped synthetic batch: images U{0..255}, n_gt ~ U{1..20}, w,h ~ U[16,272]"""
+    g = torch.Generator().manual_seed(seed)
+    images = torch.randint(0, 256, (B, 3, H, W), generator=g).float()
+    labels = torch.zeros(B, max_labels, 5)
+    for b in range(B):
+        n = int(torch.randint(1, max_gt + 1, (1,), generator=g))
+        wh = 16 + torch.rand(n, 2, generator=g) * (272 - 16)
+        cx = wh[:, 0] / 2 + torch.rand(n, generator=g) * (W - wh[:, 0])
+        cy = wh[:, 1] / 2 + torch.rand(n, generator=g) * (H - wh[:, 1])
+        labels[b, :n, 0] = torch.randint(0, num_classes, (n,), generator=g).float()
+        labels[b, :n, 1], labels[b, :n, 2] = cx, cy
+        labels[b, :n, 3:5] = wh
+    return images.to(device), labels.to(device)
+
+
+def conv_algorithmic(d):
+    """algorithmic bytes / flops of one conv_igemm launch from its descriptor (each tensor touched once)"""
+    K = d.K8 * 8
+    npix_out = d.N * d.gridH * d.gridW
+    in_pix = d.N * d.H * d.W if d.out_stride == 1 else d.N * d.H * d.W  # dgrad-s2 classes read all of dy
+    out_bytes = npix_out * d.Cout * (4 if d.flags & 2 else 2) * (2 if d.flags & 1 else 1)
+    byt = in_pix * K * 2 + out_bytes + d.ntaps * K * d.CoutPad * 2
+    flops = 2.0 * npix_out * d.Cout * K * d.ntaps
+    return byt, flops
+
+
+def roofline_block(plan, iters=5):
+    from yolov7_d2_amd import _lib as L
+    groups = {}
+    for which in ("fwd", "bwd"):
+        tot, per = plan.time_cmds(which, iters=iters)
+        descs = plan.cmd_descs[which]
+        arr, n = plan.fwd_cmds if which == "fwd" else plan.bwd_cmds
+        for k in range(n):
+            op = L.OPS[arr[k].op]
+            ms = per[k][1]
+            if op == "CONV":
+                d = descs[k]
+                dd = L.mi_conv_desc.from_buffer_copy(d)
+                L.lib().mi_conv2d_plan(C.byref(dd))
+                name = f"conv_igemm_kernel<KC={dd.KC},BN={dd.BN}>"
+                byt, fl = conv_algorithmic(d)
+            elif op == "WGRAD":
+                d = descs[k]
+                name = f"conv_wgrad_kernel<NT={d.ntaps},BCI={32 if d.CinPad % 32 == 0 else 16}>"
+                npx = d.N * d.outH * d.outW
+                byt = d.N * d.H * d.W * d.CinPad * 2 + npx * d.CoutPad * 2 + d.ntaps * d.CoutPad * d.CinPad * 4
+                fl = 2.0 * npx * d.CoutPad * d.CinPad * d.ntaps
+            else:
+                name, byt, fl = op, 0, 0
+            g = groups.setdefault(name, dict(ms=0.0, launches=0, bytes=0.0, flops=0.0))
+            g["ms"] += ms; g["launches"] += 1; g["bytes"] += byt; g["flops"] += fl
+    total_ms = sum(g["ms"] for g in groups.values())
+    convs = {k: v for k, v in groups.items() if k.startswith("conv_")}
+    name, g = max(convs.items(), key=lambda kv: kv[1]["ms"])
+    avg_ms = g["ms"] / g["launches"]
+    gbs = g["bytes"] / g["launches"] / (avg_ms * 1e-3) / 1e9
+    tfs = g["flops"] / g["launches"] / (avg_ms * 1e-3) / 1e12
+    rl = dict(bound="hbm", kernel=name, achieved=round(gbs, 1), peak=8000.0, unit="GB/s", frac=round(gbs / 8000.0, 4),
+              traffic=None, avg_launch_ms=round(avg_ms, 5), launches_per_step=g["launches"],
+              algorithmic_bytes_per_launch=int(g["bytes"] / g["launches"]), mfma_tflops=round(tfs, 1),
+              mfma_frac_of_2500=round(tfs / 2500.0, 4), share_of_step_kernel_time=round(g["ms"] / total_ms, 3))
+    breakdown = {k: dict(ms=round(v["ms"], 4), launches=v["launches"],
+                         GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] and v["ms"] > 0 else None,
+                         TFLOPs=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] and v["ms"] > 0 else None)
+                 for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}
+    return rl, breakdown, total_ms
+
+
+def cpu_baseline(batch=2, size=640, steps=2):
+    """the oracle (port of the reference CPU path) on this box's host cores: fwd + loss + bwd + SGD, fp32"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import yolox_oracle as O
+    torch.set_num_threads(os.cpu_count())
+    sd = O.init_state_dict(0.33, 0.5, 80, seed=0)
+    params = [v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k]
+    opt = torch.optim.SGD(params, lr=0.01, momentum=0.9, weight_decay=1e-4)
+    imgs, labels = O.synth_batch(batch, size, size, seed=1234)
+    ts = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        res = O.train_step_losses(sd, imgs, labels)
+        opt.zero_grad()
+        (res[0] + res[1] + res[2] + res[3]).backward()
+        opt.step()
+        ts.append(time.perf_counter() - t0)
+    t = sorted(ts[1:])[len(ts[1:]) // 2]
+    return dict(value=round(batch / t, 3), unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                sample=f"{steps} timed steps (median) after 1 warm-up of B={batch} {size}x{size} fp32 fwd+loss+bwd+SGD "
+                       f"through oracle/yolox_oracle.py (CPU restatement of the reference path)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", type=str, default="", help="write the per-kernel-class breakdown JSON here")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+
+    import yolov7_d2_amd as M
+    from yolov7_d2_amd.engine import NativeTrainer
+
+    torch.manual_seed(0)
+    model = M.build_model(M.yolox_s_cfg(device=f"cuda:{local}"))
+    trainer = NativeTrainer(model, lr=0.01 / 64 * args.batch * world, use_graph=not args.no_graph)
+    imgs, labels = synth_batch_device(args.batch, args.size, args.size, 1234 + rank, dev)
+    st = trainer.load_batch(imgs, labels)
+
+    for _ in range(max(args.warmup, 2)):   # >= 2: eager warm-up, then graph capture
+        trainer.step(st)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(st)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    losses = trainer.losses(st)[:4].tolist()
+    ms = dt / args.steps * 1e3
+    value = args.batch * world * args.steps / dt
+
+    if rank == 0:
+        rl, breakdown, kernel_ms = roofline_block(st["plan"])
+        out = {
+            "metric": "images/sec training, YOLOX-s 640x640 bs=16/GPU", "value": round(value, 2),
+            "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"YOLOX-s CSPDarknet+PAFPN {args.size}x{args.size} bs={args.batch}/GPU: fwd + SimOTA "
+                                   "loss + bwd + grad all-reduce + SGD(momentum) step, inputs resident in HBM",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "hipgraph": not args.no_graph, "sum_kernel_ms_per_step": round(kernel_ms, 3),
+                       "final_losses": [round(x, 4) for x in losses]},
+            "roofline": rl,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        if args.breakdown:
+            with open(args.breakdown, "w") as f:
+                json.dump(breakdown, f, indent=1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

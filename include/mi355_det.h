@@ -1,0 +1,269 @@
+/*
+ * mi355_det.h — C-ABI of libmi355det.so: the MI355X (gfx950) hot path of
+ * yolov7_d2's YOLOX data-parallel training step.
+ *
+ * Every entry point is `extern "C"`, takes plain device pointers + sizes and a
+ * hipStream_t (passed as void*), never allocates, frees or synchronises, and
+ * returns 0 on success or a negative MI_E* code for an argument error detected
+ * BEFORE any launch.  The caller (PyTorch caching allocator, or any other
+ * runtime) owns every buffer including workspaces.
+ *
+ * Each function names the reference interface it replaces (file:line relative
+ * to lucasjinreal/yolov7_d2).  The reference has no native code of its own on
+ * this path: these replace the ATen/cuDNN/torchvision calls the reference
+ * reaches through torch.
+ *
+ * Layout conventions
+ *   activations : bf16, NHWC ("channels_last"); a tensor is (ptr, ld) where ld is
+ *                 the element stride between consecutive pixels, so a channel
+ *                 slice of a concat buffer is just (ptr + c0, ld_of_buffer).
+ *   conv weights: fp32 OIHW masters (the nn.Parameter layout of the reference);
+ *                 mi_pack_conv_weight() produces the bf16 k8-major images the
+ *                 conv kernels read: [tap][K/8][CoutPad][8].
+ *   head preds  : fp32 [B][A][5+ncls] exactly as yolox_head.py:238-241 flattens.
+ */
+#ifndef MI355_DET_H
+#define MI355_DET_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_OK 0
+#define MI_EINVAL (-1)   /* bad argument (shape / alignment / unsupported config) */
+#define MI_ELAUNCH (-2)  /* hipGetLastError() != success after a launch          */
+#define MI_ENODEV (-3)   /* no HIP device                                          */
+
+typedef void* mi_stream_t; /* hipStream_t */
+
+/* ---- library ---------------------------------------------------------- */
+int mi_version(void);
+/* number of visible HIP devices (0 => every compute entry returns MI_ENODEV) */
+int mi_device_count(void);
+const char* mi_last_error(void);
+
+/* ---- convolution (implicit GEMM on MFMA, im2col-free, LDS halo tile) ---
+ * replaces nn.Conv2d fwd/dgrad inside BaseConv (layers/wrappers.py:60-83) and
+ * the biased 1x1 prediction convs (head/yolox_head.py:103-129).
+ * One descriptor covers: 1x1, 3x3 s1, 3x3 s2 forward; their data gradients
+ * (s2 dgrad = 4 parity-class launches with out_stride 2) via the tap table. */
+#define MI_CONV_ACCUM 1    /* y += result (gradient fan-in)                  */
+#define MI_CONV_OUT_F32 2  /* y is fp32 (prediction maps), else bf16         */
+#define MI_MAX_TAPS 9
+
+typedef struct mi_conv_desc {
+  const void* x;   /* bf16 NHWC input view, >= K8*8 channels readable        */
+  const void* w;   /* packed bf16 [n_wslabs][K8][CoutPad][8]                  */
+  void* y;         /* output view                                             */
+  const float* bias;    /* [Cout] or NULL                                     */
+  float* stats_partial; /* [n_pixel_tiles][CoutPad][2] (sum, sumsq) or NULL   */
+  int32_t ldx, ldy;
+  int32_t y_nstride;        /* elements between images of y; 0 => outH*outW*ldy */
+  int32_t N, H, W;          /* input dims                                     */
+  int32_t outH, outW;       /* real output tensor dims                        */
+  int32_t gridH, gridW;     /* output sub-grid iterated (==outH,outW if out_stride==1) */
+  int32_t in_stride;        /* input pixel  = grid*in_stride  + tap offset    */
+  int32_t out_stride, out_oy, out_ox; /* output pixel = grid*out_stride + off */
+  int32_t K8;               /* padded input channels / 8                      */
+  int32_t Cout, CoutPad;
+  int32_t ntaps;
+  int32_t tap_dy[MI_MAX_TAPS], tap_dx[MI_MAX_TAPS], tap_w[MI_MAX_TAPS];
+  int32_t flags;
+  int32_t TH, TW;           /* pixel tile; 0 => chosen by the launcher        */
+  int32_t KC, BN;           /* k-chunk / cout tile; 0 => chosen by launcher   */
+} mi_conv_desc;
+
+int mi_conv2d(const mi_conv_desc* d, mi_stream_t s);
+/* fills TH/TW/KC/BN if zero; returns number of pixel tiles (rows of stats_partial) or <0 */
+int mi_conv2d_plan(mi_conv_desc* d);
+
+/* weight gradient: gw[tap][CoutPad][CinPad] (fp32, atomically accumulated — zero it first)
+ * += sum_pixels dy[p][co] * x[p*stride + tap][ci].  replaces conv wgrad of the same modules. */
+typedef struct mi_wgrad_desc {
+  const void* x;  /* bf16 NHWC input view  (CinPad channels readable)        */
+  const void* dy; /* bf16 NHWC out-grad view (CoutPad channels readable)     */
+  float* gw;      /* fp32 [ntaps][CoutPad][CinPad]                            */
+  int32_t ldx, ldy;
+  int32_t N, H, W, outH, outW;
+  int32_t stride;
+  int32_t CinPad, CoutPad;
+  int32_t ntaps;
+  int32_t tap_dy[MI_MAX_TAPS], tap_dx[MI_MAX_TAPS];
+  int32_t TH, TW, splitk; /* 0 => chosen by launcher */
+} mi_wgrad_desc;
+int mi_conv2d_wgrad(const mi_wgrad_desc* d, mi_stream_t s);
+
+/* OIHW fp32 master -> packed bf16 images.  wf: forward [KH*KW][CinPad/8][CoutPad][8];
+ * wd: dgrad  [KH*KW][CoutPadK/8][CinPadN][8] (roles swapped).  Either may be NULL. */
+int mi_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW,
+                        void* wf, int CinPad, int CoutPad,
+                        void* wd, int CoutPadK, int CinPadN, mi_stream_t s);
+/* packed fp32 grad [taps][CoutPad][CinPad] -> OIHW fp32 grad (overwrite or accumulate) */
+int mi_unpack_conv_wgrad(const float* gw, int Cout, int Cin, int KH, int KW,
+                         int CoutPad, int CinPad, float* g_oihw, int accumulate, mi_stream_t s);
+
+/* ---- BatchNorm(train) + SiLU (+ residual) -----------------------------
+ * replaces nn.BatchNorm2d + nn.SiLU of BaseConv (wrappers.py:76-80) and the
+ * Bottleneck add (wrappers.py:119-123). */
+/* reduce conv-epilogue partials -> batch mean/var; writes scale/shift/mean/invstd [C];
+ * updates running stats exactly as nn.BatchNorm2d (momentum, unbiased running var). */
+int mi_bn_finalize(const float* partial, int ntiles, int C, int CPad, int64_t count,
+                   const float* gamma, const float* beta, float eps, float momentum,
+                   float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                   float* scale, float* shift, float* mean, float* invstd, mi_stream_t s);
+/* eval mode: scale/shift from running statistics */
+int mi_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, int C, float* scale, float* shift,
+                      mi_stream_t s);
+/* a = silu(y*scale+shift) (+res)  ; act: 1 silu, 0 identity */
+int mi_bn_act_fwd(const void* y, int ldy, const float* scale, const float* shift,
+                  const void* res, int ldres, void* a, int lda, int64_t npix, int C, int act,
+                  mi_stream_t s);
+/* pass 1: per-channel partial sums of dz and dz*xhat over pixels -> partial[nblk][C][2] */
+int mi_bn_act_bwd_reduce(const void* da, int ldda, const void* y, int ldy, const float* scale,
+                         const float* shift, const float* mean, const float* invstd,
+                         float* partial, int nblk, int64_t npix, int C, int act, mi_stream_t s);
+/* combine partials: dgamma/dbeta (overwrite) and the two correction terms c1,c2 [C] */
+int mi_bn_bwd_finalize(const float* partial, int nblk, int C, int64_t count, float* dgamma,
+                       float* dbeta, float* c1, float* c2, mi_stream_t s);
+/* pass 2: dy = gamma*invstd*(dz - c1 - xhat*c2); optional dres (+)= da */
+int mi_bn_act_bwd_apply(const void* da, int ldda, const void* y, int ldy, const float* scale,
+                        const float* shift, const float* mean, const float* invstd,
+                        const float* gamma, const float* c1, const float* c2, void* dy, int lddy,
+                        void* dres, int lddres, int dres_accum, int64_t npix, int C, int act,
+                        mi_stream_t s);
+
+/* ---- data movement ops -------------------------------------------------- */
+/* Focus space-to-depth (wrappers.py:202-220) fused with fp32 NCHW -> bf16 NHWC and 12->16 ch pad */
+int mi_focus_pack(const float* img_nchw, int N, int H, int W, void* out, int ldo, mi_stream_t s);
+/* nn.Upsample(2,"nearest") (yolo_pafpn.py:28) into a concat slice, and its gradient */
+int mi_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C,
+                      mi_stream_t s);
+int mi_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, int accumulate, int N, int H,
+                      int W, int C, mi_stream_t s);
+/* SPP max-pools k=5,9,13 s1 (wrappers.py:150-153): three outputs + argmax codes */
+int mi_spp_pool_fwd(const void* x, int ldx, void* y5, void* y9, void* y13, int ldy, uint8_t* idx,
+                    int N, int H, int W, int C, mi_stream_t s);
+int mi_spp_pool_bwd(const void* dy5, const void* dy9, const void* dy13, int lddy,
+                    const uint8_t* idx, void* dx, int lddx, int accumulate, int N, int H, int W,
+                    int C, mi_stream_t s);
+/* generic strided bf16 NHWC copy / accumulate (dst (+)= src) */
+int mi_copy_bf16(const void* src, int lds_, void* dst, int ldd, int accumulate, int64_t npix, int C,
+                 mi_stream_t s);
+/* column sums of a bf16 NHWC view -> fp32 [C] (bias gradient of the prediction convs) */
+int mi_colsum_bf16(const void* x, int ldx, int64_t npix, int C, float* out, int accumulate,
+                   mi_stream_t s);
+
+/* ---- YOLOX head: decode + SimOTA + losses ---------------------------------
+ * replaces YOLOXHead.get_output_and_grid / get_losses / get_assignments /
+ * get_in_boxes_info / dynamic_k_matching (head/yolox_head.py:226-669),
+ * bboxes_iou and IOUloss (utils/boxes.py:57-81,125-168). */
+typedef struct mi_yolox_loss_desc {
+  const float* preds;   /* [B][A][5+ncls] raw head outputs (xy,wh undecoded; logits)        */
+  const float* labels;  /* [B][max_labels][5] (cls,cx,cy,w,h), zero rows = padding          */
+  const float* anchors; /* [A][3] (grid_x, grid_y, stride)                                   */
+  int32_t B, A, ncls, max_labels;
+  int32_t gmax;         /* upper bound on valid labels per image (<= max_labels)             */
+  /* workspaces (caller-owned) */
+  float* cost;          /* [B][gmax][A]                                                       */
+  float* iou;           /* [B][gmax][A]                                                       */
+  uint8_t* match;       /* [B][gmax][A]                                                       */
+  int32_t* ngt;         /* [B]                                                                */
+  /* assignment outputs */
+  uint8_t* fg;          /* [B][A] final foreground mask                                       */
+  int32_t* matched_gt;  /* [B][A] index of matched gt or -1                                   */
+  float* matched_iou;   /* [B][A]                                                             */
+  float* partial;       /* [nblk][4] block partial sums (iou, obj, cls, nfg); nblk = B*ceil(A/256) */
+  float* out;           /* [8]: total, 5*iou, obj, cls, l1(0), num_fg/num_gt, num_fg, num_gt */
+} mi_yolox_loss_desc;
+int mi_yolox_loss_fwd(const mi_yolox_loss_desc* d, mi_stream_t s);
+/* gradient wrt raw preds; gw[4] = upstream grads of (total, 5*iou, obj, cls) on device.
+ * dpreds fp32 [B][A][5+ncls] and/or bf16 per-level NHWC maps (see plan builder). */
+int mi_yolox_loss_bwd(const mi_yolox_loss_desc* d, const float* gw, float* dpreds, mi_stream_t s);
+/* extract channels [c0, c0+nc) of dpreds fp32 [B][A][nch] for anchors a0..a0+HW into a bf16
+ * NHWC map dst [B][HW][ld] (channels >= nc zero-filled): the out-gradient of one prediction conv. */
+int mi_yolox_split_dpreds(const float* dpreds, int B, int A, int nch, int a0, int HW, int c0, int nc,
+                          void* dst, int ld, mi_stream_t s);
+/* eval decode (yolox_head.py:247-272): in-place on preds; obj/cls sigmoid applied */
+int mi_yolox_decode(float* preds, const float* anchors, int B, int A, int ncls, mi_stream_t s);
+
+/* ---- batched NMS -------------------------------------------------------------
+ * replaces torchvision.ops.batched_nms as called by postprocess (utils/boxes.py:199).
+ * boxes xyxy fp32 [n][4], scores [n], idxs (class id as float, as the reference passes) [n].
+ * keep[n] receives the kept indices in descending score order, *n_keep their count.
+ * workspaces: order int32[n], mask uint64[n*ceil(n/64)], sboxes float[5*n+1]. */
+int mi_batched_nms(const float* boxes, const float* scores, const float* idxs, int n, float iou_thr,
+                   int32_t* order, uint64_t* mask, float* sboxes, int64_t* keep, int32_t* n_keep,
+                   mi_stream_t s);
+
+/* ---- fused SGD(momentum, weight-decay) over a flat parameter arena -----------
+ * replaces torch.optim.SGD.step as built by detectron2's build_optimizer
+ * (train_det.py:73 -> DefaultTrainer). seg table: per segment (offset,count,wd,lr) */
+typedef struct mi_sgd_seg {
+  int64_t offset, count;
+  float weight_decay, lr;
+} mi_sgd_seg;
+int mi_sgd_momentum_step(float* params, const float* grads, float* momentum_buf,
+                         const mi_sgd_seg* segs_dev, int nseg, float momentum, float grad_scale,
+                         int first_step, mi_stream_t s);
+
+/* ---- command list executor -----------------------------------------------------
+ * A step (forward / backward / update) is a flat list of mi_cmd records built once
+ * by the host; mi_cmdlist_run() issues them back-to-back on one stream from C++
+ * (no per-launch Python), and mi_graph_* capture/replay the same list as a hipGraph. */
+typedef struct mi_cmd {
+  int32_t op;          /* MI_OP_* */
+  int32_t i[40];
+  float f[8];
+  void* p[12];
+  int64_t l[4];
+} mi_cmd;
+
+enum {
+  MI_OP_NOP = 0,
+  MI_OP_CONV = 1,
+  MI_OP_WGRAD = 2,
+  MI_OP_PACK_W = 3,
+  MI_OP_UNPACK_WG = 4,
+  MI_OP_BN_FINALIZE = 5,
+  MI_OP_BN_ACT_FWD = 6,
+  MI_OP_BN_BWD_REDUCE = 7,
+  MI_OP_BN_BWD_FINALIZE = 8,
+  MI_OP_BN_BWD_APPLY = 9,
+  MI_OP_FOCUS = 10,
+  MI_OP_UPSAMPLE_FWD = 11,
+  MI_OP_UPSAMPLE_BWD = 12,
+  MI_OP_SPP_FWD = 13,
+  MI_OP_SPP_BWD = 14,
+  MI_OP_COPY = 15,
+  MI_OP_COLSUM = 16,
+  MI_OP_LOSS_FWD = 17,
+  MI_OP_LOSS_BWD = 18,
+  MI_OP_SPLIT_DPREDS = 19,
+  MI_OP_MEMSET = 20,
+  MI_OP_SGD = 21,
+  MI_OP_BN_EVAL_AFFINE = 22,
+  MI_OP_DECODE = 23,
+  MI_OP_COUNT
+};
+
+int mi_cmdlist_run(const mi_cmd* cmds, int n, mi_stream_t s);
+/* returns an opaque handle (>0) or <0 */
+int64_t mi_graph_capture(const mi_cmd* cmds, int n, mi_stream_t s);
+int mi_graph_launch(int64_t handle, mi_stream_t s);
+int mi_graph_destroy(int64_t handle);
+
+/* time one command list with HIP events on stream s: runs it `iters` times, returns avg ms in *ms;
+ * if per_cmd_ms != NULL (n floats) each command is additionally timed alone (event pair per cmd). */
+int mi_cmdlist_time(const mi_cmd* cmds, int n, int iters, float* ms, float* per_cmd_ms, mi_stream_t s);
+
+/* ---- hardware probes used by tests (lane layouts of MFMA / LDS transpose read) */
+int mi_probe_mfma32(const void* a_bf16_32x16, const void* b_bf16_16x32, float* d_32x32, mi_stream_t s);
+int mi_probe_mfma16(const void* a_bf16_16x32, const void* b_bf16_32x16, float* d_16x16, mi_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_DET_H */

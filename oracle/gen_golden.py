@@ -1,0 +1,118 @@
+"""ORACLE support: generate tests/golden/*.npz by EXECUTING THE REFERENCE'S OWN SOURCE (by path, see
+ref_loader.py) on seeded inputs.  Run in the build container (where /root/reference exists):
+
+    python oracle/gen_golden.py
+
+The vectors pin oracle/yolox_oracle.py (tests/test_oracle_golden.py, CPU) and are the fixed points the
+GPU parity tests are checked against.  Weights and inputs are regenerated from seeds through
+yolox_oracle.init_state_dict / synth_batch (same torch build on the GPU box), so only reference
+OUTPUTS are stored.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_loader  # noqa: E402
+import yolox_oracle as O  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def gold_step():
+    """full training step of the reference on YOLOX-s (depth .33, width .5), B=2, 64x96"""
+    depth, width, nc = 0.33, 0.5, 80
+    ref, r = ref_loader.build_reference_yolox(depth, width, nc, seed=0)
+    sd0 = O.init_state_dict(depth, width, nc, seed=0)
+    ref.load_state_dict(sd0)
+    ref.train()
+    imgs, labels = O.synth_batch(2, 64, 96, seed=11, max_gt=4)
+    out = ref(imgs, labels)
+    loss_dict_sum = out[0] + out[1] + out[2] + out[3]   # detectron2 sums every value of the returned dict (Q1)
+    loss_dict_sum.backward()
+    grads = {k: p.grad.detach().clone() for k, p in ref.named_parameters()}
+    res = dict(losses=np.array([float(x) for x in out], dtype=np.float64))
+    for k in ("head.cls_preds.0.weight", "head.obj_preds.2.bias", "backbone.stem.conv.conv.weight",
+              "backbone.stem.conv.bn.weight", "backbone.dark3.1.m.1.conv2.conv.weight", "neck.C3_p4.conv3.bn.bias",
+              "backbone.dark2.0.conv.weight"):
+        res["grad:" + k] = grads[k].numpy()
+    names = sorted(grads)
+    res["grad_names"] = np.array(names)
+    res["grad_norms"] = np.array([float(grads[k].norm()) for k in names], dtype=np.float64)
+    st = ref.state_dict()
+    res["rm:backbone.stem.conv.bn.running_mean"] = st["backbone.stem.conv.bn.running_mean"].numpy()
+    res["rv:head.stems.1.bn.running_var"] = st["head.stems.1.bn.running_var"].numpy()
+    # eval forward with the (updated) running stats
+    ref.eval()
+    with torch.no_grad():
+        res["eval_out"] = ref(imgs).numpy()
+    np.savez_compressed(os.path.join(OUT, "yolox_s_step_64x96.npz"), **res)
+    print("step:", res["losses"])
+
+
+def gold_simota():
+    """head loss + SimOTA of the reference on synthetic raw predictions, B=3, 160x160 (A=525)"""
+    ref, r = ref_loader.build_reference_yolox(0.33, 0.5, 80, seed=0)
+    head = ref.head
+    head.train()
+    B, H, W = 3, 160, 160
+    _, labels = O.synth_batch(B, H, W, seed=21, max_gt=12)
+    labels[1] = 0.0
+    hw = [(H // s, W // s) for s in (8, 16, 32)]
+    raw, anchors = O.synth_raw(B, hw, 22, labels=labels)
+    raw.requires_grad_(True)
+    # feed the head's loss exactly what YOLOXHead.forward builds (yolox_head.py:175-224)
+    outs, xs, ys, es = [], [], [], []
+    a0 = 0
+    for (h, w), s in zip(hw, (8, 16, 32)):
+        o = (raw * 1.0)[:, a0:a0 + h * w].permute(0, 2, 1).reshape(B, 85, h, w)
+        o, grid = head.get_output_and_grid(o, len(outs), s, torch.zeros(1).type())
+        xs.append(grid[:, :, 0]); ys.append(grid[:, :, 1])
+        es.append(torch.zeros(1, grid.shape[1]).fill_(s))
+        outs.append(o)
+        a0 += h * w
+    res6 = head.get_losses(None, xs, ys, es, labels, torch.cat(outs, 1), [], dtype=torch.float32)
+    (res6[0] + res6[1] + res6[2] + res6[3]).backward()
+    out = dict(losses=np.array([float(x) for x in res6], dtype=np.float64), draw=raw.grad.numpy())
+    # per-image assignment through the reference's get_assignments
+    dec = O.decode(raw.detach(), anchors)
+    bbox, obj, cls = dec[..., :4], dec[..., 4:5], dec[..., 5:]
+    nl = (labels.sum(2) > 0).sum(1)
+    for b in range(B):
+        G = int(nl[b])
+        if G == 0:
+            continue
+        gm, fg, pi, mg, nfg = head.get_assignments(b, G, anchors.shape[0], labels[b, :G, 1:5], labels[b, :G, 0],
+                                                   bbox[b], torch.cat(es, 1), torch.cat(xs, 1), torch.cat(ys, 1),
+                                                   cls, bbox, obj, labels, None)
+        out[f"fg{b}"] = fg.numpy()
+        out[f"matched_gt{b}"] = mg.numpy()
+        out[f"matched_iou{b}"] = pi.numpy()
+        out[f"matched_cls{b}"] = gm.numpy()
+    np.savez_compressed(os.path.join(OUT, "simota_160.npz"), **out)
+    print("simota:", out["losses"])
+
+
+def gold_postprocess():
+    """postprocess (utils/boxes.py:171-210) on synthetic decoded predictions; NMS = torchvision semantics
+    as restated in yolox_oracle (torchvision itself is not installed: parity unpinned for NMS)."""
+    ref, r = ref_loader.build_reference_yolox(0.33, 0.5, 80, seed=0)
+    res = {}
+    for name, n, seed in (("small", 300, 31), ("large", 2500, 32)):
+        pred = O.synth_decoded(2, n, seed)
+        out = r.boxes.postprocess(pred.clone(), 80, 0.3, 0.65)
+        for b, o in enumerate(out):
+            res[f"{name}_out{b}"] = o.numpy() if o is not None else np.zeros((0, 7), np.float32)
+    np.savez_compressed(os.path.join(OUT, "postprocess.npz"), **res)
+    print("postprocess:", {k: v.shape for k, v in res.items() if "out" in k})
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    gold_step()
+    gold_simota()
+    gold_postprocess()

@@ -1,0 +1,132 @@
+"""ORACLE support (test infrastructure): import the reference's OWN hot-path source files by path.
+
+Works only where /root/reference exists (this container, not the GPU box).  The reference package
+cannot be imported normally (yolov7/__init__.py pulls detectron2, timm, alfred, torchvision ... none of
+which are installed), so the un-installed third-party names are stubbed and the hot-path files are
+loaded as sub-modules of namespace packages whose __init__.py is NOT executed.
+Used by oracle/gen_golden.py to pin oracle/yolox_oracle.py and to produce tests/golden/*.
+"""
+import importlib
+import os
+import sys
+import types
+
+REF = os.environ.get("MI355_REFERENCE", "/root/reference")
+
+
+def available():
+    return os.path.isdir(os.path.join(REF, "yolov7"))
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def load():
+    """returns a namespace with the reference classes/functions of the YOLOX path"""
+    if not available():
+        raise RuntimeError(f"reference not found under {REF}")
+    import torch
+    from torch import nn
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    if here not in sys.path:
+        sys.path.insert(0, here)
+    import yolox_oracle as oracle  # our torchvision-semantics NMS backs the torchvision stub
+
+    class Registry(dict):
+        def register(self, obj=None):
+            if obj is None:
+                return lambda o: self.register(o)
+            self[obj.__name__] = obj
+            return obj
+
+    class Backbone(nn.Module):
+        size_divisibility = 0
+
+    class ShapeSpec:
+        def __init__(self, channels=None, height=None, width=None, stride=None):
+            self.channels, self.height, self.width, self.stride = channels, height, width, stride
+
+    if "detectron2" not in sys.modules:
+        _stub("detectron2")
+        _stub("detectron2.layers", ShapeSpec=ShapeSpec)
+        _stub("detectron2.layers.batch_norm", get_norm=lambda *a, **k: None)
+        _stub("detectron2.modeling", META_ARCH_REGISTRY=Registry(), BACKBONE_REGISTRY=Registry(), Backbone=Backbone)
+        _stub("detectron2.modeling.backbone", Backbone=Backbone, BACKBONE_REGISTRY=sys.modules["detectron2.modeling"].BACKBONE_REGISTRY)
+        _stub("detectron2.modeling.backbone.build", BACKBONE_REGISTRY=sys.modules["detectron2.modeling"].BACKBONE_REGISTRY)
+        _stub("detectron2.utils")
+        _stub("detectron2.utils.comm")
+    if "loguru" not in sys.modules:
+        class _Logger:
+            def __getattr__(self, k):
+                return lambda *a, **kw: None
+        _stub("loguru", logger=_Logger())
+    if "omegaconf" not in sys.modules:
+        _stub("omegaconf")
+        _stub("omegaconf.base")
+    if "torchvision" not in sys.modules:
+        tv = _stub("torchvision", __version__="0.12.0", _is_tracing=lambda: False)
+        ops = _stub("torchvision.ops", nms=oracle.nms, batched_nms=oracle.batched_nms)
+        _stub("torchvision.ops.boxes", nms=oracle.nms,
+              box_area=lambda b: (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))
+        tv.ops = ops
+        _stub("torchvision.models")
+        _stub("torchvision.models._utils", IntermediateLayerGetter=object)
+    if "cv2" not in sys.modules:
+        _stub("cv2")
+    if "pycocotools" not in sys.modules:
+        _stub("pycocotools")
+        _stub("pycocotools.mask")
+
+    def ns(name, path):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [path]
+            sys.modules[name] = m
+
+    y = os.path.join(REF, "yolov7")
+    ns("yolov7", y)
+    ns("yolov7.utils", os.path.join(y, "utils"))
+    ns("yolov7.modeling", os.path.join(y, "modeling"))
+    ns("yolov7.modeling.backbone", os.path.join(y, "modeling", "backbone"))
+    ns("yolov7.modeling.backbone.layers", os.path.join(y, "modeling", "backbone", "layers"))
+    ns("yolov7.modeling.neck", os.path.join(y, "modeling", "neck"))
+    ns("yolov7.modeling.head", os.path.join(y, "modeling", "head"))
+    out = types.SimpleNamespace()
+    out.wrappers = importlib.import_module("yolov7.modeling.backbone.layers.wrappers")
+    out.boxes = importlib.import_module("yolov7.utils.boxes")
+    out.darknetx = importlib.import_module("yolov7.modeling.backbone.darknetx")
+    out.pafpn = importlib.import_module("yolov7.modeling.neck.yolo_pafpn")
+    out.head = importlib.import_module("yolov7.modeling.head.yolox_head")
+    return out
+
+
+def build_reference_yolox(depth=0.33, width=0.5, num_classes=80, seed=0):
+    """CSPDarknet + YOLOPAFPN + YOLOXHead assembled the way YOLOX.__init__ does (yolox.py:60-83)"""
+    import torch
+    from torch import nn
+    r = load()
+    torch.manual_seed(seed)
+
+    class RefYOLOX(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = r.darknetx.CSPDarknet(depth, width)
+            self.neck = r.pafpn.YOLOPAFPN(depth=depth, width=width)
+            self.head = r.head.YOLOXHead(num_classes, width=width)
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eps, m.momentum = 1e-3, 0.03
+            self.head.initialize_biases(1e-2)
+
+        def forward(self, x, labels=None):
+            f = self.neck(self.backbone(x))
+            if self.training:
+                return self.head(f, labels, x)
+            return self.head(f)
+
+    return RefYOLOX(), r

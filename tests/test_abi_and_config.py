@@ -1,0 +1,110 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mi355_det.h declares; argument errors are
+returned (not raised, not launched); the reference-shaped config / registry surface works; the product path fails
+loudly without a HIP device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+import yolov7_d2_amd as M
+from yolov7_d2_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HAVE_GPU = torch.cuda.is_available()
+
+
+def test_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "mi355_det.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 30
+    lib = C.CDLL(L.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert set(L.EXPORTS) == declared, set(L.EXPORTS) ^ declared
+
+
+def test_opcode_table_matches_header():
+    hdr = open(os.path.join(ROOT, "include", "mi355_det.h")).read()
+    enum = re.search(r"enum \{(.*?)MI_OP_COUNT", hdr, re.S).group(1)
+    vals = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"MI_OP_([A-Z_]+) = (\d+)", enum))
+    assert vals == L.OP
+
+
+def test_struct_sizes_match_c():
+    # sizes computed from the field lists in the header (no padding surprises across the FFI)
+    assert C.sizeof(L.mi_conv_desc) == 5 * 8 + (3 + 3 + 2 + 2 + 4 + 4 + 27 + 5) * 4
+    assert C.sizeof(L.mi_cmd) % 8 == 0 and C.sizeof(L.mi_cmd) == 4 + 160 + 32 + 4 + 96 + 32  # op,i[40],f[8],pad,p[12],l[4]
+    assert C.sizeof(L.mi_sgd_seg) == 24
+
+
+def test_argument_errors_without_launch():
+    lib = L.lib()
+    d = L.mi_conv_desc()
+    assert lib.mi_conv2d(C.byref(d), None) == -1
+    assert b"null" in lib.mi_last_error()
+    w = L.mi_wgrad_desc()
+    assert lib.mi_conv2d_wgrad(C.byref(w), None) == -1
+    assert lib.mi_bn_act_fwd(None, 8, None, None, None, 0, None, 8, 10, 8, 1, None) == -1
+    d.x = d.w = d.y = 256
+    d.N, d.H, d.W, d.outH, d.outW, d.gridH, d.gridW = 1, 8, 8, 8, 8, 8, 8
+    d.in_stride = d.out_stride = 1
+    d.K8, d.Cout, d.CoutPad, d.ntaps, d.ldx, d.ldy = 3, 32, 32, 1, 24, 32   # odd K8
+    assert lib.mi_conv2d_plan(C.byref(d)) == -1 and b"K8" in lib.mi_last_error()
+
+
+@pytest.mark.skipif(HAVE_GPU, reason="CPU-only behaviour")
+def test_fails_loudly_without_device():
+    lib = L.lib()
+    assert lib.mi_device_count() == 0
+    cmds = (L.mi_cmd * 1)()
+    assert lib.mi_cmdlist_run(cmds, 1, None) == -3        # MI_ENODEV
+    model = M.build_model(M.yolox_s_cfg(device="cpu"))
+    with pytest.raises(L.MI355Error):
+        model([{"image": torch.zeros(3, 64, 64, dtype=torch.uint8)}])
+    with pytest.raises(RuntimeError):
+        model.backbone.stem.conv(torch.zeros(1, 12, 8, 8))   # no eager path for the blocks
+    with pytest.raises(L.MI355Error):
+        M.batched_nms(torch.zeros(1, 4), torch.zeros(1), torch.zeros(1), 0.5)
+
+
+def test_registry_and_config_surface(tmp_path):
+    assert "YOLOX" in M.META_ARCH_REGISTRY and "build_cspdarknetx_backbone" in M.BACKBONE_REGISTRY
+    base = tmp_path / "Base-YOLOv7.yaml"
+    base.write_text("MODEL:\n  META_ARCHITECTURE: \"YOLOV7\"\n  PADDED_VALUE: 114.0\nSOLVER:\n  BASE_LR: 0.02\nVERSION: 2\n")
+    sub = tmp_path / "coco"
+    sub.mkdir()
+    y = sub / "yolox_s.yaml"
+    # the reference's yolox_s.yaml spells its base "Base-YoloV7.yaml" (case differs from the file on disk)
+    y.write_text("_BASE_: \"../Base-YoloV7.yaml\"\nMODEL:\n  META_ARCHITECTURE: \"YOLOX\"\n  BACKBONE:\n    NAME: \"build_cspdarknetx_backbone\"\n"
+                 "  YOLO:\n    CLASSES: 80\n    WIDTH_MUL: 0.50\n    DEPTH_MUL: 0.33\n    CONF_THRESHOLD: 0.001\n    NMS_THRESHOLD: 0.65\n"
+                 "  SOME_OTHER_FAMILY:\n    KEY: 1\nSOLVER:\n  AMP:\n    ENABLED: true\n")
+    cfg = M.get_yolox_cfg(str(y), ["MODEL.DEVICE", "cpu"])
+    assert cfg.MODEL.META_ARCHITECTURE == "YOLOX" and cfg.SOLVER.BASE_LR == 0.02 and cfg.MODEL.YOLO.MAX_BOXES_NUM == 100
+    assert cfg.SOLVER.REFERENCE_WORLD_SIZE == 8 and cfg.MODEL.DEVICE == "cpu"
+    model = M.build_model(cfg)
+    keys = list(model.state_dict().keys())
+    assert len(keys) == 462 and sum(p.numel() for p in model.parameters()) == 8968255
+    assert keys[0] == "backbone.stem.conv.conv.weight" and "neck.C3_p4.m.0.conv1.bn.running_mean" in keys
+    assert "head.cls_preds.0.bias" in keys
+    bn = model.backbone.dark3[0].bn
+    assert bn.eps == 1e-3 and bn.momentum == 0.03
+    import math
+    assert abs(float(model.head.obj_preds[1].bias[0]) + math.log(99.0)) < 1e-6
+    assert model.backbone.size_divisibility == 32 and model.backbone.output_shape()["dark5"].channels == 512
+
+
+def test_preprocess_matches_reference_contract():
+    from yolov7_d2_amd.d2shim import Boxes, Instances
+    model = M.build_model(M.yolox_s_cfg(device="cpu"))
+    a = {"image": torch.full((3, 50, 70), 7, dtype=torch.uint8),
+         "instances": Instances((50, 70), gt_boxes=Boxes(torch.tensor([[10., 20, 30, 60]])), gt_classes=torch.tensor([4]))}
+    b = {"image": torch.full((3, 64, 40), 9, dtype=torch.uint8),
+         "instances": Instances((64, 40), gt_boxes=Boxes(torch.zeros(0, 4)), gt_classes=torch.zeros(0, dtype=torch.long))}
+    images, labels, sizes = model.preprocess_image([a, b], True)
+    assert images.tensor.shape == (2, 3, 64, 96) and sizes == [(50, 70), (64, 40)]
+    assert float(images.tensor[0, 0, 0, 0]) == 7 and float(images.tensor[0, 0, 63, 95]) == 114.0   # pad value, no mean/std
+    assert labels.shape == (2, 100, 5)
+    assert labels[0, 0].tolist() == [4.0, 20.0, 40.0, 20.0, 40.0] and float(labels[1].abs().sum()) == 0

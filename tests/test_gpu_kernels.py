@@ -1,0 +1,273 @@
+"""GPU (-m gpu): every HIP kernel of libmi355det against a CPU fp32 reference of the same op computed from the
+same bf16-rounded operands (tolerances: bf16 outputs rtol 2e-2 / atol 2e-2; fp32 reductions 1e-3)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import yolox_oracle as O
+from yolov7_d2_amd import _lib as L
+from yolov7_d2_amd.plan import PlanBuilder, TRef
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def relerr(a, b):
+    return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
+
+
+def sp():
+    return L.stream_ptr()
+
+
+def test_library_and_device():
+    assert L.lib().mi_version() >= 100
+    assert L.lib().mi_device_count() >= 1
+
+
+def test_mfma_lane_layouts():
+    g = torch.Generator().manual_seed(0)
+    for name, (m, k, n) in (("mi_probe_mfma32", (32, 16, 32)), ("mi_probe_mfma16", (16, 32, 16))):
+        a = bf(torch.randn(m, k, generator=g))
+        b = bf(torch.randn(k, n, generator=g))   # asymmetric: catches transposed C/D maps
+        d = torch.zeros(m, n, device=DEV)
+        L.check(getattr(L.lib(), name)(a.to(DEV, torch.bfloat16).data_ptr(), b.to(DEV, torch.bfloat16).data_ptr(),
+                                       d.data_ptr(), sp()), name)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(d.cpu().numpy(), (a @ b).numpy(), rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------ BaseConv via a 1-layer plan
+class _Case:
+    """Conv(k,s) -> BN(train) -> SiLU (+res) as a one-layer plan, with a given upstream gradient."""
+
+    def __init__(self, N, H, W, Cin, Cout, k, s, res=False, xC=None, seed=0, in_slice=False):
+        g = torch.Generator().manual_seed(seed)
+        self.N, self.H, self.W, self.Cin, self.Cout, self.k, self.s = N, H, W, Cin, Cout, k, s
+        self.weight = (torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)).to(DEV)
+        self.wgrad = torch.zeros_like(self.weight)
+        self.gamma = (1 + 0.2 * torch.randn(Cout, generator=g)).to(DEV)
+        self.beta = (0.2 * torch.randn(Cout, generator=g)).to(DEV)
+        self.rm, self.rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+        self.nbt = torch.zeros((), dtype=torch.long, device=DEV)
+        self.ggamma, self.gbeta = torch.zeros(Cout, device=DEV), torch.zeros(Cout, device=DEV)
+        b = PlanBuilder(DEV, training=True)
+        xC = Cin if xC is None else xC
+        if in_slice:   # x is a channel slice of a wider concat buffer (exercises ld != C)
+            big = b.new_act(N, H, W, 2 * xC, "xbig")
+            self.x = big.slice(xC, 2 * xC)
+        else:
+            self.x = b.new_act(N, H, W, xC, "x")
+        pad = (k - 1) // 2
+        Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+        self.Ho, self.Wo = Ho, Wo
+        self.res = b.new_act(N, Ho, Wo, Cout, "res") if res else None
+        bn = dict(gamma=self.gamma, beta=self.beta, rm=self.rm, rv=self.rv, nbt=self.nbt, eps=1e-3, momentum=0.03,
+                  ggamma=self.ggamma, gbeta=self.gbeta)
+        self.out = b.base_conv("c", self.x, self.weight, bn, k, s, self.wgrad, res=self.res)
+        assert b.grad_mode(self.out) == 0          # upstream gradient is written by the test
+        self.plan = b.finalize()
+        self.b = b
+        self.xin = bf(torch.randn(N, Cin, H, W, generator=g))
+        self.rin = bf(torch.randn(N, Cout, Ho, Wo, generator=g)) if res else None
+        self.gout = bf(torch.randn(N, Cout, Ho, Wo, generator=g))
+        xv = self.plan.view(self.x)
+        xv.zero_()
+        xv[:, :Cin] = self.xin.to(DEV, torch.bfloat16)
+        if res:
+            self.plan.view(self.res).copy_(self.rin.to(DEV))
+        self.plan.view(self.out.grad).copy_(self.gout.to(DEV))
+        if self.res is not None:
+            self.plan.view(self.res.grad).fill_(0.25)   # must be overwritten (first writer) by the kernel
+
+    def run(self):
+        self.plan.run("fwd")
+        self.plan.run("bwd")
+        torch.cuda.synchronize()
+
+    def reference(self):
+        x = self.xin.clone().requires_grad_(True)
+        w = bf(self.weight.cpu()).requires_grad_(True)
+        gamma, beta = self.gamma.cpu().clone().requires_grad_(True), self.beta.cpu().clone().requires_grad_(True)
+        y = F.conv2d(x, w, None, self.s, (self.k - 1) // 2)
+        yq = y + (bf(y) - y).detach()                      # stored as bf16
+        z = F.batch_norm(yq, None, None, gamma, beta, True, 0.03, 1e-3)
+        a = F.silu(z)
+        r = None
+        if self.rin is not None:
+            r = self.rin.clone().requires_grad_(True)
+            a = a + r
+        a.backward(self.gout)
+        return dict(y=y.detach(), out=a.detach(), dx=x.grad, dw=w.grad, dgamma=gamma.grad, dbeta=beta.grad,
+                    dres=None if r is None else r.grad, mean=yq.detach().mean((0, 2, 3)),
+                    var=yq.detach().var((0, 2, 3), unbiased=True))
+
+
+CASES = [
+    # N, H, W, Cin, Cout, k, s, res
+    (2, 20, 20, 64, 64, 3, 1, True),      # KC=64 BN=64, W<TW tiling (20x20 -> 6x20 tiles)
+    (1, 40, 40, 32, 32, 3, 1, False),     # KC=32 BN=32
+    (2, 16, 24, 12, 32, 3, 1, False),     # stem: Cin 12 padded to 16, KC=16
+    (2, 32, 32, 32, 64, 3, 2, False),     # stride 2: fwd halo stride, dgrad parity classes
+    (2, 22, 14, 64, 128, 3, 2, False),    # stride 2, odd output tiles, BN=128
+    (2, 20, 12, 128, 128, 1, 1, False),   # 1x1, direct wgrad into the OIHW gradient
+    (1, 9, 7, 64, 32, 3, 1, True),        # odd sizes, partial tiles
+    (2, 8, 8, 256, 512, 1, 1, False),     # deep 1x1: 4 k-chunks, 4 cout tiles
+    (1, 80, 80, 128, 128, 3, 1, False),   # head-sized 3x3 (8x16 tiles, many blocks)
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"{c[3]}to{c[4]}_k{c[5]}s{c[6]}_{c[1]}x{c[2]}" for c in CASES])
+def test_base_conv_fwd_bwd(case):
+    N, H, W, Cin, Cout, k, s, res = case
+    c = _Case(N, H, W, Cin, Cout, k, s, res=res, xC=16 if Cin == 12 else None)
+    c.run()
+    ref = c.reference()
+    # raw conv output (bf16) and activated output
+    ynm = [t for t in c.b.bufs if t.name == "c.y"][0]
+    y = c.plan.view(TRef(ynm, N, c.Ho, c.Wo, Cout, Cout)).float().cpu()
+    np.testing.assert_allclose(y.numpy(), ref["y"].numpy(), rtol=2e-2, atol=2e-2)
+    out = c.plan.view(c.out).float().cpu()
+    np.testing.assert_allclose(out.numpy(), ref["out"].numpy(), rtol=2e-2, atol=3e-2)
+    # running statistics (fp32 path; momentum 0.03)
+    np.testing.assert_allclose(c.rm.cpu().numpy(), 0.03 * ref["mean"].numpy(), rtol=2e-3, atol=1e-4)
+    np.testing.assert_allclose(c.rv.cpu().numpy(), 0.97 + 0.03 * ref["var"].numpy(), rtol=2e-3, atol=1e-4)
+    assert int(c.nbt) == 1
+    # gradients: norm-relative error (bf16 dy operand)
+    assert relerr(c.wgrad.cpu(), ref["dw"]) < 2e-2
+    assert relerr(c.ggamma.cpu(), ref["dgamma"]) < 2e-2
+    assert relerr(c.gbeta.cpu(), ref["dbeta"]) < 2e-2
+    dx = c.plan.view(c.x.grad).float().cpu()[:, :Cin]
+    assert relerr(dx, ref["dx"]) < 2e-2
+    if res:
+        dres = c.plan.view(c.res.grad).float().cpu()
+        np.testing.assert_allclose(dres.numpy(), ref["dres"].numpy(), rtol=1e-2, atol=1e-2)
+
+
+def test_conv_input_slice():
+    """x read from / dx written to a channel slice of a wider buffer (ld != C)"""
+    c = _Case(2, 12, 12, 64, 64, 3, 1, in_slice=True, seed=3)
+    c.run()
+    ref = c.reference()
+    out = c.plan.view(c.out).float().cpu()
+    np.testing.assert_allclose(out.numpy(), ref["out"].numpy(), rtol=2e-2, atol=3e-2)
+    assert relerr(c.plan.view(c.x.grad).float().cpu(), ref["dx"]) < 2e-2
+    assert relerr(c.wgrad.cpu(), ref["dw"]) < 2e-2
+
+
+def test_dgrad_accumulates():
+    """two consumers of one tensor: the second data gradient must add to the first (MI_CONV_ACCUM)"""
+    g = torch.Generator().manual_seed(5)
+    N, H, W, C = 1, 16, 16, 64
+    b = PlanBuilder(DEV, training=True)
+    x = b.new_act(N, H, W, C, "x")
+    ws = [(torch.randn(C, C, 1, 1, generator=g) / 8).to(DEV) for _ in range(2)]
+    wg = [torch.zeros_like(w) for w in ws]
+    outs = []
+    for i in range(2):
+        bn = dict(gamma=torch.ones(C, device=DEV), beta=torch.zeros(C, device=DEV), rm=torch.zeros(C, device=DEV),
+                  rv=torch.ones(C, device=DEV), nbt=torch.zeros((), dtype=torch.long, device=DEV), eps=1e-3,
+                  momentum=0.03, ggamma=torch.zeros(C, device=DEV), gbeta=torch.zeros(C, device=DEV))
+        outs.append(b.base_conv(f"c{i}", x, ws[i], bn, 1, 1, wg[i]))
+        b.keep.append(bn)
+    for o in outs:
+        b.grad_mode(o)
+    plan = b.finalize()
+    flags = [c.desc.flags for c in b.bwd if c.tag.endswith(".dgrad")]
+    assert sorted(flags) == [0, L.MI_CONV_ACCUM]
+    xin = bf(torch.randn(N, C, H, W, generator=g))
+    gos = [bf(torch.randn(N, C, H, W, generator=g)) for _ in range(2)]
+    plan.view(x).copy_(xin.to(DEV))
+    for o, go in zip(outs, gos):
+        plan.view(o.grad).copy_(go.to(DEV))
+    plan.view(x.grad).fill_(7.0)  # garbage that the first (overwriting) dgrad must erase
+    plan.run("fwd"); plan.run("bwd"); torch.cuda.synchronize()
+    xr = xin.clone().requires_grad_(True)
+    tot = 0
+    for w, go in zip(ws, gos):
+        y = F.conv2d(xr, bf(w.cpu()))
+        yq = y + (bf(y) - y).detach()
+        tot = tot + (F.silu(F.batch_norm(yq, None, None, None, None, True, 0.03, 1e-3)) * go).sum()
+    tot.backward()
+    assert relerr(plan.view(x.grad).float().cpu(), xr.grad) < 2.5e-2
+
+
+# ------------------------------------------------------------------------------------------ data-movement ops
+def test_focus_upsample_spp():
+    g = torch.Generator().manual_seed(1)
+    N, H, W = 2, 16, 24
+    img = torch.randint(0, 256, (N, 3, H, W), generator=g).float()
+    b = PlanBuilder(DEV, training=True)
+    image = img.to(DEV)
+    f = b.focus(image, N, H, W)
+    x = b.new_act(N, 6, 5, 32, "x")
+    cat = b.new_act(N, 12, 10, 64, "cat")
+    b.upsample_into("up", x, cat.slice(32, 64))
+    sx = b.new_act(N, 7, 9, 32, "sx")
+    scat = b.new_act(N, 7, 9, 128, "scat")
+    b.spp_into("spp", sx, scat.slice(32, 64), scat.slice(64, 96), scat.slice(96, 128))
+    b.grad_mode(cat); b.grad_mode(scat)
+    plan = b.finalize()
+    xin = bf(torch.randn(N, 32, 6, 5, generator=g))
+    # bf16 ties inside a 13x13 window are likely with few mantissa bits: make the values distinct
+    sxin = bf(torch.randperm(N * 32 * 7 * 9, generator=g).float().view(N, 32, 7, 9) / 64.0)
+    gcat = bf(torch.randn(N, 64, 12, 10, generator=g))
+    gscat = bf(torch.randn(N, 128, 7, 9, generator=g))
+    plan.view(x).copy_(xin.to(DEV)); plan.view(sx).copy_(sxin.to(DEV))
+    plan.view(cat.grad).copy_(gcat.to(DEV)); plan.view(scat.grad).copy_(gscat.to(DEV))
+    plan.run("fwd"); plan.run("bwd"); torch.cuda.synchronize()
+    # focus: channel order TL, BL, TR, BR (wrappers.py:212-219), pad channels zero
+    tl, tr, bl, br = img[..., ::2, ::2], img[..., ::2, 1::2], img[..., 1::2, ::2], img[..., 1::2, 1::2]
+    fo = plan.view(f).float().cpu()
+    assert torch.equal(fo[:, :12], torch.cat((tl, bl, tr, br), 1)) and float(fo[:, 12:].abs().max()) == 0
+    up = plan.view(cat.slice(32, 64)).float().cpu()
+    assert torch.equal(up, F.interpolate(xin, scale_factor=2, mode="nearest"))
+    xr = xin.clone().requires_grad_(True)
+    (F.interpolate(xr, scale_factor=2, mode="nearest") * gcat[:, 32:]).sum().backward()
+    np.testing.assert_allclose(plan.view(x.grad).float().cpu().numpy(), bf(xr.grad).numpy(), rtol=1e-2, atol=1e-2)
+    sr = sxin.clone().requires_grad_(True)
+    tot = 0
+    for i, ks in enumerate((5, 9, 13)):
+        p = F.max_pool2d(sr, ks, 1, ks // 2)
+        assert torch.equal(plan.view(scat.slice(32 * (i + 1), 32 * (i + 2))).float().cpu(), p.detach())
+        tot = tot + (p * gscat[:, 32 * (i + 1): 32 * (i + 2)]).sum()
+    tot.backward()
+    np.testing.assert_allclose(plan.view(sx.grad).float().cpu().numpy(), sr.grad.numpy(), rtol=2e-2, atol=2e-2)
+
+
+def test_sgd_momentum_matches_torch():
+    g = torch.Generator().manual_seed(2)
+    n = 70001
+    p0, g0 = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    p = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([p], lr=0.01, momentum=0.9, weight_decay=1e-4)
+    pd, gd, md = p0.to(DEV).clone(), g0.to(DEV), torch.zeros(n, device=DEV)
+    segs = []
+    k = 0
+    while k < n:
+        c = min(16384, n - k); segs.append((k, c)); k += c
+    arr = (L.mi_sgd_seg * len(segs))()
+    for i, (o, c) in enumerate(segs):
+        arr[i].offset, arr[i].count, arr[i].weight_decay, arr[i].lr = o, c, 1e-4, 0.01
+    sd = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+    for step in range(3):
+        p.grad = g0.clone()
+        opt.step()
+        L.check(L.lib().mi_sgd_momentum_step(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), sd.data_ptr(), len(segs),
+                                             0.9, 1.0, 0, sp()), "sgd")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(pd.cpu().numpy(), p.detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_argument_errors_are_reported_not_launched():
+    d = L.mi_conv_desc()
+    rc = L.lib().mi_conv2d(C.byref(d), sp())
+    assert rc == -1 and b"null" in L.lib().mi_last_error()

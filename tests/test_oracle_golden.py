@@ -1,0 +1,83 @@
+"""CPU: the oracle restatement (oracle/yolox_oracle.py) reproduces the vectors obtained by executing the
+reference's own source (oracle/gen_golden.py -> tests/golden/*.npz)."""
+import os
+
+import numpy as np
+import torch
+
+import yolox_oracle as O
+
+
+def test_step_losses_grads_and_eval(golden_dir):
+    g = np.load(os.path.join(golden_dir, "yolox_s_step_64x96.npz"))
+    sd = O.init_state_dict(0.33, 0.5, 80, seed=0)
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    imgs, labels = O.synth_batch(2, 64, 96, seed=11, max_gt=4)
+    res = O.train_step_losses(sd, imgs, labels)
+    got = np.array([float(x) for x in res])
+    np.testing.assert_allclose(got, g["losses"], rtol=1e-6, atol=1e-6)
+    (res[0] + res[1] + res[2] + res[3]).backward()
+    for k in g.files:
+        if k.startswith("grad:"):
+            np.testing.assert_allclose(sd[k[5:]].grad.numpy(), g[k], rtol=1e-4, atol=1e-6)
+    names = [str(n) for n in g["grad_names"]]
+    norms = np.array([float(sd[n].grad.norm()) for n in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sd["backbone.stem.conv.bn.running_mean"].numpy(),
+                               g["rm:backbone.stem.conv.bn.running_mean"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(sd["head.stems.1.bn.running_var"].numpy(), g["rv:head.stems.1.bn.running_var"],
+                               rtol=1e-6, atol=1e-7)
+    with torch.no_grad():
+        net = O.Net({k: v.detach() for k, v in sd.items()}, 0.33, 0.5, 80, training=False)
+        raw, hw = net.forward_raw(imgs)
+        ev = O.decode_eval(raw, O.make_anchors(hw))
+    np.testing.assert_allclose(ev.numpy(), g["eval_out"], rtol=1e-5, atol=1e-5)
+
+
+def test_simota_assignment_bit_exact(golden_dir):
+    g = np.load(os.path.join(golden_dir, "simota_160.npz"))
+    B, H, W = 3, 160, 160
+    _, labels = O.synth_batch(B, H, W, seed=21, max_gt=12)
+    labels[1] = 0.0
+    hw = [(H // s, W // s) for s in (8, 16, 32)]
+    raw, anchors = O.synth_raw(B, hw, 22, labels=labels)
+    raw.requires_grad_(True)
+    res, assigns = O.yolox_losses(raw, labels, anchors, 80, return_assign=True)
+    np.testing.assert_allclose(np.array([float(x) for x in res]), g["losses"], rtol=1e-6)
+    (res[0] + res[1] + res[2] + res[3]).backward()
+    np.testing.assert_allclose(raw.grad.numpy(), g["draw"], rtol=1e-5, atol=1e-7)
+    assert assigns[1] is None
+    for b in (0, 2):
+        a = assigns[b]
+        assert np.array_equal(a["fg"].numpy(), g[f"fg{b}"])                 # integer / boolean: exact
+        assert np.array_equal(a["matched_gt"].numpy(), g[f"matched_gt{b}"])
+        assert np.array_equal(a["matched_cls"].numpy(), g[f"matched_cls{b}"])
+        np.testing.assert_array_equal(a["matched_iou"].numpy(), g[f"matched_iou{b}"])
+    assert len(set(assigns[2]["matched_gt"].tolist())) > 1
+    assert sum(int(assigns[b]["fg"].sum()) for b in (0, 2)) > 20   # dynamic k > 1 is exercised
+
+
+def test_postprocess(golden_dir):
+    g = np.load(os.path.join(golden_dir, "postprocess.npz"))
+    for name, n, seed in (("small", 300, 31), ("large", 2500, 32)):   # both batched_nms branches
+        pred = O.synth_decoded(2, n, seed)
+        out = O.postprocess(pred, 80, 0.3, 0.65)
+        for b in range(2):
+            np.testing.assert_array_equal(out[b].numpy(), g[f"{name}_out{b}"])
+            cls = out[b][:, 6]
+            assert (cls == cls.round()).all()
+
+
+def test_nms_edge_cases():
+    e = torch.empty(0, 4)
+    assert O.batched_nms(e, torch.empty(0), torch.empty(0), 0.5).numel() == 0
+    b = torch.tensor([[0., 0, 10, 10], [0, 0, 10, 10], [20, 20, 30, 30], [0, 0, 10, 10.5]])
+    s = torch.tensor([0.9, 0.8, 0.7, 0.6])
+    assert O.nms(b, s, 0.5).tolist() == [0, 2]
+    # same boxes, different classes: class-aware keeps all but the same-class duplicate
+    assert O.batched_nms(b, s, torch.tensor([0., 1, 0, 0]), 0.5).tolist() == [0, 1, 2]
+    # threshold is strict (IoU == thr is kept)
+    b2 = torch.tensor([[0., 0, 2, 1], [1, 0, 3, 1]])  # IoU = 1/3
+    assert O.nms(b2, torch.tensor([1., 0.5]), 1.0 / 3.0 + 1e-3).tolist() == [0, 1]

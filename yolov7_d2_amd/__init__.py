@@ -1,0 +1,13 @@
+"""yolov7_d2_amd — MI355X-native hot path of yolov7_d2's YOLOX data-parallel training step.
+
+Public surface mirrors the reference: META_ARCH `YOLOX`, backbone builder
+`build_cspdarknetx_backbone`, `postprocess` / `batched_nms`; compute lives in libmi355det.so
+(include/mi355_det.h).  Importing registers the classes into the (detectron2 or shim) registries.
+"""
+from . import _lib
+from .config import add_yolo_config, get_cfg, get_yolox_cfg, yolox_s_cfg
+from .d2shim import BACKBONE_REGISTRY, META_ARCH_REGISTRY, build_backbone, build_model
+from .modeling import YOLOX, build_cspdarknetx_backbone, batched_nms, postprocess
+
+__all__ = ["YOLOX", "build_cspdarknetx_backbone", "batched_nms", "postprocess", "build_model", "build_backbone",
+           "get_cfg", "add_yolo_config", "get_yolox_cfg", "yolox_s_cfg", "META_ARCH_REGISTRY", "BACKBONE_REGISTRY"]

@@ -1,0 +1,155 @@
+"""ctypes binding of libmi355det.so (the C-ABI declared in include/mi355_det.h).
+
+The library is the product: if it is missing, or no HIP device is present, every compute entry
+fails loudly (`MI355Error`) — there is no CPU fallback on the product path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355det.so")
+
+MI_MAX_TAPS = 9
+MI_CONV_ACCUM = 1
+MI_CONV_OUT_F32 = 2
+
+
+class MI355Error(RuntimeError):
+    pass
+
+
+class mi_conv_desc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p), ("bias", C.c_void_p),
+        ("stats_partial", C.c_void_p),
+        ("ldx", C.c_int32), ("ldy", C.c_int32), ("y_nstride", C.c_int32),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("outH", C.c_int32), ("outW", C.c_int32), ("gridH", C.c_int32), ("gridW", C.c_int32),
+        ("in_stride", C.c_int32), ("out_stride", C.c_int32), ("out_oy", C.c_int32), ("out_ox", C.c_int32),
+        ("K8", C.c_int32), ("Cout", C.c_int32), ("CoutPad", C.c_int32), ("ntaps", C.c_int32),
+        ("tap_dy", C.c_int32 * MI_MAX_TAPS), ("tap_dx", C.c_int32 * MI_MAX_TAPS),
+        ("tap_w", C.c_int32 * MI_MAX_TAPS),
+        ("flags", C.c_int32), ("TH", C.c_int32), ("TW", C.c_int32), ("KC", C.c_int32), ("BN", C.c_int32),
+    ]
+
+
+class mi_wgrad_desc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("dy", C.c_void_p), ("gw", C.c_void_p),
+        ("ldx", C.c_int32), ("ldy", C.c_int32),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("outH", C.c_int32), ("outW", C.c_int32),
+        ("stride", C.c_int32), ("CinPad", C.c_int32), ("CoutPad", C.c_int32), ("ntaps", C.c_int32),
+        ("tap_dy", C.c_int32 * MI_MAX_TAPS), ("tap_dx", C.c_int32 * MI_MAX_TAPS),
+        ("TH", C.c_int32), ("TW", C.c_int32), ("splitk", C.c_int32),
+    ]
+
+
+class mi_yolox_loss_desc(C.Structure):
+    _fields_ = [
+        ("preds", C.c_void_p), ("labels", C.c_void_p), ("anchors", C.c_void_p),
+        ("B", C.c_int32), ("A", C.c_int32), ("ncls", C.c_int32), ("max_labels", C.c_int32),
+        ("gmax", C.c_int32),
+        ("cost", C.c_void_p), ("iou", C.c_void_p), ("match", C.c_void_p), ("ngt", C.c_void_p),
+        ("fg", C.c_void_p), ("matched_gt", C.c_void_p), ("matched_iou", C.c_void_p),
+        ("partial", C.c_void_p), ("out", C.c_void_p),
+    ]
+
+
+class mi_sgd_seg(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("count", C.c_int64), ("weight_decay", C.c_float), ("lr", C.c_float)]
+
+
+class mi_cmd(C.Structure):
+    _fields_ = [("op", C.c_int32), ("i", C.c_int32 * 40), ("f", C.c_float * 8), ("p", C.c_void_p * 12),
+                ("l", C.c_int64 * 4)]
+
+
+# opcode names must match the enum in include/mi355_det.h
+OPS = ["NOP", "CONV", "WGRAD", "PACK_W", "UNPACK_WG", "BN_FINALIZE", "BN_ACT_FWD", "BN_BWD_REDUCE",
+       "BN_BWD_FINALIZE", "BN_BWD_APPLY", "FOCUS", "UPSAMPLE_FWD", "UPSAMPLE_BWD", "SPP_FWD", "SPP_BWD", "COPY",
+       "COLSUM", "LOSS_FWD", "LOSS_BWD", "SPLIT_DPREDS", "MEMSET", "SGD", "BN_EVAL_AFFINE", "DECODE"]
+OP = {n: k for k, n in enumerate(OPS)}
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_PROTOS = {
+    "mi_version": (C.c_int, []),
+    "mi_device_count": (C.c_int, []),
+    "mi_last_error": (C.c_char_p, []),
+    "mi_conv2d": (C.c_int, [C.POINTER(mi_conv_desc), _vp]),
+    "mi_conv2d_plan": (C.c_int, [C.POINTER(mi_conv_desc)]),
+    "mi_conv2d_wgrad": (C.c_int, [C.POINTER(mi_wgrad_desc), _vp]),
+    "mi_pack_conv_weight": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
+    "mi_unpack_conv_wgrad": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "mi_bn_finalize": (C.c_int, [_vp, _i, _i, _i, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mi_bn_eval_affine": (C.c_int, [_vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
+    "mi_bn_act_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i64, _i, _i, _vp]),
+    "mi_bn_act_bwd_reduce": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
+    "mi_bn_bwd_finalize": (C.c_int, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "mi_bn_act_bwd_apply": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i,
+                                      _i64, _i, _i, _vp]),
+    "mi_focus_pack": (C.c_int, [_vp, _i, _i, _i, _vp, _i, _vp]),
+    "mi_upsample2x_fwd": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mi_upsample2x_bwd": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "mi_spp_pool_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "mi_spp_pool_bwd": (C.c_int, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "mi_copy_bf16": (C.c_int, [_vp, _i, _vp, _i, _i, _i64, _i, _vp]),
+    "mi_colsum_bf16": (C.c_int, [_vp, _i, _i64, _i, _vp, _i, _vp]),
+    "mi_yolox_loss_fwd": (C.c_int, [C.POINTER(mi_yolox_loss_desc), _vp]),
+    "mi_yolox_loss_bwd": (C.c_int, [C.POINTER(mi_yolox_loss_desc), _vp, _vp, _vp]),
+    "mi_yolox_split_dpreds": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "mi_yolox_decode": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
+    "mi_batched_nms": (C.c_int, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mi_sgd_momentum_step": (C.c_int, [_vp, _vp, _vp, _vp, _i, _f, _f, _i, _vp]),
+    "mi_cmdlist_run": (C.c_int, [C.POINTER(mi_cmd), _i, _vp]),
+    "mi_graph_capture": (C.c_int64, [C.POINTER(mi_cmd), _i, _vp]),
+    "mi_graph_launch": (C.c_int, [_i64, _vp]),
+    "mi_graph_destroy": (C.c_int, [_i64]),
+    "mi_cmdlist_time": (C.c_int, [C.POINTER(mi_cmd), _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _vp]),
+    "mi_probe_mfma32": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "mi_probe_mfma16": (C.c_int, [_vp, _vp, _vp, _vp]),
+}
+EXPORTS = sorted(_PROTOS)
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once). Raises MI355Error if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MI355Error(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc is None or rc < 0:
+        msg = lib().mi_last_error()
+        raise MI355Error(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+    return rc
+
+
+def require_device():
+    n = lib().mi_device_count()
+    if n <= 0:
+        raise MI355Error("no HIP device visible: the MI355X path cannot run (no CPU fallback by design)")
+    return n
+
+
+def ptr(t):
+    """device/host pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(stream=None):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return s.cuda_stream

@@ -1,0 +1,64 @@
+// Shared device/host helpers for libmi355det (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/mi355_det.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define MI_WAVE 64
+
+extern thread_local char g_mi_err[512];
+#define MI_FAIL(code, ...)                              \
+  do {                                                  \
+    snprintf(g_mi_err, sizeof(g_mi_err), __VA_ARGS__);  \
+    return (code);                                      \
+  } while (0)
+#define MI_REQUIRE(cond, ...)              \
+  do {                                     \
+    if (!(cond)) MI_FAIL(MI_EINVAL, __VA_ARGS__); \
+  } while (0)
+#define MI_CHECK_LAUNCH(name)                                                     \
+  do {                                                                            \
+    hipError_t e_ = hipGetLastError();                                            \
+    if (e_ != hipSuccess) MI_FAIL(MI_ELAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+static inline int mi_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t mi_cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float bf2f(__bf16 v) { return (float)v; }
+__device__ __forceinline__ __bf16 f2bf(float v) { return (__bf16)v; }
+
+// unpack 8 bf16 (one 16-byte vector) to floats
+__device__ __forceinline__ void unpack8(const bf16x8& v, float* f) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+}
+__device__ __forceinline__ bf16x8 pack8(const float* f) {
+  bf16x8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (__bf16)f[i];
+  return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

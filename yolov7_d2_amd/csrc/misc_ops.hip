@@ -1,0 +1,313 @@
+// Data-movement ops of the YOLOX path (NHWC bf16): Focus space-to-depth, nearest x2 upsample,
+// SPP max-pools, strided copy, column sums, and the fused SGD-momentum update.  All HBM-bound.
+#include "common.h"
+
+static int ew_blocks(int64_t total, int cap = 4096) {
+  int64_t b = (total + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ---- Focus (yolov7/modeling/backbone/layers/wrappers.py:202-220): channel order TL, BL, TR, BR x (c0,c1,c2)
+__global__ __launch_bounds__(256) void focus_pack_kernel(const float* __restrict__ img, int N, int H, int W,
+                                                         __bf16* out, int ldo) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)N * Ho * Wo;
+  for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(idx % Wo);
+    const int64_t r = idx / Wo;
+    const int oy = (int)(r % Ho), n = (int)(r / Ho);
+    float f[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int dy = q & 1, dx = q >> 1;  // q: 0 TL, 1 BL, 2 TR, 3 BR
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        f[q * 3 + c] = img[(((int64_t)n * 3 + c) * H + (2 * oy + dy)) * W + 2 * ox + dx];
+    }
+    f[12] = f[13] = f[14] = f[15] = 0.f;
+    __bf16* op = out + idx * ldo;
+    *(bf16x8*)op = pack8(f);
+    *(bf16x8*)(op + 8) = pack8(f + 8);
+  }
+}
+
+extern "C" int mi_focus_pack(const float* img, int N, int H, int W, void* out, int ldo, mi_stream_t st) {
+  MI_REQUIRE(img && out && H % 2 == 0 && W % 2 == 0 && ldo % 8 == 0 && ldo >= 16, "focus_pack: args");
+  const int64_t total = (int64_t)N * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(focus_pack_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)st, img, N, H, W,
+                     (__bf16*)out, ldo);
+  MI_CHECK_LAUNCH("focus_pack");
+  return MI_OK;
+}
+
+// ---- nearest x2 upsample (yolov7/modeling/neck/yolo_pafpn.py:28,96,101)
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const __bf16* __restrict__ x, int ldx, __bf16* y, int ldy,
+                                                             int N, int H, int W, int C8) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const int64_t total = (int64_t)N * Ho * Wo * C8;
+  for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(idx % C8);
+    int64_t r = idx / C8;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const bf16x8 v = *(const bf16x8*)(x + (((int64_t)n * H + oy / 2) * W + ox / 2) * ldx + c8 * 8);
+    *(bf16x8*)(y + (((int64_t)n * Ho + oy) * Wo + ox) * ldy + c8 * 8) = v;
+  }
+}
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const __bf16* __restrict__ dy, int lddy, __bf16* dx,
+                                                             int lddx, int accumulate, int N, int H, int W, int C8) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const int64_t total = (int64_t)N * H * W * C8;
+  for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(idx % C8);
+    int64_t r = idx / C8;
+    const int ix = (int)(r % W); r /= W;
+    const int iy = (int)(r % H);
+    const int n = (int)(r / H);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const bf16x8 v = *(const bf16x8*)(dy + (((int64_t)n * Ho + 2 * iy + a) * Wo + 2 * ix + b) * lddy + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+      }
+    __bf16* dp = dx + (((int64_t)n * H + iy) * W + ix) * lddx + c8 * 8;
+    if (accumulate) {
+      const bf16x8 o = *(const bf16x8*)dp;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += (float)o[e];
+    }
+    *(bf16x8*)dp = pack8(acc);
+  }
+}
+
+extern "C" int mi_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C,
+                                 mi_stream_t st) {
+  MI_REQUIRE(x && y && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "upsample_fwd: args");
+  const int64_t total = (int64_t)N * 4 * H * W * (C / 8);
+  hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)st, (const __bf16*)x,
+                     ldx, (__bf16*)y, ldy, N, H, W, C / 8);
+  MI_CHECK_LAUNCH("upsample_fwd");
+  return MI_OK;
+}
+extern "C" int mi_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, int accumulate, int N, int H, int W,
+                                 int C, mi_stream_t st) {
+  MI_REQUIRE(dy && dx && C % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "upsample_bwd: args");
+  const int64_t total = (int64_t)N * H * W * (C / 8);
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)st, (const __bf16*)dy,
+                     lddy, (__bf16*)dx, lddx, accumulate, N, H, W, C / 8);
+  MI_CHECK_LAUNCH("upsample_bwd");
+  return MI_OK;
+}
+
+// ---- SPP max-pools k = 5, 9, 13, stride 1, "same" padding (wrappers.py:150-153).
+// One 13x13 row-major window scan feeds all three pools; the first maximum wins (ATen max_pool2d).
+// idx[k][pix][c] stores the winning window offset as (dy+6)*13 + (dx+6).
+__global__ __launch_bounds__(256) void spp_fwd_kernel(const __bf16* __restrict__ x, int ldx, __bf16* y5, __bf16* y9,
+                                                      __bf16* y13, int ldy, uint8_t* idx, int N, int H, int W, int C8) {
+  const int64_t npix = (int64_t)N * H * W;
+  const int64_t total = npix * C8;
+  const int C = C8 * 8;
+  for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t pix = i / C8;
+    const int px = (int)(pix % W);
+    const int64_t r = pix / W;
+    const int py = (int)(r % H), n = (int)(r / H);
+    float m[3][8];
+    uint8_t am[3][8];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        m[k][e] = -INFINITY;
+        am[k][e] = 84;  // centre
+      }
+    for (int dy = -6; dy <= 6; ++dy) {
+      const int yy = py + dy;
+      if (yy < 0 || yy >= H) continue;
+      for (int dx = -6; dx <= 6; ++dx) {
+        const int xx = px + dx;
+        if (xx < 0 || xx >= W) continue;
+        const bf16x8 v = *(const bf16x8*)(x + (((int64_t)n * H + yy) * W + xx) * ldx + c8 * 8);
+        const uint8_t code = (uint8_t)((dy + 6) * 13 + (dx + 6));
+        const int ady = dy < 0 ? -dy : dy, adx = dx < 0 ? -dx : dx;
+        const int rad = ady > adx ? ady : adx;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = (float)v[e];
+          if (f > m[2][e]) { m[2][e] = f; am[2][e] = code; }
+          if (rad <= 4 && f > m[1][e]) { m[1][e] = f; am[1][e] = code; }
+          if (rad <= 2 && f > m[0][e]) { m[0][e] = f; am[0][e] = code; }
+        }
+      }
+    }
+    const int64_t o = pix * ldy + c8 * 8;
+    *(bf16x8*)(y5 + o) = pack8(m[0]);
+    *(bf16x8*)(y9 + o) = pack8(m[1]);
+    *(bf16x8*)(y13 + o) = pack8(m[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      uint64_t pk = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pk |= (uint64_t)am[k][e] << (8 * e);
+      *(uint64_t*)(idx + ((int64_t)k * npix + pix) * C + c8 * 8) = pk;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void spp_bwd_kernel(const __bf16* __restrict__ d5, const __bf16* __restrict__ d9,
+                                                      const __bf16* __restrict__ d13, int lddy,
+                                                      const uint8_t* __restrict__ idx, __bf16* dx, int lddx,
+                                                      int accumulate, int N, int H, int W, int C8) {
+  const int64_t npix = (int64_t)N * H * W;
+  const int64_t total = npix * C8;
+  const int C = C8 * 8;
+  for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t pix = i / C8;
+    const int px = (int)(pix % W);
+    const int64_t r = pix / W;
+    const int py = (int)(r % H), n = (int)(r / H);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    // output position o = p - (dy,dx) selected input p iff its code == (dy,dx)
+    for (int dy = -6; dy <= 6; ++dy) {
+      const int oy = py - dy;
+      if (oy < 0 || oy >= H) continue;
+      for (int dxx = -6; dxx <= 6; ++dxx) {
+        const int ox = px - dxx;
+        if (ox < 0 || ox >= W) continue;
+        const uint8_t code = (uint8_t)((dy + 6) * 13 + (dxx + 6));
+        const int ady = dy < 0 ? -dy : dy, adx = dxx < 0 ? -dxx : dxx;
+        const int rad = ady > adx ? ady : adx;
+        const int64_t opix = ((int64_t)n * H + oy) * W + ox;
+        const int kmin = rad <= 2 ? 0 : (rad <= 4 ? 1 : 2);
+        for (int k = kmin; k < 3; ++k) {
+          const uint64_t pk = *(const uint64_t*)(idx + ((int64_t)k * npix + opix) * C + c8 * 8);
+          // any byte equal to code?
+          bool any = false;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) any |= (uint8_t)(pk >> (8 * e)) == code;
+          if (!any) continue;
+          const __bf16* dp = (k == 0 ? d5 : (k == 1 ? d9 : d13)) + opix * lddy + c8 * 8;
+          const bf16x8 g = *(const bf16x8*)dp;
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if ((uint8_t)(pk >> (8 * e)) == code) acc[e] += (float)g[e];
+        }
+      }
+    }
+    __bf16* op = dx + pix * lddx + c8 * 8;
+    if (accumulate) {
+      const bf16x8 o = *(const bf16x8*)op;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += (float)o[e];
+    }
+    *(bf16x8*)op = pack8(acc);
+  }
+}
+
+extern "C" int mi_spp_pool_fwd(const void* x, int ldx, void* y5, void* y9, void* y13, int ldy, uint8_t* idx, int N,
+                               int H, int W, int C, mi_stream_t st) {
+  MI_REQUIRE(x && y5 && y9 && y13 && idx && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "spp_fwd: args");
+  const int64_t total = (int64_t)N * H * W * (C / 8);
+  hipLaunchKernelGGL(spp_fwd_kernel, dim3(ew_blocks(total, 65535)), dim3(256), 0, (hipStream_t)st, (const __bf16*)x,
+                     ldx, (__bf16*)y5, (__bf16*)y9, (__bf16*)y13, ldy, idx, N, H, W, C / 8);
+  MI_CHECK_LAUNCH("spp_fwd");
+  return MI_OK;
+}
+extern "C" int mi_spp_pool_bwd(const void* dy5, const void* dy9, const void* dy13, int lddy, const uint8_t* idx,
+                               void* dx, int lddx, int accumulate, int N, int H, int W, int C, mi_stream_t st) {
+  MI_REQUIRE(dy5 && dy9 && dy13 && idx && dx && C % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "spp_bwd: args");
+  const int64_t total = (int64_t)N * H * W * (C / 8);
+  hipLaunchKernelGGL(spp_bwd_kernel, dim3(ew_blocks(total, 65535)), dim3(256), 0, (hipStream_t)st,
+                     (const __bf16*)dy5, (const __bf16*)dy9, (const __bf16*)dy13, lddy, idx, (__bf16*)dx, lddx,
+                     accumulate, N, H, W, C / 8);
+  MI_CHECK_LAUNCH("spp_bwd");
+  return MI_OK;
+}
+
+// ---- strided copy / accumulate
+__global__ __launch_bounds__(256) void copy_bf16_kernel(const __bf16* __restrict__ src, int lds_, __bf16* dst, int ldd,
+                                                        int accumulate, int64_t npix, int C8) {
+  const int64_t total = npix * C8;
+  for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t pix = idx / C8;
+    const int c8 = (int)(idx - pix * C8);
+    const bf16x8 v = *(const bf16x8*)(src + pix * lds_ + c8 * 8);
+    __bf16* dp = dst + pix * ldd + c8 * 8;
+    if (accumulate) {
+      const bf16x8 o = *(const bf16x8*)dp;
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = (float)o[e] + (float)v[e];
+      *(bf16x8*)dp = pack8(f);
+    } else {
+      *(bf16x8*)dp = v;
+    }
+  }
+}
+extern "C" int mi_copy_bf16(const void* src, int lds_, void* dst, int ldd, int accumulate, int64_t npix, int C,
+                            mi_stream_t st) {
+  MI_REQUIRE(src && dst && C % 8 == 0 && lds_ % 8 == 0 && ldd % 8 == 0, "copy_bf16: args");
+  hipLaunchKernelGGL(copy_bf16_kernel, dim3(ew_blocks(npix * (C / 8))), dim3(256), 0, (hipStream_t)st,
+                     (const __bf16*)src, lds_, (__bf16*)dst, ldd, accumulate, npix, C / 8);
+  MI_CHECK_LAUNCH("copy_bf16");
+  return MI_OK;
+}
+
+// ---- column sums (bias gradients of the prediction convs)
+__global__ __launch_bounds__(128) void colsum_kernel(const __bf16* __restrict__ x, int ldx, int64_t npix, int C,
+                                                     float* out) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
+  const int64_t p0 = blockIdx.x * per, p1 = min(npix, p0 + per);
+  float acc = 0.f;
+  for (int64_t p = p0; p < p1; ++p) acc += (float)x[p * ldx + c];
+  unsafeAtomicAdd(out + c, acc);
+}
+extern "C" int mi_colsum_bf16(const void* x, int ldx, int64_t npix, int C, float* out, int accumulate,
+                              mi_stream_t st) {
+  MI_REQUIRE(x && out && C > 0 && C <= 128, "colsum: C %d (<=128)", C);
+  hipStream_t s = (hipStream_t)st;
+  if (!accumulate) {
+    if (hipMemsetAsync(out, 0, sizeof(float) * C, s) != hipSuccess) MI_FAIL(MI_ELAUNCH, "colsum: memset");
+  }
+  hipLaunchKernelGGL(colsum_kernel, dim3(256), dim3(128), 0, s, (const __bf16*)x, ldx, npix, C, out);
+  MI_CHECK_LAUNCH("colsum");
+  return MI_OK;
+}
+
+// ---- SGD with momentum + weight decay over a flat arena (torch.optim.SGD semantics: dampening 0, no nesterov)
+__global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* __restrict__ g, float* m,
+                                                  const mi_sgd_seg* __restrict__ segs, float momentum,
+                                                  float grad_scale, int first_step) {
+  const mi_sgd_seg sg = segs[blockIdx.x];
+  for (int64_t i = threadIdx.x; i < sg.count; i += 256) {
+    const int64_t k = sg.offset + i;
+    const float pv = p[k];
+    const float d = g[k] * grad_scale + sg.weight_decay * pv;
+    const float b = first_step ? d : momentum * m[k] + d;
+    m[k] = b;
+    p[k] = pv - sg.lr * b;
+  }
+}
+extern "C" int mi_sgd_momentum_step(float* params, const float* grads, float* momentum_buf,
+                                    const mi_sgd_seg* segs_dev, int nseg, float momentum, float grad_scale,
+                                    int first_step, mi_stream_t st) {
+  MI_REQUIRE(params && grads && momentum_buf && segs_dev && nseg > 0, "sgd: args");
+  hipLaunchKernelGGL(sgd_kernel, dim3(nseg), dim3(256), 0, (hipStream_t)st, params, grads, momentum_buf, segs_dev,
+                     momentum, grad_scale, first_step);
+  MI_CHECK_LAUNCH("sgd");
+  return MI_OK;
+}

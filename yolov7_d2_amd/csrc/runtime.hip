@@ -1,0 +1,210 @@
+// Command-list executor, hipGraph capture/replay, timing and hardware layout probes.
+// The host (Python mirror of the reference modules) builds a flat list of mi_cmd once; a training
+// step is then issued from C++ in one call, or replayed as a captured hipGraph, so the ~10^3 kernel
+// launches of a YOLOX step cost no per-launch interpreter time.
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+#include "common.h"
+
+thread_local char g_mi_err[512] = {0};
+
+extern "C" int mi_version(void) { return 100; }
+extern "C" const char* mi_last_error(void) { return g_mi_err; }
+extern "C" int mi_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static int run_one(const mi_cmd& c, hipStream_t s) {
+  mi_stream_t st = (mi_stream_t)s;
+  const int32_t* i = c.i;
+  void* const* p = c.p;
+  switch (c.op) {
+    case MI_OP_NOP: return MI_OK;
+    case MI_OP_CONV: return mi_conv2d((const mi_conv_desc*)p[0], st);
+    case MI_OP_WGRAD: return mi_conv2d_wgrad((const mi_wgrad_desc*)p[0], st);
+    case MI_OP_PACK_W:
+      return mi_pack_conv_weight((const float*)p[0], i[0], i[1], i[2], i[3], p[1], i[4], i[5], p[2], i[6], i[7], st);
+    case MI_OP_UNPACK_WG:
+      return mi_unpack_conv_wgrad((const float*)p[0], i[0], i[1], i[2], i[3], i[4], i[5], (float*)p[1], i[6], st);
+    case MI_OP_BN_FINALIZE:
+      return mi_bn_finalize((const float*)p[0], i[0], i[1], i[2], c.l[0], (const float*)p[1], (const float*)p[2],
+                            c.f[0], c.f[1], (float*)p[3], (float*)p[4], (int64_t*)p[5], (float*)p[6], (float*)p[7],
+                            (float*)p[8], (float*)p[9], st);
+    case MI_OP_BN_ACT_FWD:
+      return mi_bn_act_fwd(p[0], i[0], (const float*)p[1], (const float*)p[2], p[3], i[1], p[4], i[2], c.l[0], i[3],
+                           i[4], st);
+    case MI_OP_BN_BWD_REDUCE:
+      return mi_bn_act_bwd_reduce(p[0], i[0], p[1], i[1], (const float*)p[2], (const float*)p[3], (const float*)p[4],
+                                  (const float*)p[5], (float*)p[6], i[2], c.l[0], i[3], i[4], st);
+    case MI_OP_BN_BWD_FINALIZE:
+      return mi_bn_bwd_finalize((const float*)p[0], i[0], i[1], c.l[0], (float*)p[1], (float*)p[2], (float*)p[3],
+                                (float*)p[4], st);
+    case MI_OP_BN_BWD_APPLY:
+      return mi_bn_act_bwd_apply(p[0], i[0], p[1], i[1], (const float*)p[2], (const float*)p[3], (const float*)p[4],
+                                 (const float*)p[5], (const float*)p[6], (const float*)p[7], (const float*)p[8], p[9],
+                                 i[2], p[10], i[3], i[4], c.l[0], i[5], i[6], st);
+    case MI_OP_FOCUS: return mi_focus_pack((const float*)p[0], i[0], i[1], i[2], p[1], i[3], st);
+    case MI_OP_UPSAMPLE_FWD: return mi_upsample2x_fwd(p[0], i[0], p[1], i[1], i[2], i[3], i[4], i[5], st);
+    case MI_OP_UPSAMPLE_BWD: return mi_upsample2x_bwd(p[0], i[0], p[1], i[1], i[2], i[3], i[4], i[5], i[6], st);
+    case MI_OP_SPP_FWD: return mi_spp_pool_fwd(p[0], i[0], p[1], p[2], p[3], i[1], (uint8_t*)p[4], i[2], i[3], i[4], i[5], st);
+    case MI_OP_SPP_BWD:
+      return mi_spp_pool_bwd(p[0], p[1], p[2], i[0], (const uint8_t*)p[3], p[4], i[1], i[2], i[3], i[4], i[5], i[6], st);
+    case MI_OP_COPY: return mi_copy_bf16(p[0], i[0], p[1], i[1], i[2], c.l[0], i[3], st);
+    case MI_OP_COLSUM: return mi_colsum_bf16(p[0], i[0], c.l[0], i[1], (float*)p[1], i[2], st);
+    case MI_OP_LOSS_FWD: return mi_yolox_loss_fwd((const mi_yolox_loss_desc*)p[0], st);
+    case MI_OP_LOSS_BWD: return mi_yolox_loss_bwd((const mi_yolox_loss_desc*)p[0], (const float*)p[1], (float*)p[2], st);
+    case MI_OP_SPLIT_DPREDS:
+      return mi_yolox_split_dpreds((const float*)p[0], i[0], i[1], i[2], i[3], i[4], i[5], i[6], p[1], i[7], st);
+    case MI_OP_MEMSET:
+      if (hipMemsetAsync(p[0], i[0], (size_t)c.l[0], s) != hipSuccess) MI_FAIL(MI_ELAUNCH, "memset failed");
+      return MI_OK;
+    case MI_OP_SGD:
+      return mi_sgd_momentum_step((float*)p[0], (const float*)p[1], (float*)p[2], (const mi_sgd_seg*)p[3], i[0],
+                                  c.f[0], c.f[1], i[1], st);
+    case MI_OP_BN_EVAL_AFFINE:
+      return mi_bn_eval_affine((const float*)p[0], (const float*)p[1], (const float*)p[2], (const float*)p[3], c.f[0],
+                               i[0], (float*)p[4], (float*)p[5], st);
+    case MI_OP_DECODE: return mi_yolox_decode((float*)p[0], (const float*)p[1], i[0], i[1], i[2], st);
+    default: MI_FAIL(MI_EINVAL, "cmdlist: unknown op %d", c.op);
+  }
+}
+
+extern "C" int mi_cmdlist_run(const mi_cmd* cmds, int n, mi_stream_t st) {
+  if (mi_device_count() <= 0) MI_FAIL(MI_ENODEV, "no HIP device");
+  hipStream_t s = (hipStream_t)st;
+  for (int k = 0; k < n; ++k) {
+    const int rc = run_one(cmds[k], s);
+    if (rc != MI_OK) {
+      char tmp[400];
+      snprintf(tmp, sizeof(tmp), "%s", g_mi_err);
+      snprintf(g_mi_err, sizeof(g_mi_err), "cmd %d (op %d): %s", k, cmds[k].op, tmp);
+      return rc;
+    }
+  }
+  return MI_OK;
+}
+
+// ---- hipGraph capture / replay
+static std::mutex g_graph_mu;
+static std::unordered_map<int64_t, hipGraphExec_t> g_graphs;
+static int64_t g_next_graph = 1;
+
+extern "C" int64_t mi_graph_capture(const mi_cmd* cmds, int n, mi_stream_t st) {
+  if (mi_device_count() <= 0) MI_FAIL(MI_ENODEV, "no HIP device");
+  hipStream_t s = (hipStream_t)st;
+  if (s == nullptr) MI_FAIL(MI_EINVAL, "graph capture needs a non-default stream");
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess)
+    MI_FAIL(MI_ELAUNCH, "hipStreamBeginCapture failed");
+  const int rc = mi_cmdlist_run(cmds, n, st);
+  hipGraph_t graph = nullptr;
+  const hipError_t e = hipStreamEndCapture(s, &graph);
+  if (rc != MI_OK) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
+  }
+  if (e != hipSuccess || !graph) MI_FAIL(MI_ELAUNCH, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  hipGraphExec_t exec = nullptr;
+  const hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e2 != hipSuccess) MI_FAIL(MI_ELAUNCH, "hipGraphInstantiate: %s", hipGetErrorString(e2));
+  std::lock_guard<std::mutex> lk(g_graph_mu);
+  const int64_t h = g_next_graph++;
+  g_graphs[h] = exec;
+  return h;
+}
+extern "C" int mi_graph_launch(int64_t handle, mi_stream_t st) {
+  hipGraphExec_t exec;
+  {
+    std::lock_guard<std::mutex> lk(g_graph_mu);
+    auto it = g_graphs.find(handle);
+    if (it == g_graphs.end()) MI_FAIL(MI_EINVAL, "graph: bad handle");
+    exec = it->second;
+  }
+  const hipError_t e = hipGraphLaunch(exec, (hipStream_t)st);
+  if (e != hipSuccess) MI_FAIL(MI_ELAUNCH, "hipGraphLaunch: %s", hipGetErrorString(e));
+  return MI_OK;
+}
+extern "C" int mi_graph_destroy(int64_t handle) {
+  std::lock_guard<std::mutex> lk(g_graph_mu);
+  auto it = g_graphs.find(handle);
+  if (it == g_graphs.end()) return MI_EINVAL;
+  (void)hipGraphExecDestroy(it->second);
+  g_graphs.erase(it);
+  return MI_OK;
+}
+
+extern "C" int mi_cmdlist_time(const mi_cmd* cmds, int n, int iters, float* ms, float* per_cmd_ms, mi_stream_t st) {
+  if (mi_device_count() <= 0) MI_FAIL(MI_ENODEV, "no HIP device");
+  hipStream_t s = (hipStream_t)st;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) MI_FAIL(MI_ELAUNCH, "event create");
+  int rc = MI_OK;
+  if (ms) {
+    (void)hipEventRecord(e0, s);
+    for (int it = 0; it < iters && rc == MI_OK; ++it) rc = mi_cmdlist_run(cmds, n, st);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, e0, e1);
+    *ms = t / (float)(iters > 0 ? iters : 1);
+  }
+  if (per_cmd_ms && rc == MI_OK) {
+    for (int k = 0; k < n; ++k) per_cmd_ms[k] = 0.f;
+    for (int it = 0; it < iters && rc == MI_OK; ++it)
+      for (int k = 0; k < n && rc == MI_OK; ++k) {
+        (void)hipEventRecord(e0, s);
+        rc = mi_cmdlist_run(cmds + k, 1, st);
+        (void)hipEventRecord(e1, s);
+        (void)hipEventSynchronize(e1);
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, e0, e1);
+        per_cmd_ms[k] += t / (float)iters;
+      }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
+}
+
+// ---- layout probes: D = A x B through the exact lane mappings the conv kernels assume
+__global__ void probe_mfma32_kernel(const __bf16* A, const __bf16* B, float* D) {
+  // A [32][16] row-major (M x K), B [16][32] row-major (K x N)
+  const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+  bf16x8 a, b;
+  for (int j = 0; j < 8; ++j) {
+    a[j] = A[l31 * 16 + h * 8 + j];
+    b[j] = B[(h * 8 + j) * 32 + l31];
+  }
+  f32x16 acc;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+    D[row * 32 + l31] = acc[r];
+  }
+}
+__global__ void probe_mfma16_kernel(const __bf16* A, const __bf16* B, float* D) {
+  // A [16][32] row-major (M x K), B [32][16] row-major (K x N)
+  const int lane = threadIdx.x, t = lane & 15, g = lane >> 4;
+  bf16x8 a, b;
+  for (int j = 0; j < 8; ++j) {
+    a[j] = A[t * 32 + g * 8 + j];
+    b[j] = B[(g * 8 + j) * 16 + t];
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) D[(4 * g + r) * 16 + t] = acc[r];
+}
+extern "C" int mi_probe_mfma32(const void* a, const void* b, float* d, mi_stream_t st) {
+  hipLaunchKernelGGL(probe_mfma32_kernel, dim3(1), dim3(64), 0, (hipStream_t)st, (const __bf16*)a, (const __bf16*)b, d);
+  MI_CHECK_LAUNCH("probe_mfma32");
+  return MI_OK;
+}
+extern "C" int mi_probe_mfma16(const void* a, const void* b, float* d, mi_stream_t st) {
+  hipLaunchKernelGGL(probe_mfma16_kernel, dim3(1), dim3(64), 0, (hipStream_t)st, (const __bf16*)a, (const __bf16*)b, d);
+  MI_CHECK_LAUNCH("probe_mfma16");
+  return MI_OK;
+}

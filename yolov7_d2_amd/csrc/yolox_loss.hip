@@ -1,0 +1,445 @@
+// YOLOX head on the GPU with no host round trip: decode, SimOTA assignment, IoU / objectness /
+// class losses and their gradient with respect to the raw head outputs.
+//
+// Follows yolov7/modeling/head/yolox_head.py:
+//   get_output_and_grid :226-245   (decode xy/wh)
+//   get_losses          :274-441   (targets, loss sums, normalisation by num_fg)
+//   get_assignments     :450-547   (cost = cls + 3*iou + 1e5*~(in_box & in_centre))
+//   get_in_boxes_info   :549-633   (strict > 0 tests, centre radius 2.5 strides)
+//   dynamic_k_matching  :635-669   (k = max(1,int(sum top10 iou)), k smallest cost, conflicts -> argmin cost)
+// and yolov7/utils/boxes.py: bboxes_iou :57-81 (no eps), IOUloss :125-168 (eps 1e-16, 1 - iou^2).
+// The reference loops over images and ground truths on the host with .item() syncs; here the
+// batch is processed by four launches.  Compile with -ffp-contract=off: the float expressions keep
+// the reference's operation order so near-ties resolve the same way.
+#include "common.h"
+
+#define SIMOTA_INF 3.0e38f
+
+struct LossK {
+  const float* preds;
+  const float* labels;
+  const float* anchors;
+  int B, A, ncls, max_labels, gmax, nch;
+  float* cost;
+  float* iou;
+  uint8_t* match;
+  int32_t* ngt;
+  uint8_t* fg;
+  int32_t* matched_gt;
+  float* matched_iou;
+  float* partial;
+  float* out;
+};
+
+__device__ __forceinline__ float clamp_log(float v) { return fmaxf(logf(v), -100.0f); }
+__device__ __forceinline__ float sigmoid_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// number of valid labels: rows with sum > 0 (yolox_head.py:295)
+__device__ int count_labels(const float* lab, int max_labels) {
+  int n = 0;
+  for (int r = 0; r < max_labels; ++r) {
+    float s = lab[r * 5 + 0] + lab[r * 5 + 1];
+    s = s + lab[r * 5 + 2];
+    s = s + lab[r * 5 + 3];
+    s = s + lab[r * 5 + 4];
+    if (s > 0.f) ++n;
+  }
+  return n;
+}
+
+// ---- kernel 1: candidates, pairwise IoU and cost
+__global__ __launch_bounds__(256) void simota_cost_kernel(const LossK p) {
+  extern __shared__ float slab[];  // [gmax][5]
+  __shared__ int s_ngt;
+  const int b = blockIdx.y;
+  const float* lab = p.labels + (size_t)b * p.max_labels * 5;
+  if (threadIdx.x == 0) {
+    int n = count_labels(lab, p.max_labels);
+    if (n > p.gmax) n = p.gmax;
+    s_ngt = n;
+    if (blockIdx.x == 0) p.ngt[b] = n;
+  }
+  for (int i = threadIdx.x; i < p.gmax * 5; i += 256) slab[i] = lab[i];
+  __syncthreads();
+  const int G = s_ngt;
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  if (a >= p.A) return;
+  const float* pr = p.preds + ((size_t)b * p.A + a) * p.nch;
+  const float gxs = p.anchors[a * 3 + 0], gys = p.anchors[a * 3 + 1], st = p.anchors[a * 3 + 2];
+  // anchor centre (yolox_head.py:558-570)
+  const float xc = gxs * st + 0.5f * st;
+  const float yc = gys * st + 0.5f * st;
+  bool cand = false;
+  for (int g = 0; g < G; ++g) {
+    const float gcx = slab[g * 5 + 1], gcy = slab[g * 5 + 2], gw = slab[g * 5 + 3], gh = slab[g * 5 + 4];
+    const float bl = xc - (gcx - 0.5f * gw), br = (gcx + 0.5f * gw) - xc;
+    const float bt = yc - (gcy - 0.5f * gh), bb = (gcy + 0.5f * gh) - yc;
+    const bool inb = fminf(fminf(bl, bt), fminf(br, bb)) > 0.0f;
+    const float cl = xc - (gcx - 2.5f * st), cr = (gcx + 2.5f * st) - xc;
+    const float ct = yc - (gcy - 2.5f * st), cb = (gcy + 2.5f * st) - yc;
+    const bool inc = fminf(fminf(cl, ct), fminf(cr, cb)) > 0.0f;
+    cand = cand || inb || inc;
+  }
+  const size_t rowstride = (size_t)p.A;
+  float* costp = p.cost + (size_t)b * p.gmax * rowstride + a;
+  float* ioup = p.iou + (size_t)b * p.gmax * rowstride + a;
+  uint8_t* matchp = p.match + (size_t)b * p.gmax * rowstride + a;
+  if (!cand) {
+    for (int g = 0; g < G; ++g) {
+      costp[g * rowstride] = SIMOTA_INF;
+      ioup[g * rowstride] = -1.0f;
+      matchp[g * rowstride] = 0;
+    }
+    return;
+  }
+  // decode (yolox_head.py:243-244)
+  const float px = (pr[0] + gxs) * st, py = (pr[1] + gys) * st;
+  const float pw = expf(pr[2]) * st, ph = expf(pr[3]) * st;
+  const float so = sigmoid_ref(pr[4]);
+  float S = 0.f;  // sum_c max(log(1 - p_c), -100)
+  for (int c = 0; c < p.ncls; ++c) {
+    const float pc = sqrtf(sigmoid_ref(pr[5 + c]) * so);
+    S += clamp_log(1.0f - pc);
+  }
+  const float area_b = pw * ph;
+  for (int g = 0; g < G; ++g) {
+    const float gcls = slab[g * 5 + 0];
+    const float gcx = slab[g * 5 + 1], gcy = slab[g * 5 + 2], gw = slab[g * 5 + 3], gh = slab[g * 5 + 4];
+    const float bl = xc - (gcx - 0.5f * gw), br = (gcx + 0.5f * gw) - xc;
+    const float bt = yc - (gcy - 0.5f * gh), bb = (gcy + 0.5f * gh) - yc;
+    const bool inb = fminf(fminf(bl, bt), fminf(br, bb)) > 0.0f;
+    const float cl = xc - (gcx - 2.5f * st), cr = (gcx + 2.5f * st) - xc;
+    const float ct = yc - (gcy - 2.5f * st), cb = (gcy + 2.5f * st) - yc;
+    const bool inc = fminf(fminf(cl, ct), fminf(cr, cb)) > 0.0f;
+    // bboxes_iou(gt, pred, xyxy=False) boxes.py:66-81
+    const float tlx = fmaxf(gcx - gw / 2, px - pw / 2), tly = fmaxf(gcy - gh / 2, py - ph / 2);
+    const float brx = fminf(gcx + gw / 2, px + pw / 2), bry = fminf(gcy + gh / 2, py + ph / 2);
+    const float area_a = gw * gh;
+    const float en = (tlx < brx ? 1.f : 0.f) * (tly < bry ? 1.f : 0.f);
+    const float area_i = ((brx - tlx) * (bry - tly)) * en;
+    const float iou = area_i / (area_a + area_b - area_i);
+    const float iou_loss = -logf(iou + 1e-8f);
+    const int gc = (int)gcls;
+    const float pg = sqrtf(sigmoid_ref(pr[5 + gc]) * so);
+    const float lp = clamp_log(pg), l1p = clamp_log(1.0f - pg);
+    const float cls_loss = -lp - (S - l1p);
+    float cost = cls_loss + 3.0f * iou_loss;
+    cost = cost + 100000.0f * ((inb && inc) ? 0.f : 1.f);
+    costp[g * rowstride] = cost;
+    ioup[g * rowstride] = iou;
+    matchp[g * rowstride] = 0;
+  }
+}
+
+// ---- kernel 2: dynamic-k per (image, gt): block-wide ordered selection
+struct KV { float v; int i; };
+// order: larger v first (DESC) or smaller v first (ASC); ties -> smaller index first
+template <bool DESC>
+__device__ __forceinline__ bool kv_better(float v, int i, float bv, int bi) {
+  if (bi < 0) return true;
+  if (DESC) return v > bv || (v == bv && i < bi);
+  return v < bv || (v == bv && i < bi);
+}
+template <bool DESC>
+__device__ __forceinline__ bool kv_after(float v, int i, float lv, int li) {
+  // strictly after the last selected element in the total order
+  if (li < 0) return true;
+  if (DESC) return v < lv || (v == lv && i > li);
+  return v > lv || (v == lv && i > li);
+}
+template <bool DESC>
+__device__ KV block_select(const float* row, int A, float lv, int li, float invalid_lo, float invalid_hi, KV* sred) {
+  float bv = 0.f;
+  int bi = -1;
+  for (int a = threadIdx.x; a < A; a += 256) {
+    const float v = row[a];
+    if (v <= invalid_lo || v >= invalid_hi) continue;
+    if (!kv_after<DESC>(v, a, lv, li)) continue;
+    if (kv_better<DESC>(v, a, bv, bi)) { bv = v; bi = a; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (oi >= 0 && kv_better<DESC>(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+  }
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { sred[wave].v = bv; sred[wave].i = bi; }
+  __syncthreads();
+  KV best = sred[0];
+  for (int w = 1; w < 4; ++w)
+    if (sred[w].i >= 0 && kv_better<DESC>(sred[w].v, sred[w].i, best.v, best.i)) best = sred[w];
+  return best;
+}
+
+__global__ __launch_bounds__(256) void simota_dynk_kernel(const LossK p) {
+  __shared__ KV sred[4];
+  const int g = blockIdx.x, b = blockIdx.y;
+  if (g >= p.ngt[b]) return;
+  const float* iour = p.iou + ((size_t)b * p.gmax + g) * p.A;
+  const float* costr = p.cost + ((size_t)b * p.gmax + g) * p.A;
+  uint8_t* matchr = p.match + ((size_t)b * p.gmax + g) * p.A;
+  // top-10 IoU among candidates (iou >= 0), summed in descending order
+  float sum = 0.f, lv = 0.f;
+  int li = -1;
+  for (int r = 0; r < 10; ++r) {
+    const KV s = block_select<true>(iour, p.A, lv, li, -0.5f, INFINITY, sred);
+    if (s.i < 0) break;
+    sum += s.v;
+    lv = s.v;
+    li = s.i;
+  }
+  int k = (int)sum;
+  if (k < 1) k = 1;
+  lv = 0.f;
+  li = -1;
+  for (int r = 0; r < k; ++r) {
+    const KV s = block_select<false>(costr, p.A, lv, li, -INFINITY, SIMOTA_INF, sred);
+    if (s.i < 0) break;
+    if (threadIdx.x == 0) matchr[s.i] = 1;
+    lv = s.v;
+    li = s.i;
+  }
+}
+
+// shared decode of one prediction row
+struct Box { float x, y, w, h; };
+__device__ __forceinline__ Box decode_box(const float* pr, float gxs, float gys, float st) {
+  Box b;
+  b.x = (pr[0] + gxs) * st;
+  b.y = (pr[1] + gys) * st;
+  b.w = expf(pr[2]) * st;
+  b.h = expf(pr[3]) * st;
+  return b;
+}
+__device__ __forceinline__ float bce_logits(float x, float t) {
+  // F.binary_cross_entropy_with_logits: (1-t)*x + max(-x,0) + log1p(exp(-|x|))
+  return (1.f - t) * x + fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x)));
+}
+
+// ---- kernel 3: resolve conflicts, write assignment, accumulate loss sums
+__global__ __launch_bounds__(256) void simota_resolve_loss_kernel(const LossK p) {
+  __shared__ float sred[4][4];
+  const int b = blockIdx.y;
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  const int G = p.ngt[b];
+  float l_iou = 0.f, l_obj = 0.f, l_cls = 0.f, nfg = 0.f;
+  if (a < p.A) {
+    const size_t rs = (size_t)p.A;
+    const uint8_t* matchp = p.match + (size_t)b * p.gmax * rs + a;
+    const float* costp = p.cost + (size_t)b * p.gmax * rs + a;
+    int cnt = 0, gsel = -1;
+    for (int g = 0; g < G; ++g)
+      if (matchp[g * rs]) { ++cnt; gsel = g; }
+    if (cnt > 1) {  // yolox_head.py:653-657: argmin of cost over ALL gts, first minimum
+      float bv = costp[0];
+      gsel = 0;
+      for (int g = 1; g < G; ++g) {
+        const float v = costp[g * rs];
+        if (v < bv) { bv = v; gsel = g; }
+      }
+    }
+    const bool fg = cnt > 0;
+    const size_t o = (size_t)b * p.A + a;
+    p.fg[o] = fg ? 1 : 0;
+    p.matched_gt[o] = fg ? gsel : -1;
+    const float miou = fg ? p.iou[((size_t)b * p.gmax + gsel) * rs + a] : 0.f;
+    p.matched_iou[o] = miou;
+    const float* pr = p.preds + o * p.nch;
+    l_obj = bce_logits(pr[4], fg ? 1.f : 0.f);
+    if (fg) {
+      nfg = 1.f;
+      const float* lab = p.labels + ((size_t)b * p.max_labels + gsel) * 5;
+      const Box pb = decode_box(pr, p.anchors[a * 3 + 0], p.anchors[a * 3 + 1], p.anchors[a * 3 + 2]);
+      const float gx = lab[1], gy = lab[2], gw = lab[3], gh = lab[4];
+      // IOUloss boxes.py:131-151
+      const float tlx = fmaxf(pb.x - pb.w / 2, gx - gw / 2), tly = fmaxf(pb.y - pb.h / 2, gy - gh / 2);
+      const float brx = fminf(pb.x + pb.w / 2, gx + gw / 2), bry = fminf(pb.y + pb.h / 2, gy + gh / 2);
+      const float area_p = pb.w * pb.h, area_g = gw * gh;
+      const float en = (tlx < brx ? 1.f : 0.f) * (tly < bry ? 1.f : 0.f);
+      const float area_i = ((brx - tlx) * (bry - tly)) * en;
+      const float iou = area_i / (area_p + area_g - area_i + 1e-16f);
+      l_iou = 1.f - iou * iou;
+      const int gc = (int)lab[0];
+      for (int c = 0; c < p.ncls; ++c) l_cls += bce_logits(pr[5 + c], c == gc ? miou : 0.f);
+    }
+  }
+  l_iou = wave_sum(l_iou); l_obj = wave_sum(l_obj); l_cls = wave_sum(l_cls); nfg = wave_sum(nfg);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sred[wave][0] = l_iou; sred[wave][1] = l_obj; sred[wave][2] = l_cls; sred[wave][3] = nfg; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const float v = sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] + sred[3][threadIdx.x];
+    p.partial[((size_t)b * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = v;
+  }
+}
+
+__global__ __launch_bounds__(64) void loss_final_kernel(const float* partial, int nblk, const int32_t* ngt, int B,
+                                                        float* out) {
+  const int lane = threadIdx.x;
+  double s[4] = {0, 0, 0, 0};
+  for (int t = lane; t < nblk; t += 64)
+    for (int q = 0; q < 4; ++q) s[q] += (double)partial[(size_t)t * 4 + q];
+  double g = 0;
+  for (int b = lane; b < B; b += 64) g += (double)ngt[b];
+  for (int q = 0; q < 4; ++q) s[q] = wave_sum_d(s[q]);
+  g = wave_sum_d(g);
+  if (lane == 0) {
+    const double nfg = s[3];
+    const double N = nfg > 1.0 ? nfg : 1.0;
+    const float li = (float)(s[0] / N), lo = (float)(s[1] / N), lc = (float)(s[2] / N);
+    out[1] = 5.0f * li;
+    out[2] = lo;
+    out[3] = lc;
+    out[0] = 5.0f * li + lo + lc;
+    out[4] = 0.f;
+    out[5] = (float)(N / (g > 1.0 ? g : 1.0));
+    out[6] = (float)nfg;
+    out[7] = (float)g;
+  }
+}
+
+static int loss_fill(const mi_yolox_loss_desc* d, LossK* k) {
+  MI_REQUIRE(d->preds && d->labels && d->anchors && d->cost && d->iou && d->match && d->ngt && d->fg &&
+                 d->matched_gt && d->matched_iou && d->partial && d->out,
+             "yolox_loss: null pointer");
+  MI_REQUIRE(d->B > 0 && d->A > 0 && d->ncls > 0 && d->gmax > 0 && d->gmax <= d->max_labels, "yolox_loss: sizes");
+  k->preds = d->preds; k->labels = d->labels; k->anchors = d->anchors;
+  k->B = d->B; k->A = d->A; k->ncls = d->ncls; k->max_labels = d->max_labels; k->gmax = d->gmax;
+  k->nch = 5 + d->ncls;
+  k->cost = d->cost; k->iou = d->iou; k->match = d->match; k->ngt = d->ngt; k->fg = d->fg;
+  k->matched_gt = d->matched_gt; k->matched_iou = d->matched_iou; k->partial = d->partial; k->out = d->out;
+  return MI_OK;
+}
+
+extern "C" int mi_yolox_loss_fwd(const mi_yolox_loss_desc* d, mi_stream_t st) {
+  LossK k;
+  int rc = loss_fill(d, &k);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)st;
+  const int nb = mi_cdiv(d->A, 256);
+  hipLaunchKernelGGL(simota_cost_kernel, dim3(nb, d->B), dim3(256), d->gmax * 5 * sizeof(float), s, k);
+  MI_CHECK_LAUNCH("simota_cost");
+  hipLaunchKernelGGL(simota_dynk_kernel, dim3(d->gmax, d->B), dim3(256), 0, s, k);
+  MI_CHECK_LAUNCH("simota_dynk");
+  hipLaunchKernelGGL(simota_resolve_loss_kernel, dim3(nb, d->B), dim3(256), 0, s, k);
+  MI_CHECK_LAUNCH("simota_resolve_loss");
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, d->partial, nb * d->B, d->ngt, d->B, d->out);
+  MI_CHECK_LAUNCH("loss_final");
+  return MI_OK;
+}
+
+// ---- backward: gradient with respect to the raw head outputs
+__global__ __launch_bounds__(256) void yolox_loss_bwd_kernel(const LossK p, const float* gw, float* dpreds) {
+  const int b = blockIdx.y;
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  if (a >= p.A) return;
+  const float nfg = p.out[6];
+  const float N = nfg > 1.f ? nfg : 1.f;
+  const float w_iou = 5.0f * (gw[0] + gw[1]) / N;
+  const float w_obj = (gw[0] + gw[2]) / N;
+  const float w_cls = (gw[0] + gw[3]) / N;
+  const size_t o = (size_t)b * p.A + a;
+  const float* pr = p.preds + o * p.nch;
+  float* dp = dpreds + o * p.nch;
+  const bool fg = p.fg[o] != 0;
+  dp[4] = w_obj * (sigmoid_ref(pr[4]) - (fg ? 1.f : 0.f));
+  if (!fg) {
+    dp[0] = dp[1] = dp[2] = dp[3] = 0.f;
+    for (int c = 0; c < p.ncls; ++c) dp[5 + c] = 0.f;
+    return;
+  }
+  const int gsel = p.matched_gt[o];
+  const float miou = p.matched_iou[o];
+  const float* lab = p.labels + ((size_t)b * p.max_labels + gsel) * 5;
+  const int gc = (int)lab[0];
+  for (int c = 0; c < p.ncls; ++c) dp[5 + c] = w_cls * (sigmoid_ref(pr[5 + c]) - (c == gc ? miou : 0.f));
+  const float st = p.anchors[a * 3 + 2];
+  const Box pb = decode_box(pr, p.anchors[a * 3 + 0], p.anchors[a * 3 + 1], st);
+  const float gx = lab[1], gy = lab[2], gw_ = lab[3], gh = lab[4];
+  const float ptlx = pb.x - pb.w / 2, ptly = pb.y - pb.h / 2, pbrx = pb.x + pb.w / 2, pbry = pb.y + pb.h / 2;
+  const float gtlx = gx - gw_ / 2, gtly = gy - gh / 2, gbrx = gx + gw_ / 2, gbry = gy + gh / 2;
+  const float tlx = fmaxf(ptlx, gtlx), tly = fmaxf(ptly, gtly), brx = fminf(pbrx, gbrx), bry = fminf(pbry, gbry);
+  const float en = (tlx < brx ? 1.f : 0.f) * (tly < bry ? 1.f : 0.f);
+  const float wi = brx - tlx, hi = bry - tly;
+  const float I = wi * hi * en;
+  const float D = pb.w * pb.h + gw_ * gh - I + 1e-16f;
+  const float u = I / D;
+  const float dLdu = -2.f * u;
+  const float dLdI = dLdu * (D + I) / (D * D);
+  const float dLdAp = dLdu * (-I / (D * D));
+  // max/min sub-gradients (ties split evenly, as ATen's maximum/minimum backward does)
+  const float tlx_p = ptlx > gtlx ? 1.f : (ptlx == gtlx ? 0.5f : 0.f);
+  const float tly_p = ptly > gtly ? 1.f : (ptly == gtly ? 0.5f : 0.f);
+  const float brx_p = pbrx < gbrx ? 1.f : (pbrx == gbrx ? 0.5f : 0.f);
+  const float bry_p = pbry < gbry ? 1.f : (pbry == gbry ? 0.5f : 0.f);
+  const float dI_dtlx = -hi * en, dI_dbrx = hi * en, dI_dtly = -wi * en, dI_dbry = wi * en;
+  const float dpx = dLdI * (dI_dtlx * tlx_p + dI_dbrx * brx_p);
+  const float dpy = dLdI * (dI_dtly * tly_p + dI_dbry * bry_p);
+  const float dpw = dLdI * (dI_dtlx * (-0.5f) * tlx_p + dI_dbrx * 0.5f * brx_p) + dLdAp * pb.h;
+  const float dph = dLdI * (dI_dtly * (-0.5f) * tly_p + dI_dbry * 0.5f * bry_p) + dLdAp * pb.w;
+  dp[0] = w_iou * dpx * st;
+  dp[1] = w_iou * dpy * st;
+  dp[2] = w_iou * dpw * pb.w;
+  dp[3] = w_iou * dph * pb.h;
+}
+
+extern "C" int mi_yolox_loss_bwd(const mi_yolox_loss_desc* d, const float* gw, float* dpreds, mi_stream_t st) {
+  LossK k;
+  int rc = loss_fill(d, &k);
+  if (rc) return rc;
+  MI_REQUIRE(gw && dpreds, "yolox_loss_bwd: null");
+  hipLaunchKernelGGL(yolox_loss_bwd_kernel, dim3(mi_cdiv(d->A, 256), d->B), dim3(256), 0, (hipStream_t)st, k, gw,
+                     dpreds);
+  MI_CHECK_LAUNCH("yolox_loss_bwd");
+  return MI_OK;
+}
+
+// ---- extract one prediction conv's out-gradient: channels [c0,c0+nc) -> bf16 NHWC map, pads zero
+__global__ __launch_bounds__(256) void split_dpreds_kernel(const float* __restrict__ dpreds, int B, int A, int nch,
+                                                           int a0, int HW, int c0, int nc, __bf16* dst, int ld) {
+  const int64_t total = (int64_t)B * HW * ld;
+  for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int j = (int)(idx % ld);
+    const int64_t bp = idx / ld;
+    const int b = (int)(bp / HW), pidx = (int)(bp % HW);
+    float v = 0.f;
+    if (j < nc) v = dpreds[((size_t)b * A + a0 + pidx) * nch + c0 + j];
+    dst[idx] = (__bf16)v;
+  }
+}
+extern "C" int mi_yolox_split_dpreds(const float* dpreds, int B, int A, int nch, int a0, int HW, int c0, int nc,
+                                     void* dst, int ld, mi_stream_t st) {
+  MI_REQUIRE(dpreds && dst && ld >= nc && c0 >= 0 && c0 + nc <= nch && a0 >= 0 && a0 + HW <= A, "split_dpreds: args");
+  const int64_t total = (int64_t)B * HW * ld;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(split_dpreds_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)st, dpreds, B, A, nch, a0, HW,
+                     c0, nc, (__bf16*)dst, ld);
+  MI_CHECK_LAUNCH("split_dpreds");
+  return MI_OK;
+}
+
+// ---- eval decode (yolox_head.py:197-224,247-272): sigmoid(obj, cls), xy/wh decode, in place
+__global__ __launch_bounds__(256) void yolox_decode_kernel(float* preds, const float* anchors, int B, int A, int nch) {
+  const int64_t total = (int64_t)B * A;
+  for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int a = (int)(idx % A);
+    float* pr = preds + idx * nch;
+    const float gxs = anchors[a * 3 + 0], gys = anchors[a * 3 + 1], st = anchors[a * 3 + 2];
+    pr[0] = (pr[0] + gxs) * st;
+    pr[1] = (pr[1] + gys) * st;
+    pr[2] = expf(pr[2]) * st;
+    pr[3] = expf(pr[3]) * st;
+    for (int c = 4; c < nch; ++c) pr[c] = sigmoid_ref(pr[c]);
+  }
+}
+extern "C" int mi_yolox_decode(float* preds, const float* anchors, int B, int A, int ncls, mi_stream_t st) {
+  MI_REQUIRE(preds && anchors && B > 0 && A > 0 && ncls > 0, "decode: args");
+  const int64_t total = (int64_t)B * A;
+  hipLaunchKernelGGL(yolox_decode_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)st, preds,
+                     anchors, B, A, ncls + 5);
+  MI_CHECK_LAUNCH("decode");
+  return MI_OK;
+}

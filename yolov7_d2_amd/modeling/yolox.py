@@ -1,0 +1,230 @@
+"""YOLOX meta-architecture — the drop-in for yolov7/modeling/meta_arch/yolox.py:35-252.
+
+Same registry name (`YOLOX`), constructor `(cfg)`, config keys, `forward(batched_inputs)` contract,
+loss-dict keys and state_dict keys as the reference; the compute is one MI355X step plan
+(yolov7_d2_amd/plan.py) per input shape, executed by libmi355det.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from ..d2shim import META_ARCH_REGISTRY, Boxes, ImageList, Instances, build_backbone, detector_postprocess
+from ..params import ParamArena
+from ..plan import PlanBuilder
+from .blocks import EmitCtx
+from .postprocess import postprocess
+from .yolox_net import YOLOPAFPN, YOLOXHead
+
+
+def xyxy_to_cxcywh(b):
+    """BoxModeMy.convert(XYXY_ABS -> 'XYWH_ABS') of yolov7/utils/boxes.py:547-551, which yields (cx, cy, w, h)"""
+    out = b.clone().float()
+    out[:, 2] = b[:, 2] - b[:, 0]
+    out[:, 3] = b[:, 3] - b[:, 1]
+    out[:, 0] = b[:, 0] + out[:, 2] * 0.5
+    out[:, 1] = b[:, 1] + out[:, 3] * 0.5
+    return out
+
+
+class _PlanState:
+    """one compiled step for a fixed (B, H, W): plan + persistent I/O tensors"""
+
+    def __init__(self, model, B, H, W, training, materialize=True):
+        dev = model.device
+        self.B, self.H, self.W, self.training = B, H, W, training
+        self.image = torch.zeros(B, 3, H, W, dtype=torch.float32, device=dev)
+        self.labels = torch.zeros(B, model.max_boxes_num, 5, dtype=torch.float32, device=dev)
+        hw = [(H // s, W // s) for s in model.head.strides]
+        self.A = sum(h * w for h, w in hw)
+        self.anchors = YOLOXHead.anchors_for(hw, model.head.strides).to(dev)
+        b = PlanBuilder(dev, training=training)
+        ctx = EmitCtx(b, model.params)
+        outs = model.neck.alloc(ctx, B, H // 8, W // 8)
+        feats = model.backbone.emit(ctx, self.image, B, H, W, outs=outs)
+        for k, sl in outs.items():  # a backbone that did not write in place: copy (generic fallback)
+            if feats[k].buf is not sl.buf:
+                raise NotImplementedError("backbone output not written into the neck concat slice")
+        fpn = model.neck.emit(ctx, feats)
+        nch = 5 + model.num_classes
+        self.preds_buf = b.small("preds", B * self.A * nch * 4)
+        model.head.emit(ctx, fpn, self.preds_buf, self.A)
+        if training:
+            self.loss = b.yolox_loss(self.preds_buf, self.labels, self.anchors, B, self.A, model.num_classes,
+                                     model.max_boxes_num, model.max_boxes_num)
+        else:
+            b.emit("DECODE", i=[B, self.A, model.num_classes], p=[self.preds_buf, self.anchors], tag="decode")
+        self.builder = b
+        self.plan = b.finalize(materialize)
+        self.nch = nch
+
+    def preds(self):
+        return self.plan.buf_view(self.preds_buf, torch.float32, self.B * self.A * self.nch).view(self.B, self.A, self.nch)
+
+    def loss_out(self):
+        return self.plan.buf_view(self.loss["out"], torch.float32, 8)
+
+    def gw(self):
+        return self.plan.buf_view(self.loss["gw"], torch.float32, 4)
+
+
+class _YoloxTrainFn(torch.autograd.Function):
+    """autograd bridge: forward = forward command list, backward = backward command list"""
+
+    @staticmethod
+    def forward(ctx, ps, model, images, labels, *params):
+        ps.image.copy_(images)
+        ps.labels.copy_(labels)
+        ps.plan.run("fwd")
+        ctx.ps, ctx.model = ps, model
+        return ps.loss_out()[:6].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        ps, model = ctx.ps, ctx.model
+        ps.gw().copy_(g[:4].to(torch.float32))
+        ps.plan.run("bwd")
+        grads = [model.params.grad_of(p).clone() for _, p in model.named_parameters()]
+        return (None, None, None, None, *grads)
+
+
+@META_ARCH_REGISTRY.register()
+class YOLOX(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.device = torch.device(cfg.MODEL.DEVICE)
+        self.conf_threshold = cfg.MODEL.YOLO.CONF_THRESHOLD
+        self.nms_threshold = cfg.MODEL.YOLO.NMS_THRESHOLD
+        self.nms_type = cfg.MODEL.NMS_TYPE
+        self.loss_type = cfg.MODEL.YOLO.LOSS_TYPE
+        self.use_l1 = False  # never enabled by the reference either (update_iter has no caller)
+        self.depth_mul = cfg.MODEL.YOLO.DEPTH_MUL
+        self.width_mul = cfg.MODEL.YOLO.WIDTH_MUL
+        self.iter = 0
+        self.max_iter = cfg.SOLVER.MAX_ITER
+        self.enable_l1_loss_at = cfg.INPUT.MOSAIC_AND_MIXUP.DISABLE_AT_ITER
+        self.num_classes = cfg.MODEL.YOLO.CLASSES
+        self.max_boxes_num = cfg.MODEL.YOLO.MAX_BOXES_NUM
+        self.in_features = cfg.MODEL.YOLO.IN_FEATURES
+        self.backbone = build_backbone(cfg)
+        self.size_divisibility = 32 if self.backbone.size_divisibility == 0 else self.backbone.size_divisibility
+        self.neck = YOLOPAFPN(depth=self.depth_mul, width=self.width_mul, in_features=self.in_features)
+        self.head = YOLOXHead(self.num_classes, width=self.width_mul)
+        self.padded_value = cfg.MODEL.PADDED_VALUE
+        self.onnx_export = False
+        self.apply(self._init_model)
+        self.head.initialize_biases(1e-2)
+        self.params = None
+        self._plans = {}
+        self.to(self.device)
+
+    @staticmethod
+    def _init_model(M):
+        for m in M.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eps = 1e-3
+                m.momentum = 0.03
+
+    def update_iter(self, i):
+        self.iter = i
+
+    def _apply(self, fn, *a, **k):
+        # moving the module invalidates every cached pointer
+        self.params = None
+        self._plans = {}
+        return super()._apply(fn, *a, **k)
+
+    # ------------------------------------------------------------------ plans
+    def ensure_params(self):
+        if self.params is None:
+            if self.device.type != "cuda":
+                raise L.MI355Error(f"YOLOX on MODEL.DEVICE={self.device}: the MI355X path needs a HIP device; "
+                                   "the CPU reference lives in oracle/ (test infrastructure only)")
+            L.require_device()
+            self.params = ParamArena(self, self.device)
+        return self.params
+
+    def plan_for(self, B, H, W, training):
+        self.ensure_params()
+        key = (B, H, W, bool(training))
+        ps = self._plans.get(key)
+        if ps is None:
+            assert H % 32 == 0 and W % 32 == 0, (H, W)
+            ps = _PlanState(self, B, H, W, training)
+            self._plans[key] = ps
+        return ps
+
+    # ------------------------------------------------------------------ reference-shaped preprocessing
+    def preprocess_image(self, batched_inputs, training):
+        """yolox.py:95-162: float (no mean/std), pad to /32 with PADDED_VALUE, labels [B, max_boxes, 5]"""
+        images = [x["image"].to(self.device).type(torch.float) for x in batched_inputs]
+        bs = len(images)
+        images = ImageList.from_tensors(images, size_divisibility=self.size_divisibility, pad_value=self.padded_value)
+        labels = None
+        if training:
+            key = "instances" if "instances" in batched_inputs[0] else "targets"
+            labels = torch.zeros((bs, self.max_boxes_num, 5))
+            for i, x in enumerate(batched_inputs):
+                inst = x[key]
+                boxes = inst.gt_boxes.tensor.detach().cpu()
+                t = torch.cat([inst.gt_classes.detach().cpu().float().unsqueeze(-1), xyxy_to_cxcywh(boxes)], dim=-1)
+                t = t[: self.max_boxes_num]
+                labels[i, : t.shape[0]] = t
+        return images, labels, images.image_sizes
+
+    def forward(self, batched_inputs):
+        self.ensure_params()   # raises MI355Error when there is no HIP device: no CPU fallback
+        images, labels, image_ori_sizes = self.preprocess_image(batched_inputs, self.training)
+        x = images.tensor
+        B, _, H, W = x.shape
+        if self.training:
+            ps = self.plan_for(B, H, W, True)
+            out = _YoloxTrainFn.apply(ps, self, x, labels.to(x.device), *[p for _, p in self.named_parameters()])
+            return {"total_loss": out[0], "iou_loss": out[1], "conf_loss": out[2], "cls_loss": out[3]}
+        ps = self.plan_for(B, H, W, False)
+        ps.image.copy_(x)
+        ps.plan.run("fwd")
+        outputs = ps.preds().clone()
+        detections = postprocess(outputs, self.num_classes, self.conf_threshold, self.nms_threshold)
+        results = []
+        for idx, out in enumerate(detections):
+            if out is None:
+                out = x.new_zeros((0, 7))
+            result = Instances(image_ori_sizes[idx])
+            result.pred_boxes = Boxes(out[:, :4])
+            result.scores = out[:, 5] * out[:, 4]
+            result.pred_classes = out[:, -1]
+            results.append(result)
+        processed = []
+        for r, inp, image_size in zip(results, batched_inputs, images.image_sizes):
+            height = inp.get("height", image_size[0])
+            width = inp.get("width", image_size[1])
+            processed.append({"instances": detector_postprocess(r, height, width)})
+        return processed
+
+
+def run_backbone_standalone(backbone, x):
+    """Backbone.forward(x) -> dict[name, Tensor] (darknetx.py:165-177) as a forward-only plan.
+    BatchNorm uses batch statistics iff backbone.training; no autograd through a bare backbone."""
+    if not x.is_cuda:
+        raise L.MI355Error("CSPDarknet.forward needs a HIP tensor (no CPU fallback)")
+    L.require_device()
+    B, _, H, W = x.shape
+    cache = backbone.__dict__.setdefault("_mi_plans", {})
+    key = (B, H, W, backbone.training)
+    st = cache.get(key)
+    if st is None:
+        from ..params import ParamArena  # parameters stay where they are: a grad-less arena is not needed
+
+        class _NoGrad:
+            def grad_of(self, p):
+                return None
+
+        b = PlanBuilder(x.device, training=False, bn_train=backbone.training)
+        image = torch.zeros(B, 3, H, W, dtype=torch.float32, device=x.device)
+        feats = backbone.emit(EmitCtx(b, _NoGrad()), image, B, H, W)
+        st = (b.finalize(), image, feats)
+        cache[key] = st
+    plan, image, feats = st
+    image.copy_(x)
+    plan.run("fwd")
+    return {k: plan.view(t).float() for k, t in feats.items()}

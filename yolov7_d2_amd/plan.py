@@ -1,0 +1,521 @@
+"""Step plan: the host-side graph builder that turns the reference's module tree
+(BaseConv / CSPLayer / YOLOPAFPN / YOLOXHead ...) into two flat command lists (forward, backward)
+over one device arena, executed by libmi355det's C++ command-list runner or replayed as a hipGraph.
+
+Nothing here computes: it only lays out buffers (NHWC bf16 activations, concat buffers whose channel
+slices are written in place by their producers, gradient mirrors, shared scratch) and records which
+C-ABI entry runs on which pointers.  Gradient fan-in (a tensor read by several consumers) is resolved
+statically: the first backward writer overwrites, later ones accumulate in their epilogue.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+
+def _rup(a, b):
+    return (a + b - 1) // b * b
+
+
+class Buf:
+    """A region of the arena (offset assigned at finalize)."""
+
+    def __init__(self, name, nbytes, zero=False):
+        self.name, self.nbytes, self.offset, self.zero = name, int(nbytes), None, zero
+        self.base = None
+
+    @property
+    def ptr(self):
+        return self.base + self.offset
+
+
+class TRef:
+    """bf16 NHWC view: N x H x W x C at channel offset `coff` of a buffer with pixel stride `ld`."""
+
+    def __init__(self, buf, N, H, W, C, ld, coff=0, gbuf=None):
+        self.buf, self.N, self.H, self.W, self.C, self.ld, self.coff, self.gbuf = buf, N, H, W, C, ld, coff, gbuf
+
+    @property
+    def ptr(self):
+        return self.buf.ptr + 2 * self.coff
+
+    @property
+    def npix(self):
+        return self.N * self.H * self.W
+
+    @property
+    def requires_grad(self):
+        return self.gbuf is not None
+
+    @property
+    def grad(self):
+        assert self.gbuf is not None, "tensor has no gradient buffer"
+        return TRef(self.gbuf, self.N, self.H, self.W, self.C, self.ld, self.coff, None)
+
+    def slice(self, c0, c1):
+        assert 0 <= c0 < c1 <= self.C and c0 % 8 == 0 and c1 % 8 == 0
+        return TRef(self.buf, self.N, self.H, self.W, c1 - c0, self.ld, self.coff + c0, self.gbuf)
+
+
+class _Ptr:
+    """late-bound pointer: buffer (+ byte offset) or torch tensor"""
+
+    def __init__(self, obj, off=0):
+        self.obj, self.off = obj, off
+
+    def resolve(self):
+        o = self.obj
+        if o is None:
+            return None
+        if isinstance(o, (Buf, TRef)):
+            return o.ptr + self.off
+        if isinstance(o, torch.Tensor):
+            return o.data_ptr() + self.off
+        if isinstance(o, int):
+            return o + self.off
+        raise TypeError(type(o))
+
+
+class _Cmd:
+    def __init__(self, op, i=(), f=(), p=(), l=(), desc=None, tag=""):
+        self.op, self.i, self.f, self.p, self.l, self.desc, self.tag = op, list(i), list(f), list(p), list(l), desc, tag
+
+
+class ConvSpec:
+    """symbolic mi_conv_desc"""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class PlanBuilder:
+    def __init__(self, device, training=True, bn_train=None):
+        self.device = torch.device(device)
+        self.training = training            # build the backward command list
+        self.bn_train = training if bn_train is None else bn_train  # batch statistics vs running statistics
+        self.bufs = []
+        self.shared = {}
+        self.prologue = []   # weight packing etc, start of forward
+        self.fwd = []
+        self.bwd_gens = []   # closures run in reverse at finalize
+        self.bwd = []
+        self._emitting_bwd = False
+        self.grad_init = {}  # id(gbuf) -> list of (c0,c1) initialised channel intervals
+        self.keep = []       # python objects that must outlive the plan (ctypes descs, tensors)
+        self.loss = None
+        self.conv_records = []  # (tag, spec) for roofline bookkeeping
+
+    # ---------------------------------------------------------------- buffers
+    def _new_buf(self, name, nbytes, zero=False):
+        b = Buf(name, _rup(max(int(nbytes), 16), 256), zero)
+        self.bufs.append(b)
+        return b
+
+    def new_act(self, N, H, W, C, name, requires_grad=True):
+        assert C % 8 == 0
+        b = self._new_buf(name, N * H * W * C * 2)
+        g = self._new_buf(name + ".grad", N * H * W * C * 2) if (requires_grad and self.training) else None
+        return TRef(b, N, H, W, C, C, 0, g)
+
+    def small(self, name, nbytes, zero=False):
+        return self._new_buf(name, nbytes, zero)
+
+    def scratch(self, key, nbytes):
+        """shared scratch (max size over requests); valid only between adjacent commands of one layer"""
+        b = self.shared.get(key)
+        if b is None:
+            b = Buf("scratch." + key, 0)
+            self.shared[key] = b
+            self.bufs.append(b)
+        b.nbytes = max(b.nbytes, _rup(int(nbytes), 256))
+        return b
+
+    # ---------------------------------------------------------------- command emission
+    def emit(self, op, i=(), f=(), p=(), l=(), desc=None, tag="", prologue=False):
+        c = _Cmd(L.OP[op], i, f, [x if isinstance(x, _Ptr) else _Ptr(x) for x in p], l, desc, tag)
+        if self._emitting_bwd:
+            self.bwd.append(c)
+        elif prologue:
+            self.prologue.append(c)
+        else:
+            self.fwd.append(c)
+        return c
+
+    def on_backward(self, fn):
+        if self.training:
+            self.bwd_gens.append(fn)
+
+    def grad_mode(self, t):
+        """returns 1 (accumulate) if t's gradient region was already written in this backward pass, else 0
+        and marks it written."""
+        key = id(t.gbuf)
+        iv = self.grad_init.setdefault(key, [])
+        c0, c1 = t.coff, t.coff + t.C
+        covered = [a for a in iv if a[0] < c1 and c0 < a[1]]
+        if not covered:
+            iv.append((c0, c1))
+            return 0
+        # must be fully covered by the union of existing intervals
+        pts = sorted(covered)
+        cur = c0
+        for a0, a1 in pts:
+            if a0 > cur:
+                break
+            cur = max(cur, a1)
+        if cur >= c1:
+            return 1
+        raise NotImplementedError(f"partial gradient overlap on {t.buf.name} [{c0},{c1}) vs {pts}")
+
+    def grad_ready(self, t):
+        iv = self.grad_init.get(id(t.gbuf), [])
+        c0, c1 = t.coff, t.coff + t.C
+        cur = c0
+        for a0, a1 in sorted(iv):
+            if a0 > cur:
+                break
+            cur = max(cur, a1)
+        return cur >= c1
+
+    # ---------------------------------------------------------------- conv helpers
+    @staticmethod
+    def fwd_taps(k, pad):
+        return [(r - pad, s - pad, r * k + s) for r in range(k) for s in range(k)]
+
+    def conv_cmd(self, tag, x, w_img, K8, y_ptr, ldy, outH, outW, Cout, CoutPad, taps, in_stride=1, out_stride=1,
+                 out_oy=0, out_ox=0, gridH=None, gridW=None, bias=None, stats=None, flags=0, y_nstride=0,
+                 inH=None, inW=None):
+        spec = ConvSpec(x=_Ptr(x), w=_Ptr(w_img), y=y_ptr if isinstance(y_ptr, _Ptr) else _Ptr(y_ptr),
+                        bias=_Ptr(bias), stats=_Ptr(stats), ldx=x.ld, ldy=ldy, y_nstride=y_nstride, N=x.N,
+                        H=x.H if inH is None else inH, W=x.W if inW is None else inW, outH=outH, outW=outW,
+                        gridH=outH if gridH is None else gridH, gridW=outW if gridW is None else gridW,
+                        in_stride=in_stride, out_stride=out_stride, out_oy=out_oy, out_ox=out_ox, K8=K8, Cout=Cout,
+                        CoutPad=CoutPad, taps=taps, flags=flags, tag=tag)
+        self.conv_records.append(spec)
+        return self.emit("CONV", desc=spec, tag=tag)
+
+    def plan_conv_tiles(self, N, gridH, gridW):
+        """number of pixel tiles the launcher will use (mirror of choose_tile in conv_igemm.hip via the C call)"""
+        d = L.mi_conv_desc()
+        d.N, d.gridH, d.gridW, d.outH, d.outW = N, gridH, gridW, gridH, gridW
+        d.H, d.W = gridH, gridW
+        d.in_stride = d.out_stride = 1
+        d.K8, d.Cout, d.CoutPad, d.ntaps = 2, 32, 32, 1
+        d.ldx, d.ldy = 16, 32
+        d.x = d.w = d.y = 256  # non-null, 16B aligned dummies; nothing is launched
+        n = L.lib().mi_conv2d_plan(C.byref(d))
+        L.check(n, "mi_conv2d_plan")
+        return n
+
+    # ---------------------------------------------------------------- layers
+    def base_conv(self, tag, x, weight, bn, k, stride, wgrad, out=None, res=None, act=1):
+        """Conv(k, stride, pad=(k-1)//2, no bias) -> BatchNorm -> SiLU (+ res).
+        weight: fp32 OIHW tensor; wgrad: fp32 OIHW gradient view (training);
+        bn: dict(gamma, beta, rm, rv, nbt, eps, momentum, ggamma, gbeta)."""
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        assert weight.shape[2] == k and Cout % 32 == 0
+        pad = (k - 1) // 2
+        Ho = (x.H + 2 * pad - k) // stride + 1
+        Wo = (x.W + 2 * pad - k) // stride + 1
+        CinPad = _rup(Cin, 16)
+        assert x.C >= Cin and (x.C == CinPad or x.C == Cin), (tag, x.C, Cin)
+        KK = k * k
+        wf = self.small(tag + ".wf", KK * CinPad * Cout * 2)
+        need_dgrad = self.training and x.requires_grad
+        wd = self.small(tag + ".wd", KK * Cout * _rup(Cin, 32) * 2) if need_dgrad else None
+        CinPadN = _rup(Cin, 32)
+        self.emit("PACK_W", i=[Cout, Cin, k, k, CinPad, Cout, Cout, CinPadN], p=[weight, wf, wd], tag=tag + ".pack",
+                  prologue=True)
+        y = self.new_act(x.N, Ho, Wo, Cout, tag + ".y", requires_grad=False)
+        if out is None:
+            out = self.new_act(x.N, Ho, Wo, Cout, tag + ".out")
+        assert (out.N, out.H, out.W, out.C) == (x.N, Ho, Wo, Cout)
+        scale = self.small(tag + ".scale", Cout * 4)
+        shift = self.small(tag + ".shift", Cout * 4)
+        taps = self.fwd_taps(k, pad)
+        count = x.N * Ho * Wo
+        if self.bn_train:
+            mean = self.small(tag + ".mean", Cout * 4)
+            invstd = self.small(tag + ".invstd", Cout * 4)
+            ntiles = self.plan_conv_tiles(x.N, Ho, Wo)
+            part = self.scratch("bn_partial", ntiles * Cout * 2 * 4)
+            self.conv_cmd(tag + ".conv", x, wf, CinPad // 8, y, y.ld, Ho, Wo, Cout, Cout, taps, in_stride=stride,
+                          stats=part)
+            self.emit("BN_FINALIZE", i=[ntiles, Cout, Cout], l=[count], f=[bn["eps"], bn["momentum"]],
+                      p=[part, bn["gamma"], bn["beta"], bn["rm"], bn["rv"], bn["nbt"], scale, shift, mean, invstd],
+                      tag=tag + ".bnfin")
+        else:
+            self.conv_cmd(tag + ".conv", x, wf, CinPad // 8, y, y.ld, Ho, Wo, Cout, Cout, taps, in_stride=stride)
+            self.emit("BN_EVAL_AFFINE", i=[Cout], f=[bn["eps"]],
+                      p=[bn["gamma"], bn["beta"], bn["rm"], bn["rv"], scale, shift], tag=tag + ".bnaff")
+        self.emit("BN_ACT_FWD", i=[y.ld, res.ld if res is not None else 0, out.ld, Cout, act], l=[count],
+                  p=[y, scale, shift, res, out], tag=tag + ".bnact")
+
+        def bwd():
+            da = out.grad
+            assert self.grad_ready(out), f"{tag}: output gradient never written"
+            C8 = Cout // 8
+            nblk = max(1, min(1024, math.ceil(count / (256 // C8) / 4)))
+            part2 = self.scratch("bn_bwd_partial", nblk * Cout * 2 * 4)
+            c1 = self.scratch("bn_c1", Cout * 4)
+            c2 = self.scratch("bn_c2", Cout * 4)
+            dy = self.scratch("dy", count * Cout * 2)
+            dyT = TRef(dy, x.N, Ho, Wo, Cout, Cout)
+            self.emit("BN_BWD_REDUCE", i=[da.ld, y.ld, nblk, Cout, act], l=[count],
+                      p=[da, y, scale, shift, mean, invstd, part2], tag=tag + ".bnred")
+            self.emit("BN_BWD_FINALIZE", i=[nblk, Cout], l=[count], p=[part2, bn["ggamma"], bn["gbeta"], c1, c2],
+                      tag=tag + ".bnbfin")
+            dres, dres_acc = None, 0
+            if res is not None and res.requires_grad:
+                dres = res.grad
+                dres_acc = self.grad_mode(res)
+            self.emit("BN_BWD_APPLY", i=[da.ld, y.ld, Cout, dres.ld if dres is not None else 0, dres_acc, Cout, act],
+                      l=[count], p=[da, y, scale, shift, mean, invstd, bn["gamma"], c1, c2, dyT, dres],
+                      tag=tag + ".bnapply")
+            self.wgrad_cmds(tag, x, dyT, CinPad, Cout, Cin, Cout, k, stride, pad, wgrad)
+            if need_dgrad:
+                self.dgrad_cmds(tag, dyT, wd, Cout // 8, x, Cin, CinPadN, k, stride, pad)
+
+        self.on_backward(bwd)
+        return out
+
+    def wgrad_cmds(self, tag, x, dyT, CinPad, CoutPad, Cin, Cout, k, stride, pad, wgrad):
+        KK = k * k
+        direct = (k == 1 and CinPad == Cin and CoutPad == Cout)
+        if direct:
+            gw = _Ptr(wgrad)
+            self.emit("MEMSET", i=[0], l=[Cout * Cin * 4], p=[wgrad], tag=tag + ".gwzero")
+        else:
+            gwb = self.scratch("gw", KK * CoutPad * CinPad * 4)
+            gw = _Ptr(gwb)
+            self.emit("MEMSET", i=[0], l=[KK * CoutPad * CinPad * 4], p=[gwb], tag=tag + ".gwzero")
+        taps = [(r - pad, s - pad) for r in range(k) for s in range(k)]
+        spec = ConvSpec(kind="wgrad", x=_Ptr(x), dy=_Ptr(dyT), gw=gw, ldx=x.ld, ldy=dyT.ld, N=x.N, H=x.H, W=x.W,
+                        outH=dyT.H, outW=dyT.W, stride=stride, CinPad=CinPad, CoutPad=CoutPad, taps=taps, tag=tag)
+        self.emit("WGRAD", desc=spec, tag=tag + ".wgrad")
+        if not direct:
+            self.emit("UNPACK_WG", i=[Cout, Cin, k, k, CoutPad, CinPad, 0], p=[gw, wgrad], tag=tag + ".gwunpack")
+
+    def dgrad_cmds(self, tag, dyT, wd, K8, x, Cin, CinPadN, k, stride, pad):
+        """data gradient into x.grad; dyT: out-grad view with K8*8 readable channels"""
+        dx = x.grad
+        acc = self.grad_mode(x)
+        flags = L.MI_CONV_ACCUM if acc else 0
+        # output channels written: the real Cin (x may carry zero pad channels, e.g. the 12->16 stem)
+        if stride == 1:
+            taps = [(pad - r, pad - s, r * k + s) for r in range(k) for s in range(k)]
+            self.conv_cmd(tag + ".dgrad", dyT, wd, K8, dx, dx.ld, x.H, x.W, Cin, CinPadN, taps, flags=flags)
+        else:
+            assert stride == 2 and k == 3 and pad == 1
+            cls_taps = {0: [(1, 0)], 1: [(0, 1), (2, 0)]}  # parity -> [(r, offset)]
+            for py in (0, 1):
+                for px in (0, 1):
+                    taps = [(oy, ox, r * 3 + s) for (r, oy) in cls_taps[py] for (s, ox) in cls_taps[px]]
+                    gh, gw_ = (x.H - py + 1) // 2, (x.W - px + 1) // 2
+                    self.conv_cmd(f"{tag}.dgrad{py}{px}", dyT, wd, K8, dx, dx.ld, x.H, x.W, Cin, CinPadN, taps,
+                                  out_stride=2, out_oy=py, out_ox=px, gridH=gh, gridW=gw_, flags=flags)
+
+    def pred_conv(self, tag, x, weight, bias, wgrad, bgrad, preds, A, a0, c0, nch):
+        """biased 1x1 prediction conv writing fp32 straight into preds[B][A][nch] at (anchor a0, channel c0)."""
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        CoutPad = _rup(Cout, 32)
+        wf = self.small(tag + ".wf", Cin * CoutPad * 2)
+        need_dgrad = self.training and x.requires_grad
+        wd = self.small(tag + ".wd", CoutPad * Cin * 2) if need_dgrad else None
+        self.emit("PACK_W", i=[Cout, Cin, 1, 1, Cin, CoutPad, CoutPad, Cin], p=[weight, wf, wd], tag=tag + ".pack",
+                  prologue=True)
+        yptr = _Ptr(preds, (a0 * nch + c0) * 4)
+        self.conv_cmd(tag + ".conv", x, wf, Cin // 8, yptr, nch, x.H, x.W, Cout, CoutPad, [(0, 0, 0)], bias=bias,
+                      flags=L.MI_CONV_OUT_F32, y_nstride=A * nch)
+        HW = x.H * x.W
+
+        def bwd():
+            dmap = self.scratch("dpred_map", x.N * HW * CoutPad * 2)
+            dT = TRef(dmap, x.N, x.H, x.W, CoutPad, CoutPad)
+            self.emit("SPLIT_DPREDS", i=[x.N, A, nch, a0, HW, c0, Cout, CoutPad], p=[self.loss["dpreds"], dT],
+                      tag=tag + ".split")
+            self.emit("COLSUM", i=[CoutPad, Cout, 0], l=[x.N * HW], p=[dT, bgrad], tag=tag + ".bgrad")
+            self.wgrad_cmds(tag, x, dT, Cin, CoutPad, Cin, Cout, 1, 1, 0, wgrad)
+            if need_dgrad:
+                self.dgrad_cmds(tag, dT, wd, CoutPad // 8, x, Cin, Cin, 1, 1, 0)
+
+        self.on_backward(bwd)
+
+    def focus(self, image_ptr_holder, N, H, W):
+        out = self.new_act(N, H // 2, W // 2, 16, "focus", requires_grad=False)
+        self.emit("FOCUS", i=[N, H, W, out.ld], p=[image_ptr_holder, out], tag="focus")
+        return out
+
+    def upsample_into(self, tag, x, out):
+        assert (out.H, out.W, out.C) == (2 * x.H, 2 * x.W, x.C)
+        self.emit("UPSAMPLE_FWD", i=[x.ld, out.ld, x.N, x.H, x.W, x.C], p=[x, out], tag=tag)
+
+        def bwd():
+            assert self.grad_ready(out), tag
+            acc = self.grad_mode(x)
+            self.emit("UPSAMPLE_BWD", i=[out.ld, x.ld, acc, x.N, x.H, x.W, x.C], p=[out.grad, x.grad], tag=tag + ".bwd")
+
+        self.on_backward(bwd)
+
+    def spp_into(self, tag, x, o5, o9, o13):
+        idx = self.small(tag + ".idx", 3 * x.npix * x.C)
+        assert o5.ld == o9.ld == o13.ld
+        self.emit("SPP_FWD", i=[x.ld, o5.ld, x.N, x.H, x.W, x.C], p=[x, o5, o9, o13, idx], tag=tag)
+
+        def bwd():
+            acc = self.grad_mode(x)
+            self.emit("SPP_BWD", i=[o5.ld, x.ld, acc, x.N, x.H, x.W, x.C],
+                      p=[o5.grad, o9.grad, o13.grad, idx, x.grad], tag=tag + ".bwd")
+
+        self.on_backward(bwd)
+
+    def yolox_loss(self, preds, labels_t, anchors_t, B, A, ncls, max_labels, gmax):
+        nch = 5 + ncls
+        nb = (A + 255) // 256
+        ws = dict(
+            cost=self.small("loss.cost", B * gmax * A * 4), iou=self.small("loss.iou", B * gmax * A * 4),
+            match=self.small("loss.match", B * gmax * A), ngt=self.small("loss.ngt", B * 4),
+            fg=self.small("loss.fg", B * A), matched_gt=self.small("loss.mgt", B * A * 4),
+            matched_iou=self.small("loss.miou", B * A * 4), partial=self.small("loss.partial", nb * B * 4 * 4),
+            out=self.small("loss.out", 8 * 4), gw=self.small("loss.gw", 4 * 4),
+            dpreds=self.small("loss.dpreds", B * A * nch * 4) if self.training else None)
+        spec = ConvSpec(kind="loss", preds=_Ptr(preds), labels=_Ptr(labels_t), anchors=_Ptr(anchors_t), B=B, A=A,
+                        ncls=ncls, max_labels=max_labels, gmax=gmax, ws=ws)
+        self.loss = ws
+        self.loss["spec"] = spec
+        self.emit("LOSS_FWD", desc=spec, tag="loss")
+
+        def bwd():
+            self.emit("LOSS_BWD", desc=spec, p=[None, ws["gw"], ws["dpreds"]], tag="loss.bwd")
+
+        self.on_backward(bwd)
+        return ws
+
+    # ---------------------------------------------------------------- finalize
+    def finalize(self, materialize=True):
+        # backward command generation, reverse order of forward emission
+        self._emitting_bwd = True
+        for fn in reversed(self.bwd_gens):
+            fn()
+        self._emitting_bwd = False
+        self.bwd_gens = []
+        return Plan(self) if materialize else None
+
+
+class Plan:
+    def __init__(self, b):
+        self.b = b
+        L.require_device()
+        off = 0
+        for buf in b.bufs:
+            buf.offset = off
+            off += _rup(buf.nbytes, 256)
+        self.arena_bytes = off
+        self.arena = torch.zeros(off + 256, dtype=torch.uint8, device=b.device)
+        base = self.arena.data_ptr()
+        base = _rup(base, 256)
+        for buf in b.bufs:
+            buf.base = base
+        self.descs = []
+        self.cmd_descs = {}
+        self.fwd_cmds, self.fwd_tags = self._materialize(b.prologue + b.fwd, "fwd")
+        self.bwd_cmds, self.bwd_tags = self._materialize(b.bwd, "bwd")
+        self.graphs = {}
+
+    def _make_desc(self, spec):
+        kind = getattr(spec, "kind", "conv")
+        if kind == "conv":
+            d = L.mi_conv_desc()
+            d.x, d.w, d.y = spec.x.resolve(), spec.w.resolve(), spec.y.resolve()
+            d.bias, d.stats_partial = spec.bias.resolve(), spec.stats.resolve()
+            for k in ("ldx", "ldy", "y_nstride", "N", "H", "W", "outH", "outW", "gridH", "gridW", "in_stride",
+                      "out_stride", "out_oy", "out_ox", "K8", "Cout", "CoutPad", "flags"):
+                setattr(d, k, int(getattr(spec, k)))
+            d.ntaps = len(spec.taps)
+            for t, (dy, dx, w) in enumerate(spec.taps):
+                d.tap_dy[t], d.tap_dx[t], d.tap_w[t] = dy, dx, w
+        elif kind == "wgrad":
+            d = L.mi_wgrad_desc()
+            d.x, d.dy, d.gw = spec.x.resolve(), spec.dy.resolve(), spec.gw.resolve()
+            for k in ("ldx", "ldy", "N", "H", "W", "outH", "outW", "stride", "CinPad", "CoutPad"):
+                setattr(d, k, int(getattr(spec, k)))
+            d.ntaps = len(spec.taps)
+            for t, (dy, dx) in enumerate(spec.taps):
+                d.tap_dy[t], d.tap_dx[t] = dy, dx
+        else:
+            d = L.mi_yolox_loss_desc()
+            d.preds, d.labels, d.anchors = spec.preds.resolve(), spec.labels.resolve(), spec.anchors.resolve()
+            d.B, d.A, d.ncls, d.max_labels, d.gmax = spec.B, spec.A, spec.ncls, spec.max_labels, spec.gmax
+            for k in ("cost", "iou", "match", "ngt", "fg", "matched_gt", "matched_iou", "partial", "out"):
+                setattr(d, k, spec.ws[k].ptr)
+        self.descs.append(d)
+        return d
+
+    def _materialize(self, cmds, which):
+        arr = (L.mi_cmd * max(1, len(cmds)))()
+        tags = []
+        self.cmd_descs[which] = [None] * len(cmds)
+        for k, c in enumerate(cmds):
+            m = arr[k]
+            m.op = c.op
+            for j, v in enumerate(c.i):
+                m.i[j] = int(v)
+            for j, v in enumerate(c.f):
+                m.f[j] = float(v)
+            for j, v in enumerate(c.l):
+                m.l[j] = int(v)
+            for j, v in enumerate(c.p):
+                m.p[j] = v.resolve()
+            if c.desc is not None:
+                d = self._make_desc(c.desc)
+                m.p[0] = C.cast(C.pointer(d), C.c_void_p).value
+                self.cmd_descs[which][k] = d
+            tags.append(c.tag)
+        return (arr, len(cmds)), tags
+
+    # ---------------------------------------------------------------- execution
+    def run(self, which, stream=None):
+        arr, n = self.fwd_cmds if which == "fwd" else self.bwd_cmds
+        L.check(L.lib().mi_cmdlist_run(arr, n, L.stream_ptr(stream)), f"plan.{which}")
+
+    def capture(self, which, stream):
+        arr, n = self.fwd_cmds if which == "fwd" else self.bwd_cmds
+        h = L.lib().mi_graph_capture(arr, n, L.stream_ptr(stream))
+        L.check(h, f"graph_capture.{which}")
+        self.graphs[which] = h
+        return h
+
+    def launch(self, which, stream=None):
+        L.check(L.lib().mi_graph_launch(self.graphs[which], L.stream_ptr(stream)), f"graph_launch.{which}")
+
+    def time_cmds(self, which, iters=3, stream=None):
+        """per-command HIP-event timings (ms) -> list of (tag, ms)"""
+        arr, n = self.fwd_cmds if which == "fwd" else self.bwd_cmds
+        tags = self.fwd_tags if which == "fwd" else self.bwd_tags
+        per = (C.c_float * max(1, n))()
+        tot = C.c_float(0)
+        L.check(L.lib().mi_cmdlist_time(arr, n, iters, C.byref(tot), per, L.stream_ptr(stream)), "cmdlist_time")
+        return tot.value, [(tags[k], per[k]) for k in range(n)]
+
+    def view(self, t, dtype=torch.bfloat16):
+        """torch view of a TRef (for tests / module outputs): shape [N,C,H,W] with channels_last strides"""
+        base = self.arena.data_ptr()
+        off = t.ptr - base
+        es = 2
+        flat = self.arena[off: off + ((t.npix - 1) * t.ld + t.C) * es].view(dtype)
+        return flat.as_strided((t.N, t.C, t.H, t.W), (t.H * t.W * t.ld, 1, t.W * t.ld, t.ld))
+
+    def buf_view(self, buf, dtype, numel=None):
+        base = self.arena.data_ptr()
+        off = buf.ptr - base
+        es = torch.empty((), dtype=dtype).element_size()
+        n = buf.nbytes // es if numel is None else numel
+        return self.arena[off: off + n * es].view(dtype)
+
+    def __del__(self):
+        try:
+            for h in self.graphs.values():
+                L.lib().mi_graph_destroy(h)
+        except Exception:
+            pass
