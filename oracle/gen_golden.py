@@ -59,7 +59,7 @@ def gold_simota():
     head = ref.head
     head.train()
     B, H, W = 3, 160, 160
-    _, labels = O.synth_batch(B, H, W, seed=21, max_gt=12)
+    _, labels = O.synth_batch(B, H, W, seed=21, max_gt=12, min_gt=6)
     labels[1] = 0.0
     hw = [(H // s, W // s) for s in (8, 16, 32)]
     raw, anchors = O.synth_raw(B, hw, 22, labels=labels)

@@ -320,13 +320,13 @@ def postprocess(prediction, num_classes, conf_thre=0.7, nms_thre=0.45):
 
 
 # ----------------------------------------------------------------------------- synthetic inputs
-def synth_batch(B, H, W, seed=1234, max_labels=100, num_classes=80, max_gt=20):
+def synth_batch(B, H, W, seed=1234, max_labels=100, num_classes=80, max_gt=20, min_gt=1):
     """COCO-shaped synthetic batch: images U{0..255} float [B,3,H,W]; labels [B,max_labels,5] (cls,cx,cy,w,h)"""
     g = torch.Generator().manual_seed(seed)
     images = torch.randint(0, 256, (B, 3, H, W), generator=g).float()
     labels = torch.zeros(B, max_labels, 5)
     for b in range(B):
-        n = int(torch.randint(1, max_gt + 1, (1,), generator=g))
+        n = int(torch.randint(min_gt, max_gt + 1, (1,), generator=g))
         wh = 16 + torch.rand(n, 2, generator=g) * (min(272, min(H, W) - 2) - 16)
         cx = wh[:, 0] / 2 + torch.rand(n, generator=g) * (W - wh[:, 0])
         cy = wh[:, 1] / 2 + torch.rand(n, generator=g) * (H - wh[:, 1])

@@ -42,7 +42,7 @@ def _loss_call(raw, labels, anchors, gw=(1, 1, 1, 1), gmax=None):
 def test_simota_loss_against_reference_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "simota_160.npz"))
     B, H, W = 3, 160, 160
-    _, labels = O.synth_batch(B, H, W, seed=21, max_gt=12)
+    _, labels = O.synth_batch(B, H, W, seed=21, max_gt=12, min_gt=6)
     labels[1] = 0.0                      # an image without ground truth
     hw = [(H // s, W // s) for s in (8, 16, 32)]
     raw, anchors = O.synth_raw(B, hw, 22, labels=labels)

@@ -39,7 +39,7 @@ def test_step_losses_grads_and_eval(golden_dir):
 def test_simota_assignment_bit_exact(golden_dir):
     g = np.load(os.path.join(golden_dir, "simota_160.npz"))
     B, H, W = 3, 160, 160
-    _, labels = O.synth_batch(B, H, W, seed=21, max_gt=12)
+    _, labels = O.synth_batch(B, H, W, seed=21, max_gt=12, min_gt=6)
     labels[1] = 0.0
     hw = [(H // s, W // s) for s in (8, 16, 32)]
     raw, anchors = O.synth_raw(B, hw, 22, labels=labels)
