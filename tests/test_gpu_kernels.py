@@ -39,8 +39,8 @@ def test_mfma_lane_layouts():
         a = bf(torch.randn(m, k, generator=g))
         b = bf(torch.randn(k, n, generator=g))   # asymmetric: catches transposed C/D maps
         d = torch.zeros(m, n, device=DEV)
-        L.check(getattr(L.lib(), name)(a.to(DEV, torch.bfloat16).data_ptr(), b.to(DEV, torch.bfloat16).data_ptr(),
-                                       d.data_ptr(), sp()), name)
+        ad, bd = a.to(DEV, torch.bfloat16), b.to(DEV, torch.bfloat16)   # keep alive across the launch
+        L.check(getattr(L.lib(), name)(ad.data_ptr(), bd.data_ptr(), d.data_ptr(), sp()), name)
         torch.cuda.synchronize()
         np.testing.assert_allclose(d.cpu().numpy(), (a @ b).numpy(), rtol=1e-5, atol=1e-5)
 
