@@ -98,7 +98,9 @@ def cpu_baseline(batch=2, size=640, steps=2):
     """the oracle (port of the reference CPU path) on this box's host cores: fwd + loss + bwd + SGD, fp32"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import yolox_oracle as O
-    torch.set_num_threads(os.cpu_count())
+    # bounded thread count: on a 256-thread host the oracle's small convs run slower oversubscribed (measured
+    # 0.008 img/s at 256 threads); 32 is the count we report as `cores`
+    torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("MI_CPU_BASELINE_THREADS", "32"))))
     sd = O.init_state_dict(0.33, 0.5, 80, seed=0)
     params = [v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k]
     opt = torch.optim.SGD(params, lr=0.01, momentum=0.9, weight_decay=1e-4)
