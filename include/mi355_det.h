@@ -79,30 +79,35 @@ int mi_conv2d(const mi_conv_desc* d, mi_stream_t s);
 /* fills TH/TW/KC/BN if zero; returns number of pixel tiles (rows of stats_partial) or <0 */
 int mi_conv2d_plan(mi_conv_desc* d);
 
-/* weight gradient: gw[tap][CoutPad][CinPad] (fp32, atomically accumulated — zero it first)
- * += sum_pixels dy[p][co] * x[p*stride + tap][ci].  replaces conv wgrad of the same modules. */
+/* weight gradient: g[co][ci][tap] (fp32 OIHW, the nn.Parameter gradient layout; overwritten, or += if
+ * `accumulate`) = sum_pixels dy[p][co] * x[p*stride + tap][ci].  replaces conv wgrad of the same modules.
+ * Split-K over pixel tiles with a caller-owned fp32 workspace (no atomics: the split partials are summed
+ * in a fixed order, so the result is bit-reproducible); mi_conv2d_wgrad_plan() returns the bytes needed. */
 typedef struct mi_wgrad_desc {
   const void* x;  /* bf16 NHWC input view  (CinPad channels readable)        */
   const void* dy; /* bf16 NHWC out-grad view (CoutPad channels readable)     */
-  float* gw;      /* fp32 [ntaps][CoutPad][CinPad]                            */
+  float* gw;      /* fp32 [Cout][Cin][ntaps]                                  */
+  void* ws;       /* split-K workspace, 16-byte aligned                       */
+  int64_t ws_bytes;
   int32_t ldx, ldy;
   int32_t N, H, W, outH, outW;
   int32_t stride;
-  int32_t CinPad, CoutPad;
-  int32_t ntaps;
+  int32_t Cin, Cout;        /* real channel counts written to gw              */
+  int32_t CinPad, CoutPad;  /* readable (zero-padded) channels, CinPad%16==0, CoutPad%32==0 */
+  int32_t ntaps;            /* 1 or 9 */
   int32_t tap_dy[MI_MAX_TAPS], tap_dx[MI_MAX_TAPS];
-  int32_t TH, TW, splitk; /* 0 => chosen by launcher */
+  int32_t accumulate;
+  int32_t TH, TW, splitk, cfg_tp; /* 0 => chosen by launcher */
 } mi_wgrad_desc;
 int mi_conv2d_wgrad(const mi_wgrad_desc* d, mi_stream_t s);
+/* workspace bytes mi_conv2d_wgrad needs for this descriptor (pointers may be NULL), or <0 */
+int64_t mi_conv2d_wgrad_plan(const mi_wgrad_desc* d);
 
 /* OIHW fp32 master -> packed bf16 images.  wf: forward [KH*KW][CinPad/8][CoutPad][8];
  * wd: dgrad  [KH*KW][CoutPadK/8][CinPadN][8] (roles swapped).  Either may be NULL. */
 int mi_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW,
                         void* wf, int CinPad, int CoutPad,
                         void* wd, int CoutPadK, int CinPadN, mi_stream_t s);
-/* packed fp32 grad [taps][CoutPad][CinPad] -> OIHW fp32 grad (overwrite or accumulate) */
-int mi_unpack_conv_wgrad(const float* gw, int Cout, int Cin, int KH, int KW,
-                         int CoutPad, int CinPad, float* g_oihw, int accumulate, mi_stream_t s);
 
 /* ---- BatchNorm(train) + SiLU (+ residual) -----------------------------
  * replaces nn.BatchNorm2d + nn.SiLU of BaseConv (wrappers.py:76-80) and the
@@ -226,7 +231,7 @@ enum {
   MI_OP_CONV = 1,
   MI_OP_WGRAD = 2,
   MI_OP_PACK_W = 3,
-  MI_OP_UNPACK_WG = 4,
+  MI_OP_RESERVED4 = 4, /* was UNPACK_WG: wgrad now writes OIHW directly */
   MI_OP_BN_FINALIZE = 5,
   MI_OP_BN_ACT_FWD = 6,
   MI_OP_BN_BWD_REDUCE = 7,

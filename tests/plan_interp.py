@@ -88,17 +88,6 @@ class Interp:
             img = wp.view(KK, CinPadN, CoutPadK // 8, 8).permute(0, 2, 1, 3).contiguous()
             self.raw(c.p[2].obj).view(self.dt)[: img.numel()] = img.reshape(-1).to(self.dt)
 
-    def op_UNPACK_WG(self, c):
-        Cout, Cin, KH, KW, CoutPad, CinPad, acc = c.i[:7]
-        KK = KH * KW
-        gw = self.f32(c.p[0], KK * CoutPad * CinPad).view(KK, CoutPad, CinPad)
-        g = c.p[1].obj
-        v = gw[:, :Cout, :Cin].permute(1, 2, 0).reshape(Cout, Cin, KH, KW)
-        if acc:
-            g.add_(v)
-        else:
-            g.copy_(v)
-
     def _conv_core(self, s):
         x = s.x.obj
         K = s.K8 * 8
@@ -150,10 +139,13 @@ class Interp:
         P = 4
         xp = F.pad(xin, (0, 0, P, P + 2 * s.outW, P, P + 2 * s.outH))
         KK = len(s.taps)
-        gw = self.f32(s.gw, KK * s.CoutPad * s.CinPad).view(KK, s.CoutPad, s.CinPad)
+        g = s.gw.obj   # fp32 OIHW gradient tensor (overwritten)
+        kk = int(round(KK ** 0.5))
+        res = torch.zeros(s.Cout, s.Cin, KK)
         for t, (ty, tx) in enumerate(s.taps):
             sl = xp[:, P + ty: P + ty + s.outH * s.stride: s.stride, P + tx: P + tx + s.outW * s.stride: s.stride, :]
-            gw[t] += torch.einsum("nhwo,nhwi->oi", dy, sl)
+            res[:, :, t] = torch.einsum("nhwo,nhwi->oi", dy, sl)[: s.Cout, : s.Cin]
+        g.copy_(res.view(s.Cout, s.Cin, kk, kk))
 
     def op_BN_FINALIZE(self, c):
         ntiles, C, CPad = c.i[:3]

@@ -29,7 +29,7 @@ def test_header_symbols_exported():
 def test_opcode_table_matches_header():
     hdr = open(os.path.join(ROOT, "include", "mi355_det.h")).read()
     enum = re.search(r"enum \{(.*?)MI_OP_COUNT", hdr, re.S).group(1)
-    vals = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"MI_OP_([A-Z_]+) = (\d+)", enum))
+    vals = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"MI_OP_([A-Z_0-9]+) = (\d+)", enum))
     assert vals == L.OP
 
 

@@ -35,12 +35,14 @@ class mi_conv_desc(C.Structure):
 
 class mi_wgrad_desc(C.Structure):
     _fields_ = [
-        ("x", C.c_void_p), ("dy", C.c_void_p), ("gw", C.c_void_p),
+        ("x", C.c_void_p), ("dy", C.c_void_p), ("gw", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("ldx", C.c_int32), ("ldy", C.c_int32),
         ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("outH", C.c_int32), ("outW", C.c_int32),
-        ("stride", C.c_int32), ("CinPad", C.c_int32), ("CoutPad", C.c_int32), ("ntaps", C.c_int32),
+        ("stride", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("CinPad", C.c_int32), ("CoutPad", C.c_int32),
+        ("ntaps", C.c_int32),
         ("tap_dy", C.c_int32 * MI_MAX_TAPS), ("tap_dx", C.c_int32 * MI_MAX_TAPS),
-        ("TH", C.c_int32), ("TW", C.c_int32), ("splitk", C.c_int32),
+        ("accumulate", C.c_int32),
+        ("TH", C.c_int32), ("TW", C.c_int32), ("splitk", C.c_int32), ("cfg_tp", C.c_int32),
     ]
 
 
@@ -65,7 +67,7 @@ class mi_cmd(C.Structure):
 
 
 # opcode names must match the enum in include/mi355_det.h
-OPS = ["NOP", "CONV", "WGRAD", "PACK_W", "UNPACK_WG", "BN_FINALIZE", "BN_ACT_FWD", "BN_BWD_REDUCE",
+OPS = ["NOP", "CONV", "WGRAD", "PACK_W", "RESERVED4", "BN_FINALIZE", "BN_ACT_FWD", "BN_BWD_REDUCE",
        "BN_BWD_FINALIZE", "BN_BWD_APPLY", "FOCUS", "UPSAMPLE_FWD", "UPSAMPLE_BWD", "SPP_FWD", "SPP_BWD", "COPY",
        "COLSUM", "LOSS_FWD", "LOSS_BWD", "SPLIT_DPREDS", "MEMSET", "SGD", "BN_EVAL_AFFINE", "DECODE"]
 OP = {n: k for k, n in enumerate(OPS)}
@@ -79,7 +81,7 @@ _PROTOS = {
     "mi_conv2d_plan": (C.c_int, [C.POINTER(mi_conv_desc)]),
     "mi_conv2d_wgrad": (C.c_int, [C.POINTER(mi_wgrad_desc), _vp]),
     "mi_pack_conv_weight": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
-    "mi_unpack_conv_wgrad": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "mi_conv2d_wgrad_plan": (C.c_int64, [C.POINTER(mi_wgrad_desc)]),
     "mi_bn_finalize": (C.c_int, [_vp, _i, _i, _i, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_bn_eval_affine": (C.c_int, [_vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
     "mi_bn_act_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i64, _i, _i, _vp]),

@@ -371,191 +371,6 @@ extern "C" int mi_conv2d(const mi_conv_desc* d, mi_stream_t st) {
   MI_FAIL(MI_EINVAL, "conv: no kernel for KC %d BN %d", KC, BN);
 }
 
-// ================================================================= weight gradient
-// gw[tap][co][ci] += sum_pixels dy[p][co] * x[p*stride + tap][ci]
-// K (the reduction) runs over pixels, which are NOT contiguous per channel in NHWC, so both
-// operands are fetched from row-major [pixel][channel] LDS tiles with the gfx950 hardware
-// transpose read (ds_read_b64_tr_b16) straight into v_mfma_f32_16x16x32_bf16 fragments.
-struct WgradK {
-  const __bf16* x;
-  const __bf16* dy;
-  float* gw;
-  int ldx, lddy, N, H, W, outH, outW, is, CinPad, CoutPad, ntaps;
-  int tdy[MI_MAX_TAPS], tdx[MI_MAX_TAPS];
-  int TH, TW, tilesY, tilesX, dymin, dxmin, haloH, haloW, npixh, ntiles, tps;
-};
-
-typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
-
-__device__ __forceinline__ bf16x8 tr_read2(const char* base0, const char* base1) {
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base0));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base1));
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
-  s16x8 v;
-  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-  return __builtin_bit_cast(bf16x8, v);
-}
-
-template <int NT, int BCI>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
-  constexpr int BCO = 32;
-  constexpr int NI = BCO / 16, NJ = BCI / 16;
-  constexpr int XC8 = BCI / 8;  // 16B chunks per halo row
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  u32x4* dyS = (u32x4*)smem;            // [128][4]   (64 B rows)
-  u32x4* xS = dyS + 128 * 4;            // [npixh][XC8]
-  const char* dyB = (const char*)dyS;
-  const char* xB = (const char*)xS;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, t = lane & 15;
-  const int co0 = blockIdx.y * BCO, ci0 = blockIdx.z * BCI;
-  const int TP = p.TH * p.TW;
-
-  int P[2], hb[2];
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    P[e] = wave * 32 + 16 * e + 4 * g + (t >> 2);
-    const bool v = P[e] < TP;
-    const int ty = v ? P[e] / p.TW : 0;
-    const int tx = v ? P[e] - ty * p.TW : 0;
-    hb[e] = ty * p.is * p.haloW + tx * p.is;
-  }
-  const int colb = 4 * (t & 3) * 2;  // byte offset of this lane's 4-column piece inside a 16-col group
-
-  f32x4 acc[NT][NI][NJ];
-#pragma unroll
-  for (int a = 0; a < NT; ++a)
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int tpi = p.tilesY * p.tilesX;
-  const int tbeg = blockIdx.x * p.tps;
-  const int tend = min(p.ntiles, tbeg + p.tps);
-  for (int tile = tbeg; tile < tend; ++tile) {
-    const int img = tile / tpi;
-    const int rem = tile - img * tpi;
-    const int ty0 = (rem / p.tilesX) * p.TH, tx0 = (rem % p.tilesX) * p.TW;
-    __syncthreads();
-    for (int idx = tid; idx < 128 * 4; idx += 256) {
-      const int row = idx >> 2, c = idx & 3;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (row < TP) {
-        const int ty = row / p.TW, tx = row - ty * p.TW;
-        const int oy = ty0 + ty, ox = tx0 + tx;
-        if (oy < p.outH && ox < p.outW)
-          v = *(const u32x4*)(p.dy + (((size_t)img * p.outH + oy) * p.outW + ox) * (size_t)p.lddy + co0 + c * 8);
-      }
-      dyS[idx] = v;
-    }
-    const int iy0 = ty0 * p.is + p.dymin, ix0 = tx0 * p.is + p.dxmin;
-    for (int idx = tid; idx < p.npixh * XC8; idx += 256) {
-      const int hp = idx / XC8, c = idx - hp * XC8;
-      const int hy = hp / p.haloW, hx = hp - hy * p.haloW;
-      const int iy = iy0 + hy, ix = ix0 + hx;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-        v = *(const u32x4*)(p.x + (((size_t)img * p.H + iy) * p.W + ix) * (size_t)p.ldx + ci0 + c * 8);
-      xS[idx] = v;
-    }
-    __syncthreads();
-    bf16x8 a[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-      a[i] = tr_read2(dyB + P[0] * 64 + i * 32 + colb, dyB + P[1] * 64 + i * 32 + colb);
-#pragma unroll
-    for (int tap = 0; tap < NT; ++tap) {
-      const int toff = (p.tdy[tap] - p.dymin) * p.haloW + (p.tdx[tap] - p.dxmin);
-      bf16x8 b[NJ];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        b[j] = tr_read2(xB + (hb[0] + toff) * (BCI * 2) + j * 32 + colb,
-                        xB + (hb[1] + toff) * (BCI * 2) + j * 32 + colb);
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[tap][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[tap][i][j], 0, 0, 0);
-    }
-  }
-  // D[m = co][n = ci]: lane (t = n, g) holds rows 4g + r
-#pragma unroll
-  for (int tap = 0; tap < NT; ++tap)
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = co0 + i * 16 + 4 * g + r, ci = ci0 + j * 16 + t;
-          unsafeAtomicAdd(&p.gw[((size_t)tap * p.CoutPad + co) * p.CinPad + ci], acc[tap][i][j][r]);
-        }
-}
-
-extern "C" int mi_conv2d_wgrad(const mi_wgrad_desc* d, mi_stream_t st) {
-  MI_REQUIRE(d->x && d->dy && d->gw, "wgrad: null pointer");
-  MI_REQUIRE(d->ntaps == 1 || d->ntaps == 9, "wgrad: ntaps %d", d->ntaps);
-  MI_REQUIRE(d->CoutPad % 32 == 0 && d->CinPad % 16 == 0, "wgrad: pads %d %d", d->CoutPad, d->CinPad);
-  MI_REQUIRE(d->ldx % 8 == 0 && d->ldy % 8 == 0 && ((uintptr_t)d->x % 16) == 0 && ((uintptr_t)d->dy % 16) == 0,
-             "wgrad: alignment");
-  WgradK k;
-  k.x = (const __bf16*)d->x; k.dy = (const __bf16*)d->dy; k.gw = d->gw;
-  k.ldx = d->ldx; k.lddy = d->ldy; k.N = d->N; k.H = d->H; k.W = d->W; k.outH = d->outH; k.outW = d->outW;
-  k.is = d->stride; k.CinPad = d->CinPad; k.CoutPad = d->CoutPad; k.ntaps = d->ntaps;
-  int dymin = 1 << 30, dymax = -(1 << 30), dxmin = 1 << 30, dxmax = -(1 << 30);
-  for (int t = 0; t < d->ntaps; ++t) {
-    k.tdy[t] = d->tap_dy[t]; k.tdx[t] = d->tap_dx[t];
-    if (d->tap_dy[t] < dymin) dymin = d->tap_dy[t];
-    if (d->tap_dy[t] > dymax) dymax = d->tap_dy[t];
-    if (d->tap_dx[t] < dxmin) dxmin = d->tap_dx[t];
-    if (d->tap_dx[t] > dxmax) dxmax = d->tap_dx[t];
-  }
-  int TH = d->TH, TW = d->TW;
-  if (TH <= 0 || TW <= 0) choose_tile(d->outH, d->outW, &TH, &TW);
-  MI_REQUIRE(TH * TW <= 128, "wgrad: tile");
-  k.TH = TH; k.TW = TW; k.tilesY = mi_cdiv(d->outH, TH); k.tilesX = mi_cdiv(d->outW, TW);
-  k.dymin = dymin; k.dxmin = dxmin;
-  k.haloH = (TH - 1) * d->stride + (dymax - dymin) + 1;
-  k.haloW = (TW - 1) * d->stride + (dxmax - dxmin) + 1;
-  k.npixh = k.haloH * k.haloW;
-  k.ntiles = d->N * k.tilesY * k.tilesX;
-  const int BCI = (d->CinPad % 32 == 0) ? 32 : 16;
-  const int nco = d->CoutPad / 32, nci = d->CinPad / BCI;
-  int split = d->splitk;
-  if (split <= 0) {
-    split = 2048 / (nco * nci);
-    if (split < 1) split = 1;
-  }
-  if (split > k.ntiles) split = k.ntiles;
-  k.tps = mi_cdiv(k.ntiles, split);
-  split = mi_cdiv(k.ntiles, k.tps);
-  const size_t lds = (size_t)128 * 64 + (size_t)k.npixh * BCI * 2;
-  MI_REQUIRE(lds <= 160 * 1024, "wgrad: LDS %zu", lds);
-  dim3 grid(split, nco, nci);
-  hipStream_t s = (hipStream_t)st;
-#define MI_WG(NTv, BCIv)                                                                        \
-  if (d->ntaps == NTv && BCI == BCIv) {                                                         \
-    auto fn = conv_wgrad_kernel<NTv, BCIv>;                                                      \
-    static bool attr_done = false;                                                               \
-    if (!attr_done) {                                                                            \
-      hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      attr_done = true;                                                                          \
-    }                                                                                            \
-    hipLaunchKernelGGL(fn, grid, dim3(256), lds, s, k);                                          \
-    MI_CHECK_LAUNCH("conv_wgrad");                                                               \
-    return MI_OK;                                                                                \
-  }
-  MI_WG(1, 16)
-  MI_WG(1, 32)
-  MI_WG(9, 16)
-  MI_WG(9, 32)
-#undef MI_WG
-  MI_FAIL(MI_EINVAL, "wgrad: no kernel");
-}
-
 // ================================================================= weight (un)packing
 __global__ void pack_w_kernel(const float* __restrict__ w, int Cout, int Cin, int KK, __bf16* wf,
                               int CinPad, int CoutPad, __bf16* wd, int CoutPadK, int CinPadN) {
@@ -602,30 +417,5 @@ extern "C" int mi_pack_conv_weight(const float* w, int Cout, int Cin, int KH, in
   hipLaunchKernelGGL(pack_w_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)st, w, Cout, Cin, KK, (__bf16*)wf,
                      CinPad, CoutPad, (__bf16*)wd, CoutPadK, CinPadN);
   MI_CHECK_LAUNCH("pack_w");
-  return MI_OK;
-}
-
-__global__ void unpack_wg_kernel(const float* __restrict__ gw, int Cout, int Cin, int KK, int CoutPad, int CinPad,
-                                 float* g, int accumulate) {
-  const int64_t n = (int64_t)Cout * Cin * KK;
-  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < n;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int tap = idx % KK;
-    const int64_t r = idx / KK;
-    const int ci = r % Cin, co = r / Cin;
-    const float v = gw[((int64_t)tap * CoutPad + co) * CinPad + ci];
-    g[idx] = accumulate ? g[idx] + v : v;
-  }
-}
-
-extern "C" int mi_unpack_conv_wgrad(const float* gw, int Cout, int Cin, int KH, int KW, int CoutPad, int CinPad,
-                                    float* g, int accumulate, mi_stream_t st) {
-  MI_REQUIRE(gw && g, "unpack_wg: null");
-  const int64_t n = (int64_t)Cout * Cin * KH * KW;
-  int blocks = (int)((n + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(unpack_wg_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)st, gw, Cout, Cin, KH * KW, CoutPad,
-                     CinPad, g, accumulate);
-  MI_CHECK_LAUNCH("unpack_wg");
   return MI_OK;
 }

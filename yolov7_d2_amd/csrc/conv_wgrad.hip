@@ -1,0 +1,407 @@
+// Convolution weight gradient on the gfx950 matrix cores: split-K over pixel tiles, no atomics.
+//
+//   g[co][ci][tap] = sum_pixels dy[p][co] * x[p*stride + tap][ci]
+//
+// replaces the conv wgrad ATen/cuDNN reaches from BaseConv (layers/wrappers.py:60-83) and the
+// prediction convs (head/yolox_head.py:103-129) of the reference.
+//
+// Design (MI355X):
+//   * GEMM view: M = cout, N = cin (x taps), K = pixels.  K is the slow dimension of both NHWC
+//     operands, so both MFMA fragments come out of row-major [pixel][channel] LDS tiles through
+//     the hardware transpose read (ds_read_b64_tr_b16) into v_mfma_f32_16x16x32_bf16.
+//   * a block owns a (BCO x BCI x all taps) slab of the gradient and a contiguous range of
+//     128-pixel spatial tiles (split-K).  Per tile the dy tile and the x halo tile are streamed
+//     HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR staging), double-buffered: the loads of
+//     tile t+1 are in flight while tile t is multiplied.  Rows are 32-byte-group XOR-swizzled on the
+//     SOURCE address (the LDS image of an LDS-DMA is lane-linear) so the transpose reads of 8
+//     consecutive rows hit 8 distinct bank groups.
+//   * each wave holds (16*MI cout) x (16*NJ cin) x taps of fp32 accumulators for the whole pixel
+//     range, then stores them ONCE, in fragment order (one 16-byte store per lane per 16x16 tile),
+//     to a split-K workspace; a second small kernel sums the splits in a fixed order (deterministic)
+//     and scatters into the OIHW fp32 gradient.  The earlier atomicAdd version spent ~19 M L2
+//     atomics per launch (270 us per 3x3 layer regardless of size).
+#include "common.h"
+
+struct Wg2K {
+  const __bf16* x;
+  const __bf16* dy;
+  float* part;
+  const void* zero;  // >= 16 zero bytes in global memory (source of padding rows)
+  int ldx, lddy, N, H, W, outH, outW, is;
+  int TH, TW, tilesY, tilesX, ntiles, tps, nsplit;
+  int dymin, dxmin, haloW, npixh, nqx, stage;
+  int toff[MI_MAX_TAPS];
+  int nco, nci;
+  unsigned mTW, mHW;  // ceil(65536 / TW), ceil(65536 / haloW): row / d == (row * m) >> 20 for row * d < 65536
+  long long V;        // float4 vectors per split slab
+};
+
+__device__ uint4 g_mi_zero_page[4];
+
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+__device__ __forceinline__ bf16x8 tr_read2(const char* base0, const char* base1) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(base1));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// 16-byte LDS-DMA: LDS[lds_off + lane*16 .. +16) = *g   (lds_off wave-uniform).  Issued from inline asm so the
+// compiler neither tracks it on vmcnt nor fences later ds_reads with vmcnt(0): the loop below waits explicitly.
+__device__ __forceinline__ void glds16(const void* g, unsigned lds_off) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_off)) : "memory", "m0");
+}
+
+template <int NG>
+__device__ __forceinline__ int swz32(int row) {  // 32-byte group permutation of a row
+  if (NG == 1) return 0;
+  if (NG == 2) return (row >> 2) & 1;
+  if (NG == 4) return (row >> 1) & 3;
+  return row & 7;  // NG == 8
+}
+
+template <int NT, int MI, int NJ, int WCO, int WCI, int TP>
+__global__ __launch_bounds__(WCO* WCI * 64, 2) void wgrad2_kernel(const Wg2K p) {
+  constexpr int NW = WCO * WCI, BCO = 16 * MI * WCO, BCI = 16 * NJ * WCI;
+  constexpr int RDY = BCO * 2, RX = BCI * 2, KS = TP / 32;
+  constexpr int CPR_DY = RDY / 16, RPI_DY = 64 / CPR_DY, NQ_DY = TP / RPI_DY, QW_DY = NQ_DY / NW;
+  constexpr int CPR_X = RX / 16, RPI_X = 64 / CPR_X;
+  constexpr int NG_DY = RDY / 32, NG_X = RX / 32;
+  static_assert(NQ_DY % NW == 0, "dy loader split");
+  static_assert(NG_DY <= 8 && NG_X <= 8, "row width");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;  // LDS byte offset
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, t = lane & 15;
+  const int wco = wave / WCI, wci = wave % WCI;
+
+  int id = blockIdx.x;
+  const int s = id % p.nsplit;
+  id /= p.nsplit;
+  const int cob = id % p.nco, cib = id / p.nco;
+  const int co0 = cob * BCO, ci0 = cib * BCI;
+  const int TPv = p.TH * p.TW;
+
+  // ---- per-lane fragment row bases (tile invariant)
+  int pA[KS][2], hb[KS][2];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int P = ks * 32 + 16 * e + 4 * g + (t >> 2);
+      pA[ks][e] = P * RDY + (t & 3) * 8;
+      const bool v = P < TPv;
+      const int ty = v ? (int)(((unsigned)P * p.mTW) >> 20) : 0;
+      const int tx = v ? P - ty * p.TW : 0;
+      hb[ks][e] = ty * p.is * p.haloW + tx * p.is;
+    }
+
+  f32x4 acc[NT][MI][NJ];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int tpi = p.tilesY * p.tilesX;
+  const int tbeg = s * p.tps;
+  const int tend = min(p.ntiles, tbeg + p.tps);
+
+  const char* const zero = (const char*)p.zero;
+  auto issue = [&](int tile, int st) {
+    const int img = tile / tpi;
+    const int rem = tile - img * tpi;
+    const int tyq = rem / p.tilesX;
+    const int ty0 = tyq * p.TH, tx0 = (rem - tyq * p.tilesX) * p.TW;
+    const unsigned sbase = lds0 + st * p.stage;
+    // dy tile: TP rows of BCO channels (32-bit element offsets: a tensor view is < 2^31 elements)
+    const char* const dyb = (const char*)(p.dy + ((size_t)img * p.outH * p.outW) * (size_t)p.lddy + co0);
+#pragma unroll
+    for (int i = 0; i < QW_DY; ++i) {
+      const int q = wave + NW * i;
+      const int row = q * RPI_DY + lane / CPR_DY;
+      const int chunk = (lane % CPR_DY) ^ (2 * swz32<NG_DY>(row));
+      const int ty = (int)(((unsigned)row * p.mTW) >> 20);
+      const int tx = row - ty * p.TW;
+      const int oy = ty0 + ty, ox = tx0 + tx;
+      const bool v = (row < TPv) & (oy < p.outH) & (ox < p.outW);
+      const unsigned off = (unsigned)(((oy * p.outW + ox) * p.lddy + chunk * 8) * 2);
+      glds16(v ? dyb + off : zero, sbase + q * 1024);
+    }
+    // x halo tile: nqx*RPI_X rows of BCI channels
+    const int iy0 = ty0 * p.is + p.dymin, ix0 = tx0 * p.is + p.dxmin;
+    const unsigned xbase = sbase + TP * RDY;
+    const char* const xb = (const char*)(p.x + ((size_t)img * p.H * p.W) * (size_t)p.ldx + ci0);
+    for (int q = wave; q < p.nqx; q += NW) {
+      const int row = q * RPI_X + lane / CPR_X;
+      const int chunk = (lane % CPR_X) ^ (2 * swz32<NG_X>(row));
+      const int hy = (int)(((unsigned)row * p.mHW) >> 20);
+      const int hx = row - hy * p.haloW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool v = (row < p.npixh) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+      const unsigned off = (unsigned)(((iy * p.W + ix) * p.ldx + chunk * 8) * 2);
+      glds16(v ? xb + off : zero, xbase + q * 1024);
+    }
+  };
+
+  if (tbeg < tend) issue(tbeg, 0);
+  int it = 0;
+  for (int tile = tbeg; tile < tend; ++tile, ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // tile `tile` landed for every wave; stage (it+1)&1 no longer being read
+    if (tile + 1 < tend) issue(tile + 1, (it + 1) & 1);
+    const char* dyB = smem + (it & 1) * p.stage;
+    const char* xB = dyB + TP * RDY;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 a[MI];
+      int h0 = hb[ks][0], h1 = hb[ks][1];
+      // keep the per-tap LDS addresses out of the loop-invariant set: hoisting all 2*KS*NT of them costs more
+      // registers (spills) than recomputing ~5 VALU per transpose read beside the MFMAs
+      asm volatile("" : "+v"(h0), "+v"(h1));
+      const int f0 = swz32<NG_DY>(ks * 32 + 4 * g + (t >> 2)), f1 = swz32<NG_DY>(ks * 32 + 16 + 4 * g + (t >> 2));
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int cg = wco * MI + i;
+        a[i] = tr_read2(dyB + pA[ks][0] + ((cg ^ f0) * 32), dyB + pA[ks][1] + ((cg ^ f1) * 32));
+      }
+#pragma unroll
+      for (int tap = 0; tap < NT; ++tap) {
+        const int r0 = h0 + p.toff[tap], r1 = h1 + p.toff[tap];
+        const int x0 = r0 * RX + (t & 3) * 8, x1 = r1 * RX + (t & 3) * 8;
+        const int g0 = swz32<NG_X>(r0), g1 = swz32<NG_X>(r1);
+        bf16x8 b[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int cg = wci * NJ + j;
+          b[j] = tr_read2(xB + x0 + ((cg ^ g0) * 32), xB + x1 + ((cg ^ g1) * 32));
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[tap][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[tap][i][j], 0, 0, 0);
+      }
+    }
+  }
+  // ---- split-K slab, fragment order: [split][cob][cib][wave][tap][i][j][lane] x float4
+  f32x4* out = (f32x4*)p.part + (size_t)s * (size_t)p.V +
+               ((size_t)((cob * p.nci + cib) * NW + wave) * (NT * MI * NJ)) * 64 + lane;
+#pragma unroll
+  for (int tap = 0; tap < NT; ++tap)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) out[((tap * MI + i) * NJ + j) * 64] = acc[tap][i][j];
+}
+
+struct Wg2R {
+  const f32x4* part;
+  float* g;
+  long long V;
+  int nsplit, NT, MI, NJ, WCO, WCI, nco, nci, Cout, Cin, accumulate;
+};
+
+__global__ __launch_bounds__(256) void wgrad2_reduce_kernel(const Wg2R p) {
+  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= p.V) return;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  const f32x4* src = p.part + v;
+  int k = 0;
+  for (; k + 4 <= p.nsplit; k += 4) {
+    const f32x4 a = src[(size_t)k * p.V], b = src[(size_t)(k + 1) * p.V], c = src[(size_t)(k + 2) * p.V],
+                d = src[(size_t)(k + 3) * p.V];
+    s0 += a; s1 += b; s2 += c; s3 += d;
+  }
+  for (; k < p.nsplit; ++k) s0 += src[(size_t)k * p.V];
+  const f32x4 sum = (s0 + s1) + (s2 + s3);
+  const int lane = (int)(v & 63);
+  long long r = v >> 6;
+  const int j = (int)(r % p.NJ); r /= p.NJ;
+  const int i = (int)(r % p.MI); r /= p.MI;
+  const int tap = (int)(r % p.NT); r /= p.NT;
+  const int NW = p.WCO * p.WCI;
+  const int wave = (int)(r % NW); r /= NW;
+  const int cib = (int)(r % p.nci);
+  const int cob = (int)(r / p.nci);
+  const int wco = wave / p.WCI, wci = wave % p.WCI;
+  const int ci = cib * (16 * p.NJ * p.WCI) + (wci * p.NJ + j) * 16 + (lane & 15);
+  const int cobase = cob * (16 * p.MI * p.WCO) + (wco * p.MI + i) * 16 + 4 * (lane >> 4);
+  if (ci >= p.Cin) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int co = cobase + e;
+    if (co < p.Cout) {
+      float* dst = p.g + ((size_t)co * p.Cin + ci) * p.NT + tap;
+      *dst = p.accumulate ? *dst + sum[e] : sum[e];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- host side
+struct Wg2Cfg {
+  int NT, MI, NJ, WCO, WCI, TP;
+};
+
+static void wg_choose_tile(int TP, int gridH, int gridW, int* TH, int* TW) {
+  const int cands[] = {gridW, 64, 32, 16, 8, 4};
+  long best = -1;
+  int bh = 8, bw = 16;
+  for (int c : cands) {
+    if (c <= 0 || c > TP) continue;
+    int tw = c, th = TP / tw;
+    if (th > gridH) th = gridH;
+    if (th < 1) th = 1;
+    long tiles = (long)mi_cdiv(gridH, th) * mi_cdiv(gridW, tw);
+    long halo = (long)(th + 2) * (tw + 2);
+    long score = tiles * 100000 + halo;
+    if (best < 0 || score < best) { best = score; bh = th; bw = tw; }
+  }
+  *TH = bh; *TW = bw;
+}
+
+static int wg_pick_cfg(const mi_wgrad_desc* d, Wg2Cfg* c) {
+  const int ci = d->CinPad, co = d->CoutPad;
+  if (d->ntaps == 9) {
+    c->NT = 9; c->NJ = 1;
+    if (ci % 64 == 0 && co % 64 == 0 && d->stride == 1) { c->MI = 4; c->WCO = 1; c->WCI = 4; c->TP = 128; }
+    else if (ci % 32 == 0 && co % 64 == 0) { c->MI = 2; c->WCO = 2; c->WCI = 2; c->TP = d->stride == 1 ? 128 : 64; }
+    else if (ci % 32 == 0) { c->MI = 1; c->WCO = 2; c->WCI = 2; c->TP = d->stride == 1 ? 128 : 64; }
+    else { c->MI = 1; c->WCO = 2; c->WCI = 1; c->TP = 128; }  // Cin 16 (stem)
+  } else {
+    c->NT = 1; c->WCO = 2; c->WCI = 2; c->TP = 128;
+    c->MI = (co % 128 == 0) ? 4 : (co % 64 == 0) ? 2 : 1;
+    c->NJ = (ci % 128 == 0) ? 4 : (ci % 64 == 0) ? 2 : 1;
+  }
+  if (d->cfg_tp == 64 || d->cfg_tp == 128) c->TP = d->cfg_tp;
+  return MI_OK;
+}
+
+static int wg_fill(const mi_wgrad_desc* d, Wg2K* k, Wg2Cfg* c, size_t* lds, size_t* ws) {
+  MI_REQUIRE(d->x && d->dy, "wgrad: null pointer");
+  MI_REQUIRE(d->ntaps == 1 || d->ntaps == 9, "wgrad: ntaps %d", d->ntaps);
+  MI_REQUIRE(d->CoutPad % 32 == 0 && d->CinPad % 16 == 0, "wgrad: pads %d %d", d->CoutPad, d->CinPad);
+  MI_REQUIRE(d->ntaps == 9 || d->CinPad % 32 == 0, "wgrad: 1x1 needs CinPad %% 32 (got %d)", d->CinPad);
+  MI_REQUIRE(d->Cout > 0 && d->Cout <= d->CoutPad && d->Cin > 0 && d->Cin <= d->CinPad, "wgrad: channels");
+  MI_REQUIRE(d->ldx % 8 == 0 && d->ldy % 8 == 0 && ((uintptr_t)d->x % 16) == 0 && ((uintptr_t)d->dy % 16) == 0,
+             "wgrad: alignment");
+  MI_REQUIRE(d->stride == 1 || d->stride == 2, "wgrad: stride");
+  wg_pick_cfg(d, c);
+  const int BCO = 16 * c->MI * c->WCO, BCI = 16 * c->NJ * c->WCI;
+  MI_REQUIRE(d->CoutPad % BCO == 0 && d->CinPad % BCI == 0, "wgrad: tile %dx%d vs pads %d %d", BCO, BCI, d->CoutPad,
+             d->CinPad);
+  k->x = (const __bf16*)d->x; k->dy = (const __bf16*)d->dy; k->part = (float*)d->ws;
+  k->ldx = d->ldx; k->lddy = d->ldy; k->N = d->N; k->H = d->H; k->W = d->W; k->outH = d->outH; k->outW = d->outW;
+  k->is = d->stride;
+  int dymin = 1 << 30, dymax = -(1 << 30), dxmin = 1 << 30, dxmax = -(1 << 30);
+  for (int t = 0; t < d->ntaps; ++t) {
+    if (d->tap_dy[t] < dymin) dymin = d->tap_dy[t];
+    if (d->tap_dy[t] > dymax) dymax = d->tap_dy[t];
+    if (d->tap_dx[t] < dxmin) dxmin = d->tap_dx[t];
+    if (d->tap_dx[t] > dxmax) dxmax = d->tap_dx[t];
+  }
+  int TH = d->TH, TW = d->TW;
+  if (TH <= 0 || TW <= 0) wg_choose_tile(c->TP, d->outH, d->outW, &TH, &TW);
+  MI_REQUIRE(TH * TW <= c->TP && TH >= 1 && TW >= 1, "wgrad: tile %dx%d", TH, TW);
+  k->TH = TH; k->TW = TW; k->tilesY = mi_cdiv(d->outH, TH); k->tilesX = mi_cdiv(d->outW, TW);
+  k->dymin = dymin; k->dxmin = dxmin;
+  const int haloH = (TH - 1) * d->stride + (dymax - dymin) + 1;
+  k->haloW = (TW - 1) * d->stride + (dxmax - dxmin) + 1;
+  k->npixh = haloH * k->haloW;
+  for (int t = 0; t < d->ntaps; ++t) k->toff[t] = (d->tap_dy[t] - dymin) * k->haloW + (d->tap_dx[t] - dxmin);
+  const int RPI_X = 64 / (BCI * 2 / 16);
+  k->nqx = mi_cdiv(k->npixh, RPI_X);
+  MI_REQUIRE((long)k->nqx * RPI_X * k->haloW < (1 << 20) && k->nqx * RPI_X < 4096, "wgrad: tile too large for the row decode");
+  k->mTW = ((1u << 20) + TW - 1) / TW;
+  k->mHW = ((1u << 20) + k->haloW - 1) / k->haloW;
+  k->stage = c->TP * BCO * 2 + k->nqx * 1024;
+  *lds = 2 * (size_t)k->stage;
+  MI_REQUIRE(*lds <= 160 * 1024, "wgrad: LDS %zu too large", *lds);
+  k->ntiles = d->N * k->tilesY * k->tilesX;
+  k->nco = d->CoutPad / BCO; k->nci = d->CinPad / BCI;
+  int split = d->splitk;
+  if (split <= 0) {
+    // ~2 resident blocks per CU; keep the split a multiple of 8 so a pixel range's blocks share an XCD (L2)
+    const int blocks_per_cu = (*lds <= 80 * 1024) ? 2 : 1;
+    split = (256 * blocks_per_cu) / (k->nco * k->nci);
+    if (split >= 8) split &= ~7;
+    if (split < 1) split = 1;
+  }
+  if (split > k->ntiles) split = k->ntiles;
+  k->tps = mi_cdiv(k->ntiles, split);
+  k->nsplit = mi_cdiv(k->ntiles, k->tps);
+  k->V = (long long)k->nco * k->nci * (c->WCO * c->WCI) * c->NT * c->MI * c->NJ * 64;
+  *ws = (size_t)k->nsplit * (size_t)k->V * 16;
+  return MI_OK;
+}
+
+extern "C" int64_t mi_conv2d_wgrad_plan(const mi_wgrad_desc* d) {
+  Wg2K k; Wg2Cfg c; size_t lds, ws;
+  mi_wgrad_desc t = *d;
+  if (!t.x) t.x = (const void*)256;
+  if (!t.dy) t.dy = (const void*)256;
+  const int rc = wg_fill(&t, &k, &c, &lds, &ws);
+  if (rc) return rc;
+  return (int64_t)ws;
+}
+
+template <int NT, int MI, int NJ, int WCO, int WCI, int TP>
+static int wg_launch(const Wg2K& k, size_t lds, hipStream_t s) {
+  auto fn = wgrad2_kernel<NT, MI, NJ, WCO, WCI, TP>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(fn, dim3((unsigned)(k.nsplit * k.nco * k.nci)), dim3(WCO * WCI * 64), lds, s, k);
+  MI_CHECK_LAUNCH("conv_wgrad");
+  return MI_OK;
+}
+
+extern "C" int mi_conv2d_wgrad(const mi_wgrad_desc* d, mi_stream_t st) {
+  Wg2K k; Wg2Cfg c; size_t lds, ws;
+  int rc = wg_fill(d, &k, &c, &lds, &ws);
+  if (rc) return rc;
+  MI_REQUIRE(d->gw && d->ws, "wgrad: null gradient / workspace");
+  MI_REQUIRE((uintptr_t)d->ws % 16 == 0 && (size_t)d->ws_bytes >= ws, "wgrad: workspace %lld < %zu bytes",
+             (long long)d->ws_bytes, ws);
+  static const void* zero = nullptr;
+  if (!zero) {
+    void* zp = nullptr;
+    if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_mi_zero_page)) != hipSuccess) MI_FAIL(MI_ELAUNCH, "wgrad: zero page");
+    zero = zp;
+  }
+  k.zero = zero;
+  hipStream_t s = (hipStream_t)st;
+  rc = MI_EINVAL;
+#define MI_WG(NTv, MIv, NJv, WCOv, WCIv, TPv)                                                          \
+  if (c.NT == NTv && c.MI == MIv && c.NJ == NJv && c.WCO == WCOv && c.WCI == WCIv && c.TP == TPv)     \
+    rc = wg_launch<NTv, MIv, NJv, WCOv, WCIv, TPv>(k, lds, s);
+  MI_WG(9, 4, 1, 1, 4, 128) MI_WG(9, 4, 1, 1, 4, 64)
+  MI_WG(9, 2, 1, 2, 2, 128) MI_WG(9, 2, 1, 2, 2, 64)
+  MI_WG(9, 1, 1, 2, 2, 128) MI_WG(9, 1, 1, 2, 2, 64)
+  MI_WG(9, 1, 1, 2, 1, 128) MI_WG(9, 1, 1, 2, 1, 64)
+  MI_WG(1, 1, 1, 2, 2, 128) MI_WG(1, 1, 2, 2, 2, 128) MI_WG(1, 1, 4, 2, 2, 128)
+  MI_WG(1, 2, 1, 2, 2, 128) MI_WG(1, 2, 2, 2, 2, 128) MI_WG(1, 2, 4, 2, 2, 128)
+  MI_WG(1, 4, 1, 2, 2, 128) MI_WG(1, 4, 2, 2, 2, 128) MI_WG(1, 4, 4, 2, 2, 128)
+  MI_WG(1, 1, 1, 2, 2, 64) MI_WG(1, 1, 2, 2, 2, 64) MI_WG(1, 1, 4, 2, 2, 64)
+  MI_WG(1, 2, 1, 2, 2, 64) MI_WG(1, 2, 2, 2, 2, 64) MI_WG(1, 2, 4, 2, 2, 64)
+  MI_WG(1, 4, 1, 2, 2, 64) MI_WG(1, 4, 2, 2, 2, 64) MI_WG(1, 4, 4, 2, 2, 64)
+#undef MI_WG
+  if (rc == MI_EINVAL) MI_FAIL(MI_EINVAL, "wgrad: no kernel for cfg NT%d MI%d NJ%d W%dx%d TP%d", c.NT, c.MI, c.NJ, c.WCO, c.WCI, c.TP);
+  if (rc) return rc;
+  Wg2R r;
+  r.part = (const f32x4*)d->ws; r.g = d->gw; r.V = k.V; r.nsplit = k.nsplit;
+  r.NT = c.NT; r.MI = c.MI; r.NJ = c.NJ; r.WCO = c.WCO; r.WCI = c.WCI; r.nco = k.nco; r.nci = k.nci;
+  r.Cout = d->Cout; r.Cin = d->Cin; r.accumulate = d->accumulate;
+  hipLaunchKernelGGL(wgrad2_reduce_kernel, dim3((unsigned)((k.V + 255) / 256)), dim3(256), 0, s, r);
+  MI_CHECK_LAUNCH("conv_wgrad_reduce");
+  return MI_OK;
+}

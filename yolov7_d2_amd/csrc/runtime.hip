@@ -27,8 +27,6 @@ static int run_one(const mi_cmd& c, hipStream_t s) {
     case MI_OP_WGRAD: return mi_conv2d_wgrad((const mi_wgrad_desc*)p[0], st);
     case MI_OP_PACK_W:
       return mi_pack_conv_weight((const float*)p[0], i[0], i[1], i[2], i[3], p[1], i[4], i[5], p[2], i[6], i[7], st);
-    case MI_OP_UNPACK_WG:
-      return mi_unpack_conv_wgrad((const float*)p[0], i[0], i[1], i[2], i[3], i[4], i[5], (float*)p[1], i[6], st);
     case MI_OP_BN_FINALIZE:
       return mi_bn_finalize((const float*)p[0], i[0], i[1], i[2], c.l[0], (const float*)p[1], (const float*)p[2],
                             c.f[0], c.f[1], (float*)p[3], (float*)p[4], (int64_t*)p[5], (float*)p[6], (float*)p[7],

@@ -281,21 +281,26 @@ class PlanBuilder:
         return out
 
     def wgrad_cmds(self, tag, x, dyT, CinPad, CoutPad, Cin, Cout, k, stride, pad, wgrad):
-        KK = k * k
-        direct = (k == 1 and CinPad == Cin and CoutPad == Cout)
-        if direct:
-            gw = _Ptr(wgrad)
-            self.emit("MEMSET", i=[0], l=[Cout * Cin * 4], p=[wgrad], tag=tag + ".gwzero")
-        else:
-            gwb = self.scratch("gw", KK * CoutPad * CinPad * 4)
-            gw = _Ptr(gwb)
-            self.emit("MEMSET", i=[0], l=[KK * CoutPad * CinPad * 4], p=[gwb], tag=tag + ".gwzero")
+        """weight gradient straight into the fp32 OIHW gradient view (split-K workspace shared by all layers)"""
         taps = [(r - pad, s - pad) for r in range(k) for s in range(k)]
-        spec = ConvSpec(kind="wgrad", x=_Ptr(x), dy=_Ptr(dyT), gw=gw, ldx=x.ld, ldy=dyT.ld, N=x.N, H=x.H, W=x.W,
-                        outH=dyT.H, outW=dyT.W, stride=stride, CinPad=CinPad, CoutPad=CoutPad, taps=taps, tag=tag)
+        spec = ConvSpec(kind="wgrad", x=_Ptr(x), dy=_Ptr(dyT), gw=_Ptr(wgrad), ldx=x.ld, ldy=dyT.ld, N=x.N, H=x.H,
+                        W=x.W, outH=dyT.H, outW=dyT.W, stride=stride, Cin=Cin, Cout=Cout, CinPad=CinPad,
+                        CoutPad=CoutPad, taps=taps, tag=tag)
+        d = self._wgrad_desc(spec)
+        nbytes = L.lib().mi_conv2d_wgrad_plan(C.byref(d))
+        L.check(nbytes, "mi_conv2d_wgrad_plan")
+        spec.ws = self.scratch("wgrad_ws", nbytes)
         self.emit("WGRAD", desc=spec, tag=tag + ".wgrad")
-        if not direct:
-            self.emit("UNPACK_WG", i=[Cout, Cin, k, k, CoutPad, CinPad, 0], p=[gw, wgrad], tag=tag + ".gwunpack")
+
+    @staticmethod
+    def _wgrad_desc(spec):
+        d = L.mi_wgrad_desc()
+        for kk in ("ldx", "ldy", "N", "H", "W", "outH", "outW", "stride", "Cin", "Cout", "CinPad", "CoutPad"):
+            setattr(d, kk, int(getattr(spec, kk)))
+        d.ntaps = len(spec.taps)
+        for t, (dy, dx) in enumerate(spec.taps):
+            d.tap_dy[t], d.tap_dx[t] = dy, dx
+        return d
 
     def dgrad_cmds(self, tag, dyT, wd, K8, x, Cin, CinPadN, k, stride, pad):
         """data gradient into x.grad; dyT: out-grad view with K8*8 readable channels"""
@@ -436,13 +441,9 @@ class Plan:
             for t, (dy, dx, w) in enumerate(spec.taps):
                 d.tap_dy[t], d.tap_dx[t], d.tap_w[t] = dy, dx, w
         elif kind == "wgrad":
-            d = L.mi_wgrad_desc()
+            d = PlanBuilder._wgrad_desc(spec)
             d.x, d.dy, d.gw = spec.x.resolve(), spec.dy.resolve(), spec.gw.resolve()
-            for k in ("ldx", "ldy", "N", "H", "W", "outH", "outW", "stride", "CinPad", "CoutPad"):
-                setattr(d, k, int(getattr(spec, k)))
-            d.ntaps = len(spec.taps)
-            for t, (dy, dx) in enumerate(spec.taps):
-                d.tap_dy[t], d.tap_dx[t] = dy, dx
+            d.ws, d.ws_bytes = spec.ws.ptr, spec.ws.nbytes
         else:
             d = L.mi_yolox_loss_desc()
             d.preds, d.labels, d.anchors = spec.preds.resolve(), spec.labels.resolve(), spec.anchors.resolve()
