@@ -167,10 +167,16 @@ def test_training_step_drop_in(golden_dir):
     losses.backward()
     torch.cuda.synchronize()
     got = np.array([float(loss_dict[k]) for k in ("total_loss", "iou_loss", "conf_loss", "cls_loss")])
-    np.testing.assert_allclose(got, g["losses"][:4], rtol=6e-2, atol=5e-2)
+    # (a) tight: the loss kernels against the oracle evaluated on the SAME raw head outputs the HIP path produced
+    ps = model.plan_for(2, 64, 96, True)
+    chk = O.yolox_losses(ps.preds().float().cpu(), labels, ps.anchors.float().cpu(), 80)
+    np.testing.assert_allclose(got, np.array([float(x) for x in chk[:4]]), rtol=1e-4, atol=1e-5)
+    # (b) whole network against the reference golden (fp32): bounded by bf16 storage noise; on this tiny 64x96 batch a
+    # single flipped SimOTA assignment moves the class loss by several percent, the total by < 2 %
+    np.testing.assert_allclose(got[0], g["losses"][0], rtol=3e-2)
+    np.testing.assert_allclose(got, g["losses"][:4], rtol=1.5e-1, atol=5e-2)
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
     # raw head output against the fp32 oracle
-    ps = model.plan_for(2, 64, 96, True)
     net = O.Net({k: v.clone() for k, v in sd.items()}, 0.33, 0.5, 80, training=True)
     with torch.no_grad():
         raw_ref, _ = net.forward_raw(imgs)

@@ -195,14 +195,16 @@ class PlanBuilder:
         self.conv_records.append(spec)
         return self.emit("CONV", desc=spec, tag=tag)
 
-    def plan_conv_tiles(self, N, gridH, gridW):
-        """number of pixel tiles the launcher will use (mirror of choose_tile in conv_igemm.hip via the C call)"""
+    def plan_conv_tiles(self, x, Ho, Wo, K8, Cout, taps, stride):
+        """number of pixel tiles (rows of the stats partial buffer) the launcher will use for this forward conv:
+        asked from the library itself (mi_conv2d_plan) so host and device agree on the tile heuristics"""
         d = L.mi_conv_desc()
-        d.N, d.gridH, d.gridW, d.outH, d.outW = N, gridH, gridW, gridH, gridW
-        d.H, d.W = gridH, gridW
-        d.in_stride = d.out_stride = 1
-        d.K8, d.Cout, d.CoutPad, d.ntaps = 2, 32, 32, 1
-        d.ldx, d.ldy = 16, 32
+        d.N, d.H, d.W, d.outH, d.outW, d.gridH, d.gridW = x.N, x.H, x.W, Ho, Wo, Ho, Wo
+        d.in_stride, d.out_stride = stride, 1
+        d.K8, d.Cout, d.CoutPad, d.ntaps = K8, Cout, Cout, len(taps)
+        for t, (dy, dx, w) in enumerate(taps):
+            d.tap_dy[t], d.tap_dx[t], d.tap_w[t] = dy, dx, w
+        d.ldx, d.ldy = x.ld, Cout
         d.x = d.w = d.y = 256  # non-null, 16B aligned dummies; nothing is launched
         n = L.lib().mi_conv2d_plan(C.byref(d))
         L.check(n, "mi_conv2d_plan")
@@ -238,7 +240,7 @@ class PlanBuilder:
         if self.bn_train:
             mean = self.small(tag + ".mean", Cout * 4)
             invstd = self.small(tag + ".invstd", Cout * 4)
-            ntiles = self.plan_conv_tiles(x.N, Ho, Wo)
+            ntiles = self.plan_conv_tiles(x, Ho, Wo, CinPad // 8, Cout, taps, stride)
             part = self.scratch("bn_partial", ntiles * Cout * 2 * 4)
             self.conv_cmd(tag + ".conv", x, wf, CinPad // 8, y, y.ld, Ho, Wo, Cout, Cout, taps, in_stride=stride,
                           stats=part)
