@@ -109,6 +109,16 @@ int mi_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW,
                         void* wf, int CinPad, int CoutPad,
                         void* wd, int CoutPadK, int CinPadN, mi_stream_t s);
 
+/* all layers of a step in ONE launch: jobs_dev is a device array of njobs records (same meaning as the
+ * arguments of mi_pack_conv_weight) */
+typedef struct mi_pack_job {
+  const float* w;
+  void* wf;
+  void* wd;
+  int32_t Cout, Cin, KK, CinPad, CoutPad, CoutPadK, CinPadN, pad_;
+} mi_pack_job;
+int mi_pack_conv_weights_batch(const mi_pack_job* jobs_dev, int njobs, mi_stream_t s);
+
 /* ---- BatchNorm(train) + SiLU (+ residual) -----------------------------
  * replaces nn.BatchNorm2d + nn.SiLU of BaseConv (wrappers.py:76-80) and the
  * Bottleneck add (wrappers.py:119-123). */
@@ -158,8 +168,8 @@ int mi_spp_pool_bwd(const void* dy5, const void* dy9, const void* dy13, int lddy
 int mi_copy_bf16(const void* src, int lds_, void* dst, int ldd, int accumulate, int64_t npix, int C,
                  mi_stream_t s);
 /* column sums of a bf16 NHWC view -> fp32 [C] (bias gradient of the prediction convs) */
-int mi_colsum_bf16(const void* x, int ldx, int64_t npix, int C, float* out, int accumulate,
-                   mi_stream_t s);
+int mi_colsum_bf16(const void* x, int ldx, int64_t npix, int C, float* out, int accumulate, float* ws,
+                   mi_stream_t s); /* ws: >= 128*128 floats of scratch (two-stage, fixed summation order) */
 
 /* ---- YOLOX head: decode + SimOTA + losses ---------------------------------
  * replaces YOLOXHead.get_output_and_grid / get_losses / get_assignments /
@@ -251,6 +261,7 @@ enum {
   MI_OP_SGD = 21,
   MI_OP_BN_EVAL_AFFINE = 22,
   MI_OP_DECODE = 23,
+  MI_OP_PACK_W_BATCH = 24,
   MI_OP_COUNT
 };
 

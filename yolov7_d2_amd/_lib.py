@@ -61,6 +61,12 @@ class mi_sgd_seg(C.Structure):
     _fields_ = [("offset", C.c_int64), ("count", C.c_int64), ("weight_decay", C.c_float), ("lr", C.c_float)]
 
 
+class mi_pack_job(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("wf", C.c_void_p), ("wd", C.c_void_p),
+                ("Cout", C.c_int32), ("Cin", C.c_int32), ("KK", C.c_int32), ("CinPad", C.c_int32),
+                ("CoutPad", C.c_int32), ("CoutPadK", C.c_int32), ("CinPadN", C.c_int32), ("pad_", C.c_int32)]
+
+
 class mi_cmd(C.Structure):
     _fields_ = [("op", C.c_int32), ("i", C.c_int32 * 40), ("f", C.c_float * 8), ("p", C.c_void_p * 12),
                 ("l", C.c_int64 * 4)]
@@ -69,7 +75,7 @@ class mi_cmd(C.Structure):
 # opcode names must match the enum in include/mi355_det.h
 OPS = ["NOP", "CONV", "WGRAD", "PACK_W", "RESERVED4", "BN_FINALIZE", "BN_ACT_FWD", "BN_BWD_REDUCE",
        "BN_BWD_FINALIZE", "BN_BWD_APPLY", "FOCUS", "UPSAMPLE_FWD", "UPSAMPLE_BWD", "SPP_FWD", "SPP_BWD", "COPY",
-       "COLSUM", "LOSS_FWD", "LOSS_BWD", "SPLIT_DPREDS", "MEMSET", "SGD", "BN_EVAL_AFFINE", "DECODE"]
+       "COLSUM", "LOSS_FWD", "LOSS_BWD", "SPLIT_DPREDS", "MEMSET", "SGD", "BN_EVAL_AFFINE", "DECODE", "PACK_W_BATCH"]
 OP = {n: k for k, n in enumerate(OPS)}
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -95,7 +101,8 @@ _PROTOS = {
     "mi_spp_pool_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "mi_spp_pool_bwd": (C.c_int, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mi_copy_bf16": (C.c_int, [_vp, _i, _vp, _i, _i, _i64, _i, _vp]),
-    "mi_colsum_bf16": (C.c_int, [_vp, _i, _i64, _i, _vp, _i, _vp]),
+    "mi_colsum_bf16": (C.c_int, [_vp, _i, _i64, _i, _vp, _i, _vp, _vp]),
+    "mi_pack_conv_weights_batch": (C.c_int, [_vp, _i, _vp]),
     "mi_yolox_loss_fwd": (C.c_int, [C.POINTER(mi_yolox_loss_desc), _vp]),
     "mi_yolox_loss_bwd": (C.c_int, [C.POINTER(mi_yolox_loss_desc), _vp, _vp, _vp]),
     "mi_yolox_split_dpreds": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),

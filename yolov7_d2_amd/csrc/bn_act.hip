@@ -6,7 +6,22 @@
 #include "common.h"
 
 // ------------------------------------------------------------------ forward statistics
-__global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict__ partial, int ntiles, int C, int CPad,
+__device__ __forceinline__ void block_sum2_d(double& s1, double& s2) {
+  // 256-thread block reduction of two doubles (fixed order)
+  __shared__ double red[2 * 4];
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[wave * 2 + 0] = s1;
+    red[wave * 2 + 1] = s2;
+  }
+  __syncthreads();
+  s1 = (red[0] + red[2]) + (red[4] + red[6]);
+  s2 = (red[1] + red[3]) + (red[5] + red[7]);
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int ntiles, int C, int CPad,
                                                          double inv_count, double unbias, const float* gamma,
                                                          const float* beta, float eps, float momentum, float* rmean,
                                                          float* rvar, int64_t* nbt, float* scale, float* shift,
@@ -14,13 +29,20 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float* __restrict
   const int c = blockIdx.x;
   const int lane = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int t = lane; t < ntiles; t += 64) {
-    const float* pp = partial + ((size_t)t * CPad + c) * 2;
-    s1 += (double)pp[0];
-    s2 += (double)pp[1];
+  const f32x2* pp = (const f32x2*)partial + c;
+  int t = lane;
+  for (; t + 768 < ntiles; t += 1024) {  // 4 independent 8-byte loads in flight per thread
+    const f32x2 a = pp[(size_t)t * CPad], b = pp[(size_t)(t + 256) * CPad], cc = pp[(size_t)(t + 512) * CPad],
+                d = pp[(size_t)(t + 768) * CPad];
+    s1 += ((double)a[0] + (double)b[0]) + ((double)cc[0] + (double)d[0]);
+    s2 += ((double)a[1] + (double)b[1]) + ((double)cc[1] + (double)d[1]);
   }
-  s1 = wave_sum_d(s1);
-  s2 = wave_sum_d(s2);
+  for (; t < ntiles; t += 256) {
+    const f32x2 a = pp[(size_t)t * CPad];
+    s1 += (double)a[0];
+    s2 += (double)a[1];
+  }
+  block_sum2_d(s1, s2);
   if (lane == 0) {
     const double mean = s1 * inv_count;
     double var = s2 * inv_count - mean * mean;
@@ -47,7 +69,7 @@ extern "C" int mi_bn_finalize(const float* partial, int ntiles, int C, int CPad,
   MI_REQUIRE(partial && gamma && beta && scale && shift && mean && invstd, "bn_finalize: null");
   MI_REQUIRE(C > 0 && CPad >= C && ntiles > 0 && count > 0, "bn_finalize: sizes");
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)st, partial, ntiles, C, CPad,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)st, partial, ntiles, C, CPad,
                      1.0 / (double)count, unbias, gamma, beta, eps, momentum, running_mean, running_var,
                      num_batches_tracked, scale, shift, mean, invstd);
   MI_CHECK_LAUNCH("bn_finalize");
@@ -202,18 +224,25 @@ extern "C" int mi_bn_act_bwd_reduce(const void* da, int ldda, const void* y, int
   return MI_OK;
 }
 
-__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
                                                              double inv_count, float* dgamma, float* dbeta, float* c1,
                                                              float* c2) {
   const int c = blockIdx.x, lane = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int t = lane; t < nblk; t += 64) {
-    const float* pp = partial + ((size_t)t * C + c) * 2;
-    s1 += (double)pp[0];
-    s2 += (double)pp[1];
+  const f32x2* pp = (const f32x2*)partial + c;
+  int t = lane;
+  for (; t + 768 < nblk; t += 1024) {
+    const f32x2 a = pp[(size_t)t * C], b = pp[(size_t)(t + 256) * C], cc = pp[(size_t)(t + 512) * C],
+                d = pp[(size_t)(t + 768) * C];
+    s1 += ((double)a[0] + (double)b[0]) + ((double)cc[0] + (double)d[0]);
+    s2 += ((double)a[1] + (double)b[1]) + ((double)cc[1] + (double)d[1]);
   }
-  s1 = wave_sum_d(s1);
-  s2 = wave_sum_d(s2);
+  for (; t < nblk; t += 256) {
+    const f32x2 a = pp[(size_t)t * C];
+    s1 += (double)a[0];
+    s2 += (double)a[1];
+  }
+  block_sum2_d(s1, s2);
   if (lane == 0) {
     if (dbeta) dbeta[c] = (float)s1;
     if (dgamma) dgamma[c] = (float)s2;
@@ -225,7 +254,7 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __rest
 extern "C" int mi_bn_bwd_finalize(const float* partial, int nblk, int C, int64_t count, float* dgamma, float* dbeta,
                                   float* c1, float* c2, mi_stream_t st) {
   MI_REQUIRE(partial && c1 && c2 && nblk > 0 && C > 0 && count > 0, "bn_bwd_finalize: args");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)st, partial, nblk, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)st, partial, nblk, C,
                      1.0 / (double)count, dgamma, dbeta, c1, c2);
   MI_CHECK_LAUNCH("bn_bwd_finalize");
   return MI_OK;

@@ -529,8 +529,8 @@ extern "C" int mi_conv2d(const mi_conv_desc* d, mi_stream_t st) {
 }
 
 // ================================================================= weight (un)packing
-__global__ void pack_w_kernel(const float* __restrict__ w, int Cout, int Cin, int KK, __bf16* wf,
-                              int CinPad, int CoutPad, __bf16* wd, int CoutPadK, int CinPadN) {
+__device__ __forceinline__ void pack_w_body(const float* __restrict__ w, int Cout, int Cin, int KK, __bf16* wf,
+                                            int CinPad, int CoutPad, __bf16* wd, int CoutPadK, int CinPadN) {
   // forward image: wf[tap][ci/8][co][ci%8]
   const int64_t nf = wf ? (int64_t)KK * CinPad * CoutPad : 0;
   const int64_t nd = wd ? (int64_t)KK * CoutPadK * CinPadN : 0;
@@ -560,6 +560,21 @@ __global__ void pack_w_kernel(const float* __restrict__ w, int Cout, int Cin, in
       wd[i2] = (__bf16)v;
     }
   }
+}
+
+__global__ void pack_w_kernel(const float* __restrict__ w, int Cout, int Cin, int KK, __bf16* wf, int CinPad,
+                              int CoutPad, __bf16* wd, int CoutPadK, int CinPadN) {
+  pack_w_body(w, Cout, Cin, KK, wf, CinPad, CoutPad, wd, CoutPadK, CinPadN);
+}
+__global__ void pack_w_batch_kernel(const mi_pack_job* __restrict__ jobs) {
+  const mi_pack_job j = jobs[blockIdx.y];
+  pack_w_body(j.w, j.Cout, j.Cin, j.KK, (__bf16*)j.wf, j.CinPad, j.CoutPad, (__bf16*)j.wd, j.CoutPadK, j.CinPadN);
+}
+extern "C" int mi_pack_conv_weights_batch(const mi_pack_job* jobs_dev, int njobs, mi_stream_t st) {
+  MI_REQUIRE(jobs_dev && njobs > 0 && njobs <= 65535, "pack_w_batch: args");
+  hipLaunchKernelGGL(pack_w_batch_kernel, dim3(48, njobs), dim3(256), 0, (hipStream_t)st, jobs_dev);
+  MI_CHECK_LAUNCH("pack_w_batch");
+  return MI_OK;
 }
 
 extern "C" int mi_pack_conv_weight(const float* w, int Cout, int Cin, int KH, int KW, void* wf, int CinPad,

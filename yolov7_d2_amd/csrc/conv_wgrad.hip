@@ -280,6 +280,14 @@ static int wg_pick_cfg(const mi_wgrad_desc* d, Wg2Cfg* c) {
     c->MI = (co % 128 == 0) ? 4 : (co % 64 == 0) ? 2 : 1;
     c->NJ = (ci % 128 == 0) ? 4 : (ci % 64 == 0) ? 2 : 1;
   }
+  if (c->TP == 128) {
+    int th, tw;
+    wg_choose_tile(128, d->outH, d->outW, &th, &tw);
+    const long tiles = (long)d->N * mi_cdiv(d->outH, th) * mi_cdiv(d->outW, tw);
+    const int BCO = 16 * c->MI * c->WCO, BCI = 16 * c->NJ * c->WCI;
+    const long outt = (long)(d->CoutPad / BCO) * (d->CinPad / BCI);
+    if (tiles * outt < 4 * 256) c->TP = 64;
+  }
   if (d->cfg_tp == 64 || d->cfg_tp == 128) c->TP = d->cfg_tp;
   return MI_OK;
 }
@@ -328,10 +336,12 @@ static int wg_fill(const mi_wgrad_desc* d, Wg2K* k, Wg2Cfg* c, size_t* lds, size
   k->nco = d->CoutPad / BCO; k->nci = d->CinPad / BCI;
   int split = d->splitk;
   if (split <= 0) {
-    // ~2 resident blocks per CU; keep the split a multiple of 8 so a pixel range's blocks share an XCD (L2)
-    const int blocks_per_cu = (*lds <= 80 * 1024) ? 2 : 1;
-    split = (256 * blocks_per_cu) / (k->nco * k->nci);
-    if (split >= 8) split &= ~7;
+    // one resident block per CU, but never fewer than ~4 pixel tiles per block: each block pays a fixed
+    // accumulator-slab write (and the reduce kernel a read) that only a long enough K range amortises
+    split = 256 / (k->nco * k->nci);
+    const int by_tiles = k->ntiles / 4;
+    if (split > by_tiles) split = by_tiles;
+    if (split >= 8) split &= ~7;  // multiple of 8: the blocks of one pixel range share an XCD (L2)
     if (split < 1) split = 1;
   }
   if (split > k->ntiles) split = k->ntiles;

@@ -265,26 +265,55 @@ extern "C" int mi_copy_bf16(const void* src, int lds_, void* dst, int ldd, int a
   return MI_OK;
 }
 
-// ---- column sums (bias gradients of the prediction convs)
-__global__ __launch_bounds__(128) void colsum_kernel(const __bf16* __restrict__ x, int ldx, int64_t npix, int C,
-                                                     float* out) {
+// ---- column sums (bias gradients of the prediction convs): two stages, fixed summation order
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(const __bf16* __restrict__ x, int ldx, int64_t npix,
+                                                            int C8N, float* __restrict__ part) {
+  __shared__ float red[256 * 8];
+  const int tid = threadIdx.x;
+  const int c8 = tid % C8N, pl = tid / C8N, PL = 256 / C8N;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  if (pl < PL)
+    for (int64_t p = (int64_t)blockIdx.x * PL + pl; p < npix; p += (int64_t)gridDim.x * PL) {
+      const bf16x8 v = *(const bf16x8*)(x + p * ldx + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[tid * 8 + e] = (pl < PL) ? s[e] : 0.f;
+  __syncthreads();
+  const int C = C8N * 8;
+  if (tid < C) {
+    const int cc8 = tid >> 3, e = tid & 7;
+    float a = 0.f;
+    for (int q = 0; q < PL; ++q) a += red[(q * C8N + cc8) * 8 + e];
+    part[(size_t)blockIdx.x * C + tid] = a;
+  }
+}
+__global__ __launch_bounds__(128) void colsum_stage2_kernel(const float* __restrict__ part, int nblk, int CP, int C,
+                                                            float* out, int accumulate) {
   const int c = threadIdx.x;
   if (c >= C) return;
-  const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
-  const int64_t p0 = blockIdx.x * per, p1 = min(npix, p0 + per);
-  float acc = 0.f;
-  for (int64_t p = p0; p < p1; ++p) acc += (float)x[p * ldx + c];
-  unsafeAtomicAdd(out + c, acc);
+  float a = 0.f;
+  for (int b = 0; b < nblk; ++b) a += part[(size_t)b * CP + c];
+  out[c] = accumulate ? out[c] + a : a;
 }
-extern "C" int mi_colsum_bf16(const void* x, int ldx, int64_t npix, int C, float* out, int accumulate,
+extern "C" int mi_colsum_bf16(const void* x, int ldx, int64_t npix, int C, float* out, int accumulate, float* ws,
                               mi_stream_t st) {
-  MI_REQUIRE(x && out && C > 0 && C <= 128, "colsum: C %d (<=128)", C);
+  MI_REQUIRE(x && out && ws && C > 0 && C <= 128, "colsum: C %d (<=128)", C);
+  const int CP = (C + 7) / 8 * 8;  // channels readable (the map is padded to a multiple of 8)
+  const int C8N = CP / 8;
+  MI_REQUIRE(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0 && ldx >= CP, "colsum: alignment / ld");
   hipStream_t s = (hipStream_t)st;
-  if (!accumulate) {
-    if (hipMemsetAsync(out, 0, sizeof(float) * C, s) != hipSuccess) MI_FAIL(MI_ELAUNCH, "colsum: memset");
-  }
-  hipLaunchKernelGGL(colsum_kernel, dim3(256), dim3(128), 0, s, (const __bf16*)x, ldx, npix, C, out);
-  MI_CHECK_LAUNCH("colsum");
+  const int PL = 256 / C8N;
+  int nblk = (int)((npix + PL * 8 - 1) / (PL * 8));
+  if (nblk > 128) nblk = 128;
+  if (nblk < 1) nblk = 1;
+  hipLaunchKernelGGL(colsum_stage1_kernel, dim3(nblk), dim3(256), 0, s, (const __bf16*)x, ldx, npix, C8N, ws);
+  MI_CHECK_LAUNCH("colsum1");
+  hipLaunchKernelGGL(colsum_stage2_kernel, dim3(1), dim3(128), 0, s, ws, nblk, CP, C, out, accumulate);
+  MI_CHECK_LAUNCH("colsum2");
   return MI_OK;
 }
 

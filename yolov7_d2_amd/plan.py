@@ -342,7 +342,8 @@ class PlanBuilder:
             dT = TRef(dmap, x.N, x.H, x.W, CoutPad, CoutPad)
             self.emit("SPLIT_DPREDS", i=[x.N, A, nch, a0, HW, c0, Cout, CoutPad], p=[self.loss["dpreds"], dT],
                       tag=tag + ".split")
-            self.emit("COLSUM", i=[CoutPad, Cout, 0], l=[x.N * HW], p=[dT, bgrad], tag=tag + ".bgrad")
+            self.emit("COLSUM", i=[CoutPad, Cout, 0], l=[x.N * HW], p=[dT, bgrad, self.scratch("colsum_ws", 128 * 128 * 4)],
+                      tag=tag + ".bgrad")
             self.wgrad_cmds(tag, x, dT, Cin, CoutPad, Cin, Cout, 1, 1, 0, wgrad)
             if need_dgrad:
                 self.dgrad_cmds(tag, dT, wd, CoutPad // 8, x, Cin, Cin, 1, 1, 0)
@@ -426,9 +427,24 @@ class Plan:
             buf.base = base
         self.descs = []
         self.cmd_descs = {}
-        self.fwd_cmds, self.fwd_tags = self._materialize(b.prologue + b.fwd, "fwd")
+        self.fwd_cmds, self.fwd_tags = self._materialize(self._batch_packs(b.prologue) + b.fwd, "fwd")
         self.bwd_cmds, self.bwd_tags = self._materialize(b.bwd, "bwd")
         self.graphs = {}
+
+    def _batch_packs(self, prologue):
+        """all PACK_W commands of the prologue become ONE launch over a device job table"""
+        packs = [c for c in prologue if c.op == L.OP["PACK_W"]]
+        rest = [c for c in prologue if c.op != L.OP["PACK_W"]]
+        if len(packs) < 2:
+            return prologue
+        jobs = (L.mi_pack_job * len(packs))()
+        for j, c in zip(jobs, packs):
+            Cout, Cin, KH, KW, CinPad, CoutPad, CoutPadK, CinPadN = c.i[:8]
+            j.w, j.wf, j.wd = c.p[0].resolve(), c.p[1].resolve(), c.p[2].resolve()
+            j.Cout, j.Cin, j.KK, j.CinPad, j.CoutPad, j.CoutPadK, j.CinPadN = Cout, Cin, KH * KW, CinPad, CoutPad, CoutPadK, CinPadN
+        tab = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(self.b.device)
+        self.pack_table = tab
+        return rest + [_Cmd(L.OP["PACK_W_BATCH"], i=[len(packs)], p=[_Ptr(tab)], tag="pack_all")]
 
     def _make_desc(self, spec):
         kind = getattr(spec, "kind", "conv")
