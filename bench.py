@@ -69,16 +69,23 @@ def roofline_block(plan, iters=5):
                 byt, fl = conv_algorithmic(d)
             elif op == "WGRAD":
                 d = descs[k]
-                name = f"conv_wgrad_kernel<NT={d.ntaps},BCI={32 if d.CinPad % 32 == 0 else 16}>"
+                name = f"wgrad2_kernel<NT={d.ntaps}>"
                 npx = d.N * d.outH * d.outW
                 byt = d.N * d.H * d.W * d.CinPad * 2 + npx * d.CoutPad * 2 + d.ntaps * d.CoutPad * d.CinPad * 4
                 fl = 2.0 * npx * d.CoutPad * d.CinPad * d.ntaps
+            elif op == "WGRAD_GROUP":
+                name = "wgrad2_group_kernel<*> (all layers)"
+                byt = fl = 0
+                for d in plan.wgrad_descs:
+                    npx = d.N * d.outH * d.outW
+                    byt += d.N * d.H * d.W * d.CinPad * 2 + npx * d.CoutPad * 2 + d.ntaps * d.Cout * d.Cin * 4
+                    fl += 2.0 * npx * d.CoutPad * d.CinPad * d.ntaps
             else:
                 name, byt, fl = op, 0, 0
             g = groups.setdefault(name, dict(ms=0.0, launches=0, bytes=0.0, flops=0.0))
             g["ms"] += ms; g["launches"] += 1; g["bytes"] += byt; g["flops"] += fl
     total_ms = sum(g["ms"] for g in groups.values())
-    convs = {k: v for k, v in groups.items() if k.startswith("conv_")}
+    convs = {k: v for k, v in groups.items() if k.startswith("conv_") or k.startswith("wgrad2")}
     name, g = max(convs.items(), key=lambda kv: kv[1]["ms"])
     avg_ms = g["ms"] / g["launches"]
     gbs = g["bytes"] / g["launches"] / (avg_ms * 1e-3) / 1e9

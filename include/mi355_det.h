@@ -97,11 +97,29 @@ typedef struct mi_wgrad_desc {
   int32_t ntaps;            /* 1 or 9 */
   int32_t tap_dy[MI_MAX_TAPS], tap_dx[MI_MAX_TAPS];
   int32_t accumulate;
-  int32_t TH, TW, splitk, cfg_tp; /* 0 => chosen by launcher */
+  int32_t TH, TW, splitk, cfg_tp, cfg_ns; /* 0 => chosen by launcher (pixel tile, split-K, tile pixels, LDS stages) */
 } mi_wgrad_desc;
 int mi_conv2d_wgrad(const mi_wgrad_desc* d, mi_stream_t s);
 /* workspace bytes mi_conv2d_wgrad needs for this descriptor (pointers may be NULL), or <0 */
 int64_t mi_conv2d_wgrad_plan(const mi_wgrad_desc* d);
+
+/* grouped form: all layers of a step in one grid per tile configuration + one reduce grid (weight gradients are
+ * not consumed before the optimizer step, so they can all run at the end of backward; each layer keeps its own
+ * out-gradient buffer).  _plan() lays out per-layer workspaces from ws_base, writes the device job table into
+ * table_host (caller uploads it; pass NULL/0 to query sizes) and fills *meta; _run() launches it. */
+#define MI_WGRAD_MAX_GROUPS 32
+typedef struct mi_wgrad_group {
+  int32_t ngroups, nred, red_blocks, pad_;
+  struct {
+    int32_t cfg[6];
+    int32_t njobs, nblocks, lds_bytes, pad_;
+    int64_t job_off, starts_off;
+  } g[MI_WGRAD_MAX_GROUPS];
+  int64_t red_off, red_starts_off, table_bytes, ws_bytes;
+} mi_wgrad_group;
+int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, void* ws_base, void* table_host,
+                               int64_t table_cap, mi_wgrad_group* meta);
+int mi_conv2d_wgrad_group_run(const mi_wgrad_group* meta, const void* table_dev, mi_stream_t s);
 
 /* OIHW fp32 master -> packed bf16 images.  wf: forward [KH*KW][CinPad/8][CoutPad][8];
  * wd: dgrad  [KH*KW][CoutPadK/8][CinPadN][8] (roles swapped).  Either may be NULL. */
@@ -262,6 +280,7 @@ enum {
   MI_OP_BN_EVAL_AFFINE = 22,
   MI_OP_DECODE = 23,
   MI_OP_PACK_W_BATCH = 24,
+  MI_OP_WGRAD_GROUP = 25,
   MI_OP_COUNT
 };
 

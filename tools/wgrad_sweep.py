@@ -31,10 +31,10 @@ tot_auto = tot_best = 0.0
 for key, ks in sorted(seen.items(), key=lambda kv: -len(kv[1])):
     d0 = plan.cmd_descs["bwd"][ks[0]]
     res = []
-    for tp in (0, 64, 128):
-        for sk in (0, 8, 16, 32, 64, 128, 256, 512):
+    for tp, ns in ((0, 0), (0, 2), (0, 3), (0, 4), (64, 2), (64, 3), (64, 4), (128, 2), (128, 3), (128, 4)):
+        for sk in (0, 32, 64, 128, 256, 512):
             d = L.mi_wgrad_desc.from_buffer_copy(d0)
-            d.splitk, d.cfg_tp = sk, tp
+            d.splitk, d.cfg_tp, d.cfg_ns = sk, tp, ns
             need = lib.mi_conv2d_wgrad_plan(C.byref(d))
             if need < 0 or need > ws.numel():
                 continue
@@ -46,10 +46,10 @@ for key, ks in sorted(seen.items(), key=lambda kv: -len(kv[1])):
             rc = lib.mi_cmdlist_time(cmd, 1, 5, C.byref(tot), per, L.stream_ptr())
             if rc < 0:
                 continue
-            res.append((per[0] * 1e3, tp, sk, need >> 20))
-    auto = [r for r in res if r[1] == 0 and r[2] == 0][0]
+            res.append((per[0] * 1e3, tp, sk, need >> 20, ns))
+    auto = [r for r in res if r[1] == 0 and r[2] == 0 and r[4] == 0][0]
     best = min(res)
     tot_auto += auto[0] * len(ks); tot_best += best[0] * len(ks)
     print(f"{key} x{len(ks)}: auto {auto[0]:.1f}us ws{auto[3]}MB | best {best[0]:.1f}us tp{best[1]} split{best[2]} ws{best[3]}MB | " +
-          " ".join(f"{r[1]}/{r[2]}:{r[0]:.0f}" for r in sorted(res, key=lambda r: r[0])[:6]))
+          " ".join(f"tp{r[1]}/ns{r[4]}/s{r[2]}:{r[0]:.0f}" for r in sorted(res, key=lambda r: r[0])[:6]))
 print(f"total auto {tot_auto/1e3:.3f} ms  best {tot_best/1e3:.3f} ms")

@@ -42,7 +42,7 @@ class mi_wgrad_desc(C.Structure):
         ("ntaps", C.c_int32),
         ("tap_dy", C.c_int32 * MI_MAX_TAPS), ("tap_dx", C.c_int32 * MI_MAX_TAPS),
         ("accumulate", C.c_int32),
-        ("TH", C.c_int32), ("TW", C.c_int32), ("splitk", C.c_int32), ("cfg_tp", C.c_int32),
+        ("TH", C.c_int32), ("TW", C.c_int32), ("splitk", C.c_int32), ("cfg_tp", C.c_int32), ("cfg_ns", C.c_int32),
     ]
 
 
@@ -61,6 +61,21 @@ class mi_sgd_seg(C.Structure):
     _fields_ = [("offset", C.c_int64), ("count", C.c_int64), ("weight_decay", C.c_float), ("lr", C.c_float)]
 
 
+MI_WGRAD_MAX_GROUPS = 32
+
+
+class _mi_wgrad_group_g(C.Structure):
+    _fields_ = [("cfg", C.c_int32 * 6), ("njobs", C.c_int32), ("nblocks", C.c_int32), ("lds_bytes", C.c_int32),
+                ("pad_", C.c_int32), ("job_off", C.c_int64), ("starts_off", C.c_int64)]
+
+
+class mi_wgrad_group(C.Structure):
+    _fields_ = [("ngroups", C.c_int32), ("nred", C.c_int32), ("red_blocks", C.c_int32), ("pad_", C.c_int32),
+                ("g", _mi_wgrad_group_g * MI_WGRAD_MAX_GROUPS),
+                ("red_off", C.c_int64), ("red_starts_off", C.c_int64), ("table_bytes", C.c_int64),
+                ("ws_bytes", C.c_int64)]
+
+
 class mi_pack_job(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wf", C.c_void_p), ("wd", C.c_void_p),
                 ("Cout", C.c_int32), ("Cin", C.c_int32), ("KK", C.c_int32), ("CinPad", C.c_int32),
@@ -75,7 +90,7 @@ class mi_cmd(C.Structure):
 # opcode names must match the enum in include/mi355_det.h
 OPS = ["NOP", "CONV", "WGRAD", "PACK_W", "RESERVED4", "BN_FINALIZE", "BN_ACT_FWD", "BN_BWD_REDUCE",
        "BN_BWD_FINALIZE", "BN_BWD_APPLY", "FOCUS", "UPSAMPLE_FWD", "UPSAMPLE_BWD", "SPP_FWD", "SPP_BWD", "COPY",
-       "COLSUM", "LOSS_FWD", "LOSS_BWD", "SPLIT_DPREDS", "MEMSET", "SGD", "BN_EVAL_AFFINE", "DECODE", "PACK_W_BATCH"]
+       "COLSUM", "LOSS_FWD", "LOSS_BWD", "SPLIT_DPREDS", "MEMSET", "SGD", "BN_EVAL_AFFINE", "DECODE", "PACK_W_BATCH", "WGRAD_GROUP"]
 OP = {n: k for k, n in enumerate(OPS)}
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -86,6 +101,8 @@ _PROTOS = {
     "mi_conv2d": (C.c_int, [C.POINTER(mi_conv_desc), _vp]),
     "mi_conv2d_plan": (C.c_int, [C.POINTER(mi_conv_desc)]),
     "mi_conv2d_wgrad": (C.c_int, [C.POINTER(mi_wgrad_desc), _vp]),
+    "mi_conv2d_wgrad_group_plan": (C.c_int, [C.POINTER(mi_wgrad_desc), _i, _vp, _vp, _i64, C.POINTER(mi_wgrad_group)]),
+    "mi_conv2d_wgrad_group_run": (C.c_int, [C.POINTER(mi_wgrad_group), _vp, _vp]),
     "mi_pack_conv_weight": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
     "mi_conv2d_wgrad_plan": (C.c_int64, [C.POINTER(mi_wgrad_desc)]),
     "mi_bn_finalize": (C.c_int, [_vp, _i, _i, _i, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -20,16 +20,17 @@
 //     to a split-K workspace; a second small kernel sums the splits in a fixed order (deterministic)
 //     and scatters into the OIHW fp32 gradient.  The earlier atomicAdd version spent ~19 M L2
 //     atomics per launch (270 us per 3x3 layer regardless of size).
+#include <string.h>
+#include <vector>
 #include "common.h"
 
 struct Wg2K {
   const __bf16* x;
   const __bf16* dy;
   float* part;
-  const void* zero;  // >= 16 zero bytes in global memory (source of padding rows)
   int ldx, lddy, N, H, W, outH, outW, is;
   int TH, TW, tilesY, tilesX, ntiles, tps, nsplit;
-  int dymin, dxmin, haloW, npixh, nqx, stage;
+  int dymin, dxmin, haloW, npixh, nqx, stage, ns;
   int toff[MI_MAX_TAPS];
   int nco, nci;
   unsigned mTW, mHW;  // ceil(65536 / TW), ceil(65536 / haloW): row / d == (row * m) >> 20 for row * d < 65536
@@ -56,6 +57,18 @@ __device__ __forceinline__ void glds16(const void* g, unsigned lds_off) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(__builtin_amdgcn_readfirstlane(lds_off)) : "memory", "m0");
 }
 
+// wait until at most n LDS-DMA loads of this wave are outstanding (n wave-uniform; loads retire in order).
+// s_waitcnt takes an immediate, hence the uniform branch tree; a smaller count than asked is always safe.
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define MI_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n < 0 ? 0 : (n > 30 ? 30 : n)) {
+    MI_VMC(0) MI_VMC(1) MI_VMC(2) MI_VMC(3) MI_VMC(4) MI_VMC(5) MI_VMC(6) MI_VMC(7) MI_VMC(8) MI_VMC(9) MI_VMC(10)
+    MI_VMC(11) MI_VMC(12) MI_VMC(13) MI_VMC(14) MI_VMC(15) MI_VMC(16) MI_VMC(17) MI_VMC(18) MI_VMC(19) MI_VMC(20)
+    MI_VMC(21) MI_VMC(22) MI_VMC(23) MI_VMC(24) MI_VMC(25) MI_VMC(26) MI_VMC(27) MI_VMC(28) MI_VMC(29) MI_VMC(30)
+  }
+#undef MI_VMC
+}
+
 template <int NG>
 __device__ __forceinline__ int swz32(int row) {  // 32-byte group permutation of a row
   if (NG == 1) return 0;
@@ -65,7 +78,7 @@ __device__ __forceinline__ int swz32(int row) {  // 32-byte group permutation of
 }
 
 template <int NT, int MI, int NJ, int WCO, int WCI, int TP>
-__global__ __launch_bounds__(WCO* WCI * 64, 2) void wgrad2_kernel(const Wg2K p) {
+__device__ __forceinline__ void wgrad2_body(const Wg2K& p, const int bid) {
   constexpr int NW = WCO * WCI, BCO = 16 * MI * WCO, BCI = 16 * NJ * WCI;
   constexpr int RDY = BCO * 2, RX = BCI * 2, KS = TP / 32;
   constexpr int CPR_DY = RDY / 16, RPI_DY = 64 / CPR_DY, NQ_DY = TP / RPI_DY, QW_DY = NQ_DY / NW;
@@ -81,7 +94,7 @@ __global__ __launch_bounds__(WCO* WCI * 64, 2) void wgrad2_kernel(const Wg2K p) 
   const int g = lane >> 4, t = lane & 15;
   const int wco = wave / WCI, wci = wave % WCI;
 
-  int id = blockIdx.x;
+  int id = bid;
   const int s = id % p.nsplit;
   id /= p.nsplit;
   const int cob = id % p.nco, cib = id / p.nco;
@@ -114,7 +127,7 @@ __global__ __launch_bounds__(WCO* WCI * 64, 2) void wgrad2_kernel(const Wg2K p) 
   const int tbeg = s * p.tps;
   const int tend = min(p.ntiles, tbeg + p.tps);
 
-  const char* const zero = (const char*)p.zero;
+  const char* const zero = (const char*)g_mi_zero_page;
   auto issue = [&](int tile, int st) {
     const int img = tile / tpi;
     const int rem = tile - img * tpi;
@@ -151,13 +164,24 @@ __global__ __launch_bounds__(WCO* WCI * 64, 2) void wgrad2_kernel(const Wg2K p) 
     }
   };
 
-  if (tbeg < tend) issue(tbeg, 0);
-  int it = 0;
+  // NS-stage ring: tiles it .. it+NS-2 are in flight while tile `it` is multiplied
+  const int NS = p.ns;
+  const int nload = QW_DY + (p.nqx - wave + NW - 1) / NW;  // LDS-DMA instructions this wave issues per tile
+  for (int j = 0; j < NS - 1; ++j)
+    if (tbeg + j < tend) issue(tbeg + j, j);
+  int it = 0, cur = 0;  // cur = it % NS
   for (int tile = tbeg; tile < tend; ++tile, ++it) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // tile `tile` landed for every wave; stage (it+1)&1 no longer being read
-    if (tile + 1 < tend) issue(tile + 1, (it + 1) & 1);
-    const char* dyB = smem + (it & 1) * p.stage;
+    const int ahead = min(NS - 2, tend - 1 - tile);
+    wait_vmcnt(ahead * nload);
+    __builtin_amdgcn_s_barrier();  // tile `tile` landed for every wave; the stage of tile-1 is no longer being read
+    {
+      const int nxt = tile + NS - 1;
+      int st = cur - 1;
+      if (st < 0) st += NS;
+      if (nxt < tend) issue(nxt, st);
+    }
+    const char* dyB = smem + cur * p.stage;
+    if (++cur == NS) cur = 0;
     const char* xB = dyB + TP * RDY;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -202,6 +226,22 @@ __global__ __launch_bounds__(WCO* WCI * 64, 2) void wgrad2_kernel(const Wg2K p) 
       for (int j = 0; j < NJ; ++j) out[((tap * MI + i) * NJ + j) * 64] = acc[tap][i][j];
 }
 
+template <int NT, int MI, int NJ, int WCO, int WCI, int TP>
+__global__ __launch_bounds__(WCO* WCI * 64, 2) void wgrad2_kernel(const Wg2K p) {
+  wgrad2_body<NT, MI, NJ, WCO, WCI, TP>(p, blockIdx.x);
+}
+// grouped launch: every layer of the step that uses this tile configuration, in one grid.  starts[j] = first block
+// of job j (starts[njobs] = grid size); the job record is fetched with scalar loads (uniform address).
+template <int NT, int MI, int NJ, int WCO, int WCI, int TP>
+__global__ __launch_bounds__(WCO* WCI * 64, 2) void wgrad2_group_kernel(const Wg2K* __restrict__ jobs,
+                                                                         const int* __restrict__ starts, int njobs) {
+  const int b = blockIdx.x;
+  int j = 0;
+  while (j + 1 < njobs && starts[j + 1] <= b) ++j;
+  const Wg2K p = jobs[j];
+  wgrad2_body<NT, MI, NJ, WCO, WCI, TP>(p, b - starts[j]);
+}
+
 struct Wg2R {
   const f32x4* part;
   float* g;
@@ -209,8 +249,8 @@ struct Wg2R {
   int nsplit, NT, MI, NJ, WCO, WCI, nco, nci, Cout, Cin, accumulate;
 };
 
-__global__ __launch_bounds__(256) void wgrad2_reduce_kernel(const Wg2R p) {
-  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void wgrad2_reduce_body(const Wg2R& p, const long long blk) {
+  const long long v = blk * 256 + threadIdx.x;
   if (v >= p.V) return;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
   const f32x4* src = p.part + v;
@@ -245,7 +285,32 @@ __global__ __launch_bounds__(256) void wgrad2_reduce_kernel(const Wg2R p) {
   }
 }
 
+__global__ __launch_bounds__(256) void wgrad2_reduce_kernel(const Wg2R p) { wgrad2_reduce_body(p, blockIdx.x); }
+__global__ __launch_bounds__(256) void wgrad2_reduce_group_kernel(const Wg2R* __restrict__ jobs,
+                                                                  const int* __restrict__ starts, int njobs) {
+  const int b = blockIdx.x;
+  int lo = 0, hi = njobs - 1;  // largest j with starts[j] <= b
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (starts[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const Wg2R p = jobs[lo];
+  wgrad2_reduce_body(p, b - starts[lo]);
+}
+
 // ---------------------------------------------------------------- host side
+#define MI_WG_ALL \
+  MI_WG(9, 4, 1, 1, 4, 128) MI_WG(9, 4, 1, 1, 4, 64) \
+  MI_WG(9, 2, 1, 2, 2, 128) MI_WG(9, 2, 1, 2, 2, 64) \
+  MI_WG(9, 1, 1, 2, 2, 128) MI_WG(9, 1, 1, 2, 2, 64) \
+  MI_WG(9, 1, 1, 2, 1, 128) MI_WG(9, 1, 1, 2, 1, 64) \
+  MI_WG(1, 1, 1, 2, 2, 128) MI_WG(1, 1, 2, 2, 2, 128) MI_WG(1, 1, 4, 2, 2, 128) \
+  MI_WG(1, 2, 1, 2, 2, 128) MI_WG(1, 2, 2, 2, 2, 128) MI_WG(1, 2, 4, 2, 2, 128) \
+  MI_WG(1, 4, 1, 2, 2, 128) MI_WG(1, 4, 2, 2, 2, 128) MI_WG(1, 4, 4, 2, 2, 128) \
+  MI_WG(1, 1, 1, 2, 2, 64) MI_WG(1, 1, 2, 2, 2, 64) MI_WG(1, 1, 4, 2, 2, 64) \
+  MI_WG(1, 2, 1, 2, 2, 64) MI_WG(1, 2, 2, 2, 2, 64) MI_WG(1, 2, 4, 2, 2, 64) \
+  MI_WG(1, 4, 1, 2, 2, 64) MI_WG(1, 4, 2, 2, 2, 64) MI_WG(1, 4, 4, 2, 2, 64)
+
 struct Wg2Cfg {
   int NT, MI, NJ, WCO, WCI, TP;
 };
@@ -292,7 +357,7 @@ static int wg_pick_cfg(const mi_wgrad_desc* d, Wg2Cfg* c) {
   return MI_OK;
 }
 
-static int wg_fill(const mi_wgrad_desc* d, Wg2K* k, Wg2Cfg* c, size_t* lds, size_t* ws) {
+static int wg_fill(const mi_wgrad_desc* d, Wg2K* k, Wg2Cfg* c, size_t* lds, size_t* ws, bool grouped = false) {
   MI_REQUIRE(d->x && d->dy, "wgrad: null pointer");
   MI_REQUIRE(d->ntaps == 1 || d->ntaps == 9, "wgrad: ntaps %d", d->ntaps);
   MI_REQUIRE(d->CoutPad % 32 == 0 && d->CinPad % 16 == 0, "wgrad: pads %d %d", d->CoutPad, d->CinPad);
@@ -330,7 +395,17 @@ static int wg_fill(const mi_wgrad_desc* d, Wg2K* k, Wg2Cfg* c, size_t* lds, size
   k->mTW = ((1u << 20) + TW - 1) / TW;
   k->mHW = ((1u << 20) + k->haloW - 1) / k->haloW;
   k->stage = c->TP * BCO * 2 + k->nqx * 1024;
-  *lds = 2 * (size_t)k->stage;
+  int ns = d->cfg_ns;
+  if (ns < 2 || ns > 4) {
+    // 3x3: MFMA-heavy, two co-resident blocks overlap each other's barriers -> 2 stages when two blocks fit;
+    // 1x1 and oversized stages: pure streams, one block per CU with as many tiles in flight as LDS allows
+    ns = (d->ntaps == 9 && 2 * 2 * (size_t)k->stage <= 160 * 1024) ? 2 : (int)((160 * 1024) / k->stage);
+    if (ns > 4) ns = 4;
+    if (ns < 2) ns = 2;
+  }
+  while (ns > 2 && (size_t)ns * k->stage > 160 * 1024) --ns;
+  k->ns = ns;
+  *lds = (size_t)ns * (size_t)k->stage;
   MI_REQUIRE(*lds <= 160 * 1024, "wgrad: LDS %zu too large", *lds);
   k->ntiles = d->N * k->tilesY * k->tilesX;
   k->nco = d->CoutPad / BCO; k->nci = d->CinPad / BCI;
@@ -339,7 +414,8 @@ static int wg_fill(const mi_wgrad_desc* d, Wg2K* k, Wg2Cfg* c, size_t* lds, size
     // one resident block per CU, but never fewer than ~4 pixel tiles per block: each block pays a fixed
     // accumulator-slab write (and the reduce kernel a read) that only a long enough K range amortises
     split = 256 / (k->nco * k->nci);
-    const int by_tiles = k->ntiles / 4;
+    // in a grouped launch the other layers fill the chip: favour long K ranges (less partial-slab traffic)
+    const int by_tiles = k->ntiles / (grouped ? 8 : 4);
     if (split > by_tiles) split = by_tiles;
     if (split >= 8) split &= ~7;  // multiple of 8: the blocks of one pixel range share an XCD (L2)
     if (split < 1) split = 1;
@@ -382,28 +458,12 @@ extern "C" int mi_conv2d_wgrad(const mi_wgrad_desc* d, mi_stream_t st) {
   MI_REQUIRE(d->gw && d->ws, "wgrad: null gradient / workspace");
   MI_REQUIRE((uintptr_t)d->ws % 16 == 0 && (size_t)d->ws_bytes >= ws, "wgrad: workspace %lld < %zu bytes",
              (long long)d->ws_bytes, ws);
-  static const void* zero = nullptr;
-  if (!zero) {
-    void* zp = nullptr;
-    if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_mi_zero_page)) != hipSuccess) MI_FAIL(MI_ELAUNCH, "wgrad: zero page");
-    zero = zp;
-  }
-  k.zero = zero;
   hipStream_t s = (hipStream_t)st;
   rc = MI_EINVAL;
 #define MI_WG(NTv, MIv, NJv, WCOv, WCIv, TPv)                                                          \
   if (c.NT == NTv && c.MI == MIv && c.NJ == NJv && c.WCO == WCOv && c.WCI == WCIv && c.TP == TPv)     \
     rc = wg_launch<NTv, MIv, NJv, WCOv, WCIv, TPv>(k, lds, s);
-  MI_WG(9, 4, 1, 1, 4, 128) MI_WG(9, 4, 1, 1, 4, 64)
-  MI_WG(9, 2, 1, 2, 2, 128) MI_WG(9, 2, 1, 2, 2, 64)
-  MI_WG(9, 1, 1, 2, 2, 128) MI_WG(9, 1, 1, 2, 2, 64)
-  MI_WG(9, 1, 1, 2, 1, 128) MI_WG(9, 1, 1, 2, 1, 64)
-  MI_WG(1, 1, 1, 2, 2, 128) MI_WG(1, 1, 2, 2, 2, 128) MI_WG(1, 1, 4, 2, 2, 128)
-  MI_WG(1, 2, 1, 2, 2, 128) MI_WG(1, 2, 2, 2, 2, 128) MI_WG(1, 2, 4, 2, 2, 128)
-  MI_WG(1, 4, 1, 2, 2, 128) MI_WG(1, 4, 2, 2, 2, 128) MI_WG(1, 4, 4, 2, 2, 128)
-  MI_WG(1, 1, 1, 2, 2, 64) MI_WG(1, 1, 2, 2, 2, 64) MI_WG(1, 1, 4, 2, 2, 64)
-  MI_WG(1, 2, 1, 2, 2, 64) MI_WG(1, 2, 2, 2, 2, 64) MI_WG(1, 2, 4, 2, 2, 64)
-  MI_WG(1, 4, 1, 2, 2, 64) MI_WG(1, 4, 2, 2, 2, 64) MI_WG(1, 4, 4, 2, 2, 64)
+  MI_WG_ALL
 #undef MI_WG
   if (rc == MI_EINVAL) MI_FAIL(MI_EINVAL, "wgrad: no kernel for cfg NT%d MI%d NJ%d W%dx%d TP%d", c.NT, c.MI, c.NJ, c.WCO, c.WCI, c.TP);
   if (rc) return rc;
@@ -413,5 +473,123 @@ extern "C" int mi_conv2d_wgrad(const mi_wgrad_desc* d, mi_stream_t st) {
   r.Cout = d->Cout; r.Cin = d->Cin; r.accumulate = d->accumulate;
   hipLaunchKernelGGL(wgrad2_reduce_kernel, dim3((unsigned)((k.V + 255) / 256)), dim3(256), 0, s, r);
   MI_CHECK_LAUNCH("conv_wgrad_reduce");
+  return MI_OK;
+}
+
+// ---------------------------------------------------------------- grouped launch (all layers of a step)
+// Weight gradients are not consumed before the optimizer step, so every layer's wgrad can run at the END of
+// backward: with 288 GB of HBM each layer simply keeps its own out-gradient buffer alive, and the ~80 launches of
+// a YOLOX step collapse into one grid per tile configuration plus one reduce grid (thousands of blocks, no
+// per-layer ramp-up / tail, no per-layer launch latency).
+static int wg_cfg_id(const Wg2Cfg& c) { return ((((c.NT * 8 + c.MI) * 8 + c.NJ) * 8 + c.WCO) * 8 + c.WCI) * 256 + c.TP; }
+
+extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, void* ws_base, void* table_host,
+                                          int64_t table_cap, mi_wgrad_group* meta) {
+  MI_REQUIRE(descs && n > 0 && meta, "wgrad_group_plan: args");
+  memset(meta, 0, sizeof(*meta));
+  std::vector<Wg2K> ks(n);
+  std::vector<Wg2Cfg> cs(n);
+  std::vector<size_t> ldss(n), wss(n);
+  size_t ws_off = 0;
+  for (int i = 0; i < n; ++i) {
+    mi_wgrad_desc t = descs[i];
+    if (!t.x) t.x = (const void*)256;
+    if (!t.dy) t.dy = (const void*)256;
+    int rc = wg_fill(&t, &ks[i], &cs[i], &ldss[i], &wss[i], true);
+    if (rc) return rc;
+    ks[i].part = (float*)((char*)ws_base + ws_off);
+    ws_off += (wss[i] + 255) / 256 * 256;
+  }
+  meta->ws_bytes = (int64_t)ws_off;
+  // group by configuration
+  std::vector<int> order;
+  size_t off = 0;
+  char* tab = (char*)table_host;
+  auto put = [&](const void* src, size_t bytes) -> long {
+    const size_t o = off;
+    off += (bytes + 15) / 16 * 16;
+    if (tab && (int64_t)off <= table_cap) memcpy(tab + o, src, bytes);
+    return (long)o;
+  };
+  std::vector<char> done(n, 0);
+  for (int i = 0; i < n; ++i) {
+    if (done[i]) continue;
+    MI_REQUIRE(meta->ngroups < MI_WGRAD_MAX_GROUPS, "wgrad_group_plan: too many tile configurations");
+    auto& g = meta->g[meta->ngroups++];
+    g.cfg[0] = cs[i].NT; g.cfg[1] = cs[i].MI; g.cfg[2] = cs[i].NJ; g.cfg[3] = cs[i].WCO; g.cfg[4] = cs[i].WCI;
+    g.cfg[5] = cs[i].TP;
+    std::vector<Wg2K> jobs;
+    std::vector<int> starts;
+    int blocks = 0;
+    size_t lds = 0;
+    for (int j = i; j < n; ++j)
+      if (!done[j] && wg_cfg_id(cs[j]) == wg_cfg_id(cs[i])) {
+        done[j] = 1;
+        starts.push_back(blocks);
+        jobs.push_back(ks[j]);
+        blocks += ks[j].nsplit * ks[j].nco * ks[j].nci;
+        if (ldss[j] > lds) lds = ldss[j];
+      }
+    starts.push_back(blocks);
+    g.njobs = (int)jobs.size(); g.nblocks = blocks; g.lds_bytes = (int32_t)lds;
+    g.job_off = put(jobs.data(), jobs.size() * sizeof(Wg2K));
+    g.starts_off = put(starts.data(), starts.size() * sizeof(int));
+  }
+  // reduce jobs (all layers, one grid)
+  std::vector<Wg2R> rj(n);
+  std::vector<int> rs;
+  int rblocks = 0;
+  for (int i = 0; i < n; ++i) {
+    Wg2R& r = rj[i];
+    r.part = (const f32x4*)ks[i].part; r.g = descs[i].gw; r.V = ks[i].V; r.nsplit = ks[i].nsplit;
+    r.NT = cs[i].NT; r.MI = cs[i].MI; r.NJ = cs[i].NJ; r.WCO = cs[i].WCO; r.WCI = cs[i].WCI;
+    r.nco = ks[i].nco; r.nci = ks[i].nci; r.Cout = descs[i].Cout; r.Cin = descs[i].Cin;
+    r.accumulate = descs[i].accumulate;
+    rs.push_back(rblocks);
+    rblocks += (int)((ks[i].V + 255) / 256);
+  }
+  rs.push_back(rblocks);
+  meta->nred = n; meta->red_blocks = rblocks;
+  meta->red_off = put(rj.data(), rj.size() * sizeof(Wg2R));
+  meta->red_starts_off = put(rs.data(), rs.size() * sizeof(int));
+  meta->table_bytes = (int64_t)off;
+  if (tab) MI_REQUIRE((int64_t)off <= table_cap, "wgrad_group_plan: table needs %zu bytes", off);
+  return MI_OK;
+}
+
+template <int NT, int MI, int NJ, int WCO, int WCI, int TP>
+static int wg_group_launch(const Wg2K* jobs, const int* starts, int njobs, int nblocks, size_t lds, hipStream_t s) {
+  auto fn = wgrad2_group_kernel<NT, MI, NJ, WCO, WCI, TP>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(fn, dim3((unsigned)nblocks), dim3(WCO * WCI * 64), lds, s, jobs, starts, njobs);
+  MI_CHECK_LAUNCH("conv_wgrad_group");
+  return MI_OK;
+}
+
+extern "C" int mi_conv2d_wgrad_group_run(const mi_wgrad_group* meta, const void* table_dev, mi_stream_t st) {
+  MI_REQUIRE(meta && table_dev && meta->ngroups > 0, "wgrad_group_run: args");
+  hipStream_t s = (hipStream_t)st;
+  const char* tab = (const char*)table_dev;
+  for (int gi = 0; gi < meta->ngroups; ++gi) {
+    const auto& g = meta->g[gi];
+    const Wg2K* jobs = (const Wg2K*)(tab + g.job_off);
+    const int* starts = (const int*)(tab + g.starts_off);
+    int rc = MI_EINVAL;
+#define MI_WG(NTv, MIv, NJv, WCOv, WCIv, TPv)                                                                   \
+  if (g.cfg[0] == NTv && g.cfg[1] == MIv && g.cfg[2] == NJv && g.cfg[3] == WCOv && g.cfg[4] == WCIv &&          \
+      g.cfg[5] == TPv)                                                                                          \
+    rc = wg_group_launch<NTv, MIv, NJv, WCOv, WCIv, TPv>(jobs, starts, g.njobs, g.nblocks, (size_t)g.lds_bytes, s);
+    MI_WG_ALL
+#undef MI_WG
+    if (rc == MI_EINVAL) MI_FAIL(MI_EINVAL, "wgrad_group: no kernel for group %d", gi);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(wgrad2_reduce_group_kernel, dim3((unsigned)meta->red_blocks), dim3(256), 0, s,
+                     (const Wg2R*)(tab + meta->red_off), (const int*)(tab + meta->red_starts_off), meta->nred);
+  MI_CHECK_LAUNCH("conv_wgrad_reduce_group");
   return MI_OK;
 }

@@ -33,6 +33,9 @@ def grad_write_ranges(plan, grad_tensor):
         if c.op == L.OP["WGRAD"]:
             d = C.cast(c.p[0], C.POINTER(L.mi_wgrad_desc)).contents
             ptrs.append((d.gw, d.ntaps * d.Cout * d.Cin * 4))
+        elif c.op == L.OP["WGRAD_GROUP"]:
+            for d in plan.wgrad_descs:
+                ptrs.append((d.gw, d.ntaps * d.Cout * d.Cin * 4))
         elif c.op == L.OP["BN_BWD_FINALIZE"]:
             ptrs += [(c.p[1], c.i[1] * 4), (c.p[2], c.i[1] * 4)]
         elif c.op == L.OP["COLSUM"]:

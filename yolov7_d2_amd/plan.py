@@ -91,8 +91,11 @@ class ConvSpec:
 
 
 class PlanBuilder:
-    def __init__(self, device, training=True, bn_train=None):
+    def __init__(self, device, training=True, bn_train=None, group_wgrad=None):
+        import os
         self.device = torch.device(device)
+        # all weight gradients in one grouped launch at the end of backward (each layer keeps its own dy buffer)
+        self.group_wgrad = (os.environ.get("MI_WGRAD_GROUP", "1") != "0") if group_wgrad is None else group_wgrad
         self.training = training            # build the backward command list
         self.bn_train = training if bn_train is None else bn_train  # batch statistics vs running statistics
         self.bufs = []
@@ -262,7 +265,8 @@ class PlanBuilder:
             part2 = self.scratch("bn_bwd_partial", nblk * Cout * 2 * 4)
             c1 = self.scratch("bn_c1", Cout * 4)
             c2 = self.scratch("bn_c2", Cout * 4)
-            dy = self.scratch("dy", count * Cout * 2)
+            dy = (self._new_buf(tag + ".dy", count * Cout * 2) if self.group_wgrad
+                  else self.scratch("dy", count * Cout * 2))
             dyT = TRef(dy, x.N, Ho, Wo, Cout, Cout)
             self.emit("BN_BWD_REDUCE", i=[da.ld, y.ld, nblk, Cout, act], l=[count],
                       p=[da, y, scale, shift, mean, invstd, part2], tag=tag + ".bnred")
@@ -338,7 +342,8 @@ class PlanBuilder:
         HW = x.H * x.W
 
         def bwd():
-            dmap = self.scratch("dpred_map", x.N * HW * CoutPad * 2)
+            dmap = (self._new_buf(tag + ".dmap", x.N * HW * CoutPad * 2) if self.group_wgrad
+                    else self.scratch("dpred_map", x.N * HW * CoutPad * 2))
             dT = TRef(dmap, x.N, x.H, x.W, CoutPad, CoutPad)
             self.emit("SPLIT_DPREDS", i=[x.N, A, nch, a0, HW, c0, Cout, CoutPad], p=[self.loss["dpreds"], dT],
                       tag=tag + ".split")
@@ -408,6 +413,16 @@ class PlanBuilder:
             fn()
         self._emitting_bwd = False
         self.bwd_gens = []
+        wg = [c for c in self.bwd if c.op == L.OP["WGRAD"]]
+        if self.group_wgrad and len(wg) >= 2:
+            descs = (L.mi_wgrad_desc * len(wg))()
+            for d, c in zip(descs, wg):
+                C.memmove(C.byref(d), C.byref(self._wgrad_desc(c.desc)), C.sizeof(L.mi_wgrad_desc))
+            meta = L.mi_wgrad_group()
+            L.check(L.lib().mi_conv2d_wgrad_group_plan(descs, len(wg), None, None, 0, C.byref(meta)), "wgrad_group_plan")
+            ws = self.scratch("wgrad_ws", 0)
+            ws.nbytes = _rup(int(meta.ws_bytes), 256)   # replaces the per-layer maximum
+            self.wgrad_group_ws = ws
         return Plan(self) if materialize else None
 
 
@@ -428,8 +443,35 @@ class Plan:
         self.descs = []
         self.cmd_descs = {}
         self.fwd_cmds, self.fwd_tags = self._materialize(self._batch_packs(b.prologue) + b.fwd, "fwd")
-        self.bwd_cmds, self.bwd_tags = self._materialize(b.bwd, "bwd")
+        self.bwd_cmds, self.bwd_tags = self._materialize(self._group_wgrads(b.bwd), "bwd")
         self.graphs = {}
+
+    def _group_wgrads(self, bwd):
+        """all WGRAD commands become ONE grouped launch at the end of backward (mi_conv2d_wgrad_group_run)"""
+        b = self.b
+        wg = [c for c in bwd if c.op == L.OP["WGRAD"]]
+        self.wgrad_descs = []
+        if not (b.group_wgrad and len(wg) >= 2):
+            return bwd
+        ws = b.wgrad_group_ws
+        descs = (L.mi_wgrad_desc * len(wg))()
+        for d, c in zip(descs, wg):
+            t = PlanBuilder._wgrad_desc(c.desc)
+            t.x, t.dy, t.gw = c.desc.x.resolve(), c.desc.dy.resolve(), c.desc.gw.resolve()
+            C.memmove(C.byref(d), C.byref(t), C.sizeof(L.mi_wgrad_desc))
+        meta = L.mi_wgrad_group()
+        L.check(L.lib().mi_conv2d_wgrad_group_plan(descs, len(wg), ws.ptr, None, 0, C.byref(meta)), "wgrad_group_plan")
+        assert meta.ws_bytes <= ws.nbytes, (meta.ws_bytes, ws.nbytes)
+        host = (C.c_char * int(meta.table_bytes))()
+        L.check(L.lib().mi_conv2d_wgrad_group_plan(descs, len(wg), ws.ptr, host, meta.table_bytes, C.byref(meta)),
+                "wgrad_group_plan")
+        self.wgrad_table = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(b.device)
+        self.wgrad_meta = meta
+        self.wgrad_descs = list(descs)
+        self._wgrad_descs_arr = descs
+        rest = [c for c in bwd if c.op != L.OP["WGRAD"]]
+        grp = _Cmd(L.OP["WGRAD_GROUP"], p=[_Ptr(C.addressof(meta)), _Ptr(self.wgrad_table)], tag="wgrad_group")
+        return rest + [grp]
 
     def _batch_packs(self, prologue):
         """all PACK_W commands of the prologue become ONE launch over a device job table"""
