@@ -51,7 +51,8 @@ __device__ __forceinline__ bf16x8 pack8(const float* f) {
   return v;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// 1-ulp hardware reciprocal instead of the ~10-instruction IEEE division: the consumers round to bf16 anyway
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -216,10 +216,131 @@ __global__ __launch_bounds__(256) void spp_bwd_kernel(const __bf16* __restrict__
   }
 }
 
+// LDS-plane variants: one block owns the whole H x W plane of 8 channels of one image (20x20 for YOLOX-s at 640):
+// the plane is staged once (6.4 KB) and the 13x13 windows are scanned from LDS instead of 169 global loads per output.
+__global__ __launch_bounds__(256) void spp_fwd_plane_kernel(const __bf16* __restrict__ x, int ldx, __bf16* y5,
+                                                            __bf16* y9, __bf16* y13, int ldy, uint8_t* idx, int N,
+                                                            int H, int W, int C8) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16x8* Xp = (bf16x8*)smem;  // [H*W]
+  const int c8 = blockIdx.x % C8, n = blockIdx.x / C8;
+  const int HW = H * W, C = C8 * 8;
+  const int64_t npix = (int64_t)N * HW;
+  const __bf16* xb = x + ((int64_t)n * HW) * ldx + c8 * 8;
+  for (int p = threadIdx.x; p < HW; p += 256) Xp[p] = *(const bf16x8*)(xb + (int64_t)p * ldx);
+  __syncthreads();
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    const int py = p / W, px = p - py * W;
+    float m[3][8];
+    uint8_t am[3][8];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        m[k][e] = -INFINITY;
+        am[k][e] = 84;
+      }
+    for (int dy = -6; dy <= 6; ++dy) {
+      const int yy = py + dy;
+      if (yy < 0 || yy >= H) continue;
+      for (int dx = -6; dx <= 6; ++dx) {
+        const int xx = px + dx;
+        if (xx < 0 || xx >= W) continue;
+        const bf16x8 v = Xp[yy * W + xx];
+        const uint8_t code = (uint8_t)((dy + 6) * 13 + (dx + 6));
+        const int ady = dy < 0 ? -dy : dy, adx = dx < 0 ? -dx : dx;
+        const int rad = ady > adx ? ady : adx;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = (float)v[e];
+          if (f > m[2][e]) { m[2][e] = f; am[2][e] = code; }
+          if (rad <= 4 && f > m[1][e]) { m[1][e] = f; am[1][e] = code; }
+          if (rad <= 2 && f > m[0][e]) { m[0][e] = f; am[0][e] = code; }
+        }
+      }
+    }
+    const int64_t pix = (int64_t)n * HW + p;
+    const int64_t o = pix * ldy + c8 * 8;
+    *(bf16x8*)(y5 + o) = pack8(m[0]);
+    *(bf16x8*)(y9 + o) = pack8(m[1]);
+    *(bf16x8*)(y13 + o) = pack8(m[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      uint64_t pk = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pk |= (uint64_t)am[k][e] << (8 * e);
+      *(uint64_t*)(idx + ((int64_t)k * npix + pix) * C + c8 * 8) = pk;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void spp_bwd_plane_kernel(const __bf16* __restrict__ d5, const __bf16* __restrict__ d9,
+                                                            const __bf16* __restrict__ d13, int lddy,
+                                                            const uint8_t* __restrict__ idx, __bf16* dx, int lddx,
+                                                            int accumulate, int N, int H, int W, int C8) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int HW = H * W, C = C8 * 8;
+  bf16x8* Gp = (bf16x8*)smem;                 // [3][HW] out-gradients of the three pools
+  uint64_t* Ip = (uint64_t*)(Gp + 3 * HW);    // [3][HW] argmax codes
+  const int c8 = blockIdx.x % C8, n = blockIdx.x / C8;
+  const int64_t npix = (int64_t)N * HW;
+  for (int q = threadIdx.x; q < 3 * HW; q += 256) {
+    const int k = q / HW, p = q - k * HW;
+    const int64_t pix = (int64_t)n * HW + p;
+    const __bf16* dp = (k == 0 ? d5 : (k == 1 ? d9 : d13)) + pix * lddy + c8 * 8;
+    Gp[q] = *(const bf16x8*)dp;
+    Ip[q] = *(const uint64_t*)(idx + ((int64_t)k * npix + pix) * C + c8 * 8);
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    const int py = p / W, px = p - py * W;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int dy = -6; dy <= 6; ++dy) {
+      const int oy = py - dy;
+      if (oy < 0 || oy >= H) continue;
+      for (int dxx = -6; dxx <= 6; ++dxx) {
+        const int ox = px - dxx;
+        if (ox < 0 || ox >= W) continue;
+        const uint8_t code = (uint8_t)((dy + 6) * 13 + (dxx + 6));
+        const int ady = dy < 0 ? -dy : dy, adx = dxx < 0 ? -dxx : dxx;
+        const int rad = ady > adx ? ady : adx;
+        const int op = oy * W + ox;
+        const int kmin = rad <= 2 ? 0 : (rad <= 4 ? 1 : 2);
+        for (int k = kmin; k < 3; ++k) {
+          const uint64_t pk = Ip[k * HW + op];
+          bool any = false;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) any |= (uint8_t)(pk >> (8 * e)) == code;
+          if (!any) continue;
+          const bf16x8 g = Gp[k * HW + op];
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if ((uint8_t)(pk >> (8 * e)) == code) acc[e] += (float)g[e];
+        }
+      }
+    }
+    __bf16* op_ = dx + ((int64_t)n * HW + p) * lddx + c8 * 8;
+    if (accumulate) {
+      const bf16x8 o = *(const bf16x8*)op_;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += (float)o[e];
+    }
+    *(bf16x8*)op_ = pack8(acc);
+  }
+}
+
 extern "C" int mi_spp_pool_fwd(const void* x, int ldx, void* y5, void* y9, void* y13, int ldy, uint8_t* idx, int N,
                                int H, int W, int C, mi_stream_t st) {
   MI_REQUIRE(x && y5 && y9 && y13 && idx && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "spp_fwd: args");
   const int64_t total = (int64_t)N * H * W * (C / 8);
+  if ((size_t)H * W * 16 <= 64 * 1024) {
+    hipLaunchKernelGGL(spp_fwd_plane_kernel, dim3(N * (C / 8)), dim3(256), (size_t)H * W * 16, (hipStream_t)st,
+                       (const __bf16*)x, ldx, (__bf16*)y5, (__bf16*)y9, (__bf16*)y13, ldy, idx, N, H, W, C / 8);
+    MI_CHECK_LAUNCH("spp_fwd_plane");
+    return MI_OK;
+  }
   hipLaunchKernelGGL(spp_fwd_kernel, dim3(ew_blocks(total, 65535)), dim3(256), 0, (hipStream_t)st, (const __bf16*)x,
                      ldx, (__bf16*)y5, (__bf16*)y9, (__bf16*)y13, ldy, idx, N, H, W, C / 8);
   MI_CHECK_LAUNCH("spp_fwd");
@@ -229,6 +350,13 @@ extern "C" int mi_spp_pool_bwd(const void* dy5, const void* dy9, const void* dy1
                                void* dx, int lddx, int accumulate, int N, int H, int W, int C, mi_stream_t st) {
   MI_REQUIRE(dy5 && dy9 && dy13 && idx && dx && C % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "spp_bwd: args");
   const int64_t total = (int64_t)N * H * W * (C / 8);
+  if ((size_t)H * W * 72 <= 64 * 1024) {
+    hipLaunchKernelGGL(spp_bwd_plane_kernel, dim3(N * (C / 8)), dim3(256), (size_t)H * W * 72, (hipStream_t)st,
+                       (const __bf16*)dy5, (const __bf16*)dy9, (const __bf16*)dy13, lddy, idx, (__bf16*)dx, lddx,
+                       accumulate, N, H, W, C / 8);
+    MI_CHECK_LAUNCH("spp_bwd_plane");
+    return MI_OK;
+  }
   hipLaunchKernelGGL(spp_bwd_kernel, dim3(ew_blocks(total, 65535)), dim3(256), 0, (hipStream_t)st,
                      (const __bf16*)dy5, (const __bf16*)dy9, (const __bf16*)dy13, lddy, idx, (__bf16*)dx, lddx,
                      accumulate, N, H, W, C / 8);
