@@ -52,13 +52,15 @@ const char* mi_last_error(void);
 #define MI_CONV_ACCUM 1    /* y += result (gradient fan-in)                  */
 #define MI_CONV_OUT_F32 2  /* y is fp32 (prediction maps), else bf16         */
 #define MI_MAX_TAPS 9
+#define MI_BN_SLOTS 16     /* accumulator slots per channel (slot = pixel tile % MI_BN_SLOTS) */
 
 typedef struct mi_conv_desc {
   const void* x;   /* bf16 NHWC input view, >= K8*8 channels readable        */
   const void* w;   /* packed bf16 [n_wslabs][K8][CoutPad][8]                  */
   void* y;         /* output view                                             */
   const float* bias;    /* [Cout] or NULL                                     */
-  float* stats_partial; /* [n_pixel_tiles][CoutPad][2] (sum, sumsq) or NULL   */
+  double* stats_acc;    /* [MI_BN_SLOTS][CoutPad][2] fp64 (sum, sumsq) accumulators, atomically added
+                           (caller zeroes them once per step), or NULL             */
   int32_t ldx, ldy;
   int32_t y_nstride;        /* elements between images of y; 0 => outH*outW*ldy */
   int32_t N, H, W;          /* input dims                                     */
@@ -76,7 +78,7 @@ typedef struct mi_conv_desc {
 } mi_conv_desc;
 
 int mi_conv2d(const mi_conv_desc* d, mi_stream_t s);
-/* fills TH/TW/KC/BN if zero; returns number of pixel tiles (rows of stats_partial) or <0 */
+/* fills TH/TW/KC/BN if zero; returns number of pixel tiles or <0 */
 int mi_conv2d_plan(mi_conv_desc* d);
 
 /* weight gradient: g[co][ci][tap] (fp32 OIHW, the nn.Parameter gradient layout; overwritten, or += if
@@ -140,32 +142,31 @@ int mi_pack_conv_weights_batch(const mi_pack_job* jobs_dev, int njobs, mi_stream
 /* ---- BatchNorm(train) + SiLU (+ residual) -----------------------------
  * replaces nn.BatchNorm2d + nn.SiLU of BaseConv (wrappers.py:76-80) and the
  * Bottleneck add (wrappers.py:119-123). */
-/* reduce conv-epilogue partials -> batch mean/var; writes scale/shift/mean/invstd [C];
- * updates running stats exactly as nn.BatchNorm2d (momentum, unbiased running var). */
-int mi_bn_finalize(const float* partial, int ntiles, int C, int CPad, int64_t count,
-                   const float* gamma, const float* beta, float eps, float momentum,
-                   float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                   float* scale, float* shift, float* mean, float* invstd, mi_stream_t s);
 /* eval mode: scale/shift from running statistics */
 int mi_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, int C, float* scale, float* shift,
                       mi_stream_t s);
-/* a = silu(y*scale+shift) (+res)  ; act: 1 silu, 0 identity */
-int mi_bn_act_fwd(const void* y, int ldy, const float* scale, const float* shift,
-                  const void* res, int ldres, void* a, int lda, int64_t npix, int C, int act,
-                  mi_stream_t s);
-/* pass 1: per-channel partial sums of dz and dz*xhat over pixels -> partial[nblk][C][2] */
+/* a = act(y*scale+shift) (+res); act: 1 silu, 0 identity.
+ * train mode (stats_acc != NULL): scale/shift are first derived, in the kernel prologue, from the fp64
+ * accumulators the conv epilogue filled ([MI_BN_SLOTS][C][2], `count` elements per channel); scale/shift/mean/
+ * invstd [C] are written for the backward pass and the running statistics are updated exactly as
+ * nn.BatchNorm2d does (momentum, unbiased running variance, num_batches_tracked).
+ * eval mode (stats_acc == NULL): scale/shift are inputs (mi_bn_eval_affine). */
+int mi_bn_act_fwd(const void* y, int ldy, const double* stats_acc, int64_t count, const float* gamma,
+                  const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                  int64_t* num_batches_tracked, float* scale, float* shift, float* mean, float* invstd,
+                  const void* res, int ldres, void* a, int lda, int64_t npix, int C, int act, mi_stream_t s);
+/* pass 1: per-channel sums of dz and dz*xhat over pixels, atomically added to dacc[MI_BN_SLOTS][C][2] (fp64,
+ * caller zeroes once per step); nblk = number of blocks to launch */
 int mi_bn_act_bwd_reduce(const void* da, int ldda, const void* y, int ldy, const float* scale,
                          const float* shift, const float* mean, const float* invstd,
-                         float* partial, int nblk, int64_t npix, int C, int act, mi_stream_t s);
-/* combine partials: dgamma/dbeta (overwrite) and the two correction terms c1,c2 [C] */
-int mi_bn_bwd_finalize(const float* partial, int nblk, int C, int64_t count, float* dgamma,
-                       float* dbeta, float* c1, float* c2, mi_stream_t s);
-/* pass 2: dy = gamma*invstd*(dz - c1 - xhat*c2); optional dres (+)= da */
+                         double* dacc, int nblk, int64_t npix, int C, int act, mi_stream_t s);
+/* pass 2: dy = gamma*invstd*(dz - c1 - xhat*c2), c1/c2 from dacc (prologue); writes dgamma/dbeta (overwrite);
+ * optional dres (+)= da */
 int mi_bn_act_bwd_apply(const void* da, int ldda, const void* y, int ldy, const float* scale,
                         const float* shift, const float* mean, const float* invstd,
-                        const float* gamma, const float* c1, const float* c2, void* dy, int lddy,
-                        void* dres, int lddres, int dres_accum, int64_t npix, int C, int act,
+                        const float* gamma, const double* dacc, int64_t count, float* dgamma, float* dbeta,
+                        void* dy, int lddy, void* dres, int lddres, int dres_accum, int64_t npix, int C, int act,
                         mi_stream_t s);
 
 /* ---- data movement ops -------------------------------------------------- */
@@ -250,7 +251,7 @@ typedef struct mi_cmd {
   int32_t op;          /* MI_OP_* */
   int32_t i[40];
   float f[8];
-  void* p[12];
+  void* p[16];
   int64_t l[4];
 } mi_cmd;
 
@@ -260,10 +261,10 @@ enum {
   MI_OP_WGRAD = 2,
   MI_OP_PACK_W = 3,
   MI_OP_RESERVED4 = 4, /* was UNPACK_WG: wgrad now writes OIHW directly */
-  MI_OP_BN_FINALIZE = 5,
+  MI_OP_RESERVED5 = 5, /* was BN_FINALIZE: folded into BN_ACT_FWD */
   MI_OP_BN_ACT_FWD = 6,
   MI_OP_BN_BWD_REDUCE = 7,
-  MI_OP_BN_BWD_FINALIZE = 8,
+  MI_OP_RESERVED8 = 8, /* was BN_BWD_FINALIZE: folded into BN_BWD_APPLY */
   MI_OP_BN_BWD_APPLY = 9,
   MI_OP_FOCUS = 10,
   MI_OP_UPSAMPLE_FWD = 11,

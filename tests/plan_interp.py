@@ -55,6 +55,10 @@ class Interp:
         assert isinstance(o, Buf), type(o)
         return self.raw(o).view(torch.float32)[(p.off + off_bytes) // 4: (p.off + off_bytes) // 4 + n]
 
+    def f64(self, p, n):
+        assert isinstance(p.obj, Buf) and p.off % 8 == 0
+        return self.raw(p.obj).view(torch.float64)[p.off // 8: p.off // 8 + n]
+
     def rawbytes(self, p, n):
         o = p.obj
         if isinstance(o, torch.Tensor):
@@ -125,11 +129,11 @@ class Interp:
         if s.flags & L.MI_CONV_ACCUM:
             res = res + yv[:, ys, xs, :].float()
         yv[:, ys, xs, :] = res.to(yv.dtype)
-        if s.stats.obj is not None:
-            st = self.raw(s.stats.obj).view(torch.float32)
-            st.zero_()
-            st[: s.CoutPad * 2].view(s.CoutPad, 2)[:Cout, 0] = res.sum((0, 1, 2))
-            st[: s.CoutPad * 2].view(s.CoutPad, 2)[:Cout, 1] = (res * res).sum((0, 1, 2))
+        if s.stats.obj is not None:   # fp64 accumulators [SLOTS][CoutPad][2]: the interpreter adds everything to slot 0
+            st = self.f64(s.stats, s.CoutPad * 2).view(s.CoutPad, 2)
+            stored = yv[:, ys, xs, :].float() if not (s.flags & L.MI_CONV_OUT_F32) else res
+            st[:Cout, 0] += stored.double().sum((0, 1, 2))
+            st[:Cout, 1] += (stored.double() ** 2).sum((0, 1, 2))
 
     def op_WGRAD(self, c):
         s = c.desc
@@ -147,25 +151,6 @@ class Interp:
             res[:, :, t] = torch.einsum("nhwo,nhwi->oi", dy, sl)[: s.Cout, : s.Cin]
         g.copy_(res.view(s.Cout, s.Cin, kk, kk))
 
-    def op_BN_FINALIZE(self, c):
-        ntiles, C, CPad = c.i[:3]
-        count = c.l[0]
-        part = self.f32(c.p[0], ntiles * CPad * 2).view(ntiles, CPad, 2).double().sum(0)[:C]
-        mean = part[:, 0] / count
-        var = (part[:, 1] / count - mean * mean).clamp(min=0)
-        invstd = 1.0 / torch.sqrt(var + c.f[0])
-        gamma, beta = c.p[1].obj.detach().double(), c.p[2].obj.detach().double()
-        self.f32(c.p[6], C).copy_((gamma * invstd).float())
-        self.f32(c.p[7], C).copy_((beta - mean * gamma * invstd).float())
-        self.f32(c.p[8], C).copy_(mean.float())
-        self.f32(c.p[9], C).copy_(invstd.float())
-        m = c.f[1]
-        rm, rv, nbt = c.p[3].obj, c.p[4].obj, c.p[5].obj
-        if rm is not None:
-            rm.mul_(1 - m).add_(m * mean.float())
-            rv.mul_(1 - m).add_(m * (var * count / max(count - 1, 1)).float())
-            nbt += 1
-
     def op_BN_EVAL_AFFINE(self, c):
         C = c.i[0]
         g, b, rm, rv = (c.p[k].obj.detach().float() for k in range(4))
@@ -174,9 +159,26 @@ class Interp:
         self.f32(c.p[5], C).copy_(b - rm * g * inv)
 
     def op_BN_ACT_FWD(self, c):
-        y, res, a = c.p[0].obj, c.p[3].obj, c.p[4].obj
+        y, res, a = c.p[0].obj, c.p[11].obj, c.p[12].obj
         C, act = c.i[3], c.i[4]
-        z = self.tv(y).float() * self.f32(c.p[1], C) + self.f32(c.p[2], C)
+        if c.p[1].obj is not None:   # train mode: finalize the statistics first
+            count = c.l[0]
+            part = self.f64(c.p[1], L.MI_BN_SLOTS * C * 2).view(L.MI_BN_SLOTS, C, 2).sum(0)
+            mean = part[:, 0] / count
+            var = (part[:, 1] / count - mean * mean).clamp(min=0)
+            invstd = 1.0 / torch.sqrt(var + c.f[0])
+            gamma, beta = c.p[2].obj.detach().double(), c.p[3].obj.detach().double()
+            self.f32(c.p[7], C).copy_((gamma * invstd).float())
+            self.f32(c.p[8], C).copy_((beta - mean * gamma * invstd).float())
+            self.f32(c.p[9], C).copy_(mean.float())
+            self.f32(c.p[10], C).copy_(invstd.float())
+            m = c.f[1]
+            rm, rv, nbt = c.p[4].obj, c.p[5].obj, c.p[6].obj
+            if rm is not None:
+                rm.mul_(1 - m).add_(m * mean.float())
+                rv.mul_(1 - m).add_(m * (var * count / max(count - 1, 1)).float())
+                nbt += 1
+        z = self.tv(y).float() * self.f32(c.p[7], C) + self.f32(c.p[8], C)
         o = z * torch.sigmoid(z) if act else z
         if res is not None:
             o = o + self.tv(res).float()
@@ -192,32 +194,27 @@ class Interp:
         return dz, xh
 
     def op_BN_BWD_REDUCE(self, c):
-        C, act, nblk = c.i[3], c.i[4], c.i[2]
+        C, act = c.i[3], c.i[4]
         dz, xh = self._dz(c, c.p[0].obj, c.p[1].obj, C, act)
-        part = self.f32(c.p[6], nblk * C * 2)
-        part.zero_()
-        part[: C * 2].view(C, 2)[:, 0] = dz.sum((0, 1, 2))
-        part[: C * 2].view(C, 2)[:, 1] = (dz * xh).sum((0, 1, 2))
-
-    def op_BN_BWD_FINALIZE(self, c):
-        nblk, C = c.i[:2]
-        count = c.l[0]
-        part = self.f32(c.p[0], nblk * C * 2).view(nblk, C, 2).double().sum(0)
-        if c.p[1].obj is not None:
-            c.p[1].obj.copy_(part[:, 1].float())
-        if c.p[2].obj is not None:
-            c.p[2].obj.copy_(part[:, 0].float())
-        self.f32(c.p[3], C).copy_((part[:, 0] / count).float())
-        self.f32(c.p[4], C).copy_((part[:, 1] / count).float())
+        part = self.f64(c.p[6], C * 2).view(C, 2)   # slot 0
+        part[:, 0] += dz.double().sum((0, 1, 2))
+        part[:, 1] += (dz * xh).double().sum((0, 1, 2))
 
     def op_BN_BWD_APPLY(self, c):
         C, act = c.i[5], c.i[6]
+        count = c.l[1]
         da = c.p[0].obj
         dz, xh = self._dz(c, da, c.p[1].obj, C, act)
+        part = self.f64(c.p[7], L.MI_BN_SLOTS * C * 2).view(L.MI_BN_SLOTS, C, 2).sum(0)
+        if c.p[8].obj is not None:
+            c.p[8].obj.copy_(part[:, 1].float())
+        if c.p[9].obj is not None:
+            c.p[9].obj.copy_(part[:, 0].float())
+        c1, c2 = (part[:, 0] / count).float(), (part[:, 1] / count).float()
         gamma = c.p[6].obj.detach().float()
-        dy = gamma * self.f32(c.p[5], C) * (dz - self.f32(c.p[7], C) - xh * self.f32(c.p[8], C))
-        self.tv(c.p[9].obj)[:] = dy.to(self.dt)
-        dres = c.p[10].obj
+        dy = gamma * self.f32(c.p[5], C) * (dz - c1 - xh * c2)
+        self.tv(c.p[10].obj)[:] = dy.to(self.dt)
+        dres = c.p[11].obj
         if dres is not None:
             v = self.tv(da).float()
             if c.i[4]:

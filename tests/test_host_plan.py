@@ -88,7 +88,7 @@ def test_gradient_fanin_flags_and_buffers():
     b = ps.builder
     tags = [c.tag for c in b.bwd]
     # the loss gradient comes first, the stem's weight gradient last; the image never gets a gradient
-    assert tags[0] == "loss.bwd" and "backbone.stem.conv" in tags[-1]
+    assert tags[0] == "bn_acc_zero.bwd" and tags[1] == "loss.bwd" and "backbone.stem.conv" in tags[-1]
     assert not any(t.startswith("backbone.stem.conv.dgrad") for t in tags)
     # stride-2 data gradients are 4 parity-class launches
     assert sum(t.startswith("backbone.dark3.0.dgrad") for t in tags) == 4

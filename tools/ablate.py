@@ -49,9 +49,9 @@ def timed(skip=()):
 plan.run("fwd"); plan.run("bwd"); torch.cuda.synchronize()
 base = timed()
 print(f"baseline fwd+bwd graph: {base:.3f} ms")
-classes = [("CONV",), ("WGRAD",), ("BN_FINALIZE",), ("BN_ACT_FWD",), ("BN_BWD_REDUCE",), ("BN_BWD_FINALIZE",),
+classes = [("CONV",), ("WGRAD",), ("BN_ACT_FWD",), ("BN_BWD_REDUCE",), 
            ("BN_BWD_APPLY",), ("PACK_W",), ("COLSUM",), ("SPLIT_DPREDS",), ("LOSS_FWD", "LOSS_BWD"), ("SPP_FWD", "SPP_BWD"),
-           ("BN_FINALIZE", "BN_BWD_FINALIZE", "PACK_W")]
+           ("WGRAD_GROUP",), ("MEMSET",)]
 for cl in classes:
     t = timed(cl)
     print(f"without {'+'.join(cl):40s}: {t:.3f} ms  (marginal {base - t:.3f})")

@@ -35,7 +35,7 @@ for which in ("fwd", "bwd"):
             var = []
             for (kc, bn, th, tw) in ((64, 128, 8, 16), (64, 64, 8, 16), (32, 128, 8, 16), (64, 64, 8, 8), (64, 128, 8, 8), (64, 32, 8, 16), (32, 64, 8, 16)):
                 d = L.mi_conv_desc.from_buffer_copy(d0); d.KC, d.BN, d.TH, d.TW = kc, bn, th, tw
-                d.stats_partial = None
+                d.stats_acc = None
                 try:
                     var.append(f"KC{kc}/BN{bn}/{th}x{tw}:{t(d):.1f}")
                 except Exception as e:

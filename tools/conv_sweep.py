@@ -27,7 +27,7 @@ for which in ("fwd", "bwd"):
     for k in range(n):
         if L.OPS[arr[k].op] != "CONV": continue
         d = plan.cmd_descs[which][k]
-        key = (d.H, d.W, d.K8 * 8, d.CoutPad, d.ntaps, d.in_stride, d.out_stride, bool(d.stats_partial), d.flags)
+        key = (d.H, d.W, d.K8 * 8, d.CoutPad, d.ntaps, d.in_stride, d.out_stride, bool(d.stats_acc), d.flags)
         seen.setdefault(key, []).append((which, k))
 ta = tb = 0.0
 for key, lst in sorted(seen.items(), key=lambda kv: -len(kv[1])):
@@ -36,7 +36,7 @@ for key, lst in sorted(seen.items(), key=lambda kv: -len(kv[1])):
     dd = L.mi_conv_desc.from_buffer_copy(d0); lib.mi_conv2d_plan(C.byref(dd))
     auto = t(d0)
     res = []
-    if d0.stats_partial:   # tile count changes the stats partial rows: only sweep KC/BN with the auto tile
+    if d0.stats_acc:   # tile count changes the stats partial rows: only sweep KC/BN with the auto tile
         tiles = [(dd.TH, dd.TW)]
     else:
         tiles = [(8, 16), (4, 32), (8, 8), (4, 16), (2, 32), (16, 8), (3, 40), (6, 20), (3, 20), (1, 64), (2, 64)]

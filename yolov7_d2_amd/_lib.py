@@ -7,11 +7,12 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355det.so")
+LIB_PATH = os.environ.get("MI355_LIB", os.path.join(_HERE, "libmi355det.so"))   # override: A/B testing of builds
 
 MI_MAX_TAPS = 9
 MI_CONV_ACCUM = 1
 MI_CONV_OUT_F32 = 2
+MI_BN_SLOTS = 16
 
 
 class MI355Error(RuntimeError):
@@ -21,7 +22,7 @@ class MI355Error(RuntimeError):
 class mi_conv_desc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p), ("bias", C.c_void_p),
-        ("stats_partial", C.c_void_p),
+        ("stats_acc", C.c_void_p),
         ("ldx", C.c_int32), ("ldy", C.c_int32), ("y_nstride", C.c_int32),
         ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
         ("outH", C.c_int32), ("outW", C.c_int32), ("gridH", C.c_int32), ("gridW", C.c_int32),
@@ -83,13 +84,13 @@ class mi_pack_job(C.Structure):
 
 
 class mi_cmd(C.Structure):
-    _fields_ = [("op", C.c_int32), ("i", C.c_int32 * 40), ("f", C.c_float * 8), ("p", C.c_void_p * 12),
+    _fields_ = [("op", C.c_int32), ("i", C.c_int32 * 40), ("f", C.c_float * 8), ("p", C.c_void_p * 16),
                 ("l", C.c_int64 * 4)]
 
 
 # opcode names must match the enum in include/mi355_det.h
-OPS = ["NOP", "CONV", "WGRAD", "PACK_W", "RESERVED4", "BN_FINALIZE", "BN_ACT_FWD", "BN_BWD_REDUCE",
-       "BN_BWD_FINALIZE", "BN_BWD_APPLY", "FOCUS", "UPSAMPLE_FWD", "UPSAMPLE_BWD", "SPP_FWD", "SPP_BWD", "COPY",
+OPS = ["NOP", "CONV", "WGRAD", "PACK_W", "RESERVED4", "RESERVED5", "BN_ACT_FWD", "BN_BWD_REDUCE",
+       "RESERVED8", "BN_BWD_APPLY", "FOCUS", "UPSAMPLE_FWD", "UPSAMPLE_BWD", "SPP_FWD", "SPP_BWD", "COPY",
        "COLSUM", "LOSS_FWD", "LOSS_BWD", "SPLIT_DPREDS", "MEMSET", "SGD", "BN_EVAL_AFFINE", "DECODE", "PACK_W_BATCH", "WGRAD_GROUP"]
 OP = {n: k for k, n in enumerate(OPS)}
 
@@ -105,12 +106,11 @@ _PROTOS = {
     "mi_conv2d_wgrad_group_run": (C.c_int, [C.POINTER(mi_wgrad_group), _vp, _vp]),
     "mi_pack_conv_weight": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
     "mi_conv2d_wgrad_plan": (C.c_int64, [C.POINTER(mi_wgrad_desc)]),
-    "mi_bn_finalize": (C.c_int, [_vp, _i, _i, _i, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_bn_eval_affine": (C.c_int, [_vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
-    "mi_bn_act_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i64, _i, _i, _vp]),
+    "mi_bn_act_fwd": (C.c_int, [_vp, _i, _vp, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i,
+                                _i64, _i, _i, _vp]),
     "mi_bn_act_bwd_reduce": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
-    "mi_bn_bwd_finalize": (C.c_int, [_vp, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp]),
-    "mi_bn_act_bwd_apply": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i,
+    "mi_bn_act_bwd_apply": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i, _vp, _i, _i,
                                       _i64, _i, _i, _vp]),
     "mi_focus_pack": (C.c_int, [_vp, _i, _i, _i, _vp, _i, _vp]),
     "mi_upsample2x_fwd": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -1,81 +1,22 @@
 // Train-mode BatchNorm + SiLU (+ residual add) around the conv kernels, NHWC bf16.
 // Replaces nn.BatchNorm2d / nn.SiLU of BaseConv (yolov7/modeling/backbone/layers/wrappers.py:76-80,
 // eps/momentum patched at yolov7/modeling/meta_arch/yolox.py:85-90) and the Bottleneck
-// shortcut add (wrappers.py:119-123).  Batch statistics come from the conv epilogue partials.
-// All kernels are pure HBM streams: 16-byte (8 x bf16) accesses, fp32 math.
+// shortcut add (wrappers.py:119-123).
+//
+// Three streaming kernels per layer and NO separate "finalize" launches:
+//   * the conv epilogue adds its per-tile (sum, sumsq) into fp64 accumulators acc[MI_BN_SLOTS][C][2]
+//     (hardware global_atomic_add_f64, slot = tile % MI_BN_SLOTS to spread same-address traffic);
+//   * bn_act_fwd reduces the slots in its prologue (every block, 2 x MI_BN_SLOTS loads per channel, fixed
+//     order), block 0 also publishes scale/shift/mean/invstd for the backward pass and updates the running
+//     statistics exactly as nn.BatchNorm2d does (momentum, unbiased running variance, num_batches_tracked);
+//   * bn_bwd_reduce accumulates (sum dz, sum dz*xhat) the same way and bn_bwd_apply finalizes in its prologue.
+// fp64 accumulation of fp32 tile sums makes the result independent of the atomic arrival order except in
+// astronomically rare rounding ties.  All kernels are HBM streams: 16-byte (8 x bf16) accesses, fp32 math.
 #include "common.h"
 
-// ------------------------------------------------------------------ forward statistics
-__device__ __forceinline__ void block_sum2_d(double& s1, double& s2) {
-  // 256-thread block reduction of two doubles (fixed order)
-  __shared__ double red[2 * 4];
-  s1 = wave_sum_d(s1);
-  s2 = wave_sum_d(s2);
-  const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
-    red[wave * 2 + 0] = s1;
-    red[wave * 2 + 1] = s2;
-  }
-  __syncthreads();
-  s1 = (red[0] + red[2]) + (red[4] + red[6]);
-  s2 = (red[1] + red[3]) + (red[5] + red[7]);
-}
+#define BN_MAXC 1024
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int ntiles, int C, int CPad,
-                                                         double inv_count, double unbias, const float* gamma,
-                                                         const float* beta, float eps, float momentum, float* rmean,
-                                                         float* rvar, int64_t* nbt, float* scale, float* shift,
-                                                         float* mean_o, float* invstd_o) {
-  const int c = blockIdx.x;
-  const int lane = threadIdx.x;
-  double s1 = 0.0, s2 = 0.0;
-  const f32x2* pp = (const f32x2*)partial + c;
-  int t = lane;
-  for (; t + 768 < ntiles; t += 1024) {  // 4 independent 8-byte loads in flight per thread
-    const f32x2 a = pp[(size_t)t * CPad], b = pp[(size_t)(t + 256) * CPad], cc = pp[(size_t)(t + 512) * CPad],
-                d = pp[(size_t)(t + 768) * CPad];
-    s1 += ((double)a[0] + (double)b[0]) + ((double)cc[0] + (double)d[0]);
-    s2 += ((double)a[1] + (double)b[1]) + ((double)cc[1] + (double)d[1]);
-  }
-  for (; t < ntiles; t += 256) {
-    const f32x2 a = pp[(size_t)t * CPad];
-    s1 += (double)a[0];
-    s2 += (double)a[1];
-  }
-  block_sum2_d(s1, s2);
-  if (lane == 0) {
-    const double mean = s1 * inv_count;
-    double var = s2 * inv_count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const double invstd = 1.0 / sqrt(var + (double)eps);
-    const float g = gamma[c], b = beta[c];
-    const float sc = (float)((double)g * invstd);
-    scale[c] = sc;
-    shift[c] = (float)((double)b - mean * (double)g * invstd);
-    mean_o[c] = (float)mean;
-    invstd_o[c] = (float)invstd;
-    if (rmean) {
-      rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
-      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var * unbias);
-    }
-    if (c == 0 && nbt) *nbt += 1;
-  }
-}
-
-extern "C" int mi_bn_finalize(const float* partial, int ntiles, int C, int CPad, int64_t count, const float* gamma,
-                              const float* beta, float eps, float momentum, float* running_mean, float* running_var,
-                              int64_t* num_batches_tracked, float* scale, float* shift, float* mean, float* invstd,
-                              mi_stream_t st) {
-  MI_REQUIRE(partial && gamma && beta && scale && shift && mean && invstd, "bn_finalize: null");
-  MI_REQUIRE(C > 0 && CPad >= C && ntiles > 0 && count > 0, "bn_finalize: sizes");
-  const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)st, partial, ntiles, C, CPad,
-                     1.0 / (double)count, unbias, gamma, beta, eps, momentum, running_mean, running_var,
-                     num_batches_tracked, scale, shift, mean, invstd);
-  MI_CHECK_LAUNCH("bn_finalize");
-  return MI_OK;
-}
-
+// ------------------------------------------------------------------ eval-mode affine
 __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
                                       float eps, int C, float* scale, float* shift) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -95,56 +36,127 @@ extern "C" int mi_bn_eval_affine(const float* gamma, const float* beta, const fl
   return MI_OK;
 }
 
-// ------------------------------------------------------------------ forward apply
+// ------------------------------------------------------------------ forward apply (+ statistics finalize)
+struct BnFwdK {
+  const __bf16* y;
+  const __bf16* res;
+  __bf16* a;
+  const double* acc;  // [MI_BN_SLOTS][C][2] or NULL (eval: scale/shift are inputs)
+  const float* gamma;
+  const float* beta;
+  float* rmean;
+  float* rvar;
+  int64_t* nbt;
+  float* scale;
+  float* shift;
+  float* mean;
+  float* invstd;
+  int ldy, ldres, lda, C8;
+  int64_t npix;
+  double inv_count, unbias;
+  float eps, momentum;
+};
+
 template <int ACT>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const __bf16* __restrict__ y, int ldy,
-                                                         const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, const __bf16* res, int ldres,
-                                                         __bf16* a, int lda, int64_t npix, int C8) {
-  const int64_t total = npix * C8;
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnFwdK p) {
+  __shared__ float s_sc[BN_MAXC], s_sh[BN_MAXC];
+  const int C = p.C8 * 8;
+  if (p.acc) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < MI_BN_SLOTS; ++k) {
+        s1 += p.acc[((size_t)k * C + c) * 2 + 0];
+        s2 += p.acc[((size_t)k * C + c) * 2 + 1];
+      }
+      const double mean = s1 * p.inv_count;
+      double var = s2 * p.inv_count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const double invstd = 1.0 / sqrt(var + (double)p.eps);
+      const float g = p.gamma[c], b = p.beta[c];
+      const float sc = (float)((double)g * invstd);
+      const float sh = (float)((double)b - mean * (double)g * invstd);
+      s_sc[c] = sc;
+      s_sh[c] = sh;
+      if (blockIdx.x == 0) {
+        p.scale[c] = sc;
+        p.shift[c] = sh;
+        p.mean[c] = (float)mean;
+        p.invstd[c] = (float)invstd;
+        if (p.rmean) {
+          p.rmean[c] = (1.f - p.momentum) * p.rmean[c] + p.momentum * (float)mean;
+          p.rvar[c] = (1.f - p.momentum) * p.rvar[c] + p.momentum * (float)(var * p.unbias);
+        }
+        if (c == 0 && p.nbt) *p.nbt += 1;
+      }
+    }
+  } else {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      s_sc[c] = p.scale[c];
+      s_sh[c] = p.shift[c];
+    }
+  }
+  __syncthreads();
+  const int C8 = p.C8;
+  const int64_t total = p.npix * C8;
+  // (gridDim.x * 256) % C8 == 0, so a thread keeps its channel group: hoist its 8 scale/shift pairs
+  const int c8 = (int)((blockIdx.x * 256LL + threadIdx.x) % C8);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = s_sc[c8 * 8 + e];
+    sh[e] = s_sh[c8 * 8 + e];
+  }
   for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
     const int64_t pix = idx / C8;
-    const int c8 = (int)(idx - pix * C8);
-    const bf16x8 v = *(const bf16x8*)(y + pix * ldy + c8 * 8);
-    float f[8], o[8];
-    unpack8(v, f);
-    const f32x4 sc0 = *(const f32x4*)(scale + c8 * 8), sc1 = *(const f32x4*)(scale + c8 * 8 + 4);
-    const f32x4 sh0 = *(const f32x4*)(shift + c8 * 8), sh1 = *(const f32x4*)(shift + c8 * 8 + 4);
+    const bf16x8 v = *(const bf16x8*)(p.y + pix * p.ldy + c8 * 8);
+    float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float sc = e < 4 ? sc0[e] : sc1[e - 4];
-      const float sh = e < 4 ? sh0[e] : sh1[e - 4];
-      const float z = f[e] * sc + sh;
+      const float z = (float)v[e] * sc[e] + sh[e];
       o[e] = ACT ? z * sigmoidf_(z) : z;
     }
-    if (res) {
-      const bf16x8 r = *(const bf16x8*)(res + pix * ldres + c8 * 8);
+    if (p.res) {
+      const bf16x8 r = *(const bf16x8*)(p.res + pix * p.ldres + c8 * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] += (float)r[e];
     }
-    *(bf16x8*)(a + pix * lda + c8 * 8) = pack8(o);
+    *(bf16x8*)(p.a + pix * p.lda + c8 * 8) = pack8(o);
   }
 }
 
+// every block pays the statistics prologue (2 x MI_BN_SLOTS fp64 loads + an fp64 rsqrt per channel): give each thread
+// ~8 grid-stride iterations so that it amortises, and never more than 4 blocks per CU
 static int ew_blocks(int64_t total) {
-  int64_t b = (total + 255) / 256;
-  if (b > 4096) b = 4096;
+  int64_t b = (total + 2047) / 2048;
+  if (b > 1024) b = 1024;
   if (b < 1) b = 1;
   return (int)b;
 }
 
-extern "C" int mi_bn_act_fwd(const void* y, int ldy, const float* scale, const float* shift, const void* res,
-                             int ldres, void* a, int lda, int64_t npix, int C, int act, mi_stream_t st) {
+extern "C" int mi_bn_act_fwd(const void* y, int ldy, const double* stats_acc, int64_t count, const float* gamma,
+                             const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                             int64_t* num_batches_tracked, float* scale, float* shift, float* mean, float* invstd,
+                             const void* res, int ldres, void* a, int lda, int64_t npix, int C, int act,
+                             mi_stream_t st) {
   MI_REQUIRE(y && scale && shift && a, "bn_act_fwd: null");
-  MI_REQUIRE(C % 8 == 0 && ldy % 8 == 0 && lda % 8 == 0 && (!res || ldres % 8 == 0), "bn_act_fwd: C/ld %% 8");
+  MI_REQUIRE(!stats_acc || (gamma && beta && mean && invstd && count > 0), "bn_act_fwd: train mode needs gamma/beta/mean/invstd");
+  MI_REQUIRE(C % 8 == 0 && C <= BN_MAXC && (256 % (C / 8)) == 0, "bn_act_fwd: C %d (need C<=%d, 256 %% (C/8) == 0)", C,
+             BN_MAXC);
+  MI_REQUIRE(ldy % 8 == 0 && lda % 8 == 0 && (!res || ldres % 8 == 0), "bn_act_fwd: ld %% 8");
   MI_REQUIRE(((uintptr_t)y % 16) == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)res % 16) == 0, "bn_act_fwd: align");
+  BnFwdK k;
+  k.y = (const __bf16*)y; k.res = (const __bf16*)res; k.a = (__bf16*)a; k.acc = stats_acc; k.gamma = gamma;
+  k.beta = beta; k.rmean = running_mean; k.rvar = running_var; k.nbt = num_batches_tracked; k.scale = scale;
+  k.shift = shift; k.mean = mean; k.invstd = invstd; k.ldy = ldy; k.ldres = ldres; k.lda = lda; k.C8 = C / 8;
+  k.npix = npix; k.inv_count = count > 0 ? 1.0 / (double)count : 0.0;
+  k.unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
+  k.eps = eps; k.momentum = momentum;
   const int64_t total = npix * (C / 8);
   if (act)
-    hipLaunchKernelGGL(bn_act_fwd_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)st, (const __bf16*)y,
-                       ldy, scale, shift, (const __bf16*)res, ldres, (__bf16*)a, lda, npix, C / 8);
+    hipLaunchKernelGGL(bn_act_fwd_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)st, k);
   else
-    hipLaunchKernelGGL(bn_act_fwd_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)st, (const __bf16*)y,
-                       ldy, scale, shift, (const __bf16*)res, ldres, (__bf16*)a, lda, npix, C / 8);
+    hipLaunchKernelGGL(bn_act_fwd_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)st, k);
   MI_CHECK_LAUNCH("bn_act_fwd");
   return MI_OK;
 }
@@ -157,15 +169,15 @@ __device__ __forceinline__ float act_grad(float z, int act) {
   return s * (1.f + z * (1.f - s));
 }
 
-// pass 1: block partial sums of (dz, dz*xhat) per channel.  256 % C8 == 0 so a thread's channel
-// group is fixed (c8 = tid % C8) and its pixel lane is tid / C8.
+// pass 1: per-channel sums of (dz, dz*xhat) -> fp64 accumulators dacc[MI_BN_SLOTS][C][2].  256 % C8 == 0 so a
+// thread's channel group is fixed (c8 = tid % C8) and its pixel lane is tid / C8.
 template <int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const __bf16* __restrict__ da, int ldda,
                                                             const __bf16* __restrict__ y, int ldy,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, float* partial,
+                                                            const float* __restrict__ invstd, double* dacc,
                                                             int64_t npix, int C8) {
   __shared__ float red[256 * 16];
   const int tid = threadIdx.x;
@@ -198,99 +210,103 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const __bf16* __rest
     red[(pl * C8 + c8) * 16 + 8 + e] = s2[e];
   }
   __syncthreads();
-  const int nout = C8 * 16;
+  const int nout = C8 * 16, C = C8 * 8;
+  double* slot = dacc + (size_t)(blockIdx.x % MI_BN_SLOTS) * C * 2;
   for (int j = tid; j < nout; j += 256) {
     float acc = 0.f;
     for (int q = 0; q < PL; ++q) acc += red[q * nout + j];
     const int cc8 = j / 16, v = j % 16;
     const int c = cc8 * 8 + (v & 7), which = v >> 3;
-    partial[((size_t)blockIdx.x * (C8 * 8) + c) * 2 + which] = acc;
+    atomicAdd(slot + c * 2 + which, (double)acc);
   }
 }
 
 extern "C" int mi_bn_act_bwd_reduce(const void* da, int ldda, const void* y, int ldy, const float* scale,
-                                    const float* shift, const float* mean, const float* invstd, float* partial,
+                                    const float* shift, const float* mean, const float* invstd, double* dacc,
                                     int nblk, int64_t npix, int C, int act, mi_stream_t st) {
-  MI_REQUIRE(da && y && scale && shift && mean && invstd && partial, "bn_bwd_reduce: null");
-  MI_REQUIRE(C % 8 == 0 && C <= 2048 && (256 % (C / 8)) == 0, "bn_bwd_reduce: C %d (need 256 %% (C/8) == 0)", C);
+  MI_REQUIRE(da && y && scale && shift && mean && invstd && dacc, "bn_bwd_reduce: null");
+  MI_REQUIRE(C % 8 == 0 && C <= BN_MAXC && (256 % (C / 8)) == 0, "bn_bwd_reduce: C %d (need 256 %% (C/8) == 0)", C);
   MI_REQUIRE(ldda % 8 == 0 && ldy % 8 == 0 && nblk > 0, "bn_bwd_reduce: ld");
   if (act)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(nblk), dim3(256), 0, (hipStream_t)st, (const __bf16*)da, ldda,
-                       (const __bf16*)y, ldy, scale, shift, mean, invstd, partial, npix, C / 8);
+                       (const __bf16*)y, ldy, scale, shift, mean, invstd, dacc, npix, C / 8);
   else
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, dim3(nblk), dim3(256), 0, (hipStream_t)st, (const __bf16*)da, ldda,
-                       (const __bf16*)y, ldy, scale, shift, mean, invstd, partial, npix, C / 8);
+                       (const __bf16*)y, ldy, scale, shift, mean, invstd, dacc, npix, C / 8);
   MI_CHECK_LAUNCH("bn_bwd_reduce");
   return MI_OK;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
-                                                             double inv_count, float* dgamma, float* dbeta, float* c1,
-                                                             float* c2) {
-  const int c = blockIdx.x, lane = threadIdx.x;
-  double s1 = 0.0, s2 = 0.0;
-  const f32x2* pp = (const f32x2*)partial + c;
-  int t = lane;
-  for (; t + 768 < nblk; t += 1024) {
-    const f32x2 a = pp[(size_t)t * C], b = pp[(size_t)(t + 256) * C], cc = pp[(size_t)(t + 512) * C],
-                d = pp[(size_t)(t + 768) * C];
-    s1 += ((double)a[0] + (double)b[0]) + ((double)cc[0] + (double)d[0]);
-    s2 += ((double)a[1] + (double)b[1]) + ((double)cc[1] + (double)d[1]);
-  }
-  for (; t < nblk; t += 256) {
-    const f32x2 a = pp[(size_t)t * C];
-    s1 += (double)a[0];
-    s2 += (double)a[1];
-  }
-  block_sum2_d(s1, s2);
-  if (lane == 0) {
-    if (dbeta) dbeta[c] = (float)s1;
-    if (dgamma) dgamma[c] = (float)s2;
-    c1[c] = (float)(s1 * inv_count);
-    c2[c] = (float)(s2 * inv_count);
-  }
-}
-
-extern "C" int mi_bn_bwd_finalize(const float* partial, int nblk, int C, int64_t count, float* dgamma, float* dbeta,
-                                  float* c1, float* c2, mi_stream_t st) {
-  MI_REQUIRE(partial && c1 && c2 && nblk > 0 && C > 0 && count > 0, "bn_bwd_finalize: args");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)st, partial, nblk, C,
-                     1.0 / (double)count, dgamma, dbeta, c1, c2);
-  MI_CHECK_LAUNCH("bn_bwd_finalize");
-  return MI_OK;
-}
+// pass 2: dy = gamma*invstd*(dz - c1 - xhat*c2) with c1 = sum(dz)/count, c2 = sum(dz*xhat)/count taken from the
+// accumulators in the prologue; block 0 also writes dgamma = sum(dz*xhat), dbeta = sum(dz).  optional dres (+)= da.
+struct BnBwdK {
+  const __bf16* da;
+  const __bf16* y;
+  __bf16* dy;
+  __bf16* dres;
+  const double* dacc;
+  const float* scale;
+  const float* shift;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  float* dgamma;
+  float* dbeta;
+  int ldda, ldy, lddy, lddres, dres_accum, C8;
+  int64_t npix;
+  double inv_count;
+};
 
 template <int ACT>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const __bf16* __restrict__ da, int ldda,
-                                                           const __bf16* __restrict__ y, int ldy,
-                                                           const float* __restrict__ scale,
-                                                           const float* __restrict__ shift,
-                                                           const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd,
-                                                           const float* __restrict__ gamma,
-                                                           const float* __restrict__ c1, const float* __restrict__ c2,
-                                                           __bf16* dy, int lddy, __bf16* dres, int lddres,
-                                                           int dres_accum, int64_t npix, int C8) {
-  const int64_t total = npix * C8;
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK p) {
+  __shared__ float s_c1[BN_MAXC], s_c2[BN_MAXC];
+  const int C8 = p.C8, C = C8 * 8;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < MI_BN_SLOTS; ++k) {
+      s1 += p.dacc[((size_t)k * C + c) * 2 + 0];
+      s2 += p.dacc[((size_t)k * C + c) * 2 + 1];
+    }
+    s_c1[c] = (float)(s1 * p.inv_count);
+    s_c2[c] = (float)(s2 * p.inv_count);
+    if (blockIdx.x == 0) {
+      if (p.dbeta) p.dbeta[c] = (float)s1;
+      if (p.dgamma) p.dgamma[c] = (float)s2;
+    }
+  }
+  __syncthreads();
+  const int64_t total = p.npix * C8;
+  const int c8 = (int)((blockIdx.x * 256LL + threadIdx.x) % C8);
+  float sc[8], sh[8], mu[8], is[8], gi[8], k1[8], k2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c8 * 8 + e;
+    sc[e] = p.scale[c];
+    sh[e] = p.shift[c];
+    mu[e] = p.mean[c];
+    is[e] = p.invstd[c];
+    gi[e] = p.gamma[c] * is[e];
+    k1[e] = s_c1[c];
+    k2[e] = s_c2[c];
+  }
   for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
     const int64_t pix = idx / C8;
-    const int c8 = (int)(idx - pix * C8);
-    const bf16x8 dv = *(const bf16x8*)(da + pix * ldda + c8 * 8);
-    const bf16x8 yv = *(const bf16x8*)(y + pix * ldy + c8 * 8);
+    const bf16x8 dv = *(const bf16x8*)(p.da + pix * p.ldda + c8 * 8);
+    const bf16x8 yv = *(const bf16x8*)(p.y + pix * p.ldy + c8 * 8);
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int c = c8 * 8 + e;
       const float yy = (float)yv[e];
-      const float z = yy * scale[c] + shift[c];
+      const float z = yy * sc[e] + sh[e];
       const float dz = (float)dv[e] * act_grad(z, ACT);
-      const float xh = (yy - mean[c]) * invstd[c];
-      o[e] = gamma[c] * invstd[c] * (dz - c1[c] - xh * c2[c]);
+      const float xh = (yy - mu[e]) * is[e];
+      o[e] = gi[e] * (dz - k1[e] - xh * k2[e]);
     }
-    *(bf16x8*)(dy + pix * lddy + c8 * 8) = pack8(o);
-    if (dres) {
-      __bf16* rp = dres + pix * lddres + c8 * 8;
-      if (dres_accum) {
+    *(bf16x8*)(p.dy + pix * p.lddy + c8 * 8) = pack8(o);
+    if (p.dres) {
+      __bf16* rp = p.dres + pix * p.lddres + c8 * 8;
+      if (p.dres_accum) {
         const bf16x8 r = *(const bf16x8*)rp;
         float q[8];
 #pragma unroll
@@ -305,20 +321,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const __bf16* __restr
 
 extern "C" int mi_bn_act_bwd_apply(const void* da, int ldda, const void* y, int ldy, const float* scale,
                                    const float* shift, const float* mean, const float* invstd, const float* gamma,
-                                   const float* c1, const float* c2, void* dy, int lddy, void* dres, int lddres,
-                                   int dres_accum, int64_t npix, int C, int act, mi_stream_t st) {
-  MI_REQUIRE(da && y && scale && shift && mean && invstd && gamma && c1 && c2 && dy, "bn_bwd_apply: null");
-  MI_REQUIRE(C % 8 == 0 && ldda % 8 == 0 && ldy % 8 == 0 && lddy % 8 == 0 && (!dres || lddres % 8 == 0),
-             "bn_bwd_apply: C/ld");
+                                   const double* dacc, int64_t count, float* dgamma, float* dbeta, void* dy, int lddy,
+                                   void* dres, int lddres, int dres_accum, int64_t npix, int C, int act,
+                                   mi_stream_t st) {
+  MI_REQUIRE(da && y && scale && shift && mean && invstd && gamma && dacc && dy && count > 0, "bn_bwd_apply: null");
+  MI_REQUIRE(C % 8 == 0 && C <= BN_MAXC && (256 % (C / 8)) == 0, "bn_bwd_apply: C %d", C);
+  MI_REQUIRE(ldda % 8 == 0 && ldy % 8 == 0 && lddy % 8 == 0 && (!dres || lddres % 8 == 0), "bn_bwd_apply: ld");
+  BnBwdK k;
+  k.da = (const __bf16*)da; k.y = (const __bf16*)y; k.dy = (__bf16*)dy; k.dres = (__bf16*)dres; k.dacc = dacc;
+  k.scale = scale; k.shift = shift; k.mean = mean; k.invstd = invstd; k.gamma = gamma; k.dgamma = dgamma;
+  k.dbeta = dbeta; k.ldda = ldda; k.ldy = ldy; k.lddy = lddy; k.lddres = lddres; k.dres_accum = dres_accum;
+  k.C8 = C / 8; k.npix = npix; k.inv_count = 1.0 / (double)count;
   const int64_t total = npix * (C / 8);
   if (act)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)st,
-                       (const __bf16*)da, ldda, (const __bf16*)y, ldy, scale, shift, mean, invstd, gamma, c1, c2,
-                       (__bf16*)dy, lddy, (__bf16*)dres, lddres, dres_accum, npix, C / 8);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)st, k);
   else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)st,
-                       (const __bf16*)da, ldda, (const __bf16*)y, ldy, scale, shift, mean, invstd, gamma, c1, c2,
-                       (__bf16*)dy, lddy, (__bf16*)dres, lddres, dres_accum, npix, C / 8);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)st, k);
   MI_CHECK_LAUNCH("bn_bwd_apply");
   return MI_OK;
 }

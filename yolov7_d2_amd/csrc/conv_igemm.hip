@@ -27,7 +27,7 @@ struct ConvK {
   const u32x4* w;
   void* y;
   const float* bias;
-  float* stats;
+  double* stats;  // [MI_BN_SLOTS][CoutPad][2] fp64 accumulators
   int ldx, ldy, N, H, W, outH, outW, gridH, gridW, is, os, ooy, oox, K8, Cout, CoutPad, ntaps;
   long long ynstride;
   int toff[MI_MAX_TAPS], tw[MI_MAX_TAPS];
@@ -254,9 +254,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvK 
           a1 += Rs[(q * BN + tid) * 2 + 0];
           a2 += Rs[(q * BN + tid) * 2 + 1];
         }
-        float* sp = p.stats + ((size_t)tile * p.CoutPad + co0 + tid) * 2;
-        sp[0] = a1;
-        sp[1] = a2;
+        double* sp = p.stats + ((size_t)(tile % MI_BN_SLOTS) * p.CoutPad + co0 + tid) * 2;
+        atomicAdd(sp, (double)a1);
+        atomicAdd(sp + 1, (double)a2);
       }
     }
     return;
@@ -347,9 +347,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvK 
         a1 += Ss[(w * BN + tid) * 2 + 0];
         a2 += Ss[(w * BN + tid) * 2 + 1];
       }
-      float* sp = p.stats + ((size_t)tile * p.CoutPad + co0 + tid) * 2;
-      sp[0] = a1;
-      sp[1] = a2;
+      double* sp = p.stats + ((size_t)(tile % MI_BN_SLOTS) * p.CoutPad + co0 + tid) * 2;
+      atomicAdd(sp, (double)a1);
+      atomicAdd(sp + 1, (double)a2);
     }
   }
 }
@@ -399,7 +399,7 @@ static int conv_fill(const mi_conv_desc* d, ConvK* k, ConvCfg* c, size_t* ldsByt
   k->w = (const u32x4*)d->w;
   k->y = d->y;
   k->bias = d->bias;
-  k->stats = d->stats_partial;
+  k->stats = d->stats_acc;
   k->ynstride = d->y_nstride > 0 ? (long long)d->y_nstride : (long long)d->outH * d->outW * d->ldy;
   k->ldx = d->ldx; k->ldy = d->ldy; k->N = d->N; k->H = d->H; k->W = d->W;
   k->outH = d->outH; k->outW = d->outW; k->gridH = d->gridH; k->gridW = d->gridW;

@@ -27,23 +27,17 @@ static int run_one(const mi_cmd& c, hipStream_t s) {
     case MI_OP_WGRAD: return mi_conv2d_wgrad((const mi_wgrad_desc*)p[0], st);
     case MI_OP_PACK_W:
       return mi_pack_conv_weight((const float*)p[0], i[0], i[1], i[2], i[3], p[1], i[4], i[5], p[2], i[6], i[7], st);
-    case MI_OP_BN_FINALIZE:
-      return mi_bn_finalize((const float*)p[0], i[0], i[1], i[2], c.l[0], (const float*)p[1], (const float*)p[2],
-                            c.f[0], c.f[1], (float*)p[3], (float*)p[4], (int64_t*)p[5], (float*)p[6], (float*)p[7],
-                            (float*)p[8], (float*)p[9], st);
     case MI_OP_BN_ACT_FWD:
-      return mi_bn_act_fwd(p[0], i[0], (const float*)p[1], (const float*)p[2], p[3], i[1], p[4], i[2], c.l[0], i[3],
-                           i[4], st);
+      return mi_bn_act_fwd(p[0], i[0], (const double*)p[1], c.l[0], (const float*)p[2], (const float*)p[3], c.f[0],
+                           c.f[1], (float*)p[4], (float*)p[5], (int64_t*)p[6], (float*)p[7], (float*)p[8],
+                           (float*)p[9], (float*)p[10], p[11], i[1], p[12], i[2], c.l[1], i[3], i[4], st);
     case MI_OP_BN_BWD_REDUCE:
       return mi_bn_act_bwd_reduce(p[0], i[0], p[1], i[1], (const float*)p[2], (const float*)p[3], (const float*)p[4],
-                                  (const float*)p[5], (float*)p[6], i[2], c.l[0], i[3], i[4], st);
-    case MI_OP_BN_BWD_FINALIZE:
-      return mi_bn_bwd_finalize((const float*)p[0], i[0], i[1], c.l[0], (float*)p[1], (float*)p[2], (float*)p[3],
-                                (float*)p[4], st);
+                                  (const float*)p[5], (double*)p[6], i[2], c.l[0], i[3], i[4], st);
     case MI_OP_BN_BWD_APPLY:
       return mi_bn_act_bwd_apply(p[0], i[0], p[1], i[1], (const float*)p[2], (const float*)p[3], (const float*)p[4],
-                                 (const float*)p[5], (const float*)p[6], (const float*)p[7], (const float*)p[8], p[9],
-                                 i[2], p[10], i[3], i[4], c.l[0], i[5], i[6], st);
+                                 (const float*)p[5], (const float*)p[6], (const double*)p[7], c.l[1], (float*)p[8],
+                                 (float*)p[9], p[10], i[2], p[11], i[3], i[4], c.l[0], i[5], i[6], st);
     case MI_OP_FOCUS: return mi_focus_pack((const float*)p[0], i[0], i[1], i[2], p[1], i[3], st);
     case MI_OP_UPSAMPLE_FWD: return mi_upsample2x_fwd(p[0], i[0], p[1], i[1], i[2], i[3], i[4], i[5], st);
     case MI_OP_UPSAMPLE_BWD: return mi_upsample2x_bwd(p[0], i[0], p[1], i[1], i[2], i[3], i[4], i[5], i[6], st);

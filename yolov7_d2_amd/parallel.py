@@ -36,8 +36,8 @@ def grad_write_ranges(plan, grad_tensor):
         elif c.op == L.OP["WGRAD_GROUP"]:
             for d in plan.wgrad_descs:
                 ptrs.append((d.gw, d.ntaps * d.Cout * d.Cin * 4))
-        elif c.op == L.OP["BN_BWD_FINALIZE"]:
-            ptrs += [(c.p[1], c.i[1] * 4), (c.p[2], c.i[1] * 4)]
+        elif c.op == L.OP["BN_BWD_APPLY"]:
+            ptrs += [(c.p[8], c.i[5] * 4), (c.p[9], c.i[5] * 4)]
         elif c.op == L.OP["COLSUM"]:
             ptrs.append((c.p[1], c.i[1] * 4))
         elif c.op == L.OP["MEMSET"]:

@@ -125,6 +125,19 @@ class PlanBuilder:
     def small(self, name, nbytes, zero=False):
         return self._new_buf(name, nbytes, zero)
 
+    def bn_acc(self, which, C):
+        """fp64 BatchNorm accumulators [MI_BN_SLOTS][C][2] inside ONE contiguous region per direction, zeroed by a
+        single MEMSET at the start of the forward / backward command list"""
+        key = "bn_acc_" + which
+        b = self.shared.get(key)
+        if b is None:
+            b = Buf("scratch." + key, 0)
+            self.shared[key] = b
+            self.bufs.append(b)
+        off = b.nbytes
+        b.nbytes += L.MI_BN_SLOTS * C * 2 * 8
+        return _Ptr(b, off)
+
     def scratch(self, key, nbytes):
         """shared scratch (max size over requests); valid only between adjacent commands of one layer"""
         b = self.shared.get(key)
@@ -190,7 +203,7 @@ class PlanBuilder:
                  out_oy=0, out_ox=0, gridH=None, gridW=None, bias=None, stats=None, flags=0, y_nstride=0,
                  inH=None, inW=None):
         spec = ConvSpec(x=_Ptr(x), w=_Ptr(w_img), y=y_ptr if isinstance(y_ptr, _Ptr) else _Ptr(y_ptr),
-                        bias=_Ptr(bias), stats=_Ptr(stats), ldx=x.ld, ldy=ldy, y_nstride=y_nstride, N=x.N,
+                        bias=_Ptr(bias), stats=stats if isinstance(stats, _Ptr) else _Ptr(stats), ldx=x.ld, ldy=ldy, y_nstride=y_nstride, N=x.N,
                         H=x.H if inH is None else inH, W=x.W if inW is None else inW, outH=outH, outW=outW,
                         gridH=outH if gridH is None else gridH, gridW=outW if gridW is None else gridW,
                         in_stride=in_stride, out_stride=out_stride, out_oy=out_oy, out_ox=out_ox, K8=K8, Cout=Cout,
@@ -243,42 +256,38 @@ class PlanBuilder:
         if self.bn_train:
             mean = self.small(tag + ".mean", Cout * 4)
             invstd = self.small(tag + ".invstd", Cout * 4)
-            ntiles = self.plan_conv_tiles(x, Ho, Wo, CinPad // 8, Cout, taps, stride)
-            part = self.scratch("bn_partial", ntiles * Cout * 2 * 4)
+            acc = self.bn_acc("fwd", Cout)
             self.conv_cmd(tag + ".conv", x, wf, CinPad // 8, y, y.ld, Ho, Wo, Cout, Cout, taps, in_stride=stride,
-                          stats=part)
-            self.emit("BN_FINALIZE", i=[ntiles, Cout, Cout], l=[count], f=[bn["eps"], bn["momentum"]],
-                      p=[part, bn["gamma"], bn["beta"], bn["rm"], bn["rv"], bn["nbt"], scale, shift, mean, invstd],
-                      tag=tag + ".bnfin")
+                          stats=acc)
+            self.emit("BN_ACT_FWD", i=[y.ld, res.ld if res is not None else 0, out.ld, Cout, act], l=[count, count],
+                      f=[bn["eps"], bn["momentum"]],
+                      p=[y, acc, bn["gamma"], bn["beta"], bn["rm"], bn["rv"], bn["nbt"], scale, shift, mean, invstd, res,
+                         out], tag=tag + ".bnact")
         else:
             self.conv_cmd(tag + ".conv", x, wf, CinPad // 8, y, y.ld, Ho, Wo, Cout, Cout, taps, in_stride=stride)
             self.emit("BN_EVAL_AFFINE", i=[Cout], f=[bn["eps"]],
                       p=[bn["gamma"], bn["beta"], bn["rm"], bn["rv"], scale, shift], tag=tag + ".bnaff")
-        self.emit("BN_ACT_FWD", i=[y.ld, res.ld if res is not None else 0, out.ld, Cout, act], l=[count],
-                  p=[y, scale, shift, res, out], tag=tag + ".bnact")
+            self.emit("BN_ACT_FWD", i=[y.ld, res.ld if res is not None else 0, out.ld, Cout, act], l=[0, count],
+                      p=[y, None, None, None, None, None, None, scale, shift, None, None, res, out], tag=tag + ".bnact")
 
         def bwd():
             da = out.grad
             assert self.grad_ready(out), f"{tag}: output gradient never written"
             C8 = Cout // 8
             nblk = max(1, min(1024, math.ceil(count / (256 // C8) / 4)))
-            part2 = self.scratch("bn_bwd_partial", nblk * Cout * 2 * 4)
-            c1 = self.scratch("bn_c1", Cout * 4)
-            c2 = self.scratch("bn_c2", Cout * 4)
+            dacc = self.bn_acc("bwd", Cout)
             dy = (self._new_buf(tag + ".dy", count * Cout * 2) if self.group_wgrad
                   else self.scratch("dy", count * Cout * 2))
             dyT = TRef(dy, x.N, Ho, Wo, Cout, Cout)
             self.emit("BN_BWD_REDUCE", i=[da.ld, y.ld, nblk, Cout, act], l=[count],
-                      p=[da, y, scale, shift, mean, invstd, part2], tag=tag + ".bnred")
-            self.emit("BN_BWD_FINALIZE", i=[nblk, Cout], l=[count], p=[part2, bn["ggamma"], bn["gbeta"], c1, c2],
-                      tag=tag + ".bnbfin")
+                      p=[da, y, scale, shift, mean, invstd, dacc], tag=tag + ".bnred")
             dres, dres_acc = None, 0
             if res is not None and res.requires_grad:
                 dres = res.grad
                 dres_acc = self.grad_mode(res)
             self.emit("BN_BWD_APPLY", i=[da.ld, y.ld, Cout, dres.ld if dres is not None else 0, dres_acc, Cout, act],
-                      l=[count], p=[da, y, scale, shift, mean, invstd, bn["gamma"], c1, c2, dyT, dres],
-                      tag=tag + ".bnapply")
+                      l=[count, count], p=[da, y, scale, shift, mean, invstd, bn["gamma"], dacc, bn["ggamma"], bn["gbeta"],
+                                           dyT, dres], tag=tag + ".bnapply")
             self.wgrad_cmds(tag, x, dyT, CinPad, Cout, Cin, Cout, k, stride, pad, wgrad)
             if need_dgrad:
                 self.dgrad_cmds(tag, dyT, wd, Cout // 8, x, Cin, CinPadN, k, stride, pad)
@@ -413,6 +422,12 @@ class PlanBuilder:
             fn()
         self._emitting_bwd = False
         self.bwd_gens = []
+        for which, lst in (("fwd", self.fwd), ("bwd", self.bwd)):
+            b = self.shared.get("bn_acc_" + which)
+            if b is not None and b.nbytes:
+                nb = b.nbytes
+                b.nbytes = _rup(nb, 256)
+                lst.insert(0, _Cmd(L.OP["MEMSET"], i=[0], l=[nb], p=[_Ptr(b)], tag="bn_acc_zero." + which))
         wg = [c for c in self.bwd if c.op == L.OP["WGRAD"]]
         if self.group_wgrad and len(wg) >= 2:
             descs = (L.mi_wgrad_desc * len(wg))()
@@ -493,7 +508,7 @@ class Plan:
         if kind == "conv":
             d = L.mi_conv_desc()
             d.x, d.w, d.y = spec.x.resolve(), spec.w.resolve(), spec.y.resolve()
-            d.bias, d.stats_partial = spec.bias.resolve(), spec.stats.resolve()
+            d.bias, d.stats_acc = spec.bias.resolve(), spec.stats.resolve()
             for k in ("ldx", "ldy", "y_nstride", "N", "H", "W", "outH", "outW", "gridH", "gridW", "in_stride",
                       "out_stride", "out_oy", "out_ox", "K8", "Cout", "CoutPad", "flags"):
                 setattr(d, k, int(getattr(spec, k)))
