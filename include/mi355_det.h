@@ -52,14 +52,16 @@ const char* mi_last_error(void);
 #define MI_CONV_ACCUM 1    /* y += result (gradient fan-in)                  */
 #define MI_CONV_OUT_F32 2  /* y is fp32 (prediction maps), else bf16         */
 #define MI_MAX_TAPS 9
-#define MI_BN_SLOTS 16     /* accumulator slots per channel (slot = pixel tile % MI_BN_SLOTS) */
+#define MI_BN_SLOTS 16     /* max accumulator slots per channel (slot = pixel tile % nslots); callers pick
+                              nslots per layer: more slots = less same-address atomic traffic in the conv
+                              epilogue, fewer = a shorter statistics prologue in the BN kernels */
 
 typedef struct mi_conv_desc {
   const void* x;   /* bf16 NHWC input view, >= K8*8 channels readable        */
   const void* w;   /* packed bf16 [n_wslabs][K8][CoutPad][8]                  */
   void* y;         /* output view                                             */
   const float* bias;    /* [Cout] or NULL                                     */
-  double* stats_acc;    /* [MI_BN_SLOTS][CoutPad][2] fp64 (sum, sumsq) accumulators, atomically added
+  double* stats_acc;    /* [stats_slots][CoutPad][2] fp64 (sum, sumsq) accumulators, atomically added
                            (caller zeroes them once per step), or NULL             */
   int32_t ldx, ldy;
   int32_t y_nstride;        /* elements between images of y; 0 => outH*outW*ldy */
@@ -75,6 +77,8 @@ typedef struct mi_conv_desc {
   int32_t flags;
   int32_t TH, TW;           /* pixel tile; 0 => chosen by the launcher        */
   int32_t KC, BN;           /* k-chunk / cout tile; 0 => chosen by launcher   */
+  int32_t stats_slots;      /* 1..MI_BN_SLOTS accumulator slots (0 => MI_BN_SLOTS) */
+  int32_t pad_;
 } mi_conv_desc;
 
 int mi_conv2d(const mi_conv_desc* d, mi_stream_t s);
@@ -148,24 +152,25 @@ int mi_bn_eval_affine(const float* gamma, const float* beta, const float* runnin
                       mi_stream_t s);
 /* a = act(y*scale+shift) (+res); act: 1 silu, 0 identity.
  * train mode (stats_acc != NULL): scale/shift are first derived, in the kernel prologue, from the fp64
- * accumulators the conv epilogue filled ([MI_BN_SLOTS][C][2], `count` elements per channel); scale/shift/mean/
+ * accumulators the conv epilogue filled ([nslots][C][2], `count` elements per channel); scale/shift/mean/
  * invstd [C] are written for the backward pass and the running statistics are updated exactly as
  * nn.BatchNorm2d does (momentum, unbiased running variance, num_batches_tracked).
  * eval mode (stats_acc == NULL): scale/shift are inputs (mi_bn_eval_affine). */
-int mi_bn_act_fwd(const void* y, int ldy, const double* stats_acc, int64_t count, const float* gamma,
+int mi_bn_act_fwd(const void* y, int ldy, const double* stats_acc, int nslots, int64_t count, const float* gamma,
                   const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                   int64_t* num_batches_tracked, float* scale, float* shift, float* mean, float* invstd,
                   const void* res, int ldres, void* a, int lda, int64_t npix, int C, int act, mi_stream_t s);
-/* pass 1: per-channel sums of dz and dz*xhat over pixels, atomically added to dacc[MI_BN_SLOTS][C][2] (fp64,
+/* pass 1: per-channel sums of dz and dz*xhat over pixels, atomically added to dacc[nslots][C][2] (fp64,
  * caller zeroes once per step); nblk = number of blocks to launch */
 int mi_bn_act_bwd_reduce(const void* da, int ldda, const void* y, int ldy, const float* scale,
                          const float* shift, const float* mean, const float* invstd,
-                         double* dacc, int nblk, int64_t npix, int C, int act, mi_stream_t s);
+                         double* dacc, int nslots, int nblk, int64_t npix, int C, int act, mi_stream_t s);
 /* pass 2: dy = gamma*invstd*(dz - c1 - xhat*c2), c1/c2 from dacc (prologue); writes dgamma/dbeta (overwrite);
  * optional dres (+)= da */
 int mi_bn_act_bwd_apply(const void* da, int ldda, const void* y, int ldy, const float* scale,
                         const float* shift, const float* mean, const float* invstd,
-                        const float* gamma, const double* dacc, int64_t count, float* dgamma, float* dbeta,
+                        const float* gamma, const double* dacc, int nslots, int64_t count, float* dgamma,
+                        float* dbeta,
                         void* dy, int lddy, void* dres, int lddres, int dres_accum, int64_t npix, int C, int act,
                         mi_stream_t s);
 
@@ -177,7 +182,8 @@ int mi_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, in
                       mi_stream_t s);
 int mi_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, int accumulate, int N, int H,
                       int W, int C, mi_stream_t s);
-/* SPP max-pools k=5,9,13 s1 (wrappers.py:150-153): three outputs + argmax codes */
+/* SPP max-pools k=5,9,13 s1 (wrappers.py:150-153): three outputs + argmax codes; idx: 6*N*H*W*C bytes
+ * (separable argmax: 3 planes of vertical codes, 3 of horizontal codes); H*W <= 512 for the backward */
 int mi_spp_pool_fwd(const void* x, int ldx, void* y5, void* y9, void* y13, int ldy, uint8_t* idx,
                     int N, int H, int W, int C, mi_stream_t s);
 int mi_spp_pool_bwd(const void* dy5, const void* dy9, const void* dy13, int lddy,
@@ -282,9 +288,16 @@ enum {
   MI_OP_DECODE = 23,
   MI_OP_PACK_W_BATCH = 24,
   MI_OP_WGRAD_GROUP = 25,
+  MI_OP_STREAM = 26, /* i[0] = stream id for the following commands (0 = the caller's stream, 1..MI_MAX_AUX = aux) */
+  MI_OP_FORK = 27,   /* aux stream i[0] waits for everything issued so far on the caller's stream               */
+  MI_OP_JOIN = 28,   /* the caller's stream waits for everything issued so far on aux stream i[0]               */
   MI_OP_COUNT
 };
 
+/* Independent chains (e.g. the three FPN levels of the YOLOX head) may be issued on auxiliary HIP streams owned by
+ * the library (STREAM / FORK / JOIN commands): under hipGraph capture they become parallel branches of the graph,
+ * which the MI355X runs concurrently (measured: two 64-block chains overlap ~2x). */
+#define MI_MAX_AUX 4
 int mi_cmdlist_run(const mi_cmd* cmds, int n, mi_stream_t s);
 /* returns an opaque handle (>0) or <0 */
 int64_t mi_graph_capture(const mi_cmd* cmds, int n, mi_stream_t s);

@@ -163,7 +163,8 @@ class Interp:
         C, act = c.i[3], c.i[4]
         if c.p[1].obj is not None:   # train mode: finalize the statistics first
             count = c.l[0]
-            part = self.f64(c.p[1], L.MI_BN_SLOTS * C * 2).view(L.MI_BN_SLOTS, C, 2).sum(0)
+            nsl = c.i[5]
+            part = self.f64(c.p[1], nsl * C * 2).view(nsl, C, 2).sum(0)
             mean = part[:, 0] / count
             var = (part[:, 1] / count - mean * mean).clamp(min=0)
             invstd = 1.0 / torch.sqrt(var + c.f[0])
@@ -205,7 +206,8 @@ class Interp:
         count = c.l[1]
         da = c.p[0].obj
         dz, xh = self._dz(c, da, c.p[1].obj, C, act)
-        part = self.f64(c.p[7], L.MI_BN_SLOTS * C * 2).view(L.MI_BN_SLOTS, C, 2).sum(0)
+        nsl = c.i[7]
+        part = self.f64(c.p[7], nsl * C * 2).view(nsl, C, 2).sum(0)
         if c.p[8].obj is not None:
             c.p[8].obj.copy_(part[:, 1].float())
         if c.p[9].obj is not None:

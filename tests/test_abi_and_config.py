@@ -35,7 +35,7 @@ def test_opcode_table_matches_header():
 
 def test_struct_sizes_match_c():
     # sizes computed from the field lists in the header (no padding surprises across the FFI)
-    assert C.sizeof(L.mi_conv_desc) == 5 * 8 + (3 + 3 + 2 + 2 + 4 + 4 + 27 + 5) * 4
+    assert C.sizeof(L.mi_conv_desc) == 5 * 8 + (3 + 3 + 2 + 2 + 4 + 4 + 27 + 5 + 2) * 4
     assert C.sizeof(L.mi_cmd) % 8 == 0 and C.sizeof(L.mi_cmd) == 4 + 160 + 32 + 4 + 128 + 32  # op,i[40],f[8],pad,p[16],l[4]
     assert C.sizeof(L.mi_sgd_seg) == 24
 
@@ -47,7 +47,7 @@ def test_argument_errors_without_launch():
     assert b"null" in lib.mi_last_error()
     w = L.mi_wgrad_desc()
     assert lib.mi_conv2d_wgrad(C.byref(w), None) == -1
-    assert lib.mi_bn_act_fwd(None, 8, None, 0, None, None, 1e-3, 0.03, None, None, None, None, None, None, None, None, 0, None, 8, 10, 8, 1,
+    assert lib.mi_bn_act_fwd(None, 8, None, 0, 0, None, None, 1e-3, 0.03, None, None, None, None, None, None, None, None, 0, None, 8, 10, 8, 1,
                              None) == -1
     d.x = d.w = d.y = 256
     d.N, d.H, d.W, d.outH, d.outW, d.gridH, d.gridW = 1, 8, 8, 8, 8, 8, 8

@@ -31,6 +31,7 @@ class mi_conv_desc(C.Structure):
         ("tap_dy", C.c_int32 * MI_MAX_TAPS), ("tap_dx", C.c_int32 * MI_MAX_TAPS),
         ("tap_w", C.c_int32 * MI_MAX_TAPS),
         ("flags", C.c_int32), ("TH", C.c_int32), ("TW", C.c_int32), ("KC", C.c_int32), ("BN", C.c_int32),
+        ("stats_slots", C.c_int32), ("pad_", C.c_int32),
     ]
 
 
@@ -91,7 +92,7 @@ class mi_cmd(C.Structure):
 # opcode names must match the enum in include/mi355_det.h
 OPS = ["NOP", "CONV", "WGRAD", "PACK_W", "RESERVED4", "RESERVED5", "BN_ACT_FWD", "BN_BWD_REDUCE",
        "RESERVED8", "BN_BWD_APPLY", "FOCUS", "UPSAMPLE_FWD", "UPSAMPLE_BWD", "SPP_FWD", "SPP_BWD", "COPY",
-       "COLSUM", "LOSS_FWD", "LOSS_BWD", "SPLIT_DPREDS", "MEMSET", "SGD", "BN_EVAL_AFFINE", "DECODE", "PACK_W_BATCH", "WGRAD_GROUP"]
+       "COLSUM", "LOSS_FWD", "LOSS_BWD", "SPLIT_DPREDS", "MEMSET", "SGD", "BN_EVAL_AFFINE", "DECODE", "PACK_W_BATCH", "WGRAD_GROUP", "STREAM", "FORK", "JOIN"]
 OP = {n: k for k, n in enumerate(OPS)}
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -107,10 +108,10 @@ _PROTOS = {
     "mi_pack_conv_weight": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
     "mi_conv2d_wgrad_plan": (C.c_int64, [C.POINTER(mi_wgrad_desc)]),
     "mi_bn_eval_affine": (C.c_int, [_vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
-    "mi_bn_act_fwd": (C.c_int, [_vp, _i, _vp, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i,
+    "mi_bn_act_fwd": (C.c_int, [_vp, _i, _vp, _i, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i,
                                 _i64, _i, _i, _vp]),
-    "mi_bn_act_bwd_reduce": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
-    "mi_bn_act_bwd_apply": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i, _vp, _i, _i,
+    "mi_bn_act_bwd_reduce": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i64, _i, _i, _vp]),
+    "mi_bn_act_bwd_apply": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _i, _vp, _i, _i,
                                       _i64, _i, _i, _vp]),
     "mi_focus_pack": (C.c_int, [_vp, _i, _i, _i, _vp, _i, _vp]),
     "mi_upsample2x_fwd": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -51,7 +51,7 @@ struct BnFwdK {
   float* shift;
   float* mean;
   float* invstd;
-  int ldy, ldres, lda, C8;
+  int ldy, ldres, lda, C8, nslots;
   int64_t npix;
   double inv_count, unbias;
   float eps, momentum;
@@ -64,8 +64,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnFwdK p) {
   if (p.acc) {
     for (int c = threadIdx.x; c < C; c += 256) {
       double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-      for (int k = 0; k < MI_BN_SLOTS; ++k) {
+      for (int k = 0; k < p.nslots; ++k) {
         s1 += p.acc[((size_t)k * C + c) * 2 + 0];
         s2 += p.acc[((size_t)k * C + c) * 2 + 1];
       }
@@ -134,7 +133,7 @@ static int ew_blocks(int64_t total) {
   return (int)b;
 }
 
-extern "C" int mi_bn_act_fwd(const void* y, int ldy, const double* stats_acc, int64_t count, const float* gamma,
+extern "C" int mi_bn_act_fwd(const void* y, int ldy, const double* stats_acc, int nslots, int64_t count, const float* gamma,
                              const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                              int64_t* num_batches_tracked, float* scale, float* shift, float* mean, float* invstd,
                              const void* res, int ldres, void* a, int lda, int64_t npix, int C, int act,
@@ -152,6 +151,7 @@ extern "C" int mi_bn_act_fwd(const void* y, int ldy, const double* stats_acc, in
   k.npix = npix; k.inv_count = count > 0 ? 1.0 / (double)count : 0.0;
   k.unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
   k.eps = eps; k.momentum = momentum;
+  k.nslots = (nslots >= 1 && nslots <= MI_BN_SLOTS) ? nslots : MI_BN_SLOTS;
   const int64_t total = npix * (C / 8);
   if (act)
     hipLaunchKernelGGL(bn_act_fwd_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)st, k);
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const __bf16* __rest
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, double* dacc,
+                                                            const float* __restrict__ invstd, double* dacc, int nslots,
                                                             int64_t npix, int C8) {
   __shared__ float red[256 * 16];
   const int tid = threadIdx.x;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const __bf16* __rest
   }
   __syncthreads();
   const int nout = C8 * 16, C = C8 * 8;
-  double* slot = dacc + (size_t)(blockIdx.x % MI_BN_SLOTS) * C * 2;
+  double* slot = dacc + (size_t)(blockIdx.x % nslots) * C * 2;
   for (int j = tid; j < nout; j += 256) {
     float acc = 0.f;
     for (int q = 0; q < PL; ++q) acc += red[q * nout + j];
@@ -223,16 +223,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const __bf16* __rest
 
 extern "C" int mi_bn_act_bwd_reduce(const void* da, int ldda, const void* y, int ldy, const float* scale,
                                     const float* shift, const float* mean, const float* invstd, double* dacc,
-                                    int nblk, int64_t npix, int C, int act, mi_stream_t st) {
+                                    int nslots, int nblk, int64_t npix, int C, int act, mi_stream_t st) {
+  if (nslots < 1 || nslots > MI_BN_SLOTS) nslots = MI_BN_SLOTS;
   MI_REQUIRE(da && y && scale && shift && mean && invstd && dacc, "bn_bwd_reduce: null");
   MI_REQUIRE(C % 8 == 0 && C <= BN_MAXC && (256 % (C / 8)) == 0, "bn_bwd_reduce: C %d (need 256 %% (C/8) == 0)", C);
   MI_REQUIRE(ldda % 8 == 0 && ldy % 8 == 0 && nblk > 0, "bn_bwd_reduce: ld");
   if (act)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(nblk), dim3(256), 0, (hipStream_t)st, (const __bf16*)da, ldda,
-                       (const __bf16*)y, ldy, scale, shift, mean, invstd, dacc, npix, C / 8);
+                       (const __bf16*)y, ldy, scale, shift, mean, invstd, dacc, nslots, npix, C / 8);
   else
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, dim3(nblk), dim3(256), 0, (hipStream_t)st, (const __bf16*)da, ldda,
-                       (const __bf16*)y, ldy, scale, shift, mean, invstd, dacc, npix, C / 8);
+                       (const __bf16*)y, ldy, scale, shift, mean, invstd, dacc, nslots, npix, C / 8);
   MI_CHECK_LAUNCH("bn_bwd_reduce");
   return MI_OK;
 }
@@ -252,7 +253,7 @@ struct BnBwdK {
   const float* gamma;
   float* dgamma;
   float* dbeta;
-  int ldda, ldy, lddy, lddres, dres_accum, C8;
+  int ldda, ldy, lddy, lddres, dres_accum, C8, nslots;
   int64_t npix;
   double inv_count;
 };
@@ -263,8 +264,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK p) {
   const int C8 = p.C8, C = C8 * 8;
   for (int c = threadIdx.x; c < C; c += 256) {
     double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int k = 0; k < MI_BN_SLOTS; ++k) {
+    for (int k = 0; k < p.nslots; ++k) {
       s1 += p.dacc[((size_t)k * C + c) * 2 + 0];
       s2 += p.dacc[((size_t)k * C + c) * 2 + 1];
     }
@@ -321,7 +321,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK p) {
 
 extern "C" int mi_bn_act_bwd_apply(const void* da, int ldda, const void* y, int ldy, const float* scale,
                                    const float* shift, const float* mean, const float* invstd, const float* gamma,
-                                   const double* dacc, int64_t count, float* dgamma, float* dbeta, void* dy, int lddy,
+                                   const double* dacc, int nslots, int64_t count, float* dgamma, float* dbeta, void* dy,
+                                   int lddy,
                                    void* dres, int lddres, int dres_accum, int64_t npix, int C, int act,
                                    mi_stream_t st) {
   MI_REQUIRE(da && y && scale && shift && mean && invstd && gamma && dacc && dy && count > 0, "bn_bwd_apply: null");
@@ -332,6 +333,7 @@ extern "C" int mi_bn_act_bwd_apply(const void* da, int ldda, const void* y, int 
   k.scale = scale; k.shift = shift; k.mean = mean; k.invstd = invstd; k.gamma = gamma; k.dgamma = dgamma;
   k.dbeta = dbeta; k.ldda = ldda; k.ldy = ldy; k.lddy = lddy; k.lddres = lddres; k.dres_accum = dres_accum;
   k.C8 = C / 8; k.npix = npix; k.inv_count = 1.0 / (double)count;
+  k.nslots = (nslots >= 1 && nslots <= MI_BN_SLOTS) ? nslots : MI_BN_SLOTS;
   const int64_t total = npix * (C / 8);
   if (act)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)st, k);

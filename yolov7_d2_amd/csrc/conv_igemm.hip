@@ -31,7 +31,7 @@ struct ConvK {
   int ldx, ldy, N, H, W, outH, outW, gridH, gridW, is, os, ooy, oox, K8, Cout, CoutPad, ntaps;
   long long ynstride;
   int toff[MI_MAX_TAPS], tw[MI_MAX_TAPS];
-  int flags, TH, TW, tilesY, tilesX, nco;
+  int flags, TH, TW, tilesY, tilesX, nco, nslots;
   int dymin, dxmin, haloW, npixh, nqx, xbytes;
   unsigned mTW, mHW;  // ceil(2^20 / TW), ceil(2^20 / haloW)
 };
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvK 
           a1 += Rs[(q * BN + tid) * 2 + 0];
           a2 += Rs[(q * BN + tid) * 2 + 1];
         }
-        double* sp = p.stats + ((size_t)(tile % MI_BN_SLOTS) * p.CoutPad + co0 + tid) * 2;
+        double* sp = p.stats + ((size_t)(tile % p.nslots) * p.CoutPad + co0 + tid) * 2;
         atomicAdd(sp, (double)a1);
         atomicAdd(sp + 1, (double)a2);
       }
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvK 
         a1 += Ss[(w * BN + tid) * 2 + 0];
         a2 += Ss[(w * BN + tid) * 2 + 1];
       }
-      double* sp = p.stats + ((size_t)(tile % MI_BN_SLOTS) * p.CoutPad + co0 + tid) * 2;
+      double* sp = p.stats + ((size_t)(tile % p.nslots) * p.CoutPad + co0 + tid) * 2;
       atomicAdd(sp, (double)a1);
       atomicAdd(sp + 1, (double)a2);
     }
@@ -400,6 +400,7 @@ static int conv_fill(const mi_conv_desc* d, ConvK* k, ConvCfg* c, size_t* ldsByt
   k->y = d->y;
   k->bias = d->bias;
   k->stats = d->stats_acc;
+  k->nslots = (d->stats_slots >= 1 && d->stats_slots <= MI_BN_SLOTS) ? d->stats_slots : MI_BN_SLOTS;
   k->ynstride = d->y_nstride > 0 ? (long long)d->y_nstride : (long long)d->outH * d->outW * d->ldy;
   k->ldx = d->ldx; k->ldy = d->ldy; k->N = d->N; k->H = d->H; k->W = d->W;
   k->outH = d->outH; k->outW = d->outW; k->gridH = d->gridH; k->gridW = d->gridW;

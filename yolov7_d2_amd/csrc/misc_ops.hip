@@ -107,259 +107,193 @@ extern "C" int mi_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, i
   return MI_OK;
 }
 
-// ---- SPP max-pools k = 5, 9, 13, stride 1, "same" padding (wrappers.py:150-153).
-// One 13x13 row-major window scan feeds all three pools; the first maximum wins (ATen max_pool2d).
-// idx[k][pix][c] stores the winning window offset as (dy+6)*13 + (dx+6).
-__global__ __launch_bounds__(256) void spp_fwd_kernel(const __bf16* __restrict__ x, int ldx, __bf16* y5, __bf16* y9,
-                                                      __bf16* y13, int ldy, uint8_t* idx, int N, int H, int W, int C8) {
-  const int64_t npix = (int64_t)N * H * W;
-  const int64_t total = npix * C8;
-  const int C = C8 * 8;
-  for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c8 = (int)(i % C8);
-    const int64_t pix = i / C8;
-    const int px = (int)(pix % W);
-    const int64_t r = pix / W;
-    const int py = (int)(r % H), n = (int)(r / H);
-    float m[3][8];
-    uint8_t am[3][8];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        m[k][e] = -INFINITY;
-        am[k][e] = 84;  // centre
-      }
-    for (int dy = -6; dy <= 6; ++dy) {
-      const int yy = py + dy;
-      if (yy < 0 || yy >= H) continue;
-      for (int dx = -6; dx <= 6; ++dx) {
-        const int xx = px + dx;
-        if (xx < 0 || xx >= W) continue;
-        const bf16x8 v = *(const bf16x8*)(x + (((int64_t)n * H + yy) * W + xx) * ldx + c8 * 8);
-        const uint8_t code = (uint8_t)((dy + 6) * 13 + (dx + 6));
-        const int ady = dy < 0 ? -dy : dy, adx = dx < 0 ? -dx : dx;
-        const int rad = ady > adx ? ady : adx;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float f = (float)v[e];
-          if (f > m[2][e]) { m[2][e] = f; am[2][e] = code; }
-          if (rad <= 4 && f > m[1][e]) { m[1][e] = f; am[1][e] = code; }
-          if (rad <= 2 && f > m[0][e]) { m[0][e] = f; am[0][e] = code; }
-        }
-      }
-    }
-    const int64_t o = pix * ldy + c8 * 8;
-    *(bf16x8*)(y5 + o) = pack8(m[0]);
-    *(bf16x8*)(y9 + o) = pack8(m[1]);
-    *(bf16x8*)(y13 + o) = pack8(m[2]);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      uint64_t pk = 0;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) pk |= (uint64_t)am[k][e] << (8 * e);
-      *(uint64_t*)(idx + ((int64_t)k * npix + pix) * C + c8 * 8) = pk;
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void spp_bwd_kernel(const __bf16* __restrict__ d5, const __bf16* __restrict__ d9,
-                                                      const __bf16* __restrict__ d13, int lddy,
-                                                      const uint8_t* __restrict__ idx, __bf16* dx, int lddx,
-                                                      int accumulate, int N, int H, int W, int C8) {
-  const int64_t npix = (int64_t)N * H * W;
-  const int64_t total = npix * C8;
-  const int C = C8 * 8;
-  for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c8 = (int)(i % C8);
-    const int64_t pix = i / C8;
-    const int px = (int)(pix % W);
-    const int64_t r = pix / W;
-    const int py = (int)(r % H), n = (int)(r / H);
-    float acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    // output position o = p - (dy,dx) selected input p iff its code == (dy,dx)
-    for (int dy = -6; dy <= 6; ++dy) {
-      const int oy = py - dy;
-      if (oy < 0 || oy >= H) continue;
-      for (int dxx = -6; dxx <= 6; ++dxx) {
-        const int ox = px - dxx;
-        if (ox < 0 || ox >= W) continue;
-        const uint8_t code = (uint8_t)((dy + 6) * 13 + (dxx + 6));
-        const int ady = dy < 0 ? -dy : dy, adx = dxx < 0 ? -dxx : dxx;
-        const int rad = ady > adx ? ady : adx;
-        const int64_t opix = ((int64_t)n * H + oy) * W + ox;
-        const int kmin = rad <= 2 ? 0 : (rad <= 4 ? 1 : 2);
-        for (int k = kmin; k < 3; ++k) {
-          const uint64_t pk = *(const uint64_t*)(idx + ((int64_t)k * npix + opix) * C + c8 * 8);
-          // any byte equal to code?
-          bool any = false;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) any |= (uint8_t)(pk >> (8 * e)) == code;
-          if (!any) continue;
-          const __bf16* dp = (k == 0 ? d5 : (k == 1 ? d9 : d13)) + opix * lddy + c8 * 8;
-          const bf16x8 g = *(const bf16x8*)dp;
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if ((uint8_t)(pk >> (8 * e)) == code) acc[e] += (float)g[e];
-        }
-      }
-    }
-    __bf16* op = dx + pix * lddx + c8 * 8;
-    if (accumulate) {
-      const bf16x8 o = *(const bf16x8*)op;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += (float)o[e];
-    }
-    *(bf16x8*)op = pack8(acc);
-  }
-}
-
-// LDS-plane variants: one block owns the whole H x W plane of 8 channels of one image (20x20 for YOLOX-s at 640):
-// the plane is staged once (6.4 KB) and the 13x13 windows are scanned from LDS instead of 169 global loads per output.
+// ---- SPP max-pools k = 5, 9, 13, stride 1, "same" padding (wrappers.py:150-153), separable with argmax.
+// One block owns the H x W plane of 8 channels of one image (20x20 at 640).  max over a (2r+1)^2 window =
+// vertical max of horizontal maxes; the argmax is kept as two codes so the backward pass is two gathers
+// (54 checks per pixel instead of 169..507):
+//   dxc[k][pixel][c] : dx+6 of the first maximum of row segment [x-r, x+r]            (horizontal pass)
+//   dyc[k][pixel][c] : dy+6 of the first row whose horizontal max equals the window max (vertical pass)
+// "first" = the element F.max_pool2d / the brute-force row-major scan would pick (strict > while scanning up).
+// idx buffer: [dyc 3 planes][dxc 3 planes], each N*H*W*C bytes.
 __global__ __launch_bounds__(256) void spp_fwd_plane_kernel(const __bf16* __restrict__ x, int ldx, __bf16* y5,
                                                             __bf16* y9, __bf16* y13, int ldy, uint8_t* idx, int N,
                                                             int H, int W, int C8) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16x8* Xp = (bf16x8*)smem;  // [H*W]
-  const int c8 = blockIdx.x % C8, n = blockIdx.x / C8;
   const int HW = H * W, C = C8 * 8;
+  bf16x8* Xp = (bf16x8*)smem;          // [HW] input plane
+  bf16x8* Hv = Xp + HW;                // [HW] horizontal max values of the current k
+  uint64_t* Hc = (uint64_t*)(Hv + HW); // [HW] their dx codes
+  const int c8 = blockIdx.x % C8, n = blockIdx.x / C8;
   const int64_t npix = (int64_t)N * HW;
   const __bf16* xb = x + ((int64_t)n * HW) * ldx + c8 * 8;
   for (int p = threadIdx.x; p < HW; p += 256) Xp[p] = *(const bf16x8*)(xb + (int64_t)p * ldx);
   __syncthreads();
-  for (int p = threadIdx.x; p < HW; p += 256) {
-    const int py = p / W, px = p - py * W;
-    float m[3][8];
-    uint8_t am[3][8];
+  for (int k = 0; k < 3; ++k) {
+    const int r = 2 + 2 * k;
+    for (int p = threadIdx.x; p < HW; p += 256) {
+      const int py = p / W, px = p - py * W;
+      float m[8];
+      uint8_t am[8];
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        m[k][e] = -INFINITY;
-        am[k][e] = 84;
-      }
-    for (int dy = -6; dy <= 6; ++dy) {
-      const int yy = py + dy;
-      if (yy < 0 || yy >= H) continue;
-      for (int dx = -6; dx <= 6; ++dx) {
+      for (int e = 0; e < 8; ++e) { m[e] = -INFINITY; am[e] = 6; }
+      for (int dx = -r; dx <= r; ++dx) {
         const int xx = px + dx;
         if (xx < 0 || xx >= W) continue;
-        const bf16x8 v = Xp[yy * W + xx];
-        const uint8_t code = (uint8_t)((dy + 6) * 13 + (dx + 6));
-        const int ady = dy < 0 ? -dy : dy, adx = dx < 0 ? -dx : dx;
-        const int rad = ady > adx ? ady : adx;
+        const bf16x8 v = Xp[py * W + xx];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float f = (float)v[e];
-          if (f > m[2][e]) { m[2][e] = f; am[2][e] = code; }
-          if (rad <= 4 && f > m[1][e]) { m[1][e] = f; am[1][e] = code; }
-          if (rad <= 2 && f > m[0][e]) { m[0][e] = f; am[0][e] = code; }
+          if (f > m[e]) { m[e] = f; am[e] = (uint8_t)(dx + 6); }
         }
       }
-    }
-    const int64_t pix = (int64_t)n * HW + p;
-    const int64_t o = pix * ldy + c8 * 8;
-    *(bf16x8*)(y5 + o) = pack8(m[0]);
-    *(bf16x8*)(y9 + o) = pack8(m[1]);
-    *(bf16x8*)(y13 + o) = pack8(m[2]);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
+      Hv[p] = pack8(m);
       uint64_t pk = 0;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) pk |= (uint64_t)am[k][e] << (8 * e);
+      for (int e = 0; e < 8; ++e) pk |= (uint64_t)am[e] << (8 * e);
+      Hc[p] = pk;
+      *(uint64_t*)(idx + ((int64_t)(3 + k) * npix + (int64_t)n * HW + p) * C + c8 * 8) = pk;
+    }
+    __syncthreads();
+    __bf16* yk = k == 0 ? y5 : (k == 1 ? y9 : y13);
+    for (int p = threadIdx.x; p < HW; p += 256) {
+      const int py = p / W, px = p - py * W;
+      float m[8];
+      uint8_t am[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { m[e] = -INFINITY; am[e] = 6; }
+      for (int dy = -r; dy <= r; ++dy) {
+        const int yy = py + dy;
+        if (yy < 0 || yy >= H) continue;
+        const bf16x8 v = Hv[yy * W + px];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = (float)v[e];
+          if (f > m[e]) { m[e] = f; am[e] = (uint8_t)(dy + 6); }
+        }
+      }
+      const int64_t pix = (int64_t)n * HW + p;
+      *(bf16x8*)(yk + pix * ldy + c8 * 8) = pack8(m);
+      uint64_t pk = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pk |= (uint64_t)am[e] << (8 * e);
       *(uint64_t*)(idx + ((int64_t)k * npix + pix) * C + c8 * 8) = pk;
     }
+    __syncthreads();
   }
 }
 
+// backward: gH_k[q] = sum over outputs o = q - (dy,0) with dyc_k[o] == dy of g_k[o];  gx[p] = sum_k sum over
+// q = p - (0,dx) with dxc_k[q] == dx of gH_k[q].  Gathers in a fixed order: deterministic.
 __global__ __launch_bounds__(256) void spp_bwd_plane_kernel(const __bf16* __restrict__ d5, const __bf16* __restrict__ d9,
                                                             const __bf16* __restrict__ d13, int lddy,
                                                             const uint8_t* __restrict__ idx, __bf16* dx, int lddx,
                                                             int accumulate, int N, int H, int W, int C8) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int HW = H * W, C = C8 * 8;
-  bf16x8* Gp = (bf16x8*)smem;                 // [3][HW] out-gradients of the three pools
-  uint64_t* Ip = (uint64_t*)(Gp + 3 * HW);    // [3][HW] argmax codes
+  bf16x8* Gp = (bf16x8*)smem;            // [HW] out-gradient of pool k
+  uint64_t* Dy = (uint64_t*)(Gp + HW);   // [HW] vertical codes
+  uint64_t* Dx = Dy + HW;                // [HW] horizontal codes
+  float* Gh = (float*)(Dx + HW);         // [HW][8] gradient w.r.t. the horizontal maxes
   const int c8 = blockIdx.x % C8, n = blockIdx.x / C8;
   const int64_t npix = (int64_t)N * HW;
-  for (int q = threadIdx.x; q < 3 * HW; q += 256) {
-    const int k = q / HW, p = q - k * HW;
-    const int64_t pix = (int64_t)n * HW + p;
-    const __bf16* dp = (k == 0 ? d5 : (k == 1 ? d9 : d13)) + pix * lddy + c8 * 8;
-    Gp[q] = *(const bf16x8*)dp;
-    Ip[q] = *(const uint64_t*)(idx + ((int64_t)k * npix + pix) * C + c8 * 8);
-  }
-  __syncthreads();
-  for (int p = threadIdx.x; p < HW; p += 256) {
-    const int py = p / W, px = p - py * W;
-    float acc[8];
+  float acc[2][8];  // up to 512 pixels per plane with 256 threads
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    for (int dy = -6; dy <= 6; ++dy) {
-      const int oy = py - dy;
-      if (oy < 0 || oy >= H) continue;
-      for (int dxx = -6; dxx <= 6; ++dxx) {
-        const int ox = px - dxx;
-        if (ox < 0 || ox >= W) continue;
-        const uint8_t code = (uint8_t)((dy + 6) * 13 + (dxx + 6));
-        const int ady = dy < 0 ? -dy : dy, adx = dxx < 0 ? -dxx : dxx;
-        const int rad = ady > adx ? ady : adx;
-        const int op = oy * W + ox;
-        const int kmin = rad <= 2 ? 0 : (rad <= 4 ? 1 : 2);
-        for (int k = kmin; k < 3; ++k) {
-          const uint64_t pk = Ip[k * HW + op];
-          bool any = false;
+    for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+  for (int k = 0; k < 3; ++k) {
+    const int r = 2 + 2 * k;
+    const __bf16* dk = k == 0 ? d5 : (k == 1 ? d9 : d13);
+    __syncthreads();
+    for (int p = threadIdx.x; p < HW; p += 256) {
+      const int64_t pix = (int64_t)n * HW + p;
+      Gp[p] = *(const bf16x8*)(dk + pix * lddy + c8 * 8);
+      Dy[p] = *(const uint64_t*)(idx + ((int64_t)k * npix + pix) * C + c8 * 8);
+      Dx[p] = *(const uint64_t*)(idx + ((int64_t)(3 + k) * npix + pix) * C + c8 * 8);
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < HW; q += 256) {
+      const int qy = q / W, qx = q - qy * W;
+      float g[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) any |= (uint8_t)(pk >> (8 * e)) == code;
-          if (!any) continue;
-          const bf16x8 g = Gp[k * HW + op];
+      for (int e = 0; e < 8; ++e) g[e] = 0.f;
+      for (int dy = -r; dy <= r; ++dy) {
+        const int oy = qy - dy;
+        if (oy < 0 || oy >= H) continue;
+        const int o = oy * W + qx;
+        const uint64_t pk = Dy[o];
+        const bf16x8 gv = Gp[o];
+        const uint8_t code = (uint8_t)(dy + 6);
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if ((uint8_t)(pk >> (8 * e)) == code) acc[e] += (float)g[e];
-        }
+        for (int e = 0; e < 8; ++e)
+          if ((uint8_t)(pk >> (8 * e)) == code) g[e] += (float)gv[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) Gh[q * 8 + e] = g[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = threadIdx.x + i * 256;
+      if (p >= HW) continue;
+      const int py = p / W, px = p - py * W;
+      for (int dxx = -r; dxx <= r; ++dxx) {
+        const int qx = px - dxx;
+        if (qx < 0 || qx >= W) continue;
+        const int q = py * W + qx;
+        const uint64_t pk = Dx[q];
+        const uint8_t code = (uint8_t)(dxx + 6);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if ((uint8_t)(pk >> (8 * e)) == code) acc[i][e] += Gh[q * 8 + e];
       }
     }
-    __bf16* op_ = dx + ((int64_t)n * HW + p) * lddx + c8 * 8;
-    if (accumulate) {
-      const bf16x8 o = *(const bf16x8*)op_;
+  }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += (float)o[e];
+  for (int i = 0; i < 2; ++i) {
+    const int p = threadIdx.x + i * 256;
+    if (p >= HW) continue;
+    __bf16* op_ = dx + ((int64_t)n * HW + p) * lddx + c8 * 8;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = acc[i][e];
+    if (accumulate) {
+      const bf16x8 ov = *(const bf16x8*)op_;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += (float)ov[e];
     }
-    *(bf16x8*)op_ = pack8(acc);
+    *(bf16x8*)op_ = pack8(o);
   }
 }
 
 extern "C" int mi_spp_pool_fwd(const void* x, int ldx, void* y5, void* y9, void* y13, int ldy, uint8_t* idx, int N,
                                int H, int W, int C, mi_stream_t st) {
   MI_REQUIRE(x && y5 && y9 && y13 && idx && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "spp_fwd: args");
-  const int64_t total = (int64_t)N * H * W * (C / 8);
-  if ((size_t)H * W * 16 <= 64 * 1024) {
-    hipLaunchKernelGGL(spp_fwd_plane_kernel, dim3(N * (C / 8)), dim3(256), (size_t)H * W * 16, (hipStream_t)st,
-                       (const __bf16*)x, ldx, (__bf16*)y5, (__bf16*)y9, (__bf16*)y13, ldy, idx, N, H, W, C / 8);
-    MI_CHECK_LAUNCH("spp_fwd_plane");
-    return MI_OK;
+  const size_t lds = (size_t)H * W * 40;
+  MI_REQUIRE(lds <= 160 * 1024, "spp_fwd: plane %dx%d too large for the LDS kernel", H, W);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)spp_fwd_plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)spp_bwd_plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
   }
-  hipLaunchKernelGGL(spp_fwd_kernel, dim3(ew_blocks(total, 65535)), dim3(256), 0, (hipStream_t)st, (const __bf16*)x,
-                     ldx, (__bf16*)y5, (__bf16*)y9, (__bf16*)y13, ldy, idx, N, H, W, C / 8);
+  hipLaunchKernelGGL(spp_fwd_plane_kernel, dim3(N * (C / 8)), dim3(256), lds, (hipStream_t)st, (const __bf16*)x, ldx,
+                     (__bf16*)y5, (__bf16*)y9, (__bf16*)y13, ldy, idx, N, H, W, C / 8);
   MI_CHECK_LAUNCH("spp_fwd");
   return MI_OK;
 }
 extern "C" int mi_spp_pool_bwd(const void* dy5, const void* dy9, const void* dy13, int lddy, const uint8_t* idx,
                                void* dx, int lddx, int accumulate, int N, int H, int W, int C, mi_stream_t st) {
   MI_REQUIRE(dy5 && dy9 && dy13 && idx && dx && C % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "spp_bwd: args");
-  const int64_t total = (int64_t)N * H * W * (C / 8);
-  if ((size_t)H * W * 72 <= 64 * 1024) {
-    hipLaunchKernelGGL(spp_bwd_plane_kernel, dim3(N * (C / 8)), dim3(256), (size_t)H * W * 72, (hipStream_t)st,
-                       (const __bf16*)dy5, (const __bf16*)dy9, (const __bf16*)dy13, lddy, idx, (__bf16*)dx, lddx,
-                       accumulate, N, H, W, C / 8);
-    MI_CHECK_LAUNCH("spp_bwd_plane");
-    return MI_OK;
+  MI_REQUIRE(H * W <= 512, "spp_bwd: plane %dx%d > 512 pixels (register accumulators)", H, W);
+  const size_t lds = (size_t)H * W * 64;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)spp_fwd_plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)spp_bwd_plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
   }
-  hipLaunchKernelGGL(spp_bwd_kernel, dim3(ew_blocks(total, 65535)), dim3(256), 0, (hipStream_t)st,
-                     (const __bf16*)dy5, (const __bf16*)dy9, (const __bf16*)dy13, lddy, idx, (__bf16*)dx, lddx,
-                     accumulate, N, H, W, C / 8);
+  hipLaunchKernelGGL(spp_bwd_plane_kernel, dim3(N * (C / 8)), dim3(256), lds, (hipStream_t)st, (const __bf16*)dy5,
+                     (const __bf16*)dy9, (const __bf16*)dy13, lddy, idx, (__bf16*)dx, lddx, accumulate, N, H, W, C / 8);
   MI_CHECK_LAUNCH("spp_bwd");
   return MI_OK;
 }

@@ -28,15 +28,15 @@ static int run_one(const mi_cmd& c, hipStream_t s) {
     case MI_OP_PACK_W:
       return mi_pack_conv_weight((const float*)p[0], i[0], i[1], i[2], i[3], p[1], i[4], i[5], p[2], i[6], i[7], st);
     case MI_OP_BN_ACT_FWD:
-      return mi_bn_act_fwd(p[0], i[0], (const double*)p[1], c.l[0], (const float*)p[2], (const float*)p[3], c.f[0],
+      return mi_bn_act_fwd(p[0], i[0], (const double*)p[1], i[5], c.l[0], (const float*)p[2], (const float*)p[3], c.f[0],
                            c.f[1], (float*)p[4], (float*)p[5], (int64_t*)p[6], (float*)p[7], (float*)p[8],
                            (float*)p[9], (float*)p[10], p[11], i[1], p[12], i[2], c.l[1], i[3], i[4], st);
     case MI_OP_BN_BWD_REDUCE:
       return mi_bn_act_bwd_reduce(p[0], i[0], p[1], i[1], (const float*)p[2], (const float*)p[3], (const float*)p[4],
-                                  (const float*)p[5], (double*)p[6], i[2], c.l[0], i[3], i[4], st);
+                                  (const float*)p[5], (double*)p[6], i[5], i[2], c.l[0], i[3], i[4], st);
     case MI_OP_BN_BWD_APPLY:
       return mi_bn_act_bwd_apply(p[0], i[0], p[1], i[1], (const float*)p[2], (const float*)p[3], (const float*)p[4],
-                                 (const float*)p[5], (const float*)p[6], (const double*)p[7], c.l[1], (float*)p[8],
+                                 (const float*)p[5], (const float*)p[6], (const double*)p[7], i[7], c.l[1], (float*)p[8],
                                  (float*)p[9], p[10], i[2], p[11], i[3], i[4], c.l[0], i[5], i[6], st);
     case MI_OP_FOCUS: return mi_focus_pack((const float*)p[0], i[0], i[1], i[2], p[1], i[3], st);
     case MI_OP_UPSAMPLE_FWD: return mi_upsample2x_fwd(p[0], i[0], p[1], i[1], i[2], i[3], i[4], i[5], st);
@@ -66,11 +66,46 @@ static int run_one(const mi_cmd& c, hipStream_t s) {
   }
 }
 
+// auxiliary streams / events for parallel chains (created once, never destroyed: process lifetime)
+static hipStream_t g_aux[MI_MAX_AUX];
+static hipEvent_t g_ev_fork[MI_MAX_AUX], g_ev_join[MI_MAX_AUX];
+static bool g_aux_ready = false;
+static int ensure_aux() {
+  if (g_aux_ready) return MI_OK;
+  for (int k = 0; k < MI_MAX_AUX; ++k) {
+    if (hipStreamCreateWithFlags(&g_aux[k], hipStreamNonBlocking) != hipSuccess) MI_FAIL(MI_ELAUNCH, "aux stream");
+    if (hipEventCreateWithFlags(&g_ev_fork[k], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g_ev_join[k], hipEventDisableTiming) != hipSuccess)
+      MI_FAIL(MI_ELAUNCH, "aux event");
+  }
+  g_aux_ready = true;
+  return MI_OK;
+}
+
 extern "C" int mi_cmdlist_run(const mi_cmd* cmds, int n, mi_stream_t st) {
   if (mi_device_count() <= 0) MI_FAIL(MI_ENODEV, "no HIP device");
   hipStream_t s = (hipStream_t)st;
+  hipStream_t cur = s;
   for (int k = 0; k < n; ++k) {
-    const int rc = run_one(cmds[k], s);
+    const int op = cmds[k].op;
+    if (op == MI_OP_STREAM || op == MI_OP_FORK || op == MI_OP_JOIN) {
+      const int sid = cmds[k].i[0];
+      if (sid < 0 || sid > MI_MAX_AUX) MI_FAIL(MI_EINVAL, "cmd %d: stream id %d", k, sid);
+      if (sid > 0 && ensure_aux() != MI_OK) return MI_ELAUNCH;
+      if (op == MI_OP_STREAM) {
+        cur = sid ? g_aux[sid - 1] : s;
+      } else if (sid > 0 && op == MI_OP_FORK) {
+        if (hipEventRecord(g_ev_fork[sid - 1], s) != hipSuccess ||
+            hipStreamWaitEvent(g_aux[sid - 1], g_ev_fork[sid - 1], 0) != hipSuccess)
+          MI_FAIL(MI_ELAUNCH, "cmd %d: fork", k);
+      } else if (sid > 0) {
+        if (hipEventRecord(g_ev_join[sid - 1], g_aux[sid - 1]) != hipSuccess ||
+            hipStreamWaitEvent(s, g_ev_join[sid - 1], 0) != hipSuccess)
+          MI_FAIL(MI_ELAUNCH, "cmd %d: join", k);
+      }
+      continue;
+    }
+    const int rc = run_one(cmds[k], cur);
     if (rc != MI_OK) {
       char tmp[400];
       snprintf(tmp, sizeof(tmp), "%s", g_mi_err);

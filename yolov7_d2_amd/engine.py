@@ -13,7 +13,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import _lib as L
-from .parallel import GradReducer, broadcast_params, grad_write_ranges, plan_buckets
+from .parallel import GradReducer, broadcast_params, grad_write_ranges, parallel_regions, plan_buckets
 
 
 class NativeTrainer:
@@ -56,7 +56,7 @@ class NativeTrainer:
         buckets = plan_buckets(self.params.total, writes, self.n_buckets if self.world > 1 else 1)
         red = GradReducer(self.params.grad, buckets)
         barr, bn = plan.bwd_cmds
-        segs = red.segments(bn)
+        segs = red.segments(bn, parallel_regions(plan))
         st = dict(ps=ps, plan=plan, sgd=sgd, red=red, segs=segs, graphs=None)
         self._states[key] = st
         return st

@@ -158,15 +158,20 @@ class YOLOXHead(_NoEager):
     def emit(self, ctx, fpn_outs, preds, A, tag="head"):
         nch = 5 + self.num_classes
         a0 = 0
+        # the FPN levels are independent chains (yolox_head.py:160-172 loops over them): level 0 (80x80 at 640) stays on
+        # the caller's stream, the small levels run beside it on auxiliary streams (parallel hipGraph branches)
+        ctx.b.par_begin(tag + ".levels")
         for k, x in enumerate(fpn_outs):
-            t = self.stems[k].emit(ctx, x, f"{tag}.stems.{k}")
-            c = self.cls_convs[k][0].emit(ctx, t, f"{tag}.cls_convs.{k}.0")
-            c = self.cls_convs[k][1].emit(ctx, c, f"{tag}.cls_convs.{k}.1")
-            r = self.reg_convs[k][0].emit(ctx, t, f"{tag}.reg_convs.{k}.0")
-            r = self.reg_convs[k][1].emit(ctx, r, f"{tag}.reg_convs.{k}.1")
-            for name, mod, src, c0 in (("cls_preds", self.cls_preds[k], c, 5), ("reg_preds", self.reg_preds[k], r, 0),
-                                       ("obj_preds", self.obj_preds[k], r, 4)):
-                ctx.b.pred_conv(f"{tag}.{name}.{k}", src, mod.weight, mod.bias, ctx.g(mod.weight), ctx.g(mod.bias),
-                                preds, A, a0, c0, nch)
+            with ctx.b.on_stream(k):
+                t = self.stems[k].emit(ctx, x, f"{tag}.stems.{k}")
+                c = self.cls_convs[k][0].emit(ctx, t, f"{tag}.cls_convs.{k}.0")
+                c = self.cls_convs[k][1].emit(ctx, c, f"{tag}.cls_convs.{k}.1")
+                r = self.reg_convs[k][0].emit(ctx, t, f"{tag}.reg_convs.{k}.0")
+                r = self.reg_convs[k][1].emit(ctx, r, f"{tag}.reg_convs.{k}.1")
+                for name, mod, src, c0 in (("cls_preds", self.cls_preds[k], c, 5), ("reg_preds", self.reg_preds[k], r, 0),
+                                           ("obj_preds", self.obj_preds[k], r, 4)):
+                    ctx.b.pred_conv(f"{tag}.{name}.{k}", src, mod.weight, mod.bias, ctx.g(mod.weight), ctx.g(mod.bias),
+                                    preds, A, a0, c0, nch)
             a0 += x.H * x.W
+        ctx.b.par_end(tag + ".levels")
         assert a0 == A

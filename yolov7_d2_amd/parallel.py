@@ -69,6 +69,20 @@ def plan_buckets(total_elems, writes, n_buckets):
     return res
 
 
+def parallel_regions(plan):
+    """[(first, last)] command index ranges of the FORK .. JOIN regions of the backward list (never cut inside)"""
+    arr, n = plan.bwd_cmds
+    regs, start = [], None
+    for k in range(n):
+        op = arr[k].op
+        if op == L.OP["FORK"] and start is None:
+            start = k
+        if op == L.OP["JOIN"] and (k + 1 >= n or arr[k + 1].op != L.OP["JOIN"]):
+            regs.append((start, k))
+            start = None
+    return regs
+
+
 class GradReducer:
     """all-reduce(sum) of flat-gradient buckets, launched as soon as each bucket is complete; the 1/world
     scaling is folded into the optimizer update (grad_scale)."""
@@ -78,11 +92,15 @@ class GradReducer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.pending = []
 
-    def segments(self, n_cmds):
-        """[(cmd_lo, cmd_hi, bucket or None)]: run cmds [lo,hi) then reduce the bucket"""
+    def segments(self, n_cmds, regions=()):
+        """[(cmd_lo, cmd_hi, bucket or None)]: run cmds [lo,hi) then reduce the bucket.  A cut that would fall inside a
+        multi-stream region (FORK .. JOIN) moves to the end of the region."""
         segs, prev = [], 0
         for (lo, hi, last) in self.buckets:
             cut = max(prev, last + 1)
+            for (r0, r1) in regions:
+                if r0 < cut <= r1:
+                    cut = r1 + 1
             segs.append((prev, cut, (lo, hi)))
             prev = cut
         if prev < n_cmds:

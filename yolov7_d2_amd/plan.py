@@ -79,8 +79,9 @@ class _Ptr:
 
 
 class _Cmd:
-    def __init__(self, op, i=(), f=(), p=(), l=(), desc=None, tag=""):
+    def __init__(self, op, i=(), f=(), p=(), l=(), desc=None, tag="", stream=0):
         self.op, self.i, self.f, self.p, self.l, self.desc, self.tag = op, list(i), list(f), list(p), list(l), desc, tag
+        self.stream = stream   # 0 = caller's stream, k > 0 = auxiliary stream k (inside a parallel region)
 
 
 class ConvSpec:
@@ -96,6 +97,12 @@ class PlanBuilder:
         self.device = torch.device(device)
         # all weight gradients in one grouped launch at the end of backward (each layer keeps its own dy buffer)
         self.group_wgrad = (os.environ.get("MI_WGRAD_GROUP", "1") != "0") if group_wgrad is None else group_wgrad
+        # independent chains (the head's FPN levels) on auxiliary streams -> parallel hipGraph branches
+        # measured (A/B, round 1): the branches do overlap (tools/micro/graph_branches.hip: 2x on long kernels) but with
+        # ~300 short kernels in the region the step gets 3 % SLOWER (every node of a multi-branch graph pays extra
+        # dependency handling) -> opt-in only
+        self.multi_stream = os.environ.get("MI_MULTI_STREAM", "0") != "0" and self.group_wgrad
+        self.cur_stream = 0
         self.training = training            # build the backward command list
         self.bn_train = training if bn_train is None else bn_train  # batch statistics vs running statistics
         self.bufs = []
@@ -125,7 +132,15 @@ class PlanBuilder:
     def small(self, name, nbytes, zero=False):
         return self._new_buf(name, nbytes, zero)
 
-    def bn_acc(self, which, C):
+    @staticmethod
+    def bn_slots(nunits):
+        """accumulator slots for a layer whose producers add `nunits` partial sums per channel: ~64+ adds per address
+        keep the atomics cheap, few slots keep the BN kernels' statistics prologue short"""
+        # measured (A/B, round 1): fewer slots shorten the BN prologue (0.78 -> 0.67 ms/step) but slow the conv
+        # epilogues by more (same-address fp64 atomics): 16 everywhere is the best whole-step setting
+        return L.MI_BN_SLOTS
+
+    def bn_acc(self, which, C, nslots=None):
         """fp64 BatchNorm accumulators [MI_BN_SLOTS][C][2] inside ONE contiguous region per direction, zeroed by a
         single MEMSET at the start of the forward / backward command list"""
         key = "bn_acc_" + which
@@ -135,7 +150,7 @@ class PlanBuilder:
             self.shared[key] = b
             self.bufs.append(b)
         off = b.nbytes
-        b.nbytes += L.MI_BN_SLOTS * C * 2 * 8
+        b.nbytes += (L.MI_BN_SLOTS if nslots is None else nslots) * C * 2 * 8
         return _Ptr(b, off)
 
     def scratch(self, key, nbytes):
@@ -150,7 +165,8 @@ class PlanBuilder:
 
     # ---------------------------------------------------------------- command emission
     def emit(self, op, i=(), f=(), p=(), l=(), desc=None, tag="", prologue=False):
-        c = _Cmd(L.OP[op], i, f, [x if isinstance(x, _Ptr) else _Ptr(x) for x in p], l, desc, tag)
+        c = _Cmd(L.OP[op], i, f, [x if isinstance(x, _Ptr) else _Ptr(x) for x in p], l, desc, tag,
+                 stream=0 if prologue else self.cur_stream)
         if self._emitting_bwd:
             self.bwd.append(c)
         elif prologue:
@@ -161,7 +177,31 @@ class PlanBuilder:
 
     def on_backward(self, fn):
         if self.training:
-            self.bwd_gens.append(fn)
+            self.bwd_gens.append((fn, self.cur_stream))
+
+    # ---------------------------------------------------------------- parallel regions
+    def par_begin(self, tag="par"):
+        """start of a region whose commands carry stream ids (see `on_stream`); everything before the region is visible
+        to every stream of the region (FORK), everything in it is visible after `par_end` (JOIN).  The backward list
+        gets the mirrored region automatically."""
+        self.emit("NOP", tag=tag + ".begin")
+        self.on_backward(lambda: self.emit("NOP", tag=tag + ".end"))
+
+    def par_end(self, tag="par"):
+        self.emit("NOP", tag=tag + ".end")
+        self.on_backward(lambda: self.emit("NOP", tag=tag + ".begin"))
+
+    def on_stream(self, sid):
+        b = self
+
+        class _Ctx:
+            def __enter__(self_):
+                self_.prev = b.cur_stream
+                b.cur_stream = sid if b.multi_stream else 0
+
+            def __exit__(self_, *a):
+                b.cur_stream = self_.prev
+        return _Ctx()
 
     def grad_mode(self, t):
         """returns 1 (accumulate) if t's gradient region was already written in this backward pass, else 0
@@ -201,13 +241,13 @@ class PlanBuilder:
 
     def conv_cmd(self, tag, x, w_img, K8, y_ptr, ldy, outH, outW, Cout, CoutPad, taps, in_stride=1, out_stride=1,
                  out_oy=0, out_ox=0, gridH=None, gridW=None, bias=None, stats=None, flags=0, y_nstride=0,
-                 inH=None, inW=None):
+                 inH=None, inW=None, stats_slots=0):
         spec = ConvSpec(x=_Ptr(x), w=_Ptr(w_img), y=y_ptr if isinstance(y_ptr, _Ptr) else _Ptr(y_ptr),
                         bias=_Ptr(bias), stats=stats if isinstance(stats, _Ptr) else _Ptr(stats), ldx=x.ld, ldy=ldy, y_nstride=y_nstride, N=x.N,
                         H=x.H if inH is None else inH, W=x.W if inW is None else inW, outH=outH, outW=outW,
                         gridH=outH if gridH is None else gridH, gridW=outW if gridW is None else gridW,
                         in_stride=in_stride, out_stride=out_stride, out_oy=out_oy, out_ox=out_ox, K8=K8, Cout=Cout,
-                        CoutPad=CoutPad, taps=taps, flags=flags, tag=tag)
+                        CoutPad=CoutPad, taps=taps, flags=flags, tag=tag, stats_slots=stats_slots)
         self.conv_records.append(spec)
         return self.emit("CONV", desc=spec, tag=tag)
 
@@ -256,10 +296,11 @@ class PlanBuilder:
         if self.bn_train:
             mean = self.small(tag + ".mean", Cout * 4)
             invstd = self.small(tag + ".invstd", Cout * 4)
-            acc = self.bn_acc("fwd", Cout)
+            nsl = self.bn_slots(self.plan_conv_tiles(x, Ho, Wo, CinPad // 8, Cout, taps, stride))
+            acc = self.bn_acc("fwd", Cout, nsl)
             self.conv_cmd(tag + ".conv", x, wf, CinPad // 8, y, y.ld, Ho, Wo, Cout, Cout, taps, in_stride=stride,
-                          stats=acc)
-            self.emit("BN_ACT_FWD", i=[y.ld, res.ld if res is not None else 0, out.ld, Cout, act], l=[count, count],
+                          stats=acc, stats_slots=nsl)
+            self.emit("BN_ACT_FWD", i=[y.ld, res.ld if res is not None else 0, out.ld, Cout, act, nsl], l=[count, count],
                       f=[bn["eps"], bn["momentum"]],
                       p=[y, acc, bn["gamma"], bn["beta"], bn["rm"], bn["rv"], bn["nbt"], scale, shift, mean, invstd, res,
                          out], tag=tag + ".bnact")
@@ -267,7 +308,7 @@ class PlanBuilder:
             self.conv_cmd(tag + ".conv", x, wf, CinPad // 8, y, y.ld, Ho, Wo, Cout, Cout, taps, in_stride=stride)
             self.emit("BN_EVAL_AFFINE", i=[Cout], f=[bn["eps"]],
                       p=[bn["gamma"], bn["beta"], bn["rm"], bn["rv"], scale, shift], tag=tag + ".bnaff")
-            self.emit("BN_ACT_FWD", i=[y.ld, res.ld if res is not None else 0, out.ld, Cout, act], l=[0, count],
+            self.emit("BN_ACT_FWD", i=[y.ld, res.ld if res is not None else 0, out.ld, Cout, act, 0], l=[0, count],
                       p=[y, None, None, None, None, None, None, scale, shift, None, None, res, out], tag=tag + ".bnact")
 
         def bwd():
@@ -275,17 +316,18 @@ class PlanBuilder:
             assert self.grad_ready(out), f"{tag}: output gradient never written"
             C8 = Cout // 8
             nblk = max(1, min(1024, math.ceil(count / (256 // C8) / 4)))
-            dacc = self.bn_acc("bwd", Cout)
+            nsl2 = self.bn_slots(nblk)
+            dacc = self.bn_acc("bwd", Cout, nsl2)
             dy = (self._new_buf(tag + ".dy", count * Cout * 2) if self.group_wgrad
                   else self.scratch("dy", count * Cout * 2))
             dyT = TRef(dy, x.N, Ho, Wo, Cout, Cout)
-            self.emit("BN_BWD_REDUCE", i=[da.ld, y.ld, nblk, Cout, act], l=[count],
+            self.emit("BN_BWD_REDUCE", i=[da.ld, y.ld, nblk, Cout, act, nsl2], l=[count],
                       p=[da, y, scale, shift, mean, invstd, dacc], tag=tag + ".bnred")
             dres, dres_acc = None, 0
             if res is not None and res.requires_grad:
                 dres = res.grad
                 dres_acc = self.grad_mode(res)
-            self.emit("BN_BWD_APPLY", i=[da.ld, y.ld, Cout, dres.ld if dres is not None else 0, dres_acc, Cout, act],
+            self.emit("BN_BWD_APPLY", i=[da.ld, y.ld, Cout, dres.ld if dres is not None else 0, dres_acc, Cout, act, nsl2],
                       l=[count, count], p=[da, y, scale, shift, mean, invstd, bn["gamma"], dacc, bn["ggamma"], bn["gbeta"],
                                            dyT, dres], tag=tag + ".bnapply")
             self.wgrad_cmds(tag, x, dyT, CinPad, Cout, Cin, Cout, k, stride, pad, wgrad)
@@ -356,7 +398,7 @@ class PlanBuilder:
             dT = TRef(dmap, x.N, x.H, x.W, CoutPad, CoutPad)
             self.emit("SPLIT_DPREDS", i=[x.N, A, nch, a0, HW, c0, Cout, CoutPad], p=[self.loss["dpreds"], dT],
                       tag=tag + ".split")
-            self.emit("COLSUM", i=[CoutPad, Cout, 0], l=[x.N * HW], p=[dT, bgrad, self.scratch("colsum_ws", 128 * 128 * 4)],
+            self.emit("COLSUM", i=[CoutPad, Cout, 0], l=[x.N * HW], p=[dT, bgrad, self._new_buf(tag + ".colsum_ws", 128 * 128 * 4)],
                       tag=tag + ".bgrad")
             self.wgrad_cmds(tag, x, dT, Cin, CoutPad, Cin, Cout, 1, 1, 0, wgrad)
             if need_dgrad:
@@ -381,7 +423,7 @@ class PlanBuilder:
         self.on_backward(bwd)
 
     def spp_into(self, tag, x, o5, o9, o13):
-        idx = self.small(tag + ".idx", 3 * x.npix * x.C)
+        idx = self.small(tag + ".idx", 6 * x.npix * x.C)   # [dy codes x3][dx codes x3]
         assert o5.ld == o9.ld == o13.ld
         self.emit("SPP_FWD", i=[x.ld, o5.ld, x.N, x.H, x.W, x.C], p=[x, o5, o9, o13, idx], tag=tag)
 
@@ -418,8 +460,10 @@ class PlanBuilder:
     def finalize(self, materialize=True):
         # backward command generation, reverse order of forward emission
         self._emitting_bwd = True
-        for fn in reversed(self.bwd_gens):
+        for fn, sid in reversed(self.bwd_gens):
+            self.cur_stream = sid
             fn()
+        self.cur_stream = 0
         self._emitting_bwd = False
         self.bwd_gens = []
         for which, lst in (("fwd", self.fwd), ("bwd", self.bwd)):
@@ -510,7 +554,7 @@ class Plan:
             d.x, d.w, d.y = spec.x.resolve(), spec.w.resolve(), spec.y.resolve()
             d.bias, d.stats_acc = spec.bias.resolve(), spec.stats.resolve()
             for k in ("ldx", "ldy", "y_nstride", "N", "H", "W", "outH", "outW", "gridH", "gridW", "in_stride",
-                      "out_stride", "out_oy", "out_ox", "K8", "Cout", "CoutPad", "flags"):
+                      "out_stride", "out_oy", "out_ox", "K8", "Cout", "CoutPad", "flags", "stats_slots"):
                 setattr(d, k, int(getattr(spec, k)))
             d.ntaps = len(spec.taps)
             for t, (dy, dx, w) in enumerate(spec.taps):
@@ -528,7 +572,35 @@ class Plan:
         self.descs.append(d)
         return d
 
+    @staticmethod
+    def _lower_streams(cmds):
+        """stream-tagged commands inside par.begin / par.end markers -> FORK, STREAM switches, JOIN"""
+        out, k = [], 0
+        while k < len(cmds):
+            c = cmds[k]
+            if c.op == L.OP["NOP"] and c.tag.endswith(".begin"):
+                e = k + 1
+                while not (cmds[e].op == L.OP["NOP"] and cmds[e].tag.endswith(".end")):
+                    e += 1
+                region = cmds[k + 1: e]
+                used = sorted({r.stream for r in region if r.stream > 0})
+                out += [_Cmd(L.OP["FORK"], i=[sid], tag=f"fork{sid}") for sid in used]
+                # issue the auxiliary chains first (they are the short ones), the caller's stream last
+                for sid in used + [0]:
+                    chain = [r for r in region if r.stream == sid]
+                    if chain:
+                        out.append(_Cmd(L.OP["STREAM"], i=[sid], tag=f"stream{sid}"))
+                        out += chain
+                out += [_Cmd(L.OP["JOIN"], i=[sid], tag=f"join{sid}") for sid in used]
+                k = e + 1
+            else:
+                assert c.stream == 0, f"{c.tag}: stream {c.stream} outside a parallel region"
+                out.append(c)
+                k += 1
+        return out
+
     def _materialize(self, cmds, which):
+        cmds = self._lower_streams(cmds)
         arr = (L.mi_cmd * max(1, len(cmds)))()
         tags = []
         self.cmd_descs[which] = [None] * len(cmds)
