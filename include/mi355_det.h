@@ -226,6 +226,15 @@ int mi_yolox_loss_bwd(const mi_yolox_loss_desc* d, const float* gw, float* dpred
  * NHWC map dst [B][HW][ld] (channels >= nc zero-filled): the out-gradient of one prediction conv. */
 int mi_yolox_split_dpreds(const float* dpreds, int B, int A, int nch, int a0, int HW, int c0, int nc,
                           void* dst, int ld, mi_stream_t s);
+/* bias gradients of all prediction convs (nn.Conv2d bias of yolox_head.py:103-129) in two launches:
+ * out[c] = sum_b sum_{a0 <= a < a0+HW} dpreds[b][a][c0 + c]; jobs is a HOST array (<= 16);
+ * ws: 16*512*128 floats of scratch */
+typedef struct mi_bias_job {
+  float* out;
+  int32_t a0, HW, c0, nc;
+} mi_bias_job;
+int mi_yolox_bias_grads(const float* dpreds, int B, int A, int nch, const mi_bias_job* jobs, int njobs, float* ws,
+                        mi_stream_t s);
 /* eval decode (yolox_head.py:247-272): in-place on preds; obj/cls sigmoid applied */
 int mi_yolox_decode(float* preds, const float* anchors, int B, int A, int ncls, mi_stream_t s);
 
@@ -291,6 +300,7 @@ enum {
   MI_OP_STREAM = 26, /* i[0] = stream id for the following commands (0 = the caller's stream, 1..MI_MAX_AUX = aux) */
   MI_OP_FORK = 27,   /* aux stream i[0] waits for everything issued so far on the caller's stream               */
   MI_OP_JOIN = 28,   /* the caller's stream waits for everything issued so far on aux stream i[0]               */
+  MI_OP_BIAS_GRADS = 29,
   MI_OP_COUNT
 };
 

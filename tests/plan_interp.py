@@ -273,6 +273,12 @@ class Interp:
     def op_COPY(self, c):
         raise NotImplementedError
 
+    def op_BIAS_GRADS(self, c):
+        B, A, nch, n = c.i[:4]
+        dp = self.f32(c.p[1], B * A * nch).view(B, A, nch)
+        for j in c.desc.jobs:
+            j["out"].copy_(dp[:, j["a0"]: j["a0"] + j["HW"], j["c0"]: j["c0"] + j["nc"]].sum((0, 1)).view_as(j["out"]))
+
     def op_COLSUM(self, c):
         x, out = c.p[0].obj, c.p[1].obj
         C = c.i[1]

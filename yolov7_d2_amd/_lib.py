@@ -78,6 +78,10 @@ class mi_wgrad_group(C.Structure):
                 ("ws_bytes", C.c_int64)]
 
 
+class mi_bias_job(C.Structure):
+    _fields_ = [("out", C.c_void_p), ("a0", C.c_int32), ("HW", C.c_int32), ("c0", C.c_int32), ("nc", C.c_int32)]
+
+
 class mi_pack_job(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wf", C.c_void_p), ("wd", C.c_void_p),
                 ("Cout", C.c_int32), ("Cin", C.c_int32), ("KK", C.c_int32), ("CinPad", C.c_int32),
@@ -92,7 +96,7 @@ class mi_cmd(C.Structure):
 # opcode names must match the enum in include/mi355_det.h
 OPS = ["NOP", "CONV", "WGRAD", "PACK_W", "RESERVED4", "RESERVED5", "BN_ACT_FWD", "BN_BWD_REDUCE",
        "RESERVED8", "BN_BWD_APPLY", "FOCUS", "UPSAMPLE_FWD", "UPSAMPLE_BWD", "SPP_FWD", "SPP_BWD", "COPY",
-       "COLSUM", "LOSS_FWD", "LOSS_BWD", "SPLIT_DPREDS", "MEMSET", "SGD", "BN_EVAL_AFFINE", "DECODE", "PACK_W_BATCH", "WGRAD_GROUP", "STREAM", "FORK", "JOIN"]
+       "COLSUM", "LOSS_FWD", "LOSS_BWD", "SPLIT_DPREDS", "MEMSET", "SGD", "BN_EVAL_AFFINE", "DECODE", "PACK_W_BATCH", "WGRAD_GROUP", "STREAM", "FORK", "JOIN", "BIAS_GRADS"]
 OP = {n: k for k, n in enumerate(OPS)}
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -124,6 +128,7 @@ _PROTOS = {
     "mi_yolox_loss_fwd": (C.c_int, [C.POINTER(mi_yolox_loss_desc), _vp]),
     "mi_yolox_loss_bwd": (C.c_int, [C.POINTER(mi_yolox_loss_desc), _vp, _vp, _vp]),
     "mi_yolox_split_dpreds": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "mi_yolox_bias_grads": (C.c_int, [_vp, _i, _i, _i, C.POINTER(mi_bias_job), _i, _vp, _vp]),
     "mi_yolox_decode": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
     "mi_batched_nms": (C.c_int, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_sgd_momentum_step": (C.c_int, [_vp, _vp, _vp, _vp, _i, _f, _f, _i, _vp]),

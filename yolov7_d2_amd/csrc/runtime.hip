@@ -46,6 +46,8 @@ static int run_one(const mi_cmd& c, hipStream_t s) {
       return mi_spp_pool_bwd(p[0], p[1], p[2], i[0], (const uint8_t*)p[3], p[4], i[1], i[2], i[3], i[4], i[5], i[6], st);
     case MI_OP_COPY: return mi_copy_bf16(p[0], i[0], p[1], i[1], i[2], c.l[0], i[3], st);
     case MI_OP_COLSUM: return mi_colsum_bf16(p[0], i[0], c.l[0], i[1], (float*)p[1], i[2], (float*)p[2], st);
+    case MI_OP_BIAS_GRADS:
+      return mi_yolox_bias_grads((const float*)p[1], i[0], i[1], i[2], (const mi_bias_job*)p[0], i[3], (float*)p[2], st);
     case MI_OP_WGRAD_GROUP: return mi_conv2d_wgrad_group_run((const mi_wgrad_group*)p[0], p[1], st);
     case MI_OP_PACK_W_BATCH: return mi_pack_conv_weights_batch((const mi_pack_job*)p[0], i[0], st);
     case MI_OP_LOSS_FWD: return mi_yolox_loss_fwd((const mi_yolox_loss_desc*)p[0], st);

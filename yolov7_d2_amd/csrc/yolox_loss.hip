@@ -173,6 +173,74 @@ __device__ KV block_select(const float* row, int A, float lv, int li, float inva
   return best;
 }
 
+// register-resident variant: the row is read from HBM/L2 once (NV values per thread, element a = tid + 256*j),
+// the ~20 ordered selections then scan registers.  Same total order as block_select (ties -> smaller index).
+template <bool DESC, int NV>
+__device__ __forceinline__ KV block_select_reg(const float (&vals)[NV], int A, float lv, int li, float invalid_lo,
+                                               float invalid_hi, KV* sred) {
+  float bv = 0.f;
+  int bi = -1;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int a = threadIdx.x + 256 * j;
+    const float v = vals[j];
+    if (a >= A || v <= invalid_lo || v >= invalid_hi) continue;
+    if (!kv_after<DESC>(v, a, lv, li)) continue;
+    if (kv_better<DESC>(v, a, bv, bi)) { bv = v; bi = a; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (oi >= 0 && kv_better<DESC>(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+  }
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { sred[wave].v = bv; sred[wave].i = bi; }
+  __syncthreads();
+  KV best = sred[0];
+  for (int w = 1; w < 4; ++w)
+    if (sred[w].i >= 0 && kv_better<DESC>(sred[w].v, sred[w].i, best.v, best.i)) best = sred[w];
+  return best;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void simota_dynk_reg_kernel(const LossK p) {
+  __shared__ KV sred[4];
+  const int g = blockIdx.x, b = blockIdx.y;
+  if (g >= p.ngt[b]) return;
+  const float* iour = p.iou + ((size_t)b * p.gmax + g) * p.A;
+  const float* costr = p.cost + ((size_t)b * p.gmax + g) * p.A;
+  uint8_t* matchr = p.match + ((size_t)b * p.gmax + g) * p.A;
+  float vi[NV], vc[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int a = threadIdx.x + 256 * j;
+    vi[j] = a < p.A ? iour[a] : -1.0f;
+    vc[j] = a < p.A ? costr[a] : SIMOTA_INF;
+  }
+  float sum = 0.f, lv = 0.f;
+  int li = -1;
+  for (int r = 0; r < 10; ++r) {
+    const KV s = block_select_reg<true, NV>(vi, p.A, lv, li, -0.5f, INFINITY, sred);
+    if (s.i < 0) break;
+    sum += s.v;
+    lv = s.v;
+    li = s.i;
+  }
+  int k = (int)sum;
+  if (k < 1) k = 1;
+  lv = 0.f;
+  li = -1;
+  for (int r = 0; r < k; ++r) {
+    const KV s = block_select_reg<false, NV>(vc, p.A, lv, li, -INFINITY, SIMOTA_INF, sred);
+    if (s.i < 0) break;
+    if (threadIdx.x == 0) matchr[s.i] = 1;
+    lv = s.v;
+    li = s.i;
+  }
+}
+
 __global__ __launch_bounds__(256) void simota_dynk_kernel(const LossK p) {
   __shared__ KV sred[4];
   const int g = blockIdx.x, b = blockIdx.y;
@@ -321,7 +389,12 @@ extern "C" int mi_yolox_loss_fwd(const mi_yolox_loss_desc* d, mi_stream_t st) {
   const int nb = mi_cdiv(d->A, 256);
   hipLaunchKernelGGL(simota_cost_kernel, dim3(nb, d->B), dim3(256), d->gmax * 5 * sizeof(float), s, k);
   MI_CHECK_LAUNCH("simota_cost");
-  hipLaunchKernelGGL(simota_dynk_kernel, dim3(d->gmax, d->B), dim3(256), 0, s, k);
+  if (d->A <= 256 * 9)
+    hipLaunchKernelGGL(simota_dynk_reg_kernel<9>, dim3(d->gmax, d->B), dim3(256), 0, s, k);
+  else if (d->A <= 256 * 33)
+    hipLaunchKernelGGL(simota_dynk_reg_kernel<33>, dim3(d->gmax, d->B), dim3(256), 0, s, k);
+  else
+    hipLaunchKernelGGL(simota_dynk_kernel, dim3(d->gmax, d->B), dim3(256), 0, s, k);
   MI_CHECK_LAUNCH("simota_dynk");
   hipLaunchKernelGGL(simota_resolve_loss_kernel, dim3(nb, d->B), dim3(256), 0, s, k);
   MI_CHECK_LAUNCH("simota_resolve_loss");
@@ -418,6 +491,80 @@ extern "C" int mi_yolox_split_dpreds(const float* dpreds, int B, int A, int nch,
   hipLaunchKernelGGL(split_dpreds_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)st, dpreds, B, A, nch, a0, HW,
                      c0, nc, (__bf16*)dst, ld);
   MI_CHECK_LAUNCH("split_dpreds");
+  return MI_OK;
+}
+
+// ---- bias gradients of all prediction convs in two launches (fixed summation order):
+// grad_bias[job][c] = sum_b sum_{a in [a0, a0+HW)} dpreds[b][a][c0 + c]
+// stage 1 sums ALL nch columns of every distinct anchor range (FPN level) with fully coalesced row reads;
+// stage 2 combines the block partials and scatters each job's channel slice.
+#define MI_BIAS_MAX_JOBS 16
+#define MI_BIAS_BLOCKS 512
+struct BiasK {
+  const float* dpreds;
+  float* ws;  // [nlev][MI_BIAS_BLOCKS][128]
+  int B, A, nch, njobs, nlev;
+  int lev_a0[MI_BIAS_MAX_JOBS], lev_hw[MI_BIAS_MAX_JOBS], job_lev[MI_BIAS_MAX_JOBS];
+  mi_bias_job jobs[MI_BIAS_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void bias_grads_stage1_kernel(const BiasK p) {
+  __shared__ float red[256];
+  const int a0 = p.lev_a0[blockIdx.y], HW = p.lev_hw[blockIdx.y];
+  const int c = threadIdx.x & 127, rl = threadIdx.x >> 7;  // 128 channel lanes x 2 row lanes
+  const long rows = (long)p.B * HW;
+  float acc = 0.f;
+  if (c < p.nch) {
+    const long step = (long)gridDim.x * 2;
+    long r = (long)blockIdx.x * 2 + rl;
+    float a0_ = 0.f, a1_ = 0.f, a2_ = 0.f, a3_ = 0.f;
+    auto at = [&](long rr) {
+      const long b = rr / HW, a = rr - b * HW;
+      return p.dpreds[((size_t)b * p.A + a0 + a) * p.nch + c];
+    };
+    for (; r + 3 * step < rows; r += 4 * step) {  // 4 independent loads in flight
+      const float v0 = at(r), v1 = at(r + step), v2 = at(r + 2 * step), v3 = at(r + 3 * step);
+      a0_ += v0; a1_ += v1; a2_ += v2; a3_ += v3;
+    }
+    for (; r < rows; r += step) a0_ += at(r);
+    acc = (a0_ + a1_) + (a2_ + a3_);
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < 128)
+    p.ws[((size_t)blockIdx.y * MI_BIAS_BLOCKS + blockIdx.x) * 128 + threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + 128];
+}
+__global__ __launch_bounds__(128) void bias_grads_stage2_kernel(const BiasK p) {
+  const mi_bias_job j = p.jobs[blockIdx.x];
+  const int lev = p.job_lev[blockIdx.x];
+  const int c = threadIdx.x;
+  if (c >= j.nc) return;
+  float s = 0.f;
+  for (int b = 0; b < MI_BIAS_BLOCKS; ++b) s += p.ws[((size_t)lev * MI_BIAS_BLOCKS + b) * 128 + j.c0 + c];
+  j.out[c] = s;
+}
+extern "C" int mi_yolox_bias_grads(const float* dpreds, int B, int A, int nch, const mi_bias_job* jobs, int njobs,
+                                   float* ws, mi_stream_t st) {
+  MI_REQUIRE(dpreds && jobs && ws && njobs > 0 && njobs <= MI_BIAS_MAX_JOBS && nch <= 128, "bias_grads: args");
+  BiasK k;
+  k.dpreds = dpreds; k.ws = ws; k.B = B; k.A = A; k.nch = nch; k.njobs = njobs; k.nlev = 0;
+  for (int i = 0; i < njobs; ++i) {
+    MI_REQUIRE(jobs[i].out && jobs[i].nc >= 1 && jobs[i].nc <= 128 && jobs[i].c0 >= 0 && jobs[i].c0 + jobs[i].nc <= nch &&
+                   jobs[i].a0 >= 0 && jobs[i].a0 + jobs[i].HW <= A, "bias_grads: job %d", i);
+    k.jobs[i] = jobs[i];
+    int lev = -1;
+    for (int l = 0; l < k.nlev; ++l)
+      if (k.lev_a0[l] == jobs[i].a0 && k.lev_hw[l] == jobs[i].HW) lev = l;
+    if (lev < 0) {
+      lev = k.nlev++;
+      k.lev_a0[lev] = jobs[i].a0;
+      k.lev_hw[lev] = jobs[i].HW;
+    }
+    k.job_lev[i] = lev;
+  }
+  hipLaunchKernelGGL(bias_grads_stage1_kernel, dim3(MI_BIAS_BLOCKS, k.nlev), dim3(256), 0, (hipStream_t)st, k);
+  MI_CHECK_LAUNCH("bias_grads1");
+  hipLaunchKernelGGL(bias_grads_stage2_kernel, dim3(njobs), dim3(128), 0, (hipStream_t)st, k);
+  MI_CHECK_LAUNCH("bias_grads2");
   return MI_OK;
 }
 

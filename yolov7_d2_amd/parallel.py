@@ -40,6 +40,10 @@ def grad_write_ranges(plan, grad_tensor):
             ptrs += [(c.p[8], c.i[5] * 4), (c.p[9], c.i[5] * 4)]
         elif c.op == L.OP["COLSUM"]:
             ptrs.append((c.p[1], c.i[1] * 4))
+        elif c.op == L.OP["BIAS_GRADS"]:
+            jobs = C.cast(c.p[0], C.POINTER(L.mi_bias_job))
+            for j in range(c.i[3]):
+                ptrs.append((jobs[j].out, jobs[j].nc * 4))
         elif c.op == L.OP["MEMSET"]:
             ptrs.append((c.p[0], c.l[0]))
         rs = []

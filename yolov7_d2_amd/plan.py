@@ -116,6 +116,7 @@ class PlanBuilder:
         self.keep = []       # python objects that must outlive the plan (ctypes descs, tensors)
         self.loss = None
         self.conv_records = []  # (tag, spec) for roofline bookkeeping
+        self.bias_jobs = []     # prediction-conv bias gradients (one BIAS_GRADS command after the loss backward)
 
     # ---------------------------------------------------------------- buffers
     def _new_buf(self, name, nbytes, zero=False):
@@ -391,6 +392,7 @@ class PlanBuilder:
         self.conv_cmd(tag + ".conv", x, wf, Cin // 8, yptr, nch, x.H, x.W, Cout, CoutPad, [(0, 0, 0)], bias=bias,
                       flags=L.MI_CONV_OUT_F32, y_nstride=A * nch)
         HW = x.H * x.W
+        self.bias_jobs.append(dict(out=bgrad, a0=a0, HW=HW, c0=c0, nc=Cout, tag=tag))   # gathered by the loss backward
 
         def bwd():
             dmap = (self._new_buf(tag + ".dmap", x.N * HW * CoutPad * 2) if self.group_wgrad
@@ -398,8 +400,6 @@ class PlanBuilder:
             dT = TRef(dmap, x.N, x.H, x.W, CoutPad, CoutPad)
             self.emit("SPLIT_DPREDS", i=[x.N, A, nch, a0, HW, c0, Cout, CoutPad], p=[self.loss["dpreds"], dT],
                       tag=tag + ".split")
-            self.emit("COLSUM", i=[CoutPad, Cout, 0], l=[x.N * HW], p=[dT, bgrad, self._new_buf(tag + ".colsum_ws", 128 * 128 * 4)],
-                      tag=tag + ".bgrad")
             self.wgrad_cmds(tag, x, dT, Cin, CoutPad, Cin, Cout, 1, 1, 0, wgrad)
             if need_dgrad:
                 self.dgrad_cmds(tag, dT, wd, CoutPad // 8, x, Cin, Cin, 1, 1, 0)
@@ -452,6 +452,10 @@ class PlanBuilder:
 
         def bwd():
             self.emit("LOSS_BWD", desc=spec, p=[None, ws["gw"], ws["dpreds"]], tag="loss.bwd")
+            if self.bias_jobs:
+                jobs = ConvSpec(kind="bias_jobs", jobs=list(self.bias_jobs))
+                self.emit("BIAS_GRADS", i=[B, A, nch, len(self.bias_jobs)], desc=jobs,
+                          p=[None, ws["dpreds"], self._new_buf("loss.bias_ws", 16 * 512 * 128 * 4)], tag="loss.bias_grads")
 
         self.on_backward(bwd)
         return ws
@@ -559,6 +563,10 @@ class Plan:
             d.ntaps = len(spec.taps)
             for t, (dy, dx, w) in enumerate(spec.taps):
                 d.tap_dy[t], d.tap_dx[t], d.tap_w[t] = dy, dx, w
+        elif kind == "bias_jobs":
+            d = (L.mi_bias_job * len(spec.jobs))()
+            for jd, j in zip(d, spec.jobs):
+                jd.out, jd.a0, jd.HW, jd.c0, jd.nc = j["out"].data_ptr(), j["a0"], j["HW"], j["c0"], j["nc"]
         elif kind == "wgrad":
             d = PlanBuilder._wgrad_desc(spec)
             d.x, d.dy, d.gw = spec.x.resolve(), spec.dy.resolve(), spec.gw.resolve()
