@@ -63,10 +63,16 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnFwdK p) {
   const int C = p.C8 * 8;
   if (p.acc) {
     for (int c = threadIdx.x; c < C; c += 256) {
+      // all slot loads are issued before the first add (a rolled loop serialises 16 L2 round trips: ~4.5 us)
+      f64x2 v[MI_BN_SLOTS];
+#pragma unroll
+      for (int k = 0; k < MI_BN_SLOTS; ++k)
+        v[k] = k < p.nslots ? *(const f64x2*)(p.acc + ((size_t)k * C + c) * 2) : f64x2{0.0, 0.0};
       double s1 = 0.0, s2 = 0.0;
-      for (int k = 0; k < p.nslots; ++k) {
-        s1 += p.acc[((size_t)k * C + c) * 2 + 0];
-        s2 += p.acc[((size_t)k * C + c) * 2 + 1];
+#pragma unroll
+      for (int k = 0; k < MI_BN_SLOTS; ++k) {
+        s1 += v[k][0];
+        s2 += v[k][1];
       }
       const double mean = s1 * p.inv_count;
       double var = s2 * p.inv_count - mean * mean;
@@ -263,10 +269,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK p) {
   __shared__ float s_c1[BN_MAXC], s_c2[BN_MAXC];
   const int C8 = p.C8, C = C8 * 8;
   for (int c = threadIdx.x; c < C; c += 256) {
+    f64x2 v[MI_BN_SLOTS];
+#pragma unroll
+    for (int k = 0; k < MI_BN_SLOTS; ++k)
+      v[k] = k < p.nslots ? *(const f64x2*)(p.dacc + ((size_t)k * C + c) * 2) : f64x2{0.0, 0.0};
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < p.nslots; ++k) {
-      s1 += p.dacc[((size_t)k * C + c) * 2 + 0];
-      s2 += p.dacc[((size_t)k * C + c) * 2 + 1];
+#pragma unroll
+    for (int k = 0; k < MI_BN_SLOTS; ++k) {
+      s1 += v[k][0];
+      s2 += v[k][1];
     }
     s_c1[c] = (float)(s1 * p.inv_count);
     s_c2[c] = (float)(s2 * p.inv_count);
