@@ -112,21 +112,36 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnFwdK p) {
     sc[e] = s_sc[c8 * 8 + e];
     sh[e] = s_sh[c8 * 8 + e];
   }
-  for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int64_t pix = idx / C8;
-    const bf16x8 v = *(const bf16x8*)(p.y + pix * p.ldy + c8 * 8);
-    float o[8];
+  // 4 grid-stride elements per trip, all loads issued before the first use (one load in flight per wave is
+  // latency-bound: ~1 us per trip)
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += 4 * stride) {
+    bf16x8 v[4], r[4];
+    int64_t pix[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float z = (float)v[e] * sc[e] + sh[e];
-      o[e] = ACT ? z * sigmoidf_(z) : z;
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = idx + u * stride;
+      pix[u] = i / C8;
+      if (i < total) {
+        v[u] = *(const bf16x8*)(p.y + pix[u] * p.ldy + c8 * 8);
+        if (p.res) r[u] = *(const bf16x8*)(p.res + pix[u] * p.ldres + c8 * 8);
+      }
     }
-    if (p.res) {
-      const bf16x8 r = *(const bf16x8*)(p.res + pix * p.ldres + c8 * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] += (float)r[e];
+    for (int u = 0; u < 4; ++u) {
+      if (idx + u * stride >= total) break;
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float z = (float)v[u][e] * sc[e] + sh[e];
+        o[e] = ACT ? z * sigmoidf_(z) : z;
+      }
+      if (p.res) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += (float)r[u][e];
+      }
+      *(bf16x8*)(p.a + pix[u] * p.lda + c8 * 8) = pack8(o);
     }
-    *(bf16x8*)(p.a + pix * p.lda + c8 * 8) = pack8(o);
   }
 }
 
@@ -197,16 +212,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const __bf16* __rest
     is[e] = invstd[c8 * 8 + e];
     s1[e] = s2[e] = 0.f;
   }
-  for (int64_t pix = (int64_t)blockIdx.x * PL + pl; pix < npix; pix += (int64_t)gridDim.x * PL) {
-    const bf16x8 dv = *(const bf16x8*)(da + pix * ldda + c8 * 8);
-    const bf16x8 yv = *(const bf16x8*)(y + pix * ldy + c8 * 8);
+  const int64_t pstride = (int64_t)gridDim.x * PL;
+  for (int64_t pix0 = (int64_t)blockIdx.x * PL + pl; pix0 < npix; pix0 += 4 * pstride) {
+    bf16x8 dv[4], yv[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float yy = (float)yv[e];
-      const float z = yy * sc[e] + sh[e];
-      const float dz = (float)dv[e] * act_grad(z, ACT);
-      s1[e] += dz;
-      s2[e] += dz * ((yy - mu[e]) * is[e]);
+    for (int u = 0; u < 4; ++u) {
+      const int64_t pix = pix0 + u * pstride;
+      if (pix < npix) {
+        dv[u] = *(const bf16x8*)(da + pix * ldda + c8 * 8);
+        yv[u] = *(const bf16x8*)(y + pix * ldy + c8 * 8);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (pix0 + u * pstride >= npix) break;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float yy = (float)yv[u][e];
+        const float z = yy * sc[e] + sh[e];
+        const float dz = (float)dv[u][e] * act_grad(z, ACT);
+        s1[e] += dz;
+        s2[e] += dz * ((yy - mu[e]) * is[e]);
+      }
     }
   }
   // red[pl][c8][16]
@@ -301,30 +328,43 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK p) {
     k1[e] = s_c1[c];
     k2[e] = s_c2[c];
   }
-  for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int64_t pix = idx / C8;
-    const bf16x8 dv = *(const bf16x8*)(p.da + pix * p.ldda + c8 * 8);
-    const bf16x8 yv = *(const bf16x8*)(p.y + pix * p.ldy + c8 * 8);
-    float o[8];
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += 2 * stride) {
+    bf16x8 dv[2], yv[2], rv[2];
+    int64_t pix[2];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float yy = (float)yv[e];
-      const float z = yy * sc[e] + sh[e];
-      const float dz = (float)dv[e] * act_grad(z, ACT);
-      const float xh = (yy - mu[e]) * is[e];
-      o[e] = gi[e] * (dz - k1[e] - xh * k2[e]);
+    for (int u = 0; u < 2; ++u) {
+      const int64_t i = idx + u * stride;
+      pix[u] = i / C8;
+      if (i < total) {
+        dv[u] = *(const bf16x8*)(p.da + pix[u] * p.ldda + c8 * 8);
+        yv[u] = *(const bf16x8*)(p.y + pix[u] * p.ldy + c8 * 8);
+        if (p.dres && p.dres_accum) rv[u] = *(const bf16x8*)(p.dres + pix[u] * p.lddres + c8 * 8);
+      }
     }
-    *(bf16x8*)(p.dy + pix * p.lddy + c8 * 8) = pack8(o);
-    if (p.dres) {
-      __bf16* rp = p.dres + pix * p.lddres + c8 * 8;
-      if (p.dres_accum) {
-        const bf16x8 r = *(const bf16x8*)rp;
-        float q[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) q[e] = (float)r[e] + (float)dv[e];
-        *(bf16x8*)rp = pack8(q);
-      } else {
-        *(bf16x8*)rp = dv;
+    for (int u = 0; u < 2; ++u) {
+      if (idx + u * stride >= total) break;
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float yy = (float)yv[u][e];
+        const float z = yy * sc[e] + sh[e];
+        const float dz = (float)dv[u][e] * act_grad(z, ACT);
+        const float xh = (yy - mu[e]) * is[e];
+        o[e] = gi[e] * (dz - k1[e] - xh * k2[e]);
+      }
+      *(bf16x8*)(p.dy + pix[u] * p.lddy + c8 * 8) = pack8(o);
+      if (p.dres) {
+        __bf16* rp = p.dres + pix[u] * p.lddres + c8 * 8;
+        if (p.dres_accum) {
+          float q[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) q[e] = (float)rv[u][e] + (float)dv[u][e];
+          *(bf16x8*)rp = pack8(q);
+        } else {
+          *(bf16x8*)rp = dv[u];
+        }
       }
     }
   }
