@@ -384,13 +384,39 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* __restr
                                                   const mi_sgd_seg* __restrict__ segs, float momentum,
                                                   float grad_scale, int first_step) {
   const mi_sgd_seg sg = segs[blockIdx.x];
-  for (int64_t i = threadIdx.x; i < sg.count; i += 256) {
+  const float wd = sg.weight_decay, lr = sg.lr;
+  // segments start 16-byte aligned (the arena pads every parameter to 4 floats): float4 body, 2 vectors per trip
+  const int64_t n4 = ((sg.offset & 3) == 0) ? (sg.count >> 2) : 0;
+  f32x4* p4 = (f32x4*)(p + sg.offset);
+  const f32x4* g4 = (const f32x4*)(g + sg.offset);
+  f32x4* m4 = (f32x4*)(m + sg.offset);
+  for (int64_t i = threadIdx.x; i < n4; i += 512) {
+    const bool two = i + 256 < n4;
+    const f32x4 pa = p4[i], ga = g4[i], ma = first_step ? f32x4{0.f, 0.f, 0.f, 0.f} : m4[i];
+    f32x4 pb = {0.f, 0.f, 0.f, 0.f}, gb = pb, mb = pb;
+    if (two) {
+      pb = p4[i + 256];
+      gb = g4[i + 256];
+      if (!first_step) mb = m4[i + 256];
+    }
+    f32x4 da = ga * grad_scale + pa * wd;
+    f32x4 ba = first_step ? da : ma * momentum + da;
+    m4[i] = ba;
+    p4[i] = pa - ba * lr;
+    if (two) {
+      f32x4 db = gb * grad_scale + pb * wd;
+      f32x4 bb = first_step ? db : mb * momentum + db;
+      m4[i + 256] = bb;
+      p4[i + 256] = pb - bb * lr;
+    }
+  }
+  for (int64_t i = n4 * 4 + threadIdx.x; i < sg.count; i += 256) {
     const int64_t k = sg.offset + i;
     const float pv = p[k];
-    const float d = g[k] * grad_scale + sg.weight_decay * pv;
+    const float d = g[k] * grad_scale + wd * pv;
     const float b = first_step ? d : momentum * m[k] + d;
     m[k] = b;
-    p[k] = pv - sg.lr * b;
+    p[k] = pv - lr * b;
   }
 }
 extern "C" int mi_sgd_momentum_step(float* params, const float* grads, float* momentum_buf,
