@@ -332,7 +332,7 @@ static void wg_choose_tile(int TP, int gridH, int gridW, int* TH, int* TW) {
   *TH = bh; *TW = bw;
 }
 
-static int wg_pick_cfg(const mi_wgrad_desc* d, Wg2Cfg* c) {
+static int wg_pick_cfg(const mi_wgrad_desc* d, Wg2Cfg* c, bool grouped = false) {
   const int ci = d->CinPad, co = d->CoutPad;
   if (d->ntaps == 9) {
     c->NT = 9; c->NJ = 1;
@@ -351,7 +351,7 @@ static int wg_pick_cfg(const mi_wgrad_desc* d, Wg2Cfg* c) {
     const long tiles = (long)d->N * mi_cdiv(d->outH, th) * mi_cdiv(d->outW, tw);
     const int BCO = 16 * c->MI * c->WCO, BCI = 16 * c->NJ * c->WCI;
     const long outt = (long)(d->CoutPad / BCO) * (d->CinPad / BCI);
-    if (tiles * outt < 4 * 256) c->TP = 64;
+    if (tiles * outt < 4 * 256 && !grouped) c->TP = 64;  // (a grouped launch is filled by the other layers)
   }
   if (d->cfg_tp == 64 || d->cfg_tp == 128) c->TP = d->cfg_tp;
   return MI_OK;
@@ -366,7 +366,7 @@ static int wg_fill(const mi_wgrad_desc* d, Wg2K* k, Wg2Cfg* c, size_t* lds, size
   MI_REQUIRE(d->ldx % 8 == 0 && d->ldy % 8 == 0 && ((uintptr_t)d->x % 16) == 0 && ((uintptr_t)d->dy % 16) == 0,
              "wgrad: alignment");
   MI_REQUIRE(d->stride == 1 || d->stride == 2, "wgrad: stride");
-  wg_pick_cfg(d, c);
+  wg_pick_cfg(d, c, grouped);
   const int BCO = 16 * c->MI * c->WCO, BCI = 16 * c->NJ * c->WCI;
   MI_REQUIRE(d->CoutPad % BCO == 0 && d->CinPad % BCI == 0, "wgrad: tile %dx%d vs pads %d %d", BCO, BCI, d->CoutPad,
              d->CinPad);
@@ -491,10 +491,29 @@ extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, voi
   std::vector<Wg2Cfg> cs(n);
   std::vector<size_t> ldss(n), wss(n);
   size_t ws_off = 0;
+  // pass 1: tile configuration + tile counts per layer
   for (int i = 0; i < n; ++i) {
     mi_wgrad_desc t = descs[i];
     if (!t.x) t.x = (const void*)256;
     if (!t.dy) t.dy = (const void*)256;
+    int rc = wg_fill(&t, &ks[i], &cs[i], &ldss[i], &wss[i], true);
+    if (rc) return rc;
+  }
+  // pass 2: split-K per GROUP: every grid gets ~3 blocks per CU in total, i.e. each block a K range of
+  // T = (group's tile x output-tile units) / 768 pixel tiles (>= 4): ~3x less partial-slab traffic than per-layer splits
+  for (int i = 0; i < n; ++i) {
+    long units = 0;
+    for (int j = 0; j < n; ++j)
+      if (wg_cfg_id(cs[j]) == wg_cfg_id(cs[i])) units += (long)ks[j].ntiles * ks[j].nco * ks[j].nci;
+    long T = (units + 767) / 768;
+    if (T < 4) T = 4;
+    mi_wgrad_desc t = descs[i];
+    if (!t.x) t.x = (const void*)256;
+    if (!t.dy) t.dy = (const void*)256;
+    if (t.splitk <= 0) {
+      t.splitk = (int)((ks[i].ntiles + T - 1) / T);
+      if (t.splitk < 1) t.splitk = 1;
+    }
     int rc = wg_fill(&t, &ks[i], &cs[i], &ldss[i], &wss[i], true);
     if (rc) return rc;
     ks[i].part = (float*)((char*)ws_base + ws_off);
