@@ -327,6 +327,8 @@ static void wg_choose_tile(int TP, int gridH, int gridW, int* TH, int* TW) {
     long tiles = (long)mi_cdiv(gridH, th) * mi_cdiv(gridW, tw);
     long halo = (long)(th + 2) * (tw + 2);
     long score = tiles * 100000 + halo;
+    // a 3x3 halo of more than 184 rows no longer fits two 2-stage blocks per CU (64-channel rows): worth ~2 tiles
+    if (halo > 184) score += 200000;
     if (best < 0 || score < best) { best = score; bh = th; bw = tw; }
   }
   *TH = bh; *TW = bw;
@@ -399,7 +401,7 @@ static int wg_fill(const mi_wgrad_desc* d, Wg2K* k, Wg2Cfg* c, size_t* lds, size
   if (ns < 2 || ns > 4) {
     // 3x3: MFMA-heavy, two co-resident blocks overlap each other's barriers -> 2 stages when two blocks fit;
     // 1x1 and oversized stages: pure streams, one block per CU with as many tiles in flight as LDS allows
-    ns = (d->ntaps == 9 && 2 * 2 * (size_t)k->stage <= 160 * 1024) ? 2 : (int)((160 * 1024) / k->stage);
+    ns = (d->ntaps == 9) ? 2 : (int)((160 * 1024) / k->stage);
     if (ns > 4) ns = 4;
     if (ns < 2) ns = 2;
   }
