@@ -238,6 +238,23 @@ int mi_yolox_bias_grads(const float* dpreds, int B, int A, int nch, const mi_bia
 /* eval decode (yolox_head.py:247-272): in-place on preds; obj/cls sigmoid applied */
 int mi_yolox_decode(float* preds, const float* anchors, int B, int A, int ncls, mi_stream_t s);
 
+/* ---- DETR set matching (config 4) --------------------------------------------------
+ * replaces HungarianMatcher.forward (utils/detr_utils.py:37-91): matching cost
+ * C = w_bbox*L1(cdist) + w_class*(-softmax(logits)[label]) + w_giou*(-GIoU) per image, then
+ * scipy.optimize.linear_sum_assignment (detr_utils.py:89) - which the reference runs on the CPU.
+ * logits [B][Q][NC], boxes [B][Q][4] cxcywh, tgt_labels int64 [T], tgt_boxes [T][4] cxcywh,
+ * tgt_off int32 [B+1] (targets of image b = [tgt_off[b], tgt_off[b+1])), gmax >= max targets per image.
+ * cost (workspace / output) fp32 [B][Q][gmax]; match_q / match_t int64 [B][gmax]: the first nmatch[b] =
+ * min(Q, G_b) entries are the (query, target) pairs sorted by query index, exactly what scipy returns.
+ * Q, gmax <= 128. */
+int mi_hungarian_match(const float* logits, const float* boxes, const int64_t* tgt_labels,
+                       const float* tgt_boxes, const int32_t* tgt_off, int B, int Q, int NC, int gmax,
+                       float w_class, float w_bbox, float w_giou, float* cost, int64_t* match_q,
+                       int64_t* match_t, int32_t* nmatch, mi_stream_t s);
+/* the assignment alone on a caller-provided cost matrix (same layout) */
+int mi_lsap(const float* cost, const int32_t* tgt_off, int B, int Q, int gmax, int64_t* match_q,
+            int64_t* match_t, int32_t* nmatch, mi_stream_t s);
+
 /* ---- batched NMS -------------------------------------------------------------
  * replaces torchvision.ops.batched_nms as called by postprocess (utils/boxes.py:199).
  * boxes xyxy fp32 [n][4], scores [n], idxs (class id as float, as the reference passes) [n].

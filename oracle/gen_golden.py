@@ -110,9 +110,25 @@ def gold_postprocess():
     print("postprocess:", {k: v.shape for k, v in res.items() if "out" in k})
 
 
+def gold_hungarian():
+    """the reference's own HungarianMatcher (utils/detr_utils.py:12-91, scipy LSAP) on seeded DETR-shaped inputs"""
+    import detr_oracle as D
+    r = ref_loader.load()
+    res = {}
+    for name, (bs, nq, seed, sizes) in dict(a=(3, 100, 41, None), b=(2, 100, 42, [100, 1]), c=(2, 16, 43, [30, 7])).items():
+        logits, boxes, targets = D.synth_detr(bs, nq, 91, seed, sizes=sizes)
+        m = r.detr_utils.HungarianMatcher(cost_class=1.0, cost_bbox=5.0, cost_giou=2.0)   # DETR weights (config.py:216-218)
+        idx = m({"pred_logits": logits, "pred_boxes": boxes}, targets)
+        for b, (i, j) in enumerate(idx):
+            res[f"{name}_i{b}"], res[f"{name}_j{b}"] = i.numpy(), j.numpy()
+    np.savez_compressed(os.path.join(OUT, "hungarian.npz"), **res)
+    print("hungarian:", {k: v.shape for k, v in res.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     gold_step()
     gold_simota()
     gold_postprocess()
+    gold_hungarian()

@@ -102,6 +102,7 @@ def load():
     out.darknetx = importlib.import_module("yolov7.modeling.backbone.darknetx")
     out.pafpn = importlib.import_module("yolov7.modeling.neck.yolo_pafpn")
     out.head = importlib.import_module("yolov7.modeling.head.yolox_head")
+    out.detr_utils = importlib.import_module("yolov7.utils.detr_utils")   # HungarianMatcher (needs scipy: installed)
     return out
 
 

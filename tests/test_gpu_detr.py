@@ -1,0 +1,74 @@
+"""GPU (-m gpu): DETR set matching (cost matrix + linear sum assignment) through the C-ABI, against the oracle and
+the golden vectors produced by the reference's own HungarianMatcher (oracle/gen_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from scipy.optimize import linear_sum_assignment   # test infrastructure: the checker
+
+import detr_oracle as D
+from yolov7_d2_amd import _lib as L
+from yolov7_d2_amd.modeling import HungarianMatcher
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _to_dev(targets):
+    return [dict(labels=t["labels"].to(DEV), boxes=t["boxes"].to(DEV)) for t in targets]
+
+
+def test_hungarian_matcher_against_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "hungarian.npz"))
+    for name, (bs, nq, seed, sizes) in dict(a=(3, 100, 41, None), b=(2, 100, 42, [100, 1]), c=(2, 16, 43, [30, 7])).items():
+        logits, boxes, targets = D.synth_detr(bs, nq, 91, seed, sizes=sizes)
+        m = HungarianMatcher(cost_class=1.0, cost_bbox=5.0, cost_giou=2.0)
+        idx = m({"pred_logits": logits.to(DEV), "pred_boxes": boxes.to(DEV)}, _to_dev(targets))
+        # cost matrix: float parity with the fp32 CPU restatement
+        Cref = D.matching_cost(logits, boxes, targets, 1.0, 5.0, 2.0)
+        off = 0
+        for b, t in enumerate(targets):
+            G = len(t["boxes"])
+            np.testing.assert_allclose(m.last_cost[b, :, :G].cpu().numpy(), Cref[b, :, off:off + G].numpy(), rtol=1e-5, atol=1e-6)
+            off += G
+        # indices: bit-exact (int64, rows sorted) against the reference's scipy result
+        for b, (i, j) in enumerate(idx):
+            assert i.dtype == torch.int64 and j.dtype == torch.int64
+            assert np.array_equal(i.cpu().numpy(), g[f"{name}_i{b}"]), (name, b)
+            assert np.array_equal(j.cpu().numpy(), g[f"{name}_j{b}"]), (name, b)
+
+
+@pytest.mark.parametrize("Q,G", [(100, 1), (100, 7), (100, 20), (100, 100), (128, 128), (16, 30), (1, 1), (1, 5), (64, 63)])
+def test_lsap_exact_on_given_cost(Q, G):
+    """assignment kernel alone on oracle-provided cost matrices: identical pairs and optimal total cost (properties:
+    one-to-one, min(Q,G) pairs, rows sorted)"""
+    gen = torch.Generator().manual_seed(1000 + Q * 131 + G)
+    B = 4
+    C = torch.rand(B, Q, G, generator=gen)
+    off = torch.arange(0, (B + 1) * G, G, dtype=torch.int32, device=DEV)
+    mq = torch.full((B, G), -1, dtype=torch.int64, device=DEV)
+    mt = torch.full((B, G), -1, dtype=torch.int64, device=DEV)
+    nm = torch.zeros(B, dtype=torch.int32, device=DEV)
+    Cd = C.to(DEV).contiguous()
+    L.check(L.lib().mi_lsap(Cd.data_ptr(), off.data_ptr(), B, Q, G, mq.data_ptr(), mt.data_ptr(), nm.data_ptr(),
+                            L.stream_ptr()), "mi_lsap")
+    torch.cuda.synchronize()
+    for b in range(B):
+        ri, ci = linear_sum_assignment(C[b].numpy())
+        n = int(nm[b])
+        assert n == min(Q, G) == len(ri)
+        got_q, got_t = mq[b, :n].cpu().numpy(), mt[b, :n].cpu().numpy()
+        assert np.array_equal(got_q, ri) and np.array_equal(got_t, ci)
+        assert len(set(got_q.tolist())) == n and len(set(got_t.tolist())) == n
+        assert (np.diff(got_q) > 0).all() if n > 1 else True
+
+
+def test_matcher_edge_cases():
+    logits, boxes, targets = D.synth_detr(2, 100, 91, 7, sizes=[3, 3])
+    targets[1] = dict(labels=torch.zeros(0, dtype=torch.int64), boxes=torch.zeros(0, 4))   # image without objects
+    m = HungarianMatcher(1.0, 5.0, 2.0)
+    idx = m({"pred_logits": logits.to(DEV), "pred_boxes": boxes.to(DEV)}, _to_dev(targets))
+    assert len(idx[0][0]) == 3 and len(idx[1][0]) == 0 and len(idx[1][1]) == 0
+    ref, _ = D.hungarian_match(logits[:1], boxes[:1], targets[:1], 1.0, 5.0, 2.0)
+    assert torch.equal(idx[0][0].cpu(), ref[0][0]) and torch.equal(idx[0][1].cpu(), ref[0][1])

@@ -81,3 +81,14 @@ def test_nms_edge_cases():
     # threshold is strict (IoU == thr is kept)
     b2 = torch.tensor([[0., 0, 2, 1], [1, 0, 3, 1]])  # IoU = 1/3
     assert O.nms(b2, torch.tensor([1., 0.5]), 1.0 / 3.0 + 1e-3).tolist() == [0, 1]
+
+
+def test_detr_matcher_oracle_against_reference_golden(golden_dir):
+    """oracle/detr_oracle.py (restated cost + scipy LSAP) == the reference's own HungarianMatcher run by path"""
+    import detr_oracle as D
+    g = np.load(os.path.join(golden_dir, "hungarian.npz"))
+    for name, (bs, nq, seed, sizes) in dict(a=(3, 100, 41, None), b=(2, 100, 42, [100, 1]), c=(2, 16, 43, [30, 7])).items():
+        logits, boxes, targets = D.synth_detr(bs, nq, 91, seed, sizes=sizes)
+        idx, _ = D.hungarian_match(logits, boxes, targets, 1.0, 5.0, 2.0)
+        for b, (i, j) in enumerate(idx):
+            assert np.array_equal(i.numpy(), g[f"{name}_i{b}"]) and np.array_equal(j.numpy(), g[f"{name}_j{b}"])

@@ -2,3 +2,4 @@ from .blocks import BaseConv, Bottleneck, CSPLayer, Focus, SPPBottleneck
 from .postprocess import batched_nms, postprocess
 from .yolox import YOLOX
 from .yolox_net import CSPDarknet, YOLOPAFPN, YOLOXHead, build_cspdarknetx_backbone
+from .detr_matcher import HungarianMatcher

@@ -1,0 +1,45 @@
+"""HungarianMatcher — drop-in for yolov7/utils/detr_utils.py:12-91 (DETR set-prediction matching, config 4).
+
+Same constructor (cost_class, cost_bbox, cost_giou), same forward(outputs, targets) contract and return value
+(list of (index_i, index_j) int64 tensor pairs, rows sorted) — but the cost matrix AND the linear sum assignment
+run on the GPU (libmi355det: mi_hungarian_match); the reference copies the cost matrix to the host and calls
+scipy.optimize.linear_sum_assignment per image (detr_utils.py:84-90), six times per step.
+"""
+import torch
+from torch import nn
+
+from .. import _lib as L
+
+
+class HungarianMatcher(nn.Module):
+    def __init__(self, cost_class: float = 1, cost_bbox: float = 1, cost_giou: float = 1):
+        super().__init__()
+        self.cost_class, self.cost_bbox, self.cost_giou = cost_class, cost_bbox, cost_giou
+        assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0, "all costs cant be 0"
+
+    @torch.no_grad()
+    def forward(self, outputs, targets):
+        logits = outputs["pred_logits"].float().contiguous()
+        boxes = outputs["pred_boxes"].float().contiguous()
+        if not logits.is_cuda:
+            raise L.MI355Error("HungarianMatcher: the MI355X path needs device tensors (no CPU fallback)")
+        bs, nq, nc = logits.shape
+        dev = logits.device
+        sizes = [len(v["boxes"]) for v in targets]
+        gmax = max(max(sizes), 1)
+        off = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32, device=dev)
+        tl = torch.cat([v["labels"] for v in targets]).to(dev, torch.int64).contiguous()
+        tb = torch.cat([v["boxes"] for v in targets]).to(dev, torch.float32).contiguous()
+        if tl.numel() == 0:   # no targets at all: keep the pointers valid
+            tl, tb = torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(1, 4, device=dev)
+        cost = torch.empty(bs, nq, gmax, device=dev)
+        mq = torch.empty(bs, gmax, dtype=torch.int64, device=dev)
+        mt = torch.empty(bs, gmax, dtype=torch.int64, device=dev)
+        nm = torch.zeros(bs, dtype=torch.int32, device=dev)
+        L.check(L.lib().mi_hungarian_match(logits.data_ptr(), boxes.data_ptr(), tl.data_ptr(), tb.data_ptr(),
+                                           off.data_ptr(), bs, nq, nc, gmax, float(self.cost_class),
+                                           float(self.cost_bbox), float(self.cost_giou), cost.data_ptr(), mq.data_ptr(),
+                                           mt.data_ptr(), nm.data_ptr(), L.stream_ptr()), "mi_hungarian_match")
+        self.last_cost = cost
+        n = nm.tolist()   # one small D2H (the reference moves the whole cost matrix instead)
+        return [(mq[b, : n[b]].clone(), mt[b, : n[b]].clone()) for b in range(bs)]
