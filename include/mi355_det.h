@@ -255,6 +255,19 @@ int mi_hungarian_match(const float* logits, const float* boxes, const int64_t* t
 int mi_lsap(const float* cost, const int32_t* tgt_off, int B, int Q, int gmax, int64_t* match_q,
             int64_t* match_t, int32_t* nmatch, mi_stream_t s);
 
+/* ---- multi-head attention core (DETR, config 4) -------------------------------------
+ * O = softmax(scale * Q K^T + key_padding_mask) V per (batch, head); head_dim = 32 (DETR: 256 = 8 x 32).
+ * replaces the attention inside nn.MultiheadAttention as called by the transformer layers
+ * (modeling/backbone/detr_backbone.py:140,155-157,200-202,222-230).  Tensors are bf16 [L][B][E] (sequence first,
+ * E = H*32: the layout nn.MultiheadAttention's in-projection produces; = NHWC "pixel l*B+b, channel h*32+d", so
+ * the projections are 1x1 convolutions of this library).  key_padding_mask uint8 [B][Lk] (1 = ignore) or NULL;
+ * lse fp32 [B][H][Lq] is saved for the backward; delta_ws: fp32 [B][H][Lq] scratch.  No attention-weight dropout. */
+int mi_mha_fwd(const void* q, const void* k, const void* v, const uint8_t* key_padding_mask, void* o, float* lse,
+               int B, int H, int Lq, int Lk, int E, float scale, mi_stream_t s);
+int mi_mha_bwd(const void* q, const void* k, const void* v, const uint8_t* key_padding_mask, const void* o,
+               const float* lse, const void* dout, float* delta_ws, void* dq, void* dk, void* dv, int B, int H,
+               int Lq, int Lk, int E, float scale, mi_stream_t s);
+
 /* ---- batched NMS -------------------------------------------------------------
  * replaces torchvision.ops.batched_nms as called by postprocess (utils/boxes.py:199).
  * boxes xyxy fp32 [n][4], scores [n], idxs (class id as float, as the reference passes) [n].

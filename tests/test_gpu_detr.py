@@ -72,3 +72,44 @@ def test_matcher_edge_cases():
     assert len(idx[0][0]) == 3 and len(idx[1][0]) == 0 and len(idx[1][1]) == 0
     ref, _ = D.hungarian_match(logits[:1], boxes[:1], targets[:1], 1.0, 5.0, 2.0)
     assert torch.equal(idx[0][0].cpu(), ref[0][0]) and torch.equal(idx[0][1].cpu(), ref[0][1])
+
+
+# ------------------------------------------------------------------------------------------ attention core
+def _mha_ref(q, k, v, mask, H):
+    """fp32 reference of nn.MultiheadAttention's core (after in-projection, before out-projection, no dropout)"""
+    Lq, B, E = q.shape
+    Lk, D = k.shape[0], E // H
+    qh = q.reshape(Lq, B * H, D).transpose(0, 1)
+    kh = k.reshape(Lk, B * H, D).transpose(0, 1)
+    vh = v.reshape(Lk, B * H, D).transpose(0, 1)
+    s = torch.bmm(qh, kh.transpose(1, 2)) / (D ** 0.5)
+    if mask is not None:
+        s = s.view(B, H, Lq, Lk).masked_fill(mask[:, None, None, :], float("-inf")).view(B * H, Lq, Lk)
+    p = torch.softmax(s, dim=-1)
+    return torch.bmm(p, vh).transpose(0, 1).reshape(Lq, B, E)
+
+
+@pytest.mark.parametrize("Lq,Lk,B,masked", [(100, 100, 2, False), (100, 1050, 2, True), (1050, 1050, 1, True), (37, 65, 3, True),
+                                            (64, 32, 1, False)])
+def test_mha_core_fwd_bwd(Lq, Lk, B, masked):
+    from yolov7_d2_amd.modeling import mha_core
+    H, E = 8, 256
+    g = torch.Generator().manual_seed(Lq * 7 + Lk)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    q, k, v = (bf(torch.randn(L_, B, E, generator=g)) for L_ in (Lq, Lk, Lk))
+    go = bf(torch.randn(Lq, B, E, generator=g))
+    mask = None
+    if masked:
+        mask = torch.zeros(B, Lk, dtype=torch.bool)
+        mask[0, Lk - Lk // 5:] = True            # image 0 is narrower: its last keys are padding
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    ref = _mha_ref(qr, kr, vr, mask, H)
+    ref.backward(go)
+    qd, kd, vd = (t.to(DEV, torch.bfloat16).requires_grad_(True) for t in (q, k, v))
+    out = mha_core(qd, kd, vd, None if mask is None else mask.to(DEV), H)
+    out.backward(go.to(DEV, torch.bfloat16))
+    torch.cuda.synchronize()
+    rel = lambda a, b: float((a.detach().float().cpu() - b).norm() / (b.norm() + 1e-12))
+    assert rel(out, ref.detach()) < 1e-2
+    np.testing.assert_allclose(out.detach().float().cpu().numpy(), ref.detach().numpy(), rtol=3e-2, atol=3e-2)
+    assert rel(qd.grad, qr.grad) < 2e-2 and rel(kd.grad, kr.grad) < 2e-2 and rel(vd.grad, vr.grad) < 2e-2

@@ -1,0 +1,374 @@
+// Fused multi-head attention core for DETR (config 4), forward + backward, on the gfx950 matrix cores.
+//
+//   O = softmax(scale * Q K^T + key_padding_mask) V        per (batch, head), head_dim = 32
+//
+// replaces the attention inside nn.MultiheadAttention as DETR's encoder / decoder layers call it
+// (yolov7/modeling/backbone/detr_backbone.py:140,155-157,200-202,222-230): d_model 256 = 8 heads x 32, post-norm,
+// key_padding_mask from the padded image batch.  The reference materialises the [B*8, Lq, Lk] fp32 score matrix
+// (35 MB per image per encoder layer at 800x1333); here scores never leave registers (online softmax), and the
+// backward recomputes them from Q, K and the saved log-sum-exp.
+//
+// Layouts: Q, K, V, O, dO, dQ, dK, dV are bf16 [L][B][E] (sequence-first, E = H*32, exactly the tensors
+// nn.MultiheadAttention produces after its in-projection), i.e. "pixel = l*B + b, channel = h*32 + d" in the NHWC
+// convention of the conv kernels, so the in/out projections are 1x1 convolutions of the same library.
+// mask: uint8 [B][Lk], 1 = padded key (ignored); lse: fp32 [B][H][Lq].
+//
+// MFMA plan (v_mfma_f32_16x16x32_bf16, D = head_dim = 32 = ONE k-step for the score products):
+//   forward / dQ :  S^T tile = K_tile (A: [16 keys][32 d]) x Q^T (B: [32 d][16 queries])   -> lane (t = query, g)
+//                   holds keys 4g..4g+3: the softmax row statistics of a query need only 2 cross-lane steps, and
+//                   two such tiles (keys 0-15, 16-31) ARE the A fragment (8 key slots) of the next product
+//                   O / dQ += P (A: [16 q][32 key slots]) x V / K (B via ds_read_b64_tr_b16 from row-major LDS).
+//   dK, dV      :  S tile = Q_tile (A) x K^T (B) -> lane (t = key, g) holds queries 4g..4g+3, again directly the
+//                   A fragment of dV += P^T dO and dK += dS^T Q.
+// A wave owns 16 queries (forward, dQ) or 16 keys (dK/dV); a block = 4 waves shares the K/V (or Q/dO) tiles in LDS.
+#include <string.h>
+#include "common.h"
+
+#define MHA_D 32
+
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr_;
+__device__ __forceinline__ bf16x8 mha_tr_read2(const char* base0, const char* base1) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_)(base0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr_)(base1));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+struct MhaK {
+  const __bf16* q;
+  const __bf16* k;
+  const __bf16* v;
+  const uint8_t* mask;  // [B][Lk] or NULL
+  __bf16* o;
+  float* lse;           // [B][H][Lq]
+  // backward
+  const __bf16* dout;
+  const float* delta;   // [B][H][Lq]
+  __bf16* dq;
+  __bf16* dk;
+  __bf16* dv;
+  int B, H, Lq, Lk, E;
+  float scale;
+};
+
+// LDS tile of 32 rows x 32 d (64-byte rows), 16-byte chunks XOR-swizzled by (row >> 2) & 3 for the direct b128
+// fragment reads and -- equivalently for 32-byte groups -- (row >> 2) & 1 for the transpose reads.
+__device__ __forceinline__ int tile_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+// stage rows [r0, r0+32) of a [L][B][E] tensor (head h, batch b) into a tile; rows >= L are zero
+__device__ __forceinline__ void stage_tile(char* T, const __bf16* src, int r0, int L, int B, int E, int b, int h,
+                                           int tid) {
+  if (tid >= 0 && tid < 128) {
+    const int row = tid >> 2, chunk = tid & 3;
+    u32x4 val = {0u, 0u, 0u, 0u};
+    if (r0 + row < L) val = *(const u32x4*)(src + ((size_t)(r0 + row) * B + b) * E + h * MHA_D + chunk * 8);
+    *(u32x4*)(T + tile_off(row, chunk)) = val;
+  }
+}
+
+// direct fragment: lane (t = row, g) -> 8 consecutive d = 8g..8g+7 of row (r16*16 + t)
+__device__ __forceinline__ bf16x8 frag_rows(const char* T, int r16, int t, int g) {
+  return __builtin_bit_cast(bf16x8, *(const u32x4*)(T + tile_off(r16 * 16 + t, g)));
+}
+// transposed fragment for the B operand "rows as k slots": lane (t = d within group j, g) -> rows 4g+{0..3} and
+// 16+4g+{0..3}; d group j in {0,1}
+__device__ __forceinline__ bf16x8 frag_cols(const char* T, int j, int t, int g) {
+  const int r0 = 4 * g + (t >> 2), r1 = 16 + r0;
+  // 32-byte group j of a row sits at chunks 2j, 2j+1 -> swizzled by the same XOR (it preserves the pair: the XOR
+  // value's low bit moves within the pair only if odd, so build the address per 8-byte piece explicitly)
+  const int piece = t & 3;                    // 8-byte piece inside the 32-byte group
+  const int c0 = 2 * j + (piece >> 1);        // 16-byte chunk holding the piece
+  const int a0 = tile_off(r0, c0) + (piece & 1) * 8;
+  const int a1 = tile_off(r1, c0) + (piece & 1) * 8;
+  return mha_tr_read2(T + a0, T + a1);
+}
+
+// ------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaK p) {
+  __shared__ __attribute__((aligned(16))) char Ks[2][2048], Vs[2][2048];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  // this lane's query (B operand of S^T: lane (t = query, g) holds d = 8g..8g+7)
+  bf16x8 qf = {};
+  const int myq = q0 + t;
+  if (myq < p.Lq) qf = *(const bf16x8*)(p.q + ((size_t)myq * p.B + b) * p.E + h * MHA_D + g * 8);
+  f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // [d group]: lane (t = d, g): queries 4g+r
+  float m_run = -INFINITY, l_run = 0.f;  // of query `t` (replicated over g)
+  const int ntiles = (p.Lk + 31) / 32;
+  stage_tile(Ks[0], p.k, 0, p.Lk, p.B, p.E, b, h, tid);
+  stage_tile(Vs[0], p.v, 0, p.Lk, p.B, p.E, b, h, tid - 128);
+  for (int it = 0; it < ntiles; ++it) {
+    __syncthreads();
+    const int cur = it & 1;
+    if (it + 1 < ntiles) {
+      stage_tile(Ks[cur ^ 1], p.k, (it + 1) * 32, p.Lk, p.B, p.E, b, h, tid);
+      stage_tile(Vs[cur ^ 1], p.v, (it + 1) * 32, p.Lk, p.B, p.E, b, h, tid - 128);
+    }
+    const int k0 = it * 32;
+    // S^T tiles: keys [0,16) and [16,32) of this tile x 16 queries
+    f32x4 s[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const bf16x8 kf = frag_rows(Ks[cur], a, t, g);
+      s[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    }
+    // lane (t = query, g): s[a][r] = score of key k0 + 16a + 4g + r
+    float sv[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = k0 + 16 * a + 4 * g + r;
+        float x = s[a][r] * p.scale;
+        const bool dead = key >= p.Lk || (p.mask && p.mask[(size_t)b * p.Lk + key]);
+        x = dead ? -INFINITY : x;
+        sv[a * 4 + r] = x;
+        mx = fmaxf(mx, x);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = (m_new == -INFINITY) ? 1.f : __expf(m_run - m_new);  // (m_run = -inf -> 0)
+    float psum = 0.f;
+    bf16x8 pf;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float pe = (m_new == -INFINITY) ? 0.f : __expf(sv[e] - m_new);
+      psum += pe;
+      pf[e] = (__bf16)pe;
+    }
+    psum += __shfl_xor(psum, 16, 64);
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    // rescale O: lane (t = d, g) holds queries 4g + r -> alpha of lane (4g + r)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ar = __shfl(alpha, 4 * g + r, 64);
+      oacc[0][r] *= ar;
+      oacc[1][r] *= ar;
+    }
+    // O += P (A: lane (t = query, g), 8 key slots) x V (B: transpose read, d group j)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bf16x8 vf = frag_cols(Vs[cur], j, t, g);
+      oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, oacc[j], 0, 0, 0);
+    }
+  }
+  // epilogue: O[q][d] / l ; lane (t = d, g): queries 4g + r
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qq = q0 + 4 * g + r;
+    const float lr = __shfl(l_run, 4 * g + r, 64);
+    const float inv = lr > 0.f ? 1.f / lr : 0.f;
+    if (qq < p.Lq) {
+      __bf16* op = p.o + ((size_t)qq * p.B + b) * p.E + h * MHA_D;
+      op[t] = (__bf16)(oacc[0][r] * inv);
+      op[16 + t] = (__bf16)(oacc[1][r] * inv);
+    }
+  }
+  if (g == 0 && myq < p.Lq && p.lse)
+    p.lse[((size_t)b * p.H + h) * p.Lq + myq] = (l_run > 0.f) ? m_run + __logf(l_run) : -INFINITY;
+}
+
+// ------------------------------------------------------------------ backward
+// delta[b][h][q] = sum_d dO[q][d] * O[q][d]
+__global__ __launch_bounds__(256) void mha_delta_kernel(const MhaK p, float* delta) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // over B*H*Lq*4 (4 threads of 8 d per row)
+  const int part = idx & 3, row = idx >> 2;
+  if (row >= p.B * p.H * p.Lq) return;
+  const int q = row % p.Lq, bh = row / p.Lq, b = bh / p.H, h = bh % p.H;
+  const size_t off = ((size_t)q * p.B + b) * p.E + h * MHA_D + part * 8;
+  const bf16x8 a = *(const bf16x8*)(p.dout + off), c = *(const bf16x8*)(p.o + off);
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)c[e];
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  if (part == 0) delta[row] = s;
+}
+
+// dQ: same loop structure as the forward (a wave owns 16 queries, streams K/V tiles)
+__global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const MhaK p) {
+  __shared__ __attribute__((aligned(16))) char Ks[2][2048], Vs[2][2048];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int myq = q0 + t;
+  bf16x8 qf = {}, dof = {};
+  float lse = 0.f, dl = 0.f;
+  if (myq < p.Lq) {
+    const size_t off = ((size_t)myq * p.B + b) * p.E + h * MHA_D + g * 8;
+    qf = *(const bf16x8*)(p.q + off);
+    dof = *(const bf16x8*)(p.dout + off);
+    lse = p.lse[((size_t)b * p.H + h) * p.Lq + myq];
+    dl = p.delta[((size_t)b * p.H + h) * p.Lq + myq];
+  }
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const int ntiles = (p.Lk + 31) / 32;
+  stage_tile(Ks[0], p.k, 0, p.Lk, p.B, p.E, b, h, tid);
+  stage_tile(Vs[0], p.v, 0, p.Lk, p.B, p.E, b, h, tid - 128);
+  for (int it = 0; it < ntiles; ++it) {
+    __syncthreads();
+    const int cur = it & 1;
+    if (it + 1 < ntiles) {
+      stage_tile(Ks[cur ^ 1], p.k, (it + 1) * 32, p.Lk, p.B, p.E, b, h, tid);
+      stage_tile(Vs[cur ^ 1], p.v, (it + 1) * 32, p.Lk, p.B, p.E, b, h, tid - 128);
+    }
+    const int k0 = it * 32;
+    bf16x8 dsf;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const bf16x8 kf = frag_rows(Ks[cur], a, t, g), vf = frag_rows(Vs[cur], a, t, g);
+      const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = k0 + 16 * a + 4 * g + r;
+        const bool dead = key >= p.Lk || (p.mask && p.mask[(size_t)b * p.Lk + key]) || myq >= p.Lq;
+        const float pe = (dead || lse == -INFINITY) ? 0.f : __expf(s[r] * p.scale - lse);
+        dsf[a * 4 + r] = (__bf16)(pe * (dp[r] - dl) * p.scale);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bf16x8 kc = frag_cols(Ks[cur], j, t, g);
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, kc, acc[j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qq = q0 + 4 * g + r;
+    if (qq < p.Lq) {
+      __bf16* op = p.dq + ((size_t)qq * p.B + b) * p.E + h * MHA_D;
+      op[t] = (__bf16)acc[0][r];
+      op[16 + t] = (__bf16)acc[1][r];
+    }
+  }
+}
+
+// dK, dV: a wave owns 16 keys and streams Q / dO tiles
+__global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const MhaK p) {
+  __shared__ __attribute__((aligned(16))) char Qs[2][2048], Ds[2][2048];
+  __shared__ float Ls[2][32], Dl[2][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+  const int key0 = blockIdx.x * 64 + wave * 16;
+  const int mykey = key0 + t;
+  bf16x8 kf = {}, vf = {};
+  bool kdead = mykey >= p.Lk;
+  if (!kdead) {
+    const size_t off = ((size_t)mykey * p.B + b) * p.E + h * MHA_D + g * 8;
+    kf = *(const bf16x8*)(p.k + off);
+    vf = *(const bf16x8*)(p.v + off);
+    kdead = p.mask && p.mask[(size_t)b * p.Lk + mykey];
+  }
+  f32x4 dk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  f32x4 dv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const int ntiles = (p.Lq + 31) / 32;
+  auto stage_stats = [&](int buf, int r0) {
+    if (tid >= 192 && tid < 224) {
+      const int row = tid - 192;
+      const bool ok = r0 + row < p.Lq;
+      float lv = ok ? p.lse[((size_t)b * p.H + h) * p.Lq + r0 + row] : INFINITY;  // exp(s - inf) = 0
+      if (lv == -INFINITY) lv = INFINITY;  // fully masked query row: contributes nothing
+      Ls[buf][row] = lv;
+      Dl[buf][row] = ok ? p.delta[((size_t)b * p.H + h) * p.Lq + r0 + row] : 0.f;
+    }
+  };
+  stage_tile(Qs[0], p.q, 0, p.Lq, p.B, p.E, b, h, tid);
+  stage_tile(Ds[0], p.dout, 0, p.Lq, p.B, p.E, b, h, tid - 128);
+  stage_stats(0, 0);
+  for (int it = 0; it < ntiles; ++it) {
+    __syncthreads();
+    const int cur = it & 1;
+    if (it + 1 < ntiles) {
+      stage_tile(Qs[cur ^ 1], p.q, (it + 1) * 32, p.Lq, p.B, p.E, b, h, tid);
+      stage_tile(Ds[cur ^ 1], p.dout, (it + 1) * 32, p.Lq, p.B, p.E, b, h, tid - 128);
+      stage_stats(cur ^ 1, (it + 1) * 32);
+    }
+    bf16x8 pf, dsf;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      // S tile = Q (A: lane (t = query 16a + t, g)) x K^T (B: lane (t = key, g)) -> lane (t = key, g): queries 16a+4g+r
+      const bf16x8 qa = frag_rows(Qs[cur], a, t, g), da = frag_rows(Ds[cur], a, t, g);
+      const f32x4 s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = 16 * a + 4 * g + r;
+        const float pe = kdead ? 0.f : __expf(s[r] * p.scale - Ls[cur][ql]);
+        pf[a * 4 + r] = (__bf16)pe;
+        dsf[a * 4 + r] = (__bf16)(pe * (dp[r] - Dl[cur][ql]) * p.scale);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bf16x8 dc = frag_cols(Ds[cur], j, t, g), qc = frag_cols(Qs[cur], j, t, g);
+      dv[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, dc, dv[j], 0, 0, 0);
+      dk[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, qc, dk[j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int kk = key0 + 4 * g + r;
+    if (kk < p.Lk) {
+      const size_t off = ((size_t)kk * p.B + b) * p.E + h * MHA_D;
+      p.dk[off + t] = (__bf16)dk[0][r];
+      p.dk[off + 16 + t] = (__bf16)dk[1][r];
+      p.dv[off + t] = (__bf16)dv[0][r];
+      p.dv[off + 16 + t] = (__bf16)dv[1][r];
+    }
+  }
+}
+
+static int mha_check(const void* q, const void* k, const void* v, int B, int H, int Lq, int Lk, int E) {
+  MI_REQUIRE(q && k && v, "mha: null");
+  MI_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0 && E == H * MHA_D, "mha: E %d must be H*%d (H %d)", E, MHA_D, H);
+  MI_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0, "mha: alignment");
+  MI_REQUIRE((long long)B * H < 65536, "mha: B*H too large");
+  return MI_OK;
+}
+
+extern "C" int mi_mha_fwd(const void* q, const void* k, const void* v, const uint8_t* key_padding_mask, void* o,
+                          float* lse, int B, int H, int Lq, int Lk, int E, float scale, mi_stream_t st) {
+  int rc = mha_check(q, k, v, B, H, Lq, Lk, E);
+  if (rc) return rc;
+  MI_REQUIRE(o, "mha_fwd: null output");
+  MhaK p;
+  memset(&p, 0, sizeof(p));
+  p.q = (const __bf16*)q; p.k = (const __bf16*)k; p.v = (const __bf16*)v; p.mask = key_padding_mask;
+  p.o = (__bf16*)o; p.lse = lse; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.E = E; p.scale = scale;
+  hipLaunchKernelGGL(mha_fwd_kernel, dim3(mi_cdiv(Lq, 64), B * H), dim3(256), 0, (hipStream_t)st, p);
+  MI_CHECK_LAUNCH("mha_fwd");
+  return MI_OK;
+}
+
+extern "C" int mi_mha_bwd(const void* q, const void* k, const void* v, const uint8_t* key_padding_mask, const void* o,
+                          const float* lse, const void* dout, float* delta_ws, void* dq, void* dk, void* dv, int B,
+                          int H, int Lq, int Lk, int E, float scale, mi_stream_t st) {
+  int rc = mha_check(q, k, v, B, H, Lq, Lk, E);
+  if (rc) return rc;
+  MI_REQUIRE(o && lse && dout && delta_ws && dq && dk && dv, "mha_bwd: null");
+  MhaK p;
+  memset(&p, 0, sizeof(p));
+  p.q = (const __bf16*)q; p.k = (const __bf16*)k; p.v = (const __bf16*)v; p.mask = key_padding_mask;
+  p.o = (__bf16*)o; p.lse = (float*)lse; p.dout = (const __bf16*)dout; p.delta = delta_ws; p.dq = (__bf16*)dq;
+  p.dk = (__bf16*)dk; p.dv = (__bf16*)dv; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.E = E; p.scale = scale;
+  hipStream_t s = (hipStream_t)st;
+  hipLaunchKernelGGL(mha_delta_kernel, dim3(mi_cdiv(B * H * Lq * 4, 256)), dim3(256), 0, s, p, delta_ws);
+  MI_CHECK_LAUNCH("mha_delta");
+  hipLaunchKernelGGL(mha_bwd_dq_kernel, dim3(mi_cdiv(Lq, 64), B * H), dim3(256), 0, s, p);
+  MI_CHECK_LAUNCH("mha_bwd_dq");
+  hipLaunchKernelGGL(mha_bwd_dkv_kernel, dim3(mi_cdiv(Lk, 64), B * H), dim3(256), 0, s, p);
+  MI_CHECK_LAUNCH("mha_bwd_dkv");
+  return MI_OK;
+}

@@ -3,3 +3,4 @@ from .postprocess import batched_nms, postprocess
 from .yolox import YOLOX
 from .yolox_net import CSPDarknet, YOLOPAFPN, YOLOXHead, build_cspdarknetx_backbone
 from .detr_matcher import HungarianMatcher
+from .attention import mha_core

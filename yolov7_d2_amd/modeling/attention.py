@@ -1,0 +1,47 @@
+"""Attention core of nn.MultiheadAttention for DETR's transformer (detr_backbone.py:140,155-157,200-202,222-230),
+as a torch.autograd.Function over libmi355det's fused MFMA kernels (mi_mha_fwd / mi_mha_bwd).
+
+q, k, v: bf16 [L, B, E] (sequence first, E = num_heads * 32) — the tensors after the in-projection;
+key_padding_mask: bool/uint8 [B, Lk] (True = padded key).  Returns bf16 [Lq, B, E] (before the out-projection).
+"""
+import math
+
+import torch
+
+from .. import _lib as L
+
+
+class _MhaCore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask, num_heads):
+        if not q.is_cuda:
+            raise L.MI355Error("mha_core: the MI355X path needs device tensors (no CPU fallback)")
+        Lq, B, E = q.shape
+        Lk = k.shape[0]
+        q, k, v = (t.to(torch.bfloat16).contiguous() for t in (q, k, v))
+        m = None if mask is None else mask.to(torch.uint8).contiguous()
+        o = torch.empty_like(q)
+        lse = torch.empty(B, num_heads, Lq, dtype=torch.float32, device=q.device)
+        scale = 1.0 / math.sqrt(E // num_heads)
+        L.check(L.lib().mi_mha_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), L.ptr(m), o.data_ptr(), lse.data_ptr(), B,
+                                   num_heads, Lq, Lk, E, scale, L.stream_ptr()), "mi_mha_fwd")
+        ctx.save_for_backward(q, k, v, m, o, lse)
+        ctx.num_heads, ctx.scale = num_heads, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, m, o, lse = ctx.saved_tensors
+        Lq, B, E = q.shape
+        Lk = k.shape[0]
+        do = do.to(torch.bfloat16).contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        delta = torch.empty_like(lse)
+        L.check(L.lib().mi_mha_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), L.ptr(m), o.data_ptr(), lse.data_ptr(),
+                                   do.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B,
+                                   ctx.num_heads, Lq, Lk, E, ctx.scale, L.stream_ptr()), "mi_mha_bwd")
+        return dq, dk, dv, None, None
+
+
+def mha_core(q, k, v, key_padding_mask=None, num_heads=8):
+    return _MhaCore.apply(q, k, v, key_padding_mask, num_heads)
