@@ -268,6 +268,14 @@ int mi_mha_bwd(const void* q, const void* k, const void* v, const uint8_t* key_p
                const float* lse, const void* dout, float* delta_ws, void* dq, void* dk, void* dv, int B, int H,
                int Lq, int Lk, int E, float scale, mi_stream_t s);
 
+/* ---- IoU-family regression losses (CIoU / DIoU / GIoU / SIoU / IoU) with gradient ------
+ * replaces IOUlossV6.__call__ + its autograd backward (utils/boxes.py:666-752; YOLOv6 head, yolov6_head.py:346,512):
+ * loss[n] = 1 - iou_variant(pred[n], target[n]) (reduction "none"), dpred[n][4] = dloss[n] * d loss / d pred
+ * (dloss NULL => ones; CIoU's alpha is a constant for the gradient, as under torch.no_grad()).
+ * pred/target fp32 [n][4] in (cx,cy,w,h) (box_xyxy 0) or (x1,y1,x2,y2); iou_type: 0 iou, 1 giou, 2 diou, 3 ciou, 4 siou */
+int mi_iou_loss_v6(const float* pred, const float* target, int n, int iou_type, int box_xyxy, float eps,
+                   const float* dloss, float* loss, float* dpred, mi_stream_t s);
+
 /* ---- batched NMS -------------------------------------------------------------
  * replaces torchvision.ops.batched_nms as called by postprocess (utils/boxes.py:199).
  * boxes xyxy fp32 [n][4], scores [n], idxs (class id as float, as the reference passes) [n].

@@ -125,6 +125,23 @@ def gold_hungarian():
     print("hungarian:", {k: v.shape for k, v in res.items()})
 
 
+from gen_golden_inputs import synth_box_pairs  # noqa: E402
+
+
+def gold_iou_v6():
+    """the reference's own IOUlossV6 (utils/boxes.py:666-752) + autograd on seeded box pairs"""
+    r = ref_loader.load()
+    res = {}
+    pred, tgt = synth_box_pairs(257, 51)
+    for t in ("giou", "diou", "ciou", "siou"):
+        p = pred.clone().requires_grad_(True)
+        loss = r.boxes.IOUlossV6(box_format="xywh", iou_type=t, reduction="none")(p.T, tgt)
+        loss.sum().backward()
+        res[t + "_loss"], res[t + "_grad"] = loss.detach().numpy(), p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "iou_v6.npz"), **res)
+    print("iou_v6:", {k: float(np.abs(v).mean()) for k, v in res.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -132,3 +149,4 @@ if __name__ == "__main__":
     gold_simota()
     gold_postprocess()
     gold_hungarian()
+    gold_iou_v6()

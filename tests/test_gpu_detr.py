@@ -113,3 +113,21 @@ def test_mha_core_fwd_bwd(Lq, Lk, B, masked):
     assert rel(out, ref.detach()) < 1e-2
     np.testing.assert_allclose(out.detach().float().cpu().numpy(), ref.detach().numpy(), rtol=3e-2, atol=3e-2)
     assert rel(qd.grad, qr.grad) < 2e-2 and rel(kd.grad, kr.grad) < 2e-2 and rel(vd.grad, vr.grad) < 2e-2
+
+
+# ------------------------------------------------------------------------------------------ IOUlossV6 family
+@pytest.mark.parametrize("iou_type", ["giou", "diou", "ciou", "siou"])
+def test_iou_loss_v6_against_reference_golden(golden_dir, iou_type):
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle")
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    from gen_golden_inputs import synth_box_pairs
+    from yolov7_d2_amd.modeling import IOUlossV6
+    g = np.load(os.path.join(golden_dir, "iou_v6.npz"))
+    pred, tgt = synth_box_pairs(257, 51)
+    p = pred.to(DEV).requires_grad_(True)
+    loss = IOUlossV6(box_format="xywh", iou_type=iou_type, reduction="none")(p.T, tgt.to(DEV))
+    loss.sum().backward()
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), g[iou_type + "_loss"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(p.grad.cpu().numpy(), g[iou_type + "_grad"], rtol=2e-3, atol=2e-6)

@@ -1,0 +1,108 @@
+// IoU-family box regression losses with gradient: CIoU / DIoU / GIoU / SIoU / plain IoU.
+// replaces IOUlossV6.__call__ (yolov7/utils/boxes.py:666-752; used by the YOLOv6 head, head/yolov6_head.py:346,512)
+// and its autograd backward: loss[n] = 1 - iou_variant(pred[n], target[n]), eps 1e-7, CIoU's alpha under no_grad.
+// The gradient with respect to the prediction is carried along the forward expression as forward-mode dual numbers
+// (value + 4 partials), so forward and backward are ONE pass over the boxes and cannot drift apart.
+#include "common.h"
+
+struct D4 {  // value and d/d(pred x, y, w, h)  (or x1, y1, x2, y2)
+  float v, d[4];
+};
+__device__ __forceinline__ D4 dconst(float c) { return D4{c, {0.f, 0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ D4 dvar(float c, int i) { D4 r = dconst(c); r.d[i] = 1.f; return r; }
+__device__ __forceinline__ D4 operator+(D4 a, D4 b) { D4 r; r.v = a.v + b.v; for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+__device__ __forceinline__ D4 operator-(D4 a, D4 b) { D4 r; r.v = a.v - b.v; for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+__device__ __forceinline__ D4 operator*(D4 a, D4 b) { D4 r; r.v = a.v * b.v; for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+__device__ __forceinline__ D4 operator/(D4 a, D4 b) {
+  D4 r; r.v = a.v / b.v;
+  for (int i = 0; i < 4; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) / b.v;
+  return r;
+}
+__device__ __forceinline__ D4 operator+(D4 a, float c) { a.v += c; return a; }
+__device__ __forceinline__ D4 operator-(D4 a, float c) { a.v -= c; return a; }
+__device__ __forceinline__ D4 operator*(D4 a, float c) { a.v *= c; for (int i = 0; i < 4; ++i) a.d[i] *= c; return a; }
+__device__ __forceinline__ D4 dmin(D4 a, D4 b) { return a.v <= b.v ? a : b; }   // torch.min / max: gradient to the selected
+__device__ __forceinline__ D4 dmax(D4 a, D4 b) { return a.v >= b.v ? a : b; }
+__device__ __forceinline__ D4 dclamp0(D4 a) { return a.v > 0.f ? a : dconst(0.f); }  // clamp(0): zero gradient below
+__device__ __forceinline__ D4 dabs(D4 a) { return a.v >= 0.f ? a : a * -1.f; }
+__device__ __forceinline__ D4 dchain(D4 a, float fv, float fd) { D4 r; r.v = fv; for (int i = 0; i < 4; ++i) r.d[i] = fd * a.d[i]; return r; }
+__device__ __forceinline__ D4 dsqr(D4 a) { return dchain(a, a.v * a.v, 2.f * a.v); }
+__device__ __forceinline__ D4 dsqrt(D4 a) { const float s = sqrtf(a.v); return dchain(a, s, 0.5f / s); }
+__device__ __forceinline__ D4 datan(D4 a) { return dchain(a, atanf(a.v), 1.f / (1.f + a.v * a.v)); }
+__device__ __forceinline__ D4 dexp(D4 a) { const float e = expf(a.v); return dchain(a, e, e); }
+__device__ __forceinline__ D4 dpow4(D4 a) { const float a2 = a.v * a.v; return dchain(a, a2 * a2, 4.f * a2 * a.v); }
+
+enum { IOU_PLAIN = 0, IOU_GIOU = 1, IOU_DIOU = 2, IOU_CIOU = 3, IOU_SIOU = 4 };
+
+__global__ __launch_bounds__(256) void iou_loss_v6_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                          int n, int type, int xyxy, float eps, const float* dloss,
+                                                          float* loss, float* dpred) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* pb = pred + (size_t)i * 4;
+  const float* tb = tgt + (size_t)i * 4;
+  D4 b1x1, b1y1, b1x2, b1y2;
+  float b2x1, b2y1, b2x2, b2y2;
+  if (xyxy) {
+    b1x1 = dvar(pb[0], 0); b1y1 = dvar(pb[1], 1); b1x2 = dvar(pb[2], 2); b1y2 = dvar(pb[3], 3);
+    b2x1 = tb[0]; b2y1 = tb[1]; b2x2 = tb[2]; b2y2 = tb[3];
+  } else {
+    const D4 x = dvar(pb[0], 0), y = dvar(pb[1], 1), w = dvar(pb[2], 2), h = dvar(pb[3], 3);
+    b1x1 = x - w * 0.5f; b1x2 = x + w * 0.5f; b1y1 = y - h * 0.5f; b1y2 = y + h * 0.5f;
+    b2x1 = tb[0] - tb[2] / 2; b2x2 = tb[0] + tb[2] / 2; b2y1 = tb[1] - tb[3] / 2; b2y2 = tb[1] + tb[3] / 2;
+  }
+  const D4 c2x1 = dconst(b2x1), c2y1 = dconst(b2y1), c2x2 = dconst(b2x2), c2y2 = dconst(b2y2);
+  const D4 inter = dclamp0(dmin(b1x2, c2x2) - dmax(b1x1, c2x1)) * dclamp0(dmin(b1y2, c2y2) - dmax(b1y1, c2y1));
+  const D4 w1 = b1x2 - b1x1, h1 = b1y2 - b1y1 + eps;
+  const float w2 = b2x2 - b2x1, h2 = b2y2 - b2y1 + eps;
+  const D4 uni = w1 * h1 + (w2 * h2) - inter + eps;
+  D4 iou = inter / uni;
+  const D4 cw = dmax(b1x2, c2x2) - dmin(b1x1, c2x1), ch = dmax(b1y2, c2y2) - dmin(b1y1, c2y1);
+  if (type == IOU_GIOU) {
+    const D4 carea = cw * ch + eps;
+    iou = iou - (carea - uni) / carea;
+  } else if (type == IOU_DIOU || type == IOU_CIOU) {
+    const D4 c2 = dsqr(cw) + dsqr(ch) + eps;
+    const D4 rho2 = (dsqr(dconst(b2x1 + b2x2) - b1x1 - b1x2) + dsqr(dconst(b2y1 + b2y2) - b1y1 - b1y2)) * 0.25f;
+    if (type == IOU_DIOU) {
+      iou = iou - rho2 / c2;
+    } else {
+      const float k = 4.0f / (3.14159265358979323846f * 3.14159265358979323846f);
+      const D4 v = dsqr(dconst(atanf(w2 / h2)) - datan(w1 / h1)) * k;
+      const float alpha = v.v / (v.v - iou.v + (1.f + eps));  // torch.no_grad(): a constant for the gradient
+      iou = iou - (rho2 / c2 + v * alpha);
+    }
+  } else if (type == IOU_SIOU) {
+    const D4 scw = (dconst(b2x1 + b2x2) - b1x1 - b1x2) * 0.5f, sch = (dconst(b2y1 + b2y2) - b1y1 - b1y2) * 0.5f;
+    const D4 sigma = dsqrt(dsqr(scw) + dsqr(sch));
+    const D4 sa1 = dabs(scw) / sigma, sa2 = dabs(sch) / sigma;
+    const D4 sa = sa1.v > 0.70710678118654752f ? sa2 : sa1;
+    // cos(2 asin(s) - pi/2) = sin(2 asin s) = 2 s sqrt(1 - s^2);  d/ds = cos(2 asin s) * 2 / sqrt(1 - s^2)
+    const float as = asinf(sa.v);
+    const float om = sqrtf(fmaxf(1.f - sa.v * sa.v, 1e-30f));
+    const D4 angle = dchain(sa, cosf(as * 2.f - 1.57079632679489661923f), cosf(2.f * as) * 2.f / om);
+    const D4 rx = dsqr(scw / cw), ry = dsqr(sch / ch);
+    const D4 gamma = angle - 2.f;
+    const D4 dist = dconst(2.f) - dexp(gamma * rx) - dexp(gamma * ry);
+    const D4 cw2 = dconst(w2), chh2 = dconst(h2);
+    const D4 ow = dabs(w1 - cw2) / dmax(w1, cw2), oh = dabs(h1 - chh2) / dmax(h1, chh2);
+    const D4 shape = dpow4(dconst(1.f) - dexp(ow * -1.f)) + dpow4(dconst(1.f) - dexp(oh * -1.f));
+    iou = iou - (dist + shape) * 0.5f;
+  }
+  if (loss) loss[i] = 1.0f - iou.v;
+  if (dpred) {
+    const float gl = dloss ? dloss[i] : 1.f;
+    for (int c = 0; c < 4; ++c) dpred[(size_t)i * 4 + c] = -iou.d[c] * gl;
+  }
+}
+
+extern "C" int mi_iou_loss_v6(const float* pred, const float* target, int n, int iou_type, int box_xyxy, float eps,
+                              const float* dloss, float* loss, float* dpred, mi_stream_t st) {
+  MI_REQUIRE(pred && target && (loss || dpred) && n >= 0, "iou_loss_v6: args");
+  MI_REQUIRE(iou_type >= IOU_PLAIN && iou_type <= IOU_SIOU, "iou_loss_v6: type %d", iou_type);
+  if (n == 0) return MI_OK;
+  hipLaunchKernelGGL(iou_loss_v6_kernel, dim3(mi_cdiv(n, 256)), dim3(256), 0, (hipStream_t)st, pred, target, n, iou_type,
+                     box_xyxy, eps, dloss, loss, dpred);
+  MI_CHECK_LAUNCH("iou_loss_v6");
+  return MI_OK;
+}

@@ -4,3 +4,4 @@ from .yolox import YOLOX
 from .yolox_net import CSPDarknet, YOLOPAFPN, YOLOXHead, build_cspdarknetx_backbone
 from .detr_matcher import HungarianMatcher
 from .attention import mha_core
+from .iou_loss import IOUlossV6
