@@ -268,6 +268,16 @@ int mi_mha_bwd(const void* q, const void* k, const void* v, const uint8_t* key_p
                const float* lse, const void* dout, float* delta_ws, void* dq, void* dk, void* dv, int B, int H,
                int Lq, int Lk, int E, float scale, mi_stream_t s);
 
+/* ---- row-wise ops of DETR's transformer layers (detr_backbone.py:135-278) -------------------
+ * nn.LayerNorm(E) forward / backward over bf16 [T][E] token rows (fp32 gamma/beta/mean/rstd), eps 1e-5;
+ * E %% 64 == 0, E <= 1024; ws (backward): fp32 [ceil(T/64)][E][2].  mi_ew_bf16: op 0 out = a + b (residual),
+ * op 1 out = relu(a), op 2 out = a * (b > 0) (ReLU backward: a = dy, b = forward output); n %% 8 == 0. */
+int mi_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int T,
+                     int E, float eps, mi_stream_t s);
+int mi_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
+                     float* dgamma, float* dbeta, float* ws, int T, int E, mi_stream_t s);
+int mi_ew_bf16(const void* a, const void* b, void* out, int64_t n, int op, mi_stream_t s);
+
 /* ---- IoU-family regression losses (CIoU / DIoU / GIoU / SIoU / IoU) with gradient ------
  * replaces IOUlossV6.__call__ + its autograd backward (utils/boxes.py:666-752; YOLOv6 head, yolov6_head.py:346,512):
  * loss[n] = 1 - iou_variant(pred[n], target[n]) (reduction "none"), dpred[n][4] = dloss[n] * d loss / d pred

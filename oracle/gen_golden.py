@@ -142,6 +142,29 @@ def gold_iou_v6():
     print("iou_v6:", {k: float(np.abs(v).mean()) for k, v in res.items()})
 
 
+def gold_encoder_layer():
+    """the reference's own TransformerEncoderLayer (backbone/detr_backbone.py:135-194), eval mode (dropout off), fp32"""
+    import importlib
+    from gen_golden_inputs import synth_encoder_case, encoder_state_dict
+    ref_loader.load()
+    m = importlib.import_module("yolov7.modeling.backbone.detr_backbone")
+    res = {}
+    for name, pre in (("post", False), ("pre", True)):
+        layer = m.TransformerEncoderLayer(256, 8, 2048, dropout=0.1, normalize_before=pre)
+        layer.load_state_dict(encoder_state_dict())
+        layer.eval()
+        src, pos, mask, go = synth_encoder_case()
+        x = src.clone().requires_grad_(True)
+        out = layer(x, src_key_padding_mask=mask, pos=pos)
+        out.backward(go)
+        res[name + "_out"] = out.detach().numpy()
+        res[name + "_dsrc"] = x.grad.numpy()
+        for k, p in layer.named_parameters():   # large matrices: every 16th row keeps the fixture small
+            res[f"{name}_g:{k}"] = (p.grad[::16] if p.dim() == 2 else p.grad).numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "encoder_layer.npz"), **res)
+    print("encoder_layer:", {k: float(np.abs(v).mean()) for k, v in res.items() if "out" in k or "dsrc" in k})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -150,3 +173,4 @@ if __name__ == "__main__":
     gold_postprocess()
     gold_hungarian()
     gold_iou_v6()
+    gold_encoder_layer()

@@ -11,3 +11,26 @@ def synth_box_pairs(n, seed):
     tgt = torch.cat([c + 30 * (torch.rand(n, 2, generator=g) - 0.5), wh * (0.6 + 0.8 * torch.rand(n, 2, generator=g))], 1)
     tgt[: n // 8] = torch.cat([c[: n // 8] + 300, wh[: n // 8]], 1)     # some disjoint pairs
     return pred, tgt
+
+
+def synth_encoder_case(L=70, B=2, E=256, seed=61):
+    """seeded inputs of one DETR encoder layer call: tokens, positional embedding, key-padding mask, output gradient"""
+    g = torch.Generator().manual_seed(seed)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    src = bf(torch.randn(L, B, E, generator=g))
+    pos = bf(0.5 * torch.randn(L, B, E, generator=g))
+    go = bf(torch.randn(L, B, E, generator=g))
+    mask = torch.zeros(B, L, dtype=torch.bool)
+    mask[1, L - L // 4:] = True
+    return src, pos, mask, go
+
+
+def encoder_state_dict(E=256, ff=2048, seed=62):
+    """seeded parameters with the reference's key names (TransformerEncoderLayer state_dict)"""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, sc=0.05: sc * torch.randn(*s, generator=g)
+    return {"self_attn.in_proj_weight": r(3 * E, E), "self_attn.in_proj_bias": r(3 * E, sc=0.02),
+            "self_attn.out_proj.weight": r(E, E), "self_attn.out_proj.bias": r(E, sc=0.02),
+            "linear1.weight": r(ff, E), "linear1.bias": r(ff, sc=0.02), "linear2.weight": r(E, ff, sc=0.02),
+            "linear2.bias": r(E, sc=0.02), "norm1.weight": 1 + r(E, sc=0.1), "norm1.bias": r(E, sc=0.1),
+            "norm2.weight": 1 + r(E, sc=0.1), "norm2.bias": r(E, sc=0.1)}

@@ -131,3 +131,33 @@ def test_iou_loss_v6_against_reference_golden(golden_dir, iou_type):
     loss.sum().backward()
     np.testing.assert_allclose(loss.detach().cpu().numpy(), g[iou_type + "_loss"], rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(p.grad.cpu().numpy(), g[iou_type + "_grad"], rtol=2e-3, atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------ transformer encoder layer
+@pytest.mark.parametrize("name,pre", [("post", False), ("pre", True)])
+def test_transformer_encoder_layer_against_reference_golden(golden_dir, name, pre):
+    """our TransformerEncoderLayer (HIP kernels: 1x1-conv linears, fused MFMA attention, LayerNorm) loaded with the
+    reference's state_dict vs the reference's own layer (fp32, eval mode): outputs and all gradients, bf16 tolerance"""
+    import sys
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle")
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    from gen_golden_inputs import synth_encoder_case, encoder_state_dict
+    from yolov7_d2_amd.modeling import TransformerEncoderLayer
+    g = np.load(os.path.join(golden_dir, "encoder_layer.npz"))
+    layer = TransformerEncoderLayer(256, 8, 2048, dropout=0.1, normalize_before=pre)
+    layer.load_state_dict(encoder_state_dict())      # same keys as the reference module
+    layer.to(DEV).eval()
+    src, pos, mask, go = synth_encoder_case()
+    x = src.to(DEV, torch.bfloat16).requires_grad_(True)
+    out = layer(x, src_key_padding_mask=mask.to(DEV), pos=pos.to(DEV, torch.bfloat16))
+    out.backward(go.to(DEV, torch.bfloat16))
+    torch.cuda.synchronize()
+    rel = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-12))
+    assert rel(out.detach().float().cpu().numpy(), g[name + "_out"]) < 2e-2
+    assert rel(x.grad.float().cpu().numpy(), g[name + "_dsrc"]) < 4e-2
+    # parameter gradients (golden keeps every 16th row of the matrices): bf16 storage noise through LayerNorm / ReLU
+    # masks / softmax gives 2-5 % norm-relative differences against the fp32 reference
+    for k, p in layer.named_parameters():
+        got = (p.grad[::16] if p.dim() == 2 else p.grad).float().cpu().numpy()
+        assert rel(got, g[f"{name}_g:{k}"]) < 7e-2, k

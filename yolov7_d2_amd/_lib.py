@@ -134,6 +134,9 @@ _PROTOS = {
     "mi_lsap": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mi_mha_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "mi_mha_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "mi_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "mi_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "mi_ew_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i, _vp]),
     "mi_iou_loss_v6": (C.c_int, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "mi_batched_nms": (C.c_int, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_sgd_momentum_step": (C.c_int, [_vp, _vp, _vp, _vp, _i, _f, _f, _i, _vp]),

@@ -1,0 +1,135 @@
+// Row-wise ops around the attention core of DETR's transformer layers (modeling/backbone/detr_backbone.py:135-278):
+// LayerNorm forward / backward (nn.LayerNorm(d_model), eps 1e-5, biased variance), ReLU backward mask, residual add.
+// bf16 [T][E] token tensors (T = L*B rows), fp32 statistics and parameters.  All HBM streams; one wave per row.
+#include "common.h"
+
+// ---- LayerNorm forward: y = (x - mean) * rstd * gamma + beta ; saves mean / rstd [T]
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const __bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, __bf16* y, float* mean,
+                                                            float* rstd, int T, int E, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= T) return;
+  const __bf16* xr = x + (size_t)row * E;
+  float v[16];  // E <= 1024: 16 values per lane
+  const int per = E / 64;
+  float s = 0.f;
+  for (int j = 0; j < per; ++j) { v[j] = (float)xr[lane + 64 * j]; s += v[j]; }
+  const float mu = wave_sum(s) / (float)E;
+  float q = 0.f;
+  for (int j = 0; j < per; ++j) { const float d = v[j] - mu; q += d * d; }
+  const float rs = rsqrtf(wave_sum(q) / (float)E + eps);
+  for (int j = 0; j < per; ++j) {
+    const int c = lane + 64 * j;
+    y[(size_t)row * E + c] = (__bf16)((v[j] - mu) * rs * gamma[c] + beta[c]);
+  }
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// ---- LayerNorm backward: dx per row; dgamma / dbeta as block partials [nblk][E][2] (second stage below)
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ dy,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, __bf16* dx, float* part,
+                                                            int T, int E, int rows_per_block) {
+  extern __shared__ float sacc[];  // [4 waves][E][2]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int per = E / 64;
+  float ag[16], ab[16];
+  for (int j = 0; j < per; ++j) ag[j] = ab[j] = 0.f;
+  const int r0 = blockIdx.x * rows_per_block;
+  for (int rr = wave; rr < rows_per_block; rr += 4) {
+    const int row = r0 + rr;
+    if (row >= T) break;
+    const float mu = mean[row], rs = rstd[row];
+    float xh[16], g[16];
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < per; ++j) {
+      const int c = lane + 64 * j;
+      const float d = (float)dy[(size_t)row * E + c];
+      xh[j] = ((float)x[(size_t)row * E + c] - mu) * rs;
+      g[j] = d * gamma[c];
+      s1 += g[j];
+      s2 += g[j] * xh[j];
+      ag[j] += d * xh[j];
+      ab[j] += d;
+    }
+    s1 = wave_sum(s1) / (float)E;
+    s2 = wave_sum(s2) / (float)E;
+    for (int j = 0; j < per; ++j)
+      dx[(size_t)row * E + lane + 64 * j] = (__bf16)(rs * (g[j] - s1 - xh[j] * s2));
+  }
+  for (int j = 0; j < per; ++j) {
+    sacc[(wave * E + lane + 64 * j) * 2 + 0] = ag[j];
+    sacc[(wave * E + lane + 64 * j) * 2 + 1] = ab[j];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < E; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (int w = 0; w < 4; ++w) { a += sacc[(w * E + c) * 2]; b += sacc[(w * E + c) * 2 + 1]; }
+    part[((size_t)blockIdx.x * E + c) * 2 + 0] = a;
+    part[((size_t)blockIdx.x * E + c) * 2 + 1] = b;
+  }
+}
+__global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const float* __restrict__ part, int nblk, int E,
+                                                                   float* dgamma, float* dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= E) return;
+  float a = 0.f, b = 0.f;
+  for (int k = 0; k < nblk; ++k) { a += part[((size_t)k * E + c) * 2]; b += part[((size_t)k * E + c) * 2 + 1]; }
+  dgamma[c] = a;
+  dbeta[c] = b;
+}
+
+extern "C" int mi_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                int T, int E, float eps, mi_stream_t st) {
+  MI_REQUIRE(x && gamma && beta && y && mean && rstd && T > 0, "layernorm_fwd: args");
+  MI_REQUIRE(E % 64 == 0 && E <= 1024, "layernorm_fwd: E %d (multiple of 64, <= 1024)", E);
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(mi_cdiv(T, 4)), dim3(256), 0, (hipStream_t)st, (const __bf16*)x, gamma, beta,
+                     (__bf16*)y, mean, rstd, T, E, eps);
+  MI_CHECK_LAUNCH("layernorm_fwd");
+  return MI_OK;
+}
+/* ws: fp32 [ceil(T/64)][E][2] */
+extern "C" int mi_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd,
+                                void* dx, float* dgamma, float* dbeta, float* ws, int T, int E, mi_stream_t st) {
+  MI_REQUIRE(x && dy && gamma && mean && rstd && dx && dgamma && dbeta && ws && T > 0, "layernorm_bwd: args");
+  MI_REQUIRE(E % 64 == 0 && E <= 1024, "layernorm_bwd: E %d", E);
+  const int rpb = 64, nblk = mi_cdiv(T, rpb);
+  hipStream_t s = (hipStream_t)st;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), (size_t)4 * E * 2 * sizeof(float), s, (const __bf16*)x,
+                     (const __bf16*)dy, gamma, mean, rstd, (__bf16*)dx, ws, T, E, rpb);
+  MI_CHECK_LAUNCH("layernorm_bwd");
+  hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3(mi_cdiv(E, 256)), dim3(256), 0, s, ws, nblk, E, dgamma, dbeta);
+  MI_CHECK_LAUNCH("layernorm_bwd_params");
+  return MI_OK;
+}
+
+// ---- elementwise: out = a + b ; out = relu(a) ; dx = dy * (y > 0)        (n multiple of 8, 16-byte aligned)
+__global__ __launch_bounds__(256) void ew_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ b, __bf16* o,
+                                                 int64_t n8, int op) {
+  for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const bf16x8 va = *(const bf16x8*)(a + i * 8);
+    bf16x8 vb = va;
+    if (b) vb = *(const bf16x8*)(b + i * 8);
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = (float)va[e], y = (float)vb[e];
+      float z;
+      if (op == 0) z = x + y;
+      else if (op == 1) z = fmaxf(x, 0.f);
+      else z = y > 0.f ? x : 0.f;  // op 2: a = dy, b = forward output
+      r[e] = (__bf16)z;
+    }
+    *(bf16x8*)(o + i * 8) = r;
+  }
+}
+extern "C" int mi_ew_bf16(const void* a, const void* b, void* out, int64_t n, int op, mi_stream_t st) {
+  MI_REQUIRE(a && out && n > 0 && n % 8 == 0 && op >= 0 && op <= 2 && (op == 1 || b), "ew_bf16: args");
+  MI_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && ((uintptr_t)out % 16) == 0, "ew_bf16: alignment");
+  int64_t blocks = (n / 8 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(ew_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)st, (const __bf16*)a, (const __bf16*)b,
+                     (__bf16*)out, n / 8, op);
+  MI_CHECK_LAUNCH("ew_bf16");
+  return MI_OK;
+}

@@ -5,3 +5,4 @@ from .yolox_net import CSPDarknet, YOLOPAFPN, YOLOXHead, build_cspdarknetx_backb
 from .detr_matcher import HungarianMatcher
 from .attention import mha_core
 from .iou_loss import IOUlossV6
+from .transformer import MultiheadAttention, TransformerEncoderLayer

@@ -1,0 +1,235 @@
+"""DETR transformer encoder layer on the MI355X kernels — drop-in for
+yolov7/modeling/backbone/detr_backbone.py:135-194 (`TransformerEncoderLayer`) and the `nn.MultiheadAttention` /
+`nn.Linear` / `nn.LayerNorm` it is built from (config 4 of BASELINE.json).
+
+Same constructor, attribute names and state_dict keys as the reference (self_attn.in_proj_weight / in_proj_bias /
+out_proj.{weight,bias}, linear1, linear2, norm1, norm2), same forward signature.  Every op runs in libmi355det:
+  * nn.Linear       -> the implicit-GEMM conv kernel as a 1x1 convolution over the token rows (fwd, dgrad, wgrad)
+  * attention core  -> mi_mha_fwd / mi_mha_bwd (fused MFMA attention, key-padding mask)
+  * nn.LayerNorm    -> mi_layernorm_fwd / bwd
+  * residual / ReLU -> mi_ew_bf16
+Tokens are bf16 [L, B, E] (sequence first, as the reference passes them).  Dropout: the reference trains with
+p = 0.1 (torch RNG stream: no parity target exists for it); this layer implements p = 0 / eval semantics and raises
+for p > 0 in training mode.
+"""
+import ctypes as C
+import math
+
+import torch
+from torch import nn
+
+from .. import _lib as L
+from .attention import mha_core
+
+
+def _rup(a, b):
+    return (a + b - 1) // b * b
+
+
+def _factor(T):
+    for w in (64, 32, 16, 8, 4, 2, 1):
+        if T % w == 0:
+            return T // w, w
+
+
+def _conv1x1(x, w_img, y, T, K, Cout, CoutPad, bias=None):
+    H, W = _factor(T)
+    d = L.mi_conv_desc()
+    d.x, d.w, d.y = x.data_ptr(), w_img.data_ptr(), y.data_ptr()
+    d.bias = L.ptr(bias)
+    d.ldx, d.ldy = x.shape[-1], y.shape[-1]
+    d.N, d.H, d.W, d.outH, d.outW, d.gridH, d.gridW = 1, H, W, H, W, H, W
+    d.in_stride = d.out_stride = 1
+    d.K8, d.Cout, d.CoutPad, d.ntaps = K // 8, Cout, CoutPad, 1
+    L.check(L.lib().mi_conv2d(C.byref(d), L.stream_ptr()), "mi_conv2d (linear)")
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b over token rows; x bf16 [T, Cin], W fp32 [Cout, Cin] (nn.Linear layout), b fp32 [Cout]"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        T, Cin = x.shape
+        Cout = weight.shape[0]
+        assert Cin % 32 == 0 and Cout % 32 == 0, "linear: channels must be multiples of 32"
+        dev = x.device
+        wf = torch.empty(Cin // 8 * Cout * 8, dtype=torch.bfloat16, device=dev)
+        wd = torch.empty(Cout // 8 * Cin * 8, dtype=torch.bfloat16, device=dev)
+        w32 = weight.detach().float().contiguous()
+        L.check(L.lib().mi_pack_conv_weight(w32.data_ptr(), Cout, Cin, 1, 1, wf.data_ptr(), Cin, Cout, wd.data_ptr(), Cout,
+                                            Cin, L.stream_ptr()), "mi_pack_conv_weight")
+        y = torch.empty(T, Cout, dtype=torch.bfloat16, device=dev)
+        b32 = None if bias is None else bias.detach().float().contiguous()
+        _conv1x1(x, wf, y, T, Cin, Cout, Cout, b32)
+        ctx.save_for_backward(x, wd)
+        ctx.dims = (T, Cin, Cout, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wd = ctx.saved_tensors
+        T, Cin, Cout, has_bias = ctx.dims
+        dev = x.device
+        dy = dy.contiguous()
+        dx = torch.empty(T, Cin, dtype=torch.bfloat16, device=dev)
+        _conv1x1(dy, wd, dx, T, Cout, Cin, Cin)
+        # weight gradient
+        gw = torch.empty(Cout, Cin, dtype=torch.float32, device=dev)
+        H, W = _factor(T)
+        d = L.mi_wgrad_desc()
+        d.x, d.dy, d.gw = x.data_ptr(), dy.data_ptr(), gw.data_ptr()
+        d.ldx, d.ldy, d.N, d.H, d.W, d.outH, d.outW, d.stride = Cin, Cout, 1, H, W, H, W, 1
+        d.Cin, d.Cout, d.CinPad, d.CoutPad, d.ntaps = Cin, Cout, Cin, Cout, 1
+        need = L.lib().mi_conv2d_wgrad_plan(C.byref(d))
+        L.check(need, "mi_conv2d_wgrad_plan")
+        ws = torch.empty(max(int(need), 16), dtype=torch.uint8, device=dev)
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
+        L.check(L.lib().mi_conv2d_wgrad(C.byref(d), L.stream_ptr()), "mi_conv2d_wgrad (linear)")
+        gb = None
+        if has_bias:
+            gb = torch.empty(Cout, dtype=torch.float32, device=dev)
+            cws = torch.empty(128 * 128, dtype=torch.float32, device=dev)
+            for c0 in range(0, Cout, 128):   # column sums in blocks of <= 128 channels
+                nc = min(128, Cout - c0)
+                L.check(L.lib().mi_colsum_bf16(dy.data_ptr() + 2 * c0, Cout, T, nc, gb.data_ptr() + 4 * c0, 0,
+                                               cws.data_ptr(), L.stream_ptr()), "mi_colsum_bf16")
+        return dx, gw, gb
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        T, E = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(T, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(T, dtype=torch.float32, device=x.device)
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        L.check(L.lib().mi_layernorm_fwd(x.data_ptr(), g32.data_ptr(), b32.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                         rstd.data_ptr(), T, E, eps, L.stream_ptr()), "mi_layernorm_fwd")
+        ctx.save_for_backward(x, g32, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g32, mean, rstd = ctx.saved_tensors
+        T, E = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg = torch.empty(E, dtype=torch.float32, device=x.device)
+        db = torch.empty(E, dtype=torch.float32, device=x.device)
+        ws = torch.empty((T + 63) // 64 * E * 2, dtype=torch.float32, device=x.device)
+        L.check(L.lib().mi_layernorm_bwd(x.data_ptr(), dy.data_ptr(), g32.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                         dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), T, E,
+                                         L.stream_ptr()), "mi_layernorm_bwd")
+        return dx, dg, db, None
+
+
+def _ew(a, b, op):
+    out = torch.empty_like(a)
+    L.check(L.lib().mi_ew_bf16(a.data_ptr(), L.ptr(b), out.data_ptr(), a.numel(), op, L.stream_ptr()), "mi_ew_bf16")
+    return out
+
+
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return _ew(a.contiguous(), b.contiguous(), 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class _ReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a):
+        y = _ew(a.contiguous(), None, 1)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return _ew(g.contiguous(), y, 2)
+
+
+def _tok(x):
+    if not x.is_cuda:
+        raise L.MI355Error("transformer: the MI355X path needs device tensors (no CPU fallback)")
+    return x.to(torch.bfloat16).contiguous()
+
+
+class MultiheadAttention(nn.Module):
+    """nn.MultiheadAttention(embed_dim, num_heads) with the reference's usage: separate query/key/value, key_padding_mask,
+    no attn_mask, batch_first=False; parameters named as torch names them."""
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0):
+        super().__init__()
+        assert embed_dim == num_heads * 32, "the MFMA attention kernel is built for head_dim 32 (DETR: 256 = 8 x 32)"
+        self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+
+    def forward(self, query, key, value, attn_mask=None, key_padding_mask=None):
+        if attn_mask is not None:
+            raise NotImplementedError("attn_mask (the reference always passes None)")
+        if self.training and self.dropout > 0:
+            raise NotImplementedError("attention dropout > 0 in training mode (see module docstring)")
+        E = self.embed_dim
+        Lq, B, _ = query.shape
+        Lk = key.shape[0]
+        w, b = self.in_proj_weight, self.in_proj_bias
+        q = _LinearFn.apply(_tok(query).view(Lq * B, E), w[:E], b[:E]).view(Lq, B, E)
+        k = _LinearFn.apply(_tok(key).view(Lk * B, E), w[E:2 * E], b[E:2 * E]).view(Lk, B, E)
+        v = _LinearFn.apply(_tok(value).view(Lk * B, E), w[2 * E:], b[2 * E:]).view(Lk, B, E)
+        o = mha_core(q, k, v, key_padding_mask, self.num_heads)
+        out = _LinearFn.apply(o.reshape(Lq * B, E), self.out_proj.weight, self.out_proj.bias).view(Lq, B, E)
+        return out, None
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", normalize_before=False):
+        super().__init__()
+        if activation != "relu":
+            raise NotImplementedError(activation)
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.dropout_p = dropout
+        self.normalize_before = normalize_before
+
+    @staticmethod
+    def with_pos_embed(tensor, pos):
+        return tensor if pos is None else _AddFn.apply(_tok(tensor), _tok(pos))
+
+    def _ln(self, norm, x):
+        Lx, B, E = x.shape
+        return _LayerNormFn.apply(x.reshape(Lx * B, E), norm.weight, norm.bias, norm.eps).view(Lx, B, E)
+
+    def _ffn(self, x):
+        Lx, B, E = x.shape
+        h = _LinearFn.apply(x.reshape(Lx * B, E), self.linear1.weight, self.linear1.bias)
+        h = _ReluFn.apply(h)
+        return _LinearFn.apply(h, self.linear2.weight, self.linear2.bias).view(Lx, B, E)
+
+    def forward(self, src, src_mask=None, src_key_padding_mask=None, pos=None):
+        if self.training and self.dropout_p > 0:
+            raise NotImplementedError("dropout > 0 in training mode (see module docstring)")
+        src = _tok(src)
+        if self.normalize_before:   # forward_pre (detr_backbone.py:170-182)
+            src2 = self._ln(self.norm1, src)
+            q = k = self.with_pos_embed(src2, pos)
+            src2 = self.self_attn(q, k, value=src2, attn_mask=src_mask, key_padding_mask=src_key_padding_mask)[0]
+            src = _AddFn.apply(src, src2)
+            src2 = self._ffn(self._ln(self.norm2, src))
+            return _AddFn.apply(src, src2)
+        # forward_post (detr_backbone.py:156-168)
+        q = k = self.with_pos_embed(src, pos)
+        src2 = self.self_attn(q, k, value=src, attn_mask=src_mask, key_padding_mask=src_key_padding_mask)[0]
+        src = self._ln(self.norm1, _AddFn.apply(src, src2))
+        src2 = self._ffn(src)
+        return self._ln(self.norm2, _AddFn.apply(src, src2))
