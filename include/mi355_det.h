@@ -255,6 +255,30 @@ int mi_hungarian_match(const float* logits, const float* boxes, const int64_t* t
 int mi_lsap(const float* cost, const int32_t* tgt_off, int B, int Q, int gmax, int64_t* match_q,
             int64_t* match_t, int32_t* nmatch, mi_stream_t s);
 
+/* DETR set-prediction losses for the match indices above, forward + backward.
+ * replaces SetCriterion.loss_labels / loss_cardinality / loss_boxes (modeling/meta_arch/detr.py:504-556) and their
+ * autograd backward.  NC = num_classes + 1 (last class = no-object, weight eos_coef); num_boxes as detr.py:615-619
+ * computes it (host).  losses[8] = loss_ce, class_error, cardinality_error, loss_bbox, loss_giou, sum of CE weights,
+ * matched pairs, 0.  rowstate: caller workspace of B*Q*16 floats, written by fwd and read by bwd.
+ * bwd: gw[3] on device = upstream gradients of (loss_ce, loss_bbox, loss_giou); dlogits [B][Q][NC], dboxes [B][Q][4].
+ * B <= 256. */
+typedef struct mi_detr_loss_desc {
+  const float* logits;
+  const float* boxes;
+  const int64_t* tgt_labels;
+  const float* tgt_boxes;
+  const int32_t* tgt_off;
+  const int64_t* match_q;
+  const int64_t* match_t;
+  const int32_t* nmatch;
+  int32_t B, Q, NC, gmax;
+  float eos_coef, num_boxes;
+  float* losses;
+  float* rowstate;
+} mi_detr_loss_desc;
+int mi_detr_set_loss_fwd(const mi_detr_loss_desc* d, mi_stream_t s);
+int mi_detr_set_loss_bwd(const mi_detr_loss_desc* d, const float* gw, float* dlogits, float* dboxes, mi_stream_t s);
+
 /* ---- multi-head attention core (DETR, config 4) -------------------------------------
  * O = softmax(scale * Q K^T + key_padding_mask) V per (batch, head); head_dim = 32 (DETR: 256 = 8 x 32).
  * replaces the attention inside nn.MultiheadAttention as called by the transformer layers

@@ -165,6 +165,62 @@ def gold_encoder_layer():
     print("encoder_layer:", {k: float(np.abs(v).mean()) for k, v in res.items() if "out" in k or "dsrc" in k})
 
 
+def gold_set_criterion():
+    """the reference's own SetCriterion (meta_arch/detr.py:475-647) with its own HungarianMatcher, DETR weights
+    (config.py:214-219: giou 2, l1 5, eos 0.1, deep supervision = aux outputs) + autograd of the weighted total"""
+    import detr_oracle as D
+    r = ref_loader.load()
+    det = ref_loader.load_detr()
+    res = {}
+    cases = dict(a=(3, 100, 91, 81, None), b=(2, 100, 80, 82, [100, 0]), c=(2, 16, 20, 83, [30, 7]))
+    for name, (bs, nq, ncls, seed, sizes) in cases.items():
+        outs, targets = D.synth_detr_levels(bs, nq, ncls, seed, levels=3, sizes=sizes)
+        leaves = [(l.clone().requires_grad_(True), b.clone().requires_grad_(True)) for l, b in outs]
+        outputs = {"pred_logits": leaves[-1][0], "pred_boxes": leaves[-1][1],
+                   "aux_outputs": [{"pred_logits": l, "pred_boxes": b} for l, b in leaves[:-1]]}
+        wd = {"loss_ce": 1.0, "loss_bbox": 5.0, "loss_giou": 2.0}
+        wd.update({k + f"_{i}": v for i in range(2) for k, v in list(wd.items())[:3]})
+        crit = det.SetCriterion(ncls, r.detr_utils.HungarianMatcher(1.0, 5.0, 2.0), wd, 0.1, ["labels", "boxes", "cardinality"])
+        ld = crit(outputs, targets)
+        total = sum(ld[k] * wd[k] for k in ld if k in wd)
+        total.backward()
+        for k, v in ld.items():
+            res[f"{name}:{k}"] = np.float32(v.detach().item())
+        res[f"{name}:total"] = np.float32(total.item())
+        for i, (l, b) in enumerate(leaves):
+            res[f"{name}:dlogits{i}"], res[f"{name}:dboxes{i}"] = l.grad.numpy(), b.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "set_criterion.npz"), **res)
+    print("set_criterion:", {k: float(v) for k, v in res.items() if k.startswith("a:") and v.ndim == 0})
+
+
+def gold_transformer():
+    """the reference's own Transformer (backbone/detr_backbone.py:25-65): 2 encoder + 2 decoder layers, d_model 256,
+    8 heads, ffn 512, return_intermediate_dec, eval mode, fp32; post- and pre-norm"""
+    import importlib
+    from gen_golden_inputs import synth_transformer_case, seeded_state_dict
+    ref_loader.load()
+    m = importlib.import_module("yolov7.modeling.backbone.detr_backbone")
+    res = {}
+    for name, pre in (("post", False), ("pre", True)):
+        net = m.Transformer(256, 8, 2, 2, 512, 0.1, normalize_before=pre, return_intermediate_dec=True)
+        net.load_state_dict(seeded_state_dict(net))
+        net.eval()
+        src, mask, qe, pos = synth_transformer_case()
+        x = src.clone().requires_grad_(True)
+        q = qe.clone().requires_grad_(True)
+        hs, mem = net(x, mask, q, pos)
+        gh = torch.randn(hs.shape, generator=torch.Generator().manual_seed(73)).to(torch.bfloat16).float()
+        (hs * gh).sum().backward()
+        res[name + "_hs"] = hs.detach().numpy()
+        res[name + "_mem"] = mem.detach().numpy()
+        res[name + "_dsrc"] = x.grad.numpy()
+        res[name + "_dquery"] = q.grad.numpy()
+        for k, p in net.named_parameters():   # matrices: every 32nd row keeps the fixture small
+            res[f"{name}_g:{k}"] = (p.grad[::32] if p.dim() == 2 else p.grad).numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "transformer.npz"), **res)
+    print("transformer:", {k: float(np.abs(v).mean()) for k, v in res.items() if "_g:" not in k})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -174,3 +230,5 @@ if __name__ == "__main__":
     gold_hungarian()
     gold_iou_v6()
     gold_encoder_layer()
+    gold_transformer()
+    gold_set_criterion()

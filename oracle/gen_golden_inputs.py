@@ -34,3 +34,33 @@ def encoder_state_dict(E=256, ff=2048, seed=62):
             "linear1.weight": r(ff, E), "linear1.bias": r(ff, sc=0.02), "linear2.weight": r(E, ff, sc=0.02),
             "linear2.bias": r(E, sc=0.02), "norm1.weight": 1 + r(E, sc=0.1), "norm1.bias": r(E, sc=0.1),
             "norm2.weight": 1 + r(E, sc=0.1), "norm2.bias": r(E, sc=0.1)}
+
+
+def synth_transformer_case(B=2, E=256, H=6, W=10, Q=40, seed=71):
+    """seeded inputs of one DETR Transformer call (detr_backbone.py:56): feature map, padding mask, query embedding,
+    positional embedding, and the gradient fed back into hs"""
+    g = torch.Generator().manual_seed(seed)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    src = bf(torch.randn(B, E, H, W, generator=g))
+    pos = bf(0.5 * torch.randn(B, E, H, W, generator=g))
+    qe = bf(torch.randn(Q, E, generator=g))
+    mask = torch.zeros(B, H, W, dtype=torch.bool)
+    mask[1, :, W - 3:] = True
+    mask[1, H - 1:, :] = True
+    return src, mask, qe, pos
+
+
+def seeded_state_dict(module, seed=72):
+    """seeded parameters for any module, keyed and shaped by the module's own state_dict (sorted key order):
+    LayerNorm weights around 1, matrices N(0, 0.05) (N(0, 0.02) when the fan-in is > 1024), biases N(0, 0.02)"""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k in sorted(module.state_dict().keys()):
+        shp = module.state_dict()[k].shape
+        if "norm" in k and k.endswith("weight"):
+            out[k] = 1 + 0.1 * torch.randn(*shp, generator=g)
+        elif len(shp) == 2:
+            out[k] = (0.02 if shp[1] > 1024 else 0.05) * torch.randn(*shp, generator=g)
+        else:
+            out[k] = 0.02 * torch.randn(*shp, generator=g)
+    return out

@@ -106,6 +106,34 @@ def load():
     return out
 
 
+def load_detr():
+    """the reference's DETR meta-arch file (meta_arch/detr.py: SetCriterion, PostProcess, MLP) loaded by path; the
+    un-installed names it imports at module level (detectron2.structures, fvcore, alfred) are stubbed - none of them is
+    touched by SetCriterion's labels / cardinality / boxes losses"""
+    load()
+    comm = sys.modules["detectron2.utils.comm"]
+    comm.get_world_size = lambda: 1
+    sys.modules["detectron2.utils"].comm = comm
+    dm = sys.modules["detectron2.modeling"]
+    dm.build_backbone = dm.detector_postprocess = None
+    if "detectron2.structures" not in sys.modules:
+        _stub("detectron2.structures", Boxes=object, ImageList=object, Instances=object, BitMasks=object, PolygonMasks=object)
+        _stub("detectron2.utils.logger", log_first_n=lambda *a, **k: None)
+    if "fvcore" not in sys.modules:
+        _stub("fvcore")
+        _stub("fvcore.nn", giou_loss=None, smooth_l1_loss=None)
+    if "alfred" not in sys.modules:
+        _stub("alfred")
+        _stub("alfred.utils")
+        _stub("alfred.utils.log", logger=sys.modules["loguru"].logger)
+    name = "yolov7.modeling.meta_arch"
+    if name not in sys.modules:
+        m = types.ModuleType(name)
+        m.__path__ = [os.path.join(REF, "yolov7", "modeling", "meta_arch")]
+        sys.modules[name] = m
+    return importlib.import_module("yolov7.modeling.meta_arch.detr")
+
+
 def build_reference_yolox(depth=0.33, width=0.5, num_classes=80, seed=0):
     """CSPDarknet + YOLOPAFPN + YOLOXHead assembled the way YOLOX.__init__ does (yolox.py:60-83)"""
     import torch

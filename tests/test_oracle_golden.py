@@ -92,3 +92,35 @@ def test_detr_matcher_oracle_against_reference_golden(golden_dir):
         idx, _ = D.hungarian_match(logits, boxes, targets, 1.0, 5.0, 2.0)
         for b, (i, j) in enumerate(idx):
             assert np.array_equal(i.numpy(), g[f"{name}_i{b}"]) and np.array_equal(j.numpy(), g[f"{name}_j{b}"])
+
+
+SET_CRIT_CASES = dict(a=(3, 100, 91, 81, None), b=(2, 100, 80, 82, [100, 0]), c=(2, 16, 20, 83, [30, 7]))
+SET_CRIT_W = {"loss_ce": 1.0, "loss_bbox": 5.0, "loss_giou": 2.0}
+
+
+def set_crit_weights(naux=2):
+    wd = dict(SET_CRIT_W)
+    wd.update({k + f"_{i}": v for i in range(naux) for k, v in SET_CRIT_W.items()})
+    return wd
+
+
+def test_detr_set_criterion_oracle_against_reference_golden(golden_dir):
+    """oracle/detr_oracle.py::set_criterion == the reference's own SetCriterion (+ its matcher) run by path: every
+    loss of every decoder level, and the gradients of the weighted total wrt logits and boxes"""
+    import detr_oracle as D
+    g = np.load(os.path.join(golden_dir, "set_criterion.npz"))
+    wd = set_crit_weights()
+    for name, (bs, nq, ncls, seed, sizes) in SET_CRIT_CASES.items():
+        outs, targets = D.synth_detr_levels(bs, nq, ncls, seed, levels=3, sizes=sizes)
+        leaves = [(l.clone().requires_grad_(True), b.clone().requires_grad_(True)) for l, b in outs]
+        outputs = {"pred_logits": leaves[-1][0], "pred_boxes": leaves[-1][1],
+                   "aux_outputs": [{"pred_logits": l, "pred_boxes": b} for l, b in leaves[:-1]]}
+        ld = D.set_criterion(outputs, targets, ncls, 0.1)
+        keys = {k.split(":", 1)[1] for k in g.files if k.startswith(name + ":") and g[k].ndim == 0} - {"total"}
+        assert set(ld.keys()) == keys
+        for k in keys:
+            np.testing.assert_allclose(float(ld[k].detach()), float(g[f"{name}:{k}"]), rtol=2e-6, atol=1e-6, err_msg=k)
+        sum(ld[k] * wd[k] for k in ld if k in wd).backward()
+        for i, (l, b) in enumerate(leaves):
+            np.testing.assert_allclose(l.grad.numpy(), g[f"{name}:dlogits{i}"], rtol=1e-5, atol=1e-8)
+            np.testing.assert_allclose(b.grad.numpy(), g[f"{name}:dboxes{i}"], rtol=1e-5, atol=1e-7)

@@ -35,6 +35,16 @@ class mi_conv_desc(C.Structure):
     ]
 
 
+class mi_detr_loss_desc(C.Structure):
+    _fields_ = [
+        ("logits", C.c_void_p), ("boxes", C.c_void_p), ("tgt_labels", C.c_void_p), ("tgt_boxes", C.c_void_p),
+        ("tgt_off", C.c_void_p), ("match_q", C.c_void_p), ("match_t", C.c_void_p), ("nmatch", C.c_void_p),
+        ("B", C.c_int32), ("Q", C.c_int32), ("NC", C.c_int32), ("gmax", C.c_int32),
+        ("eos_coef", C.c_float), ("num_boxes", C.c_float),
+        ("losses", C.c_void_p), ("rowstate", C.c_void_p),
+    ]
+
+
 class mi_wgrad_desc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("dy", C.c_void_p), ("gw", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
@@ -132,6 +142,8 @@ _PROTOS = {
     "mi_yolox_decode": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
     "mi_hungarian_match": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "mi_lsap": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "mi_detr_set_loss_fwd": (C.c_int, [C.POINTER(mi_detr_loss_desc), _vp]),
+    "mi_detr_set_loss_bwd": (C.c_int, [C.POINTER(mi_detr_loss_desc), _vp, _vp, _vp, _vp]),
     "mi_mha_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "mi_mha_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "mi_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),

@@ -18,9 +18,12 @@ class HungarianMatcher(nn.Module):
         assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0, "all costs cant be 0"
 
     @torch.no_grad()
-    def forward(self, outputs, targets):
-        logits = outputs["pred_logits"].float().contiguous()
-        boxes = outputs["pred_boxes"].float().contiguous()
+    def match_device(self, outputs, targets):
+        """the matching without any host round trip: returns a dict of device tensors (match_q / match_t int64
+        [B][gmax], nmatch int32 [B], tgt_off int32 [B+1], concatenated tgt_labels / tgt_boxes, gmax) in the layout
+        mi_detr_set_loss_* consumes"""
+        logits = outputs["pred_logits"].detach().float().contiguous()
+        boxes = outputs["pred_boxes"].detach().float().contiguous()
         if not logits.is_cuda:
             raise L.MI355Error("HungarianMatcher: the MI355X path needs device tensors (no CPU fallback)")
         bs, nq, nc = logits.shape
@@ -41,5 +44,11 @@ class HungarianMatcher(nn.Module):
                                            float(self.cost_bbox), float(self.cost_giou), cost.data_ptr(), mq.data_ptr(),
                                            mt.data_ptr(), nm.data_ptr(), L.stream_ptr()), "mi_hungarian_match")
         self.last_cost = cost
-        n = nm.tolist()   # one small D2H (the reference moves the whole cost matrix instead)
-        return [(mq[b, : n[b]].clone(), mt[b, : n[b]].clone()) for b in range(bs)]
+        return dict(match_q=mq, match_t=mt, nmatch=nm, tgt_off=off, tgt_labels=tl, tgt_boxes=tb, gmax=gmax,
+                    num_targets=sum(sizes))
+
+    @torch.no_grad()
+    def forward(self, outputs, targets):
+        m = self.match_device(outputs, targets)
+        n = m["nmatch"].tolist()   # one small D2H (the reference moves the whole cost matrix instead)
+        return [(m["match_q"][b, : n[b]].clone(), m["match_t"][b, : n[b]].clone()) for b in range(len(n))]

@@ -1,9 +1,10 @@
-"""DETR transformer encoder layer on the MI355X kernels — drop-in for
-yolov7/modeling/backbone/detr_backbone.py:135-194 (`TransformerEncoderLayer`) and the `nn.MultiheadAttention` /
-`nn.Linear` / `nn.LayerNorm` it is built from (config 4 of BASELINE.json).
+"""DETR transformer on the MI355X kernels — drop-in for yolov7/modeling/backbone/detr_backbone.py:25-278
+(`Transformer`, `TransformerEncoder`, `TransformerDecoder`, `TransformerEncoderLayer`, `TransformerDecoderLayer`) and the
+`nn.MultiheadAttention` / `nn.Linear` / `nn.LayerNorm` they are built from (config 4 of BASELINE.json).
 
-Same constructor, attribute names and state_dict keys as the reference (self_attn.in_proj_weight / in_proj_bias /
-out_proj.{weight,bias}, linear1, linear2, norm1, norm2), same forward signature.  Every op runs in libmi355det:
+Same constructor, attribute names and state_dict keys as the reference (self_attn / multihead_attn .in_proj_weight /
+in_proj_bias / out_proj.{weight,bias}, linear1, linear2, norm1..3, encoder.layers.N.*, decoder.layers.N.*, *.norm),
+same forward signatures.  Every op runs in libmi355det:
   * nn.Linear       -> the implicit-GEMM conv kernel as a 1x1 convolution over the token rows (fwd, dgrad, wgrad)
   * attention core  -> mi_mha_fwd / mi_mha_bwd (fused MFMA attention, key-padding mask)
   * nn.LayerNorm    -> mi_layernorm_fwd / bwd
@@ -233,3 +234,140 @@ class TransformerEncoderLayer(nn.Module):
         src = self._ln(self.norm1, _AddFn.apply(src, src2))
         src2 = self._ffn(src)
         return self._ln(self.norm2, _AddFn.apply(src, src2))
+
+
+class TransformerDecoderLayer(nn.Module):
+    """detr_backbone.py:197-278: self-attention over the queries, cross-attention into the encoder memory, FFN"""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", normalize_before=False):
+        super().__init__()
+        if activation != "relu":
+            raise NotImplementedError(activation)
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.multihead_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.dropout_p = dropout
+        self.normalize_before = normalize_before
+
+    with_pos_embed = staticmethod(TransformerEncoderLayer.with_pos_embed)
+    _ln = TransformerEncoderLayer._ln
+    _ffn = TransformerEncoderLayer._ffn
+
+    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                memory_key_padding_mask=None, pos=None, query_pos=None):
+        if self.training and self.dropout_p > 0:
+            raise NotImplementedError("dropout > 0 in training mode (see module docstring)")
+        tgt, memory = _tok(tgt), _tok(memory)
+        mem_k = self.with_pos_embed(memory, pos)
+        if self.normalize_before:   # forward_pre (detr_backbone.py:245-264)
+            tgt2 = self._ln(self.norm1, tgt)
+            q = k = self.with_pos_embed(tgt2, query_pos)
+            tgt2 = self.self_attn(q, k, value=tgt2, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
+            tgt = _AddFn.apply(tgt, tgt2)
+            tgt2 = self._ln(self.norm2, tgt)
+            tgt2 = self.multihead_attn(self.with_pos_embed(tgt2, query_pos), mem_k, value=memory, attn_mask=memory_mask,
+                                       key_padding_mask=memory_key_padding_mask)[0]
+            tgt = _AddFn.apply(tgt, tgt2)
+            tgt2 = self._ffn(self._ln(self.norm3, tgt))
+            return _AddFn.apply(tgt, tgt2)
+        # forward_post (detr_backbone.py:222-243)
+        q = k = self.with_pos_embed(tgt, query_pos)
+        tgt2 = self.self_attn(q, k, value=tgt, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
+        tgt = self._ln(self.norm1, _AddFn.apply(tgt, tgt2))
+        tgt2 = self.multihead_attn(self.with_pos_embed(tgt, query_pos), mem_k, value=memory, attn_mask=memory_mask,
+                                   key_padding_mask=memory_key_padding_mask)[0]
+        tgt = self._ln(self.norm2, _AddFn.apply(tgt, tgt2))
+        tgt2 = self._ffn(tgt)
+        return self._ln(self.norm3, _AddFn.apply(tgt, tgt2))
+
+
+def _norm_tokens(norm, x):
+    Lx, B, E = x.shape
+    return _LayerNormFn.apply(x.reshape(Lx * B, E), norm.weight, norm.bias, norm.eps).view(Lx, B, E)
+
+
+def _clones(module, n):
+    import copy
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(n)])
+
+
+class TransformerEncoder(nn.Module):
+    """detr_backbone.py:68-90"""
+
+    def __init__(self, encoder_layer, num_layers, norm=None):
+        super().__init__()
+        self.layers = _clones(encoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.norm = norm
+
+    def forward(self, src, mask=None, src_key_padding_mask=None, pos=None):
+        output = _tok(src)
+        pos = None if pos is None else _tok(pos)
+        for layer in self.layers:
+            output = layer(output, src_mask=mask, src_key_padding_mask=src_key_padding_mask, pos=pos)
+        if self.norm is not None:
+            output = _norm_tokens(self.norm, output)
+        return output
+
+
+class TransformerDecoder(nn.Module):
+    """detr_backbone.py:93-132 (return_intermediate: the final norm applied to every layer's output, stacked)"""
+
+    def __init__(self, decoder_layer, num_layers, norm=None, return_intermediate=False):
+        super().__init__()
+        self.layers = _clones(decoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.norm = norm
+        self.return_intermediate = return_intermediate
+
+    def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
+                memory_key_padding_mask=None, pos=None, query_pos=None):
+        output = _tok(tgt)
+        memory = _tok(memory)
+        pos = None if pos is None else _tok(pos)
+        query_pos = None if query_pos is None else _tok(query_pos)
+        intermediate = []
+        for layer in self.layers:
+            output = layer(output, memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
+                           tgt_key_padding_mask=tgt_key_padding_mask, memory_key_padding_mask=memory_key_padding_mask,
+                           pos=pos, query_pos=query_pos)
+            if self.return_intermediate:
+                intermediate.append(_norm_tokens(self.norm, output))
+        if self.norm is not None:
+            output = intermediate[-1] if self.return_intermediate else _norm_tokens(self.norm, output)
+        if self.return_intermediate:
+            return torch.stack(intermediate)
+        return output.unsqueeze(0)
+
+
+class Transformer(nn.Module):
+    """detr_backbone.py:25-65: src [B, C, H, W] feature map, mask [B, H, W] (True = padding), query_embed [Q, C],
+    pos_embed [B, C, H, W]  ->  (hs [layers, B, Q, C], memory [B, C, H, W]), both bf16"""
+
+    def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=2048,
+                 dropout=0.1, activation="relu", normalize_before=False, return_intermediate_dec=False):
+        super().__init__()
+        enc = TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout, activation, normalize_before)
+        self.encoder = TransformerEncoder(enc, num_encoder_layers, nn.LayerNorm(d_model) if normalize_before else None)
+        dec = TransformerDecoderLayer(d_model, nhead, dim_feedforward, dropout, activation, normalize_before)
+        self.decoder = TransformerDecoder(dec, num_decoder_layers, nn.LayerNorm(d_model),
+                                          return_intermediate=return_intermediate_dec)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        self.d_model, self.nhead = d_model, nhead
+
+    def forward(self, src, mask, query_embed, pos_embed):
+        bs, c, h, w = src.shape
+        src = src.flatten(2).permute(2, 0, 1)
+        pos_embed = pos_embed.flatten(2).permute(2, 0, 1)
+        query_embed = query_embed.unsqueeze(1).repeat(1, bs, 1)
+        mask = mask.flatten(1)
+        tgt = torch.zeros_like(query_embed, dtype=torch.bfloat16)
+        memory = self.encoder(src, src_key_padding_mask=mask, pos=pos_embed)
+        hs = self.decoder(tgt, memory, memory_key_padding_mask=mask, pos=pos_embed, query_pos=query_embed)
+        return hs.transpose(1, 2), memory.permute(1, 2, 0).reshape(bs, c, h, w)
