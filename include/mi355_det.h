@@ -78,11 +78,11 @@ typedef struct mi_conv_desc {
   int32_t TH, TW;           /* pixel tile; 0 => chosen by the launcher        */
   int32_t KC, BN;           /* k-chunk / cout tile; 0 => chosen by launcher   */
   int32_t stats_slots;      /* 1..MI_BN_SLOTS accumulator slots (0 => MI_BN_SLOTS) */
-  int32_t pad_;
+  int32_t TPS;              /* taps multiplied per main-loop step (divides ntaps); 0 => chosen by launcher */
 } mi_conv_desc;
 
 int mi_conv2d(const mi_conv_desc* d, mi_stream_t s);
-/* fills TH/TW/KC/BN if zero; returns number of pixel tiles or <0 */
+/* fills TH/TW/KC/BN/TPS if zero; returns number of pixel tiles or <0 */
 int mi_conv2d_plan(mi_conv_desc* d);
 
 /* weight gradient: g[co][ci][tap] (fp32 OIHW, the nn.Parameter gradient layout; overwritten, or += if

@@ -163,6 +163,65 @@ def test_conv_input_slice():
     assert relerr(c.wgrad.cpu(), ref["dw"]) < 2e-2
 
 
+FORCED = [
+    # N, H, W, Cin, Cout, k, s
+    (1, 40, 40, 128, 128, 3, 1),
+    (2, 32, 32, 64, 128, 3, 2),
+    (2, 20, 20, 256, 64, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", FORCED, ids=[f"{c[3]}to{c[4]}_k{c[5]}s{c[6]}" for c in FORCED])
+def test_conv_forced_configs_agree(case):
+    """every (k-chunk, taps-per-step, cout tile, pixel tile) configuration the launcher may pick computes the same
+    convolution (forward and every data-gradient launch): outputs equal up to the fp32 accumulation order"""
+    import ctypes as C
+    N, H, W, Cin, Cout, k, s = case
+    c = _Case(N, H, W, Cin, Cout, k, s)
+    c.run()
+    lib = L.lib()
+    ran = 0
+    for which in ("fwd", "bwd"):
+        arr, n = c.plan.fwd_cmds if which == "fwd" else c.plan.bwd_cmds
+        for i in range(n):
+            if L.OPS[arr[i].op] != "CONV":
+                continue
+            d0 = c.plan.cmd_descs[which][i]
+            if d0.flags & L.MI_CONV_ACCUM:
+                continue
+            elems = d0.N * d0.outH * d0.outW * d0.ldy
+            base = torch.empty(elems, dtype=torch.bfloat16, device=DEV)
+            got = torch.empty(elems, dtype=torch.bfloat16, device=DEV)
+
+            def run(d, dst):
+                dst.fill_(0)
+                d.y = dst.data_ptr()
+                d.stats_acc = None
+                L.check(lib.mi_conv2d(C.byref(d), L.stream_ptr()), "mi_conv2d")
+                torch.cuda.synchronize()
+
+            d = L.mi_conv_desc.from_buffer_copy(d0)
+            run(d, base)
+            K = d0.K8 * 8
+            for kc in (16, 32, 64, 128):
+                if K % kc:
+                    continue
+                for tps in [t for t in (1, 2, 3, 4, 9) if d0.ntaps % t == 0]:
+                    for bn, th, tw in ((32, 8, 16), (64, 8, 8), (128, 4, 32), (64, 3, 20)):
+                        if d0.CoutPad % bn:
+                            continue
+                        d = L.mi_conv_desc.from_buffer_copy(d0)
+                        d.KC, d.TPS, d.BN, d.TH, d.TW = kc, tps, bn, th, tw
+                        probe = L.mi_conv_desc.from_buffer_copy(d)
+                        if lib.mi_conv2d_plan(C.byref(probe)) < 0:   # does not fit in LDS: the launcher refuses
+                            continue
+                        run(d, got)
+                        np.testing.assert_allclose(got.float().cpu().numpy(), base.float().cpu().numpy(), rtol=2e-2,
+                                                   atol=2e-2, err_msg=f"{which}[{i}] KC{kc} TPS{tps} BN{bn} {th}x{tw}")
+                        ran += 1
+    assert ran > 20
+
+
 def test_dgrad_accumulates():
     """two consumers of one tensor: the second data gradient must add to the first (MI_CONV_ACCUM)"""
     g = torch.Generator().manual_seed(5)

@@ -32,6 +32,8 @@ for which in ("fwd", "bwd"):
             for fl in (0, 256, 512):
                 d = L.mi_conv_desc.from_buffer_copy(d0); d.flags |= fl
                 out.append(t(d))
+            d = L.mi_conv_desc.from_buffer_copy(d0); d.stats_acc = None
+            out.append(t(d))
             var = []
             for (kc, bn, th, tw) in ((64, 128, 8, 16), (64, 64, 8, 16), (32, 128, 8, 16), (64, 64, 8, 8), (64, 128, 8, 8), (64, 32, 8, 16), (32, 64, 8, 16)):
                 d = L.mi_conv_desc.from_buffer_copy(d0); d.KC, d.BN, d.TH, d.TW = kc, bn, th, tw
@@ -40,4 +42,4 @@ for which in ("fwd", "bwd"):
                     var.append(f"KC{kc}/BN{bn}/{th}x{tw}:{t(d):.1f}")
                 except Exception as e:
                     var.append(f"KC{kc}/BN{bn}/{th}x{tw}:ERR")
-            print(f"{tag:36s} full {out[0]:.1f}us  no-mainloop {out[1]:.1f}us  no-epilogue {out[2]:.1f}us | " + " ".join(var))
+            print(f"{tag:36s} full {out[0]:.1f}us  no-mainloop {out[1]:.1f}us  no-epilogue {out[2]:.1f}us  no-stats {out[3]:.1f}us | " + " ".join(var[:0]))

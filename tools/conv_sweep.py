@@ -30,24 +30,28 @@ for which in ("fwd", "bwd"):
         key = (d.H, d.W, d.K8 * 8, d.CoutPad, d.ntaps, d.in_stride, d.out_stride, bool(d.stats_acc), d.flags)
         seen.setdefault(key, []).append((which, k))
 ta = tb = 0.0
+def divisors(n):
+    return [x for x in range(n, 0, -1) if n % x == 0]
 for key, lst in sorted(seen.items(), key=lambda kv: -len(kv[1])):
     which, k = lst[0]
     d0 = plan.cmd_descs[which][k]
     dd = L.mi_conv_desc.from_buffer_copy(d0); lib.mi_conv2d_plan(C.byref(dd))
     auto = t(d0)
     res = []
-    if d0.stats_acc:   # tile count changes the stats partial rows: only sweep KC/BN with the auto tile
-        tiles = [(dd.TH, dd.TW)]
-    else:
-        tiles = [(8, 16), (4, 32), (8, 8), (4, 16), (2, 32), (16, 8), (3, 40), (6, 20), (3, 20), (1, 64), (2, 64)]
+    small = d0.gridH * d0.gridW <= 1600
+    tiles = [(8, 16), (4, 32), (8, 8), (4, 16)] + ([(3, 40), (6, 20), (3, 20), (2, 20), (5, 20)] if small else [])
     for (th, tw) in tiles:
-        for kc in (16, 32, 64):
+        if tw > d0.gridW * 2: continue
+        for kc in (16, 32, 64, 128):
+            if (d0.K8 * 8) % kc: continue
             for bn in (32, 64, 128):
-                d = L.mi_conv_desc.from_buffer_copy(d0); d.KC, d.BN, d.TH, d.TW = kc, bn, th, tw
-                r = t(d, 3)
-                if r is not None: res.append((r, kc, bn, th, tw))
-    best = min(res) if res else (auto, 0, 0, 0, 0)
+                if d0.CoutPad % bn: continue
+                for tps in divisors(d0.ntaps):
+                    d = L.mi_conv_desc.from_buffer_copy(d0); d.KC, d.BN, d.TH, d.TW, d.TPS = kc, bn, th, tw, tps
+                    r = t(d, 3)
+                    if r is not None and r > 0: res.append((r, kc, bn, th, tw, tps))
+    best = min(res) if res else (auto, 0, 0, 0, 0, 0)
     ta += auto * len(lst); tb += min(best[0], auto) * len(lst)
-    print(f"{key} x{len(lst)}: auto {auto:.1f}us (KC{dd.KC} BN{dd.BN} {dd.TH}x{dd.TW}) | best " +
-          " ".join(f"{r[0]:.1f}:KC{r[1]}/BN{r[2]}/{r[3]}x{r[4]}" for r in sorted(res)[:4]))
+    print(f"{key} x{len(lst)}: auto {auto:.1f}us (KC{dd.KC} BN{dd.BN} {dd.TH}x{dd.TW} T{dd.TPS}) | best " +
+          " ".join(f"{r[0]:.1f}:KC{r[1]}/BN{r[2]}/{r[3]}x{r[4]}/T{r[5]}" for r in sorted(res)[:6]), flush=True)
 print(f"total auto {ta/1e3:.3f} ms, best {tb/1e3:.3f} ms")

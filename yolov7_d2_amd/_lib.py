@@ -31,7 +31,7 @@ class mi_conv_desc(C.Structure):
         ("tap_dy", C.c_int32 * MI_MAX_TAPS), ("tap_dx", C.c_int32 * MI_MAX_TAPS),
         ("tap_w", C.c_int32 * MI_MAX_TAPS),
         ("flags", C.c_int32), ("TH", C.c_int32), ("TW", C.c_int32), ("KC", C.c_int32), ("BN", C.c_int32),
-        ("stats_slots", C.c_int32), ("pad_", C.c_int32),
+        ("stats_slots", C.c_int32), ("TPS", C.c_int32),
     ]
 
 

@@ -12,8 +12,10 @@
 //     16-byte chunks of a row are XOR-permuted on the SOURCE address (an LDS-DMA image is lane-linear)
 //     so the ds_read_b128 of 16 consecutive pixels hits 16 distinct bank groups.
 //   * weights are pre-packed [tap][K/8][CoutPad][8]: a (tap, k-chunk) slab is a run of contiguous
-//     16-byte rows, also LDS-DMA'd.  Both the next weight slab and the next halo chunk are in flight
-//     (double-buffered) while the current (chunk, tap) step is multiplied; one barrier per step.
+//     16-byte rows, also LDS-DMA'd.  A step multiplies one k-chunk against `tps` taps (1 .. all of them);
+//     the next step's weight slabs and the next halo chunk are in flight (double-buffered) meanwhile;
+//     one barrier per step.  Steps are latency-bound (a barrier + the wait for the previous step's DMA), so
+//     the launcher makes them as fat as LDS allows: a 3x3 K=32 conv or a 1x1 K<=128 conv is ONE step.
 //   * v_mfma_f32_32x32x16_bf16 with A = weights (M = cout), B = pixels (N = pixel): each
 //     lane then owns 4 consecutive couts x 4 groups of ONE pixel -> 8-byte NHWC stores.
 //   * epilogue optionally emits per-tile per-channel (sum, sumsq) from the fp32 accumulators:
@@ -33,6 +35,7 @@ struct ConvK {
   int toff[MI_MAX_TAPS], tw[MI_MAX_TAPS];
   int flags, TH, TW, tilesY, tilesX, nco, nslots;
   int dymin, dxmin, haloW, npixh, nqx, xbytes;
+  int tps, xstride, wstride;  // taps per weight slab; byte strides of the (double) halo / slab buffers (0: single)
   unsigned mTW, mHW;  // ceil(2^20 / TW), ceil(2^20 / haloW)
 };
 
@@ -46,22 +49,25 @@ __device__ __forceinline__ void glds16(const void* g, unsigned lds_off) {
                : "memory", "m0");
 }
 
-template <int KC, int BN, int WM, int WN, int CT, int PT>
+// TPS: taps per step as a compile-time constant (1: the classic one-tap step, fully scheduled by the compiler) or
+// 0: run-time p.tps (multi-tap steps of the small-K / stride-2 / parity-class launches)
+template <int KC, int BN, int WM, int WN, int CT, int PT, int TPS>
 __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvK p) {
   static_assert(WM * CT * 32 == BN, "cout tiling");
   constexpr int NW = WM * WN;
   constexpr int TPIX = WN * PT * 32;
   constexpr int KC8 = KC / 8, KS = KC / 16, R = KC * 2;
-  constexpr int RBSH = (KC == 64) ? 1 : (KC == 32) ? 2 : 3;  // log2(rows per 256-byte bank row)
+  constexpr int RBSH = (KC == 128) ? 0 : (KC == 64) ? 1 : (KC == 32) ? 2 : 3;  // log2(rows per 256-byte bank row)
   constexpr int RPI = 64 / KC8;                              // halo rows per LDS-DMA instruction
   constexpr int WCH = KC8 * BN;                              // 16-byte rows per weight slab
   constexpr int WQ = WCH / 64;                               // LDS-DMA instructions per weight slab
   static_assert(WCH % 64 == 0, "weight slab");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // [x0][x1][w0][w1][stats]
+  // [x0][x1 (if > 1 k-chunk)][w0][w1 (if > 1 step)]
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int xbytes = p.xbytes;
-  char* const Wb = smem + 2 * xbytes;
+  const int wbase = xbytes + p.xstride;
+  char* const Wb = smem + wbase;
   float* Ss = (float*)smem;  // [WN][BN][2] (direct epilogue only; aliases the halo buffer after the last step)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -103,22 +109,25 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvK 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nchunks = p.K8 / KC8;
-  const int nsteps = nchunks * p.ntaps;
+  const int tps = TPS ? TPS : p.tps;
+  const int ngr = TPS == 1 ? p.ntaps : p.ntaps / tps;  // tap groups per k-chunk
+  const int nsteps = nchunks * ngr;
   const char* const zero = (const char*)g_conv_zero_page;
   const char* const xb = (const char*)(p.x + ((size_t)img * p.H * p.W) * (size_t)p.ldx);
 
   auto issue_w = [&](int step) {
-    const int kc = step / p.ntaps, t = step - kc * p.ntaps;
-    const u32x4* src = p.w + ((size_t)(p.tw[t] * p.K8 + kc * KC8)) * p.CoutPad + co0;
-    const unsigned dst = lds0 + 2 * xbytes + (step & 1) * (WCH * 16);
-    for (int q = wave; q < WQ; q += NW) {
-      const int idx = q * 64 + lane;
+    const int kc = step / ngr, t0 = (step - kc * ngr) * tps;
+    const unsigned dst = lds0 + wbase + (step & 1) * p.wstride;
+    for (int q = wave; q < WQ * tps; q += NW) {
+      const int tt = TPS == 1 ? 0 : q / WQ, qq = q - tt * WQ;
+      const u32x4* src = p.w + ((size_t)(p.tw[t0 + tt] * p.K8 + kc * KC8)) * p.CoutPad + co0;
+      const int idx = qq * 64 + lane;
       const int c8 = idx / BN, co = idx % BN;
       glds16(src + (size_t)c8 * p.CoutPad + co, dst + q * 1024);
     }
   };
   auto issue_x = [&](int kc) {
-    const unsigned dst = lds0 + (kc & 1) * xbytes;
+    const unsigned dst = lds0 + (kc & 1) * p.xstride;
     for (int q = wave; q < p.nqx; q += NW) {
       const int row = q * RPI + lane / KC8;
       const int chunk = (lane % KC8) ^ ((row >> RBSH) & (KC8 - 1));
@@ -134,14 +143,15 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvK 
   const int nsteps_run = (p.flags & 256) ? 0 : nsteps;
   if (nsteps_run) { issue_w(0); issue_x(0); }
   for (int step = 0; step < nsteps_run; ++step) {
-    const int kc = step / p.ntaps, t = step - kc * p.ntaps;
+    const int kc = step / ngr, g = step - kc * ngr;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // slab `step` and chunk `kc` landed; the other buffers are no longer read
+    __builtin_amdgcn_s_barrier();  // slabs `step` and chunk `kc` landed; the other buffers are no longer read
     if (step + 1 < nsteps) issue_w(step + 1);
-    if (t == 0 && kc + 1 < nchunks) issue_x(kc + 1);
-    const char* Xs = smem + (kc & 1) * xbytes;
-    const u32x4* Ws = (const u32x4*)(Wb + (step & 1) * (WCH * 16));
-    const int toff = p.toff[t];
+    if (g == 0 && kc + 1 < nchunks) issue_x(kc + 1);
+    const char* Xs = smem + (kc & 1) * p.xstride;
+    for (int tt = 0; tt < tps; ++tt) {
+    const u32x4* Ws = (const u32x4*)(Wb + (step & 1) * p.wstride) + tt * WCH;
+    const int toff = p.toff[g * tps + tt];
     int xrow[PT], xsw[PT];
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
@@ -164,6 +174,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvK 
 #pragma unroll
         for (int j = 0; j < PT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
     }
   }
 
@@ -379,7 +390,7 @@ static void choose_tile(int TPIX, int gridH, int gridW, int* TH, int* TW) {
 }
 
 struct ConvCfg {
-  int KC, BN, TPIX;
+  int KC, BN, TPIX, TPS;
 };
 
 static int conv_fill(const mi_conv_desc* d, ConvK* k, ConvCfg* c, size_t* ldsBytes) {
@@ -450,26 +461,68 @@ static int conv_fill(const mi_conv_desc* d, ConvK* k, ConvCfg* c, size_t* ldsByt
   k->haloW = (TW - 1) * d->in_stride + (dxmax - dxmin) + 1;
   k->npixh = haloH * k->haloW;
   for (int t = 0; t < d->ntaps; ++t) k->toff[t] = (d->tap_dy[t] - dymin) * k->haloW + (d->tap_dx[t] - dxmin);
-  int KC = d->KC;
-  if (KC <= 0) {
-    KC = (Kp % 64 == 0) ? 64 : (Kp % 32 == 0) ? 32 : 16;
-    // keep two blocks per CU: shrink the k-chunk when the halo image is large (stride-2 tiles)
-    while (KC > 16) {
-      size_t b = 2 * ((size_t)mi_cdiv(k->npixh, 64 / (KC / 8)) * 1024 + (size_t)(KC / 8) * BN * 16);
-      if (b <= 80 * 1024) break;
-      KC /= 2;
+  // ---- k-chunk and taps per step.  A step costs a barrier + the wait for the previous step's DMA (~0.25 us), a
+  // (chunk, tap) iteration inside it exposes one LDS round trip (~0.09 us); co-resident blocks (LDS-, register- and
+  // grid-limited) hide each other's latencies.  Constants fitted to tools/conv_sweep.py on MI355X; the plan-level
+  // autotuner (plan.py) replaces this estimate by measurements.
+  k->nco = d->CoutPad / BN;
+  const long nblocks = (long)d->N * k->tilesY * k->tilesX * k->nco;
+  int KC = d->KC, tps = d->TPS;
+  auto lds_need = [&](int kc, int tp) {
+    const size_t xb = (size_t)mi_cdiv(k->npixh, 64 / (kc / 8)) * 1024;
+    const size_t wb = (size_t)tp * (kc / 8) * BN * 16;
+    const int nch = Kp / kc, nst = nch * (d->ntaps / tp);
+    return xb * (nch > 1 ? 2 : 1) + wb * (nst > 1 ? 2 : 1);
+  };
+  if (KC <= 0 || tps <= 0) {
+    static const int maxkc = getenv("MI_CONV_MAXKC") ? atoi(getenv("MI_CONV_MAXKC")) : 128;
+    static const int cap2 = getenv("MI_CONV_LDSCAP") ? atoi(getenv("MI_CONV_LDSCAP")) : 80;
+    static const int cap1 = getenv("MI_CONV_LDSCAP1") ? atoi(getenv("MI_CONV_LDSCAP1")) : 160;
+    static const double cS = getenv("MI_CONV_S") ? atof(getenv("MI_CONV_S")) : 0.25;
+    static const double cT = getenv("MI_CONV_T") ? atof(getenv("MI_CONV_T")) : 0.3;
+    static const int useocc = getenv("MI_CONV_OCC") ? atoi(getenv("MI_CONV_OCC")) : 1;
+    const size_t cap = (size_t)(nblocks > 256 ? cap2 : cap1) * 1024;
+    double bestCost = -1.0;
+    int bk = 16, bt = 1;
+    size_t bestLds = 0;
+    const double vocc = BN == 32 ? 8.0 : (BN == 64 ? (TPIX == 128 ? 4.0 : 8.0) : (TPIX == 128 ? 3.0 : 5.0));
+    const double gocc = nblocks > 256 ? nblocks / 256.0 : 1.0;
+    const int kcs[4] = {128, 64, 32, 16};
+    for (int ci = 0; ci < 4; ++ci) {
+      const int kc = kcs[ci];
+      if (Kp % kc != 0 || (d->KC > 0 && kc != d->KC) || (d->KC <= 0 && kc > maxkc)) continue;
+      for (int tp = d->ntaps; tp >= 1; --tp) {
+        if (d->ntaps % tp != 0 || (d->TPS > 0 && tp != d->TPS)) continue;
+        const size_t need = lds_need(kc, tp);
+        if (need > cap && !(kc == 16 && tp == 1)) continue;
+        double occ = (double)((160 * 1024) / (need > 20480 ? need : 20480));
+        if (occ < 1.0) occ = 1.0;
+        if (occ > vocc) occ = vocc;
+        if (occ > gocc) occ = gocc;
+        if (!useocc) occ = 1.0;
+        const double steps = (double)(Kp / kc) * (d->ntaps / tp), iters = (double)(Kp / kc) * d->ntaps;
+        const double cost = (steps * cS + iters * cT) / occ;
+        if (bestCost < 0 || cost < bestCost * 0.999 || (cost <= bestCost * 1.001 && need < bestLds)) {
+          bestCost = cost; bk = kc; bt = tp; bestLds = need;
+        }
+      }
     }
+    KC = bk; tps = bt;
   }
-  MI_REQUIRE((KC == 16 || KC == 32 || KC == 64) && Kp % KC == 0, "conv: KC %d for K %d", KC, Kp);
+  MI_REQUIRE((KC == 16 || KC == 32 || KC == 64 || KC == 128) && Kp % KC == 0, "conv: KC %d for K %d", KC, Kp);
+  MI_REQUIRE(tps >= 1 && d->ntaps % tps == 0, "conv: TPS %d for %d taps", tps, d->ntaps);
   const int RPI = 64 / (KC / 8);
   k->nqx = mi_cdiv(k->npixh, RPI);
   k->xbytes = k->nqx * 1024;
   MI_REQUIRE((long)k->nqx * RPI * k->haloW < (1 << 20) && k->nqx * RPI < 4096, "conv: halo too large for the row decode");
   k->mTW = ((1u << 20) + TW - 1) / TW;
   k->mHW = ((1u << 20) + k->haloW - 1) / k->haloW;
-  k->nco = d->CoutPad / BN;
-  c->KC = KC; c->BN = BN; c->TPIX = TPIX;
-  *ldsBytes = 2 * (size_t)k->xbytes + 2 * (size_t)(KC / 8) * BN * 16;
+  const int nch = Kp / KC, nst = nch * (d->ntaps / tps);
+  k->tps = tps;
+  k->xstride = nch > 1 ? k->xbytes : 0;
+  k->wstride = nst > 1 ? tps * (KC / 8) * BN * 16 : 0;
+  c->KC = KC; c->BN = BN; c->TPIX = TPIX; c->TPS = tps;
+  *ldsBytes = lds_need(KC, tps);
   const size_t stage = (size_t)TPIX * (BN * 2 + 16);          // staged epilogue tile
   const size_t red = (size_t)(TPIX == 128 && BN == 32 ? 256 : (TPIX == 64 && BN == 32 ? 128 : 256)) / (BN / 8) * BN * 8;
   if (*ldsBytes < stage) *ldsBytes = stage;
@@ -485,13 +538,13 @@ extern "C" int mi_conv2d_plan(mi_conv_desc* d) {
   size_t lds;
   int rc = conv_fill(d, &k, &c, &lds);
   if (rc) return rc;
-  d->TH = k.TH; d->TW = k.TW; d->KC = c.KC; d->BN = c.BN;
+  d->TH = k.TH; d->TW = k.TW; d->KC = c.KC; d->BN = c.BN; d->TPS = c.TPS;
   return d->N * k.tilesY * k.tilesX;
 }
 
-template <int KC, int BN, int WM, int WN, int CT, int PT>
-static int launch_cfg(const ConvK& k, size_t lds, hipStream_t s) {
-  auto fn = conv_igemm_kernel<KC, BN, WM, WN, CT, PT>;
+template <int KC, int BN, int WM, int WN, int CT, int PT, int TPS>
+static int launch_one(const ConvK& k, size_t lds, hipStream_t s) {
+  auto fn = conv_igemm_kernel<KC, BN, WM, WN, CT, PT, TPS>;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -501,6 +554,11 @@ static int launch_cfg(const ConvK& k, size_t lds, hipStream_t s) {
   hipLaunchKernelGGL(fn, grid, dim3(WM * WN * 64), lds, s, k);
   MI_CHECK_LAUNCH("conv_igemm");
   return MI_OK;
+}
+template <int KC, int BN, int WM, int WN, int CT, int PT>
+static int launch_cfg(const ConvK& k, size_t lds, hipStream_t s) {
+  if (k.tps == 1) return launch_one<KC, BN, WM, WN, CT, PT, 1>(k, lds, s);
+  return launch_one<KC, BN, WM, WN, CT, PT, 0>(k, lds, s);
 }
 
 extern "C" int mi_conv2d(const mi_conv_desc* d, mi_stream_t st) {
@@ -525,6 +583,7 @@ extern "C" int mi_conv2d(const mi_conv_desc* d, mi_stream_t st) {
   MI_DISPATCH(16)
   MI_DISPATCH(32)
   MI_DISPATCH(64)
+  MI_DISPATCH(128)
 #undef MI_DISPATCH
   MI_FAIL(MI_EINVAL, "conv: no kernel for KC %d BN %d TPIX %d", c.KC, c.BN, c.TPIX);
 }

@@ -183,17 +183,26 @@ extern "C" int mi_cmdlist_time(const mi_cmd* cmds, int n, int iters, float* ms, 
     *ms = t / (float)(iters > 0 ? iters : 1);
   }
   if (per_cmd_ms && rc == MI_OK) {
+    // events recorded in-stream between the commands, ONE host synchronisation per replay: the device runs the list
+    // back to back (clocks and caches as in a real step) and the event deltas are the per-command durations
     for (int k = 0; k < n; ++k) per_cmd_ms[k] = 0.f;
-    for (int it = 0; it < iters && rc == MI_OK; ++it)
+    std::vector<hipEvent_t> ev((size_t)n + 1);
+    for (auto& e : ev)
+      if (hipEventCreate(&e) != hipSuccess) MI_FAIL(MI_ELAUNCH, "event create");
+    for (int it = 0; it < iters && rc == MI_OK; ++it) {
+      (void)hipEventRecord(ev[0], s);
       for (int k = 0; k < n && rc == MI_OK; ++k) {
-        (void)hipEventRecord(e0, s);
         rc = mi_cmdlist_run(cmds + k, 1, st);
-        (void)hipEventRecord(e1, s);
-        (void)hipEventSynchronize(e1);
+        (void)hipEventRecord(ev[k + 1], s);
+      }
+      (void)hipEventSynchronize(ev[n]);
+      for (int k = 0; k < n && rc == MI_OK; ++k) {
         float t = 0.f;
-        (void)hipEventElapsedTime(&t, e0, e1);
+        (void)hipEventElapsedTime(&t, ev[k], ev[k + 1]);
         per_cmd_ms[k] += t / (float)iters;
       }
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);

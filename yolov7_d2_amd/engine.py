@@ -7,6 +7,7 @@ model(data) (train_det.py:21-50,73-75 -> DefaultTrainer; d2 upstream): sum of th
 weight decay 1e-4, WEIGHT_DECAY_NORM 0 for norm layers).  bf16 needs no GradScaler.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -18,7 +19,7 @@ from .parallel import GradReducer, broadcast_params, grad_write_ranges, parallel
 
 class NativeTrainer:
     def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=1e-4, weight_decay_norm=0.0, n_buckets=3,
-                 use_graph=True, loss_weights=(1.0, 1.0, 1.0, 1.0)):
+                 use_graph=True, loss_weights=(1.0, 1.0, 1.0, 1.0), tune=None):
         self.model = model
         model.train()
         self.params = model.ensure_params()
@@ -33,6 +34,10 @@ class NativeTrainer:
         self.loss_weights = loss_weights
         self._states = {}
         self.stream = torch.cuda.Stream()
+        # optional on-device selection of the conv tile configurations before the graphs are captured (MI_CONV_TUNE=1).
+        # Off by default: on the YOLOX-s step the launcher's cost model is within measurement noise of the tuned result.
+        self.tune = (os.environ.get("MI_CONV_TUNE", "0") == "1") if tune is None else bool(tune)
+        self.tune_report = None
 
     def set_lr(self, lr):
         self.params.set_lr(lr)
@@ -101,6 +106,8 @@ class NativeTrainer:
             if self.use_graph and st["graphs"] is None:
                 # first call runs eagerly (sets kernel attributes, warms allocators), second call captures
                 if st.get("warm"):
+                    if self.tune:
+                        self.tune_report = plan.autotune_convs(stream=self.stream)
                     self._capture(st)
                 st["warm"] = True
             gs = st["graphs"] if self.use_graph else None

@@ -114,6 +114,7 @@ class PlanBuilder:
         self._emitting_bwd = False
         self.grad_init = {}  # id(gbuf) -> list of (c0,c1) initialised channel intervals
         self.keep = []       # python objects that must outlive the plan (ctypes descs, tensors)
+        self.tune_restore = []   # tensors a replay of the forward list mutates (BN running statistics)
         self.loss = None
         self.conv_records = []  # (tag, spec) for roofline bookkeeping
         self.bias_jobs = []     # prediction-conv bias gradients (one BIAS_GRADS command after the loss backward)
@@ -301,6 +302,7 @@ class PlanBuilder:
             acc = self.bn_acc("fwd", Cout, nsl)
             self.conv_cmd(tag + ".conv", x, wf, CinPad // 8, y, y.ld, Ho, Wo, Cout, Cout, taps, in_stride=stride,
                           stats=acc, stats_slots=nsl)
+            self.tune_restore += [t for t in (bn["rm"], bn["rv"], bn["nbt"]) if torch.is_tensor(t)]
             self.emit("BN_ACT_FWD", i=[y.ld, res.ld if res is not None else 0, out.ld, Cout, act, nsl], l=[count, count],
                       f=[bn["eps"], bn["momentum"]],
                       p=[y, acc, bn["gamma"], bn["beta"], bn["rm"], bn["rv"], bn["nbt"], scale, shift, mean, invstd, res,
@@ -653,6 +655,119 @@ class Plan:
         tot = C.c_float(0)
         L.check(L.lib().mi_cmdlist_time(arr, n, iters, C.byref(tot), per, L.stream_ptr(stream)), "cmdlist_time")
         return tot.value, [(tags[k], per[k]) for k in range(n)]
+
+    # ---------------------------------------------------------------- conv autotuning
+    def _time_list(self, which, iters, sp):
+        arr, n = self.fwd_cmds if which == "fwd" else self.bwd_cmds
+        per = (C.c_float * max(1, n))()
+        L.check(L.lib().mi_cmdlist_time(arr, n, iters, None, per, sp), "cmdlist_time")
+        return per
+
+    @staticmethod
+    def _valid_cfg(d0, cfg):
+        d = L.mi_conv_desc.from_buffer_copy(d0)
+        d.KC, d.BN, d.TH, d.TW, d.TPS = cfg
+        if L.lib().mi_conv2d_plan(C.byref(d)) < 0:
+            return None
+        return (d.KC, d.BN, d.TH, d.TW, d.TPS)
+
+    def autotune_convs(self, iters=5, stream=None, verbose=False, min_gain=0.03):
+        """choose (pixel tile, cout tile, k-chunk, taps per step) of every conv launch by timing candidates ON THE
+        DEVICE, IN SEQUENCE: the whole forward / backward list is replayed command by command (HIP events around
+        each launch) with candidate r applied to every conv at once, so each conv sees the cache state its producer
+        leaves behind - timing a conv in isolation (operands L2-hot) prefers big-LDS, low-occupancy configurations
+        that lose inside the step.  Phase A varies the tiles with the heuristic k-chunk, phase B the k-chunk / taps per
+        step on the chosen tile.  Must run before the lists are captured into graphs; the replays only write buffers
+        that every step overwrites, plus BN running statistics (saved and restored here)."""
+        lib, sp = L.lib(), L.stream_ptr(stream)
+        lib.mi_last_error()
+        saved = [(t, t.clone()) for t in getattr(self.b, "tune_restore", [])]
+        convs = {}
+        for which in ("fwd", "bwd"):
+            arr, n = self.fwd_cmds if which == "fwd" else self.bwd_cmds
+            convs[which] = [k for k in range(n) if arr[k].op == L.OP["CONV"]]
+        report = {}
+
+        def phase(gen):
+            for which in ("fwd", "bwd"):
+                idx = convs[which]
+                descs = self.cmd_descs[which]
+                cur = {k: (descs[k].KC, descs[k].BN, descs[k].TH, descs[k].TW, descs[k].TPS) for k in idx}
+                cands = {}
+                for k in idx:
+                    base = self._valid_cfg(descs[k], cur[k])
+                    lst = []
+                    for c in gen(descs[k], base):
+                        v = self._valid_cfg(descs[k], c)
+                        if v is not None and v != base and v not in lst:
+                            lst.append(v)
+                    cands[k] = [base] + lst
+                R = max(len(v) for v in cands.values())
+                best = {k: (None, None) for k in idx}
+                t0 = {}
+                for r in range(R):
+                    for k in idx:
+                        c = cands[k][r] if r < len(cands[k]) else cands[k][0]
+                        descs[k].KC, descs[k].BN, descs[k].TH, descs[k].TW, descs[k].TPS = c
+                    per = self._time_list(which, iters, sp)
+                    for k in idx:
+                        if r < len(cands[k]):
+                            t = per[k]
+                            if r == 0:
+                                t0[k] = t
+                                best[k] = (t, cands[k][0])
+                            elif t < best[k][0] and t < (1.0 - min_gain) * t0[k]:
+                                best[k] = (t, cands[k][r])
+                # validation: candidates won a noisy one-shot comparison (winner's curse) - replay base and winners
+                # alternately and keep a winner only if it is still ahead on the means
+                tb, tw = {k: 0.0 for k in idx}, {k: 0.0 for k in idx}
+                rounds = 3
+                for _ in range(rounds):
+                    for cfgs, acc in ((cands, None), (best, tw)):
+                        for k in idx:
+                            c = cands[k][0] if acc is None else best[k][1]
+                            descs[k].KC, descs[k].BN, descs[k].TH, descs[k].TW, descs[k].TPS = c
+                        per = self._time_list(which, iters, sp)
+                        for k in idx:
+                            (tb if acc is None else tw)[k] += per[k] / rounds
+                for k in idx:
+                    keep = best[k][1] != cands[k][0] and tw[k] < (1.0 - min_gain) * tb[k]
+                    c = best[k][1] if keep else cands[k][0]
+                    descs[k].KC, descs[k].BN, descs[k].TH, descs[k].TW, descs[k].TPS = c
+                    first = report[(which, k)][0] if (which, k) in report else tb[k]
+                    report[(which, k)] = (first, tw[k] if keep else tb[k], c)
+
+        def gen_tiles(d, base):
+            tiles = [(8, 16), (4, 32), (8, 8), (4, 16)]
+            if d.gridH * d.gridW <= 1600:
+                tiles += [(3, 40), (6, 20), (5, 20), (3, 20), (2, 20)]
+            for th, tw in tiles:
+                if tw > 2 * d.gridW:
+                    continue
+                for bn in (32, 64, 128):
+                    if d.CoutPad % bn == 0:
+                        yield (0, bn, th, tw, 0)
+
+        def gen_k(d, base):
+            K = d.K8 * 8
+            for kc in (128, 64, 32, 16):
+                if K % kc:
+                    continue
+                for tps in range(d.ntaps, 0, -1):
+                    if d.ntaps % tps == 0:
+                        yield (kc, base[1], base[2], base[3], tps)
+
+        phase(gen_tiles)
+        phase(gen_k)
+        for t, v in saved:
+            t.copy_(v)
+        auto = sum(v[0] for v in report.values()) * 1e3
+        tuned = sum(v[1] for v in report.values()) * 1e3
+        if verbose:
+            for (which, k), v in sorted(report.items()):
+                tag = (self.fwd_tags if which == "fwd" else self.bwd_tags)[k]
+                print(f"[tune] {which} {tag:40s} {v[0] * 1e3:7.1f} -> {v[1] * 1e3:7.1f} us  {v[2]}", flush=True)
+        return auto, tuned
 
     def view(self, t, dtype=torch.bfloat16):
         """torch view of a TRef (for tests / module outputs): shape [N,C,H,W] with channels_last strides"""
