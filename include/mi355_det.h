@@ -51,6 +51,10 @@ const char* mi_last_error(void);
  * (s2 dgrad = 4 parity-class launches with out_stride 2) via the tap table. */
 #define MI_CONV_ACCUM 1    /* y += result (gradient fan-in)                  */
 #define MI_CONV_OUT_F32 2  /* y is fp32 (prediction maps), else bf16         */
+#define MI_CONV_BNBWD 4    /* data-gradient launch that also reduces the BatchNorm backward sums of the layer that
+                              PRODUCED its output tensor: stats_acc += (sum dz, sum dz*xhat) per channel with
+                              dz = y_out * act'(bn_y*scale+shift), xhat = (bn_y-mean)*invstd - replaces the
+                              mi_bn_act_bwd_reduce pass over (da, y) of that layer (bf16 staged outputs only) */
 #define MI_MAX_TAPS 9
 #define MI_BN_SLOTS 16     /* max accumulator slots per channel (slot = pixel tile % nslots); callers pick
                               nslots per layer: more slots = less same-address atomic traffic in the conv
@@ -79,6 +83,14 @@ typedef struct mi_conv_desc {
   int32_t KC, BN;           /* k-chunk / cout tile; 0 => chosen by launcher   */
   int32_t stats_slots;      /* 1..MI_BN_SLOTS accumulator slots (0 => MI_BN_SLOTS) */
   int32_t TPS;              /* taps multiplied per main-loop step (divides ntaps); 0 => chosen by launcher */
+  /* MI_CONV_BNBWD only: raw conv output of the producing layer (bf16 NHWC, same N x outH x outW x Cout as y),
+   * its BatchNorm scale / shift / mean / invstd [Cout] and activation (1 = SiLU, 0 = none) */
+  const void* bn_y;
+  const float* bn_scale;
+  const float* bn_shift;
+  const float* bn_mean;
+  const float* bn_invstd;
+  int32_t bn_ldy, bn_act;
 } mi_conv_desc;
 
 int mi_conv2d(const mi_conv_desc* d, mi_stream_t s);

@@ -129,7 +129,19 @@ class Interp:
         if s.flags & L.MI_CONV_ACCUM:
             res = res + yv[:, ys, xs, :].float()
         yv[:, ys, xs, :] = res.to(yv.dtype)
-        if s.stats.obj is not None:   # fp64 accumulators [SLOTS][CoutPad][2]: the interpreter adds everything to slot 0
+        if s.flags & L.MI_CONV_BNBWD:   # BatchNorm-backward sums of the layer that produced this gradient's tensor
+            b = s.bnb
+            C = Cout
+            yy = self.tv(b["y"].obj).float()[:, ys, xs, :]
+            z = yy * self.f32(b["scale"], C) + self.f32(b["shift"], C)
+            sg = torch.sigmoid(z)
+            g = sg * (1 + z * (1 - sg)) if b["act"] else torch.ones_like(z)
+            dz = yv[:, ys, xs, :].float() * g
+            xh = (yy - self.f32(b["mean"], C)) * self.f32(b["invstd"], C)
+            st = self.f64(s.stats, C * 2).view(C, 2)
+            st[:, 0] += dz.double().sum((0, 1, 2))
+            st[:, 1] += (dz * xh).double().sum((0, 1, 2))
+        elif s.stats.obj is not None:   # fp64 accumulators [SLOTS][CoutPad][2]: the interpreter adds everything to slot 0
             st = self.f64(s.stats, s.CoutPad * 2).view(s.CoutPad, 2)
             stored = yv[:, ys, xs, :].float() if not (s.flags & L.MI_CONV_OUT_F32) else res
             st[:Cout, 0] += stored.double().sum((0, 1, 2))

@@ -222,6 +222,48 @@ def test_conv_forced_configs_agree(case):
     assert ran > 20
 
 
+@pytest.mark.parametrize("strides,nfused", [((1, 2), 1), ((2, 1), 4)])
+def test_bn_backward_sums_fused_into_dgrad(monkeypatch, strides, nfused):
+    """conv -> BN -> SiLU -> two consumer convs (3x3 stride 1, and stride 2 = four parity-class launches): with
+    MI_FUSE_BN_BWD=1 the first layer's BatchNorm-backward sums come from the data-gradient epilogue(s) of the consumer
+    that writes its output gradient LAST (the first consumer in forward order; MI_CONV_BNBWD); every gradient must
+    equal the unfused plan's (same math, different summation order)"""
+    outs = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("MI_FUSE_BN_BWD", fuse)
+        g = torch.Generator().manual_seed(9)
+        N, H, W, C0, C1, C2 = 2, 24, 24, 32, 64, 64
+        b = PlanBuilder(DEV, training=True)
+        x = b.new_act(N, H, W, C0, "x")
+        mk = lambda co, ci, k: (torch.randn(co, ci, k, k, generator=g) / (ci * k * k) ** 0.5).to(DEV)
+        ws = [mk(C1, C0, 3), mk(C2, C1, 3), mk(C2, C1, 3)]
+        wg = [torch.zeros_like(w) for w in ws]
+        bns = []
+        for co in (C1, C2, C2):
+            bns.append(dict(gamma=(1 + 0.1 * torch.randn(co, generator=g)).to(DEV), beta=(0.1 * torch.randn(co, generator=g)).to(DEV),
+                            rm=torch.zeros(co, device=DEV), rv=torch.ones(co, device=DEV),
+                            nbt=torch.zeros((), dtype=torch.long, device=DEV), eps=1e-3, momentum=0.03,
+                            ggamma=torch.zeros(co, device=DEV), gbeta=torch.zeros(co, device=DEV)))
+        h = b.base_conv("c0", x, ws[0], bns[0], 3, 1, wg[0])
+        o1 = b.base_conv("c1", h, ws[1], bns[1], 3, strides[0], wg[1])
+        o2 = b.base_conv("c2", h, ws[2], bns[2], 3, strides[1], wg[2])
+        b.keep += bns
+        for o in (o1, o2):
+            assert b.grad_mode(o) == 0
+        plan = b.finalize()
+        tags = [c.tag for c in b.bwd]
+        assert ("c0.bnred" in tags) == (fuse == "0")
+        assert sum(t.endswith("+bnred") for t in tags) == (nfused if fuse == "1" else 0)
+        plan.view(x).copy_(bf(torch.randn(N, C0, H, W, generator=g)).to(DEV))
+        plan.view(o1.grad).copy_(bf(torch.randn(N, C2, H // strides[0], W // strides[0], generator=g)).to(DEV))
+        plan.view(o2.grad).copy_(bf(torch.randn(N, C2, H // strides[1], W // strides[1], generator=g)).to(DEV))
+        plan.run("fwd"); plan.run("bwd"); torch.cuda.synchronize()
+        outs[fuse] = dict(dx=plan.view(x.grad).float().cpu(), dw0=wg[0].cpu(), dg0=bns[0]["ggamma"].cpu(),
+                          db0=bns[0]["gbeta"].cpu(), dw1=wg[1].cpu())
+    for k in outs["0"]:
+        assert relerr(outs["1"][k], outs["0"][k]) < 2e-3, k
+
+
 def test_dgrad_accumulates():
     """two consumers of one tensor: the second data gradient must add to the first (MI_CONV_ACCUM)"""
     g = torch.Generator().manual_seed(5)

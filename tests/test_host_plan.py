@@ -9,6 +9,7 @@ import yolox_oracle as O
 from plan_interp import Interp
 
 import yolov7_d2_amd as M
+from yolov7_d2_amd import _lib as L
 from yolov7_d2_amd.modeling.yolox import _PlanState
 from yolov7_d2_amd.params import ParamArena
 
@@ -22,7 +23,11 @@ def _model(seed=0):
     return model, sd
 
 
-def test_plan_step_matches_oracle():
+@pytest.mark.parametrize("fuse_bn_bwd", ["0", "1"])
+def test_plan_step_matches_oracle(monkeypatch, fuse_bn_bwd):
+    # "1": the BatchNorm-backward sums are taken by the data-gradient convs (MI_CONV_BNBWD) wherever the latest writer
+    # of a layer's output gradient is such a conv; the remaining layers keep their BN_BWD_REDUCE command
+    monkeypatch.setenv("MI_FUSE_BN_BWD", fuse_bn_bwd)
     model, sd = _model()
     B, H, W = 2, 64, 96
     imgs, labels = O.synth_batch(B, H, W, seed=11, max_gt=4)
@@ -33,6 +38,9 @@ def test_plan_step_matches_oracle():
     # fp32 storage: isolates the host logic (wiring, flags, packing, tap tables) from bf16 storage noise, which
     # the oracle's own bf16 emulation shows to be ~50% on single-step gradients of this random-init network
     # (gradient condition number ~500 w.r.t. per-layer relative perturbations; see DESIGN.md "Precision").
+    nfused = sum(c.tag.endswith("+bnred") for c in b.bwd)
+    nred = sum(c.op == L.OP["BN_BWD_REDUCE"] for c in b.bwd)
+    assert (nfused, nred) == ((71, 21) if fuse_bn_bwd == "1" else (0, 74))
     it = Interp(b, torch.float32)
     it.run(b.prologue + b.fwd)
     out = it.raw(ps.loss["out"]).view(torch.float32)[:8].clone()

@@ -19,4 +19,10 @@ for which in ("fwd", "bwd"):
             d = plan.cmd_descs[which][k]
             dd = L.mi_conv_desc.from_buffer_copy(d); L.lib().mi_conv2d_plan(C.byref(dd))
             info = f"{d.H}x{d.W} K{d.K8*8} Co{d.Cout} t{d.ntaps} s{d.in_stride}{d.out_stride} tile{dd.TH}x{dd.TW} BN{dd.BN} KC{dd.KC} T{dd.TPS}"
+        elif op == "BN_ACT_FWD":
+            info = f"count{arr[k].l[1]} C{arr[k].i[3]} res{int(arr[k].i[1] > 0)}"
+        elif op == "BN_BWD_REDUCE":
+            info = f"count{arr[k].l[0]} C{arr[k].i[3]} res0"
+        elif op == "BN_BWD_APPLY":
+            info = f"count{arr[k].l[0]} C{arr[k].i[2]} res{int(arr[k].i[3] > 0)}"
         print(which, k, op, tags[k], info)

@@ -47,3 +47,25 @@ for i, t in enumerate(convs):
         line += f" {db:7.1f} {db - da:+6.1f}  {res[b][1][i][0][-28:]}"
     print(line)
 print("conv total", tot)
+
+# ---- BatchNorm launches: achieved bytes/s (fwd: read y [+res], write out; reduce: read dy, y; apply: read dy, y, write dy [+dres])
+import re
+for op, kname, nrw in (("BN_ACT_FWD", "bn_act_fwd", (1, 1)), ("BN_BWD_REDUCE", "bn_bwd_reduce", (2, 0)), ("BN_BWD_APPLY", "bn_bwd_apply", (2, 1))):
+    cmds = [t for t in tags if t[2] == op]
+    rows = [r for r in res[a][0] if kname in r[0]]
+    if len(cmds) != len(rows):
+        print(op, "count mismatch", len(cmds), len(rows)); continue
+    tot_b = tot_t = 0.0
+    by = {}
+    for t, r in zip(cmds, rows):
+        m = re.search(r"count(\d+) C(\d+) res(\d)", t[4])
+        if not m: continue
+        cnt, Cc, rs = int(m.group(1)), int(m.group(2)), int(m.group(3))
+        b = cnt * Cc * 2 * (nrw[0] + nrw[1] + rs)
+        tot_b += b; tot_t += r[1]
+        key = (cnt // 16, Cc)
+        by.setdefault(key, [0, 0.0, 0.0]); by[key][0] += 1; by[key][1] += b; by[key][2] += r[1]
+    print(f"{op}: {tot_t:.1f} us, {tot_b / 1e6:.0f} MB, {tot_b / tot_t / 1e6:.2f} TB/s")
+    for key in sorted(by, reverse=True):
+        n, b, tt = by[key]
+        print(f"    HW{key[0]:6d} C{key[1]:4d} x{n:2d}: {tt / n:6.1f} us  {b / tt / 1e6:5.2f} TB/s")

@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("MI355_LIB", os.path.join(_HERE, "libmi355det.so"))   
 
 MI_MAX_TAPS = 9
 MI_CONV_ACCUM = 1
+MI_CONV_BNBWD = 4
 MI_CONV_OUT_F32 = 2
 MI_BN_SLOTS = 16
 
@@ -32,6 +33,8 @@ class mi_conv_desc(C.Structure):
         ("tap_w", C.c_int32 * MI_MAX_TAPS),
         ("flags", C.c_int32), ("TH", C.c_int32), ("TW", C.c_int32), ("KC", C.c_int32), ("BN", C.c_int32),
         ("stats_slots", C.c_int32), ("TPS", C.c_int32),
+        ("bn_y", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p), ("bn_mean", C.c_void_p),
+        ("bn_invstd", C.c_void_p), ("bn_ldy", C.c_int32), ("bn_act", C.c_int32),
     ]
 
 

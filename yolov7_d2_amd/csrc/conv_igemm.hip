@@ -19,7 +19,9 @@
 //   * v_mfma_f32_32x32x16_bf16 with A = weights (M = cout), B = pixels (N = pixel): each
 //     lane then owns 4 consecutive couts x 4 groups of ONE pixel -> 8-byte NHWC stores.
 //   * epilogue optionally emits per-tile per-channel (sum, sumsq) from the fp32 accumulators:
-//     the BatchNorm batch statistics cost no extra pass over the conv output.
+//     the BatchNorm batch statistics cost no extra pass over the conv output.  A data-gradient launch can
+//     instead emit the BatchNorm BACKWARD sums (sum dz, sum dz*xhat) of the layer that produced its output
+//     tensor (MI_CONV_BNBWD): the final da tile is in registers, only that layer's raw conv output is re-read.
 //   * small feature maps (20x20, 40x40) get 64-pixel tiles / narrower cout tiles so that every
 //     launch has >= ~2 blocks per CU.
 #include "common.h"
@@ -36,6 +38,10 @@ struct ConvK {
   int flags, TH, TW, tilesY, tilesX, nco, nslots;
   int dymin, dxmin, haloW, npixh, nqx, xbytes;
   int tps, xstride, wstride;  // taps per weight slab; byte strides of the (double) halo / slab buffers (0: single)
+  // MI_CONV_BNBWD: BatchNorm-backward sums of the layer that produced this launch's output tensor
+  const __bf16* bn_y;
+  const float *bn_scale, *bn_shift, *bn_mean, *bn_invstd;
+  int bn_ldy, bn_act;
   unsigned mTW, mHW;  // ceil(2^20 / TW), ceil(2^20 / haloW)
 };
 
@@ -51,7 +57,10 @@ __device__ __forceinline__ void glds16(const void* g, unsigned lds_off) {
 
 // TPS: taps per step as a compile-time constant (1: the classic one-tap step, fully scheduled by the compiler) or
 // 0: run-time p.tps (multi-tap steps of the small-K / stride-2 / parity-class launches)
-template <int KC, int BN, int WM, int WN, int CT, int PT, int TPS>
+// EPI: 1 = the staged epilogue may accumulate into y (MI_CONV_ACCUM) and / or take the BatchNorm-backward sums
+// (MI_CONV_BNBWD) - its global operands are prefetched into registers; 0 = plain store (+ forward statistics), which
+// keeps the forward kernels' register count (occupancy) low
+template <int KC, int BN, int WM, int WN, int CT, int PT, int TPS, int EPI>
 __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvK p) {
   static_assert(WM * CT * 32 == BN, "cout tiling");
   constexpr int NW = WM * WN;
@@ -199,54 +208,120 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvK 
     constexpr int RS = BN * 2 + 16;  // staging row stride: +16 B keeps the 8-byte fragment writes conflict-free
     constexpr int C8N = BN / 8, PPI = NTH / C8N;
     static_assert(NTH % C8N == 0, "epilogue thread mapping");
-    __syncthreads();  // every wave is done with the halo / weight buffers
-    char* Tb = smem;
-#pragma unroll
-    for (int i = 0; i < CT; ++i)
-#pragma unroll
-      for (int j = 0; j < PT; ++j) {
-        const int row = (wn * PT + j) * 32 + l31;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int cl = (wm * CT + i) * 32 + 8 * q + 4 * h;
-          bf16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = acc[i][j][4 * q + e];
-            if (p.bias && co0 + cl + e < p.Cout) v += p.bias[co0 + cl + e];
-            o[e] = (__bf16)v;
-          }
-          *(bf16x4*)(Tb + row * RS + cl * 2) = o;
-        }
-      }
-    __syncthreads();
+    // this thread's output rows: NP pixels x one 8-channel group
+    constexpr int NP = TPIX / PPI;
+    static_assert(TPIX % PPI == 0, "epilogue rows");
     const int c8 = tid % C8N, pr = tid / C8N;
     const int cbase = co0 + c8 * 8;
     const bool cvalid = cbase < p.Cout;
-    float s1[8], s2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
     __bf16* const yb = (__bf16*)p.y + (size_t)img * (size_t)p.ynstride + cbase;
-#pragma unroll 2
-    for (int P = pr; P < TPIX; P += PPI) {
+    auto out_pixel = [&](int P) {   // linear output pixel of tile row P, or -1
       const int ty = (int)(((unsigned)P * p.mTW) >> 20);
       const int tx = P - ty * p.TW;
       const int gyy = ty0 + ty, gxx = tx0 + tx;
-      if ((P < TP) & (gyy < p.gridH) & (gxx < p.gridW) & cvalid) {
-        bf16x8 v = *(const bf16x8*)(Tb + P * RS + c8 * 16);
-        const int oy = gyy * p.os + p.ooy, ox = gxx * p.os + p.oox;
-        __bf16* yp = yb + ((size_t)oy * p.outW + ox) * (size_t)p.ldy;
-        if (accum) {
-          const bf16x8 o = *(const bf16x8*)yp;
+      const bool v = (P < TP) & (gyy < p.gridH) & (gxx < p.gridW) & cvalid;
+      return v ? (gyy * p.os + p.ooy) * p.outW + gxx * p.os + p.oox : -1;
+    };
+    auto stage = [&]() {
+      __syncthreads();  // every wave is done with the halo / weight buffers
+      char* Tb = smem;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] + (float)o[e]);
+      for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+          const int row = (wn * PT + j) * 32 + l31;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int cl = (wm * CT + i) * 32 + 8 * q + 4 * h;
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float v = acc[i][j][4 * q + e];
+              if (p.bias && co0 + cl + e < p.Cout) v += p.bias[co0 + cl + e];
+              o[e] = (__bf16)v;
+            }
+            *(bf16x4*)(Tb + row * RS + cl * 2) = o;
+          }
         }
-        *(bf16x8*)yp = v;
+      __syncthreads();
+    };
+    const char* const Tb = smem;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    if constexpr (EPI == 0) {
+      // (measured dead end: taking the statistics from the staged tile FIRST and issuing the atomics before the stores
+      //  - so that their latency overlaps the store phase - is 0.6 % slower than this order)
+      stage();
+#pragma unroll 2
+      for (int P = pr; P < TPIX; P += PPI) {
+        const int op = out_pixel(P);
+        if (op >= 0) {
+          const bf16x8 v = *(const bf16x8*)(Tb + P * RS + c8 * 16);
+          *(bf16x8*)(yb + (size_t)op * (size_t)p.ldy) = v;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float f = (float)v[e];
+            s1[e] += f;
+            s2[e] += f * f;
+          }
+        }
+      }
+    } else {
+      // the global operands of the store loop (old values of an accumulating launch, the producing layer's conv
+      // output of a BNBWD launch) are requested BEFORE the staging, so their latency overlaps it instead of
+      // serialising NP round trips in the loop
+      const bool bnb = (p.flags & MI_CONV_BNBWD) != 0;
+      const __bf16* const byb = p.bn_y + (size_t)img * (size_t)p.outH * p.outW * p.bn_ldy + cbase;
+      int opix[NP];
+      bf16x8 oldv[NP], yv[NP];
+#pragma unroll
+      for (int it = 0; it < NP; ++it) {
+        opix[it] = out_pixel(pr + it * PPI);
+        if (opix[it] >= 0 && accum) oldv[it] = *(const bf16x8*)(yb + (size_t)opix[it] * (size_t)p.ldy);
+        if (opix[it] >= 0 && bnb) yv[it] = *(const bf16x8*)(byb + (size_t)opix[it] * (size_t)p.bn_ldy);
+      }
+      float bsc[8], bsh[8], bmu[8], bis[8];
+      if (bnb && cvalid) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float f = (float)v[e];
-          s1[e] += f;
-          s2[e] += f * f;
+          bsc[e] = p.bn_scale[cbase + e]; bsh[e] = p.bn_shift[cbase + e];
+          bmu[e] = p.bn_mean[cbase + e];  bis[e] = p.bn_invstd[cbase + e];
+        }
+      }
+      stage();
+#pragma unroll
+      for (int it = 0; it < NP; ++it) {
+        if (opix[it] >= 0) {
+          const int P = pr + it * PPI;
+          bf16x8 v = *(const bf16x8*)(Tb + P * RS + c8 * 16);
+          if (accum) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] + (float)oldv[it][e]);
+          }
+          *(bf16x8*)(yb + (size_t)opix[it] * (size_t)p.ldy) = v;
+          if (bnb) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float yy = (float)yv[it][e];
+              const float z = yy * bsc[e] + bsh[e];
+              float g = 1.f;
+              if (p.bn_act) {
+                const float sg = sigmoidf_(z);
+                g = sg * (1.f + z * (1.f - sg));
+              }
+              const float dz = (float)v[e] * g;
+              s1[e] += dz;
+              s2[e] += dz * ((yy - bmu[e]) * bis[e]);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float f = (float)v[e];
+              s1[e] += f;
+              s2[e] += f * f;
+            }
+          }
         }
       }
     }
@@ -426,6 +501,16 @@ static int conv_fill(const mi_conv_desc* d, ConvK* k, ConvCfg* c, size_t* ldsByt
     if (d->tap_dx[t] > dxmax) dxmax = d->tap_dx[t];
   }
   k->flags = d->flags;
+  if (d->flags & MI_CONV_BNBWD) {
+    MI_REQUIRE(d->stats_acc && d->bn_y && d->bn_scale && d->bn_shift && d->bn_mean && d->bn_invstd,
+               "conv: MI_CONV_BNBWD needs stats_acc and the producing layer's bn_* arrays");
+    MI_REQUIRE(!(d->flags & MI_CONV_OUT_F32) && d->Cout % 8 == 0 && d->bn_ldy % 8 == 0 && ((uintptr_t)d->bn_y % 16) == 0,
+               "conv: MI_CONV_BNBWD needs a bf16 output with Cout %% 8 == 0 (staged epilogue) and 16B-aligned bn_y");
+    k->bn_y = (const __bf16*)d->bn_y; k->bn_scale = d->bn_scale; k->bn_shift = d->bn_shift;
+    k->bn_mean = d->bn_mean; k->bn_invstd = d->bn_invstd; k->bn_ldy = d->bn_ldy; k->bn_act = d->bn_act;
+  } else {
+    k->bn_y = nullptr; k->bn_scale = k->bn_shift = k->bn_mean = k->bn_invstd = nullptr; k->bn_ldy = 0; k->bn_act = 0;
+  }
   // ---- tile configuration: largest tile that still gives >= ~2 blocks per CU
   const int Kp = d->K8 * 8;
   int BNmax = (d->CoutPad % 128 == 0) ? 128 : (d->CoutPad % 64 == 0) ? 64 : 32;
@@ -542,9 +627,9 @@ extern "C" int mi_conv2d_plan(mi_conv_desc* d) {
   return d->N * k.tilesY * k.tilesX;
 }
 
-template <int KC, int BN, int WM, int WN, int CT, int PT, int TPS>
+template <int KC, int BN, int WM, int WN, int CT, int PT, int TPS, int EPI>
 static int launch_one(const ConvK& k, size_t lds, hipStream_t s) {
-  auto fn = conv_igemm_kernel<KC, BN, WM, WN, CT, PT, TPS>;
+  auto fn = conv_igemm_kernel<KC, BN, WM, WN, CT, PT, TPS, EPI>;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -557,8 +642,9 @@ static int launch_one(const ConvK& k, size_t lds, hipStream_t s) {
 }
 template <int KC, int BN, int WM, int WN, int CT, int PT>
 static int launch_cfg(const ConvK& k, size_t lds, hipStream_t s) {
-  if (k.tps == 1) return launch_one<KC, BN, WM, WN, CT, PT, 1>(k, lds, s);
-  return launch_one<KC, BN, WM, WN, CT, PT, 0>(k, lds, s);
+  const bool epi = (k.flags & (MI_CONV_ACCUM | MI_CONV_BNBWD)) != 0;
+  if (k.tps == 1) return epi ? launch_one<KC, BN, WM, WN, CT, PT, 1, 1>(k, lds, s) : launch_one<KC, BN, WM, WN, CT, PT, 1, 0>(k, lds, s);
+  return epi ? launch_one<KC, BN, WM, WN, CT, PT, 0, 1>(k, lds, s) : launch_one<KC, BN, WM, WN, CT, PT, 0, 0>(k, lds, s);
 }
 
 extern "C" int mi_conv2d(const mi_conv_desc* d, mi_stream_t st) {

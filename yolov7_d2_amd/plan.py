@@ -113,6 +113,12 @@ class PlanBuilder:
         self.bwd = []
         self._emitting_bwd = False
         self.grad_init = {}  # id(gbuf) -> list of (c0,c1) initialised channel intervals
+        self.last_writer = {}  # id(gbuf) -> [(c0, c1, [conv cmds])]: channel ranges whose LATEST writer is a data-gradient conv
+        # BatchNorm-backward sums taken by the data-gradient conv that writes the final da (MI_CONV_BNBWD) instead of a
+        # separate reduce pass over (da, y): 53 of the 74 reduce launches of YOLOX-s disappear, but measured (A/B, round 1)
+        # the step time does not move - the fp64 accumulator atomics a block must wait for cost the data-gradient
+        # kernels what the reduce kernels cost -> opt-in
+        self.fuse_bn_bwd = os.environ.get("MI_FUSE_BN_BWD", "0") != "0"
         self.keep = []       # python objects that must outlive the plan (ctypes descs, tensors)
         self.tune_restore = []   # tensors a replay of the forward list mutates (BN running statistics)
         self.loss = None
@@ -211,6 +217,8 @@ class PlanBuilder:
         key = id(t.gbuf)
         iv = self.grad_init.setdefault(key, [])
         c0, c1 = t.coff, t.coff + t.C
+        lw = self.last_writer.setdefault(key, [])   # whoever asks is about to write [c0, c1): older records are stale
+        lw[:] = [w for w in lw if not (w[0] < c1 and c0 < w[1])]
         covered = [a for a in iv if a[0] < c1 and c0 < a[1]]
         if not covered:
             iv.append((c0, c1))
@@ -320,12 +328,28 @@ class PlanBuilder:
             C8 = Cout // 8
             nblk = max(1, min(1024, math.ceil(count / (256 // C8) / 4)))
             nsl2 = self.bn_slots(nblk)
+            fused = None
+            if self.fuse_bn_bwd:   # the latest writer of exactly this gradient view is a data-gradient conv (set)
+                for (w0, w1, cmds) in self.last_writer.get(id(out.gbuf), []):
+                    if (w0, w1) == (out.coff, out.coff + Cout) and all(c.desc.ldy == da.ld for c in cmds):
+                        fused = cmds
+            if fused is not None:
+                nsl2 = self.bn_slots(1 << 30)
             dacc = self.bn_acc("bwd", Cout, nsl2)
             dy = (self._new_buf(tag + ".dy", count * Cout * 2) if self.group_wgrad
                   else self.scratch("dy", count * Cout * 2))
             dyT = TRef(dy, x.N, Ho, Wo, Cout, Cout)
-            self.emit("BN_BWD_REDUCE", i=[da.ld, y.ld, nblk, Cout, act, nsl2], l=[count],
-                      p=[da, y, scale, shift, mean, invstd, dacc], tag=tag + ".bnred")
+            if fused is not None:
+                for c in fused:
+                    sp = c.desc
+                    sp.flags |= L.MI_CONV_BNBWD
+                    sp.stats, sp.stats_slots = (dacc if isinstance(dacc, _Ptr) else _Ptr(dacc)), nsl2
+                    sp.bnb = dict(y=_Ptr(y), ldy=y.ld, scale=_Ptr(scale), shift=_Ptr(shift), mean=_Ptr(mean),
+                                  invstd=_Ptr(invstd), act=act)
+                    c.tag += "+bnred"
+            else:
+                self.emit("BN_BWD_REDUCE", i=[da.ld, y.ld, nblk, Cout, act, nsl2], l=[count],
+                          p=[da, y, scale, shift, mean, invstd, dacc], tag=tag + ".bnred")
             dres, dres_acc = None, 0
             if res is not None and res.requires_grad:
                 dres = res.grad
@@ -368,9 +392,10 @@ class PlanBuilder:
         acc = self.grad_mode(x)
         flags = L.MI_CONV_ACCUM if acc else 0
         # output channels written: the real Cin (x may carry zero pad channels, e.g. the 12->16 stem)
+        cmds = []
         if stride == 1:
             taps = [(pad - r, pad - s, r * k + s) for r in range(k) for s in range(k)]
-            self.conv_cmd(tag + ".dgrad", dyT, wd, K8, dx, dx.ld, x.H, x.W, Cin, CinPadN, taps, flags=flags)
+            cmds.append(self.conv_cmd(tag + ".dgrad", dyT, wd, K8, dx, dx.ld, x.H, x.W, Cin, CinPadN, taps, flags=flags))
         else:
             assert stride == 2 and k == 3 and pad == 1
             cls_taps = {0: [(1, 0)], 1: [(0, 1), (2, 0)]}  # parity -> [(r, offset)]
@@ -378,8 +403,10 @@ class PlanBuilder:
                 for px in (0, 1):
                     taps = [(oy, ox, r * 3 + s) for (r, oy) in cls_taps[py] for (s, ox) in cls_taps[px]]
                     gh, gw_ = (x.H - py + 1) // 2, (x.W - px + 1) // 2
-                    self.conv_cmd(f"{tag}.dgrad{py}{px}", dyT, wd, K8, dx, dx.ld, x.H, x.W, Cin, CinPadN, taps,
-                                  out_stride=2, out_oy=py, out_ox=px, gridH=gh, gridW=gw_, flags=flags)
+                    cmds.append(self.conv_cmd(f"{tag}.dgrad{py}{px}", dyT, wd, K8, dx, dx.ld, x.H, x.W, Cin, CinPadN, taps,
+                                              out_stride=2, out_oy=py, out_ox=px, gridH=gh, gridW=gw_, flags=flags))
+        if x.C == Cin and Cin % 8 == 0:
+            self.last_writer.setdefault(id(x.gbuf), []).append((x.coff, x.coff + x.C, cmds))
 
     def pred_conv(self, tag, x, weight, bias, wgrad, bgrad, preds, A, a0, c0, nch):
         """biased 1x1 prediction conv writing fp32 straight into preds[B][A][nch] at (anchor a0, channel c0)."""
@@ -565,6 +592,11 @@ class Plan:
             d.ntaps = len(spec.taps)
             for t, (dy, dx, w) in enumerate(spec.taps):
                 d.tap_dy[t], d.tap_dx[t], d.tap_w[t] = dy, dx, w
+            bnb = getattr(spec, "bnb", None)
+            if bnb is not None:
+                d.bn_y, d.bn_ldy, d.bn_act = bnb["y"].resolve(), bnb["ldy"], bnb["act"]
+                d.bn_scale, d.bn_shift = bnb["scale"].resolve(), bnb["shift"].resolve()
+                d.bn_mean, d.bn_invstd = bnb["mean"].resolve(), bnb["invstd"].resolve()
         elif kind == "bias_jobs":
             d = (L.mi_bias_job * len(spec.jobs))()
             for jd, j in zip(d, spec.jobs):
