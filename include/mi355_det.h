@@ -97,6 +97,20 @@ int mi_conv2d(const mi_conv_desc* d, mi_stream_t s);
 /* fills TH/TW/KC/BN/TPS if zero; returns number of pixel tiles or <0 */
 int mi_conv2d_plan(mi_conv_desc* d);
 
+/* several independent convolutions in ONE launch (the FPN levels of the head: the 40x40 / 20x20 launches are
+ * latency-bound alone).  All jobs run the template configuration chosen for the job with the most output pixels, so
+ * their K must be a multiple of its k-chunk, CoutPad of its cout tile, and they must agree on ntaps-divisibility and
+ * on MI_CONV_ACCUM / MI_CONV_BNBWD.  _plan() writes the device job table into table_host (caller uploads it; NULL / 0
+ * to query meta->table_bytes); _run() launches it. */
+#define MI_CONV_MAX_GROUP 8
+typedef struct mi_conv_group {
+  int32_t njobs, nblocks, lds_bytes;
+  int32_t KC, BN, TPIX, TPS, EPI;
+  int64_t starts_off, table_bytes;
+} mi_conv_group;
+int mi_conv2d_group_plan(const mi_conv_desc* descs, int n, void* table_host, int64_t table_cap, mi_conv_group* meta);
+int mi_conv2d_group_run(const mi_conv_group* meta, const void* table_dev, mi_stream_t s);
+
 /* weight gradient: g[co][ci][tap] (fp32 OIHW, the nn.Parameter gradient layout; overwritten, or += if
  * `accumulate`) = sum_pixels dy[p][co] * x[p*stride + tap][ci].  replaces conv wgrad of the same modules.
  * Split-K over pixel tiles with a caller-owned fp32 workspace (no atomics: the split partials are summed
@@ -158,6 +172,27 @@ int mi_pack_conv_weights_batch(const mi_pack_job* jobs_dev, int njobs, mi_stream
 /* ---- BatchNorm(train) + SiLU (+ residual) -----------------------------
  * replaces nn.BatchNorm2d + nn.SiLU of BaseConv (wrappers.py:76-80) and the
  * Bottleneck add (wrappers.py:119-123). */
+/* the same BatchNorm pass of several independent layers in ONE launch (FPN levels of the head).
+ * kind 0 = mi_bn_act_fwd, 1 = mi_bn_act_bwd_reduce, 2 = mi_bn_act_bwd_apply; the fields of a job mean what the
+ * arguments of those calls mean (acc = stats_acc / dacc).  All jobs share `act`. */
+#define MI_BN_MAX_GROUP 8
+typedef struct mi_bn_job {
+  const void* y; const void* res; void* a;
+  const void* da; void* dy; void* dres;
+  double* acc;
+  const float* gamma; const float* beta; float* rmean; float* rvar; int64_t* nbt;
+  float* scale; float* shift; float* mean; float* invstd; float* dgamma; float* dbeta;
+  int64_t npix, count;
+  int32_t ldy, ldres, lda, ldda, lddy, lddres, dres_accum, C, nslots, nblk, act, pad_;
+  float eps, momentum;
+} mi_bn_job;
+typedef struct mi_bn_group {
+  int32_t kind, njobs, nblocks, act;
+  int64_t starts_off, table_bytes;
+} mi_bn_group;
+int mi_bn_group_plan(int kind, const mi_bn_job* jobs, int n, void* table_host, int64_t table_cap, mi_bn_group* meta);
+int mi_bn_group_run(const mi_bn_group* meta, const void* table_dev, mi_stream_t s);
+
 /* eval mode: scale/shift from running statistics */
 int mi_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                       const float* running_var, float eps, int C, float* scale, float* shift,
@@ -385,6 +420,8 @@ enum {
   MI_OP_FORK = 27,   /* aux stream i[0] waits for everything issued so far on the caller's stream               */
   MI_OP_JOIN = 28,   /* the caller's stream waits for everything issued so far on aux stream i[0]               */
   MI_OP_BIAS_GRADS = 29,
+  MI_OP_CONV_GROUP = 30,   /* p0 = mi_conv_group* (host), p1 = device job table */
+  MI_OP_BN_GROUP = 31,     /* p0 = mi_bn_group* (host),   p1 = device job table */
   MI_OP_COUNT
 };
 

@@ -48,6 +48,25 @@ class mi_detr_loss_desc(C.Structure):
     ]
 
 
+class mi_conv_group(C.Structure):
+    _fields_ = [("njobs", C.c_int32), ("nblocks", C.c_int32), ("lds_bytes", C.c_int32), ("KC", C.c_int32),
+                ("BN", C.c_int32), ("TPIX", C.c_int32), ("TPS", C.c_int32), ("EPI", C.c_int32),
+                ("starts_off", C.c_int64), ("table_bytes", C.c_int64)]
+
+
+class mi_bn_job(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("y", "res", "a", "da", "dy", "dres", "acc", "gamma", "beta", "rmean", "rvar",
+                                          "nbt", "scale", "shift", "mean", "invstd", "dgamma", "dbeta")] + \
+               [("npix", C.c_int64), ("count", C.c_int64)] + \
+               [(n, C.c_int32) for n in ("ldy", "ldres", "lda", "ldda", "lddy", "lddres", "dres_accum", "C", "nslots",
+                                         "nblk", "act", "pad_")] + [("eps", C.c_float), ("momentum", C.c_float)]
+
+
+class mi_bn_group(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("njobs", C.c_int32), ("nblocks", C.c_int32), ("act", C.c_int32),
+                ("starts_off", C.c_int64), ("table_bytes", C.c_int64)]
+
+
 class mi_wgrad_desc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("dy", C.c_void_p), ("gw", C.c_void_p), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
@@ -109,7 +128,8 @@ class mi_cmd(C.Structure):
 # opcode names must match the enum in include/mi355_det.h
 OPS = ["NOP", "CONV", "WGRAD", "PACK_W", "RESERVED4", "RESERVED5", "BN_ACT_FWD", "BN_BWD_REDUCE",
        "RESERVED8", "BN_BWD_APPLY", "FOCUS", "UPSAMPLE_FWD", "UPSAMPLE_BWD", "SPP_FWD", "SPP_BWD", "COPY",
-       "COLSUM", "LOSS_FWD", "LOSS_BWD", "SPLIT_DPREDS", "MEMSET", "SGD", "BN_EVAL_AFFINE", "DECODE", "PACK_W_BATCH", "WGRAD_GROUP", "STREAM", "FORK", "JOIN", "BIAS_GRADS"]
+       "COLSUM", "LOSS_FWD", "LOSS_BWD", "SPLIT_DPREDS", "MEMSET", "SGD", "BN_EVAL_AFFINE", "DECODE", "PACK_W_BATCH", "WGRAD_GROUP", "STREAM", "FORK", "JOIN", "BIAS_GRADS",
+       "CONV_GROUP", "BN_GROUP"]
 OP = {n: k for k, n in enumerate(OPS)}
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -145,6 +165,10 @@ _PROTOS = {
     "mi_yolox_decode": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
     "mi_hungarian_match": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "mi_lsap": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "mi_conv2d_group_plan": (C.c_int, [C.POINTER(mi_conv_desc), _i, _vp, _i64, C.POINTER(mi_conv_group)]),
+    "mi_conv2d_group_run": (C.c_int, [C.POINTER(mi_conv_group), _vp, _vp]),
+    "mi_bn_group_plan": (C.c_int, [_i, C.POINTER(mi_bn_job), _i, _vp, _i64, C.POINTER(mi_bn_group)]),
+    "mi_bn_group_run": (C.c_int, [C.POINTER(mi_bn_group), _vp, _vp]),
     "mi_detr_set_loss_fwd": (C.c_int, [C.POINTER(mi_detr_loss_desc), _vp]),
     "mi_detr_set_loss_bwd": (C.c_int, [C.POINTER(mi_detr_loss_desc), _vp, _vp, _vp, _vp]),
     "mi_mha_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),

@@ -12,6 +12,7 @@
 //   * bn_bwd_reduce accumulates (sum dz, sum dz*xhat) the same way and bn_bwd_apply finalizes in its prologue.
 // fp64 accumulation of fp32 tile sums makes the result independent of the atomic arrival order except in
 // astronomically rare rounding ties.  All kernels are HBM streams: 16-byte (8 x bf16) accesses, fp32 math.
+#include <string.h>
 #include "common.h"
 
 #define BN_MAXC 1024
@@ -57,8 +58,8 @@ struct BnFwdK {
   float eps, momentum;
 };
 
-template <int ACT>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnFwdK p) {
+template <int ACT, class PK>
+__device__ __forceinline__ void bn_act_fwd_body(PK& p, const int bid, const int nb) {
   __shared__ float s_sc[BN_MAXC], s_sh[BN_MAXC];
   const int C = p.C8 * 8;
   if (p.acc) {
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnFwdK p) {
       const float sh = (float)((double)b - mean * (double)g * invstd);
       s_sc[c] = sc;
       s_sh[c] = sh;
-      if (blockIdx.x == 0) {
+      if (bid == 0) {
         p.scale[c] = sc;
         p.shift[c] = sh;
         p.mean[c] = (float)mean;
@@ -104,8 +105,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnFwdK p) {
   __syncthreads();
   const int C8 = p.C8;
   const int64_t total = p.npix * C8;
-  // (gridDim.x * 256) % C8 == 0, so a thread keeps its channel group: hoist its 8 scale/shift pairs
-  const int c8 = (int)((blockIdx.x * 256LL + threadIdx.x) % C8);
+  // (nb * 256) % C8 == 0, so a thread keeps its channel group: hoist its 8 scale/shift pairs
+  const int c8 = (int)((bid * 256LL + threadIdx.x) % C8);
   float sc[8], sh[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -114,8 +115,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnFwdK p) {
   }
   // 4 grid-stride elements per trip, all loads issued before the first use (one load in flight per wave is
   // latency-bound: ~1 us per trip)
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += 4 * stride) {
+  const int64_t stride = (int64_t)nb * 256;
+  for (int64_t idx = bid * 256LL + threadIdx.x; idx < total; idx += 4 * stride) {
     bf16x8 v[4], r[4];
     int64_t pix[4];
 #pragma unroll
@@ -143,6 +144,26 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnFwdK p) {
       *(bf16x8*)(p.a + pix[u] * p.lda + c8 * 8) = pack8(o);
     }
   }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const BnFwdK p) {
+  bn_act_fwd_body<ACT, const BnFwdK>(p, blockIdx.x, gridDim.x);
+}
+// several layers in one launch (the FPN levels of the head): the block looks its layer up in a device table
+__device__ __forceinline__ int bn_group_job(const int* __restrict__ starts, int njobs) {
+  int j = 0;
+  while (j + 1 < njobs && (int)blockIdx.x >= starts[j + 1]) ++j;
+  return __builtin_amdgcn_readfirstlane(j);
+}
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_act_fwd_group_kernel(const BnFwdK* __restrict__ jobs, const int* __restrict__ starts,
+                                                               int njobs) {
+  const int j = bn_group_job(starts, njobs);
+  // constant-address-space view of the table entry: invariant loads, the fields stay in SGPRs across the stores
+  typedef const __attribute__((address_space(4))) BnFwdK KC4;
+  KC4* pj = (KC4*)(uintptr_t)(jobs + j);
+  bn_act_fwd_body<ACT, KC4>(*pj, (int)blockIdx.x - starts[j], starts[j + 1] - starts[j]);
 }
 
 // every block pays the statistics prologue (2 x MI_BN_SLOTS fp64 loads + an fp64 rsqrt per channel): give each thread
@@ -192,40 +213,46 @@ __device__ __forceinline__ float act_grad(float z, int act) {
 
 // pass 1: per-channel sums of (dz, dz*xhat) -> fp64 accumulators dacc[MI_BN_SLOTS][C][2].  256 % C8 == 0 so a
 // thread's channel group is fixed (c8 = tid % C8) and its pixel lane is tid / C8.
-template <int ACT>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const __bf16* __restrict__ da, int ldda,
-                                                            const __bf16* __restrict__ y, int ldy,
-                                                            const float* __restrict__ scale,
-                                                            const float* __restrict__ shift,
-                                                            const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, double* dacc, int nslots,
-                                                            int64_t npix, int C8) {
+struct BnRedK {
+  const __bf16* da;
+  const __bf16* y;
+  const float* scale;
+  const float* shift;
+  const float* mean;
+  const float* invstd;
+  double* dacc;
+  int ldda, ldy, nslots, C8;
+  int64_t npix;
+};
+template <int ACT, class PK>
+__device__ __forceinline__ void bn_bwd_reduce_body(PK& p, const int bid, const int nb) {
   __shared__ float red[256 * 16];
   const int tid = threadIdx.x;
+  const int C8 = p.C8;
   const int c8 = tid % C8, pl = tid / C8, PL = 256 / C8;
   float sc[8], sh[8], mu[8], is[8], s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    sc[e] = scale[c8 * 8 + e];
-    sh[e] = shift[c8 * 8 + e];
-    mu[e] = mean[c8 * 8 + e];
-    is[e] = invstd[c8 * 8 + e];
+    sc[e] = p.scale[c8 * 8 + e];
+    sh[e] = p.shift[c8 * 8 + e];
+    mu[e] = p.mean[c8 * 8 + e];
+    is[e] = p.invstd[c8 * 8 + e];
     s1[e] = s2[e] = 0.f;
   }
-  const int64_t pstride = (int64_t)gridDim.x * PL;
-  for (int64_t pix0 = (int64_t)blockIdx.x * PL + pl; pix0 < npix; pix0 += 4 * pstride) {
+  const int64_t pstride = (int64_t)nb * PL;
+  for (int64_t pix0 = (int64_t)bid * PL + pl; pix0 < p.npix; pix0 += 4 * pstride) {
     bf16x8 dv[4], yv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int64_t pix = pix0 + u * pstride;
-      if (pix < npix) {
-        dv[u] = *(const bf16x8*)(da + pix * ldda + c8 * 8);
-        yv[u] = *(const bf16x8*)(y + pix * ldy + c8 * 8);
+      if (pix < p.npix) {
+        dv[u] = *(const bf16x8*)(p.da + pix * p.ldda + c8 * 8);
+        yv[u] = *(const bf16x8*)(p.y + pix * p.ldy + c8 * 8);
       }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      if (pix0 + u * pstride >= npix) break;
+      if (pix0 + u * pstride >= p.npix) break;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float yy = (float)yv[u][e];
@@ -244,7 +271,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const __bf16* __rest
   }
   __syncthreads();
   const int nout = C8 * 16, C = C8 * 8;
-  double* slot = dacc + (size_t)(blockIdx.x % nslots) * C * 2;
+  double* slot = p.dacc + (size_t)(bid % p.nslots) * C * 2;
   for (int j = tid; j < nout; j += 256) {
     float acc = 0.f;
     for (int q = 0; q < PL; ++q) acc += red[q * nout + j];
@@ -254,6 +281,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const __bf16* __rest
   }
 }
 
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnRedK p) {
+  bn_bwd_reduce_body<ACT, const BnRedK>(p, blockIdx.x, gridDim.x);
+}
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_group_kernel(const BnRedK* __restrict__ jobs,
+                                                                  const int* __restrict__ starts, int njobs) {
+  const int j = bn_group_job(starts, njobs);
+  // constant-address-space view of the table entry: invariant loads, the fields stay in SGPRs across the stores
+  typedef const __attribute__((address_space(4))) BnRedK KC4;
+  KC4* pj = (KC4*)(uintptr_t)(jobs + j);
+  bn_bwd_reduce_body<ACT, KC4>(*pj, (int)blockIdx.x - starts[j], starts[j + 1] - starts[j]);
+}
+
 extern "C" int mi_bn_act_bwd_reduce(const void* da, int ldda, const void* y, int ldy, const float* scale,
                                     const float* shift, const float* mean, const float* invstd, double* dacc,
                                     int nslots, int nblk, int64_t npix, int C, int act, mi_stream_t st) {
@@ -261,12 +302,13 @@ extern "C" int mi_bn_act_bwd_reduce(const void* da, int ldda, const void* y, int
   MI_REQUIRE(da && y && scale && shift && mean && invstd && dacc, "bn_bwd_reduce: null");
   MI_REQUIRE(C % 8 == 0 && C <= BN_MAXC && (256 % (C / 8)) == 0, "bn_bwd_reduce: C %d (need 256 %% (C/8) == 0)", C);
   MI_REQUIRE(ldda % 8 == 0 && ldy % 8 == 0 && nblk > 0, "bn_bwd_reduce: ld");
+  BnRedK k;
+  k.da = (const __bf16*)da; k.y = (const __bf16*)y; k.scale = scale; k.shift = shift; k.mean = mean; k.invstd = invstd;
+  k.dacc = dacc; k.ldda = ldda; k.ldy = ldy; k.nslots = nslots; k.C8 = C / 8; k.npix = npix;
   if (act)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(nblk), dim3(256), 0, (hipStream_t)st, (const __bf16*)da, ldda,
-                       (const __bf16*)y, ldy, scale, shift, mean, invstd, dacc, nslots, npix, C / 8);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(nblk), dim3(256), 0, (hipStream_t)st, k);
   else
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, dim3(nblk), dim3(256), 0, (hipStream_t)st, (const __bf16*)da, ldda,
-                       (const __bf16*)y, ldy, scale, shift, mean, invstd, dacc, nslots, npix, C / 8);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, dim3(nblk), dim3(256), 0, (hipStream_t)st, k);
   MI_CHECK_LAUNCH("bn_bwd_reduce");
   return MI_OK;
 }
@@ -291,8 +333,8 @@ struct BnBwdK {
   double inv_count;
 };
 
-template <int ACT>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK p) {
+template <int ACT, class PK>
+__device__ __forceinline__ void bn_bwd_apply_body(PK& p, const int bid, const int nb) {
   __shared__ float s_c1[BN_MAXC], s_c2[BN_MAXC];
   const int C8 = p.C8, C = C8 * 8;
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -308,14 +350,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK p) {
     }
     s_c1[c] = (float)(s1 * p.inv_count);
     s_c2[c] = (float)(s2 * p.inv_count);
-    if (blockIdx.x == 0) {
+    if (bid == 0) {
       if (p.dbeta) p.dbeta[c] = (float)s1;
       if (p.dgamma) p.dgamma[c] = (float)s2;
     }
   }
   __syncthreads();
   const int64_t total = p.npix * C8;
-  const int c8 = (int)((blockIdx.x * 256LL + threadIdx.x) % C8);
+  const int c8 = (int)((bid * 256LL + threadIdx.x) % C8);
   float sc[8], sh[8], mu[8], is[8], gi[8], k1[8], k2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -328,8 +370,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK p) {
     k1[e] = s_c1[c];
     k2[e] = s_c2[c];
   }
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += 2 * stride) {
+  const int64_t stride = (int64_t)nb * 256;
+  for (int64_t idx = bid * 256LL + threadIdx.x; idx < total; idx += 2 * stride) {
     bf16x8 dv[2], yv[2], rv[2];
     int64_t pix[2];
 #pragma unroll
@@ -370,6 +412,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK p) {
   }
 }
 
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdK p) {
+  bn_bwd_apply_body<ACT, const BnBwdK>(p, blockIdx.x, gridDim.x);
+}
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_group_kernel(const BnBwdK* __restrict__ jobs,
+                                                                 const int* __restrict__ starts, int njobs) {
+  const int j = bn_group_job(starts, njobs);
+  // constant-address-space view of the table entry: invariant loads, the fields stay in SGPRs across the stores
+  typedef const __attribute__((address_space(4))) BnBwdK KC4;
+  KC4* pj = (KC4*)(uintptr_t)(jobs + j);
+  bn_bwd_apply_body<ACT, KC4>(*pj, (int)blockIdx.x - starts[j], starts[j + 1] - starts[j]);
+}
+
 extern "C" int mi_bn_act_bwd_apply(const void* da, int ldda, const void* y, int ldy, const float* scale,
                                    const float* shift, const float* mean, const float* invstd, const float* gamma,
                                    const double* dacc, int nslots, int64_t count, float* dgamma, float* dbeta, void* dy,
@@ -391,5 +447,88 @@ extern "C" int mi_bn_act_bwd_apply(const void* da, int ldda, const void* y, int 
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)st, k);
   MI_CHECK_LAUNCH("bn_bwd_apply");
+  return MI_OK;
+}
+
+// ------------------------------------------------------------------ grouped launches
+// one launch for the same BatchNorm pass of several independent layers (the FPN levels of the head)
+extern "C" int mi_bn_group_plan(int kind, const mi_bn_job* jobs, int n, void* table_host, int64_t table_cap,
+                                mi_bn_group* meta) {
+  MI_REQUIRE(jobs && meta && n >= 1 && n <= MI_BN_MAX_GROUP && kind >= 0 && kind <= 2, "bn_group_plan: args");
+  int starts[MI_BN_MAX_GROUP + 1];
+  starts[0] = 0;
+  BnFwdK kf[MI_BN_MAX_GROUP];
+  BnRedK kr[MI_BN_MAX_GROUP];
+  BnBwdK ka[MI_BN_MAX_GROUP];
+  for (int j = 0; j < n; ++j) {
+    const mi_bn_job& b = jobs[j];
+    const int C = b.C;
+    MI_REQUIRE(C % 8 == 0 && C <= BN_MAXC && (256 % (C / 8)) == 0 && b.npix > 0, "bn_group_plan: job %d C %d", j, C);
+    MI_REQUIRE(b.act == jobs[0].act, "bn_group_plan: jobs must agree on the activation");
+    const int nslots = (b.nslots >= 1 && b.nslots <= MI_BN_SLOTS) ? b.nslots : MI_BN_SLOTS;
+    const int64_t total = b.npix * (C / 8);
+    int nb = ew_blocks(total);
+    if (kind == 0) {
+      MI_REQUIRE(b.y && b.a && b.scale && b.shift && b.ldy % 8 == 0 && b.lda % 8 == 0 && (!b.res || b.ldres % 8 == 0),
+                 "bn_group_plan: fwd job %d", j);
+      BnFwdK& k = kf[j];
+      k.y = (const __bf16*)b.y; k.res = (const __bf16*)b.res; k.a = (__bf16*)b.a; k.acc = b.acc; k.gamma = b.gamma;
+      k.beta = b.beta; k.rmean = b.rmean; k.rvar = b.rvar; k.nbt = b.nbt; k.scale = b.scale; k.shift = b.shift;
+      k.mean = b.mean; k.invstd = b.invstd; k.ldy = b.ldy; k.ldres = b.ldres; k.lda = b.lda; k.C8 = C / 8;
+      k.npix = b.npix; k.nslots = nslots;
+      if (b.acc) {
+        MI_REQUIRE(b.gamma && b.beta && b.mean && b.invstd && b.count > 0, "bn_group_plan: train-mode fwd job %d", j);
+        k.inv_count = 1.0 / (double)b.count;
+        k.unbias = b.count > 1 ? (double)b.count / (double)(b.count - 1) : 1.0;
+      } else {
+        k.inv_count = 0.0; k.unbias = 1.0;
+      }
+      k.eps = b.eps; k.momentum = b.momentum;
+    } else if (kind == 1) {
+      MI_REQUIRE(b.da && b.y && b.scale && b.shift && b.mean && b.invstd && b.acc && b.nblk > 0, "bn_group_plan: reduce job %d", j);
+      BnRedK& k = kr[j];
+      k.da = (const __bf16*)b.da; k.y = (const __bf16*)b.y; k.scale = b.scale; k.shift = b.shift; k.mean = b.mean;
+      k.invstd = b.invstd; k.dacc = b.acc; k.ldda = b.ldda; k.ldy = b.ldy; k.nslots = nslots; k.C8 = C / 8; k.npix = b.npix;
+      nb = b.nblk;
+    } else {
+      MI_REQUIRE(b.da && b.y && b.scale && b.shift && b.mean && b.invstd && b.gamma && b.acc && b.dy && b.count > 0,
+                 "bn_group_plan: apply job %d", j);
+      BnBwdK& k = ka[j];
+      k.da = (const __bf16*)b.da; k.y = (const __bf16*)b.y; k.dy = (__bf16*)b.dy; k.dres = (__bf16*)b.dres; k.dacc = b.acc;
+      k.scale = b.scale; k.shift = b.shift; k.mean = b.mean; k.invstd = b.invstd; k.gamma = b.gamma; k.dgamma = b.dgamma;
+      k.dbeta = b.dbeta; k.ldda = b.ldda; k.ldy = b.ldy; k.lddy = b.lddy; k.lddres = b.lddres; k.dres_accum = b.dres_accum;
+      k.C8 = C / 8; k.npix = b.npix; k.inv_count = 1.0 / (double)b.count; k.nslots = nslots;
+    }
+    starts[j + 1] = starts[j] + nb;
+  }
+  const size_t rec = kind == 0 ? sizeof(BnFwdK) : (kind == 1 ? sizeof(BnRedK) : sizeof(BnBwdK));
+  const void* src = kind == 0 ? (const void*)kf : (kind == 1 ? (const void*)kr : (const void*)ka);
+  meta->kind = kind; meta->njobs = n; meta->nblocks = starts[n]; meta->act = jobs[0].act;
+  meta->starts_off = (int64_t)(rec * n);
+  meta->table_bytes = meta->starts_off + (int64_t)sizeof(int) * (n + 1);
+  if (table_host) {
+    MI_REQUIRE(table_cap >= meta->table_bytes, "bn_group_plan: table too small");
+    memcpy(table_host, src, rec * n);
+    memcpy((char*)table_host + meta->starts_off, starts, sizeof(int) * (n + 1));
+  }
+  return MI_OK;
+}
+
+extern "C" int mi_bn_group_run(const mi_bn_group* m, const void* table_dev, mi_stream_t st) {
+  MI_REQUIRE(m && table_dev && m->njobs >= 1 && m->nblocks >= 1, "bn_group_run: args");
+  const int* starts = (const int*)((const char*)table_dev + m->starts_off);
+  hipStream_t s = (hipStream_t)st;
+  const dim3 g((unsigned)m->nblocks), b(256);
+  if (m->kind == 0) {
+    if (m->act) hipLaunchKernelGGL(bn_act_fwd_group_kernel<1>, g, b, 0, s, (const BnFwdK*)table_dev, starts, m->njobs);
+    else hipLaunchKernelGGL(bn_act_fwd_group_kernel<0>, g, b, 0, s, (const BnFwdK*)table_dev, starts, m->njobs);
+  } else if (m->kind == 1) {
+    if (m->act) hipLaunchKernelGGL(bn_bwd_reduce_group_kernel<1>, g, b, 0, s, (const BnRedK*)table_dev, starts, m->njobs);
+    else hipLaunchKernelGGL(bn_bwd_reduce_group_kernel<0>, g, b, 0, s, (const BnRedK*)table_dev, starts, m->njobs);
+  } else {
+    if (m->act) hipLaunchKernelGGL(bn_bwd_apply_group_kernel<1>, g, b, 0, s, (const BnBwdK*)table_dev, starts, m->njobs);
+    else hipLaunchKernelGGL(bn_bwd_apply_group_kernel<0>, g, b, 0, s, (const BnBwdK*)table_dev, starts, m->njobs);
+  }
+  MI_CHECK_LAUNCH("bn_group");
   return MI_OK;
 }

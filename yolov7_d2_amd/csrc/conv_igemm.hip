@@ -24,6 +24,7 @@
 //     tensor (MI_CONV_BNBWD): the final da tile is in registers, only that layer's raw conv output is re-read.
 //   * small feature maps (20x20, 40x40) get 64-pixel tiles / narrower cout tiles so that every
 //     launch has >= ~2 blocks per CU.
+#include <string.h>
 #include "common.h"
 
 struct ConvK {
@@ -60,8 +61,12 @@ __device__ __forceinline__ void glds16(const void* g, unsigned lds_off) {
 // EPI: 1 = the staged epilogue may accumulate into y (MI_CONV_ACCUM) and / or take the BatchNorm-backward sums
 // (MI_CONV_BNBWD) - its global operands are prefetched into registers; 0 = plain store (+ forward statistics), which
 // keeps the forward kernels' register count (occupancy) low
-template <int KC, int BN, int WM, int WN, int CT, int PT, int TPS, int EPI>
-__global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvK p) {
+// PK: ConvK (kernel argument) or an address-space-4 (constant) ConvK for a job table entry: constant-address-space
+// loads are invariant, so the compiler keeps the fields in SGPRs across the "memory"-clobbering LDS-DMA asm and the
+// stores instead of re-loading them at every use
+typedef const __attribute__((address_space(4))) ConvK ConvKC;
+template <int KC, int BN, int WM, int WN, int CT, int PT, int TPS, int EPI, class PK>
+__device__ __forceinline__ void conv_igemm_body(PK& p, const int bid) {
   static_assert(WM * CT * 32 == BN, "cout tiling");
   constexpr int NW = WM * WN;
   constexpr int TPIX = WN * PT * 32;
@@ -84,8 +89,8 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvK 
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
 
-  const int cot = blockIdx.x % p.nco;
-  const int tile = blockIdx.x / p.nco;
+  const int cot = bid % p.nco;
+  const int tile = bid / p.nco;
   const int tpi = p.tilesY * p.tilesX;
   const int img = tile / tpi;
   const int rem = tile - img * tpi;
@@ -440,6 +445,24 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvK 
   }
 }
 
+template <int KC, int BN, int WM, int WN, int CT, int PT, int TPS, int EPI>
+__global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_kernel(const ConvK p) {
+  conv_igemm_body<KC, BN, WM, WN, CT, PT, TPS, EPI, const ConvK>(p, blockIdx.x);
+}
+
+// several independent convolutions (same template configuration, their own shapes / tensors) in ONE launch: the
+// block looks its job up in a device table.  Used for the three FPN levels of the head, whose 40x40 / 20x20
+// launches are latency-bound on their own and ride along with the 80x80 level here.
+template <int KC, int BN, int WM, int WN, int CT, int PT, int TPS, int EPI>
+__global__ __launch_bounds__(WM* WN * 64, 2) void conv_igemm_group_kernel(const ConvK* __restrict__ jobs,
+                                                                          const int* __restrict__ starts, int njobs) {
+  int j = 0;
+  while (j + 1 < njobs && (int)blockIdx.x >= starts[j + 1]) ++j;
+  j = __builtin_amdgcn_readfirstlane(j);
+  ConvKC* pj = (ConvKC*)(uintptr_t)(jobs + j);
+  conv_igemm_body<KC, BN, WM, WN, CT, PT, TPS, EPI, ConvKC>(*pj, (int)blockIdx.x - starts[j]);
+}
+
 // ---------------------------------------------------------------- host side
 static void choose_tile(int TPIX, int gridH, int gridW, int* TH, int* TW) {
   const int cands[] = {gridW, 64, 32, 16, 8, 4};
@@ -672,6 +695,107 @@ extern "C" int mi_conv2d(const mi_conv_desc* d, mi_stream_t st) {
   MI_DISPATCH(128)
 #undef MI_DISPATCH
   MI_FAIL(MI_EINVAL, "conv: no kernel for KC %d BN %d TPIX %d", c.KC, c.BN, c.TPIX);
+}
+
+// ---------------------------------------------------------------- grouped launch
+template <int KC, int BN, int WM, int WN, int CT, int PT, int TPS, int EPI>
+static int launch_group_one(const ConvK* jobs, const int* starts, int njobs, int nblocks, size_t lds, hipStream_t s) {
+  auto fn = conv_igemm_group_kernel<KC, BN, WM, WN, CT, PT, TPS, EPI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(fn, dim3((unsigned)nblocks), dim3(WM * WN * 64), lds, s, jobs, starts, njobs);
+  MI_CHECK_LAUNCH("conv_igemm_group");
+  return MI_OK;
+}
+template <int KC, int BN, int WM, int WN, int CT, int PT>
+static int launch_group_cfg(const mi_conv_group* m, const ConvK* jobs, const int* starts, hipStream_t s) {
+  const size_t lds = (size_t)m->lds_bytes;
+  if (m->TPS == 1)
+    return m->EPI ? launch_group_one<KC, BN, WM, WN, CT, PT, 1, 1>(jobs, starts, m->njobs, m->nblocks, lds, s)
+                  : launch_group_one<KC, BN, WM, WN, CT, PT, 1, 0>(jobs, starts, m->njobs, m->nblocks, lds, s);
+  return m->EPI ? launch_group_one<KC, BN, WM, WN, CT, PT, 0, 1>(jobs, starts, m->njobs, m->nblocks, lds, s)
+                : launch_group_one<KC, BN, WM, WN, CT, PT, 0, 0>(jobs, starts, m->njobs, m->nblocks, lds, s);
+}
+
+extern "C" int mi_conv2d_group_plan(const mi_conv_desc* descs, int n, void* table_host, int64_t table_cap,
+                                    mi_conv_group* meta) {
+  MI_REQUIRE(descs && meta && n >= 1 && n <= MI_CONV_MAX_GROUP, "conv_group_plan: 1..%d jobs", MI_CONV_MAX_GROUP);
+  // the job with the most output pixels picks the configuration; the others are forced onto its template
+  int big = 0;
+  for (int j = 1; j < n; ++j)
+    if ((long)descs[j].N * descs[j].gridH * descs[j].gridW > (long)descs[big].N * descs[big].gridH * descs[big].gridW) big = j;
+  ConvK kb;
+  ConvCfg cb;
+  size_t lb;
+  int rc = conv_fill(&descs[big], &kb, &cb, &lb);
+  if (rc) return rc;
+  ConvK ks[MI_CONV_MAX_GROUP];
+  int starts[MI_CONV_MAX_GROUP + 1];
+  size_t lds = 0;
+  int epi = -1;
+  starts[0] = 0;
+  for (int j = 0; j < n; ++j) {
+    mi_conv_desc d = descs[j];
+    MI_REQUIRE((d.K8 * 8) % cb.KC == 0 && d.CoutPad % cb.BN == 0 && d.ntaps % cb.TPS == 0,
+               "conv_group_plan: job %d does not fit the group's configuration (KC %d BN %d TPS %d)", j, cb.KC, cb.BN, cb.TPS);
+    d.KC = cb.KC; d.BN = cb.BN; d.TPS = cb.TPS;
+    if (j != big) {   // same pixel-tile CLASS (64 / 128 pixels); the tile shape itself is chosen per job
+      d.TH = d.TW = 0;
+      int th, tw;
+      choose_tile(cb.TPIX, d.gridH, d.gridW, &th, &tw);
+      d.TH = th; d.TW = tw;
+      if (cb.TPIX == 128 && th * tw <= 64) { d.TH = 0; d.TW = 0; }   // fall back to the launcher (checked below)
+    } else { d.TH = kb.TH; d.TW = kb.TW; }
+    ConvCfg c;
+    size_t l;
+    rc = conv_fill(&d, &ks[j], &c, &l);
+    if (rc) return rc;
+    MI_REQUIRE(c.KC == cb.KC && c.BN == cb.BN && c.TPIX == cb.TPIX && c.TPS == cb.TPS,
+               "conv_group_plan: job %d resolved to another configuration", j);
+    const int e = (ks[j].flags & (MI_CONV_ACCUM | MI_CONV_BNBWD)) != 0;
+    MI_REQUIRE(epi < 0 || epi == e, "conv_group_plan: jobs mix accumulating and plain launches");
+    epi = e;
+    if (l > lds) lds = l;
+    starts[j + 1] = starts[j] + ks[j].N * ks[j].tilesY * ks[j].tilesX * ks[j].nco;
+  }
+  meta->njobs = n; meta->nblocks = starts[n]; meta->lds_bytes = (int32_t)lds;
+  meta->KC = cb.KC; meta->BN = cb.BN; meta->TPIX = cb.TPIX; meta->TPS = cb.TPS; meta->EPI = epi;
+  meta->starts_off = (int64_t)sizeof(ConvK) * n;
+  meta->table_bytes = meta->starts_off + (int64_t)sizeof(int) * (n + 1);
+  if (table_host) {
+    MI_REQUIRE(table_cap >= meta->table_bytes, "conv_group_plan: table too small");
+    memcpy(table_host, ks, sizeof(ConvK) * n);
+    memcpy((char*)table_host + meta->starts_off, starts, sizeof(int) * (n + 1));
+  }
+  return MI_OK;
+}
+
+extern "C" int mi_conv2d_group_run(const mi_conv_group* m, const void* table_dev, mi_stream_t st) {
+  MI_REQUIRE(m && table_dev && m->njobs >= 1, "conv_group_run: null");
+  const ConvK* jobs = (const ConvK*)table_dev;
+  const int* starts = (const int*)((const char*)table_dev + m->starts_off);
+  hipStream_t s = (hipStream_t)st;
+#define MI_GDISPATCH(KCv)                                                                           \
+  if (m->KC == KCv) {                                                                               \
+    if (m->TPIX == 128) {                                                                           \
+      if (m->BN == 32) return launch_group_cfg<KCv, 32, 1, 4, 1, 1>(m, jobs, starts, s);            \
+      if (m->BN == 64) return launch_group_cfg<KCv, 64, 2, 2, 1, 2>(m, jobs, starts, s);            \
+      return launch_group_cfg<KCv, 128, 2, 2, 2, 2>(m, jobs, starts, s);                            \
+    } else {                                                                                        \
+      if (m->BN == 32) return launch_group_cfg<KCv, 32, 1, 2, 1, 1>(m, jobs, starts, s);            \
+      if (m->BN == 64) return launch_group_cfg<KCv, 64, 2, 2, 1, 1>(m, jobs, starts, s);            \
+      return launch_group_cfg<KCv, 128, 2, 2, 2, 1>(m, jobs, starts, s);                            \
+    }                                                                                               \
+  }
+  MI_GDISPATCH(16)
+  MI_GDISPATCH(32)
+  MI_GDISPATCH(64)
+  MI_GDISPATCH(128)
+#undef MI_GDISPATCH
+  MI_FAIL(MI_EINVAL, "conv_group: no kernel for KC %d BN %d TPIX %d", m->KC, m->BN, m->TPIX);
 }
 
 // ================================================================= weight (un)packing

@@ -38,6 +38,9 @@ def grad_write_ranges(plan, grad_tensor):
                 ptrs.append((d.gw, d.ntaps * d.Cout * d.Cin * 4))
         elif c.op == L.OP["BN_BWD_APPLY"]:
             ptrs += [(c.p[8], c.i[5] * 4), (c.p[9], c.i[5] * 4)]
+        elif c.op == L.OP["BN_GROUP"] and c.i[0] == 2:
+            for j in plan.cmd_descs["bwd"][k]:
+                ptrs += [(j.dgamma, j.C * 4), (j.dbeta, j.C * 4)]
         elif c.op == L.OP["COLSUM"]:
             ptrs.append((c.p[1], c.i[1] * 4))
         elif c.op == L.OP["BIAS_GRADS"]:

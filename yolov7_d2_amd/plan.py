@@ -82,6 +82,7 @@ class _Cmd:
     def __init__(self, op, i=(), f=(), p=(), l=(), desc=None, tag="", stream=0):
         self.op, self.i, self.f, self.p, self.l, self.desc, self.tag = op, list(i), list(f), list(p), list(l), desc, tag
         self.stream = stream   # 0 = caller's stream, k > 0 = auxiliary stream k (inside a parallel region)
+        self.lane = 0          # index of the independent chain (inside a parallel region) this command belongs to
 
 
 class ConvSpec:
@@ -103,6 +104,10 @@ class PlanBuilder:
         # dependency handling) -> opt-in only
         self.multi_stream = os.environ.get("MI_MULTI_STREAM", "0") != "0" and self.group_wgrad
         self.cur_stream = 0
+        self.cur_lane = 0
+        # the independent chains of a parallel region (the head's FPN levels) zipped into grouped launches: one
+        # CONV_GROUP / BN_GROUP per chain position instead of one launch per level
+        self.group_lanes = os.environ.get("MI_GROUP_LEVELS", "1") != "0"
         self.training = training            # build the backward command list
         self.bn_train = training if bn_train is None else bn_train  # batch statistics vs running statistics
         self.bufs = []
@@ -175,6 +180,7 @@ class PlanBuilder:
     def emit(self, op, i=(), f=(), p=(), l=(), desc=None, tag="", prologue=False):
         c = _Cmd(L.OP[op], i, f, [x if isinstance(x, _Ptr) else _Ptr(x) for x in p], l, desc, tag,
                  stream=0 if prologue else self.cur_stream)
+        c.lane = 0 if prologue else self.cur_lane
         if self._emitting_bwd:
             self.bwd.append(c)
         elif prologue:
@@ -185,7 +191,7 @@ class PlanBuilder:
 
     def on_backward(self, fn):
         if self.training:
-            self.bwd_gens.append((fn, self.cur_stream))
+            self.bwd_gens.append((fn, self.cur_stream, self.cur_lane))
 
     # ---------------------------------------------------------------- parallel regions
     def par_begin(self, tag="par"):
@@ -204,11 +210,12 @@ class PlanBuilder:
 
         class _Ctx:
             def __enter__(self_):
-                self_.prev = b.cur_stream
+                self_.prev, self_.prev_lane = b.cur_stream, b.cur_lane
                 b.cur_stream = sid if b.multi_stream else 0
+                b.cur_lane = sid
 
             def __exit__(self_, *a):
-                b.cur_stream = self_.prev
+                b.cur_stream, b.cur_lane = self_.prev, self_.prev_lane
         return _Ctx()
 
     def grad_mode(self, t):
@@ -493,10 +500,10 @@ class PlanBuilder:
     def finalize(self, materialize=True):
         # backward command generation, reverse order of forward emission
         self._emitting_bwd = True
-        for fn, sid in reversed(self.bwd_gens):
-            self.cur_stream = sid
+        for fn, sid, lane in reversed(self.bwd_gens):
+            self.cur_stream, self.cur_lane = sid, lane
             fn()
-        self.cur_stream = 0
+        self.cur_stream = self.cur_lane = 0
         self._emitting_bwd = False
         self.bwd_gens = []
         for which, lst in (("fwd", self.fwd), ("bwd", self.bwd)):
@@ -641,8 +648,113 @@ class Plan:
                 k += 1
         return out
 
+    def _group_lanes(self, cmds):
+        """parallel region whose chains (lanes) run the same op sequence -> one grouped launch per chain position
+        for the convolutions and the BatchNorm passes; every other op keeps its per-lane commands"""
+        b = self.b
+        if not b.group_lanes or b.multi_stream:
+            return cmds
+        NOP, CONV = L.OP["NOP"], L.OP["CONV"]
+        BN_KIND = {L.OP["BN_ACT_FWD"]: 0, L.OP["BN_BWD_REDUCE"]: 1, L.OP["BN_BWD_APPLY"]: 2}
+        out, k = [], 0
+        while k < len(cmds):
+            c = cmds[k]
+            if not (c.op == NOP and c.tag.endswith(".begin")):
+                out.append(c)
+                k += 1
+                continue
+            e = k + 1
+            while not (cmds[e].op == NOP and cmds[e].tag.endswith(".end")):
+                e += 1
+            region = cmds[k + 1: e]
+            lanes = sorted({r.lane for r in region})
+            chains = [[r for r in region if r.lane == ln] for ln in lanes]
+            aligned = len(lanes) >= 2 and all(len(ch) == len(chains[0]) for ch in chains) and all(
+                len({ch[i].op for ch in chains}) == 1 for i in range(len(chains[0])))
+            out.append(c)
+            if not aligned:
+                out += region
+            else:
+                for i in range(len(chains[0])):
+                    cs = [ch[i] for ch in chains]
+                    g = None
+                    if cs[0].op == CONV and len(cs[0].desc.taps) > 1 and len(cs) >= 3:
+                        # measured: a 3x3 level-0 launch already fills its block rounds; adding the small levels' blocks
+                        # costs it an extra (mostly idle) round.  Only the small levels share a launch.
+                        px = [c.desc.N * c.desc.gridH * c.desc.gridW for c in cs]
+                        big = px.index(max(px))
+                        rest = [c for j, c in enumerate(cs) if j != big]
+                        g2 = self._conv_group_cmd(rest)
+                        out += [cs[big]] + ([g2] if g2 is not None else rest)
+                        continue
+                    if cs[0].op == CONV:
+                        g = self._conv_group_cmd(cs)
+                    elif cs[0].op in BN_KIND:
+                        g = self._bn_group_cmd(BN_KIND[cs[0].op], cs)
+                    out += [g] if g is not None else cs
+            out.append(cmds[e])
+            k = e + 1
+        return out
+
+    def _upload_table(self, host, nbytes):
+        t = torch.frombuffer(bytearray(bytes(host)[:nbytes]), dtype=torch.uint8).to(self.b.device)
+        self.descs.append(t)
+        return t
+
+    def _conv_group_cmd(self, cs):
+        n = len(cs)
+        descs = (L.mi_conv_desc * n)()
+        keep = [self._make_desc(c.desc) for c in cs]
+        for d, t in zip(descs, keep):
+            C.memmove(C.byref(d), C.byref(t), C.sizeof(L.mi_conv_desc))
+        meta = L.mi_conv_group()
+        lib = L.lib()
+        if lib.mi_conv2d_group_plan(descs, n, None, 0, C.byref(meta)) < 0:
+            lib.mi_last_error()
+            return None     # shapes that do not share a kernel configuration stay separate launches
+        host = (C.c_char * int(meta.table_bytes))()
+        L.check(lib.mi_conv2d_group_plan(descs, n, host, meta.table_bytes, C.byref(meta)), "conv_group_plan")
+        tab = self._upload_table(host, meta.table_bytes)
+        self.descs += [meta, descs]
+        g = _Cmd(L.OP["CONV_GROUP"], p=[_Ptr(C.addressof(meta)), _Ptr(tab)], tag="+".join(c.tag for c in cs))
+        g.group_descs = list(descs)
+        return g
+
+    def _bn_group_cmd(self, kind, cs):
+        n = len(cs)
+        jobs = (L.mi_bn_job * n)()
+        for j, c in zip(jobs, cs):
+            P = [x.resolve() for x in c.p]
+            if kind == 0:    # BN_ACT_FWD: i=[ldy, ldres, lda, C, act, nslots] l=[count, npix] f=[eps, momentum]
+                (j.y, j.acc, j.gamma, j.beta, j.rmean, j.rvar, j.nbt, j.scale, j.shift, j.mean, j.invstd, j.res,
+                 j.a) = P[:13]
+                j.ldy, j.ldres, j.lda, j.C, j.act, j.nslots = c.i[:6]
+                j.count, j.npix = c.l[0], c.l[1]
+                j.eps, j.momentum = (c.f + [0.0, 0.0])[:2]
+            elif kind == 1:  # BN_BWD_REDUCE: i=[ldda, ldy, nblk, C, act, nslots] l=[npix]
+                j.da, j.y, j.scale, j.shift, j.mean, j.invstd, j.acc = P[:7]
+                j.ldda, j.ldy, j.nblk, j.C, j.act, j.nslots = c.i[:6]
+                j.npix = j.count = c.l[0]
+            else:            # BN_BWD_APPLY: i=[ldda, ldy, lddy, lddres, dres_acc, C, act, nslots] l=[count, npix]
+                (j.da, j.y, j.scale, j.shift, j.mean, j.invstd, j.gamma, j.acc, j.dgamma, j.dbeta, j.dy,
+                 j.dres) = P[:12]
+                j.ldda, j.ldy, j.lddy, j.lddres, j.dres_accum, j.C, j.act, j.nslots = c.i[:8]
+                j.npix, j.count = c.l[0], c.l[1]
+        meta = L.mi_bn_group()
+        lib = L.lib()
+        if lib.mi_bn_group_plan(kind, jobs, n, None, 0, C.byref(meta)) < 0:
+            lib.mi_last_error()
+            return None
+        host = (C.c_char * int(meta.table_bytes))()
+        L.check(lib.mi_bn_group_plan(kind, jobs, n, host, meta.table_bytes, C.byref(meta)), "bn_group_plan")
+        tab = self._upload_table(host, meta.table_bytes)
+        self.descs += [meta, jobs]
+        g = _Cmd(L.OP["BN_GROUP"], i=[kind, n], p=[_Ptr(C.addressof(meta)), _Ptr(tab)], tag="+".join(c.tag for c in cs))
+        g.group_jobs = list(jobs)
+        return g
+
     def _materialize(self, cmds, which):
-        cmds = self._lower_streams(cmds)
+        cmds = self._lower_streams(self._group_lanes(cmds))
         arr = (L.mi_cmd * max(1, len(cmds)))()
         tags = []
         self.cmd_descs[which] = [None] * len(cmds)
@@ -661,6 +773,10 @@ class Plan:
                 d = self._make_desc(c.desc)
                 m.p[0] = C.cast(C.pointer(d), C.c_void_p).value
                 self.cmd_descs[which][k] = d
+            elif hasattr(c, "group_descs"):
+                self.cmd_descs[which][k] = c.group_descs
+            elif hasattr(c, "group_jobs"):
+                self.cmd_descs[which][k] = c.group_jobs
             tags.append(c.tag)
         return (arr, len(cmds)), tags
 
