@@ -67,6 +67,15 @@ def roofline_block(plan, iters=5):
                 L.lib().mi_conv2d_plan(C.byref(dd))
                 name = f"conv_igemm_kernel<KC={dd.KC},BN={dd.BN}>"
                 byt, fl = conv_algorithmic(d)
+            elif op == "CONV_GROUP":
+                meta = C.cast(arr[k].p[0], C.POINTER(L.mi_conv_group)).contents
+                name = f"conv_igemm_group_kernel<KC={meta.KC},BN={meta.BN}>"
+                byt = fl = 0
+                for d in descs[k]:
+                    b1, f1 = conv_algorithmic(d)
+                    byt += b1; fl += f1
+            elif op == "BN_GROUP":
+                name, byt, fl = ("BN_ACT_FWD", "BN_BWD_REDUCE", "BN_BWD_APPLY")[arr[k].i[0]] + " (grouped)", 0, 0
             elif op == "WGRAD":
                 d = descs[k]
                 name = f"wgrad2_kernel<NT={d.ntaps}>"
@@ -90,9 +99,16 @@ def roofline_block(plan, iters=5):
     avg_ms = g["ms"] / g["launches"]
     gbs = g["bytes"] / g["launches"] / (avg_ms * 1e-3) / 1e9
     tfs = g["flops"] / g["launches"] / (avg_ms * 1e-3) / 1e12
-    rl = dict(bound="hbm", kernel=name, achieved=round(gbs, 1), peak=8000.0, unit="GB/s", frac=round(gbs / 8000.0, 4),
+    # the roofline that bounds this kernel class: arithmetic intensity above the ridge (2500 TF/s / 8 TB/s = 312 flop/B)
+    # -> matrix cores, else HBM; both utilisations are reported
+    mfma_bound = g["flops"] / max(g["bytes"], 1.0) > 2500e12 / 8000e9
+    rl = dict(bound="mfma" if mfma_bound else "hbm", kernel=name,
+              achieved=round(tfs if mfma_bound else gbs, 1), peak=2500.0 if mfma_bound else 8000.0,
+              unit="TFLOP/s" if mfma_bound else "GB/s", frac=round(tfs / 2500.0 if mfma_bound else gbs / 8000.0, 4),
               traffic=None, avg_launch_ms=round(avg_ms, 5), launches_per_step=g["launches"],
-              algorithmic_bytes_per_launch=int(g["bytes"] / g["launches"]), mfma_tflops=round(tfs, 1),
+              algorithmic_bytes_per_launch=int(g["bytes"] / g["launches"]),
+              algorithmic_flops_per_launch=int(g["flops"] / g["launches"]), hbm_GBps=round(gbs, 1),
+              hbm_frac_of_8000=round(gbs / 8000.0, 4), mfma_tflops=round(tfs, 1),
               mfma_frac_of_2500=round(tfs / 2500.0, 4), share_of_step_kernel_time=round(g["ms"] / total_ms, 3))
     breakdown = {k: dict(ms=round(v["ms"], 4), launches=v["launches"],
                          GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] and v["ms"] > 0 else None,

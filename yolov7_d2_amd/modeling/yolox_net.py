@@ -158,20 +158,30 @@ class YOLOXHead(_NoEager):
     def emit(self, ctx, fpn_outs, preds, A, tag="head"):
         nch = 5 + self.num_classes
         a0 = 0
-        # the FPN levels are independent chains (yolox_head.py:160-172 loops over them): level 0 (80x80 at 640) stays on
-        # the caller's stream, the small levels run beside it on auxiliary streams (parallel hipGraph branches)
-        ctx.b.par_begin(tag + ".levels")
+        # the FPN levels - and inside a level the classification and the regression branch - are independent chains
+        # (yolox_head.py:160-172 loops over them): the plan zips them into grouped launches (Plan._group_lanes), or, with
+        # MI_MULTI_STREAM, runs the small levels on auxiliary streams
+        b = ctx.b
+        stems = []
+        b.par_begin(tag + ".stems")
         for k, x in enumerate(fpn_outs):
-            with ctx.b.on_stream(k):
-                t = self.stems[k].emit(ctx, x, f"{tag}.stems.{k}")
+            with b.on_stream(k), b.on_lane(k):
+                stems.append(self.stems[k].emit(ctx, x, f"{tag}.stems.{k}"))
+        b.par_end(tag + ".stems")
+        b.par_begin(tag + ".levels")
+        for k, x in enumerate(fpn_outs):
+            t = stems[k]
+            with b.on_stream(k), b.on_lane(2 * k):
                 c = self.cls_convs[k][0].emit(ctx, t, f"{tag}.cls_convs.{k}.0")
                 c = self.cls_convs[k][1].emit(ctx, c, f"{tag}.cls_convs.{k}.1")
+                b.pred_conv(f"{tag}.cls_preds.{k}", c, self.cls_preds[k].weight, self.cls_preds[k].bias,
+                            ctx.g(self.cls_preds[k].weight), ctx.g(self.cls_preds[k].bias), preds, A, a0, 5, nch)
+            with b.on_stream(k), b.on_lane(2 * k + 1):
                 r = self.reg_convs[k][0].emit(ctx, t, f"{tag}.reg_convs.{k}.0")
                 r = self.reg_convs[k][1].emit(ctx, r, f"{tag}.reg_convs.{k}.1")
-                for name, mod, src, c0 in (("cls_preds", self.cls_preds[k], c, 5), ("reg_preds", self.reg_preds[k], r, 0),
-                                           ("obj_preds", self.obj_preds[k], r, 4)):
-                    ctx.b.pred_conv(f"{tag}.{name}.{k}", src, mod.weight, mod.bias, ctx.g(mod.weight), ctx.g(mod.bias),
-                                    preds, A, a0, c0, nch)
+                for name, mod, c0 in (("reg_preds", self.reg_preds[k], 0), ("obj_preds", self.obj_preds[k], 4)):
+                    b.pred_conv(f"{tag}.{name}.{k}", r, mod.weight, mod.bias, ctx.g(mod.weight), ctx.g(mod.bias),
+                                preds, A, a0, c0, nch)
             a0 += x.H * x.W
-        ctx.b.par_end(tag + ".levels")
+        b.par_end(tag + ".levels")
         assert a0 == A

@@ -9,6 +9,7 @@ statically: the first backward writer overwrites, later ones accumulate in their
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -216,6 +217,20 @@ class PlanBuilder:
 
             def __exit__(self_, *a):
                 b.cur_stream, b.cur_lane = self_.prev, self_.prev_lane
+        return _Ctx()
+
+    def on_lane(self, lane):
+        """commands emitted inside belong to independent chain `lane` of the enclosing parallel region (see
+        Plan._group_lanes); unlike on_stream this never changes the stream"""
+        b = self
+
+        class _Ctx:
+            def __enter__(self_):
+                self_.prev = b.cur_lane
+                b.cur_lane = lane
+
+            def __exit__(self_, *a):
+                b.cur_lane = self_.prev
         return _Ctx()
 
     def grad_mode(self, t):
@@ -649,13 +664,57 @@ class Plan:
         return out
 
     def _group_lanes(self, cmds):
-        """parallel region whose chains (lanes) run the same op sequence -> one grouped launch per chain position
-        for the convolutions and the BatchNorm passes; every other op keeps its per-lane commands"""
+        """parallel region = independent chains (lanes).  A list scheduler walks the chains in lock step: the op kind
+        most lanes have next is issued for all of them at once - as ONE grouped launch when it is a convolution or a
+        BatchNorm pass (CONV_GROUP / BN_GROUP), one command per lane otherwise.  Commands that write the same tensor
+        (two data gradients accumulating into one input gradient) are never grouped and keep their original order."""
         b = self.b
         if not b.group_lanes or b.multi_stream:
             return cmds
         NOP, CONV = L.OP["NOP"], L.OP["CONV"]
         BN_KIND = {L.OP["BN_ACT_FWD"]: 0, L.OP["BN_BWD_REDUCE"]: 1, L.OP["BN_BWD_APPLY"]: 2}
+
+        def out_key(c):   # identity of the tensor a groupable command writes
+            if c.op == CONV:
+                y = c.desc.y
+                return (id(getattr(y.obj, "buf", y.obj)), getattr(y.obj, "coff", 0), y.off)
+            if c.op == L.OP["BN_BWD_APPLY"] and c.p[11].obj is not None:
+                return (id(c.p[11].obj.buf), c.p[11].obj.coff, 0)
+            return id(c)
+
+        def issue(cs, order):
+            cs = sorted(cs, key=lambda c: order[id(c)])
+            keys = [out_key(c) for c in cs]
+            if len(set(keys)) < len(cs):   # writers of one tensor: split into waves that keep their original order
+                seen, waves = {}, {}
+                for c, kk in zip(cs, keys):
+                    w = seen.get(kk, 0)
+                    seen[kk] = w + 1
+                    waves.setdefault(w, []).append(c)
+                res = []
+                for w in sorted(waves):
+                    res += issue(waves[w], order)
+                return res
+            if len(cs) < 2:
+                return cs
+            if cs[0].op == CONV:
+                if len(cs[0].desc.taps) > 1:
+                    # measured: a 3x3 launch of a big level already fills its block rounds and the small levels' blocks
+                    # cost it an extra, mostly idle round -> big and small jobs get separate launches
+                    px = [c.desc.N * c.desc.gridH * c.desc.gridW for c in cs]
+                    parts = [[c for c, n_ in zip(cs, px) if 2 * n_ >= max(px)], [c for c, n_ in zip(cs, px) if 2 * n_ < max(px)]]
+                else:
+                    parts = [cs]
+                res = []
+                for part in parts:
+                    g = self._conv_group_cmd(part) if len(part) >= 2 else None
+                    res += [g] if g is not None else part
+                return res
+            if cs[0].op in BN_KIND:
+                g = self._bn_group_cmd(BN_KIND[cs[0].op], cs)
+                return [g] if g is not None else cs
+            return cs
+
         out, k = [], 0
         while k < len(cmds):
             c = cmds[k]
@@ -667,31 +726,25 @@ class Plan:
             while not (cmds[e].op == NOP and cmds[e].tag.endswith(".end")):
                 e += 1
             region = cmds[k + 1: e]
+            order = {id(r): i for i, r in enumerate(region)}
             lanes = sorted({r.lane for r in region})
             chains = [[r for r in region if r.lane == ln] for ln in lanes]
-            aligned = len(lanes) >= 2 and all(len(ch) == len(chains[0]) for ch in chains) and all(
-                len({ch[i].op for ch in chains}) == 1 for i in range(len(chains[0])))
             out.append(c)
-            if not aligned:
+            skip = os.environ.get("MI_GROUP_SKIP", "")
+            if len(lanes) < 2 or (skip and any(t and t in c.tag for t in skip.split(","))):
                 out += region
             else:
-                for i in range(len(chains[0])):
-                    cs = [ch[i] for ch in chains]
-                    g = None
-                    if cs[0].op == CONV and len(cs[0].desc.taps) > 1 and len(cs) >= 3:
-                        # measured: a 3x3 level-0 launch already fills its block rounds; adding the small levels' blocks
-                        # costs it an extra (mostly idle) round.  Only the small levels share a launch.
-                        px = [c.desc.N * c.desc.gridH * c.desc.gridW for c in cs]
-                        big = px.index(max(px))
-                        rest = [c for j, c in enumerate(cs) if j != big]
-                        g2 = self._conv_group_cmd(rest)
-                        out += [cs[big]] + ([g2] if g2 is not None else rest)
-                        continue
-                    if cs[0].op == CONV:
-                        g = self._conv_group_cmd(cs)
-                    elif cs[0].op in BN_KIND:
-                        g = self._bn_group_cmd(BN_KIND[cs[0].op], cs)
-                    out += [g] if g is not None else cs
+                pos = [0] * len(chains)
+                while any(p < len(ch) for p, ch in zip(pos, chains)):
+                    nxt = [(ch[p].op, li) for li, (p, ch) in enumerate(zip(pos, chains)) if p < len(ch)]
+                    kinds = {}
+                    for op, li in nxt:
+                        kinds.setdefault(op, []).append(li)
+                    op = max(kinds, key=lambda o: (len(kinds[o]), o in BN_KIND or o == CONV))
+                    sel = kinds[op]
+                    out += issue([chains[li][pos[li]] for li in sel], order)
+                    for li in sel:
+                        pos[li] += 1
             out.append(cmds[e])
             k = e + 1
         return out
