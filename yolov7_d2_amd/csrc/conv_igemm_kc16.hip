@@ -1,0 +1,6 @@
+// conv_igemm kernels with a 16-channel k-chunk (see conv_igemm_kernel.h / conv_igemm.hip)
+#include "conv_igemm_kernel.h"
+int conv_launch_kc16(const ConvK& k, int BN, int TPIX, size_t lds, hipStream_t s) { return conv_launch_kc<16>(k, BN, TPIX, lds, s); }
+int conv_group_launch_kc16(const mi_conv_group* m, const ConvK* jobs, const int* starts, hipStream_t s) {
+  return conv_group_launch_kc<16>(m, jobs, starts, s);
+}
