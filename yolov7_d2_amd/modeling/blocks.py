@@ -98,6 +98,20 @@ class CSPLayer(_NoEager):
         h = self.hidden
         cat = ctx.b.new_act(x.N, x.H, x.W, 2 * h, tag + ".cat")
         n = len(self.m)
+        b = ctx.b
+        if getattr(b, "csp_lanes", False):
+            # conv1 and conv2 read the same x and are independent: two lanes of a parallel region (grouped launches,
+            # Plan._group_lanes; their data gradients both accumulate into x.grad and stay separate, in order).  The
+            # reference runs conv2 after the bottlenecks (same values, it only reads x).
+            b.par_begin(tag + ".split")
+            with b.on_lane(0):
+                t = self.conv1.emit(ctx, x, tag + ".conv1", out=cat.slice(0, h) if n == 0 else None)
+            with b.on_lane(1):
+                self.conv2.emit(ctx, x, tag + ".conv2", out=cat.slice(h, 2 * h))
+            b.par_end(tag + ".split")
+            for i, blk in enumerate(self.m):
+                t = blk.emit(ctx, t, f"{tag}.m.{i}", out=cat.slice(0, h) if i == n - 1 else None)
+            return self.conv3.emit(ctx, cat, tag + ".conv3", out=out)
         t = self.conv1.emit(ctx, x, tag + ".conv1", out=cat.slice(0, h) if n == 0 else None)
         for i, blk in enumerate(self.m):
             t = blk.emit(ctx, t, f"{tag}.m.{i}", out=cat.slice(0, h) if i == n - 1 else None)

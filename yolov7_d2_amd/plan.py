@@ -109,6 +109,7 @@ class PlanBuilder:
         # the independent chains of a parallel region (the head's FPN levels) zipped into grouped launches: one
         # CONV_GROUP / BN_GROUP per chain position instead of one launch per level
         self.group_lanes = os.environ.get("MI_GROUP_LEVELS", "1") != "0"
+        self.csp_lanes = os.environ.get("MI_CSP_LANES", "1") != "0"   # CSP conv1 / conv2 as lanes (see blocks.CSPLayer)
         self.training = training            # build the backward command list
         self.bn_train = training if bn_train is None else bn_train  # batch statistics vs running statistics
         self.bufs = []
@@ -698,21 +699,52 @@ class Plan:
             if len(cs) < 2:
                 return cs
             if cs[0].op == CONV:
-                if len(cs[0].desc.taps) > 1:
-                    # measured: a 3x3 launch of a big level already fills its block rounds and the small levels' blocks
-                    # cost it an extra, mostly idle round -> big and small jobs get separate launches
-                    px = [c.desc.N * c.desc.gridH * c.desc.gridW for c in cs]
-                    parts = [[c for c, n_ in zip(cs, px) if 2 * n_ >= max(px)], [c for c, n_ in zip(cs, px) if 2 * n_ < max(px)]]
-                else:
+                # measured (in-graph traces): blocks of a grouped launch run in rounds of ~512; short blocks (a 1x1 conv
+                # with one or two k-steps) ride along with anything, but long blocks only gain when the whole group fits
+                # ONE round - a job that nearly fills a round alone (a 3x3 level-0 launch, a CSP conv at 40x40) loses a
+                # mostly idle extra round when more blocks are added to its launch
+                def nblocks(c):
+                    d = self._make_desc(c.desc)
+                    self.descs.pop()
+                    n_ = L.lib().mi_conv2d_plan(C.byref(d))
+                    return max(n_, 1) * (d.CoutPad // d.BN), (d.K8 * 8 // d.KC) * (d.ntaps // d.TPS)
+                info = [nblocks(c) for c in cs]
+                if all(st <= 2 for _, st in info):
                     parts = [cs]
+                else:
+                    parts, cur, tot = [], [], 0
+                    for c, (nb_, _) in sorted(zip(cs, info), key=lambda t: t[1][0]):
+                        if nb_ >= 384 or tot + nb_ > 640:
+                            if cur:
+                                parts.append(cur)
+                            cur, tot = [], 0
+                        if nb_ >= 384:
+                            parts.append([c])
+                        else:
+                            cur.append(c)
+                            tot += nb_
+                    if cur:
+                        parts.append(cur)
                 res = []
                 for part in parts:
+                    part = sorted(part, key=lambda c: order[id(c)])
                     g = self._conv_group_cmd(part) if len(part) >= 2 else None
                     res += [g] if g is not None else part
                 return res
             if cs[0].op in BN_KIND:
-                g = self._bn_group_cmd(BN_KIND[cs[0].op], cs)
-                return [g] if g is not None else cs
+                # at most one bandwidth-sized job (> 512 blocks) per launch: two of them together were slower than apart
+                def bn_blocks(c):
+                    npix, Cc = (c.l[1], c.i[3]) if cs[0].op == L.OP["BN_ACT_FWD"] else (c.l[0], c.i[3] if cs[0].op == L.OP["BN_BWD_REDUCE"] else c.i[5])
+                    return npix * (Cc // 8) / 2048
+                big = [c for c in cs if bn_blocks(c) > 512]
+                small = [c for c in cs if bn_blocks(c) <= 512]
+                parts = [small + big[:1]] + [[c] for c in big[1:]]
+                res = []
+                for part in parts:
+                    part = sorted(part, key=lambda c: order[id(c)])
+                    g = self._bn_group_cmd(BN_KIND[cs[0].op], part) if len(part) >= 2 else None
+                    res += [g] if g is not None else part
+                return res
             return cs
 
         out, k = [], 0
