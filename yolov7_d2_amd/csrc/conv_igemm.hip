@@ -261,17 +261,39 @@ extern "C" int mi_conv2d_group_plan(const mi_conv_desc* descs, int n, void* tabl
     MI_REQUIRE((d.K8 * 8) % cb.KC == 0 && d.CoutPad % cb.BN == 0 && d.ntaps % cb.TPS == 0,
                "conv_group_plan: job %d does not fit the group's configuration (KC %d BN %d TPS %d)", j, cb.KC, cb.BN, cb.TPS);
     d.KC = cb.KC; d.BN = cb.BN; d.TPS = cb.TPS;
-    if (j != big) {   // same pixel-tile CLASS (64 / 128 pixels); the tile shape itself is chosen per job
-      d.TH = d.TW = 0;
-      int th, tw;
-      choose_tile(cb.TPIX, d.gridH, d.gridW, &th, &tw);
-      d.TH = th; d.TW = tw;
-      if (cb.TPIX == 128 && th * tw <= 64) { d.TH = 0; d.TW = 0; }   // fall back to the launcher (checked below)
-    } else { d.TH = kb.TH; d.TW = kb.TW; }
     ConvCfg c;
-    size_t l;
-    rc = conv_fill(&d, &ks[j], &c, &l);
-    if (rc) return rc;
+    size_t l = 0;
+    if (j == big) {
+      d.TH = kb.TH; d.TW = kb.TW;
+      rc = conv_fill(&d, &ks[j], &c, &l);
+      if (rc) return rc;
+    } else {
+      // same pixel-tile CLASS (64 / 128 pixels) as the group; among the tile shapes of that class take the one with
+      // the fewest tiles whose LDS footprint does not exceed the leading job's (a wider halo - e.g. 3x40 tiles of a
+      // 40x40 map next to 8x16 tiles of an 80x80 map - would cut the occupancy of EVERY block of the launch)
+      const size_t cap = lb > 80 * 1024 ? lb : 80 * 1024;
+      const int cands[6][2] = {{0, 0}, {8, 16}, {4, 32}, {16, 8}, {8, 8}, {4, 16}};
+      long bestTiles = -1;
+      for (int q = 0; q < 6; ++q) {
+        mi_conv_desc t = d;
+        if (q == 0) {
+          int th, tw;
+          choose_tile(cb.TPIX, d.gridH, d.gridW, &th, &tw);
+          t.TH = th; t.TW = tw;
+        } else {
+          t.TH = cands[q][0]; t.TW = cands[q][1];
+        }
+        if ((t.TH * t.TW <= 64 ? 64 : 128) != cb.TPIX) continue;
+        ConvK kt;
+        ConvCfg ct;
+        size_t lt;
+        if (conv_fill(&t, &kt, &ct, &lt) != MI_OK) continue;
+        if (lt > cap || ct.KC != cb.KC || ct.BN != cb.BN || ct.TPS != cb.TPS) continue;
+        const long tiles = (long)kt.N * kt.tilesY * kt.tilesX;
+        if (bestTiles < 0 || tiles < bestTiles) { bestTiles = tiles; ks[j] = kt; c = ct; l = lt; }
+      }
+      MI_REQUIRE(bestTiles > 0, "conv_group_plan: job %d has no tile shape within the group's LDS footprint", j);
+    }
     MI_REQUIRE(c.KC == cb.KC && c.BN == cb.BN && c.TPIX == cb.TPIX && c.TPS == cb.TPS,
                "conv_group_plan: job %d resolved to another configuration", j);
     const int e = (ks[j].flags & (MI_CONV_ACCUM | MI_CONV_BNBWD)) != 0;

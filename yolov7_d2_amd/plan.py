@@ -699,32 +699,34 @@ class Plan:
             if len(cs) < 2:
                 return cs
             if cs[0].op == CONV:
-                # measured (in-graph traces): blocks of a grouped launch run in rounds of ~512; short blocks (a 1x1 conv
-                # with one or two k-steps) ride along with anything, but long blocks only gain when the whole group fits
-                # ONE round - a job that nearly fills a round alone (a 3x3 level-0 launch, a CSP conv at 40x40) loses a
-                # mostly idle extra round when more blocks are added to its launch
-                def nblocks(c):
-                    d = self._make_desc(c.desc)
-                    self.descs.pop()
-                    n_ = L.lib().mi_conv2d_plan(C.byref(d))
-                    return max(n_, 1) * (d.CoutPad // d.BN), (d.K8 * 8 // d.KC) * (d.ntaps // d.TPS)
-                info = [nblocks(c) for c in cs]
-                if all(st <= 2 for _, st in info):
-                    parts = [cs]
-                else:
-                    parts, cur, tot = [], [], 0
-                    for c, (nb_, _) in sorted(zip(cs, info), key=lambda t: t[1][0]):
-                        if nb_ >= 384 or tot + nb_ > 640:
-                            if cur:
-                                parts.append(cur)
-                            cur, tot = [], 0
-                        if nb_ >= 384:
-                            parts.append([c])
-                        else:
-                            cur.append(c)
-                            tot += nb_
-                    if cur:
-                        parts.append(cur)
+                # all lanes' convolutions of this position in one launch.  (History, measured with in-graph traces: mixing a
+                # 3x3 level-0 job with the small levels first LOST 15 us per launch - the small maps' wide 3x40 tiles raised
+                # the launch's LDS footprint past 80 KB and halved the occupancy of every block; mi_conv2d_group_plan now
+                # picks tile shapes within the leading job's footprint and the same grouping gains 3 % of the step.
+                # MI_GROUP_LONG=0 restores the conservative rule: jobs with more than two k-steps share a launch only if
+                # the whole group fits one round of ~512 blocks.)
+                parts = [cs]
+                if os.environ.get("MI_GROUP_LONG", "1") == "0":
+                    def nblocks(c):
+                        d = self._make_desc(c.desc)
+                        self.descs.pop()
+                        n_ = L.lib().mi_conv2d_plan(C.byref(d))
+                        return max(n_, 1) * (d.CoutPad // d.BN), (d.K8 * 8 // d.KC) * (d.ntaps // d.TPS)
+                    info = [nblocks(c) for c in cs]
+                    if not all(st <= 2 for _, st in info):
+                        parts, cur, tot = [], [], 0
+                        for c, (nb_, _) in sorted(zip(cs, info), key=lambda t: t[1][0]):
+                            if nb_ >= 384 or tot + nb_ > 640:
+                                if cur:
+                                    parts.append(cur)
+                                cur, tot = [], 0
+                            if nb_ >= 384:
+                                parts.append([c])
+                            else:
+                                cur.append(c)
+                                tot += nb_
+                        if cur:
+                            parts.append(cur)
                 res = []
                 for part in parts:
                     part = sorted(part, key=lambda c: order[id(c)])
