@@ -377,6 +377,20 @@ int mi_sgd_momentum_step(float* params, const float* grads, float* momentum_buf,
                          const mi_sgd_seg* segs_dev, int nseg, float momentum, float grad_scale,
                          int first_step, mi_stream_t s);
 
+/* fused AdamW (decoupled weight decay, bias-corrected moments) over the flat arena: replaces torch.optim.AdamW.step of
+ * the DETR / SparseInst trainers (train_transformer.py, train_inseg.py -> optimizer/build.py); `step` is the 1-based
+ * update count, seg table as for SGD */
+int mi_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const mi_sgd_seg* segs_dev,
+                  int nseg, float beta1, float beta2, float eps, int64_t step, float grad_scale, mi_stream_t s);
+/* full-model gradient clipping (FullModelGradientClippingOptimizer, yolov7/optimizer/build.py:206-223 =
+ * torch.nn.utils.clip_grad_norm_ over all parameters): grads *= min(1, max_norm / (||grads||_2 + 1e-6)) without a host
+ * synchronisation; ws: 1024 doubles of scratch; norm_out (optional, device) receives the norm */
+int mi_grad_clip_full_model(float* grads, int64_t n, float max_norm, double* ws, float* norm_out, mi_stream_t s);
+/* PositionEmbeddingSine.forward (modeling/backbone/detr_backbone.py:309-375): mask [B][H][W] bytes (non-zero = padding)
+ * -> pos fp32 [B][2*num_pos_feats][H][W] */
+int mi_pos_embed_sine(const uint8_t* mask, int B, int H, int W, int num_pos_feats, float temperature, int normalize,
+                      float scale, int centered, float* out, mi_stream_t s);
+
 /* ---- command list executor -----------------------------------------------------
  * A step (forward / backward / update) is a flat list of mi_cmd records built once
  * by the host; mi_cmdlist_run() issues them back-to-back on one stream from C++

@@ -193,6 +193,28 @@ def gold_set_criterion():
     print("set_criterion:", {k: float(v) for k, v in res.items() if k.startswith("a:") and v.ndim == 0})
 
 
+def gold_pos_embed():
+    """the reference's own PositionEmbeddingSine (backbone/detr_backbone.py:309-375) on seeded padding masks"""
+    import importlib
+    import types
+    ref_loader.load()
+    m = importlib.import_module("yolov7.modeling.backbone.detr_backbone")
+    g = torch.Generator().manual_seed(91)
+    B, H, W = 3, 19, 25
+    mask = torch.zeros(B, H, W, dtype=torch.bool)
+    mask[1, :, 18:] = True
+    mask[1, 15:, :] = True
+    mask[2, :, 24:] = True
+    res = {"mask": mask.numpy()}
+    for name, kw in dict(detr=dict(num_pos_feats=128, normalize=True), raw=dict(num_pos_feats=64),
+                         centered=dict(num_pos_feats=32, normalize=True, centered=True, temperature=20)).items():
+        pe = m.PositionEmbeddingSine(**kw)
+        out = pe(types.SimpleNamespace(tensors=torch.zeros(B, 1, H, W), mask=mask))
+        res[name] = out.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "pos_embed.npz"), **res)
+    print("pos_embed:", {k: v.shape for k, v in res.items()})
+
+
 def gold_transformer():
     """the reference's own Transformer (backbone/detr_backbone.py:25-65): 2 encoder + 2 decoder layers, d_model 256,
     8 heads, ffn 512, return_intermediate_dec, eval mode, fp32; post- and pre-norm"""
@@ -231,4 +253,5 @@ if __name__ == "__main__":
     gold_iou_v6()
     gold_encoder_layer()
     gold_transformer()
+    gold_pos_embed()
     gold_set_criterion()

@@ -275,3 +275,62 @@ def test_set_criterion_foreign_matcher_and_errors():
         np.testing.assert_allclose(float(a[k]), float(ref[k]), rtol=1e-5, atol=1e-6)
     with pytest.raises(NotImplementedError):
         SetCriterion(20, ListMatcher(), {}, 0.1, ["labels", "masks"])
+
+
+# ------------------------------------------------------------------------------------------ positional encoding, optimizer
+def test_position_embedding_sine_against_reference_golden(golden_dir):
+    """mi_pos_embed_sine vs the reference's own PositionEmbeddingSine (run by path): DETR setting (normalize), raw
+    counts, and the centered variant"""
+    import types
+    from yolov7_d2_amd.modeling import PositionEmbeddingSine
+    g = np.load(os.path.join(golden_dir, "pos_embed.npz"))
+    mask = torch.from_numpy(g["mask"]).to(DEV)
+    for name, kw in dict(detr=dict(num_pos_feats=128, normalize=True), raw=dict(num_pos_feats=64),
+                         centered=dict(num_pos_feats=32, normalize=True, centered=True, temperature=20)).items():
+        pe = PositionEmbeddingSine(**kw)
+        out = pe(types.SimpleNamespace(tensors=None, mask=mask))
+        assert out.shape == g[name].shape and out.dtype == torch.float32
+        # fp32 pow / division / sin of arguments up to ~25: a few ulp of the argument.  Padded cells are excluded: in a
+        # fully padded row / column the centered variant divides -0.5 by eps (sin of ~3e6: noise in any implementation)
+        valid = ~g["mask"]
+        got, ref = out.cpu().numpy().transpose(0, 2, 3, 1)[valid], g[name].transpose(0, 2, 3, 1)[valid]
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5, err_msg=name)
+    with pytest.raises(ValueError):
+        PositionEmbeddingSine(scale=3.0)
+
+
+def test_flat_adamw_matches_torch():
+    """mi_adamw_step over two segments (different lr / weight decay) == torch.optim.AdamW with two param groups"""
+    from yolov7_d2_amd.optim import FlatAdamW
+    g = torch.Generator().manual_seed(5)
+    n0, n1 = 1000, 777
+    p = torch.randn(n0 + n1, generator=g).to(DEV)
+    ref = [p[:n0].clone().requires_grad_(True), p[n0:].clone().requires_grad_(True)]
+    opt = torch.optim.AdamW([dict(params=[ref[0]], lr=1e-3, weight_decay=1e-2),
+                             dict(params=[ref[1]], lr=3e-4, weight_decay=0.0)], betas=(0.9, 0.999), eps=1e-8)
+    grads = torch.zeros_like(p)
+    mine = FlatAdamW(p, grads, [(0, n0, 1e-3, 1e-2), (n0, n1, 3e-4, 0.0)])
+    for it in range(5):
+        gr = torch.randn(n0 + n1, generator=g).to(DEV)
+        grads.copy_(gr)
+        ref[0].grad, ref[1].grad = gr[:n0].clone(), gr[n0:].clone()
+        opt.step()
+        mine.step()
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(p.cpu().numpy(), torch.cat([r.detach() for r in ref]).cpu().numpy(), rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("scale", [0.01, 30.0])
+def test_full_model_grad_clip_matches_torch(scale):
+    """mi_grad_clip_full_model == torch.nn.utils.clip_grad_norm_ over all parameters (clips at scale 30, no-op at 0.01)"""
+    from yolov7_d2_amd.optim import clip_grad_norm_flat_
+    g = torch.Generator().manual_seed(6)
+    n = 1_234_567
+    gr = (scale * torch.randn(n, generator=g)).to(DEV)
+    ref = torch.nn.Parameter(torch.zeros(n, device=DEV))
+    ref.grad = gr.clone()
+    tn = torch.nn.utils.clip_grad_norm_([ref], 10.0)
+    norm = clip_grad_norm_flat_(gr, 10.0)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(norm), float(tn), rtol=1e-5)
+    np.testing.assert_allclose(gr.cpu().numpy(), ref.grad.cpu().numpy(), rtol=1e-5, atol=1e-9)

@@ -8,3 +8,4 @@ from .attention import mha_core
 from .iou_loss import IOUlossV6
 from .transformer import (MultiheadAttention, TransformerEncoderLayer, TransformerDecoderLayer, TransformerEncoder,
                           TransformerDecoder, Transformer)
+from .position_encoding import PositionEmbeddingSine
