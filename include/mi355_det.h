@@ -377,6 +377,9 @@ int mi_sgd_momentum_step(float* params, const float* grads, float* momentum_buf,
                          const mi_sgd_seg* segs_dev, int nseg, float momentum, float grad_scale,
                          int first_step, mi_stream_t s);
 
+/* fp32 sigmoid of the DETR box head (meta_arch/detr.py:452): forward (x -> y; dy = dx = NULL) or backward
+ * (dx = dy * y * (1 - y); x may be NULL) */
+int mi_sigmoid_f32(const float* x, const float* dy, float* y, float* dx, int64_t n, mi_stream_t s);
 /* fused AdamW (decoupled weight decay, bias-corrected moments) over the flat arena: replaces torch.optim.AdamW.step of
  * the DETR / SparseInst trainers (train_transformer.py, train_inseg.py -> optimizer/build.py); `step` is the 1-based
  * update count, seg table as for SGD */

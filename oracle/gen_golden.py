@@ -215,6 +215,37 @@ def gold_pos_embed():
     print("pos_embed:", {k: v.shape for k, v in res.items()})
 
 
+def gold_detr():
+    """the reference's own DETR module (meta_arch/detr.py:406-472) around its own Transformer / MLP /
+    PositionEmbeddingSine, with a stub backbone handing over a seeded feature map: logits and boxes of every decoder
+    level, and the gradients of a seeded linear functional of them"""
+    import importlib
+    from gen_golden_inputs import synth_detr_case, seeded_state_dict, StubBackbone, SimpleNested
+    ref_loader.load()
+    det = ref_loader.load_detr()
+    tb = importlib.import_module("yolov7.modeling.backbone.detr_backbone")
+    feat, mask = synth_detr_case()
+    x = feat.clone().requires_grad_(True)
+    pos = tb.PositionEmbeddingSine(128, normalize=True)(SimpleNested(x, mask))
+    tr = tb.Transformer(256, 8, 2, 2, 512, 0.1, normalize_before=False, return_intermediate_dec=True)
+    net = det.DETR(StubBackbone(x, mask, pos, SimpleNested), tr, num_classes=20, num_queries=40, aux_loss=True)
+    net.load_state_dict(seeded_state_dict(net))
+    net.eval()
+    out = net(SimpleNested(x, mask))
+    logits = torch.stack([a["pred_logits"] for a in out["aux_outputs"]] + [out["pred_logits"]])
+    boxes = torch.stack([a["pred_boxes"] for a in out["aux_outputs"]] + [out["pred_boxes"]])
+    g = torch.Generator().manual_seed(102)
+    gl = torch.randn(logits.shape, generator=g)
+    gb = torch.randn(boxes.shape, generator=g)
+    ((logits * gl).sum() + (boxes * gb).sum()).backward()
+    res = {"logits": logits.detach().numpy(), "boxes": boxes.detach().numpy(), "dfeat": x.grad.numpy()}
+    for k in ("query_embed.weight", "class_embed.weight", "class_embed.bias", "bbox_embed.layers.2.weight",
+              "bbox_embed.layers.2.bias", "bbox_embed.layers.0.weight", "input_proj.weight", "input_proj.bias"):
+        res["g:" + k] = dict(net.named_parameters())[k].grad.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "detr_module.npz"), **res)
+    print("detr_module:", {k: v.shape for k, v in res.items()})
+
+
 def gold_transformer():
     """the reference's own Transformer (backbone/detr_backbone.py:25-65): 2 encoder + 2 decoder layers, d_model 256,
     8 heads, ffn 512, return_intermediate_dec, eval mode, fp32; post- and pre-norm"""
@@ -254,4 +285,5 @@ if __name__ == "__main__":
     gold_encoder_layer()
     gold_transformer()
     gold_pos_embed()
+    gold_detr()
     gold_set_criterion()

@@ -64,3 +64,35 @@ def seeded_state_dict(module, seed=72):
         else:
             out[k] = 0.02 * torch.randn(*shp, generator=g)
     return out
+
+
+def synth_detr_case(B=2, C=64, H=6, W=10, seed=101):
+    """seeded backbone feature map + padding mask of one DETR forward, and the seeds of the output gradients"""
+    g = torch.Generator().manual_seed(seed)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    feat = bf(torch.randn(B, C, H, W, generator=g))
+    mask = torch.zeros(B, H, W, dtype=torch.bool)
+    mask[1, :, W - 3:] = True
+    mask[1, H - 1:, :] = True
+    return feat, mask
+
+
+class StubBackbone(torch.nn.Module):
+    """stands in for the (un-vendored) detectron2 ResNet-50 wrapper: hands a fixed feature map and its positional
+    encoding to DETR in the (features, pos) structure detr.py:441-443 expects"""
+
+    def __init__(self, feat, mask, pos, nested_cls):
+        super().__init__()
+        self.num_channels = feat.shape[1]
+        self.feat, self.mask, self.pos, self.nested_cls = feat, mask, pos, nested_cls
+
+    def forward(self, samples):
+        return [self.nested_cls(self.feat, self.mask)], [self.pos]
+
+
+class SimpleNested:
+    def __init__(self, tensors, mask):
+        self.tensors, self.mask = tensors, mask
+
+    def decompose(self):
+        return self.tensors, self.mask

@@ -334,3 +334,42 @@ def test_full_model_grad_clip_matches_torch(scale):
     torch.cuda.synchronize()
     np.testing.assert_allclose(float(norm), float(tn), rtol=1e-5)
     np.testing.assert_allclose(gr.cpu().numpy(), ref.grad.cpu().numpy(), rtol=1e-5, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------ DETR module
+def test_detr_module_against_reference_golden(golden_dir):
+    """our DETR (input_proj, Transformer, class_embed, bbox_embed MLP + sigmoid; aux outputs) with the reference's
+    state_dict vs the reference's own DETR run by path around a stub backbone: logits / boxes of every decoder level and
+    the gradients of a seeded linear functional of them"""
+    import sys
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle")
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    from gen_golden_inputs import synth_detr_case, seeded_state_dict, StubBackbone, SimpleNested
+    from yolov7_d2_amd.modeling import DETR, Transformer, PositionEmbeddingSine
+    g = np.load(os.path.join(golden_dir, "detr_module.npz"))
+    feat, mask = synth_detr_case()
+    x = feat.to(DEV, torch.bfloat16).requires_grad_(True)
+    mask = mask.to(DEV)
+    pos = PositionEmbeddingSine(128, normalize=True)(SimpleNested(None, mask))
+    tr = Transformer(256, 8, 2, 2, 512, 0.1, normalize_before=False, return_intermediate_dec=True)
+    net = DETR(StubBackbone(x, mask, pos, SimpleNested), tr, num_classes=20, num_queries=40, aux_loss=True)
+    net.load_state_dict(seeded_state_dict(net))        # same keys as the reference module
+    net.to(DEV).eval()
+    out = net(SimpleNested(x, mask))
+    logits = torch.stack([a["pred_logits"] for a in out["aux_outputs"]] + [out["pred_logits"]])
+    boxes = torch.stack([a["pred_boxes"] for a in out["aux_outputs"]] + [out["pred_boxes"]])
+    assert logits.shape == (2, 2, 40, 21) and boxes.shape == (2, 2, 40, 4) and logits.dtype == torch.float32
+    gen = torch.Generator().manual_seed(102)
+    gl = torch.randn(logits.shape, generator=gen).to(DEV)
+    gb = torch.randn(boxes.shape, generator=gen).to(DEV)
+    ((logits * gl).sum() + (boxes * gb).sum()).backward()
+    torch.cuda.synchronize()
+    rel = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-12))
+    assert rel(logits.detach().cpu().numpy(), g["logits"]) < 3e-2
+    np.testing.assert_allclose(boxes.detach().cpu().numpy(), g["boxes"], rtol=0, atol=2e-2)
+    assert rel(x.grad.float().cpu().numpy(), g["dfeat"]) < 1e-1
+    params = dict(net.named_parameters())
+    for k in [f[2:] for f in g.files if f.startswith("g:")]:
+        r = rel(params[k].grad.float().cpu().numpy(), g["g:" + k])
+        assert r < 1.5e-1, (k, r)   # bf16 storage through the 4 transformer layers (see the transformer test)

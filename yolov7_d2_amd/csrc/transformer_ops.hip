@@ -133,3 +133,25 @@ extern "C" int mi_ew_bf16(const void* a, const void* b, void* out, int64_t n, in
   MI_CHECK_LAUNCH("ew_bf16");
   return MI_OK;
 }
+
+// ---- fp32 sigmoid with gradient: the box head's final activation (meta_arch/detr.py:452, outputs_coord.sigmoid());
+// dx may be NULL (forward) - with dy given, dx = dy * y * (1 - y) from the stored output y
+__global__ __launch_bounds__(256) void sigmoid_f32_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ y, float* __restrict__ dx, int64_t n) {
+  for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    if (dy) {
+      const float v = y[i];
+      dx[i] = dy[i] * v * (1.f - v);
+    } else {
+      y[i] = 1.f / (1.f + expf(-x[i]));
+    }
+  }
+}
+extern "C" int mi_sigmoid_f32(const float* x, const float* dy, float* y, float* dx, int64_t n, mi_stream_t st) {
+  MI_REQUIRE(y && n > 0 && ((x && !dy && !dx) || (dy && dx)), "sigmoid_f32: forward needs (x, y), backward (dy, y, dx)");
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(sigmoid_f32_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)st, x, dy, y, dx, n);
+  MI_CHECK_LAUNCH("sigmoid_f32");
+  return MI_OK;
+}

@@ -9,3 +9,4 @@ from .iou_loss import IOUlossV6
 from .transformer import (MultiheadAttention, TransformerEncoderLayer, TransformerDecoderLayer, TransformerEncoder,
                           TransformerDecoder, Transformer)
 from .position_encoding import PositionEmbeddingSine
+from .detr import DETR, MLP

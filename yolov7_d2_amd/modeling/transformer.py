@@ -46,41 +46,51 @@ def _conv1x1(x, w_img, y, T, K, Cout, CoutPad, bias=None):
 
 
 class _LinearFn(torch.autograd.Function):
-    """y = x W^T + b over token rows; x bf16 [T, Cin], W fp32 [Cout, Cin] (nn.Linear layout), b fp32 [Cout]"""
+    """y = x W^T + b over token rows; x bf16 [T, Cin], W fp32 [Cout, Cin] (nn.Linear layout), b fp32 [Cout].
+    Cin must be a multiple of 32; any Cout: the output channels are zero-padded to a multiple of 32 inside (the packed
+    weight image and the bias carry zero rows), the caller sees [T, Cout]."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         T, Cin = x.shape
         Cout = weight.shape[0]
-        assert Cin % 32 == 0 and Cout % 32 == 0, "linear: channels must be multiples of 32"
+        assert Cin % 32 == 0, "linear: input channels must be a multiple of 32"
+        CoutP = _rup(Cout, 32)
         dev = x.device
-        wf = torch.empty(Cin // 8 * Cout * 8, dtype=torch.bfloat16, device=dev)
-        wd = torch.empty(Cout // 8 * Cin * 8, dtype=torch.bfloat16, device=dev)
+        wf = torch.empty(Cin // 8 * CoutP * 8, dtype=torch.bfloat16, device=dev)
+        wd = torch.empty(CoutP // 8 * Cin * 8, dtype=torch.bfloat16, device=dev)
         w32 = weight.detach().float().contiguous()
-        L.check(L.lib().mi_pack_conv_weight(w32.data_ptr(), Cout, Cin, 1, 1, wf.data_ptr(), Cin, Cout, wd.data_ptr(), Cout,
+        L.check(L.lib().mi_pack_conv_weight(w32.data_ptr(), Cout, Cin, 1, 1, wf.data_ptr(), Cin, CoutP, wd.data_ptr(), CoutP,
                                             Cin, L.stream_ptr()), "mi_pack_conv_weight")
-        y = torch.empty(T, Cout, dtype=torch.bfloat16, device=dev)
-        b32 = None if bias is None else bias.detach().float().contiguous()
-        _conv1x1(x, wf, y, T, Cin, Cout, Cout, b32)
+        y = torch.empty(T, CoutP, dtype=torch.bfloat16, device=dev)
+        b32 = None
+        if bias is not None:
+            b32 = torch.zeros(CoutP, dtype=torch.float32, device=dev)
+            b32[:Cout] = bias.detach().float()
+        _conv1x1(x, wf, y, T, Cin, CoutP, CoutP, b32)
         ctx.save_for_backward(x, wd)
-        ctx.dims = (T, Cin, Cout, bias is not None)
-        return y
+        ctx.dims = (T, Cin, Cout, CoutP, bias is not None)
+        return y if CoutP == Cout else y[:, :Cout]
 
     @staticmethod
     def backward(ctx, dy):
         x, wd = ctx.saved_tensors
-        T, Cin, Cout, has_bias = ctx.dims
+        T, Cin, Cout, CoutP, has_bias = ctx.dims
         dev = x.device
+        if CoutP != Cout:   # zero-padded out-gradient: K of the data-gradient GEMM is the padded channel count
+            dyp = torch.zeros(T, CoutP, dtype=torch.bfloat16, device=dev)
+            dyp[:, :Cout] = dy
+            dy = dyp
         dy = dy.contiguous()
         dx = torch.empty(T, Cin, dtype=torch.bfloat16, device=dev)
-        _conv1x1(dy, wd, dx, T, Cout, Cin, Cin)
+        _conv1x1(dy, wd, dx, T, CoutP, Cin, Cin)
         # weight gradient
         gw = torch.empty(Cout, Cin, dtype=torch.float32, device=dev)
         H, W = _factor(T)
         d = L.mi_wgrad_desc()
         d.x, d.dy, d.gw = x.data_ptr(), dy.data_ptr(), gw.data_ptr()
-        d.ldx, d.ldy, d.N, d.H, d.W, d.outH, d.outW, d.stride = Cin, Cout, 1, H, W, H, W, 1
-        d.Cin, d.Cout, d.CinPad, d.CoutPad, d.ntaps = Cin, Cout, Cin, Cout, 1
+        d.ldx, d.ldy, d.N, d.H, d.W, d.outH, d.outW, d.stride = Cin, CoutP, 1, H, W, H, W, 1
+        d.Cin, d.Cout, d.CinPad, d.CoutPad, d.ntaps = Cin, Cout, Cin, CoutP, 1
         need = L.lib().mi_conv2d_wgrad_plan(C.byref(d))
         L.check(need, "mi_conv2d_wgrad_plan")
         ws = torch.empty(max(int(need), 16), dtype=torch.uint8, device=dev)
@@ -88,12 +98,13 @@ class _LinearFn(torch.autograd.Function):
         L.check(L.lib().mi_conv2d_wgrad(C.byref(d), L.stream_ptr()), "mi_conv2d_wgrad (linear)")
         gb = None
         if has_bias:
-            gb = torch.empty(Cout, dtype=torch.float32, device=dev)
+            gbp = torch.empty(CoutP, dtype=torch.float32, device=dev)
             cws = torch.empty(128 * 128, dtype=torch.float32, device=dev)
-            for c0 in range(0, Cout, 128):   # column sums in blocks of <= 128 channels
-                nc = min(128, Cout - c0)
-                L.check(L.lib().mi_colsum_bf16(dy.data_ptr() + 2 * c0, Cout, T, nc, gb.data_ptr() + 4 * c0, 0,
+            for c0 in range(0, CoutP, 64):   # column sums of the padded map in blocks of 64 / 32 channels
+                nc = min(64, CoutP - c0)
+                L.check(L.lib().mi_colsum_bf16(dy.data_ptr() + 2 * c0, CoutP, T, nc, gbp.data_ptr() + 4 * c0, 0,
                                                cws.data_ptr(), L.stream_ptr()), "mi_colsum_bf16")
+            gb = gbp[:Cout]
         return dx, gw, gb
 
 
