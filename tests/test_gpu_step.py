@@ -326,3 +326,31 @@ def test_graph_replay_equals_eager():
     s.synchronize()
     assert torch.equal(ps.loss_out()[:4], l0[:4])
     assert float((model.params.grad - g0).norm() / g0.norm()) < 1e-3   # atomics in wgrad: order-dependent rounding only
+
+
+def test_grouped_launches_equal_separate_launches(monkeypatch):
+    """the lane scheduler (grouped CONV / BatchNorm launches for the head's level x branch chains and the CSP conv1 / conv2
+    pairs, with their ordering rules for accumulating data gradients) must not change the step: losses and EVERY
+    parameter gradient against the same plan with one launch per command (MI_GROUP_LEVELS=0)"""
+    res = {}
+    imgs, labels = O.synth_batch(2, 96, 128, seed=17, max_gt=4)
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MI_GROUP_LEVELS", mode)
+        model, _ = _gpu_model(seed=3)
+        model.train()
+        ps = model.plan_for(2, 96, 128, True)
+        ops = [L.OPS[ps.plan.bwd_cmds[0][k].op] for k in range(ps.plan.bwd_cmds[1])]
+        assert ("CONV_GROUP" in ops) == (mode == "1") and ("BN_GROUP" in ops) == (mode == "1")
+        ps.image.copy_(imgs.to(DEV)); ps.labels.copy_(labels.to(DEV))
+        ps.gw().fill_(1.0)
+        ps.plan.run("fwd"); ps.plan.run("bwd"); torch.cuda.synchronize()
+        grads = {n: model.params.grad_of(p).detach().float().cpu().clone() for n, p in model.named_parameters()}
+        res[mode] = (ps.loss_out()[:4].cpu().clone(), grads)
+    np.testing.assert_allclose(res["1"][0].numpy(), res["0"][0].numpy(), rtol=1e-5)
+    bad = []
+    for n, g0 in res["0"][1].items():
+        g1 = res["1"][1][n]
+        r = float((g1 - g0).norm() / (g0.norm() + 1e-12))
+        if r > 1e-2:     # same kernels, same math: only fp64-atomic / split-K summation order differs
+            bad.append((n, r))
+    assert not bad, bad[:8]

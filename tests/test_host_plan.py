@@ -105,3 +105,53 @@ def test_gradient_fanin_flags_and_buffers():
     assert all(c.op != L.OP["COPY"] for c in b.fwd + b.bwd)
     n_conv = sum(c.op == L.OP["CONV"] for c in b.fwd)
     assert n_conv == 83      # 83 convolutions in YOLOX-s
+
+
+def test_lane_scheduling_invariants():
+    """Plan._group_lanes' pure part (plan.schedule_lanes) on the real YOLOX-s step plan: every parallel region (head
+    stems, head level x branch chains, CSP conv1 / conv2) is scheduled into issue sets that (1) contain every command
+    exactly once, (2) keep each lane's order, (3) never put two writers of one tensor into the same set and keep their
+    original order, (4) are homogeneous in op, and (5) actually group: the head's 12 3x3 convs per direction come out
+    as sets of 6"""
+    from yolov7_d2_amd.plan import schedule_lanes, lane_out_key
+    model, _ = _model()
+    ps = _PlanState(model, 2, 64, 96, True, materialize=False)
+    b = ps.builder
+    NOP, CONV = L.OP["NOP"], L.OP["CONV"]
+    nregions = 0
+    sizes = {"fwd": [], "bwd": []}
+    for which, cmds in (("fwd", b.fwd), ("bwd", b.bwd)):
+        k = 0
+        while k < len(cmds):
+            if cmds[k].op == NOP and cmds[k].tag.endswith(".begin"):
+                e = k + 1
+                while not (cmds[e].op == NOP and cmds[e].tag.endswith(".end")):
+                    e += 1
+                region = cmds[k + 1: e]
+                nregions += 1
+                order = {id(c): i for i, c in enumerate(region)}
+                sets = schedule_lanes(region)
+                flat = [c for s_ in sets for c in s_]
+                assert sorted(map(id, flat)) == sorted(map(id, region))                       # (1)
+                for ln in {c.lane for c in region}:                                            # (2)
+                    seq = [order[id(c)] for c in flat if c.lane == ln]
+                    assert seq == sorted(seq)
+                last = {}
+                for si, s_ in enumerate(sets):
+                    assert len({c.op for c in s_}) == 1                                        # (4)
+                    keys = [lane_out_key(c) for c in s_]
+                    assert len(set(keys)) == len(keys)                                         # (3a)
+                    for c, kk in zip(s_, keys):
+                        if kk in last:
+                            assert last[kk][0] < si and last[kk][1] < order[id(c)]             # (3b)
+                        last[kk] = (si, order[id(c)])
+                    if s_[0].op == CONV and len(s_[0].desc.taps) == 9 and "head" in s_[0].tag:
+                        sizes[which].append(len(s_))
+                k = e + 1
+            else:
+                k += 1
+    assert nregions == 2 * (2 + 8)           # head stems + head chains + 8 CSP layers, forward and backward
+    assert sizes["fwd"] == [6, 6]             # cls/reg conv 0 and conv 1 of the three levels
+    # backward: conv-1 data gradients of the 6 chains together; the conv-0 data gradients write the 3 stem gradients
+    # twice (cls + reg branch) -> two ordered sets of 3
+    assert sorted(sizes["bwd"]) == [3, 3, 6]

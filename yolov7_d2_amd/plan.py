@@ -93,6 +93,68 @@ class ConvSpec:
         self.__dict__.update(kw)
 
 
+def lane_out_key(c):
+    """identity of the tensor a groupable command writes (two commands with the same key must never share a launch and
+    must keep their original order)"""
+    if c.op == L.OP["CONV"]:
+        y = c.desc.y
+        return (id(getattr(y.obj, "buf", y.obj)), getattr(y.obj, "coff", 0), y.off)
+    if c.op == L.OP["BN_BWD_APPLY"] and c.p[11].obj is not None:
+        return (id(c.p[11].obj.buf), c.p[11].obj.coff, 0)
+    return id(c)
+
+
+def schedule_lanes(region):
+    """list scheduling of the independent chains (lanes) of a parallel region (pure host logic, no device needed).
+    Walks the chains in lock step: the op kind most lanes have next (convolutions / BatchNorm passes win ties) is taken
+    from all those lanes at once.  Returns a list of issue sets; the commands of a set are mutually independent, have
+    the same op and pairwise different output tensors - writers of one tensor (two data gradients accumulating into the
+    same input gradient) are split into consecutive sets in their original order."""
+    groupable = {L.OP["CONV"], L.OP["BN_ACT_FWD"], L.OP["BN_BWD_REDUCE"], L.OP["BN_BWD_APPLY"]}
+    order = {id(r): i for i, r in enumerate(region)}
+    lanes = sorted({r.lane for r in region})
+    chains = [[r for r in region if r.lane == ln] for ln in lanes]
+    pos = [0] * len(chains)
+    sets = []
+    # writers of one tensor must run in their original order (a first writer overwrites, later ones accumulate): a
+    # command is ready only when every earlier writer of its output has been issued.  The earliest unissued command of
+    # the original order is always ready, so the walk cannot dead-lock.
+    writers = {}
+    for r in region:
+        writers.setdefault(lane_out_key(r), []).append(r)
+    issued = set()
+
+    def ready(c):
+        for w in writers[lane_out_key(c)]:
+            if w is c:
+                return True
+            if id(w) not in issued:
+                return False
+        return True
+
+    while any(p < len(ch) for p, ch in zip(pos, chains)):
+        kinds = {}
+        for li, (p, ch) in enumerate(zip(pos, chains)):
+            if p < len(ch) and ready(ch[p]):
+                kinds.setdefault(ch[p].op, []).append(li)
+        # most lanes first; on a tie the lanes that still have the most commands left (so shorter chains wait for longer
+        # ones to catch up and their convolutions / BatchNorm passes line up), then groupable ops
+        op = max(kinds, key=lambda o: (len(kinds[o]), sum(len(chains[li]) - pos[li] for li in kinds[o]), o in groupable))
+        sel = kinds[op]
+        cs = sorted((chains[li][pos[li]] for li in sel), key=lambda c: order[id(c)])
+        for li in sel:
+            pos[li] += 1
+        seen, waves = {}, {}
+        for c in cs:
+            kk = lane_out_key(c)
+            w = seen.get(kk, 0)
+            seen[kk] = w + 1
+            waves.setdefault(w, []).append(c)
+        sets += [waves[w] for w in sorted(waves)]
+        issued.update(id(c) for c in cs)
+    return sets
+
+
 class PlanBuilder:
     def __init__(self, device, training=True, bn_train=None, group_wgrad=None):
         import os
@@ -675,27 +737,8 @@ class Plan:
         NOP, CONV = L.OP["NOP"], L.OP["CONV"]
         BN_KIND = {L.OP["BN_ACT_FWD"]: 0, L.OP["BN_BWD_REDUCE"]: 1, L.OP["BN_BWD_APPLY"]: 2}
 
-        def out_key(c):   # identity of the tensor a groupable command writes
-            if c.op == CONV:
-                y = c.desc.y
-                return (id(getattr(y.obj, "buf", y.obj)), getattr(y.obj, "coff", 0), y.off)
-            if c.op == L.OP["BN_BWD_APPLY"] and c.p[11].obj is not None:
-                return (id(c.p[11].obj.buf), c.p[11].obj.coff, 0)
-            return id(c)
-
         def issue(cs, order):
             cs = sorted(cs, key=lambda c: order[id(c)])
-            keys = [out_key(c) for c in cs]
-            if len(set(keys)) < len(cs):   # writers of one tensor: split into waves that keep their original order
-                seen, waves = {}, {}
-                for c, kk in zip(cs, keys):
-                    w = seen.get(kk, 0)
-                    seen[kk] = w + 1
-                    waves.setdefault(w, []).append(c)
-                res = []
-                for w in sorted(waves):
-                    res += issue(waves[w], order)
-                return res
             if len(cs) < 2:
                 return cs
             if cs[0].op == CONV:
@@ -768,17 +811,8 @@ class Plan:
             if len(lanes) < 2 or (skip and any(t and t in c.tag for t in skip.split(","))):
                 out += region
             else:
-                pos = [0] * len(chains)
-                while any(p < len(ch) for p, ch in zip(pos, chains)):
-                    nxt = [(ch[p].op, li) for li, (p, ch) in enumerate(zip(pos, chains)) if p < len(ch)]
-                    kinds = {}
-                    for op, li in nxt:
-                        kinds.setdefault(op, []).append(li)
-                    op = max(kinds, key=lambda o: (len(kinds[o]), o in BN_KIND or o == CONV))
-                    sel = kinds[op]
-                    out += issue([chains[li][pos[li]] for li in sel], order)
-                    for li in sel:
-                        pos[li] += 1
+                for cs in schedule_lanes(region):
+                    out += issue(cs, order)
             out.append(cmds[e])
             k = e + 1
         return out
