@@ -51,6 +51,28 @@ def conv_algorithmic(d):
     return byt, flops
 
 
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of a kernel class from the committed rocprofv3 PMC passes of this same command
+    (tools/gpu_pmc.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs, KB units, FETCH_SIZE x2 on gfx950 as
+    MI355X_MICROARCH.md prescribes) -> profiles/r01d_hbm_traffic_pmc.csv; None when the file is absent"""
+    import csv
+    import re
+    path = os.path.join(ROOT, "profiles", "r01d_hbm_traffic_pmc.csv")
+    if not os.path.exists(path):
+        return None
+    rows = list(csv.DictReader(open(path)))
+    tot = lambda r: float(r["fetch_bytes_per_launch_x2corrected"]) + float(r["write_bytes_per_launch"])
+    if kernel_class.startswith("wgrad2_group_kernel"):     # one WGRAD_GROUP command = all wgrad grids + the reduce grid
+        sel = [r for r in rows if "wgrad2" in r["kernel"]]
+        return int(sum(tot(r) for r in sel)) if sel else None
+    m = re.match(r"(conv_igemm(?:_group)?_kernel)<KC=(\d+),BN=(\d+)>", kernel_class)
+    if m:
+        sel = [r for r in rows if re.search(r"%s<%s, %s," % (m.group(1), m.group(2), m.group(3)), r["kernel"])]
+        n = sum(int(r["launches"]) for r in sel)
+        return int(sum(tot(r) * int(r["launches"]) for r in sel) / n) if n else None
+    return None
+
+
 def roofline_block(plan, iters=5):
     from yolov7_d2_amd import _lib as L
     groups = {}
@@ -105,7 +127,7 @@ def roofline_block(plan, iters=5):
     rl = dict(bound="mfma" if mfma_bound else "hbm", kernel=name,
               achieved=round(tfs if mfma_bound else gbs, 1), peak=2500.0 if mfma_bound else 8000.0,
               unit="TFLOP/s" if mfma_bound else "GB/s", frac=round(tfs / 2500.0 if mfma_bound else gbs / 8000.0, 4),
-              traffic=None, avg_launch_ms=round(avg_ms, 5), launches_per_step=g["launches"],
+              traffic=pmc_traffic(name), avg_launch_ms=round(avg_ms, 5), launches_per_step=g["launches"],
               algorithmic_bytes_per_launch=int(g["bytes"] / g["launches"]),
               algorithmic_flops_per_launch=int(g["flops"] / g["launches"]), hbm_GBps=round(gbs, 1),
               hbm_frac_of_8000=round(gbs / 8000.0, 4), mfma_tflops=round(tfs, 1),
