@@ -394,6 +394,11 @@ int mi_grad_clip_full_model(float* grads, int64_t n, float max_norm, double* ws,
 int mi_pos_embed_sine(const uint8_t* mask, int B, int H, int W, int num_pos_feats, float temperature, int normalize,
                       float scale, int centered, float* out, mi_stream_t s);
 
+/* sizeof() of the public structs as compiled into the library (binding self-check): 0 mi_conv_desc, 1 mi_wgrad_desc,
+ * 2 mi_wgrad_group, 3 mi_pack_job, 4 mi_bias_job, 5 mi_yolox_loss_desc, 6 mi_detr_loss_desc, 7 mi_sgd_seg, 8 mi_cmd,
+ * 9 mi_conv_group, 10 mi_bn_job, 11 mi_bn_group; -1 for an unknown id */
+int mi_abi_sizeof(int which);
+
 /* ---- command list executor -----------------------------------------------------
  * A step (forward / backward / update) is a flat list of mi_cmd records built once
  * by the host; mi_cmdlist_run() issues them back-to-back on one stream from C++

@@ -40,6 +40,96 @@ def test_struct_sizes_match_c():
     assert C.sizeof(L.mi_sgd_seg) == 24
 
 
+def test_struct_layouts_match_the_loaded_library():
+    """every public struct: ctypes.sizeof == the C compiler's sizeof inside the library that was loaded"""
+    names = ["mi_conv_desc", "mi_wgrad_desc", "mi_wgrad_group", "mi_pack_job", "mi_bias_job", "mi_yolox_loss_desc",
+             "mi_detr_loss_desc", "mi_sgd_seg", "mi_cmd", "mi_conv_group", "mi_bn_job", "mi_bn_group"]
+    lib = L.lib()
+    for i, n in enumerate(names):
+        assert lib.mi_abi_sizeof(i) == C.sizeof(getattr(L, n)), n
+    assert lib.mi_abi_sizeof(len(names)) == -1
+
+
+def _conv_desc(H, W, K, Cout, taps, stride=1, N=16):
+    d = L.mi_conv_desc()
+    d.x = d.w = d.y = 4096          # non-null, aligned dummies: the planners never touch memory
+    d.ldx, d.ldy, d.N, d.H, d.W = K, Cout, N, H, W
+    d.outH, d.outW, d.gridH, d.gridW = H // stride, W // stride, H // stride, W // stride
+    d.in_stride, d.out_stride, d.K8, d.Cout, d.CoutPad, d.ntaps = stride, 1, K // 8, Cout, Cout, taps
+    offs = [(a, b) for a in (-1, 0, 1) for b in (-1, 0, 1)] if taps == 9 else [(0, 0)]
+    for i, (a, b) in enumerate(offs):
+        d.tap_dy[i], d.tap_dx[i], d.tap_w[i] = a, b, i
+    return d
+
+
+def test_conv_launcher_configurations_are_valid():
+    """host side of mi_conv2d (no GPU): for every conv shape class of YOLOX-s and a few odd ones the
+    launcher's choice is a legal configuration: k-chunk divides K, taps-per-step divides the taps, the cout tile divides
+    CoutPad, the pixel tile has <= 128 pixels"""
+    lib = L.lib()
+    shapes = [(320, 320, 16, 32, 9, 1), (320, 320, 32, 64, 9, 2), (160, 160, 64, 32, 1, 1), (160, 160, 32, 32, 9, 1),
+              (160, 160, 64, 128, 9, 2), (80, 80, 128, 64, 1, 1), (80, 80, 64, 64, 9, 1), (80, 80, 128, 128, 9, 1),
+              (80, 80, 128, 256, 9, 2), (40, 40, 256, 128, 1, 1), (40, 40, 128, 128, 9, 1), (40, 40, 256, 512, 9, 2),
+              (20, 20, 512, 256, 1, 1), (20, 20, 1024, 512, 1, 1), (20, 20, 256, 256, 9, 1), (20, 20, 128, 96, 1, 1),
+              (13, 17, 48, 160, 9, 1), (7, 5, 64, 32, 1, 1)]
+    for (H, W, K, Co, taps, s) in shapes:
+        d = _conv_desc(H, W, K, Co, taps, s)
+        n = lib.mi_conv2d_plan(C.byref(d))
+        assert n > 0, (H, W, K, Co, taps, s, lib.mi_last_error())
+        assert d.KC in (16, 32, 64, 128) and K % d.KC == 0
+        assert d.TPS >= 1 and taps % d.TPS == 0
+        assert d.BN in (32, 64, 128) and d.CoutPad % d.BN == 0
+        assert 1 <= d.TH * d.TW <= 128
+        assert n == d.N * -(-d.gridH // d.TH) * -(-d.gridW // d.TW)
+    bad = _conv_desc(20, 20, 64, 64, 1)
+    bad.KC, bad.TPS = 48, 1                          # a forced k-chunk that is not a kernel configuration
+    assert lib.mi_conv2d_plan(C.byref(bad)) < 0 and b"KC" in lib.mi_last_error()
+
+
+def test_conv_group_planner_host_side():
+    """mi_conv2d_group_plan (no GPU): the head's three 3x3 level convs share one configuration, the smaller maps get tile
+    shapes inside the leading job's LDS footprint, block ranges are contiguous; jobs that cannot share a configuration
+    or mix accumulate / plain launches are refused"""
+    lib = L.lib()
+    descs = (L.mi_conv_desc * 3)()
+    for d, hw in zip(descs, (80, 40, 20)):
+        C.memmove(C.byref(d), C.byref(_conv_desc(hw, hw, 128, 128, 9)), C.sizeof(L.mi_conv_desc))
+    meta = L.mi_conv_group()
+    assert lib.mi_conv2d_group_plan(descs, 3, None, 0, C.byref(meta)) == 0, lib.mi_last_error()
+    assert meta.njobs == 3 and meta.KC in (32, 64, 128) and meta.BN in (64, 128) and meta.lds_bytes <= 80 * 1024 + 4096
+    host = (C.c_char * meta.table_bytes)()
+    assert lib.mi_conv2d_group_plan(descs, 3, host, meta.table_bytes, C.byref(meta)) == 0
+    starts = (C.c_int * 4).from_buffer_copy(bytes(host)[meta.starts_off: meta.starts_off + 16])
+    assert starts[0] == 0 and starts[3] == meta.nblocks and starts[0] < starts[1] < starts[2] < starts[3]
+    one = L.mi_conv_desc.from_buffer_copy(descs[0])      # the leading job alone needs the same blocks as in the group
+    n0 = lib.mi_conv2d_plan(C.byref(one))
+    assert starts[1] == n0 * (one.CoutPad // one.BN)
+    assert lib.mi_conv2d_group_plan(descs, 3, host, 8, C.byref(meta)) < 0            # table too small
+    descs[1].flags = L.MI_CONV_ACCUM
+    assert lib.mi_conv2d_group_plan(descs, 3, None, 0, C.byref(meta)) < 0            # accumulate mixed with plain
+    descs[1].flags = 0
+    descs[2].K8 = 6                                                                  # K = 48: not a multiple of the k-chunk
+    assert lib.mi_conv2d_group_plan(descs, 3, None, 0, C.byref(meta)) < 0
+
+
+def test_bn_group_planner_host_side():
+    lib = L.lib()
+    jobs = (L.mi_bn_job * 2)()
+    for j, (npix, Cc) in zip(jobs, ((16 * 1600, 128), (16 * 400, 256))):
+        for f in ("y", "a", "scale", "shift", "acc", "gamma", "beta", "mean", "invstd"):
+            setattr(j, f, 4096)
+        j.npix = j.count = npix
+        j.C, j.ldy, j.lda, j.act, j.nslots, j.eps, j.momentum = Cc, Cc, Cc, 1, 16, 1e-3, 0.03
+    meta = L.mi_bn_group()
+    assert lib.mi_bn_group_plan(0, jobs, 2, None, 0, C.byref(meta)) == 0, lib.mi_last_error()
+    assert meta.kind == 0 and meta.njobs == 2 and meta.act == 1
+    assert meta.nblocks == (16 * 1600 * 16 + 2047) // 2048 + (16 * 400 * 32 + 2047) // 2048
+    jobs[1].act = 0
+    assert lib.mi_bn_group_plan(0, jobs, 2, None, 0, C.byref(meta)) < 0              # the jobs must agree on the activation
+    jobs[1].act, jobs[1].C = 1, 100
+    assert lib.mi_bn_group_plan(0, jobs, 2, None, 0, C.byref(meta)) < 0              # C must be a multiple of 8 dividing 2048
+
+
 def test_argument_errors_without_launch():
     lib = L.lib()
     d = L.mi_conv_desc()
@@ -93,7 +183,7 @@ def test_registry_and_config_surface(tmp_path):
     bn = model.backbone.dark3[0].bn
     assert bn.eps == 1e-3 and bn.momentum == 0.03
     import math
-    assert abs(float(model.head.obj_preds[1].bias[0]) + math.log(99.0)) < 1e-6
+    assert abs(float(model.head.obj_preds[1].bias[0].detach()) + math.log(99.0)) < 1e-6
     assert model.backbone.size_divisibility == 32 and model.backbone.output_shape()["dark5"].channels == 512
 
 

@@ -178,6 +178,7 @@ _PROTOS = {
     "mi_ew_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i, _vp]),
     "mi_iou_loss_v6": (C.c_int, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "mi_batched_nms": (C.c_int, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mi_abi_sizeof": (C.c_int, [_i]),
     "mi_sigmoid_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "mi_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _i64, _f, _vp]),
     "mi_grad_clip_full_model": (C.c_int, [_vp, _i64, _f, _vp, _vp, _vp]),

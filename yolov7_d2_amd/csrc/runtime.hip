@@ -250,3 +250,24 @@ extern "C" int mi_probe_mfma16(const void* a, const void* b, float* d, mi_stream
   MI_CHECK_LAUNCH("probe_mfma16");
   return MI_OK;
 }
+
+// sizeof() of every public struct, so that a binding (ctypes, cgo, JNI ...) can verify its own layout against the
+// library it loaded: 0 mi_conv_desc, 1 mi_wgrad_desc, 2 mi_wgrad_group, 3 mi_pack_job, 4 mi_bias_job,
+// 5 mi_yolox_loss_desc, 6 mi_detr_loss_desc, 7 mi_sgd_seg, 8 mi_cmd, 9 mi_conv_group, 10 mi_bn_job, 11 mi_bn_group
+extern "C" int mi_abi_sizeof(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(mi_conv_desc);
+    case 1: return (int)sizeof(mi_wgrad_desc);
+    case 2: return (int)sizeof(mi_wgrad_group);
+    case 3: return (int)sizeof(mi_pack_job);
+    case 4: return (int)sizeof(mi_bias_job);
+    case 5: return (int)sizeof(mi_yolox_loss_desc);
+    case 6: return (int)sizeof(mi_detr_loss_desc);
+    case 7: return (int)sizeof(mi_sgd_seg);
+    case 8: return (int)sizeof(mi_cmd);
+    case 9: return (int)sizeof(mi_conv_group);
+    case 10: return (int)sizeof(mi_bn_job);
+    case 11: return (int)sizeof(mi_bn_group);
+  }
+  return -1;
+}
