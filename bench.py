@@ -107,7 +107,7 @@ def roofline_block(plan, iters=5):
             elif op == "WGRAD_GROUP":
                 name = "wgrad2_group_kernel<*> (all layers)"
                 byt = fl = 0
-                for d in plan.wgrad_descs:
+                for d in descs[k]:
                     npx = d.N * d.outH * d.outW
                     byt += d.N * d.H * d.W * d.CinPad * 2 + npx * d.CoutPad * 2 + d.ntaps * d.Cout * d.Cin * 4
                     fl += 2.0 * npx * d.CoutPad * d.CinPad * d.ntaps

@@ -28,6 +28,17 @@ def test_plan_buckets_orders_by_completion():
     assert covered[0][0] == 0 and covered[-1][1] == 1000
 
 
+def test_plan_buckets_with_explicit_bounds():
+    """the split weight-gradient groups cut the arena where the early (neck + head) group starts: that bucket completes
+    at the early group's command, the backbone bucket at the end"""
+    writes = [[(600 * 4, 1000 * 4)], [], [(0, 600 * 4)]]          # cmd0 = early wgrad group, cmd2 = late group
+    b = plan_buckets(1000, writes, 3, bounds=[600])
+    assert b == [(600, 1000, 0), (0, 600, 2)]
+    red = GradReducer(torch.zeros(1000), b)
+    assert red.segments(3) == [(0, 1, (600, 1000)), (1, 3, (0, 600))]
+    assert plan_buckets(1000, writes, 2, bounds=[0, 1000, 5000]) == plan_buckets(1000, writes, 1)   # degenerate bounds
+
+
 def _worker(rank, world, port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)

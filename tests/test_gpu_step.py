@@ -358,3 +358,31 @@ def test_grouped_launches_equal_separate_launches(monkeypatch, B, H, W):
         if r > 5e-2:
             bad.append((n, r))
     assert not bad, bad[:8]
+
+
+def test_wgrad_split_groups_equal_single_group(monkeypatch):
+    """data-parallel layout of the weight gradients (MI_WGRAD_SPLIT=1: head + neck group mid-backward, backbone group at
+    the end, so the first gradient bucket can be all-reduced under the backbone's backward) against the single group:
+    same kernels on the same operands - only the split-K partition of a layer may differ (fp32 summation order)"""
+    res = {}
+    imgs, labels = O.synth_batch(2, 96, 128, seed=19, max_gt=4)
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MI_WGRAD_SPLIT", mode)
+        model, _ = _gpu_model(seed=4)
+        model.train()
+        ps = model.plan_for(2, 96, 128, True)
+        tags = ps.plan.bwd_tags
+        assert ("wgrad_group.early" in tags) == (mode == "1") and tags[-1] == "wgrad_group"
+        if mode == "1":
+            k = tags.index("wgrad_group.early")
+            # every head / neck out-gradient (written by the layer's BatchNorm backward) exists before the early group
+            # and no backbone backward command has been issued yet (only data gradients of the first neck layers follow)
+            assert not any(t.startswith(("head.", "neck.")) and "bnapply" in t for t in tags[k + 1:])
+            assert not any(t.startswith("backbone.") for t in tags[:k])
+        ps.image.copy_(imgs.to(DEV)); ps.labels.copy_(labels.to(DEV))
+        ps.gw().fill_(1.0)
+        ps.plan.run("fwd"); ps.plan.run("bwd"); torch.cuda.synchronize()
+        res[mode] = (ps.loss_out()[:4].cpu().clone(), model.params.grad.detach().cpu().clone())
+    assert torch.equal(res["0"][0], res["1"][0]) or torch.allclose(res["0"][0], res["1"][0], rtol=1e-5)
+    g0, g1 = res["0"][1], res["1"][1]
+    assert float((g1 - g0).norm() / g0.norm()) < 2e-3

@@ -155,3 +155,21 @@ def test_lane_scheduling_invariants():
     # backward: conv-1 data gradients of the 6 chains together; the conv-0 data gradients write the 3 stem gradients
     # twice (cls + reg branch) -> two ordered sets of 3
     assert sorted(sizes["bwd"]) == [3, 3, 6]
+
+
+def test_wgrad_split_is_opt_in_and_ordered(monkeypatch):
+    """MI_WGRAD_SPLIT (default: only under torch.distributed with world_size > 1): the head + neck weight gradients form
+    an early group placed after the last head / neck backward command and before any backbone backward command"""
+    model, _ = _model()
+    b0 = _PlanState(model, 2, 64, 96, True, materialize=False).builder
+    assert b0.wgrad_split is False
+    monkeypatch.setenv("MI_WGRAD_SPLIT", "1")
+    b1 = _PlanState(model, 2, 64, 96, True, materialize=False).builder
+    assert b1.wgrad_split is True and b1.wgrad_early_prefixes == ("head.", "neck.")
+    tags = [c.tag for c in b1.bwd]
+    wg = [i for i, c in enumerate(b1.bwd) if c.op == L.OP["WGRAD"]]
+    early = [i for i in wg if tags[i].startswith(("head.", "neck."))]
+    late = [i for i in wg if i not in early]
+    assert len(early) == 48 and len(late) == 35                 # SURVEY Appendix A: 24 + 24 convs, 35 in the backbone
+    first_backbone = min(i for i, t in enumerate(tags) if t.startswith("backbone."))
+    assert max(early) < first_backbone                            # the early group can be issued before the backbone's backward

@@ -58,7 +58,14 @@ class NativeTrainer:
         sgd[0].i[0], sgd[0].i[1] = self.nseg, 0
         sgd[0].f[0], sgd[0].f[1] = self.momentum, 1.0 / self.world
         writes = grad_write_ranges(plan, self.params.grad)
-        buckets = plan_buckets(self.params.total, writes, self.n_buckets if self.world > 1 else 1)
+        bounds = None
+        if self.world > 1 and getattr(ps.builder, "wgrad_split", False):
+            # two buckets cut where the early weight-gradient group ends in the arena (parameters are laid out backbone,
+            # neck, head): the neck + head bucket is complete - and on the wire - while the backbone's backward runs
+            early = [o for (name, p, o, n) in self.params.entries if name.startswith(ps.builder.wgrad_early_prefixes)]
+            if early:
+                bounds = [min(early)]
+        buckets = plan_buckets(self.params.total, writes, self.n_buckets if self.world > 1 else 1, bounds=bounds)
         red = GradReducer(self.params.grad, buckets)
         barr, bn = plan.bwd_cmds
         segs = red.segments(bn, parallel_regions(plan))

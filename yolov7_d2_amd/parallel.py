@@ -34,7 +34,7 @@ def grad_write_ranges(plan, grad_tensor):
             d = C.cast(c.p[0], C.POINTER(L.mi_wgrad_desc)).contents
             ptrs.append((d.gw, d.ntaps * d.Cout * d.Cin * 4))
         elif c.op == L.OP["WGRAD_GROUP"]:
-            for d in plan.wgrad_descs:
+            for d in plan.cmd_descs["bwd"][k]:
                 ptrs.append((d.gw, d.ntaps * d.Cout * d.Cin * 4))
         elif c.op == L.OP["BN_BWD_APPLY"]:
             ptrs += [(c.p[8], c.i[5] * 4), (c.p[9], c.i[5] * 4)]
@@ -57,12 +57,17 @@ def grad_write_ranges(plan, grad_tensor):
     return out
 
 
-def plan_buckets(total_elems, writes, n_buckets):
-    """split [0,total) into n contiguous buckets (element ranges) and return, per bucket, the index of the
-    LAST backward command that writes into it: [(lo, hi, last_cmd)], ordered by completion time."""
-    n_buckets = max(1, min(n_buckets, total_elems))
-    bounds = [total_elems * i // n_buckets for i in range(n_buckets + 1)]
-    bounds = [b // 4 * 4 for b in bounds[:-1]] + [total_elems]
+def plan_buckets(total_elems, writes, n_buckets, bounds=None):
+    """split [0,total) into n contiguous buckets (element ranges; equal parts, or the given interior `bounds`) and
+    return, per bucket, the index of the LAST backward command that writes into it: [(lo, hi, last_cmd)], ordered by
+    completion time."""
+    if bounds:
+        bounds = [0] + sorted(int(b) // 4 * 4 for b in bounds if 0 < b < total_elems) + [total_elems]
+        n_buckets = len(bounds) - 1
+    else:
+        n_buckets = max(1, min(n_buckets, total_elems))
+        bounds = [total_elems * i // n_buckets for i in range(n_buckets + 1)]
+        bounds = [b // 4 * 4 for b in bounds[:-1]] + [total_elems]
     res = []
     for i in range(n_buckets):
         lo, hi = bounds[i], bounds[i + 1]

@@ -171,6 +171,16 @@ class PlanBuilder:
         # the independent chains of a parallel region (the head's FPN levels) zipped into grouped launches: one
         # CONV_GROUP / BN_GROUP per chain position instead of one launch per level
         self.group_lanes = os.environ.get("MI_GROUP_LEVELS", "1") != "0"
+        # weight gradients of the head + neck layers in their own grouped launch as soon as those layers' backward is done,
+        # so that their gradient bucket can be all-reduced while the backbone's backward still runs (data parallel only:
+        # MI_WGRAD_SPLIT unset -> on iff torch.distributed is initialised with world_size > 1)
+        ws_env = os.environ.get("MI_WGRAD_SPLIT", "")
+        if ws_env:
+            self.wgrad_split = ws_env != "0"
+        else:
+            import torch.distributed as dist
+            self.wgrad_split = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.wgrad_early_prefixes = ("head.", "neck.")
         self.csp_lanes = os.environ.get("MI_CSP_LANES", "1") != "0"   # CSP conv1 / conv2 as lanes (see blocks.CSPLayer)
         self.training = training            # build the backward command list
         self.bn_train = training if bn_train is None else bn_train  # batch statistics vs running statistics
@@ -624,13 +634,31 @@ class Plan:
         self.graphs = {}
 
     def _group_wgrads(self, bwd):
-        """all WGRAD commands become ONE grouped launch at the end of backward (mi_conv2d_wgrad_group_run)"""
+        """all WGRAD commands become ONE grouped launch at the end of backward (mi_conv2d_wgrad_group_run) - or two when
+        the builder asks for the split (data parallel): the head + neck layers' group is issued right after the last of
+        their backward commands, the backbone's group at the end.  Both share the split-K workspace (they run one after
+        the other on the stream)."""
         b = self.b
         wg = [c for c in bwd if c.op == L.OP["WGRAD"]]
         self.wgrad_descs = []
         if not (b.group_wgrad and len(wg) >= 2):
             return bwd
-        ws = b.wgrad_group_ws
+        early = [c for c in wg if b.wgrad_split and c.tag.startswith(b.wgrad_early_prefixes)]
+        late = [c for c in wg if c not in early]
+        if len(early) < 2 or len(late) < 2:
+            early, late = [], wg
+        out = []
+        last_early = max((i for i, c in enumerate(bwd) if c in early), default=-1)
+        for i, c in enumerate(bwd):
+            if c.op != L.OP["WGRAD"]:
+                out.append(c)
+            if i == last_early:
+                out.append(self._wgrad_group_cmd(early, "wgrad_group.early"))
+        out.append(self._wgrad_group_cmd(late, "wgrad_group"))
+        return out
+
+    def _wgrad_group_cmd(self, wg, tag):
+        ws = self.b.wgrad_group_ws
         descs = (L.mi_wgrad_desc * len(wg))()
         for d, c in zip(descs, wg):
             t = PlanBuilder._wgrad_desc(c.desc)
@@ -642,13 +670,12 @@ class Plan:
         host = (C.c_char * int(meta.table_bytes))()
         L.check(L.lib().mi_conv2d_wgrad_group_plan(descs, len(wg), ws.ptr, host, meta.table_bytes, C.byref(meta)),
                 "wgrad_group_plan")
-        self.wgrad_table = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(b.device)
-        self.wgrad_meta = meta
-        self.wgrad_descs = list(descs)
-        self._wgrad_descs_arr = descs
-        rest = [c for c in bwd if c.op != L.OP["WGRAD"]]
-        grp = _Cmd(L.OP["WGRAD_GROUP"], p=[_Ptr(C.addressof(meta)), _Ptr(self.wgrad_table)], tag="wgrad_group")
-        return rest + [grp]
+        table = self._upload_table(host, meta.table_bytes)
+        self.descs += [meta, descs]
+        self.wgrad_descs += list(descs)
+        grp = _Cmd(L.OP["WGRAD_GROUP"], p=[_Ptr(C.addressof(meta)), _Ptr(table)], tag=tag)
+        grp.group_descs = list(descs)
+        return grp
 
     def _batch_packs(self, prologue):
         """all PACK_W commands of the prologue become ONE launch over a device job table"""
