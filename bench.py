@@ -7,7 +7,7 @@ gradient all-reduce + SGD update), bs=16/GPU, synthetic COCO-shaped data, on N M
         bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line (see BASELINE.json for the metric).  `roofline` describes the dominant
-kernel (the conv_igemm instantiation with the largest total time per step), `cpu_baseline` the oracle
+kernel class (the conv / wgrad class with the largest total time per step; since the head / CSP convs are grouped that is the grouped weight gradient), `cpu_baseline` the oracle
 (CPU fp32 restatement of the reference path) timed on this box's host cores on a bounded sample.
 """
 import argparse

@@ -53,6 +53,30 @@ def gold_step():
     print("step:", res["losses"])
 
 
+def gold_tiny_step():
+    """config 0 of BASELINE.json: YOLOX-tiny (depth .33, width .375), 416x416, bs=2, fp32 on the CPU device - the
+    reference's own CPU-runnable case; losses, gradient norms of every parameter and the eval output"""
+    depth, width, nc = 0.33, 0.375, 80
+    ref, r = ref_loader.build_reference_yolox(depth, width, nc, seed=0)
+    sd0 = O.init_state_dict(depth, width, nc, seed=0)
+    ref.load_state_dict(sd0)
+    ref.train()
+    imgs, labels = O.synth_batch(2, 416, 416, seed=31, max_gt=6)
+    out = ref(imgs, labels)
+    (out[0] + out[1] + out[2] + out[3]).backward()
+    grads = {k: p.grad.detach().clone() for k, p in ref.named_parameters()}
+    names = sorted(grads)
+    res = dict(losses=np.array([float(x) for x in out], dtype=np.float64), grad_names=np.array(names),
+               grad_norms=np.array([float(grads[k].norm()) for k in names], dtype=np.float64))
+    res["grad:head.cls_preds.1.weight"] = grads["head.cls_preds.1.weight"].numpy()
+    ref.eval()
+    with torch.no_grad():
+        ev = ref(imgs)
+    res["eval_out_stride"] = ev[:, ::7].numpy()          # every 7th anchor keeps the fixture small
+    np.savez_compressed(os.path.join(OUT, "yolox_tiny_step_416.npz"), **res)
+    print("tiny step:", res["losses"])
+
+
 def gold_simota():
     """head loss + SimOTA of the reference on synthetic raw predictions, B=3, 160x160 (A=525)"""
     ref, r = ref_loader.build_reference_yolox(0.33, 0.5, 80, seed=0)
@@ -278,6 +302,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     gold_step()
+    gold_tiny_step()
     gold_simota()
     gold_postprocess()
     gold_hungarian()

@@ -36,6 +36,32 @@ def test_step_losses_grads_and_eval(golden_dir):
     np.testing.assert_allclose(ev.numpy(), g["eval_out"], rtol=1e-5, atol=1e-5)
 
 
+def test_config0_yolox_tiny_416_cpu_step(golden_dir):
+    """BASELINE.json configs[0] (YOLOX-tiny, width .375, 416x416, bs=2, CPU): the oracle against the reference's own
+    modules run by path - the 4 losses, the gradient norm of every parameter, one full gradient and the eval output.
+    (The HIP path serves widths whose channel counts are multiples of 32; tiny's 24/48/96/192/384 channels are a
+    next-round item)"""
+    g = np.load(os.path.join(golden_dir, "yolox_tiny_step_416.npz"))
+    sd = O.init_state_dict(0.33, 0.375, 80, seed=0)
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    imgs, labels = O.synth_batch(2, 416, 416, seed=31, max_gt=6)
+    res = O.train_step_losses(sd, imgs, labels, depth=0.33, width=0.375)
+    np.testing.assert_allclose(np.array([float(x) for x in res]), g["losses"], rtol=1e-5, atol=1e-6)
+    (res[0] + res[1] + res[2] + res[3]).backward()
+    names = [str(n) for n in g["grad_names"]]
+    norms = np.array([float(sd[n].grad.norm()) for n in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(sd["head.cls_preds.1.weight"].grad.numpy(), g["grad:head.cls_preds.1.weight"], rtol=2e-4,
+                               atol=1e-6)
+    with torch.no_grad():
+        net = O.Net({k: v.detach() for k, v in sd.items()}, 0.33, 0.375, 80, training=False)
+        raw, hw = net.forward_raw(imgs)
+        ev = O.decode_eval(raw, O.make_anchors(hw))
+    np.testing.assert_allclose(ev[:, ::7].numpy(), g["eval_out_stride"], rtol=1e-5, atol=1e-5)
+
+
 def test_simota_assignment_bit_exact(golden_dir):
     g = np.load(os.path.join(golden_dir, "simota_160.npz"))
     B, H, W = 3, 160, 160
