@@ -173,3 +173,40 @@ def test_wgrad_split_is_opt_in_and_ordered(monkeypatch):
     assert len(early) == 48 and len(late) == 35                 # 24 + 24 convs, 35 in the backbone
     first_backbone = min(i for i, t in enumerate(tags) if t.startswith("backbone."))
     assert max(early) < first_backbone                            # the early group can be issued before the backbone's backward
+
+
+def test_plan_step_matches_oracle_yolox_l():
+    """the same plan builder on YOLOX-l (depth 1.0, width 1.0: 54.2 M parameters, 9/9/9/3-bottleneck CSP stages, up to
+    1024 channels): losses and every parameter gradient of the interpreted plan against the fp32 oracle - the host logic
+    is not specialised to the YOLOX-s shapes of the benchmark"""
+    cfg = M.yolox_s_cfg(device="cpu")
+    cfg.MODEL.YOLO.DEPTH_MUL, cfg.MODEL.YOLO.WIDTH_MUL = 1.0, 1.0
+    model = M.build_model(cfg)
+    sd = O.init_state_dict(1.0, 1.0, 80, seed=0)
+    model.load_state_dict(sd)
+    model.params = ParamArena(model, "cpu")
+    assert sum(p.numel() for p in model.parameters()) == 54208895
+    B, H, W = 2, 128, 128
+    imgs, labels = O.synth_batch(B, H, W, seed=11, max_gt=4)
+    ps = _PlanState(model, B, H, W, True, materialize=False)
+    b = ps.builder
+    ps.image.copy_(imgs)
+    ps.labels.copy_(labels)
+    it = Interp(b, torch.float32)
+    it.run(b.prologue + b.fwd)
+    out = it.raw(ps.loss["out"]).view(torch.float32)[:4].clone()
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    res = O.train_step_losses(sd, imgs, labels, depth=1.0, width=1.0)
+    np.testing.assert_allclose(out.numpy(), np.array([float(x.detach()) for x in res[:4]]), rtol=1e-5, atol=1e-5)
+    it.raw(ps.loss["gw"]).view(torch.float32)[:4] = 1.0
+    it.run(b.bwd)
+    (res[0] + res[1] + res[2] + res[3]).backward()
+    bad = []
+    for name, p in model.named_parameters():
+        g, r = model.params.grad_of(p).detach().float(), sd[name].grad
+        rel = float((g - r).norm()) / (float(r.norm()) + 1e-6)
+        if rel > 3e-3:
+            bad.append((name, rel))
+    assert not bad, bad[:8]
