@@ -210,3 +210,51 @@ def test_plan_step_matches_oracle_yolox_l():
         if rel > 3e-3:
             bad.append((name, rel))
     assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_gradient_buckets_are_complete_before_their_allreduce(monkeypatch, split):
+    """data-parallel schedule on the REAL YOLOX-s backward list (materialised against a host arena: grouped conv /
+    BatchNorm / weight-gradient launches, job tables and all): every byte of the flat gradient arena is written by some
+    backward command, the buckets tile the arena, and each bucket's all-reduce is issued only after the LAST command that
+    writes into it - with the split weight-gradient groups the neck + head bucket goes out before the first backbone
+    command"""
+    from yolov7_d2_amd.plan import Plan
+    from yolov7_d2_amd.parallel import GradReducer, grad_write_ranges, plan_buckets
+    monkeypatch.setenv("MI_WGRAD_SPLIT", split)
+    model, _ = _model()
+    ps = _PlanState(model, 2, 64, 96, True, materialize=False)
+    plan = Plan(ps.builder, dry_run=True)
+    arena = model.params
+    writes = grad_write_ranges(plan, arena.grad)
+    n = plan.bwd_cmds[1]
+    assert len(writes) == n
+    # (1) every parameter's gradient is written by some command
+    covered = np.zeros(arena.total, dtype=bool)
+    for rs in writes:
+        for (b0, b1) in rs:
+            covered[b0 // 4: b1 // 4] = True
+    for name, p, off, cnt in arena.entries:
+        assert covered[off: off + cnt].all(), name
+    # (2) buckets (the engine's choice for world > 1) tile the arena and are reduced after their last writer
+    bounds = None
+    if split == "1":
+        bounds = [min(o for (nm, p, o, c) in arena.entries if nm.startswith(("head.", "neck.")))]
+    buckets = plan_buckets(arena.total, writes, 3, bounds=bounds)
+    assert sorted((lo, hi) for lo, hi, _ in buckets)[0][0] == 0
+    assert sum(hi - lo for lo, hi, _ in buckets) == arena.total
+    segs = GradReducer(arena.grad, buckets).segments(n)
+    assert segs[0][0] == 0 and segs[-1][1] == n and all(a[1] == b_[0] for a, b_ in zip(segs, segs[1:]))
+    for (c0, c1, bucket) in segs:
+        if bucket is None:
+            continue
+        lo, hi = bucket
+        for k, rs in enumerate(writes):
+            if any(b0 < hi * 4 and lo * 4 < b1 for (b0, b1) in rs):
+                assert k < c1, (bucket, k, c1, plan.bwd_tags[k])
+    tags = plan.bwd_tags
+    if split == "1":
+        first_backbone = min(i for i, t in enumerate(tags) if t.startswith("backbone."))
+        assert len(buckets) == 2 and segs[0][1] <= first_backbone and "wgrad_group.early" in tags
+    else:
+        assert "wgrad_group.early" not in tags and tags[-1] == "wgrad_group"

@@ -614,9 +614,13 @@ class PlanBuilder:
 
 
 class Plan:
-    def __init__(self, b):
+    def __init__(self, b, dry_run=False):
+        """dry_run (tests only): materialise the command lists, descriptors and job tables against a HOST arena so that
+        the host-side scheduling (grouped launches, gradient write ranges, all-reduce buckets) can be checked without a
+        GPU; such a plan cannot be run - every executor entry point refuses without a device."""
         self.b = b
-        L.require_device()
+        if not (dry_run and b.device.type == "cpu"):
+            L.require_device()
         off = 0
         for buf in b.bufs:
             buf.offset = off
