@@ -258,3 +258,27 @@ def test_gradient_buckets_are_complete_before_their_allreduce(monkeypatch, split
         assert len(buckets) == 2 and segs[0][1] <= first_backbone and "wgrad_group.early" in tags
     else:
         assert "wgrad_group.early" not in tags and tags[-1] == "wgrad_group"
+
+
+def test_grouped_launches_of_the_640_plan():
+    """regression guard for the launch structure of the benchmark-sized plan (dry-run, 640x640): the head's level x branch
+    chains and the CSP conv1 / conv2 pairs really come out as grouped launches (a group planner that silently falls back
+    to one launch per layer costs ~6 % of the step and no other test would notice), and no grouped conv launch exceeds
+    the 80 KB LDS footprint that keeps two blocks per CU"""
+    import collections
+    import ctypes as C
+    from yolov7_d2_amd.plan import Plan
+    model, _ = _model()
+    ps = _PlanState(model, 2, 640, 640, True, materialize=False)
+    plan = Plan(ps.builder, dry_run=True)
+    want = {"fwd": dict(CONV_GROUP=13, BN_GROUP=11, CONV=43, BN_ACT_FWD=43),
+            "bwd": dict(CONV_GROUP=6, BN_GROUP=22, BN_BWD_REDUCE=43, BN_BWD_APPLY=43, WGRAD_GROUP=1)}
+    jobs = {"fwd": [2] * 8 + [3, 6, 6, 6, 3], "bwd": [6, 3, 6, 3, 3, 3]}
+    for which in ("fwd", "bwd"):
+        arr, n = plan.fwd_cmds if which == "fwd" else plan.bwd_cmds
+        ops = collections.Counter(L.OPS[arr[k].op] for k in range(n))
+        for op, cnt in want[which].items():
+            assert ops[op] == cnt, (which, op, ops[op], cnt)
+        metas = [C.cast(arr[k].p[0], C.POINTER(L.mi_conv_group)).contents for k in range(n) if L.OPS[arr[k].op] == "CONV_GROUP"]
+        assert [m.njobs for m in metas] == jobs[which]
+        assert all(m.lds_bytes <= 80 * 1024 for m in metas)
