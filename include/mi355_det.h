@@ -148,6 +148,9 @@ typedef struct mi_wgrad_group {
     int64_t job_off, starts_off;
   } g[MI_WGRAD_MAX_GROUPS];
   int64_t red_off, red_starts_off, table_bytes, ws_bytes;
+  /* second reduce grid: the 3x3 layers (one 576-thread block per 16x16 fragment tile x 9 taps) */
+  int64_t red9_off, red9_starts_off;
+  int32_t nred9, red9_blocks;
 } mi_wgrad_group;
 int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, void* ws_base, void* table_host,
                                int64_t table_cap, mi_wgrad_group* meta);

@@ -150,3 +150,64 @@ def test_detr_set_criterion_oracle_against_reference_golden(golden_dir):
         for i, (l, b) in enumerate(leaves):
             np.testing.assert_allclose(l.grad.numpy(), g[f"{name}:dlogits{i}"], rtol=1e-5, atol=1e-8)
             np.testing.assert_allclose(b.grad.numpy(), g[f"{name}:dboxes{i}"], rtol=1e-5, atol=1e-7)
+
+
+def test_bf16_storage_noise_floor():
+    """Why the whole-step GPU parity test (tests/test_gpu_parity_bench.py) pins the forward state: two bf16-STORAGE
+    executions of the same network that differ only by a sub-ulp jitter before each rounding (i.e. two correct
+    implementations with different accumulation orders) agree to ~1 % at the head output, but train-mode BatchNorm's
+    backward amplifies that forward noise so much that their weight gradients agree only to cosine ~0.8 in the backbone.
+    With the conv outputs of one run forced into the other (teacher forcing, O.Net(force=...)) the same two
+    implementations agree to cosine > 0.999 on EVERY parameter - that is the bound the GPU test asserts."""
+    torch.manual_seed(0)
+
+    def mk(jitter):
+        class Q(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, t):
+                if jitter:
+                    t = t * (1 + jitter * (torch.rand_like(t) - 0.5))
+                return t.to(torch.bfloat16).float()
+
+            @staticmethod
+            def backward(ctx, g):
+                if jitter:
+                    g = g * (1 + jitter * (torch.rand_like(g) - 0.5))
+                return g.to(torch.bfloat16).float()
+        return Q.apply
+
+    B, H, W = 2, 128, 160
+    imgs, labels = O.synth_batch(B, H, W, seed=1234, max_gt=6)
+    sd0 = O.init_state_dict(0.33, 0.5, 80, seed=0)
+
+    def run(quant, dpreds=None, force=None):
+        sd = {k: v.clone() for k, v in sd0.items()}
+        for k, v in sd.items():
+            if v.is_floating_point() and "running" not in k:
+                v.requires_grad_(True)
+        net = O.Net(sd, 0.33, 0.5, 80, training=True, quant=quant, force=force)
+        raw, hw = net.forward_raw(imgs)
+        if dpreds is None:
+            r = raw.detach().clone().requires_grad_(True)
+            res = O.yolox_losses(r, labels, O.make_anchors(hw), 80)
+            (res[0] + res[1] + res[2] + res[3]).backward()
+            dpreds = r.grad
+        raw.backward(dpreds)
+        ys = {k: v.detach().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous().flatten() for k, v in net.taps.items()
+              if k.endswith(".y")}
+        return raw.detach(), dpreds, {k: v.grad for k, v in sd.items() if v.requires_grad}, ys
+
+    def cosines(a, b):
+        return {k: float((a[k] * b[k]).sum() / (a[k].norm() * b[k].norm() + 1e-30)) for k in a if float(b[k].norm()) > 0}
+
+    raw_a, dp, g_a, ys_a = run(mk(0.0))
+    raw_b, _, g_b, _ = run(mk(1e-3), dp)
+    raw_f, _, g_f, _ = run(mk(1e-3), dp, force=ys_a)
+    free, forced = cosines(g_b, g_a), cosines(g_f, g_a)
+    rel_raw = float((raw_b - raw_a).norm() / raw_a.norm())
+    print("raw rel L2 between the two bf16 executions", rel_raw)
+    print("un-forced: cos min %.3f median %.3f | forced: cos min %.5f" %
+          (min(free.values()), float(np.median(list(free.values()))), min(forced.values())))
+    assert rel_raw < 3e-2
+    assert min(free.values()) < 0.95        # an end-to-end cos >= 0.99 bound fails between two correct implementations
+    assert min(forced.values()) > 0.999     # ... and holds for every parameter once the forward state is pinned

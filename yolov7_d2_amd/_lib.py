@@ -107,7 +107,8 @@ class mi_wgrad_group(C.Structure):
     _fields_ = [("ngroups", C.c_int32), ("nred", C.c_int32), ("red_blocks", C.c_int32), ("pad_", C.c_int32),
                 ("g", _mi_wgrad_group_g * MI_WGRAD_MAX_GROUPS),
                 ("red_off", C.c_int64), ("red_starts_off", C.c_int64), ("table_bytes", C.c_int64),
-                ("ws_bytes", C.c_int64)]
+                ("ws_bytes", C.c_int64), ("red9_off", C.c_int64), ("red9_starts_off", C.c_int64),
+                ("nred9", C.c_int32), ("red9_blocks", C.c_int32)]
 
 
 class mi_bias_job(C.Structure):

@@ -20,6 +20,7 @@
 //     to a split-K workspace; a second small kernel sums the splits in a fixed order (deterministic)
 //     and scatters into the OIHW fp32 gradient.  The earlier atomicAdd version spent ~19 M L2
 //     atomics per launch (270 us per 3x3 layer regardless of size).
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include "common.h"
@@ -33,6 +34,7 @@ struct Wg2K {
   int dymin, dxmin, haloW, npixh, nqx, stage, ns;
   int toff[MI_MAX_TAPS];
   int nco, nci;
+  int xmap;           // 1: XCD-aware block order (blocks sharing a pixel range are 8 ids apart: same XCD, dispatched together)
   unsigned mTW, mHW;  // ceil(65536 / TW), ceil(65536 / haloW): row / d == (row * m) >> 20 for row * d < 65536
   long long V;        // float4 vectors per split slab
 };
@@ -94,10 +96,25 @@ __device__ __forceinline__ void wgrad2_body(const Wg2K& p, const int bid) {
   const int g = lane >> 4, t = lane & 15;
   const int wco = wave / WCI, wci = wave % WCI;
 
-  int id = bid;
-  const int s = id % p.nsplit;
-  id /= p.nsplit;
-  const int cob = id % p.nco, cib = id / p.nco;
+  // block id -> (split s, output tile pair).  Workgroup b runs on XCD b % 8 (observed placement, speed only): with the
+  // XCD-aware order the nco*nci blocks that read the SAME pixel range (dy re-read per cin block, x per cout block) sit
+  // 8 ids apart - same XCD, dispatched together, so the second reader finds the tile in that XCD's L2 instead of HBM.
+  int s, pair;
+  {
+    const int npairs = p.nco * p.nci;
+    const int s8 = p.xmap ? (p.nsplit & ~7) : 0;  // splits covered by full groups of 8
+    const int full = s8 * npairs;
+    if (bid < full) {
+      const int k = bid >> 3;
+      pair = k % npairs;
+      s = (k / npairs) * 8 + (bid & 7);
+    } else {
+      const int rem = bid - full, r = p.nsplit - s8;
+      s = s8 + rem % r;
+      pair = rem / r;
+    }
+  }
+  const int cob = pair % p.nco, cib = pair / p.nco;
   const int co0 = cob * BCO, ci0 = cib * BCI;
   const int TPv = p.TH * p.TW;
 
@@ -285,6 +302,65 @@ __device__ __forceinline__ void wgrad2_reduce_body(const Wg2R& p, const long lon
   }
 }
 
+// 3x3 layers: one block = one 16(cout) x 16(cin) fragment tile, wave w = tap w.  The split sums go through an LDS
+// transpose so that the OIHW rows leave as contiguous 576-byte runs (16 cin x 9 taps) instead of 4-byte stores 36 bytes
+// apart (measured round 1: the scattered form wrote 175 MB for a 36 MB gradient), with the same read parallelism (one
+// thread per partial float4 per tap - summing all taps in one thread was 3x slower).
+__device__ __forceinline__ void wgrad2_reduce9_body(const Wg2R& p, const int blk) {
+  __shared__ float tile[16 * 16 * 9 + 16];
+  const int tid = threadIdx.x, lane = tid & 63, tap = tid >> 6;
+  int r = blk;
+  const int j = r % p.NJ; r /= p.NJ;
+  const int i = r % p.MI; r /= p.MI;
+  const int NW = p.WCO * p.WCI;
+  const int wave = r % NW; r /= NW;     // r = cob * nci + cib
+  const int cib = r % p.nci, cob = r / p.nci;
+  const long long v = ((((long long)(r * NW + wave) * 9 + tap) * p.MI + i) * p.NJ + j) * 64 + lane;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  const f32x4* src = p.part + v;
+  int k = 0;
+  for (; k + 4 <= p.nsplit; k += 4) {
+    const f32x4 a = src[(size_t)k * p.V], b = src[(size_t)(k + 1) * p.V], c = src[(size_t)(k + 2) * p.V],
+                d = src[(size_t)(k + 3) * p.V];
+    s0 += a; s1 += b; s2 += c; s3 += d;
+  }
+  for (; k < p.nsplit; ++k) s0 += src[(size_t)k * p.V];
+  const f32x4 sum = (s0 + s1) + (s2 + s3);
+  // fragment element (lane, e): cout 4*(lane>>4)+e, cin lane&15  ->  tile[cout][cin][tap]
+#pragma unroll
+  for (int e = 0; e < 4; ++e) tile[((4 * (lane >> 4) + e) * 16 + (lane & 15)) * 9 + tap] = sum[e];
+  __syncthreads();
+  const int wco = wave / p.WCI, wci = wave % p.WCI;
+  const int ci0 = cib * (16 * p.NJ * p.WCI) + (wci * p.NJ + j) * 16;
+  const int co0 = cob * (16 * p.MI * p.WCO) + (wco * p.MI + i) * 16;
+  if (ci0 >= p.Cin) return;
+  const int row = tid / 36, c4 = (tid % 36) * 4;            // 16 rows x 36 float4
+  const int co = co0 + row;
+  const int nval = min(16, p.Cin - ci0) * 9;                 // valid floats of a row
+  if (co >= p.Cout || c4 >= nval) return;
+  float* dst = p.g + ((size_t)co * p.Cin + ci0) * 9 + c4;
+  const float* t = tile + row * 144 + c4;
+  if (c4 + 4 <= nval && ((uintptr_t)dst & 15) == 0) {
+    f32x4 o = {t[0], t[1], t[2], t[3]};
+    if (p.accumulate) o += *(const f32x4*)dst;
+    *(f32x4*)dst = o;
+  } else {
+    for (int e = 0; e < 4 && c4 + e < nval; ++e) dst[e] = p.accumulate ? dst[e] + t[e] : t[e];
+  }
+}
+__global__ __launch_bounds__(576) void wgrad2_reduce9_kernel(const Wg2R p) { wgrad2_reduce9_body(p, blockIdx.x); }
+__global__ __launch_bounds__(576) void wgrad2_reduce9_group_kernel(const Wg2R* __restrict__ jobs,
+                                                                   const int* __restrict__ starts, int njobs) {
+  const int b = blockIdx.x;
+  int lo = 0, hi = njobs - 1;  // largest j with starts[j] <= b
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (starts[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const Wg2R p = jobs[lo];
+  wgrad2_reduce9_body(p, b - starts[lo]);
+}
+
 __global__ __launch_bounds__(256) void wgrad2_reduce_kernel(const Wg2R p) { wgrad2_reduce_body(p, blockIdx.x); }
 __global__ __launch_bounds__(256) void wgrad2_reduce_group_kernel(const Wg2R* __restrict__ jobs,
                                                                   const int* __restrict__ starts, int njobs) {
@@ -314,6 +390,15 @@ __global__ __launch_bounds__(256) void wgrad2_reduce_group_kernel(const Wg2R* __
 struct Wg2Cfg {
   int NT, MI, NJ, WCO, WCI, TP;
 };
+
+// tuning switches (read once; the defaults are the measured best, the environment overrides are for A/B runs)
+static int wg_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && *e) ? atoi(e) : dflt;
+}
+static int wg_xmap() { static const int v = wg_env("MI_WG_XMAP", 1); return v; }
+static int wg_units() { static const int v = wg_env("MI_WG_UNITS", 768); return v; }
+static int wg_red9() { static const int v = wg_env("MI_WG_RED9", 1); return v; }
 
 static void wg_choose_tile(int TP, int gridH, int gridW, int* TH, int* TW) {
   const int cands[] = {gridW, 64, 32, 16, 8, 4};
@@ -411,6 +496,7 @@ static int wg_fill(const mi_wgrad_desc* d, Wg2K* k, Wg2Cfg* c, size_t* lds, size
   MI_REQUIRE(*lds <= 160 * 1024, "wgrad: LDS %zu too large", *lds);
   k->ntiles = d->N * k->tilesY * k->tilesX;
   k->nco = d->CoutPad / BCO; k->nci = d->CinPad / BCI;
+  k->xmap = wg_xmap();
   int split = d->splitk;
   if (split <= 0) {
     // one resident block per CU, but never fewer than ~4 pixel tiles per block: each block pays a fixed
@@ -473,7 +559,10 @@ extern "C" int mi_conv2d_wgrad(const mi_wgrad_desc* d, mi_stream_t st) {
   r.part = (const f32x4*)d->ws; r.g = d->gw; r.V = k.V; r.nsplit = k.nsplit;
   r.NT = c.NT; r.MI = c.MI; r.NJ = c.NJ; r.WCO = c.WCO; r.WCI = c.WCI; r.nco = k.nco; r.nci = k.nci;
   r.Cout = d->Cout; r.Cin = d->Cin; r.accumulate = d->accumulate;
-  hipLaunchKernelGGL(wgrad2_reduce_kernel, dim3((unsigned)((k.V + 255) / 256)), dim3(256), 0, s, r);
+  if (c.NT == 9 && wg_red9())
+    hipLaunchKernelGGL(wgrad2_reduce9_kernel, dim3((unsigned)(k.V / (64 * 9))), dim3(576), 0, s, r);
+  else
+    hipLaunchKernelGGL(wgrad2_reduce_kernel, dim3((unsigned)((k.V + 255) / 256)), dim3(256), 0, s, r);
   MI_CHECK_LAUNCH("conv_wgrad_reduce");
   return MI_OK;
 }
@@ -507,7 +596,8 @@ extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, voi
     long units = 0;
     for (int j = 0; j < n; ++j)
       if (wg_cfg_id(cs[j]) == wg_cfg_id(cs[i])) units += (long)ks[j].ntiles * ks[j].nco * ks[j].nci;
-    long T = (units + 767) / 768;
+    const long U = wg_units();
+    long T = (units + U - 1) / U;
     if (T < 4) T = 4;
     mi_wgrad_desc t = descs[i];
     if (!t.x) t.x = (const void*)256;
@@ -556,23 +646,35 @@ extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, voi
     g.job_off = put(jobs.data(), jobs.size() * sizeof(Wg2K));
     g.starts_off = put(starts.data(), starts.size() * sizeof(int));
   }
-  // reduce jobs (all layers, one grid)
-  std::vector<Wg2R> rj(n);
-  std::vector<int> rs;
-  int rblocks = 0;
+  // reduce jobs: one grid for the 1x1 layers (256-thread blocks, 4 fragment tiles each) and one for the 3x3 layers
+  // (576-thread blocks = one fragment tile x 9 taps, LDS-transposed rows)
+  std::vector<Wg2R> rj, rj9;
+  std::vector<int> rs, rs9;
+  int rblocks = 0, rblocks9 = 0;
   for (int i = 0; i < n; ++i) {
-    Wg2R& r = rj[i];
+    Wg2R r;
     r.part = (const f32x4*)ks[i].part; r.g = descs[i].gw; r.V = ks[i].V; r.nsplit = ks[i].nsplit;
     r.NT = cs[i].NT; r.MI = cs[i].MI; r.NJ = cs[i].NJ; r.WCO = cs[i].WCO; r.WCI = cs[i].WCI;
     r.nco = ks[i].nco; r.nci = ks[i].nci; r.Cout = descs[i].Cout; r.Cin = descs[i].Cin;
     r.accumulate = descs[i].accumulate;
-    rs.push_back(rblocks);
-    rblocks += (int)((ks[i].V + 255) / 256);
+    if (cs[i].NT == 9 && wg_red9()) {
+      rj9.push_back(r);
+      rs9.push_back(rblocks9);
+      rblocks9 += (int)(ks[i].V / (64 * 9));
+    } else {
+      rj.push_back(r);
+      rs.push_back(rblocks);
+      rblocks += (int)((ks[i].V + 255) / 256);
+    }
   }
   rs.push_back(rblocks);
-  meta->nred = n; meta->red_blocks = rblocks;
+  rs9.push_back(rblocks9);
+  meta->nred = (int)rj.size(); meta->red_blocks = rblocks;
   meta->red_off = put(rj.data(), rj.size() * sizeof(Wg2R));
   meta->red_starts_off = put(rs.data(), rs.size() * sizeof(int));
+  meta->nred9 = (int)rj9.size(); meta->red9_blocks = rblocks9;
+  meta->red9_off = put(rj9.data(), rj9.size() * sizeof(Wg2R));
+  meta->red9_starts_off = put(rs9.data(), rs9.size() * sizeof(int));
   meta->table_bytes = (int64_t)off;
   if (tab) MI_REQUIRE((int64_t)off <= table_cap, "wgrad_group_plan: table needs %zu bytes", off);
   return MI_OK;
@@ -609,8 +711,15 @@ extern "C" int mi_conv2d_wgrad_group_run(const mi_wgrad_group* meta, const void*
     if (rc == MI_EINVAL) MI_FAIL(MI_EINVAL, "wgrad_group: no kernel for group %d", gi);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(wgrad2_reduce_group_kernel, dim3((unsigned)meta->red_blocks), dim3(256), 0, s,
-                     (const Wg2R*)(tab + meta->red_off), (const int*)(tab + meta->red_starts_off), meta->nred);
-  MI_CHECK_LAUNCH("conv_wgrad_reduce_group");
+  if (meta->red9_blocks > 0) {
+    hipLaunchKernelGGL(wgrad2_reduce9_group_kernel, dim3((unsigned)meta->red9_blocks), dim3(576), 0, s,
+                       (const Wg2R*)(tab + meta->red9_off), (const int*)(tab + meta->red9_starts_off), meta->nred9);
+    MI_CHECK_LAUNCH("conv_wgrad_reduce9_group");
+  }
+  if (meta->red_blocks > 0) {
+    hipLaunchKernelGGL(wgrad2_reduce_group_kernel, dim3((unsigned)meta->red_blocks), dim3(256), 0, s,
+                       (const Wg2R*)(tab + meta->red_off), (const int*)(tab + meta->red_starts_off), meta->nred);
+    MI_CHECK_LAUNCH("conv_wgrad_reduce_group");
+  }
   return MI_OK;
 }

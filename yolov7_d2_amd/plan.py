@@ -485,6 +485,13 @@ class PlanBuilder:
         """data gradient into x.grad; dyT: out-grad view with K8*8 readable channels"""
         dx = x.grad
         acc = self.grad_mode(x)
+        if acc:
+            # test-only mutation (tests/test_gpu_parity_bench.py): MI_TEST_DROP_ACCUM=n makes the n-th accumulating data
+            # gradient OVERWRITE its target, i.e. drops the earlier consumers' contribution - the whole-step parity
+            # check must catch it
+            self._n_accum = getattr(self, "_n_accum", 0) + 1
+            if os.environ.get("MI_TEST_DROP_ACCUM", "") == str(self._n_accum):
+                acc = 0
         flags = L.MI_CONV_ACCUM if acc else 0
         # output channels written: the real Cin (x may carry zero pad channels, e.g. the 12->16 stem)
         cmds = []
