@@ -227,6 +227,8 @@ int mi_bn_act_bwd_apply(const void* da, int ldda, const void* y, int ldy, const 
 /* ---- data movement ops -------------------------------------------------- */
 /* Focus space-to-depth (wrappers.py:202-220) fused with fp32 NCHW -> bf16 NHWC and 12->16 ch pad */
 int mi_focus_pack(const float* img_nchw, int N, int H, int W, void* out, int ldo, mi_stream_t s);
+/* same from the uint8 NCHW image of the data loader (preprocess_image's .type(torch.float), yolox.py:96-99, fused) */
+int mi_focus_pack_u8(const uint8_t* img_nchw, int N, int H, int W, void* out, int ldo, mi_stream_t s);
 /* nn.Upsample(2,"nearest") (yolo_pafpn.py:28) into a concat slice, and its gradient */
 int mi_upsample2x_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C,
                       mi_stream_t s);

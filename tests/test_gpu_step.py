@@ -423,3 +423,41 @@ def test_yolox_l_training_step():
         if rn > 1e-6:
             ratios.append(float(g.norm()) / rn)
     assert 0.7 < float(np.median(ratios)) < 1.4
+
+
+def test_async_wgrad_branch_equals_single_group(monkeypatch):
+    """MI_WGRAD_ASYNC=G: the weight gradients as G grouped launches on the low-priority auxiliary stream beside the
+    backward chain (eager list and captured hipGraph with the parallel branch) against the single group at the end of
+    backward: same kernels on the same operands - only the split-K partition of a layer may differ"""
+    res = {}
+    imgs, labels = O.synth_batch(2, 96, 128, seed=19, max_gt=4)
+    for mode in ("0", "3"):
+        monkeypatch.setenv("MI_WGRAD_ASYNC", mode)
+        model, _ = _gpu_model(seed=4)
+        model.train()
+        ps = model.plan_for(2, 96, 128, True)
+        tags = ps.plan.bwd_tags
+        assert (sum(t.startswith("wgrad_group.async") for t in tags) == 3) == (mode == "3")
+        if mode == "3":
+            assert tags[-1] == "wgrad.join"
+            # a group is issued only after every out-gradient it reads exists (BatchNorm backward of its layers)
+            for gi in range(3):
+                k = tags.index(f"wgrad_group.async{gi}")
+                cmd = ps.plan.cmd_descs["bwd"][k]
+                assert len(cmd) >= 2
+        ps.image.copy_(imgs.to(DEV)); ps.labels.copy_(labels.to(DEV))
+        ps.gw().fill_(1.0)
+        ps.plan.run("fwd"); ps.plan.run("bwd"); torch.cuda.synchronize()
+        g_eager = model.params.grad.detach().cpu().clone()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            ps.plan.capture("bwd", s)
+            model.params.grad.zero_()
+            ps.plan.launch("bwd", s)
+        s.synchronize()
+        g_graph = model.params.grad.detach().cpu().clone()
+        assert float((g_graph - g_eager).norm() / g_eager.norm()) < 1e-3
+        res[mode] = (ps.loss_out()[:4].cpu().clone(), g_eager)
+    assert torch.allclose(res["0"][0], res["3"][0], rtol=1e-5)
+    g0, g1 = res["0"][1], res["3"][1]
+    assert float((g1 - g0).norm() / g0.norm()) < 2e-3

@@ -14,6 +14,8 @@ MI_CONV_ACCUM = 1
 MI_CONV_BNBWD = 4
 MI_CONV_OUT_F32 = 2
 MI_BN_SLOTS = 16
+MI_MAX_AUX = 4
+MI_WGRAD_STREAM = MI_MAX_AUX   # the last auxiliary stream is created with the lowest priority (background work)
 
 
 class MI355Error(RuntimeError):
@@ -152,6 +154,7 @@ _PROTOS = {
     "mi_bn_act_bwd_apply": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _i, _vp, _i, _i,
                                       _i64, _i, _i, _vp]),
     "mi_focus_pack": (C.c_int, [_vp, _i, _i, _i, _vp, _i, _vp]),
+    "mi_focus_pack_u8": (C.c_int, [_vp, _i, _i, _i, _vp, _i, _vp]),
     "mi_upsample2x_fwd": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "mi_upsample2x_bwd": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mi_spp_pool_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),

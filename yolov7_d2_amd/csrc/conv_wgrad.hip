@@ -34,6 +34,7 @@ struct Wg2K {
   int dymin, dxmin, haloW, npixh, nqx, stage, ns;
   int toff[MI_MAX_TAPS];
   int nco, nci;
+  int nrx;            // v3 layout: rows per channel group of the x tile = max(npixh, 32)
   int xmap;           // 1: XCD-aware block order (blocks sharing a pixel range are 8 ids apart: same XCD, dispatched together)
   unsigned mTW, mHW;  // ceil(65536 / TW), ceil(65536 / haloW): row / d == (row * m) >> 20 for row * d < 65536
   long long V;        // float4 vectors per split slab
@@ -259,6 +260,187 @@ __global__ __launch_bounds__(WCO* WCI * 64, 2) void wgrad2_group_kernel(const Wg
   wgrad2_body<NT, MI, NJ, WCO, WCI, TP>(p, b - starts[j]);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// v3 LDS layout ("column-major by 32-byte channel group").  PMC of the v2 kernel on the YOLOX-s step (round 2,
+// profiles/r02_sq_counters.csv): 6 VALU instructions per MFMA - the XOR-swizzled row-major layout makes every
+// transpose read recompute shift / and / xor / add per lane - and the matrix pipe 30 % busy.  Here a tile is stored
+// as [channel group of 16][pixel row][32 bytes]: a half-wave of a ds_read_b64_tr_b16 (8 consecutive pixel rows of one
+// group) reads 256 contiguous bytes (conflict-free without a swizzle) and the address is LINEAR in the row, so
+//   * the dy (A) fragments of all k-steps / cout groups are one VGPR + immediate offsets,
+//   * an x (B) fragment of tap t is base[ks][e] + toff[t]*32: one v_add with a scalar per read.
+// An LDS-DMA instruction (64 lanes x 16 B, lane-linear in LDS) therefore covers 32 pixel rows of ONE group: each lane
+// pair fetches the 32 bytes of its row; the four groups of a 128-byte line are fetched by consecutive instructions
+// of the same wave (L2 merges them).  The split-K slab format is unchanged (same reduce kernels).
+template <int NT, int MI, int NJ, int WCO, int WCI, int TP>
+__device__ __forceinline__ void wgrad3_body(const Wg2K& p, const int bid) {
+  constexpr int NW = WCO * WCI, BCO = 16 * MI * WCO, BCI = 16 * NJ * WCI;
+  constexpr int GD = BCO / 16, GX = BCI / 16, KS = TP / 32, PB = TP / 32;
+  constexpr int UD = PB * GD;                 // dy DMA units (32 rows x one group) per tile
+  static_assert(UD % NW == 0, "dy loader split");
+  constexpr int QW_DY = UD / NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, t = lane & 15;
+  const int wco = wave / WCI, wci = wave % WCI;
+
+  int s, pair;
+  {
+    const int npairs = p.nco * p.nci;
+    const int s8 = p.xmap ? (p.nsplit & ~7) : 0;
+    const int full = s8 * npairs;
+    if (bid < full) {
+      const int k = bid >> 3;
+      pair = k % npairs;
+      s = (k / npairs) * 8 + (bid & 7);
+    } else {
+      const int rem = bid - full, r = p.nsplit - s8;
+      s = s8 + rem % r;
+      pair = rem / r;
+    }
+  }
+  const int cob = pair % p.nco, cib = pair / p.nco;
+  const int co0 = cob * BCO, ci0 = cib * BCI;
+  const int TPv = p.TH * p.TW;
+  const int nrx = p.nrx;                         // x rows per group (npixh, at least 32; the last DMA unit overlaps its predecessor)
+  const int nrb = (nrx + 31) >> 5;               // 32-row DMA units per x group
+
+  // ---- per-lane fragment addresses (tile invariant, relative to the stage base)
+  // dy: row P = ks*32 + 16*e + 4g + (t>>2), group cg = wco*MI + i  ->  (cg*TP + P)*32 + (t&3)*8
+  const int aoff = ((wco * MI) * TP + 4 * g + (t >> 2)) * 32 + (t & 3) * 8;
+  // x: halo row of pixel P (+ tap offset), group cg = wci*NJ + j -> (cg*nrx + row)*32 + (t&3)*8
+  int hb[KS][2];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int P = ks * 32 + 16 * e + 4 * g + (t >> 2);
+      const bool v = P < TPv;
+      const int ty = v ? (int)(((unsigned)P * p.mTW) >> 20) : 0;
+      const int tx = v ? P - ty * p.TW : 0;
+      hb[ks][e] = ((wci * NJ) * nrx + ty * p.is * p.haloW + tx * p.is) * 32 + (t & 3) * 8 + TP * BCO * 2;
+    }
+  int toff32[NT];
+#pragma unroll
+  for (int tap = 0; tap < NT; ++tap) toff32[tap] = p.toff[tap] * 32;
+  const int jstride = nrx * 32;
+
+  f32x4 acc[NT][MI][NJ];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[a][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int tpi = p.tilesY * p.tilesX;
+  const int tbeg = s * p.tps;
+  const int tend = min(p.ntiles, tbeg + p.tps);
+
+  const char* const zero = (const char*)g_mi_zero_page;
+  const int half8 = (lane & 1) * 8;   // this lane's 16-byte half of the 32-byte group (in elements)
+  auto issue = [&](int tile, int st) {
+    const int img = tile / tpi;
+    const int rem = tile - img * tpi;
+    const int tyq = rem / p.tilesX;
+    const int ty0 = tyq * p.TH, tx0 = (rem - tyq * p.tilesX) * p.TW;
+    const unsigned sbase = lds0 + st * p.stage;
+    const char* const dyb = (const char*)(p.dy + ((size_t)img * p.outH * p.outW) * (size_t)p.lddy + co0);
+#pragma unroll
+    for (int i = 0; i < QW_DY; ++i) {
+      const int u = wave + NW * i;
+      const int pb = u % PB, G = u / PB;
+      const int row = pb * 32 + (lane >> 1);
+      const int ty = (int)(((unsigned)row * p.mTW) >> 20);
+      const int tx = row - ty * p.TW;
+      const int oy = ty0 + ty, ox = tx0 + tx;
+      const bool v = (row < TPv) & (oy < p.outH) & (ox < p.outW);
+      const unsigned off = (unsigned)(((oy * p.outW + ox) * p.lddy + G * 16 + half8) * 2);
+      glds16(v ? dyb + off : zero, sbase + (G * TP + pb * 32) * 32);
+    }
+    const int iy0 = ty0 * p.is + p.dymin, ix0 = tx0 * p.is + p.dxmin;
+    const unsigned xbase = sbase + TP * BCO * 2;
+    const char* const xb = (const char*)(p.x + ((size_t)img * p.H * p.W) * (size_t)p.ldx + ci0);
+    for (int rb = wave; rb < nrb; rb += NW) {
+      const int r0 = min(rb * 32, nrx - 32);   // the last unit re-covers rows of its predecessor (same bytes)
+      const int row = r0 + (lane >> 1);
+      const int hy = (int)(((unsigned)row * p.mHW) >> 20);
+      const int hx = row - hy * p.haloW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool v = (row < p.npixh) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+      const char* src = xb + (unsigned)(((iy * p.W + ix) * p.ldx + half8) * 2);
+#pragma unroll
+      for (int G = 0; G < GX; ++G) glds16(v ? src + G * 32 : zero, xbase + (G * nrx + r0) * 32);
+    }
+  };
+
+  const int NS = p.ns;
+  const int nload = QW_DY + ((nrb - wave + NW - 1) / NW) * GX;
+  for (int j = 0; j < NS - 1; ++j)
+    if (tbeg + j < tend) issue(tbeg + j, j);
+  int it = 0, cur = 0;
+  for (int tile = tbeg; tile < tend; ++tile, ++it) {
+    const int ahead = min(NS - 2, tend - 1 - tile);
+    wait_vmcnt(ahead * nload);
+    __builtin_amdgcn_s_barrier();
+    {
+      const int nxt = tile + NS - 1;
+      int st = cur - 1;
+      if (st < 0) st += NS;
+      if (nxt < tend) issue(nxt, st);
+    }
+    const char* const sB = smem + cur * p.stage;
+    if (++cur == NS) cur = 0;
+    const char* const aB = sB + aoff;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 a[MI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        a[i] = tr_read2(aB + (i * TP + ks * 32) * 32, aB + (i * TP + ks * 32 + 16) * 32);
+      const char* const b0 = sB + hb[ks][0];
+      const char* const b1 = sB + hb[ks][1];
+#pragma unroll
+      for (int tap = 0; tap < NT; ++tap) {
+        bf16x8 b[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          b[j] = tr_read2(b0 + toff32[tap] + j * jstride, b1 + toff32[tap] + j * jstride);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[tap][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[tap][i][j], 0, 0, 0);
+      }
+    }
+  }
+  f32x4* out = (f32x4*)p.part + (size_t)s * (size_t)p.V +
+               ((size_t)((cob * p.nci + cib) * NW + wave) * (NT * MI * NJ)) * 64 + lane;
+#pragma unroll
+  for (int tap = 0; tap < NT; ++tap)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) out[((tap * MI + i) * NJ + j) * 64] = acc[tap][i][j];
+}
+
+template <int NT, int MI, int NJ, int WCO, int WCI, int TP>
+__global__ __launch_bounds__(WCO* WCI * 64, 2) void wgrad3_kernel(const Wg2K p) {
+  wgrad3_body<NT, MI, NJ, WCO, WCI, TP>(p, blockIdx.x);
+}
+template <int NT, int MI, int NJ, int WCO, int WCI, int TP>
+__global__ __launch_bounds__(WCO* WCI * 64, 2) void wgrad3_group_kernel(const Wg2K* __restrict__ jobs,
+                                                                         const int* __restrict__ starts, int njobs) {
+  const int b = blockIdx.x;
+  int j = 0;
+  while (j + 1 < njobs && starts[j + 1] <= b) ++j;
+  const Wg2K p = jobs[j];
+  wgrad3_body<NT, MI, NJ, WCO, WCI, TP>(p, b - starts[j]);
+}
+
 struct Wg2R {
   const f32x4* part;
   float* g;
@@ -397,8 +579,14 @@ static int wg_env(const char* name, int dflt) {
   return (e && *e) ? atoi(e) : dflt;
 }
 static int wg_xmap() { static const int v = wg_env("MI_WG_XMAP", 1); return v; }
-static int wg_units() { static const int v = wg_env("MI_WG_UNITS", 768); return v; }
-static int wg_red9() { static const int v = wg_env("MI_WG_RED9", 1); return v; }
+static int wg_units() { static const int v = wg_env("MI_WG_UNITS", 0); return v; }
+static int wg_red9() { static const int v = wg_env("MI_WG_RED9", 0); return v; }
+// at least this much dynamic LDS per block of a grouped launch (e.g. 84000: one block per CU, the rest of the CU's LDS
+// stays free for kernels of another stream)
+// 1: v3 LDS layout (column-major by channel group, see wgrad3_body) for the 3x3 configurations, 2: for all, 0: v2
+static int wg_v3() { static const int v = wg_env("MI_WG_V3", 1); return v; }
+static bool wg_use_v3(int NT) { return wg_v3() == 2 || (wg_v3() == 1 && NT == 9); }
+static int wg_min_lds() { static const int v = wg_env("MI_WG_MIN_LDS", 0); return v; }
 
 static void wg_choose_tile(int TP, int gridH, int gridW, int* TH, int* TW) {
   const int cands[] = {gridW, 64, 32, 16, 8, 4};
@@ -439,6 +627,11 @@ static int wg_pick_cfg(const mi_wgrad_desc* d, Wg2Cfg* c, bool grouped = false) 
     const int BCO = 16 * c->MI * c->WCO, BCI = 16 * c->NJ * c->WCI;
     const long outt = (long)(d->CoutPad / BCO) * (d->CinPad / BCI);
     if (tiles * outt < 4 * 256 && !grouped) c->TP = 64;  // (a grouped launch is filled by the other layers)
+  }
+  {  // A/B overrides of the pixel-tile size per tap class (MI_WG_TP9 / MI_WG_TP1 = 64 | 128)
+    static const int tp9 = wg_env("MI_WG_TP9", 64), tp1 = wg_env("MI_WG_TP1", 64);
+    const int tpe = d->ntaps == 9 ? tp9 : tp1;
+    if (tpe == 64 || tpe == 128) c->TP = tpe;
   }
   if (d->cfg_tp == 64 || d->cfg_tp == 128) c->TP = d->cfg_tp;
   return MI_OK;
@@ -482,7 +675,17 @@ static int wg_fill(const mi_wgrad_desc* d, Wg2K* k, Wg2Cfg* c, size_t* lds, size
   k->mTW = ((1u << 20) + TW - 1) / TW;
   k->mHW = ((1u << 20) + k->haloW - 1) / k->haloW;
   k->stage = c->TP * BCO * 2 + k->nqx * 1024;
+  if (wg_use_v3(c->NT)) {
+    k->nrx = k->npixh < 32 ? 32 : k->npixh;
+    k->stage = c->TP * BCO * 2 + k->nrx * BCI * 2;   // [group][row][32 B]
+    k->stage = (k->stage + 15) / 16 * 16;
+  }
   int ns = d->cfg_ns;
+  {  // A/B override of the LDS ring depth per tap class (MI_WG_NS9 / MI_WG_NS1 = 2..4)
+    static const int ns9 = wg_env("MI_WG_NS9", 2), ns1 = wg_env("MI_WG_NS1", 2);
+    const int nse = d->ntaps == 9 ? ns9 : ns1;
+    if ((ns < 2 || ns > 4) && nse >= 2 && nse <= 4) ns = nse;
+  }
   if (ns < 2 || ns > 4) {
     // 3x3: MFMA-heavy, two co-resident blocks overlap each other's barriers -> 2 stages when two blocks fit;
     // 1x1 and oversized stages: pure streams, one block per CU with as many tiles in flight as LDS allows
@@ -497,6 +700,7 @@ static int wg_fill(const mi_wgrad_desc* d, Wg2K* k, Wg2Cfg* c, size_t* lds, size
   k->ntiles = d->N * k->tilesY * k->tilesX;
   k->nco = d->CoutPad / BCO; k->nci = d->CinPad / BCI;
   k->xmap = wg_xmap();
+  if (!wg_use_v3(c->NT)) k->nrx = 0;
   int split = d->splitk;
   if (split <= 0) {
     // one resident block per CU, but never fewer than ~4 pixel tiles per block: each block pays a fixed
@@ -528,10 +732,11 @@ extern "C" int64_t mi_conv2d_wgrad_plan(const mi_wgrad_desc* d) {
 
 template <int NT, int MI, int NJ, int WCO, int WCI, int TP>
 static int wg_launch(const Wg2K& k, size_t lds, hipStream_t s) {
-  auto fn = wgrad2_kernel<NT, MI, NJ, WCO, WCI, TP>;
+  auto fn = wg_use_v3(NT) ? wgrad3_kernel<NT, MI, NJ, WCO, WCI, TP> : wgrad2_kernel<NT, MI, NJ, WCO, WCI, TP>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)wgrad2_kernel<NT, MI, NJ, WCO, WCI, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)wgrad3_kernel<NT, MI, NJ, WCO, WCI, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   hipLaunchKernelGGL(fn, dim3((unsigned)(k.nsplit * k.nco * k.nci)), dim3(WCO * WCI * 64), lds, s, k);
@@ -590,15 +795,53 @@ extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, voi
     int rc = wg_fill(&t, &ks[i], &cs[i], &ldss[i], &wss[i], true);
     if (rc) return rc;
   }
-  // pass 2: split-K per GROUP: every grid gets ~3 blocks per CU in total, i.e. each block a K range of
-  // T = (group's tile x output-tile units) / 768 pixel tiles (>= 4): ~3x less partial-slab traffic than per-layer splits
+  // pass 2: split-K per GROUP (= one grid per tile configuration).  Every block of a grid runs the same number T of
+  // pixel tiles, so the grid's duration is (rounds of resident blocks) x (block time): the measured round-2 failure
+  // mode was a grid of 576-788 blocks on 512 resident slots - a second round at 13-54 % occupancy.  MI_WG_UNITS=0
+  // (default): T = the smallest K range for which the whole grid is resident at once (slots = CUs x blocks per CU of
+  // this configuration's LDS / register footprint): one full round, no tail.  MI_WG_UNITS=U > 0: T = units / U (A/B).
+  std::vector<long> Tsel(n, 0);
   for (int i = 0; i < n; ++i) {
+    if (Tsel[i]) continue;
     long units = 0;
+    size_t lds = 0;
     for (int j = 0; j < n; ++j)
-      if (wg_cfg_id(cs[j]) == wg_cfg_id(cs[i])) units += (long)ks[j].ntiles * ks[j].nco * ks[j].nci;
+      if (wg_cfg_id(cs[j]) == wg_cfg_id(cs[i])) {
+        units += (long)ks[j].ntiles * ks[j].nco * ks[j].nci;
+        if (ldss[j] > lds) lds = ldss[j];
+      }
+    auto blocks_for = [&](long T) {
+      long b = 0;
+      for (int j = 0; j < n; ++j)
+        if (wg_cfg_id(cs[j]) == wg_cfg_id(cs[i])) {
+          long split = (ks[j].ntiles + T - 1) / T;
+          if (split < 1) split = 1;
+          const long tps = (ks[j].ntiles + split - 1) / split;
+          b += ((ks[j].ntiles + tps - 1) / tps) * ks[j].nco * ks[j].nci;
+        }
+      return b;
+    };
+    long T;
     const long U = wg_units();
-    long T = (units + U - 1) / U;
-    if (T < 4) T = 4;
+    if (U > 0) {
+      T = (units + U - 1) / U;
+      if (T < 4) T = 4;
+    } else {
+      const int NW = cs[i].WCO * cs[i].WCI;
+      long per_cu = (long)(160 * 1024 / (lds ? lds : 1));
+      const long by_waves = 8 / NW;      // __launch_bounds__(NW * 64, 2): two waves per SIMD
+      if (per_cu > by_waves) per_cu = by_waves;
+      if (per_cu < 1) per_cu = 1;
+      const long slots = 256 * per_cu;
+      T = (units + slots - 1) / slots;
+      if (T < 4) T = 4;
+      while (blocks_for(T) > slots && T < (1 << 20)) ++T;   // per-layer rounding: first T whose grid fits
+    }
+    for (int j = 0; j < n; ++j)
+      if (wg_cfg_id(cs[j]) == wg_cfg_id(cs[i])) Tsel[j] = T;
+  }
+  for (int i = 0; i < n; ++i) {
+    const long T = Tsel[i];
     mi_wgrad_desc t = descs[i];
     if (!t.x) t.x = (const void*)256;
     if (!t.dy) t.dy = (const void*)256;
@@ -682,12 +925,14 @@ extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, voi
 
 template <int NT, int MI, int NJ, int WCO, int WCI, int TP>
 static int wg_group_launch(const Wg2K* jobs, const int* starts, int njobs, int nblocks, size_t lds, hipStream_t s) {
-  auto fn = wgrad2_group_kernel<NT, MI, NJ, WCO, WCI, TP>;
+  auto fn = wg_use_v3(NT) ? wgrad3_group_kernel<NT, MI, NJ, WCO, WCI, TP> : wgrad2_group_kernel<NT, MI, NJ, WCO, WCI, TP>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)wgrad2_group_kernel<NT, MI, NJ, WCO, WCI, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)wgrad3_group_kernel<NT, MI, NJ, WCO, WCI, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
+  if ((size_t)wg_min_lds() > lds && wg_min_lds() <= 160 * 1024) lds = (size_t)wg_min_lds();
   hipLaunchKernelGGL(fn, dim3((unsigned)nblocks), dim3(WCO * WCI * 64), lds, s, jobs, starts, njobs);
   MI_CHECK_LAUNCH("conv_wgrad_group");
   return MI_OK;

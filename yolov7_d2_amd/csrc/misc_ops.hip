@@ -33,6 +33,43 @@ __global__ __launch_bounds__(256) void focus_pack_kernel(const float* __restrict
   }
 }
 
+// the same from the uint8 image a data loader hands over (yolox.py:96-99 converts to float on the device; values
+// 0..255 are exact in bf16): 4x less input traffic than the float image and no conversion pass
+__global__ __launch_bounds__(256) void focus_pack_u8_kernel(const uint8_t* __restrict__ img, int N, int H, int W,
+                                                            __bf16* out, int ldo) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)N * Ho * Wo;
+  for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(idx % Wo);
+    const int64_t r = idx / Wo;
+    const int oy = (int)(r % Ho), n = (int)(r / Ho);
+    float f[16];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+        // the two horizontally adjacent pixels (TL/TR or BL/BR) are one aligned 2-byte load (W is even)
+        const unsigned short v = *(const unsigned short*)(img + (((int64_t)n * 3 + c) * H + (2 * oy + dy)) * W + 2 * ox);
+        f[dy * 3 + c] = (float)(v & 0xff);          // q = dy      (dx = 0)
+        f[(2 + dy) * 3 + c] = (float)(v >> 8);      // q = 2 + dy  (dx = 1)
+      }
+    f[12] = f[13] = f[14] = f[15] = 0.f;
+    __bf16* op = out + idx * ldo;
+    *(bf16x8*)op = pack8(f);
+    *(bf16x8*)(op + 8) = pack8(f + 8);
+  }
+}
+
+extern "C" int mi_focus_pack_u8(const uint8_t* img, int N, int H, int W, void* out, int ldo, mi_stream_t st) {
+  MI_REQUIRE(img && out && H % 2 == 0 && W % 2 == 0 && ldo % 8 == 0 && ldo >= 16 && ((uintptr_t)img & 1) == 0,
+             "focus_pack_u8: args");
+  const int64_t total = (int64_t)N * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(focus_pack_u8_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)st, img, N, H, W,
+                     (__bf16*)out, ldo);
+  MI_CHECK_LAUNCH("focus_pack_u8");
+  return MI_OK;
+}
+
 extern "C" int mi_focus_pack(const float* img, int N, int H, int W, void* out, int ldo, mi_stream_t st) {
   MI_REQUIRE(img && out && H % 2 == 0 && W % 2 == 0 && ldo % 8 == 0 && ldo >= 16, "focus_pack: args");
   const int64_t total = (int64_t)N * (H / 2) * (W / 2);

@@ -38,7 +38,9 @@ static int run_one(const mi_cmd& c, hipStream_t s) {
       return mi_bn_act_bwd_apply(p[0], i[0], p[1], i[1], (const float*)p[2], (const float*)p[3], (const float*)p[4],
                                  (const float*)p[5], (const float*)p[6], (const double*)p[7], i[7], c.l[1], (float*)p[8],
                                  (float*)p[9], p[10], i[2], p[11], i[3], i[4], c.l[0], i[5], i[6], st);
-    case MI_OP_FOCUS: return mi_focus_pack((const float*)p[0], i[0], i[1], i[2], p[1], i[3], st);
+    case MI_OP_FOCUS:
+      return i[4] ? mi_focus_pack_u8((const uint8_t*)p[0], i[0], i[1], i[2], p[1], i[3], st)
+                  : mi_focus_pack((const float*)p[0], i[0], i[1], i[2], p[1], i[3], st);
     case MI_OP_UPSAMPLE_FWD: return mi_upsample2x_fwd(p[0], i[0], p[1], i[1], i[2], i[3], i[4], i[5], st);
     case MI_OP_UPSAMPLE_BWD: return mi_upsample2x_bwd(p[0], i[0], p[1], i[1], i[2], i[3], i[4], i[5], i[6], st);
     case MI_OP_SPP_FWD: return mi_spp_pool_fwd(p[0], i[0], p[1], p[2], p[3], i[1], (uint8_t*)p[4], i[2], i[3], i[4], i[5], st);
@@ -76,8 +78,15 @@ static hipEvent_t g_ev_fork[MI_MAX_AUX], g_ev_join[MI_MAX_AUX];
 static bool g_aux_ready = false;
 static int ensure_aux() {
   if (g_aux_ready) return MI_OK;
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   for (int k = 0; k < MI_MAX_AUX; ++k) {
-    if (hipStreamCreateWithFlags(&g_aux[k], hipStreamNonBlocking) != hipSuccess) MI_FAIL(MI_ELAUNCH, "aux stream");
+    // the LAST auxiliary stream carries background work (weight gradients beside the backward chain): lowest priority,
+    // so that the chain's workgroups are dispatched first whenever both have blocks pending
+    const hipError_t e = (k == MI_MAX_AUX - 1)
+                             ? hipStreamCreateWithPriority(&g_aux[k], hipStreamNonBlocking, prio_least)
+                             : hipStreamCreateWithFlags(&g_aux[k], hipStreamNonBlocking);
+    if (e != hipSuccess) MI_FAIL(MI_ELAUNCH, "aux stream");
     if (hipEventCreateWithFlags(&g_ev_fork[k], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&g_ev_join[k], hipEventDisableTiming) != hipSuccess)
       MI_FAIL(MI_ELAUNCH, "aux event");

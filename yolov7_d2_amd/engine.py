@@ -19,8 +19,12 @@ from .parallel import GradReducer, broadcast_params, grad_write_ranges, parallel
 
 class NativeTrainer:
     def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=1e-4, weight_decay_norm=0.0, n_buckets=3,
-                 use_graph=True, loss_weights=(1.0, 1.0, 1.0, 1.0), tune=None):
+                 use_graph=True, loss_weights=(1.0, 1.0, 1.0, 1.0), tune=None, input_u8=False):
         self.model = model
+        # input_u8: batches arrive as uint8 [B,3,H,W] (what a data loader produces); the plan's Focus packer converts
+        self.input_u8 = bool(input_u8)
+        self.copy_stream = None
+        self._feed = None
         model.train()
         self.params = model.ensure_params()
         self.world = dist.get_world_size() if dist.is_initialized() else 1
@@ -40,14 +44,17 @@ class NativeTrainer:
         self.tune_report = None
 
     def set_lr(self, lr):
-        self.params.set_lr(lr)
+        # the lr table is read by the SGD graph on self.stream: update it on that stream (stream order = no race with
+        # an in-flight step)
+        with torch.cuda.stream(self.stream):
+            self.params.set_lr(lr)
 
     def _state(self, B, H, W):
         key = (B, H, W)
         st = self._states.get(key)
         if st is not None:
             return st
-        ps = self.model.plan_for(B, H, W, True)
+        ps = self.model.plan_for(B, H, W, True, input_u8=self.input_u8)
         ps.gw().copy_(torch.tensor(self.loss_weights, dtype=torch.float32))
         plan = ps.plan
         # SGD command
@@ -98,18 +105,48 @@ class NativeTrainer:
         """images float [B,3,H,W] (0..255, already padded to /32), labels [B,max_boxes,5] — device tensors"""
         B, _, H, W = images.shape
         st = self._state(B, H, W)
-        torch.cuda.synchronize()
+        # order the copies after whatever produced the inputs on the caller's stream (no device-wide synchronise)
+        self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             st["ps"].image.copy_(images, non_blocking=True)
             st["ps"].labels.copy_(labels, non_blocking=True)
         return st
 
+    def feed(self, st, images_host, labels_host):
+        """asynchronous host -> device copy of the NEXT batch (pinned host tensors: images in the plan's input dtype,
+        labels [B,max_boxes,5] float) on a dedicated copy stream into one of two staging buffers; the following step()
+        waits for it on the compute stream and moves it into the plan's input buffers (device copy), so the PCIe
+        transfer of batch i+1 runs under the compute of batch i.  Replaces the synchronous .to(device) of
+        yolox.py:96,183."""
+        if self.copy_stream is None:
+            self.copy_stream = torch.cuda.Stream()
+            self._stage = [dict(img=torch.empty_like(st["ps"].image), lab=torch.empty_like(st["ps"].labels),
+                                ready=torch.cuda.Event(), free=torch.cuda.Event()) for _ in range(2)]
+            self._stage_k = 0
+            for b in self._stage:
+                b["free"].record(self.stream)
+        b = self._stage[self._stage_k]
+        self._stage_k ^= 1
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(b["free"])          # the step that consumed this buffer has copied it out
+            b["img"].copy_(images_host, non_blocking=True)
+            b["lab"].copy_(labels_host, non_blocking=True)
+            b["ready"].record(self.copy_stream)
+        self._feed = b
+
     def step(self, st):
-        """one optimisation step on the batch resident in the plan's input buffers; returns nothing (no host sync)."""
+        """one optimisation step on the batch resident in the plan's input buffers (or on the batch handed to feed()
+        since the last step); returns nothing (no host sync)."""
         lib = L.lib()
         plan, red = st["plan"], st["red"]
         with torch.cuda.stream(self.stream):
             sp = L.stream_ptr(self.stream)
+            if self._feed is not None:
+                b, self._feed = self._feed, None
+                self.stream.wait_event(b["ready"])
+                st["ps"].image.copy_(b["img"], non_blocking=True)
+                st["ps"].labels.copy_(b["lab"], non_blocking=True)
+                b["free"].record(self.stream)
             if self.use_graph and st["graphs"] is None:
                 # first call runs eagerly (sets kernel attributes, warms allocators), second call captures
                 if st.get("warm"):

@@ -29,10 +29,12 @@ def xyxy_to_cxcywh(b):
 class _PlanState:
     """one compiled step for a fixed (B, H, W): plan + persistent I/O tensors"""
 
-    def __init__(self, model, B, H, W, training, materialize=True):
+    def __init__(self, model, B, H, W, training, materialize=True, input_u8=False):
         dev = model.device
         self.B, self.H, self.W, self.training = B, H, W, training
-        self.image = torch.zeros(B, 3, H, W, dtype=torch.float32, device=dev)
+        # input_u8: the plan reads the uint8 image of the data loader directly (the .type(torch.float) of
+        # yolox.py:96-99 is fused into the Focus packer); float32 is the reference-shaped default
+        self.image = torch.zeros(B, 3, H, W, dtype=torch.uint8 if input_u8 else torch.float32, device=dev)
         self.labels = torch.zeros(B, model.max_boxes_num, 5, dtype=torch.float32, device=dev)
         hw = [(H // s, W // s) for s in model.head.strides]
         self.A = sum(h * w for h, w in hw)
@@ -83,7 +85,22 @@ class _YoloxTrainFn(torch.autograd.Function):
         ps, model = ctx.ps, ctx.model
         ps.gw().copy_(g[:4].to(torch.float32))
         ps.plan.run("bwd")
-        grads = [model.params.grad_of(p).clone() for _, p in model.named_parameters()]
+        # The kernels have written every parameter gradient into the flat arena.  Zero-copy hand-over: a parameter
+        # whose .grad is None (optimizer.zero_grad(set_to_none=True), what detectron2's trainer does each iteration) or
+        # already the arena view gets the view bound as its .grad and autograd receives None for it - no 240-tensor
+        # clone (36 MB per step).  A parameter with some other .grad tensor receives the view and autograd adds it.
+        # model.grad_accumulate = True restores plain autograd semantics (clone; needed only to accumulate several
+        # backward passes into one .grad, because the next step's kernels overwrite the arena).
+        if getattr(model, "grad_accumulate", False):
+            return (None, None, None, None, *[model.params.grad_of(p).clone() for _, p in model.named_parameters()])
+        grads = []
+        for _, p in model.named_parameters():
+            v = model.params.grad_of(p)
+            if p.grad is None or p.grad.data_ptr() == v.data_ptr():
+                p.grad = v
+                grads.append(None)
+            else:
+                grads.append(v)
         return (None, None, None, None, *grads)
 
 
@@ -143,13 +160,13 @@ class YOLOX(nn.Module):
             self.params = ParamArena(self, self.device)
         return self.params
 
-    def plan_for(self, B, H, W, training):
+    def plan_for(self, B, H, W, training, input_u8=False):
         self.ensure_params()
-        key = (B, H, W, bool(training))
+        key = (B, H, W, bool(training)) + (("u8",) if input_u8 else ())
         ps = self._plans.get(key)
         if ps is None:
             assert H % 32 == 0 and W % 32 == 0, (H, W)
-            ps = _PlanState(self, B, H, W, training)
+            ps = _PlanState(self, B, H, W, training, input_u8=input_u8)
             self._plans[key] = ps
         return ps
 

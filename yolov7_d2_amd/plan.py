@@ -181,6 +181,12 @@ class PlanBuilder:
             import torch.distributed as dist
             self.wgrad_split = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.wgrad_early_prefixes = ("head.", "neck.")
+        # MI_WGRAD_ASYNC=G: the weight gradients run as G grouped launches on an auxiliary LOW-PRIORITY stream (a parallel
+        # hipGraph branch), each issued as soon as the last of its layers' out-gradients exists, so that their blocks
+        # fill the CUs the latency-bound backward chain of ~200 small kernels leaves idle.  The branch joins before the
+        # optimizer.  The groups are cut from the backward-ordered layer list at equal shares of the weight-gradient
+        # FLOPs (head first, stem last).
+        self.wgrad_async = int(os.environ.get("MI_WGRAD_ASYNC", "0") or 0)
         self.csp_lanes = os.environ.get("MI_CSP_LANES", "1") != "0"   # CSP conv1 / conv2 as lanes (see blocks.CSPLayer)
         self.training = training            # build the backward command list
         self.bn_train = training if bn_train is None else bn_train  # batch statistics vs running statistics
@@ -539,7 +545,8 @@ class PlanBuilder:
 
     def focus(self, image_ptr_holder, N, H, W):
         out = self.new_act(N, H // 2, W // 2, 16, "focus", requires_grad=False)
-        self.emit("FOCUS", i=[N, H, W, out.ld], p=[image_ptr_holder, out], tag="focus")
+        u8 = int(torch.is_tensor(image_ptr_holder) and image_ptr_holder.dtype == torch.uint8)
+        self.emit("FOCUS", i=[N, H, W, out.ld, u8], p=[image_ptr_holder, out], tag="focus")
         return out
 
     def upsample_into(self, tag, x, out):
@@ -654,6 +661,8 @@ class Plan:
         self.wgrad_descs = []
         if not (b.group_wgrad and len(wg) >= 2):
             return bwd
+        if getattr(b, "wgrad_async", 0) > 0 and not b.wgrad_split:
+            return self._async_wgrads(bwd, wg, b.wgrad_async)
         early = [c for c in wg if b.wgrad_split and c.tag.startswith(b.wgrad_early_prefixes)]
         late = [c for c in wg if c not in early]
         if len(early) < 2 or len(late) < 2:
@@ -666,6 +675,41 @@ class Plan:
             if i == last_early:
                 out.append(self._wgrad_group_cmd(early, "wgrad_group.early"))
         out.append(self._wgrad_group_cmd(late, "wgrad_group"))
+        return out
+
+    def _async_wgrads(self, bwd, wg, G):
+        """G weight-gradient groups on auxiliary stream MI_WGRAD_STREAM (see PlanBuilder.wgrad_async).  Group g is
+        issued right after the backward command that produces the last out-gradient of its layers: FORK (the aux stream
+        waits for everything issued so far), the grouped launch on the aux stream, back to the caller's stream.  The
+        groups serialise on the aux stream (they share the split-K workspace); one JOIN at the end of the list."""
+        sid = L.MI_WGRAD_STREAM
+        def flops(c):
+            d = c.desc
+            return 2.0 * d.N * d.outH * d.outW * d.CoutPad * d.CinPad * len(d.taps)
+        tot = sum(flops(c) for c in wg)
+        groups, cur, acc = [], [], 0.0
+        for c in wg:                       # backward order: head ... stem
+            cur.append(c)
+            acc += flops(c)
+            if acc >= tot * (len(groups) + 1) / G and len(groups) < G - 1:
+                groups.append(cur)
+                cur = []
+        if cur:
+            groups.append(cur)
+        groups = [g for g in groups if g]
+        last = {}
+        for gi, g in enumerate(groups):
+            last[max(i for i, c in enumerate(bwd) if any(c is w for w in g))] = gi
+        out = []
+        for i, c in enumerate(bwd):
+            if c.op != L.OP["WGRAD"]:
+                out.append(c)
+            if i in last:
+                gi = last[i]
+                grp = self._wgrad_group_cmd(groups[gi], f"wgrad_group.async{gi}") if len(groups[gi]) >= 2 else groups[gi][0]
+                out += [_Cmd(L.OP["FORK"], i=[sid], tag=f"wgrad.fork{gi}"), _Cmd(L.OP["STREAM"], i=[sid], tag="wgrad.stream"),
+                        grp, _Cmd(L.OP["STREAM"], i=[0], tag="wgrad.stream0")]
+        out.append(_Cmd(L.OP["JOIN"], i=[sid], tag="wgrad.join"))
         return out
 
     def _wgrad_group_cmd(self, wg, tag):
