@@ -176,7 +176,8 @@ class Interp:
         if c.p[1].obj is not None:   # train mode: finalize the statistics first
             count = c.l[0]
             nsl = c.i[5]
-            part = self.f64(c.p[1], nsl * C * 2).view(nsl, C, 2).sum(0)
+            CA = (C + 31) // 32 * 32   # accumulator layout [slot][C rounded up to 32][2] (bn_act.hip BN_ACC_C)
+            part = self.f64(c.p[1], nsl * CA * 2).view(nsl, CA, 2).sum(0)[:C]
             mean = part[:, 0] / count
             var = (part[:, 1] / count - mean * mean).clamp(min=0)
             invstd = 1.0 / torch.sqrt(var + c.f[0])
@@ -209,7 +210,7 @@ class Interp:
     def op_BN_BWD_REDUCE(self, c):
         C, act = c.i[3], c.i[4]
         dz, xh = self._dz(c, c.p[0].obj, c.p[1].obj, C, act)
-        part = self.f64(c.p[6], C * 2).view(C, 2)   # slot 0
+        part = self.f64(c.p[6], ((C + 31) // 32 * 32) * 2).view(-1, 2)[:C]   # slot 0, [C rounded up to 32][2]
         part[:, 0] += dz.double().sum((0, 1, 2))
         part[:, 1] += (dz * xh).double().sum((0, 1, 2))
 
@@ -219,7 +220,8 @@ class Interp:
         da = c.p[0].obj
         dz, xh = self._dz(c, da, c.p[1].obj, C, act)
         nsl = c.i[7]
-        part = self.f64(c.p[7], nsl * C * 2).view(nsl, C, 2).sum(0)
+        CA = (C + 31) // 32 * 32
+        part = self.f64(c.p[7], nsl * CA * 2).view(nsl, CA, 2).sum(0)[:C]
         if c.p[8].obj is not None:
             c.p[8].obj.copy_(part[:, 1].float())
         if c.p[9].obj is not None:
@@ -227,7 +229,7 @@ class Interp:
         c1, c2 = (part[:, 0] / count).float(), (part[:, 1] / count).float()
         gamma = c.p[6].obj.detach().float()
         dy = gamma * self.f32(c.p[5], C) * (dz - c1 - xh * c2)
-        self.tv(c.p[10].obj)[:] = dy.to(self.dt)
+        self.tv(c.p[10].obj)[..., :C] = dy.to(self.dt)   # the out-gradient view carries zero pad channels up to 32
         dres = c.p[11].obj
         if dres is not None:
             v = self.tv(da).float()

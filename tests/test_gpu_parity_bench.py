@@ -44,66 +44,16 @@ RAW_REL_MAX = 1e-5      # fp32 prediction convs on forced features (measured 4.5
 RAW_FREE_REL_MAX = 3e-2  # un-forced end-to-end raw output (bf16 storage noise through ~40 layers)
 
 
-class _Q(torch.autograd.Function):
-    """the product's storage rounding: bf16 activations forward, bf16 gradients backward"""
-
-    @staticmethod
-    def forward(ctx, t):
-        return t.to(torch.bfloat16).float()
-
-    @staticmethod
-    def backward(ctx, g):
-        return g.to(torch.bfloat16).float()
+from parity_util import grad_table as _grad_table, hip_step, oracle_backward
 
 
 def _hip_step(seed_model, imgs, labels, want_y=False):
-    cfg = M.yolox_s_cfg(device=DEV)
-    model = M.build_model(cfg)
     sd = O.init_state_dict(0.33, 0.5, 80, seed=seed_model)
-    model.load_state_dict(sd)
-    model.train()
-    ps = model.plan_for(B, H, W, True)
-    ps.image.copy_(imgs.to(DEV)); ps.labels.copy_(labels.to(DEV))
-    ps.gw().fill_(1.0)
-    ps.plan.run("fwd"); ps.plan.run("bwd")
-    torch.cuda.synchronize()
-    nch = ps.nch
-    out = dict(
-        raw=ps.preds().float().cpu().clone(), anchors=ps.anchors.float().cpu().clone(),
-        losses=ps.loss_out()[:8].cpu().clone(),
-        dpreds=ps.plan.buf_view(ps.loss["dpreds"], torch.float32, B * ps.A * nch).view(B, ps.A, nch).cpu().clone(),
-        fg=ps.plan.buf_view(ps.loss["fg"], torch.uint8, B * ps.A).view(B, ps.A).cpu().clone(),
-        mgt=ps.plan.buf_view(ps.loss["matched_gt"], torch.int32, B * ps.A).view(B, ps.A).cpu().clone(),
-        grads={n: model.params.grad_of(p).detach().float().cpu().clone() for n, p in model.named_parameters()},
-        rm={k: v.detach().float().cpu().clone() for k, v in model.state_dict().items() if "running_mean" in k})
-    if want_y:   # every BaseConv's stored conv output (bf16 NHWC, buffer "<layer>.y"), flat
-        out["y"] = {b.name: ps.plan.buf_view(b, torch.bfloat16).cpu().clone() for b in ps.builder.bufs
-                    if b.name.endswith(".y")}
-    del model
-    return sd, out
-
-
-def _grad_table(hip_grads, ref_grads):
-    rows = []
-    for n, g in hip_grads.items():
-        r = ref_grads[n]
-        gn, rn = float(g.norm()), float(r.norm())
-        cos = float((g * r).sum() / (gn * rn + 1e-30))
-        rel = float((g - r).norm() / (rn + 1e-30))
-        rows.append((n, cos, rel, gn, rn))
-    return rows
+    return sd, hip_step(sd, imgs, labels, want_y=want_y)
 
 
 def _oracle_backward(sd, imgs, dpreds, force):
-    osd = {k: v.clone() for k, v in sd.items()}
-    for k, v in osd.items():
-        if v.is_floating_point() and "running" not in k:
-            v.requires_grad_(True)
-    net = O.Net(osd, 0.33, 0.5, 80, training=True, quant=_Q.apply, force=force)
-    raw_ref, hw = net.forward_raw(imgs)
-    raw_ref.backward(dpreds)
-    return dict(raw=raw_ref.detach(), grads={k: v.grad.detach().clone() for k, v in osd.items() if v.requires_grad},
-                osd=osd, force_err=dict(net.force_err))
+    return oracle_backward(sd, imgs, dpreds, force)
 
 
 @pytest.fixture(scope="module")

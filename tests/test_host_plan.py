@@ -282,3 +282,43 @@ def test_grouped_launches_of_the_640_plan():
         metas = [C.cast(arr[k].p[0], C.POINTER(L.mi_conv_group)).contents for k in range(n) if L.OPS[arr[k].op] == "CONV_GROUP"]
         assert [m.njobs for m in metas] == jobs[which]
         assert all(m.lds_bytes <= 80 * 1024 for m in metas)
+
+
+@pytest.mark.parametrize("depth,width", [(0.33, 0.375), (0.67, 0.75), (1.33, 1.25)], ids=["tiny", "m", "x"])
+def test_plan_step_other_widths(depth, width):
+    """YOLOX-tiny / -m / -x: channel counts that are not multiples of 32 (24, 48, 80 ...; C/8 not a power of two) - padded
+    pixel strides, zero-padded weight images, real-channel BatchNorm - through the same plan builder, interpreted on
+    the CPU in fp32 against the oracle: the four losses and every parameter gradient"""
+    cfg = M.yolox_s_cfg(device="cpu")
+    cfg.MODEL.YOLO.DEPTH_MUL, cfg.MODEL.YOLO.WIDTH_MUL = depth, width
+    model = M.build_model(cfg)
+    sd = O.init_state_dict(depth, width, 80, seed=1)
+    model.load_state_dict(sd)
+    model.params = ParamArena(model, "cpu")
+    B, H, W = 2, 64, 96
+    imgs, labels = O.synth_batch(B, H, W, seed=11, max_gt=4)
+    ps = _PlanState(model, B, H, W, True, materialize=False)
+    b = ps.builder
+    ps.image.copy_(imgs)
+    ps.labels.copy_(labels)
+    it = Interp(b, torch.float32)
+    it.run(b.prologue + b.fwd)
+    out = it.raw(ps.loss["out"]).view(torch.float32)[:8].clone()
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    res = O.train_step_losses(sd, imgs, labels, depth=depth, width=width)
+    ref = torch.tensor([float(x) for x in res[:4]])
+    np.testing.assert_allclose(out[:4].numpy(), ref.numpy(), rtol=1e-3, atol=1e-4)   # few anchors: bf16 weight images move a loss by ~3e-4
+    it.raw(ps.loss["gw"]).view(torch.float32)[:4] = 1.0
+    it.run(b.bwd)
+    (res[0] + res[1] + res[2] + res[3]).backward()
+    bad = []
+    for name, p in model.named_parameters():
+        g = model.params.grad_of(p).detach().float()
+        r = sd[name].grad
+        rel = float((g - r).norm()) / (float(r.norm()) + 1e-6)
+        if rel > 5e-3:   # (a mis-wired slice / pad channel is an O(1) error; fp32 summation order with 12 samples per
+            #  channel in the deepest BatchNorm layers is ~1e-3)
+            bad.append((name, rel, float(r.norm())))
+    assert not bad, bad[:10]

@@ -39,8 +39,7 @@ def test_step_losses_grads_and_eval(golden_dir):
 def test_config0_yolox_tiny_416_cpu_step(golden_dir):
     """BASELINE.json configs[0] (YOLOX-tiny, width .375, 416x416, bs=2, CPU): the oracle against the reference's own
     modules run by path - the 4 losses, the gradient norm of every parameter, one full gradient and the eval output.
-    (The HIP path serves widths whose channel counts are multiples of 32; tiny's 24/48/96/192/384 channels are a
-    next-round item)"""
+    (The same configuration on the HIP device: tests/test_gpu_widths.py::test_yolox_tiny_config0_against_reference_golden.)"""
     g = np.load(os.path.join(golden_dir, "yolox_tiny_step_416.npz"))
     sd = O.init_state_dict(0.33, 0.375, 80, seed=0)
     for k, v in sd.items():

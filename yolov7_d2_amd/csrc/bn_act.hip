@@ -3,6 +3,11 @@
 // eps/momentum patched at yolov7/modeling/meta_arch/yolox.py:85-90) and the Bottleneck
 // shortcut add (wrappers.py:119-123).
 //
+// Channel counts: any multiple of 8 up to BN_MAXC.  A block uses TPB = (256 / C8) * C8 of its 256 threads for the
+// streaming loops (C8 = C / 8 channel groups), so that a thread keeps ONE channel group across the grid stride and
+// its scale / shift live in registers: all 256 threads when C8 is a power of two (YOLOX-s / -l), 240-252 of them for the
+// 0.375 / 0.75 / 1.25 width multipliers (C8 = 3, 6, 12, 24, 48, 10, 20, 40, 80, 160).
+//
 // Three streaming kernels per layer and NO separate "finalize" launches:
 //   * the conv epilogue adds its per-tile (sum, sumsq) into fp64 accumulators acc[MI_BN_SLOTS][C][2]
 //     (hardware global_atomic_add_f64, slot = tile % MI_BN_SLOTS to spread same-address traffic);
@@ -15,7 +20,9 @@
 #include <string.h>
 #include "common.h"
 
-#define BN_MAXC 1024
+#define BN_MAXC 2048
+// accumulator layout: [slot][CA][2] with CA = C rounded up to 32 - the CoutPad the conv epilogue adds its tile sums with
+#define BN_ACC_C(C) (((C) + 31) / 32 * 32)
 
 // ------------------------------------------------------------------ eval-mode affine
 __global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
@@ -61,14 +68,14 @@ struct BnFwdK {
 template <int ACT, class PK>
 __device__ __forceinline__ void bn_act_fwd_body(PK& p, const int bid, const int nb) {
   __shared__ float s_sc[BN_MAXC], s_sh[BN_MAXC];
-  const int C = p.C8 * 8;
+  const int C = p.C8 * 8, CA = BN_ACC_C(C);
   if (p.acc) {
     for (int c = threadIdx.x; c < C; c += 256) {
       // all slot loads are issued before the first add (a rolled loop serialises 16 L2 round trips: ~4.5 us)
       f64x2 v[MI_BN_SLOTS];
 #pragma unroll
       for (int k = 0; k < MI_BN_SLOTS; ++k)
-        v[k] = k < p.nslots ? *(const f64x2*)(p.acc + ((size_t)k * C + c) * 2) : f64x2{0.0, 0.0};
+        v[k] = k < p.nslots ? *(const f64x2*)(p.acc + ((size_t)k * CA + c) * 2) : f64x2{0.0, 0.0};
       double s1 = 0.0, s2 = 0.0;
 #pragma unroll
       for (int k = 0; k < MI_BN_SLOTS; ++k) {
@@ -105,8 +112,10 @@ __device__ __forceinline__ void bn_act_fwd_body(PK& p, const int bid, const int 
   __syncthreads();
   const int C8 = p.C8;
   const int64_t total = p.npix * C8;
-  // (nb * 256) % C8 == 0, so a thread keeps its channel group: hoist its 8 scale/shift pairs
-  const int c8 = (int)((bid * 256LL + threadIdx.x) % C8);
+  // TPB % C8 == 0, so a thread keeps its channel group: hoist its 8 scale/shift pairs
+  const int TPB = (256 / C8) * C8;
+  if ((int)threadIdx.x >= TPB) return;
+  const int c8 = (int)threadIdx.x % C8;
   float sc[8], sh[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -115,8 +124,8 @@ __device__ __forceinline__ void bn_act_fwd_body(PK& p, const int bid, const int 
   }
   // 4 grid-stride elements per trip, all loads issued before the first use (one load in flight per wave is
   // latency-bound: ~1 us per trip)
-  const int64_t stride = (int64_t)nb * 256;
-  for (int64_t idx = bid * 256LL + threadIdx.x; idx < total; idx += 4 * stride) {
+  const int64_t stride = (int64_t)nb * TPB;
+  for (int64_t idx = (int64_t)bid * TPB + threadIdx.x; idx < total; idx += 4 * stride) {
     bf16x8 v[4], r[4];
     int64_t pix[4];
 #pragma unroll
@@ -182,8 +191,7 @@ extern "C" int mi_bn_act_fwd(const void* y, int ldy, const double* stats_acc, in
                              mi_stream_t st) {
   MI_REQUIRE(y && scale && shift && a, "bn_act_fwd: null");
   MI_REQUIRE(!stats_acc || (gamma && beta && mean && invstd && count > 0), "bn_act_fwd: train mode needs gamma/beta/mean/invstd");
-  MI_REQUIRE(C % 8 == 0 && C <= BN_MAXC && (256 % (C / 8)) == 0, "bn_act_fwd: C %d (need C<=%d, 256 %% (C/8) == 0)", C,
-             BN_MAXC);
+  MI_REQUIRE(C % 8 == 0 && C > 0 && C <= BN_MAXC, "bn_act_fwd: C %d (need C %% 8 == 0, C <= %d)", C, BN_MAXC);
   MI_REQUIRE(ldy % 8 == 0 && lda % 8 == 0 && (!res || ldres % 8 == 0), "bn_act_fwd: ld %% 8");
   MI_REQUIRE(((uintptr_t)y % 16) == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)res % 16) == 0, "bn_act_fwd: align");
   BnFwdK k;
@@ -211,7 +219,7 @@ __device__ __forceinline__ float act_grad(float z, int act) {
   return s * (1.f + z * (1.f - s));
 }
 
-// pass 1: per-channel sums of (dz, dz*xhat) -> fp64 accumulators dacc[MI_BN_SLOTS][C][2].  256 % C8 == 0 so a
+// pass 1: per-channel sums of (dz, dz*xhat) -> fp64 accumulators dacc[MI_BN_SLOTS][CA][2].  PL = 256 / C8 pixel lanes: a
 // thread's channel group is fixed (c8 = tid % C8) and its pixel lane is tid / C8.
 struct BnRedK {
   const __bf16* da;
@@ -229,7 +237,9 @@ __device__ __forceinline__ void bn_bwd_reduce_body(PK& p, const int bid, const i
   __shared__ float red[256 * 16];
   const int tid = threadIdx.x;
   const int C8 = p.C8;
-  const int c8 = tid % C8, pl = tid / C8, PL = 256 / C8;
+  const int PL = 256 / C8;                       // pixel lanes; threads beyond PL * C8 only take part in the barriers
+  const bool active = tid < PL * C8;
+  const int c8 = tid % C8, pl = active ? tid / C8 : 0;
   float sc[8], sh[8], mu[8], is[8], s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -240,7 +250,7 @@ __device__ __forceinline__ void bn_bwd_reduce_body(PK& p, const int bid, const i
     s1[e] = s2[e] = 0.f;
   }
   const int64_t pstride = (int64_t)nb * PL;
-  for (int64_t pix0 = (int64_t)bid * PL + pl; pix0 < p.npix; pix0 += 4 * pstride) {
+  for (int64_t pix0 = active ? (int64_t)bid * PL + pl : p.npix; pix0 < p.npix; pix0 += 4 * pstride) {
     bf16x8 dv[4], yv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -264,14 +274,16 @@ __device__ __forceinline__ void bn_bwd_reduce_body(PK& p, const int bid, const i
     }
   }
   // red[pl][c8][16]
+  if (active) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    red[(pl * C8 + c8) * 16 + e] = s1[e];
-    red[(pl * C8 + c8) * 16 + 8 + e] = s2[e];
+    for (int e = 0; e < 8; ++e) {
+      red[(pl * C8 + c8) * 16 + e] = s1[e];
+      red[(pl * C8 + c8) * 16 + 8 + e] = s2[e];
+    }
   }
   __syncthreads();
   const int nout = C8 * 16, C = C8 * 8;
-  double* slot = p.dacc + (size_t)(bid % p.nslots) * C * 2;
+  double* slot = p.dacc + (size_t)(bid % p.nslots) * BN_ACC_C(C) * 2;
   for (int j = tid; j < nout; j += 256) {
     float acc = 0.f;
     for (int q = 0; q < PL; ++q) acc += red[q * nout + j];
@@ -300,7 +312,7 @@ extern "C" int mi_bn_act_bwd_reduce(const void* da, int ldda, const void* y, int
                                     int nslots, int nblk, int64_t npix, int C, int act, mi_stream_t st) {
   if (nslots < 1 || nslots > MI_BN_SLOTS) nslots = MI_BN_SLOTS;
   MI_REQUIRE(da && y && scale && shift && mean && invstd && dacc, "bn_bwd_reduce: null");
-  MI_REQUIRE(C % 8 == 0 && C <= BN_MAXC && (256 % (C / 8)) == 0, "bn_bwd_reduce: C %d (need 256 %% (C/8) == 0)", C);
+  MI_REQUIRE(C % 8 == 0 && C > 0 && C <= BN_MAXC, "bn_bwd_reduce: C %d (need C %% 8 == 0, C <= %d)", C, BN_MAXC);
   MI_REQUIRE(ldda % 8 == 0 && ldy % 8 == 0 && nblk > 0, "bn_bwd_reduce: ld");
   BnRedK k;
   k.da = (const __bf16*)da; k.y = (const __bf16*)y; k.scale = scale; k.shift = shift; k.mean = mean; k.invstd = invstd;
@@ -336,12 +348,12 @@ struct BnBwdK {
 template <int ACT, class PK>
 __device__ __forceinline__ void bn_bwd_apply_body(PK& p, const int bid, const int nb) {
   __shared__ float s_c1[BN_MAXC], s_c2[BN_MAXC];
-  const int C8 = p.C8, C = C8 * 8;
+  const int C8 = p.C8, C = C8 * 8, CA = BN_ACC_C(C);
   for (int c = threadIdx.x; c < C; c += 256) {
     f64x2 v[MI_BN_SLOTS];
 #pragma unroll
     for (int k = 0; k < MI_BN_SLOTS; ++k)
-      v[k] = k < p.nslots ? *(const f64x2*)(p.dacc + ((size_t)k * C + c) * 2) : f64x2{0.0, 0.0};
+      v[k] = k < p.nslots ? *(const f64x2*)(p.dacc + ((size_t)k * CA + c) * 2) : f64x2{0.0, 0.0};
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int k = 0; k < MI_BN_SLOTS; ++k) {
@@ -357,7 +369,9 @@ __device__ __forceinline__ void bn_bwd_apply_body(PK& p, const int bid, const in
   }
   __syncthreads();
   const int64_t total = p.npix * C8;
-  const int c8 = (int)((bid * 256LL + threadIdx.x) % C8);
+  const int TPB = (256 / C8) * C8;
+  if ((int)threadIdx.x >= TPB) return;
+  const int c8 = (int)threadIdx.x % C8;
   float sc[8], sh[8], mu[8], is[8], gi[8], k1[8], k2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -370,8 +384,8 @@ __device__ __forceinline__ void bn_bwd_apply_body(PK& p, const int bid, const in
     k1[e] = s_c1[c];
     k2[e] = s_c2[c];
   }
-  const int64_t stride = (int64_t)nb * 256;
-  for (int64_t idx = bid * 256LL + threadIdx.x; idx < total; idx += 2 * stride) {
+  const int64_t stride = (int64_t)nb * TPB;
+  for (int64_t idx = (int64_t)bid * TPB + threadIdx.x; idx < total; idx += 2 * stride) {
     bf16x8 dv[2], yv[2], rv[2];
     int64_t pix[2];
 #pragma unroll
@@ -433,7 +447,7 @@ extern "C" int mi_bn_act_bwd_apply(const void* da, int ldda, const void* y, int 
                                    void* dres, int lddres, int dres_accum, int64_t npix, int C, int act,
                                    mi_stream_t st) {
   MI_REQUIRE(da && y && scale && shift && mean && invstd && gamma && dacc && dy && count > 0, "bn_bwd_apply: null");
-  MI_REQUIRE(C % 8 == 0 && C <= BN_MAXC && (256 % (C / 8)) == 0, "bn_bwd_apply: C %d", C);
+  MI_REQUIRE(C % 8 == 0 && C > 0 && C <= BN_MAXC, "bn_bwd_apply: C %d", C);
   MI_REQUIRE(ldda % 8 == 0 && ldy % 8 == 0 && lddy % 8 == 0 && (!dres || lddres % 8 == 0), "bn_bwd_apply: ld");
   BnBwdK k;
   k.da = (const __bf16*)da; k.y = (const __bf16*)y; k.dy = (__bf16*)dy; k.dres = (__bf16*)dres; k.dacc = dacc;
@@ -463,7 +477,7 @@ extern "C" int mi_bn_group_plan(int kind, const mi_bn_job* jobs, int n, void* ta
   for (int j = 0; j < n; ++j) {
     const mi_bn_job& b = jobs[j];
     const int C = b.C;
-    MI_REQUIRE(C % 8 == 0 && C <= BN_MAXC && (256 % (C / 8)) == 0 && b.npix > 0, "bn_group_plan: job %d C %d", j, C);
+    MI_REQUIRE(C % 8 == 0 && C > 0 && C <= BN_MAXC && b.npix > 0, "bn_group_plan: job %d C %d", j, C);
     MI_REQUIRE(b.act == jobs[0].act, "bn_group_plan: jobs must agree on the activation");
     const int nslots = (b.nslots >= 1 && b.nslots <= MI_BN_SLOTS) ? b.nslots : MI_BN_SLOTS;
     const int64_t total = b.npix * (C / 8);

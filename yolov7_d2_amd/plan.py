@@ -216,11 +216,16 @@ class PlanBuilder:
         self.bufs.append(b)
         return b
 
-    def new_act(self, N, H, W, C, name, requires_grad=True):
+    def new_act(self, N, H, W, C, name, requires_grad=True, pad=True):
+        """bf16 NHWC activation (+ gradient mirror).  The pixel stride is C rounded up to 32 channels: a consumer conv
+        reads whole 32-channel k-groups, so widths that are not multiples of 32 (24 / 48 / 80 ... of the 0.375 / 0.75 /
+        1.25 width multipliers) carry zero pad channels that nothing ever writes (the arena starts zeroed; producers
+        store real channel groups only) and that meet zero-padded weight rows in the packed weight images."""
         assert C % 8 == 0
-        b = self._new_buf(name, N * H * W * C * 2)
-        g = self._new_buf(name + ".grad", N * H * W * C * 2) if (requires_grad and self.training) else None
-        return TRef(b, N, H, W, C, C, 0, g)
+        ld = _rup(C, 32) if pad else C
+        b = self._new_buf(name, N * H * W * ld * 2)
+        g = self._new_buf(name + ".grad", N * H * W * ld * 2) if (requires_grad and self.training) else None
+        return TRef(b, N, H, W, C, ld, 0, g)
 
     def small(self, name, nbytes, zero=False):
         return self._new_buf(name, nbytes, zero)
@@ -243,7 +248,7 @@ class PlanBuilder:
             self.shared[key] = b
             self.bufs.append(b)
         off = b.nbytes
-        b.nbytes += (L.MI_BN_SLOTS if nslots is None else nslots) * C * 2 * 8
+        b.nbytes += (L.MI_BN_SLOTS if nslots is None else nslots) * _rup(C, 32) * 2 * 8   # [slot][C rounded to 32][2]
         return _Ptr(b, off)
 
     def scratch(self, key, nbytes):
@@ -368,7 +373,7 @@ class PlanBuilder:
         d = L.mi_conv_desc()
         d.N, d.H, d.W, d.outH, d.outW, d.gridH, d.gridW = x.N, x.H, x.W, Ho, Wo, Ho, Wo
         d.in_stride, d.out_stride = stride, 1
-        d.K8, d.Cout, d.CoutPad, d.ntaps = K8, Cout, Cout, len(taps)
+        d.K8, d.Cout, d.CoutPad, d.ntaps = K8, Cout, _rup(Cout, 32), len(taps)
         for t, (dy, dx, w) in enumerate(taps):
             d.tap_dy[t], d.tap_dx[t], d.tap_w[t] = dy, dx, w
         d.ldx, d.ldy = x.ld, Cout
@@ -383,20 +388,23 @@ class PlanBuilder:
         weight: fp32 OIHW tensor; wgrad: fp32 OIHW gradient view (training);
         bn: dict(gamma, beta, rm, rv, nbt, eps, momentum, ggamma, gbeta)."""
         Cout, Cin = weight.shape[0], weight.shape[1]
-        assert weight.shape[2] == k and Cout % 32 == 0
+        assert weight.shape[2] == k and Cout % 8 == 0, (tag, tuple(weight.shape))
+        CoutPad = _rup(Cout, 32)        # cout tile granularity of the conv / weight-gradient kernels
         pad = (k - 1) // 2
         Ho = (x.H + 2 * pad - k) // stride + 1
         Wo = (x.W + 2 * pad - k) // stride + 1
-        CinPad = _rup(Cin, 16)
-        assert x.C >= Cin and (x.C == CinPad or x.C == Cin), (tag, x.C, Cin)
+        # readable input channels: whole 32-channel k-groups when the view has them (its buffer's pixel stride covers the
+        # pad), 16 for the 12-channel stem.  Channels between Cin and CinPad meet zero weight rows.
+        CinPad = _rup(Cin, 32) if x.coff + _rup(Cin, 32) <= x.ld else _rup(Cin, 16)
+        assert x.C >= Cin and x.coff + CinPad <= x.ld, (tag, x.C, x.coff, x.ld, Cin)
         KK = k * k
-        wf = self.small(tag + ".wf", KK * CinPad * Cout * 2)
+        wf = self.small(tag + ".wf", KK * CinPad * CoutPad * 2)
         need_dgrad = self.training and x.requires_grad
-        wd = self.small(tag + ".wd", KK * Cout * _rup(Cin, 32) * 2) if need_dgrad else None
         CinPadN = _rup(Cin, 32)
-        self.emit("PACK_W", i=[Cout, Cin, k, k, CinPad, Cout, Cout, CinPadN], p=[weight, wf, wd], tag=tag + ".pack",
+        wd = self.small(tag + ".wd", KK * CoutPad * CinPadN * 2) if need_dgrad else None
+        self.emit("PACK_W", i=[Cout, Cin, k, k, CinPad, CoutPad, CoutPad, CinPadN], p=[weight, wf, wd], tag=tag + ".pack",
                   prologue=True)
-        y = self.new_act(x.N, Ho, Wo, Cout, tag + ".y", requires_grad=False)
+        y = self.new_act(x.N, Ho, Wo, Cout, tag + ".y", requires_grad=False, pad=False)
         if out is None:
             out = self.new_act(x.N, Ho, Wo, Cout, tag + ".out")
         assert (out.N, out.H, out.W, out.C) == (x.N, Ho, Wo, Cout)
@@ -409,7 +417,7 @@ class PlanBuilder:
             invstd = self.small(tag + ".invstd", Cout * 4)
             nsl = self.bn_slots(self.plan_conv_tiles(x, Ho, Wo, CinPad // 8, Cout, taps, stride))
             acc = self.bn_acc("fwd", Cout, nsl)
-            self.conv_cmd(tag + ".conv", x, wf, CinPad // 8, y, y.ld, Ho, Wo, Cout, Cout, taps, in_stride=stride,
+            self.conv_cmd(tag + ".conv", x, wf, CinPad // 8, y, y.ld, Ho, Wo, Cout, CoutPad, taps, in_stride=stride,
                           stats=acc, stats_slots=nsl)
             self.tune_restore += [t for t in (bn["rm"], bn["rv"], bn["nbt"]) if torch.is_tensor(t)]
             self.emit("BN_ACT_FWD", i=[y.ld, res.ld if res is not None else 0, out.ld, Cout, act, nsl], l=[count, count],
@@ -417,7 +425,7 @@ class PlanBuilder:
                       p=[y, acc, bn["gamma"], bn["beta"], bn["rm"], bn["rv"], bn["nbt"], scale, shift, mean, invstd, res,
                          out], tag=tag + ".bnact")
         else:
-            self.conv_cmd(tag + ".conv", x, wf, CinPad // 8, y, y.ld, Ho, Wo, Cout, Cout, taps, in_stride=stride)
+            self.conv_cmd(tag + ".conv", x, wf, CinPad // 8, y, y.ld, Ho, Wo, Cout, CoutPad, taps, in_stride=stride)
             self.emit("BN_EVAL_AFFINE", i=[Cout], f=[bn["eps"]],
                       p=[bn["gamma"], bn["beta"], bn["rm"], bn["rv"], scale, shift], tag=tag + ".bnaff")
             self.emit("BN_ACT_FWD", i=[y.ld, res.ld if res is not None else 0, out.ld, Cout, act, 0], l=[0, count],
@@ -430,16 +438,19 @@ class PlanBuilder:
             nblk = max(1, min(1024, math.ceil(count / (256 // C8) / 4)))
             nsl2 = self.bn_slots(nblk)
             fused = None
-            if self.fuse_bn_bwd:   # the latest writer of exactly this gradient view is a data-gradient conv (set)
+            if self.fuse_bn_bwd and Cout == CoutPad:   # the latest writer of exactly this gradient view is a data-gradient conv (set)
                 for (w0, w1, cmds) in self.last_writer.get(id(out.gbuf), []):
                     if (w0, w1) == (out.coff, out.coff + Cout) and all(c.desc.ldy == da.ld for c in cmds):
                         fused = cmds
             if fused is not None:
                 nsl2 = self.bn_slots(1 << 30)
             dacc = self.bn_acc("bwd", Cout, nsl2)
-            dy = (self._new_buf(tag + ".dy", count * Cout * 2) if self.group_wgrad
-                  else self.scratch("dy", count * Cout * 2))
-            dyT = TRef(dy, x.N, Ho, Wo, Cout, Cout)
+            # the out-gradient is read by the data / weight gradient kernels in whole 32-channel groups: pad channels
+            # stay zero (a dedicated, never-written part of the zero-initialised arena)
+            assert Cout == CoutPad or self.group_wgrad, "padded channel counts need per-layer dy buffers (MI_WGRAD_GROUP=1)"
+            dy = (self._new_buf(tag + ".dy", count * CoutPad * 2) if self.group_wgrad
+                  else self.scratch("dy", count * CoutPad * 2))
+            dyT = TRef(dy, x.N, Ho, Wo, CoutPad, CoutPad)
             if fused is not None:
                 for c in fused:
                     sp = c.desc
@@ -455,12 +466,13 @@ class PlanBuilder:
             if res is not None and res.requires_grad:
                 dres = res.grad
                 dres_acc = self.grad_mode(res)
-            self.emit("BN_BWD_APPLY", i=[da.ld, y.ld, Cout, dres.ld if dres is not None else 0, dres_acc, Cout, act, nsl2],
+            self.emit("BN_BWD_APPLY", i=[da.ld, y.ld, CoutPad, dres.ld if dres is not None else 0, dres_acc, Cout, act, nsl2],
                       l=[count, count], p=[da, y, scale, shift, mean, invstd, bn["gamma"], dacc, bn["ggamma"], bn["gbeta"],
                                            dyT, dres], tag=tag + ".bnapply")
-            self.wgrad_cmds(tag, x, dyT, CinPad, Cout, Cin, Cout, k, stride, pad, wgrad)
+            self.wgrad_cmds(tag, x, dyT, CinPad if (k > 1 or CinPad % 32 == 0) else _rup(Cin, 32), CoutPad, Cin, Cout, k,
+                            stride, pad, wgrad)
             if need_dgrad:
-                self.dgrad_cmds(tag, dyT, wd, Cout // 8, x, Cin, CinPadN, k, stride, pad)
+                self.dgrad_cmds(tag, dyT, wd, CoutPad // 8, x, Cin, CinPadN, k, stride, pad)
 
         self.on_backward(bwd)
         return out
