@@ -327,6 +327,35 @@ def main():
     ms = dt / args.steps * 1e3
     value = args.batch * world * args.steps / dt
 
+    ddp = None
+    if world > 1:
+        # self-explaining scaling line: the buckets, what each all-reduce costs alone, and how much of the communication
+        # is NOT hidden under backward (same timed loop with the collectives skipped)
+        red = st["red"]
+        sizes, alone = [], []
+        for (lo, hi, _) in red.buckets:
+            buf = trainer.params.grad[lo:hi]
+            for _ in range(2):
+                dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            alone.append(round((time.perf_counter() - t1) / 5 * 1e3, 4))
+            sizes.append(round((hi - lo) * 4 / 1e6, 2))
+        red.enabled = False
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.step(st)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t_nocomm = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        dist.all_reduce(t_nocomm, op=dist.ReduceOp.MAX)
+        red.enabled = True
+        ddp = dict(ranks=world, backend="nccl (RCCL over xGMI)", buckets_MB=sizes, bucket_allreduce_alone_ms=alone,
+                   bwd_segments=len(st["segs"]), ms_per_step_without_allreduce=round(float(t_nocomm) / args.steps * 1e3, 3),
+                   exposed_comm_ms=round(ms - float(t_nocomm) / args.steps * 1e3, 3))
     incl = None
     if not args.no_h2d:
         incl = h2d_inclusive(model, args, world, rank, dev)
@@ -344,6 +373,8 @@ def main():
                        "final_losses": [round(x, 4) for x in losses]},
             "roofline": rl,
         }
+        if ddp is not None:
+            out["ddp"] = ddp
         if incl is not None:
             # the same step fed from pinned host memory (fresh uint8 batch per step, double-buffered, overlapped):
             # SURVEY 8(d)'s definition of the step; `value` keeps the inputs resident as the task statement prescribes

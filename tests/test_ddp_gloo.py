@@ -64,3 +64,125 @@ def test_bucketed_allreduce_world2_gloo():
     port = s.getsockname()[1]
     s.close()
     mp.spawn(_worker, args=(2, port), nprocs=2, join=True)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The REAL data-parallel schedule of a YOLOX-s step, executed: engine.ddp_schedule() on the materialised backward list
+# (staged weight-gradient groups, three buckets, cut points), the command list run by the CPU plan interpreter segment by
+# segment with the gloo all-reduce of each bucket issued exactly where NativeTrainer.step issues the RCCL one.
+def _members(plan, builder, k):
+    """symbolic commands (PlanBuilder._Cmd) behind materialised backward command k"""
+    from yolov7_d2_amd import _lib as L
+    tag = plan.bwd_tags[k]
+    by_tag = {}
+    for c in builder.bwd:
+        by_tag.setdefault(c.tag, []).append(c)
+    if tag.startswith("wgrad_group"):
+        idx = 0 if tag == "wgrad_group.early" else (int(tag.split("stage")[1]) if "stage" in tag else len(plan.wgrad_stage_tags) - 1)
+        out = []
+        for t in plan.wgrad_stage_tags[idx]:
+            out += [c for c in by_tag[t] if c.op == L.OP["WGRAD"]]
+        return out
+    arr, _ = plan.bwd_cmds
+    if L.OPS[arr[k].op] in ("FORK", "JOIN", "STREAM", "NOP"):
+        return []
+    out = []
+    for t in tag.split("+"):
+        out += [c for c in by_tag[t] if c.op != L.OP["WGRAD"]]
+    return out
+
+
+def _step_worker(rank, world, port, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p_ in (here, os.path.join(here, "..", "oracle")):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import yolox_oracle as O
+    from plan_interp import Interp
+    import yolov7_d2_amd as M
+    from yolov7_d2_amd import _lib as L
+    from yolov7_d2_amd.engine import ddp_schedule
+    from yolov7_d2_amd.modeling.yolox import _PlanState
+    from yolov7_d2_amd.params import ParamArena
+    from yolov7_d2_amd.plan import Plan
+
+    def fresh(seed):
+        cfg = M.yolox_s_cfg(device="cpu")
+        model = M.build_model(cfg)
+        model.load_state_dict(O.init_state_dict(0.33, 0.5, 80, seed=seed))
+        model.params = ParamArena(model, "cpu")
+        return model
+
+    B, H, W = 2, 64, 96
+    model = fresh(seed=rank)                     # different weights per rank ...
+    broadcast_params(model.params.data)          # ... until rank 0's are broadcast (DDP construction semantics)
+    imgs, labels = O.synth_batch(B, H, W, seed=100 + rank, max_gt=4)      # a different batch per rank
+    ps = _PlanState(model, B, H, W, True, materialize=False)
+    b = ps.builder
+    assert b.wgrad_split                         # on by itself under torch.distributed with world_size > 1
+    plan = Plan(b, dry_run=True)
+    red, segs = ddp_schedule(plan, b, model.params, world, 3)
+    assert len(red.buckets) == 3 and len([s for s in segs if s[2] is not None]) == 3
+    ps.image.copy_(imgs); ps.labels.copy_(labels)
+    it = Interp(b, torch.float32)
+    it.run(b.prologue + b.fwd)
+    it.raw(ps.loss["gw"]).view(torch.float32)[:4] = 1.0
+    ran = set()
+    for (lo, hi, bucket) in segs:                # exactly NativeTrainer.step's loop
+        for k in range(lo, hi):
+            for c in _members(plan, b, k):
+                assert id(c) not in ran
+                ran.add(id(c))
+                it.run([c])
+        red.reduce_bucket(bucket)
+    red.wait()
+    assert ran == {id(c) for c in b.bwd if L.OPS[c.op] != "NOP"}   # every backward command ran exactly once
+    G = model.params.grad.clone()                # sum over ranks of the local gradients
+
+    # reference: every rank's LOCAL gradient from a plain (un-partitioned) run of the same plan, summed
+    m2 = fresh(seed=0)                           # = the broadcast weights
+    ps2 = _PlanState(m2, B, H, W, True, materialize=False)
+    ps2.image.copy_(imgs); ps2.labels.copy_(labels)
+    it2 = Interp(ps2.builder, torch.float32)
+    it2.run(ps2.builder.prologue + ps2.builder.fwd)
+    it2.raw(ps2.loss["gw"]).view(torch.float32)[:4] = 1.0
+    it2.run(ps2.builder.bwd)
+    local = m2.params.grad.clone()
+    parts = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(parts, local)
+    ref = sum(parts)
+    err = float((G - ref).abs().max() / ref.abs().max())
+    # the optimizer step (sgd_kernel semantics: d = g / world + wd * p; m = d on the first step; p -= lr * m)
+    lr, wd = 0.01, 1e-4
+    p0 = model.params.data.clone()
+    model.params.data.sub_(lr * (G / world + wd * p0))
+    mine = model.params.data.clone()
+    allp = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allp, mine)
+    same = all(torch.equal(allp[0], a) for a in allp[1:])
+    moved = float((mine - p0).abs().max())
+    if rank == 0:
+        q.put(dict(err=err, same=same, moved=moved, nseg=len(segs), tags=[plan.bwd_tags[s[1] - 1] for s in segs if s[2]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_real_step_schedule_world2_gloo():
+    """rank-0 broadcast + one step on DIFFERENT batches through the real bucket / segment schedule: the reduced gradient
+    equals the sum of the two ranks' local gradients (every range reduced exactly once, after its last writer - a
+    bucket sent too early would miss the late contribution), and both ranks hold identical parameters afterwards"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    mp.spawn(_step_worker, args=(2, port, q), nprocs=2, join=True)
+    r = q.get()
+    assert r["err"] < 1e-6, r
+    assert r["same"] and r["moved"] > 0, r
+    assert r["tags"] == ["wgrad_group.early", "wgrad_group.stage1", "wgrad_group"], r

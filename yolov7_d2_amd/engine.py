@@ -17,6 +17,26 @@ from . import _lib as L
 from .parallel import GradReducer, broadcast_params, grad_write_ranges, parallel_regions, plan_buckets
 
 
+def ddp_schedule(plan, builder, params, world, n_buckets=3, group=None):
+    """gradient buckets + the cut points of the backward command list for data parallelism: (GradReducer, segments).
+    With the staged weight-gradient groups (PlanBuilder.wgrad_split, on iff world > 1) the buckets are cut where the
+    stages end in the flat arena (parameters are laid out backbone.stem .. dark5, neck, head): the neck + head bucket is
+    complete - and on the wire - while the backbone's backward runs, the dark4 + dark5 bucket while dark3 .. stem run.
+    Each segment is (first cmd, one past last cmd, bucket to all-reduce after it or None)."""
+    writes = grad_write_ranges(plan, params.grad)
+    bounds = None
+    if world > 1 and getattr(builder, "wgrad_split", False):
+        bounds = []
+        for pre in builder.wgrad_stages:
+            offs = [o for (name, p, o, n) in params.entries if name.startswith(tuple(pre))]
+            if offs:
+                bounds.append(min(offs))
+    buckets = plan_buckets(params.total, writes, n_buckets if world > 1 else 1, bounds=bounds or None)
+    red = GradReducer(params.grad, buckets, group=group)
+    barr, bn = plan.bwd_cmds
+    return red, red.segments(bn, parallel_regions(plan))
+
+
 class NativeTrainer:
     def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=1e-4, weight_decay_norm=0.0, n_buckets=3,
                  use_graph=True, loss_weights=(1.0, 1.0, 1.0, 1.0), tune=None, input_u8=False):
@@ -64,18 +84,7 @@ class NativeTrainer:
                                                              self.params.mom.data_ptr(), self.segs.data_ptr())
         sgd[0].i[0], sgd[0].i[1] = self.nseg, 0
         sgd[0].f[0], sgd[0].f[1] = self.momentum, 1.0 / self.world
-        writes = grad_write_ranges(plan, self.params.grad)
-        bounds = None
-        if self.world > 1 and getattr(ps.builder, "wgrad_split", False):
-            # two buckets cut where the early weight-gradient group ends in the arena (parameters are laid out backbone,
-            # neck, head): the neck + head bucket is complete - and on the wire - while the backbone's backward runs
-            early = [o for (name, p, o, n) in self.params.entries if name.startswith(ps.builder.wgrad_early_prefixes)]
-            if early:
-                bounds = [min(early)]
-        buckets = plan_buckets(self.params.total, writes, self.n_buckets if self.world > 1 else 1, bounds=bounds)
-        red = GradReducer(self.params.grad, buckets)
-        barr, bn = plan.bwd_cmds
-        segs = red.segments(bn, parallel_regions(plan))
+        red, segs = ddp_schedule(plan, ps.builder, self.params, self.world, self.n_buckets)
         st = dict(ps=ps, plan=plan, sgd=sgd, red=red, segs=segs, graphs=None)
         self._states[key] = st
         return st

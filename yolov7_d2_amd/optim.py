@@ -21,7 +21,17 @@ class FlatAdamW:
         self.betas, self.eps, self.steps = betas, eps, 0
         self.set_segments(segments)
 
-    def set_segments(self, segments):
+    def set_segments(self, segments, chunk=16384):
+        # one 256-thread block per table entry: natural per-lr-group segments (2-3 for DETR, ~41 M parameters) would run
+        # the whole update on 2-3 CUs -> cut them into 16 k-element chunks like ParamArena.build_sgd_segments does
+        cut = []
+        for (off, cnt, lr, wd) in segments:
+            k = 0
+            while k < cnt:
+                c = min(chunk, cnt - k)
+                cut.append((off + k, c, lr, wd))
+                k += c
+        segments = cut
         segs = (L.mi_sgd_seg * len(segments))()
         for s, (off, cnt, lr, wd) in zip(segs, segments):
             s.offset, s.count, s.lr, s.weight_decay = int(off), int(cnt), float(lr), float(wd)

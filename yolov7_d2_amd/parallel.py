@@ -103,6 +103,7 @@ class GradReducer:
         self.grad, self.buckets, self.group = grad, buckets, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.pending = []
+        self.enabled = True      # False: skip the collectives (bench.py measures the exposed communication time that way)
 
     def segments(self, n_cmds, regions=()):
         """[(cmd_lo, cmd_hi, bucket or None)]: run cmds [lo,hi) then reduce the bucket.  A cut that would fall inside a
@@ -120,7 +121,7 @@ class GradReducer:
         return segs
 
     def reduce_bucket(self, bucket):
-        if self.world == 1 or bucket is None:
+        if self.world == 1 or bucket is None or not self.enabled:
             return
         lo, hi = bucket
         self.pending.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))

@@ -181,6 +181,12 @@ class PlanBuilder:
             import torch.distributed as dist
             self.wgrad_split = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.wgrad_early_prefixes = ("head.", "neck.")
+        # the split as STAGES (backward order): each stage's weight gradients form one grouped launch issued right after
+        # the stage's last backward command, and one gradient bucket (parameters are laid out backbone.stem .. dark5,
+        # neck, head, so a stage is a contiguous range of the flat arena); whatever matches no stage runs at the end.
+        # Three buckets: [neck + head] on the wire under the whole backbone, [dark4 + dark5] under dark3 .. stem, only the
+        # last (stem .. dark3, 2.4 MB of the 35.9) is exposed.
+        self.wgrad_stages = [("head.", "neck."), ("backbone.dark5.", "backbone.dark4.")]
         # MI_WGRAD_ASYNC=G: the weight gradients run as G grouped launches on an auxiliary LOW-PRIORITY stream (a parallel
         # hipGraph branch), each issued as soon as the last of its layers' out-gradients exists, so that their blocks
         # fill the CUs the latency-bound backward chain of ~200 small kernels leaves idle.  The branch joins before the
@@ -675,18 +681,27 @@ class Plan:
             return bwd
         if getattr(b, "wgrad_async", 0) > 0 and not b.wgrad_split:
             return self._async_wgrads(bwd, wg, b.wgrad_async)
-        early = [c for c in wg if b.wgrad_split and c.tag.startswith(b.wgrad_early_prefixes)]
-        late = [c for c in wg if c not in early]
-        if len(early) < 2 or len(late) < 2:
-            early, late = [], wg
+        stages, rest = [], list(wg)
+        if b.wgrad_split:
+            for pre in b.wgrad_stages:
+                st = [c for c in rest if c.tag.startswith(tuple(pre))]
+                if len(st) >= 2:
+                    stages.append(st)
+                    rest = [c for c in rest if not any(c is x for x in st)]
+        if len(rest) < 2:          # nothing (or a single layer) left for the final group: fold the last stage back in
+            if stages:
+                rest = stages.pop() + rest
+        pos = {id(c): i for i, c in enumerate(bwd)}
+        issue_at = {max(pos[id(c)] for c in st): si for si, st in enumerate(stages)}
         out = []
-        last_early = max((i for i, c in enumerate(bwd) if c in early), default=-1)
         for i, c in enumerate(bwd):
             if c.op != L.OP["WGRAD"]:
                 out.append(c)
-            if i == last_early:
-                out.append(self._wgrad_group_cmd(early, "wgrad_group.early"))
-        out.append(self._wgrad_group_cmd(late, "wgrad_group"))
+            if i in issue_at:
+                si = issue_at[i]
+                out.append(self._wgrad_group_cmd(stages[si], "wgrad_group.early" if si == 0 else f"wgrad_group.stage{si}"))
+        out.append(self._wgrad_group_cmd(rest, "wgrad_group"))
+        self.wgrad_stage_tags = [[c.tag for c in st] for st in stages] + [[c.tag for c in rest]]
         return out
 
     def _async_wgrads(self, bwd, wg, G):
