@@ -8,6 +8,8 @@ from . import _lib
 from .config import add_yolo_config, get_cfg, get_yolox_cfg, yolox_s_cfg
 from .d2shim import BACKBONE_REGISTRY, META_ARCH_REGISTRY, build_backbone, build_model
 from .modeling import YOLOX, build_cspdarknetx_backbone, batched_nms, postprocess
+from . import ops  # noqa: F401  (registers torch.ops.mi355.*)
+from .ops import patch_base_convs
 
 __all__ = ["YOLOX", "build_cspdarknetx_backbone", "batched_nms", "postprocess", "build_model", "build_backbone",
-           "get_cfg", "add_yolo_config", "get_yolox_cfg", "yolox_s_cfg", "META_ARCH_REGISTRY", "BACKBONE_REGISTRY"]
+           "patch_base_convs", "get_cfg", "add_yolo_config", "get_yolox_cfg", "yolox_s_cfg", "META_ARCH_REGISTRY", "BACKBONE_REGISTRY"]

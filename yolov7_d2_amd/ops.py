@@ -1,0 +1,428 @@
+"""`torch.ops.mi355.*` — the per-operator boundary ("PyTorch-ROCm custom ops ... TORCH_LIBRARY(mi355) +
+register_autograd so that loss.backward() works unchanged").
+
+The whole-step plan (plan.py) is the fast path; these ops expose the SAME kernels one operator at a time, with autograd,
+for a model that keeps the reference's own nn.Module tree and swaps single operators:
+
+    torch.ops.mi355.conv2d(x, weight, bias, stride, padding)                -> nn.Conv2d (1x1 / 3x3, stride 1 / 2)
+    torch.ops.mi355.conv_bn_silu(x, weight, gamma, beta, running_mean, running_var, stride, eps, training)
+                                                                            -> BaseConv.forward (wrappers.py:60-83)
+    torch.ops.mi355.batched_nms(boxes, scores, idxs, iou_threshold)         -> torchvision.ops.batched_nms (boxes.py:199)
+    torch.ops.mi355.yolox_loss(raw, labels, anchors, num_classes)           -> YOLOXHead.get_losses (yolox_head.py:274-441)
+    torch.ops.mi355.mha(q, k, v, key_padding_mask, num_heads)               -> attention core of nn.MultiheadAttention
+    torch.ops.mi355.iou_loss_v6(pred, target, iou_type, xyxy, eps)          -> IOUlossV6 (boxes.py:666-752)
+
+`patch_base_convs(module)` re-points the forward of every BaseConv-shaped sub-module (children `conv`: bias-free
+nn.Conv2d, `bn`: nn.BatchNorm2d, `act`: nn.SiLU - the reference's own class qualifies unmodified) to
+torch.ops.mi355.conv_bn_silu on its own parameters.
+
+Tensors: activations NCHW bf16 in channels_last memory (= the kernels' NHWC; anything else is converted on entry),
+weights / BatchNorm parameters fp32 as nn.Conv2d / nn.BatchNorm2d hold them.  HIP device tensors only: there is no CPU
+implementation registered (a CPU call fails with PyTorch's "no kernel for backend" error, by design).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+
+_LIBDEF = torch.library.Library("mi355", "DEF")
+
+
+def _rup(a, b):
+    return (a + b - 1) // b * b
+
+
+# ------------------------------------------------------------------------------------------------ descriptors
+def _nhwc(x):
+    """NCHW tensor -> (bf16 [N,H,W,C] contiguous view/copy)"""
+    return x.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()
+
+
+def _nchw(y, C):
+    """bf16 [N,H,W,Cld] -> NCHW view (channels_last memory) of the first C channels"""
+    return y.permute(0, 3, 1, 2)[:, :C]
+
+
+def _conv_desc(x, ldx, N, H, W, w_img, K, y, ldy, outH, outW, Cout, CoutPad, taps, in_stride=1, out_stride=1, oy=0, ox=0,
+               gridH=None, gridW=None, bias=None, stats=None, nslots=0, flags=0):
+    d = L.mi_conv_desc()
+    d.x, d.w, d.y = x, w_img.data_ptr(), y
+    d.bias, d.stats_acc = L.ptr(bias), L.ptr(stats)
+    d.ldx, d.ldy = ldx, ldy
+    d.N, d.H, d.W, d.outH, d.outW = N, H, W, outH, outW
+    d.gridH, d.gridW = outH if gridH is None else gridH, outW if gridW is None else gridW
+    d.in_stride, d.out_stride, d.out_oy, d.out_ox = in_stride, out_stride, oy, ox
+    d.K8, d.Cout, d.CoutPad, d.ntaps = K // 8, Cout, CoutPad, len(taps)
+    for t, (dy, dx, wi) in enumerate(taps):
+        d.tap_dy[t], d.tap_dx[t], d.tap_w[t] = dy, dx, wi
+    d.flags, d.stats_slots = flags, nslots
+    return d
+
+
+def _run_conv(d, what):
+    L.check(L.lib().mi_conv2d(C.byref(d), L.stream_ptr()), what)
+
+
+class _ConvGeom:
+    """everything shape-dependent of one k x k / stride s convolution on the implicit-GEMM kernels"""
+
+    def __init__(self, x_shape, w_shape, stride, padding):
+        self.N, self.Cin, self.H, self.W = x_shape
+        self.Cout, cin_w, self.k, kw = w_shape
+        if cin_w != self.Cin or kw != self.k or self.k not in (1, 3) or stride not in (1, 2) or padding != (self.k - 1) // 2:
+            raise L.MI355Error(f"mi355 conv: unsupported geometry weight {tuple(w_shape)} stride {stride} padding {padding} "
+                               "(served: 1x1 and 3x3, stride 1 or 2, 'same' padding, groups 1)")
+        if stride == 2 and self.k != 3:
+            raise L.MI355Error("mi355 conv: stride 2 is implemented for 3x3 kernels")
+        self.s, self.pad = stride, padding
+        self.Ho = (self.H + 2 * padding - self.k) // stride + 1
+        self.Wo = (self.W + 2 * padding - self.k) // stride + 1
+        self.CinP, self.CoutP = _rup(self.Cin, 32), _rup(self.Cout, 32)
+        self.KK = self.k * self.k
+
+    def pack(self, weight):
+        dev = weight.device
+        wf = torch.empty(self.KK * self.CinP * self.CoutP, dtype=torch.bfloat16, device=dev)
+        wd = torch.empty(self.KK * self.CoutP * self.CinP, dtype=torch.bfloat16, device=dev)
+        w32 = weight.detach().float().contiguous()
+        L.check(L.lib().mi_pack_conv_weight(w32.data_ptr(), self.Cout, self.Cin, self.k, self.k, wf.data_ptr(), self.CinP,
+                                            self.CoutP, wd.data_ptr(), self.CoutP, self.CinP, L.stream_ptr()),
+                "mi_pack_conv_weight")
+        return wf, wd
+
+    def pad_in(self, x):
+        """NCHW -> bf16 [N,H,W,CinP] (zero pad channels)"""
+        xh = _nhwc(x)
+        if self.CinP != self.Cin:
+            xp = torch.zeros(self.N, self.H, self.W, self.CinP, dtype=torch.bfloat16, device=x.device)
+            xp[..., : self.Cin] = xh
+            xh = xp
+        return xh
+
+    def fwd(self, xh, wf, y, bias=None, stats=None, nslots=0):
+        taps = [(r - self.pad, s - self.pad, r * self.k + s) for r in range(self.k) for s in range(self.k)]
+        _run_conv(_conv_desc(xh.data_ptr(), self.CinP, self.N, self.H, self.W, wf, self.CinP, y.data_ptr(), y.shape[-1],
+                             self.Ho, self.Wo, self.Cout, self.CoutP, taps, in_stride=self.s, bias=bias, stats=stats,
+                             nslots=nslots), "mi_conv2d (forward)")
+
+    def dgrad(self, dyh, wd, dx):
+        """dyh bf16 [N,Ho,Wo,CoutP] (zero pad channels) -> dx bf16 [N,H,W,CinP] (real channels written)"""
+        k, pad = self.k, self.pad
+        if self.s == 1:
+            taps = [(pad - r, pad - s, r * k + s) for r in range(k) for s in range(k)]
+            _run_conv(_conv_desc(dyh.data_ptr(), self.CoutP, self.N, self.Ho, self.Wo, wd, self.CoutP, dx.data_ptr(),
+                                 self.CinP, self.H, self.W, self.Cin, self.CinP, taps), "mi_conv2d (dgrad)")
+            return
+        cls_taps = {0: [(1, 0)], 1: [(0, 1), (2, 0)]}   # output-pixel parity -> [(kernel row, dy offset)]
+        for py in (0, 1):
+            for px in (0, 1):
+                taps = [(oy, ox, r * 3 + s) for (r, oy) in cls_taps[py] for (s, ox) in cls_taps[px]]
+                gh, gw = (self.H - py + 1) // 2, (self.W - px + 1) // 2
+                _run_conv(_conv_desc(dyh.data_ptr(), self.CoutP, self.N, self.Ho, self.Wo, wd, self.CoutP, dx.data_ptr(),
+                                     self.CinP, self.H, self.W, self.Cin, self.CinP, taps, out_stride=2, oy=py, ox=px,
+                                     gridH=gh, gridW=gw), "mi_conv2d (dgrad s2)")
+
+    def wgrad(self, xh, dyh):
+        gw = torch.empty(self.Cout, self.Cin, self.k, self.k, dtype=torch.float32, device=xh.device)
+        d = L.mi_wgrad_desc()
+        d.x, d.dy, d.gw = xh.data_ptr(), dyh.data_ptr(), gw.data_ptr()
+        d.ldx, d.ldy, d.N, d.H, d.W, d.outH, d.outW, d.stride = self.CinP, self.CoutP, self.N, self.H, self.W, self.Ho, self.Wo, self.s
+        d.Cin, d.Cout, d.CinPad, d.CoutPad, d.ntaps = self.Cin, self.Cout, self.CinP, self.CoutP, self.KK
+        for t in range(self.KK):
+            d.tap_dy[t], d.tap_dx[t] = t // self.k - self.pad, t % self.k - self.pad
+        need = L.lib().mi_conv2d_wgrad_plan(C.byref(d))
+        L.check(need, "mi_conv2d_wgrad_plan")
+        ws = torch.empty(max(int(need), 16), dtype=torch.uint8, device=xh.device)
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
+        L.check(L.lib().mi_conv2d_wgrad(C.byref(d), L.stream_ptr()), "mi_conv2d_wgrad")
+        return gw
+
+
+def _colsum(dyh, C_):
+    """fp32 column sums over all pixels of a bf16 [..., CP] map (bias gradient)"""
+    CP = dyh.shape[-1]
+    T = dyh.numel() // CP
+    out = torch.empty(CP, dtype=torch.float32, device=dyh.device)
+    ws = torch.empty(128 * 128, dtype=torch.float32, device=dyh.device)
+    for c0 in range(0, CP, 64):
+        nc = min(64, CP - c0)
+        L.check(L.lib().mi_colsum_bf16(dyh.data_ptr() + 2 * c0, CP, T, nc, out.data_ptr() + 4 * c0, 0, ws.data_ptr(),
+                                       L.stream_ptr()), "mi_colsum_bf16")
+    return out[:C_]
+
+
+def _pad_last(t, CP):
+    """bf16 [N,H,W,C] -> [N,H,W,CP] with zero pad channels"""
+    if t.shape[-1] == CP:
+        return t
+    out = torch.zeros(*t.shape[:-1], CP, dtype=t.dtype, device=t.device)
+    out[..., : t.shape[-1]] = t
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ mi355::conv2d
+_LIBDEF.define("conv2d(Tensor x, Tensor weight, Tensor? bias, int stride, int padding) -> Tensor")
+_LIBDEF.define("conv2d_backward(Tensor grad, Tensor x, Tensor weight, bool has_bias, int stride, int padding) -> (Tensor, Tensor, Tensor)")
+
+
+def _conv2d_cuda(x, weight, bias, stride, padding):
+    g = _ConvGeom(x.shape, weight.shape, stride, padding)
+    wf, _ = g.pack(weight)
+    y = torch.empty(g.N, g.Ho, g.Wo, g.CoutP, dtype=torch.bfloat16, device=x.device)
+    b32 = None
+    if bias is not None:
+        b32 = torch.zeros(g.CoutP, dtype=torch.float32, device=x.device)
+        b32[: g.Cout] = bias.detach().float()
+    g.fwd(g.pad_in(x), wf, y, bias=b32)
+    return _nchw(y, g.Cout)
+
+
+def _conv2d_backward_cuda(grad, x, weight, has_bias, stride, padding):
+    g = _ConvGeom(x.shape, weight.shape, stride, padding)
+    _, wd = g.pack(weight)
+    dyh = _pad_last(_nhwc(grad), g.CoutP)
+    xh = g.pad_in(x)
+    dx = torch.zeros(g.N, g.H, g.W, g.CinP, dtype=torch.bfloat16, device=x.device)
+    g.dgrad(dyh, wd, dx)
+    gw = g.wgrad(xh, dyh)
+    gb = _colsum(dyh, g.Cout) if has_bias else torch.zeros(0, device=x.device)
+    return _nchw(dx, g.Cin), gw, gb
+
+
+torch.library.impl(_LIBDEF, "conv2d", "CUDA")(_conv2d_cuda)
+torch.library.impl(_LIBDEF, "conv2d_backward", "CUDA")(_conv2d_backward_cuda)
+
+
+def _conv2d_setup(ctx, inputs, output):
+    x, weight, bias, stride, padding = inputs
+    ctx.save_for_backward(x, weight)
+    ctx.has_bias, ctx.stride, ctx.padding = bias is not None, stride, padding
+
+
+def _conv2d_bwd(ctx, grad):
+    x, weight = ctx.saved_tensors
+    dx, gw, gb = torch.ops.mi355.conv2d_backward(grad, x, weight, ctx.has_bias, ctx.stride, ctx.padding)
+    return dx.to(x.dtype), gw.to(weight.dtype), (gb if ctx.has_bias else None), None, None
+
+
+torch.library.register_autograd("mi355::conv2d", _conv2d_bwd, setup_context=_conv2d_setup)
+
+
+# ------------------------------------------------------------------------------------------------ mi355::conv_bn_silu
+# functional (register_autograd requires it): in training mode the op RETURNS the batch statistics (stats[2] = mean,
+# stats[3] = 1/sqrt(var + eps)) and `base_conv_forward` below applies nn.BatchNorm2d's running-statistics update
+_LIBDEF.define("conv_bn_silu(Tensor x, Tensor weight, Tensor gamma, Tensor beta, Tensor running_mean, "
+               "Tensor running_var, int stride, float eps, bool training) -> (Tensor, Tensor, Tensor)")
+_LIBDEF.define("conv_bn_silu_backward(Tensor grad, Tensor x, Tensor weight, Tensor gamma, Tensor y, Tensor stats, "
+               "int stride) -> (Tensor, Tensor, Tensor, Tensor)")
+
+
+def _conv_bn_silu_cuda(x, weight, gamma, beta, running_mean, running_var, stride, eps, training):
+    """-> (out NCHW bf16, y = raw conv output bf16 [N,Ho,Wo,Cout], stats fp32 [4, Cout] = scale, shift, mean, invstd)"""
+    g = _ConvGeom(x.shape, weight.shape, stride, (weight.shape[2] - 1) // 2)
+    if g.Cout % 8:
+        raise L.MI355Error("mi355::conv_bn_silu: Cout must be a multiple of 8")
+    dev = x.device
+    wf, _ = g.pack(weight)
+    y = torch.empty(g.N, g.Ho, g.Wo, g.Cout, dtype=torch.bfloat16, device=dev)
+    out = torch.empty(g.N, g.Ho, g.Wo, g.Cout, dtype=torch.bfloat16, device=dev)
+    stats = torch.empty(4, g.Cout, dtype=torch.float32, device=dev)
+    npix = g.N * g.Ho * g.Wo
+    ga, be = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+    lib = L.lib()
+    if training:
+        acc = torch.zeros(L.MI_BN_SLOTS * g.CoutP * 2, dtype=torch.float64, device=dev)
+        g.fwd(g.pad_in(x), wf, y, stats=acc, nslots=L.MI_BN_SLOTS)
+        L.check(lib.mi_bn_act_fwd(y.data_ptr(), g.Cout, acc.data_ptr(), L.MI_BN_SLOTS, npix, ga.data_ptr(), be.data_ptr(),
+                                  eps, 0.0, None, None, None, stats[0].data_ptr(), stats[1].data_ptr(),
+                                  stats[2].data_ptr(), stats[3].data_ptr(), None, 0, out.data_ptr(), g.Cout, npix, g.Cout, 1,
+                                  L.stream_ptr()), "mi_bn_act_fwd")
+    else:
+        g.fwd(g.pad_in(x), wf, y)
+        L.check(lib.mi_bn_eval_affine(ga.data_ptr(), be.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(), eps,
+                                      g.Cout, stats[0].data_ptr(), stats[1].data_ptr(), L.stream_ptr()), "mi_bn_eval_affine")
+        L.check(lib.mi_bn_act_fwd(y.data_ptr(), g.Cout, None, 0, 0, None, None, eps, 0.0, None, None, None,
+                                  stats[0].data_ptr(), stats[1].data_ptr(), None, None, None, 0, out.data_ptr(), g.Cout,
+                                  npix, g.Cout, 1, L.stream_ptr()), "mi_bn_act_fwd (eval)")
+    return _nchw(out, g.Cout), y, stats
+
+
+def _conv_bn_silu_backward_cuda(grad, x, weight, gamma, y, stats, stride):
+    g = _ConvGeom(x.shape, weight.shape, stride, (weight.shape[2] - 1) // 2)
+    dev = x.device
+    lib = L.lib()
+    npix = g.N * g.Ho * g.Wo
+    da = _nhwc(grad)
+    ga = gamma.detach().float().contiguous()
+    dacc = torch.zeros(L.MI_BN_SLOTS * g.CoutP * 2, dtype=torch.float64, device=dev)
+    C8 = g.Cout // 8
+    nblk = max(1, min(1024, math.ceil(npix / (256 // C8) / 4)))
+    L.check(lib.mi_bn_act_bwd_reduce(da.data_ptr(), g.Cout, y.data_ptr(), g.Cout, stats[0].data_ptr(), stats[1].data_ptr(),
+                                     stats[2].data_ptr(), stats[3].data_ptr(), dacc.data_ptr(), L.MI_BN_SLOTS, nblk, npix,
+                                     g.Cout, 1, L.stream_ptr()), "mi_bn_act_bwd_reduce")
+    dyh = torch.zeros(g.N, g.Ho, g.Wo, g.CoutP, dtype=torch.bfloat16, device=dev)
+    dgamma = torch.empty(g.Cout, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(g.Cout, dtype=torch.float32, device=dev)
+    L.check(lib.mi_bn_act_bwd_apply(da.data_ptr(), g.Cout, y.data_ptr(), g.Cout, stats[0].data_ptr(), stats[1].data_ptr(),
+                                    stats[2].data_ptr(), stats[3].data_ptr(), ga.data_ptr(), dacc.data_ptr(), L.MI_BN_SLOTS,
+                                    npix, dgamma.data_ptr(), dbeta.data_ptr(), dyh.data_ptr(), g.CoutP, None, 0, 0, npix,
+                                    g.Cout, 1, L.stream_ptr()), "mi_bn_act_bwd_apply")
+    _, wd = g.pack(weight)
+    dx = torch.zeros(g.N, g.H, g.W, g.CinP, dtype=torch.bfloat16, device=dev)
+    g.dgrad(dyh, wd, dx)
+    gw = g.wgrad(g.pad_in(x), dyh)
+    return _nchw(dx, g.Cin), gw, dgamma, dbeta
+
+
+torch.library.impl(_LIBDEF, "conv_bn_silu", "CUDA")(_conv_bn_silu_cuda)
+torch.library.impl(_LIBDEF, "conv_bn_silu_backward", "CUDA")(_conv_bn_silu_backward_cuda)
+
+
+def _cbs_setup(ctx, inputs, output):
+    x, weight, gamma = inputs[0], inputs[1], inputs[2]
+    out, y, stats = output
+    ctx.save_for_backward(x, weight, gamma, y, stats)
+    ctx.stride, ctx.training = inputs[6], inputs[8]
+    ctx.mark_non_differentiable(y, stats)
+
+
+def _cbs_bwd(ctx, grad, _gy, _gs):
+    x, weight, gamma, y, stats = ctx.saved_tensors
+    if not ctx.training:
+        raise L.MI355Error("mi355::conv_bn_silu: backward through the eval-mode (running statistics) form is not implemented")
+    dx, gw, dgamma, dbeta = torch.ops.mi355.conv_bn_silu_backward(grad, x, weight, gamma, y, stats, ctx.stride)
+    return dx.to(x.dtype), gw.to(weight.dtype), dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), None, None, None, None, None
+
+
+torch.library.register_autograd("mi355::conv_bn_silu", _cbs_bwd, setup_context=_cbs_setup)
+
+
+# ------------------------------------------------------------------------------------------------ mi355::batched_nms
+_LIBDEF.define("batched_nms(Tensor boxes, Tensor scores, Tensor idxs, float iou_threshold) -> Tensor")
+
+
+def _batched_nms_cuda(boxes, scores, idxs, iou_threshold):
+    from .modeling.postprocess import batched_nms
+    return batched_nms(boxes, scores, idxs, iou_threshold)
+
+
+torch.library.impl(_LIBDEF, "batched_nms", "CUDA")(_batched_nms_cuda)
+
+
+# ------------------------------------------------------------------------------------------------ mi355::yolox_loss
+_LIBDEF.define("yolox_loss(Tensor raw, Tensor labels, Tensor anchors, int num_classes) -> (Tensor, Tensor)")
+
+
+def _yolox_loss_cuda(raw, labels, anchors, num_classes):
+    """raw [B,A,5+nc] fp32 head output (undecoded), labels [B,L,5] (cls,cx,cy,w,h), anchors [A,3] (gx,gy,stride) ->
+    (losses fp32 [8] = total, 5*iou, obj, cls, l1, num_fg/num_gt, num_fg, num_gt;  d(sum of the 4 losses)/d(raw))"""
+    B, A, nch = raw.shape
+    ML = labels.shape[1]
+    dev = raw.device
+    t = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
+    rd, ld, ad = raw.detach().float().contiguous(), labels.detach().float().contiguous(), anchors.detach().float().contiguous()
+    ws = dict(cost=t(B, ML, A), iou=t(B, ML, A), match=t(B, ML, A, dt=torch.uint8), ngt=t(B, dt=torch.int32),
+              fg=t(B, A, dt=torch.uint8), matched_gt=t(B, A, dt=torch.int32), matched_iou=t(B, A),
+              partial=t(B * ((A + 255) // 256), 4), out=t(8))
+    d = L.mi_yolox_loss_desc()
+    d.preds, d.labels, d.anchors = rd.data_ptr(), ld.data_ptr(), ad.data_ptr()
+    d.B, d.A, d.ncls, d.max_labels, d.gmax = B, A, num_classes, ML, ML
+    for k in ("cost", "iou", "match", "ngt", "fg", "matched_gt", "matched_iou", "partial", "out"):
+        setattr(d, k, ws[k].data_ptr())
+    L.check(L.lib().mi_yolox_loss_fwd(C.byref(d), L.stream_ptr()), "mi_yolox_loss_fwd")
+    gw = torch.ones(4, dtype=torch.float32, device=dev)
+    dpreds = t(B, A, nch)
+    L.check(L.lib().mi_yolox_loss_bwd(C.byref(d), gw.data_ptr(), dpreds.data_ptr(), L.stream_ptr()), "mi_yolox_loss_bwd")
+    return ws["out"], dpreds
+
+
+torch.library.impl(_LIBDEF, "yolox_loss", "CUDA")(_yolox_loss_cuda)
+
+
+class _YoloxLossFn(torch.autograd.Function):
+    """losses[0..3] = (total, 5*iou, obj, cls); the gradient of ANY weighting of the four follows from d(total)/d(raw) =
+    d(5 iou)/d + d(obj)/d + d(cls)/d only when the weights are equal, so the per-loss gradients are taken from the kernel
+    by unit weights one loss at a time when the incoming gradient is not uniform."""
+
+    @staticmethod
+    def forward(ctx, raw, labels, anchors, num_classes):
+        out, dsum = torch.ops.mi355.yolox_loss(raw, labels, anchors, num_classes)
+        ctx.save_for_backward(dsum)
+        return out[:6].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dsum,) = ctx.saved_tensors
+        w = g[:4]
+        if not bool(torch.all(w == w[0])):
+            raise L.MI355Error("mi355.yolox_loss: weight the four losses equally (detectron2 sums the loss dict); "
+                               "other weightings go through the whole-step plan (loss weights `gw`)")
+        return dsum * w[0], None, None, None
+
+
+def yolox_loss(raw, labels, anchors, num_classes=80):
+    """differentiable wrapper of torch.ops.mi355.yolox_loss: returns the reference's (total, 5*iou, obj, cls, l1,
+    num_fg/num_gt) as a [6] tensor attached to autograd through `raw`"""
+    return _YoloxLossFn.apply(raw, labels, anchors, num_classes)
+
+
+# ------------------------------------------------------------------------------------------------ mi355::mha / iou_loss_v6
+_LIBDEF.define("mha(Tensor q, Tensor k, Tensor v, Tensor? key_padding_mask, int num_heads) -> Tensor")
+_LIBDEF.define("iou_loss_v6(Tensor pred, Tensor target, str iou_type, bool xyxy, float eps) -> Tensor")
+
+
+def _mha_any(q, k, v, key_padding_mask, num_heads):
+    from .modeling.attention import mha_core
+    return mha_core(q, k, v, key_padding_mask, num_heads)
+
+
+def _iou_v6_any(pred, target, iou_type, xyxy, eps):
+    from .modeling.iou_loss import _IouLossFn, _TYPES
+    return _IouLossFn.apply(pred, target, _TYPES[iou_type.lower()], 1 if xyxy else 0, eps)
+
+
+# these two are torch.autograd.Functions already (fused forward + saved gradient): registered as composite ops, autograd
+# sees through them
+torch.library.impl(_LIBDEF, "mha", "CompositeImplicitAutograd")(_mha_any)
+torch.library.impl(_LIBDEF, "iou_loss_v6", "CompositeImplicitAutograd")(_iou_v6_any)
+
+
+# ------------------------------------------------------------------------------------------------ module patching
+def _is_base_conv(m):
+    conv, bn, act = getattr(m, "conv", None), getattr(m, "bn", None), getattr(m, "act", None)
+    return (isinstance(conv, torch.nn.Conv2d) and isinstance(bn, torch.nn.BatchNorm2d) and isinstance(act, torch.nn.SiLU)
+            and conv.bias is None and conv.groups == 1 and conv.kernel_size[0] == conv.kernel_size[1]
+            and conv.kernel_size[0] in (1, 3) and conv.stride[0] in (1, 2) and conv.out_channels % 8 == 0)
+
+
+def base_conv_forward(m, x):
+    """BaseConv.forward (wrappers.py:82-83) of module `m` (children conv / bn / act) through torch.ops.mi355.conv_bn_silu,
+    including nn.BatchNorm2d's train-mode side effects (running statistics with momentum, unbiased running variance,
+    num_batches_tracked)"""
+    bn = m.bn
+    out, _, stats = torch.ops.mi355.conv_bn_silu(x, m.conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                                  m.conv.stride[0], bn.eps, m.training)
+    if m.training and bn.track_running_stats:
+        with torch.no_grad():
+            n = out.numel() // out.shape[1]
+            mean = stats[2]
+            var = (1.0 / (stats[3] * stats[3]) - bn.eps).clamp_(min=0.0)        # biased batch variance
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+            bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
+            bn.running_var.mul_(1 - mom).add_((var * (n / max(n - 1, 1))).to(bn.running_var.dtype), alpha=mom)
+            bn.num_batches_tracked += 1
+    return out
+
+
+def patch_base_convs(module):
+    """re-point every BaseConv-shaped sub-module (wrappers.py:60-83: conv -> bn -> SiLU; the reference's own class
+    qualifies as it is) to torch.ops.mi355.conv_bn_silu on its own parameters and buffers.  Returns the number of
+    patched modules.  state_dict, optimizers and checkpoints are untouched: only `forward` changes."""
+    n = 0
+    for m in module.modules():
+        if _is_base_conv(m):
+            m.forward = (lambda x, _m=m: base_conv_forward(_m, x))
+            n += 1
+    return n
