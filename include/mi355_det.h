@@ -55,7 +55,7 @@ const char* mi_last_error(void);
                               PRODUCED its output tensor: stats_acc += (sum dz, sum dz*xhat) per channel with
                               dz = y_out * act'(bn_y*scale+shift), xhat = (bn_y-mean)*invstd - replaces the
                               mi_bn_act_bwd_reduce pass over (da, y) of that layer (bf16 staged outputs only) */
-#define MI_MAX_TAPS 9
+#define MI_MAX_TAPS 16 /* 3x3 = 9; 16 = the 7x7 stride-2 ResNet stem as a 4x4 conv over the 2x2 space-to-depth image */
 #define MI_BN_SLOTS 16     /* max accumulator slots per channel (slot = pixel tile % nslots); callers pick
                               nslots per layer: more slots = less same-address atomic traffic in the conv
                               epilogue, fewer = a shorter statistics prologue in the BN kernels */
@@ -241,6 +241,12 @@ int mi_spp_pool_fwd(const void* x, int ldx, void* y5, void* y9, void* y13, int l
 int mi_spp_pool_bwd(const void* dy5, const void* dy9, const void* dy13, int lddy,
                     const uint8_t* idx, void* dx, int lddx, int accumulate, int N, int H, int W,
                     int C, mi_stream_t s);
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of detectron2's ResNet stem (BasicStem.forward; d2 upstream), bf16
+ * NHWC views, C %% 8 == 0.  outH = (H + 1) / 2.  Backward routes each output gradient to the FIRST maximum of its
+ * window in row-major order (ATen's tie rule): dx (+)= sum over the <= 4 windows that contain the pixel. */
+int mi_maxpool3x3s2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, mi_stream_t s);
+int mi_maxpool3x3s2_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int accumulate, int N,
+                        int H, int W, int C, mi_stream_t s);
 /* generic strided bf16 NHWC copy / accumulate (dst (+)= src) */
 int mi_copy_bf16(const void* src, int lds_, void* dst, int ldd, int accumulate, int64_t npix, int C,
                  mi_stream_t s);

@@ -1,0 +1,61 @@
+"""ORACLE (test infrastructure, not product): CPU fp32 restatement of detectron2's ResNet (BasicStem + BottleneckBlock
+with FrozenBatchNorm2d, eps 1e-5) over a state_dict with detectron2's key names.  detectron2 is an un-vendored, unpinned
+dependency of the reference (readme.md:178 "latest"; call sites meta_arch/detr.py:348, sparseinst.py:63): PARITY UNPINNED -
+this follows d2 upstream's modeling/backbone/resnet.py semantics (stride in the 3x3 conv when STRIDE_IN_1X1 is False,
+shortcut = 1x1 conv with the block's stride when the channel count changes, ReLU after the residual add)."""
+import torch
+import torch.nn.functional as F
+
+EPS = 1e-5
+BLOCKS = {50: (3, 4, 6, 3)}
+
+
+def init_state_dict(depth=50, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def conv(p, cin, cout, k):
+        std = (2.0 / (cout * k * k)) ** 0.5
+        sd[p + ".weight"] = torch.randn(cout, cin, k, k, generator=g) * std
+        sd[p + ".norm.weight"] = 0.5 + torch.rand(cout, generator=g)
+        sd[p + ".norm.bias"] = torch.randn(cout, generator=g) * 0.1
+        sd[p + ".norm.running_mean"] = torch.randn(cout, generator=g) * 0.1
+        sd[p + ".norm.running_var"] = 0.5 + torch.rand(cout, generator=g)
+
+    conv("stem.conv1", 3, 64, 7)
+    cin, bc, cout = 64, 64, 256
+    for i, nb in enumerate(BLOCKS[depth]):
+        for k in range(nb):
+            p = f"res{i + 2}.{k}"
+            c0 = cin if k == 0 else cout
+            if c0 != cout:
+                conv(p + ".shortcut", c0, cout, 1)
+            conv(p + ".conv1", c0, bc, 1); conv(p + ".conv2", bc, bc, 3); conv(p + ".conv3", bc, cout, 1)
+        cin, bc, cout = cout, bc * 2, cout * 2
+    return sd
+
+
+def _cn(sd, p, x, stride, pad, q):
+    scale = sd[p + ".norm.weight"] * (sd[p + ".norm.running_var"] + EPS).rsqrt()
+    shift = sd[p + ".norm.bias"] - sd[p + ".norm.running_mean"] * scale
+    return q(F.conv2d(q(x), q(sd[p + ".weight"] * scale.view(-1, 1, 1, 1)), shift, stride, pad))
+
+
+def forward(sd, x, depth=50, stride_in_1x1=False, quant=None):
+    """-> {"res2".."res5"}; quant: optional storage-rounding emulation (bf16) applied where the product stores"""
+    q = quant if quant is not None else (lambda t: t)
+    x = q(F.relu(_cn(sd, "stem.conv1", x, 2, 3, q)))
+    x = F.max_pool2d(x, 3, 2, 1)
+    outs = {}
+    for i, nb in enumerate(BLOCKS[depth]):
+        for k in range(nb):
+            p = f"res{i + 2}.{k}"
+            stride = 2 if (k == 0 and i > 0) else 1
+            s1, s3 = (stride, 1) if stride_in_1x1 else (1, stride)
+            out = q(F.relu(_cn(sd, p + ".conv1", x, s1, 0, q)))
+            out = q(F.relu(_cn(sd, p + ".conv2", out, s3, 1, q)))
+            out = _cn(sd, p + ".conv3", out, 1, 0, q)
+            sc = _cn(sd, p + ".shortcut", x, stride, 0, q) if (p + ".shortcut.weight") in sd else x
+            x = q(F.relu(out + sc))
+        outs[f"res{i + 2}"] = x
+    return outs

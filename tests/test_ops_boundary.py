@@ -100,7 +100,7 @@ def _rel(a, b):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k,s,bias", [(2, 20, 24, 64, 96, 3, 1, True), (2, 16, 16, 32, 64, 1, 1, False),
-                                                     (1, 22, 18, 48, 80, 3, 2, True)])
+                                                     (1, 22, 18, 48, 80, 3, 2, True), (2, 15, 18, 64, 128, 1, 2, False)])
 def test_op_conv2d_with_autograd(N, H, W, Cin, Cout, k, s, bias):
     g = torch.Generator().manual_seed(3)
     x = _bf(torch.randn(N, Cin, H, W, generator=g))

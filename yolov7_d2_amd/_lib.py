@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI355_LIB", os.path.join(_HERE, "libmi355det.so"))   # override: A/B testing of builds
 
-MI_MAX_TAPS = 9
+MI_MAX_TAPS = 16
 MI_CONV_ACCUM = 1
 MI_CONV_BNBWD = 4
 MI_CONV_OUT_F32 = 2
@@ -155,6 +155,8 @@ _PROTOS = {
                                       _i64, _i, _i, _vp]),
     "mi_focus_pack": (C.c_int, [_vp, _i, _i, _i, _vp, _i, _vp]),
     "mi_focus_pack_u8": (C.c_int, [_vp, _i, _i, _i, _vp, _i, _vp]),
+    "mi_maxpool3x3s2_fwd": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mi_maxpool3x3s2_bwd": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mi_upsample2x_fwd": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "mi_upsample2x_bwd": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mi_spp_pool_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),

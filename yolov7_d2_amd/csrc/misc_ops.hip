@@ -79,6 +79,107 @@ extern "C" int mi_focus_pack(const float* img, int N, int H, int W, void* out, i
   return MI_OK;
 }
 
+// ---- MaxPool2d(3, stride 2, padding 1): detectron2 BasicStem (ResNet-50 of the DETR / SparseInst configurations)
+__global__ __launch_bounds__(256) void maxpool3x3s2_fwd_kernel(const __bf16* __restrict__ x, int ldx, __bf16* y, int ldy,
+                                                               int N, int H, int W, int C8) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int64_t total = (int64_t)N * Ho * Wo * C8;
+  for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(idx % C8);
+    int64_t r = idx / C8;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = 2 * oy - 1 + dy;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ix = 2 * ox - 1 + dx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const bf16x8 v = *(const bf16x8*)(x + (((int64_t)n * H + iy) * W + ix) * ldx + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+      }
+    }
+    *(bf16x8*)(y + (((int64_t)n * Ho + oy) * Wo + ox) * ldy + c8 * 8) = pack8(m);
+  }
+}
+// gather form of the backward pass: an input pixel collects dy of every window (<= 2 x 2) whose FIRST maximum it is
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const __bf16* __restrict__ x, int ldx,
+                                                               const __bf16* __restrict__ dy, int lddy, __bf16* dx,
+                                                               int lddx, int accumulate, int N, int H, int W, int C8) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int64_t total = (int64_t)N * H * W * C8;
+  for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(idx % C8);
+    int64_t r = idx / C8;
+    const int ix = (int)(r % W); r /= W;
+    const int iy = (int)(r % H);
+    const int n = (int)(r / H);
+    const __bf16* xp = x + ((int64_t)n * H * W) * ldx + c8 * 8;
+    const bf16x8 me = *(const bf16x8*)(xp + ((int64_t)iy * W + ix) * ldx);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {   // windows with 2*oy-1 <= iy <= 2*oy+1: one (iy even) or two (odd)
+      if (oy < 0 || oy >= Ho) continue;
+      for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
+        if (ox < 0 || ox >= Wo) continue;
+        const bf16x8 g = *(const bf16x8*)(dy + (((int64_t)n * Ho + oy) * Wo + ox) * lddy + c8 * 8);
+        // am I the first maximum of this window (row-major scan)?
+        bool first[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) first[e] = true;
+        for (int wy = 0; wy < 3; ++wy) {
+          const int yy = 2 * oy - 1 + wy;
+          if ((unsigned)yy >= (unsigned)H) continue;
+          for (int wx = 0; wx < 3; ++wx) {
+            const int xx = 2 * ox - 1 + wx;
+            if ((unsigned)xx >= (unsigned)W || (yy == iy && xx == ix)) continue;
+            const bf16x8 v = *(const bf16x8*)(xp + ((int64_t)yy * W + xx) * ldx);
+            const bool before = (yy < iy) || (yy == iy && xx < ix);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float a = (float)v[e], b = (float)me[e];
+              if (before ? (a >= b) : (a > b)) first[e] = false;
+            }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (first[e]) acc[e] += (float)g[e];
+      }
+    }
+    __bf16* dp = dx + (((int64_t)n * H + iy) * W + ix) * lddx + c8 * 8;
+    if (accumulate) {
+      const bf16x8 o = *(const bf16x8*)dp;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += (float)o[e];
+    }
+    *(bf16x8*)dp = pack8(acc);
+  }
+}
+extern "C" int mi_maxpool3x3s2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, mi_stream_t st) {
+  MI_REQUIRE(x && y && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && N > 0 && H > 0 && W > 0, "maxpool3x3s2_fwd: args");
+  const int64_t total = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
+  hipLaunchKernelGGL(maxpool3x3s2_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)st, (const __bf16*)x,
+                     ldx, (__bf16*)y, ldy, N, H, W, C / 8);
+  MI_CHECK_LAUNCH("maxpool3x3s2_fwd");
+  return MI_OK;
+}
+extern "C" int mi_maxpool3x3s2_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int accumulate,
+                                   int N, int H, int W, int C, mi_stream_t st) {
+  MI_REQUIRE(x && dy && dx && C % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "maxpool3x3s2_bwd: args");
+  const int64_t total = (int64_t)N * H * W * (C / 8);
+  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)st, (const __bf16*)x,
+                     ldx, (const __bf16*)dy, lddy, (__bf16*)dx, lddx, accumulate, N, H, W, C / 8);
+  MI_CHECK_LAUNCH("maxpool3x3s2_bwd");
+  return MI_OK;
+}
+
 // ---- nearest x2 upsample (yolov7/modeling/neck/yolo_pafpn.py:28,96,101)
 __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const __bf16* __restrict__ x, int ldx, __bf16* y, int ldy,
                                                              int N, int H, int W, int C8) {

@@ -1,0 +1,255 @@
+"""detectron2's ResNet-50 (`build_resnet_backbone`, BasicStem + BottleneckBlock, FrozenBatchNorm2d) on the MI355X kernels -
+the backbone of BASELINE.json configs 4 / 5 (configs/coco/detr/detr_256_6_6_torchvision.yaml:7-10,
+configs/coco/sparseinst/Base-SparseInst.yaml:8).  detectron2 is NOT vendored in the reference and not installed here:
+module structure, state_dict keys (`stem.conv1.weight`, `stem.conv1.norm.{weight,bias,running_mean,running_var}`,
+`res3.0.shortcut.weight`, `res3.0.conv2.norm.*` ...) and semantics are restated from d2 upstream (parity unpinned: the
+CPU restatement is oracle/resnet_oracle.py).
+
+How it runs:
+  * every Conv2d + FrozenBatchNorm2d pair is ONE implicit-GEMM launch (torch.ops.mi355.conv2d): the frozen affine
+    (scale = w / sqrt(var + 1e-5), shift = b - mean * scale) is folded into the packed weight image and the conv bias -
+    a frozen norm has no statistics pass at all;
+  * the 7x7 stride-2 stem conv (3 -> 64) is a 4x4 conv over the 2x2 space-to-depth image: the Focus packer of the YOLOX
+    stem (mi_focus_pack: fp32 NCHW -> bf16 [N, H/2, W/2, 12+4]) followed by a 16-tap conv with the 7x7 weights scattered
+    into an 8x8 kernel (row / column -1 are zero) - no 3-channel implicit GEMM with 13/16 of the k-chunk wasted;
+  * ReLU / residual add: mi_ew_bf16; MaxPool2d(3, 2, 1): mi_maxpool3x3s2_*;
+  * MODEL.BACKBONE.FREEZE_AT (default 2): the stem and res2 run forward-only (no saved activations, no data / weight
+    gradients), exactly the layers detectron2 freezes.
+Activations are bf16 NCHW tensors in channels_last memory (= NHWC for the kernels).
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from .. import _lib as L
+from ..d2shim import BACKBONE_REGISTRY, Backbone, ShapeSpec
+from ..ops import _conv_desc, _run_conv
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """detectron2.layers.FrozenBatchNorm2d: four BUFFERS, eps 1e-5, y = x * scale + shift"""
+
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.num_features, self.eps = num_features, eps
+        self.register_buffer("weight", torch.ones(num_features))
+        self.register_buffer("bias", torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features) - eps)
+
+    def affine(self):
+        scale = self.weight * (self.running_var + self.eps).rsqrt()
+        return scale, self.bias - self.running_mean * scale
+
+
+def _nhwc_view(x):
+    """bf16 NCHW tensor -> its NHWC image (no copy when x is channels_last)"""
+    return x.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()
+
+
+class _EwRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a):          # a: contiguous bf16
+        y = torch.empty_like(a)
+        L.check(L.lib().mi_ew_bf16(a.data_ptr(), None, y.data_ptr(), a.numel(), 1, L.stream_ptr()), "mi_ew_bf16 relu")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = g.contiguous()
+        out = torch.empty_like(g)
+        L.check(L.lib().mi_ew_bf16(g.data_ptr(), y.data_ptr(), out.data_ptr(), g.numel(), 2, L.stream_ptr()), "mi_ew_bf16 relu'")
+        return out
+
+
+class _EwAddRelu(torch.autograd.Function):
+    """relu(a + b): the tail of a bottleneck block"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        s = torch.empty_like(a)
+        lib = L.lib()
+        L.check(lib.mi_ew_bf16(a.data_ptr(), b.data_ptr(), s.data_ptr(), a.numel(), 0, L.stream_ptr()), "mi_ew_bf16 add")
+        y = torch.empty_like(a)
+        L.check(lib.mi_ew_bf16(s.data_ptr(), None, y.data_ptr(), a.numel(), 1, L.stream_ptr()), "mi_ew_bf16 relu")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = g.contiguous()
+        out = torch.empty_like(g)
+        L.check(L.lib().mi_ew_bf16(g.data_ptr(), y.data_ptr(), out.data_ptr(), g.numel(), 2, L.stream_ptr()), "mi_ew_bf16 relu'")
+        return out, out
+
+
+def _relu(x):
+    """NCHW (channels_last) bf16 -> same layout"""
+    return _EwRelu.apply(_nhwc_view(x)).permute(0, 3, 1, 2)
+
+
+def _add_relu(a, b):
+    return _EwAddRelu.apply(_nhwc_view(a), _nhwc_view(b)).permute(0, 3, 1, 2)
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xh):          # xh bf16 [N,H,W,C] contiguous
+        N, H, W, Cc = xh.shape
+        y = torch.empty(N, (H + 1) // 2, (W + 1) // 2, Cc, dtype=torch.bfloat16, device=xh.device)
+        L.check(L.lib().mi_maxpool3x3s2_fwd(xh.data_ptr(), Cc, y.data_ptr(), Cc, N, H, W, Cc, L.stream_ptr()), "maxpool fwd")
+        ctx.save_for_backward(xh)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (xh,) = ctx.saved_tensors
+        N, H, W, Cc = xh.shape
+        g = g.contiguous()
+        dx = torch.empty_like(xh)
+        L.check(L.lib().mi_maxpool3x3s2_bwd(xh.data_ptr(), Cc, g.data_ptr(), Cc, dx.data_ptr(), Cc, 0, N, H, W, Cc,
+                                            L.stream_ptr()), "maxpool bwd")
+        return dx
+
+
+class Conv2d(nn.Module):
+    """detectron2.layers.Conv2d(..., bias=False, norm=FrozenBatchNorm2d) as the reference's configs build it"""
+
+    def __init__(self, cin, cout, kernel_size, stride=1, padding=0):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, kernel_size, kernel_size))
+        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")      # c2_msra_fill
+        self.norm = FrozenBatchNorm2d(cout)
+        self.stride, self.padding = stride, padding
+
+    def forward(self, x):
+        scale, shift = self.norm.affine()
+        w = self.weight * scale.view(-1, 1, 1, 1)          # the frozen affine folded into the weight image / bias
+        if not self.weight.requires_grad:
+            with torch.no_grad():
+                return torch.ops.mi355.conv2d(x, w, shift, self.stride, self.padding)
+        return torch.ops.mi355.conv2d(x, w, shift, self.stride, self.padding)
+
+
+class BasicStem(nn.Module):
+    def __init__(self, cin=3, cout=64):
+        super().__init__()
+        self.conv1 = Conv2d(cin, cout, 7, stride=2, padding=3)
+        self.out_channels = cout
+
+    def forward(self, x):
+        """x: fp32 NCHW image (already normalised).  7x7 s2 conv + frozen norm + ReLU + max-pool."""
+        w7 = self.conv1.weight
+        if w7.requires_grad and torch.is_grad_enabled():
+            raise L.MI355Error("ResNet stem: MODEL.BACKBONE.FREEZE_AT >= 1 is required (the 7x7 stem runs forward-only, "
+                               "as in every configuration of the reference)")
+        with torch.no_grad():
+            scale, shift = self.conv1.norm.affine()
+            N, Cin, H, W = x.shape
+            Cout = w7.shape[0]
+            He, We = H + (H & 1), W + (W & 1)
+            if (He, We) != (H, W):       # an odd border: one more zero row / column = the conv's own zero padding
+                xp = x.new_zeros(N, Cin, He, We)
+                xp[:, :, :H, :W] = x
+                x = xp
+            x = x.float().contiguous()
+            s2d = torch.empty(N, He // 2, We // 2, 16, dtype=torch.bfloat16, device=x.device)
+            L.check(L.lib().mi_focus_pack(x.data_ptr(), N, He, We, s2d.data_ptr(), 16, L.stream_ptr()), "mi_focus_pack")
+            # 7x7 kernel -> 8x8 with a zero first row / column -> [Cout][q = py + 2 px][c] x 4x4 taps (ay, ax in -2..1)
+            w8 = w7.new_zeros(Cout, Cin, 8, 8)
+            w8[:, :, 1:, 1:] = w7 * scale.view(-1, 1, 1, 1)
+            w4 = w8.view(Cout, Cin, 4, 2, 4, 2).permute(0, 5, 3, 1, 2, 4).reshape(Cout, 4 * Cin, 4, 4)   # ch = (px*2+py)*3+c
+            wf = torch.empty(16 * 16 * Cout, dtype=torch.bfloat16, device=x.device)
+            L.check(L.lib().mi_pack_conv_weight(w4.contiguous().data_ptr(), Cout, 4 * Cin, 4, 4, wf.data_ptr(), 16, Cout,
+                                                None, 0, 0, L.stream_ptr()), "mi_pack_conv_weight (stem)")
+            y = torch.empty(N, He // 2, We // 2, Cout, dtype=torch.bfloat16, device=x.device)
+            taps = [(ay - 2, ax - 2, ay * 4 + ax) for ay in range(4) for ax in range(4)]
+            b32 = shift.float().contiguous()
+            _run_conv(_conv_desc(s2d.data_ptr(), 16, N, He // 2, We // 2, wf, 16, y.data_ptr(), Cout, He // 2, We // 2, Cout,
+                                 Cout, taps, bias=b32), "mi_conv2d (7x7 stem as 4x4 over space-to-depth)")
+            y = _EwRelu.apply(y)
+            return _MaxPool.apply(y).permute(0, 3, 1, 2)
+
+
+class BottleneckBlock(nn.Module):
+    def __init__(self, cin, cout, bottleneck_channels, stride=1, stride_in_1x1=False):
+        super().__init__()
+        self.shortcut = Conv2d(cin, cout, 1, stride=stride) if cin != cout else None
+        s1, s3 = (stride, 1) if stride_in_1x1 else (1, stride)
+        self.conv1 = Conv2d(cin, bottleneck_channels, 1, stride=s1)
+        self.conv2 = Conv2d(bottleneck_channels, bottleneck_channels, 3, stride=s3, padding=1)
+        self.conv3 = Conv2d(bottleneck_channels, cout, 1)
+        self.stride = stride
+
+    def forward(self, x):
+        out = _relu(self.conv1(x))
+        out = _relu(self.conv2(out))
+        out = self.conv3(out)
+        sc = self.shortcut(x) if self.shortcut is not None else x
+        return _add_relu(out, sc)
+
+
+class ResNet(Backbone):
+    def __init__(self, depth=50, out_features=("res5",), freeze_at=2, stride_in_1x1=False):
+        super().__init__()
+        blocks = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}[depth]
+        self.stem = BasicStem(3, 64)
+        self._out_features = list(out_features)
+        self._shapes = {"stem": ShapeSpec(channels=64, stride=4)}
+        cin, bc, cout, stride = 64, 64, 256, 4
+        self.stage_names = []
+        for i, nb in enumerate(blocks):
+            name = f"res{i + 2}"
+            first = 1 if i == 0 else 2
+            stage = nn.Sequential(*[BottleneckBlock(cin if k == 0 else cout, cout, bc, stride=first if k == 0 else 1,
+                                                    stride_in_1x1=stride_in_1x1) for k in range(nb)])
+            self.add_module(name, stage)
+            self.stage_names.append(name)
+            stride *= first
+            self._shapes[name] = ShapeSpec(channels=cout, stride=stride)
+            cin, bc, cout = cout, bc * 2, cout * 2
+        self.freeze(freeze_at)
+
+    def freeze(self, freeze_at):
+        """detectron2 ResNet.freeze: 1 = stem, 2 = stem + res2, ..."""
+        if freeze_at >= 1:
+            for p in self.stem.parameters():
+                p.requires_grad = False
+        for idx, name in enumerate(self.stage_names, start=2):
+            if freeze_at >= idx:
+                for p in getattr(self, name).parameters():
+                    p.requires_grad = False
+        return self
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise L.MI355Error("ResNet: the MI355X path needs device tensors (no CPU fallback)")
+        outs = {}
+        x = self.stem(x)
+        if "stem" in self._out_features:
+            outs["stem"] = x
+        for name in self.stage_names:
+            x = getattr(self, name)(x)
+            if name in self._out_features:
+                outs[name] = x
+        return outs
+
+    def output_shape(self):
+        return {k: self._shapes[k] for k in self._out_features}
+
+    @property
+    def size_divisibility(self):
+        return 0
+
+
+@BACKBONE_REGISTRY.register()
+def build_resnet_backbone(cfg, input_shape=None):
+    r = cfg.MODEL.RESNETS
+    if r.NORM != "FrozenBN":
+        raise NotImplementedError("build_resnet_backbone: MODEL.RESNETS.NORM FrozenBN (the reference's DETR / SparseInst configs)")
+    return ResNet(depth=r.DEPTH, out_features=r.OUT_FEATURES, freeze_at=cfg.MODEL.BACKBONE.FREEZE_AT,
+                  stride_in_1x1=r.STRIDE_IN_1X1)

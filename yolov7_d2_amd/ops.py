@@ -73,9 +73,7 @@ class _ConvGeom:
         self.Cout, cin_w, self.k, kw = w_shape
         if cin_w != self.Cin or kw != self.k or self.k not in (1, 3) or stride not in (1, 2) or padding != (self.k - 1) // 2:
             raise L.MI355Error(f"mi355 conv: unsupported geometry weight {tuple(w_shape)} stride {stride} padding {padding} "
-                               "(served: 1x1 and 3x3, stride 1 or 2, 'same' padding, groups 1)")
-        if stride == 2 and self.k != 3:
-            raise L.MI355Error("mi355 conv: stride 2 is implemented for 3x3 kernels")
+                               "(served: 1x1 and 3x3, stride 1 or 2, padding (k-1)/2, groups 1)")
         self.s, self.pad = stride, padding
         self.Ho = (self.H + 2 * padding - self.k) // stride + 1
         self.Wo = (self.W + 2 * padding - self.k) // stride + 1
@@ -114,6 +112,11 @@ class _ConvGeom:
             taps = [(pad - r, pad - s, r * k + s) for r in range(k) for s in range(k)]
             _run_conv(_conv_desc(dyh.data_ptr(), self.CoutP, self.N, self.Ho, self.Wo, wd, self.CoutP, dx.data_ptr(),
                                  self.CinP, self.H, self.W, self.Cin, self.CinP, taps), "mi_conv2d (dgrad)")
+            return
+        if k == 1:      # 1x1 stride 2 (ResNet shortcut): only the even pixels receive a gradient; dx arrives zeroed
+            _run_conv(_conv_desc(dyh.data_ptr(), self.CoutP, self.N, self.Ho, self.Wo, wd, self.CoutP, dx.data_ptr(),
+                                 self.CinP, self.H, self.W, self.Cin, self.CinP, [(0, 0, 0)], out_stride=2, oy=0, ox=0,
+                                 gridH=(self.H + 1) // 2, gridW=(self.W + 1) // 2), "mi_conv2d (dgrad 1x1 s2)")
             return
         cls_taps = {0: [(1, 0)], 1: [(0, 1), (2, 0)]}   # output-pixel parity -> [(kernel row, dy offset)]
         for py in (0, 1):
