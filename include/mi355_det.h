@@ -349,6 +349,18 @@ int mi_mha_fwd(const void* q, const void* k, const void* v, const uint8_t* key_p
 int mi_mha_bwd(const void* q, const void* k, const void* v, const uint8_t* key_padding_mask, const void* o,
                const float* lse, const void* dout, float* delta_ws, void* dq, void* dk, void* dv, int B, int H,
                int Lq, int Lk, int E, float scale, mi_stream_t s);
+/* the same with attention-weight dropout (nn.MultiheadAttention(dropout=p) in training mode, detr_backbone.py:140):
+ * survivors scaled by 1/(1-p); the keep mask is a pure function of (seed, ((b*H+h)*Lq+q)*Lk+key), recomputed by the
+ * backward - pass the SAME p and seed to both.  mi_mha_dropout_mask writes that mask (uint8 [B][H][Lq][Lk]) for tests. */
+int mi_mha_fwd_dropout(const void* q, const void* k, const void* v, const uint8_t* key_padding_mask, void* o, float* lse,
+                       int B, int H, int Lq, int Lk, int E, float scale, float drop_p, uint64_t seed, mi_stream_t s);
+int mi_mha_bwd_dropout(const void* q, const void* k, const void* v, const uint8_t* key_padding_mask, const void* o,
+                       const float* lse, const void* dout, float* delta_ws, void* dq, void* dk, void* dv, int B, int H,
+                       int Lq, int Lk, int E, float scale, float drop_p, uint64_t seed, mi_stream_t s);
+int mi_mha_dropout_mask(uint8_t* out, int B, int H, int Lq, int Lk, float drop_p, uint64_t seed, mi_stream_t s);
+/* elementwise dropout of a bf16 tensor (F.dropout of detr_backbone.py:147-150,163-167,...): out[i] = keep(seed, i) ?
+ * x[i] / (1-p) : 0; applying it with the same (p, seed) to the output gradient IS the backward. n %% 8 == 0. */
+int mi_dropout_bf16(const void* x, void* out, int64_t n, float drop_p, uint64_t seed, mi_stream_t s);
 
 /* ---- row-wise ops of DETR's transformer layers (detr_backbone.py:135-278) -------------------
  * nn.LayerNorm(E) forward / backward over bf16 [T][E] token rows (fp32 gamma/beta/mean/rstd), eps 1e-5;

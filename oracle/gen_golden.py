@@ -270,6 +270,60 @@ def gold_detr():
     print("detr_module:", {k: v.shape for k, v in res.items()})
 
 
+def gold_detr_meta():
+    """the reference's own `Detr` META ARCH (meta_arch/detr.py:33-279) executed by path: its preprocess_image /
+    MaskedBackboneTraceFriendly / Joiner / DETR / Transformer / SetCriterion / HungarianMatcher / inference, around the
+    CPU restatement of detectron2's ResNet-50 (resnet_oracle.R50Module standing in for the un-vendored
+    detectron2.modeling.build_backbone; ImageList / Instances / Boxes / detector_postprocess from the product's d2 shim,
+    which restates the same un-vendored classes).  2 encoder + 2 decoder layers, 30 queries, dropout 0 (no parity target
+    exists for torch's dropout stream).  Stores the training loss dict and the eval-mode logits / boxes / detections."""
+    import importlib
+    import resnet_oracle as R
+    from gen_golden_inputs import seeded_tensor_dict, synth_detr_batch
+    root = os.path.dirname(HERE)
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from yolov7_d2_amd import d2shim, detr_r50_cfg
+    ref_loader.load()
+    det = ref_loader.load_detr()
+    det.build_backbone = lambda cfg: R.R50Module(50, cfg.MODEL.RESNETS.OUT_FEATURES, cfg.MODEL.RESNETS.STRIDE_IN_1X1)
+    det.ImageList, det.Instances, det.Boxes = d2shim.ImageList, d2shim.Instances, d2shim.Boxes
+    det.detector_postprocess = d2shim.detector_postprocess
+    cfg = detr_r50_cfg(device="cpu")
+    cfg.MODEL.DETR.ENC_LAYERS, cfg.MODEL.DETR.DEC_LAYERS, cfg.MODEL.DETR.NUM_OBJECT_QUERIES = 2, 2, 30
+    cfg.MODEL.DETR.DROPOUT = 0.0
+    cfg.MODEL.YOLO.CONF_THRESHOLD = 0.02
+    torch.manual_seed(0)
+    model = det.Detr(cfg)
+    sd = model.state_dict()
+    model.load_state_dict(seeded_tensor_dict({k: v.shape for k, v in sd.items()}, seed=203), strict=False)
+    batch = synth_detr_batch()
+    inputs = [dict(image=b["image"], instances=d2shim.Instances(b["size"], gt_boxes=d2shim.Boxes(b["boxes"]),
+                                                                gt_classes=b["classes"])) for b in batch]
+    model.train()
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):       # (the reference prints the loss dict every step)
+        losses = model(inputs)
+    res = {"loss:" + k: np.float32(v.detach()) for k, v in losses.items()}
+    res["loss_keys"] = np.array(sorted(losses.keys()))
+    model.eval()
+    with torch.no_grad():
+        images = model.preprocess_image(inputs)
+        out = model.detr(images)
+        dets = model(inputs)
+    res["eval_logits"] = out["pred_logits"].numpy()
+    res["eval_boxes"] = out["pred_boxes"].numpy()
+    for i, d_ in enumerate(dets):
+        inst = d_["instances"]
+        res[f"det{i}_boxes"] = inst.pred_boxes.tensor.numpy()
+        res[f"det{i}_scores"] = inst.scores.numpy()
+        res[f"det{i}_classes"] = inst.pred_classes.numpy()
+    res["state_keys"] = np.array(sorted(sd.keys()))
+    np.savez_compressed(os.path.join(OUT, "detr_meta.npz"), **res)
+    print("detr_meta:", {k: (v.shape if hasattr(v, "shape") else v) for k, v in res.items() if not k.startswith("state")},
+          "ndet", [len(d_["instances"]) for d_ in dets])
+
+
 def gold_transformer():
     """the reference's own Transformer (backbone/detr_backbone.py:25-65): 2 encoder + 2 decoder layers, d_model 256,
     8 heads, ffn 512, return_intermediate_dec, eval mode, fp32; post- and pre-norm"""
@@ -311,4 +365,5 @@ if __name__ == "__main__":
     gold_transformer()
     gold_pos_embed()
     gold_detr()
+    gold_detr_meta()
     gold_set_criterion()

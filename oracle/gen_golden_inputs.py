@@ -96,3 +96,43 @@ class SimpleNested:
 
     def decompose(self):
         return self.tensors, self.mask
+
+
+def seeded_tensor_dict(shapes, seed=72):
+    """seeded values for a {key: shape} table (sorted key order), the rule of seeded_state_dict plus detectron2 ResNet
+    entries: conv weights N(0, sqrt(2 / fan_out)), frozen-norm weight in [0.5, 1.5], running_var in [0.5, 1.5]"""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k in sorted(shapes):
+        shp = tuple(shapes[k])
+        if k.endswith("empty_weight"):      # SetCriterion's class-weight buffer (ones, eos_coef last): a constant, not a weight
+            continue
+        if k.endswith("running_var") or (".norm.weight" in k and ".backbone." in k):
+            out[k] = 0.5 + torch.rand(*shp, generator=g)
+        elif len(shp) == 4 and ".backbone." in k:
+            out[k] = torch.randn(*shp, generator=g) * (2.0 / (shp[0] * shp[2] * shp[3])) ** 0.5
+        elif "norm" in k and k.endswith("weight"):
+            out[k] = 1 + 0.1 * torch.randn(*shp, generator=g)
+        elif len(shp) == 2:
+            out[k] = (0.02 if shp[1] > 1024 else 0.05) * torch.randn(*shp, generator=g)
+        elif len(shp) == 0:
+            out[k] = torch.zeros(shp, dtype=torch.long)
+        else:
+            out[k] = 0.02 * torch.randn(*shp, generator=g)
+    return out
+
+
+def synth_detr_batch(seed=201, sizes=((160, 200), (128, 224)), ncls=80):
+    """batched_inputs of the Detr meta-arch: float images 0..255 of DIFFERENT sizes (padding masks), 2-4 ground truths
+    each as (XYXY absolute boxes, classes)"""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for (h, w) in sizes:
+        img = torch.randint(0, 256, (3, h, w), generator=g).float()
+        n = int(torch.randint(2, 5, (1,), generator=g))
+        wh = 20 + torch.rand(n, 2, generator=g) * torch.tensor([w * 0.5, h * 0.5])
+        xy = torch.rand(n, 2, generator=g) * (torch.tensor([w, h]) - wh)
+        boxes = torch.cat([xy, xy + wh], 1)
+        cls = torch.randint(0, ncls, (n,), generator=g)
+        out.append(dict(image=img, boxes=boxes, classes=cls, size=(h, w)))
+    return out

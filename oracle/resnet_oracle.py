@@ -59,3 +59,40 @@ def forward(sd, x, depth=50, stride_in_1x1=False, quant=None):
             x = q(F.relu(out + sc))
         outs[f"res{i + 2}"] = x
     return outs
+
+
+class _Holder(torch.nn.Module):
+    pass
+
+
+class R50Module(torch.nn.Module):
+    """the restatement as an nn.Module tree with detectron2's parameter / buffer names (stem.conv1.weight,
+    res3.0.conv2.norm.running_var ...) and the Backbone surface the reference's MaskedBackbone uses (forward ->
+    {name: feature}, output_shape() -> {name: .channels / .stride}); stands in for detectron2.modeling.build_backbone when
+    the reference's own Detr is executed by path (oracle/gen_golden.py)"""
+
+    def __init__(self, depth=50, out_features=("res2", "res3", "res4", "res5"), stride_in_1x1=False):
+        super().__init__()
+        self.depth, self.out_features, self.stride_in_1x1 = depth, list(out_features), stride_in_1x1
+        for k, v in init_state_dict(depth, 0).items():
+            parts = k.split(".")
+            m = self
+            for name in parts[:-1]:
+                if not hasattr(m, name):
+                    m.add_module(name, _Holder())
+                m = getattr(m, name)
+            if ".norm." in k:
+                m.register_buffer(parts[-1], v.clone())
+            else:
+                m.register_parameter(parts[-1], torch.nn.Parameter(v.clone()))
+
+    def forward(self, x):
+        sd = dict(list(self.named_parameters()) + list(self.named_buffers()))
+        outs = forward(sd, x, self.depth, self.stride_in_1x1)
+        return {k: outs[k] for k in self.out_features}
+
+    def output_shape(self):
+        import types
+        ch = {"res2": 256, "res3": 512, "res4": 1024, "res5": 2048}
+        st = {"res2": 4, "res3": 8, "res4": 16, "res5": 32}
+        return {k: types.SimpleNamespace(channels=ch[k], stride=st[k]) for k in self.out_features}

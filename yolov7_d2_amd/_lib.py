@@ -182,6 +182,11 @@ _PROTOS = {
     "mi_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "mi_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mi_ew_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i, _vp]),
+    "mi_dropout_bf16": (C.c_int, [_vp, _vp, _i64, _f, C.c_uint64, _vp]),
+    "mi_mha_fwd_dropout": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, C.c_uint64, _vp]),
+    "mi_mha_bwd_dropout": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f,
+                                     C.c_uint64, _vp]),
+    "mi_mha_dropout_mask": (C.c_int, [_vp, _i, _i, _i, _i, _f, C.c_uint64, _vp]),
     "mi_iou_loss_v6": (C.c_int, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "mi_batched_nms": (C.c_int, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_abi_sizeof": (C.c_int, [_i]),

@@ -140,7 +140,44 @@ def add_yolo_config(cfg):
                            "OUT_FEATURES": ["dark3", "dark4", "dark5"], "WEIGHTS": "", "DEPTH_WISE": False})
     _C.INPUT.MOSAIC_AND_MIXUP = CN({"ENABLED": False, "DEBUG_VIS": False, "ENABLE_MIXUP": False,
                                     "DISABLE_AT_ITER": 120000})
+    # DETR (yolov7/config.py:199-245)
+    _C.MODEL.DETR = CN({
+        "NUM_CLASSES": 80, "FROZEN_WEIGHTS": "", "DEFORMABLE": False, "USE_FOCAL_LOSS": False,
+        "CENTERED_POSITION_ENCODIND": False, "CLS_WEIGHT": 1.0, "NUM_FEATURE_LEVELS": 1, "GIOU_WEIGHT": 2.0,
+        "L1_WEIGHT": 5.0, "DEEP_SUPERVISION": True, "NO_OBJECT_WEIGHT": 0.1, "WITH_BOX_REFINE": False, "TWO_STAGE": False,
+        "DECODER_BLOCK_GRAD": True, "ATTENTION_TYPE": "DETR", "NHEADS": 8, "DROPOUT": 0.1, "DIM_FEEDFORWARD": 2048,
+        "ENC_LAYERS": 6, "DEC_LAYERS": 6, "PRE_NORM": False, "BBOX_EMBED_NUM_LAYERS": 3, "HIDDEN_DIM": 256,
+        "NUM_OBJECT_QUERIES": 100, "NUM_QUERY_POSITION": 300, "NUM_QUERY_PATTERN": 3, "SPATIAL_PRIOR": "learned",
+    })
+    _C.MODEL.BACKBONE.SIMPLE = False
+    _C.MODEL.BACKBONE.STRIDE = 1
+    _C.MODEL.BACKBONE.CHANNEL = 0
+    _C.SOLVER.BACKBONE_MULTIPLIER = 0.1
     return _C
+
+
+def detr_r50_cfg(device="cuda", **over):
+    """the settings of configs/coco/detr/detr_256_6_6_torchvision.yaml without needing the file"""
+    cfg = add_yolo_config(get_cfg())
+    cfg.MODEL.DEVICE = device
+    cfg.MODEL.META_ARCHITECTURE = "Detr"
+    cfg.MODEL.PIXEL_MEAN = [123.675, 116.280, 103.530]
+    cfg.MODEL.PIXEL_STD = [58.395, 57.120, 57.375]
+    cfg.MODEL.MASK_ON = False
+    cfg.MODEL.BACKBONE.NAME = "build_resnet_backbone"
+    cfg.MODEL.RESNETS.DEPTH = 50
+    cfg.MODEL.RESNETS.STRIDE_IN_1X1 = False
+    cfg.MODEL.RESNETS.OUT_FEATURES = ["res2", "res3", "res4", "res5"]
+    cfg.MODEL.DETR.GIOU_WEIGHT, cfg.MODEL.DETR.L1_WEIGHT = 2.0, 5.0
+    cfg.MODEL.DETR.NUM_OBJECT_QUERIES = 100
+    cfg.MODEL.DETR.ENC_LAYERS = cfg.MODEL.DETR.DEC_LAYERS = 6
+    cfg.MODEL.DETR.HIDDEN_DIM = 256
+    cfg.SOLVER.OPTIMIZER = "ADAMW"
+    cfg.SOLVER.BASE_LR = 0.0001
+    cfg.INPUT.FORMAT = "RGB"
+    for k, v in over.items():
+        cfg.merge_from_list([k, v])
+    return cfg
 
 
 def get_yolox_cfg(config_file=None, opts=()):

@@ -55,6 +55,16 @@ __device__ __forceinline__ bf16x8 pack8(const float* f) {
 // 1-ulp hardware reciprocal instead of the ~10-instruction IEEE division: the consumers round to bf16 anyway
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
+// counter-based random bits (splitmix64 of seed-keyed index): dropout masks are pure functions of (seed, element index),
+// so a backward kernel recomputes the mask of its forward instead of loading it
+__device__ __forceinline__ unsigned mi_rng32(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (unsigned)(z >> 32);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

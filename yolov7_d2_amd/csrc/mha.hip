@@ -52,7 +52,19 @@ struct MhaK {
   __bf16* dv;
   int B, H, Lq, Lk, E;
   float scale;
+  // attention dropout (nn.MultiheadAttention(dropout=p) drops attention WEIGHTS, detr_backbone.py:140,200-202): a
+  // weight survives iff mi_rng(seed, ((b*H + h)*Lq + q)*Lk + key) >= drop_thr; survivors are scaled by drop_scale =
+  // 1/(1-p).  The mask is a pure function of (seed, index): the backward kernels recompute it, nothing is stored.
+  unsigned drop_thr;   // 0 = no dropout
+  float drop_scale;
+  unsigned long long seed;
 };
+
+__device__ __forceinline__ float mha_keep(const MhaK& p, int b, int h, int q, int key) {
+  if (p.drop_thr == 0u) return 1.f;
+  const unsigned long long idx = (((unsigned long long)(b * p.H + h) * p.Lq + q) * p.Lk + key);
+  return mi_rng32(p.seed, idx) >= p.drop_thr ? p.drop_scale : 0.f;
+}
 
 // LDS tile of 32 rows x 32 d (64-byte rows), 16-byte chunks XOR-swizzled by (row >> 2) & 3 for the direct b128
 // fragment reads and -- equivalently for 32-byte groups -- (row >> 2) & 1 for the transpose reads.
@@ -140,8 +152,8 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaK p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float pe = (m_new == -INFINITY) ? 0.f : __expf(sv[e] - m_new);
-      psum += pe;
-      pf[e] = (__bf16)pe;
+      psum += pe;           // the softmax normaliser is taken BEFORE the dropout, as F.multi_head_attention_forward does
+      pf[e] = (__bf16)(pe * mha_keep(p, b, h, myq, k0 + 16 * (e >> 2) + 4 * g + (e & 3)));
     }
     psum += __shfl_xor(psum, 16, 64);
     psum += __shfl_xor(psum, 32, 64);
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const MhaK p) {
         const int key = k0 + 16 * a + 4 * g + r;
         const bool dead = key >= p.Lk || (p.mask && p.mask[(size_t)b * p.Lk + key]) || myq >= p.Lq;
         const float pe = (dead || lse == -INFINITY) ? 0.f : __expf(s[r] * p.scale - lse);
-        dsf[a * 4 + r] = (__bf16)(pe * (dp[r] - dl) * p.scale);
+        dsf[a * 4 + r] = (__bf16)(pe * (dp[r] * mha_keep(p, b, h, myq, key) - dl) * p.scale);
       }
     }
 #pragma unroll
@@ -306,8 +318,9 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const MhaK p) {
       for (int r = 0; r < 4; ++r) {
         const int ql = 16 * a + 4 * g + r;
         const float pe = kdead ? 0.f : __expf(s[r] * p.scale - Ls[cur][ql]);
-        pf[a * 4 + r] = (__bf16)pe;
-        dsf[a * 4 + r] = (__bf16)(pe * (dp[r] - Dl[cur][ql]) * p.scale);
+        const float keep = mha_keep(p, b, h, it * 32 + ql, mykey);
+        pf[a * 4 + r] = (__bf16)(pe * keep);
+        dsf[a * 4 + r] = (__bf16)(pe * (dp[r] * keep - Dl[cur][ql]) * p.scale);
       }
     }
 #pragma unroll
@@ -338,13 +351,30 @@ static int mha_check(const void* q, const void* k, const void* v, int B, int H, 
   return MI_OK;
 }
 
+static int mha_set_dropout(MhaK* p, float drop_p, unsigned long long seed) {
+  MI_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "mha: dropout p %f", drop_p);
+  p->seed = seed;
+  p->drop_thr = drop_p > 0.f ? (unsigned)((double)drop_p * 4294967296.0) : 0u;
+  if (drop_p > 0.f && p->drop_thr == 0u) p->drop_thr = 1u;
+  p->drop_scale = 1.f / (1.f - drop_p);
+  return MI_OK;
+}
+
 extern "C" int mi_mha_fwd(const void* q, const void* k, const void* v, const uint8_t* key_padding_mask, void* o,
                           float* lse, int B, int H, int Lq, int Lk, int E, float scale, mi_stream_t st) {
+  return mi_mha_fwd_dropout(q, k, v, key_padding_mask, o, lse, B, H, Lq, Lk, E, scale, 0.f, 0ull, st);
+}
+
+extern "C" int mi_mha_fwd_dropout(const void* q, const void* k, const void* v, const uint8_t* key_padding_mask, void* o,
+                                  float* lse, int B, int H, int Lq, int Lk, int E, float scale, float drop_p,
+                                  uint64_t seed, mi_stream_t st) {
   int rc = mha_check(q, k, v, B, H, Lq, Lk, E);
   if (rc) return rc;
   MI_REQUIRE(o, "mha_fwd: null output");
   MhaK p;
   memset(&p, 0, sizeof(p));
+  rc = mha_set_dropout(&p, drop_p, seed);
+  if (rc) return rc;
   p.q = (const __bf16*)q; p.k = (const __bf16*)k; p.v = (const __bf16*)v; p.mask = key_padding_mask;
   p.o = (__bf16*)o; p.lse = lse; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.E = E; p.scale = scale;
   hipLaunchKernelGGL(mha_fwd_kernel, dim3(mi_cdiv(Lq, 64), B * H), dim3(256), 0, (hipStream_t)st, p);
@@ -355,11 +385,41 @@ extern "C" int mi_mha_fwd(const void* q, const void* k, const void* v, const uin
 extern "C" int mi_mha_bwd(const void* q, const void* k, const void* v, const uint8_t* key_padding_mask, const void* o,
                           const float* lse, const void* dout, float* delta_ws, void* dq, void* dk, void* dv, int B,
                           int H, int Lq, int Lk, int E, float scale, mi_stream_t st) {
+  return mi_mha_bwd_dropout(q, k, v, key_padding_mask, o, lse, dout, delta_ws, dq, dk, dv, B, H, Lq, Lk, E, scale, 0.f,
+                            0ull, st);
+}
+
+// the keep mask itself (uint8 [B][H][Lq][Lk]) - for tests of the dropout path against a reference that applies the
+// same mask
+__global__ __launch_bounds__(256) void mha_mask_kernel(const MhaK p, uint8_t* out, long long n) {
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  if (i >= n) return;
+  out[i] = mi_rng32(p.seed, (unsigned long long)i) >= p.drop_thr ? 1 : 0;
+}
+extern "C" int mi_mha_dropout_mask(uint8_t* out, int B, int H, int Lq, int Lk, float drop_p, uint64_t seed,
+                                   mi_stream_t st) {
+  MI_REQUIRE(out && B > 0 && H > 0 && Lq > 0 && Lk > 0, "mha_dropout_mask: args");
+  MhaK p;
+  memset(&p, 0, sizeof(p));
+  int rc = mha_set_dropout(&p, drop_p, seed);
+  if (rc) return rc;
+  const long long n = (long long)B * H * Lq * Lk;
+  hipLaunchKernelGGL(mha_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)st, p, out, n);
+  MI_CHECK_LAUNCH("mha_dropout_mask");
+  return MI_OK;
+}
+
+extern "C" int mi_mha_bwd_dropout(const void* q, const void* k, const void* v, const uint8_t* key_padding_mask,
+                                  const void* o, const float* lse, const void* dout, float* delta_ws, void* dq, void* dk,
+                                  void* dv, int B, int H, int Lq, int Lk, int E, float scale, float drop_p, uint64_t seed,
+                                  mi_stream_t st) {
   int rc = mha_check(q, k, v, B, H, Lq, Lk, E);
   if (rc) return rc;
   MI_REQUIRE(o && lse && dout && delta_ws && dq && dk && dv, "mha_bwd: null");
   MhaK p;
   memset(&p, 0, sizeof(p));
+  rc = mha_set_dropout(&p, drop_p, seed);
+  if (rc) return rc;
   p.q = (const __bf16*)q; p.k = (const __bf16*)k; p.v = (const __bf16*)v; p.mask = key_padding_mask;
   p.o = (__bf16*)o; p.lse = (float*)lse; p.dout = (const __bf16*)dout; p.delta = delta_ws; p.dq = (__bf16*)dq;
   p.dk = (__bf16*)dk; p.dv = (__bf16*)dv; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.E = E; p.scale = scale;

@@ -74,9 +74,9 @@ except Exception:
         def to(self, device):
             return Boxes(self.tensor.to(device))
 
-        def scale(self, sx, sy):
-            self.tensor[:, 0::2] *= sx
-            self.tensor[:, 1::2] *= sy
+        def scale(self, scale_x, scale_y):
+            self.tensor[:, 0::2] *= scale_x
+            self.tensor[:, 1::2] *= scale_y
 
         def clip(self, box_size):
             h, w = box_size

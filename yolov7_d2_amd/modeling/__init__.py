@@ -10,3 +10,7 @@ from .transformer import (MultiheadAttention, TransformerEncoderLayer, Transform
                           TransformerDecoder, Transformer)
 from .position_encoding import PositionEmbeddingSine
 from .detr import DETR, MLP
+from .resnet import ResNet, build_resnet_backbone, FrozenBatchNorm2d
+from .box_ops import box_cxcywh_to_xyxy, box_xyxy_to_cxcywh, box_iou, generalized_box_iou
+from .detr_meta import (Detr, Joiner, MaskedBackbone, MaskedBackboneTraceFriendly, NestedTensor, PostProcess,
+                        nested_tensor_from_tensor_list)

@@ -13,7 +13,7 @@ from .. import _lib as L
 
 class _MhaCore(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, mask, num_heads):
+    def forward(ctx, q, k, v, mask, num_heads, drop_p=0.0, seed=0):
         if not q.is_cuda:
             raise L.MI355Error("mha_core: the MI355X path needs device tensors (no CPU fallback)")
         Lq, B, E = q.shape
@@ -23,10 +23,11 @@ class _MhaCore(torch.autograd.Function):
         o = torch.empty_like(q)
         lse = torch.empty(B, num_heads, Lq, dtype=torch.float32, device=q.device)
         scale = 1.0 / math.sqrt(E // num_heads)
-        L.check(L.lib().mi_mha_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), L.ptr(m), o.data_ptr(), lse.data_ptr(), B,
-                                   num_heads, Lq, Lk, E, scale, L.stream_ptr()), "mi_mha_fwd")
+        L.check(L.lib().mi_mha_fwd_dropout(q.data_ptr(), k.data_ptr(), v.data_ptr(), L.ptr(m), o.data_ptr(), lse.data_ptr(),
+                                           B, num_heads, Lq, Lk, E, scale, float(drop_p), int(seed), L.stream_ptr()),
+                "mi_mha_fwd")
         ctx.save_for_backward(q, k, v, m, o, lse)
-        ctx.num_heads, ctx.scale = num_heads, scale
+        ctx.num_heads, ctx.scale, ctx.drop = num_heads, scale, (float(drop_p), int(seed))
         return o
 
     @staticmethod
@@ -37,11 +38,14 @@ class _MhaCore(torch.autograd.Function):
         do = do.to(torch.bfloat16).contiguous()
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         delta = torch.empty_like(lse)
-        L.check(L.lib().mi_mha_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), L.ptr(m), o.data_ptr(), lse.data_ptr(),
-                                   do.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B,
-                                   ctx.num_heads, Lq, Lk, E, ctx.scale, L.stream_ptr()), "mi_mha_bwd")
-        return dq, dk, dv, None, None
+        L.check(L.lib().mi_mha_bwd_dropout(q.data_ptr(), k.data_ptr(), v.data_ptr(), L.ptr(m), o.data_ptr(), lse.data_ptr(),
+                                           do.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B,
+                                           ctx.num_heads, Lq, Lk, E, ctx.scale, ctx.drop[0], ctx.drop[1], L.stream_ptr()),
+                "mi_mha_bwd")
+        return dq, dk, dv, None, None, None, None
 
 
-def mha_core(q, k, v, key_padding_mask=None, num_heads=8):
-    return _MhaCore.apply(q, k, v, key_padding_mask, num_heads)
+def mha_core(q, k, v, key_padding_mask=None, num_heads=8, dropout_p=0.0, seed=0):
+    """dropout_p > 0: attention-weight dropout (training mode of nn.MultiheadAttention(dropout=p)); the mask is a pure
+    function of `seed`, recomputed by the backward kernels"""
+    return _MhaCore.apply(q, k, v, key_padding_mask, num_heads, dropout_p, seed)

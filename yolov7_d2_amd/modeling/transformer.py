@@ -9,9 +9,12 @@ same forward signatures.  Every op runs in libmi355det:
   * attention core  -> mi_mha_fwd / mi_mha_bwd (fused MFMA attention, key-padding mask)
   * nn.LayerNorm    -> mi_layernorm_fwd / bwd
   * residual / ReLU -> mi_ew_bf16
-Tokens are bf16 [L, B, E] (sequence first, as the reference passes them).  Dropout: the reference trains with
-p = 0.1 (torch RNG stream: no parity target exists for it); this layer implements p = 0 / eval semantics and raises
-for p > 0 in training mode.
+  * dropout (p = 0.1 in the reference's configs, yolov7/config.py:228) -> mi_dropout_bf16 for the residual / FFN
+    dropouts and a mask inside the fused attention kernels for nn.MultiheadAttention's attention-weight dropout.  Masks
+    are counter-based (a pure function of a per-call seed drawn from torch's default generator, so torch.manual_seed
+    makes a run reproducible) and recomputed in the backward pass; torch's own Philox stream is not reproduced - no
+    parity target exists for it - the tests check the statistics and the exact gradient for the mask in use.
+Tokens are bf16 [L, B, E] (sequence first, as the reference passes them).
 """
 import ctypes as C
 import math
@@ -142,6 +145,36 @@ def _ew(a, b, op):
     return out
 
 
+def _next_seed():
+    """a fresh 62-bit seed from torch's default (CPU) generator"""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))
+
+
+class _DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        L.check(L.lib().mi_dropout_bf16(x.data_ptr(), out.data_ptr(), x.numel(), float(p), int(seed), L.stream_ptr()),
+                "mi_dropout_bf16")
+        ctx.ps = (float(p), int(seed))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        out = torch.empty_like(g)
+        L.check(L.lib().mi_dropout_bf16(g.data_ptr(), out.data_ptr(), g.numel(), ctx.ps[0], ctx.ps[1], L.stream_ptr()),
+                "mi_dropout_bf16 (backward)")
+        return out, None, None
+
+
+def _dropout(x, p, training):
+    if not training or p <= 0:
+        return x
+    return _DropoutFn.apply(x, p, _next_seed())
+
+
 class _AddFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
@@ -187,8 +220,6 @@ class MultiheadAttention(nn.Module):
     def forward(self, query, key, value, attn_mask=None, key_padding_mask=None):
         if attn_mask is not None:
             raise NotImplementedError("attn_mask (the reference always passes None)")
-        if self.training and self.dropout > 0:
-            raise NotImplementedError("attention dropout > 0 in training mode (see module docstring)")
         E = self.embed_dim
         Lq, B, _ = query.shape
         Lk = key.shape[0]
@@ -196,7 +227,8 @@ class MultiheadAttention(nn.Module):
         q = _LinearFn.apply(_tok(query).view(Lq * B, E), w[:E], b[:E]).view(Lq, B, E)
         k = _LinearFn.apply(_tok(key).view(Lk * B, E), w[E:2 * E], b[E:2 * E]).view(Lk, B, E)
         v = _LinearFn.apply(_tok(value).view(Lk * B, E), w[2 * E:], b[2 * E:]).view(Lk, B, E)
-        o = mha_core(q, k, v, key_padding_mask, self.num_heads)
+        drop = self.dropout if self.training else 0.0
+        o = mha_core(q, k, v, key_padding_mask, self.num_heads, drop, _next_seed() if drop > 0 else 0)
         out = _LinearFn.apply(o.reshape(Lq * B, E), self.out_proj.weight, self.out_proj.bias).view(Lq, B, E)
         return out, None
 
@@ -225,26 +257,25 @@ class TransformerEncoderLayer(nn.Module):
     def _ffn(self, x):
         Lx, B, E = x.shape
         h = _LinearFn.apply(x.reshape(Lx * B, E), self.linear1.weight, self.linear1.bias)
-        h = _ReluFn.apply(h)
+        h = _dropout(_ReluFn.apply(h), self.dropout_p, self.training)
         return _LinearFn.apply(h, self.linear2.weight, self.linear2.bias).view(Lx, B, E)
 
     def forward(self, src, src_mask=None, src_key_padding_mask=None, pos=None):
-        if self.training and self.dropout_p > 0:
-            raise NotImplementedError("dropout > 0 in training mode (see module docstring)")
         src = _tok(src)
+        D = lambda t: _dropout(t, self.dropout_p, self.training)
         if self.normalize_before:   # forward_pre (detr_backbone.py:170-182)
             src2 = self._ln(self.norm1, src)
             q = k = self.with_pos_embed(src2, pos)
             src2 = self.self_attn(q, k, value=src2, attn_mask=src_mask, key_padding_mask=src_key_padding_mask)[0]
-            src = _AddFn.apply(src, src2)
+            src = _AddFn.apply(src, D(src2))
             src2 = self._ffn(self._ln(self.norm2, src))
-            return _AddFn.apply(src, src2)
+            return _AddFn.apply(src, D(src2))
         # forward_post (detr_backbone.py:156-168)
         q = k = self.with_pos_embed(src, pos)
         src2 = self.self_attn(q, k, value=src, attn_mask=src_mask, key_padding_mask=src_key_padding_mask)[0]
-        src = self._ln(self.norm1, _AddFn.apply(src, src2))
+        src = self._ln(self.norm1, _AddFn.apply(src, D(src2)))
         src2 = self._ffn(src)
-        return self._ln(self.norm2, _AddFn.apply(src, src2))
+        return self._ln(self.norm2, _AddFn.apply(src, D(src2)))
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -270,30 +301,29 @@ class TransformerDecoderLayer(nn.Module):
 
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                 memory_key_padding_mask=None, pos=None, query_pos=None):
-        if self.training and self.dropout_p > 0:
-            raise NotImplementedError("dropout > 0 in training mode (see module docstring)")
         tgt, memory = _tok(tgt), _tok(memory)
+        D = lambda t: _dropout(t, self.dropout_p, self.training)
         mem_k = self.with_pos_embed(memory, pos)
         if self.normalize_before:   # forward_pre (detr_backbone.py:245-264)
             tgt2 = self._ln(self.norm1, tgt)
             q = k = self.with_pos_embed(tgt2, query_pos)
             tgt2 = self.self_attn(q, k, value=tgt2, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
-            tgt = _AddFn.apply(tgt, tgt2)
+            tgt = _AddFn.apply(tgt, D(tgt2))
             tgt2 = self._ln(self.norm2, tgt)
             tgt2 = self.multihead_attn(self.with_pos_embed(tgt2, query_pos), mem_k, value=memory, attn_mask=memory_mask,
                                        key_padding_mask=memory_key_padding_mask)[0]
-            tgt = _AddFn.apply(tgt, tgt2)
+            tgt = _AddFn.apply(tgt, D(tgt2))
             tgt2 = self._ffn(self._ln(self.norm3, tgt))
-            return _AddFn.apply(tgt, tgt2)
+            return _AddFn.apply(tgt, D(tgt2))
         # forward_post (detr_backbone.py:222-243)
         q = k = self.with_pos_embed(tgt, query_pos)
         tgt2 = self.self_attn(q, k, value=tgt, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
-        tgt = self._ln(self.norm1, _AddFn.apply(tgt, tgt2))
+        tgt = self._ln(self.norm1, _AddFn.apply(tgt, D(tgt2)))
         tgt2 = self.multihead_attn(self.with_pos_embed(tgt, query_pos), mem_k, value=memory, attn_mask=memory_mask,
                                    key_padding_mask=memory_key_padding_mask)[0]
-        tgt = self._ln(self.norm2, _AddFn.apply(tgt, tgt2))
+        tgt = self._ln(self.norm2, _AddFn.apply(tgt, D(tgt2)))
         tgt2 = self._ffn(tgt)
-        return self._ln(self.norm3, _AddFn.apply(tgt, tgt2))
+        return self._ln(self.norm3, _AddFn.apply(tgt, D(tgt2)))
 
 
 def _norm_tokens(norm, x):
