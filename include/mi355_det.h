@@ -365,7 +365,8 @@ int mi_dropout_bf16(const void* x, void* out, int64_t n, float drop_p, uint64_t 
 /* ---- row-wise ops of DETR's transformer layers (detr_backbone.py:135-278) -------------------
  * nn.LayerNorm(E) forward / backward over bf16 [T][E] token rows (fp32 gamma/beta/mean/rstd), eps 1e-5;
  * E %% 64 == 0, E <= 1024; ws (backward): fp32 [ceil(T/64)][E][2].  mi_ew_bf16: op 0 out = a + b (residual),
- * op 1 out = relu(a), op 2 out = a * (b > 0) (ReLU backward: a = dy, b = forward output); n %% 8 == 0. */
+ * op 1 out = relu(a), op 2 out = a * (b > 0) (ReLU backward: a = dy, b = forward output), op 3 out = sigmoid(a),
+ * op 4 out = a * b * (1 - b) (sigmoid backward: a = dy, b = forward output); n %% 8 == 0. */
 int mi_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int T,
                      int E, float eps, mi_stream_t s);
 int mi_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
@@ -416,6 +417,19 @@ int mi_grad_clip_full_model(float* grads, int64_t n, float max_norm, double* ws,
  * -> pos fp32 [B][2*num_pos_feats][H][W] */
 int mi_pos_embed_sine(const uint8_t* mask, int B, int H, int W, int num_pos_feats, float temperature, int normalize,
                       float scale, int centered, float* out, mi_stream_t s);
+
+/* ---- SparseInst (config 5): bilinear resize (align_corners False) of bf16 NHWC maps and the mask losses of the matched
+ * (prediction, target) pairs of SparseInstCriterion (loss/sparseinst_loss.py:123-187).  See csrc/sparseinst_ops.hip. */
+int mi_bilinear_resize_bf16(const void* x, int ldx, int N, int H, int W, int C, void* y, int ldy, int Ho, int Wo,
+                            mi_stream_t s);
+int mi_bilinear_resize_bwd_bf16(const void* dy, int lddy, int N, int H, int W, int C, void* dx, int lddx, int Ho, int Wo,
+                                float* acc_ws_zeroed, mi_stream_t s);
+/* masks bf16 logits [B][P][ldm] (instance = channel), targets fp32 [T][P], pairs int32 [K][3] = (b, n, t);
+ * stats fp32 [K][8] = sum BCE, sum sig*t, sum sig^2, sum t^2, |sig>=.4 & t>.5|, |sig>=.4|, |t>.5|, 0 */
+int mi_sparseinst_mask_stats(const void* masks, int ldm, int P, const float* targets, const int32_t* pairs, int K,
+                             float* stats, mi_stream_t s);
+int mi_sparseinst_mask_grad(const void* masks, int ldm, int P, const float* targets, const int32_t* pairs, int K,
+                            const float* stats, float c_bce, float c_dice, void* dmasks_zeroed, mi_stream_t s);
 
 /* sizeof() of the public structs as compiled into the library (binding self-check): 0 mi_conv_desc, 1 mi_wgrad_desc,
  * 2 mi_wgrad_group, 3 mi_pack_job, 4 mi_bias_job, 5 mi_yolox_loss_desc, 6 mi_detr_loss_desc, 7 mi_sgd_seg, 8 mi_cmd,

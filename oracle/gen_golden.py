@@ -324,6 +324,62 @@ def gold_detr_meta():
           "ndet", [len(d_["instances"]) for d_ in dets])
 
 
+def gold_sparseinst():
+    """the reference's own InstanceContextEncoder + GroupIAMDecoder + SparseInstCriterion / SparseInstMatcher (loaded by
+    path) on seeded ResNet features and bitmask targets: encoder output, decoder outputs, matcher indices, the four
+    weighted losses, and the gradients of their sum with respect to the input features and every parameter (norms + two
+    full tensors)"""
+    import types
+    from gen_golden_inputs import seeded_tensor_dict, synth_sparseinst_case
+    root = os.path.dirname(HERE)
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from yolov7_d2_amd import sparse_inst_r50_giam_cfg
+    si = ref_loader.load_sparseinst()
+    cfg = sparse_inst_r50_giam_cfg(device="cpu")
+    shapes = {n: types.SimpleNamespace(channels=c, stride=s) for n, c, s in (("res3", 512, 8), ("res4", 1024, 16), ("res5", 2048, 32))}
+    torch.manual_seed(0)
+    enc = si.encoder.InstanceContextEncoder(cfg, shapes)
+    dec = si.decoder.GroupIAMDecoder(cfg)
+    crit = si.loss.SparseInstCriterion(cfg, si.loss.SparseInstMatcher(cfg))
+    net = torch.nn.ModuleDict(dict(encoder=enc, decoder=dec))
+    from gen_golden_inputs import sparseinst_spread
+    net.load_state_dict(sparseinst_spread(seeded_tensor_dict({k: v.shape for k, v in net.state_dict().items()}, seed=303)))
+    feats, targets, input_shape = synth_sparseinst_case()
+    fin = {k: v.clone().requires_grad_(True) for k, v in feats.items()}
+    e = enc(fin)
+    out = dec(e)
+    class _BM:                       # BitMasks stand-in: .tensor + len()
+        def __init__(self, t): self.tensor = t
+        def __len__(self): return self.tensor.shape[0]
+    tg = [dict(labels=t["labels"], masks=_BM(t["masks"])) for t in targets]
+    indices = crit.matcher(out, tg, input_shape)
+    with torch.no_grad():      # how decisive is the matching?  (margin of the chosen entries over the column medians)
+        pm = out["pred_masks"][0].flatten(1); tm = torch.nn.functional.interpolate(
+            si.loss.nested_masks_from_list([t["masks"].tensor for t in tg], input_shape).tensors[:, None], size=out["pred_masks"].shape[-2:],
+            mode="bilinear", align_corners=False).squeeze(1).flatten(1)[:3]
+        sc = si.loss.dice_score(pm, tm)
+        print("dice score image 0: col max", sc.max(0).values.tolist(), "col 2nd", sc.topk(2, 0).values[1].tolist())
+    losses = crit(out, tg, input_shape)
+    total = sum(losses.values())
+    total.backward()
+    res = {"enc_out": e.detach().numpy()[:, ::8], "pred_logits": out["pred_logits"].detach().numpy(),
+           "pred_scores": out["pred_scores"].detach().numpy(), "pred_masks": out["pred_masks"].detach().numpy()[:, ::5, ::2, ::2]}
+    for b, (i, j) in enumerate(indices):
+        res[f"match_i{b}"], res[f"match_j{b}"] = i.numpy(), j.numpy()
+    for k, v in losses.items():
+        res["loss:" + k] = np.float32(v.detach())
+    for k, v in fin.items():
+        res["dfeat_norm:" + k] = np.float32(v.grad.norm())
+    names = sorted(dict(net.named_parameters()).keys())
+    res["param_names"] = np.array(names)
+    res["param_grad_norms"] = np.array([float(dict(net.named_parameters())[n].grad.norm()) for n in names], dtype=np.float32)
+    for n in ("decoder.inst_branch.mask_kernel.weight", "encoder.fusion.weight"):
+        res["g:" + n] = dict(net.named_parameters())[n].grad.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "sparseinst.npz"), **res)
+    print("sparseinst:", {k: float(v) for k, v in losses.items()}, [(i.tolist(), j.tolist()) for i, j in indices])
+
+
 def gold_transformer():
     """the reference's own Transformer (backbone/detr_backbone.py:25-65): 2 encoder + 2 decoder layers, d_model 256,
     8 heads, ffn 512, return_intermediate_dec, eval mode, fp32; post- and pre-norm"""
@@ -366,4 +422,5 @@ if __name__ == "__main__":
     gold_pos_embed()
     gold_detr()
     gold_detr_meta()
+    gold_sparseinst()
     gold_set_criterion()

@@ -136,3 +136,39 @@ def synth_detr_batch(seed=201, sizes=((160, 200), (128, 224)), ncls=80):
         cls = torch.randint(0, ncls, (n,), generator=g)
         out.append(dict(image=img, boxes=boxes, classes=cls, size=(h, w)))
     return out
+
+
+def synth_sparseinst_case(seed=301, B=2, H=128, W=160):
+    """seeded ResNet features (res3 / res4 / res5 of a padded B x 3 x H x W batch) and bitmask targets (random rectangles
+    and ellipses on images SMALLER than the padded batch, so the zero padding of nested_masks_from_list is exercised)"""
+    g = torch.Generator().manual_seed(seed)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    feats = {n: bf(torch.relu(torch.randn(B, c, H // s, W // s, generator=g))) for n, c, s in
+             (("res3", 512, 8), ("res4", 1024, 16), ("res5", 2048, 32))}
+    targets = []
+    for b in range(B):
+        h, w = (H, W) if b == 0 else (H - 24, W - 32)
+        n = 3 if b == 0 else 2
+        masks = torch.zeros(n, h, w)
+        yy, xx = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+        for k in range(n):
+            cy, cx = float(torch.rand(1, generator=g)) * h, float(torch.rand(1, generator=g)) * w
+            ry, rx = 10 + float(torch.rand(1, generator=g)) * h * 0.3, 10 + float(torch.rand(1, generator=g)) * w * 0.3
+            if k % 2 == 0:
+                masks[k] = ((yy - cy).abs() < ry) & ((xx - cx).abs() < rx)
+            else:
+                masks[k] = (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2) < 1
+        targets.append(dict(labels=torch.randint(0, 80, (n,), generator=g), masks=masks, size=(h, w)))
+    return feats, targets, (H, W)
+
+
+def sparseinst_spread(sd):
+    """de-generate a seeded SparseInst state dict: with small random weights all 100 instance activation maps (and hence
+    all predictions) are nearly identical and the Hungarian matching is decided by rounding noise.  Larger IAM / kernel /
+    class weights make the instances differ, as a trained model's do."""
+    sd = dict(sd)
+    for k, f in (("decoder.inst_branch.iam_conv.weight", 40.0), ("decoder.inst_branch.mask_kernel.weight", 6.0),
+                 ("decoder.inst_branch.cls_score.weight", 0.3), ("decoder.inst_branch.fc.weight", 0.5)):
+        sd[k] = sd[k] * f
+    sd["decoder.inst_branch.cls_score.bias"] = sd["decoder.inst_branch.cls_score.bias"] - 2.0
+    return sd

@@ -159,3 +159,67 @@ def build_reference_yolox(depth=0.33, width=0.5, num_classes=80, seed=0):
             return self.head(f)
 
     return RefYOLOX(), r
+
+
+def load_sparseinst():
+    """the reference's SparseInst files loaded by path: transcoders/encoder_sparseinst.py, transcoders/decoder_sparseinst.py,
+    loss/sparseinst_loss.py.  Un-installed names they import at module level are stubbed: fvcore's weight-init helpers
+    (initialisation only), fvcore.nn.sigmoid_focal_loss_jit (restated from its published formula: PARITY UNPINNED for that
+    one function), detectron2.layers.Conv2d (= nn.Conv2d when no norm / activation is passed, which is how these files
+    use it), detectron2.utils.registry.Registry, alfred's logger."""
+    load()
+    import torch
+    from torch import nn
+    import torch.nn.functional as F
+
+    class Registry(dict):
+        def __init__(self, name=""):
+            super().__init__()
+
+        def register(self, obj=None):
+            if obj is None:
+                return lambda o: self.register(o)
+            self[obj.__name__] = obj
+            return obj
+
+    def sigmoid_focal_loss_jit(inputs, targets, alpha=-1, gamma=2, reduction="none"):
+        p = torch.sigmoid(inputs)
+        ce = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+        p_t = p * targets + (1 - p) * (1 - targets)
+        loss = ce * ((1 - p_t) ** gamma)
+        if alpha >= 0:
+            loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
+        return loss.sum() if reduction == "sum" else (loss.mean() if reduction == "mean" else loss)
+
+    def c2_msra_fill(m):
+        nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+
+    def c2_xavier_fill(m):
+        nn.init.kaiming_uniform_(m.weight, a=1)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+
+    if "fvcore" not in sys.modules:
+        _stub("fvcore")
+    fn = sys.modules.get("fvcore.nn") or _stub("fvcore.nn")
+    fn.sigmoid_focal_loss_jit = sigmoid_focal_loss_jit
+    _stub("fvcore.nn.weight_init", c2_msra_fill=c2_msra_fill, c2_xavier_fill=c2_xavier_fill)
+    _stub("detectron2.utils.registry", Registry=Registry)
+    sys.modules["detectron2.layers"].Conv2d = nn.Conv2d
+    if "alfred" not in sys.modules:
+        _stub("alfred", print_shape=lambda *a, **k: None)
+        _stub("alfred.utils")
+        _stub("alfred.utils.log", logger=sys.modules["loguru"].logger)
+    y = os.path.join(REF, "yolov7")
+    for name, sub in (("yolov7.modeling.transcoders", ("modeling", "transcoders")), ("yolov7.modeling.loss", ("modeling", "loss"))):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [os.path.join(y, *sub)]
+            sys.modules[name] = m
+    out = types.SimpleNamespace()
+    out.encoder = importlib.import_module("yolov7.modeling.transcoders.encoder_sparseinst")
+    out.decoder = importlib.import_module("yolov7.modeling.transcoders.decoder_sparseinst")
+    out.loss = importlib.import_module("yolov7.modeling.loss.sparseinst_loss")
+    return out

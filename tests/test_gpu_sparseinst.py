@@ -1,0 +1,187 @@
+"""GPU (-m gpu): SparseInst (BASELINE.json config 5) against tests/golden/sparseinst.npz = the reference's OWN
+InstanceContextEncoder + GroupIAMDecoder + SparseInstCriterion / SparseInstMatcher executed by path on seeded ResNet
+features and bitmask targets (oracle/gen_golden.py::gold_sparseinst): encoder output, class logits / objectness / masks,
+the Hungarian matching (indices exact), the four weighted losses, gradient norms of every parameter and two full
+gradients; the op-level pieces (bilinear resize, pixel-sum outer product, mask-loss kernels) against torch; and one
+end-to-end training step + inference of the registered META_ARCH around the ResNet-50."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import yolov7_d2_amd as M
+from yolov7_d2_amd.d2shim import Instances
+from yolov7_d2_amd.modeling import sparseinst as S
+from gen_golden_inputs import seeded_tensor_dict, sparseinst_spread, synth_sparseinst_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).float().cpu(), torch.as_tensor(b).float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def test_bilinear_resize_and_pixel_outer_against_torch():
+    g = torch.Generator().manual_seed(0)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    for (N, C, H, W, Ho, Wo) in ((2, 64, 10, 13, 20, 26), (1, 32, 4, 5, 16, 20), (2, 104, 16, 20, 32, 40), (1, 64, 1, 1, 6, 7)):
+        x = bf(torch.randn(N, C, H, W, generator=g))
+        xr = x.clone().requires_grad_(True)
+        ref = F.interpolate(xr, size=(Ho, Wo), mode="bilinear", align_corners=False)
+        go = bf(torch.randn(ref.shape, generator=g))
+        ref.backward(go)
+        xd = x.to(DEV, torch.bfloat16).requires_grad_(True)
+        y = S.resize_bilinear(xd, (Ho, Wo))
+        assert _rel(y, ref.detach()) < 5e-3
+        y.backward(go.to(DEV, torch.bfloat16))
+        assert _rel(xd.grad, xr.grad) < 5e-3
+    a = bf(torch.rand(1000, 128, generator=g)); b = bf(torch.randn(1000, 256, generator=g))
+    ad, bd = a.to(DEV, torch.bfloat16).requires_grad_(True), b.to(DEV, torch.bfloat16).requires_grad_(True)
+    out = S._PixelOuterFn.apply(ad, bd)
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = ar.t() @ br
+    assert _rel(out, ref.detach()) < 2e-3
+    gg = torch.randn(ref.shape, generator=g)
+    ref.backward(gg); out.backward(gg.to(DEV))
+    assert _rel(ad.grad, ar.grad) < 1e-2 and _rel(bd.grad, br.grad) < 1e-2
+
+
+def _build(cfg):
+    shapes = {n: types.SimpleNamespace(channels=c, stride=s) for n, c, s in (("res3", 512, 8), ("res4", 1024, 16), ("res5", 2048, 32))}
+    enc = S.InstanceContextEncoder(cfg, shapes)
+    dec = S.GroupIAMDecoder(cfg)
+    net = torch.nn.ModuleDict(dict(encoder=enc, decoder=dec))
+    net.load_state_dict(sparseinst_spread(seeded_tensor_dict({k: v.shape for k, v in net.state_dict().items()}, seed=303)))
+    return net.to(DEV)
+
+
+def test_encoder_decoder_criterion_against_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "sparseinst.npz"))
+    cfg = M.sparse_inst_r50_giam_cfg(device=DEV)
+    net = _build(cfg)
+    assert sorted(dict(net.named_parameters()).keys()) == [str(n) for n in g["param_names"]]     # the reference's keys
+    crit = S.build_sparse_inst_criterion(cfg)
+    feats, targets, input_shape = synth_sparseinst_case()
+    fin = {k: v.to(DEV, torch.bfloat16).requires_grad_(True) for k, v in feats.items()}
+    e = net["encoder"](fin)
+    out = net["decoder"](e)
+    assert _rel(e.detach()[:, ::8], g["enc_out"]) < 2e-2
+    assert _rel(out["pred_logits"].detach(), g["pred_logits"]) < 3e-2
+    assert _rel(out["pred_scores"].detach(), g["pred_scores"]) < 3e-2
+    assert _rel(out["pred_masks"].detach()[:, ::5, ::2, ::2], g["pred_masks"]) < 3e-2
+    tg = [dict(labels=t["labels"].to(DEV), masks=t["masks"].to(DEV)) for t in targets]
+    indices, mm = crit.matcher(out, tg, input_shape)
+    # On a random-weight network the 100 instances are near copies of each other (the reference's own dice scores tie
+    # to the 5th digit), so WHICH of the tied queries is picked is rounding noise: check optimality instead of identity -
+    # the kernel's assignment must reach the objective of scipy's on the reference's fp32 cost (exact-index equality is
+    # checked on a decisive case in test_matcher_indices_exact_on_a_decisive_case)
+    from scipy.optimize import linear_sum_assignment
+    pm = out["pred_masks"].detach().float()
+    for b, (i, j) in enumerate(indices):
+        M_ = len(tg[b]["labels"])
+        tm = mm["tgt"][int(mm["off"][b]): int(mm["off"][b]) + M_]
+        sg = pm[b].flatten(1).sigmoid()
+        score = 2 * sg @ tm.t() / ((sg * sg).sum(-1)[:, None] + (tm * tm).sum(-1)[None] + 1e-4)
+        Cm = (score ** 0.8) * (out["pred_logits"][b].detach().float().sigmoid()[:, tg[b]["labels"]] ** 0.2)
+        ri, rj = linear_sum_assignment(Cm.cpu().numpy(), maximize=True)
+        best = float(Cm.cpu().numpy()[ri, rj].sum())
+        mine = float(Cm[i, j].sum())
+        assert sorted(j.cpu().tolist()) == list(range(M_)) and len(set(i.cpu().tolist())) == M_
+        assert mine >= best - 2e-3 * abs(best), (b, mine, best)
+    losses = crit(out, tg, input_shape)
+    got = {k: float(v.detach()) for k, v in losses.items()}
+    print({k: (round(got[k], 4), round(float(g["loss:" + k]), 4)) for k in got})
+    for k in got:
+        ref = float(g["loss:" + k])
+        assert abs(got[k] - ref) <= 3e-2 * abs(ref) + 1e-3, (k, got[k], ref)
+    sum(losses.values()).backward()
+    for k, v in fin.items():
+        assert abs(float(v.grad.float().norm()) - float(g["dfeat_norm:" + k])) < 0.1 * float(g["dfeat_norm:" + k]), k
+    params = dict(net.named_parameters())
+    ratio = np.array([float(params[str(n)].grad.float().norm()) / (gn + 1e-12) for n, gn in zip(g["param_names"], g["param_grad_norms"])])
+    print("parameter gradient norm ratio: min %.3f max %.3f" % (ratio.min(), ratio.max()))
+    # (the matched queries may differ from the reference's among the tied instances: the heads' gradients move a little)
+    assert ratio.min() > 0.8 and ratio.max() < 1.3 and abs(float(np.median(ratio)) - 1.0) < 0.05
+    for n in ("decoder.inst_branch.mask_kernel.weight", "encoder.fusion.weight"):
+        a, b = params[n].grad.float().cpu().flatten(), torch.as_tensor(g["g:" + n]).flatten()
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        assert cos > 0.99, (n, cos)
+
+
+def test_matcher_indices_exact_on_a_decisive_case():
+    """SparseInstMatcher (dice^0.8 * prob^0.2, maximise) on predictions where every target has a clearly best query:
+    indices identical to scipy.optimize.linear_sum_assignment on the reference's formula"""
+    from scipy.optimize import linear_sum_assignment
+    cfg = M.sparse_inst_r50_giam_cfg(device=DEV)
+    matcher = S.SparseInstMatcher(cfg)
+    _, targets, input_shape = synth_sparseinst_case(seed=5)
+    g = torch.Generator().manual_seed(6)
+    B, N, Ho, Wo = 2, 100, input_shape[0] // 4, input_shape[1] // 4
+    tg = [dict(labels=t["labels"].to(DEV), masks=t["masks"].to(DEV)) for t in targets]
+    logits = torch.randn(B, N, 80, generator=g) * 2 - 2
+    masks = torch.randn(B, N, Ho, Wo, generator=g) * 0.5 - 3
+    for b, t in enumerate(targets):
+        small = F.interpolate(F.pad(t["masks"], (0, input_shape[1] - t["masks"].shape[2], 0, input_shape[0] - t["masks"].shape[1]))[None],
+                              size=(Ho, Wo), mode="bilinear", align_corners=False)[0]
+        for k in range(small.shape[0]):
+            q = int(torch.randint(0, N, (1,), generator=g))
+            masks[b, q] += 7 * small[k]                      # query q predicts target k's mask
+            logits[b, q, t["labels"][k]] += 4
+    nhwc = torch.zeros(B, Ho, Wo, 128)
+    nhwc[..., :N] = masks.permute(0, 2, 3, 1)
+    out = {"pred_logits": logits.to(DEV), "_masks_nhwc": nhwc.to(DEV, torch.bfloat16)}
+    indices, mm = matcher(out, tg, input_shape)
+    for b, (i, j) in enumerate(indices):
+        M_ = len(tg[b]["labels"])
+        tm = mm["tgt"][int(mm["off"][b]): int(mm["off"][b]) + M_].cpu()
+        sg = masks[b].to(torch.bfloat16).float().flatten(1).sigmoid()
+        score = 2 * sg @ tm.t() / ((sg * sg).sum(-1)[:, None] + (tm * tm).sum(-1)[None] + 1e-4)
+        Cm = (score ** 0.8) * (logits[b].sigmoid()[:, targets[b]["labels"]] ** 0.2)
+        ri, rj = linear_sum_assignment(Cm.numpy(), maximize=True)
+        assert i.cpu().tolist() == ri.tolist() and j.cpu().tolist() == rj.tolist(), (b, i, j, ri, rj)
+
+
+def test_sparseinst_meta_arch_step_and_inference():
+    torch.manual_seed(0)
+    cfg = M.sparse_inst_r50_giam_cfg(device=DEV)
+    cfg.MODEL.YOLO.CONF_THRESHOLD = 0.005
+    model = M.build_model(cfg)
+    assert M.META_ARCH_REGISTRY.get("SparseInst") is M.SparseInst
+    _, targets, _ = synth_sparseinst_case(seed=9, H=192, W=224)
+    gen = torch.Generator().manual_seed(1)
+    inputs = []
+    for t in targets:
+        h, w = t["size"]
+        inst = Instances((h, w), gt_classes=t["labels"], gt_masks=t["masks"])
+        inputs.append(dict(image=torch.randint(0, 256, (3, h, w), generator=gen).float(), instances=inst, height=h, width=w))
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    assert any(n.startswith("backbone.stem") for n, p in model.named_parameters() if p.requires_grad)    # FREEZE_AT 0
+    opt = torch.optim.AdamW(params, lr=5e-5, weight_decay=0.05)
+    hist = []
+    for it in range(3):
+        losses = model(inputs)
+        assert set(losses) == {"loss_ce", "loss_mask", "loss_dice", "loss_objectness"}
+        total = sum(losses.values())
+        opt.zero_grad()
+        total.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+        opt.step()
+        hist.append(float(total))
+    print("sparseinst loss:", [round(h, 3) for h in hist])
+    assert np.isfinite(hist).all() and hist[-1] < hist[0]
+    model.eval()
+    with torch.no_grad():
+        res = model(inputs)
+    assert len(res) == 2
+    for r, t in zip(res, targets):
+        inst = r["instances"]
+        assert inst.image_size == t["size"]
+        if len(inst):
+            assert inst.pred_masks.shape[1:] == t["size"] and inst.pred_masks.dtype == torch.bool
+            assert inst.scores.shape[0] == inst.pred_classes.shape[0] == inst.pred_masks.shape[0]

@@ -5,9 +5,9 @@ Public surface mirrors the reference: META_ARCH `YOLOX`, backbone builder
 (include/mi355_det.h).  Importing registers the classes into the (detectron2 or shim) registries.
 """
 from . import _lib
-from .config import add_yolo_config, detr_r50_cfg, get_cfg, get_yolox_cfg, yolox_s_cfg
+from .config import add_sparse_inst_config, add_yolo_config, detr_r50_cfg, sparse_inst_r50_giam_cfg, get_cfg, get_yolox_cfg, yolox_s_cfg
 from .d2shim import BACKBONE_REGISTRY, META_ARCH_REGISTRY, build_backbone, build_model
-from .modeling import YOLOX, Detr, build_cspdarknetx_backbone, build_resnet_backbone, batched_nms, postprocess
+from .modeling import YOLOX, Detr, SparseInst, build_cspdarknetx_backbone, build_resnet_backbone, batched_nms, postprocess
 from . import ops  # noqa: F401  (registers torch.ops.mi355.*)
 from .ops import patch_base_convs
 

@@ -183,6 +183,10 @@ _PROTOS = {
     "mi_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mi_ew_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i, _vp]),
     "mi_dropout_bf16": (C.c_int, [_vp, _vp, _i64, _f, C.c_uint64, _vp]),
+    "mi_bilinear_resize_bf16": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "mi_bilinear_resize_bwd_bf16": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "mi_sparseinst_mask_stats": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "mi_sparseinst_mask_grad": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _vp, _f, _f, _vp, _vp]),
     "mi_mha_fwd_dropout": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, C.c_uint64, _vp]),
     "mi_mha_bwd_dropout": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f,
                                      C.c_uint64, _vp]),

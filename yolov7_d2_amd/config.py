@@ -156,6 +156,49 @@ def add_yolo_config(cfg):
     return _C
 
 
+def add_sparse_inst_config(cfg):
+    """yolov7/configs/config_sparseinst.py:6-68"""
+    cfg.MODEL.MASK_ON = True
+    cfg.MODEL.SPARSE_INST = CN({
+        "CLS_THRESHOLD": 0.005, "MASK_THRESHOLD": 0.45, "MAX_DETECTIONS": 100,
+        "ENCODER": {"NAME": "FPNPPMEncoder", "NORM": "", "IN_FEATURES": ["res3", "res4", "res5"], "NUM_CHANNELS": 256},
+        "DECODER": {"NAME": "BaseIAMDecoder", "NUM_MASKS": 100, "NUM_CLASSES": 80, "KERNEL_DIM": 128, "SCALE_FACTOR": 2.0,
+                    "OUTPUT_IAM": False, "GROUPS": 4, "INST": {"DIM": 256, "CONVS": 4}, "MASK": {"DIM": 256, "CONVS": 4}},
+        "LOSS": {"NAME": "SparseInstCriterion", "ITEMS": ("labels", "masks"), "CLASS_WEIGHT": 2.0,
+                 "MASK_PIXEL_WEIGHT": 5.0, "MASK_DICE_WEIGHT": 2.0, "OBJECTNESS_WEIGHT": 1.0},
+        "MATCHER": {"NAME": "SparseInstMatcher", "ALPHA": 0.8, "BETA": 0.2},
+        "DATASET_MAPPER": "SparseInstDatasetMapper",
+    })
+    cfg.SOLVER.OPTIMIZER = "ADAMW"
+    cfg.SOLVER.BACKBONE_MULTIPLIER = 1.0
+    cfg.SOLVER.AMSGRAD = False
+    return cfg
+
+
+def sparse_inst_r50_giam_cfg(device="cuda", **over):
+    """configs/coco/sparseinst/Base-SparseInst.yaml + sparse_inst_r50_giam.yaml without needing the files"""
+    cfg = add_sparse_inst_config(add_yolo_config(get_cfg()))
+    cfg.MODEL.DEVICE = device
+    cfg.MODEL.META_ARCHITECTURE = "SparseInst"
+    cfg.MODEL.PIXEL_MEAN = [123.675, 116.280, 103.530]
+    cfg.MODEL.PIXEL_STD = [58.395, 57.120, 57.375]
+    cfg.MODEL.BACKBONE.FREEZE_AT = 0
+    cfg.MODEL.BACKBONE.NAME = "build_resnet_backbone"
+    cfg.MODEL.RESNETS.NORM = "FrozenBN"
+    cfg.MODEL.RESNETS.DEPTH = 50
+    cfg.MODEL.RESNETS.STRIDE_IN_1X1 = False
+    cfg.MODEL.RESNETS.OUT_FEATURES = ["res3", "res4", "res5"]
+    cfg.MODEL.SPARSE_INST.ENCODER.NAME = "InstanceContextEncoder"
+    cfg.MODEL.SPARSE_INST.DECODER.NAME = "GroupIAMDecoder"
+    cfg.SOLVER.BASE_LR = 0.00005
+    cfg.SOLVER.WEIGHT_DECAY = 0.05
+    cfg.INPUT.FORMAT = "RGB"
+    cfg.INPUT.MASK_FORMAT = "bitmask"
+    for k, v in over.items():
+        cfg.merge_from_list([k, v])
+    return cfg
+
+
 def detr_r50_cfg(device="cuda", **over):
     """the settings of configs/coco/detr/detr_256_6_6_torchvision.yaml without needing the file"""
     cfg = add_yolo_config(get_cfg())

@@ -562,6 +562,7 @@ __global__ __launch_bounds__(256) void wgrad2_reduce_group_kernel(const Wg2R* __
   MI_WG(9, 2, 1, 2, 2, 128) MI_WG(9, 2, 1, 2, 2, 64) \
   MI_WG(9, 1, 1, 2, 2, 128) MI_WG(9, 1, 1, 2, 2, 64) \
   MI_WG(9, 1, 1, 2, 1, 128) MI_WG(9, 1, 1, 2, 1, 64) \
+  MI_WG(16, 1, 1, 2, 1, 128) MI_WG(16, 1, 1, 2, 1, 64) \
   MI_WG(1, 1, 1, 2, 2, 128) MI_WG(1, 1, 2, 2, 2, 128) MI_WG(1, 1, 4, 2, 2, 128) \
   MI_WG(1, 2, 1, 2, 2, 128) MI_WG(1, 2, 2, 2, 2, 128) MI_WG(1, 2, 4, 2, 2, 128) \
   MI_WG(1, 4, 1, 2, 2, 128) MI_WG(1, 4, 2, 2, 2, 128) MI_WG(1, 4, 4, 2, 2, 128) \
@@ -609,7 +610,9 @@ static void wg_choose_tile(int TP, int gridH, int gridW, int* TH, int* TW) {
 
 static int wg_pick_cfg(const mi_wgrad_desc* d, Wg2Cfg* c, bool grouped = false) {
   const int ci = d->CinPad, co = d->CoutPad;
-  if (d->ntaps == 9) {
+  if (d->ntaps == 16) {   // the 7x7 stride-2 ResNet stem as a 4x4 conv over the space-to-depth image (Cin 12 -> 16)
+    c->NT = 16; c->NJ = 1; c->MI = 1; c->WCO = 2; c->WCI = 1; c->TP = 128;
+  } else if (d->ntaps == 9) {
     c->NT = 9; c->NJ = 1;
     if (ci % 64 == 0 && co % 64 == 0 && d->stride == 1) { c->MI = 4; c->WCO = 1; c->WCI = 4; c->TP = 128; }
     else if (ci % 32 == 0 && co % 64 == 0) { c->MI = 2; c->WCO = 2; c->WCI = 2; c->TP = d->stride == 1 ? 128 : 64; }
@@ -630,7 +633,7 @@ static int wg_pick_cfg(const mi_wgrad_desc* d, Wg2Cfg* c, bool grouped = false) 
   }
   {  // A/B overrides of the pixel-tile size per tap class (MI_WG_TP9 / MI_WG_TP1 = 64 | 128)
     static const int tp9 = wg_env("MI_WG_TP9", 64), tp1 = wg_env("MI_WG_TP1", 64);
-    const int tpe = d->ntaps == 9 ? tp9 : tp1;
+    const int tpe = d->ntaps >= 9 ? tp9 : tp1;
     if (tpe == 64 || tpe == 128) c->TP = tpe;
   }
   if (d->cfg_tp == 64 || d->cfg_tp == 128) c->TP = d->cfg_tp;
@@ -639,9 +642,9 @@ static int wg_pick_cfg(const mi_wgrad_desc* d, Wg2Cfg* c, bool grouped = false) 
 
 static int wg_fill(const mi_wgrad_desc* d, Wg2K* k, Wg2Cfg* c, size_t* lds, size_t* ws, bool grouped = false) {
   MI_REQUIRE(d->x && d->dy, "wgrad: null pointer");
-  MI_REQUIRE(d->ntaps == 1 || d->ntaps == 9, "wgrad: ntaps %d", d->ntaps);
+  MI_REQUIRE(d->ntaps == 1 || d->ntaps == 9 || d->ntaps == 16, "wgrad: ntaps %d", d->ntaps);
   MI_REQUIRE(d->CoutPad % 32 == 0 && d->CinPad % 16 == 0, "wgrad: pads %d %d", d->CoutPad, d->CinPad);
-  MI_REQUIRE(d->ntaps == 9 || d->CinPad % 32 == 0, "wgrad: 1x1 needs CinPad %% 32 (got %d)", d->CinPad);
+  MI_REQUIRE(d->ntaps != 1 || d->CinPad % 32 == 0, "wgrad: 1x1 needs CinPad %% 32 (got %d)", d->CinPad);
   MI_REQUIRE(d->Cout > 0 && d->Cout <= d->CoutPad && d->Cin > 0 && d->Cin <= d->CinPad, "wgrad: channels");
   MI_REQUIRE(d->ldx % 8 == 0 && d->ldy % 8 == 0 && ((uintptr_t)d->x % 16) == 0 && ((uintptr_t)d->dy % 16) == 0,
              "wgrad: alignment");
@@ -683,13 +686,13 @@ static int wg_fill(const mi_wgrad_desc* d, Wg2K* k, Wg2Cfg* c, size_t* lds, size
   int ns = d->cfg_ns;
   {  // A/B override of the LDS ring depth per tap class (MI_WG_NS9 / MI_WG_NS1 = 2..4)
     static const int ns9 = wg_env("MI_WG_NS9", 2), ns1 = wg_env("MI_WG_NS1", 2);
-    const int nse = d->ntaps == 9 ? ns9 : ns1;
+    const int nse = d->ntaps >= 9 ? ns9 : ns1;
     if ((ns < 2 || ns > 4) && nse >= 2 && nse <= 4) ns = nse;
   }
   if (ns < 2 || ns > 4) {
     // 3x3: MFMA-heavy, two co-resident blocks overlap each other's barriers -> 2 stages when two blocks fit;
     // 1x1 and oversized stages: pure streams, one block per CU with as many tiles in flight as LDS allows
-    ns = (d->ntaps == 9) ? 2 : (int)((160 * 1024) / k->stage);
+    ns = (d->ntaps >= 9) ? 2 : (int)((160 * 1024) / k->stage);
     if (ns > 4) ns = 4;
     if (ns < 2) ns = 2;
   }

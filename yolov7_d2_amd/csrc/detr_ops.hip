@@ -117,7 +117,15 @@ __global__ __launch_bounds__(64) void lsap_kernel(const MatchK p) {
         }
       }
       minVal = best;
-      const int j = bestj;  // (bestj < 0 only for an infeasible, i.e. all-inf, matrix: cannot happen with finite costs)
+      const int j = bestj;
+      if (j < 0) {
+        // no finite candidate: NaN / inf costs (diverged logits or boxes).  scipy.optimize.linear_sum_assignment raises
+        // ValueError("matrix contains invalid numeric entries") here; the kernel flags the image (nmatch = -1, checked
+        // on the host by HungarianMatcher) instead of indexing row4col[-1] and spinning.  bestj is wave-uniform after
+        // the reduction, so the whole (one-wave) block leaves together.
+        if (lane == 0) p.nmatch[b] = -1;
+        return;
+      }
       if (row4col[j] < 0) sink = j; else i = row4col[j];
       __syncthreads();
       if (lane == 0) SC[j] = 1;

@@ -1,0 +1,213 @@
+// SparseInst (BASELINE.json config 5) - the ops that are not convolutions:
+//   * bilinear resize (align_corners = False) of bf16 NHWC maps, forward + backward: F.interpolate of the FPN outputs
+//     (transcoders/encoder_sparseinst.py:120-124), of the PPM priors (:63-70) and of the predicted masks / IAMs
+//     (transcoders/decoder_sparseinst.py:141-160)
+//   * the mask part of SparseInstCriterion (loss/sparseinst_loss.py:123-187): for every matched (prediction, target)
+//     pair ONE pass over the pair's pixels yields the BCE sum, the dice terms and the thresholded mask IoU
+//     (compute_mask_iou :19-28, dice_loss :38-47); a second pass writes d(loss)/d(mask logits).
+// The convolutions, the IAM aggregation / dynamic mask "bmm"s and the matcher's dice-score matmul run on the conv /
+// wgrad MFMA kernels (modeling/sparseinst.py), the assignment on mi_lsap.
+#include <string.h>
+#include "common.h"
+
+// ---------------------------------------------------------------- bilinear resize, NHWC bf16
+struct ResizeK {
+  const __bf16* x;
+  __bf16* y;
+  float* acc;     // backward: fp32 [N][H][W][C] accumulator
+  int ldx, ldy, N, H, W, Ho, Wo, C8;
+  float sh, sw;   // H / Ho, W / Wo
+};
+
+__device__ __forceinline__ void src_index(int o, float scale, int n, int* i0, int* i1, float* l1) {
+  // ATen area_pixel_compute_source_index (align_corners = False): src = scale * (dst + 0.5) - 0.5, clamped at 0
+  float s = scale * ((float)o + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  const int a = (int)s;
+  *i0 = a < n - 1 ? a : n - 1;
+  *i1 = a < n - 1 ? a + 1 : n - 1;
+  *l1 = s - (float)a;
+}
+
+__global__ __launch_bounds__(256) void resize_fwd_kernel(const ResizeK p) {
+  const int64_t total = (int64_t)p.N * p.Ho * p.Wo * p.C8;
+  for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(idx % p.C8);
+    int64_t r = idx / p.C8;
+    const int ox = (int)(r % p.Wo); r /= p.Wo;
+    const int oy = (int)(r % p.Ho);
+    const int n = (int)(r / p.Ho);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    src_index(oy, p.sh, p.H, &y0, &y1, &ly);
+    src_index(ox, p.sw, p.W, &x0, &x1, &lx);
+    const __bf16* b = p.x + ((int64_t)n * p.H * p.W) * p.ldx + c8 * 8;
+    const bf16x8 v00 = *(const bf16x8*)(b + ((int64_t)y0 * p.W + x0) * p.ldx), v01 = *(const bf16x8*)(b + ((int64_t)y0 * p.W + x1) * p.ldx);
+    const bf16x8 v10 = *(const bf16x8*)(b + ((int64_t)y1 * p.W + x0) * p.ldx), v11 = *(const bf16x8*)(b + ((int64_t)y1 * p.W + x1) * p.ldx);
+    const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      o[e] = w00 * (float)v00[e] + w01 * (float)v01[e] + w10 * (float)v10[e] + w11 * (float)v11[e];
+    *(bf16x8*)(p.y + (((int64_t)n * p.Ho + oy) * p.Wo + ox) * p.ldy + c8 * 8) = pack8(o);
+  }
+}
+
+// backward: every output-gradient pixel adds its four weighted contributions into the fp32 accumulator (hardware
+// float atomics), a second launch rounds the accumulator to bf16
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const ResizeK p) {   // p.x = dy (Ho x Wo), p.acc = dx accumulator
+  const int64_t total = (int64_t)p.N * p.Ho * p.Wo * p.C8;
+  const int C = p.C8 * 8;
+  for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(idx % p.C8);
+    int64_t r = idx / p.C8;
+    const int ox = (int)(r % p.Wo); r /= p.Wo;
+    const int oy = (int)(r % p.Ho);
+    const int n = (int)(r / p.Ho);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    src_index(oy, p.sh, p.H, &y0, &y1, &ly);
+    src_index(ox, p.sw, p.W, &x0, &x1, &lx);
+    const bf16x8 g = *(const bf16x8*)(p.x + (((int64_t)n * p.Ho + oy) * p.Wo + ox) * p.ldx + c8 * 8);
+    float* a = p.acc + ((int64_t)n * p.H * p.W) * C + c8 * 8;
+    const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float ge = (float)g[e];
+      atomicAdd(a + ((int64_t)y0 * p.W + x0) * C + e, w00 * ge);
+      atomicAdd(a + ((int64_t)y0 * p.W + x1) * C + e, w01 * ge);
+      atomicAdd(a + ((int64_t)y1 * p.W + x0) * C + e, w10 * ge);
+      atomicAdd(a + ((int64_t)y1 * p.W + x1) * C + e, w11 * ge);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void f32_to_bf16_rows_kernel(const float* __restrict__ a, __bf16* o, int ldo, int64_t npix, int C8) {
+  const int64_t total = npix * C8;
+  for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(idx % C8);
+    const int64_t px = idx / C8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = a[px * C8 * 8 + c8 * 8 + e];
+    *(bf16x8*)(o + px * ldo + c8 * 8) = pack8(v);
+  }
+}
+
+static int nblocks(int64_t total) {
+  int64_t b = (total + 1023) / 1024;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+extern "C" int mi_bilinear_resize_bf16(const void* x, int ldx, int N, int H, int W, int C, void* y, int ldy, int Ho, int Wo,
+                                       mi_stream_t st) {
+  MI_REQUIRE(x && y && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0,
+             "bilinear_resize: args");
+  ResizeK k;
+  memset(&k, 0, sizeof(k));
+  k.x = (const __bf16*)x; k.y = (__bf16*)y; k.ldx = ldx; k.ldy = ldy; k.N = N; k.H = H; k.W = W; k.Ho = Ho; k.Wo = Wo;
+  k.C8 = C / 8; k.sh = (float)H / (float)Ho; k.sw = (float)W / (float)Wo;
+  hipLaunchKernelGGL(resize_fwd_kernel, dim3(nblocks((int64_t)N * Ho * Wo * k.C8)), dim3(256), 0, (hipStream_t)st, k);
+  MI_CHECK_LAUNCH("bilinear_resize");
+  return MI_OK;
+}
+// dy: [N][Ho][Wo][C] (lddy) -> dx: [N][H][W][C] (lddx); acc_ws: fp32 N*H*W*C, zeroed by the caller
+extern "C" int mi_bilinear_resize_bwd_bf16(const void* dy, int lddy, int N, int H, int W, int C, void* dx, int lddx, int Ho,
+                                           int Wo, float* acc_ws, mi_stream_t st) {
+  MI_REQUIRE(dy && dx && acc_ws && C % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "bilinear_resize_bwd: args");
+  ResizeK k;
+  memset(&k, 0, sizeof(k));
+  k.x = (const __bf16*)dy; k.acc = acc_ws; k.ldx = lddy; k.N = N; k.H = H; k.W = W; k.Ho = Ho; k.Wo = Wo; k.C8 = C / 8;
+  k.sh = (float)H / (float)Ho; k.sw = (float)W / (float)Wo;
+  hipStream_t s = (hipStream_t)st;
+  hipLaunchKernelGGL(resize_bwd_kernel, dim3(nblocks((int64_t)N * Ho * Wo * k.C8)), dim3(256), 0, s, k);
+  MI_CHECK_LAUNCH("bilinear_resize_bwd");
+  hipLaunchKernelGGL(f32_to_bf16_rows_kernel, dim3(nblocks((int64_t)N * H * W * k.C8)), dim3(256), 0, s, acc_ws,
+                     (__bf16*)dx, lddx, (int64_t)N * H * W, k.C8);
+  MI_CHECK_LAUNCH("bilinear_resize_bwd_round");
+  return MI_OK;
+}
+
+// ---------------------------------------------------------------- mask losses of the matched pairs
+// masks: bf16 logits [B][P][ldm] (pixel-major, instance n = channel); targets: fp32 [T][P]; pairs: int32 [K][3] =
+// (image b, instance n, target row t).  stats[k][8] = (sum BCE, A = sum sig*t, S = sum sig^2, Tt = sum t^2,
+// |bin(sig >= 0.4) & (t > 0.5)|, |sig >= 0.4|, |t > 0.5|, 0)
+struct MaskLossK {
+  const __bf16* masks;
+  const float* tgt;
+  const int* pairs;
+  float* stats;
+  __bf16* dmasks;
+  int K, P, ldm;
+  float c_bce, c_dice;   // backward: upstream-gradient-scaled weights: c_bce = g_mask * w / (K * P), c_dice = g_dice * w / num_inst
+};
+
+__global__ __launch_bounds__(256) void mask_stats_kernel(const MaskLossK p) {
+  __shared__ float red[4][8];
+  const int k = blockIdx.y;
+  const int b = p.pairs[k * 3], n = p.pairs[k * 3 + 1], t = p.pairs[k * 3 + 2];
+  const __bf16* m = p.masks + (size_t)b * p.P * p.ldm + n;
+  const float* tg = p.tgt + (size_t)t * p.P;
+  float a[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int px = blockIdx.x * 256 + threadIdx.x; px < p.P; px += gridDim.x * 256) {
+    const float x = (float)m[(size_t)px * p.ldm], tt = tg[px];
+    const float sg = 1.f / (1.f + __expf(-x));
+    // binary_cross_entropy_with_logits: max(x, 0) - x t + log(1 + exp(-|x|))
+    a[0] += fmaxf(x, 0.f) - x * tt + log1pf(__expf(-fabsf(x)));
+    a[1] += sg * tt; a[2] += sg * sg; a[3] += tt * tt;
+    const float bs = sg >= 0.4f ? 1.f : 0.f, bt = tt > 0.5f ? 1.f : 0.f;
+    a[4] += bs * bt; a[5] += bs; a[6] += bt;
+  }
+#pragma unroll
+  for (int e = 0; e < 7; ++e) a[e] = wave_sum(a[e]);
+  if ((threadIdx.x & 63) == 0)
+    for (int e = 0; e < 7; ++e) red[threadIdx.x >> 6][e] = a[e];
+  __syncthreads();
+  if (threadIdx.x < 7) atomicAdd(p.stats + k * 8 + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// d(loss)/d(logit) of pair k at pixel px: c_bce * (sig - t) + c_dice * (-2 t / D + 4 A sig / D^2) * sig (1 - sig), D = S + Tt + 1e-4
+__global__ __launch_bounds__(256) void mask_grad_kernel(const MaskLossK p) {
+  const int k = blockIdx.y;
+  const int b = p.pairs[k * 3], n = p.pairs[k * 3 + 1], t = p.pairs[k * 3 + 2];
+  const __bf16* m = p.masks + (size_t)b * p.P * p.ldm + n;
+  __bf16* dm = p.dmasks + (size_t)b * p.P * p.ldm + n;
+  const float* tg = p.tgt + (size_t)t * p.P;
+  const float A = p.stats[k * 8 + 1], D = p.stats[k * 8 + 2] + p.stats[k * 8 + 3] + 1e-4f;
+  for (int px = blockIdx.x * 256 + threadIdx.x; px < p.P; px += gridDim.x * 256) {
+    const float x = (float)m[(size_t)px * p.ldm], tt = tg[px];
+    const float sg = 1.f / (1.f + __expf(-x));
+    const float g = p.c_bce * (sg - tt) + p.c_dice * (-2.f * tt / D + 4.f * A * sg / (D * D)) * sg * (1.f - sg);
+    dm[(size_t)px * p.ldm] = (__bf16)g;
+  }
+}
+
+extern "C" int mi_sparseinst_mask_stats(const void* masks, int ldm, int P, const float* targets, const int32_t* pairs, int K,
+                                        float* stats, mi_stream_t st) {
+  MI_REQUIRE(masks && targets && pairs && stats && K > 0 && P > 0 && ldm > 0, "sparseinst_mask_stats: args");
+  MaskLossK k;
+  memset(&k, 0, sizeof(k));
+  k.masks = (const __bf16*)masks; k.tgt = targets; k.pairs = pairs; k.stats = stats; k.K = K; k.P = P; k.ldm = ldm;
+  hipStream_t s = (hipStream_t)st;
+  if (hipMemsetAsync(stats, 0, (size_t)K * 8 * sizeof(float), s) != hipSuccess) MI_FAIL(MI_ELAUNCH, "memset");
+  int bx = (P + 2047) / 2048;
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(mask_stats_kernel, dim3(bx, K), dim3(256), 0, s, k);
+  MI_CHECK_LAUNCH("sparseinst_mask_stats");
+  return MI_OK;
+}
+// dmasks: bf16 [B][P][ldm], zeroed by the caller (only the matched instances' columns are written)
+extern "C" int mi_sparseinst_mask_grad(const void* masks, int ldm, int P, const float* targets, const int32_t* pairs, int K,
+                                       const float* stats, float c_bce, float c_dice, void* dmasks, mi_stream_t st) {
+  MI_REQUIRE(masks && targets && pairs && stats && dmasks && K > 0 && P > 0, "sparseinst_mask_grad: args");
+  MaskLossK k;
+  memset(&k, 0, sizeof(k));
+  k.masks = (const __bf16*)masks; k.tgt = targets; k.pairs = pairs; k.stats = (float*)stats; k.dmasks = (__bf16*)dmasks;
+  k.K = K; k.P = P; k.ldm = ldm; k.c_bce = c_bce; k.c_dice = c_dice;
+  int bx = (P + 1023) / 1024;
+  if (bx > 128) bx = 128;
+  hipLaunchKernelGGL(mask_grad_kernel, dim3(bx, K), dim3(256), 0, (hipStream_t)st, k);
+  MI_CHECK_LAUNCH("sparseinst_mask_grad");
+  return MI_OK;
+}

@@ -14,3 +14,7 @@ from .resnet import ResNet, build_resnet_backbone, FrozenBatchNorm2d
 from .box_ops import box_cxcywh_to_xyxy, box_xyxy_to_cxcywh, box_iou, generalized_box_iou
 from .detr_meta import (Detr, Joiner, MaskedBackbone, MaskedBackboneTraceFriendly, NestedTensor, PostProcess,
                         nested_tensor_from_tensor_list)
+from .sparseinst import (SparseInst, InstanceContextEncoder, PyramidPoolingModule, MyAdaptiveAvgPool2d, InstanceBranch,
+                         GroupInstanceBranch, MaskBranch, BaseIAMDecoder, GroupIAMDecoder, SparseInstCriterion,
+                         SparseInstMatcher, build_sparse_inst_encoder, build_sparse_inst_decoder,
+                         build_sparse_inst_criterion, rescoring_mask)

@@ -51,4 +51,6 @@ class HungarianMatcher(nn.Module):
     def forward(self, outputs, targets):
         m = self.match_device(outputs, targets)
         n = m["nmatch"].tolist()   # one small D2H (the reference moves the whole cost matrix instead)
+        if any(v < 0 for v in n):  # the kernel's flag for NaN / inf costs: scipy raises ValueError in the same situation
+            raise ValueError("matrix contains invalid numeric entries")
         return [(m["match_q"][b, : n[b]].clone(), m["match_t"][b, : n[b]].clone()) for b in range(len(n))]

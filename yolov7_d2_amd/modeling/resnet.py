@@ -14,7 +14,8 @@ How it runs:
     into an 8x8 kernel (row / column -1 are zero) - no 3-channel implicit GEMM with 13/16 of the k-chunk wasted;
   * ReLU / residual add: mi_ew_bf16; MaxPool2d(3, 2, 1): mi_maxpool3x3s2_*;
   * MODEL.BACKBONE.FREEZE_AT (default 2): the stem and res2 run forward-only (no saved activations, no data / weight
-    gradients), exactly the layers detectron2 freezes.
+    gradients), exactly the layers detectron2 freezes; FREEZE_AT 0 (SparseInst) trains the stem through the 16-tap
+    weight-gradient kernel.
 Activations are bf16 NCHW tensors in channels_last memory (= NHWC for the kernels).
 """
 import ctypes as C
@@ -135,6 +136,72 @@ class Conv2d(nn.Module):
         return torch.ops.mi355.conv2d(x, w, shift, self.stride, self.padding)
 
 
+class _StemFn(torch.autograd.Function):
+    """trainable stem (MODEL.BACKBONE.FREEZE_AT 0, configs/coco/sparseinst/Base-SparseInst.yaml:7): forward as
+    BasicStem.forward; backward = max-pool routing, ReLU mask and the weight gradient of the 16-tap conv (wgrad kernel,
+    NT = 16) mapped back from the 4x4 space-to-depth layout to the 7x7 OIHW gradient.  The input image needs no gradient."""
+
+    @staticmethod
+    def forward(ctx, s2d, w7, scale, shift):
+        N, Hh, Wh, _ = s2d.shape
+        Cout, Cin = w7.shape[0], w7.shape[1]
+        w4 = _w7_to_w4(w7 * scale.view(-1, 1, 1, 1))
+        wf = torch.empty(16 * 16 * Cout, dtype=torch.bfloat16, device=s2d.device)
+        L.check(L.lib().mi_pack_conv_weight(w4.contiguous().data_ptr(), Cout, 4 * Cin, 4, 4, wf.data_ptr(), 16, Cout,
+                                            None, 0, 0, L.stream_ptr()), "mi_pack_conv_weight (stem)")
+        y = torch.empty(N, Hh, Wh, Cout, dtype=torch.bfloat16, device=s2d.device)
+        _run_conv(_conv_desc(s2d.data_ptr(), 16, N, Hh, Wh, wf, 16, y.data_ptr(), Cout, Hh, Wh, Cout, Cout, _STEM_TAPS,
+                             bias=shift.float().contiguous()), "mi_conv2d (7x7 stem as 4x4 over space-to-depth)")
+        a = torch.empty_like(y)
+        L.check(L.lib().mi_ew_bf16(y.data_ptr(), None, a.data_ptr(), y.numel(), 1, L.stream_ptr()), "relu")
+        out = torch.empty(N, (Hh + 1) // 2, (Wh + 1) // 2, Cout, dtype=torch.bfloat16, device=s2d.device)
+        L.check(L.lib().mi_maxpool3x3s2_fwd(a.data_ptr(), Cout, out.data_ptr(), Cout, N, Hh, Wh, Cout, L.stream_ptr()), "maxpool")
+        ctx.save_for_backward(s2d, a, scale)
+        ctx.shape = (Cout, Cin)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        s2d, a, scale = ctx.saved_tensors
+        Cout, Cin = ctx.shape
+        N, Hh, Wh, _ = s2d.shape
+        g = g.contiguous()
+        da = torch.empty_like(a)
+        lib = L.lib()
+        L.check(lib.mi_maxpool3x3s2_bwd(a.data_ptr(), Cout, g.data_ptr(), Cout, da.data_ptr(), Cout, 0, N, Hh, Wh, Cout,
+                                        L.stream_ptr()), "maxpool bwd")
+        dy = torch.empty_like(a)
+        L.check(lib.mi_ew_bf16(da.data_ptr(), a.data_ptr(), dy.data_ptr(), a.numel(), 2, L.stream_ptr()), "relu bwd")
+        gw4 = torch.empty(Cout, 4 * Cin, 4, 4, dtype=torch.float32, device=a.device)
+        d = L.mi_wgrad_desc()
+        d.x, d.dy, d.gw = s2d.data_ptr(), dy.data_ptr(), gw4.data_ptr()
+        d.ldx, d.ldy, d.N, d.H, d.W, d.outH, d.outW, d.stride = 16, Cout, N, Hh, Wh, Hh, Wh, 1
+        d.Cin, d.Cout, d.CinPad, d.CoutPad, d.ntaps = 4 * Cin, Cout, 16, Cout, 16
+        for t, (dy_, dx_, _) in enumerate(_STEM_TAPS):
+            d.tap_dy[t], d.tap_dx[t] = dy_, dx_
+        need = lib.mi_conv2d_wgrad_plan(C.byref(d))
+        L.check(need, "mi_conv2d_wgrad_plan (stem)")
+        ws = torch.empty(max(int(need), 16), dtype=torch.uint8, device=a.device)
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
+        L.check(lib.mi_conv2d_wgrad(C.byref(d), L.stream_ptr()), "mi_conv2d_wgrad (stem)")
+        # [Cout][(px*2+py)*Cin + c][Ay][Ax] -> 8x8 kernel rows R = 2 Ay + py -> drop the zero row / column -> 7x7
+        g8 = gw4.view(Cout, 2, 2, Cin, 4, 4).permute(0, 3, 4, 2, 5, 1).reshape(Cout, Cin, 8, 8)
+        gw7 = g8[:, :, 1:, 1:] * scale.view(-1, 1, 1, 1)
+        dshift = dy.float().sum((0, 1, 2))
+        return None, gw7, None, dshift
+
+
+_STEM_TAPS = [(ay - 2, ax - 2, ay * 4 + ax) for ay in range(4) for ax in range(4)]
+
+
+def _w7_to_w4(w7s):
+    """7x7 kernel -> 8x8 with a zero first row / column -> [Cout][q = py + 2 px][c] x 4x4 taps (ay, ax in -2..1)"""
+    Cout, Cin = w7s.shape[:2]
+    w8 = w7s.new_zeros(Cout, Cin, 8, 8)
+    w8[:, :, 1:, 1:] = w7s
+    return w8.view(Cout, Cin, 4, 2, 4, 2).permute(0, 5, 3, 1, 2, 4).reshape(Cout, 4 * Cin, 4, 4)   # ch = (px*2+py)*Cin+c
+
+
 class BasicStem(nn.Module):
     def __init__(self, cin=3, cout=64):
         super().__init__()
@@ -144,14 +211,10 @@ class BasicStem(nn.Module):
     def forward(self, x):
         """x: fp32 NCHW image (already normalised).  7x7 s2 conv + frozen norm + ReLU + max-pool."""
         w7 = self.conv1.weight
-        if w7.requires_grad and torch.is_grad_enabled():
-            raise L.MI355Error("ResNet stem: MODEL.BACKBONE.FREEZE_AT >= 1 is required (the 7x7 stem runs forward-only, "
-                               "as in every configuration of the reference)")
+        scale, shift = self.conv1.norm.affine()
+        N, Cin, H, W = x.shape
+        He, We = H + (H & 1), W + (W & 1)
         with torch.no_grad():
-            scale, shift = self.conv1.norm.affine()
-            N, Cin, H, W = x.shape
-            Cout = w7.shape[0]
-            He, We = H + (H & 1), W + (W & 1)
             if (He, We) != (H, W):       # an odd border: one more zero row / column = the conv's own zero padding
                 xp = x.new_zeros(N, Cin, He, We)
                 xp[:, :, :H, :W] = x
@@ -159,20 +222,10 @@ class BasicStem(nn.Module):
             x = x.float().contiguous()
             s2d = torch.empty(N, He // 2, We // 2, 16, dtype=torch.bfloat16, device=x.device)
             L.check(L.lib().mi_focus_pack(x.data_ptr(), N, He, We, s2d.data_ptr(), 16, L.stream_ptr()), "mi_focus_pack")
-            # 7x7 kernel -> 8x8 with a zero first row / column -> [Cout][q = py + 2 px][c] x 4x4 taps (ay, ax in -2..1)
-            w8 = w7.new_zeros(Cout, Cin, 8, 8)
-            w8[:, :, 1:, 1:] = w7 * scale.view(-1, 1, 1, 1)
-            w4 = w8.view(Cout, Cin, 4, 2, 4, 2).permute(0, 5, 3, 1, 2, 4).reshape(Cout, 4 * Cin, 4, 4)   # ch = (px*2+py)*3+c
-            wf = torch.empty(16 * 16 * Cout, dtype=torch.bfloat16, device=x.device)
-            L.check(L.lib().mi_pack_conv_weight(w4.contiguous().data_ptr(), Cout, 4 * Cin, 4, 4, wf.data_ptr(), 16, Cout,
-                                                None, 0, 0, L.stream_ptr()), "mi_pack_conv_weight (stem)")
-            y = torch.empty(N, He // 2, We // 2, Cout, dtype=torch.bfloat16, device=x.device)
-            taps = [(ay - 2, ax - 2, ay * 4 + ax) for ay in range(4) for ax in range(4)]
-            b32 = shift.float().contiguous()
-            _run_conv(_conv_desc(s2d.data_ptr(), 16, N, He // 2, We // 2, wf, 16, y.data_ptr(), Cout, He // 2, We // 2, Cout,
-                                 Cout, taps, bias=b32), "mi_conv2d (7x7 stem as 4x4 over space-to-depth)")
-            y = _EwRelu.apply(y)
-            return _MaxPool.apply(y).permute(0, 3, 1, 2)
+        if w7.requires_grad and torch.is_grad_enabled():
+            return _StemFn.apply(s2d, w7, scale, shift).permute(0, 3, 1, 2)
+        with torch.no_grad():
+            return _StemFn.apply(s2d, w7, scale, shift).permute(0, 3, 1, 2)
 
 
 class BottleneckBlock(nn.Module):

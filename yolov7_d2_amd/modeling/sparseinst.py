@@ -1,0 +1,694 @@
+"""SparseInst (BASELINE.json config 5) on the MI355X kernels - drop-ins, with the reference's names, constructors, config
+keys and state_dict keys, for
+
+    SparseInst (META_ARCH)                         yolov7/modeling/meta_arch/sparseinst.py:54-234 (+ rescoring_mask :24-27)
+    InstanceContextEncoder, PyramidPoolingModule,
+    MyAdaptiveAvgPool2d                            yolov7/modeling/transcoders/encoder_sparseinst.py:18-127
+    InstanceBranch, GroupInstanceBranch, MaskBranch,
+    BaseIAMDecoder, GroupIAMDecoder                yolov7/modeling/transcoders/decoder_sparseinst.py:18-255
+    SparseInstCriterion, SparseInstMatcher,
+    dice_score, dice_loss, compute_mask_iou        yolov7/modeling/loss/sparseinst_loss.py:19-354
+
+How it maps to the kernels (activations are bf16 NCHW tensors in channels_last memory = NHWC):
+  * every convolution (FPN laterals / outputs, PPM, the two 4 x (3x3 + ReLU) stacks over the 258-channel coordinate-augmented
+    map, the grouped IAM conv as its 4 independent groups, projection, fusion)      -> torch.ops.mi355.conv2d
+  * IAM aggregation  inst[b, n, c] = sum_p sigmoid(iam)[b, n, p] * feat[b, c, p]   -> the weight-gradient MFMA kernel
+    (a "sum over pixels of an outer product" IS a conv wgrad: dy = iam probabilities, x = features), backward through the
+    1x1 conv kernel
+  * dynamic mask head  mask[b, n, p] = sum_c kernel[b, n, c] * feat[b, c, p]        -> the 1x1 conv kernel with the
+    per-image predicted kernels as weights (forward, data gradient, and the weight gradient = d kernel)
+  * the matcher's dice-score matmul [B*N, HW] x [HW, M]                            -> the same pixel-sum MFMA kernel;
+    scipy's linear_sum_assignment(maximize=True)                                   -> mi_lsap on the negated scores
+  * bilinear resizes, nearest x2, sigmoid / ReLU / add                              -> mi_bilinear_resize_*, mi_upsample2x_*,
+    mi_ew_bf16
+  * mask BCE + dice + thresholded mask IoU of the matched pairs, and their gradient  -> mi_sparseinst_mask_stats / _grad
+Small tensors (the [B, 100, 80] class logits' focal loss, the PPM's 1..6-pixel average pools, normalisers) stay torch
+device ops.  No CPU path: device tensors only.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import _lib as L
+from ..d2shim import META_ARCH_REGISTRY, ImageList, Instances, build_backbone
+from .transformer import _LinearFn, _factor
+
+# ------------------------------------------------------------------------------------------------ small op wrappers
+
+
+def _nhwc(x):
+    return x.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()
+
+
+class _Ew1(torch.autograd.Function):
+    """unary elementwise on a contiguous bf16 tensor: kind 'relu' (ops 1 / 2) or 'sigmoid' (ops 3 / 4)"""
+
+    @staticmethod
+    def forward(ctx, a, kind):
+        a = a.contiguous()
+        y = torch.empty_like(a)
+        L.check(L.lib().mi_ew_bf16(a.data_ptr(), None, y.data_ptr(), a.numel(), 1 if kind == "relu" else 3,
+                                   L.stream_ptr()), "mi_ew_bf16")
+        ctx.save_for_backward(y)
+        ctx.kind = kind
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = g.contiguous()
+        out = torch.empty_like(g)
+        L.check(L.lib().mi_ew_bf16(g.data_ptr(), y.data_ptr(), out.data_ptr(), g.numel(), 2 if ctx.kind == "relu" else 4,
+                                   L.stream_ptr()), "mi_ew_bf16 (backward)")
+        return out, None
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        y = torch.empty_like(a)
+        L.check(L.lib().mi_ew_bf16(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), 0, L.stream_ptr()), "mi_ew_bf16 add")
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def relu(x):
+    """NCHW (channels_last) bf16 -> same"""
+    return _Ew1.apply(_nhwc(x), "relu").permute(0, 3, 1, 2)
+
+
+class _Resize(torch.autograd.Function):
+    """F.interpolate(mode='bilinear', align_corners=False) on an NHWC bf16 image"""
+
+    @staticmethod
+    def forward(ctx, xh, Ho, Wo):
+        N, H, W, Cc = xh.shape
+        assert Cc % 8 == 0
+        y = torch.empty(N, Ho, Wo, Cc, dtype=torch.bfloat16, device=xh.device)
+        L.check(L.lib().mi_bilinear_resize_bf16(xh.data_ptr(), Cc, N, H, W, Cc, y.data_ptr(), Cc, Ho, Wo, L.stream_ptr()),
+                "mi_bilinear_resize_bf16")
+        ctx.shape = (N, H, W, Cc, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        N, H, W, Cc, Ho, Wo = ctx.shape
+        g = g.contiguous()
+        dx = torch.empty(N, H, W, Cc, dtype=torch.bfloat16, device=g.device)
+        acc = torch.zeros(N * H * W * Cc, dtype=torch.float32, device=g.device)
+        L.check(L.lib().mi_bilinear_resize_bwd_bf16(g.data_ptr(), Cc, N, H, W, Cc, dx.data_ptr(), Cc, Ho, Wo, acc.data_ptr(),
+                                                    L.stream_ptr()), "mi_bilinear_resize_bwd_bf16")
+        return dx, None, None
+
+
+def resize_bilinear(x, size):
+    """NCHW (channels_last) -> NCHW (channels_last), size = (Ho, Wo)"""
+    if tuple(x.shape[-2:]) == tuple(size):
+        return x
+    return _Resize.apply(_nhwc(x), int(size[0]), int(size[1])).permute(0, 3, 1, 2)
+
+
+class _Up2(torch.autograd.Function):
+    """F.interpolate(scale_factor=2, mode='nearest') on NHWC bf16"""
+
+    @staticmethod
+    def forward(ctx, xh):
+        N, H, W, Cc = xh.shape
+        y = torch.empty(N, 2 * H, 2 * W, Cc, dtype=torch.bfloat16, device=xh.device)
+        L.check(L.lib().mi_upsample2x_fwd(xh.data_ptr(), Cc, y.data_ptr(), Cc, N, H, W, Cc, L.stream_ptr()), "mi_upsample2x_fwd")
+        ctx.shape = (N, H, W, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        N, H, W, Cc = ctx.shape
+        g = g.contiguous()
+        dx = torch.empty(N, H, W, Cc, dtype=torch.bfloat16, device=g.device)
+        L.check(L.lib().mi_upsample2x_bwd(g.data_ptr(), Cc, dx.data_ptr(), Cc, 0, N, H, W, Cc, L.stream_ptr()), "mi_upsample2x_bwd")
+        return dx
+
+
+def _rup(a, b):
+    return (a + b - 1) // b * b
+
+
+def _pad_cols(t, Cp):
+    if t.shape[-1] == Cp:
+        return t.contiguous()
+    out = torch.zeros(*t.shape[:-1], Cp, dtype=t.dtype, device=t.device)
+    out[..., : t.shape[-1]] = t
+    return out
+
+
+def pixel_outer(a, b):
+    """out[i, j] = sum_p a[p, i] * b[p, j]  (a: bf16 [P, Ca], b: bf16 [P, Cb], Ca / Cb multiples of 32) -> fp32 [Ca, Cb]:
+    the conv weight-gradient kernel with dy = a, x = b over the P 'pixels' (split-K over pixel tiles, MFMA)"""
+    P, Ca = a.shape
+    Cb = b.shape[1]
+    assert Ca % 32 == 0 and Cb % 32 == 0 and a.is_contiguous() and b.is_contiguous()
+    H, W = _factor(P)
+    out = torch.empty(Ca, Cb, dtype=torch.float32, device=a.device)
+    d = L.mi_wgrad_desc()
+    d.x, d.dy, d.gw = b.data_ptr(), a.data_ptr(), out.data_ptr()
+    d.ldx, d.ldy, d.N, d.H, d.W, d.outH, d.outW, d.stride = Cb, Ca, 1, H, W, H, W, 1
+    d.Cin, d.Cout, d.CinPad, d.CoutPad, d.ntaps = Cb, Ca, Cb, Ca, 1
+    need = L.lib().mi_conv2d_wgrad_plan(C.byref(d))
+    L.check(need, "mi_conv2d_wgrad_plan (pixel_outer)")
+    ws = torch.empty(max(int(need), 16), dtype=torch.uint8, device=a.device)
+    d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
+    L.check(L.lib().mi_conv2d_wgrad(C.byref(d), L.stream_ptr()), "mi_conv2d_wgrad (pixel_outer)")
+    return out
+
+
+class _PixelOuterFn(torch.autograd.Function):
+    """differentiable pixel_outer: d a[p, i] = sum_j g[i, j] b[p, j], d b[p, j] = sum_i a[p, i] g[i, j] (1x1 conv kernel)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return pixel_outer(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        with torch.no_grad():
+            da = _LinearFn.apply(b, g.float().contiguous(), None)                 # [P, Ca]
+            db = _LinearFn.apply(a, g.float().t().contiguous(), None)             # [P, Cb]
+        return da.contiguous(), db.contiguous()
+
+
+def _conv(x, m, stride=1):
+    """nn.Conv2d / detectron2 Conv2d (bias, no norm) through the implicit-GEMM op"""
+    return torch.ops.mi355.conv2d(x, m.weight, m.bias, stride, m.padding[0])
+
+
+def _linear(x, lin):
+    shp = x.shape
+    y = _LinearFn.apply(x.to(torch.bfloat16).reshape(-1, shp[-1]).contiguous(), lin.weight, lin.bias)
+    return y.reshape(*shp[:-1], lin.out_features)
+
+
+# ------------------------------------------------------------------------------------------------ encoder
+class MyAdaptiveAvgPool2d(nn.Module):
+    """encoder_sparseinst.py:18-40: avg_pool2d with kernel = ceil(size / sz) (NOT nn.AdaptiveAvgPool2d)"""
+
+    def __init__(self, sz=None):
+        super().__init__()
+        self.sz = sz
+
+    def forward(self, x):
+        kh, kw = x.shape[2], x.shape[3]
+        if self.sz is not None:
+            sz = (self.sz, self.sz) if isinstance(self.sz, int) else self.sz
+            kh, kw = math.ceil(x.shape[2] / sz[0]), math.ceil(x.shape[3] / sz[1])
+        return F.avg_pool2d(x.float(), kernel_size=(kh, kw), ceil_mode=False).to(x.dtype)      # 1..36 output pixels
+
+
+class PyramidPoolingModule(nn.Module):
+    def __init__(self, in_channels, channels=512, sizes=(1, 2, 3, 6)):
+        super().__init__()
+        self.stages = nn.ModuleList([nn.Sequential(MyAdaptiveAvgPool2d((s, s)), nn.Conv2d(in_channels, channels, 1))
+                                     for s in sizes])
+        self.bottleneck = nn.Conv2d(in_channels + len(sizes) * channels, in_channels, 1)
+
+    def forward(self, feats):
+        h, w = feats.shape[2], feats.shape[3]
+        priors = [resize_bilinear(relu(_conv(st[0](feats), st[1])), (h, w)) for st in self.stages] + [feats]
+        return relu(_conv(torch.cat(priors, 1), self.bottleneck))
+
+
+class InstanceContextEncoder(nn.Module):
+    def __init__(self, cfg, input_shape):
+        super().__init__()
+        self.num_channels = cfg.MODEL.SPARSE_INST.ENCODER.NUM_CHANNELS
+        self.in_features = cfg.MODEL.SPARSE_INST.ENCODER.IN_FEATURES
+        self.in_channels = [input_shape[f].channels for f in self.in_features]
+        lat, outc = [], []
+        for cin in reversed(self.in_channels):
+            l_ = nn.Conv2d(cin, self.num_channels, 1)
+            o_ = nn.Conv2d(self.num_channels, self.num_channels, 3, padding=1)
+            for m in (l_, o_):      # c2_xavier_fill
+                nn.init.kaiming_uniform_(m.weight, a=1)
+                nn.init.constant_(m.bias, 0)
+            lat.append(l_); outc.append(o_)
+        self.fpn_laterals, self.fpn_outputs = nn.ModuleList(lat), nn.ModuleList(outc)
+        self.ppm = PyramidPoolingModule(self.num_channels, self.num_channels // 4)
+        self.fusion = nn.Conv2d(self.num_channels * 3, self.num_channels, 1)
+        nn.init.kaiming_normal_(self.fusion.weight, mode="fan_out", nonlinearity="relu")       # c2_msra_fill
+        nn.init.constant_(self.fusion.bias, 0)
+
+    def forward(self, features):
+        feats = [features[f] for f in self.in_features][::-1]
+        prev = self.ppm(_conv(feats[0], self.fpn_laterals[0]))
+        outputs = [_conv(prev, self.fpn_outputs[0])]
+        for feature, lat_conv, out_conv in zip(feats[1:], self.fpn_laterals[1:], self.fpn_outputs[1:]):
+            lat = _conv(feature, lat_conv)
+            top = _Up2.apply(_nhwc(prev))
+            prev = _Add.apply(_nhwc(lat), top).permute(0, 3, 1, 2)
+            outputs.insert(0, _conv(prev, out_conv))
+        size = outputs[0].shape[2:]
+        fused = [outputs[0]] + [resize_bilinear(x, size) for x in outputs[1:]]
+        return _conv(torch.cat(fused, dim=1), self.fusion)
+
+
+# ------------------------------------------------------------------------------------------------ decoder
+def _make_stack_3x3_convs(num_convs, in_channels, out_channels):
+    convs = []
+    for _ in range(num_convs):
+        c = nn.Conv2d(in_channels, out_channels, 3, padding=1)
+        nn.init.kaiming_normal_(c.weight, mode="fan_out", nonlinearity="relu")
+        nn.init.constant_(c.bias, 0)
+        convs += [c, nn.ReLU(True)]
+        in_channels = out_channels
+    return nn.Sequential(*convs)
+
+
+def _run_stack(seq, x):
+    for m in seq:
+        x = relu(x) if isinstance(m, nn.ReLU) else _conv(x, m)
+    return x
+
+
+def _aggregate(iam, features):
+    """iam [B, N, H, W] logits, features [B, C, H, W] -> inst [B, N, C] = (sigmoid(iam) @ features^T) / normaliser
+    (decoder_sparseinst.py:62-74 / 217-228)"""
+    B, N, H, W = iam.shape
+    Cc = features.shape[1]
+    Np = _rup(N, 32)
+    prob = _Ew1.apply(_nhwc(iam), "sigmoid")                          # [B, H, W, N]
+    fh = _nhwc(features)
+    outs = []
+    for b in range(B):
+        a = _pad_cols(prob[b].reshape(H * W, N), Np)
+        outs.append(_PixelOuterFn.apply(a, fh[b].reshape(H * W, Cc))[:N])
+    inst = torch.stack(outs)                                           # fp32 [B, N, C]
+    return inst, prob.float().sum((1, 2))                             # normaliser [B, N]
+
+
+class InstanceBranch(nn.Module):
+    def __init__(self, cfg, in_channels):
+        super().__init__()
+        d = cfg.MODEL.SPARSE_INST.DECODER
+        dim, self.num_classes = d.INST.DIM, d.NUM_CLASSES
+        self.inst_convs = _make_stack_3x3_convs(d.INST.CONVS, in_channels, dim)
+        self.iam_conv = nn.Conv2d(dim, d.NUM_MASKS, 3, padding=1)
+        self.cls_score = nn.Linear(dim, self.num_classes)
+        self.mask_kernel = nn.Linear(dim, d.KERNEL_DIM)
+        self.objectness = nn.Linear(dim, 1)
+        self.prior_prob = 0.01
+        _init_inst_heads(self)
+
+    def forward(self, features):
+        features = _run_stack(self.inst_convs, features)
+        iam = _conv(features, self.iam_conv)
+        inst, norm = _aggregate(iam, features)
+        inst = inst / norm.clamp(min=1e-6)[:, :, None]
+        return _linear(inst, self.cls_score), _linear(inst, self.mask_kernel), _linear(inst, self.objectness), iam
+
+
+def _init_inst_heads(m):
+    bias_value = -math.log((1 - m.prior_prob) / m.prior_prob)
+    for module in (m.iam_conv, m.cls_score):
+        nn.init.constant_(module.bias, bias_value)
+    nn.init.normal_(m.iam_conv.weight, std=0.01)
+    nn.init.normal_(m.cls_score.weight, std=0.01)
+    nn.init.normal_(m.mask_kernel.weight, std=0.01)
+    nn.init.constant_(m.mask_kernel.bias, 0.0)
+
+
+class GroupInstanceBranch(nn.Module):
+    def __init__(self, cfg, in_channels):
+        super().__init__()
+        d = cfg.MODEL.SPARSE_INST.DECODER
+        dim, self.num_groups, self.num_classes = d.INST.DIM, d.GROUPS, d.NUM_CLASSES
+        self.inst_convs = _make_stack_3x3_convs(d.INST.CONVS, in_channels, dim)
+        expand_dim = dim * self.num_groups
+        self.iam_conv = nn.Conv2d(dim, d.NUM_MASKS * self.num_groups, 3, padding=1, groups=self.num_groups)
+        self.fc = nn.Linear(expand_dim, expand_dim)
+        self.cls_score = nn.Linear(expand_dim, self.num_classes)
+        self.mask_kernel = nn.Linear(expand_dim, d.KERNEL_DIM)
+        self.objectness = nn.Linear(expand_dim, 1)
+        self.prior_prob = 0.01
+        _init_inst_heads(self)
+        nn.init.kaiming_uniform_(self.fc.weight, a=1)
+        nn.init.constant_(self.fc.bias, 0)
+
+    def forward(self, features):
+        features = _run_stack(self.inst_convs, features)
+        # grouped 3x3 conv = its `groups` independent convs over channel slices
+        G = self.num_groups
+        cin, cout = features.shape[1] // G, self.iam_conv.out_channels // G
+        iam = torch.cat([torch.ops.mi355.conv2d(features[:, g * cin:(g + 1) * cin], self.iam_conv.weight[g * cout:(g + 1) * cout],
+                                                self.iam_conv.bias[g * cout:(g + 1) * cout], 1, 1) for g in range(G)], 1)
+        inst, norm = _aggregate(iam, features)
+        inst = inst / norm.clamp(min=1e-6, max=1e5)[:, :, None]
+        B, N = inst.shape[:2]
+        d4 = N // 4
+        inst = inst.reshape(B, 4, d4, -1).transpose(1, 2).reshape(B, d4, -1)
+        inst = _Ew1.apply(_linear(inst, self.fc), "relu")
+        return _linear(inst, self.cls_score), _linear(inst, self.mask_kernel), _linear(inst, self.objectness), iam
+
+
+class MaskBranch(nn.Module):
+    def __init__(self, cfg, in_channels):
+        super().__init__()
+        d = cfg.MODEL.SPARSE_INST.DECODER
+        self.mask_convs = _make_stack_3x3_convs(d.MASK.CONVS, in_channels, d.MASK.DIM)
+        self.projection = nn.Conv2d(d.MASK.DIM, d.KERNEL_DIM, kernel_size=1)
+        nn.init.kaiming_normal_(self.projection.weight, mode="fan_out", nonlinearity="relu")
+        nn.init.constant_(self.projection.bias, 0)
+
+    def forward(self, features):
+        return _conv(_run_stack(self.mask_convs, features), self.projection)
+
+
+class BaseIAMDecoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        in_channels = cfg.MODEL.SPARSE_INST.ENCODER.NUM_CHANNELS + 2
+        self.scale_factor = cfg.MODEL.SPARSE_INST.DECODER.SCALE_FACTOR
+        self.output_iam = cfg.MODEL.SPARSE_INST.DECODER.OUTPUT_IAM
+        self.inst_branch = InstanceBranch(cfg, in_channels)
+        self.mask_branch = MaskBranch(cfg, in_channels)
+
+    @torch.no_grad()
+    def compute_coordinates(self, x):
+        h, w = x.size(2), x.size(3)
+        y_loc = torch.linspace(-1, 1, h, device=x.device)
+        x_loc = torch.linspace(-1, 1, w, device=x.device)
+        y_loc, x_loc = torch.meshgrid(y_loc, x_loc, indexing="ij")
+        y_loc = y_loc.expand([x.shape[0], 1, -1, -1])
+        x_loc = x_loc.expand([x.shape[0], 1, -1, -1])
+        return torch.cat([x_loc, y_loc], 1).to(x)
+
+    def forward(self, features):
+        if not features.is_cuda:
+            raise L.MI355Error("SparseInst decoder: the MI355X path needs device tensors (no CPU fallback)")
+        features = torch.cat([self.compute_coordinates(features), features], dim=1)
+        pred_logits, pred_kernel, pred_scores, iam = self.inst_branch(features)
+        mask_features = self.mask_branch(features)
+        B, Cc, H, W = mask_features.shape
+        N = pred_kernel.shape[1]
+        Np = _rup(N, 32)
+        mf = _nhwc(mask_features)
+        # the predicted kernels ARE the weights of a per-image 1x1 conv over the mask features (padded to 32 instances)
+        masks = torch.stack([_LinearFn.apply(mf[b].reshape(H * W, Cc), _pad_rows(pred_kernel[b].float(), Np), None)
+                             for b in range(B)]).reshape(B, H, W, Np)
+        Ho, Wo = int(H * self.scale_factor), int(W * self.scale_factor)
+        masks = _Resize.apply(masks.contiguous(), Ho, Wo)                       # [B, Ho, Wo, Np] (NHWC, instance = channel)
+        output = {"pred_logits": pred_logits.float(), "pred_masks": masks.permute(0, 3, 1, 2)[:, :N],
+                  "pred_scores": pred_scores.float(), "_masks_nhwc": masks}
+        if self.output_iam:
+            output["pred_iam"] = resize_bilinear(iam, (Ho, Wo))
+        return output
+
+
+def _pad_rows(w, Np):
+    if w.shape[0] == Np:
+        return w
+    return torch.cat([w, w.new_zeros(Np - w.shape[0], w.shape[1])], 0)
+
+
+class GroupIAMDecoder(BaseIAMDecoder):
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        in_channels = cfg.MODEL.SPARSE_INST.ENCODER.NUM_CHANNELS + 2
+        self.inst_branch = GroupInstanceBranch(cfg, in_channels)
+
+
+_ENCODERS = {"InstanceContextEncoder": InstanceContextEncoder}
+_DECODERS = {"BaseIAMDecoder": BaseIAMDecoder, "GroupIAMDecoder": GroupIAMDecoder}
+
+
+def build_sparse_inst_encoder(cfg, input_shape):
+    return _ENCODERS[cfg.MODEL.SPARSE_INST.ENCODER.NAME](cfg, input_shape)
+
+
+def build_sparse_inst_decoder(cfg):
+    return _DECODERS[cfg.MODEL.SPARSE_INST.DECODER.NAME](cfg)
+
+
+# ------------------------------------------------------------------------------------------------ criterion
+def _target_masks(targets, input_shape, size, device):
+    """nested_masks_from_list (utils/misc.py:148-170) + bilinear resize to the prediction size: fp32 [sum M, Ho*Wo]"""
+    ms = [t["masks"] for t in targets]
+    ms = [m.tensor if hasattr(m, "tensor") else m for m in ms]
+    if sum(m.shape[0] for m in ms) == 0:
+        return torch.zeros(0, size[0] * size[1], device=device)
+    pad = []
+    for m in ms:
+        p = torch.zeros(m.shape[0], input_shape[0], input_shape[1], device=device)
+        p[:, : m.shape[1], : m.shape[2]] = m.to(device).float()
+        pad.append(p)
+    t = torch.cat(pad, 0)
+    t = F.interpolate(t[:, None], size=size, mode="bilinear", align_corners=False).squeeze(1)     # ground-truth preparation
+    return t.flatten(1).contiguous()
+
+
+def dice_score_device(masks_nhwc, tgt, sizes):
+    """dice_score (sparseinst_loss.py:31-36) of every prediction against every target OF ITS IMAGE: list of fp32 [N, M_i].
+    masks_nhwc: bf16 logits [B, Ho, Wo, Np]; tgt: fp32 [sum M, P]"""
+    B, Ho, Wo, Np = masks_nhwc.shape
+    P = Ho * Wo
+    sig = _Ew1.apply(masks_nhwc.contiguous(), "sigmoid").reshape(B, P, Np)
+    out, off = [], 0
+    for b, M in enumerate(sizes):
+        if M == 0:
+            out.append(torch.zeros(Np, 0, device=tgt.device))
+            continue
+        tb = tgt[off: off + M]                                          # [M, P]
+        Mp = _rup(M, 32)
+        tT = _pad_cols(tb.t().to(torch.bfloat16), Mp)                   # [P, Mp]
+        num = 2.0 * pixel_outer(sig[b].contiguous(), tT)[:, :M]         # [Np, M]
+        den = (sig[b].float() ** 2).sum(0)[:, None] + (tb * tb).sum(-1)[None, :]
+        out.append(num / (den + 1e-4))
+        off += M
+    return out
+
+
+class SparseInstMatcher(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.alpha = cfg.MODEL.SPARSE_INST.MATCHER.ALPHA
+        self.beta = cfg.MODEL.SPARSE_INST.MATCHER.BETA
+
+    @torch.no_grad()
+    def match_device(self, outputs, targets, input_shape):
+        masks = outputs["_masks_nhwc"]
+        B, Ho, Wo, Np = masks.shape
+        N = outputs["pred_logits"].shape[1]
+        dev = masks.device
+        sizes = [len(t["labels"]) for t in targets]
+        tgt = _target_masks(targets, input_shape, (Ho, Wo), dev)
+        gmax = max(max(sizes), 1)
+        off = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32, device=dev)
+        mq = torch.zeros(B, gmax, dtype=torch.int64, device=dev)
+        mt = torch.zeros(B, gmax, dtype=torch.int64, device=dev)
+        nm = torch.zeros(B, dtype=torch.int32, device=dev)
+        if sum(sizes) > 0:
+            prob = outputs["pred_logits"].float().sigmoid()
+            scores = dice_score_device(masks, tgt, sizes)
+            cost = torch.zeros(B, N, gmax, device=dev)
+            for b, M in enumerate(sizes):
+                if M:
+                    ids = targets[b]["labels"].to(dev)
+                    Cm = (scores[b][:N] ** self.alpha) * (prob[b][:, ids] ** self.beta)
+                    cost[b, :, :M] = -Cm                               # linear_sum_assignment(maximize=True)
+            L.check(L.lib().mi_lsap(cost.data_ptr(), off.data_ptr(), B, N, gmax, mq.data_ptr(), mt.data_ptr(), nm.data_ptr(),
+                                    L.stream_ptr()), "mi_lsap")
+        return dict(match_q=mq, match_t=mt, nmatch=nm, tgt=tgt, sizes=sizes, off=off)
+
+    @torch.no_grad()
+    def forward(self, outputs, targets, input_shape):
+        m = self.match_device(outputs, targets, input_shape)
+        n = m["nmatch"].tolist()
+        if any(v < 0 for v in n):
+            raise ValueError("matrix contains invalid numeric entries")
+        return [(m["match_q"][b, : n[b]].clone(), m["match_t"][b, : n[b]].clone()) for b in range(len(n))], m
+
+
+class _MaskLossFn(torch.autograd.Function):
+    """(mask logits NHWC, matched pairs) -> tensor [2 + K] = (sum of per-pair BCE sums, sum of per-pair dice losses,
+    mask IoU of every pair ...); d/d(mask logits) from the second kernel"""
+
+    @staticmethod
+    def forward(ctx, masks, tgt, pairs, K):
+        B, Ho, Wo, Np = masks.shape
+        P = Ho * Wo
+        stats = torch.empty(K, 8, dtype=torch.float32, device=masks.device)
+        L.check(L.lib().mi_sparseinst_mask_stats(masks.data_ptr(), Np, P, tgt.data_ptr(), pairs.data_ptr(), K,
+                                                 stats.data_ptr(), L.stream_ptr()), "mi_sparseinst_mask_stats")
+        bce = stats[:, 0].sum()
+        dice = (1.0 - 2.0 * stats[:, 1] / (stats[:, 2] + stats[:, 3] + 1e-4)).sum()
+        iou = stats[:, 4] / (stats[:, 6] + stats[:, 5] - stats[:, 4] + 1e-6)
+        ctx.save_for_backward(masks, tgt, pairs, stats)
+        ctx.K = K
+        return torch.cat([bce[None], dice[None], iou])
+
+    @staticmethod
+    def backward(ctx, g):
+        masks, tgt, pairs, stats = ctx.saved_tensors
+        B, Ho, Wo, Np = masks.shape
+        dm = torch.zeros_like(masks)
+        L.check(L.lib().mi_sparseinst_mask_grad(masks.data_ptr(), Np, Ho * Wo, tgt.data_ptr(), pairs.data_ptr(), ctx.K,
+                                                stats.data_ptr(), float(g[0]), float(g[1]), dm.data_ptr(), L.stream_ptr()),
+                "mi_sparseinst_mask_grad")
+        return dm, None, None, None
+
+
+def sigmoid_focal_loss(inputs, targets, alpha=0.25, gamma=2.0):
+    """fvcore.nn.sigmoid_focal_loss_jit(reduction='sum') (un-vendored; published formula)"""
+    p = torch.sigmoid(inputs)
+    ce = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    p_t = p * targets + (1 - p) * (1 - targets)
+    loss = ce * ((1 - p_t) ** gamma)
+    loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
+    return loss.sum()
+
+
+class SparseInstCriterion(nn.Module):
+    def __init__(self, cfg, matcher):
+        super().__init__()
+        self.matcher = matcher
+        ls = cfg.MODEL.SPARSE_INST.LOSS
+        self.losses = ls.ITEMS
+        self.weight_dict = dict(loss_ce=ls.CLASS_WEIGHT, loss_mask=ls.MASK_PIXEL_WEIGHT, loss_dice=ls.MASK_DICE_WEIGHT,
+                                loss_objectness=ls.OBJECTNESS_WEIGHT)
+        self.num_classes = cfg.MODEL.SPARSE_INST.DECODER.NUM_CLASSES
+
+    def forward(self, outputs, targets, input_shape):
+        indices, m = self.matcher(outputs, targets, input_shape)
+        dev = outputs["pred_logits"].device
+        num_instances = torch.as_tensor([sum(len(t["labels"]) for t in targets)], dtype=torch.float, device=dev)
+        world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(num_instances)
+            world = torch.distributed.get_world_size()
+        num_instances = torch.clamp(num_instances / world, min=1).item()
+        losses = {}
+        if "labels" in self.losses:
+            src_logits = outputs["pred_logits"]
+            labels = torch.zeros_like(src_logits)
+            for b, (src, tgt_j) in enumerate(indices):
+                if len(src):
+                    labels[b, src, targets[b]["labels"].to(dev)[tgt_j]] = 1
+            losses["loss_ce"] = sigmoid_focal_loss(src_logits.flatten(0, 1), labels.flatten(0, 1)) / num_instances
+        if "masks" in self.losses:
+            masks = outputs["_masks_nhwc"]
+            K = sum(len(s) for s, _ in indices)
+            if K == 0:
+                z = masks.float().sum() * 0.0
+                losses.update(loss_dice=z, loss_mask=z, loss_objectness=outputs["pred_scores"].sum() * 0.0)
+            else:
+                rows, scr = [], []
+                for b, (src, tgt_j) in enumerate(indices):
+                    o = int(m["off"][b])
+                    for q, j in zip(src.tolist(), tgt_j.tolist()):
+                        rows.append((b, q, o + j))
+                        scr.append(outputs["pred_scores"][b, q, 0])
+                pairs = torch.tensor(rows, dtype=torch.int32, device=dev)
+                r = _MaskLossFn.apply(masks.contiguous(), m["tgt"], pairs, K)
+                P = masks.shape[1] * masks.shape[2]
+                losses["loss_mask"] = r[0] / (K * P)                      # BCE 'mean' over the K x P matched elements
+                losses["loss_dice"] = r[1] / num_instances
+                losses["loss_objectness"] = F.binary_cross_entropy_with_logits(torch.stack(scr), r[2:].detach(), reduction="mean")
+        for k in list(losses.keys()):
+            if k in self.weight_dict:
+                losses[k] = losses[k] * self.weight_dict[k]
+        return losses
+
+
+def build_sparse_inst_criterion(cfg):
+    return SparseInstCriterion(cfg, SparseInstMatcher(cfg))
+
+
+# ------------------------------------------------------------------------------------------------ meta architecture
+def rescoring_mask(scores, mask_pred, masks):
+    mask_pred_ = mask_pred.float()
+    return scores * ((masks * mask_pred_).sum([1, 2]) / (mask_pred_.sum([1, 2]) + 1e-6))
+
+
+@META_ARCH_REGISTRY.register()
+class SparseInst(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.device = torch.device(cfg.MODEL.DEVICE)
+        self.backbone = build_backbone(cfg)
+        self.size_divisibility = self.backbone.size_divisibility
+        self.encoder = build_sparse_inst_encoder(cfg, self.backbone.output_shape())
+        self.decoder = build_sparse_inst_decoder(cfg)
+        self.criterion = build_sparse_inst_criterion(cfg)
+        self.mask_format = cfg.INPUT.MASK_FORMAT
+        self.register_buffer("pixel_mean", torch.Tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1), persistent=False)
+        self.register_buffer("pixel_std", torch.Tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1), persistent=False)
+        self.cls_threshold = cfg.MODEL.YOLO.CONF_THRESHOLD
+        self.mask_threshold = cfg.MODEL.SPARSE_INST.MASK_THRESHOLD
+        self.max_detections = cfg.MODEL.SPARSE_INST.MAX_DETECTIONS
+        self.to(self.device)
+
+    def normalizer(self, image):
+        return (image - self.pixel_mean) / self.pixel_std
+
+    def preprocess_inputs(self, batched_inputs):
+        images = [self.normalizer(x["image"].to(self.device).float()) for x in batched_inputs]
+        return ImageList.from_tensors(images, 32)
+
+    def prepare_targets(self, targets):
+        new_targets = []
+        for t in targets:
+            h, w = t.image_size
+            if not t.has("gt_masks"):
+                gt_masks = torch.empty(0, h, w)
+            else:
+                gt_masks = t.gt_masks
+                if self.mask_format == "polygon":
+                    raise NotImplementedError("SparseInst: INPUT.MASK_FORMAT bitmask (Base-SparseInst.yaml:34)")
+                gt_masks = gt_masks.tensor if hasattr(gt_masks, "tensor") else gt_masks
+            new_targets.append({"labels": t.gt_classes.to(self.device), "masks": gt_masks.to(self.device)})
+        return new_targets
+
+    def forward(self, batched_inputs):
+        if self.device.type != "cuda":
+            raise L.MI355Error(f"SparseInst on MODEL.DEVICE={self.device}: the MI355X path needs a HIP device (no CPU fallback)")
+        images = self.preprocess_inputs(batched_inputs)
+        max_shape = images.tensor.shape[2:]
+        features = self.backbone(images.tensor)
+        output = self.decoder(self.encoder(features))
+        if self.training:
+            gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+            return self.criterion(output, self.prepare_targets(gt_instances), max_shape)
+        results = self.inference(output, batched_inputs, max_shape, images.image_sizes)
+        return [{"instances": r} for r in results]
+
+    @torch.no_grad()
+    def inference(self, output, batched_inputs, max_shape, image_sizes):
+        """sparseinst.py:169-234: sqrt(cls * objectness) scores, threshold, maskness rescoring, masks resized to the
+        padded input, cropped to the image, resized to the requested output size, thresholded"""
+        results = []
+        pred_scores = torch.sqrt(output["pred_logits"].sigmoid() * output["pred_scores"].sigmoid())
+        pred_masks = output["pred_masks"].float().sigmoid()
+        for scores_per_image, mask_pred, inp, img_shape in zip(pred_scores, pred_masks, batched_inputs, image_sizes):
+            ori_shape = (inp.get("height", img_shape[0]), inp.get("width", img_shape[1]))
+            result = Instances(ori_shape)
+            scores, labels = scores_per_image.max(dim=-1)
+            keep = scores > self.cls_threshold
+            scores, labels, mask_pred = scores[keep], labels[keep], mask_pred[keep]
+            if scores.size(0) == 0:
+                result.scores, result.pred_classes = scores, labels
+                results.append(result)
+                continue
+            h, w = img_shape
+            scores = rescoring_mask(scores, mask_pred > self.mask_threshold, mask_pred)
+            mask_pred = F.interpolate(mask_pred.unsqueeze(1), size=tuple(max_shape), mode="bilinear", align_corners=False)[:, :, :h, :w]
+            mask_pred = F.interpolate(mask_pred, size=ori_shape, mode="bilinear", align_corners=False).squeeze(1)
+            result.pred_masks = mask_pred > self.mask_threshold
+            result.scores, result.pred_classes = scores, labels
+            results.append(result)
+        return results
