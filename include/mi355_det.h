@@ -168,9 +168,12 @@ typedef struct mi_pack_job {
   const float* w;
   void* wf;
   void* wd;
-  int32_t Cout, Cin, KK, CinPad, CoutPad, CoutPadK, CinPadN, pad_;
+  int32_t Cout, Cin, KK, CinPad, CoutPad, CoutPadK, CinPadN;
+  int32_t blk0; /* first block of this job in the flat launch: filled by mi_pack_jobs_layout */
 } mi_pack_job;
-int mi_pack_conv_weights_batch(const mi_pack_job* jobs_dev, int njobs, mi_stream_t s);
+/* validates the (host) job table, fills blk0 and returns the number of blocks of the flat launch (<0 on error) */
+int mi_pack_jobs_layout(mi_pack_job* jobs_host, int njobs);
+int mi_pack_conv_weights_batch(const mi_pack_job* jobs_dev, int njobs, int total_blocks, mi_stream_t s);
 
 /* ---- BatchNorm(train) + SiLU (+ residual) -----------------------------
  * replaces nn.BatchNorm2d + nn.SiLU of BaseConv (wrappers.py:76-80) and the
@@ -293,6 +296,14 @@ typedef struct mi_bias_job {
 } mi_bias_job;
 int mi_yolox_bias_grads(const float* dpreds, int B, int A, int nch, const mi_bias_job* jobs, int njobs, float* ws,
                         mi_stream_t s);
+/* the out-gradient maps of ALL prediction convs in one launch (the per-conv form is mi_yolox_split_dpreds):
+ * dst[b][pix][0..ld) (bf16, ld % 8 == 0) = dpreds[b][a0 + pix][c0 .. c0 + nc), pad channels zero. */
+typedef struct mi_split_job {
+  void* dst;
+  int32_t a0, HW, c0, nc, ld, rsv_;
+} mi_split_job;
+int mi_yolox_split_dpreds_batch(const float* dpreds, int B, int A, int nch, const mi_split_job* jobs, int njobs,
+                                mi_stream_t s);
 /* eval decode (yolox_head.py:247-272): in-place on preds; obj/cls sigmoid applied */
 int mi_yolox_decode(float* preds, const float* anchors, int B, int A, int ncls, mi_stream_t s);
 
@@ -481,6 +492,7 @@ enum {
   MI_OP_BIAS_GRADS = 29,
   MI_OP_CONV_GROUP = 30,   /* p0 = mi_conv_group* (host), p1 = device job table */
   MI_OP_BN_GROUP = 31,     /* p0 = mi_bn_group* (host),   p1 = device job table */
+  MI_OP_SPLIT_DPREDS_BATCH = 32, /* p0 = mi_split_job* (host), p1 = dpreds, i = B, A, nch, njobs */
   MI_OP_COUNT
 };
 

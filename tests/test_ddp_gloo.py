@@ -86,10 +86,10 @@ def _members(plan, builder, k):
     arr, _ = plan.bwd_cmds
     if L.OPS[arr[k].op] in ("FORK", "JOIN", "STREAM", "NOP"):
         return []
-    out = []
-    for t in tag.split("+"):
-        out += [c for c in by_tag[t] if c.op != L.OP["WGRAD"]]
-    return out
+    merged = plan.cmd_members["bwd"][k]
+    if merged is not None:                       # a grouped launch: the builder commands it was made of
+        return list(merged)
+    return [c for c in by_tag[tag] if c.op != L.OP["WGRAD"]]
 
 
 def _step_worker(rank, world, port, q):

@@ -372,3 +372,58 @@ def test_argument_errors_are_reported_not_launched():
     d = L.mi_conv_desc()
     rc = L.lib().mi_conv2d(C.byref(d), sp())
     assert rc == -1 and b"null" in L.lib().mi_last_error()
+
+
+def test_batched_pack_and_split_match_the_per_layer_launches():
+    """the one-launch weight packing (flat grid over all layers) and the one-launch split of the loss gradient write the
+    same bytes as the per-layer kernels - including padded channel counts and 1x1 / 3x3 / 4x4-tap weights"""
+    lib = L.lib()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(32, 16, 3, 16, 32, 32, 16), (24, 48, 1, 64, 32, 32, 64), (85, 128, 1, 128, 96, 96, 128),
+              (64, 12, 4, 16, 64, 64, 16), (256, 256, 3, 256, 256, 256, 256), (40, 24, 3, 32, 64, 64, 32)]
+    jobs = (L.mi_pack_job * len(shapes))()
+    keep, single = [], []
+    for j, (Cout, Cin, k, CinPad, CoutPad, CoutPadK, CinPadN) in zip(jobs, shapes):
+        w = torch.randn(Cout, Cin, k, k, generator=g).to(DEV)
+        KK = k * k
+        wf = torch.full((KK * CinPad * CoutPad,), 7.0, dtype=torch.bfloat16, device=DEV)
+        wd = torch.full((KK * CoutPadK * CinPadN,), 7.0, dtype=torch.bfloat16, device=DEV) if Cout != 85 else None
+        wf1, wd1 = torch.zeros_like(wf), (torch.zeros_like(wd) if wd is not None else None)
+        L.check(lib.mi_pack_conv_weight(w.data_ptr(), Cout, Cin, k, k, wf1.data_ptr(), CinPad, CoutPad,
+                                        wd1.data_ptr() if wd1 is not None else None, CoutPadK, CinPadN, sp()), "pack")
+        j.w, j.wf, j.wd = w.data_ptr(), wf.data_ptr(), (wd.data_ptr() if wd is not None else None)
+        j.Cout, j.Cin, j.KK, j.CinPad, j.CoutPad, j.CoutPadK, j.CinPadN = Cout, Cin, KK, CinPad, CoutPad, CoutPadK, CinPadN
+        keep.append((w, wf, wd))
+        single.append((wf1, wd1))
+    nblk = L.check(lib.mi_pack_jobs_layout(jobs, len(shapes)), "layout")
+    assert nblk == sum(-(-((s[3] // 8) * s[4] + ((s[5] // 8) * s[6] if s[0] != 85 else 0)) // 256) for s in shapes)
+    tab = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(DEV)
+    L.check(lib.mi_pack_conv_weights_batch(tab.data_ptr(), len(shapes), nblk, sp()), "pack_batch")
+    torch.cuda.synchronize()
+    for (w, wf, wd), (wf1, wd1) in zip(keep, single):
+        assert torch.equal(wf.view(torch.int16), wf1.view(torch.int16))
+        if wd is not None:
+            assert torch.equal(wd.view(torch.int16), wd1.view(torch.int16))
+
+    B, nch = 3, 85
+    levels = [(0, 20 * 12), (240, 10 * 6), (300, 5 * 3)]
+    A = 315
+    dp = torch.randn(B, A, nch, generator=g).to(DEV)
+    sj = (L.mi_split_job * 9)()
+    outs = []
+    for li, (a0, HW) in enumerate(levels):
+        for bi, (c0, nc) in enumerate([(0, 4), (4, 1), (5, 80)]):
+            ld = (nc + 31) // 32 * 32
+            d1 = torch.full((B * HW * ld,), 3.0, dtype=torch.bfloat16, device=DEV)
+            d2 = torch.full((B * HW * ld,), 5.0, dtype=torch.bfloat16, device=DEV)
+            L.check(lib.mi_yolox_split_dpreds(dp.data_ptr(), B, A, nch, a0, HW, c0, nc, d1.data_ptr(), ld, sp()), "split")
+            j = sj[li * 3 + bi]
+            j.dst, j.a0, j.HW, j.c0, j.nc, j.ld = d2.data_ptr(), a0, HW, c0, nc, ld
+            outs.append((d1, d2))
+    L.check(lib.mi_yolox_split_dpreds_batch(dp.data_ptr(), B, A, nch, sj, 9, sp()), "split_batch")
+    torch.cuda.synchronize()
+    for d1, d2 in outs:
+        assert torch.equal(d1.view(torch.int16), d2.view(torch.int16))
+    sj[0].ld = 12
+    assert lib.mi_yolox_split_dpreds_batch(dp.data_ptr(), B, A, nch, sj, 9, sp()) < 0
+    lib.mi_last_error()

@@ -117,10 +117,15 @@ class mi_bias_job(C.Structure):
     _fields_ = [("out", C.c_void_p), ("a0", C.c_int32), ("HW", C.c_int32), ("c0", C.c_int32), ("nc", C.c_int32)]
 
 
+class mi_split_job(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("a0", C.c_int32), ("HW", C.c_int32), ("c0", C.c_int32), ("nc", C.c_int32),
+                ("ld", C.c_int32), ("rsv_", C.c_int32)]
+
+
 class mi_pack_job(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wf", C.c_void_p), ("wd", C.c_void_p),
                 ("Cout", C.c_int32), ("Cin", C.c_int32), ("KK", C.c_int32), ("CinPad", C.c_int32),
-                ("CoutPad", C.c_int32), ("CoutPadK", C.c_int32), ("CinPadN", C.c_int32), ("pad_", C.c_int32)]
+                ("CoutPad", C.c_int32), ("CoutPadK", C.c_int32), ("CinPadN", C.c_int32), ("blk0", C.c_int32)]
 
 
 class mi_cmd(C.Structure):
@@ -132,7 +137,7 @@ class mi_cmd(C.Structure):
 OPS = ["NOP", "CONV", "WGRAD", "PACK_W", "RESERVED4", "RESERVED5", "BN_ACT_FWD", "BN_BWD_REDUCE",
        "RESERVED8", "BN_BWD_APPLY", "FOCUS", "UPSAMPLE_FWD", "UPSAMPLE_BWD", "SPP_FWD", "SPP_BWD", "COPY",
        "COLSUM", "LOSS_FWD", "LOSS_BWD", "SPLIT_DPREDS", "MEMSET", "SGD", "BN_EVAL_AFFINE", "DECODE", "PACK_W_BATCH", "WGRAD_GROUP", "STREAM", "FORK", "JOIN", "BIAS_GRADS",
-       "CONV_GROUP", "BN_GROUP"]
+       "CONV_GROUP", "BN_GROUP", "SPLIT_DPREDS_BATCH"]
 OP = {n: k for k, n in enumerate(OPS)}
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -163,10 +168,12 @@ _PROTOS = {
     "mi_spp_pool_bwd": (C.c_int, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mi_copy_bf16": (C.c_int, [_vp, _i, _vp, _i, _i, _i64, _i, _vp]),
     "mi_colsum_bf16": (C.c_int, [_vp, _i, _i64, _i, _vp, _i, _vp, _vp]),
-    "mi_pack_conv_weights_batch": (C.c_int, [_vp, _i, _vp]),
+    "mi_pack_conv_weights_batch": (C.c_int, [_vp, _i, _i, _vp]),
+    "mi_pack_jobs_layout": (C.c_int, [C.POINTER(mi_pack_job), _i]),
     "mi_yolox_loss_fwd": (C.c_int, [C.POINTER(mi_yolox_loss_desc), _vp]),
     "mi_yolox_loss_bwd": (C.c_int, [C.POINTER(mi_yolox_loss_desc), _vp, _vp, _vp]),
     "mi_yolox_split_dpreds": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "mi_yolox_split_dpreds_batch": (C.c_int, [_vp, _i, _i, _i, C.POINTER(mi_split_job), _i, _vp]),
     "mi_yolox_bias_grads": (C.c_int, [_vp, _i, _i, _i, C.POINTER(mi_bias_job), _i, _vp, _vp]),
     "mi_yolox_decode": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
     "mi_hungarian_match": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),

@@ -366,13 +366,74 @@ __global__ void pack_w_kernel(const float* __restrict__ w, int Cout, int Cin, in
                               int CoutPad, __bf16* wd, int CoutPadK, int CinPadN) {
   pack_w_body(w, Cout, Cin, KK, wf, CinPad, CoutPad, wd, CoutPadK, CinPadN);
 }
-__global__ void pack_w_batch_kernel(const mi_pack_job* __restrict__ jobs) {
-  const mi_pack_job j = jobs[blockIdx.y];
-  pack_w_body(j.w, j.Cout, j.Cin, j.KK, (__bf16*)j.wf, j.CinPad, j.CoutPad, (__bf16*)j.wd, j.CoutPadK, j.CinPadN);
+// all layers in one flat launch.  Work item = one (co, ci/8) pair of the forward image or one (ci, co/8) pair of the
+// data-gradient image, ALL taps: the item reads 8 runs of KK consecutive fp32 weights and writes KK 16-byte vectors whose
+// neighbours (co+1 / ci+1) belong to the neighbouring threads.  blk0 = first block of the job (prefix sum of
+// ceil(items / 256), mi_pack_jobs_layout); a block finds its job by bisection.
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  const __bf16 x = (__bf16)a, y = (__bf16)b;
+  return (uint32_t)__builtin_bit_cast(unsigned short, x) | ((uint32_t)__builtin_bit_cast(unsigned short, y) << 16);
 }
-extern "C" int mi_pack_conv_weights_batch(const mi_pack_job* jobs_dev, int njobs, mi_stream_t st) {
-  MI_REQUIRE(jobs_dev && njobs > 0 && njobs <= 65535, "pack_w_batch: args");
-  hipLaunchKernelGGL(pack_w_batch_kernel, dim3(48, njobs), dim3(256), 0, (hipStream_t)st, jobs_dev);
+__global__ __launch_bounds__(256) void pack_w_batch_kernel(const mi_pack_job* __restrict__ jobs, int njobs) {
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const mi_pack_job j = jobs[lo];
+  const int K8f = j.CinPad / 8, K8d = j.CoutPadK / 8, KK = j.KK;
+  const int nf = j.wf ? K8f * j.CoutPad : 0, nd = j.wd ? K8d * j.CinPadN : 0;
+  const int it = ((int)blockIdx.x - j.blk0) * 256 + (int)threadIdx.x;
+  if (it >= nf + nd) return;
+  const float* __restrict__ w = j.w;
+  if (it < nf) {
+    const int co = it % j.CoutPad, k8 = it / j.CoutPad;
+    uint4* dst = (uint4*)j.wf + ((int64_t)k8 * j.CoutPad + co);
+    const int64_t tstride = (int64_t)K8f * j.CoutPad;
+    const bool row = co < j.Cout;
+    const float* src = w + ((int64_t)co * j.Cin + k8 * 8) * KK;
+    for (int tap = 0; tap < KK; ++tap) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (row && k8 * 8 + e < j.Cin) ? src[e * KK + tap] : 0.f;
+      dst[tap * tstride] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                      pack_bf16x2(v[6], v[7]));
+    }
+  } else {
+    const int i2 = it - nf;
+    const int ci = i2 % j.CinPadN, k8 = i2 / j.CinPadN;
+    uint4* dst = (uint4*)j.wd + ((int64_t)k8 * j.CinPadN + ci);
+    const int64_t tstride = (int64_t)K8d * j.CinPadN;
+    const bool col = ci < j.Cin;
+    const int64_t rs = (int64_t)j.Cin * KK;
+    const float* src = w + (int64_t)(k8 * 8) * rs + (int64_t)ci * KK;
+    for (int tap = 0; tap < KK; ++tap) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (col && k8 * 8 + e < j.Cout) ? src[e * rs + tap] : 0.f;
+      dst[tap * tstride] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                      pack_bf16x2(v[6], v[7]));
+    }
+  }
+}
+extern "C" int mi_pack_jobs_layout(mi_pack_job* jobs_host, int njobs) {
+  MI_REQUIRE(jobs_host && njobs > 0, "pack_jobs_layout: args");
+  int64_t blk = 0;
+  for (int k = 0; k < njobs; ++k) {
+    mi_pack_job& j = jobs_host[k];
+    MI_REQUIRE(j.w && (j.wf || j.wd), "pack_jobs_layout: job %d: null", k);
+    if (j.wf) MI_REQUIRE(j.CinPad % 8 == 0 && j.CinPad >= j.Cin && j.CoutPad >= j.Cout, "pack_jobs_layout: job %d: fwd pads", k);
+    if (j.wd) MI_REQUIRE(j.CoutPadK % 8 == 0 && j.CoutPadK >= j.Cout && j.CinPadN >= j.Cin, "pack_jobs_layout: job %d: dgrad pads", k);
+    const int64_t items = (j.wf ? (int64_t)(j.CinPad / 8) * j.CoutPad : 0) + (j.wd ? (int64_t)(j.CoutPadK / 8) * j.CinPadN : 0);
+    j.blk0 = (int32_t)blk;
+    blk += (items + 255) / 256;
+    MI_REQUIRE(blk < (1LL << 30), "pack_jobs_layout: too many blocks");
+  }
+  return (int)blk;
+}
+extern "C" int mi_pack_conv_weights_batch(const mi_pack_job* jobs_dev, int njobs, int total_blocks, mi_stream_t st) {
+  MI_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0, "pack_w_batch: args");
+  hipLaunchKernelGGL(pack_w_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)st, jobs_dev, njobs);
   MI_CHECK_LAUNCH("pack_w_batch");
   return MI_OK;
 }

@@ -494,6 +494,55 @@ extern "C" int mi_yolox_split_dpreds(const float* dpreds, int B, int A, int nch,
   return MI_OK;
 }
 
+// all prediction convs' out-gradient maps in ONE launch: blockIdx.y = job
+#define MI_SPLIT_MAX_JOBS 16
+struct SplitK {
+  const float* dpreds;
+  int B, A, nch, njobs;
+  mi_split_job jobs[MI_SPLIT_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void split_dpreds_batch_kernel(const SplitK p) {
+  const mi_split_job j = p.jobs[blockIdx.y];
+  const int ld8 = j.ld >> 3;
+  const int64_t total = (int64_t)p.B * j.HW * ld8;  // one 16-byte vector (8 channels) per item
+  uint4* dst = (uint4*)j.dst;
+  for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int j8 = (int)(idx % ld8);
+    const int64_t bp = idx / ld8;
+    const int b = (int)(bp / j.HW), pidx = (int)(bp % j.HW);
+    const float* src = p.dpreds + ((size_t)b * p.A + j.a0 + pidx) * p.nch + j.c0 + j8 * 8;
+    unsigned short h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = (j8 * 8 + e < j.nc) ? src[e] : 0.f;
+      h[e] = __builtin_bit_cast(unsigned short, (__bf16)v);
+    }
+    dst[idx] = make_uint4(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16), h[4] | ((uint32_t)h[5] << 16),
+                          h[6] | ((uint32_t)h[7] << 16));
+  }
+}
+extern "C" int mi_yolox_split_dpreds_batch(const float* dpreds, int B, int A, int nch, const mi_split_job* jobs, int njobs,
+                                           mi_stream_t st) {
+  MI_REQUIRE(dpreds && jobs && njobs > 0 && njobs <= MI_SPLIT_MAX_JOBS, "split_dpreds_batch: args");
+  SplitK k;
+  k.dpreds = dpreds; k.B = B; k.A = A; k.nch = nch; k.njobs = njobs;
+  int64_t most = 0;
+  for (int n = 0; n < njobs; ++n) {
+    const mi_split_job& j = jobs[n];
+    MI_REQUIRE(j.dst && j.ld % 8 == 0 && j.ld >= j.nc && j.c0 >= 0 && j.c0 + j.nc <= nch && j.a0 >= 0 && j.a0 + j.HW <= A,
+               "split_dpreds_batch: job %d", n);
+    k.jobs[n] = j;
+    const int64_t t = (int64_t)B * j.HW * (j.ld / 8);
+    if (t > most) most = t;
+  }
+  int64_t blocks = (most + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(split_dpreds_batch_kernel, dim3((int)blocks, njobs), dim3(256), 0, (hipStream_t)st, k);
+  MI_CHECK_LAUNCH("split_dpreds_batch");
+  return MI_OK;
+}
+
 // ---- bias gradients of all prediction convs in two launches (fixed summation order):
 // grad_bias[job][c] = sum_b sum_{a in [a0, a0+HW)} dpreds[b][a][c0 + c]
 // stage 1 sums ALL nch columns of every distinct anchor range (FPN level) with fully coalesced row reads;

@@ -666,7 +666,7 @@ class Plan:
         self.descs = []
         self.cmd_descs = {}
         self.fwd_cmds, self.fwd_tags = self._materialize(self._batch_packs(b.prologue) + b.fwd, "fwd")
-        self.bwd_cmds, self.bwd_tags = self._materialize(self._group_wgrads(b.bwd), "bwd")
+        self.bwd_cmds, self.bwd_tags = self._materialize(self._group_wgrads(self._batch_splits(b.bwd)), "bwd")
         self.graphs = {}
 
     def _group_wgrads(self, bwd):
@@ -759,6 +759,25 @@ class Plan:
         grp.group_descs = list(descs)
         return grp
 
+    def _batch_splits(self, bwd):
+        """the out-gradient maps of all prediction convs (SPLIT_DPREDS, one per conv) in ONE launch right after the loss
+        backward: every map has its own buffer (group_wgrad), so writing them early is safe"""
+        sp = [c for c in bwd if c.op == L.OP["SPLIT_DPREDS"]]
+        if not (self.b.group_wgrad and 2 <= len(sp) <= 16) or os.environ.get("MI_SPLIT_BATCH", "1") == "0":
+            return bwd
+        at = max(k for k, c in enumerate(bwd) if c.op in (L.OP["LOSS_BWD"], L.OP["BIAS_GRADS"]))
+        assert all(k > at for k, c in enumerate(bwd) if c.op == L.OP["SPLIT_DPREDS"])
+        B, A, nch = sp[0].i[:3]
+        spec = ConvSpec(kind="split_jobs", jobs=[dict(dst=c.p[1], a0=c.i[3], HW=c.i[4], c0=c.i[5], nc=c.i[6], ld=c.i[7])
+                                                 for c in sp])
+        cmd = _Cmd(L.OP["SPLIT_DPREDS_BATCH"], i=[B, A, nch, len(sp)], p=[_Ptr(None), sp[0].p[0]], desc=spec,
+                   tag="loss.split_all", stream=bwd[at].stream)
+        cmd.lane = bwd[at].lane
+        cmd.members = list(sp)
+        rest = [c for c in bwd if c.op != L.OP["SPLIT_DPREDS"]]
+        k = next(k for k, c in enumerate(rest) if c is bwd[at])
+        return rest[:k + 1] + [cmd] + rest[k + 1:]
+
     def _batch_packs(self, prologue):
         """all PACK_W commands of the prologue become ONE launch over a device job table"""
         packs = [c for c in prologue if c.op == L.OP["PACK_W"]]
@@ -770,9 +789,10 @@ class Plan:
             Cout, Cin, KH, KW, CinPad, CoutPad, CoutPadK, CinPadN = c.i[:8]
             j.w, j.wf, j.wd = c.p[0].resolve(), c.p[1].resolve(), c.p[2].resolve()
             j.Cout, j.Cin, j.KK, j.CinPad, j.CoutPad, j.CoutPadK, j.CinPadN = Cout, Cin, KH * KW, CinPad, CoutPad, CoutPadK, CinPadN
+        nblk = L.check(L.lib().mi_pack_jobs_layout(jobs, len(packs)), "pack_jobs_layout")
         tab = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(self.b.device)
         self.pack_table = tab
-        return rest + [_Cmd(L.OP["PACK_W_BATCH"], i=[len(packs)], p=[_Ptr(tab)], tag="pack_all")]
+        return rest + [_Cmd(L.OP["PACK_W_BATCH"], i=[len(packs), nblk], p=[_Ptr(tab)], tag="pack_all")]
 
     def _make_desc(self, spec):
         kind = getattr(spec, "kind", "conv")
@@ -795,6 +815,10 @@ class Plan:
             d = (L.mi_bias_job * len(spec.jobs))()
             for jd, j in zip(d, spec.jobs):
                 jd.out, jd.a0, jd.HW, jd.c0, jd.nc = j["out"].data_ptr(), j["a0"], j["HW"], j["c0"], j["nc"]
+        elif kind == "split_jobs":
+            d = (L.mi_split_job * len(spec.jobs))()
+            for jd, j in zip(d, spec.jobs):
+                jd.dst, jd.a0, jd.HW, jd.c0, jd.nc, jd.ld = j["dst"].resolve(), j["a0"], j["HW"], j["c0"], j["nc"], j["ld"]
         elif kind == "wgrad":
             d = PlanBuilder._wgrad_desc(spec)
             d.x, d.dy, d.gw = spec.x.resolve(), spec.dy.resolve(), spec.gw.resolve()
@@ -926,12 +950,34 @@ class Plan:
             k = e + 1
         return out
 
+    def _group_parity(self, cmds):
+        """the data gradient of a stride-2 3x3 conv is four launches, one per output-pixel parity class (1, 2, 2 and 4
+        taps); they write disjoint pixels of the same tensor, so they share ONE grouped launch (4-tap class first - its
+        blocks run longest - when the group's kernel configuration allows it)"""
+        if not self.b.group_lanes or os.environ.get("MI_GROUP_PARITY", "1") == "0":
+            return cmds
+        out, k, CONV = [], 0, L.OP["CONV"]
+        while k < len(cmds):
+            run = cmds[k:k + 4]
+            base = cmds[k].tag[:-2] if cmds[k].op == CONV and cmds[k].tag.endswith(".dgrad00") else None
+            if base and len(run) == 4 and all(c.op == CONV and c.tag == base + s and c.lane == run[0].lane and c.stream == run[0].stream
+                                              for c, s in zip(run, ("00", "01", "10", "11"))):
+                g = self._conv_group_cmd(run[::-1], tag=base + "(4 classes)") or self._conv_group_cmd(run, tag=base + "(4 classes)")
+                if g is not None:
+                    g.lane, g.stream = run[0].lane, run[0].stream
+                    out.append(g)
+                    k += 4
+                    continue
+            out.append(cmds[k])
+            k += 1
+        return out
+
     def _upload_table(self, host, nbytes):
         t = torch.frombuffer(bytearray(bytes(host)[:nbytes]), dtype=torch.uint8).to(self.b.device)
         self.descs.append(t)
         return t
 
-    def _conv_group_cmd(self, cs):
+    def _conv_group_cmd(self, cs, tag=None):
         n = len(cs)
         descs = (L.mi_conv_desc * n)()
         keep = [self._make_desc(c.desc) for c in cs]
@@ -946,8 +992,9 @@ class Plan:
         L.check(lib.mi_conv2d_group_plan(descs, n, host, meta.table_bytes, C.byref(meta)), "conv_group_plan")
         tab = self._upload_table(host, meta.table_bytes)
         self.descs += [meta, descs]
-        g = _Cmd(L.OP["CONV_GROUP"], p=[_Ptr(C.addressof(meta)), _Ptr(tab)], tag="+".join(c.tag for c in cs))
+        g = _Cmd(L.OP["CONV_GROUP"], p=[_Ptr(C.addressof(meta)), _Ptr(tab)], tag=tag or "+".join(c.tag for c in cs))
         g.group_descs = list(descs)
+        g.members = list(cs)
         return g
 
     def _bn_group_cmd(self, kind, cs):
@@ -981,13 +1028,17 @@ class Plan:
         self.descs += [meta, jobs]
         g = _Cmd(L.OP["BN_GROUP"], i=[kind, n], p=[_Ptr(C.addressof(meta)), _Ptr(tab)], tag="+".join(c.tag for c in cs))
         g.group_jobs = list(jobs)
+        g.members = list(cs)
         return g
 
     def _materialize(self, cmds, which):
-        cmds = self._lower_streams(self._group_lanes(cmds))
+        cmds = self._lower_streams(self._group_lanes(self._group_parity(cmds)))
         arr = (L.mi_cmd * max(1, len(cmds)))()
         tags = []
         self.cmd_descs[which] = [None] * len(cmds)
+        # symbolic builder commands behind a merged launch (None: the command is its own member); tests/plan_interp.py runs those
+        self.cmd_members = getattr(self, "cmd_members", {})
+        self.cmd_members[which] = [getattr(c, "members", None) for c in cmds]
         for k, c in enumerate(cmds):
             m = arr[k]
             m.op = c.op
