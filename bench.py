@@ -86,7 +86,8 @@ def pmc_traffic(kernel_class):
         sel = [r for r in rows if re.search(r"%s<%s, %s," % (m.group(1), m.group(2), m.group(3)), r["kernel"])]
         n = sum(int(r["launches"]) for r in sel)
         return int(sum(tot(r) * int(r["launches"]) for r in sel) / n) if n else None
-    bn = {"BN_ACT_FWD": "bn_act_fwd", "BN_BWD_REDUCE": "bn_bwd_reduce", "BN_BWD_APPLY": "bn_bwd_apply"}
+    bn = {"BN_ACT_FWD": "bn_act_fwd", "BN_BWD_REDUCE": "bn_bwd_reduce", "BN_BWD_APPLY": "bn_bwd_apply",
+          "BN_BWD_FUSED": "bn_bwd_fused"}
     for k, v in bn.items():
         if kernel_class.startswith(k):
             grouped = "grouped" in kernel_class
@@ -98,7 +99,7 @@ def pmc_traffic(kernel_class):
 
 def bn_algorithmic(kind, C, npix, res=False, dres=False, dres_acc=False):
     """algorithmic bytes of one BatchNorm pass (bf16, every tensor touched once): fwd reads y (+res) writes a; reduce
-    reads da, y; apply reads da, y (+old dres) writes dy (+dres)"""
+    reads da, y; apply reads da, y (+old dres) writes dy (+dres); the fused backward (kind 3) touches what apply touches"""
     e = npix * C * 2
     if kind == 0:
         return e * (2 + int(res))
@@ -132,7 +133,7 @@ def roofline_block(plan, iters=5):
                     byt += b1; fl += f1
             elif op == "BN_GROUP":
                 kind = arr[k].i[0]
-                name, byt, fl = ("BN_ACT_FWD", "BN_BWD_REDUCE", "BN_BWD_APPLY")[kind] + " (grouped)", 0, 0
+                name, byt, fl = ("BN_ACT_FWD", "BN_BWD_REDUCE", "BN_BWD_APPLY", "BN_BWD_FUSED")[kind] + " (grouped)", 0, 0
                 for j in descs[k]:
                     byt += bn_algorithmic(kind, j.C, j.npix, bool(j.res), bool(j.dres), bool(j.dres_accum))
             elif op == "BN_ACT_FWD":
@@ -141,7 +142,7 @@ def roofline_block(plan, iters=5):
             elif op == "BN_BWD_REDUCE":
                 name, fl = op, 0
                 byt = bn_algorithmic(1, arr[k].i[3], arr[k].l[0])
-            elif op == "BN_BWD_APPLY":
+            elif op in ("BN_BWD_APPLY", "BN_BWD_FUSED"):
                 name, fl = op, 0
                 byt = bn_algorithmic(2, arr[k].i[5], arr[k].l[0], dres=arr[k].i[3] > 0, dres_acc=arr[k].i[4] > 0)
             elif op == "WGRAD":
@@ -453,7 +454,9 @@ def main():
                                    "loss + bwd + grad all-reduce + SGD(momentum) step, inputs resident in HBM",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "hipgraph": not args.no_graph, "sum_kernel_ms_per_step": round(kernel_ms, 3),
-                       "final_losses": [round(x, 4) for x in losses]},
+                       "final_losses": [round(x, 4) for x in losses],
+                       "bn_backward": dict(form="fused (one launch, grid barrier)" if st["plan"].bn_fused else "reduce + apply",
+                                           selected_on_device=st["plan"].bn_fused_timing)},
             "roofline": rl,
         }
         if ddp is not None:

@@ -179,7 +179,7 @@ int mi_pack_conv_weights_batch(const mi_pack_job* jobs_dev, int njobs, int total
  * replaces nn.BatchNorm2d + nn.SiLU of BaseConv (wrappers.py:76-80) and the
  * Bottleneck add (wrappers.py:119-123). */
 /* the same BatchNorm pass of several independent layers in ONE launch (FPN levels of the head).
- * kind 0 = mi_bn_act_fwd, 1 = mi_bn_act_bwd_reduce, 2 = mi_bn_act_bwd_apply; the fields of a job mean what the
+ * kind 0 = mi_bn_act_fwd, 1 = mi_bn_act_bwd_reduce, 2 = mi_bn_act_bwd_apply, 3 = mi_bn_act_bwd_fused; the fields of a job mean what the
  * arguments of those calls mean (acc = stats_acc / dacc).  All jobs share `act`. */
 #define MI_BN_MAX_GROUP 8
 typedef struct mi_bn_job {
@@ -191,6 +191,7 @@ typedef struct mi_bn_job {
   int64_t npix, count;
   int32_t ldy, ldres, lda, ldda, lddy, lddres, dres_accum, C, nslots, nblk, act, pad_;
   float eps, momentum;
+  uint32_t* bar; /* kind 3: the layer's barrier words (see mi_bn_act_bwd_fused) */
 } mi_bn_job;
 typedef struct mi_bn_group {
   int32_t kind, njobs, nblocks, act;
@@ -226,6 +227,22 @@ int mi_bn_act_bwd_apply(const void* da, int ldda, const void* y, int ldy, const 
                         float* dbeta,
                         void* dy, int lddy, void* dres, int lddres, int dres_accum, int64_t npix, int C, int act,
                         mi_stream_t s);
+/* both backward passes in ONE launch: every block stays resident, keeps its share of (da, y) in registers across a
+ * grid-wide barrier and writes dy from them - 3 tensor passes instead of 5 (layers beyond the register capacity stream the
+ * excess twice, as the two-pass form does).  Same arguments and results as reduce + apply; dacc must be zero on entry.
+ * barrier_words: MI_BN_BAR_WORDS x uint32 of device memory (256-byte aligned) owned by this layer, zero before the first
+ * use, not shared between launches that may run concurrently ([2] != 0 afterwards means a wait gave up: the launch was
+ * not fully resident).
+ * Must not run concurrently with another fused launch on the same device (both would wait for blocks that cannot start). */
+#define MI_BN_BAR_GROUPS 16
+#define MI_BN_BAR_WORDS (64 * (1 + 2 * MI_BN_BAR_GROUPS))
+/* resident-block budget of the fused launches: 0 = everything the device runs at once (default); a data-parallel
+ * trainer leaves headroom for the collective's kernels.  Returns the budget in effect. */
+int mi_bn_fused_set_capacity(int blocks);
+int mi_bn_act_bwd_fused(const void* da, int ldda, const void* y, int ldy, const float* scale, const float* shift,
+                        const float* mean, const float* invstd, const float* gamma, double* dacc, int nslots,
+                        int64_t count, float* dgamma, float* dbeta, void* dy, int lddy, void* dres, int lddres,
+                        int dres_accum, int64_t npix, int C, int act, uint32_t* barrier_words, mi_stream_t s);
 
 /* ---- data movement ops -------------------------------------------------- */
 /* Focus space-to-depth (wrappers.py:202-220) fused with fp32 NCHW -> bf16 NHWC and 12->16 ch pad */
@@ -493,6 +510,7 @@ enum {
   MI_OP_CONV_GROUP = 30,   /* p0 = mi_conv_group* (host), p1 = device job table */
   MI_OP_BN_GROUP = 31,     /* p0 = mi_bn_group* (host),   p1 = device job table */
   MI_OP_SPLIT_DPREDS_BATCH = 32, /* p0 = mi_split_job* (host), p1 = dpreds, i = B, A, nch, njobs */
+  MI_OP_BN_BWD_FUSED = 33, /* BN_BWD_APPLY's arguments + p[12] = barrier words */
   MI_OP_COUNT
 };
 

@@ -87,8 +87,10 @@ def _members(plan, builder, k):
     if L.OPS[arr[k].op] in ("FORK", "JOIN", "STREAM", "NOP"):
         return []
     merged = plan.cmd_members["bwd"][k]
-    if merged is not None:                       # a grouped launch: the builder commands it was made of
-        return list(merged)
+    if merged is not None:                       # a merged launch: the builder commands it was made of (merges nest)
+        def flat(cs):
+            return [x for c in cs for x in (flat(c.members) if getattr(c, "members", None) else [c])]
+        return flat(merged)
     return [c for c in by_tag[tag] if c.op != L.OP["WGRAD"]]
 
 

@@ -427,3 +427,58 @@ def test_batched_pack_and_split_match_the_per_layer_launches():
     sj[0].ld = 12
     assert lib.mi_yolox_split_dpreds_batch(dp.data_ptr(), B, A, nch, sj, 9, sp()) < 0
     lib.mi_last_error()
+
+
+@pytest.mark.parametrize("C,npix,act,res", [(64, 16 * 40 * 40, 1, 0), (24, 5000, 1, 1), (256, 3 * 20 * 20, 0, 2),
+                                           (32, 16 * 320 * 320, 1, 0), (128, 16 * 80 * 80, 1, 2), (80, 777, 1, 0)])
+def test_bn_backward_fused_matches_two_pass(C, npix, act, res):
+    """the one-launch BatchNorm backward (registers across a grid-wide barrier) against reduce + apply on the same inputs:
+    the channel sums (dgamma, dbeta) agree to fp32 summation-order noise and dy / dres to one bf16 ulp of that; every
+    block reached the barrier (the give-up flag stays 0); the 16x320x320x32 case exceeds the register capacity and streams
+    its tail; C = 24 / 80 are not powers of two; res = 1 overwrites, 2 accumulates the residual gradient"""
+    lib = L.lib()
+    g = torch.Generator().manual_seed(C + npix)
+    ld = (C + 31) // 32 * 32
+    da = torch.randn(npix, ld, generator=g).to(DEV).to(torch.bfloat16)
+    y = (torch.randn(npix, ld, generator=g) * 1.5 + 0.3).to(DEV).to(torch.bfloat16)
+    yf = y[:, :C].float()
+    mean, var = yf.mean(0), yf.var(0, unbiased=False)
+    invstd = (var + 1e-3).rsqrt()
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(C, generator=g) * 0.1).to(DEV)
+    scale = (gamma * invstd).contiguous()
+    shift = (beta - mean * gamma * invstd).contiguous()
+    CA = ld
+    outs = []
+    for fused in (0, 1):
+        dacc = torch.zeros(L.MI_BN_SLOTS * CA * 2, dtype=torch.float64, device=DEV)
+        dy = torch.zeros(npix, ld, dtype=torch.bfloat16, device=DEV)
+        dres = (torch.ones(npix, ld, dtype=torch.bfloat16, device=DEV) * 0.25) if res else None
+        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        bar = torch.zeros(L.MI_BN_BAR_WORDS, dtype=torch.int32, device=DEV)
+        common = (da.data_ptr(), ld, y.data_ptr(), ld, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), invstd.data_ptr())
+        tail = (dg.data_ptr(), db.data_ptr(), dy.data_ptr(), ld, dres.data_ptr() if res else None, ld if res else 0,
+                int(res == 2), npix, C, act)
+        if fused:
+            for _ in range(3):      # repeated launches reuse the barrier words (generation counter)
+                dacc.zero_()
+                if res == 2:
+                    dres.fill_(0.25)
+                L.check(lib.mi_bn_act_bwd_fused(*common, gamma.data_ptr(), dacc.data_ptr(), L.MI_BN_SLOTS, npix, *tail,
+                                                bar.data_ptr(), sp()), "fused")
+        else:
+            nblk = max(1, min(1024, math.ceil(npix / (256 // (C // 8)) / 4)))
+            L.check(lib.mi_bn_act_bwd_reduce(*common, dacc.data_ptr(), L.MI_BN_SLOTS, nblk, npix, C, act, sp()), "reduce")
+            L.check(lib.mi_bn_act_bwd_apply(*common, gamma.data_ptr(), dacc.data_ptr(), L.MI_BN_SLOTS, npix, *tail, sp()), "apply")
+        torch.cuda.synchronize()
+        outs.append((dy.float(), dres.float() if res else None, dg.clone(), db.clone(), bar.cpu()))
+    (dy0, dr0, dg0, db0, _), (dy1, dr1, dg1, db1, bar1) = outs
+    assert int(bar1[2]) == 0 and int(bar1[0]) == 0 and int(bar1[64]) == 3     # flag, top arrivals, generation of group 0
+    scale_g = dg0.abs().max().clamp_min(1.0)
+    assert float((dg0 - dg1).abs().max() / scale_g) < 2e-5 and float((db0 - db1).abs().max() / db0.abs().max().clamp_min(1.0)) < 2e-5
+    assert torch.all(dy1[:, C:] == 0)
+    diff = (dy0 - dy1).abs()
+    assert float(diff.max()) <= float(dy0.abs().max()) * 2 ** -7         # at most an ulp of the largest magnitude
+    assert float((diff > 0).float().mean()) < 0.02                       # and almost every element identical
+    if res:
+        assert torch.equal(dr0, dr1)

@@ -334,6 +334,7 @@ def test_grouped_launches_equal_separate_launches(monkeypatch, B, H, W):
     pairs, with their ordering rules for accumulating data gradients) must not change the step: losses and EVERY
     parameter gradient against the same plan with one launch per command (MI_GROUP_LEVELS=0)"""
     res = {}
+    monkeypatch.setenv("MI_BN_FUSED", "1")     # (not "auto": both plans must make the same choice)
     imgs, labels = O.synth_batch(B, H, W, seed=17, max_gt=4)
     for mode in ("0", "1"):
         monkeypatch.setenv("MI_GROUP_LEVELS", mode)
@@ -365,6 +366,7 @@ def test_wgrad_split_groups_equal_single_group(monkeypatch):
     the end, so the first gradient bucket can be all-reduced under the backbone's backward) against the single group:
     same kernels on the same operands - only the split-K partition of a layer may differ (fp32 summation order)"""
     res = {}
+    monkeypatch.setenv("MI_BN_FUSED", "1")
     imgs, labels = O.synth_batch(2, 96, 128, seed=19, max_gt=4)
     for mode in ("0", "1"):
         monkeypatch.setenv("MI_WGRAD_SPLIT", mode)
@@ -377,7 +379,8 @@ def test_wgrad_split_groups_equal_single_group(monkeypatch):
             k = tags.index("wgrad_group.early")
             # every head / neck out-gradient (written by the layer's BatchNorm backward) exists before the early group
             # and no backbone backward command has been issued yet (only data gradients of the first neck layers follow)
-            assert not any(t.startswith(("head.", "neck.")) and "bnapply" in t for t in tags[k + 1:])
+            assert any("bnbwd" in t for t in tags[:k])
+            assert not any(t.startswith(("head.", "neck.")) and ("bnapply" in t or "bnbwd" in t) for t in tags[k + 1:])
             assert not any(t.startswith("backbone.") for t in tags[:k])
         ps.image.copy_(imgs.to(DEV)); ps.labels.copy_(labels.to(DEV))
         ps.gw().fill_(1.0)
@@ -393,6 +396,7 @@ def test_async_wgrad_branch_equals_single_group(monkeypatch):
     backward chain (eager list and captured hipGraph with the parallel branch) against the single group at the end of
     backward: same kernels on the same operands - only the split-K partition of a layer may differ"""
     res = {}
+    monkeypatch.setenv("MI_BN_FUSED", "0")     # the fused BatchNorm backward is not used beside an auxiliary stream
     imgs, labels = O.synth_batch(2, 96, 128, seed=19, max_gt=4)
     for mode in ("0", "3"):
         monkeypatch.setenv("MI_WGRAD_ASYNC", mode)
@@ -424,3 +428,48 @@ def test_async_wgrad_branch_equals_single_group(monkeypatch):
     assert torch.allclose(res["0"][0], res["3"][0], rtol=1e-5)
     g0, g1 = res["0"][1], res["3"][1]
     assert float((g1 - g0).norm() / g0.norm()) < 2e-3
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 96, 128), (16, 640, 640)], ids=["2x96x128", "bench_16x640x640"])
+def test_bn_backward_fused_step_equals_two_pass(monkeypatch, B, H, W):
+    """BatchNorm backward as ONE launch per layer (registers / LDS across a grid-wide barrier, also inside the grouped
+    launches of the head and the CSP pairs) against reduce + apply on the whole step: same losses, every parameter
+    gradient within the bf16 decorrelation level, no barrier wait gave up; "auto" picks one of the two by timing them"""
+    res = {}
+    imgs, labels = O.synth_batch(B, H, W, seed=23, max_gt=4)
+    for mode in ("0", "1", "auto"):
+        monkeypatch.setenv("MI_BN_FUSED", mode)
+        model, _ = _gpu_model(seed=5)
+        model.train()
+        ps = model.plan_for(B, H, W, True)
+        plan = ps.plan
+        arr, n = plan.bwd_cmds
+        ops = [L.OPS[arr[k].op] for k in range(n)]
+        kinds = [arr[k].i[0] for k in range(n) if L.OPS[arr[k].op] == "BN_GROUP"]
+        if mode == "auto":
+            assert plan.bn_fused_timing is not None and set(plan.bn_fused_timing) == {"fused_ms", "two_pass_ms"}
+            assert plan.bn_fused == (plan.bn_fused_timing["fused_ms"] <= plan.bn_fused_timing["two_pass_ms"])
+        else:
+            assert plan.bn_fused == (mode == "1") and plan.bn_fused_timing is None
+        assert ("BN_BWD_FUSED" in ops) == plan.bn_fused and ("BN_BWD_REDUCE" in ops) == (not plan.bn_fused)
+        assert all(k == 3 for k in kinds) if plan.bn_fused else all(k in (1, 2) for k in kinds)
+        ps.image.copy_(imgs.to(DEV)); ps.labels.copy_(labels.to(DEV))
+        ps.gw().fill_(1.0)
+        for _ in range(2):          # twice: the barrier words carry their generation over
+            plan.run("fwd"); plan.run("bwd")
+        torch.cuda.synchronize()
+        for c in ps.builder.bwd:
+            if L.OPS[c.op] == "BN_BWD_APPLY":
+                words = plan.buf_view(c.p[12].obj, torch.int32)
+                assert int(words[2]) == 0 and int(words[0]) == 0, c.tag
+        grads = {n_: model.params.grad_of(p).detach().float().cpu().clone() for n_, p in model.named_parameters()}
+        res[mode] = (ps.loss_out()[:4].cpu().clone(), grads)
+    for mode in ("1", "auto"):
+        np.testing.assert_allclose(res[mode][0].numpy(), res["0"][0].numpy(), rtol=1e-5)
+        bad = []
+        for n_, g0 in res["0"][1].items():
+            g1 = res[mode][1][n_]
+            r = float((g1 - g0).norm() / (g0.norm() + 1e-12))
+            if r > 5e-2:
+                bad.append((n_, r))
+        assert not bad, bad[:8]

@@ -13,6 +13,7 @@ MI_MAX_TAPS = 16
 MI_CONV_ACCUM = 1
 MI_CONV_BNBWD = 4
 MI_CONV_OUT_F32 = 2
+MI_BN_BAR_WORDS = 64 * (1 + 2 * 16)
 MI_BN_SLOTS = 16
 MI_MAX_AUX = 4
 MI_WGRAD_STREAM = MI_MAX_AUX   # the last auxiliary stream is created with the lowest priority (background work)
@@ -61,7 +62,7 @@ class mi_bn_job(C.Structure):
                                           "nbt", "scale", "shift", "mean", "invstd", "dgamma", "dbeta")] + \
                [("npix", C.c_int64), ("count", C.c_int64)] + \
                [(n, C.c_int32) for n in ("ldy", "ldres", "lda", "ldda", "lddy", "lddres", "dres_accum", "C", "nslots",
-                                         "nblk", "act", "pad_")] + [("eps", C.c_float), ("momentum", C.c_float)]
+                                         "nblk", "act", "pad_")] + [("eps", C.c_float), ("momentum", C.c_float), ("bar", C.c_void_p)]
 
 
 class mi_bn_group(C.Structure):
@@ -137,7 +138,7 @@ class mi_cmd(C.Structure):
 OPS = ["NOP", "CONV", "WGRAD", "PACK_W", "RESERVED4", "RESERVED5", "BN_ACT_FWD", "BN_BWD_REDUCE",
        "RESERVED8", "BN_BWD_APPLY", "FOCUS", "UPSAMPLE_FWD", "UPSAMPLE_BWD", "SPP_FWD", "SPP_BWD", "COPY",
        "COLSUM", "LOSS_FWD", "LOSS_BWD", "SPLIT_DPREDS", "MEMSET", "SGD", "BN_EVAL_AFFINE", "DECODE", "PACK_W_BATCH", "WGRAD_GROUP", "STREAM", "FORK", "JOIN", "BIAS_GRADS",
-       "CONV_GROUP", "BN_GROUP", "SPLIT_DPREDS_BATCH"]
+       "CONV_GROUP", "BN_GROUP", "SPLIT_DPREDS_BATCH", "BN_BWD_FUSED"]
 OP = {n: k for k, n in enumerate(OPS)}
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -180,6 +181,9 @@ _PROTOS = {
     "mi_lsap": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mi_conv2d_group_plan": (C.c_int, [C.POINTER(mi_conv_desc), _i, _vp, _i64, C.POINTER(mi_conv_group)]),
     "mi_conv2d_group_run": (C.c_int, [C.POINTER(mi_conv_group), _vp, _vp]),
+    "mi_bn_act_bwd_fused": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _i, _vp, _i,
+                                      _i, _i64, _i, _i, _vp, _vp]),
+    "mi_bn_fused_set_capacity": (C.c_int, [_i]),
     "mi_bn_group_plan": (C.c_int, [_i, C.POINTER(mi_bn_job), _i, _vp, _i64, C.POINTER(mi_bn_group)]),
     "mi_bn_group_run": (C.c_int, [C.POINTER(mi_bn_group), _vp, _vp]),
     "mi_detr_set_loss_fwd": (C.c_int, [C.POINTER(mi_detr_loss_desc), _vp]),

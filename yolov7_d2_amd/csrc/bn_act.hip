@@ -464,16 +464,393 @@ extern "C" int mi_bn_act_bwd_apply(const void* da, int ldda, const void* y, int 
   return MI_OK;
 }
 
+// ------------------------------------------------------------------ backward, both passes in ONE launch
+// The two-pass form reads da and y twice (5 tensor passes: 2 + 2 reads, 1 write).  The chip holds far more than one
+// layer's (da, y) on-chip: 256 CUs x 512 KB of vector registers.  bn_bwd_fused keeps every block resident (grid <= what
+// the GPU runs concurrently), loads its share of da and y into REGISTERS (14-16 16-byte items of each per thread),
+// adds the block's channel sums to the fp64 accumulators, crosses a grid-wide barrier (agent-scope atomics on a counter
+// + generation word), reads the finished sums and writes dy from the registers: 3 tensor passes and one launch.  Items
+// beyond the register capacity (the 160x160 / 320x320 maps) are streamed in both phases like the two-pass kernels do.
+#define BN_FUS_SPIN_LIMIT (1 << 22)
+struct BnFusK {
+  const __bf16* da;
+  const __bf16* y;
+  __bf16* dy;
+  __bf16* dres;
+  double* dacc;
+  unsigned* bar;  // MI_BN_BAR_WORDS barrier words (bn_grid_barrier); [2] is set when a wait gave up (never in a healthy run)
+  const float* scale;
+  const float* shift;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  float* dgamma;
+  float* dbeta;
+  int ldda, ldy, lddy, lddres, dres_accum, C8, nslots, rsv_;
+  int64_t npix;
+  double inv_count;
+};
+
+// Grid-wide barrier over nb resident blocks.  Agent-scope atomics are performed memory-side, one after the other per
+// address (~0.1 us each: 512 arrivals on ONE counter cost ~50 us, measured), so arrivals go through a two-level tree -
+// MI_BN_BAR_GROUPS group counters (block % groups), whose last arrivers meet on the top counter - and every group waits
+// on its own generation word; each word sits on its own 256-byte line.  Word layout (uint32):
+//   [0] top arrivals  [2] give-up flag  [64 * (1 + g)] generation of group g  [64 * (1 + G + g)] arrivals of group g
+#define BN_BAR_G MI_BN_BAR_GROUPS
+__device__ __forceinline__ unsigned* bn_bar_gen(unsigned* bar, int g) { return bar + 64 * (1 + g); }
+__device__ __forceinline__ unsigned* bn_bar_cnt(unsigned* bar, int g) { return bar + 64 * (1 + BN_BAR_G + g); }
+// No cache maintenance: an agent-scope acquire / release (or __threadfence) writes back and invalidates the XCD's whole L2
+// - issued by hundreds of polling blocks that stalls every block still streaming (measured: +90 us per launch).  It is not
+// needed here: the only data that crosses blocks are the fp64 sums, added by memory-side atomics that have been
+// acknowledged when the block passes its __syncthreads (workgroup release = s_waitcnt vmcnt(0)), and read back after the
+// barrier by agent-scope atomic loads, which bypass the non-coherent caches.
+__device__ __forceinline__ void bn_grid_barrier(unsigned* bar, const unsigned gen0, const int bid, const int nb) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int G = nb < BN_BAR_G ? nb : BN_BAR_G;
+    const int g = bid % G;
+    const unsigned gsize = (unsigned)((nb - g + G - 1) / G);
+    bool released = false;
+    if (__hip_atomic_fetch_add(bn_bar_cnt(bar, g), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1u) {
+      __hip_atomic_store(bn_bar_cnt(bar, g), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)G - 1u) {
+        __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 0; q < G; ++q)
+          __hip_atomic_fetch_add(bn_bar_gen(bar, q), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        released = true;
+      }
+    }
+    if (!released) {
+      int spins = 0;
+      while (__hip_atomic_load(bn_bar_gen(bar, g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > BN_FUS_SPIN_LIMIT) {  // a block that never became resident: report instead of hanging the GPU
+          __hip_atomic_store(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// MODE 0: da and y stay in registers as loaded (bf16, 8 VGPRs per item, 16 items); phase 2 recomputes the activation
+//         gradient.  MODE 1: dz stays in fp32 registers and y in LDS (14 items, 72 KB per block); phase 2 is 5 flops per
+//         element.
+template <int ACT, int MODE, class PK>
+__device__ __forceinline__ void bn_bwd_fused_body(PK& p, const int bid, const int nb) {
+  constexpr int R = MODE ? 14 : 16;
+  // LDS: 16 KB block reduction scratch (re-used for the finished sums after the barrier) + (MODE 1) the retained y items
+  __shared__ float red[256 * 16];
+  __shared__ bf16x8 ylds[MODE ? R : 1][MODE ? 256 : 1];
+  float* s_c1 = red;
+  float* s_c2 = red + BN_MAXC;
+  const int tid = threadIdx.x;
+  const int C8 = p.C8, C = C8 * 8, CA = BN_ACC_C(C);
+  const int PL = 256 / C8, TPB = PL * C8;
+  const bool active = tid < TPB;
+  const int c8 = tid % C8, pl = active ? tid / C8 : 0;
+  unsigned gen0 = 0;   // thread 0 only
+  if (tid == 0)
+    gen0 = __hip_atomic_load(bn_bar_gen(p.bar, bid % (nb < BN_BAR_G ? nb : BN_BAR_G)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // item = (pixel, channel group); TPB % C8 == 0: the thread's pixels are pix0 + k * pstep.  Addresses are a uniform
+  // 64-bit base (+ k * uniform step) plus ONE 32-bit per-thread byte offset per tensor (host checks the 4 GB bound), so
+  // the retained items cost no address registers.
+  const int64_t pstep = (int64_t)nb * PL;
+  const int64_t pix0 = (int64_t)bid * PL + pl;
+  const int nmine = (active && pix0 < p.npix) ? (int)((p.npix - pix0 + pstep - 1) / pstep) : 0;  // this thread's items
+  const char* dab = (const char*)p.da;
+  const char* yb = (const char*)p.y;
+  const unsigned oda = (unsigned)((pix0 * p.ldda + c8 * 8) * 2), oy = (unsigned)((pix0 * p.ldy + c8 * 8) * 2);
+  const int64_t sda = pstep * p.ldda * 2, sy = pstep * p.ldy * 2;
+  // the residual gradient (dres (+)= da) does not depend on the sums: written in phase 1, while da is at hand
+  char* drb = (char*)p.dres;
+  const unsigned odr = (unsigned)((pix0 * p.lddres + c8 * 8) * 2);
+  const int64_t sdr = pstep * p.lddres * 2;
+  const bool racc = drb && p.dres_accum;
+  auto pass_res = [&](const int k, const bf16x8& d) {
+    if (!drb) return;
+    bf16x8* rp = (bf16x8*)(drb + k * sdr + odr);
+    if (racc) {
+      const bf16x8 r = *rp;
+      float q[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) q[e] = (float)r[e] + (float)d[e];
+      *rp = pack8(q);
+    } else {
+      *rp = d;
+    }
+  };
+  bf16x8 dv[R], yv[R];          // MODE 0: live across the barrier
+  float dzr[MODE ? R : 1][8];   // MODE 1
+  float s1[8], s2[8];
+  {
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      if (u < nmine) {
+        dv[u] = *(const bf16x8*)(dab + u * sda + oda);
+        yv[u] = *(const bf16x8*)(yb + u * sy + oy);
+      }
+    }
+    float sc[8], sh[8], mu[8], is[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] = p.scale[c8 * 8 + e];
+      sh[e] = p.shift[c8 * 8 + e];
+      mu[e] = p.mean[c8 * 8 + e];
+      is[e] = p.invstd[c8 * 8 + e];
+      s1[e] = s2[e] = 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      if (u < nmine) {
+        pass_res(u, dv[u]);
+        if (MODE) ylds[MODE ? u : 0][MODE ? tid : 0] = yv[u];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float yy = (float)yv[u][e];
+          const float z = yy * sc[e] + sh[e];
+          const float dz = (float)dv[u][e] * act_grad(z, ACT);
+          if (MODE) dzr[MODE ? u : 0][e] = dz;
+          s1[e] += dz;
+          s2[e] += dz * ((yy - mu[e]) * is[e]);
+        }
+      }
+    }
+    // beyond the on-chip capacity: stream (4 items in flight)
+    for (int k0 = R; k0 < nmine; k0 += 4) {
+      bf16x8 d4[4], y4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (k0 + u < nmine) {
+          d4[u] = *(const bf16x8*)(dab + (k0 + u) * sda + oda);
+          y4[u] = *(const bf16x8*)(yb + (k0 + u) * sy + oy);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (k0 + u >= nmine) break;
+        pass_res(k0 + u, d4[u]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float yy = (float)y4[u][e];
+          const float z = yy * sc[e] + sh[e];
+          const float dz = (float)d4[u][e] * act_grad(z, ACT);
+          s1[e] += dz;
+          s2[e] += dz * ((yy - mu[e]) * is[e]);
+        }
+      }
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[(pl * C8 + c8) * 16 + e] = s1[e];
+      red[(pl * C8 + c8) * 16 + 8 + e] = s2[e];
+    }
+  }
+  __syncthreads();
+  {
+    const int nout = C8 * 16;
+    double* slot = p.dacc + (size_t)(bid % p.nslots) * CA * 2;
+    for (int j = tid; j < nout; j += 256) {
+      float acc = 0.f;
+      for (int q = 0; q < PL; ++q) acc += red[q * nout + j];
+      const int cc8 = j / 16, v = j % 16;
+      atomicAdd(slot + (cc8 * 8 + (v & 7)) * 2 + (v >> 3), (double)acc);
+    }
+  }
+  bn_grid_barrier(p.bar, gen0, bid, nb);   // (its leading __syncthreads also ends the reads of red[])
+  // ---- phase 2: the finished sums (agent-scope loads: the adds were performed by other XCDs)
+  for (int c = tid; c < C; c += 256) {
+    double v1[MI_BN_SLOTS], v2[MI_BN_SLOTS];
+#pragma unroll
+    for (int k = 0; k < MI_BN_SLOTS; ++k) {
+      if (k < p.nslots) {
+        v1[k] = __hip_atomic_load(p.dacc + ((size_t)k * CA + c) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v2[k] = __hip_atomic_load(p.dacc + ((size_t)k * CA + c) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        v1[k] = v2[k] = 0.0;
+      }
+    }
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < MI_BN_SLOTS; ++k) {
+      t1 += v1[k];
+      t2 += v2[k];
+    }
+    s_c1[c] = (float)(t1 * p.inv_count);
+    s_c2[c] = (float)(t2 * p.inv_count);
+    if (bid == 0) {
+      if (p.dbeta) p.dbeta[c] = (float)t1;
+      if (p.dgamma) p.dgamma[c] = (float)t2;
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  float sc[8], sh[8], mu[8], is[8], gi[8], k1[8], k2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c8 * 8 + e;
+    sc[e] = p.scale[c];
+    sh[e] = p.shift[c];
+    mu[e] = p.mean[c];
+    is[e] = p.invstd[c];
+    gi[e] = p.gamma[c] * is[e];
+    k1[e] = s_c1[c];
+    k2[e] = s_c2[c];
+  }
+  char* dyb = (char*)p.dy;
+  const unsigned ody = (unsigned)((pix0 * p.lddy + c8 * 8) * 2);
+  const int64_t sdy = pstep * p.lddy * 2;
+  auto full = [&](const int k, const bf16x8& d, const bf16x8& yy8) {
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float yy = (float)yy8[e];
+      const float z = yy * sc[e] + sh[e];
+      const float dz = (float)d[e] * act_grad(z, ACT);
+      const float xh = (yy - mu[e]) * is[e];
+      o[e] = gi[e] * (dz - k1[e] - xh * k2[e]);
+    }
+    *(bf16x8*)(dyb + k * sdy + ody) = pack8(o);
+  };
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    if (u < nmine) {
+      if (MODE) {
+        const bf16x8 yk = ylds[MODE ? u : 0][MODE ? tid : 0];
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = ((float)yk[e] - mu[e]) * is[e];
+          o[e] = gi[e] * (dzr[MODE ? u : 0][e] - k1[e] - xh * k2[e]);
+        }
+        *(bf16x8*)(dyb + u * sdy + ody) = pack8(o);
+      } else {
+        full(u, dv[u], yv[u]);
+      }
+    }
+  }
+  for (int k0 = R; k0 < nmine; k0 += 2) {
+    bf16x8 d2[2], y2[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (k0 + u < nmine) {
+        d2[u] = *(const bf16x8*)(dab + (k0 + u) * sda + oda);
+        y2[u] = *(const bf16x8*)(yb + (k0 + u) * sy + oy);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (k0 + u < nmine) full(k0 + u, d2[u], y2[u]);
+  }
+}
+
+template <int ACT, int MODE>
+__global__ __launch_bounds__(256, 2) void bn_bwd_fused_kernel(const BnFusK p) {
+  bn_bwd_fused_body<ACT, MODE, const BnFusK>(p, blockIdx.x, gridDim.x);
+}
+template <int ACT, int MODE>
+__global__ __launch_bounds__(256, 2) void bn_bwd_fused_group_kernel(const BnFusK* __restrict__ jobs,
+                                                                    const int* __restrict__ starts, int njobs) {
+  const int j = bn_group_job(starts, njobs);
+  typedef const __attribute__((address_space(4))) BnFusK KC4;
+  KC4* pj = (KC4*)(uintptr_t)(jobs + j);
+  bn_bwd_fused_body<ACT, MODE, KC4>(*pj, (int)blockIdx.x - starts[j], starts[j + 1] - starts[j]);
+}
+static int bn_fused_mode() {
+  static int m = -1;
+  if (m < 0) {
+    const char* e = getenv("MI_BN_FUSED_MODE");
+    m = e ? atoi(e) : 1;
+    if (m != 0) m = 1;
+  }
+  return m;
+}
+
+// number of 256-thread blocks of the fused kernel the GPU keeps resident at once (the grid barrier needs all of them)
+static int g_fused_cap_user = 0;
+static int bn_fused_capacity_hw() {
+  static int cap = 0;
+  if (cap) return cap;
+  int dev = 0, ncu = 0, per = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      ncu <= 0) {
+    (void)hipGetLastError();
+    return 512;  // no device (host-side planning of a dry run): the MI355X figure, 256 CUs x 2
+  }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, bn_bwd_fused_kernel<1, 1>, 256, 0) != hipSuccess || per < 1) per = 1;
+  if (per > 2) per = 2;
+  cap = ncu * per;
+  return cap;
+}
+static int bn_fused_capacity() {
+  const int hw = bn_fused_capacity_hw();
+  return (g_fused_cap_user > 0 && g_fused_cap_user < hw) ? g_fused_cap_user : hw;
+}
+extern "C" int mi_bn_fused_set_capacity(int blocks) {
+  g_fused_cap_user = blocks > 0 ? blocks : 0;
+  return bn_fused_capacity();
+}
+static bool bn_fused_fits(int64_t npix, int ldda, int ldy, int lddy, int lddres) {
+  int ld = ldda > ldy ? ldda : ldy;
+  if (lddy > ld) ld = lddy;
+  if (lddres > ld) ld = lddres;
+  return npix * ld * 2 < (1LL << 32) - 4096;   // 32-bit per-thread byte offsets
+}
+static int bn_fused_blocks(int64_t npix, int C8, int cap) {
+  // at least ~4 items per thread (the barrier costs one atomic round trip per block), never more than `cap` blocks
+  const int64_t TPB = (256 / C8) * C8;
+  int64_t b = (npix * C8 + TPB * 4 - 1) / (TPB * 4);
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+extern "C" int mi_bn_act_bwd_fused(const void* da, int ldda, const void* y, int ldy, const float* scale, const float* shift,
+                                   const float* mean, const float* invstd, const float* gamma, double* dacc, int nslots,
+                                   int64_t count, float* dgamma, float* dbeta, void* dy, int lddy, void* dres, int lddres,
+                                   int dres_accum, int64_t npix, int C, int act, uint32_t* barrier_words, mi_stream_t st) {
+  MI_REQUIRE(da && y && scale && shift && mean && invstd && gamma && dacc && dy && barrier_words && count > 0, "bn_bwd_fused: null");
+  MI_REQUIRE(C % 8 == 0 && C > 0 && C <= BN_MAXC, "bn_bwd_fused: C %d", C);
+  MI_REQUIRE(ldda % 8 == 0 && ldy % 8 == 0 && lddy % 8 == 0 && (!dres || lddres % 8 == 0), "bn_bwd_fused: ld");
+  MI_REQUIRE(bn_fused_fits(npix, ldda, ldy, lddy, dres ? lddres : 0), "bn_bwd_fused: tensors beyond 4 GB (use reduce + apply)");
+  BnFusK k;
+  k.da = (const __bf16*)da; k.y = (const __bf16*)y; k.dy = (__bf16*)dy; k.dres = (__bf16*)dres; k.dacc = dacc;
+  k.bar = barrier_words; k.scale = scale; k.shift = shift; k.mean = mean; k.invstd = invstd; k.gamma = gamma;
+  k.dgamma = dgamma; k.dbeta = dbeta; k.ldda = ldda; k.ldy = ldy; k.lddy = lddy; k.lddres = lddres;
+  k.dres_accum = dres_accum; k.C8 = C / 8; k.rsv_ = 0; k.npix = npix; k.inv_count = 1.0 / (double)count;
+  k.nslots = (nslots >= 1 && nslots <= MI_BN_SLOTS) ? nslots : MI_BN_SLOTS;
+  const int nb = bn_fused_blocks(npix, C / 8, bn_fused_capacity());
+  const int mode = bn_fused_mode();
+  if (act && mode) hipLaunchKernelGGL((bn_bwd_fused_kernel<1, 1>), dim3(nb), dim3(256), 0, (hipStream_t)st, k);
+  else if (act) hipLaunchKernelGGL((bn_bwd_fused_kernel<1, 0>), dim3(nb), dim3(256), 0, (hipStream_t)st, k);
+  else if (mode) hipLaunchKernelGGL((bn_bwd_fused_kernel<0, 1>), dim3(nb), dim3(256), 0, (hipStream_t)st, k);
+  else hipLaunchKernelGGL((bn_bwd_fused_kernel<0, 0>), dim3(nb), dim3(256), 0, (hipStream_t)st, k);
+  MI_CHECK_LAUNCH("bn_bwd_fused");
+  return MI_OK;
+}
+
 // ------------------------------------------------------------------ grouped launches
 // one launch for the same BatchNorm pass of several independent layers (the FPN levels of the head)
 extern "C" int mi_bn_group_plan(int kind, const mi_bn_job* jobs, int n, void* table_host, int64_t table_cap,
                                 mi_bn_group* meta) {
-  MI_REQUIRE(jobs && meta && n >= 1 && n <= MI_BN_MAX_GROUP && kind >= 0 && kind <= 2, "bn_group_plan: args");
+  MI_REQUIRE(jobs && meta && n >= 1 && n <= MI_BN_MAX_GROUP && kind >= 0 && kind <= 3, "bn_group_plan: args");
   int starts[MI_BN_MAX_GROUP + 1];
   starts[0] = 0;
   BnFwdK kf[MI_BN_MAX_GROUP];
   BnRedK kr[MI_BN_MAX_GROUP];
   BnBwdK ka[MI_BN_MAX_GROUP];
+  BnFusK ku[MI_BN_MAX_GROUP];
+  // fused backward: the whole launch must be resident at once - the jobs share the capacity in proportion to their size
+  const int cap = kind == 3 ? bn_fused_capacity() : 0;
+  int64_t want = 0;
+  if (kind == 3) {
+    MI_REQUIRE(n <= cap, "bn_group_plan: more fused jobs than resident blocks");
+    for (int j = 0; j < n; ++j)
+      if (jobs[j].C > 0 && jobs[j].C % 8 == 0) want += bn_fused_blocks(jobs[j].npix, jobs[j].C / 8, cap);
+  }
   for (int j = 0; j < n; ++j) {
     const mi_bn_job& b = jobs[j];
     const int C = b.C;
@@ -504,6 +881,21 @@ extern "C" int mi_bn_group_plan(int kind, const mi_bn_job* jobs, int n, void* ta
       k.da = (const __bf16*)b.da; k.y = (const __bf16*)b.y; k.scale = b.scale; k.shift = b.shift; k.mean = b.mean;
       k.invstd = b.invstd; k.dacc = b.acc; k.ldda = b.ldda; k.ldy = b.ldy; k.nslots = nslots; k.C8 = C / 8; k.npix = b.npix;
       nb = b.nblk;
+    } else if (kind == 3) {
+      MI_REQUIRE(b.da && b.y && b.scale && b.shift && b.mean && b.invstd && b.gamma && b.acc && b.dy && b.bar && b.count > 0,
+                 "bn_group_plan: fused job %d", j);
+      MI_REQUIRE(bn_fused_fits(b.npix, b.ldda, b.ldy, b.lddy, b.dres ? b.lddres : 0), "bn_group_plan: fused job %d beyond 4 GB", j);
+      BnFusK& k = ku[j];
+      k.da = (const __bf16*)b.da; k.y = (const __bf16*)b.y; k.dy = (__bf16*)b.dy; k.dres = (__bf16*)b.dres; k.dacc = b.acc;
+      k.bar = b.bar; k.scale = b.scale; k.shift = b.shift; k.mean = b.mean; k.invstd = b.invstd; k.gamma = b.gamma;
+      k.dgamma = b.dgamma; k.dbeta = b.dbeta; k.ldda = b.ldda; k.ldy = b.ldy; k.lddy = b.lddy; k.lddres = b.lddres;
+      k.dres_accum = b.dres_accum; k.C8 = C / 8; k.rsv_ = 0; k.npix = b.npix; k.inv_count = 1.0 / (double)b.count;
+      k.nslots = nslots;
+      nb = bn_fused_blocks(b.npix, C / 8, cap);
+      if (want > cap) {
+        nb = (int)((int64_t)nb * (cap - n) / want);   // sum <= cap - n, + 1 each below
+        nb += 1;
+      }
     } else {
       MI_REQUIRE(b.da && b.y && b.scale && b.shift && b.mean && b.invstd && b.gamma && b.acc && b.dy && b.count > 0,
                  "bn_group_plan: apply job %d", j);
@@ -515,8 +907,8 @@ extern "C" int mi_bn_group_plan(int kind, const mi_bn_job* jobs, int n, void* ta
     }
     starts[j + 1] = starts[j] + nb;
   }
-  const size_t rec = kind == 0 ? sizeof(BnFwdK) : (kind == 1 ? sizeof(BnRedK) : sizeof(BnBwdK));
-  const void* src = kind == 0 ? (const void*)kf : (kind == 1 ? (const void*)kr : (const void*)ka);
+  const size_t rec = kind == 0 ? sizeof(BnFwdK) : (kind == 1 ? sizeof(BnRedK) : (kind == 2 ? sizeof(BnBwdK) : sizeof(BnFusK)));
+  const void* src = kind == 0 ? (const void*)kf : (kind == 1 ? (const void*)kr : (kind == 2 ? (const void*)ka : (const void*)ku));
   meta->kind = kind; meta->njobs = n; meta->nblocks = starts[n]; meta->act = jobs[0].act;
   meta->starts_off = (int64_t)(rec * n);
   meta->table_bytes = meta->starts_off + (int64_t)sizeof(int) * (n + 1);
@@ -539,9 +931,17 @@ extern "C" int mi_bn_group_run(const mi_bn_group* m, const void* table_dev, mi_s
   } else if (m->kind == 1) {
     if (m->act) hipLaunchKernelGGL(bn_bwd_reduce_group_kernel<1>, g, b, 0, s, (const BnRedK*)table_dev, starts, m->njobs);
     else hipLaunchKernelGGL(bn_bwd_reduce_group_kernel<0>, g, b, 0, s, (const BnRedK*)table_dev, starts, m->njobs);
-  } else {
+  } else if (m->kind == 2) {
     if (m->act) hipLaunchKernelGGL(bn_bwd_apply_group_kernel<1>, g, b, 0, s, (const BnBwdK*)table_dev, starts, m->njobs);
     else hipLaunchKernelGGL(bn_bwd_apply_group_kernel<0>, g, b, 0, s, (const BnBwdK*)table_dev, starts, m->njobs);
+  } else {
+    MI_REQUIRE(m->nblocks <= bn_fused_capacity(), "bn_group_run: fused launch of %d blocks exceeds the resident capacity", m->nblocks);
+    const int mode = bn_fused_mode();
+    const BnFusK* jt = (const BnFusK*)table_dev;
+    if (m->act && mode) hipLaunchKernelGGL((bn_bwd_fused_group_kernel<1, 1>), g, b, 0, s, jt, starts, m->njobs);
+    else if (m->act) hipLaunchKernelGGL((bn_bwd_fused_group_kernel<1, 0>), g, b, 0, s, jt, starts, m->njobs);
+    else if (mode) hipLaunchKernelGGL((bn_bwd_fused_group_kernel<0, 1>), g, b, 0, s, jt, starts, m->njobs);
+    else hipLaunchKernelGGL((bn_bwd_fused_group_kernel<0, 0>), g, b, 0, s, jt, starts, m->njobs);
   }
   MI_CHECK_LAUNCH("bn_group");
   return MI_OK;

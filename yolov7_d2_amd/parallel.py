@@ -36,9 +36,9 @@ def grad_write_ranges(plan, grad_tensor):
         elif c.op == L.OP["WGRAD_GROUP"]:
             for d in plan.cmd_descs["bwd"][k]:
                 ptrs.append((d.gw, d.ntaps * d.Cout * d.Cin * 4))
-        elif c.op == L.OP["BN_BWD_APPLY"]:
+        elif c.op in (L.OP["BN_BWD_APPLY"], L.OP["BN_BWD_FUSED"]):
             ptrs += [(c.p[8], c.i[5] * 4), (c.p[9], c.i[5] * 4)]
-        elif c.op == L.OP["BN_GROUP"] and c.i[0] == 2:
+        elif c.op == L.OP["BN_GROUP"] and c.i[0] in (2, 3):
             for j in plan.cmd_descs["bwd"][k]:
                 ptrs += [(j.dgamma, j.C * 4), (j.dbeta, j.C * 4)]
         elif c.op == L.OP["COLSUM"]:

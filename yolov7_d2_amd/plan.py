@@ -99,7 +99,7 @@ def lane_out_key(c):
     if c.op == L.OP["CONV"]:
         y = c.desc.y
         return (id(getattr(y.obj, "buf", y.obj)), getattr(y.obj, "coff", 0), y.off)
-    if c.op == L.OP["BN_BWD_APPLY"] and c.p[11].obj is not None:
+    if c.op in (L.OP["BN_BWD_APPLY"], L.OP["BN_BWD_FUSED"]) and c.p[11].obj is not None:
         return (id(c.p[11].obj.buf), c.p[11].obj.coff, 0)
     return id(c)
 
@@ -110,7 +110,7 @@ def schedule_lanes(region):
     from all those lanes at once.  Returns a list of issue sets; the commands of a set are mutually independent, have
     the same op and pairwise different output tensors - writers of one tensor (two data gradients accumulating into the
     same input gradient) are split into consecutive sets in their original order."""
-    groupable = {L.OP["CONV"], L.OP["BN_ACT_FWD"], L.OP["BN_BWD_REDUCE"], L.OP["BN_BWD_APPLY"]}
+    groupable = {L.OP["CONV"], L.OP["BN_ACT_FWD"], L.OP["BN_BWD_REDUCE"], L.OP["BN_BWD_APPLY"], L.OP["BN_BWD_FUSED"]}
     order = {id(r): i for i, r in enumerate(region)}
     lanes = sorted({r.lane for r in region})
     chains = [[r for r in region if r.lane == ln] for ln in lanes]
@@ -474,7 +474,7 @@ class PlanBuilder:
                 dres_acc = self.grad_mode(res)
             self.emit("BN_BWD_APPLY", i=[da.ld, y.ld, CoutPad, dres.ld if dres is not None else 0, dres_acc, Cout, act, nsl2],
                       l=[count, count], p=[da, y, scale, shift, mean, invstd, bn["gamma"], dacc, bn["ggamma"], bn["gbeta"],
-                                           dyT, dres], tag=tag + ".bnapply")
+                                           dyT, dres, self.small(tag + ".bar", 4 * L.MI_BN_BAR_WORDS)], tag=tag + ".bnapply")
             self.wgrad_cmds(tag, x, dyT, CinPad if (k > 1 or CinPad % 32 == 0) else _rup(Cin, 32), CoutPad, Cin, Cout, k,
                             stride, pad, wgrad)
             if need_dgrad:
@@ -666,8 +666,64 @@ class Plan:
         self.descs = []
         self.cmd_descs = {}
         self.fwd_cmds, self.fwd_tags = self._materialize(self._batch_packs(b.prologue) + b.fwd, "fwd")
-        self.bwd_cmds, self.bwd_tags = self._materialize(self._group_wgrads(self._batch_splits(b.bwd)), "bwd")
         self.graphs = {}
+        # BatchNorm backward as one fused launch per layer or as reduce + apply: MI_BN_FUSED=1 / 0, default "auto" = both
+        # backward lists are captured and timed ON THIS DEVICE and the faster one is kept.  (Measured: on most boxes of the
+        # pool the fused form gains 2.3 % of the YOLOX-s step, on some - identical kernel timings in isolation, ~3 us more
+        # per kernel boundary in the step - it loses 1 %.)
+        mode = os.environ.get("MI_BN_FUSED", "auto")
+        self.bn_fused = mode != "0"
+        self.bn_fused_timing = None
+        self._materialize_bwd()
+        if (mode == "auto" and not dry_run and b.device.type == "cuda" and b.training
+                and any(L.OPS[self.bwd_cmds[0][k].op] == "BN_BWD_FUSED" or
+                        (L.OPS[self.bwd_cmds[0][k].op] == "BN_GROUP" and self.bwd_cmds[0][k].i[0] == 3)
+                        for k in range(self.bwd_cmds[1]))):
+            self._select_bn_backward()
+
+    def _materialize_bwd(self):
+        b = self.b
+        bwd = self._batch_splits(b.bwd)
+        if self.bn_fused:
+            bwd = self._fuse_bn_bwd_pairs(bwd)
+        self.bwd_cmds, self.bwd_tags = self._materialize(self._group_wgrads(bwd), "bwd")
+
+    def _select_bn_backward(self, rounds=3, launches=4):
+        """time the fused and the two-pass backward lists as hipGraphs (alternating, best mean of `rounds`) and keep the
+        faster.  The replays only write buffers that every step overwrites (activation / parameter gradients, scratch)."""
+        lib = L.lib()
+        s = torch.cuda.Stream()
+        sp = L.stream_ptr(s)
+        best = {}
+        handles = {}
+        keep = {}
+        for fused in (True, False):
+            self.bn_fused = fused
+            self._materialize_bwd()
+            arr, n = self.bwd_cmds
+            keep[fused] = (self.bwd_cmds, self.bwd_tags, self.cmd_descs["bwd"], self.cmd_members["bwd"],
+                           list(self.wgrad_descs), list(getattr(self, "wgrad_stage_tags", [])))
+            with torch.cuda.stream(s):
+                L.check(lib.mi_cmdlist_run(arr, n, sp), "bn select: eager run")
+                handles[fused] = L.check(lib.mi_graph_capture(arr, n, sp), "bn select: capture")
+        with torch.cuda.stream(s):
+            for r in range(rounds + 1):
+                for fused in (True, False):
+                    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(s)
+                    for _ in range(launches):
+                        L.check(lib.mi_graph_launch(handles[fused], sp), "bn select: launch")
+                    e.record(s)
+                    e.synchronize()
+                    if r > 0:   # round 0 warms up
+                        t = a.elapsed_time(e) / launches
+                        best[fused] = min(best.get(fused, 1e9), t)
+        for h in handles.values():
+            lib.mi_graph_destroy(h)
+        self.bn_fused_timing = dict(fused_ms=round(best[True], 4), two_pass_ms=round(best[False], 4))
+        self.bn_fused = best[True] <= best[False]
+        (self.bwd_cmds, self.bwd_tags, self.cmd_descs["bwd"], self.cmd_members["bwd"], self.wgrad_descs,
+         self.wgrad_stage_tags) = keep[self.bn_fused]
 
     def _group_wgrads(self, bwd):
         """all WGRAD commands become ONE grouped launch at the end of backward (mi_conv2d_wgrad_group_run) - or two when
@@ -758,6 +814,30 @@ class Plan:
         grp = _Cmd(L.OP["WGRAD_GROUP"], p=[_Ptr(C.addressof(meta)), _Ptr(table)], tag=tag)
         grp.group_descs = list(descs)
         return grp
+
+    def _fuse_bn_bwd_pairs(self, bwd):
+        """BN_BWD_REDUCE + BN_BWD_APPLY of one layer -> ONE launch that keeps (da, y) in registers across a grid-wide
+        barrier (mi_bn_act_bwd_fused): 3 tensor passes instead of 5.  Not with auxiliary streams: two fused launches running
+        concurrently would each wait for blocks the other keeps from starting."""
+        b = self.b
+        if b.multi_stream or getattr(b, "wgrad_async", 0) > 0:
+            return bwd
+        RED, APP = L.OP["BN_BWD_REDUCE"], L.OP["BN_BWD_APPLY"]
+        out, k = [], 0
+        while k < len(bwd):
+            c = bwd[k]
+            n = bwd[k + 1] if k + 1 < len(bwd) else None
+            if (c.op == RED and n is not None and n.op == APP and c.tag.endswith(".bnred")
+                    and n.tag == c.tag[:-len(".bnred")] + ".bnapply" and len(n.p) > 12 and n.p[12].obj is not None):
+                f = _Cmd(L.OP["BN_BWD_FUSED"], i=n.i, l=n.l, p=n.p, tag=c.tag[:-len(".bnred")] + ".bnbwd", stream=n.stream)
+                f.lane = n.lane
+                f.members = [c, n]
+                out.append(f)
+                k += 2
+            else:
+                out.append(c)
+                k += 1
+        return out
 
     def _batch_splits(self, bwd):
         """the out-gradient maps of all prediction convs (SPLIT_DPREDS, one per conv) in ONE launch right after the loss
@@ -868,7 +948,7 @@ class Plan:
         if not b.group_lanes or b.multi_stream:
             return cmds
         NOP, CONV = L.OP["NOP"], L.OP["CONV"]
-        BN_KIND = {L.OP["BN_ACT_FWD"]: 0, L.OP["BN_BWD_REDUCE"]: 1, L.OP["BN_BWD_APPLY"]: 2}
+        BN_KIND = {L.OP["BN_ACT_FWD"]: 0, L.OP["BN_BWD_REDUCE"]: 1, L.OP["BN_BWD_APPLY"]: 2, L.OP["BN_BWD_FUSED"]: 3}
 
         def issue(cs, order):
             cs = sorted(cs, key=lambda c: order[id(c)])
@@ -1012,9 +1092,10 @@ class Plan:
                 j.da, j.y, j.scale, j.shift, j.mean, j.invstd, j.acc = P[:7]
                 j.ldda, j.ldy, j.nblk, j.C, j.act, j.nslots = c.i[:6]
                 j.npix = j.count = c.l[0]
-            else:            # BN_BWD_APPLY: i=[ldda, ldy, lddy, lddres, dres_acc, C, act, nslots] l=[count, npix]
+            else:            # BN_BWD_APPLY / BN_BWD_FUSED: i=[ldda, ldy, lddy, lddres, dres_acc, C, act, nslots] l=[count, npix]
                 (j.da, j.y, j.scale, j.shift, j.mean, j.invstd, j.gamma, j.acc, j.dgamma, j.dbeta, j.dy,
                  j.dres) = P[:12]
+                j.bar = P[12] if kind == 3 else None
                 j.ldda, j.ldy, j.lddy, j.lddres, j.dres_accum, j.C, j.act, j.nslots = c.i[:8]
                 j.npix, j.count = c.l[0], c.l[1]
         meta = L.mi_bn_group()
