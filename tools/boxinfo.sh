@@ -21,3 +21,4 @@ for _ in range(10): m @ m
 b.record(); torch.cuda.synchronize()
 print(f"bf16 gemm 8192^3: {2 * 8192 ** 3 * 10 / (a.elapsed_time(b) * 1e-3) / 1e12:.0f} TFLOP/s")
 P
+[ -x tools/micro/launch_floor.bin ] && tools/micro/launch_floor.bin 2>/dev/null | head -8
