@@ -294,10 +294,14 @@ typedef struct mi_yolox_loss_desc {
   int32_t* matched_gt;  /* [B][A] index of matched gt or -1                                   */
   float* matched_iou;   /* [B][A]                                                             */
   float* partial;       /* [nblk][4] block partial sums (iou, obj, cls, nfg); nblk = B*ceil(A/256) */
-  float* out;           /* [8]: total, 5*iou, obj, cls, l1(0), num_fg/num_gt, num_fg, num_gt */
+  float* out;           /* [8]: total, 5*iou, obj, cls, l1, num_fg/num_gt, num_fg, num_gt */
+  /* head.use_l1 (yolox_head.py:131, switched on by the meta-arch after INPUT.MOSAIC_AND_MIXUP.DISABLE_AT_ITER,
+   * meta_arch/yolox.py:105-118): adds sum|raw_reg - get_l1_target| / num_fg to the total; 0 = the default */
+  int32_t use_l1, rsv_;
+  float* partial_l1;    /* [nblk] (use_l1 only) */
 } mi_yolox_loss_desc;
 int mi_yolox_loss_fwd(const mi_yolox_loss_desc* d, mi_stream_t s);
-/* gradient wrt raw preds; gw[4] = upstream grads of (total, 5*iou, obj, cls) on device.
+/* gradient wrt raw preds; gw[4] = upstream grads of (total, 5*iou, obj, cls) on device (+ gw[4] = of l1 iff use_l1).
  * dpreds fp32 [B][A][5+ncls] and/or bf16 per-level NHWC maps (see plan builder). */
 int mi_yolox_loss_bwd(const mi_yolox_loss_desc* d, const float* gw, float* dpreds, mi_stream_t s);
 /* extract channels [c0, c0+nc) of dpreds fp32 [B][A][nch] for anchors a0..a0+HW into a bf16
@@ -323,6 +327,9 @@ int mi_yolox_split_dpreds_batch(const float* dpreds, int B, int A, int nch, cons
                                 mi_stream_t s);
 /* eval decode (yolox_head.py:247-272): in-place on preds; obj/cls sigmoid applied */
 int mi_yolox_decode(float* preds, const float* anchors, int B, int A, int ncls, mi_stream_t s);
+/* the ONNX-export layout of decode_outputs (yolox_head.py:263-269) from the decoded predictions:
+ * out [B][A][6+ncls] = (xy, wh, conf, argmax(prob) as float - first maximum, prob) */
+int mi_yolox_onnx_layout(const float* decoded, float* out, int B, int A, int ncls, mi_stream_t s);
 
 /* ---- DETR set matching (config 4) --------------------------------------------------
  * replaces HungarianMatcher.forward (utils/detr_utils.py:37-91): matching cost
@@ -408,6 +415,15 @@ int mi_ew_bf16(const void* a, const void* b, void* out, int64_t n, int op, mi_st
  * pred/target fp32 [n][4] in (cx,cy,w,h) (box_xyxy 0) or (x1,y1,x2,y2); iou_type: 0 iou, 1 giou, 2 diou, 3 ciou, 4 siou */
 int mi_iou_loss_v6(const float* pred, const float* target, int n, int iou_type, int box_xyxy, float eps,
                    const float* dloss, float* loss, float* dpred, mi_stream_t s);
+
+/* IOUloss of the YOLOX head as a standalone op (utils/boxes.py:125-168): boxes (cx,cy,w,h) fp32 [n][4];
+ * loss_type 0 "iou" (1 - iou^2), 1 "giou" (1 - clamp(giou, -1, 1)); loss[n] (reduction "none") and
+ * dpred[n][4] = dloss[n] * d loss / d pred (dloss NULL => ones).  Either output may be NULL. */
+int mi_yolox_iou_loss(const float* pred, const float* target, int n, int loss_type, const float* dloss, float* loss,
+                      float* dpred, mi_stream_t s);
+/* pairwise IoU matrix out[N][M]: bboxes_iou (utils/boxes.py:57-81) and pairwise_bbox_iou (utils/boxes.py:755-779);
+ * boxes (cx,cy,w,h) (box_xyxy 0) or (x1,y1,x2,y2) */
+int mi_pairwise_bbox_iou(const float* box1, const float* box2, int N, int M, int box_xyxy, float* out, mi_stream_t s);
 
 /* ---- batched NMS -------------------------------------------------------------
  * replaces torchvision.ops.batched_nms as called by postprocess (utils/boxes.py:199).

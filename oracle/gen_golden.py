@@ -53,6 +53,21 @@ def gold_step():
     print("step:", res["losses"])
 
 
+def gold_onnx_layout():
+    """eval forward of the reference with head.onnx_export = True (decode_outputs' export layout, yolox_head.py:263-269):
+    [B, A, 4 + 1 + 1 + nc] = (xy, wh, conf, argmax class as float, class probabilities)"""
+    depth, width, nc = 0.33, 0.5, 80
+    ref, r = ref_loader.build_reference_yolox(depth, width, nc, seed=0)
+    ref.load_state_dict(O.init_state_dict(depth, width, nc, seed=0))
+    ref.eval()
+    ref.head.onnx_export = True
+    imgs, _ = O.synth_batch(2, 64, 96, seed=11, max_gt=4)
+    with torch.no_grad():
+        out = ref(imgs)
+    np.savez_compressed(os.path.join(OUT, "yolox_s_onnx_layout_64x96.npz"), out=out.numpy())
+    print("onnx layout:", tuple(out.shape), float(out[..., 5].mean()))
+
+
 def gold_tiny_step():
     """config 0 of BASELINE.json: YOLOX-tiny (depth .33, width .375), 416x416, bs=2, fp32 on the CPU device - the
     reference's own CPU-runnable case; losses, gradient norms of every parameter and the eval output"""
@@ -120,6 +135,37 @@ def gold_simota():
     print("simota:", out["losses"])
 
 
+def gold_simota_l1():
+    """the same head loss with head.use_l1 = True (yolox_head.py:186-196, 389-427): origin_preds are the raw regression
+    outputs per level; upstream gradient 1 on total, iou, conf, cls and l1"""
+    ref, r = ref_loader.build_reference_yolox(0.33, 0.5, 80, seed=0)
+    head = ref.head
+    head.train()
+    head.use_l1 = True
+    B, H, W = 3, 160, 160
+    _, labels = O.synth_batch(B, H, W, seed=21, max_gt=12, min_gt=6)
+    labels[1] = 0.0
+    hw = [(H // s, W // s) for s in (8, 16, 32)]
+    raw, anchors = O.synth_raw(B, hw, 22, labels=labels)
+    raw.requires_grad_(True)
+    outs, xs, ys, es, origin = [], [], [], [], []
+    a0 = 0
+    for (h, w), s in zip(hw, (8, 16, 32)):
+        o = (raw * 1.0)[:, a0:a0 + h * w].permute(0, 2, 1).reshape(B, 85, h, w)
+        reg = o[:, :4]                                      # reg_output of this level, [B,4,h,w]
+        origin.append(reg.view(B, 1, 4, h, w).permute(0, 1, 3, 4, 2).reshape(B, -1, 4).clone())
+        o, grid = head.get_output_and_grid(o, len(outs), s, torch.zeros(1).type())
+        xs.append(grid[:, :, 0]); ys.append(grid[:, :, 1])
+        es.append(torch.zeros(1, grid.shape[1]).fill_(s))
+        outs.append(o)
+        a0 += h * w
+    res6 = head.get_losses(None, xs, ys, es, labels, torch.cat(outs, 1), origin, dtype=torch.float32)
+    (res6[0] + res6[1] + res6[2] + res6[3] + res6[4]).backward()
+    out = dict(losses=np.array([float(x) for x in res6], dtype=np.float64), draw=raw.grad.numpy())
+    np.savez_compressed(os.path.join(OUT, "simota_160_l1.npz"), **out)
+    print("simota l1:", out["losses"])
+
+
 def gold_postprocess():
     """postprocess (utils/boxes.py:171-210) on synthetic decoded predictions; NMS = torchvision semantics
     as restated in yolox_oracle (torchvision itself is not installed: parity unpinned for NMS)."""
@@ -164,6 +210,30 @@ def gold_iou_v6():
         res[t + "_loss"], res[t + "_grad"] = loss.detach().numpy(), p.grad.numpy()
     np.savez_compressed(os.path.join(OUT, "iou_v6.npz"), **res)
     print("iou_v6:", {k: float(np.abs(v).mean()) for k, v in res.items()})
+
+
+def gold_yolox_iou():
+    """the reference's IOUloss module (utils/boxes.py:125-168, "iou" and "giou") with autograd, bboxes_iou (:57-81) and
+    pairwise_bbox_iou (:755-779) on seeded boxes (some pairs disjoint, some identical: ties of max / min)"""
+    r = ref_loader.load()
+    res = {}
+    pred, tgt = synth_box_pairs(257, 52)
+    tgt[200:210] = pred[200:210]                   # identical boxes: every max / min is a tie
+    tgt[210:220, :2] = pred[210:220, :2]           # same centre, different size
+    for t in ("iou", "giou"):
+        p = pred.clone().requires_grad_(True)
+        loss = r.boxes.IOUloss(reduction="none", loss_type=t)(p, tgt)
+        loss.sum().backward()
+        res[t + "_loss"], res[t + "_grad"] = loss.detach().numpy(), p.grad.numpy()
+    a, b = synth_box_pairs(37, 53)[0], synth_box_pairs(61, 54)[1]
+    res["pair_xywh"] = r.boxes.pairwise_bbox_iou(a, b, "xywh").numpy()
+    ax = torch.cat([a[:, :2] - a[:, 2:] / 2, a[:, :2] + a[:, 2:] / 2], 1)
+    bx = torch.cat([b[:, :2] - b[:, 2:] / 2, b[:, :2] + b[:, 2:] / 2], 1)
+    res["pair_xyxy"] = r.boxes.pairwise_bbox_iou(ax, bx, "xyxy").numpy()
+    res["bboxes_iou_xyxy"] = r.boxes.bboxes_iou(ax, bx, True).numpy()
+    res["bboxes_iou_xywh"] = r.boxes.bboxes_iou(a, b, False).numpy()
+    np.savez_compressed(os.path.join(OUT, "yolox_iou.npz"), **res)
+    print("yolox_iou:", {k: float(np.abs(v).mean()) for k, v in res.items()})
 
 
 def gold_encoder_layer():
@@ -412,11 +482,14 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     gold_step()
+    gold_onnx_layout()
     gold_tiny_step()
     gold_simota()
+    gold_simota_l1()
     gold_postprocess()
     gold_hungarian()
     gold_iou_v6()
+    gold_yolox_iou()
     gold_encoder_layer()
     gold_transformer()
     gold_pos_embed()

@@ -234,14 +234,22 @@ def simota_image(gt, gcls, bbox, obj_logit, cls_logit, anchors, num_classes):
                 matched_iou=(M * iou).sum(0)[fg_in], num_fg=int(fg_in.sum()))
 
 
-def yolox_losses(raw, labels, anchors, num_classes=80, return_assign=False):
+def l1_target(gt, stride, x_shifts, y_shifts, eps=1e-8):
+    """get_l1_target (yolox_head.py:443-448): gt [n,4] cxcywh in pixels, the matched anchors' stride / grid position"""
+    return torch.stack([gt[:, 0] / stride - x_shifts, gt[:, 1] / stride - y_shifts,
+                        torch.log(gt[:, 2] / stride + eps), torch.log(gt[:, 3] / stride + eps)], 1)
+
+
+def yolox_losses(raw, labels, anchors, num_classes=80, return_assign=False, use_l1=False):
     """get_losses (yolox_head.py:274-441) on raw head output [B,A,5+nc] and labels [B,L,5].
-    returns (total, 5*iou, obj, cls, l1=0.0, num_fg/num_gt) (+ per-image assignments)"""
+    returns (total, 5*iou, obj, cls, l1, num_fg/num_gt) (+ per-image assignments); l1 (head.use_l1, :389-427) is
+    nn.L1Loss(reduction="none") between the RAW regression outputs of the foreground anchors and get_l1_target,
+    summed / num_fg, and 0.0 when the switch is off"""
     out = decode(raw, anchors)
     bbox, obj, cls = out[..., :4], out[..., 4:5], out[..., 5:]
     nlabel = (labels.sum(dim=2) > 0).sum(dim=1)
     B, A = raw.shape[:2]
-    cls_t, reg_t, obj_t, fgs, assigns = [], [], [], [], []
+    cls_t, reg_t, obj_t, fgs, assigns, l1_t = [], [], [], [], [], []
     num_fg, num_gts = 0.0, 0.0
     for b in range(B):
         G = int(nlabel[b])
@@ -252,6 +260,7 @@ def yolox_losses(raw, labels, anchors, num_classes=80, return_assign=False):
             obj_t.append(raw.new_zeros((A, 1)))
             fgs.append(torch.zeros(A, dtype=torch.bool))
             assigns.append(None)
+            l1_t.append(raw.new_zeros((0, 4)))
             continue
         gt, gcls = labels[b, :G, 1:5], labels[b, :G, 0]
         a = simota_image(gt, gcls, bbox[b].detach(), obj[b, :, 0].detach(), cls[b].detach(), anchors, num_classes)
@@ -261,13 +270,18 @@ def yolox_losses(raw, labels, anchors, num_classes=80, return_assign=False):
         obj_t.append(a["fg"].unsqueeze(-1).to(raw.dtype))
         reg_t.append(gt[a["matched_gt"]])
         fgs.append(a["fg"])
+        if use_l1:
+            l1_t.append(l1_target(gt[a["matched_gt"]], anchors[a["fg"], 2], anchors[a["fg"], 0], anchors[a["fg"], 1]))
     cls_t, reg_t, obj_t, fg = torch.cat(cls_t, 0), torch.cat(reg_t, 0), torch.cat(obj_t, 0), torch.cat(fgs, 0)
     num_fg = max(num_fg, 1)
     l_iou = iou_loss(bbox.reshape(-1, 4)[fg], reg_t).sum() / num_fg
     l_obj = F.binary_cross_entropy_with_logits(obj.reshape(-1, 1), obj_t, reduction="none").sum() / num_fg
     l_cls = F.binary_cross_entropy_with_logits(cls.reshape(-1, num_classes)[fg], cls_t, reduction="none").sum() / num_fg
-    total = 5.0 * l_iou + l_obj + l_cls
-    res = (total, 5.0 * l_iou, l_obj, l_cls, 0.0, num_fg / max(num_gts, 1))
+    l_l1 = 0.0
+    if use_l1:
+        l_l1 = (raw[..., :4].reshape(-1, 4)[fg] - torch.cat(l1_t, 0)).abs().sum() / num_fg
+    total = 5.0 * l_iou + l_obj + l_cls + l_l1
+    res = (total, 5.0 * l_iou, l_obj, l_cls, l_l1, num_fg / max(num_gts, 1))
     return (res, assigns) if return_assign else res
 
 
@@ -451,12 +465,13 @@ def init_state_dict(depth=0.33, width=0.5, num_classes=80, seed=0):
     return sd
 
 
-def train_step_losses(sd, images, labels, depth=0.33, width=0.5, num_classes=80, quant=None, return_all=False):
+def train_step_losses(sd, images, labels, depth=0.33, width=0.5, num_classes=80, quant=None, return_all=False,
+                      use_l1=False):
     """forward + loss on CPU fp32; sd tensors may require grad"""
     net = Net(sd, depth, width, num_classes, training=True, quant=quant)
     raw, hw = net.forward_raw(images)
     anchors = make_anchors(hw)
     if return_all:
-        res, assigns = yolox_losses(raw, labels, anchors, num_classes, return_assign=True)
+        res, assigns = yolox_losses(raw, labels, anchors, num_classes, return_assign=True, use_l1=use_l1)
         return res, dict(raw=raw, hw=hw, anchors=anchors, assigns=assigns, taps=net.taps)
-    return yolox_losses(raw, labels, anchors, num_classes)
+    return yolox_losses(raw, labels, anchors, num_classes, use_l1=use_l1)

@@ -310,20 +310,25 @@ class Interp:
     def op_LOSS_FWD(self, c):
         s = c.desc
         preds, labels, anchors = self._loss_inputs(s)
-        res, assigns = O.yolox_losses(preds.clone(), labels, anchors, s.ncls, return_assign=True)
+        res, assigns = O.yolox_losses(preds.clone(), labels, anchors, s.ncls, return_assign=True,
+                                      use_l1=getattr(s, "use_l1", False))
         out = self.raw(s.ws["out"]).view(torch.float32)
         nfg = sum(a["num_fg"] for a in assigns if a is not None)
         ngt = int((labels.sum(2) > 0).sum())
-        out[:8] = torch.tensor([float(res[0]), float(res[1]), float(res[2]), float(res[3]), 0.0, float(res[5]),
+        out[:8] = torch.tensor([float(res[0]), float(res[1]), float(res[2]), float(res[3]), float(res[4]), float(res[5]),
                                 float(nfg), float(ngt)])
 
     def op_LOSS_BWD(self, c):
         s = c.desc
         preds, labels, anchors = self._loss_inputs(s)
         raw = preds.clone().requires_grad_(True)
-        res = O.yolox_losses(raw, labels, anchors, s.ncls)
-        gw = self.f32(c.p[1], 4)
-        (gw[0] * res[0] + gw[1] * res[1] + gw[2] * res[2] + gw[3] * res[3]).backward()
+        l1 = getattr(s, "use_l1", False)
+        res = O.yolox_losses(raw, labels, anchors, s.ncls, use_l1=l1)
+        gw = self.f32(c.p[1], 5 if l1 else 4)
+        tot = gw[0] * res[0] + gw[1] * res[1] + gw[2] * res[2] + gw[3] * res[3]
+        if l1:
+            tot = tot + gw[4] * res[4]
+        tot.backward()
         self.f32(c.p[2], raw.numel()).copy_(raw.grad.reshape(-1))
 
     def op_SPLIT_DPREDS(self, c):

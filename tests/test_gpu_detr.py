@@ -373,3 +373,48 @@ def test_detr_module_against_reference_golden(golden_dir):
     for k in [f[2:] for f in g.files if f.startswith("g:")]:
         r = rel(params[k].grad.float().cpu().numpy(), g["g:" + k])
         assert r < 1.5e-1, (k, r)   # bf16 storage through the 4 transformer layers (see the transformer test)
+
+
+# ------------------------------------------------------------------------------------------ YOLOX IOUloss / pairwise IoU
+@pytest.mark.parametrize("loss_type", ["iou", "giou"])
+def test_yolox_iou_loss_module_against_reference_golden(golden_dir, loss_type):
+    """IOUloss as a module (utils/boxes.py:125-168) against the reference class + autograd, including identical boxes
+    (every max / min a tie: ATen splits the gradient evenly) and disjoint pairs"""
+    import sys
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle")
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    from gen_golden_inputs import synth_box_pairs
+    from yolov7_d2_amd.modeling import IOUloss
+    g = np.load(os.path.join(golden_dir, "yolox_iou.npz"))
+    pred, tgt = synth_box_pairs(257, 52)
+    tgt[200:210] = pred[200:210]
+    tgt[210:220, :2] = pred[210:220, :2]
+    p = pred.to(DEV).requires_grad_(True)
+    loss = IOUloss(reduction="none", loss_type=loss_type)(p, tgt.to(DEV))
+    loss.sum().backward()
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), g[loss_type + "_loss"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(p.grad.cpu().numpy(), g[loss_type + "_grad"], rtol=2e-3, atol=2e-7)
+    assert float(IOUloss("mean", loss_type)(p, tgt.to(DEV))) == pytest.approx(float(g[loss_type + "_loss"].mean()), rel=1e-5)
+    with pytest.raises(ValueError):
+        IOUloss(loss_type="ciou")
+
+
+def test_pairwise_bbox_iou_against_reference_golden(golden_dir):
+    import sys
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle")
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    from gen_golden_inputs import synth_box_pairs
+    from yolov7_d2_amd.modeling import pairwise_bbox_iou, bboxes_iou
+    g = np.load(os.path.join(golden_dir, "yolox_iou.npz"))
+    a, b = synth_box_pairs(37, 53)[0], synth_box_pairs(61, 54)[1]
+    ax = torch.cat([a[:, :2] - a[:, 2:] / 2, a[:, :2] + a[:, 2:] / 2], 1)
+    bx = torch.cat([b[:, :2] - b[:, 2:] / 2, b[:, :2] + b[:, 2:] / 2], 1)
+    np.testing.assert_allclose(pairwise_bbox_iou(a.to(DEV), b.to(DEV), "xywh").cpu().numpy(), g["pair_xywh"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(pairwise_bbox_iou(ax.to(DEV), bx.to(DEV), "xyxy").cpu().numpy(), g["pair_xyxy"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(bboxes_iou(ax.to(DEV), bx.to(DEV), True).cpu().numpy(), g["bboxes_iou_xyxy"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(bboxes_iou(a.to(DEV), b.to(DEV), False).cpu().numpy(), g["bboxes_iou_xywh"], rtol=1e-5, atol=1e-7)
+    assert pairwise_bbox_iou(a[:0].to(DEV), b.to(DEV)).shape == (0, 61)
+    big = pairwise_bbox_iou(synth_box_pairs(8400, 55)[0].to(DEV), synth_box_pairs(120, 56)[1].to(DEV))   # SimOTA-sized
+    assert big.shape == (8400, 120) and bool(((big >= 0) & (big <= 1)).all())

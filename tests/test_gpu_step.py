@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _loss_call(raw, labels, anchors, gw=(1, 1, 1, 1), gmax=None):
+def _loss_call(raw, labels, anchors, gw=(1, 1, 1, 1), gmax=None, use_l1=False):
     B, A, nch = raw.shape
     ML = labels.shape[1]
     gmax = ML if gmax is None else gmax
@@ -26,13 +26,15 @@ def _loss_call(raw, labels, anchors, gw=(1, 1, 1, 1), gmax=None):
     ws = dict(cost=t(B, gmax, A), iou=t(B, gmax, A), match=t(B, gmax, A, dt=torch.uint8), ngt=t(B, dt=torch.int32),
               fg=t(B, A, dt=torch.uint8), matched_gt=t(B, A, dt=torch.int32), matched_iou=t(B, A),
               partial=t(B * ((A + 255) // 256), 4), out=t(8), dpreds=t(B, A, nch),
-              gw=torch.tensor(gw, dtype=torch.float32, device=DEV))
+              partial_l1=t(B * ((A + 255) // 256)), gw=torch.tensor(gw, dtype=torch.float32, device=DEV))
     rd, ld, ad = raw.to(DEV).contiguous(), labels.to(DEV).contiguous(), anchors.to(DEV).contiguous()
     d = L.mi_yolox_loss_desc()
     d.preds, d.labels, d.anchors = rd.data_ptr(), ld.data_ptr(), ad.data_ptr()
     d.B, d.A, d.ncls, d.max_labels, d.gmax = B, A, nch - 5, ML, gmax
     for k in ("cost", "iou", "match", "ngt", "fg", "matched_gt", "matched_iou", "partial", "out"):
         setattr(d, k, ws[k].data_ptr())
+    if use_l1:
+        d.use_l1, d.partial_l1 = 1, ws["partial_l1"].data_ptr()
     L.check(L.lib().mi_yolox_loss_fwd(C.byref(d), L.stream_ptr()), "loss_fwd")
     L.check(L.lib().mi_yolox_loss_bwd(C.byref(d), ws["gw"].data_ptr(), ws["dpreds"].data_ptr(), L.stream_ptr()), "loss_bwd")
     torch.cuda.synchronize()
@@ -56,6 +58,25 @@ def test_simota_loss_against_reference_golden(golden_dir):
         np.testing.assert_allclose(ws["matched_iou"][b][fg].numpy(), g[f"matched_iou{b}"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(ws["out"][:6].numpy(), g["losses"], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(ws["dpreds"].numpy(), g["draw"], rtol=2e-4, atol=1e-6)
+
+
+def test_l1_loss_against_reference_golden(golden_dir):
+    """head.use_l1 (get_l1_target + L1 on the raw regression outputs, yolox_head.py:389-448) against the reference head
+    run with the switch on: the six returned values and d(total + iou + conf + cls + l1)/d(raw)"""
+    g = np.load(os.path.join(golden_dir, "simota_160_l1.npz"))
+    B, H, W = 3, 160, 160
+    _, labels = O.synth_batch(B, H, W, seed=21, max_gt=12, min_gt=6)
+    labels[1] = 0.0
+    hw = [(H // s, W // s) for s in (8, 16, 32)]
+    raw, anchors = O.synth_raw(B, hw, 22, labels=labels)
+    ws = _loss_call(raw, labels, anchors, gw=(1, 1, 1, 1, 1), use_l1=True)
+    np.testing.assert_allclose(ws["out"][:6].numpy(), g["losses"], rtol=1e-5, atol=1e-5)
+    assert float(ws["out"][4]) > 0.5
+    np.testing.assert_allclose(ws["dpreds"].numpy(), g["draw"], rtol=2e-4, atol=1e-6)
+    # the switch off leaves the l1 slot at 0 and the total without it
+    ws0 = _loss_call(raw, labels, anchors)
+    assert float(ws0["out"][4]) == 0.0
+    np.testing.assert_allclose(float(ws0["out"][0]) + float(ws["out"][4]), float(ws["out"][0]), rtol=1e-6)
 
 
 def test_simota_full_size_properties():
@@ -303,6 +324,48 @@ def test_eval_forward_and_instances(golden_dir):
         res = model(_batched_inputs(imgs, labels))
     assert len(res) == 2 and all("instances" in r for r in res)
     assert all(len(r["instances"]) == 0 for r in res)   # random-init net: nothing above conf 0.001
+
+
+def test_onnx_export_layout_and_l1_switch(golden_dir):
+    """(a13) model.onnx_export: forward(NHWC tensor) -> decode_outputs' export layout (xy, wh, conf, argmax class, probs)
+    against the reference head run with onnx_export = True; the class-index column is exactly argmax of the probability
+    columns; onnx_vis returns the post-processed detections.  (a15) update_iter() past DISABLE_AT_ITER switches the l1
+    loss on: the loss dict gains l1_loss and the step still back-propagates."""
+    g = np.load(os.path.join(golden_dir, "yolox_s_onnx_layout_64x96.npz"))["out"]
+    model, sd = _gpu_model()
+    model.eval()
+    imgs, labels = O.synth_batch(2, 64, 96, seed=11, max_gt=4)
+    model.onnx_export = True
+    with torch.no_grad():
+        out = model(imgs.permute(0, 2, 3, 1).contiguous().to(DEV))
+    assert tuple(out.shape) == (2, 126, 86)
+    o = out.cpu().numpy()
+    np.testing.assert_allclose(o[..., :4], g[..., :4], rtol=5e-2, atol=1.0)
+    np.testing.assert_allclose(o[..., 4], g[..., 4], rtol=5e-2, atol=5e-3)
+    np.testing.assert_allclose(o[..., 6:], g[..., 6:], rtol=5e-2, atol=5e-3)
+    assert np.array_equal(o[..., 5], o[..., 6:].argmax(-1).astype(np.float32))      # integer column: exact on our probs
+    assert (o[..., 5] == g[..., 5]).mean() > 0.5     # random-init class scores are near ties: most, not all, agree
+    model.onnx_vis = True
+    with torch.no_grad():
+        det = model(imgs.permute(0, 2, 3, 1).contiguous().to(DEV))
+    assert isinstance(det, list) and len(det) == 2
+    model.onnx_export = model.onnx_vis = False
+    with pytest.raises(RuntimeError):
+        model.train(); model.onnx_export = True; model(_batched_inputs(imgs, labels))
+    model.onnx_export = False
+    # l1 switch
+    assert not model.use_l1
+    out0 = model(_batched_inputs(imgs, labels))
+    assert "l1_loss" not in out0
+    model.update_iter(model.enable_l1_loss_at + 1)
+    out1 = model(_batched_inputs(imgs, labels))
+    assert model.use_l1 and model.head.use_l1 and set(out1) == {"total_loss", "iou_loss", "conf_loss", "cls_loss", "l1_loss"}
+    assert float(out1["l1_loss"]) > 0
+    np.testing.assert_allclose(float(out1["total_loss"]) - float(out1["l1_loss"]),
+                               float(out1["iou_loss"]) + float(out1["conf_loss"]) + float(out1["cls_loss"]), rtol=1e-4)
+    sum(out1.values()).backward()
+    gn = model.params.grad.norm()
+    assert torch.isfinite(gn) and float(gn) > 0
 
 
 def test_graph_replay_equals_eager():

@@ -70,6 +70,39 @@ def test_plan_step_matches_oracle(monkeypatch, fuse_bn_bwd):
     assert int(model.state_dict()["head.stems.2.bn.num_batches_tracked"]) == 1
 
 
+def test_plan_step_with_l1_loss_matches_oracle():
+    """the step plan with head.use_l1 on (what YOLOX.forward builds once update_iter() has passed
+    INPUT.MOSAIC_AND_MIXUP.DISABLE_AT_ITER): five losses and every parameter gradient, detectron2 summing the loss dict
+    including l1_loss"""
+    model, sd = _model(seed=2)
+    B, H, W = 2, 64, 96
+    imgs, labels = O.synth_batch(B, H, W, seed=9, max_gt=4)
+    ps = _PlanState(model, B, H, W, True, materialize=False, use_l1=True)
+    b = ps.builder
+    ps.image.copy_(imgs)
+    ps.labels.copy_(labels)
+    it = Interp(b, torch.float32)
+    it.run(b.prologue + b.fwd)
+    out = it.raw(ps.loss["out"]).view(torch.float32)[:8].clone()
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    res = O.train_step_losses(sd, imgs, labels, use_l1=True)
+    assert float(res[4]) > 0.1
+    np.testing.assert_allclose(out[:5].numpy(), np.array([float(x) for x in res[:5]]), rtol=1e-4, atol=1e-4)
+    it.raw(ps.loss["gw"]).view(torch.float32)[:5] = 1.0
+    it.run(b.bwd)
+    (res[0] + res[1] + res[2] + res[3] + res[4]).backward()
+    bad = []
+    for name, p in model.named_parameters():
+        g = model.params.grad_of(p).detach().float()
+        r = sd[name].grad
+        rel = float((g - r).norm()) / (float(r.norm()) + 1e-6)
+        if rel > 2e-3:
+            bad.append((name, rel))
+    assert not bad, bad[:10]
+
+
 def test_eval_plan_matches_oracle():
     model, sd = _model(seed=3)
     model.eval()

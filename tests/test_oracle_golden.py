@@ -61,6 +61,21 @@ def test_config0_yolox_tiny_416_cpu_step(golden_dir):
     np.testing.assert_allclose(ev[:, ::7].numpy(), g["eval_out_stride"], rtol=1e-5, atol=1e-5)
 
 
+def test_l1_loss_oracle_against_reference(golden_dir):
+    """oracle restatement of head.use_l1 (yolox_head.py:389-448) against the reference head run with the switch on"""
+    g = np.load(os.path.join(golden_dir, "simota_160_l1.npz"))
+    B, H, W = 3, 160, 160
+    _, labels = O.synth_batch(B, H, W, seed=21, max_gt=12, min_gt=6)
+    labels[1] = 0.0
+    hw = [(H // s, W // s) for s in (8, 16, 32)]
+    raw, anchors = O.synth_raw(B, hw, 22, labels=labels)
+    raw.requires_grad_(True)
+    res = O.yolox_losses(raw, labels, anchors, 80, use_l1=True)
+    np.testing.assert_allclose(np.array([float(x) for x in res]), g["losses"], rtol=1e-6)
+    (res[0] + res[1] + res[2] + res[3] + res[4]).backward()
+    np.testing.assert_allclose(raw.grad.numpy(), g["draw"], rtol=1e-5, atol=1e-7)
+
+
 def test_simota_assignment_bit_exact(golden_dir):
     g = np.load(os.path.join(golden_dir, "simota_160.npz"))
     B, H, W = 3, 160, 160

@@ -90,7 +90,7 @@ class mi_yolox_loss_desc(C.Structure):
         ("gmax", C.c_int32),
         ("cost", C.c_void_p), ("iou", C.c_void_p), ("match", C.c_void_p), ("ngt", C.c_void_p),
         ("fg", C.c_void_p), ("matched_gt", C.c_void_p), ("matched_iou", C.c_void_p),
-        ("partial", C.c_void_p), ("out", C.c_void_p),
+        ("partial", C.c_void_p), ("out", C.c_void_p), ("use_l1", C.c_int32), ("rsv_", C.c_int32), ("partial_l1", C.c_void_p),
     ]
 
 
@@ -184,6 +184,9 @@ _PROTOS = {
     "mi_bn_act_bwd_fused": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _i, _vp, _i,
                                       _i, _i64, _i, _i, _vp, _vp]),
     "mi_bn_fused_set_capacity": (C.c_int, [_i]),
+    "mi_yolox_onnx_layout": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
+    "mi_yolox_iou_loss": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "mi_pairwise_bbox_iou": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "mi_bn_group_plan": (C.c_int, [_i, C.POINTER(mi_bn_job), _i, _vp, _i64, C.POINTER(mi_bn_group)]),
     "mi_bn_group_run": (C.c_int, [C.POINTER(mi_bn_group), _vp, _vp]),
     "mi_detr_set_loss_fwd": (C.c_int, [C.POINTER(mi_detr_loss_desc), _vp]),

@@ -29,7 +29,17 @@ struct LossK {
   float* matched_iou;
   float* partial;
   float* out;
+  int use_l1;          // get_l1_target + nn.L1Loss on the raw regression outputs (yolox_head.py:389-427, 443-448)
+  float* partial_l1;   // [nblk] block sums of the L1 term
 };
+
+// l1 target of one foreground anchor (yolox_head.py:443-448; eps = 1e-8)
+__device__ __forceinline__ void l1_target(const float* lab, float gx_, float gy_, float st, float* t) {
+  t[0] = lab[1] / st - gx_;
+  t[1] = lab[2] / st - gy_;
+  t[2] = logf(lab[3] / st + 1e-8f);
+  t[3] = logf(lab[4] / st + 1e-8f);
+}
 
 __device__ __forceinline__ float clamp_log(float v) { return fmaxf(logf(v), -100.0f); }
 __device__ __forceinline__ float sigmoid_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -288,11 +298,11 @@ __device__ __forceinline__ float bce_logits(float x, float t) {
 
 // ---- kernel 3: resolve conflicts, write assignment, accumulate loss sums
 __global__ __launch_bounds__(256) void simota_resolve_loss_kernel(const LossK p) {
-  __shared__ float sred[4][4];
+  __shared__ float sred[4][5];
   const int b = blockIdx.y;
   const int a = blockIdx.x * 256 + threadIdx.x;
   const int G = p.ngt[b];
-  float l_iou = 0.f, l_obj = 0.f, l_cls = 0.f, nfg = 0.f;
+  float l_iou = 0.f, l_obj = 0.f, l_cls = 0.f, nfg = 0.f, l_l1 = 0.f;
   if (a < p.A) {
     const size_t rs = (size_t)p.A;
     const uint8_t* matchp = p.match + (size_t)b * p.gmax * rs + a;
@@ -331,27 +341,41 @@ __global__ __launch_bounds__(256) void simota_resolve_loss_kernel(const LossK p)
       l_iou = 1.f - iou * iou;
       const int gc = (int)lab[0];
       for (int c = 0; c < p.ncls; ++c) l_cls += bce_logits(pr[5 + c], c == gc ? miou : 0.f);
+      if (p.use_l1) {
+        float t[4];
+        l1_target(lab, p.anchors[a * 3 + 0], p.anchors[a * 3 + 1], p.anchors[a * 3 + 2], t);
+        l_l1 = fabsf(pr[0] - t[0]) + fabsf(pr[1] - t[1]) + fabsf(pr[2] - t[2]) + fabsf(pr[3] - t[3]);
+      }
     }
   }
   l_iou = wave_sum(l_iou); l_obj = wave_sum(l_obj); l_cls = wave_sum(l_cls); nfg = wave_sum(nfg);
+  if (p.use_l1) l_l1 = wave_sum(l_l1);
   const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { sred[wave][0] = l_iou; sred[wave][1] = l_obj; sred[wave][2] = l_cls; sred[wave][3] = nfg; }
+  if ((threadIdx.x & 63) == 0) {
+    sred[wave][0] = l_iou; sred[wave][1] = l_obj; sred[wave][2] = l_cls; sred[wave][3] = nfg; sred[wave][4] = l_l1;
+  }
   __syncthreads();
   if (threadIdx.x < 4) {
     const float v = sred[0][threadIdx.x] + sred[1][threadIdx.x] + sred[2][threadIdx.x] + sred[3][threadIdx.x];
     p.partial[((size_t)b * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = v;
   }
+  if (threadIdx.x == 4 && p.use_l1)
+    p.partial_l1[(size_t)b * gridDim.x + blockIdx.x] = sred[0][4] + sred[1][4] + sred[2][4] + sred[3][4];
 }
 
-__global__ __launch_bounds__(64) void loss_final_kernel(const float* partial, int nblk, const int32_t* ngt, int B,
-                                                        float* out) {
+__global__ __launch_bounds__(64) void loss_final_kernel(const float* partial, const float* partial_l1, int nblk,
+                                                        const int32_t* ngt, int B, float* out) {
   const int lane = threadIdx.x;
   double s[4] = {0, 0, 0, 0};
-  for (int t = lane; t < nblk; t += 64)
+  double s_l1 = 0;
+  for (int t = lane; t < nblk; t += 64) {
     for (int q = 0; q < 4; ++q) s[q] += (double)partial[(size_t)t * 4 + q];
+    if (partial_l1) s_l1 += (double)partial_l1[t];
+  }
   double g = 0;
   for (int b = lane; b < B; b += 64) g += (double)ngt[b];
   for (int q = 0; q < 4; ++q) s[q] = wave_sum_d(s[q]);
+  s_l1 = wave_sum_d(s_l1);
   g = wave_sum_d(g);
   if (lane == 0) {
     const double nfg = s[3];
@@ -360,8 +384,9 @@ __global__ __launch_bounds__(64) void loss_final_kernel(const float* partial, in
     out[1] = 5.0f * li;
     out[2] = lo;
     out[3] = lc;
-    out[0] = 5.0f * li + lo + lc;
-    out[4] = 0.f;
+    const float l1 = (float)(s_l1 / N);   // 0 unless use_l1
+    out[0] = 5.0f * li + lo + lc + l1;
+    out[4] = l1;
     out[5] = (float)(N / (g > 1.0 ? g : 1.0));
     out[6] = (float)nfg;
     out[7] = (float)g;
@@ -378,6 +403,8 @@ static int loss_fill(const mi_yolox_loss_desc* d, LossK* k) {
   k->nch = 5 + d->ncls;
   k->cost = d->cost; k->iou = d->iou; k->match = d->match; k->ngt = d->ngt; k->fg = d->fg;
   k->matched_gt = d->matched_gt; k->matched_iou = d->matched_iou; k->partial = d->partial; k->out = d->out;
+  k->use_l1 = d->use_l1 != 0; k->partial_l1 = d->partial_l1;
+  MI_REQUIRE(!k->use_l1 || d->partial_l1, "yolox_loss: use_l1 needs partial_l1");
   return MI_OK;
 }
 
@@ -398,7 +425,8 @@ extern "C" int mi_yolox_loss_fwd(const mi_yolox_loss_desc* d, mi_stream_t st) {
   MI_CHECK_LAUNCH("simota_dynk");
   hipLaunchKernelGGL(simota_resolve_loss_kernel, dim3(nb, d->B), dim3(256), 0, s, k);
   MI_CHECK_LAUNCH("simota_resolve_loss");
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, d->partial, nb * d->B, d->ngt, d->B, d->out);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, d->partial, k.use_l1 ? d->partial_l1 : nullptr,
+                     nb * d->B, d->ngt, d->B, d->out);
   MI_CHECK_LAUNCH("loss_final");
   return MI_OK;
 }
@@ -413,6 +441,7 @@ __global__ __launch_bounds__(256) void yolox_loss_bwd_kernel(const LossK p, cons
   const float w_iou = 5.0f * (gw[0] + gw[1]) / N;
   const float w_obj = (gw[0] + gw[2]) / N;
   const float w_cls = (gw[0] + gw[3]) / N;
+  const float w_l1 = p.use_l1 ? (gw[0] + gw[4]) / N : 0.f;   // gw has a fifth entry (upstream of l1_loss) iff use_l1
   const size_t o = (size_t)b * p.A + a;
   const float* pr = p.preds + o * p.nch;
   float* dp = dpreds + o * p.nch;
@@ -456,6 +485,15 @@ __global__ __launch_bounds__(256) void yolox_loss_bwd_kernel(const LossK p, cons
   dp[1] = w_iou * dpy * st;
   dp[2] = w_iou * dpw * pb.w;
   dp[3] = w_iou * dph * pb.h;
+  if (p.use_l1) {   // d|x - t| = sign(x - t) (0 at x == t, as ATen's l1 backward)
+    float t[4];
+    l1_target(lab, p.anchors[a * 3 + 0], p.anchors[a * 3 + 1], st, t);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float e = pr[q] - t[q];
+      dp[q] += w_l1 * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
+    }
+  }
 }
 
 extern "C" int mi_yolox_loss_bwd(const mi_yolox_loss_desc* d, const float* gw, float* dpreds, mi_stream_t st) {
@@ -637,5 +675,34 @@ extern "C" int mi_yolox_decode(float* preds, const float* anchors, int B, int A,
   hipLaunchKernelGGL(yolox_decode_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)st, preds,
                      anchors, B, A, ncls + 5);
   MI_CHECK_LAUNCH("decode");
+  return MI_OK;
+}
+
+
+// ---- decode_outputs, ONNX-export layout (yolox_head.py:263-269): from the DECODED predictions [B][A][5+ncls]
+// (mi_yolox_decode: boxes in pixels, sigmoid on obj / cls) to [B][A][6+ncls] = (xy, wh, conf, argmax(prob) as float, prob);
+// torch.argmax: the first maximal class
+__global__ __launch_bounds__(256) void yolox_onnx_layout_kernel(const float* __restrict__ dec, float* __restrict__ out,
+                                                                int64_t rows, int ncls) {
+  const int64_t r = blockIdx.x * 256LL + threadIdx.x;
+  if (r >= rows) return;
+  const float* p = dec + r * (5 + ncls);
+  float* o = out + r * (6 + ncls);
+  for (int c = 0; c < 5; ++c) o[c] = p[c];
+  int best = 0;
+  float bv = p[5];
+  for (int c = 0; c < ncls; ++c) {
+    const float v = p[5 + c];
+    o[6 + c] = v;
+    if (v > bv) { bv = v; best = c; }
+  }
+  o[5] = (float)best;
+}
+extern "C" int mi_yolox_onnx_layout(const float* decoded, float* out, int B, int A, int ncls, mi_stream_t st) {
+  MI_REQUIRE(decoded && out && B > 0 && A > 0 && ncls > 0, "onnx_layout: args");
+  const int64_t rows = (int64_t)B * A;
+  hipLaunchKernelGGL(yolox_onnx_layout_kernel, dim3((int)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)st, decoded, out,
+                     rows, ncls);
+  MI_CHECK_LAUNCH("onnx_layout");
   return MI_OK;
 }

@@ -5,7 +5,7 @@ from .yolox_net import CSPDarknet, YOLOPAFPN, YOLOXHead, build_cspdarknetx_backb
 from .detr_matcher import HungarianMatcher
 from .detr_criterion import SetCriterion
 from .attention import mha_core
-from .iou_loss import IOUlossV6
+from .iou_loss import IOUlossV6, IOUloss, pairwise_bbox_iou, bboxes_iou
 from .transformer import (MultiheadAttention, TransformerEncoderLayer, TransformerDecoderLayer, TransformerEncoder,
                           TransformerDecoder, Transformer)
 from .position_encoding import PositionEmbeddingSine

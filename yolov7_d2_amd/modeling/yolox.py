@@ -29,8 +29,9 @@ def xyxy_to_cxcywh(b):
 class _PlanState:
     """one compiled step for a fixed (B, H, W): plan + persistent I/O tensors"""
 
-    def __init__(self, model, B, H, W, training, materialize=True, input_u8=False):
+    def __init__(self, model, B, H, W, training, materialize=True, input_u8=False, use_l1=False):
         dev = model.device
+        self.use_l1 = bool(use_l1)
         self.B, self.H, self.W, self.training = B, H, W, training
         # input_u8: the plan reads the uint8 image of the data loader directly (the .type(torch.float) of
         # yolox.py:96-99 is fused into the Focus packer); float32 is the reference-shaped default
@@ -52,7 +53,7 @@ class _PlanState:
         model.head.emit(ctx, fpn, self.preds_buf, self.A)
         if training:
             self.loss = b.yolox_loss(self.preds_buf, self.labels, self.anchors, B, self.A, model.num_classes,
-                                     model.max_boxes_num, model.max_boxes_num)
+                                     model.max_boxes_num, model.max_boxes_num, use_l1=use_l1)
         else:
             b.emit("DECODE", i=[B, self.A, model.num_classes], p=[self.preds_buf, self.anchors], tag="decode")
         self.builder = b
@@ -66,7 +67,8 @@ class _PlanState:
         return self.plan.buf_view(self.loss["out"], torch.float32, 8)
 
     def gw(self):
-        return self.plan.buf_view(self.loss["gw"], torch.float32, 4)
+        """upstream gradients of (total, iou, conf, cls[, l1]) read by the loss backward"""
+        return self.plan.buf_view(self.loss["gw"], torch.float32, 5 if self.use_l1 else 4)
 
 
 class _YoloxTrainFn(torch.autograd.Function):
@@ -83,7 +85,7 @@ class _YoloxTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         ps, model = ctx.ps, ctx.model
-        ps.gw().copy_(g[:4].to(torch.float32))
+        ps.gw().copy_(g[:5 if ps.use_l1 else 4].to(torch.float32))
         ps.plan.run("bwd")
         # The kernels have written every parameter gradient into the flat arena.  Zero-copy hand-over: a parameter
         # whose .grad is None (optimizer.zero_grad(set_to_none=True), what detectron2's trainer does each iteration) or
@@ -113,7 +115,10 @@ class YOLOX(nn.Module):
         self.nms_threshold = cfg.MODEL.YOLO.NMS_THRESHOLD
         self.nms_type = cfg.MODEL.NMS_TYPE
         self.loss_type = cfg.MODEL.YOLO.LOSS_TYPE
-        self.use_l1 = False  # never enabled by the reference either (update_iter has no caller)
+        # l1 loss on the raw regression outputs "at last 15 epochs" (yolox.py:47-55): switched on in forward() once
+        # self.iter (update_iter) passes INPUT.MOSAIC_AND_MIXUP.DISABLE_AT_ITER; nothing in the reference tree calls
+        # update_iter, a trainer hook that does gets the same behaviour here
+        self.use_l1 = False
         self.depth_mul = cfg.MODEL.YOLO.DEPTH_MUL
         self.width_mul = cfg.MODEL.YOLO.WIDTH_MUL
         self.iter = 0
@@ -127,7 +132,8 @@ class YOLOX(nn.Module):
         self.neck = YOLOPAFPN(depth=self.depth_mul, width=self.width_mul, in_features=self.in_features)
         self.head = YOLOXHead(self.num_classes, width=self.width_mul)
         self.padded_value = cfg.MODEL.PADDED_VALUE
-        self.onnx_export = False
+        self.onnx_export = False   # yolox.py:79-80: forward(tensor [B,H,W,3]) -> decoded predictions in the export layout
+        self.onnx_vis = False      # ... or, with onnx_vis, the post-processed detections
         self.apply(self._init_model)
         self.head.initialize_biases(1e-2)
         self.params = None
@@ -162,11 +168,12 @@ class YOLOX(nn.Module):
 
     def plan_for(self, B, H, W, training, input_u8=False):
         self.ensure_params()
-        key = (B, H, W, bool(training)) + (("u8",) if input_u8 else ())
+        l1 = bool(training and self.use_l1)
+        key = (B, H, W, bool(training)) + (("u8",) if input_u8 else ()) + (("l1",) if l1 else ())
         ps = self._plans.get(key)
         if ps is None:
             assert H % 32 == 0 and W % 32 == 0, (H, W)
-            ps = _PlanState(self, B, H, W, training, input_u8=input_u8)
+            ps = _PlanState(self, B, H, W, training, input_u8=input_u8, use_l1=l1)
             self._plans[key] = ps
         return ps
 
@@ -188,15 +195,47 @@ class YOLOX(nn.Module):
                 labels[i, : t.shape[0]] = t
         return images, labels, images.image_sizes
 
+    def preprocess_input(self, x):
+        """yolox.py:164-170 (export path): NHWC image tensor -> NCHW, no normalisation"""
+        return x.permute(0, 3, 1, 2)
+
+    def _forward_export(self, batched_inputs):
+        """yolox.py:172-178, 211-224: the graph the reference hands to torch.onnx.export, run on the HIP path"""
+        assert isinstance(batched_inputs, (torch.Tensor, list)), "onnx export, batched_inputs only needs image tensor"
+        x = self.preprocess_input(batched_inputs).to(self.device).float().contiguous()
+        B, _, H, W = x.shape
+        ps = self.plan_for(B, H, W, False)
+        ps.image.copy_(x)
+        ps.plan.run("fwd")
+        dec = ps.preds()
+        if self.onnx_vis:
+            return postprocess(dec.clone(), self.num_classes, self.conf_threshold, self.nms_threshold)
+        out = torch.empty(B, ps.A, 6 + self.num_classes, dtype=torch.float32, device=x.device)
+        L.check(L.lib().mi_yolox_onnx_layout(dec.data_ptr(), out.data_ptr(), B, ps.A, self.num_classes, L.stream_ptr()),
+                "mi_yolox_onnx_layout")
+        return out
+
     def forward(self, batched_inputs):
         self.ensure_params()   # raises MI355Error when there is no HIP device: no CPU fallback
+        if self.onnx_export:
+            if self.training:
+                raise RuntimeError("YOLOX.onnx_export is an inference mode (the reference's export.py calls model.eval())")
+            return self._forward_export(batched_inputs)
         images, labels, image_ori_sizes = self.preprocess_image(batched_inputs, self.training)
         x = images.tensor
         B, _, H, W = x.shape
+        if self.training and self.iter > self.enable_l1_loss_at and not self.use_l1:
+            # yolox.py:105-121.  The reference broadcasts rank 0's flag; every rank evaluates the same condition on the
+            # same iteration counter, so the flag is identical without the collective.
+            self.use_l1 = True
+            self.head.use_l1 = True
         if self.training:
             ps = self.plan_for(B, H, W, True)
             out = _YoloxTrainFn.apply(ps, self, x, labels.to(x.device), *[p for _, p in self.named_parameters()])
-            return {"total_loss": out[0], "iou_loss": out[1], "conf_loss": out[2], "cls_loss": out[3]}
+            losses = {"total_loss": out[0], "iou_loss": out[1], "conf_loss": out[2], "cls_loss": out[3]}
+            if self.use_l1:
+                losses["l1_loss"] = out[4]
+            return losses
         ps = self.plan_for(B, H, W, False)
         ps.image.copy_(x)
         ps.plan.run("fwd")

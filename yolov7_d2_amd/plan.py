@@ -590,7 +590,7 @@ class PlanBuilder:
 
         self.on_backward(bwd)
 
-    def yolox_loss(self, preds, labels_t, anchors_t, B, A, ncls, max_labels, gmax):
+    def yolox_loss(self, preds, labels_t, anchors_t, B, A, ncls, max_labels, gmax, use_l1=False):
         nch = 5 + ncls
         nb = (A + 255) // 256
         ws = dict(
@@ -598,10 +598,11 @@ class PlanBuilder:
             match=self.small("loss.match", B * gmax * A), ngt=self.small("loss.ngt", B * 4),
             fg=self.small("loss.fg", B * A), matched_gt=self.small("loss.mgt", B * A * 4),
             matched_iou=self.small("loss.miou", B * A * 4), partial=self.small("loss.partial", nb * B * 4 * 4),
-            out=self.small("loss.out", 8 * 4), gw=self.small("loss.gw", 4 * 4),
+            out=self.small("loss.out", 8 * 4), gw=self.small("loss.gw", 5 * 4),
+            partial_l1=self.small("loss.partial_l1", nb * B * 4),
             dpreds=self.small("loss.dpreds", B * A * nch * 4) if self.training else None)
         spec = ConvSpec(kind="loss", preds=_Ptr(preds), labels=_Ptr(labels_t), anchors=_Ptr(anchors_t), B=B, A=A,
-                        ncls=ncls, max_labels=max_labels, gmax=gmax, ws=ws)
+                        ncls=ncls, max_labels=max_labels, gmax=gmax, ws=ws, use_l1=bool(use_l1))
         self.loss = ws
         self.loss["spec"] = spec
         self.emit("LOSS_FWD", desc=spec, tag="loss")
@@ -907,8 +908,9 @@ class Plan:
             d = L.mi_yolox_loss_desc()
             d.preds, d.labels, d.anchors = spec.preds.resolve(), spec.labels.resolve(), spec.anchors.resolve()
             d.B, d.A, d.ncls, d.max_labels, d.gmax = spec.B, spec.A, spec.ncls, spec.max_labels, spec.gmax
-            for k in ("cost", "iou", "match", "ngt", "fg", "matched_gt", "matched_iou", "partial", "out"):
+            for k in ("cost", "iou", "match", "ngt", "fg", "matched_gt", "matched_iou", "partial", "out", "partial_l1"):
                 setattr(d, k, spec.ws[k].ptr)
+            d.use_l1 = int(getattr(spec, "use_l1", False))
         self.descs.append(d)
         return d
 
