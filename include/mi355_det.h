@@ -175,6 +175,22 @@ typedef struct mi_pack_job {
 int mi_pack_jobs_layout(mi_pack_job* jobs_host, int njobs);
 int mi_pack_conv_weights_batch(const mi_pack_job* jobs_dev, int njobs, int total_blocks, mi_stream_t s);
 
+/* ---- depthwise 3x3 convolution ------------------------------------------------
+ * the `dconv` of DWConv (backbone/layers/wrappers.py:86-102: BaseConv(C, C, ksize, stride, groups=C); the reference
+ * builds it with ksize 3 everywhere, darknetx.py:113-160): NHWC bf16, pad 1, stride 1 or 2, C % 8 == 0.
+ * w: the fp32 parameter tensor [C][1][3][3] (rounded to bf16 in the kernel like every conv operand).
+ * fwd: y = dwconv(x); stats_acc (may be NULL): fp64 [nslots][rup(C,32)][2] (sum, sumsq) accumulators of the following
+ *      BatchNorm, added to atomically exactly as the dense conv's epilogue does (caller zeroes them once per step).
+ * dgrad: dx (+)= dwconv^T(dy).  wgrad: dw[C][1][3][3] fp32 = correlation(x, dy), overwritten, deterministic
+ *      (block partials in ws, mi_dwconv3x3_wgrad_ws_bytes(C) bytes, summed in a fixed order). */
+int mi_dwconv3x3_fwd(const void* x, int ldx, const float* w, void* y, int ldy, int N, int H, int W, int C, int stride,
+                     int outH, int outW, double* stats_acc, int nslots, mi_stream_t s);
+int mi_dwconv3x3_dgrad(const void* dy, int lddy, const float* w, void* dx, int lddx, int N, int H, int W, int C,
+                       int stride, int outH, int outW, int accumulate, mi_stream_t s);
+int64_t mi_dwconv3x3_wgrad_ws_bytes(int C);
+int mi_dwconv3x3_wgrad(const void* x, int ldx, const void* dy, int lddy, int N, int H, int W, int C, int stride,
+                       int outH, int outW, float* ws, int64_t ws_bytes, float* dw, mi_stream_t s);
+
 /* ---- BatchNorm(train) + SiLU (+ residual) -----------------------------
  * replaces nn.BatchNorm2d + nn.SiLU of BaseConv (wrappers.py:76-80) and the
  * Bottleneck add (wrappers.py:119-123). */
@@ -527,6 +543,10 @@ enum {
   MI_OP_BN_GROUP = 31,     /* p0 = mi_bn_group* (host),   p1 = device job table */
   MI_OP_SPLIT_DPREDS_BATCH = 32, /* p0 = mi_split_job* (host), p1 = dpreds, i = B, A, nch, njobs */
   MI_OP_BN_BWD_FUSED = 33, /* BN_BWD_APPLY's arguments + p[12] = barrier words */
+  /* depthwise 3x3: i = ldx/lddy, ldy/lddx, N, H, W, C, stride, outH, outW, nslots/accumulate */
+  MI_OP_DWCONV_FWD = 34,   /* p = x, w, y, stats_acc */
+  MI_OP_DWCONV_DGRAD = 35, /* p = dy, w, dx */
+  MI_OP_DWCONV_WGRAD = 36, /* p = x, dy, ws, dw; l0 = ws bytes */
   MI_OP_COUNT
 };
 

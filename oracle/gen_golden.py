@@ -68,6 +68,30 @@ def gold_onnx_layout():
     print("onnx layout:", tuple(out.shape), float(out[..., 5].mean()))
 
 
+def gold_dw_step():
+    """full training step of the reference with MODEL.DARKNET.DEPTH_WISE True (DWConv in the backbone's 3x3 convs,
+    darknetx.py:113; neck and head dense, as yolox.py:60-83 builds them), YOLOX-s widths, B=2, 64x96"""
+    depth, width, nc = 0.33, 0.5, 80
+    ref, r = ref_loader.build_reference_yolox(depth, width, nc, seed=0, depthwise=True)
+    ref.load_state_dict(O.init_state_dict(depth, width, nc, seed=3, depthwise=True))
+    ref.train()
+    imgs, labels = O.synth_batch(2, 64, 96, seed=12, max_gt=4)
+    out = ref(imgs, labels)
+    (out[0] + out[1] + out[2] + out[3]).backward()
+    grads = {k: p.grad.detach().clone() for k, p in ref.named_parameters()}
+    res = dict(losses=np.array([float(x) for x in out], dtype=np.float64))
+    for k in ("backbone.dark2.0.dconv.conv.weight", "backbone.dark2.0.pconv.conv.weight", "backbone.dark4.1.m.1.conv2.dconv.conv.weight",
+              "backbone.dark5.0.dconv.bn.weight", "backbone.dark3.1.m.0.conv2.dconv.bn.bias", "backbone.stem.conv.conv.weight"):
+        res["grad:" + k] = grads[k].numpy()
+    names = sorted(grads)
+    res["grad_names"] = np.array(names)
+    res["grad_norms"] = np.array([float(grads[k].norm()) for k in names], dtype=np.float64)
+    st = ref.state_dict()
+    res["rm:backbone.dark3.0.dconv.bn.running_mean"] = st["backbone.dark3.0.dconv.bn.running_mean"].numpy()
+    np.savez_compressed(os.path.join(OUT, "yolox_s_dw_step_64x96.npz"), **res)
+    print("dw step:", res["losses"], len(names))
+
+
 def gold_tiny_step():
     """config 0 of BASELINE.json: YOLOX-tiny (depth .33, width .375), 416x416, bs=2, fp32 on the CPU device - the
     reference's own CPU-runnable case; losses, gradient norms of every parameter and the eval output"""
@@ -483,6 +507,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     gold_step()
     gold_onnx_layout()
+    gold_dw_step()
     gold_tiny_step()
     gold_simota()
     gold_simota_l1()

@@ -134,7 +134,7 @@ def load_detr():
     return importlib.import_module("yolov7.modeling.meta_arch.detr")
 
 
-def build_reference_yolox(depth=0.33, width=0.5, num_classes=80, seed=0):
+def build_reference_yolox(depth=0.33, width=0.5, num_classes=80, seed=0, depthwise=False):
     """CSPDarknet + YOLOPAFPN + YOLOXHead assembled the way YOLOX.__init__ does (yolox.py:60-83)"""
     import torch
     from torch import nn
@@ -144,7 +144,7 @@ def build_reference_yolox(depth=0.33, width=0.5, num_classes=80, seed=0):
     class RefYOLOX(nn.Module):
         def __init__(self):
             super().__init__()
-            self.backbone = r.darknetx.CSPDarknet(depth, width)
+            self.backbone = r.darknetx.CSPDarknet(depth, width, depthwise=depthwise)   # MODEL.DARKNET.DEPTH_WISE
             self.neck = r.pafpn.YOLOPAFPN(depth=depth, width=width)
             self.head = r.head.YOLOXHead(num_classes, width=width)
             for m in self.modules():

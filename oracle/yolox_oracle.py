@@ -32,8 +32,11 @@ class Net:
     """functional YOLOX over a state_dict `sd` (reference key names). training=True -> batch-stat BN
     (running stats in `sd` are updated in place, like nn.BatchNorm2d)."""
 
-    def __init__(self, sd, depth=0.33, width=0.5, num_classes=80, training=True, quant=None, force=None):
+    def __init__(self, sd, depth=0.33, width=0.5, num_classes=80, training=True, quant=None, force=None, depthwise=False):
         self.sd, self.depth, self.width, self.nc, self.training = sd, depth, width, num_classes, training
+        # MODEL.DARKNET.DEPTH_WISE (darknetx.py:113,210): the 3x3 convs of the BACKBONE become DWConv (the meta-arch
+        # builds neck and head with depthwise=False, yolox.py:60-83)
+        self.depthwise = depthwise
         # quant: optional callable emulating the product's storage rounding (e.g. bf16) after each op
         self.q = quant if quant is not None else (lambda t: t)
         self.taps = {}
@@ -47,9 +50,17 @@ class Net:
         self.force = force
         self.force_err = {}
 
-    def base_conv(self, p, x, k, s, res=None):
+    def dw_conv(self, p, x, k, s, res=None):
+        """DWConv (wrappers.py:86-102): depthwise BaseConv(k, s, groups=C) then pointwise BaseConv(1, 1)"""
+        return self.base_conv(p + ".pconv", self.base_conv(p + ".dconv", x, k, s, groups=x.shape[1]), 1, 1, res=res)
+
+    def conv3(self, p, x, s, res=None):
+        """the 3x3 convs darknetx.py / wrappers.Bottleneck switch to DWConv under depthwise"""
+        return self.dw_conv(p, x, 3, s, res=res) if self.depthwise else self.base_conv(p, x, 3, s, res=res)
+
+    def base_conv(self, p, x, k, s, res=None, groups=1):
         sd = self.sd
-        y = F.conv2d(self.q(x), self.q(sd[p + ".conv.weight"]), None, stride=s, padding=(k - 1) // 2)
+        y = F.conv2d(self.q(x), self.q(sd[p + ".conv.weight"]), None, stride=s, padding=(k - 1) // 2, groups=groups)
         self.taps[p + ".y"] = y
         y = self.q(y)
         if self.force is not None and p + ".y" in self.force:
@@ -76,6 +87,8 @@ class Net:
 
     def bottleneck(self, p, x, shortcut):
         h = self.base_conv(p + ".conv1", x, 1, 1)
+        if p.startswith("backbone"):
+            return self.conv3(p + ".conv2", h, 1, res=x if shortcut else None)
         return self.base_conv(p + ".conv2", h, 3, 1, res=x if shortcut else None)
 
     def csp(self, p, x, n, shortcut):
@@ -98,10 +111,10 @@ class Net:
     def backbone(self, x, p="backbone"):
         bd = max(round(self.depth * 3), 1)
         x = self.focus(p + ".stem", x)
-        x = self.csp(p + ".dark2.1", self.base_conv(p + ".dark2.0", x, 3, 2), bd, True)
-        d3 = self.csp(p + ".dark3.1", self.base_conv(p + ".dark3.0", x, 3, 2), bd * 3, True)
-        d4 = self.csp(p + ".dark4.1", self.base_conv(p + ".dark4.0", d3, 3, 2), bd * 3, True)
-        x = self.spp(p + ".dark5.1", self.base_conv(p + ".dark5.0", d4, 3, 2))
+        x = self.csp(p + ".dark2.1", self.conv3(p + ".dark2.0", x, 2), bd, True)
+        d3 = self.csp(p + ".dark3.1", self.conv3(p + ".dark3.0", x, 2), bd * 3, True)
+        d4 = self.csp(p + ".dark4.1", self.conv3(p + ".dark4.0", d3, 2), bd * 3, True)
+        x = self.spp(p + ".dark5.1", self.conv3(p + ".dark5.0", d4, 2))
         d5 = self.csp(p + ".dark5.2", x, bd, False)
         return {"dark3": d3, "dark4": d4, "dark5": d5}
 
@@ -414,16 +427,20 @@ def synth_raw(B, hw, seed, num_classes=80, labels=None):
     return raw, anchors
 
 
-def init_state_dict(depth=0.33, width=0.5, num_classes=80, seed=0):
+def init_state_dict(depth=0.33, width=0.5, num_classes=80, seed=0, depthwise=False):
     """random-init weights of the architecture with the reference's key names / shapes (default PyTorch
     init, BN defaults, initialize_biases(0.01)). Built from a key/shape table, not from reference code."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
 
-    def conv(p, cin, cout, k):
-        fan_in = cin * k * k
+    def conv(p, cin, cout, k, groups=1):
+        if depthwise and k == 3 and groups == 1 and p.startswith("backbone") and "stem" not in p:
+            conv(p + ".dconv", cin, cin, 3, groups=cin)      # DWConv (wrappers.py:86-102)
+            conv(p + ".pconv", cin, cout, 1)
+            return
+        fan_in = cin // groups * k * k
         bound = 1.0 / math.sqrt(fan_in)  # kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))
-        sd[p + ".conv.weight"] = (torch.rand(cout, cin, k, k, generator=g) * 2 - 1) * bound
+        sd[p + ".conv.weight"] = (torch.rand(cout, cin // groups, k, k, generator=g) * 2 - 1) * bound
         sd[p + ".bn.weight"] = torch.ones(cout)
         sd[p + ".bn.bias"] = torch.zeros(cout)
         sd[p + ".bn.running_mean"] = torch.zeros(cout)
@@ -466,9 +483,9 @@ def init_state_dict(depth=0.33, width=0.5, num_classes=80, seed=0):
 
 
 def train_step_losses(sd, images, labels, depth=0.33, width=0.5, num_classes=80, quant=None, return_all=False,
-                      use_l1=False):
+                      use_l1=False, depthwise=False):
     """forward + loss on CPU fp32; sd tensors may require grad"""
-    net = Net(sd, depth, width, num_classes, training=True, quant=quant)
+    net = Net(sd, depth, width, num_classes, training=True, quant=quant, depthwise=depthwise)
     raw, hw = net.forward_raw(images)
     anchors = make_anchors(hw)
     if return_all:

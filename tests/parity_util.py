@@ -21,9 +21,10 @@ class QuantBf16(torch.autograd.Function):
         return g.to(torch.bfloat16).float()
 
 
-def build_model(depth, width, sd, conf=None):
+def build_model(depth, width, sd, conf=None, depthwise=False):
     cfg = M.yolox_s_cfg(device=DEV)
     cfg.MODEL.YOLO.DEPTH_MUL, cfg.MODEL.YOLO.WIDTH_MUL = depth, width
+    cfg.MODEL.DARKNET.DEPTH_WISE = bool(depthwise)
     if conf is not None:
         cfg.MODEL.YOLO.CONF_THRESHOLD = conf
     model = M.build_model(cfg)
@@ -31,10 +32,10 @@ def build_model(depth, width, sd, conf=None):
     return model
 
 
-def hip_step(sd, imgs, labels, depth=0.33, width=0.5, want_y=False):
+def hip_step(sd, imgs, labels, depth=0.33, width=0.5, want_y=False, depthwise=False):
     """forward + loss + backward of the HIP plan on (imgs, labels); returns host copies"""
     B, _, H, W = imgs.shape
-    model = build_model(depth, width, sd)
+    model = build_model(depth, width, sd, depthwise=depthwise)
     model.train()
     ps = model.plan_for(B, H, W, True)
     ps.image.copy_(imgs.to(DEV)); ps.labels.copy_(labels.to(DEV))
@@ -57,14 +58,14 @@ def hip_step(sd, imgs, labels, depth=0.33, width=0.5, want_y=False):
     return out
 
 
-def oracle_backward(sd, imgs, dpreds, force, depth=0.33, width=0.5):
+def oracle_backward(sd, imgs, dpreds, force, depth=0.33, width=0.5, depthwise=False):
     """oracle forward (bf16 storage emulation; conv outputs forced to `force` when given) and autograd backward from
     the given d(loss)/d(raw)"""
     osd = {k: v.clone() for k, v in sd.items()}
     for k, v in osd.items():
         if v.is_floating_point() and "running" not in k:
             v.requires_grad_(True)
-    net = O.Net(osd, depth, width, 80, training=True, quant=QuantBf16.apply, force=force)
+    net = O.Net(osd, depth, width, 80, training=True, quant=QuantBf16.apply, force=force, depthwise=depthwise)
     raw_ref, hw = net.forward_raw(imgs)
     raw_ref.backward(dpreds)
     return dict(raw=raw_ref.detach(), grads={k: v.grad.detach().clone() for k, v in osd.items() if v.requires_grad},

@@ -163,6 +163,40 @@ class Interp:
             res[:, :, t] = torch.einsum("nhwo,nhwi->oi", dy, sl)[: s.Cout, : s.Cin]
         g.copy_(res.view(s.Cout, s.Cin, kk, kk))
 
+    # ---- depthwise 3x3 (DWConv.dconv)
+    def _dw_w(self, p, C):
+        return p.obj.detach().float().to(self.dt).float().view(C, 1, 3, 3)   # rounded like every conv operand
+
+    def op_DWCONV_FWD(self, c):
+        ldx, ldy, N, H, W, C, stride, Ho, Wo, nsl = c.i[:10]
+        x, y = c.p[0].obj, c.p[2].obj
+        xin = self.tv(x, C).float().permute(0, 3, 1, 2)
+        res = F.conv2d(xin, self._dw_w(c.p[1], C), None, stride=stride, padding=1, groups=C).permute(0, 2, 3, 1)
+        assert tuple(res.shape) == (N, Ho, Wo, C)
+        self.tv(y, C)[:] = res.to(self.dt)
+        if c.p[3].obj is not None:
+            CA = (C + 31) // 32 * 32
+            st = self.f64(c.p[3], CA * 2).view(CA, 2)
+            st[:C, 0] += res.double().sum((0, 1, 2))
+            st[:C, 1] += (res.double() ** 2).sum((0, 1, 2))
+
+    def op_DWCONV_DGRAD(self, c):
+        lddy, lddx, N, H, W, C, stride, Ho, Wo, acc = c.i[:10]
+        dy = self.tv(c.p[0].obj, C).float().permute(0, 3, 1, 2)
+        dxv = self.tv(c.p[2].obj, C)
+        xz = torch.zeros(N, C, H, W, requires_grad=True)
+        F.conv2d(xz, self._dw_w(c.p[1], C), None, stride=stride, padding=1, groups=C).backward(dy)
+        g = xz.grad.permute(0, 2, 3, 1)
+        dxv[:] = (g + (dxv.float() if acc else 0)).to(self.dt)
+
+    def op_DWCONV_WGRAD(self, c):
+        ldx, lddy, N, H, W, C, stride, Ho, Wo = c.i[:9]
+        x = self.tv(c.p[0].obj, C).float().permute(0, 3, 1, 2)
+        dy = self.tv(c.p[1].obj, C).float().permute(0, 3, 1, 2)
+        wz = torch.zeros(C, 1, 3, 3, requires_grad=True)
+        F.conv2d(x, wz, None, stride=stride, padding=1, groups=C).backward(dy)
+        c.p[3].obj.copy_(wz.grad)
+
     def op_BN_EVAL_AFFINE(self, c):
         C = c.i[0]
         g, b, rm, rv = (c.p[k].obj.detach().float() for k in range(4))

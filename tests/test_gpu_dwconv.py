@@ -1,0 +1,111 @@
+"""GPU (-m gpu): DWConv (row a6; yolov7/modeling/backbone/layers/wrappers.py:86-102, MODEL.DARKNET.DEPTH_WISE True).
+
+  * the depthwise 3x3 kernels (forward + BatchNorm statistics, data gradient, weight gradient) against torch's grouped
+    conv in fp32 on the same bf16-rounded operands: strides 1 / 2, odd sizes, channel counts whose C / 8 is not a power of
+    two, padded pixel strides, accumulation into an existing gradient;
+  * one whole training step of the depthwise backbone: every conv output on identical inputs, SimOTA / losses, and every
+    one of the 276 parameter gradients with the forward state pinned (tests/test_gpu_parity_bench.py explains why), and the
+    losses against the reference's own step (tests/golden/yolox_s_dw_step_64x96.npz, oracle/gen_golden.py::gold_dw_step)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import yolox_oracle as O
+from parity_util import DEV, grad_table, hip_step, oracle_backward
+from yolov7_d2_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("N,H,W,C,stride,ld", [(2, 20, 24, 64, 1, 64), (3, 17, 23, 24, 2, 32), (1, 8, 5, 80, 1, 96),
+                                               (2, 40, 40, 256, 2, 256), (16, 80, 80, 128, 1, 128), (2, 1, 1, 8, 1, 8)])
+def test_dwconv3x3_kernels_against_torch(N, H, W, C, stride, ld):
+    lib, sp = L.lib(), L.stream_ptr()
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + C)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    x = torch.randn(N, H, W, ld, generator=g).to(torch.bfloat16)
+    w = (torch.randn(C, 1, 3, 3, generator=g) * 0.4)
+    dy = torch.randn(N, Ho, Wo, ld, generator=g).to(torch.bfloat16)
+    xd, wd, dyd = x.to(DEV), w.to(DEV), dy.to(DEV)
+    CA = (C + 31) // 32 * 32
+    y = torch.full((N, Ho, Wo, ld), 9.0, dtype=torch.bfloat16, device=DEV)
+    acc = torch.zeros(L.MI_BN_SLOTS * CA * 2, dtype=torch.float64, device=DEV)
+    L.check(lib.mi_dwconv3x3_fwd(xd.data_ptr(), ld, wd.data_ptr(), y.data_ptr(), ld, N, H, W, C, stride, Ho, Wo,
+                                 acc.data_ptr(), L.MI_BN_SLOTS, sp), "fwd")
+    xr = x[..., :C].float().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.to(torch.bfloat16).float().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, stride=stride, padding=1, groups=C)
+    ref.backward(dy[..., :C].float().permute(0, 3, 1, 2))
+    refn = ref.detach().permute(0, 2, 3, 1)
+    got = y.float().cpu()
+    assert torch.all(got[..., C:] == 9.0)                                      # pad channels untouched
+    assert float((got[..., :C] - refn).abs().max()) <= float(refn.abs().max()) * 2 ** -8 + 1e-6     # bf16 store of fp32 sums
+    st = acc.cpu().view(L.MI_BN_SLOTS, CA, 2).sum(0)
+    np.testing.assert_allclose(st[:C, 0].numpy(), refn.double().sum((0, 1, 2)).numpy(), rtol=1e-4, atol=1e-3 * N * Ho * Wo ** 0.5)
+    np.testing.assert_allclose(st[:C, 1].numpy(), (refn.double() ** 2).sum((0, 1, 2)).numpy(), rtol=1e-4, atol=1e-4)
+    assert torch.all(st[C:] == 0)
+    # data gradient: overwrite, then accumulate on top of an existing gradient
+    for accum in (0, 1):
+        dx = torch.full((N, H, W, ld), 0.5, dtype=torch.bfloat16, device=DEV)
+        L.check(lib.mi_dwconv3x3_dgrad(dyd.data_ptr(), ld, wd.data_ptr(), dx.data_ptr(), ld, N, H, W, C, stride, Ho, Wo, accum,
+                                       sp), "dgrad")
+        want = xr.grad.permute(0, 2, 3, 1) + (0.5 if accum else 0.0)
+        gotx = dx.float().cpu()
+        assert torch.all(gotx[..., C:] == 0.5)
+        assert float((gotx[..., :C] - want).abs().max()) <= float(want.abs().max()) * 2 ** -7 + 1e-6
+    # weight gradient (fp32, deterministic)
+    nb = lib.mi_dwconv3x3_wgrad_ws_bytes(C)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    outs = []
+    for _ in range(2):
+        dw = torch.full((C, 1, 3, 3), 7.0, device=DEV)
+        L.check(lib.mi_dwconv3x3_wgrad(xd.data_ptr(), ld, dyd.data_ptr(), ld, N, H, W, C, stride, Ho, Wo, ws.data_ptr(), nb,
+                                       dw.data_ptr(), sp), "wgrad")
+        outs.append(dw.cpu())
+    assert torch.equal(outs[0], outs[1])
+    np.testing.assert_allclose(outs[0].numpy(), wr.grad.numpy(), rtol=2e-4, atol=2e-4 * float(wr.grad.abs().max()))
+    # argument errors are reported, nothing is launched
+    assert lib.mi_dwconv3x3_fwd(xd.data_ptr(), ld, wd.data_ptr(), y.data_ptr(), ld, N, H, W, C, 3, Ho, Wo, None, 0, sp) < 0
+    assert b"stride" in lib.mi_last_error()
+    assert lib.mi_dwconv3x3_wgrad(xd.data_ptr(), ld, dyd.data_ptr(), ld, N, H, W, C, stride, Ho, Wo, ws.data_ptr(), 16, dw.data_ptr(), sp) < 0
+    lib.mi_last_error()
+
+
+def test_depthwise_backbone_training_step(golden_dir):
+    g = np.load(os.path.join(golden_dir, "yolox_s_dw_step_64x96.npz"))
+    depth, width = 0.33, 0.5
+    sd = O.init_state_dict(depth, width, 80, seed=3, depthwise=True)
+    imgs, labels = O.synth_batch(2, 64, 96, seed=12, max_gt=4)             # the batch gold_dw_step used
+    hip = hip_step(sd, imgs, labels, depth, width, want_y=True, depthwise=True)
+    ys = hip.pop("y")
+    assert sum(k.endswith(".dconv.y") for k in ys) == 12
+    forced = oracle_backward(sd, imgs, hip["dpreds"], ys, depth, width, depthwise=True)
+    fe = forced["force_err"]
+    assert len(fe) == len(ys)
+    worst = max(fe.items(), key=lambda kv: kv[1])
+    # every BaseConv output on identical inputs: <= 2.5e-4 everywhere (measured) except the pointwise convs behind a
+    # depthwise BatchNorm, 1e-3 .. 3e-3 growing as 1/sqrt(samples per channel): the kernels take the batch statistics from
+    # the fp32 sums, the oracle from the bf16-stored tensor it was handed, and a depthwise output channel has |mean| >> std,
+    # so the two means differ by ~2^-9 |mean| / sqrt(n) - a visible fraction of the std the next layer is normalised by
+    for k, v in fe.items():
+        assert v < (5e-3 if k.endswith(".pconv") else 1e-3), (k, v)
+    rel = float((hip["raw"] - forced["raw"]).norm() / forced["raw"].norm())
+    assert rel < 1e-5, rel
+    raw = hip["raw"].clone().requires_grad_(True)
+    res, assigns = O.yolox_losses(raw, labels, hip["anchors"], 80, return_assign=True)
+    np.testing.assert_allclose(hip["losses"][:4].numpy(), np.array([float(x.detach()) for x in res[:4]]), rtol=1e-4, atol=1e-5)
+    for b in range(2):
+        if assigns[b] is not None:
+            assert torch.equal(hip["fg"][b].bool(), assigns[b]["fg"])
+    rows = grad_table(hip["grads"], forced["grads"])
+    assert len(rows) == 276 == len(g["grad_names"])
+    bad = [r for r in rows if not (r[1] >= 0.999 and r[2] <= 0.05)]
+    assert not bad, bad[:6]
+    # against the reference's own fp32 step: within the bf16 storage noise
+    np.testing.assert_allclose(hip["losses"][0].numpy(), g["losses"][0], rtol=3e-2)
+    np.testing.assert_allclose(hip["losses"][:4].numpy(), g["losses"][:4], rtol=1e-1, atol=5e-2)
+    np.testing.assert_allclose(hip["rm"]["backbone.dark3.0.dconv.bn.running_mean"].numpy(),
+                               g["rm:backbone.dark3.0.dconv.bn.running_mean"], rtol=5e-2, atol=2e-3)

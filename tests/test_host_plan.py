@@ -103,6 +103,55 @@ def test_plan_step_with_l1_loss_matches_oracle():
     assert not bad, bad[:10]
 
 
+def test_plan_step_depthwise_backbone_matches_oracle():
+    """MODEL.DARKNET.DEPTH_WISE True: the backbone's 3x3 convs become DWConv (depthwise 3x3 + pointwise) - built from the
+    config key, same state_dict keys as the reference, the plan (DWCONV_FWD / DGRAD / WGRAD commands between the usual
+    BatchNorm passes) interpreted on the CPU against the oracle: losses and every parameter gradient"""
+    cfg = M.yolox_s_cfg(device="cpu")
+    cfg.MODEL.DARKNET.DEPTH_WISE = True
+    model = M.build_model(cfg)
+    sd = O.init_state_dict(0.33, 0.5, 80, seed=3, depthwise=True)
+    model.load_state_dict(sd)          # strict: the DWConv keys (dconv.conv / dconv.bn / pconv.conv / pconv.bn) line up
+    model.params = ParamArena(model, "cpu")
+    B, H, W = 2, 64, 96
+    imgs, labels = O.synth_batch(B, H, W, seed=12, max_gt=4)
+    ps = _PlanState(model, B, H, W, True, materialize=False)
+    b = ps.builder
+    ops = [L.OPS[c.op] for c in b.fwd + b.bwd]
+    assert ops.count("DWCONV_FWD") == 12 and ops.count("DWCONV_WGRAD") == 12 and ops.count("DWCONV_DGRAD") == 12   # 4 stage stems + 8 bottlenecks
+    ps.image.copy_(imgs)
+    ps.labels.copy_(labels)
+    it = Interp(b, torch.float32)
+    it.run(b.prologue + b.fwd)
+    out = it.raw(ps.loss["out"]).view(torch.float32)[:8].clone()
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    res = O.train_step_losses(sd, imgs, labels, depthwise=True)
+    np.testing.assert_allclose(out[:4].numpy(), np.array([float(x) for x in res[:4]]), rtol=1e-4, atol=1e-4)
+    it.raw(ps.loss["gw"]).view(torch.float32)[:4] = 1.0
+    it.run(b.bwd)
+    (res[0] + res[1] + res[2] + res[3]).backward()
+    bad = []
+    for name, p in model.named_parameters():
+        g = model.params.grad_of(p).detach().float()
+        r = sd[name].grad
+        rel = float((g - r).norm()) / (float(r.norm()) + 1e-6)
+        if rel > 2e-3:
+            bad.append((name, rel))
+    assert not bad, bad[:10]
+    # the materialised (dry-run) plan knows the depthwise weight gradients' place in the flat gradient arena
+    from yolov7_d2_amd.plan import Plan
+    from yolov7_d2_amd.parallel import grad_write_ranges
+    plan = Plan(b, dry_run=True)
+    covered = np.zeros(model.params.total, dtype=bool)
+    for rs in grad_write_ranges(plan, model.params.grad):
+        for (b0, b1) in rs:
+            covered[b0 // 4: b1 // 4] = True
+    for name, p, off, cnt in model.params.entries:
+        assert covered[off: off + cnt].all(), name
+
+
 def test_eval_plan_matches_oracle():
     model, sd = _model(seed=3)
     model.eval()

@@ -36,6 +36,29 @@ def test_step_losses_grads_and_eval(golden_dir):
     np.testing.assert_allclose(ev.numpy(), g["eval_out"], rtol=1e-5, atol=1e-5)
 
 
+def test_depthwise_backbone_step_oracle_against_reference(golden_dir):
+    """MODEL.DARKNET.DEPTH_WISE True (DWConv = depthwise 3x3 BaseConv + pointwise BaseConv in the backbone,
+    wrappers.py:86-102, darknetx.py:113): the oracle's restatement against the reference's own step"""
+    g = np.load(os.path.join(golden_dir, "yolox_s_dw_step_64x96.npz"))
+    sd = O.init_state_dict(0.33, 0.5, 80, seed=3, depthwise=True)
+    assert sd["backbone.dark2.0.dconv.conv.weight"].shape == (32, 1, 3, 3)
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    imgs, labels = O.synth_batch(2, 64, 96, seed=12, max_gt=4)
+    res = O.train_step_losses(sd, imgs, labels, depthwise=True)
+    np.testing.assert_allclose(np.array([float(x) for x in res]), g["losses"], rtol=1e-6, atol=1e-6)
+    (res[0] + res[1] + res[2] + res[3]).backward()
+    for k in g.files:
+        if k.startswith("grad:"):
+            np.testing.assert_allclose(sd[k[5:]].grad.numpy(), g[k], rtol=1e-4, atol=1e-6)
+    names = [str(n) for n in g["grad_names"]]
+    assert sorted(k for k, v in sd.items() if v.requires_grad) == names
+    np.testing.assert_allclose(np.array([float(sd[n].grad.norm()) for n in names]), g["grad_norms"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(sd["backbone.dark3.0.dconv.bn.running_mean"].numpy(),
+                               g["rm:backbone.dark3.0.dconv.bn.running_mean"], rtol=1e-6, atol=1e-6)
+
+
 def test_config0_yolox_tiny_416_cpu_step(golden_dir):
     """BASELINE.json configs[0] (YOLOX-tiny, width .375, 416x416, bs=2, CPU): the oracle against the reference's own
     modules run by path - the 4 losses, the gradient norm of every parameter, one full gradient and the eval output.

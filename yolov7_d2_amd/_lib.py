@@ -138,7 +138,7 @@ class mi_cmd(C.Structure):
 OPS = ["NOP", "CONV", "WGRAD", "PACK_W", "RESERVED4", "RESERVED5", "BN_ACT_FWD", "BN_BWD_REDUCE",
        "RESERVED8", "BN_BWD_APPLY", "FOCUS", "UPSAMPLE_FWD", "UPSAMPLE_BWD", "SPP_FWD", "SPP_BWD", "COPY",
        "COLSUM", "LOSS_FWD", "LOSS_BWD", "SPLIT_DPREDS", "MEMSET", "SGD", "BN_EVAL_AFFINE", "DECODE", "PACK_W_BATCH", "WGRAD_GROUP", "STREAM", "FORK", "JOIN", "BIAS_GRADS",
-       "CONV_GROUP", "BN_GROUP", "SPLIT_DPREDS_BATCH", "BN_BWD_FUSED"]
+       "CONV_GROUP", "BN_GROUP", "SPLIT_DPREDS_BATCH", "BN_BWD_FUSED", "DWCONV_FWD", "DWCONV_DGRAD", "DWCONV_WGRAD"]
 OP = {n: k for k, n in enumerate(OPS)}
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -184,6 +184,10 @@ _PROTOS = {
     "mi_bn_act_bwd_fused": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _i, _vp, _i,
                                       _i, _i64, _i, _i, _vp, _vp]),
     "mi_bn_fused_set_capacity": (C.c_int, [_i]),
+    "mi_dwconv3x3_fwd": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "mi_dwconv3x3_dgrad": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "mi_dwconv3x3_wgrad_ws_bytes": (C.c_int64, [_i]),
+    "mi_dwconv3x3_wgrad": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _vp]),
     "mi_yolox_onnx_layout": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
     "mi_yolox_iou_loss": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "mi_pairwise_bbox_iou": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp]),

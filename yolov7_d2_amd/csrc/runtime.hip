@@ -42,6 +42,14 @@ static int run_one(const mi_cmd& c, hipStream_t s) {
       return mi_bn_act_bwd_fused(p[0], i[0], p[1], i[1], (const float*)p[2], (const float*)p[3], (const float*)p[4],
                                  (const float*)p[5], (const float*)p[6], (double*)p[7], i[7], c.l[1], (float*)p[8],
                                  (float*)p[9], p[10], i[2], p[11], i[3], i[4], c.l[0], i[5], i[6], (uint32_t*)p[12], st);
+    case MI_OP_DWCONV_FWD:
+      return mi_dwconv3x3_fwd(p[0], i[0], (const float*)p[1], p[2], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8],
+                              (double*)p[3], i[9], st);
+    case MI_OP_DWCONV_DGRAD:
+      return mi_dwconv3x3_dgrad(p[0], i[0], (const float*)p[1], p[2], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8], i[9], st);
+    case MI_OP_DWCONV_WGRAD:
+      return mi_dwconv3x3_wgrad(p[0], i[0], p[1], i[1], i[2], i[3], i[4], i[5], i[6], i[7], i[8], (float*)p[2], c.l[0],
+                                (float*)p[3], st);
     case MI_OP_FOCUS:
       return i[4] ? mi_focus_pack_u8((const uint8_t*)p[0], i[0], i[1], i[2], p[1], i[3], st)
                   : mi_focus_pack((const float*)p[0], i[0], i[1], i[2], p[1], i[3], st);

@@ -35,29 +35,42 @@ class BaseConv(_NoEager):
 
     def __init__(self, in_channels, out_channels, ksize, stride, groups=1, bias=False, act="silu"):
         super().__init__()
-        if groups != 1 or bias or act != "silu":
-            raise NotImplementedError("MI355X path implements the yolox_s.yaml configuration: dense conv, no bias, "
-                                      "SiLU (MODEL.DARKNET.DEPTH_WISE False)")
+        if bias or act != "silu":
+            raise NotImplementedError("MI355X path: BaseConv without bias, SiLU (what every reference config builds)")
+        if groups != 1 and not (groups == in_channels == out_channels and ksize == 3):
+            raise NotImplementedError("grouped conv: only depthwise 3x3 (the dconv of DWConv) is built")
         pad = (ksize - 1) // 2
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=ksize, stride=stride, padding=pad, groups=groups,
                               bias=bias)
         self.bn = nn.BatchNorm2d(out_channels)
         self.act = nn.SiLU(inplace=True)
-        self.ksize, self.stride = ksize, stride
+        self.ksize, self.stride, self.groups = ksize, stride, groups
 
     def emit(self, ctx, x, tag, out=None, res=None):
         return ctx.b.base_conv(tag, x, self.conv.weight, _bn_dict(ctx, self.bn), self.ksize, self.stride,
-                               ctx.g(self.conv.weight), out=out, res=res, act=1)
+                               ctx.g(self.conv.weight), out=out, res=res, act=1, groups=self.groups)
+
+
+class DWConv(_NoEager):
+    """Depthwise Conv + Conv (wrappers.py:86-102): BaseConv(C, C, k, stride, groups=C) -> BaseConv(C, Cout, 1)"""
+
+    def __init__(self, in_channels, out_channels, ksize, stride=1, act="silu"):
+        super().__init__()
+        self.dconv = BaseConv(in_channels, in_channels, ksize=ksize, stride=stride, groups=in_channels, act=act)
+        self.pconv = BaseConv(in_channels, out_channels, ksize=1, stride=1, groups=1, act=act)
+
+    def emit(self, ctx, x, tag, out=None, res=None):
+        h = self.dconv.emit(ctx, x, tag + ".dconv")
+        return self.pconv.emit(ctx, h, tag + ".pconv", out=out, res=res)
 
 
 class Bottleneck(_NoEager):
     def __init__(self, in_channels, out_channels, shortcut=True, expansion=0.5, depthwise=False, act="silu"):
         super().__init__()
-        if depthwise:
-            raise NotImplementedError("DWConv path (MODEL.DARKNET.DEPTH_WISE True) is not on the YOLOX-s hot path")
         hidden = int(out_channels * expansion)
+        Conv = DWConv if depthwise else BaseConv
         self.conv1 = BaseConv(in_channels, hidden, 1, stride=1, act=act)
-        self.conv2 = BaseConv(hidden, out_channels, 3, stride=1, act=act)
+        self.conv2 = Conv(hidden, out_channels, 3, stride=1, act=act)
         self.use_add = shortcut and in_channels == out_channels
 
     def emit(self, ctx, x, tag, out=None):

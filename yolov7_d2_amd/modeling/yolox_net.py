@@ -8,28 +8,29 @@ import torch
 from torch import nn
 
 from ..d2shim import BACKBONE_REGISTRY, Backbone, ShapeSpec
-from .blocks import BaseConv, CSPLayer, Focus, SPPBottleneck, _NoEager
+from .blocks import BaseConv, CSPLayer, DWConv, Focus, SPPBottleneck, _NoEager
 
 
 class CSPDarknet(Backbone):
     def __init__(self, dep_mul, wid_mul, out_features=("dark3", "dark4", "dark5"), depthwise=False, act="silu"):
         super().__init__()
         assert out_features, "please provide output features of Darknet"
-        if depthwise:
-            raise NotImplementedError("depthwise CSPDarknet is not on the YOLOX-s hot path")
+        Conv = DWConv if depthwise else BaseConv     # darknetx.py:113 (MODEL.DARKNET.DEPTH_WISE)
         self.out_features = out_features
         bc = int(wid_mul * 64)
         bd = max(round(dep_mul * 3), 1)
         self.output_shape_dict = dict()
         self.stem = Focus(3, bc, ksize=3, act=act)
-        self.dark2 = nn.Sequential(BaseConv(bc, bc * 2, 3, 2, act=act), CSPLayer(bc * 2, bc * 2, n=bd, act=act))
+        self.dark2 = nn.Sequential(Conv(bc, bc * 2, 3, 2, act=act), CSPLayer(bc * 2, bc * 2, n=bd, depthwise=depthwise, act=act))
         self.output_shape_dict["dark2"] = ShapeSpec(channels=bc * 2)
-        self.dark3 = nn.Sequential(BaseConv(bc * 2, bc * 4, 3, 2, act=act), CSPLayer(bc * 4, bc * 4, n=bd * 3, act=act))
+        self.dark3 = nn.Sequential(Conv(bc * 2, bc * 4, 3, 2, act=act),
+                                   CSPLayer(bc * 4, bc * 4, n=bd * 3, depthwise=depthwise, act=act))
         self.output_shape_dict["dark3"] = ShapeSpec(channels=bc * 4)
-        self.dark4 = nn.Sequential(BaseConv(bc * 4, bc * 8, 3, 2, act=act), CSPLayer(bc * 8, bc * 8, n=bd * 3, act=act))
+        self.dark4 = nn.Sequential(Conv(bc * 4, bc * 8, 3, 2, act=act),
+                                   CSPLayer(bc * 8, bc * 8, n=bd * 3, depthwise=depthwise, act=act))
         self.output_shape_dict["dark4"] = ShapeSpec(channels=bc * 8)
-        self.dark5 = nn.Sequential(BaseConv(bc * 8, bc * 16, 3, 2, act=act), SPPBottleneck(bc * 16, bc * 16, activation=act),
-                                   CSPLayer(bc * 16, bc * 16, n=bd, shortcut=False, act=act))
+        self.dark5 = nn.Sequential(Conv(bc * 8, bc * 16, 3, 2, act=act), SPPBottleneck(bc * 16, bc * 16, activation=act),
+                                   CSPLayer(bc * 16, bc * 16, n=bd, shortcut=False, depthwise=depthwise, act=act))
         self.output_shape_dict["dark5"] = ShapeSpec(channels=bc * 16)
         self.channels = {"dark2": bc * 2, "dark3": bc * 4, "dark4": bc * 8, "dark5": bc * 16}
 
@@ -71,21 +72,20 @@ class YOLOPAFPN(_NoEager):
     def __init__(self, depth=1.0, width=1.0, in_features=("dark3", "dark4", "dark5"), in_channels=[256, 512, 1024],
                  depthwise=False, act="silu"):
         super().__init__()
-        if depthwise:
-            raise NotImplementedError
+        Conv = DWConv if depthwise else BaseConv     # yolo_pafpn.py:26
         self.in_features, self.in_channels = in_features, in_channels
         c0, c1, c2 = (int(c * width) for c in in_channels)
         self.c = (c0, c1, c2)
         n = round(3 * depth)
         self.upsample = nn.Upsample(scale_factor=2, mode="nearest")
         self.lateral_conv0 = BaseConv(c2, c1, 1, 1, act=act)
-        self.C3_p4 = CSPLayer(2 * c1, c1, n, False, act=act)
+        self.C3_p4 = CSPLayer(2 * c1, c1, n, False, depthwise=depthwise, act=act)
         self.reduce_conv1 = BaseConv(c1, c0, 1, 1, act=act)
-        self.C3_p3 = CSPLayer(2 * c0, c0, n, False, act=act)
-        self.bu_conv2 = BaseConv(c0, c0, 3, 2, act=act)
-        self.C3_n3 = CSPLayer(2 * c0, c1, n, False, act=act)
-        self.bu_conv1 = BaseConv(c1, c1, 3, 2, act=act)
-        self.C3_n4 = CSPLayer(2 * c1, c2, n, False, act=act)
+        self.C3_p3 = CSPLayer(2 * c0, c0, n, False, depthwise=depthwise, act=act)
+        self.bu_conv2 = Conv(c0, c0, 3, 2, act=act)
+        self.C3_n3 = CSPLayer(2 * c0, c1, n, False, depthwise=depthwise, act=act)
+        self.bu_conv1 = Conv(c1, c1, 3, 2, act=act)
+        self.C3_n4 = CSPLayer(2 * c1, c2, n, False, depthwise=depthwise, act=act)
 
     def alloc(self, ctx, N, H8, W8):
         """concat buffers; returns the slices the backbone should write dark3 / dark4 into"""
@@ -119,8 +119,7 @@ class YOLOXHead(_NoEager):
     def __init__(self, num_classes, width=1.0, strides=[8, 16, 32], in_channels=[256, 512, 1024], act="silu",
                  depthwise=False):
         super().__init__()
-        if depthwise:
-            raise NotImplementedError
+        Conv = DWConv if depthwise else BaseConv     # yolox_head.py:51
         self.n_anchors = 1
         self.num_classes = num_classes
         self.decode_in_inference = True
@@ -130,8 +129,8 @@ class YOLOXHead(_NoEager):
         hid = int(256 * width)
         for i in range(len(in_channels)):
             self.stems.append(BaseConv(int(in_channels[i] * width), hid, 1, 1, act=act))
-            self.cls_convs.append(nn.Sequential(BaseConv(hid, hid, 3, 1, act=act), BaseConv(hid, hid, 3, 1, act=act)))
-            self.reg_convs.append(nn.Sequential(BaseConv(hid, hid, 3, 1, act=act), BaseConv(hid, hid, 3, 1, act=act)))
+            self.cls_convs.append(nn.Sequential(Conv(hid, hid, 3, 1, act=act), Conv(hid, hid, 3, 1, act=act)))
+            self.reg_convs.append(nn.Sequential(Conv(hid, hid, 3, 1, act=act), Conv(hid, hid, 3, 1, act=act)))
             self.cls_preds.append(nn.Conv2d(hid, self.n_anchors * num_classes, 1, 1, 0))
             self.reg_preds.append(nn.Conv2d(hid, 4, 1, 1, 0))
             self.obj_preds.append(nn.Conv2d(hid, self.n_anchors * 1, 1, 1, 0))

@@ -41,6 +41,8 @@ def grad_write_ranges(plan, grad_tensor):
         elif c.op == L.OP["BN_GROUP"] and c.i[0] in (2, 3):
             for j in plan.cmd_descs["bwd"][k]:
                 ptrs += [(j.dgamma, j.C * 4), (j.dbeta, j.C * 4)]
+        elif c.op == L.OP["DWCONV_WGRAD"]:
+            ptrs.append((c.p[3], c.i[5] * 9 * 4))
         elif c.op == L.OP["COLSUM"]:
             ptrs.append((c.p[1], c.i[1] * 4))
         elif c.op == L.OP["BIAS_GRADS"]:

@@ -389,11 +389,15 @@ class PlanBuilder:
         return n
 
     # ---------------------------------------------------------------- layers
-    def base_conv(self, tag, x, weight, bn, k, stride, wgrad, out=None, res=None, act=1):
+    def base_conv(self, tag, x, weight, bn, k, stride, wgrad, out=None, res=None, act=1, groups=1):
         """Conv(k, stride, pad=(k-1)//2, no bias) -> BatchNorm -> SiLU (+ res).
         weight: fp32 OIHW tensor; wgrad: fp32 OIHW gradient view (training);
-        bn: dict(gamma, beta, rm, rv, nbt, eps, momentum, ggamma, gbeta)."""
-        Cout, Cin = weight.shape[0], weight.shape[1]
+        bn: dict(gamma, beta, rm, rv, nbt, eps, momentum, ggamma, gbeta).
+        groups: 1, or the channel count (depthwise 3x3: the dconv of DWConv, wrappers.py:86-102)."""
+        Cout, Cin = weight.shape[0], weight.shape[1] * groups
+        dw = groups != 1
+        if dw:
+            assert groups == Cout == Cin and k == 3 and weight.shape[1] == 1, (tag, groups, tuple(weight.shape))
         assert weight.shape[2] == k and Cout % 8 == 0, (tag, tuple(weight.shape))
         CoutPad = _rup(Cout, 32)        # cout tile granularity of the conv / weight-gradient kernels
         pad = (k - 1) // 2
@@ -404,12 +408,22 @@ class PlanBuilder:
         CinPad = _rup(Cin, 32) if x.coff + _rup(Cin, 32) <= x.ld else _rup(Cin, 16)
         assert x.C >= Cin and x.coff + CinPad <= x.ld, (tag, x.C, x.coff, x.ld, Cin)
         KK = k * k
-        wf = self.small(tag + ".wf", KK * CinPad * CoutPad * 2)
         need_dgrad = self.training and x.requires_grad
         CinPadN = _rup(Cin, 32)
-        wd = self.small(tag + ".wd", KK * CoutPad * CinPadN * 2) if need_dgrad else None
-        self.emit("PACK_W", i=[Cout, Cin, k, k, CinPad, CoutPad, CoutPad, CinPadN], p=[weight, wf, wd], tag=tag + ".pack",
-                  prologue=True)
+        wf = wd = None
+        if not dw:
+            wf = self.small(tag + ".wf", KK * CinPad * CoutPad * 2)
+            wd = self.small(tag + ".wd", KK * CoutPad * CinPadN * 2) if need_dgrad else None
+            self.emit("PACK_W", i=[Cout, Cin, k, k, CinPad, CoutPad, CoutPad, CinPadN], p=[weight, wf, wd],
+                      tag=tag + ".pack", prologue=True)
+
+        def fwd_conv(acc, nsl):
+            if dw:     # no weight image: the kernel reads (and bf16-rounds) the fp32 parameter
+                self.emit("DWCONV_FWD", i=[x.ld, y.ld, x.N, x.H, x.W, Cout, stride, Ho, Wo, nsl], p=[x, weight, y, acc],
+                          tag=tag + ".conv")
+            else:
+                self.conv_cmd(tag + ".conv", x, wf, CinPad // 8, y, y.ld, Ho, Wo, Cout, CoutPad, taps, in_stride=stride,
+                              stats=acc, stats_slots=nsl)
         y = self.new_act(x.N, Ho, Wo, Cout, tag + ".y", requires_grad=False, pad=False)
         if out is None:
             out = self.new_act(x.N, Ho, Wo, Cout, tag + ".out")
@@ -421,17 +435,16 @@ class PlanBuilder:
         if self.bn_train:
             mean = self.small(tag + ".mean", Cout * 4)
             invstd = self.small(tag + ".invstd", Cout * 4)
-            nsl = self.bn_slots(self.plan_conv_tiles(x, Ho, Wo, CinPad // 8, Cout, taps, stride))
+            nsl = self.bn_slots(0 if dw else self.plan_conv_tiles(x, Ho, Wo, CinPad // 8, Cout, taps, stride))
             acc = self.bn_acc("fwd", Cout, nsl)
-            self.conv_cmd(tag + ".conv", x, wf, CinPad // 8, y, y.ld, Ho, Wo, Cout, CoutPad, taps, in_stride=stride,
-                          stats=acc, stats_slots=nsl)
+            fwd_conv(acc, nsl)
             self.tune_restore += [t for t in (bn["rm"], bn["rv"], bn["nbt"]) if torch.is_tensor(t)]
             self.emit("BN_ACT_FWD", i=[y.ld, res.ld if res is not None else 0, out.ld, Cout, act, nsl], l=[count, count],
                       f=[bn["eps"], bn["momentum"]],
                       p=[y, acc, bn["gamma"], bn["beta"], bn["rm"], bn["rv"], bn["nbt"], scale, shift, mean, invstd, res,
                          out], tag=tag + ".bnact")
         else:
-            self.conv_cmd(tag + ".conv", x, wf, CinPad // 8, y, y.ld, Ho, Wo, Cout, CoutPad, taps, in_stride=stride)
+            fwd_conv(None, 0)
             self.emit("BN_EVAL_AFFINE", i=[Cout], f=[bn["eps"]],
                       p=[bn["gamma"], bn["beta"], bn["rm"], bn["rv"], scale, shift], tag=tag + ".bnaff")
             self.emit("BN_ACT_FWD", i=[y.ld, res.ld if res is not None else 0, out.ld, Cout, act, 0], l=[0, count],
@@ -475,6 +488,14 @@ class PlanBuilder:
             self.emit("BN_BWD_APPLY", i=[da.ld, y.ld, CoutPad, dres.ld if dres is not None else 0, dres_acc, Cout, act, nsl2],
                       l=[count, count], p=[da, y, scale, shift, mean, invstd, bn["gamma"], dacc, bn["ggamma"], bn["gbeta"],
                                            dyT, dres, self.small(tag + ".bar", 4 * L.MI_BN_BAR_WORDS)], tag=tag + ".bnapply")
+            if dw:
+                nb = L.lib().mi_dwconv3x3_wgrad_ws_bytes(Cout)
+                self.emit("DWCONV_WGRAD", i=[x.ld, dyT.ld, x.N, x.H, x.W, Cout, stride, Ho, Wo], l=[nb],
+                          p=[x, dyT, self.scratch("dw_wgrad_ws", nb), wgrad], tag=tag + ".wgrad")
+                if need_dgrad:
+                    self.emit("DWCONV_DGRAD", i=[dyT.ld, x.grad.ld, x.N, x.H, x.W, Cout, stride, Ho, Wo, self.grad_mode(x)],
+                              p=[dyT, weight, x.grad], tag=tag + ".dgrad")
+                return
             self.wgrad_cmds(tag, x, dyT, CinPad if (k > 1 or CinPad % 32 == 0) else _rup(Cin, 32), CoutPad, Cin, Cout, k,
                             stride, pad, wgrad)
             if need_dgrad:
