@@ -449,6 +449,21 @@ int mi_pairwise_bbox_iou(const float* box1, const float* box2, int N, int M, int
 int mi_batched_nms(const float* boxes, const float* scores, const float* idxs, int n, float iou_thr,
                    int32_t* order, uint64_t* mask, float* sboxes, int64_t* keep, int32_t* n_keep,
                    mi_stream_t s);
+/* the same with the IoU arithmetic chosen by the caller: -1 torchvision's choice by size, 0 class by class on the raw
+ * coordinates, 1 the per-class coordinate offsets.  0 is also what batched_clusternms (meta_arch/utils.py:66-95) computes:
+ * its fixed-point iteration over the IoU matrix converges to the greedy result. */
+int mi_batched_nms_ex(const float* boxes, const float* scores, const float* idxs, int n, float iou_thr, int arithmetic,
+                      int32_t* order, uint64_t* mask, float* sboxes, int64_t* keep, int32_t* n_keep, mi_stream_t s);
+/* class-aware Soft-NMS (batched_softnms, meta_arch/utils.py:33-63): scores are rescaled IN PLACE, keep[] receives the
+ * indices with score > score_threshold in descending score order (ties: ascending index).  sigma is the reference's
+ * iou_threshold argument; linear 0 = "gaussian" exp(-iou^2 / sigma), 1 = "linear".  n <= 16384. */
+int mi_batched_softnms(const float* boxes, float* scores, const float* idxs, int n, float sigma, float score_threshold,
+                       int linear, int64_t* keep, int32_t* n_keep, mi_stream_t s);
+/* Matrix NMS (utils/solov2_utils.py:160-206) from the mask-intersection matrix inter[n][n] = masks @ masks^T
+ * (candidates in descending score order), sum_masks[n], labels[n] (as float): out_scores[n] = scores * decay.
+ * comp_ws: n floats of scratch. */
+int mi_matrix_nms(const float* inter, const float* sum_masks, const float* labels, const float* scores, int n, float sigma,
+                  int linear, float* comp_ws, float* out_scores, mi_stream_t s);
 
 /* ---- fused SGD(momentum, weight-decay) over a flat parameter arena -----------
  * replaces torch.optim.SGD.step as built by detectron2's build_optimizer

@@ -260,6 +260,31 @@ def gold_yolox_iou():
     print("yolox_iou:", {k: float(np.abs(v).mean()) for k, v in res.items()})
 
 
+def gold_nms_family():
+    """the reference's own softnms (linear / gaussian), cluster NMS and matrix NMS (meta_arch/utils.py:33-113,
+    utils/solov2_utils.py:160-206) on seeded candidates"""
+    from gen_golden_inputs import synth_nms_case, synth_mask_case
+    r = ref_loader.load_nms_family()
+    res = {}
+    # case d: tight clusters and a high score threshold, so that Soft-NMS retires boxes
+    for name, (n, ncls, seed, spread, thr) in dict(a=(300, 5, 71, 14.0, 0.001), b=(1500, 80, 72, 14.0, 0.001),
+                                                   c=(7, 1, 73, 14.0, 0.001), d=(400, 2, 74, 4.0, 0.05)).items():
+        boxes, scores, idxs = synth_nms_case(n, ncls, seed, spread)
+        for t in ("softnms-linear", "softnms-gaussian", "cluster"):
+            sc = scores.clone()
+            keep = r.nms_utils.generalized_batched_nms(boxes.clone(), sc, idxs, 0.5, score_threshold=thr, nms_type=t)
+            res[f"{name}_{t}_keep"] = keep.numpy()
+            if t != "cluster":
+                res[f"{name}_{t}_scores"] = sc.numpy()
+    for name, (n, H, W, ncls, seed) in dict(m1=(60, 40, 48, 3, 81), m2=(500, 64, 64, 10, 82), m3=(1, 8, 8, 1, 83)).items():
+        labels, masks, sums, scores = synth_mask_case(n, H, W, ncls, seed)
+        for kern in ("gaussian", "linear"):
+            out = r.solov2_utils.matrix_nms(labels, masks, sums, scores, sigma=2.0, kernel=kern)
+            res[f"{name}_{kern}"] = out.numpy()
+    np.savez_compressed(os.path.join(OUT, "nms_family.npz"), **res)
+    print("nms family:", {k: v.shape for k, v in res.items() if "keep" in k or "m2" in k})
+
+
 def gold_encoder_layer():
     """the reference's own TransformerEncoderLayer (backbone/detr_backbone.py:135-194), eval mode (dropout off), fp32"""
     import importlib
@@ -515,6 +540,7 @@ if __name__ == "__main__":
     gold_hungarian()
     gold_iou_v6()
     gold_yolox_iou()
+    gold_nms_family()
     gold_encoder_layer()
     gold_transformer()
     gold_pos_embed()

@@ -172,3 +172,39 @@ def sparseinst_spread(sd):
         sd[k] = sd[k] * f
     sd["decoder.inst_branch.cls_score.bias"] = sd["decoder.inst_branch.cls_score.bias"] - 2.0
     return sd
+
+
+def synth_nms_case(n, ncls, seed, spread=14.0):
+    """overlapping boxes in clusters (xyxy), scores, class ids (as float, the way the meta-archs pass them)"""
+    g = torch.Generator().manual_seed(seed)
+    nc = max(2, n // 6)
+    centers = 40 + 500 * torch.rand(nc, 2, generator=g)
+    which = torch.randint(0, nc, (n,), generator=g)
+    c = centers[which] + spread * torch.randn(n, 2, generator=g)
+    wh = 30 + 60 * torch.rand(n, 2, generator=g)
+    boxes = torch.cat([c - wh / 2, c + wh / 2], 1)
+    scores = 0.05 + 0.9 * torch.rand(n, generator=g)
+    scores[: n // 10] = 0.0001 + 0.0008 * torch.rand(n // 10, generator=g)     # already below the score threshold (distinct:
+    #                                                                          the order of tied scores is unspecified)
+    idxs = torch.randint(0, ncls, (n,), generator=g).float()
+    return boxes, scores, idxs
+
+
+def synth_mask_case(n, H, W, ncls, seed):
+    """n binary masks (overlapping blobs), descending scores, labels: the inputs of matrix_nms"""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    nc = max(2, n // 5)
+    centers = torch.rand(nc, 2, generator=g) * torch.tensor([H, W]).float()
+    which = torch.randint(0, nc, (n,), generator=g)
+    c = centers[which] + 3 * torch.randn(n, 2, generator=g)
+    r = 4 + 8 * torch.rand(n, generator=g)
+    masks = (((yy[None] - c[:, 0, None, None]) ** 2 + (xx[None] - c[:, 1, None, None]) ** 2) < r[:, None, None] ** 2)
+    masks[0, 0, 0] = True                # no empty mask (the reference would divide 0 / 0)
+    masks = masks | (torch.arange(n)[:, None, None] == 10 ** 9)
+    for k in range(n):
+        if not masks[k].any():
+            masks[k, int(c[k, 0].clamp(0, H - 1)), int(c[k, 1].clamp(0, W - 1))] = True
+    scores = torch.sort(0.1 + 0.85 * torch.rand(n, generator=g), descending=True)[0]
+    labels = torch.randint(0, ncls, (n,), generator=g)
+    return labels, masks, masks.flatten(1).sum(1).float(), scores

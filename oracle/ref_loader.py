@@ -223,3 +223,39 @@ def load_sparseinst():
     out.decoder = importlib.import_module("yolov7.modeling.transcoders.decoder_sparseinst")
     out.loss = importlib.import_module("yolov7.modeling.loss.sparseinst_loss")
     return out
+
+
+def load_nms_family():
+    """the reference's NMS variants loaded by path: meta_arch/utils.py (softnms / cluster_nms / generalized_batched_nms) and
+    utils/solov2_utils.py (matrix_nms).  Their un-vendored imports are stubbed: detectron2.layers.nms.batched_nms and
+    torchvision.ops.boxes.box_iou are restated here (torchvision semantics; *parity unpinned* for those two, as for NMS
+    itself) - the soft / cluster / matrix arithmetic under test is the reference's own."""
+    import torch
+    load()
+    import yolox_oracle as oracle
+
+    def box_iou(b1, b2):      # torchvision.ops.boxes.box_iou
+        a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+        a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+        lt = torch.max(b1[:, None, :2], b2[:, :2])
+        rb = torch.min(b1[:, None, 2:], b2[:, 2:])
+        wh = (rb - lt).clamp(min=0)
+        inter = wh[:, :, 0] * wh[:, :, 1]
+        return inter / (a1[:, None] + a2 - inter)
+
+    _stub("detectron2.layers.nms", batched_nms=oracle.batched_nms)
+    sys.modules["torchvision.ops.boxes"].box_iou = box_iou
+    sys.modules["torchvision.ops"].boxes = sys.modules["torchvision.ops.boxes"]
+    cv2 = sys.modules["cv2"]
+    for k in ("INTER_NEAREST", "INTER_LINEAR", "INTER_CUBIC", "INTER_AREA", "INTER_LANCZOS4"):
+        if not hasattr(cv2, k):
+            setattr(cv2, k, 0)
+    y = os.path.join(REF, "yolov7")
+    if "yolov7.modeling.meta_arch" not in sys.modules:
+        m = types.ModuleType("yolov7.modeling.meta_arch")
+        m.__path__ = [os.path.join(y, "modeling", "meta_arch")]
+        sys.modules["yolov7.modeling.meta_arch"] = m
+    out = types.SimpleNamespace()
+    out.nms_utils = importlib.import_module("yolov7.modeling.meta_arch.utils")
+    out.solov2_utils = importlib.import_module("yolov7.utils.solov2_utils")
+    return out

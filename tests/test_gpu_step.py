@@ -536,3 +536,74 @@ def test_bn_backward_fused_step_equals_two_pass(monkeypatch, B, H, W):
             if r > 5e-2:
                 bad.append((n_, r))
         assert not bad, bad[:8]
+
+
+# ------------------------------------------------------------------------------------------------ NMS family (f3)
+NMS_CASES = dict(a=(300, 5, 71, 14.0, 0.001), b=(1500, 80, 72, 14.0, 0.001), c=(7, 1, 73, 14.0, 0.001), d=(400, 2, 74, 4.0, 0.05))
+
+
+@pytest.mark.parametrize("case", sorted(NMS_CASES))
+@pytest.mark.parametrize("nms_type", ["softnms-linear", "softnms-gaussian", "cluster"])
+def test_generalized_batched_nms_against_reference_golden(golden_dir, case, nms_type):
+    """MODEL.NMS_TYPE variants (meta_arch/utils.py:33-113) against the reference's own functions run on the same seeded
+    candidates: Soft-NMS rescales the scores in place (fp32 tolerance) and keeps what stays above the threshold, in
+    descending score order; Cluster-NMS's fixed point equals class-by-class greedy NMS (index sets identical)"""
+    import sys
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle")
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    from gen_golden_inputs import synth_nms_case
+    from yolov7_d2_amd.modeling import generalized_batched_nms
+    g = np.load(os.path.join(golden_dir, "nms_family.npz"))
+    n, ncls, seed, spread, thr = NMS_CASES[case]
+    boxes, scores, idxs = synth_nms_case(n, ncls, seed, spread)
+    sc = scores.clone().to(DEV)
+    keep = generalized_batched_nms(boxes.to(DEV), sc, idxs.to(DEV), 0.5, score_threshold=thr, nms_type=nms_type).cpu().numpy()
+    ref_keep = g[f"{case}_{nms_type}_keep"]
+    if nms_type == "cluster":
+        assert sorted(keep.tolist()) == sorted(ref_keep.tolist())
+        assert np.all(np.diff(scores.numpy()[keep]) <= 0)                       # descending score
+        assert torch.equal(sc.cpu(), scores)                                     # scores untouched
+        return
+    ref_sc = g[f"{case}_{nms_type}_scores"]
+    np.testing.assert_allclose(sc.cpu().numpy(), ref_sc, rtol=2e-5, atol=1e-7)
+    # membership: everything clearly above / below the threshold agrees (a score within 1e-5 of it may fall either side)
+    clear = np.abs(ref_sc - thr) > 1e-5 * max(thr, 1e-3)
+    mine, theirs = np.zeros(n, bool), np.zeros(n, bool)
+    mine[keep] = True; theirs[ref_keep] = True
+    assert np.array_equal(mine[clear], theirs[clear])
+    assert np.all(np.diff(sc.cpu().numpy()[keep]) <= 0)
+    if case == "d":
+        assert theirs.sum() < 0.8 * n      # the case really retires boxes
+
+
+def test_generalized_batched_nms_dispatch_and_edges():
+    from yolov7_d2_amd.modeling import generalized_batched_nms, batched_nms
+    b = torch.tensor([[0, 0, 10, 10], [1, 1, 11, 11], [50, 50, 60, 60]], dtype=torch.float32, device=DEV)
+    s = torch.tensor([0.9, 0.8, 0.7], device=DEV)
+    i = torch.zeros(3, device=DEV)
+    assert generalized_batched_nms(b, s.clone(), i, 0.5, nms_type="normal").tolist() == batched_nms(b, s, i, 0.5).tolist() == [0, 2]
+    with pytest.raises(NotImplementedError):
+        generalized_batched_nms(b, s.clone(), i, 0.5, nms_type="matrix")
+    e = generalized_batched_nms(b[:0], s[:0].clone(), i[:0], 0.5, nms_type="softnms-gaussian")
+    assert e.numel() == 0 and e.dtype == torch.int64
+    with pytest.raises(ValueError):
+        generalized_batched_nms(b, s.double(), i, 0.5, nms_type="softnms-linear")
+
+
+@pytest.mark.parametrize("case,n,H,W,ncls,seed", [("m1", 60, 40, 48, 3, 81), ("m2", 500, 64, 64, 10, 82), ("m3", 1, 8, 8, 1, 83)])
+@pytest.mark.parametrize("kernel", ["gaussian", "linear"])
+def test_matrix_nms_against_reference_golden(golden_dir, case, n, H, W, ncls, seed, kernel):
+    """SOLOv2's Matrix NMS (utils/solov2_utils.py:160-206) against the reference function: the mask-intersection matrix
+    comes from the MFMA pixel-sum kernel (exact integers), the decay is fp32"""
+    import sys
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle")
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    from gen_golden_inputs import synth_mask_case
+    from yolov7_d2_amd.modeling import matrix_nms
+    g = np.load(os.path.join(golden_dir, "nms_family.npz"))
+    labels, masks, sums, scores = synth_mask_case(n, H, W, ncls, seed)
+    out = matrix_nms(labels.to(DEV), masks.to(DEV), sums.to(DEV), scores.to(DEV), sigma=2.0, kernel=kernel)
+    np.testing.assert_allclose(out.cpu().numpy(), g[f"{case}_{kernel}"], rtol=2e-5, atol=1e-7)
+    assert matrix_nms(labels[:0], masks[:0], sums[:0], scores[:0]) == []

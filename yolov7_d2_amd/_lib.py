@@ -188,6 +188,9 @@ _PROTOS = {
     "mi_dwconv3x3_dgrad": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "mi_dwconv3x3_wgrad_ws_bytes": (C.c_int64, [_i]),
     "mi_dwconv3x3_wgrad": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _vp]),
+    "mi_batched_nms_ex": (C.c_int, [_vp, _vp, _vp, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mi_batched_softnms": (C.c_int, [_vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp, _vp]),
+    "mi_matrix_nms": (C.c_int, [_vp, _vp, _vp, _vp, _i, _f, _i, _vp, _vp, _vp]),
     "mi_yolox_onnx_layout": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
     "mi_yolox_iou_loss": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "mi_pairwise_bbox_iou": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -139,7 +139,13 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const uint64_t* __restrict
 extern "C" int mi_batched_nms(const float* boxes, const float* scores, const float* idxs, int n, float iou_thr,
                               int32_t* order, uint64_t* mask, float* sboxes, int64_t* keep, int32_t* n_keep,
                               mi_stream_t st) {
+  return mi_batched_nms_ex(boxes, scores, idxs, n, iou_thr, -1, order, mask, sboxes, keep, n_keep, st);
+}
+extern "C" int mi_batched_nms_ex(const float* boxes, const float* scores, const float* idxs, int n, float iou_thr,
+                                 int arithmetic, int32_t* order, uint64_t* mask, float* sboxes, int64_t* keep,
+                                 int32_t* n_keep, mi_stream_t st) {
   MI_REQUIRE(n_keep && (n == 0 || (boxes && scores && idxs && order && mask && sboxes && keep)), "nms: null");
+  MI_REQUIRE(arithmetic >= -1 && arithmetic <= 1, "nms: arithmetic %d (-1 torchvision's choice, 0 per class, 1 offsets)", arithmetic);
   hipStream_t s = (hipStream_t)st;
   if (n == 0) {
     if (hipMemsetAsync(n_keep, 0, sizeof(int32_t), s) != hipSuccess) MI_FAIL(MI_ELAUNCH, "nms: memset");
@@ -148,7 +154,7 @@ extern "C" int mi_batched_nms(const float* boxes, const float* scores, const flo
   MI_REQUIRE(n <= 65536, "nms: n %d too large", n);
   const int nw = mi_cdiv(n, 64);
   // torchvision: coordinate trick when boxes.numel() <= 4000, per-class NMS above
-  const int mode = (4 * (int64_t)n > 4000) ? 0 : 1;
+  const int mode = arithmetic >= 0 ? arithmetic : ((4 * (int64_t)n > 4000) ? 0 : 1);
   float* scls = sboxes + (size_t)n * 4;   // caller provides n*5 + 1 floats
   float* maxc = scls + n;
   const int nb = mi_cdiv(n, 256);
@@ -158,5 +164,177 @@ extern "C" int mi_batched_nms(const float* boxes, const float* scores, const flo
   hipLaunchKernelGGL(nms_mask_kernel, dim3(nw, nw), dim3(64), 0, s, sboxes, scls, n, iou_thr, mode, mask, nw);
   hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), nw * sizeof(uint64_t), s, mask, order, n, nw, keep, n_keep);
   MI_CHECK_LAUNCH("nms");
+  return MI_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Soft-NMS, class-aware (batched_softnms / softnms / scale_by_iou, yolov7/modeling/meta_arch/utils.py:7-63):
+// repeatedly take the highest-scoring undone box, rescale the scores of the undone boxes of ITS class by
+// exp(-iou^2 / sigma) ("gaussian") or (1 - iou where iou >= sigma) ("linear"), retire what fell below the score threshold.
+// The reference loops class by class; classes do not interact, so one global sequence of "take the maximum" visits
+// every class's boxes in that class's own order and gives the same scores.  A class's last undone box is never
+// "taken" by the reference (while undone.sum() > 1); taking it here touches nothing.
+// One block of 1024 threads, SNMS_PER boxes per thread in registers (n <= 16384): an iteration is a block-wide arg-max
+// (score descending, index ascending = torch.argmax's first maximum) and one pass over the registers.
+#define SNMS_T 1024
+#define SNMS_PER 16
+__global__ __launch_bounds__(SNMS_T) void softnms_kernel(const float* __restrict__ boxes, float* __restrict__ scores,
+                                                         const float* __restrict__ idxs, int n, float sigma, float thr,
+                                                         int linear) {
+  __shared__ float s_v[SNMS_T / 64];
+  __shared__ int s_i[SNMS_T / 64];
+  __shared__ float s_top[6];
+  __shared__ int s_topi;
+  const int tid = threadIdx.x;
+  float bx[SNMS_PER][4], sc[SNMS_PER], cl[SNMS_PER];
+  bool undone[SNMS_PER];
+#pragma unroll
+  for (int k = 0; k < SNMS_PER; ++k) {
+    const int i = k * SNMS_T + tid;
+    undone[k] = false;
+    if (i < n) {
+      for (int c = 0; c < 4; ++c) bx[k][c] = boxes[(size_t)i * 4 + c];
+      sc[k] = scores[i];
+      cl[k] = idxs[i];
+      undone[k] = sc[k] >= thr;
+    }
+  }
+  for (int iter = 0; iter < n; ++iter) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < SNMS_PER; ++k) {
+      const int i = k * SNMS_T + tid;
+      if (undone[k] && (sc[k] > bv || (sc[k] == bv && i < bi))) { bv = sc[k]; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { s_v[tid >> 6] = bv; s_i[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      float v = s_v[0];
+      int ix = s_i[0];
+      for (int w = 1; w < SNMS_T / 64; ++w)
+        if (s_v[w] > v || (s_v[w] == v && s_i[w] < ix)) { v = s_v[w]; ix = s_i[w]; }
+      s_topi = ix;
+    }
+    __syncthreads();
+    const int top = s_topi;
+    if (top == 0x7fffffff) break;   // nothing undone
+    if ((top % SNMS_T) == tid) {    // the owner publishes the box and retires it
+      const int k = top / SNMS_T;
+#pragma unroll
+      for (int q = 0; q < SNMS_PER; ++q)
+        if (q == k) {
+          s_top[0] = bx[q][0]; s_top[1] = bx[q][1]; s_top[2] = bx[q][2]; s_top[3] = bx[q][3]; s_top[4] = cl[q];
+          undone[q] = false;
+        }
+    }
+    __syncthreads();
+    const float t0 = s_top[0], t1 = s_top[1], t2 = s_top[2], t3 = s_top[3], tc = s_top[4];
+    const float tarea = (t2 - t0) * (t3 - t1);
+#pragma unroll
+    for (int k = 0; k < SNMS_PER; ++k) {
+      if (undone[k] && cl[k] == tc) {
+        // iou(): clamp the candidate's corners into the top box (utils.py:7-18)
+        const float x1 = fmaxf(bx[k][0], t0), y1 = fmaxf(bx[k][1], t1), x2 = fminf(bx[k][2], t2), y2 = fminf(bx[k][3], t3);
+        const float inter = fmaxf(x2 - x1, 0.f) * fmaxf(y2 - y1, 0.f);
+        const float area = (bx[k][2] - bx[k][0]) * (bx[k][3] - bx[k][1]);
+        const float iou = inter / (tarea + area - inter);
+        const float scale = linear ? (iou >= sigma ? 1.f - iou : 1.f) : expf(-(iou * iou) / sigma);
+        sc[k] *= scale;
+        if (sc[k] < thr) undone[k] = false;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < SNMS_PER; ++k) {
+    const int i = k * SNMS_T + tid;
+    if (i < n) scores[i] = sc[k];
+  }
+}
+// keep = indices with score > thr, descending score (ties: ascending index)
+__global__ __launch_bounds__(256) void softnms_keep_kernel(const float* __restrict__ scores, int n, float thr,
+                                                           int64_t* __restrict__ keep, int32_t* __restrict__ n_keep) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = scores[i];
+  if (!(v > thr)) return;
+  int rank = 0;
+  for (int j = 0; j < n; ++j) {
+    const float u = scores[j];
+    rank += (u > thr) && (u > v || (u == v && j < i));
+  }
+  keep[rank] = i;
+  atomicAdd(n_keep, 1);
+}
+extern "C" int mi_batched_softnms(const float* boxes, float* scores, const float* idxs, int n, float sigma,
+                                  float score_threshold, int linear, int64_t* keep, int32_t* n_keep, mi_stream_t st) {
+  MI_REQUIRE(n_keep && (n == 0 || (boxes && scores && idxs && keep)), "softnms: null");
+  MI_REQUIRE(n >= 0 && n <= SNMS_T * SNMS_PER, "softnms: n %d (at most %d boxes)", n, SNMS_T * SNMS_PER);
+  hipStream_t s = (hipStream_t)st;
+  if (hipMemsetAsync(n_keep, 0, sizeof(int32_t), s) != hipSuccess) MI_FAIL(MI_ELAUNCH, "softnms: memset");
+  if (n == 0) return MI_OK;
+  hipLaunchKernelGGL(softnms_kernel, dim3(1), dim3(SNMS_T), 0, s, boxes, scores, idxs, n, sigma, score_threshold, linear);
+  hipLaunchKernelGGL(softnms_keep_kernel, dim3(mi_cdiv(n, 256)), dim3(256), 0, s, scores, n, score_threshold, keep, n_keep);
+  MI_CHECK_LAUNCH("softnms");
+  return MI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Matrix NMS (SOLOv2; yolov7/utils/solov2_utils.py:160-206) on the mask-intersection matrix inter[n][n] =
+// masks @ masks^T (exact in any float format: 0 / 1 masks): score decay of candidate j by every higher-ranked candidate i
+// of the same class, compensated by how much i itself was overlapped.  Candidates are in descending score order.
+//   iou[i][j] = inter / (sum_i + sum_j - inter) for i < j, else 0;   delay = iou where the labels agree, else 0
+//   comp[i] = max_k delay[k][i];   coef[j] = min over ALL i of  f(delay[i][j]) / f(comp[i])
+//   f = exp(-sigma x^2) (gaussian) or 1 - x (linear);   score[j] *= coef[j]
+__global__ __launch_bounds__(256) void matrix_nms_comp_kernel(const float* __restrict__ inter, const float* __restrict__ sums,
+                                                              const float* __restrict__ labels, int n, float* comp) {
+  const int i = blockIdx.x * 256 + threadIdx.x;   // column
+  if (i >= n) return;
+  float m = 0.f;                                   // the masked matrix holds zeros: the maximum is at least 0
+  const float li = labels[i], si = sums[i];
+  for (int k = 0; k < i; ++k) {
+    if (labels[k] != li) continue;
+    const float in = inter[(size_t)k * n + i];
+    m = fmaxf(m, in / (sums[k] + si - in));
+  }
+  comp[i] = m;
+}
+__global__ __launch_bounds__(256) void matrix_nms_decay_kernel(const float* __restrict__ inter, const float* __restrict__ sums,
+                                                               const float* __restrict__ labels, const float* __restrict__ comp,
+                                                               const float* __restrict__ scores, int n, float sigma, int linear,
+                                                               float* __restrict__ out) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const float lj = labels[j], sj = sums[j];
+  float coef = INFINITY;
+  for (int i = 0; i < n; ++i) {
+    float d = 0.f;
+    if (i < j && labels[i] == lj) {
+      const float in = inter[(size_t)i * n + j];
+      d = in / (sums[i] + sj - in);
+    }
+    const float c = comp[i];
+    const float r = linear ? (1.f - d) / (1.f - c) : expf(-sigma * d * d) / expf(-sigma * c * c);
+    coef = fminf(coef, r);
+  }
+  out[j] = scores[j] * coef;
+}
+extern "C" int mi_matrix_nms(const float* inter, const float* sum_masks, const float* labels, const float* scores, int n,
+                             float sigma, int linear, float* comp_ws, float* out_scores, mi_stream_t st) {
+  MI_REQUIRE(n >= 0, "matrix_nms: n");
+  if (n == 0) return MI_OK;
+  MI_REQUIRE(inter && sum_masks && labels && scores && comp_ws && out_scores, "matrix_nms: null");
+  hipStream_t s = (hipStream_t)st;
+  hipLaunchKernelGGL(matrix_nms_comp_kernel, dim3(mi_cdiv(n, 256)), dim3(256), 0, s, inter, sum_masks, labels, n, comp_ws);
+  hipLaunchKernelGGL(matrix_nms_decay_kernel, dim3(mi_cdiv(n, 256)), dim3(256), 0, s, inter, sum_masks, labels, comp_ws,
+                     scores, n, sigma, linear, out_scores);
+  MI_CHECK_LAUNCH("matrix_nms");
   return MI_OK;
 }

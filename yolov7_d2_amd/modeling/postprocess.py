@@ -54,3 +54,93 @@ def postprocess(prediction, num_classes, conf_thre=0.7, nms_thre=0.45):
         keep = batched_nms(detections[:, :4], detections[:, 4] * detections[:, 5], detections[:, 6], nms_thre)
         output[i] = detections[keep]
     return output
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the NMS family of the sibling heads: yolov7/modeling/meta_arch/utils.py:33-113 and
+# yolov7/utils/solov2_utils.py:160-206
+def _nms_ex(boxes, scores, idxs, iou_threshold, arithmetic):
+    n, dev = boxes.shape[0], boxes.device
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=dev)
+    boxes, scores, idxs = boxes.contiguous().float(), scores.contiguous().float(), idxs.contiguous().float()
+    nw = (n + 63) // 64
+    order = torch.empty(n, dtype=torch.int32, device=dev)
+    mask = torch.empty(n * nw, dtype=torch.int64, device=dev)
+    sboxes = torch.empty(5 * n + 1, dtype=torch.float32, device=dev)
+    keep = torch.empty(n, dtype=torch.int64, device=dev)
+    nkeep = torch.zeros(1, dtype=torch.int32, device=dev)
+    L.check(L.lib().mi_batched_nms_ex(boxes.data_ptr(), scores.data_ptr(), idxs.data_ptr(), n, float(iou_threshold),
+                                      arithmetic, order.data_ptr(), mask.data_ptr(), sboxes.data_ptr(), keep.data_ptr(),
+                                      nkeep.data_ptr(), L.stream_ptr()), "mi_batched_nms_ex")
+    return keep[: int(nkeep.item())]
+
+
+def batched_softnms(boxes, scores, idxs, iou_threshold, score_threshold=0.001, soft_mode="gaussian"):
+    """meta_arch/utils.py:47-63: class-aware Soft-NMS; `scores` is rescaled IN PLACE (as the reference does) and the
+    indices with score > score_threshold come back in descending score order"""
+    assert soft_mode in ["linear", "gaussian"]
+    assert boxes.shape[-1] == 4
+    if not boxes.is_cuda:
+        raise L.MI355Error("batched_softnms: HIP tensors required (no CPU fallback)")
+    n, dev = boxes.shape[0], boxes.device
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=dev)
+    if not (scores.dtype == torch.float32 and scores.is_contiguous()):
+        raise ValueError("batched_softnms rescales `scores` in place: pass a contiguous float32 tensor")
+    b, ix = boxes.contiguous().float(), idxs.contiguous().float()
+    keep = torch.empty(n, dtype=torch.int64, device=dev)
+    nkeep = torch.zeros(1, dtype=torch.int32, device=dev)
+    L.check(L.lib().mi_batched_softnms(b.data_ptr(), scores.data_ptr(), ix.data_ptr(), n, float(iou_threshold),
+                                       float(score_threshold), int(soft_mode == "linear"), keep.data_ptr(), nkeep.data_ptr(),
+                                       L.stream_ptr()), "mi_batched_softnms")
+    return keep[: int(nkeep.item())]
+
+
+def batched_clusternms(boxes, scores, idxs, iou_threshold):
+    """meta_arch/utils.py:66-95.  Cluster-NMS iterates keep = (max_i keep_i * iou_ij <= thr) over the score-sorted,
+    upper-triangular IoU matrix of one class until nothing changes; that fixed point IS the greedy NMS result (box j is
+    dropped iff a KEPT higher-scoring box overlaps it by more than thr), so the class-by-class NMS kernel computes it in
+    one pass."""
+    assert boxes.shape[-1] == 4
+    if not boxes.is_cuda:
+        raise L.MI355Error("batched_clusternms: HIP tensors required (no CPU fallback)")
+    return _nms_ex(boxes, scores, idxs, iou_threshold, 0)
+
+
+def generalized_batched_nms(boxes, scores, idxs, iou_threshold, score_threshold=0.001, nms_type="normal"):
+    """meta_arch/utils.py:98-113 (MODEL.NMS_TYPE): "normal", "softnms-linear", "softnms-gaussian", "cluster" """
+    assert boxes.shape[-1] == 4
+    if nms_type == "normal":
+        return batched_nms(boxes, scores, idxs, iou_threshold)
+    if nms_type.startswith("softnms"):
+        return batched_softnms(boxes, scores, idxs, iou_threshold, score_threshold=score_threshold,
+                               soft_mode=nms_type.lstrip("softnms-"))      # (sic) the reference's way to drop the prefix
+    if nms_type == "cluster":
+        return batched_clusternms(boxes, scores, idxs, iou_threshold)
+    raise NotImplementedError("NMS type not implemented: \"{}\"".format(nms_type))
+
+
+def matrix_nms(cate_labels, seg_masks, sum_masks, cate_scores, sigma=2.0, kernel="gaussian"):
+    """utils/solov2_utils.py:160-206 (SOLOv2): decayed scores of n mask candidates sorted by descending score.
+    The n x n mask intersections are one MFMA pass over the pixels (masks are 0 / 1: exact in bf16 with fp32 sums)."""
+    n = len(cate_labels)
+    if n == 0:
+        return []
+    if not seg_masks.is_cuda:
+        raise L.MI355Error("matrix_nms: HIP tensors required (no CPU fallback)")
+    from .sparseinst import pixel_outer
+    dev = seg_masks.device
+    m = seg_masks.reshape(n, -1)
+    P = m.shape[1]
+    npad, ppad = (n + 31) // 32 * 32, (P + 7) // 8 * 8
+    mt = torch.zeros(ppad, npad, dtype=torch.bfloat16, device=dev)      # pixels x candidates, zero padded
+    mt[:P, :n] = m.t().to(torch.bfloat16)
+    inter = pixel_outer(mt, mt)[:n, :n].contiguous()
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    comp = torch.empty(n, dtype=torch.float32, device=dev)
+    L.check(L.lib().mi_matrix_nms(inter.data_ptr(), sum_masks.contiguous().float().data_ptr(),
+                                  cate_labels.contiguous().float().data_ptr(), cate_scores.contiguous().float().data_ptr(), n,
+                                  float(sigma), int(kernel == "linear"), comp.data_ptr(), out.data_ptr(), L.stream_ptr()),
+            "mi_matrix_nms")
+    return out
