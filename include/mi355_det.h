@@ -315,6 +315,11 @@ typedef struct mi_yolox_loss_desc {
    * meta_arch/yolox.py:105-118): adds sum|raw_reg - get_l1_target| / num_fg to the total; 0 = the default */
   int32_t use_l1, rsv_;
   float* partial_l1;    /* [nblk] (use_l1 only) */
+  /* the YOLOv6 head's form of this loss (ComputeLoss, head/yolov6_head.py:315-754) differs in constants only; a zero
+   * selects the YOLOX value: centre radius 2.5, SimOTA cost weights cls 1 / iou 3, box-loss weight 5 */
+  float center_radius, cls_weight, iou_weight, reg_weight;
+  int32_t iou_type;     /* box loss: 0 IOUloss "iou" (1 - iou^2); 1..4 IOUlossV6 giou / diou / ciou / siou, eps 1e-7 */
+  int32_t rsv2_;
 } mi_yolox_loss_desc;
 int mi_yolox_loss_fwd(const mi_yolox_loss_desc* d, mi_stream_t s);
 /* gradient wrt raw preds; gw[4] = upstream grads of (total, 5*iou, obj, cls) on device (+ gw[4] = of l1 iff use_l1).

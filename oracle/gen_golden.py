@@ -285,6 +285,29 @@ def gold_nms_family():
     print("nms family:", {k: v.shape for k, v in res.items() if "keep" in k or "m2" in k})
 
 
+def gold_yolov6_loss():
+    """the reference's ComputeLoss (head/yolov6_head.py:315-754) on seeded head outputs: total, the four components and
+    the gradient with respect to the raw outputs, for two parameter sets"""
+    import contextlib, io
+    from gen_golden_inputs import synth_yolov6_case
+    m = ref_loader.load_yolov6_loss()
+    res = {}
+    for name, kw in dict(ciou=dict(iou_type="ciou"),
+                         siou=dict(iou_type="siou", center_radius=1.5, iou_weight=2.0, cls_weight=0.5, reg_weight=2.5)).items():
+        outs, t, _, _, _ = synth_yolov6_case()
+        outs = [o.requires_grad_(True) for o in outs]
+        cl = m.ComputeLoss(**kw)
+        with contextlib.redirect_stdout(io.StringIO()):        # the reference prints the targets
+            total, parts = cl([o * 1.0 for o in outs], t)      # (it decodes in place: hand it non-leaf tensors)
+        total.sum().backward()
+        res[name + "_total"] = total.detach().numpy()
+        res[name + "_parts"] = parts.numpy()
+        res[name + "_grad"] = torch.cat([o.grad.reshape(o.shape[0], -1, o.shape[-1]) for o in outs], 1).numpy()
+        res[name + "_targets_after"] = t.numpy()
+    np.savez_compressed(os.path.join(OUT, "yolov6_loss.npz"), **res)
+    print("yolov6 loss:", {k: v for k, v in res.items() if "parts" in k or "total" in k})
+
+
 def gold_encoder_layer():
     """the reference's own TransformerEncoderLayer (backbone/detr_backbone.py:135-194), eval mode (dropout off), fp32"""
     import importlib
@@ -541,6 +564,7 @@ if __name__ == "__main__":
     gold_iou_v6()
     gold_yolox_iou()
     gold_nms_family()
+    gold_yolov6_loss()
     gold_encoder_layer()
     gold_transformer()
     gold_pos_embed()

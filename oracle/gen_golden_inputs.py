@@ -208,3 +208,21 @@ def synth_mask_case(n, H, W, ncls, seed):
     scores = torch.sort(0.1 + 0.85 * torch.rand(n, generator=g), descending=True)[0]
     labels = torch.randint(0, ncls, (n,), generator=g)
     return labels, masks, masks.flatten(1).sum(1).float(), scores
+
+
+def synth_yolov6_case(B=3, H=160, W=192, seed=91, nc=80):
+    """raw head outputs per level [B, 1, h, w, 5 + nc] and NORMALISED targets [B, 30, 5] for ComputeLoss"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import yolox_oracle as O
+    _, labels = O.synth_batch(B, H, W, seed=seed, max_gt=10, min_gt=4)
+    labels[1] = 0.0
+    hw = [(H // s, W // s) for s in (8, 16, 32)]
+    raw, anchors = O.synth_raw(B, hw, seed + 1, labels=labels)
+    outs, a0 = [], 0
+    for (h, w) in hw:
+        outs.append(raw[:, a0:a0 + h * w].reshape(B, 1, h, w, 5 + nc).clone())
+        a0 += h * w
+    t = labels.clone()
+    t[..., 1:5] = t[..., 1:5] / torch.tensor([W, H, W, H]).float()
+    return outs, t, labels, raw, anchors

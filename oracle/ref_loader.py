@@ -259,3 +259,13 @@ def load_nms_family():
     out.nms_utils = importlib.import_module("yolov7.modeling.meta_arch.utils")
     out.solov2_utils = importlib.import_module("yolov7.utils.solov2_utils")
     return out
+
+
+def load_yolov6_loss():
+    """head/yolov6_head.py loaded by path for its ComputeLoss (SimOTA + IOUlossV6 + L1).  The EfficientRep `Conv` import
+    (unused by the loss) and `alfred.print_shape` (a debug print) are stubbed."""
+    from torch import nn
+    load()
+    _stub("alfred", print_shape=lambda *a, **k: None)
+    _stub("yolov7.modeling.backbone.efficientrep", Conv=nn.Module)
+    return importlib.import_module("yolov7.modeling.head.yolov6_head")

@@ -203,9 +203,11 @@ def iou_loss(pred, target):
 
 # ----------------------------------------------------------------------------- SimOTA
 @torch.no_grad()
-def simota_image(gt, gcls, bbox, obj_logit, cls_logit, anchors, num_classes):
+def simota_image(gt, gcls, bbox, obj_logit, cls_logit, anchors, num_classes, center_radius=2.5, cls_weight=1.0,
+                 iou_weight=3.0):
     """one image. gt [G,4] cxcywh, gcls [G]; bbox [A,4] decoded; returns dict with the reference's
-    intermediate and final assignment tensors (yolox_head.py:450-669)."""
+    intermediate and final assignment tensors (yolox_head.py:450-669).  The keyword arguments are the constants the
+    YOLOv6 head's copy of this code makes configurable (yolov6_head.py:320-337, 597-754)."""
     G, A = gt.shape[0], bbox.shape[0]
     s = anchors[:, 2]
     xc = (anchors[:, 0] * s + 0.5 * s)[None].repeat(G, 1)
@@ -213,7 +215,7 @@ def simota_image(gt, gcls, bbox, obj_logit, cls_logit, anchors, num_classes):
     l_, r_ = (gt[:, 0] - 0.5 * gt[:, 2])[:, None], (gt[:, 0] + 0.5 * gt[:, 2])[:, None]
     t_, b_ = (gt[:, 1] - 0.5 * gt[:, 3])[:, None], (gt[:, 1] + 0.5 * gt[:, 3])[:, None]
     in_box = torch.stack([xc - l_, yc - t_, r_ - xc, b_ - yc], 2).min(-1).values > 0.0
-    rad = 2.5 * s[None]
+    rad = center_radius * s[None]
     cl, cr = gt[:, 0:1] - rad, gt[:, 0:1] + rad
     ct, cb = gt[:, 1:2] - rad, gt[:, 1:2] + rad
     in_ctr = torch.stack([xc - cl, yc - ct, cr - xc, cb - yc], 2).min(-1).values > 0.0
@@ -225,7 +227,7 @@ def simota_image(gt, gcls, bbox, obj_logit, cls_logit, anchors, num_classes):
     onehot = F.one_hot(gcls.to(torch.int64), num_classes).float()                                   # [G, nc]
     cls_cost = F.binary_cross_entropy(p[None].repeat(G, 1, 1), onehot[:, None].repeat(1, p.shape[0], 1),
                                       reduction="none").sum(-1)
-    cost = cls_cost + 3.0 * iou_cost + 100000.0 * (~both)
+    cost = cls_weight * cls_cost + iou_weight * iou_cost + 100000.0 * (~both)
     # dynamic-k
     M = torch.zeros_like(cost)
     nk = min(10, iou.size(1))
@@ -253,11 +255,57 @@ def l1_target(gt, stride, x_shifts, y_shifts, eps=1e-8):
                         torch.log(gt[:, 2] / stride + eps), torch.log(gt[:, 3] / stride + eps)], 1)
 
 
-def yolox_losses(raw, labels, anchors, num_classes=80, return_assign=False, use_l1=False):
+def iou_loss_v6(pred, target, iou_type="ciou", eps=1e-7):
+    """IOUlossV6 (utils/boxes.py:666-752), box_format "xywh", reduction "none": pred / target [n,4] (cx,cy,w,h)"""
+    px1, px2 = pred[:, 0] - pred[:, 2] / 2, pred[:, 0] + pred[:, 2] / 2
+    py1, py2 = pred[:, 1] - pred[:, 3] / 2, pred[:, 1] + pred[:, 3] / 2
+    tx1, tx2 = target[:, 0] - target[:, 2] / 2, target[:, 0] + target[:, 2] / 2
+    ty1, ty2 = target[:, 1] - target[:, 3] / 2, target[:, 1] + target[:, 3] / 2
+    inter = (torch.min(px2, tx2) - torch.max(px1, tx1)).clamp(0) * (torch.min(py2, ty2) - torch.max(py1, ty1)).clamp(0)
+    w1, h1 = px2 - px1, py2 - py1 + eps
+    w2, h2 = tx2 - tx1, ty2 - ty1 + eps
+    union = w1 * h1 + w2 * h2 - inter + eps
+    iou = inter / union
+    cw = torch.max(px2, tx2) - torch.min(px1, tx1)
+    ch = torch.max(py2, ty2) - torch.min(py1, ty1)
+    if iou_type == "giou":
+        ca = cw * ch + eps
+        iou = iou - (ca - union) / ca
+    elif iou_type in ("diou", "ciou"):
+        c2 = cw ** 2 + ch ** 2 + eps
+        rho2 = ((tx1 + tx2 - px1 - px2) ** 2 + (ty1 + ty2 - py1 - py2) ** 2) / 4
+        if iou_type == "diou":
+            iou = iou - rho2 / c2
+        else:
+            v = (4 / math.pi ** 2) * (torch.atan(w2 / h2) - torch.atan(w1 / h1)) ** 2
+            with torch.no_grad():
+                alpha = v / (v - iou + (1 + eps))
+            iou = iou - (rho2 / c2 + v * alpha)
+    elif iou_type == "siou":
+        scw, sch = (tx1 + tx2 - px1 - px2) * 0.5, (ty1 + ty2 - py1 - py2) * 0.5
+        sigma = (scw ** 2 + sch ** 2) ** 0.5
+        s1, s2 = scw.abs() / sigma, sch.abs() / sigma
+        sa = torch.where(s1 > 2 ** 0.5 / 2, s2, s1)
+        angle = torch.cos(torch.arcsin(sa) * 2 - math.pi / 2)
+        gamma = angle - 2
+        dist = 2 - torch.exp(gamma * (scw / cw) ** 2) - torch.exp(gamma * (sch / ch) ** 2)
+        ow, oh = (w1 - w2).abs() / torch.max(w1, w2), (h1 - h2).abs() / torch.max(h1, h2)
+        shape = (1 - torch.exp(-ow)) ** 4 + (1 - torch.exp(-oh)) ** 4
+        iou = iou - 0.5 * (dist + shape)
+    elif iou_type != "iou":
+        raise ValueError(iou_type)
+    return 1.0 - iou
+
+
+def yolox_losses(raw, labels, anchors, num_classes=80, return_assign=False, use_l1=False, center_radius=2.5,
+                 cls_weight=1.0, iou_weight=3.0, reg_weight=5.0, iou_type=None):
     """get_losses (yolox_head.py:274-441) on raw head output [B,A,5+nc] and labels [B,L,5].
     returns (total, 5*iou, obj, cls, l1, num_fg/num_gt) (+ per-image assignments); l1 (head.use_l1, :389-427) is
     nn.L1Loss(reduction="none") between the RAW regression outputs of the foreground anchors and get_l1_target,
-    summed / num_fg, and 0.0 when the switch is off"""
+    summed / num_fg, and 0.0 when the switch is off.
+    The YOLOv6 head's ComputeLoss (yolov6_head.py:315-531) is the same computation with configurable constants
+    (center_radius, cls_weight, iou_weight, reg_weight), an IOUlossV6 box loss (iou_type "giou" / "diou" / "ciou" /
+    "siou"; None = the YOLOX head's 1 - iou^2) and the l1 term always on."""
     out = decode(raw, anchors)
     bbox, obj, cls = out[..., :4], out[..., 4:5], out[..., 5:]
     nlabel = (labels.sum(dim=2) > 0).sum(dim=1)
@@ -276,7 +324,8 @@ def yolox_losses(raw, labels, anchors, num_classes=80, return_assign=False, use_
             l1_t.append(raw.new_zeros((0, 4)))
             continue
         gt, gcls = labels[b, :G, 1:5], labels[b, :G, 0]
-        a = simota_image(gt, gcls, bbox[b].detach(), obj[b, :, 0].detach(), cls[b].detach(), anchors, num_classes)
+        a = simota_image(gt, gcls, bbox[b].detach(), obj[b, :, 0].detach(), cls[b].detach(), anchors, num_classes,
+                         center_radius, cls_weight, iou_weight)
         assigns.append(a)
         num_fg += a["num_fg"]
         cls_t.append(F.one_hot(a["matched_cls"].to(torch.int64), num_classes) * a["matched_iou"].unsqueeze(-1))
@@ -287,14 +336,17 @@ def yolox_losses(raw, labels, anchors, num_classes=80, return_assign=False, use_
             l1_t.append(l1_target(gt[a["matched_gt"]], anchors[a["fg"], 2], anchors[a["fg"], 0], anchors[a["fg"], 1]))
     cls_t, reg_t, obj_t, fg = torch.cat(cls_t, 0), torch.cat(reg_t, 0), torch.cat(obj_t, 0), torch.cat(fgs, 0)
     num_fg = max(num_fg, 1)
-    l_iou = iou_loss(bbox.reshape(-1, 4)[fg], reg_t).sum() / num_fg
+    if iou_type is None:
+        l_iou = iou_loss(bbox.reshape(-1, 4)[fg], reg_t).sum() / num_fg
+    else:
+        l_iou = iou_loss_v6(bbox.reshape(-1, 4)[fg], reg_t, iou_type).sum() / num_fg
     l_obj = F.binary_cross_entropy_with_logits(obj.reshape(-1, 1), obj_t, reduction="none").sum() / num_fg
     l_cls = F.binary_cross_entropy_with_logits(cls.reshape(-1, num_classes)[fg], cls_t, reduction="none").sum() / num_fg
     l_l1 = 0.0
     if use_l1:
         l_l1 = (raw[..., :4].reshape(-1, 4)[fg] - torch.cat(l1_t, 0)).abs().sum() / num_fg
-    total = 5.0 * l_iou + l_obj + l_cls + l_l1
-    res = (total, 5.0 * l_iou, l_obj, l_cls, l_l1, num_fg / max(num_gts, 1))
+    total = reg_weight * l_iou + l_obj + l_cls + l_l1
+    res = (total, reg_weight * l_iou, l_obj, l_cls, l_l1, num_fg / max(num_gts, 1))
     return (res, assigns) if return_assign else res
 
 

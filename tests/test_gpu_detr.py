@@ -418,3 +418,32 @@ def test_pairwise_bbox_iou_against_reference_golden(golden_dir):
     assert pairwise_bbox_iou(a[:0].to(DEV), b.to(DEV)).shape == (0, 61)
     big = pairwise_bbox_iou(synth_box_pairs(8400, 55)[0].to(DEV), synth_box_pairs(120, 56)[1].to(DEV))   # SimOTA-sized
     assert big.shape == (8400, 120) and bool(((big >= 0) & (big <= 1)).all())
+
+
+# ------------------------------------------------------------------------------------------ YOLOv6 ComputeLoss
+@pytest.mark.parametrize("name,kw", [("ciou", dict(iou_type="ciou")),
+                                     ("siou", dict(iou_type="siou", center_radius=1.5, iou_weight=2.0, cls_weight=0.5, reg_weight=2.5))])
+def test_yolov6_compute_loss_against_reference_golden(golden_dir, name, kw):
+    """ComputeLoss (head/yolov6_head.py:315-754) on the HIP SimOTA / loss kernels against the reference class run on the
+    same seeded head outputs: total, (reg_weight * iou, l1, obj, cls), the gradient with respect to the head outputs, and
+    the in-place scaling of the normalised targets"""
+    import sys
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle")
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    from gen_golden_inputs import synth_yolov6_case
+    from yolov7_d2_amd.modeling import ComputeLoss
+    g = np.load(os.path.join(golden_dir, "yolov6_loss.npz"))
+    outs, t, _, _, _ = synth_yolov6_case()
+    outs = [o.to(DEV).requires_grad_(True) for o in outs]
+    t = t.to(DEV)
+    total, parts = ComputeLoss(**kw)(outs, t)
+    assert not parts.requires_grad and total.requires_grad
+    np.testing.assert_allclose(float(total), float(g[name + "_total"][0]), rtol=2e-5)
+    np.testing.assert_allclose(parts.cpu().numpy(), g[name + "_parts"], rtol=2e-5, atol=1e-6)
+    total.backward()
+    grad = torch.cat([o.grad.reshape(o.shape[0], -1, o.shape[-1]) for o in outs], 1).cpu().numpy()
+    np.testing.assert_allclose(grad, g[name + "_grad"], rtol=2e-3, atol=2e-6)
+    np.testing.assert_allclose(t.cpu().numpy(), g[name + "_targets_after"], rtol=1e-6, atol=1e-4)
+    with pytest.raises(ValueError):
+        ComputeLoss(iou_type="iou")

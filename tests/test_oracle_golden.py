@@ -3,6 +3,7 @@ reference's own source (oracle/gen_golden.py -> tests/golden/*.npz)."""
 import os
 
 import numpy as np
+import pytest
 import torch
 
 import yolox_oracle as O
@@ -97,6 +98,26 @@ def test_l1_loss_oracle_against_reference(golden_dir):
     np.testing.assert_allclose(np.array([float(x) for x in res]), g["losses"], rtol=1e-6)
     (res[0] + res[1] + res[2] + res[3] + res[4]).backward()
     np.testing.assert_allclose(raw.grad.numpy(), g["draw"], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("name,kw", [("ciou", dict(iou_type="ciou")),
+                                     ("siou", dict(iou_type="siou", center_radius=1.5, iou_weight=2.0, cls_weight=0.5, reg_weight=2.5))])
+def test_yolov6_compute_loss_oracle_against_reference(golden_dir, name, kw):
+    """the YOLOv6 head's ComputeLoss (yolov6_head.py:315-754) = the YOLOX loss with other constants, an IOUlossV6 box loss
+    and the l1 term always on: the oracle's parameterised restatement against the reference class itself"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    from gen_golden_inputs import synth_yolov6_case
+    g = np.load(os.path.join(golden_dir, "yolov6_loss.npz"))
+    _, t, labels, raw, anchors = synth_yolov6_case()
+    raw = raw.clone().requires_grad_(True)
+    res = O.yolox_losses(raw, labels, anchors, 80, use_l1=True, **kw)
+    np.testing.assert_allclose(float(res[0]), float(g[name + "_total"][0]), rtol=2e-6)
+    np.testing.assert_allclose(np.array([float(res[1]), float(res[4]), float(res[2]), float(res[3])]), g[name + "_parts"], rtol=2e-6)
+    res[0].backward()
+    np.testing.assert_allclose(raw.grad.numpy(), g[name + "_grad"], rtol=1e-4, atol=1e-7)
+    # the reference scaled its normalised targets to pixels in place: those are the labels the oracle was given
+    np.testing.assert_allclose(g[name + "_targets_after"], labels.numpy(), rtol=1e-6, atol=1e-4)
 
 
 def test_simota_assignment_bit_exact(golden_dir):

@@ -91,6 +91,8 @@ class mi_yolox_loss_desc(C.Structure):
         ("cost", C.c_void_p), ("iou", C.c_void_p), ("match", C.c_void_p), ("ngt", C.c_void_p),
         ("fg", C.c_void_p), ("matched_gt", C.c_void_p), ("matched_iou", C.c_void_p),
         ("partial", C.c_void_p), ("out", C.c_void_p), ("use_l1", C.c_int32), ("rsv_", C.c_int32), ("partial_l1", C.c_void_p),
+        ("center_radius", C.c_float), ("cls_weight", C.c_float), ("iou_weight", C.c_float), ("reg_weight", C.c_float),
+        ("iou_type", C.c_int32), ("rsv2_", C.c_int32),
     ]
 
 

@@ -12,6 +12,7 @@
 // batch is processed by four launches.  Compile with -ffp-contract=off: the float expressions keep
 // the reference's operation order so near-ties resolve the same way.
 #include "common.h"
+#include "iou_v6.h"
 
 #define SIMOTA_INF 3.0e38f
 
@@ -31,6 +32,10 @@ struct LossK {
   float* out;
   int use_l1;          // get_l1_target + nn.L1Loss on the raw regression outputs (yolox_head.py:389-427, 443-448)
   float* partial_l1;   // [nblk] block sums of the L1 term
+  // the YOLOv6 head's form of the same loss (ComputeLoss, head/yolov6_head.py:315-754): configurable SimOTA weights /
+  // centre radius and an IOUlossV6 box loss; the YOLOX values are 2.5, 1, 3, 5 and box loss 1 - iou^2 (iou_type 0)
+  float center_radius, cls_weight, iou_weight, reg_weight;
+  int iou_type;        // 0: IOUloss "iou" of the YOLOX head; 1..4: IOUlossV6 giou / diou / ciou / siou (eps 1e-7)
 };
 
 // l1 target of one foreground anchor (yolox_head.py:443-448; eps = 1e-8)
@@ -85,8 +90,8 @@ __global__ __launch_bounds__(256) void simota_cost_kernel(const LossK p) {
     const float bl = xc - (gcx - 0.5f * gw), br = (gcx + 0.5f * gw) - xc;
     const float bt = yc - (gcy - 0.5f * gh), bb = (gcy + 0.5f * gh) - yc;
     const bool inb = fminf(fminf(bl, bt), fminf(br, bb)) > 0.0f;
-    const float cl = xc - (gcx - 2.5f * st), cr = (gcx + 2.5f * st) - xc;
-    const float ct = yc - (gcy - 2.5f * st), cb = (gcy + 2.5f * st) - yc;
+    const float cl = xc - (gcx - p.center_radius * st), cr = (gcx + p.center_radius * st) - xc;
+    const float ct = yc - (gcy - p.center_radius * st), cb = (gcy + p.center_radius * st) - yc;
     const bool inc = fminf(fminf(cl, ct), fminf(cr, cb)) > 0.0f;
     cand = cand || inb || inc;
   }
@@ -118,8 +123,8 @@ __global__ __launch_bounds__(256) void simota_cost_kernel(const LossK p) {
     const float bl = xc - (gcx - 0.5f * gw), br = (gcx + 0.5f * gw) - xc;
     const float bt = yc - (gcy - 0.5f * gh), bb = (gcy + 0.5f * gh) - yc;
     const bool inb = fminf(fminf(bl, bt), fminf(br, bb)) > 0.0f;
-    const float cl = xc - (gcx - 2.5f * st), cr = (gcx + 2.5f * st) - xc;
-    const float ct = yc - (gcy - 2.5f * st), cb = (gcy + 2.5f * st) - yc;
+    const float cl = xc - (gcx - p.center_radius * st), cr = (gcx + p.center_radius * st) - xc;
+    const float ct = yc - (gcy - p.center_radius * st), cb = (gcy + p.center_radius * st) - yc;
     const bool inc = fminf(fminf(cl, ct), fminf(cr, cb)) > 0.0f;
     // bboxes_iou(gt, pred, xyxy=False) boxes.py:66-81
     const float tlx = fmaxf(gcx - gw / 2, px - pw / 2), tly = fmaxf(gcy - gh / 2, py - ph / 2);
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256) void simota_cost_kernel(const LossK p) {
     const float pg = sqrtf(sigmoid_ref(pr[5 + gc]) * so);
     const float lp = clamp_log(pg), l1p = clamp_log(1.0f - pg);
     const float cls_loss = -lp - (S - l1p);
-    float cost = cls_loss + 3.0f * iou_loss;
+    float cost = p.cls_weight * cls_loss + p.iou_weight * iou_loss;
     cost = cost + 100000.0f * ((inb && inc) ? 0.f : 1.f);
     costp[g * rowstride] = cost;
     ioup[g * rowstride] = iou;
@@ -339,6 +344,10 @@ __global__ __launch_bounds__(256) void simota_resolve_loss_kernel(const LossK p)
       const float area_i = ((brx - tlx) * (bry - tly)) * en;
       const float iou = area_i / (area_p + area_g - area_i + 1e-16f);
       l_iou = 1.f - iou * iou;
+      if (p.iou_type) {   // IOUlossV6 on the decoded box (yolov6_head.py:346,512)
+        const float pbox[4] = {pb.x, pb.y, pb.w, pb.h};
+        l_iou = 1.f - iou_v6_dual(pbox, lab + 1, p.iou_type, 0, 1e-7f).v;
+      }
       const int gc = (int)lab[0];
       for (int c = 0; c < p.ncls; ++c) l_cls += bce_logits(pr[5 + c], c == gc ? miou : 0.f);
       if (p.use_l1) {
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(256) void simota_resolve_loss_kernel(const LossK p)
 }
 
 __global__ __launch_bounds__(64) void loss_final_kernel(const float* partial, const float* partial_l1, int nblk,
-                                                        const int32_t* ngt, int B, float* out) {
+                                                        const int32_t* ngt, int B, float reg_weight, float* out) {
   const int lane = threadIdx.x;
   double s[4] = {0, 0, 0, 0};
   double s_l1 = 0;
@@ -381,11 +390,11 @@ __global__ __launch_bounds__(64) void loss_final_kernel(const float* partial, co
     const double nfg = s[3];
     const double N = nfg > 1.0 ? nfg : 1.0;
     const float li = (float)(s[0] / N), lo = (float)(s[1] / N), lc = (float)(s[2] / N);
-    out[1] = 5.0f * li;
+    out[1] = reg_weight * li;
     out[2] = lo;
     out[3] = lc;
     const float l1 = (float)(s_l1 / N);   // 0 unless use_l1
-    out[0] = 5.0f * li + lo + lc + l1;
+    out[0] = reg_weight * li + lo + lc + l1;
     out[4] = l1;
     out[5] = (float)(N / (g > 1.0 ? g : 1.0));
     out[6] = (float)nfg;
@@ -404,6 +413,12 @@ static int loss_fill(const mi_yolox_loss_desc* d, LossK* k) {
   k->cost = d->cost; k->iou = d->iou; k->match = d->match; k->ngt = d->ngt; k->fg = d->fg;
   k->matched_gt = d->matched_gt; k->matched_iou = d->matched_iou; k->partial = d->partial; k->out = d->out;
   k->use_l1 = d->use_l1 != 0; k->partial_l1 = d->partial_l1;
+  k->center_radius = d->center_radius > 0.f ? d->center_radius : 2.5f;
+  k->cls_weight = d->cls_weight > 0.f ? d->cls_weight : 1.0f;
+  k->iou_weight = d->iou_weight > 0.f ? d->iou_weight : 3.0f;
+  k->reg_weight = d->reg_weight > 0.f ? d->reg_weight : 5.0f;
+  k->iou_type = d->iou_type;
+  MI_REQUIRE(d->iou_type >= 0 && d->iou_type <= 4, "yolox_loss: iou_type %d", d->iou_type);
   MI_REQUIRE(!k->use_l1 || d->partial_l1, "yolox_loss: use_l1 needs partial_l1");
   return MI_OK;
 }
@@ -426,7 +441,7 @@ extern "C" int mi_yolox_loss_fwd(const mi_yolox_loss_desc* d, mi_stream_t st) {
   hipLaunchKernelGGL(simota_resolve_loss_kernel, dim3(nb, d->B), dim3(256), 0, s, k);
   MI_CHECK_LAUNCH("simota_resolve_loss");
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, d->partial, k.use_l1 ? d->partial_l1 : nullptr,
-                     nb * d->B, d->ngt, d->B, d->out);
+                     nb * d->B, d->ngt, d->B, k.reg_weight, d->out);
   MI_CHECK_LAUNCH("loss_final");
   return MI_OK;
 }
@@ -438,7 +453,7 @@ __global__ __launch_bounds__(256) void yolox_loss_bwd_kernel(const LossK p, cons
   if (a >= p.A) return;
   const float nfg = p.out[6];
   const float N = nfg > 1.f ? nfg : 1.f;
-  const float w_iou = 5.0f * (gw[0] + gw[1]) / N;
+  const float w_iou = p.reg_weight * (gw[0] + gw[1]) / N;
   const float w_obj = (gw[0] + gw[2]) / N;
   const float w_cls = (gw[0] + gw[3]) / N;
   const float w_l1 = p.use_l1 ? (gw[0] + gw[4]) / N : 0.f;   // gw has a fifth entry (upstream of l1_loss) iff use_l1
@@ -485,6 +500,14 @@ __global__ __launch_bounds__(256) void yolox_loss_bwd_kernel(const LossK p, cons
   dp[1] = w_iou * dpy * st;
   dp[2] = w_iou * dpw * pb.w;
   dp[3] = w_iou * dph * pb.h;
+  if (p.iou_type) {   // d(1 - iou_variant)/d(decoded box), chained through the decode (x, y: * stride; w, h: * themselves)
+    const float pbox[4] = {pb.x, pb.y, pb.w, pb.h};
+    const D4 v = iou_v6_dual(pbox, lab + 1, p.iou_type, 0, 1e-7f);
+    dp[0] = w_iou * -v.d[0] * st;
+    dp[1] = w_iou * -v.d[1] * st;
+    dp[2] = w_iou * -v.d[2] * pb.w;
+    dp[3] = w_iou * -v.d[3] * pb.h;
+  }
   if (p.use_l1) {   // d|x - t| = sign(x - t) (0 at x == t, as ATen's l1 backward)
     float t[4];
     l1_target(lab, p.anchors[a * 3 + 0], p.anchors[a * 3 + 1], st, t);

@@ -19,3 +19,4 @@ from .sparseinst import (SparseInst, InstanceContextEncoder, PyramidPoolingModul
                          GroupInstanceBranch, MaskBranch, BaseIAMDecoder, GroupIAMDecoder, SparseInstCriterion,
                          SparseInstMatcher, build_sparse_inst_encoder, build_sparse_inst_decoder,
                          build_sparse_inst_criterion, rescoring_mask)
+from .yolov6_loss import ComputeLoss
