@@ -48,6 +48,12 @@ class NativeTrainer:
         model.train()
         self.params = model.ensure_params()
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        if self.world > 1:
+            # the one-launch BatchNorm backward needs every block of its grid resident at once: leave an eighth of the
+            # device to the collective's kernels, which run beside the backward pass (a block that has to wait for them
+            # would hold the whole launch at its barrier until the all-reduce is over)
+            full = L.lib().mi_bn_fused_set_capacity(0)
+            L.lib().mi_bn_fused_set_capacity(full - full // 8)
         broadcast_params(self.params.data)
         norm_ids = set()
         for m in model.modules():
