@@ -173,7 +173,8 @@ typedef struct mi_pack_job {
 } mi_pack_job;
 /* validates the (host) job table, fills blk0 and returns the number of blocks of the flat launch (<0 on error) */
 int mi_pack_jobs_layout(mi_pack_job* jobs_host, int njobs);
-int mi_pack_conv_weights_batch(const mi_pack_job* jobs_dev, int njobs, int total_blocks, mi_stream_t s);
+/* kk_max: the largest tap count (KK) of the table: sizes the kernel's LDS tile */
+int mi_pack_conv_weights_batch(const mi_pack_job* jobs_dev, int njobs, int total_blocks, int kk_max, mi_stream_t s);
 
 /* ---- depthwise 3x3 convolution ------------------------------------------------
  * the `dconv` of DWConv (backbone/layers/wrappers.py:86-102: BaseConv(C, C, ksize, stride, groups=C); the reference
@@ -303,7 +304,7 @@ typedef struct mi_yolox_loss_desc {
   /* workspaces (caller-owned) */
   float* cost;          /* [B][gmax][A]                                                       */
   float* iou;           /* [B][gmax][A]                                                       */
-  uint8_t* match;       /* [B][gmax][A]                                                       */
+  uint8_t* match;       /* unused since round 2 (the match matrix became a per-anchor counter); may be NULL       */
   int32_t* ngt;         /* [B]                                                                */
   /* assignment outputs */
   uint8_t* fg;          /* [B][A] final foreground mask                                       */

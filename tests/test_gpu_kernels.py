@@ -396,9 +396,9 @@ def test_batched_pack_and_split_match_the_per_layer_launches():
         keep.append((w, wf, wd))
         single.append((wf1, wd1))
     nblk = L.check(lib.mi_pack_jobs_layout(jobs, len(shapes)), "layout")
-    assert nblk == sum(-(-((s[3] // 8) * s[4] + ((s[5] // 8) * s[6] if s[0] != 85 else 0)) // 256) for s in shapes)
+    assert nblk == sum(-(-max(s[4], s[5] if s[0] != 85 else 0) // 32) * -(-max(s[3], s[6] if s[0] != 85 else 0) // 64) for s in shapes)
     tab = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(DEV)
-    L.check(lib.mi_pack_conv_weights_batch(tab.data_ptr(), len(shapes), nblk, sp()), "pack_batch")
+    L.check(lib.mi_pack_conv_weights_batch(tab.data_ptr(), len(shapes), nblk, 16, sp()), "pack_batch")
     torch.cuda.synchronize()
     for (w, wf, wd), (wf1, wd1) in zip(keep, single):
         assert torch.equal(wf.view(torch.int16), wf1.view(torch.int16))
@@ -482,3 +482,21 @@ def test_bn_backward_fused_matches_two_pass(C, npix, act, res):
     assert float((diff > 0).float().mean()) < 0.02                       # and almost every element identical
     if res:
         assert torch.equal(dr0, dr1)
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 16, 24), (1, 6, 10), (3, 64, 96), (2, 8, 12)])
+def test_focus_pack_float_and_uint8_bit_exact(N, H, W):
+    """Focus (wrappers.py:202-220) from the float image and from the uint8 image, the 4-pixels-per-thread kernels (W % 8
+    == 0) and the scalar ones: TL, BL, TR, BR x (c0, c1, c2) into 16-channel pixels, the 4 pad channels zero - exact"""
+    lib = L.lib()
+    g = torch.Generator().manual_seed(H * W)
+    u8 = torch.randint(0, 256, (N, 3, H, W), generator=g, dtype=torch.uint8)
+    f32 = u8.float()
+    ref = torch.cat([f32[..., ::2, ::2], f32[..., 1::2, ::2], f32[..., ::2, 1::2], f32[..., 1::2, 1::2]], 1)   # [N,12,H/2,W/2]
+    ref = ref.permute(0, 2, 3, 1)
+    for src, fn in ((f32.to(DEV), lib.mi_focus_pack), (u8.to(DEV), lib.mi_focus_pack_u8)):
+        out = torch.full((N, H // 2, W // 2, 16), 5.0, dtype=torch.bfloat16, device=DEV)
+        L.check(fn(src.data_ptr(), N, H, W, out.data_ptr(), 16, sp()), "focus")
+        torch.cuda.synchronize()
+        o = out.float().cpu()
+        assert torch.equal(o[..., :12], ref) and torch.all(o[..., 12:] == 0)

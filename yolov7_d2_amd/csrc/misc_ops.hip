@@ -33,30 +33,52 @@ __global__ __launch_bounds__(256) void focus_pack_kernel(const float* __restrict
   }
 }
 
-// the same from the uint8 image a data loader hands over (yolox.py:96-99 converts to float on the device; values
-// 0..255 are exact in bf16): 4x less input traffic than the float image and no conversion pass
-__global__ __launch_bounds__(256) void focus_pack_u8_kernel(const uint8_t* __restrict__ img, int N, int H, int W,
-                                                            __bf16* out, int ldo) {
+// The uint8 image a data loader hands over (yolox.py:96-99 converts to float on the device; values 0..255 are exact in
+// bf16) goes through the same kernel: 4x less input traffic than the float image and no conversion pass.
+// one output pixel per thread and trip, four trips in flight: per (channel, row) the two horizontally adjacent source
+// pixels are ONE 8-byte (fp32) / 2-byte (uint8) load, neighbouring lanes read neighbouring pairs and write neighbouring
+// 32-byte output pixels.  (Four adjacent pixels per thread read wider but scatter the stores: 16 bytes out of every 128
+// per instruction - measured slower.)  T = float or uint8_t.
+template <class T>
+__global__ __launch_bounds__(256) void focus_pack4_kernel(const T* __restrict__ img, int N, int H, int W, __bf16* out,
+                                                          int ldo) {
   const int Ho = H / 2, Wo = W / 2;
   const int64_t total = (int64_t)N * Ho * Wo;
-  for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int ox = (int)(idx % Wo);
-    const int64_t r = idx / Wo;
-    const int oy = (int)(r % Ho), n = (int)(r / Ho);
-    float f[16];
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t idx0 = blockIdx.x * 256LL + threadIdx.x; idx0 < total; idx0 += 4 * stride) {
+    float f[4][16];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int j = 0; j < 4; ++j) {
+      const int64_t idx = idx0 + j * stride;
+      if (idx >= total) break;
+      const int ox = (int)(idx % Wo);
+      const int64_t r = idx / Wo;
+      const int oy = (int)(r % Ho), n = (int)(r / Ho);
 #pragma unroll
-      for (int dy = 0; dy < 2; ++dy) {
-        // the two horizontally adjacent pixels (TL/TR or BL/BR) are one aligned 2-byte load (W is even)
-        const unsigned short v = *(const unsigned short*)(img + (((int64_t)n * 3 + c) * H + (2 * oy + dy)) * W + 2 * ox);
-        f[dy * 3 + c] = (float)(v & 0xff);          // q = dy      (dx = 0)
-        f[(2 + dy) * 3 + c] = (float)(v >> 8);      // q = 2 + dy  (dx = 1)
-      }
-    f[12] = f[13] = f[14] = f[15] = 0.f;
-    __bf16* op = out + idx * ldo;
-    *(bf16x8*)op = pack8(f);
-    *(bf16x8*)(op + 8) = pack8(f + 8);
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+          const T* src = img + (((int64_t)n * 3 + c) * H + (2 * oy + dy)) * W + 2 * ox;
+          if constexpr (sizeof(T) == 4) {
+            const float2 v = *(const float2*)src;
+            f[j][dy * 3 + c] = v.x;
+            f[j][(2 + dy) * 3 + c] = v.y;
+          } else {
+            const unsigned short v = *(const unsigned short*)src;
+            f[j][dy * 3 + c] = (float)(v & 0xff);
+            f[j][(2 + dy) * 3 + c] = (float)(v >> 8);
+          }
+        }
+      f[j][12] = f[j][13] = f[j][14] = f[j][15] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t idx = idx0 + j * stride;
+      if (idx >= total) break;
+      __bf16* op = out + idx * ldo;
+      *(bf16x8*)op = pack8(f[j]);
+      *(bf16x8*)(op + 8) = pack8(f[j] + 8);
+    }
   }
 }
 
@@ -64,8 +86,8 @@ extern "C" int mi_focus_pack_u8(const uint8_t* img, int N, int H, int W, void* o
   MI_REQUIRE(img && out && H % 2 == 0 && W % 2 == 0 && ldo % 8 == 0 && ldo >= 16 && ((uintptr_t)img & 1) == 0,
              "focus_pack_u8: args");
   const int64_t total = (int64_t)N * (H / 2) * (W / 2);
-  hipLaunchKernelGGL(focus_pack_u8_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)st, img, N, H, W,
-                     (__bf16*)out, ldo);
+  hipLaunchKernelGGL(focus_pack4_kernel<uint8_t>, dim3(ew_blocks((total + 3) / 4)), dim3(256), 0, (hipStream_t)st, img, N, H,
+                     W, (__bf16*)out, ldo);
   MI_CHECK_LAUNCH("focus_pack_u8");
   return MI_OK;
 }
@@ -73,8 +95,12 @@ extern "C" int mi_focus_pack_u8(const uint8_t* img, int N, int H, int W, void* o
 extern "C" int mi_focus_pack(const float* img, int N, int H, int W, void* out, int ldo, mi_stream_t st) {
   MI_REQUIRE(img && out && H % 2 == 0 && W % 2 == 0 && ldo % 8 == 0 && ldo >= 16, "focus_pack: args");
   const int64_t total = (int64_t)N * (H / 2) * (W / 2);
-  hipLaunchKernelGGL(focus_pack_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)st, img, N, H, W,
-                     (__bf16*)out, ldo);
+  if (((uintptr_t)img & 7) == 0)
+    hipLaunchKernelGGL(focus_pack4_kernel<float>, dim3(ew_blocks((total + 3) / 4)), dim3(256), 0, (hipStream_t)st, img, N, H,
+                       W, (__bf16*)out, ldo);
+  else
+    hipLaunchKernelGGL(focus_pack_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)st, img, N, H, W,
+                       (__bf16*)out, ldo);
   MI_CHECK_LAUNCH("focus_pack");
   return MI_OK;
 }
@@ -253,7 +279,10 @@ extern "C" int mi_upsample2x_bwd(const void* dy, int lddy, void* dx, int lddx, i
 //   dyc[k][pixel][c] : dy+6 of the first row whose horizontal max equals the window max (vertical pass)
 // "first" = the element F.max_pool2d / the brute-force row-major scan would pick (strict > while scanning up).
 // idx buffer: [dyc 3 planes][dxc 3 planes], each N*H*W*C bytes.
-__global__ __launch_bounds__(256) void spp_fwd_plane_kernel(const __bf16* __restrict__ x, int ldx, __bf16* y5,
+// SPP_T threads per plane: at 640x640 a plane is 20x20 = 400 pixels - one pixel per thread in a single round (with 256
+// threads the second round ran 144 of them), and 16 waves per CU instead of 8 for the same 2 blocks
+#define SPP_T 512
+__global__ __launch_bounds__(SPP_T) void spp_fwd_plane_kernel(const __bf16* __restrict__ x, int ldx, __bf16* y5,
                                                             __bf16* y9, __bf16* y13, int ldy, uint8_t* idx, int N,
                                                             int H, int W, int C8) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -261,14 +290,18 @@ __global__ __launch_bounds__(256) void spp_fwd_plane_kernel(const __bf16* __rest
   bf16x8* Xp = (bf16x8*)smem;          // [HW] input plane
   bf16x8* Hv = Xp + HW;                // [HW] horizontal max values of the current k
   uint64_t* Hc = (uint64_t*)(Hv + HW); // [HW] their dx codes
-  const int c8 = blockIdx.x % C8, n = blockIdx.x / C8;
+  // a block touches 16 bytes of every 128-byte line of its plane; the 8 blocks that share those lines (adjacent c8) must sit
+  // on the SAME XCD to meet in its L2 - block ids go round-robin over the 8 XCDs, so give each XCD a contiguous range of
+  // (image, channel group) pairs (measured before: every line fetched / written back by 8 different L2s, 47 us)
+  const int lb = (gridDim.x % 8 == 0) ? (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int c8 = lb % C8, n = lb / C8;
   const int64_t npix = (int64_t)N * HW;
   const __bf16* xb = x + ((int64_t)n * HW) * ldx + c8 * 8;
-  for (int p = threadIdx.x; p < HW; p += 256) Xp[p] = *(const bf16x8*)(xb + (int64_t)p * ldx);
+  for (int p = threadIdx.x; p < HW; p += SPP_T) Xp[p] = *(const bf16x8*)(xb + (int64_t)p * ldx);
   __syncthreads();
   for (int k = 0; k < 3; ++k) {
     const int r = 2 + 2 * k;
-    for (int p = threadIdx.x; p < HW; p += 256) {
+    for (int p = threadIdx.x; p < HW; p += SPP_T) {
       const int py = p / W, px = p - py * W;
       float m[8];
       uint8_t am[8];
@@ -293,7 +326,7 @@ __global__ __launch_bounds__(256) void spp_fwd_plane_kernel(const __bf16* __rest
     }
     __syncthreads();
     __bf16* yk = k == 0 ? y5 : (k == 1 ? y9 : y13);
-    for (int p = threadIdx.x; p < HW; p += 256) {
+    for (int p = threadIdx.x; p < HW; p += SPP_T) {
       const int py = p / W, px = p - py * W;
       float m[8];
       uint8_t am[8];
@@ -322,7 +355,7 @@ __global__ __launch_bounds__(256) void spp_fwd_plane_kernel(const __bf16* __rest
 
 // backward: gH_k[q] = sum over outputs o = q - (dy,0) with dyc_k[o] == dy of g_k[o];  gx[p] = sum_k sum over
 // q = p - (0,dx) with dxc_k[q] == dx of gH_k[q].  Gathers in a fixed order: deterministic.
-__global__ __launch_bounds__(256) void spp_bwd_plane_kernel(const __bf16* __restrict__ d5, const __bf16* __restrict__ d9,
+__global__ __launch_bounds__(SPP_T) void spp_bwd_plane_kernel(const __bf16* __restrict__ d5, const __bf16* __restrict__ d9,
                                                             const __bf16* __restrict__ d13, int lddy,
                                                             const uint8_t* __restrict__ idx, __bf16* dx, int lddx,
                                                             int accumulate, int N, int H, int W, int C8) {
@@ -332,9 +365,13 @@ __global__ __launch_bounds__(256) void spp_bwd_plane_kernel(const __bf16* __rest
   uint64_t* Dy = (uint64_t*)(Gp + HW);   // [HW] vertical codes
   uint64_t* Dx = Dy + HW;                // [HW] horizontal codes
   float* Gh = (float*)(Dx + HW);         // [HW][8] gradient w.r.t. the horizontal maxes
-  const int c8 = blockIdx.x % C8, n = blockIdx.x / C8;
+  // a block touches 16 bytes of every 128-byte line of its plane; the 8 blocks that share those lines (adjacent c8) must sit
+  // on the SAME XCD to meet in its L2 - block ids go round-robin over the 8 XCDs, so give each XCD a contiguous range of
+  // (image, channel group) pairs (measured before: every line fetched / written back by 8 different L2s, 47 us)
+  const int lb = (gridDim.x % 8 == 0) ? (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int c8 = lb % C8, n = lb / C8;
   const int64_t npix = (int64_t)N * HW;
-  float acc[2][8];  // up to 512 pixels per plane with 256 threads
+  float acc[2][8];  // up to 2 * SPP_T pixels per plane
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
@@ -342,14 +379,14 @@ __global__ __launch_bounds__(256) void spp_bwd_plane_kernel(const __bf16* __rest
     const int r = 2 + 2 * k;
     const __bf16* dk = k == 0 ? d5 : (k == 1 ? d9 : d13);
     __syncthreads();
-    for (int p = threadIdx.x; p < HW; p += 256) {
+    for (int p = threadIdx.x; p < HW; p += SPP_T) {
       const int64_t pix = (int64_t)n * HW + p;
       Gp[p] = *(const bf16x8*)(dk + pix * lddy + c8 * 8);
       Dy[p] = *(const uint64_t*)(idx + ((int64_t)k * npix + pix) * C + c8 * 8);
       Dx[p] = *(const uint64_t*)(idx + ((int64_t)(3 + k) * npix + pix) * C + c8 * 8);
     }
     __syncthreads();
-    for (int q = threadIdx.x; q < HW; q += 256) {
+    for (int q = threadIdx.x; q < HW; q += SPP_T) {
       const int qy = q / W, qx = q - qy * W;
       float g[8];
 #pragma unroll
@@ -371,7 +408,7 @@ __global__ __launch_bounds__(256) void spp_bwd_plane_kernel(const __bf16* __rest
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int p = threadIdx.x + i * 256;
+      const int p = threadIdx.x + i * SPP_T;
       if (p >= HW) continue;
       const int py = p / W, px = p - py * W;
       for (int dxx = -r; dxx <= r; ++dxx) {
@@ -388,7 +425,7 @@ __global__ __launch_bounds__(256) void spp_bwd_plane_kernel(const __bf16* __rest
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int p = threadIdx.x + i * 256;
+    const int p = threadIdx.x + i * SPP_T;
     if (p >= HW) continue;
     __bf16* op_ = dx + ((int64_t)n * HW + p) * lddx + c8 * 8;
     float o[8];
@@ -414,7 +451,7 @@ extern "C" int mi_spp_pool_fwd(const void* x, int ldx, void* y5, void* y9, void*
     hipFuncSetAttribute((const void*)spp_bwd_plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL(spp_fwd_plane_kernel, dim3(N * (C / 8)), dim3(256), lds, (hipStream_t)st, (const __bf16*)x, ldx,
+  hipLaunchKernelGGL(spp_fwd_plane_kernel, dim3(N * (C / 8)), dim3(SPP_T), lds, (hipStream_t)st, (const __bf16*)x, ldx,
                      (__bf16*)y5, (__bf16*)y9, (__bf16*)y13, ldy, idx, N, H, W, C / 8);
   MI_CHECK_LAUNCH("spp_fwd");
   return MI_OK;
@@ -422,7 +459,7 @@ extern "C" int mi_spp_pool_fwd(const void* x, int ldx, void* y5, void* y9, void*
 extern "C" int mi_spp_pool_bwd(const void* dy5, const void* dy9, const void* dy13, int lddy, const uint8_t* idx,
                                void* dx, int lddx, int accumulate, int N, int H, int W, int C, mi_stream_t st) {
   MI_REQUIRE(dy5 && dy9 && dy13 && idx && dx && C % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "spp_bwd: args");
-  MI_REQUIRE(H * W <= 512, "spp_bwd: plane %dx%d > 512 pixels (register accumulators)", H, W);
+  MI_REQUIRE(H * W <= 2 * SPP_T, "spp_bwd: plane %dx%d > %d pixels (register accumulators)", H, W, 2 * SPP_T);
   const size_t lds = (size_t)H * W * 64;
   static bool attr_done = false;
   if (!attr_done) {
@@ -430,7 +467,7 @@ extern "C" int mi_spp_pool_bwd(const void* dy5, const void* dy9, const void* dy1
     hipFuncSetAttribute((const void*)spp_bwd_plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL(spp_bwd_plane_kernel, dim3(N * (C / 8)), dim3(256), lds, (hipStream_t)st, (const __bf16*)dy5,
+  hipLaunchKernelGGL(spp_bwd_plane_kernel, dim3(N * (C / 8)), dim3(SPP_T), lds, (hipStream_t)st, (const __bf16*)dy5,
                      (const __bf16*)dy9, (const __bf16*)dy13, lddy, idx, (__bf16*)dx, lddx, accumulate, N, H, W, C / 8);
   MI_CHECK_LAUNCH("spp_bwd");
   return MI_OK;

@@ -894,7 +894,7 @@ class Plan:
         nblk = L.check(L.lib().mi_pack_jobs_layout(jobs, len(packs)), "pack_jobs_layout")
         tab = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(self.b.device)
         self.pack_table = tab
-        return rest + [_Cmd(L.OP["PACK_W_BATCH"], i=[len(packs), nblk], p=[_Ptr(tab)], tag="pack_all")]
+        return rest + [_Cmd(L.OP["PACK_W_BATCH"], i=[len(packs), nblk, max(j.KK for j in jobs)], p=[_Ptr(tab)], tag="pack_all")]
 
     def _make_desc(self, spec):
         kind = getattr(spec, "kind", "conv")
