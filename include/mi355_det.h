@@ -447,6 +447,15 @@ int mi_yolox_iou_loss(const float* pred, const float* target, int n, int loss_ty
  * boxes (cx,cy,w,h) (box_xyxy 0) or (x1,y1,x2,y2) */
 int mi_pairwise_bbox_iou(const float* box1, const float* box2, int N, int M, int box_xyxy, float* out, mi_stream_t s);
 
+/* ---- COCO run-length encoding of masks (evaluation output format) ----------------------
+ * what pycocotools.mask.encode does for instances_to_coco_json (evaluation/coco_evaluation.py:38-50; the algorithm is
+ * cocoapi's maskApi.c rleEncode / rleToString, un-vendored): masks uint8 [n][H][W] (device, non-zero = foreground) ->
+ * counts[n][max_runs] = lengths of the alternating runs of the COLUMN-major scan, starting with a (possibly empty) run of
+ * zeros; nruns[n] = number of runs, or -(needed runs) when max_runs is too small (that mask's counts are undefined).
+ * mi_rle_to_string is host code: counts -> the compact ASCII "counts" string; returns its length (NUL-terminated). */
+int mi_rle_encode(const uint8_t* masks, int n, int H, int W, int max_runs, uint32_t* counts, int32_t* nruns, mi_stream_t s);
+int mi_rle_to_string(const uint32_t* counts, int nruns, char* out, int out_cap);
+
 /* ---- batched NMS -------------------------------------------------------------
  * replaces torchvision.ops.batched_nms as called by postprocess (utils/boxes.py:199).
  * boxes xyxy fp32 [n][4], scores [n], idxs (class id as float, as the reference passes) [n].

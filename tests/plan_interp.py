@@ -177,8 +177,9 @@ class Interp:
         if c.p[3].obj is not None:
             CA = (C + 31) // 32 * 32
             st = self.f64(c.p[3], CA * 2).view(CA, 2)
-            st[:C, 0] += res.double().sum((0, 1, 2))
-            st[:C, 1] += (res.double() ** 2).sum((0, 1, 2))
+            stored = self.tv(y, C).float()
+            st[:C, 0] += stored.double().sum((0, 1, 2))
+            st[:C, 1] += (stored.double() ** 2).sum((0, 1, 2))
 
     def op_DWCONV_DGRAD(self, c):
         lddy, lddx, N, H, W, C, stride, Ho, Wo, acc = c.i[:10]

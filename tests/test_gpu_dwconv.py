@@ -44,8 +44,9 @@ def test_dwconv3x3_kernels_against_torch(N, H, W, C, stride, ld):
     assert torch.all(got[..., C:] == 9.0)                                      # pad channels untouched
     assert float((got[..., :C] - refn).abs().max()) <= float(refn.abs().max()) * 2 ** -8 + 1e-6     # bf16 store of fp32 sums
     st = acc.cpu().view(L.MI_BN_SLOTS, CA, 2).sum(0)
-    np.testing.assert_allclose(st[:C, 0].numpy(), refn.double().sum((0, 1, 2)).numpy(), rtol=1e-4, atol=1e-3 * N * Ho * Wo ** 0.5)
-    np.testing.assert_allclose(st[:C, 1].numpy(), (refn.double() ** 2).sum((0, 1, 2)).numpy(), rtol=1e-4, atol=1e-4)
+    stored = got[..., :C].double()                                             # statistics of the stored (bf16) values
+    np.testing.assert_allclose(st[:C, 0].numpy(), stored.sum((0, 1, 2)).numpy(), rtol=1e-5, atol=1e-4 * N * Ho * Wo ** 0.5)
+    np.testing.assert_allclose(st[:C, 1].numpy(), (stored ** 2).sum((0, 1, 2)).numpy(), rtol=1e-5, atol=1e-5)
     assert torch.all(st[C:] == 0)
     # data gradient: overwrite, then accumulate on top of an existing gradient
     for accum in (0, 1):
@@ -86,12 +87,11 @@ def test_depthwise_backbone_training_step(golden_dir):
     fe = forced["force_err"]
     assert len(fe) == len(ys)
     worst = max(fe.items(), key=lambda kv: kv[1])
-    # every BaseConv output on identical inputs: <= 2.5e-4 everywhere (measured) except the pointwise convs behind a
-    # depthwise BatchNorm, 1e-3 .. 3e-3 growing as 1/sqrt(samples per channel): the kernels take the batch statistics from
-    # the fp32 sums, the oracle from the bf16-stored tensor it was handed, and a depthwise output channel has |mean| >> std,
-    # so the two means differ by ~2^-9 |mean| / sqrt(n) - a visible fraction of the std the next layer is normalised by
+    # every BaseConv output on identical inputs (the depthwise kernel takes the BatchNorm statistics from the bf16 values
+    # it stores, like the dense conv's epilogue - with fp32 sums the pointwise convs behind a depthwise BatchNorm sat at
+    # 1e-3 .. 3e-3: a depthwise output channel has |mean| >> std, so a 2^-9 |mean| / sqrt(n) shift of the mean is visible)
     for k, v in fe.items():
-        assert v < (5e-3 if k.endswith(".pconv") else 1e-3), (k, v)
+        assert v < 1e-3, (k, v)
     rel = float((hip["raw"] - forced["raw"]).norm() / forced["raw"].norm())
     assert rel < 1e-5, rel
     raw = hip["raw"].clone().requires_grad_(True)
@@ -104,8 +104,9 @@ def test_depthwise_backbone_training_step(golden_dir):
     assert len(rows) == 276 == len(g["grad_names"])
     bad = [r for r in rows if not (r[1] >= 0.999 and r[2] <= 0.05)]
     assert not bad, bad[:6]
-    # against the reference's own fp32 step: within the bf16 storage noise
-    np.testing.assert_allclose(hip["losses"][0].numpy(), g["losses"][0], rtol=3e-2)
-    np.testing.assert_allclose(hip["losses"][:4].numpy(), g["losses"][:4], rtol=1e-1, atol=5e-2)
+    # against the reference's own fp32 step: within the bf16 storage noise (a sanity bound - at 64x96 a few SimOTA
+    # assignments flip between a bf16 and an fp32 forward; the pinned-forward checks above are the parity statement)
+    np.testing.assert_allclose(hip["losses"][0].numpy(), g["losses"][0], rtol=8e-2)
+    np.testing.assert_allclose(hip["losses"][:4].numpy(), g["losses"][:4], rtol=2e-1, atol=5e-2)
     np.testing.assert_allclose(hip["rm"]["backbone.dark3.0.dconv.bn.running_mean"].numpy(),
                                g["rm:backbone.dark3.0.dconv.bn.running_mean"], rtol=5e-2, atol=2e-3)

@@ -193,6 +193,8 @@ _PROTOS = {
     "mi_batched_nms_ex": (C.c_int, [_vp, _vp, _vp, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_batched_softnms": (C.c_int, [_vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp, _vp]),
     "mi_matrix_nms": (C.c_int, [_vp, _vp, _vp, _vp, _i, _f, _i, _vp, _vp, _vp]),
+    "mi_rle_encode": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mi_rle_to_string": (C.c_int, [_vp, _i, C.c_char_p, _i]),
     "mi_yolox_onnx_layout": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
     "mi_yolox_iou_loss": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "mi_pairwise_bbox_iou": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp]),

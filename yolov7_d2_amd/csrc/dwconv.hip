@@ -74,11 +74,15 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const DwK p) {
     for (int j = 0; j < DW_STRIP; ++j) {
       const int ox = ox0 + j;
       if (ox >= p.Wo) break;
-      *(bf16x8*)(p.y + ((size_t)((size_t)n * p.Ho + oy) * p.Wo + ox) * p.ldy + c8 * 8) = pack8(acc[j]);
+      const bf16x8 ob = pack8(acc[j]);
+      *(bf16x8*)(p.y + ((size_t)((size_t)n * p.Ho + oy) * p.Wo + ox) * p.ldy + c8 * 8) = ob;
+      // the statistics of the values that are STORED (bf16-rounded), like the dense conv's epilogue: the BatchNorm
+      // that follows normalises exactly this tensor
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        s1[e] += acc[j][e];
-        s2[e] += acc[j][e] * acc[j][e];
+        const float f = (float)ob[e];
+        s1[e] += f;
+        s2[e] += f * f;
       }
     }
   }
