@@ -448,19 +448,37 @@ struct Wg2R {
   int nsplit, NT, MI, NJ, WCO, WCI, nco, nci, Cout, Cin, accumulate;
 };
 
+// SL "split lanes": the nsplit partials of one output float4 are summed by SL threads (wave w = splits w, w + SL, ...,
+// 4 loads in flight each), combined through LDS in a fixed order.  With one thread per output (SL = 1) a layer with 30-60
+// splits is a chain of 8-15 dependent round trips per thread and the launch was latency-bound: 183 us for 219 MB
+// (profiles/r02a); four lanes per output and a 4x larger grid cut the chain to a quarter.
+template <int SL>
 __device__ __forceinline__ void wgrad2_reduce_body(const Wg2R& p, const long long blk) {
-  const long long v = blk * 256 + threadIdx.x;
-  if (v >= p.V) return;
+  constexpr int OUTS = 256 / SL;                 // output float4s per block
+  __shared__ f32x4 red[SL > 1 ? SL - 1 : 1][OUTS];
+  const int o = threadIdx.x % OUTS, sl = threadIdx.x / OUTS;
+  const long long v = blk * OUTS + o;
+  const bool valid = v < p.V;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-  const f32x4* src = p.part + v;
-  int k = 0;
-  for (; k + 4 <= p.nsplit; k += 4) {
-    const f32x4 a = src[(size_t)k * p.V], b = src[(size_t)(k + 1) * p.V], c = src[(size_t)(k + 2) * p.V],
-                d = src[(size_t)(k + 3) * p.V];
-    s0 += a; s1 += b; s2 += c; s3 += d;
+  if (valid) {
+    const f32x4* src = p.part + v;
+    int k = sl;
+    for (; k + 3 * SL < p.nsplit; k += 4 * SL) {
+      const f32x4 a = src[(size_t)k * p.V], b = src[(size_t)(k + SL) * p.V], c = src[(size_t)(k + 2 * SL) * p.V],
+                  d = src[(size_t)(k + 3 * SL) * p.V];
+      s0 += a; s1 += b; s2 += c; s3 += d;
+    }
+    for (; k < p.nsplit; k += SL) s0 += src[(size_t)k * p.V];
   }
-  for (; k < p.nsplit; ++k) s0 += src[(size_t)k * p.V];
-  const f32x4 sum = (s0 + s1) + (s2 + s3);
+  f32x4 sum = (s0 + s1) + (s2 + s3);
+  if (SL > 1) {
+    if (sl > 0) red[sl - 1][o] = sum;
+    __syncthreads();
+    if (sl > 0) return;
+#pragma unroll
+    for (int q = 0; q < SL - 1; ++q) sum += red[q][o];
+  }
+  if (!valid) return;
   const int lane = (int)(v & 63);
   long long r = v >> 6;
   const int j = (int)(r % p.NJ); r /= p.NJ;
@@ -543,7 +561,9 @@ __global__ __launch_bounds__(576) void wgrad2_reduce9_group_kernel(const Wg2R* _
   wgrad2_reduce9_body(p, b - starts[lo]);
 }
 
-__global__ __launch_bounds__(256) void wgrad2_reduce_kernel(const Wg2R p) { wgrad2_reduce_body(p, blockIdx.x); }
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad2_reduce_kernel(const Wg2R p) { wgrad2_reduce_body<SL>(p, blockIdx.x); }
+template <int SL>
 __global__ __launch_bounds__(256) void wgrad2_reduce_group_kernel(const Wg2R* __restrict__ jobs,
                                                                   const int* __restrict__ starts, int njobs) {
   const int b = blockIdx.x;
@@ -553,7 +573,7 @@ __global__ __launch_bounds__(256) void wgrad2_reduce_group_kernel(const Wg2R* __
     if (starts[mid] <= b) lo = mid; else hi = mid - 1;
   }
   const Wg2R p = jobs[lo];
-  wgrad2_reduce_body(p, b - starts[lo]);
+  wgrad2_reduce_body<SL>(p, b - starts[lo]);
 }
 
 // ---------------------------------------------------------------- host side
@@ -582,6 +602,11 @@ static int wg_env(const char* name, int dflt) {
 static int wg_xmap() { static const int v = wg_env("MI_WG_XMAP", 1); return v; }
 static int wg_units() { static const int v = wg_env("MI_WG_UNITS", 0); return v; }
 static int wg_red9() { static const int v = wg_env("MI_WG_RED9", 0); return v; }
+// threads per output float4 of the split-K reduction (1 or 4; see wgrad2_reduce_body)
+static int wg_redsl() {
+  static const int v = [] { const int e = wg_env("MI_WG_REDSL", 4); return (e == 1 || e == 4 || e == 8 || e == 16) ? e : 4; }();
+  return v;
+}
 // at least this much dynamic LDS per block of a grouped launch (e.g. 84000: one block per CU, the rest of the CU's LDS
 // stays free for kernels of another stream)
 // 1: v3 LDS layout (column-major by channel group, see wgrad3_body) for the 3x3 configurations, 2: for all, 0: v2
@@ -769,8 +794,16 @@ extern "C" int mi_conv2d_wgrad(const mi_wgrad_desc* d, mi_stream_t st) {
   r.Cout = d->Cout; r.Cin = d->Cin; r.accumulate = d->accumulate;
   if (c.NT == 9 && wg_red9())
     hipLaunchKernelGGL(wgrad2_reduce9_kernel, dim3((unsigned)(k.V / (64 * 9))), dim3(576), 0, s, r);
-  else
-    hipLaunchKernelGGL(wgrad2_reduce_kernel, dim3((unsigned)((k.V + 255) / 256)), dim3(256), 0, s, r);
+  else {
+    const int outs = 256 / wg_redsl();
+    const dim3 g((unsigned)((k.V + outs - 1) / outs));
+    switch (wg_redsl()) {
+      case 16: hipLaunchKernelGGL(wgrad2_reduce_kernel<16>, g, dim3(256), 0, s, r); break;
+      case 8: hipLaunchKernelGGL(wgrad2_reduce_kernel<8>, g, dim3(256), 0, s, r); break;
+      case 4: hipLaunchKernelGGL(wgrad2_reduce_kernel<4>, g, dim3(256), 0, s, r); break;
+      default: hipLaunchKernelGGL(wgrad2_reduce_kernel<1>, g, dim3(256), 0, s, r);
+    }
+  }
   MI_CHECK_LAUNCH("conv_wgrad_reduce");
   return MI_OK;
 }
@@ -910,7 +943,8 @@ extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, voi
     } else {
       rj.push_back(r);
       rs.push_back(rblocks);
-      rblocks += (int)((ks[i].V + 255) / 256);
+      const int outs = 256 / wg_redsl();
+      rblocks += (int)((ks[i].V + outs - 1) / outs);
     }
   }
   rs.push_back(rblocks);
@@ -965,8 +999,15 @@ extern "C" int mi_conv2d_wgrad_group_run(const mi_wgrad_group* meta, const void*
     MI_CHECK_LAUNCH("conv_wgrad_reduce9_group");
   }
   if (meta->red_blocks > 0) {
-    hipLaunchKernelGGL(wgrad2_reduce_group_kernel, dim3((unsigned)meta->red_blocks), dim3(256), 0, s,
-                       (const Wg2R*)(tab + meta->red_off), (const int*)(tab + meta->red_starts_off), meta->nred);
+    const dim3 g((unsigned)meta->red_blocks);
+    const Wg2R* jt = (const Wg2R*)(tab + meta->red_off);
+    const int* st_ = (const int*)(tab + meta->red_starts_off);
+    switch (wg_redsl()) {
+      case 16: hipLaunchKernelGGL(wgrad2_reduce_group_kernel<16>, g, dim3(256), 0, s, jt, st_, meta->nred); break;
+      case 8: hipLaunchKernelGGL(wgrad2_reduce_group_kernel<8>, g, dim3(256), 0, s, jt, st_, meta->nred); break;
+      case 4: hipLaunchKernelGGL(wgrad2_reduce_group_kernel<4>, g, dim3(256), 0, s, jt, st_, meta->nred); break;
+      default: hipLaunchKernelGGL(wgrad2_reduce_group_kernel<1>, g, dim3(256), 0, s, jt, st_, meta->nred);
+    }
     MI_CHECK_LAUNCH("conv_wgrad_reduce_group");
   }
   return MI_OK;
