@@ -106,6 +106,18 @@ def load():
     return out
 
 
+def _stub_alfred():
+    """`alfred` (the reference author's utility package, un-vendored): the debug print and the logger the loaded files
+    import at module level"""
+    if "alfred" not in sys.modules:
+        a = _stub("alfred", print_shape=lambda *a, **k: None)
+        a.__path__ = []
+        _stub("alfred.utils").__path__ = []
+        _stub("alfred.utils.log", logger=sys.modules["loguru"].logger)
+    elif not hasattr(sys.modules["alfred"], "print_shape"):
+        sys.modules["alfred"].print_shape = lambda *a, **k: None
+
+
 def load_detr():
     """the reference's DETR meta-arch file (meta_arch/detr.py: SetCriterion, PostProcess, MLP) loaded by path; the
     un-installed names it imports at module level (detectron2.structures, fvcore, alfred) are stubbed - none of them is
@@ -122,10 +134,7 @@ def load_detr():
     if "fvcore" not in sys.modules:
         _stub("fvcore")
         _stub("fvcore.nn", giou_loss=None, smooth_l1_loss=None)
-    if "alfred" not in sys.modules:
-        _stub("alfred")
-        _stub("alfred.utils")
-        _stub("alfred.utils.log", logger=sys.modules["loguru"].logger)
+    _stub_alfred()
     name = "yolov7.modeling.meta_arch"
     if name not in sys.modules:
         m = types.ModuleType(name)
@@ -266,6 +275,6 @@ def load_yolov6_loss():
     (unused by the loss) and `alfred.print_shape` (a debug print) are stubbed."""
     from torch import nn
     load()
-    _stub("alfred", print_shape=lambda *a, **k: None)
+    _stub_alfred()
     _stub("yolov7.modeling.backbone.efficientrep", Conv=nn.Module)
     return importlib.import_module("yolov7.modeling.head.yolov6_head")
