@@ -114,9 +114,19 @@ __global__ __launch_bounds__(256) void simota_cost_kernel(const LossK p) {
   const float pw = expf(pr[2]) * st, ph = expf(pr[3]) * st;
   const float so = sigmoid_ref(pr[4]);
   float S = 0.f;  // sum_c max(log(1 - p_c), -100)
-  for (int c = 0; c < p.ncls; ++c) {
-    const float pc = sqrtf(sigmoid_ref(pr[5 + c]) * so);
-    S += clamp_log(1.0f - pc);
+  // the row is read in batches of 16 logits issued together: one load per iteration is a chain of ncls dependent
+  // round trips for the lanes that own a candidate anchor, and the whole wave waits for them (same summation order)
+  for (int c0 = 0; c0 < p.ncls; c0 += 16) {
+    float lg[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) lg[u] = (c0 + u < p.ncls) ? pr[5 + c0 + u] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (c0 + u < p.ncls) {
+        const float pc = sqrtf(sigmoid_ref(lg[u]) * so);
+        S += clamp_log(1.0f - pc);
+      }
+    }
   }
   const float area_b = pw * ph;
   for (int g = 0; g < G; ++g) {
@@ -356,7 +366,14 @@ __global__ __launch_bounds__(256) void simota_resolve_loss_kernel(const LossK p)
         l_iou = 1.f - iou_v6_dual(pbox, lab + 1, p.iou_type, 0, 1e-7f).v;
       }
       const int gc = (int)lab[0];
-      for (int c = 0; c < p.ncls; ++c) l_cls += bce_logits(pr[5 + c], c == gc ? miou : 0.f);
+      for (int c0 = 0; c0 < p.ncls; c0 += 16) {   // batched row reads (see simota_cost_kernel), same summation order
+        float lg[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) lg[u] = (c0 + u < p.ncls) ? pr[5 + c0 + u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (c0 + u < p.ncls) l_cls += bce_logits(lg[u], (c0 + u) == gc ? miou : 0.f);
+      }
       if (p.use_l1) {
         float t[4];
         l1_target(lab, p.anchors[a * 3 + 0], p.anchors[a * 3 + 1], p.anchors[a * 3 + 2], t);
