@@ -202,6 +202,10 @@ static int conv_fill(const mi_conv_desc* d, ConvK* k, ConvCfg* c, size_t* ldsByt
   k->xstride = nch > 1 ? k->xbytes : 0;
   k->wstride = nst > 1 ? tps * (KC / 8) * BN * 16 : 0;
   c->KC = KC; c->BN = BN; c->TPIX = TPIX; c->TPS = tps;
+  {
+    static const int xm = getenv("MI_CONV_XMAP") ? atoi(getenv("MI_CONV_XMAP")) : 1;
+    k->xmap = (xm && k->nco > 1 && nblocks % 8 == 0) ? (int)(nblocks / 8) : 0;
+  }
   *ldsBytes = lds_need(KC, tps);
   const size_t stage = (size_t)TPIX * (BN * 2 + 16);          // staged epilogue tile
   const size_t red = (size_t)(TPIX == 128 && BN == 32 ? 256 : (TPIX == 64 && BN == 32 ? 128 : 256)) / (BN / 8) * BN * 8;
@@ -300,6 +304,7 @@ extern "C" int mi_conv2d_group_plan(const mi_conv_desc* descs, int n, void* tabl
     MI_REQUIRE(epi < 0 || epi == e, "conv_group_plan: jobs mix accumulating and plain launches");
     epi = e;
     if (l > lds) lds = l;
+    if (starts[j] % 8) ks[j].xmap = 0;   // the XCD of a block is its GLOBAL id % 8: the remap needs the job to start on XCD 0
     starts[j + 1] = starts[j] + ks[j].N * ks[j].tilesY * ks[j].tilesX * ks[j].nco;
   }
   meta->njobs = n; meta->nblocks = starts[n]; meta->lds_bytes = (int32_t)lds;

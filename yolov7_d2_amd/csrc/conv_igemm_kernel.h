@@ -48,6 +48,7 @@ struct ConvK {
   const float *bn_scale, *bn_shift, *bn_mean, *bn_invstd;
   int bn_ldy, bn_act;
   unsigned mTW, mHW;  // ceil(2^20 / TW), ceil(2^20 / haloW)
+  int xmap;           // XCD-aware block order: blocks / 8 when the launch has several cout tiles and blocks % 8 == 0, else 0
 };
 
 static __device__ uint4 g_conv_zero_page[4];
@@ -93,8 +94,11 @@ __device__ __forceinline__ void conv_igemm_body(PK& p, const int bid) {
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, h = lane >> 5;
 
-  const int cot = bid % p.nco;
-  const int tile = bid / p.nco;
+  // blocks of one pixel tile (its nco cout tiles) read the same halo: give each XCD (block id % 8) a contiguous range of
+  // (tile, cout tile) pairs so that they meet in one L2 instead of fetching the tile once per XCD (p.xmap = blocks / 8)
+  const int lb = p.xmap ? (bid & 7) * p.xmap + (bid >> 3) : bid;
+  const int cot = lb % p.nco;
+  const int tile = lb / p.nco;
   const int tpi = p.tilesY * p.tilesX;
   const int img = tile / tpi;
   const int rem = tile - img * tpi;
