@@ -203,8 +203,11 @@ static int conv_fill(const mi_conv_desc* d, ConvK* k, ConvCfg* c, size_t* ldsByt
   k->wstride = nst > 1 ? tps * (KC / 8) * BN * 16 : 0;
   c->KC = KC; c->BN = BN; c->TPIX = TPIX; c->TPS = tps;
   {
-    static const int xm = getenv("MI_CONV_XMAP") ? atoi(getenv("MI_CONV_XMAP")) : 1;
-    k->xmap = (xm && k->nco > 1 && nblocks % 8 == 0) ? (int)(nblocks / 8) : 0;
+    static const int xm = getenv("MI_CONV_XMAP") ? atoi(getenv("MI_CONV_XMAP")) : 2;
+    // 1: launches with several cout tiles per pixel tile; 2: also multi-tap launches (vertically adjacent tiles share
+    // halo rows); 3: every launch
+    const bool on = xm >= 3 || (xm == 2 && (k->nco > 1 || d->ntaps > 1)) || (xm == 1 && k->nco > 1);
+    k->xmap = (on && nblocks % 8 == 0) ? (int)(nblocks / 8) : 0;
   }
   *ldsBytes = lds_need(KC, tps);
   const size_t stage = (size_t)TPIX * (BN * 2 + 16);          // staged epilogue tile
