@@ -477,6 +477,9 @@ int mi_batched_softnms(const float* boxes, float* scores, const float* idxs, int
 /* Matrix NMS (utils/solov2_utils.py:160-206) from the mask-intersection matrix inter[n][n] = masks @ masks^T
  * (candidates in descending score order), sum_masks[n], labels[n] (as float): out_scores[n] = scores * decay.
  * comp_ws: n floats of scratch. */
+/* greedy mask NMS (utils/solov2_utils.py:209-236) on the same intersection matrix: keep[n] (1 = kept) */
+int mi_mask_nms(const float* inter, const float* sum_masks, const float* labels, int n, float nms_thr, uint8_t* keep,
+                mi_stream_t s);
 int mi_matrix_nms(const float* inter, const float* sum_masks, const float* labels, const float* scores, int n, float sigma,
                   int linear, float* comp_ws, float* out_scores, mi_stream_t s);
 

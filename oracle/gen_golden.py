@@ -281,6 +281,8 @@ def gold_nms_family():
         for kern in ("gaussian", "linear"):
             out = r.solov2_utils.matrix_nms(labels, masks, sums, scores, sigma=2.0, kernel=kern)
             res[f"{name}_{kern}"] = out.numpy()
+        if n <= 60:      # the reference's greedy mask_nms is an O(n^2) Python loop over full masks
+            res[f"{name}_masknms"] = np.asarray(r.solov2_utils.mask_nms(labels, masks, sums, scores, nms_thr=0.3)).astype(np.float32)
     np.savez_compressed(os.path.join(OUT, "nms_family.npz"), **res)
     print("nms family:", {k: v.shape for k, v in res.items() if "keep" in k or "m2" in k})
 

@@ -607,3 +607,20 @@ def test_matrix_nms_against_reference_golden(golden_dir, case, n, H, W, ncls, se
     out = matrix_nms(labels.to(DEV), masks.to(DEV), sums.to(DEV), scores.to(DEV), sigma=2.0, kernel=kernel)
     np.testing.assert_allclose(out.cpu().numpy(), g[f"{case}_{kernel}"], rtol=2e-5, atol=1e-7)
     assert matrix_nms(labels[:0], masks[:0], sums[:0], scores[:0]) == []
+
+
+@pytest.mark.parametrize("case,n,H,W,ncls,seed", [("m1", 60, 40, 48, 3, 81), ("m3", 1, 8, 8, 1, 83)])
+def test_mask_nms_against_reference_golden(golden_dir, case, n, H, W, ncls, seed):
+    """greedy mask NMS (utils/solov2_utils.py:209-236) against the reference's own double loop: keep flags exact"""
+    import sys
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle")
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    from gen_golden_inputs import synth_mask_case
+    from yolov7_d2_amd.modeling import mask_nms
+    g = np.load(os.path.join(golden_dir, "nms_family.npz"))
+    labels, masks, sums, scores = synth_mask_case(n, H, W, ncls, seed)
+    keep = mask_nms(labels.to(DEV), masks.to(DEV), sums.to(DEV), scores.to(DEV), nms_thr=0.3)
+    assert np.array_equal(keep.cpu().numpy().astype(np.float32), g[f"{case}_masknms"])
+    if n > 1:
+        assert 0 < float(keep.sum()) < n

@@ -192,6 +192,7 @@ _PROTOS = {
     "mi_dwconv3x3_wgrad": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _vp]),
     "mi_batched_nms_ex": (C.c_int, [_vp, _vp, _vp, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_batched_softnms": (C.c_int, [_vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp, _vp]),
+    "mi_mask_nms": (C.c_int, [_vp, _vp, _vp, _i, _f, _vp, _vp]),
     "mi_matrix_nms": (C.c_int, [_vp, _vp, _vp, _vp, _i, _f, _i, _vp, _vp, _vp]),
     "mi_rle_encode": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mi_rle_to_string": (C.c_int, [_vp, _i, C.c_char_p, _i]),

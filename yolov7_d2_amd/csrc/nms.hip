@@ -338,3 +338,44 @@ extern "C" int mi_matrix_nms(const float* inter, const float* sum_masks, const f
   MI_CHECK_LAUNCH("matrix_nms");
   return MI_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Greedy mask NMS (mask_nms, yolov7/utils/solov2_utils.py:209-236) on the mask-intersection matrix: candidates in
+// descending score order; a kept candidate i removes every later j of the same label whose mask IoU
+// inter / (sum_i + sum_j - inter) exceeds thr - and every later same-label j whose union is 0.  One block: the scan over i
+// is sequential (a candidate's fate depends on the kept ones before it), the sweep over j is parallel.
+__global__ __launch_bounds__(1024) void mask_nms_kernel(const float* __restrict__ inter, const float* __restrict__ sums,
+                                                        const float* __restrict__ labels, int n, float thr,
+                                                        uint8_t* __restrict__ keep) {
+  extern __shared__ uint8_t s_keep[];
+  for (int j = threadIdx.x; j < n; j += 1024) s_keep[j] = 1;
+  __syncthreads();
+  for (int i = 0; i + 1 < n; ++i) {
+    if (s_keep[i]) {   // (uniform: read from LDS after the barrier)
+      const float li = labels[i], si = sums[i];
+      for (int j = i + 1 + threadIdx.x; j < n; j += 1024) {
+        if (!s_keep[j] || labels[j] != li) continue;
+        const float in = inter[(size_t)i * n + j];
+        const float uni = si + sums[j] - in;
+        if (uni > 0.f) {
+          if (in / uni > thr) s_keep[j] = 0;
+        } else {
+          s_keep[j] = 0;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int j = threadIdx.x; j < n; j += 1024) keep[j] = s_keep[j];
+}
+extern "C" int mi_mask_nms(const float* inter, const float* sum_masks, const float* labels, int n, float nms_thr,
+                           uint8_t* keep, mi_stream_t st) {
+  MI_REQUIRE(n >= 0 && n <= 65536, "mask_nms: n %d", n);
+  if (n == 0) return MI_OK;
+  MI_REQUIRE(inter && sum_masks && labels && keep, "mask_nms: null");
+  hipLaunchKernelGGL(mask_nms_kernel, dim3(1), dim3(1024), (size_t)n, (hipStream_t)st, inter, sum_masks, labels, n, nms_thr,
+                     keep);
+  MI_CHECK_LAUNCH("mask_nms");
+  return MI_OK;
+}

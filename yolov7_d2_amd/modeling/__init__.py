@@ -1,6 +1,6 @@
 from .blocks import BaseConv, Bottleneck, CSPLayer, Focus, SPPBottleneck
 from .postprocess import (batched_nms, postprocess, generalized_batched_nms, batched_softnms, batched_clusternms,
-                          matrix_nms)
+                          matrix_nms, mask_nms)
 from .yolox import YOLOX
 from .yolox_net import CSPDarknet, YOLOPAFPN, YOLOXHead, build_cspdarknetx_backbone
 from .detr_matcher import HungarianMatcher

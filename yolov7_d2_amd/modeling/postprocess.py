@@ -121,6 +121,34 @@ def generalized_batched_nms(boxes, scores, idxs, iou_threshold, score_threshold=
     raise NotImplementedError("NMS type not implemented: \"{}\"".format(nms_type))
 
 
+def _mask_inter(seg_masks, n):
+    """n x n mask intersections = masks @ masks^T, one MFMA pass over the pixels (0 / 1 masks: exact)"""
+    from .sparseinst import pixel_outer
+    dev = seg_masks.device
+    m = seg_masks.reshape(n, -1)
+    P = m.shape[1]
+    npad, ppad = (n + 31) // 32 * 32, (P + 7) // 8 * 8
+    mt = torch.zeros(ppad, npad, dtype=torch.bfloat16, device=dev)      # pixels x candidates, zero padded
+    mt[:P, :n] = m.t().to(torch.bfloat16)
+    return pixel_outer(mt, mt)[:n, :n].contiguous()
+
+
+def mask_nms(cate_labels, seg_masks, sum_masks, cate_scores, nms_thr=0.5):
+    """utils/solov2_utils.py:209-236: greedy NMS on mask IoU (candidates sorted by descending score) -> keep [n]
+    (1.0 / 0.0 in the masks' dtype, like the reference's `seg_masks.new_ones`)"""
+    n = len(cate_scores)
+    if n == 0:
+        return []
+    if not seg_masks.is_cuda:
+        raise L.MI355Error("mask_nms: HIP tensors required (no CPU fallback)")
+    inter = _mask_inter(seg_masks, n)
+    keep = torch.empty(n, dtype=torch.uint8, device=seg_masks.device)
+    L.check(L.lib().mi_mask_nms(inter.data_ptr(), sum_masks.contiguous().float().data_ptr(),
+                                cate_labels.contiguous().float().data_ptr(), n, float(nms_thr), keep.data_ptr(), L.stream_ptr()),
+            "mi_mask_nms")
+    return keep.to(seg_masks.dtype if seg_masks.dtype != torch.bool else torch.float32)
+
+
 def matrix_nms(cate_labels, seg_masks, sum_masks, cate_scores, sigma=2.0, kernel="gaussian"):
     """utils/solov2_utils.py:160-206 (SOLOv2): decayed scores of n mask candidates sorted by descending score.
     The n x n mask intersections are one MFMA pass over the pixels (masks are 0 / 1: exact in bf16 with fp32 sums)."""
@@ -129,14 +157,8 @@ def matrix_nms(cate_labels, seg_masks, sum_masks, cate_scores, sigma=2.0, kernel
         return []
     if not seg_masks.is_cuda:
         raise L.MI355Error("matrix_nms: HIP tensors required (no CPU fallback)")
-    from .sparseinst import pixel_outer
     dev = seg_masks.device
-    m = seg_masks.reshape(n, -1)
-    P = m.shape[1]
-    npad, ppad = (n + 31) // 32 * 32, (P + 7) // 8 * 8
-    mt = torch.zeros(ppad, npad, dtype=torch.bfloat16, device=dev)      # pixels x candidates, zero padded
-    mt[:P, :n] = m.t().to(torch.bfloat16)
-    inter = pixel_outer(mt, mt)[:n, :n].contiguous()
+    inter = _mask_inter(seg_masks, n)
     out = torch.empty(n, dtype=torch.float32, device=dev)
     comp = torch.empty(n, dtype=torch.float32, device=dev)
     L.check(L.lib().mi_matrix_nms(inter.data_ptr(), sum_masks.contiguous().float().data_ptr(),
