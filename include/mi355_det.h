@@ -447,6 +447,28 @@ int mi_yolox_iou_loss(const float* pred, const float* target, int n, int loss_ty
  * boxes (cx,cy,w,h) (box_xyxy 0) or (x1,y1,x2,y2) */
 int mi_pairwise_bbox_iou(const float* box1, const float* box2, int N, int M, int box_xyxy, float* out, mi_stream_t s);
 
+/* ---- BiFPN neck (neck/bifpn.py:184-395, build_resnet_bifpn_backbone) -------------------
+ * GroupNorm = detectron2 get_norm("GN") = nn.GroupNorm(32, C) (MODEL.BIFPN.NORM default): NHWC bf16, x [N][HW][ldx],
+ * C % 8 == 0, C % G == 0 (C / G need not be a multiple of 8), eps as nn.GroupNorm (1e-5).  mean_rstd [N][G][2] is written
+ * by fwd and read by bwd; ws: mi_groupnorm_ws_bytes(N, C) bytes of scratch (zeroed inside).  bwd overwrites dgamma / dbeta. */
+int64_t mi_groupnorm_ws_bytes(int N, int C);
+int mi_groupnorm_fwd(const void* x, int ldx, int N, int HW, int C, int G, const float* gamma, const float* beta, float eps,
+                     void* y, int ldy, float* mean_rstd, double* ws, mi_stream_t s);
+int mi_groupnorm_bwd(const void* dy, int lddy, const void* x, int ldx, int N, int HW, int C, int G, const float* gamma,
+                     const float* mean_rstd, void* dx, int lddx, float* dgamma, float* dbeta, double* ws, mi_stream_t s);
+/* nn.MaxPool2d(2, 2) of ResampleFeatureMap (bifpn.py:151-155), floor mode; bwd recomputes the arg-max from x (first
+ * maximum in row-major window order); with odd H / W the caller zero-fills dx first */
+int mi_maxpool2x2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, mi_stream_t s);
+int mi_maxpool2x2_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int C,
+                      mi_stream_t s);
+/* FpnCombine "fastattn" (bifpn.py:221-236): out = sum_i x_i * relu(w_i) / (sum relu(w) + 1e-4) over nin = 2 or 3
+ * contiguous bf16 tensors of n elements (n % 8 == 0); bwd: dx_i (dxs[i] may be NULL) and d edge_weights [nin]
+ * (deterministic: per-block partials in ws, mi_fastattn_ws_bytes() bytes) */
+int64_t mi_fastattn_ws_bytes(void);
+int mi_fastattn_fwd(const void* const* xs, int nin, const float* edge_weights, void* out, int64_t n, mi_stream_t s);
+int mi_fastattn_bwd(const void* const* xs, int nin, const float* edge_weights, const void* g, void* const* dxs, float* dedge,
+                    float* ws, int64_t n, mi_stream_t s);
+
 /* ---- COCO run-length encoding of masks (evaluation output format) ----------------------
  * what pycocotools.mask.encode does for instances_to_coco_json (evaluation/coco_evaluation.py:38-50; the algorithm is
  * cocoapi's maskApi.c rleEncode / rleToString, un-vendored): masks uint8 [n][H][W] (device, non-zero = foreground) ->

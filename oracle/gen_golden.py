@@ -10,6 +10,7 @@ OUTPUTS are stored.
 """
 import os
 import sys
+import types
 
 import numpy as np
 import torch
@@ -310,6 +311,46 @@ def gold_yolov6_loss():
     print("yolov6 loss:", {k: v for k, v in res.items() if "parts" in k or "total" in k})
 
 
+def gold_bifpn():
+    """the reference's BiFPN (neck/bifpn.py:307-395) over seeded C3..C5 maps, fp32: p3..p7, the gradients with respect to
+    the inputs, every edge weight / GroupNorm parameter, and two convolution weights; dense and separable variants"""
+    from gen_golden_inputs import BIFPN_CASES, synth_bifpn_case, bifpn_state_dict
+    m = ref_loader.load_bifpn()
+
+    class Feats(m.Backbone):
+        def __init__(self, chans):
+            super().__init__()
+            self.chans = chans
+
+        def output_shape(self):
+            return {f"res{i + 3}": types.SimpleNamespace(channels=c, stride=8 << i) for i, c in enumerate(self.chans)}
+
+        def forward(self, x):
+            return x
+
+    res = {}
+    for name, kw in BIFPN_CASES.items():
+        feats, gos = synth_bifpn_case(out_channels=kw["out_channels"])
+        net = m.BiFPN(cfg=None, bottom_up=Feats([v.shape[1] for v in feats.values()]), in_features=list(feats.keys()),
+                      norm="GN", num_levels=5, **kw)
+        net.load_state_dict(bifpn_state_dict(net))
+        xs = {k: v.clone().requires_grad_(True) for k, v in feats.items()}
+        out = net(xs)
+        sum((out[k] * gos[k]).sum() for k in out).backward()
+        res[name + "_keys"] = np.array([f"{k}:{tuple(v.shape)}" for k, v in net.state_dict().items()])
+        for k, v in out.items():
+            res[f"{name}_out_{k}"] = v.detach().numpy()
+        for k, v in xs.items():
+            res[f"{name}_dx_{k}"] = v.grad.numpy()
+        big = [k for k, p in net.named_parameters() if p.dim() == 4]
+        keep = {big[0], big[-1]}
+        for k, p in net.named_parameters():
+            if p.dim() == 1 or k in keep:
+                res[f"{name}_grad_{k}"] = p.grad.numpy()
+        print("bifpn", name, {k: float(v.abs().mean()) for k, v in out.items()}, len(list(net.parameters())), "parameters")
+    np.savez_compressed(os.path.join(OUT, "bifpn.npz"), **res)
+
+
 def gold_encoder_layer():
     """the reference's own TransformerEncoderLayer (backbone/detr_backbone.py:135-194), eval mode (dropout off), fp32"""
     import importlib
@@ -567,6 +608,7 @@ if __name__ == "__main__":
     gold_yolox_iou()
     gold_nms_family()
     gold_yolov6_loss()
+    gold_bifpn()
     gold_encoder_layer()
     gold_transformer()
     gold_pos_embed()

@@ -226,3 +226,37 @@ def synth_yolov6_case(B=3, H=160, W=192, seed=91, nc=80):
     t = labels.clone()
     t[..., 1:5] = t[..., 1:5] / torch.tensor([W, H, W, H]).float()
     return outs, t, labels, raw, anchors
+
+
+BIFPN_CASES = {"dense": dict(out_channels=64, num_bifpn=2, separable_conv=False),
+               "separable": dict(out_channels=96, num_bifpn=1, separable_conv=True)}
+
+
+def synth_bifpn_case(B=2, chans=(32, 64, 128), size=256, out_channels=64, seed=131):
+    """seeded C3..C5 feature maps of a `size` x `size` image (strides 8 / 16 / 32) and the gradients fed into p3..p7"""
+    g = torch.Generator().manual_seed(seed)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    feats = {f"res{i + 3}": bf(torch.randn(B, c, size // s, size // s, generator=g)) for i, (c, s) in enumerate(zip(chans, (8, 16, 32)))}
+    gos = {f"p{l}": bf(torch.randn(B, out_channels, size >> l, size >> l, generator=g)) for l in range(3, 8)}
+    return feats, gos
+
+
+def bifpn_state_dict(module, seed=132):
+    """seeded parameters keyed / shaped by the module's own state_dict (sorted key order): GroupNorm weights around 1,
+    edge weights spread around 1 with one negative entry per 7 (the relu of fastattn), conv weights N(0, 1/sqrt(fan_in))"""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for i, k in enumerate(sorted(module.state_dict().keys())):
+        shp = module.state_dict()[k].shape
+        if k.endswith("edge_weights"):
+            w = 1.0 + 0.5 * torch.randn(*shp, generator=g)
+            if i % 7 == 0:
+                w[0] = -0.3
+            out[k] = w
+        elif ".bn." in k:
+            out[k] = (1 + 0.1 * torch.randn(*shp, generator=g)) if k.endswith("weight") else 0.1 * torch.randn(*shp, generator=g)
+        elif len(shp) == 4:
+            out[k] = torch.randn(*shp, generator=g) / (shp[1] * shp[2] * shp[3]) ** 0.5
+        else:
+            out[k] = 0.02 * torch.randn(*shp, generator=g)
+    return out

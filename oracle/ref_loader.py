@@ -278,3 +278,28 @@ def load_yolov6_loss():
     _stub_alfred()
     _stub("yolov7.modeling.backbone.efficientrep", Conv=nn.Module)
     return importlib.import_module("yolov7.modeling.head.yolov6_head")
+
+
+def load_bifpn():
+    """neck/bifpn.py loaded by path.  Stubbed module-level imports it never calls on this path: fvcore's weight init,
+    detectron2's ResNet builder, the reference's EfficientNet / DLA builders and `MaxPool2d` wrapper (used only by the
+    RetinaNet-style LastLevelP6P7).  detectron2.layers.Conv2d is nn.Conv2d when no norm / activation is passed (how bifpn.py
+    uses it) and get_norm("GN", C) is nn.GroupNorm(32, C) (detectron2/layers/batch_norm.py, published behaviour)."""
+    from torch import nn
+    load()
+    if "fvcore" not in sys.modules:
+        _stub("fvcore")
+    if "fvcore.nn" not in sys.modules:
+        _stub("fvcore.nn")
+    if "fvcore.nn.weight_init" not in sys.modules:
+        _stub("fvcore.nn.weight_init", c2_xavier_fill=lambda m: None, c2_msra_fill=lambda m: None)
+    sys.modules["fvcore.nn"].weight_init = sys.modules["fvcore.nn.weight_init"]
+    sys.modules["detectron2.layers"].Conv2d = nn.Conv2d
+    sys.modules["detectron2.layers.batch_norm"].get_norm = lambda norm, c: nn.GroupNorm(32, c) if norm == "GN" else None
+    _stub("detectron2.modeling.backbone.resnet", build_resnet_backbone=None)
+    sys.modules["yolov7.modeling.backbone.layers"].MaxPool2d = nn.MaxPool2d
+    _stub("yolov7.modeling.backbone.efficientnet", build_efficientnet_backbone=None)
+    _stub("yolov7.modeling.backbone.dlafpn", dla34=None)
+    m = importlib.import_module("yolov7.modeling.neck.bifpn")
+    m.Backbone = sys.modules["detectron2.modeling.backbone"].Backbone
+    return m

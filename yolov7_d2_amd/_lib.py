@@ -194,6 +194,14 @@ _PROTOS = {
     "mi_batched_softnms": (C.c_int, [_vp, _vp, _vp, _i, _f, _f, _i, _vp, _vp, _vp]),
     "mi_mask_nms": (C.c_int, [_vp, _vp, _vp, _i, _f, _vp, _vp]),
     "mi_matrix_nms": (C.c_int, [_vp, _vp, _vp, _vp, _i, _f, _i, _vp, _vp, _vp]),
+    "mi_groupnorm_ws_bytes": (C.c_int64, [_i, _i]),
+    "mi_groupnorm_fwd": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp]),
+    "mi_groupnorm_bwd": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "mi_maxpool2x2_fwd": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mi_maxpool2x2_bwd": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mi_fastattn_ws_bytes": (C.c_int64, []),
+    "mi_fastattn_fwd": (C.c_int, [C.POINTER(C.c_void_p), _i, _vp, _vp, _i64, _vp]),
+    "mi_fastattn_bwd": (C.c_int, [C.POINTER(C.c_void_p), _i, _vp, _vp, C.POINTER(C.c_void_p), _vp, _vp, _i64, _vp]),
     "mi_rle_encode": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mi_rle_to_string": (C.c_int, [_vp, _i, C.c_char_p, _i]),
     "mi_yolox_onnx_layout": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),

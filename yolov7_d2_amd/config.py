@@ -126,6 +126,7 @@ def add_yolo_config(cfg):
     _C.MODEL.PADDED_VALUE = 114.0
     _C.MODEL.FPN.REPEAT = 2
     _C.MODEL.FPN.OUT_CHANNELS_LIST = [256, 512, 1024]
+    _C.MODEL.BIFPN = CN({"NUM_LEVELS": 5, "NUM_BIFPN": 6, "NORM": "GN", "OUT_CHANNELS": 160, "SEPARABLE_CONV": False})
     _C.INPUT.INPUT_SIZE = [640, 640]
     _C.MODEL.YOLO = CN({
         "NUM_BRANCH": 3, "VARIANT": "yolov3", "ANCHOR_MASK": [], "CLASSES": 80, "MAX_BOXES_NUM": 100,

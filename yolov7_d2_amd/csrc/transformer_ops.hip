@@ -119,14 +119,19 @@ __global__ __launch_bounds__(256) void ew_kernel(const __bf16* __restrict__ a, c
       else if (op == 1) z = fmaxf(x, 0.f);
       else if (op == 2) z = y > 0.f ? x : 0.f;  // a = dy, b = forward output
       else if (op == 3) z = 1.f / (1.f + __expf(-x));
-      else z = x * y * (1.f - y);              // op 4: sigmoid backward, a = dy, b = forward output
+      else if (op == 4) z = x * y * (1.f - y); // sigmoid backward, a = dy, b = forward output
+      else if (op == 5) z = x / (1.f + __expf(-x));   // swish / SiLU (BiFPN's Swish, neck/bifpn.py:49-61)
+      else {                                   // op 6: swish backward, a = dy, b = forward INPUT
+        const float sg = 1.f / (1.f + __expf(-y));
+        z = x * sg * (1.f + y * (1.f - sg));
+      }
       r[e] = (__bf16)z;
     }
     *(bf16x8*)(o + i * 8) = r;
   }
 }
 extern "C" int mi_ew_bf16(const void* a, const void* b, void* out, int64_t n, int op, mi_stream_t st) {
-  MI_REQUIRE(a && out && n > 0 && n % 8 == 0 && op >= 0 && op <= 4 && (op == 1 || op == 3 || b), "ew_bf16: args");
+  MI_REQUIRE(a && out && n > 0 && n % 8 == 0 && op >= 0 && op <= 6 && (op == 1 || op == 3 || op == 5 || b), "ew_bf16: args");
   MI_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && ((uintptr_t)out % 16) == 0, "ew_bf16: alignment");
   int64_t blocks = (n / 8 + 255) / 256;
   if (blocks > 2048) blocks = 2048;

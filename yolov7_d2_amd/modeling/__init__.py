@@ -20,3 +20,5 @@ from .sparseinst import (SparseInst, InstanceContextEncoder, PyramidPoolingModul
                          SparseInstMatcher, build_sparse_inst_encoder, build_sparse_inst_decoder,
                          build_sparse_inst_criterion, rescoring_mask)
 from .yolov6_loss import ComputeLoss
+from .bifpn import (BiFPN, BiFpnLayer, FpnCombine, ResampleFeatureMap, SeparableConv2d, ConvBnAct2d, Swish, GroupNorm,
+                    get_fpn_config, build_resnet_bifpn_backbone)
