@@ -411,7 +411,9 @@ def test_grouped_launches_equal_separate_launches(monkeypatch, B, H, W):
         ps.plan.run("fwd"); ps.plan.run("bwd"); torch.cuda.synchronize()
         grads = {n: model.params.grad_of(p).detach().float().cpu().clone() for n, p in model.named_parameters()}
         res[mode] = (ps.loss_out()[:4].cpu().clone(), grads)
-    np.testing.assert_allclose(res["1"][0].numpy(), res["0"][0].numpy(), rtol=1e-5)
+    # (a grouped member runs on the group's tile shape: its fp32 per-tile BatchNorm partial sums are taken in another order,
+    #  and one flipped bf16 rounding of an activation moves a loss component by ~1e-5 relative at 16 x 640 x 640)
+    np.testing.assert_allclose(res["1"][0].numpy(), res["0"][0].numpy(), rtol=1e-4)
     bad = []
     for n, g0 in res["0"][1].items():
         g1 = res["1"][1][n]

@@ -63,6 +63,10 @@ struct ConvCfg {
   int KC, BN, TPIX, TPS;
 };
 
+#ifdef MI_CONV_TIMELINE
+static long long* g_conv_tl = nullptr;
+extern "C" void mi_debug_conv_timeline(long long* dev_buf) { g_conv_tl = dev_buf; }
+#endif
 static int conv_fill(const mi_conv_desc* d, ConvK* k, ConvCfg* c, size_t* ldsBytes) {
   MI_REQUIRE(d->x && d->w && d->y, "conv: null pointer");
   MI_REQUIRE(d->ntaps >= 1 && d->ntaps <= MI_MAX_TAPS, "conv: ntaps %d", d->ntaps);
@@ -208,10 +212,13 @@ static int conv_fill(const mi_conv_desc* d, ConvK* k, ConvCfg* c, size_t* ldsByt
     // halo rows); 3: every launch
     const bool on = xm >= 3 || (xm == 2 && (k->nco > 1 || d->ntaps > 1)) || (xm == 1 && k->nco > 1);
     k->xmap = (on && nblocks % 8 == 0) ? (int)(nblocks / 8) : 0;
+#ifdef MI_CONV_TIMELINE
+    k->tl = g_conv_tl;
+#endif
   }
   *ldsBytes = lds_need(KC, tps);
   const size_t stage = (size_t)TPIX * (BN * 2 + 16);          // staged epilogue tile
-  const size_t red = (size_t)(TPIX == 128 && BN == 32 ? 256 : (TPIX == 64 && BN == 32 ? 128 : 256)) / (BN / 8) * BN * 8;
+  const size_t red = (size_t)16 * BN * 8;                     // statistics rows of up to 16 waves
   if (*ldsBytes < stage) *ldsBytes = stage;
   if (*ldsBytes < red) *ldsBytes = red;
   if (*ldsBytes < 4 * BN * 8) *ldsBytes = 4 * BN * 8;
@@ -236,11 +243,23 @@ extern "C" int mi_conv2d(const mi_conv_desc* d, mi_stream_t st) {
   int rc = conv_fill(d, &k, &c, &lds);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)st;
+  // 8-wave form of the same tile: half the 32x32 MFMA tiles, half the staging / store rows and ~40 % fewer registers per
+  // wave.  The blocks are latency-bound per wave (LDS round trips of the fragments, the serial epilogue), so twice the
+  // waves per SIMD on the same data is worth 1.5 % (fast boxes) to 6 % (slow boxes) of the step; 16 waves lose again.
+  // MI_CONV_W8 / MI_CONV_W8G: largest grid (blocks) of a single / grouped launch that takes it (0: never).
+  static const long w8max = getenv("MI_CONV_W8") ? atol(getenv("MI_CONV_W8")) : (1L << 40);
+  static const int w8mask = getenv("MI_CONV_W8MASK") ? atoi(getenv("MI_CONV_W8MASK")) : 7;
+  const long nblocks = (long)k.N * k.tilesY * k.tilesX * k.nco;
+  int tp = c.TPIX;
+  const int cls = (c.TPIX == 128 && c.BN == 64) ? 1 : (c.TPIX == 128 && c.BN == 128) ? 2 : (c.TPIX == 64 && c.BN == 128) ? 4 : 0;
+  if (nblocks <= w8max && (cls & w8mask) && !(d->flags & MI_CONV_OUT_F32) && (d->Cout & 7) == 0) {
+    tp |= 1024;
+  }
   switch (c.KC) {
-    case 16: return conv_launch_kc16(k, c.BN, c.TPIX, lds, s);
-    case 32: return conv_launch_kc32(k, c.BN, c.TPIX, lds, s);
-    case 64: return conv_launch_kc64(k, c.BN, c.TPIX, lds, s);
-    case 128: return conv_launch_kc128(k, c.BN, c.TPIX, lds, s);
+    case 16: return conv_launch_kc16(k, c.BN, tp, lds, s);
+    case 32: return conv_launch_kc32(k, c.BN, tp, lds, s);
+    case 64: return conv_launch_kc64(k, c.BN, tp, lds, s);
+    case 128: return conv_launch_kc128(k, c.BN, tp, lds, s);
   }
   MI_FAIL(MI_EINVAL, "conv: no kernel for KC %d BN %d TPIX %d", c.KC, c.BN, c.TPIX);
 }
@@ -310,8 +329,19 @@ extern "C" int mi_conv2d_group_plan(const mi_conv_desc* descs, int n, void* tabl
     if (starts[j] % 8) ks[j].xmap = 0;   // the XCD of a block is its GLOBAL id % 8: the remap needs the job to start on XCD 0
     starts[j + 1] = starts[j] + ks[j].N * ks[j].tilesY * ks[j].tilesX * ks[j].nco;
   }
+  int tpix = cb.TPIX;
+  {
+    static const long w8max = getenv("MI_CONV_W8G") ? atol(getenv("MI_CONV_W8G")) : (1L << 40);
+    static const int w8mask = getenv("MI_CONV_W8MASK") ? atoi(getenv("MI_CONV_W8MASK")) : 7;
+    const int cls = (cb.TPIX == 128 && cb.BN == 64) ? 1 : (cb.TPIX == 128 && cb.BN == 128) ? 2 : (cb.TPIX == 64 && cb.BN == 128) ? 4 : 0;
+    bool staged = true;
+    for (int j = 0; j < n; ++j) staged = staged && !(descs[j].flags & MI_CONV_OUT_F32) && (descs[j].Cout & 7) == 0;
+    if (starts[n] <= w8max && (cls & w8mask) && staged) {
+      tpix |= 1024;   // 8-wave form (see mi_conv2d)
+    }
+  }
   meta->njobs = n; meta->nblocks = starts[n]; meta->lds_bytes = (int32_t)lds;
-  meta->KC = cb.KC; meta->BN = cb.BN; meta->TPIX = cb.TPIX; meta->TPS = cb.TPS; meta->EPI = epi;
+  meta->KC = cb.KC; meta->BN = cb.BN; meta->TPIX = tpix; meta->TPS = cb.TPS; meta->EPI = epi;
   meta->starts_off = (int64_t)sizeof(ConvK) * n;
   meta->table_bytes = meta->starts_off + (int64_t)sizeof(int) * (n + 1);
   if (table_host) {

@@ -49,7 +49,15 @@ struct ConvK {
   int bn_ldy, bn_act;
   unsigned mTW, mHW;  // ceil(2^20 / TW), ceil(2^20 / haloW)
   int xmap;           // XCD-aware block order: blocks / 8 when the launch has several cout tiles and blocks % 8 == 0, else 0
+#ifdef MI_CONV_TIMELINE
+  long long* tl;      // [blocks][8] phase timestamps (tools/conv_timeline.py; diagnostic builds only)
+#endif
 };
+#ifdef MI_CONV_TIMELINE
+#define CONV_TL(k) do { if (p.tl && threadIdx.x == 0 && bid < 8192) p.tl[bid * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define CONV_TL(k)
+#endif
 
 static __device__ uint4 g_conv_zero_page[4];
 
@@ -163,11 +171,14 @@ __device__ __forceinline__ void conv_igemm_body(PK& p, const int bid) {
   };
 
   const int nsteps_run = (p.flags & 256) ? 0 : nsteps;
+  CONV_TL(0);
   if (nsteps_run) { issue_w(0); issue_x(0); }
+  CONV_TL(1);
   for (int step = 0; step < nsteps_run; ++step) {
     const int kc = step / ngr, g = step - kc * ngr;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // slabs `step` and chunk `kc` landed; the other buffers are no longer read
+    if (step == 0) CONV_TL(2);
     if (step + 1 < nsteps) issue_w(step + 1);
     if (g == 0 && kc + 1 < nchunks) issue_x(kc + 1);
     const char* Xs = smem + (kc & 1) * p.xstride;
@@ -200,6 +211,7 @@ __device__ __forceinline__ void conv_igemm_body(PK& p, const int bid) {
     }
   }
 
+  CONV_TL(3);
   if (p.flags & 512) {
     float z = 0.f;
 #pragma unroll
@@ -266,6 +278,7 @@ __device__ __forceinline__ void conv_igemm_body(PK& p, const int bid) {
       // (measured dead end: taking the statistics from the staged tile FIRST and issuing the atomics before the stores
       //  - so that their latency overlaps the store phase - is 0.6 % slower than this order)
       stage();
+      CONV_TL(4);
 #pragma unroll 2
       for (int P = pr; P < TPIX; P += PPI) {
         const int op = out_pixel(P);
@@ -303,6 +316,7 @@ __device__ __forceinline__ void conv_igemm_body(PK& p, const int bid) {
         }
       }
       stage();
+      CONV_TL(4);
 #pragma unroll
       for (int it = 0; it < NP; ++it) {
         if (opix[it] >= 0) {
@@ -338,18 +352,31 @@ __device__ __forceinline__ void conv_igemm_body(PK& p, const int bid) {
         }
       }
     }
+    CONV_TL(5);
     if (do_stats) {
-      __syncthreads();  // staging tile fully consumed
-      float* Rs = (float*)smem;  // [PPI][BN][2]
+      // threads of a wave that own the same 8 channels (lane % C8N) fold their sums by lane exchange; one row per wave
+      // goes through LDS, and BN threads add the NW rows and issue the atomics
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        Rs[(pr * BN + c8 * 8 + e) * 2 + 0] = s1[e];
-        Rs[(pr * BN + c8 * 8 + e) * 2 + 1] = s2[e];
+      for (int off = C8N; off < 64; off <<= 1)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          s1[e] += __shfl_xor(s1[e], off, 64);
+          s2[e] += __shfl_xor(s2[e], off, 64);
+        }
+      __syncthreads();  // staging tile fully consumed
+      float* Rs = (float*)smem;  // [NW][BN][2]
+      if (lane < C8N) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          Rs[(wave * BN + c8 * 8 + e) * 2 + 0] = s1[e];
+          Rs[(wave * BN + c8 * 8 + e) * 2 + 1] = s2[e];
+        }
       }
       __syncthreads();
       if (tid < BN) {
         float a1 = 0.f, a2 = 0.f;
-        for (int q = 0; q < PPI; ++q) {
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
           a1 += Rs[(q * BN + tid) * 2 + 0];
           a2 += Rs[(q * BN + tid) * 2 + 1];
         }
@@ -358,6 +385,7 @@ __device__ __forceinline__ void conv_igemm_body(PK& p, const int bid) {
         atomicAdd(sp + 1, (double)a2);
       }
     }
+    CONV_TL(6);
     return;
   }
   // ---- direct epilogue (fp32 prediction maps / ragged channel counts): D[m = cout][n = pixel]
@@ -516,6 +544,12 @@ static int launch_group_cfg(const mi_conv_group* m, const ConvK* jobs, const int
 
 template <int KCv>
 static int conv_launch_kc(const ConvK& k, int BN, int TPIX, size_t lds, hipStream_t s) {
+  if (TPIX & 1024) {   // 8 waves on the same tile
+    TPIX &= 1023;
+    if (TPIX == 128 && BN == 64) return launch_cfg<KCv, 64, 2, 4, 1, 1>(k, lds, s);
+    if (TPIX == 128 && BN == 128) return launch_cfg<KCv, 128, 2, 4, 2, 1>(k, lds, s);
+    if (TPIX == 64 && BN == 128) return launch_cfg<KCv, 128, 4, 2, 1, 1>(k, lds, s);
+  }
   if (TPIX == 128) {
     if (BN == 32) return launch_cfg<KCv, 32, 1, 4, 1, 1>(k, lds, s);
     if (BN == 64) return launch_cfg<KCv, 64, 2, 2, 1, 2>(k, lds, s);
@@ -527,6 +561,12 @@ static int conv_launch_kc(const ConvK& k, int BN, int TPIX, size_t lds, hipStrea
 }
 template <int KCv>
 static int conv_group_launch_kc(const mi_conv_group* m, const ConvK* jobs, const int* starts, hipStream_t s) {
+  if (m->TPIX & 1024) {   // 8 waves on the same tile
+    const int tp = m->TPIX & 1023;
+    if (tp == 128 && m->BN == 64) return launch_group_cfg<KCv, 64, 2, 4, 1, 1>(m, jobs, starts, s);
+    if (tp == 128 && m->BN == 128) return launch_group_cfg<KCv, 128, 2, 4, 2, 1>(m, jobs, starts, s);
+    if (tp == 64 && m->BN == 128) return launch_group_cfg<KCv, 128, 4, 2, 1, 1>(m, jobs, starts, s);
+  }
   if (m->TPIX == 128) {
     if (m->BN == 32) return launch_group_cfg<KCv, 32, 1, 4, 1, 1>(m, jobs, starts, s);
     if (m->BN == 64) return launch_group_cfg<KCv, 64, 2, 2, 1, 2>(m, jobs, starts, s);
