@@ -374,10 +374,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # MI_DIST_SHARE_DEVICE=1 + MI_DIST_BACKEND=gloo: a 1-GPU box rehearses the world > 1 code path (two ranks on device 0,
+    # gradients exchanged through gloo's host staging) - a functional check of the schedule, not a measurement
+    backend = os.environ.get("MI_DIST_BACKEND", "nccl")
+    if os.environ.get("MI_DIST_SHARE_DEVICE", "0") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
 
     import yolov7_d2_amd as M
@@ -437,7 +445,7 @@ def main():
         t_nocomm = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
         dist.all_reduce(t_nocomm, op=dist.ReduceOp.MAX)
         red.enabled = True
-        ddp = dict(ranks=world, backend="nccl (RCCL over xGMI)", buckets_MB=sizes, bucket_allreduce_alone_ms=alone,
+        ddp = dict(ranks=world, backend="nccl (RCCL over xGMI)" if backend == "nccl" else backend + " (rehearsal)", buckets_MB=sizes, bucket_allreduce_alone_ms=alone,
                    bwd_segments=len(st["segs"]), ms_per_step_without_allreduce=round(float(t_nocomm) / args.steps * 1e3, 3),
                    exposed_comm_ms=round(ms - float(t_nocomm) / args.steps * 1e3, 3))
     incl = None
