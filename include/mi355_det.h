@@ -469,6 +469,31 @@ int mi_fastattn_fwd(const void* const* xs, int nin, const float* edge_weights, v
 int mi_fastattn_bwd(const void* const* xs, int nin, const float* edge_weights, const void* g, void* const* dxs, float* dedge,
                     float* ws, int64_t n, mi_stream_t s);
 
+/* ---- input pipeline: mosaic + random_perspective + pad on the GPU ---------------
+ * replaces, for a whole batch, the cv2.resize / canvas paste of MyDatasetMapper2.__call__ (data/dataset_mapper.py:523-598),
+ * the cv2.warpAffine of random_perspective (data/transforms/data_augment.py:67-75) and the pad-to-batch with 114 of
+ * YOLOX.preprocess_image (meta_arch/yolox.py:95-130).  uint8, OpenCV's fixed-point INTER_LINEAR arithmetic.
+ * paste job: source image src [h0][w0][3] (HWC) resized to rw x rh; canvas[y1a:y2a, x1a:x2a] = resized[y1b.., x1b..]
+ *            (canvas row pitch cw pixels, pre-filled with 114 by the caller).
+ * warp job:  out[c][y][x] (planes of Hp x Wp bytes, y < h, x < w) = INTER_LINEAR sample of the ch x cw canvas at
+ *            minv * (x, y, 1)  (minv: the INVERTED 2x3 matrix, row-major; taps outside the canvas read `border`).
+ * mi_mosaic_jobs_layout validates both (host) tables and fills blk0; returns max(blocks of the paste launch, blocks of the
+ * warp launch); the launches take the device copies of the tables and their own block counts. */
+typedef struct mi_mosaic_paste_job {
+  const void* src;
+  void* canvas;
+  int32_t h0, w0, rh, rw, cw, x1a, y1a, x2a, y2a, x1b, y1b, blk0;
+} mi_mosaic_paste_job;
+typedef struct mi_warp_job {
+  const void* canvas;
+  void* out;
+  double minv[6];
+  int32_t ch, cw, h, w, Hp, Wp, border, blk0;
+} mi_warp_job;
+int mi_mosaic_jobs_layout(mi_mosaic_paste_job* paste_host, int npaste, mi_warp_job* warp_host, int nwarp);
+int mi_mosaic_paste(const mi_mosaic_paste_job* jobs_dev, int njobs, int total_blocks, mi_stream_t s);
+int mi_warp_affine_u8(const mi_warp_job* jobs_dev, int njobs, int total_blocks, mi_stream_t s);
+
 /* ---- COCO run-length encoding of masks (evaluation output format) ----------------------
  * what pycocotools.mask.encode does for instances_to_coco_json (evaluation/coco_evaluation.py:38-50; the algorithm is
  * cocoapi's maskApi.c rleEncode / rleToString, un-vendored): masks uint8 [n][H][W] (device, non-zero = foreground) ->

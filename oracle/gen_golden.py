@@ -311,6 +311,40 @@ def gold_yolov6_loss():
     print("yolov6 loss:", {k: v for k, v in res.items() if "parts" in k or "total" in k})
 
 
+def gold_random_perspective():
+    """the reference's own random_perspective (data/transforms/data_augment.py:31-101) with its random.uniform draws fixed:
+    the matrix it hands to cv2.warpAffine (captured by a spy in place of cv2), the output size and the filtered labels"""
+    m = ref_loader.load_data_augment()
+    draws = [(3.7, 0.8, 1.2, -0.7, 0.45, 0.55), (-9.5, 1.45, -2.0, 2.0, 0.6, 0.4), (0.0, 1.0, 0.0, 0.0, 0.5, 0.5), (10.0, 0.5, 0.3, 0.1, 0.41, 0.59)]
+    res = {}
+    orig_uniform, orig_warp = m.random.uniform, sys.modules["cv2"].warpAffine
+    try:
+        for k, d in enumerate(draws):
+            r = np.random.RandomState(100 + k)
+            hw, n = (1200, 1400), 12
+            r.randint(0, 256, (hw[0], hw[1], 3), dtype=np.uint8)           # (the test's image draw: keeps the streams aligned)
+            x1 = r.uniform(0, hw[1] - 50, n); y1 = r.uniform(0, hw[0] - 50, n)
+            t = np.stack([x1, y1, x1 + r.uniform(3, 400, n), y1 + r.uniform(3, 400, n), r.randint(0, 80, n).astype(np.float64)], 1)
+            seq = list(d)
+            m.random.uniform = lambda a, b, _s=seq: _s.pop(0)
+            seen = {}
+
+            def spy(img, M, dsize, borderValue=(0, 0, 0)):
+                seen["M"], seen["dsize"] = np.array(M), dsize
+                return np.zeros((dsize[1], dsize[0], 3), np.uint8)
+            sys.modules["cv2"].warpAffine = spy
+            img = np.zeros((hw[0], hw[1], 3), np.uint8)
+            _, lab = m.random_perspective(img, t.copy(), degrees=10, translate=0.1, scale=(0.5, 1.5), shear=2.0,
+                                          border=[-hw[0] // 4, -hw[1] // 4])
+            M3 = np.eye(3)
+            M3[:2] = seen["M"]
+            res[f"M{k}"], res[f"labels{k}"], res[f"wh{k}"] = M3, lab, np.array(seen["dsize"])
+    finally:
+        m.random.uniform, sys.modules["cv2"].warpAffine = orig_uniform, orig_warp
+    np.savez_compressed(os.path.join(OUT, "random_perspective.npz"), **res)
+    print("random_perspective:", [len(res[f"labels{k}"]) for k in range(4)], "labels kept")
+
+
 def gold_bifpn():
     """the reference's BiFPN (neck/bifpn.py:307-395) over seeded C3..C5 maps, fp32: p3..p7, the gradients with respect to
     the inputs, every edge weight / GroupNorm parameter, and two convolution weights; dense and separable variants"""
@@ -609,6 +643,7 @@ if __name__ == "__main__":
     gold_nms_family()
     gold_yolov6_loss()
     gold_bifpn()
+    gold_random_perspective()
     gold_encoder_layer()
     gold_transformer()
     gold_pos_embed()

@@ -303,3 +303,22 @@ def load_bifpn():
     m = importlib.import_module("yolov7.modeling.neck.bifpn")
     m.Backbone = sys.modules["detectron2.modeling.backbone"].Backbone
     return m
+
+
+def load_data_augment():
+    """yolov7/data/transforms/data_augment.py loaded by path (random_perspective, box_candidates).  cv2 is not installed:
+    the three cv2 functions it calls are provided by oracle/augment_oracle.py's restatement of OpenCV (getRotationMatrix2D
+    exactly; warpAffine as the restated fixed-point algorithm) - the reference's own numpy label / matrix code runs as is."""
+    load()
+    import augment_oracle as A
+    cv2 = sys.modules["cv2"]
+    cv2.getRotationMatrix2D = lambda angle, center, scale: A.rotation_matrix_2d(angle, scale)
+    cv2.warpAffine = lambda img, M, dsize, borderValue=(0, 0, 0): A.warp_affine_u8(img, M, dsize, borderValue[0])
+    cv2.INTER_LINEAR = 1
+    y = os.path.join(REF, "yolov7")
+    for name, sub in (("yolov7.data", ("data",)), ("yolov7.data.transforms", ("data", "transforms"))):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [os.path.join(y, *sub)]
+            sys.modules[name] = m
+    return importlib.import_module("yolov7.data.transforms.data_augment")

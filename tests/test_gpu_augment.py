@@ -1,0 +1,100 @@
+"""GPU (-m gpu): the input pipeline kernels (mosaic resize + paste, affine warp + transpose + pad) against
+oracle/augment_oracle.py on the same draws: uint8 images and label rows bit-exact; then one training step fed by it."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import augment_oracle as A
+from yolov7_d2_amd import _lib as L
+from yolov7_d2_amd.data_pipeline import GpuMosaicMapper, MosaicPool
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _pool(seed, sizes):
+    rs = np.random.RandomState(seed)
+    pool, imgs, labs = MosaicPool(DEV), [], []
+    for (h, w) in sizes:
+        # smooth content + noise: interpolation differences would show, a pure-noise image hides nothing either
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = (127 + 90 * np.sin(xx / 17.0 + rs.uniform(0, 6)) * np.cos(yy / 23.0 + rs.uniform(0, 6)))[..., None]
+        img = np.clip(base + rs.randint(-30, 31, (h, w, 3)), 0, 255).astype(np.uint8)
+        n = rs.randint(0, 8)
+        x1 = rs.uniform(0, w - 30, n); y1 = rs.uniform(0, h - 30, n)
+        lab = np.stack([x1, y1, np.minimum(x1 + rs.uniform(6, 300, n), w), np.minimum(y1 + rs.uniform(6, 300, n), h),
+                        rs.randint(0, 80, n).astype(np.float64)], 1)
+        pool.append(torch.from_numpy(img), lab)
+        imgs.append(img); labs.append(lab)
+    return pool, imgs, labs
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_mosaic_batch_bit_exact(seed):
+    sizes = [(480, 640), (375, 500), (640, 427), (333, 500), (720, 1280), (1080, 1920), (200, 150), (427, 640), (512, 512),
+             (900, 700), (96, 2000), (1500, 110)]
+    pool, imgs, labs = _pool(10 + seed, sizes)
+    mapper = GpuMosaicMapper(device=DEV)
+    rng_np, rng_py = np.random.RandomState(20 + seed), random.Random(30 + seed)
+    B = 6
+    groups = [tuple(int(i) for i in rng_np.randint(0, len(sizes), 4)) for _ in range(B)]
+    params = [mapper.draw(rng_np, rng_py) for _ in range(B)]
+    out, rows, dims = mapper.make_batch(pool, groups, params)
+    torch.cuda.synchronize()
+    samples = []
+    for g, p in zip(groups, params):
+        samples.append(A.mosaic_sample([imgs[i] for i in g], [labs[i] for i in g], p["input_dim"], p["yc"], p["xc"], p["draws"]))
+    ref_img, ref_rows = A.preprocess_batch(samples)
+    assert tuple(out.shape) == ref_img.shape and out.dtype == torch.uint8
+    got = out.cpu().numpy()
+    for b in range(B):
+        bad = int((got[b] != ref_img[b]).sum())
+        assert bad == 0, (b, bad, dims[b], np.abs(got[b].astype(int) - ref_img[b].astype(int)).max())
+    assert np.array_equal(rows.cpu().numpy(), ref_rows)
+    assert any(len(s[1]) for s in samples) and out.shape[2] % 32 == 0 and out.shape[3] % 32 == 0
+
+
+def test_draw_order_matches_oracle():
+    mapper = GpuMosaicMapper(device=DEV)
+    p = mapper.draw(np.random.RandomState(4), random.Random(5))
+    dim, yc, xc, draws = A.draw_mosaic_params(np.random.RandomState(4), random.Random(5), A.MOSAIC_DEFAULTS)
+    assert (p["input_dim"], p["yc"], p["xc"], p["draws"]) == (dim, yc, xc, draws)
+
+
+def test_degenerate_quadrants_and_identity():
+    """mosaic centre at the canvas corner range limits (a quadrant of zero area), and the paste of an image that needs no
+    resizing (scale 1: the fixed-point pass must reproduce the bytes)"""
+    pool, imgs, labs = _pool(7, [(600, 600)] * 4)
+    mapper = GpuMosaicMapper(device=DEV)
+    for yc, xc in ((300, 300), (899, 899), (300, 899)):
+        p = dict(input_dim=(600, 600), yc=yc, xc=xc, draws=(0.0, 1.0, 0.0, 0.0, 0.5, 0.5))
+        out, rows, _ = mapper.make_batch(pool, [(0, 1, 2, 3)], [p])
+        torch.cuda.synchronize()
+        ref, t = A.mosaic_sample(imgs, labs, (600, 600), yc, xc, p["draws"])
+        bi, br = A.preprocess_batch([(ref, t)])
+        assert np.array_equal(out.cpu().numpy(), bi) and np.array_equal(rows.cpu().numpy(), br)
+    # identity warp of the canvas centre: the output is the centre crop of the canvas, whose quadrants are raw image crops
+    canvas, _ = A.mosaic4(imgs, labs, (600, 600), 600, 600)
+    assert np.array_equal(canvas[:600, :600], imgs[0]) and np.array_equal(canvas[600:, 600:], imgs[3])
+
+
+def test_train_step_fed_by_the_pipeline():
+    import yolov7_d2_amd as M
+    from yolov7_d2_amd.engine import NativeTrainer
+    pool, _, _ = _pool(3, [(480, 640), (375, 500), (640, 427), (333, 500), (500, 375), (427, 640)])
+    mapper = GpuMosaicMapper(dict(MOSAIC_WIDTH_RANGE=(256, 320), MOSAIC_HEIGHT_RANGE=(256, 320)), device=DEV)
+    rng_np, rng_py = np.random.RandomState(1), random.Random(2)
+    torch.manual_seed(0)
+    model = M.build_model(M.yolox_s_cfg(device=DEV))
+    trainer = NativeTrainer(model, lr=1e-3, use_graph=False, input_u8=True)
+    for _ in range(2):
+        groups = [tuple(int(i) for i in rng_np.randint(0, len(pool), 4)) for _ in range(2)]
+        imgs, rows, _ = mapper.make_batch(pool, groups, [mapper.draw(rng_np, rng_py) for _ in range(2)])
+        st = trainer.load_batch(imgs, rows)
+        trainer.step(st)
+        losses = trainer.losses(st)[:4]
+        assert bool(torch.isfinite(losses).all()) and float(losses[0]) > 0
+    with pytest.raises(L.MI355Error):
+        GpuMosaicMapper(device="cpu").make_batch(pool, [(0, 1, 2, 3)], [mapper.draw(rng_np, rng_py)])

@@ -131,6 +131,16 @@ class mi_pack_job(C.Structure):
                 ("CoutPad", C.c_int32), ("CoutPadK", C.c_int32), ("CinPadN", C.c_int32), ("blk0", C.c_int32)]
 
 
+class mi_mosaic_paste_job(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("canvas", C.c_void_p)] + [(n, C.c_int32) for n in
+                ("h0", "w0", "rh", "rw", "cw", "x1a", "y1a", "x2a", "y2a", "x1b", "y1b", "blk0")]
+
+
+class mi_warp_job(C.Structure):
+    _fields_ = [("canvas", C.c_void_p), ("out", C.c_void_p), ("minv", C.c_double * 6)] + [(n, C.c_int32) for n in
+                ("ch", "cw", "h", "w", "Hp", "Wp", "border", "blk0")]
+
+
 class mi_cmd(C.Structure):
     _fields_ = [("op", C.c_int32), ("i", C.c_int32 * 40), ("f", C.c_float * 8), ("p", C.c_void_p * 16),
                 ("l", C.c_int64 * 4)]
@@ -202,6 +212,9 @@ _PROTOS = {
     "mi_fastattn_ws_bytes": (C.c_int64, []),
     "mi_fastattn_fwd": (C.c_int, [C.POINTER(C.c_void_p), _i, _vp, _vp, _i64, _vp]),
     "mi_fastattn_bwd": (C.c_int, [C.POINTER(C.c_void_p), _i, _vp, _vp, C.POINTER(C.c_void_p), _vp, _vp, _i64, _vp]),
+    "mi_mosaic_jobs_layout": (C.c_int, [C.POINTER(mi_mosaic_paste_job), _i, C.POINTER(mi_warp_job), _i]),
+    "mi_mosaic_paste": (C.c_int, [_vp, _i, _i, _vp]),
+    "mi_warp_affine_u8": (C.c_int, [_vp, _i, _i, _vp]),
     "mi_rle_encode": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mi_rle_to_string": (C.c_int, [_vp, _i, C.c_char_p, _i]),
     "mi_yolox_onnx_layout": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),

@@ -1,0 +1,178 @@
+// Input pipeline on the GPU: the pixel work of the reference's mosaic branch
+//   MyDatasetMapper2.__call__  yolov7/data/dataset_mapper.py:523-598  (cv2.resize of four images, paste on a 114 canvas)
+//   random_perspective         yolov7/data/transforms/data_augment.py:67-75 (cv2.warpAffine, border 114)
+//   YOLOX.preprocess_image     yolov7/modeling/meta_arch/yolox.py:95-130 (pad to the batch size with 114, NCHW)
+// for a whole batch in two launches over device-resident decoded images.  Byte / integer arithmetic only: OpenCV's
+// fixed-point INTER_LINEAR resize (11-bit coefficients, its 8-bit vertical pass) and warpAffine (source coordinates in
+// 1/32 px, 15-bit weight table), exactly as oracle/augment_oracle.py restates them - the tests hold the two bit-identical.
+// Compiled with -ffp-contract=off: the fp64 / fp32 coordinate expressions must round as the restatement's do.
+#include "common.h"
+
+struct PasteJob {   // mirrors mi_mosaic_paste_job
+  const unsigned char* src;
+  unsigned char* canvas;
+  int h0, w0, rh, rw, cw, x1a, y1a, x2a, y2a, x1b, y1b, blk0;
+};
+struct WarpJob {    // mirrors mi_warp_job
+  const unsigned char* canvas;
+  unsigned char* out;          // plane 0 of this sample: [3][Hp][Wp]
+  double minv[6];
+  int ch, cw, h, w, Hp, Wp, border, blk0;
+};
+
+__device__ __forceinline__ void resize_coef(int d, double scale, int src, int* s, int* a0, int* a1) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int si = (int)floorf(f);
+  f = f - (float)si;
+  if (si < 0) { f = 0.f; si = 0; }
+  if (si >= src - 1) { f = 0.f; si = src - 1; }
+  float v0 = rintf((1.0f - f) * 2048.f), v1 = rintf(f * 2048.f);
+  *a0 = (int)fminf(fmaxf(v0, -32768.f), 32767.f);
+  *a1 = (int)fminf(fmaxf(v1, -32768.f), 32767.f);
+  *s = si;
+}
+
+__global__ __launch_bounds__(256) void mosaic_paste_kernel(const PasteJob* __restrict__ jobs, int njobs) {
+  int j = 0;
+  while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].blk0) ++j;
+  const PasteJob p = jobs[j];
+  const int rw_ = p.x2a - p.x1a, rh_ = p.y2a - p.y1a;
+  const int idx = ((int)blockIdx.x - p.blk0) * 256 + threadIdx.x;
+  if (idx >= rw_ * rh_) return;
+  const int yy = idx / rw_, xx = idx - yy * rw_;
+  const int rx = xx + p.x1b, ry = yy + p.y1b;
+  int sx, ax0, ax1, sy, by0, by1;
+  resize_coef(rx, (double)p.w0 / (double)p.rw, p.w0, &sx, &ax0, &ax1);
+  resize_coef(ry, (double)p.h0 / (double)p.rh, p.h0, &sy, &by0, &by1);
+  const int sx1 = min(sx + 1, p.w0 - 1), sy1 = min(sy + 1, p.h0 - 1);
+  const unsigned char* r0 = p.src + (size_t)sy * p.w0 * 3;
+  const unsigned char* r1 = p.src + (size_t)sy1 * p.w0 * 3;
+  unsigned char* d = p.canvas + ((size_t)(p.y1a + yy) * p.cw + p.x1a + xx) * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int h0 = (int)r0[sx * 3 + c] * ax0 + (int)r0[sx1 * 3 + c] * ax1;
+    const int h1 = (int)r1[sx * 3 + c] * ax0 + (int)r1[sx1 * 3 + c] * ax1;
+    int v = ((by0 * (h0 >> 4)) >> 16) + ((by1 * (h1 >> 4)) >> 16);
+    v = (v + 2) >> 2;
+    d[c] = (unsigned char)min(max(v, 0), 255);
+  }
+}
+
+__device__ __forceinline__ long long sat_i32(double v) {
+  v = rint(v);
+  if (v < -2147483648.0) v = -2147483648.0;
+  if (v > 2147483647.0) v = 2147483647.0;
+  return (long long)v;
+}
+
+__global__ __launch_bounds__(256) void warp_affine_kernel(const WarpJob* __restrict__ jobs, int njobs,
+                                                          const int* __restrict__ tab) {
+  int j = 0;
+  while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].blk0) ++j;
+  const WarpJob& p = jobs[j];
+  const int idx = ((int)blockIdx.x - p.blk0) * 256 + threadIdx.x;
+  if (idx >= p.w * p.h) return;
+  const int y = idx / p.w, x = idx - y * p.w;
+  const long long ax = sat_i32(p.minv[0] * (double)x * 1024.0), bx = sat_i32(p.minv[3] * (double)x * 1024.0);
+  const long long ay = sat_i32((p.minv[1] * (double)y + p.minv[2]) * 1024.0) + 16;
+  const long long by = sat_i32((p.minv[4] * (double)y + p.minv[5]) * 1024.0) + 16;
+  const long long X = (ax + ay) >> 5, Y = (bx + by) >> 5;
+  long long sxl = X >> 5, syl = Y >> 5;
+  sxl = sxl < -32768 ? -32768 : (sxl > 32767 ? 32767 : sxl);
+  syl = syl < -32768 ? -32768 : (syl > 32767 ? 32767 : syl);
+  const int sx = (int)sxl, sy = (int)syl;
+  const int* w = tab + (((int)(Y & 31) * 32) + (int)(X & 31)) * 4;
+  const bool x0 = sx >= 0 && sx < p.cw, x1 = sx + 1 >= 0 && sx + 1 < p.cw;
+  const bool y0 = sy >= 0 && sy < p.ch, y1 = sy + 1 >= 0 && sy + 1 < p.ch;
+  const unsigned char* r0 = p.canvas + (size_t)(y0 ? sy : 0) * p.cw * 3;
+  const unsigned char* r1 = p.canvas + (size_t)(y1 ? sy + 1 : 0) * p.cw * 3;
+  const int o0 = (x0 ? sx : 0) * 3, o1 = (x1 ? sx + 1 : 0) * 3;
+  unsigned char* d = p.out + (size_t)y * p.Wp + x;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int t00 = (y0 && x0) ? r0[o0 + c] : p.border, t01 = (y0 && x1) ? r0[o1 + c] : p.border;
+    const int t10 = (y1 && x0) ? r1[o0 + c] : p.border, t11 = (y1 && x1) ? r1[o1 + c] : p.border;
+    int acc = t00 * w[0] + t01 * w[1] + t10 * w[2] + t11 * w[3];
+    acc = (acc + (1 << 14)) >> 15;
+    d[(size_t)c * p.Hp * p.Wp] = (unsigned char)min(max(acc, 0), 255);
+  }
+}
+
+// imgwarp.cpp initInterTab2D(INTER_LINEAR, fixed point): see oracle/augment_oracle.py::bilinear_tab.  Kept as int: the
+// cell of an integer source position carries the full weight 32768, which a short cannot hold.
+static void build_bilinear_tab(int* tab) {
+  float t1[32][2];
+  for (int i = 0; i < 32; ++i) {
+    const float x = (float)i * (1.0f / 32);
+    t1[i][0] = 1.0f - x;
+    t1[i][1] = x;
+  }
+  for (int i = 0; i < 32; ++i)
+    for (int j = 0; j < 32; ++j) {
+      const float w[4] = {t1[i][0] * t1[j][0], t1[i][0] * t1[j][1], t1[i][1] * t1[j][0], t1[i][1] * t1[j][1]};
+      int it[4], sum = 0;
+      for (int k = 0; k < 4; ++k) {
+        float v = rintf(w[k] * 32768.f);
+        if (v > 32767.f) v = 32767.f;
+        it[k] = (int)v;
+        sum += it[k];
+      }
+      const int diff = sum - 32768;
+      int hi = 0, lo = 0;
+      for (int k = 1; k < 4; ++k) {
+        if (it[k] > it[hi]) hi = k;
+        if (it[k] < it[lo]) lo = k;
+      }
+      if (diff < 0) it[hi] -= diff;
+      else if (diff > 0) it[lo] -= diff;
+      for (int k = 0; k < 4; ++k) tab[(i * 32 + j) * 4 + k] = it[k];
+    }
+}
+
+static int* g_tab_dev = nullptr;
+
+extern "C" int mi_mosaic_jobs_layout(mi_mosaic_paste_job* paste, int npaste, mi_warp_job* warp, int nwarp) {
+  MI_REQUIRE((paste || !npaste) && (warp || !nwarp) && npaste >= 0 && nwarp >= 0, "mosaic_jobs_layout: args");
+  int blk = 0;
+  for (int j = 0; j < npaste; ++j) {
+    mi_mosaic_paste_job& p = paste[j];
+    MI_REQUIRE(p.h0 > 0 && p.w0 > 0 && p.rh > 0 && p.rw > 0 && p.cw > 0 && p.x2a >= p.x1a && p.y2a >= p.y1a && p.x1b >= 0 &&
+                   p.y1b >= 0 && p.x1b + (p.x2a - p.x1a) <= p.rw && p.y1b + (p.y2a - p.y1a) <= p.rh && p.x1a >= 0 && p.x2a <= p.cw,
+               "mosaic_jobs_layout: paste job %d geometry", j);
+    p.blk0 = blk;
+    blk += (int)(((long long)(p.x2a - p.x1a) * (p.y2a - p.y1a) + 255) / 256);
+  }
+  const int pb = blk;
+  blk = 0;
+  for (int j = 0; j < nwarp; ++j) {
+    mi_warp_job& w = warp[j];
+    MI_REQUIRE(w.h > 0 && w.w > 0 && w.ch > 0 && w.cw > 0 && w.Hp >= w.h && w.Wp >= w.w, "mosaic_jobs_layout: warp job %d geometry", j);
+    w.blk0 = blk;
+    blk += (int)(((long long)w.w * w.h + 255) / 256);
+  }
+  return pb > blk ? pb : blk;
+}
+
+extern "C" int mi_mosaic_paste(const mi_mosaic_paste_job* jobs_dev, int njobs, int total_blocks, mi_stream_t st) {
+  MI_REQUIRE(jobs_dev && njobs > 0 && total_blocks >= 0, "mosaic_paste: args");
+  static_assert(sizeof(PasteJob) == sizeof(mi_mosaic_paste_job), "job layout");
+  if (total_blocks == 0) return MI_OK;
+  hipLaunchKernelGGL(mosaic_paste_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)st, (const PasteJob*)jobs_dev, njobs);
+  MI_CHECK_LAUNCH("mosaic_paste");
+  return MI_OK;
+}
+
+extern "C" int mi_warp_affine_u8(const mi_warp_job* jobs_dev, int njobs, int total_blocks, mi_stream_t st) {
+  MI_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0, "warp_affine_u8: args");
+  static_assert(sizeof(WarpJob) == sizeof(mi_warp_job), "job layout");
+  if (!g_tab_dev) {
+    int host[32 * 32 * 4];
+    build_bilinear_tab(host);
+    if (hipMalloc(&g_tab_dev, sizeof(host)) != hipSuccess) MI_FAIL(MI_ELAUNCH, "warp_affine_u8: table allocation");
+    if (hipMemcpy(g_tab_dev, host, sizeof(host), hipMemcpyHostToDevice) != hipSuccess) MI_FAIL(MI_ELAUNCH, "warp_affine_u8: table copy");
+  }
+  hipLaunchKernelGGL(warp_affine_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)st, (const WarpJob*)jobs_dev, njobs,
+                     (const int*)g_tab_dev);
+  MI_CHECK_LAUNCH("warp_affine_u8");
+  return MI_OK;
+}

@@ -1,0 +1,233 @@
+"""Training input pipeline of the YOLOX path on the GPU: a batch-level drop-in for what the reference
+does per image on CPU workers with cv2 -
+
+    MyDatasetMapper2.__call__, mosaic branch          yolov7/data/dataset_mapper.py:477-612
+    random_perspective, box_candidates                yolov7/data/transforms/data_augment.py:15-101
+    YOLOX.preprocess_image (pad with 114, label rows) yolov7/modeling/meta_arch/yolox.py:95-162
+
+Decoded images live in HBM (`MosaicPool`, uint8 HWC); per batch the host draws the reference's random numbers in the
+reference's order, does the reference's float64 label arithmetic (a few dozen boxes: numpy, as the reference), and the GPU
+does every pixel: four resizes + pastes per sample in ONE launch, the affine warp + NCHW transpose + pad-to-batch in a
+second - `GpuMosaicMapper.make_batch` returns exactly what `NativeTrainer.load_batch` / `feed` take (uint8 [B, 3, H, W],
+float32 [B, 100, 5] rows (cls, cx, cy, w, h)).  At 2 600 images / s / GPU this replaces ~40 cv2 CPU workers per GPU.
+
+Mixup (`ENABLE_MIXUP`; False in configs/coco/yolox_s.yaml:61) and the detectron2 `T.*` augmentations ahead of the mosaic are
+not built.  No CPU path for the pixels: device tensors only.
+"""
+import ctypes as C
+import math
+import random
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+MOSAIC_DEFAULTS = dict(NUM_IMAGES=4, DEGREES=10.0, TRANSLATE=0.1, SCALE=[0.5, 1.5], SHEAR=2.0, PERSPECTIVE=0.0,
+                       MOSAIC_WIDTH_RANGE=(512, 800), MOSAIC_HEIGHT_RANGE=(512, 800))        # yolov7/config.py:258-272
+
+
+def _get(cfg, k):
+    return cfg[k] if isinstance(cfg, dict) else getattr(cfg, k)
+
+
+def box_candidates(box1, box2, wh_thr=2, ar_thr=20, area_thr=0.2):
+    """data_augment.py:15-28"""
+    w1, h1 = box1[2] - box1[0], box1[3] - box1[1]
+    w2, h2 = box2[2] - box2[0], box2[3] - box2[1]
+    ar = np.maximum(w2 / (h2 + 1e-16), h2 / (w2 + 1e-16))
+    return (w2 > wh_thr) & (h2 > wh_thr) & (w2 * h2 / (w1 * h1 + 1e-16) > area_thr) & (ar < ar_thr)
+
+
+class MosaicPool:
+    """the reference's `mosaic_pool` deque (dataset_mapper.py:404-405) with the decoded images resident on the device"""
+
+    def __init__(self, device="cuda", capacity=1000):
+        self.device, self.capacity = torch.device(device), capacity
+        self.images, self.labels = [], []
+
+    def append(self, image_hwc_u8, labels_xyxy_cls):
+        img = torch.as_tensor(image_hwc_u8)
+        if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
+            raise ValueError("MosaicPool.append: uint8 [H, W, 3] image")
+        self.images.append(img.to(self.device).contiguous())
+        self.labels.append(np.asarray(labels_xyxy_cls, np.float64).reshape(-1, 5))
+        if len(self.images) > self.capacity:
+            self.images.pop(0)
+            self.labels.pop(0)
+
+    def __len__(self):
+        return len(self.images)
+
+
+class GpuMosaicMapper:
+    def __init__(self, mosaic_cfg=None, device="cuda", max_boxes=100, pad_value=114, size_divisibility=32):
+        cfg = dict(MOSAIC_DEFAULTS)
+        if mosaic_cfg is not None:
+            for k in MOSAIC_DEFAULTS:
+                try:
+                    cfg[k] = _get(mosaic_cfg, k)
+                except (KeyError, AttributeError):
+                    pass
+        if cfg["NUM_IMAGES"] != 4 or cfg["PERSPECTIVE"] != 0.0:
+            raise NotImplementedError("GpuMosaicMapper: 4-image mosaic with an affine warp (the reference's defaults)")
+        self.cfg, self.device = cfg, torch.device(device)
+        self.max_boxes, self.pad, self.divis = max_boxes, pad_value, size_divisibility
+
+    # ---- the reference's random draws, in its order ----------------------------------------------------------------
+    def draw(self, rng_np=np.random, rng_py=random):
+        """dataset_mapper.py:505-520 (np.random.randint width, height; random.uniform yc, xc) then data_augment.py:45-62
+        (random.uniform angle, scale, shear x, shear y, translate x, translate y)"""
+        c = self.cfg
+        w = int(rng_np.randint(c["MOSAIC_WIDTH_RANGE"][0], c["MOSAIC_WIDTH_RANGE"][1] + 1))
+        h = int(rng_np.randint(c["MOSAIC_HEIGHT_RANGE"][0], c["MOSAIC_HEIGHT_RANGE"][1] + 1))
+        if max(w / h, h / w) > 1.2:
+            h = min(h, w)
+            w = int(1.2 * h)
+        dim = (h, w)
+        yc = int(rng_py.uniform(0.5 * dim[0], 1.5 * dim[0]))
+        xc = int(rng_py.uniform(0.5 * dim[1], 1.5 * dim[1]))
+        a = rng_py.uniform(-c["DEGREES"], c["DEGREES"])
+        s = rng_py.uniform(c["SCALE"][0], c["SCALE"][1])
+        shx = rng_py.uniform(-c["SHEAR"], c["SHEAR"])
+        shy = rng_py.uniform(-c["SHEAR"], c["SHEAR"])
+        tx = rng_py.uniform(0.5 - c["TRANSLATE"], 0.5 + c["TRANSLATE"])
+        ty = rng_py.uniform(0.5 - c["TRANSLATE"], 0.5 + c["TRANSLATE"])
+        return dict(input_dim=dim, yc=yc, xc=xc, draws=(a, s, shx, shy, tx, ty))
+
+    # ---- host geometry / labels (float64, the reference's operation order) ------------------------------------------
+    @staticmethod
+    def _placement(i, w, h, xc, yc, dim):
+        H2, W2 = dim[0] * 2, dim[1] * 2
+        if i == 0:
+            x1a, y1a, x2a, y2a = max(xc - w, 0), max(yc - h, 0), xc, yc
+            x1b, y1b = w - (x2a - x1a), h - (y2a - y1a)
+        elif i == 1:
+            x1a, y1a, x2a, y2a = xc, max(yc - h, 0), min(xc + w, W2), yc
+            x1b, y1b = 0, h - (y2a - y1a)
+        elif i == 2:
+            x1a, y1a, x2a, y2a = max(xc - w, 0), yc, xc, min(H2, yc + h)
+            x1b, y1b = w - (x2a - x1a), 0
+        else:
+            x1a, y1a, x2a, y2a = xc, yc, min(xc + w, W2), min(H2, yc + h)
+            x1b, y1b = 0, 0
+        return (x1a, y1a, x2a, y2a), (x1b, y1b)
+
+    @staticmethod
+    def _matrix(canvas_hw, draws, border):
+        a, s, shx, shy, tx, ty = draws
+        height, width = canvas_hw[0] + border[0] * 2, canvas_hw[1] + border[1] * 2
+        Cm = np.eye(3)
+        Cm[0, 2] = -canvas_hw[1] / 2
+        Cm[1, 2] = -canvas_hw[0] / 2
+        R = np.eye(3)
+        r = a * math.pi / 180.0                                   # cv2.getRotationMatrix2D(center=(0, 0))
+        al, be = s * math.cos(r), s * math.sin(r)
+        R[:2] = [[al, be, 0.0], [-be, al, 0.0]]
+        S = np.eye(3)
+        S[0, 1] = math.tan(shx * math.pi / 180)
+        S[1, 0] = math.tan(shy * math.pi / 180)
+        T = np.eye(3)
+        T[0, 2] = tx * width
+        T[1, 2] = ty * height
+        return T @ S @ R @ Cm, width, height
+
+    @staticmethod
+    def _warp_labels(targets, M, s, width, height):
+        n = len(targets)
+        if not n:
+            return targets
+        xy = np.ones((n * 4, 3))
+        xy[:, :2] = targets[:, [0, 1, 2, 3, 0, 3, 2, 1]].reshape(n * 4, 2)
+        xy = xy @ M.T
+        xy = xy[:, :2].reshape(n, 8)
+        x, y = xy[:, [0, 2, 4, 6]], xy[:, [1, 3, 5, 7]]
+        xy = np.concatenate((x.min(1), y.min(1), x.max(1), y.max(1))).reshape(4, n).T
+        xy[:, [0, 2]] = xy[:, [0, 2]].clip(0, width)
+        xy[:, [1, 3]] = xy[:, [1, 3]].clip(0, height)
+        i = box_candidates(box1=targets[:, :4].T * s, box2=xy.T)
+        targets = targets[i]
+        targets[:, :4] = xy[i]
+        return targets
+
+    @staticmethod
+    def _invert(M):
+        """the inversion cv2.warpAffine applies to a forward matrix (imgwarp.cpp)"""
+        D = M[0, 0] * M[1, 1] - M[0, 1] * M[1, 0]
+        D = 1.0 / D if D != 0 else 0.0
+        A11, A22 = M[1, 1] * D, M[0, 0] * D
+        A12, A21 = -M[0, 1] * D, -M[1, 0] * D
+        return [A11, A12, -A11 * M[0, 2] - A12 * M[1, 2], A21, A22, -A21 * M[0, 2] - A22 * M[1, 2]]
+
+    # ---- one batch --------------------------------------------------------------------------------------------------
+    def make_batch(self, pool, groups, params):
+        """groups: B tuples of four pool indices (the current image first, then the three sampled ones); params: B dicts
+        from draw().  Returns (uint8 [B, 3, H, W] on the device, float32 [B, max_boxes, 5] (cls, cx, cy, w, h) on the
+        device, per-sample (h, w))"""
+        if self.device.type != "cuda":
+            raise L.MI355Error("GpuMosaicMapper: the MI355X path needs a device (no CPU pixel path)")
+        B = len(groups)
+        lib = L.lib()
+        dims = [p["input_dim"] for p in params]
+        Hp = (max(d[0] for d in dims) + self.divis - 1) // self.divis * self.divis
+        Wp = (max(d[1] for d in dims) + self.divis - 1) // self.divis * self.divis
+        out = torch.full((B, 3, Hp, Wp), self.pad, dtype=torch.uint8, device=self.device)
+        csz = [4 * d[0] * d[1] * 3 for d in dims]
+        coff = np.concatenate([[0], np.cumsum(csz)])
+        canvas = torch.full((int(coff[-1]),), self.pad, dtype=torch.uint8, device=self.device)
+        paste = (L.mi_mosaic_paste_job * (4 * B))()
+        warp = (L.mi_warp_job * B)()
+        rows = np.zeros((B, self.max_boxes, 5), np.float32)
+        for b, (grp, p) in enumerate(zip(groups, params)):
+            dim, yc, xc = p["input_dim"], p["yc"], p["xc"]
+            cbase = canvas.data_ptr() + int(coff[b])
+            labels4 = []
+            for i, idx in enumerate(grp):
+                img, lab = pool.images[idx], pool.labels[idx]
+                h0, w0 = img.shape[:2]
+                scale = min(1. * dim[0] / h0, 1. * dim[1] / w0)
+                w, h = int(w0 * scale), int(h0 * scale)
+                (x1a, y1a, x2a, y2a), (x1b, y1b) = self._placement(i, w, h, xc, yc, dim)
+                j = paste[4 * b + i]
+                j.src, j.canvas = img.data_ptr(), cbase
+                j.h0, j.w0, j.rh, j.rw, j.cw = h0, w0, h, w, dim[1] * 2
+                j.x1a, j.y1a, j.x2a, j.y2a, j.x1b, j.y1b = x1a, y1a, max(x2a, x1a), max(y2a, y1a), x1b, y1b
+                if lab.size > 0:
+                    t = lab.copy()
+                    padw, padh = x1a - x1b, y1a - y1b
+                    t[:, 0] = scale * lab[:, 0] + padw
+                    t[:, 1] = scale * lab[:, 1] + padh
+                    t[:, 2] = scale * lab[:, 2] + padw
+                    t[:, 3] = scale * lab[:, 3] + padh
+                    labels4.append(t)
+            if labels4:
+                labels4 = np.concatenate(labels4, 0)
+                np.clip(labels4[:, 0], 0, 2 * dim[1], out=labels4[:, 0])
+                np.clip(labels4[:, 1], 0, 2 * dim[0], out=labels4[:, 1])
+                np.clip(labels4[:, 2], 0, 2 * dim[1], out=labels4[:, 2])
+                np.clip(labels4[:, 3], 0, 2 * dim[0], out=labels4[:, 3])
+            else:
+                labels4 = np.zeros((0, 5))
+            M, width, height = self._matrix((dim[0] * 2, dim[1] * 2), p["draws"], [-dim[0] // 2, -dim[1] // 2])
+            t = self._warp_labels(labels4, M, p["draws"][1], width, height)[: self.max_boxes]
+            wj = warp[b]
+            wj.canvas, wj.out = cbase, out.data_ptr() + b * 3 * Hp * Wp
+            for q, v in enumerate(self._invert(M)):
+                wj.minv[q] = v
+            wj.ch, wj.cw, wj.h, wj.w, wj.Hp, wj.Wp, wj.border = dim[0] * 2, dim[1] * 2, height, width, Hp, Wp, self.pad
+            if len(t):                                             # meta_arch/yolox.py:131-160: XYXY -> (cls, cx, cy, w, h)
+                box = t[:, :4].astype(np.float32)
+                rows[b, : len(t), 0] = t[:, 4]
+                rows[b, : len(t), 1] = (box[:, 0] + box[:, 2]) / 2
+                rows[b, : len(t), 2] = (box[:, 1] + box[:, 3]) / 2
+                rows[b, : len(t), 3] = box[:, 2] - box[:, 0]
+                rows[b, : len(t), 4] = box[:, 3] - box[:, 1]
+        L.check(lib.mi_mosaic_jobs_layout(paste, 4 * B, warp, B), "mi_mosaic_jobs_layout")
+        pb = paste[4 * B - 1].blk0 + ((paste[4 * B - 1].x2a - paste[4 * B - 1].x1a) * (paste[4 * B - 1].y2a - paste[4 * B - 1].y1a) + 255) // 256
+        wb = warp[B - 1].blk0 + (warp[B - 1].w * warp[B - 1].h + 255) // 256
+        tab = torch.frombuffer(bytearray(bytes(paste) + bytes(warp)), dtype=torch.uint8).to(self.device)
+        st = L.stream_ptr()
+        L.check(lib.mi_mosaic_paste(tab.data_ptr(), 4 * B, pb, st), "mi_mosaic_paste")
+        L.check(lib.mi_warp_affine_u8(tab.data_ptr() + C.sizeof(paste), B, wb, st), "mi_warp_affine_u8")
+        self._keep = (canvas, tab)                                 # alive until the stream has run the two launches
+        return out, torch.from_numpy(rows).to(self.device, non_blocking=True), [(d[0], d[1]) for d in dims]
