@@ -332,7 +332,8 @@ int mi_yolox_split_dpreds(const float* dpreds, int B, int A, int nch, int a0, in
                           void* dst, int ld, mi_stream_t s);
 /* bias gradients of all prediction convs (nn.Conv2d bias of yolox_head.py:103-129) in two launches:
  * out[c] = sum_b sum_{a0 <= a < a0+HW} dpreds[b][a][c0 + c]; jobs is a HOST array (<= 16);
- * ws: 16*512*128 floats of scratch */
+ * ws: 16*512*128 floats of scratch = 16 slabs; a call uses (distinct (a0, HW) levels) x ceil(nch / 128) of them
+ * (3 levels: nch <= 640, i.e. up to 635 classes) */
 typedef struct mi_bias_job {
   float* out;
   int32_t a0, HW, c0, nc;
@@ -361,7 +362,7 @@ int mi_yolox_onnx_layout(const float* decoded, float* out, int B, int A, int ncl
  * tgt_off int32 [B+1] (targets of image b = [tgt_off[b], tgt_off[b+1])), gmax >= max targets per image.
  * cost (workspace / output) fp32 [B][Q][gmax]; match_q / match_t int64 [B][gmax]: the first nmatch[b] =
  * min(Q, G_b) entries are the (query, target) pairs sorted by query index, exactly what scipy returns.
- * Q, gmax <= 128. */
+ * Q, gmax <= 1024. */
 int mi_hungarian_match(const float* logits, const float* boxes, const int64_t* tgt_labels,
                        const float* tgt_boxes, const int32_t* tgt_off, int B, int Q, int NC, int gmax,
                        float w_class, float w_bbox, float w_giou, float* cost, int64_t* match_q,

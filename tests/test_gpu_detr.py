@@ -39,7 +39,8 @@ def test_hungarian_matcher_against_reference_golden(golden_dir):
             assert np.array_equal(j.cpu().numpy(), g[f"{name}_j{b}"]), (name, b)
 
 
-@pytest.mark.parametrize("Q,G", [(100, 1), (100, 7), (100, 20), (100, 100), (128, 128), (16, 30), (1, 1), (1, 5), (64, 63)])
+@pytest.mark.parametrize("Q,G", [(100, 1), (100, 7), (100, 20), (100, 100), (128, 128), (16, 30), (1, 1), (1, 5), (64, 63), (300, 40), (300, 300), (1024, 3),
+                                 (129, 130)])
 def test_lsap_exact_on_given_cost(Q, G):
     """assignment kernel alone on oracle-provided cost matrices: identical pairs and optimal total cost (properties:
     one-to-one, min(Q,G) pairs, rows sorted)"""

@@ -157,6 +157,36 @@ def _gpu_model(seed=0):
     return model, sd
 
 
+def test_many_classes_loss_and_bias_gradients():
+    """MODEL.YOLO.CLASSES = 200 (5 + 200 prediction channels: two 128-channel chunks in the bias-gradient kernel, class
+    loops of the loss kernels beyond one batch): losses against the oracle on the head outputs the HIP path produced, the
+    prediction convs' bias gradients against the oracle's autograd through the same loss"""
+    cfg = M.yolox_s_cfg(device=DEV)
+    cfg.MODEL.YOLO.CLASSES = 200
+    model = M.build_model(cfg)
+    model.load_state_dict(O.init_state_dict(0.33, 0.5, 200, seed=5))
+    model.train()
+    imgs, labels = O.synth_batch(2, 64, 96, seed=12, max_gt=4)
+    labels[..., 0] = (labels[..., 0] * 2.4).floor() * (labels.sum(-1) > 0)       # classes up to 189
+    loss_dict = model(_batched_inputs(imgs, labels))
+    sum(loss_dict.values()).backward()
+    torch.cuda.synchronize()
+    ps = model.plan_for(2, 64, 96, True)
+    raw = ps.preds().float().cpu().clone().requires_grad_(True)
+    chk = O.yolox_losses(raw, labels, ps.anchors.float().cpu(), 200)
+    got = np.array([float(loss_dict[k]) for k in ("total_loss", "iou_loss", "conf_loss", "cls_loss")])
+    np.testing.assert_allclose(got, np.array([float(x) for x in chk[:4]]), rtol=1e-4, atol=1e-5)
+    (chk[0] + chk[1] + chk[2] + chk[3]).backward()
+    d = raw.grad                                                                  # [B, A, 205]
+    a0 = 0
+    for k, (h, w) in enumerate(((8, 12), (4, 6), (2, 3))):
+        seg = d[:, a0:a0 + h * w].sum((0, 1))
+        a0 += h * w
+        for name, sl in (("reg_preds", slice(0, 4)), ("obj_preds", slice(4, 5)), ("cls_preds", slice(5, 205))):
+            g = model.params.grad_of(getattr(model.head, name)[k].bias).float().cpu()
+            np.testing.assert_allclose(g.numpy(), seg[sl].numpy(), rtol=2e-4, atol=2e-6, err_msg=f"{name}[{k}].bias")
+
+
 def _batched_inputs(imgs, labels):
     from yolov7_d2_amd.d2shim import Boxes, Instances
     out = []

@@ -11,7 +11,7 @@
 #include <string.h>
 #include "common.h"
 
-#define LSAP_MAXN 128  // longer side (queries / targets per image) supported by the LDS-resident state
+#define LSAP_MAXN 1024  // longer side (queries / targets per image) supported by the LDS-resident state
 
 struct MatchK {
   const float* logits;   // [B][Q][NC]

@@ -652,15 +652,15 @@ extern "C" int mi_yolox_split_dpreds_batch(const float* dpreds, int B, int A, in
 #define MI_BIAS_BLOCKS 512
 struct BiasK {
   const float* dpreds;
-  float* ws;  // [nlev][MI_BIAS_BLOCKS][128]
-  int B, A, nch, njobs, nlev;
+  float* ws;  // [nlev][chunks][MI_BIAS_BLOCKS][128]
+  int B, A, nch, njobs, nlev, chunks;
   int lev_a0[MI_BIAS_MAX_JOBS], lev_hw[MI_BIAS_MAX_JOBS], job_lev[MI_BIAS_MAX_JOBS];
   mi_bias_job jobs[MI_BIAS_MAX_JOBS];
 };
 __global__ __launch_bounds__(256) void bias_grads_stage1_kernel(const BiasK p) {
   __shared__ float red[256];
   const int a0 = p.lev_a0[blockIdx.y], HW = p.lev_hw[blockIdx.y];
-  const int c = threadIdx.x & 127, rl = threadIdx.x >> 7;  // 128 channel lanes x 2 row lanes
+  const int c = blockIdx.z * 128 + (threadIdx.x & 127), rl = threadIdx.x >> 7;  // 128 channel lanes x 2 row lanes
   const long rows = (long)p.B * HW;
   float acc = 0.f;
   if (c < p.nch) {
@@ -681,24 +681,27 @@ __global__ __launch_bounds__(256) void bias_grads_stage1_kernel(const BiasK p) {
   red[threadIdx.x] = acc;
   __syncthreads();
   if (threadIdx.x < 128)
-    p.ws[((size_t)blockIdx.y * MI_BIAS_BLOCKS + blockIdx.x) * 128 + threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + 128];
+    p.ws[(((size_t)blockIdx.y * p.chunks + blockIdx.z) * MI_BIAS_BLOCKS + blockIdx.x) * 128 + threadIdx.x] =
+        red[threadIdx.x] + red[threadIdx.x + 128];
 }
 __global__ __launch_bounds__(128) void bias_grads_stage2_kernel(const BiasK p) {
   const mi_bias_job j = p.jobs[blockIdx.x];
   const int lev = p.job_lev[blockIdx.x];
-  const int c = threadIdx.x;
-  if (c >= j.nc) return;
-  float s = 0.f;
-  for (int b = 0; b < MI_BIAS_BLOCKS; ++b) s += p.ws[((size_t)lev * MI_BIAS_BLOCKS + b) * 128 + j.c0 + c];
-  j.out[c] = s;
+  for (int c = threadIdx.x; c < j.nc; c += 128) {
+    const int cc = j.c0 + c;
+    const float* w = p.ws + ((size_t)lev * p.chunks + (cc >> 7)) * MI_BIAS_BLOCKS * 128 + (cc & 127);
+    float s = 0.f;
+    for (int b = 0; b < MI_BIAS_BLOCKS; ++b) s += w[(size_t)b * 128];
+    j.out[c] = s;
+  }
 }
 extern "C" int mi_yolox_bias_grads(const float* dpreds, int B, int A, int nch, const mi_bias_job* jobs, int njobs,
                                    float* ws, mi_stream_t st) {
-  MI_REQUIRE(dpreds && jobs && ws && njobs > 0 && njobs <= MI_BIAS_MAX_JOBS && nch <= 128, "bias_grads: args");
+  MI_REQUIRE(dpreds && jobs && ws && njobs > 0 && njobs <= MI_BIAS_MAX_JOBS && nch > 0, "bias_grads: args");
   BiasK k;
-  k.dpreds = dpreds; k.ws = ws; k.B = B; k.A = A; k.nch = nch; k.njobs = njobs; k.nlev = 0;
+  k.dpreds = dpreds; k.ws = ws; k.B = B; k.A = A; k.nch = nch; k.njobs = njobs; k.nlev = 0; k.chunks = (nch + 127) / 128;
   for (int i = 0; i < njobs; ++i) {
-    MI_REQUIRE(jobs[i].out && jobs[i].nc >= 1 && jobs[i].nc <= 128 && jobs[i].c0 >= 0 && jobs[i].c0 + jobs[i].nc <= nch &&
+    MI_REQUIRE(jobs[i].out && jobs[i].nc >= 1 && jobs[i].c0 >= 0 && jobs[i].c0 + jobs[i].nc <= nch &&
                    jobs[i].a0 >= 0 && jobs[i].a0 + jobs[i].HW <= A, "bias_grads: job %d", i);
     k.jobs[i] = jobs[i];
     int lev = -1;
@@ -711,7 +714,8 @@ extern "C" int mi_yolox_bias_grads(const float* dpreds, int B, int A, int nch, c
     }
     k.job_lev[i] = lev;
   }
-  hipLaunchKernelGGL(bias_grads_stage1_kernel, dim3(MI_BIAS_BLOCKS, k.nlev), dim3(256), 0, (hipStream_t)st, k);
+  MI_REQUIRE(k.nlev * k.chunks <= 16, "bias_grads: %d levels x %d channel chunks of 128 exceed the 16-slab scratch", k.nlev, k.chunks);
+  hipLaunchKernelGGL(bias_grads_stage1_kernel, dim3(MI_BIAS_BLOCKS, k.nlev, k.chunks), dim3(256), 0, (hipStream_t)st, k);
   MI_CHECK_LAUNCH("bias_grads1");
   hipLaunchKernelGGL(bias_grads_stage2_kernel, dim3(njobs), dim3(128), 0, (hipStream_t)st, k);
   MI_CHECK_LAUNCH("bias_grads2");
