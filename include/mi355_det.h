@@ -494,6 +494,17 @@ typedef struct mi_warp_job {
 int mi_mosaic_jobs_layout(mi_mosaic_paste_job* paste_host, int npaste, mi_warp_job* warp_host, int nwarp);
 int mi_mosaic_paste(const mi_mosaic_paste_job* jobs_dev, int njobs, int total_blocks, mi_stream_t s);
 int mi_warp_affine_u8(const mi_warp_job* jobs_dev, int njobs, int total_blocks, mi_stream_t s);
+/* MyDatasetMapper2.mixup (data/dataset_mapper.py:686-768) in place on a warped sample: out[c][y][x] (y < th, x < tw) =
+ * uint8(0.5 * out + 0.5 * partner), partner = the pool image src [h0][w0][3] resized to rw1 x rh1 (8-bit fixed point) into
+ * the corner of a 114.0 canvas dh x dw, that canvas resized to ow x oh (float64 path), optionally mirrored, zero-padded to the
+ * target, cropped at (x_off, y_off), truncated to uint8.  mi_mixup_jobs_layout fills blk0 and returns the block count. */
+typedef struct mi_mixup_job {
+  const void* src;
+  void* out;
+  int32_t h0, w0, rh1, rw1, dh, dw, oh, ow, flip, x_off, y_off, th, tw, Hp, Wp, blk0;
+} mi_mixup_job;
+int mi_mixup_jobs_layout(mi_mixup_job* jobs_host, int njobs);
+int mi_mixup_blend(const mi_mixup_job* jobs_dev, int njobs, int total_blocks, mi_stream_t s);
 
 /* ---- COCO run-length encoding of masks (evaluation output format) ----------------------
  * what pycocotools.mask.encode does for instances_to_coco_json (evaluation/coco_evaluation.py:38-50; the algorithm is

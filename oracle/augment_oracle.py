@@ -312,3 +312,90 @@ def draw_mosaic_params(rng_np, rng_py, cfg):
 
 MOSAIC_DEFAULTS = dict(DEGREES=10.0, TRANSLATE=0.1, SCALE=[0.5, 1.5], SHEAR=2.0, MOSAIC_WIDTH_RANGE=(512, 800),
                        MOSAIC_HEIGHT_RANGE=(512, 800))        # yolov7/config.py:258-272
+
+
+# ------------------------------------------------------------------------------------------------ mixup
+def resize_linear_f64(img, dsize):
+    """cv2.resize(img, (w, h)) of a float64 image (default INTER_LINEAR): resize.cpp's generic path - the same source
+    index / fraction rule as the 8-bit one, coefficients kept as float32 (1 - fx, fx), rows combined in double:
+    horizontal D = S[sx] * a0 + S[sx + 1] * a1, then vertical dst = D0 * b0 + D1 * b1"""
+    w, h = int(dsize[0]), int(dsize[1])
+    H, W = img.shape[:2]
+
+    def coef(src, dst):
+        scale = np.float64(src) / np.float64(dst)
+        d = np.arange(dst, dtype=np.float64)
+        f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        lo = s < 0
+        f[lo] = 0.0
+        s[lo] = 0
+        hi = s >= src - 1
+        f[hi] = 0.0
+        s[hi] = src - 1
+        return s, (np.float32(1.0) - f).astype(np.float64), f.astype(np.float64)
+    sx, ax0, ax1 = coef(W, w)
+    sy, by0, by1 = coef(H, h)
+    sx1, sy1 = np.minimum(sx + 1, W - 1), np.minimum(sy + 1, H - 1)
+    src = img.astype(np.float64)
+    rows = src[:, sx] * ax0[None, :, None] + src[:, sx1] * ax1[None, :, None]
+    return rows[sy] * by0[:, None, None] + rows[sy1] * by1[:, None, None]
+
+
+def adjust_box_anns(bbox, scale_ratio, padw, padh, w_max, h_max):
+    """utils/boxes.py:381-384 (in place, as the reference)"""
+    bbox[:, 0::2] = np.clip(bbox[:, 0::2] * scale_ratio + padw, 0, w_max)
+    bbox[:, 1::2] = np.clip(bbox[:, 1::2] * scale_ratio + padh, 0, h_max)
+    return bbox
+
+
+def mixup_geometry(img_hw, input_dim, jit):
+    """sizes of dataset_mapper.py:703-727: first resize (rw1, rh1), the 114 canvas (input_dim), second resize (ow, oh)"""
+    r = min(input_dim[0] / img_hw[0], input_dim[1] / img_hw[1])
+    rw1, rh1 = int(img_hw[1] * r), int(img_hw[0] * r)
+    ow, oh = int(input_dim[1] * jit), int(input_dim[0] * jit)
+    return r, (rw1, rh1), (ow, oh)
+
+
+def mixup(origin_img, origin_labels, img, cp_labels, input_dim, jit, flip, offsets):
+    """MyDatasetMapper2.mixup (dataset_mapper.py:686-768) with its draws given: jit = random.uniform(*MSCALE), flip =
+    random.uniform(0, 1) > 0.5, the pool sample (img, cp_labels) and offsets = (x_offset, y_offset) - the two
+    random.randint draws, taken only when the padded image exceeds the target (mixup_offsets_range gives their ranges)"""
+    cp_labels = np.array(cp_labels, np.float64).reshape(-1, 5).copy()
+    origin_labels = np.asarray(origin_labels, np.float64).reshape(-1, 5)
+    cp_img = np.ones((input_dim[0], input_dim[1], 3)) * 114.0
+    r, (rw1, rh1), (ow, oh) = mixup_geometry(img.shape[:2], input_dim, jit)
+    cp_img[:rh1, :rw1] = resize_linear_u8(img, (rw1, rh1)).astype(np.float32)
+    cp_img = resize_linear_f64(cp_img, (ow, oh))
+    cp_scale_ratio = r * jit
+    if flip:
+        cp_img = cp_img[:, ::-1, :]
+    origin_h, origin_w = cp_img.shape[:2]
+    target_h, target_w = origin_img.shape[:2]
+    padded = np.zeros((max(origin_h, target_h), max(origin_w, target_w), 3)).astype(np.uint8)
+    padded[:origin_h, :origin_w] = cp_img                      # float64 -> uint8: truncation
+    x_offset, y_offset = offsets
+    crop = padded[y_offset: y_offset + target_h, x_offset: x_offset + target_w]
+    bo = adjust_box_anns(cp_labels[:, :4], cp_scale_ratio, 0, 0, origin_w, origin_h)
+    if flip:
+        bo[:, 0::2] = origin_w - bo[:, 0::2][:, ::-1]
+    bt = bo.copy()
+    bt[:, 0::2] = np.clip(bt[:, 0::2] - x_offset, 0, target_w)
+    bt[:, 1::2] = np.clip(bt[:, 1::2] - y_offset, 0, target_h)
+    keep = box_candidates(bo.T, bt.T, 5)
+    if keep.sum() >= 1.0:
+        labels = np.hstack((bt[keep], cp_labels[keep, 4:5]))
+        origin_labels = np.vstack((origin_labels, labels))
+        out = origin_img.astype(np.float32)
+        out = 0.5 * out + 0.5 * crop.astype(np.float32)
+        return out.astype(np.uint8), origin_labels
+    return origin_img.astype(np.uint8), origin_labels
+
+
+def mixup_offsets_range(img_hw, input_dim, jit, target_hw):
+    """the (exclusive-free) upper bounds of the two random.randint(0, n) draws of dataset_mapper.py:738-743, or None where
+    the reference does not draw: (x_max, y_max)"""
+    _, _, (ow, oh) = mixup_geometry(img_hw, input_dim, jit)
+    ph, pw = max(oh, target_hw[0]), max(ow, target_hw[1])
+    return (pw - target_hw[1] - 1 if pw > target_hw[1] else None, ph - target_hw[0] - 1 if ph > target_hw[0] else None)

@@ -115,3 +115,33 @@ def test_mosaic_geometry_and_batch():
     assert np.array_equal(batch[0, :, : dim[0], : dim[1]], out.transpose(2, 0, 1))
     n = len(lab)
     assert (rows[0, n:] == 0).all() and np.allclose(rows[0, :n, 3], lab[:, 2] - lab[:, 0], rtol=1e-6)
+
+
+def test_mixup_properties():
+    rs = np.random.RandomState(9)
+    origin = rs.randint(0, 256, (300, 360, 3), dtype=np.uint8)
+    ol = np.array([[10.0, 20, 100, 200, 3]])
+    img = rs.randint(0, 256, (240, 320, 3), dtype=np.uint8)
+    cl = np.array([[30.0, 40, 200, 220, 7], [0.0, 0, 3, 3, 9]])
+    dim = (300, 360)
+    # jit 1, no flip, no offset: the blend partner is the 114 canvas with the resized image in its top-left corner
+    out, lab = A.mixup(origin, ol, img, cl, dim, 1.0, False, (0, 0))
+    r, (rw1, rh1), (ow, oh) = A.mixup_geometry(img.shape[:2], dim, 1.0)
+    assert (ow, oh) == (360, 300) and np.array_equal(A.resize_linear_f64(np.ones((5, 7, 3)) * 114.0, (9, 4)), np.ones((4, 9, 3)) * 114.0)
+    part = np.full((300, 360, 3), 114, np.uint8)
+    part[:rh1, :rw1] = A.resize_linear_u8(img, (rw1, rh1))
+    ref = (0.5 * origin.astype(np.float32) + 0.5 * part.astype(np.float32)).astype(np.uint8)
+    assert np.array_equal(out, ref)
+    assert len(lab) == 2 and lab[1, 4] == 7 and np.allclose(lab[1, :4], cl[0, :4] * r)       # the 3 x 3 box is filtered
+    # flip mirrors the partner and the boxes; a larger jit crops at the drawn offset
+    out2, lab2 = A.mixup(origin, ol, img, cl, dim, 1.4, True, (17, 5))
+    xm, ym = A.mixup_offsets_range(img.shape[:2], dim, 1.4, origin.shape[:2])
+    assert xm == int(360 * 1.4) - 360 - 1 and ym == int(300 * 1.4) - 300 - 1 and out2.shape == origin.shape
+    assert len(lab2) >= 1 and (lab2[:, 0] >= 0).all() and (lab2[:, 2] <= 360).all()
+    # no surviving box: the image comes back unblended
+    out3, lab3 = A.mixup(origin, ol, img, cl[1:], dim, 1.0, False, (0, 0))
+    assert np.array_equal(out3, origin) and len(lab3) == 1
+    # a small jit leaves the partner smaller than the target: zeros (not 114) outside it, as the reference pads
+    out4, _ = A.mixup(origin, ol, img, cl, dim, 0.5, False, (0, 0))
+    assert np.array_equal(out4[200:, 250:], (0.5 * origin[200:, 250:].astype(np.float32)).astype(np.uint8))
+    assert A.mixup_offsets_range(img.shape[:2], dim, 0.5, origin.shape[:2]) == (None, None)

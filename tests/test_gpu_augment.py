@@ -56,6 +56,40 @@ def test_mosaic_batch_bit_exact(seed):
     assert any(len(s[1]) for s in samples) and out.shape[2] % 32 == 0 and out.shape[3] % 32 == 0
 
 
+@pytest.mark.parametrize("seed", [0, 1])
+def test_mosaic_mixup_batch_bit_exact(seed):
+    sizes = [(480, 640), (375, 500), (640, 427), (333, 500), (720, 1280), (200, 150), (427, 640), (512, 512), (900, 700)]
+    pool, imgs, labs = _pool(40 + seed, sizes)
+    mapper = GpuMosaicMapper(device=DEV)
+    rng_np, rng_py = np.random.RandomState(50 + seed), random.Random(60 + seed)
+    B = 6
+    groups = [tuple(int(i) for i in rng_np.randint(0, len(sizes), 4)) for _ in range(B)]
+    params = [mapper.draw(rng_np, rng_py) for _ in range(B)]
+    mixups = []
+    for p in params:
+        d = p["input_dim"]
+        tgt = (d[0] * 2 + (-d[0] // 2) * 2, d[1] * 2 + (-d[1] // 2) * 2)       # random_perspective's output size
+        mixups.append(mapper.draw_mixup(pool, d, tgt, rng_np, rng_py))
+    mixups[2] = None
+    out, rows, dims = mapper.make_batch(pool, groups, params, mixups)
+    torch.cuda.synchronize()
+    samples, nblend = [], 0
+    for g, p, mx in zip(groups, params, mixups):
+        img, t = A.mosaic_sample([imgs[i] for i in g], [labs[i] for i in g], p["input_dim"], p["yc"], p["xc"], p["draws"])
+        if mx is not None and len(t):
+            n0 = len(t)
+            img, t = A.mixup(img, t, imgs[mx["idx"]], labs[mx["idx"]], p["input_dim"], mx["jit"], mx["flip"], (mx["x_off"], mx["y_off"]))
+            nblend += len(t) > n0
+        samples.append((img, t))
+    ref_img, ref_rows = A.preprocess_batch(samples)
+    got = out.cpu().numpy()
+    assert nblend >= 2
+    for b in range(B):
+        bad = int((got[b] != ref_img[b]).sum())
+        assert bad == 0, (b, bad, dims[b], mixups[b], np.abs(got[b].astype(int) - ref_img[b].astype(int)).max())
+    assert np.array_equal(rows.cpu().numpy(), ref_rows)
+
+
 def test_draw_order_matches_oracle():
     mapper = GpuMosaicMapper(device=DEV)
     p = mapper.draw(np.random.RandomState(4), random.Random(5))

@@ -141,6 +141,11 @@ class mi_warp_job(C.Structure):
                 ("ch", "cw", "h", "w", "Hp", "Wp", "border", "blk0")]
 
 
+class mi_mixup_job(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("out", C.c_void_p)] + [(n, C.c_int32) for n in
+                ("h0", "w0", "rh1", "rw1", "dh", "dw", "oh", "ow", "flip", "x_off", "y_off", "th", "tw", "Hp", "Wp", "blk0")]
+
+
 class mi_cmd(C.Structure):
     _fields_ = [("op", C.c_int32), ("i", C.c_int32 * 40), ("f", C.c_float * 8), ("p", C.c_void_p * 16),
                 ("l", C.c_int64 * 4)]
@@ -215,6 +220,8 @@ _PROTOS = {
     "mi_mosaic_jobs_layout": (C.c_int, [C.POINTER(mi_mosaic_paste_job), _i, C.POINTER(mi_warp_job), _i]),
     "mi_mosaic_paste": (C.c_int, [_vp, _i, _i, _vp]),
     "mi_warp_affine_u8": (C.c_int, [_vp, _i, _i, _vp]),
+    "mi_mixup_jobs_layout": (C.c_int, [C.POINTER(mi_mixup_job), _i]),
+    "mi_mixup_blend": (C.c_int, [_vp, _i, _i, _vp]),
     "mi_rle_encode": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mi_rle_to_string": (C.c_int, [_vp, _i, C.c_char_p, _i]),
     "mi_yolox_onnx_layout": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),

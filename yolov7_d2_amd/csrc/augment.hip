@@ -58,6 +58,79 @@ __global__ __launch_bounds__(256) void mosaic_paste_kernel(const PasteJob* __res
   }
 }
 
+// ---- mixup (MyDatasetMapper2.mixup, dataset_mapper.py:686-768), in place on the warped sample
+struct MixJob {     // mirrors mi_mixup_job
+  const unsigned char* src;
+  unsigned char* out;
+  int h0, w0, rh1, rw1, dh, dw, oh, ow, flip, x_off, y_off, th, tw, Hp, Wp, blk0;
+};
+__device__ __forceinline__ void lin_coef_f(int d, double scale, int src, int* s, float* f0, float* f1) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int si = (int)floorf(f);
+  f = f - (float)si;
+  if (si < 0) { f = 0.f; si = 0; }
+  if (si >= src - 1) { f = 0.f; si = src - 1; }
+  *s = si; *f0 = 1.0f - f; *f1 = f;
+}
+__global__ __launch_bounds__(256) void mixup_blend_kernel(const MixJob* __restrict__ jobs, int njobs) {
+  int j = 0;
+  while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].blk0) ++j;
+  const MixJob p = jobs[j];
+  const int idx = ((int)blockIdx.x - p.blk0) * 256 + threadIdx.x;
+  if (idx >= p.tw * p.th) return;
+  const int y = idx / p.tw, x = idx - y * p.tw;
+  const int py = y + p.y_off, px = x + p.x_off;
+  int pad[3] = {0, 0, 0};
+  if (py < p.oh && px < p.ow) {
+    const int u = p.flip ? p.ow - 1 - px : px;
+    // second resize (float64 image, float32 coefficients): canvas dh x dw -> oh x ow
+    int sx, sy;
+    float fx0, fx1, fy0, fy1;
+    lin_coef_f(u, (double)p.dw / (double)p.ow, p.dw, &sx, &fx0, &fx1);
+    lin_coef_f(py, (double)p.dh / (double)p.oh, p.dh, &sy, &fy0, &fy1);
+    const int xs[2] = {sx, min(sx + 1, p.dw - 1)}, ys[2] = {sy, min(sy + 1, p.dh - 1)};
+    // first resize (uint8 fixed point): source h0 x w0 -> rh1 x rw1, in the canvas' top-left corner; 114.0 elsewhere
+    int cxs[2], cxa0[2], cxa1[2], cys[2], cyb0[2], cyb1[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      resize_coef(min(xs[k], p.rw1 - 1), (double)p.w0 / (double)p.rw1, p.w0, &cxs[k], &cxa0[k], &cxa1[k]);
+      resize_coef(min(ys[k], p.rh1 - 1), (double)p.h0 / (double)p.rh1, p.h0, &cys[k], &cyb0[k], &cyb1[k]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double S[2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          if (ys[a] < p.rh1 && xs[b] < p.rw1) {
+            const int x0 = cxs[b], x1 = min(x0 + 1, p.w0 - 1), y0 = cys[a], y1 = min(y0 + 1, p.h0 - 1);
+            const unsigned char* r0 = p.src + (size_t)y0 * p.w0 * 3;
+            const unsigned char* r1 = p.src + (size_t)y1 * p.w0 * 3;
+            const int h0 = (int)r0[x0 * 3 + c] * cxa0[b] + (int)r0[x1 * 3 + c] * cxa1[b];
+            const int h1 = (int)r1[x0 * 3 + c] * cxa0[b] + (int)r1[x1 * 3 + c] * cxa1[b];
+            int v = ((cyb0[a] * (h0 >> 4)) >> 16) + ((cyb1[a] * (h1 >> 4)) >> 16);
+            v = min(max((v + 2) >> 2, 0), 255);
+            S[a][b] = (double)v;
+          } else {
+            S[a][b] = 114.0;
+          }
+        }
+      const double r0 = S[0][0] * (double)fx0 + S[0][1] * (double)fx1;
+      const double r1 = S[1][0] * (double)fx0 + S[1][1] * (double)fx1;
+      const double v = r0 * (double)fy0 + r1 * (double)fy1;
+      pad[c] = (int)(unsigned char)v;
+    }
+  }
+  unsigned char* d = p.out + (size_t)y * p.Wp + x;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    unsigned char* q = d + (size_t)c * p.Hp * p.Wp;
+    const float f = 0.5f * (float)(*q) + 0.5f * (float)pad[c];
+    *q = (unsigned char)f;
+  }
+}
+
 __device__ __forceinline__ long long sat_i32(double v) {
   v = rint(v);
   if (v < -2147483648.0) v = -2147483648.0;
@@ -151,6 +224,27 @@ extern "C" int mi_mosaic_jobs_layout(mi_mosaic_paste_job* paste, int npaste, mi_
     blk += (int)(((long long)w.w * w.h + 255) / 256);
   }
   return pb > blk ? pb : blk;
+}
+
+extern "C" int mi_mixup_jobs_layout(mi_mixup_job* jobs, int njobs) {
+  MI_REQUIRE(jobs && njobs > 0, "mixup_jobs_layout: args");
+  int blk = 0;
+  for (int j = 0; j < njobs; ++j) {
+    mi_mixup_job& p = jobs[j];
+    MI_REQUIRE(p.src && p.out && p.h0 > 0 && p.w0 > 0 && p.rh1 > 0 && p.rw1 > 0 && p.rh1 <= p.dh && p.rw1 <= p.dw && p.oh > 0 && p.ow > 0 &&
+                   p.th > 0 && p.tw > 0 && p.Hp >= p.th && p.Wp >= p.tw && p.x_off >= 0 && p.y_off >= 0,
+               "mixup_jobs_layout: job %d geometry", j);
+    p.blk0 = blk;
+    blk += (int)(((long long)p.tw * p.th + 255) / 256);
+  }
+  return blk;
+}
+extern "C" int mi_mixup_blend(const mi_mixup_job* jobs_dev, int njobs, int total_blocks, mi_stream_t st) {
+  MI_REQUIRE(jobs_dev && njobs > 0 && total_blocks > 0, "mixup_blend: args");
+  static_assert(sizeof(MixJob) == sizeof(mi_mixup_job), "job layout");
+  hipLaunchKernelGGL(mixup_blend_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)st, (const MixJob*)jobs_dev, njobs);
+  MI_CHECK_LAUNCH("mixup_blend");
+  return MI_OK;
 }
 
 extern "C" int mi_mosaic_paste(const mi_mosaic_paste_job* jobs_dev, int njobs, int total_blocks, mi_stream_t st) {

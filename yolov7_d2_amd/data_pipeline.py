@@ -11,8 +11,9 @@ does every pixel: four resizes + pastes per sample in ONE launch, the affine war
 second - `GpuMosaicMapper.make_batch` returns exactly what `NativeTrainer.load_batch` / `feed` take (uint8 [B, 3, H, W],
 float32 [B, 100, 5] rows (cls, cx, cy, w, h)).  At 2 600 images / s / GPU this replaces ~40 cv2 CPU workers per GPU.
 
-Mixup (`ENABLE_MIXUP`; False in configs/coco/yolox_s.yaml:61) and the detectron2 `T.*` augmentations ahead of the mosaic are
-not built.  No CPU path for the pixels: device tensors only.
+Mixup (`ENABLE_MIXUP`, dataset_mapper.py:686-768) is a third launch that blends a resized / jittered / mirrored pool image
+into the warped sample in place.  The detectron2 `T.*` augmentations ahead of the mosaic are not built.  No CPU path for the
+pixels: device tensors only.
 """
 import ctypes as C
 import math
@@ -23,7 +24,7 @@ import torch
 
 from . import _lib as L
 
-MOSAIC_DEFAULTS = dict(NUM_IMAGES=4, DEGREES=10.0, TRANSLATE=0.1, SCALE=[0.5, 1.5], SHEAR=2.0, PERSPECTIVE=0.0,
+MOSAIC_DEFAULTS = dict(NUM_IMAGES=4, DEGREES=10.0, TRANSLATE=0.1, SCALE=[0.5, 1.5], MSCALE=[0.5, 1.5], SHEAR=2.0, PERSPECTIVE=0.0,
                        MOSAIC_WIDTH_RANGE=(512, 800), MOSAIC_HEIGHT_RANGE=(512, 800))        # yolov7/config.py:258-272
 
 
@@ -95,6 +96,38 @@ class GpuMosaicMapper:
         ty = rng_py.uniform(0.5 - c["TRANSLATE"], 0.5 + c["TRANSLATE"])
         return dict(input_dim=dim, yc=yc, xc=xc, draws=(a, s, shx, shy, tx, ty))
 
+    def draw_mixup(self, pool, input_dim, target_hw, rng_np=np.random, rng_py=random):
+        """the draws of MyDatasetMapper2.mixup in its order (dataset_mapper.py:687-743): random.uniform(*MSCALE),
+        random.uniform(0, 1) > 0.5, np.random.choice over the pool, then random.randint for the y and the x offset where the
+        jittered image exceeds the target (height, width) of the warped sample"""
+        jit = rng_py.uniform(*self.cfg["MSCALE"])
+        flip = rng_py.uniform(0, 1) > 0.5
+        idx = int(rng_np.choice(len(pool), 1)[0])
+        oh, ow = int(input_dim[0] * jit), int(input_dim[1] * jit)
+        ph, pw = max(oh, target_hw[0]), max(ow, target_hw[1])
+        y_off = rng_py.randint(0, ph - target_hw[0] - 1) if ph > target_hw[0] else 0
+        x_off = rng_py.randint(0, pw - target_hw[1] - 1) if pw > target_hw[1] else 0
+        return dict(idx=idx, jit=jit, flip=bool(flip), x_off=x_off, y_off=y_off)
+
+    @staticmethod
+    def _mixup_labels(origin_labels, cp_labels, r, jit, flip, x_off, y_off, origin_hw, target_hw):
+        """dataset_mapper.py:745-766: returns (labels, blended?)"""
+        cp = np.array(cp_labels, np.float64).reshape(-1, 5).copy()
+        oh, ow = origin_hw
+        bo = cp[:, :4]
+        ratio = r * jit
+        bo[:, 0::2] = np.clip(bo[:, 0::2] * ratio + 0, 0, ow)            # adjust_box_anns (utils/boxes.py:381-384)
+        bo[:, 1::2] = np.clip(bo[:, 1::2] * ratio + 0, 0, oh)
+        if flip:
+            bo[:, 0::2] = ow - bo[:, 0::2][:, ::-1]
+        bt = bo.copy()
+        bt[:, 0::2] = np.clip(bt[:, 0::2] - x_off, 0, target_hw[1])
+        bt[:, 1::2] = np.clip(bt[:, 1::2] - y_off, 0, target_hw[0])
+        keep = box_candidates(bo.T, bt.T, 5)
+        if keep.sum() >= 1.0:
+            return np.vstack((origin_labels.reshape(-1, 5), np.hstack((bt[keep], cp[keep, 4:5])))), True
+        return origin_labels, False
+
     # ---- host geometry / labels (float64, the reference's operation order) ------------------------------------------
     @staticmethod
     def _placement(i, w, h, xc, yc, dim):
@@ -160,9 +193,9 @@ class GpuMosaicMapper:
         return [A11, A12, -A11 * M[0, 2] - A12 * M[1, 2], A21, A22, -A21 * M[0, 2] - A22 * M[1, 2]]
 
     # ---- one batch --------------------------------------------------------------------------------------------------
-    def make_batch(self, pool, groups, params):
+    def make_batch(self, pool, groups, params, mixups=None):
         """groups: B tuples of four pool indices (the current image first, then the three sampled ones); params: B dicts
-        from draw().  Returns (uint8 [B, 3, H, W] on the device, float32 [B, max_boxes, 5] (cls, cx, cy, w, h) on the
+        from draw(); mixups: None or B entries (None or a dict from draw_mixup()).  Returns (uint8 [B, 3, H, W] on the device, float32 [B, max_boxes, 5] (cls, cx, cy, w, h) on the
         device, per-sample (h, w))"""
         if self.device.type != "cuda":
             raise L.MI355Error("GpuMosaicMapper: the MI355X path needs a device (no CPU pixel path)")
@@ -177,6 +210,8 @@ class GpuMosaicMapper:
         canvas = torch.full((int(coff[-1]),), self.pad, dtype=torch.uint8, device=self.device)
         paste = (L.mi_mosaic_paste_job * (4 * B))()
         warp = (L.mi_warp_job * B)()
+        mix = (L.mi_mixup_job * B)()
+        nmix = 0
         rows = np.zeros((B, self.max_boxes, 5), np.float32)
         for b, (grp, p) in enumerate(zip(groups, params)):
             dim, yc, xc = p["input_dim"], p["yc"], p["xc"]
@@ -209,7 +244,23 @@ class GpuMosaicMapper:
             else:
                 labels4 = np.zeros((0, 5))
             M, width, height = self._matrix((dim[0] * 2, dim[1] * 2), p["draws"], [-dim[0] // 2, -dim[1] // 2])
-            t = self._warp_labels(labels4, M, p["draws"][1], width, height)[: self.max_boxes]
+            t = self._warp_labels(labels4, M, p["draws"][1], width, height)
+            mx = mixups[b] if mixups is not None else None
+            if mx is not None and len(t):                           # dataset_mapper.py:602: only with surviving labels
+                im = pool.images[mx["idx"]]
+                h0, w0 = im.shape[:2]
+                r = min(dim[0] / h0, dim[1] / w0)
+                oh, ow = int(dim[0] * mx["jit"]), int(dim[1] * mx["jit"])
+                t, blended = self._mixup_labels(t, pool.labels[mx["idx"]], r, mx["jit"], mx["flip"], mx["x_off"], mx["y_off"],
+                                                (oh, ow), (height, width))
+                if blended:
+                    mj = mix[nmix]
+                    nmix += 1
+                    mj.src, mj.out = im.data_ptr(), out.data_ptr() + b * 3 * Hp * Wp
+                    mj.h0, mj.w0, mj.rh1, mj.rw1, mj.dh, mj.dw = h0, w0, int(h0 * r), int(w0 * r), dim[0], dim[1]
+                    mj.oh, mj.ow, mj.flip, mj.x_off, mj.y_off = oh, ow, int(mx["flip"]), mx["x_off"], mx["y_off"]
+                    mj.th, mj.tw, mj.Hp, mj.Wp = height, width, Hp, Wp
+            t = t[: self.max_boxes]
             wj = warp[b]
             wj.canvas, wj.out = cbase, out.data_ptr() + b * 3 * Hp * Wp
             for q, v in enumerate(self._invert(M)):
@@ -225,9 +276,12 @@ class GpuMosaicMapper:
         L.check(lib.mi_mosaic_jobs_layout(paste, 4 * B, warp, B), "mi_mosaic_jobs_layout")
         pb = paste[4 * B - 1].blk0 + ((paste[4 * B - 1].x2a - paste[4 * B - 1].x1a) * (paste[4 * B - 1].y2a - paste[4 * B - 1].y1a) + 255) // 256
         wb = warp[B - 1].blk0 + (warp[B - 1].w * warp[B - 1].h + 255) // 256
-        tab = torch.frombuffer(bytearray(bytes(paste) + bytes(warp)), dtype=torch.uint8).to(self.device)
+        mb = L.check(lib.mi_mixup_jobs_layout(mix, nmix), "mi_mixup_jobs_layout") if nmix else 0
+        tab = torch.frombuffer(bytearray(bytes(paste) + bytes(warp) + bytes(mix)), dtype=torch.uint8).to(self.device)
         st = L.stream_ptr()
         L.check(lib.mi_mosaic_paste(tab.data_ptr(), 4 * B, pb, st), "mi_mosaic_paste")
         L.check(lib.mi_warp_affine_u8(tab.data_ptr() + C.sizeof(paste), B, wb, st), "mi_warp_affine_u8")
+        if nmix:
+            L.check(lib.mi_mixup_blend(tab.data_ptr() + C.sizeof(paste) + C.sizeof(warp), nmix, mb, st), "mi_mixup_blend")
         self._keep = (canvas, tab)                                 # alive until the stream has run the two launches
         return out, torch.from_numpy(rows).to(self.device, non_blocking=True), [(d[0], d[1]) for d in dims]
