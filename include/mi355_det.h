@@ -348,6 +348,13 @@ typedef struct mi_split_job {
 } mi_split_job;
 int mi_yolox_split_dpreds_batch(const float* dpreds, int B, int A, int nch, const mi_split_job* jobs, int njobs,
                                 mi_stream_t s);
+/* mi_yolox_loss_bwd + mi_yolox_split_dpreds_batch + mi_yolox_bias_grads in ONE pass over the gradient: every value is
+ * computed once and written as the bf16 out-gradient map of its prediction conv, into per-block column sums and - only when
+ * dpreds is not NULL (tests / diagnostics) - as fp32 dpreds [B][A][5 + ncls]; per-block column sums (bias gradients; a second small launch adds the blocks).  The split jobs must tile [A][5 + ncls]
+ * exactly (each job = the box columns, the objectness column or class columns of one level); every bias job must name the
+ * (a0, HW, c0, nc) of one split job.  ws: scratch of ws_floats floats (>= njobs * max ld; 16 * 512 * 128 serves all plans). */
+int mi_yolox_loss_bwd_fused(const mi_yolox_loss_desc* d, const float* gw, float* dpreds, const mi_split_job* split_jobs,
+                            int nsplit, const mi_bias_job* bias_jobs, int nbias, float* ws, int64_t ws_floats, mi_stream_t s);
 /* eval decode (yolox_head.py:247-272): in-place on preds; obj/cls sigmoid applied */
 int mi_yolox_decode(float* preds, const float* anchors, int B, int A, int ncls, mi_stream_t s);
 /* the ONNX-export layout of decode_outputs (yolox_head.py:263-269) from the decoded predictions:
@@ -639,6 +646,7 @@ enum {
   MI_OP_DWCONV_FWD = 34,   /* p = x, w, y, stats_acc */
   MI_OP_DWCONV_DGRAD = 35, /* p = dy, w, dx */
   MI_OP_DWCONV_WGRAD = 36, /* p = x, dy, ws, dw; l0 = ws bytes */
+  MI_OP_LOSS_BWD_FUSED = 37, /* p = loss desc, gw, dpreds, split jobs (host), bias jobs (host), ws; i = nsplit, nbias; l0 = ws floats */
   MI_OP_COUNT
 };
 

@@ -1,7 +1,11 @@
 """Shared helpers of the whole-step GPU parity tests: one HIP step with every stored tensor the comparison needs, and the
 oracle's forward / backward with the product's bf16 storage emulation, optionally with the forward state pinned to the
 HIP values (teacher forcing, see tests/test_gpu_parity_bench.py for why)."""
+import os
+
 import torch
+
+os.environ.setdefault("MI_LOSS_DPREDS", "1")   # the fused loss backward keeps the fp32 gradient tensor only on request
 
 import yolox_oracle as O
 import yolov7_d2_amd as M

@@ -456,6 +456,41 @@ def test_grouped_launches_equal_separate_launches(monkeypatch, B, H, W):
     assert not bad, bad[:8]
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 96, 128), (16, 640, 640)], ids=["2x96x128", "bench_16x640x640"])
+def test_fused_loss_backward_equals_three_passes(monkeypatch, B, H, W):
+    """LOSS_BWD_FUSED (gradient tensor + prediction-conv out-gradient maps + bias-gradient block sums in one pass) against
+    LOSS_BWD + BIAS_GRADS + SPLIT_DPREDS_BATCH: the fp32 gradient bit-identical, hence every activation / weight gradient
+    downstream; the bias gradients differ in summation order only"""
+    res = {}
+    monkeypatch.setenv("MI_BN_FUSED", "1")
+    monkeypatch.setenv("MI_LOSS_DPREDS", "1")
+    imgs, labels = O.synth_batch(B, H, W, seed=23, max_gt=6)
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MI_LOSS_BWD_FUSED", mode)
+        model, _ = _gpu_model(seed=6)
+        model.train()
+        ps = model.plan_for(B, H, W, True)
+        ops = [L.OPS[ps.plan.bwd_cmds[0][k].op] for k in range(ps.plan.bwd_cmds[1])]
+        assert ("LOSS_BWD_FUSED" in ops) == (mode == "1") and ("SPLIT_DPREDS_BATCH" in ops) == (mode == "0")
+        ps.image.copy_(imgs.to(DEV)); ps.labels.copy_(labels.to(DEV))
+        ps.gw().fill_(1.0)
+        ps.plan.run("fwd"); ps.plan.run("bwd"); torch.cuda.synchronize()
+        nch = 85
+        dp = ps.plan.buf_view(ps.loss["dpreds"], torch.float32, B * ps.A * nch).cpu().clone()
+        grads = {n: model.params.grad_of(p).detach().float().cpu().clone() for n, p in model.named_parameters()}
+        res[mode] = (dp, grads)
+    assert torch.equal(res["0"][0], res["1"][0]) and float(res["0"][0].abs().max()) > 0
+    for n, g0 in res["0"][1].items():
+        g1 = res["1"][1][n]
+        if "_preds" in n and n.endswith("bias"):
+            np.testing.assert_allclose(g1.numpy(), g0.numpy(), rtol=2e-5, atol=1e-7, err_msg=n)
+        elif "head." in n and "_preds" in n:
+            assert torch.equal(g0, g1), n                      # (the prediction convs' weight gradients read the maps directly)
+    # everything below the head: same maps in, same kernels -> only the order of BatchNorm atomics can differ
+    worst = max(float((res["1"][1][n] - g0).norm() / (g0.norm() + 1e-12)) for n, g0 in res["0"][1].items())
+    assert worst < 5e-2, worst
+
+
 def test_wgrad_split_groups_equal_single_group(monkeypatch):
     """data-parallel layout of the weight gradients (MI_WGRAD_SPLIT=1: head + neck group mid-backward, backbone group at
     the end, so the first gradient bucket can be all-reduced under the backbone's backward) against the single group:

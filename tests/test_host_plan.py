@@ -355,7 +355,7 @@ def test_grouped_launches_of_the_640_plan():
     plan = Plan(ps.builder, dry_run=True)
     want = {"fwd": dict(CONV_GROUP=13, BN_GROUP=11, CONV=43, BN_ACT_FWD=43),
             "bwd": dict(CONV_GROUP=12, BN_GROUP=11, BN_BWD_FUSED=43, BN_BWD_REDUCE=0, BN_BWD_APPLY=0, WGRAD_GROUP=1,
-                        SPLIT_DPREDS_BATCH=1, SPLIT_DPREDS=0)}
+                        SPLIT_DPREDS_BATCH=0, SPLIT_DPREDS=0, LOSS_BWD_FUSED=1, LOSS_BWD=0, BIAS_GRADS=0)}
     jobs = {"fwd": [2] * 8 + [3, 6, 6, 6, 3], "bwd": [6, 3, 6, 3, 3, 3] + [4] * 6}    # + the parity classes of the six stride-2 data gradients
     for which in ("fwd", "bwd"):
         arr, n = plan.fwd_cmds if which == "fwd" else plan.bwd_cmds

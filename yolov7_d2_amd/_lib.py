@@ -155,7 +155,8 @@ class mi_cmd(C.Structure):
 OPS = ["NOP", "CONV", "WGRAD", "PACK_W", "RESERVED4", "RESERVED5", "BN_ACT_FWD", "BN_BWD_REDUCE",
        "RESERVED8", "BN_BWD_APPLY", "FOCUS", "UPSAMPLE_FWD", "UPSAMPLE_BWD", "SPP_FWD", "SPP_BWD", "COPY",
        "COLSUM", "LOSS_FWD", "LOSS_BWD", "SPLIT_DPREDS", "MEMSET", "SGD", "BN_EVAL_AFFINE", "DECODE", "PACK_W_BATCH", "WGRAD_GROUP", "STREAM", "FORK", "JOIN", "BIAS_GRADS",
-       "CONV_GROUP", "BN_GROUP", "SPLIT_DPREDS_BATCH", "BN_BWD_FUSED", "DWCONV_FWD", "DWCONV_DGRAD", "DWCONV_WGRAD"]
+       "CONV_GROUP", "BN_GROUP", "SPLIT_DPREDS_BATCH", "BN_BWD_FUSED", "DWCONV_FWD", "DWCONV_DGRAD", "DWCONV_WGRAD",
+       "LOSS_BWD_FUSED"]
 OP = {n: k for k, n in enumerate(OPS)}
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -190,6 +191,8 @@ _PROTOS = {
     "mi_pack_jobs_layout": (C.c_int, [C.POINTER(mi_pack_job), _i]),
     "mi_yolox_loss_fwd": (C.c_int, [C.POINTER(mi_yolox_loss_desc), _vp]),
     "mi_yolox_loss_bwd": (C.c_int, [C.POINTER(mi_yolox_loss_desc), _vp, _vp, _vp]),
+    "mi_yolox_loss_bwd_fused": (C.c_int, [C.POINTER(mi_yolox_loss_desc), _vp, _vp, C.POINTER(mi_split_job), _i,
+                                          C.POINTER(mi_bias_job), _i, _vp, _i64, _vp]),
     "mi_yolox_split_dpreds": (C.c_int, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "mi_yolox_split_dpreds_batch": (C.c_int, [_vp, _i, _i, _i, C.POINTER(mi_split_job), _i, _vp]),
     "mi_yolox_bias_grads": (C.c_int, [_vp, _i, _i, _i, C.POINTER(mi_bias_job), _i, _vp, _vp]),

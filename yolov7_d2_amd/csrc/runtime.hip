@@ -67,6 +67,9 @@ static int run_one(const mi_cmd& c, hipStream_t s) {
     case MI_OP_BN_GROUP: return mi_bn_group_run((const mi_bn_group*)p[0], p[1], st);
     case MI_OP_PACK_W_BATCH: return mi_pack_conv_weights_batch((const mi_pack_job*)p[0], i[0], i[1], i[2], st);
     case MI_OP_LOSS_FWD: return mi_yolox_loss_fwd((const mi_yolox_loss_desc*)p[0], st);
+    case MI_OP_LOSS_BWD_FUSED:
+      return mi_yolox_loss_bwd_fused((const mi_yolox_loss_desc*)p[0], (const float*)p[1], (float*)p[2], (const mi_split_job*)p[3], i[0],
+                                     (const mi_bias_job*)p[4], i[1], (float*)p[5], c.l[0], st);
     case MI_OP_LOSS_BWD: return mi_yolox_loss_bwd((const mi_yolox_loss_desc*)p[0], (const float*)p[1], (float*)p[2], st);
     case MI_OP_SPLIT_DPREDS:
       return mi_yolox_split_dpreds((const float*)p[0], i[0], i[1], i[2], i[3], i[4], i[5], i[6], p[1], i[7], st);

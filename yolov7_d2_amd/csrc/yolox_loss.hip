@@ -509,18 +509,13 @@ __global__ __launch_bounds__(256) void yolox_loss_bwd_cls_kernel(const LossK p, 
     dpreds[idx] = v;
   }
 }
-__global__ __launch_bounds__(256) void yolox_loss_bwd_box_kernel(const LossK p, const float* gw, float* dpreds) {
-  const int b = blockIdx.y;
-  const int a = blockIdx.x * 256 + threadIdx.x;
-  if (a >= p.A) return;
-  const size_t o = (size_t)b * p.A + a;
-  if (!p.fg[o]) return;
+// box-column gradient of one foreground anchor: dp[0..3] = d loss / d raw (x, y, w, h)
+__device__ __forceinline__ void box_grad(const LossK& p, const float* gw, const size_t o, const int a, const int b, float* dp) {
   const float nfg = p.out[6];
   const float N = nfg > 1.f ? nfg : 1.f;
   const float w_iou = p.reg_weight * (gw[0] + gw[1]) / N;
   const float w_l1 = p.use_l1 ? (gw[0] + gw[4]) / N : 0.f;   // gw has a fifth entry (upstream of l1_loss) iff use_l1
   const float* pr = p.preds + o * p.nch;
-  float* dp = dpreds + o * p.nch;
   const float* lab = p.labels + ((size_t)b * p.max_labels + p.matched_gt[o]) * 5;
   const float st = p.anchors[a * 3 + 2];
   const Box pb = decode_box(pr, p.anchors[a * 3 + 0], p.anchors[a * 3 + 1], st);
@@ -566,6 +561,137 @@ __global__ __launch_bounds__(256) void yolox_loss_bwd_box_kernel(const LossK p, 
       const float e = pr[q] - t[q];
       dp[q] += w_l1 * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
     }
+  }
+}
+__global__ __launch_bounds__(256) void yolox_loss_bwd_box_kernel(const LossK p, const float* gw, float* dpreds) {
+  const int b = blockIdx.y;
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  if (a >= p.A) return;
+  const size_t o = (size_t)b * p.A + a;
+  if (!p.fg[o]) return;
+  float dp[4];
+  box_grad(p, gw, o, a, b, dp);
+  float* d = dpreds + o * p.nch;
+  d[0] = dp[0]; d[1] = dp[1]; d[2] = dp[2]; d[3] = dp[3];
+}
+
+// ---- the same gradient written ONCE in every form the backward pass needs (MI_LOSS_BWD_FUSED, default on): the fp32
+// [B][A][5 + ncls] tensor, the bf16 NHWC out-gradient map of every prediction conv (what mi_yolox_split_dpreds_batch
+// produced from a second read of that tensor) and per-block column sums for the convs' bias gradients (what
+// bias_grads_stage1 produced from a third read).  One thread item = (prediction conv, image, pixel, 8-channel group).
+#define MI_LBF_MAX_JOBS 16
+struct LossBwdFusedK {
+  LossK l;
+  const float* gw;
+  float* dpreds;
+  float* ws;        // [njobs][gridDim.x][ldmax]
+  int njobs, ldmax;
+  mi_split_job jobs[MI_LBF_MAX_JOBS];
+  float* bias_out[MI_LBF_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void yolox_loss_bwd_fused_kernel(const LossBwdFusedK q) {
+  __shared__ float red[256 * 8];
+  const LossK& p = q.l;
+  const mi_split_job j = q.jobs[blockIdx.y];
+  const int ld8 = j.ld >> 3;
+  const int TPB = (256 / ld8) * ld8;          // active threads: a thread keeps its channel group across its items
+  const bool active = (int)threadIdx.x < TPB;
+  const int j8 = active ? (int)threadIdx.x % ld8 : 0;
+  const float nfg = p.out[6];
+  const float N = nfg > 1.f ? nfg : 1.f;
+  const float w_obj = (q.gw[0] + q.gw[2]) / N;
+  const float w_cls = (q.gw[0] + q.gw[3]) / N;
+  const unsigned total = (unsigned)p.B * (unsigned)j.HW * (unsigned)ld8;
+  uint4* dst = (uint4*)j.dst;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  for (unsigned idx = blockIdx.x * (unsigned)TPB + threadIdx.x; active && idx < total; idx += gridDim.x * (unsigned)TPB) {
+    const unsigned bp = idx / (unsigned)ld8;
+    const int b = (int)(bp / (unsigned)j.HW), pidx = (int)(bp - (unsigned)b * j.HW);
+    const int a = j.a0 + pidx;
+    const size_t o = (size_t)b * p.A + a;
+    const bool fg = p.fg[o] != 0;
+    const int cb = j.c0 + j8 * 8;             // first prediction channel of this item
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (cb < 4) {                              // the regression conv: box columns, foreground only
+      if (fg) {
+        float dp[4];
+        box_grad(p, q.gw, o, a, b, dp);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (cb + e < 4 && j8 * 8 + e < j.nc) v[e] = dp[cb + e];
+      }
+    } else if (cb == 4 && j.nc == 1) {         // the objectness conv
+      v[0] = w_obj * (sigmoid_ref(p.preds[o * p.nch + 4]) - (fg ? 1.f : 0.f));
+    } else if (fg) {                           // the class conv (background rows: zero, their logits are not read)
+      const float* lab = p.labels + ((size_t)b * p.max_labels + p.matched_gt[o]) * 5;
+      const int gc = (int)lab[0];
+      const float miou = p.matched_iou[o];
+      const float* pr = p.preds + o * p.nch + cb;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (j8 * 8 + e < j.nc) v[e] = w_cls * (sigmoid_ref(pr[e]) - ((cb + e - 5) == gc ? miou : 0.f));
+    }
+    unsigned short h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s[e] += v[e];
+      h[e] = __builtin_bit_cast(unsigned short, (__bf16)v[e]);
+    }
+    if (q.dpreds) {   // (diagnostic: 4-byte stores 32 bytes apart across the lanes - this alone doubles the kernel's time)
+      float* dpr = q.dpreds + o * p.nch + cb;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (j8 * 8 + e < j.nc) dpr[e] = v[e];
+    }
+    dst[idx] = make_uint4(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16), h[4] | ((uint32_t)h[5] << 16),
+                          h[6] | ((uint32_t)h[7] << 16));
+  }
+  if (!q.bias_out[blockIdx.y]) return;         // (uniform per block)
+  // column sums of this block: threads with the same j8 are tid = j8 + k * ld8
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = s[e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < j.ld; c += 256) {
+    const int g = c >> 3, e = c & 7;
+    float t = 0.f;
+    for (int k = g; k < TPB; k += ld8) t += red[k * 8 + e];
+    q.ws[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * q.ldmax + c] = t;
+  }
+}
+// bias gradient of one prediction conv = sum of its blocks' column sums: 128 channels x 8 parts of the block list per trip,
+// four loads in flight per thread (a rolled loop over 512 partials is a chain of 512 L2 round trips: ~100 us)
+__global__ __launch_bounds__(1024) void yolox_loss_bwd_bias_kernel(const LossBwdFusedK q, int nblk) {
+  __shared__ float red[1024];
+  const mi_split_job j = q.jobs[blockIdx.x];
+  float* out = q.bias_out[blockIdx.x];
+  if (!out) return;
+  const float* w = q.ws + (size_t)blockIdx.x * nblk * q.ldmax;
+  const int lane = threadIdx.x & 127, part = threadIdx.x >> 7;
+  for (int c0 = 0; c0 < j.nc; c0 += 128) {
+    const int c = c0 + lane;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    if (c < j.nc) {
+      int b = part;
+      for (; b + 24 < nblk; b += 32) {
+        const float v0 = w[(size_t)b * q.ldmax + c], v1 = w[(size_t)(b + 8) * q.ldmax + c];
+        const float v2 = w[(size_t)(b + 16) * q.ldmax + c], v3 = w[(size_t)(b + 24) * q.ldmax + c];
+        t0 += v0; t1 += v1; t2 += v2; t3 += v3;
+      }
+      for (; b < nblk; b += 8) t0 += w[(size_t)b * q.ldmax + c];
+    }
+    red[threadIdx.x] = (t0 + t1) + (t2 + t3);
+    __syncthreads();
+    if (part == 0 && c < j.nc) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += red[k * 128 + lane];
+      out[c] = t;
+    }
+    __syncthreads();
   }
 }
 
@@ -733,6 +859,52 @@ extern "C" int mi_yolox_bias_grads(const float* dpreds, int B, int A, int nch, c
   MI_CHECK_LAUNCH("bias_grads1");
   hipLaunchKernelGGL(bias_grads_stage2_kernel, dim3(njobs), dim3(128), 0, (hipStream_t)st, k);
   MI_CHECK_LAUNCH("bias_grads2");
+  return MI_OK;
+}
+
+extern "C" int mi_yolox_loss_bwd_fused(const mi_yolox_loss_desc* d, const float* gw, float* dpreds, const mi_split_job* split_jobs,
+                                       int nsplit, const mi_bias_job* bias_jobs, int nbias, float* ws, int64_t ws_floats,
+                                       mi_stream_t st) {
+  LossBwdFusedK k;
+  int rc = loss_fill(d, &k.l);
+  if (rc) return rc;
+  MI_REQUIRE(gw && split_jobs && nsplit > 0 && nsplit <= MI_LBF_MAX_JOBS && nbias >= 0 && (nbias == 0 || (bias_jobs && ws)),
+             "yolox_loss_bwd_fused: args");
+  const int nch = k.l.nch;
+  MI_REQUIRE((int64_t)d->B * d->A * nch < (1LL << 31) - (1 << 22), "yolox_loss_bwd_fused: element index exceeds 32 bits");
+  k.gw = gw; k.dpreds = dpreds; k.ws = ws; k.njobs = nsplit; k.ldmax = 0;
+  int64_t most = 0, cover = 0;
+  for (int n = 0; n < nsplit; ++n) {
+    const mi_split_job& j = split_jobs[n];
+    MI_REQUIRE(j.dst && j.ld % 8 == 0 && j.ld >= j.nc && j.ld <= 2048 && j.nc >= 1 && j.c0 >= 0 && j.c0 + j.nc <= nch && j.a0 >= 0 &&
+                   j.a0 + j.HW <= d->A && (j.c0 >= 5 || j.c0 + j.nc <= 5) && (j.c0 >= 4 || j.c0 + j.nc <= 4),
+               "yolox_loss_bwd_fused: job %d (a job is the box columns, the objectness column or class columns)", n);
+    k.jobs[n] = j;
+    k.bias_out[n] = nullptr;
+    if (j.ld > k.ldmax) k.ldmax = j.ld;
+    const int64_t t = (int64_t)d->B * j.HW * (j.ld / 8);
+    if (t > most) most = t;
+    cover += (int64_t)j.HW * j.nc;
+  }
+  // the jobs must tile [A][nch] exactly once: dpreds is WRITTEN here, not zero-filled first
+  MI_REQUIRE(cover == (int64_t)d->A * nch, "yolox_loss_bwd_fused: the jobs cover %lld of %lld (anchor, channel) cells", (long long)cover,
+             (long long)d->A * nch);
+  for (int n = 0; n < nbias; ++n) {
+    int hit = -1;
+    for (int m = 0; m < nsplit; ++m)
+      if (split_jobs[m].a0 == bias_jobs[n].a0 && split_jobs[m].HW == bias_jobs[n].HW && split_jobs[m].c0 == bias_jobs[n].c0 &&
+          split_jobs[m].nc == bias_jobs[n].nc) hit = m;
+    MI_REQUIRE(hit >= 0 && bias_jobs[n].out, "yolox_loss_bwd_fused: bias job %d matches no out-gradient map", n);
+    k.bias_out[hit] = bias_jobs[n].out;
+  }
+  int64_t blocks = (most + 255) / 256;
+  if (blocks > 512) blocks = 512;
+  if (nbias && blocks * nsplit * k.ldmax > ws_floats) blocks = ws_floats / ((int64_t)nsplit * k.ldmax);
+  MI_REQUIRE(blocks >= 1, "yolox_loss_bwd_fused: scratch of %lld floats too small", (long long)ws_floats);
+  hipStream_t s = (hipStream_t)st;
+  hipLaunchKernelGGL(yolox_loss_bwd_fused_kernel, dim3((int)blocks, nsplit), dim3(256), 0, s, k);
+  if (nbias) hipLaunchKernelGGL(yolox_loss_bwd_bias_kernel, dim3(nsplit), dim3(1024), 0, s, k, (int)blocks);
+  MI_CHECK_LAUNCH("yolox_loss_bwd_fused");
   return MI_OK;
 }
 

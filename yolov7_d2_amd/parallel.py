@@ -49,6 +49,10 @@ def grad_write_ranges(plan, grad_tensor):
             jobs = C.cast(c.p[0], C.POINTER(L.mi_bias_job))
             for j in range(c.i[3]):
                 ptrs.append((jobs[j].out, jobs[j].nc * 4))
+        elif c.op == L.OP["LOSS_BWD_FUSED"]:
+            jobs = C.cast(c.p[4], C.POINTER(L.mi_bias_job))
+            for j in range(c.i[1]):
+                ptrs.append((jobs[j].out, jobs[j].nc * 4))
         elif c.op == L.OP["MEMSET"]:
             ptrs.append((c.p[0], c.l[0]))
         rs = []

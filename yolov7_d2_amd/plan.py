@@ -705,7 +705,7 @@ class Plan:
 
     def _materialize_bwd(self):
         b = self.b
-        bwd = self._batch_splits(b.bwd)
+        bwd = self._fuse_loss_bwd(self._batch_splits(b.bwd))
         if self.bn_fused:
             bwd = self._fuse_bn_bwd_pairs(bwd)
         self.bwd_cmds, self.bwd_tags = self._materialize(self._group_wgrads(bwd), "bwd")
@@ -879,6 +879,36 @@ class Plan:
         rest = [c for c in bwd if c.op != L.OP["SPLIT_DPREDS"]]
         k = next(k for k, c in enumerate(rest) if c is bwd[at])
         return rest[:k + 1] + [cmd] + rest[k + 1:]
+
+    def _fuse_loss_bwd(self, bwd):
+        """LOSS_BWD + BIAS_GRADS + SPLIT_DPREDS_BATCH (three passes over the [B][A][5 + ncls] gradient: write, read, read)
+        -> one LOSS_BWD_FUSED pass that writes the fp32 tensor, the prediction convs' bf16 out-gradient maps and the bias
+        gradients' block sums together.  MI_LOSS_BWD_FUSED=0 keeps the three commands."""
+        if os.environ.get("MI_LOSS_BWD_FUSED", "1") == "0":
+            return bwd
+        ops = [c.op for c in bwd]
+        try:
+            k = ops.index(L.OP["LOSS_BWD"])
+        except ValueError:
+            return bwd
+        if ops[k + 1: k + 3] != [L.OP["BIAS_GRADS"], L.OP["SPLIT_DPREDS_BATCH"]]:
+            return bwd
+        lb, bg, sp = bwd[k: k + 3]
+        B, A, nch = sp.i[:3]
+        cells = sum(j["HW"] * j["nc"] for j in sp.desc.jobs)
+        if cells != A * nch or len(sp.desc.jobs) > 16:       # the maps do not tile the gradient: keep the separate passes
+            return bwd
+        sj, bj = self._make_desc(sp.desc), self._make_desc(bg.desc)
+        # the fp32 [B][A][5 + ncls] tensor itself has no consumer left; MI_LOSS_DPREDS=1 (the parity tests, which hand it to
+        # the oracle's backward) keeps it
+        keep = os.environ.get("MI_LOSS_DPREDS", "0") == "1"
+        cmd = _Cmd(L.OP["LOSS_BWD_FUSED"], i=[len(sp.desc.jobs), len(bg.desc.jobs)], l=[bg.p[2].obj.nbytes // 4], desc=lb.desc,
+                   p=[_Ptr(None), lb.p[1], lb.p[2] if keep else _Ptr(None), _Ptr(C.addressof(sj)), _Ptr(C.addressof(bj)), bg.p[2]],
+                   tag="loss.bwd_fused", stream=lb.stream)
+        cmd.lane = getattr(lb, "lane", 0)
+        cmd.members = [lb, bg] + list(sp.members)
+        cmd.bias_jobs = bj
+        return bwd[:k] + [cmd] + bwd[k + 3:]
 
     def _batch_packs(self, prologue):
         """all PACK_W commands of the prologue become ONE launch over a device job table"""
