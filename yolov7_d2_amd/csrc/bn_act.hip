@@ -124,14 +124,18 @@ __device__ __forceinline__ void bn_act_fwd_body(PK& p, const int bid, const int 
   }
   // 4 grid-stride elements per trip, all loads issued before the first use (one load in flight per wave is
   // latency-bound: ~1 us per trip)
+  // TPB % C8 == 0: the thread's items are the pixels pix0 + k * pstep of its channel group - no division per item (a
+  // 64-bit one costs as much as the item's arithmetic)
   const int64_t stride = (int64_t)nb * TPB;
-  for (int64_t idx = (int64_t)bid * TPB + threadIdx.x; idx < total; idx += 4 * stride) {
+  const int64_t pstep = (int64_t)nb * (TPB / C8);
+  int64_t pixb = (int64_t)bid * (TPB / C8) + (int)threadIdx.x / C8;
+  for (int64_t idx = (int64_t)bid * TPB + threadIdx.x; idx < total; idx += 4 * stride, pixb += 4 * pstep) {
     bf16x8 v[4], r[4];
     int64_t pix[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int64_t i = idx + u * stride;
-      pix[u] = i / C8;
+      pix[u] = pixb + u * pstep;
       if (i < total) {
         v[u] = *(const bf16x8*)(p.y + pix[u] * p.ldy + c8 * 8);
         if (p.res) r[u] = *(const bf16x8*)(p.res + pix[u] * p.ldres + c8 * 8);
@@ -385,13 +389,15 @@ __device__ __forceinline__ void bn_bwd_apply_body(PK& p, const int bid, const in
     k2[e] = s_c2[c];
   }
   const int64_t stride = (int64_t)nb * TPB;
-  for (int64_t idx = (int64_t)bid * TPB + threadIdx.x; idx < total; idx += 2 * stride) {
+  const int64_t pstep = (int64_t)nb * (TPB / C8);   // (no division per item: see bn_act_fwd_body)
+  int64_t pixb = (int64_t)bid * (TPB / C8) + (int)threadIdx.x / C8;
+  for (int64_t idx = (int64_t)bid * TPB + threadIdx.x; idx < total; idx += 2 * stride, pixb += 2 * pstep) {
     bf16x8 dv[2], yv[2], rv[2];
     int64_t pix[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int64_t i = idx + u * stride;
-      pix[u] = i / C8;
+      pix[u] = pixb + u * pstep;
       if (i < total) {
         dv[u] = *(const bf16x8*)(p.da + pix[u] * p.ldda + c8 * 8);
         yv[u] = *(const bf16x8*)(p.y + pix[u] * p.ldy + c8 * 8);

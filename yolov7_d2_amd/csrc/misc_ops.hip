@@ -43,17 +43,19 @@ template <class T>
 __global__ __launch_bounds__(256) void focus_pack4_kernel(const T* __restrict__ img, int N, int H, int W, __bf16* out,
                                                           int ldo) {
   const int Ho = H / 2, Wo = W / 2;
-  const int64_t total = (int64_t)N * Ho * Wo;
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t idx0 = blockIdx.x * 256LL + threadIdx.x; idx0 < total; idx0 += 4 * stride) {
+  // 32-bit pixel indices (the launchers check N * Ho * Wo < 2^31): two 64-bit divisions per pixel cost more than its loads
+  const unsigned total = (unsigned)N * (unsigned)Ho * (unsigned)Wo;
+  const unsigned stride = gridDim.x * 256u;
+  for (unsigned idx0 = blockIdx.x * 256u + threadIdx.x; idx0 < total; idx0 += 4 * stride) {
     float f[4][16];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int64_t idx = idx0 + j * stride;
+      const unsigned idx = idx0 + j * stride;
       if (idx >= total) break;
-      const int ox = (int)(idx % Wo);
-      const int64_t r = idx / Wo;
-      const int oy = (int)(r % Ho), n = (int)(r / Ho);
+      const unsigned r = idx / (unsigned)Wo;
+      const int ox = (int)(idx - r * (unsigned)Wo);
+      const unsigned nn = r / (unsigned)Ho;
+      const int oy = (int)(r - nn * (unsigned)Ho), n = (int)nn;
 #pragma unroll
       for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -73,9 +75,9 @@ __global__ __launch_bounds__(256) void focus_pack4_kernel(const T* __restrict__ 
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int64_t idx = idx0 + j * stride;
+      const unsigned idx = idx0 + j * stride;
       if (idx >= total) break;
-      __bf16* op = out + idx * ldo;
+      __bf16* op = out + (size_t)idx * ldo;
       *(bf16x8*)op = pack8(f[j]);
       *(bf16x8*)(op + 8) = pack8(f[j] + 8);
     }
@@ -86,6 +88,7 @@ extern "C" int mi_focus_pack_u8(const uint8_t* img, int N, int H, int W, void* o
   MI_REQUIRE(img && out && H % 2 == 0 && W % 2 == 0 && ldo % 8 == 0 && ldo >= 16 && ((uintptr_t)img & 1) == 0,
              "focus_pack_u8: args");
   const int64_t total = (int64_t)N * (H / 2) * (W / 2);
+  MI_REQUIRE(total < (1LL << 31) - (1 << 24), "focus_pack_u8: %lld output pixels exceed the 32-bit index", (long long)total);
   hipLaunchKernelGGL(focus_pack4_kernel<uint8_t>, dim3(ew_blocks((total + 3) / 4)), dim3(256), 0, (hipStream_t)st, img, N, H,
                      W, (__bf16*)out, ldo);
   MI_CHECK_LAUNCH("focus_pack_u8");
@@ -95,6 +98,7 @@ extern "C" int mi_focus_pack_u8(const uint8_t* img, int N, int H, int W, void* o
 extern "C" int mi_focus_pack(const float* img, int N, int H, int W, void* out, int ldo, mi_stream_t st) {
   MI_REQUIRE(img && out && H % 2 == 0 && W % 2 == 0 && ldo % 8 == 0 && ldo >= 16, "focus_pack: args");
   const int64_t total = (int64_t)N * (H / 2) * (W / 2);
+  MI_REQUIRE(total < (1LL << 31) - (1 << 24), "focus_pack: %lld output pixels exceed the 32-bit index", (long long)total);
   if (((uintptr_t)img & 7) == 0)
     hipLaunchKernelGGL(focus_pack4_kernel<float>, dim3(ew_blocks((total + 3) / 4)), dim3(256), 0, (hipStream_t)st, img, N, H,
                        W, (__bf16*)out, ldo);
