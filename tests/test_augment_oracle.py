@@ -145,3 +145,39 @@ def test_mixup_properties():
     out4, _ = A.mixup(origin, ol, img, cl, dim, 0.5, False, (0, 0))
     assert np.array_equal(out4[200:, 250:], (0.5 * origin[200:, 250:].astype(np.float32)).astype(np.uint8))
     assert A.mixup_offsets_range(img.shape[:2], dim, 0.5, origin.shape[:2]) == (None, None)
+
+
+def test_host_mirror_label_logic_matches_oracle():
+    """yolov7_d2_amd.data_pipeline's host side (the random draws in the reference's order, mosaic placement, the combined
+    matrix, label warp / filter, the matrix inversion handed to the warp kernel, mixup labels) against the oracle, which is
+    pinned to the reference's own random_perspective - no device needed"""
+    from yolov7_d2_amd.data_pipeline import GpuMosaicMapper
+    mp = GpuMosaicMapper.__new__(GpuMosaicMapper)
+    mp.cfg = dict(A.MOSAIC_DEFAULTS, MSCALE=[0.5, 1.5], NUM_IMAGES=4, PERSPECTIVE=0.0)
+    for seed in range(6):
+        p = mp.draw(np.random.RandomState(seed), random.Random(100 + seed))
+        dim, yc, xc, draws = A.draw_mosaic_params(np.random.RandomState(seed), random.Random(100 + seed), A.MOSAIC_DEFAULTS)
+        assert (p["input_dim"], p["yc"], p["xc"], p["draws"]) == (dim, yc, xc, draws)
+        for i in range(4):
+            w, h = 300 + 37 * i + seed, 280 + 11 * i
+            (a, _b) = A.mosaic_placement(i, w, h, xc, yc, dim)
+            got_a, got_b = mp._placement(i, w, h, xc, yc, dim)
+            assert got_a == a and got_b == _b[:2]
+        border = [-dim[0] // 2, -dim[1] // 2]
+        M, width, height = mp._matrix((2 * dim[0], 2 * dim[1]), draws, border)
+        Mr, wr, hr = A.perspective_matrix((2 * dim[0], 2 * dim[1]), draws, border)
+        assert np.array_equal(M, Mr) and (width, height) == (wr, hr)
+        assert np.array_equal(np.array(mp._invert(M)).reshape(2, 3), A.invert_affine(M[:2]))
+        _, t = _case(200 + seed, n=15, hw=(2 * dim[0], 2 * dim[1]))
+        assert np.array_equal(mp._warp_labels(t.copy(), M, draws[1], width, height), A.perspective_labels(t.copy(), Mr, draws[1], wr, hr))
+    # mixup labels: same boxes, same filter, same stacking as the oracle's mixup on a dummy image pair
+    rs = np.random.RandomState(3)
+    origin = np.zeros((300, 360, 3), np.uint8)
+    img = rs.randint(0, 256, (240, 320, 3), dtype=np.uint8)
+    ol = np.array([[10.0, 20, 100, 200, 3]])
+    cl = np.array([[30.0, 40, 200, 220, 7], [0.0, 0, 3, 3, 9], [100.0, 100, 310, 230, 1]])
+    for jit, flip, off in ((1.0, False, (0, 0)), (1.4, True, (17, 5)), (0.6, True, (0, 0))):
+        _, ref = A.mixup(origin, ol, img, cl, (300, 360), jit, flip, off)
+        r, _, (ow, oh) = A.mixup_geometry(img.shape[:2], (300, 360), jit)
+        got, blended = mp._mixup_labels(ol.copy(), cl, r, jit, flip, off[0], off[1], (oh, ow), (300, 360))
+        assert np.array_equal(got, ref) and blended == (len(ref) > 1)
