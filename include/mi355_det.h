@@ -107,9 +107,20 @@ typedef struct mi_conv_group {
   int32_t njobs, nblocks, lds_bytes;
   int32_t KC, BN, TPIX, TPS, EPI;
   int64_t starts_off, table_bytes;
+  int64_t priv[96];         /* KC == -1: the jobs are 1x1 convolutions of one input and run as ONE streaming launch
+                               (mi_conv1x1_stream); its launch record lives here, no device table is read */
 } mi_conv_group;
 int mi_conv2d_group_plan(const mi_conv_desc* descs, int n, void* table_host, int64_t table_cap, mi_conv_group* meta);
 int mi_conv2d_group_run(const mi_conv_group* meta, const void* table_dev, mi_stream_t s);
+
+/* streaming 1x1 convolution (csrc/conv1x1_stream.h): n >= 1 bf16 1x1 stride-1 convolutions that read the SAME input
+ * view (x, ldx, N, H, W, K8 equal; K in {32, 64, 128, 256, 512}; Cout == CoutPad, a multiple of 32; no bias; all with
+ * stats_acc, all with MI_CONV_ACCUM, or all plain) as one persistent launch: weights stay in registers, the input is
+ * read once, BatchNorm statistics leave as one set of atomics per block.  Replaces the 1x1 nn.Conv2d forward / data
+ * gradient of CSPLayer / Bottleneck / SPP / head stems (layers/wrappers.py:60-83,150-197).  mi_conv2d and
+ * mi_conv2d_group_plan take this path by themselves for eligible descriptors (MI_CONV_STREAM=0 disables that);
+ * this entry returns MI_EINVAL instead of falling back. */
+int mi_conv1x1_stream(const mi_conv_desc* descs, int n, mi_stream_t s);
 
 /* weight gradient: g[co][ci][tap] (fp32 OIHW, the nn.Parameter gradient layout; overwritten, or += if
  * `accumulate`) = sum_pixels dy[p][co] * x[p*stride + tap][ci].  replaces conv wgrad of the same modules.

@@ -1,0 +1,290 @@
+// Streaming 1x1 convolution for gfx950: persistent blocks, weights stationary in registers.
+//
+// Replaces the 1x1 nn.Conv2d forward / data gradient of BaseConv (yolov7/modeling/backbone/layers/wrappers.py:60-83:
+// CSPLayer conv1 / conv2 / conv3, Bottleneck conv1, SPP / lateral / reduce convs, the head stems of
+// yolov7/modeling/head/yolox_head.py:60-72) for K <= 512 input channels.  These layers are HBM-bound (~60 FLOP/B,
+// SURVEY 8d) and the tile-per-block implicit-GEMM kernel spent its time on everything but memory: every block
+// re-loaded the whole weight matrix into LDS (as many bytes as its pixel tile), staged its output through LDS behind
+// two barriers and paid 2 x BN fp64 atomics for the BatchNorm statistics of 128 pixels.  Here
+//   * a block is persistent: it walks pixel tiles t = b, b + nb, ... of the flat [N*H*W][K] activation;
+//   * each wave keeps the A fragments (32 output channels x all K) of ITS 32-channel slice in VGPRs for the whole
+//     launch - loaded once, straight from the packed weight image, no LDS;
+//   * the x tile goes HBM -> LDS by LDS-DMA into an NBUF-deep ring, NBUF - 1 tiles ahead, behind COUNTED vmcnt waits
+//     (one s_barrier per tile); 16-byte chunks are XOR-permuted on the source address so that the ds_read_b128 of the
+//     B fragments is conflict-free;
+//   * the epilogue never touches LDS: accumulators -> bf16 -> v_permlane32_swap pairs -> one 16-byte store per lane
+//     and 16 channels (cdna guide T21), fire and forget;
+//   * BatchNorm (sum, sumsq) of the stored (bf16-rounded) values accumulate in registers over ALL tiles of the block
+//     and leave as one set of fp64 atomics per block (256-512 blocks instead of thousands);
+//   * a slice table gives every 32-channel slice its own weight image / output view / statistics: the two 1x1 convs
+//     of a CSP layer that read the same tensor are ONE launch that reads it once.
+// MODE 0: plain store; 1: + BatchNorm statistics; 2: y += result (gradient fan-in; the old values are requested a
+// tile's compute ahead of their use and waited for with a counted vmcnt).
+#pragma once
+#include "common.h"
+
+#define C1_MAX_SLICES 16
+struct C1Slice {
+  const u32x4* w;   // first row of the slice in the packed image: row(k8, co) = k8 * wld + co (16-byte rows)
+  __bf16* y;        // first output channel of the slice, pixel 0
+  double* stats;    // fp64 accumulators of the slice's first channel, slot 0 ([slot][sld / 2][2]); MODE 1 only
+  int wld, ldy, sld, nslots;
+};
+struct C1K {
+  const __bf16* x;
+  int ldx, ntiles, nco, nb;   // nb: blocks per cout tile (grid = nb * nco)
+  int xcd_order, dbg;         // dbg & 1: skip the statistics atomics (timing experiments only).  xcd_order 1: block id = cot * nb + b (cout tiles of a pixel tile share an XCD), 0: b * nco + cot
+  C1Slice s[C1_MAX_SLICES];
+};
+struct C1Launch {
+  int K, WM, PT, NBUF, MODE, grid, lds;
+  C1K k;
+};
+
+#define C1_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+static __device__ uint4 g_c1_zero_page[4];
+
+// LDS-DMA, 16 bytes per lane: LDS[lds_off + lane * 16 ..) = *(sbase + voff); sbase / lds_off wave-uniform.
+// (s_nop 4: an SGPR base that was produced by v_readfirstlane needs 5 wait states before a VMEM instruction reads it;
+//  the same pad covers the M0 write)
+__device__ __forceinline__ void c1_glds16(const void* sbase, unsigned voff, unsigned lds_off) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase),
+               "s"(lds_off)
+               : "memory");
+}
+
+template <int K, int WM, int WN, int PT, int NBUF, int MODE>
+__global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
+  constexpr int NW = WM * WN, TPIX = WN * PT * 32, KC8 = K / 8, KS = K / 16, R = K * 2;
+  constexpr int XB = TPIX * R;              // bytes of one x tile
+  constexpr int D = XB / (1024 * NW);       // LDS-DMA instructions per wave and tile
+  static_assert(D >= 1 && XB % (1024 * NW) == 0, "tile / DMA split");
+  constexpr int RPI = KC8 >= 64 ? 1 : 64 / KC8;              // pixel rows per DMA instruction
+  constexpr int RBSH = K >= 128 ? 0 : (K == 64 ? 1 : 2);     // log2(pixel rows per 256-byte bank row)
+  constexpr int SWM = KC8 - 1 < 15 ? KC8 - 1 : 15;           // swizzle mask (16-byte slots of a bank row)
+  constexpr int S = 2 * PT;                                  // 16-byte stores per wave and tile
+  constexpr int L = MODE == 2 ? 2 * PT : 0;                  // old-value loads per wave and tile
+  // VMEM operations newer than tile i's DMA when iteration i waits for it (queue per iteration: OLD, DMA, ST)
+  constexpr int W0 = (NBUF - 2) * D + L;
+  constexpr int W1 = NBUF > 2 ? (NBUF - 2) * D + (S + L) + L : (S + L);
+  constexpr int W2 = NBUF > 3 ? (NBUF - 2) * D + 2 * (S + L) + L : (NBUF - 2) * D + (NBUF - 1) * (S + L);
+  constexpr int W3 = (NBUF - 2) * D + (NBUF - 1) * (S + L);
+  static_assert(W3 < 64 && W2 < 64, "vmcnt field");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int nb = p.nb;
+  const int cot = p.xcd_order ? (int)blockIdx.x / nb : (int)blockIdx.x % p.nco;
+  const int b = p.xcd_order ? (int)blockIdx.x % nb : (int)blockIdx.x / p.nco;
+  const int nt = (p.ntiles - b + nb - 1) / nb;   // tiles of this block (>= 1: nb <= ntiles)
+  const C1Slice sl = p.s[cot * WM + wm];
+
+  // ---- this wave's weights: A fragments of 32 output channels x K, resident for the whole launch
+  bf16x8 a[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) a[ks] = __builtin_bit_cast(bf16x8, sl.w[(size_t)(ks * 2 + h) * sl.wld + l31]);
+
+  // ---- per-lane source offsets of this wave's D DMA instructions (relative to the tile's first pixel)
+  const int ldxb = p.ldx * 2;
+  unsigned doff[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const int q = wave * D + d;
+    const int row = q * RPI + (KC8 >= 64 ? 0 : lane / KC8);
+    const int c = KC8 >= 64 ? lane : lane % KC8;
+    doff[d] = (unsigned)(row * ldxb + ((c ^ ((row >> RBSH) & SWM)) << 4));
+  }
+  const size_t xtile = (size_t)TPIX * (size_t)ldxb;
+  auto issue_x = [&](int i, int buf) {
+    // tile i of this block; past the last tile the same number of DMAs is issued from a 16-byte zero page (one cache
+    // line for the whole wave), so that the counted waits keep their meaning
+    const bool live = i < nt;
+    const char* xt = live ? (const char*)p.x + (size_t)(b + i * nb) * xtile : (const char*)g_c1_zero_page;
+#pragma unroll
+    for (int d = 0; d < D; ++d) c1_glds16(xt, live ? doff[d] : 0u, lds0 + buf * XB + (wave * D + d) * 1024);
+  };
+
+  // ---- B fragment addresses: pixel row r, 16-byte slot (ks * 2 + h) ^ swz(r) = (ks * 2) ^ (h ^ swz(r))
+  unsigned brow[PT], bsw[PT];
+#pragma unroll
+  for (int j = 0; j < PT; ++j) {
+    const int r = (wn * PT + j) * 32 + l31;
+    brow[j] = (unsigned)(r * R);
+    bsw[j] = (unsigned)((h ^ ((r >> RBSH) & SWM)) << 4);
+  }
+  // ---- output: lane (l31, h) owns pixel r, bytes [h * 16, h * 16 + 16) of each 32-byte channel group pair
+  const int ldyb = sl.ldy * 2;
+  unsigned yoff[PT];
+#pragma unroll
+  for (int j = 0; j < PT; ++j) yoff[j] = (unsigned)(((wn * PT + j) * 32 + l31) * ldyb + h * 16);
+  const size_t ytile = (size_t)TPIX * (size_t)ldyb;
+
+  float s1[16], s2[16];
+  if constexpr (MODE == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s1[r] = s2[r] = 0.f;
+  }
+
+#pragma unroll
+  for (int i = 0; i < NBUF - 1; ++i) issue_x(i, i);
+
+  int buf = 0, nbuf = NBUF - 1;   // ring slots of tile i / tile i + NBUF - 1
+  for (int i = 0; i < nt; ++i) {
+    char* const yt = (char*)sl.y + (size_t)(b + i * nb) * ytile;
+    u32x4 old[2 * PT];
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int j = 0; j < PT; ++j) {
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(old[j * 2]) : "v"(yoff[j]), "s"(yt) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=v"(old[j * 2 + 1]) : "v"(yoff[j]), "s"(yt) : "memory");
+      }
+    }
+    if (i == 0) C1_VMCNT(W0);
+    else if (i == 1) C1_VMCNT(W1);
+    else if (i == 2) C1_VMCNT(W2);
+    else C1_VMCNT(W3);
+    __builtin_amdgcn_s_barrier();   // tile i landed (every wave's share); slot nbuf is no longer read by anyone
+    issue_x(i + NBUF - 1, nbuf);
+
+    f32x16 acc[PT];
+#pragma unroll
+    for (int j = 0; j < PT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const char* Xs = smem + buf * XB;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 bf[PT];
+#pragma unroll
+      for (int j = 0; j < PT; ++j) bf[j] = __builtin_bit_cast(bf16x8, *(const u32x4*)(Xs + brow[j] + ((unsigned)(ks * 32) ^ bsw[j])));
+#pragma unroll
+      for (int j = 0; j < PT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], bf[j], acc[j], 0, 0, 0);
+    }
+
+    if constexpr (MODE == 2) {
+      // the old values were requested before this tile's DMA: D newer operations may stay in flight
+      if constexpr (PT == 1)
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(old[0]), "+v"(old[1]) : "n"(D) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]) : "n"(D) : "memory");
+    }
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+      unsigned pk[8];   // [q][2 dwords]: channels 8q + 4h + (0..3) of this lane's pixel
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (__bf16)acc[j][4 * q + e];
+        if constexpr (MODE == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float f = (float)o[e];
+            s1[4 * q + e] += f;
+            s2[4 * q + e] = __builtin_fmaf(f, f, s2[4 * q + e]);
+          }
+        }
+        const u32x2 u = __builtin_bit_cast(u32x2, o);
+        pk[2 * q] = u[0];
+        pk[2 * q + 1] = u[1];
+      }
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        // lanes 0-31 end up with channels 16 pr + 0..7 (own 4 | upper half's 4), lanes 32-63 with 16 pr + 8..15
+        const int q0 = 2 * pr, q1 = 2 * pr + 1;
+        const auto w0 = __builtin_amdgcn_permlane32_swap(pk[2 * q0], pk[2 * q1], false, false);
+        const auto w1 = __builtin_amdgcn_permlane32_swap(pk[2 * q0 + 1], pk[2 * q1 + 1], false, false);
+        u32x4 v = {w0[0], w1[0], w0[1], w1[1]};
+        if constexpr (MODE == 2) {
+          // same double rounding as the tile kernel's accumulate path: bf16(result), then bf16(that + old)
+          const bf16x8 nv = __builtin_bit_cast(bf16x8, v), ov = __builtin_bit_cast(bf16x8, old[j * 2 + pr]);
+          bf16x8 rv;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) rv[e] = (__bf16)((float)nv[e] + (float)ov[e]);
+          v = __builtin_bit_cast(u32x4, rv);
+        }
+        *(u32x4*)(yt + yoff[j] + pr * 32) = v;
+      }
+    }
+    buf = buf + 1 == NBUF ? 0 : buf + 1;
+    nbuf = nbuf + 1 == NBUF ? 0 : nbuf + 1;
+  }
+
+  C1_VMCNT(0);   // the tail DMAs still target this block's LDS
+  if constexpr (MODE == 1) {
+    // one set of atomics per block: lanes fold over their 32 pixels, waves over the WN pixel groups through LDS
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s1[r] += __shfl_xor(s1[r], off, 64);
+        s2[r] += __shfl_xor(s2[r], off, 64);
+      }
+    __syncthreads();
+    float* red = (float*)smem;   // [WN][WM * 32][2]
+    if (l31 == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = wm * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        red[(wn * WM * 32 + c) * 2 + 0] = s1[r];
+        red[(wn * WM * 32 + c) * 2 + 1] = s2[r];
+      }
+    }
+    __syncthreads();
+    if (wave < WM && lane < 32) {
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < WN; ++q) {
+        a1 += red[(q * WM * 32 + wave * 32 + lane) * 2 + 0];
+        a2 += red[(q * WM * 32 + wave * 32 + lane) * 2 + 1];
+      }
+      const C1Slice so = p.s[cot * WM + wave];
+      double* sp = so.stats + (size_t)((int)blockIdx.x % so.nslots) * so.sld + lane * 2;
+      if (!(p.dbg & 1)) {
+        atomicAdd(sp, (double)a1);
+        atomicAdd(sp + 1, (double)a2);
+      }
+    }
+  }
+}
+
+template <int K, int WM, int WN, int PT, int NBUF, int MODE>
+static int c1s_launch_one(const C1Launch& l, hipStream_t s) {
+  auto fn = c1s_kernel<K, WM, WN, PT, NBUF, MODE>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(fn, dim3((unsigned)l.grid), dim3(WM * WN * 64), (size_t)l.lds, s, l.k);
+  MI_CHECK_LAUNCH("conv1x1_stream");
+  return MI_OK;
+}
+
+// ring depth by tile bytes: >= 48 KB of loads in flight per CU (HBM latency x per-CU share of the bandwidth)
+constexpr int c1s_nbuf(int K, int tpix) { return tpix * K * 2 >= 65536 ? 2 : (tpix * K * 2 >= 32768 ? 3 : 4); }
+
+// a (K, pixel tile) pair has a kernel when the tile splits into whole 1 KB DMA instructions per wave and the ring fits LDS
+constexpr bool c1s_valid(int K, int tpix) {
+  return (tpix * K * 2) % 8192 == 0 && tpix * K * 2 * c1s_nbuf(K, tpix) <= 160 * 1024;
+}
+
+template <int K, int MODE>
+static int c1s_launch_k(const C1Launch& l, hipStream_t s) {
+  if constexpr (c1s_valid(K, 128)) {
+    if (l.WM == 4 && l.PT == 2) return c1s_launch_one<K, 4, 2, 2, c1s_nbuf(K, 128), MODE>(l, s);
+    if (l.WM == 2 && l.PT == 1) return c1s_launch_one<K, 2, 4, 1, c1s_nbuf(K, 128), MODE>(l, s);
+  }
+  if constexpr (c1s_valid(K, 64)) {
+    if (l.WM == 4 && l.PT == 1) return c1s_launch_one<K, 4, 2, 1, c1s_nbuf(K, 64), MODE>(l, s);
+  }
+  if constexpr (c1s_valid(K, 256)) {
+    if (l.WM == 1 && l.PT == 1) return c1s_launch_one<K, 1, 8, 1, c1s_nbuf(K, 256), MODE>(l, s);
+  }
+  MI_FAIL(MI_EINVAL, "conv1x1_stream: no kernel for K %d WM %d PT %d", K, l.WM, l.PT);
+}

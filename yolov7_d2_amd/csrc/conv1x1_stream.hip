@@ -1,0 +1,142 @@
+// Host side of the streaming 1x1 convolution (conv1x1_stream.h): eligibility, slice table, launch configuration.
+// mi_conv2d / mi_conv2d_group_plan route eligible descriptors here (MI_CONV_STREAM=0 keeps everything on the tile kernel);
+// mi_conv1x1_stream is the explicit entry (it fails instead of falling back).
+#include <stdlib.h>
+#include <string.h>
+#include "common.h"
+#include "conv1x1_stream.h"
+
+int c1s_launch_mode0(const C1Launch& l, hipStream_t s);
+int c1s_launch_mode1(const C1Launch& l, hipStream_t s);
+int c1s_launch_mode2(const C1Launch& l, hipStream_t s);
+
+static int c1s_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+// what the kernel cannot do stays on the tile kernel: taps, strides, fp32 outputs, bias, ragged channel counts
+static bool c1s_desc_ok(const mi_conv_desc* d) {
+  const int K = d->K8 * 8;
+  if (d->ntaps != 1 || d->tap_dy[0] != 0 || d->tap_dx[0] != 0) return false;
+  if (d->in_stride != 1 || d->out_stride != 1 || d->out_oy || d->out_ox) return false;
+  if (d->gridH != d->outH || d->gridW != d->outW || d->outH != d->H || d->outW != d->W) return false;
+  if (d->flags & ~MI_CONV_ACCUM) return false;
+  if (d->bias) return false;
+  if (!(K == 32 || K == 64 || K == 128 || K == 256 || K == 512)) return false;
+  if (d->Cout != d->CoutPad || d->Cout % 32) return false;
+  if (d->ldx % 8 || d->ldy % 8 || ((uintptr_t)d->x & 15) || ((uintptr_t)d->y & 15) || ((uintptr_t)d->w & 15)) return false;
+  const long long npix = (long long)d->N * d->H * d->W;
+  if (d->y_nstride && (long long)d->y_nstride != (long long)d->outH * d->outW * d->ldy) return false;
+  if (npix * d->ldx * 2 >= (1LL << 31) || npix * d->ldy * 2 >= (1LL << 31)) return false;
+  if ((d->flags & MI_CONV_ACCUM) && d->stats_acc) return false;
+  return true;
+}
+
+// n descriptors that read the same tensor -> one launch; returns false when the stream kernel does not apply
+static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l) {
+  if (n < 1) return false;
+  const mi_conv_desc& d0 = ds[0];
+  int ns = 0;
+  for (int j = 0; j < n; ++j) {
+    const mi_conv_desc& d = ds[j];
+    if (!c1s_desc_ok(&d)) return false;
+    if (d.x != d0.x || d.ldx != d0.ldx || d.N != d0.N || d.H != d0.H || d.W != d0.W || d.K8 != d0.K8) return false;
+    if ((d.flags & MI_CONV_ACCUM) != (d0.flags & MI_CONV_ACCUM) || (d.stats_acc != nullptr) != (d0.stats_acc != nullptr)) return false;
+    ns += d.Cout / 32;
+  }
+  if (ns > C1_MAX_SLICES) return false;
+  const int K = d0.K8 * 8;
+  const long long npix = (long long)d0.N * d0.H * d0.W;
+  const int WM = ns % 4 == 0 ? 4 : (ns % 2 == 0 ? 2 : 1);
+  const int nco = ns / WM;
+  // pixel tile: 128 (WM 4 / 2), 256 (WM 1); WM = 4 falls to 64 pixels when the ring would not fit LDS, when the map is
+  // small (the chip wants >= ~2 tiles per CU in flight) or when the pixel count asks for it
+  int PT = 1, tpix = WM == 4 ? 128 : (WM == 2 ? 128 : 256);
+  if (WM == 4) {
+    PT = 2;
+    const bool fits = c1s_valid(K, 128), small = (npix / 128) * nco < 2 * c1s_cus();
+    if (!fits || npix % 128 || (small && c1s_valid(K, 64))) { PT = 1; tpix = 64; }
+  }
+  if (!c1s_valid(K, tpix) || npix % tpix) return false;
+  memset(l, 0, sizeof(*l));
+  l->K = K; l->WM = WM; l->PT = PT; l->NBUF = c1s_nbuf(K, tpix);
+  l->MODE = (d0.flags & MI_CONV_ACCUM) ? 2 : (d0.stats_acc ? 1 : 0);
+  l->lds = l->NBUF * tpix * K * 2;
+  C1K& k = l->k;
+  k.x = (const __bf16*)d0.x;
+  k.ldx = d0.ldx;
+  k.ntiles = (int)(npix / tpix);
+  k.nco = nco;
+  // persistent grid: as many blocks as are resident at once (LDS-limited, at most 2 per CU), never more than tiles
+  int per_cu = (160 * 1024) / l->lds;
+  if (per_cu > 2) per_cu = 2;
+  if (per_cu < 1) per_cu = 1;
+  static const int ovr = getenv("MI_C1S_PERCU") ? atoi(getenv("MI_C1S_PERCU")) : 0;
+  if (ovr > 0) per_cu = ovr;
+  int nb = (c1s_cus() * per_cu) / nco;
+  if (nb > k.ntiles) nb = k.ntiles;
+  if (nb < 1) nb = 1;
+  if (nco > 1 && nb >= 8) nb &= ~7;   // cot * nb + b: the cout tiles of a pixel tile meet in one XCD's L2
+  k.nb = nb;
+  k.xcd_order = (nco > 1 && nb % 8 == 0) ? 1 : 0;
+  l->grid = nb * nco;
+  static const int dbg = getenv("MI_DEBUG_NOATOM") ? atoi(getenv("MI_DEBUG_NOATOM")) : 0;
+  k.dbg = dbg;
+  int si = 0;
+  for (int j = 0; j < n; ++j) {
+    const mi_conv_desc& d = ds[j];
+    const int nsl = (d.stats_slots >= 1 && d.stats_slots <= MI_BN_SLOTS) ? d.stats_slots : MI_BN_SLOTS;
+    for (int c = 0; c < d.Cout; c += 32, ++si) {
+      C1Slice& s = k.s[si];
+      s.w = (const u32x4*)d.w + c;
+      s.wld = d.CoutPad;
+      s.y = (__bf16*)d.y + c;
+      s.ldy = d.ldy;
+      s.stats = d.stats_acc ? d.stats_acc + (size_t)c * 2 : nullptr;
+      s.sld = d.CoutPad * 2;
+      s.nslots = nsl;
+    }
+  }
+  return true;
+}
+
+static int c1s_run(const C1Launch& l, hipStream_t s) {
+  switch (l.MODE) {
+    case 0: return c1s_launch_mode0(l, s);
+    case 1: return c1s_launch_mode1(l, s);
+    default: return c1s_launch_mode2(l, s);
+  }
+}
+
+// 0: off, 1: on (default).  Read per call: the tests flip it inside one process.
+static bool c1s_enabled() {
+  const char* e = getenv("MI_CONV_STREAM");
+  return !e || atoi(e) != 0;
+}
+
+// internal entry points for conv_igemm.hip
+bool c1s_try_launch(const mi_conv_desc* ds, int n, hipStream_t s, int* rc) {
+  if (!c1s_enabled()) return false;
+  C1Launch l;
+  if (!c1s_fill(ds, n, &l)) return false;
+  *rc = c1s_run(l, s);
+  return true;
+}
+bool c1s_try_plan(const mi_conv_desc* ds, int n, C1Launch* l) { return c1s_enabled() && c1s_fill(ds, n, l); }
+int c1s_run_planned(const C1Launch* l, hipStream_t s) { return c1s_run(*l, s); }
+
+extern "C" int mi_conv1x1_stream(const mi_conv_desc* descs, int n, mi_stream_t st) {
+  MI_REQUIRE(descs && n >= 1, "conv1x1_stream: null");
+  C1Launch l;
+  MI_REQUIRE(c1s_fill(descs, n, &l),
+             "conv1x1_stream: needs 1x1 stride-1 bf16 convs of one input with K in {32..512}, Cout %% 32 == 0, no bias, "
+             "N*H*W a multiple of the pixel tile");
+  return c1s_run(l, (hipStream_t)st);
+}

@@ -28,6 +28,13 @@
 #include <string.h>
 #include "common.h"
 #include "conv_igemm_kernel.h"
+#include "conv1x1_stream.h"
+
+// streaming 1x1 path (conv1x1_stream.hip): eligible descriptors leave the tile kernel
+bool c1s_try_launch(const mi_conv_desc* ds, int n, hipStream_t s, int* rc);
+bool c1s_try_plan(const mi_conv_desc* ds, int n, C1Launch* l);
+int c1s_run_planned(const C1Launch* l, hipStream_t s);
+static_assert(sizeof(C1Launch) <= sizeof(((mi_conv_group*)0)->priv), "mi_conv_group.priv holds the stream launch record");
 
 #define MI_DECL_KC(KCv)                                                                      \
   int conv_launch_kc##KCv(const ConvK& k, int BN, int TPIX, size_t lds, hipStream_t s);       \
@@ -100,6 +107,10 @@ static int conv_fill(const mi_conv_desc* d, ConvK* k, ConvCfg* c, size_t* ldsByt
     if (d->tap_dx[t] > dxmax) dxmax = d->tap_dx[t];
   }
   k->flags = d->flags;
+  {
+    static const int noatom = getenv("MI_DEBUG_NOATOM") ? atoi(getenv("MI_DEBUG_NOATOM")) : 0;
+    if (noatom) k->flags |= 1024;
+  }
   if (d->flags & MI_CONV_BNBWD) {
     MI_REQUIRE(d->stats_acc && d->bn_y && d->bn_scale && d->bn_shift && d->bn_mean && d->bn_invstd,
                "conv: MI_CONV_BNBWD needs stats_acc and the producing layer's bn_* arrays");
@@ -237,6 +248,10 @@ extern "C" int mi_conv2d_plan(mi_conv_desc* d) {
 }
 
 extern "C" int mi_conv2d(const mi_conv_desc* d, mi_stream_t st) {
+  {
+    int rc = MI_OK;
+    if (d && c1s_try_launch(d, 1, (hipStream_t)st, &rc)) return rc;
+  }
   ConvK k;
   ConvCfg c;
   size_t lds;
@@ -268,6 +283,22 @@ extern "C" int mi_conv2d(const mi_conv_desc* d, mi_stream_t st) {
 extern "C" int mi_conv2d_group_plan(const mi_conv_desc* descs, int n, void* table_host, int64_t table_cap,
                                     mi_conv_group* meta) {
   MI_REQUIRE(descs && meta && n >= 1 && n <= MI_CONV_MAX_GROUP, "conv_group_plan: 1..%d jobs", MI_CONV_MAX_GROUP);
+  {
+    // 1x1 convolutions of ONE input tensor (CSP conv1 + conv2): a single streaming launch that reads it once
+    C1Launch cl;
+    if (c1s_try_plan(descs, n, &cl)) {
+      memset(meta, 0, sizeof(*meta));
+      meta->njobs = n; meta->nblocks = cl.grid; meta->lds_bytes = cl.lds;
+      meta->KC = -1; meta->BN = cl.WM * 32; meta->TPIX = cl.PT; meta->TPS = cl.NBUF; meta->EPI = cl.MODE;
+      meta->starts_off = 0; meta->table_bytes = 16;   // no device table: the launch record travels in meta->priv
+      memcpy(meta->priv, &cl, sizeof(cl));
+      if (table_host) {
+        MI_REQUIRE(table_cap >= meta->table_bytes, "conv_group_plan: table too small");
+        memset(table_host, 0, (size_t)meta->table_bytes);
+      }
+      return MI_OK;
+    }
+  }
   // the job with the most output pixels picks the configuration; the others are forced onto its template
   int big = 0;
   for (int j = 1; j < n; ++j)
@@ -354,6 +385,7 @@ extern "C" int mi_conv2d_group_plan(const mi_conv_desc* descs, int n, void* tabl
 
 extern "C" int mi_conv2d_group_run(const mi_conv_group* m, const void* table_dev, mi_stream_t st) {
   MI_REQUIRE(m && table_dev && m->njobs >= 1, "conv_group_run: null");
+  if (m->KC == -1) return c1s_run_planned((const C1Launch*)m->priv, (hipStream_t)st);
   const ConvK* jobs = (const ConvK*)table_dev;
   const int* starts = (const int*)((const char*)table_dev + m->starts_off);
   hipStream_t s = (hipStream_t)st;
