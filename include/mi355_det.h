@@ -107,8 +107,9 @@ typedef struct mi_conv_group {
   int32_t njobs, nblocks, lds_bytes;
   int32_t KC, BN, TPIX, TPS, EPI;
   int64_t starts_off, table_bytes;
-  int64_t priv[96];         /* KC == -1: the jobs are 1x1 convolutions of one input and run as ONE streaming launch
-                               (mi_conv1x1_stream); its launch record lives here, no device table is read */
+  int64_t priv[136];        /* KC == -1: the jobs are 1x1 convolutions of one input and run as ONE streaming launch
+                               (mi_conv1x1_stream); KC == -2: 3x3 K -> K convolutions as ONE weight-stationary launch
+                               (mi_conv3x3_ws); the launch record lives here, no device table is read */
 } mi_conv_group;
 int mi_conv2d_group_plan(const mi_conv_desc* descs, int n, void* table_host, int64_t table_cap, mi_conv_group* meta);
 int mi_conv2d_group_run(const mi_conv_group* meta, const void* table_dev, mi_stream_t s);
@@ -121,6 +122,15 @@ int mi_conv2d_group_run(const mi_conv_group* meta, const void* table_dev, mi_str
  * mi_conv2d_group_plan take this path by themselves for eligible descriptors (MI_CONV_STREAM=0 disables that);
  * this entry returns MI_EINVAL instead of falling back. */
 int mi_conv1x1_stream(const mi_conv_desc* descs, int n, mi_stream_t s);
+
+/* weight-stationary 3x3 convolution (csrc/conv3x3_ws.h): 1..8 bf16 3x3 stride-1 convolutions with Cin == Cout == K in
+ * {32, 64, 128} (the same K for all; their own tensors and shapes), no bias, all plain / all with stats_acc / all
+ * MI_CONV_ACCUM, as ONE launch of persistent blocks: each wave keeps its 32 output channels x 9 taps x K of weights in
+ * registers, only the input halo tiles move (LDS-DMA, double-buffered).  Forward and data gradient (any tap order) of
+ * Bottleneck conv2 and of the YOLOXHead cls / reg towers (layers/wrappers.py:105-123, head/yolox_head.py:73-102).
+ * mi_conv2d and mi_conv2d_group_plan take this path by themselves (MI_CONV_WS=0 disables that); this entry returns
+ * MI_EINVAL instead of falling back. */
+int mi_conv3x3_ws(const mi_conv_desc* descs, int n, mi_stream_t s);
 
 /* weight gradient: g[co][ci][tap] (fp32 OIHW, the nn.Parameter gradient layout; overwritten, or += if
  * `accumulate`) = sum_pixels dy[p][co] * x[p*stride + tap][ci].  replaces conv wgrad of the same modules.

@@ -87,10 +87,35 @@ def test_conv_launcher_configurations_are_valid():
     assert lib.mi_conv2d_plan(C.byref(bad)) < 0 and b"KC" in lib.mi_last_error()
 
 
-def test_conv_group_planner_host_side():
-    """mi_conv2d_group_plan (no GPU): the head's three 3x3 level convs share one configuration, the smaller maps get tile
-    shapes inside the leading job's LDS footprint, block ranges are contiguous; jobs that cannot share a configuration
-    or mix accumulate / plain launches are refused"""
+def test_ws_and_stream_group_plans_host_side():
+    """mi_conv2d_group_plan (no GPU) hands 3x3 K -> K jobs to the weight-stationary kernel (KC == -2: one persistent
+    block per CU shared between the jobs in proportion to their tiles, 96 KB halo ring) and 1x1 jobs of ONE input to the
+    streaming kernel (KC == -1); MI_CONV_WS=0 / MI_CONV_STREAM=0 and ineligible shapes fall back to the tile planner"""
+    lib = L.lib()
+    descs = (L.mi_conv_desc * 3)()
+    tiles = 0
+    for d, hw in zip(descs, (80, 40, 20)):
+        C.memmove(C.byref(d), C.byref(_conv_desc(hw, hw, 128, 128, 9)), C.sizeof(L.mi_conv_desc))
+        tiles += d.N * -(-hw // 8) * -(-hw // 16)
+    meta = L.mi_conv_group()
+    assert lib.mi_conv2d_group_plan(descs, 3, None, 0, C.byref(meta)) == 0, lib.mi_last_error()
+    assert meta.KC == -2 and meta.njobs == 3 and meta.BN == 128 and meta.lds_bytes == 2 * 16 * 192 * 16
+    assert meta.nblocks == min(256, tiles)
+    descs[2].K8 = 32                                  # 256 channels: not a weight-stationary shape -> tile planner (and it
+    assert lib.mi_conv2d_group_plan(descs, 3, None, 0, C.byref(meta)) == 0 and meta.KC > 0   # shares the 128-channel config)
+    pair = (L.mi_conv_desc * 2)()
+    for d in pair:
+        C.memmove(C.byref(d), C.byref(_conv_desc(80, 80, 128, 64, 1)), C.sizeof(L.mi_conv_desc))
+    assert lib.mi_conv2d_group_plan(pair, 2, None, 0, C.byref(meta)) == 0 and meta.KC == -1 and meta.BN == 128
+    pair[1].x += 4096                                 # another input tensor: two launches' worth of work, tile planner
+    assert lib.mi_conv2d_group_plan(pair, 2, None, 0, C.byref(meta)) == 0 and meta.KC > 0
+
+
+def test_conv_group_planner_host_side(monkeypatch):
+    """mi_conv2d_group_plan (no GPU), tile kernel: the head's three 3x3 level convs share one configuration, the smaller
+    maps get tile shapes inside the leading job's LDS footprint, block ranges are contiguous; jobs that cannot share a
+    configuration or mix accumulate / plain launches are refused"""
+    monkeypatch.setenv("MI_CONV_WS", "0")
     lib = L.lib()
     descs = (L.mi_conv_desc * 3)()
     for d, hw in zip(descs, (80, 40, 20)):

@@ -368,7 +368,11 @@ def test_grouped_launches_of_the_640_plan():
         # persistent blocks with an LDS ring, one or two per CU by design) wherever N*H*W is a multiple of its pixel tile
         stream = [m.njobs for m in metas if m.KC == -1]
         assert stream == ([2] * 6 if which == "fwd" else []), (which, stream)
-        assert all(m.lds_bytes <= 80 * 1024 for m in metas if m.KC != -1)
+        # the head's 3x3 128 -> 128 towers (six jobs per launch) run on the weight-stationary kernel (KC == -2): one
+        # persistent block per CU by design
+        ws = [m.njobs for m in metas if m.KC == -2]
+        assert ws == ([6, 6] if which == "fwd" else [6, 3, 3]), (which, ws)
+        assert all(m.lds_bytes <= 80 * 1024 for m in metas if m.KC > 0)
 
 
 @pytest.mark.parametrize("depth,width", [(0.33, 0.375), (0.67, 0.75), (1.33, 1.25)], ids=["tiny", "m", "x"])

@@ -1,0 +1,369 @@
+// Weight-stationary 3x3 stride-1 convolution for gfx950 (forward and data gradient of the K -> K BaseConv layers:
+// Bottleneck conv2 of CSPDarknet / YOLOPAFPN, the cls / reg towers of YOLOXHead - yolov7/modeling/backbone/layers/
+// wrappers.py:105-123, yolov7/modeling/head/yolox_head.py:73-102).
+//
+// The tile-per-block implicit GEMM streams the whole 3x3 weight set (K*K*18 bytes: 295 KB for 128 channels) through
+// LDS for every 128-pixel tile - several times the bytes of the tile's own halo - and pays a barrier + DMA wait per
+// (k-chunk, tap group) step.  Here
+//   * blocks are persistent (one or two per CU) and each WAVE keeps the A fragments of its 32 output channels for all
+//     9 taps x K input channels in registers for the whole launch (K = 128: 288 VGPRs, one wave per SIMD);
+//   * the only thing that moves per tile is the input halo (10 x 18 pixels for an 8 x 16 tile): HBM -> LDS by LDS-DMA,
+//     double-buffered one tile ahead behind counted vmcnt waits, ONE barrier per tile;
+//   * the LDS image is [8-channel group][halo pixel][16 B] (one plane per 16-byte chunk) and the 32 pixel columns of an
+//     MFMA are handed to the lanes so that each 16-lane service group of ds_read_b128 ({0-3,12-15,20-27} /
+//     {4-11,16-19,28-31}) owns 16 CONSECUTIVE pixels of ONE tile row: every B fragment read is 256 contiguous bytes -
+//     conflict-free for every tap without a swizzle - and its address is one per-lane base + an immediate
+//     (k-step * plane + tap offset): ZERO VALU instructions per fragment (the XOR-swizzled pixel-major image of the
+//     tile kernel needs a VGPR address per (k-step, tap column, pixel group), 6.4 VALU per MFMA);
+//   * 9 x K/16 k-steps run back to back without any synchronisation (288 MFMAs per wave and tile at K = 128);
+//   * outputs: bf16 -> permlane32_swap -> 16 contiguous bytes per lane, stored during the NEXT tile's main loop; BatchNorm
+//     sums per lane, parked in LDS between tiles, one set of fp64 atomics per block.
+// A launch carries up to 8 jobs (the head's three levels x two towers run as one launch); a block belongs to one job.
+// MODE 0: plain, 1: + BatchNorm statistics, 2: y += result.
+#pragma once
+#include "common.h"
+
+#define W3_MAX_JOBS 8
+#define W3_TH 8
+#define W3_TW 16
+#define W3_HW (W3_TW + 2)              // halo width
+#define W3_HPIX ((W3_TH + 2) * W3_HW)  // 180 halo pixels
+#define W3_HROWS 192                   // padded to whole DMA instructions for every K
+
+struct W3Job {
+  const __bf16* x;
+  const u32x4* w;    // packed [tap][K/8][CoutPad][8]
+  __bf16* y;
+  double* stats;
+  int ldx, ldy, N, H, W, tilesY, tilesX, ntiles;   // ntiles = N * tilesY * tilesX
+  int blk0, nblk;                                  // this job's blocks: [blk0, blk0 + nblk)
+  int wld, nslots, sld, pad_;
+  int tw[9];                                       // weight slab of tap position t = (dy + 1) * 3 + (dx + 1)
+  int pad2_;
+};
+struct W3K {
+  int njobs, dbg;
+  W3Job j[W3_MAX_JOBS];
+};
+struct W3Launch {
+  int K, MODE, grid, lds;
+  W3K k;
+};
+
+#define W3_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+static __device__ uint4 g_w3_zero_page[4];
+
+__device__ __forceinline__ void w3_glds16(const void* g, unsigned lds_off) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_off) : "memory");
+}
+
+// A wave owns G pixel groups (32 pixels each) of the 8 x 16 tile and its 32 output channels.  The tile loop is software-
+// pipelined through the MFMA stream: while the 9 * K / 16 k-steps of tile i run, the wave issues - a few k-steps apart -
+// the LDS-DMA of tile i + 1's halo, the stores of tile i - 1's (already converted, packed) outputs and, in the accumulate
+// mode, the loads of tile i's old values.  Issued in one burst at the tile boundary, those 20-28 KB per wave run at the
+// chip's HBM rate with every CU in the same phase and the matrix pipes idle (measured: 2 + 2 us per 3.8 us tile).
+template <int K, int WM, int WN, int G, int MODE>
+__global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const W3K p) {
+  constexpr int NW = WM * WN, KC8 = K / 8, KS = K / 16;
+  static_assert(WN * G * 32 == W3_TH * W3_TW, "pixel tile");
+  constexpr int PLANE = W3_HROWS * 16;           // bytes of one 8-channel plane
+  constexpr int NQ = (W3_HROWS / 64) * KC8;      // DMA instructions per tile: (64-pixel block, plane)
+  constexpr int D = NQ / NW;                     // per wave
+  static_assert(NQ % NW == 0 && D >= 1, "DMA split");
+  constexpr int XB = KC8 * PLANE;                // bytes of one halo buffer
+  static_assert((KC8 - 1) * PLANE + (2 * W3_HW + 2) * 16 < 65536, "ds_read immediate");
+  constexpr int NS = 9 * KS, NDS = NS / 2;       // k-steps, double steps
+  static_assert(NS % 2 == 0, "k-steps come in pairs");
+  constexpr int S = 2 * G;                       // 16-byte stores (and old-value loads) per wave and tile
+  // schedule inside the main loop (double-step index): DMA d at 2 d, store s at 2 s + 1, old-value load l at 2 S + l
+  static_assert(2 * (D - 1) < NDS && 2 * S + S <= NDS, "the memory operations of a tile fit its main loop");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  int ji = 0;
+  while (ji + 1 < p.njobs && (int)blockIdx.x >= p.j[ji + 1].blk0) ++ji;
+  ji = __builtin_amdgcn_readfirstlane(ji);
+  const W3Job& jb = p.j[ji];
+  const int b = (int)blockIdx.x - jb.blk0, nb = jb.nblk;
+  const int nt = (jb.ntiles - b + nb - 1) / nb;
+  const int H = jb.H, Wd = jb.W, tpi = jb.tilesY * jb.tilesX;
+  const int ldxb = jb.ldx * 2, ldyb = jb.ldy * 2;
+
+  // ---- weights: this wave's 32 output channels x 9 taps x K, resident in registers
+  bf16x8 a[9][KS];
+  {
+    const u32x4* wb = jb.w + wm * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int slab = jb.tw[t] * KC8;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) a[t][ks] = __builtin_bit_cast(bf16x8, wb[(size_t)(slab + ks * 2 + h) * jb.wld]);
+    }
+  }
+
+  // ---- halo DMA, one instruction: q = (64-pixel block pb, plane k8): lane -> halo pixel pb * 64 + lane, 16 bytes =
+  // channels 8 k8 .. of that pixel.  The planes of one 128-byte source line are requested by consecutive instructions of
+  // one wave (the first misses, the others hit the CU's L1).  Geometry recomputed per instruction (~10 VALU per 1 KB).
+  struct Org { int img, ty0, tx0; };   // a tile's image and first output pixel (two integer divisions: once per tile)
+  auto tile_origin = [&](int i) {
+    const int t = b + i * nb;
+    Org o;
+    o.img = t / tpi;
+    const int rem = t - o.img * tpi, tyq = rem / jb.tilesX;
+    o.ty0 = tyq * W3_TH;
+    o.tx0 = (rem - tyq * jb.tilesX) * W3_TW;
+    return o;
+  };
+  auto issue_x1 = [&](const Org& o, int buf, int d) {   // instruction d of a tile's halo into buffer buf
+    const int iy0 = o.ty0 - 1, ix0 = o.tx0 - 1;
+    const char* xt = (const char*)jb.x + ((size_t)o.img * H * Wd + (ptrdiff_t)iy0 * Wd + ix0) * (ptrdiff_t)ldxb;
+    const int q = wave * D + d;
+    const int pb = q / KC8, k8 = q % KC8;
+    const int pix = pb * 64 + lane;
+    const int hy = (int)(((unsigned)pix * 3641u) >> 16);   // pix / 18 for pix < 192
+    const int hx = pix - hy * W3_HW;
+    const bool v = (pix < W3_HPIX) & ((unsigned)(iy0 + hy) < (unsigned)H) & ((unsigned)(ix0 + hx) < (unsigned)Wd);
+    const char* g = v ? xt + (unsigned)((hy * Wd + hx) * ldxb + k8 * 16) : (const char*)g_w3_zero_page;
+    w3_glds16(g, lds0 + buf * XB + k8 * PLANE + pb * 1024);
+  };
+
+  // ---- B fragments: MFMA column l31 of pixel group g is pixel (row 2 g' + lg, column lidx) of the tile, where (lg, lidx)
+  // is the lane's place in its ds_read_b128 service group; plane (2 ks + h); tap (dy, dx) = + (dy * 18 + dx) pixels
+  int lg, lidx;
+  {
+    const int l = l31;
+    lg = ((l >= 4) & (l < 12)) | ((l >= 16) & (l < 20)) | (l >= 28);
+    lidx = l - (l < 4 ? 0 : l < 12 ? 4 : l < 20 ? 8 : l < 28 ? 12 : 16);
+  }
+  unsigned bbase[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) bbase[g] = (unsigned)(h * PLANE + (((wn * G + g) * 2 + lg) * W3_HW + lidx) * 16);
+  // output pixel of group g: (ty0 + (wn G + g) 2 + lg, tx0 + lidx); address (or null when outside the map)
+  auto out_ptr = [&](const Org& o, int g) -> char* {
+    const int py = o.ty0 + (wn * G + g) * 2 + lg, px = o.tx0 + lidx;
+    char* q = (char*)jb.y + (((size_t)o.img * H + py) * Wd + px) * (size_t)ldyb + wm * 64 + h * 16;
+    return ((py < H) & (px < Wd)) ? q : nullptr;
+  };
+
+  // BatchNorm sums: per lane 16 channels x (sum, sumsq), kept in LDS between tiles ([8][threads][16 B] behind the two halo
+  // buffers) - 32 more live registers across the main loop do not fit next to the weights
+  float* const sacc = (float*)(smem + 2 * XB) + tid * 4;
+  constexpr int SAS = NW * 64 * 4;   // floats between the 8 vectors of a lane
+  if constexpr (MODE == 1) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) *(f32x4*)(sacc + q * SAS) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  Org oc = tile_origin(0), op = oc;   // current / previous tile
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue_x1(oc, 0, d);
+
+  u32x4 pk[S];   // packed bf16 outputs of the previous tile: [group][pair of 8-channel halves], stored during this tile
+#pragma unroll
+  for (int q = 0; q < S; ++q) pk[q] = u32x4{0u, 0u, 0u, 0u};
+  for (int i = 0; i < nt; ++i) {
+    W3_VMCNT(0);                    // this wave's share of halo i (issued >= a third of a tile ago)
+    __builtin_amdgcn_s_barrier();   // halo i complete; the other buffer is no longer read
+    const bool more = (i + 1 < nt) & !(p.dbg & 2);
+    const bool prev = i > 0;
+    const Org on = tile_origin(i + 1 < nt ? i + 1 : i);
+    const char* Xs = smem + (i & 1) * XB;
+    u32x4 old[S];
+
+    f32x16 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+    // 9 * KS k-steps, B fragments double-buffered one step ahead.  (Left to itself the compiler - at the register limit -
+    // issues read, wait, MFMA, read, wait ... through ONE fragment register: every MFMA then waits a full LDS round trip,
+    // and with one wave per SIMD nothing hides it.  The sched_barriers pin: reads of step s + 1, then the MFMAs of step s.)
+    auto ldb = [&](int step, bf16x8(&dst)[G]) {
+      const int t9 = step / KS, ks = step % KS, dy = t9 / 3, dx = t9 % 3;
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        dst[g] = __builtin_bit_cast(bf16x8, *(const u32x4*)(Xs + bbase[g] + (2 * ks * PLANE + (dy * W3_HW + dx) * 16)));
+    };
+    bf16x8 bfA[G], bfB[G];
+    ldb(0, bfA);
+    if (!(p.dbg & 4))   // (dbg 4: timing experiment without the main loop)
+#pragma unroll
+    for (int ds = 0; ds < NDS; ++ds) {
+      const int st = 2 * ds;
+      // -- the tile's memory traffic, one operation per double step
+      if (ds % 2 == 0 && ds / 2 < D) {
+        if (more) issue_x1(on, (i + 1) & 1, ds / 2);
+      }
+      if (ds % 2 == 1 && ds / 2 < S) {
+        char* q = prev ? out_ptr(op, (ds / 2) / 2) : nullptr;
+        if (q) *(u32x4*)(q + ((ds / 2) % 2) * 32) = pk[ds / 2];
+      }
+      if constexpr (MODE == 2) {
+        if (ds >= 2 * S && ds < 3 * S) {
+          const int l = ds - 2 * S;
+          char* q = out_ptr(oc, l / 2);
+          old[l] = u32x4{0u, 0u, 0u, 0u};
+          if (q) {
+            if (l % 2 == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(old[l]) : "v"(q) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "+v"(old[l]) : "v"(q) : "memory");
+          }
+        }
+      }
+      ldb(st + 1, bfB);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[st / KS][st % KS], bfA[g], acc[g], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (st + 2 < NS) ldb(st + 2, bfA);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(st + 1) / KS][(st + 1) % KS], bfB[g], acc[g], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- convert: accumulators -> bf16 -> permlane32_swap pairs -> 16 contiguous bytes per lane, kept for the next tile
+    if constexpr (MODE == 2) {
+      if constexpr (S == 2)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(old[0]), "+v"(old[1])::"memory");
+      else if constexpr (S == 4)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3])::"memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]), "+v"(old[4]), "+v"(old[5]), "+v"(old[6]), "+v"(old[7])::"memory");
+    }
+    float s1[16], s2[16];
+    if constexpr (MODE == 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 u = *(const f32x4*)(sacc + q * SAS), w = *(const f32x4*)(sacc + (4 + q) * SAS);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1[4 * q + e] = u[e]; s2[4 * q + e] = w[e]; }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      bool pvg = true;
+      if constexpr (MODE == 1) pvg = out_ptr(oc, g) != nullptr;
+      unsigned pw[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (__bf16)acc[g][4 * q + e];
+        if constexpr (MODE == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float f = pvg ? (float)o[e] : 0.f;
+            s1[4 * q + e] += f;
+            s2[4 * q + e] = __builtin_fmaf(f, f, s2[4 * q + e]);
+          }
+        }
+        const u32x2 u = __builtin_bit_cast(u32x2, o);
+        pw[2 * q] = u[0];
+        pw[2 * q + 1] = u[1];
+      }
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const int q0 = 2 * pr, q1 = 2 * pr + 1;
+        const auto w0 = __builtin_amdgcn_permlane32_swap(pw[2 * q0], pw[2 * q1], false, false);
+        const auto w1 = __builtin_amdgcn_permlane32_swap(pw[2 * q0 + 1], pw[2 * q1 + 1], false, false);
+        u32x4 v = {w0[0], w1[0], w0[1], w1[1]};
+        if constexpr (MODE == 2) {
+          // same double rounding as the tile kernel's accumulate path: bf16(result), then bf16(that + old)
+          const bf16x8 nv = __builtin_bit_cast(bf16x8, v), ov = __builtin_bit_cast(bf16x8, old[g * 2 + pr]);
+          bf16x8 rv;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) rv[e] = (__bf16)((float)nv[e] + (float)ov[e]);
+          v = __builtin_bit_cast(u32x4, rv);
+        }
+        pk[g * 2 + pr] = v;
+      }
+    }
+    if constexpr (MODE == 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        *(f32x4*)(sacc + q * SAS) = f32x4{s1[4 * q], s1[4 * q + 1], s1[4 * q + 2], s1[4 * q + 3]};
+        *(f32x4*)(sacc + (4 + q) * SAS) = f32x4{s2[4 * q], s2[4 * q + 1], s2[4 * q + 2], s2[4 * q + 3]};
+      }
+    }
+    op = oc;
+    oc = on;
+  }
+  // the last tile's outputs
+#pragma unroll
+  for (int q = 0; q < S; ++q) {
+    char* o = out_ptr(op, q / 2);
+    if (o) *(u32x4*)(o + (q % 2) * 32) = pk[q];
+  }
+
+  W3_VMCNT(0);
+  if constexpr (MODE == 1) {
+    float s1[16], s2[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 u = *(const f32x4*)(sacc + q * SAS), w = *(const f32x4*)(sacc + (4 + q) * SAS);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s1[4 * q + e] = u[e]; s2[4 * q + e] = w[e]; }
+    }
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s1[r] += __shfl_xor(s1[r], off, 64);
+        s2[r] += __shfl_xor(s2[r], off, 64);
+      }
+    __syncthreads();
+    float* red = (float*)smem;   // [WN][WM * 32][2]
+    if (l31 == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = wm * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        red[(wn * WM * 32 + c) * 2 + 0] = s1[r];
+        red[(wn * WM * 32 + c) * 2 + 1] = s2[r];
+      }
+    }
+    __syncthreads();
+    if (tid < WM * 32) {
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < WN; ++q) {
+        a1 += red[(q * WM * 32 + tid) * 2 + 0];
+        a2 += red[(q * WM * 32 + tid) * 2 + 1];
+      }
+      double* sp = jb.stats + (size_t)((int)blockIdx.x % jb.nslots) * jb.sld + tid * 2;
+      if (!(p.dbg & 1)) {
+        atomicAdd(sp, (double)a1);
+        atomicAdd(sp + 1, (double)a2);
+      }
+    }
+  }
+}
+
+template <int K, int WM, int WN, int G, int MODE>
+static int w3_launch_one(const W3Launch& l, hipStream_t s) {
+  auto fn = w3_kernel<K, WM, WN, G, MODE>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(fn, dim3((unsigned)l.grid), dim3(WM * WN * 64), (size_t)l.lds, s, l.k);
+  MI_CHECK_LAUNCH("conv3x3_ws");
+  return MI_OK;
+}
+template <int MODE>
+static int w3_launch_mode(const W3Launch& l, hipStream_t s) {
+  switch (l.K) {
+    case 128: return w3_launch_one<128, 4, 1, 4, MODE>(l, s);
+    case 64: return w3_launch_one<64, 2, 2, 2, MODE>(l, s);
+    case 32: return w3_launch_one<32, 1, 4, 1, MODE>(l, s);
+  }
+  MI_FAIL(MI_EINVAL, "conv3x3_ws: K %d", l.K);
+}

@@ -1,0 +1,140 @@
+// Host side of the weight-stationary 3x3 convolution (conv3x3_ws.h): eligibility, job table, block partition.
+// mi_conv2d / mi_conv2d_group_plan route eligible descriptors here (MI_CONV_WS=0 keeps them on the tile kernel);
+// mi_conv3x3_ws is the explicit entry (it fails instead of falling back).
+#include <stdlib.h>
+#include <string.h>
+#include "common.h"
+#include "conv3x3_ws.h"
+
+int w3_launch_mode0(const W3Launch& l, hipStream_t s);
+int w3_launch_mode1(const W3Launch& l, hipStream_t s);
+int w3_launch_mode2(const W3Launch& l, hipStream_t s);
+
+static int w3_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+// 3x3, stride 1, K -> K with K in {32, 64, 128}, bf16 in / out, no bias; tw[] = weight slab per tap position
+static bool w3_desc_ok(const mi_conv_desc* d, int* tw) {
+  const int K = d->K8 * 8;
+  if (d->ntaps != 9 || d->in_stride != 1 || d->out_stride != 1 || d->out_oy || d->out_ox) return false;
+  if (d->gridH != d->outH || d->gridW != d->outW || d->outH != d->H || d->outW != d->W) return false;
+  if (d->flags & ~MI_CONV_ACCUM) return false;
+  if (d->bias) return false;
+  if (!(K == 32 || K == 64 || K == 128) || d->Cout != K || d->CoutPad != K) return false;
+  if (d->ldx % 8 || d->ldy % 8 || ((uintptr_t)d->x & 15) || ((uintptr_t)d->y & 15) || ((uintptr_t)d->w & 15)) return false;
+  if (d->y_nstride && (long long)d->y_nstride != (long long)d->outH * d->outW * d->ldy) return false;
+  if ((long long)d->H * d->W * d->ldx * 2 >= (1LL << 31)) return false;   // per-lane 32-bit offsets inside one image
+  if ((d->flags & MI_CONV_ACCUM) && d->stats_acc) return false;
+  int seen = 0;
+  for (int t = 0; t < 9; ++t) {
+    const int dy = d->tap_dy[t], dx = d->tap_dx[t];
+    if (dy < -1 || dy > 1 || dx < -1 || dx > 1) return false;
+    const int pos = (dy + 1) * 3 + dx + 1;
+    if (seen & (1 << pos)) return false;
+    seen |= 1 << pos;
+    tw[pos] = d->tap_w[t];
+  }
+  return seen == 0x1ff;
+}
+
+static bool w3_fill(const mi_conv_desc* ds, int n, W3Launch* l) {
+  if (n < 1 || n > W3_MAX_JOBS) return false;
+  memset(l, 0, sizeof(*l));
+  const int K = ds[0].K8 * 8;
+  long long total = 0;
+  for (int j = 0; j < n; ++j) {
+    const mi_conv_desc& d = ds[j];
+    W3Job& jb = l->k.j[j];
+    if (!w3_desc_ok(&d, jb.tw) || d.K8 * 8 != K) return false;
+    if ((d.flags & MI_CONV_ACCUM) != (ds[0].flags & MI_CONV_ACCUM) || (d.stats_acc != nullptr) != (ds[0].stats_acc != nullptr)) return false;
+    jb.x = (const __bf16*)d.x; jb.w = (const u32x4*)d.w; jb.y = (__bf16*)d.y; jb.stats = d.stats_acc;
+    jb.ldx = d.ldx; jb.ldy = d.ldy; jb.N = d.N; jb.H = d.H; jb.W = d.W;
+    jb.tilesY = mi_cdiv(d.H, W3_TH); jb.tilesX = mi_cdiv(d.W, W3_TW);
+    jb.ntiles = d.N * jb.tilesY * jb.tilesX;
+    jb.wld = d.CoutPad;
+    jb.nslots = (d.stats_slots >= 1 && d.stats_slots <= MI_BN_SLOTS) ? d.stats_slots : MI_BN_SLOTS;
+    jb.sld = d.CoutPad * 2;
+    total += jb.ntiles;
+  }
+  // persistent blocks: K = 128 one per CU (288 VGPRs of weights per wave), K = 64 two, K = 32 four; shared between
+  // the jobs in proportion to their tiles (every job gets at least one block, none more blocks than tiles)
+  static const int ovr = getenv("MI_W3_PERCU") ? atoi(getenv("MI_W3_PERCU")) : 0;
+  const int per_cu = ovr > 0 ? ovr : (K == 128 ? 1 : (K == 64 ? 2 : 4));
+  long long cap = (long long)w3_cus() * per_cu;
+  if (cap > total) cap = total;
+  int used = 0;
+  for (int j = 0; j < n; ++j) {
+    W3Job& jb = l->k.j[j];
+    long long nb = (cap * jb.ntiles) / total;
+    if (nb < 1) nb = 1;
+    if (nb > jb.ntiles) nb = jb.ntiles;
+    jb.nblk = (int)nb;
+    used += jb.nblk;
+  }
+  // leftover blocks go to the jobs with the most tiles per block
+  while (used < cap) {
+    int best = -1;
+    double br = 0;
+    for (int j = 0; j < n; ++j) {
+      const W3Job& jb = l->k.j[j];
+      const double r = (double)jb.ntiles / jb.nblk;
+      if (jb.nblk < jb.ntiles && r > br) { br = r; best = j; }
+    }
+    if (best < 0) break;
+    l->k.j[best].nblk++;
+    used++;
+  }
+  int blk = 0;
+  for (int j = 0; j < n; ++j) {
+    l->k.j[j].blk0 = blk;
+    blk += l->k.j[j].nblk;
+  }
+  l->k.njobs = n;
+  // (timing experiments; read per call.  1: no statistics atomics, 2: no halo traffic after the first tile, 4: no main loop)
+  l->k.dbg = (getenv("MI_DEBUG_NOATOM") ? atoi(getenv("MI_DEBUG_NOATOM")) & 1 : 0) | (getenv("MI_W3_DBG") ? atoi(getenv("MI_W3_DBG")) & 6 : 0);
+  l->K = K;
+  l->MODE = (ds[0].flags & MI_CONV_ACCUM) ? 2 : (ds[0].stats_acc ? 1 : 0);
+  l->grid = blk;
+  l->lds = 2 * (K / 8) * W3_HROWS * 16 + (l->MODE == 1 ? 256 * 32 * 4 : 0);   // halo ring (+ per-lane BatchNorm sums)
+  return true;
+}
+
+static int w3_run(const W3Launch& l, hipStream_t s) {
+  switch (l.MODE) {
+    case 0: return w3_launch_mode0(l, s);
+    case 1: return w3_launch_mode1(l, s);
+    default: return w3_launch_mode2(l, s);
+  }
+}
+
+static bool w3_enabled() {
+  const char* e = getenv("MI_CONV_WS");
+  return !e || atoi(e) != 0;
+}
+
+bool w3_try_launch(const mi_conv_desc* ds, int n, hipStream_t s, int* rc) {
+  if (!w3_enabled()) return false;
+  W3Launch l;
+  if (!w3_fill(ds, n, &l)) return false;
+  *rc = w3_run(l, s);
+  return true;
+}
+bool w3_try_plan(const mi_conv_desc* ds, int n, W3Launch* l) { return w3_enabled() && w3_fill(ds, n, l); }
+int w3_run_planned(const W3Launch* l, hipStream_t s) { return w3_run(*l, s); }
+
+extern "C" int mi_conv3x3_ws(const mi_conv_desc* descs, int n, mi_stream_t st) {
+  MI_REQUIRE(descs && n >= 1, "conv3x3_ws: null");
+  W3Launch l;
+  MI_REQUIRE(w3_fill(descs, n, &l),
+             "conv3x3_ws: needs 1..%d bf16 3x3 stride-1 convs with K == Cout in {32, 64, 128} (all the same K), no bias, "
+             "all plain / all with stats_acc / all MI_CONV_ACCUM", W3_MAX_JOBS);
+  return w3_run(l, (hipStream_t)st);
+}

@@ -35,6 +35,12 @@ bool c1s_try_launch(const mi_conv_desc* ds, int n, hipStream_t s, int* rc);
 bool c1s_try_plan(const mi_conv_desc* ds, int n, C1Launch* l);
 int c1s_run_planned(const C1Launch* l, hipStream_t s);
 static_assert(sizeof(C1Launch) <= sizeof(((mi_conv_group*)0)->priv), "mi_conv_group.priv holds the stream launch record");
+#include "conv3x3_ws.h"
+// weight-stationary 3x3 path (conv3x3_ws.hip)
+bool w3_try_launch(const mi_conv_desc* ds, int n, hipStream_t s, int* rc);
+bool w3_try_plan(const mi_conv_desc* ds, int n, W3Launch* l);
+int w3_run_planned(const W3Launch* l, hipStream_t s);
+static_assert(sizeof(W3Launch) <= sizeof(((mi_conv_group*)0)->priv), "mi_conv_group.priv holds the 3x3 launch record");
 
 #define MI_DECL_KC(KCv)                                                                      \
   int conv_launch_kc##KCv(const ConvK& k, int BN, int TPIX, size_t lds, hipStream_t s);       \
@@ -251,6 +257,7 @@ extern "C" int mi_conv2d(const mi_conv_desc* d, mi_stream_t st) {
   {
     int rc = MI_OK;
     if (d && c1s_try_launch(d, 1, (hipStream_t)st, &rc)) return rc;
+    if (d && w3_try_launch(d, 1, (hipStream_t)st, &rc)) return rc;
   }
   ConvK k;
   ConvCfg c;
@@ -292,6 +299,20 @@ extern "C" int mi_conv2d_group_plan(const mi_conv_desc* descs, int n, void* tabl
       meta->KC = -1; meta->BN = cl.WM * 32; meta->TPIX = cl.PT; meta->TPS = cl.NBUF; meta->EPI = cl.MODE;
       meta->starts_off = 0; meta->table_bytes = 16;   // no device table: the launch record travels in meta->priv
       memcpy(meta->priv, &cl, sizeof(cl));
+      if (table_host) {
+        MI_REQUIRE(table_cap >= meta->table_bytes, "conv_group_plan: table too small");
+        memset(table_host, 0, (size_t)meta->table_bytes);
+      }
+      return MI_OK;
+    }
+    // 3x3 K -> K convolutions (the head's levels x towers): persistent weight-stationary blocks, one launch
+    W3Launch wl;
+    if (w3_try_plan(descs, n, &wl)) {
+      memset(meta, 0, sizeof(*meta));
+      meta->njobs = n; meta->nblocks = wl.grid; meta->lds_bytes = wl.lds;
+      meta->KC = -2; meta->BN = wl.K; meta->TPIX = 128; meta->TPS = 9; meta->EPI = wl.MODE;
+      meta->starts_off = 0; meta->table_bytes = 16;
+      memcpy(meta->priv, &wl, sizeof(wl));
       if (table_host) {
         MI_REQUIRE(table_cap >= meta->table_bytes, "conv_group_plan: table too small");
         memset(table_host, 0, (size_t)meta->table_bytes);
@@ -386,6 +407,7 @@ extern "C" int mi_conv2d_group_plan(const mi_conv_desc* descs, int n, void* tabl
 extern "C" int mi_conv2d_group_run(const mi_conv_group* m, const void* table_dev, mi_stream_t st) {
   MI_REQUIRE(m && table_dev && m->njobs >= 1, "conv_group_run: null");
   if (m->KC == -1) return c1s_run_planned((const C1Launch*)m->priv, (hipStream_t)st);
+  if (m->KC == -2) return w3_run_planned((const W3Launch*)m->priv, (hipStream_t)st);
   const ConvK* jobs = (const ConvK*)table_dev;
   const int* starts = (const int*)((const char*)table_dev + m->starts_off);
   hipStream_t s = (hipStream_t)st;
