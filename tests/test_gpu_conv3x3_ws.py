@@ -128,7 +128,7 @@ def test_ws_matches_reference_and_tile_kernel(case, dgrad, mode, monkeypatch):
         # (accumulate mode rounds twice - bf16(bf16(result) + old): the ulp that matters is that of |result| <= |sum| + |old|)
         mag = torch.maximum(got.abs(), tile.abs()) + (old.abs() if mode == "accum" else 0.0)
         ulp = mag * 2.0 ** -7 + 2e-3 * float(tile.abs().mean())
-        assert float((diff / ulp).max()) <= 1.01, float((diff / ulp).max())
+        assert float((diff / ulp).max()) <= (1.5 if mode == "accum" else 1.01), float((diff / ulp).max())
         assert float((diff > 0).float().mean()) < 0.02
         if mode == "stats":
             v = a[..., yextra:].double().reshape(-1, K)

@@ -444,8 +444,8 @@ def test_grouped_launches_equal_separate_launches(monkeypatch, B, H, W):
     # (a grouped member runs on the group's tile shape: its fp32 BatchNorm partial sums are taken in another order - the
     #  streaming 1x1 kernel sums a whole block's tiles in fp32 before its fp64 atomics - and one flipped bf16 rounding of an
     #  activation moves a loss component by ~1e-5 relative at 16 x 640 x 640; a flipped SimOTA assignment moves the class
-    #  loss by ~1e-3 (measured 8.5e-4).  A dropped contribution is >> 1 %.)
-    np.testing.assert_allclose(res["1"][0].numpy(), res["0"][0].numpy(), rtol=3e-3)
+    #  loss by ~1e-3 (measured 8.5e-4, and 3.4e-3 on another box).  A dropped contribution is >> 1 %.)
+    np.testing.assert_allclose(res["1"][0].numpy(), res["0"][0].numpy(), rtol=1e-2)
     bad = []
     for n, g0 in res["0"][1].items():
         g1 = res["1"][1][n]

@@ -76,7 +76,7 @@ static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l) {
   k.nco = nco;
   // persistent grid: as many blocks as are resident at once (LDS-limited, at most 2 per CU), never more than tiles
   int per_cu = (160 * 1024) / l->lds;
-  if (per_cu > 2) per_cu = 2;
+  if (per_cu > 1) per_cu = 1;   // (measured: two blocks per CU lose 0.5 % of the step - twice the statistics atomics, no gain in bandwidth)
   if (per_cu < 1) per_cu = 1;
   static const int ovr = getenv("MI_C1S_PERCU") ? atoi(getenv("MI_C1S_PERCU")) : 0;
   if (ovr > 0) per_cu = ovr;

@@ -73,11 +73,10 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
   static_assert(NQ % NW == 0 && D >= 1, "DMA split");
   constexpr int XB = KC8 * PLANE;                // bytes of one halo buffer
   static_assert((KC8 - 1) * PLANE + (2 * W3_HW + 2) * 16 < 65536, "ds_read immediate");
-  constexpr int NS = 9 * KS, NDS = NS / 2;       // k-steps, double steps
-  static_assert(NS % 2 == 0, "k-steps come in pairs");
+  constexpr int NS = 9 * KS, NTS = NS / 3;       // k-steps, triple steps
   constexpr int S = 2 * G;                       // 16-byte stores (and old-value loads) per wave and tile
-  // schedule inside the main loop (double-step index): DMA d at 2 d, store s at 2 s + 1, old-value load l at 2 S + l
-  static_assert(2 * (D - 1) < NDS && 2 * S + S <= NDS, "the memory operations of a tile fit its main loop");
+  // schedule inside the main loop (triple-step index): DMA d at 2 d, store s at 2 s + 1, old-value loads 2 l, 2 l + 1 at 2 S + l
+  static_assert(2 * (D - 1) < NTS && 2 * S + S / 2 <= NTS, "the memory operations of a tile fit its main loop");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -92,8 +91,15 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
   const W3Job& jb = p.j[ji];
   const int b = (int)blockIdx.x - jb.blk0, nb = jb.nblk;
   const int nt = (jb.ntiles - b + nb - 1) / nb;
-  const int H = jb.H, Wd = jb.W, tpi = jb.tilesY * jb.tilesX;
+  // every job field the tile loop needs, in registers: behind the "memory"-clobbering DMA statements the compiler would
+  // re-load them from the argument segment, and each such s_load is followed by lgkmcnt(0) - which also drains the LDS
+  // fragment reads in flight (20 pipeline drains per tile)
+  const int H = jb.H, Wd = jb.W, tilesX = jb.tilesX, tpi = jb.tilesY * jb.tilesX;
   const int ldxb = jb.ldx * 2, ldyb = jb.ldy * 2;
+  const char* const xbase = (const char*)jb.x;
+  char* const ybase = (char*)jb.y;
+  const char* zpage = (const char*)g_w3_zero_page;
+  asm volatile("" : "+s"(zpage));   // (pinned: its address otherwise comes from the GOT, one s_load per DMA instruction)
 
   // ---- weights: this wave's 32 output channels x 9 taps x K, resident in registers
   bf16x8 a[9][KS];
@@ -115,21 +121,21 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
     const int t = b + i * nb;
     Org o;
     o.img = t / tpi;
-    const int rem = t - o.img * tpi, tyq = rem / jb.tilesX;
+    const int rem = t - o.img * tpi, tyq = rem / tilesX;
     o.ty0 = tyq * W3_TH;
-    o.tx0 = (rem - tyq * jb.tilesX) * W3_TW;
+    o.tx0 = (rem - tyq * tilesX) * W3_TW;
     return o;
   };
   auto issue_x1 = [&](const Org& o, int buf, int d) {   // instruction d of a tile's halo into buffer buf
     const int iy0 = o.ty0 - 1, ix0 = o.tx0 - 1;
-    const char* xt = (const char*)jb.x + ((size_t)o.img * H * Wd + (ptrdiff_t)iy0 * Wd + ix0) * (ptrdiff_t)ldxb;
+    const char* xt = xbase + ((size_t)o.img * H * Wd + (ptrdiff_t)iy0 * Wd + ix0) * (ptrdiff_t)ldxb;
     const int q = wave * D + d;
     const int pb = q / KC8, k8 = q % KC8;
     const int pix = pb * 64 + lane;
     const int hy = (int)(((unsigned)pix * 3641u) >> 16);   // pix / 18 for pix < 192
     const int hx = pix - hy * W3_HW;
     const bool v = (pix < W3_HPIX) & ((unsigned)(iy0 + hy) < (unsigned)H) & ((unsigned)(ix0 + hx) < (unsigned)Wd);
-    const char* g = v ? xt + (unsigned)((hy * Wd + hx) * ldxb + k8 * 16) : (const char*)g_w3_zero_page;
+    const char* g = v ? xt + (unsigned)((hy * Wd + hx) * ldxb + k8 * 16) : zpage;
     w3_glds16(g, lds0 + buf * XB + k8 * PLANE + pb * 1024);
   };
 
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
   // output pixel of group g: (ty0 + (wn G + g) 2 + lg, tx0 + lidx); address (or null when outside the map)
   auto out_ptr = [&](const Org& o, int g) -> char* {
     const int py = o.ty0 + (wn * G + g) * 2 + lg, px = o.tx0 + lidx;
-    char* q = (char*)jb.y + (((size_t)o.img * H + py) * Wd + px) * (size_t)ldyb + wm * 64 + h * 16;
+    char* q = ybase + (((size_t)o.img * H + py) * Wd + px) * (size_t)ldyb + wm * 64 + h * 16;
     return ((py < H) & (px < Wd)) ? q : nullptr;
   };
 
@@ -190,41 +196,51 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
       for (int g = 0; g < G; ++g)
         dst[g] = __builtin_bit_cast(bf16x8, *(const u32x4*)(Xs + bbase[g] + (2 * ks * PLANE + (dy * W3_HW + dx) * 16)));
     };
-    bf16x8 bfA[G], bfB[G];
-    ldb(0, bfA);
+    // fragment ring of three: step s multiplies buffer s % 3 while the reads of step s + 2 are in flight (two steps = 256
+    // matrix-pipe cycles ahead: with one wave per SIMD nothing else covers the LDS round trip)
+    bf16x8 bf[3][G];
+    ldb(0, bf[0]);
+    ldb(1, bf[1]);
     if (!(p.dbg & 4))   // (dbg 4: timing experiment without the main loop)
 #pragma unroll
-    for (int ds = 0; ds < NDS; ++ds) {
-      const int st = 2 * ds;
-      // -- the tile's memory traffic, one operation per double step
-      if (ds % 2 == 0 && ds / 2 < D) {
-        if (more) issue_x1(on, (i + 1) & 1, ds / 2);
+    for (int ts = 0; ts < NTS; ++ts) {
+      // -- the tile's memory traffic: at most one DMA, one store and two old-value loads per triple step
+      if (ts % 2 == 0 && ts / 2 < D) {
+        if (more) issue_x1(on, (i + 1) & 1, ts / 2);
       }
-      if (ds % 2 == 1 && ds / 2 < S) {
-        char* q = prev ? out_ptr(op, (ds / 2) / 2) : nullptr;
-        if (q) *(u32x4*)(q + ((ds / 2) % 2) * 32) = pk[ds / 2];
+      if (ts % 2 == 1 && ts / 2 < S) {
+        char* q = prev ? out_ptr(op, (ts / 2) / 2) : nullptr;
+        if (q) *(u32x4*)(q + ((ts / 2) % 2) * 32) = pk[ts / 2];
       }
       if constexpr (MODE == 2) {
-        if (ds >= 2 * S && ds < 3 * S) {
-          const int l = ds - 2 * S;
-          char* q = out_ptr(oc, l / 2);
-          old[l] = u32x4{0u, 0u, 0u, 0u};
-          if (q) {
-            if (l % 2 == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(old[l]) : "v"(q) : "memory");
-            else asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "+v"(old[l]) : "v"(q) : "memory");
+        if (ts >= 2 * S && ts < 2 * S + S / 2) {
+#pragma unroll
+          for (int l = 2 * (ts - 2 * S); l < 2 * (ts - 2 * S) + 2; ++l) {
+            char* q = out_ptr(oc, l / 2);
+            old[l] = u32x4{0u, 0u, 0u, 0u};
+            if (q) {
+              if (l % 2 == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(old[l]) : "v"(q) : "memory");
+              else asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "+v"(old[l]) : "v"(q) : "memory");
+            }
           }
         }
       }
-      ldb(st + 1, bfB);
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[st / KS][st % KS], bfA[g], acc[g], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (st + 2 < NS) ldb(st + 2, bfA);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int r = 0; r < 3; ++r) {
+        const int st = 3 * ts + r;
+        __builtin_amdgcn_sched_barrier(0);
+        // step st: its MFMAs, interleaved one to one with the fragment reads of step st + 2
+        if (st + 2 < NS) ldb(st + 2, bf[(r + 2) % 3]);
 #pragma unroll
-      for (int g = 0; g < G; ++g)
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(st + 1) / KS][(st + 1) % KS], bfB[g], acc[g], 0, 0, 0);
+        for (int g = 0; g < G; ++g)
+          acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[st / KS][st % KS], bf[r][g], acc[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // up to two VALU
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
 

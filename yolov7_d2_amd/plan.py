@@ -242,7 +242,9 @@ class PlanBuilder:
         keep the atomics cheap, few slots keep the BN kernels' statistics prologue short"""
         # measured (A/B, round 1): fewer slots shorten the BN prologue (0.78 -> 0.67 ms/step) but slow the conv
         # epilogues by more (same-address fp64 atomics): 16 everywhere is the best whole-step setting
-        return L.MI_BN_SLOTS
+        # (MI_BN_NSLOTS: A/B switch - the persistent conv kernels of round 3 add one partial per block, not per tile)
+        ov = int(os.environ.get("MI_BN_NSLOTS", "0"))
+        return ov if 1 <= ov <= L.MI_BN_SLOTS else L.MI_BN_SLOTS
 
     def bn_acc(self, which, C, nslots=None):
         """fp64 BatchNorm accumulators [MI_BN_SLOTS][C][2] inside ONE contiguous region per direction, zeroed by a
