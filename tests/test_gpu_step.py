@@ -244,6 +244,40 @@ def test_training_step_drop_in(golden_dir):
     assert 0.5 < float(np.median(ratios)) < 2.0
 
 
+def test_backward_keeps_autograd_accumulation_semantics():
+    """.grad hand-over of the meta-arch's autograd bridge: after zero_grad(set_to_none=True) the arena view is
+    bound without a copy; a second backward WITHOUT zero_grad accumulates (2 x the single gradient - BatchNorm running
+    statistics aside, the two forwards see the same batch statistics); zero_grad(set_to_none=False) zeroes the arena in
+    place and the next backward leaves exactly one gradient"""
+    model, _ = _gpu_model(seed=5)
+    model.train()
+    imgs, labels = O.synth_batch(2, 64, 96, seed=13, max_gt=4)
+
+    def step():
+        sum(model(_batched_inputs(imgs, labels)).values()).backward()
+        torch.cuda.synchronize()
+
+    step()
+    arena = model.params.grad
+    assert all(p.grad.data_ptr() == model.params.grad_of(p).data_ptr() for p in model.parameters())   # zero-copy bind
+    g1 = arena.clone()
+    assert float(g1.norm()) > 0
+    step()                                      # no zero_grad: accumulate
+    g2 = arena.clone()
+    rel = float((g2 - 2 * g1).norm() / (2 * g1).norm())
+    assert rel < 2e-2, rel                      # (bf16 activations: the second forward differs by running-stat-free noise only)
+    for p in model.parameters():
+        p.grad.zero_()                          # zero_grad(set_to_none=False)
+    step()
+    g3 = arena.clone()
+    assert float((g3 - g1).norm() / g1.norm()) < 2e-2
+    for p in model.parameters():
+        p.grad = None                           # zero_grad(set_to_none=True): bound again without a copy
+    step()
+    assert all(p.grad.data_ptr() == model.params.grad_of(p).data_ptr() for p in model.parameters())
+    assert float((arena - g1).norm() / g1.norm()) < 2e-2
+
+
 def _block_case(kind, seed):
     """a multi-layer block (fan-out, concat slices, residual adds, pools) as its own plan: GPU vs fp32 autograd"""
     from yolov7_d2_amd.modeling.blocks import CSPLayer, SPPBottleneck, EmitCtx

@@ -510,9 +510,11 @@ __device__ __forceinline__ unsigned* bn_bar_cnt(unsigned* bar, int g) { return b
 // needed here: the only data that crosses blocks are the fp64 sums, added by memory-side atomics that have been
 // acknowledged when the block passes its __syncthreads (workgroup release = s_waitcnt vmcnt(0)), and read back after the
 // barrier by agent-scope atomic loads, which bypass the non-coherent caches.
-__device__ __forceinline__ void bn_grid_barrier(unsigned* bar, const unsigned gen0, const int bid, const int nb) {
+// *gave_up (LDS) = 1 when this block's wait timed out: its sums are incomplete and it must poison what it writes.
+__device__ __forceinline__ void bn_grid_barrier(unsigned* bar, const unsigned gen0, const int bid, const int nb, int* gave_up) {
   __syncthreads();
   if (threadIdx.x == 0) {
+    *gave_up = 0;
     const int G = nb < BN_BAR_G ? nb : BN_BAR_G;
     const int g = bid % G;
     const unsigned gsize = (unsigned)((nb - g + G - 1) / G);
@@ -532,6 +534,7 @@ __device__ __forceinline__ void bn_grid_barrier(unsigned* bar, const unsigned ge
         __builtin_amdgcn_s_sleep(8);
         if (++spins > BN_FUS_SPIN_LIMIT) {  // a block that never became resident: report instead of hanging the GPU
           __hip_atomic_store(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          *gave_up = 1;
           break;
         }
       }
@@ -666,7 +669,11 @@ __device__ __forceinline__ void bn_bwd_fused_body(PK& p, const int bid, const in
       atomicAdd(slot + (cc8 * 8 + (v & 7)) * 2 + (v >> 3), (double)acc);
     }
   }
-  bn_grid_barrier(p.bar, gen0, bid, nb);   // (its leading __syncthreads also ends the reads of red[])
+  __shared__ int s_gave_up;
+  bn_grid_barrier(p.bar, gen0, bid, nb, &s_gave_up);   // (its leading __syncthreads also ends the reads of red[])
+  // a block whose wait timed out holds incomplete sums: everything it writes from here on is NaN (dy of its items, and
+  // dgamma / dbeta if it is block 0), and the host finds word 2 of the barrier record set (Plan.check_bn_barriers)
+  const float poison = s_gave_up ? __builtin_nanf("") : 0.f;
   // ---- phase 2: the finished sums (agent-scope loads: the adds were performed by other XCDs)
   for (int c = tid; c < C; c += 256) {
     double v1[MI_BN_SLOTS], v2[MI_BN_SLOTS];
@@ -685,11 +692,11 @@ __device__ __forceinline__ void bn_bwd_fused_body(PK& p, const int bid, const in
       t1 += v1[k];
       t2 += v2[k];
     }
-    s_c1[c] = (float)(t1 * p.inv_count);
-    s_c2[c] = (float)(t2 * p.inv_count);
+    s_c1[c] = (float)(t1 * p.inv_count) + poison;
+    s_c2[c] = (float)(t2 * p.inv_count) + poison;
     if (bid == 0) {
-      if (p.dbeta) p.dbeta[c] = (float)t1;
-      if (p.dgamma) p.dgamma[c] = (float)t2;
+      if (p.dbeta) p.dbeta[c] = (float)t1 + poison;
+      if (p.dgamma) p.dgamma[c] = (float)t2 + poison;
     }
   }
   __syncthreads();
@@ -786,8 +793,18 @@ static int bn_fused_capacity_hw() {
     (void)hipGetLastError();
     return 512;  // no device (host-side planning of a dry run): the MI355X figure, 256 CUs x 2
   }
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, bn_bwd_fused_kernel<1, 1>, 256, 0) != hipSuccess || per < 1) per = 1;
-  if (per > 2) per = 2;
+  // the grid size is shared by all four instantiations (MI_BN_FUSED_MODE, activation on / off) and their grouped forms: the
+  // one with the fewest resident blocks per CU bounds it (MODE 0 keeps 32 16-byte items in registers)
+  per = 2;
+  const void* variants[] = {(const void*)bn_bwd_fused_kernel<1, 1>, (const void*)bn_bwd_fused_kernel<1, 0>,
+                            (const void*)bn_bwd_fused_kernel<0, 1>, (const void*)bn_bwd_fused_kernel<0, 0>,
+                            (const void*)bn_bwd_fused_group_kernel<1, 1>, (const void*)bn_bwd_fused_group_kernel<1, 0>,
+                            (const void*)bn_bwd_fused_group_kernel<0, 1>, (const void*)bn_bwd_fused_group_kernel<0, 0>};
+  for (const void* fn : variants) {
+    int q = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, fn, 256, 0) != hipSuccess || q < 1) q = 1;
+    if (q < per) per = q;
+  }
   cap = ncu * per;
   return cap;
 }

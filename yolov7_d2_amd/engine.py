@@ -49,9 +49,10 @@ class NativeTrainer:
         self.params = model.ensure_params()
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         if self.world > 1:
-            # the one-launch BatchNorm backward needs every block of its grid resident at once: leave an eighth of the
-            # device to the collective's kernels, which run beside the backward pass (a block that has to wait for them
-            # would hold the whole launch at its barrier until the all-reduce is over)
+            # the one-launch BatchNorm backward needs every block of its grid resident at once, and under data parallelism
+            # RCCL's kernels share the device with the backward pass: how many CUs they take has not been measured on
+            # this pool (1-GPU boxes), so the plan defaults to the two-pass form there (plan.py: MI_BN_FUSED unset and
+            # world > 1 -> "0").  Forced on (MI_BN_FUSED=1 / auto) it leaves an eighth of the device to the collective.
             full = L.lib().mi_bn_fused_set_capacity(0)
             L.lib().mi_bn_fused_set_capacity(full - full // 8)
         broadcast_params(self.params.data)
@@ -125,6 +126,11 @@ class NativeTrainer:
         with torch.cuda.stream(self.stream):
             st["ps"].image.copy_(images, non_blocking=True)
             st["ps"].labels.copy_(labels, non_blocking=True)
+        # the copies are queued behind the previous step on self.stream while the sources belong to the caller's stream:
+        # without this the caching allocator may hand their blocks to the caller's next batch before the copies have run
+        for t in (images, labels):
+            if t.is_cuda:
+                t.record_stream(self.stream)
         return st
 
     def feed(self, st, images_host, labels_host):
@@ -135,13 +141,18 @@ class NativeTrainer:
         yolox.py:96,183."""
         if self.copy_stream is None:
             self.copy_stream = torch.cuda.Stream()
-            self._stage = [dict(img=torch.empty_like(st["ps"].image), lab=torch.empty_like(st["ps"].labels),
-                                ready=torch.cuda.Event(), free=torch.cuda.Event()) for _ in range(2)]
-            self._stage_k = 0
-            for b in self._stage:
+        # two staging buffers PER input shape (multi-scale training feeds several (B, H, W) states)
+        if "stage" not in st:
+            st["stage"] = [dict(img=torch.empty_like(st["ps"].image), lab=torch.empty_like(st["ps"].labels),
+                                ready=torch.cuda.Event(), free=torch.cuda.Event(), st=st) for _ in range(2)]
+            st["stage_k"] = 0
+            for b in st["stage"]:
                 b["free"].record(self.stream)
-        b = self._stage[self._stage_k]
-        self._stage_k ^= 1
+        b = st["stage"][st["stage_k"]]
+        st["stage_k"] ^= 1
+        if tuple(images_host.shape) != tuple(b["img"].shape) or tuple(labels_host.shape) != tuple(b["lab"].shape):
+            raise ValueError(f"feed(): batch {tuple(images_host.shape)} / {tuple(labels_host.shape)} does not match the "
+                             f"state's input buffers {tuple(b['img'].shape)} / {tuple(b['lab'].shape)}")
         with torch.cuda.stream(self.copy_stream):
             self.copy_stream.wait_event(b["free"])          # the step that consumed this buffer has copied it out
             b["img"].copy_(images_host, non_blocking=True)
@@ -158,6 +169,8 @@ class NativeTrainer:
             sp = L.stream_ptr(self.stream)
             if self._feed is not None:
                 b, self._feed = self._feed, None
+                if b["st"] is not st:
+                    raise ValueError("step(): the batch handed to feed() belongs to another input shape's state")
                 self.stream.wait_event(b["ready"])
                 st["ps"].image.copy_(b["img"], non_blocking=True)
                 st["ps"].labels.copy_(b["lab"], non_blocking=True)
@@ -190,6 +203,9 @@ class NativeTrainer:
                 self._run_cmds(st["sgd"], 0, 1, sp)
 
     def losses(self, st):
-        """host copy of (total, 5*iou, obj, cls, l1, num_fg/num_gt, num_fg, num_gt) — synchronises"""
+        """host copy of (total, 5*iou, obj, cls, l1, num_fg/num_gt, num_fg, num_gt) — synchronises.  Also the point
+        where a grid barrier of the one-launch BatchNorm backward that gave up (a block that never became resident) is
+        reported: the blocks that gave up poisoned their outputs with NaN, here it becomes an error."""
         self.stream.synchronize()
+        st["plan"].check_bn_barriers()
         return st["ps"].loss_out().cpu()

@@ -86,18 +86,31 @@ class _YoloxTrainFn(torch.autograd.Function):
     def backward(ctx, g):
         ps, model = ctx.ps, ctx.model
         ps.gw().copy_(g[:5 if ps.use_l1 else 4].to(torch.float32))
+        # The kernels write every parameter gradient into the flat arena.  Zero-copy hand-over: a parameter whose .grad
+        # is None (optimizer.zero_grad(), set_to_none=True - the default, and what detectron2's trainer does each
+        # iteration) gets the arena view bound as its .grad and autograd receives None for it - no 240-tensor clone
+        # (36 MB per step).  A parameter whose .grad IS that view already (zero_grad(set_to_none=False), gradient
+        # accumulation over micro-batches, a second backward of another loss term) keeps autograd's semantics: its
+        # current contents are saved before the kernels overwrite the arena and added back afterwards (zeros after a
+        # zero_grad, the earlier gradient otherwise).  A parameter with some other .grad tensor receives the view and
+        # autograd adds it.
+        named = list(model.named_parameters())
+        views = [model.params.grad_of(p) for _, p in named]
+        bound = [k for k, ((_, p), v) in enumerate(zip(named, views)) if p.grad is not None and p.grad.data_ptr() == v.data_ptr()]
+        saved = None
+        if bound:
+            saved = model.params.grad.clone() if len(bound) == len(named) else [views[k].clone() for k in bound]
         ps.plan.run("bwd")
-        # The kernels have written every parameter gradient into the flat arena.  Zero-copy hand-over: a parameter
-        # whose .grad is None (optimizer.zero_grad(set_to_none=True), what detectron2's trainer does each iteration) or
-        # already the arena view gets the view bound as its .grad and autograd receives None for it - no 240-tensor
-        # clone (36 MB per step).  A parameter with some other .grad tensor receives the view and autograd adds it.
-        # model.grad_accumulate = True restores plain autograd semantics (clone; needed only to accumulate several
-        # backward passes into one .grad, because the next step's kernels overwrite the arena).
-        if getattr(model, "grad_accumulate", False):
-            return (None, None, None, None, *[model.params.grad_of(p).clone() for _, p in model.named_parameters()])
+        if bound:
+            if len(bound) == len(named):
+                model.params.grad.add_(saved)
+            else:
+                for k, o in zip(bound, saved):
+                    views[k].add_(o)
+        if getattr(model, "grad_accumulate", False):   # (kept for callers of round 2: plain clones for autograd)
+            return (None, None, None, None, *[v.clone() for v in views])
         grads = []
-        for _, p in model.named_parameters():
-            v = model.params.grad_of(p)
+        for (_, p), v in zip(named, views):
             if p.grad is None or p.grad.data_ptr() == v.data_ptr():
                 p.grad = v
                 grads.append(None)

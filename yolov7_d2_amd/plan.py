@@ -241,10 +241,11 @@ class PlanBuilder:
         """accumulator slots for a layer whose producers add `nunits` partial sums per channel: ~64+ adds per address
         keep the atomics cheap, few slots keep the BN kernels' statistics prologue short"""
         # measured (A/B, round 1): fewer slots shorten the BN prologue (0.78 -> 0.67 ms/step) but slow the conv
-        # epilogues by more (same-address fp64 atomics): 16 everywhere is the best whole-step setting
-        # (MI_BN_NSLOTS: A/B switch - the persistent conv kernels of round 3 add one partial per block, not per tile)
+        # epilogues by more (same-address fp64 atomics): 16 everywhere was the best whole-step setting.  Round 3: the
+        # persistent 1x1 / 3x3 kernels add one partial per BLOCK (256 per layer), which moves the optimum to 8
+        # (same-box A/B: 16: 5.701, 8: 5.677, 4: 5.713, 2: 5.92 ms/step; MI_BN_NSLOTS overrides)
         ov = int(os.environ.get("MI_BN_NSLOTS", "0"))
-        return ov if 1 <= ov <= L.MI_BN_SLOTS else L.MI_BN_SLOTS
+        return ov if 1 <= ov <= L.MI_BN_SLOTS else 8
 
     def bn_acc(self, which, C, nslots=None):
         """fp64 BatchNorm accumulators [MI_BN_SLOTS][C][2] inside ONE contiguous region per direction, zeroed by a
@@ -695,7 +696,12 @@ class Plan:
         # backward lists are captured and timed ON THIS DEVICE and the faster one is kept.  (Measured: on most boxes of the
         # pool the fused form gains 2.3 % of the YOLOX-s step, on some - identical kernel timings in isolation, ~3 us more
         # per kernel boundary in the step - it loses 1 %.)
-        mode = os.environ.get("MI_BN_FUSED", "auto")
+        mode = os.environ.get("MI_BN_FUSED")
+        if mode is None:
+            # data parallel: RCCL's kernels share the CUs with the backward pass and the fused kernel's grid barrier needs
+            # every block resident - two-pass until the collective's footprint has been measured (MI_BN_FUSED=1 forces it)
+            import torch.distributed as dist
+            mode = "0" if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else "auto"
         self.bn_fused = mode != "0"
         self.bn_fused_timing = None
         self._materialize_bwd()
@@ -704,6 +710,21 @@ class Plan:
                         (L.OPS[self.bwd_cmds[0][k].op] == "BN_GROUP" and self.bwd_cmds[0][k].i[0] == 3)
                         for k in range(self.bwd_cmds[1]))):
             self._select_bn_backward()
+
+    def check_bn_barriers(self):
+        """raise if any grid barrier of the one-launch BatchNorm backward gave up since the last check (word 2 of a
+        layer's barrier record; the kernel NaN-poisons what the timed-out block wrote).  Host-synchronising: called
+        where the trainer reads the losses anyway."""
+        bars = [bf for bf in self.b.bufs if bf.name.endswith(".bar")]
+        if not bars or self.b.device.type != "cuda":
+            return
+        flags = torch.stack([self.buf_view(bf, torch.int32, 4)[2] for bf in bars])
+        if int(flags.max()) != 0:
+            bad = [bf.name for bf, f in zip(bars, flags.tolist()) if f]
+            for bf in bars:
+                self.buf_view(bf, torch.int32, 4)[2] = 0
+            raise L.MI355Error(f"BatchNorm backward grid barrier timed out in {bad[:4]} ({len(bad)} layers): a block was not "
+                               "resident (another kernel holds CUs?); set MI_BN_FUSED=0")
 
     def _materialize_bwd(self):
         b = self.b
