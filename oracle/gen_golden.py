@@ -20,7 +20,7 @@ sys.path.insert(0, HERE)
 import ref_loader  # noqa: E402
 import yolox_oracle as O  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+OUT = os.environ.get("MI_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
 def gold_step():

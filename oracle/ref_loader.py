@@ -106,6 +106,30 @@ def load():
     return out
 
 
+def _fvcore(nn_names=None, weight_init=None):
+    """fvcore (un-vendored, not installed): get-or-create the stub packages and ADD whatever names are missing - every
+    loader asks for its own, in any order (a loader that installed a bare `fvcore.nn` first used to make a later one's
+    `from fvcore.nn import giou_loss` fail: the one-shot golden recipe died at gold_detr)"""
+    pk = sys.modules.get("fvcore") or _stub("fvcore")
+    if not hasattr(pk, "__path__"):
+        pk.__path__ = []
+    fn = sys.modules.get("fvcore.nn") or _stub("fvcore.nn")
+    if not hasattr(fn, "__path__"):
+        fn.__path__ = []
+    pk.nn = fn
+    for k, v in (nn_names or {}).items():
+        if getattr(fn, k, None) is None:
+            setattr(fn, k, v)
+    wi = sys.modules.get("fvcore.nn.weight_init") or _stub("fvcore.nn.weight_init")
+    for k, v in (weight_init or {}).items():
+        setattr(wi, k, v)
+    for k in ("c2_msra_fill", "c2_xavier_fill"):
+        if not hasattr(wi, k):
+            setattr(wi, k, lambda m: None)
+    fn.weight_init = wi
+    return fn
+
+
 def _stub_alfred():
     """`alfred` (the reference author's utility package, un-vendored): the debug print and the logger the loaded files
     import at module level"""
@@ -131,9 +155,10 @@ def load_detr():
     if "detectron2.structures" not in sys.modules:
         _stub("detectron2.structures", Boxes=object, ImageList=object, Instances=object, BitMasks=object, PolygonMasks=object)
         _stub("detectron2.utils.logger", log_first_n=lambda *a, **k: None)
-    if "fvcore" not in sys.modules:
-        _stub("fvcore")
-        _stub("fvcore.nn", giou_loss=None, smooth_l1_loss=None)
+    fn = _fvcore()
+    for k in ("giou_loss", "smooth_l1_loss"):     # imported at module level, never called by the set criterion
+        if not hasattr(fn, k):
+            setattr(fn, k, None)
     _stub_alfred()
     name = "yolov7.modeling.meta_arch"
     if name not in sys.modules:
@@ -210,11 +235,8 @@ def load_sparseinst():
         if m.bias is not None:
             nn.init.constant_(m.bias, 0)
 
-    if "fvcore" not in sys.modules:
-        _stub("fvcore")
-    fn = sys.modules.get("fvcore.nn") or _stub("fvcore.nn")
+    fn = _fvcore(weight_init=dict(c2_msra_fill=c2_msra_fill, c2_xavier_fill=c2_xavier_fill))
     fn.sigmoid_focal_loss_jit = sigmoid_focal_loss_jit
-    _stub("fvcore.nn.weight_init", c2_msra_fill=c2_msra_fill, c2_xavier_fill=c2_xavier_fill)
     _stub("detectron2.utils.registry", Registry=Registry)
     sys.modules["detectron2.layers"].Conv2d = nn.Conv2d
     if "alfred" not in sys.modules:
@@ -287,13 +309,7 @@ def load_bifpn():
     uses it) and get_norm("GN", C) is nn.GroupNorm(32, C) (detectron2/layers/batch_norm.py, published behaviour)."""
     from torch import nn
     load()
-    if "fvcore" not in sys.modules:
-        _stub("fvcore")
-    if "fvcore.nn" not in sys.modules:
-        _stub("fvcore.nn")
-    if "fvcore.nn.weight_init" not in sys.modules:
-        _stub("fvcore.nn.weight_init", c2_xavier_fill=lambda m: None, c2_msra_fill=lambda m: None)
-    sys.modules["fvcore.nn"].weight_init = sys.modules["fvcore.nn.weight_init"]
+    _fvcore()
     sys.modules["detectron2.layers"].Conv2d = nn.Conv2d
     sys.modules["detectron2.layers.batch_norm"].get_norm = lambda norm, c: nn.GroupNorm(32, c) if norm == "GN" else None
     _stub("detectron2.modeling.backbone.resnet", build_resnet_backbone=None)
