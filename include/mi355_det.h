@@ -611,6 +611,15 @@ int mi_sparseinst_mask_stats(const void* masks, int ldm, int P, const float* tar
 int mi_sparseinst_mask_grad(const void* masks, int ldm, int P, const float* targets, const int32_t* pairs, int K,
                             const float* stats, float c_bce, float c_dice, void* dmasks_zeroed, mi_stream_t s);
 
+/* ---- box utilities of the DETR path (yolov7/utils/boxes.py:28-37,85-122) ------------------------------------------
+ * mi_box_convert: n boxes [n][4] fp32; to_cxcywh 0 = box_cxcywh_to_xyxy, 1 = box_xyxy_to_cxcywh.
+ * mi_box_iou_pairwise: box_iou (iou and union, [n][m]) and, when giou != NULL, generalized_box_iou of xyxy boxes in the
+ * reference's operation order; *degenerate (may be NULL, caller zeroes it) gets bit 0 / 1 set when a box of the first /
+ * second set has x1 < x0 or y1 < y0 - the condition generalized_box_iou asserts on. */
+int mi_box_convert(const float* in, float* out, int64_t n, int to_cxcywh, mi_stream_t s);
+int mi_box_iou_pairwise(const float* boxes1, int n, const float* boxes2, int m, float* iou, float* uni, float* giou,
+                        int32_t* degenerate, mi_stream_t s);
+
 /* sizeof() of the public structs as compiled into the library (binding self-check): 0 mi_conv_desc, 1 mi_wgrad_desc,
  * 2 mi_wgrad_group, 3 mi_pack_job, 4 mi_bias_job, 5 mi_yolox_loss_desc, 6 mi_detr_loss_desc, 7 mi_sgd_seg, 8 mi_cmd,
  * 9 mi_conv_group, 10 mi_bn_job, 11 mi_bn_group; -1 for an unknown id */

@@ -261,6 +261,21 @@ def gold_yolox_iou():
     print("yolox_iou:", {k: float(np.abs(v).mean()) for k, v in res.items()})
 
 
+def gold_box_ops():
+    """the reference's DETR box utilities (utils/boxes.py:28-37 box_cxcywh_to_xyxy / box_xyxy_to_cxcywh, :85-122 box_iou /
+    generalized_box_iou) on seeded boxes incl. identical and disjoint pairs"""
+    r = ref_loader.load()
+    g = torch.Generator().manual_seed(77)
+    c = torch.rand(3, 37, 4, generator=g) * torch.tensor([1.0, 1.0, 0.4, 0.4]) + torch.tensor([0.0, 0.0, 0.01, 0.01])
+    xyxy = r.boxes.box_cxcywh_to_xyxy(c)
+    a, b = xyxy[0], torch.cat([xyxy[1][:23], xyxy[0][:2]])
+    iou, uni = r.boxes.box_iou(a, b)
+    res = dict(cxcywh=c.numpy(), xyxy=xyxy.numpy(), back=r.boxes.box_xyxy_to_cxcywh(xyxy).numpy(), a=a.numpy(), b=b.numpy(),
+               iou=iou.numpy(), union=uni.numpy(), giou=r.boxes.generalized_box_iou(a, b).numpy())
+    np.savez_compressed(os.path.join(OUT, "box_ops.npz"), **res)
+    print("box_ops:", {k: v.shape for k, v in res.items()})
+
+
 def gold_nms_family():
     """the reference's own softnms (linear / gaussian), cluster NMS and matrix NMS (meta_arch/utils.py:33-113,
     utils/solov2_utils.py:160-206) on seeded candidates"""
@@ -640,6 +655,7 @@ if __name__ == "__main__":
     gold_hungarian()
     gold_iou_v6()
     gold_yolox_iou()
+    gold_box_ops()
     gold_nms_family()
     gold_yolov6_loss()
     gold_bifpn()

@@ -448,3 +448,29 @@ def test_yolov6_compute_loss_against_reference_golden(golden_dir, name, kw):
     np.testing.assert_allclose(t.cpu().numpy(), g[name + "_targets_after"], rtol=1e-6, atol=1e-4)
     with pytest.raises(ValueError):
         ComputeLoss(iou_type="iou")
+
+
+def test_box_ops_hip_against_reference_golden(golden_dir):
+    """box_cxcywh_to_xyxy / box_xyxy_to_cxcywh / box_iou / generalized_box_iou (utils/boxes.py:28-37,85-122) as HIP
+    entries against the reference's own functions (golden box_ops.npz): the same float operation order -> the conversions
+    are bit-equal, the ratios equal to fp32 division rounding; degenerate boxes raise like the reference's assertion;
+    empty sets and [B, Q, 4] shapes pass through; host tensors are refused"""
+    from yolov7_d2_amd.modeling import box_cxcywh_to_xyxy, box_xyxy_to_cxcywh, box_iou, generalized_box_iou
+    g = np.load(os.path.join(golden_dir, "box_ops.npz"))
+    c = torch.from_numpy(g["cxcywh"])
+    xyxy = box_cxcywh_to_xyxy(c.to(DEV))
+    assert xyxy.shape == c.shape and np.array_equal(xyxy.cpu().numpy(), g["xyxy"])
+    assert np.array_equal(box_xyxy_to_cxcywh(xyxy).cpu().numpy(), g["back"])
+    a, b = torch.from_numpy(g["a"]).to(DEV), torch.from_numpy(g["b"]).to(DEV)
+    iou, uni = box_iou(a, b)
+    np.testing.assert_allclose(iou.cpu().numpy(), g["iou"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(uni.cpu().numpy(), g["union"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(generalized_box_iou(a, b).cpu().numpy(), g["giou"], rtol=1e-5, atol=1e-6)
+    assert generalized_box_iou(a[:0], b).shape == (0, 25) and box_iou(a, b[:0])[0].shape == (37, 0)
+    bad = a.clone(); bad[3, 2] = bad[3, 0] - 0.1
+    with pytest.raises(AssertionError):
+        generalized_box_iou(bad, b)
+    with pytest.raises(AssertionError):
+        generalized_box_iou(a, bad)
+    with pytest.raises(L.MI355Error):
+        box_iou(a.cpu(), b.cpu())

@@ -291,3 +291,15 @@ def test_golden_recipe_regenerates_every_fixture_in_one_run(golden_dir, tmp_path
         for k in a.files:
             assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype, (name, k)
             assert np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f"), (name, k)
+
+
+def test_detr_box_ops_oracle_against_reference_golden(golden_dir):
+    """oracle/detr_oracle.py's box utilities (what the matcher / criterion oracles are built on) against the reference's
+    own functions (utils/boxes.py:28-37,85-122; golden box_ops.npz)"""
+    import detr_oracle as DO
+    g = np.load(os.path.join(golden_dir, "box_ops.npz"))
+    assert np.array_equal(DO.box_cxcywh_to_xyxy(torch.from_numpy(g["cxcywh"])).numpy(), g["xyxy"])
+    a, b = torch.from_numpy(g["a"]), torch.from_numpy(g["b"])
+    iou, uni = DO.box_iou(a, b)
+    assert np.array_equal(iou.numpy(), g["iou"]) and np.array_equal(uni.numpy(), g["union"])
+    assert np.array_equal(DO.generalized_box_iou(a, b).numpy(), g["giou"])

@@ -232,6 +232,8 @@ _PROTOS = {
     "mi_yolox_onnx_layout": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),
     "mi_yolox_iou_loss": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "mi_pairwise_bbox_iou": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "mi_box_convert": (C.c_int, [_vp, _vp, _i64, _i, _vp]),
+    "mi_box_iou_pairwise": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "mi_bn_group_plan": (C.c_int, [_i, C.POINTER(mi_bn_job), _i, _vp, _i64, C.POINTER(mi_bn_group)]),
     "mi_bn_group_run": (C.c_int, [C.POINTER(mi_bn_group), _vp, _vp]),
     "mi_detr_set_loss_fwd": (C.c_int, [C.POINTER(mi_detr_loss_desc), _vp]),

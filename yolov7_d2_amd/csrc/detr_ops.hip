@@ -201,3 +201,66 @@ extern "C" int mi_lsap(const float* cost, const int32_t* tgt_off, int B, int Q, 
   MI_CHECK_LAUNCH("lsap");
   return MI_OK;
 }
+
+// ------------------------------------------------------------------ box utilities of the DETR path
+// box_cxcywh_to_xyxy / box_xyxy_to_cxcywh / box_iou / generalized_box_iou (yolov7/utils/boxes.py:28-37,85-122) as
+// elementwise / pairwise kernels in the reference's operation order (this file is built with -ffp-contract=off).  The
+// training step never calls them (matching cost and GIoU loss are fused in mi_hungarian_match / mi_detr_set_loss_*);
+// they serve target preparation, inference and callers of the reference's API.
+__global__ void box_convert_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, int to_cxcywh) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 b = ((const float4*)in)[i];
+  float4 o;
+  if (to_cxcywh) {   // (x0 + x1) / 2, (y0 + y1) / 2, x1 - x0, y1 - y0
+    o.x = (b.x + b.z) / 2.f; o.y = (b.y + b.w) / 2.f; o.z = b.z - b.x; o.w = b.w - b.y;
+  } else {           // x_c - 0.5 w, y_c - 0.5 h, x_c + 0.5 w, y_c + 0.5 h
+    o.x = b.x - 0.5f * b.z; o.y = b.y - 0.5f * b.w; o.z = b.x + 0.5f * b.z; o.w = b.y + 0.5f * b.w;
+  }
+  ((float4*)out)[i] = o;
+}
+extern "C" int mi_box_convert(const float* in, float* out, int64_t n, int to_cxcywh, mi_stream_t st) {
+  MI_REQUIRE(in && out && n >= 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0, "box_convert: null / unaligned");
+  if (n == 0) return MI_OK;
+  hipLaunchKernelGGL(box_convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)st, in, out, n, to_cxcywh);
+  MI_CHECK_LAUNCH("box_convert");
+  return MI_OK;
+}
+
+// iou[n][m], uni[n][m] (may be null), giou[n][m] (may be null); *degenerate |= 1 / 2 when a box of the first / second
+// set has x1 < x0 or y1 < y0 (what generalized_box_iou asserts on the host)
+__global__ void box_iou_pairwise_kernel(const float* __restrict__ b1, int n, const float* __restrict__ b2, int m,
+                                        float* __restrict__ iou, float* __restrict__ uni, float* __restrict__ giou,
+                                        int* __restrict__ degenerate) {
+  const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n * m) return;
+  const int i = (int)(idx / m), j = (int)(idx - (int64_t)i * m);
+  const float4 a = ((const float4*)b1)[i], b = ((const float4*)b2)[j];
+  if (degenerate) {
+    if (j == 0 && !(a.z >= a.x && a.w >= a.y)) atomicOr(degenerate, 1);
+    if (i == 0 && !(b.z >= b.x && b.w >= b.y)) atomicOr(degenerate, 2);
+  }
+  const float area1 = (a.z - a.x) * (a.w - a.y), area2 = (b.z - b.x) * (b.w - b.y);
+  const float w = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x), 0.f), h = fmaxf(fminf(a.w, b.w) - fmaxf(a.y, b.y), 0.f);
+  const float inter = w * h;
+  const float un = area1 + area2 - inter;
+  const float io = inter / un;
+  iou[idx] = io;
+  if (uni) uni[idx] = un;
+  if (giou) {
+    const float ew = fmaxf(fmaxf(a.z, b.z) - fminf(a.x, b.x), 0.f), eh = fmaxf(fmaxf(a.w, b.w) - fminf(a.y, b.y), 0.f);
+    const float ea = ew * eh;
+    giou[idx] = io - (ea - un) / ea;
+  }
+}
+extern "C" int mi_box_iou_pairwise(const float* boxes1, int n, const float* boxes2, int m, float* iou, float* uni, float* giou,
+                                   int32_t* degenerate, mi_stream_t st) {
+  MI_REQUIRE(n >= 0 && m >= 0, "box_iou_pairwise: sizes");
+  if (n == 0 || m == 0) return MI_OK;
+  MI_REQUIRE(boxes1 && boxes2 && iou && ((uintptr_t)boxes1 % 16) == 0 && ((uintptr_t)boxes2 % 16) == 0, "box_iou_pairwise: null / unaligned");
+  const int64_t tot = (int64_t)n * m;
+  hipLaunchKernelGGL(box_iou_pairwise_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)st, boxes1, n, boxes2, m,
+                     iou, uni, giou, degenerate);
+  MI_CHECK_LAUNCH("box_iou_pairwise");
+  return MI_OK;
+}
