@@ -614,6 +614,36 @@ def gold_sparseinst():
     print("sparseinst:", {k: float(v) for k, v in losses.items()}, [(i.tolist(), j.tolist()) for i, j in indices])
 
 
+def gold_sparseinst_inference():
+    """the reference's own SparseInst.inference (meta_arch/sparseinst.py:173-234, with its jit-scripted rescoring_mask
+    :24-27) on seeded decoder outputs (class logits, objectness, smooth mask-logit fields whose thresholded masks are
+    blobs; some queries below the class threshold): per image the kept queries' rescored scores, classes and the
+    thresholded masks at the requested output size - one image asks for an up-scaled, one for a down-scaled output, the
+    second is smaller than the padded batch"""
+    import types
+    meta = ref_loader.load_sparseinst_meta()
+    g = torch.Generator().manual_seed(909)
+    B, Q, NC, mh, mw = 2, 40, 80, 16, 20
+    max_shape = (128, 160)
+    coarse = torch.randn(B, Q, 4, 5, generator=g)
+    out = dict(pred_logits=torch.randn(B, Q, NC, generator=g) * 1.5 - 2.0, pred_scores=torch.randn(B, Q, 1, generator=g),
+               pred_masks=torch.nn.functional.interpolate(coarse, size=(mh, mw), mode="bicubic", align_corners=False) * 3.0)
+    image_sizes = [(128, 160), (104, 128)]
+    batched_inputs = [dict(height=200, width=250), dict(height=80, width=100)]
+    stub = types.SimpleNamespace(cls_threshold=0.3, mask_threshold=0.45)
+    with torch.no_grad():
+        results = meta.SparseInst.inference(stub, out, batched_inputs, max_shape, image_sizes)
+    res = dict(pred_logits=out["pred_logits"].numpy(), pred_scores=out["pred_scores"].numpy(), pred_masks=out["pred_masks"].numpy(),
+               max_shape=np.array(max_shape), image_sizes=np.array(image_sizes), out_sizes=np.array([[200, 250], [80, 100]]),
+               cls_threshold=np.float32(stub.cls_threshold), mask_threshold=np.float32(stub.mask_threshold))
+    for b, r in enumerate(results):
+        res[f"scores{b}"], res[f"classes{b}"] = r.scores.numpy(), r.pred_classes.numpy()
+        res[f"masks{b}"] = np.packbits(r.pred_masks.numpy().astype(np.uint8), axis=-1)
+        res[f"mask_area{b}"] = r.pred_masks.flatten(1).sum(1).numpy()
+    np.savez_compressed(os.path.join(OUT, "sparseinst_inference.npz"), **res)
+    print("sparseinst_inference:", [(len(r.scores), float(r.scores.min()), float(r.scores.max()), float(r.pred_masks.float().mean())) for r in results])
+
+
 def gold_transformer():
     """the reference's own Transformer (backbone/detr_backbone.py:25-65): 2 encoder + 2 decoder layers, d_model 256,
     8 heads, ffn 512, return_intermediate_dec, eval mode, fp32; post- and pre-norm"""
@@ -666,4 +696,5 @@ if __name__ == "__main__":
     gold_detr()
     gold_detr_meta()
     gold_sparseinst()
+    gold_sparseinst_inference()
     gold_set_criterion()

@@ -256,6 +256,23 @@ def load_sparseinst():
     return out
 
 
+def load_sparseinst_meta():
+    """meta_arch/sparseinst.py (the SparseInst META_ARCH: rescoring_mask, inference) loaded by path on top of
+    load_sparseinst().  detectron2.structures.Instances - un-vendored - is a plain attribute bag with image_size here
+    (its published behaviour as far as `inference` uses it: construct, set fields)."""
+    load_sparseinst()
+    load_detr()          # detectron2.structures / detectron2.modeling stubs, yolov7.modeling.meta_arch package
+
+    class Instances:
+        def __init__(self, image_size):
+            self.image_size = tuple(image_size)
+
+    sys.modules["detectron2.structures"].Instances = Instances
+    m = importlib.import_module("yolov7.modeling.meta_arch.sparseinst")
+    m.Instances = Instances
+    return m
+
+
 def load_nms_family():
     """the reference's NMS variants loaded by path: meta_arch/utils.py (softnms / cluster_nms / generalized_batched_nms) and
     utils/solov2_utils.py (matrix_nms).  Their un-vendored imports are stubbed: detectron2.layers.nms.batched_nms and

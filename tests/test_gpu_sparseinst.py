@@ -185,3 +185,28 @@ def test_sparseinst_meta_arch_step_and_inference():
         if len(inst):
             assert inst.pred_masks.shape[1:] == t["size"] and inst.pred_masks.dtype == torch.bool
             assert inst.scores.shape[0] == inst.pred_classes.shape[0] == inst.pred_masks.shape[0]
+
+
+def test_sparseinst_inference_against_reference_golden(golden_dir):
+    """SparseInst.inference (meta_arch/sparseinst.py:173-234 + rescoring_mask :24-27) against the REFERENCE'S OWN method run
+    by path on the same decoder outputs (golden sparseinst_inference.npz): which queries survive the class threshold and
+    their classes exactly, the maskness-rescored scores to fp32 rounding, the thresholded masks after the two bilinear
+    resizes (padded batch -> crop -> requested size; one image up-, one down-scaled) pixel for pixel up to the handful
+    whose interpolated value sits within rounding of the threshold"""
+    import types
+    g = np.load(os.path.join(golden_dir, "sparseinst_inference.npz"))
+    out = {k: torch.from_numpy(g[k]).to(DEV) for k in ("pred_logits", "pred_scores", "pred_masks")}
+    stub = types.SimpleNamespace(cls_threshold=float(g["cls_threshold"]), mask_threshold=float(g["mask_threshold"]))
+    batched_inputs = [dict(height=int(h), width=int(w)) for h, w in g["out_sizes"]]
+    image_sizes = [tuple(int(v) for v in s) for s in g["image_sizes"]]
+    res = M.SparseInst.inference(stub, out, batched_inputs, tuple(int(v) for v in g["max_shape"]), image_sizes)
+    assert len(res) == 2
+    for b, r in enumerate(res):
+        assert r.image_size == tuple(int(v) for v in g["out_sizes"][b])
+        assert np.array_equal(r.pred_classes.cpu().numpy(), g[f"classes{b}"])
+        np.testing.assert_allclose(r.scores.cpu().numpy(), g[f"scores{b}"], rtol=2e-5, atol=1e-7)
+        ref = np.unpackbits(g[f"masks{b}"], axis=-1)[..., : r.pred_masks.shape[-1]].astype(bool)
+        got = r.pred_masks.cpu().numpy()
+        assert got.shape == ref.shape and got.dtype == np.bool_
+        assert (got != ref).mean() < 1e-4, float((got != ref).mean())
+        assert np.abs(got.reshape(len(got), -1).sum(1) - g[f"mask_area{b}"]).max() <= 3
