@@ -35,27 +35,40 @@ def init_state_dict(depth=50, seed=0):
     return sd
 
 
-def _cn(sd, p, x, stride, pad, q):
+def _cn(sd, p, x, stride, pad, q, force=None):
     scale = sd[p + ".norm.weight"] * (sd[p + ".norm.running_var"] + EPS).rsqrt()
     shift = sd[p + ".norm.bias"] - sd[p + ".norm.running_mean"] * scale
-    return q(F.conv2d(q(x), q(sd[p + ".weight"] * scale.view(-1, 1, 1, 1)), shift, stride, pad))
+    y = q(F.conv2d(q(x), q(sd[p + ".weight"] * scale.view(-1, 1, 1, 1)), shift, stride, pad))
+    if force is not None and p in force:
+        # teacher forcing: the VALUE of this conv output becomes the given one (the ReLU gates and everything downstream
+        # then see the same forward state as the implementation under test), the gradient path stays the oracle's own
+        y = y + (force[p].to(y.dtype) - y).detach()
+    return y
 
 
-def forward(sd, x, depth=50, stride_in_1x1=False, quant=None):
-    """-> {"res2".."res5"}; quant: optional storage-rounding emulation (bf16) applied where the product stores"""
+def forward(sd, x, depth=50, stride_in_1x1=False, quant=None, force=None, start=None):
+    """-> {"res2".."res5"}; quant: optional storage-rounding emulation (bf16) applied where the product stores.
+    force: {conv name ("res3.0.conv1", "res4.2.shortcut", ...): tensor} pins those conv outputs (pre-ReLU) to given values.
+    start: (stage name, tensor) = begin at that stage with the tensor as its input (skips the stem and earlier stages)."""
     q = quant if quant is not None else (lambda t: t)
-    x = q(F.relu(_cn(sd, "stem.conv1", x, 2, 3, q)))
-    x = F.max_pool2d(x, 3, 2, 1)
     outs = {}
+    if start is None:
+        x = q(F.relu(_cn(sd, "stem.conv1", x, 2, 3, q, force)))
+        x = F.max_pool2d(x, 3, 2, 1)
     for i, nb in enumerate(BLOCKS[depth]):
+        if start is not None:
+            if f"res{i + 2}" != start[0] and f"res{i + 2}" not in outs and not outs:
+                continue
+        if start is not None and f"res{i + 2}" == start[0]:
+            x = start[1]
         for k in range(nb):
             p = f"res{i + 2}.{k}"
             stride = 2 if (k == 0 and i > 0) else 1
             s1, s3 = (stride, 1) if stride_in_1x1 else (1, stride)
-            out = q(F.relu(_cn(sd, p + ".conv1", x, s1, 0, q)))
-            out = q(F.relu(_cn(sd, p + ".conv2", out, s3, 1, q)))
-            out = _cn(sd, p + ".conv3", out, 1, 0, q)
-            sc = _cn(sd, p + ".shortcut", x, stride, 0, q) if (p + ".shortcut.weight") in sd else x
+            out = q(F.relu(_cn(sd, p + ".conv1", x, s1, 0, q, force)))
+            out = q(F.relu(_cn(sd, p + ".conv2", out, s3, 1, q, force)))
+            out = _cn(sd, p + ".conv3", out, 1, 0, q, force)
+            sc = _cn(sd, p + ".shortcut", x, stride, 0, q, force) if (p + ".shortcut.weight") in sd else x
             x = q(F.relu(out + sc))
         outs[f"res{i + 2}"] = x
     return outs
