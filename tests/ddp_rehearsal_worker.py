@@ -13,6 +13,7 @@ import torch
 import torch.distributed as dist
 
 import yolov7_d2_amd as M
+from yolov7_d2_amd import _lib as L
 import yolox_oracle as O
 from yolov7_d2_amd.engine import NativeTrainer
 
@@ -49,7 +50,7 @@ assert tr2.world == 2
 st2 = tr2.load_batch(imgs.cuda(), labels.cuda())
 res["bn_fused_under_ddp"] = bool(st2["plan"].bn_fused)
 res["segments"] = [[lo, hi, list(b) if b else None] for lo, hi, b in st2["segs"]]
-res["wgrad_groups"] = sum(1 for k in range(st2["plan"].bwd_cmds[1]) if M._lib.OPS[st2["plan"].bwd_cmds[0][k].op] == "WGRAD_GROUP")
+res["wgrad_groups"] = sum(1 for k in range(st2["plan"].bwd_cmds[1]) if L.OPS[st2["plan"].bwd_cmds[0][k].op] == "WGRAD_GROUP")
 for it in range(3):                   # eager, capture + replay, replay
     tr2.step(st2)
 tr2.stream.synchronize()

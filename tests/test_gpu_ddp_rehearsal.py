@@ -38,7 +38,7 @@ def test_two_ranks_on_one_device(tmp_path):
     assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
     for out in outs:
         r = json.load(open(out))
-        assert r["single_segments"] == 1                       # world 1: one backward list
+        assert r["single_segments"] <= 2                       # world 1: one backward list (+ a tail without gradients)
         assert len(r["segments"]) >= 3 and sum(1 for s in r["segments"] if s[2] is not None) == 3, r["segments"]
         assert r["wgrad_groups"] == 3 and r["graphs"] >= 3     # three staged weight-gradient groups, >= 3 captured segments
         assert r["bn_fused_under_ddp"] is False                # two-pass unless MI_BN_FUSED forces the grid-barrier kernel
