@@ -70,31 +70,16 @@ def _pmc_file():
 
 
 def pmc_traffic(kernel_class):
-    """HBM bytes per launch of a kernel class from the committed rocprofv3 PMC passes; None when absent"""
+    """fallback: HBM bytes per launch of a kernel class from the newest COMMITTED rocprofv3 PMC passes (another box,
+    possibly another BatchNorm form: labelled as such in traffic_source); None when absent"""
     import csv
-    import re
     path, _ = _pmc_file()
     if path is None:
         return None
-    rows = list(csv.DictReader(open(path)))
-    tot = lambda r: float(r["fetch_bytes_per_launch_x2corrected"]) + float(r["write_bytes_per_launch"])
-    if kernel_class.startswith("wgrad"):     # one WGRAD_GROUP command = all wgrad grids + the reduce grids
-        sel = [r for r in rows if "wgrad" in r["kernel"]]
-        return int(sum(tot(r) for r in sel)) if sel else None
-    m = re.match(r"(conv_igemm(?:_group)?_kernel)<KC=(\d+),BN=(\d+)>", kernel_class)
-    if m:
-        sel = [r for r in rows if re.search(r"%s<%s, %s," % (m.group(1), m.group(2), m.group(3)), r["kernel"])]
-        n = sum(int(r["launches"]) for r in sel)
-        return int(sum(tot(r) * int(r["launches"]) for r in sel) / n) if n else None
-    bn = {"BN_ACT_FWD": "bn_act_fwd", "BN_BWD_REDUCE": "bn_bwd_reduce", "BN_BWD_APPLY": "bn_bwd_apply",
-          "BN_BWD_FUSED": "bn_bwd_fused"}
-    for k, v in bn.items():
-        if kernel_class.startswith(k):
-            grouped = "grouped" in kernel_class
-            sel = [r for r in rows if v in r["kernel"] and (("group" in r["kernel"]) == grouped)]
-            n = sum(int(r["launches"]) for r in sel)
-            return int(sum(tot(r) * int(r["launches"]) for r in sel) / n) if n else None
-    return None
+    live = {}
+    for r in csv.DictReader(open(path)):
+        live[r["kernel"]] = (float(r["fetch_bytes_per_launch_x2corrected"]), float(r["write_bytes_per_launch"]), int(r["launches"]))
+    return class_traffic(kernel_class, live, 0)
 
 
 def bn_algorithmic(kind, C, npix, res=False, dres=False, dres_acc=False):
@@ -108,7 +93,78 @@ def bn_algorithmic(kind, C, npix, res=False, dres=False, dres_acc=False):
     return e * (3 + int(dres) * (1 + int(dres_acc)))
 
 
-def roofline_block(plan, iters=5):
+# the three forward / data-gradient convolution kernels (one class each: a template's <KC, BN, ...> instantiations are
+# ONE family - round 2 listed them separately and no convolution class ever came out dominant)
+CONV_FAMILY = {0: "conv_igemm_kernel (tile implicit GEMM: stride-2 3x3, K > 128 3x3, K = 1024 1x1, prediction convs)",
+               1: "c1s_kernel (streaming 1x1, persistent, weights in registers)",
+               2: "w3_kernel (weight-stationary 3x3, persistent)"}
+# kernel-name substrings of a class in a rocprofv3 trace
+PMC_MATCH = {"conv_igemm": ("conv_igemm",), "c1s_kernel": ("c1s_kernel",), "w3_kernel": ("w3_kernel",), "wgrad": ("wgrad",),
+             "BN_ACT_FWD": ("bn_act_fwd",), "BN_BWD_REDUCE": ("bn_bwd_reduce",), "BN_BWD_APPLY": ("bn_bwd_apply",),
+             "BN_BWD_FUSED": ("bn_bwd_fused",)}
+
+
+def _pmc_keys(kernel_class):
+    for k, v in PMC_MATCH.items():
+        if kernel_class.startswith(k):
+            return v, ("group" in kernel_class or "grouped" in kernel_class) if kernel_class.startswith("BN_") else None
+    return None, None
+
+
+def live_pmc_traffic(args):
+    """HBM bytes per dispatch of every kernel of THIS command on THIS box: two rocprofv3 passes (--pmc FETCH_SIZE, then
+    WRITE_SIZE: they do not fit one pass) over a short eager child run of bench.py; KB units, FETCH_SIZE x 2 on gfx950
+    (MI355X_MICROARCH.md, HBM section).  -> {kernel name: (fetch bytes, write bytes, dispatches)} or None (no rocprofv3 on
+    the box, or a pass failed: the committed CSV is the fallback)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get("MI_BENCH_LIVE_PMC", "1") == "0" or shutil.which("rocprofv3") is None:
+        return None
+    res = {}
+    tmp = tempfile.mkdtemp(prefix="mi_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--batch", str(args.batch), "--size", str(args.size)]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] != ctr:
+                    continue
+                e = res.setdefault(row["Kernel_Name"], [0.0, 0.0, 0, 0])
+                v = float(row["Counter_Value"]) * 1024.0
+                if ctr == "FETCH_SIZE":
+                    e[0] += 2.0 * v; e[2] += 1
+                else:
+                    e[1] += v; e[3] += 1
+        return {k: (f / max(nf, 1), w / max(nw, 1), max(nf, nw)) for k, (f, w, nf, nw) in res.items()}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def class_traffic(kernel_class, live, launches_per_step):
+    """HBM bytes per launch (= per command) of a class from the live passes"""
+    keys, grouped = _pmc_keys(kernel_class)
+    if live is None or keys is None:
+        return None
+    sel = {k: v for k, v in live.items() if any(s in k for s in keys) and (grouped is None or ("group" in k) == grouped)}
+    if not sel:
+        return None
+    if kernel_class.startswith("wgrad"):   # one command = one dispatch of every weight-gradient grid + the reduce grids
+        return int(sum(f + w for f, w, n in sel.values()))
+    n = sum(v[2] for v in sel.values())
+    return int(sum((f + w) * nn for f, w, nn in sel.values()) / n) if n else None
+
+
+def roofline_block(plan, iters=5, live=None):
     from yolov7_d2_amd import _lib as L
     groups = {}
     for which in ("fwd", "bwd"):
@@ -120,13 +176,11 @@ def roofline_block(plan, iters=5):
             ms = per[k][1]
             if op == "CONV":
                 d = descs[k]
-                dd = L.mi_conv_desc.from_buffer_copy(d)
-                L.lib().mi_conv2d_plan(C.byref(dd))
-                name = f"conv_igemm_kernel<KC={dd.KC},BN={dd.BN}>"
+                name = CONV_FAMILY[L.lib().mi_conv2d_route(C.byref(d))]
                 byt, fl = conv_algorithmic(d)
             elif op == "CONV_GROUP":
                 meta = C.cast(arr[k].p[0], C.POINTER(L.mi_conv_group)).contents
-                name = f"conv_igemm_group_kernel<KC={meta.KC},BN={meta.BN}>"
+                name = CONV_FAMILY[{-1: 1, -2: 2}.get(meta.KC, 0)]
                 byt = fl = 0
                 for d in descs[k]:
                     b1, f1 = conv_algorithmic(d)
@@ -175,7 +229,8 @@ def roofline_block(plan, iters=5):
                     achieved=round(tfs if mfma_bound else gbs, 1), peak=2500.0 if mfma_bound else 8000.0,
                     unit="TFLOP/s" if mfma_bound else "GB/s",
                     frac=round(tfs / 2500.0 if mfma_bound else gbs / 8000.0, 4),
-                    traffic=pmc_traffic(name), avg_launch_ms=round(avg_ms, 5), launches_per_step=g["launches"],
+                    traffic=(class_traffic(name, live, g["launches"]) if live is not None else pmc_traffic(name)),
+                    avg_launch_ms=round(avg_ms, 5), launches_per_step=g["launches"],
                     algorithmic_bytes_per_launch=int(g["bytes"] / g["launches"]),
                     algorithmic_flops_per_launch=int(g["flops"] / g["launches"]), hbm_GBps=round(gbs, 1),
                     hbm_frac_of_8000=round(gbs / 8000.0, 4), mfma_tflops=round(tfs, 1),
@@ -186,11 +241,30 @@ def roofline_block(plan, iters=5):
     ranked = sorted(cand.items(), key=lambda kv: -kv[1]["ms"])
     rl = describe(*ranked[0])
     _, commit = _pmc_file()
-    rl["traffic_source"] = ("rocprofv3 PMC passes of this command, profiles/*_hbm_traffic_pmc.csv @ commit %s" % commit
-                            if rl["traffic"] is not None else None)
-    rl["top3"] = [{k: d[k] for k in ("kernel", "bound", "achieved", "unit", "frac", "avg_launch_ms", "launches_per_step",
-                                      "share_of_step_kernel_time", "hbm_frac_of_8000", "mfma_frac_of_2500")}
-                  for d in (describe(*kv) for kv in ranked[:3])]
+    if rl["traffic"] is None:
+        rl["traffic_source"] = None
+    elif live is not None:
+        rl["traffic_source"] = "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run on this box (KB units, FETCH_SIZE x2)"
+    else:
+        rl["traffic_source"] = "committed CSV (no rocprofv3 pass on this box): profiles/*_hbm_traffic_pmc.csv @ commit %s" % commit
+    keys = ("kernel", "bound", "achieved", "unit", "frac", "avg_launch_ms", "launches_per_step",
+            "share_of_step_kernel_time", "hbm_frac_of_8000", "mfma_frac_of_2500", "traffic")
+    rl["top3"] = [{k: d[k] for k in keys} for d in (describe(*kv) for kv in ranked[:3])]
+    # family aggregates: all forward / data-gradient convolution launches together, all BatchNorm passes together
+    fam = {}
+    for name, g in groups.items():
+        f = ("conv fwd + dgrad (all three kernels)" if name in CONV_FAMILY.values() else
+             "BatchNorm fwd + bwd (all passes)" if name.startswith("BN_") else
+             "weight gradient" if name.startswith("wgrad") else None)
+        if f:
+            a = fam.setdefault(f, dict(ms=0.0, launches=0, bytes=0.0, flops=0.0))
+            for k in a:
+                a[k] += g[k]
+    rl["families"] = [dict(family=f, ms_per_step=round(a["ms"], 4), launches_per_step=a["launches"],
+                           hbm_GBps=round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1), hbm_frac_of_8000=round(a["bytes"] / (a["ms"] * 1e-3) / 8e12, 4),
+                           mfma_tflops=round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 1), mfma_frac_of_2500=round(a["flops"] / (a["ms"] * 1e-3) / 2.5e15, 4),
+                           share_of_step_kernel_time=round(a["ms"] / total_ms, 3))
+                      for f, a in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])]
     breakdown = {k: dict(ms=round(v["ms"], 4), launches=v["launches"],
                          GBps=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] and v["ms"] > 0 else None,
                          TFLOPs=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] and v["ms"] > 0 else None)
@@ -355,6 +429,22 @@ def bench_detr(args):
     print(json.dumps(out))
 
 
+def pmc_child(args):
+    """the workload of the live counter passes: the same plan, three eager steps (graphs hide the dispatches from the
+    counter collection on some ROCm builds), the BatchNorm backward form fixed to the parent's choice"""
+    import yolov7_d2_amd as M
+    from yolov7_d2_amd.engine import NativeTrainer
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    model = M.build_model(M.yolox_s_cfg(device="cuda:0"))
+    tr = NativeTrainer(model, lr=0.01 / 64 * args.batch, use_graph=False)
+    imgs, labels = synth_batch_device(args.batch, args.size, args.size, 1234, torch.device("cuda", 0))
+    st = tr.load_batch(imgs, labels)
+    for _ in range(3):
+        tr.step(st)
+    torch.cuda.synchronize()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -367,7 +457,10 @@ def main():
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-fed (PCIe-inclusive) measurement")
     ap.add_argument("--breakdown", type=str, default="", help="write the per-kernel-class breakdown JSON here")
     ap.add_argument("--config", type=str, default="yolox", help="yolox (the headline metric) | detr (BASELINE configs[3])")
+    ap.add_argument("--pmc-child", action="store_true", help="(internal) a few eager steps under rocprofv3 --pmc, no output")
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
     if args.config == "detr":
         return bench_detr(args)
 
@@ -452,7 +545,18 @@ def main():
     if not args.no_h2d:
         incl = h2d_inclusive(model, args, world, rank, dev)
     if rank == 0:
-        rl, breakdown, kernel_ms = roofline_block(st["plan"])
+        live = None
+        if world == 1:
+            # counters of THIS box (the committed CSV of an earlier box is only the fallback): the child must take the
+            # same BatchNorm backward form as this run
+            prev = os.environ.get("MI_BN_FUSED")
+            os.environ["MI_BN_FUSED"] = "1" if st["plan"].bn_fused else "0"
+            live = live_pmc_traffic(args)
+            if prev is None:
+                os.environ.pop("MI_BN_FUSED", None)
+            else:
+                os.environ["MI_BN_FUSED"] = prev
+        rl, breakdown, kernel_ms = roofline_block(st["plan"], live=live)
         out = {
             "metric": "images/sec training, YOLOX-s 640x640 bs=16/GPU", "value": round(value, 2),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -96,6 +96,8 @@ typedef struct mi_conv_desc {
 int mi_conv2d(const mi_conv_desc* d, mi_stream_t s);
 /* fills TH/TW/KC/BN/TPS if zero; returns number of pixel tiles or <0 */
 int mi_conv2d_plan(mi_conv_desc* d);
+/* the kernel family mi_conv2d runs for this descriptor: 0 tile kernel (conv_igemm), 1 mi_conv1x1_stream, 2 mi_conv3x3_ws */
+int mi_conv2d_route(const mi_conv_desc* d);
 
 /* several independent convolutions in ONE launch (the FPN levels of the head: the 40x40 / 20x20 launches are
  * latency-bound alone).  All jobs run the template configuration chosen for the job with the most output pixels, so

@@ -201,6 +201,7 @@ _PROTOS = {
     "mi_lsap": (C.c_int, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mi_conv2d_group_plan": (C.c_int, [C.POINTER(mi_conv_desc), _i, _vp, _i64, C.POINTER(mi_conv_group)]),
     "mi_conv2d_group_run": (C.c_int, [C.POINTER(mi_conv_group), _vp, _vp]),
+    "mi_conv2d_route": (C.c_int, [C.POINTER(mi_conv_desc)]),
     "mi_conv1x1_stream": (C.c_int, [C.POINTER(mi_conv_desc), _i, _vp]),
     "mi_conv3x3_ws": (C.c_int, [C.POINTER(mi_conv_desc), _i, _vp]),
     "mi_bn_act_bwd_fused": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _i, _vp, _i,

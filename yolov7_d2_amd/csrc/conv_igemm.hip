@@ -243,6 +243,16 @@ static int conv_fill(const mi_conv_desc* d, ConvK* k, ConvCfg* c, size_t* ldsByt
   return MI_OK;
 }
 
+// which kernel family mi_conv2d runs for this descriptor: 0 tile (conv_igemm), 1 streaming 1x1, 2 weight-stationary 3x3
+extern "C" int mi_conv2d_route(const mi_conv_desc* d) {
+  MI_REQUIRE(d, "conv2d_route: null");
+  C1Launch cl;
+  if (c1s_try_plan(d, 1, &cl)) return 1;
+  W3Launch wl;
+  if (w3_try_plan(d, 1, &wl)) return 2;
+  return 0;
+}
+
 extern "C" int mi_conv2d_plan(mi_conv_desc* d) {
   ConvK k;
   ConvCfg c;
