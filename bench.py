@@ -429,6 +429,148 @@ def bench_detr(args):
     print(json.dumps(out))
 
 
+def _time_conv(K, Cout, N, H, W, taps, iters=20):
+    """one forward convolution of the library alone (HIP events on the launch stream): (ms, flops, algorithmic bytes)"""
+    from yolov7_d2_amd import _lib as L
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(N, H, W, K, generator=g).to(dev, torch.bfloat16)
+    k = 3 if taps == 9 else 1
+    w = (torch.randn(Cout, K, k, k, generator=g) / (k * K ** 0.5)).to(dev)
+    img = torch.empty(taps * K * Cout, dtype=torch.bfloat16, device=dev)
+    L.check(L.lib().mi_pack_conv_weight(w.data_ptr(), Cout, K, k, k, img.data_ptr(), K, Cout, None, 0, 0, L.stream_ptr()), "pack")
+    y = torch.empty(N, H, W, Cout, dtype=torch.bfloat16, device=dev)
+    d = L.mi_conv_desc()
+    d.x, d.w, d.y, d.ldx, d.ldy = x.data_ptr(), img.data_ptr(), y.data_ptr(), K, Cout
+    d.N, d.H, d.W, d.outH, d.outW, d.gridH, d.gridW = N, H, W, H, W, H, W
+    d.in_stride = d.out_stride = 1
+    d.K8, d.Cout, d.CoutPad, d.ntaps = K // 8, Cout, Cout, taps
+    t = 0
+    for r in range(k):
+        for c in range(k):
+            d.tap_dy[t], d.tap_dx[t], d.tap_w[t] = r - k // 2, c - k // 2, r * k + c
+            t += 1
+    for _ in range(3):
+        L.check(L.lib().mi_conv2d(C.byref(d), L.stream_ptr()), "conv2d")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        L.check(L.lib().mi_conv2d(C.byref(d), L.stream_ptr()), "conv2d")
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters, 2.0 * N * H * W * Cout * K * taps, N * H * W * (K + Cout) * 2 + taps * K * Cout * 2
+
+
+def bench_sparseinst(args):
+    """--config sparseinst: BASELINE.json configs[4] on ONE GPU - SparseInst-R50 (InstanceContextEncoder + GroupIAMDecoder,
+    100 instance queries, FREEZE_AT 0) training step at 640 x 640: fwd + matcher + criterion (focal / dice / BCE / objectness)
+    + bwd + AdamW on bitmask targets.  roofline = the decoder's 3x3 256-channel convolution stack at 80 x 80 (eight such
+    layers per step: 4 instance-branch + 4 mask-branch) on the matrix cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import yolov7_d2_amd as M
+    from yolov7_d2_amd.d2shim import Instances
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    B = args.batch if args.batch != 16 else 8
+    S = args.size
+    model = M.build_model(M.sparse_inst_r50_giam_cfg(device="cuda:0"))
+    model.train()
+    g = torch.Generator().manual_seed(1234)
+    inputs = []
+    yy, xx = torch.meshgrid(torch.arange(S).float(), torch.arange(S).float(), indexing="ij")
+    for b in range(B):
+        n = int(torch.randint(1, 11, (1,), generator=g))
+        masks = torch.zeros(n, S, S)
+        for k in range(n):           # random rectangles / ellipses (SURVEY 8d: "bitmask GTs = random rectangles/ellipses")
+            cy, cx = float(torch.rand(1, generator=g)) * S, float(torch.rand(1, generator=g)) * S
+            ry, rx = 16 + float(torch.rand(1, generator=g)) * S * 0.25, 16 + float(torch.rand(1, generator=g)) * S * 0.25
+            masks[k] = (((yy - cy).abs() < ry) & ((xx - cx).abs() < rx)) if k % 2 == 0 else ((((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2) < 1)
+        inst = Instances((S, S), gt_classes=torch.randint(0, 80, (n,), generator=g).to(dev), gt_masks=masks.to(dev))
+        inputs.append(dict(image=torch.randint(0, 256, (3, S, S), generator=g).float().to(dev), instances=inst, height=S, width=S))
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=5e-5, weight_decay=0.05)
+
+    def step():
+        losses = model(inputs)
+        total = sum(losses.values())
+        opt.zero_grad(set_to_none=True)
+        total.backward()
+        opt.step()
+        return total
+
+    for _ in range(max(args.warmup, 2)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms, fl, byt = _time_conv(256, 256, B, S // 8, S // 8, 9)
+    tf = fl / (ms * 1e-3) / 1e12
+    out = {
+        "metric": "images/sec training, SparseInst-R50 640x640", "value": round(B * args.steps / dt, 2), "unit": "images/sec",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"SparseInst-R50 G-IAM (100 queries, FREEZE_AT 0) bs={B}/GPU {S}x{S}: fwd + matcher + criterion + "
+                               "bwd + AdamW (eager ops), random rectangle / ellipse bitmask targets",
+                   "final_loss": round(float(last), 4)},
+        "roofline": {"bound": "mfma", "kernel": f"conv_igemm_kernel, 3x3 256->256 at {S // 8}x{S // 8}, B={B} (the decoder's eight-layer stack)",
+                     "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": None,
+                     "avg_launch_ms": round(ms, 4), "algorithmic_flops_per_launch": int(fl), "algorithmic_bytes_per_launch": int(byt)},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_sparseinst(S)
+    print(json.dumps(out))
+
+
+def cpu_baseline_sparseinst(S, B=2, steps=2):
+    """config 5 on the host cores: detectron2's ResNet-50 as restated by oracle/resnet_oracle.py (d2 is un-vendored) feeding the
+    REFERENCE'S OWN InstanceContextEncoder / GroupIAMDecoder / SparseInstCriterion loaded by path where /root/reference exists
+    ("reference"); without that tree only the backbone restatement can run ("port": fwd + bwd of R50 + a mean loss)."""
+    import types
+    import resnet_oracle as RO
+    import ref_loader
+    torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("MI_CPU_BASELINE_THREADS", "32"))))
+    g = torch.Generator().manual_seed(7)
+    bb = RO.R50Module(50, ("res3", "res4", "res5"))
+    x = torch.randn(B, 3, S, S, generator=g)
+    kind, mods, crit = "port", None, None
+    if ref_loader.available():
+        import yolov7_d2_amd as M
+        si = ref_loader.load_sparseinst()
+        cfg = M.sparse_inst_r50_giam_cfg(device="cpu")
+        enc = si.encoder.InstanceContextEncoder(cfg, bb.output_shape())
+        dec = si.decoder.GroupIAMDecoder(cfg)
+        crit = si.loss.SparseInstCriterion(cfg, si.loss.SparseInstMatcher(cfg))
+        mods, kind = (enc, dec), "reference"
+
+        class _BM:
+            def __init__(self, t): self.tensor = t
+            def __len__(self): return self.tensor.shape[0]
+        tg = [dict(labels=torch.randint(0, 80, (3,), generator=g), masks=_BM((torch.rand(3, S, S, generator=g) > 0.7).float())) for _ in range(B)]
+    params = list(bb.parameters()) + ([p for m in mods for p in m.parameters()] if mods else [])
+    opt = torch.optim.AdamW(params, lr=5e-5)
+    ts = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        f = bb(x)
+        if mods:
+            loss = sum(crit(mods[1](mods[0](f)), tg, (S, S)).values())
+        else:
+            loss = sum(v.mean() for v in f.values())
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        ts.append(time.perf_counter() - t0)
+    t = sorted(ts[1:])[len(ts[1:]) // 2]
+    what = ("oracle R50 restatement + the reference's own encoder / decoder / criterion by path" if kind == "reference"
+            else "oracle/resnet_oracle.py backbone only (no reference tree on this box): an upper bound of the CPU rate")
+    return dict(value=round(B / t, 3), unit="images/sec", cores=torch.get_num_threads(), kind=kind,
+                sample=f"median of {steps} timed steps after 1 warm-up, B={B} {S}x{S} fp32 fwd+loss+bwd+AdamW through {what}")
+
+
 def pmc_child(args):
     """the workload of the live counter passes: the same plan, three eager steps (graphs hide the dispatches from the
     counter collection on some ROCm builds), the BatchNorm backward form fixed to the parent's choice"""
@@ -456,13 +598,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-fed (PCIe-inclusive) measurement")
     ap.add_argument("--breakdown", type=str, default="", help="write the per-kernel-class breakdown JSON here")
-    ap.add_argument("--config", type=str, default="yolox", help="yolox (the headline metric) | detr (BASELINE configs[3])")
+    ap.add_argument("--config", type=str, default="yolox", help="yolox (the headline metric) | detr (BASELINE configs[3]) | sparseinst (configs[4], one GPU)")
     ap.add_argument("--pmc-child", action="store_true", help="(internal) a few eager steps under rocprofv3 --pmc, no output")
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child(args)
     if args.config == "detr":
         return bench_detr(args)
+    if args.config == "sparseinst":
+        return bench_sparseinst(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -312,7 +312,11 @@ int mi_copy_bf16(const void* src, int lds_, void* dst, int ldd, int accumulate, 
                  mi_stream_t s);
 /* column sums of a bf16 NHWC view -> fp32 [C] (bias gradient of the prediction convs) */
 int mi_colsum_bf16(const void* x, int ldx, int64_t npix, int C, float* out, int accumulate, float* ws,
-                   mi_stream_t s); /* ws: >= 128*128 floats of scratch (two-stage, fixed summation order) */
+                   mi_stream_t s);
+/* the same for any channel count (a multiple of 8 readable) in one launch pair; ws: mi_colsum_wide_ws_bytes(C) bytes.
+ * Bias gradients of nn.Linear in the transformer (backbone/detr_backbone.py:140-230: 256 .. 2048 output channels). */
+int64_t mi_colsum_wide_ws_bytes(int C);
+int mi_colsum_bf16_wide(const void* x, int ldx, int64_t npix, int C, float* out, int accumulate, float* ws, mi_stream_t s); /* ws: >= 128*128 floats of scratch (two-stage, fixed summation order) */
 
 /* ---- YOLOX head: decode + SimOTA + losses ---------------------------------
  * replaces YOLOXHead.get_output_and_grid / get_losses / get_assignments /

@@ -187,6 +187,8 @@ _PROTOS = {
     "mi_spp_pool_bwd": (C.c_int, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mi_copy_bf16": (C.c_int, [_vp, _i, _vp, _i, _i, _i64, _i, _vp]),
     "mi_colsum_bf16": (C.c_int, [_vp, _i, _i64, _i, _vp, _i, _vp, _vp]),
+    "mi_colsum_bf16_wide": (C.c_int, [_vp, _i, _i64, _i, _vp, _i, _vp, _vp]),
+    "mi_colsum_wide_ws_bytes": (C.c_int64, [_i]),
     "mi_pack_conv_weights_batch": (C.c_int, [_vp, _i, _i, _i, _vp]),
     "mi_pack_jobs_layout": (C.c_int, [C.POINTER(mi_pack_job), _i]),
     "mi_yolox_loss_fwd": (C.c_int, [C.POINTER(mi_yolox_loss_desc), _vp]),

@@ -558,6 +558,58 @@ extern "C" int mi_colsum_bf16(const void* x, int ldx, int64_t npix, int C, float
   return MI_OK;
 }
 
+// any channel count in ONE launch pair (bias gradients of the transformer's Linear layers: 2048 channels were 32 x 2
+// launches of the 64-channel form above - 1100 launches per DETR step): grid.y = 64-channel chunk
+__global__ __launch_bounds__(256) void colsum_wide_stage1_kernel(const __bf16* __restrict__ x, int ldx, int64_t npix, int CP,
+                                                                 float* __restrict__ part) {
+  __shared__ float red[256 * 8];
+  const int tid = threadIdx.x, c0 = blockIdx.y * 64;
+  const int C8N = (CP - c0 >= 64) ? 8 : (CP - c0) / 8, PL = 256 / C8N;
+  const int c8 = tid % C8N, pl = tid / C8N;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  if (pl < PL)
+    for (int64_t p = (int64_t)blockIdx.x * PL + pl; p < npix; p += (int64_t)gridDim.x * PL) {
+      const bf16x8 v = *(const bf16x8*)(x + p * ldx + c0 + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[tid * 8 + e] = (pl < PL) ? s[e] : 0.f;
+  __syncthreads();
+  if (tid < C8N * 8) {
+    const int cc8 = tid >> 3, e = tid & 7;
+    float a = 0.f;
+    for (int q = 0; q < PL; ++q) a += red[(q * C8N + cc8) * 8 + e];
+    part[(size_t)blockIdx.x * CP + c0 + tid] = a;
+  }
+}
+__global__ __launch_bounds__(128) void colsum_wide_stage2_kernel(const float* __restrict__ part, int nblk, int CP, int C,
+                                                                 float* out, int accumulate) {
+  const int c = blockIdx.x * 128 + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f;
+  for (int b = 0; b < nblk; ++b) a += part[(size_t)b * CP + c];
+  out[c] = accumulate ? out[c] + a : a;
+}
+extern "C" int64_t mi_colsum_wide_ws_bytes(int C) { return (int64_t)128 * ((C + 7) / 8 * 8) * 4; }
+extern "C" int mi_colsum_bf16_wide(const void* x, int ldx, int64_t npix, int C, float* out, int accumulate, float* ws,
+                                   mi_stream_t st) {
+  MI_REQUIRE(x && out && ws && C > 0, "colsum_wide: null / C %d", C);
+  const int CP = (C + 7) / 8 * 8;
+  MI_REQUIRE(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0 && ldx >= CP, "colsum_wide: alignment / ld");
+  hipStream_t s = (hipStream_t)st;
+  int nblk = (int)((npix + 255) / 256);
+  if (nblk > 128) nblk = 128;
+  if (nblk < 1) nblk = 1;
+  hipLaunchKernelGGL(colsum_wide_stage1_kernel, dim3(nblk, (CP + 63) / 64), dim3(256), 0, s, (const __bf16*)x, ldx, npix, CP, ws);
+  MI_CHECK_LAUNCH("colsum_wide1");
+  hipLaunchKernelGGL(colsum_wide_stage2_kernel, dim3((C + 127) / 128), dim3(128), 0, s, ws, nblk, CP, C, out, accumulate);
+  MI_CHECK_LAUNCH("colsum_wide2");
+  return MI_OK;
+}
+
 // ---- SGD with momentum + weight decay over a flat arena (torch.optim.SGD semantics: dampening 0, no nesterov)
 __global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* __restrict__ g, float* m,
                                                   const mi_sgd_seg* __restrict__ segs, float momentum,

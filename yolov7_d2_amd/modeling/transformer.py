@@ -102,11 +102,9 @@ class _LinearFn(torch.autograd.Function):
         gb = None
         if has_bias:
             gbp = torch.empty(CoutP, dtype=torch.float32, device=dev)
-            cws = torch.empty(128 * 128, dtype=torch.float32, device=dev)
-            for c0 in range(0, CoutP, 64):   # column sums of the padded map in blocks of 64 / 32 channels
-                nc = min(64, CoutP - c0)
-                L.check(L.lib().mi_colsum_bf16(dy.data_ptr() + 2 * c0, CoutP, T, nc, gbp.data_ptr() + 4 * c0, 0,
-                                               cws.data_ptr(), L.stream_ptr()), "mi_colsum_bf16")
+            cws = torch.empty(128 * CoutP, dtype=torch.float32, device=dev)
+            L.check(L.lib().mi_colsum_bf16_wide(dy.data_ptr(), CoutP, T, CoutP, gbp.data_ptr(), 0, cws.data_ptr(), L.stream_ptr()),
+                    "mi_colsum_bf16_wide")
             gb = gbp[:Cout]
         return dx, gw, gb
 

@@ -148,11 +148,8 @@ def _colsum(dyh, C_):
     CP = dyh.shape[-1]
     T = dyh.numel() // CP
     out = torch.empty(CP, dtype=torch.float32, device=dyh.device)
-    ws = torch.empty(128 * 128, dtype=torch.float32, device=dyh.device)
-    for c0 in range(0, CP, 64):
-        nc = min(64, CP - c0)
-        L.check(L.lib().mi_colsum_bf16(dyh.data_ptr() + 2 * c0, CP, T, nc, out.data_ptr() + 4 * c0, 0, ws.data_ptr(),
-                                       L.stream_ptr()), "mi_colsum_bf16")
+    ws = torch.empty(128 * CP, dtype=torch.float32, device=dyh.device)
+    L.check(L.lib().mi_colsum_bf16_wide(dyh.data_ptr(), CP, T, CP, out.data_ptr(), 0, ws.data_ptr(), L.stream_ptr()), "mi_colsum_bf16_wide")
     return out[:C_]
 
 
