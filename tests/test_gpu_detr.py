@@ -91,7 +91,11 @@ def _mha_ref(q, k, v, mask, H):
 
 
 @pytest.mark.parametrize("Lq,Lk,B,masked", [(100, 100, 2, False), (100, 1050, 2, True), (1050, 1050, 1, True), (37, 65, 3, True),
-                                            (64, 32, 1, False)])
+                                            (64, 32, 1, False),
+                                            # block shapes of the v2 forward: 8 waves + 1 group split four ways, 4 + 2 split,
+                                            # 4 + 1 split, every group split over 8 waves, 12 full waves
+                                            (1050, 1050, 4, True), (700, 1050, 4, True), (600, 700, 4, False), (100, 1050, 4, True),
+                                            (1050, 600, 16, True)])
 def test_mha_core_fwd_bwd(Lq, Lk, B, masked):
     from yolov7_d2_amd.modeling import mha_core
     H, E = 8, 256

@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from yolov7_d2_amd.modeling import mha_core
-for (Lq, Lk, B) in ((1050, 1050, 16), (100, 1050, 16), (100, 100, 16)):
+for (Lq, Lk, B) in ((1050, 1050, 4), (1050, 1050, 16), (100, 1050, 4), (100, 100, 4)):
     H, E = 8, 256
     q = torch.randn(Lq, B, E, device="cuda", dtype=torch.bfloat16, requires_grad=True)
     k = torch.randn(Lk, B, E, device="cuda", dtype=torch.bfloat16, requires_grad=True)

@@ -21,6 +21,7 @@
 //   dK, dV      :  S tile = Q_tile (A) x K^T (B) -> lane (t = key, g) holds queries 4g..4g+3, again directly the
 //                   A fragment of dV += P^T dO and dK += dS^T Q.
 // A wave owns 16 queries (forward, dQ) or 16 keys (dK/dV); a block = 4 waves shares the K/V (or Q/dO) tiles in LDS.
+#include <stdlib.h>
 #include <string.h>
 #include "common.h"
 
@@ -187,6 +188,169 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaK p) {
   }
   if (g == 0 && myq < p.Lq && p.lse)
     p.lse[((size_t)b * p.H + h) * p.Lq + myq] = (l_run > 0.f) ? m_run + __logf(l_run) : -INFINITY;
+}
+
+// ------------------------------------------------------------------ forward, version 2
+// The first kernel crossed a block barrier and staged 2 + 2 KB for every 32 keys (33 barriers at L = 1050), gave each wave
+// 16 queries of a 64-query block (544 blocks of 4 waves) and ran one softmax update - two cross-lane maxima, two sums, four
+// broadcasts of the rescale factor - per 4 tiny MFMAs: 92 TFLOP/s kernel-only at B = 4, L = 1050.  With head_dim 32 the
+// matrix cores are NOT the limit (128 flops per score = 0.13 SIMD cycles): the kernel is bound by vector instructions per
+// score (max, fma, exp2, bf16 pack = 3.5 issue slots of 4 cycles per 64 scores = 0.22 cycles per score at best) and by how
+// the 16-query groups fall on the 1024 SIMDs.  Hence
+//   * a block is nwv waves x 16 queries, nwv chosen so that the grid is ONE round of blocks (L = 1050, B x H = 32:
+//     9 waves = 144 queries, 8 blocks per head, 256 blocks on 256 CUs);
+//   * K / V stream through LDS in chunks of 128 keys, double-buffered, ONE barrier per chunk; the next chunk's global
+//     loads are issued (unconditionally - no select on the loaded value) before the chunk's compute and written to LDS
+//     after it, so that only the LDS store waits for them;
+//   * one softmax step per chunk: 32 scores per lane in one basic block.  Per score: half a max3, one fma (scale and
+//     reference maximum folded: exp2(s * c - m * c)), one exp2, half a bf16 pack.  The key-padding mask is a 0 / -inf bias
+//     row staged with the chunk that enters the score MFMA as its accumulator input; the normaliser l = P x ones is a third
+//     MFMA accumulating exactly the bf16 weights that entered O (consistent normalisation; with dropout it is summed on
+//     the vector unit before the drop instead);
+//   * the reference maximum is lazy (see below): the common step has no cross-lane traffic.
+// (Measured and dropped: sharing a 16-query group between four waves by chunk to even out the SIMDs - the waves run in
+// lockstep with the chunk barriers, so the split group is still processed serially.)
+#define MHA2_KC 128
+template <bool DROP>
+__global__ __launch_bounds__(768) void mha_fwd2_kernel(const MhaK p) {
+  __shared__ __attribute__((aligned(16))) char Ks[2 * 8192], Vs[2 * 8192];
+  __shared__ __attribute__((aligned(16))) float Mb[2][MHA2_KC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nth = blockDim.x;
+  const int t = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+  const int q0 = blockIdx.x * (nth >> 2) + wave * 16;      // nth / 64 waves x 16 queries
+  const int myq = q0 + t;
+  bf16x8 qf = {};
+  if (myq < p.Lq) qf = *(const bf16x8*)(p.q + ((size_t)myq * p.B + b) * p.E + h * MHA_D + g * 8);
+  f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  f32x4 lacc = {0.f, 0.f, 0.f, 0.f};                       // normaliser, same layout as oacc (every column alike)
+  float m_run = -INFINITY, neg_m = 0.f, l_part = 0.f;      // reference maximum of query t in raw score units; -m * sc2
+  const float sc2 = p.scale * 1.44269504088896341f;        // raw score -> exp2 domain
+  const float slack = 8.f / sc2;
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.f;
+  const int nchunks = (p.Lk + MHA2_KC - 1) / MHA2_KC;
+  // this thread's share of a chunk: two 16-byte pieces of K and of V (512 pieces each; a block of more than 256 threads
+  // repeats the last piece) and one mask byte.  Loads are unconditional - rows past the last key repeat it (finite
+  // values; their bias is -inf, their weight exactly 0) - so that nothing but the LDS store waits for them.
+  u32x4 kreg[2], vreg[2];
+  unsigned char mreg = 0;
+  const uint8_t* const mrow = p.mask ? p.mask + (size_t)b * p.Lk : (const uint8_t*)p.k;
+  auto load_chunk = [&](int c) {
+    const int k0 = c * MHA2_KC;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int idx = tid + u * nth;
+      idx = idx < 511 ? idx : 511;
+      int row = k0 + (idx >> 2);
+      row = row < p.Lk ? row : p.Lk - 1;
+      const size_t off = ((size_t)row * p.B + b) * p.E + h * MHA_D + (idx & 3) * 8;
+      kreg[u] = *(const u32x4*)(p.k + off);
+      vreg[u] = *(const u32x4*)(p.v + off);
+    }
+    const int key = k0 + (tid & (MHA2_KC - 1));
+    mreg = mrow[key < p.Lk ? key : p.Lk - 1];
+  };
+  auto store_chunk = [&](int c) {
+    const int buf = c & 1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int idx = tid + u * nth;
+      idx = idx < 511 ? idx : 511;
+      const int row = idx >> 2;
+      const int o = buf * 8192 + (row >> 5) * 2048 + tile_off(row & 31, idx & 3);
+      *(u32x4*)(Ks + o) = kreg[u];
+      *(u32x4*)(Vs + o) = vreg[u];
+    }
+    const int key = c * MHA2_KC + (tid & (MHA2_KC - 1));
+    Mb[buf][tid & (MHA2_KC - 1)] = (key >= p.Lk || (p.mask && mreg)) ? -INFINITY : 0.f;
+  };
+  load_chunk(0);
+  store_chunk(0);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();   // chunk c is visible; the other buffer is no longer read
+    const int cur = c & 1;
+    if (c + 1 < nchunks) load_chunk(c + 1);
+    const int k0 = c * MHA2_KC;
+    // S^T: eight 16-key x 16-query tiles, the mask bias (0 / -inf) entering as the accumulator input;
+    // lane (t = query, g): s[a][r] = raw score of key k0 + 16 a + 4 g + r.  (Keys past Lk: bias -inf, weight 0.)
+    f32x4 s[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const bf16x8 kf = frag_rows(Ks + cur * 8192 + (a >> 1) * 2048, a & 1, t, g);
+      const f32x4 bias = *(const f32x4*)(&Mb[cur][16 * a + 4 * g]);
+      s[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, bias, 0, 0, 0);
+    }
+    float mx = fmaxf(s[0][0], s[0][1]);
+#pragma unroll
+    for (int e = 2; e < 32; e += 2) mx = fmaxf(fmaxf(mx, s[e >> 2][e & 3]), s[e >> 2][(e & 3) + 1]);   // v_max3_f32
+    // the reference maximum is LAZY: it moves only when some score of the wave exceeds it by more than `slack` (exp2
+    // arguments stay <= 8: p <= 256, inside bf16's exponent range and harmless in the fp32 sums); the common step then
+    // has no cross-lane traffic at all.  O and l carry the same factor, so the result does not depend on it.
+    if (__any(mx > m_run + slack)) {
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f((m_run - m_new) * sc2);
+      m_run = m_new;
+      neg_m = (m_new == -INFINITY) ? 0.f : -m_new * sc2;
+      if constexpr (DROP) l_part *= alpha;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ar = __shfl(alpha, 4 * g + r, 64);
+        oacc[0][r] *= ar;
+        oacc[1][r] *= ar;
+        lacc[r] *= ar;
+      }
+    }
+    // O += P (A: lane (t = query, g), 8 key slots of a 32-key tile) x V (B: transpose read, d group j)
+#pragma unroll
+    for (int t2 = 0; t2 < 4; ++t2) {
+      bf16x8 pf;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[2 * t2 + (e >> 2)][e & 3], sc2, neg_m));
+        if constexpr (DROP) {
+          l_part += pe;    // the softmax normaliser is taken BEFORE the dropout, as F.multi_head_attention_forward does
+          pe *= mha_keep(p, b, h, myq, k0 + 32 * t2 + 16 * (e >> 2) + 4 * g + (e & 3));
+        }
+        pf[e] = (__bf16)pe;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16x8 vf = frag_cols(Vs + cur * 8192 + t2 * 2048, j, t, g);
+        oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, oacc[j], 0, 0, 0);
+      }
+      if constexpr (!DROP) lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, ones, lacc, 0, 0, 0);
+    }
+    if (c + 1 < nchunks) store_chunk(c + 1);
+  }
+  if constexpr (DROP) {   // normaliser of query 4g + r in the O layout
+    l_part += __shfl_xor(l_part, 16, 64);
+    l_part += __shfl_xor(l_part, 32, 64);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lacc[r] = __shfl(l_part, 4 * g + r, 64);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qq = q0 + 4 * g + r;
+    const float inv = lacc[r] > 0.f ? 1.f / lacc[r] : 0.f;
+    if (qq < p.Lq) {
+      __bf16* op = p.o + ((size_t)qq * p.B + b) * p.E + h * MHA_D;
+      op[t] = (__bf16)(oacc[0][r] * inv);
+      op[16 + t] = (__bf16)(oacc[1][r] * inv);
+    }
+  }
+  // lse of query t: its normaliser sits in lanes of group t >> 2, register t & 3
+  float lq = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float v = __shfl(lacc[r], (t >> 2) * 16, 64);
+    lq = (t & 3) == r ? v : lq;
+  }
+  if (g == 0 && myq < p.Lq && p.lse)
+    p.lse[((size_t)b * p.H + h) * p.Lq + myq] = (lq > 0.f) ? (m_run * sc2 + log2f(lq)) * 0.69314718055994531f : -INFINITY;
 }
 
 // ------------------------------------------------------------------ backward
@@ -377,8 +541,27 @@ extern "C" int mi_mha_fwd_dropout(const void* q, const void* k, const void* v, c
   if (rc) return rc;
   p.q = (const __bf16*)q; p.k = (const __bf16*)k; p.v = (const __bf16*)v; p.mask = key_padding_mask;
   p.o = (__bf16*)o; p.lse = lse; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.E = E; p.scale = scale;
-  hipLaunchKernelGGL(mha_fwd_kernel, dim3(mi_cdiv(Lq, 64), B * H), dim3(256), 0, (hipStream_t)st, p);
-  MI_CHECK_LAUNCH("mha_fwd");
+  static const int v2 = getenv("MI_MHA_V2") ? atoi(getenv("MI_MHA_V2")) : 1;
+  if (!v2) {
+    hipLaunchKernelGGL(mha_fwd_kernel, dim3(mi_cdiv(Lq, 64), B * H), dim3(256), 0, (hipStream_t)st, p);
+    MI_CHECK_LAUNCH("mha_fwd");
+    return MI_OK;
+  }
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+  }
+  // waves (16 queries each) per block: one round of blocks on the device, 4 .. 12 waves
+  const int gq = mi_cdiv(Lq, 16);
+  const long groups = (long)gq * B * H;
+  int nwv = (int)((groups + ncu - 1) / ncu);
+  nwv = nwv < 4 ? 4 : (nwv > 12 ? 12 : nwv);
+  if (nwv > gq) nwv = gq < 4 ? 4 : gq;
+  const dim3 grid(mi_cdiv(gq, nwv), B * H), blk(nwv * 64);
+  if (p.drop_thr) hipLaunchKernelGGL(mha_fwd2_kernel<true>, grid, blk, 0, (hipStream_t)st, p);
+  else hipLaunchKernelGGL(mha_fwd2_kernel<false>, grid, blk, 0, (hipStream_t)st, p);
+  MI_CHECK_LAUNCH("mha_fwd2");
   return MI_OK;
 }
 
