@@ -156,6 +156,10 @@ def class_traffic(kernel_class, live, launches_per_step):
     if live is None or keys is None:
         return None
     sel = {k: v for k, v in live.items() if any(s in k for s in keys) and (grouped is None or ("group" in k) == grouped)}
+    if kernel_class.startswith(("c1s_kernel", "w3_kernel")):
+        # the last template argument is the MODE: 3 = the launches that carry their BatchNorm phase
+        fused = "BatchNorm/SiLU phase" in kernel_class
+        sel = {k: v for k, v in sel.items() if (", 3>(" in k) == fused}
     if not sel:
         return None
     if kernel_class.startswith("wgrad"):   # one command = one dispatch of every weight-gradient grid + the reduce grids
@@ -185,6 +189,11 @@ def roofline_block(plan, iters=5, live=None):
                 for d in descs[k]:
                     b1, f1 = conv_algorithmic(d)
                     byt += b1; fl += f1
+                fused = getattr(plan.fwd_list[k], "bn_jobs", None) if which == "fwd" else None
+                if fused:   # MODE 3: the BatchNorm + SiLU (+ shortcut) pass is the launch's second phase
+                    name += " + BatchNorm/SiLU phase"
+                    for j in fused:
+                        byt += bn_algorithmic(0, j.C, j.npix, bool(j.res))
             elif op == "BN_GROUP":
                 kind = arr[k].i[0]
                 name, byt, fl = ("BN_ACT_FWD", "BN_BWD_REDUCE", "BN_BWD_APPLY", "BN_BWD_FUSED")[kind] + " (grouped)", 0, 0
@@ -253,7 +262,8 @@ def roofline_block(plan, iters=5, live=None):
     # family aggregates: all forward / data-gradient convolution launches together, all BatchNorm passes together
     fam = {}
     for name, g in groups.items():
-        f = ("conv fwd + dgrad (all three kernels)" if name in CONV_FAMILY.values() else
+        f = ("conv fwd + dgrad (all three kernels; fused launches include their BatchNorm phase)"
+             if any(name.startswith(v) for v in CONV_FAMILY.values()) else
              "BatchNorm fwd + bwd (all passes)" if name.startswith("BN_") else
              "weight gradient" if name.startswith("wgrad") else None)
         if f:

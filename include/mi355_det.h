@@ -109,12 +109,29 @@ typedef struct mi_conv_group {
   int32_t njobs, nblocks, lds_bytes;
   int32_t KC, BN, TPIX, TPS, EPI;
   int64_t starts_off, table_bytes;
-  int64_t priv[136];        /* KC == -1: the jobs are 1x1 convolutions of one input and run as ONE streaming launch
+  int64_t priv[288];        /* KC == -1: the jobs are 1x1 convolutions of one input and run as ONE streaming launch
                                (mi_conv1x1_stream); KC == -2: 3x3 K -> K convolutions as ONE weight-stationary launch
                                (mi_conv3x3_ws); the launch record lives here, no device table is read */
 } mi_conv_group;
 int mi_conv2d_group_plan(const mi_conv_desc* descs, int n, void* table_host, int64_t table_cap, mi_conv_group* meta);
 int mi_conv2d_group_run(const mi_conv_group* meta, const void* table_dev, mi_stream_t s);
+
+/* Convolution + train-mode BatchNorm + activation (+ residual) as ONE launch: the whole BaseConv.forward
+ * (backbone/layers/wrappers.py:76-83) and the Bottleneck shortcut (:119-123).  descs[j] must carry stats_acc and bn[j]
+ * must be exactly the mi_bn_act_fwd that would follow it (y / ldy / C / acc / nslots / npix == count == N*H*W of the
+ * conv's output).  When the convolutions run on the streaming 1x1 kernel (<= 2 convs of one input) or on the weight-
+ * stationary 3x3 kernel (<= 8 jobs), the BatchNorm pass is the second phase of the SAME persistent launch behind a grid
+ * barrier: every block applies scale / shift / SiLU to the output pieces it stored itself.  Bit-identical to
+ * mi_conv2d followed by mi_bn_act_fwd.
+ * _plan: returns 1 and fills meta (run it with mi_conv2d_group_run(meta, NULL, s)) when such a launch exists, 0 when the
+ *        caller has to keep the two launches (tile-kernel shapes, MI_CONV_BN_FUSE=0), < 0 on bad arguments.
+ * _fwd:  plan + run; MI_EINVAL when no fused launch exists (it never falls back).
+ * mi_conv_bn_barrier_status: bit 0 / 1 set when a block of a streaming / weight-stationary launch ever gave up waiting at
+ *        the grid barrier (its outputs were written as NaN); synchronises the device. */
+struct mi_bn_job;
+int mi_conv2d_bn_plan(const mi_conv_desc* descs, const struct mi_bn_job* bn, int n, mi_conv_group* meta);
+int mi_conv2d_bn_fwd(const mi_conv_desc* descs, const struct mi_bn_job* bn, int n, mi_stream_t s);
+int mi_conv_bn_barrier_status(uint32_t* flags);
 
 /* streaming 1x1 convolution (csrc/conv1x1_stream.h): n >= 1 bf16 1x1 stride-1 convolutions that read the SAME input
  * view (x, ldx, N, H, W, K8 equal; K in {32, 64, 128, 256, 512}; Cout == CoutPad, a multiple of 32; no bias; all with

@@ -54,7 +54,7 @@ class mi_detr_loss_desc(C.Structure):
 class mi_conv_group(C.Structure):
     _fields_ = [("njobs", C.c_int32), ("nblocks", C.c_int32), ("lds_bytes", C.c_int32), ("KC", C.c_int32),
                 ("BN", C.c_int32), ("TPIX", C.c_int32), ("TPS", C.c_int32), ("EPI", C.c_int32),
-                ("starts_off", C.c_int64), ("table_bytes", C.c_int64), ("priv", C.c_int64 * 136)]
+                ("starts_off", C.c_int64), ("table_bytes", C.c_int64), ("priv", C.c_int64 * 288)]
 
 
 class mi_bn_job(C.Structure):
@@ -204,6 +204,9 @@ _PROTOS = {
     "mi_conv2d_group_plan": (C.c_int, [C.POINTER(mi_conv_desc), _i, _vp, _i64, C.POINTER(mi_conv_group)]),
     "mi_conv2d_group_run": (C.c_int, [C.POINTER(mi_conv_group), _vp, _vp]),
     "mi_conv2d_route": (C.c_int, [C.POINTER(mi_conv_desc)]),
+    "mi_conv2d_bn_plan": (C.c_int, [C.POINTER(mi_conv_desc), C.POINTER(mi_bn_job), _i, C.POINTER(mi_conv_group)]),
+    "mi_conv2d_bn_fwd": (C.c_int, [C.POINTER(mi_conv_desc), C.POINTER(mi_bn_job), _i, _vp]),
+    "mi_conv_bn_barrier_status": (C.c_int, [C.POINTER(C.c_uint32)]),
     "mi_conv1x1_stream": (C.c_int, [C.POINTER(mi_conv_desc), _i, _vp]),
     "mi_conv3x3_ws": (C.c_int, [C.POINTER(mi_conv_desc), _i, _vp]),
     "mi_bn_act_bwd_fused": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _vp, _i, _vp, _i,

@@ -19,6 +19,7 @@
 // astronomically rare rounding ties.  All kernels are HBM streams: 16-byte (8 x bf16) accesses, fp32 math.
 #include <string.h>
 #include "common.h"
+#include "conv_bn.h"
 
 #define BN_MAXC 2048
 // accumulator layout: [slot][CA][2] with CA = C rounded up to 32 - the CoutPad the conv epilogue adds its tile sums with
@@ -477,7 +478,6 @@ extern "C" int mi_bn_act_bwd_apply(const void* da, int ldda, const void* y, int 
 // adds the block's channel sums to the fp64 accumulators, crosses a grid-wide barrier (agent-scope atomics on a counter
 // + generation word), reads the finished sums and writes dy from the registers: 3 tensor passes and one launch.  Items
 // beyond the register capacity (the 160x160 / 320x320 maps) are streamed in both phases like the two-pass kernels do.
-#define BN_FUS_SPIN_LIMIT (1 << 22)
 struct BnFusK {
   const __bf16* da;
   const __bf16* y;
@@ -496,52 +496,6 @@ struct BnFusK {
   int64_t npix;
   double inv_count;
 };
-
-// Grid-wide barrier over nb resident blocks.  Agent-scope atomics are performed memory-side, one after the other per
-// address (~0.1 us each: 512 arrivals on ONE counter cost ~50 us, measured), so arrivals go through a two-level tree -
-// MI_BN_BAR_GROUPS group counters (block % groups), whose last arrivers meet on the top counter - and every group waits
-// on its own generation word; each word sits on its own 256-byte line.  Word layout (uint32):
-//   [0] top arrivals  [2] give-up flag  [64 * (1 + g)] generation of group g  [64 * (1 + G + g)] arrivals of group g
-#define BN_BAR_G MI_BN_BAR_GROUPS
-__device__ __forceinline__ unsigned* bn_bar_gen(unsigned* bar, int g) { return bar + 64 * (1 + g); }
-__device__ __forceinline__ unsigned* bn_bar_cnt(unsigned* bar, int g) { return bar + 64 * (1 + BN_BAR_G + g); }
-// No cache maintenance: an agent-scope acquire / release (or __threadfence) writes back and invalidates the XCD's whole L2
-// - issued by hundreds of polling blocks that stalls every block still streaming (measured: +90 us per launch).  It is not
-// needed here: the only data that crosses blocks are the fp64 sums, added by memory-side atomics that have been
-// acknowledged when the block passes its __syncthreads (workgroup release = s_waitcnt vmcnt(0)), and read back after the
-// barrier by agent-scope atomic loads, which bypass the non-coherent caches.
-// *gave_up (LDS) = 1 when this block's wait timed out: its sums are incomplete and it must poison what it writes.
-__device__ __forceinline__ void bn_grid_barrier(unsigned* bar, const unsigned gen0, const int bid, const int nb, int* gave_up) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    *gave_up = 0;
-    const int G = nb < BN_BAR_G ? nb : BN_BAR_G;
-    const int g = bid % G;
-    const unsigned gsize = (unsigned)((nb - g + G - 1) / G);
-    bool released = false;
-    if (__hip_atomic_fetch_add(bn_bar_cnt(bar, g), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1u) {
-      __hip_atomic_store(bn_bar_cnt(bar, g), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)G - 1u) {
-        __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int q = 0; q < G; ++q)
-          __hip_atomic_fetch_add(bn_bar_gen(bar, q), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        released = true;
-      }
-    }
-    if (!released) {
-      int spins = 0;
-      while (__hip_atomic_load(bn_bar_gen(bar, g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen0) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > BN_FUS_SPIN_LIMIT) {  // a block that never became resident: report instead of hanging the GPU
-          __hip_atomic_store(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          *gave_up = 1;
-          break;
-        }
-      }
-    }
-  }
-  __syncthreads();
-}
 
 // MODE 0: da and y stay in registers as loaded (bf16, 8 VGPRs per item, 16 items); phase 2 recomputes the activation
 //         gradient.  MODE 1: dz stays in fp32 registers and y in LDS (14 items, 72 KB per block); phase 2 is 5 flops per

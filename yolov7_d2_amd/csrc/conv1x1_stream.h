@@ -19,22 +19,29 @@
 //   * a slice table gives every 32-channel slice its own weight image / output view / statistics: the two 1x1 convs
 //     of a CSP layer that read the same tensor are ONE launch that reads it once.
 // MODE 0: plain store; 1: + BatchNorm statistics; 2: y += result (gradient fan-in; the old values are requested a
-// tile's compute ahead of their use and waited for with a counted vmcnt).
+// tile's compute ahead of their use and waited for with a counted vmcnt); 3: MODE 1, then - behind a grid barrier - the
+// BatchNorm(train) + SiLU (+ residual) of the block's OWN output tiles (conv_bn.h): scale / shift come from the finished
+// fp64 sums, every lane re-reads the 16-byte pieces it stored itself (same CU, same L2: no cross-XCD coherence needed) and
+// writes the activation.  The whole BaseConv forward (layers/wrappers.py:76-83) in one launch.
 #pragma once
 #include "common.h"
+#include "conv_bn.h"
 
 #define C1_MAX_SLICES 16
+#define C1_MAX_BN 2
 struct C1Slice {
   const u32x4* w;   // first row of the slice in the packed image: row(k8, co) = k8 * wld + co (16-byte rows)
   __bf16* y;        // first output channel of the slice, pixel 0
   double* stats;    // fp64 accumulators of the slice's first channel, slot 0 ([slot][sld / 2][2]); MODE 1 only
   int wld, ldy, sld, nslots;
+  int bnj, c0;      // MODE 3: the slice's convolution (index into C1K::bn) and its first channel inside that convolution
 };
 struct C1K {
   const __bf16* x;
   int ldx, ntiles, nco, nb;   // nb: blocks per cout tile (grid = nb * nco)
   int xcd_order, dbg;         // dbg & 1: skip the statistics atomics (timing experiments only).  xcd_order 1: block id = cot * nb + b (cout tiles of a pixel tile share an XCD), 0: b * nco + cot
   C1Slice s[C1_MAX_SLICES];
+  CBnFwd bn[C1_MAX_BN];       // MODE 3
 };
 struct C1Launch {
   int K, WM, PT, NBUF, MODE, grid, lds;
@@ -44,6 +51,7 @@ struct C1Launch {
 #define C1_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 static __device__ uint4 g_c1_zero_page[4];
+static __device__ __attribute__((aligned(256))) unsigned g_c1_bar[MI_BN_BAR_WORDS];   // grid barrier of the MODE 3 launches (one at a time)
 
 // LDS-DMA, 16 bytes per lane: LDS[lds_off + lane * 16 ..) = *(sbase + voff); sbase / lds_off wave-uniform.
 // (s_nop 4: an SGPR base that was produced by v_readfirstlane needs 5 wait states before a VMEM instruction reads it;
@@ -83,6 +91,13 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
   const int b = p.xcd_order ? (int)blockIdx.x % nb : (int)blockIdx.x / p.nco;
   const int nt = (p.ntiles - b + nb - 1) / nb;   // tiles of this block (>= 1: nb <= ntiles)
   const C1Slice sl = p.s[cot * WM + wm];
+  unsigned gen0 = 0;   // thread 0 only: the barrier generation this launch starts in
+  if constexpr (MODE == 3) {
+    const int nblk = (int)gridDim.x;
+    if (tid == 0)
+      gen0 = __hip_atomic_load(bn_bar_gen(g_c1_bar, (int)blockIdx.x % (nblk < BN_BAR_G ? nblk : BN_BAR_G)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  constexpr bool STATS = MODE == 1 || MODE == 3;
 
   // ---- this wave's weights: A fragments of 32 output channels x K, resident for the whole launch
   bf16x8 a[KS];
@@ -125,7 +140,7 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
   const size_t ytile = (size_t)TPIX * (size_t)ldyb;
 
   float s1[16], s2[16];
-  if constexpr (MODE == 1) {
+  if constexpr (STATS) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) s1[r] = s2[r] = 0.f;
   }
@@ -181,7 +196,7 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
         bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (__bf16)acc[j][4 * q + e];
-        if constexpr (MODE == 1) {
+        if constexpr (STATS) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float f = (float)o[e];
@@ -216,7 +231,7 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
   }
 
   C1_VMCNT(0);   // the tail DMAs still target this block's LDS
-  if constexpr (MODE == 1) {
+  if constexpr (STATS) {
     // one set of atomics per block: lanes fold over their 32 pixels, waves over the WN pixel groups through LDS
 #pragma unroll
     for (int off = 1; off < 32; off <<= 1)
@@ -249,6 +264,55 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
         atomicAdd(sp, (double)a1);
         atomicAdd(sp + 1, (double)a2);
       }
+    }
+  }
+  if constexpr (MODE == 3) {
+    // ---- phase 2: every block's sums are in; BatchNorm + activation of this block's own tiles
+    // (no static LDS: the ring may use the whole dynamic limit; the tile buffers are dead by now, red[] sits below 16 KB)
+    int* const s_gave_up = (int*)(smem + 16384);
+    bn_grid_barrier(g_c1_bar, gen0, (int)blockIdx.x, (int)gridDim.x, s_gave_up);
+    const float poison = *s_gave_up ? __builtin_nanf("") : 0.f;   // (a timed-out wait: the sums are incomplete)
+    const CBnFwd& bn = p.bn[sl.bnj];
+    float scl, shl;   // of channel c0 + l31 (both halves of the wave compute it; block 0's first pixel group records it)
+    cbn_finalize(bn, sl.stats + l31 * 2, sl.sld, sl.nslots, sl.c0 + l31, b == 0 && wn == 0 && h == 0, poison, scl, shl);
+    float sc[2][8], sh[2][8];   // this lane's channels 16 pr + 8 h + e
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sc[pr][e] = __shfl(scl, pr * 16 + h * 8 + e, 64);
+        sh[pr][e] = __shfl(shl, pr * 16 + h * 8 + e, 64);
+      }
+    const int act = bn.act;
+    const bool has_res = bn.res != nullptr;
+    const int ldab = bn.lda * 2, ldrb = bn.ldres * 2;
+    unsigned aoff[PT], roff[PT];
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+      aoff[j] = (unsigned)(((wn * PT + j) * 32 + l31) * ldab + h * 16);
+      roff[j] = (unsigned)(((wn * PT + j) * 32 + l31) * ldrb + h * 16);
+    }
+    char* const a0 = (char*)(bn.a + sl.c0);
+    const char* const r0 = (const char*)(bn.res + sl.c0);
+    const size_t atile = (size_t)TPIX * (size_t)ldab, rtile = (size_t)TPIX * (size_t)ldrb;
+    for (int i = 0; i < nt; ++i) {
+      const size_t t = (size_t)(b + i * nb);
+      const char* const yt = (const char*)sl.y + t * ytile;
+      char* const at = a0 + t * atile;
+      const char* const rt = r0 + t * rtile;
+      u32x4 v[2 * PT], r[2 * PT];
+#pragma unroll
+      for (int j = 0; j < PT; ++j)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          v[j * 2 + pr] = *(const u32x4*)(yt + yoff[j] + pr * 32);
+          r[j * 2 + pr] = has_res ? *(const u32x4*)(rt + roff[j] + pr * 32) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+      for (int j = 0; j < PT; ++j)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr)
+          *(u32x4*)(at + aoff[j] + pr * 32) = cbn_apply8(v[j * 2 + pr], sc[pr], sh[pr], act, has_res, r[j * 2 + pr]);
     }
   }
 }

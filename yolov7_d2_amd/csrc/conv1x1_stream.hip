@@ -9,6 +9,8 @@
 int c1s_launch_mode0(const C1Launch& l, hipStream_t s);
 int c1s_launch_mode1(const C1Launch& l, hipStream_t s);
 int c1s_launch_mode2(const C1Launch& l, hipStream_t s);
+int c1s_launch_mode3(const C1Launch& l, hipStream_t s);
+int c1s_bar_status(unsigned* flag);
 
 static int c1s_cus() {
   static int cus = 0;
@@ -39,9 +41,32 @@ static bool c1s_desc_ok(const mi_conv_desc* d) {
   return true;
 }
 
-// n descriptors that read the same tensor -> one launch; returns false when the stream kernel does not apply
-static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l) {
+// the BatchNorm pass that follows convolution d, as the kernel's phase 2; false when the job does not describe exactly that
+bool cbn_from_job(const mi_conv_desc& d, const mi_bn_job& j, CBnFwd* o) {
+  const long long npix = (long long)d.N * d.outH * d.outW;
+  if (j.y != d.y || j.ldy != d.ldy || j.C != d.Cout || j.acc != d.stats_acc || !j.acc || !j.a) return false;
+  if (j.npix != npix || j.count != npix) return false;
+  const int nsl = (d.stats_slots >= 1 && d.stats_slots <= MI_BN_SLOTS) ? d.stats_slots : MI_BN_SLOTS;
+  if (j.nslots != nsl) return false;
+  if (!j.gamma || !j.beta || !j.scale || !j.shift || !j.mean || !j.invstd) return false;
+  if (j.lda % 8 || ((uintptr_t)j.a & 15) || npix * j.lda * 2 >= (1LL << 31)) return false;
+  if (j.res && (j.ldres % 8 || ((uintptr_t)j.res & 15) || npix * j.ldres * 2 >= (1LL << 31))) return false;
+  memset(o, 0, sizeof(*o));
+  o->res = (const __bf16*)j.res; o->a = (__bf16*)j.a;
+  o->gamma = j.gamma; o->beta = j.beta; o->rmean = j.rmean; o->rvar = j.rvar; o->nbt = (long long*)j.nbt;
+  o->scale = j.scale; o->shift = j.shift; o->mean = j.mean; o->invstd = j.invstd;
+  o->ldres = j.ldres; o->lda = j.lda; o->act = j.act;
+  o->inv_count = 1.0 / (double)j.count;                                    // (as mi_bn_act_fwd derives them)
+  o->unbias = j.count > 1 ? (double)j.count / (double)(j.count - 1) : 1.0;
+  o->eps = j.eps; o->momentum = j.momentum;
+  return true;
+}
+
+// n descriptors that read the same tensor -> one launch; returns false when the stream kernel does not apply.
+// bn (may be NULL): the BatchNorm jobs of the n convolutions -> MODE 3
+static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l, const mi_bn_job* bn = nullptr) {
   if (n < 1) return false;
+  if (bn && n > C1_MAX_BN) return false;
   const mi_conv_desc& d0 = ds[0];
   int ns = 0;
   for (int j = 0; j < n; ++j) {
@@ -68,6 +93,10 @@ static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l) {
   memset(l, 0, sizeof(*l));
   l->K = K; l->WM = WM; l->PT = PT; l->NBUF = c1s_nbuf(K, tpix);
   l->MODE = (d0.flags & MI_CONV_ACCUM) ? 2 : (d0.stats_acc ? 1 : 0);
+  if (bn) {
+    if (l->MODE != 1) return false;
+    l->MODE = 3;
+  }
   l->lds = l->NBUF * tpix * K * 2;
   C1K& k = l->k;
   k.x = (const __bf16*)d0.x;
@@ -79,7 +108,7 @@ static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l) {
   if (per_cu > 1) per_cu = 1;   // (measured: two blocks per CU lose 0.5 % of the step - twice the statistics atomics, no gain in bandwidth)
   if (per_cu < 1) per_cu = 1;
   static const int ovr = getenv("MI_C1S_PERCU") ? atoi(getenv("MI_C1S_PERCU")) : 0;
-  if (ovr > 0) per_cu = ovr;
+  if (ovr > 0 && !bn) per_cu = ovr;   // (MODE 3: the grid barrier needs every block resident - one per CU always is)
   int nb = (c1s_cus() * per_cu) / nco;
   if (nb > k.ntiles) nb = k.ntiles;
   if (nb < 1) nb = 1;
@@ -102,7 +131,10 @@ static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l) {
       s.stats = d.stats_acc ? d.stats_acc + (size_t)c * 2 : nullptr;
       s.sld = d.CoutPad * 2;
       s.nslots = nsl;
+      s.bnj = j;
+      s.c0 = c;
     }
+    if (bn && !cbn_from_job(d, bn[j], &k.bn[j])) return false;
   }
   return true;
 }
@@ -111,6 +143,7 @@ static int c1s_run(const C1Launch& l, hipStream_t s) {
   switch (l.MODE) {
     case 0: return c1s_launch_mode0(l, s);
     case 1: return c1s_launch_mode1(l, s);
+    case 3: return c1s_launch_mode3(l, s);
     default: return c1s_launch_mode2(l, s);
   }
 }
@@ -130,6 +163,8 @@ bool c1s_try_launch(const mi_conv_desc* ds, int n, hipStream_t s, int* rc) {
   return true;
 }
 bool c1s_try_plan(const mi_conv_desc* ds, int n, C1Launch* l) { return c1s_enabled() && c1s_fill(ds, n, l); }
+bool c1s_try_plan_bn(const mi_conv_desc* ds, const mi_bn_job* bn, int n, C1Launch* l) { return c1s_enabled() && c1s_fill(ds, n, l, bn); }
+int c1s_barrier_status(unsigned* flag) { return c1s_bar_status(flag); }
 int c1s_run_planned(const C1Launch* l, hipStream_t s) { return c1s_run(*l, s); }
 
 extern "C" int mi_conv1x1_stream(const mi_conv_desc* descs, int n, mi_stream_t st) {

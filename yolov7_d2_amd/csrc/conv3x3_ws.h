@@ -19,9 +19,12 @@
 //   * outputs: bf16 -> permlane32_swap -> 16 contiguous bytes per lane, stored during the NEXT tile's main loop; BatchNorm
 //     sums per lane, parked in LDS between tiles, one set of fp64 atomics per block.
 // A launch carries up to 8 jobs (the head's three levels x two towers run as one launch); a block belongs to one job.
-// MODE 0: plain, 1: + BatchNorm statistics, 2: y += result.
+// MODE 0: plain, 1: + BatchNorm statistics, 2: y += result, 3: MODE 1 and then, behind a grid barrier, BatchNorm(train) +
+// SiLU (+ residual) of the block's own output tiles (conv_bn.h; see conv1x1_stream.h MODE 3): conv2 + bn + act + shortcut
+// of a Bottleneck (layers/wrappers.py:119-123) in one launch.
 #pragma once
 #include "common.h"
+#include "conv_bn.h"
 
 #define W3_MAX_JOBS 8
 #define W3_TH 8
@@ -40,6 +43,7 @@ struct W3Job {
   int wld, nslots, sld, pad_;
   int tw[9];                                       // weight slab of tap position t = (dy + 1) * 3 + (dx + 1)
   int pad2_;
+  CBnFwd bn;                                       // MODE 3
 };
 struct W3K {
   int njobs, dbg;
@@ -53,6 +57,7 @@ struct W3Launch {
 #define W3_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 static __device__ uint4 g_w3_zero_page[4];
+static __device__ __attribute__((aligned(256))) unsigned g_w3_bar[MI_BN_BAR_WORDS];   // grid barrier of the MODE 3 launches (one at a time)
 
 __device__ __forceinline__ void w3_glds16(const void* g, unsigned lds_off) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_off) : "memory");
@@ -91,6 +96,13 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
   const W3Job& jb = p.j[ji];
   const int b = (int)blockIdx.x - jb.blk0, nb = jb.nblk;
   const int nt = (jb.ntiles - b + nb - 1) / nb;
+  constexpr bool STATS = MODE == 1 || MODE == 3;
+  unsigned gen0 = 0;   // thread 0 only: the barrier generation this launch starts in
+  if constexpr (MODE == 3) {
+    const int nblk = (int)gridDim.x;
+    if (tid == 0)
+      gen0 = __hip_atomic_load(bn_bar_gen(g_w3_bar, (int)blockIdx.x % (nblk < BN_BAR_G ? nblk : BN_BAR_G)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   // every job field the tile loop needs, in registers: behind the "memory"-clobbering DMA statements the compiler would
   // re-load them from the argument segment, and each such s_load is followed by lgkmcnt(0) - which also drains the LDS
   // fragment reads in flight (20 pipeline drains per tile)
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
   // buffers) - 32 more live registers across the main loop do not fit next to the weights
   float* const sacc = (float*)(smem + 2 * XB) + tid * 4;
   constexpr int SAS = NW * 64 * 4;   // floats between the 8 vectors of a lane
-  if constexpr (MODE == 1) {
+  if constexpr (STATS) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) *(f32x4*)(sacc + q * SAS) = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -255,7 +267,7 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
                      : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]), "+v"(old[4]), "+v"(old[5]), "+v"(old[6]), "+v"(old[7])::"memory");
     }
     float s1[16], s2[16];
-    if constexpr (MODE == 1) {
+    if constexpr (STATS) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 u = *(const f32x4*)(sacc + q * SAS), w = *(const f32x4*)(sacc + (4 + q) * SAS);
@@ -266,14 +278,14 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       bool pvg = true;
-      if constexpr (MODE == 1) pvg = out_ptr(oc, g) != nullptr;
+      if constexpr (STATS) pvg = out_ptr(oc, g) != nullptr;
       unsigned pw[8];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (__bf16)acc[g][4 * q + e];
-        if constexpr (MODE == 1) {
+        if constexpr (STATS) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float f = pvg ? (float)o[e] : 0.f;
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
         pk[g * 2 + pr] = v;
       }
     }
-    if constexpr (MODE == 1) {
+    if constexpr (STATS) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         *(f32x4*)(sacc + q * SAS) = f32x4{s1[4 * q], s1[4 * q + 1], s1[4 * q + 2], s1[4 * q + 3]};
@@ -320,7 +332,7 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
   }
 
   W3_VMCNT(0);
-  if constexpr (MODE == 1) {
+  if constexpr (STATS) {
     float s1[16], s2[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -358,6 +370,54 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
         atomicAdd(sp, (double)a1);
         atomicAdd(sp + 1, (double)a2);
       }
+    }
+  }
+  if constexpr (MODE == 3) {
+    // ---- phase 2: every block's sums are in; BatchNorm + activation (+ residual) of this block's own tiles
+    // (no static LDS: the ring may use the whole dynamic limit; the tile buffers are dead by now, red[] sits below 16 KB)
+    int* const s_gave_up = (int*)(smem + 16384);
+    bn_grid_barrier(g_w3_bar, gen0, (int)blockIdx.x, (int)gridDim.x, s_gave_up);
+    const float poison = *s_gave_up ? __builtin_nanf("") : 0.f;   // (a timed-out wait: the sums are incomplete)
+    const CBnFwd& bn = jb.bn;
+    float scl, shl;   // of channel wm * 32 + l31
+    cbn_finalize(bn, jb.stats + (wm * 32 + l31) * 2, jb.sld, jb.nslots, wm * 32 + l31, b == 0 && wn == 0 && h == 0, poison, scl, shl);
+    float sc[2][8], sh[2][8];   // this lane's channels wm * 32 + 16 pr + 8 h + e
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sc[pr][e] = __shfl(scl, pr * 16 + h * 8 + e, 64);
+        sh[pr][e] = __shfl(shl, pr * 16 + h * 8 + e, 64);
+      }
+    const int act = bn.act;
+    const bool has_res = bn.res != nullptr;
+    const size_t ldab = (size_t)bn.lda * 2, ldrb = (size_t)bn.ldres * 2;
+    char* const abase = (char*)bn.a + wm * 64 + h * 16;
+    const char* const rbase = (const char*)bn.res + wm * 64 + h * 16;
+    for (int i = 0; i < nt; ++i) {
+      const Org o = tile_origin(i);
+      u32x4 v[S], r[S];
+      size_t pixi[G];
+      bool ok[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int py = o.ty0 + (wn * G + g) * 2 + lg, px = o.tx0 + lidx;
+        ok[g] = (py < H) & (px < Wd);
+        pixi[g] = ((size_t)o.img * H + py) * Wd + px;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          v[g * 2 + pr] = r[g * 2 + pr] = u32x4{0u, 0u, 0u, 0u};
+          if (ok[g]) {
+            v[g * 2 + pr] = *(const u32x4*)(ybase + pixi[g] * (size_t)ldyb + wm * 64 + h * 16 + pr * 32);
+            if (has_res) r[g * 2 + pr] = *(const u32x4*)(rbase + pixi[g] * ldrb + pr * 32);
+          }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr)
+          if (ok[g]) *(u32x4*)(abase + pixi[g] * ldab + pr * 32) = cbn_apply8(v[g * 2 + pr], sc[pr], sh[pr], act, has_res, r[g * 2 + pr]);
     }
   }
 }

@@ -9,6 +9,10 @@
 int w3_launch_mode0(const W3Launch& l, hipStream_t s);
 int w3_launch_mode1(const W3Launch& l, hipStream_t s);
 int w3_launch_mode2(const W3Launch& l, hipStream_t s);
+int w3_launch_mode3(const W3Launch& l, hipStream_t s);
+int w3_mode3_blocks_per_cu(int K, int lds);
+int w3_bar_status(unsigned* flag);
+bool cbn_from_job(const mi_conv_desc& d, const mi_bn_job& j, CBnFwd* o);   // conv1x1_stream.hip
 
 static int w3_cus() {
   static int cus = 0;
@@ -45,10 +49,14 @@ static bool w3_desc_ok(const mi_conv_desc* d, int* tw) {
   return seen == 0x1ff;
 }
 
-static bool w3_fill(const mi_conv_desc* ds, int n, W3Launch* l) {
+// bn (may be NULL): the BatchNorm jobs of the n convolutions -> MODE 3
+static bool w3_fill(const mi_conv_desc* ds, int n, W3Launch* l, const mi_bn_job* bn = nullptr) {
   if (n < 1 || n > W3_MAX_JOBS) return false;
   memset(l, 0, sizeof(*l));
   const int K = ds[0].K8 * 8;
+  if (bn && ((ds[0].flags & MI_CONV_ACCUM) || !ds[0].stats_acc)) return false;
+  const int mode = (ds[0].flags & MI_CONV_ACCUM) ? 2 : (ds[0].stats_acc ? (bn ? 3 : 1) : 0);
+  const int lds = 2 * (K / 8) * W3_HROWS * 16 + ((mode == 1 || mode == 3) ? 256 * 32 * 4 : 0);   // halo ring (+ per-lane BatchNorm sums)
   long long total = 0;
   for (int j = 0; j < n; ++j) {
     const mi_conv_desc& d = ds[j];
@@ -63,11 +71,19 @@ static bool w3_fill(const mi_conv_desc* ds, int n, W3Launch* l) {
     jb.nslots = (d.stats_slots >= 1 && d.stats_slots <= MI_BN_SLOTS) ? d.stats_slots : MI_BN_SLOTS;
     jb.sld = d.CoutPad * 2;
     total += jb.ntiles;
+    if (bn && !cbn_from_job(d, bn[j], &jb.bn)) return false;
   }
   // persistent blocks: K = 128 one per CU (288 VGPRs of weights per wave), K = 64 two, K = 32 four; shared between
   // the jobs in proportion to their tiles (every job gets at least one block, none more blocks than tiles)
   static const int ovr = getenv("MI_W3_PERCU") ? atoi(getenv("MI_W3_PERCU")) : 0;
-  const int per_cu = ovr > 0 ? ovr : (K == 128 ? 1 : (K == 64 ? 2 : 4));
+  int per_cu = ovr > 0 ? ovr : (K == 128 ? 1 : (K == 64 ? 2 : 4));
+  if (mode == 3) {   // the grid barrier needs every block resident
+    static int occ[3] = {-1, -1, -1};
+    int& o = occ[K == 128 ? 0 : (K == 64 ? 1 : 2)];
+    if (o < 0) o = w3_mode3_blocks_per_cu(K, lds);
+    if (o < 1) return false;
+    if (per_cu > o) per_cu = o;
+  }
   long long cap = (long long)w3_cus() * per_cu;
   if (cap > total) cap = total;
   int used = 0;
@@ -101,9 +117,9 @@ static bool w3_fill(const mi_conv_desc* ds, int n, W3Launch* l) {
   // (timing experiments; read per call.  1: no statistics atomics, 2: no halo traffic after the first tile, 4: no main loop)
   l->k.dbg = (getenv("MI_DEBUG_NOATOM") ? atoi(getenv("MI_DEBUG_NOATOM")) & 1 : 0) | (getenv("MI_W3_DBG") ? atoi(getenv("MI_W3_DBG")) & 6 : 0);
   l->K = K;
-  l->MODE = (ds[0].flags & MI_CONV_ACCUM) ? 2 : (ds[0].stats_acc ? 1 : 0);
+  l->MODE = mode;
   l->grid = blk;
-  l->lds = 2 * (K / 8) * W3_HROWS * 16 + (l->MODE == 1 ? 256 * 32 * 4 : 0);   // halo ring (+ per-lane BatchNorm sums)
+  l->lds = lds;
   return true;
 }
 
@@ -111,6 +127,7 @@ static int w3_run(const W3Launch& l, hipStream_t s) {
   switch (l.MODE) {
     case 0: return w3_launch_mode0(l, s);
     case 1: return w3_launch_mode1(l, s);
+    case 3: return w3_launch_mode3(l, s);
     default: return w3_launch_mode2(l, s);
   }
 }
@@ -128,6 +145,8 @@ bool w3_try_launch(const mi_conv_desc* ds, int n, hipStream_t s, int* rc) {
   return true;
 }
 bool w3_try_plan(const mi_conv_desc* ds, int n, W3Launch* l) { return w3_enabled() && w3_fill(ds, n, l); }
+bool w3_try_plan_bn(const mi_conv_desc* ds, const mi_bn_job* bn, int n, W3Launch* l) { return w3_enabled() && w3_fill(ds, n, l, bn); }
+int w3_barrier_status(unsigned* flag) { return w3_bar_status(flag); }
 int w3_run_planned(const W3Launch* l, hipStream_t s) { return w3_run(*l, s); }
 
 extern "C" int mi_conv3x3_ws(const mi_conv_desc* descs, int n, mi_stream_t st) {

@@ -1,0 +1,133 @@
+// Grid-wide barrier over the resident blocks of one launch + the BatchNorm(train) + activation (+ residual) pass that a
+// persistent convolution kernel runs over ITS OWN output tiles behind that barrier (conv1x1_stream.h / conv3x3_ws.h,
+// MODE 3): the second half of BaseConv.forward (yolov7/modeling/backbone/layers/wrappers.py:76-83) without a second
+// launch.  Used by bn_act.hip (fused BatchNorm backward) and by the two convolution kernels.
+#pragma once
+#include "common.h"
+
+#define BN_FUS_SPIN_LIMIT (1 << 22)
+// Grid-wide barrier over nb resident blocks.  Agent-scope atomics are performed memory-side, one after the other per
+// address (~0.1 us each: 512 arrivals on ONE counter cost ~50 us, measured), so arrivals go through a two-level tree -
+// MI_BN_BAR_GROUPS group counters (block % groups), whose last arrivers meet on the top counter - and every group waits
+// on its own generation word; each word sits on its own 256-byte line.  Word layout (uint32):
+//   [0] top arrivals  [2] give-up flag  [64 * (1 + g)] generation of group g  [64 * (1 + G + g)] arrivals of group g
+#define BN_BAR_G MI_BN_BAR_GROUPS
+__device__ __forceinline__ unsigned* bn_bar_gen(unsigned* bar, int g) { return bar + 64 * (1 + g); }
+__device__ __forceinline__ unsigned* bn_bar_cnt(unsigned* bar, int g) { return bar + 64 * (1 + BN_BAR_G + g); }
+// No cache maintenance: an agent-scope acquire / release (or __threadfence) writes back and invalidates the XCD's whole L2
+// - issued by hundreds of polling blocks that stalls every block still streaming (measured: +90 us per launch).  It is not
+// needed here: the only data that crosses blocks are the fp64 sums, added by memory-side atomics that have been
+// acknowledged when the block passes its __syncthreads (workgroup release = s_waitcnt vmcnt(0)), and read back after the
+// barrier by agent-scope atomic loads, which bypass the non-coherent caches.
+// *gave_up (LDS) = 1 when this block's wait timed out: its sums are incomplete and it must poison what it writes.
+__device__ __forceinline__ void bn_grid_barrier(unsigned* bar, const unsigned gen0, const int bid, const int nb, int* gave_up) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *gave_up = 0;
+    const int G = nb < BN_BAR_G ? nb : BN_BAR_G;
+    const int g = bid % G;
+    const unsigned gsize = (unsigned)((nb - g + G - 1) / G);
+    bool released = false;
+    if (__hip_atomic_fetch_add(bn_bar_cnt(bar, g), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1u) {
+      __hip_atomic_store(bn_bar_cnt(bar, g), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)G - 1u) {
+        __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 0; q < G; ++q)
+          __hip_atomic_fetch_add(bn_bar_gen(bar, q), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        released = true;
+      }
+    }
+    if (!released) {
+      int spins = 0;
+      while (__hip_atomic_load(bn_bar_gen(bar, g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > BN_FUS_SPIN_LIMIT) {  // a block that never became resident: report instead of hanging the GPU
+          __hip_atomic_store(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          *gave_up = 1;
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+
+// ---- BatchNorm(train) forward of a convolution, phase 2 of the convolution launch
+struct CBnFwd {
+  const __bf16* res;   // residual added after the activation (Bottleneck shortcut) or NULL
+  __bf16* a;           // activated output
+  const float* gamma;
+  const float* beta;
+  float* rmean;        // running statistics (may be NULL)
+  float* rvar;
+  long long* nbt;
+  float* scale;        // written for the backward pass: scale / shift / mean / invstd [C]
+  float* shift;
+  float* mean;
+  float* invstd;
+  int ldres, lda, act, pad_;
+  double inv_count, unbias;
+  float eps, momentum;
+};
+
+// channel c's (scale, shift) from ITS fp64 accumulators acc[slot * sld + {0, 1}] (acc points at the channel) - the arithmetic of
+// bn_act_fwd_body (bn_act.hip), bit for bit.  Agent-scope loads: the sums were added memory-side by every block.
+// `writer`: this lane also records scale / shift / mean / invstd and updates the running statistics (one lane per channel
+// of the launch); `poison` (NaN after a barrier timeout, else 0) marks results computed from incomplete sums.
+__device__ __forceinline__ void cbn_finalize(const CBnFwd& bn, const double* acc, int sld, int nslots, int c, bool writer,
+                                             float poison, float& sc_out, float& sh_out) {
+  double v1[MI_BN_SLOTS], v2[MI_BN_SLOTS];
+#pragma unroll
+  for (int k = 0; k < MI_BN_SLOTS; ++k) {
+    if (k < nslots) {
+      v1[k] = __hip_atomic_load(acc + (size_t)k * sld, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v2[k] = __hip_atomic_load(acc + (size_t)k * sld + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      v1[k] = v2[k] = 0.0;
+    }
+  }
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < MI_BN_SLOTS; ++k) {
+    s1 += v1[k];
+    s2 += v2[k];
+  }
+  const double mean = s1 * bn.inv_count;
+  double var = s2 * bn.inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)bn.eps);
+  const float g = bn.gamma[c], b = bn.beta[c];
+  const float sc = (float)((double)g * invstd) + poison;
+  const float sh = (float)((double)b - mean * (double)g * invstd) + poison;
+  sc_out = sc;
+  sh_out = sh;
+  if (writer) {
+    bn.scale[c] = sc;
+    bn.shift[c] = sh;
+    bn.mean[c] = (float)mean + poison;
+    bn.invstd[c] = (float)invstd + poison;
+    if (bn.rmean) {
+      bn.rmean[c] = (1.f - bn.momentum) * bn.rmean[c] + bn.momentum * (float)mean;
+      bn.rvar[c] = (1.f - bn.momentum) * bn.rvar[c] + bn.momentum * (float)(var * bn.unbias);
+    }
+    if (c == 0 && bn.nbt) *bn.nbt += 1;
+  }
+}
+
+// 8 channels of one pixel: a = act(y * scale + shift) (+ res), the expression of bn_act_fwd_body
+__device__ __forceinline__ u32x4 cbn_apply8(const u32x4 yv, const float* sc, const float* sh, const int act, const bool has_res,
+                                            const u32x4 rv) {
+  const bf16x8 v = __builtin_bit_cast(bf16x8, yv), r = __builtin_bit_cast(bf16x8, rv);
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float z = (float)v[e] * sc[e] + sh[e];
+    o[e] = act ? z * sigmoidf_(z) : z;
+  }
+  if (has_res) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] += (float)r[e];
+  }
+  return __builtin_bit_cast(u32x4, pack8(o));
+}

@@ -34,12 +34,16 @@
 bool c1s_try_launch(const mi_conv_desc* ds, int n, hipStream_t s, int* rc);
 bool c1s_try_plan(const mi_conv_desc* ds, int n, C1Launch* l);
 int c1s_run_planned(const C1Launch* l, hipStream_t s);
+bool c1s_try_plan_bn(const mi_conv_desc* ds, const mi_bn_job* bn, int n, C1Launch* l);
+int c1s_barrier_status(unsigned* flag);
 static_assert(sizeof(C1Launch) <= sizeof(((mi_conv_group*)0)->priv), "mi_conv_group.priv holds the stream launch record");
 #include "conv3x3_ws.h"
 // weight-stationary 3x3 path (conv3x3_ws.hip)
 bool w3_try_launch(const mi_conv_desc* ds, int n, hipStream_t s, int* rc);
 bool w3_try_plan(const mi_conv_desc* ds, int n, W3Launch* l);
 int w3_run_planned(const W3Launch* l, hipStream_t s);
+bool w3_try_plan_bn(const mi_conv_desc* ds, const mi_bn_job* bn, int n, W3Launch* l);
+int w3_barrier_status(unsigned* flag);
 static_assert(sizeof(W3Launch) <= sizeof(((mi_conv_group*)0)->priv), "mi_conv_group.priv holds the 3x3 launch record");
 
 #define MI_DECL_KC(KCv)                                                                      \
@@ -414,8 +418,53 @@ extern "C" int mi_conv2d_group_plan(const mi_conv_desc* descs, int n, void* tabl
   return MI_OK;
 }
 
+// ---------------------------------------------------------------- convolution + BatchNorm(train) + activation, one launch
+extern "C" int mi_conv2d_bn_plan(const mi_conv_desc* descs, const mi_bn_job* bn, int n, mi_conv_group* meta) {
+  MI_REQUIRE(descs && bn && meta && n >= 1 && n <= MI_CONV_MAX_GROUP, "conv_bn_plan: 1..%d jobs", MI_CONV_MAX_GROUP);
+  C1Launch cl;
+  if (c1s_try_plan_bn(descs, bn, n, &cl)) {
+    memset(meta, 0, sizeof(*meta));
+    meta->njobs = n; meta->nblocks = cl.grid; meta->lds_bytes = cl.lds;
+    meta->KC = -1; meta->BN = cl.WM * 32; meta->TPIX = cl.PT; meta->TPS = cl.NBUF; meta->EPI = cl.MODE;
+    meta->table_bytes = 16;
+    memcpy(meta->priv, &cl, sizeof(cl));
+    return 1;
+  }
+  W3Launch wl;
+  if (w3_try_plan_bn(descs, bn, n, &wl)) {
+    memset(meta, 0, sizeof(*meta));
+    meta->njobs = n; meta->nblocks = wl.grid; meta->lds_bytes = wl.lds;
+    meta->KC = -2; meta->BN = wl.K; meta->TPIX = 128; meta->TPS = 9; meta->EPI = wl.MODE;
+    meta->table_bytes = 16;
+    memcpy(meta->priv, &wl, sizeof(wl));
+    return 1;
+  }
+  return 0;
+}
+
+extern "C" int mi_conv2d_bn_fwd(const mi_conv_desc* descs, const mi_bn_job* bn, int n, mi_stream_t st) {
+  mi_conv_group meta;
+  const int rc = mi_conv2d_bn_plan(descs, bn, n, &meta);
+  if (rc < 0) return rc;
+  MI_REQUIRE(rc == 1, "conv_bn_fwd: needs convolutions that run on the streaming 1x1 (at most %d of one input) or the weight-"
+             "stationary 3x3 kernel with stats_acc, each followed by the train-mode BatchNorm of exactly its output", C1_MAX_BN);
+  if (meta.KC == -1) return c1s_run_planned((const C1Launch*)meta.priv, (hipStream_t)st);
+  return w3_run_planned((const W3Launch*)meta.priv, (hipStream_t)st);
+}
+
+extern "C" int mi_conv_bn_barrier_status(uint32_t* flags) {
+  MI_REQUIRE(flags, "conv_bn_barrier_status: null");
+  unsigned a = 0, b = 0;
+  int rc = c1s_barrier_status(&a);
+  if (rc) return rc;
+  rc = w3_barrier_status(&b);
+  if (rc) return rc;
+  *flags = (a ? 1u : 0u) | (b ? 2u : 0u);
+  return MI_OK;
+}
+
 extern "C" int mi_conv2d_group_run(const mi_conv_group* m, const void* table_dev, mi_stream_t st) {
-  MI_REQUIRE(m && table_dev && m->njobs >= 1, "conv_group_run: null");
+  MI_REQUIRE(m && (table_dev || m->KC < 0) && m->njobs >= 1, "conv_group_run: null");
   if (m->KC == -1) return c1s_run_planned((const C1Launch*)m->priv, (hipStream_t)st);
   if (m->KC == -2) return w3_run_planned((const W3Launch*)m->priv, (hipStream_t)st);
   const ConvK* jobs = (const ConvK*)table_dev;

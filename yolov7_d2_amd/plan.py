@@ -715,8 +715,16 @@ class Plan:
         """raise if any grid barrier of the one-launch BatchNorm backward gave up since the last check (word 2 of a
         layer's barrier record; the kernel NaN-poisons what the timed-out block wrote).  Host-synchronising: called
         where the trainer reads the losses anyway."""
+        if self.b.device.type != "cuda":
+            return
+        if any(getattr(c, "fused_bn", False) for c in getattr(self, "fwd_list", [])):
+            fl = C.c_uint32(0)
+            L.check(L.lib().mi_conv_bn_barrier_status(C.byref(fl)), "conv_bn_barrier_status")
+            if fl.value:
+                raise L.MI355Error(f"conv + BatchNorm grid barrier timed out (kernel families {fl.value:#x}): a block was not "
+                                   "resident (another kernel holds CUs?); set MI_CONV_BN_FUSE=0")
         bars = [bf for bf in self.b.bufs if bf.name.endswith(".bar")]
-        if not bars or self.b.device.type != "cuda":
+        if not bars:
             return
         flags = torch.stack([self.buf_view(bf, torch.int32, 4)[2] for bf in bars])
         if int(flags.max()) != 0:
@@ -1158,12 +1166,8 @@ class Plan:
         jobs = (L.mi_bn_job * n)()
         for j, c in zip(jobs, cs):
             P = [x.resolve() for x in c.p]
-            if kind == 0:    # BN_ACT_FWD: i=[ldy, ldres, lda, C, act, nslots] l=[count, npix] f=[eps, momentum]
-                (j.y, j.acc, j.gamma, j.beta, j.rmean, j.rvar, j.nbt, j.scale, j.shift, j.mean, j.invstd, j.res,
-                 j.a) = P[:13]
-                j.ldy, j.ldres, j.lda, j.C, j.act, j.nslots = c.i[:6]
-                j.count, j.npix = c.l[0], c.l[1]
-                j.eps, j.momentum = (c.f + [0.0, 0.0])[:2]
+            if kind == 0:
+                self._fill_bn_fwd_job(j, c)
             elif kind == 1:  # BN_BWD_REDUCE: i=[ldda, ldy, nblk, C, act, nslots] l=[npix]
                 j.da, j.y, j.scale, j.shift, j.mean, j.invstd, j.acc = P[:7]
                 j.ldda, j.ldy, j.nblk, j.C, j.act, j.nslots = c.i[:6]
@@ -1188,10 +1192,78 @@ class Plan:
         g.members = list(cs)
         return g
 
+    def _fuse_conv_bn(self, cmds):
+        """CONV (+ BatchNorm statistics) directly followed by the train-mode BN_ACT_FWD of its output - or a CONV_GROUP
+        followed by the BN_GROUP of the same layers - becomes ONE launch when the convolutions run on the persistent
+        streaming 1x1 / weight-stationary 3x3 kernels: the BatchNorm pass is their second phase behind a grid barrier
+        (mi_conv2d_bn_plan).  The whole BaseConv.forward of backbone/layers/wrappers.py:76-83 and the Bottleneck shortcut
+        add in one command.  OPT-IN (MI_CONV_BN_FUSE=1): measured on the YOLOX-s step (same box, graphs on) the 41 fused
+        launches are 1.7 % SLOWER than the 82 separate ones (5.698 vs 5.600 ms) although they are 2 % faster when each
+        command is timed alone: a launch inside the hipGraph costs ~1-2 us, less than the barrier + the statistics read-back
+        behind it, and the second phase streams with the convolution kernel's 4-8 waves per CU instead of the BatchNorm
+        kernel's 16+ (profiles/r03_conv_bn_fused_ab.txt)."""
+        if os.environ.get("MI_CONV_BN_FUSE", "0") != "1" or self.b.device.type != "cuda":
+            return cmds
+        CONV, CONVG, BNF, BNG = L.OP["CONV"], L.OP["CONV_GROUP"], L.OP["BN_ACT_FWD"], L.OP["BN_GROUP"]
+        lib = L.lib()
+        out, k = [], 0
+        while k < len(cmds):
+            c = cmds[k]
+            nxt = cmds[k + 1] if k + 1 < len(cmds) else None
+            convs = bns = None
+            if nxt is not None and c.op == CONV and nxt.op == BNF:
+                convs, bns = [c], [nxt]
+            elif nxt is not None and c.op == CONVG and nxt.op == BNG and nxt.i[0] == 0 and len(c.members) == len(nxt.members):
+                convs, bns = c.members, nxt.members
+            g = None
+            if convs is not None and all(b_.p[1].resolve() for b_ in bns):      # (train mode: the jobs carry accumulators)
+                n = len(convs)
+                descs = (L.mi_conv_desc * n)()
+                for d, cv in zip(descs, convs):
+                    t = self._make_desc(cv.desc)
+                    self.descs.pop()
+                    C.memmove(C.byref(d), C.byref(t), C.sizeof(L.mi_conv_desc))
+                jobs = (L.mi_bn_job * n)()
+                for j, bc in zip(jobs, bns):
+                    self._fill_bn_fwd_job(j, bc)
+                # the BatchNorm job of position j must belong to convolution j (lanes are issued in the same order)
+                if all(d.y == j.y for d, j in zip(descs, jobs)):
+                    meta = L.mi_conv_group()
+                    rc = lib.mi_conv2d_bn_plan(descs, jobs, n, C.byref(meta))
+                    if rc < 0:
+                        lib.mi_last_error()
+                    elif rc == 1:
+                        self.descs += [meta, descs, jobs]
+                        g = _Cmd(CONVG, p=[_Ptr(C.addressof(meta)), _Ptr(0)], tag=c.tag + "+" + nxt.tag)
+                        g.group_descs = list(descs)
+                        g.members = list(convs) + list(bns)
+                        g.fused_bn = True
+                        g.bn_jobs = list(jobs)
+            if g is not None:
+                out.append(g)
+                k += 2
+            else:
+                out.append(c)
+                k += 1
+        return out
+
+    @staticmethod
+    def _fill_bn_fwd_job(j, c):
+        """BN_ACT_FWD command -> mi_bn_job: i=[ldy, ldres, lda, C, act, nslots] l=[count, npix] f=[eps, momentum]"""
+        P = [x.resolve() for x in c.p]
+        (j.y, j.acc, j.gamma, j.beta, j.rmean, j.rvar, j.nbt, j.scale, j.shift, j.mean, j.invstd, j.res, j.a) = P[:13]
+        j.ldy, j.ldres, j.lda, j.C, j.act, j.nslots = c.i[:6]
+        j.count, j.npix = c.l[0], c.l[1]
+        j.eps, j.momentum = (c.f + [0.0, 0.0])[:2]
+
     def _materialize(self, cmds, which):
         cmds = self._lower_streams(self._group_lanes(self._group_parity(cmds)))
+        if which == "fwd":
+            cmds = self._fuse_conv_bn(cmds)
         arr = (L.mi_cmd * max(1, len(cmds)))()
         tags = []
+        if which == "fwd":
+            self.fwd_list = cmds
         self.cmd_descs[which] = [None] * len(cmds)
         # symbolic builder commands behind a merged launch (None: the command is its own member); tests/plan_interp.py runs those
         self.cmd_members = getattr(self, "cmd_members", {})
