@@ -507,12 +507,264 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const MhaK p) {
   }
 }
 
+// ------------------------------------------------------------------ backward, version 2
+// The forward v2 structure for the two backward kernels: nwv waves x 16 rows per block sized to one round of blocks, the
+// streamed operand pair in 128-row LDS chunks (double-buffered, one barrier per chunk, unconditional prefetch loads), one
+// basic block per chunk.  Per score: one fma + exp2 (P recomputed from the saved log-sum-exp in the exp2 domain), one
+// multiply, the bf16 packs; "- delta" enters the dP product as its accumulator input, the key-padding mask the score
+// product's (dQ) or is applied to the finished rows (dK / dV: a padded key's rows are computed and discarded); the
+// softmax scale multiplies the accumulators once at the end.
+// dQ: a wave owns 16 queries (as the forward), streams K / V
+template <bool DROP>
+__global__ __launch_bounds__(768) void mha_bwd_dq2_kernel(const MhaK p) {
+  __shared__ __attribute__((aligned(16))) char Ks[2 * 8192], Vs[2 * 8192];
+  __shared__ __attribute__((aligned(16))) float Mb[2][MHA2_KC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nth = blockDim.x;
+  const int t = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+  const int q0 = blockIdx.x * (nth >> 2) + wave * 16;
+  const int myq = q0 + t;
+  bf16x8 qf = {}, dof = {};
+  float neg_l = -INFINITY, dl = 0.f;   // -lse * log2(e) of query t (-inf: a fully masked or out-of-range row weighs nothing)
+  if (myq < p.Lq) {
+    const size_t off = ((size_t)myq * p.B + b) * p.E + h * MHA_D + g * 8;
+    qf = *(const bf16x8*)(p.q + off);
+    dof = *(const bf16x8*)(p.dout + off);
+    const float lse = p.lse[((size_t)b * p.H + h) * p.Lq + myq];
+    neg_l = lse == -INFINITY ? -INFINITY : -lse * 1.44269504088896341f;
+    dl = p.delta[((size_t)b * p.H + h) * p.Lq + myq];
+  }
+  const float sc2 = p.scale * 1.44269504088896341f;
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const f32x4 ndl = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{-dl, -dl, -dl, -dl};
+  const int nchunks = (p.Lk + MHA2_KC - 1) / MHA2_KC;
+  u32x4 kreg[2], vreg[2];
+  unsigned char mreg = 0;
+  const uint8_t* const mrow = p.mask ? p.mask + (size_t)b * p.Lk : (const uint8_t*)p.k;
+  auto load_chunk = [&](int c) {
+    const int k0 = c * MHA2_KC;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int idx = tid + u * nth;
+      idx = idx < 511 ? idx : 511;
+      int row = k0 + (idx >> 2);
+      row = row < p.Lk ? row : p.Lk - 1;
+      const size_t off = ((size_t)row * p.B + b) * p.E + h * MHA_D + (idx & 3) * 8;
+      kreg[u] = *(const u32x4*)(p.k + off);
+      vreg[u] = *(const u32x4*)(p.v + off);
+    }
+    const int key = k0 + (tid & (MHA2_KC - 1));
+    mreg = mrow[key < p.Lk ? key : p.Lk - 1];
+  };
+  auto store_chunk = [&](int c) {
+    const int buf = c & 1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int idx = tid + u * nth;
+      idx = idx < 511 ? idx : 511;
+      const int row = idx >> 2;
+      const int o = buf * 8192 + (row >> 5) * 2048 + tile_off(row & 31, idx & 3);
+      *(u32x4*)(Ks + o) = kreg[u];
+      *(u32x4*)(Vs + o) = vreg[u];
+    }
+    const int key = c * MHA2_KC + (tid & (MHA2_KC - 1));
+    Mb[buf][tid & (MHA2_KC - 1)] = (key >= p.Lk || (p.mask && mreg)) ? -INFINITY : 0.f;
+  };
+  load_chunk(0);
+  store_chunk(0);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();
+    const int cur = c & 1;
+    if (c + 1 < nchunks) load_chunk(c + 1);
+    const int k0 = c * MHA2_KC;
+    // S^T and dP^T - delta: lane (t = query, g): [a][r] = key k0 + 16 a + 4 g + r
+    f32x4 s[8], dp[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const bf16x8 kf = frag_rows(Ks + cur * 8192 + (a >> 1) * 2048, a & 1, t, g);
+      const bf16x8 vf = frag_rows(Vs + cur * 8192 + (a >> 1) * 2048, a & 1, t, g);
+      const f32x4 bias = *(const f32x4*)(&Mb[cur][16 * a + 4 * g]);
+      s[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, bias, 0, 0, 0);
+      dp[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof, ndl, 0, 0, 0);
+    }
+#pragma unroll
+    for (int t2 = 0; t2 < 4; ++t2) {
+      bf16x8 dsf;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int a = 2 * t2 + (e >> 2), r = e & 3;
+        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[a][r], sc2, neg_l));   // (masked key: s = -inf -> 0)
+        float ds;
+        if constexpr (DROP) ds = pe * (dp[a][r] * mha_keep(p, b, h, myq, k0 + 16 * a + 4 * g + r) - dl);
+        else ds = pe * dp[a][r];
+        dsf[e] = (__bf16)ds;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bf16x8 kc = frag_cols(Ks + cur * 8192 + t2 * 2048, j, t, g);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, kc, acc[j], 0, 0, 0);
+      }
+    }
+    if (c + 1 < nchunks) store_chunk(c + 1);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qq = q0 + 4 * g + r;
+    if (qq < p.Lq) {
+      __bf16* op = p.dq + ((size_t)qq * p.B + b) * p.E + h * MHA_D;
+      op[t] = (__bf16)(acc[0][r] * p.scale);
+      op[16 + t] = (__bf16)(acc[1][r] * p.scale);
+    }
+  }
+}
+
+// dK, dV: a wave owns 16 keys, streams Q / dO with the queries' -lse * log2(e) and -delta
+template <bool DROP>
+__global__ __launch_bounds__(768) void mha_bwd_dkv2_kernel(const MhaK p) {
+  __shared__ __attribute__((aligned(16))) char Qs[2 * 8192], Ds[2 * 8192];
+  __shared__ __attribute__((aligned(16))) float Nl[2][MHA2_KC], Nd[2][MHA2_KC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nth = blockDim.x;
+  const int t = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.H, h = bh % p.H;
+  const int key0 = blockIdx.x * (nth >> 2) + wave * 16;
+  const int mykey = key0 + t;
+  bf16x8 kf = {}, vf = {};
+  {
+    const int row = mykey < p.Lk ? mykey : p.Lk - 1;   // (rows past the last key and padded keys are discarded at the end)
+    const size_t off = ((size_t)row * p.B + b) * p.E + h * MHA_D + g * 8;
+    kf = *(const bf16x8*)(p.k + off);
+    vf = *(const bf16x8*)(p.v + off);
+  }
+  const float sc2 = p.scale * 1.44269504088896341f;
+  f32x4 dk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  f32x4 dv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  const int nchunks = (p.Lq + MHA2_KC - 1) / MHA2_KC;
+  u32x4 qreg[2], dreg[2];
+  float lreg = 0.f, ereg = 0.f;
+  const float* const lrow = p.lse + ((size_t)b * p.H + h) * p.Lq;
+  const float* const drow = p.delta + ((size_t)b * p.H + h) * p.Lq;
+  auto load_chunk = [&](int c) {
+    const int r0 = c * MHA2_KC;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int idx = tid + u * nth;
+      idx = idx < 511 ? idx : 511;
+      int row = r0 + (idx >> 2);
+      row = row < p.Lq ? row : p.Lq - 1;
+      const size_t off = ((size_t)row * p.B + b) * p.E + h * MHA_D + (idx & 3) * 8;
+      qreg[u] = *(const u32x4*)(p.q + off);
+      dreg[u] = *(const u32x4*)(p.dout + off);
+    }
+    const int qq = r0 + (tid & (MHA2_KC - 1));
+    lreg = lrow[qq < p.Lq ? qq : p.Lq - 1];
+    ereg = drow[qq < p.Lq ? qq : p.Lq - 1];
+  };
+  auto store_chunk = [&](int c) {
+    const int buf = c & 1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      int idx = tid + u * nth;
+      idx = idx < 511 ? idx : 511;
+      const int row = idx >> 2;
+      const int o = buf * 8192 + (row >> 5) * 2048 + tile_off(row & 31, idx & 3);
+      *(u32x4*)(Qs + o) = qreg[u];
+      *(u32x4*)(Ds + o) = dreg[u];
+    }
+    const int qq = c * MHA2_KC + (tid & (MHA2_KC - 1));
+    const bool live = qq < p.Lq && lreg != -INFINITY;   // (a fully masked query row contributes nothing)
+    Nl[buf][tid & (MHA2_KC - 1)] = live ? -lreg * 1.44269504088896341f : -INFINITY;
+    Nd[buf][tid & (MHA2_KC - 1)] = qq < p.Lq ? -ereg : 0.f;
+  };
+  load_chunk(0);
+  store_chunk(0);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();
+    const int cur = c & 1;
+    if (c + 1 < nchunks) load_chunk(c + 1);
+    const int r0 = c * MHA2_KC;
+    // S and dP - delta: lane (t = key, g): [a][r] = query r0 + 16 a + 4 g + r.  All eight tile pairs of the chunk up front
+    // (one 32-query tile at a time with dropout: its random numbers need the registers)
+    constexpr int TG = DROP ? 1 : 4;
+#pragma unroll
+    for (int tg = 0; tg < 4; tg += TG) {
+      f32x4 s[2 * TG], dp[2 * TG];
+#pragma unroll
+      for (int aa = 0; aa < 2 * TG; ++aa) {
+        const int a = 2 * tg + aa;
+        const bf16x8 qa = frag_rows(Qs + cur * 8192 + (a >> 1) * 2048, a & 1, t, g);
+        const bf16x8 da = frag_rows(Ds + cur * 8192 + (a >> 1) * 2048, a & 1, t, g);
+        const f32x4 nd = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(&Nd[cur][16 * a + 4 * g]);
+        s[aa] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        dp[aa] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf, nd, 0, 0, 0);
+      }
+#pragma unroll
+      for (int tt = 0; tt < TG; ++tt) {
+        const int t2 = tg + tt;
+        bf16x8 pf, dsf;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int a = 2 * t2 + hh, aa = 2 * tt + hh;
+          const f32x4 nl = *(const f32x4*)(&Nl[cur][16 * a + 4 * g]);
+          f32x4 nd = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (DROP) nd = *(const f32x4*)(&Nd[cur][16 * a + 4 * g]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[aa][r], sc2, nl[r]));
+            if constexpr (DROP) {
+              const float keep = mha_keep(p, b, h, r0 + 16 * a + 4 * g + r, mykey);
+              pf[hh * 4 + r] = (__bf16)(pe * keep);
+              dsf[hh * 4 + r] = (__bf16)(pe * (dp[aa][r] * keep + nd[r]));
+            } else {
+              pf[hh * 4 + r] = (__bf16)pe;
+              dsf[hh * 4 + r] = (__bf16)(pe * dp[aa][r]);
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bf16x8 dc = frag_cols(Ds + cur * 8192 + t2 * 2048, j, t, g), qc = frag_cols(Qs + cur * 8192 + t2 * 2048, j, t, g);
+          dv[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, dc, dv[j], 0, 0, 0);
+          dk[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsf, qc, dk[j], 0, 0, 0);
+        }
+      }
+    }
+    if (c + 1 < nchunks) store_chunk(c + 1);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int kk = key0 + 4 * g + r;
+    if (kk < p.Lk) {
+      const bool dead = p.mask && p.mask[(size_t)b * p.Lk + kk];   // a padded key: its rows (possibly inf / NaN) are discarded
+      const size_t off = ((size_t)kk * p.B + b) * p.E + h * MHA_D;
+      p.dk[off + t] = (__bf16)(dead ? 0.f : dk[0][r] * p.scale);
+      p.dk[off + 16 + t] = (__bf16)(dead ? 0.f : dk[1][r] * p.scale);
+      p.dv[off + t] = (__bf16)(dead ? 0.f : dv[0][r]);
+      p.dv[off + 16 + t] = (__bf16)(dead ? 0.f : dv[1][r]);
+    }
+  }
+}
+
 static int mha_check(const void* q, const void* k, const void* v, int B, int H, int Lq, int Lk, int E) {
   MI_REQUIRE(q && k && v, "mha: null");
   MI_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0 && E == H * MHA_D, "mha: E %d must be H*%d (H %d)", E, MHA_D, H);
   MI_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0, "mha: alignment");
   MI_REQUIRE((long long)B * H < 65536, "mha: B*H too large");
   return MI_OK;
+}
+
+// waves (16 rows each) per block of the v2 kernels: one round of blocks on the device, 4 .. 12 waves
+static int mha2_waves(int L, int BH) {
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+  }
+  const int gq = mi_cdiv(L, 16);
+  const long groups = (long)gq * BH;
+  int nwv = (int)((groups + ncu - 1) / ncu);
+  nwv = nwv < 4 ? 4 : (nwv > 12 ? 12 : nwv);
+  if (nwv > gq) nwv = gq < 4 ? 4 : gq;
+  return nwv;
 }
 
 static int mha_set_dropout(MhaK* p, float drop_p, unsigned long long seed) {
@@ -547,18 +799,8 @@ extern "C" int mi_mha_fwd_dropout(const void* q, const void* k, const void* v, c
     MI_CHECK_LAUNCH("mha_fwd");
     return MI_OK;
   }
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
-  }
-  // waves (16 queries each) per block: one round of blocks on the device, 4 .. 12 waves
-  const int gq = mi_cdiv(Lq, 16);
-  const long groups = (long)gq * B * H;
-  int nwv = (int)((groups + ncu - 1) / ncu);
-  nwv = nwv < 4 ? 4 : (nwv > 12 ? 12 : nwv);
-  if (nwv > gq) nwv = gq < 4 ? 4 : gq;
-  const dim3 grid(mi_cdiv(gq, nwv), B * H), blk(nwv * 64);
+  const int nwv = mha2_waves(Lq, B * H);
+  const dim3 grid(mi_cdiv(mi_cdiv(Lq, 16), nwv), B * H), blk(nwv * 64);
   if (p.drop_thr) hipLaunchKernelGGL(mha_fwd2_kernel<true>, grid, blk, 0, (hipStream_t)st, p);
   else hipLaunchKernelGGL(mha_fwd2_kernel<false>, grid, blk, 0, (hipStream_t)st, p);
   MI_CHECK_LAUNCH("mha_fwd2");
@@ -609,9 +851,21 @@ extern "C" int mi_mha_bwd_dropout(const void* q, const void* k, const void* v, c
   hipStream_t s = (hipStream_t)st;
   hipLaunchKernelGGL(mha_delta_kernel, dim3(mi_cdiv(B * H * Lq * 4, 256)), dim3(256), 0, s, p, delta_ws);
   MI_CHECK_LAUNCH("mha_delta");
-  hipLaunchKernelGGL(mha_bwd_dq_kernel, dim3(mi_cdiv(Lq, 64), B * H), dim3(256), 0, s, p);
-  MI_CHECK_LAUNCH("mha_bwd_dq");
-  hipLaunchKernelGGL(mha_bwd_dkv_kernel, dim3(mi_cdiv(Lk, 64), B * H), dim3(256), 0, s, p);
-  MI_CHECK_LAUNCH("mha_bwd_dkv");
+  static const int v2 = getenv("MI_MHA_V2") ? atoi(getenv("MI_MHA_V2")) : 1;
+  if (!v2) {
+    hipLaunchKernelGGL(mha_bwd_dq_kernel, dim3(mi_cdiv(Lq, 64), B * H), dim3(256), 0, s, p);
+    MI_CHECK_LAUNCH("mha_bwd_dq");
+    hipLaunchKernelGGL(mha_bwd_dkv_kernel, dim3(mi_cdiv(Lk, 64), B * H), dim3(256), 0, s, p);
+    MI_CHECK_LAUNCH("mha_bwd_dkv");
+    return MI_OK;
+  }
+  const int nq = mha2_waves(Lq, B * H), nk = mha2_waves(Lk, B * H);
+  const dim3 gq(mi_cdiv(mi_cdiv(Lq, 16), nq), B * H), gk(mi_cdiv(mi_cdiv(Lk, 16), nk), B * H);
+  if (p.drop_thr) hipLaunchKernelGGL(mha_bwd_dq2_kernel<true>, gq, dim3(nq * 64), 0, s, p);
+  else hipLaunchKernelGGL(mha_bwd_dq2_kernel<false>, gq, dim3(nq * 64), 0, s, p);
+  MI_CHECK_LAUNCH("mha_bwd_dq2");
+  if (p.drop_thr) hipLaunchKernelGGL(mha_bwd_dkv2_kernel<true>, gk, dim3(nk * 64), 0, s, p);
+  else hipLaunchKernelGGL(mha_bwd_dkv2_kernel<false>, gk, dim3(nk * 64), 0, s, p);
+  MI_CHECK_LAUNCH("mha_bwd_dkv2");
   return MI_OK;
 }
