@@ -558,6 +558,89 @@ def gold_detr_meta():
           "ndet", [len(d_["instances"]) for d_ in dets])
 
 
+def gold_detr_real():
+    """the reference's own `Detr` meta-arch (meta_arch/detr.py:33-279, by path) at the REAL configuration of BASELINE
+    configs[3]: 6 + 6 layers, 100 queries, deep supervision, 800 x 1333 and 768 x 1205 images in one padded batch; dropout 0
+    (torch's dropout stream has no parity target).  Stores the 25-entry loss dict of the training forward, the eval logits /
+    boxes and grad_signature() of every trainable parameter's gradient of the weighted loss sum."""
+    import contextlib, io
+    import resnet_oracle as R
+    from gen_golden_inputs import seeded_tensor_dict, synth_detr_batch, grad_signature
+    root = os.path.dirname(HERE)
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from yolov7_d2_amd import d2shim, detr_r50_cfg
+    ref_loader.load()
+    det = ref_loader.load_detr()
+    det.build_backbone = lambda cfg: R.R50Module(50, cfg.MODEL.RESNETS.OUT_FEATURES, cfg.MODEL.RESNETS.STRIDE_IN_1X1)
+    det.ImageList, det.Instances, det.Boxes = d2shim.ImageList, d2shim.Instances, d2shim.Boxes
+    det.detector_postprocess = d2shim.detector_postprocess
+    cfg = detr_r50_cfg(device="cpu")
+    cfg.MODEL.DETR.DROPOUT = 0.0
+    torch.manual_seed(0)
+    model = det.Detr(cfg)
+    sd = model.state_dict()
+    model.load_state_dict(seeded_tensor_dict({k: v.shape for k, v in sd.items()}, seed=207), strict=False)
+    # conditioning: the seeded ResNet's res5 activations are ~1e2 per channel, input_proj would hand the encoder tokens of
+    # norm 1.4e4 - attention then is one-hot and the gradient a lottery of arg-max flips (measured: two boundary tokens
+    # carry 99 % of d src).  A trained network's tokens have norm O(10): scale input_proj accordingly
+    with torch.no_grad():
+        model.detr.input_proj.weight.mul_(1e-3)
+    batch = synth_detr_batch(seed=211, sizes=((800, 1333), (768, 1205)))
+    inputs = [dict(image=b["image"], instances=d2shim.Instances(b["size"], gt_boxes=d2shim.Boxes(b["boxes"]),
+                                                                gt_classes=b["classes"])) for b in batch]
+    model.train()
+    feats = {}
+    def keep(m, i, o):
+        for k, v in o.items():
+            v.retain_grad()
+            feats[k] = v
+    hk = model.detr.backbone[0].backbone.register_forward_hook(keep)
+
+    def keep_src(m, args):
+        args[0].retain_grad()
+        feats["src"] = args[0]
+    hk2 = model.detr.transformer.register_forward_pre_hook(keep_src)
+    # the matcher's answers in call order (last decoder level, then the aux levels 0..4): near ties at random
+    # initialisation make the assignment - and with it which two queries per image carry the box gradients - a coin toss
+    # under bf16 noise, so the gradient comparison is made with these assignments forced
+    matches = []
+    orig_match = model.criterion.matcher.forward
+
+    def rec(outputs, targets):
+        r = orig_match(outputs, targets)
+        matches.append([(i.clone(), j.clone()) for i, j in r])
+        return r
+    model.criterion.matcher.forward = rec
+    with contextlib.redirect_stdout(io.StringIO()):
+        losses = model(inputs)
+    model.criterion.matcher.forward = orig_match
+    hk.remove()
+    hk2.remove()
+    res = {"loss:" + k: np.float32(v.detach()) for k, v in losses.items()}
+    res["loss_keys"] = np.array(sorted(losses.keys()))
+    res["n_match_calls"] = np.int64(len(matches))
+    for c, m_ in enumerate(matches):
+        for b_, (i, j) in enumerate(m_):
+            res[f"match:{c}:{b_}:q"], res[f"match:{c}:{b_}:t"] = i.numpy().astype(np.int64), j.numpy().astype(np.int64)
+    total = sum(v for k, v in losses.items() if k in model.criterion.weight_dict)
+    total.backward()
+    named = [(n, p.grad) for n, p in model.named_parameters() if p.requires_grad and p.grad is not None]
+    for n, v in grad_signature(named).items():
+        res["gsig:" + n] = v
+    res["dfsig:src"] = grad_signature([("dfeat:src", feats.pop("src").grad)])["dfeat:src"]   # gradient of the transformer's input
+    for n, v in grad_signature([("feat:" + k, v) for k, v in feats.items()]).items():     # the backbone's output maps (NCHW)
+        res["fsig:" + n[5:]] = v
+    res["dfsig:res5"] = grad_signature([("dfeat:res5", feats["res5"].grad)])["dfeat:res5"]  # and the gradient that enters it
+    model.eval()
+    with torch.no_grad():
+        out = model.detr(model.preprocess_image(inputs))
+    res["eval_logits"] = out["pred_logits"].numpy()
+    res["eval_boxes"] = out["pred_boxes"].numpy()
+    np.savez_compressed(os.path.join(OUT, "detr_real.npz"), **res)
+    print("detr_real: losses", {k: round(float(v.detach()), 4) for k, v in losses.items() if "_" not in k[-2:]}, "params", len(named))
+
+
 def gold_sparseinst():
     """the reference's own InstanceContextEncoder + GroupIAMDecoder + SparseInstCriterion / SparseInstMatcher (loaded by
     path) on seeded ResNet features and bitmask targets: encoder output, decoder outputs, matcher indices, the four
@@ -670,6 +753,27 @@ def gold_transformer():
             res[f"{name}_g:{k}"] = (p.grad[::32] if p.dim() == 2 else p.grad).numpy().astype(np.float32)
     np.savez_compressed(os.path.join(OUT, "transformer.npz"), **res)
     print("transformer:", {k: float(np.abs(v).mean()) for k, v in res.items() if "_g:" not in k})
+    # the configuration DETR-R50 runs (6 + 6 layers, ffn 2048, 100 queries) on an 800 x 1333 batch's 25 x 42 map: fingerprints
+    from gen_golden_inputs import grad_signature
+    net = m.Transformer(256, 8, 6, 6, 2048, 0.1, normalize_before=False, return_intermediate_dec=True)
+    net.load_state_dict(seeded_state_dict(net, seed=76))
+    net.eval()
+    src, mask, qe, pos = synth_transformer_case(B=2, H=25, W=42, Q=100, seed=75)
+    x = src.clone().requires_grad_(True)
+    q = qe.clone().requires_grad_(True)
+    hs, mem = net(x, mask, q, pos)
+    gh = torch.randn(hs.shape, generator=torch.Generator().manual_seed(77)).to(torch.bfloat16).float()
+    (hs * gh).sum().backward()
+    real = {"hs_last": hs[-1].detach().numpy(), "dquery": q.grad.numpy()}
+    valid = ~mask.flatten(1)
+    real["sig:mem_valid"] = grad_signature([("mem_valid", mem.detach().flatten(2).transpose(1, 2)[valid])])["mem_valid"]
+    real["sig:hs"] = grad_signature([("hs", hs.detach())])["hs"]
+    real["sig:dsrc"] = grad_signature([("dsrc", x.grad)])["dsrc"]
+    real["sig:dsrc_valid"] = grad_signature([("dsrc_valid", x.grad.flatten(2).transpose(1, 2)[valid])])["dsrc_valid"]
+    for k, v in grad_signature([(k, p.grad) for k, p in net.named_parameters()]).items():
+        real["gsig:" + k] = v
+    np.savez_compressed(os.path.join(OUT, "transformer_real.npz"), **real)
+    print("transformer_real: |dsrc|", float(x.grad.norm()), "|dsrc valid|", real["sig:dsrc_valid"][0], "|hs|", float(hs.norm()))
 
 
 if __name__ == "__main__":
@@ -695,6 +799,7 @@ if __name__ == "__main__":
     gold_pos_embed()
     gold_detr()
     gold_detr_meta()
+    gold_detr_real()
     gold_sparseinst()
     gold_sparseinst_inference()
     gold_set_criterion()

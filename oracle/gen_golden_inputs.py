@@ -260,3 +260,21 @@ def bifpn_state_dict(module, seed=132):
         else:
             out[k] = 0.02 * torch.randn(*shp, generator=g)
     return out
+
+
+def grad_signature(named_grads, nproj=8):
+    """compact fingerprint of a set of gradients: per tensor its L2 norm and `nproj` projections on seeded +-1 vectors
+    (seed = crc32 of the parameter name).  For Rademacher r: E[(r . d)^2] = |d|^2, so the mean squared difference of two
+    tensors' projections estimates |g1 - g2|^2 - enough to bound a relative gradient error without shipping 160 MB"""
+    import zlib
+    import numpy as np
+    sig = {}
+    for name, g in named_grads:
+        g = g.detach().float().reshape(-1).cpu()
+        gen = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+        proj = []
+        for _ in range(nproj):
+            r = torch.randint(0, 2, (g.numel(),), generator=gen, dtype=torch.int8).float() * 2 - 1
+            proj.append(float((r.double() * g.double()).sum()))
+        sig[name] = np.array([float(g.double().norm())] + proj, dtype=np.float64)
+    return sig
