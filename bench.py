@@ -700,7 +700,10 @@ def main():
         t_nocomm = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
         dist.all_reduce(t_nocomm, op=dist.ReduceOp.MAX)
         red.enabled = True
-        ddp = dict(ranks=world, backend="nccl (RCCL over xGMI)" if backend == "nccl" else backend + " (rehearsal)", buckets_MB=sizes, bucket_allreduce_alone_ms=alone,
+        # bus bandwidth of each bucket's all-reduce alone, the NCCL-tests convention: algbw * 2 (n - 1) / n
+        busbw = [round(sz * 1e6 / (t * 1e-3) * 2 * (world - 1) / world / 1e9, 2) if t > 0 else None for sz, t in zip(sizes, alone)]
+        ddp = dict(ranks=world, rccl_ranks=world if backend == "nccl" else 0, busbw_GBps=busbw,
+                   backend="nccl (RCCL over xGMI)" if backend == "nccl" else backend + " (rehearsal)", buckets_MB=sizes, bucket_allreduce_alone_ms=alone,
                    bwd_segments=len(st["segs"]), ms_per_step_without_allreduce=round(float(t_nocomm) / args.steps * 1e3, 3),
                    exposed_comm_ms=round(ms - float(t_nocomm) / args.steps * 1e3, 3))
     incl = None
