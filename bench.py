@@ -386,15 +386,24 @@ def bench_detr(args):
                          gt_classes=torch.randint(0, 80, (n,), generator=g))
         inputs.append(dict(image=torch.randint(0, 256, (3, h, w), generator=g).float().to(dev), instances=inst))
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4)
+    graphed = not args.no_graph
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, capturable=graphed)
+    if graphed:
+        # forward + backward + AdamW of the eager module tree as ONE hipGraph per padded batch shape (graph_step.py); the
+        # host half (image padding, ground truth -> device) runs every step, outside the graph
+        from yolov7_d2_amd.graph_step import GraphedTrainStep
+        gstep = GraphedTrainStep(model, opt)
 
-    def step():
-        losses = model(inputs)
-        total = sum(v for k, v in losses.items() if k in model.criterion.weight_dict)
-        opt.zero_grad(set_to_none=True)
-        total.backward()
-        opt.step()
-        return total
+        def step():
+            return gstep(inputs)["total"]
+    else:
+        def step():
+            losses = model(inputs)
+            total = sum(v for k, v in losses.items() if k in model.criterion.weight_dict)
+            opt.zero_grad(set_to_none=True)
+            total.backward()
+            opt.step()
+            return total
 
     for _ in range(max(args.warmup, 2)):
         step()
@@ -435,7 +444,9 @@ def bench_detr(args):
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"DETR-R50 (6+6, 100 queries, dropout 0.1, FREEZE_AT 2) bs={B}/GPU, padded batch of "
-                               f"<=800x1333 images: fwd + Hungarian matcher + SetCriterion + bwd + AdamW (eager ops)",
+                               f"<=800x1333 images: fwd + Hungarian matcher + SetCriterion + bwd + AdamW "
+                               + ("(one hipGraph per padded shape, host half outside)" if graphed else "(eager ops)"),
+                   "hipgraph": graphed,
                    "final_loss": round(float(last), 4)},
         "roofline": {"bound": "mfma", "kernel": "mha_fwd2_kernel (encoder self-attention, L=%d, B=%d, 8 heads x 32)" % (L_, B),
                      "achieved": round(fl_f / (tf * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",

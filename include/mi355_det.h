@@ -470,6 +470,11 @@ int mi_mha_dropout_mask(uint8_t* out, int B, int H, int Lq, int Lk, float drop_p
 /* elementwise dropout of a bf16 tensor (F.dropout of detr_backbone.py:147-150,163-167,...): out[i] = keep(seed, i) ?
  * x[i] / (1-p) : 0; applying it with the same (p, seed) to the output gradient IS the backward. n %% 8 == 0. */
 int mi_dropout_bf16(const void* x, void* out, int64_t n, float drop_p, uint64_t seed, mi_stream_t s);
+/* A step captured as a hipGraph bakes its seeds into the kernel arguments.  With a device word registered here every
+ * dropout kernel launched afterwards (mi_dropout_bf16, mi_mha_*_dropout, forward and backward alike) uses seed + *dev_word,
+ * read at RUN time: advance the word once per replay (after the backward) and every replay draws fresh masks while the
+ * backward of a step still recomputes its own forward's.  NULL (default) switches it off.  Process-global, not per stream. */
+int mi_dropout_seed_offset(const uint64_t* dev_word);
 
 /* ---- row-wise ops of DETR's transformer layers (detr_backbone.py:135-278) -------------------
  * nn.LayerNorm(E) forward / backward over bf16 [T][E] token rows (fp32 gamma/beta/mean/rstd), eps 1e-5;

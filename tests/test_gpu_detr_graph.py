@@ -1,0 +1,93 @@
+"""GPU (-m gpu): the DETR training step (configs[3]: meta_arch/detr.py:136-279 forward + SetCriterion + backward + AdamW)
+captured as ONE hipGraph (yolov7_d2_amd/graph_step.py) against the eager module-by-module step: same losses, same
+parameters after several optimizer steps; a second batch with other images, other box counts and other image sizes inside
+the same padded shape REPLAYS the same graph (masks, targets and 1 / num_boxes live on the device); dropout draws a fresh
+mask on every replay (mi_dropout_seed_offset) although seeds are launch constants of the captured graph."""
+import copy
+
+import pytest
+import torch
+
+import yolov7_d2_amd as M
+from yolov7_d2_amd.d2shim import Boxes, Instances
+from yolov7_d2_amd.graph_step import GraphedTrainStep
+from gen_golden_inputs import seeded_tensor_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _batch(seed, sizes, counts):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for (h, w), n in zip(sizes, counts):
+        wh = 16 + torch.rand(n, 2, generator=g) * 96
+        xy = torch.rand(n, 2, generator=g) * (torch.tensor([w, h]) - wh).clamp(min=1)
+        inst = Instances((h, w), gt_boxes=Boxes(torch.cat([xy, xy + wh], 1)), gt_classes=torch.randint(0, 80, (n,), generator=g))
+        out.append(dict(image=torch.randint(0, 256, (3, h, w), generator=g).float().to(DEV), instances=inst))
+    return out
+
+
+def _model(dropout):
+    cfg = M.detr_r50_cfg(device=DEV)
+    cfg.MODEL.DETR.ENC_LAYERS, cfg.MODEL.DETR.DEC_LAYERS, cfg.MODEL.DETR.NUM_OBJECT_QUERIES = 2, 2, 30
+    cfg.MODEL.DETR.DROPOUT = dropout
+    model = M.build_model(cfg)
+    sd = model.state_dict()
+    model.load_state_dict(seeded_tensor_dict({k: v.shape for k, v in sd.items()}, seed=203), strict=False)
+    with torch.no_grad():
+        model.detr.input_proj.weight.mul_(1e-3)     # (encoder tokens of trained magnitude: see test_gpu_detr_meta real-size test)
+    model.train()
+    return model
+
+
+def _opt(model, lr=1e-4):
+    return torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=lr, weight_decay=1e-4, capturable=True)
+
+
+def test_graphed_step_equals_eager_step_and_serves_other_batches():
+    batches = [_batch(1, ((256, 320), (224, 288)), (3, 2)),
+               _batch(2, ((256, 320), (256, 256)), (1, 5)),      # other sizes inside the same padded shape, other box counts
+               _batch(3, ((240, 320), (256, 300)), (4, 4))]
+    eager, graphed = _model(0.0), _model(0.0)
+    oe, og = _opt(eager), _opt(graphed)
+    step = GraphedTrainStep(graphed, og)
+    try:
+        for it, b in enumerate(batches):
+            losses = eager(b)
+            total = sum(v for k, v in losses.items() if k in eager.criterion.weight_dict)
+            oe.zero_grad(set_to_none=True)
+            total.backward()
+            oe.step()
+            out = step(b)
+            assert len(step.graphs) == 1                      # one capture serves all three batches
+            for k, v in losses.items():
+                torch.testing.assert_close(out[k].float(), v.detach().float(), rtol=2e-3, atol=2e-3, msg=f"step {it} {k}")
+        torch.cuda.synchronize()
+        worst = 0.0
+        for (n, p), (_, q) in zip(eager.named_parameters(), graphed.named_parameters()):
+            if p.requires_grad:
+                d = float((p.detach() - q.detach()).abs().max())
+                worst = max(worst, d)
+                # three AdamW steps of lr 1e-4 move a weight by <= 3e-4; both paths must have moved it the same way
+                assert d <= 1.5e-4, (n, d)
+        assert int(step.seed_word) == len(batches)
+    finally:
+        step.close()
+
+
+def test_graphed_step_draws_fresh_dropout_masks_per_replay():
+    model = _model(0.1)
+    opt = _opt(model, lr=0.0)                                   # parameters stay put: only the masks can change the loss
+    step = GraphedTrainStep(model, opt)
+    try:
+        b = _batch(5, ((256, 320), (224, 288)), (3, 2))
+        a1 = float(step(b)["total"])
+        a2 = float(step(b)["total"])
+        a3 = float(step(b)["total"])
+        assert len({a1, a2, a3}) == 3, (a1, a2, a3)             # a captured seed constant alone would repeat the same mask
+        assert abs(a1 - a2) < 0.2 * abs(a1)
+        step.seed_word.fill_(0)                                  # the word back at 0: the first replay's mask again
+        assert float(step(b)["total"]) == a1
+    finally:
+        step.close()

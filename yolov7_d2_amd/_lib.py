@@ -204,6 +204,7 @@ _PROTOS = {
     "mi_conv2d_group_plan": (C.c_int, [C.POINTER(mi_conv_desc), _i, _vp, _i64, C.POINTER(mi_conv_group)]),
     "mi_conv2d_group_run": (C.c_int, [C.POINTER(mi_conv_group), _vp, _vp]),
     "mi_conv2d_route": (C.c_int, [C.POINTER(mi_conv_desc)]),
+    "mi_dropout_seed_offset": (C.c_int, [_vp]),
     "mi_conv2d_bn_plan": (C.c_int, [C.POINTER(mi_conv_desc), C.POINTER(mi_bn_job), _i, C.POINTER(mi_conv_group)]),
     "mi_conv2d_bn_fwd": (C.c_int, [C.POINTER(mi_conv_desc), C.POINTER(mi_bn_job), _i, _vp]),
     "mi_conv_bn_barrier_status": (C.c_int, [C.POINTER(C.c_uint32)]),

@@ -59,12 +59,14 @@ struct MhaK {
   unsigned drop_thr;   // 0 = no dropout
   float drop_scale;
   unsigned long long seed;
+  const unsigned long long* seed_off;   // device word added to seed (mi_dropout_seed_offset) or NULL
 };
 
 __device__ __forceinline__ float mha_keep(const MhaK& p, int b, int h, int q, int key) {
   if (p.drop_thr == 0u) return 1.f;
   const unsigned long long idx = (((unsigned long long)(b * p.H + h) * p.Lq + q) * p.Lk + key);
-  return mi_rng32(p.seed, idx) >= p.drop_thr ? p.drop_scale : 0.f;
+  const unsigned long long seed = p.seed + (p.seed_off ? *p.seed_off : 0ull);   // (uniform scalar load, cached)
+  return mi_rng32(seed, idx) >= p.drop_thr ? p.drop_scale : 0.f;
 }
 
 // LDS tile of 32 rows x 32 d (64-byte rows), 16-byte chunks XOR-swizzled by (row >> 2) & 3 for the direct b128
@@ -767,9 +769,11 @@ static int mha2_waves(int L, int BH) {
   return nwv;
 }
 
+extern const unsigned long long* g_mi_seed_off;   // runtime.hip
 static int mha_set_dropout(MhaK* p, float drop_p, unsigned long long seed) {
   MI_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "mha: dropout p %f", drop_p);
   p->seed = seed;
+  p->seed_off = g_mi_seed_off;
   p->drop_thr = drop_p > 0.f ? (unsigned)((double)drop_p * 4294967296.0) : 0u;
   if (drop_p > 0.f && p->drop_thr == 0u) p->drop_thr = 1u;
   p->drop_scale = 1.f / (1.f - drop_p);

@@ -11,6 +11,13 @@ thread_local char g_mi_err[512] = {0};
 
 extern "C" int mi_version(void) { return 100; }
 extern "C" const char* mi_last_error(void) { return g_mi_err; }
+
+// device word added to every dropout seed (see mi_dropout_seed_offset in the header); NULL = none
+const unsigned long long* g_mi_seed_off = nullptr;
+extern "C" int mi_dropout_seed_offset(const uint64_t* dev_word) {
+  g_mi_seed_off = (const unsigned long long*)dev_word;
+  return MI_OK;
+}
 extern "C" int mi_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -164,8 +164,10 @@ extern "C" int mi_sigmoid_f32(const float* x, const float* dy, float* y, float* 
 }
 
 // ---- elementwise dropout (F.dropout in the transformer layers, detr_backbone.py:147-150,163-167,212-217,235-243)
+extern const unsigned long long* g_mi_seed_off;   // runtime.hip
 __global__ __launch_bounds__(256) void dropout_kernel(const __bf16* __restrict__ x, __bf16* o, int64_t n8, unsigned thr,
-                                                      float scale, unsigned long long seed) {
+                                                      float scale, unsigned long long seed, const unsigned long long* seed_off) {
+  if (seed_off) seed += *seed_off;   // (a captured step: the word is advanced once per replay)
   for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
     const bf16x8 v = *(const bf16x8*)(x + i * 8);
     bf16x8 r;
@@ -184,7 +186,7 @@ extern "C" int mi_dropout_bf16(const void* x, void* out, int64_t n, float drop_p
   int64_t nb = (n / 8 + 255) / 256;
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)st, (const __bf16*)x, (__bf16*)out,
-                     n / 8, thr, 1.f / (1.f - drop_p), (unsigned long long)seed);
+                     n / 8, thr, 1.f / (1.f - drop_p), (unsigned long long)seed, g_mi_seed_off);
   MI_CHECK_LAUNCH("dropout");
   return MI_OK;
 }

@@ -1,0 +1,98 @@
+"""One training step of an eager module tree as ONE hipGraph.
+
+The YOLOX path has its own step plan (plan.py: a command list built per input shape, replayed as hipGraphs).  DETR and
+SparseInst run module by module through the per-op autograd functions - ~3 000 launches and as many Python calls per
+step, host-bound (26 ms of kernels in a 37 ms DETR step).  GraphedTrainStep captures forward + backward + optimizer of such
+a model with torch.cuda.graph, once per padded batch shape, and replays it: no per-op Python, no launch gaps.
+
+Contract with the model (yolov7_d2_amd.modeling.detr_meta.Detr implements it):
+  batch_key(batched_inputs) -> hashable   what a captured graph is specialised for (batch size, padded image size)
+  prepare_batch(batched_inputs, static=None) -> static
+        everything that touches the host - image padding, ground truth -> device - into tensors that are REFILLED IN
+        PLACE when `static` is passed back (the graph reads the same addresses for every batch)
+  forward_prepared(static) -> {name: loss}   device work only: no host value of the batch may enter a launch argument
+
+Dropout: seeds are launch arguments, i.e. constants of the captured graph.  The library adds a device word to every
+dropout seed at run time (mi_dropout_seed_offset); the captured step advances it after the backward, so every replay draws
+fresh masks and each backward still recomputes its own forward's.
+"""
+import torch
+
+from . import _lib as L
+
+
+class GraphedTrainStep:
+    def __init__(self, model, optimizer, loss_keys=None, warmup=2):
+        """optimizer: a torch optimizer created with capturable=True (AdamW / Adam / SGD).
+        loss_keys: the entries of the loss dict that are summed into the objective (default: model.criterion.weight_dict)."""
+        self.model, self.opt, self.warmup = model, optimizer, warmup
+        self.loss_keys = loss_keys
+        self.graphs = {}
+        self.seed_word = torch.zeros(1, dtype=torch.int64, device=model.device)
+        L.check(L.lib().mi_dropout_seed_offset(self.seed_word.data_ptr()), "mi_dropout_seed_offset")
+
+    def close(self):
+        L.check(L.lib().mi_dropout_seed_offset(None), "mi_dropout_seed_offset")
+        self.graphs.clear()
+
+    def _keys(self, losses):
+        if self.loss_keys is not None:
+            return self.loss_keys
+        wd = getattr(getattr(self.model, "criterion", None), "weight_dict", None)
+        return [k for k in losses if wd is None or k in wd]
+
+    def _body(self, static):
+        losses = self.model.forward_prepared(static)
+        total = sum(losses[k] for k in self._keys(losses))
+        self.opt.zero_grad(set_to_none=True)
+        total.backward()
+        self.opt.step()
+        self.seed_word += 1
+        out = {k: v.detach() for k, v in losses.items()}
+        out["total"] = total.detach()
+        return out
+
+    def _snapshot(self):
+        st = [p.detach().clone() for g in self.opt.param_groups for p in g["params"]]
+        os_ = {id(p): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in s.items()} for p, s in self.opt.state.items()}
+        return st, os_, self.seed_word.clone()
+
+    def _restore(self, snap):
+        st, os_, sw = snap
+        with torch.no_grad():
+            for p, v in zip((p for g in self.opt.param_groups for p in g["params"]), st):
+                p.copy_(v)
+            for p, s in self.opt.state.items():
+                old = os_.get(id(p))
+                for k, v in s.items():
+                    if torch.is_tensor(v):
+                        if old is not None and k in old:
+                            v.copy_(old[k])
+                        else:
+                            v.zero_()      # state created by the warm-up steps: back to its initial value
+            self.seed_word.copy_(sw)
+
+    def __call__(self, batched_inputs):
+        """one optimizer step on the batch; returns the loss dict (device scalars of the step just run)"""
+        key = self.model.batch_key(batched_inputs)
+        ent = self.graphs.get(key)
+        if ent is None:
+            static = self.model.prepare_batch(batched_inputs)
+            # warm-up on a side stream (lazy initialisation inside the library, allocator pools), undone afterwards:
+            # the first real step on this batch is the first replay
+            snap = self._snapshot()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(self.warmup):
+                    self._body(static)
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self._body(static)
+            self._restore(snap)
+            ent = self.graphs[key] = (g, static, out)
+        else:
+            self.model.prepare_batch(batched_inputs, static=ent[1])
+        ent[0].replay()
+        return ent[2]

@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from .. import _lib as L
-from .detr_matcher import HungarianMatcher
+from .detr_matcher import HungarianMatcher, PackedTargets
 
 
 class _SetLossFn(torch.autograd.Function):
@@ -44,7 +44,7 @@ class _SetLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         lg, bx = ctx.keep[0], ctx.keep[1]
-        gw = g.float()[[0, 3, 4]].contiguous()
+        gw = torch.stack((g[0], g[3], g[4])).float().contiguous()     # (no index tensor: nothing is copied from the host)
         dl, db = torch.empty_like(lg), torch.empty_like(bx)
         L.check(L.lib().mi_detr_set_loss_bwd(C.byref(ctx.desc), gw.data_ptr(), dl.data_ptr(), db.data_ptr(),
                                              L.stream_ptr()), "mi_detr_set_loss_bwd")
@@ -89,7 +89,7 @@ class SetCriterion(nn.Module):
             return self.matcher.match_device(outputs, targets)
         return _pack_indices(self.matcher(outputs, targets), targets, outputs["pred_logits"].device)
 
-    def _level(self, outputs, targets, num_boxes, log):
+    def _level(self, outputs, targets, num_boxes, log, inv_nb=None):
         if not outputs["pred_logits"].is_cuda:
             raise L.MI355Error("SetCriterion: the MI355X path needs device tensors (no CPU fallback)")
         if outputs["pred_logits"].shape[-1] != self.num_classes + 1:
@@ -105,9 +105,19 @@ class SetCriterion(nn.Module):
             out["cardinality_error"] = v[2].detach()
         if "boxes" in self.losses:
             out["loss_bbox"], out["loss_giou"] = v[3], v[4]
+            if inv_nb is not None:     # the kernels ran with num_boxes = 1: both sums are linear in 1 / num_boxes
+                out["loss_bbox"], out["loss_giou"] = v[3] * inv_nb[0], v[4] * inv_nb[0]
         return out
 
     def forward(self, outputs, targets):
+        if isinstance(targets, PackedTargets):
+            # device-resident targets (Detr.prepare_batch): 1 / num_boxes is a device scalar (already averaged over the
+            # ranks there), so that a captured step serves batches with any number of boxes
+            inv = targets.inv_num_boxes
+            losses = self._level({k: v for k, v in outputs.items() if k != "aux_outputs"}, targets, 1.0, True, inv)
+            for i, aux in enumerate(outputs.get("aux_outputs", [])):
+                losses.update({k + f"_{i}": v for k, v in self._level(aux, targets, 1.0, False, inv).items()})
+            return losses
         num_boxes = float(sum(len(t["labels"]) for t in targets))
         world = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():   # detr.py:616-619

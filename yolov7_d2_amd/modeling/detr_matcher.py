@@ -11,6 +11,18 @@ from torch import nn
 from .. import _lib as L
 
 
+class PackedTargets(list):
+    """the ground truth of a batch in the criterion's DEVICE layout, with a fixed capacity per image: a list of the
+    reference's {"labels", "boxes"} dicts (so foreign code still sees detr.py:199-213's targets) that also carries
+    tgt_off int32 [B + 1], tgt_labels int64 [B * cap], tgt_boxes fp32 [B * cap, 4] (compact, indexed through tgt_off) and
+    inv_num_boxes fp32 [1] = 1 / max(sum of boxes / world, 1).  Nothing in it lives on the host: a step captured as a
+    hipGraph reads the SAME tensors for every batch (Detr.prepare_batch refills them in place)."""
+
+    def __init__(self, dicts, cap, tgt_off, tgt_labels, tgt_boxes, inv_num_boxes):
+        super().__init__(dicts)
+        self.cap, self.tgt_off, self.tgt_labels, self.tgt_boxes, self.inv_num_boxes = cap, tgt_off, tgt_labels, tgt_boxes, inv_num_boxes
+
+
 class HungarianMatcher(nn.Module):
     def __init__(self, cost_class: float = 1, cost_bbox: float = 1, cost_giou: float = 1):
         super().__init__()
@@ -28,13 +40,16 @@ class HungarianMatcher(nn.Module):
             raise L.MI355Error("HungarianMatcher: the MI355X path needs device tensors (no CPU fallback)")
         bs, nq, nc = logits.shape
         dev = logits.device
-        sizes = [len(v["boxes"]) for v in targets]
-        gmax = max(max(sizes), 1)
-        off = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32, device=dev)
-        tl = torch.cat([v["labels"] for v in targets]).to(dev, torch.int64).contiguous()
-        tb = torch.cat([v["boxes"] for v in targets]).to(dev, torch.float32).contiguous()
-        if tl.numel() == 0:   # no targets at all: keep the pointers valid
-            tl, tb = torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(1, 4, device=dev)
+        if isinstance(targets, PackedTargets):     # device-resident, fixed capacity: no host value enters the launch
+            gmax, off, tl, tb, ntot = targets.cap, targets.tgt_off, targets.tgt_labels, targets.tgt_boxes, -1
+        else:
+            sizes = [len(v["boxes"]) for v in targets]
+            gmax, ntot = max(max(sizes), 1), sum(sizes)
+            off = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32, device=dev)
+            tl = torch.cat([v["labels"] for v in targets]).to(dev, torch.int64).contiguous()
+            tb = torch.cat([v["boxes"] for v in targets]).to(dev, torch.float32).contiguous()
+            if tl.numel() == 0:   # no targets at all: keep the pointers valid
+                tl, tb = torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(1, 4, device=dev)
         cost = torch.empty(bs, nq, gmax, device=dev)
         mq = torch.empty(bs, gmax, dtype=torch.int64, device=dev)
         mt = torch.empty(bs, gmax, dtype=torch.int64, device=dev)
@@ -45,7 +60,7 @@ class HungarianMatcher(nn.Module):
                                            mt.data_ptr(), nm.data_ptr(), L.stream_ptr()), "mi_hungarian_match")
         self.last_cost = cost
         return dict(match_q=mq, match_t=mt, nmatch=nm, tgt_off=off, tgt_labels=tl, tgt_boxes=tb, gmax=gmax,
-                    num_targets=sum(sizes))
+                    num_targets=ntot)
 
     @torch.no_grad()
     def forward(self, outputs, targets):

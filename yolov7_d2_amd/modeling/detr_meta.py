@@ -73,7 +73,9 @@ class MaskedBackbone(nn.Module):
     def forward(self, images):
         tensor = images.tensor if isinstance(images, ImageList) else images.tensors
         features = self.backbone(tensor)
-        if isinstance(images, ImageList):
+        if isinstance(images, ImageList) and getattr(images, "sizes_dev", None) is not None:
+            masks = self.mask_out_padding_dev([f.shape for f in features.values()], images.sizes_dev)
+        elif isinstance(images, ImageList):
             masks = self.mask_out_padding([f.shape for f in features.values()], images.image_sizes, tensor.device)
         else:   # a NestedTensor carries its own pixel mask: nearest down-sampling, as the reference's export branch does
             m = images.mask
@@ -92,6 +94,22 @@ class MaskedBackbone(nn.Module):
                 m[img_idx, : int(np.ceil(float(h) / self.feature_strides[idx])),
                   : int(np.ceil(float(w) / self.feature_strides[idx]))] = 0
             masks.append(m)
+        return masks
+
+
+    def mask_out_padding_dev(self, feature_shapes, sizes_dev):
+        """the same masks from a DEVICE tensor of (h, w) rows: no host value enters a launch argument, so a step captured
+        as a hipGraph serves every batch of the same padded shape (Detr.prepare_batch)"""
+        masks = []
+        dev = sizes_dev.device
+        for idx, shape in enumerate(feature_shapes):
+            N, _, H, W = shape
+            st = self.feature_strides[idx]
+            hv = torch.div(sizes_dev[:, 0] + (st - 1), st, rounding_mode="floor")      # ceil(h / stride)
+            wv = torch.div(sizes_dev[:, 1] + (st - 1), st, rounding_mode="floor")
+            ys = torch.arange(H, device=dev)[None, :, None]
+            xs = torch.arange(W, device=dev)[None, None, :]
+            masks.append((ys >= hv[:, None, None]) | (xs >= wv[:, None, None]))
         return masks
 
 
@@ -183,6 +201,79 @@ class Detr(nn.Module):
             gt_boxes = box_xyxy_to_cxcywh(t.gt_boxes.tensor.to(self.device) / image_size_xyxy)
             new_targets.append({"labels": t.gt_classes.to(self.device), "boxes": gt_boxes})
         return new_targets
+
+    # ---- the training step split at the host / device line (graph_step.GraphedTrainStep captures the device half)
+    target_capacity = 100     # ground-truth boxes per image the packed layout holds (COCO: <= 93 after crowd removal)
+
+    def batch_key(self, batched_inputs):
+        return (len(batched_inputs), max(int(x["image"].shape[-2]) for x in batched_inputs),
+                max(int(x["image"].shape[-1]) for x in batched_inputs))
+
+    def prepare_batch(self, batched_inputs, static=None):
+        """Everything of forward() that touches the host: normalise + zero-pad the images into one tensor, record the
+        image sizes ON THE DEVICE, and (training) move the ground truth over packed in the criterion's device layout
+        (detr_matcher.PackedTargets).  With `static` - an earlier result for the same batch_key - the tensors are
+        refilled IN PLACE, so a captured step that reads them sees the new batch."""
+        from .detr_matcher import PackedTargets
+        B, Hp, Wp = self.batch_key(batched_inputs)
+        dev = self.device
+        if static is None:
+            tensor = torch.zeros(B, 3, Hp, Wp, device=dev)
+            images = ImageList(tensor, [(0, 0)] * B)
+            images.sizes_dev = torch.zeros(B, 2, dtype=torch.int64, device=dev)
+            cap = self.target_capacity
+            targets = PackedTargets([None] * B, cap, torch.zeros(B + 1, dtype=torch.int32, device=dev),
+                                    torch.zeros(B * cap, dtype=torch.int64, device=dev),
+                                    torch.zeros(B * cap, 4, dtype=torch.float32, device=dev), torch.ones(1, device=dev))
+            static = dict(images=images, targets=targets, key=(B, Hp, Wp))
+        assert static["key"] == (B, Hp, Wp), (static["key"], (B, Hp, Wp))
+        images, targets = static["images"], static["targets"]
+        images.tensor.zero_()
+        sizes = []
+        for b, x in enumerate(batched_inputs):
+            img = x["image"].to(dev).float()
+            h, w = int(img.shape[-2]), int(img.shape[-1])
+            images.tensor[b, :, :h, :w].copy_(self.normalizer(img))
+            sizes.append((h, w))
+        images.image_sizes = sizes
+        images.sizes_dev.copy_(torch.tensor(sizes, dtype=torch.int64), non_blocking=False)
+        if self.training:
+            cap = targets.cap
+            labels, boxes, off = [], [], [0]
+            for b, x in enumerate(batched_inputs):
+                t = x["instances"]
+                n = len(t)
+                if n > cap:
+                    raise ValueError(f"Detr.prepare_batch: {n} ground-truth boxes in one image, target_capacity is {cap}")
+                h, w = t.image_size
+                xy = t.gt_boxes.tensor.float().cpu() / torch.tensor([w, h, w, h], dtype=torch.float)
+                x0, y0, x1, y1 = xy.unbind(-1)          # (box_xyxy_to_cxcywh of utils/boxes.py:28-32, on the host)
+                bx = torch.stack([(x0 + x1) / 2, (y0 + y1) / 2, (x1 - x0), (y1 - y0)], dim=-1)
+                labels.append(t.gt_classes.cpu().to(torch.int64))
+                boxes.append(bx)
+                off.append(off[-1] + n)
+                targets[b] = None      # (the per-image dicts are views of the packed tensors, rebuilt below)
+            ntot = off[-1]
+            if ntot:
+                targets.tgt_labels[:ntot].copy_(torch.cat(labels))
+                targets.tgt_boxes[:ntot].copy_(torch.cat(boxes))
+            targets.tgt_off.copy_(torch.tensor(off, dtype=torch.int32))
+            nb = torch.tensor([float(ntot)], device=dev)
+            world = 1
+            if torch.distributed.is_available() and torch.distributed.is_initialized():      # detr.py:616-619
+                torch.distributed.all_reduce(nb)
+                world = torch.distributed.get_world_size()
+            targets.inv_num_boxes.copy_(1.0 / torch.clamp(nb / world, min=1.0))
+            for b in range(B):
+                targets[b] = {"labels": targets.tgt_labels[off[b]:off[b + 1]], "boxes": targets.tgt_boxes[off[b]:off[b + 1]]}
+        return static
+
+    def forward_prepared(self, static):
+        """the device half of the training forward: no host value of the batch enters a launch (capturable)"""
+        output = self.detr(static["images"])
+        loss_dict = self.criterion(output, static["targets"])
+        weight_dict = self.criterion.weight_dict
+        return {k: (v * weight_dict[k] if k in weight_dict else v) for k, v in loss_dict.items()}
 
     def forward(self, batched_inputs):
         if self.device.type != "cuda":
