@@ -524,3 +524,58 @@ def test_transformer_real_size_against_reference_golden(golden_dir):
     assert out["hs_last"] < 3e-2 and out["hs"][0] < 3e-2 and out["mem_valid"][0] < 3e-2
     assert out["dsrc"][0] < 0.1 and out["dquery"] < 0.1, out
     assert np.median(rels) < 0.06 and rels[-1] < 0.15      # measured: median 0.035, max 0.09
+
+
+# ------------------------------------------------------------------------------------------ row-wise kernels, direct
+@pytest.mark.parametrize("T,E", [(4200, 256), (100, 256), (37, 64), (1050, 512), (333, 1024), (64, 128)])
+def test_layernorm_fwd_bwd_against_torch(T, E):
+    """mi_layernorm_fwd / _bwd (nn.LayerNorm of detr_backbone.py:135-278) against torch fp32 on the same bf16 operands"""
+    g = torch.Generator().manual_seed(T + E)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    x, dy = bf(torch.randn(T, E, generator=g) * 2 + 0.5), bf(torch.randn(T, E, generator=g))
+    gamma, beta = 1 + 0.1 * torch.randn(E, generator=g), 0.1 * torch.randn(E, generator=g)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (E,), gr, br, 1e-5)
+    yr.backward(dy)
+    xd, dyd = x.to(DEV, torch.bfloat16), dy.to(DEV, torch.bfloat16)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    y = torch.empty_like(xd)
+    mean, rstd = torch.empty(T, device=DEV), torch.empty(T, device=DEV)
+    L.check(L.lib().mi_layernorm_fwd(xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                     T, E, 1e-5, L.stream_ptr()), "ln_fwd")
+    dx = torch.empty_like(xd)
+    dgam, dbet = torch.empty(E, device=DEV), torch.empty(E, device=DEV)
+    ws = torch.empty((T + 63) // 64 * E * 2, device=DEV)
+    L.check(L.lib().mi_layernorm_bwd(xd.data_ptr(), dyd.data_ptr(), gd.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                                     dgam.data_ptr(), dbet.data_ptr(), ws.data_ptr(), T, E, L.stream_ptr()), "ln_bwd")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(y.float().cpu().numpy(), yr.detach().numpy(), rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(dx.float().cpu().numpy(), xr.grad.numpy(), rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(dgam.cpu().numpy(), gr.grad.numpy(), rtol=1e-3, atol=1e-3 * T ** 0.5)
+    np.testing.assert_allclose(dbet.cpu().numpy(), br.grad.numpy(), rtol=1e-3, atol=1e-3 * T ** 0.5)
+
+
+@pytest.mark.parametrize("T,C,extra,acc", [(4200, 256, 0, 0), (4200, 2048, 0, 1), (100, 92, 4, 0), (7, 8, 8, 0), (20000, 96, 32, 1)])
+def test_colsum_wide_one_launch_equals_two_stage(T, C, extra, acc, monkeypatch):
+    """mi_colsum_bf16_wide (bias gradients of the transformer's Linear layers): the one-launch form (last block of a
+    channel chunk sums the partials in block order) is bit-identical to the two-stage form and close to fp64 sums"""
+    g = torch.Generator().manual_seed(T + C)
+    x = torch.randn(T, C + extra, generator=g).to(DEV, torch.bfloat16)
+    outs = []
+    for two in ("0", "1"):
+        out = torch.full((C,), 3.0, device=DEV)
+        ws = torch.empty(L.lib().mi_colsum_wide_ws_bytes(C) // 4, device=DEV)
+        monkeypatch.setenv("MI_COLSUM_TWO_STAGE", two)
+        L.check(L.lib().mi_colsum_bf16_wide(x.data_ptr(), C + extra, T, C, out.data_ptr(), acc, ws.data_ptr(), L.stream_ptr()), "colsum")
+        torch.cuda.synchronize()
+        outs.append(out)
+    monkeypatch.delenv("MI_COLSUM_TWO_STAGE")
+    assert torch.equal(outs[0], outs[1])
+    ref = x[:, :C].double().sum(0) + (3.0 if acc else 0.0)
+    np.testing.assert_allclose(outs[0].cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-3 * T ** 0.5)
+    for _ in range(3):                                     # the chunk counters persist across launches: again
+        out = torch.full((C,), 3.0, device=DEV)
+        ws = torch.empty(L.lib().mi_colsum_wide_ws_bytes(C) // 4, device=DEV)
+        L.check(L.lib().mi_colsum_bf16_wide(x.data_ptr(), C + extra, T, C, out.data_ptr(), acc, ws.data_ptr(), L.stream_ptr()), "colsum")
+        assert torch.equal(out, outs[0])

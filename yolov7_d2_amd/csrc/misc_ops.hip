@@ -1,5 +1,6 @@
 // Data-movement ops of the YOLOX path (NHWC bf16): Focus space-to-depth, nearest x2 upsample,
 // SPP max-pools, strided copy, column sums, and the fused SGD-momentum update.  All HBM-bound.
+#include <stdlib.h>
 #include "common.h"
 
 static int ew_blocks(int64_t total, int cap = 4096) {
@@ -593,6 +594,50 @@ __global__ __launch_bounds__(128) void colsum_wide_stage2_kernel(const float* __
   for (int b = 0; b < nblk; ++b) a += part[(size_t)b * CP + c];
   out[c] = accumulate ? out[c] + a : a;
 }
+// one launch: stage 1 as above, then the LAST block of each 64-channel chunk to arrive (a counter per chunk) sums the chunk's
+// partials in block order - deterministic, and no second launch (143 bias gradients per DETR step).  The partials cross
+// blocks as agent-scope atomic stores / loads (performed memory-side: no cache maintenance needed, cf. bn_grid_barrier).
+// The counters are a library-wide static: launches of this kernel must not overlap (they are issued on one stream).
+#define COLSUM_MAX_CHUNKS 64
+static __device__ unsigned g_colsum_cnt[COLSUM_MAX_CHUNKS];
+__global__ __launch_bounds__(256) void colsum_wide_fused_kernel(const __bf16* __restrict__ x, int ldx, int64_t npix, int CP, int C,
+                                                                float* __restrict__ part, float* out, int accumulate) {
+  __shared__ float red[256 * 8];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, c0 = blockIdx.y * 64;
+  const int C8N = (CP - c0 >= 64) ? 8 : (CP - c0) / 8, PL = 256 / C8N;
+  const int c8 = tid % C8N, pl = tid / C8N;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  if (pl < PL)
+    for (int64_t p = (int64_t)blockIdx.x * PL + pl; p < npix; p += (int64_t)gridDim.x * PL) {
+      const bf16x8 v = *(const bf16x8*)(x + p * ldx + c0 + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[tid * 8 + e] = (pl < PL) ? s[e] : 0.f;
+  __syncthreads();
+  if (tid < C8N * 8) {
+    const int cc8 = tid >> 3, e = tid & 7;
+    float a = 0.f;
+    for (int q = 0; q < PL; ++q) a += red[(q * C8N + cc8) * 8 + e];
+    __hip_atomic_store(part + (size_t)blockIdx.x * CP + c0 + tid, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();   // (workgroup release: the stores above are acknowledged)
+  if (tid == 0)
+    s_last = __hip_atomic_fetch_add(&g_colsum_cnt[blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  if (tid == 0) __hip_atomic_store(&g_colsum_cnt[blockIdx.y], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid < C8N * 8 && c0 + tid < C) {
+    float a = 0.f;
+    for (int b = 0; b < (int)gridDim.x; ++b)
+      a += __hip_atomic_load(part + (size_t)b * CP + c0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[c0 + tid] = accumulate ? out[c0 + tid] + a : a;
+  }
+}
 extern "C" int64_t mi_colsum_wide_ws_bytes(int C) { return (int64_t)128 * ((C + 7) / 8 * 8) * 4; }
 extern "C" int mi_colsum_bf16_wide(const void* x, int ldx, int64_t npix, int C, float* out, int accumulate, float* ws,
                                    mi_stream_t st) {
@@ -603,6 +648,14 @@ extern "C" int mi_colsum_bf16_wide(const void* x, int ldx, int64_t npix, int C, 
   int nblk = (int)((npix + 255) / 256);
   if (nblk > 128) nblk = 128;
   if (nblk < 1) nblk = 1;
+  const char* two_e = getenv("MI_COLSUM_TWO_STAGE");   // (read per call: the tests compare the two forms in one process)
+  const int two = two_e ? atoi(two_e) : 0;
+  if ((CP + 63) / 64 <= COLSUM_MAX_CHUNKS && !two) {
+    hipLaunchKernelGGL(colsum_wide_fused_kernel, dim3(nblk, (CP + 63) / 64), dim3(256), 0, s, (const __bf16*)x, ldx, npix, CP, C, ws,
+                       out, accumulate);
+    MI_CHECK_LAUNCH("colsum_wide");
+    return MI_OK;
+  }
   hipLaunchKernelGGL(colsum_wide_stage1_kernel, dim3(nblk, (CP + 63) / 64), dim3(256), 0, s, (const __bf16*)x, ldx, npix, CP, ws);
   MI_CHECK_LAUNCH("colsum_wide1");
   hipLaunchKernelGGL(colsum_wide_stage2_kernel, dim3((C + 127) / 128), dim3(128), 0, s, ws, nblk, CP, C, out, accumulate);

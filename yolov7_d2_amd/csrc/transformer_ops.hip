@@ -25,28 +25,35 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const __bf16* __rest
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-// ---- LayerNorm backward: dx per row; dgamma / dbeta as block partials [nblk][E][2] (second stage below)
+// ---- LayerNorm backward: dx per row; dgamma / dbeta as block partials [nblk][E][2] (second stage below).
+// A lane owns PER = E / 64 CONSECUTIVE channels (one 2 PER-byte load per tensor and row); a block takes rows_per_block rows,
+// chosen by the launcher so that the grid is ~2 blocks per CU (T = 4200 tokens: 16 rows, 263 blocks; the first version's
+// fixed 64 rows gave 66 blocks of scalar 2-byte loads: 37 us per call).
+template <int PER>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ dy,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, __bf16* dx, float* part,
                                                             int T, int E, int rows_per_block) {
   extern __shared__ float sacc[];  // [4 waves][E][2]
+  typedef __attribute__((ext_vector_type(PER))) __bf16 bvec;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int per = E / 64;
-  float ag[16], ab[16];
-  for (int j = 0; j < per; ++j) ag[j] = ab[j] = 0.f;
+  const int c0 = lane * PER;
+  float ag[PER], ab[PER], gm[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) { ag[j] = ab[j] = 0.f; gm[j] = gamma[c0 + j]; }
   const int r0 = blockIdx.x * rows_per_block;
   for (int rr = wave; rr < rows_per_block; rr += 4) {
     const int row = r0 + rr;
     if (row >= T) break;
     const float mu = mean[row], rs = rstd[row];
-    float xh[16], g[16];
+    const bvec xv = *(const bvec*)(x + (size_t)row * E + c0), dv = *(const bvec*)(dy + (size_t)row * E + c0);
+    float xh[PER], g[PER];
     float s1 = 0.f, s2 = 0.f;
-    for (int j = 0; j < per; ++j) {
-      const int c = lane + 64 * j;
-      const float d = (float)dy[(size_t)row * E + c];
-      xh[j] = ((float)x[(size_t)row * E + c] - mu) * rs;
-      g[j] = d * gamma[c];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const float d = (float)dv[j];
+      xh[j] = ((float)xv[j] - mu) * rs;
+      g[j] = d * gm[j];
       s1 += g[j];
       s2 += g[j] * xh[j];
       ag[j] += d * xh[j];
@@ -54,12 +61,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const __bf16* __rest
     }
     s1 = wave_sum(s1) / (float)E;
     s2 = wave_sum(s2) / (float)E;
-    for (int j = 0; j < per; ++j)
-      dx[(size_t)row * E + lane + 64 * j] = (__bf16)(rs * (g[j] - s1 - xh[j] * s2));
+    bvec o;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) o[j] = (__bf16)(rs * (g[j] - s1 - xh[j] * s2));
+    *(bvec*)(dx + (size_t)row * E + c0) = o;
   }
-  for (int j = 0; j < per; ++j) {
-    sacc[(wave * E + lane + 64 * j) * 2 + 0] = ag[j];
-    sacc[(wave * E + lane + 64 * j) * 2 + 1] = ab[j];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    sacc[(wave * E + c0 + j) * 2 + 0] = ag[j];
+    sacc[(wave * E + c0 + j) * 2 + 1] = ab[j];
   }
   __syncthreads();
   for (int c = threadIdx.x; c < E; c += 256) {
@@ -69,14 +79,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const __bf16* __rest
     part[((size_t)blockIdx.x * E + c) * 2 + 1] = b;
   }
 }
+// dgamma / dbeta: sum of the block partials, four independent chains per channel (the loop is latency-bound)
 __global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const float* __restrict__ part, int nblk, int E,
                                                                    float* dgamma, float* dbeta) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= E) return;
-  float a = 0.f, b = 0.f;
-  for (int k = 0; k < nblk; ++k) { a += part[((size_t)k * E + c) * 2]; b += part[((size_t)k * E + c) * 2 + 1]; }
-  dgamma[c] = a;
-  dbeta[c] = b;
+  float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 4 <= nblk; k += 4)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const f32x2 v = *(const f32x2*)(part + ((size_t)(k + u) * E + c) * 2);
+      a[u] += v[0];
+      b[u] += v[1];
+    }
+  for (; k < nblk; ++k) { a[0] += part[((size_t)k * E + c) * 2]; b[0] += part[((size_t)k * E + c) * 2 + 1]; }
+  dgamma[c] = (a[0] + a[1]) + (a[2] + a[3]);
+  dbeta[c] = (b[0] + b[1]) + (b[2] + b[3]);
 }
 
 extern "C" int mi_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
@@ -93,10 +112,26 @@ extern "C" int mi_layernorm_bwd(const void* x, const void* dy, const float* gamm
                                 void* dx, float* dgamma, float* dbeta, float* ws, int T, int E, mi_stream_t st) {
   MI_REQUIRE(x && dy && gamma && mean && rstd && dx && dgamma && dbeta && ws && T > 0, "layernorm_bwd: args");
   MI_REQUIRE(E % 64 == 0 && E <= 1024, "layernorm_bwd: E %d", E);
-  const int rpb = 64, nblk = mi_cdiv(T, rpb);
+  // rows per block: ~512 blocks, never more partial rows than the workspace holds ([ceil(T / 64)][E][2] floats by contract)
+  int rpb = mi_cdiv(mi_cdiv(T, 512), 4) * 4;
+  if (rpb < 4) rpb = 4;
+  const int cap = mi_cdiv(T, 64);
+  while (mi_cdiv(T, rpb) > cap && rpb < 64) rpb += 4;
+  const int nblk = mi_cdiv(T, rpb);
   hipStream_t s = (hipStream_t)st;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), (size_t)4 * E * 2 * sizeof(float), s, (const __bf16*)x,
-                     (const __bf16*)dy, gamma, mean, rstd, (__bf16*)dx, ws, T, E, rpb);
+  const size_t lds = (size_t)4 * E * 2 * sizeof(float);
+#define MI_LN_BWD(PERv)                                                                                                  \
+  hipLaunchKernelGGL(layernorm_bwd_kernel<PERv>, dim3(nblk), dim3(256), lds, s, (const __bf16*)x, (const __bf16*)dy, gamma, \
+                     mean, rstd, (__bf16*)dx, ws, T, E, rpb)
+  switch (E / 64) {
+    case 1: MI_LN_BWD(1); break;
+    case 2: MI_LN_BWD(2); break;
+    case 4: MI_LN_BWD(4); break;
+    case 8: MI_LN_BWD(8); break;
+    case 16: MI_LN_BWD(16); break;
+    default: MI_FAIL(MI_EINVAL, "layernorm_bwd: E %d (64, 128, 256, 512 or 1024)", E);
+  }
+#undef MI_LN_BWD
   MI_CHECK_LAUNCH("layernorm_bwd");
   hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3(mi_cdiv(E, 256)), dim3(256), 0, s, ws, nblk, E, dgamma, dbeta);
   MI_CHECK_LAUNCH("layernorm_bwd_params");
