@@ -387,7 +387,11 @@ def bench_detr(args):
         inputs.append(dict(image=torch.randint(0, 256, (3, h, w), generator=g).float().to(dev), instances=inst))
     params = [p for p in model.parameters() if p.requires_grad]
     graphed = not args.no_graph
-    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, capturable=graphed)
+    if graphed:     # the same AdamW update as ONE launch over the 235 parameter tensors (optim.MultiTensorAdamW)
+        from yolov7_d2_amd.optim import MultiTensorAdamW
+        opt = MultiTensorAdamW(params, lr=1e-4, weight_decay=1e-4)
+    else:
+        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4)
     if graphed:
         # forward + backward + AdamW of the eager module tree as ONE hipGraph per padded batch shape (graph_step.py); the
         # host half (image padding, ground truth -> device) runs every step, outside the graph

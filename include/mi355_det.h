@@ -617,6 +617,22 @@ int mi_sigmoid_f32(const float* x, const float* dy, float* y, float* dx, int64_t
  * update count, seg table as for SGD */
 int mi_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const mi_sgd_seg* segs_dev,
                   int nseg, float beta1, float beta2, float eps, int64_t step, float grad_scale, mi_stream_t s);
+/* the same update over SEPARATELY ALLOCATED tensors (an eager nn.Module tree: no flat arena) in one launch.  tensors_dev:
+ * device table of (param, grad, exp_avg, exp_avg_sq, count, lr, weight_decay); chunks_dev: device table of (tensor index,
+ * element offset, count <= 16384), one block each; step_dev: device int64 holding the 1-based update count of THIS step
+ * (the caller advances it).  Everything the kernel dereferences is read at run time, so a captured hipGraph stays valid
+ * when the tables are refilled (gradient addresses are only known once the capture has ended). */
+typedef struct mi_adamw_tensor {
+  float* p; const float* g; float* m; float* v;
+  int64_t count;
+  float lr, weight_decay;
+} mi_adamw_tensor;
+typedef struct mi_adamw_chunk {
+  int32_t tensor, count;
+  int64_t offset;
+} mi_adamw_chunk;
+int mi_adamw_step_multi(const mi_adamw_tensor* tensors_dev, const mi_adamw_chunk* chunks_dev, int nchunks, float beta1,
+                        float beta2, float eps, const int64_t* step_dev, float grad_scale, mi_stream_t s);
 /* full-model gradient clipping (FullModelGradientClippingOptimizer, yolov7/optimizer/build.py:206-223 =
  * torch.nn.utils.clip_grad_norm_ over all parameters): grads *= min(1, max_norm / (||grads||_2 + 1e-6)) without a host
  * synchronisation; ws: 1024 doubles of scratch; norm_out (optional, device) receives the norm */

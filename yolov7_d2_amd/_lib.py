@@ -57,6 +57,15 @@ class mi_conv_group(C.Structure):
                 ("starts_off", C.c_int64), ("table_bytes", C.c_int64), ("priv", C.c_int64 * 288)]
 
 
+class mi_adamw_tensor(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("count", C.c_int64),
+                ("lr", C.c_float), ("weight_decay", C.c_float)]
+
+
+class mi_adamw_chunk(C.Structure):
+    _fields_ = [("tensor", C.c_int32), ("count", C.c_int32), ("offset", C.c_int64)]
+
+
 class mi_bn_job(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("y", "res", "a", "da", "dy", "dres", "acc", "gamma", "beta", "rmean", "rvar",
                                           "nbt", "scale", "shift", "mean", "invstd", "dgamma", "dbeta")] + \
@@ -205,6 +214,7 @@ _PROTOS = {
     "mi_conv2d_group_run": (C.c_int, [C.POINTER(mi_conv_group), _vp, _vp]),
     "mi_conv2d_route": (C.c_int, [C.POINTER(mi_conv_desc)]),
     "mi_dropout_seed_offset": (C.c_int, [_vp]),
+    "mi_adamw_step_multi": (C.c_int, [_vp, _vp, _i, _f, _f, _f, _vp, _f, _vp]),
     "mi_conv2d_bn_plan": (C.c_int, [C.POINTER(mi_conv_desc), C.POINTER(mi_bn_job), _i, C.POINTER(mi_conv_group)]),
     "mi_conv2d_bn_fwd": (C.c_int, [C.POINTER(mi_conv_desc), C.POINTER(mi_bn_job), _i, _vp]),
     "mi_conv_bn_barrier_status": (C.c_int, [C.POINTER(C.c_uint32)]),

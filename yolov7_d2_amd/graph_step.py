@@ -23,7 +23,7 @@ from . import _lib as L
 
 class GraphedTrainStep:
     def __init__(self, model, optimizer, loss_keys=None, warmup=2):
-        """optimizer: a torch optimizer created with capturable=True (AdamW / Adam / SGD).
+        """optimizer: optim.MultiTensorAdamW (one launch per step) or a torch optimizer created with capturable=True.
         loss_keys: the entries of the loss dict that are summed into the objective (default: model.criterion.weight_dict)."""
         self.model, self.opt, self.warmup = model, optimizer, warmup
         self.loss_keys = loss_keys
@@ -54,7 +54,10 @@ class GraphedTrainStep:
 
     def _snapshot(self):
         st = [p.detach().clone() for g in self.opt.param_groups for p in g["params"]]
-        os_ = {id(p): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in s.items()} for p, s in self.opt.state.items()}
+        if hasattr(self.opt, "state_tensors"):       # optim.MultiTensorAdamW
+            os_ = [t.clone() for t in self.opt.state_tensors()]
+        else:
+            os_ = {id(p): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in s.items()} for p, s in self.opt.state.items()}
         return st, os_, self.seed_word.clone()
 
     def _restore(self, snap):
@@ -62,6 +65,11 @@ class GraphedTrainStep:
         with torch.no_grad():
             for p, v in zip((p for g in self.opt.param_groups for p in g["params"]), st):
                 p.copy_(v)
+            if hasattr(self.opt, "state_tensors"):
+                for t, v in zip(self.opt.state_tensors(), os_):
+                    t.copy_(v)
+                self.seed_word.copy_(sw)
+                return
             for p, s in self.opt.state.items():
                 old = os_.get(id(p))
                 for k, v in s.items():
@@ -90,6 +98,8 @@ class GraphedTrainStep:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = self._body(static)
+            if hasattr(self.opt, "finish_capture"):
+                self.opt.finish_capture()       # the gradient addresses of the graph's pool -> the device table
             self._restore(snap)
             ent = self.graphs[key] = (g, static, out)
         else:
