@@ -558,8 +558,9 @@ def test_layernorm_fwd_bwd_against_torch(T, E):
 
 @pytest.mark.parametrize("T,C,extra,acc", [(4200, 256, 0, 0), (4200, 2048, 0, 1), (100, 92, 4, 0), (7, 8, 8, 0), (20000, 96, 32, 1)])
 def test_colsum_wide_one_launch_equals_two_stage(T, C, extra, acc, monkeypatch):
-    """mi_colsum_bf16_wide (bias gradients of the transformer's Linear layers): the one-launch form (last block of a
-    channel chunk sums the partials in block order) is bit-identical to the two-stage form and close to fp64 sums"""
+    """mi_colsum_bf16_wide (bias gradients of the transformer's Linear layers): the one-launch form (the last block of a
+    channel chunk to arrive sums the partials in a fixed (slice, block) order) against the two-stage form (fp32 rounding of
+    another summation order), fp64 sums, and itself (deterministic whatever the arrival order)"""
     g = torch.Generator().manual_seed(T + C)
     x = torch.randn(T, C + extra, generator=g).to(DEV, torch.bfloat16)
     outs = []
@@ -571,7 +572,7 @@ def test_colsum_wide_one_launch_equals_two_stage(T, C, extra, acc, monkeypatch):
         torch.cuda.synchronize()
         outs.append(out)
     monkeypatch.delenv("MI_COLSUM_TWO_STAGE")
-    assert torch.equal(outs[0], outs[1])
+    torch.testing.assert_close(outs[0], outs[1], rtol=1e-5, atol=1e-4 * T ** 0.5)
     ref = x[:, :C].double().sum(0) + (3.0 if acc else 0.0)
     np.testing.assert_allclose(outs[0].cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-3 * T ** 0.5)
     for _ in range(3):                                     # the chunk counters persist across launches: again

@@ -631,11 +631,27 @@ __global__ __launch_bounds__(256) void colsum_wide_fused_kernel(const __bf16* __
   __syncthreads();
   if (!s_last) return;
   if (tid == 0) __hip_atomic_store(&g_colsum_cnt[blockIdx.y], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (tid < C8N * 8 && c0 + tid < C) {
+  // four threads per channel, each summing every fourth block's partial, four loads in flight (a single chain of up to 128
+  // memory-side loads was 8 us); the order of the additions is fixed by (slice, block), not by arrival
+  {
+    const int c = tid & 63, q = tid >> 6, nbk = (int)gridDim.x;
     float a = 0.f;
-    for (int b = 0; b < (int)gridDim.x; ++b)
-      a += __hip_atomic_load(part + (size_t)b * CP + c0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    out[c0 + tid] = accumulate ? out[c0 + tid] + a : a;
+    if (c < C8N * 8) {
+      int b = q;
+      for (; b + 12 < nbk; b += 16) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __hip_atomic_load(part + (size_t)(b + 4 * u) * CP + c0 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+      for (; b < nbk; b += 4) a += __hip_atomic_load(part + (size_t)b * CP + c0 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    red[q * 64 + c] = a;
+    __syncthreads();
+    if (tid < C8N * 8 && c0 + tid < C) {
+      const float t = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+      out[c0 + tid] = accumulate ? out[c0 + tid] + t : t;
+    }
   }
 }
 extern "C" int64_t mi_colsum_wide_ws_bytes(int C) { return (int64_t)128 * ((C + 7) / 8 * 8) * 4; }

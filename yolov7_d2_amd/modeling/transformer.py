@@ -68,8 +68,11 @@ class _LinearFn(torch.autograd.Function):
         y = torch.empty(T, CoutP, dtype=torch.bfloat16, device=dev)
         b32 = None
         if bias is not None:
-            b32 = torch.zeros(CoutP, dtype=torch.float32, device=dev)
-            b32[:Cout] = bias.detach().float()
+            if CoutP == Cout and bias.dtype == torch.float32 and bias.is_contiguous():
+                b32 = bias.detach()          # (no padded copy: two launches per Linear call otherwise)
+            else:
+                b32 = torch.zeros(CoutP, dtype=torch.float32, device=dev)
+                b32[:Cout] = bias.detach().float()
         _conv1x1(x, wf, y, T, Cin, CoutP, CoutP, b32)
         ctx.save_for_backward(x, wd)
         ctx.dims = (T, Cin, Cout, CoutP, bias is not None)
