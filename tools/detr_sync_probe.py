@@ -24,18 +24,17 @@ for b in range(B):
     xy = torch.rand(n, 2, generator=g) * (torch.tensor([w, h]) - wh).clamp(min=1)
     inst = Instances((h, w), gt_boxes=Boxes(torch.cat([xy, xy + wh], 1)), gt_classes=torch.randint(0, 80, (n,), generator=g))
     if which != "detr":
-        from yolov7_d2_amd.d2shim import BitMasks
-        m = torch.zeros(n, h, w, dtype=torch.bool)
+        m = torch.zeros(n, h, w)
         for k in range(n):
             x0, y0, x1, y1 = [int(v) for v in torch.cat([xy[k], xy[k] + wh[k]])]
-            m[k, y0:y1, x0:x1] = True
-        inst.gt_masks = BitMasks(m)
-    inputs.append(dict(image=torch.randint(0, 256, (3, h, w), generator=g).float().to(dev), instances=inst))
+            m[k, y0:y1, x0:x1] = 1
+        inst = Instances((h, w), gt_classes=torch.randint(0, 80, (n,), generator=g).to(dev), gt_masks=m.to(dev))
+    inputs.append(dict(image=torch.randint(0, 256, (3, h, w), generator=g).float().to(dev), instances=inst, height=h, width=w))
 params = [p for p in model.parameters() if p.requires_grad]
 opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, capturable=True)
 def step():
     losses = model(inputs)
-    wd = getattr(getattr(model, "criterion", None), "weight_dict", None)
+    wd = getattr(getattr(model, "criterion", None), "weight_dict", None) if which == "detr" else None
     total = sum(v for k, v in losses.items() if wd is None or k in wd)
     opt.zero_grad(set_to_none=False)
     total.backward()
