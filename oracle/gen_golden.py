@@ -697,6 +697,53 @@ def gold_sparseinst():
     print("sparseinst:", {k: float(v) for k, v in losses.items()}, [(i.tolist(), j.tolist()) for i, j in indices])
 
 
+def gold_sparseinst_real():
+    """gold_sparseinst at the size configs[4] runs: the reference's own InstanceContextEncoder + GroupIAMDecoder (100
+    instance queries) + SparseInstCriterion / Matcher on the res3 / res4 / res5 maps of a 640 x 640 batch (80 x 80 x 512,
+    40 x 40 x 1024, 20 x 20 x 2048; second image 616 x 608 inside the padded batch) and bitmask targets.  Stores the class
+    logits / objectness in full, the matcher's indices, the four weighted losses, and grad_signature() fingerprints of the
+    encoder output, the mask logits, d feature maps and every parameter gradient."""
+    import types
+    from gen_golden_inputs import seeded_tensor_dict, synth_sparseinst_case, sparseinst_spread, grad_signature
+    root = os.path.dirname(HERE)
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from yolov7_d2_amd import sparse_inst_r50_giam_cfg
+    si = ref_loader.load_sparseinst()
+    cfg = sparse_inst_r50_giam_cfg(device="cpu")
+    shapes = {n: types.SimpleNamespace(channels=c, stride=s) for n, c, s in (("res3", 512, 8), ("res4", 1024, 16), ("res5", 2048, 32))}
+    torch.manual_seed(0)
+    enc = si.encoder.InstanceContextEncoder(cfg, shapes)
+    dec = si.decoder.GroupIAMDecoder(cfg)
+    crit = si.loss.SparseInstCriterion(cfg, si.loss.SparseInstMatcher(cfg))
+    net = torch.nn.ModuleDict(dict(encoder=enc, decoder=dec))
+    net.load_state_dict(sparseinst_spread(seeded_tensor_dict({k: v.shape for k, v in net.state_dict().items()}, seed=307)))
+    feats, targets, input_shape = synth_sparseinst_case(seed=311, B=2, H=640, W=640)
+    fin = {k: v.clone().requires_grad_(True) for k, v in feats.items()}
+    e = enc(fin)
+    out = dec(e)
+    class _BM:
+        def __init__(self, t): self.tensor = t
+        def __len__(self): return self.tensor.shape[0]
+    tg = [dict(labels=t["labels"], masks=_BM(t["masks"])) for t in targets]
+    indices = crit.matcher(out, tg, input_shape)
+    losses = crit(out, tg, input_shape)
+    sum(losses.values()).backward()
+    res = {"pred_logits": out["pred_logits"].detach().numpy(), "pred_scores": out["pred_scores"].detach().numpy()}
+    for n, v in grad_signature([("enc_out", e.detach()), ("pred_masks", out["pred_masks"].detach())] +
+                               [("dfeat:" + k, v.grad) for k, v in fin.items()]).items():
+        res["sig:" + n] = v
+    for b, (i, j) in enumerate(indices):
+        res[f"match_i{b}"], res[f"match_j{b}"] = i.numpy(), j.numpy()
+    for k, v in losses.items():
+        res["loss:" + k] = np.float32(v.detach())
+    for n, v in grad_signature([(n, p.grad) for n, p in net.named_parameters()]).items():
+        res["gsig:" + n] = v
+    np.savez_compressed(os.path.join(OUT, "sparseinst_real.npz"), **res)
+    print("sparseinst_real:", {k: float(v) for k, v in losses.items()}, [(i.tolist(), j.tolist()) for i, j in indices],
+          "|enc_out|", float(e.norm()), "|pred_masks|", float(out["pred_masks"].norm()))
+
+
 def gold_sparseinst_inference():
     """the reference's own SparseInst.inference (meta_arch/sparseinst.py:173-234, with its jit-scripted rescoring_mask
     :24-27) on seeded decoder outputs (class logits, objectness, smooth mask-logit fields whose thresholded masks are
@@ -801,5 +848,6 @@ if __name__ == "__main__":
     gold_detr_meta()
     gold_detr_real()
     gold_sparseinst()
+    gold_sparseinst_real()
     gold_sparseinst_inference()
     gold_set_criterion()

@@ -210,3 +210,65 @@ def test_sparseinst_inference_against_reference_golden(golden_dir):
         assert got.shape == ref.shape and got.dtype == np.bool_
         assert (got != ref).mean() < 1e-4, float((got != ref).mean())
         assert np.abs(got.reshape(len(got), -1).sum(1) - g[f"mask_area{b}"]).max() <= 3
+
+
+def test_encoder_decoder_criterion_at_real_size_against_reference_golden(golden_dir):
+    """configs[4] at its real size - the res3 / res4 / res5 maps of a 640 x 640 batch (80 x 80 x 512 ... 20 x 20 x 2048),
+    100 instance queries - against the reference's own encoder / decoder / criterion in fp32
+    (gen_golden.py::gold_sparseinst_real): class logits and objectness in full, encoder output / mask logits / d features /
+    EVERY parameter gradient through grad_signature fingerprints (norm + 8 seeded +-1 projections), the four losses.  The
+    assignment is teacher-forced to the reference's (our matcher's own answer is checked for optimality at the small size and
+    for exact indices on a decisive case; here its agreement is only reported)."""
+    from gen_golden_inputs import grad_signature
+    g = np.load(os.path.join(golden_dir, "sparseinst_real.npz"))
+    cfg = M.sparse_inst_r50_giam_cfg(device=DEV)
+    shapes = {n: types.SimpleNamespace(channels=c, stride=s) for n, c, s in (("res3", 512, 8), ("res4", 1024, 16), ("res5", 2048, 32))}
+    net = torch.nn.ModuleDict(dict(encoder=S.InstanceContextEncoder(cfg, shapes), decoder=S.GroupIAMDecoder(cfg)))
+    net.load_state_dict(sparseinst_spread(seeded_tensor_dict({k: v.shape for k, v in net.state_dict().items()}, seed=307)))
+    net = net.to(DEV)
+    crit = S.build_sparse_inst_criterion(cfg)
+    feats, targets, input_shape = synth_sparseinst_case(seed=311, B=2, H=640, W=640)
+    fin = {k: v.to(DEV, torch.bfloat16).requires_grad_(True) for k, v in feats.items()}
+    e = net["encoder"](fin)
+    out = net["decoder"](e)
+
+    def frel(name, t, key):
+        v, r = grad_signature([(name, t)])[name], g[key]
+        return float(np.sqrt(np.mean((v[1:] - r[1:]) ** 2)) / r[0]), float(v[0] / r[0])
+    fwd = {"enc_out": frel("enc_out", e.detach().float().cpu(), "sig:enc_out"),
+           "pred_masks": frel("pred_masks", out["pred_masks"].detach().float().cpu(), "sig:pred_masks"),
+           "pred_logits": _rel(out["pred_logits"].detach(), g["pred_logits"]), "pred_scores": _rel(out["pred_scores"].detach(), g["pred_scores"])}
+    print("forward", fwd)
+    assert fwd["enc_out"][0] < 2e-2 and fwd["pred_masks"][0] < 3e-2 and fwd["pred_logits"] < 3e-2 and fwd["pred_scores"] < 3e-2
+    tg = [dict(labels=t["labels"].to(DEV), masks=t["masks"].to(DEV)) for t in targets]
+    own = crit.matcher
+    agree = {}
+
+    class _Forced(torch.nn.Module):
+        def forward(self, outputs, tgts, shape):
+            mine, m = own(outputs, tgts, shape)
+            ref = [(torch.from_numpy(g[f"match_i{b}"]).to(DEV), torch.from_numpy(g[f"match_j{b}"]).to(DEV)) for b in range(len(tgts))]
+            agree["same"] = sum(len({(int(a), int(c)) for a, c in zip(i.tolist(), j.tolist())} & {(int(a), int(c)) for a, c in zip(ri.tolist(), rj.tolist())})
+                                for (i, j), (ri, rj) in zip(mine, ref))
+            agree["total"] = sum(len(ri) for ri, _ in ref)
+            return ref, m
+    crit.matcher = _Forced()
+    losses = crit(out, tg, input_shape)
+    crit.matcher = own
+    print("matcher agreement on own outputs: %d of %d pairs" % (agree["same"], agree["total"]))
+    got = {k: float(v.detach()) for k, v in losses.items()}
+    print({k: (round(got[k], 4), round(float(g["loss:" + k]), 4)) for k in got})
+    for k in got:
+        ref = float(g["loss:" + k])
+        assert abs(got[k] - ref) <= 3e-2 * abs(ref) + 1e-3, (k, got[k], ref)
+    sum(losses.values()).backward()
+    drel = {k: frel("dfeat:" + k, v.grad.float().cpu(), "sig:dfeat:" + k) for k, v in fin.items()}
+    prel = {n: frel(n, p.grad.float().cpu(), "gsig:" + n) for n, p in net.named_parameters()}
+    rels = np.array(sorted(v[0] for v in prel.values()))
+    worst = sorted(prel.items(), key=lambda kv: -kv[1][0])[:5]
+    print("d features", drel)
+    print("param grad rel err: median %.4f p90 %.4f max %.4f" % (np.median(rels), rels[int(0.9 * len(rels))], rels[-1]), worst)
+    # measured: d res3 0.10, d res4 / res5 0.033 (norm ratios 1.001); parameter gradients median 0.016, p90 0.037, max 0.13
+    # (the pooled 1x1 PPM stage); the fingerprint estimate itself carries ~25 % relative noise at 8 projections
+    assert all(v[0] < 0.15 and 0.95 < v[1] < 1.05 for v in drel.values()), drel
+    assert np.median(rels) < 0.04 and rels[int(0.9 * len(rels))] < 0.08 and rels[-1] < 0.2
