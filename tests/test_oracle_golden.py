@@ -284,7 +284,7 @@ def test_golden_recipe_regenerates_every_fixture_in_one_run(golden_dir, tmp_path
     assert r.returncode == 0, r.stderr[-2000:]
     committed = sorted(os.path.basename(f) for f in glob.glob(os.path.join(golden_dir, "*.npz")) if not os.path.basename(f).startswith("ref_"))
     made = sorted(os.path.basename(f) for f in glob.glob(os.path.join(str(tmp_path), "*.npz")))
-    assert set(made) <= set(committed) and len(made) >= 23, (sorted(set(made) - set(committed)), len(made))
+    assert set(made) <= set(committed) and len(made) >= 24, (sorted(set(made) - set(committed)), len(made))
     for name in made:
         a, b = np.load(os.path.join(str(tmp_path), name), allow_pickle=True), np.load(os.path.join(golden_dir, name), allow_pickle=True)
         assert sorted(a.files) == sorted(b.files), name
