@@ -85,12 +85,14 @@ class Interp:
             wp = torch.zeros(KK, CoutPad, CinPad)
             wp[:, :Cout, :Cin] = w.permute(2, 0, 1)
             img[:] = wp.view(KK, CoutPad, CinPad // 8, 8).permute(0, 2, 1, 3)
-            self.raw(c.p[1].obj).view(self.dt)[: img.numel()] = img.reshape(-1).to(self.dt)
+            o = c.p[1].off // 2
+            self.raw(c.p[1].obj).view(self.dt)[o: o + img.numel()] = img.reshape(-1).to(self.dt)
         if c.p[2].obj is not None:  # wd[tap][co/8][ci][co%8]
             wp = torch.zeros(KK, CinPadN, CoutPadK)
             wp[:, :Cin, :Cout] = w.permute(2, 1, 0)
             img = wp.view(KK, CinPadN, CoutPadK // 8, 8).permute(0, 2, 1, 3).contiguous()
-            self.raw(c.p[2].obj).view(self.dt)[: img.numel()] = img.reshape(-1).to(self.dt)
+            o = c.p[2].off // 2      # (a CSP pair's two data-gradient images are row ranges of one buffer)
+            self.raw(c.p[2].obj).view(self.dt)[o: o + img.numel()] = img.reshape(-1).to(self.dt)
 
     def _conv_core(self, s):
         x = s.x.obj
@@ -98,7 +100,8 @@ class Interp:
         xin = self.tv(x, K).float() if not isinstance(x, Buf) else None
         N, H, W = s.N, s.H, s.W
         nslab = max(t[2] for t in s.taps) + 1
-        wimg = self.raw(s.w.obj).view(self.dt)[: nslab * s.K8 * s.CoutPad * 8].float().view(nslab, s.K8, s.CoutPad, 8)
+        wo = s.w.off // 2
+        wimg = self.raw(s.w.obj).view(self.dt)[wo: wo + nslab * s.K8 * s.CoutPad * 8].float().view(nslab, s.K8, s.CoutPad, 8)
         wt = wimg.permute(0, 2, 1, 3).reshape(nslab, s.CoutPad, K)
         P = 4
         xp = F.pad(xin, (0, 0, P, P + 2 * s.gridW, P, P + 2 * s.gridH))

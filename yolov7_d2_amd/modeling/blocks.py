@@ -46,9 +46,9 @@ class BaseConv(_NoEager):
         self.act = nn.SiLU(inplace=True)
         self.ksize, self.stride, self.groups = ksize, stride, groups
 
-    def emit(self, ctx, x, tag, out=None, res=None):
+    def emit(self, ctx, x, tag, out=None, res=None, dgrad_pair=None):
         return ctx.b.base_conv(tag, x, self.conv.weight, _bn_dict(ctx, self.bn), self.ksize, self.stride,
-                               ctx.g(self.conv.weight), out=out, res=res, act=1, groups=self.groups)
+                               ctx.g(self.conv.weight), out=out, res=res, act=1, groups=self.groups, dgrad_pair=dgrad_pair)
 
 
 class DWConv(_NoEager):
@@ -114,13 +114,16 @@ class CSPLayer(_NoEager):
         b = ctx.b
         if getattr(b, "csp_lanes", False):
             # conv1 and conv2 read the same x and are independent: two lanes of a parallel region (grouped launches,
-            # Plan._group_lanes; their data gradients both accumulate into x.grad and stay separate, in order).  The
-            # reference runs conv2 after the bottlenecks (same values, it only reads x).
+            # Plan._group_lanes).  Their data gradients are ONE convolution over [dy1 | dy2] (PlanBuilder.DgradPair; where
+            # that does not apply they stay two launches, the second accumulating, in order).  The reference runs conv2
+            # after the bottlenecks (same values, it only reads x).
+            pair = b.dgrad_pair(tag + ".split", x, [h, h]) if hasattr(b, "dgrad_pair") else None
             b.par_begin(tag + ".split")
             with b.on_lane(0):
-                t = self.conv1.emit(ctx, x, tag + ".conv1", out=cat.slice(0, h) if n == 0 else None)
+                t = self.conv1.emit(ctx, x, tag + ".conv1", out=cat.slice(0, h) if n == 0 else None,
+                                    dgrad_pair=(pair, 0) if pair else None)
             with b.on_lane(1):
-                self.conv2.emit(ctx, x, tag + ".conv2", out=cat.slice(h, 2 * h))
+                self.conv2.emit(ctx, x, tag + ".conv2", out=cat.slice(h, 2 * h), dgrad_pair=(pair, 1) if pair else None)
             b.par_end(tag + ".split")
             for i, blk in enumerate(self.m):
                 t = blk.emit(ctx, t, f"{tag}.m.{i}", out=cat.slice(0, h) if i == n - 1 else None)

@@ -392,7 +392,50 @@ class PlanBuilder:
         return n
 
     # ---------------------------------------------------------------- layers
-    def base_conv(self, tag, x, weight, bn, k, stride, wgrad, out=None, res=None, act=1, groups=1):
+    class DgradPair:
+        """two 1x1 BaseConvs that read the SAME tensor (CSPLayer conv1 / conv2, darknetx CSPLayer.forward): their data
+        gradients dx = W1^T dy1 + W2^T dy2 are ONE convolution over the channel concatenation [dy1 | dy2] with the two
+        weight images stacked along K - one launch that writes dx once instead of a second launch that reads dx back and
+        adds to it.  The two layers write their out-gradients into the two channel slices of one buffer."""
+
+        def __init__(self, b, tag, x, couts):
+            self.b, self.tag, self.x, self.couts = b, tag, x, list(couts)
+            self.offs = [0]
+            for c in couts:
+                self.offs.append(self.offs[-1] + c)
+            self.K = self.offs[-1]
+            self.CinPadN = _rup(x.C, 32)
+            self.wd = b.small(tag + ".wd_pair", self.K * self.CinPadN * 2)
+            self.dy = None
+            self.ready = []
+
+        def wd_slice(self, slot):
+            return _Ptr(self.wd, self.offs[slot] * self.CinPadN * 2)      # rows [k8][CinPadN][8]: slot's rows follow
+
+        def dy_view(self, slot, N, H, W):
+            if self.dy is None:
+                self.dy = self.b._new_buf(self.tag + ".dy_pair", N * H * W * self.K * 2)
+            self.ready.append(slot)
+            return TRef(self.dy, N, H, W, self.couts[slot], self.K, self.offs[slot])
+
+        def flush(self):
+            """after both layers' backward commands (and after the parallel region that holds them): the one data gradient"""
+            assert sorted(self.ready) == list(range(len(self.couts))), (self.tag, self.ready)
+            x = self.x
+            dyT = TRef(self.dy, x.N, x.H, x.W, self.K, self.K)
+            self.b.dgrad_cmds(self.tag + ".pair", dyT, self.wd, self.K // 8, x, x.C, self.CinPadN, 1, 1, 0)
+
+    def dgrad_pair(self, tag, x, couts):
+        """-> DgradPair or None when the pair form does not apply (see base_conv(dgrad_pair=))"""
+        ok = (self.training and x.requires_grad and self.group_wgrad and os.environ.get("MI_CSP_DGRAD_PAIR", "1") != "0"
+              and all(c % 32 == 0 for c in couts) and x.C % 8 == 0)
+        if not ok:
+            return None
+        pair = PlanBuilder.DgradPair(self, tag, x, couts)
+        self.on_backward(pair.flush)
+        return pair
+
+    def base_conv(self, tag, x, weight, bn, k, stride, wgrad, out=None, res=None, act=1, groups=1, dgrad_pair=None):
         """Conv(k, stride, pad=(k-1)//2, no bias) -> BatchNorm -> SiLU (+ res).
         weight: fp32 OIHW tensor; wgrad: fp32 OIHW gradient view (training);
         bn: dict(gamma, beta, rm, rv, nbt, eps, momentum, ggamma, gbeta).
@@ -414,9 +457,14 @@ class PlanBuilder:
         need_dgrad = self.training and x.requires_grad
         CinPadN = _rup(Cin, 32)
         wf = wd = None
+        if dgrad_pair is not None:
+            pair, slot = dgrad_pair
+            assert k == 1 and stride == 1 and not dw and need_dgrad and Cout == CoutPad == pair.couts[slot] and pair.x is x
         if not dw:
             wf = self.small(tag + ".wf", KK * CinPad * CoutPad * 2)
             wd = self.small(tag + ".wd", KK * CoutPad * CinPadN * 2) if need_dgrad else None
+            if dgrad_pair is not None:
+                wd = pair.wd_slice(slot)
             self.emit("PACK_W", i=[Cout, Cin, k, k, CinPad, CoutPad, CoutPad, CinPadN], p=[weight, wf, wd],
                       tag=tag + ".pack", prologue=True)
 
@@ -470,9 +518,12 @@ class PlanBuilder:
             # the out-gradient is read by the data / weight gradient kernels in whole 32-channel groups: pad channels
             # stay zero (a dedicated, never-written part of the zero-initialised arena)
             assert Cout == CoutPad or self.group_wgrad, "padded channel counts need per-layer dy buffers (MI_WGRAD_GROUP=1)"
-            dy = (self._new_buf(tag + ".dy", count * CoutPad * 2) if self.group_wgrad
-                  else self.scratch("dy", count * CoutPad * 2))
-            dyT = TRef(dy, x.N, Ho, Wo, CoutPad, CoutPad)
+            if dgrad_pair is not None:
+                dyT = pair.dy_view(slot, x.N, Ho, Wo)
+            else:
+                dy = (self._new_buf(tag + ".dy", count * CoutPad * 2) if self.group_wgrad
+                      else self.scratch("dy", count * CoutPad * 2))
+                dyT = TRef(dy, x.N, Ho, Wo, CoutPad, CoutPad)
             if fused is not None:
                 for c in fused:
                     sp = c.desc
@@ -488,7 +539,7 @@ class PlanBuilder:
             if res is not None and res.requires_grad:
                 dres = res.grad
                 dres_acc = self.grad_mode(res)
-            self.emit("BN_BWD_APPLY", i=[da.ld, y.ld, CoutPad, dres.ld if dres is not None else 0, dres_acc, Cout, act, nsl2],
+            self.emit("BN_BWD_APPLY", i=[da.ld, y.ld, dyT.ld, dres.ld if dres is not None else 0, dres_acc, Cout, act, nsl2],
                       l=[count, count], p=[da, y, scale, shift, mean, invstd, bn["gamma"], dacc, bn["ggamma"], bn["gbeta"],
                                            dyT, dres, self.small(tag + ".bar", 4 * L.MI_BN_BAR_WORDS)], tag=tag + ".bnapply")
             if dw:
@@ -501,7 +552,7 @@ class PlanBuilder:
                 return
             self.wgrad_cmds(tag, x, dyT, CinPad if (k > 1 or CinPad % 32 == 0) else _rup(Cin, 32), CoutPad, Cin, Cout, k,
                             stride, pad, wgrad)
-            if need_dgrad:
+            if need_dgrad and dgrad_pair is None:      # (a pair's single data gradient is emitted by DgradPair.flush)
                 self.dgrad_cmds(tag, dyT, wd, CoutPad // 8, x, Cin, CinPadN, k, stride, pad)
 
         self.on_backward(bwd)
