@@ -173,8 +173,11 @@ def _conv2d_cuda(x, weight, bias, stride, padding):
     y = torch.empty(g.N, g.Ho, g.Wo, g.CoutP, dtype=torch.bfloat16, device=x.device)
     b32 = None
     if bias is not None:
-        b32 = torch.zeros(g.CoutP, dtype=torch.float32, device=x.device)
-        b32[: g.Cout] = bias.detach().float()
+        if g.CoutP == g.Cout and bias.dtype == torch.float32 and bias.is_contiguous():
+            b32 = bias.detach()        # (no padded copy: a fill + a copy launch per call otherwise)
+        else:
+            b32 = torch.zeros(g.CoutP, dtype=torch.float32, device=x.device)
+            b32[: g.Cout] = bias.detach().float()
     g.fwd(g.pad_in(x), wf, y, bias=b32)
     return _nchw(y, g.Cout)
 
@@ -184,7 +187,10 @@ def _conv2d_backward_cuda(grad, x, weight, has_bias, stride, padding):
     _, wd = g.pack(weight)
     dyh = _pad_last(_nhwc(grad), g.CoutP)
     xh = g.pad_in(x)
-    dx = torch.zeros(g.N, g.H, g.W, g.CinP, dtype=torch.bfloat16, device=x.device)
+    # the data gradient writes every real channel of every pixel - except the 1x1 stride-2 form (odd pixels receive
+    # nothing) and pad channels: only those need the zero fill (it was a full-tensor pass per convolution)
+    full = g.CinP == g.Cin and not (g.k == 1 and g.s == 2)
+    dx = (torch.empty if full else torch.zeros)(g.N, g.H, g.W, g.CinP, dtype=torch.bfloat16, device=x.device)
     g.dgrad(dyh, wd, dx)
     gw = g.wgrad(xh, dyh)
     gb = _colsum(dyh, g.Cout) if has_bias else torch.zeros(0, device=x.device)
