@@ -322,6 +322,12 @@ int mi_spp_pool_bwd(const void* dy5, const void* dy9, const void* dy13, int lddy
  * NHWC views, C %% 8 == 0.  outH = (H + 1) / 2.  Backward routes each output gradient to the FIRST maximum of its
  * window in row-major order (ATen's tie rule): dx (+)= sum over the <= 4 windows that contain the pixel. */
 int mi_maxpool3x3s2_fwd(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, mi_stream_t s);
+/* the same pooling recording, per output element, the window position (0..8, row-major) of its first maximum in
+ * code[N][Ho][Wo][C] (uint8, 8-byte aligned), and the backward that reads the codes instead of re-deriving them from x:
+ * identical results (torch's MaxPool2d gradient goes to the first maximum), a twentieth of the time on the stem's map */
+int mi_maxpool3x3s2_fwd_idx(const void* x, int ldx, void* y, int ldy, uint8_t* code, int N, int H, int W, int C, mi_stream_t s);
+int mi_maxpool3x3s2_bwd_idx(const uint8_t* code, const void* dy, int lddy, void* dx, int lddx, int accumulate, int N, int H,
+                            int W, int C, mi_stream_t s);
 int mi_maxpool3x3s2_bwd(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int accumulate, int N,
                         int H, int W, int C, mi_stream_t s);
 /* generic strided bf16 NHWC copy / accumulate (dst (+)= src) */

@@ -190,6 +190,8 @@ _PROTOS = {
     "mi_focus_pack_u8": (C.c_int, [_vp, _i, _i, _i, _vp, _i, _vp]),
     "mi_maxpool3x3s2_fwd": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "mi_maxpool3x3s2_bwd": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "mi_maxpool3x3s2_fwd_idx": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "mi_maxpool3x3s2_bwd_idx": (C.c_int, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mi_upsample2x_fwd": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "mi_upsample2x_bwd": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mi_spp_pool_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),

@@ -7,6 +7,7 @@
 //     (compute_mask_iou :19-28, dice_loss :38-47); a second pass writes d(loss)/d(mask logits).
 // The convolutions, the IAM aggregation / dynamic mask "bmm"s and the matcher's dice-score matmul run on the conv /
 // wgrad MFMA kernels (modeling/sparseinst.py), the assignment on mi_lsap.
+#include <stdlib.h>
 #include <string.h>
 #include "common.h"
 
@@ -81,6 +82,48 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const ResizeK p) {   //
     }
   }
 }
+// gather form: an input pixel collects, in a fixed order, the weighted out-gradients of every output pixel whose bilinear
+// footprint contains it - no atomics, no fp32 accumulator tensor, no rounding pass, deterministic.  (The scatter form above
+// was 32 float atomics per output element: 1.03 ms per call, a quarter of the SparseInst step.)  The candidate output rows /
+// columns of input index i are those with source coordinate in (i - 1, i + 1); each candidate's (i0, i1, l1) is recomputed
+// with the forward's own src_index, so the two passes agree bit for bit on which pixels touch which.
+__device__ __forceinline__ float resize_w(int o, float scale, int n, int i) {
+  int i0, i1;
+  float l1;
+  src_index(o, scale, n, &i0, &i1, &l1);
+  return (i0 == i ? 1.f - l1 : 0.f) + (i1 == i ? l1 : 0.f);
+}
+__global__ __launch_bounds__(256) void resize_bwd_gather_kernel(const ResizeK p) {   // p.x = dy (Ho x Wo, ldx), p.y = dx (H x W, ldy)
+  const int64_t total = (int64_t)p.N * p.H * p.W * p.C8;
+  const float ish = 1.f / p.sh, isw = 1.f / p.sw;
+  for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(idx % p.C8);
+    int64_t r = idx / p.C8;
+    const int ix = (int)(r % p.W); r /= p.W;
+    const int iy = (int)(r % p.H);
+    const int n = (int)(r / p.H);
+    int oy0 = (int)floorf(((float)iy - 0.5f) * ish - 0.5f) - 1, oy1 = (int)ceilf(((float)iy + 1.5f) * ish - 0.5f) + 1;
+    int ox0 = (int)floorf(((float)ix - 0.5f) * isw - 0.5f) - 1, ox1 = (int)ceilf(((float)ix + 1.5f) * isw - 0.5f) + 1;
+    oy0 = oy0 < 0 ? 0 : oy0; ox0 = ox0 < 0 ? 0 : ox0;
+    oy1 = oy1 > p.Ho - 1 ? p.Ho - 1 : oy1; ox1 = ox1 > p.Wo - 1 ? p.Wo - 1 : ox1;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    const __bf16* g0 = p.x + ((int64_t)n * p.Ho * p.Wo) * p.ldx + c8 * 8;
+    for (int oy = oy0; oy <= oy1; ++oy) {
+      const float wy = resize_w(oy, p.sh, p.H, iy);
+      if (wy == 0.f) continue;
+      for (int ox = ox0; ox <= ox1; ++ox) {
+        const float w = wy * resize_w(ox, p.sw, p.W, ix);
+        if (w == 0.f) continue;
+        const bf16x8 g = *(const bf16x8*)(g0 + ((int64_t)oy * p.Wo + ox) * p.ldx);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += w * (float)g[e];
+      }
+    }
+    *(bf16x8*)(p.y + (((int64_t)n * p.H + iy) * p.W + ix) * p.ldy + c8 * 8) = pack8(acc);
+  }
+}
 __global__ __launch_bounds__(256) void f32_to_bf16_rows_kernel(const float* __restrict__ a, __bf16* o, int ldo, int64_t npix, int C8) {
   const int64_t total = npix * C8;
   for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
@@ -112,15 +155,24 @@ extern "C" int mi_bilinear_resize_bf16(const void* x, int ldx, int N, int H, int
   MI_CHECK_LAUNCH("bilinear_resize");
   return MI_OK;
 }
-// dy: [N][Ho][Wo][C] (lddy) -> dx: [N][H][W][C] (lddx); acc_ws: fp32 N*H*W*C, zeroed by the caller
+// dy: [N][Ho][Wo][C] (lddy) -> dx: [N][H][W][C] (lddx); acc_ws: unused (may be NULL) - only MI_RESIZE_BWD_SCATTER=1, the
+// first atomic form, needs it: fp32 N*H*W*C, zeroed by the caller
 extern "C" int mi_bilinear_resize_bwd_bf16(const void* dy, int lddy, int N, int H, int W, int C, void* dx, int lddx, int Ho,
                                            int Wo, float* acc_ws, mi_stream_t st) {
-  MI_REQUIRE(dy && dx && acc_ws && C % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "bilinear_resize_bwd: args");
+  MI_REQUIRE(dy && dx && C % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "bilinear_resize_bwd: args");
   ResizeK k;
   memset(&k, 0, sizeof(k));
   k.x = (const __bf16*)dy; k.acc = acc_ws; k.ldx = lddy; k.N = N; k.H = H; k.W = W; k.Ho = Ho; k.Wo = Wo; k.C8 = C / 8;
   k.sh = (float)H / (float)Ho; k.sw = (float)W / (float)Wo;
   hipStream_t s = (hipStream_t)st;
+  const char* sc = getenv("MI_RESIZE_BWD_SCATTER");      // (the first, atomic form: kept for comparison; it needs acc_ws zeroed)
+  if (!(sc && atoi(sc))) {
+    k.y = (__bf16*)dx; k.ldy = lddx;
+    hipLaunchKernelGGL(resize_bwd_gather_kernel, dim3(nblocks((int64_t)N * H * W * k.C8)), dim3(256), 0, s, k);
+    MI_CHECK_LAUNCH("bilinear_resize_bwd");
+    return MI_OK;
+  }
+  MI_REQUIRE(acc_ws, "bilinear_resize_bwd: the scatter form needs the fp32 accumulator");
   hipLaunchKernelGGL(resize_bwd_kernel, dim3(nblocks((int64_t)N * Ho * Wo * k.C8)), dim3(256), 0, s, k);
   MI_CHECK_LAUNCH("bilinear_resize_bwd");
   hipLaunchKernelGGL(f32_to_bf16_rows_kernel, dim3(nblocks((int64_t)N * H * W * k.C8)), dim3(256), 0, s, acc_ws,

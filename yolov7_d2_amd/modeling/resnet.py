@@ -102,18 +102,26 @@ class _MaxPool(torch.autograd.Function):
     def forward(ctx, xh):          # xh bf16 [N,H,W,C] contiguous
         N, H, W, Cc = xh.shape
         y = torch.empty(N, (H + 1) // 2, (W + 1) // 2, Cc, dtype=torch.bfloat16, device=xh.device)
-        L.check(L.lib().mi_maxpool3x3s2_fwd(xh.data_ptr(), Cc, y.data_ptr(), Cc, N, H, W, Cc, L.stream_ptr()), "maxpool fwd")
-        ctx.save_for_backward(xh)
+        if not xh.requires_grad:
+            L.check(L.lib().mi_maxpool3x3s2_fwd(xh.data_ptr(), Cc, y.data_ptr(), Cc, N, H, W, Cc, L.stream_ptr()), "maxpool fwd")
+            return y
+        # training through the stem (FREEZE_AT 0): one byte per output element records where its first maximum sits, the
+        # backward reads that instead of re-deriving it from x (and x need not be kept)
+        code = torch.empty(N, (H + 1) // 2, (W + 1) // 2, Cc, dtype=torch.uint8, device=xh.device)
+        L.check(L.lib().mi_maxpool3x3s2_fwd_idx(xh.data_ptr(), Cc, y.data_ptr(), Cc, code.data_ptr(), N, H, W, Cc, L.stream_ptr()),
+                "maxpool fwd")
+        ctx.save_for_backward(code)
+        ctx.in_shape = (N, H, W, Cc)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        (xh,) = ctx.saved_tensors
-        N, H, W, Cc = xh.shape
+        (code,) = ctx.saved_tensors
+        N, H, W, Cc = ctx.in_shape
         g = g.contiguous()
-        dx = torch.empty_like(xh)
-        L.check(L.lib().mi_maxpool3x3s2_bwd(xh.data_ptr(), Cc, g.data_ptr(), Cc, dx.data_ptr(), Cc, 0, N, H, W, Cc,
-                                            L.stream_ptr()), "maxpool bwd")
+        dx = torch.empty(N, H, W, Cc, dtype=torch.bfloat16, device=g.device)
+        L.check(L.lib().mi_maxpool3x3s2_bwd_idx(code.data_ptr(), g.data_ptr(), Cc, dx.data_ptr(), Cc, 0, N, H, W, Cc,
+                                                L.stream_ptr()), "maxpool bwd")
         return dx
 
 

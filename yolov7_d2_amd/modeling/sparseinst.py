@@ -102,8 +102,7 @@ class _Resize(torch.autograd.Function):
         N, H, W, Cc, Ho, Wo = ctx.shape
         g = g.contiguous()
         dx = torch.empty(N, H, W, Cc, dtype=torch.bfloat16, device=g.device)
-        acc = torch.zeros(N * H * W * Cc, dtype=torch.float32, device=g.device)
-        L.check(L.lib().mi_bilinear_resize_bwd_bf16(g.data_ptr(), Cc, N, H, W, Cc, dx.data_ptr(), Cc, Ho, Wo, acc.data_ptr(),
+        L.check(L.lib().mi_bilinear_resize_bwd_bf16(g.data_ptr(), Cc, N, H, W, Cc, dx.data_ptr(), Cc, Ho, Wo, None,
                                                     L.stream_ptr()), "mi_bilinear_resize_bwd_bf16")
         return dx, None, None
 
