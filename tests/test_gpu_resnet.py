@@ -151,3 +151,34 @@ def test_bottleneck_block_fwd_bwd(cin, cout, bc, stride):
     assert _rel(xd.grad, xr.grad) < 3e-2
     for n, p in blk.named_parameters():
         assert _rel(p.grad, osd[n].grad) < 3e-2, (n, _rel(p.grad, osd[n].grad))
+
+
+@pytest.mark.parametrize("H,W", [(64, 96), (75, 101)])
+def test_trainable_stem_forward_and_weight_gradient_match_torch(H, W):
+    """BasicStem with FREEZE_AT 0 (SparseInst: configs/coco/sparseinst/Base-SparseInst.yaml): 7x7 stride-2 conv (as a 4x4
+    conv over the space-to-depth image) + frozen affine + ReLU + MaxPool(3, 2, 1) with recorded first-maximum positions,
+    and its backward - max-pool routing, ReLU mask, the 16-tap weight gradient mapped back to 7x7 - against torch fp32 on
+    the same bf16-rounded operands"""
+    from yolov7_d2_amd.modeling.resnet import BasicStem
+    g = torch.Generator().manual_seed(H)
+    stem = BasicStem(3, 64).cuda()
+    with torch.no_grad():
+        stem.conv1.norm.weight.copy_(0.5 + torch.rand(64, generator=g))
+        stem.conv1.norm.bias.copy_(0.1 * torch.randn(64, generator=g))
+        stem.conv1.norm.running_mean.copy_(0.1 * torch.randn(64, generator=g))
+        stem.conv1.norm.running_var.copy_(0.5 + torch.rand(64, generator=g))
+    x = torch.randn(2, 3, H, W, generator=g)
+    out = stem(x.cuda())
+    go = _bf(torch.randn(out.shape, generator=g))
+    out.backward(go.cuda().to(out.dtype))
+    scale, shift = (t.detach().float().cpu() for t in stem.conv1.norm.affine())
+    w = stem.conv1.weight.detach().float().cpu().clone().requires_grad_(True)
+    ref = F.max_pool2d(F.relu(F.conv2d(_bf(x), w * scale.view(-1, 1, 1, 1), shift, stride=2, padding=3)), 3, 2, 1)
+    ref.backward(go)
+    assert _rel(out, ref) < 1e-2
+    ga, gb = stem.conv1.weight.grad.float().cpu(), w.grad
+    # bf16 weights / activations on our side only (ReLU decisions of near-zero pre-activations may differ): measured cos 0.997
+    cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
+    assert cos > 0.995 and abs(float(ga.norm() / gb.norm()) - 1.0) < 0.01, (cos, float(ga.norm() / gb.norm()))
+    per_cout = (ga * gb).sum((1, 2, 3)) / (gb * gb).sum((1, 2, 3))
+    assert float((per_cout - 1).abs().max()) < 0.05       # (the frozen scale is applied per output channel)

@@ -163,21 +163,23 @@ class _StemFn(torch.autograd.Function):
         a = torch.empty_like(y)
         L.check(L.lib().mi_ew_bf16(y.data_ptr(), None, a.data_ptr(), y.numel(), 1, L.stream_ptr()), "relu")
         out = torch.empty(N, (Hh + 1) // 2, (Wh + 1) // 2, Cout, dtype=torch.bfloat16, device=s2d.device)
-        L.check(L.lib().mi_maxpool3x3s2_fwd(a.data_ptr(), Cout, out.data_ptr(), Cout, N, Hh, Wh, Cout, L.stream_ptr()), "maxpool")
-        ctx.save_for_backward(s2d, a, scale)
+        code = torch.empty(N, (Hh + 1) // 2, (Wh + 1) // 2, Cout, dtype=torch.uint8, device=s2d.device)
+        L.check(L.lib().mi_maxpool3x3s2_fwd_idx(a.data_ptr(), Cout, out.data_ptr(), Cout, code.data_ptr(), N, Hh, Wh, Cout,
+                                                L.stream_ptr()), "maxpool")
+        ctx.save_for_backward(s2d, a, scale, code)
         ctx.shape = (Cout, Cin)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        s2d, a, scale = ctx.saved_tensors
+        s2d, a, scale, code = ctx.saved_tensors
         Cout, Cin = ctx.shape
         N, Hh, Wh, _ = s2d.shape
         g = g.contiguous()
         da = torch.empty_like(a)
         lib = L.lib()
-        L.check(lib.mi_maxpool3x3s2_bwd(a.data_ptr(), Cout, g.data_ptr(), Cout, da.data_ptr(), Cout, 0, N, Hh, Wh, Cout,
-                                        L.stream_ptr()), "maxpool bwd")
+        L.check(lib.mi_maxpool3x3s2_bwd_idx(code.data_ptr(), g.data_ptr(), Cout, da.data_ptr(), Cout, 0, N, Hh, Wh, Cout,
+                                            L.stream_ptr()), "maxpool bwd")
         dy = torch.empty_like(a)
         L.check(lib.mi_ew_bf16(da.data_ptr(), a.data_ptr(), dy.data_ptr(), a.numel(), 2, L.stream_ptr()), "relu bwd")
         gw4 = torch.empty(Cout, 4 * Cin, 4, 4, dtype=torch.float32, device=a.device)
