@@ -145,3 +145,75 @@ def test_ws_rejects_what_it_cannot_do():
     assert L.lib().mi_conv3x3_ws(C.byref(d), 1, sp()) < 0 and b"conv3x3_ws" in L.lib().mi_last_error()
     L.check(L.lib().mi_conv2d(C.byref(d), sp()), "conv2d")         # ... the tile kernel serves it
     torch.cuda.synchronize()
+
+
+# ---------------------------------------------------------------------------------- stride 2 (the down-sampling convs)
+def _desc_s2(x, N, H, W, K, wimg, y, Cout, stats=None):
+    d = L.mi_conv_desc()
+    d.x, d.w, d.y = x.data_ptr(), wimg.data_ptr(), y.data_ptr()
+    d.ldx, d.ldy = K, Cout
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    d.N, d.H, d.W, d.outH, d.outW, d.gridH, d.gridW = N, H, W, Ho, Wo, Ho, Wo
+    d.in_stride, d.out_stride = 2, 1
+    d.K8, d.Cout, d.CoutPad, d.ntaps = K // 8, Cout, Cout, 9
+    t = 0
+    for r in range(3):
+        for s_ in range(3):
+            d.tap_dy[t], d.tap_dx[t], d.tap_w[t] = r - 1, s_ - 1, r * 3 + s_
+            t += 1
+    if stats is not None:
+        d.stats_acc, d.stats_slots = stats.data_ptr(), 16
+    return d
+
+
+S2_CASES = [
+    # K, Cout, N, H, W
+    (32, 64, 16, 320, 320),      # dark2.0
+    (64, 128, 16, 160, 160),     # dark3.0
+    (128, 256, 16, 80, 80),      # dark4.0: two 128-channel blocks over one input
+    (128, 128, 16, 80, 80),      # bu_conv2
+    (128, 128, 2, 37, 45),       # odd input, ragged tiles
+    (64, 128, 1, 9, 34),
+    (32, 64, 3, 50, 31),
+]
+
+
+@pytest.mark.parametrize("with_stats", [True, False], ids=["stats", "plain"])
+@pytest.mark.parametrize("case", S2_CASES, ids=["K%d_Co%d_%dx%dx%d" % c for c in S2_CASES])
+def test_ws_stride2_matches_reference_and_tile_kernel(case, with_stats, monkeypatch):
+    """the stride-2 form (BaseConv(k=3, s=2) of CSPDarknet's dark2-4 / PAFPN's bu_conv2: darknetx.py:113-160,
+    yolo_pafpn.py:60-77): de-interleaved halo columns, K -> 2 K as two 128-channel jobs of one input"""
+    K, Cout, N, H, W = case
+    g = torch.Generator().manual_seed(K + Cout + H)
+    w = (torch.randn(Cout, K, 3, 3, generator=g) / (3 * K ** 0.5)).to(DEV)
+    img = torch.empty(9 * K * Cout, dtype=torch.bfloat16, device=DEV)
+    L.check(L.lib().mi_pack_conv_weight(w.data_ptr(), Cout, K, 3, 3, img.data_ptr(), K, Cout, None, 0, 0, sp()), "pack")
+    x = torch.randn(N, H, W, K, generator=g).to(DEV, torch.bfloat16)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+
+    def run(ws_on):
+        y = torch.full((N, Ho, Wo, Cout), 5.0, dtype=torch.bfloat16, device=DEV)
+        st = torch.zeros(16, Cout, 2, dtype=torch.float64, device=DEV) if with_stats else None
+        d = _desc_s2(x, N, H, W, K, img, y, Cout, st)
+        if ws_on:
+            assert L.lib().mi_conv2d_route(C.byref(d)) == 2
+            L.check(L.lib().mi_conv3x3_ws(C.byref(d), 1, sp()), "conv3x3_ws")
+        else:
+            monkeypatch.setenv("MI_CONV_WS", "0")
+            L.check(L.lib().mi_conv2d(C.byref(d), sp()), "conv2d")
+            monkeypatch.delenv("MI_CONV_WS")
+        torch.cuda.synchronize()
+        return y, st
+    yw, sw = run(True)
+    yt, stt = run(False)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), None, 2, 1).permute(0, 2, 3, 1).cpu()
+    got, tile = yw.float().cpu(), yt.float().cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-2, atol=2e-2)
+    diff = (got - tile).abs()
+    ulp = torch.maximum(got.abs(), tile.abs()) * 2.0 ** -7 + 2e-3 * float(tile.abs().mean())
+    assert float((diff / ulp).max()) <= 1.01 and float((diff > 0).float().mean()) < 0.02
+    if with_stats:
+        v = yw.double().reshape(-1, Cout)
+        s = sw.sum(0)
+        np.testing.assert_allclose(s[:, 0].cpu().numpy(), v.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3 * v.shape[0] ** 0.5)
+        np.testing.assert_allclose(s[:, 1].cpu().numpy(), (v * v).sum(0).cpu().numpy(), rtol=1e-5)

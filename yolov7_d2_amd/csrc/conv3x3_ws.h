@@ -27,30 +27,41 @@
 #include "conv_bn.h"
 
 #define W3_MAX_JOBS 8
-#define W3_TH 8
 #define W3_TW 16
-#define W3_HW (W3_TW + 2)              // halo width
-#define W3_HPIX ((W3_TH + 2) * W3_HW)  // 180 halo pixels
-#define W3_HROWS 192                   // padded to whole DMA instructions for every K
+// Geometry of a tile for stride S and tile height TH (output pixels): S = 1: 8 x 16 outputs from a 10 x 18 halo; S = 2 (the
+// down-sampling convs of CSPDarknet / the PAFPN bottom-up path, darknetx.py:113-160, yolo_pafpn.py:60-77): TH x 16 outputs
+// from a (2 TH + 1) x 33 halo whose COLUMNS are stored de-interleaved - the 17 even columns, then the 16 odd ones - so
+// that the pixels 2 ox + dx of 16 consecutive outputs are 16 consecutive LDS positions for every tap: the B fragment reads
+// stay 256 contiguous bytes with immediate tap offsets, exactly as for stride 1.
+template <int S, int TH>
+struct W3Geo {
+  static constexpr int HH = S == 1 ? TH + 2 : 2 * TH + 1;      // halo rows
+  static constexpr int HW = S == 1 ? W3_TW + 2 : 2 * W3_TW + 1;  // halo columns
+  static constexpr int HPIX = HH * HW;
+  static constexpr int HROWS = (HPIX + 63) / 64 * 64;            // padded to whole 64-pixel DMA instructions
+  // LDS pixel offset of tap (dy, dx in 0..2) relative to the output pixel's base position
+  static constexpr int tap(int dy, int dx) { return S == 1 ? dy * HW + dx : dy * HW + (dx & 1) * (W3_TW + 1) + (dx >> 1); }
+};
 
 struct W3Job {
   const __bf16* x;
   const u32x4* w;    // packed [tap][K/8][CoutPad][8]
   __bf16* y;
   double* stats;
-  int ldx, ldy, N, H, W, tilesY, tilesX, ntiles;   // ntiles = N * tilesY * tilesX
+  int ldx, ldy, N, H, W, tilesY, tilesX, ntiles;   // H x W: the OUTPUT map; ntiles = N * tilesY * tilesX
   int blk0, nblk;                                  // this job's blocks: [blk0, blk0 + nblk)
   int wld, nslots, sld, pad_;
   int tw[9];                                       // weight slab of tap position t = (dy + 1) * 3 + (dx + 1)
-  int pad2_;
+  int inH;                                         // input map height (= H for stride 1; input width = inW)
   CBnFwd bn;                                       // MODE 3
+  int inW, pad3_;
 };
 struct W3K {
   int njobs, dbg;
   W3Job j[W3_MAX_JOBS];
 };
 struct W3Launch {
-  int K, MODE, grid, lds;
+  int K, MODE, grid, lds, S, pad_;
   W3K k;
 };
 
@@ -68,20 +79,24 @@ __device__ __forceinline__ void w3_glds16(const void* g, unsigned lds_off) {
 // the LDS-DMA of tile i + 1's halo, the stores of tile i - 1's (already converted, packed) outputs and, in the accumulate
 // mode, the loads of tile i's old values.  Issued in one burst at the tile boundary, those 20-28 KB per wave run at the
 // chip's HBM rate with every CU in the same phase and the matrix pipes idle (measured: 2 + 2 us per 3.8 us tile).
-template <int K, int WM, int WN, int G, int MODE>
-__global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const W3K p) {
+template <int K, int WM, int WN, int G, int MODE, int S = 1, int TH = 8>
+__global__ __launch_bounds__(WM* WN * 64, (K == 128 || (S == 2 && K == 64)) ? 1 : 2) void w3_kernel(const W3K p) {
   constexpr int NW = WM * WN, KC8 = K / 8, KS = K / 16;
+  using Geo = W3Geo<S, TH>;
+  constexpr int W3_TH = TH, W3_HW = Geo::HW, W3_HPIX = Geo::HPIX, W3_HROWS = Geo::HROWS;
   static_assert(WN * G * 32 == W3_TH * W3_TW, "pixel tile");
   constexpr int PLANE = W3_HROWS * 16;           // bytes of one 8-channel plane
   constexpr int NQ = (W3_HROWS / 64) * KC8;      // DMA instructions per tile: (64-pixel block, plane)
   constexpr int D = NQ / NW;                     // per wave
   static_assert(NQ % NW == 0 && D >= 1, "DMA split");
   constexpr int XB = KC8 * PLANE;                // bytes of one halo buffer
-  static_assert((KC8 - 1) * PLANE + (2 * W3_HW + 2) * 16 < 65536, "ds_read immediate");
+  static_assert((KC8 - 1) * PLANE + Geo::tap(2, 2) * 16 < 65536, "ds_read immediate");
   constexpr int NS = 9 * KS, NTS = NS / 3;       // k-steps, triple steps
-  constexpr int S = 2 * G;                       // 16-byte stores (and old-value loads) per wave and tile
-  // schedule inside the main loop (triple-step index): DMA d at 2 d, store s at 2 s + 1, old-value loads 2 l, 2 l + 1 at 2 S + l
-  static_assert(2 * (D - 1) < NTS && 2 * S + S / 2 <= NTS, "the memory operations of a tile fit its main loop");
+  // schedule inside the main loop (triple-step index): DMA d at DST d, store s at SST s + SST - 1, old-value loads 2 l, 2 l + 1
+  // at SST S + l.  (Two triple steps apart where the tile's k-loop is long enough, every triple step otherwise.)
+  constexpr int NST = 2 * G;                     // 16-byte stores (and old-value loads) per wave and tile
+  constexpr int DST = 2 * (D - 1) < NTS ? 2 : 1, SST = 2 * NST + NST / 2 <= NTS ? 2 : 1;
+  static_assert(DST * (D - 1) < NTS && SST * NST + (MODE == 2 ? NST / 2 : 0) <= NTS, "the memory operations of a tile fit its main loop");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -106,7 +121,8 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
   // every job field the tile loop needs, in registers: behind the "memory"-clobbering DMA statements the compiler would
   // re-load them from the argument segment, and each such s_load is followed by lgkmcnt(0) - which also drains the LDS
   // fragment reads in flight (20 pipeline drains per tile)
-  const int H = jb.H, Wd = jb.W, tilesX = jb.tilesX, tpi = jb.tilesY * jb.tilesX;
+  const int H = jb.H, Wd = jb.W, tilesX = jb.tilesX, tpi = jb.tilesY * jb.tilesX;   // (H x Wd: the output map)
+  const int inH = S == 1 ? jb.H : jb.inH, inW = S == 1 ? jb.W : jb.inW;
   const int ldxb = jb.ldx * 2, ldyb = jb.ldy * 2;
   const char* const xbase = (const char*)jb.x;
   char* const ybase = (char*)jb.y;
@@ -139,15 +155,18 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
     return o;
   };
   auto issue_x1 = [&](const Org& o, int buf, int d) {   // instruction d of a tile's halo into buffer buf
-    const int iy0 = o.ty0 - 1, ix0 = o.tx0 - 1;
-    const char* xt = xbase + ((size_t)o.img * H * Wd + (ptrdiff_t)iy0 * Wd + ix0) * (ptrdiff_t)ldxb;
+    const int iy0 = S * o.ty0 - 1, ix0 = S * o.tx0 - 1;
+    const char* xt = xbase + ((size_t)o.img * inH * inW + (ptrdiff_t)iy0 * inW + ix0) * (ptrdiff_t)ldxb;
     const int q = wave * D + d;
     const int pb = q / KC8, k8 = q % KC8;
     const int pix = pb * 64 + lane;
-    const int hy = (int)(((unsigned)pix * 3641u) >> 16);   // pix / 18 for pix < 192
-    const int hx = pix - hy * W3_HW;
-    const bool v = (pix < W3_HPIX) & ((unsigned)(iy0 + hy) < (unsigned)H) & ((unsigned)(ix0 + hx) < (unsigned)Wd);
-    const char* g = v ? xt + (unsigned)((hy * Wd + hx) * ldxb + k8 * 16) : zpage;
+    // LDS position -> halo pixel: row = pix / HW (exact multiply-shift for pix < 384); stride 2 stores the even columns
+    // first: position c < 17 is column 2 c, position c >= 17 is column 2 (c - 17) + 1
+    const int hy = S == 1 ? (int)(((unsigned)pix * 3641u) >> 16) : (int)(((unsigned)pix * 1986u) >> 16);
+    const int hp = pix - hy * W3_HW;
+    const int hx = S == 1 ? hp : (hp <= W3_TW ? 2 * hp : 2 * (hp - (W3_TW + 1)) + 1);
+    const bool v = (pix < W3_HPIX) & ((unsigned)(iy0 + hy) < (unsigned)inH) & ((unsigned)(ix0 + hx) < (unsigned)inW);
+    const char* g = v ? xt + (unsigned)((hy * inW + hx) * ldxb + k8 * 16) : zpage;
     w3_glds16(g, lds0 + buf * XB + k8 * PLANE + pb * 1024);
   };
 
@@ -161,7 +180,7 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
   }
   unsigned bbase[G];
 #pragma unroll
-  for (int g = 0; g < G; ++g) bbase[g] = (unsigned)(h * PLANE + (((wn * G + g) * 2 + lg) * W3_HW + lidx) * 16);
+  for (int g = 0; g < G; ++g) bbase[g] = (unsigned)(h * PLANE + (S * ((wn * G + g) * 2 + lg) * W3_HW + lidx) * 16);
   // output pixel of group g: (ty0 + (wn G + g) 2 + lg, tx0 + lidx); address (or null when outside the map)
   auto out_ptr = [&](const Org& o, int g) -> char* {
     const int py = o.ty0 + (wn * G + g) * 2 + lg, px = o.tx0 + lidx;
@@ -182,9 +201,9 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
 #pragma unroll
   for (int d = 0; d < D; ++d) issue_x1(oc, 0, d);
 
-  u32x4 pk[S];   // packed bf16 outputs of the previous tile: [group][pair of 8-channel halves], stored during this tile
+  u32x4 pk[NST];   // packed bf16 outputs of the previous tile: [group][pair of 8-channel halves], stored during this tile
 #pragma unroll
-  for (int q = 0; q < S; ++q) pk[q] = u32x4{0u, 0u, 0u, 0u};
+  for (int q = 0; q < NST; ++q) pk[q] = u32x4{0u, 0u, 0u, 0u};
   for (int i = 0; i < nt; ++i) {
     W3_VMCNT(0);                    // this wave's share of halo i (issued >= a third of a tile ago)
     __builtin_amdgcn_s_barrier();   // halo i complete; the other buffer is no longer read
@@ -192,7 +211,7 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
     const bool prev = i > 0;
     const Org on = tile_origin(i + 1 < nt ? i + 1 : i);
     const char* Xs = smem + (i & 1) * XB;
-    u32x4 old[S];
+    u32x4 old[NST];
 
     f32x16 acc[G];
 #pragma unroll
@@ -206,7 +225,7 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
       const int t9 = step / KS, ks = step % KS, dy = t9 / 3, dx = t9 % 3;
 #pragma unroll
       for (int g = 0; g < G; ++g)
-        dst[g] = __builtin_bit_cast(bf16x8, *(const u32x4*)(Xs + bbase[g] + (2 * ks * PLANE + (dy * W3_HW + dx) * 16)));
+        dst[g] = __builtin_bit_cast(bf16x8, *(const u32x4*)(Xs + bbase[g] + (2 * ks * PLANE + Geo::tap(dy, dx) * 16)));
     };
     // fragment ring of three: step s multiplies buffer s % 3 while the reads of step s + 2 are in flight (two steps = 256
     // matrix-pipe cycles ahead: with one wave per SIMD nothing else covers the LDS round trip)
@@ -217,17 +236,17 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
 #pragma unroll
     for (int ts = 0; ts < NTS; ++ts) {
       // -- the tile's memory traffic: at most one DMA, one store and two old-value loads per triple step
-      if (ts % 2 == 0 && ts / 2 < D) {
-        if (more) issue_x1(on, (i + 1) & 1, ts / 2);
+      if (ts % DST == 0 && ts / DST < D) {
+        if (more) issue_x1(on, (i + 1) & 1, ts / DST);
       }
-      if (ts % 2 == 1 && ts / 2 < S) {
-        char* q = prev ? out_ptr(op, (ts / 2) / 2) : nullptr;
-        if (q) *(u32x4*)(q + ((ts / 2) % 2) * 32) = pk[ts / 2];
+      if (ts % SST == SST - 1 && ts / SST < NST) {
+        char* q = prev ? out_ptr(op, (ts / SST) / 2) : nullptr;
+        if (q) *(u32x4*)(q + ((ts / SST) % 2) * 32) = pk[ts / SST];
       }
       if constexpr (MODE == 2) {
-        if (ts >= 2 * S && ts < 2 * S + S / 2) {
+        if (ts >= SST * NST && ts < SST * NST + NST / 2) {
 #pragma unroll
-          for (int l = 2 * (ts - 2 * S); l < 2 * (ts - 2 * S) + 2; ++l) {
+          for (int l = 2 * (ts - SST * NST); l < 2 * (ts - SST * NST) + 2; ++l) {
             char* q = out_ptr(oc, l / 2);
             old[l] = u32x4{0u, 0u, 0u, 0u};
             if (q) {
@@ -258,9 +277,9 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
 
     // ---- convert: accumulators -> bf16 -> permlane32_swap pairs -> 16 contiguous bytes per lane, kept for the next tile
     if constexpr (MODE == 2) {
-      if constexpr (S == 2)
+      if constexpr (NST == 2)
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(old[0]), "+v"(old[1])::"memory");
-      else if constexpr (S == 4)
+      else if constexpr (NST == 4)
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3])::"memory");
       else
         asm volatile("s_waitcnt vmcnt(0)"
@@ -326,7 +345,7 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
   }
   // the last tile's outputs
 #pragma unroll
-  for (int q = 0; q < S; ++q) {
+  for (int q = 0; q < NST; ++q) {
     char* o = out_ptr(op, q / 2);
     if (o) *(u32x4*)(o + (q % 2) * 32) = pk[q];
   }
@@ -396,7 +415,7 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
     const char* const rbase = (const char*)bn.res + wm * 64 + h * 16;
     for (int i = 0; i < nt; ++i) {
       const Org o = tile_origin(i);
-      u32x4 v[S], r[S];
+      u32x4 v[NST], r[NST];
       size_t pixi[G];
       bool ok[G];
 #pragma unroll
@@ -422,9 +441,9 @@ __global__ __launch_bounds__(WM* WN * 64, K == 128 ? 1 : 2) void w3_kernel(const
   }
 }
 
-template <int K, int WM, int WN, int G, int MODE>
+template <int K, int WM, int WN, int G, int MODE, int S = 1, int TH = 8>
 static int w3_launch_one(const W3Launch& l, hipStream_t s) {
-  auto fn = w3_kernel<K, WM, WN, G, MODE>;
+  auto fn = w3_kernel<K, WM, WN, G, MODE, S, TH>;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -434,8 +453,21 @@ static int w3_launch_one(const W3Launch& l, hipStream_t s) {
   MI_CHECK_LAUNCH("conv3x3_ws");
   return MI_OK;
 }
+// output rows of a tile / output channels of a block for (stride, K)
+constexpr int w3_tile_h(int S, int K) { return S == 1 ? 8 : (K == 128 ? 2 : 4); }
+constexpr int w3_block_cout(int S, int K) { return S == 1 ? K : (K == 32 ? 64 : 128); }
 template <int MODE>
 static int w3_launch_mode(const W3Launch& l, hipStream_t s) {
+  if (l.S == 2) {
+    if constexpr (MODE == 1 || MODE == 0) {
+      switch (l.K) {
+        case 128: return w3_launch_one<128, 4, 1, 1, MODE, 2, 2>(l, s);
+        case 64: return w3_launch_one<64, 4, 1, 2, MODE, 2, 4>(l, s);
+        case 32: return w3_launch_one<32, 2, 2, 1, MODE, 2, 4>(l, s);
+      }
+    }
+    MI_FAIL(MI_EINVAL, "conv3x3_ws: stride 2 with K %d / mode %d", l.K, MODE);
+  }
   switch (l.K) {
     case 128: return w3_launch_one<128, 4, 1, 4, MODE>(l, s);
     case 64: return w3_launch_one<64, 2, 2, 2, MODE>(l, s);

@@ -25,14 +25,24 @@ static int w3_cus() {
   return cus;
 }
 
-// 3x3, stride 1, K -> K with K in {32, 64, 128}, bf16 in / out, no bias; tw[] = weight slab per tap position
+// 3x3, K in {32, 64, 128} input channels, bf16 in / out, no bias; stride 1: K -> K; stride 2 (forward only): K -> a multiple
+// of the block's output channels (64 for K = 32, else 128), pad 1.  tw[] = weight slab per tap position
 static bool w3_desc_ok(const mi_conv_desc* d, int* tw) {
   const int K = d->K8 * 8;
-  if (d->ntaps != 9 || d->in_stride != 1 || d->out_stride != 1 || d->out_oy || d->out_ox) return false;
-  if (d->gridH != d->outH || d->gridW != d->outW || d->outH != d->H || d->outW != d->W) return false;
+  if (d->ntaps != 9 || (d->in_stride != 1 && d->in_stride != 2) || d->out_stride != 1 || d->out_oy || d->out_ox) return false;
+  if (d->gridH != d->outH || d->gridW != d->outW) return false;
   if (d->flags & ~MI_CONV_ACCUM) return false;
   if (d->bias) return false;
-  if (!(K == 32 || K == 64 || K == 128) || d->Cout != K || d->CoutPad != K) return false;
+  if (!(K == 32 || K == 64 || K == 128) || d->Cout != d->CoutPad) return false;
+  if (d->in_stride == 1) {
+    if (d->outH != d->H || d->outW != d->W || d->Cout != K) return false;
+  } else {
+    const char* s2 = getenv("MI_CONV_WS_S2");     // (read per call: tests compare the two kernels in one process)
+    if ((s2 && atoi(s2) == 0) || (d->flags & MI_CONV_ACCUM)) return false;
+    if (d->outH != (d->H - 1) / 2 + 1 || d->outW != (d->W - 1) / 2 + 1) return false;
+    const int bc = w3_block_cout(2, K);
+    if (d->Cout % bc || d->Cout / bc > W3_MAX_JOBS) return false;
+  }
   if (d->ldx % 8 || d->ldy % 8 || ((uintptr_t)d->x & 15) || ((uintptr_t)d->y & 15) || ((uintptr_t)d->w & 15)) return false;
   if (d->y_nstride && (long long)d->y_nstride != (long long)d->outH * d->outW * d->ldy) return false;
   if ((long long)d->H * d->W * d->ldx * 2 >= (1LL << 31)) return false;   // per-lane 32-bit offsets inside one image
@@ -53,30 +63,43 @@ static bool w3_desc_ok(const mi_conv_desc* d, int* tw) {
 static bool w3_fill(const mi_conv_desc* ds, int n, W3Launch* l, const mi_bn_job* bn = nullptr) {
   if (n < 1 || n > W3_MAX_JOBS) return false;
   memset(l, 0, sizeof(*l));
-  const int K = ds[0].K8 * 8;
-  if (bn && ((ds[0].flags & MI_CONV_ACCUM) || !ds[0].stats_acc)) return false;
+  const int K = ds[0].K8 * 8, S = ds[0].in_stride;
+  if (bn && ((ds[0].flags & MI_CONV_ACCUM) || !ds[0].stats_acc || S != 1)) return false;
   const int mode = (ds[0].flags & MI_CONV_ACCUM) ? 2 : (ds[0].stats_acc ? (bn ? 3 : 1) : 0);
-  const int lds = 2 * (K / 8) * W3_HROWS * 16 + ((mode == 1 || mode == 3) ? 256 * 32 * 4 : 0);   // halo ring (+ per-lane BatchNorm sums)
+  const int TH = w3_tile_h(S, K);
+  const int hrows = ((S == 1 ? (TH + 2) * (W3_TW + 2) : (2 * TH + 1) * (2 * W3_TW + 1)) + 63) / 64 * 64;
+  const int lds = 2 * (K / 8) * hrows * 16 + ((mode == 1 || mode == 3) ? 256 * 32 * 4 : 0);   // halo ring (+ per-lane BatchNorm sums)
   long long total = 0;
+  int nj = 0;
   for (int j = 0; j < n; ++j) {
     const mi_conv_desc& d = ds[j];
-    W3Job& jb = l->k.j[j];
-    if (!w3_desc_ok(&d, jb.tw) || d.K8 * 8 != K) return false;
+    int tw[9];
+    if (!w3_desc_ok(&d, tw) || d.K8 * 8 != K || d.in_stride != S) return false;
     if ((d.flags & MI_CONV_ACCUM) != (ds[0].flags & MI_CONV_ACCUM) || (d.stats_acc != nullptr) != (ds[0].stats_acc != nullptr)) return false;
-    jb.x = (const __bf16*)d.x; jb.w = (const u32x4*)d.w; jb.y = (__bf16*)d.y; jb.stats = d.stats_acc;
-    jb.ldx = d.ldx; jb.ldy = d.ldy; jb.N = d.N; jb.H = d.H; jb.W = d.W;
-    jb.tilesY = mi_cdiv(d.H, W3_TH); jb.tilesX = mi_cdiv(d.W, W3_TW);
-    jb.ntiles = d.N * jb.tilesY * jb.tilesX;
-    jb.wld = d.CoutPad;
-    jb.nslots = (d.stats_slots >= 1 && d.stats_slots <= MI_BN_SLOTS) ? d.stats_slots : MI_BN_SLOTS;
-    jb.sld = d.CoutPad * 2;
-    total += jb.ntiles;
-    if (bn && !cbn_from_job(d, bn[j], &jb.bn)) return false;
+    // a block computes w3_block_cout output channels: a wider convolution (stride 2: K -> 2 K) is that many jobs over one input
+    const int bc = w3_block_cout(S, K);
+    for (int c0 = 0; c0 < d.Cout; c0 += bc, ++nj) {
+      if (nj >= W3_MAX_JOBS) return false;
+      W3Job& jb = l->k.j[nj];
+      memcpy(jb.tw, tw, sizeof(tw));
+      jb.x = (const __bf16*)d.x; jb.w = (const u32x4*)d.w + c0; jb.y = (__bf16*)d.y + c0;
+      jb.stats = d.stats_acc ? d.stats_acc + (size_t)c0 * 2 : nullptr;
+      jb.ldx = d.ldx; jb.ldy = d.ldy; jb.N = d.N; jb.H = d.outH; jb.W = d.outW; jb.inH = d.H; jb.inW = d.W;
+      jb.tilesY = mi_cdiv(d.outH, TH); jb.tilesX = mi_cdiv(d.outW, W3_TW);
+      jb.ntiles = d.N * jb.tilesY * jb.tilesX;
+      jb.wld = d.CoutPad;
+      jb.nslots = (d.stats_slots >= 1 && d.stats_slots <= MI_BN_SLOTS) ? d.stats_slots : MI_BN_SLOTS;
+      jb.sld = d.CoutPad * 2;
+      total += jb.ntiles;
+      if (bn && !cbn_from_job(d, bn[j], &jb.bn)) return false;
+    }
   }
+  n = nj;
   // persistent blocks: K = 128 one per CU (288 VGPRs of weights per wave), K = 64 two, K = 32 four; shared between
   // the jobs in proportion to their tiles (every job gets at least one block, none more blocks than tiles)
   static const int ovr = getenv("MI_W3_PERCU") ? atoi(getenv("MI_W3_PERCU")) : 0;
   int per_cu = ovr > 0 ? ovr : (K == 128 ? 1 : (K == 64 ? 2 : 4));
+  if (S == 2 && ovr <= 0) per_cu = (160 * 1024) / lds >= 2 && K != 128 ? 2 : 1;    // (the stride-2 halo ring is 41 - 98 KB)
   if (mode == 3) {   // the grid barrier needs every block resident
     static int occ[3] = {-1, -1, -1};
     int& o = occ[K == 128 ? 0 : (K == 64 ? 1 : 2)];
@@ -117,6 +140,7 @@ static bool w3_fill(const mi_conv_desc* ds, int n, W3Launch* l, const mi_bn_job*
   // (timing experiments; read per call.  1: no statistics atomics, 2: no halo traffic after the first tile, 4: no main loop)
   l->k.dbg = (getenv("MI_DEBUG_NOATOM") ? atoi(getenv("MI_DEBUG_NOATOM")) & 1 : 0) | (getenv("MI_W3_DBG") ? atoi(getenv("MI_W3_DBG")) & 6 : 0);
   l->K = K;
+  l->S = S;
   l->MODE = mode;
   l->grid = blk;
   l->lds = lds;
