@@ -486,7 +486,8 @@ int mi_dropout_seed_offset(const uint64_t* dev_word);
  * nn.LayerNorm(E) forward / backward over bf16 [T][E] token rows (fp32 gamma/beta/mean/rstd), eps 1e-5;
  * E %% 64 == 0, E <= 1024; ws (backward): fp32 [ceil(T/64)][E][2].  mi_ew_bf16: op 0 out = a + b (residual),
  * op 1 out = relu(a), op 2 out = a * (b > 0) (ReLU backward: a = dy, b = forward output), op 3 out = sigmoid(a),
- * op 4 out = a * b * (1 - b) (sigmoid backward: a = dy, b = forward output); n %% 8 == 0. */
+ * op 4 out = a * b * (1 - b) (sigmoid backward: a = dy, b = forward output); op 5 / 6 swish and its backward; op 7 out =
+ * relu(a + b) (the tail of a ResNet bottleneck, bit-identical to op 0 followed by op 1); n %% 8 == 0. */
 int mi_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int T,
                      int E, float eps, mi_stream_t s);
 int mi_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,

@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void ew_kernel(const __bf16* __restrict__ a, c
       else if (op == 3) z = 1.f / (1.f + __expf(-x));
       else if (op == 4) z = x * y * (1.f - y); // sigmoid backward, a = dy, b = forward output
       else if (op == 5) z = x / (1.f + __expf(-x));   // swish / SiLU (BiFPN's Swish, neck/bifpn.py:49-61)
+      else if (op == 7) z = fmaxf((float)(__bf16)(x + y), 0.f);   // relu(a + b): the tail of a ResNet bottleneck in one pass
       else {                                   // op 6: swish backward, a = dy, b = forward INPUT
         const float sg = 1.f / (1.f + __expf(-y));
         z = x * sg * (1.f + y * (1.f - sg));
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void ew_kernel(const __bf16* __restrict__ a, c
   }
 }
 extern "C" int mi_ew_bf16(const void* a, const void* b, void* out, int64_t n, int op, mi_stream_t st) {
-  MI_REQUIRE(a && out && n > 0 && n % 8 == 0 && op >= 0 && op <= 6 && (op == 1 || op == 3 || op == 5 || b), "ew_bf16: args");
+  MI_REQUIRE(a && out && n > 0 && n % 8 == 0 && op >= 0 && op <= 7 && (op == 1 || op == 3 || op == 5 || b), "ew_bf16: args");
   MI_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && ((uintptr_t)out % 16) == 0, "ew_bf16: alignment");
   int64_t blocks = (n / 8 + 255) / 256;
   if (blocks > 2048) blocks = 2048;

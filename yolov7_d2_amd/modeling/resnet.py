@@ -71,11 +71,8 @@ class _EwAddRelu(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, b):
-        s = torch.empty_like(a)
-        lib = L.lib()
-        L.check(lib.mi_ew_bf16(a.data_ptr(), b.data_ptr(), s.data_ptr(), a.numel(), 0, L.stream_ptr()), "mi_ew_bf16 add")
         y = torch.empty_like(a)
-        L.check(lib.mi_ew_bf16(s.data_ptr(), None, y.data_ptr(), a.numel(), 1, L.stream_ptr()), "mi_ew_bf16 relu")
+        L.check(L.lib().mi_ew_bf16(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), 7, L.stream_ptr()), "mi_ew_bf16 add+relu")
         ctx.save_for_backward(y)
         return y
 
