@@ -51,6 +51,8 @@ const char* mi_last_error(void);
  * (s2 dgrad = 4 parity-class launches with out_stride 2) via the tap table. */
 #define MI_CONV_ACCUM 1    /* y += result (gradient fan-in)                  */
 #define MI_CONV_OUT_F32 2  /* y is fp32 (prediction maps), else bf16         */
+#define MI_CONV_RELU 8     /* y = max(result + bias, 0): the ReLU behind a Conv2d + FrozenBatchNorm2d of detectron2's ResNet
+                              (forward, bf16 output, no MI_CONV_ACCUM / statistics); tile kernel only              */
 #define MI_CONV_BNBWD 4    /* data-gradient launch that also reduces the BatchNorm backward sums of the layer that
                               PRODUCED its output tensor: stats_acc += (sum dz, sum dz*xhat) per channel with
                               dz = y_out * act'(bn_y*scale+shift), xhat = (bn_y-mean)*invstd - replaces the

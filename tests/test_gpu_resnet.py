@@ -182,3 +182,31 @@ def test_trainable_stem_forward_and_weight_gradient_match_torch(H, W):
     assert cos > 0.995 and abs(float(ga.norm() / gb.norm()) - 1.0) < 0.01, (cos, float(ga.norm() / gb.norm()))
     per_cout = (ga * gb).sum((1, 2, 3)) / (gb * gb).sum((1, 2, 3))
     assert float((per_cout - 1).abs().max()) < 0.05       # (the frozen scale is applied per output channel)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,bias", [(64, 64, 1, 1, True), (64, 64, 3, 1, True), (128, 128, 3, 2, True),
+                                                    (256, 256, 3, 1, True), (64, 48, 3, 1, False)])
+def test_conv2d_relu_epilogue_equals_conv_then_relu(cin, cout, k, stride, bias):
+    """MI_CONV_RELU: the fused launch must give bit-identical outputs and gradients to conv2d followed by the separate ReLU
+    pass (same convolution kernel, the clamp applied to the fp32 value before the single bf16 rounding)"""
+    from yolov7_d2_amd.modeling.sparseinst import relu as ew_relu
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, cin, 20, 28, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).cuda()
+    b = torch.randn(cout, generator=g).cuda() * 0.1 if bias else None
+    dy = torch.randn(2, cout, (20 + 2 * (k // 2) - k) // stride + 1, (28 + 2 * (k // 2) - k) // stride + 1, generator=g)
+    dy = dy.to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    outs = []
+    for fused in (True, False):
+        xi, wi = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        bi = b.clone().requires_grad_(True) if bias else None
+        if fused:
+            y = torch.ops.mi355.conv2d_relu(xi, wi, bi, stride, k // 2)
+        else:
+            y = ew_relu(torch.ops.mi355.conv2d(xi, wi, bi, stride, k // 2))
+        y.backward(dy)
+        outs.append((y.detach().float(), xi.grad.float(), wi.grad.float(), bi.grad.float() if bias else None))
+    assert (outs[0][0] > 0).float().mean().item() > 0.2
+    for a, r in zip(*outs):
+        if a is not None:
+            assert torch.equal(a, r)

@@ -121,6 +121,8 @@ static int conv_fill(const mi_conv_desc* d, ConvK* k, ConvCfg* c, size_t* ldsByt
     static const int noatom = getenv("MI_DEBUG_NOATOM") ? atoi(getenv("MI_DEBUG_NOATOM")) : 0;
     if (noatom) k->flags |= 1024;
   }
+  MI_REQUIRE(!(d->flags & MI_CONV_RELU) || !((d->flags & (MI_CONV_ACCUM | MI_CONV_BNBWD | MI_CONV_OUT_F32)) || d->stats_acc),
+             "conv: MI_CONV_RELU is a plain forward epilogue (bf16 output, no accumulate / statistics)");
   if (d->flags & MI_CONV_BNBWD) {
     MI_REQUIRE(d->stats_acc && d->bn_y && d->bn_scale && d->bn_shift && d->bn_mean && d->bn_invstd,
                "conv: MI_CONV_BNBWD needs stats_acc and the producing layer's bn_* arrays");

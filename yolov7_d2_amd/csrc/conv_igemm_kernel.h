@@ -263,6 +263,7 @@ __device__ __forceinline__ void conv_igemm_body(PK& p, const int bid) {
             for (int e = 0; e < 4; ++e) {
               float v = acc[i][j][4 * q + e];
               if (p.bias && co0 + cl + e < p.Cout) v += p.bias[co0 + cl + e];
+              if (p.flags & MI_CONV_RELU) v = fmaxf(v, 0.f);
               o[e] = (__bf16)v;
             }
             *(bf16x4*)(Tb + row * RS + cl * 2) = o;
@@ -413,6 +414,10 @@ __device__ __forceinline__ void conv_igemm_body(PK& p, const int bid) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (c + e < p.Cout) v[e] += p.bias[c + e];
+        }
+        if (p.flags & MI_CONV_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (outf32) {
           float* yp = (float*)p.y + po + c;

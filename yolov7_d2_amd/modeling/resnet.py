@@ -19,6 +19,7 @@ How it runs:
 Activations are bf16 NCHW tensors in channels_last memory (= NHWC for the kernels).
 """
 import ctypes as C
+import os
 
 import torch
 from torch import nn
@@ -85,6 +86,11 @@ class _EwAddRelu(torch.autograd.Function):
         return out, out
 
 
+def _conv_relu_fused():
+    """MI_CONV_RELU_FUSE=0 keeps the ReLU after a bottleneck's conv1 / conv2 as its own pass (A/B switch)"""
+    return os.environ.get("MI_CONV_RELU_FUSE", "1") != "0"
+
+
 def _relu(x):
     """NCHW (channels_last) bf16 -> same layout"""
     return _EwRelu.apply(_nhwc_view(x)).permute(0, 3, 1, 2)
@@ -132,13 +138,15 @@ class Conv2d(nn.Module):
         self.norm = FrozenBatchNorm2d(cout)
         self.stride, self.padding = stride, padding
 
-    def forward(self, x):
+    def forward(self, x, relu=False):
+        """relu=True: the ReLU that follows runs in the convolution's epilogue (MI_CONV_RELU), one launch instead of two"""
         scale, shift = self.norm.affine()
         w = self.weight * scale.view(-1, 1, 1, 1)          # the frozen affine folded into the weight image / bias
+        op = torch.ops.mi355.conv2d_relu if relu else torch.ops.mi355.conv2d
         if not self.weight.requires_grad:
             with torch.no_grad():
-                return torch.ops.mi355.conv2d(x, w, shift, self.stride, self.padding)
-        return torch.ops.mi355.conv2d(x, w, shift, self.stride, self.padding)
+                return op(x, w, shift, self.stride, self.padding)
+        return op(x, w, shift, self.stride, self.padding)
 
 
 class _StemFn(torch.autograd.Function):
@@ -246,8 +254,10 @@ class BottleneckBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = _relu(self.conv1(x))
-        out = _relu(self.conv2(out))
+        if _conv_relu_fused():
+            out = self.conv2(self.conv1(x, relu=True), relu=True)
+        else:
+            out = _relu(self.conv2(_relu(self.conv1(x))))
         out = self.conv3(out)
         sc = self.shortcut(x) if self.shortcut is not None else x
         return _add_relu(out, sc)

@@ -183,9 +183,11 @@ class _PixelOuterFn(torch.autograd.Function):
         return da.contiguous(), db.contiguous()
 
 
-def _conv(x, m, stride=1):
-    """nn.Conv2d / detectron2 Conv2d (bias, no norm) through the implicit-GEMM op"""
-    return torch.ops.mi355.conv2d(x, m.weight, m.bias, stride, m.padding[0])
+def _conv(x, m, stride=1, relu=False):
+    """nn.Conv2d / detectron2 Conv2d (bias, no norm) through the implicit-GEMM op; relu=True applies the ReLU that follows
+    in the convolution's epilogue (MI_CONV_RELU) instead of as a second pass over the map"""
+    op = torch.ops.mi355.conv2d_relu if relu else torch.ops.mi355.conv2d
+    return op(x, m.weight, m.bias, stride, m.padding[0])
 
 
 def _linear(x, lin):
@@ -219,8 +221,8 @@ class PyramidPoolingModule(nn.Module):
 
     def forward(self, feats):
         h, w = feats.shape[2], feats.shape[3]
-        priors = [resize_bilinear(relu(_conv(st[0](feats), st[1])), (h, w)) for st in self.stages] + [feats]
-        return relu(_conv(torch.cat(priors, 1), self.bottleneck))
+        priors = [resize_bilinear(_conv(st[0](feats), st[1], relu=True), (h, w)) for st in self.stages] + [feats]
+        return _conv(torch.cat(priors, 1), self.bottleneck, relu=True)
 
 
 class InstanceContextEncoder(nn.Module):
@@ -270,8 +272,16 @@ def _make_stack_3x3_convs(num_convs, in_channels, out_channels):
 
 
 def _run_stack(seq, x):
-    for m in seq:
-        x = relu(x) if isinstance(m, nn.ReLU) else _conv(x, m)
+    mods, i = list(seq), 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.ReLU):
+            x = relu(x)
+        else:
+            act = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)      # conv + ReLU pair: one launch
+            x = _conv(x, m, relu=act)
+            i += act
+        i += 1
     return x
 
 

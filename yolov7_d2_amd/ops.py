@@ -99,11 +99,11 @@ class _ConvGeom:
             xh = xp
         return xh
 
-    def fwd(self, xh, wf, y, bias=None, stats=None, nslots=0):
+    def fwd(self, xh, wf, y, bias=None, stats=None, nslots=0, relu=False):
         taps = [(r - self.pad, s - self.pad, r * self.k + s) for r in range(self.k) for s in range(self.k)]
         _run_conv(_conv_desc(xh.data_ptr(), self.CinP, self.N, self.H, self.W, wf, self.CinP, y.data_ptr(), y.shape[-1],
                              self.Ho, self.Wo, self.Cout, self.CoutP, taps, in_stride=self.s, bias=bias, stats=stats,
-                             nslots=nslots), "mi_conv2d (forward)")
+                             nslots=nslots, flags=L.MI_CONV_RELU if relu else 0), "mi_conv2d (forward)")
 
     def dgrad(self, dyh, wd, dx):
         """dyh bf16 [N,Ho,Wo,CoutP] (zero pad channels) -> dx bf16 [N,H,W,CinP] (real channels written)"""
@@ -167,7 +167,7 @@ _LIBDEF.define("conv2d(Tensor x, Tensor weight, Tensor? bias, int stride, int pa
 _LIBDEF.define("conv2d_backward(Tensor grad, Tensor x, Tensor weight, bool has_bias, int stride, int padding) -> (Tensor, Tensor, Tensor)")
 
 
-def _conv2d_cuda(x, weight, bias, stride, padding):
+def _conv2d_cuda(x, weight, bias, stride, padding, relu=False):
     g = _ConvGeom(x.shape, weight.shape, stride, padding)
     wf, _ = g.pack(weight)
     y = torch.empty(g.N, g.Ho, g.Wo, g.CoutP, dtype=torch.bfloat16, device=x.device)
@@ -178,7 +178,7 @@ def _conv2d_cuda(x, weight, bias, stride, padding):
         else:
             b32 = torch.zeros(g.CoutP, dtype=torch.float32, device=x.device)
             b32[: g.Cout] = bias.detach().float()
-    g.fwd(g.pad_in(x), wf, y, bias=b32)
+    g.fwd(g.pad_in(x), wf, y, bias=b32, relu=relu)
     return _nchw(y, g.Cout)
 
 
@@ -214,6 +214,30 @@ def _conv2d_bwd(ctx, grad):
 
 
 torch.library.register_autograd("mi355::conv2d", _conv2d_bwd, setup_context=_conv2d_setup)
+
+# conv2d + ReLU in the convolution's epilogue (MI_CONV_RELU): detectron2's Conv2d(norm=FrozenBN, activation=relu) as ONE
+# launch - the separate ReLU was a read + write of the whole map per convolution.  Backward: the ReLU mask comes from the
+# saved OUTPUT (out > 0), then the plain convolution backward.
+_LIBDEF.define("conv2d_relu(Tensor x, Tensor weight, Tensor? bias, int stride, int padding) -> Tensor")
+torch.library.impl(_LIBDEF, "conv2d_relu", "CUDA")(lambda x, weight, bias, stride, padding: _conv2d_cuda(x, weight, bias, stride, padding, relu=True))
+
+
+def _conv2d_relu_setup(ctx, inputs, output):
+    x, weight, bias, stride, padding = inputs
+    ctx.save_for_backward(x, weight, output)
+    ctx.has_bias, ctx.stride, ctx.padding = bias is not None, stride, padding
+
+
+def _conv2d_relu_bwd(ctx, grad):
+    x, weight, out = ctx.saved_tensors
+    gh, oh = _nhwc(grad), _nhwc(out)
+    gm = torch.empty_like(gh)
+    L.check(L.lib().mi_ew_bf16(gh.data_ptr(), oh.data_ptr(), gm.data_ptr(), gh.numel(), 2, L.stream_ptr()), "mi_ew_bf16 relu'")
+    dx, gw, gb = torch.ops.mi355.conv2d_backward(gm.permute(0, 3, 1, 2), x, weight, ctx.has_bias, ctx.stride, ctx.padding)
+    return dx.to(x.dtype), gw.to(weight.dtype), (gb if ctx.has_bias else None), None, None
+
+
+torch.library.register_autograd("mi355::conv2d_relu", _conv2d_relu_bwd, setup_context=_conv2d_relu_setup)
 
 
 # ------------------------------------------------------------------------------------------------ mi355::conv_bn_silu
