@@ -26,7 +26,7 @@ from torch import nn
 
 from .. import _lib as L
 from ..d2shim import BACKBONE_REGISTRY, Backbone, ShapeSpec
-from ..ops import _conv_desc, _run_conv
+from ..ops import _ConvGeom, _conv_desc, _nchw, _nhwc, _pad_last, _run_conv
 
 
 class FrozenBatchNorm2d(nn.Module):
@@ -41,8 +41,17 @@ class FrozenBatchNorm2d(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features) - eps)
 
     def affine(self):
-        scale = self.weight * (self.running_var + self.eps).rsqrt()
-        return scale, self.bias - self.running_mean * scale
+        """(scale, shift), fp32 [C].  The four buffers are constants of a training run: the pair is computed once and kept
+        until a buffer is written or replaced (five tiny launches per convolution per step otherwise)."""
+        bufs = (self.weight, self.bias, self.running_mean, self.running_var)
+        key = tuple((t.data_ptr(), t._version) for t in bufs)
+        c = self.__dict__.get("_affine")
+        if c is None or c[0] != key:
+            with torch.no_grad():
+                scale = (self.weight.float() * (self.running_var.float() + self.eps).rsqrt()).contiguous()
+                shift = (self.bias.float() - self.running_mean.float() * scale).contiguous()
+            c = self.__dict__["_affine"] = (key, scale, shift)
+        return c[1], c[2]
 
 
 def _nhwc_view(x):
@@ -139,14 +148,82 @@ class Conv2d(nn.Module):
         self.stride, self.padding = stride, padding
 
     def forward(self, x, relu=False):
-        """relu=True: the ReLU that follows runs in the convolution's epilogue (MI_CONV_RELU), one launch instead of two"""
+        """relu=True: the ReLU that follows runs in the convolution's epilogue (MI_CONV_RELU), one launch instead of two.
+        The frozen affine is folded into the packed weight image (scale) and the bias (shift)."""
         scale, shift = self.norm.affine()
-        w = self.weight * scale.view(-1, 1, 1, 1)          # the frozen affine folded into the weight image / bias
-        op = torch.ops.mi355.conv2d_relu if relu else torch.ops.mi355.conv2d
-        if not self.weight.requires_grad:
+        if not _FOLDED_FN():
+            w = self.weight * scale.view(-1, 1, 1, 1)
+            op = torch.ops.mi355.conv2d_relu if relu else torch.ops.mi355.conv2d
+            if not self.weight.requires_grad:
+                with torch.no_grad():
+                    return op(x, w, shift, self.stride, self.padding)
+            return op(x, w, shift, self.stride, self.padding)
+        train_w = self.weight.requires_grad and torch.is_grad_enabled()
+        if not train_w and not (x.requires_grad and torch.is_grad_enabled()):
+            # a frozen layer under a frozen prefix (FREEZE_AT): its packed image is a constant too
+            g = _ConvGeom(x.shape, self.weight.shape, self.stride, self.padding)
+            key = (self.weight.data_ptr(), self.weight._version, scale.data_ptr())
+            c = self.__dict__.get("_image")
+            if c is None or c[0] != key:
+                with torch.no_grad():
+                    c = self.__dict__["_image"] = (key, g.pack(self.weight * scale.view(-1, 1, 1, 1), dgrad=False)[0])
             with torch.no_grad():
-                return op(x, w, shift, self.stride, self.padding)
-        return op(x, w, shift, self.stride, self.padding)
+                return _folded_forward(g, x, c[1], shift, relu)[1]
+        return _FoldedConvFn.apply(x, self.weight, scale, shift, self.stride, self.padding, relu)
+
+
+def _FOLDED_FN():
+    """MI_RESNET_FOLDED_FN=0: the round-2 form (mi355::conv2d on `weight * scale`; packs in forward AND backward,
+    a bias gradient nobody reads) - A/B switch"""
+    return os.environ.get("MI_RESNET_FOLDED_FN", "1") != "0"
+
+
+def _folded_forward(g, x, wf, shift, relu):
+    xh = g.pad_in(x)
+    y = torch.empty(g.N, g.Ho, g.Wo, g.CoutP, dtype=torch.bfloat16, device=x.device)
+    b32 = shift
+    if g.CoutP != g.Cout:
+        b32 = torch.zeros(g.CoutP, dtype=torch.float32, device=x.device)
+        b32[: g.Cout] = shift
+    g.fwd(xh, wf, y, bias=b32, relu=relu)
+    return xh, _nchw(y, g.Cout)
+
+
+class _FoldedConvFn(torch.autograd.Function):
+    """Conv2d + FrozenBatchNorm2d (+ ReLU) of a TRAINABLE layer as one autograd node: y = act(conv(x, W * scale) + shift).
+    One pack launch writes the forward and the data-gradient image (the latter is kept for backward), no bias gradient
+    (shift is a buffer), the ReLU mask comes from the saved output, gW = scale * gW'."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scale, shift, stride, padding, relu):
+        g = _ConvGeom(x.shape, weight.shape, stride, padding)
+        need_dx = x.requires_grad
+        wf, wd = g.pack(weight.detach() * scale.view(-1, 1, 1, 1), dgrad=need_dx)
+        xh, y = _folded_forward(g, x, wf, shift, relu)
+        ctx.g, ctx.relu = g, relu
+        ctx.save_for_backward(xh, wd, scale, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad):
+        xh, wd, scale, y = ctx.saved_tensors
+        g = ctx.g
+        dyh = _nhwc(grad)
+        if ctx.relu:
+            yh = _nhwc(y)
+            gm = torch.empty_like(dyh)
+            L.check(L.lib().mi_ew_bf16(dyh.data_ptr(), yh.data_ptr(), gm.data_ptr(), dyh.numel(), 2, L.stream_ptr()), "mi_ew_bf16 relu'")
+            dyh = gm
+        dyh = _pad_last(dyh, g.CoutP)
+        dx = gw = None
+        if ctx.needs_input_grad[0]:
+            full = g.CinP == g.Cin and not (g.k == 1 and g.s == 2)
+            dxh = (torch.empty if full else torch.zeros)(g.N, g.H, g.W, g.CinP, dtype=torch.bfloat16, device=xh.device)
+            g.dgrad(dyh, wd, dxh)
+            dx = _nchw(dxh, g.Cin)
+        if ctx.needs_input_grad[1]:
+            gw = g.wgrad(xh, dyh) * scale.view(-1, 1, 1, 1)
+        return dx, gw, None, None, None, None, None
 
 
 class _StemFn(torch.autograd.Function):
@@ -162,11 +239,10 @@ class _StemFn(torch.autograd.Function):
         wf = torch.empty(16 * 16 * Cout, dtype=torch.bfloat16, device=s2d.device)
         L.check(L.lib().mi_pack_conv_weight(w4.contiguous().data_ptr(), Cout, 4 * Cin, 4, 4, wf.data_ptr(), 16, Cout,
                                             None, 0, 0, L.stream_ptr()), "mi_pack_conv_weight (stem)")
-        y = torch.empty(N, Hh, Wh, Cout, dtype=torch.bfloat16, device=s2d.device)
-        _run_conv(_conv_desc(s2d.data_ptr(), 16, N, Hh, Wh, wf, 16, y.data_ptr(), Cout, Hh, Wh, Cout, Cout, _STEM_TAPS,
-                             bias=shift.float().contiguous()), "mi_conv2d (7x7 stem as 4x4 over space-to-depth)")
-        a = torch.empty_like(y)
-        L.check(L.lib().mi_ew_bf16(y.data_ptr(), None, a.data_ptr(), y.numel(), 1, L.stream_ptr()), "relu")
+        a = torch.empty(N, Hh, Wh, Cout, dtype=torch.bfloat16, device=s2d.device)
+        _run_conv(_conv_desc(s2d.data_ptr(), 16, N, Hh, Wh, wf, 16, a.data_ptr(), Cout, Hh, Wh, Cout, Cout, _STEM_TAPS,
+                             bias=shift.float().contiguous(), flags=L.MI_CONV_RELU),
+                  "mi_conv2d (7x7 stem as 4x4 over space-to-depth, ReLU in the epilogue)")
         out = torch.empty(N, (Hh + 1) // 2, (Wh + 1) // 2, Cout, dtype=torch.bfloat16, device=s2d.device)
         code = torch.empty(N, (Hh + 1) // 2, (Wh + 1) // 2, Cout, dtype=torch.uint8, device=s2d.device)
         L.check(L.lib().mi_maxpool3x3s2_fwd_idx(a.data_ptr(), Cout, out.data_ptr(), Cout, code.data_ptr(), N, Hh, Wh, Cout,
@@ -239,8 +315,24 @@ class BasicStem(nn.Module):
             L.check(L.lib().mi_focus_pack(x.data_ptr(), N, He, We, s2d.data_ptr(), 16, L.stream_ptr()), "mi_focus_pack")
         if w7.requires_grad and torch.is_grad_enabled():
             return _StemFn.apply(s2d, w7, scale, shift).permute(0, 3, 1, 2)
-        with torch.no_grad():
-            return _StemFn.apply(s2d, w7, scale, shift).permute(0, 3, 1, 2)
+        with torch.no_grad():       # frozen stem (FREEZE_AT >= 1): the packed image is a constant, kept across steps
+            Cout = w7.shape[0]
+            key = (w7.data_ptr(), w7._version, scale.data_ptr())
+            c = self.__dict__.get("_image")
+            if c is None or c[0] != key:
+                w4 = _w7_to_w4(w7 * scale.view(-1, 1, 1, 1)).contiguous()
+                wf = torch.empty(16 * 16 * Cout, dtype=torch.bfloat16, device=x.device)
+                L.check(L.lib().mi_pack_conv_weight(w4.data_ptr(), Cout, 4 * Cin, 4, 4, wf.data_ptr(), 16, Cout, None, 0, 0,
+                                                    L.stream_ptr()), "mi_pack_conv_weight (stem)")
+                c = self.__dict__["_image"] = (key, wf)
+            Hh, Wh = He // 2, We // 2
+            a = torch.empty(N, Hh, Wh, Cout, dtype=torch.bfloat16, device=x.device)
+            _run_conv(_conv_desc(s2d.data_ptr(), 16, N, Hh, Wh, c[1], 16, a.data_ptr(), Cout, Hh, Wh, Cout, Cout, _STEM_TAPS,
+                                 bias=shift, flags=L.MI_CONV_RELU), "mi_conv2d (7x7 stem as 4x4 over space-to-depth)")
+            out = torch.empty(N, (Hh + 1) // 2, (Wh + 1) // 2, Cout, dtype=torch.bfloat16, device=x.device)
+            L.check(L.lib().mi_maxpool3x3s2_fwd(a.data_ptr(), Cout, out.data_ptr(), Cout, N, Hh, Wh, Cout, L.stream_ptr()),
+                    "maxpool fwd")
+            return out.permute(0, 3, 1, 2)
 
 
 class BottleneckBlock(nn.Module):

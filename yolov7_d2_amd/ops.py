@@ -80,13 +80,14 @@ class _ConvGeom:
         self.CinP, self.CoutP = _rup(self.Cin, 32), _rup(self.Cout, 32)
         self.KK = self.k * self.k
 
-    def pack(self, weight):
+    def pack(self, weight, fwd=True, dgrad=True):
+        """(forward image, data-gradient image) of an OIHW weight; an image that is not asked for is None"""
         dev = weight.device
-        wf = torch.empty(self.KK * self.CinP * self.CoutP, dtype=torch.bfloat16, device=dev)
-        wd = torch.empty(self.KK * self.CoutP * self.CinP, dtype=torch.bfloat16, device=dev)
+        wf = torch.empty(self.KK * self.CinP * self.CoutP, dtype=torch.bfloat16, device=dev) if fwd else None
+        wd = torch.empty(self.KK * self.CoutP * self.CinP, dtype=torch.bfloat16, device=dev) if dgrad else None
         w32 = weight.detach().float().contiguous()
-        L.check(L.lib().mi_pack_conv_weight(w32.data_ptr(), self.Cout, self.Cin, self.k, self.k, wf.data_ptr(), self.CinP,
-                                            self.CoutP, wd.data_ptr(), self.CoutP, self.CinP, L.stream_ptr()),
+        L.check(L.lib().mi_pack_conv_weight(w32.data_ptr(), self.Cout, self.Cin, self.k, self.k, L.ptr(wf), self.CinP,
+                                            self.CoutP, L.ptr(wd), self.CoutP, self.CinP, L.stream_ptr()),
                 "mi_pack_conv_weight")
         return wf, wd
 
@@ -169,7 +170,7 @@ _LIBDEF.define("conv2d_backward(Tensor grad, Tensor x, Tensor weight, bool has_b
 
 def _conv2d_cuda(x, weight, bias, stride, padding, relu=False):
     g = _ConvGeom(x.shape, weight.shape, stride, padding)
-    wf, _ = g.pack(weight)
+    wf, _ = g.pack(weight, dgrad=False)
     y = torch.empty(g.N, g.Ho, g.Wo, g.CoutP, dtype=torch.bfloat16, device=x.device)
     b32 = None
     if bias is not None:
@@ -184,7 +185,7 @@ def _conv2d_cuda(x, weight, bias, stride, padding, relu=False):
 
 def _conv2d_backward_cuda(grad, x, weight, has_bias, stride, padding):
     g = _ConvGeom(x.shape, weight.shape, stride, padding)
-    _, wd = g.pack(weight)
+    _, wd = g.pack(weight, fwd=False)
     dyh = _pad_last(_nhwc(grad), g.CoutP)
     xh = g.pad_in(x)
     # the data gradient writes every real channel of every pixel - except the 1x1 stride-2 form (odd pixels receive
@@ -209,8 +210,9 @@ def _conv2d_setup(ctx, inputs, output):
 
 def _conv2d_bwd(ctx, grad):
     x, weight = ctx.saved_tensors
-    dx, gw, gb = torch.ops.mi355.conv2d_backward(grad, x, weight, ctx.has_bias, ctx.stride, ctx.padding)
-    return dx.to(x.dtype), gw.to(weight.dtype), (gb if ctx.has_bias else None), None, None
+    need_gb = ctx.has_bias and ctx.needs_input_grad[2]     # (a frozen-norm shift passed as bias has no gradient to compute)
+    dx, gw, gb = torch.ops.mi355.conv2d_backward(grad, x, weight, need_gb, ctx.stride, ctx.padding)
+    return dx.to(x.dtype), gw.to(weight.dtype), (gb if need_gb else None), None, None
 
 
 torch.library.register_autograd("mi355::conv2d", _conv2d_bwd, setup_context=_conv2d_setup)
@@ -233,8 +235,9 @@ def _conv2d_relu_bwd(ctx, grad):
     gh, oh = _nhwc(grad), _nhwc(out)
     gm = torch.empty_like(gh)
     L.check(L.lib().mi_ew_bf16(gh.data_ptr(), oh.data_ptr(), gm.data_ptr(), gh.numel(), 2, L.stream_ptr()), "mi_ew_bf16 relu'")
-    dx, gw, gb = torch.ops.mi355.conv2d_backward(gm.permute(0, 3, 1, 2), x, weight, ctx.has_bias, ctx.stride, ctx.padding)
-    return dx.to(x.dtype), gw.to(weight.dtype), (gb if ctx.has_bias else None), None, None
+    need_gb = ctx.has_bias and ctx.needs_input_grad[2]
+    dx, gw, gb = torch.ops.mi355.conv2d_backward(gm.permute(0, 3, 1, 2), x, weight, need_gb, ctx.stride, ctx.padding)
+    return dx.to(x.dtype), gw.to(weight.dtype), (gb if need_gb else None), None, None
 
 
 torch.library.register_autograd("mi355::conv2d_relu", _conv2d_relu_bwd, setup_context=_conv2d_relu_setup)
@@ -255,7 +258,7 @@ def _conv_bn_silu_cuda(x, weight, gamma, beta, running_mean, running_var, stride
     if g.Cout % 8:
         raise L.MI355Error("mi355::conv_bn_silu: Cout must be a multiple of 8")
     dev = x.device
-    wf, _ = g.pack(weight)
+    wf, _ = g.pack(weight, dgrad=False)
     y = torch.empty(g.N, g.Ho, g.Wo, g.Cout, dtype=torch.bfloat16, device=dev)
     out = torch.empty(g.N, g.Ho, g.Wo, g.Cout, dtype=torch.bfloat16, device=dev)
     stats = torch.empty(4, g.Cout, dtype=torch.float32, device=dev)
@@ -299,7 +302,7 @@ def _conv_bn_silu_backward_cuda(grad, x, weight, gamma, y, stats, stride):
                                     stats[2].data_ptr(), stats[3].data_ptr(), ga.data_ptr(), dacc.data_ptr(), L.MI_BN_SLOTS,
                                     npix, dgamma.data_ptr(), dbeta.data_ptr(), dyh.data_ptr(), g.CoutP, None, 0, 0, npix,
                                     g.Cout, 1, L.stream_ptr()), "mi_bn_act_bwd_apply")
-    _, wd = g.pack(weight)
+    _, wd = g.pack(weight, fwd=False)
     dx = torch.zeros(g.N, g.H, g.W, g.CinP, dtype=torch.bfloat16, device=dev)
     g.dgrad(dyh, wd, dx)
     gw = g.wgrad(g.pad_in(x), dyh)
