@@ -522,7 +522,8 @@ def bench_sparseinst(args):
         inst = Instances((S, S), gt_classes=torch.randint(0, 80, (n,), generator=g).to(dev), gt_masks=masks.to(dev))
         inputs.append(dict(image=torch.randint(0, 256, (3, S, S), generator=g).float().to(dev), instances=inst, height=S, width=S))
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.AdamW(params, lr=5e-5, weight_decay=0.05)
+    from yolov7_d2_amd.optim import MultiTensorAdamW      # the AdamW update as ONE launch over all parameter tensors
+    opt = MultiTensorAdamW(params, lr=5e-5, weight_decay=0.05)
 
     def step():
         losses = model(inputs)

@@ -70,13 +70,16 @@ def test_resnet50_forward_and_gradients(H, W):
     assert max(rels.values()) < 0.7
 
 
-def test_resnet50_gradients_with_the_forward_state_pinned():
+def test_resnet50_gradients_with_the_forward_state_pinned(monkeypatch):
     """the tight whole-network check (what tests/test_gpu_parity_bench.py does for YOLOX): every conv output of the
     trainable stages (res3 .. res5, FREEZE_AT 2) that the HIP network produced is forced into the oracle's forward
     (teacher forcing: same ReLU gates, same operands), then the oracle's autograd from the same output gradient must give
     the HIP weight gradients - cosine >= 0.999 and relative L2 <= 0.05 on every one of the 42 trainable conv weights.  The
     un-forced comparison above can only bound the bf16 noise floor (< 0.7)."""
     from yolov7_d2_amd.modeling.resnet import Conv2d
+    # the per-convolution modules are hooked for their outputs: run the blocks as per-convolution autograd nodes (the
+    # one-node form is tied to this one by test_bottleneck_as_one_node_equals_per_convolution_nodes)
+    monkeypatch.setenv("MI_RESNET_BLOCK_FN", "0")
     sd = R.init_state_dict(50, seed=0)
     m = ResNet(50, ("res2", "res3", "res4", "res5"), freeze_at=2)
     m.load_state_dict(sd)
@@ -210,3 +213,33 @@ def test_conv2d_relu_epilogue_equals_conv_then_relu(cin, cout, k, stride, bias):
     for a, r in zip(*outs):
         if a is not None:
             assert torch.equal(a, r)
+
+
+@pytest.mark.parametrize("cin,cout,bc,stride,xgrad", [(256, 512, 128, 2, True), (512, 512, 128, 1, True), (256, 256, 64, 1, True),
+                                                      (256, 512, 128, 2, False)],
+                         ids=["shortcut_s2", "identity", "identity_64", "shortcut_s2_no_dx"])
+def test_bottleneck_as_one_node_equals_per_convolution_nodes(cin, cout, bc, stride, xgrad, monkeypatch):
+    """_BottleneckFn (the second path of the input gradient accumulated in the convolution epilogue, MI_CONV_ACCUM) against the
+    per-convolution autograd nodes + autograd's own additions: same kernels and roundings -> identical output and weight gradients, the input gradient to a bf16 rounding"""
+    from yolov7_d2_amd.modeling.resnet import BottleneckBlock
+    torch.manual_seed(3)
+    blk = BottleneckBlock(cin, cout, bc, stride=stride).cuda()
+    for m in blk.modules():
+        if hasattr(m, "running_var"):
+            m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.1); m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, cin, 24, 36, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    go = torch.randn(2, cout, 24 // stride, 36 // stride, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MI_RESNET_BLOCK_FN", flag)
+        blk.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(xgrad)
+        out = blk(xi)
+        out.backward(go)
+        res.append([out.detach().float()] + ([xi.grad.float()] if xgrad else []) + [p.grad.float().clone() for p in blk.parameters()])
+    for i, (a, b) in enumerate(zip(*res)):
+        if xgrad and i == 1:      # the input gradient: one rounding may move (accumulate-in-epilogue vs a separate bf16 add)
+            assert _rel(a, b) < 4e-3
+        else:
+            assert torch.equal(a, b), (i, float((a - b).abs().max()))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace --stats of a secondary bench: CFG=detr|sparseinst bash tools/prof_secondary.sh
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_detr; mkdir -p $OUT; cd /tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${CFG:-detr}; mkdir -p $OUT; cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/raw -o trace -- python $GRAFT_REPO_ROOT/bench.py --config ${CFG:-detr} --steps 5 --warmup 2 > $OUT/bench.log 2>&1
 find $OUT/raw -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats.csv \;
 rm -rf $OUT/raw

@@ -1,14 +1,15 @@
 #!/usr/bin/env python
-"""which lines of the eager DETR / SparseInst step launch the torch elementwise kernels (fill / copy / add / mul ...)?
-torch.profiler with stacks, one eager step at the bench shape; prints device time and launch count per (aten op, innermost
-frames inside yolov7_d2_amd).  usage: torch_ops_probe.py [detr|sparseinst]"""
-import collections, os, sys
+"""which lines of the eager DETR / SparseInst step launch torch's own elementwise kernels (fill / copy / add / mul ...)?
+A TorchDispatchMode records every aten op on a device tensor with the innermost frames inside yolov7_d2_amd (backward runs
+on the calling thread so that the mode sees it); prints launches and output bytes per (op, call site) for ONE eager step at
+the bench shape.  usage: torch_ops_probe.py [detr|sparseinst]"""
+import collections, os, sys, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
+from torch.utils._python_dispatch import TorchDispatchMode
 import yolov7_d2_amd as M
 from yolov7_d2_amd.d2shim import Boxes, Instances
-from torch.profiler import ProfilerActivity, profile
 
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
@@ -19,7 +20,7 @@ model.train()
 g = torch.Generator().manual_seed(1234)
 inputs = []
 for b in range(B):
-    h, w = (H_, W_) if b == 0 else (H_ - 32 * (b % 2), W_ - 64 * (b % 3))
+    h, w = (H_, W_) if (b == 0 or which != "detr") else (H_ - 32 * (b % 2), W_ - 64 * (b % 3))
     n = 5
     wh = 16 + torch.rand(n, 2, generator=g) * 128
     xy = torch.rand(n, 2, generator=g) * (torch.tensor([w, h]) - wh).clamp(min=1)
@@ -33,7 +34,8 @@ for b in range(B):
         inst = Instances((h, w), gt_classes=torch.randint(0, 80, (n,), generator=g).to(dev), gt_masks=m.to(dev))
     inputs.append(dict(image=torch.randint(0, 256, (3, h, w), generator=g).float().to(dev), instances=inst, height=h, width=w))
 params = [p for p in model.parameters() if p.requires_grad]
-opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=1e-4, capturable=True)
+from yolov7_d2_amd.optim import MultiTensorAdamW
+opt = MultiTensorAdamW(params, lr=1e-4, weight_decay=1e-4)
 
 
 def step():
@@ -48,21 +50,38 @@ def step():
 for _ in range(2):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+NOKERNEL = ("view", "permute", "reshape", "slice", "select", "expand", "transpose", "detach", "alias", "as_strided", "unsqueeze",
+            "squeeze", "empty", "t.default", "unbind", "split", "_unsafe_view", "unfold", "narrow", "flatten", "chunk", "lift_fresh",
+            "is_", "sym_", "_local_scalar", "stride", "size", "numel", "dim", "result_type", "_has_compatible")
+agg = collections.defaultdict(lambda: [0, 0])
+
+
+class Rec(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+        name = str(func).replace("aten.", "")
+        if any(s in name for s in NOKERNEL):
+            return out
+        t = out if isinstance(out, torch.Tensor) else (out[0] if isinstance(out, (tuple, list)) and out and isinstance(out[0], torch.Tensor) else None)
+        if t is None or not t.is_cuda:
+            return out
+        st = traceback.extract_stack()
+        ours = [f for f in st if "/yolov7_d2_amd/" in f.filename]
+        site = " < ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in reversed(ours[-2:])) or "(native autograd node / probe)"
+        a = agg[(name, site)]
+        a[0] += 1
+        a[1] += t.numel() * t.element_size()
+        return out
+
+
+with torch.autograd.set_multithreading_enabled(False), Rec():
     step()
-    torch.cuda.synchronize()
-agg = collections.defaultdict(lambda: [0.0, 0])
-tot = 0.0
-for e in prof.events():
-    dt = getattr(e, "self_device_time_total", 0) or 0
-    if dt <= 0 or not e.name.startswith("aten::"):
-        continue
-    ours = [f for f in (e.stack or []) if "yolov7_d2_amd/" in f or "tools/" in f]
-    site = " < ".join(s.split("yolov7_d2_amd/")[-1][:70] for s in ours[:2]) or "(autograd engine / optimizer)"
-    k = (e.name, site)
-    agg[k][0] += dt
-    agg[k][1] += 1
-    tot += dt
-print(f"{which}: aten:: device time of one eager step {tot / 1e3:.2f} ms")
-for (name, site), (dt, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
-    print(f"{dt:9.1f} us {n:5d}  {name:28s} {site}")
+torch.cuda.synchronize()
+n_all = sum(v[0] for v in agg.values())
+print(f"{which}: {n_all} torch kernel-launching ops in one eager step")
+print("--- by output bytes")
+for (name, site), (n, byt) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+    print(f"{byt / 1e6:9.2f} MB {n:5d}  {name:26s} {site}")
+print("--- by count")
+for (name, site), (n, byt) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
+    print(f"{byt / 1e6:9.2f} MB {n:5d}  {name:26s} {site}")

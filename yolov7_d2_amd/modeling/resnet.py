@@ -278,7 +278,7 @@ class _StemFn(torch.autograd.Function):
         # [Cout][(px*2+py)*Cin + c][Ay][Ax] -> 8x8 kernel rows R = 2 Ay + py -> drop the zero row / column -> 7x7
         g8 = gw4.view(Cout, 2, 2, Cin, 4, 4).permute(0, 3, 4, 2, 5, 1).reshape(Cout, Cin, 8, 8)
         gw7 = g8[:, :, 1:, 1:] * scale.view(-1, 1, 1, 1)
-        dshift = dy.float().sum((0, 1, 2))
+        dshift = dy.float().sum((0, 1, 2)) if ctx.needs_input_grad[3] else None     # (a FrozenBN shift has none)
         return None, gw7, None, dshift
 
 
@@ -335,6 +335,98 @@ class BasicStem(nn.Module):
             return out.permute(0, 3, 1, 2)
 
 
+def _BLOCK_FN():
+    """MI_RESNET_BLOCK_FN=0: every convolution of a trainable bottleneck block is its own autograd node again (A/B switch)"""
+    return _FOLDED_FN() and os.environ.get("MI_RESNET_BLOCK_FN", "1") != "0"
+
+
+def _relu_mask(g, a):
+    """g * (a > 0) (bf16, same shape)"""
+    out = torch.empty_like(g)
+    L.check(L.lib().mi_ew_bf16(g.data_ptr(), a.data_ptr(), out.data_ptr(), g.numel(), 2, L.stream_ptr()), "mi_ew_bf16 relu'")
+    return out
+
+
+class _BottleneckFn(torch.autograd.Function):
+    """A trainable BottleneckBlock (detectron2 resnet.py BottleneckBlock: conv1 1x1 - conv2 3x3 - conv3 1x1, FrozenBN folded,
+    + shortcut, ReLU) as ONE autograd node.  What the per-convolution nodes cannot do: the block input's gradient is the
+    sum of two paths - autograd materialised both and added them (a three-tensor pass over the block's largest map, and a
+    full zero fill under the stride-2 shortcut's data gradient, which writes only the even pixels); here the second path
+    ACCUMULATES into the first in the convolution's epilogue (MI_CONV_ACCUM): identity blocks add conv1's data gradient
+    into the (masked) output gradient, shortcut blocks add the shortcut's data gradient into conv1's.  Same kernels, same
+    roundings as the separate nodes (bf16 + bf16 -> bf16)."""
+
+    @staticmethod
+    def forward(ctx, x, s2, ssc, *rest):
+        n = 4 if ssc else 3
+        ws, aff = rest[:n], rest[n:]
+        scales, shifts = aff[0::2], aff[1::2]
+        need_dx = x.requires_grad
+        N, Cin, H, W = x.shape
+        bc = ws[0].shape[0]
+        g1 = _ConvGeom((N, Cin, H, W), ws[0].shape, 1, 0)
+        g2 = _ConvGeom((N, bc, H, W), ws[1].shape, s2, 1)
+        g3 = _ConvGeom((N, bc, g2.Ho, g2.Wo), ws[2].shape, 1, 0)
+        gs = _ConvGeom((N, Cin, H, W), ws[3].shape, ssc, 0) if ssc else None
+        geoms = [g1, g2, g3] + ([gs] if ssc else [])
+        for g in geoms:
+            if g.CinP != g.Cin or g.CoutP != g.Cout:
+                raise L.MI355Error("ResNet bottleneck: channel counts must be multiples of 32")
+        imgs = [g.pack(w.detach() * sc.view(-1, 1, 1, 1), dgrad=(need_dx or i in (1, 2)))
+                for i, (g, w, sc) in enumerate(zip(geoms, ws, scales))]
+        dev = x.device
+        xh = _nhwc(x)
+
+        def run(g, inp, i, relu):
+            y = torch.empty(g.N, g.Ho, g.Wo, g.CoutP, dtype=torch.bfloat16, device=dev)
+            g.fwd(inp, imgs[i][0], y, bias=shifts[i], relu=relu)
+            return y
+        a1 = run(g1, xh, 0, True)
+        a2 = run(g2, a1, 1, True)
+        o = run(g3, a2, 2, False)
+        sc = run(gs, xh, 3, False) if ssc else xh
+        y = torch.empty_like(o)
+        L.check(L.lib().mi_ew_bf16(o.data_ptr(), sc.data_ptr(), y.data_ptr(), o.numel(), 7, L.stream_ptr()), "mi_ew_bf16 add+relu")
+        ctx.geoms, ctx.has_sc = geoms, bool(ssc)
+        ctx.save_for_backward(xh, a1, a2, y, *[im[1] for im in imgs], *scales)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gy):
+        n = 4 if ctx.has_sc else 3
+        xh, a1, a2, y = ctx.saved_tensors[:4]
+        wds, scales = ctx.saved_tensors[4:4 + n], ctx.saved_tensors[4 + n:]
+        g1, g2, g3 = ctx.geoms[:3]
+        gs = ctx.geoms[3] if ctx.has_sc else None
+        dev = xh.device
+        gyh = _nhwc(gy)
+        gm = torch.empty_like(gyh)          # (a fresh tensor: identity blocks accumulate the input gradient into it)
+        L.check(L.lib().mi_ew_bf16(gyh.data_ptr(), y.data_ptr(), gm.data_ptr(), gm.numel(), 2, L.stream_ptr()), "mi_ew_bf16 relu'")
+        gws = [None] * n
+        gws[2] = g3.wgrad(a2, gm) * scales[2].view(-1, 1, 1, 1)
+        da2 = torch.empty_like(a2)
+        g3.dgrad(gm, wds[2], da2)
+        da2 = _relu_mask(da2, a2)
+        gws[1] = g2.wgrad(a1, da2) * scales[1].view(-1, 1, 1, 1)
+        da1 = torch.empty_like(a1)
+        g2.dgrad(da2, wds[1], da1)
+        da1 = _relu_mask(da1, a1)
+        gws[0] = g1.wgrad(xh, da1) * scales[0].view(-1, 1, 1, 1)
+        if gs is not None:
+            gws[3] = gs.wgrad(xh, gm) * scales[3].view(-1, 1, 1, 1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if gs is None:
+                dxh = gm
+                g1.dgrad(da1, wds[0], dxh, accum=True)
+            else:
+                dxh = torch.empty_like(xh)
+                g1.dgrad(da1, wds[0], dxh)
+                gs.dgrad(gm, wds[3], dxh, accum=True)
+            dx = dxh.permute(0, 3, 1, 2)
+        return (dx, None, None, *gws, *([None] * (2 * n)))
+
+
 class BottleneckBlock(nn.Module):
     def __init__(self, cin, cout, bottleneck_channels, stride=1, stride_in_1x1=False):
         super().__init__()
@@ -346,6 +438,11 @@ class BottleneckBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        convs = [self.conv1, self.conv2, self.conv3] + ([self.shortcut] if self.shortcut is not None else [])
+        if (_BLOCK_FN() and torch.is_grad_enabled() and all(c.weight.requires_grad for c in convs) and self.conv1.stride == 1):
+            aff = [t for c in convs for t in c.norm.affine()]
+            return _BottleneckFn.apply(x, self.conv2.stride, self.shortcut.stride if self.shortcut is not None else 0,
+                                       *[c.weight for c in convs], *aff)
         if _conv_relu_fused():
             out = self.conv2(self.conv1(x, relu=True), relu=True)
         else:

@@ -298,7 +298,7 @@ def _aggregate(iam, features):
         a = _pad_cols(prob[b].reshape(H * W, N), Np)
         outs.append(_PixelOuterFn.apply(a, fh[b].reshape(H * W, Cc))[:N])
     inst = torch.stack(outs)                                           # fp32 [B, N, C]
-    return inst, prob.float().sum((1, 2))                             # normaliser [B, N]
+    return inst, prob.sum((1, 2), dtype=torch.float32)                # normaliser [B, N] (fp32 accumulation, no fp32 copy of the map)
 
 
 class InstanceBranch(nn.Module):
@@ -476,7 +476,7 @@ def dice_score_device(masks_nhwc, tgt, sizes):
         Mp = _rup(M, 32)
         tT = _pad_cols(tb.t().to(torch.bfloat16), Mp)                   # [P, Mp]
         num = 2.0 * pixel_outer(sig[b].contiguous(), tT)[:, :M]         # [Np, M]
-        den = (sig[b].float() ** 2).sum(0)[:, None] + (tb * tb).sum(-1)[None, :]
+        den = torch.linalg.vector_norm(sig[b], dim=0, dtype=torch.float32).square()[:, None] + (tb * tb).sum(-1)[None, :]
         out.append(num / (den + 1e-4))
         off += M
     return out

@@ -106,18 +106,21 @@ class _ConvGeom:
                              self.Ho, self.Wo, self.Cout, self.CoutP, taps, in_stride=self.s, bias=bias, stats=stats,
                              nslots=nslots, flags=L.MI_CONV_RELU if relu else 0), "mi_conv2d (forward)")
 
-    def dgrad(self, dyh, wd, dx):
-        """dyh bf16 [N,Ho,Wo,CoutP] (zero pad channels) -> dx bf16 [N,H,W,CinP] (real channels written)"""
+    def dgrad(self, dyh, wd, dx, accum=False):
+        """dyh bf16 [N,Ho,Wo,CoutP] (zero pad channels) -> dx bf16 [N,H,W,CinP] (real channels written).
+        accum: dx += (MI_CONV_ACCUM; the strided forms then touch only the pixels that receive a gradient, so dx need not be
+        zeroed for them)"""
         k, pad = self.k, self.pad
+        fl = L.MI_CONV_ACCUM if accum else 0
         if self.s == 1:
             taps = [(pad - r, pad - s, r * k + s) for r in range(k) for s in range(k)]
             _run_conv(_conv_desc(dyh.data_ptr(), self.CoutP, self.N, self.Ho, self.Wo, wd, self.CoutP, dx.data_ptr(),
-                                 self.CinP, self.H, self.W, self.Cin, self.CinP, taps), "mi_conv2d (dgrad)")
+                                 self.CinP, self.H, self.W, self.Cin, self.CinP, taps, flags=fl), "mi_conv2d (dgrad)")
             return
         if k == 1:      # 1x1 stride 2 (ResNet shortcut): only the even pixels receive a gradient; dx arrives zeroed
             _run_conv(_conv_desc(dyh.data_ptr(), self.CoutP, self.N, self.Ho, self.Wo, wd, self.CoutP, dx.data_ptr(),
                                  self.CinP, self.H, self.W, self.Cin, self.CinP, [(0, 0, 0)], out_stride=2, oy=0, ox=0,
-                                 gridH=(self.H + 1) // 2, gridW=(self.W + 1) // 2), "mi_conv2d (dgrad 1x1 s2)")
+                                 gridH=(self.H + 1) // 2, gridW=(self.W + 1) // 2, flags=fl), "mi_conv2d (dgrad 1x1 s2)")
             return
         cls_taps = {0: [(1, 0)], 1: [(0, 1), (2, 0)]}   # output-pixel parity -> [(kernel row, dy offset)]
         for py in (0, 1):
@@ -126,7 +129,7 @@ class _ConvGeom:
                 gh, gw = (self.H - py + 1) // 2, (self.W - px + 1) // 2
                 _run_conv(_conv_desc(dyh.data_ptr(), self.CoutP, self.N, self.Ho, self.Wo, wd, self.CoutP, dx.data_ptr(),
                                      self.CinP, self.H, self.W, self.Cin, self.CinP, taps, out_stride=2, oy=py, ox=px,
-                                     gridH=gh, gridW=gw), "mi_conv2d (dgrad s2)")
+                                     gridH=gh, gridW=gw, flags=fl), "mi_conv2d (dgrad s2)")
 
     def wgrad(self, xh, dyh):
         gw = torch.empty(self.Cout, self.Cin, self.k, self.k, dtype=torch.float32, device=xh.device)
