@@ -204,6 +204,15 @@ int mi_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int KH, int KW,
                         void* wf, int CinPad, int CoutPad,
                         void* wd, int CoutPadK, int CinPadN, mi_stream_t s);
 
+/* the same with a per-output-channel fp32 factor folded in before the bf16 rounding: detectron2's Conv2d(norm =
+ * FrozenBatchNorm2d) as the reference's DETR / SparseInst backbones build it (W * scale[co]; un-vendored d2
+ * layers/batch_norm.py FrozenBatchNorm2d + layers/wrappers.py Conv2d) without a folded fp32 copy of the weight */
+int mi_pack_conv_weight_scaled(const float* w_oihw, const float* cout_scale, int Cout, int Cin, int KH, int KW,
+                               void* wf, int CinPad, int CoutPad,
+                               void* wd, int CoutPadK, int CinPadN, mi_stream_t s);
+/* out[r][:] = g[r][:] * scale[r], fp32 [rows][rowlen]: the weight gradient of such a layer (dW = scale[co] * dW') */
+int mi_scale_rows_f32(const float* g, const float* scale, float* out, int rows, int rowlen, mi_stream_t s);
+
 /* all layers of a step in ONE launch: jobs_dev is a device array of njobs records (same meaning as the
  * arguments of mi_pack_conv_weight) */
 typedef struct mi_pack_job {

@@ -243,3 +243,27 @@ def test_bottleneck_as_one_node_equals_per_convolution_nodes(cin, cout, bc, stri
             assert _rel(a, b) < 4e-3
         else:
             assert torch.equal(a, b), (i, float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("k,stride,cin,cout", [(1, 1, 64, 256), (3, 2, 128, 128), (1, 2, 256, 512)])
+def test_folded_frozen_norm_conv_equals_the_explicit_fold(k, stride, cin, cout, monkeypatch):
+    """Conv2d + FrozenBatchNorm2d with the scale folded INSIDE the pack kernel (mi_pack_conv_weight_scaled) and the weight
+    gradient rescaled by mi_scale_rows_f32, against the explicit form (torch `weight * scale`, mi355::conv2d, autograd's
+    mul backward): the same fp32 products and roundings -> identical output, input gradient and weight gradient"""
+    from yolov7_d2_amd.modeling.resnet import Conv2d
+    torch.manual_seed(5)
+    m = Conv2d(cin, cout, k, stride=stride, padding=k // 2).cuda()
+    m.norm.weight.uniform_(0.5, 1.5); m.norm.bias.normal_(0, 0.1); m.norm.running_mean.normal_(0, 0.1); m.norm.running_var.uniform_(0.5, 1.5)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, cin, 20, 28, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    go = torch.randn(2, cout, (20 - 1) // stride + 1, (28 - 1) // stride + 1, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MI_RESNET_FOLDED_FN", flag)
+        m.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        out = m(xi, relu=True)
+        out.backward(go)
+        res.append((out.detach().float(), xi.grad.float(), m.weight.grad.float().clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b), float((a - b).abs().max())

@@ -180,6 +180,8 @@ _PROTOS = {
     "mi_conv2d_wgrad_group_plan": (C.c_int, [C.POINTER(mi_wgrad_desc), _i, _vp, _vp, _i64, C.POINTER(mi_wgrad_group)]),
     "mi_conv2d_wgrad_group_run": (C.c_int, [C.POINTER(mi_wgrad_group), _vp, _vp]),
     "mi_pack_conv_weight": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
+    "mi_pack_conv_weight_scaled": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
+    "mi_scale_rows_f32": (C.c_int, [_vp, _vp, _vp, _i, _i, _vp]),
     "mi_conv2d_wgrad_plan": (C.c_int64, [C.POINTER(mi_wgrad_desc)]),
     "mi_bn_eval_affine": (C.c_int, [_vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
     "mi_bn_act_fwd": (C.c_int, [_vp, _i, _vp, _i, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i,

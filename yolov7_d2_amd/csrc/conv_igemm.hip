@@ -483,7 +483,8 @@ extern "C" int mi_conv2d_group_run(const mi_conv_group* m, const void* table_dev
 
 // ================================================================= weight (un)packing
 __device__ __forceinline__ void pack_w_body(const float* __restrict__ w, int Cout, int Cin, int KK, __bf16* wf,
-                                            int CinPad, int CoutPad, __bf16* wd, int CoutPadK, int CinPadN) {
+                                            int CinPad, int CoutPad, __bf16* wd, int CoutPadK, int CinPadN,
+                                            const float* __restrict__ cs = nullptr) {   // cs: per-Cout factor (fp32 product, then the bf16 rounding)
   // forward image: wf[tap][ci/8][co][ci%8]
   const int64_t nf = wf ? (int64_t)KK * CinPad * CoutPad : 0;
   const int64_t nd = wd ? (int64_t)KK * CoutPadK * CinPadN : 0;
@@ -497,7 +498,7 @@ __device__ __forceinline__ void pack_w_body(const float* __restrict__ w, int Cou
       const int tap = r / (CinPad / 8);
       const int ci = k8 * 8 + e;
       float v = 0.f;
-      if (co < Cout && ci < Cin) v = w[((int64_t)co * Cin + ci) * KK + tap];
+      if (co < Cout && ci < Cin) v = w[((int64_t)co * Cin + ci) * KK + tap] * (cs ? cs[co] : 1.f);
       wf[idx] = (__bf16)v;
     } else {
       // dgrad image: wd[tap][co/8][ci][co%8]   (k = cout, "n" = cin)
@@ -509,7 +510,7 @@ __device__ __forceinline__ void pack_w_body(const float* __restrict__ w, int Cou
       const int tap = r / (CoutPadK / 8);
       const int co = k8 * 8 + e;
       float v = 0.f;
-      if (co < Cout && ci < Cin) v = w[((int64_t)co * Cin + ci) * KK + tap];
+      if (co < Cout && ci < Cin) v = w[((int64_t)co * Cin + ci) * KK + tap] * (cs ? cs[co] : 1.f);
       wd[i2] = (__bf16)v;
     }
   }
@@ -518,6 +519,10 @@ __device__ __forceinline__ void pack_w_body(const float* __restrict__ w, int Cou
 __global__ void pack_w_kernel(const float* __restrict__ w, int Cout, int Cin, int KK, __bf16* wf, int CinPad,
                               int CoutPad, __bf16* wd, int CoutPadK, int CinPadN) {
   pack_w_body(w, Cout, Cin, KK, wf, CinPad, CoutPad, wd, CoutPadK, CinPadN);
+}
+__global__ void pack_w_scaled_kernel(const float* __restrict__ w, const float* __restrict__ cs, int Cout, int Cin, int KK,
+                                     __bf16* wf, int CinPad, int CoutPad, __bf16* wd, int CoutPadK, int CinPadN) {
+  pack_w_body(w, Cout, Cin, KK, wf, CinPad, CoutPad, wd, CoutPadK, CinPadN, cs);
 }
 // all layers in one flat launch, one block per (32 output channels x 64 input channels x all taps) tile of one layer:
 // the tile's fp32 weights are read in memory order (coalesced), rounded to bf16 into LDS, and both packed images are written
@@ -625,5 +630,21 @@ extern "C" int mi_pack_conv_weight(const float* w, int Cout, int Cin, int KH, in
   hipLaunchKernelGGL(pack_w_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)st, w, Cout, Cin, KK, (__bf16*)wf,
                      CinPad, CoutPad, (__bf16*)wd, CoutPadK, CinPadN);
   MI_CHECK_LAUNCH("pack_w");
+  return MI_OK;
+}
+
+// the same with a per-output-channel factor folded in (detectron2 Conv2d + FrozenBatchNorm2d: W * scale[co])
+extern "C" int mi_pack_conv_weight_scaled(const float* w, const float* cout_scale, int Cout, int Cin, int KH, int KW, void* wf, int CinPad,
+                                   int CoutPad, void* wd, int CoutPadK, int CinPadN, mi_stream_t st) {
+  MI_REQUIRE(w && cout_scale && (wf || wd), "pack_w_scaled: null");
+  if (wf) MI_REQUIRE(CinPad % 8 == 0 && CinPad >= Cin && CoutPad >= Cout, "pack_w: fwd pads");
+  if (wd) MI_REQUIRE(CoutPadK % 8 == 0 && CoutPadK >= Cout && CinPadN >= Cin, "pack_w: dgrad pads");
+  const int KK = KH * KW;
+  const int64_t n = (wf ? (int64_t)KK * CinPad * CoutPad : 0) + (wd ? (int64_t)KK * CoutPadK * CinPadN : 0);
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(pack_w_scaled_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)st, w, cout_scale, Cout, Cin, KK, (__bf16*)wf,
+                     CinPad, CoutPad, (__bf16*)wd, CoutPadK, CinPadN);
+  MI_CHECK_LAUNCH("pack_w_scaled");
   return MI_OK;
 }

@@ -774,6 +774,35 @@ extern "C" int mi_colsum_bf16_wide(const void* x, int ldx, int64_t npix, int C, 
   return MI_OK;
 }
 
+// ---- out[r][:] = g[r][:] * scale[r]  (fp32; the weight gradient of a convolution whose weight image carried a folded per-Cout
+// factor: d/dW = scale[co] * d/dW').  rowlen % 4 == 0 takes the 16-byte path.
+__global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ g, const float* __restrict__ sc, float* out,
+                                                         int rows, int rowlen) {
+  const int64_t n = (int64_t)rows * rowlen;
+  if ((rowlen & 3) == 0) {
+    const int64_t n4 = n >> 2;
+    const int rl4 = rowlen >> 2;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+      const float f = sc[i / rl4];
+      float4 v = ((const float4*)g)[i];
+      v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+      ((float4*)out)[i] = v;
+    }
+  } else {
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = g[i] * sc[i / rowlen];
+  }
+}
+extern "C" int mi_scale_rows_f32(const float* g, const float* scale, float* out, int rows, int rowlen, mi_stream_t st) {
+  MI_REQUIRE(g && scale && out && rows > 0 && rowlen > 0, "scale_rows: args");
+  MI_REQUIRE(((uintptr_t)g % 16) == 0 && ((uintptr_t)out % 16) == 0, "scale_rows: alignment");
+  int64_t blocks = ((int64_t)rows * rowlen / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)st, g, scale, out, rows, rowlen);
+  MI_CHECK_LAUNCH("scale_rows");
+  return MI_OK;
+}
+
 // ---- SGD with momentum + weight decay over a flat arena (torch.optim.SGD semantics: dampening 0, no nesterov)
 __global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* __restrict__ g, float* m,
                                                   const mi_sgd_seg* __restrict__ segs, float momentum,

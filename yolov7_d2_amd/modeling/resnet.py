@@ -166,7 +166,7 @@ class Conv2d(nn.Module):
             c = self.__dict__.get("_image")
             if c is None or c[0] != key:
                 with torch.no_grad():
-                    c = self.__dict__["_image"] = (key, g.pack(self.weight * scale.view(-1, 1, 1, 1), dgrad=False)[0])
+                    c = self.__dict__["_image"] = (key, g.pack(self.weight, dgrad=False, scale=scale)[0])
             with torch.no_grad():
                 return _folded_forward(g, x, c[1], shift, relu)[1]
         return _FoldedConvFn.apply(x, self.weight, scale, shift, self.stride, self.padding, relu)
@@ -198,7 +198,7 @@ class _FoldedConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, scale, shift, stride, padding, relu):
         g = _ConvGeom(x.shape, weight.shape, stride, padding)
         need_dx = x.requires_grad
-        wf, wd = g.pack(weight.detach() * scale.view(-1, 1, 1, 1), dgrad=need_dx)
+        wf, wd = g.pack(weight, dgrad=need_dx, scale=scale)
         xh, y = _folded_forward(g, x, wf, shift, relu)
         ctx.g, ctx.relu = g, relu
         ctx.save_for_backward(xh, wd, scale, y if relu else None)
@@ -222,7 +222,7 @@ class _FoldedConvFn(torch.autograd.Function):
             g.dgrad(dyh, wd, dxh)
             dx = _nchw(dxh, g.Cin)
         if ctx.needs_input_grad[1]:
-            gw = g.wgrad(xh, dyh) * scale.view(-1, 1, 1, 1)
+            gw = g.wgrad_scaled(xh, dyh, scale)
         return dx, gw, None, None, None, None, None
 
 
@@ -372,7 +372,7 @@ class _BottleneckFn(torch.autograd.Function):
         for g in geoms:
             if g.CinP != g.Cin or g.CoutP != g.Cout:
                 raise L.MI355Error("ResNet bottleneck: channel counts must be multiples of 32")
-        imgs = [g.pack(w.detach() * sc.view(-1, 1, 1, 1), dgrad=(need_dx or i in (1, 2)))
+        imgs = [g.pack(w, dgrad=(need_dx or i in (1, 2)), scale=sc)
                 for i, (g, w, sc) in enumerate(zip(geoms, ws, scales))]
         dev = x.device
         xh = _nhwc(x)
@@ -403,17 +403,17 @@ class _BottleneckFn(torch.autograd.Function):
         gm = torch.empty_like(gyh)          # (a fresh tensor: identity blocks accumulate the input gradient into it)
         L.check(L.lib().mi_ew_bf16(gyh.data_ptr(), y.data_ptr(), gm.data_ptr(), gm.numel(), 2, L.stream_ptr()), "mi_ew_bf16 relu'")
         gws = [None] * n
-        gws[2] = g3.wgrad(a2, gm) * scales[2].view(-1, 1, 1, 1)
+        gws[2] = g3.wgrad_scaled(a2, gm, scales[2])
         da2 = torch.empty_like(a2)
         g3.dgrad(gm, wds[2], da2)
         da2 = _relu_mask(da2, a2)
-        gws[1] = g2.wgrad(a1, da2) * scales[1].view(-1, 1, 1, 1)
+        gws[1] = g2.wgrad_scaled(a1, da2, scales[1])
         da1 = torch.empty_like(a1)
         g2.dgrad(da2, wds[1], da1)
         da1 = _relu_mask(da1, a1)
-        gws[0] = g1.wgrad(xh, da1) * scales[0].view(-1, 1, 1, 1)
+        gws[0] = g1.wgrad_scaled(xh, da1, scales[0])
         if gs is not None:
-            gws[3] = gs.wgrad(xh, gm) * scales[3].view(-1, 1, 1, 1)
+            gws[3] = gs.wgrad_scaled(xh, gm, scales[3])
         dx = None
         if ctx.needs_input_grad[0]:
             if gs is None:

@@ -80,16 +80,31 @@ class _ConvGeom:
         self.CinP, self.CoutP = _rup(self.Cin, 32), _rup(self.Cout, 32)
         self.KK = self.k * self.k
 
-    def pack(self, weight, fwd=True, dgrad=True):
-        """(forward image, data-gradient image) of an OIHW weight; an image that is not asked for is None"""
+    def pack(self, weight, fwd=True, dgrad=True, scale=None):
+        """(forward image, data-gradient image) of an OIHW weight; an image that is not asked for is None.
+        scale: fp32 [Cout] folded into the images (W * scale[co], fp32 product then the bf16 rounding)"""
         dev = weight.device
         wf = torch.empty(self.KK * self.CinP * self.CoutP, dtype=torch.bfloat16, device=dev) if fwd else None
         wd = torch.empty(self.KK * self.CoutP * self.CinP, dtype=torch.bfloat16, device=dev) if dgrad else None
         w32 = weight.detach().float().contiguous()
-        L.check(L.lib().mi_pack_conv_weight(w32.data_ptr(), self.Cout, self.Cin, self.k, self.k, L.ptr(wf), self.CinP,
-                                            self.CoutP, L.ptr(wd), self.CoutP, self.CinP, L.stream_ptr()),
-                "mi_pack_conv_weight")
+        if scale is None:
+            L.check(L.lib().mi_pack_conv_weight(w32.data_ptr(), self.Cout, self.Cin, self.k, self.k, L.ptr(wf), self.CinP,
+                                                self.CoutP, L.ptr(wd), self.CoutP, self.CinP, L.stream_ptr()),
+                    "mi_pack_conv_weight")
+        else:
+            assert scale.dtype == torch.float32 and scale.is_contiguous() and scale.numel() == self.Cout
+            L.check(L.lib().mi_pack_conv_weight_scaled(w32.data_ptr(), scale.data_ptr(), self.Cout, self.Cin, self.k, self.k,
+                                                       L.ptr(wf), self.CinP, self.CoutP, L.ptr(wd), self.CoutP, self.CinP,
+                                                       L.stream_ptr()), "mi_pack_conv_weight_scaled")
         return wf, wd
+
+    def wgrad_scaled(self, xh, dyh, scale):
+        """weight gradient of a layer whose image carried a folded per-Cout factor: scale[co] * dW'"""
+        gw = self.wgrad(xh, dyh)
+        out = torch.empty_like(gw)
+        L.check(L.lib().mi_scale_rows_f32(gw.data_ptr(), scale.data_ptr(), out.data_ptr(), self.Cout, gw.numel() // self.Cout,
+                                          L.stream_ptr()), "mi_scale_rows_f32")
+        return out
 
     def pad_in(self, x):
         """NCHW -> bf16 [N,H,W,CinP] (zero pad channels)"""
