@@ -162,7 +162,9 @@ class Conv2d(nn.Module):
         if not train_w and not (x.requires_grad and torch.is_grad_enabled()):
             # a frozen layer under a frozen prefix (FREEZE_AT): its packed image is a constant too
             g = _ConvGeom(x.shape, self.weight.shape, self.stride, self.padding)
-            key = (self.weight.data_ptr(), self.weight._version, scale.data_ptr())
+            # (keyed on the identity + write counters of the weight and of the four norm buffers, not on the address of
+            #  `scale`: a recomputed scale may be handed the freed one's address)
+            key = (self.weight.data_ptr(), self.weight._version, self.norm.__dict__["_affine"][0])
             c = self.__dict__.get("_image")
             if c is None or c[0] != key:
                 with torch.no_grad():
@@ -317,7 +319,7 @@ class BasicStem(nn.Module):
             return _StemFn.apply(s2d, w7, scale, shift).permute(0, 3, 1, 2)
         with torch.no_grad():       # frozen stem (FREEZE_AT >= 1): the packed image is a constant, kept across steps
             Cout = w7.shape[0]
-            key = (w7.data_ptr(), w7._version, scale.data_ptr())
+            key = (w7.data_ptr(), w7._version, self.conv1.norm.__dict__["_affine"][0])
             c = self.__dict__.get("_image")
             if c is None or c[0] != key:
                 w4 = _w7_to_w4(w7 * scale.view(-1, 1, 1, 1)).contiguous()
