@@ -580,6 +580,30 @@ typedef struct mi_mixup_job {
 int mi_mixup_jobs_layout(mi_mixup_job* jobs_host, int njobs);
 int mi_mixup_blend(const mi_mixup_job* jobs_dev, int njobs, int total_blocks, mi_stream_t s);
 
+/* ---- the detectron2 T.* front of the reference's input pipeline --------------------------------------------------
+ * build_normal_augmentation (yolov7/data/detection_utils.py:37-86) as MyDatasetMapper2._load_image_with_annos applies it
+ * to every image it loads (yolov7/data/dataset_mapper.py:642-683): T.ResizeShortestEdge = PIL.Image.resize(BILINEAR) of
+ * the uint8 image (Pillow libImaging/Resample.c: fp64 coefficients -> 22-bit fixed point, horizontal pass rounded to 8
+ * bits, then the vertical pass), T.RandomFlip horizontal / vertical, YOLOFRandomShift (data/transforms/transform.py:341-388:
+ * zeros where the shifted image does not reach).  One job per image: src HWC uint8 [h0][w0][3] -> nh x nw, element
+ * (c, y, x) at dst + c dsc + y dsy + x dsx bytes (HWC: 1, 3 nw, 3; a sample of a padded NCHW batch: Hp Wp, Wp, 1);
+ * tmp = [h0][nw][3] scratch of the horizontal pass (unused when nw == w0).  The colour augmentations of that list
+ * (RandomSaturation / RandomBrightness / YOLOFRandomDistortion: cv2 HSV tables) are not built.
+ * mi_pil_resize_jobs_layout validates the (host) table, fills blk0h / blk0v and returns the block counts of the two flat
+ * launches; the launches take the device copy of the table.  Down-scaling factors up to 8. */
+typedef struct mi_pil_resize_job {
+  const void* src;
+  void* tmp;
+  void* dst;
+  int64_t dsc, dsy, dsx;
+  int32_t h0, w0, nh, nw;
+  int32_t hflip, vflip, shift_x, shift_y;
+  int32_t blk0h, blk0v;
+} mi_pil_resize_job;
+int mi_pil_resize_jobs_layout(mi_pil_resize_job* jobs_host, int njobs, int32_t* blocks_h, int32_t* blocks_v);
+int mi_pil_resize_h(const mi_pil_resize_job* jobs_dev, int njobs, int total_blocks, mi_stream_t s);
+int mi_pil_resize_v(const mi_pil_resize_job* jobs_dev, int njobs, int total_blocks, mi_stream_t s);
+
 /* ---- COCO run-length encoding of masks (evaluation output format) ----------------------
  * what pycocotools.mask.encode does for instances_to_coco_json (evaluation/coco_evaluation.py:38-50; the algorithm is
  * cocoapi's maskApi.c rleEncode / rleToString, un-vendored): masks uint8 [n][H][W] (device, non-zero = foreground) ->
@@ -684,7 +708,7 @@ int mi_box_iou_pairwise(const float* boxes1, int n, const float* boxes2, int m, 
 
 /* sizeof() of the public structs as compiled into the library (binding self-check): 0 mi_conv_desc, 1 mi_wgrad_desc,
  * 2 mi_wgrad_group, 3 mi_pack_job, 4 mi_bias_job, 5 mi_yolox_loss_desc, 6 mi_detr_loss_desc, 7 mi_sgd_seg, 8 mi_cmd,
- * 9 mi_conv_group, 10 mi_bn_job, 11 mi_bn_group; -1 for an unknown id */
+ * 9 mi_conv_group, 10 mi_bn_job, 11 mi_bn_group, 12 mi_pil_resize_job; -1 for an unknown id */
 int mi_abi_sizeof(int which);
 
 /* ---- command list executor -----------------------------------------------------

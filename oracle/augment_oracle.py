@@ -399,3 +399,187 @@ def mixup_offsets_range(img_hw, input_dim, jit, target_hw):
     _, _, (ow, oh) = mixup_geometry(img_hw, input_dim, jit)
     ph, pw = max(oh, target_hw[0]), max(ow, target_hw[1])
     return (pw - target_hw[1] - 1 if pw > target_hw[1] else None, ph - target_hw[0] - 1 if ph > target_hw[0] else None)
+
+
+# ------------------------------------------------------------------------------------------------ detectron2 T.* front
+# The augmentations `MyDatasetMapper2._load_image_with_annos` (dataset_mapper.py:642-683) applies to EVERY loaded image -
+# the current one and the three mosaic samples - before the mosaic branch, and all there is in the non-mosaic branch
+# (dataset_mapper.py:615-640): `build_normal_augmentation` (data/detection_utils.py:37-86) = T.ResizeShortestEdge,
+# T.RandomFlip (horizontal), T.RandomFlip (vertical), [colour: not restated], YOLOFRandomShift
+# (data/transforms/augmentation_impl.py:168-191, transform.py:341-410).  detectron2 is un-vendored (readme.md:178 "latest"):
+# ResizeShortestEdge.get_output_shape / ResizeTransform / HFlipTransform / Transform.apply_box are restated from its
+# published source (detectron2/data/transforms/{augmentation_impl,transform}.py, fvcore/transforms/transform.py) - PARITY
+# UNPINNED for those few lines of arithmetic; the pixel work of ResizeTransform is Pillow's Image.resize(BILINEAR), which IS
+# installed here and on the GPU box (12.2.0): `pil_resize_bilinear_u8` restates libImaging/Resample.c's 8-bit path and is
+# PINNED against the real library (tests/test_augment_oracle.py, golden `pil_resize.npz` made by oracle/gen_golden.py).
+PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def pil_bilinear_coeffs(in_size, out_size):
+    """libImaging/Resample.c precompute_coeffs + normalize_coeffs_8bpc for the bilinear filter (support 1.0) over the full
+    axis: (bounds int32 [out, 2] = (first input index, tap count), coefficients int32 [out, ksize], ksize)"""
+    scale = float(in_size) / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        xmin = max(xmin, 0)
+        xmax = int(center + support + 0.5)
+        xmax = min(xmax, in_size) - xmin
+        w = np.zeros(ksize, np.float64)
+        for x in range(xmax):
+            a = abs((x + xmin - center + 0.5) * ss)
+            w[x] = 1.0 - a if a < 1.0 else 0.0
+        ww = 0.0
+        for x in range(xmax):       # (the C loop's own left-to-right summation order)
+            ww += w[x]
+        if ww != 0.0:
+            w[:xmax] = w[:xmax] / ww
+        for x in range(ksize):
+            v = w[x]
+            kk[xx, x] = int(-0.5 + v * (1 << PIL_PRECISION_BITS)) if v < 0 else int(0.5 + v * (1 << PIL_PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk, ksize
+
+
+def _pil_pass(a, bounds, kk, axis):
+    """one 8-bit resampling pass along `axis` (0 rows / 1 columns) of an HWC uint8 array"""
+    a = np.moveaxis(a, axis, 0).astype(np.int64)
+    out = np.empty((bounds.shape[0],) + a.shape[1:], np.uint8)
+    for i in range(bounds.shape[0]):
+        x0, n = int(bounds[i, 0]), int(bounds[i, 1])
+        acc = np.full(a.shape[1:], 1 << (PIL_PRECISION_BITS - 1), np.int64)
+        for t in range(n):
+            acc += a[x0 + t] * int(kk[i, t])
+        out[i] = np.clip(acc >> PIL_PRECISION_BITS, 0, 255).astype(np.uint8)
+    return np.moveaxis(out, 0, axis)
+
+
+def pil_resize_bilinear_u8(img, new_h, new_w):
+    """PIL.Image.fromarray(img).resize((new_w, new_h), Image.BILINEAR) for an HWC uint8 image: horizontal pass first (skipped
+    when the width is unchanged), then the vertical pass on its 8-bit result (skipped when the height is unchanged)"""
+    h, w = img.shape[:2]
+    out = img
+    if new_w != w:
+        b, k, _ = pil_bilinear_coeffs(w, new_w)
+        out = _pil_pass(out, b, k, 1)
+    if new_h != h:
+        b, k, _ = pil_bilinear_coeffs(h, new_h)
+        out = _pil_pass(out, b, k, 0)
+    return np.ascontiguousarray(out)
+
+
+def resize_shortest_edge_shape(oldh, oldw, short_edge_length, max_size):
+    """detectron2 ResizeShortestEdge.get_output_shape (d2 upstream)"""
+    h, w = oldh, oldw
+    size = short_edge_length * 1.0
+    scale = size / min(h, w)
+    if h < w:
+        newh, neww = size, scale * w
+    else:
+        newh, neww = scale * h, size
+    if max(newh, neww) > max_size:
+        scale = max_size * 1.0 / max(newh, neww)
+        newh = newh * scale
+        neww = neww * scale
+    return int(newh + 0.5), int(neww + 0.5)
+
+
+def draw_front(rng_np, hw, min_sizes=(416, 512, 608, 768), max_size=800, sample_style="choice", hflip_prob=0.5, vflip_prob=0.5,
+               shift_prob=0.5, max_shifts=32, hflip=True, vflip=True, shift=True):
+    """the random numbers of the chain in the reference's order (AugmentationList: each get_transform sees the image the
+    previous transforms produced): ResizeShortestEdge (np.random.choice / randint), RandomFlip x2 (np.random.uniform),
+    YOLOFRandomShift (uniform, then randint x, randint y when it fires)"""
+    h, w = hw
+    if sample_style == "range":
+        size = int(rng_np.randint(min_sizes[0], min_sizes[1] + 1))
+    else:
+        size = int(rng_np.choice(min_sizes))
+    nh, nw = (h, w) if size == 0 else resize_shortest_edge_shape(h, w, size, max_size)
+    d = dict(nh=nh, nw=nw, hflip=False, vflip=False, sx=0, sy=0)
+    if hflip:
+        d["hflip"] = bool(rng_np.uniform(0, 1.0) < hflip_prob)
+    if vflip:
+        d["vflip"] = bool(rng_np.uniform(0, 1.0) < vflip_prob)
+    if shift and max_shifts > 0:
+        if rng_np.uniform(0, 1.0) < shift_prob:
+            d["sx"] = int(rng_np.randint(low=-max_shifts, high=max_shifts))
+            d["sy"] = int(rng_np.randint(low=-max_shifts, high=max_shifts))
+    return d
+
+
+def front_image(img, d):
+    """ResizeTransform.apply_image (PIL bilinear) -> HFlipTransform -> VFlipTransform -> YOLOFShiftTransform.apply_image
+    (zeros where the shifted image does not reach)"""
+    out = pil_resize_bilinear_u8(img, d["nh"], d["nw"])
+    if d["hflip"]:
+        out = np.flip(out, axis=1)
+    if d["vflip"]:
+        out = np.flip(out, axis=0)
+    sx, sy = d["sx"], d["sy"]
+    if sx or sy:
+        new = np.zeros_like(out)
+        new_x, orig_x = (0, -sx) if sx < 0 else (sx, 0)
+        new_y, orig_y = (0, -sy) if sy < 0 else (sy, 0)
+        hh, ww = out.shape[0] - abs(sy), out.shape[1] - abs(sx)
+        new[new_y:new_y + hh, new_x:new_x + ww] = out[orig_y:orig_y + hh, orig_x:orig_x + ww]
+        out = new
+    return np.ascontiguousarray(out)
+
+
+def _apply_box(boxes, fn):
+    """fvcore Transform.apply_box: the four corners through apply_coords, then the axis-aligned hull"""
+    idxs = np.array([(0, 1), (2, 1), (0, 3), (2, 3)]).flatten()
+    coords = np.asarray(boxes, np.float64).reshape(-1, 4)[:, idxs].reshape(-1, 2)
+    coords = fn(coords).reshape((-1, 4, 2))
+    return np.concatenate((coords.min(axis=1), coords.max(axis=1)), axis=1)
+
+
+def front_boxes(boxes_xyxy, hw, d):
+    """transform_instance_annotations (data/detection_utils.py:158-190) for every box: TransformList.apply_box = each
+    transform's apply_box in turn, then clip(min=0) and the minimum with (w, h, w, h) of the FINAL image"""
+    h, w = hw
+    nh, nw = d["nh"], d["nw"]
+    b = np.asarray(boxes_xyxy, np.float64).reshape(-1, 4)
+    if len(b) == 0:
+        return b
+
+    def resize(c):
+        c[:, 0] = c[:, 0] * (nw * 1.0 / w)
+        c[:, 1] = c[:, 1] * (nh * 1.0 / h)
+        return c
+
+    def hf(c):
+        c[:, 0] = nw - c[:, 0]
+        return c
+
+    def vf(c):
+        c[:, 1] = nh - c[:, 1]
+        return c
+
+    def sh(c):
+        c[:, 0] += d["sx"]
+        c[:, 1] += d["sy"]
+        return c
+    if (nh, nw) != (h, w):
+        b = _apply_box(b, resize)
+    if d["hflip"]:
+        b = _apply_box(b, hf)
+    if d["vflip"]:
+        b = _apply_box(b, vf)
+    if d["sx"] or d["sy"]:
+        b = _apply_box(b, sh)
+    b = b.clip(min=0)
+    return np.minimum(b, np.array([nw, nh, nw, nh], np.float64))
+
+
+def filter_empty(boxes_xyxy, classes, threshold=1e-5):
+    """detectron2 annotations_to_instances (Boxes = float32) + filter_empty_instances(by_box): keep width, height > 1e-5"""
+    b = np.asarray(boxes_xyxy, np.float64).reshape(-1, 4).astype(np.float32)
+    keep = ((b[:, 2] - b[:, 0]) > threshold) & ((b[:, 3] - b[:, 1]) > threshold)
+    return b[keep], np.asarray(classes)[keep]

@@ -360,6 +360,27 @@ def gold_random_perspective():
     print("random_perspective:", [len(res[f"labels{k}"]) for k in range(4)], "labels kept")
 
 
+def gold_pil_resize():
+    """Pillow's own Image.resize(BILINEAR) - what detectron2's ResizeTransform.apply_image runs for a uint8 image inside
+    T.ResizeShortestEdge (the first entry of build_normal_augmentation, data/detection_utils.py:37-86) - on seeded images:
+    up- and down-scaling, one axis unchanged, both unchanged, a real-size COCO shape.  Pillow is a third-party dependency of
+    the reference's detectron2 (un-vendored); the version installed in this image made these (`pil_version`)."""
+    import PIL
+    from PIL import Image
+    r = np.random.RandomState(77)
+    res = {"pil_version": np.array(PIL.__version__)}
+    cases = [(37, 53, 20, 29), (37, 53, 74, 106), (40, 60, 40, 31), (40, 60, 17, 60), (33, 47, 33, 47), (50, 80, 31, 50),
+             (23, 31, 64, 80), (48, 64, 13, 17), (30, 30, 7, 91), (120, 160, 152, 203)]
+    for k, (h, w, nh, nw) in enumerate(cases):
+        img = r.randint(0, 256, (h, w, 3), dtype=np.uint8)
+        if k % 3 == 2:
+            img = (np.linspace(0, 255, h * w * 3).reshape(h, w, 3)).astype(np.uint8)        # a smooth ramp: rounding ties
+        res[f"src{k}"] = img
+        res[f"size{k}"] = np.array([nh, nw])
+        res[f"out{k}"] = np.asarray(Image.fromarray(img).resize((nw, nh), Image.BILINEAR))
+    np.savez_compressed(os.path.join(OUT, "pil_resize.npz"), **res)
+
+
 def gold_bifpn():
     """the reference's BiFPN (neck/bifpn.py:307-395) over seeded C3..C5 maps, fp32: p3..p7, the gradients with respect to
     the inputs, every edge weight / GroupNorm parameter, and two convolution weights; dense and separable variants"""
@@ -841,6 +862,7 @@ if __name__ == "__main__":
     gold_yolov6_loss()
     gold_bifpn()
     gold_random_perspective()
+    gold_pil_resize()
     gold_encoder_layer()
     gold_transformer()
     gold_pos_embed()

@@ -1,0 +1,186 @@
+"""The detectron2 T.* front of the input pipeline (yolov7/data/detection_utils.py:37-86,158-190,
+dataset_mapper.py:615-683) without a GPU:
+
+* the oracle's restatement of Pillow's 8-bit bilinear resampling against the committed golden (made by the real library,
+  oracle/gen_golden.py::gold_pil_resize) and, when Pillow is importable, against the library itself on fresh shapes;
+* the per-pixel functions the HIP kernels call (yolov7_d2_amd/csrc/pil_resize_core.h) compiled for the HOST
+  (tests/native/pil_resize_host.cpp, g++ -ffp-contract=off) against the same - resize + flips + shift, HWC and padded-NCHW
+  destination strides;
+* the product's host half (random draws in the reference's order, float64 box arithmetic, instance filtering, label rows)
+  against the oracle."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import augment_oracle as A  # noqa: E402
+
+
+def _cases(seed, n):
+    r = np.random.RandomState(seed)
+    out = [(480, 640, 608, 811), (427, 640, 416, 623), (96, 64, 96, 40), (64, 96, 31, 96), (50, 70, 50, 70)]
+    for _ in range(n):
+        h, w = r.randint(8, 90, 2)
+        nh, nw = r.randint(4, 140, 2)
+        out.append((int(h), int(w), int(nh), int(nw)))
+    return out
+
+
+def test_pil_oracle_against_the_golden_made_by_pillow(golden_dir):
+    g = np.load(os.path.join(golden_dir, "pil_resize.npz"))
+    k = 0
+    while f"src{k}" in g.files:
+        nh, nw = (int(v) for v in g[f"size{k}"])
+        assert np.array_equal(A.pil_resize_bilinear_u8(g[f"src{k}"], nh, nw), g[f"out{k}"]), k
+        k += 1
+    assert k == 10
+
+
+def test_pil_oracle_against_the_installed_pillow():
+    Image = pytest.importorskip("PIL.Image")
+    r = np.random.RandomState(5)
+    for (h, w, nh, nw) in _cases(11, 25):
+        img = r.randint(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((nw, nh), Image.BILINEAR))
+        assert np.array_equal(A.pil_resize_bilinear_u8(img, nh, nw), ref), (h, w, nh, nw)
+
+
+@pytest.fixture(scope="module")
+def host_lib(tmp_path_factory):
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    so = str(tmp_path_factory.mktemp("pil") / "pil_host.so")
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tests", "native", "pil_resize_host.cpp")],
+                   check=True)
+    return C.CDLL(so)
+
+
+def _run_host(lib, img, d, nchw_pad=None):
+    h, w = img.shape[:2]
+    nh, nw = d["nh"], d["nw"]
+    tmp = np.zeros((h, nw, 3), np.uint8)
+    if nchw_pad is None:
+        dst = np.full((nh, nw, 3), 77, np.uint8)
+        strides = (1, 3 * nw, 3)
+    else:
+        Hp, Wp = nchw_pad
+        dst = np.full((3, Hp, Wp), 114, np.uint8)
+        strides = (Hp * Wp, Wp, 1)
+    lib.pil_front_host(img.ctypes.data_as(C.c_void_p), h, w, nh, nw, int(d["hflip"]), int(d["vflip"]), d["sx"], d["sy"],
+                       tmp.ctypes.data_as(C.c_void_p), dst.ctypes.data_as(C.c_void_p), C.c_longlong(strides[0]),
+                       C.c_longlong(strides[1]), C.c_longlong(strides[2]))
+    return dst
+
+
+def test_kernel_pixel_functions_on_the_host_equal_pillow_and_the_oracle(host_lib, golden_dir):
+    g = np.load(os.path.join(golden_dir, "pil_resize.npz"))
+    for k in range(10):                                         # the golden: plain resizes
+        nh, nw = (int(v) for v in g[f"size{k}"])
+        d = dict(nh=nh, nw=nw, hflip=False, vflip=False, sx=0, sy=0)
+        assert np.array_equal(_run_host(host_lib, np.ascontiguousarray(g[f"src{k}"]), d), g[f"out{k}"]), k
+    r = np.random.RandomState(9)
+    for i, (h, w, nh, nw) in enumerate(_cases(3, 20)):          # the whole front against the oracle (itself pinned above)
+        img = r.randint(0, 256, (h, w, 3), dtype=np.uint8)
+        lim = max(1, min(nh, nw, 32) - 1)
+        d = dict(nh=nh, nw=nw, hflip=bool(i & 1), vflip=bool(i & 2), sx=int(r.randint(-lim, lim)) if i % 3 else 0,
+                 sy=int(r.randint(-lim, lim)) if i % 3 else 0)
+        ref = A.front_image(img, d)
+        assert np.array_equal(_run_host(host_lib, img, d), ref), (h, w, d)
+        Hp, Wp = (nh + 31) // 32 * 32, (nw + 31) // 32 * 32 + 32
+        out = _run_host(host_lib, img, d, nchw_pad=(Hp, Wp))
+        assert np.array_equal(out[:, :nh, :nw], ref.transpose(2, 0, 1)) and (out[:, nh:] == 114).all() and (out[:, :, nw:] == 114).all()
+
+
+def test_front_host_logic_equals_the_oracle():
+    """draws (same numpy stream -> same values, same number of variates consumed), boxes through the four transforms +
+    clipping, filter_empty_instances and preprocess_image's rows"""
+    from yolov7_d2_amd.data_pipeline import GpuFrontAugment
+    fa = GpuFrontAugment(device="cpu")
+    assert fa.output_shape(480, 640, 608, 800) == A.resize_shortest_edge_shape(480, 640, 608, 800) == (600, 800)
+    assert fa.output_shape(640, 427, 768, 800) == A.resize_shortest_edge_shape(640, 427, 768, 800)
+    r1, r2 = np.random.RandomState(21), np.random.RandomState(21)
+    fired = dict(h=0, v=0, s=0)
+    images, labels, draws = [], [], []
+    for k in range(40):
+        h, w = int(r1.randint(200, 700)), int(r1.randint(200, 700))
+        assert (int(r2.randint(200, 700)), int(r2.randint(200, 700))) == (h, w)
+        d1, d2 = fa.draw((h, w), r1), A.draw_front(r2, (h, w))
+        assert d1 == d2
+        fired["h"] += d1["hflip"]; fired["v"] += d1["vflip"]; fired["s"] += bool(d1["sx"] or d1["sy"])
+        n = int(r1.randint(0, 9)); r2.randint(0, 9)
+        x1 = r1.uniform(-5, w - 10, n); y1 = r1.uniform(-5, h - 10, n)
+        lab = np.stack([x1, y1, x1 + r1.uniform(0, 300, n), y1 + r1.uniform(0, 300, n), r1.randint(0, 80, n).astype(np.float64)], 1)
+        r2.uniform(-5, w - 10, n); r2.uniform(-5, h - 10, n); r2.uniform(0, 300, n); r2.uniform(0, 300, n); r2.randint(0, 80, n)
+        if n > 2:
+            lab[0, 2:4] = lab[0, :2]                              # an empty box: dropped by filter_empty_instances
+        got = fa.boxes(lab, (h, w), d1)
+        ref = A.front_boxes(lab[:, :4], (h, w), d2)
+        assert np.array_equal(got[:, :4], ref) and np.array_equal(got[:, 4], lab[:, 4])
+        images.append(np.zeros((h, w, 3), np.uint8)); labels.append(lab); draws.append(d1)
+    assert min(fired.values()) > 5
+    rows = fa.label_rows(images, labels, draws)
+    for b in range(40):
+        box, cls_ = A.filter_empty(A.front_boxes(labels[b][:, :4], images[b].shape[:2], draws[b]), labels[b][:, 4])
+        _, ref = A.preprocess_batch([(np.zeros((draws[b]["nh"], draws[b]["nw"], 3), np.uint8), np.concatenate([box.astype(np.float64), cls_[:, None]], 1))])
+        assert np.array_equal(rows[b], ref[0]), b
+
+
+def test_front_refuses_a_cpu_pixel_path():
+    from yolov7_d2_amd import _lib as L
+    from yolov7_d2_amd.data_pipeline import GpuFrontAugment
+    import torch
+    fa = GpuFrontAugment(device="cpu")
+    with pytest.raises(L.MI355Error):
+        fa.apply([torch.zeros(8, 8, 3, dtype=torch.uint8)], [dict(nh=4, nw=4, hflip=False, vflip=False, sx=0, sy=0)])
+
+
+def test_job_table_layout_and_both_launches_emulated_on_the_host(host_lib):
+    """everything of `GpuFrontAugment.make_batch` / `.apply` except hipLaunchKernelGGL: the product's job table (host
+    tensors here), mi_pil_resize_jobs_layout from the real library (host code), then the kernels' thread bodies walked over
+    the same grid by the host build - against the oracle"""
+    import torch
+    from yolov7_d2_amd import _lib as L
+    from yolov7_d2_amd.data_pipeline import GpuFrontAugment
+    fa = GpuFrontAugment(device="cpu")
+    r = np.random.RandomState(31)
+    shapes = [(120, 160), (107, 160), (160, 120), (96, 64), (50, 70), (64, 64)]
+    imgs = [r.randint(0, 256, (h, w, 3), dtype=np.uint8) for h, w in shapes]
+    draws = [dict(nh=104, nw=139, hflip=False, vflip=True, sx=31, sy=0), dict(nh=134, nw=200, hflip=True, vflip=True, sx=-6, sy=10),
+             dict(nh=200, nw=150, hflip=True, vflip=False, sx=0, sy=0), dict(nh=96, nw=40, hflip=True, vflip=False, sx=0, sy=-7),
+             dict(nh=50, nw=70, hflip=False, vflip=True, sx=5, sy=0), dict(nh=32, nw=64, hflip=False, vflip=False, sx=0, sy=0)]
+    timgs = [torch.from_numpy(i) for i in imgs]
+    lib = L.lib()
+
+    def run(jobs):
+        bh, bv = C.c_int32(0), C.c_int32(0)
+        L.check(lib.mi_pil_resize_jobs_layout(jobs, len(jobs), C.byref(bh), C.byref(bv)), "layout")
+        assert bv.value == sum((d["nh"] * d["nw"] + 255) // 256 for d in draws)
+        assert bh.value == sum((i.shape[0] * d["nw"] + 255) // 256 for i, d in zip(imgs, draws) if d["nw"] != i.shape[1])
+        host_lib.pil_emulate_launches(C.cast(jobs, C.c_void_p), len(jobs), bh.value, bv.value)
+
+    # apply(): HWC outputs
+    outs = [torch.full((d["nh"], d["nw"], 3), 7, dtype=torch.uint8) for d in draws]
+    jobs, tmps = fa._jobs(timgs, draws, [(o.data_ptr(), 1, 3 * d["nw"], 3) for o, d in zip(outs, draws)])
+    run(jobs)
+    for o, i, d in zip(outs, imgs, draws):
+        assert np.array_equal(o.numpy(), A.front_image(i, d)), d
+    # make_batch(): one padded NCHW tensor
+    Hp, Wp = fa.batch_shape(draws)
+    assert (Hp, Wp) == (224, 224)
+    out = torch.full((len(imgs), 3, Hp, Wp), 114, dtype=torch.uint8)
+    jobs, tmps = fa._jobs(timgs, draws, [(out.data_ptr() + b * 3 * Hp * Wp, Hp * Wp, Wp, 1) for b in range(len(imgs))])
+    run(jobs)
+    ref, _ = A.preprocess_batch([(A.front_image(i, d), np.zeros((0, 5))) for i, d in zip(imgs, draws)])
+    assert np.array_equal(out.numpy(), ref)
+    # the layout refuses what the kernels do not serve
+    bad = (L.mi_pil_resize_job * 1)()
+    C.memmove(bad, jobs, C.sizeof(L.mi_pil_resize_job))
+    bad[0].nw, bad[0].nh = 8, 8                                  # 120 x 160 -> 8 x 8: shrinks by more than 8
+    bh, bv = C.c_int32(0), C.c_int32(0)
+    assert lib.mi_pil_resize_jobs_layout(bad, 1, C.byref(bh), C.byref(bv)) != 0

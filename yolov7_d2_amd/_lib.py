@@ -156,6 +156,12 @@ class mi_mixup_job(C.Structure):
                 ("h0", "w0", "rh1", "rw1", "dh", "dw", "oh", "ow", "flip", "x_off", "y_off", "th", "tw", "Hp", "Wp", "blk0")]
 
 
+class mi_pil_resize_job(C.Structure):
+    _fields_ = ([("src", C.c_void_p), ("tmp", C.c_void_p), ("dst", C.c_void_p), ("dsc", C.c_int64), ("dsy", C.c_int64),
+                 ("dsx", C.c_int64)] +
+                [(n, C.c_int32) for n in ("h0", "w0", "nh", "nw", "hflip", "vflip", "shift_x", "shift_y", "blk0h", "blk0v")])
+
+
 class mi_cmd(C.Structure):
     _fields_ = [("op", C.c_int32), ("i", C.c_int32 * 40), ("f", C.c_float * 8), ("p", C.c_void_p * 16),
                 ("l", C.c_int64 * 4)]
@@ -249,6 +255,9 @@ _PROTOS = {
     "mi_warp_affine_u8": (C.c_int, [_vp, _i, _i, _vp]),
     "mi_mixup_jobs_layout": (C.c_int, [C.POINTER(mi_mixup_job), _i]),
     "mi_mixup_blend": (C.c_int, [_vp, _i, _i, _vp]),
+    "mi_pil_resize_jobs_layout": (C.c_int, [C.POINTER(mi_pil_resize_job), _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "mi_pil_resize_h": (C.c_int, [_vp, _i, _i, _vp]),
+    "mi_pil_resize_v": (C.c_int, [_vp, _i, _i, _vp]),
     "mi_rle_encode": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mi_rle_to_string": (C.c_int, [_vp, _i, C.c_char_p, _i]),
     "mi_yolox_onnx_layout": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),

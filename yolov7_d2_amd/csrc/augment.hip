@@ -270,3 +270,53 @@ extern "C" int mi_warp_affine_u8(const mi_warp_job* jobs_dev, int njobs, int tot
   MI_CHECK_LAUNCH("warp_affine_u8");
   return MI_OK;
 }
+
+
+// ================================================================= detectron2 T.* front of the input pipeline
+// T.ResizeShortestEdge (Pillow's 8-bit bilinear resampling, pil_resize_core.h) + T.RandomFlip (horizontal, vertical) +
+// YOLOFRandomShift of every image the mapper loads (yolov7/data/detection_utils.py:37-86, dataset_mapper.py:642-683): two
+// flat launches over a job table - the horizontal pass into a scratch image, then vertical pass + flips + shift + the
+// caller's destination strides (an HWC image for the mosaic pool, or a plane triple of the padded NCHW batch).
+#include "pil_resize_core.h"
+static_assert(sizeof(PilJob) == sizeof(mi_pil_resize_job), "PilJob mirrors mi_pil_resize_job");
+
+__global__ __launch_bounds__(256) void pil_resize_h_kernel(const PilJob* __restrict__ jobs, int njobs) {
+  pil_h_thread(jobs, njobs, (int)blockIdx.x, (int)threadIdx.x);
+}
+__global__ __launch_bounds__(256) void pil_resize_v_kernel(const PilJob* __restrict__ jobs, int njobs) {
+  pil_v_thread(jobs, njobs, (int)blockIdx.x, (int)threadIdx.x);
+}
+
+extern "C" int mi_pil_resize_jobs_layout(mi_pil_resize_job* jobs, int n, int32_t* blocks_h, int32_t* blocks_v) {
+  MI_REQUIRE(jobs && n > 0 && blocks_h && blocks_v, "pil_resize_layout: args");
+  int64_t bh = 0, bv = 0;
+  for (int i = 0; i < n; ++i) {
+    mi_pil_resize_job& j = jobs[i];
+    MI_REQUIRE(j.src && j.dst && j.h0 > 0 && j.w0 > 0 && j.nh > 0 && j.nw > 0, "pil_resize_layout: job %d: null / empty", i);
+    MI_REQUIRE(j.nw == j.w0 || j.tmp, "pil_resize_layout: job %d needs the scratch image of the horizontal pass", i);
+    const int kx = (int)((j.w0 + j.nw - 1) / j.nw), ky = (int)((j.h0 + j.nh - 1) / j.nh);    // ceil(scale)
+    MI_REQUIRE(kx * 2 + 1 <= PIL_MAX_TAPS && ky * 2 + 1 <= PIL_MAX_TAPS, "pil_resize_layout: job %d shrinks by more than 8", i);
+    MI_REQUIRE(j.shift_x > -j.nw && j.shift_x < j.nw && j.shift_y > -j.nh && j.shift_y < j.nh, "pil_resize_layout: job %d: shift", i);
+    j.blk0h = (int32_t)bh;
+    j.blk0v = (int32_t)bv;
+    if (j.nw != j.w0) bh += ((int64_t)j.h0 * j.nw + 255) / 256;
+    bv += ((int64_t)j.nh * j.nw + 255) / 256;
+    MI_REQUIRE(bh < (1LL << 30) && bv < (1LL << 30), "pil_resize_layout: too many blocks");
+  }
+  *blocks_h = (int32_t)bh;
+  *blocks_v = (int32_t)bv;
+  return MI_OK;
+}
+extern "C" int mi_pil_resize_h(const mi_pil_resize_job* jobs_dev, int n, int total_blocks, mi_stream_t st) {
+  MI_REQUIRE(jobs_dev && n > 0 && total_blocks >= 0, "pil_resize_h: args");
+  if (total_blocks == 0) return MI_OK;                        // every job keeps its width
+  hipLaunchKernelGGL(pil_resize_h_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)st, (const PilJob*)jobs_dev, n);
+  MI_CHECK_LAUNCH("pil_resize_h");
+  return MI_OK;
+}
+extern "C" int mi_pil_resize_v(const mi_pil_resize_job* jobs_dev, int n, int total_blocks, mi_stream_t st) {
+  MI_REQUIRE(jobs_dev && n > 0 && total_blocks > 0, "pil_resize_v: args");
+  hipLaunchKernelGGL(pil_resize_v_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)st, (const PilJob*)jobs_dev, n);
+  MI_CHECK_LAUNCH("pil_resize_v");
+  return MI_OK;
+}

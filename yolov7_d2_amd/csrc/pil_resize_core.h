@@ -1,0 +1,140 @@
+// Pillow's 8-bit bilinear resampling (libImaging/Resample.c: precompute_coeffs, normalize_coeffs_8bpc,
+// ImagingResampleHorizontal_8bpc / Vertical_8bpc) as per-output-pixel functions: what detectron2's ResizeTransform.apply_image
+// runs for a uint8 image (PIL.Image.resize(BILINEAR)) inside T.ResizeShortestEdge - the first augmentation of the
+// reference's build_normal_augmentation (yolov7/data/detection_utils.py:37-86), applied to every image
+// MyDatasetMapper2._load_image_with_annos loads (yolov7/data/dataset_mapper.py:642-683).
+// Plain C++ with no HIP types: the kernels in augment.hip call these on the device, tests/native/pil_resize_host.cpp
+// compiles the SAME functions for the host and the CPU test holds them bit-identical to the installed Pillow.
+// Coefficients are fp64 exactly as the C library computes them (translation units including this are built with
+// -ffp-contract=off), then 22-bit fixed point; the horizontal pass rounds to 8 bits before the vertical pass reads it.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MI_HD __host__ __device__ __forceinline__
+#else
+#define MI_HD static inline
+#endif
+
+#define PIL_PRECISION_BITS 22          // 32 - 8 - 2
+#define PIL_MAX_TAPS 17                // ceil(scale) * 2 + 1: down-scaling factors up to 8
+
+struct PilJob {   // mirrors mi_pil_resize_job (include/mi355_det.h)
+  const unsigned char* src;
+  unsigned char* tmp;
+  unsigned char* dst;
+  int64_t dsc, dsy, dsx;
+  int32_t h0, w0, nh, nw;
+  int32_t hflip, vflip, shift_x, shift_y;
+  int32_t blk0h, blk0v;
+};
+
+struct PilTaps {
+  int x0, n;
+  int k[PIL_MAX_TAPS];
+};
+
+// taps of output index xx of an axis resampled from in_size to out_size (full-axis box)
+MI_HD void pil_taps(int in_size, int out_size, int xx, PilTaps* t) {
+  const double scale = (double)in_size / (double)out_size;
+  const double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double support = 1.0 * filterscale;                  // bilinear: filterp->support = 1.0
+  const double center = (xx + 0.5) * scale;
+  const double ss = 1.0 / filterscale;
+  int xmin = (int)(center - support + 0.5);
+  if (xmin < 0) xmin = 0;
+  int xmax = (int)(center + support + 0.5);
+  if (xmax > in_size) xmax = in_size;
+  xmax -= xmin;
+  if (xmax > PIL_MAX_TAPS) xmax = PIL_MAX_TAPS;               // (excluded by mi_pil_resize_jobs_layout)
+  double w[PIL_MAX_TAPS];
+  double ww = 0.0;
+  for (int x = 0; x < xmax; ++x) {
+    double a = (x + xmin - center + 0.5) * ss;
+    if (a < 0.0) a = -a;
+    w[x] = a < 1.0 ? 1.0 - a : 0.0;
+    ww += w[x];
+  }
+  for (int x = 0; x < xmax; ++x) {
+    double v = w[x];
+    if (ww != 0.0) v /= ww;
+    t->k[x] = v < 0 ? (int)(-0.5 + v * (double)(1 << PIL_PRECISION_BITS)) : (int)(0.5 + v * (double)(1 << PIL_PRECISION_BITS));
+  }
+  t->x0 = xmin;
+  t->n = xmax;
+}
+
+MI_HD unsigned char pil_clip8(int v) {
+  v >>= PIL_PRECISION_BITS;
+  return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+// horizontal pass: tmp[y][xo][0..2] from src row y (called only when nw != w0)
+MI_HD void pil_h_pixel(const PilJob& j, int y, int xo, unsigned char out[3]) {
+  PilTaps t;
+  pil_taps(j.w0, j.nw, xo, &t);
+  const unsigned char* r = j.src + ((int64_t)y * j.w0 + t.x0) * 3;
+  int s0 = 1 << (PIL_PRECISION_BITS - 1), s1 = s0, s2 = s0;
+  for (int x = 0; x < t.n; ++x) {
+    s0 += (int)r[x * 3 + 0] * t.k[x];
+    s1 += (int)r[x * 3 + 1] * t.k[x];
+    s2 += (int)r[x * 3 + 2] * t.k[x];
+  }
+  out[0] = pil_clip8(s0); out[1] = pil_clip8(s1); out[2] = pil_clip8(s2);
+}
+
+// destination pixel (yd, xd) of the nh x nw result after the vertical pass, HFlipTransform, VFlipTransform and
+// YOLOFShiftTransform (zeros where the shifted image does not reach; transform.py:355-388), in that order.
+// h_img: the horizontally resampled image [h0][nw][3] (= src when nw == w0).
+MI_HD void pil_v_pixel(const PilJob& j, const unsigned char* h_img, int yd, int xd, unsigned char out[3]) {
+  int ys = yd - j.shift_y, xs = xd - j.shift_x;
+  if (ys < 0 || ys >= j.nh || xs < 0 || xs >= j.nw) {
+    out[0] = out[1] = out[2] = 0;
+    return;
+  }
+  if (j.vflip) ys = j.nh - 1 - ys;
+  if (j.hflip) xs = j.nw - 1 - xs;
+  if (j.nh == j.h0) {                                          // no vertical pass: the row passes through unchanged
+    const unsigned char* p = h_img + ((int64_t)ys * j.nw + xs) * 3;
+    out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
+    return;
+  }
+  PilTaps t;
+  pil_taps(j.h0, j.nh, ys, &t);
+  int s0 = 1 << (PIL_PRECISION_BITS - 1), s1 = s0, s2 = s0;
+  for (int y = 0; y < t.n; ++y) {
+    const unsigned char* p = h_img + ((int64_t)(t.x0 + y) * j.nw + xs) * 3;
+    s0 += (int)p[0] * t.k[y];
+    s1 += (int)p[1] * t.k[y];
+    s2 += (int)p[2] * t.k[y];
+  }
+  out[0] = pil_clip8(s0); out[1] = pil_clip8(s1); out[2] = pil_clip8(s2);
+}
+
+// one thread of the two flat launches (block = 256 threads; a job's first block is blk0h / blk0v, filled by
+// mi_pil_resize_jobs_layout): the kernels pass blockIdx.x / threadIdx.x, the host test build walks the same grid in loops
+MI_HD void pil_h_thread(const PilJob* jobs, int njobs, int block, int thread) {
+  int j = 0;
+  while (j + 1 < njobs && block >= jobs[j + 1].blk0h) ++j;
+  const PilJob p = jobs[j];
+  if (p.nw == p.w0) return;                                    // no horizontal pass: the job owns no blocks of this launch
+  const int64_t idx = ((int64_t)block - p.blk0h) * 256 + thread;
+  if (idx >= (int64_t)p.h0 * p.nw) return;
+  const int y = (int)(idx / p.nw), x = (int)(idx - (int64_t)y * p.nw);
+  unsigned char o[3];
+  pil_h_pixel(p, y, x, o);
+  unsigned char* d = p.tmp + idx * 3;
+  d[0] = o[0]; d[1] = o[1]; d[2] = o[2];
+}
+MI_HD void pil_v_thread(const PilJob* jobs, int njobs, int block, int thread) {
+  int j = 0;
+  while (j + 1 < njobs && block >= jobs[j + 1].blk0v) ++j;
+  const PilJob p = jobs[j];
+  const int64_t idx = ((int64_t)block - p.blk0v) * 256 + thread;
+  if (idx >= (int64_t)p.nh * p.nw) return;
+  const int y = (int)(idx / p.nw), x = (int)(idx - (int64_t)y * p.nw);
+  unsigned char o[3];
+  pil_v_pixel(p, p.nw == p.w0 ? p.src : p.tmp, y, x, o);
+  unsigned char* d = p.dst + (int64_t)y * p.dsy + (int64_t)x * p.dsx;
+  d[0] = o[0]; d[p.dsc] = o[1]; d[2 * p.dsc] = o[2];
+}

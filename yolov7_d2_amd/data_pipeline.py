@@ -285,3 +285,183 @@ class GpuMosaicMapper:
             L.check(lib.mi_mixup_blend(tab.data_ptr() + C.sizeof(paste) + C.sizeof(warp), nmix, mb, st), "mi_mixup_blend")
         self._keep = (canvas, tab)                                 # alive until the stream has run the two launches
         return out, torch.from_numpy(rows).to(self.device, non_blocking=True), [(d[0], d[1]) for d in dims]
+
+
+# ------------------------------------------------------------------------------------------------ the T.* front
+FRONT_DEFAULTS = dict(MIN_SIZE_TRAIN=(416, 512, 608, 768), MAX_SIZE_TRAIN=800, MIN_SIZE_TRAIN_SAMPLING="choice",
+                      HFLIP=True, HFLIP_PROB=0.5, VFLIP=True, VFLIP_PROB=0.5, SHIFT=True, SHIFT_PIXELS=32)
+# (configs/coco/yolox_s.yaml:35-38 + yolov7/config.py:276-286: INPUT.RANDOM_FLIP_HORIZONTAL / _VERTICAL / SHIFT defaults)
+
+
+class GpuFrontAugment:
+    """The detectron2 augmentation list every loaded image goes through before anything else
+    (`MyDatasetMapper2._load_image_with_annos`, yolov7/data/dataset_mapper.py:642-683; `build_normal_augmentation`,
+    yolov7/data/detection_utils.py:37-86): T.ResizeShortestEdge -> T.RandomFlip(horizontal) -> T.RandomFlip(vertical) ->
+    YOLOFRandomShift, with `transform_instance_annotations` (detection_utils.py:158-190) for the boxes - and, with the mosaic
+    off (after INPUT.MOSAIC_AND_MIXUP.DISABLE_AT_ITER, or mosaic_flag 0), the WHOLE mapper: dataset_mapper.py:615-640 then
+    only builds Instances and drops empty boxes.  The host draws the reference's random numbers in the reference's order and
+    does its float64 box arithmetic; the pixels (Pillow's 8-bit bilinear resampling, the flips, the shift) are two launches
+    for any number of images (mi_pil_resize_h / _v).  The colour entries of that list (RandomSaturation, RandomBrightness,
+    YOLOFRandomDistortion) are not built: with INPUT.COLOR_JITTER / INPUT.DISTORTION off (the config.py defaults) the
+    random stream and the result are the reference's, with them on (yolox_s.yaml) this front skips them."""
+
+    def __init__(self, cfg=None, device="cuda", max_boxes=100, pad_value=114, size_divisibility=32):
+        c = dict(FRONT_DEFAULTS)
+        c.update(cfg or {})
+        self.cfg, self.device = c, torch.device(device)
+        self.max_boxes, self.pad, self.divis = max_boxes, pad_value, size_divisibility
+
+    # ---- ResizeShortestEdge.get_output_shape (d2 upstream)
+    @staticmethod
+    def output_shape(oldh, oldw, short_edge_length, max_size):
+        size = short_edge_length * 1.0
+        scale = size / min(oldh, oldw)
+        newh, neww = (size, scale * oldw) if oldh < oldw else (scale * oldh, size)
+        if max(newh, neww) > max_size:
+            scale = max_size * 1.0 / max(newh, neww)
+            newh, neww = newh * scale, neww * scale
+        return int(newh + 0.5), int(neww + 0.5)
+
+    def draw(self, hw, rng_np=np.random):
+        """one image's random numbers, in AugmentationList order (each get_transform sees the previous result)"""
+        c = self.cfg
+        h, w = hw
+        sizes = c["MIN_SIZE_TRAIN"]
+        if c["MIN_SIZE_TRAIN_SAMPLING"] == "range":
+            size = int(rng_np.randint(sizes[0], sizes[1] + 1))
+        else:
+            size = int(rng_np.choice(sizes))
+        nh, nw = (h, w) if size == 0 else self.output_shape(h, w, size, c["MAX_SIZE_TRAIN"])
+        d = dict(nh=nh, nw=nw, hflip=False, vflip=False, sx=0, sy=0)
+        if c["HFLIP"]:
+            d["hflip"] = bool(rng_np.uniform(0, 1.0) < c["HFLIP_PROB"])
+        if c["VFLIP"]:
+            d["vflip"] = bool(rng_np.uniform(0, 1.0) < c["VFLIP_PROB"])
+        if c["SHIFT"] and c["SHIFT_PIXELS"] > 0:
+            if rng_np.uniform(0, 1.0) < 0.5:                       # YOLOFRandomShift(prob=0.5 default, max_shifts)
+                d["sx"] = int(rng_np.randint(low=-c["SHIFT_PIXELS"], high=c["SHIFT_PIXELS"]))
+                d["sy"] = int(rng_np.randint(low=-c["SHIFT_PIXELS"], high=c["SHIFT_PIXELS"]))
+        return d
+
+    @staticmethod
+    def _hull(b, fn):
+        """fvcore Transform.apply_box: corners through the coordinate map, then the axis-aligned hull"""
+        idxs = np.array([(0, 1), (2, 1), (0, 3), (2, 3)]).flatten()
+        coords = fn(b.reshape(-1, 4)[:, idxs].reshape(-1, 2)).reshape((-1, 4, 2))
+        return np.concatenate((coords.min(axis=1), coords.max(axis=1)), axis=1)
+
+    @classmethod
+    def boxes(cls, labels, hw, d):
+        """labels float64 [n, 5] (x1, y1, x2, y2, cls) of the source image -> the same rows on the augmented image
+        (clipped to it; empty boxes are NOT dropped here: the mosaic branch keeps them, the plain branch filters)"""
+        lab = np.asarray(labels, np.float64).reshape(-1, 5).copy()
+        if len(lab) == 0:
+            return lab
+        h, w = hw
+        nh, nw = d["nh"], d["nw"]
+        b = lab[:, :4]
+
+        def scale(c):
+            c[:, 0] = c[:, 0] * (nw * 1.0 / w)
+            c[:, 1] = c[:, 1] * (nh * 1.0 / h)
+            return c
+
+        def hf(c):
+            c[:, 0] = nw - c[:, 0]
+            return c
+
+        def vf(c):
+            c[:, 1] = nh - c[:, 1]
+            return c
+
+        def sh(c):
+            c[:, 0] += d["sx"]
+            c[:, 1] += d["sy"]
+            return c
+        if (nh, nw) != (h, w):
+            b = cls._hull(b, scale)
+        if d["hflip"]:
+            b = cls._hull(b, hf)
+        if d["vflip"]:
+            b = cls._hull(b, vf)
+        if d["sx"] or d["sy"]:
+            b = cls._hull(b, sh)
+        lab[:, :4] = np.minimum(b.clip(min=0), np.array([nw, nh, nw, nh], np.float64))
+        return lab
+
+    def _launch(self, jobs, keep):
+        n = len(jobs)
+        bh, bv = C.c_int32(0), C.c_int32(0)
+        lib = L.lib()
+        L.check(lib.mi_pil_resize_jobs_layout(jobs, n, C.byref(bh), C.byref(bv)), "mi_pil_resize_jobs_layout")
+        tab = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(self.device)
+        st = L.stream_ptr()
+        L.check(lib.mi_pil_resize_h(tab.data_ptr(), n, bh.value, st), "mi_pil_resize_h")
+        L.check(lib.mi_pil_resize_v(tab.data_ptr(), n, bv.value, st), "mi_pil_resize_v")
+        self._keep = (tab, keep)                                   # alive until the stream has run the two launches
+
+    def _jobs(self, images, draws, dsts):
+        """the job table: dsts = (address, channel / row / column stride in bytes) of each image's destination"""
+        jobs = (L.mi_pil_resize_job * len(images))()
+        tmps = []
+        for j, img, d, (ptr, dsc, dsy, dsx) in zip(jobs, images, draws, dsts):
+            if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3 or not img.is_contiguous():
+                raise ValueError("GpuFrontAugment: contiguous uint8 [H, W, 3] images")
+            h0, w0 = img.shape[:2]
+            j.src, j.h0, j.w0, j.nh, j.nw = img.data_ptr(), h0, w0, d["nh"], d["nw"]
+            j.hflip, j.vflip, j.shift_x, j.shift_y = int(d["hflip"]), int(d["vflip"]), d["sx"], d["sy"]
+            if d["nw"] != w0:
+                t = torch.empty(h0, d["nw"], 3, dtype=torch.uint8, device=img.device)
+                tmps.append(t)
+                j.tmp = t.data_ptr()
+            j.dst, j.dsc, j.dsy, j.dsx = ptr, dsc, dsy, dsx
+        return jobs, tmps
+
+    def _check_device(self, images):
+        if self.device.type != "cuda" or not all(i.is_cuda for i in images):
+            raise L.MI355Error("GpuFrontAugment: the MI355X path needs device tensors (no CPU pixel path)")
+
+    def apply(self, images, draws):
+        """images: device uint8 HWC tensors (decoded, as MosaicPool holds them); draws: one dict from draw() each.
+        Returns the augmented HWC device images (what the mosaic branch then resizes and pastes)."""
+        self._check_device(images)
+        outs = [torch.empty(d["nh"], d["nw"], 3, dtype=torch.uint8, device=self.device) for d in draws]
+        jobs, tmps = self._jobs(images, draws, [(o.data_ptr(), 1, 3 * d["nw"], 3) for o, d in zip(outs, draws)])
+        self._launch(jobs, (tmps, list(images)))
+        return outs
+
+    def batch_shape(self, draws):
+        Hp = (max(d["nh"] for d in draws) + self.divis - 1) // self.divis * self.divis
+        Wp = (max(d["nw"] for d in draws) + self.divis - 1) // self.divis * self.divis
+        return Hp, Wp
+
+    def make_batch(self, images, labels, draws):
+        """the mapper with the mosaic OFF (dataset_mapper.py:615-640) + YOLOX.preprocess_image (meta_arch/yolox.py:95-162) for
+        a batch: images as in apply(), labels float64 [n_i, 5] (x1, y1, x2, y2, cls) per image.  Returns what
+        GpuMosaicMapper.make_batch returns: (uint8 [B, 3, Hp, Wp] padded with 114, float32 [B, max_boxes, 5] rows
+        (cls, cx, cy, w, h), per-sample (h, w))."""
+        self._check_device(images)
+        B = len(images)
+        Hp, Wp = self.batch_shape(draws)
+        out = torch.full((B, 3, Hp, Wp), self.pad, dtype=torch.uint8, device=self.device)
+        rows = self.label_rows(images, labels, draws)
+        jobs, tmps = self._jobs(images, draws, [(out.data_ptr() + b * 3 * Hp * Wp, Hp * Wp, Wp, 1) for b in range(B)])
+        self._launch(jobs, (tmps, list(images)))
+        return out, torch.from_numpy(rows).to(self.device, non_blocking=True), [(d["nh"], d["nw"]) for d in draws]
+
+    def label_rows(self, images, labels, draws):
+        """host half of make_batch: transform_instance_annotations -> annotations_to_instances (float32 Boxes) ->
+        filter_empty_instances (width, height > 1e-5) -> preprocess_image's (cls, cx, cy, w, h) rows"""
+        rows = np.zeros((len(images), self.max_boxes, 5), np.float32)
+        for b, (img, lab, d) in enumerate(zip(images, labels, draws)):
+            t = self.boxes(lab, tuple(img.shape[:2]), d)
+            box = t[:, :4].astype(np.float32)
+            keep = ((box[:, 2] - box[:, 0]) > 1e-5) & ((box[:, 3] - box[:, 1]) > 1e-5)
+            box, cls_ = box[keep][: self.max_boxes], t[keep, 4][: self.max_boxes]
+            n = len(box)
+            rows[b, :n, 0] = cls_
+            rows[b, :n, 1] = (box[:, 0] + box[:, 2]) / 2
+            rows[b, :n, 2] = (box[:, 1] + box[:, 3]) / 2
+            rows[b, :n, 3] = box[:, 2] - box[:, 0]
+            rows[b, :n, 4] = box[:, 3] - box[:, 1]
+        return rows
