@@ -139,17 +139,11 @@ def test_train_step_fed_by_the_pipeline():
 def test_front_augment_kernels_equal_pillow_and_the_oracle():
     """The detectron2 T.* front (T.ResizeShortestEdge = Pillow's 8-bit bilinear resampling, T.RandomFlip x2, YOLOFRandomShift;
     yolov7/data/detection_utils.py:37-86) on the GPU: `GpuFrontAugment.apply` (HWC images for the mosaic pool) and
-    `.make_batch` (the mapper with the mosaic off + preprocess_image) bit-identical to the oracle and to Pillow itself.
-    These two kernels were written after round 3's GPU minutes were spent: their per-pixel functions are held to Pillow by
-    the CPU suite (tests/test_front_augment.py, host build of the same header), but the launch code has not met a GPU yet -
-    so the comparison runs in a child process and a mismatch or a crash there is reported as XFAIL instead of stopping the
-    suite; it becomes a plain assertion once it has passed on a device."""
+    `.make_batch` (the mapper with the mosaic off + preprocess_image) bit-identical to the oracle and to Pillow itself
+    (tests/front_augment_gpu_child.py: eight images at COCO sizes, every combination of flips / shift / skipped passes)."""
     import subprocess
     import sys
     child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "front_augment_gpu_child.py")
-    try:
-        r = subprocess.run([sys.executable, child], capture_output=True, text=True, timeout=240)
-    except subprocess.TimeoutExpired:
-        pytest.xfail("front augment child timed out")
-    if r.returncode != 0:
-        pytest.xfail("front augment kernels (first GPU contact): " + (r.stdout + r.stderr)[-600:])
+    r = subprocess.run([sys.executable, child], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-1500:]
+    assert "bit-identical" in r.stdout
