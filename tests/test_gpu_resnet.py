@@ -267,3 +267,31 @@ def test_folded_frozen_norm_conv_equals_the_explicit_fold(k, stride, cin, cout, 
         res.append((out.detach().float(), xi.grad.float(), m.weight.grad.float().clone()))
     for a, b in zip(*res):
         assert torch.equal(a, b), float((a - b).abs().max())
+
+
+def test_trainable_layer_without_autograd_never_reuses_a_packed_image():
+    """Evaluation between training steps: a TRAINABLE Conv2d run under no_grad must see a weight update that bypasses torch's
+    version counter (mi_adamw_step_multi and the arena SGD write through raw pointers) - its packed image is never cached;
+    a FROZEN layer's is (same tensor object until its buffers or weight are written through torch)."""
+    from yolov7_d2_amd.modeling.resnet import Conv2d
+    if not hasattr(torch.autograd, "_unsafe_preserve_version_counter"):
+        pytest.skip("no torch.autograd._unsafe_preserve_version_counter in this torch")
+    torch.manual_seed(1)
+    m = Conv2d(64, 64, 3, padding=1).cuda()
+    x = torch.randn(2, 64, 16, 24).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y1 = m(x).float().clone()
+        with torch.autograd._unsafe_preserve_version_counter(m.weight):
+            m.weight.mul_(2.0)                                   # what an optimizer kernel does: no version bump
+        y2 = m(x).float().clone()
+        shift = m.norm.affine()[1].view(1, -1, 1, 1)
+        assert _rel(y2 - shift, 2.0 * (y1 - shift)) < 1e-2
+        assert "_image" not in m.__dict__
+        m.weight.requires_grad_(False)                           # frozen: cached, and refreshed when written through torch
+        y3 = m(x).float().clone()
+        assert "_image" in m.__dict__ and torch.equal(y3, y2)
+        img = m.__dict__["_image"][1]
+        assert m(x) is not None and m.__dict__["_image"][1] is img
+        m.weight.mul_(0.5)
+        y4 = m(x).float()
+        assert m.__dict__["_image"][1] is not img and _rel(y4 - shift, y1 - shift) < 1e-2

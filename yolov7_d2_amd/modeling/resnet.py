@@ -160,17 +160,23 @@ class Conv2d(nn.Module):
             return op(x, w, shift, self.stride, self.padding)
         train_w = self.weight.requires_grad and torch.is_grad_enabled()
         if not train_w and not (x.requires_grad and torch.is_grad_enabled()):
-            # a frozen layer under a frozen prefix (FREEZE_AT): its packed image is a constant too
             g = _ConvGeom(x.shape, self.weight.shape, self.stride, self.padding)
-            # (keyed on the identity + write counters of the weight and of the four norm buffers, not on the address of
-            #  `scale`: a recomputed scale may be handed the freed one's address)
-            key = (self.weight.data_ptr(), self.weight._version, self.norm.__dict__["_affine"][0])
-            c = self.__dict__.get("_image")
-            if c is None or c[0] != key:
-                with torch.no_grad():
-                    c = self.__dict__["_image"] = (key, g.pack(self.weight, dgrad=False, scale=scale)[0])
             with torch.no_grad():
-                return _folded_forward(g, x, c[1], shift, relu)[1]
+                if self.weight.requires_grad:
+                    # a TRAINABLE layer run without autograd (evaluation between training steps): packed per call - its
+                    # weight may have been updated by a kernel that torch's version counter does not see
+                    # (mi_adamw_step_multi, the arena SGD), so no key could tell a stale image from a fresh one
+                    wf = g.pack(self.weight, dgrad=False, scale=scale)[0]
+                else:
+                    # a frozen layer under a frozen prefix (FREEZE_AT): its packed image is a constant too.  Keyed on the
+                    # identity + write counters of the weight and of the four norm buffers (load_state_dict / .to() change
+                    # them), not on the address of `scale`: a recomputed scale may be handed the freed one's address
+                    key = (self.weight.data_ptr(), self.weight._version, self.norm.__dict__["_affine"][0])
+                    c = self.__dict__.get("_image")
+                    if c is None or c[0] != key:
+                        c = self.__dict__["_image"] = (key, g.pack(self.weight, dgrad=False, scale=scale)[0])
+                    wf = c[1]
+                return _folded_forward(g, x, wf, shift, relu)[1]
         return _FoldedConvFn.apply(x, self.weight, scale, shift, self.stride, self.padding, relu)
 
 
@@ -319,14 +325,18 @@ class BasicStem(nn.Module):
             return _StemFn.apply(s2d, w7, scale, shift).permute(0, 3, 1, 2)
         with torch.no_grad():       # frozen stem (FREEZE_AT >= 1): the packed image is a constant, kept across steps
             Cout = w7.shape[0]
-            key = (w7.data_ptr(), w7._version, self.conv1.norm.__dict__["_affine"][0])
+            # (a TRAINABLE stem run without autograd is packed per call: kernels that update weights bypass torch's
+            #  version counter, see Conv2d.forward)
+            key = None if w7.requires_grad else (w7.data_ptr(), w7._version, self.conv1.norm.__dict__["_affine"][0])
             c = self.__dict__.get("_image")
-            if c is None or c[0] != key:
+            if key is None or c is None or c[0] != key:
                 w4 = _w7_to_w4(w7 * scale.view(-1, 1, 1, 1)).contiguous()
                 wf = torch.empty(16 * 16 * Cout, dtype=torch.bfloat16, device=x.device)
                 L.check(L.lib().mi_pack_conv_weight(w4.data_ptr(), Cout, 4 * Cin, 4, 4, wf.data_ptr(), 16, Cout, None, 0, 0,
                                                     L.stream_ptr()), "mi_pack_conv_weight (stem)")
-                c = self.__dict__["_image"] = (key, wf)
+                c = (key, wf)
+                if key is not None:
+                    self.__dict__["_image"] = c
             Hh, Wh = He // 2, We // 2
             a = torch.empty(N, Hh, Wh, Cout, dtype=torch.bfloat16, device=x.device)
             _run_conv(_conv_desc(s2d.data_ptr(), 16, N, Hh, Wh, c[1], 16, a.data_ptr(), Cout, Hh, Wh, Cout, Cout, _STEM_TAPS,
