@@ -583,3 +583,45 @@ def filter_empty(boxes_xyxy, classes, threshold=1e-5):
     b = np.asarray(boxes_xyxy, np.float64).reshape(-1, 4).astype(np.float32)
     keep = ((b[:, 2] - b[:, 0]) > threshold) & ((b[:, 3] - b[:, 1]) > threshold)
     return b[keep], np.asarray(classes)[keep]
+
+
+# ------------------------------------------------------------------------------------------------ the whole mapper call
+def mapper_call(pool, cur, rng_np, rng_py, mcfg=None, front_kw=None, enable_mosaic=True, enable_aug=True, enable_mixup=False,
+                mscale=(0.5, 1.5), num_images=4, capacity=1000):
+    """MyDatasetMapper2.__call__ (dataset_mapper.py:477-640) for one dataset_dict: `pool` = the mosaic_pool deque as a list of
+    (image, labels) (mutated: the current entry is appended), cur = (HWC uint8 image, labels float64 [n, 5] xyxy + cls).
+    Returns (image, labels, mosaic?) - labels of a plain sample after filter_empty_instances, of a mosaic sample as
+    random_perspective / mixup leave them.  Every image is loaded through the T.* front (`_load_image_with_annos`)."""
+    mcfg = dict(MOSAIC_DEFAULTS, **(mcfg or {}))
+    front_kw = front_kw or {}
+    flag, partners = 0, None
+    if enable_mosaic and enable_aug:
+        if len(pool) > num_images:
+            flag = int(rng_np.randint(2))
+            if flag == 1:
+                partners = [pool[int(i)] for i in rng_np.choice(len(pool), num_images - 1)]
+        pool.append(cur)
+        if len(pool) > capacity:
+            pool.pop(0)
+
+    def load(entry):
+        img, lab = entry
+        lab = np.asarray(lab, np.float64).reshape(-1, 5)
+        d = draw_front(rng_np, img.shape[:2], **front_kw)
+        return front_image(img, d), np.concatenate([front_boxes(lab[:, :4], img.shape[:2], d), lab[:, 4:5]], 1)
+    img, lab = load(cur)
+    if flag == 1 and partners is not None:
+        input_dim, yc, xc, draws = draw_mosaic_params(rng_np, rng_py, mcfg)
+        loaded = [(img, lab)] + [load(e) for e in partners]
+        out, t = mosaic_sample([x[0] for x in loaded], [x[1] for x in loaded], input_dim, yc, xc, draws)
+        if enable_mixup and len(t):
+            jit = rng_py.uniform(*mscale)
+            flip = rng_py.uniform(0, 1) > 0.5
+            cp_img, cp_lab = load(pool[int(rng_np.choice(len(pool), 1)[0])])
+            xm, ym = mixup_offsets_range(cp_img.shape[:2], input_dim, jit, out.shape[:2])
+            y_off = rng_py.randint(0, ym) if ym is not None else 0
+            x_off = rng_py.randint(0, xm) if xm is not None else 0
+            out, t = mixup(out, t, cp_img, cp_lab, input_dim, jit, flip, (x_off, y_off))
+        return out, np.asarray(t, np.float64).reshape(-1, 5), True
+    box, cls_ = filter_empty(lab[:, :4], lab[:, 4])
+    return img, np.concatenate([box.astype(np.float64), np.asarray(cls_, np.float64)[:, None]], 1), False

@@ -465,3 +465,169 @@ class GpuFrontAugment:
             rows[b, :n, 3] = box[:, 2] - box[:, 0]
             rows[b, :n, 4] = box[:, 3] - box[:, 1]
         return rows
+
+
+# ------------------------------------------------------------------------------------------------ the whole mapper
+class _PoolView:
+    """what GpuMosaicMapper.make_batch reads of a pool: `images` (device uint8 HWC) and `labels` (float64 [n, 5])"""
+
+    def __init__(self):
+        self.images, self.labels = [], []
+
+    def add(self, image, labels):
+        self.images.append(image)
+        self.labels.append(labels)
+        return len(self.images) - 1
+
+    def __len__(self):
+        return len(self.images)
+
+
+class GpuDatasetMapper:
+    """`MyDatasetMapper2.__call__` (yolov7/data/dataset_mapper.py:477-640) for a batch of decoded images, one call per
+    training batch instead of one per image on a CPU worker:
+
+      per sample, in the reference's order - mosaic_flag = np.random.randint(2) once the pool holds more than NUM_IMAGES
+      entries, the three partners by np.random.choice over the pool, the sample appended to the pool; the T.* front on the
+      current image; with the flag set: the mosaic size / centre draws, the front on each partner as it is loaded, the four
+      pastes, random_perspective, and (ENABLE_MIXUP, only when labels survived) mixup with one more pool image, itself
+      loaded through the front; without the flag: Instances of the fronted image, empty boxes dropped;
+      then YOLOX.preprocess_image's pad-to-batch and label rows over the MIXED batch (both kinds of sample, as the
+      reference's loader collates them).
+
+    The host draws every random number from the two streams the reference uses (numpy's and Python's `random`) in the
+    reference's order and does its float64 label arithmetic; the pixels are the launches of GpuFrontAugment (one pair for all
+    loads of the batch) and GpuMosaicMapper (paste, warp, mixup), the mixed batch is assembled on the device.  `enable_aug`
+    False = `MyDatasetMapper2.disable_aug()` (after DISABLE_AT_ITER): the front only.  Not built: image decoding, the colour
+    entries of the augmentation list (see GpuFrontAugment)."""
+
+    def __init__(self, mosaic_cfg=None, front_cfg=None, device="cuda", enable_mosaic=True, enable_mixup=False, pool_capacity=1000,
+                 max_boxes=100, pad_value=114, size_divisibility=32):
+        self.device = torch.device(device)
+        self.front = GpuFrontAugment(front_cfg, device, max_boxes, pad_value, size_divisibility)
+        self.mosaic = GpuMosaicMapper(mosaic_cfg, device, max_boxes, pad_value, size_divisibility)
+        self.pool = MosaicPool(device, pool_capacity)
+        self.enable_mosaic, self.enable_mixup, self.enable_aug = enable_mosaic, enable_mixup, True
+        self.max_boxes, self.pad, self.divis = max_boxes, pad_value, size_divisibility
+
+    def disable_aug(self):
+        self.enable_aug = False
+
+    @staticmethod
+    def _mosaic_labels(shapes, labels, p):
+        """dataset_mapper.py:537-590 for the labels: the four images' rows scaled by their resize factor, shifted to their
+        quadrant and clipped to the 2x canvas (shapes = the (h, w) of the four LOADED images)"""
+        dim, yc, xc = p["input_dim"], p["yc"], p["xc"]
+        labels4 = []
+        for i, ((h0, w0), lab) in enumerate(zip(shapes, labels)):
+            scale = min(1. * dim[0] / h0, 1. * dim[1] / w0)
+            w, h = int(w0 * scale), int(h0 * scale)
+            (x1a, y1a, _x2a, _y2a), (x1b, y1b) = GpuMosaicMapper._placement(i, w, h, xc, yc, dim)
+            if lab.size > 0:
+                t = lab.copy()
+                padw, padh = x1a - x1b, y1a - y1b
+                t[:, 0] = scale * lab[:, 0] + padw
+                t[:, 1] = scale * lab[:, 1] + padh
+                t[:, 2] = scale * lab[:, 2] + padw
+                t[:, 3] = scale * lab[:, 3] + padh
+                labels4.append(t)
+        if not labels4:
+            return np.zeros((0, 5))
+        labels4 = np.concatenate(labels4, 0)
+        np.clip(labels4[:, 0], 0, 2 * dim[1], out=labels4[:, 0])
+        np.clip(labels4[:, 1], 0, 2 * dim[0], out=labels4[:, 1])
+        np.clip(labels4[:, 2], 0, 2 * dim[1], out=labels4[:, 2])
+        np.clip(labels4[:, 3], 0, 2 * dim[0], out=labels4[:, 3])
+        return labels4
+
+    def plan(self, image, labels, rng_np=np.random, rng_py=random):
+        """the host half of one `__call__`: appends (image, labels) to the pool and returns the sample's plan -
+        loads = [(pool image, its labels, its front draw)] (the current image first), and for a mosaic sample the mosaic
+        draws and the mixup draw (or None)"""
+        pool = self.pool
+        flag, partners = 0, None
+        if self.enable_mosaic and self.enable_aug and len(pool) > self.mosaic.cfg["NUM_IMAGES"]:
+            flag = int(rng_np.randint(2))
+            if flag == 1:
+                partners = [int(i) for i in rng_np.choice(len(pool), self.mosaic.cfg["NUM_IMAGES"] - 1)]
+                partners = [(pool.images[i], pool.labels[i]) for i in partners]      # (the entries, not their positions)
+        if self.enable_mosaic and self.enable_aug:
+            pool.append(image, labels)
+            cur = (pool.images[-1], pool.labels[-1])
+        else:
+            img = torch.as_tensor(image)
+            cur = (img.to(self.device).contiguous(), np.asarray(labels, np.float64).reshape(-1, 5))
+
+        def load(entry):
+            img, lab = entry
+            return (img, lab, self.front.draw(tuple(img.shape[:2]), rng_np))
+        plan = dict(mosaic=False, loads=[load(cur)], params=None, mixup=None)
+        if not (flag == 1 and partners is not None):
+            return plan
+        plan["mosaic"] = True
+        p = plan["params"] = self.mosaic.draw(rng_np, rng_py)           # (w, h from numpy's stream BEFORE the partners load)
+        plan["loads"] += [load(e) for e in partners]
+        if self.enable_mixup:
+            shapes = [(d["nh"], d["nw"]) for (_, _, d) in plan["loads"]]
+            labs = [self.front.boxes(lab, tuple(img.shape[:2]), d) for (img, lab, d) in plan["loads"]]
+            dim = p["input_dim"]
+            M, width, height = self.mosaic._matrix((dim[0] * 2, dim[1] * 2), p["draws"], [-dim[0] // 2, -dim[1] // 2])
+            t = self.mosaic._warp_labels(self._mosaic_labels(shapes, labs, p), M, p["draws"][1], width, height)
+            if len(t):                                                  # dataset_mapper.py:602
+                jit = rng_py.uniform(*self.mosaic.cfg["MSCALE"])
+                flip = rng_py.uniform(0, 1) > 0.5
+                idx = int(rng_np.choice(len(pool), 1)[0])
+                plan["loads"].append(load((pool.images[idx], pool.labels[idx])))
+                oh, ow = int(dim[0] * jit), int(dim[1] * jit)
+                ph, pw = max(oh, height), max(ow, width)
+                y_off = rng_py.randint(0, ph - height - 1) if ph > height else 0
+                x_off = rng_py.randint(0, pw - width - 1) if pw > width else 0
+                plan["mixup"] = dict(jit=jit, flip=bool(flip), x_off=x_off, y_off=y_off)
+        return plan
+
+    def make_batch(self, samples, rng_np=np.random, rng_py=random):
+        """samples: [(uint8 HWC image (numpy / tensor, host or device), labels float64 [n, 5] (x1, y1, x2, y2, cls))].
+        Returns (uint8 [B, 3, Hp, Wp], float32 [B, max_boxes, 5] rows (cls, cx, cy, w, h), per-sample (h, w)) on the device -
+        what NativeTrainer.load_batch / feed take."""
+        if self.device.type != "cuda":
+            raise L.MI355Error("GpuDatasetMapper: the MI355X path needs a device (no CPU pixel path)")
+        plans = [self.plan(img, lab, rng_np, rng_py) for img, lab in samples]
+        return self.run(plans)
+
+    def run(self, plans):
+        B = len(plans)
+        plain = [b for b, p in enumerate(plans) if not p["mosaic"]]
+        mos = [b for b, p in enumerate(plans) if p["mosaic"]]
+        parts = {}
+        if plain:
+            imgs = [plans[b]["loads"][0][0] for b in plain]
+            out, rows, sizes = self.front.make_batch(imgs, [plans[b]["loads"][0][1] for b in plain], [plans[b]["loads"][0][2] for b in plain])
+            for k, b in enumerate(plain):
+                parts[b] = (out[k], rows[k], sizes[k])
+        if mos:
+            loads = [ld for b in mos for ld in plans[b]["loads"]]
+            fronted = self.front.apply([ld[0] for ld in loads], [ld[2] for ld in loads])
+            view, groups, params, mixups, k = _PoolView(), [], [], [], 0
+            for b in mos:
+                p = plans[b]
+                ids = []
+                for (img, lab, d) in p["loads"]:
+                    ids.append(view.add(fronted[k], self.front.boxes(lab, tuple(img.shape[:2]), d)))
+                    k += 1
+                groups.append(tuple(ids[:4]))
+                params.append(p["params"])
+                mixups.append(dict(p["mixup"], idx=ids[4]) if p["mixup"] is not None else None)
+            out, rows, sizes = self.mosaic.make_batch(view, groups, params, mixups if any(m is not None for m in mixups) else None)
+            for k, b in enumerate(mos):
+                parts[b] = (out[k], rows[k], sizes[k])
+        if not plain or not mos:                                   # one kind of sample only: that launch's batch is the batch
+            return out, rows, [parts[b][2] for b in range(B)]
+        Hp = max(parts[b][0].shape[1] for b in range(B))
+        Wp = max(parts[b][0].shape[2] for b in range(B))
+        batch = torch.full((B, 3, Hp, Wp), self.pad, dtype=torch.uint8, device=self.device)
+        rows_all = torch.zeros(B, self.max_boxes, 5, dtype=torch.float32, device=self.device)
+        for b in range(B):
+            img, r, _ = parts[b]
+            batch[b, :, : img.shape[1], : img.shape[2]] = img      # (each part is padded with 114 beyond its own size already)
+            rows_all[b] = r
+        return batch, rows_all, [parts[b][2] for b in range(B)]
