@@ -604,6 +604,48 @@ int mi_pil_resize_jobs_layout(mi_pil_resize_job* jobs_host, int njobs, int32_t* 
 int mi_pil_resize_h(const mi_pil_resize_job* jobs_dev, int njobs, int total_blocks, mi_stream_t s);
 int mi_pil_resize_v(const mi_pil_resize_job* jobs_dev, int njobs, int total_blocks, mi_stream_t s);
 
+/* ---- image decoding of the input pipeline: baseline JPEG ---------------------------------------------------------
+ * What detectron2's utils.read_image(file, format="BGR") does for MyDatasetMapper2._load_image_with_annos
+ * (yolov7/data/dataset_mapper.py:646-648; d2 un-vendored): PIL.Image.open -> EXIF orientation -> convert("RGB") -> BGR,
+ * i.e. Pillow's libjpeg(-turbo) defaults - sequential Huffman decoding (jdhuff.c), JDCT_ISLOW (jidctint.c), fancy
+ * up-sampling (jdsample.c), YCbCr -> RGB (jdcolor.c).  Served: SOF0 / SOF1 Huffman, 8 bit, grey or three components in one
+ * interleaved scan, sampling factors 1 or 2 (4:4:4, 4:2:2, 4:2:0, 4:4:0), restart intervals, Adobe transform 0, EXIF
+ * orientations 1-8.  Refused with MI_EINVAL: progressive / lossless / arithmetic-coded / 12-bit / CMYK files.
+ * HOST functions (no GPU needed): mi_jpeg_parse reads the markers up to the scan; mi_jpeg_huffman decodes the entropy-coded
+ * data into int16 coefficient blocks (natural order, not de-quantised; info->coef_count values, component c's blocks_h[c] x
+ * blocks_w[c] blocks of 64 from coef_off[c]) - the caller copies them to the device; mi_jpeg_job_fill builds one image's
+ * device job (planes: sum over components of blocks * 64 bytes of scratch; out: HWC uint8 [h][w][3], h and w swapped for
+ * orientations 5-8 when apply_orientation); mi_jpeg_jobs_layout lays a batch out.  DEVICE: mi_jpeg_idct (one thread per
+ * 8x8 block), then mi_jpeg_color (one thread per output pixel), over the device copy of the job table. */
+typedef struct mi_jpeg_info {
+  int32_t width, height, ncomp, restart_interval, orientation, adobe_transform;   /* adobe_transform -1: no Adobe marker */
+  int32_t hs[3], vs[3], tq[3], td[3], ta[3];
+  int32_t hmax, vmax, mcu_w, mcu_h;
+  int32_t blocks_w[3], blocks_h[3];
+  int64_t coef_off[3], coef_count, scan_start;
+  uint16_t qt[4][64];                  /* natural (row-major) order */
+  uint8_t dc_bits[4][17], dc_vals[4][256], ac_bits[4][17], ac_vals[4][256];
+  uint8_t have_qt[4], have_dc[4], have_ac[4], pad_[4];
+} mi_jpeg_info;
+typedef struct mi_jpeg_job {
+  const int16_t* coef;
+  void* planes;
+  void* out;
+  int64_t coef_off[3], plane_off[3];
+  int32_t width, height, ncomp, orientation, bgr, ycc;
+  int32_t hs[3], vs[3], blocks_w[3], blocks_h[3];
+  int32_t hmax, vmax;
+  int32_t blk0_idct, blk0_pix;
+  uint16_t qt[3][64];
+} mi_jpeg_job;
+int mi_jpeg_parse(const uint8_t* data, int64_t len, mi_jpeg_info* info);
+int mi_jpeg_huffman(const uint8_t* data, int64_t len, const mi_jpeg_info* info, int16_t* coef_host);
+int mi_jpeg_job_fill(const mi_jpeg_info* info, const void* coef_dev, void* planes_dev, void* out_dev, int bgr,
+                     int apply_orientation, mi_jpeg_job* job);
+int mi_jpeg_jobs_layout(mi_jpeg_job* jobs_host, int njobs, int32_t* blocks_idct, int32_t* blocks_pix);
+int mi_jpeg_idct(const mi_jpeg_job* jobs_dev, int njobs, int total_blocks, mi_stream_t s);
+int mi_jpeg_color(const mi_jpeg_job* jobs_dev, int njobs, int total_blocks, mi_stream_t s);
+
 /* ---- COCO run-length encoding of masks (evaluation output format) ----------------------
  * what pycocotools.mask.encode does for instances_to_coco_json (evaluation/coco_evaluation.py:38-50; the algorithm is
  * cocoapi's maskApi.c rleEncode / rleToString, un-vendored): masks uint8 [n][H][W] (device, non-zero = foreground) ->
@@ -708,7 +750,7 @@ int mi_box_iou_pairwise(const float* boxes1, int n, const float* boxes2, int m, 
 
 /* sizeof() of the public structs as compiled into the library (binding self-check): 0 mi_conv_desc, 1 mi_wgrad_desc,
  * 2 mi_wgrad_group, 3 mi_pack_job, 4 mi_bias_job, 5 mi_yolox_loss_desc, 6 mi_detr_loss_desc, 7 mi_sgd_seg, 8 mi_cmd,
- * 9 mi_conv_group, 10 mi_bn_job, 11 mi_bn_group, 12 mi_pil_resize_job; -1 for an unknown id */
+ * 9 mi_conv_group, 10 mi_bn_job, 11 mi_bn_group, 12 mi_pil_resize_job, 13 mi_jpeg_info, 14 mi_jpeg_job; -1 for an unknown id */
 int mi_abi_sizeof(int which);
 
 /* ---- command list executor -----------------------------------------------------

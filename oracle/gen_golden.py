@@ -381,6 +381,42 @@ def gold_pil_resize():
     np.savez_compressed(os.path.join(OUT, "pil_resize.npz"), **res)
 
 
+def gold_jpeg():
+    """JPEG files written AND decoded by the Pillow of this image (libjpeg-turbo underneath): what detectron2's
+    utils.read_image hands the reference's mapper (data/dataset_mapper.py:646-648) - `rgb` = Image.open(f).convert("RGB"),
+    `bgr` = the same after the EXIF transpose, channels reversed (read_image(..., format="BGR")).  Qualities, chroma
+    sub-samplings, a grey file, optimised Huffman tables, restart intervals, EXIF orientations 3 / 6 / 8."""
+    import io
+    import PIL
+    from PIL import Image, ImageOps
+    r = np.random.RandomState(123)
+
+    def smooth(h, w):
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = np.stack([127 + 100 * np.sin(xx / 9.0 + yy / 17.0), 127 + 100 * np.cos(xx / 13.0), 127 + 100 * np.sin(yy / 7.0)], -1)
+        return np.clip(base + r.randint(-20, 21, (h, w, 3)), 0, 255).astype(np.uint8)
+    specs = [((48, 64), dict(quality=75, subsampling=2)), ((33, 47), dict(quality=90, subsampling=1)), ((40, 40), dict(quality=50, subsampling=0)),
+             ((17, 23), dict(quality=95, subsampling=2)), ((64, 96), dict(quality=85, subsampling=2, optimize=True)),
+             ((64, 96), dict(quality=85, subsampling=2, restart_marker_blocks=3)), ((50, 3), dict(quality=80, subsampling=2)),
+             ((40, 60), "grey"), ((40, 56), 3), ((40, 56), 6), ((40, 56), 8), ((96, 128), dict(quality=92, subsampling=2))]
+    res = {"pil_version": np.array(PIL.__version__)}
+    for k, ((h, w), kw) in enumerate(specs):
+        buf = io.BytesIO()
+        if kw == "grey":
+            Image.fromarray(smooth(h, w)[..., 0]).save(buf, format="JPEG", quality=80)
+        elif isinstance(kw, int):
+            ex = Image.Exif()
+            ex[0x0112] = kw
+            Image.fromarray(smooth(h, w)).save(buf, format="JPEG", quality=90, exif=ex.tobytes())
+        else:
+            Image.fromarray(smooth(h, w)).save(buf, format="JPEG", **kw)
+        data = buf.getvalue()
+        res[f"file{k}"] = np.frombuffer(data, np.uint8)
+        res[f"rgb{k}"] = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+        res[f"bgr{k}"] = np.ascontiguousarray(np.asarray(ImageOps.exif_transpose(Image.open(io.BytesIO(data))).convert("RGB"))[:, :, ::-1])
+    np.savez_compressed(os.path.join(OUT, "jpeg_decode.npz"), **res)
+
+
 def gold_bifpn():
     """the reference's BiFPN (neck/bifpn.py:307-395) over seeded C3..C5 maps, fp32: p3..p7, the gradients with respect to
     the inputs, every edge weight / GroupNorm parameter, and two convolution weights; dense and separable variants"""
@@ -863,6 +899,7 @@ if __name__ == "__main__":
     gold_bifpn()
     gold_random_perspective()
     gold_pil_resize()
+    gold_jpeg()
     gold_encoder_layer()
     gold_transformer()
     gold_pos_embed()

@@ -162,6 +162,24 @@ class mi_pil_resize_job(C.Structure):
                 [(n, C.c_int32) for n in ("h0", "w0", "nh", "nw", "hflip", "vflip", "shift_x", "shift_y", "blk0h", "blk0v")])
 
 
+class mi_jpeg_info(C.Structure):
+    _fields_ = ([(n, C.c_int32) for n in ("width", "height", "ncomp", "restart_interval", "orientation", "adobe_transform")] +
+                [(n, C.c_int32 * 3) for n in ("hs", "vs", "tq", "td", "ta")] +
+                [(n, C.c_int32) for n in ("hmax", "vmax", "mcu_w", "mcu_h")] +
+                [("blocks_w", C.c_int32 * 3), ("blocks_h", C.c_int32 * 3), ("coef_off", C.c_int64 * 3), ("coef_count", C.c_int64),
+                 ("scan_start", C.c_int64), ("qt", (C.c_uint16 * 64) * 4), ("dc_bits", (C.c_uint8 * 17) * 4),
+                 ("dc_vals", (C.c_uint8 * 256) * 4), ("ac_bits", (C.c_uint8 * 17) * 4), ("ac_vals", (C.c_uint8 * 256) * 4),
+                 ("have_qt", C.c_uint8 * 4), ("have_dc", C.c_uint8 * 4), ("have_ac", C.c_uint8 * 4), ("pad_", C.c_uint8 * 4)])
+
+
+class mi_jpeg_job(C.Structure):
+    _fields_ = ([("coef", C.c_void_p), ("planes", C.c_void_p), ("out", C.c_void_p), ("coef_off", C.c_int64 * 3),
+                 ("plane_off", C.c_int64 * 3)] +
+                [(n, C.c_int32) for n in ("width", "height", "ncomp", "orientation", "bgr", "ycc")] +
+                [(n, C.c_int32 * 3) for n in ("hs", "vs", "blocks_w", "blocks_h")] +
+                [(n, C.c_int32) for n in ("hmax", "vmax", "blk0_idct", "blk0_pix")] + [("qt", (C.c_uint16 * 64) * 3)])
+
+
 class mi_cmd(C.Structure):
     _fields_ = [("op", C.c_int32), ("i", C.c_int32 * 40), ("f", C.c_float * 8), ("p", C.c_void_p * 16),
                 ("l", C.c_int64 * 4)]
@@ -258,6 +276,12 @@ _PROTOS = {
     "mi_pil_resize_jobs_layout": (C.c_int, [C.POINTER(mi_pil_resize_job), _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mi_pil_resize_h": (C.c_int, [_vp, _i, _i, _vp]),
     "mi_pil_resize_v": (C.c_int, [_vp, _i, _i, _vp]),
+    "mi_jpeg_parse": (C.c_int, [_vp, C.c_int64, C.POINTER(mi_jpeg_info)]),
+    "mi_jpeg_huffman": (C.c_int, [_vp, C.c_int64, C.POINTER(mi_jpeg_info), _vp]),
+    "mi_jpeg_job_fill": (C.c_int, [C.POINTER(mi_jpeg_info), _vp, _vp, _vp, _i, _i, C.POINTER(mi_jpeg_job)]),
+    "mi_jpeg_jobs_layout": (C.c_int, [C.POINTER(mi_jpeg_job), _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "mi_jpeg_idct": (C.c_int, [_vp, _i, _i, _vp]),
+    "mi_jpeg_color": (C.c_int, [_vp, _i, _i, _vp]),
     "mi_rle_encode": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mi_rle_to_string": (C.c_int, [_vp, _i, C.c_char_p, _i]),
     "mi_yolox_onnx_layout": (C.c_int, [_vp, _vp, _i, _i, _i, _vp]),

@@ -286,7 +286,7 @@ extern "C" int mi_probe_mfma16(const void* a, const void* b, float* d, mi_stream
 
 // sizeof() of every public struct, so that a binding (ctypes, cgo, JNI ...) can verify its own layout against the
 // library it loaded: 0 mi_conv_desc, 1 mi_wgrad_desc, 2 mi_wgrad_group, 3 mi_pack_job, 4 mi_bias_job,
-// 5 mi_yolox_loss_desc, 6 mi_detr_loss_desc, 7 mi_sgd_seg, 8 mi_cmd, 9 mi_conv_group, 10 mi_bn_job, 11 mi_bn_group, 12 mi_pil_resize_job
+// 5 mi_yolox_loss_desc, 6 mi_detr_loss_desc, 7 mi_sgd_seg, 8 mi_cmd, 9 mi_conv_group, 10 mi_bn_job, 11 mi_bn_group, 12 mi_pil_resize_job, 13 mi_jpeg_info, 14 mi_jpeg_job
 extern "C" int mi_abi_sizeof(int which) {
   switch (which) {
     case 0: return (int)sizeof(mi_conv_desc);
@@ -302,6 +302,8 @@ extern "C" int mi_abi_sizeof(int which) {
     case 10: return (int)sizeof(mi_bn_job);
     case 11: return (int)sizeof(mi_bn_group);
     case 12: return (int)sizeof(mi_pil_resize_job);
+    case 13: return (int)sizeof(mi_jpeg_info);
+    case 14: return (int)sizeof(mi_jpeg_job);
   }
   return -1;
 }

@@ -631,3 +631,81 @@ class GpuDatasetMapper:
             batch[b, :, : img.shape[1], : img.shape[2]] = img      # (each part is padded with 114 beyond its own size already)
             rows_all[b] = r
         return batch, rows_all, [parts[b][2] for b in range(B)]
+
+
+# ------------------------------------------------------------------------------------------------ image decoding
+class GpuJpegDecoder:
+    """detectron2 `utils.read_image(file_name, format)` - the first thing `MyDatasetMapper2._load_image_with_annos` does
+    (yolov7/data/dataset_mapper.py:646-648; d2 un-vendored: PIL.Image.open -> EXIF orientation -> convert("RGB") -> channel
+    order) - for a BATCH of baseline JPEG files: the sequential Huffman decoding runs on host threads inside the library
+    (`mi_jpeg_parse`, `mi_jpeg_huffman`; ctypes drops the GIL), the coefficient blocks go to the device in one pinned copy,
+    and two launches do the rest for all images (de-quantisation + libjpeg's ISLOW IDCT per block; fancy chroma up-sampling,
+    YCbCr -> RGB, EXIF transpose and channel order per pixel).  Bit-identical to Pillow's decode.  Progressive, arithmetic-
+    coded, 12-bit and CMYK files raise MI355Error (there is no CPU decoder to fall back to)."""
+
+    def __init__(self, device="cuda", format="BGR", apply_orientation=True, workers=8):      # noqa: A002 (d2's argument name)
+        if format not in ("BGR", "RGB"):
+            raise ValueError("GpuJpegDecoder: format BGR (the reference's INPUT.FORMAT default) or RGB")
+        self.device, self.bgr, self.orient, self.workers = torch.device(device), format == "BGR", bool(apply_orientation), workers
+
+    def _host_half(self, files, alloc):
+        """parse every file, decode the entropy-coded data on host threads into ONE int16 buffer.  alloc(count) ->
+        (owner, address) of that buffer.  Returns (infos, offsets of each file's coefficients in the buffer, owner)"""
+        lib = L.lib()
+        n = len(files)
+        bufs = [(C.c_uint8 * len(f)).from_buffer_copy(f) for f in files]
+        infos = [L.mi_jpeg_info() for _ in range(n)]
+        for k in range(n):
+            L.check(lib.mi_jpeg_parse(bufs[k], len(files[k]), C.byref(infos[k])), f"mi_jpeg_parse (file {k})")
+        offs = np.concatenate([[0], np.cumsum([i.coef_count for i in infos])]).astype(np.int64)
+        host, base = alloc(int(offs[-1]))
+
+        def huff(k):
+            return lib.mi_jpeg_huffman(bufs[k], len(files[k]), C.byref(infos[k]), C.c_void_p(base + 2 * int(offs[k])))
+        if self.workers > 1 and n > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(min(self.workers, n)) as ex:
+                rcs = list(ex.map(huff, range(n)))
+        else:
+            rcs = [huff(k) for k in range(n)]
+        for k, rc in enumerate(rcs):
+            L.check(rc, f"mi_jpeg_huffman (file {k})")
+        return infos, offs, host
+
+    def out_shape(self, info):
+        tr = self.orient and info.orientation >= 5
+        return (info.width, info.height) if tr else (info.height, info.width)
+
+    def _jobs(self, infos, offs, coef_ptr, planes_ptr, out_ptrs):
+        """the job table of a batch (addresses of the coefficient buffer, the plane scratch and each output) + block counts"""
+        lib = L.lib()
+        n = len(infos)
+        jobs = (L.mi_jpeg_job * n)()
+        for k, info in enumerate(infos):
+            L.check(lib.mi_jpeg_job_fill(C.byref(info), coef_ptr + 2 * int(offs[k]), planes_ptr + int(offs[k]), out_ptrs[k],
+                                         int(self.bgr), int(self.orient), C.byref(jobs[k])), "mi_jpeg_job_fill")
+        bi, bp = C.c_int32(0), C.c_int32(0)
+        L.check(lib.mi_jpeg_jobs_layout(jobs, n, C.byref(bi), C.byref(bp)), "mi_jpeg_jobs_layout")
+        return jobs, bi.value, bp.value
+
+    def decode(self, files):
+        """files: bytes-like JPEG files.  Returns device uint8 [H, W, 3] tensors (H, W after the EXIF transpose)."""
+        if self.device.type != "cuda":
+            raise L.MI355Error("GpuJpegDecoder: the MI355X path needs a device (no CPU decode)")
+        lib = L.lib()
+
+        def pinned(count):
+            t = torch.empty(count, dtype=torch.int16, pin_memory=True)
+            return t, t.data_ptr()
+        infos, offs, host = self._host_half(files, pinned)
+        total = int(offs[-1])
+        coef = host.to(self.device, non_blocking=True)
+        planes = torch.empty(total, dtype=torch.uint8, device=self.device)
+        outs = [torch.empty(*self.out_shape(i), 3, dtype=torch.uint8, device=self.device) for i in infos]
+        jobs, bi, bp = self._jobs(infos, offs, coef.data_ptr(), planes.data_ptr(), [o.data_ptr() for o in outs])
+        tab = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(self.device)
+        st = L.stream_ptr()
+        L.check(lib.mi_jpeg_idct(tab.data_ptr(), len(files), bi, st), "mi_jpeg_idct")
+        L.check(lib.mi_jpeg_color(tab.data_ptr(), len(files), bp, st), "mi_jpeg_color")
+        self._keep = (host, coef, planes, tab)                      # alive until the stream has run the copy and the launches
+        return outs
