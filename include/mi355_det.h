@@ -608,23 +608,25 @@ int mi_pil_resize_v(const mi_pil_resize_job* jobs_dev, int njobs, int total_bloc
  * What detectron2's utils.read_image(file, format="BGR") does for MyDatasetMapper2._load_image_with_annos
  * (yolov7/data/dataset_mapper.py:646-648; d2 un-vendored): PIL.Image.open -> EXIF orientation -> convert("RGB") -> BGR,
  * i.e. Pillow's libjpeg(-turbo) defaults - sequential Huffman decoding (jdhuff.c), JDCT_ISLOW (jidctint.c), fancy
- * up-sampling (jdsample.c), YCbCr -> RGB (jdcolor.c).  Served: SOF0 / SOF1 Huffman, 8 bit, grey or three components in one
- * interleaved scan, sampling factors 1 or 2 (4:4:4, 4:2:2, 4:2:0, 4:4:0), restart intervals, Adobe transform 0, EXIF
- * orientations 1-8.  Refused with MI_EINVAL: progressive / lossless / arithmetic-coded / 12-bit / CMYK files.
- * HOST functions (no GPU needed): mi_jpeg_parse reads the markers up to the scan; mi_jpeg_huffman decodes the entropy-coded
- * data into int16 coefficient blocks (natural order, not de-quantised; info->coef_count values, component c's blocks_h[c] x
+ * up-sampling (jdsample.c), YCbCr -> RGB (jdcolor.c).  Served: SOF0 / SOF1 sequential and SOF2 progressive Huffman files
+ * (jdphuff.c; any scan script, tables redefined between scans), 8 bit, grey or three components, sampling factors 1 or 2
+ * (4:4:4, 4:2:2, 4:2:0, 4:4:0), restart intervals, Adobe transform 0, EXIF orientations 1-8.  Refused with MI_EINVAL:
+ * lossless / hierarchical / arithmetic-coded / 12-bit / CMYK files.
+ * HOST functions (no GPU needed): mi_jpeg_parse reads the markers up to the first scan; mi_jpeg_huffman decodes every scan's
+ * entropy-coded data into int16 coefficient blocks (natural order, not de-quantised; info->coef_count values, component c's blocks_h[c] x
  * blocks_w[c] blocks of 64 from coef_off[c]) - the caller copies them to the device; mi_jpeg_job_fill builds one image's
  * device job (planes: sum over components of blocks * 64 bytes of scratch; out: HWC uint8 [h][w][3], h and w swapped for
  * orientations 5-8 when apply_orientation); mi_jpeg_jobs_layout lays a batch out.  DEVICE: mi_jpeg_idct (one thread per
  * 8x8 block), then mi_jpeg_color (one thread per output pixel), over the device copy of the job table. */
 typedef struct mi_jpeg_info {
   int32_t width, height, ncomp, restart_interval, orientation, adobe_transform;   /* adobe_transform -1: no Adobe marker */
-  int32_t hs[3], vs[3], tq[3], td[3], ta[3];
+  int32_t progressive, pad0_;
+  int32_t comp_id[3], hs[3], vs[3], tq[3];
   int32_t hmax, vmax, mcu_w, mcu_h;
   int32_t blocks_w[3], blocks_h[3];
-  int64_t coef_off[3], coef_count, scan_start;
+  int64_t coef_off[3], coef_count, sos_pos;   /* sos_pos: offset of the first SOS segment's length field */
   uint16_t qt[4][64];                  /* natural (row-major) order */
-  uint8_t dc_bits[4][17], dc_vals[4][256], ac_bits[4][17], ac_vals[4][256];
+  uint8_t dc_bits[4][17], dc_vals[4][256], ac_bits[4][17], ac_vals[4][256];     /* the tables defined before the first scan */
   uint8_t have_qt[4], have_dc[4], have_ac[4], pad_[4];
 } mi_jpeg_info;
 typedef struct mi_jpeg_job {

@@ -385,7 +385,7 @@ def gold_jpeg():
     """JPEG files written AND decoded by the Pillow of this image (libjpeg-turbo underneath): what detectron2's
     utils.read_image hands the reference's mapper (data/dataset_mapper.py:646-648) - `rgb` = Image.open(f).convert("RGB"),
     `bgr` = the same after the EXIF transpose, channels reversed (read_image(..., format="BGR")).  Qualities, chroma
-    sub-samplings, a grey file, optimised Huffman tables, restart intervals, EXIF orientations 3 / 6 / 8."""
+    sub-samplings, a grey file, optimised Huffman tables, restart intervals, EXIF orientations 3 / 6 / 8, two progressive files."""
     import io
     import PIL
     from PIL import Image, ImageOps
@@ -398,7 +398,8 @@ def gold_jpeg():
     specs = [((48, 64), dict(quality=75, subsampling=2)), ((33, 47), dict(quality=90, subsampling=1)), ((40, 40), dict(quality=50, subsampling=0)),
              ((17, 23), dict(quality=95, subsampling=2)), ((64, 96), dict(quality=85, subsampling=2, optimize=True)),
              ((64, 96), dict(quality=85, subsampling=2, restart_marker_blocks=3)), ((50, 3), dict(quality=80, subsampling=2)),
-             ((40, 60), "grey"), ((40, 56), 3), ((40, 56), 6), ((40, 56), 8), ((96, 128), dict(quality=92, subsampling=2))]
+             ((40, 60), "grey"), ((40, 56), 3), ((40, 56), 6), ((40, 56), 8), ((96, 128), dict(quality=92, subsampling=2)),
+             ((64, 96), dict(quality=85, subsampling=2, progressive=True)), ((33, 47), dict(quality=60, subsampling=0, progressive=True))]
     res = {"pil_version": np.array(PIL.__version__)}
     for k, ((h, w), kw) in enumerate(specs):
         buf = io.BytesIO()

@@ -6,11 +6,11 @@
 
 Pillow decodes through libjpeg(-turbo) with its defaults: JDCT_ISLOW, fancy up-sampling, no colour quantisation.  This file
 restates that pipeline from the library's published sources (jdhuff.c, jidctint.c, jdsample.c, jdcolor.c, jdmainct.c) for
-BASELINE sequential JPEGs (SOF0 / SOF1 Huffman, 8 bit, one interleaved scan or one component; 4:4:4, 4:2:2, 4:2:0, 4:4:0,
-grey; restart intervals) and is PINNED against the Pillow installed in this image: tests/test_jpeg_decode.py decodes files
+sequential AND progressive Huffman JPEGs (SOF0 / SOF1 / SOF2, 8 bit, any scan script; 4:4:4, 4:2:2, 4:2:0, 4:4:0, grey;
+restart intervals) and is PINNED against the Pillow installed in this image: tests/test_jpeg_decode.py decodes files
 written by Pillow at several qualities / sub-samplings / sizes and compares bit for bit with Pillow's own decode, and the
 golden `jpeg_decode.npz` (made by oracle/gen_golden.py::gold_jpeg) carries such files with Pillow's output.
-Progressive / arithmetic / 12-bit / CMYK files are refused (JpegUnsupported)."""
+Arithmetic-coded / lossless / 12-bit / CMYK files are refused (JpegUnsupported)."""
 import numpy as np
 
 
@@ -53,14 +53,15 @@ def parse(data):
                 t[ZIGZAG] = np.frombuffer(seg[q + 1: q + 65], np.uint8)
                 info["qt"][tq] = t
                 q += 65
-        elif m in (0xC0, 0xC1):
+        elif m in (0xC0, 0xC1, 0xC2):
+            info["progressive"] = m == 0xC2
             if seg[0] != 8:
                 raise JpegUnsupported("sample precision %d" % seg[0])
             info["height"], info["width"] = (seg[1] << 8) | seg[2], (seg[3] << 8) | seg[4]
             n = seg[5]
             info["comps"] = [(seg[6 + 3 * i], seg[7 + 3 * i] >> 4, seg[7 + 3 * i] & 15, seg[8 + 3 * i]) for i in range(n)]
-        elif m in (0xC2, 0xC3, 0xC5, 0xC6, 0xC7, 0xC9, 0xCA, 0xCB, 0xCD, 0xCE, 0xCF):
-            raise JpegUnsupported("SOF marker 0x%02X (progressive / lossless / arithmetic)" % m)
+        elif m in (0xC3, 0xC5, 0xC6, 0xC7, 0xC9, 0xCA, 0xCB, 0xCD, 0xCE, 0xCF):
+            raise JpegUnsupported("SOF marker 0x%02X (lossless / hierarchical / arithmetic)" % m)
         elif m == 0xC4:
             q = 0
             while q < len(seg):
@@ -77,12 +78,7 @@ def parse(data):
         elif m == 0xEE and seg[:5] == b"Adobe":
             info["adobe_transform"] = seg[11]
         elif m == 0xDA:
-            n = seg[0]
-            ids = [c[0] for c in info["comps"]]
-            info["scan"] = [(ids.index(seg[1 + 2 * i]), seg[2 + 2 * i] >> 4, seg[2 + 2 * i] & 15) for i in range(n)]
-            if n != len(info["comps"]):
-                raise JpegUnsupported("non-interleaved scans")
-            info["scan_start"] = p + L
+            info["sos_pos"] = p                       # (the length field of the first SOS: the scans are walked from here)
             return info
         elif m == 0xD9:
             raise JpegUnsupported("EOI before a scan")
@@ -187,47 +183,134 @@ def _extend(v, s):
 
 
 def huffman(data, info):
-    """the entropy-coded segment -> per component int16 coefficient blocks [blocks_h][blocks_w][64] (natural order, NOT
-    dequantised), covering whole MCUs"""
+    """every scan of the file -> per component int16 coefficient blocks [blocks_h][blocks_w][64] (natural order, NOT
+    de-quantised), covering whole MCUs.  Sequential scans (jdhuff.c) and progressive ones (jdphuff.c: DC / AC, first /
+    refinement passes, end-of-band runs); tables (DHT) and the restart interval (DRI) may change between scans."""
+    data = bytes(data)
     comps = info["comps"]
+    if len(comps) == 1:
+        comps = info["comps"] = [(comps[0][0], 1, 1, comps[0][3])]            # a single component is never interleaved
+    ids = [c[0] for c in comps]
     hmax, vmax = max(c[1] for c in comps), max(c[2] for c in comps)
-    mw, mh = -(-info["width"] // (8 * hmax)), -(-info["height"] // (8 * vmax))
+    W, H = info["width"], info["height"]
+    mw, mh = -(-W // (8 * hmax)), -(-H // (8 * vmax))
     coef = [np.zeros((mh * c[2], mw * c[1], 64), np.int16) for c in comps]
-    dct = {k: _huff_table(*v) for k, v in info["dc"].items()}
-    act = {k: _huff_table(*v) for k, v in info["ac"].items()}
-    br = _Bits(bytes(data), info["scan_start"])
-    pred = [0] * len(comps)
-    dri, todo = info["dri"], info["dri"]
-    for my in range(mh):
-        for mx in range(mw):
+    dc, ac, dri = dict(info["dc"]), dict(info["ac"]), info["dri"]
+    p = info["sos_pos"]
+    while True:
+        L = (data[p] << 8) | data[p + 1]
+        seg = data[p + 2: p + L]
+        n = seg[0]
+        scan = [(ids.index(seg[1 + 2 * i]), seg[2 + 2 * i] >> 4, seg[2 + 2 * i] & 15) for i in range(n)]
+        Ss, Se, Ah, Al = seg[1 + 2 * n], seg[2 + 2 * n], seg[3 + 2 * n] >> 4, seg[3 + 2 * n] & 15
+        if not info.get("progressive"):
+            Ss, Se, Ah, Al = 0, 63, 0, 0
+        br = _Bits(data, p + L)
+        dct = {k: _huff_table(*v) for k, v in dc.items()}
+        act = {k: _huff_table(*v) for k, v in ac.items()}
+        if n > 1:
+            units = [(my, mx) for my in range(mh) for mx in range(mw)]
+        else:
+            ci = scan[0][0]
+            bw, bh = -(-(-(-W * comps[ci][1] // hmax)) // 8), -(-(-(-H * comps[ci][2] // vmax)) // 8)
+            units = [(by, bx) for by in range(bh) for bx in range(bw)]
+        pred = [0] * len(comps)
+        eobrun, todo = 0, dri
+        for (uy, ux) in units:
             if dri:
                 if todo == 0:
                     br.restart()
-                    pred = [0] * len(comps)
-                    todo = dri
+                    pred, eobrun, todo = [0] * len(comps), 0, dri
                 todo -= 1
-            for (ci, td, ta) in info["scan"]:
-                _, h, v, _ = comps[ci]
+            blocks = []
+            for (ci, td, ta) in scan:
+                h, v = (comps[ci][1], comps[ci][2]) if n > 1 else (1, 1)
                 for by in range(v):
                     for bx in range(h):
-                        blk = coef[ci][my * v + by, mx * h + bx]
-                        s = br.decode(dct[td])
-                        diff = _extend(br.get(s), s) if s else 0
-                        pred[ci] += diff
-                        blk[0] = pred[ci]
-                        k = 1
-                        while k < 64:
-                            rs = br.decode(act[ta])
-                            r, s = rs >> 4, rs & 15
-                            if s:
-                                k += r
-                                blk[ZIGZAG[k]] = _extend(br.get(s), s)
-                                k += 1
+                        blocks.append((ci, td, ta, coef[ci][uy * v + by, ux * h + bx]))
+            for (ci, td, ta, blk) in blocks:
+                if Ss == 0:
+                    if Ah == 0:
+                        s_ = br.decode(dct[td])
+                        pred[ci] += _extend(br.get(s_), s_) if s_ else 0
+                        blk[0] = pred[ci] << Al
+                    elif br.get(1):
+                        blk[0] |= (1 << Al)
+                    if Se == 0:
+                        continue
+                k = max(Ss, 1)
+                if Ah == 0:                                           # sequential, or an AC first pass
+                    if eobrun > 0:
+                        eobrun -= 1
+                        continue
+                    while k <= Se:
+                        rs = br.decode(act[ta])
+                        r, s_ = rs >> 4, rs & 15
+                        if s_:
+                            k += r
+                            blk[ZIGZAG[k]] = _extend(br.get(s_), s_) << Al
+                            k += 1
+                        elif r == 15:
+                            k += 16
+                        else:
+                            if info.get("progressive"):
+                                eobrun = (1 << r) + (br.get(r) if r else 0) - 1
+                            break
+                    continue
+                p1, m1 = 1 << Al, -1 << Al                            # AC refinement
+                if eobrun == 0:
+                    while k <= Se:
+                        rs = br.decode(act[ta])
+                        r, s_ = rs >> 4, rs & 15
+                        if s_:
+                            s_ = p1 if br.get(1) else m1
+                        elif r != 15:
+                            eobrun = (1 << r) + (br.get(r) if r else 0)
+                            break
+                        while k <= Se:
+                            z = ZIGZAG[k]
+                            if blk[z] != 0:
+                                if br.get(1) and (int(blk[z]) & p1) == 0:
+                                    blk[z] += p1 if blk[z] >= 0 else m1
                             else:
-                                if r != 15:
+                                r -= 1
+                                if r < 0:
                                     break
-                                k += 16
-    return coef
+                            k += 1
+                        if s_:
+                            blk[ZIGZAG[k]] = s_
+                        k += 1
+                if eobrun > 0:
+                    while k <= Se:
+                        z = ZIGZAG[k]
+                        if blk[z] != 0 and br.get(1) and (int(blk[z]) & p1) == 0:
+                            blk[z] += p1 if blk[z] >= 0 else m1
+                        k += 1
+                    eobrun -= 1
+        # the next marker segment(s): tables may be redefined between scans
+        p = br.p
+        while True:
+            while not (data[p] == 0xFF and data[p + 1] != 0x00 and not (0xD0 <= data[p + 1] <= 0xD7) and data[p + 1] != 0xFF):
+                p += 1
+            m = data[p + 1]
+            p += 2
+            if m == 0xD9:
+                return coef
+            L2 = (data[p] << 8) | data[p + 1]
+            seg2 = data[p + 2: p + L2]
+            if m == 0xDA:
+                break
+            if m == 0xC4:
+                q = 0
+                while q < len(seg2):
+                    tc, th = seg2[q] >> 4, seg2[q] & 15
+                    bits = [0] + list(seg2[q + 1: q + 17])
+                    nv = sum(bits)
+                    (ac if tc else dc)[th] = (bits, list(seg2[q + 17: q + 17 + nv]))
+                    q += 17 + nv
+            elif m == 0xDD:
+                dri = (seg2[0] << 8) | seg2[1]
+            p += L2
 
 
 # ---- jidctint.c (JDCT_ISLOW), 8x8

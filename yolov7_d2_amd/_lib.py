@@ -163,11 +163,12 @@ class mi_pil_resize_job(C.Structure):
 
 
 class mi_jpeg_info(C.Structure):
-    _fields_ = ([(n, C.c_int32) for n in ("width", "height", "ncomp", "restart_interval", "orientation", "adobe_transform")] +
-                [(n, C.c_int32 * 3) for n in ("hs", "vs", "tq", "td", "ta")] +
+    _fields_ = ([(n, C.c_int32) for n in ("width", "height", "ncomp", "restart_interval", "orientation", "adobe_transform",
+                                         "progressive", "pad0_")] +
+                [(n, C.c_int32 * 3) for n in ("comp_id", "hs", "vs", "tq")] +
                 [(n, C.c_int32) for n in ("hmax", "vmax", "mcu_w", "mcu_h")] +
                 [("blocks_w", C.c_int32 * 3), ("blocks_h", C.c_int32 * 3), ("coef_off", C.c_int64 * 3), ("coef_count", C.c_int64),
-                 ("scan_start", C.c_int64), ("qt", (C.c_uint16 * 64) * 4), ("dc_bits", (C.c_uint8 * 17) * 4),
+                 ("sos_pos", C.c_int64), ("qt", (C.c_uint16 * 64) * 4), ("dc_bits", (C.c_uint8 * 17) * 4),
                  ("dc_vals", (C.c_uint8 * 256) * 4), ("ac_bits", (C.c_uint8 * 17) * 4), ("ac_vals", (C.c_uint8 * 256) * 4),
                  ("have_qt", C.c_uint8 * 4), ("have_dc", C.c_uint8 * 4), ("have_ac", C.c_uint8 * 4), ("pad_", C.c_uint8 * 4)])
 

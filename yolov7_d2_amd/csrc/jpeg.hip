@@ -1,10 +1,11 @@
 // Image decoding for the input pipeline: what detectron2's utils.read_image does for the reference's
 // mapper (yolov7/data/dataset_mapper.py:646-648) - PIL.Image.open -> EXIF orientation -> RGB -> BGR - for baseline JPEGs.
-// Host half (this file, plain C++): marker parsing and the sequential Huffman decoding of jdhuff.c into int16 coefficient
-// blocks (natural order, not dequantised).  Device half: de-quantisation + jidctint.c's ISLOW IDCT, one thread per block, then
+// Host half (this file, plain C++): marker parsing and the Huffman decoding of every scan - sequential (jdhuff.c) and
+// progressive (jdphuff.c: DC / AC, first / refinement passes, end-of-band runs) - into int16 coefficient blocks (natural
+// order, not dequantised).  Device half: de-quantisation + jidctint.c's ISLOW IDCT, one thread per block, then
 // one thread per output pixel for fancy up-sampling (jdsample.c), YCbCr -> RGB (jdcolor.c), the EXIF transpose and the
-// channel order (jpeg_core.h).  Two flat launches for a batch of images.  Progressive / arithmetic-coded / 12-bit / CMYK
-// files are refused with MI_EINVAL - there is no CPU decode to fall back to.
+// channel order (jpeg_core.h).  Two flat launches for a batch of images.  Arithmetic-coded / lossless / 12-bit / CMYK files
+// are refused with MI_EINVAL - there is no CPU decode to fall back to.
 #include <string.h>
 #include "common.h"
 #include "jpeg_core.h"
@@ -39,7 +40,6 @@ extern "C" int mi_jpeg_parse(const uint8_t* b, int64_t len, mi_jpeg_info* info) 
   memset(info, 0, sizeof(*info));
   info->orientation = 1;
   info->adobe_transform = -1;
-  int comp_id[3] = {0, 0, 0};
   int64_t p = 2;
   bool have_frame = false;
   while (true) {
@@ -63,7 +63,8 @@ extern "C" int mi_jpeg_parse(const uint8_t* b, int64_t len, mi_jpeg_info* info) 
         info->have_qt[tq] = 1;
         q += 65;
       }
-    } else if (m == 0xC0 || m == 0xC1) {
+    } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+      info->progressive = m == 0xC2;
       MI_REQUIRE(n >= 6 && seg[0] == 8, "jpeg_parse: sample precision %d (8-bit files only)", n >= 1 ? seg[0] : -1);
       info->height = (seg[1] << 8) | seg[2];
       info->width = (seg[3] << 8) | seg[4];
@@ -71,15 +72,15 @@ extern "C" int mi_jpeg_parse(const uint8_t* b, int64_t len, mi_jpeg_info* info) 
       MI_REQUIRE((info->ncomp == 1 || info->ncomp == 3) && n >= 6 + 3 * info->ncomp, "jpeg_parse: %d components (grey or three-component files only)", info->ncomp);
       MI_REQUIRE(info->width > 0 && info->height > 0, "jpeg_parse: empty frame");
       for (int i = 0; i < info->ncomp; ++i) {
-        comp_id[i] = seg[6 + 3 * i];
+        info->comp_id[i] = seg[6 + 3 * i];
         info->hs[i] = seg[7 + 3 * i] >> 4;
         info->vs[i] = seg[7 + 3 * i] & 15;
         info->tq[i] = seg[8 + 3 * i];
         MI_REQUIRE(info->tq[i] < 4, "jpeg_parse: quantisation table index");
       }
       have_frame = true;
-    } else if ((m >= 0xC2 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
-      MI_FAIL(MI_EINVAL, "jpeg_parse: SOF marker 0x%02X (progressive / lossless / arithmetic coding is not served)", m);
+    } else if ((m >= 0xC3 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+      MI_FAIL(MI_EINVAL, "jpeg_parse: SOF marker 0x%02X (lossless / hierarchical / arithmetic coding is not served)", m);
     } else if (m == 0xC4) {
       int64_t q = 0;
       while (q < n) {
@@ -105,15 +106,7 @@ extern "C" int mi_jpeg_parse(const uint8_t* b, int64_t len, mi_jpeg_info* info) 
       info->adobe_transform = seg[11];
     } else if (m == 0xDA) {
       MI_REQUIRE(have_frame, "jpeg_parse: scan before the frame header");
-      MI_REQUIRE(n >= 1 && seg[0] == info->ncomp && n >= 1 + 2 * info->ncomp, "jpeg_parse: non-interleaved scans are not served");
-      for (int i = 0; i < info->ncomp; ++i) {
-        MI_REQUIRE(seg[1 + 2 * i] == comp_id[i], "jpeg_parse: scan component order");
-        info->td[i] = seg[2 + 2 * i] >> 4;
-        info->ta[i] = seg[2 + 2 * i] & 15;
-        MI_REQUIRE(info->td[i] < 4 && info->ta[i] < 4 && info->have_dc[info->td[i]] && info->have_ac[info->ta[i]] && info->have_qt[info->tq[i]],
-                   "jpeg_parse: the scan names a table the file does not define");
-      }
-      info->scan_start = p + L;
+      info->sos_pos = p;               // the length field of the first SOS: mi_jpeg_huffman walks the scans from here
       break;
     }
     p += L;
@@ -210,55 +203,180 @@ struct BitReader {
 inline int extend(int v, int s) { return v >= (1 << (s - 1)) ? v : v - (1 << s) + 1; }
 }  // namespace
 
-extern "C" int mi_jpeg_huffman(const uint8_t* data, int64_t len, const mi_jpeg_info* info, int16_t* coef) {
-  MI_REQUIRE(data && info && coef && info->coef_count > 0 && info->scan_start > 0 && info->scan_start <= len, "jpeg_huffman: args");
-  memset(coef, 0, (size_t)info->coef_count * sizeof(int16_t));
-  HuffTab dc[4], ac[4];
-  for (int i = 0; i < 4; ++i) {
-    if (info->have_dc[i]) MI_REQUIRE(make_tab(info->dc_bits[i], info->dc_vals[i], &dc[i]), "jpeg_huffman: DC table %d", i);
-    if (info->have_ac[i]) MI_REQUIRE(make_tab(info->ac_bits[i], info->ac_vals[i], &ac[i]), "jpeg_huffman: AC table %d", i);
+namespace {
+struct Tables {
+  uint8_t bits[2][4][17], vals[2][4][256];
+  bool have[2][4];
+};
+// one DHT segment -> the table set (tables may be redefined between scans)
+bool read_dht(const uint8_t* seg, int64_t n, Tables* t) {
+  int64_t q = 0;
+  while (q < n) {
+    if (q + 17 > n) return false;
+    const int tc = seg[q] >> 4, th = seg[q] & 15;
+    if (tc > 1 || th > 3) return false;
+    int nv = 0;
+    t->bits[tc][th][0] = 0;
+    for (int i = 1; i <= 16; ++i) { t->bits[tc][th][i] = seg[q + i]; nv += seg[q + i]; }
+    if (nv > 256 || q + 17 + nv > n) return false;
+    for (int i = 0; i < nv; ++i) t->vals[tc][th][i] = seg[q + 17 + i];
+    t->have[tc][th] = true;
+    q += 17 + nv;
   }
-  BitReader br{data, info->scan_start, len, 0, 0};
-  int pred[3] = {0, 0, 0};
-  const int dri = info->restart_interval;
-  int todo = dri;
-  for (int my = 0; my < info->mcu_h; ++my)
-    for (int mx = 0; mx < info->mcu_w; ++mx) {
-      if (dri) {
-        if (todo == 0) {
-          br.restart();
-          pred[0] = pred[1] = pred[2] = 0;
-          todo = dri;
-        }
-        --todo;
+  return true;
+}
+inline void refine(int16_t* c, BitReader& br, int p1, int m1) {      // jdphuff.c: correction bit of an already-nonzero coefficient
+  if (br.get(1) && ((int)*c & p1) == 0) *c = (int16_t)(*c + (*c >= 0 ? p1 : m1));
+}
+}  // namespace
+
+extern "C" int mi_jpeg_huffman(const uint8_t* data, int64_t len, const mi_jpeg_info* info, int16_t* coef) {
+  MI_REQUIRE(data && info && coef && info->coef_count > 0 && info->sos_pos > 0 && info->sos_pos + 2 <= len, "jpeg_huffman: args");
+  memset(coef, 0, (size_t)info->coef_count * sizeof(int16_t));
+  Tables tb;
+  memset(&tb, 0, sizeof(tb));
+  for (int i = 0; i < 4; ++i) {
+    memcpy(tb.bits[0][i], info->dc_bits[i], 17); memcpy(tb.vals[0][i], info->dc_vals[i], 256); tb.have[0][i] = info->have_dc[i];
+    memcpy(tb.bits[1][i], info->ac_bits[i], 17); memcpy(tb.vals[1][i], info->ac_vals[i], 256); tb.have[1][i] = info->have_ac[i];
+  }
+  int dri = info->restart_interval;
+  const int nc = info->ncomp, W = info->width, H = info->height;
+  int64_t p = info->sos_pos;
+  for (int nscan = 0; nscan < 1024; ++nscan) {
+    const int64_t L = ((int64_t)data[p] << 8) | data[p + 1];
+    MI_REQUIRE(L >= 6 && p + L <= len, "jpeg_huffman: truncated scan header");
+    const uint8_t* seg = data + p + 2;
+    const int n = seg[0];
+    MI_REQUIRE(n >= 1 && n <= nc && L >= 2 + 1 + 2 * n + 3, "jpeg_huffman: scan header");
+    int sci[3], std_[3], sta[3];
+    for (int i = 0; i < n; ++i) {
+      int ci = -1;
+      for (int c = 0; c < nc; ++c) if (info->comp_id[c] == seg[1 + 2 * i]) ci = c;
+      MI_REQUIRE(ci >= 0, "jpeg_huffman: the scan names a component the frame does not have");
+      sci[i] = ci; std_[i] = seg[2 + 2 * i] >> 4; sta[i] = seg[2 + 2 * i] & 15;
+      MI_REQUIRE(std_[i] < 4 && sta[i] < 4, "jpeg_huffman: table index");
+    }
+    int Ss = seg[1 + 2 * n], Se = seg[2 + 2 * n], Ah = seg[3 + 2 * n] >> 4, Al = seg[3 + 2 * n] & 15;
+    if (!info->progressive) { Ss = 0; Se = 63; Ah = 0; Al = 0; }
+    MI_REQUIRE(Ss <= Se && Se <= 63 && Al <= 13 && (Ss > 0 ? n == 1 : true) && (info->progressive && Ss == 0 ? Se == 0 : true),
+               "jpeg_huffman: spectral selection / approximation parameters");
+    HuffTab dct[3], act[3];
+    for (int i = 0; i < n; ++i) {
+      if (Ss == 0 && Ah == 0) {
+        MI_REQUIRE(tb.have[0][std_[i]] && make_tab(tb.bits[0][std_[i]], tb.vals[0][std_[i]], &dct[i]), "jpeg_huffman: DC table %d", std_[i]);
       }
-      for (int ci = 0; ci < info->ncomp; ++ci) {
-        const int h = info->hs[ci], v = info->vs[ci];
-        for (int by = 0; by < v; ++by)
-          for (int bx = 0; bx < h; ++bx) {
-            int16_t* blk = coef + info->coef_off[ci] + ((int64_t)(my * v + by) * info->blocks_w[ci] + (mx * h + bx)) * 64;
-            int s = br.decode(dc[info->td[ci]]);
-            if (s > 15) s = 15;
-            pred[ci] += s ? extend(br.get(s), s) : 0;
-            blk[0] = (int16_t)pred[ci];
-            int k = 1;
-            while (k < 64) {
-              const int rs = br.decode(ac[info->ta[ci]]);
-              const int r = rs >> 4, sz = rs & 15;
-              if (sz) {
-                k += r;
-                const int val = extend(br.get(sz), sz);
-                if (k < 64) blk[kZigzag[k]] = (int16_t)val;
-                ++k;
-              } else {
-                if (r != 15) break;
-                k += 16;
-              }
-            }
-          }
+      if (Se > 0) {
+        MI_REQUIRE(tb.have[1][sta[i]] && make_tab(tb.bits[1][sta[i]], tb.vals[1][sta[i]], &act[i]), "jpeg_huffman: AC table %d", sta[i]);
       }
     }
-  return MI_OK;
+    // units of the scan: MCUs when interleaved, the component's own 8x8 blocks (not padded to the MCU grid) otherwise
+    int uw, uh;
+    if (n > 1) { uw = info->mcu_w; uh = info->mcu_h; }
+    else {
+      const int c = sci[0];
+      const int dw = (int)(((int64_t)W * info->hs[c] + info->hmax - 1) / info->hmax), dh = (int)(((int64_t)H * info->vs[c] + info->vmax - 1) / info->vmax);
+      uw = (dw + 7) / 8; uh = (dh + 7) / 8;
+    }
+    BitReader br{data, p + L, len, 0, 0};
+    int pred[3] = {0, 0, 0};
+    int eobrun = 0, todo = dri;
+    const int p1 = 1 << Al, m1 = -(1 << Al);
+    for (int uy = 0; uy < uh; ++uy)
+      for (int ux = 0; ux < uw; ++ux) {
+        if (dri) {
+          if (todo == 0) {
+            br.restart();
+            pred[0] = pred[1] = pred[2] = 0;
+            eobrun = 0;
+            todo = dri;
+          }
+          --todo;
+        }
+        for (int i = 0; i < n; ++i) {
+          const int ci = sci[i];
+          const int h = n > 1 ? info->hs[ci] : 1, v = n > 1 ? info->vs[ci] : 1;
+          for (int by = 0; by < v; ++by)
+            for (int bx = 0; bx < h; ++bx) {
+              int16_t* blk = coef + info->coef_off[ci] + ((int64_t)(uy * v + by) * info->blocks_w[ci] + (ux * h + bx)) * 64;
+              if (Ss == 0) {
+                if (Ah == 0) {
+                  int s = br.decode(dct[i]);
+                  if (s > 15) s = 15;
+                  pred[ci] += s ? extend(br.get(s), s) : 0;
+                  blk[0] = (int16_t)(pred[ci] * p1);
+                } else if (br.get(1)) {
+                  blk[0] = (int16_t)(blk[0] | p1);
+                }
+                if (Se == 0) continue;
+              }
+              int k = Ss > 1 ? Ss : 1;
+              if (Ah == 0) {                                   // sequential, or an AC first pass
+                if (eobrun > 0) { --eobrun; continue; }
+                while (k <= Se) {
+                  const int rs = br.decode(act[i]);
+                  const int r = rs >> 4, sz = rs & 15;
+                  if (sz) {
+                    k += r;
+                    const int val = extend(br.get(sz), sz);
+                    if (k <= 63) blk[kZigzag[k]] = (int16_t)(val * p1);
+                    ++k;
+                  } else if (r == 15) {
+                    k += 16;
+                  } else {
+                    if (info->progressive) eobrun = (1 << r) + (r ? br.get(r) : 0) - 1;
+                    break;
+                  }
+                }
+                continue;
+              }
+              if (eobrun == 0) {                               // AC refinement (jdphuff.c decode_mcu_AC_refine)
+                while (k <= Se) {
+                  const int rs = br.decode(act[i]);
+                  int r = rs >> 4, sz = rs & 15;
+                  if (sz) {
+                    sz = br.get(1) ? p1 : m1;
+                  } else if (r != 15) {
+                    eobrun = (1 << r) + (r ? br.get(r) : 0);
+                    break;
+                  }
+                  while (k <= Se) {
+                    int16_t* c = blk + kZigzag[k];
+                    if (*c != 0) refine(c, br, p1, m1);
+                    else if (--r < 0) break;
+                    ++k;
+                  }
+                  if (sz && k <= 63) blk[kZigzag[k]] = (int16_t)sz;
+                  ++k;
+                }
+              }
+              if (eobrun > 0) {
+                for (; k <= Se; ++k) {
+                  int16_t* c = blk + kZigzag[k];
+                  if (*c != 0) refine(c, br, p1, m1);
+                }
+                --eobrun;
+              }
+            }
+        }
+      }
+    // the marker segments after the scan: tables and the restart interval may be redefined between scans
+    p = br.p;
+    while (true) {
+      while (p + 1 < len && !(data[p] == 0xFF && data[p + 1] != 0x00 && data[p + 1] != 0xFF && !(data[p + 1] >= 0xD0 && data[p + 1] <= 0xD7))) ++p;
+      if (p + 1 >= len) return MI_OK;                          // no EOI: what was decoded stands (as libjpeg's premature-end warning)
+      const int m = data[p + 1];
+      p += 2;
+      if (m == 0xD9) return MI_OK;
+      MI_REQUIRE(p + 2 <= len, "jpeg_huffman: truncated segment");
+      const int64_t L2 = ((int64_t)data[p] << 8) | data[p + 1];
+      MI_REQUIRE(L2 >= 2 && p + L2 <= len, "jpeg_huffman: truncated segment");
+      if (m == 0xDA) break;
+      if (m == 0xC4) MI_REQUIRE(read_dht(data + p + 2, L2 - 2, &tb), "jpeg_huffman: Huffman table between scans");
+      else if (m == 0xDD && L2 >= 4) dri = (data[p + 2] << 8) | data[p + 3];
+      p += L2;
+    }
+  }
+  MI_FAIL(MI_EINVAL, "jpeg_huffman: more than 1024 scans");
 }
 
 // ---------------------------------------------------------------- device half

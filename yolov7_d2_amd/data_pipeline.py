@@ -640,7 +640,7 @@ class GpuJpegDecoder:
     order) - for a BATCH of baseline JPEG files: the sequential Huffman decoding runs on host threads inside the library
     (`mi_jpeg_parse`, `mi_jpeg_huffman`; ctypes drops the GIL), the coefficient blocks go to the device in one pinned copy,
     and two launches do the rest for all images (de-quantisation + libjpeg's ISLOW IDCT per block; fancy chroma up-sampling,
-    YCbCr -> RGB, EXIF transpose and channel order per pixel).  Bit-identical to Pillow's decode.  Progressive, arithmetic-
+    YCbCr -> RGB, EXIF transpose and channel order per pixel).  Bit-identical to Pillow's decode.  Arithmetic-
     coded, 12-bit and CMYK files raise MI355Error (there is no CPU decoder to fall back to)."""
 
     def __init__(self, device="cuda", format="BGR", apply_orientation=True, workers=8):      # noqa: A002 (d2's argument name)
