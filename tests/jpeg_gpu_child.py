@@ -29,6 +29,7 @@ for (h, w, kw) in [(480, 640, dict(quality=90, subsampling=2)), (427, 640, dict(
     Image.fromarray(smooth(h, w)).save(buf, format="JPEG", **kw)
     files.append(buf.getvalue())
 buf = io.BytesIO(); Image.fromarray(smooth(120, 90)[..., 0]).save(buf, format="JPEG", quality=80); files.append(buf.getvalue())
+buf = io.BytesIO(); Image.fromarray(smooth(300, 400)).save(buf, format="JPEG", quality=85, subsampling=2, progressive=True); files.append(buf.getvalue())
 for o in (3, 6, 8, 5):
     ex = Image.Exif(); ex[0x0112] = o
     buf = io.BytesIO(); Image.fromarray(smooth(96, 140)).save(buf, format="JPEG", quality=90, exif=ex.tobytes()); files.append(buf.getvalue())
