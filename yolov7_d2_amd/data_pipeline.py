@@ -637,7 +637,7 @@ class GpuDatasetMapper:
 class GpuJpegDecoder:
     """detectron2 `utils.read_image(file_name, format)` - the first thing `MyDatasetMapper2._load_image_with_annos` does
     (yolov7/data/dataset_mapper.py:646-648; d2 un-vendored: PIL.Image.open -> EXIF orientation -> convert("RGB") -> channel
-    order) - for a BATCH of baseline JPEG files: the sequential Huffman decoding runs on host threads inside the library
+    order) - for a BATCH of JPEG files (sequential and progressive): the Huffman decoding of every scan runs on host threads inside the library
     (`mi_jpeg_parse`, `mi_jpeg_huffman`; ctypes drops the GIL), the coefficient blocks go to the device in one pinned copy,
     and two launches do the rest for all images (de-quantisation + libjpeg's ISLOW IDCT per block; fancy chroma up-sampling,
     YCbCr -> RGB, EXIF transpose and channel order per pixel).  Bit-identical to Pillow's decode.  Arithmetic-
