@@ -585,7 +585,9 @@ int mi_mixup_blend(const mi_mixup_job* jobs_dev, int njobs, int total_blocks, mi
  * to every image it loads (yolov7/data/dataset_mapper.py:642-683): T.ResizeShortestEdge = PIL.Image.resize(BILINEAR) of
  * the uint8 image (Pillow libImaging/Resample.c: fp64 coefficients -> 22-bit fixed point, horizontal pass rounded to 8
  * bits, then the vertical pass), T.RandomFlip horizontal / vertical, YOLOFRandomShift (data/transforms/transform.py:341-388:
- * zeros where the shifted image does not reach).  One job per image: src HWC uint8 [h0][w0][3] -> nh x nw, element
+ * zeros where the shifted image does not reach).  One job per image: src HWC uint8 [h0][w0][3] (rows src_ld bytes apart, so a
+ * T.RandomCrop window is an offset pointer; optionally mirrored first, as DetrDatasetMapper's flip-then-resize order needs,
+ * data/dataset_mapper.py:777-800) -> nh x nw, element
  * (c, y, x) at dst + c dsc + y dsy + x dsx bytes (HWC: 1, 3 nw, 3; a sample of a padded NCHW batch: Hp Wp, Wp, 1);
  * tmp = [h0][nw][3] scratch of the horizontal pass (unused when nw == w0).  The colour augmentations of that list
  * (RandomSaturation / RandomBrightness / YOLOFRandomDistortion: cv2 HSV tables) are not built.
@@ -596,8 +598,10 @@ typedef struct mi_pil_resize_job {
   void* tmp;
   void* dst;
   int64_t dsc, dsy, dsx;
+  int64_t src_ld;            /* bytes between source rows (3 w0 for a whole image; the parent's for a crop window) */
   int32_t h0, w0, nh, nw;
   int32_t hflip, vflip, shift_x, shift_y;
+  int32_t src_hflip, pad_;   /* src_hflip: mirror the source BEFORE the resampling (DetrDatasetMapper: T.RandomFlip, then the resizes) */
   int32_t blk0h, blk0v;
 } mi_pil_resize_job;
 int mi_pil_resize_jobs_layout(mi_pil_resize_job* jobs_host, int njobs, int32_t* blocks_h, int32_t* blocks_v);

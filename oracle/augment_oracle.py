@@ -625,3 +625,67 @@ def mapper_call(pool, cur, rng_np, rng_py, mcfg=None, front_kw=None, enable_mosa
         return out, np.asarray(t, np.float64).reshape(-1, 5), True
     box, cls_ = filter_empty(lab[:, :4], lab[:, 4])
     return img, np.concatenate([box.astype(np.float64), np.asarray(cls_, np.float64)[:, None]], 1), False
+
+
+# ------------------------------------------------------------------------------------------------ DetrDatasetMapper
+def detr_mapper_call(img, labels, rng_np, min_sizes=(480, 512, 544, 576, 608, 640, 672, 704, 736, 768, 800, 832), max_size=1333,
+                     sample_style="choice", crop=(384, 600), crop_sizes=(400, 500, 600)):
+    """DetrDatasetMapper.__call__ (yolov7/data/dataset_mapper.py:836-900, training; configs/coco/detr/*.yaml INPUT) after
+    read_image: with INPUT.CROP on, np.random.rand() > 0.5 picks the plain list [T.RandomFlip(), T.ResizeShortestEdge(min_size,
+    max_size)], otherwise RandomFlip, T.ResizeShortestEdge([400, 500, 600]), T.RandomCrop("absolute_range", (384, 600)), then the
+    final resize (build_transform_gen :777-800).  The transforms are detectron2's (un-vendored; restated: RandomFlip /
+    ResizeShortestEdge as above, RandomCrop.get_crop_size / get_transform, CropTransform.apply_coords); the pixels are Pillow's
+    bilinear resampling of the FLIPPED (and cropped) image.  labels float64 [n, 5] (x1, y1, x2, y2, cls).
+    Returns (HWC uint8 image, float32 boxes [m, 4], classes [m], record of the draws)."""
+    import sys
+    lab = np.asarray(labels, np.float64).reshape(-1, 5)
+    h, w = img.shape[:2]
+    take_crop = crop is not None and not (rng_np.rand() > 0.5)
+    b = lab[:, :4].copy()
+    rec = dict(crop=None)
+    rec["flip"] = bool(rng_np.uniform(0, 1.0) < 0.5)
+    if rec["flip"]:
+        img = np.flip(img, axis=1)
+        ww = w
+
+        def hf(c):
+            c[:, 0] = ww - c[:, 0]
+            return c
+        b = _apply_box(b, hf) if len(b) else b
+
+    def resize(img, b, size, mx):
+        h, w = img.shape[:2]
+        nh, nw = resize_shortest_edge_shape(h, w, size, mx)
+        out = pil_resize_bilinear_u8(np.ascontiguousarray(img), nh, nw)
+
+        def sc(c):
+            c[:, 0] = c[:, 0] * (nw * 1.0 / w)
+            c[:, 1] = c[:, 1] * (nh * 1.0 / h)
+            return c
+        return out, (_apply_box(b, sc) if len(b) else b)
+    if take_crop:
+        img, b = resize(img, b, int(rng_np.choice(crop_sizes)), sys.maxsize)
+        h, w = img.shape[:2]
+        ch = int(rng_np.randint(min(h, crop[0]), min(h, crop[1]) + 1))
+        cw = int(rng_np.randint(min(w, crop[0]), min(w, crop[1]) + 1))
+        y0 = int(rng_np.randint(h - ch + 1))
+        x0 = int(rng_np.randint(w - cw + 1))
+        rec["crop"] = (h, w, x0, y0, cw, ch)
+        img = img[y0: y0 + ch, x0: x0 + cw]
+
+        def cr(c):
+            c[:, 0] -= x0
+            c[:, 1] -= y0
+            return c
+        b = _apply_box(b, cr) if len(b) else b
+    if sample_style == "range":
+        size = int(rng_np.randint(min_sizes[0], min_sizes[1] + 1))
+    else:
+        size = int(rng_np.choice(min_sizes))
+    img, b = resize(img, b, size, max_size)
+    H, W = img.shape[:2]
+    rec["size"] = (H, W)
+    if len(b):
+        b = np.minimum(b.clip(min=0), np.array([W, H, W, H], np.float64))
+    box, cls_ = filter_empty(b, lab[:, 4])
+    return np.ascontiguousarray(img), box, cls_, rec

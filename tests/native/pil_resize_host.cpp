@@ -6,19 +6,18 @@
 extern "C" int pil_front_host(const unsigned char* src, int h0, int w0, int nh, int nw, int hflip, int vflip, int shift_x,
                               int shift_y, unsigned char* tmp, unsigned char* dst, long long dsc, long long dsy, long long dsx) {
   PilJob j;
-  j.src = src; j.tmp = tmp; j.dst = dst; j.dsc = dsc; j.dsy = dsy; j.dsx = dsx;
+  j.src = src; j.tmp = tmp; j.dst = dst; j.dsc = dsc; j.dsy = dsy; j.dsx = dsx; j.src_ld = (long long)w0 * 3;
   j.h0 = h0; j.w0 = w0; j.nh = nh; j.nw = nw; j.hflip = hflip; j.vflip = vflip; j.shift_x = shift_x; j.shift_y = shift_y;
+  j.src_hflip = 0; j.pad_ = 0;
   j.blk0h = j.blk0v = 0;
-  const unsigned char* h_img = src;
   if (nw != w0) {
     for (int y = 0; y < h0; ++y)
       for (int x = 0; x < nw; ++x) pil_h_pixel(j, y, x, tmp + ((long long)y * nw + x) * 3);
-    h_img = tmp;
   }
   for (int y = 0; y < nh; ++y)
     for (int x = 0; x < nw; ++x) {
       unsigned char o[3];
-      pil_v_pixel(j, h_img, y, x, o);
+      pil_v_pixel(j, y, x, o);
       for (int c = 0; c < 3; ++c) dst[c * dsc + y * dsy + x * dsx] = o[c];
     }
   return 0;

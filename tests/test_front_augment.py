@@ -259,3 +259,79 @@ def test_mapper_without_augmentation_is_the_front_only():
         _, _, omos = A.mapper_call(pool, (img, lab), r2n, random.Random(0), mcfg=MAPPER_MOSAIC, front_kw=ORACLE_FRONT, enable_aug=False)
         assert not plan["mosaic"] and not omos and len(mp.pool) == 0 and len(pool) == 0
         assert r1n.randint(1 << 30) == r2n.randint(1 << 30)
+
+
+def _detr_data(seed, n):
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        h, w = int(rs.randint(90, 220)), int(rs.randint(90, 220))
+        img = rs.randint(0, 256, (h, w, 3), dtype=np.uint8)
+        m = int(rs.randint(0, 6))
+        x1 = rs.uniform(0, w - 20, m); y1 = rs.uniform(0, h - 20, m)
+        lab = np.stack([x1, y1, np.minimum(x1 + rs.uniform(6, 120, m), w), np.minimum(y1 + rs.uniform(6, 120, m), h),
+                        rs.randint(0, 80, m).astype(np.float64)], 1)
+        out.append((img, lab))
+    return out
+
+
+DETR_KW = dict(min_sizes=(96, 112, 128, 144), max_size=200, crop=(60, 100), crop_sizes=(80, 100, 120))
+
+
+def test_detr_mapper_oracle_pixels_are_pillows():
+    """the oracle's DetrDatasetMapper chain with the REAL Pillow doing every resize of the flipped / cropped arrays"""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.RandomState(2)
+    seen = dict(crop=0, plain=0, flip=0)
+    for img, lab in _detr_data(1, 16):
+        out, box, cls_, rec = A.detr_mapper_call(img, lab, rng, **DETR_KW)
+        ref = np.flip(img, 1) if rec["flip"] else img
+        if rec["crop"] is not None:
+            h1, w1, x0, y0, cw, ch = rec["crop"]
+            ref = np.asarray(Image.fromarray(np.ascontiguousarray(ref)).resize((w1, h1), Image.BILINEAR))[y0: y0 + ch, x0: x0 + cw]
+        H, W = rec["size"]
+        ref = np.asarray(Image.fromarray(np.ascontiguousarray(ref)).resize((W, H), Image.BILINEAR))
+        assert np.array_equal(out, ref)
+        assert len(box) == len(cls_) and (len(box) == 0 or (box[:, 2] <= W).all() and (box[:, 3] <= H).all() and (box >= 0).all())
+        seen["crop"] += rec["crop"] is not None; seen["plain"] += rec["crop"] is None; seen["flip"] += rec["flip"]
+    assert min(seen.values()) >= 3, seen
+
+
+def test_detr_mapper_host_half_and_emulated_launches_equal_the_oracle(host_lib):
+    """`GpuDetrMapper`: draws (stream alignment after every sample), boxes, and the two stages of jobs - first resize of the
+    crop samples from the (mirrored) source, final resize from the crop window / the source into [3, h, w] - walked by the
+    host build of the kernels' thread bodies, against the oracle"""
+    import torch
+    from yolov7_d2_amd import _lib as L
+    from yolov7_d2_amd.data_pipeline import GpuDetrMapper
+    mp = GpuDetrMapper(device="cpu", **DETR_KW)
+    r1, r2 = np.random.RandomState(4), np.random.RandomState(4)
+    data = _detr_data(6, 12)
+    plans, refs = [], []
+    for img, lab in data:
+        p = mp.plan(img.shape[:2], r1)
+        out, box, cls_, rec = A.detr_mapper_call(img, lab, r2, **DETR_KW)
+        assert r1.randint(1 << 30) == r2.randint(1 << 30)
+        assert p["flip"] == rec["flip"] and p["crop"] == rec["crop"] and p["size"] == rec["size"]
+        b2, c2 = mp.boxes(lab, p)
+        assert np.array_equal(b2, box) and np.array_equal(c2, cls_)
+        plans.append(p); refs.append(out)
+    assert sum(p["crop"] is not None for p in plans) >= 3 and sum(p["crop"] is None for p in plans) >= 3
+    timgs = [torch.from_numpy(i) for i, _ in data]
+    mids = [torch.zeros(p["crop"][0], p["crop"][1], 3, dtype=torch.uint8) if p["crop"] is not None else None for p in plans]
+    outs = [torch.full((3,) + tuple(p["size"]), 9, dtype=torch.uint8) for p in plans]
+    J1, J2 = mp._stage_jobs(timgs, plans, mids, outs)
+
+    def alloc(h, w):
+        t = torch.empty(h, w, 3, dtype=torch.uint8)
+        return t, t.data_ptr()
+    lib = L.lib()
+    for specs in (J1, J2):
+        jobs, owners = mp._table(specs, alloc)
+        bh, bv = C.c_int32(0), C.c_int32(0)
+        L.check(lib.mi_pil_resize_jobs_layout(jobs, len(jobs), C.byref(bh), C.byref(bv)), "layout")
+        host_lib.pil_emulate_launches(C.cast(jobs, C.c_void_p), len(jobs), bh.value, bv.value)
+    for o, ref in zip(outs, refs):
+        assert np.array_equal(o.numpy(), ref.transpose(2, 0, 1))
+    with pytest.raises(L.MI355Error):
+        mp.make_batch(timgs, [l for _, l in data])

@@ -294,6 +294,7 @@ extern "C" int mi_pil_resize_jobs_layout(mi_pil_resize_job* jobs, int n, int32_t
     mi_pil_resize_job& j = jobs[i];
     MI_REQUIRE(j.src && j.dst && j.h0 > 0 && j.w0 > 0 && j.nh > 0 && j.nw > 0, "pil_resize_layout: job %d: null / empty", i);
     MI_REQUIRE(j.nw == j.w0 || j.tmp, "pil_resize_layout: job %d needs the scratch image of the horizontal pass", i);
+    MI_REQUIRE(j.src_ld >= (int64_t)j.w0 * 3, "pil_resize_layout: job %d: source row stride %lld < 3 w0", i, (long long)j.src_ld);
     const int kx = (int)((j.w0 + j.nw - 1) / j.nw), ky = (int)((j.h0 + j.nh - 1) / j.nh);    // ceil(scale)
     MI_REQUIRE(kx * 2 + 1 <= PIL_MAX_TAPS && ky * 2 + 1 <= PIL_MAX_TAPS, "pil_resize_layout: job %d shrinks by more than 8", i);
     MI_REQUIRE(j.shift_x > -j.nw && j.shift_x < j.nw && j.shift_y > -j.nh && j.shift_y < j.nh, "pil_resize_layout: job %d: shift", i);

@@ -20,12 +20,14 @@
 #define PIL_MAX_TAPS 17                // ceil(scale) * 2 + 1: down-scaling factors up to 8
 
 struct PilJob {   // mirrors mi_pil_resize_job (include/mi355_det.h)
-  const unsigned char* src;
+  const unsigned char* src;    // HWC uint8, rows src_ld bytes apart (a crop window = an offset pointer + the parent's row stride)
   unsigned char* tmp;
   unsigned char* dst;
   int64_t dsc, dsy, dsx;
+  int64_t src_ld;
   int32_t h0, w0, nh, nw;
   int32_t hflip, vflip, shift_x, shift_y;
+  int32_t src_hflip, pad_;     // src_hflip: the source is mirrored left-right BEFORE the resampling (T.RandomFlip ahead of the resize)
   int32_t blk0h, blk0v;
 };
 
@@ -73,20 +75,25 @@ MI_HD unsigned char pil_clip8(int v) {
 MI_HD void pil_h_pixel(const PilJob& j, int y, int xo, unsigned char out[3]) {
   PilTaps t;
   pil_taps(j.w0, j.nw, xo, &t);
-  const unsigned char* r = j.src + ((int64_t)y * j.w0 + t.x0) * 3;
+  const unsigned char* row = j.src + (int64_t)y * j.src_ld;
   int s0 = 1 << (PIL_PRECISION_BITS - 1), s1 = s0, s2 = s0;
   for (int x = 0; x < t.n; ++x) {
-    s0 += (int)r[x * 3 + 0] * t.k[x];
-    s1 += (int)r[x * 3 + 1] * t.k[x];
-    s2 += (int)r[x * 3 + 2] * t.k[x];
+    const int sx = j.src_hflip ? j.w0 - 1 - (t.x0 + x) : t.x0 + x;
+    const unsigned char* r = row + (int64_t)sx * 3;
+    s0 += (int)r[0] * t.k[x];
+    s1 += (int)r[1] * t.k[x];
+    s2 += (int)r[2] * t.k[x];
   }
   out[0] = pil_clip8(s0); out[1] = pil_clip8(s1); out[2] = pil_clip8(s2);
 }
 
 // destination pixel (yd, xd) of the nh x nw result after the vertical pass, HFlipTransform, VFlipTransform and
 // YOLOFShiftTransform (zeros where the shifted image does not reach; transform.py:355-388), in that order.
-// h_img: the horizontally resampled image [h0][nw][3] (= src when nw == w0).
-MI_HD void pil_v_pixel(const PilJob& j, const unsigned char* h_img, int yd, int xd, unsigned char out[3]) {
+// Reads the horizontally resampled image tmp [h0][nw][3], or the source itself when nw == w0.
+MI_HD void pil_v_pixel(const PilJob& j, int yd, int xd, unsigned char out[3]) {
+  const bool direct = j.nw == j.w0;                            // no horizontal pass: the vertical pass reads the source itself
+  const unsigned char* h_img = direct ? j.src : j.tmp;
+  const int64_t h_ld = direct ? j.src_ld : (int64_t)j.nw * 3;
   int ys = yd - j.shift_y, xs = xd - j.shift_x;
   if (ys < 0 || ys >= j.nh || xs < 0 || xs >= j.nw) {
     out[0] = out[1] = out[2] = 0;
@@ -94,8 +101,9 @@ MI_HD void pil_v_pixel(const PilJob& j, const unsigned char* h_img, int yd, int 
   }
   if (j.vflip) ys = j.nh - 1 - ys;
   if (j.hflip) xs = j.nw - 1 - xs;
+  if (direct && j.src_hflip) xs = j.w0 - 1 - xs;
   if (j.nh == j.h0) {                                          // no vertical pass: the row passes through unchanged
-    const unsigned char* p = h_img + ((int64_t)ys * j.nw + xs) * 3;
+    const unsigned char* p = h_img + (int64_t)ys * h_ld + (int64_t)xs * 3;
     out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
     return;
   }
@@ -103,7 +111,7 @@ MI_HD void pil_v_pixel(const PilJob& j, const unsigned char* h_img, int yd, int 
   pil_taps(j.h0, j.nh, ys, &t);
   int s0 = 1 << (PIL_PRECISION_BITS - 1), s1 = s0, s2 = s0;
   for (int y = 0; y < t.n; ++y) {
-    const unsigned char* p = h_img + ((int64_t)(t.x0 + y) * j.nw + xs) * 3;
+    const unsigned char* p = h_img + (int64_t)(t.x0 + y) * h_ld + (int64_t)xs * 3;
     s0 += (int)p[0] * t.k[y];
     s1 += (int)p[1] * t.k[y];
     s2 += (int)p[2] * t.k[y];
@@ -134,7 +142,7 @@ MI_HD void pil_v_thread(const PilJob* jobs, int njobs, int block, int thread) {
   if (idx >= (int64_t)p.nh * p.nw) return;
   const int y = (int)(idx / p.nw), x = (int)(idx - (int64_t)y * p.nw);
   unsigned char o[3];
-  pil_v_pixel(p, p.nw == p.w0 ? p.src : p.tmp, y, x, o);
+  pil_v_pixel(p, y, x, o);
   unsigned char* d = p.dst + (int64_t)y * p.dsy + (int64_t)x * p.dsx;
   d[0] = o[0]; d[p.dsc] = o[1]; d[2 * p.dsc] = o[2];
 }

@@ -408,7 +408,7 @@ class GpuFrontAugment:
             if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3 or not img.is_contiguous():
                 raise ValueError("GpuFrontAugment: contiguous uint8 [H, W, 3] images")
             h0, w0 = img.shape[:2]
-            j.src, j.h0, j.w0, j.nh, j.nw = img.data_ptr(), h0, w0, d["nh"], d["nw"]
+            j.src, j.src_ld, j.h0, j.w0, j.nh, j.nw = img.data_ptr(), 3 * w0, h0, w0, d["nh"], d["nw"]
             j.hflip, j.vflip, j.shift_x, j.shift_y = int(d["hflip"]), int(d["vflip"]), d["sx"], d["sy"]
             if d["nw"] != w0:
                 t = torch.empty(h0, d["nw"], 3, dtype=torch.uint8, device=img.device)
@@ -709,3 +709,141 @@ class GpuJpegDecoder:
         L.check(lib.mi_jpeg_color(tab.data_ptr(), len(files), bp, st), "mi_jpeg_color")
         self._keep = (host, coef, planes, tab)                      # alive until the stream has run the copy and the launches
         return outs
+
+
+# ------------------------------------------------------------------------------------------------ DETR's mapper
+class GpuDetrMapper:
+    """`DetrDatasetMapper.__call__` (yolov7/data/dataset_mapper.py:804-900, training) for a batch of decoded images - the input
+    pipeline of BASELINE configs[3]: T.RandomFlip, then with INPUT.CROP on and np.random.rand() <= 0.5 a
+    T.ResizeShortestEdge([400, 500, 600]) + T.RandomCrop("absolute_range", SIZE), then T.ResizeShortestEdge(MIN_SIZE_TRAIN,
+    MAX_SIZE_TRAIN) (`build_transform_gen` :777-800); boxes through `transform_instance_annotations`, Instances, empty boxes
+    dropped.  The host draws the reference's random numbers in its order and does the float64 box arithmetic; the pixels are
+    the Pillow-exact resampling launches of the front (`mi_pil_resize_h / _v`): the flip is applied to the SOURCE of the first
+    resize (`src_hflip`: d2 flips before it resizes), the crop is an offset pointer + row stride into the first resize's
+    output, and the last resize writes each sample as the [3, h, w] uint8 tensor the DETR meta-architecture takes."""
+
+    def __init__(self, device="cuda", min_sizes=(480, 512, 544, 576, 608, 640, 672, 704, 736, 768, 800, 832), max_size=1333,
+                 sample_style="choice", crop=(384, 600), crop_sizes=(400, 500, 600)):
+        self.device = torch.device(device)
+        self.min_sizes, self.max_size, self.sample_style = tuple(min_sizes), max_size, sample_style
+        self.crop, self.crop_sizes = (tuple(crop) if crop else None), tuple(crop_sizes)
+        self._front = GpuFrontAugment(device=device)
+
+    def plan(self, hw, rng_np=np.random):
+        """one image's draws, in the reference's order: rand (branch), uniform (flip), [choice, 4 x randint], choice"""
+        import sys
+        h, w = hw
+        p = dict(src=(h, w), crop=None)
+        take_crop = self.crop is not None and not (rng_np.rand() > 0.5)
+        p["flip"] = bool(rng_np.uniform(0, 1.0) < 0.5)
+        if take_crop:
+            h, w = GpuFrontAugment.output_shape(h, w, int(rng_np.choice(self.crop_sizes)), sys.maxsize)
+            ch = int(rng_np.randint(min(h, self.crop[0]), min(h, self.crop[1]) + 1))
+            cw = int(rng_np.randint(min(w, self.crop[0]), min(w, self.crop[1]) + 1))
+            y0 = int(rng_np.randint(h - ch + 1))
+            x0 = int(rng_np.randint(w - cw + 1))
+            p["crop"] = (h, w, x0, y0, cw, ch)
+            h, w = ch, cw
+        if self.sample_style == "range":
+            size = int(rng_np.randint(self.min_sizes[0], self.min_sizes[1] + 1))
+        else:
+            size = int(rng_np.choice(self.min_sizes))
+        p["size"] = GpuFrontAugment.output_shape(h, w, size, self.max_size)
+        return p
+
+    @staticmethod
+    def boxes(labels, p):
+        """float64 [n, 5] (x1, y1, x2, y2, cls) -> (float32 boxes [m, 4], classes [m]) on the output image"""
+        lab = np.asarray(labels, np.float64).reshape(-1, 5)
+        b = lab[:, :4].copy()
+        h, w = p["src"]
+        hull = GpuFrontAugment._hull
+        if len(b):
+            if p["flip"]:
+                def hf(c, w=w):
+                    c[:, 0] = w - c[:, 0]
+                    return c
+                b = hull(b, hf)
+
+            def scale(h, w, nh, nw):
+                def f(c):
+                    c[:, 0] = c[:, 0] * (nw * 1.0 / w)
+                    c[:, 1] = c[:, 1] * (nh * 1.0 / h)
+                    return c
+                return f
+            if p["crop"] is not None:
+                h1, w1, x0, y0, cw, ch = p["crop"]
+                b = hull(b, scale(h, w, h1, w1))
+
+                def cr(c):
+                    c[:, 0] -= x0
+                    c[:, 1] -= y0
+                    return c
+                b = hull(b, cr)
+                h, w = ch, cw
+            H, W = p["size"]
+            b = hull(b, scale(h, w, H, W))
+            b = np.minimum(b.clip(min=0), np.array([W, H, W, H], np.float64))
+        box = b.astype(np.float32)
+        keep = ((box[:, 2] - box[:, 0]) > 1e-5) & ((box[:, 3] - box[:, 1]) > 1e-5)
+        return box[keep], lab[keep, 4]
+
+    def _stage_jobs(self, images, plans, mids, outs):
+        """(first-resize jobs of the crop samples, final-resize jobs of all samples); mids[k]: the crop samples' intermediate
+        HWC tensors, outs[k]: every sample's [3, H, W] output"""
+        J1, J2 = [], []
+        for k, (img, p) in enumerate(zip(images, plans)):
+            h0, w0 = p["src"]
+            H, W = p["size"]
+            j2 = dict(dst=outs[k].data_ptr(), dsc=H * W, dsy=W, dsx=1, nh=H, nw=W)
+            if p["crop"] is not None:
+                h1, w1, x0, y0, cw, ch = p["crop"]
+                J1.append(dict(src=img.data_ptr(), src_ld=3 * w0, h0=h0, w0=w0, nh=h1, nw=w1, flip=int(p["flip"]), dst=mids[k].data_ptr(),
+                               dsc=1, dsy=3 * w1, dsx=3))
+                j2.update(src=mids[k].data_ptr() + (y0 * w1 + x0) * 3, src_ld=3 * w1, h0=ch, w0=cw, flip=0)
+            else:
+                j2.update(src=img.data_ptr(), src_ld=3 * w0, h0=h0, w0=w0, flip=int(p["flip"]))
+            J2.append(j2)
+        return J1, J2
+
+    @staticmethod
+    def _table(specs, alloc):
+        """job dicts -> the C table; alloc(h, w) -> (owner, address) of a [h][w][3] scratch of the horizontal pass"""
+        jobs = (L.mi_pil_resize_job * len(specs))()
+        owners = []
+        for j, s in zip(jobs, specs):
+            j.src, j.src_ld, j.h0, j.w0, j.nh, j.nw, j.src_hflip = s["src"], s["src_ld"], s["h0"], s["w0"], s["nh"], s["nw"], s["flip"]
+            j.dst, j.dsc, j.dsy, j.dsx = s["dst"], s["dsc"], s["dsy"], s["dsx"]
+            if s["nw"] != s["w0"]:
+                o, a = alloc(s["h0"], s["nw"])
+                owners.append(o)
+                j.tmp = a
+        return jobs, owners
+
+    def make_batch(self, images, labels, rng_np=np.random):
+        """images: device uint8 HWC tensors (e.g. GpuJpegDecoder(format="RGB") output), labels: float64 [n_i, 5] each.
+        Returns [(uint8 [3, h, w] device tensor, float32 boxes [m, 4], classes [m])] - the "image" / gt_boxes / gt_classes of
+        the reference's dataset dicts."""
+        if self.device.type != "cuda" or not all(i.is_cuda for i in images):
+            raise L.MI355Error("GpuDetrMapper: the MI355X path needs device tensors (no CPU pixel path)")
+        plans = [self.plan(tuple(i.shape[:2]), rng_np) for i in images]
+        mids = [torch.empty(p["crop"][0], p["crop"][1], 3, dtype=torch.uint8, device=self.device) if p["crop"] is not None else None
+                for p in plans]
+        outs = [torch.empty(3, p["size"][0], p["size"][1], dtype=torch.uint8, device=self.device) for p in plans]
+        J1, J2 = self._stage_jobs(images, plans, mids, outs)
+
+        def alloc(h, w):
+            t = torch.empty(h, w, 3, dtype=torch.uint8, device=self.device)
+            return t, t.data_ptr()
+        keep = [images, mids]
+        for specs in (J1, J2):
+            if specs:
+                jobs, owners = self._table(specs, alloc)
+                self._front._launch(jobs, owners)
+                keep.append((owners, self._front._keep))
+        self._keep = keep
+        res = []
+        for k, p in enumerate(plans):
+            box, cls_ = self.boxes(labels[k], p)
+            res.append((outs[k], box, cls_))
+        return res
