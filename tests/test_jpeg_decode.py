@@ -188,3 +188,12 @@ def test_decoder_host_mirror_through_the_emulated_launches(emu, fmt, orient):
         assert np.array_equal(out, ref[:, :, ::-1] if fmt == "BGR" else ref), tag
     with pytest.raises(L.MI355Error):
         dec.decode(datas[:1])
+
+
+def test_host_half_survives_corrupt_files():
+    """600 mutated files through the library's parser and Huffman decoder in a child process: decoded or refused, never a crash"""
+    pytest.importorskip("PIL.Image")
+    child = os.path.join(ROOT, "tests", "jpeg_fuzz_child.py")
+    r = subprocess.run([sys.executable, child, "600"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stderr[-500:])
+    assert "fuzz done" in r.stdout
