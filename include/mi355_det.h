@@ -646,6 +646,9 @@ typedef struct mi_jpeg_job {
 } mi_jpeg_job;
 int mi_jpeg_parse(const uint8_t* data, int64_t len, mi_jpeg_info* info);
 int mi_jpeg_huffman(const uint8_t* data, int64_t len, const mi_jpeg_info* info, int16_t* coef_host);
+/* n files on `threads` host threads of the library; rcs[k] = file k's return code, the call returns the first non-zero one */
+int mi_jpeg_huffman_batch(const uint8_t* const* datas, const int64_t* lens, const mi_jpeg_info* infos, int16_t* const* coefs_host,
+                          int n, int threads, int32_t* rcs);
 int mi_jpeg_job_fill(const mi_jpeg_info* info, const void* coef_dev, void* planes_dev, void* out_dev, int bgr,
                      int apply_orientation, mi_jpeg_job* job);
 int mi_jpeg_jobs_layout(mi_jpeg_job* jobs_host, int njobs, int32_t* blocks_idct, int32_t* blocks_pix);

@@ -280,6 +280,7 @@ _PROTOS = {
     "mi_pil_resize_v": (C.c_int, [_vp, _i, _i, _vp]),
     "mi_jpeg_parse": (C.c_int, [_vp, C.c_int64, C.POINTER(mi_jpeg_info)]),
     "mi_jpeg_huffman": (C.c_int, [_vp, C.c_int64, C.POINTER(mi_jpeg_info), _vp]),
+    "mi_jpeg_huffman_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mi_jpeg_job_fill": (C.c_int, [C.POINTER(mi_jpeg_info), _vp, _vp, _vp, _i, _i, C.POINTER(mi_jpeg_job)]),
     "mi_jpeg_jobs_layout": (C.c_int, [C.POINTER(mi_jpeg_job), _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mi_jpeg_idct": (C.c_int, [_vp, _i, _i, _vp]),

@@ -7,6 +7,9 @@
 // channel order (jpeg_core.h).  Two flat launches for a batch of images.  Arithmetic-coded / lossless / 12-bit / CMYK files
 // are refused with MI_EINVAL - there is no CPU decode to fall back to.
 #include <string.h>
+#include <atomic>
+#include <thread>
+#include <vector>
 #include "common.h"
 #include "jpeg_core.h"
 static_assert(sizeof(JpegJob) == sizeof(mi_jpeg_job), "JpegJob mirrors mi_jpeg_job");
@@ -135,9 +138,11 @@ extern "C" int mi_jpeg_parse(const uint8_t* b, int64_t len, mi_jpeg_info* info) 
 }
 
 namespace {
+constexpr int kLook = 10;    // codes of up to kLook bits resolve in one table read (jdhuff.c's HUFF_LOOKAHEAD idea)
 struct HuffTab {       // jdhuff.c jpeg_make_d_derived_tbl
   int32_t maxcode[18], valptr[17], mincode[17];
   const uint8_t* vals;
+  uint16_t look[1 << kLook];   // (code length << 8) | symbol for the codes of <= kLook bits, 0 otherwise
 };
 bool make_tab(const uint8_t* bits, const uint8_t* vals, HuffTab* t) {
   int huffsize[257], huffcode[257], n = 0;
@@ -161,6 +166,14 @@ bool make_tab(const uint8_t* bits, const uint8_t* vals, HuffTab* t) {
   }
   t->maxcode[17] = 0xFFFFF;
   t->vals = vals;
+  memset(t->look, 0, sizeof(t->look));
+  for (int i = 0; i < n; ++i) {
+    const int l = huffsize[i];
+    if (l > kLook) continue;
+    const int first = huffcode[i] << (kLook - l), cnt = 1 << (kLook - l);
+    if (first + cnt > (1 << kLook)) return false;
+    for (int q = 0; q < cnt; ++q) t->look[first + q] = (uint16_t)((l << 8) | vals[i]);
+  }
   return true;
 }
 struct BitReader {
@@ -169,6 +182,11 @@ struct BitReader {
   uint64_t acc;
   int n;
   void fill() {
+    while (n <= 32 && p + 4 <= len && d[p] != 0xFF && d[p + 1] != 0xFF && d[p + 2] != 0xFF && d[p + 3] != 0xFF) {
+      acc = (acc << 32) | ((uint64_t)d[p] << 24) | ((uint64_t)d[p + 1] << 16) | ((uint64_t)d[p + 2] << 8) | (uint64_t)d[p + 3];
+      p += 4;
+      n += 32;
+    }
     while (n <= 48) {
       int c = p < len ? d[p] : 0;
       if (c == 0xFF) {
@@ -189,9 +207,20 @@ struct BitReader {
     return (int)((acc >> n) & ((1u << k) - 1));
   }
   int decode(const HuffTab& t) {
-    int code = get(1), l = 1;
-    while (code > t.maxcode[l]) { code = (code << 1) | get(1); ++l; }
-    if (l > 16) return 0;
+    if (n < 16) fill();
+    const uint16_t e = t.look[(acc >> (n - kLook)) & ((1u << kLook) - 1)];
+    if (e) {
+      n -= e >> 8;
+      return e & 255;
+    }
+    int l = kLook + 1;
+    int code = (int)((acc >> (n - l)) & ((1u << l) - 1));
+    while (l <= 16 && code > t.maxcode[l]) {
+      ++l;
+      code = (int)((acc >> (n - l)) & ((1u << l) - 1));
+    }
+    if (l > 16) { n -= 16; return 0; }
+    n -= l;
     return t.vals[(t.valptr[l] + code - t.mincode[l]) & 255];
   }
   void restart() {                   // byte-align, skip the RSTn marker
@@ -377,6 +406,26 @@ extern "C" int mi_jpeg_huffman(const uint8_t* data, int64_t len, const mi_jpeg_i
     }
   }
   MI_FAIL(MI_EINVAL, "jpeg_huffman: more than 1024 scans");
+}
+
+// a batch of files on `threads` host threads (the library's own: no Python thread per file, no GIL hand-offs); rcs[k] receives
+// file k's return code, the call returns the first non-zero one
+extern "C" int mi_jpeg_huffman_batch(const uint8_t* const* datas, const int64_t* lens, const mi_jpeg_info* infos, int16_t* const* coefs,
+                                     int n, int threads, int32_t* rcs) {
+  MI_REQUIRE(datas && lens && infos && coefs && rcs && n > 0, "jpeg_huffman_batch: args");
+  if (threads < 1) threads = 1;
+  if (threads > n) threads = n;
+  std::atomic<int> next(0);
+  auto work = [&]() {
+    for (int k = next.fetch_add(1); k < n; k = next.fetch_add(1)) rcs[k] = mi_jpeg_huffman(datas[k], lens[k], &infos[k], coefs[k]);
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+  work();
+  for (auto& t : pool) t.join();
+  for (int k = 0; k < n; ++k)
+    if (rcs[k] != MI_OK) return rcs[k];
+  return MI_OK;
 }
 
 // ---------------------------------------------------------------- device half

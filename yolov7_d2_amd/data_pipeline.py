@@ -660,16 +660,16 @@ class GpuJpegDecoder:
         offs = np.concatenate([[0], np.cumsum([i.coef_count for i in infos])]).astype(np.int64)
         host, base = alloc(int(offs[-1]))
 
-        def huff(k):
-            return lib.mi_jpeg_huffman(bufs[k], len(files[k]), C.byref(infos[k]), C.c_void_p(base + 2 * int(offs[k])))
-        if self.workers > 1 and n > 1:
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(min(self.workers, n)) as ex:
-                rcs = list(ex.map(huff, range(n)))
-        else:
-            rcs = [huff(k) for k in range(n)]
-        for k, rc in enumerate(rcs):
-            L.check(rc, f"mi_jpeg_huffman (file {k})")
+        # one call: the library spreads the files over its own host threads (no Python thread / GIL hand-off per file)
+        datas = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+        lens = (C.c_int64 * n)(*[len(f) for f in files])
+        iarr = (L.mi_jpeg_info * n)(*infos)
+        coefs = (C.c_void_p * n)(*[base + 2 * int(offs[k]) for k in range(n)])
+        rcs = (C.c_int32 * n)()
+        rc = lib.mi_jpeg_huffman_batch(datas, lens, iarr, coefs, n, max(1, int(self.workers)), rcs)
+        if rc != 0:
+            k = next(i for i in range(n) if rcs[i] != 0)
+            L.check(rcs[k], f"mi_jpeg_huffman (file {k})")
         return infos, offs, host
 
     def out_shape(self, info):
