@@ -20,6 +20,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import jpeg_oracle as J  # noqa: E402
 from yolov7_d2_amd import _lib as L  # noqa: E402
 
@@ -60,6 +61,10 @@ def _files():
         buf = io.BytesIO(); Image.fromarray(_smooth(rng, h, w)).save(buf, format="JPEG", quality=q, subsampling=sub, progressive=True)
         out.append((f"progressive {h}x{w} sub{sub} q{q}", buf.getvalue()))
     buf = io.BytesIO(); Image.fromarray(_smooth(rng, 40, 60)[..., 0]).save(buf, format="JPEG", quality=80, progressive=True); out.append(("progressive grey", buf.getvalue()))
+    from jpeg_craft import craft_jpeg                              # samplings Pillow cannot write, random coefficients
+    for (W, H, samp) in [(40, 56, [(1, 2), (1, 1), (1, 1)]), (33, 47, [(1, 2), (1, 1), (1, 1)]), (17, 70, [(1, 2), (1, 1), (1, 1)]),
+                         (64, 64, [(2, 2), (1, 1), (1, 1)]), (50, 30, [(2, 1), (1, 1), (1, 1)]), (9, 9, [(2, 2), (1, 1), (1, 1)])]:
+        out.append((f"crafted {W}x{H} {samp[0]}", craft_jpeg(W, H, samp, rng)))
     try:
         buf = io.BytesIO(); Image.fromarray(_smooth(rng, 64, 96)).save(buf, format="JPEG", quality=85, progressive=True, restart_marker_blocks=4)
         out.append(("progressive + restart", buf.getvalue()))
@@ -90,7 +95,7 @@ def test_oracle_against_the_golden_made_by_pillow(golden_dir):
 def test_oracle_against_the_installed_pillow():
     pytest.importorskip("PIL.Image")
     files = _files()
-    assert len(files) >= 42 and sum(t.startswith("progressive") for t, _ in files) >= 6
+    assert len(files) >= 48 and sum(t.startswith("progressive") for t, _ in files) >= 6 and sum(t.startswith("crafted") for t, _ in files) == 6
     for tag, data in files:
         assert np.array_equal(J.decode_rgb(data), _pillow(data, False)), tag
         assert np.array_equal(J.decode_rgb(data, orient=True), _pillow(data, True)), tag
