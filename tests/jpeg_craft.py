@@ -85,3 +85,75 @@ def craft_jpeg(width, height, samp, rng, density=0.15):
     out += seg(0xDA, bytes([3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0]))
     out += w.out + b"\xff\xd9"
     return bytes(out)
+
+
+def craft_noninterleaved(width, height, samp, rng, density=0.15, dri=0):
+    """the same, as a NON-interleaved sequential file: one scan per component over the component's own block grid (not padded to
+    the MCU grid), optional restart interval (in blocks) - the multi-scan script baseline JPEG allows and encoders rarely write"""
+    t = _std_tables()
+    hmax, vmax = max(s[0] for s in samp), max(s[1] for s in samp)
+    dc = [_codes(*t["dc"][0]), _codes(*t["dc"][1])]
+    ac = [_codes(*t["ac"][0]), _codes(*t["ac"][1])]
+
+    def seg(m, payload):
+        return bytes([0xFF, m]) + (len(payload) + 2).to_bytes(2, "big") + payload
+    out = bytearray(b"\xff\xd8")
+    zz = J.ZIGZAG
+    for tq in (0, 1):
+        q = t["qt"][tq]
+        out += seg(0xDB, bytes([tq]) + bytes(int(q[zz[i]]) for i in range(64)))
+    out += seg(0xC0, bytes([8]) + height.to_bytes(2, "big") + width.to_bytes(2, "big") + bytes([3]) +
+               b"".join(bytes([ci + 1, (h << 4) | v, 0 if ci == 0 else 1]) for ci, (h, v) in enumerate(samp)))
+    for cls, tabs in ((0, t["dc"]), (1, t["ac"])):
+        for th in (0, 1):
+            bits, vals = tabs[th]
+            out += seg(0xC4, bytes([(cls << 4) | th]) + bytes(bits[1:17]) + bytes(vals))
+    if dri:
+        out += seg(0xDD, dri.to_bytes(2, "big"))
+    for ci, (h, v) in enumerate(samp):
+        tb = 0 if ci == 0 else 1
+        dw, dh = -(-width * h // hmax), -(-height * v // vmax)
+        bw, bh = -(-dw // 8), -(-dh // 8)
+        w = _W()
+        pred = cnt = rst = 0
+        for _ in range(bw * bh):
+            if dri and cnt == dri:
+                w.flush()
+                w.out += bytes([0xFF, 0xD0 + (rst & 7)])
+                rst += 1
+                pred = cnt = 0
+            cnt += 1
+            blk = np.zeros(64, np.int64)
+            blk[0] = rng.randint(-60, 61)
+            nz = rng.rand(63) < density
+            blk[1:][nz] = rng.randint(-12, 13, nz.sum())
+            diff = int(blk[0]) - pred
+            pred = int(blk[0])
+            s = _cat(diff)
+            c, l = dc[tb][s]
+            w.put(c, l)
+            if s:
+                w.put(diff if diff > 0 else diff + (1 << s) - 1, s)
+            run = 0
+            last = max([k for k in range(1, 64) if blk[k]] + [0])
+            for k in range(1, last + 1):
+                v_ = int(blk[k])
+                if v_ == 0:
+                    run += 1
+                    continue
+                while run > 15:
+                    c, l = ac[tb][0xF0]
+                    w.put(c, l)
+                    run -= 16
+                s = _cat(v_)
+                c, l = ac[tb][(run << 4) | s]
+                w.put(c, l)
+                w.put(v_ if v_ > 0 else v_ + (1 << s) - 1, s)
+                run = 0
+            if last < 63:
+                c, l = ac[tb][0]
+                w.put(c, l)
+        w.flush()
+        out += seg(0xDA, bytes([1, ci + 1, (tb << 4) | tb, 0, 63, 0])) + w.out
+    out += b"\xff\xd9"
+    return bytes(out)

@@ -65,6 +65,9 @@ def _files():
     for (W, H, samp) in [(40, 56, [(1, 2), (1, 1), (1, 1)]), (33, 47, [(1, 2), (1, 1), (1, 1)]), (17, 70, [(1, 2), (1, 1), (1, 1)]),
                          (64, 64, [(2, 2), (1, 1), (1, 1)]), (50, 30, [(2, 1), (1, 1), (1, 1)]), (9, 9, [(2, 2), (1, 1), (1, 1)])]:
         out.append((f"crafted {W}x{H} {samp[0]}", craft_jpeg(W, H, samp, rng)))
+    from jpeg_craft import craft_noninterleaved                  # one scan per component, restart intervals in blocks
+    for (W, H, samp, dri) in [(40, 56, [(2, 2), (1, 1), (1, 1)], 0), (50, 30, [(1, 2), (1, 1), (1, 1)], 3), (70, 9, [(2, 2), (1, 1), (1, 1)], 5)]:
+        out.append((f"crafted non-interleaved {W}x{H} {samp[0]} dri {dri}", craft_noninterleaved(W, H, samp, rng, dri=dri)))
     try:
         buf = io.BytesIO(); Image.fromarray(_smooth(rng, 64, 96)).save(buf, format="JPEG", quality=85, progressive=True, restart_marker_blocks=4)
         out.append(("progressive + restart", buf.getvalue()))
@@ -95,7 +98,7 @@ def test_oracle_against_the_golden_made_by_pillow(golden_dir):
 def test_oracle_against_the_installed_pillow():
     pytest.importorskip("PIL.Image")
     files = _files()
-    assert len(files) >= 48 and sum(t.startswith("progressive") for t, _ in files) >= 6 and sum(t.startswith("crafted") for t, _ in files) == 6
+    assert len(files) >= 51 and sum(t.startswith("progressive") for t, _ in files) >= 6 and sum(t.startswith("crafted") for t, _ in files) == 9
     for tag, data in files:
         assert np.array_equal(J.decode_rgb(data), _pillow(data, False)), tag
         assert np.array_equal(J.decode_rgb(data, orient=True), _pillow(data, True)), tag
