@@ -12,8 +12,9 @@ second - `GpuMosaicMapper.make_batch` returns exactly what `NativeTrainer.load_b
 float32 [B, 100, 5] rows (cls, cx, cy, w, h)).  At 2 600 images / s / GPU this replaces ~40 cv2 CPU workers per GPU.
 
 Mixup (`ENABLE_MIXUP`, dataset_mapper.py:686-768) is a third launch that blends a resized / jittered / mirrored pool image
-into the warped sample in place.  The detectron2 `T.*` augmentations ahead of the mosaic are not built.  No CPU path for the
-pixels: device tensors only.
+into the warped sample in place.  Further down in this file: the detectron2 `T.*` augmentations ahead of the mosaic
+(`GpuFrontAugment`), the whole mapper call (`GpuDatasetMapper`), JPEG decoding (`GpuJpegDecoder`), DETR's mapper
+(`GpuDetrMapper`).  No CPU path for the pixels: device tensors only.
 """
 import ctypes as C
 import math
@@ -498,8 +499,8 @@ class GpuDatasetMapper:
     The host draws every random number from the two streams the reference uses (numpy's and Python's `random`) in the
     reference's order and does its float64 label arithmetic; the pixels are the launches of GpuFrontAugment (one pair for all
     loads of the batch) and GpuMosaicMapper (paste, warp, mixup), the mixed batch is assembled on the device.  `enable_aug`
-    False = `MyDatasetMapper2.disable_aug()` (after DISABLE_AT_ITER): the front only.  Not built: image decoding, the colour
-    entries of the augmentation list (see GpuFrontAugment)."""
+    False = `MyDatasetMapper2.disable_aug()` (after DISABLE_AT_ITER): the front only.  The images come decoded (device uint8
+    HWC: `GpuJpegDecoder`).  Not built: the colour entries of the augmentation list (see GpuFrontAugment)."""
 
     def __init__(self, mosaic_cfg=None, front_cfg=None, device="cuda", enable_mosaic=True, enable_mixup=False, pool_capacity=1000,
                  max_boxes=100, pad_value=114, size_divisibility=32):
