@@ -1,0 +1,195 @@
+"""TEST INFRASTRUCTURE: a protobuf reader for ONNX ModelProto files and an interpreter for the handful of operators the YOLOX
+export uses (torch ops on CPU), so that an exported file can be EXECUTED in an image that has neither `onnx` nor
+`onnxruntime`.  The reader / interpreter pair is itself checked against files torch's own exporter writes
+(tests/test_export_onnx.py)."""
+import struct
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _rv(b, p):
+    v = s = 0
+    while True:
+        c = b[p]
+        p += 1
+        v |= (c & 127) << s
+        s += 7
+        if c < 128:
+            return v, p
+
+
+def fields(b):
+    p, out = 0, []
+    while p < len(b):
+        k, p = _rv(b, p)
+        f, w = k >> 3, k & 7
+        if w == 0:
+            v, p = _rv(b, p)
+        elif w == 2:
+            n, p = _rv(b, p)
+            v = bytes(b[p: p + n])
+            p += n
+        elif w == 5:
+            v = struct.unpack("<f", b[p: p + 4])[0]
+            p += 4
+        elif w == 1:
+            v = struct.unpack("<d", b[p: p + 8])[0]
+            p += 8
+        else:
+            raise ValueError("wire type %d" % w)
+        out.append((f, w, v))
+    return out
+
+
+def _sint(v):
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def tensor(b):
+    dims, dt, name, raw, f32, i64 = [], None, "", None, [], []
+    for f, w, v in fields(b):
+        if f == 1:
+            dims += [_sint(x) for x in ([v] if w == 0 else [t[2] for t in _packed(v)])]
+        elif f == 2:
+            dt = v
+        elif f == 8:
+            name = v.decode()
+        elif f == 9:
+            raw = v
+        elif f == 4:
+            f32 += [v] if w == 5 else list(struct.unpack("<%df" % (len(v) // 4), v))
+        elif f == 7:
+            i64 += [_sint(v)] if w == 0 else [_sint(t[2]) for t in _packed(v)]
+    np_dt = {1: np.float32, 7: np.int64, 6: np.int32, 9: np.bool_, 11: np.float64}[dt]
+    if raw is not None:
+        a = np.frombuffer(raw, np_dt).copy()
+    else:
+        a = np.array(f32 if dt == 1 else i64, np_dt)
+    return name, a.reshape(dims)
+
+
+def _packed(v):
+    p, out = 0, []
+    while p < len(v):
+        x, p = _rv(v, p)
+        out.append((0, 0, x))
+    return out
+
+
+def attribute(b):
+    name, val, ints, floats = None, None, [], []
+    for f, w, v in fields(b):
+        if f == 1:
+            name = v.decode()
+        elif f == 2:
+            val = v
+        elif f == 3:
+            val = _sint(v)
+        elif f == 4:
+            val = v.decode()
+        elif f == 5:
+            val = tensor(v)[1]
+        elif f == 8:
+            ints += [_sint(v)] if w == 0 else [_sint(t[2]) for t in _packed(v)]
+        elif f == 7:
+            floats += [v] if w == 5 else list(struct.unpack("<%df" % (len(v) // 4), v))
+    if ints:
+        val = ints
+    elif floats:
+        val = floats
+    return name, val
+
+
+def load(data):
+    """-> dict(nodes=[(op, inputs, outputs, attrs)], inits={name: array}, inputs=[names], outputs=[names], opset, ir_version)"""
+    m = dict(nodes=[], inits={}, inputs=[], outputs=[], opset=None, ir_version=None)
+    for f, w, v in fields(data):
+        if f == 1:
+            m["ir_version"] = v
+        elif f == 8:
+            for f2, _, v2 in fields(v):
+                if f2 == 2:
+                    m["opset"] = v2
+        elif f == 7:
+            for f2, _, v2 in fields(v):
+                if f2 == 1:
+                    ins, outs, op, attrs = [], [], None, {}
+                    for f3, _, v3 in fields(v2):
+                        if f3 == 1:
+                            ins.append(v3.decode())
+                        elif f3 == 2:
+                            outs.append(v3.decode())
+                        elif f3 == 4:
+                            op = v3.decode()
+                        elif f3 == 5:
+                            k, a = attribute(v3)
+                            attrs[k] = a
+                    m["nodes"].append((op, ins, outs, attrs))
+                elif f2 == 5:
+                    n, a = tensor(v2)
+                    m["inits"][n] = a
+                elif f2 in (11, 12):
+                    nm = [v3.decode() for f3, _, v3 in fields(v2) if f3 == 1][0]
+                    m["inputs" if f2 == 11 else "outputs"].append(nm)
+    m["inputs"] = [n for n in m["inputs"] if n not in m["inits"]]
+    return m
+
+
+def run(model, feeds):
+    env = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in model["inits"].items()}
+    env.update({k: torch.as_tensor(v) for k, v in feeds.items()})
+    for op, ins, outs, a in model["nodes"]:
+        x = [env[i] if i else None for i in ins]
+        if op == "Conv":
+            p = a.get("pads", [0, 0, 0, 0])
+            assert p[0] == p[2] and p[1] == p[3] and a.get("dilations", [1, 1]) == [1, 1]
+            y = F.conv2d(x[0], x[1], x[2] if len(x) > 2 else None, stride=a.get("strides", [1, 1]), padding=(p[0], p[1]), groups=a.get("group", 1))
+        elif op == "Sigmoid":
+            y = torch.sigmoid(x[0])
+        elif op == "Mul":
+            y = x[0] * x[1]
+        elif op == "Add":
+            y = x[0] + x[1]
+        elif op == "Exp":
+            y = torch.exp(x[0])
+        elif op == "Concat":
+            y = torch.cat(x, a["axis"])
+        elif op == "Transpose":
+            y = x[0].permute(*a["perm"])
+        elif op == "MaxPool":
+            k, p = a["kernel_shape"], a["pads"]
+            assert p[0] == p[2] and p[1] == p[3] and not a.get("ceil_mode", 0)
+            y = F.max_pool2d(x[0], k, a.get("strides", [1, 1]), (p[0], p[1]))
+        elif op == "Slice":
+            y = x[0]
+            starts, ends = x[1].tolist(), x[2].tolist()
+            axes = x[3].tolist() if len(x) > 3 and x[3] is not None else list(range(len(starts)))
+            steps = x[4].tolist() if len(x) > 4 and x[4] is not None else [1] * len(starts)
+            for s, e_, ax, st in zip(starts, ends, axes, steps):
+                n = y.shape[ax]
+                s = max(0, min(n, s + n if s < 0 else s))
+                e_ = max(0, min(n, e_ + n if e_ < 0 else e_))
+                y = y.index_select(ax, torch.arange(s, e_, st))
+        elif op == "Resize":
+            assert a["mode"] == "nearest" and a["coordinate_transformation_mode"] == "asymmetric" and a.get("nearest_mode", "round_prefer_floor") == "floor"
+            sc = x[2].tolist()
+            assert sc[:2] == [1.0, 1.0] and sc[2] == int(sc[2]) and sc[3] == int(sc[3])
+            y = x[0].repeat_interleave(int(sc[2]), 2).repeat_interleave(int(sc[3]), 3)
+        elif op == "Reshape":
+            shp = [x[0].shape[i] if d == 0 else d for i, d in enumerate(x[1].tolist())]
+            y = x[0].reshape(shp)
+        elif op == "Split":
+            y = list(torch.split(x[0], a["split"], a["axis"]))
+        elif op == "ArgMax":
+            y = torch.argmax(x[0], a["axis"], keepdim=bool(a.get("keepdims", 1)))
+        elif op == "Cast":
+            y = x[0].to({1: torch.float32, 7: torch.int64}[a["to"]])
+        elif op == "Constant":
+            y = torch.from_numpy(np.ascontiguousarray(a["value"]))
+        else:
+            raise NotImplementedError(op)
+        for name, v in zip(outs, y if isinstance(y, list) else [y]):
+            env[name] = v
+    return [env[o].numpy() for o in model["outputs"]]
