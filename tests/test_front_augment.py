@@ -335,3 +335,111 @@ def test_detr_mapper_host_half_and_emulated_launches_equal_the_oracle(host_lib):
         assert np.array_equal(o.numpy(), ref.transpose(2, 0, 1))
     with pytest.raises(L.MI355Error):
         mp.make_batch(timgs, [l for _, l in data])
+
+
+@pytest.mark.parametrize("mixup", [False, True])
+def test_mapper_run_plumbing_on_the_host(host_lib, monkeypatch, mixup):
+    """`GpuDatasetMapper.run` - which loads go through the front, the pool view handed to the mosaic mapper (fronted images,
+    fronted labels, the mixup partner's index), the assembly of the MIXED batch - executed on host tensors: the front's
+    launches are walked by the host build of its thread bodies, the mosaic mapper's three launches are stood in for by the
+    oracle's `mosaic_sample` / `mixup` on the same view (they have their own bit-exact GPU tests); the batch must equal
+    `preprocess_batch` of the oracle's `mapper_call` outputs, pixels and rows"""
+    import random
+    import torch
+    from yolov7_d2_amd import _lib as L
+    from yolov7_d2_amd.data_pipeline import GpuDatasetMapper, GpuFrontAugment, GpuMosaicMapper
+    lib = L.lib()
+
+    def launch(self, jobs, keep):
+        bh, bv = C.c_int32(0), C.c_int32(0)
+        L.check(lib.mi_pil_resize_jobs_layout(jobs, len(jobs), C.byref(bh), C.byref(bv)), "layout")
+        host_lib.pil_emulate_launches(C.cast(jobs, C.c_void_p), len(jobs), bh.value, bv.value)
+        self._keep = keep
+
+    def fake_mosaic(self, pool, groups, params, mixups=None):
+        samples = []
+        for b, (grp, p) in enumerate(zip(groups, params)):
+            img, t = A.mosaic_sample([pool.images[i].numpy() for i in grp], [pool.labels[i] for i in grp], p["input_dim"], p["yc"], p["xc"], p["draws"])
+            mx = mixups[b] if mixups is not None else None
+            if mx is not None and len(t):
+                img, t = A.mixup(img, t, pool.images[mx["idx"]].numpy(), pool.labels[mx["idx"]], p["input_dim"], mx["jit"], mx["flip"], (mx["x_off"], mx["y_off"]))
+            samples.append((img, t))
+        out, rows = A.preprocess_batch(samples)
+        return torch.from_numpy(out), torch.from_numpy(rows), [tuple(p["input_dim"]) for p in params]
+    monkeypatch.setattr(GpuFrontAugment, "_launch", launch)
+    monkeypatch.setattr(GpuFrontAugment, "_check_device", lambda self, images: None)
+    monkeypatch.setattr(GpuMosaicMapper, "make_batch", fake_mosaic)
+    mp = GpuDatasetMapper(device="cpu", enable_mixup=mixup, front_cfg=MAPPER_FRONT, mosaic_cfg=MAPPER_MOSAIC)
+    r1n, r1p, r2n, r2p = np.random.RandomState(17), random.Random(18), np.random.RandomState(17), random.Random(18)
+    pool, kinds = [], []
+    data = _mapper_data(40 + mixup, 24)
+    for k in range(0, 24, 6):
+        chunk = data[k: k + 6]
+        plans = [mp.plan(torch.from_numpy(i), l, r1n, r1p) for i, l in chunk]
+        out, rows, sizes = mp.run(plans)
+        ref = [A.mapper_call(pool, (i, l), r2n, r2p, mcfg=MAPPER_MOSAIC, front_kw=ORACLE_FRONT, enable_mixup=mixup) for i, l in chunk]
+        ref_img, ref_rows = A.preprocess_batch([(r[0], r[1]) for r in ref])
+        kinds += [r[2] for r in ref]
+        assert tuple(out.shape) == ref_img.shape
+        assert np.array_equal(out.numpy(), ref_img), k
+        assert np.array_equal(rows.numpy(), ref_rows), k
+        assert all(tuple(s) == r[0].shape[:2] for s, r in zip(sizes, ref) if not r[2])
+    assert kinds.count(True) >= 4 and kinds.count(False) >= 8
+
+
+def test_detr_mapper_make_batch_on_the_host(host_lib, monkeypatch):
+    """`GpuDetrMapper.make_batch` end to end on host tensors (its allocations, the two stages of launches in order, the
+    boxes): the launches walked by the host build of the thread bodies, against the oracle"""
+    import torch
+    from yolov7_d2_amd import _lib as L
+    from yolov7_d2_amd.data_pipeline import GpuDetrMapper, GpuFrontAugment
+    lib = L.lib()
+
+    def launch(self, jobs, keep):
+        bh, bv = C.c_int32(0), C.c_int32(0)
+        L.check(lib.mi_pil_resize_jobs_layout(jobs, len(jobs), C.byref(bh), C.byref(bv)), "layout")
+        host_lib.pil_emulate_launches(C.cast(jobs, C.c_void_p), len(jobs), bh.value, bv.value)
+        self._keep = keep
+    monkeypatch.setattr(GpuFrontAugment, "_launch", launch)
+    monkeypatch.setattr(GpuDetrMapper, "_check_device", lambda self, images: None)
+    mp = GpuDetrMapper(device="cpu", **DETR_KW)
+    r1, r2 = np.random.RandomState(14), np.random.RandomState(14)
+    data = _detr_data(16, 10)
+    res = mp.make_batch([torch.from_numpy(i) for i, _ in data], [l for _, l in data], r1)
+    crops = 0
+    for (img, lab), (o, box, cls_) in zip(data, res):
+        ref, rbox, rcls, rec = A.detr_mapper_call(img, lab, r2, **DETR_KW)
+        crops += rec["crop"] is not None
+        assert np.array_equal(o.numpy(), ref.transpose(2, 0, 1))
+        assert np.array_equal(box, rbox) and np.array_equal(cls_, rcls)
+    assert 0 < crops < len(data)
+
+
+def test_front_apply_and_make_batch_bodies_on_the_host(host_lib, monkeypatch):
+    """the bodies of `GpuFrontAugment.apply` / `.make_batch` (allocations, destination strides, the launch call) on host tensors"""
+    import torch
+    from yolov7_d2_amd import _lib as L
+    from yolov7_d2_amd.data_pipeline import GpuFrontAugment
+    lib = L.lib()
+
+    def launch(self, jobs, keep):
+        bh, bv = C.c_int32(0), C.c_int32(0)
+        L.check(lib.mi_pil_resize_jobs_layout(jobs, len(jobs), C.byref(bh), C.byref(bv)), "layout")
+        host_lib.pil_emulate_launches(C.cast(jobs, C.c_void_p), len(jobs), bh.value, bv.value)
+        self._keep = keep
+    monkeypatch.setattr(GpuFrontAugment, "_launch", launch)
+    monkeypatch.setattr(GpuFrontAugment, "_check_device", lambda self, images: None)
+    fa = GpuFrontAugment(MAPPER_FRONT, device="cpu")
+    r = np.random.RandomState(8)
+    data = _mapper_data(9, 7)
+    draws = [fa.draw(i.shape[:2], r) for i, _ in data]
+    timgs = [torch.from_numpy(i) for i, _ in data]
+    for o, (i, _), d in zip(fa.apply(timgs, draws), data, draws):
+        assert np.array_equal(o.numpy(), A.front_image(i, d))
+    out, rows, sizes = fa.make_batch(timgs, [l for _, l in data], draws)
+    samples = []
+    for (i, l), d in zip(data, draws):
+        box, cls_ = A.filter_empty(A.front_boxes(l[:, :4], i.shape[:2], d), l[:, 4])
+        samples.append((A.front_image(i, d), np.concatenate([box.astype(np.float64), cls_[:, None]], 1)))
+    ref, ref_rows = A.preprocess_batch(samples)
+    assert np.array_equal(out.numpy(), ref) and np.array_equal(rows.numpy(), ref_rows) and sizes == [(d["nh"], d["nw"]) for d in draws]

@@ -196,6 +196,22 @@ def test_decoder_host_mirror_through_the_emulated_launches(emu, fmt, orient):
         assert np.array_equal(out, ref[:, :, ::-1] if fmt == "BGR" else ref), tag
     with pytest.raises(L.MI355Error):
         dec.decode(datas[:1])
+    # the body of decode() itself on host tensors: allocations, the H2D stand-in, the job table, the launches (emulated)
+    import torch
+
+    def alloc(count):
+        t = torch.empty(count, dtype=torch.int16)
+        return t, t.data_ptr()
+
+    def launch(jobs, n, bi_, bp_):
+        emu.jpeg_emulate_launches(C.cast(jobs, C.c_void_p), n, bi_, bp_)
+        return None
+    dec._check_device = lambda: None
+    dec._alloc_host = alloc
+    dec._launch = launch
+    for (tag, data), o in zip(files, dec.decode(datas)):
+        ref = _pillow(data, orient)
+        assert np.array_equal(o.numpy(), ref[:, :, ::-1] if fmt == "BGR" else ref), tag
 
 
 def test_host_half_survives_corrupt_files():

@@ -689,25 +689,32 @@ class GpuJpegDecoder:
         L.check(lib.mi_jpeg_jobs_layout(jobs, n, C.byref(bi), C.byref(bp)), "mi_jpeg_jobs_layout")
         return jobs, bi.value, bp.value
 
-    def decode(self, files):
-        """files: bytes-like JPEG files.  Returns device uint8 [H, W, 3] tensors (H, W after the EXIF transpose)."""
+    def _check_device(self):
         if self.device.type != "cuda":
             raise L.MI355Error("GpuJpegDecoder: the MI355X path needs a device (no CPU decode)")
-        lib = L.lib()
 
-        def pinned(count):
-            t = torch.empty(count, dtype=torch.int16, pin_memory=True)
-            return t, t.data_ptr()
-        infos, offs, host = self._host_half(files, pinned)
+    def _alloc_host(self, count):
+        t = torch.empty(count, dtype=torch.int16, pin_memory=True)
+        return t, t.data_ptr()
+
+    def _launch(self, jobs, n, blocks_idct, blocks_pix):
+        lib = L.lib()
+        tab = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(self.device)
+        st = L.stream_ptr()
+        L.check(lib.mi_jpeg_idct(tab.data_ptr(), n, blocks_idct, st), "mi_jpeg_idct")
+        L.check(lib.mi_jpeg_color(tab.data_ptr(), n, blocks_pix, st), "mi_jpeg_color")
+        return tab
+
+    def decode(self, files):
+        """files: bytes-like JPEG files.  Returns device uint8 [H, W, 3] tensors (H, W after the EXIF transpose)."""
+        self._check_device()
+        infos, offs, host = self._host_half(files, self._alloc_host)
         total = int(offs[-1])
         coef = host.to(self.device, non_blocking=True)
         planes = torch.empty(total, dtype=torch.uint8, device=self.device)
         outs = [torch.empty(*self.out_shape(i), 3, dtype=torch.uint8, device=self.device) for i in infos]
         jobs, bi, bp = self._jobs(infos, offs, coef.data_ptr(), planes.data_ptr(), [o.data_ptr() for o in outs])
-        tab = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(self.device)
-        st = L.stream_ptr()
-        L.check(lib.mi_jpeg_idct(tab.data_ptr(), len(files), bi, st), "mi_jpeg_idct")
-        L.check(lib.mi_jpeg_color(tab.data_ptr(), len(files), bp, st), "mi_jpeg_color")
+        tab = self._launch(jobs, len(files), bi, bp)
         self._keep = (host, coef, planes, tab)                      # alive until the stream has run the copy and the launches
         return outs
 
@@ -821,12 +828,15 @@ class GpuDetrMapper:
                 j.tmp = a
         return jobs, owners
 
+    def _check_device(self, images):
+        if self.device.type != "cuda" or not all(i.is_cuda for i in images):
+            raise L.MI355Error("GpuDetrMapper: the MI355X path needs device tensors (no CPU pixel path)")
+
     def make_batch(self, images, labels, rng_np=np.random):
         """images: device uint8 HWC tensors (e.g. GpuJpegDecoder(format="RGB") output), labels: float64 [n_i, 5] each.
         Returns [(uint8 [3, h, w] device tensor, float32 boxes [m, 4], classes [m])] - the "image" / gt_boxes / gt_classes of
         the reference's dataset dicts."""
-        if self.device.type != "cuda" or not all(i.is_cuda for i in images):
-            raise L.MI355Error("GpuDetrMapper: the MI355X path needs device tensors (no CPU pixel path)")
+        self._check_device(images)
         plans = [self.plan(tuple(i.shape[:2]), rng_np) for i in images]
         mids = [torch.empty(p["crop"][0], p["crop"][1], 3, dtype=torch.uint8, device=self.device) if p["crop"] is not None else None
                 for p in plans]
