@@ -53,6 +53,10 @@ const char* mi_last_error(void);
 #define MI_CONV_OUT_F32 2  /* y is fp32 (prediction maps), else bf16         */
 #define MI_CONV_RELU 8     /* y = max(result + bias, 0): the ReLU behind a Conv2d + FrozenBatchNorm2d of detectron2's ResNet
                               (forward, bf16 output, no MI_CONV_ACCUM / statistics); tile kernel only              */
+#define MI_CONV_RELUMASK 16 /* y = result where aux > 0, else 0; aux = bn_y (bf16 NHWC, the shape of y, pixel stride bn_ldy): the
+                              OUTPUT of the ReLU this data gradient flows back through - ReLU backward in the epilogue     */
+#define MI_CONV_ADDRELU 32  /* y = max(bf16(result + bias) + aux, 0) rounded as mi_ew_bf16 op 7: conv3 + shortcut + ReLU of a
+                              bottleneck block (detectron2 BottleneckBlock.forward) in the epilogue; aux = bn_y           */
 #define MI_CONV_BNBWD 4    /* data-gradient launch that also reduces the BatchNorm backward sums of the layer that
                               PRODUCED its output tensor: stats_acc += (sum dz, sum dz*xhat) per channel with
                               dz = y_out * act'(bn_y*scale+shift), xhat = (bn_y-mean)*invstd - replaces the

@@ -1,6 +1,8 @@
 """GPU (-m gpu): detectron2-shaped ResNet-50 (modeling/resnet.py) against the CPU restatement oracle/resnet_oracle.py -
 7x7 stem as 4x4 over space-to-depth (even and odd image sizes), frozen norms folded into the conv, max-pool, all four
 stages forward, and the gradients of the trainable stages (FREEZE_AT 2) with respect to weights and the res2 output."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -295,3 +297,31 @@ def test_trainable_layer_without_autograd_never_reuses_a_packed_image():
         m.weight.mul_(0.5)
         y4 = m(x).float()
         assert m.__dict__["_image"][1] is not img and _rel(y4 - shift, y1 - shift) < 1e-2
+
+
+@pytest.mark.skipif(os.environ.get("MI_TEST_UNVERIFIED") != "1",
+                    reason="the EPI 2 epilogues (MI_CONV_ADDRELU / MI_CONV_RELUMASK) were written after round 3's GPU minutes were "
+                           "spent; run with MI_TEST_UNVERIFIED=1 (tools/r4_first_call.sh does) before MI_RESNET_EPI_FUSE becomes a default")
+@pytest.mark.parametrize("cin,cout,bc,stride", [(256, 512, 128, 2), (512, 512, 128, 1), (256, 256, 64, 1)], ids=["shortcut_s2", "identity", "identity_64"])
+def test_bottleneck_epilogue_fusions_equal_the_elementwise_passes(cin, cout, bc, stride, monkeypatch):
+    """MI_RESNET_EPI_FUSE=1: conv3 + shortcut + ReLU in conv3's epilogue and the two ReLU masks in the data-gradient epilogues,
+    against the elementwise passes they replace - same roundings, so identical output and gradients"""
+    from yolov7_d2_amd.modeling.resnet import BottleneckBlock
+    torch.manual_seed(3)
+    blk = BottleneckBlock(cin, cout, bc, stride=stride).cuda()
+    for m in blk.modules():
+        if hasattr(m, "running_var"):
+            m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.1); m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, cin, 24, 36, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    go = torch.randn(2, cout, 24 // stride, 36 // stride, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MI_RESNET_EPI_FUSE", flag)
+        blk.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        out = blk(xi)
+        out.backward(go)
+        res.append([out.detach().float(), xi.grad.float()] + [p.grad.float().clone() for p in blk.parameters()])
+    for i, (a, b) in enumerate(zip(*res)):
+        assert torch.equal(a, b), (i, float((a - b).abs().max()))

@@ -1,6 +1,7 @@
 """CPU: the oracle restatement (oracle/yolox_oracle.py) reproduces the vectors obtained by executing the
 reference's own source (oracle/gen_golden.py -> tests/golden/*.npz)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -312,8 +313,21 @@ def test_resnet50_oracle_against_an_independent_implementation():
     statistics mapped key by key (stem.conv1 <-> embedder, res{s}.{b}.conv{k} <-> stages.{s-2}.layers.{b}.layer.{k-1}, shortcut
     <-> shortcut) - the four stage outputs in fp32.  Not detectron2 itself (parity with it stays unpinned), but an
     independent reading of the architecture: stem 7x7 s2 + max-pool 3/2/1, bottlenecks (3, 4, 6, 3), 1x1 stride-2 shortcuts."""
-    tr = pytest.importorskip("transformers")
     import resnet_oracle as R
+    # oracle/ref_loader.py (other tests of this suite) leaves spec-less stub modules in sys.modules (torchvision, detectron2,
+    # cv2, ...): transformers probes those names with importlib.util.find_spec, which raises on them - hide them meanwhile
+    stub_roots = ("alfred", "cv2", "detectron2", "fvcore", "loguru", "omegaconf", "pycocotools", "torchvision", "timm")
+    hidden = {k: sys.modules.pop(k) for k in list(sys.modules)
+              if k.split(".")[0] in stub_roots and getattr(sys.modules[k], "__spec__", 1) is None}
+    try:
+        tr = pytest.importorskip("transformers")
+        hf, hsd = _hf_resnet50(tr)
+    finally:
+        sys.modules.update(hidden)
+    _check_resnet_oracle_against(hf, hsd, R)
+
+
+def _hf_resnet50(tr):
     cfg = tr.ResNetConfig(num_channels=3, embedding_size=64, hidden_sizes=[256, 512, 1024, 2048], depths=[3, 4, 6, 3],
                           layer_type="bottleneck", hidden_act="relu", downsample_in_first_stage=False, downsample_in_bottleneck=False)
     torch.manual_seed(0)
@@ -325,7 +339,11 @@ def test_resnet50_oracle_against_an_independent_implementation():
             m.running_var.copy_(0.5 + torch.rand(m.num_features, generator=g))
             m.weight.data.copy_(0.5 + torch.rand(m.num_features, generator=g))
             m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
-    hsd = hf.state_dict()
+    return hf, hf.state_dict()
+
+
+def _check_resnet_oracle_against(hf, hsd, R):
+    g = torch.Generator().manual_seed(2)
     sd = R.init_state_dict(50, seed=0)
 
     def put(ours, theirs):

@@ -12,6 +12,8 @@ LIB_PATH = os.environ.get("MI355_LIB", os.path.join(_HERE, "libmi355det.so"))   
 MI_MAX_TAPS = 16
 MI_CONV_ACCUM = 1
 MI_CONV_RELU = 8
+MI_CONV_RELUMASK = 16
+MI_CONV_ADDRELU = 32
 MI_CONV_BNBWD = 4
 MI_CONV_OUT_F32 = 2
 MI_BN_BAR_WORDS = 64 * (1 + 2 * 16)

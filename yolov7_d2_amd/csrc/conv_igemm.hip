@@ -121,7 +121,7 @@ static int conv_fill(const mi_conv_desc* d, ConvK* k, ConvCfg* c, size_t* ldsByt
     static const int noatom = getenv("MI_DEBUG_NOATOM") ? atoi(getenv("MI_DEBUG_NOATOM")) : 0;
     if (noatom) k->flags |= 1024;
   }
-  MI_REQUIRE(!(d->flags & MI_CONV_RELU) || !((d->flags & (MI_CONV_ACCUM | MI_CONV_BNBWD | MI_CONV_OUT_F32)) || d->stats_acc),
+  MI_REQUIRE(!(d->flags & MI_CONV_RELU) || !((d->flags & (MI_CONV_ACCUM | MI_CONV_BNBWD | MI_CONV_OUT_F32 | MI_CONV_RELUMASK | MI_CONV_ADDRELU)) || d->stats_acc),
              "conv: MI_CONV_RELU is a plain forward epilogue (bf16 output, no accumulate / statistics)");
   if (d->flags & MI_CONV_BNBWD) {
     MI_REQUIRE(d->stats_acc && d->bn_y && d->bn_scale && d->bn_shift && d->bn_mean && d->bn_invstd,
@@ -130,6 +130,14 @@ static int conv_fill(const mi_conv_desc* d, ConvK* k, ConvCfg* c, size_t* ldsByt
                "conv: MI_CONV_BNBWD needs a bf16 output with Cout %% 8 == 0 (staged epilogue) and 16B-aligned bn_y");
     k->bn_y = (const __bf16*)d->bn_y; k->bn_scale = d->bn_scale; k->bn_shift = d->bn_shift;
     k->bn_mean = d->bn_mean; k->bn_invstd = d->bn_invstd; k->bn_ldy = d->bn_ldy; k->bn_act = d->bn_act;
+  } else if (d->flags & (MI_CONV_RELUMASK | MI_CONV_ADDRELU)) {
+    MI_REQUIRE((d->flags & (MI_CONV_RELUMASK | MI_CONV_ADDRELU)) != (MI_CONV_RELUMASK | MI_CONV_ADDRELU) && !d->stats_acc,
+               "conv: MI_CONV_RELUMASK and MI_CONV_ADDRELU exclude each other and the forward statistics");
+    MI_REQUIRE(d->bn_y && !(d->flags & MI_CONV_OUT_F32) && d->Cout % 8 == 0 && d->bn_ldy % 8 == 0 && d->bn_ldy >= d->Cout &&
+               ((uintptr_t)d->bn_y % 16) == 0,
+               "conv: the aux-tensor epilogue needs bn_y (16B-aligned, bn_ldy %% 8 == 0) and a bf16 output with Cout %% 8 == 0");
+    k->bn_y = (const __bf16*)d->bn_y; k->bn_ldy = d->bn_ldy;
+    k->bn_scale = k->bn_shift = k->bn_mean = k->bn_invstd = nullptr; k->bn_act = 0;
   } else {
     k->bn_y = nullptr; k->bn_scale = k->bn_shift = k->bn_mean = k->bn_invstd = nullptr; k->bn_ldy = 0; k->bn_act = 0;
   }
@@ -390,6 +398,7 @@ extern "C" int mi_conv2d_group_plan(const mi_conv_desc* descs, int n, void* tabl
     }
     MI_REQUIRE(c.KC == cb.KC && c.BN == cb.BN && c.TPIX == cb.TPIX && c.TPS == cb.TPS,
                "conv_group_plan: job %d resolved to another configuration", j);
+    MI_REQUIRE(!(ks[j].flags & (MI_CONV_RELUMASK | MI_CONV_ADDRELU)), "conv_group_plan: the aux-tensor epilogue (RELUMASK / ADDRELU) is a single-launch feature");
     const int e = (ks[j].flags & (MI_CONV_ACCUM | MI_CONV_BNBWD)) != 0;
     MI_REQUIRE(epi < 0 || epi == e, "conv_group_plan: jobs mix accumulating and plain launches");
     epi = e;

@@ -73,7 +73,8 @@ __device__ __forceinline__ void glds16(const void* g, unsigned lds_off) {
 // 0: run-time p.tps (multi-tap steps of the small-K / stride-2 / parity-class launches)
 // EPI: 1 = the staged epilogue may accumulate into y (MI_CONV_ACCUM) and / or take the BatchNorm-backward sums
 // (MI_CONV_BNBWD) - its global operands are prefetched into registers; 0 = plain store (+ forward statistics), which
-// keeps the forward kernels' register count (occupancy) low
+// keeps the forward kernels' register count (occupancy) low; 2 = EPI 1 + a second tensor at the output pixels used as a
+// ReLU mask or as a residual under a ReLU (MI_CONV_RELUMASK / MI_CONV_ADDRELU; single launches only)
 // PK: ConvK (kernel argument) or an address-space-4 (constant) ConvK for a job table entry: constant-address-space
 // loads are invariant, so the compiler keeps the fields in SGPRs across the "memory"-clobbering LDS-DMA asm and the
 // stores instead of re-loading them at every use
@@ -299,6 +300,11 @@ __device__ __forceinline__ void conv_igemm_body(PK& p, const int bid) {
       // output of a BNBWD launch) are requested BEFORE the staging, so their latency overlaps it instead of
       // serialising NP round trips in the loop
       const bool bnb = (p.flags & MI_CONV_BNBWD) != 0;
+      // EPI 2 (its own instantiations: the EPI 1 kernels keep their code): the second tensor at the output pixels is a ReLU
+      // OUTPUT whose sign masks the result (MI_CONV_RELUMASK: the ReLU backward of the layer this data gradient flows into)
+      // or a residual that is added before a ReLU (MI_CONV_ADDRELU: conv3 + shortcut + ReLU of a bottleneck block)
+      bool aux = false;
+      if constexpr (EPI == 2) aux = (p.flags & (MI_CONV_RELUMASK | MI_CONV_ADDRELU)) != 0;
       const __bf16* const byb = p.bn_y + (size_t)img * (size_t)p.outH * p.outW * p.bn_ldy + cbase;
       int opix[NP];
       bf16x8 oldv[NP], yv[NP];
@@ -306,7 +312,7 @@ __device__ __forceinline__ void conv_igemm_body(PK& p, const int bid) {
       for (int it = 0; it < NP; ++it) {
         opix[it] = out_pixel(pr + it * PPI);
         if (opix[it] >= 0 && accum) oldv[it] = *(const bf16x8*)(yb + (size_t)opix[it] * (size_t)p.ldy);
-        if (opix[it] >= 0 && bnb) yv[it] = *(const bf16x8*)(byb + (size_t)opix[it] * (size_t)p.bn_ldy);
+        if (opix[it] >= 0 && (bnb || aux)) yv[it] = *(const bf16x8*)(byb + (size_t)opix[it] * (size_t)p.bn_ldy);
       }
       float bsc[8], bsh[8], bmu[8], bis[8];
       if (bnb && cvalid) {
@@ -326,6 +332,15 @@ __device__ __forceinline__ void conv_igemm_body(PK& p, const int bid) {
           if (accum) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)v[e] + (float)oldv[it][e]);
+          }
+          if constexpr (EPI == 2) {
+            if (p.flags & MI_CONV_ADDRELU) {          // relu(bf16(conv + residual)): the rounding of mi_ew_bf16 op 7
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = (__bf16)fmaxf((float)(__bf16)((float)v[e] + (float)yv[it][e]), 0.f);
+            } else if (p.flags & MI_CONV_RELUMASK) {   // dy * (a > 0): mi_ew_bf16 op 2
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = (float)yv[it][e] > 0.f ? v[e] : (__bf16)0.f;
+            }
           }
           *(bf16x8*)(yb + (size_t)opix[it] * (size_t)p.ldy) = v;
           if (bnb) {
@@ -523,6 +538,8 @@ static int launch_one(const ConvK& k, size_t lds, hipStream_t s) {
 template <int KC, int BN, int WM, int WN, int CT, int PT>
 static int launch_cfg(const ConvK& k, size_t lds, hipStream_t s) {
   const bool epi = (k.flags & (MI_CONV_ACCUM | MI_CONV_BNBWD)) != 0;
+  if (k.flags & (MI_CONV_RELUMASK | MI_CONV_ADDRELU))      // the aux-tensor epilogue: separate instantiations
+    return k.tps == 1 ? launch_one<KC, BN, WM, WN, CT, PT, 1, 2>(k, lds, s) : launch_one<KC, BN, WM, WN, CT, PT, 0, 2>(k, lds, s);
   if (k.tps == 1) return epi ? launch_one<KC, BN, WM, WN, CT, PT, 1, 1>(k, lds, s) : launch_one<KC, BN, WM, WN, CT, PT, 1, 0>(k, lds, s);
   return epi ? launch_one<KC, BN, WM, WN, CT, PT, 0, 1>(k, lds, s) : launch_one<KC, BN, WM, WN, CT, PT, 0, 0>(k, lds, s);
 }

@@ -352,6 +352,13 @@ def _BLOCK_FN():
     return _FOLDED_FN() and os.environ.get("MI_RESNET_BLOCK_FN", "1") != "0"
 
 
+def _EPI_FUSE():
+    """MI_RESNET_EPI_FUSE=1 (default 0: written after round 3's GPU minutes were spent, not yet run on a device): the block's
+    conv3 + shortcut + ReLU and the two ReLU backward masks run in convolution epilogues (MI_CONV_ADDRELU / MI_CONV_RELUMASK,
+    the tile kernel's EPI 2 instantiations) instead of as three elementwise passes per block"""
+    return os.environ.get("MI_RESNET_EPI_FUSE", "0") == "1"
+
+
 def _relu_mask(g, a):
     """g * (a > 0) (bf16, same shape)"""
     out = torch.empty_like(g)
@@ -389,16 +396,20 @@ class _BottleneckFn(torch.autograd.Function):
         dev = x.device
         xh = _nhwc(x)
 
-        def run(g, inp, i, relu):
+        def run(g, inp, i, relu, add_relu=None):
             y = torch.empty(g.N, g.Ho, g.Wo, g.CoutP, dtype=torch.bfloat16, device=dev)
-            g.fwd(inp, imgs[i][0], y, bias=shifts[i], relu=relu)
+            g.fwd(inp, imgs[i][0], y, bias=shifts[i], relu=relu, add_relu=add_relu)
             return y
         a1 = run(g1, xh, 0, True)
         a2 = run(g2, a1, 1, True)
-        o = run(g3, a2, 2, False)
         sc = run(gs, xh, 3, False) if ssc else xh
-        y = torch.empty_like(o)
-        L.check(L.lib().mi_ew_bf16(o.data_ptr(), sc.data_ptr(), y.data_ptr(), o.numel(), 7, L.stream_ptr()), "mi_ew_bf16 add+relu")
+        ctx.epi = _EPI_FUSE()
+        if ctx.epi:
+            y = run(g3, a2, 2, False, add_relu=sc)            # relu(bf16(conv3 + shift) + shortcut) in conv3's epilogue
+        else:
+            o = run(g3, a2, 2, False)
+            y = torch.empty_like(o)
+            L.check(L.lib().mi_ew_bf16(o.data_ptr(), sc.data_ptr(), y.data_ptr(), o.numel(), 7, L.stream_ptr()), "mi_ew_bf16 add+relu")
         ctx.geoms, ctx.has_sc = geoms, bool(ssc)
         ctx.save_for_backward(xh, a1, a2, y, *[im[1] for im in imgs], *scales)
         return y.permute(0, 3, 1, 2)
@@ -417,12 +428,18 @@ class _BottleneckFn(torch.autograd.Function):
         gws = [None] * n
         gws[2] = g3.wgrad_scaled(a2, gm, scales[2])
         da2 = torch.empty_like(a2)
-        g3.dgrad(gm, wds[2], da2)
-        da2 = _relu_mask(da2, a2)
+        if ctx.epi:
+            g3.dgrad(gm, wds[2], da2, relu_mask=a2)
+        else:
+            g3.dgrad(gm, wds[2], da2)
+            da2 = _relu_mask(da2, a2)
         gws[1] = g2.wgrad_scaled(a1, da2, scales[1])
         da1 = torch.empty_like(a1)
-        g2.dgrad(da2, wds[1], da1)
-        da1 = _relu_mask(da1, a1)
+        if ctx.epi:
+            g2.dgrad(da2, wds[1], da1, relu_mask=a1)
+        else:
+            g2.dgrad(da2, wds[1], da1)
+            da1 = _relu_mask(da1, a1)
         gws[0] = g1.wgrad_scaled(xh, da1, scales[0])
         if gs is not None:
             gws[3] = gs.wgrad_scaled(xh, gm, scales[3])

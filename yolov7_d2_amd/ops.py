@@ -46,7 +46,8 @@ def _nchw(y, C):
 
 
 def _conv_desc(x, ldx, N, H, W, w_img, K, y, ldy, outH, outW, Cout, CoutPad, taps, in_stride=1, out_stride=1, oy=0, ox=0,
-               gridH=None, gridW=None, bias=None, stats=None, nslots=0, flags=0):
+               gridH=None, gridW=None, bias=None, stats=None, nslots=0, flags=0, aux=None):
+    """aux = (address, pixel stride) of the second tensor of the MI_CONV_RELUMASK / MI_CONV_ADDRELU epilogues"""
     d = L.mi_conv_desc()
     d.x, d.w, d.y = x, w_img.data_ptr(), y
     d.bias, d.stats_acc = L.ptr(bias), L.ptr(stats)
@@ -58,6 +59,8 @@ def _conv_desc(x, ldx, N, H, W, w_img, K, y, ldy, outH, outW, Cout, CoutPad, tap
     for t, (dy, dx, wi) in enumerate(taps):
         d.tap_dy[t], d.tap_dx[t], d.tap_w[t] = dy, dx, wi
     d.flags, d.stats_slots = flags, nslots
+    if aux is not None:
+        d.bn_y, d.bn_ldy = aux
     return d
 
 
@@ -115,27 +118,36 @@ class _ConvGeom:
             xh = xp
         return xh
 
-    def fwd(self, xh, wf, y, bias=None, stats=None, nslots=0, relu=False):
+    def fwd(self, xh, wf, y, bias=None, stats=None, nslots=0, relu=False, add_relu=None):
+        """add_relu: a bf16 NHWC tensor of y's shape: y = relu(bf16(conv + bias) + add_relu) in the epilogue (MI_CONV_ADDRELU)"""
         taps = [(r - self.pad, s - self.pad, r * self.k + s) for r in range(self.k) for s in range(self.k)]
+        fl = L.MI_CONV_RELU if relu else 0
+        aux = None
+        if add_relu is not None:
+            fl, aux = L.MI_CONV_ADDRELU, (add_relu.data_ptr(), add_relu.shape[-1])
         _run_conv(_conv_desc(xh.data_ptr(), self.CinP, self.N, self.H, self.W, wf, self.CinP, y.data_ptr(), y.shape[-1],
                              self.Ho, self.Wo, self.Cout, self.CoutP, taps, in_stride=self.s, bias=bias, stats=stats,
-                             nslots=nslots, flags=L.MI_CONV_RELU if relu else 0), "mi_conv2d (forward)")
+                             nslots=nslots, flags=fl, aux=aux), "mi_conv2d (forward)")
 
-    def dgrad(self, dyh, wd, dx, accum=False):
+    def dgrad(self, dyh, wd, dx, accum=False, relu_mask=None):
         """dyh bf16 [N,Ho,Wo,CoutP] (zero pad channels) -> dx bf16 [N,H,W,CinP] (real channels written).
         accum: dx += (MI_CONV_ACCUM; the strided forms then touch only the pixels that receive a gradient, so dx need not be
         zeroed for them)"""
         k, pad = self.k, self.pad
         fl = L.MI_CONV_ACCUM if accum else 0
+        aux = None
+        if relu_mask is not None:       # dx *= (relu_mask > 0) in the epilogue (MI_CONV_RELUMASK): relu_mask = the ReLU OUTPUT that was this conv's input
+            assert not accum and tuple(relu_mask.shape[:3]) == (self.N, self.H, self.W)
+            fl, aux = L.MI_CONV_RELUMASK, (relu_mask.data_ptr(), relu_mask.shape[-1])
         if self.s == 1:
             taps = [(pad - r, pad - s, r * k + s) for r in range(k) for s in range(k)]
             _run_conv(_conv_desc(dyh.data_ptr(), self.CoutP, self.N, self.Ho, self.Wo, wd, self.CoutP, dx.data_ptr(),
-                                 self.CinP, self.H, self.W, self.Cin, self.CinP, taps, flags=fl), "mi_conv2d (dgrad)")
+                                 self.CinP, self.H, self.W, self.Cin, self.CinP, taps, flags=fl, aux=aux), "mi_conv2d (dgrad)")
             return
         if k == 1:      # 1x1 stride 2 (ResNet shortcut): only the even pixels receive a gradient; dx arrives zeroed
             _run_conv(_conv_desc(dyh.data_ptr(), self.CoutP, self.N, self.Ho, self.Wo, wd, self.CoutP, dx.data_ptr(),
                                  self.CinP, self.H, self.W, self.Cin, self.CinP, [(0, 0, 0)], out_stride=2, oy=0, ox=0,
-                                 gridH=(self.H + 1) // 2, gridW=(self.W + 1) // 2, flags=fl), "mi_conv2d (dgrad 1x1 s2)")
+                                 gridH=(self.H + 1) // 2, gridW=(self.W + 1) // 2, flags=fl, aux=aux), "mi_conv2d (dgrad 1x1 s2)")
             return
         cls_taps = {0: [(1, 0)], 1: [(0, 1), (2, 0)]}   # output-pixel parity -> [(kernel row, dy offset)]
         for py in (0, 1):
@@ -144,7 +156,7 @@ class _ConvGeom:
                 gh, gw = (self.H - py + 1) // 2, (self.W - px + 1) // 2
                 _run_conv(_conv_desc(dyh.data_ptr(), self.CoutP, self.N, self.Ho, self.Wo, wd, self.CoutP, dx.data_ptr(),
                                      self.CinP, self.H, self.W, self.Cin, self.CinP, taps, out_stride=2, oy=py, ox=px,
-                                     gridH=gh, gridW=gw, flags=fl), "mi_conv2d (dgrad s2)")
+                                     gridH=gh, gridW=gw, flags=fl, aux=aux), "mi_conv2d (dgrad s2)")
 
     def wgrad(self, xh, dyh):
         gw = torch.empty(self.Cout, self.Cin, self.k, self.k, dtype=torch.float32, device=xh.device)
