@@ -188,6 +188,19 @@ def run(model, feeds):
             y = x[0].to({1: torch.float32, 7: torch.int64}[a["to"]])
         elif op == "Constant":
             y = torch.from_numpy(np.ascontiguousarray(a["value"]))
+        elif op == "Identity":
+            y = x[0]
+        elif op == "Shape":
+            y = torch.tensor(list(x[0].shape), dtype=torch.int64)
+        elif op == "Unsqueeze":
+            y = x[0]
+            for ax in sorted(a["axes"]):
+                y = y.unsqueeze(ax)
+        elif op == "Expand":
+            y = x[0] * torch.ones([int(v) for v in x[1].tolist()], dtype=x[0].dtype)
+        elif op == "Gather":
+            y = torch.index_select(x[0], a.get("axis", 0), x[1].reshape(-1)).reshape(
+                x[0].shape[: a.get("axis", 0)] + tuple(x[1].shape) + x[0].shape[a.get("axis", 0) + 1:])
         else:
             raise NotImplementedError(op)
         for name, v in zip(outs, y if isinstance(y, list) else [y]):

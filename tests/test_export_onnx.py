@@ -134,3 +134,37 @@ def test_exported_variants_against_the_reference_run_by_path(depth, width, depth
     keep = [c for c in range(6 + nc) if c != 5]
     np.testing.assert_allclose(out[..., keep], want[..., keep], rtol=5e-4, atol=5e-4)
     assert (out[..., 5] == want[..., 5]).mean() > 0.97
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/yolov7"), reason="the reference tree only exists in the build container")
+def test_written_graph_equals_the_file_torchs_exporter_traces_from_the_reference():
+    """what export.py itself would write: the REFERENCE's modules (by path, head.onnx_export = True) traced by torch's
+    TorchScript exporter at opset 11 with constant folding - against the graph this package writes from its module tree
+    with the same weights: the same operator census where it matters (83 Conv, 80 Sigmoid, 76 Mul, 8 Add, 3 MaxPool, 2
+    Resize, no BatchNormalization in either) and the same output when both files are executed"""
+    import collections
+    import contextlib
+    import ref_loader
+    import yolox_oracle as O
+    from yolov7_d2_amd.export_onnx import export_yolox_onnx
+    ref, _ = ref_loader.build_reference_yolox(0.33, 0.5, 80, seed=0)
+    ref.load_state_dict(O.init_state_dict(0.33, 0.5, 80, seed=0))
+    ref.eval()
+    ref.head.onnx_export = True
+    imgs, _ = O.synth_batch(2, 64, 96, seed=11, max_gt=4)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            traced = _torch_export(ref, imgs, do_constant_folding=True, input_names=["images"], output_names=["outs"])
+    except Exception as e:       # noqa: BLE001
+        pytest.skip("torch's exporter is unavailable here: %r" % (e,))
+    model, _ = _model()
+    mine = export_yolox_onnx(model, io.BytesIO(), height=64, width=96)
+    gt, gm = OI.load(traced), OI.load(mine)
+    ct, cm = collections.Counter(n[0] for n in gt["nodes"]), collections.Counter(n[0] for n in gm["nodes"])
+    for op in ("Conv", "Sigmoid", "Mul", "Add", "MaxPool", "Resize", "Exp", "ArgMax", "Split", "BatchNormalization"):
+        assert ct[op] == cm[op], (op, ct[op], cm[op])
+    (a,) = OI.run(gt, {"images": imgs.numpy()})                                   # the traced file takes NCHW (the meta-arch's
+    (b,) = OI.run(gm, {"images": imgs.permute(0, 2, 3, 1).contiguous().numpy()})  # preprocess_input permute sits outside `ref`)
+    keep = [c for c in range(86) if c != 5]
+    np.testing.assert_allclose(b[..., keep], a[..., keep], rtol=2e-4, atol=2e-4)
+    assert (a[..., 5] == b[..., 5]).mean() > 0.98
