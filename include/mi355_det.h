@@ -593,8 +593,9 @@ int mi_mixup_blend(const mi_mixup_job* jobs_dev, int njobs, int total_blocks, mi
  * T.RandomCrop window is an offset pointer; optionally mirrored first, as DetrDatasetMapper's flip-then-resize order needs,
  * data/dataset_mapper.py:777-800) -> nh x nw, element
  * (c, y, x) at dst + c dsc + y dsy + x dsx bytes (HWC: 1, 3 nw, 3; a sample of a padded NCHW batch: Hp Wp, Wp, 1);
- * tmp = [h0][nw][3] scratch of the horizontal pass (unused when nw == w0).  The colour augmentations of that list
- * (RandomSaturation / RandomBrightness / YOLOFRandomDistortion: cv2 HSV tables) are not built.
+ * tmp = [h0][nw][3] scratch of the horizontal pass (unused when nw == w0).  RandomSaturation / RandomBrightness (detectron2
+ * BlendTransform, numpy's fp64 / fp32 arithmetic) are applied per pixel between the flips and the shift; YOLOFRandomDistortion
+ * (cv2's HSV tables) is not built.
  * mi_pil_resize_jobs_layout validates the (host) table, fills blk0h / blk0v and returns the block counts of the two flat
  * launches; the launches take the device copy of the table.  Down-scaling factors up to 8. */
 typedef struct mi_pil_resize_job {
@@ -603,9 +604,12 @@ typedef struct mi_pil_resize_job {
   void* dst;
   int64_t dsc, dsy, dsx;
   int64_t src_ld;            /* bytes between source rows (3 w0 for a whole image; the parent's for a crop window) */
+  double sat_src;            /* RandomSaturation: 1 - w (fp64, the grey image's weight) */
   int32_t h0, w0, nh, nw;
   int32_t hflip, vflip, shift_x, shift_y;
-  int32_t src_hflip, pad_;   /* src_hflip: mirror the source BEFORE the resampling (DetrDatasetMapper: T.RandomFlip, then the resizes) */
+  int32_t src_hflip;         /* mirror the source BEFORE the resampling (DetrDatasetMapper: T.RandomFlip, then the resizes) */
+  int32_t color;             /* bit 0 RandomSaturation, bit 1 RandomBrightness (d2 BlendTransform on the uint8 image), after the flips */
+  float sat_dst, bri_dst;    /* w as float32 */
   int32_t blk0h, blk0v;
 } mi_pil_resize_job;
 int mi_pil_resize_jobs_layout(mi_pil_resize_job* jobs_host, int njobs, int32_t* blocks_h, int32_t* blocks_v);

@@ -491,7 +491,7 @@ def resize_shortest_edge_shape(oldh, oldw, short_edge_length, max_size):
 
 
 def draw_front(rng_np, hw, min_sizes=(416, 512, 608, 768), max_size=800, sample_style="choice", hflip_prob=0.5, vflip_prob=0.5,
-               shift_prob=0.5, max_shifts=32, hflip=True, vflip=True, shift=True):
+               shift_prob=0.5, max_shifts=32, hflip=True, vflip=True, shift=True, saturation=False, brightness=False):
     """the random numbers of the chain in the reference's order (AugmentationList: each get_transform sees the image the
     previous transforms produced): ResizeShortestEdge (np.random.choice / randint), RandomFlip x2 (np.random.uniform),
     YOLOFRandomShift (uniform, then randint x, randint y when it fires)"""
@@ -506,6 +506,10 @@ def draw_front(rng_np, hw, min_sizes=(416, 512, 608, 768), max_size=800, sample_
         d["hflip"] = bool(rng_np.uniform(0, 1.0) < hflip_prob)
     if vflip:
         d["vflip"] = bool(rng_np.uniform(0, 1.0) < vflip_prob)
+    if saturation:                  # detection_utils.py:70-73: RandomSaturation(0.8, 1.2), RandomBrightness(0.8, 1.2) (d2 upstream)
+        d["sat"] = float(rng_np.uniform(0.8, 1.2))
+    if brightness:
+        d["bri"] = float(rng_np.uniform(0.8, 1.2))
     if shift and max_shifts > 0:
         if rng_np.uniform(0, 1.0) < shift_prob:
             d["sx"] = int(rng_np.randint(low=-max_shifts, high=max_shifts))
@@ -521,6 +525,17 @@ def front_image(img, d):
         out = np.flip(out, axis=1)
     if d["vflip"]:
         out = np.flip(out, axis=0)
+    if d.get("sat") is not None:    # detectron2 RandomSaturation.get_transform + BlendTransform.apply_image, verbatim numpy
+        w = d["sat"]
+        grayscale = out.dot([0.299, 0.587, 0.114])[:, :, np.newaxis]
+        x = out.astype(np.float32)
+        x = (1 - w) * grayscale + w * x
+        out = np.clip(x, 0, 255).astype(np.uint8)
+    if d.get("bri") is not None:    # RandomBrightness: BlendTransform(src_image=0, src_weight=1 - w, dst_weight=w)
+        w = d["bri"]
+        x = out.astype(np.float32)
+        x = (1 - w) * 0 + w * x
+        out = np.clip(x, 0, 255).astype(np.uint8)
     sx, sy = d["sx"], d["sy"]
     if sx or sy:
         new = np.zeros_like(out)

@@ -443,3 +443,38 @@ def test_front_apply_and_make_batch_bodies_on_the_host(host_lib, monkeypatch):
         samples.append((A.front_image(i, d), np.concatenate([box.astype(np.float64), cls_[:, None]], 1)))
     ref, ref_rows = A.preprocess_batch(samples)
     assert np.array_equal(out.numpy(), ref) and np.array_equal(rows.numpy(), ref_rows) and sizes == [(d["nh"], d["nw"]) for d in draws]
+
+
+def test_colour_blends_equal_numpys_arithmetic(host_lib, monkeypatch):
+    """INPUT.COLOR_JITTER: detectron2's RandomSaturation / RandomBrightness (BlendTransform on the uint8 image) between the
+    flips and the shift - the oracle runs the d2 lines verbatim in numpy (fp64 grey + fp32 image product for the saturation,
+    fp32 for the brightness, truncation); the kernels' thread bodies (host build) must reproduce every pixel; the draws take
+    their place in the stream (after the flips, before the shift)"""
+    import torch
+    from yolov7_d2_amd import _lib as L
+    from yolov7_d2_amd.data_pipeline import GpuFrontAugment
+    lib = L.lib()
+
+    def launch(self, jobs, keep):
+        bh, bv = C.c_int32(0), C.c_int32(0)
+        L.check(lib.mi_pil_resize_jobs_layout(jobs, len(jobs), C.byref(bh), C.byref(bv)), "layout")
+        host_lib.pil_emulate_launches(C.cast(jobs, C.c_void_p), len(jobs), bh.value, bv.value)
+        self._keep = keep
+    monkeypatch.setattr(GpuFrontAugment, "_launch", launch)
+    monkeypatch.setattr(GpuFrontAugment, "_check_device", lambda self, images: None)
+    for sat, bri in ((True, True), (True, False), (False, True)):
+        fa = GpuFrontAugment(dict(MAPPER_FRONT, SATURATION=sat, BRIGHTNESS=bri), device="cpu")
+        r1, r2 = np.random.RandomState(3), np.random.RandomState(3)
+        data = _mapper_data(12, 8)
+        draws = []
+        for i, _ in data:
+            d1 = fa.draw(i.shape[:2], r1)
+            d2 = A.draw_front(r2, i.shape[:2], saturation=sat, brightness=bri, **ORACLE_FRONT)
+            assert d1 == d2 and (("sat" in d1) == sat) and (("bri" in d1) == bri)
+            draws.append(d1)
+        assert r1.randint(1 << 30) == r2.randint(1 << 30)
+        outs = fa.apply([torch.from_numpy(i) for i, _ in data], draws)
+        for o, (i, _), d in zip(outs, data, draws):
+            ref = A.front_image(i, d)
+            assert np.array_equal(o.numpy(), ref), d
+            assert not np.array_equal(ref, A.front_image(i, dict(d, sat=None, bri=None)))      # the blends did something

@@ -160,9 +160,9 @@ class mi_mixup_job(C.Structure):
 
 class mi_pil_resize_job(C.Structure):
     _fields_ = ([("src", C.c_void_p), ("tmp", C.c_void_p), ("dst", C.c_void_p), ("dsc", C.c_int64), ("dsy", C.c_int64),
-                 ("dsx", C.c_int64), ("src_ld", C.c_int64)] +
-                [(n, C.c_int32) for n in ("h0", "w0", "nh", "nw", "hflip", "vflip", "shift_x", "shift_y", "src_hflip", "pad_",
-                                         "blk0h", "blk0v")])
+                 ("dsx", C.c_int64), ("src_ld", C.c_int64), ("sat_src", C.c_double)] +
+                [(n, C.c_int32) for n in ("h0", "w0", "nh", "nw", "hflip", "vflip", "shift_x", "shift_y", "src_hflip", "color")] +
+                [("sat_dst", C.c_float), ("bri_dst", C.c_float), ("blk0h", C.c_int32), ("blk0v", C.c_int32)])
 
 
 class mi_jpeg_info(C.Structure):

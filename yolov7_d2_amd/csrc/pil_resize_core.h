@@ -25,9 +25,12 @@ struct PilJob {   // mirrors mi_pil_resize_job (include/mi355_det.h)
   unsigned char* dst;
   int64_t dsc, dsy, dsx;
   int64_t src_ld;
+  double sat_src;              // RandomSaturation: 1 - w as Python computes it (the weight of the grey image, fp64)
   int32_t h0, w0, nh, nw;
   int32_t hflip, vflip, shift_x, shift_y;
-  int32_t src_hflip, pad_;     // src_hflip: the source is mirrored left-right BEFORE the resampling (T.RandomFlip ahead of the resize)
+  int32_t src_hflip;           // the source is mirrored left-right BEFORE the resampling (T.RandomFlip ahead of the resize)
+  int32_t color;               // bit 0: RandomSaturation, bit 1: RandomBrightness (detectron2 BlendTransform), after the flips
+  float sat_dst, bri_dst;      // w as float32 (numpy multiplies the float32 image by the weak Python scalar in float32)
   int32_t blk0h, blk0v;
 };
 
@@ -87,8 +90,33 @@ MI_HD void pil_h_pixel(const PilJob& j, int y, int xo, unsigned char out[3]) {
   out[0] = pil_clip8(s0); out[1] = pil_clip8(s1); out[2] = pil_clip8(s2);
 }
 
+// detectron2 RandomSaturation / RandomBrightness = BlendTransform.apply_image on a uint8 image, numpy's dtypes exactly:
+//   saturation: grey = img.dot([0.299, 0.587, 0.114]) (fp64, the channel order as stored), out = (1 - w) * grey [fp64] +
+//               w * float32(img) [fp32 product, then widened]; brightness: out = w * float32(img) in fp32;
+//   np.clip(out, 0, 255).astype(np.uint8) truncates.  No fused multiply-add (-ffp-contract=off).
+MI_HD void pil_color(const PilJob& j, unsigned char o[3]) {
+  if (j.color & 1) {
+    const double grey = ((double)o[0] * 0.299 + (double)o[1] * 0.587) + (double)o[2] * 0.114;
+    const double g = j.sat_src * grey;
+    for (int c = 0; c < 3; ++c) {
+      const float u = j.sat_dst * (float)o[c];
+      double v = g + (double)u;
+      v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+      o[c] = (unsigned char)v;
+    }
+  }
+  if (j.color & 2) {
+    for (int c = 0; c < 3; ++c) {
+      float v = j.bri_dst * (float)o[c];
+      v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
+      o[c] = (unsigned char)v;
+    }
+  }
+}
+
 // destination pixel (yd, xd) of the nh x nw result after the vertical pass, HFlipTransform, VFlipTransform and
-// YOLOFShiftTransform (zeros where the shifted image does not reach; transform.py:355-388), in that order.
+// the colour blends (pil_color) and YOLOFShiftTransform (zeros where the shifted image does not reach; transform.py:355-388),
+// in that order.
 // Reads the horizontally resampled image tmp [h0][nw][3], or the source itself when nw == w0.
 MI_HD void pil_v_pixel(const PilJob& j, int yd, int xd, unsigned char out[3]) {
   const bool direct = j.nw == j.w0;                            // no horizontal pass: the vertical pass reads the source itself
@@ -105,6 +133,7 @@ MI_HD void pil_v_pixel(const PilJob& j, int yd, int xd, unsigned char out[3]) {
   if (j.nh == j.h0) {                                          // no vertical pass: the row passes through unchanged
     const unsigned char* p = h_img + (int64_t)ys * h_ld + (int64_t)xs * 3;
     out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
+    if (j.color) pil_color(j, out);
     return;
   }
   PilTaps t;
@@ -117,6 +146,7 @@ MI_HD void pil_v_pixel(const PilJob& j, int yd, int xd, unsigned char out[3]) {
     s2 += (int)p[2] * t.k[y];
   }
   out[0] = pil_clip8(s0); out[1] = pil_clip8(s1); out[2] = pil_clip8(s2);
+  if (j.color) pil_color(j, out);
 }
 
 // one thread of the two flat launches (block = 256 threads; a job's first block is blk0h / blk0v, filled by

@@ -290,7 +290,8 @@ class GpuMosaicMapper:
 
 # ------------------------------------------------------------------------------------------------ the T.* front
 FRONT_DEFAULTS = dict(MIN_SIZE_TRAIN=(416, 512, 608, 768), MAX_SIZE_TRAIN=800, MIN_SIZE_TRAIN_SAMPLING="choice",
-                      HFLIP=True, HFLIP_PROB=0.5, VFLIP=True, VFLIP_PROB=0.5, SHIFT=True, SHIFT_PIXELS=32)
+                      HFLIP=True, HFLIP_PROB=0.5, VFLIP=True, VFLIP_PROB=0.5, SATURATION=False, BRIGHTNESS=False,
+                      SHIFT=True, SHIFT_PIXELS=32)
 # (configs/coco/yolox_s.yaml:35-38 + yolov7/config.py:276-286: INPUT.RANDOM_FLIP_HORIZONTAL / _VERTICAL / SHIFT defaults)
 
 
@@ -302,9 +303,11 @@ class GpuFrontAugment:
     off (after INPUT.MOSAIC_AND_MIXUP.DISABLE_AT_ITER, or mosaic_flag 0), the WHOLE mapper: dataset_mapper.py:615-640 then
     only builds Instances and drops empty boxes.  The host draws the reference's random numbers in the reference's order and
     does its float64 box arithmetic; the pixels (Pillow's 8-bit bilinear resampling, the flips, the shift) are two launches
-    for any number of images (mi_pil_resize_h / _v).  The colour entries of that list (RandomSaturation, RandomBrightness,
-    YOLOFRandomDistortion) are not built: with INPUT.COLOR_JITTER / INPUT.DISTORTION off (the config.py defaults) the
-    random stream and the result are the reference's, with them on (yolox_s.yaml) this front skips them."""
+    for any number of images (mi_pil_resize_h / _v), RandomSaturation / RandomBrightness (INPUT.COLOR_JITTER; detectron2's
+    BlendTransform in numpy's fp64 / fp32 arithmetic) included, per pixel between the flips and the shift.
+    YOLOFRandomDistortion (cv2's 8-bit HSV conversion both ways, after which the reference's image is float32) is NOT built:
+    with INPUT.DISTORTION off (the config.py default) the random stream and the result are the reference's, with it on
+    (yolox_s.yaml) this front skips it."""
 
     def __init__(self, cfg=None, device="cuda", max_boxes=100, pad_value=114, size_divisibility=32):
         c = dict(FRONT_DEFAULTS)
@@ -338,6 +341,10 @@ class GpuFrontAugment:
             d["hflip"] = bool(rng_np.uniform(0, 1.0) < c["HFLIP_PROB"])
         if c["VFLIP"]:
             d["vflip"] = bool(rng_np.uniform(0, 1.0) < c["VFLIP_PROB"])
+        if c["SATURATION"]:                                        # INPUT.COLOR_JITTER.SATURATION: RandomSaturation(0.8, 1.2)
+            d["sat"] = float(rng_np.uniform(0.8, 1.2))
+        if c["BRIGHTNESS"]:                                        # INPUT.COLOR_JITTER.BRIGHTNESS: RandomBrightness(0.8, 1.2)
+            d["bri"] = float(rng_np.uniform(0.8, 1.2))
         if c["SHIFT"] and c["SHIFT_PIXELS"] > 0:
             if rng_np.uniform(0, 1.0) < 0.5:                       # YOLOFRandomShift(prob=0.5 default, max_shifts)
                 d["sx"] = int(rng_np.randint(low=-c["SHIFT_PIXELS"], high=c["SHIFT_PIXELS"]))
@@ -411,6 +418,12 @@ class GpuFrontAugment:
             h0, w0 = img.shape[:2]
             j.src, j.src_ld, j.h0, j.w0, j.nh, j.nw = img.data_ptr(), 3 * w0, h0, w0, d["nh"], d["nw"]
             j.hflip, j.vflip, j.shift_x, j.shift_y = int(d["hflip"]), int(d["vflip"]), d["sx"], d["sy"]
+            if d.get("sat") is not None:                           # BlendTransform(grey, 1 - w, w): numpy's dtypes (see pil_color)
+                j.color |= 1
+                j.sat_src, j.sat_dst = 1 - d["sat"], float(np.float32(d["sat"]))
+            if d.get("bri") is not None:
+                j.color |= 2
+                j.bri_dst = float(np.float32(d["bri"]))
             if d["nw"] != w0:
                 t = torch.empty(h0, d["nw"], 3, dtype=torch.uint8, device=img.device)
                 tmps.append(t)
