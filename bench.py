@@ -621,6 +621,30 @@ def pmc_child(args):
     torch.cuda.synchronize()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no rendezvous in the environment: re-execute this command line as N ranks of one
+    node (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>`),
+    the form the driver itself uses for N > 1.  The children inherit stdout: rank 0's JSON line is this process's line."""
+    import socket
+    import subprocess
+    share = os.environ.get("MI_DIST_SHARE_DEVICE", "0") == "1"
+    have = torch.cuda.device_count()
+    if not share and have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible (MI_DIST_SHARE_DEVICE=1 "
+                         "MI_DIST_BACKEND=gloo rehearses the world > 1 path on one device)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's peer mappings fail without it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc:
+        raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -642,6 +666,10 @@ def main():
     if args.config == "sparseinst":
         return bench_sparseinst(args)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started bare (`python bench.py --gpus N`): become the launcher of the reference's `launch(main, num_gpus, ...)`
+        # (train_det.py:78-87) - one rank per GPU under torch.distributed.run on a free local port; rank 0 prints the line
+        return self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

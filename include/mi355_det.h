@@ -499,7 +499,7 @@ int mi_dropout_seed_offset(const uint64_t* dev_word);
 
 /* ---- row-wise ops of DETR's transformer layers (detr_backbone.py:135-278) -------------------
  * nn.LayerNorm(E) forward / backward over bf16 [T][E] token rows (fp32 gamma/beta/mean/rstd), eps 1e-5;
- * E %% 64 == 0, E <= 1024; ws (backward): fp32 [ceil(T/64)][E][2].  mi_ew_bf16: op 0 out = a + b (residual),
+ * E %% 64 == 0, E <= 1024; ws (backward): fp32 [ceil(T/16)][E][2].  mi_ew_bf16: op 0 out = a + b (residual),
  * op 1 out = relu(a), op 2 out = a * (b > 0) (ReLU backward: a = dy, b = forward output), op 3 out = sigmoid(a),
  * op 4 out = a * b * (1 - b) (sigmoid backward: a = dy, b = forward output); op 5 / 6 swish and its backward; op 7 out =
  * relu(a + b) (the tail of a ResNet bottleneck, bit-identical to op 0 followed by op 1); n %% 8 == 0. */
@@ -734,10 +734,22 @@ typedef struct mi_adamw_chunk {
 } mi_adamw_chunk;
 int mi_adamw_step_multi(const mi_adamw_tensor* tensors_dev, const mi_adamw_chunk* chunks_dev, int nchunks, float beta1,
                         float beta2, float eps, const int64_t* step_dev, float grad_scale, mi_stream_t s);
+/* FullModelGradientClippingOptimizer.step (yolov7/optimizer/build.py:206-223: clip_grad_norm_ over all parameters, then
+ * the update) over the same tables without touching the host: mi_grad_norm_multi leaves coef_norm_out[0] = min(1, max_norm
+ * / (||g||_2 + 1e-6)) and [1] = the norm on the device (partial_dev: nchunks doubles of scratch, summed in index order);
+ * mi_adamw_step_multi_clip multiplies every gradient by grad_scale * *grad_scale_dev (NULL: grad_scale alone) */
+int mi_grad_norm_multi(const mi_adamw_tensor* tensors_dev, const mi_adamw_chunk* chunks_dev, int nchunks,
+                       double* partial_dev, float max_norm, float* coef_norm_out, mi_stream_t s);
+int mi_adamw_step_multi_clip(const mi_adamw_tensor* tensors_dev, const mi_adamw_chunk* chunks_dev, int nchunks, float beta1,
+                             float beta2, float eps, const int64_t* step_dev, float grad_scale,
+                             const float* grad_scale_dev, mi_stream_t s);
 /* full-model gradient clipping (FullModelGradientClippingOptimizer, yolov7/optimizer/build.py:206-223 =
  * torch.nn.utils.clip_grad_norm_ over all parameters): grads *= min(1, max_norm / (||grads||_2 + 1e-6)) without a host
  * synchronisation; ws: 1024 doubles of scratch; norm_out (optional, device) receives the norm */
 int mi_grad_clip_full_model(float* grads, int64_t n, float max_norm, double* ws, float* norm_out, mi_stream_t s);
+/* diagnostic (tools/icache_probe.py; not on the product path): a kernel of `kb` KiB (8 / 16 / 32 / 64 / 128) of straight-line
+ * scalar no-ops on `blocks` single-wave blocks - displaces that much of every instruction cache without touching data */
+int mi_debug_code_polluter(int kb, int blocks, mi_stream_t s);
 /* PositionEmbeddingSine.forward (modeling/backbone/detr_backbone.py:309-375): mask [B][H][W] bytes (non-zero = padding)
  * -> pos fp32 [B][2*num_pos_feats][H][W] */
 int mi_pos_embed_sine(const uint8_t* mask, int B, int H, int W, int num_pos_feats, float temperature, int normalize,

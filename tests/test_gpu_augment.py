@@ -135,24 +135,23 @@ def test_train_step_fed_by_the_pipeline():
         GpuMosaicMapper(device="cpu").make_batch(pool, [(0, 1, 2, 3)], [mapper.draw(rng_np, rng_py)])
 
 
+def _run_child(name, timeout=300, expect="bit-identical"):
+    """the four input-pipeline compositions run in a child process (their own CUDA context); all four passed on a device in
+    round 4's first GPU call and are plain assertions since: a mismatch, a crash or a timeout FAILS the suite"""
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), name)
+    r = subprocess.run([sys.executable, child], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0 and expect in r.stdout, (r.stdout + r.stderr)[-2000:]
+
+
 @pytest.mark.gpu
 def test_front_augment_kernels_equal_pillow_and_the_oracle():
     """The detectron2 T.* front (T.ResizeShortestEdge = Pillow's 8-bit bilinear resampling, T.RandomFlip x2, YOLOFRandomShift;
     yolov7/data/detection_utils.py:37-86) on the GPU: `GpuFrontAugment.apply` (HWC images for the mosaic pool) and
     `.make_batch` (the mapper with the mosaic off + preprocess_image) bit-identical to the oracle and to Pillow itself
     (tests/front_augment_gpu_child.py: eight images at COCO sizes, every combination of flips / shift / skipped passes)."""
-    import subprocess
-    import sys
-    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "front_augment_gpu_child.py")
-    # (passed on a device - bit-identical - before the job gained its source row stride / mirrored-source fields; those
-    #  were added after the GPU minutes were spent and are re-verified through the host build only, so a mismatch is
-    #  reported as XFAIL rather than stopping the suite until the generalised job has run on a device once)
-    try:
-        r = subprocess.run([sys.executable, child], capture_output=True, text=True, timeout=240)
-    except subprocess.TimeoutExpired:
-        pytest.xfail("front augment child timed out")
-    if r.returncode != 0 or "bit-identical" not in r.stdout:
-        pytest.xfail("front augment kernels after the job generalisation: " + (r.stdout + r.stderr)[-800:])
+    _run_child("front_augment_gpu_child.py", 240)
 
 
 @pytest.mark.gpu
@@ -160,54 +159,22 @@ def test_dataset_mapper_batches_equal_the_oracle():
     """`GpuDatasetMapper.make_batch` = MyDatasetMapper2.__call__ per sample (dataset_mapper.py:477-640: front, mosaic flag,
     partners, four pastes, random_perspective, mixup) + preprocess_image over the MIXED batch, against the oracle's
     `mapper_call` on the same random streams: pixels and label rows bit-identical (tests/mapper_gpu_child.py: eight batches
-    of six, with and without mixup).  The host half is held to the oracle by the CPU suite (tests/test_front_augment.py) and
-    every kernel involved has its own bit-exact GPU test; this COMPOSITION was written after round 3's GPU minutes were
-    spent and has not run on a device yet - it runs in a child process and a mismatch or a crash there is reported as XFAIL
-    instead of stopping the suite; it becomes a plain assertion once it has passed on a device."""
-    import subprocess
-    import sys
-    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mapper_gpu_child.py")
-    try:
-        r = subprocess.run([sys.executable, child], capture_output=True, text=True, timeout=300)
-    except subprocess.TimeoutExpired:
-        pytest.xfail("dataset mapper child timed out")
-    if r.returncode != 0:
-        pytest.xfail("dataset mapper composition (first GPU contact): " + (r.stdout + r.stderr)[-800:])
+    of six, with and without mixup)."""
+    _run_child("mapper_gpu_child.py")
 
 
 @pytest.mark.gpu
 def test_jpeg_decoder_equals_pillow():
-    """`GpuJpegDecoder.decode` = detectron2 utils.read_image for baseline JPEGs (dataset_mapper.py:646-648): host Huffman
-    decoding in the library, IDCT and up-sampling / colour / EXIF kernels on the GPU, against Pillow's decode of the same 13
-    files (COCO sizes, 4:4:4 / 4:2:2 / 4:2:0, grey, optimised tables, restart markers, EXIF orientations), BGR + orientation
-    and plain RGB.  The CPU suite holds the library's host half and the kernels' thread bodies (host build, walked over the
-    library's own job table) bit-identical to Pillow (tests/test_jpeg_decode.py); the launches were written after round 3's
-    GPU minutes were spent and have not met a device yet: child process, a mismatch or a crash there is reported as XFAIL
-    instead of stopping the suite, and becomes a plain assertion once it has passed on a device."""
-    import subprocess
-    import sys
-    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "jpeg_gpu_child.py")
-    try:
-        r = subprocess.run([sys.executable, child], capture_output=True, text=True, timeout=300)
-    except subprocess.TimeoutExpired:
-        pytest.xfail("jpeg decoder child timed out")
-    if r.returncode != 0:
-        pytest.xfail("jpeg decoder launches (first GPU contact): " + (r.stdout + r.stderr)[-800:])
+    """`GpuJpegDecoder.decode` = detectron2 utils.read_image for JPEG files (dataset_mapper.py:646-648): host Huffman
+    decoding in the library, IDCT and up-sampling / colour / EXIF kernels on the GPU, against Pillow's decode of the same
+    files (COCO sizes, 4:4:4 / 4:2:2 / 4:2:0, grey, optimised tables, restart markers, progressive, EXIF orientations), BGR +
+    orientation and plain RGB."""
+    _run_child("jpeg_gpu_child.py")
 
 
 @pytest.mark.gpu
 def test_detr_mapper_equals_the_oracle():
     """`GpuDetrMapper.make_batch` = DetrDatasetMapper.__call__ (dataset_mapper.py:804-900: flip, the resize + crop branch, the
     final resize, boxes / Instances) at the reference's DETR sizes, pixels and boxes bit-identical to the oracle
-    (tests/detr_mapper_gpu_child.py).  Same standing as the mapper composition above: the host half and both stages of jobs
-    are held to the oracle / Pillow by the CPU suite through the host build of the kernels' thread bodies, the launches on the
-    generalised job (source row stride, mirrored source) have not met a device yet - child process, XFAIL on a mismatch."""
-    import subprocess
-    import sys
-    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "detr_mapper_gpu_child.py")
-    try:
-        r = subprocess.run([sys.executable, child], capture_output=True, text=True, timeout=300)
-    except subprocess.TimeoutExpired:
-        pytest.xfail("detr mapper child timed out")
-    if r.returncode != 0:
-        pytest.xfail("detr mapper launches (first GPU contact): " + (r.stdout + r.stderr)[-800:])
+    (tests/detr_mapper_gpu_child.py)."""
+    _run_child("detr_mapper_gpu_child.py")

@@ -47,3 +47,23 @@ def test_two_ranks_on_one_device(tmp_path):
         assert r["reduced_vs_sum_rel"] < 1e-5 and r["reduced_vs_sum_max"] < 1e-5, r
         assert r["sum_norm"] > r["local_norm"] * 0.5
         assert r["params_equal"] and r["finite"] and r["params_moved"] > 1e-6, r
+
+
+def test_bench_starts_itself_for_n_gpus():
+    """`python bench.py --gpus 2` with NO rendezvous in the environment (the form a driver uses) must launch its own two
+    ranks (train_det.py:78-87: d2 `launch(main, num_gpus)`) and print one JSON line from rank 0 - here in the rehearsal
+    mode (two gloo ranks on cuda:0), which exercises the same `self_launch` -> torch.distributed.run -> `ddp` block path
+    that `--gpus 8` takes on a full node over RCCL."""
+    env = dict(os.environ, MI_DIST_SHARE_DEVICE="1", MI_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MI_BN_FUSED"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-h2d"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["global_batch"] == 32 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["ddp"]["ranks"] == 2 and d["ddp"]["rccl_ranks"] == 0 and len(d["ddp"]["buckets_MB"]) == 3
+    assert all(x == x for x in d["config"]["final_losses"])

@@ -546,7 +546,7 @@ def test_layernorm_fwd_bwd_against_torch(T, E):
                                      T, E, 1e-5, L.stream_ptr()), "ln_fwd")
     dx = torch.empty_like(xd)
     dgam, dbet = torch.empty(E, device=DEV), torch.empty(E, device=DEV)
-    ws = torch.empty((T + 63) // 64 * E * 2, device=DEV)
+    ws = torch.empty((T + 15) // 16 * E * 2, device=DEV)
     L.check(L.lib().mi_layernorm_bwd(xd.data_ptr(), dyd.data_ptr(), gd.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
                                      dgam.data_ptr(), dbet.data_ptr(), ws.data_ptr(), T, E, L.stream_ptr()), "ln_bwd")
     torch.cuda.synchronize()

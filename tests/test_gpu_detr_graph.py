@@ -122,3 +122,71 @@ def test_graphed_step_draws_fresh_dropout_masks_per_replay():
         assert float(step(b)["total"]) == a1
     finally:
         step.close()
+
+
+def test_multi_tensor_adamw_clip_equals_torch_clip_then_adamw():
+    """FullModelGradientClippingOptimizer.step (yolov7/optimizer/build.py:206-223): torch.nn.utils.clip_grad_norm_ over ALL
+    parameters, then AdamW - against MultiTensorAdamW(clip_norm=): norm and coefficient on the device, gradients scaled
+    inside the update kernel.  Steps with the norm above and below the threshold."""
+    from yolov7_d2_amd.optim import MultiTensorAdamW
+    g = torch.Generator().manual_seed(5)
+    shapes = [(256, 256), (2048,), (64, 3, 7, 7), (1,), (300, 33), (40000,)]
+    a = [torch.randn(*s, generator=g).to(DEV).requires_grad_(True) for s in shapes]
+    b = [t.detach().clone().requires_grad_(True) for t in a]
+    groups = lambda ps: [dict(params=ps[:2], lr=1e-3, weight_decay=1e-2), dict(params=ps[2:], lr=1e-4, weight_decay=0.0)]
+    oa = torch.optim.AdamW(groups(a))
+    ob = MultiTensorAdamW(groups(b), clip_norm=0.1)
+    for it, mag in enumerate([1.0, 1e-5, 3.0, 1e-4, 0.5]):          # norms ~ 4e2 .. 4e-3 around the 0.1 threshold
+        for x, y in zip(a, b):
+            gr = torch.randn(x.shape, generator=g).to(DEV) * mag
+            x.grad, y.grad = gr.clone(), gr.clone()
+        ref_norm = torch.nn.utils.clip_grad_norm_(a, 0.1)
+        oa.step()
+        ob.step()
+        coef, norm = ob.clip_out.tolist()
+        assert abs(norm - float(ref_norm)) <= 1e-5 * float(ref_norm), (it, norm, float(ref_norm))
+        assert abs(coef - min(1.0, 0.1 / (float(ref_norm) + 1e-6))) <= 1e-5 * coef
+    for x, y in zip(a, b):
+        torch.testing.assert_close(y.detach(), x.detach(), rtol=2e-5, atol=2e-6)
+
+
+def test_two_captured_shapes_alternate_and_lr_changes_reach_the_replays():
+    """every captured graph has its own gradient pool, so every capture needs its own pointer table - alternating
+    two padded shapes (DETR's multi-scale input does this almost every batch) must keep equalling the eager step; and a
+    learning rate written into param_groups after the captures (the reference's LR drop / warm-up schedule) must reach the
+    replays of BOTH graphs.  Full-model clipping on, as the DETR YAMLs have it (CLIP_VALUE 0.01 there; 1.0 here so that
+    some steps clip and some do not)."""
+    from yolov7_d2_amd.optim import MultiTensorAdamW
+    small = lambda s: _batch(s, ((256, 320), (224, 288)), (3, 2))
+    large = lambda s: _batch(s, ((320, 384), (300, 352)), (2, 4))
+    seq = [small(1), large(2), small(3), large(4), small(5), large(6)]
+    eager, graphed = _model(0.0), _model(0.0)
+    mk = lambda m: MultiTensorAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-4, clip_norm=1.0)
+    oe, og = mk(eager), mk(graphed)
+    step = GraphedTrainStep(graphed, og)
+    try:
+        for it, b in enumerate(seq):
+            if it == 4:                                          # LR drop after both shapes were captured
+                for o in (oe, og):
+                    for grp in o.param_groups:
+                        grp["lr"] = 3e-5
+            losses = eager(b)
+            total = sum(v for k, v in losses.items() if k in eager.criterion.weight_dict)
+            oe.zero_grad(set_to_none=True)
+            total.backward()
+            oe.step()
+            out = step(b)
+            for k, v in losses.items():
+                torch.testing.assert_close(out[k].float(), v.detach().float(), rtol=2e-3, atol=2e-3, msg=f"step {it} {k}")
+            torch.testing.assert_close(og.clip_out, oe.clip_out, rtol=2e-3, atol=1e-6, msg=f"step {it} clip")
+        assert len(step.graphs) == 2 and len(og.captures) == 2
+        assert og.captures[0][0].data_ptr() != og.captures[1][0].data_ptr()
+        torch.cuda.synchronize()
+        for (n, p), (_, q) in zip(eager.named_parameters(), graphed.named_parameters()):
+            if p.requires_grad:
+                d = float((p.detach() - q.detach()).abs().max())
+                assert d <= 2.5e-4, (n, d)                       # six AdamW steps of lr <= 1e-4 move a weight by <= 6e-4
+        # the LR change took effect in the replays: steps 5 and 6 at 3e-5 instead of 1e-4.  A graph that kept its captured
+        # lr would leave the two models a full (1e-4 - 3e-5) * 2 apart on most weights - far outside the bound above
+    finally:
+        step.close()

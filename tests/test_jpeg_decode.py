@@ -221,3 +221,29 @@ def test_host_half_survives_corrupt_files():
     r = subprocess.run([sys.executable, child, "600"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.returncode, r.stderr[-500:])
     assert "fuzz done" in r.stdout
+
+
+def test_decompression_bomb_is_refused_before_any_allocation():
+    """a header that declares a huge frame (a 300-byte file can claim 65535 x 65535) must be refused the way
+    PIL.Image.open refuses it (DecompressionBombError above 2 * MAX_IMAGE_PIXELS) - before the coefficient buffer sized by
+    the header is allocated"""
+    from PIL import Image
+    from yolov7_d2_amd.data_pipeline import GpuJpegDecoder
+    buf = io.BytesIO(); Image.fromarray(_smooth(np.random.RandomState(1), 64, 96)).save(buf, format="JPEG", quality=85)
+    data = bytearray(buf.getvalue())
+    k = data.index(b"\xff\xc0")                               # SOF0: marker, length(2), precision(1), height(2), width(2)
+    data[k + 5:k + 9] = bytes([0xFF, 0xFF, 0xFF, 0xFF])       # 65535 x 65535
+    dec = GpuJpegDecoder(device="cpu")
+    called = []
+
+    def alloc(count):
+        called.append(count)
+        a = np.empty(count, np.int16)
+        return a, a.ctypes.data
+    with pytest.raises(L.MI355Error, match="decompression-bomb"):
+        dec._host_half([bytes(data)], alloc)
+    assert not called
+    small = GpuJpegDecoder(device="cpu", max_image_pixels=1000)       # configurable, like Image.MAX_IMAGE_PIXELS
+    with pytest.raises(L.MI355Error, match="decompression-bomb"):
+        small._host_half([buf.getvalue()], alloc)
+    assert GpuJpegDecoder.MAX_IMAGE_PIXELS == 2 * Image.MAX_IMAGE_PIXELS

@@ -720,7 +720,10 @@ __global__ __launch_bounds__(256) void colsum_wide_fused_kernel(const __bf16* __
     for (int q = 0; q < PL; ++q) a += red[(q * C8N + cc8) * 8 + e];
     __hip_atomic_store(part + (size_t)blockIdx.x * CP + c0 + tid, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __syncthreads();   // (workgroup release: the stores above are acknowledged)
+  // every storing wave waits for ITS stores to be acknowledged (the barrier alone orders the waves, not their memory
+  // traffic: thread 0's counter increment below must not become visible before another wave's partials have landed)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   if (tid == 0)
     s_last = __hip_atomic_fetch_add(&g_colsum_cnt[blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
   __syncthreads();

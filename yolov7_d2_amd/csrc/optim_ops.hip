@@ -47,9 +47,11 @@ extern "C" int mi_adamw_step(float* params, const float* grads, float* exp_avg, 
 // replay.  A block owns one chunk (<= 16 k elements) of one tensor.
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const mi_adamw_tensor* __restrict__ tensors,
                                                           const mi_adamw_chunk* __restrict__ chunks, float beta1, float beta2,
-                                                          float eps, const long long* __restrict__ step_dev, float grad_scale) {
+                                                          float eps, const long long* __restrict__ step_dev, float grad_scale,
+                                                          const float* __restrict__ grad_scale_dev) {
   const mi_adamw_chunk ch = chunks[blockIdx.x];
   const mi_adamw_tensor t = tensors[ch.tensor];
+  if (grad_scale_dev) grad_scale *= *grad_scale_dev;   // the clip coefficient of THIS step (mi_grad_norm_multi), read at run time
   const double step = (double)*step_dev;
   const float bc1 = (float)(1.0 - pow((double)beta1, step));
   const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, step));
@@ -71,13 +73,63 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const mi_adamw_tensor*
     p[i] = pv - step_size * (mk / denom);
   }
 }
+extern "C" int mi_adamw_step_multi_clip(const mi_adamw_tensor* tensors_dev, const mi_adamw_chunk* chunks_dev, int nchunks,
+                                        float beta1, float beta2, float eps, const int64_t* step_dev, float grad_scale,
+                                        const float* grad_scale_dev, mi_stream_t st) {
+  MI_REQUIRE(tensors_dev && chunks_dev && step_dev && nchunks > 0, "adamw_multi: args");
+  hipLaunchKernelGGL(adamw_multi_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)st, tensors_dev, chunks_dev, beta1, beta2,
+                     eps, (const long long*)step_dev, grad_scale, grad_scale_dev);
+  MI_CHECK_LAUNCH("adamw_multi");
+  return MI_OK;
+}
 extern "C" int mi_adamw_step_multi(const mi_adamw_tensor* tensors_dev, const mi_adamw_chunk* chunks_dev, int nchunks,
                                    float beta1, float beta2, float eps, const int64_t* step_dev, float grad_scale,
                                    mi_stream_t st) {
-  MI_REQUIRE(tensors_dev && chunks_dev && step_dev && nchunks > 0, "adamw_multi: args");
-  hipLaunchKernelGGL(adamw_multi_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)st, tensors_dev, chunks_dev, beta1, beta2,
-                     eps, (const long long*)step_dev, grad_scale);
-  MI_CHECK_LAUNCH("adamw_multi");
+  return mi_adamw_step_multi_clip(tensors_dev, chunks_dev, nchunks, beta1, beta2, eps, step_dev, grad_scale, nullptr, st);
+}
+
+// full-model gradient norm over the SAME tables (FullModelGradientClippingOptimizer.step = clip_grad_norm_ over every
+// parameter, then the update: yolov7/optimizer/build.py:206-223).  One block per chunk leaves an fp64 partial; a single
+// block adds them in index order (deterministic) and writes coef = min(1, max_norm / (norm + 1e-6)) and the norm to the
+// device - the update kernel multiplies every gradient by it, so the clipped gradients are never written back and nothing
+// of the step touches the host: the whole clip + update is capturable.
+__global__ __launch_bounds__(256) void sqsum_multi_kernel(const mi_adamw_tensor* __restrict__ tensors,
+                                                          const mi_adamw_chunk* __restrict__ chunks, double* __restrict__ partial) {
+  __shared__ double red[4];
+  const mi_adamw_chunk ch = chunks[blockIdx.x];
+  const float* g = tensors[ch.tensor].g + ch.offset;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < ch.count; i += 256) {
+    const float a = g[i];
+    s += (double)a * (double)a;
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void clip_coef_kernel(const double* __restrict__ partial, int n, float max_norm,
+                                                        float* __restrict__ out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float norm = (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
+    const float c = max_norm / (norm + 1e-6f);
+    out[0] = c < 1.f ? c : 1.f;
+    out[1] = norm;
+  }
+}
+extern "C" int mi_grad_norm_multi(const mi_adamw_tensor* tensors_dev, const mi_adamw_chunk* chunks_dev, int nchunks,
+                                  double* partial_dev, float max_norm, float* coef_norm_out, mi_stream_t st) {
+  MI_REQUIRE(tensors_dev && chunks_dev && partial_dev && coef_norm_out && nchunks > 0 && max_norm > 0.f, "grad_norm_multi: args");
+  hipLaunchKernelGGL(sqsum_multi_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)st, tensors_dev, chunks_dev, partial_dev);
+  MI_CHECK_LAUNCH("grad_sqsum_multi");
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)st, partial_dev, nchunks, max_norm, coef_norm_out);
+  MI_CHECK_LAUNCH("clip_coef");
   return MI_OK;
 }
 

@@ -657,10 +657,16 @@ class GpuJpegDecoder:
     YCbCr -> RGB, EXIF transpose and channel order per pixel).  Bit-identical to Pillow's decode.  Arithmetic-
     coded, 12-bit and CMYK files raise MI355Error (there is no CPU decoder to fall back to)."""
 
-    def __init__(self, device="cuda", format="BGR", apply_orientation=True, workers=8):      # noqa: A002 (d2's argument name)
+    # Pillow refuses an image above 2 * Image.MAX_IMAGE_PIXELS (DecompressionBombError; MAX_IMAGE_PIXELS = 89 478 485) - the
+    # PIL path this replaces never allocates for a 65535 x 65535 header; neither does this one (a SOF of that size would ask
+    # for ~13 GB of pinned coefficients before a single scan byte is checked)
+    MAX_IMAGE_PIXELS = 2 * 89478485
+
+    def __init__(self, device="cuda", format="BGR", apply_orientation=True, workers=8, max_image_pixels=None):      # noqa: A002 (d2's argument name)
         if format not in ("BGR", "RGB"):
             raise ValueError("GpuJpegDecoder: format BGR (the reference's INPUT.FORMAT default) or RGB")
         self.device, self.bgr, self.orient, self.workers = torch.device(device), format == "BGR", bool(apply_orientation), workers
+        self.max_image_pixels = self.MAX_IMAGE_PIXELS if max_image_pixels is None else int(max_image_pixels)
 
     def _host_half(self, files, alloc):
         """parse every file, decode the entropy-coded data on host threads into ONE int16 buffer.  alloc(count) ->
@@ -671,6 +677,9 @@ class GpuJpegDecoder:
         infos = [L.mi_jpeg_info() for _ in range(n)]
         for k in range(n):
             L.check(lib.mi_jpeg_parse(bufs[k], len(files[k]), C.byref(infos[k])), f"mi_jpeg_parse (file {k})")
+            if int(infos[k].width) * int(infos[k].height) > self.max_image_pixels:      # before ANY allocation sized by the header
+                raise L.MI355Error(f"GpuJpegDecoder: file {k} declares {infos[k].width} x {infos[k].height} pixels, above the "
+                                   f"limit of {self.max_image_pixels} (decompression-bomb guard, as PIL.Image.MAX_IMAGE_PIXELS)")
         offs = np.concatenate([[0], np.cumsum([i.coef_count for i in infos])]).astype(np.int64)
         host, base = alloc(int(offs[-1]))
 

@@ -23,7 +23,9 @@ from . import _lib as L
 
 class GraphedTrainStep:
     def __init__(self, model, optimizer, loss_keys=None, warmup=2):
-        """optimizer: optim.MultiTensorAdamW (one launch per step) or a torch optimizer created with capturable=True.
+        """optimizer: optim.MultiTensorAdamW (one launch per step; `clip_norm=` for the reference DETR configs' full-model
+        gradient clipping, learning-rate changes honoured per replay) or a torch optimizer created with capturable=True (its
+        lr must then be a device tensor for a scheduler to have any effect; no clipping).
         loss_keys: the entries of the loss dict that are summed into the objective (default: model.criterion.weight_dict)."""
         self.model, self.opt, self.warmup = model, optimizer, warmup
         self.loss_keys = loss_keys
@@ -96,13 +98,17 @@ class GraphedTrainStep:
                     self._body(static)
             torch.cuda.current_stream().wait_stream(s)
             g = torch.cuda.CUDAGraph()
+            if hasattr(self.opt, "begin_capture"):
+                self.opt.begin_capture()        # a device table of its own for this graph (its pool has its own gradients)
             with torch.cuda.graph(g):
                 out = self._body(static)
             if hasattr(self.opt, "finish_capture"):
-                self.opt.finish_capture()       # the gradient addresses of the graph's pool -> the device table
+                self.opt.finish_capture()       # the gradient addresses of the graph's pool -> that table
             self._restore(snap)
             ent = self.graphs[key] = (g, static, out)
         else:
             self.model.prepare_batch(batched_inputs, static=ent[1])
+        if hasattr(self.opt, "sync_lr"):
+            self.opt.sync_lr()                  # an LR scheduler's new param_groups[i]["lr"] -> the captured launches' tables
         ent[0].replay()
         return ent[2]

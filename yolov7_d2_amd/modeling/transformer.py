@@ -133,7 +133,7 @@ class _LayerNormFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dg = torch.empty(E, dtype=torch.float32, device=x.device)
         db = torch.empty(E, dtype=torch.float32, device=x.device)
-        ws = torch.empty((T + 63) // 64 * E * 2, dtype=torch.float32, device=x.device)
+        ws = torch.empty((T + 15) // 16 * E * 2, dtype=torch.float32, device=x.device)
         L.check(L.lib().mi_layernorm_bwd(x.data_ptr(), dy.data_ptr(), g32.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                          dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), T, E,
                                          L.stream_ptr()), "mi_layernorm_bwd")

@@ -51,12 +51,21 @@ class MultiTensorAdamW:
     (mi_adamw_step_multi), usable inside a captured hipGraph: the tables of pointers and the update count live on the
     device and are read at run time.  Same constructor shape as torch.optim.AdamW (params or param groups with their own
     lr / weight_decay), same update rule (decoupled weight decay, bias-corrected moments), `param_groups` with a mutable
-    "lr" (re-uploaded by refresh()).  Inside a capture the gradient tensors are the graph pool's: step() records the
-    launch and remembers them, finish_capture() uploads the table once the capture has ended."""
+    "lr".
+
+    `clip_norm`: FullModelGradientClippingOptimizer (yolov7/optimizer/build.py:206-223; the DETR configs set
+    SOLVER.CLIP_GRADIENTS full_model 0.01 / 0.1): the global gradient norm is taken on the device over the same tables
+    (mi_grad_norm_multi) and the update kernel multiplies by the coefficient it left there - no host value, capturable.
+
+    Captured steps: every capture gets ITS OWN device table (`begin_capture` / `finish_capture`): the gradient tensors of a
+    captured graph live in that graph's private pool, so two captured batch shapes have two sets of gradient addresses and
+    a shared table would make the replays of the first graph read the second graph's (stale) gradients.  A learning-rate
+    change (`param_groups[i]["lr"] = ...`, an LR scheduler) is carried into every table by `sync_lr()`, which
+    GraphedTrainStep calls before each replay: the captured launch reads lr from its table at run time."""
 
     CHUNK = 16384
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, clip_norm=None):
         params = list(params)
         if params and not isinstance(params[0], dict):
             params = [dict(params=params)]
@@ -70,7 +79,7 @@ class MultiTensorAdamW:
         self.betas, self.eps = betas, eps
         self.params = [p for g in self.param_groups for p in g["params"]]
         assert self.params and all(p.is_cuda and p.dtype == torch.float32 for p in self.params)
-        dev = self.params[0].device
+        dev = self.device = self.params[0].device
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
         self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -86,8 +95,16 @@ class MultiTensorAdamW:
             a.tensor, a.count, a.offset = ti, c, k
         self.nchunks = len(chunks)
         self.chunks = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-        self.table = torch.zeros(len(self.params) * C.sizeof(L.mi_adamw_tensor), dtype=torch.uint8, device=dev)
+        self.table_bytes = len(self.params) * C.sizeof(L.mi_adamw_tensor)
+        self.table = torch.zeros(self.table_bytes, dtype=torch.uint8, device=dev)   # the eager steps' table
         self._grad_ptrs = None
+        self._eager_lrs = None
+        self._cap_table = None
+        self.captures = []          # [device table, host ctypes array, lrs it was uploaded with, gradient tensors]
+        self.clip_norm = None if clip_norm is None or clip_norm <= 0 else float(clip_norm)
+        if self.clip_norm is not None:
+            self.norm_partial = torch.zeros(self.nchunks, dtype=torch.float64, device=dev)
+            self.clip_out = torch.ones(2, dtype=torch.float32, device=dev)      # [coefficient, norm] of the last step
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -95,6 +112,9 @@ class MultiTensorAdamW:
                 p.grad = None
             elif p.grad is not None:
                 p.grad.zero_()
+
+    def _lrs(self):
+        return [float(g["lr"]) for g in self.param_groups]
 
     def _host_table(self):
         arr = (L.mi_adamw_tensor * len(self.params))()
@@ -108,27 +128,62 @@ class MultiTensorAdamW:
                 k += 1
         return arr
 
+    @staticmethod
+    def _upload(table, arr):
+        table.copy_(torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8))
+
     def refresh(self):
-        """upload the table (new gradient addresses, changed learning rates); outside a capture only"""
-        arr = self._host_table()
-        self.table.copy_(torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8))
+        """upload the eager table (new gradient addresses, changed learning rates); outside a capture only"""
+        self._upload(self.table, self._host_table())
         self._grad_ptrs = [p.grad.data_ptr() for p in self.params]
+        self._eager_lrs = self._lrs()
+
+    def begin_capture(self):
+        """a fresh device table for the capture that follows (allocated outside the graph's pool)"""
+        self._cap_table = torch.zeros(self.table_bytes, dtype=torch.uint8, device=self.device)
 
     def finish_capture(self):
-        self.refresh()
+        """the capture has ended: the gradient addresses of the graph's pool are final -> fill THIS capture's table"""
+        assert self._cap_table is not None, "finish_capture without a captured step()"
+        arr = self._host_table()
+        self._upload(self._cap_table, arr)
+        self.captures.append([self._cap_table, arr, self._lrs(), [p.grad for p in self.params]])
+        self._cap_table = None
+
+    def sync_lr(self):
+        """carry changed learning rates into every captured table (cheap no-op when nothing changed)"""
+        lrs = self._lrs()
+        for ent in self.captures:
+            if ent[2] != lrs:
+                k = 0
+                for g in self.param_groups:
+                    for _ in g["params"]:
+                        ent[1][k].lr = float(g["lr"])
+                        k += 1
+                self._upload(ent[0], ent[1])
+                ent[2] = lrs
 
     def step(self, grad_scale=1.0):
         capturing = torch.cuda.is_current_stream_capturing()
         if not capturing:
             ptrs = [p.grad.data_ptr() if p.grad is not None else 0 for p in self.params]
-            if ptrs != self._grad_ptrs:
+            if ptrs != self._grad_ptrs or self._eager_lrs != self._lrs():
                 self.refresh()
+            table = self.table
         else:
-            self._pending = [p.grad for p in self.params]       # (keeps the graph pool's gradient tensors referenced)
+            if self._cap_table is None:      # (a caller without begin_capture: allocated from the graph's pool, kept alive here)
+                self._cap_table = torch.zeros(self.table_bytes, dtype=torch.uint8, device=self.device)
+            table = self._cap_table
         self.step_count += 1
-        L.check(L.lib().mi_adamw_step_multi(self.table.data_ptr(), self.chunks.data_ptr(), self.nchunks, self.betas[0],
-                                            self.betas[1], self.eps, self.step_count.data_ptr(), float(grad_scale),
-                                            L.stream_ptr()), "mi_adamw_step_multi")
+        coef = None
+        if self.clip_norm is not None:
+            L.check(L.lib().mi_grad_norm_multi(table.data_ptr(), self.chunks.data_ptr(), self.nchunks,
+                                               self.norm_partial.data_ptr(), self.clip_norm, self.clip_out.data_ptr(),
+                                               L.stream_ptr()), "mi_grad_norm_multi")
+            coef = self.clip_out.data_ptr()
+        L.check(L.lib().mi_adamw_step_multi_clip(table.data_ptr(), self.chunks.data_ptr(), self.nchunks, self.betas[0],
+                                                 self.betas[1], self.eps, self.step_count.data_ptr(), float(grad_scale),
+                                                 coef, L.stream_ptr()), "mi_adamw_step_multi_clip")
 
     # ---- what GraphedTrainStep snapshots around its warm-up steps
     def state_tensors(self):
