@@ -737,9 +737,16 @@ int mi_adamw_step_multi(const mi_adamw_tensor* tensors_dev, const mi_adamw_chunk
 /* FullModelGradientClippingOptimizer.step (yolov7/optimizer/build.py:206-223: clip_grad_norm_ over all parameters, then
  * the update) over the same tables without touching the host: mi_grad_norm_multi leaves coef_norm_out[0] = min(1, max_norm
  * / (||g||_2 + 1e-6)) and [1] = the norm on the device (partial_dev: nchunks doubles of scratch, summed in index order);
- * mi_adamw_step_multi_clip multiplies every gradient by grad_scale * *grad_scale_dev (NULL: grad_scale alone) */
+ * (of the gradients times grad_scale); mi_adamw_step_multi_clip multiplies every gradient by grad_scale * *grad_scale_dev
+ * (NULL: grad_scale alone) */
 int mi_grad_norm_multi(const mi_adamw_tensor* tensors_dev, const mi_adamw_chunk* chunks_dev, int nchunks,
-                       double* partial_dev, float max_norm, float* coef_norm_out, mi_stream_t s);
+                       double* partial_dev, float max_norm, float grad_scale, float* coef_norm_out, mi_stream_t s);
+/* data-parallel form of the captured step (train_transformer.py:188-203 / train_inseg.py:63-77 -> d2 create_ddp_model): the
+ * gradients of every tensor copied into ONE flat fp32 buffer (tensor k at element offset flat_off_dev[k]) in one launch -
+ * the buffer is all-reduced in a few large messages and the update reads it (a table whose g fields point into it) with
+ * grad_scale = 1 / world_size; mi_grad_norm_multi's grad_scale makes the clipped norm the AVERAGED gradient's */
+int mi_grad_gather_multi(const mi_adamw_tensor* tensors_dev, const mi_adamw_chunk* chunks_dev, int nchunks,
+                         const int64_t* flat_off_dev, float* flat, mi_stream_t s);
 int mi_adamw_step_multi_clip(const mi_adamw_tensor* tensors_dev, const mi_adamw_chunk* chunks_dev, int nchunks, float beta1,
                              float beta2, float eps, const int64_t* step_dev, float grad_scale,
                              const float* grad_scale_dev, mi_stream_t s);

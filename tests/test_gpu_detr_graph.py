@@ -190,3 +190,69 @@ def test_two_captured_shapes_alternate_and_lr_changes_reach_the_replays():
         # lr would leave the two models a full (1e-4 - 3e-5) * 2 apart on most weights - far outside the bound above
     finally:
         step.close()
+
+
+def test_graphed_step_data_parallel_two_ranks(tmp_path):
+    """GraphedTrainStep under torch.distributed (train_transformer.py:188-203 / train_inseg.py:63-77 -> d2 create_ddp_model):
+    two gloo ranks on cuda:0 (tests/detr_ddp_worker.py).  Rank 1 starts from other weights (the construction-time
+    broadcast must overwrite them), the ranks see different batches and at one step different padded shapes (one captures
+    while the other replays: the collectives sit between the graphs, so their order never diverges).  Asserted on the
+    device: all-reduced flat gradient == sum of the two local ones (bit-exact), the update == clip_grad_norm_(mean
+    gradient) + torch AdamW on copies, both ranks hold identical parameters after five steps."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs, outs = [], []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        out = str(tmp_path / f"rank{r}.json")
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "detr_ddp_worker.py"), out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-3000:] for l in logs)
+    for out in outs:
+        r = json.load(open(out))
+        assert r["buckets"] >= 2 and r["graphs"] == 2 and r["steps"] == 5, r
+        assert r["sum_exact"] and r["update_ok"] and r["params_equal"] and r["finite"], r
+
+
+def test_shape_buckets_serve_nearby_shapes_with_one_capture():
+    """Detr.shape_bucket = 64: batches whose exact padded shapes differ ((250, 310), (241, 300), (256, 320)) share ONE key and
+    one capture; against the exact padding (shape_bucket = 1) the losses move only by what the stated consequence allows -
+    the largest image's border column / row sees in-tensor padding like a smaller image's - a fraction of a percent"""
+    model = _model(0.0)
+    bs = [_batch(7, ((250, 310), (224, 288)), (3, 2)), _batch(8, ((241, 300), (230, 260)), (2, 2)), _batch(9, ((256, 320), (200, 300)), (1, 4))]
+    assert {model.batch_key(b) for b in bs} == {(2, 256, 320)}
+    with torch.no_grad():
+        for b in bs[:2]:
+            lb = model.forward_prepared(model.prepare_batch(b))
+            model.shape_bucket = 1
+            assert model.batch_key(b) != (2, 256, 320)
+            le = model.forward_prepared(model.prepare_batch(b))
+            model.shape_bucket = 64
+            for k in le:
+                if k in model.criterion.weight_dict:
+                    a, e = float(lb[k]), float(le[k])
+                    assert abs(a - e) <= 2e-2 * abs(e) + 1e-3, (k, a, e)
+    opt = _opt(model, kind="multi")
+    step = GraphedTrainStep(model, opt)
+    try:
+        for b in bs:
+            assert bool(torch.isfinite(step(b)["total"]))
+        assert len(step.graphs) == 1
+    finally:
+        step.close()

@@ -410,10 +410,12 @@ def test_bottleneck_epilogue_fusions_equal_the_elementwise_passes(cin, cout, bc,
         if stride == 2:
             assert torch.equal(a, b), (i, float((a - b).abs().max()))
             continue
-        if i == 1:                                                  # bf16 input gradient: <= 1 ulp on a small fraction
-            ulp = torch.maximum(a.abs(), b.abs()).clamp(min=2.0 ** -120).log2().floor().exp2() * 2.0 ** -7
+        if i == 1:
+            # bf16 input gradient = sum of two bf16 paths: where the paths cancel, one ulp of a PATH is several ulps of the
+            # sum - so the bound is one bf16 ulp at the scale of the tensor (rms) or of the element, on a small fraction
             d = (a - b).abs()
-            assert bool((d <= ulp).all()), float((d / ulp).max())
+            bound = 2.0 ** -7 * torch.maximum(torch.maximum(a.abs(), b.abs()), b.pow(2).mean().sqrt().expand_as(b))
+            assert bool((d <= bound).all()), float((d / bound).max())
             assert float((d > 0).float().mean()) < 0.05
         elif i > 1:                                                 # fp32 weight gradients: sums of those bf16 values
             assert float((a - b).norm() / b.norm().clamp(min=1e-12)) < 2e-3, i

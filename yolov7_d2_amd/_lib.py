@@ -250,7 +250,8 @@ _PROTOS = {
     "mi_adamw_step_multi": (C.c_int, [_vp, _vp, _i, _f, _f, _f, _vp, _f, _vp]),
     "mi_debug_code_polluter": (C.c_int, [_i, _i, _vp]),
     "mi_adamw_step_multi_clip": (C.c_int, [_vp, _vp, _i, _f, _f, _f, _vp, _f, _vp, _vp]),
-    "mi_grad_norm_multi": (C.c_int, [_vp, _vp, _i, _vp, _f, _vp, _vp]),
+    "mi_grad_norm_multi": (C.c_int, [_vp, _vp, _i, _vp, _f, _f, _vp, _vp]),
+    "mi_grad_gather_multi": (C.c_int, [_vp, _vp, _i, _vp, _vp, _vp]),
     "mi_conv2d_bn_plan": (C.c_int, [C.POINTER(mi_conv_desc), C.POINTER(mi_bn_job), _i, C.POINTER(mi_conv_group)]),
     "mi_conv2d_bn_fwd": (C.c_int, [C.POINTER(mi_conv_desc), C.POINTER(mi_bn_job), _i, _vp]),
     "mi_conv_bn_barrier_status": (C.c_int, [C.POINTER(C.c_uint32)]),

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void sqsum_multi_kernel(const mi_adamw_tensor*
   if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 __global__ __launch_bounds__(256) void clip_coef_kernel(const double* __restrict__ partial, int n, float max_norm,
-                                                        float* __restrict__ out) {
+                                                        float grad_scale, float* __restrict__ out) {
   __shared__ double red[4];
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
@@ -117,19 +117,44 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const double* __restrict
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float norm = (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
+    // grad_scale: the factor the update will apply to every gradient BEFORE clipping (1 / world_size of a data-parallel
+    // step whose buffers hold the all-reduced SUM): the norm that is clipped is the averaged gradient's
+    const float norm = grad_scale * (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
     const float c = max_norm / (norm + 1e-6f);
     out[0] = c < 1.f ? c : 1.f;
     out[1] = norm;
   }
 }
 extern "C" int mi_grad_norm_multi(const mi_adamw_tensor* tensors_dev, const mi_adamw_chunk* chunks_dev, int nchunks,
-                                  double* partial_dev, float max_norm, float* coef_norm_out, mi_stream_t st) {
-  MI_REQUIRE(tensors_dev && chunks_dev && partial_dev && coef_norm_out && nchunks > 0 && max_norm > 0.f, "grad_norm_multi: args");
+                                  double* partial_dev, float max_norm, float grad_scale, float* coef_norm_out,
+                                  mi_stream_t st) {
+  MI_REQUIRE(tensors_dev && chunks_dev && partial_dev && coef_norm_out && nchunks > 0 && max_norm > 0.f && grad_scale > 0.f,
+             "grad_norm_multi: args");
   hipLaunchKernelGGL(sqsum_multi_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)st, tensors_dev, chunks_dev, partial_dev);
   MI_CHECK_LAUNCH("grad_sqsum_multi");
-  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)st, partial_dev, nchunks, max_norm, coef_norm_out);
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)st, partial_dev, nchunks, max_norm, grad_scale,
+                     coef_norm_out);
   MI_CHECK_LAUNCH("clip_coef");
+  return MI_OK;
+}
+
+// the gradients of an eager module tree -> ONE flat fp32 buffer (tensor k at element offset flat_off[k]), one launch over the
+// same chunk table: what a data-parallel step all-reduces in a few large messages (train_transformer.py:188-203 -> d2
+// create_ddp_model's buckets) and what the update then reads at addresses that do not depend on the captured graph's pool
+__global__ __launch_bounds__(256) void grad_gather_kernel(const mi_adamw_tensor* __restrict__ tensors,
+                                                          const mi_adamw_chunk* __restrict__ chunks,
+                                                          const long long* __restrict__ flat_off, float* __restrict__ flat) {
+  const mi_adamw_chunk ch = chunks[blockIdx.x];
+  const float* g = tensors[ch.tensor].g + ch.offset;
+  float* o = flat + flat_off[ch.tensor] + ch.offset;
+  for (int i = threadIdx.x; i < ch.count; i += 256) o[i] = g[i];
+}
+extern "C" int mi_grad_gather_multi(const mi_adamw_tensor* tensors_dev, const mi_adamw_chunk* chunks_dev, int nchunks,
+                                    const int64_t* flat_off_dev, float* flat, mi_stream_t st) {
+  MI_REQUIRE(tensors_dev && chunks_dev && flat_off_dev && flat && nchunks > 0, "grad_gather_multi: args");
+  hipLaunchKernelGGL(grad_gather_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)st, tensors_dev, chunks_dev,
+                     (const long long*)flat_off_dev, flat);
+  MI_CHECK_LAUNCH("grad_gather_multi");
   return MI_OK;
 }
 

@@ -22,14 +22,35 @@ from . import _lib as L
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, loss_keys=None, warmup=2):
+    def __init__(self, model, optimizer, loss_keys=None, warmup=2, max_graphs=24, bucket_bytes=64 << 20):
         """optimizer: optim.MultiTensorAdamW (one launch per step; `clip_norm=` for the reference DETR configs' full-model
         gradient clipping, learning-rate changes honoured per replay) or a torch optimizer created with capturable=True (its
-        lr must then be a device tensor for a scheduler to have any effect; no clipping).
-        loss_keys: the entries of the loss dict that are summed into the objective (default: model.criterion.weight_dict)."""
+        lr must then be a device tensor for a scheduler to have any effect; no clipping; single process only).
+        loss_keys: the entries of the loss dict that are summed into the objective (default: model.criterion.weight_dict).
+        max_graphs: captured batch shapes kept (least recently used evicted; all captures share ONE memory pool, so the
+        count costs instantiated graphs, not activation memory).
+
+        Data parallel (torch.distributed initialised with world_size > 1; train_transformer.py:188-203 and
+        train_inseg.py:63-77 reach d2's create_ddp_model for this): rank 0's parameters and buffers are broadcast here; a
+        step is then graph A (forward, backward, gradients gathered into the optimizer's flat buffer) -> the bucketed
+        all-reduce of that buffer (a few messages of ~bucket_bytes; RCCL over xGMI, or gloo in rehearsal) -> graph B (clip +
+        AdamW reading the flat buffer with 1 / world_size).  The collectives sit BETWEEN the two graphs: ranks may capture
+        different padded shapes at different steps without ever disagreeing on the sequence of collectives, and the
+        warm-up / capture passes issue none."""
+        import torch.distributed as dist
         self.model, self.opt, self.warmup = model, optimizer, warmup
         self.loss_keys = loss_keys
-        self.graphs = {}
+        self.graphs = {}            # key -> [graph A, graph B or None, static, out]; insertion order = recency
+        self.max_graphs = max_graphs
+        self.pool = None
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        if self.world > 1:
+            if not hasattr(optimizer, "enable_flat_grads"):
+                raise L.MI355Error("GraphedTrainStep: data parallel needs optim.MultiTensorAdamW (flat gradient buckets)")
+            optimizer.enable_flat_grads(bucket_bytes)
+            with torch.no_grad():       # DDP's construction-time _sync_module_states
+                for t in list(model.parameters()) + list(model.buffers()):
+                    dist.broadcast(t.data, 0)
         self.seed_word = torch.zeros(1, dtype=torch.int64, device=model.device)
         L.check(L.lib().mi_dropout_seed_offset(self.seed_word.data_ptr()), "mi_dropout_seed_offset")
 
@@ -43,16 +64,33 @@ class GraphedTrainStep:
         wd = getattr(getattr(self.model, "criterion", None), "weight_dict", None)
         return [k for k in losses if wd is None or k in wd]
 
-    def _body(self, static):
+    def _body_fb(self, static):
         losses = self.model.forward_prepared(static)
         total = sum(losses[k] for k in self._keys(losses))
         self.opt.zero_grad(set_to_none=True)
         total.backward()
-        self.opt.step()
+        if self.world > 1:
+            self.opt.gather_grads()
         self.seed_word += 1
         out = {k: v.detach() for k, v in losses.items()}
         out["total"] = total.detach()
         return out
+
+    def _body_opt(self):
+        if self.world > 1:
+            self.opt.step(grad_scale=1.0 / self.world, from_flat=True)
+        else:
+            self.opt.step()
+
+    def _body(self, static):
+        out = self._body_fb(static)
+        self._body_opt()
+        return out
+
+    def _allreduce(self):
+        import torch.distributed as dist
+        for lo, hi in self.opt.buckets:
+            dist.all_reduce(self.opt.flat[lo:hi])
 
     def _snapshot(self):
         st = [p.detach().clone() for g in self.opt.param_groups for p in g["params"]]
@@ -82,14 +120,32 @@ class GraphedTrainStep:
                             v.zero_()      # state created by the warm-up steps: back to its initial value
             self.seed_word.copy_(sw)
 
+    def _capture(self, fn):
+        g = torch.cuda.CUDAGraph()
+        if hasattr(self.opt, "begin_capture"):
+            self.opt.begin_capture()        # a device table of its own for this graph (its pool has its own gradients)
+        if self.pool is None:
+            with torch.cuda.graph(g):
+                out = fn()
+            self.pool = g.pool()
+        else:
+            with torch.cuda.graph(g, pool=self.pool):
+                out = fn()
+        if hasattr(self.opt, "finish_capture"):
+            self.opt.finish_capture()       # the gradient addresses of the graph's pool -> that table
+        return g, out
+
     def __call__(self, batched_inputs):
-        """one optimizer step on the batch; returns the loss dict (device scalars of the step just run)"""
+        """one optimizer step on the batch; returns the loss dict (device scalars of the step just run; valid until the
+        next call)"""
         key = self.model.batch_key(batched_inputs)
-        ent = self.graphs.get(key)
+        ent = self.graphs.pop(key, None)
         if ent is None:
+            while len(self.graphs) >= self.max_graphs:             # least recently used capture goes
+                self.graphs.pop(next(iter(self.graphs)))
             static = self.model.prepare_batch(batched_inputs)
             # warm-up on a side stream (lazy initialisation inside the library, allocator pools), undone afterwards:
-            # the first real step on this batch is the first replay
+            # the first real step on this batch is the first replay.  No collective in here (see __init__)
             snap = self._snapshot()
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
@@ -97,18 +153,21 @@ class GraphedTrainStep:
                 for _ in range(self.warmup):
                     self._body(static)
             torch.cuda.current_stream().wait_stream(s)
-            g = torch.cuda.CUDAGraph()
-            if hasattr(self.opt, "begin_capture"):
-                self.opt.begin_capture()        # a device table of its own for this graph (its pool has its own gradients)
-            with torch.cuda.graph(g):
-                out = self._body(static)
-            if hasattr(self.opt, "finish_capture"):
-                self.opt.finish_capture()       # the gradient addresses of the graph's pool -> that table
+            if self.world > 1:
+                ga, out = self._capture(lambda: self._body_fb(static))
+                gb, _ = self._capture(self._body_opt)
+            else:
+                ga, out = self._capture(lambda: self._body(static))
+                gb = None
             self._restore(snap)
-            ent = self.graphs[key] = (g, static, out)
+            ent = [ga, gb, static, out]
         else:
-            self.model.prepare_batch(batched_inputs, static=ent[1])
+            self.model.prepare_batch(batched_inputs, static=ent[2])
+        self.graphs[key] = ent                                     # (most recent last)
         if hasattr(self.opt, "sync_lr"):
             self.opt.sync_lr()                  # an LR scheduler's new param_groups[i]["lr"] -> the captured launches' tables
         ent[0].replay()
-        return ent[2]
+        if ent[1] is not None:
+            self._allreduce()
+            ent[1].replay()
+        return ent[3]

@@ -208,9 +208,23 @@ class Detr(nn.Module):
     # ---- the training step split at the host / device line (graph_step.GraphedTrainStep captures the device half)
     target_capacity = 100     # ground-truth boxes per image the packed layout holds (COCO: <= 93 after crowd removal)
 
+    # the captured step's padded shape is rounded UP to a multiple of this (0 / 1: the exact batch maximum, as
+    # ImageList.from_tensors pads in forward()).  DETR's multi-scale input (MIN_SIZE_TRAIN 480..832, max 1333, random crops)
+    # makes the exact (max h, max w) nearly unique per batch - a capture each; in 64-pixel buckets a few dozen shapes serve
+    # the whole schedule (GraphedTrainStep keeps the most recent max_graphs of them in ONE memory pool).  Arithmetic
+    # consequence, stated: the extra rows / columns are ordinary padding - zeros in the image, True in the mask, so no
+    # attention weight and no position-embedding count reaches them - and every image keeps its own mask; what changes is
+    # that the batch's LARGEST image now has padding pixels inside the tensor at its right / bottom border like every
+    # smaller image of a batch always has (the backbone's FrozenBN shift makes padding non-zero after the first layer,
+    # where the tensor border would have been an implicit zero): its last feature column / row sees the same values a
+    # smaller image's does.  The eager forward() is unchanged (exact padding).
+    shape_bucket = 64
+
     def batch_key(self, batched_inputs):
-        return (len(batched_inputs), max(int(x["image"].shape[-2]) for x in batched_inputs),
-                max(int(x["image"].shape[-1]) for x in batched_inputs))
+        r = max(int(self.shape_bucket), 1)
+        up = lambda v: (v + r - 1) // r * r
+        return (len(batched_inputs), up(max(int(x["image"].shape[-2]) for x in batched_inputs)),
+                up(max(int(x["image"].shape[-1]) for x in batched_inputs)))
 
     def prepare_batch(self, batched_inputs, static=None):
         """Everything of forward() that touches the host: normalise + zero-pad the images into one tensor, record the

@@ -99,8 +99,8 @@ class MultiTensorAdamW:
         self.table = torch.zeros(self.table_bytes, dtype=torch.uint8, device=dev)   # the eager steps' table
         self._grad_ptrs = None
         self._eager_lrs = None
-        self._cap_table = None
-        self.captures = []          # [device table, host ctypes array, lrs it was uploaded with, gradient tensors]
+        self._cap_table, self._cap_used = None, False
+        self.captures = []          # [device table, host ctypes array, lrs it was uploaded with, -]
         self.clip_norm = None if clip_norm is None or clip_norm <= 0 else float(clip_norm)
         if self.clip_norm is not None:
             self.norm_partial = torch.zeros(self.nchunks, dtype=torch.float64, device=dev)
@@ -141,13 +141,18 @@ class MultiTensorAdamW:
     def begin_capture(self):
         """a fresh device table for the capture that follows (allocated outside the graph's pool)"""
         self._cap_table = torch.zeros(self.table_bytes, dtype=torch.uint8, device=self.device)
+        self._cap_used = False
 
     def finish_capture(self):
         """the capture has ended: the gradient addresses of the graph's pool are final -> fill THIS capture's table"""
-        assert self._cap_table is not None, "finish_capture without a captured step()"
+        if self._cap_table is None or not self._cap_used:      # (a captured segment that read no gradient table: the
+            self._cap_table = None                              #  data-parallel update reads the flat buffer's table)
+            return
         arr = self._host_table()
         self._upload(self._cap_table, arr)
-        self.captures.append([self._cap_table, arr, self._lrs(), [p.grad for p in self.params]])
+        # (no reference to the gradient tensors is kept: they belong to the graph's memory pool, which GraphedTrainStep
+        #  shares between captures - a later capture may lay its own tensors over them, replays never overlap)
+        self.captures.append([self._cap_table, arr, self._lrs(), None])
         self._cap_table = None
 
     def sync_lr(self):
@@ -163,23 +168,72 @@ class MultiTensorAdamW:
                 self._upload(ent[0], ent[1])
                 ent[2] = lrs
 
-    def step(self, grad_scale=1.0):
-        capturing = torch.cuda.is_current_stream_capturing()
-        if not capturing:
-            ptrs = [p.grad.data_ptr() if p.grad is not None else 0 for p in self.params]
-            if ptrs != self._grad_ptrs or self._eager_lrs != self._lrs():
-                self.refresh()
-            table = self.table
-        else:
+    def _grad_table(self):
+        """the table whose g fields are the parameters' CURRENT .grad tensors: this capture's, or the eager one"""
+        if torch.cuda.is_current_stream_capturing():
             if self._cap_table is None:      # (a caller without begin_capture: allocated from the graph's pool, kept alive here)
                 self._cap_table = torch.zeros(self.table_bytes, dtype=torch.uint8, device=self.device)
-            table = self._cap_table
+            self._cap_used = True
+            return self._cap_table
+        ptrs = [p.grad.data_ptr() if p.grad is not None else 0 for p in self.params]
+        if ptrs != self._grad_ptrs or self._eager_lrs != self._lrs():
+            self.refresh()
+        return self.table
+
+    # ---- data parallel: gradients gathered into one flat buffer, all-reduced in a few large buckets, updated from there
+    def enable_flat_grads(self, bucket_bytes=64 << 20):
+        """allocate the flat gradient buffer (tensor k at element offset flat_off[k], 64-element aligned), a table whose g
+        fields point INTO it (addresses that no captured graph's pool can change) and the all-reduce buckets
+        [(lo, hi)] - contiguous element ranges of ~bucket_bytes cut at tensor boundaries: a few large messages, the shape
+        RCCL's ring over xGMI wants (not the 25 MiB NCCL-on-NVSwitch habit)"""
+        if getattr(self, "flat", None) is not None:
+            return
+        offs, n = [], 0
+        for p in self.params:
+            offs.append(n)
+            n += (p.numel() + 63) // 64 * 64
+        self.flat = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.flat_off = torch.tensor(offs, dtype=torch.int64, device=self.device)
+        arr = (L.mi_adamw_tensor * len(self.params))()
+        k = 0
+        for g in self.param_groups:
+            for p in g["params"]:
+                a = arr[k]
+                a.p, a.g = p.data_ptr(), self.flat.data_ptr() + 4 * offs[k]
+                a.m, a.v = self.exp_avg[k].data_ptr(), self.exp_avg_sq[k].data_ptr()
+                a.count, a.lr, a.weight_decay = p.numel(), float(g["lr"]), float(g["weight_decay"])
+                k += 1
+        self.flat_table = torch.zeros(self.table_bytes, dtype=torch.uint8, device=self.device)
+        self._upload(self.flat_table, arr)
+        self.captures.append([self.flat_table, arr, self._lrs(), None])      # (sync_lr keeps its lr fields current too)
+        per = max(1, int(bucket_bytes) // 4)
+        self.buckets, lo = [], 0
+        for k in range(len(offs)):
+            end = offs[k + 1] if k + 1 < len(offs) else n
+            if end - lo >= per or k + 1 == len(offs):
+                self.buckets.append((lo, end))
+                lo = end
+
+    def gather_grads(self):
+        """.grad of every parameter -> the flat buffer (one launch; capturable: reads this capture's own table)"""
+        L.check(L.lib().mi_grad_gather_multi(self._grad_table().data_ptr(), self.chunks.data_ptr(), self.nchunks,
+                                             self.flat_off.data_ptr(), self.flat.data_ptr(), L.stream_ptr()),
+                "mi_grad_gather_multi")
+
+    def step(self, grad_scale=1.0, from_flat=False):
+        """from_flat: the gradients are the flat buffer's (gather_grads + all-reduce happened); grad_scale = 1 / world there"""
+        if from_flat:
+            if not torch.cuda.is_current_stream_capturing():
+                self.sync_lr()
+            table = self.flat_table
+        else:
+            table = self._grad_table()
         self.step_count += 1
         coef = None
         if self.clip_norm is not None:
             L.check(L.lib().mi_grad_norm_multi(table.data_ptr(), self.chunks.data_ptr(), self.nchunks,
-                                               self.norm_partial.data_ptr(), self.clip_norm, self.clip_out.data_ptr(),
-                                               L.stream_ptr()), "mi_grad_norm_multi")
+                                               self.norm_partial.data_ptr(), self.clip_norm, float(grad_scale),
+                                               self.clip_out.data_ptr(), L.stream_ptr()), "mi_grad_norm_multi")
             coef = self.clip_out.data_ptr()
         L.check(L.lib().mi_adamw_step_multi_clip(table.data_ptr(), self.chunks.data_ptr(), self.nchunks, self.betas[0],
                                                  self.betas[1], self.eps, self.step_count.data_ptr(), float(grad_scale),
