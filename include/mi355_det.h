@@ -354,7 +354,9 @@ int mi_colsum_bf16(const void* x, int ldx, int64_t npix, int C, float* out, int 
 /* the same for any channel count (a multiple of 8 readable) in one launch pair; ws: mi_colsum_wide_ws_bytes(C) bytes.
  * Bias gradients of nn.Linear in the transformer (backbone/detr_backbone.py:140-230: 256 .. 2048 output channels). */
 int64_t mi_colsum_wide_ws_bytes(int C);
-int mi_colsum_bf16_wide(const void* x, int ldx, int64_t npix, int C, float* out, int accumulate, float* ws, mi_stream_t s); /* ws: >= 128*128 floats of scratch (two-stage, fixed summation order) */
+int mi_colsum_bf16_wide(const void* x, int ldx, int64_t npix, int C, float* out, int accumulate, float* ws, mi_stream_t s);
+/* the same over the SQUARES of the values (fp32 products): column norms^2 */
+int mi_colsumsq_bf16_wide(const void* x, int ldx, int64_t npix, int C, float* out, int accumulate, float* ws, mi_stream_t s); /* ws: >= 128*128 floats of scratch (two-stage, fixed summation order) */
 
 /* ---- YOLOX head: decode + SimOTA + losses ---------------------------------
  * replaces YOLOXHead.get_output_and_grid / get_losses / get_assignments /
@@ -774,6 +776,10 @@ int mi_sparseinst_mask_stats(const void* masks, int ldm, int P, const float* tar
                              float* stats, mi_stream_t s);
 int mi_sparseinst_mask_grad(const void* masks, int ldm, int P, const float* targets, const int32_t* pairs, int K,
                             const float* stats, float c_bce, float c_dice, void* dmasks_zeroed, mi_stream_t s);
+/* the form a captured step uses: pair rows whose image index is < 0 are skipped by both kernels (a fixed-capacity pair table
+ * filled by the device-side matching), and the two upstream gradients come from the device (coef_dev[0], coef_dev[1]) */
+int mi_sparseinst_mask_grad_dev(const void* masks, int ldm, int P, const float* targets, const int32_t* pairs, int K,
+                                const float* stats, const float* coef_dev, void* dmasks, mi_stream_t s);
 
 /* ---- box utilities of the DETR path (yolov7/utils/boxes.py:28-37,85-122) ------------------------------------------
  * mi_box_convert: n boxes [n][4] fp32; to_cxcywh 0 = box_cxcywh_to_xyxy, 1 = box_xyxy_to_cxcywh.

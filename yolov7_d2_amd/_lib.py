@@ -230,6 +230,7 @@ _PROTOS = {
     "mi_copy_bf16": (C.c_int, [_vp, _i, _vp, _i, _i, _i64, _i, _vp]),
     "mi_colsum_bf16": (C.c_int, [_vp, _i, _i64, _i, _vp, _i, _vp, _vp]),
     "mi_colsum_bf16_wide": (C.c_int, [_vp, _i, _i64, _i, _vp, _i, _vp, _vp]),
+    "mi_colsumsq_bf16_wide": (C.c_int, [_vp, _i, _i64, _i, _vp, _i, _vp, _vp]),
     "mi_colsum_wide_ws_bytes": (C.c_int64, [_i]),
     "mi_pack_conv_weights_batch": (C.c_int, [_vp, _i, _i, _i, _vp]),
     "mi_pack_jobs_layout": (C.c_int, [C.POINTER(mi_pack_job), _i]),
@@ -312,6 +313,7 @@ _PROTOS = {
     "mi_bilinear_resize_bwd_bf16": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "mi_sparseinst_mask_stats": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "mi_sparseinst_mask_grad": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _vp, _f, _f, _vp, _vp]),
+    "mi_sparseinst_mask_grad_dev": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "mi_mha_fwd_dropout": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, C.c_uint64, _vp]),
     "mi_mha_bwd_dropout": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f,
                                      C.c_uint64, _vp]),

@@ -657,7 +657,7 @@ extern "C" int mi_colsum_bf16(const void* x, int ldx, int64_t npix, int C, float
 // any channel count in ONE launch pair (bias gradients of the transformer's Linear layers: 2048 channels were 32 x 2
 // launches of the 64-channel form above - 1100 launches per DETR step): grid.y = 64-channel chunk
 __global__ __launch_bounds__(256) void colsum_wide_stage1_kernel(const __bf16* __restrict__ x, int ldx, int64_t npix, int CP,
-                                                                 float* __restrict__ part) {
+                                                                 float* __restrict__ part, int sq) {
   __shared__ float red[256 * 8];
   const int tid = threadIdx.x, c0 = blockIdx.y * 64;
   const int C8N = (CP - c0 >= 64) ? 8 : (CP - c0) / 8, PL = 256 / C8N;
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(256) void colsum_wide_stage1_kernel(const __bf16* _
     for (int64_t p = (int64_t)blockIdx.x * PL + pl; p < npix; p += (int64_t)gridDim.x * PL) {
       const bf16x8 v = *(const bf16x8*)(x + p * ldx + c0 + c8 * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+      for (int e = 0; e < 8; ++e) s[e] += sq ? (float)v[e] * (float)v[e] : (float)v[e];
     }
 #pragma unroll
   for (int e = 0; e < 8; ++e) red[tid * 8 + e] = (pl < PL) ? s[e] : 0.f;
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(128) void colsum_wide_stage2_kernel(const float* __
 #define COLSUM_MAX_CHUNKS 64
 static __device__ unsigned g_colsum_cnt[COLSUM_MAX_CHUNKS];
 __global__ __launch_bounds__(256) void colsum_wide_fused_kernel(const __bf16* __restrict__ x, int ldx, int64_t npix, int CP, int C,
-                                                                float* __restrict__ part, float* out, int accumulate) {
+                                                                float* __restrict__ part, float* out, int accumulate, int sq) {
   __shared__ float red[256 * 8];
   __shared__ int s_last;
   const int tid = threadIdx.x, c0 = blockIdx.y * 64;
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256) void colsum_wide_fused_kernel(const __bf16* __
     for (int64_t p = (int64_t)blockIdx.x * PL + pl; p < npix; p += (int64_t)gridDim.x * PL) {
       const bf16x8 v = *(const bf16x8*)(x + p * ldx + c0 + c8 * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+      for (int e = 0; e < 8; ++e) s[e] += sq ? (float)v[e] * (float)v[e] : (float)v[e];
     }
 #pragma unroll
   for (int e = 0; e < 8; ++e) red[tid * 8 + e] = (pl < PL) ? s[e] : 0.f;
@@ -753,8 +753,8 @@ __global__ __launch_bounds__(256) void colsum_wide_fused_kernel(const __bf16* __
   }
 }
 extern "C" int64_t mi_colsum_wide_ws_bytes(int C) { return (int64_t)128 * ((C + 7) / 8 * 8) * 4; }
-extern "C" int mi_colsum_bf16_wide(const void* x, int ldx, int64_t npix, int C, float* out, int accumulate, float* ws,
-                                   mi_stream_t st) {
+static int colsum_wide_launch(const void* x, int ldx, int64_t npix, int C, float* out, int accumulate, float* ws, int sq,
+                              mi_stream_t st) {
   MI_REQUIRE(x && out && ws && C > 0, "colsum_wide: null / C %d", C);
   const int CP = (C + 7) / 8 * 8;
   MI_REQUIRE(ldx % 8 == 0 && ((uintptr_t)x % 16) == 0 && ldx >= CP, "colsum_wide: alignment / ld");
@@ -766,15 +766,26 @@ extern "C" int mi_colsum_bf16_wide(const void* x, int ldx, int64_t npix, int C, 
   const int two = two_e ? atoi(two_e) : 0;
   if ((CP + 63) / 64 <= COLSUM_MAX_CHUNKS && !two) {
     hipLaunchKernelGGL(colsum_wide_fused_kernel, dim3(nblk, (CP + 63) / 64), dim3(256), 0, s, (const __bf16*)x, ldx, npix, CP, C, ws,
-                       out, accumulate);
+                       out, accumulate, sq);
     MI_CHECK_LAUNCH("colsum_wide");
     return MI_OK;
   }
-  hipLaunchKernelGGL(colsum_wide_stage1_kernel, dim3(nblk, (CP + 63) / 64), dim3(256), 0, s, (const __bf16*)x, ldx, npix, CP, ws);
+  hipLaunchKernelGGL(colsum_wide_stage1_kernel, dim3(nblk, (CP + 63) / 64), dim3(256), 0, s, (const __bf16*)x, ldx, npix, CP, ws, sq);
   MI_CHECK_LAUNCH("colsum_wide1");
   hipLaunchKernelGGL(colsum_wide_stage2_kernel, dim3((C + 127) / 128), dim3(128), 0, s, ws, nblk, CP, C, out, accumulate);
   MI_CHECK_LAUNCH("colsum_wide2");
   return MI_OK;
+}
+extern "C" int mi_colsum_bf16_wide(const void* x, int ldx, int64_t npix, int C, float* out, int accumulate, float* ws,
+                                   mi_stream_t st) {
+  return colsum_wide_launch(x, ldx, npix, C, out, accumulate, ws, 0, st);
+}
+// column sums of SQUARES (fp32 products of the bf16 values): the ||sigmoid(mask)||^2 term of the dice scores of SparseInst's
+// matcher / IAM normalisers over 25 600 pixels - a torch reduction of that shape splits across blocks, and that form was
+// measured NOT replay-safe inside a captured hipGraph on this stack (tools/si_graph_debug3.py)
+extern "C" int mi_colsumsq_bf16_wide(const void* x, int ldx, int64_t npix, int C, float* out, int accumulate, float* ws,
+                                     mi_stream_t st) {
+  return colsum_wide_launch(x, ldx, npix, C, out, accumulate, ws, 1, st);
 }
 
 // ---- out[r][:] = g[r][:] * scale[r]  (fp32; the weight gradient of a convolution whose weight image carried a folded per-Cout

@@ -7,6 +7,11 @@
 #include <vector>
 #include "common.h"
 
+__global__ __launch_bounds__(256) void fill16_kernel(u32x4* p, size_t n16, unsigned v) {
+  const u32x4 w = {v, v, v, v};
+  for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n16; k += (size_t)gridDim.x * 256) p[k] = w;
+}
+
 thread_local char g_mi_err[512] = {0};
 
 extern "C" int mi_version(void) { return 100; }
@@ -82,9 +87,23 @@ static int run_one(const mi_cmd& c, hipStream_t s) {
       return mi_yolox_split_dpreds((const float*)p[0], i[0], i[1], i[2], i[3], i[4], i[5], i[6], p[1], i[7], st);
     case MI_OP_SPLIT_DPREDS_BATCH:
       return mi_yolox_split_dpreds_batch((const float*)p[1], i[0], i[1], i[2], (const mi_split_job*)p[0], i[3], st);
-    case MI_OP_MEMSET:
-      if (hipMemsetAsync(p[0], i[0], (size_t)c.l[0], s) != hipSuccess) MI_FAIL(MI_ELAUNCH, "memset failed");
+    case MI_OP_MEMSET: {
+      // a fill KERNEL for the aligned case (every use in the step plans: the fp64 BatchNorm accumulators, 256-byte
+      // multiples): a kernel node is ordered like its neighbours inside a captured hipGraph; hipMemsetAsync nodes were the
+      // one node kind whose effect went missing on later replays of a large captured graph (round 4, SparseInst step)
+      const size_t n = (size_t)c.l[0];
+      if (((uintptr_t)p[0] % 16) == 0 && n % 16 == 0 && n > 0 && n < ((size_t)1 << 40)) {
+        const unsigned v = (unsigned)(i[0] & 0xff) * 0x01010101u;
+        const size_t n16 = n / 16;
+        size_t nb = (n16 + 255) / 256;
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(fill16_kernel, dim3((unsigned)nb), dim3(256), 0, s, (u32x4*)p[0], n16, v);
+        MI_CHECK_LAUNCH("memset (fill kernel)");
+        return MI_OK;
+      }
+      if (hipMemsetAsync(p[0], i[0], n, s) != hipSuccess) MI_FAIL(MI_ELAUNCH, "memset failed");
       return MI_OK;
+    }
     case MI_OP_SGD:
       return mi_sgd_momentum_step((float*)p[0], (const float*)p[1], (float*)p[2], (const mi_sgd_seg*)p[3], i[0],
                                   c.f[0], c.f[1], i[1], st);

@@ -193,12 +193,19 @@ struct MaskLossK {
   __bf16* dmasks;
   int K, P, ldm;
   float c_bce, c_dice;   // backward: upstream-gradient-scaled weights: c_bce = g_mask * w / (K * P), c_dice = g_dice * w / num_inst
+  const float* coef;     // optional device pair (c_bce, c_dice) that replaces the two launch constants
 };
+
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
 
 __global__ __launch_bounds__(256) void mask_stats_kernel(const MaskLossK p) {
   __shared__ float red[4][8];
   const int k = blockIdx.y;
   const int b = p.pairs[k * 3], n = p.pairs[k * 3 + 1], t = p.pairs[k * 3 + 2];
+  if (b < 0) return;   // an unused row of a fixed-capacity pair table (device-side matching): its statistics stay zero
   const __bf16* m = p.masks + (size_t)b * p.P * p.ldm + n;
   const float* tg = p.tgt + (size_t)t * p.P;
   float a[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -223,14 +230,17 @@ __global__ __launch_bounds__(256) void mask_stats_kernel(const MaskLossK p) {
 __global__ __launch_bounds__(256) void mask_grad_kernel(const MaskLossK p) {
   const int k = blockIdx.y;
   const int b = p.pairs[k * 3], n = p.pairs[k * 3 + 1], t = p.pairs[k * 3 + 2];
+  if (b < 0) return;
   const __bf16* m = p.masks + (size_t)b * p.P * p.ldm + n;
   __bf16* dm = p.dmasks + (size_t)b * p.P * p.ldm + n;
   const float* tg = p.tgt + (size_t)t * p.P;
   const float A = p.stats[k * 8 + 1], D = p.stats[k * 8 + 2] + p.stats[k * 8 + 3] + 1e-4f;
+  // the two upstream gradients: launch constants, or read from the device (a captured step has no host value of them)
+  const float c_bce = p.coef ? p.coef[0] : p.c_bce, c_dice = p.coef ? p.coef[1] : p.c_dice;
   for (int px = blockIdx.x * 256 + threadIdx.x; px < p.P; px += gridDim.x * 256) {
     const float x = (float)m[(size_t)px * p.ldm], tt = tg[px];
     const float sg = 1.f / (1.f + __expf(-x));
-    const float g = p.c_bce * (sg - tt) + p.c_dice * (-2.f * tt / D + 4.f * A * sg / (D * D)) * sg * (1.f - sg);
+    const float g = c_bce * (sg - tt) + c_dice * (-2.f * tt / D + 4.f * A * sg / (D * D)) * sg * (1.f - sg);
     dm[(size_t)px * p.ldm] = (__bf16)g;
   }
 }
@@ -242,7 +252,11 @@ extern "C" int mi_sparseinst_mask_stats(const void* masks, int ldm, int P, const
   memset(&k, 0, sizeof(k));
   k.masks = (const __bf16*)masks; k.tgt = targets; k.pairs = pairs; k.stats = stats; k.K = K; k.P = P; k.ldm = ldm;
   hipStream_t s = (hipStream_t)st;
-  if (hipMemsetAsync(stats, 0, (size_t)K * 8 * sizeof(float), s) != hipSuccess) MI_FAIL(MI_ELAUNCH, "memset");
+  // (a kernel, not hipMemsetAsync: inside the captured SparseInst step - a hipGraph of ~3000 nodes from a shared memory pool -
+  //  memset nodes were the one node kind whose effect went missing on replays after the first: the statistics accumulated
+  //  onto the previous replay's values; tools/si_graph_debug*.py, round 4)
+  hipLaunchKernelGGL(zero_f32_kernel, dim3((K * 8 + 255) / 256), dim3(256), 0, s, stats, K * 8);
+  MI_CHECK_LAUNCH("sparseinst_mask_stats zero");
   int bx = (P + 2047) / 2048;
   if (bx > 64) bx = 64;
   hipLaunchKernelGGL(mask_stats_kernel, dim3(bx, K), dim3(256), 0, s, k);
@@ -250,13 +264,26 @@ extern "C" int mi_sparseinst_mask_stats(const void* masks, int ldm, int P, const
   return MI_OK;
 }
 // dmasks: bf16 [B][P][ldm], zeroed by the caller (only the matched instances' columns are written)
+static int mask_grad_launch(const void* masks, int ldm, int P, const float* targets, const int32_t* pairs, int K,
+                            const float* stats, float c_bce, float c_dice, const float* coef_dev, void* dmasks, mi_stream_t st);
 extern "C" int mi_sparseinst_mask_grad(const void* masks, int ldm, int P, const float* targets, const int32_t* pairs, int K,
                                        const float* stats, float c_bce, float c_dice, void* dmasks, mi_stream_t st) {
+  return mask_grad_launch(masks, ldm, P, targets, pairs, K, stats, c_bce, c_dice, nullptr, dmasks, st);
+}
+// the same with the two upstream gradients read from the device (coef_dev[0] = d / d(sum of BCE sums), [1] = d / d(sum of
+// dice losses)) and pair rows with image index < 0 skipped: the form a captured step uses (fixed-capacity pair table)
+extern "C" int mi_sparseinst_mask_grad_dev(const void* masks, int ldm, int P, const float* targets, const int32_t* pairs,
+                                           int K, const float* stats, const float* coef_dev, void* dmasks, mi_stream_t st) {
+  MI_REQUIRE(coef_dev, "sparseinst_mask_grad_dev: coef_dev");
+  return mask_grad_launch(masks, ldm, P, targets, pairs, K, stats, 0.f, 0.f, coef_dev, dmasks, st);
+}
+static int mask_grad_launch(const void* masks, int ldm, int P, const float* targets, const int32_t* pairs, int K,
+                            const float* stats, float c_bce, float c_dice, const float* coef_dev, void* dmasks, mi_stream_t st) {
   MI_REQUIRE(masks && targets && pairs && stats && dmasks && K > 0 && P > 0, "sparseinst_mask_grad: args");
   MaskLossK k;
   memset(&k, 0, sizeof(k));
   k.masks = (const __bf16*)masks; k.tgt = targets; k.pairs = pairs; k.stats = (float*)stats; k.dmasks = (__bf16*)dmasks;
-  k.K = K; k.P = P; k.ldm = ldm; k.c_bce = c_bce; k.c_dice = c_dice;
+  k.K = K; k.P = P; k.ldm = ldm; k.c_bce = c_bce; k.c_dice = c_dice; k.coef = coef_dev;
   int bx = (P + 1023) / 1024;
   if (bx > 128) bx = 128;
   hipLaunchKernelGGL(mask_grad_kernel, dim3(bx, K), dim3(256), 0, (hipStream_t)st, k);

@@ -353,10 +353,13 @@ def _BLOCK_FN():
 
 
 def _EPI_FUSE():
-    """MI_RESNET_EPI_FUSE=1 (default 0: written after round 3's GPU minutes were spent, not yet run on a device): the block's
-    conv3 + shortcut + ReLU and the two ReLU backward masks run in convolution epilogues (MI_CONV_ADDRELU / MI_CONV_RELUMASK,
-    the tile kernel's EPI 2 instantiations) instead of as three elementwise passes per block"""
-    return os.environ.get("MI_RESNET_EPI_FUSE", "0") == "1"
+    """MI_RESNET_EPI_FUSE (default 1 since round 4; 0 restores the three elementwise passes per block): the block's conv3 +
+    shortcut + ReLU and the two ReLU backward masks run in convolution epilogues (MI_CONV_ADDRELU / MI_CONV_RELUMASK, the tile
+    kernel's EPI 2 instantiations).  First device run + same-call A/B in round 4 (profiles/r04_epi_fuse_ab.txt): DETR-R50
+    bs 4 213-216 -> 218.6-219.5 images/s, SparseInst bs 8 353-371 -> 379-382; forward output identical, gradients within one
+    bf16 ulp at tensor scale where the masked data gradients change kernel family
+    (tests/test_gpu_resnet.py::test_bottleneck_epilogue_fusions_equal_the_elementwise_passes)."""
+    return os.environ.get("MI_RESNET_EPI_FUSE", "1") == "1"
 
 
 def _relu_mask(g, a):

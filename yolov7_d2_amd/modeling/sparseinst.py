@@ -285,6 +285,23 @@ def _run_stack(seq, x):
     return x
 
 
+def _colsums(x, square=False):
+    """x: bf16 [B, P, C] contiguous (C % 8 == 0) -> fp32 [B, C]: sum over the P pixels of every image of x (or x^2).  The
+    library's column-sum kernel, one launch per image - NOT `x.sum(1, dtype=float32)`: a torch reduction of this shape
+    (thousands of rows per output, few outputs) splits each output across blocks, and that multi-block form returned
+    wrong sums on every replay after the first inside a captured hipGraph on this stack (PyTorch 2.10 / ROCm 7.x;
+    tools/si_graph_debug3.py localised it: norm 1635.7 eager / first replay, 1489.0 on every later replay, all inputs
+    identical).  The captured SparseInst step therefore keeps torch reductions to shapes that stay single-block."""
+    B, P, Cc = x.shape
+    assert x.is_contiguous() and Cc % 8 == 0 and x.dtype == torch.bfloat16
+    out = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+    ws = torch.empty(128 * Cc, dtype=torch.float32, device=x.device)
+    fn = L.lib().mi_colsumsq_bf16_wide if square else L.lib().mi_colsum_bf16_wide
+    for b in range(B):
+        L.check(fn(x[b].data_ptr(), Cc, P, Cc, out[b].data_ptr(), 0, ws.data_ptr(), L.stream_ptr()), "mi_colsum_bf16_wide")
+    return out
+
+
 def _aggregate(iam, features):
     """iam [B, N, H, W] logits, features [B, C, H, W] -> inst [B, N, C] = (sigmoid(iam) @ features^T) / normaliser
     (decoder_sparseinst.py:62-74 / 217-228)"""
@@ -298,7 +315,21 @@ def _aggregate(iam, features):
         a = _pad_cols(prob[b].reshape(H * W, N), Np)
         outs.append(_PixelOuterFn.apply(a, fh[b].reshape(H * W, Cc))[:N])
     inst = torch.stack(outs)                                           # fp32 [B, N, C]
-    return inst, prob.sum((1, 2), dtype=torch.float32)                # normaliser [B, N] (fp32 accumulation, no fp32 copy of the map)
+    return inst, _ColSumFn.apply(prob.reshape(B, H * W, N))           # normaliser [B, N] (fp32 accumulation, no fp32 copy of the map)
+
+
+class _ColSumFn(torch.autograd.Function):
+    """[B, P, N] bf16 -> fp32 [B, N] sums over P (see _colsums); backward: the [B, N] gradient broadcast over the pixels"""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        return _colsums(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        B, P, N = ctx.shape
+        return g.to(torch.bfloat16)[:, None, :].expand(B, P, N)
 
 
 class InstanceBranch(nn.Module):
@@ -445,41 +476,78 @@ def build_sparse_inst_decoder(cfg):
 
 
 # ------------------------------------------------------------------------------------------------ criterion
-def _target_masks(targets, input_shape, size, device):
-    """nested_masks_from_list (utils/misc.py:148-170) + bilinear resize to the prediction size: fp32 [sum M, Ho*Wo]"""
-    ms = [t["masks"] for t in targets]
-    ms = [m.tensor if hasattr(m, "tensor") else m for m in ms]
-    if sum(m.shape[0] for m in ms) == 0:
-        return torch.zeros(0, size[0] * size[1], device=device)
-    pad = []
-    for m in ms:
-        p = torch.zeros(m.shape[0], input_shape[0], input_shape[1], device=device)
-        p[:, : m.shape[1], : m.shape[2]] = m.to(device).float()
-        pad.append(p)
-    t = torch.cat(pad, 0)
-    t = F.interpolate(t[:, None], size=size, mode="bilinear", align_corners=False).squeeze(1)     # ground-truth preparation
-    return t.flatten(1).contiguous()
+class PackedMaskTargets:
+    """The ground truth of a batch on the DEVICE at fixed capacity (`cap` instances per image, a multiple of 32): target
+    masks already resized to the prediction size (nested_masks_from_list, utils/misc.py:148-170, + the bilinear resize of
+    sparseinst_loss.py:138-143) as fp32 [B * cap, Ho * Wo] - image b's instance j is row b * cap + j, unused rows zero -,
+    labels int64 [B, cap], the instance counts as the cumulative table the assignment kernel reads, and 1 / num_instances
+    (already averaged over the ranks, sparseinst_loss.py:206-212) as a device scalar.  Everything the criterion needs without
+    a host value: a captured step serves any batch of the same padded shape, and the eager step never synchronises."""
+
+    def __init__(self, B, cap, size, device):
+        assert cap % 32 == 0
+        self.B, self.cap, self.size = B, cap, tuple(size)
+        P = size[0] * size[1]
+        self.tgt = torch.zeros(B * cap, P, dtype=torch.float32, device=device)
+        self.labels = torch.zeros(B, cap, dtype=torch.int64, device=device)
+        self.off = torch.zeros(B + 1, dtype=torch.int32, device=device)
+        self.inv_num = torch.ones(1, dtype=torch.float32, device=device)
+        self.t2 = torch.zeros(B, cap, dtype=torch.float32, device=device)      # sum_p t^2 of every row (dice denominators)
+        self.sizes = [0] * B
+
+    def fill(self, targets, input_shape):
+        """targets: per image {"labels": int64 [M], "masks": [M, h, w]} (prepare_targets); refilled IN PLACE"""
+        dev = self.tgt.device
+        self.tgt.zero_()
+        self.labels.zero_()
+        sizes = []
+        for b, t in enumerate(targets):
+            m = t["masks"]
+            m = m.tensor if hasattr(m, "tensor") else m
+            M = int(m.shape[0])
+            if M > self.cap:
+                raise ValueError(f"SparseInst: {M} instances in one image, target capacity is {self.cap}")
+            sizes.append(M)
+            if M == 0:
+                continue
+            pad = torch.zeros(M, input_shape[0], input_shape[1], device=dev)
+            pad[:, : m.shape[1], : m.shape[2]] = m.to(dev).float()
+            r = F.interpolate(pad[:, None], size=self.size, mode="bilinear", align_corners=False).squeeze(1)     # ground-truth preparation
+            self.tgt[b * self.cap: b * self.cap + M] = r.flatten(1)
+            self.labels[b, :M] = t["labels"].to(dev)
+        self.sizes = sizes
+        self.t2.copy_((self.tgt * self.tgt).sum(-1).view(self.B, self.cap))      # (eager, in the host half)
+        self.off.copy_(torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32))
+        num = torch.tensor([float(sum(sizes))], device=dev)
+        world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():      # sparseinst_loss.py:210-212
+            torch.distributed.all_reduce(num)
+            world = torch.distributed.get_world_size()
+        self.inv_num.copy_(1.0 / torch.clamp(num / world, min=1.0))
+        return self
 
 
-def dice_score_device(masks_nhwc, tgt, sizes):
-    """dice_score (sparseinst_loss.py:31-36) of every prediction against every target OF ITS IMAGE: list of fp32 [N, M_i].
-    masks_nhwc: bf16 logits [B, Ho, Wo, Np]; tgt: fp32 [sum M, P]"""
+def _pack_targets(targets, input_shape, size, device, cap=None):
+    if cap is None:
+        cap = max(32, _rup(max([len(t["labels"]) for t in targets] + [1]), 32))
+    return PackedMaskTargets(len(targets), cap, size, device).fill(targets, input_shape)
+
+
+def dice_score_packed(masks_nhwc, pk):
+    """dice_score (sparseinst_loss.py:31-36) of every prediction against the `cap` target rows OF ITS IMAGE: fp32 [B, Np, cap]
+    (columns of unused rows are 0).  masks_nhwc: bf16 logits [B, Ho, Wo, Np]"""
     B, Ho, Wo, Np = masks_nhwc.shape
     P = Ho * Wo
     sig = _Ew1.apply(masks_nhwc.contiguous(), "sigmoid").reshape(B, P, Np)
-    out, off = [], 0
-    for b, M in enumerate(sizes):
-        if M == 0:
-            out.append(torch.zeros(Np, 0, device=tgt.device))
-            continue
-        tb = tgt[off: off + M]                                          # [M, P]
-        Mp = _rup(M, 32)
-        tT = _pad_cols(tb.t().to(torch.bfloat16), Mp)                   # [P, Mp]
-        num = 2.0 * pixel_outer(sig[b].contiguous(), tT)[:, :M]         # [Np, M]
-        den = torch.linalg.vector_norm(sig[b], dim=0, dtype=torch.float32).square()[:, None] + (tb * tb).sum(-1)[None, :]
-        out.append(num / (den + 1e-4))
-        off += M
-    return out
+    tg = pk.tgt.view(B, pk.cap, P)
+    s2 = _colsums(sig, square=True)                                                   # [B, Np]  sum_p sigmoid^2
+    t2 = pk.t2                                                                        # [B, cap] sum_p t^2 (PackedMaskTargets.fill)
+    out = []
+    for b in range(B):
+        tT = tg[b].t().to(torch.bfloat16).contiguous()                                # [P, cap]
+        num = 2.0 * pixel_outer(sig[b], tT)                                           # [Np, cap]
+        out.append(num / (s2[b][:, None] + t2[b][None, :] + 1e-4))
+    return torch.stack(out)
 
 
 class SparseInstMatcher(nn.Module):
@@ -489,56 +557,57 @@ class SparseInstMatcher(nn.Module):
         self.beta = cfg.MODEL.SPARSE_INST.MATCHER.BETA
 
     @torch.no_grad()
-    def match_device(self, outputs, targets, input_shape):
+    def match_packed(self, outputs, pk):
+        """SparseInstMatcher.forward (sparseinst_loss.py:300-354) with nothing on the host: cost = dice^alpha * prob^beta of
+        every (prediction, target) pair of an image as [B, N, cap], maximised by the device assignment kernel (mi_lsap on
+        the negated matrix; scipy's linear_sum_assignment(maximize=True) in the reference).  Returns match_q / match_t int64
+        [B, cap] (the first nmatch[b] entries are the pairs, sorted by prediction index) and nmatch int32 [B]"""
         masks = outputs["_masks_nhwc"]
         B, Ho, Wo, Np = masks.shape
         N = outputs["pred_logits"].shape[1]
         dev = masks.device
-        sizes = [len(t["labels"]) for t in targets]
-        tgt = _target_masks(targets, input_shape, (Ho, Wo), dev)
-        gmax = max(max(sizes), 1)
-        off = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32, device=dev)
-        mq = torch.zeros(B, gmax, dtype=torch.int64, device=dev)
-        mt = torch.zeros(B, gmax, dtype=torch.int64, device=dev)
+        cap = pk.cap
+        prob = outputs["pred_logits"].float().sigmoid()                                          # [B, N, C]
+        scores = dice_score_packed(masks, pk)[:, :N]                                             # [B, N, cap]
+        pl = prob.gather(2, pk.labels[:, None, :].expand(B, N, cap))
+        cost = (-((scores ** self.alpha) * (pl ** self.beta))).contiguous()
+        mq = torch.zeros(B, cap, dtype=torch.int64, device=dev)
+        mt = torch.zeros(B, cap, dtype=torch.int64, device=dev)
         nm = torch.zeros(B, dtype=torch.int32, device=dev)
-        if sum(sizes) > 0:
-            prob = outputs["pred_logits"].float().sigmoid()
-            scores = dice_score_device(masks, tgt, sizes)
-            cost = torch.zeros(B, N, gmax, device=dev)
-            for b, M in enumerate(sizes):
-                if M:
-                    ids = targets[b]["labels"].to(dev)
-                    Cm = (scores[b][:N] ** self.alpha) * (prob[b][:, ids] ** self.beta)
-                    cost[b, :, :M] = -Cm                               # linear_sum_assignment(maximize=True)
-            L.check(L.lib().mi_lsap(cost.data_ptr(), off.data_ptr(), B, N, gmax, mq.data_ptr(), mt.data_ptr(), nm.data_ptr(),
-                                    L.stream_ptr()), "mi_lsap")
-        return dict(match_q=mq, match_t=mt, nmatch=nm, tgt=tgt, sizes=sizes, off=off)
+        L.check(L.lib().mi_lsap(cost.data_ptr(), pk.off.data_ptr(), B, N, cap, mq.data_ptr(), mt.data_ptr(), nm.data_ptr(),
+                                L.stream_ptr()), "mi_lsap")
+        return mq, mt, nm
 
     @torch.no_grad()
     def forward(self, outputs, targets, input_shape):
-        m = self.match_device(outputs, targets, input_shape)
-        n = m["nmatch"].tolist()
+        """the reference's return value - a list of (prediction indices, target indices) per image - for callers that want
+        it on the host (tests; this one synchronises).  A NaN cost matrix raises like scipy does."""
+        masks = outputs["_masks_nhwc"]
+        pk = _pack_targets(targets, input_shape, masks.shape[1:3], masks.device)
+        mq, mt, nm = self.match_packed(outputs, pk)
+        n = nm.tolist()
         if any(v < 0 for v in n):
             raise ValueError("matrix contains invalid numeric entries")
-        return [(m["match_q"][b, : n[b]].clone(), m["match_t"][b, : n[b]].clone()) for b in range(len(n))], m
+        return [(mq[b, : n[b]].clone(), mt[b, : n[b]].clone()) for b in range(len(n))], pk
 
 
 class _MaskLossFn(torch.autograd.Function):
-    """(mask logits NHWC, matched pairs) -> tensor [2 + K] = (sum of per-pair BCE sums, sum of per-pair dice losses,
-    mask IoU of every pair ...); d/d(mask logits) from the second kernel"""
+    """(mask logits NHWC, fixed-capacity pair table) -> stats fp32 [K, 8] of every pair (rows of unused pairs zero; layout in
+    csrc/sparseinst_ops.hip); backward: d/d(mask logits) from the upstream gradients of (sum of BCE sums, sum of dice
+    losses), handed to the kernel as a DEVICE pair"""
 
     @staticmethod
-    def forward(ctx, masks, tgt, pairs, K):
+    def forward(ctx, masks, tgt, pairs, valid):
         B, Ho, Wo, Np = masks.shape
         P = Ho * Wo
+        K = pairs.shape[0]
         stats = torch.empty(K, 8, dtype=torch.float32, device=masks.device)
         L.check(L.lib().mi_sparseinst_mask_stats(masks.data_ptr(), Np, P, tgt.data_ptr(), pairs.data_ptr(), K,
                                                  stats.data_ptr(), L.stream_ptr()), "mi_sparseinst_mask_stats")
         bce = stats[:, 0].sum()
-        dice = (1.0 - 2.0 * stats[:, 1] / (stats[:, 2] + stats[:, 3] + 1e-4)).sum()
+        dice = ((1.0 - 2.0 * stats[:, 1] / (stats[:, 2] + stats[:, 3] + 1e-4)) * valid).sum()
         iou = stats[:, 4] / (stats[:, 6] + stats[:, 5] - stats[:, 4] + 1e-6)
         ctx.save_for_backward(masks, tgt, pairs, stats)
-        ctx.K = K
         return torch.cat([bce[None], dice[None], iou])
 
     @staticmethod
@@ -546,9 +615,10 @@ class _MaskLossFn(torch.autograd.Function):
         masks, tgt, pairs, stats = ctx.saved_tensors
         B, Ho, Wo, Np = masks.shape
         dm = torch.zeros_like(masks)
-        L.check(L.lib().mi_sparseinst_mask_grad(masks.data_ptr(), Np, Ho * Wo, tgt.data_ptr(), pairs.data_ptr(), ctx.K,
-                                                stats.data_ptr(), float(g[0]), float(g[1]), dm.data_ptr(), L.stream_ptr()),
-                "mi_sparseinst_mask_grad")
+        coef = g[:2].float().contiguous()
+        L.check(L.lib().mi_sparseinst_mask_grad_dev(masks.data_ptr(), Np, Ho * Wo, tgt.data_ptr(), pairs.data_ptr(),
+                                                    pairs.shape[0], stats.data_ptr(), coef.data_ptr(), dm.data_ptr(),
+                                                    L.stream_ptr()), "mi_sparseinst_mask_grad_dev")
         return dm, None, None, None
 
 
@@ -559,10 +629,18 @@ def sigmoid_focal_loss(inputs, targets, alpha=0.25, gamma=2.0):
     p_t = p * targets + (1 - p) * (1 - targets)
     loss = ce * ((1 - p_t) ** gamma)
     loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
-    return loss.sum()
+    return loss.sum(-1).sum()        # (rows first: both reductions stay single-block, see _colsums)
 
 
 class SparseInstCriterion(nn.Module):
+    """SparseInstCriterion (loss/sparseinst_loss.py:190-297) with the matching AND the matched-pair bookkeeping on the device
+    (round 4; rounds 2-3 built the pair table on the host from `nmatch.tolist()` - three synchronisations per step, which
+    also kept the step from being captured).  The assignment leaves (match_q, match_t, nmatch) on the device; every loss is
+    written over the FIXED B x cap pair grid with the unused pairs masked:
+      labels   the one-hot target gets 1 at (b, match_q, label[match_t]) by an index_put of the pair-validity mask
+      masks    pair table rows (b or -1, q, b * cap + t): the kernels skip rows with b < 0
+      counts   K = sum nmatch (clamped to 1 where it divides) and 1 / num_instances are device scalars"""
+
     def __init__(self, cfg, matcher):
         super().__init__()
         self.matcher = matcher
@@ -572,42 +650,38 @@ class SparseInstCriterion(nn.Module):
                                 loss_objectness=ls.OBJECTNESS_WEIGHT)
         self.num_classes = cfg.MODEL.SPARSE_INST.DECODER.NUM_CLASSES
 
-    def forward(self, outputs, targets, input_shape):
-        indices, m = self.matcher(outputs, targets, input_shape)
-        dev = outputs["pred_logits"].device
-        num_instances = torch.as_tensor([sum(len(t["labels"]) for t in targets)], dtype=torch.float, device=dev)
-        world = 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            torch.distributed.all_reduce(num_instances)
-            world = torch.distributed.get_world_size()
-        num_instances = torch.clamp(num_instances / world, min=1).item()
+    def forward(self, outputs, targets, input_shape=None):
+        """targets: PackedMaskTargets (SparseInst.prepare_batch) or the reference's list of per-image dicts (packed here)"""
+        masks = outputs["_masks_nhwc"]
+        pk = targets if isinstance(targets, PackedMaskTargets) else \
+            _pack_targets(targets, input_shape, masks.shape[1:3], masks.device)
+        mq, mt, nm = self.matcher.match_packed(outputs, pk)
+        B, cap = mq.shape
+        dev = masks.device
+        nmc = nm.clamp(min=0)                       # (an invalid cost matrix - nmatch < 0 - contributes no pair; no host raise)
+        valid = torch.arange(cap, device=dev)[None, :] < nmc[:, None]                           # [B, cap]
+        vf = valid.float()
+        inv_num = pk.inv_num[0]
+        bi = torch.arange(B, device=dev)[:, None].expand(B, cap)
         losses = {}
         if "labels" in self.losses:
             src_logits = outputs["pred_logits"]
+            cls = pk.labels.gather(1, mt)                                                       # label of the matched target
             labels = torch.zeros_like(src_logits)
-            for b, (src, tgt_j) in enumerate(indices):
-                if len(src):
-                    labels[b, src, targets[b]["labels"].to(dev)[tgt_j]] = 1
-            losses["loss_ce"] = sigmoid_focal_loss(src_logits.flatten(0, 1), labels.flatten(0, 1)) / num_instances
+            labels.index_put_((bi.reshape(-1), mq.reshape(-1), cls.reshape(-1)), vf.reshape(-1).to(labels.dtype),
+                              accumulate=True)       # (unused pairs add 0 somewhere in row 0 of their image)
+            losses["loss_ce"] = sigmoid_focal_loss(src_logits.flatten(0, 1), labels.flatten(0, 1)) * inv_num
         if "masks" in self.losses:
-            masks = outputs["_masks_nhwc"]
-            K = sum(len(s) for s, _ in indices)
-            if K == 0:
-                z = masks.float().sum() * 0.0
-                losses.update(loss_dice=z, loss_mask=z, loss_objectness=outputs["pred_scores"].sum() * 0.0)
-            else:
-                rows, scr = [], []
-                for b, (src, tgt_j) in enumerate(indices):
-                    o = int(m["off"][b])
-                    for q, j in zip(src.tolist(), tgt_j.tolist()):
-                        rows.append((b, q, o + j))
-                        scr.append(outputs["pred_scores"][b, q, 0])
-                pairs = torch.tensor(rows, dtype=torch.int32, device=dev)
-                r = _MaskLossFn.apply(masks.contiguous(), m["tgt"], pairs, K)
-                P = masks.shape[1] * masks.shape[2]
-                losses["loss_mask"] = r[0] / (K * P)                      # BCE 'mean' over the K x P matched elements
-                losses["loss_dice"] = r[1] / num_instances
-                losses["loss_objectness"] = F.binary_cross_entropy_with_logits(torch.stack(scr), r[2:].detach(), reduction="mean")
+            kdev = vf.sum().clamp(min=1.0)
+            rows = torch.stack([torch.where(valid, bi, torch.full_like(bi, -1)), mq, bi * cap + mt], -1)
+            pairs = rows.reshape(-1, 3).to(torch.int32).contiguous()
+            r = _MaskLossFn.apply(masks.contiguous(), pk.tgt, pairs, vf.reshape(-1))
+            P = masks.shape[1] * masks.shape[2]
+            losses["loss_mask"] = r[0] / (kdev * P)                   # BCE 'mean' over the K x P matched elements
+            losses["loss_dice"] = r[1] * inv_num
+            scr = outputs["pred_scores"][..., 0].gather(1, mq)                                  # [B, cap]
+            obj = F.binary_cross_entropy_with_logits(scr, r[2:].detach().view(B, cap).to(scr.dtype), reduction="none")
+            losses["loss_objectness"] = (obj.float() * vf).sum() / kdev
         for k in list(losses.keys()):
             if k in self.weight_dict:
                 losses[k] = losses[k] * self.weight_dict[k]
@@ -640,6 +714,8 @@ class SparseInst(nn.Module):
         self.cls_threshold = cfg.MODEL.YOLO.CONF_THRESHOLD
         self.mask_threshold = cfg.MODEL.SPARSE_INST.MASK_THRESHOLD
         self.max_detections = cfg.MODEL.SPARSE_INST.MAX_DETECTIONS
+        # prediction masks: the stride-8 encoder map up-sampled by DECODER.SCALE_FACTOR (2.0 -> stride 4)
+        self.mask_stride = int(round(8 / cfg.MODEL.SPARSE_INST.DECODER.SCALE_FACTOR))
         self.to(self.device)
 
     def normalizer(self, image):
@@ -663,6 +739,41 @@ class SparseInst(nn.Module):
             new_targets.append({"labels": t.gt_classes.to(self.device), "masks": gt_masks.to(self.device)})
         return new_targets
 
+    # ---- the training step split at the host / device line (graph_step.GraphedTrainStep captures the device half)
+    target_capacity = 96      # instances per image the packed targets hold (a multiple of 32; COCO: <= 93 after crowd removal)
+
+    def batch_key(self, batched_inputs):
+        r = 32                          # ImageList.from_tensors(images, 32) of preprocess_inputs (sparseinst.py:95-98)
+        up = lambda v: (v + r - 1) // r * r
+        return (len(batched_inputs), up(max(int(x["image"].shape[-2]) for x in batched_inputs)),
+                up(max(int(x["image"].shape[-1]) for x in batched_inputs)))
+
+    def prepare_batch(self, batched_inputs, static=None):
+        """everything of the training forward that touches the host: normalise + zero-pad the images into one tensor
+        (ImageList.from_tensors(images, 32), sparseinst.py:95-98) and move the ground truth over as PackedMaskTargets (masks
+        padded to the batch shape and resized to the prediction size HERE, eagerly).  With `static` - an earlier result for
+        the same batch_key - everything is refilled IN PLACE."""
+        B, Hp, Wp = self.batch_key(batched_inputs)
+        dev = self.device
+        if static is None:
+            st = self.mask_stride
+            static = dict(images=torch.zeros(B, 3, Hp, Wp, device=dev), key=(B, Hp, Wp),
+                          targets=PackedMaskTargets(B, self.target_capacity, (Hp // st, Wp // st), dev))
+        assert static["key"] == (B, Hp, Wp), (static["key"], (B, Hp, Wp))
+        img = static["images"]
+        img.zero_()
+        for b, x in enumerate(batched_inputs):
+            t = self.normalizer(x["image"].to(dev).float())
+            img[b, :, : t.shape[-2], : t.shape[-1]].copy_(t)
+        gt = self.prepare_targets([x["instances"].to(dev) for x in batched_inputs])
+        static["targets"].fill(gt, (Hp, Wp))
+        return static
+
+    def forward_prepared(self, static):
+        """the device half: backbone, encoder, decoder, criterion - no host value of the batch enters a launch"""
+        output = self.decoder(self.encoder(self.backbone(static["images"])))
+        return self.criterion(output, static["targets"])
+
     def forward(self, batched_inputs):
         if self.device.type != "cuda":
             raise L.MI355Error(f"SparseInst on MODEL.DEVICE={self.device}: the MI355X path needs a HIP device (no CPU fallback)")
@@ -672,7 +783,10 @@ class SparseInst(nn.Module):
         output = self.decoder(self.encoder(features))
         if self.training:
             gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
-            return self.criterion(output, self.prepare_targets(gt_instances), max_shape)
+            # (the same fixed-capacity packing as prepare_batch: the eager and the captured step run identical launches)
+            pk = _pack_targets(self.prepare_targets(gt_instances), max_shape, output["_masks_nhwc"].shape[1:3], self.device,
+                               cap=self.target_capacity)
+            return self.criterion(output, pk)
         results = self.inference(output, batched_inputs, max_shape, images.image_sizes)
         return [{"instances": r} for r in results]
 

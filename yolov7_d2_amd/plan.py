@@ -1257,6 +1257,7 @@ class Plan:
             return cmds
         CONV, CONVG, BNF, BNG = L.OP["CONV"], L.OP["CONV_GROUP"], L.OP["BN_ACT_FWD"], L.OP["BN_GROUP"]
         lib = L.lib()
+        maxpix = int(os.environ.get("MI_CONV_BN_FUSE_MAXPIX", "0"))
         out, k = [], 0
         while k < len(cmds):
             c = cmds[k]
@@ -1267,6 +1268,10 @@ class Plan:
             elif nxt is not None and c.op == CONVG and nxt.op == BNG and nxt.i[0] == 0 and len(c.members) == len(nxt.members):
                 convs, bns = c.members, nxt.members
             g = None
+            # MI_CONV_BN_FUSE_MAXPIX=n: only layers whose maps have <= n pixels per image (1600 = the 40x40 / 20x20 sub-network,
+            # where a launch is mostly fixed cost and the second phase has little to stream)
+            if convs is not None and maxpix and any(cv.desc.outH * cv.desc.outW > maxpix for cv in convs):
+                convs = None
             if convs is not None and all(b_.p[1].resolve() for b_ in bns):      # (train mode: the jobs carry accumulators)
                 n = len(convs)
                 descs = (L.mi_conv_desc * n)()
