@@ -345,3 +345,37 @@ def test_sparseinst_device_half_never_reads_the_host_and_is_captured():
                 assert d <= 1.0e-4, (n, d)           # three AdamW steps of lr 5e-5 move a weight by <= 1.5e-4
     finally:
         step.close()
+
+
+def test_sparseinst_captured_step_at_the_bench_size_equals_eager():
+    """configs[4] at the size bench.py runs (B = 8, 640 x 640, up to 10 instances per image): captured == eager over four
+    optimizer steps, parameters identical.  The small test above never saw what this size shows: memset nodes losing their
+    ordering on later replays of the large graph, and torch's multi-block reductions with them (profiles/
+    r04_graph_memset_finding.txt) - with either back in the captured path this test fails from the second step on."""
+    from yolov7_d2_amd.graph_step import GraphedTrainStep
+    from yolov7_d2_amd.optim import MultiTensorAdamW
+    import copy
+    torch.manual_seed(0)
+    cfg = M.sparse_inst_r50_giam_cfg(device=DEV)
+    eager = M.build_model(cfg)
+    graphed = copy.deepcopy(eager)
+    eager.train(); graphed.train()
+    mk = lambda m: MultiTensorAdamW([p for p in m.parameters() if p.requires_grad], lr=5e-5, weight_decay=0.05)
+    oe, og = mk(eager), mk(graphed)
+    b = [dict(x, image=x["image"].to(DEV)) for x in _si_inputs(11, [(640, 640)] * 8, counts=(3, 10, 1, 7, 5, 2, 9, 4))]
+    step = GraphedTrainStep(graphed, og)
+    try:
+        for it in range(4):
+            losses = eager(b)
+            total = sum(losses.values())
+            oe.zero_grad(set_to_none=True)
+            total.backward()
+            oe.step()
+            out = step(b)
+            for k, v in losses.items():
+                torch.testing.assert_close(out[k].float(), v.detach().float(), rtol=1e-4, atol=1e-4, msg=f"step {it} {k}")
+        torch.cuda.synchronize()
+        worst = max(float((p.detach() - q.detach()).abs().max()) for p, q in zip(eager.parameters(), graphed.parameters()))
+        assert worst <= 1e-6, worst
+    finally:
+        step.close()
