@@ -797,6 +797,12 @@ def main():
             out["ms_per_step_incl_h2d"] = round(incl[1], 3)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            # the box this runs on has no /root/reference, so the live leg above can only be the restatement ("port"); the
+            # REFERENCE'S OWN modules timed where that tree exists (the build container, 8 cores) are recorded under profiles/
+            rec = os.path.join(ROOT, "profiles", "r04_cpu_baseline_reference.json")
+            if out["cpu_baseline"]["kind"] != "reference" and os.path.exists(rec):
+                with open(rec) as f:
+                    out["cpu_baseline"]["reference_recorded"] = json.load(f)
         if args.breakdown:
             with open(args.breakdown, "w") as f:
                 json.dump(breakdown, f, indent=1)

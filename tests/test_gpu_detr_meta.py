@@ -261,3 +261,165 @@ def test_detr_r50_real_size_against_reference_golden(golden_dir):
     lg, bx = out["pred_logits"].float().cpu().numpy(), out["pred_boxes"].float().cpu().numpy()
     print("eval max abs: logits", np.abs(lg - g["eval_logits"]).max(), "boxes", np.abs(bx - g["eval_boxes"]).max())
     assert np.abs(lg - g["eval_logits"]).max() < 0.25 and np.abs(bx - g["eval_boxes"]).max() < 3e-2
+
+
+def test_detr_r50_real_size_gradients_with_the_forward_state_pinned(monkeypatch):
+    """configs[3] to the YOLOX standard (tests/test_gpu_parity_bench.py): DETR-R50 at its real size (6 + 6 layers, 100 queries,
+    an 800 x 1333 + 768 x 1205 padded batch), EVERY trainable parameter's gradient against an fp32 restatement whose forward
+    is pinned to the HIP network's own activations (teacher forcing: every trainable conv output of res3 .. res5, the input
+    projection, all six encoder and all six decoder layer outputs), so that both sides differentiate the same function at the
+    same point and the comparison measures the backward kernels - not which ReLU gate or attention row a bf16 rounding tipped.
+    Two segments, each fed the HIP network's own upstream gradient: [input_proj + transformer + heads] from d loss / d (class
+    logits, boxes) of all six levels (oracle/detr_net_oracle.py, pinned to the reference's Transformer by the CPU suite), and
+    [ResNet-50 res3 .. res5] from d loss / d res5 (oracle/resnet_oracle.py).  Replaces the un-forced norm + 8-projection
+    fingerprints (median 4.6 %, max 12 %) as the gradient bound of this configuration: cosine >= 0.999, rel L2 <= 0.05."""
+    import detr_net_oracle as DN
+    import resnet_oracle as R
+    from yolov7_d2_amd.modeling.resnet import Conv2d
+    from yolov7_d2_amd.modeling.transformer import TransformerDecoderLayer, TransformerEncoderLayer
+    monkeypatch.setenv("MI_RESNET_BLOCK_FN", "0")         # per-convolution autograd nodes: their outputs can be hooked
+    cfg = M.detr_r50_cfg(device=DEV)
+    cfg.MODEL.DETR.DROPOUT = 0.0
+    model = M.build_model(cfg)
+    sd = model.state_dict()
+    model.load_state_dict(seeded_tensor_dict({k: v.shape for k, v in sd.items()}, seed=207), strict=False)
+    with torch.no_grad():
+        model.detr.input_proj.weight.mul_(1e-3)           # (tokens of trained magnitude, as in the real-size golden test)
+    model.train()
+    inputs = _inputs(synth_detr_batch(seed=211, sizes=((800, 1333), (768, 1205))))
+    cpu = lambda t: t.detach().float().cpu()
+    caps, grads, keep = {}, {}, {}
+    bb = model.detr.backbone[0].backbone
+    BP = "detr.backbone.0.backbone."
+    for name, mod in bb.named_modules():
+        if isinstance(mod, Conv2d) and name.startswith(("res3", "res4", "res5")):
+            mod.register_forward_hook(lambda m, i, o, name=name: caps.__setitem__(name, cpu(o)))
+
+    def feat_hook(m, i, o):
+        o["res5"].retain_grad()
+        keep["res5"] = o["res5"]
+    bb.register_forward_hook(feat_hook)
+    bb.res3.register_forward_pre_hook(lambda m, args: keep.__setitem__("res2", args[0]))      # (the frozen stages' output)
+
+    def tr_pre(m, args):
+        args[0].retain_grad()
+        keep["src"], keep["mask"], keep["pos"] = args[0], args[1], args[3]
+    model.detr.transformer.register_forward_pre_hook(tr_pre)
+    for i, layer in enumerate(model.detr.transformer.encoder.layers):
+        assert isinstance(layer, TransformerEncoderLayer)
+        layer.register_forward_hook(lambda m, inp, o, i=i: caps.__setitem__(f"enc.{i}", cpu(o)))
+    for i, layer in enumerate(model.detr.transformer.decoder.layers):
+        assert isinstance(layer, TransformerDecoderLayer)
+        layer.register_forward_hook(lambda m, inp, o, i=i: caps.__setitem__(f"dec.{i}", cpu(o)))
+
+    def out_hook(m, i, o):
+        levels = list(o["aux_outputs"]) + [dict(pred_logits=o["pred_logits"], pred_boxes=o["pred_boxes"])]
+        for lv in levels:
+            lv["pred_logits"].retain_grad(); lv["pred_boxes"].retain_grad()
+        keep["levels"] = levels
+    model.detr.register_forward_hook(out_hook)
+    losses = model(inputs)
+    total = sum(v for k, v in losses.items() if k in model.criterion.weight_dict)
+    total.backward()
+    torch.cuda.synchronize()
+    hip = {n: cpu(p.grad) for n, p in model.named_parameters() if p.requires_grad}
+    q = lambda t: t + (t.to(torch.bfloat16).float() - t).detach()
+
+    # ---- segment 1: input_proj + transformer + heads, forward pinned, backward from the HIP d / d (logits, boxes)
+    osd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items() if k.startswith("detr.") and not k.startswith(BP)}
+    tkeys = [k for k in osd if k in hip]
+    for k in tkeys:
+        osd[k].requires_grad_(True)
+    feat = cpu(keep["res5"]).requires_grad_(True)
+    force = {k: v for k, v in caps.items() if k.startswith(("enc.", "dec."))}
+    force["src"] = cpu(keep["src"])
+    assert len(force) == 13
+    # query_embed enters every decoder layer three times (self-attention query and key, cross-attention query): per-use
+    # copies give the 18 TERMS of its gradient
+    qes = [tuple(osd["detr.query_embed.weight"].detach().clone().requires_grad_(True) for _ in range(3)) for _ in range(6)]
+    ref = DN.detr_after_backbone(osd, feat, keep["mask"].cpu(), cpu(keep["pos"]), nhead=8, prefix="detr.", quant=q, force=force,
+                                 query_embed_layers=qes)
+    dl = torch.stack([cpu(lv["pred_logits"].grad) for lv in keep["levels"]])
+    db = torch.stack([cpu(lv["pred_boxes"].grad) for lv in keep["levels"]])
+    lg_hip = torch.stack([cpu(lv["pred_logits"]) for lv in keep["levels"]])
+    bx_hip = torch.stack([cpu(lv["pred_boxes"]) for lv in keep["levels"]])
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    print("forced forward: logits rel %.2e boxes rel %.2e" % (rel(lg_hip, ref["logits"].detach()), rel(bx_hip, ref["boxes"].detach())))
+    assert rel(lg_hip, ref["logits"].detach()) < 2e-2 and rel(bx_hip, ref["boxes"].detach()) < 2e-2
+    torch.autograd.backward([ref["logits"], ref["boxes"]], [dl, db])
+
+    def table(keys, get_ref):
+        rows = []
+        for k in keys:
+            a, b = hip[k].flatten(), get_ref(k).flatten()
+            na, nb = float(a.norm()), float(b.norm())
+            cos = float(torch.dot(a, b) / (na * nb + 1e-30))
+            rows.append((k, cos, float((a - b).norm() / (nb + 1e-30)), na, nb))
+        return rows
+    qflat = [t for tri in qes for t in tri]
+    osd["detr.query_embed.weight"].grad = sum(t.grad for t in qflat)
+    rows = table(tkeys, lambda k: osd[k].grad)
+    # the first decoder layer attends over tgt = 0: its q / k in-projection gradients are mathematically zero (both sides
+    # hold rounding residue) - compared against the same parameter's v rows instead.  query_embed: bounded below against
+    # the size of its six summed terms.  linear1 (the layer in front of the FFN's ReLU): the hidden activations are not a
+    # pinned site, so gates of near-zero pre-activations are each side's own - 0.998 / 0.07 there
+    special = {k for k in tkeys if "decoder.layers.0.self_attn.in_proj" in k} | {"detr.query_embed.weight"}
+    lim = lambda k: (0.998, 0.07) if ".linear1." in k else (0.999, 0.05)
+    bad = [(k, round(c, 5), round(r, 4)) for k, c, r, na, nb in rows if k not in special and (c < lim(k)[0] or r > lim(k)[1])]
+    worst = sorted((r for r in rows if r[0] not in special), key=lambda r: r[1])[:4]
+    print("transformer segment: %d tensors, worst cosines" % len(rows), [(k[-46:], round(c, 5), round(r, 4)) for k, c, r, _, _ in worst])
+    assert not bad, bad[:8]
+    qerr = float((hip["detr.query_embed.weight"] - osd["detr.query_embed.weight"].grad).norm())
+    qterms = sum(float(t.grad.norm()) for t in qflat)
+    print("query_embed: |error| %.3e, |sum| %.3e, sum of the 18 terms' norms %.3e" % (qerr, float(osd["detr.query_embed.weight"].grad.norm()), qterms),
+          "per layer (self q, self k, cross q):", [[round(float(t.grad.norm()), 5) for t in tri] for tri in qes])
+    # d / d query_embed and the q / k rows of every in-projection are what flows through dS = P o (dP - rowsum(dO o O)): at
+    # random initialisation the attention is near-uniform (dP ~ rowsum: the difference cancels to a few percent of its
+    # operands) and the product's O is a bf16 tensor, so this path carries the forward's storage rounding amplified by the
+    # cancellation - a property of bf16 attention outputs, not of the backward kernels (the value / output projections, which
+    # do not cross the cancellation, are among the 193 tensors held to 0.999 above).  Reported, bounded loosely:
+    E = 256
+    qk = []
+    for k in tkeys:
+        if k.endswith("in_proj_weight") and "decoder.layers.0.self_attn" not in k:
+            a, b = hip[k][: 2 * E].flatten(), osd[k].grad[: 2 * E].flatten()
+            qk.append((k[len("detr.transformer."):-len(".in_proj_weight")], float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)),
+                       float((a - b).norm() / (b.norm() + 1e-30)), float(b.norm() / osd[k].grad[2 * E:].norm())))
+    print("q / k rows of the in-projections (name, cosine, rel L2, |qk rows| / |v rows|):", [(n, round(c, 4), round(r, 3), round(f, 4)) for n, c, r, f in qk])
+    # measured: encoder self-attention 3-15 % (cosine 0.989-0.9997), decoder cross-attention 18-60 % (0.86-0.98) on a component
+    # that is 0.3-3 % of its tensor; the decoder's SELF-attention q / k gradients are ~0 on both sides (100 near-identical
+    # queries: exactly uniform attention) - there the HIP rows must be noise-small against the value rows
+    for n, c, r, f in qk:
+        if f > 1e-3:
+            assert c > 0.85, (n, c, r, f)
+    for k in tkeys:
+        if k.endswith("self_attn.in_proj_weight") and ".decoder." in k and ".layers.0." not in k:      # (layer 0: below)
+            assert float(hip[k][: 2 * E].norm()) < 1e-2 * float(hip[k][2 * E:].norm()), k
+    assert qerr < 0.3 * qterms
+    for k in special - {"detr.query_embed.weight"}:
+        E = 256
+        a, b = hip[k][2 * E:].flatten(), osd[k].grad[2 * E:].flatten()       # the value projection rows
+        if float(b.norm()) > 1e-12:
+            assert float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)) > 0.999, k
+        assert float(hip[k][: 2 * E].norm()) < 3e-2 * float(hip[k.replace("layers.0", "layers.1")][: 2 * E].norm()), k
+    dres5 = cpu(keep["res5"].grad)
+    c5 = float(torch.dot(dres5.flatten(), feat.grad.flatten()) / (dres5.norm() * feat.grad.norm() + 1e-30))
+    print("d res5: cosine %.5f rel %.4f" % (c5, rel(dres5, feat.grad)))
+    # (d res5 = input_proj^T d src, and d src has crossed six encoder layers' q / k paths, see above: measured 0.9988 / 0.049)
+    assert c5 > 0.998 and rel(dres5, feat.grad) < 0.07
+
+    # ---- segment 2: ResNet-50 res3 .. res5 (FREEZE_AT 2), every conv output pinned, backward from the HIP d / d res5
+    bsd = {k[len(BP):]: v.detach().float().cpu().clone() for k, v in model.state_dict().items() if k.startswith(BP)}
+    bkeys = [k for k in hip if k.startswith(BP)]
+    assert len(bkeys) == 42 and len([k for k in caps if k.startswith("res")]) == 42
+    for k in bkeys:
+        bsd[k[len(BP):]].requires_grad_(True)
+    bref = R.forward(bsd, None, quant=q, force={k: v for k, v in caps.items() if k.startswith("res")},
+                     start=("res3", cpu(keep["res2"])))
+    assert rel(cpu(keep["res5"]), bref["res5"].detach()) < 1e-3
+    bref["res5"].backward(dres5)
+    brows = table(bkeys, lambda k: bsd[k[len(BP):]].grad)
+    bbad = [(k, round(c, 5), round(r, 4)) for k, c, r, na, nb in brows if c < 0.999 or r > 0.05]
+    print("backbone segment: 42 tensors, worst cosines", [(k[-30:], round(c, 5), round(r, 4)) for k, c, r, _, _ in sorted(brows, key=lambda r: r[1])[:4]])
+    assert not bbad, bbad[:8]
+    assert len(rows) + len(brows) == len(hip)              # every trainable parameter of the model was compared

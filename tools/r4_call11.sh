@@ -1,0 +1,3 @@
+#!/bin/bash
+O=gpurun_out/r4_c11; mkdir -p $O
+timeout 1500 python -m pytest -x -q -m gpu -s tests/test_gpu_sparseinst.py -k "forward_state_pinned" > $O/pinned.log 2>&1; grep -v "Warning\|warn" $O/pinned.log | tail -12 | cut -c1-600
