@@ -741,7 +741,7 @@ class Plan:
             buf.base = base
         self.descs = []
         self.cmd_descs = {}
-        self.fwd_cmds, self.fwd_tags = self._materialize(self._batch_packs(b.prologue) + b.fwd, "fwd")
+        self.fwd_cmds, self.fwd_tags = self._materialize(self._overlap_prologue(self._batch_packs(b.prologue), list(b.fwd)), "fwd")
         self.graphs = {}
         # BatchNorm backward as one fused launch per layer or as reduce + apply: MI_BN_FUSED=1 / 0, default "auto" = both
         # backward lists are captured and timed ON THIS DEVICE and the faster one is kept.  (Measured: on most boxes of the
@@ -761,6 +761,21 @@ class Plan:
                         (L.OPS[self.bwd_cmds[0][k].op] == "BN_GROUP" and self.bwd_cmds[0][k].i[0] == 3)
                         for k in range(self.bwd_cmds[1]))):
             self._select_bn_backward()
+
+    @staticmethod
+    def _overlap_prologue(pro, fwd):
+        """the weight re-pack (reads the fp32 masters, writes the bf16 images: ~54 MB, 45 us) and the Focus packer (reads the
+        uint8 batch, writes the stem's input: ~125 MB, 49 us) depend on nothing of each other and both stream; MI_PACK_ASYNC=1
+        issues them as two branches of the captured graph, joined by the first convolution.  OPT-IN: measured SLOWER - 5.50 vs
+        5.41 ms per step, four alternating pairs (profiles/r04_pack_async_ab.txt): one fork / join inside the hipGraph costs
+        more than the ~45 us the overlap can save, like the head's branch experiment of round 1 (-3 %)."""
+        if os.environ.get("MI_PACK_ASYNC", "0") != "1" or len(pro) != 1 or pro[0].op != L.OP["PACK_W_BATCH"]:
+            return pro + fwd
+        k = next((i for i, c in enumerate(fwd) if c.op == L.OP["FOCUS"]), None)
+        if k is None or any(c.op not in (L.OP["MEMSET"], L.OP["FOCUS"]) for c in fwd[: k + 1]):
+            return pro + fwd
+        pro[0].stream = 1
+        return [_Cmd(L.OP["NOP"], tag="prologue.begin")] + pro + fwd[: k + 1] + [_Cmd(L.OP["NOP"], tag="prologue.end")] + fwd[k + 1:]
 
     def check_bn_barriers(self):
         """raise if any grid barrier of the one-launch BatchNorm backward gave up since the last check (word 2 of a
