@@ -176,6 +176,9 @@ typedef struct mi_wgrad_desc {
   int32_t tap_dy[MI_MAX_TAPS], tap_dx[MI_MAX_TAPS];
   int32_t accumulate;
   int32_t TH, TW, splitk, cfg_tp, cfg_ns; /* 0 => chosen by launcher (pixel tile, split-K, tile pixels, LDS stages) */
+  const float* row_scale; /* NULL, or fp32 [Cout]: gw[co] (+)= row_scale[co] * dW[co] - the gradient of a weight whose
+                           * image carried a folded per-Cout factor (mi_pack_conv_weight_scaled), applied to the fp32
+                           * sum in the split-K reduction */
 } mi_wgrad_desc;
 int mi_conv2d_wgrad(const mi_wgrad_desc* d, mi_stream_t s);
 /* workspace bytes mi_conv2d_wgrad needs for this descriptor (pointers may be NULL), or <0 */
@@ -225,6 +228,7 @@ typedef struct mi_pack_job {
   void* wd;
   int32_t Cout, Cin, KK, CinPad, CoutPad, CoutPadK, CinPadN;
   int32_t blk0; /* first block of this job in the flat launch: filled by mi_pack_jobs_layout */
+  const float* scale; /* NULL, or fp32 [Cout] folded into both images as mi_pack_conv_weight_scaled does (W * scale[co]) */
 } mi_pack_job;
 /* validates the (host) job table, fills blk0 and returns the number of blocks of the flat launch (<0 on error) */
 int mi_pack_jobs_layout(mi_pack_job* jobs_host, int njobs);
@@ -493,6 +497,11 @@ int mi_mha_dropout_mask(uint8_t* out, int B, int H, int Lq, int Lk, float drop_p
 /* elementwise dropout of a bf16 tensor (F.dropout of detr_backbone.py:147-150,163-167,...): out[i] = keep(seed, i) ?
  * x[i] / (1-p) : 0; applying it with the same (p, seed) to the output gradient IS the backward. n %% 8 == 0. */
 int mi_dropout_bf16(const void* x, void* out, int64_t n, float drop_p, uint64_t seed, mi_stream_t s);
+/* out = res + dropout(x): the residual add that follows every F.dropout of the transformer layers
+ * (detr_backbone.py:163,167,235,239,243: `src = src + self.dropout1(src2)`) in the same pass; the dropped value is rounded
+ * to bf16 before the fp32 add, so the result equals mi_dropout_bf16 followed by mi_ew_bf16(op 0) bit for bit.  res NULL:
+ * mi_dropout_bf16. */
+int mi_dropout_add_bf16(const void* x, const void* res, void* out, int64_t n, float drop_p, uint64_t seed, mi_stream_t s);
 /* A step captured as a hipGraph bakes its seeds into the kernel arguments.  With a device word registered here every
  * dropout kernel launched afterwards (mi_dropout_bf16, mi_mha_*_dropout, forward and backward alike) uses seed + *dev_word,
  * read at RUN time: advance the word once per replay (after the backward) and every replay draws fresh masks while the

@@ -82,6 +82,50 @@ def test_elementwise_dropout_statistics_and_backward():
     assert torch.equal(x.grad != 0, nz)                        # the backward applies the SAME mask
 
 
+def test_residual_add_fused_into_the_dropout_pass_equals_two_launches():
+    """_AddDroppedFn (mi_dropout_add_bf16: res + dropout(x) in one pass) against _DropoutFn followed by the elementwise add:
+    identical bits forward, identical gradients (g to the residual, the SAME mask applied to g for the branch)"""
+    from yolov7_d2_amd.modeling.transformer import _AddDroppedFn, _AddFn
+    g = torch.Generator().manual_seed(4)
+    mk = lambda: torch.randn(300, 4, 256, generator=g).to(torch.bfloat16).to(DEV)
+    res, x, go = mk(), mk(), mk()
+    r1, x1 = res.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    r2, x2 = res.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    a = _AddDroppedFn.apply(r1, x1, 0.1, 777)
+    b = _AddFn.apply(r2, _DropoutFn.apply(x2, 0.1, 777))
+    assert torch.equal(a, b)
+    a.backward(go)
+    b.backward(go)
+    assert torch.equal(r1.grad, r2.grad) and torch.equal(x1.grad, x2.grad)
+    assert 0.08 < float((x1.grad == 0).float().mean()) < 0.12
+
+
+def test_in_projection_as_one_node_equals_three_sliced_linears():
+    """_InProjFn (q, k, v from the WHOLE in_proj_weight / in_proj_bias in one autograd node, the three weight-gradient
+    launches writing their row blocks of one [3E, E] tensor) against three _LinearFn calls on parameter slices (autograd's
+    SliceBackward + accumulation): identical outputs, input gradients and parameter gradients"""
+    from yolov7_d2_amd.modeling.transformer import _InProjFn, _LinearFn
+    g = torch.Generator().manual_seed(6)
+    E, Tq, Tk = 256, 400, 1040
+    w = (torch.randn(3 * E, E, generator=g) * 0.05).to(DEV)
+    b = (torch.randn(3 * E, generator=g) * 0.1).to(DEV)
+    xq, xk, xv = (torch.randn(t, E, generator=g).to(torch.bfloat16).to(DEV) for t in (Tq, Tk, Tk))
+    gos = [torch.randn(t, E, generator=g).to(torch.bfloat16).to(DEV) for t in (Tq, Tk, Tk)]
+    res = []
+    for one in (True, False):
+        ws, bs = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        xs = [t.clone().requires_grad_(i != 2) for i, t in enumerate((xq, xk, xv))]       # (value without a gradient: memory)
+        if one:
+            outs = _InProjFn.apply(xs[0], xs[1], xs[2], ws, bs)
+        else:
+            outs = [_LinearFn.apply(xs[i], ws[i * E:(i + 1) * E], bs[i * E:(i + 1) * E]) for i in range(3)]
+        torch.autograd.backward(list(outs), gos)
+        res.append([o.detach() for o in outs] + [xs[0].grad, xs[1].grad, ws.grad, bs.grad])
+        assert xs[2].grad is None
+    for a, c in zip(*res):
+        assert torch.equal(a, c), float((a.float() - c.float()).abs().max())
+
+
 def test_attention_dropout_exact_for_its_mask():
     """mha with attention-weight dropout against fp32 softmax attention that applies the SAME keep mask (exported by
     mi_mha_dropout_mask): forward and dq / dk / dv; plus: unbiased over seeds"""

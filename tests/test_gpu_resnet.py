@@ -339,3 +339,54 @@ def test_bottleneck_epilogue_fusions_equal_the_elementwise_passes(cin, cout, bc,
             assert float((d > 0).float().mean()) < 0.05
         elif i > 1:                                                 # fp32 weight gradients: sums of those bf16 values
             assert float((a - b).norm() / b.norm().clamp(min=1e-12)) < 2e-3, i
+
+
+def test_weight_images_one_launch_equals_the_per_layer_packs():
+    """ops.WeightImages (the captured steps' ONE pack launch per step, mi_pack_conv_weights_batch with the folded per-Cout
+    factor in the job): record three layers through their ordinary pack calls - a 3x3 conv with a folded FrozenBatchNorm
+    scale, a plain 1x1 conv, a row block of an attention in-projection - freeze, change the parameters the way an optimizer
+    kernel does, run(): every image equals a fresh single-layer pack of the new values bit for bit; a weight that is not
+    parameter-backed and a layer that was not recorded are served by their own launch."""
+    from yolov7_d2_amd import ops
+    g = torch.Generator().manual_seed(11)
+    w3 = torch.nn.Parameter(torch.randn(72, 64, 3, 3, generator=g).cuda())          # Cout 72 -> padded to 96
+    w1 = torch.nn.Parameter(torch.randn(256, 64, 1, 1, generator=g).cuda())
+    wi = torch.nn.Parameter(torch.randn(3 * 256, 256, generator=g).cuda())
+    late = torch.nn.Parameter(torch.randn(64, 64, 1, 1, generator=g).cuda())
+    scale = (0.5 + torch.rand(72, generator=g)).cuda()
+    reg = ops.WeightImages([w3, w1, wi, late])
+
+    def packs():
+        a = ops.pack_images(w3.detach(), 72, 64, 3, 3, 64, 96, 96, 64, True, True, scale)
+        b = ops.pack_images(w1.detach(), 256, 64, 1, 1, 64, 256, 256, 64, True, False, None)
+        c = ops.pack_images(wi.detach()[256:512], 256, 256, 1, 1, 256, 256, 256, 256)
+        return a, b, c
+
+    fresh = lambda: [tuple(None if t is None else t.clone() for t in p) for p in packs()]
+    ops.WeightImages.active = reg
+    try:
+        rec = packs()                                                   # recording pass: own launches + registration
+        reg.freeze()
+        assert reg.launch[0] == 3 and reg.launch[2] == 9
+        with torch.no_grad():
+            for p in (w3, w1, wi):
+                p.mul_(1.7).add_(0.01)
+        reg.run()
+        hit = packs()                                                   # no launch: the registered tensors themselves
+        for r, h in zip(rec, hit):
+            assert all(x is y for x, y in zip(r, h))
+        other = ops.pack_images((w1.detach() * 2.0), 256, 64, 1, 1, 64, 256, 256, 64)       # a temporary: never registered
+        assert other[0] is not rec[1][0]
+        unrec = ops.pack_images(late.detach(), 64, 64, 1, 1, 64, 64, 64, 64)                 # after freeze: own launch
+        assert len(reg.images) == 3
+    finally:
+        ops.WeightImages.active = None
+    want = fresh()
+    torch.cuda.synchronize()
+    for h, w in zip(hit, want):
+        for x, y in zip(h, w):
+            assert (x is None) == (y is None)
+            if x is not None:
+                assert torch.equal(x.view(torch.int16), y.view(torch.int16))
+    ref = ops.pack_images(late.detach(), 64, 64, 1, 1, 64, 64, 64, 64)
+    assert torch.equal(unrec[0].view(torch.int16), ref[0].view(torch.int16))

@@ -92,6 +92,7 @@ class mi_wgrad_desc(C.Structure):
         ("tap_dy", C.c_int32 * MI_MAX_TAPS), ("tap_dx", C.c_int32 * MI_MAX_TAPS),
         ("accumulate", C.c_int32),
         ("TH", C.c_int32), ("TW", C.c_int32), ("splitk", C.c_int32), ("cfg_tp", C.c_int32), ("cfg_ns", C.c_int32),
+        ("row_scale", C.c_void_p),
     ]
 
 
@@ -140,7 +141,8 @@ class mi_split_job(C.Structure):
 class mi_pack_job(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wf", C.c_void_p), ("wd", C.c_void_p),
                 ("Cout", C.c_int32), ("Cin", C.c_int32), ("KK", C.c_int32), ("CinPad", C.c_int32),
-                ("CoutPad", C.c_int32), ("CoutPadK", C.c_int32), ("CinPadN", C.c_int32), ("blk0", C.c_int32)]
+                ("CoutPad", C.c_int32), ("CoutPadK", C.c_int32), ("CinPadN", C.c_int32), ("blk0", C.c_int32),
+                ("scale", C.c_void_p)]
 
 
 class mi_mosaic_paste_job(C.Structure):
@@ -309,6 +311,7 @@ _PROTOS = {
     "mi_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mi_ew_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i, _vp]),
     "mi_dropout_bf16": (C.c_int, [_vp, _vp, _i64, _f, C.c_uint64, _vp]),
+    "mi_dropout_add_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _f, C.c_uint64, _vp]),
     "mi_bilinear_resize_bf16": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "mi_bilinear_resize_bwd_bf16": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "mi_sparseinst_mask_stats": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp]),

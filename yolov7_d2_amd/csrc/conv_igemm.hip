@@ -562,7 +562,10 @@ __global__ __launch_bounds__(256) void pack_w_batch_kernel(const mi_pack_job* __
     const int co_l = idx / rowlen, q = idx - co_l * rowlen;
     const int row = co0 + co_l;
     float v = 0.f;
-    if (row < j.Cout && q < nci * KK) v = j.w[((size_t)row * j.Cin + ci0) * KK + q];
+    if (row < j.Cout && q < nci * KK) {
+      v = j.w[((size_t)row * j.Cin + ci0) * KK + q];
+      if (j.scale) v *= j.scale[row];                      // (fp32 product, then the bf16 rounding: pack_w_body's order)
+    }
     pk_s[co_l * rs + q] = (__bf16)v;
   }
   __syncthreads();

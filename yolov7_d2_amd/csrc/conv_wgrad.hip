@@ -446,6 +446,7 @@ struct Wg2R {
   float* g;
   long long V;
   int nsplit, NT, MI, NJ, WCO, WCI, nco, nci, Cout, Cin, accumulate;
+  const float* row_scale;   // NULL or [Cout]
 };
 
 // SL "split lanes": the nsplit partials of one output float4 are summed by SL threads (wave w = splits w, w + SL, ...,
@@ -497,7 +498,8 @@ __device__ __forceinline__ void wgrad2_reduce_body(const Wg2R& p, const long lon
     const int co = cobase + e;
     if (co < p.Cout) {
       float* dst = p.g + ((size_t)co * p.Cin + ci) * p.NT + tap;
-      *dst = p.accumulate ? *dst + sum[e] : sum[e];
+      const float val = p.row_scale ? sum[e] * p.row_scale[co] : sum[e];
+      *dst = p.accumulate ? *dst + val : val;
     }
   }
 }
@@ -540,12 +542,13 @@ __device__ __forceinline__ void wgrad2_reduce9_body(const Wg2R& p, const int blk
   if (co >= p.Cout || c4 >= nval) return;
   float* dst = p.g + ((size_t)co * p.Cin + ci0) * 9 + c4;
   const float* t = tile + row * 144 + c4;
+  const float rs = p.row_scale ? p.row_scale[co] : 1.f;     // (x * 1.f is exact: one code path)
   if (c4 + 4 <= nval && ((uintptr_t)dst & 15) == 0) {
-    f32x4 o = {t[0], t[1], t[2], t[3]};
+    f32x4 o = {t[0] * rs, t[1] * rs, t[2] * rs, t[3] * rs};
     if (p.accumulate) o += *(const f32x4*)dst;
     *(f32x4*)dst = o;
   } else {
-    for (int e = 0; e < 4 && c4 + e < nval; ++e) dst[e] = p.accumulate ? dst[e] + t[e] : t[e];
+    for (int e = 0; e < 4 && c4 + e < nval; ++e) dst[e] = p.accumulate ? dst[e] + t[e] * rs : t[e] * rs;
   }
 }
 __global__ __launch_bounds__(576) void wgrad2_reduce9_kernel(const Wg2R p) { wgrad2_reduce9_body(p, blockIdx.x); }
@@ -791,7 +794,7 @@ extern "C" int mi_conv2d_wgrad(const mi_wgrad_desc* d, mi_stream_t st) {
   Wg2R r;
   r.part = (const f32x4*)d->ws; r.g = d->gw; r.V = k.V; r.nsplit = k.nsplit;
   r.NT = c.NT; r.MI = c.MI; r.NJ = c.NJ; r.WCO = c.WCO; r.WCI = c.WCI; r.nco = k.nco; r.nci = k.nci;
-  r.Cout = d->Cout; r.Cin = d->Cin; r.accumulate = d->accumulate;
+  r.Cout = d->Cout; r.Cin = d->Cin; r.accumulate = d->accumulate; r.row_scale = d->row_scale;
   if (c.NT == 9 && wg_red9())
     hipLaunchKernelGGL(wgrad2_reduce9_kernel, dim3((unsigned)(k.V / (64 * 9))), dim3(576), 0, s, r);
   else {
@@ -935,7 +938,7 @@ extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, voi
     r.part = (const f32x4*)ks[i].part; r.g = descs[i].gw; r.V = ks[i].V; r.nsplit = ks[i].nsplit;
     r.NT = cs[i].NT; r.MI = cs[i].MI; r.NJ = cs[i].NJ; r.WCO = cs[i].WCO; r.WCI = cs[i].WCI;
     r.nco = ks[i].nco; r.nci = ks[i].nci; r.Cout = descs[i].Cout; r.Cin = descs[i].Cin;
-    r.accumulate = descs[i].accumulate;
+    r.accumulate = descs[i].accumulate; r.row_scale = descs[i].row_scale;
     if (cs[i].NT == 9 && wg_red9()) {
       rj9.push_back(r);
       rs9.push_back(rblocks9);

@@ -200,8 +200,11 @@ extern "C" int mi_sigmoid_f32(const float* x, const float* dy, float* y, float* 
 
 // ---- elementwise dropout (F.dropout in the transformer layers, detr_backbone.py:147-150,163-167,212-217,235-243)
 extern const unsigned long long* g_mi_seed_off;   // runtime.hip
-__global__ __launch_bounds__(256) void dropout_kernel(const __bf16* __restrict__ x, __bf16* o, int64_t n8, unsigned thr,
-                                                      float scale, unsigned long long seed, const unsigned long long* seed_off) {
+// res != NULL: o = res + dropout(x), the residual add of the same layer in the same pass (the dropped value is rounded to
+// bf16 before the fp32 add, as the two-launch form dropout -> mi_ew_bf16 add rounds it: identical bits)
+__global__ __launch_bounds__(256) void dropout_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ res, __bf16* o,
+                                                      int64_t n8, unsigned thr, float scale, unsigned long long seed,
+                                                      const unsigned long long* seed_off) {
   if (seed_off) seed += *seed_off;   // (a captured step: the word is advanced once per replay)
   for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
     const bf16x8 v = *(const bf16x8*)(x + i * 8);
@@ -209,19 +212,28 @@ __global__ __launch_bounds__(256) void dropout_kernel(const __bf16* __restrict__
 #pragma unroll
     for (int e = 0; e < 8; ++e)
       r[e] = (__bf16)(mi_rng32(seed, (unsigned long long)(i * 8 + e)) >= thr ? (float)v[e] * scale : 0.f);
+    if (res) {
+      const bf16x8 a = *(const bf16x8*)(res + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = (__bf16)((float)a[e] + (float)r[e]);
+    }
     *(bf16x8*)(o + i * 8) = r;
   }
 }
 extern "C" int mi_dropout_bf16(const void* x, void* out, int64_t n, float drop_p, uint64_t seed, mi_stream_t st) {
+  return mi_dropout_add_bf16(x, nullptr, out, n, drop_p, seed, st);
+}
+extern "C" int mi_dropout_add_bf16(const void* x, const void* res, void* out, int64_t n, float drop_p, uint64_t seed,
+                                   mi_stream_t st) {
   MI_REQUIRE(x && out && n > 0 && n % 8 == 0 && drop_p >= 0.f && drop_p < 1.f, "dropout: args (n %lld, p %f)", (long long)n,
              drop_p);
-  MI_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0, "dropout: alignment");
+  MI_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)res % 16) == 0, "dropout: alignment");
   unsigned thr = drop_p > 0.f ? (unsigned)((double)drop_p * 4294967296.0) : 0u;
   if (drop_p > 0.f && thr == 0u) thr = 1u;
   int64_t nb = (n / 8 + 255) / 256;
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)st, (const __bf16*)x, (__bf16*)out,
-                     n / 8, thr, 1.f / (1.f - drop_p), (unsigned long long)seed, g_mi_seed_off);
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)st, (const __bf16*)x, (const __bf16*)res,
+                     (__bf16*)out, n / 8, thr, 1.f / (1.f - drop_p), (unsigned long long)seed, g_mi_seed_off);
   MI_CHECK_LAUNCH("dropout");
   return MI_OK;
 }

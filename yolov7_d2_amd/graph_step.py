@@ -22,7 +22,7 @@ from . import _lib as L
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, loss_keys=None, warmup=2, max_graphs=24, bucket_bytes=64 << 20):
+    def __init__(self, model, optimizer, loss_keys=None, warmup=2, max_graphs=24, bucket_bytes=64 << 20, batch_packs=None):
         """optimizer: optim.MultiTensorAdamW (one launch per step; `clip_norm=` for the reference DETR configs' full-model
         gradient clipping, learning-rate changes honoured per replay) or a torch optimizer created with capturable=True (its
         lr must then be a device tensor for a scheduler to have any effect; no clipping; single process only).
@@ -37,8 +37,15 @@ class GraphedTrainStep:
         AdamW reading the flat buffer with 1 / world_size).  The collectives sit BETWEEN the two graphs: ranks may capture
         different padded shapes at different steps without ever disagreeing on the sequence of collectives, and the
         warm-up / capture passes issue none."""
+        import os
         import torch.distributed as dist
-        self.model, self.opt, self.warmup = model, optimizer, warmup
+        from .ops import WeightImages
+        # the bf16 images of every parameter-backed weight from ONE launch at the start of the step (ops.WeightImages;
+        # MI_BATCH_PACK=0: one pack launch per layer call, as the eager modules do)
+        if batch_packs is None:
+            batch_packs = os.environ.get("MI_BATCH_PACK", "1") == "1"
+        self.images = WeightImages(list(model.parameters())) if batch_packs else None
+        self.model, self.opt, self.warmup = model, optimizer, max(warmup, 2 if batch_packs else 1)
         self.loss_keys = loss_keys
         self.graphs = {}            # key -> [graph A, graph B or None, static, out]; insertion order = recency
         self.max_graphs = max_graphs
@@ -65,10 +72,19 @@ class GraphedTrainStep:
         return [k for k in losses if wd is None or k in wd]
 
     def _body_fb(self, static):
-        losses = self.model.forward_prepared(static)
-        total = sum(losses[k] for k in self._keys(losses))
-        self.opt.zero_grad(set_to_none=True)
-        total.backward()
+        from .ops import WeightImages
+        if self.images is not None:
+            self.images.run()
+        WeightImages.active = self.images
+        try:
+            losses = self.model.forward_prepared(static)
+            total = sum(losses[k] for k in self._keys(losses))
+            self.opt.zero_grad(set_to_none=True)
+            total.backward()
+        finally:
+            WeightImages.active = None
+        if self.images is not None:
+            self.images.freeze()            # (after the first pass: the recorded jobs become the step's one pack launch)
         if self.world > 1:
             self.opt.gather_grads()
         self.seed_word += 1

@@ -23,6 +23,7 @@ import torch
 from torch import nn
 
 from .. import _lib as L
+from ..ops import pack_images
 from .attention import mha_core
 
 
@@ -48,50 +49,43 @@ def _conv1x1(x, w_img, y, T, K, Cout, CoutPad, bias=None):
     L.check(L.lib().mi_conv2d(C.byref(d), L.stream_ptr()), "mi_conv2d (linear)")
 
 
-class _LinearFn(torch.autograd.Function):
-    """y = x W^T + b over token rows; x bf16 [T, Cin], W fp32 [Cout, Cin] (nn.Linear layout), b fp32 [Cout].
-    Cin must be a multiple of 32; any Cout: the output channels are zero-padded to a multiple of 32 inside (the packed
-    weight image and the bias carry zero rows), the caller sees [T, Cout]."""
+def _linear_fwd(x, w32, bias):
+    """y [T, rup(Cout,32)] = x W^T + b and the data-gradient image of W.  x bf16 [T, Cin] contiguous, w32 fp32 [Cout, Cin]
+    contiguous (a row block of a larger parameter is), bias fp32 [Cout] or None"""
+    T, Cin = x.shape
+    Cout = w32.shape[0]
+    assert Cin % 32 == 0, "linear: input channels must be a multiple of 32"
+    CoutP = _rup(Cout, 32)
+    dev = x.device
+    wf, wd = pack_images(w32, Cout, Cin, 1, 1, Cin, CoutP, CoutP, Cin)
+    y = torch.empty(T, CoutP, dtype=torch.bfloat16, device=dev)
+    b32 = None
+    if bias is not None:
+        if CoutP == Cout and bias.dtype == torch.float32 and bias.is_contiguous():
+            b32 = bias                   # (no padded copy: two launches per Linear call otherwise)
+        else:
+            b32 = torch.zeros(CoutP, dtype=torch.float32, device=dev)
+            b32[:Cout] = bias.float()
+    _conv1x1(x, wf, y, T, Cin, CoutP, CoutP, b32)
+    return y, wd
 
-    @staticmethod
-    def forward(ctx, x, weight, bias):
-        T, Cin = x.shape
-        Cout = weight.shape[0]
-        assert Cin % 32 == 0, "linear: input channels must be a multiple of 32"
-        CoutP = _rup(Cout, 32)
-        dev = x.device
-        wf = torch.empty(Cin // 8 * CoutP * 8, dtype=torch.bfloat16, device=dev)
-        wd = torch.empty(CoutP // 8 * Cin * 8, dtype=torch.bfloat16, device=dev)
-        w32 = weight.detach().float().contiguous()
-        L.check(L.lib().mi_pack_conv_weight(w32.data_ptr(), Cout, Cin, 1, 1, wf.data_ptr(), Cin, CoutP, wd.data_ptr(), CoutP,
-                                            Cin, L.stream_ptr()), "mi_pack_conv_weight")
-        y = torch.empty(T, CoutP, dtype=torch.bfloat16, device=dev)
-        b32 = None
-        if bias is not None:
-            if CoutP == Cout and bias.dtype == torch.float32 and bias.is_contiguous():
-                b32 = bias.detach()          # (no padded copy: two launches per Linear call otherwise)
-            else:
-                b32 = torch.zeros(CoutP, dtype=torch.float32, device=dev)
-                b32[:Cout] = bias.detach().float()
-        _conv1x1(x, wf, y, T, Cin, CoutP, CoutP, b32)
-        ctx.save_for_backward(x, wd)
-        ctx.dims = (T, Cin, Cout, CoutP, bias is not None)
-        return y if CoutP == Cout else y[:, :Cout]
 
-    @staticmethod
-    def backward(ctx, dy):
-        x, wd = ctx.saved_tensors
-        T, Cin, Cout, CoutP, has_bias = ctx.dims
-        dev = x.device
-        if CoutP != Cout:   # zero-padded out-gradient: K of the data-gradient GEMM is the padded channel count
-            dyp = torch.zeros(T, CoutP, dtype=torch.bfloat16, device=dev)
-            dyp[:, :Cout] = dy
-            dy = dyp
-        dy = dy.contiguous()
+def _linear_bwd(x, wd, dy, Cout, need_dx=True, gw=None, gb=None):
+    """(dx or None); the weight gradient is WRITTEN to gw (fp32 [Cout, Cin] contiguous: a row block of a larger gradient
+    is) and the bias gradient to gb (fp32 [Cout]) when they are given"""
+    T, Cin = x.shape
+    CoutP = _rup(Cout, 32)
+    dev = x.device
+    if CoutP != Cout:   # zero-padded out-gradient: K of the data-gradient GEMM is the padded channel count
+        dyp = torch.zeros(T, CoutP, dtype=torch.bfloat16, device=dev)
+        dyp[:, :Cout] = dy
+        dy = dyp
+    dy = dy.contiguous()
+    dx = None
+    if need_dx:
         dx = torch.empty(T, Cin, dtype=torch.bfloat16, device=dev)
         _conv1x1(dy, wd, dx, T, CoutP, Cin, Cin)
-        # weight gradient
-        gw = torch.empty(Cout, Cin, dtype=torch.float32, device=dev)
+    if gw is not None:
         H, W = _factor(T)
         d = L.mi_wgrad_desc()
         d.x, d.dy, d.gw = x.data_ptr(), dy.data_ptr(), gw.data_ptr()
@@ -102,14 +96,70 @@ class _LinearFn(torch.autograd.Function):
         ws = torch.empty(max(int(need), 16), dtype=torch.uint8, device=dev)
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
         L.check(L.lib().mi_conv2d_wgrad(C.byref(d), L.stream_ptr()), "mi_conv2d_wgrad (linear)")
-        gb = None
-        if has_bias:
-            gbp = torch.empty(CoutP, dtype=torch.float32, device=dev)
-            cws = torch.empty(128 * CoutP, dtype=torch.float32, device=dev)
-            L.check(L.lib().mi_colsum_bf16_wide(dy.data_ptr(), CoutP, T, CoutP, gbp.data_ptr(), 0, cws.data_ptr(), L.stream_ptr()),
-                    "mi_colsum_bf16_wide")
-            gb = gbp[:Cout]
+    if gb is not None:
+        gbp = gb if CoutP == Cout else torch.empty(CoutP, dtype=torch.float32, device=dev)
+        cws = torch.empty(128 * CoutP, dtype=torch.float32, device=dev)
+        L.check(L.lib().mi_colsum_bf16_wide(dy.data_ptr(), CoutP, T, CoutP, gbp.data_ptr(), 0, cws.data_ptr(), L.stream_ptr()),
+                "mi_colsum_bf16_wide")
+        if gbp is not gb:
+            gb.copy_(gbp[:Cout])
+    return dx
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b over token rows; x bf16 [T, Cin], W fp32 [Cout, Cin] (nn.Linear layout), b fp32 [Cout].
+    Cin must be a multiple of 32; any Cout: the output channels are zero-padded to a multiple of 32 inside (the packed
+    weight image and the bias carry zero rows), the caller sees [T, Cout]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        Cout = weight.shape[0]
+        y, wd = _linear_fwd(x, weight.detach().float().contiguous(), None if bias is None else bias.detach())
+        ctx.save_for_backward(x, wd)
+        ctx.dims = (Cout, bias is not None)
+        return y if y.shape[1] == Cout else y[:, :Cout]
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wd = ctx.saved_tensors
+        Cout, has_bias = ctx.dims
+        gw = torch.empty(Cout, x.shape[1], dtype=torch.float32, device=x.device)
+        gb = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_bias else None
+        dx = _linear_bwd(x, wd, dy, Cout, True, gw, gb)
         return dx, gw, gb
+
+
+class _InProjFn(torch.autograd.Function):
+    """nn.MultiheadAttention's in-projection (detr_backbone.py:140,155-157,222-230 reach F.multi_head_attention_forward's
+    _in_projection_packed): q, k, v = query W[:E]^T + b[:E], key W[E:2E]^T + b[E:2E], value W[2E:]^T + b[2E:], as ONE
+    autograd node over the WHOLE in_proj_weight [3E, E] / in_proj_bias [3E].  Slicing the parameters through autograd
+    instead costs, per attention module and step, 6 zero fills + 6 slice copies + 4 full-size additions (SliceBackward of
+    three weight and three bias blocks, then their accumulation): 288 of the ~1900 launches of a DETR-R50 step.  Here the
+    three weight-gradient launches write their row blocks of one [3E, E] tensor directly."""
+
+    @staticmethod
+    def forward(ctx, xq, xk, xv, w, b):
+        E = w.shape[1]
+        w32, b32 = w.detach().float().contiguous(), b.detach().float().contiguous()
+        outs, wds = [], []
+        for i, x in enumerate((xq, xk, xv)):
+            y, wd = _linear_fwd(x, w32[i * E:(i + 1) * E], b32[i * E:(i + 1) * E])
+            outs.append(y)
+            wds.append(wd)
+        ctx.save_for_backward(xq, xk, xv, *wds)
+        ctx.E = E
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        xq, xk, xv, wq, wk, wv = ctx.saved_tensors
+        E = ctx.E
+        gw = torch.empty(3 * E, E, dtype=torch.float32, device=xq.device)
+        gb = torch.empty(3 * E, dtype=torch.float32, device=xq.device)
+        dxs = []
+        for i, (x, wd, dy) in enumerate(((xq, wq, dq), (xk, wk, dk), (xv, wv, dv))):
+            dxs.append(_linear_bwd(x, wd, dy, E, ctx.needs_input_grad[i], gw[i * E:(i + 1) * E], gb[i * E:(i + 1) * E]))
+        return dxs[0], dxs[1], dxs[2], gw, gb
 
 
 class _LayerNormFn(torch.autograd.Function):
@@ -176,6 +226,34 @@ def _dropout(x, p, training):
     return _DropoutFn.apply(x, p, _next_seed())
 
 
+class _AddDroppedFn(torch.autograd.Function):
+    """res + dropout(x) in one pass (mi_dropout_add_bf16); backward: (g, dropout(g)) - the mask is a pure function of the seed"""
+
+    @staticmethod
+    def forward(ctx, res, x, p, seed):
+        res, x = res.contiguous(), x.contiguous()
+        out = torch.empty_like(x)
+        L.check(L.lib().mi_dropout_add_bf16(x.data_ptr(), res.data_ptr(), out.data_ptr(), x.numel(), float(p), int(seed),
+                                            L.stream_ptr()), "mi_dropout_add_bf16")
+        ctx.ps = (float(p), int(seed))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        gx = torch.empty_like(g)
+        L.check(L.lib().mi_dropout_bf16(g.data_ptr(), gx.data_ptr(), g.numel(), ctx.ps[0], ctx.ps[1], L.stream_ptr()),
+                "mi_dropout_bf16 (backward)")
+        return g, gx, None, None
+
+
+def _add_dropped(res, x, p, training):
+    """res + F.dropout(x, p, training)"""
+    if not training or p <= 0:
+        return _AddFn.apply(res, x)
+    return _AddDroppedFn.apply(res, x, p, _next_seed())
+
+
 class _AddFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
@@ -224,10 +302,9 @@ class MultiheadAttention(nn.Module):
         E = self.embed_dim
         Lq, B, _ = query.shape
         Lk = key.shape[0]
-        w, b = self.in_proj_weight, self.in_proj_bias
-        q = _LinearFn.apply(_tok(query).view(Lq * B, E), w[:E], b[:E]).view(Lq, B, E)
-        k = _LinearFn.apply(_tok(key).view(Lk * B, E), w[E:2 * E], b[E:2 * E]).view(Lk, B, E)
-        v = _LinearFn.apply(_tok(value).view(Lk * B, E), w[2 * E:], b[2 * E:]).view(Lk, B, E)
+        q, k, v = _InProjFn.apply(_tok(query).view(Lq * B, E), _tok(key).view(Lk * B, E), _tok(value).view(Lk * B, E),
+                                  self.in_proj_weight, self.in_proj_bias)
+        q, k, v = q.view(Lq, B, E), k.view(Lk, B, E), v.view(Lk, B, E)
         drop = self.dropout if self.training else 0.0
         o = mha_core(q, k, v, key_padding_mask, self.num_heads, drop, _next_seed() if drop > 0 else 0)
         out = _LinearFn.apply(o.reshape(Lq * B, E), self.out_proj.weight, self.out_proj.bias).view(Lq, B, E)
@@ -263,20 +340,19 @@ class TransformerEncoderLayer(nn.Module):
 
     def forward(self, src, src_mask=None, src_key_padding_mask=None, pos=None):
         src = _tok(src)
-        D = lambda t: _dropout(t, self.dropout_p, self.training)
         if self.normalize_before:   # forward_pre (detr_backbone.py:170-182)
             src2 = self._ln(self.norm1, src)
             q = k = self.with_pos_embed(src2, pos)
             src2 = self.self_attn(q, k, value=src2, attn_mask=src_mask, key_padding_mask=src_key_padding_mask)[0]
-            src = _AddFn.apply(src, D(src2))
+            src = _add_dropped(src, src2, self.dropout_p, self.training)
             src2 = self._ffn(self._ln(self.norm2, src))
-            return _AddFn.apply(src, D(src2))
+            return _add_dropped(src, src2, self.dropout_p, self.training)
         # forward_post (detr_backbone.py:156-168)
         q = k = self.with_pos_embed(src, pos)
         src2 = self.self_attn(q, k, value=src, attn_mask=src_mask, key_padding_mask=src_key_padding_mask)[0]
-        src = self._ln(self.norm1, _AddFn.apply(src, D(src2)))
+        src = self._ln(self.norm1, _add_dropped(src, src2, self.dropout_p, self.training))
         src2 = self._ffn(src)
-        return self._ln(self.norm2, _AddFn.apply(src, D(src2)))
+        return self._ln(self.norm2, _add_dropped(src, src2, self.dropout_p, self.training))
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -303,28 +379,27 @@ class TransformerDecoderLayer(nn.Module):
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                 memory_key_padding_mask=None, pos=None, query_pos=None):
         tgt, memory = _tok(tgt), _tok(memory)
-        D = lambda t: _dropout(t, self.dropout_p, self.training)
         mem_k = self.with_pos_embed(memory, pos)
         if self.normalize_before:   # forward_pre (detr_backbone.py:245-264)
             tgt2 = self._ln(self.norm1, tgt)
             q = k = self.with_pos_embed(tgt2, query_pos)
             tgt2 = self.self_attn(q, k, value=tgt2, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
-            tgt = _AddFn.apply(tgt, D(tgt2))
+            tgt = _add_dropped(tgt, tgt2, self.dropout_p, self.training)
             tgt2 = self._ln(self.norm2, tgt)
             tgt2 = self.multihead_attn(self.with_pos_embed(tgt2, query_pos), mem_k, value=memory, attn_mask=memory_mask,
                                        key_padding_mask=memory_key_padding_mask)[0]
-            tgt = _AddFn.apply(tgt, D(tgt2))
+            tgt = _add_dropped(tgt, tgt2, self.dropout_p, self.training)
             tgt2 = self._ffn(self._ln(self.norm3, tgt))
-            return _AddFn.apply(tgt, D(tgt2))
+            return _add_dropped(tgt, tgt2, self.dropout_p, self.training)
         # forward_post (detr_backbone.py:222-243)
         q = k = self.with_pos_embed(tgt, query_pos)
         tgt2 = self.self_attn(q, k, value=tgt, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
-        tgt = self._ln(self.norm1, _AddFn.apply(tgt, D(tgt2)))
+        tgt = self._ln(self.norm1, _add_dropped(tgt, tgt2, self.dropout_p, self.training))
         tgt2 = self.multihead_attn(self.with_pos_embed(tgt, query_pos), mem_k, value=memory, attn_mask=memory_mask,
                                    key_padding_mask=memory_key_padding_mask)[0]
-        tgt = self._ln(self.norm2, _AddFn.apply(tgt, D(tgt2)))
+        tgt = self._ln(self.norm2, _add_dropped(tgt, tgt2, self.dropout_p, self.training))
         tgt2 = self._ffn(tgt)
-        return self._ln(self.norm3, _AddFn.apply(tgt, D(tgt2)))
+        return self._ln(self.norm3, _add_dropped(tgt, tgt2, self.dropout_p, self.training))
 
 
 def _norm_tokens(norm, x):

@@ -34,6 +34,102 @@ def _rup(a, b):
     return (a + b - 1) // b * b
 
 
+# ------------------------------------------------------------------------------------------------ weight images
+class WeightImages:
+    """The packed bf16 images (forward + data gradient) of every PARAMETER-backed weight of a training step, written by ONE
+    launch (mi_pack_conv_weights_batch, the YOLOX plan's PACK_W_BATCH) at the start of the step instead of one pack launch
+    per layer call: 143 of the ~1900 launches of a captured DETR-R50 step, 131 of SparseInst-R50's ~1330
+    (graph_step.GraphedTrainStep owns one; `active` is set only inside its step body, right after run()).
+
+    A weight qualifies when its fp32 storage lies inside one of the model's parameters (a row block of in_proj_weight
+    does; `weight * scale`, a space-to-depth rearrangement or an activation used as a weight do not: those are packed by
+    their own launch as before).  The first step RECORDS: every qualifying pack call allocates persistent images, packs
+    them with its own launch and registers the job; freeze() uploads the job table; from then on run() re-packs all
+    images from the current parameter values and the pack calls return them without a launch.  A call that was not
+    recorded (a layer that did not run in the first step) is served by its own launch."""
+    active = None
+
+    def __init__(self, params):
+        import bisect
+        self._bisect = bisect.bisect_right
+        rs = sorted((p.data_ptr(), p.data_ptr() + p.numel() * 4) for p in params if p.dtype == torch.float32 and p.is_contiguous())
+        self._lo, self._hi = [r[0] for r in rs], [r[1] for r in rs]
+        self.images = {}        # key -> (wf, wd)
+        self._jobs, self._hold = [], []
+        self.table = None       # device job table once frozen
+        self.launch = None
+
+    def _stable(self, ptr, nbytes):
+        i = self._bisect(self._lo, ptr) - 1
+        return i >= 0 and ptr + nbytes <= self._hi[i]
+
+    def get(self, w32, Cout, Cin, KK, CinP, CoutP, CoutPK, CinPN, fwd, dgrad, scale, pack_now):
+        """(wf, wd) or None when the weight does not qualify / was not recorded; pack_now(wf, wd): the single-layer launch"""
+        if not self._stable(w32.data_ptr(), Cout * Cin * KK * 4):
+            return None
+        key = (w32.data_ptr(), Cout, Cin, KK, CinP, CoutP, CoutPK, CinPN, bool(fwd), bool(dgrad), 0 if scale is None else scale.data_ptr())
+        hit = self.images.get(key)
+        if hit is not None:
+            if self.table is None:
+                pack_now(*hit)              # (still recording: a second use of the layer in the first step)
+            return hit
+        if self.table is not None:
+            return None
+        dev = w32.device
+        wf = torch.empty(KK * CinP * CoutP, dtype=torch.bfloat16, device=dev) if fwd else None
+        wd = torch.empty(KK * CoutPK * CinPN, dtype=torch.bfloat16, device=dev) if dgrad else None
+        pack_now(wf, wd)
+        j = L.mi_pack_job()
+        j.w, j.wf, j.wd = w32.data_ptr(), L.ptr(wf), L.ptr(wd)
+        j.Cout, j.Cin, j.KK, j.CinPad, j.CoutPad, j.CoutPadK, j.CinPadN = Cout, Cin, KK, CinP, CoutP, CoutPK, CinPN
+        j.scale = L.ptr(scale)
+        self._jobs.append(j)
+        self._hold.append((w32, scale))     # (their addresses are in the table: never freed, never reused)
+        self.images[key] = (wf, wd)
+        return wf, wd
+
+    def freeze(self):
+        if self.table is not None or not self._jobs:
+            return
+        n = len(self._jobs)
+        jobs = (L.mi_pack_job * n)(*self._jobs)
+        nblk = L.check(L.lib().mi_pack_jobs_layout(jobs, n), "mi_pack_jobs_layout")
+        self.table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(self._hold[0][0].device)
+        self.launch = (n, nblk, max(j.KK for j in self._jobs))
+
+    def run(self):
+        """all recorded images from the current parameter values, one launch (a no-op while recording)"""
+        if self.table is not None:
+            n, nblk, kk = self.launch
+            L.check(L.lib().mi_pack_conv_weights_batch(self.table.data_ptr(), n, nblk, kk, L.stream_ptr()), "mi_pack_conv_weights_batch")
+
+
+def pack_images(w32, Cout, Cin, kh, kw, CinP, CoutP, CoutPK, CinPN, fwd=True, dgrad=True, scale=None):
+    """(forward image wf[tap][ci/8][co][ci%8] or None, data-gradient image wd[tap][co/8][ci][co%8] or None) of the fp32
+    OIHW weight w32 (contiguous); scale: fp32 [Cout] folded in (W * scale[co], fp32 product then the bf16 rounding)"""
+    KK = kh * kw
+
+    def pack_now(wf, wd):
+        if scale is None:
+            L.check(L.lib().mi_pack_conv_weight(w32.data_ptr(), Cout, Cin, kh, kw, L.ptr(wf), CinP, CoutP, L.ptr(wd), CoutPK, CinPN,
+                                                L.stream_ptr()), "mi_pack_conv_weight")
+        else:
+            assert scale.dtype == torch.float32 and scale.is_contiguous() and scale.numel() == Cout
+            L.check(L.lib().mi_pack_conv_weight_scaled(w32.data_ptr(), scale.data_ptr(), Cout, Cin, kh, kw, L.ptr(wf), CinP, CoutP,
+                                                       L.ptr(wd), CoutPK, CinPN, L.stream_ptr()), "mi_pack_conv_weight_scaled")
+
+    reg = WeightImages.active
+    if reg is not None:
+        hit = reg.get(w32, Cout, Cin, KK, CinP, CoutP, CoutPK, CinPN, fwd, dgrad, scale, pack_now)
+        if hit is not None:
+            return hit
+    dev = w32.device
+    wf = torch.empty(KK * CinP * CoutP, dtype=torch.bfloat16, device=dev) if fwd else None
+    wd = torch.empty(KK * CoutPK * CinPN, dtype=torch.bfloat16, device=dev) if dgrad else None
+    pack_now(wf, wd)
+    return wf, wd
+
+
 # ------------------------------------------------------------------------------------------------ descriptors
 def _nhwc(x):
     """NCHW tensor -> (bf16 [N,H,W,C] contiguous view/copy)"""
@@ -86,28 +182,14 @@ class _ConvGeom:
     def pack(self, weight, fwd=True, dgrad=True, scale=None):
         """(forward image, data-gradient image) of an OIHW weight; an image that is not asked for is None.
         scale: fp32 [Cout] folded into the images (W * scale[co], fp32 product then the bf16 rounding)"""
-        dev = weight.device
-        wf = torch.empty(self.KK * self.CinP * self.CoutP, dtype=torch.bfloat16, device=dev) if fwd else None
-        wd = torch.empty(self.KK * self.CoutP * self.CinP, dtype=torch.bfloat16, device=dev) if dgrad else None
-        w32 = weight.detach().float().contiguous()
-        if scale is None:
-            L.check(L.lib().mi_pack_conv_weight(w32.data_ptr(), self.Cout, self.Cin, self.k, self.k, L.ptr(wf), self.CinP,
-                                                self.CoutP, L.ptr(wd), self.CoutP, self.CinP, L.stream_ptr()),
-                    "mi_pack_conv_weight")
-        else:
-            assert scale.dtype == torch.float32 and scale.is_contiguous() and scale.numel() == self.Cout
-            L.check(L.lib().mi_pack_conv_weight_scaled(w32.data_ptr(), scale.data_ptr(), self.Cout, self.Cin, self.k, self.k,
-                                                       L.ptr(wf), self.CinP, self.CoutP, L.ptr(wd), self.CoutP, self.CinP,
-                                                       L.stream_ptr()), "mi_pack_conv_weight_scaled")
-        return wf, wd
+        return pack_images(weight.detach().float().contiguous(), self.Cout, self.Cin, self.k, self.k, self.CinP, self.CoutP,
+                           self.CoutP, self.CinP, fwd, dgrad, scale)
 
     def wgrad_scaled(self, xh, dyh, scale):
-        """weight gradient of a layer whose image carried a folded per-Cout factor: scale[co] * dW'"""
-        gw = self.wgrad(xh, dyh)
-        out = torch.empty_like(gw)
-        L.check(L.lib().mi_scale_rows_f32(gw.data_ptr(), scale.data_ptr(), out.data_ptr(), self.Cout, gw.numel() // self.Cout,
-                                          L.stream_ptr()), "mi_scale_rows_f32")
-        return out
+        """weight gradient of a layer whose image carried a folded per-Cout factor: scale[co] * dW' (the factor is applied
+        to the fp32 sums in the split-K reduction: mi_wgrad_desc.row_scale)"""
+        assert scale.dtype == torch.float32 and scale.is_contiguous() and scale.numel() == self.Cout
+        return self.wgrad(xh, dyh, row_scale=scale)
 
     def pad_in(self, x):
         """NCHW -> bf16 [N,H,W,CinP] (zero pad channels)"""
@@ -158,10 +240,11 @@ class _ConvGeom:
                                      self.CinP, self.H, self.W, self.Cin, self.CinP, taps, out_stride=2, oy=py, ox=px,
                                      gridH=gh, gridW=gw, flags=fl, aux=aux), "mi_conv2d (dgrad s2)")
 
-    def wgrad(self, xh, dyh):
+    def wgrad(self, xh, dyh, row_scale=None):
         gw = torch.empty(self.Cout, self.Cin, self.k, self.k, dtype=torch.float32, device=xh.device)
         d = L.mi_wgrad_desc()
         d.x, d.dy, d.gw = xh.data_ptr(), dyh.data_ptr(), gw.data_ptr()
+        d.row_scale = L.ptr(row_scale)
         d.ldx, d.ldy, d.N, d.H, d.W, d.outH, d.outW, d.stride = self.CinP, self.CoutP, self.N, self.H, self.W, self.Ho, self.Wo, self.s
         d.Cin, d.Cout, d.CinPad, d.CoutPad, d.ntaps = self.Cin, self.Cout, self.CinP, self.CoutP, self.KK
         for t in range(self.KK):
