@@ -126,6 +126,27 @@ def test_in_projection_as_one_node_equals_three_sliced_linears():
         assert torch.equal(a, c), float((a.float() - c.float()).abs().max())
 
 
+def test_linear_with_relu_epilogue_equals_linear_then_relu():
+    """_LinearFn(relu=True) (MI_CONV_RELU in the 1x1 convolution's epilogue, the mask applied to dy in backward) against
+    _LinearFn followed by _ReluFn: identical bits, forward and all three gradients (Cout 2048 and a padded Cout 72)"""
+    from yolov7_d2_amd.modeling.transformer import _LinearFn, _ReluFn
+    g = torch.Generator().manual_seed(8)
+    for T, cin, cout in ((1200, 256, 2048), (400, 256, 72)):
+        x = torch.randn(T, cin, generator=g).to(torch.bfloat16).to(DEV)
+        w = (torch.randn(cout, cin, generator=g) * 0.05).to(DEV)
+        b = (torch.randn(cout, generator=g) * 0.1).to(DEV)
+        go = torch.randn(T, cout, generator=g).to(torch.bfloat16).to(DEV)
+        res = []
+        for fused in (True, False):
+            xs, ws, bs = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            y = _LinearFn.apply(xs, ws, bs, True) if fused else _ReluFn.apply(_LinearFn.apply(xs, ws, bs).contiguous())
+            y.backward(go)
+            res.append((y.detach(), xs.grad, ws.grad, bs.grad))
+        for a, c in zip(*res):
+            assert torch.equal(a, c), (T, cout, float((a.float() - c.float()).abs().max()))
+        assert float((res[0][0] == 0).float().mean()) > 0.2
+
+
 def test_attention_dropout_exact_for_its_mask():
     """mha with attention-weight dropout against fp32 softmax attention that applies the SAME keep mask (exported by
     mi_mha_dropout_mask): forward and dq / dk / dv; plus: unbiased over seeds"""

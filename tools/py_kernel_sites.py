@@ -94,7 +94,7 @@ static = model.prepare_batch(inputs)
 def step():
     losses = model.forward_prepared(static)
     wd = getattr(getattr(model, "criterion", None), "weight_dict", None) if which == "detr" else None
-    total = sum(v for k, v in losses.items() if wd is None or k in wd)
+    total = losses["total"] if "total" in losses else sum(v for k, v in losses.items() if wd is None or k in wd)
     opt.zero_grad(set_to_none=True)
     total.backward()
     opt.step()

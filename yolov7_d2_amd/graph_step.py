@@ -10,7 +10,8 @@ Contract with the model (yolov7_d2_amd.modeling.detr_meta.Detr implements it):
   prepare_batch(batched_inputs, static=None) -> static
         everything that touches the host - image padding, ground truth -> device - into tensors that are REFILLED IN
         PLACE when `static` is passed back (the graph reads the same addresses for every batch)
-  forward_prepared(static) -> {name: loss}   device work only: no host value of the batch may enter a launch argument
+  forward_prepared(static) -> {name: loss}   device work only: no host value of the batch may enter a launch argument;
+        an entry "total" (with autograd) is taken as the objective instead of the sum over loss_keys
 
 Dropout: seeds are launch arguments, i.e. constants of the captured graph.  The library adds a device word to every
 dropout seed at run time (mi_dropout_seed_offset); the captured step advances it after the backward, so every replay draws
@@ -78,7 +79,7 @@ class GraphedTrainStep:
         WeightImages.active = self.images
         try:
             losses = self.model.forward_prepared(static)
-            total = sum(losses[k] for k in self._keys(losses))
+            total = losses["total"] if "total" in losses else sum(losses[k] for k in self._keys(losses))
             self.opt.zero_grad(set_to_none=True)
             total.backward()
         finally:

@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from .. import _lib as L
-from .transformer import _LinearFn, _ReluFn, _tok
+from .transformer import _LinearFn, _tok
 
 
 class _SigmoidF32(torch.autograd.Function):
@@ -35,10 +35,10 @@ class _SigmoidF32(torch.autograd.Function):
         return dx
 
 
-def _linear(x, lin):
-    """nn.Linear applied to the last dimension of a bf16 device tensor through the conv kernels"""
+def _linear(x, lin, relu=False):
+    """nn.Linear applied to the last dimension of a bf16 device tensor through the conv kernels (relu: in the epilogue)"""
     shp = x.shape
-    y = _LinearFn.apply(_tok(x).reshape(-1, shp[-1]), lin.weight, lin.bias)
+    y = _LinearFn.apply(_tok(x).reshape(-1, shp[-1]), lin.weight, lin.bias, relu)
     return y.reshape(*shp[:-1], lin.out_features)
 
 
@@ -53,9 +53,7 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
-            x = _linear(x, layer)
-            if i < self.num_layers - 1:
-                x = _ReluFn.apply(x.contiguous())
+            x = _linear(x, layer, relu=i < self.num_layers - 1)
         return x
 
 

@@ -109,6 +109,41 @@ class SetCriterion(nn.Module):
                 out["loss_bbox"], out["loss_giou"] = v[3] * inv_nb[0], v[4] * inv_nb[0]
         return out
 
+    def weighted_packed(self, outputs, targets):
+        """The PackedTargets path for a captured step, with the scalar bookkeeping of all decoder levels as a few vector
+        ops: -> the reference's loss dict ALREADY multiplied by weight_dict (what Detr.forward returns, detr.py:262-267) plus
+        "total" = the sum of the weighted entries.  Level by level (`v[3] * inv`, `* weight_dict[k]`, 17 additions and their
+        backward nodes) the same arithmetic is ~100 one-element launches per DETR step."""
+        inv = targets.inv_num_boxes
+        levels = [{k: v for k, v in outputs.items() if k != "aux_outputs"}] + list(outputs.get("aux_outputs", []))
+        vs = []
+        for lv in levels:
+            if not lv["pred_logits"].is_cuda:
+                raise L.MI355Error("SetCriterion: the MI355X path needs device tensors (no CPU fallback)")
+            if lv["pred_logits"].shape[-1] != self.num_classes + 1:
+                raise ValueError("pred_logits must have num_classes + 1 channels")
+            vs.append(_SetLossFn.apply(lv["pred_logits"], lv["pred_boxes"], self._match(lv, targets), self.eos_coef, 1.0))
+        V = torch.stack(vs)                                               # [levels, 5]: ce, class_error, cardinality, bbox, giou
+        names = ("loss_ce", "class_error", "cardinality_error", "loss_bbox", "loss_giou")
+        need = ("labels", "labels", "cardinality", "boxes", "boxes")
+        key = (len(levels), V.device)
+        c = self.__dict__.get("_packed_consts")
+        if c is None or c[0] != key:
+            sfx = [""] + [f"_{i}" for i in range(len(levels) - 1)]
+            w = torch.tensor([[float(self.weight_dict.get(n + s_, 1.0)) for n in names] for s_ in sfx])
+            m = torch.tensor([[float(n + s_ in self.weight_dict and q in self.losses) for n, q in zip(names, need)] for s_ in sfx])
+            a, b = torch.tensor([1.0, 1.0, 1.0, 0.0, 0.0]), torch.tensor([0.0, 0.0, 0.0, 1.0, 1.0])
+            c = self.__dict__["_packed_consts"] = (key, w.to(V.device), m.to(V.device), a.to(V.device), b.to(V.device), sfx)
+        _, w, m, a, b, sfx = c
+        R = V * (w * torch.addcmul(a, b, inv[0]))                         # bbox / giou sums ran with num_boxes = 1 (linear in 1 / n)
+        out = {}
+        for l_, s_ in enumerate(sfx):
+            for j, (n, q) in enumerate(zip(names, need)):
+                if q in self.losses and (n != "class_error" or l_ == 0):
+                    out[n + s_] = R[l_, j] if n.startswith("loss_") else R[l_, j].detach()
+        out["total"] = (R * m).sum()
+        return out
+
     def forward(self, outputs, targets):
         if isinstance(targets, PackedTargets):
             # device-resident targets (Detr.prepare_batch): 1 / num_boxes is a device scalar (already averaged over the

@@ -288,6 +288,8 @@ class Detr(nn.Module):
     def forward_prepared(self, static):
         """the device half of the training forward: no host value of the batch enters a launch (capturable)"""
         output = self.detr(static["images"])
+        if hasattr(self.criterion, "weighted_packed"):
+            return self.criterion.weighted_packed(output, static["targets"])      # (+ "total": see GraphedTrainStep)
         loss_dict = self.criterion(output, static["targets"])
         weight_dict = self.criterion.weight_dict
         return {k: (v * weight_dict[k] if k in weight_dict else v) for k, v in loss_dict.items()}

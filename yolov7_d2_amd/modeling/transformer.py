@@ -37,11 +37,12 @@ def _factor(T):
             return T // w, w
 
 
-def _conv1x1(x, w_img, y, T, K, Cout, CoutPad, bias=None):
+def _conv1x1(x, w_img, y, T, K, Cout, CoutPad, bias=None, relu=False):
     H, W = _factor(T)
     d = L.mi_conv_desc()
     d.x, d.w, d.y = x.data_ptr(), w_img.data_ptr(), y.data_ptr()
     d.bias = L.ptr(bias)
+    d.flags = L.MI_CONV_RELU if relu else 0
     d.ldx, d.ldy = x.shape[-1], y.shape[-1]
     d.N, d.H, d.W, d.outH, d.outW, d.gridH, d.gridW = 1, H, W, H, W, H, W
     d.in_stride = d.out_stride = 1
@@ -49,9 +50,9 @@ def _conv1x1(x, w_img, y, T, K, Cout, CoutPad, bias=None):
     L.check(L.lib().mi_conv2d(C.byref(d), L.stream_ptr()), "mi_conv2d (linear)")
 
 
-def _linear_fwd(x, w32, bias):
-    """y [T, rup(Cout,32)] = x W^T + b and the data-gradient image of W.  x bf16 [T, Cin] contiguous, w32 fp32 [Cout, Cin]
-    contiguous (a row block of a larger parameter is), bias fp32 [Cout] or None"""
+def _linear_fwd(x, w32, bias, relu=False):
+    """y [T, rup(Cout,32)] = x W^T + b (relu: max(., 0) in the epilogue) and the data-gradient image of W.  x bf16 [T, Cin]
+    contiguous, w32 fp32 [Cout, Cin] contiguous (a row block of a larger parameter is), bias fp32 [Cout] or None"""
     T, Cin = x.shape
     Cout = w32.shape[0]
     assert Cin % 32 == 0, "linear: input channels must be a multiple of 32"
@@ -66,7 +67,7 @@ def _linear_fwd(x, w32, bias):
         else:
             b32 = torch.zeros(CoutP, dtype=torch.float32, device=dev)
             b32[:Cout] = bias.float()
-    _conv1x1(x, wf, y, T, Cin, CoutP, CoutP, b32)
+    _conv1x1(x, wf, y, T, Cin, CoutP, CoutP, b32, relu)
     return y, wd
 
 
@@ -112,21 +113,26 @@ class _LinearFn(torch.autograd.Function):
     weight image and the bias carry zero rows), the caller sees [T, Cout]."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, relu=False):
+        """relu=True: y = relu(x W^T + b) with the ReLU in the convolution's epilogue (the FFN's linear1 + activation,
+        detr_backbone.py:166 `self.linear2(self.dropout(self.activation(self.linear1(src))))`: one launch instead of two)"""
         Cout = weight.shape[0]
-        y, wd = _linear_fwd(x, weight.detach().float().contiguous(), None if bias is None else bias.detach())
-        ctx.save_for_backward(x, wd)
+        y, wd = _linear_fwd(x, weight.detach().float().contiguous(), None if bias is None else bias.detach(), relu)
+        out = y if y.shape[1] == Cout else y[:, :Cout]
+        ctx.save_for_backward(x, wd, out if relu else None)
         ctx.dims = (Cout, bias is not None)
-        return y if y.shape[1] == Cout else y[:, :Cout]
+        return out
 
     @staticmethod
     def backward(ctx, dy):
-        x, wd = ctx.saved_tensors
+        x, wd, y = ctx.saved_tensors
         Cout, has_bias = ctx.dims
+        if y is not None:
+            dy = _ew(dy.contiguous(), y.contiguous(), 2)       # dy * (y > 0)
         gw = torch.empty(Cout, x.shape[1], dtype=torch.float32, device=x.device)
         gb = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_bias else None
         dx = _linear_bwd(x, wd, dy, Cout, True, gw, gb)
-        return dx, gw, gb
+        return dx, gw, gb, None
 
 
 class _InProjFn(torch.autograd.Function):
@@ -334,8 +340,8 @@ class TransformerEncoderLayer(nn.Module):
 
     def _ffn(self, x):
         Lx, B, E = x.shape
-        h = _LinearFn.apply(x.reshape(Lx * B, E), self.linear1.weight, self.linear1.bias)
-        h = _dropout(_ReluFn.apply(h), self.dropout_p, self.training)
+        h = _LinearFn.apply(x.reshape(Lx * B, E), self.linear1.weight, self.linear1.bias, True)
+        h = _dropout(h, self.dropout_p, self.training)
         return _LinearFn.apply(h, self.linear2.weight, self.linear2.bias).view(Lx, B, E)
 
     def forward(self, src, src_mask=None, src_key_padding_mask=None, pos=None):
