@@ -70,46 +70,18 @@ template <int ACT, class PK>
 __device__ __forceinline__ void bn_act_fwd_body(PK& p, const int bid, const int nb) {
   __shared__ float s_sc[BN_MAXC], s_sh[BN_MAXC];
   const int C = p.C8 * 8, CA = BN_ACC_C(C);
-  // TPB % C8 == 0, so a thread keeps its channel group: its items are the pixels pix0 + k * pstep of that group - no
-  // division per item (a 64-bit one costs as much as the item's arithmetic)
-  const int C8 = p.C8;
-  const int64_t total = p.npix * C8;
-  const int TPB = (256 / C8) * C8;
-  const bool active = (int)threadIdx.x < TPB;
-  const int c8 = (int)threadIdx.x % C8;
-  const int64_t stride = (int64_t)nb * TPB;
-  const int64_t pstep = (int64_t)nb * (TPB / C8);
-  int64_t pixb = (int64_t)bid * (TPB / C8) + (int)threadIdx.x / C8;
-  int64_t idx = (int64_t)bid * TPB + threadIdx.x;
-  // 4 grid-stride elements per trip, all loads issued before the first use (one load in flight per wave is
-  // latency-bound: ~1 us per trip).  The FIRST trip's loads are issued before the statistics prologue: they do not depend
-  // on it, and on the 20x20 / 40x40 maps (one trip per thread) prologue and load latency were the whole kernel, in series
-  bf16x8 v[4], r[4];
-  int64_t pix[4];
-  auto issue = [&]() {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t i = idx + u * stride;
-      pix[u] = pixb + u * pstep;
-      if (i < total) {
-        v[u] = *(const bf16x8*)(p.y + pix[u] * p.ldy + c8 * 8);
-        if (p.res) r[u] = *(const bf16x8*)(p.res + pix[u] * p.ldres + c8 * 8);
-      }
-    }
-  };
-  if (active && idx < total) issue();
   if (p.acc) {
     for (int c = threadIdx.x; c < C; c += 256) {
       // all slot loads are issued before the first add (a rolled loop serialises 16 L2 round trips: ~4.5 us)
-      f64x2 w[MI_BN_SLOTS];
+      f64x2 v[MI_BN_SLOTS];
 #pragma unroll
       for (int k = 0; k < MI_BN_SLOTS; ++k)
-        w[k] = k < p.nslots ? *(const f64x2*)(p.acc + ((size_t)k * CA + c) * 2) : f64x2{0.0, 0.0};
+        v[k] = k < p.nslots ? *(const f64x2*)(p.acc + ((size_t)k * CA + c) * 2) : f64x2{0.0, 0.0};
       double s1 = 0.0, s2 = 0.0;
 #pragma unroll
       for (int k = 0; k < MI_BN_SLOTS; ++k) {
-        s1 += w[k][0];
-        s2 += w[k][1];
+        s1 += v[k][0];
+        s2 += v[k][1];
       }
       const double mean = s1 * p.inv_count;
       double var = s2 * p.inv_count - mean * mean;
@@ -139,14 +111,37 @@ __device__ __forceinline__ void bn_act_fwd_body(PK& p, const int bid, const int 
     }
   }
   __syncthreads();
-  if (!active) return;
+  const int C8 = p.C8;
+  const int64_t total = p.npix * C8;
+  // TPB % C8 == 0, so a thread keeps its channel group: hoist its 8 scale/shift pairs
+  const int TPB = (256 / C8) * C8;
+  if ((int)threadIdx.x >= TPB) return;
+  const int c8 = (int)threadIdx.x % C8;
   float sc[8], sh[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     sc[e] = s_sc[c8 * 8 + e];
     sh[e] = s_sh[c8 * 8 + e];
   }
-  while (idx < total) {
+  // 4 grid-stride elements per trip, all loads issued before the first use (one load in flight per wave is
+  // latency-bound: ~1 us per trip)
+  // TPB % C8 == 0: the thread's items are the pixels pix0 + k * pstep of its channel group - no division per item (a
+  // 64-bit one costs as much as the item's arithmetic)
+  const int64_t stride = (int64_t)nb * TPB;
+  const int64_t pstep = (int64_t)nb * (TPB / C8);
+  int64_t pixb = (int64_t)bid * (TPB / C8) + (int)threadIdx.x / C8;
+  for (int64_t idx = (int64_t)bid * TPB + threadIdx.x; idx < total; idx += 4 * stride, pixb += 4 * pstep) {
+    bf16x8 v[4], r[4];
+    int64_t pix[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = idx + u * stride;
+      pix[u] = pixb + u * pstep;
+      if (i < total) {
+        v[u] = *(const bf16x8*)(p.y + pix[u] * p.ldy + c8 * 8);
+        if (p.res) r[u] = *(const bf16x8*)(p.res + pix[u] * p.ldres + c8 * 8);
+      }
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (idx + u * stride >= total) break;
@@ -162,9 +157,6 @@ __device__ __forceinline__ void bn_act_fwd_body(PK& p, const int bid, const int 
       }
       *(bf16x8*)(p.a + pix[u] * p.lda + c8 * 8) = pack8(o);
     }
-    idx += 4 * stride;
-    pixb += 4 * pstep;
-    if (idx < total) issue();
   }
 }
 
