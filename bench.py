@@ -763,7 +763,7 @@ def main():
         incl = h2d_inclusive(model, args, world, rank, dev)
     if rank == 0:
         live = None
-        if world == 1:
+        if world == 1 and os.environ.get("MI_BENCH_NO_PMC") != "1":      # (A/B scripts: tools/abn.sh skips the two counter passes)
             # counters of THIS box (the committed CSV of an earlier box is only the fallback): the child must take the
             # same BatchNorm backward form as this run
             prev = os.environ.get("MI_BN_FUSED")

@@ -1,0 +1,8 @@
+#!/bin/bash
+# split-K floor of single wgrad launches (MI_WG_MIN_TILES pixel tiles per block, default 4): DETR / SparseInst A/B
+cd $GRAFT_REPO_ROOT
+val() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['value'], d['ms_per_step'], d['config'].get('final_loss'))"; }
+for r in 1 2; do for f in 4 2 1; do
+  MI_WG_MIN_TILES=$f timeout 120 python bench.py --config detr --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | val "detr MIN_TILES=$f"
+  MI_WG_MIN_TILES=$f timeout 120 python bench.py --config sparseinst --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | val "sparseinst MIN_TILES=$f"
+done; done

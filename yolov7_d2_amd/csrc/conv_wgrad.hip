@@ -734,11 +734,15 @@ static int wg_fill(const mi_wgrad_desc* d, Wg2K* k, Wg2Cfg* c, size_t* lds, size
   if (!wg_use_v3(c->NT)) k->nrx = 0;
   int split = d->splitk;
   if (split <= 0) {
-    // one resident block per CU, but never fewer than ~4 pixel tiles per block: each block pays a fixed
-    // accumulator-slab write (and the reduce kernel a read) that only a long enough K range amortises
+    // one resident block per CU, but never fewer than a few pixel tiles per block: each block pays a fixed
+    // accumulator-slab write (and the reduce kernel a read) that only a long enough K range amortises.  Single launches:
+    // >= 2 tiles (round 4; 4 before): the token-row GEMMs of a transformer have 7-66 pixel tiles in all, with 4 per block a
+    // 256 x 256 Linear ran on 64 blocks of a 256-CU chip (DETR-R50 step 238.7 -> 242.7 img/s, 1 tile: 244.3 but
+    // SparseInst's captured loss stopped being reproducible run to run; profiles/r04_wgrad_min_tiles_ab.txt)
     split = 256 / (k->nco * k->nci);
     // in a grouped launch the other layers fill the chip: favour long K ranges (less partial-slab traffic)
-    const int by_tiles = k->ntiles / (grouped ? 8 : 4);
+    static const int min_tiles = wg_env("MI_WG_MIN_TILES", 2);
+    const int by_tiles = k->ntiles / (grouped ? 8 : (min_tiles >= 1 ? min_tiles : 4));
     if (split > by_tiles) split = by_tiles;
     if (split >= 8) split &= ~7;  // multiple of 8: the blocks of one pixel range share an XCD (L2)
     if (split < 1) split = 1;
