@@ -502,6 +502,16 @@ int mi_dropout_bf16(const void* x, void* out, int64_t n, float drop_p, uint64_t 
  * to bf16 before the fp32 add, so the result equals mi_dropout_bf16 followed by mi_ew_bf16(op 0) bit for bit.  res NULL:
  * mi_dropout_bf16. */
 int mi_dropout_add_bf16(const void* x, const void* res, void* out, int64_t n, float drop_p, uint64_t seed, mi_stream_t s);
+/* The post-norm residual of the transformer layers in one pass (detr_backbone.py:163-168,235-243:
+ * `src = self.norm1(src + self.dropout1(src2))`): sum_out = bf16(res + dropout(x)) - the bits mi_dropout_add_bf16 writes -
+ * and y / mean / rstd = mi_layernorm_fwd(sum_out).  mi_layernorm_bwd_dropout is mi_layernorm_bwd that ALSO writes
+ * dx_drop = dropout(dx) with the forward's (p, seed): the gradient of the dropped branch (dx itself is the residual's).
+ * dx_drop NULL: mi_layernorm_bwd. */
+int mi_dropout_add_layernorm_fwd(const void* x, const void* res, void* sum_out, const float* gamma, const float* beta, void* y,
+                                 float* mean, float* rstd, int T, int E, float eps, float drop_p, uint64_t seed, mi_stream_t s);
+int mi_layernorm_bwd_dropout(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
+                             void* dx_drop, float* dgamma, float* dbeta, float* ws, int T, int E, float drop_p, uint64_t seed,
+                             mi_stream_t s);
 /* A step captured as a hipGraph bakes its seeds into the kernel arguments.  With a device word registered here every
  * dropout kernel launched afterwards (mi_dropout_bf16, mi_mha_*_dropout, forward and backward alike) uses seed + *dev_word,
  * read at RUN time: advance the word once per replay (after the backward) and every replay draws fresh masks while the

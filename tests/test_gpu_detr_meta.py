@@ -100,6 +100,33 @@ def test_residual_add_fused_into_the_dropout_pass_equals_two_launches():
     assert 0.08 < float((x1.grad == 0).float().mean()) < 0.12
 
 
+@pytest.mark.parametrize("p", [0.1, 0.0])
+def test_post_norm_residual_as_one_node_equals_add_dropped_then_layernorm(p):
+    """_AddDroppedLayerNormFn (mi_dropout_add_layernorm_fwd / mi_layernorm_bwd_dropout) against _AddDroppedFn (or _AddFn for
+    p = 0) followed by _LayerNormFn: identical output and identical gradients for the residual, the dropped branch, gamma and
+    beta (T = 4200 rows: the DETR encoder at 800 x 1333, and a ragged T)"""
+    from yolov7_d2_amd.modeling.transformer import _AddDroppedFn, _AddDroppedLayerNormFn, _AddFn, _LayerNormFn
+    g = torch.Generator().manual_seed(9)
+    for T in (4200, 403):
+        E = 256
+        mk = lambda: torch.randn(T, E, generator=g).to(torch.bfloat16).to(DEV)
+        res, x, go = mk(), mk(), mk()
+        gam, bet = (1 + 0.1 * torch.randn(E, generator=g)).to(DEV), (0.1 * torch.randn(E, generator=g)).to(DEV)
+        out = []
+        for fused in (True, False):
+            r, xx = res.clone().requires_grad_(True), x.clone().requires_grad_(True)
+            ga, be = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+            if fused:
+                y = _AddDroppedLayerNormFn.apply(r, xx, ga, be, 1e-5, p, 4242)
+            else:
+                sm = _AddDroppedFn.apply(r, xx, p, 4242) if p > 0 else _AddFn.apply(r, xx)
+                y = _LayerNormFn.apply(sm, ga, be, 1e-5)
+            y.backward(go)
+            out.append((y.detach(), r.grad, xx.grad, ga.grad, be.grad))
+        for a, c in zip(*out):
+            assert torch.equal(a, c), (T, p, float((a.float() - c.float()).abs().max()))
+
+
 def test_in_projection_as_one_node_equals_three_sliced_linears():
     """_InProjFn (q, k, v from the WHOLE in_proj_weight / in_proj_bias in one autograd node, the three weight-gradient
     launches writing their row blocks of one [3E, E] tensor) against three _LinearFn calls on parameter slices (autograd's

@@ -312,6 +312,8 @@ _PROTOS = {
     "mi_ew_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i, _vp]),
     "mi_dropout_bf16": (C.c_int, [_vp, _vp, _i64, _f, C.c_uint64, _vp]),
     "mi_dropout_add_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _f, C.c_uint64, _vp]),
+    "mi_dropout_add_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, C.c_uint64, _vp]),
+    "mi_layernorm_bwd_dropout": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, C.c_uint64, _vp]),
     "mi_bilinear_resize_bf16": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "mi_bilinear_resize_bwd_bf16": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "mi_sparseinst_mask_stats": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp]),

@@ -4,15 +4,33 @@
 #include "common.h"
 
 // ---- LayerNorm forward: y = (x - mean) * rstd * gamma + beta ; saves mean / rstd [T]
+// res != NULL: the layer's input is res + dropout(x) (the post-norm residual of detr_backbone.py:163-168,235-243:
+// `src = self.norm1(src + self.dropout1(src2))`), formed here, rounded to bf16 and written to sum_out - the bits
+// mi_dropout_add_bf16 would have written - so that the row is read once and the step has one launch less per norm
+extern const unsigned long long* g_mi_seed_off;   // runtime.hip
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const __bf16* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, __bf16* y, float* mean,
-                                                            float* rstd, int T, int E, float eps) {
+                                                            float* rstd, int T, int E, float eps,
+                                                            const __bf16* __restrict__ res, __bf16* sum_out, unsigned thr,
+                                                            float dscale, unsigned long long seed,
+                                                            const unsigned long long* seed_off) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= T) return;
   const __bf16* xr = x + (size_t)row * E;
   float v[16];  // E <= 1024: 16 values per lane
   const int per = E / 64;
   float s = 0.f;
+  if (res) {
+    if (seed_off) seed += *seed_off;
+    for (int j = 0; j < per; ++j) {
+      const size_t i = (size_t)row * E + lane + 64 * j;
+      const __bf16 d = (__bf16)(mi_rng32(seed, (unsigned long long)i) >= thr ? (float)xr[lane + 64 * j] * dscale : 0.f);
+      const __bf16 t = (__bf16)((float)res[i] + (float)d);
+      sum_out[i] = t;
+      v[j] = (float)t;
+      s += v[j];
+    }
+  } else
   for (int j = 0; j < per; ++j) { v[j] = (float)xr[lane + 64 * j]; s += v[j]; }
   const float mu = wave_sum(s) / (float)E;
   float q = 0.f;
@@ -33,7 +51,12 @@ template <int PER>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const __bf16* __restrict__ x, const __bf16* __restrict__ dy,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, __bf16* dx, float* part,
-                                                            int T, int E, int rows_per_block) {
+                                                            int T, int E, int rows_per_block, __bf16* dx_drop, unsigned thr,
+                                                            float dscale, unsigned long long seed,
+                                                            const unsigned long long* seed_off) {
+  // dx_drop != NULL: also dropout(dx) with the forward's (p, seed) - the gradient of the dropped branch of
+  // res + dropout(x) in front of this norm (what mi_dropout_bf16 applied to dx would write)
+  if (dx_drop && seed_off) seed += *seed_off;
   extern __shared__ float sacc[];  // [4 waves][E][2]
   typedef __attribute__((ext_vector_type(PER))) __bf16 bvec;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -65,6 +88,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const __bf16* __rest
 #pragma unroll
     for (int j = 0; j < PER; ++j) o[j] = (__bf16)(rs * (g[j] - s1 - xh[j] * s2));
     *(bvec*)(dx + (size_t)row * E + c0) = o;
+    if (dx_drop) {
+      bvec od;
+#pragma unroll
+      for (int j = 0; j < PER; ++j)
+        od[j] = (__bf16)(mi_rng32(seed, (unsigned long long)((size_t)row * E + c0 + j)) >= thr ? (float)o[j] * dscale : 0.f);
+      *(bvec*)(dx_drop + (size_t)row * E + c0) = od;
+    }
   }
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
@@ -79,38 +109,85 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const __bf16* __rest
     part[((size_t)blockIdx.x * E + c) * 2 + 1] = b;
   }
 }
-// dgamma / dbeta: sum of the block partials, four independent chains per channel (the loop is latency-bound)
+// dgamma / dbeta: sum of the block partials.  One block = 32 channels x 8 row groups (thread (g, c) sums the rows g, g + 8,
+// ... with four independent chains, the groups are combined through LDS in a fixed order).  The first form - one thread
+// per channel walking ALL partial rows - was a chain of nblk / 4 dependent L2 round trips in a single block: 10 us for the
+// 263 rows of a DETR encoder layer (T = 4 200), 36 launches per step.
 __global__ __launch_bounds__(256) void layernorm_bwd_params_kernel(const float* __restrict__ part, int nblk, int E,
                                                                    float* dgamma, float* dbeta) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= E) return;
+  __shared__ float sa[8][32], sb[8][32];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
-  int k = 0;
-  for (; k + 4 <= nblk; k += 4)
+  if (c < E) {
+    int k = g;
+    for (; k + 24 < nblk; k += 32)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const f32x2 v = *(const f32x2*)(part + ((size_t)(k + u) * E + c) * 2);
-      a[u] += v[0];
-      b[u] += v[1];
+      for (int u = 0; u < 4; ++u) {
+        const f32x2 v = *(const f32x2*)(part + ((size_t)(k + 8 * u) * E + c) * 2);
+        a[u] += v[0];
+        b[u] += v[1];
+      }
+    for (; k < nblk; k += 8) {
+      const f32x2 v = *(const f32x2*)(part + ((size_t)k * E + c) * 2);
+      a[0] += v[0];
+      b[0] += v[1];
     }
-  for (; k < nblk; ++k) { a[0] += part[((size_t)k * E + c) * 2]; b[0] += part[((size_t)k * E + c) * 2 + 1]; }
-  dgamma[c] = (a[0] + a[1]) + (a[2] + a[3]);
-  dbeta[c] = (b[0] + b[1]) + (b[2] + b[3]);
+  }
+  sa[g][cl] = (a[0] + a[1]) + (a[2] + a[3]);
+  sb[g][cl] = (b[0] + b[1]) + (b[2] + b[3]);
+  __syncthreads();
+  if (g == 0 && c < E) {
+    float x = sa[0][cl], y = sb[0][cl];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+      x += sa[q][cl];
+      y += sb[q][cl];
+    }
+    dgamma[c] = x;
+    dbeta[c] = y;
+  }
 }
 
+static unsigned drop_threshold(float drop_p) {
+  unsigned thr = drop_p > 0.f ? (unsigned)((double)drop_p * 4294967296.0) : 0u;
+  if (drop_p > 0.f && thr == 0u) thr = 1u;
+  return thr;
+}
 extern "C" int mi_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                 int T, int E, float eps, mi_stream_t st) {
   MI_REQUIRE(x && gamma && beta && y && mean && rstd && T > 0, "layernorm_fwd: args");
   MI_REQUIRE(E % 64 == 0 && E <= 1024, "layernorm_fwd: E %d (multiple of 64, <= 1024)", E);
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(mi_cdiv(T, 4)), dim3(256), 0, (hipStream_t)st, (const __bf16*)x, gamma, beta,
-                     (__bf16*)y, mean, rstd, T, E, eps);
+                     (__bf16*)y, mean, rstd, T, E, eps, (const __bf16*)nullptr, (__bf16*)nullptr, 0u, 1.f, 0ull,
+                     (const unsigned long long*)nullptr);
   MI_CHECK_LAUNCH("layernorm_fwd");
+  return MI_OK;
+}
+extern "C" int mi_dropout_add_layernorm_fwd(const void* x, const void* res, void* sum_out, const float* gamma, const float* beta,
+                                            void* y, float* mean, float* rstd, int T, int E, float eps, float drop_p,
+                                            uint64_t seed, mi_stream_t st) {
+  MI_REQUIRE(x && res && sum_out && gamma && beta && y && mean && rstd && T > 0, "dropout_add_layernorm_fwd: args");
+  MI_REQUIRE(E % 64 == 0 && E <= 1024, "dropout_add_layernorm_fwd: E %d (multiple of 64, <= 1024)", E);
+  MI_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "dropout_add_layernorm_fwd: p %f", drop_p);
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(mi_cdiv(T, 4)), dim3(256), 0, (hipStream_t)st, (const __bf16*)x, gamma, beta,
+                     (__bf16*)y, mean, rstd, T, E, eps, (const __bf16*)res, (__bf16*)sum_out, drop_threshold(drop_p),
+                     1.f / (1.f - drop_p), (unsigned long long)seed, g_mi_seed_off);
+  MI_CHECK_LAUNCH("dropout_add_layernorm_fwd");
   return MI_OK;
 }
 /* ws: fp32 [ceil(T/16)][E][2] (one partial row per block; a block takes >= 16 token rows) */
 extern "C" int mi_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd,
                                 void* dx, float* dgamma, float* dbeta, float* ws, int T, int E, mi_stream_t st) {
+  return mi_layernorm_bwd_dropout(x, dy, gamma, mean, rstd, dx, nullptr, dgamma, dbeta, ws, T, E, 0.f, 0, st);
+}
+extern "C" int mi_layernorm_bwd_dropout(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd,
+                                        void* dx, void* dx_drop, float* dgamma, float* dbeta, float* ws, int T, int E,
+                                        float drop_p, uint64_t seed, mi_stream_t st) {
   MI_REQUIRE(x && dy && gamma && mean && rstd && dx && dgamma && dbeta && ws && T > 0, "layernorm_bwd: args");
+  MI_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "layernorm_bwd: p %f", drop_p);
+  const unsigned thr = drop_threshold(drop_p);
+  const float dscale = 1.f / (1.f - drop_p);
   MI_REQUIRE(E % 64 == 0 && E <= 1024, "layernorm_bwd: E %d", E);
   // rows per block: ~512 blocks for long sequences, 16 rows at least (the workspace contract: ceil(T / 16) partial rows) -
   // T = 4200 (DETR's encoder at 800 x 1333, bs 4) runs 263 blocks of 16 rows
@@ -121,7 +198,8 @@ extern "C" int mi_layernorm_bwd(const void* x, const void* dy, const float* gamm
   const size_t lds = (size_t)4 * E * 2 * sizeof(float);
 #define MI_LN_BWD(PERv)                                                                                                  \
   hipLaunchKernelGGL(layernorm_bwd_kernel<PERv>, dim3(nblk), dim3(256), lds, s, (const __bf16*)x, (const __bf16*)dy, gamma, \
-                     mean, rstd, (__bf16*)dx, ws, T, E, rpb)
+                     mean, rstd, (__bf16*)dx, ws, T, E, rpb, (__bf16*)dx_drop, thr, dscale, (unsigned long long)seed,          \
+                     g_mi_seed_off)
   switch (E / 64) {
     case 1: MI_LN_BWD(1); break;
     case 2: MI_LN_BWD(2); break;
@@ -132,7 +210,7 @@ extern "C" int mi_layernorm_bwd(const void* x, const void* dy, const float* gamm
   }
 #undef MI_LN_BWD
   MI_CHECK_LAUNCH("layernorm_bwd");
-  hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3(mi_cdiv(E, 256)), dim3(256), 0, s, ws, nblk, E, dgamma, dbeta);
+  hipLaunchKernelGGL(layernorm_bwd_params_kernel, dim3(mi_cdiv(E, 32)), dim3(256), 0, s, ws, nblk, E, dgamma, dbeta);
   MI_CHECK_LAUNCH("layernorm_bwd_params");
   return MI_OK;
 }

@@ -196,6 +196,44 @@ class _LayerNormFn(torch.autograd.Function):
         return dx, dg, db, None
 
 
+class _AddDroppedLayerNormFn(torch.autograd.Function):
+    """LayerNorm(res + dropout(x)) - the post-norm residual of every transformer sub-layer (detr_backbone.py:163-168,
+    235-243) - as one node: forward = ONE launch (mi_dropout_add_layernorm_fwd: the sum is formed, rounded to bf16 and
+    written while the row's statistics are taken), backward = mi_layernorm_bwd_dropout, which writes the residual's
+    gradient dx and the dropped branch's dropout(dx) in the same pass.  Bit-identical to _AddDroppedFn (or _AddFn for
+    p = 0) followed by _LayerNormFn: two launches forward and two backward less per norm."""
+
+    @staticmethod
+    def forward(ctx, res, x, gamma, beta, eps, p, seed):
+        T, E = x.shape
+        res, x = res.contiguous(), x.contiguous()
+        y, sm = torch.empty_like(x), torch.empty_like(x)
+        mean = torch.empty(T, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(T, dtype=torch.float32, device=x.device)
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        L.check(L.lib().mi_dropout_add_layernorm_fwd(x.data_ptr(), res.data_ptr(), sm.data_ptr(), g32.data_ptr(), b32.data_ptr(),
+                                                     y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), T, E, eps, float(p), int(seed),
+                                                     L.stream_ptr()), "mi_dropout_add_layernorm_fwd")
+        ctx.save_for_backward(sm, g32, mean, rstd)
+        ctx.ps = (float(p), int(seed))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        sm, g32, mean, rstd = ctx.saved_tensors
+        T, E = sm.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(sm)
+        dxd = torch.empty_like(sm) if ctx.ps[0] > 0 else None
+        dg = torch.empty(E, dtype=torch.float32, device=sm.device)
+        db = torch.empty(E, dtype=torch.float32, device=sm.device)
+        ws = torch.empty((T + 15) // 16 * E * 2, dtype=torch.float32, device=sm.device)
+        L.check(L.lib().mi_layernorm_bwd_dropout(sm.data_ptr(), dy.data_ptr(), g32.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                 dx.data_ptr(), L.ptr(dxd), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), T, E,
+                                                 ctx.ps[0], ctx.ps[1], L.stream_ptr()), "mi_layernorm_bwd_dropout")
+        return dx, (dx if dxd is None else dxd), dg, db, None, None, None
+
+
 def _ew(a, b, op):
     out = torch.empty_like(a)
     L.check(L.lib().mi_ew_bf16(a.data_ptr(), L.ptr(b), out.data_ptr(), a.numel(), op, L.stream_ptr()), "mi_ew_bf16")
@@ -338,6 +376,13 @@ class TransformerEncoderLayer(nn.Module):
         Lx, B, E = x.shape
         return _LayerNormFn.apply(x.reshape(Lx * B, E), norm.weight, norm.bias, norm.eps).view(Lx, B, E)
 
+    def _ln_res(self, norm, res, x):
+        """norm(res + dropout(x)): one node, one launch forward (see _AddDroppedLayerNormFn)"""
+        Lx, B, E = x.shape
+        p = self.dropout_p if self.training else 0.0
+        return _AddDroppedLayerNormFn.apply(res.reshape(Lx * B, E), x.reshape(Lx * B, E), norm.weight, norm.bias, norm.eps, p,
+                                            _next_seed() if p > 0 else 0).view(Lx, B, E)
+
     def _ffn(self, x):
         Lx, B, E = x.shape
         h = _LinearFn.apply(x.reshape(Lx * B, E), self.linear1.weight, self.linear1.bias, True)
@@ -356,9 +401,9 @@ class TransformerEncoderLayer(nn.Module):
         # forward_post (detr_backbone.py:156-168)
         q = k = self.with_pos_embed(src, pos)
         src2 = self.self_attn(q, k, value=src, attn_mask=src_mask, key_padding_mask=src_key_padding_mask)[0]
-        src = self._ln(self.norm1, _add_dropped(src, src2, self.dropout_p, self.training))
+        src = self._ln_res(self.norm1, src, src2)
         src2 = self._ffn(src)
-        return self._ln(self.norm2, _add_dropped(src, src2, self.dropout_p, self.training))
+        return self._ln_res(self.norm2, src, src2)
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -380,6 +425,7 @@ class TransformerDecoderLayer(nn.Module):
 
     with_pos_embed = staticmethod(TransformerEncoderLayer.with_pos_embed)
     _ln = TransformerEncoderLayer._ln
+    _ln_res = TransformerEncoderLayer._ln_res
     _ffn = TransformerEncoderLayer._ffn
 
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
@@ -400,12 +446,12 @@ class TransformerDecoderLayer(nn.Module):
         # forward_post (detr_backbone.py:222-243)
         q = k = self.with_pos_embed(tgt, query_pos)
         tgt2 = self.self_attn(q, k, value=tgt, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
-        tgt = self._ln(self.norm1, _add_dropped(tgt, tgt2, self.dropout_p, self.training))
+        tgt = self._ln_res(self.norm1, tgt, tgt2)
         tgt2 = self.multihead_attn(self.with_pos_embed(tgt, query_pos), mem_k, value=memory, attn_mask=memory_mask,
                                    key_padding_mask=memory_key_padding_mask)[0]
-        tgt = self._ln(self.norm2, _add_dropped(tgt, tgt2, self.dropout_p, self.training))
+        tgt = self._ln_res(self.norm2, tgt, tgt2)
         tgt2 = self._ffn(tgt)
-        return self._ln(self.norm3, _add_dropped(tgt, tgt2, self.dropout_p, self.training))
+        return self._ln_res(self.norm3, tgt, tgt2)
 
 
 def _norm_tokens(norm, x):
