@@ -790,9 +790,12 @@ int mi_bilinear_resize_bf16(const void* x, int ldx, int N, int H, int W, int C, 
 int mi_bilinear_resize_bwd_bf16(const void* dy, int lddy, int N, int H, int W, int C, void* dx, int lddx, int Ho, int Wo,
                                 float* acc_ws_zeroed, mi_stream_t s);
 /* masks bf16 logits [B][P][ldm] (instance = channel), targets fp32 [T][P], pairs int32 [K][3] = (b, n, t);
- * stats fp32 [K][8] = sum BCE, sum sig*t, sum sig^2, sum t^2, |sig>=.4 & t>.5|, |sig>=.4|, |t>.5|, 0 */
+ * stats fp32 [K][8] = sum BCE, sum sig*t, sum sig^2, sum t^2, |sig>=.4 & t>.5|, |sig>=.4|, |t>.5|, 0 (rows with b < 0: zeros).
+ * ws: mi_sparseinst_mask_stats_ws_floats(K, P) floats of block partials, summed in a fixed order (bit-reproducible; no
+ * float atomics) */
+int64_t mi_sparseinst_mask_stats_ws_floats(int K, int P);
 int mi_sparseinst_mask_stats(const void* masks, int ldm, int P, const float* targets, const int32_t* pairs, int K,
-                             float* stats, mi_stream_t s);
+                             float* stats, float* ws, mi_stream_t s);
 int mi_sparseinst_mask_grad(const void* masks, int ldm, int P, const float* targets, const int32_t* pairs, int K,
                             const float* stats, float c_bce, float c_dice, void* dmasks_zeroed, mi_stream_t s);
 /* the form a captured step uses: pair rows whose image index is < 0 are skipped by both kernels (a fixed-capacity pair table

@@ -453,3 +453,37 @@ def test_encoder_decoder_real_size_gradients_with_the_forward_state_pinned(monke
     bad = [(n, round(c, 5), round(r, 4)) for n, c, r in rows if c < lim(n)[0] or r > lim(n)[1]]
     assert not bad, bad[:8]
     assert all(c > 0.999 and r < 0.05 for c, r in drel.values()), drel
+
+
+def test_mask_statistics_are_exact_sums_in_a_fixed_order():
+    """mi_sparseinst_mask_stats at the bench's mask size (P = 160 x 160: 13 blocks per pair): every call returns the same bits
+    (block partials summed in a fixed order - the first form added them with fp32 atomics and the captured SparseInst step
+    alternated between two final losses run to run), unused rows (image index < 0) are zero, and the sums match fp64."""
+    from yolov7_d2_amd import _lib as L
+    g = torch.Generator().manual_seed(21)
+    B, P, Np, K = 2, 160 * 160, 128, 24
+    masks = (torch.randn(B, P, Np, generator=g) * 3).to(torch.bfloat16).to(DEV)
+    tgt = (torch.rand(K, P, generator=g) > 0.7).float().to(DEV)
+    pairs = torch.stack([torch.randint(0, B, (K,), generator=g), torch.randint(0, 100, (K,), generator=g), torch.arange(K)], 1).int()
+    pairs[5, 0] = pairs[17, 0] = -1
+    pairs = pairs.to(DEV).contiguous()
+    ws = torch.empty(int(L.lib().mi_sparseinst_mask_stats_ws_floats(K, P)), dtype=torch.float32, device=DEV)
+    outs = []
+    for _ in range(6):
+        stats = torch.full((K, 8), float("nan"), dtype=torch.float32, device=DEV)
+        L.check(L.lib().mi_sparseinst_mask_stats(masks.data_ptr(), Np, P, tgt.data_ptr(), pairs.data_ptr(), K, stats.data_ptr(),
+                                                 ws.data_ptr(), L.stream_ptr()), "mi_sparseinst_mask_stats")
+        outs.append(stats.clone())
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    st = outs[0].cpu().double()
+    assert float(st[5].abs().max()) == 0.0 and float(st[17].abs().max()) == 0.0 and float(st[:, 7].abs().max()) == 0.0
+    pc = pairs.cpu()
+    for k in (0, 3, 11, 23):
+        x = masks[pc[k, 0], :, pc[k, 1]].double().cpu()
+        t = tgt[k].double().cpu()
+        sg = torch.sigmoid(x)
+        ref = [float((x.clamp(min=0) - x * t + torch.log1p(torch.exp(-x.abs()))).sum()), float((sg * t).sum()), float((sg * sg).sum()),
+               float((t * t).sum())]
+        for e in range(4):
+            assert abs(float(st[k, e]) - ref[e]) <= 2e-4 * abs(ref[e]) + 1e-3, (k, e, float(st[k, e]), ref[e])

@@ -316,7 +316,8 @@ _PROTOS = {
     "mi_layernorm_bwd_dropout": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, C.c_uint64, _vp]),
     "mi_bilinear_resize_bf16": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "mi_bilinear_resize_bwd_bf16": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
-    "mi_sparseinst_mask_stats": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "mi_sparseinst_mask_stats": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "mi_sparseinst_mask_stats_ws_floats": (C.c_int64, [_i, _i]),
     "mi_sparseinst_mask_grad": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _vp, _f, _f, _vp, _vp]),
     "mi_sparseinst_mask_grad_dev": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "mi_mha_fwd_dropout": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, C.c_uint64, _vp]),

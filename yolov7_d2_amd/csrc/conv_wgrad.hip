@@ -737,8 +737,8 @@ static int wg_fill(const mi_wgrad_desc* d, Wg2K* k, Wg2Cfg* c, size_t* lds, size
     // one resident block per CU, but never fewer than a few pixel tiles per block: each block pays a fixed
     // accumulator-slab write (and the reduce kernel a read) that only a long enough K range amortises.  Single launches:
     // >= 2 tiles (round 4; 4 before): the token-row GEMMs of a transformer have 7-66 pixel tiles in all, with 4 per block a
-    // 256 x 256 Linear ran on 64 blocks of a 256-CU chip (DETR-R50 step 238.7 -> 242.7 img/s, 1 tile: 244.3 but
-    // SparseInst's captured loss stopped being reproducible run to run; profiles/r04_wgrad_min_tiles_ab.txt)
+    // 256 x 256 Linear ran on 64 blocks of a 256-CU chip (DETR-R50 step 238.7 -> 242.7 img/s; 1 tile: 244.3, SparseInst
+    // -0.3 %; profiles/r04_wgrad_min_tiles_ab.txt)
     split = 256 / (k->nco * k->nci);
     // in a grouped launch the other layers fill the chip: favour long K ranges (less partial-slab traffic)
     static const int min_tiles = wg_env("MI_WG_MIN_TILES", 2);

@@ -190,16 +190,12 @@ struct MaskLossK {
   const float* tgt;
   const int* pairs;
   float* stats;
+  float* part;       // mask_stats: block partials [K][blocks][8]
   __bf16* dmasks;
   int K, P, ldm;
   float c_bce, c_dice;   // backward: upstream-gradient-scaled weights: c_bce = g_mask * w / (K * P), c_dice = g_dice * w / num_inst
   const float* coef;     // optional device pair (c_bce, c_dice) that replaces the two launch constants
 };
-
-__global__ __launch_bounds__(256) void zero_f32_kernel(float* p, int n) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) p[i] = 0.f;
-}
 
 __global__ __launch_bounds__(256) void mask_stats_kernel(const MaskLossK p) {
   __shared__ float red[4][8];
@@ -223,7 +219,21 @@ __global__ __launch_bounds__(256) void mask_stats_kernel(const MaskLossK p) {
   if ((threadIdx.x & 63) == 0)
     for (int e = 0; e < 7; ++e) red[threadIdx.x >> 6][e] = a[e];
   __syncthreads();
-  if (threadIdx.x < 7) atomicAdd(p.stats + k * 8 + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  // block partial -> workspace [k][block][8]; mask_stats_final_kernel adds the blocks in a fixed order.  (Round 4: this was an
+  // fp32 atomicAdd into stats - 13 blocks per pair arriving in any order - and the captured SparseInst step was not
+  // reproducible run to run: two final losses alternated.  Same two launches: the final pass replaces the zero fill.)
+  if (threadIdx.x < 8)
+    p.part[((size_t)k * gridDim.x + blockIdx.x) * 8 + threadIdx.x] =
+        threadIdx.x < 7 ? (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]) : 0.f;
+}
+__global__ __launch_bounds__(256) void mask_stats_final_kernel(const MaskLossK p, int nblk) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.K * 8) return;
+  const int k = i >> 3, e = i & 7;
+  float s = 0.f;
+  if (p.pairs[k * 3] >= 0)          // (an unused row's blocks returned before writing: its statistics are zero)
+    for (int b = 0; b < nblk; ++b) s += p.part[((size_t)k * nblk + b) * 8 + e];
+  p.stats[i] = s;
 }
 
 // d(loss)/d(logit) of pair k at pixel px: c_bce * (sig - t) + c_dice * (-2 t / D + 4 A sig / D^2) * sig (1 - sig), D = S + Tt + 1e-4
@@ -245,22 +255,27 @@ __global__ __launch_bounds__(256) void mask_grad_kernel(const MaskLossK p) {
   }
 }
 
+static int mask_stats_blocks(int P) {
+  int bx = (P + 2047) / 2048;
+  return bx > 64 ? 64 : bx;
+}
+extern "C" int64_t mi_sparseinst_mask_stats_ws_floats(int K, int P) {
+  return K > 0 && P > 0 ? (int64_t)K * mask_stats_blocks(P) * 8 : -1;
+}
 extern "C" int mi_sparseinst_mask_stats(const void* masks, int ldm, int P, const float* targets, const int32_t* pairs, int K,
-                                        float* stats, mi_stream_t st) {
-  MI_REQUIRE(masks && targets && pairs && stats && K > 0 && P > 0 && ldm > 0, "sparseinst_mask_stats: args");
+                                        float* stats, float* ws, mi_stream_t st) {
+  MI_REQUIRE(masks && targets && pairs && stats && ws && K > 0 && P > 0 && ldm > 0, "sparseinst_mask_stats: args");
   MaskLossK k;
   memset(&k, 0, sizeof(k));
-  k.masks = (const __bf16*)masks; k.tgt = targets; k.pairs = pairs; k.stats = stats; k.K = K; k.P = P; k.ldm = ldm;
+  k.masks = (const __bf16*)masks; k.tgt = targets; k.pairs = pairs; k.stats = stats; k.part = ws; k.K = K; k.P = P; k.ldm = ldm;
   hipStream_t s = (hipStream_t)st;
-  // (a kernel, not hipMemsetAsync: inside the captured SparseInst step - a hipGraph of ~3000 nodes from a shared memory pool -
-  //  memset nodes were the one node kind whose effect went missing on replays after the first: the statistics accumulated
-  //  onto the previous replay's values; tools/si_graph_debug*.py, round 4)
-  hipLaunchKernelGGL(zero_f32_kernel, dim3((K * 8 + 255) / 256), dim3(256), 0, s, stats, K * 8);
-  MI_CHECK_LAUNCH("sparseinst_mask_stats zero");
-  int bx = (P + 2047) / 2048;
-  if (bx > 64) bx = 64;
+  const int bx = mask_stats_blocks(P);
   hipLaunchKernelGGL(mask_stats_kernel, dim3(bx, K), dim3(256), 0, s, k);
   MI_CHECK_LAUNCH("sparseinst_mask_stats");
+  // (no hipMemsetAsync anywhere near this: inside the captured SparseInst step - a hipGraph of ~3000 nodes from a shared memory
+  //  pool - memset nodes were the one node kind whose effect went missing on replays after the first; tools/si_graph_debug*.py)
+  hipLaunchKernelGGL(mask_stats_final_kernel, dim3((K * 8 + 255) / 256), dim3(256), 0, s, k, bx);
+  MI_CHECK_LAUNCH("sparseinst_mask_stats final");
   return MI_OK;
 }
 // dmasks: bf16 [B][P][ldm], zeroed by the caller (only the matched instances' columns are written)

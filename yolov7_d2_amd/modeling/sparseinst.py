@@ -602,8 +602,9 @@ class _MaskLossFn(torch.autograd.Function):
         P = Ho * Wo
         K = pairs.shape[0]
         stats = torch.empty(K, 8, dtype=torch.float32, device=masks.device)
+        ws = torch.empty(int(L.lib().mi_sparseinst_mask_stats_ws_floats(K, P)), dtype=torch.float32, device=masks.device)
         L.check(L.lib().mi_sparseinst_mask_stats(masks.data_ptr(), Np, P, tgt.data_ptr(), pairs.data_ptr(), K,
-                                                 stats.data_ptr(), L.stream_ptr()), "mi_sparseinst_mask_stats")
+                                                 stats.data_ptr(), ws.data_ptr(), L.stream_ptr()), "mi_sparseinst_mask_stats")
         bce = stats[:, 0].sum()
         dice = ((1.0 - 2.0 * stats[:, 1] / (stats[:, 2] + stats[:, 3] + 1e-4)) * valid).sum()
         iou = stats[:, 4] / (stats[:, 6] + stats[:, 5] - stats[:, 4] + 1e-6)
