@@ -18,6 +18,7 @@
 // fp64 accumulation of fp32 tile sums makes the result independent of the atomic arrival order except in
 // astronomically rare rounding ties.  All kernels are HBM streams: 16-byte (8 x bf16) accesses, fp32 math.
 #include <string.h>
+#include <stdlib.h>
 #include "common.h"
 #include "conv_bn.h"
 
@@ -180,10 +181,14 @@ __global__ __launch_bounds__(256) void bn_act_fwd_group_kernel(const BnFwdK* __r
   bn_act_fwd_body<ACT, KC4>(*pj, (int)blockIdx.x - starts[j], starts[j + 1] - starts[j]);
 }
 
-// every block pays the statistics prologue (2 x MI_BN_SLOTS fp64 loads + an fp64 rsqrt per channel): give each thread
-// ~8 grid-stride iterations so that it amortises, and never more than 4 blocks per CU
+// every block pays the statistics prologue (2 x MI_BN_SLOTS fp64 loads + an fp64 rsqrt per channel), so never more than
+// 4 blocks per CU; 512 items (two 16-byte items per thread) per block: the 20x20 / 40x40 maps then spread over 400-800 blocks
+// instead of 100-200 with the 2048 of rounds 1-3 (same-box A/B, round 4: 5.405 / 5.419 -> 5.384 / 5.385 ms and 5.506 /
+// 5.511 / 5.515 -> 5.481 / 5.477 / 5.490 ms per step; 256 and 1024 are in between)
 static int ew_blocks(int64_t total) {
-  int64_t b = (total + 2047) / 2048;
+  static const int per = getenv("MI_BN_EW_ITEMS") ? atoi(getenv("MI_BN_EW_ITEMS")) : 512;   // items per block (A/B knob)
+  const int64_t ipb = per >= 256 ? per : 512;
+  int64_t b = (total + ipb - 1) / ipb;
   if (b > 1024) b = 1024;
   if (b < 1) b = 1;
   return (int)b;

@@ -742,7 +742,8 @@ static int wg_fill(const mi_wgrad_desc* d, Wg2K* k, Wg2Cfg* c, size_t* lds, size
     split = 256 / (k->nco * k->nci);
     // in a grouped launch the other layers fill the chip: favour long K ranges (less partial-slab traffic)
     static const int min_tiles = wg_env("MI_WG_MIN_TILES", 2);
-    const int by_tiles = k->ntiles / (grouped ? 8 : (min_tiles >= 1 ? min_tiles : 4));
+    static const int min_tiles_g = wg_env("MI_WG_MIN_TILES_GROUP", 8);
+    const int by_tiles = k->ntiles / (grouped ? (min_tiles_g >= 1 ? min_tiles_g : 8) : (min_tiles >= 1 ? min_tiles : 4));
     if (split > by_tiles) split = by_tiles;
     if (split >= 8) split &= ~7;  // multiple of 8: the blocks of one pixel range share an XCD (L2)
     if (split < 1) split = 1;
