@@ -256,3 +256,40 @@ def test_shape_buckets_serve_nearby_shapes_with_one_capture():
         assert len(step.graphs) == 1
     finally:
         step.close()
+
+
+def test_all_decoder_levels_matched_in_one_launch_equal_the_per_level_matching():
+    """HungarianMatcher.match_device_levels ((level, image) pairs as the batch of ONE mi_hungarian_match call over the
+    level-replicated ground truth) against match_device level by level: the same assignments, bit for bit, and the same
+    weighted losses from SetCriterion.weighted_packed with and without it"""
+    model = _model(0.0)
+    b = _batch(7, ((256, 320), (224, 288)), (3, 5))
+    static = model.prepare_batch(b)
+    targets = static["targets"]
+    assert targets.lv is not None and targets.lv["n"] == 2
+    with torch.no_grad():
+        out = model.detr(static["images"])
+    levels = [{k: v for k, v in out.items() if k != "aux_outputs"}] + list(out["aux_outputs"])
+    matcher = model.criterion.matcher
+    one = matcher.match_device_levels(levels, targets)
+    for lv, m1 in zip(levels, one):
+        m0 = matcher.match_device(lv, targets)
+        assert torch.equal(m0["nmatch"], m1["nmatch"])
+        for bi, n in enumerate(m0["nmatch"].tolist()):
+            assert n == len(b[bi]["instances"])
+            assert torch.equal(m0["match_q"][bi, :n], m1["match_q"][bi, :n]) and torch.equal(m0["match_t"][bi, :n], m1["match_t"][bi, :n])
+    with torch.no_grad():
+        a = model.criterion.weighted_packed(out, targets)
+        lv_saved, targets.lv = targets.lv, None          # per-level matching
+        c = model.criterion.weighted_packed(out, targets)
+        targets.lv = lv_saved
+    for k in a:
+        assert torch.equal(a[k], c[k]), k
+    # a batch without any box: every level matches nothing, the level offsets stay valid
+    e = _batch(8, ((256, 320), (224, 288)), (0, 0))
+    static = model.prepare_batch(e, static=static)
+    with torch.no_grad():
+        out = model.detr(static["images"])
+    levels = [{k: v for k, v in out.items() if k != "aux_outputs"}] + list(out["aux_outputs"])
+    for m in matcher.match_device_levels(levels, static["targets"]):
+        assert int(m["nmatch"].abs().sum()) == 0

@@ -784,7 +784,9 @@ static bool bn_fused_fits(int64_t npix, int ldda, int ldy, int lddy, int lddres)
 static int bn_fused_blocks(int64_t npix, int C8, int cap) {
   // at least ~4 items per thread (the barrier costs one atomic round trip per block), never more than `cap` blocks
   const int64_t TPB = (256 / C8) * C8;
-  int64_t b = (npix * C8 + TPB * 4 - 1) / (TPB * 4);
+  static const int ipt_e = getenv("MI_BN_FUSED_ITEMS") ? atoi(getenv("MI_BN_FUSED_ITEMS")) : 4;   // A/B knob
+  const int64_t ipt = ipt_e >= 1 && ipt_e <= 16 ? ipt_e : 4;
+  int64_t b = (npix * C8 + TPB * ipt - 1) / (TPB * ipt);
   if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;

@@ -116,13 +116,19 @@ class SetCriterion(nn.Module):
         backward nodes) the same arithmetic is ~100 one-element launches per DETR step."""
         inv = targets.inv_num_boxes
         levels = [{k: v for k, v in outputs.items() if k != "aux_outputs"}] + list(outputs.get("aux_outputs", []))
-        vs = []
         for lv in levels:
             if not lv["pred_logits"].is_cuda:
                 raise L.MI355Error("SetCriterion: the MI355X path needs device tensors (no CPU fallback)")
             if lv["pred_logits"].shape[-1] != self.num_classes + 1:
                 raise ValueError("pred_logits must have num_classes + 1 channels")
-            vs.append(_SetLossFn.apply(lv["pred_logits"], lv["pred_boxes"], self._match(lv, targets), self.eos_coef, 1.0))
+        lvt = getattr(targets, "lv", None)
+        import os
+        if (isinstance(self.matcher, HungarianMatcher) and lvt is not None and lvt["n"] == len(levels)
+                and os.environ.get("MI_DETR_MATCH_LEVELS", "1") == "1"):       # (=0: one matching per level, A/B switch)
+            ms = self.matcher.match_device_levels(levels, targets)          # all levels: one cost + one assignment launch
+        else:
+            ms = [self._match(lv, targets) for lv in levels]
+        vs = [_SetLossFn.apply(lv["pred_logits"], lv["pred_boxes"], m, self.eos_coef, 1.0) for lv, m in zip(levels, ms)]
         V = torch.stack(vs)                                               # [levels, 5]: ce, class_error, cardinality, bbox, giou
         names = ("loss_ce", "class_error", "cardinality_error", "loss_bbox", "loss_giou")
         need = ("labels", "labels", "cardinality", "boxes", "boxes")

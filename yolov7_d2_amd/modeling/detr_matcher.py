@@ -18,9 +18,27 @@ class PackedTargets(list):
     inv_num_boxes fp32 [1] = 1 / max(sum of boxes / world, 1).  Nothing in it lives on the host: a step captured as a
     hipGraph reads the SAME tensors for every batch (Detr.prepare_batch refills them in place)."""
 
-    def __init__(self, dicts, cap, tgt_off, tgt_labels, tgt_boxes, inv_num_boxes):
+    def __init__(self, dicts, cap, tgt_off, tgt_labels, tgt_boxes, inv_num_boxes, levels=1):
         super().__init__(dicts)
         self.cap, self.tgt_off, self.tgt_labels, self.tgt_boxes, self.inv_num_boxes = cap, tgt_off, tgt_labels, tgt_boxes, inv_num_boxes
+        # the same ground truth `levels` times over (level l's copy starts where level l - 1's ends): what ONE matching launch
+        # over (decoder level, image) pairs indexes - HungarianMatcher.match_device_levels.  Filled by Detr.prepare_batch.
+        self.lv = None
+        if levels > 1:
+            B, dev = len(dicts), tgt_off.device
+            self.lv = dict(n=levels, off=torch.zeros(levels * B + 1, dtype=torch.int32, device=dev),
+                           labels=torch.zeros(levels * B * cap, dtype=torch.int64, device=dev),
+                           boxes=torch.zeros(levels * B * cap, 4, dtype=torch.float32, device=dev))
+
+    def fill_levels(self, off, labels, boxes):
+        """host lists of one batch (prefix offsets, concatenated labels / boxes or None) -> the replicated device arrays"""
+        if self.lv is None:
+            return
+        n, B, ntot = self.lv["n"], len(self), off[-1]
+        self.lv["off"].copy_(torch.tensor([l * ntot + off[b] for l in range(n) for b in range(B)] + [n * ntot], dtype=torch.int32))
+        if ntot:
+            self.lv["labels"][:n * ntot].copy_(labels.repeat(n))
+            self.lv["boxes"][:n * ntot].copy_(boxes.repeat(n, 1))
 
 
 class HungarianMatcher(nn.Module):
@@ -61,6 +79,35 @@ class HungarianMatcher(nn.Module):
         self.last_cost = cost
         return dict(match_q=mq, match_t=mt, nmatch=nm, tgt_off=off, tgt_labels=tl, tgt_boxes=tb, gmax=gmax,
                     num_targets=ntot)
+
+    @torch.no_grad()
+    def match_device_levels(self, levels, targets):
+        """match_device for ALL decoder levels of a step in one launch pair: the (level, image) pairs are the batch of one
+        mi_hungarian_match call over the level-replicated ground truth (PackedTargets.lv) - one cost launch and one
+        assignment launch of levels x B blocks instead of `levels` launches of B blocks each (the assignment kernel is one
+        wave per image and ~65 us long: six of them in series were 0.4 ms of a DETR step).  Returns one dict per level in
+        match_device's layout (row blocks of the shared match arrays; targets indexed through the ORIGINAL tgt_off)."""
+        lv = targets.lv
+        n = len(levels)
+        assert lv is not None and lv["n"] == n
+        logits = torch.stack([x["pred_logits"].detach() for x in levels]).float().contiguous()
+        boxes = torch.stack([x["pred_boxes"].detach() for x in levels]).float().contiguous()
+        if not logits.is_cuda:
+            raise L.MI355Error("HungarianMatcher: the MI355X path needs device tensors (no CPU fallback)")
+        _, bs, nq, nc = logits.shape
+        dev, gmax = logits.device, targets.cap
+        cost = torch.empty(n * bs, nq, gmax, device=dev)
+        mq = torch.empty(n * bs, gmax, dtype=torch.int64, device=dev)
+        mt = torch.empty(n * bs, gmax, dtype=torch.int64, device=dev)
+        nm = torch.zeros(n * bs, dtype=torch.int32, device=dev)
+        L.check(L.lib().mi_hungarian_match(logits.data_ptr(), boxes.data_ptr(), lv["labels"].data_ptr(), lv["boxes"].data_ptr(),
+                                           lv["off"].data_ptr(), n * bs, nq, nc, gmax, float(self.cost_class),
+                                           float(self.cost_bbox), float(self.cost_giou), cost.data_ptr(), mq.data_ptr(),
+                                           mt.data_ptr(), nm.data_ptr(), L.stream_ptr()), "mi_hungarian_match (all levels)")
+        self.last_cost = cost[:bs]
+        return [dict(match_q=mq[l * bs:(l + 1) * bs], match_t=mt[l * bs:(l + 1) * bs], nmatch=nm[l * bs:(l + 1) * bs],
+                     tgt_off=targets.tgt_off, tgt_labels=targets.tgt_labels, tgt_boxes=targets.tgt_boxes, gmax=gmax,
+                     num_targets=-1) for l in range(n)]
 
     @torch.no_grad()
     def forward(self, outputs, targets):

@@ -239,9 +239,11 @@ class Detr(nn.Module):
             images = ImageList(tensor, [(0, 0)] * B)
             images.sizes_dev = torch.zeros(B, 2, dtype=torch.int64, device=dev)
             cap = self.target_capacity
+            levels = len(self.detr.transformer.decoder.layers) if self.detr.aux_loss else 1
             targets = PackedTargets([None] * B, cap, torch.zeros(B + 1, dtype=torch.int32, device=dev),
                                     torch.zeros(B * cap, dtype=torch.int64, device=dev),
-                                    torch.zeros(B * cap, 4, dtype=torch.float32, device=dev), torch.ones(1, device=dev))
+                                    torch.zeros(B * cap, 4, dtype=torch.float32, device=dev), torch.ones(1, device=dev),
+                                    levels=levels)
             static = dict(images=images, targets=targets, key=(B, Hp, Wp))
         assert static["key"] == (B, Hp, Wp), (static["key"], (B, Hp, Wp))
         images, targets = static["images"], static["targets"]
@@ -275,6 +277,7 @@ class Detr(nn.Module):
                 targets.tgt_labels[:ntot].copy_(torch.cat(labels))
                 targets.tgt_boxes[:ntot].copy_(torch.cat(boxes))
             targets.tgt_off.copy_(torch.tensor(off, dtype=torch.int32))
+            targets.fill_levels(off, torch.cat(labels) if ntot else None, torch.cat(boxes) if ntot else None)
             nb = torch.tensor([float(ntot)], device=dev)
             world = 1
             if torch.distributed.is_available() and torch.distributed.is_initialized():      # detr.py:616-619

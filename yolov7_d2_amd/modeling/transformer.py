@@ -47,6 +47,10 @@ def _conv1x1(x, w_img, y, T, K, Cout, CoutPad, bias=None, relu=False):
     d.N, d.H, d.W, d.outH, d.outW, d.gridH, d.gridW = 1, H, W, H, W, H, W
     d.in_stride = d.out_stride = 1
     d.K8, d.Cout, d.CoutPad, d.ntaps = K // 8, Cout, CoutPad, 1
+    if T <= 1024 and K >= 1024 and W >= 16 and CoutPad % 64 == 0:
+        # a long reduction over few rows (the decoder's FFN: 400 x 2048 -> 256): 16-row tiles put 4x as many blocks on the
+        # chip as the launcher's 64-row default, each with the same K loop (tools/linear_sweep.py: 25.3 -> 16.2 us)
+        d.TH, d.TW, d.KC, d.BN = 1, 16, 128, 64
     L.check(L.lib().mi_conv2d(C.byref(d), L.stream_ptr()), "mi_conv2d (linear)")
 
 
