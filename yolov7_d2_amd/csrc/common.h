@@ -55,14 +55,28 @@ __device__ __forceinline__ bf16x8 pack8(const float* f) {
 // 1-ulp hardware reciprocal instead of the ~10-instruction IEEE division: the consumers round to bf16 anyway
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
-// counter-based random bits (splitmix64 of seed-keyed index): dropout masks are pure functions of (seed, element index),
-// so a backward kernel recomputes the mask of its forward instead of loading it
-__device__ __forceinline__ unsigned mi_rng32(unsigned long long seed, unsigned long long idx) {
-  unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+// counter-based random bits: dropout masks are pure functions of (seed, element index), so a backward kernel recomputes the
+// mask of its forward instead of loading it.  Two stages: mi_rng_key(seed) - one splitmix64 round, uniform over a launch
+// (scalar ALU, once per thread) - and mi_rng32k(key, idx), the per-element part in 32-bit arithmetic (lowbias32 mixer: two
+// 32-bit multiplies; the high index word only enters through xor / rotate).  Round 4: the first form ran splitmix64 - two
+// 64-bit multiplies, ~8 quarter-rate VALU multiplies - PER ELEMENT, and attention-weight dropout made the encoder's
+// attention kernels 4x slower than without it (80 us vs 19 us forward at L = 1 050: 35 M scores per layer).
+__device__ __forceinline__ unsigned long long mi_rng_key(unsigned long long seed) {
+  unsigned long long z = seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (unsigned)(z >> 32);
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ unsigned mi_rng32k(unsigned long long key, unsigned long long idx) {
+  const unsigned hi = (unsigned)(idx >> 32);
+  unsigned x = (unsigned)idx ^ (unsigned)key ^ hi ^ ((hi << 16) | (hi >> 16));
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x ^ (unsigned)(key >> 32);
+}
+__device__ __forceinline__ unsigned mi_rng32(unsigned long long seed, unsigned long long idx) {
+  return mi_rng32k(mi_rng_key(seed), idx);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -62,11 +62,17 @@ struct MhaK {
   const unsigned long long* seed_off;   // device word added to seed (mi_dropout_seed_offset) or NULL
 };
 
-__device__ __forceinline__ float mha_keep(const MhaK& p, int b, int h, int q, int key) {
+// rk: mha_rng_key(p), taken ONCE at the top of a kernel (the seed word is a uniform load + a 64-bit hash: not per element).
+// The element index is the linear index into [B][H][Lq][Lk] (what mi_mha_dropout_mask enumerates): a uniform 64-bit base
+// per (b, h) plus a 32-bit offset q * Lk + key (the launchers require Lq * Lk < 2^32)
+__device__ __forceinline__ unsigned long long mha_rng_key(const MhaK& p) {
+  return p.drop_thr ? mi_rng_key(p.seed + (p.seed_off ? *p.seed_off : 0ull)) : 0ull;
+}
+__device__ __forceinline__ float mha_keep(const MhaK& p, unsigned long long rk, int b, int h, int q, int key) {
   if (p.drop_thr == 0u) return 1.f;
-  const unsigned long long idx = (((unsigned long long)(b * p.H + h) * p.Lq + q) * p.Lk + key);
-  const unsigned long long seed = p.seed + (p.seed_off ? *p.seed_off : 0ull);   // (uniform scalar load, cached)
-  return mi_rng32(seed, idx) >= p.drop_thr ? p.drop_scale : 0.f;
+  const unsigned long long base = (unsigned long long)(b * p.H + h) * (unsigned long long)p.Lq * (unsigned long long)p.Lk;
+  const unsigned off = (unsigned)q * (unsigned)p.Lk + (unsigned)key;
+  return mi_rng32k(rk, base + off) >= p.drop_thr ? p.drop_scale : 0.f;
 }
 
 // LDS tile of 32 rows x 32 d (64-byte rows), 16-byte chunks XOR-swizzled by (row >> 2) & 3 for the direct b128
@@ -103,6 +109,7 @@ __device__ __forceinline__ bf16x8 frag_cols(const char* T, int j, int t, int g) 
 
 // ------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaK p) {
+  const unsigned long long rk = mha_rng_key(p);
   __shared__ __attribute__((aligned(16))) char Ks[2][2048], Vs[2][2048];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t = lane & 15, g = lane >> 4;
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaK p) {
     for (int e = 0; e < 8; ++e) {
       const float pe = (m_new == -INFINITY) ? 0.f : __expf(sv[e] - m_new);
       psum += pe;           // the softmax normaliser is taken BEFORE the dropout, as F.multi_head_attention_forward does
-      pf[e] = (__bf16)(pe * mha_keep(p, b, h, myq, k0 + 16 * (e >> 2) + 4 * g + (e & 3)));
+      pf[e] = (__bf16)(pe * mha_keep(p, rk, b, h, myq, k0 + 16 * (e >> 2) + 4 * g + (e & 3)));
     }
     psum += __shfl_xor(psum, 16, 64);
     psum += __shfl_xor(psum, 32, 64);
@@ -215,6 +222,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaK p) {
 #define MHA2_KC 128
 template <bool DROP>
 __global__ __launch_bounds__(768) void mha_fwd2_kernel(const MhaK p) {
+  const unsigned long long rk = mha_rng_key(p);
   __shared__ __attribute__((aligned(16))) char Ks[2 * 8192], Vs[2 * 8192];
   __shared__ __attribute__((aligned(16))) float Mb[2][MHA2_KC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nth = blockDim.x;
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(768) void mha_fwd2_kernel(const MhaK p) {
         float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[2 * t2 + (e >> 2)][e & 3], sc2, neg_m));
         if constexpr (DROP) {
           l_part += pe;    // the softmax normaliser is taken BEFORE the dropout, as F.multi_head_attention_forward does
-          pe *= mha_keep(p, b, h, myq, k0 + 32 * t2 + 16 * (e >> 2) + 4 * g + (e & 3));
+          pe *= mha_keep(p, rk, b, h, myq, k0 + 32 * t2 + 16 * (e >> 2) + 4 * g + (e & 3));
         }
         pf[e] = (__bf16)pe;
       }
@@ -374,6 +382,7 @@ __global__ __launch_bounds__(256) void mha_delta_kernel(const MhaK p, float* del
 
 // dQ: same loop structure as the forward (a wave owns 16 queries, streams K/V tiles)
 __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const MhaK p) {
+  const unsigned long long rk = mha_rng_key(p);
   __shared__ __attribute__((aligned(16))) char Ks[2][2048], Vs[2][2048];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t = lane & 15, g = lane >> 4;
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const MhaK p) {
         const int key = k0 + 16 * a + 4 * g + r;
         const bool dead = key >= p.Lk || (p.mask && p.mask[(size_t)b * p.Lk + key]) || myq >= p.Lq;
         const float pe = (dead || lse == -INFINITY) ? 0.f : __expf(s[r] * p.scale - lse);
-        dsf[a * 4 + r] = (__bf16)(pe * (dp[r] * mha_keep(p, b, h, myq, key) - dl) * p.scale);
+        dsf[a * 4 + r] = (__bf16)(pe * (dp[r] * mha_keep(p, rk, b, h, myq, key) - dl) * p.scale);
       }
     }
 #pragma unroll
@@ -434,6 +443,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const MhaK p) {
 
 // dK, dV: a wave owns 16 keys and streams Q / dO tiles
 __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const MhaK p) {
+  const unsigned long long rk = mha_rng_key(p);
   __shared__ __attribute__((aligned(16))) char Qs[2][2048], Ds[2][2048];
   __shared__ float Ls[2][32], Dl[2][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -484,7 +494,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const MhaK p) {
       for (int r = 0; r < 4; ++r) {
         const int ql = 16 * a + 4 * g + r;
         const float pe = kdead ? 0.f : __expf(s[r] * p.scale - Ls[cur][ql]);
-        const float keep = mha_keep(p, b, h, it * 32 + ql, mykey);
+        const float keep = mha_keep(p, rk, b, h, it * 32 + ql, mykey);
         pf[a * 4 + r] = (__bf16)(pe * keep);
         dsf[a * 4 + r] = (__bf16)(pe * (dp[r] * keep - Dl[cur][ql]) * p.scale);
       }
@@ -519,6 +529,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const MhaK p) {
 // dQ: a wave owns 16 queries (as the forward), streams K / V
 template <bool DROP>
 __global__ __launch_bounds__(768) void mha_bwd_dq2_kernel(const MhaK p) {
+  const unsigned long long rk = mha_rng_key(p);
   __shared__ __attribute__((aligned(16))) char Ks[2 * 8192], Vs[2 * 8192];
   __shared__ __attribute__((aligned(16))) float Mb[2][MHA2_KC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nth = blockDim.x;
@@ -597,7 +608,7 @@ __global__ __launch_bounds__(768) void mha_bwd_dq2_kernel(const MhaK p) {
         const int a = 2 * t2 + (e >> 2), r = e & 3;
         const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[a][r], sc2, neg_l));   // (masked key: s = -inf -> 0)
         float ds;
-        if constexpr (DROP) ds = pe * (dp[a][r] * mha_keep(p, b, h, myq, k0 + 16 * a + 4 * g + r) - dl);
+        if constexpr (DROP) ds = pe * (dp[a][r] * mha_keep(p, rk, b, h, myq, k0 + 16 * a + 4 * g + r) - dl);
         else ds = pe * dp[a][r];
         dsf[e] = (__bf16)ds;
       }
@@ -623,6 +634,7 @@ __global__ __launch_bounds__(768) void mha_bwd_dq2_kernel(const MhaK p) {
 // dK, dV: a wave owns 16 keys, streams Q / dO with the queries' -lse * log2(e) and -delta
 template <bool DROP>
 __global__ __launch_bounds__(768) void mha_bwd_dkv2_kernel(const MhaK p) {
+  const unsigned long long rk = mha_rng_key(p);
   __shared__ __attribute__((aligned(16))) char Qs[2 * 8192], Ds[2 * 8192];
   __shared__ __attribute__((aligned(16))) float Nl[2][MHA2_KC], Nd[2][MHA2_KC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nth = blockDim.x;
@@ -713,7 +725,7 @@ __global__ __launch_bounds__(768) void mha_bwd_dkv2_kernel(const MhaK p) {
           for (int r = 0; r < 4; ++r) {
             const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[aa][r], sc2, nl[r]));
             if constexpr (DROP) {
-              const float keep = mha_keep(p, b, h, r0 + 16 * a + 4 * g + r, mykey);
+              const float keep = mha_keep(p, rk, b, h, r0 + 16 * a + 4 * g + r, mykey);
               pf[hh * 4 + r] = (__bf16)(pe * keep);
               dsf[hh * 4 + r] = (__bf16)(pe * (dp[aa][r] * keep + nd[r]));
             } else {
@@ -751,6 +763,7 @@ static int mha_check(const void* q, const void* k, const void* v, int B, int H, 
   MI_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0 && E == H * MHA_D, "mha: E %d must be H*%d (H %d)", E, MHA_D, H);
   MI_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0, "mha: alignment");
   MI_REQUIRE((long long)B * H < 65536, "mha: B*H too large");
+  MI_REQUIRE((long long)Lq * Lk < (1LL << 32), "mha: Lq * Lk must stay below 2^32 (32-bit score offsets inside a head)");
   return MI_OK;
 }
 

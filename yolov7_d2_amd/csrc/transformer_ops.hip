@@ -22,9 +22,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const __bf16* __rest
   float s = 0.f;
   if (res) {
     if (seed_off) seed += *seed_off;
+    const unsigned long long rk = mi_rng_key(seed);
     for (int j = 0; j < per; ++j) {
       const size_t i = (size_t)row * E + lane + 64 * j;
-      const __bf16 d = (__bf16)(mi_rng32(seed, (unsigned long long)i) >= thr ? (float)xr[lane + 64 * j] * dscale : 0.f);
+      const __bf16 d = (__bf16)(mi_rng32k(rk, (unsigned long long)i) >= thr ? (float)xr[lane + 64 * j] * dscale : 0.f);
       const __bf16 t = (__bf16)((float)res[i] + (float)d);
       sum_out[i] = t;
       v[j] = (float)t;
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const __bf16* __rest
   // dx_drop != NULL: also dropout(dx) with the forward's (p, seed) - the gradient of the dropped branch of
   // res + dropout(x) in front of this norm (what mi_dropout_bf16 applied to dx would write)
   if (dx_drop && seed_off) seed += *seed_off;
+  const unsigned long long rk = dx_drop ? mi_rng_key(seed) : 0ull;
   extern __shared__ float sacc[];  // [4 waves][E][2]
   typedef __attribute__((ext_vector_type(PER))) __bf16 bvec;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const __bf16* __rest
       bvec od;
 #pragma unroll
       for (int j = 0; j < PER; ++j)
-        od[j] = (__bf16)(mi_rng32(seed, (unsigned long long)((size_t)row * E + c0 + j)) >= thr ? (float)o[j] * dscale : 0.f);
+        od[j] = (__bf16)(mi_rng32k(rk, (unsigned long long)((size_t)row * E + c0 + j)) >= thr ? (float)o[j] * dscale : 0.f);
       *(bvec*)(dx_drop + (size_t)row * E + c0) = od;
     }
   }
@@ -284,12 +286,13 @@ __global__ __launch_bounds__(256) void dropout_kernel(const __bf16* __restrict__
                                                       int64_t n8, unsigned thr, float scale, unsigned long long seed,
                                                       const unsigned long long* seed_off) {
   if (seed_off) seed += *seed_off;   // (a captured step: the word is advanced once per replay)
+  const unsigned long long rk = mi_rng_key(seed);
   for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
     const bf16x8 v = *(const bf16x8*)(x + i * 8);
     bf16x8 r;
 #pragma unroll
     for (int e = 0; e < 8; ++e)
-      r[e] = (__bf16)(mi_rng32(seed, (unsigned long long)(i * 8 + e)) >= thr ? (float)v[e] * scale : 0.f);
+      r[e] = (__bf16)(mi_rng32k(rk, (unsigned long long)(i * 8 + e)) >= thr ? (float)v[e] * scale : 0.f);
     if (res) {
       const bf16x8 a = *(const bf16x8*)(res + i * 8);
 #pragma unroll
