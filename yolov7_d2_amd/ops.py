@@ -46,7 +46,9 @@ class WeightImages:
     their own launch as before).  The first step RECORDS: every qualifying pack call allocates persistent images, packs
     them with its own launch and registers the job; freeze() uploads the job table; from then on run() re-packs all
     images from the current parameter values and the pack calls return them without a launch.  A call that was not
-    recorded (a layer that did not run in the first step) is served by its own launch."""
+    recorded (a layer that did not run in the first step, or a FrozenBatchNorm factor that was recomputed since - its key
+    carries the factor's address, and the recorded tensor is kept alive so that the address cannot be reused) is served by
+    its own launch: correct, one launch slower."""
     active = None
 
     def __init__(self, params):
