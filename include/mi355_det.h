@@ -97,12 +97,34 @@ typedef struct mi_conv_desc {
   const float* bn_mean;
   const float* bn_invstd;
   int32_t bn_ldy, bn_act;
+  /* BatchNorm(train) + activation of the INPUT, applied by this launch ("BN in the consumer", csrc/conv_bn.h): x is the
+   * RAW output of the producing convolution and xf a DEVICE record (mi_bnx) with that layer's accumulators, parameters and
+   * the activated tensor `a`; the launch derives scale / shift itself, transforms the tiles it fetched in LDS and - when
+   * xf_write - stores a for the tensor's later readers, records scale / shift / mean / invstd and updates the running
+   * statistics: mi_bn_act_fwd(x -> a) followed by this convolution on a, bit for bit, in one launch.  Forward
+   * convolutions with stats_acc on the streaming 1x1 / weight-stationary 3x3 kernels only (mi_conv2d returns MI_EINVAL
+   * otherwise); jobs of one launch that read the same x share the record and exactly one of them sets xf_write. */
+  const void* xf;
+  int32_t xf_write, xf_C;   /* xf_C: the record's channel count (== K8 * 8) */
 } mi_conv_desc;
+
+/* device record behind mi_conv_desc.xf (host-built, uploaded by the caller; all pointers are device pointers) */
+typedef struct mi_bnx {
+  const void* res_unused; void* a;
+  const float* gamma; const float* beta; float* rmean; float* rvar; int64_t* nbt;
+  float* scale; float* shift; float* mean; float* invstd;
+  int32_t ldres_unused, lda, act, pad0_;
+  double inv_count, unbias;
+  float eps, momentum;
+  const double* acc;        /* the producer's fp64 (sum, sumsq) accumulators [nslots][sld / 2][2] */
+  int32_t sld, nslots, C, pad1_;
+} mi_bnx;
 
 int mi_conv2d(const mi_conv_desc* d, mi_stream_t s);
 /* fills TH/TW/KC/BN/TPS if zero; returns number of pixel tiles or <0 */
 int mi_conv2d_plan(mi_conv_desc* d);
-/* the kernel family mi_conv2d runs for this descriptor: 0 tile kernel (conv_igemm), 1 mi_conv1x1_stream, 2 mi_conv3x3_ws */
+/* the kernel family mi_conv2d runs for this descriptor: 0 tile kernel (conv_igemm), 1 mi_conv1x1_stream, 2 mi_conv3x3_ws;
+ * -1 when the descriptor carries an input BatchNorm (xf) and neither 1 nor 2 applies (mi_conv2d would refuse it) */
 int mi_conv2d_route(const mi_conv_desc* d);
 
 /* several independent convolutions in ONE launch (the FPN levels of the head: the 40x40 / 20x20 launches are

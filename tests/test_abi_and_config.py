@@ -44,7 +44,7 @@ def test_struct_sizes_match_c():
 def test_struct_layouts_match_the_loaded_library():
     """every public struct: ctypes.sizeof == the C compiler's sizeof inside the library that was loaded"""
     names = ["mi_conv_desc", "mi_wgrad_desc", "mi_wgrad_group", "mi_pack_job", "mi_bias_job", "mi_yolox_loss_desc",
-             "mi_detr_loss_desc", "mi_sgd_seg", "mi_cmd", "mi_conv_group", "mi_bn_job", "mi_bn_group", "mi_pil_resize_job", "mi_jpeg_info", "mi_jpeg_job"]
+             "mi_detr_loss_desc", "mi_sgd_seg", "mi_cmd", "mi_conv_group", "mi_bn_job", "mi_bn_group", "mi_pil_resize_job", "mi_jpeg_info", "mi_jpeg_job", "mi_bnx"]
     lib = L.lib()
     for i, n in enumerate(names):
         assert lib.mi_abi_sizeof(i) == C.sizeof(getattr(L, n)), n

@@ -24,9 +24,10 @@ def load(tag):
     return out, span
 
 
-def commands():
+def commands(tag=None):
     cmds = []
-    for l in open(os.path.join(ROOT, "gpurun_out", "tags.txt")):
+    per_tag = os.path.join(ROOT, "gpurun_out", f"tags_{tag}.txt")
+    for l in open(per_tag if tag and os.path.exists(per_tag) else os.path.join(ROOT, "gpurun_out", "tags.txt")):
         if l.startswith(("fwd", "bwd")):
             p = l.rstrip("\n").split(None, 4)
             cmds.append((p[0], p[2], p[3], p[4] if len(p) > 4 else ""))
@@ -37,7 +38,7 @@ def commands():
 
 def join(tag):
     disp, span = load(tag)
-    cmds = commands()
+    cmds = commands(tag)
     fixed = sum(NDISP.get(c[1], 1) or 0 for c in cmds if c[1] != "WGRAD_GROUP")
     nwg = len(disp) - fixed
     out, i = [], 0

@@ -41,6 +41,20 @@ class mi_conv_desc(C.Structure):
         ("stats_slots", C.c_int32), ("TPS", C.c_int32),
         ("bn_y", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p), ("bn_mean", C.c_void_p),
         ("bn_invstd", C.c_void_p), ("bn_ldy", C.c_int32), ("bn_act", C.c_int32),
+        ("xf", C.c_void_p), ("xf_write", C.c_int32), ("xf_C", C.c_int32),
+    ]
+
+
+class mi_bnx(C.Structure):
+    """device record behind mi_conv_desc.xf: BatchNorm(train) + activation of a convolution's INPUT applied by the
+    consuming launch (csrc/conv_bn.h BnXf)"""
+    _fields_ = [
+        ("res_unused", C.c_void_p), ("a", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("rmean", C.c_void_p), ("rvar", C.c_void_p), ("nbt", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+        ("mean", C.c_void_p), ("invstd", C.c_void_p),
+        ("ldres_unused", C.c_int32), ("lda", C.c_int32), ("act", C.c_int32), ("pad0_", C.c_int32),
+        ("inv_count", C.c_double), ("unbias", C.c_double), ("eps", C.c_float), ("momentum", C.c_float),
+        ("acc", C.c_void_p), ("sld", C.c_int32), ("nslots", C.c_int32), ("C", C.c_int32), ("pad1_", C.c_int32),
     ]
 
 

@@ -23,6 +23,8 @@
 // BatchNorm(train) + SiLU (+ residual) of the block's OWN output tiles (conv_bn.h): scale / shift come from the finished
 // fp64 sums, every lane re-reads the 16-byte pieces it stored itself (same CU, same L2: no cross-XCD coherence needed) and
 // writes the activation.  The whole BaseConv forward (layers/wrappers.py:76-83) in one launch.
+// XF 1 (with MODE 1): x is the RAW output of the producing convolution; its BatchNorm(train) + SiLU runs here, on the x tile
+// in LDS, by the wave that fetched the piece (conv_bn.h, BnXf); the blocks of cout tile 0 store the activated tile.
 #pragma once
 #include "common.h"
 #include "conv_bn.h"
@@ -42,9 +44,11 @@ struct C1K {
   int xcd_order, dbg;         // dbg & 1: skip the statistics atomics (timing experiments only).  xcd_order 1: block id = cot * nb + b (cout tiles of a pixel tile share an XCD), 0: b * nco + cot
   C1Slice s[C1_MAX_SLICES];
   CBnFwd bn[C1_MAX_BN];       // MODE 3
+  const BnXf* xf;             // XF launches: BatchNorm + activation of the input (device record)
+  int xfw, pad_;              // xfw: store the activated input (cout tile 0's blocks do it)
 };
 struct C1Launch {
-  int K, WM, PT, NBUF, MODE, grid, lds;
+  int K, WM, PT, NBUF, MODE, grid, lds, XF;
   C1K k;
 };
 
@@ -62,8 +66,9 @@ __device__ __forceinline__ void c1_glds16(const void* sbase, unsigned voff, unsi
                : "memory");
 }
 
-template <int K, int WM, int WN, int PT, int NBUF, int MODE>
+template <int K, int WM, int WN, int PT, int NBUF, int MODE, int XF = 0>
 __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
+  static_assert(!XF || MODE == 1, "the input transform comes with the forward (statistics) mode");
   constexpr int NW = WM * WN, TPIX = WN * PT * 32, KC8 = K / 8, KS = K / 16, R = K * 2;
   constexpr int XB = TPIX * R;              // bytes of one x tile
   constexpr int D = XB / (1024 * NW);       // LDS-DMA instructions per wave and tile
@@ -79,6 +84,13 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
   constexpr int W2 = NBUF > 3 ? (NBUF - 2) * D + 2 * (S + L) + L : (NBUF - 2) * D + (NBUF - 1) * (S + L);
   constexpr int W3 = (NBUF - 2) * D + (NBUF - 1) * (S + L);
   static_assert(W3 < 64 && W2 < 64, "vmcnt field");
+  // XF, writer blocks: D stores of the activated tile per iteration, issued between the wait and the tile's barrier (queue
+  // per iteration: SIDE, DMA, ST).  Newer than tile i's DMA at iteration i: i <= NBUF - 2 (DMA issued in the preamble):
+  // (NBUF - 2 - i) D + i (2 D + S); later: (NBUF - 1) S + (NBUF - 2) 2 D
+  constexpr int X1 = NBUF > 2 ? (NBUF - 3) * D + (2 * D + S) : S;
+  constexpr int X2 = NBUF > 3 ? (NBUF - 4) * D + 2 * (2 * D + S) : (NBUF - 1) * S + (NBUF - 2) * 2 * D;
+  constexpr int X3 = (NBUF - 1) * S + (NBUF - 2) * 2 * D;
+  static_assert(!XF || (X3 < 64 && X2 < 64 && X1 < 64), "vmcnt field");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -148,6 +160,19 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
 #pragma unroll
   for (int i = 0; i < NBUF - 1; ++i) issue_x(i, i);
 
+  // XF: (scale, shift) tables of the K input channels behind the ring; block 0 records the layer's statistics
+  float* const s_sc = (float*)(smem + NBUF * XB);
+  float* const s_sh = s_sc + K;
+  int xf_act = 0, xf_ldab = 0;
+  char* xf_a = nullptr;
+  if constexpr (XF) {
+    bnx_tables(p.xf, s_sc, s_sh, NW * 64, blockIdx.x == 0);
+    xf_act = p.xf->bn.act;
+    xf_ldab = p.xf->bn.lda * 2;
+    xf_a = (p.xfw && cot == 0) ? (char*)p.xf->bn.a : nullptr;
+    __syncthreads();
+  }
+
   int buf = 0, nbuf = NBUF - 1;   // ring slots of tile i / tile i + NBUF - 1
   for (int i = 0; i < nt; ++i) {
     char* const yt = (char*)sl.y + (size_t)(b + i * nb) * ytile;
@@ -159,10 +184,33 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=v"(old[j * 2 + 1]) : "v"(yoff[j]), "s"(yt) : "memory");
       }
     }
-    if (i == 0) C1_VMCNT(W0);
-    else if (i == 1) C1_VMCNT(W1);
-    else if (i == 2) C1_VMCNT(W2);
-    else C1_VMCNT(W3);
+    if (XF && xf_a) {
+      if (i == 0) C1_VMCNT(W0);
+      else if (i == 1) C1_VMCNT(X1);
+      else if (i == 2) C1_VMCNT(X2);
+      else C1_VMCNT(X3);
+    } else {
+      if (i == 0) C1_VMCNT(W0);
+      else if (i == 1) C1_VMCNT(W1);
+      else if (i == 2) C1_VMCNT(W2);
+      else C1_VMCNT(W3);
+    }
+    if constexpr (XF) {
+      // BatchNorm + SiLU of the pieces this wave fetched itself, in place: lane (row, slot c) holds channel group
+      // c ^ swz(row) of pixel row (the source-side permutation of doff[])
+      char* const Xw = smem + buf * XB;
+      char* const at = xf_a + (size_t)(b + i * nb) * ((size_t)TPIX * (size_t)xf_ldab);
+#pragma unroll 2
+      for (int d = 0; d < D; ++d) {
+        const int q = wave * D + d;
+        const int row = q * RPI + (KC8 >= 64 ? 0 : lane / KC8);
+        const int c = KC8 >= 64 ? lane : lane % KC8;
+        const int cg = c ^ ((row >> RBSH) & SWM);
+        const u32x4 o = bnx_apply_lds(Xw + q * 1024 + lane * 16, s_sc, s_sh, cg, xf_act, true);
+        if (xf_a) *(u32x4*)(at + (unsigned)(row * xf_ldab + cg * 16)) = o;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();   // tile i landed (every wave's share); slot nbuf is no longer read by anyone
     issue_x(i + NBUF - 1, nbuf);
 
@@ -317,9 +365,9 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
   }
 }
 
-template <int K, int WM, int WN, int PT, int NBUF, int MODE>
+template <int K, int WM, int WN, int PT, int NBUF, int MODE, int XF = 0>
 static int c1s_launch_one(const C1Launch& l, hipStream_t s) {
-  auto fn = c1s_kernel<K, WM, WN, PT, NBUF, MODE>;
+  auto fn = c1s_kernel<K, WM, WN, PT, NBUF, MODE, XF>;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -338,17 +386,17 @@ constexpr bool c1s_valid(int K, int tpix) {
   return (tpix * K * 2) % 8192 == 0 && tpix * K * 2 * c1s_nbuf(K, tpix) <= 160 * 1024;
 }
 
-template <int K, int MODE>
+template <int K, int MODE, int XF = 0>
 static int c1s_launch_k(const C1Launch& l, hipStream_t s) {
   if constexpr (c1s_valid(K, 128)) {
-    if (l.WM == 4 && l.PT == 2) return c1s_launch_one<K, 4, 2, 2, c1s_nbuf(K, 128), MODE>(l, s);
-    if (l.WM == 2 && l.PT == 1) return c1s_launch_one<K, 2, 4, 1, c1s_nbuf(K, 128), MODE>(l, s);
+    if (l.WM == 4 && l.PT == 2) return c1s_launch_one<K, 4, 2, 2, c1s_nbuf(K, 128), MODE, XF>(l, s);
+    if (l.WM == 2 && l.PT == 1) return c1s_launch_one<K, 2, 4, 1, c1s_nbuf(K, 128), MODE, XF>(l, s);
   }
   if constexpr (c1s_valid(K, 64)) {
-    if (l.WM == 4 && l.PT == 1) return c1s_launch_one<K, 4, 2, 1, c1s_nbuf(K, 64), MODE>(l, s);
+    if (l.WM == 4 && l.PT == 1) return c1s_launch_one<K, 4, 2, 1, c1s_nbuf(K, 64), MODE, XF>(l, s);
   }
   if constexpr (c1s_valid(K, 256)) {
-    if (l.WM == 1 && l.PT == 1) return c1s_launch_one<K, 1, 8, 1, c1s_nbuf(K, 256), MODE>(l, s);
+    if (l.WM == 1 && l.PT == 1) return c1s_launch_one<K, 1, 8, 1, c1s_nbuf(K, 256), MODE, XF>(l, s);
   }
   MI_FAIL(MI_EINVAL, "conv1x1_stream: no kernel for K %d WM %d PT %d", K, l.WM, l.PT);
 }

@@ -8,6 +8,7 @@
 
 int c1s_launch_mode0(const C1Launch& l, hipStream_t s);
 int c1s_launch_mode1(const C1Launch& l, hipStream_t s);
+int c1s_launch_mode1x(const C1Launch& l, hipStream_t s);
 int c1s_launch_mode2(const C1Launch& l, hipStream_t s);
 int c1s_launch_mode3(const C1Launch& l, hipStream_t s);
 int c1s_bar_status(unsigned* flag);
@@ -74,6 +75,7 @@ static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l, const mi_bn_job
     if (!c1s_desc_ok(&d)) return false;
     if (d.x != d0.x || d.ldx != d0.ldx || d.N != d0.N || d.H != d0.H || d.W != d0.W || d.K8 != d0.K8) return false;
     if ((d.flags & MI_CONV_ACCUM) != (d0.flags & MI_CONV_ACCUM) || (d.stats_acc != nullptr) != (d0.stats_acc != nullptr)) return false;
+    if (d.xf != d0.xf || (d.xf && (d.xf_C != d.K8 * 8 || ((uintptr_t)d.xf & 7)))) return false;   // one input tensor, one record
     ns += d.Cout / 32;
   }
   if (ns > C1_MAX_SLICES) return false;
@@ -97,10 +99,17 @@ static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l, const mi_bn_job
     if (l->MODE != 1) return false;
     l->MODE = 3;
   }
-  l->lds = l->NBUF * tpix * K * 2;
+  // BatchNorm + activation of the input inside this launch (conv_bn.h, BnXf): forward-with-statistics launches only
+  const bool xf = d0.xf != nullptr;
+  if (xf && (l->MODE != 1 || bn)) return false;
+  l->XF = xf ? 1 : 0;
+  l->lds = l->NBUF * tpix * K * 2 + (xf ? 2 * K * 4 : 0);
+  if (l->lds > 160 * 1024) return false;
   C1K& k = l->k;
   k.x = (const __bf16*)d0.x;
   k.ldx = d0.ldx;
+  k.xf = (const BnXf*)d0.xf;
+  for (int j = 0; j < n; ++j) k.xfw |= (xf && ds[j].xf_write) ? 1 : 0;
   k.ntiles = (int)(npix / tpix);
   k.nco = nco;
   // persistent grid: as many blocks as are resident at once (LDS-limited, at most 2 per CU), never more than tiles
@@ -142,7 +151,7 @@ static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l, const mi_bn_job
 static int c1s_run(const C1Launch& l, hipStream_t s) {
   switch (l.MODE) {
     case 0: return c1s_launch_mode0(l, s);
-    case 1: return c1s_launch_mode1(l, s);
+    case 1: return l.XF ? c1s_launch_mode1x(l, s) : c1s_launch_mode1(l, s);
     case 3: return c1s_launch_mode3(l, s);
     default: return c1s_launch_mode2(l, s);
   }

@@ -22,6 +22,9 @@
 // MODE 0: plain, 1: + BatchNorm statistics, 2: y += result, 3: MODE 1 and then, behind a grid barrier, BatchNorm(train) +
 // SiLU (+ residual) of the block's own output tiles (conv_bn.h; see conv1x1_stream.h MODE 3): conv2 + bn + act + shortcut
 // of a Bottleneck (layers/wrappers.py:119-123) in one launch.
+// XF 1 (with MODE 1): the job's input x is the RAW output of the producing convolution; the BatchNorm(train) + SiLU that
+// BaseConv applies to it (wrappers.py:76-83) runs here, on the halo in LDS, by the wave that fetched the piece (conv_bn.h,
+// BnXf): no bn_act_fwd launch, y is read once instead of y + a; the writer job stores the activated interior pixels.
 #pragma once
 #include "common.h"
 #include "conv_bn.h"
@@ -54,14 +57,15 @@ struct W3Job {
   int tw[9];                                       // weight slab of tap position t = (dy + 1) * 3 + (dx + 1)
   int inH;                                         // input map height (= H for stride 1; input width = inW)
   CBnFwd bn;                                       // MODE 3
-  int inW, pad3_;
+  int inW, xfw;                                    // xfw: this job stores the activated input (XF launches; one job per input tensor)
+  const BnXf* xf;                                  // XF launches: the BatchNorm + activation of this job's INPUT (device record)
 };
 struct W3K {
   int njobs, dbg;
   W3Job j[W3_MAX_JOBS];
 };
 struct W3Launch {
-  int K, MODE, grid, lds, S, pad_;
+  int K, MODE, grid, lds, S, XF;
   W3K k;
 };
 
@@ -79,8 +83,9 @@ __device__ __forceinline__ void w3_glds16(const void* g, unsigned lds_off) {
 // the LDS-DMA of tile i + 1's halo, the stores of tile i - 1's (already converted, packed) outputs and, in the accumulate
 // mode, the loads of tile i's old values.  Issued in one burst at the tile boundary, those 20-28 KB per wave run at the
 // chip's HBM rate with every CU in the same phase and the matrix pipes idle (measured: 2 + 2 us per 3.8 us tile).
-template <int K, int WM, int WN, int G, int MODE, int S = 1, int TH = 8>
+template <int K, int WM, int WN, int G, int MODE, int S = 1, int TH = 8, int XF = 0>
 __global__ __launch_bounds__(WM* WN * 64, (K == 128 || (S == 2 && K == 64)) ? 1 : 2) void w3_kernel(const W3K p) {
+  static_assert(!XF || MODE == 1, "the input transform comes with the forward (statistics) mode");
   constexpr int NW = WM * WN, KC8 = K / 8, KS = K / 16;
   using Geo = W3Geo<S, TH>;
   constexpr int W3_TH = TH, W3_HW = Geo::HW, W3_HPIX = Geo::HPIX, W3_HROWS = Geo::HROWS;
@@ -128,6 +133,19 @@ __global__ __launch_bounds__(WM* WN * 64, (K == 128 || (S == 2 && K == 64)) ? 1 
   char* const ybase = (char*)jb.y;
   const char* zpage = (const char*)g_w3_zero_page;
   asm volatile("" : "+s"(zpage));   // (pinned: its address otherwise comes from the GOT, one s_load per DMA instruction)
+  // XF: (scale, shift) tables of the K input channels behind the halo ring and the per-lane sums; block 0 of the writer job
+  // records the layer's statistics.  (The table loads go out before the weight loads below: both wait on L2 together.)
+  float* const s_sc = (float*)(smem + 2 * (K / 8) * Geo::HROWS * 16 + 256 * 32 * 4);
+  float* const s_sh = s_sc + K;
+  int xf_act = 0, xf_ldab = 0;
+  char* xf_a = nullptr;
+  if constexpr (XF) {
+    const BnXf* const xf = jb.xf;
+    bnx_tables(xf, s_sc, s_sh, NW * 64, jb.xfw != 0 && b == 0);
+    xf_act = xf->bn.act;
+    xf_ldab = xf->bn.lda * 2;
+    xf_a = jb.xfw ? (char*)xf->bn.a : nullptr;
+  }
 
   // ---- weights: this wave's 32 output channels x 9 taps x K, resident in registers
   bf16x8 a[9][KS];
@@ -206,6 +224,28 @@ __global__ __launch_bounds__(WM* WN * 64, (K == 128 || (S == 2 && K == 64)) ? 1 
   for (int q = 0; q < NST; ++q) pk[q] = u32x4{0u, 0u, 0u, 0u};
   for (int i = 0; i < nt; ++i) {
     W3_VMCNT(0);                    // this wave's share of halo i (issued >= a third of a tile ago)
+    if constexpr (XF) {
+      // BatchNorm + SiLU of the pieces this wave fetched itself, in place (same q -> (pixel block, plane) map as issue_x1);
+      // pixels outside the map stay zero; the writer job stores the tile's interior to the activated tensor
+      if (i == 0) __syncthreads();   // the tables
+      const int iy0 = S * oc.ty0 - 1, ix0 = S * oc.tx0 - 1;
+      char* const Xw = smem + (i & 1) * XB;
+      char* const at = xf_a + ((size_t)oc.img * inH * inW + (ptrdiff_t)iy0 * inW + ix0) * (ptrdiff_t)xf_ldab;
+#pragma unroll 2
+      for (int d = 0; d < D; ++d) {
+        const int q = wave * D + d;
+        const int pb = q / KC8, k8 = q % KC8;
+        const int pix = pb * 64 + lane;
+        const int hy = S == 1 ? (int)(((unsigned)pix * 3641u) >> 16) : (int)(((unsigned)pix * 1986u) >> 16);
+        const int hp = pix - hy * W3_HW;
+        const int hx = S == 1 ? hp : (hp <= W3_TW ? 2 * hp : 2 * (hp - (W3_TW + 1)) + 1);
+        const bool v = (pix < W3_HPIX) & ((unsigned)(iy0 + hy) < (unsigned)inH) & ((unsigned)(ix0 + hx) < (unsigned)inW);
+        const u32x4 o = bnx_apply_lds(Xw + k8 * PLANE + pb * 1024 + lane * 16, s_sc, s_sh, k8, xf_act, v);
+        const bool inner = v & (hy >= 1) & (hy <= S * W3_TH) & (hx >= 1) & (hx <= S * W3_TW);
+        if (xf_a && inner) *(u32x4*)(at + (unsigned)((hy * inW + hx) * xf_ldab + k8 * 16)) = o;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();   // halo i complete; the other buffer is no longer read
     const bool more = (i + 1 < nt) & !(p.dbg & 2);
     const bool prev = i > 0;
@@ -441,9 +481,9 @@ __global__ __launch_bounds__(WM* WN * 64, (K == 128 || (S == 2 && K == 64)) ? 1 
   }
 }
 
-template <int K, int WM, int WN, int G, int MODE, int S = 1, int TH = 8>
+template <int K, int WM, int WN, int G, int MODE, int S = 1, int TH = 8, int XF = 0>
 static int w3_launch_one(const W3Launch& l, hipStream_t s) {
-  auto fn = w3_kernel<K, WM, WN, G, MODE, S, TH>;
+  auto fn = w3_kernel<K, WM, WN, G, MODE, S, TH, XF>;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -456,22 +496,22 @@ static int w3_launch_one(const W3Launch& l, hipStream_t s) {
 // output rows of a tile / output channels of a block for (stride, K)
 constexpr int w3_tile_h(int S, int K) { return S == 1 ? 8 : (K == 128 ? 2 : 4); }
 constexpr int w3_block_cout(int S, int K) { return S == 1 ? K : (K == 32 ? 64 : 128); }
-template <int MODE>
+template <int MODE, int XF = 0>
 static int w3_launch_mode(const W3Launch& l, hipStream_t s) {
   if (l.S == 2) {
     if constexpr (MODE == 1 || MODE == 0) {
       switch (l.K) {
-        case 128: return w3_launch_one<128, 4, 1, 1, MODE, 2, 2>(l, s);
-        case 64: return w3_launch_one<64, 4, 1, 2, MODE, 2, 4>(l, s);
-        case 32: return w3_launch_one<32, 2, 2, 1, MODE, 2, 4>(l, s);
+        case 128: return w3_launch_one<128, 4, 1, 1, MODE, 2, 2, XF>(l, s);
+        case 64: return w3_launch_one<64, 4, 1, 2, MODE, 2, 4, XF>(l, s);
+        case 32: return w3_launch_one<32, 2, 2, 1, MODE, 2, 4, XF>(l, s);
       }
     }
     MI_FAIL(MI_EINVAL, "conv3x3_ws: stride 2 with K %d / mode %d", l.K, MODE);
   }
   switch (l.K) {
-    case 128: return w3_launch_one<128, 4, 1, 4, MODE>(l, s);
-    case 64: return w3_launch_one<64, 2, 2, 2, MODE>(l, s);
-    case 32: return w3_launch_one<32, 1, 4, 1, MODE>(l, s);
+    case 128: return w3_launch_one<128, 4, 1, 4, MODE, 1, 8, XF>(l, s);
+    case 64: return w3_launch_one<64, 2, 2, 2, MODE, 1, 8, XF>(l, s);
+    case 32: return w3_launch_one<32, 1, 4, 1, MODE, 1, 8, XF>(l, s);
   }
   MI_FAIL(MI_EINVAL, "conv3x3_ws: K %d", l.K);
 }

@@ -8,6 +8,7 @@
 
 int w3_launch_mode0(const W3Launch& l, hipStream_t s);
 int w3_launch_mode1(const W3Launch& l, hipStream_t s);
+int w3_launch_mode1x(const W3Launch& l, hipStream_t s);
 int w3_launch_mode2(const W3Launch& l, hipStream_t s);
 int w3_launch_mode3(const W3Launch& l, hipStream_t s);
 int w3_mode3_blocks_per_cu(int K, int lds);
@@ -66,9 +67,13 @@ static bool w3_fill(const mi_conv_desc* ds, int n, W3Launch* l, const mi_bn_job*
   const int K = ds[0].K8 * 8, S = ds[0].in_stride;
   if (bn && ((ds[0].flags & MI_CONV_ACCUM) || !ds[0].stats_acc || S != 1)) return false;
   const int mode = (ds[0].flags & MI_CONV_ACCUM) ? 2 : (ds[0].stats_acc ? (bn ? 3 : 1) : 0);
+  // BatchNorm + activation of the INPUT inside this launch (conv_bn.h, BnXf): forward-with-statistics launches only, every
+  // job carries its record (jobs over one input tensor share it; exactly one of them has xf_write)
+  const bool xf = ds[0].xf != nullptr;
+  if (xf && mode != 1) return false;
   const int TH = w3_tile_h(S, K);
   const int hrows = ((S == 1 ? (TH + 2) * (W3_TW + 2) : (2 * TH + 1) * (2 * W3_TW + 1)) + 63) / 64 * 64;
-  const int lds = 2 * (K / 8) * hrows * 16 + ((mode == 1 || mode == 3) ? 256 * 32 * 4 : 0);   // halo ring (+ per-lane BatchNorm sums)
+  const int lds = 2 * (K / 8) * hrows * 16 + ((mode == 1 || mode == 3) ? 256 * 32 * 4 : 0) + (xf ? 2 * K * 4 : 0);   // halo ring (+ per-lane BatchNorm sums) (+ input scale / shift)
   long long total = 0;
   int nj = 0;
   for (int j = 0; j < n; ++j) {
@@ -76,6 +81,7 @@ static bool w3_fill(const mi_conv_desc* ds, int n, W3Launch* l, const mi_bn_job*
     int tw[9];
     if (!w3_desc_ok(&d, tw) || d.K8 * 8 != K || d.in_stride != S) return false;
     if ((d.flags & MI_CONV_ACCUM) != (ds[0].flags & MI_CONV_ACCUM) || (d.stats_acc != nullptr) != (ds[0].stats_acc != nullptr)) return false;
+    if ((d.xf != nullptr) != xf || (xf && (d.xf_C != K || ((uintptr_t)d.xf & 7)))) return false;
     // a block computes w3_block_cout output channels: a wider convolution (stride 2: K -> 2 K) is that many jobs over one input
     const int bc = w3_block_cout(S, K);
     for (int c0 = 0; c0 < d.Cout; c0 += bc, ++nj) {
@@ -92,6 +98,8 @@ static bool w3_fill(const mi_conv_desc* ds, int n, W3Launch* l, const mi_bn_job*
       jb.sld = d.CoutPad * 2;
       total += jb.ntiles;
       if (bn && !cbn_from_job(d, bn[j], &jb.bn)) return false;
+      jb.xf = (const BnXf*)d.xf;
+      jb.xfw = (xf && d.xf_write && c0 == 0) ? 1 : 0;
     }
   }
   n = nj;
@@ -142,6 +150,7 @@ static bool w3_fill(const mi_conv_desc* ds, int n, W3Launch* l, const mi_bn_job*
   l->K = K;
   l->S = S;
   l->MODE = mode;
+  l->XF = xf ? 1 : 0;
   l->grid = blk;
   l->lds = lds;
   return true;
@@ -150,7 +159,7 @@ static bool w3_fill(const mi_conv_desc* ds, int n, W3Launch* l, const mi_bn_job*
 static int w3_run(const W3Launch& l, hipStream_t s) {
   switch (l.MODE) {
     case 0: return w3_launch_mode0(l, s);
-    case 1: return w3_launch_mode1(l, s);
+    case 1: return l.XF ? w3_launch_mode1x(l, s) : w3_launch_mode1(l, s);
     case 3: return w3_launch_mode3(l, s);
     default: return w3_launch_mode2(l, s);
   }

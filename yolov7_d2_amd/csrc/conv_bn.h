@@ -131,3 +131,73 @@ __device__ __forceinline__ u32x4 cbn_apply8(const u32x4 yv, const float* sc, con
   }
   return __builtin_bit_cast(u32x4, pack8(o));
 }
+
+// ---- BatchNorm(train) + activation of a convolution's INPUT, applied by the consuming launch ("BN in the consumer")
+// The producer left the raw output y and its fp64 (sum, sumsq) accumulators; instead of a bn_act_fwd launch that reads y
+// and writes a = act(y * scale + shift), the consumer fetches y tiles (LDS-DMA), every wave rewrites the 16-byte pieces it
+// fetched itself IN LDS with cbn_apply8 (the expression and the rounding point of bn_act_fwd_body: the fragments the
+// matrix cores see are bit-identical to the two-launch form) and the launch's writer job stores the same values to `a`
+// for the later readers of the tensor (weight gradient, residuals, pooling).  BaseConv.forward's norm + act
+// (yolov7/modeling/backbone/layers/wrappers.py:76-83) without a launch of its own and without re-reading y.
+struct BnXf {
+  CBnFwd bn;           // gamma .. invstd, running statistics, eps / momentum / counts; a / lda: the activated tensor; res unused
+  const double* acc;   // the producer's accumulators [nslots][sld / 2][2]
+  int sld, nslots, C, pad_;
+};
+static_assert(sizeof(BnXf) == sizeof(mi_bnx) && __builtin_offsetof(BnXf, acc) == __builtin_offsetof(mi_bnx, acc) &&
+              __builtin_offsetof(BnXf, bn.inv_count) == __builtin_offsetof(mi_bnx, inv_count) &&
+              __builtin_offsetof(BnXf, bn.lda) == __builtin_offsetof(mi_bnx, lda), "mi_bnx (include/mi355_det.h) mirrors BnXf");
+// every block: (scale, shift) of all C input channels into LDS tables - the arithmetic of bn_act_fwd_body's prologue, bit for
+// bit, with ITS loads: plain 16-byte loads, thread c next to thread c + 1 (the sums were completed by the previous launch;
+// cbn_finalize's agent-scope 8-byte atomic loads are for readers BEHIND a grid barrier and cost one L2 request each: with
+// every block of a launch asking for the same C x nslots x 16 bytes they took ~9 us of a 512-channel 20x20 launch).
+// `rec`: this block also records scale / shift / mean / invstd for the backward pass and updates the running statistics
+__device__ __forceinline__ void bnx_tables(const BnXf* __restrict__ xf, float* s_sc, float* s_sh, const int nthreads, const bool rec) {
+  const int C = xf->C, nslots = xf->nslots;
+  const size_t sld2 = (size_t)(xf->sld >> 1);   // f64x2 elements between slots
+  const CBnFwd& bn = xf->bn;
+  for (int c = threadIdx.x; c < C; c += nthreads) {
+    const f64x2* const ap = (const f64x2*)xf->acc + c;
+    f64x2 v[MI_BN_SLOTS];
+#pragma unroll
+    for (int k = 0; k < MI_BN_SLOTS; ++k) v[k] = ap[(k < nslots ? (size_t)k : 0) * sld2];   // (unconditional: all in flight together)
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < MI_BN_SLOTS; ++k) {
+      s1 += k < nslots ? v[k][0] : 0.0;
+      s2 += k < nslots ? v[k][1] : 0.0;
+    }
+    const double mean = s1 * bn.inv_count;
+    double var = s2 * bn.inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)bn.eps);
+    const float g = bn.gamma[c], b = bn.beta[c];
+    const float sc = (float)((double)g * invstd);
+    const float sh = (float)((double)b - mean * (double)g * invstd);
+    s_sc[c] = sc;
+    s_sh[c] = sh;
+    if (rec) {
+      bn.scale[c] = sc;
+      bn.shift[c] = sh;
+      bn.mean[c] = (float)mean;
+      bn.invstd[c] = (float)invstd;
+      if (bn.rmean) {
+        bn.rmean[c] = (1.f - bn.momentum) * bn.rmean[c] + bn.momentum * (float)mean;
+        bn.rvar[c] = (1.f - bn.momentum) * bn.rvar[c] + bn.momentum * (float)(var * bn.unbias);
+      }
+      if (c == 0 && bn.nbt) *bn.nbt += 1;
+    }
+  }
+}
+// one 16-byte piece (8 channels cg * 8 .. of one pixel), in place; returns what it wrote
+__device__ __forceinline__ u32x4 bnx_apply_lds(char* sp, const float* s_sc, const float* s_sh, const int cg, const int act, const bool valid) {
+  const u32x4 raw = *(const u32x4*)sp;
+  const f32x4 c0 = *(const f32x4*)(s_sc + cg * 8), c1 = *(const f32x4*)(s_sc + cg * 8 + 4);
+  const f32x4 h0 = *(const f32x4*)(s_sh + cg * 8), h1 = *(const f32x4*)(s_sh + cg * 8 + 4);
+  const float sc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+  const float sh[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+  u32x4 o = cbn_apply8(raw, sc, sh, act, false, u32x4{0u, 0u, 0u, 0u});
+  if (!valid) o = u32x4{0u, 0u, 0u, 0u};   // zero padding stays zero (act(shift) is not)
+  *(u32x4*)sp = o;
+  return o;
+}

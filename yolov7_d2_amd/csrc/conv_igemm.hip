@@ -264,7 +264,7 @@ extern "C" int mi_conv2d_route(const mi_conv_desc* d) {
   if (c1s_try_plan(d, 1, &cl)) return 1;
   W3Launch wl;
   if (w3_try_plan(d, 1, &wl)) return 2;
-  return 0;
+  return d->xf ? -1 : 0;   // (no kernel applies the input BatchNorm on the tile path: -1 without an error record)
 }
 
 extern "C" int mi_conv2d_plan(mi_conv_desc* d) {
@@ -283,6 +283,7 @@ extern "C" int mi_conv2d(const mi_conv_desc* d, mi_stream_t st) {
     if (d && c1s_try_launch(d, 1, (hipStream_t)st, &rc)) return rc;
     if (d && w3_try_launch(d, 1, (hipStream_t)st, &rc)) return rc;
   }
+  MI_REQUIRE(!d || !d->xf, "conv: the BatchNorm of the input (xf) runs on the streaming 1x1 / weight-stationary 3x3 kernels only");
   ConvK k;
   ConvCfg c;
   size_t lds;
@@ -344,6 +345,8 @@ extern "C" int mi_conv2d_group_plan(const mi_conv_desc* descs, int n, void* tabl
       return MI_OK;
     }
   }
+  for (int j = 0; j < n; ++j)
+    MI_REQUIRE(!descs[j].xf, "conv_group_plan: the BatchNorm of the input (xf) runs on the streaming 1x1 / weight-stationary 3x3 kernels only");
   // the job with the most output pixels picks the configuration; the others are forced onto its template
   int big = 0;
   for (int j = 1; j < n; ++j)

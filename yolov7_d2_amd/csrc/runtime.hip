@@ -323,6 +323,7 @@ extern "C" int mi_abi_sizeof(int which) {
     case 12: return (int)sizeof(mi_pil_resize_job);
     case 13: return (int)sizeof(mi_jpeg_info);
     case 14: return (int)sizeof(mi_jpeg_job);
+    case 15: return (int)sizeof(mi_bnx);
   }
   return -1;
 }

@@ -1035,6 +1035,9 @@ class Plan:
             d.ntaps = len(spec.taps)
             for t, (dy, dx, w) in enumerate(spec.taps):
                 d.tap_dy[t], d.tap_dx[t], d.tap_w[t] = dy, dx, w
+            xf = getattr(spec, "xf", None)
+            if xf is not None:
+                d.xf, d.xf_write, d.xf_C = xf.resolve(), int(spec.xf_write), int(spec.xf_C)
             bnb = getattr(spec, "bnb", None)
             if bnb is not None:
                 d.bn_y, d.bn_ldy, d.bn_act = bnb["y"].resolve(), bnb["ldy"], bnb["act"]
@@ -1318,6 +1321,181 @@ class Plan:
                 k += 1
         return out
 
+    # ---------------------------------------------------------------- BatchNorm + SiLU in the consumer
+    @staticmethod
+    def _cmd_bufs(c):
+        """ids of the arena buffers a (possibly merged) command touches"""
+        out = set()
+
+        def add(o):
+            if isinstance(o, _Ptr):
+                o = o.obj
+            if isinstance(o, TRef):
+                out.add(id(o.buf))
+                if o.gbuf is not None:
+                    out.add(id(o.gbuf))
+            elif isinstance(o, Buf):
+                out.add(id(o))
+
+        for m in (getattr(c, "members", None) or [c]):
+            for x in m.p:
+                add(x)
+            if m.desc is not None:
+                for v in m.desc.__dict__.values():
+                    if isinstance(v, dict):
+                        for w in v.values():
+                            add(w)
+                    else:
+                        add(v)
+        return out
+
+    def _defer_bn(self, cmds):
+        """BatchNorm(train) + SiLU of a layer applied by the layer's FIRST reader instead of a launch of its own
+        (MI_BN_IN_CONSUMER=0 keeps every BN_ACT_FWD).  A BN_ACT_FWD job (alone or inside a BN_GROUP) without a residual
+        whose output tensor is first read - whole, as the input view - by a forward convolution launch that runs on the
+        streaming 1x1 / weight-stationary 3x3 kernel is dropped; that launch reads the raw conv output y instead, derives
+        scale / shift from the accumulators in its prologue, rewrites the tiles it fetched in LDS and stores the activated
+        tensor for the later readers (csrc/conv_bn.h BnXf; mi_conv_desc.xf).  All members of a grouped launch convert
+        together or not at all.  Bit-identical to the two-launch form (same expression, same rounding point); the builder's
+        own lists are not touched (tests/plan_interp.py keeps interpreting BaseConv as conv, BatchNorm, conv)."""
+        self.deferred_bn = []
+        mode = os.environ.get("MI_BN_IN_CONSUMER", "auto")
+        if mode == "0" or not self.b.bn_train or os.environ.get("MI_CONV_BN_FUSE", "0") == "1":
+            return cmds
+
+        def pays(sp, x):
+            """MI_BN_IN_CONSUMER=auto (default): only where the fold measured FASTER than the launch it removes (same-box
+            in-graph traces, profiles/r05_bn_in_consumer_ab.txt).  SiLU costs two quarter-rate transcendentals per element
+            and a consumer launch of this network is a serial chain of one or two tiles per block, so the transform adds
+            its whole latency to the chain: 3x3 readers (halo pixels transformed 1.3 - 2.6 times, 7 - 35 us added against
+            6 - 21 us removed) and the 20x20 / 40x40 maps (6 - 11 us added against 6 - 8 us) LOSE; the streaming 1x1
+            readers of the large maps and the K = 32 stride-2 stem win 2 - 8 us each.  MI_BN_IN_CONSUMER=1 converts every
+            eligible layer."""
+            if mode != "auto":
+                return True
+            k3 = len(sp.taps) == 9
+            elems = x.N * x.H * x.W * x.C
+            if k3:
+                return sp.in_stride == 2 and x.C == 32
+            return x.C <= 128 and elems >= 6_000_000
+        only = [t for t in os.environ.get("MI_BN_IN_CONSUMER_ONLY", "").split(",") if t]   # substrings of BatchNorm tags (A/B runs)
+        CONV, CONVG, BNF, BNG = L.OP["CONV"], L.OP["CONV_GROUP"], L.OP["BN_ACT_FWD"], L.OP["BN_GROUP"]
+        lib = L.lib()
+        pending = {}        # (buf id, coff) of an activation -> (container command, symbolic BN_ACT_FWD command)
+        drop = {}           # id(container) -> [symbolic BN commands taken out of it]
+        replace = {}        # id(conv launch) -> new command
+
+        def bn_jobs(c):
+            if c.op == BNF:
+                return [(c, c)]
+            if c.op == BNG and c.i[0] == 0:
+                return [(c, m) for m in c.members]
+            return []
+
+        def try_convert(c):
+            members = [c] if c.op == CONV else list(c.members)
+            picks = []
+            for m in members:
+                sp = m.desc
+                x = sp.x.obj
+                if getattr(sp, "kind", "conv") != "conv" or not isinstance(x, TRef) or sp.x.off or getattr(sp, "xf", None) is not None:
+                    return None
+                ent = pending.get((id(x.buf), x.coff))
+                if ent is None or sp.stats.obj is None or sp.flags or sp.bias.obj is not None:
+                    return None
+                bn = ent[1]
+                out, y = bn.p[12].obj, bn.p[0].obj
+                Cc = bn.i[3]
+                if not (out.C == Cc == sp.K8 * 8 == x.C and x.ld == out.ld and isinstance(y, TRef) and y.C == Cc
+                        and (x.N, x.H, x.W) == (y.N, y.H, y.W)):
+                    return None
+                if (only and not any(t in bn.tag for t in only)) or not pays(sp, x):
+                    return None
+                picks.append((m, ent))
+            # one device record per input tensor
+            keys = []
+            for m, ent in picks:
+                if id(ent[1]) not in [id(k_) for k_ in keys]:
+                    keys.append(ent[1])
+            recs = (L.mi_bnx * len(keys))()
+            for r, bn in zip(recs, keys):
+                P = [q.resolve() for q in bn.p]
+                (_, r.acc, r.gamma, r.beta, r.rmean, r.rvar, r.nbt, r.scale, r.shift, r.mean, r.invstd, _, r.a) = P[:13]
+                out = bn.p[12].obj
+                r.lda, r.act, r.C, r.nslots = out.ld, bn.i[4], bn.i[3], bn.i[5]
+                r.sld = _rup(bn.i[3], 32) * 2
+                cnt = bn.l[0]
+                r.inv_count = 1.0 / cnt
+                r.unbias = cnt / (cnt - 1.0) if cnt > 1 else 1.0
+                r.eps, r.momentum = (bn.f + [0.0, 0.0])[:2]
+            tab = torch.frombuffer(bytearray(bytes(recs)), dtype=torch.uint8).to(self.b.device)
+            new, seen = [], set()
+            for m, ent in picks:
+                bn = ent[1]
+                y = bn.p[0].obj
+                sp = ConvSpec(**m.desc.__dict__)
+                sp.x, sp.ldx = _Ptr(y), y.ld
+                sp.xf = _Ptr(tab, C.sizeof(L.mi_bnx) * [id(k_) for k_ in keys].index(id(bn)))
+                sp.xf_write, sp.xf_C = int(id(bn) not in seen), bn.i[3]
+                seen.add(id(bn))
+                nm = _Cmd(m.op, m.i, m.f, m.p, m.l, sp, m.tag, stream=m.stream)
+                nm.lane = m.lane
+                new.append(nm)
+            if c.op == CONV:
+                d = self._make_desc(new[0].desc)
+                self.descs.pop()
+                if lib.mi_conv2d_route(C.byref(d)) not in (1, 2):
+                    return None
+                res = new[0]
+            else:
+                res = self._conv_group_cmd(new, tag=c.tag)
+                if res is None:
+                    return None
+                res.lane, res.stream = c.lane, c.stream
+            self.descs.append(tab)
+            res.deferred_bn = [ent[1] for _, ent in picks]
+            return res, picks
+
+        for c in cmds:
+            refs = self._cmd_bufs(c)
+            if c.op in (CONV, CONVG) and not getattr(c, "fused_bn", False) and pending:
+                got = try_convert(c)
+                if got is not None:
+                    res, picks = got
+                    replace[id(c)] = res
+                    done = set()
+                    for _, (cont, bn) in picks:
+                        if id(bn) not in done:
+                            done.add(id(bn))
+                            drop.setdefault(id(cont), []).append(bn)
+                            self.deferred_bn.append(bn.tag)
+            for key in [k_ for k_, ent in pending.items() if k_[0] in refs]:
+                del pending[key]
+            for cont, bn in bn_jobs(c):
+                out = bn.p[12].obj
+                if bn.p[1].obj is not None and bn.p[11].obj is None and isinstance(out, TRef) and bn.i[3] % 32 == 0:
+                    pending[(id(out.buf), out.coff)] = (cont, bn)
+        if not replace:
+            return cmds
+        out = []
+        for c in cmds:
+            if id(c) in replace:
+                out.append(replace[id(c)])
+            elif id(c) in drop:
+                rest = [m for m in (c.members if c.op == BNG else [c]) if not any(m is d_ for d_ in drop[id(c)])]
+                if len(rest) >= 2:
+                    g = self._bn_group_cmd(0, rest)
+                    if g is None:
+                        out += rest
+                    else:
+                        g.lane, g.stream = c.lane, c.stream
+                        out.append(g)
+                else:
+                    out += rest
+            else:
+                out.append(c)
+        return out
+
     @staticmethod
     def _fill_bn_fwd_job(j, c):
         """BN_ACT_FWD command -> mi_bn_job: i=[ldy, ldres, lda, C, act, nslots] l=[count, npix] f=[eps, momentum]"""
@@ -1330,7 +1508,7 @@ class Plan:
     def _materialize(self, cmds, which):
         cmds = self._lower_streams(self._group_lanes(self._group_parity(cmds)))
         if which == "fwd":
-            cmds = self._fuse_conv_bn(cmds)
+            cmds = self._fuse_conv_bn(self._defer_bn(cmds))
         arr = (L.mi_cmd * max(1, len(cmds)))()
         tags = []
         if which == "fwd":
