@@ -516,6 +516,18 @@ int mi_mha_bwd_dropout(const void* q, const void* k, const void* v, const uint8_
                        const float* lse, const void* dout, float* delta_ws, void* dq, void* dk, void* dv, int B, int H,
                        int Lq, int Lk, int E, float scale, float drop_p, uint64_t seed, mi_stream_t s);
 int mi_mha_dropout_mask(uint8_t* out, int B, int H, int Lq, int Lk, float drop_p, uint64_t seed, mi_stream_t s);
+/* the same again with an fp32 copy of the output, o_f32 [Lq][B][E] (NULL = the forms above): the forward writes it, the
+ * backward takes delta = rowsum(dO o O) from it.  dS = P o (dP - delta) cancels to a few percent of its operands whenever
+ * the values of a row's keys are alike (every attention of a freshly initialised DETR); the 2^-9 rounding of a bf16 O is
+ * coherent over the row and leaves that difference as a 30 - 80 % error of dq (measured on device operands, tools/
+ * attn_bwd_error.py: dq rel 0.78 -> 0.0014).  4 bytes per output element, read once by the backward. */
+int mi_mha_fwd_dropout_o32(const void* q, const void* k, const void* v, const uint8_t* key_padding_mask, void* o, float* o_f32,
+                           float* lse, int B, int H, int Lq, int Lk, int E, float scale, float drop_p, uint64_t seed,
+                           mi_stream_t s);
+int mi_mha_bwd_dropout_o32(const void* q, const void* k, const void* v, const uint8_t* key_padding_mask, const void* o,
+                           const float* o_f32, const float* lse, const void* dout, float* delta_ws, void* dq, void* dk,
+                           void* dv, int B, int H, int Lq, int Lk, int E, float scale, float drop_p, uint64_t seed,
+                           mi_stream_t s);
 /* elementwise dropout of a bf16 tensor (F.dropout of detr_backbone.py:147-150,163-167,...): out[i] = keep(seed, i) ?
  * x[i] / (1-p) : 0; applying it with the same (p, seed) to the output gradient IS the backward. n %% 8 == 0. */
 int mi_dropout_bf16(const void* x, void* out, int64_t n, float drop_p, uint64_t seed, mi_stream_t s);

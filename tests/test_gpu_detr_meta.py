@@ -355,7 +355,8 @@ def test_detr_r50_real_size_against_reference_golden(golden_dir):
     assert np.abs(lg - g["eval_logits"]).max() < 0.25 and np.abs(bx - g["eval_boxes"]).max() < 3e-2
 
 
-def test_detr_r50_real_size_gradients_with_the_forward_state_pinned(monkeypatch):
+@pytest.mark.parametrize("peak", [1.0, 2.83])
+def test_detr_r50_real_size_gradients_with_the_forward_state_pinned(monkeypatch, peak):
     """configs[3] to the YOLOX standard (tests/test_gpu_parity_bench.py): DETR-R50 at its real size (6 + 6 layers, 100 queries,
     an 800 x 1333 + 768 x 1205 padded batch), EVERY trainable parameter's gradient against an fp32 restatement whose forward
     is pinned to the HIP network's own activations (teacher forcing: every trainable conv output of res3 .. res5, the input
@@ -377,6 +378,12 @@ def test_detr_r50_real_size_gradients_with_the_forward_state_pinned(monkeypatch)
     model.load_state_dict(seeded_tensor_dict({k: v.shape for k, v in sd.items()}, seed=207), strict=False)
     with torch.no_grad():
         model.detr.input_proj.weight.mul_(1e-3)           # (tokens of trained magnitude, as in the real-size golden test)
+        if peak != 1.0:
+            # PEAKED attention (a trained network's regime; random initialisation is near-uniform): the q and k rows of every
+            # in-projection scaled, i.e. the attention logits by peak^2
+            for n_, p_ in model.named_parameters():
+                if n_.endswith("in_proj_weight"):
+                    p_[: 2 * p_.shape[1]].mul_(peak)
     model.train()
     inputs = _inputs(synth_detr_batch(seed=211, sizes=((800, 1333), (768, 1205))))
     cpu = lambda t: t.detach().float().cpu()
@@ -466,10 +473,12 @@ def test_detr_r50_real_size_gradients_with_the_forward_state_pinned(monkeypatch)
     print("query_embed: |error| %.3e, |sum| %.3e, sum of the 18 terms' norms %.3e" % (qerr, float(osd["detr.query_embed.weight"].grad.norm()), qterms),
           "per layer (self q, self k, cross q):", [[round(float(t.grad.norm()), 5) for t in tri] for tri in qes])
     # d / d query_embed and the q / k rows of every in-projection are what flows through dS = P o (dP - rowsum(dO o O)): at
-    # random initialisation the attention is near-uniform (dP ~ rowsum: the difference cancels to a few percent of its
-    # operands) and the product's O is a bf16 tensor, so this path carries the forward's storage rounding amplified by the
-    # cancellation - a property of bf16 attention outputs, not of the backward kernels (the value / output projections, which
-    # do not cross the cancellation, are among the 193 tensors held to 0.999 above).  Reported, bounded loosely:
+    # random initialisation the values of a row's keys are alike, dP ~ rowsum (|delta| is 10 - 100 x |dP - delta|) and the
+    # difference cancels.  Rounds 3 - 4 took rowsum from the bf16 O: its 2^-9 rounding, coherent over the row, came out of the
+    # difference as 3 - 15 % (encoder) / 18 - 60 % (cross-attention) errors of these rows.  Round 5: the forward also writes O
+    # in fp32 for the backward's delta (mi_mha_fwd_dropout_o32; offline analysis of device operands: tools/attn_bwd_error.py,
+    # dq rel 0.78 -> 0.0014) - measured here 1.7 - 7.6 % at random initialisation and 1.1 - 3.7 % with peaked attention
+    # (logits x 8), on a component that is 0.3 - 10 % of its tensor.  Held to cosine 0.99 / rel 0.1.
     E = 256
     qk = []
     for k in tkeys:
@@ -478,16 +487,15 @@ def test_detr_r50_real_size_gradients_with_the_forward_state_pinned(monkeypatch)
             qk.append((k[len("detr.transformer."):-len(".in_proj_weight")], float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)),
                        float((a - b).norm() / (b.norm() + 1e-30)), float(b.norm() / osd[k].grad[2 * E:].norm())))
     print("q / k rows of the in-projections (name, cosine, rel L2, |qk rows| / |v rows|):", [(n, round(c, 4), round(r, 3), round(f, 4)) for n, c, r, f in qk])
-    # measured: encoder self-attention 3-15 % (cosine 0.989-0.9997), decoder cross-attention 18-60 % (0.86-0.98) on a component
-    # that is 0.3-3 % of its tensor; the decoder's SELF-attention q / k gradients are ~0 on both sides (100 near-identical
-    # queries: exactly uniform attention) - there the HIP rows must be noise-small against the value rows
+    # the decoder's SELF-attention q / k gradients are ~0 on both sides (100 near-identical queries: exactly uniform
+    # attention) - there the HIP rows must be noise-small against the value rows
     for n, c, r, f in qk:
         if f > 1e-3:
-            assert c > 0.85, (n, c, r, f)
+            assert c > 0.99 and r < 0.1, (n, c, r, f)
     for k in tkeys:
         if k.endswith("self_attn.in_proj_weight") and ".decoder." in k and ".layers.0." not in k:      # (layer 0: below)
             assert float(hip[k][: 2 * E].norm()) < 1e-2 * float(hip[k][2 * E:].norm()), k
-    assert qerr < 0.3 * qterms
+    assert qerr < 0.1 * qterms
     for k in special - {"detr.query_embed.weight"}:
         E = 256
         a, b = hip[k][2 * E:].flatten(), osd[k].grad[2 * E:].flatten()       # the value projection rows

@@ -44,6 +44,7 @@ struct MhaK {
   const __bf16* v;
   const uint8_t* mask;  // [B][Lk] or NULL
   __bf16* o;
+  float* o32;           // [Lq][B][E] fp32 copy of o or NULL (forward: written; backward: the operand of delta)
   float* lse;           // [B][H][Lq]
   // backward
   const __bf16* dout;
@@ -193,6 +194,11 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaK p) {
       __bf16* op = p.o + ((size_t)qq * p.B + b) * p.E + h * MHA_D;
       op[t] = (__bf16)(oacc[0][r] * inv);
       op[16 + t] = (__bf16)(oacc[1][r] * inv);
+      if (p.o32) {
+        float* o3 = p.o32 + ((size_t)qq * p.B + b) * p.E + h * MHA_D;
+        o3[t] = oacc[0][r] * inv;
+        o3[16 + t] = oacc[1][r] * inv;
+      }
     }
   }
   if (g == 0 && myq < p.Lq && p.lse)
@@ -350,6 +356,11 @@ __global__ __launch_bounds__(768) void mha_fwd2_kernel(const MhaK p) {
       __bf16* op = p.o + ((size_t)qq * p.B + b) * p.E + h * MHA_D;
       op[t] = (__bf16)(oacc[0][r] * inv);
       op[16 + t] = (__bf16)(oacc[1][r] * inv);
+      if (p.o32) {
+        float* o3 = p.o32 + ((size_t)qq * p.B + b) * p.E + h * MHA_D;
+        o3[t] = oacc[0][r] * inv;
+        o3[16 + t] = oacc[1][r] * inv;
+      }
     }
   }
   // lse of query t: its normaliser sits in lanes of group t >> 2, register t & 3
@@ -364,17 +375,30 @@ __global__ __launch_bounds__(768) void mha_fwd2_kernel(const MhaK p) {
 }
 
 // ------------------------------------------------------------------ backward
-// delta[b][h][q] = sum_d dO[q][d] * O[q][d]
+// delta[b][h][q] = sum_d dO[q][d] * O[q][d].  With the bf16 O this is the backward's weak point: dS = P o (dP - delta) is a
+// difference of nearly equal numbers whenever the values of a row's keys are alike (a freshly initialised DETR: |delta| is
+// 10 - 100 x |dP - delta|), and the 2^-9 rounding of the stored O, coherent over all keys of the row, comes out of the
+// difference as a 30 - 80 % error of dq (tools/attn_bwd_error.py on operands dumped from the device: dq rel 0.78 -> 0.0014
+// with the fp32 O, every other term unchanged).  The forward therefore also writes O in fp32 (p.o32) for this kernel.
 __global__ __launch_bounds__(256) void mha_delta_kernel(const MhaK p, float* delta) {
   const int idx = blockIdx.x * 256 + threadIdx.x;  // over B*H*Lq*4 (4 threads of 8 d per row)
   const int part = idx & 3, row = idx >> 2;
   if (row >= p.B * p.H * p.Lq) return;
   const int q = row % p.Lq, bh = row / p.Lq, b = bh / p.H, h = bh % p.H;
   const size_t off = ((size_t)q * p.B + b) * p.E + h * MHA_D + part * 8;
-  const bf16x8 a = *(const bf16x8*)(p.dout + off), c = *(const bf16x8*)(p.o + off);
+  const bf16x8 a = *(const bf16x8*)(p.dout + off);
   float s = 0.f;
+  if (p.o32) {
+    const f32x4 c0 = *(const f32x4*)(p.o32 + off), c1 = *(const f32x4*)(p.o32 + off + 4);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)c[e];
+    for (int e = 0; e < 4; ++e) s += (float)a[e] * c0[e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += (float)a[4 + e] * c1[e];
+  } else {
+    const bf16x8 c = *(const bf16x8*)(p.o + off);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += (float)a[e] * (float)c[e];
+  }
   s += __shfl_xor(s, 1, 64);
   s += __shfl_xor(s, 2, 64);
   if (part == 0) delta[row] = s;
@@ -801,6 +825,12 @@ extern "C" int mi_mha_fwd(const void* q, const void* k, const void* v, const uin
 extern "C" int mi_mha_fwd_dropout(const void* q, const void* k, const void* v, const uint8_t* key_padding_mask, void* o,
                                   float* lse, int B, int H, int Lq, int Lk, int E, float scale, float drop_p,
                                   uint64_t seed, mi_stream_t st) {
+  return mi_mha_fwd_dropout_o32(q, k, v, key_padding_mask, o, nullptr, lse, B, H, Lq, Lk, E, scale, drop_p, seed, st);
+}
+
+extern "C" int mi_mha_fwd_dropout_o32(const void* q, const void* k, const void* v, const uint8_t* key_padding_mask, void* o,
+                                      float* o_f32, float* lse, int B, int H, int Lq, int Lk, int E, float scale,
+                                      float drop_p, uint64_t seed, mi_stream_t st) {
   int rc = mha_check(q, k, v, B, H, Lq, Lk, E);
   if (rc) return rc;
   MI_REQUIRE(o, "mha_fwd: null output");
@@ -809,7 +839,8 @@ extern "C" int mi_mha_fwd_dropout(const void* q, const void* k, const void* v, c
   rc = mha_set_dropout(&p, drop_p, seed);
   if (rc) return rc;
   p.q = (const __bf16*)q; p.k = (const __bf16*)k; p.v = (const __bf16*)v; p.mask = key_padding_mask;
-  p.o = (__bf16*)o; p.lse = lse; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.E = E; p.scale = scale;
+  p.o = (__bf16*)o; p.o32 = o_f32; p.lse = lse; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.E = E; p.scale = scale;
+  MI_REQUIRE(!o_f32 || ((uintptr_t)o_f32 & 15) == 0, "mha_fwd: o_f32 alignment");
   static const int v2 = getenv("MI_MHA_V2") ? atoi(getenv("MI_MHA_V2")) : 1;
   if (!v2) {
     hipLaunchKernelGGL(mha_fwd_kernel, dim3(mi_cdiv(Lq, 64), B * H), dim3(256), 0, (hipStream_t)st, p);
@@ -855,6 +886,14 @@ extern "C" int mi_mha_bwd_dropout(const void* q, const void* k, const void* v, c
                                   const void* o, const float* lse, const void* dout, float* delta_ws, void* dq, void* dk,
                                   void* dv, int B, int H, int Lq, int Lk, int E, float scale, float drop_p, uint64_t seed,
                                   mi_stream_t st) {
+  return mi_mha_bwd_dropout_o32(q, k, v, key_padding_mask, o, nullptr, lse, dout, delta_ws, dq, dk, dv, B, H, Lq, Lk, E, scale,
+                                drop_p, seed, st);
+}
+
+extern "C" int mi_mha_bwd_dropout_o32(const void* q, const void* k, const void* v, const uint8_t* key_padding_mask,
+                                      const void* o, const float* o_f32, const float* lse, const void* dout, float* delta_ws,
+                                      void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int E, float scale,
+                                      float drop_p, uint64_t seed, mi_stream_t st) {
   int rc = mha_check(q, k, v, B, H, Lq, Lk, E);
   if (rc) return rc;
   MI_REQUIRE(o && lse && dout && delta_ws && dq && dk && dv, "mha_bwd: null");
@@ -863,7 +902,7 @@ extern "C" int mi_mha_bwd_dropout(const void* q, const void* k, const void* v, c
   rc = mha_set_dropout(&p, drop_p, seed);
   if (rc) return rc;
   p.q = (const __bf16*)q; p.k = (const __bf16*)k; p.v = (const __bf16*)v; p.mask = key_padding_mask;
-  p.o = (__bf16*)o; p.lse = (float*)lse; p.dout = (const __bf16*)dout; p.delta = delta_ws; p.dq = (__bf16*)dq;
+  p.o = (__bf16*)o; p.o32 = (float*)o_f32; p.lse = (float*)lse; p.dout = (const __bf16*)dout; p.delta = delta_ws; p.dq = (__bf16*)dq;
   p.dk = (__bf16*)dk; p.dv = (__bf16*)dv; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.E = E; p.scale = scale;
   hipStream_t s = (hipStream_t)st;
   hipLaunchKernelGGL(mha_delta_kernel, dim3(mi_cdiv(B * H * Lq * 4, 256)), dim3(256), 0, s, p, delta_ws);

@@ -11,6 +11,11 @@ import torch
 from .. import _lib as L
 
 
+def _O32():
+    import os
+    return os.environ.get("MI_MHA_O32", "1") != "0"
+
+
 class _MhaCore(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, mask, num_heads, drop_p=0.0, seed=0):
@@ -21,28 +26,53 @@ class _MhaCore(torch.autograd.Function):
         q, k, v = (t.to(torch.bfloat16).contiguous() for t in (q, k, v))
         m = None if mask is None else mask.to(torch.uint8).contiguous()
         o = torch.empty_like(q)
+        # fp32 copy of the output for the backward's delta = rowsum(dO o O) (see mi_mha_fwd_dropout_o32): only when a
+        # backward will follow; MI_MHA_O32=0 keeps the bf16-only form (A/B, tests)
+        need32 = _O32() and any(ctx.needs_input_grad[:3])
+        o32 = torch.empty(Lq, B, E, dtype=torch.float32, device=q.device) if need32 else None
         lse = torch.empty(B, num_heads, Lq, dtype=torch.float32, device=q.device)
         scale = 1.0 / math.sqrt(E // num_heads)
-        L.check(L.lib().mi_mha_fwd_dropout(q.data_ptr(), k.data_ptr(), v.data_ptr(), L.ptr(m), o.data_ptr(), lse.data_ptr(),
-                                           B, num_heads, Lq, Lk, E, scale, float(drop_p), int(seed), L.stream_ptr()),
-                "mi_mha_fwd")
-        ctx.save_for_backward(q, k, v, m, o, lse)
+        L.check(L.lib().mi_mha_fwd_dropout_o32(q.data_ptr(), k.data_ptr(), v.data_ptr(), L.ptr(m), o.data_ptr(), L.ptr(o32),
+                                               lse.data_ptr(), B, num_heads, Lq, Lk, E, scale, float(drop_p), int(seed),
+                                               L.stream_ptr()), "mi_mha_fwd")
+        ctx.save_for_backward(q, k, v, m, o, lse, o32)
         ctx.num_heads, ctx.scale, ctx.drop = num_heads, scale, (float(drop_p), int(seed))
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, m, o, lse = ctx.saved_tensors
+        q, k, v, m, o, lse, o32 = ctx.saved_tensors
         Lq, B, E = q.shape
         Lk = k.shape[0]
         do = do.to(torch.bfloat16).contiguous()
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         delta = torch.empty_like(lse)
-        L.check(L.lib().mi_mha_bwd_dropout(q.data_ptr(), k.data_ptr(), v.data_ptr(), L.ptr(m), o.data_ptr(), lse.data_ptr(),
-                                           do.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B,
-                                           ctx.num_heads, Lq, Lk, E, ctx.scale, ctx.drop[0], ctx.drop[1], L.stream_ptr()),
-                "mi_mha_bwd")
+        L.check(L.lib().mi_mha_bwd_dropout_o32(q.data_ptr(), k.data_ptr(), v.data_ptr(), L.ptr(m), o.data_ptr(), L.ptr(o32),
+                                               lse.data_ptr(), do.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                                               dv.data_ptr(), B, ctx.num_heads, Lq, Lk, E, ctx.scale, ctx.drop[0], ctx.drop[1],
+                                               L.stream_ptr()), "mi_mha_bwd")
+        _dump(ctx, q, k, v, m, o, lse, do, dq, dk, dv)
         return dq, dk, dv, None, None, None, None
+
+
+_DUMPS = [0]
+
+
+def _dump(ctx, q, k, v, m, o, lse, do, dq, dk, dv):
+    """debugging aid (MI_MHA_DUMP=<dir>, MI_MHA_DUMP_SEL=<comma-separated backward-call indices>): the operands and
+    results of selected backward calls as .pt files, for the offline error analysis of tools/attn_bwd_error.py"""
+    import os
+    d = os.environ.get("MI_MHA_DUMP")
+    if not d:
+        return
+    i = _DUMPS[0]
+    _DUMPS[0] += 1
+    sel = os.environ.get("MI_MHA_DUMP_SEL", "")
+    if sel and str(i) not in sel.split(","):
+        return
+    os.makedirs(d, exist_ok=True)
+    torch.save(dict(q=q.cpu(), k=k.cpu(), v=v.cpu(), mask=None if m is None else m.cpu(), o=o.cpu(), lse=lse.cpu(), do=do.cpu(),
+                    dq=dq.cpu(), dk=dk.cpu(), dv=dv.cpu(), heads=ctx.num_heads, scale=ctx.scale, drop=ctx.drop), os.path.join(d, f"mha_bwd_{i}.pt"))
 
 
 def mha_core(q, k, v, key_padding_mask=None, num_heads=8, dropout_p=0.0, seed=0):
