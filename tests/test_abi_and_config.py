@@ -35,7 +35,7 @@ def test_opcode_table_matches_header():
 
 def test_struct_sizes_match_c():
     # sizes computed from the field lists in the header (no padding surprises across the FFI)
-    raw = 5 * 8 + (3 + 3 + 2 + 2 + 4 + 4 + 3 * L.MI_MAX_TAPS + 5 + 2) * 4 + 5 * 8 + 2 * 4
+    raw = 5 * 8 + (3 + 3 + 2 + 2 + 4 + 4 + 3 * L.MI_MAX_TAPS + 5 + 2) * 4 + 5 * 8 + 2 * 4 + 8 + 2 * 4     # (.. bn_*, xf, xf_write, xf_C)
     assert C.sizeof(L.mi_conv_desc) == (raw + 7) // 8 * 8      # (pointer members: the struct is 8-byte aligned)
     assert C.sizeof(L.mi_cmd) % 8 == 0 and C.sizeof(L.mi_cmd) == 4 + 160 + 32 + 4 + 128 + 32  # op,i[40],f[8],pad,p[16],l[4]
     assert C.sizeof(L.mi_sgd_seg) == 24

@@ -192,6 +192,41 @@ def test_two_captured_shapes_alternate_and_lr_changes_reach_the_replays():
         step.close()
 
 
+def test_evicted_captures_release_their_optimizer_tables():
+    """the LRU drops a graph -> its optimizer pointer table goes too (a multi-scale DETR run re-captures
+    endlessly: tables must not pile up, and an LR change must be uploaded only into the table of the graph about to replay).
+    max_graphs = 2, three padded shapes in rotation: never more than two live tables, results still equal the eager step."""
+    from yolov7_d2_amd.optim import MultiTensorAdamW
+    shapes = [((256, 320), (224, 288)), ((320, 384), (300, 352)), ((192, 256), (160, 224))]
+    seq = [_batch(10 + i, shapes[i % 3], (2, 3)) for i in range(7)]
+    eager, graphed = _model(0.0), _model(0.0)
+    mk = lambda m: MultiTensorAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-4, clip_norm=1.0)
+    oe, og = mk(eager), mk(graphed)
+    step = GraphedTrainStep(graphed, og, max_graphs=2)
+    try:
+        for it, b in enumerate(seq):
+            if it == 5:
+                for o in (oe, og):
+                    for grp in o.param_groups:
+                        grp["lr"] = 5e-5
+            losses = eager(b)
+            total = sum(v for k, v in losses.items() if k in eager.criterion.weight_dict)
+            oe.zero_grad(set_to_none=True)
+            total.backward()
+            oe.step()
+            out = step(b)
+            for k, v in losses.items():
+                torch.testing.assert_close(out[k].float(), v.detach().float(), rtol=2e-3, atol=2e-3, msg=f"step {it} {k}")
+            assert len(step.graphs) <= 2 and len(og.captures) == len(step.graphs), (it, len(step.graphs), len(og.captures))
+        torch.cuda.synchronize()
+        for (n, p), (_, q) in zip(eager.named_parameters(), graphed.named_parameters()):
+            if p.requires_grad:
+                assert float((p.detach() - q.detach()).abs().max()) <= 3e-4, n
+    finally:
+        step.close()
+    assert og.captures == []
+
+
 def test_graphed_step_data_parallel_two_ranks(tmp_path):
     """GraphedTrainStep under torch.distributed (train_transformer.py:188-203 / train_inseg.py:63-77 -> d2 create_ddp_model):
     two gloo ranks on cuda:0 (tests/detr_ddp_worker.py).  Rank 1 starts from other weights (the construction-time

@@ -342,7 +342,7 @@ def test_gradient_buckets_are_complete_before_their_allreduce(monkeypatch, split
         assert "wgrad_group.early" not in tags and tags[-1] == "wgrad_group"
 
 
-def test_grouped_launches_of_the_640_plan():
+def test_grouped_launches_of_the_640_plan(monkeypatch):
     """regression guard for the launch structure of the benchmark-sized plan (dry-run, 640x640): the head's level x branch
     chains and the CSP conv1 / conv2 pairs really come out as grouped launches (a group planner that silently falls back
     to one launch per layer costs ~6 % of the step and no other test would notice), and no grouped conv launch exceeds
@@ -350,6 +350,7 @@ def test_grouped_launches_of_the_640_plan():
     import collections
     import ctypes as C
     from yolov7_d2_amd.plan import Plan
+    monkeypatch.setenv("MI_BN_IN_CONSUMER", "0")      # (the launch structure WITHOUT the BatchNorm fold; the fold has its own test below)
     model, _ = _model()
     ps = _PlanState(model, 2, 640, 640, True, materialize=False)
     plan = Plan(ps.builder, dry_run=True)
@@ -413,3 +414,43 @@ def test_plan_step_other_widths(depth, width):
             #  channel in the deepest BatchNorm layers is ~1e-3)
             bad.append((name, rel, float(r.norm())))
     assert not bad, bad[:10]
+
+
+def test_batchnorm_in_the_consumer_pass_of_the_640_plan(monkeypatch):
+    """plan.Plan._defer_bn on the benchmark-sized plan (dry run): MI_BN_IN_CONSUMER=1 drops the BN_ACT_FWD job of every layer
+    whose first reader is a forward convolution on the streaming 1x1 / weight-stationary 3x3 kernel (never one with a
+    residual, never a reader on the tile kernel), the reader's descriptor then reads the RAW conv output and carries the
+    device record; launches of one input share the record and exactly one of them writes the activated tensor; `auto` (the
+    default) keeps the measured winners only; the builder's symbolic lists are untouched."""
+    import collections
+    import ctypes as C
+    from yolov7_d2_amd.plan import Plan
+    model, _ = _model()
+    ps = _PlanState(model, 16, 640, 640, True, materialize=False)
+    nfwd = len(ps.builder.fwd)
+    counts = {}
+    for mode in ("0", "auto", "1"):
+        monkeypatch.setenv("MI_BN_IN_CONSUMER", mode)
+        plan = Plan(ps.builder, dry_run=True)
+        assert len(ps.builder.fwd) == nfwd and sum(c.op == L.OP["BN_ACT_FWD"] for c in ps.builder.fwd) == 74
+        arr, n = plan.fwd_cmds
+        members = plan.cmd_members["fwd"]
+        nbn = sum((len(members[k]) if members[k] else 1) for k in range(n) if L.OPS[arr[k].op] in ("BN_ACT_FWD", "BN_GROUP"))
+        assert nbn == 74 - len(plan.deferred_bn)
+        counts[mode] = len(plan.deferred_bn)
+        assert not any(".conv2.bnact" in t and ".m." in t and t.startswith("backbone.dark2") for t in plan.deferred_bn)   # (shortcut: has a residual)
+        xf = collections.defaultdict(list)
+        for k in range(n):
+            ds = plan.cmd_descs["fwd"][k]
+            if L.OPS[arr[k].op] == "CONV":
+                ds = [ds]
+            elif L.OPS[arr[k].op] != "CONV_GROUP":
+                continue
+            for d in ds:
+                if d.xf:
+                    assert d.stats_acc and not d.flags and d.xf_C == d.K8 * 8
+                    assert L.lib().mi_conv2d_route(C.byref(d)) in (1, 2)
+                    xf[(k, d.xf)].append(d.xf_write)
+        assert all(sum(w) == 1 for w in xf.values()), xf
+        assert len(xf) == len(plan.deferred_bn)
+    assert counts["0"] == 0 and counts["1"] >= 35 and 1 <= counts["auto"] <= 10, counts

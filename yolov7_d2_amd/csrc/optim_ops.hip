@@ -121,7 +121,10 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const double* __restrict
     // step whose buffers hold the all-reduced SUM): the norm that is clipped is the averaged gradient's
     const float norm = grad_scale * (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
     const float c = max_norm / (norm + 1e-6f);
-    out[0] = c < 1.f ? c : 1.f;
+    // torch.nn.utils.clip_grad_norm_ (the reference's FullModelGradientClippingOptimizer, optimizer/build.py:206-223):
+    // clamp(max_norm / (norm + 1e-6), max = 1) - a NaN norm gives a NaN coefficient and the divergence shows in the very
+    // next loss, an infinite norm gives 0.  (`c < 1 ? c : 1` alone turned NaN into 1: a silent step on garbage.)
+    out[0] = (norm != norm) ? norm : (c < 1.f ? c : 1.f);
     out[1] = norm;
   }
 }

@@ -48,7 +48,7 @@ class GraphedTrainStep:
         self.images = WeightImages(list(model.parameters())) if batch_packs else None
         self.model, self.opt, self.warmup = model, optimizer, max(warmup, 2 if batch_packs else 1)
         self.loss_keys = loss_keys
-        self.graphs = {}            # key -> [graph A, graph B or None, static, out]; insertion order = recency
+        self.graphs = {}            # key -> [graph A, graph B or None, static, out, optimizer table handles]; insertion order = recency
         self.max_graphs = max_graphs
         self.pool = None
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
@@ -62,8 +62,16 @@ class GraphedTrainStep:
         self.seed_word = torch.zeros(1, dtype=torch.int64, device=model.device)
         L.check(L.lib().mi_dropout_seed_offset(self.seed_word.data_ptr()), "mi_dropout_seed_offset")
 
+    def _drop(self, ent):
+        """a capture leaves the cache: its optimizer pointer tables go with it (optim.MultiTensorAdamW.release_capture)"""
+        if hasattr(self.opt, "release_capture"):
+            for h in (ent[4] if len(ent) > 4 else []):
+                self.opt.release_capture(h)
+
     def close(self):
         L.check(L.lib().mi_dropout_seed_offset(None), "mi_dropout_seed_offset")
+        for ent in self.graphs.values():
+            self._drop(ent)
         self.graphs.clear()
 
     def _keys(self, losses):
@@ -111,6 +119,9 @@ class GraphedTrainStep:
 
     def _snapshot(self):
         st = [p.detach().clone() for g in self.opt.param_groups for p in g["params"]]
+        # module buffers too (train-mode BatchNorm running statistics / num_batches_tracked of a model that has them: the
+        # warm-up passes run the whole training forward and would advance them by `warmup` steps per captured shape)
+        self._buf_snap = [(b, b.detach().clone()) for b in self.model.buffers()]
         if hasattr(self.opt, "state_tensors"):       # optim.MultiTensorAdamW
             os_ = [t.clone() for t in self.opt.state_tensors()]
         else:
@@ -120,6 +131,9 @@ class GraphedTrainStep:
     def _restore(self, snap):
         st, os_, sw = snap
         with torch.no_grad():
+            for b, v in getattr(self, "_buf_snap", []):
+                b.copy_(v)
+            self._buf_snap = []
             for p, v in zip((p for g in self.opt.param_groups for p in g["params"]), st):
                 p.copy_(v)
             if hasattr(self.opt, "state_tensors"):
@@ -148,41 +162,47 @@ class GraphedTrainStep:
         else:
             with torch.cuda.graph(g, pool=self.pool):
                 out = fn()
+        handle = None
         if hasattr(self.opt, "finish_capture"):
-            self.opt.finish_capture()       # the gradient addresses of the graph's pool -> that table
-        return g, out
+            handle = self.opt.finish_capture()       # the gradient addresses of the graph's pool -> that table
+        return g, out, handle
 
     def __call__(self, batched_inputs):
         """one optimizer step on the batch; returns the loss dict (device scalars of the step just run; valid until the
         next call)"""
         key = self.model.batch_key(batched_inputs)
+        if self.images is not None:
+            self.images.verify()                # (replays read recorded parameter addresses: they must still be the parameters')
         ent = self.graphs.pop(key, None)
         if ent is None:
-            while len(self.graphs) >= self.max_graphs:             # least recently used capture goes
-                self.graphs.pop(next(iter(self.graphs)))
+            while len(self.graphs) >= self.max_graphs:             # least recently used capture goes, with its tables
+                self._drop(self.graphs.pop(next(iter(self.graphs))))
             static = self.model.prepare_batch(batched_inputs)
             # warm-up on a side stream (lazy initialisation inside the library, allocator pools), undone afterwards:
             # the first real step on this batch is the first replay.  No collective in here (see __init__)
             snap = self._snapshot()
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                for _ in range(self.warmup):
-                    self._body(static)
-            torch.cuda.current_stream().wait_stream(s)
-            if self.world > 1:
-                ga, out = self._capture(lambda: self._body_fb(static))
-                gb, _ = self._capture(self._body_opt)
-            else:
-                ga, out = self._capture(lambda: self._body(static))
-                gb = None
-            self._restore(snap)
-            ent = [ga, gb, static, out]
+            try:                                # (a failed warm-up / capture must not leave its updates behind)
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    for _ in range(self.warmup):
+                        self._body(static)
+                torch.cuda.current_stream().wait_stream(s)
+                if self.world > 1:
+                    ga, out, ha = self._capture(lambda: self._body_fb(static))
+                    gb, _, hb = self._capture(self._body_opt)
+                else:
+                    ga, out, ha = self._capture(lambda: self._body(static))
+                    gb = hb = None
+            finally:
+                self._restore(snap)
+            ent = [ga, gb, static, out, [h for h in (ha, hb) if h is not None]]
         else:
             self.model.prepare_batch(batched_inputs, static=ent[2])
         self.graphs[key] = ent                                     # (most recent last)
         if hasattr(self.opt, "sync_lr"):
-            self.opt.sync_lr()                  # an LR scheduler's new param_groups[i]["lr"] -> the captured launches' tables
+            # an LR scheduler's new param_groups[i]["lr"] -> the tables THIS replay reads (not every table ever captured)
+            self.opt.sync_lr(only=ent[4]) if hasattr(self.opt, "release_capture") else self.opt.sync_lr()
         ent[0].replay()
         if ent[1] is not None:
             self._allreduce()

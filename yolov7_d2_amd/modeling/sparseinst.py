@@ -741,26 +741,32 @@ class SparseInst(nn.Module):
         return new_targets
 
     # ---- the training step split at the host / device line (graph_step.GraphedTrainStep captures the device half)
-    target_capacity = 96      # instances per image the packed targets hold (a multiple of 32; COCO: <= 93 after crowd removal)
+    target_capacity = 96      # instances per image the packed targets hold AT LEAST (a multiple of 32; COCO: <= 93 after crowd
+                              # removal); an image with more instances raises the batch's capacity to the next multiple of 32
+                              # (the reference's criterion takes any count, sparseinst_loss.py:320-346) - a shape of its own
+
+    def _capacity(self, batched_inputs):
+        mx = max((len(x["instances"]) for x in batched_inputs if "instances" in x), default=0)
+        return max(self.target_capacity, (mx + 31) // 32 * 32)
 
     def batch_key(self, batched_inputs):
         r = 32                          # ImageList.from_tensors(images, 32) of preprocess_inputs (sparseinst.py:95-98)
         up = lambda v: (v + r - 1) // r * r
         return (len(batched_inputs), up(max(int(x["image"].shape[-2]) for x in batched_inputs)),
-                up(max(int(x["image"].shape[-1]) for x in batched_inputs)))
+                up(max(int(x["image"].shape[-1]) for x in batched_inputs)), self._capacity(batched_inputs))
 
     def prepare_batch(self, batched_inputs, static=None):
         """everything of the training forward that touches the host: normalise + zero-pad the images into one tensor
         (ImageList.from_tensors(images, 32), sparseinst.py:95-98) and move the ground truth over as PackedMaskTargets (masks
         padded to the batch shape and resized to the prediction size HERE, eagerly).  With `static` - an earlier result for
         the same batch_key - everything is refilled IN PLACE."""
-        B, Hp, Wp = self.batch_key(batched_inputs)
+        B, Hp, Wp, cap = self.batch_key(batched_inputs)
         dev = self.device
         if static is None:
             st = self.mask_stride
-            static = dict(images=torch.zeros(B, 3, Hp, Wp, device=dev), key=(B, Hp, Wp),
-                          targets=PackedMaskTargets(B, self.target_capacity, (Hp // st, Wp // st), dev))
-        assert static["key"] == (B, Hp, Wp), (static["key"], (B, Hp, Wp))
+            static = dict(images=torch.zeros(B, 3, Hp, Wp, device=dev), key=(B, Hp, Wp, cap),
+                          targets=PackedMaskTargets(B, cap, (Hp // st, Wp // st), dev))
+        assert static["key"] == (B, Hp, Wp, cap), (static["key"], (B, Hp, Wp, cap))
         img = static["images"]
         img.zero_()
         for b, x in enumerate(batched_inputs):
@@ -786,7 +792,7 @@ class SparseInst(nn.Module):
             gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
             # (the same fixed-capacity packing as prepare_batch: the eager and the captured step run identical launches)
             pk = _pack_targets(self.prepare_targets(gt_instances), max_shape, output["_masks_nhwc"].shape[1:3], self.device,
-                               cap=self.target_capacity)
+                               cap=self._capacity(batched_inputs))
             return self.criterion(output, pk)
         results = self.inference(output, batched_inputs, max_shape, images.image_sizes)
         return [{"instances": r} for r in results]

@@ -56,6 +56,9 @@ class WeightImages:
         self._bisect = bisect.bisect_right
         rs = sorted((p.data_ptr(), p.data_ptr() + p.numel() * 4) for p in params if p.dtype == torch.float32 and p.is_contiguous())
         self._lo, self._hi = [r[0] for r in rs], [r[1] for r in rs]
+        # the job table (and every captured replay of it) reads these ADDRESSES: verify() notices a parameter whose storage
+        # was replaced afterwards (model.to(), load_state_dict(assign=True), an EMA swap through .data)
+        self._params = [(p, p.data_ptr()) for p in params if p.dtype == torch.float32 and p.is_contiguous()]
         self.images = {}        # key -> (wf, wd)
         self._jobs, self._hold = [], []
         self.table = None       # device job table once frozen
@@ -98,6 +101,15 @@ class WeightImages:
         nblk = L.check(L.lib().mi_pack_jobs_layout(jobs, n), "mi_pack_jobs_layout")
         self.table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(self._hold[0][0].device)
         self.launch = (n, nblk, max(j.KK for j in self._jobs))
+
+    def verify(self):
+        """raise if a parameter's storage moved since construction: the recorded jobs (and the graphs that replay them)
+        would keep packing the OLD storage - training on stale weights without any error"""
+        moved = [i for i, (p, ptr) in enumerate(self._params) if p.data_ptr() != ptr]
+        if moved:
+            raise L.MI355Error(f"WeightImages: the storage of {len(moved)} parameter(s) was replaced after the step was "
+                               "recorded (model.to() / load_state_dict(assign=True) / .data swap): the captured weight "
+                               "re-pack reads the old addresses - build a new GraphedTrainStep")
 
     def run(self):
         """all recorded images from the current parameter values, one launch (a no-op while recording)"""

@@ -147,18 +147,29 @@ class MultiTensorAdamW:
         """the capture has ended: the gradient addresses of the graph's pool are final -> fill THIS capture's table"""
         if self._cap_table is None or not self._cap_used:      # (a captured segment that read no gradient table: the
             self._cap_table = None                              #  data-parallel update reads the flat buffer's table)
-            return
+            return None
         arr = self._host_table()
         self._upload(self._cap_table, arr)
         # (no reference to the gradient tensors is kept: they belong to the graph's memory pool, which GraphedTrainStep
         #  shares between captures - a later capture may lay its own tensors over them, replays never overlap)
-        self.captures.append([self._cap_table, arr, self._lrs(), None])
+        ent = [self._cap_table, arr, self._lrs(), None]
+        self.captures.append(ent)
         self._cap_table = None
+        return ent            # the capture's handle: release_capture(handle) when its graph is dropped
 
-    def sync_lr(self):
-        """carry changed learning rates into every captured table (cheap no-op when nothing changed)"""
+    def release_capture(self, handle):
+        """the graph that reads this table is gone (GraphedTrainStep's LRU eviction / close()): drop the device table and its
+        host mirror, so that a long multi-scale run neither grows by one table per re-capture nor re-uploads dead ones"""
+        if handle is None:
+            return
+        self.captures[:] = [e for e in self.captures if e is not handle]
+
+    def sync_lr(self, only=None):
+        """carry changed learning rates into the captured tables (cheap no-op when nothing changed).  only: the handles
+        of the graph about to be replayed (+ the flat buffer's table, always) instead of every live table"""
         lrs = self._lrs()
-        for ent in self.captures:
+        ents = self.captures if only is None else [e for e in self.captures if any(e is h for h in only) or e[3] == "flat"]
+        for ent in ents:
             if ent[2] != lrs:
                 k = 0
                 for g in self.param_groups:
@@ -205,7 +216,7 @@ class MultiTensorAdamW:
                 k += 1
         self.flat_table = torch.zeros(self.table_bytes, dtype=torch.uint8, device=self.device)
         self._upload(self.flat_table, arr)
-        self.captures.append([self.flat_table, arr, self._lrs(), None])      # (sync_lr keeps its lr fields current too)
+        self.captures.append([self.flat_table, arr, self._lrs(), "flat"])    # (sync_lr keeps its lr fields current too)
         per = max(1, int(bucket_bytes) // 4)
         self.buckets, lo = [], 0
         for k in range(len(offs)):
