@@ -617,6 +617,9 @@ typedef struct mi_mosaic_paste_job {
   const void* src;
   void* canvas;
   int32_t h0, w0, rh, rw, cw, x1a, y1a, x2a, y2a, x1b, y1b, blk0;
+  int32_t fsrc, pad_;        /* fsrc: the loaded image is float32 in the reference (YOLOFRandomDistortion ran): cv2.resize takes
+                                its FLOAT path (float32 coefficients, products and sums) and the assignment into the uint8
+                                canvas truncates (dataset_mapper.py:531-567) */
 } mi_mosaic_paste_job;
 typedef struct mi_warp_job {
   const void* canvas;
@@ -635,6 +638,8 @@ typedef struct mi_mixup_job {
   const void* src;
   void* out;
   int32_t h0, w0, rh1, rw1, dh, dw, oh, ow, flip, x_off, y_off, th, tw, Hp, Wp, blk0;
+  int32_t fsrc, pad_;        /* fsrc: the pool image is float32 in the reference: the FIRST resize takes cv2's float path and is
+                                not rounded (dataset_mapper.py:706-711) */
 } mi_mixup_job;
 int mi_mixup_jobs_layout(mi_mixup_job* jobs_host, int njobs);
 int mi_mixup_blend(const mi_mixup_job* jobs_dev, int njobs, int total_blocks, mi_stream_t s);
@@ -649,8 +654,8 @@ int mi_mixup_blend(const mi_mixup_job* jobs_dev, int njobs, int total_blocks, mi
  * data/dataset_mapper.py:777-800) -> nh x nw, element
  * (c, y, x) at dst + c dsc + y dsy + x dsx bytes (HWC: 1, 3 nw, 3; a sample of a padded NCHW batch: Hp Wp, Wp, 1);
  * tmp = [h0][nw][3] scratch of the horizontal pass (unused when nw == w0).  RandomSaturation / RandomBrightness (detectron2
- * BlendTransform, numpy's fp64 / fp32 arithmetic) are applied per pixel between the flips and the shift; YOLOFRandomDistortion
- * (cv2's HSV tables) is not built.
+ * BlendTransform, numpy's fp64 / fp32 arithmetic) and YOLOFRandomDistortion (OpenCV's 8-bit RGB2HSV_b / HSV2RGB_b, restated:
+ * no cv2 here to pin them) are applied per pixel between the flips and the shift.
  * mi_pil_resize_jobs_layout validates the (host) table, fills blk0h / blk0v and returns the block counts of the two flat
  * launches; the launches take the device copy of the table.  Down-scaling factors up to 8. */
 typedef struct mi_pil_resize_job {
@@ -663,8 +668,12 @@ typedef struct mi_pil_resize_job {
   int32_t h0, w0, nh, nw;
   int32_t hflip, vflip, shift_x, shift_y;
   int32_t src_hflip;         /* mirror the source BEFORE the resampling (DetrDatasetMapper: T.RandomFlip, then the resizes) */
-  int32_t color;             /* bit 0 RandomSaturation, bit 1 RandomBrightness (d2 BlendTransform on the uint8 image), after the flips */
+  int32_t color;             /* bit 0 RandomSaturation, bit 1 RandomBrightness (d2 BlendTransform on the uint8 image), bit 2
+                                YOLOFRandomDistortion (data/transforms/transform.py:250-308: cv2's 8-bit RGB <-> HSV around
+                                three float32 scalings); in that order, after the flips */
   float sat_dst, bri_dst;    /* w as float32 */
+  float dis_hue, dis_sat, dis_exp;   /* float32(dhue * 179 / 255.), float32(dsat), float32(dexp) */
+  int32_t dis_pos;           /* dhue > 0 */
   int32_t blk0h, blk0v;
 } mi_pil_resize_job;
 int mi_pil_resize_jobs_layout(mi_pil_resize_job* jobs_host, int njobs, int32_t* blocks_h, int32_t* blocks_v);

@@ -74,6 +74,132 @@ def resize_linear_u8(img, dsize):
     return np.clip((v + 2) >> 2, 0, 255).astype(np.uint8)
 
 
+def resize_linear_f32(img, dsize):
+    """cv2.resize(img, (w, h), interpolation=cv2.INTER_LINEAR) of a FLOAT32 image (what the mosaic / mixup branches resize
+    once YOLOFRandomDistortion has turned the loaded image into float32): resize.cpp's generic path with WT = float - the
+    source index / fraction rule of the 8-bit path, coefficients (1 - fx, fx) in float32, horizontal D = S[sx] * a0 +
+    S[sx + 1] * a1, vertical dst = D0 * b0 + D1 * b1, every product and sum rounded to float32 (no fused multiply-add).
+    PARITY UNPINNED (no cv2), and inherently build-dependent where it matters: on a flat region S * a0 + S * a1 lands one
+    ulp under S as often as not, the uint8 assignment that follows truncates, and whether a given OpenCV build contracts the
+    expression into an FMA decides the result - the restatement documents one consistent choice."""
+    w, h = int(dsize[0]), int(dsize[1])
+    H, W = img.shape[:2]
+    src = np.asarray(img, np.float32)
+    if (w, h) == (W, H):
+        return src.copy()
+
+    def coef(n_src, n_dst):
+        scale = np.float64(n_src) / np.float64(n_dst)
+        d = np.arange(n_dst, dtype=np.float64)
+        f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+        s_ = np.floor(f).astype(np.int64)
+        f = (f - s_.astype(np.float32)).astype(np.float32)
+        lo = s_ < 0
+        f[lo] = 0.0
+        s_[lo] = 0
+        hi = s_ >= n_src - 1
+        f[hi] = 0.0
+        s_[hi] = n_src - 1
+        return s_, (np.float32(1.0) - f).astype(np.float32), f
+    sx, ax0, ax1 = coef(W, w)
+    sy, by0, by1 = coef(H, h)
+    sx1, sy1 = np.minimum(sx + 1, W - 1), np.minimum(sy + 1, H - 1)
+    rows = (src[:, sx] * ax0[None, :, None]).astype(np.float32) + (src[:, sx1] * ax1[None, :, None]).astype(np.float32)
+    rows = rows.astype(np.float32)
+    out = (rows[sy] * by0[:, None, None]).astype(np.float32) + (rows[sy1] * by1[:, None, None]).astype(np.float32)
+    return out.astype(np.float32)
+
+
+# ---- YOLOFRandomDistortion (data/transforms/augmentation_impl.py:115-133, transform.py:250-308): cv2.cvtColor's 8-bit
+# RGB <-> HSV both ways around three float32 scalings.  OpenCV's published 8-bit algorithms (modules/imgproc/src/
+# color_hsv.simd.hpp): RGB2HSV_b = integer arithmetic over two 12-bit reciprocal tables (H in [0, 180)); HSV2RGB_b = the
+# float formula on (h, s / 255, v / 255), the result x 255 rounded to nearest-even and saturated.  PARITY UNPINNED (no cv2).
+# cv2.COLOR_RGB2HSV takes channel 0 as R whatever the image's real order is (the YAML's FORMAT is BGR: the reference
+# distorts "the wrong way round" and so does this restatement).
+HSV_SHIFT = 12
+
+
+def _hsv_div_tables():
+    i = np.arange(1, 256, dtype=np.float64)
+    sdiv = np.zeros(256, np.int64)
+    hdiv = np.zeros(256, np.int64)
+    sdiv[1:] = np.rint((255 << HSV_SHIFT) / (1.0 * i)).astype(np.int64)        # saturate_cast<int>(double) = cvRound
+    hdiv[1:] = np.rint((180 << HSV_SHIFT) / (6.0 * i)).astype(np.int64)
+    return sdiv, hdiv
+
+
+def rgb2hsv_u8(img):
+    """cv2.cvtColor(img, cv2.COLOR_RGB2HSV), uint8 HWC: RGB2HSV_b with hrange 180"""
+    sdiv, hdiv = _hsv_div_tables()
+    r, g, b = (img[..., k].astype(np.int64) for k in range(3))
+    v = np.maximum(np.maximum(b, g), r)
+    vmin = np.minimum(np.minimum(b, g), r)
+    diff = v - vmin
+    vr = np.where(v == r, -1, 0)
+    vg = np.where(v == g, -1, 0)
+    s_ = (diff * sdiv[v] + (1 << (HSV_SHIFT - 1))) >> HSV_SHIFT
+    h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))))
+    h = (h * hdiv[diff] + (1 << (HSV_SHIFT - 1))) >> HSV_SHIFT
+    h = h + np.where(h < 0, 180, 0)
+    return np.stack([np.clip(h, 0, 255), s_ & 255, v], axis=-1).astype(np.uint8)
+
+
+def hsv2rgb_u8(hsv):
+    """cv2.cvtColor(hsv, cv2.COLOR_HSV2RGB), uint8 HWC: HSV2RGB_b = HSV2RGB_native on (h, s * (1 / 255), v * (1 / 255)) with
+    hscale = 6 / 180 in float32, then saturate_cast<uchar>(x * 255) (round to nearest even)"""
+    f32 = np.float32
+    h = hsv[..., 0].astype(f32)
+    s_ = (hsv[..., 1].astype(f32) * f32(1.0 / 255.0)).astype(f32)
+    v = (hsv[..., 2].astype(f32) * f32(1.0 / 255.0)).astype(f32)
+    h = (h * f32(6.0 / 180.0)).astype(f32)
+    h = np.where(h >= 6, (h - f32(6)).astype(f32), h)          # (h8 <= 255: at most one turn)
+    sector = np.floor(h).astype(np.int64)
+    h = (h - sector.astype(f32)).astype(f32)
+    bad = (sector < 0) | (sector >= 6)
+    sector = np.where(bad, 0, sector)
+    h = np.where(bad, f32(0), h)
+    one = f32(1)
+    t0 = v
+    t1 = (v * (one - s_).astype(f32)).astype(f32)
+    t2 = (v * (one - (s_ * h).astype(f32)).astype(f32)).astype(f32)
+    t3 = (v * (one - (s_ * (one - h).astype(f32)).astype(f32)).astype(f32)).astype(f32)
+    tab = np.stack([t0, t1, t2, t3], axis=-1)
+    sd = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])      # (b, g, r) table rows per sector
+    pick = lambda k: np.take_along_axis(tab, sd[sector][..., k][..., None], axis=-1)[..., 0]
+    b, g, r = pick(0), pick(1), pick(2)
+    grey = s_ == 0
+    b, g, r = (np.where(grey, v, c) for c in (b, g, r))
+    q = lambda c: np.clip(np.rint((c * f32(255)).astype(f32)), 0, 255).astype(np.uint8)
+    return np.stack([q(r), q(g), q(b)], axis=-1)
+
+
+def draw_distortion(rng_np, hue, saturation, exposure):
+    """YOLOFDistortTransform.apply_image's draws (transform.py:268-270, _rand_scale :293-308): (dhue, dsat, dexp)"""
+    def rand_scale(upper):
+        scale = rng_np.uniform(low=1, high=upper)
+        return scale if rng_np.rand() > 0.5 else 1 / scale
+    dhue = rng_np.uniform(low=-hue, high=hue)
+    dsat = rand_scale(saturation)
+    dexp = rand_scale(exposure)
+    return float(dhue), float(dsat), float(dexp)
+
+
+def distort_image(img, dhue, dsat, dexp):
+    """YOLOFDistortTransform.apply_image (transform.py:272-288) on a uint8 HWC image, numpy's float32 arithmetic as the
+    reference runs it; returns uint8 (the reference returns the same integers as float32)"""
+    x = np.asarray(rgb2hsv_u8(img), dtype=np.float32) / 255.
+    x[:, :, 1] *= dsat
+    x[:, :, 2] *= dexp
+    H = x[:, :, 0] + dhue * 179 / 255.
+    if dhue > 0:
+        H[H > 1.0] -= 1.0
+    else:
+        H[H < 0.0] += 1.0
+    x[:, :, 0] = H
+    x = (x * 255).clip(0, 255).astype(np.uint8)
+    return hsv2rgb_u8(x)
+
+
 def bilinear_tab():
     """imgwarp.cpp initInterTab2D(INTER_LINEAR, fixpt): 32 x 32 x (2 x 2) weights saturate_cast<short>(w * 32768), each cell
     then made to sum to 32768 (a deficit goes to the largest weight, an excess is taken from the smallest).  The cell of an
@@ -229,16 +355,21 @@ def mosaic_placement(i, w, h, xc, yc, input_dim):
     return (x1a, y1a, x2a, y2a), (x1b, y1b, x2b, y2b)
 
 
-def mosaic4(imgs, labels, input_dim, yc, xc):
+def mosaic4(imgs, labels, input_dim, yc, xc, float_src=False):
     """dataset_mapper.py:523-590: four images resized by min(h / h0, w / w0), pasted around (xc, yc) on a 114 canvas;
-    labels rows (x1, y1, x2, y2, cls) scaled, shifted and clipped to the canvas"""
+    labels rows (x1, y1, x2, y2, cls) scaled, shifted and clipped to the canvas.  float_src: the loaded images are float32
+    (YOLOFRandomDistortion ran: transform.py:286) - cv2.resize then takes its float path and the assignment into the uint8
+    canvas truncates"""
     img4 = np.full((input_dim[0] * 2, input_dim[1] * 2, 3), 114, dtype=np.uint8)
     labels4 = []
     for i in range(4):
         img, _labels = imgs[i], np.asarray(labels[i], np.float64).reshape(-1, 5)
         h0, w0 = img.shape[:2]
         scale = min(1. * input_dim[0] / h0, 1. * input_dim[1] / w0)
-        img = resize_linear_u8(img, (int(w0 * scale), int(h0 * scale)))
+        if float_src:
+            img = resize_linear_f32(img, (int(w0 * scale), int(h0 * scale)))       # (float32; img4[...] = img truncates)
+        else:
+            img = resize_linear_u8(img, (int(w0 * scale), int(h0 * scale)))
         h, w = img.shape[:2]
         (x1a, y1a, x2a, y2a), (x1b, y1b, x2b, y2b) = mosaic_placement(i, w, h, xc, yc, input_dim)
         img4[y1a:y2a, x1a:x2a] = img[y1b:y2b, x1b:x2b]
@@ -261,10 +392,10 @@ def mosaic4(imgs, labels, input_dim, yc, xc):
     return img4, labels4
 
 
-def mosaic_sample(imgs, labels, input_dim, yc, xc, draws):
+def mosaic_sample(imgs, labels, input_dim, yc, xc, draws, float_src=False):
     """one training sample of the mosaic branch (mixup off, as configs/coco/yolox_s.yaml:57-62): HWC uint8 image of size
     input_dim and its (x1, y1, x2, y2, cls) rows"""
-    img4, labels4 = mosaic4(imgs, labels, input_dim, yc, xc)
+    img4, labels4 = mosaic4(imgs, labels, input_dim, yc, xc, float_src)
     return random_perspective(img4, labels4, draws, border=[-input_dim[0] // 2, -input_dim[1] // 2])
 
 
@@ -358,7 +489,7 @@ def mixup_geometry(img_hw, input_dim, jit):
     return r, (rw1, rh1), (ow, oh)
 
 
-def mixup(origin_img, origin_labels, img, cp_labels, input_dim, jit, flip, offsets):
+def mixup(origin_img, origin_labels, img, cp_labels, input_dim, jit, flip, offsets, float_src=False):
     """MyDatasetMapper2.mixup (dataset_mapper.py:686-768) with its draws given: jit = random.uniform(*MSCALE), flip =
     random.uniform(0, 1) > 0.5, the pool sample (img, cp_labels) and offsets = (x_offset, y_offset) - the two
     random.randint draws, taken only when the padded image exceeds the target (mixup_offsets_range gives their ranges)"""
@@ -366,7 +497,8 @@ def mixup(origin_img, origin_labels, img, cp_labels, input_dim, jit, flip, offse
     origin_labels = np.asarray(origin_labels, np.float64).reshape(-1, 5)
     cp_img = np.ones((input_dim[0], input_dim[1], 3)) * 114.0
     r, (rw1, rh1), (ow, oh) = mixup_geometry(img.shape[:2], input_dim, jit)
-    cp_img[:rh1, :rw1] = resize_linear_u8(img, (rw1, rh1)).astype(np.float32)
+    # (float_src: the pool image went through YOLOFRandomDistortion and is float32 - cv2.resize's float path, no rounding)
+    cp_img[:rh1, :rw1] = (resize_linear_f32(img, (rw1, rh1)) if float_src else resize_linear_u8(img, (rw1, rh1))).astype(np.float32)
     cp_img = resize_linear_f64(cp_img, (ow, oh))
     cp_scale_ratio = r * jit
     if flip:
@@ -405,7 +537,7 @@ def mixup_offsets_range(img_hw, input_dim, jit, target_hw):
 # The augmentations `MyDatasetMapper2._load_image_with_annos` (dataset_mapper.py:642-683) applies to EVERY loaded image -
 # the current one and the three mosaic samples - before the mosaic branch, and all there is in the non-mosaic branch
 # (dataset_mapper.py:615-640): `build_normal_augmentation` (data/detection_utils.py:37-86) = T.ResizeShortestEdge,
-# T.RandomFlip (horizontal), T.RandomFlip (vertical), [colour: not restated], YOLOFRandomShift
+# T.RandomFlip (horizontal), T.RandomFlip (vertical), RandomSaturation, RandomBrightness, YOLOFRandomDistortion, YOLOFRandomShift
 # (data/transforms/augmentation_impl.py:168-191, transform.py:341-410).  detectron2 is un-vendored (readme.md:178 "latest"):
 # ResizeShortestEdge.get_output_shape / ResizeTransform / HFlipTransform / Transform.apply_box are restated from its
 # published source (detectron2/data/transforms/{augmentation_impl,transform}.py, fvcore/transforms/transform.py) - PARITY
@@ -491,10 +623,14 @@ def resize_shortest_edge_shape(oldh, oldw, short_edge_length, max_size):
 
 
 def draw_front(rng_np, hw, min_sizes=(416, 512, 608, 768), max_size=800, sample_style="choice", hflip_prob=0.5, vflip_prob=0.5,
-               shift_prob=0.5, max_shifts=32, hflip=True, vflip=True, shift=True, saturation=False, brightness=False):
+               shift_prob=0.5, max_shifts=32, hflip=True, vflip=True, shift=True, saturation=False, brightness=False,
+               distortion=None):
     """the random numbers of the chain in the reference's order (AugmentationList: each get_transform sees the image the
     previous transforms produced): ResizeShortestEdge (np.random.choice / randint), RandomFlip x2 (np.random.uniform),
-    YOLOFRandomShift (uniform, then randint x, randint y when it fires)"""
+    YOLOFRandomShift (uniform, then randint x, randint y when it fires).  NOTE on the order of the stream with
+    distortion=(hue, saturation, exposure): AugmentationList calls get_transform AND applies the transform to the image
+    before the next augmentation draws, and YOLOFDistortTransform draws inside apply_image - so its three draws sit between
+    RandomBrightness's and YOLOFRandomShift's, exactly where this function takes them"""
     h, w = hw
     if sample_style == "range":
         size = int(rng_np.randint(min_sizes[0], min_sizes[1] + 1))
@@ -510,6 +646,9 @@ def draw_front(rng_np, hw, min_sizes=(416, 512, 608, 768), max_size=800, sample_
         d["sat"] = float(rng_np.uniform(0.8, 1.2))
     if brightness:
         d["bri"] = float(rng_np.uniform(0.8, 1.2))
+    if distortion is not None:      # detection_utils.py:75-80: YOLOFRandomDistortion(hue, saturation, exposure) - its draws
+        hue, sat_hi, exp_hi = distortion                           # happen in YOLOFDistortTransform.apply_image (transform.py:268-270)
+        d["dis"] = draw_distortion(rng_np, hue, sat_hi, exp_hi)
     if shift and max_shifts > 0:
         if rng_np.uniform(0, 1.0) < shift_prob:
             d["sx"] = int(rng_np.randint(low=-max_shifts, high=max_shifts))
@@ -536,6 +675,8 @@ def front_image(img, d):
         x = out.astype(np.float32)
         x = (1 - w) * 0 + w * x
         out = np.clip(x, 0, 255).astype(np.uint8)
+    if d.get("dis") is not None:    # YOLOFDistortTransform.apply_image; the reference returns this image as float32
+        out = distort_image(out, *d["dis"])
     sx, sy = d["sx"], d["sy"]
     if sx or sy:
         new = np.zeros_like(out)
@@ -609,6 +750,7 @@ def mapper_call(pool, cur, rng_np, rng_py, mcfg=None, front_kw=None, enable_mosa
     random_perspective / mixup leave them.  Every image is loaded through the T.* front (`_load_image_with_annos`)."""
     mcfg = dict(MOSAIC_DEFAULTS, **(mcfg or {}))
     front_kw = front_kw or {}
+    fsrc = front_kw.get("distortion") is not None     # every loaded image is float32 then (YOLOFDistortTransform's return)
     flag, partners = 0, None
     if enable_mosaic and enable_aug:
         if len(pool) > num_images:
@@ -628,7 +770,7 @@ def mapper_call(pool, cur, rng_np, rng_py, mcfg=None, front_kw=None, enable_mosa
     if flag == 1 and partners is not None:
         input_dim, yc, xc, draws = draw_mosaic_params(rng_np, rng_py, mcfg)
         loaded = [(img, lab)] + [load(e) for e in partners]
-        out, t = mosaic_sample([x[0] for x in loaded], [x[1] for x in loaded], input_dim, yc, xc, draws)
+        out, t = mosaic_sample([x[0] for x in loaded], [x[1] for x in loaded], input_dim, yc, xc, draws, float_src=fsrc)
         if enable_mixup and len(t):
             jit = rng_py.uniform(*mscale)
             flip = rng_py.uniform(0, 1) > 0.5
@@ -636,7 +778,7 @@ def mapper_call(pool, cur, rng_np, rng_py, mcfg=None, front_kw=None, enable_mosa
             xm, ym = mixup_offsets_range(cp_img.shape[:2], input_dim, jit, out.shape[:2])
             y_off = rng_py.randint(0, ym) if ym is not None else 0
             x_off = rng_py.randint(0, xm) if xm is not None else 0
-            out, t = mixup(out, t, cp_img, cp_lab, input_dim, jit, flip, (x_off, y_off))
+            out, t = mixup(out, t, cp_img, cp_lab, input_dim, jit, flip, (x_off, y_off), float_src=fsrc)
         return out, np.asarray(t, np.float64).reshape(-1, 5), True
     box, cls_ = filter_empty(lab[:, :4], lab[:, 4])
     return img, np.concatenate([box.astype(np.float64), np.asarray(cls_, np.float64)[:, None]], 1), False

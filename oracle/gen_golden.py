@@ -360,6 +360,27 @@ def gold_random_perspective():
     print("random_perspective:", [len(res[f"labels{k}"]) for k in range(4)], "labels kept")
 
 
+def gold_distortion():
+    """the reference's own YOLOFDistortTransform.apply_image (data/transforms/transform.py:250-308) on seeded uint8 images
+    with numpy's global stream seeded: the distorted image (float32 in the reference; stored as uint8 - same integers) and
+    the state of the stream afterwards (one more uniform draw: pins HOW MANY variates the transform consumed).  cv2.cvtColor
+    is oracle/augment_oracle.py's restatement (no cv2 here): this pins the reference's numpy arithmetic, dtype rules and
+    draws, not OpenCV's colour conversion."""
+    m = ref_loader.load_transforms()
+    res = {}
+    for k, (hw, seed) in enumerate((((33, 47), 3), ((64, 40), 4), ((21, 90), 5), ((50, 50), 6))):
+        img = np.random.RandomState(200 + k).randint(0, 256, (hw[0], hw[1], 3), dtype=np.uint8)
+        if k == 3:
+            img[:, :25] = img[:, :25, :1]                            # grey pixels (S = 0) and a flat region
+            img[30:, :] = 255
+        np.random.seed(seed)
+        out = m.YOLOFDistortTransform(hue=0.1, saturation=1.5, exposure=1.5).apply_image(img)
+        assert out.dtype == np.float32 and np.array_equal(out, np.floor(out))
+        res[f"out{k}"], res[f"next{k}"] = out.astype(np.uint8), np.float64(np.random.uniform())
+    np.savez_compressed(os.path.join(OUT, "distortion.npz"), **res)
+    print("distortion:", {k: (v.shape if v.ndim else float(v)) for k, v in res.items()})
+
+
 def gold_pil_resize():
     """Pillow's own Image.resize(BILINEAR) - what detectron2's ResizeTransform.apply_image runs for a uint8 image inside
     T.ResizeShortestEdge (the first entry of build_normal_augmentation, data/detection_utils.py:37-86) - on seeded images:
@@ -899,6 +920,7 @@ if __name__ == "__main__":
     gold_yolov6_loss()
     gold_bifpn()
     gold_random_perspective()
+    gold_distortion()
     gold_pil_resize()
     gold_jpeg()
     gold_encoder_layer()

@@ -309,6 +309,47 @@ def load_nms_family():
     return out
 
 
+def load_transforms():
+    """yolov7/data/transforms/transform.py loaded by path (YOLOFDistortTransform, YOLOFShiftTransform).  cv2 is not installed:
+    cv2.cvtColor is provided by oracle/augment_oracle.py's restatement of OpenCV's 8-bit RGB <-> HSV conversions, so the
+    reference's own numpy arithmetic and random draws run as they are (this pins THOSE, not cv2).  fvcore / detectron2's
+    Transform base (un-vendored) is a stub with the two members the module uses: `_set_attributes` and `register_type`."""
+    load()
+    import augment_oracle as A
+    cv2 = sys.modules["cv2"]
+    cv2.COLOR_RGB2HSV, cv2.COLOR_HSV2RGB = 41, 55
+    cv2.cvtColor = lambda img, code: A.rgb2hsv_u8(img) if code == 41 else A.hsv2rgb_u8(img)
+
+    class Transform:
+        def _set_attributes(self, params=None):
+            for k, v in (params or {}).items():
+                if k != "self" and not k.startswith("_"):
+                    setattr(self, k, v)
+
+        @classmethod
+        def register_type(cls, data_type, func=None):
+            return (lambda f: f) if func is None else func
+    _stub("fvcore.transforms.transform", Transform=Transform, TransformList=list, NoOpTransform=Transform)
+    _stub("fvcore.transforms", transform=sys.modules["fvcore.transforms.transform"])
+    if "fvcore" not in sys.modules:
+        _stub("fvcore")
+    sys.modules["fvcore"].transforms = sys.modules["fvcore.transforms"]
+    _stub("detectron2.data.transforms", Transform=Transform, HFlipTransform=type("HFlipTransform", (Transform,), {}),
+          VFlipTransform=type("VFlipTransform", (Transform,), {}), ResizeTransform=type("ResizeTransform", (Transform,), {}))
+    if "PIL" not in sys.modules:
+        try:
+            import PIL.Image  # noqa: F401
+        except ImportError:
+            _stub("PIL", Image=None)
+    y = os.path.join(REF, "yolov7")
+    for name, sub in (("yolov7.data", ("data",)), ("yolov7.data.transforms", ("data", "transforms"))):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [os.path.join(y, *sub)]
+            sys.modules[name] = m
+    return importlib.import_module("yolov7.data.transforms.transform")
+
+
 def load_yolov6_loss():
     """head/yolov6_head.py loaded by path for its ComputeLoss (SimOTA + IOUlossV6 + L1).  The EfficientRep `Conv` import
     (unused by the loss) and `alfred.print_shape` (a debug print) are stubbed."""

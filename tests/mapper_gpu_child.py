@@ -36,7 +36,11 @@ def data(seed, n):
 
 
 bad, seen = [], dict(plain=0, mosaic=0, mixed_batches=0)
-for mixup in (False, True):
+# distort: the colour entries of configs/coco/yolox_s.yaml:46-50 (RandomSaturation, RandomBrightness, YOLOFRandomDistortion) on -
+# every loaded image is then float32 in the reference and the mosaic / mixup resizes take cv2's float path
+for mixup, distort in ((False, False), (True, False), (False, True), (True, True)):
+    FRONT = dict(FRONT, SATURATION=distort, BRIGHTNESS=distort, DISTORTION=distort)
+    OFRONT = dict(OFRONT, saturation=distort, brightness=distort, distortion=(0.1, 1.5, 1.5) if distort else None)
     mp = GpuDatasetMapper(device="cuda", enable_mixup=mixup, front_cfg=FRONT, mosaic_cfg=MOSAIC)
     r1n, r1p, r2n, r2p = np.random.RandomState(17), random.Random(18), np.random.RandomState(17), random.Random(18)
     pool = []
@@ -51,17 +55,17 @@ for mixup in (False, True):
         seen["plain"] += kinds.count(False); seen["mosaic"] += kinds.count(True); seen["mixed_batches"] += len(set(kinds)) == 2
         got = out.cpu().numpy()
         if got.shape != ref_img.shape:
-            bad.append(("shape", mixup, k, got.shape, ref_img.shape))
+            bad.append(("shape", mixup, distort, k, got.shape, ref_img.shape))
             continue
         for b in range(len(chunk)):
             n = int((got[b] != ref_img[b]).sum())
             if n:
-                bad.append(("pixels", mixup, k, b, kinds[b], n))
+                bad.append(("pixels", mixup, distort, k, b, kinds[b], n))
         if not np.array_equal(rows.cpu().numpy(), ref_rows):
-            bad.append(("rows", mixup, k))
+            bad.append(("rows", mixup, distort, k))
         if any(tuple(s) != r[0].shape[:2] for s, r in zip(sizes, ref) if not r[2]):     # (a mosaic sample reports its input_dim)
-            bad.append(("sizes", mixup, k))
-if seen["mosaic"] < 4 or seen["plain"] < 8 or seen["mixed_batches"] < 2:
+            bad.append(("sizes", mixup, distort, k))
+if seen["mosaic"] < 8 or seen["plain"] < 16 or seen["mixed_batches"] < 4:
     bad.append(("coverage", seen))
 print("dataset mapper on the GPU:", "bit-identical " + str(seen) if not bad else bad[:8])
 sys.exit(1 if bad else 0)

@@ -9,6 +9,7 @@ extern "C" int pil_front_host(const unsigned char* src, int h0, int w0, int nh, 
   j.src = src; j.tmp = tmp; j.dst = dst; j.dsc = dsc; j.dsy = dsy; j.dsx = dsx; j.src_ld = (long long)w0 * 3;
   j.h0 = h0; j.w0 = w0; j.nh = nh; j.nw = nw; j.hflip = hflip; j.vflip = vflip; j.shift_x = shift_x; j.shift_y = shift_y;
   j.src_hflip = 0; j.color = 0; j.sat_src = 0.0; j.sat_dst = j.bri_dst = 0.f;
+  j.dis_hue = j.dis_sat = j.dis_exp = 0.f; j.dis_pos = 0;
   j.blk0h = j.blk0v = 0;
   if (nw != w0) {
     for (int y = 0; y < h0; ++y)

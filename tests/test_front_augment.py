@@ -337,8 +337,8 @@ def test_detr_mapper_host_half_and_emulated_launches_equal_the_oracle(host_lib):
         mp.make_batch(timgs, [l for _, l in data])
 
 
-@pytest.mark.parametrize("mixup", [False, True])
-def test_mapper_run_plumbing_on_the_host(host_lib, monkeypatch, mixup):
+@pytest.mark.parametrize("mixup,distort", [(False, False), (True, False), (False, True), (True, True)])
+def test_mapper_run_plumbing_on_the_host(host_lib, monkeypatch, mixup, distort):
     """`GpuDatasetMapper.run` - which loads go through the front, the pool view handed to the mosaic mapper (fronted images,
     fronted labels, the mixup partner's index), the assembly of the MIXED batch - executed on host tensors: the front's
     launches are walked by the host build of its thread bodies, the mosaic mapper's three launches are stood in for by the
@@ -356,20 +356,25 @@ def test_mapper_run_plumbing_on_the_host(host_lib, monkeypatch, mixup):
         host_lib.pil_emulate_launches(C.cast(jobs, C.c_void_p), len(jobs), bh.value, bv.value)
         self._keep = keep
 
-    def fake_mosaic(self, pool, groups, params, mixups=None):
+    def fake_mosaic(self, pool, groups, params, mixups=None, float_src=False):
+        assert float_src == distort              # (the front's DISTORTION makes every loaded image float32 in the reference)
         samples = []
         for b, (grp, p) in enumerate(zip(groups, params)):
-            img, t = A.mosaic_sample([pool.images[i].numpy() for i in grp], [pool.labels[i] for i in grp], p["input_dim"], p["yc"], p["xc"], p["draws"])
+            img, t = A.mosaic_sample([pool.images[i].numpy() for i in grp], [pool.labels[i] for i in grp], p["input_dim"], p["yc"], p["xc"], p["draws"],
+                                     float_src=float_src)
             mx = mixups[b] if mixups is not None else None
             if mx is not None and len(t):
-                img, t = A.mixup(img, t, pool.images[mx["idx"]].numpy(), pool.labels[mx["idx"]], p["input_dim"], mx["jit"], mx["flip"], (mx["x_off"], mx["y_off"]))
+                img, t = A.mixup(img, t, pool.images[mx["idx"]].numpy(), pool.labels[mx["idx"]], p["input_dim"], mx["jit"], mx["flip"], (mx["x_off"], mx["y_off"]),
+                                 float_src=float_src)
             samples.append((img, t))
         out, rows = A.preprocess_batch(samples)
         return torch.from_numpy(out), torch.from_numpy(rows), [tuple(p["input_dim"]) for p in params]
     monkeypatch.setattr(GpuFrontAugment, "_launch", launch)
     monkeypatch.setattr(GpuFrontAugment, "_check_device", lambda self, images: None)
     monkeypatch.setattr(GpuMosaicMapper, "make_batch", fake_mosaic)
-    mp = GpuDatasetMapper(device="cpu", enable_mixup=mixup, front_cfg=MAPPER_FRONT, mosaic_cfg=MAPPER_MOSAIC)
+    fcfg = dict(MAPPER_FRONT, SATURATION=distort, BRIGHTNESS=distort, DISTORTION=distort)     # (yolox_s.yaml switches the three on together)
+    okw = dict(ORACLE_FRONT, saturation=distort, brightness=distort, distortion=(0.1, 1.5, 1.5) if distort else None)
+    mp = GpuDatasetMapper(device="cpu", enable_mixup=mixup, front_cfg=fcfg, mosaic_cfg=MAPPER_MOSAIC)
     r1n, r1p, r2n, r2p = np.random.RandomState(17), random.Random(18), np.random.RandomState(17), random.Random(18)
     pool, kinds = [], []
     data = _mapper_data(40 + mixup, 24)
@@ -377,7 +382,7 @@ def test_mapper_run_plumbing_on_the_host(host_lib, monkeypatch, mixup):
         chunk = data[k: k + 6]
         plans = [mp.plan(torch.from_numpy(i), l, r1n, r1p) for i, l in chunk]
         out, rows, sizes = mp.run(plans)
-        ref = [A.mapper_call(pool, (i, l), r2n, r2p, mcfg=MAPPER_MOSAIC, front_kw=ORACLE_FRONT, enable_mixup=mixup) for i, l in chunk]
+        ref = [A.mapper_call(pool, (i, l), r2n, r2p, mcfg=MAPPER_MOSAIC, front_kw=okw, enable_mixup=mixup) for i, l in chunk]
         ref_img, ref_rows = A.preprocess_batch([(r[0], r[1]) for r in ref])
         kinds += [r[2] for r in ref]
         assert tuple(out.shape) == ref_img.shape
@@ -478,3 +483,87 @@ def test_colour_blends_equal_numpys_arithmetic(host_lib, monkeypatch):
             ref = A.front_image(i, d)
             assert np.array_equal(o.numpy(), ref), d
             assert not np.array_equal(ref, A.front_image(i, dict(d, sat=None, bri=None)))      # the blends did something
+
+
+# ------------------------------------------------------------------------------------------------ YOLOFRandomDistortion
+def test_distortion_oracle_against_the_reference_golden(golden_dir):
+    """oracle distort_image / draw_distortion against the reference's own YOLOFDistortTransform.apply_image run by path
+    (golden distortion.npz, oracle/gen_golden.py::gold_distortion): same pixels, same number of variates drawn.  cv2.cvtColor
+    is the restatement on both sides: this pins the numpy arithmetic, its dtype rules and the random stream - not OpenCV"""
+    g = np.load(os.path.join(golden_dir, "distortion.npz"))
+    for k, (hw, seed) in enumerate((((33, 47), 3), ((64, 40), 4), ((21, 90), 5), ((50, 50), 6))):
+        img = np.random.RandomState(200 + k).randint(0, 256, (hw[0], hw[1], 3), dtype=np.uint8)
+        if k == 3:
+            img[:, :25] = img[:, :25, :1]
+            img[30:, :] = 255
+        r = np.random.RandomState(seed)
+        d = A.draw_distortion(r, 0.1, 1.5, 1.5)
+        assert np.array_equal(A.distort_image(img, *d), g[f"out{k}"]), k
+        assert float(r.uniform()) == float(g[f"next{k}"]), k         # five variates consumed, as the reference consumed
+
+
+def test_hsv_restatement_sanity():
+    """OpenCV's 8-bit RGB <-> HSV as restated (no cv2 to pin it): against colorsys within the quantisation (H in 2-degree
+    steps: one unit of 180), grey pixels have S = 0 and survive the round trip exactly, pure colours land on their hue"""
+    import colorsys
+    r = np.random.RandomState(1)
+    img = r.randint(0, 256, (40, 50, 3), dtype=np.uint8)
+    hsv = A.rgb2hsv_u8(img).astype(np.float64)
+    ref = np.array([[colorsys.rgb_to_hsv(*(img[y, x] / 255.0)) for x in range(50)] for y in range(40)])
+    dh = np.abs(hsv[..., 0] - ref[..., 0] * 180)
+    dh = np.minimum(dh, 180 - dh)
+    assert dh.max() <= 1.0 and np.abs(hsv[..., 1] - ref[..., 1] * 255).max() <= 1.0 and np.array_equal(hsv[..., 2], img.max(-1))
+    grey = np.repeat(r.randint(0, 256, (8, 8, 1), dtype=np.uint8), 3, axis=2)
+    assert (A.rgb2hsv_u8(grey)[..., 1] == 0).all() and np.array_equal(A.hsv2rgb_u8(A.rgb2hsv_u8(grey)), grey)
+    pure = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0]]], np.uint8)
+    assert A.rgb2hsv_u8(pure)[0, :, 0].tolist() == [0, 60, 120, 30]
+    assert np.array_equal(A.hsv2rgb_u8(A.rgb2hsv_u8(pure)), pure)
+    assert np.abs(A.hsv2rgb_u8(A.rgb2hsv_u8(img)).astype(int) - img.astype(int)).max() <= 6     # (the hue quantisation)
+
+
+def test_distortion_pixel_function_on_the_host_equals_the_oracle(host_lib):
+    """the per-pixel function the HIP kernel calls (csrc/pil_resize_core.h pil_distort, host build) through the product's own
+    job table: resize + flips + saturation + brightness + DISTORTION + shift against oracle.front_image - bit for bit"""
+    import torch
+    from yolov7_d2_amd import _lib as L
+    from yolov7_d2_amd.data_pipeline import GpuFrontAugment
+    lib = L.lib()
+    fa = GpuFrontAugment(dict(MIN_SIZE_TRAIN=(48, 64, 96), MAX_SIZE_TRAIN=128, SHIFT_PIXELS=6, SATURATION=True, BRIGHTNESS=True,
+                              DISTORTION=True), device="cpu")
+    r1, r2 = np.random.RandomState(31), np.random.RandomState(31)
+    imgs, draws = [], []
+    for k in range(10):
+        h, w = int(r1.randint(40, 120)), int(r1.randint(40, 120)); r2.randint(40, 120); r2.randint(40, 120)
+        img = r1.randint(0, 256, (h, w, 3), dtype=np.uint8); r2.randint(0, 256, (h, w, 3), dtype=np.uint8)
+        if k % 3 == 0:
+            img[: h // 2] = img[: h // 2, :, 1:2]                   # grey half
+        d1 = fa.draw((h, w), r1)
+        d2 = A.draw_front(r2, (h, w), min_sizes=(48, 64, 96), max_size=128, max_shifts=6, saturation=True, brightness=True,
+                          distortion=(0.1, 1.5, 1.5))
+        assert d1 == d2 and d1["dis"] is not None
+        imgs.append(img); draws.append(d1)
+    assert any(d["dis"][0] > 0 for d in draws) and any(d["dis"][0] <= 0 for d in draws)
+    timgs = [torch.from_numpy(i) for i in imgs]
+    outs = [torch.full((d["nh"], d["nw"], 3), 7, dtype=torch.uint8) for d in draws]
+    jobs, tmps = fa._jobs(timgs, draws, [(o.data_ptr(), 1, 3 * d["nw"], 3) for o, d in zip(outs, draws)])
+    assert all(j.color == 7 for j in jobs)
+    bh, bv = C.c_int32(0), C.c_int32(0)
+    L.check(lib.mi_pil_resize_jobs_layout(jobs, len(jobs), C.byref(bh), C.byref(bv)), "layout")
+    host_lib.pil_emulate_launches(C.cast(jobs, C.c_void_p), len(jobs), bh.value, bv.value)
+    for o, i, d in zip(outs, imgs, draws):
+        assert np.array_equal(o.numpy(), A.front_image(i, d)), d
+
+
+def test_float_source_resize_oracle():
+    """cv2.resize's float path as restated (what the mosaic / mixup branches run once the distortion has made the image
+    float32): equals the float64 restatement to float32 rounding, the identity size copies, a constant image stays within one
+    ulp of its value (and therefore truncates to c or c - 1: the build-dependent case the docstring names)"""
+    r = np.random.RandomState(2)
+    img = r.randint(0, 256, (37, 53, 3)).astype(np.float32)
+    for dsize in ((80, 60), (20, 17), (53, 90)):
+        a, b = A.resize_linear_f32(img, dsize), A.resize_linear_f64(img.astype(np.float64), dsize)
+        assert a.dtype == np.float32 and np.abs(a - b).max() < 1e-3
+    assert np.array_equal(A.resize_linear_f32(img, (53, 37)), img)
+    flat = np.full((16, 16, 3), 200, np.float32)
+    out = A.resize_linear_f32(flat, (37, 29))
+    assert np.abs(out - 200).max() < 1e-4 and set(np.unique(out.astype(np.uint8))) <= {199, 200}

@@ -159,7 +159,8 @@ def test_dataset_mapper_batches_equal_the_oracle():
     """`GpuDatasetMapper.make_batch` = MyDatasetMapper2.__call__ per sample (dataset_mapper.py:477-640: front, mosaic flag,
     partners, four pastes, random_perspective, mixup) + preprocess_image over the MIXED batch, against the oracle's
     `mapper_call` on the same random streams: pixels and label rows bit-identical (tests/mapper_gpu_child.py: eight batches
-    of six, with and without mixup)."""
+    of six, with and without mixup, with and without the colour entries of yolox_s.yaml - RandomSaturation, RandomBrightness,
+    YOLOFRandomDistortion - after which the mosaic / mixup resizes run cv2's float path)."""
     _run_child("mapper_gpu_child.py")
 
 

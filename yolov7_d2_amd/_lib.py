@@ -161,7 +161,7 @@ class mi_pack_job(C.Structure):
 
 class mi_mosaic_paste_job(C.Structure):
     _fields_ = [("src", C.c_void_p), ("canvas", C.c_void_p)] + [(n, C.c_int32) for n in
-                ("h0", "w0", "rh", "rw", "cw", "x1a", "y1a", "x2a", "y2a", "x1b", "y1b", "blk0")]
+                ("h0", "w0", "rh", "rw", "cw", "x1a", "y1a", "x2a", "y2a", "x1b", "y1b", "blk0", "fsrc", "pad_")]
 
 
 class mi_warp_job(C.Structure):
@@ -171,14 +171,15 @@ class mi_warp_job(C.Structure):
 
 class mi_mixup_job(C.Structure):
     _fields_ = [("src", C.c_void_p), ("out", C.c_void_p)] + [(n, C.c_int32) for n in
-                ("h0", "w0", "rh1", "rw1", "dh", "dw", "oh", "ow", "flip", "x_off", "y_off", "th", "tw", "Hp", "Wp", "blk0")]
+                ("h0", "w0", "rh1", "rw1", "dh", "dw", "oh", "ow", "flip", "x_off", "y_off", "th", "tw", "Hp", "Wp", "blk0", "fsrc", "pad_")]
 
 
 class mi_pil_resize_job(C.Structure):
     _fields_ = ([("src", C.c_void_p), ("tmp", C.c_void_p), ("dst", C.c_void_p), ("dsc", C.c_int64), ("dsy", C.c_int64),
                  ("dsx", C.c_int64), ("src_ld", C.c_int64), ("sat_src", C.c_double)] +
                 [(n, C.c_int32) for n in ("h0", "w0", "nh", "nw", "hflip", "vflip", "shift_x", "shift_y", "src_hflip", "color")] +
-                [("sat_dst", C.c_float), ("bri_dst", C.c_float), ("blk0h", C.c_int32), ("blk0v", C.c_int32)])
+                [("sat_dst", C.c_float), ("bri_dst", C.c_float), ("dis_hue", C.c_float), ("dis_sat", C.c_float), ("dis_exp", C.c_float),
+                 ("dis_pos", C.c_int32), ("blk0h", C.c_int32), ("blk0v", C.c_int32)])
 
 
 class mi_jpeg_info(C.Structure):

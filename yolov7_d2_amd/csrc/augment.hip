@@ -12,6 +12,7 @@ struct PasteJob {   // mirrors mi_mosaic_paste_job
   const unsigned char* src;
   unsigned char* canvas;
   int h0, w0, rh, rw, cw, x1a, y1a, x2a, y2a, x1b, y1b, blk0;
+  int fsrc, pad_;   // fsrc: the reference's image is float32 here (YOLOFRandomDistortion): cv2.resize's float path, then truncation
 };
 struct WarpJob {    // mirrors mi_warp_job
   const unsigned char* canvas;
@@ -32,6 +33,15 @@ __device__ __forceinline__ void resize_coef(int d, double scale, int src, int* s
   *s = si;
 }
 
+__device__ __forceinline__ void lin_coef_f(int d, double scale, int src, int* s, float* f0, float* f1) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int si = (int)floorf(f);
+  f = f - (float)si;
+  if (si < 0) { f = 0.f; si = 0; }
+  if (si >= src - 1) { f = 0.f; si = src - 1; }
+  *s = si; *f0 = 1.0f - f; *f1 = f;
+}
+
 __global__ __launch_bounds__(256) void mosaic_paste_kernel(const PasteJob* __restrict__ jobs, int njobs) {
   int j = 0;
   while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].blk0) ++j;
@@ -48,6 +58,32 @@ __global__ __launch_bounds__(256) void mosaic_paste_kernel(const PasteJob* __res
   const unsigned char* r0 = p.src + (size_t)sy * p.w0 * 3;
   const unsigned char* r1 = p.src + (size_t)sy1 * p.w0 * 3;
   unsigned char* d = p.canvas + ((size_t)(p.y1a + yy) * p.cw + p.x1a + xx) * 3;
+  if (p.fsrc) {
+    // cv2.resize of a float32 image (resize.cpp generic path, WT = float): D = S[sx] * a0 + S[sx + 1] * a1 per row, then
+    // D0 * b0 + D1 * b1, every product and sum in float32, no fused multiply-add (-ffp-contract=off); img4[...] = img
+    // truncates (oracle/augment_oracle.py::resize_linear_f32: build-dependent in the real library on flat regions)
+    if (p.rw == p.w0 && p.rh == p.h0) {      // (same size: cv2.resize copies)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) d[c] = p.src[((size_t)ry * p.w0 + rx) * 3 + c];
+      return;
+    }
+    int fsx, fsy;
+    float fx0, fx1, fy0, fy1;
+    lin_coef_f(rx, (double)p.w0 / (double)p.rw, p.w0, &fsx, &fx0, &fx1);
+    lin_coef_f(ry, (double)p.h0 / (double)p.rh, p.h0, &fsy, &fy0, &fy1);
+    const int fsx1 = min(fsx + 1, p.w0 - 1), fsy1 = min(fsy + 1, p.h0 - 1);
+    const unsigned char* q0 = p.src + (size_t)fsy * p.w0 * 3;
+    const unsigned char* q1 = p.src + (size_t)fsy1 * p.w0 * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float h0 = (float)q0[fsx * 3 + c] * fx0 + (float)q0[fsx1 * 3 + c] * fx1;
+      const float h1 = (float)q1[fsx * 3 + c] * fx0 + (float)q1[fsx1 * 3 + c] * fx1;
+      float v = h0 * fy0 + h1 * fy1;
+      v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
+      d[c] = (unsigned char)v;
+    }
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const int h0 = (int)r0[sx * 3 + c] * ax0 + (int)r0[sx1 * 3 + c] * ax1;
@@ -63,15 +99,8 @@ struct MixJob {     // mirrors mi_mixup_job
   const unsigned char* src;
   unsigned char* out;
   int h0, w0, rh1, rw1, dh, dw, oh, ow, flip, x_off, y_off, th, tw, Hp, Wp, blk0;
+  int fsrc, pad_;   // fsrc: the pool image is float32 in the reference: the first resize runs cv2's float path, unrounded
 };
-__device__ __forceinline__ void lin_coef_f(int d, double scale, int src, int* s, float* f0, float* f1) {
-  float f = (float)(((double)d + 0.5) * scale - 0.5);
-  int si = (int)floorf(f);
-  f = f - (float)si;
-  if (si < 0) { f = 0.f; si = 0; }
-  if (si >= src - 1) { f = 0.f; si = src - 1; }
-  *s = si; *f0 = 1.0f - f; *f1 = f;
-}
 __global__ __launch_bounds__(256) void mixup_blend_kernel(const MixJob* __restrict__ jobs, int njobs) {
   int j = 0;
   while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].blk0) ++j;
@@ -103,7 +132,24 @@ __global__ __launch_bounds__(256) void mixup_blend_kernel(const MixJob* __restri
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          if (ys[a] < p.rh1 && xs[b] < p.rw1) {
+          if (ys[a] < p.rh1 && xs[b] < p.rw1 && p.fsrc) {
+            // float32 source (YOLOFRandomDistortion): cv2.resize's float path, the result kept as it is (.astype(float32))
+            const int cx = min(xs[b], p.rw1 - 1), cy = min(ys[a], p.rh1 - 1);
+            if (p.rw1 == p.w0 && p.rh1 == p.h0) {
+              S[a][b] = (double)p.src[((size_t)cy * p.w0 + cx) * 3 + c];
+            } else {
+              int fsx, fsy;
+              float gx0, gx1, gy0, gy1;
+              lin_coef_f(cx, (double)p.w0 / (double)p.rw1, p.w0, &fsx, &gx0, &gx1);
+              lin_coef_f(cy, (double)p.h0 / (double)p.rh1, p.h0, &fsy, &gy0, &gy1);
+              const int fsx1 = min(fsx + 1, p.w0 - 1), fsy1 = min(fsy + 1, p.h0 - 1);
+              const unsigned char* q0 = p.src + (size_t)fsy * p.w0 * 3;
+              const unsigned char* q1 = p.src + (size_t)fsy1 * p.w0 * 3;
+              const float h0 = (float)q0[fsx * 3 + c] * gx0 + (float)q0[fsx1 * 3 + c] * gx1;
+              const float h1 = (float)q1[fsx * 3 + c] * gx0 + (float)q1[fsx1 * 3 + c] * gx1;
+              S[a][b] = (double)(h0 * gy0 + h1 * gy1);
+            }
+          } else if (ys[a] < p.rh1 && xs[b] < p.rw1) {
             const int x0 = cxs[b], x1 = min(x0 + 1, p.w0 - 1), y0 = cys[a], y1 = min(y0 + 1, p.h0 - 1);
             const unsigned char* r0 = p.src + (size_t)y0 * p.w0 * 3;
             const unsigned char* r1 = p.src + (size_t)y1 * p.w0 * 3;

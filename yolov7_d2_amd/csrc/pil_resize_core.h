@@ -9,6 +9,7 @@
 // -ffp-contract=off), then 22-bit fixed point; the horizontal pass rounds to 8 bits before the vertical pass reads it.
 #pragma once
 #include <stdint.h>
+#include <math.h>
 
 #if defined(__HIPCC__)
 #define MI_HD __host__ __device__ __forceinline__
@@ -29,8 +30,11 @@ struct PilJob {   // mirrors mi_pil_resize_job (include/mi355_det.h)
   int32_t h0, w0, nh, nw;
   int32_t hflip, vflip, shift_x, shift_y;
   int32_t src_hflip;           // the source is mirrored left-right BEFORE the resampling (T.RandomFlip ahead of the resize)
-  int32_t color;               // bit 0: RandomSaturation, bit 1: RandomBrightness (detectron2 BlendTransform), after the flips
+  int32_t color;               // bit 0: RandomSaturation, bit 1: RandomBrightness (detectron2 BlendTransform), bit 2:
+                               // YOLOFRandomDistortion (cv2's 8-bit RGB <-> HSV around three float32 scalings); after the flips
   float sat_dst, bri_dst;      // w as float32 (numpy multiplies the float32 image by the weak Python scalar in float32)
+  float dis_hue, dis_sat, dis_exp;   // float32(dhue * 179 / 255.), float32(dsat), float32(dexp) (transform.py:268-279)
+  int32_t dis_pos;             // dhue > 0: H > 1 wraps down; else H < 0 wraps up
   int32_t blk0h, blk0v;
 };
 
@@ -94,6 +98,7 @@ MI_HD void pil_h_pixel(const PilJob& j, int y, int xo, unsigned char out[3]) {
 //   saturation: grey = img.dot([0.299, 0.587, 0.114]) (fp64, the channel order as stored), out = (1 - w) * grey [fp64] +
 //               w * float32(img) [fp32 product, then widened]; brightness: out = w * float32(img) in fp32;
 //   np.clip(out, 0, 255).astype(np.uint8) truncates.  No fused multiply-add (-ffp-contract=off).
+MI_HD void pil_distort(const PilJob& j, unsigned char o[3]);
 MI_HD void pil_color(const PilJob& j, unsigned char o[3]) {
   if (j.color & 1) {
     const double grey = ((double)o[0] * 0.299 + (double)o[1] * 0.587) + (double)o[2] * 0.114;
@@ -112,6 +117,67 @@ MI_HD void pil_color(const PilJob& j, unsigned char o[3]) {
       o[c] = (unsigned char)v;
     }
   }
+  if (j.color & 4) pil_distort(j, o);
+}
+
+// YOLOFDistortTransform.apply_image (yolov7/data/transforms/transform.py:272-288) on one pixel: cv2.cvtColor(RGB2HSV) of the
+// uint8 pixel - OpenCV's RGB2HSV_b: integer arithmetic over two 12-bit reciprocal tables, H in [0, 180), channel 0 taken as
+// R whatever the image's order is -, numpy's float32 steps (/ 255., S *= dsat, V *= dexp, H += dhue * 179 / 255. with one
+// wrap, * 255, clip, truncate to uint8), cv2.cvtColor(HSV2RGB) - HSV2RGB_b: the float formula on (h, s / 255, v / 255), x 255,
+// rounded to nearest-even, saturated.  The reference returns these integers as a float32 image (see mosaic_paste's fsrc).
+// oracle/augment_oracle.py::distort_image restates the same (cv2 itself is not installed: parity unpinned).
+MI_HD unsigned char pil_trunc8(float v) {
+  v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
+  return (unsigned char)v;
+}
+MI_HD unsigned char pil_round8(float v) {
+  v = rintf(v);
+  return (unsigned char)(v < 0.f ? 0.f : (v > 255.f ? 255.f : v));
+}
+MI_HD void pil_distort(const PilJob& j, unsigned char o[3]) {
+  const int r = o[0], g = o[1], b = o[2];
+  int v = b > g ? b : g;
+  v = v > r ? v : r;
+  int vmin = b < g ? b : g;
+  vmin = vmin < r ? vmin : r;
+  const int diff = v - vmin;
+  const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+  const int sdiv = v ? (int)rint((double)(255 << 12) / (1.0 * (double)v)) : 0;          // sdiv_table[v]
+  const int hdiv = diff ? (int)rint((double)(180 << 12) / (6.0 * (double)diff)) : 0;    // hdiv_table180[diff]
+  const int s = (diff * sdiv + (1 << 11)) >> 12;
+  int h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+  h = (h * hdiv + (1 << 11)) >> 12;
+  h += h < 0 ? 180 : 0;
+  h = h < 0 ? 0 : (h > 255 ? 255 : h);
+  // numpy, float32
+  float x0 = (float)h / 255.f, x1 = (float)(s & 255) / 255.f, x2 = (float)v / 255.f;
+  x1 *= j.dis_sat;
+  x2 *= j.dis_exp;
+  float H = x0 + j.dis_hue;
+  if (j.dis_pos) { if (H > 1.0f) H -= 1.0f; }
+  else { if (H < 0.0f) H += 1.0f; }
+  const unsigned char h8 = pil_trunc8(H * 255.f), s8 = pil_trunc8(x1 * 255.f), v8 = pil_trunc8(x2 * 255.f);
+  // HSV2RGB_b
+  float hf = (float)h8;
+  const float sf = (float)s8 * (1.f / 255.f), vf = (float)v8 * (1.f / 255.f);
+  float bb, gg, rr;
+  if (sf == 0.f) {
+    bb = gg = rr = vf;
+  } else {
+    hf *= (6.f / 180.f);
+    if (hf >= 6.f) hf -= 6.f;
+    int sector = (int)floorf(hf);
+    hf -= (float)sector;
+    if ((unsigned)sector >= 6u) { sector = 0; hf = 0.f; }
+    float tab[4];
+    tab[0] = vf;
+    tab[1] = vf * (1.f - sf);
+    tab[2] = vf * (1.f - sf * hf);
+    tab[3] = vf * (1.f - sf * (1.f - hf));
+    const int sd[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+    bb = tab[sd[sector][0]]; gg = tab[sd[sector][1]]; rr = tab[sd[sector][2]];
+  }
+  o[0] = pil_round8(rr * 255.f); o[1] = pil_round8(gg * 255.f); o[2] = pil_round8(bb * 255.f);
 }
 
 // destination pixel (yd, xd) of the nh x nw result after the vertical pass, HFlipTransform, VFlipTransform and

@@ -194,9 +194,10 @@ class GpuMosaicMapper:
         return [A11, A12, -A11 * M[0, 2] - A12 * M[1, 2], A21, A22, -A21 * M[0, 2] - A22 * M[1, 2]]
 
     # ---- one batch --------------------------------------------------------------------------------------------------
-    def make_batch(self, pool, groups, params, mixups=None):
+    def make_batch(self, pool, groups, params, mixups=None, float_src=False):
         """groups: B tuples of four pool indices (the current image first, then the three sampled ones); params: B dicts
-        from draw(); mixups: None or B entries (None or a dict from draw_mixup()).  Returns (uint8 [B, 3, H, W] on the device, float32 [B, max_boxes, 5] (cls, cx, cy, w, h) on the
+        from draw(); mixups: None or B entries (None or a dict from draw_mixup()); float_src: the pool images are float32
+        in the reference (its front ended with YOLOFRandomDistortion): cv2.resize's float path + truncation.  Returns (uint8 [B, 3, H, W] on the device, float32 [B, max_boxes, 5] (cls, cx, cy, w, h) on the
         device, per-sample (h, w))"""
         if self.device.type != "cuda":
             raise L.MI355Error("GpuMosaicMapper: the MI355X path needs a device (no CPU pixel path)")
@@ -228,6 +229,7 @@ class GpuMosaicMapper:
                 j.src, j.canvas = img.data_ptr(), cbase
                 j.h0, j.w0, j.rh, j.rw, j.cw = h0, w0, h, w, dim[1] * 2
                 j.x1a, j.y1a, j.x2a, j.y2a, j.x1b, j.y1b = x1a, y1a, max(x2a, x1a), max(y2a, y1a), x1b, y1b
+                j.fsrc = int(bool(float_src))
                 if lab.size > 0:
                     t = lab.copy()
                     padw, padh = x1a - x1b, y1a - y1b
@@ -261,6 +263,7 @@ class GpuMosaicMapper:
                     mj.h0, mj.w0, mj.rh1, mj.rw1, mj.dh, mj.dw = h0, w0, int(h0 * r), int(w0 * r), dim[0], dim[1]
                     mj.oh, mj.ow, mj.flip, mj.x_off, mj.y_off = oh, ow, int(mx["flip"]), mx["x_off"], mx["y_off"]
                     mj.th, mj.tw, mj.Hp, mj.Wp = height, width, Hp, Wp
+                    mj.fsrc = int(bool(float_src))
             t = t[: self.max_boxes]
             wj = warp[b]
             wj.canvas, wj.out = cbase, out.data_ptr() + b * 3 * Hp * Wp
@@ -291,8 +294,35 @@ class GpuMosaicMapper:
 # ------------------------------------------------------------------------------------------------ the T.* front
 FRONT_DEFAULTS = dict(MIN_SIZE_TRAIN=(416, 512, 608, 768), MAX_SIZE_TRAIN=800, MIN_SIZE_TRAIN_SAMPLING="choice",
                       HFLIP=True, HFLIP_PROB=0.5, VFLIP=True, VFLIP_PROB=0.5, SATURATION=False, BRIGHTNESS=False,
+                      DISTORTION=False, DISTORTION_HUE=0.1, DISTORTION_SATURATION=1.5, DISTORTION_EXPOSURE=1.5,
                       SHIFT=True, SHIFT_PIXELS=32)
-# (configs/coco/yolox_s.yaml:35-38 + yolov7/config.py:276-286: INPUT.RANDOM_FLIP_HORIZONTAL / _VERTICAL / SHIFT defaults)
+# (configs/coco/yolox_s.yaml:35-50 + yolov7/config.py:276-299: INPUT.RANDOM_FLIP_HORIZONTAL / _VERTICAL / SHIFT / DISTORTION
+#  defaults; yolox_s.yaml:46-50 switches DISTORTION and both COLOR_JITTER entries on)
+
+
+def front_cfg_from_cfg(cfg):
+    """FRONT_DEFAULTS overridden by the INPUT.* keys `build_normal_augmentation` reads (yolov7/data/detection_utils.py:37-86;
+    defaults of absent keys: yolov7/config.py:276-299) - so that `configs/coco/yolox_s.yaml` (DISTORTION + both COLOR_JITTER
+    entries on) configures this front as it configures the reference's"""
+    import ast
+    inp = cfg.INPUT
+
+    def get(node, path, default):
+        for k in path.split("."):
+            if not (hasattr(node, "get") and k in node):
+                return default
+            node = node[k]
+        return ast.literal_eval(node) if isinstance(node, str) and node[:1] in "([" else node
+    c = dict(FRONT_DEFAULTS)
+    c.update(MIN_SIZE_TRAIN=tuple(get(inp, "MIN_SIZE_TRAIN", c["MIN_SIZE_TRAIN"])), MAX_SIZE_TRAIN=get(inp, "MAX_SIZE_TRAIN", c["MAX_SIZE_TRAIN"]),
+             MIN_SIZE_TRAIN_SAMPLING=get(inp, "MIN_SIZE_TRAIN_SAMPLING", "choice"),
+             HFLIP=bool(get(inp, "RANDOM_FLIP_HORIZONTAL.ENABLED", True)), HFLIP_PROB=get(inp, "RANDOM_FLIP_HORIZONTAL.PROB", 0.5),
+             VFLIP=bool(get(inp, "RANDOM_FLIP_VERTICAL.ENABLED", True)), VFLIP_PROB=get(inp, "RANDOM_FLIP_VERTICAL.PROB", 0.5),
+             SATURATION=bool(get(inp, "COLOR_JITTER.SATURATION", False)), BRIGHTNESS=bool(get(inp, "COLOR_JITTER.BRIGHTNESS", False)),
+             DISTORTION=bool(get(inp, "DISTORTION.ENABLED", False)), DISTORTION_HUE=get(inp, "DISTORTION.HUE", 0.1),
+             DISTORTION_SATURATION=get(inp, "DISTORTION.SATURATION", 1.5), DISTORTION_EXPOSURE=get(inp, "DISTORTION.EXPOSURE", 1.5),
+             SHIFT=bool(get(inp, "SHIFT.ENABLED", True)), SHIFT_PIXELS=get(inp, "SHIFT.SHIFT_PIXELS", 32))
+    return c
 
 
 class GpuFrontAugment:
@@ -304,10 +334,11 @@ class GpuFrontAugment:
     only builds Instances and drops empty boxes.  The host draws the reference's random numbers in the reference's order and
     does its float64 box arithmetic; the pixels (Pillow's 8-bit bilinear resampling, the flips, the shift) are two launches
     for any number of images (mi_pil_resize_h / _v), RandomSaturation / RandomBrightness (INPUT.COLOR_JITTER; detectron2's
-    BlendTransform in numpy's fp64 / fp32 arithmetic) included, per pixel between the flips and the shift.
-    YOLOFRandomDistortion (cv2's 8-bit HSV conversion both ways, after which the reference's image is float32) is NOT built:
-    with INPUT.DISTORTION off (the config.py default) the random stream and the result are the reference's, with it on
-    (yolox_s.yaml) this front skips it."""
+    BlendTransform in numpy's fp64 / fp32 arithmetic) and YOLOFRandomDistortion (DISTORTION: cv2's 8-bit RGB <-> HSV
+    conversions around three float32 scalings, data/transforms/transform.py:250-308; OpenCV's published integer / float
+    algorithms restated, csrc/pil_resize_core.h pil_distort) included, per pixel between the flips and the shift.  After the
+    distortion the reference's image is float32 (same integers): `float_images` tells the mosaic / mixup launches to take
+    cv2.resize's float path for these sources (GpuMosaicMapper.make_batch(float_src=...))."""
 
     def __init__(self, cfg=None, device="cuda", max_boxes=100, pad_value=114, size_divisibility=32):
         c = dict(FRONT_DEFAULTS)
@@ -345,6 +376,14 @@ class GpuFrontAugment:
             d["sat"] = float(rng_np.uniform(0.8, 1.2))
         if c["BRIGHTNESS"]:                                        # INPUT.COLOR_JITTER.BRIGHTNESS: RandomBrightness(0.8, 1.2)
             d["bri"] = float(rng_np.uniform(0.8, 1.2))
+        if c["DISTORTION"]:
+            # YOLOFDistortTransform.apply_image draws while the image is transformed (transform.py:268-270, _rand_scale
+            # :293-308), i.e. after RandomBrightness's draw and before YOLOFRandomShift's: dhue, then (scale, coin) twice
+            def rand_scale(upper):
+                scale = rng_np.uniform(low=1, high=upper)
+                return scale if rng_np.rand() > 0.5 else 1 / scale
+            dhue = rng_np.uniform(low=-c["DISTORTION_HUE"], high=c["DISTORTION_HUE"])
+            d["dis"] = (float(dhue), float(rand_scale(c["DISTORTION_SATURATION"])), float(rand_scale(c["DISTORTION_EXPOSURE"])))
         if c["SHIFT"] and c["SHIFT_PIXELS"] > 0:
             if rng_np.uniform(0, 1.0) < 0.5:                       # YOLOFRandomShift(prob=0.5 default, max_shifts)
                 d["sx"] = int(rng_np.randint(low=-c["SHIFT_PIXELS"], high=c["SHIFT_PIXELS"]))
@@ -424,6 +463,12 @@ class GpuFrontAugment:
             if d.get("bri") is not None:
                 j.color |= 2
                 j.bri_dst = float(np.float32(d["bri"]))
+            if d.get("dis") is not None:                           # numpy: float32 image (op) weak Python scalar -> float32
+                dhue, dsat, dexp = d["dis"]
+                j.color |= 4
+                j.dis_hue, j.dis_sat, j.dis_exp = (float(np.float32(dhue * 179 / 255.)), float(np.float32(dsat)),
+                                                    float(np.float32(dexp)))
+                j.dis_pos = int(dhue > 0)
             if d["nw"] != w0:
                 t = torch.empty(h0, d["nw"], 3, dtype=torch.uint8, device=img.device)
                 tmps.append(t)
@@ -513,7 +558,8 @@ class GpuDatasetMapper:
     reference's order and does its float64 label arithmetic; the pixels are the launches of GpuFrontAugment (one pair for all
     loads of the batch) and GpuMosaicMapper (paste, warp, mixup), the mixed batch is assembled on the device.  `enable_aug`
     False = `MyDatasetMapper2.disable_aug()` (after DISABLE_AT_ITER): the front only.  The images come decoded (device uint8
-    HWC: `GpuJpegDecoder`).  Not built: the colour entries of the augmentation list (see GpuFrontAugment)."""
+    HWC: `GpuJpegDecoder`).  With the front's DISTORTION on (configs/coco/yolox_s.yaml:46-47) every loaded image is float32 in
+    the reference from there on: the mosaic / mixup resizes then take cv2's float path (see GpuFrontAugment)."""
 
     def __init__(self, mosaic_cfg=None, front_cfg=None, device="cuda", enable_mosaic=True, enable_mixup=False, pool_capacity=1000,
                  max_boxes=100, pad_value=114, size_divisibility=32):
@@ -631,7 +677,8 @@ class GpuDatasetMapper:
                 groups.append(tuple(ids[:4]))
                 params.append(p["params"])
                 mixups.append(dict(p["mixup"], idx=ids[4]) if p["mixup"] is not None else None)
-            out, rows, sizes = self.mosaic.make_batch(view, groups, params, mixups if any(m is not None for m in mixups) else None)
+            out, rows, sizes = self.mosaic.make_batch(view, groups, params, mixups if any(m is not None for m in mixups) else None,
+                                                      float_src=bool(self.front.cfg["DISTORTION"]))
             for k, b in enumerate(mos):
                 parts[b] = (out[k], rows[k], sizes[k])
         if not plain or not mos:                                   # one kind of sample only: that launch's batch is the batch
