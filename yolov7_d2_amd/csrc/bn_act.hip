@@ -497,7 +497,7 @@ struct BnFusK {
   const float* gamma;
   float* dgamma;
   float* dbeta;
-  int ldda, ldy, lddy, lddres, dres_accum, C8, nslots, rsv_;
+  int ldda, ldy, lddy, lddres, dres_accum, C8, nslots, rsv_;   // rsv_ 1: round 4's form of phase 2 (every block reads every slot; A/B only)
   int64_t npix;
   double inv_count;
 };
@@ -628,35 +628,59 @@ __device__ __forceinline__ void bn_bwd_fused_body(PK& p, const int bid, const in
       atomicAdd(slot + (cc8 * 8 + (v & 7)) * 2 + (v >> 3), (double)acc);
     }
   }
-  __shared__ int s_gave_up;
-  bn_grid_barrier(p.bar, gen0, bid, nb, &s_gave_up);   // (its leading __syncthreads also ends the reads of red[])
-  // a block whose wait timed out holds incomplete sums: everything it writes from here on is NaN (dy of its items, and
-  // dgamma / dbeta if it is block 0), and the host finds word 2 of the barrier record set (Plan.check_bn_barriers)
-  const float poison = s_gave_up ? __builtin_nanf("") : 0.f;
-  // ---- phase 2: the finished sums (agent-scope loads: the adds were performed by other XCDs)
-  for (int c = tid; c < C; c += 256) {
-    double v1[MI_BN_SLOTS], v2[MI_BN_SLOTS];
+  __shared__ int s_gave_up, s_last;
+  // The grid barrier in two halves (conv_bn.h): the block that arrives last folds the nslots accumulator slots of every
+  // channel into slot 0 (same fixed order as before: identical totals) and records dgamma / dbeta BEFORE it releases the
+  // others, which then read two fp64 totals per channel.  Round 4 had EVERY block read every slot after the barrier:
+  // C x nslots x 2 agent-scope 8-byte loads per block (they bypass the XCD's L2: one memory-side request each), 2 M requests
+  // for a 256-channel layer on 512 blocks - measured on the same pattern in round 5's first conv prologue: ~9 us for
+  // C = 512 (profiles/r05_bn_bwd_last_arriver_ab.txt).
+  bn_bar_arrive(p.bar, bid, nb, &s_gave_up, &s_last);   // (its leading __syncthreads also ends the reads of red[])
+  const bool legacy = p.rsv_ != 0;
+  if (s_last && !legacy) {
+    for (int c = tid; c < C; c += 256) {
+      double v1[MI_BN_SLOTS], v2[MI_BN_SLOTS];
 #pragma unroll
-    for (int k = 0; k < MI_BN_SLOTS; ++k) {
-      if (k < p.nslots) {
-        v1[k] = __hip_atomic_load(p.dacc + ((size_t)k * CA + c) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v2[k] = __hip_atomic_load(p.dacc + ((size_t)k * CA + c) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        v1[k] = v2[k] = 0.0;
+      for (int k = 0; k < MI_BN_SLOTS; ++k) {
+        if (k < p.nslots) {
+          v1[k] = __hip_atomic_load(p.dacc + ((size_t)k * CA + c) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          v2[k] = __hip_atomic_load(p.dacc + ((size_t)k * CA + c) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          v1[k] = v2[k] = 0.0;
+        }
       }
-    }
-    double t1 = 0.0, t2 = 0.0;
+      double t1 = 0.0, t2 = 0.0;
 #pragma unroll
-    for (int k = 0; k < MI_BN_SLOTS; ++k) {
-      t1 += v1[k];
-      t2 += v2[k];
+      for (int k = 0; k < MI_BN_SLOTS; ++k) {
+        t1 += v1[k];
+        t2 += v2[k];
+      }
+      __hip_atomic_store(p.dacc + (size_t)c * 2, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.dacc + (size_t)c * 2 + 1, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (p.dbeta) p.dbeta[c] = (float)t1;
+      if (p.dgamma) p.dgamma[c] = (float)t2;
+    }
+  }
+  bn_bar_finish(p.bar, gen0, bid, nb, &s_gave_up, &s_last);
+  // a block whose wait timed out holds incomplete sums: everything it writes from here on is NaN (dy of its items), and
+  // the host finds word 2 of the barrier record set (Plan.check_bn_barriers)
+  const float poison = s_gave_up ? __builtin_nanf("") : 0.f;
+  // ---- phase 2: the finished totals (agent-scope loads: written by a block of another XCD)
+  for (int c = tid; c < C; c += 256) {
+    double t1 = __hip_atomic_load(p.dacc + (size_t)c * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double t2 = __hip_atomic_load(p.dacc + (size_t)c * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (legacy) {   // (slot 0 still holds its own partial: add the others)
+      for (int k = 1; k < p.nslots; ++k) {
+        t1 += __hip_atomic_load(p.dacc + ((size_t)k * CA + c) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t2 += __hip_atomic_load(p.dacc + ((size_t)k * CA + c) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (bid == 0) {
+        if (p.dbeta) p.dbeta[c] = (float)t1 + poison;
+        if (p.dgamma) p.dgamma[c] = (float)t2 + poison;
+      }
     }
     s_c1[c] = (float)(t1 * p.inv_count) + poison;
     s_c2[c] = (float)(t2 * p.inv_count) + poison;
-    if (bid == 0) {
-      if (p.dbeta) p.dbeta[c] = (float)t1 + poison;
-      if (p.dgamma) p.dgamma[c] = (float)t2 + poison;
-    }
   }
   __syncthreads();
   if (!active) return;
@@ -731,6 +755,15 @@ __global__ __launch_bounds__(256, 2) void bn_bwd_fused_group_kernel(const BnFusK
   KC4* pj = (KC4*)(uintptr_t)(jobs + j);
   bn_bwd_fused_body<ACT, MODE, KC4>(*pj, (int)blockIdx.x - starts[j], starts[j + 1] - starts[j]);
 }
+// MI_BN_BWD_LAST=0: the round-4 form of the phase between the two halves (A/B runs); read once
+static int bn_fused_every_block_reads() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MI_BN_BWD_LAST");
+    v = (e && atoi(e) == 0) ? 1 : 0;
+  }
+  return v;
+}
 static int bn_fused_mode() {
   static int m = -1;
   if (m < 0) {
@@ -804,7 +837,7 @@ extern "C" int mi_bn_act_bwd_fused(const void* da, int ldda, const void* y, int 
   k.da = (const __bf16*)da; k.y = (const __bf16*)y; k.dy = (__bf16*)dy; k.dres = (__bf16*)dres; k.dacc = dacc;
   k.bar = barrier_words; k.scale = scale; k.shift = shift; k.mean = mean; k.invstd = invstd; k.gamma = gamma;
   k.dgamma = dgamma; k.dbeta = dbeta; k.ldda = ldda; k.ldy = ldy; k.lddy = lddy; k.lddres = lddres;
-  k.dres_accum = dres_accum; k.C8 = C / 8; k.rsv_ = 0; k.npix = npix; k.inv_count = 1.0 / (double)count;
+  k.dres_accum = dres_accum; k.C8 = C / 8; k.rsv_ = bn_fused_every_block_reads(); k.npix = npix; k.inv_count = 1.0 / (double)count;
   k.nslots = (nslots >= 1 && nslots <= MI_BN_SLOTS) ? nslots : MI_BN_SLOTS;
   const int nb = bn_fused_blocks(npix, C / 8, bn_fused_capacity());
   const int mode = bn_fused_mode();
@@ -873,7 +906,7 @@ extern "C" int mi_bn_group_plan(int kind, const mi_bn_job* jobs, int n, void* ta
       k.da = (const __bf16*)b.da; k.y = (const __bf16*)b.y; k.dy = (__bf16*)b.dy; k.dres = (__bf16*)b.dres; k.dacc = b.acc;
       k.bar = b.bar; k.scale = b.scale; k.shift = b.shift; k.mean = b.mean; k.invstd = b.invstd; k.gamma = b.gamma;
       k.dgamma = b.dgamma; k.dbeta = b.dbeta; k.ldda = b.ldda; k.ldy = b.ldy; k.lddy = b.lddy; k.lddres = b.lddres;
-      k.dres_accum = b.dres_accum; k.C8 = C / 8; k.rsv_ = 0; k.npix = b.npix; k.inv_count = 1.0 / (double)b.count;
+      k.dres_accum = b.dres_accum; k.C8 = C / 8; k.rsv_ = bn_fused_every_block_reads(); k.npix = b.npix; k.inv_count = 1.0 / (double)b.count;
       k.nslots = nslots;
       nb = bn_fused_blocks(b.npix, C / 8, cap);
       if (want > cap) {

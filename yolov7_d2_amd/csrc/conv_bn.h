@@ -52,6 +52,51 @@ __device__ __forceinline__ void bn_grid_barrier(unsigned* bar, const unsigned ge
   __syncthreads();
 }
 
+// The same barrier in two halves, so that the block that arrives LAST can do work for everybody before it releases the
+// others (bn_bwd_fused: it folds the accumulator slots into one total per channel - one block's worth of loads instead of
+// every block's; see bn_act.hip).  *is_last / *gave_up live in LDS.
+__device__ __forceinline__ void bn_bar_arrive(unsigned* bar, const int bid, const int nb, int* gave_up, int* is_last) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *gave_up = 0;
+    *is_last = 0;
+    const int G = nb < BN_BAR_G ? nb : BN_BAR_G;
+    const int g = bid % G;
+    const unsigned gsize = (unsigned)((nb - g + G - 1) / G);
+    if (__hip_atomic_fetch_add(bn_bar_cnt(bar, g), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1u) {
+      __hip_atomic_store(bn_bar_cnt(bar, g), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)G - 1u) {
+        __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *is_last = 1;
+      }
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void bn_bar_finish(unsigned* bar, const unsigned gen0, const int bid, const int nb, int* gave_up,
+                                              const int* is_last) {
+  __syncthreads();   // (the last block's stores have been acknowledged: the barrier's s_waitcnt vmcnt(0))
+  if (threadIdx.x == 0) {
+    const int G = nb < BN_BAR_G ? nb : BN_BAR_G;
+    const int g = bid % G;
+    if (*is_last) {
+      for (int q = 0; q < G; ++q)
+        __hip_atomic_fetch_add(bn_bar_gen(bar, q), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      int spins = 0;
+      while (__hip_atomic_load(bn_bar_gen(bar, g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > BN_FUS_SPIN_LIMIT) {  // a block that never became resident: report instead of hanging the GPU
+          __hip_atomic_store(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          *gave_up = 1;
+          break;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
 
 // ---- BatchNorm(train) forward of a convolution, phase 2 of the convolution launch
 struct CBnFwd {
