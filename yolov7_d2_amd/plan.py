@@ -1035,6 +1035,8 @@ class Plan:
             d.ntaps = len(spec.taps)
             for t, (dy, dx, w) in enumerate(spec.taps):
                 d.tap_dy[t], d.tap_dx[t], d.tap_w[t] = dy, dx, w
+            if getattr(spec, "tps", 0):
+                d.TPS = int(spec.tps)       # taps per main-loop step forced by the plan (see _group_parity)
             xf = getattr(spec, "xf", None)
             if xf is not None:
                 d.xf, d.xf_write, d.xf_C = xf.resolve(), int(spec.xf_write), int(spec.xf_C)
@@ -1196,6 +1198,17 @@ class Plan:
             if base and len(run) == 4 and all(c.op == CONV and c.tag == base + s and c.lane == run[0].lane and c.stream == run[0].stream
                                               for c, s in zip(run, ("00", "01", "10", "11"))):
                 g = self._conv_group_cmd(run[::-1], tag=base + "(4 classes)") or self._conv_group_cmd(run, tag=base + "(4 classes)")
+                if g is None and os.environ.get("MI_GROUP_PARITY_TPS1", "1") != "0":
+                    # K = 256 / 512 (dark5.0, bu_conv1): the 4-tap class picks two taps per step, which the 1-tap class cannot
+                    # follow - one tap per step for all four classes lets them share a launch (was four launches of 8-18 us)
+                    one = []
+                    for c in run[::-1]:
+                        sp = ConvSpec(**c.desc.__dict__)
+                        sp.tps = 1
+                        nc = _Cmd(c.op, c.i, c.f, c.p, c.l, sp, c.tag, stream=c.stream)
+                        nc.lane = c.lane
+                        one.append(nc)
+                    g = self._conv_group_cmd(one, tag=base + "(4 classes)")
                 if g is not None:
                     g.lane, g.stream = run[0].lane, run[0].stream
                     out.append(g)
