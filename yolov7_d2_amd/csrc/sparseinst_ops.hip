@@ -110,9 +110,30 @@ __global__ __launch_bounds__(256) void resize_bwd_gather_kernel(const ResizeK p)
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
     const __bf16* g0 = p.x + ((int64_t)n * p.Ho * p.Wo) * p.ldx + c8 * 8;
+    // the column weights once per input pixel (they do not depend on the row): the candidate window carries a margin of
+    // zero-weight columns on both sides, trimmed here; windows wider than RW_MAX (the 1 x 1 .. 6 x 6 pooled maps blown up
+    // to 20 x 20) keep the per-candidate evaluation.  Same products in the same order as before: bit-identical.
+    constexpr int RW_MAX = 12;
+    float wxs[RW_MAX];
+    const bool cached = ox1 - ox0 < RW_MAX;
+    if (cached) {
+#pragma unroll
+      for (int k = 0; k < RW_MAX; ++k) wxs[k] = ox0 + k <= ox1 ? resize_w(ox0 + k, p.sw, p.W, ix) : 0.f;
+    }
     for (int oy = oy0; oy <= oy1; ++oy) {
       const float wy = resize_w(oy, p.sh, p.H, iy);
       if (wy == 0.f) continue;
+      if (cached) {
+#pragma unroll
+        for (int k = 0; k < RW_MAX; ++k) {
+          const float w = wy * wxs[k];
+          if (w == 0.f) continue;
+          const bf16x8 g = *(const bf16x8*)(g0 + ((int64_t)oy * p.Wo + ox0 + k) * p.ldx);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += w * (float)g[e];
+        }
+        continue;
+      }
       for (int ox = ox0; ox <= ox1; ++ox) {
         const float w = wy * resize_w(ox, p.sw, p.W, ix);
         if (w == 0.f) continue;
