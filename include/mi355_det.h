@@ -201,6 +201,11 @@ typedef struct mi_wgrad_desc {
   const float* row_scale; /* NULL, or fp32 [Cout]: gw[co] (+)= row_scale[co] * dW[co] - the gradient of a weight whose
                            * image carried a folded per-Cout factor (mi_pack_conv_weight_scaled), applied to the fp32
                            * sum in the split-K reduction */
+  float* gbias;           /* NULL, or fp32 [Cout]: the BIAS gradient = column sums of dy over all pixels, written by the
+                           * same two launches (the blocks of input-channel tile 0 add up the dy rows they stream, the
+                           * split-K reduction adds the splits in a fixed order) instead of a separate column-sum launch;
+                           * mi_conv2d_wgrad only (single layers: nn.Linear / biased nn.Conv2d of DETR and SparseInst);
+                           * mi_conv2d_wgrad_plan then returns the workspace INCLUDING nsplit * CoutPad floats for it */
 } mi_wgrad_desc;
 int mi_conv2d_wgrad(const mi_wgrad_desc* d, mi_stream_t s);
 /* workspace bytes mi_conv2d_wgrad needs for this descriptor (pointers may be NULL), or <0 */

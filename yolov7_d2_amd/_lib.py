@@ -106,7 +106,7 @@ class mi_wgrad_desc(C.Structure):
         ("tap_dy", C.c_int32 * MI_MAX_TAPS), ("tap_dx", C.c_int32 * MI_MAX_TAPS),
         ("accumulate", C.c_int32),
         ("TH", C.c_int32), ("TW", C.c_int32), ("splitk", C.c_int32), ("cfg_tp", C.c_int32), ("cfg_ns", C.c_int32),
-        ("row_scale", C.c_void_p),
+        ("row_scale", C.c_void_p), ("gbias", C.c_void_p),
     ]
 
 

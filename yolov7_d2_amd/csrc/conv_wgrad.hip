@@ -38,6 +38,8 @@ struct Wg2K {
   int xmap;           // 1: XCD-aware block order (blocks sharing a pixel range are 8 ids apart: same XCD, dispatched together)
   unsigned mTW, mHW;  // ceil(65536 / TW), ceil(65536 / haloW): row / d == (row * m) >> 20 for row * d < 65536
   long long V;        // float4 vectors per split slab
+  float* bpart;       // NULL, or [nsplit][bld] fp32: the bias gradient's split partials (column sums of dy), written by the cib == 0 blocks
+  int bld, pad_;
 };
 
 __device__ uint4 g_mi_zero_page[4];
@@ -79,6 +81,58 @@ __device__ __forceinline__ int swz32(int row) {  // 32-byte group permutation of
   if (NG == 4) return (row >> 1) & 3;
   return row & 7;  // NG == 8
 }
+
+// Bias gradient inside the weight-gradient launch (mi_wgrad_desc.gbias): the blocks of input-channel tile 0 add up the dy
+// rows of their pixel range - read again from global memory right after the tile's LDS-DMA asked for them (L2 hits; the
+// LDS images of the two kernels are swizzled differently, this read is layout-free) - and leave one partial row per split;
+// the split-K reduction adds the splits in a fixed order.  Thread (chunk = tid % (BCO / 8), row lane = tid / (BCO / 8)).
+template <int NTHR, int BCO>
+struct WgBias {
+  static constexpr int NCH = BCO / 8, RL = NTHR / NCH;
+  float s[8];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  }
+  template <int TP>
+  __device__ __forceinline__ void tile(const Wg2K& p, const int img, const int ty0, const int tx0, const int co0, const int TPv) {
+    const int tid = threadIdx.x, ch = tid % NCH, rl = tid / NCH;
+    if (rl >= RL) return;
+    const __bf16* const dyb = p.dy + ((size_t)img * p.outH * p.outW) * (size_t)p.lddy + co0 + ch * 8;
+    constexpr int NR = (TP + RL - 1) / RL;     // rows of a tile per thread: all loads in flight before the first add
+    bf16x8 v[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int row = rl + k * RL;
+      const int ty = (int)(((unsigned)row * p.mTW) >> 20);
+      const int tx = row - ty * p.TW;
+      const int oy = ty0 + ty, ox = tx0 + tx;
+      const bool ok = (row < TPv) & (oy < p.outH) & (ox < p.outW);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[k][e] = (__bf16)0.f;
+      if (ok) v[k] = *(const bf16x8*)(dyb + (size_t)(oy * p.outW + ox) * p.lddy);
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += (float)v[k][e];
+  }
+  // after the block's last barrier: fold the row lanes through LDS (fixed order) and write this split's partial row
+  __device__ __forceinline__ void finish(const Wg2K& p, float* red, const int split, const int co0) {
+    const int tid = threadIdx.x, ch = tid % NCH, rl = tid / NCH;
+    __syncthreads();
+    if (rl < RL) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[rl * BCO + ch * 8 + e] = s[e];
+    }
+    __syncthreads();
+    if (tid < BCO) {
+      float a = 0.f;
+      for (int q = 0; q < RL; ++q) a += red[q * BCO + tid];
+      p.bpart[(size_t)split * p.bld + co0 + tid] = a;
+    }
+  }
+};
 
 template <int NT, int MI, int NJ, int WCO, int WCI, int TP>
 __device__ __forceinline__ void wgrad2_body(const Wg2K& p, const int bid) {
@@ -144,6 +198,9 @@ __device__ __forceinline__ void wgrad2_body(const Wg2K& p, const int bid) {
   const int tpi = p.tilesY * p.tilesX;
   const int tbeg = s * p.tps;
   const int tend = min(p.ntiles, tbeg + p.tps);
+  WgBias<NW * 64, BCO> bias;
+  const bool do_bias = p.bpart != nullptr && cib == 0;
+  bias.init();
 
   const char* const zero = (const char*)g_mi_zero_page;
   auto issue = [&](int tile, int st) {
@@ -198,6 +255,10 @@ __device__ __forceinline__ void wgrad2_body(const Wg2K& p, const int bid) {
       if (st < 0) st += NS;
       if (nxt < tend) issue(nxt, st);
     }
+    if (do_bias) {
+      const int img = tile / tpi, rem = tile - img * tpi, tyq = rem / p.tilesX;
+      bias.template tile<TP>(p, img, tyq * p.TH, (rem - tyq * p.tilesX) * p.TW, co0, TPv);
+    }
     const char* dyB = smem + cur * p.stage;
     if (++cur == NS) cur = 0;
     const char* xB = dyB + TP * RDY;
@@ -242,6 +303,9 @@ __device__ __forceinline__ void wgrad2_body(const Wg2K& p, const int bid) {
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) out[((tap * MI + i) * NJ + j) * 64] = acc[tap][i][j];
+  if (p.bpart != nullptr) {          // (block-uniform; the tile buffers are dead: the partial rows fold through them)
+    if (do_bias) bias.finish(p, (float*)smem, s, co0);
+  }
 }
 
 template <int NT, int MI, int NJ, int WCO, int WCI, int TP>
@@ -339,6 +403,9 @@ __device__ __forceinline__ void wgrad3_body(const Wg2K& p, const int bid) {
   const int tpi = p.tilesY * p.tilesX;
   const int tbeg = s * p.tps;
   const int tend = min(p.ntiles, tbeg + p.tps);
+  WgBias<NW * 64, BCO> bias;
+  const bool do_bias = p.bpart != nullptr && cib == 0;
+  bias.init();
 
   const char* const zero = (const char*)g_mi_zero_page;
   const int half8 = (lane & 1) * 8;   // this lane's 16-byte half of the 32-byte group (in elements)
@@ -392,6 +459,10 @@ __device__ __forceinline__ void wgrad3_body(const Wg2K& p, const int bid) {
       if (st < 0) st += NS;
       if (nxt < tend) issue(nxt, st);
     }
+    if (do_bias) {
+      const int img = tile / tpi, rem = tile - img * tpi, tyq = rem / p.tilesX;
+      bias.template tile<TP>(p, img, tyq * p.TH, (rem - tyq * p.tilesX) * p.TW, co0, TPv);
+    }
     const char* const sB = smem + cur * p.stage;
     if (++cur == NS) cur = 0;
     const char* const aB = sB + aoff;
@@ -425,6 +496,9 @@ __device__ __forceinline__ void wgrad3_body(const Wg2K& p, const int bid) {
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) out[((tap * MI + i) * NJ + j) * 64] = acc[tap][i][j];
+  if (p.bpart != nullptr) {          // (block-uniform; the tile buffers are dead: the partial rows fold through them)
+    if (do_bias) bias.finish(p, (float*)smem, s, co0);
+  }
 }
 
 template <int NT, int MI, int NJ, int WCO, int WCI, int TP>
@@ -447,7 +521,17 @@ struct Wg2R {
   long long V;
   int nsplit, NT, MI, NJ, WCO, WCI, nco, nci, Cout, Cin, accumulate;
   const float* row_scale;   // NULL or [Cout]
+  const float* bpart;       // NULL or [nsplit][bld]: split partials of the bias gradient
+  float* gbias;             // [Cout]
+  int bld, main_blocks;     // blocks >= main_blocks add up the bias partials (one thread per channel, fixed split order)
 };
+__device__ __forceinline__ void wgrad2_reduce_bias(const Wg2R& p, const long long blk) {
+  const int c = (int)(blk - p.main_blocks) * 256 + (int)threadIdx.x;
+  if (c >= p.Cout) return;
+  float a = 0.f;
+  for (int k = 0; k < p.nsplit; ++k) a += p.bpart[(size_t)k * p.bld + c];
+  p.gbias[c] = a;
+}
 
 // SL "split lanes": the nsplit partials of one output float4 are summed by SL threads (wave w = splits w, w + SL, ...,
 // 4 loads in flight each), combined through LDS in a fixed order.  With one thread per output (SL = 1) a layer with 30-60
@@ -565,7 +649,13 @@ __global__ __launch_bounds__(576) void wgrad2_reduce9_group_kernel(const Wg2R* _
 }
 
 template <int SL>
-__global__ __launch_bounds__(256) void wgrad2_reduce_kernel(const Wg2R p) { wgrad2_reduce_body<SL>(p, blockIdx.x); }
+__global__ __launch_bounds__(256) void wgrad2_reduce_kernel(const Wg2R p) {
+  if (p.bpart != nullptr && (int)blockIdx.x >= p.main_blocks) {
+    wgrad2_reduce_bias(p, blockIdx.x);
+    return;
+  }
+  wgrad2_reduce_body<SL>(p, blockIdx.x);
+}
 template <int SL>
 __global__ __launch_bounds__(256) void wgrad2_reduce_group_kernel(const Wg2R* __restrict__ jobs,
                                                                   const int* __restrict__ starts, int njobs) {
@@ -753,6 +843,12 @@ static int wg_fill(const mi_wgrad_desc* d, Wg2K* k, Wg2Cfg* c, size_t* lds, size
   k->nsplit = mi_cdiv(k->ntiles, k->tps);
   k->V = (long long)k->nco * k->nci * (c->WCO * c->WCI) * c->NT * c->MI * c->NJ * 64;
   *ws = (size_t)k->nsplit * (size_t)k->V * 16;
+  k->bpart = nullptr; k->bld = 0; k->pad_ = 0;
+  if (d->gbias && !grouped) {     // the bias partials behind the slabs (single launches only)
+    k->bld = d->CoutPad;
+    k->bpart = d->ws ? (float*)((char*)d->ws + *ws) : (float*)(uintptr_t)16;   // (planning call without a workspace: non-null marker)
+    *ws += (size_t)k->nsplit * (size_t)k->bld * 4;
+  }
   return MI_OK;
 }
 
@@ -800,11 +896,18 @@ extern "C" int mi_conv2d_wgrad(const mi_wgrad_desc* d, mi_stream_t st) {
   r.part = (const f32x4*)d->ws; r.g = d->gw; r.V = k.V; r.nsplit = k.nsplit;
   r.NT = c.NT; r.MI = c.MI; r.NJ = c.NJ; r.WCO = c.WCO; r.WCI = c.WCI; r.nco = k.nco; r.nci = k.nci;
   r.Cout = d->Cout; r.Cin = d->Cin; r.accumulate = d->accumulate; r.row_scale = d->row_scale;
-  if (c.NT == 9 && wg_red9())
+  r.bpart = nullptr; r.gbias = nullptr; r.bld = 0; r.main_blocks = 0;
+  if (c.NT == 9 && wg_red9() && !d->gbias)
     hipLaunchKernelGGL(wgrad2_reduce9_kernel, dim3((unsigned)(k.V / (64 * 9))), dim3(576), 0, s, r);
   else {
     const int outs = 256 / wg_redsl();
-    const dim3 g((unsigned)((k.V + outs - 1) / outs));
+    unsigned nblk = (unsigned)((k.V + outs - 1) / outs);
+    if (d->gbias) {
+      MI_REQUIRE(!d->accumulate, "wgrad: gbias is written, not accumulated");
+      r.bpart = k.bpart; r.gbias = d->gbias; r.bld = k.bld; r.main_blocks = (int)nblk;
+      nblk += (unsigned)((d->Cout + 255) / 256);
+    }
+    const dim3 g(nblk);
     switch (wg_redsl()) {
       case 16: hipLaunchKernelGGL(wgrad2_reduce_kernel<16>, g, dim3(256), 0, s, r); break;
       case 8: hipLaunchKernelGGL(wgrad2_reduce_kernel<8>, g, dim3(256), 0, s, r); break;
@@ -834,6 +937,7 @@ extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, voi
   // pass 1: tile configuration + tile counts per layer
   for (int i = 0; i < n; ++i) {
     mi_wgrad_desc t = descs[i];
+    MI_REQUIRE(!t.gbias, "wgrad_group_plan: job %d carries a bias gradient (gbias): single launches only", i);
     if (!t.x) t.x = (const void*)256;
     if (!t.dy) t.dy = (const void*)256;
     int rc = wg_fill(&t, &ks[i], &cs[i], &ldss[i], &wss[i], true);
@@ -944,6 +1048,7 @@ extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, voi
     r.NT = cs[i].NT; r.MI = cs[i].MI; r.NJ = cs[i].NJ; r.WCO = cs[i].WCO; r.WCI = cs[i].WCI;
     r.nco = ks[i].nco; r.nci = ks[i].nci; r.Cout = descs[i].Cout; r.Cin = descs[i].Cin;
     r.accumulate = descs[i].accumulate; r.row_scale = descs[i].row_scale;
+    r.bpart = nullptr; r.gbias = nullptr; r.bld = 0; r.main_blocks = 0;     // (grouped launches carry no bias gradient)
     if (cs[i].NT == 9 && wg_red9()) {
       rj9.push_back(r);
       rs9.push_back(rblocks9);

@@ -23,7 +23,7 @@ import torch
 from torch import nn
 
 from .. import _lib as L
-from ..ops import pack_images
+from ..ops import pack_images, wgrad_bias_fused
 from .attention import mha_core
 
 
@@ -90,10 +90,13 @@ def _linear_bwd(x, wd, dy, Cout, need_dx=True, gw=None, gb=None):
     if need_dx:
         dx = torch.empty(T, Cin, dtype=torch.bfloat16, device=dev)
         _conv1x1(dy, wd, dx, T, CoutP, Cin, Cin)
+    fused_gb = gb is not None and gw is not None and CoutP == Cout and wgrad_bias_fused(T)
     if gw is not None:
         H, W = _factor(T)
         d = L.mi_wgrad_desc()
         d.x, d.dy, d.gw = x.data_ptr(), dy.data_ptr(), gw.data_ptr()
+        if fused_gb:
+            d.gbias = gb.data_ptr()          # the bias gradient from the same two launches (mi_wgrad_desc.gbias)
         d.ldx, d.ldy, d.N, d.H, d.W, d.outH, d.outW, d.stride = Cin, CoutP, 1, H, W, H, W, 1
         d.Cin, d.Cout, d.CinPad, d.CoutPad, d.ntaps = Cin, Cout, Cin, CoutP, 1
         need = L.lib().mi_conv2d_wgrad_plan(C.byref(d))
@@ -101,7 +104,7 @@ def _linear_bwd(x, wd, dy, Cout, need_dx=True, gw=None, gb=None):
         ws = torch.empty(max(int(need), 16), dtype=torch.uint8, device=dev)
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
         L.check(L.lib().mi_conv2d_wgrad(C.byref(d), L.stream_ptr()), "mi_conv2d_wgrad (linear)")
-    if gb is not None:
+    if gb is not None and not fused_gb:
         gbp = gb if CoutP == Cout else torch.empty(CoutP, dtype=torch.float32, device=dev)
         cws = torch.empty(128 * CoutP, dtype=torch.float32, device=dev)
         L.check(L.lib().mi_colsum_bf16_wide(dy.data_ptr(), CoutP, T, CoutP, gbp.data_ptr(), 0, cws.data_ptr(), L.stream_ptr()),

@@ -254,11 +254,12 @@ class _ConvGeom:
                                      self.CinP, self.H, self.W, self.Cin, self.CinP, taps, out_stride=2, oy=py, ox=px,
                                      gridH=gh, gridW=gw, flags=fl, aux=aux), "mi_conv2d (dgrad s2)")
 
-    def wgrad(self, xh, dyh, row_scale=None):
+    def wgrad(self, xh, dyh, row_scale=None, gbias=None):
+        """gbias: fp32 [Cout] tensor that receives the bias gradient (column sums of dyh) from the same two launches"""
         gw = torch.empty(self.Cout, self.Cin, self.k, self.k, dtype=torch.float32, device=xh.device)
         d = L.mi_wgrad_desc()
         d.x, d.dy, d.gw = xh.data_ptr(), dyh.data_ptr(), gw.data_ptr()
-        d.row_scale = L.ptr(row_scale)
+        d.row_scale, d.gbias = L.ptr(row_scale), L.ptr(gbias)
         d.ldx, d.ldy, d.N, d.H, d.W, d.outH, d.outW, d.stride = self.CinP, self.CoutP, self.N, self.H, self.W, self.Ho, self.Wo, self.s
         d.Cin, d.Cout, d.CinPad, d.CoutPad, d.ntaps = self.Cin, self.Cout, self.CinP, self.CoutP, self.KK
         for t in range(self.KK):
@@ -269,6 +270,19 @@ class _ConvGeom:
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
         L.check(L.lib().mi_conv2d_wgrad(C.byref(d), L.stream_ptr()), "mi_conv2d_wgrad")
         return gw
+
+
+def wgrad_bias_fused(npix=0):
+    """the bias gradient from the weight-gradient launches (mi_wgrad_desc.gbias) instead of a column-sum launch of its own.
+    Pays where the layer is a handful of pixel tiles per block - the transformer's token-row GEMMs (T = 4 200: DETR-R50 267 ->
+    272 images/s, same box) - and LOSES on the long pixel ranges of SparseInst's 80 x 80 convolutions (-1.2 %: the blocks of
+    input-channel tile 0 re-read every dy tile while the others wait for them; profiles/r05_wgrad_bias_ab.txt): above
+    MI_WGRAD_BIAS_MAXPIX (16 384) pixels the separate launch stays.  MI_WGRAD_BIAS=0: never (round 4's form); =2: always."""
+    import os
+    m = os.environ.get("MI_WGRAD_BIAS", "1")
+    if m == "0":
+        return False
+    return m == "2" or npix <= int(os.environ.get("MI_WGRAD_BIAS_MAXPIX", "16384"))
 
 
 def _colsum(dyh, C_):
@@ -320,8 +334,12 @@ def _conv2d_backward_cuda(grad, x, weight, has_bias, stride, padding):
     full = g.CinP == g.Cin and not (g.k == 1 and g.s == 2)
     dx = (torch.empty if full else torch.zeros)(g.N, g.H, g.W, g.CinP, dtype=torch.bfloat16, device=x.device)
     g.dgrad(dyh, wd, dx)
-    gw = g.wgrad(xh, dyh)
-    gb = _colsum(dyh, g.Cout) if has_bias else torch.zeros(0, device=x.device)
+    if has_bias and wgrad_bias_fused(g.N * g.Ho * g.Wo):
+        gb = torch.empty(g.Cout, dtype=torch.float32, device=x.device)
+        gw = g.wgrad(xh, dyh, gbias=gb)       # (the bias gradient leaves with the weight gradient: no column-sum launch)
+    else:
+        gw = g.wgrad(xh, dyh)
+        gb = _colsum(dyh, g.Cout) if has_bias else torch.zeros(0, device=x.device)
     return _nchw(dx, g.Cin), gw, gb
 
 
