@@ -533,6 +533,17 @@ int mi_mha_bwd_dropout_o32(const void* q, const void* k, const void* v, const ui
                            const float* o_f32, const float* lse, const void* dout, float* delta_ws, void* dq, void* dk,
                            void* dv, int B, int H, int Lq, int Lk, int E, float scale, float drop_p, uint64_t seed,
                            mi_stream_t s);
+/* and with row strides for q / dq (ldq) and k / dk (ldk), in elements, >= E: a self-attention whose query and key are the
+ * same tensor (the encoder layers and the decoder's self-attention, detr_backbone.py:155-157,222-224: q = k = x + pos) takes
+ * q and k from ONE [T, 2E] projection (k = q + E, ldq = ldk = 2E) and hands dq | dk back the same way - one projection, one
+ * data-gradient and one weight-gradient launch instead of two each.  v, o, dout, dv, o_f32 keep row stride E. */
+int mi_mha_fwd_dropout_ld(const void* q, int ldq, const void* k, int ldk, const void* v, const uint8_t* key_padding_mask,
+                          void* o, float* o_f32, float* lse, int B, int H, int Lq, int Lk, int E, float scale, float drop_p,
+                          uint64_t seed, mi_stream_t s);
+int mi_mha_bwd_dropout_ld(const void* q, int ldq, const void* k, int ldk, const void* v, const uint8_t* key_padding_mask,
+                          const void* o, const float* o_f32, const float* lse, const void* dout, float* delta_ws, void* dq,
+                          void* dk, void* dv, int B, int H, int Lq, int Lk, int E, float scale, float drop_p, uint64_t seed,
+                          mi_stream_t s);
 /* elementwise dropout of a bf16 tensor (F.dropout of detr_backbone.py:147-150,163-167,...): out[i] = keep(seed, i) ?
  * x[i] / (1-p) : 0; applying it with the same (p, seed) to the output gradient IS the backward. n %% 8 == 0. */
 int mi_dropout_bf16(const void* x, void* out, int64_t n, float drop_p, uint64_t seed, mi_stream_t s);

@@ -153,6 +153,45 @@ def test_in_projection_as_one_node_equals_three_sliced_linears():
         assert torch.equal(a, c), float((a.float() - c.float()).abs().max())
 
 
+@pytest.mark.parametrize("L_,B,masked,p", [(1050, 2, True, 0.0), (100, 4, False, 0.0), (333, 3, True, 0.1)])
+def test_self_attention_with_packed_q_k_projection_equals_two_projections(monkeypatch, L_, B, masked, p):
+    """a self-attention whose query and key are the same tensor (q = k = x + pos, detr_backbone.py:155-157,222-224) projects
+    q | k with ONE [T, 2E] launch and the attention kernels read / write them with row stride 2E (mi_mha_*_ld): against the
+    two-projection form (MI_MHA_QK_PACKED=0) - same dot products, so the outputs agree to bf16 rounding of a differently
+    tiled GEMM and the gradients to the tolerance of the bf16 kernels (the packed form adds dq W_q + dk W_k inside one
+    reduction where the other rounds twice)"""
+    from yolov7_d2_amd.modeling.transformer import MultiheadAttention
+    E, H = 256, 8
+    g = torch.Generator().manual_seed(L_ + B)
+    x = torch.randn(L_, B, E, generator=g).to(torch.bfloat16)
+    val = torch.randn(L_, B, E, generator=g).to(torch.bfloat16)
+    go = torch.randn(L_, B, E, generator=g).to(torch.bfloat16)
+    kpm = None
+    if masked:
+        kpm = torch.zeros(B, L_, dtype=torch.bool)
+        kpm[0, L_ - L_ // 4:] = True
+        kpm = kpm.to(DEV)
+    sd = seeded_tensor_dict({"in_proj_weight": (3 * E, E), "in_proj_bias": (3 * E,), "out_proj.weight": (E, E), "out_proj.bias": (E,)}, seed=5)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MI_MHA_QK_PACKED", mode)
+        m = MultiheadAttention(E, H, dropout=p).to(DEV)
+        m.load_state_dict(sd)
+        m.train()
+        torch.manual_seed(11)                              # (the dropout seed comes from torch's generator)
+        xq = x.to(DEV).requires_grad_(True)
+        xv = val.to(DEV).requires_grad_(True)
+        out, _ = m(xq, xq, xv, key_padding_mask=kpm)
+        out.backward(go.to(DEV))
+        torch.cuda.synchronize()
+        res[mode] = dict(out=out.detach().float().cpu(), dx=xq.grad.float().cpu(), dv=xv.grad.float().cpu(),
+                         gw=m.in_proj_weight.grad.cpu(), gb=m.in_proj_bias.grad.cpu(), go=m.out_proj.weight.grad.cpu())
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    for k in res["0"]:
+        assert rel(res["1"][k], res["0"][k]) < 2e-2, (k, rel(res["1"][k], res["0"][k]))
+    assert rel(res["1"]["out"], res["0"]["out"]) < 5e-3
+
+
 def test_linear_with_relu_epilogue_equals_linear_then_relu():
     """_LinearFn(relu=True) (MI_CONV_RELU in the 1x1 convolution's epilogue, the mask applied to dy in backward) against
     _LinearFn followed by _ReluFn: identical bits, forward and all three gradients (Cout 2048 and a padded Cout 72)"""

@@ -342,6 +342,9 @@ _PROTOS = {
     "mi_mha_fwd_dropout_o32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, C.c_uint64, _vp]),
     "mi_mha_bwd_dropout_o32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f,
                                         C.c_uint64, _vp]),
+    "mi_mha_fwd_dropout_ld": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, C.c_uint64, _vp]),
+    "mi_mha_bwd_dropout_ld": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f,
+                                       C.c_uint64, _vp]),
     "mi_iou_loss_v6": (C.c_int, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "mi_batched_nms": (C.c_int, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_abi_sizeof": (C.c_int, [_i]),

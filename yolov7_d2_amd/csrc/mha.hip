@@ -53,6 +53,8 @@ struct MhaK {
   __bf16* dk;
   __bf16* dv;
   int B, H, Lq, Lk, E;
+  int ldq, ldk;        // row strides (elements) of q / dq and of k / dk: E, or 2 E when a self-attention's q and k are the two
+                       // halves of ONE [T, 2E] projection (k = q + E); v, o, dout, dv, o32 always have row stride E
   float scale;
   // attention dropout (nn.MultiheadAttention(dropout=p) drops attention WEIGHTS, detr_backbone.py:140,200-202): a
   // weight survives iff mi_rng(seed, ((b*H + h)*Lq + q)*Lk + key) >= drop_thr; survivors are scaled by drop_scale =
@@ -119,17 +121,17 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaK p) {
   // this lane's query (B operand of S^T: lane (t = query, g) holds d = 8g..8g+7)
   bf16x8 qf = {};
   const int myq = q0 + t;
-  if (myq < p.Lq) qf = *(const bf16x8*)(p.q + ((size_t)myq * p.B + b) * p.E + h * MHA_D + g * 8);
+  if (myq < p.Lq) qf = *(const bf16x8*)(p.q + ((size_t)myq * p.B + b) * p.ldq + h * MHA_D + g * 8);
   f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // [d group]: lane (t = d, g): queries 4g+r
   float m_run = -INFINITY, l_run = 0.f;  // of query `t` (replicated over g)
   const int ntiles = (p.Lk + 31) / 32;
-  stage_tile(Ks[0], p.k, 0, p.Lk, p.B, p.E, b, h, tid);
+  stage_tile(Ks[0], p.k, 0, p.Lk, p.B, p.ldk, b, h, tid);
   stage_tile(Vs[0], p.v, 0, p.Lk, p.B, p.E, b, h, tid - 128);
   for (int it = 0; it < ntiles; ++it) {
     __syncthreads();
     const int cur = it & 1;
     if (it + 1 < ntiles) {
-      stage_tile(Ks[cur ^ 1], p.k, (it + 1) * 32, p.Lk, p.B, p.E, b, h, tid);
+      stage_tile(Ks[cur ^ 1], p.k, (it + 1) * 32, p.Lk, p.B, p.ldk, b, h, tid);
       stage_tile(Vs[cur ^ 1], p.v, (it + 1) * 32, p.Lk, p.B, p.E, b, h, tid - 128);
     }
     const int k0 = it * 32;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(768) void mha_fwd2_kernel(const MhaK p) {
   const int q0 = blockIdx.x * (nth >> 2) + wave * 16;      // nth / 64 waves x 16 queries
   const int myq = q0 + t;
   bf16x8 qf = {};
-  if (myq < p.Lq) qf = *(const bf16x8*)(p.q + ((size_t)myq * p.B + b) * p.E + h * MHA_D + g * 8);
+  if (myq < p.Lq) qf = *(const bf16x8*)(p.q + ((size_t)myq * p.B + b) * p.ldq + h * MHA_D + g * 8);
   f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   f32x4 lacc = {0.f, 0.f, 0.f, 0.f};                       // normaliser, same layout as oacc (every column alike)
   float m_run = -INFINITY, neg_m = 0.f, l_part = 0.f;      // reference maximum of query t in raw score units; -m * sc2
@@ -261,9 +263,10 @@ __global__ __launch_bounds__(768) void mha_fwd2_kernel(const MhaK p) {
       idx = idx < 511 ? idx : 511;
       int row = k0 + (idx >> 2);
       row = row < p.Lk ? row : p.Lk - 1;
-      const size_t off = ((size_t)row * p.B + b) * p.E + h * MHA_D + (idx & 3) * 8;
-      kreg[u] = *(const u32x4*)(p.k + off);
-      vreg[u] = *(const u32x4*)(p.v + off);
+      const size_t rb = (size_t)row * p.B + b;
+      const int tail = h * MHA_D + (idx & 3) * 8;
+      kreg[u] = *(const u32x4*)(p.k + rb * p.ldk + tail);
+      vreg[u] = *(const u32x4*)(p.v + rb * p.E + tail);
     }
     const int key = k0 + (tid & (MHA2_KC - 1));
     mreg = mrow[key < p.Lk ? key : p.Lk - 1];
@@ -416,21 +419,21 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const MhaK p) {
   bf16x8 qf = {}, dof = {};
   float lse = 0.f, dl = 0.f;
   if (myq < p.Lq) {
-    const size_t off = ((size_t)myq * p.B + b) * p.E + h * MHA_D + g * 8;
-    qf = *(const bf16x8*)(p.q + off);
-    dof = *(const bf16x8*)(p.dout + off);
+    const size_t rb = (size_t)myq * p.B + b;
+    qf = *(const bf16x8*)(p.q + rb * p.ldq + h * MHA_D + g * 8);
+    dof = *(const bf16x8*)(p.dout + rb * p.E + h * MHA_D + g * 8);
     lse = p.lse[((size_t)b * p.H + h) * p.Lq + myq];
     dl = p.delta[((size_t)b * p.H + h) * p.Lq + myq];
   }
   f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
   const int ntiles = (p.Lk + 31) / 32;
-  stage_tile(Ks[0], p.k, 0, p.Lk, p.B, p.E, b, h, tid);
+  stage_tile(Ks[0], p.k, 0, p.Lk, p.B, p.ldk, b, h, tid);
   stage_tile(Vs[0], p.v, 0, p.Lk, p.B, p.E, b, h, tid - 128);
   for (int it = 0; it < ntiles; ++it) {
     __syncthreads();
     const int cur = it & 1;
     if (it + 1 < ntiles) {
-      stage_tile(Ks[cur ^ 1], p.k, (it + 1) * 32, p.Lk, p.B, p.E, b, h, tid);
+      stage_tile(Ks[cur ^ 1], p.k, (it + 1) * 32, p.Lk, p.B, p.ldk, b, h, tid);
       stage_tile(Vs[cur ^ 1], p.v, (it + 1) * 32, p.Lk, p.B, p.E, b, h, tid - 128);
     }
     const int k0 = it * 32;
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const MhaK p) {
   for (int r = 0; r < 4; ++r) {
     const int qq = q0 + 4 * g + r;
     if (qq < p.Lq) {
-      __bf16* op = p.dq + ((size_t)qq * p.B + b) * p.E + h * MHA_D;
+      __bf16* op = p.dq + ((size_t)qq * p.B + b) * p.ldq + h * MHA_D;
       op[t] = (__bf16)acc[0][r];
       op[16 + t] = (__bf16)acc[1][r];
     }
@@ -478,9 +481,9 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const MhaK p) {
   bf16x8 kf = {}, vf = {};
   bool kdead = mykey >= p.Lk;
   if (!kdead) {
-    const size_t off = ((size_t)mykey * p.B + b) * p.E + h * MHA_D + g * 8;
-    kf = *(const bf16x8*)(p.k + off);
-    vf = *(const bf16x8*)(p.v + off);
+    const size_t rb = (size_t)mykey * p.B + b;
+    kf = *(const bf16x8*)(p.k + rb * p.ldk + h * MHA_D + g * 8);
+    vf = *(const bf16x8*)(p.v + rb * p.E + h * MHA_D + g * 8);
     kdead = p.mask && p.mask[(size_t)b * p.Lk + mykey];
   }
   f32x4 dk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -496,14 +499,14 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const MhaK p) {
       Dl[buf][row] = ok ? p.delta[((size_t)b * p.H + h) * p.Lq + r0 + row] : 0.f;
     }
   };
-  stage_tile(Qs[0], p.q, 0, p.Lq, p.B, p.E, b, h, tid);
+  stage_tile(Qs[0], p.q, 0, p.Lq, p.B, p.ldq, b, h, tid);
   stage_tile(Ds[0], p.dout, 0, p.Lq, p.B, p.E, b, h, tid - 128);
   stage_stats(0, 0);
   for (int it = 0; it < ntiles; ++it) {
     __syncthreads();
     const int cur = it & 1;
     if (it + 1 < ntiles) {
-      stage_tile(Qs[cur ^ 1], p.q, (it + 1) * 32, p.Lq, p.B, p.E, b, h, tid);
+      stage_tile(Qs[cur ^ 1], p.q, (it + 1) * 32, p.Lq, p.B, p.ldq, b, h, tid);
       stage_tile(Ds[cur ^ 1], p.dout, (it + 1) * 32, p.Lq, p.B, p.E, b, h, tid - 128);
       stage_stats(cur ^ 1, (it + 1) * 32);
     }
@@ -534,9 +537,9 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const MhaK p) {
   for (int r = 0; r < 4; ++r) {
     const int kk = key0 + 4 * g + r;
     if (kk < p.Lk) {
-      const size_t off = ((size_t)kk * p.B + b) * p.E + h * MHA_D;
-      p.dk[off + t] = (__bf16)dk[0][r];
-      p.dk[off + 16 + t] = (__bf16)dk[1][r];
+      const size_t off = ((size_t)kk * p.B + b) * p.E + h * MHA_D, offk = ((size_t)kk * p.B + b) * p.ldk + h * MHA_D;
+      p.dk[offk + t] = (__bf16)dk[0][r];
+      p.dk[offk + 16 + t] = (__bf16)dk[1][r];
       p.dv[off + t] = (__bf16)dv[0][r];
       p.dv[off + 16 + t] = (__bf16)dv[1][r];
     }
@@ -564,9 +567,9 @@ __global__ __launch_bounds__(768) void mha_bwd_dq2_kernel(const MhaK p) {
   bf16x8 qf = {}, dof = {};
   float neg_l = -INFINITY, dl = 0.f;   // -lse * log2(e) of query t (-inf: a fully masked or out-of-range row weighs nothing)
   if (myq < p.Lq) {
-    const size_t off = ((size_t)myq * p.B + b) * p.E + h * MHA_D + g * 8;
-    qf = *(const bf16x8*)(p.q + off);
-    dof = *(const bf16x8*)(p.dout + off);
+    const size_t rb = (size_t)myq * p.B + b;
+    qf = *(const bf16x8*)(p.q + rb * p.ldq + h * MHA_D + g * 8);
+    dof = *(const bf16x8*)(p.dout + rb * p.E + h * MHA_D + g * 8);
     const float lse = p.lse[((size_t)b * p.H + h) * p.Lq + myq];
     neg_l = lse == -INFINITY ? -INFINITY : -lse * 1.44269504088896341f;
     dl = p.delta[((size_t)b * p.H + h) * p.Lq + myq];
@@ -586,9 +589,10 @@ __global__ __launch_bounds__(768) void mha_bwd_dq2_kernel(const MhaK p) {
       idx = idx < 511 ? idx : 511;
       int row = k0 + (idx >> 2);
       row = row < p.Lk ? row : p.Lk - 1;
-      const size_t off = ((size_t)row * p.B + b) * p.E + h * MHA_D + (idx & 3) * 8;
-      kreg[u] = *(const u32x4*)(p.k + off);
-      vreg[u] = *(const u32x4*)(p.v + off);
+      const size_t rb = (size_t)row * p.B + b;
+      const int tail = h * MHA_D + (idx & 3) * 8;
+      kreg[u] = *(const u32x4*)(p.k + rb * p.ldk + tail);
+      vreg[u] = *(const u32x4*)(p.v + rb * p.E + tail);
     }
     const int key = k0 + (tid & (MHA2_KC - 1));
     mreg = mrow[key < p.Lk ? key : p.Lk - 1];
@@ -648,7 +652,7 @@ __global__ __launch_bounds__(768) void mha_bwd_dq2_kernel(const MhaK p) {
   for (int r = 0; r < 4; ++r) {
     const int qq = q0 + 4 * g + r;
     if (qq < p.Lq) {
-      __bf16* op = p.dq + ((size_t)qq * p.B + b) * p.E + h * MHA_D;
+      __bf16* op = p.dq + ((size_t)qq * p.B + b) * p.ldq + h * MHA_D;
       op[t] = (__bf16)(acc[0][r] * p.scale);
       op[16 + t] = (__bf16)(acc[1][r] * p.scale);
     }
@@ -669,9 +673,9 @@ __global__ __launch_bounds__(768) void mha_bwd_dkv2_kernel(const MhaK p) {
   bf16x8 kf = {}, vf = {};
   {
     const int row = mykey < p.Lk ? mykey : p.Lk - 1;   // (rows past the last key and padded keys are discarded at the end)
-    const size_t off = ((size_t)row * p.B + b) * p.E + h * MHA_D + g * 8;
-    kf = *(const bf16x8*)(p.k + off);
-    vf = *(const bf16x8*)(p.v + off);
+    const size_t rb = (size_t)row * p.B + b;
+    kf = *(const bf16x8*)(p.k + rb * p.ldk + h * MHA_D + g * 8);
+    vf = *(const bf16x8*)(p.v + rb * p.E + h * MHA_D + g * 8);
   }
   const float sc2 = p.scale * 1.44269504088896341f;
   f32x4 dk[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -689,9 +693,10 @@ __global__ __launch_bounds__(768) void mha_bwd_dkv2_kernel(const MhaK p) {
       idx = idx < 511 ? idx : 511;
       int row = r0 + (idx >> 2);
       row = row < p.Lq ? row : p.Lq - 1;
-      const size_t off = ((size_t)row * p.B + b) * p.E + h * MHA_D + (idx & 3) * 8;
-      qreg[u] = *(const u32x4*)(p.q + off);
-      dreg[u] = *(const u32x4*)(p.dout + off);
+      const size_t rb = (size_t)row * p.B + b;
+      const int tail = h * MHA_D + (idx & 3) * 8;
+      qreg[u] = *(const u32x4*)(p.q + rb * p.ldq + tail);
+      dreg[u] = *(const u32x4*)(p.dout + rb * p.E + tail);
     }
     const int qq = r0 + (tid & (MHA2_KC - 1));
     lreg = lrow[qq < p.Lq ? qq : p.Lq - 1];
@@ -773,9 +778,9 @@ __global__ __launch_bounds__(768) void mha_bwd_dkv2_kernel(const MhaK p) {
     const int kk = key0 + 4 * g + r;
     if (kk < p.Lk) {
       const bool dead = p.mask && p.mask[(size_t)b * p.Lk + kk];   // a padded key: its rows (possibly inf / NaN) are discarded
-      const size_t off = ((size_t)kk * p.B + b) * p.E + h * MHA_D;
-      p.dk[off + t] = (__bf16)(dead ? 0.f : dk[0][r] * p.scale);
-      p.dk[off + 16 + t] = (__bf16)(dead ? 0.f : dk[1][r] * p.scale);
+      const size_t off = ((size_t)kk * p.B + b) * p.E + h * MHA_D, offk = ((size_t)kk * p.B + b) * p.ldk + h * MHA_D;
+      p.dk[offk + t] = (__bf16)(dead ? 0.f : dk[0][r] * p.scale);
+      p.dk[offk + 16 + t] = (__bf16)(dead ? 0.f : dk[1][r] * p.scale);
       p.dv[off + t] = (__bf16)(dead ? 0.f : dv[0][r]);
       p.dv[off + 16 + t] = (__bf16)(dead ? 0.f : dv[1][r]);
     }
@@ -831,8 +836,15 @@ extern "C" int mi_mha_fwd_dropout(const void* q, const void* k, const void* v, c
 extern "C" int mi_mha_fwd_dropout_o32(const void* q, const void* k, const void* v, const uint8_t* key_padding_mask, void* o,
                                       float* o_f32, float* lse, int B, int H, int Lq, int Lk, int E, float scale,
                                       float drop_p, uint64_t seed, mi_stream_t st) {
+  return mi_mha_fwd_dropout_ld(q, E, k, E, v, key_padding_mask, o, o_f32, lse, B, H, Lq, Lk, E, scale, drop_p, seed, st);
+}
+
+extern "C" int mi_mha_fwd_dropout_ld(const void* q, int ldq, const void* k, int ldk, const void* v,
+                                     const uint8_t* key_padding_mask, void* o, float* o_f32, float* lse, int B, int H, int Lq,
+                                     int Lk, int E, float scale, float drop_p, uint64_t seed, mi_stream_t st) {
   int rc = mha_check(q, k, v, B, H, Lq, Lk, E);
   if (rc) return rc;
+  MI_REQUIRE(ldq >= E && ldk >= E && ldq % 8 == 0 && ldk % 8 == 0, "mha_fwd: row strides ldq %d / ldk %d (>= E, multiples of 8)", ldq, ldk);
   MI_REQUIRE(o, "mha_fwd: null output");
   MhaK p;
   memset(&p, 0, sizeof(p));
@@ -840,6 +852,7 @@ extern "C" int mi_mha_fwd_dropout_o32(const void* q, const void* k, const void* 
   if (rc) return rc;
   p.q = (const __bf16*)q; p.k = (const __bf16*)k; p.v = (const __bf16*)v; p.mask = key_padding_mask;
   p.o = (__bf16*)o; p.o32 = o_f32; p.lse = lse; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.E = E; p.scale = scale;
+  p.ldq = ldq; p.ldk = ldk;
   MI_REQUIRE(!o_f32 || ((uintptr_t)o_f32 & 15) == 0, "mha_fwd: o_f32 alignment");
   static const int v2 = getenv("MI_MHA_V2") ? atoi(getenv("MI_MHA_V2")) : 1;
   if (!v2) {
@@ -894,8 +907,18 @@ extern "C" int mi_mha_bwd_dropout_o32(const void* q, const void* k, const void* 
                                       const void* o, const float* o_f32, const float* lse, const void* dout, float* delta_ws,
                                       void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int E, float scale,
                                       float drop_p, uint64_t seed, mi_stream_t st) {
+  return mi_mha_bwd_dropout_ld(q, E, k, E, v, key_padding_mask, o, o_f32, lse, dout, delta_ws, dq, dk, dv, B, H, Lq, Lk, E, scale,
+                               drop_p, seed, st);
+}
+
+extern "C" int mi_mha_bwd_dropout_ld(const void* q, int ldq, const void* k, int ldk, const void* v,
+                                     const uint8_t* key_padding_mask, const void* o, const float* o_f32, const float* lse,
+                                     const void* dout, float* delta_ws, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk,
+                                     int E, float scale, float drop_p, uint64_t seed, mi_stream_t st) {
   int rc = mha_check(q, k, v, B, H, Lq, Lk, E);
   if (rc) return rc;
+  MI_REQUIRE(ldq >= E && ldk >= E && ldq % 8 == 0 && ldk % 8 == 0, "mha_bwd: row strides ldq %d / ldk %d (>= E, multiples of 8)", ldq, ldk);
+  MI_REQUIRE(((uintptr_t)dq % 16) == 0 && ((uintptr_t)dk % 16) == 0, "mha_bwd: dq / dk alignment");
   MI_REQUIRE(o && lse && dout && delta_ws && dq && dk && dv, "mha_bwd: null");
   MhaK p;
   memset(&p, 0, sizeof(p));
@@ -904,6 +927,7 @@ extern "C" int mi_mha_bwd_dropout_o32(const void* q, const void* k, const void* 
   p.q = (const __bf16*)q; p.k = (const __bf16*)k; p.v = (const __bf16*)v; p.mask = key_padding_mask;
   p.o = (__bf16*)o; p.o32 = (float*)o_f32; p.lse = (float*)lse; p.dout = (const __bf16*)dout; p.delta = delta_ws; p.dq = (__bf16*)dq;
   p.dk = (__bf16*)dk; p.dv = (__bf16*)dv; p.B = B; p.H = H; p.Lq = Lq; p.Lk = Lk; p.E = E; p.scale = scale;
+  p.ldq = ldq; p.ldk = ldk;
   hipStream_t s = (hipStream_t)st;
   hipLaunchKernelGGL(mha_delta_kernel, dim3(mi_cdiv(B * H * Lq * 4, 256)), dim3(256), 0, s, p, delta_ws);
   MI_CHECK_LAUNCH("mha_delta");

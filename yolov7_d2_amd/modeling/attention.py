@@ -55,6 +55,51 @@ class _MhaCore(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None
 
 
+class _MhaCoreQK(torch.autograd.Function):
+    """the attention core of a SELF-attention whose query and key are one tensor (q = k = x + pos: every encoder layer and
+    the decoder's self-attention, detr_backbone.py:155-157,222-224): qk bf16 [L, B, 2E] holds q in columns [0, E) and k in
+    [E, 2E) - ONE in-projection launch produced both - and the backward hands dq | dk back in the same layout, so that the
+    projection's data gradient and weight gradient are one launch each (mi_mha_fwd / bwd_dropout_ld, row strides 2E)"""
+
+    @staticmethod
+    def forward(ctx, qk, v, mask, num_heads, drop_p=0.0, seed=0):
+        if not qk.is_cuda:
+            raise L.MI355Error("mha_core: the MI355X path needs device tensors (no CPU fallback)")
+        Lq, B, E2 = qk.shape
+        E = E2 // 2
+        qk, v = qk.to(torch.bfloat16).contiguous(), v.to(torch.bfloat16).contiguous()
+        m = None if mask is None else mask.to(torch.uint8).contiguous()
+        o = torch.empty_like(v)
+        need32 = _O32() and any(ctx.needs_input_grad[:2])
+        o32 = torch.empty(Lq, B, E, dtype=torch.float32, device=qk.device) if need32 else None
+        lse = torch.empty(B, num_heads, Lq, dtype=torch.float32, device=qk.device)
+        scale = 1.0 / math.sqrt(E // num_heads)
+        L.check(L.lib().mi_mha_fwd_dropout_ld(qk.data_ptr(), E2, qk.data_ptr() + 2 * E, E2, v.data_ptr(), L.ptr(m), o.data_ptr(),
+                                              L.ptr(o32), lse.data_ptr(), B, num_heads, Lq, Lq, E, scale, float(drop_p), int(seed),
+                                              L.stream_ptr()), "mi_mha_fwd (packed q | k)")
+        ctx.save_for_backward(qk, v, m, o, lse, o32)
+        ctx.num_heads, ctx.scale, ctx.drop = num_heads, scale, (float(drop_p), int(seed))
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qk, v, m, o, lse, o32 = ctx.saved_tensors
+        Lq, B, E2 = qk.shape
+        E = E2 // 2
+        do = do.to(torch.bfloat16).contiguous()
+        dqk, dv = torch.empty_like(qk), torch.empty_like(v)
+        delta = torch.empty_like(lse)
+        L.check(L.lib().mi_mha_bwd_dropout_ld(qk.data_ptr(), E2, qk.data_ptr() + 2 * E, E2, v.data_ptr(), L.ptr(m), o.data_ptr(),
+                                              L.ptr(o32), lse.data_ptr(), do.data_ptr(), delta.data_ptr(), dqk.data_ptr(),
+                                              dqk.data_ptr() + 2 * E, dv.data_ptr(), B, ctx.num_heads, Lq, Lq, E, ctx.scale,
+                                              ctx.drop[0], ctx.drop[1], L.stream_ptr()), "mi_mha_bwd (packed q | k)")
+        return dqk, dv, None, None, None, None
+
+
+def mha_core_qk(qk, v, key_padding_mask=None, num_heads=8, dropout_p=0.0, seed=0):
+    return _MhaCoreQK.apply(qk, v, key_padding_mask, num_heads, dropout_p, seed)
+
+
 _DUMPS = [0]
 
 

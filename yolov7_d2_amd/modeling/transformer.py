@@ -24,7 +24,7 @@ from torch import nn
 
 from .. import _lib as L
 from ..ops import pack_images, wgrad_bias_fused
-from .attention import mha_core
+from .attention import mha_core, mha_core_qk
 
 
 def _rup(a, b):
@@ -173,6 +173,33 @@ class _InProjFn(torch.autograd.Function):
         for i, (x, wd, dy) in enumerate(((xq, wq, dq), (xk, wk, dk), (xv, wv, dv))):
             dxs.append(_linear_bwd(x, wd, dy, E, ctx.needs_input_grad[i], gw[i * E:(i + 1) * E], gb[i * E:(i + 1) * E]))
         return dxs[0], dxs[1], dxs[2], gw, gb
+
+
+class _InProjQKFn(torch.autograd.Function):
+    """_InProjFn for a self-attention whose query and key are the SAME tensor: q | k = x W[:2E]^T + b[:2E] as ONE [T, 2E]
+    projection (one forward, one data-gradient, one weight-gradient launch where _InProjFn runs two of each, and no
+    accumulation of the two data gradients by autograd), v as before.  Bit-identical values: the packed image of W[:2E] is the
+    two row blocks' images side by side, every output element is the same dot product."""
+
+    @staticmethod
+    def forward(ctx, xqk, xv, w, b):
+        E = w.shape[1]
+        w32, b32 = w.detach().float().contiguous(), b.detach().float().contiguous()
+        yqk, wdqk = _linear_fwd(xqk, w32[: 2 * E], b32[: 2 * E])
+        yv, wdv = _linear_fwd(xv, w32[2 * E:], b32[2 * E:])
+        ctx.save_for_backward(xqk, xv, wdqk, wdv)
+        ctx.E = E
+        return yqk, yv
+
+    @staticmethod
+    def backward(ctx, dqk, dv):
+        xqk, xv, wdqk, wdv = ctx.saved_tensors
+        E = ctx.E
+        gw = torch.empty(3 * E, E, dtype=torch.float32, device=xqk.device)
+        gb = torch.empty(3 * E, dtype=torch.float32, device=xqk.device)
+        dxqk = _linear_bwd(xqk, wdqk, dqk, 2 * E, ctx.needs_input_grad[0], gw[: 2 * E], gb[: 2 * E])
+        dxv = _linear_bwd(xv, wdv, dv, E, ctx.needs_input_grad[1], gw[2 * E:], gb[2 * E:])
+        return dxqk, dxv, gw, gb
 
 
 class _LayerNormFn(torch.autograd.Function):
@@ -334,6 +361,12 @@ def _tok(x):
     return x.to(torch.bfloat16).contiguous()
 
 
+def _qk_packed():
+    """MI_MHA_QK_PACKED=0: q and k of a self-attention as two projections (round 4's form; A/B, tests)"""
+    import os
+    return os.environ.get("MI_MHA_QK_PACKED", "1") != "0"
+
+
 class MultiheadAttention(nn.Module):
     """nn.MultiheadAttention(embed_dim, num_heads) with the reference's usage: separate query/key/value, key_padding_mask,
     no attn_mask, batch_first=False; parameters named as torch names them."""
@@ -353,6 +386,14 @@ class MultiheadAttention(nn.Module):
         E = self.embed_dim
         Lq, B, _ = query.shape
         Lk = key.shape[0]
+        drop = self.dropout if self.training else 0.0
+        if query is key and _qk_packed():
+            # self-attention with q = k = x + pos (detr_backbone.py:155-157,222-224): one [T, 2E] projection feeds both
+            qk, v = _InProjQKFn.apply(_tok(query).view(Lq * B, E), _tok(value).view(Lk * B, E), self.in_proj_weight, self.in_proj_bias)
+            o = mha_core_qk(qk.view(Lq, B, 2 * E), v.view(Lk, B, E), key_padding_mask, self.num_heads, drop,
+                            _next_seed() if drop > 0 else 0)
+            out = _LinearFn.apply(o.reshape(Lq * B, E), self.out_proj.weight, self.out_proj.bias).view(Lq, B, E)
+            return out, None
         q, k, v = _InProjFn.apply(_tok(query).view(Lq * B, E), _tok(key).view(Lk * B, E), _tok(value).view(Lk * B, E),
                                   self.in_proj_weight, self.in_proj_bias)
         q, k, v = q.view(Lq, B, E), k.view(Lk, B, E), v.view(Lk, B, E)
