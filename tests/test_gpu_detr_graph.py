@@ -263,6 +263,9 @@ def test_graphed_step_data_parallel_two_ranks(tmp_path):
         r = json.load(open(out))
         assert r["buckets"] >= 2 and r["graphs"] == 2 and r["steps"] == 5, r
         assert r["sum_exact"] and r["update_ok"] and r["params_equal"] and r["finite"], r
+        # the backward in stages (transformer + heads, res5, res4, res3), each with messages of its own
+        assert r["stages"] == 4 and all(n >= 1 for n in r["stage_messages"]) and all(n > 0 for n in r["stage_params"]), r
+        assert r["staged_equals_eager"] and r["whole_equals_apart"], r
 
 
 def test_shape_buckets_serve_nearby_shapes_with_one_capture():

@@ -219,12 +219,16 @@ extern "C" int mi_grad_clip_full_model(float* grads, int64_t n, float max_norm, 
 // ---------------------------------------------------------------- sine positional embedding
 // mask [B][H][W] bytes (non-zero = padding) -> pos fp32 [B][2N][H][W]: channels [0,N) from the row count of valid cells
 // (y), [N,2N) from the column count (x); channel 2p = sin(e / T^(2p/N)), 2p+1 = cos(e / T^(2p/N))
+#define POS_CG 8
 __global__ __launch_bounds__(256) void pos_embed_sine_kernel(const uint8_t* __restrict__ mask, int B, int H, int W, int N,
                                                              float temperature, int normalize, float scale,
                                                              int centered, float* __restrict__ out) {
+  // blockIdx.z = a group of POS_CG channels: the 2 N powf / sinf / cosf of a cell were one thread's serial work (102 us per
+  // DETR step for 4 200 cells on 17 blocks); the same calls spread over N / POS_CG times as many threads - identical results
   const int b = blockIdx.y;
   const int cell = blockIdx.x * 256 + threadIdx.x;
   if (cell >= H * W) return;
+  const int i0 = (int)blockIdx.z * POS_CG, i1 = i0 + POS_CG < N ? i0 + POS_CG : N;
   const int h = cell / W, w = cell - h * W;
   const uint8_t* mb = mask + (size_t)b * H * W;
   float ye = 0.f, xe = 0.f, ylast = 0.f, xlast = 0.f;
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(256) void pos_embed_sine_kernel(const uint8_t* __re
     }
   }
   float* ob = out + (size_t)b * 2 * N * H * W + cell;
-  for (int i = 0; i < N; ++i) {
+  for (int i = i0; i < i1; ++i) {
     const float dim_t = powf(temperature, (float)(2 * (i / 2)) / (float)N);
     const float py = ye / dim_t, px = xe / dim_t;
     ob[(size_t)i * H * W] = (i & 1) ? cosf(py) : sinf(py);
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(256) void pos_embed_sine_kernel(const uint8_t* __re
 extern "C" int mi_pos_embed_sine(const uint8_t* mask, int B, int H, int W, int num_pos_feats, float temperature,
                                  int normalize, float scale, int centered, float* out, mi_stream_t st) {
   MI_REQUIRE(mask && out && B > 0 && H > 0 && W > 0 && num_pos_feats > 0 && num_pos_feats % 2 == 0, "pos_embed_sine: args");
-  hipLaunchKernelGGL(pos_embed_sine_kernel, dim3(mi_cdiv(H * W, 256), B), dim3(256), 0, (hipStream_t)st, mask, B, H, W,
+  hipLaunchKernelGGL(pos_embed_sine_kernel, dim3(mi_cdiv(H * W, 256), B, mi_cdiv(num_pos_feats, POS_CG)), dim3(256), 0, (hipStream_t)st, mask, B, H, W,
                      num_pos_feats, temperature, normalize, scale, centered, out);
   MI_CHECK_LAUNCH("pos_embed_sine");
   return MI_OK;

@@ -33,11 +33,19 @@ class GraphedTrainStep:
 
         Data parallel (torch.distributed initialised with world_size > 1; train_transformer.py:188-203 and
         train_inseg.py:63-77 reach d2's create_ddp_model for this): rank 0's parameters and buffers are broadcast here; a
-        step is then graph A (forward, backward, gradients gathered into the optimizer's flat buffer) -> the bucketed
-        all-reduce of that buffer (a few messages of ~bucket_bytes; RCCL over xGMI, or gloo in rehearsal) -> graph B (clip +
-        AdamW reading the flat buffer with 1 / world_size).  The collectives sit BETWEEN the two graphs: ranks may capture
-        different padded shapes at different steps without ever disagreeing on the sequence of collectives, and the
-        warm-up / capture passes issue none."""
+        step is then graphs A0 .. Ak (forward + the backward cut into stages, each stage's gradients gathered into the
+        optimizer's flat buffer) -> the bucketed all-reduce of that buffer (a few messages of ~bucket_bytes; RCCL over
+        xGMI, or gloo in rehearsal) -> graph B (clip + AdamW reading the flat buffer with 1 / world_size).  The collectives
+        sit BETWEEN graphs: ranks may capture different padded shapes at different steps without ever disagreeing on the
+        sequence of collectives, and the warm-up / capture passes issue none.
+
+        Overlap (what DDP's bucket hooks do for the reference): `model.grad_cut_modules()` names modules with a single
+        tensor output, in forward order (the ResNet stages for DETR / SparseInst).  Their outputs are detached during
+        the forward, so the backward falls into stages - A0: forward + everything after the last cut, A1: the last cut
+        module's backward, ... - each its own graph.  Stage j's slice of the flat buffer is all-reduced (async) as soon
+        as Aj is ENQUEUED, so it travels while A(j+1).. compute; only the last stage's message is exposed.  The stage a
+        parameter belongs to is found, not declared: whatever gained a .grad during that stage's backward.
+        MI_DDP_STAGES=0: one backward graph, all-reduce after it (the round-4 form)."""
         import os
         import torch.distributed as dist
         from .ops import WeightImages
@@ -48,11 +56,18 @@ class GraphedTrainStep:
         self.images = WeightImages(list(model.parameters())) if batch_packs else None
         self.model, self.opt, self.warmup = model, optimizer, max(warmup, 2 if batch_packs else 1)
         self.loss_keys = loss_keys
-        self.graphs = {}            # key -> [graph A, graph B or None, static, out, optimizer table handles]; insertion order = recency
+        self.graphs = {}            # key -> [[graphs A0..Ak], graph B or None, static, out, optimizer table handles]; insertion order = recency
         self.max_graphs = max_graphs
         self.pool = None
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.cut_modules = []
+        self.stage_params = None    # [[parameter indices (optimizer order)] per backward stage], found at the first pass
+        self.stage_buckets = None   # [[(lo, hi) element ranges of the flat buffer] per stage]
         if self.world > 1:
+            self.bucket_bytes = int(bucket_bytes)
+            cuts = getattr(model, "grad_cut_modules", None)
+            if cuts is not None and os.environ.get("MI_DDP_STAGES", "1") != "0":
+                self.cut_modules = list(cuts())
             if not hasattr(optimizer, "enable_flat_grads"):
                 raise L.MI355Error("GraphedTrainStep: data parallel needs optim.MultiTensorAdamW (flat gradient buckets)")
             optimizer.enable_flat_grads(bucket_bytes)
@@ -80,26 +95,121 @@ class GraphedTrainStep:
         wd = getattr(getattr(self.model, "criterion", None), "weight_dict", None)
         return [k for k in losses if wd is None or k in wd]
 
-    def _body_fb(self, static):
+    def _stage_fns(self, static):
+        """the step's forward + backward as closures, one per backward stage (run in order; each may be captured as its
+        own graph).  Stage 0 = forward + the backward down to the last cut, returns the loss dict; stage j = the backward
+        of the j-th cut module from the end.  No cut modules: one entry."""
         from .ops import WeightImages
-        if self.images is not None:
-            self.images.run()
-        WeightImages.active = self.images
-        try:
-            losses = self.model.forward_prepared(static)
-            total = losses["total"] if "total" in losses else sum(losses[k] for k in self._keys(losses))
-            self.opt.zero_grad(set_to_none=True)
-            total.backward()
-        finally:
+        cuts = []           # (output of a cut module as autograd produced it, the detached leaf its consumers saw)
+        seen, found = set(), []
+        plist = [p for g in self.opt.param_groups for p in g["params"]]
+
+        def detach_output(_m, _inp, out):
+            if not (torch.is_tensor(out) and out.requires_grad):       # (frozen prefix: nothing flows back through it)
+                return None
+            leaf = out.detach().requires_grad_(True)
+            cuts.append((out, leaf))
+            return leaf
+
+        def finish(last):
+            idx = [k for k, p in enumerate(plist) if p.grad is not None and k not in seen]
+            seen.update(idx)
+            found.append(idx)
+            if self.world > 1:
+                self.opt.gather_grads(only=None if (last and len(found) == 1) else idx)
+            if last:
+                WeightImages.active = None
+                if self.images is not None:
+                    self.images.freeze()        # (after the first pass: the recorded jobs become the step's one pack launch)
+                self._note_stages(found)
+                self.seed_word += 1
+                cuts.clear()
+
+        def abort():
             WeightImages.active = None
-        if self.images is not None:
-            self.images.freeze()            # (after the first pass: the recorded jobs become the step's one pack launch)
-        if self.world > 1:
-            self.opt.gather_grads()
-        self.seed_word += 1
-        out = {k: v.detach() for k, v in losses.items()}
-        out["total"] = total.detach()
-        return out
+            cuts.clear()
+
+        def stage0():
+            if self.images is not None:
+                self.images.run()
+            WeightImages.active = self.images
+            try:
+                hooks = [m.register_forward_hook(detach_output) for m in self.cut_modules]
+                try:
+                    losses = self.model.forward_prepared(static)
+                finally:
+                    for h in hooks:
+                        h.remove()
+                if len(cuts) != len(nstage) - 1:
+                    raise L.MI355Error("GraphedTrainStep: grad_cut_modules() lists a module whose output carries no gradient")
+                total = losses["total"] if "total" in losses else sum(losses[k] for k in self._keys(losses))
+                self.opt.zero_grad(set_to_none=True)
+                total.backward()
+                finish(last=not cuts)
+            except BaseException:
+                abort()
+                raise
+            out = {k: v.detach() for k, v in losses.items()}
+            out["total"] = total.detach()
+            return out
+
+        def later(j):
+            def run():
+                try:
+                    out, leaf = cuts[len(cuts) - j]         # stage 1 = the LAST cut module's backward
+                    g, leaf.grad = leaf.grad, None
+                    if g is None:
+                        raise L.MI355Error("GraphedTrainStep: a cut module's output received no gradient")
+                    out.backward(g)
+                    finish(last=j == len(cuts))
+                except BaseException:
+                    abort()
+                    raise
+            return run
+
+        nstage = [stage0] + [later(j) for j in range(1, len(self._live_cut_modules()) + 1)]
+        return nstage
+
+    def _live_cut_modules(self):
+        """the cut modules that have a trainable parameter at or before them in forward order would be the exact rule;
+        what is checked here is cheaper and enough for the backbones in use: a cut module with no trainable parameter
+        of its own AND none in any earlier cut module carries no gradient (d2's FREEZE_AT prefix)"""
+        live, any_before = [], False
+        for m in self.cut_modules:
+            any_before = any_before or any(p.requires_grad for p in m.parameters())
+            if any_before:
+                live.append(m)
+        self.cut_modules = live
+        return live
+
+    def _note_stages(self, found):
+        """the parameters per backward stage (same for every batch shape and every rank: a property of the module tree)
+        and, under data parallel, each stage's all-reduce messages: contiguous runs of its tensors in the flat buffer,
+        cut at ~bucket_bytes"""
+        if self.stage_params is not None:
+            if self.stage_params != found:
+                raise L.MI355Error("GraphedTrainStep: the backward stages changed between passes")
+            return
+        self.stage_params = [list(f) for f in found]
+        if self.world == 1:
+            return
+        offs, n = [int(v) for v in self.opt.flat_off.tolist()], self.opt.flat.numel()
+        end = lambda k: offs[k + 1] if k + 1 < len(offs) else n
+        per = max(1, self.bucket_bytes // 4)
+        self.stage_buckets = []
+        for idx in self.stage_params:
+            runs, b = [], []
+            for k in sorted(idx):
+                if runs and runs[-1][1] == offs[k]:
+                    runs[-1][1] = end(k)
+                else:
+                    runs.append([offs[k], end(k)])
+            for lo, hi in runs:
+                while hi - lo > per + per // 2:
+                    b.append((lo, lo + per))
+                    lo += per
+                b.append((lo, hi))
+            self.stage_buckets.append(b)
 
     def _body_opt(self):
         if self.world > 1:
@@ -108,14 +218,35 @@ class GraphedTrainStep:
             self.opt.step()
 
     def _body(self, static):
-        out = self._body_fb(static)
+        fns = self._stage_fns(static)
+        out = fns[0]()
+        for f in fns[1:]:
+            f()
         self._body_opt()
         return out
 
-    def _allreduce(self):
+    def _allreduce(self, stage=None, async_op=False):
+        """stage None: every stage's messages, blocking (tests take the step apart with it); stage j: that backward
+        stage's messages, as work handles when async_op"""
         import torch.distributed as dist
-        for lo, hi in self.opt.buckets:
-            dist.all_reduce(self.opt.flat[lo:hi])
+        if stage is None:           # (the SAME message sequence as replay_backward: a rank taking its step apart and a
+            for b in self.stage_buckets:        # rank running it whole must agree on the collectives)
+                for lo, hi in b:
+                    dist.all_reduce(self.opt.flat[lo:hi])
+            return []
+        return [dist.all_reduce(self.opt.flat[lo:hi], async_op=async_op) for lo, hi in self.stage_buckets[stage]]
+
+    def replay_backward(self, ent, reduce=True):
+        """graphs A0 .. Ak of a captured step.  reduce: stage j's all-reduce is issued right after Aj is enqueued and is
+        waited for (by the stream, not the host, under RCCL) only before graph B: it overlaps the later stages' backward"""
+        works = []
+        for j, g in enumerate(ent[0]):
+            g.replay()
+            if reduce and self.world > 1:
+                works += self._allreduce(stage=j, async_op=True)
+        for w in works:
+            if w is not None:
+                w.wait()
 
     def _snapshot(self):
         st = [p.detach().clone() for g in self.opt.param_groups for p in g["params"]]
@@ -189,22 +320,27 @@ class GraphedTrainStep:
                         self._body(static)
                 torch.cuda.current_stream().wait_stream(s)
                 if self.world > 1:
-                    ga, out, ha = self._capture(lambda: self._body_fb(static))
+                    ga, hs, out = [], [], None
+                    for j, f in enumerate(self._stage_fns(static)):     # one graph per backward stage (see __init__)
+                        g, o, h = self._capture(f)
+                        ga.append(g)
+                        hs.append(h)
+                        out = o if j == 0 else out
                     gb, _, hb = self._capture(self._body_opt)
+                    hs.append(hb)
                 else:
-                    ga, out, ha = self._capture(lambda: self._body(static))
-                    gb = hb = None
+                    g, out, ha = self._capture(lambda: self._body(static))
+                    ga, gb, hs = [g], None, [ha]
             finally:
                 self._restore(snap)
-            ent = [ga, gb, static, out, [h for h in (ha, hb) if h is not None]]
+            ent = [ga, gb, static, out, [h for h in hs if h is not None]]
         else:
             self.model.prepare_batch(batched_inputs, static=ent[2])
         self.graphs[key] = ent                                     # (most recent last)
         if hasattr(self.opt, "sync_lr"):
             # an LR scheduler's new param_groups[i]["lr"] -> the tables THIS replay reads (not every table ever captured)
             self.opt.sync_lr(only=ent[4]) if hasattr(self.opt, "release_capture") else self.opt.sync_lr()
-        ent[0].replay()
+        self.replay_backward(ent)
         if ent[1] is not None:
-            self._allreduce()
             ent[1].replay()
         return ent[3]

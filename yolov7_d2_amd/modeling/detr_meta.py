@@ -220,6 +220,12 @@ class Detr(nn.Module):
     # smaller image's does.  The eager forward() is unchanged (exact padding).
     shape_bucket = 64
 
+    def grad_cut_modules(self):
+        """where GraphedTrainStep may cut the backward under data parallel: the ResNet stages (transformer + heads are
+        stage 0; res5 / res4 / res3 follow, each stage's gradients on the wire while the next one computes)"""
+        bb = self.detr.backbone[0].backbone
+        return bb.stage_modules() if hasattr(bb, "stage_modules") else []
+
     def batch_key(self, batched_inputs):
         r = max(int(self.shape_bucket), 1)
         up = lambda v: (v + r - 1) // r * r

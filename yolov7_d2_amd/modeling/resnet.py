@@ -42,7 +42,13 @@ class FrozenBatchNorm2d(nn.Module):
 
     def affine(self):
         """(scale, shift), fp32 [C].  The four buffers are constants of a training run: the pair is computed once and kept
-        until a buffer is written or replaced (five tiny launches per convolution per step otherwise)."""
+        until a buffer is written or replaced (five tiny launches per convolution per step otherwise).
+
+        The two tensors are ADDRESS-STABLE: a changed buffer (load_state_dict, or just a version bump - GraphedTrainStep
+        restores every buffer with copy_ after its warm-up passes) recomputes INTO them.  Captured graphs hold their
+        addresses as launch arguments; replacing the pair would free memory an earlier capture still reads, and the
+        allocator hands it to the next tensor (found with two captured shapes and an eager forward in between: the
+        second shape's replays read another tensor's bytes as the BatchNorm shift)."""
         bufs = (self.weight, self.bias, self.running_mean, self.running_var)
         key = tuple((t.data_ptr(), t._version) for t in bufs)
         c = self.__dict__.get("_affine")
@@ -50,6 +56,10 @@ class FrozenBatchNorm2d(nn.Module):
             with torch.no_grad():
                 scale = (self.weight.float() * (self.running_var.float() + self.eps).rsqrt()).contiguous()
                 shift = (self.bias.float() - self.running_mean.float() * scale).contiguous()
+                if c is not None and c[1].device == scale.device and c[1].shape == scale.shape:
+                    c[1].copy_(scale)
+                    c[2].copy_(shift)
+                    scale, shift = c[1], c[2]
             c = self.__dict__["_affine"] = (key, scale, shift)
         return c[1], c[2]
 
@@ -174,10 +184,19 @@ class Conv2d(nn.Module):
                     key = (self.weight.data_ptr(), self.weight._version, self.norm.__dict__["_affine"][0])
                     c = self.__dict__.get("_image")
                     if c is None or c[0] != key:
-                        c = self.__dict__["_image"] = (key, g.pack(self.weight, dgrad=False, scale=scale)[0])
+                        c = self.__dict__["_image"] = (key, _same_address(c, g.pack(self.weight, dgrad=False, scale=scale)[0]))
                     wf = c[1]
                 return _folded_forward(g, x, wf, shift, relu)[1]
         return _FoldedConvFn.apply(x, self.weight, scale, shift, self.stride, self.padding, relu)
+
+
+def _same_address(cached, new):
+    """a re-packed constant image goes INTO the tensor the previous one lived in (captured graphs hold its address; see
+    FrozenBatchNorm2d.affine)"""
+    if cached is not None and cached[1].device == new.device and cached[1].shape == new.shape and cached[1].dtype == new.dtype:
+        cached[1].copy_(new)
+        return cached[1]
+    return new
 
 
 def _FOLDED_FN():
@@ -334,7 +353,7 @@ class BasicStem(nn.Module):
                 wf = torch.empty(16 * 16 * Cout, dtype=torch.bfloat16, device=x.device)
                 L.check(L.lib().mi_pack_conv_weight(w4.data_ptr(), Cout, 4 * Cin, 4, 4, wf.data_ptr(), 16, Cout, None, 0, 0,
                                                     L.stream_ptr()), "mi_pack_conv_weight (stem)")
-                c = (key, wf)
+                c = (key, _same_address(c, wf) if key is not None else wf)
                 if key is not None:
                     self.__dict__["_image"] = c
             Hh, Wh = He // 2, We // 2
@@ -531,6 +550,11 @@ class ResNet(Backbone):
 
     def output_shape(self):
         return {k: self._shapes[k] for k in self._out_features}
+
+    def stage_modules(self):
+        """res2 .. res5 in forward order: single-tensor outputs that cut the backward into stages
+        (graph_step.GraphedTrainStep's data-parallel overlap)"""
+        return [getattr(self, n) for n in self.stage_names]
 
     @property
     def size_divisibility(self):

@@ -749,6 +749,10 @@ class SparseInst(nn.Module):
         mx = max((len(x["instances"]) for x in batched_inputs if "instances" in x), default=0)
         return max(self.target_capacity, (mx + 31) // 32 * 32)
 
+    def grad_cut_modules(self):
+        """GraphedTrainStep's backward stages under data parallel: encoder + decoder + criterion, then res5, res4, res3"""
+        return self.backbone.stage_modules() if hasattr(self.backbone, "stage_modules") else []
+
     def batch_key(self, batched_inputs):
         r = 32                          # ImageList.from_tensors(images, 32) of preprocess_inputs (sparseinst.py:95-98)
         up = lambda v: (v + r - 1) // r * r

@@ -94,6 +94,7 @@ class MultiTensorAdamW:
         for a, (ti, c, k) in zip(arr, chunks):
             a.tensor, a.count, a.offset = ti, c, k
         self.nchunks = len(chunks)
+        self._chunks_host, self._sub_chunks = chunks, {}
         self.chunks = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         self.table_bytes = len(self.params) * C.sizeof(L.mi_adamw_tensor)
         self.table = torch.zeros(self.table_bytes, dtype=torch.uint8, device=dev)   # the eager steps' table
@@ -116,14 +117,18 @@ class MultiTensorAdamW:
     def _lrs(self):
         return [float(g["lr"]) for g in self.param_groups]
 
-    def _host_table(self):
+    def _host_table(self, partial=False):
+        """partial: a table for a launch that reads only some tensors' gradients (one backward stage's gather): the
+        others may not exist yet, their g stays null"""
         arr = (L.mi_adamw_tensor * len(self.params))()
         k = 0
         for g in self.param_groups:
             for p in g["params"]:
                 a = arr[k]
-                assert p.grad is not None and p.grad.is_contiguous() and p.is_contiguous(), "MultiTensorAdamW: missing / strided gradient"
-                a.p, a.g, a.m, a.v = p.data_ptr(), p.grad.data_ptr(), self.exp_avg[k].data_ptr(), self.exp_avg_sq[k].data_ptr()
+                assert (p.grad is not None or partial) and p.is_contiguous(), "MultiTensorAdamW: missing gradient"
+                assert p.grad is None or p.grad.is_contiguous(), "MultiTensorAdamW: strided gradient"
+                a.p, a.m, a.v = p.data_ptr(), self.exp_avg[k].data_ptr(), self.exp_avg_sq[k].data_ptr()
+                a.g = p.grad.data_ptr() if p.grad is not None else 0
                 a.count, a.lr, a.weight_decay = p.numel(), float(g["lr"]), float(g["weight_decay"])
                 k += 1
         return arr
@@ -132,23 +137,23 @@ class MultiTensorAdamW:
     def _upload(table, arr):
         table.copy_(torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8))
 
-    def refresh(self):
+    def refresh(self, partial=False):
         """upload the eager table (new gradient addresses, changed learning rates); outside a capture only"""
-        self._upload(self.table, self._host_table())
-        self._grad_ptrs = [p.grad.data_ptr() for p in self.params]
+        self._upload(self.table, self._host_table(partial))
+        self._grad_ptrs = [p.grad.data_ptr() if p.grad is not None else 0 for p in self.params]
         self._eager_lrs = self._lrs()
 
     def begin_capture(self):
         """a fresh device table for the capture that follows (allocated outside the graph's pool)"""
         self._cap_table = torch.zeros(self.table_bytes, dtype=torch.uint8, device=self.device)
-        self._cap_used = False
+        self._cap_used = self._cap_partial = False
 
     def finish_capture(self):
         """the capture has ended: the gradient addresses of the graph's pool are final -> fill THIS capture's table"""
         if self._cap_table is None or not self._cap_used:      # (a captured segment that read no gradient table: the
             self._cap_table = None                              #  data-parallel update reads the flat buffer's table)
             return None
-        arr = self._host_table()
+        arr = self._host_table(partial=self._cap_partial)
         self._upload(self._cap_table, arr)
         # (no reference to the gradient tensors is kept: they belong to the graph's memory pool, which GraphedTrainStep
         #  shares between captures - a later capture may lay its own tensors over them, replays never overlap)
@@ -179,8 +184,9 @@ class MultiTensorAdamW:
                 self._upload(ent[0], ent[1])
                 ent[2] = lrs
 
-    def _grad_table(self):
-        """the table whose g fields are the parameters' CURRENT .grad tensors: this capture's, or the eager one"""
+    def _grad_table(self, partial=False):
+        """the table whose g fields are the parameters' CURRENT .grad tensors: this capture's, or the eager one
+        (partial: the caller reads only tensors that have a gradient - gather_grads(only=...))"""
         if torch.cuda.is_current_stream_capturing():
             if self._cap_table is None:      # (a caller without begin_capture: allocated from the graph's pool, kept alive here)
                 self._cap_table = torch.zeros(self.table_bytes, dtype=torch.uint8, device=self.device)
@@ -188,7 +194,7 @@ class MultiTensorAdamW:
             return self._cap_table
         ptrs = [p.grad.data_ptr() if p.grad is not None else 0 for p in self.params]
         if ptrs != self._grad_ptrs or self._eager_lrs != self._lrs():
-            self.refresh()
+            self.refresh(partial)
         return self.table
 
     # ---- data parallel: gradients gathered into one flat buffer, all-reduced in a few large buckets, updated from there
@@ -225,9 +231,27 @@ class MultiTensorAdamW:
                 self.buckets.append((lo, end))
                 lo = end
 
-    def gather_grads(self):
-        """.grad of every parameter -> the flat buffer (one launch; capturable: reads this capture's own table)"""
-        L.check(L.lib().mi_grad_gather_multi(self._grad_table().data_ptr(), self.chunks.data_ptr(), self.nchunks,
+    def gather_grads(self, only=None):
+        """.grad of every parameter -> the flat buffer (one launch; capturable: reads this capture's own table).
+        only: parameter indices - the tensors of one backward stage (GraphedTrainStep cuts the backward into stages whose
+        slices of the flat buffer are all-reduced while the later stages still compute); the launch then walks just their
+        chunks, and the captured table may hold null gradients for the rest"""
+        chunks, n = self.chunks, self.nchunks
+        if only is not None:
+            key = tuple(only)
+            if key not in self._sub_chunks:
+                want = set(key)
+                sub = [c for c in self._chunks_host if c[0] in want]
+                arr = (L.mi_adamw_chunk * max(1, len(sub)))()
+                for a, (ti, c, k) in zip(arr, sub):
+                    a.tensor, a.count, a.offset = ti, c, k
+                self._sub_chunks[key] = (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device), len(sub))
+            chunks, n = self._sub_chunks[key]
+            if torch.cuda.is_current_stream_capturing():
+                self._cap_partial = True
+            if n == 0:
+                return
+        L.check(L.lib().mi_grad_gather_multi(self._grad_table(partial=only is not None).data_ptr(), chunks.data_ptr(), n,
                                              self.flat_off.data_ptr(), self.flat.data_ptr(), L.stream_ptr()),
                 "mi_grad_gather_multi")
 
