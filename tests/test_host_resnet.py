@@ -15,15 +15,18 @@ def test_frozen_norm_affine_is_cached_until_a_buffer_changes():
     ref_s = m.weight * (m.running_var + m.eps).rsqrt()
     torch.testing.assert_close(s1, ref_s)
     torch.testing.assert_close(b1, m.bias - m.running_mean * ref_s)
-    m.running_var.mul_(2.0)                                   # an in-place write bumps the buffer's version
-    s3, _ = m.affine()
-    assert s3 is not s1 and not torch.equal(s3, s1)
+    old = s1.clone()
+    m.running_var.mul_(2.0)                                   # an in-place write bumps the buffer's version: recomputed -
+    s3, _ = m.affine()                                        # INTO the same tensors (captured graphs hold their addresses:
+    assert s3 is s1 and not torch.equal(s3, old)              #  tests/test_frozen_constants.py)
+    torch.testing.assert_close(s3, m.weight * (m.running_var + m.eps).rsqrt())
+    keep = s3.clone()
     m.load_state_dict({k: v.clone() for k, v in m.state_dict().items()})     # copy_ into the buffers: recomputed, same values
     s4, _ = m.affine()
-    assert s4 is not s3 and torch.equal(s4, s3)
+    assert s4 is s1 and torch.equal(s4, keep)
     m.double().float()                                        # buffers REPLACED by new tensors (module._apply)
     s5, _ = m.affine()
-    assert s5 is not s4 and torch.equal(s5, s4)
+    assert s5 is s1 and torch.equal(s5, keep)
 
 
 def test_resnet_freeze_at_marks_the_prefix_only():

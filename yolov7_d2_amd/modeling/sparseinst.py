@@ -34,6 +34,7 @@ from torch import nn
 
 from .. import _lib as L
 from ..d2shim import META_ARCH_REGISTRY, ImageList, Instances, build_backbone
+from ..ops import ConvPaddedFn, _ld, nhwc_strided_ok
 from .transformer import _LinearFn, _factor
 
 # ------------------------------------------------------------------------------------------------ small op wrappers
@@ -100,9 +101,10 @@ class _Resize(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         N, H, W, Cc, Ho, Wo = ctx.shape
-        g = g.contiguous()
+        if not nhwc_strided_ok(g):       # (a channel slice of the fusion cat's gradient is read in place: pixel stride _ld(g))
+            g = g.contiguous()
         dx = torch.empty(N, H, W, Cc, dtype=torch.bfloat16, device=g.device)
-        L.check(L.lib().mi_bilinear_resize_bwd_bf16(g.data_ptr(), Cc, N, H, W, Cc, dx.data_ptr(), Cc, Ho, Wo, None,
+        L.check(L.lib().mi_bilinear_resize_bwd_bf16(g.data_ptr(), _ld(g), N, H, W, Cc, dx.data_ptr(), Cc, Ho, Wo, None,
                                                     L.stream_ptr()), "mi_bilinear_resize_bwd_bf16")
         return dx, None, None
 
@@ -128,9 +130,10 @@ class _Up2(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         N, H, W, Cc = ctx.shape
-        g = g.contiguous()
+        if not nhwc_strided_ok(g):
+            g = g.contiguous()
         dx = torch.empty(N, H, W, Cc, dtype=torch.bfloat16, device=g.device)
-        L.check(L.lib().mi_upsample2x_bwd(g.data_ptr(), Cc, dx.data_ptr(), Cc, 0, N, H, W, Cc, L.stream_ptr()), "mi_upsample2x_bwd")
+        L.check(L.lib().mi_upsample2x_bwd(g.data_ptr(), _ld(g), dx.data_ptr(), Cc, 0, N, H, W, Cc, L.stream_ptr()), "mi_upsample2x_bwd")
         return dx
 
 
@@ -186,8 +189,44 @@ class _PixelOuterFn(torch.autograd.Function):
 def _conv(x, m, stride=1, relu=False):
     """nn.Conv2d / detectron2 Conv2d (bias, no norm) through the implicit-GEMM op; relu=True applies the ReLU that follows
     in the convolution's epilogue (MI_CONV_RELU) instead of as a second pass over the map"""
+    if isinstance(x, PaddedNHWC):        # the kernels' operand built once by the caller (ops.ConvPaddedFn)
+        return ConvPaddedFn.apply(x.xh, m.weight, m.bias, x.cin, stride, m.padding[0], relu)
     op = torch.ops.mi355.conv2d_relu if relu else torch.ops.mi355.conv2d
     return op(x, m.weight, m.bias, stride, m.padding[0])
+
+
+class PaddedNHWC:
+    """a feature map as bf16 [N, H, W, CinP] with `cin` real channels and zero pad channels (what the implicit-GEMM kernels
+    read); `_conv` takes it in place of an NCHW tensor"""
+
+    def __init__(self, xh, cin):
+        self.xh, self.cin = xh, cin
+
+    @property
+    def is_cuda(self):
+        return self.xh.is_cuda
+
+
+class _CoordCat(torch.autograd.Function):
+    """decoder_sparseinst.py:117-131: torch.cat([coordinates(x), x], 1) - written ONCE as the padded NHWC operand of the two
+    branches' first convolutions (PaddedNHWC): a zero fill + two strided copies, where every one of those convolutions
+    (two branches, forward and backward) made its own layout copy + zero fill + strided copy of the 258-channel cat"""
+
+    @staticmethod
+    def forward(ctx, x, coords):
+        N, Cc, H, W = x.shape
+        nco = coords.shape[-1]
+        CP = _rup(Cc + nco, 32)
+        xh = torch.zeros(N, H, W, CP, dtype=torch.bfloat16, device=x.device)
+        xh[..., :nco] = coords
+        xh[..., nco: nco + Cc] = x.permute(0, 2, 3, 1)
+        ctx.sl = (nco, Cc)
+        return xh
+
+    @staticmethod
+    def backward(ctx, g):
+        nco, Cc = ctx.sl
+        return g[..., nco: nco + Cc].permute(0, 3, 1, 2), None
 
 
 def _linear(x, lin):
@@ -431,7 +470,15 @@ class BaseIAMDecoder(nn.Module):
     def forward(self, features):
         if not features.is_cuda:
             raise L.MI355Error("SparseInst decoder: the MI355X path needs device tensors (no CPU fallback)")
-        features = torch.cat([self.compute_coordinates(features), features], dim=1)
+        if _PADDED_COORDS():
+            # the coordinate planes are a constant of the map shape: built once per shape, kept (address-stable) across steps
+            key = (tuple(features.shape[:1] + features.shape[2:]), features.device, features.dtype)
+            cache = self.__dict__.setdefault("_coords", {})
+            if key not in cache:
+                cache[key] = self.compute_coordinates(features).permute(0, 2, 3, 1).contiguous()     # [B, H, W, 2] (x, y)
+            features = PaddedNHWC(_CoordCat.apply(features, cache[key]), features.shape[1] + 2)
+        else:
+            features = torch.cat([self.compute_coordinates(features), features], dim=1)
         pred_logits, pred_kernel, pred_scores, iam = self.inst_branch(features)
         mask_features = self.mask_branch(features)
         B, Cc, H, W = mask_features.shape
@@ -461,6 +508,12 @@ class GroupIAMDecoder(BaseIAMDecoder):
         super().__init__(cfg)
         in_channels = cfg.MODEL.SPARSE_INST.ENCODER.NUM_CHANNELS + 2
         self.inst_branch = GroupInstanceBranch(cfg, in_channels)
+
+
+def _PADDED_COORDS():
+    """MI_SI_PADDED_COORDS=0: the cat + per-convolution operand building of round 4 (A/B switch)"""
+    import os
+    return os.environ.get("MI_SI_PADDED_COORDS", "1") != "0"
 
 
 _ENCODERS = {"InstanceContextEncoder": InstanceContextEncoder}
@@ -493,6 +546,9 @@ class PackedMaskTargets:
         self.off = torch.zeros(B + 1, dtype=torch.int32, device=device)
         self.inv_num = torch.ones(1, dtype=torch.float32, device=device)
         self.t2 = torch.zeros(B, cap, dtype=torch.float32, device=device)      # sum_p t^2 of every row (dice denominators)
+        # the matcher's operand: every image's targets as bf16 [P, cap] (pixel-major).  Ground truth, so it is laid out
+        # HERE, once per batch, not by 2 x B transpose / cast launches inside every captured step
+        self.tgtT = torch.zeros(B, P, cap, dtype=torch.bfloat16, device=device)
         self.sizes = [0] * B
 
     def fill(self, targets, input_shape):
@@ -517,6 +573,7 @@ class PackedMaskTargets:
             self.labels[b, :M] = t["labels"].to(dev)
         self.sizes = sizes
         self.t2.copy_((self.tgt * self.tgt).sum(-1).view(self.B, self.cap))      # (eager, in the host half)
+        self.tgtT.copy_(self.tgt.view(self.B, self.cap, -1).transpose(1, 2))
         self.off.copy_(torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32))
         num = torch.tensor([float(sum(sizes))], device=dev)
         world = 1
@@ -539,13 +596,11 @@ def dice_score_packed(masks_nhwc, pk):
     B, Ho, Wo, Np = masks_nhwc.shape
     P = Ho * Wo
     sig = _Ew1.apply(masks_nhwc.contiguous(), "sigmoid").reshape(B, P, Np)
-    tg = pk.tgt.view(B, pk.cap, P)
     s2 = _colsums(sig, square=True)                                                   # [B, Np]  sum_p sigmoid^2
     t2 = pk.t2                                                                        # [B, cap] sum_p t^2 (PackedMaskTargets.fill)
     out = []
     for b in range(B):
-        tT = tg[b].t().to(torch.bfloat16).contiguous()                                # [P, cap]
-        num = 2.0 * pixel_outer(sig[b], tT)                                           # [Np, cap]
+        num = 2.0 * pixel_outer(sig[b], pk.tgtT[b])                                   # [Np, cap]; tgtT[b] = bf16 [P, cap]
         out.append(num / (s2[b][:, None] + t2[b][None, :] + 1e-4))
     return torch.stack(out)
 

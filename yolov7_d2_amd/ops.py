@@ -150,6 +150,42 @@ def _nhwc(x):
     return x.to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()
 
 
+def _nhwc_v(x):
+    """NCHW-shaped tensor -> NHWC-shaped bf16 tensor WITHOUT a copy when x's memory already is an NHWC image whose pixel
+    stride may exceed its channel count: a channel slice of a wider map (the gradient torch.cat hands each of its inputs,
+    one group of a grouped convolution).  Every kernel takes (pointer, pixel stride); `_ld(t)` is that stride.  Anything
+    else gets the contiguous copy of _nhwc.  (MI_NHWC_VIEWS=0: always copy - the round-4 form, A/B switch.)
+    SparseInst-R50's step made 18 such copies (251 MB) + 6 more in its resize backward."""
+    if x.dtype == torch.bfloat16 and x.dim() == 4 and _NHWC_VIEWS:
+        N, Cc, H, W = x.shape
+        sn, sc, sh, sw = x.stride()
+        if (W > 1 and H > 1 and sc == 1 and Cc % 8 == 0 and sw >= Cc and sw % 8 == 0 and sh == W * sw
+                and (N == 1 or sn == H * W * sw) and x.data_ptr() % 16 == 0):
+            return x.permute(0, 2, 3, 1)
+    return _nhwc(x)
+
+
+def nhwc_strided_ok(t):
+    """an NHWC-SHAPED bf16 tensor the kernels can read in place through (data_ptr, _ld): dense, or a channel slice"""
+    if t.dtype != torch.bfloat16 or t.dim() != 4:
+        return False
+    if t.is_contiguous():
+        return True
+    N, H, W, Cc = t.shape
+    sn, sh, sw, sc = t.stride()
+    return bool(_NHWC_VIEWS and W > 1 and H > 1 and sc == 1 and Cc % 8 == 0 and sw >= Cc and sw % 8 == 0 and sh == W * sw
+                and (N == 1 or sn == H * W * sw) and t.data_ptr() % 16 == 0)
+
+
+def _ld(t):
+    """pixel stride (elements) of an NHWC-shaped tensor that is dense or came from _nhwc_v"""
+    return t.shape[-1] if t.is_contiguous() else t.stride(2)
+
+
+import os as _os
+_NHWC_VIEWS = _os.environ.get("MI_NHWC_VIEWS", "1") != "0"
+
+
 def _nchw(y, C):
     """bf16 [N,H,W,Cld] -> NCHW view (channels_last memory) of the first C channels"""
     return y.permute(0, 3, 1, 2)[:, :C]
@@ -207,7 +243,7 @@ class _ConvGeom:
 
     def pad_in(self, x):
         """NCHW -> bf16 [N,H,W,CinP] (zero pad channels)"""
-        xh = _nhwc(x)
+        xh = _nhwc_v(x) if self.CinP == self.Cin else _nhwc(x)
         if self.CinP != self.Cin:
             xp = torch.zeros(self.N, self.H, self.W, self.CinP, dtype=torch.bfloat16, device=x.device)
             xp[..., : self.Cin] = xh
@@ -220,8 +256,8 @@ class _ConvGeom:
         fl = L.MI_CONV_RELU if relu else 0
         aux = None
         if add_relu is not None:
-            fl, aux = L.MI_CONV_ADDRELU, (add_relu.data_ptr(), add_relu.shape[-1])
-        _run_conv(_conv_desc(xh.data_ptr(), self.CinP, self.N, self.H, self.W, wf, self.CinP, y.data_ptr(), y.shape[-1],
+            fl, aux = L.MI_CONV_ADDRELU, (add_relu.data_ptr(), _ld(add_relu))
+        _run_conv(_conv_desc(xh.data_ptr(), _ld(xh), self.N, self.H, self.W, wf, self.CinP, y.data_ptr(), y.shape[-1],
                              self.Ho, self.Wo, self.Cout, self.CoutP, taps, in_stride=self.s, bias=bias, stats=stats,
                              nslots=nslots, flags=fl, aux=aux), "mi_conv2d (forward)")
 
@@ -234,14 +270,15 @@ class _ConvGeom:
         aux = None
         if relu_mask is not None:       # dx *= (relu_mask > 0) in the epilogue (MI_CONV_RELUMASK): relu_mask = the ReLU OUTPUT that was this conv's input
             assert not accum and tuple(relu_mask.shape[:3]) == (self.N, self.H, self.W)
-            fl, aux = L.MI_CONV_RELUMASK, (relu_mask.data_ptr(), relu_mask.shape[-1])
+            fl, aux = L.MI_CONV_RELUMASK, (relu_mask.data_ptr(), _ld(relu_mask))
+        ldy = _ld(dyh)
         if self.s == 1:
             taps = [(pad - r, pad - s, r * k + s) for r in range(k) for s in range(k)]
-            _run_conv(_conv_desc(dyh.data_ptr(), self.CoutP, self.N, self.Ho, self.Wo, wd, self.CoutP, dx.data_ptr(),
+            _run_conv(_conv_desc(dyh.data_ptr(), ldy, self.N, self.Ho, self.Wo, wd, self.CoutP, dx.data_ptr(),
                                  self.CinP, self.H, self.W, self.Cin, self.CinP, taps, flags=fl, aux=aux), "mi_conv2d (dgrad)")
             return
         if k == 1:      # 1x1 stride 2 (ResNet shortcut): only the even pixels receive a gradient; dx arrives zeroed
-            _run_conv(_conv_desc(dyh.data_ptr(), self.CoutP, self.N, self.Ho, self.Wo, wd, self.CoutP, dx.data_ptr(),
+            _run_conv(_conv_desc(dyh.data_ptr(), ldy, self.N, self.Ho, self.Wo, wd, self.CoutP, dx.data_ptr(),
                                  self.CinP, self.H, self.W, self.Cin, self.CinP, [(0, 0, 0)], out_stride=2, oy=0, ox=0,
                                  gridH=(self.H + 1) // 2, gridW=(self.W + 1) // 2, flags=fl, aux=aux), "mi_conv2d (dgrad 1x1 s2)")
             return
@@ -250,7 +287,7 @@ class _ConvGeom:
             for px in (0, 1):
                 taps = [(oy, ox, r * 3 + s) for (r, oy) in cls_taps[py] for (s, ox) in cls_taps[px]]
                 gh, gw = (self.H - py + 1) // 2, (self.W - px + 1) // 2
-                _run_conv(_conv_desc(dyh.data_ptr(), self.CoutP, self.N, self.Ho, self.Wo, wd, self.CoutP, dx.data_ptr(),
+                _run_conv(_conv_desc(dyh.data_ptr(), ldy, self.N, self.Ho, self.Wo, wd, self.CoutP, dx.data_ptr(),
                                      self.CinP, self.H, self.W, self.Cin, self.CinP, taps, out_stride=2, oy=py, ox=px,
                                      gridH=gh, gridW=gw, flags=fl, aux=aux), "mi_conv2d (dgrad s2)")
 
@@ -260,7 +297,7 @@ class _ConvGeom:
         d = L.mi_wgrad_desc()
         d.x, d.dy, d.gw = xh.data_ptr(), dyh.data_ptr(), gw.data_ptr()
         d.row_scale, d.gbias = L.ptr(row_scale), L.ptr(gbias)
-        d.ldx, d.ldy, d.N, d.H, d.W, d.outH, d.outW, d.stride = self.CinP, self.CoutP, self.N, self.H, self.W, self.Ho, self.Wo, self.s
+        d.ldx, d.ldy, d.N, d.H, d.W, d.outH, d.outW, d.stride = _ld(xh), _ld(dyh), self.N, self.H, self.W, self.Ho, self.Wo, self.s
         d.Cin, d.Cout, d.CinPad, d.CoutPad, d.ntaps = self.Cin, self.Cout, self.CinP, self.CoutP, self.KK
         for t in range(self.KK):
             d.tap_dy[t], d.tap_dx[t] = t // self.k - self.pad, t % self.k - self.pad
@@ -291,7 +328,7 @@ def _colsum(dyh, C_):
     T = dyh.numel() // CP
     out = torch.empty(CP, dtype=torch.float32, device=dyh.device)
     ws = torch.empty(128 * CP, dtype=torch.float32, device=dyh.device)
-    L.check(L.lib().mi_colsum_bf16_wide(dyh.data_ptr(), CP, T, CP, out.data_ptr(), 0, ws.data_ptr(), L.stream_ptr()), "mi_colsum_bf16_wide")
+    L.check(L.lib().mi_colsum_bf16_wide(dyh.data_ptr(), _ld(dyh), T, CP, out.data_ptr(), 0, ws.data_ptr(), L.stream_ptr()), "mi_colsum_bf16_wide")
     return out[:C_]
 
 
@@ -327,7 +364,7 @@ def _conv2d_cuda(x, weight, bias, stride, padding, relu=False):
 def _conv2d_backward_cuda(grad, x, weight, has_bias, stride, padding):
     g = _ConvGeom(x.shape, weight.shape, stride, padding)
     _, wd = g.pack(weight, fwd=False)
-    dyh = _pad_last(_nhwc(grad), g.CoutP)
+    dyh = _pad_last(_nhwc_v(grad), g.CoutP)
     xh = g.pad_in(x)
     # the data gradient writes every real channel of every pixel - except the 1x1 stride-2 form (odd pixels receive
     # nothing) and pad channels: only those need the zero fill (it was a full-tensor pass per convolution)
@@ -361,6 +398,64 @@ def _conv2d_bwd(ctx, grad):
 
 
 torch.library.register_autograd("mi355::conv2d", _conv2d_bwd, setup_context=_conv2d_setup)
+
+class ConvPaddedFn(torch.autograd.Function):
+    """conv2d (+ ReLU) on an input that ALREADY is the kernels' operand: bf16 NHWC, channels zero-padded to a multiple of
+    32 (xh [N, H, W, CinP]; `cin` real channels).  mi355::conv2d builds that operand from an NCHW tensor on every call -
+    forward AND backward - which for a 258-channel input (SparseInst's decoder: 256 features + 2 coordinates, two branches)
+    was a 26 MB layout copy + a 29 MB zero fill + a 29 MB strided copy, four times per step.  Here the caller builds it
+    once (sparseinst._CoordCat) and both branches, forward and backward, read it.  Returns NCHW (channels_last memory);
+    backward returns the gradient for xh with its pad channels untouched (never read: the producer slices them off)."""
+
+    @staticmethod
+    def forward(ctx, xh, weight, bias, cin, stride, padding, relu):
+        N, H, W, CP = xh.shape
+        g = _ConvGeom((N, cin, H, W), weight.shape, stride, padding)
+        if CP != g.CinP or xh.dtype != torch.bfloat16 or not xh.is_contiguous():
+            raise L.MI355Error(f"ConvPaddedFn: operand {tuple(xh.shape)} {xh.dtype} is not the padded bf16 NHWC image of {cin} channels")
+        wf, wd = g.pack(weight, dgrad=ctx.needs_input_grad[0])
+        y = torch.empty(N, g.Ho, g.Wo, g.CoutP, dtype=torch.bfloat16, device=xh.device)
+        b32 = None
+        if bias is not None:
+            if g.CoutP == g.Cout and bias.dtype == torch.float32 and bias.is_contiguous():
+                b32 = bias.detach()
+            else:
+                b32 = torch.zeros(g.CoutP, dtype=torch.float32, device=xh.device)
+                b32[: g.Cout] = bias.detach().float()
+        g.fwd(xh, wf, y, bias=b32, relu=relu)
+        ctx.g, ctx.relu, ctx.has_bias = g, relu, bias is not None
+        ctx.save_for_backward(xh, wd, y if relu else None)
+        return _nchw(y, g.Cout)
+
+    @staticmethod
+    def backward(ctx, grad):
+        xh, wd, y = ctx.saved_tensors
+        g = ctx.g
+        dyh = _nhwc_v(grad)
+        if ctx.relu:
+            dyh = dyh.contiguous()
+            yh = y[..., : g.Cout].contiguous()
+            gm = torch.empty_like(dyh)
+            L.check(L.lib().mi_ew_bf16(dyh.data_ptr(), yh.data_ptr(), gm.data_ptr(), dyh.numel(), 2, L.stream_ptr()), "mi_ew_bf16 relu'")
+            dyh = gm
+        dyh = _pad_last(dyh, g.CoutP)
+        dx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(g.N, g.H, g.W, g.CinP, dtype=torch.bfloat16, device=xh.device)
+            if g.CinP != g.Cin:
+                dx[..., g.Cin:].zero_()          # (the pad channels: a few bytes per pixel, so sums of such gradients stay finite)
+            g.dgrad(dyh, wd, dx)
+        need_gb = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            if need_gb and wgrad_bias_fused(g.N * g.Ho * g.Wo):
+                gb = torch.empty(g.Cout, dtype=torch.float32, device=xh.device)
+                gw = g.wgrad(xh, dyh, gbias=gb)
+            else:
+                gw = g.wgrad(xh, dyh)
+        if need_gb and gb is None:
+            gb = _colsum(dyh, g.Cout)
+        return dx, gw, gb, None, None, None, None
+
 
 # conv2d + ReLU in the convolution's epilogue (MI_CONV_RELU): detectron2's Conv2d(norm=FrozenBN, activation=relu) as ONE
 # launch - the separate ReLU was a read + write of the whole map per convolution.  Backward: the ReLU mask comes from the
