@@ -853,6 +853,112 @@ def gold_sparseinst_inference():
     print("sparseinst_inference:", [(len(r.scores), float(r.scores.min()), float(r.scores.max()), float(r.pred_masks.float().mean())) for r in results])
 
 
+def gold_sparseinst_onnx():
+    """what the reference's SparseInst computes in EXPORT mode (meta_arch/sparseinst.py:127-162 under
+    torch.onnx.is_in_onnx_export(): preprocess_inputs_onnx -> backbone -> encoder -> decoder -> inference_onnx), from its own
+    InstanceContextEncoder / GroupIAMDecoder modules and its own `inference_onnx` (:236-345; rescoring_mask_batch :30-44), all
+    loaded by path.  detectron2's ResNet is un-vendored: the backbone is oracle/resnet_oracle.py (PARITY UNPINNED for that
+    part, as everywhere).  Batch of 1 (what export.py traces with) and batch of 2 (where inference_onnx's flattened top-k
+    indexing selects from the first image only - the exported graph must reproduce that, not fix it).  64 x 96 input."""
+    import types
+    from gen_golden_inputs import sparseinst_onnx_weights, synth_sparseinst_images
+    import resnet_oracle as RO
+    root = os.path.dirname(HERE)
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from yolov7_d2_amd import sparse_inst_r50_giam_cfg
+    si = ref_loader.load_sparseinst()
+    meta = ref_loader.load_sparseinst_meta()
+    cfg = sparse_inst_r50_giam_cfg(device="cpu")
+    shapes = {n: types.SimpleNamespace(channels=c, stride=s) for n, c, s in (("res3", 512, 8), ("res4", 1024, 16), ("res5", 2048, 32))}
+    torch.manual_seed(0)
+    net = torch.nn.ModuleDict(dict(backbone=RO.R50Module(50, ("res3", "res4", "res5")), encoder=si.encoder.InstanceContextEncoder(cfg, shapes),
+                                   decoder=si.decoder.GroupIAMDecoder(cfg)))
+    sd = sparseinst_onnx_weights({k: v.shape for k, v in net.state_dict().items()})
+    net.load_state_dict(sd)
+    net.eval()
+    H, W = 64, 96
+    mean = torch.tensor(cfg.MODEL.PIXEL_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(cfg.MODEL.PIXEL_STD).view(1, 3, 1, 1)
+    stub = types.SimpleNamespace(max_detections=cfg.MODEL.SPARSE_INST.MAX_DETECTIONS, mask_threshold=cfg.MODEL.SPARSE_INST.MASK_THRESHOLD)
+    res = dict(hw=np.array([H, W]))
+    import contextlib, io
+    for B in (1, 2):
+        seed = 500 + 100 * B
+        while True:       # a case whose 50th and 51st scores are clearly apart (the top-k SET must not hinge on rounding; the
+                          # order inside it may: the test matches rows, it does not compare them position by position)
+            img = synth_sparseinst_images(B, H, W, seed)
+            with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+                x = (img.permute(0, 3, 1, 2) - mean) / std                       # preprocess_inputs_onnx (:122-125)
+                out = net["decoder"](net["encoder"](net["backbone"](x)))
+                ps = torch.sqrt(out["pred_logits"].sigmoid() * out["pred_scores"].sigmoid() + 1e-3).max(-1)[0]
+                v = ps.sort(dim=1, descending=True)[0]
+                if float((v[:, 49] - v[:, 50]).min()) > 5e-4:
+                    masks, scores, labels = meta.SparseInst.inference_onnx(stub, out, img, (H, W))
+                    break
+            seed += 1
+        res[f"seed{B}"] = np.int64(seed)
+        res[f"masks{B}"] = np.packbits(masks.numpy().astype(np.uint8), axis=-1)
+        res[f"mask_shape{B}"] = np.array(masks.shape)
+        res[f"scores{B}"], res[f"labels{B}"] = scores.numpy(), labels.numpy()
+    np.savez_compressed(os.path.join(OUT, "sparseinst_onnx.npz"), **res)
+    print("sparseinst_onnx:", res["mask_shape1"], int(res["seed1"]), int(res["seed2"]), float(res["scores1"].max()), float(res["scores2"].min()), res["labels1"][0, :6])
+
+
+def gold_detr_onnx():
+    """the reference's own `Detr` (meta_arch/detr.py, by path) in EXPORT mode - `model.onnx_export = True; model(x)` with x
+    [B, 3, H, W] as export.py:283-300 runs it: preprocess_input (:126-134), nested_tensor_from_tensor_list, the
+    trace-friendly MaskedBackbone branch (:362-375), DETR.forward's (logits, boxes) of the last decoder layer (:458-459) and
+    the [x0, y0, x1, y1, score, label] rows of :178-185.  6 + 6 layers, 100 queries, 64 x 96 input; backbone = the ResNet
+    restatement (d2 un-vendored)."""
+    import contextlib, io
+    import resnet_oracle as R
+    from gen_golden_inputs import seeded_tensor_dict, synth_sparseinst_images
+    root = os.path.dirname(HERE)
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from yolov7_d2_amd import d2shim, detr_r50_cfg
+    ref_loader.load()
+    det = ref_loader.load_detr()
+    det.build_backbone = lambda cfg: R.R50Module(50, cfg.MODEL.RESNETS.OUT_FEATURES, cfg.MODEL.RESNETS.STRIDE_IN_1X1)
+    det.ImageList, det.Instances, det.Boxes = d2shim.ImageList, d2shim.Instances, d2shim.Boxes
+    det.detector_postprocess = d2shim.detector_postprocess
+    cfg = detr_r50_cfg(device="cpu")
+    torch.manual_seed(0)
+    model = det.Detr(cfg)
+    model.load_state_dict(detr_onnx_weights({k: v.shape for k, v in model.state_dict().items()}), strict=False)
+    model.eval()
+    model.onnx_export = True
+    H, W = 64, 96
+    res = dict(hw=np.array([H, W]))
+    for B in (1, 2):
+        x = synth_sparseinst_images(B, H, W, 900 + B).permute(0, 3, 1, 2).contiguous()
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            out = model(x)
+        res[f"seed{B}"] = np.int64(900 + B)
+        res[f"outs{B}"] = out.numpy()
+    np.savez_compressed(os.path.join(OUT, "detr_onnx.npz"), **res)
+    print("detr_onnx:", res["outs2"].shape, "scores", float(res["outs1"][..., 4].min()), float(res["outs1"][..., 4].max()),
+          "labels", sorted(set(res["outs1"][0, :, 5].astype(int).tolist()))[:8])
+
+
+def detr_onnx_weights(shapes, seed=431):
+    """seeded weights of the whole reference Detr for the export golden: input_proj scaled down (tokens of norm O(10^2), not
+    10^4), the class head widened so that the arg-max class of a query is not a rounding-noise tie"""
+    from gen_golden_inputs import seeded_tensor_dict
+    sd = seeded_tensor_dict(shapes, seed=seed)
+    sd["detr.input_proj.weight"] = sd["detr.input_proj.weight"] * 1e-2
+    sd["detr.class_embed.weight"] = sd["detr.class_embed.weight"] * 8.0
+    # sharper attention and wider query embeddings: the queries differ a little (a random-init encoder still maps its six
+    # tokens to nearly the same vector, so the 100 rows stay close to each other - every layer's arithmetic is in them all the
+    # same, which is what the comparison needs)
+    for k in list(sd):
+        if k.endswith("in_proj_weight"):
+            sd[k] = sd[k] * 4.0
+    sd["detr.query_embed.weight"] = sd["detr.query_embed.weight"] * 30.0
+    return sd
+
+
 def gold_transformer():
     """the reference's own Transformer (backbone/detr_backbone.py:25-65): 2 encoder + 2 decoder layers, d_model 256,
     8 heads, ffn 512, return_intermediate_dec, eval mode, fp32; post- and pre-norm"""
@@ -932,4 +1038,6 @@ if __name__ == "__main__":
     gold_sparseinst()
     gold_sparseinst_real()
     gold_sparseinst_inference()
+    gold_sparseinst_onnx()
+    gold_detr_onnx()
     gold_set_criterion()

@@ -174,6 +174,34 @@ def sparseinst_spread(sd):
     return sd
 
 
+def sparseinst_onnx_weights(shapes, seed=411):
+    """seeded weights of the WHOLE SparseInst (backbone.* + encoder.* + decoder.*) for the export-mode golden: a randomly
+    initialised ResNet shrinks its activations to ~0.04, after which all 100 instances predict the same thing and the
+    top-k order is rounding noise - the lateral convolutions are scaled so that the encoder works at unit scale, the IAM /
+    class / objectness weights so that the instances differ (scores 0.6 .. 0.7, half a dozen classes)"""
+    sd = sparseinst_spread(seeded_tensor_dict(shapes, seed=seed))
+    for k in list(sd):
+        if k.startswith("encoder.fpn_laterals") and k.endswith("weight"):
+            sd[k] = sd[k] * 25.0
+    for k, f in (("decoder.inst_branch.iam_conv.weight", 20.0), ("decoder.inst_branch.cls_score.weight", 30.0),
+                 ("decoder.inst_branch.objectness.weight", 30.0)):
+        sd[k] = sd[k] * f
+    return sd
+
+
+def synth_sparseinst_images(B, H, W, seed):
+    """float NHWC images in [0, 255] with structure (plane waves + a little noise): spatially varying features"""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    out = []
+    for b in range(B):
+        ph = torch.rand(6, generator=g) * 6.28
+        base = 127 + 90 * torch.sin(xx / (5 + 3 * b) + ph[0]) * torch.cos(yy / 7.0 + ph[1])
+        img = torch.stack([base, 127 + 80 * torch.sin(xx / 11 + yy / 5 + ph[2]), 127 + 70 * torch.cos(xx / 4 - yy / 9 + ph[3])], -1)
+        out.append((img + torch.randn(H, W, 3, generator=g) * 8).clamp(0, 255))
+    return torch.stack(out)
+
+
 def synth_nms_case(n, ncls, seed, spread=14.0):
     """overlapping boxes in clusters (xyxy), scores, class ids (as float, the way the meta-archs pass them)"""
     g = torch.Generator().manual_seed(seed)

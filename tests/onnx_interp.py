@@ -4,6 +4,8 @@ export uses (torch ops on CPU), so that an exported file can be EXECUTED in an i
 (tests/test_export_onnx.py)."""
 import struct
 
+import math
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -137,11 +139,18 @@ def load(data):
     return m
 
 
-def run(model, feeds):
-    env = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in model["inits"].items()}
+def _t(v):
+    v = np.asarray(v)
+    return torch.from_numpy(v.copy() if v.ndim == 0 else np.ascontiguousarray(v))      # (ascontiguousarray makes a 0-d array 1-d)
+
+
+def run(model, feeds, trace=None):
+    env = {k: _t(v) for k, v in model["inits"].items()}
     env.update({k: torch.as_tensor(v) for k, v in feeds.items()})
     for op, ins, outs, a in model["nodes"]:
         x = [env[i] if i else None for i in ins]
+        if trace is not None:
+            trace.append((op, ins, outs, a, [tuple(t.shape) if t is not None else None for t in x]))
         if op == "Conv":
             p = a.get("pads", [0, 0, 0, 0])
             assert p[0] == p[2] and p[1] == p[3] and a.get("dilations", [1, 1]) == [1, 1]
@@ -172,11 +181,32 @@ def run(model, feeds):
                 s = max(0, min(n, s + n if s < 0 else s))
                 e_ = max(0, min(n, e_ + n if e_ < 0 else e_))
                 y = y.index_select(ax, torch.arange(s, e_, st))
+        elif op == "Resize" and a["mode"] == "linear":
+            # align_corners=False bilinear: "pytorch_half_pixel" (what torch's exporter writes) equals "half_pixel" unless an
+            # output dimension is 1
+            assert a["coordinate_transformation_mode"] in ("pytorch_half_pixel", "half_pixel")
+            if len(x) > 3 and x[3] is not None and x[3].numel():
+                size = [int(v) for v in x[3].tolist()]
+                assert size[:2] == list(x[0].shape[:2])
+                size = size[2:]
+            else:
+                sc = x[2].tolist()
+                assert sc[:2] == [1.0, 1.0]
+                size = [int(math.floor(x[0].shape[2] * sc[2])), int(math.floor(x[0].shape[3] * sc[3]))]
+            assert a["coordinate_transformation_mode"] == "pytorch_half_pixel" or min(size) > 1
+            y = F.interpolate(x[0], size=size, mode="bilinear", align_corners=False)
         elif op == "Resize":
             assert a["mode"] == "nearest" and a["coordinate_transformation_mode"] == "asymmetric" and a.get("nearest_mode", "round_prefer_floor") == "floor"
-            sc = x[2].tolist()
-            assert sc[:2] == [1.0, 1.0] and sc[2] == int(sc[2]) and sc[3] == int(sc[3])
-            y = x[0].repeat_interleave(int(sc[2]), 2).repeat_interleave(int(sc[3]), 3)
+            if len(x) > 3 and x[3] is not None and x[3].numel():
+                size = [int(v) for v in x[3].tolist()][2:]
+                sc = [1.0, 1.0, size[0] / x[0].shape[2], size[1] / x[0].shape[3]]
+            else:
+                sc = x[2].tolist()
+                assert sc[:2] == [1.0, 1.0]
+                size = [int(math.floor(x[0].shape[2] * sc[2])), int(math.floor(x[0].shape[3] * sc[3]))]
+            iy = torch.clamp(torch.floor(torch.arange(size[0]) / sc[2]).long(), max=x[0].shape[2] - 1)     # x_orig = x_out / scale, floor
+            ix = torch.clamp(torch.floor(torch.arange(size[1]) / sc[3]).long(), max=x[0].shape[3] - 1)
+            y = x[0].index_select(2, iy).index_select(3, ix)
         elif op == "Reshape":
             shp = [x[0].shape[i] if d == 0 else d for i, d in enumerate(x[1].tolist())]
             y = x[0].reshape(shp)
@@ -185,9 +215,9 @@ def run(model, feeds):
         elif op == "ArgMax":
             y = torch.argmax(x[0], a["axis"], keepdim=bool(a.get("keepdims", 1)))
         elif op == "Cast":
-            y = x[0].to({1: torch.float32, 7: torch.int64}[a["to"]])
+            y = x[0].to({1: torch.float32, 7: torch.int64, 9: torch.bool, 6: torch.int32}[a["to"]])
         elif op == "Constant":
-            y = torch.from_numpy(np.ascontiguousarray(a["value"]))
+            y = _t(a["value"])
         elif op == "Identity":
             y = x[0]
         elif op == "Shape":
@@ -199,10 +229,94 @@ def run(model, feeds):
         elif op == "Expand":
             y = x[0] * torch.ones([int(v) for v in x[1].tolist()], dtype=x[0].dtype)
         elif op == "Gather":
-            y = torch.index_select(x[0], a.get("axis", 0), x[1].reshape(-1)).reshape(
+            idx = x[1].reshape(-1)
+            idx = torch.where(idx < 0, idx + x[0].shape[a.get("axis", 0)], idx)          # (negative indices count from the end)
+            y = torch.index_select(x[0], a.get("axis", 0), idx).reshape(
                 x[0].shape[: a.get("axis", 0)] + tuple(x[1].shape) + x[0].shape[a.get("axis", 0) + 1:])
+        elif op == "Relu":
+            y = torch.relu(x[0])
+        elif op == "Sub":
+            y = x[0] - x[1]
+        elif op == "Div":
+            y = x[0] / x[1]
+        elif op == "Sqrt":
+            y = torch.sqrt(x[0])
+        elif op == "MatMul":
+            y = torch.matmul(x[0], x[1])
+        elif op == "Softmax":
+            assert a.get("axis", 1) in (-1, x[0].dim() - 1)      # (opset 11 flattens to 2-D at `axis`: identical for the last axis)
+            y = torch.softmax(x[0], -1)
+        elif op == "Clip":
+            y = torch.clamp(x[0], min=None if len(x) < 2 or x[1] is None else float(x[1]), max=None if len(x) < 3 or x[2] is None else float(x[2]))
+        elif op == "AveragePool":
+            k, p = a["kernel_shape"], a.get("pads", [0, 0, 0, 0])
+            assert p == [0, 0, 0, 0] and not a.get("ceil_mode", 0)
+            y = F.avg_pool2d(x[0], k, a.get("strides", [1, 1]))
+        elif op in ("ReduceSum", "ReduceMax", "ReduceMean"):
+            ax, kd = a["axes"], bool(a.get("keepdims", 1))
+            y = x[0].sum(ax, keepdim=kd) if op == "ReduceSum" else x[0].mean(ax, keepdim=kd) if op == "ReduceMean" else x[0].amax(ax, keepdim=kd)
+        elif op == "TopK":
+            assert a.get("largest", 1) == 1 and a.get("sorted", 1) == 1
+            v, i = torch.topk(x[0], int(x[1].reshape(-1)[0]), dim=a.get("axis", -1))
+            y = [v, i]
+        elif op == "Greater":
+            y = x[0] > x[1]
+        elif op == "CumSum":
+            assert not a.get("exclusive", 0) and not a.get("reverse", 0)
+            y = torch.cumsum(x[0], int(x[1].item()))
+        elif op == "Sin":
+            y = torch.sin(x[0])
+        elif op == "Cos":
+            y = torch.cos(x[0])
+        elif op == "Tile":
+            y = x[0].repeat(*[int(v) for v in x[1].tolist()])
+        elif op == "Flatten":
+            ax = a.get("axis", 1)
+            y = x[0].reshape(int(np.prod(x[0].shape[:ax])) if ax else 1, -1)
+        elif op == "Gemm":
+            A = x[0].t() if a.get("transA", 0) else x[0]
+            Bm = x[1].t() if a.get("transB", 0) else x[1]
+            y = a.get("alpha", 1.0) * (A @ Bm)
+            if len(x) > 2 and x[2] is not None:
+                y = y + a.get("beta", 1.0) * x[2]
+        elif op == "Less":
+            y = x[0] < x[1]
+        elif op == "Equal":
+            y = x[0] == x[1]
+        elif op == "Not":
+            y = ~x[0]
+        elif op == "And":
+            y = x[0] & x[1]
+        elif op == "Where":
+            y = torch.where(x[0], x[1], x[2])
+        elif op == "Neg":
+            y = -x[0]
+        elif op == "Floor":
+            y = torch.floor(x[0])
+        elif op == "Min":
+            y = torch.minimum(x[0], x[1])
+        elif op == "Max":
+            y = torch.maximum(x[0], x[1])
+        elif op == "Range":
+            y = torch.arange(x[0].item(), x[1].item(), x[2].item(), dtype=x[0].dtype)
+        elif op == "Pow":
+            y = torch.pow(x[0], x[1])
+        elif op == "Erf":
+            y = torch.erf(x[0])
+        elif op == "Tanh":
+            y = torch.tanh(x[0])
+        elif op == "Squeeze":
+            y = x[0]
+            for ax in sorted(a["axes"], reverse=True):
+                y = y.squeeze(ax)
+        elif op == "ConstantOfShape":
+            v = a.get("value")
+            y = torch.full([int(t) for t in x[0].tolist()], float(v.reshape(-1)[0]) if v is not None else 0.0,
+                           dtype=torch.from_numpy(np.ascontiguousarray(v)).dtype if v is not None else torch.float32)
         else:
             raise NotImplementedError(op)
         for name, v in zip(outs, y if isinstance(y, list) else [y]):
             env[name] = v
+            if trace is not None and v.is_floating_point() and bool(torch.isnan(v).any()) and not any(t[0] == "NaN" for t in trace):
+                trace.append(("NaN", ins, outs, a, [op], dict(env)))
     return [env[o].numpy() for o in model["outputs"]]

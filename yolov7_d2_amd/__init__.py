@@ -10,7 +10,7 @@ from .d2shim import BACKBONE_REGISTRY, META_ARCH_REGISTRY, build_backbone, build
 from .modeling import YOLOX, Detr, SparseInst, build_cspdarknetx_backbone, build_resnet_backbone, batched_nms, postprocess
 from . import ops  # noqa: F401  (registers torch.ops.mi355.*)
 from .ops import patch_base_convs
-from .export_onnx import export_yolox_onnx
+from .export_onnx import export_yolox_onnx, export_sparseinst_onnx, export_detr_onnx, export_onnx
 
-__all__ = ["export_yolox_onnx", "YOLOX", "build_cspdarknetx_backbone", "batched_nms", "postprocess", "build_model", "build_backbone",
+__all__ = ["export_yolox_onnx", "export_sparseinst_onnx", "export_detr_onnx", "export_onnx", "YOLOX", "build_cspdarknetx_backbone", "batched_nms", "postprocess", "build_model", "build_backbone",
            "patch_base_convs", "get_cfg", "add_yolo_config", "get_yolox_cfg", "yolox_s_cfg", "META_ARCH_REGISTRY", "BACKBONE_REGISTRY"]
