@@ -29,7 +29,10 @@ def _rel(a, b):
 def test_bilinear_resize_and_pixel_outer_against_torch():
     g = torch.Generator().manual_seed(0)
     bf = lambda t: t.to(torch.bfloat16).float()
-    for (N, C, H, W, Ho, Wo) in ((2, 64, 10, 13, 20, 26), (1, 32, 4, 5, 16, 20), (2, 104, 16, 20, 32, 40), (1, 64, 1, 1, 6, 7)):
+    # (the last four: small maps with wide windows - the pyramid-pooling priors and the 20 -> 80 fusion resize - whose backward
+    #  runs the block-per-pixel kernel; 104 channels = 13 channel groups, which do not divide the block)
+    for (N, C, H, W, Ho, Wo) in ((2, 64, 10, 13, 20, 26), (1, 32, 4, 5, 16, 20), (2, 104, 16, 20, 32, 40), (1, 64, 1, 1, 6, 7),
+                                 (2, 128, 1, 1, 20, 20), (2, 128, 6, 6, 20, 20), (2, 104, 3, 3, 20, 20), (2, 256, 20, 20, 80, 80)):
         x = bf(torch.randn(N, C, H, W, generator=g))
         xr = x.clone().requires_grad_(True)
         ref = F.interpolate(xr, size=(Ho, Wo), mode="bilinear", align_corners=False)

@@ -145,6 +145,50 @@ __global__ __launch_bounds__(256) void resize_bwd_gather_kernel(const ResizeK p)
     *(bf16x8*)(p.y + (((int64_t)n * p.H + iy) * p.W + ix) * p.ldy + c8 * 8) = pack8(acc);
   }
 }
+// The gather form for SMALL input maps with WIDE windows (the pyramid-pooling priors: 1 x 1 .. 6 x 6 maps blown up to 20 x 20,
+// every input pixel collects 100 - 400 out-gradients; the 20 x 20 -> 80 x 80 fusion resize: ~120): one thread per
+// (pixel, channel group) walked its whole window alone, and the launch was one or two blocks - 112 - 171 us of serial loads
+// for a few KB of output (4 of the 7 resize backward launches of a SparseInst step, 0.55 ms).  Here a BLOCK owns one input
+// pixel: 256 / C8 slices share the window (candidate q goes to slice q mod nslices), every slice accumulates its 8 channels
+// in fp32, the slices are added in index order through LDS - fixed order, no atomics.
+__global__ __launch_bounds__(256) void resize_bwd_pixel_kernel(const ResizeK p) {
+  __shared__ float red[256 * 8];
+  const int C8 = p.C8, nsl = 256 / C8;
+  const int c8 = threadIdx.x % C8, sl = threadIdx.x / C8;
+  int64_t r = blockIdx.x;
+  const int ix = (int)(r % p.W); r /= p.W;
+  const int iy = (int)(r % p.H);
+  const int n = (int)(r / p.H);
+  const float ish = 1.f / p.sh, isw = 1.f / p.sw;
+  int oy0 = (int)floorf(((float)iy - 0.5f) * ish - 0.5f) - 1, oy1 = (int)ceilf(((float)iy + 1.5f) * ish - 0.5f) + 1;
+  int ox0 = (int)floorf(((float)ix - 0.5f) * isw - 0.5f) - 1, ox1 = (int)ceilf(((float)ix + 1.5f) * isw - 0.5f) + 1;
+  oy0 = oy0 < 0 ? 0 : oy0; ox0 = ox0 < 0 ? 0 : ox0;
+  oy1 = oy1 > p.Ho - 1 ? p.Ho - 1 : oy1; ox1 = ox1 > p.Wo - 1 ? p.Wo - 1 : ox1;
+  const int ww = ox1 - ox0 + 1, nq = (oy1 - oy0 + 1) * ww;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (sl < nsl) {
+    const __bf16* g0 = p.x + ((int64_t)n * p.Ho * p.Wo) * p.ldx + c8 * 8;
+    for (int q = sl; q < nq; q += nsl) {
+      const int oy = oy0 + q / ww, ox = ox0 + q % ww;
+      const float w = resize_w(oy, p.sh, p.H, iy) * resize_w(ox, p.sw, p.W, ix);
+      if (w == 0.f) continue;
+      const bf16x8 g = *(const bf16x8*)(g0 + ((int64_t)oy * p.Wo + ox) * p.ldx);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += w * (float)g[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(sl * C8 + c8) * 8 + e] = acc[e];
+  }
+  __syncthreads();
+  if (sl == 0) {
+    for (int k = 1; k < nsl; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += red[(k * C8 + c8) * 8 + e];
+    *(bf16x8*)(p.y + (((int64_t)n * p.H + iy) * p.W + ix) * p.ldy + c8 * 8) = pack8(acc);
+  }
+}
 __global__ __launch_bounds__(256) void f32_to_bf16_rows_kernel(const float* __restrict__ a, __bf16* o, int ldo, int64_t npix, int C8) {
   const int64_t total = npix * C8;
   for (int64_t idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
@@ -189,6 +233,15 @@ extern "C" int mi_bilinear_resize_bwd_bf16(const void* dy, int lddy, int N, int 
   const char* sc = getenv("MI_RESIZE_BWD_SCATTER");      // (the first, atomic form: kept for comparison; it needs acc_ws zeroed)
   if (!(sc && atoi(sc))) {
     k.y = (__bf16*)dx; k.ldy = lddx;
+    // window of one input pixel ~ (2 Ho / H + 3) x (2 Wo / W + 3) candidates (clamped to the map)
+    const float wy = 2.f / k.sh + 3.f, wx = 2.f / k.sw + 3.f;
+    const float cand = (wy < (float)Ho ? wy : (float)Ho) * (wx < (float)Wo ? wx : (float)Wo);
+    static const int px_mode = getenv("MI_RESIZE_BWD_PIXEL") ? atoi(getenv("MI_RESIZE_BWD_PIXEL")) : 1;   // 0: round-4 form everywhere
+    if (px_mode && cand >= 64.f && (int64_t)N * H * W <= 65536 && k.C8 <= 256) {
+      hipLaunchKernelGGL(resize_bwd_pixel_kernel, dim3((unsigned)((int64_t)N * H * W)), dim3(256), 0, s, k);
+      MI_CHECK_LAUNCH("bilinear_resize_bwd (block per pixel)");
+      return MI_OK;
+    }
     hipLaunchKernelGGL(resize_bwd_gather_kernel, dim3(nblocks((int64_t)N * H * W * k.C8)), dim3(256), 0, s, k);
     MI_CHECK_LAUNCH("bilinear_resize_bwd");
     return MI_OK;
