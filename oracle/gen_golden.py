@@ -913,7 +913,7 @@ def gold_detr_onnx():
     restatement (d2 un-vendored)."""
     import contextlib, io
     import resnet_oracle as R
-    from gen_golden_inputs import seeded_tensor_dict, synth_sparseinst_images
+    from gen_golden_inputs import detr_onnx_weights, synth_sparseinst_images
     root = os.path.dirname(HERE)
     if root not in sys.path:
         sys.path.insert(0, root)
@@ -940,23 +940,6 @@ def gold_detr_onnx():
     np.savez_compressed(os.path.join(OUT, "detr_onnx.npz"), **res)
     print("detr_onnx:", res["outs2"].shape, "scores", float(res["outs1"][..., 4].min()), float(res["outs1"][..., 4].max()),
           "labels", sorted(set(res["outs1"][0, :, 5].astype(int).tolist()))[:8])
-
-
-def detr_onnx_weights(shapes, seed=431):
-    """seeded weights of the whole reference Detr for the export golden: input_proj scaled down (tokens of norm O(10^2), not
-    10^4), the class head widened so that the arg-max class of a query is not a rounding-noise tie"""
-    from gen_golden_inputs import seeded_tensor_dict
-    sd = seeded_tensor_dict(shapes, seed=seed)
-    sd["detr.input_proj.weight"] = sd["detr.input_proj.weight"] * 1e-2
-    sd["detr.class_embed.weight"] = sd["detr.class_embed.weight"] * 8.0
-    # sharper attention and wider query embeddings: the queries differ a little (a random-init encoder still maps its six
-    # tokens to nearly the same vector, so the 100 rows stay close to each other - every layer's arithmetic is in them all the
-    # same, which is what the comparison needs)
-    for k in list(sd):
-        if k.endswith("in_proj_weight"):
-            sd[k] = sd[k] * 4.0
-    sd["detr.query_embed.weight"] = sd["detr.query_embed.weight"] * 30.0
-    return sd
 
 
 def gold_transformer():

@@ -202,6 +202,22 @@ def synth_sparseinst_images(B, H, W, seed):
     return torch.stack(out)
 
 
+def detr_onnx_weights(shapes, seed=431):
+    """seeded weights of the whole reference Detr for the export golden: input_proj scaled down (tokens of norm O(10^2), not
+    10^4), the class head widened so that the arg-max class of a query is not a rounding-noise tie"""
+    sd = seeded_tensor_dict(shapes, seed=seed)
+    sd["detr.input_proj.weight"] = sd["detr.input_proj.weight"] * 1e-2
+    sd["detr.class_embed.weight"] = sd["detr.class_embed.weight"] * 8.0
+    # sharper attention and wider query embeddings: the queries differ a little (a random-init encoder still maps its six
+    # tokens to nearly the same vector, so the 100 rows stay close to each other - every layer's arithmetic is in them all the
+    # same, which is what the comparison needs)
+    for k in list(sd):
+        if k.endswith("in_proj_weight"):
+            sd[k] = sd[k] * 4.0
+    sd["detr.query_embed.weight"] = sd["detr.query_embed.weight"] * 30.0
+    return sd
+
+
 def synth_nms_case(n, ncls, seed, spread=14.0):
     """overlapping boxes in clusters (xyxy), scores, class ids (as float, the way the meta-archs pass them)"""
     g = torch.Generator().manual_seed(seed)

@@ -337,7 +337,7 @@ def test_written_sparseinst_graph_equals_the_trace_of_the_references_modules():
 # ------------------------------------------------------------------------------------------------ DETR
 def _detr_model():
     import yolov7_d2_amd as M
-    from gen_golden import detr_onnx_weights
+    from gen_golden_inputs import detr_onnx_weights
     model = M.build_model(M.detr_r50_cfg(device="cpu"))
     sd = detr_onnx_weights({k: v.shape for k, v in model.state_dict().items()})
     missing = model.load_state_dict(sd, strict=False)
@@ -392,10 +392,9 @@ def test_written_detr_graph_equals_the_trace_of_the_references_detr():
     of the operators that carry the model and, executed, the same output"""
     import collections
     import contextlib
-    import gen_golden as G
     import ref_loader
     import resnet_oracle as R
-    from gen_golden_inputs import synth_sparseinst_images
+    from gen_golden_inputs import detr_onnx_weights, synth_sparseinst_images
     from yolov7_d2_amd import d2shim, detr_r50_cfg
     from yolov7_d2_amd.export_onnx import export_detr_onnx
     ref_loader.load()
@@ -404,7 +403,7 @@ def test_written_detr_graph_equals_the_trace_of_the_references_detr():
     det.ImageList, det.Instances, det.Boxes = d2shim.ImageList, d2shim.Instances, d2shim.Boxes
     torch.manual_seed(0)
     ref = det.Detr(detr_r50_cfg(device="cpu"))
-    ref.load_state_dict(G.detr_onnx_weights({k: v.shape for k, v in ref.state_dict().items()}), strict=False)
+    ref.load_state_dict(detr_onnx_weights({k: v.shape for k, v in ref.state_dict().items()}), strict=False)
     ref.eval()
     ref.onnx_export = True
     H, W = 64, 96
