@@ -490,3 +490,36 @@ def test_mask_statistics_are_exact_sums_in_a_fixed_order():
                float((t * t).sum())]
         for e in range(4):
             assert abs(float(st[k, e]) - ref[e]) <= 2e-4 * abs(ref[e]) + 1e-3, (k, e, float(st[k, e]), ref[e])
+
+
+def test_staged_backward_graphs_reproduce_the_one_graph_step():
+    """GraphedTrainStep(backward_stages=True): the backward cut at the ResNet stages into one hipGraph per stage (what the
+    data-parallel step does to overlap its all-reduce, graph_step.py) against the one-graph capture, single process.
+    SparseInst is the hard case: res3 / res4 / res5 all feed the encoder AND the next stage, so every cut tensor's gradient
+    is the sum of two consumers that arrive in different stages.  Same weights, same three batches: identical losses and
+    parameters (two-term sums commute)."""
+    from yolov7_d2_amd.graph_step import GraphedTrainStep
+    from yolov7_d2_amd.optim import MultiTensorAdamW
+    import copy
+    torch.manual_seed(0)
+    cfg = M.sparse_inst_r50_giam_cfg(device=DEV)
+    one = M.build_model(cfg)
+    cut = copy.deepcopy(one)
+    one.train(); cut.train()
+    mk = lambda m: MultiTensorAdamW([p for p in m.parameters() if p.requires_grad], lr=5e-5, weight_decay=0.05)
+    s1, s2 = GraphedTrainStep(one, mk(one)), GraphedTrainStep(cut, mk(cut), backward_stages=True)
+    batches = [_si_inputs(1, ((192, 224), (160, 200))), _si_inputs(2, ((180, 210), (192, 224)), counts=(3, 0)),
+               _si_inputs(3, ((170, 224), (192, 200)))]
+    try:
+        for it, b in enumerate(batches):
+            a, c = s1(b), s2(b)
+            for k in a:
+                assert torch.equal(a[k], c[k]), (it, k, float(a[k]), float(c[k]))
+        # encoder + decoder + criterion, res5, res4, res3, res2 + stem (Base-SparseInst.yaml:7 FREEZE_AT 0: everything trains)
+        assert len(s2.stage_params) == 5 and all(len(x) > 0 for x in s2.stage_params)
+        assert len(next(iter(s2.graphs.values()))[0]) == 5 and len(next(iter(s1.graphs.values()))[0]) == 1
+        torch.cuda.synchronize()
+        for (n, p), (_, q) in zip(one.named_parameters(), cut.named_parameters()):
+            assert torch.equal(p.detach(), q.detach()), n
+    finally:
+        s1.close(); s2.close()

@@ -23,7 +23,8 @@ from . import _lib as L
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, loss_keys=None, warmup=2, max_graphs=24, bucket_bytes=64 << 20, batch_packs=None):
+    def __init__(self, model, optimizer, loss_keys=None, warmup=2, max_graphs=24, bucket_bytes=64 << 20, batch_packs=None,
+                 backward_stages=None):
         """optimizer: optim.MultiTensorAdamW (one launch per step; `clip_norm=` for the reference DETR configs' full-model
         gradient clipping, learning-rate changes honoured per replay) or a torch optimizer created with capturable=True (its
         lr must then be a device tensor for a scheduler to have any effect; no clipping; single process only).
@@ -45,7 +46,9 @@ class GraphedTrainStep:
         module's backward, ... - each its own graph.  Stage j's slice of the flat buffer is all-reduced (async) as soon
         as Aj is ENQUEUED, so it travels while A(j+1).. compute; only the last stage's message is exposed.  The stage a
         parameter belongs to is found, not declared: whatever gained a .grad during that stage's backward.
-        MI_DDP_STAGES=0: one backward graph, all-reduce after it (the round-4 form)."""
+        MI_DDP_STAGES=0: one backward graph, all-reduce after it (the round-4 form).
+        backward_stages: None = staged exactly when data parallel (and MI_DDP_STAGES is not 0); True = also in a single
+        process (what the tests use: the staged graphs must reproduce the one-graph step); False = never."""
         import os
         import torch.distributed as dist
         from .ops import WeightImages
@@ -63,11 +66,12 @@ class GraphedTrainStep:
         self.cut_modules = []
         self.stage_params = None    # [[parameter indices (optimizer order)] per backward stage], found at the first pass
         self.stage_buckets = None   # [[(lo, hi) element ranges of the flat buffer] per stage]
+        self.bucket_bytes = int(bucket_bytes)
+        want = (self.world > 1 and os.environ.get("MI_DDP_STAGES", "1") != "0") if backward_stages is None else bool(backward_stages)
+        cuts = getattr(model, "grad_cut_modules", None)
+        if want and cuts is not None:
+            self.cut_modules = list(cuts())
         if self.world > 1:
-            self.bucket_bytes = int(bucket_bytes)
-            cuts = getattr(model, "grad_cut_modules", None)
-            if cuts is not None and os.environ.get("MI_DDP_STAGES", "1") != "0":
-                self.cut_modules = list(cuts())
             if not hasattr(optimizer, "enable_flat_grads"):
                 raise L.MI355Error("GraphedTrainStep: data parallel needs optim.MultiTensorAdamW (flat gradient buckets)")
             optimizer.enable_flat_grads(bucket_bytes)
@@ -319,7 +323,7 @@ class GraphedTrainStep:
                     for _ in range(self.warmup):
                         self._body(static)
                 torch.cuda.current_stream().wait_stream(s)
-                if self.world > 1:
+                if self.world > 1 or self.cut_modules:
                     ga, hs, out = [], [], None
                     for j, f in enumerate(self._stage_fns(static)):     # one graph per backward stage (see __init__)
                         g, o, h = self._capture(f)
