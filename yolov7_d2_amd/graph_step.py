@@ -67,7 +67,8 @@ class GraphedTrainStep:
         self.stage_params = None    # [[parameter indices (optimizer order)] per backward stage], found at the first pass
         self.stage_buckets = None   # [[(lo, hi) element ranges of the flat buffer] per stage]
         self.bucket_bytes = int(bucket_bytes)
-        want = (self.world > 1 and os.environ.get("MI_DDP_STAGES", "1") != "0") if backward_stages is None else bool(backward_stages)
+        env = os.environ.get("MI_DDP_STAGES", "1")          # 0: never, 1: when data parallel, 2: always (measures what the cuts cost)
+        want = ((self.world > 1 and env != "0") or env == "2") if backward_stages is None else bool(backward_stages)
         cuts = getattr(model, "grad_cut_modules", None)
         if want and cuts is not None:
             self.cut_modules = list(cuts())
