@@ -484,10 +484,11 @@ def test_bn_backward_fused_matches_two_pass(C, npix, act, res):
         assert torch.equal(dr0, dr1)
 
 
-@pytest.mark.parametrize("N,H,W", [(2, 16, 24), (1, 6, 10), (3, 64, 96), (2, 8, 12)])
+@pytest.mark.parametrize("N,H,W", [(2, 16, 24), (1, 6, 10), (3, 64, 96), (2, 8, 12), (2, 6, 32), (1, 70, 64), (2, 640, 640)])
 def test_focus_pack_float_and_uint8_bit_exact(N, H, W):
     """Focus (wrappers.py:202-220) from the float image and from the uint8 image, the 4-pixels-per-thread kernels (W % 8
-    == 0) and the scalar ones: TL, BL, TR, BR x (c0, c1, c2) into 16-channel pixels, the 4 pad channels zero - exact"""
+    == 0), the scalar ones and the row-staged uint8 kernel (W % 16 == 0; an odd number of output rows leaves half a row
+    pair): TL, BL, TR, BR x (c0, c1, c2) into 16-channel pixels, the 4 pad channels zero - exact"""
     lib = L.lib()
     g = torch.Generator().manual_seed(H * W)
     u8 = torch.randint(0, 256, (N, 3, H, W), generator=g, dtype=torch.uint8)
