@@ -195,11 +195,27 @@ def build_reference_yolox(depth=0.33, width=0.5, num_classes=80, seed=0, depthwi
     return RefYOLOX(), r
 
 
+def fvcore_sigmoid_focal_loss(inputs, targets, alpha=-1, gamma=2, reduction="none"):
+    """stand-in for fvcore.nn.sigmoid_focal_loss_jit (fvcore is neither vendored in the reference nor installed): the
+    RetinaNet focal loss restated from its published formula.  Not pinned to fvcore itself; cross-checked against the one
+    independent implementation of the same formula that IS installed (transformers' `sigmoid_focal_loss`,
+    tests/test_oracle_golden.py::test_focal_loss_restatement_against_an_independent_implementation)."""
+    import torch
+    import torch.nn.functional as F
+    p = torch.sigmoid(inputs)
+    ce = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    p_t = p * targets + (1 - p) * (1 - targets)
+    loss = ce * ((1 - p_t) ** gamma)
+    if alpha >= 0:
+        loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
+    return loss.sum() if reduction == "sum" else (loss.mean() if reduction == "mean" else loss)
+
+
 def load_sparseinst():
     """the reference's SparseInst files loaded by path: transcoders/encoder_sparseinst.py, transcoders/decoder_sparseinst.py,
     loss/sparseinst_loss.py.  Un-installed names they import at module level are stubbed: fvcore's weight-init helpers
-    (initialisation only), fvcore.nn.sigmoid_focal_loss_jit (restated from its published formula: PARITY UNPINNED for that
-    one function), detectron2.layers.Conv2d (= nn.Conv2d when no norm / activation is passed, which is how these files
+    (initialisation only), fvcore.nn.sigmoid_focal_loss_jit (`fvcore_sigmoid_focal_loss` above: restated from its published formula, PARITY
+    UNPINNED against fvcore, cross-checked against transformers' implementation), detectron2.layers.Conv2d (= nn.Conv2d when no norm / activation is passed, which is how these files
     use it), detectron2.utils.registry.Registry, alfred's logger."""
     load()
     import torch
@@ -216,15 +232,6 @@ def load_sparseinst():
             self[obj.__name__] = obj
             return obj
 
-    def sigmoid_focal_loss_jit(inputs, targets, alpha=-1, gamma=2, reduction="none"):
-        p = torch.sigmoid(inputs)
-        ce = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
-        p_t = p * targets + (1 - p) * (1 - targets)
-        loss = ce * ((1 - p_t) ** gamma)
-        if alpha >= 0:
-            loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
-        return loss.sum() if reduction == "sum" else (loss.mean() if reduction == "mean" else loss)
-
     def c2_msra_fill(m):
         nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
         if m.bias is not None:
@@ -236,7 +243,7 @@ def load_sparseinst():
             nn.init.constant_(m.bias, 0)
 
     fn = _fvcore(weight_init=dict(c2_msra_fill=c2_msra_fill, c2_xavier_fill=c2_xavier_fill))
-    fn.sigmoid_focal_loss_jit = sigmoid_focal_loss_jit
+    fn.sigmoid_focal_loss_jit = fvcore_sigmoid_focal_loss
     _stub("detectron2.utils.registry", Registry=Registry)
     sys.modules["detectron2.layers"].Conv2d = nn.Conv2d
     if "alfred" not in sys.modules:
