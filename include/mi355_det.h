@@ -220,7 +220,8 @@ typedef struct mi_wgrad_group {
   int32_t ngroups, nred, red_blocks, pad_;
   struct {
     int32_t cfg[6];
-    int32_t njobs, nblocks, lds_bytes, pad_;
+    int32_t njobs, nblocks, lds_bytes, fixup; /* fixup = 1: the launch sums its split-K partials itself (MI_WG_FIXUP=1;
+                                               * the table then starts with the tile counters and carries no reduce jobs) */
     int64_t job_off, starts_off;
   } g[MI_WGRAD_MAX_GROUPS];
   int64_t red_off, red_starts_off, table_bytes, ws_bytes;

@@ -454,3 +454,30 @@ def test_batchnorm_in_the_consumer_pass_of_the_640_plan(monkeypatch):
         assert all(sum(w) == 1 for w in xf.values()), xf
         assert len(xf) == len(plan.deferred_bn)
     assert counts["0"] == 0 and counts["1"] >= 35 and 1 <= counts["auto"] <= 10, counts
+
+
+def test_wgrad_fixup_plan_is_opt_in(monkeypatch):
+    """MI_WG_FIXUP=1 (csrc/conv_wgrad.hip wg_fixup: the split-K reduction inside the grouped weight-gradient launches):
+    the same grids and the same split-K workspace, no reduce grid, every group flagged, the table longer by the tile
+    counters (256 bytes per output tile, ahead of the job records); the default plan keeps the reduce grid"""
+    import ctypes as C
+    from yolov7_d2_amd.plan import Plan
+    model, _ = _model()
+    metas = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MI_WG_FIXUP", mode)
+        ps = _PlanState(model, 2, 640, 640, True, materialize=False)
+        plan = Plan(ps.builder, dry_run=True)
+        arr, n = plan.bwd_cmds
+        grp = [k for k in range(n) if L.OPS[arr[k].op] == "WGRAD_GROUP"]
+        assert len(grp) == 1
+        metas[mode] = L.mi_wgrad_group.from_buffer_copy(C.cast(arr[grp[0]].p[0], C.POINTER(L.mi_wgrad_group)).contents)
+    monkeypatch.delenv("MI_WG_FIXUP")
+    a, b = metas["0"], metas["1"]
+    assert a.red_blocks > 0 and b.red_blocks == 0 and b.red9_blocks == 0 and b.nred == 0
+    assert a.ngroups == b.ngroups and a.ws_bytes == b.ws_bytes
+    for i in range(a.ngroups):
+        assert a.g[i].fixup == 0 and b.g[i].fixup == 1
+        assert list(a.g[i].cfg) == list(b.g[i].cfg) and a.g[i].nblocks == b.g[i].nblocks and a.g[i].njobs == b.g[i].njobs
+        assert b.g[i].lds_bytes >= a.g[i].lds_bytes
+    assert b.table_bytes > a.table_bytes and (b.g[0].job_off % 256) == 0 and b.g[0].job_off >= 256

@@ -132,7 +132,7 @@ MI_WGRAD_MAX_GROUPS = 32
 
 class _mi_wgrad_group_g(C.Structure):
     _fields_ = [("cfg", C.c_int32 * 6), ("njobs", C.c_int32), ("nblocks", C.c_int32), ("lds_bytes", C.c_int32),
-                ("pad_", C.c_int32), ("job_off", C.c_int64), ("starts_off", C.c_int64)]
+                ("fixup", C.c_int32), ("job_off", C.c_int64), ("starts_off", C.c_int64)]
 
 
 class mi_wgrad_group(C.Structure):

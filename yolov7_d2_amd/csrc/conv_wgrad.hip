@@ -39,7 +39,12 @@ struct Wg2K {
   unsigned mTW, mHW;  // ceil(65536 / TW), ceil(65536 / haloW): row / d == (row * m) >> 20 for row * d < 65536
   long long V;        // float4 vectors per split slab
   float* bpart;       // NULL, or [nsplit][bld] fp32: the bias gradient's split partials (column sums of dy), written by the cib == 0 blocks
-  int bld, pad_;
+  int bld, fix;       // fix: the blocks of an output tile sum the tile's splits themselves (wg_fixup; grouped launches, MI_WG_FIXUP=1)
+  // fix-up operands (the split-K reduction's: Wg2R)
+  float* g;
+  const float* row_scale;
+  int Cout, Cin, accumulate, pad_;
+  long long cnt_rel;  // byte offset from the group's job array to this job's tile counters (64 words per output tile)
 };
 
 __device__ uint4 g_mi_zero_page[4];
@@ -134,8 +139,156 @@ struct WgBias {
   }
 };
 
-template <int NT, int MI, int NJ, int WCO, int WCI, int TP>
-__device__ __forceinline__ void wgrad2_body(const Wg2K& p, const int bid) {
+// ---------------------------------------------------------------------------------------------------------------
+// Stream-K style fix-up (MI_WG_FIXUP=1, grouped launches): the split-K reduction inside the producing launch.  The nsplit
+// blocks of one (cout, cin) output tile leave their slabs as agent-scope (write-through) stores, meet on the tile's arrival
+// counter, and then EVERY one of them sums 1 / nsplit of the tile over all splits - in wgrad2_reduce_body<4>'s order, bit
+// for bit - and scatters it into the OIHW gradient: the reduce grid and its launch boundary go, the partials are read while
+// the memory-side cache still holds them, and the read runs as wide as the launch (a LAST-ARRIVER fix-up would read
+// nsplit x 147 KB from one CU: slower than the reduce grid).  The wait needs every block of a tile resident: the grouped
+// plan sizes each grid to one round of resident blocks (mi_conv2d_wgrad_group_plan); a wait that does not end in
+// WG_FIX_SPIN_LIMIT polls gives up and writes NaN into its share of the gradient instead of hanging the GPU.
+// No cache maintenance (see conv_bn.h): slabs and counters are written / read with agent-scope accesses (sc1), the stores
+// are acknowledged (s_waitcnt vmcnt(0)) before the arrival is counted.  The counters reset themselves: the block that
+// finishes a tile's reduction last clears them for the next replay.
+#define WG_FIX_SPIN_LIMIT (1 << 20)
+#define WG_FIX_U 3
+// 16-byte agent-scope accesses to a layer's slabs: raw buffer instructions with the sc1 cache-policy bit (aux 16 on gfx940+:
+// what the compiler emits for a relaxed agent-scope atomic, 128 bits wide), the descriptor over the layer's workspace, byte
+// offsets < 2^31 (checked by the plan).  Compiler-tracked: waits and store-data hazards are its business.
+#define WG_SC1 16
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_slab_rsrc(const float* part) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)part, 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ void st_agent16(__amdgpu_buffer_rsrc_t r, const unsigned voff, const unsigned soff, const f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, WG_SC1);
+}
+__device__ __forceinline__ f32x4 ld_agent16(__amdgpu_buffer_rsrc_t r, const unsigned voff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, WG_SC1));
+}
+
+// fragment-order float4 index v of a layer's slab -> 4 couts x 1 cin x 1 tap of the OIHW gradient (the split-K reduction's
+// epilogue, shared by the reduce kernels and the fix-up)
+__device__ __forceinline__ void wg_scatter(float* g, const float* row_scale, const int accumulate, const int NT, const int MI,
+                                           const int NJ, const int WCO, const int WCI, const int nci, const int Cout,
+                                           const int Cin, const long long v, const f32x4 sum) {
+  const int lane = (int)(v & 63);
+  long long r = v >> 6;
+  const int j = (int)(r % NJ); r /= NJ;
+  const int i = (int)(r % MI); r /= MI;
+  const int tap = (int)(r % NT); r /= NT;
+  const int NW = WCO * WCI;
+  const int wave = (int)(r % NW); r /= NW;
+  const int cib = (int)(r % nci);
+  const int cob = (int)(r / nci);
+  const int wco = wave / WCI, wci = wave % WCI;
+  const int ci = cib * (16 * NJ * WCI) + (wci * NJ + j) * 16 + (lane & 15);
+  const int cobase = cob * (16 * MI * WCO) + (wco * MI + i) * 16 + 4 * (lane >> 4);
+  if (ci >= Cin) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int co = cobase + e;
+    if (co < Cout) {
+      float* dst = g + ((size_t)co * Cin + ci) * NT + tap;
+      // (__fmul_rn / __fadd_rn: never contracted into an fma - the reduce kernels and the fix-up must round alike)
+      const float val = row_scale ? __fmul_rn(sum[e], row_scale[co]) : sum[e];
+      *dst = accumulate ? __fadd_rn(*dst, val) : val;
+    }
+  }
+}
+
+template <int NT, int MI, int NJ, int WCO, int WCI>
+__device__ __forceinline__ void wg_fixup(const Wg2K& p, unsigned* const cnt, const int s, const int pl, char* const smem) {
+  constexpr int NW = WCO * WCI, NTH = NW * 64, OUTS = NTH / 4, U = WG_FIX_U;
+  constexpr int VT = NW * NT * MI * NJ * 64;          // float4s of one output tile in a slab
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this block's slab stores are acknowledged
+  __syncthreads();                                    // ... all waves'; the tile buffers in LDS are dead from here
+  unsigned* const A = cnt + (size_t)pl * 64;          // arrivals of this tile; A + 32: finished reductions
+  int* const flag = (int*)smem;
+  f32x4* const red = (f32x4*)(smem + 16);             // [3][U][OUTS]
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(A, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 1, spins = 0;
+    while (__hip_atomic_load(A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.nsplit) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > WG_FIX_SPIN_LIMIT) { ok = 0; break; }   // a block of this tile never became resident
+    }
+    *flag = ok;
+  }
+  __syncthreads();
+  const bool ok = *flag != 0;
+  // this block's share of the tile: `per` consecutive float4s (a multiple of OUTS)
+  const int per = ((VT + p.nsplit - 1) / p.nsplit + OUTS - 1) / OUTS * OUTS;
+  const int beg = s * per, end = min(VT, beg + per);
+  const int o = threadIdx.x % OUTS, sl = threadIdx.x / OUTS;
+  const long long vbase = (long long)pl * VT;
+  const __amdgpu_buffer_rsrc_t rs = wg_slab_rsrc(p.part);
+  const unsigned Vb = (unsigned)(p.V * 16);           // bytes between consecutive splits of one float4
+  const int nsplit = p.nsplit;
+  for (int b0 = beg; b0 < end; b0 += U * OUTS) {
+    f32x4 s0[U], s1[U], s2[U], s3[U];
+    bool valid[U];
+    unsigned src[U];                                  // byte offset of split 0 of this thread's float4
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = b0 + u * OUTS + o;
+      valid[u] = q < end;
+      src[u] = (unsigned)((vbase + (valid[u] ? q : beg)) * 16);
+      s0[u] = s1[u] = s2[u] = s3[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // wgrad2_reduce_body<4>: lane sl takes splits sl, sl + 4, ... - four at a time into s0..s3, the rest into s0
+    int k = sl;
+    for (; k + 12 < nsplit; k += 16) {
+      f32x4 a[U], b[U], c[U], d[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        a[u] = ld_agent16(rs, src[u] + (unsigned)k * Vb);
+        b[u] = ld_agent16(rs, src[u] + (unsigned)(k + 4) * Vb);
+        c[u] = ld_agent16(rs, src[u] + (unsigned)(k + 8) * Vb);
+        d[u] = ld_agent16(rs, src[u] + (unsigned)(k + 12) * Vb);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) { s0[u] += a[u]; s1[u] += b[u]; s2[u] += c[u]; s3[u] += d[u]; }
+    }
+    for (; k < nsplit; k += 4) {
+      f32x4 a[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) a[u] = ld_agent16(rs, src[u] + (unsigned)k * Vb);
+#pragma unroll
+      for (int u = 0; u < U; ++u) s0[u] += a[u];
+    }
+    f32x4 sum[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      sum[u] = (s0[u] + s1[u]) + (s2[u] + s3[u]);
+      if (sl > 0) red[((sl - 1) * U + u) * OUTS + o] = sum[u];
+    }
+    __syncthreads();
+    if (sl == 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) sum[u] += red[(q * U + u) * OUTS + o];
+        if (!ok) sum[u] = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+        if (valid[u])
+          wg_scatter(p.g, p.row_scale, p.accumulate, NT, MI, NJ, WCO, WCI, p.nci, p.Cout, p.Cin,
+                     vbase + b0 + u * OUTS + o, sum[u]);
+      }
+    }
+    __syncthreads();   // red is rewritten by the next pass
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && ok) {
+    // every block of the tile has passed its wait once it counts here: the last one re-arms the counters
+    if (__hip_atomic_fetch_add(A + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nsplit - 1u) {
+      __hip_atomic_store(A + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(A, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <int NT, int MI, int NJ, int WCO, int WCI, int TP, bool FIX = false>
+__device__ __forceinline__ void wgrad2_body(const Wg2K& p, const int bid, unsigned* const cnt = nullptr) {
   constexpr int NW = WCO * WCI, BCO = 16 * MI * WCO, BCI = 16 * NJ * WCI;
   constexpr int RDY = BCO * 2, RX = BCI * 2, KS = TP / 32;
   constexpr int CPR_DY = RDY / 16, RPI_DY = 64 / CPR_DY, NQ_DY = TP / RPI_DY, QW_DY = NQ_DY / NW;
@@ -297,6 +450,18 @@ __device__ __forceinline__ void wgrad2_body(const Wg2K& p, const int bid) {
   // ---- split-K slab, fragment order: [split][cob][cib][wave][tap][i][j][lane] x float4
   f32x4* out = (f32x4*)p.part + (size_t)s * (size_t)p.V +
                ((size_t)((cob * p.nci + cib) * NW + wave) * (NT * MI * NJ)) * 64 + lane;
+  if (FIX) {                         // fix-up form (its own instantiation): write-through slab, then this block's share of the tile's sum
+    const __amdgpu_buffer_rsrc_t rs = wg_slab_rsrc(p.part);
+    const unsigned ob = (unsigned)(((size_t)s * (size_t)p.V + ((size_t)((cob * p.nci + cib) * NW + wave) * (NT * MI * NJ)) * 64 + lane) * 16);
+#pragma unroll
+    for (int tap = 0; tap < NT; ++tap)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) st_agent16(rs, ob, (unsigned)(((tap * MI + i) * NJ + j) * 1024), acc[tap][i][j]);
+    wg_fixup<NT, MI, NJ, WCO, WCI>(p, cnt, s, cob * p.nci + cib, smem);
+    return;
+  }
 #pragma unroll
   for (int tap = 0; tap < NT; ++tap)
 #pragma unroll
@@ -323,6 +488,16 @@ __global__ __launch_bounds__(WCO* WCI * 64, 2) void wgrad2_group_kernel(const Wg
   const Wg2K p = jobs[j];
   wgrad2_body<NT, MI, NJ, WCO, WCI, TP>(p, b - starts[j]);
 }
+// the same grid with the split-K reduction inside (wg_fixup): every job of the group carries fix = 1
+template <int NT, int MI, int NJ, int WCO, int WCI, int TP>
+__global__ __launch_bounds__(WCO* WCI * 64, 2) void wgrad2_group_fix_kernel(const Wg2K* __restrict__ jobs,
+                                                                             const int* __restrict__ starts, int njobs) {
+  const int b = blockIdx.x;
+  int j = 0;
+  while (j + 1 < njobs && starts[j + 1] <= b) ++j;
+  const Wg2K p = jobs[j];
+  wgrad2_body<NT, MI, NJ, WCO, WCI, TP, true>(p, b - starts[j], (unsigned*)((char*)const_cast<Wg2K*>(jobs) + p.cnt_rel));
+}
 
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -336,8 +511,8 @@ __global__ __launch_bounds__(WCO* WCI * 64, 2) void wgrad2_group_kernel(const Wg
 // An LDS-DMA instruction (64 lanes x 16 B, lane-linear in LDS) therefore covers 32 pixel rows of ONE group: each lane
 // pair fetches the 32 bytes of its row; the four groups of a 128-byte line are fetched by consecutive instructions
 // of the same wave (L2 merges them).  The split-K slab format is unchanged (same reduce kernels).
-template <int NT, int MI, int NJ, int WCO, int WCI, int TP>
-__device__ __forceinline__ void wgrad3_body(const Wg2K& p, const int bid) {
+template <int NT, int MI, int NJ, int WCO, int WCI, int TP, bool FIX = false>
+__device__ __forceinline__ void wgrad3_body(const Wg2K& p, const int bid, unsigned* const cnt = nullptr) {
   constexpr int NW = WCO * WCI, BCO = 16 * MI * WCO, BCI = 16 * NJ * WCI;
   constexpr int GD = BCO / 16, GX = BCI / 16, KS = TP / 32, PB = TP / 32;
   constexpr int UD = PB * GD;                 // dy DMA units (32 rows x one group) per tile
@@ -490,6 +665,18 @@ __device__ __forceinline__ void wgrad3_body(const Wg2K& p, const int bid) {
   }
   f32x4* out = (f32x4*)p.part + (size_t)s * (size_t)p.V +
                ((size_t)((cob * p.nci + cib) * NW + wave) * (NT * MI * NJ)) * 64 + lane;
+  if (FIX) {                         // fix-up form (its own instantiation): write-through slab, then this block's share of the tile's sum
+    const __amdgpu_buffer_rsrc_t rs = wg_slab_rsrc(p.part);
+    const unsigned ob = (unsigned)(((size_t)s * (size_t)p.V + ((size_t)((cob * p.nci + cib) * NW + wave) * (NT * MI * NJ)) * 64 + lane) * 16);
+#pragma unroll
+    for (int tap = 0; tap < NT; ++tap)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) st_agent16(rs, ob, (unsigned)(((tap * MI + i) * NJ + j) * 1024), acc[tap][i][j]);
+    wg_fixup<NT, MI, NJ, WCO, WCI>(p, cnt, s, cob * p.nci + cib, smem);
+    return;
+  }
 #pragma unroll
   for (int tap = 0; tap < NT; ++tap)
 #pragma unroll
@@ -513,6 +700,16 @@ __global__ __launch_bounds__(WCO* WCI * 64, 2) void wgrad3_group_kernel(const Wg
   while (j + 1 < njobs && starts[j + 1] <= b) ++j;
   const Wg2K p = jobs[j];
   wgrad3_body<NT, MI, NJ, WCO, WCI, TP>(p, b - starts[j]);
+}
+// the same grid with the split-K reduction inside (wg_fixup): every job of the group carries fix = 1
+template <int NT, int MI, int NJ, int WCO, int WCI, int TP>
+__global__ __launch_bounds__(WCO* WCI * 64, 2) void wgrad3_group_fix_kernel(const Wg2K* __restrict__ jobs,
+                                                                             const int* __restrict__ starts, int njobs) {
+  const int b = blockIdx.x;
+  int j = 0;
+  while (j + 1 < njobs && starts[j + 1] <= b) ++j;
+  const Wg2K p = jobs[j];
+  wgrad3_body<NT, MI, NJ, WCO, WCI, TP, true>(p, b - starts[j], (unsigned*)((char*)const_cast<Wg2K*>(jobs) + p.cnt_rel));
 }
 
 struct Wg2R {
@@ -564,28 +761,7 @@ __device__ __forceinline__ void wgrad2_reduce_body(const Wg2R& p, const long lon
     for (int q = 0; q < SL - 1; ++q) sum += red[q][o];
   }
   if (!valid) return;
-  const int lane = (int)(v & 63);
-  long long r = v >> 6;
-  const int j = (int)(r % p.NJ); r /= p.NJ;
-  const int i = (int)(r % p.MI); r /= p.MI;
-  const int tap = (int)(r % p.NT); r /= p.NT;
-  const int NW = p.WCO * p.WCI;
-  const int wave = (int)(r % NW); r /= NW;
-  const int cib = (int)(r % p.nci);
-  const int cob = (int)(r / p.nci);
-  const int wco = wave / p.WCI, wci = wave % p.WCI;
-  const int ci = cib * (16 * p.NJ * p.WCI) + (wci * p.NJ + j) * 16 + (lane & 15);
-  const int cobase = cob * (16 * p.MI * p.WCO) + (wco * p.MI + i) * 16 + 4 * (lane >> 4);
-  if (ci >= p.Cin) return;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int co = cobase + e;
-    if (co < p.Cout) {
-      float* dst = p.g + ((size_t)co * p.Cin + ci) * p.NT + tap;
-      const float val = p.row_scale ? sum[e] * p.row_scale[co] : sum[e];
-      *dst = p.accumulate ? *dst + val : val;
-    }
-  }
+  wg_scatter(p.g, p.row_scale, p.accumulate, p.NT, p.MI, p.NJ, p.WCO, p.WCI, p.nci, p.Cout, p.Cin, v, sum);
 }
 
 // 3x3 layers: one block = one 16(cout) x 16(cin) fragment tile, wave w = tap w.  The split sums go through an LDS
@@ -705,6 +881,8 @@ static int wg_redsl() {
 // 1: v3 LDS layout (column-major by channel group, see wgrad3_body) for the 3x3 configurations, 2: for all, 0: v2
 static int wg_v3() { static const int v = wg_env("MI_WG_V3", 1); return v; }
 static bool wg_use_v3(int NT) { return wg_v3() == 2 || (wg_v3() == 1 && NT == 9); }
+// 1: grouped launches sum their split-K partials themselves (wg_fixup) instead of leaving them to the reduce grid
+static int wg_fixup_on() { return wg_env("MI_WG_FIXUP", 0); }   // (read per plan: a test builds both forms in one process)
 static int wg_min_lds() { static const int v = wg_env("MI_WG_MIN_LDS", 0); return v; }
 
 static void wg_choose_tile(int TP, int gridH, int gridW, int* TH, int* TW) {
@@ -844,6 +1022,8 @@ static int wg_fill(const mi_wgrad_desc* d, Wg2K* k, Wg2Cfg* c, size_t* lds, size
   k->V = (long long)k->nco * k->nci * (c->WCO * c->WCI) * c->NT * c->MI * c->NJ * 64;
   *ws = (size_t)k->nsplit * (size_t)k->V * 16;
   k->bpart = nullptr; k->bld = 0; k->pad_ = 0;
+  k->fix = 0; k->g = d->gw; k->row_scale = d->row_scale; k->Cout = d->Cout; k->Cin = d->Cin; k->accumulate = d->accumulate;
+  k->cnt_rel = 0;
   if (d->gbias && !grouped) {     // the bias partials behind the slabs (single launches only)
     k->bld = d->CoutPad;
     k->bpart = d->ws ? (float*)((char*)d->ws + *ws) : (float*)(uintptr_t)16;   // (planning call without a workspace: non-null marker)
@@ -1013,6 +1193,21 @@ extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, voi
     if (tab && (int64_t)off <= table_cap) memcpy(tab + o, src, bytes);
     return (long)o;
   };
+  // MI_WG_FIXUP=1: the tile counters of every job come first in the table (uploaded as zeros; they re-arm themselves), 64
+  // words per (cout, cin) output tile: [0] arrivals, [32] finished reductions, each on its own 128-byte line
+  const bool fix = wg_fixup_on() != 0;
+  std::vector<long> cnt_off(n, 0);
+  if (fix) {
+    size_t words = 0;
+    for (int i = 0; i < n; ++i) {
+      MI_REQUIRE(wss[i] < ((size_t)1 << 31), "wgrad_group_plan: job %d has %zu bytes of split slabs (the fix-up addresses < 2^31)", i, wss[i]);
+      cnt_off[i] = (long)(words * 4);
+      words += (size_t)ks[i].nco * ks[i].nci * 64;
+    }
+    std::vector<unsigned> zeros(words, 0u);
+    put(zeros.data(), words * 4);
+    off = (off + 255) / 256 * 256;
+  }
   std::vector<char> done(n, 0);
   for (int i = 0; i < n; ++i) {
     if (done[i]) continue;
@@ -1024,17 +1219,27 @@ extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, voi
     std::vector<int> starts;
     int blocks = 0;
     size_t lds = 0;
+    const long job_off = (long)off;      // (what the put() below returns)
     for (int j = i; j < n; ++j)
       if (!done[j] && wg_cfg_id(cs[j]) == wg_cfg_id(cs[i])) {
         done[j] = 1;
         starts.push_back(blocks);
+        if (fix) {
+          ks[j].fix = 1;
+          ks[j].cnt_rel = (long long)cnt_off[j] - (long long)job_off;
+        }
         jobs.push_back(ks[j]);
         blocks += ks[j].nsplit * ks[j].nco * ks[j].nci;
         if (ldss[j] > lds) lds = ldss[j];
       }
     starts.push_back(blocks);
-    g.njobs = (int)jobs.size(); g.nblocks = blocks; g.lds_bytes = (int32_t)lds;
+    if (fix) {   // the fix-up folds its four split lanes through LDS: flag + [3][WG_FIX_U][threads / 4] float4
+      const size_t need = 16 + (size_t)3 * WG_FIX_U * (cs[i].WCO * cs[i].WCI * 16) * 16;
+      if (lds < need) lds = need;
+    }
+    g.njobs = (int)jobs.size(); g.nblocks = blocks; g.lds_bytes = (int32_t)lds; g.fixup = fix ? 1 : 0;
     g.job_off = put(jobs.data(), jobs.size() * sizeof(Wg2K));
+    MI_REQUIRE(g.job_off == job_off, "wgrad_group_plan: table layout");
     g.starts_off = put(starts.data(), starts.size() * sizeof(int));
   }
   // reduce jobs: one grid for the 1x1 layers (256-thread blocks, 4 fragment tiles each) and one for the 3x3 layers
@@ -1042,7 +1247,7 @@ extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, voi
   std::vector<Wg2R> rj, rj9;
   std::vector<int> rs, rs9;
   int rblocks = 0, rblocks9 = 0;
-  for (int i = 0; i < n; ++i) {
+  for (int i = 0; i < n && !fix; ++i) {
     Wg2R r;
     r.part = (const f32x4*)ks[i].part; r.g = descs[i].gw; r.V = ks[i].V; r.nsplit = ks[i].nsplit;
     r.NT = cs[i].NT; r.MI = cs[i].MI; r.NJ = cs[i].NJ; r.WCO = cs[i].WCO; r.WCI = cs[i].WCI;
@@ -1074,12 +1279,15 @@ extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, voi
 }
 
 template <int NT, int MI, int NJ, int WCO, int WCI, int TP>
-static int wg_group_launch(const Wg2K* jobs, const int* starts, int njobs, int nblocks, size_t lds, hipStream_t s) {
-  auto fn = wg_use_v3(NT) ? wgrad3_group_kernel<NT, MI, NJ, WCO, WCI, TP> : wgrad2_group_kernel<NT, MI, NJ, WCO, WCI, TP>;
+static int wg_group_launch(const Wg2K* jobs, const int* starts, int njobs, int nblocks, size_t lds, hipStream_t s, bool fix) {
+  auto fn = fix ? (wg_use_v3(NT) ? wgrad3_group_fix_kernel<NT, MI, NJ, WCO, WCI, TP> : wgrad2_group_fix_kernel<NT, MI, NJ, WCO, WCI, TP>)
+                : (wg_use_v3(NT) ? wgrad3_group_kernel<NT, MI, NJ, WCO, WCI, TP> : wgrad2_group_kernel<NT, MI, NJ, WCO, WCI, TP>);
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute((const void*)wgrad2_group_kernel<NT, MI, NJ, WCO, WCI, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)wgrad3_group_kernel<NT, MI, NJ, WCO, WCI, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)wgrad2_group_fix_kernel<NT, MI, NJ, WCO, WCI, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)wgrad3_group_fix_kernel<NT, MI, NJ, WCO, WCI, TP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   if ((size_t)wg_min_lds() > lds && wg_min_lds() <= 160 * 1024) lds = (size_t)wg_min_lds();
@@ -1100,7 +1308,7 @@ extern "C" int mi_conv2d_wgrad_group_run(const mi_wgrad_group* meta, const void*
 #define MI_WG(NTv, MIv, NJv, WCOv, WCIv, TPv)                                                                   \
   if (g.cfg[0] == NTv && g.cfg[1] == MIv && g.cfg[2] == NJv && g.cfg[3] == WCOv && g.cfg[4] == WCIv &&          \
       g.cfg[5] == TPv)                                                                                          \
-    rc = wg_group_launch<NTv, MIv, NJv, WCOv, WCIv, TPv>(jobs, starts, g.njobs, g.nblocks, (size_t)g.lds_bytes, s);
+    rc = wg_group_launch<NTv, MIv, NJv, WCOv, WCIv, TPv>(jobs, starts, g.njobs, g.nblocks, (size_t)g.lds_bytes, s, g.fixup == 1);
     MI_WG_ALL
 #undef MI_WG
     if (rc == MI_EINVAL) MI_FAIL(MI_EINVAL, "wgrad_group: no kernel for group %d", gi);
