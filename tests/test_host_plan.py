@@ -481,3 +481,61 @@ def test_wgrad_fixup_plan_is_opt_in(monkeypatch):
         assert list(a.g[i].cfg) == list(b.g[i].cfg) and a.g[i].nblocks == b.g[i].nblocks and a.g[i].njobs == b.g[i].njobs
         assert b.g[i].lds_bytes >= a.g[i].lds_bytes
     assert b.table_bytes > a.table_bytes and (b.g[0].job_off % 256) == 0 and b.g[0].job_off >= 256
+
+
+def test_wgrad_fixup_table_layout(monkeypatch):
+    """the job table of a MI_WG_FIXUP=1 plan, read back through a mirror of csrc/conv_wgrad.hip's job record: the tile
+    counters come first and are zero, every job points at its own 256 bytes per (cout, cin) output tile - inside the counter
+    region, overlapping no other job's - and carries the split-K reduction's operands (gradient pointer, channel counts)"""
+    import ctypes as C
+    from yolov7_d2_amd.plan import PlanBuilder
+
+    class Wg2K(C.Structure):          # (struct Wg2K; a changed record shows up in the size check below)
+        _fields_ = ([("x", C.c_void_p), ("dy", C.c_void_p), ("part", C.c_void_p)] +
+                    [(n, C.c_int32) for n in ("ldx", "lddy", "N", "H", "W", "outH", "outW", "is_", "TH", "TW", "tilesY", "tilesX",
+                                              "ntiles", "tps", "nsplit", "dymin", "dxmin", "haloW", "npixh", "nqx", "stage", "ns")] +
+                    [("toff", C.c_int32 * L.MI_MAX_TAPS), ("nco", C.c_int32), ("nci", C.c_int32), ("nrx", C.c_int32),
+                     ("xmap", C.c_int32), ("mTW", C.c_uint32), ("mHW", C.c_uint32), ("V", C.c_longlong), ("bpart", C.c_void_p),
+                     ("bld", C.c_int32), ("fix", C.c_int32), ("g", C.c_void_p), ("row_scale", C.c_void_p), ("Cout", C.c_int32),
+                     ("Cin", C.c_int32), ("accumulate", C.c_int32), ("pad_", C.c_int32), ("cnt_rel", C.c_longlong)])
+
+    model, _ = _model()
+    monkeypatch.setenv("MI_WG_FIXUP", "1")
+    ps = _PlanState(model, 2, 320, 320, True, materialize=False)
+    wg = [c for c in ps.builder.bwd if c.op == L.OP["WGRAD"]]
+    descs = (L.mi_wgrad_desc * len(wg))()
+    for i, (d, c) in enumerate(zip(descs, wg)):
+        C.memmove(C.byref(d), C.byref(PlanBuilder._wgrad_desc(c.desc)), C.sizeof(L.mi_wgrad_desc))
+        d.gw = 4096 * (i + 1)                      # (a recognisable gradient address per layer)
+    lib, meta = L.lib(), L.mi_wgrad_group()
+    L.check(lib.mi_conv2d_wgrad_group_plan(descs, len(wg), None, None, 0, C.byref(meta)), "plan (sizes)")
+    host = (C.c_char * int(meta.table_bytes))()
+    L.check(lib.mi_conv2d_wgrad_group_plan(descs, len(wg), 1 << 30, host, meta.table_bytes, C.byref(meta)), "plan")
+    raw = bytes(host)
+    first_job = min(meta.g[i].job_off for i in range(meta.ngroups))
+    jobs, ranges = [], []
+    for gi in range(meta.ngroups):
+        g = meta.g[gi]
+        assert g.fixup == 1
+        # the record size the library used: the starts array follows the job array (16-byte granules)
+        assert (C.sizeof(Wg2K) * g.njobs + 15) // 16 * 16 == g.starts_off - g.job_off, "struct Wg2K changed: update this mirror"
+        NT, MI, NJ, WCO, WCI, TP = list(g.cfg)
+        assert g.lds_bytes >= 16 + 3 * 3 * (WCO * WCI * 16) * 16
+        for j in range(g.njobs):
+            k = Wg2K.from_buffer_copy(raw[g.job_off + j * C.sizeof(Wg2K): g.job_off + (j + 1) * C.sizeof(Wg2K)])
+            assert k.fix == 1 and k.nsplit >= 1 and k.nco * k.nci >= 1
+            lo = g.job_off + k.cnt_rel
+            ranges.append((lo, lo + k.nco * k.nci * 256))
+            jobs.append(k)
+    assert len(jobs) == len(wg)
+    ranges.sort()
+    assert ranges[0][0] == 0 and ranges[-1][1] <= first_job                       # inside the counter region, ahead of every record
+    assert all(a[1] <= b[0] for a, b in zip(ranges[:-1], ranges[1:]))             # no two jobs share a counter line
+    assert raw[:ranges[-1][1]] == bytes(ranges[-1][1])                            # uploaded as zeros
+    # the reduction's operands travel with the job: every layer's gradient address and channel counts exactly once
+    assert sorted(k.g for k in jobs) == [4096 * (i + 1) for i in range(len(wg))]
+    by_g = {k.g: k for k in jobs}
+    for i, d in enumerate(descs):
+        k = by_g[4096 * (i + 1)]
+        assert (k.Cout, k.Cin, k.accumulate) == (d.Cout, d.Cin, d.accumulate)
+        assert k.nsplit * k.V * 16 < 2 ** 31                                      # the fix-up's 32-bit slab offsets
