@@ -422,8 +422,11 @@ def cpu_baseline(batch=16, size=640, steps=5):
 
 def h2d_inclusive(model, args, world, rank, dev):
     """the same step fed from PINNED HOST memory: a fresh uint8 batch per step (16x3x640x640 B = 19.7 MB) + labels,
-    copied on a dedicated stream into a double buffer while the previous step computes (NativeTrainer.feed); the plan
-    reads the uint8 image directly (Focus packer).  SURVEY.md 8(d) defines the step as including this copy."""
+    copied on a dedicated stream into a double buffer while the previous step computes (NativeTrainer.feed); the forward
+    graph of each staging buffer reads the staged uint8 image directly (Focus packer).  SURVEY.md 8(d) defines the step
+    as including this copy (meta_arch/yolox.py:96,183).  Same contract as the resident loop: `warmup` untimed FED steps
+    (the first ones create the copy stream, the staging buffers and the staged forward graphs - round 5 timed those
+    one-off costs inside a 20-step region: profiles/r06_h2d_where_the_gap_was.txt), then exactly `steps` timed ones."""
     from yolov7_d2_amd.engine import NativeTrainer
     tr = NativeTrainer(model, lr=0.01 / 64 * args.batch * world, use_graph=not args.no_graph, input_u8=True)
     host = []
@@ -431,19 +434,24 @@ def h2d_inclusive(model, args, world, rank, dev):
         imgs, labels = synth_batch_device(args.batch, args.size, args.size, 4321 + 7 * k + rank, "cpu")
         host.append((imgs.to(torch.uint8).pin_memory(), labels.pin_memory()))
     st = tr.load_batch(host[0][0].to(dev), host[0][1].to(dev))
-    for _ in range(3):
+    for _ in range(2):                       # eager pass, capture
         tr.step(st)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
     tr.feed(st, *host[0])
-    for i in range(args.steps):
+    for i in range(max(args.warmup, 3)):     # fed warm-up: both staged forward graphs captured and replayed
         tr.step(st)
         tr.feed(st, *host[(i + 1) % 2])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):              # `steps` steps, `steps` host -> device copies (the one in flight at the
+        tr.step(st)                          # start was enqueued above and lands under step 0's wait; the last feed's
+        tr.feed(st, *host[(i + 1) % 2])      # copy completes inside the region)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)

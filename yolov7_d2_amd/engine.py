@@ -45,6 +45,7 @@ class NativeTrainer:
         self.input_u8 = bool(input_u8)
         self.copy_stream = None
         self._feed = None
+        self.feed_direct = os.environ.get("MI_FEED_DIRECT", "1") != "0"
         model.train()
         self.params = model.ensure_params()
         self.world = dist.get_world_size() if dist.is_initialized() else 1
@@ -107,7 +108,7 @@ class NativeTrainer:
         plan = st["plan"]
         farr, fn = plan.fwd_cmds
         barr, bn = plan.bwd_cmds
-        gs = {"fwd": L.check(lib.mi_graph_capture(farr, fn, sp), "capture fwd"), "bwd": []}
+        gs = {"fwd": L.check(lib.mi_graph_capture(farr, fn, sp), "capture fwd"), "bwd": [], "fwd_stage": {}}
         for (lo, hi, bucket) in st["segs"]:
             h = None
             if hi > lo:
@@ -135,16 +136,23 @@ class NativeTrainer:
 
     def feed(self, st, images_host, labels_host):
         """asynchronous host -> device copy of the NEXT batch (pinned host tensors: images in the plan's input dtype,
-        labels [B,max_boxes,5] float) on a dedicated copy stream into one of two staging buffers; the following step()
-        waits for it on the compute stream and moves it into the plan's input buffers (device copy), so the PCIe
-        transfer of batch i+1 runs under the compute of batch i.  Replaces the synchronous .to(device) of
-        yolox.py:96,183."""
+        labels [B,max_boxes,5] float) on a dedicated copy stream into one of two staging buffers, so that the PCIe
+        transfer of batch i+1 runs under the compute of batch i.  The following step() waits for the copy on the compute
+        stream and replays the forward graph OF THAT STAGING BUFFER: its Focus packer reads the staged image in place and
+        its first command copies the 38 KB of labels into the plan's label buffer (which the backward reads too), so the
+        only operation outside the graphs is the event wait (MI_FEED_DIRECT=0: the round-5 form, two device copies on the
+        compute stream in front of the one forward graph).  Replaces the synchronous .to(device) of yolox.py:96,183."""
         if self.copy_stream is None:
             self.copy_stream = torch.cuda.Stream()
         # two staging buffers PER input shape (multi-scale training feeds several (B, H, W) states)
         if "stage" not in st:
-            st["stage"] = [dict(img=torch.empty_like(st["ps"].image), lab=torch.empty_like(st["ps"].labels),
-                                ready=torch.cuda.Event(), free=torch.cuda.Event(), st=st) for _ in range(2)]
+            ps = st["ps"]
+            st["stage"] = []
+            for k in range(2):
+                lab_flat = torch.zeros_like(ps.labels_flat)
+                st["stage"].append(dict(img=torch.empty_like(ps.image), lab_flat=lab_flat,
+                                        lab=lab_flat[:ps.labels.numel()].view(ps.labels.shape), k=k,
+                                        ready=torch.cuda.Event(), free=torch.cuda.Event(), st=st))
             st["stage_k"] = 0
             for b in st["stage"]:
                 b["free"].record(self.stream)
@@ -153,12 +161,40 @@ class NativeTrainer:
         if tuple(images_host.shape) != tuple(b["img"].shape) or tuple(labels_host.shape) != tuple(b["lab"].shape):
             raise ValueError(f"feed(): batch {tuple(images_host.shape)} / {tuple(labels_host.shape)} does not match the "
                              f"state's input buffers {tuple(b['img'].shape)} / {tuple(b['lab'].shape)}")
+        # the step that consumed this buffer must have read it.  Waited for ON THE HOST: the event is one and a half steps
+        # old (two buffers), so the call returns at once or - when the host has run ahead - holds it back while the device
+        # still has more than a whole step queued.  A device-side wait of the copy stream on an event of the compute
+        # stream costs the STEP 0.12 ms (2.3 %) on this runtime, the copy itself nothing: tools/h2d_probe.py,
+        # profiles/r06_h2d_where_the_gap_was.txt (e2 against e1 / e4).
+        b["free"].synchronize()
         with torch.cuda.stream(self.copy_stream):
-            self.copy_stream.wait_event(b["free"])          # the step that consumed this buffer has copied it out
             b["img"].copy_(images_host, non_blocking=True)
             b["lab"].copy_(labels_host, non_blocking=True)
             b["ready"].record(self.copy_stream)
         self._feed = b
+
+    def _staged_fwd(self, st, k):
+        """the forward command list reading staging buffer k: [COPY staged labels -> plan labels] + the plan's forward
+        list with the Focus packer's source replaced.  Returns (array, n); built once per (state, buffer)."""
+        key = ("fwd_stage_cmds", k)
+        if key in st:
+            return st[key]
+        ps, b = st["ps"], st["stage"][k]
+        farr, fn = st["plan"].fwd_cmds
+        arr = (L.mi_cmd * (fn + 1))()
+        c = arr[0]
+        c.op = L.OP["COPY"]                                   # mi_copy_bf16: npix rows of 8 bf16 = 16-byte pieces
+        c.p[0], c.p[1] = b["lab_flat"].data_ptr(), ps.labels_flat.data_ptr()
+        c.i[0], c.i[1], c.i[2], c.i[3] = 8, 8, 0, 8
+        c.l[0] = ps.labels_flat.numel() // 4
+        C.memmove(C.byref(arr, C.sizeof(L.mi_cmd)), farr, fn * C.sizeof(L.mi_cmd))
+        img = ps.image.data_ptr()
+        hits = [j for j in range(1, fn + 1) if arr[j].op == L.OP["FOCUS"] and arr[j].p[0] == img]
+        if len(hits) != 1:
+            raise L.MI355Error(f"staged forward: expected one Focus command reading the plan's image, found {len(hits)}")
+        arr[hits[0]].p[0] = b["img"].data_ptr()
+        st[key] = (arr, fn + 1)
+        return st[key]
 
     def step(self, st):
         """one optimisation step on the batch resident in the plan's input buffers (or on the batch handed to feed()
@@ -167,14 +203,18 @@ class NativeTrainer:
         plan, red = st["plan"], st["red"]
         with torch.cuda.stream(self.stream):
             sp = L.stream_ptr(self.stream)
+            staged = None
             if self._feed is not None:
                 b, self._feed = self._feed, None
                 if b["st"] is not st:
                     raise ValueError("step(): the batch handed to feed() belongs to another input shape's state")
                 self.stream.wait_event(b["ready"])
-                st["ps"].image.copy_(b["img"], non_blocking=True)
-                st["ps"].labels.copy_(b["lab"], non_blocking=True)
-                b["free"].record(self.stream)
+                if self.feed_direct:
+                    staged = b
+                else:
+                    st["ps"].image.copy_(b["img"], non_blocking=True)
+                    st["ps"].labels.copy_(b["lab"], non_blocking=True)
+                    b["free"].record(self.stream)
             if self.use_graph and st["graphs"] is None:
                 # first call runs eagerly (sets kernel attributes, warms allocators), second call captures
                 if st.get("warm"):
@@ -185,7 +225,17 @@ class NativeTrainer:
             gs = st["graphs"] if self.use_graph else None
             farr, fn = plan.fwd_cmds
             barr, bn = plan.bwd_cmds
-            if gs:
+            if staged is not None:
+                sarr, sn = self._staged_fwd(st, staged["k"])
+                if gs:
+                    h = gs["fwd_stage"].get(staged["k"])
+                    if h is None:
+                        h = gs["fwd_stage"][staged["k"]] = L.check(lib.mi_graph_capture(sarr, sn, sp), "capture staged fwd")
+                    L.check(lib.mi_graph_launch(h, sp), "launch staged fwd")
+                else:
+                    self._run_cmds(sarr, 0, sn, sp)
+                staged["free"].record(self.stream)      # only the forward list reads the staging buffer
+            elif gs:
                 L.check(lib.mi_graph_launch(gs["fwd"], sp), "launch fwd")
             else:
                 self._run_cmds(farr, 0, fn, sp)

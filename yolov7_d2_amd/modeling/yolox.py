@@ -36,7 +36,11 @@ class _PlanState:
         # input_u8: the plan reads the uint8 image of the data loader directly (the .type(torch.float) of
         # yolox.py:96-99 is fused into the Focus packer); float32 is the reference-shaped default
         self.image = torch.zeros(B, 3, H, W, dtype=torch.uint8 if input_u8 else torch.float32, device=dev)
-        self.labels = torch.zeros(B, model.max_boxes_num, 5, dtype=torch.float32, device=dev)
+        # labels in a flat allocation padded to whole 16-byte pieces: a host-fed step copies them from its staging buffer
+        # with an in-graph strided-copy command that moves 16 bytes per lane (engine.NativeTrainer.feed)
+        nlab = B * model.max_boxes_num * 5
+        self.labels_flat = torch.zeros((nlab + 3) // 4 * 4, dtype=torch.float32, device=dev)
+        self.labels = self.labels_flat[:nlab].view(B, model.max_boxes_num, 5)
         hw = [(H // s, W // s) for s in model.head.strides]
         self.A = sum(h * w for h, w in hw)
         self.anchors = YOLOXHead.anchors_for(hw, model.head.strides).to(dev)
