@@ -835,9 +835,6 @@ int mi_adamw_step_multi_clip(const mi_adamw_tensor* tensors_dev, const mi_adamw_
  * torch.nn.utils.clip_grad_norm_ over all parameters): grads *= min(1, max_norm / (||grads||_2 + 1e-6)) without a host
  * synchronisation; ws: 1024 doubles of scratch; norm_out (optional, device) receives the norm */
 int mi_grad_clip_full_model(float* grads, int64_t n, float max_norm, double* ws, float* norm_out, mi_stream_t s);
-/* diagnostic (tools/icache_probe.py; not on the product path): a kernel of `kb` KiB (8 / 16 / 32 / 64 / 128) of straight-line
- * scalar no-ops on `blocks` single-wave blocks - displaces that much of every instruction cache without touching data */
-int mi_debug_code_polluter(int kb, int blocks, mi_stream_t s);
 /* PositionEmbeddingSine.forward (modeling/backbone/detr_backbone.py:309-375): mask [B][H][W] bytes (non-zero = padding)
  * -> pos fp32 [B][2*num_pos_feats][H][W] */
 int mi_pos_embed_sine(const uint8_t* mask, int B, int H, int W, int num_pos_feats, float temperature, int normalize,
@@ -937,6 +934,15 @@ enum {
  * which the MI355X runs concurrently (measured: two 64-block chains overlap ~2x). */
 #define MI_MAX_AUX 4
 int mi_cmdlist_run(const mi_cmd* cmds, int n, mi_stream_t s);
+/* A HIP stream whose kernels run only on the compute units of `mask` (hipExtStreamCreateWithCUMask; nwords 32-bit words,
+ * bit i of the mask = logical CU i; on the 8-XCD MI355X the driver deals logical CUs round-robin over the XCDs, so the low
+ * 64 bits are 8 CUs of EVERY XCD - measured with the census probe of include/mi355_debug.h).  The caller owns the stream
+ * (mi_stream_destroy).  Used for the weight-gradient side queue beside the backward chain (engine.NativeTrainer). */
+int mi_stream_create_cu_mask(const uint32_t* mask, int nwords, mi_stream_t* out);
+int mi_stream_destroy(mi_stream_t s);
+/* replace auxiliary stream `sid` (1..MI_MAX_AUX) of the executor's STREAM / FORK / JOIN commands by a caller-owned stream
+ * (NULL: back to the library's own); takes effect for command lists run or captured afterwards */
+int mi_aux_stream_set(int sid, mi_stream_t s);
 /* returns an opaque handle (>0) or <0 */
 int64_t mi_graph_capture(const mi_cmd* cmds, int n, mi_stream_t s);
 int mi_graph_launch(int64_t handle, mi_stream_t s);

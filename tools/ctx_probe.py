@@ -36,7 +36,7 @@ def run(k, cnt=1):
 
 
 def mark():
-    L.check(L.lib().mi_debug_code_polluter(8, 1, sp), "marker")
+    L.check(L.dbg().mi_debug_code_polluter(8, 1, sp), "marker")
 
 
 order = []

@@ -57,7 +57,7 @@ def conv(i):
 
 
 def code(kb):
-    L.check(L.lib().mi_debug_code_polluter(kb, 512, sp()), "polluter")
+    L.check(L.dbg().mi_debug_code_polluter(kb, 512, sp()), "polluter")
 
 
 def flush():
@@ -88,7 +88,7 @@ with torch.cuda.stream(s):
 torch.cuda.synchronize()
 for name, gr in graphs.items():
     for _ in range(4):
-        L.check(L.lib().mi_debug_code_polluter(8, 1, sp()), "marker")     # ONE-block launch = the marker between replays
+        L.check(L.dbg().mi_debug_code_polluter(8, 1, sp()), "marker")     # ONE-block launch = the marker between replays
         gr.replay()
     torch.cuda.synchronize()
 print("ORDER", " ".join(SEQS))

@@ -266,7 +266,6 @@ _PROTOS = {
     "mi_conv2d_route": (C.c_int, [C.POINTER(mi_conv_desc)]),
     "mi_dropout_seed_offset": (C.c_int, [_vp]),
     "mi_adamw_step_multi": (C.c_int, [_vp, _vp, _i, _f, _f, _f, _vp, _f, _vp]),
-    "mi_debug_code_polluter": (C.c_int, [_i, _i, _vp]),
     "mi_adamw_step_multi_clip": (C.c_int, [_vp, _vp, _i, _f, _f, _f, _vp, _f, _vp, _vp]),
     "mi_grad_norm_multi": (C.c_int, [_vp, _vp, _i, _vp, _f, _f, _vp, _vp]),
     "mi_grad_gather_multi": (C.c_int, [_vp, _vp, _i, _vp, _vp, _vp]),
@@ -354,6 +353,9 @@ _PROTOS = {
     "mi_pos_embed_sine": (C.c_int, [_vp, _i, _i, _i, _i, _f, _i, _f, _i, _vp, _vp]),
     "mi_sgd_momentum_step": (C.c_int, [_vp, _vp, _vp, _vp, _i, _f, _f, _i, _vp]),
     "mi_cmdlist_run": (C.c_int, [C.POINTER(mi_cmd), _i, _vp]),
+    "mi_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_uint32), _i, C.POINTER(C.c_void_p)]),
+    "mi_stream_destroy": (C.c_int, [_vp]),
+    "mi_aux_stream_set": (C.c_int, [_i, _vp]),
     "mi_graph_capture": (C.c_int64, [C.POINTER(mi_cmd), _i, _vp]),
     "mi_graph_launch": (C.c_int, [_i64, _vp]),
     "mi_graph_destroy": (C.c_int, [_i64]),
@@ -381,6 +383,25 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+_dbg = None
+
+
+def dbg():
+    """libmi355dbg.so (include/mi355_debug.h): diagnostic kernels for tools/ - not part of the product library"""
+    global _dbg
+    if _dbg is None:
+        path = os.path.join(os.path.dirname(LIB_PATH), "libmi355dbg.so")
+        if not os.path.exists(path):
+            raise MI355Error(f"{path} not found (make -C yolov7_d2_amd/csrc)")
+        D = C.CDLL(path)
+        D.mi_debug_code_polluter.restype = C.c_int
+        D.mi_debug_code_polluter.argtypes = [_i, _i, _vp]
+        D.mi_debug_cu_census.restype = C.c_int
+        D.mi_debug_cu_census.argtypes = [_vp, _i, _i, _vp]
+        _dbg = D
+    return _dbg
 
 
 def check(rc, what=""):

@@ -119,6 +119,8 @@ static int run_one(const mi_cmd& c, hipStream_t s) {
 static hipStream_t g_aux[MI_MAX_AUX];
 static hipEvent_t g_ev_fork[MI_MAX_AUX], g_ev_join[MI_MAX_AUX];
 static bool g_aux_ready = false;
+static hipStream_t g_aux_user[MI_MAX_AUX] = {nullptr, nullptr, nullptr, nullptr};   // caller-owned replacements (mi_aux_stream_set)
+static inline hipStream_t aux_stream(int k) { return g_aux_user[k] ? g_aux_user[k] : g_aux[k]; }
 static int ensure_aux() {
   if (g_aux_ready) return MI_OK;
   int prio_least = 0, prio_greatest = 0;
@@ -149,13 +151,13 @@ extern "C" int mi_cmdlist_run(const mi_cmd* cmds, int n, mi_stream_t st) {
       if (sid < 0 || sid > MI_MAX_AUX) MI_FAIL(MI_EINVAL, "cmd %d: stream id %d", k, sid);
       if (sid > 0 && ensure_aux() != MI_OK) return MI_ELAUNCH;
       if (op == MI_OP_STREAM) {
-        cur = sid ? g_aux[sid - 1] : s;
+        cur = sid ? aux_stream(sid - 1) : s;
       } else if (sid > 0 && op == MI_OP_FORK) {
         if (hipEventRecord(g_ev_fork[sid - 1], s) != hipSuccess ||
-            hipStreamWaitEvent(g_aux[sid - 1], g_ev_fork[sid - 1], 0) != hipSuccess)
+            hipStreamWaitEvent(aux_stream(sid - 1), g_ev_fork[sid - 1], 0) != hipSuccess)
           MI_FAIL(MI_ELAUNCH, "cmd %d: fork", k);
       } else if (sid > 0) {
-        if (hipEventRecord(g_ev_join[sid - 1], g_aux[sid - 1]) != hipSuccess ||
+        if (hipEventRecord(g_ev_join[sid - 1], aux_stream(sid - 1)) != hipSuccess ||
             hipStreamWaitEvent(s, g_ev_join[sid - 1], 0) != hipSuccess)
           MI_FAIL(MI_ELAUNCH, "cmd %d: join", k);
       }
@@ -169,6 +171,32 @@ extern "C" int mi_cmdlist_run(const mi_cmd* cmds, int n, mi_stream_t st) {
       return rc;
     }
   }
+  return MI_OK;
+}
+
+// ---- CU-masked streams (the weight-gradient side queue)
+extern "C" int mi_stream_create_cu_mask(const uint32_t* mask, int nwords, mi_stream_t* out) {
+  if (mi_device_count() <= 0) MI_FAIL(MI_ENODEV, "no HIP device");
+  MI_REQUIRE(mask && out && nwords > 0 && nwords <= 32, "stream_create_cu_mask: args");
+  bool any = false;
+  for (int k = 0; k < nwords; ++k) any = any || mask[k] != 0;
+  MI_REQUIRE(any, "stream_create_cu_mask: empty mask");
+  hipStream_t s = nullptr;
+  const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)nwords, mask);
+  if (e != hipSuccess || !s) MI_FAIL(MI_ELAUNCH, "hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+  *out = (mi_stream_t)s;
+  return MI_OK;
+}
+extern "C" int mi_stream_destroy(mi_stream_t st) {
+  MI_REQUIRE(st, "stream_destroy: null");
+  for (int k = 0; k < MI_MAX_AUX; ++k)
+    if (g_aux_user[k] == (hipStream_t)st) g_aux_user[k] = nullptr;
+  if (hipStreamDestroy((hipStream_t)st) != hipSuccess) MI_FAIL(MI_ELAUNCH, "hipStreamDestroy failed");
+  return MI_OK;
+}
+extern "C" int mi_aux_stream_set(int sid, mi_stream_t st) {
+  MI_REQUIRE(sid >= 1 && sid <= MI_MAX_AUX, "aux_stream_set: stream id %d", sid);
+  g_aux_user[sid - 1] = (hipStream_t)st;
   return MI_OK;
 }
 

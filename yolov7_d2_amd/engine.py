@@ -46,6 +46,19 @@ class NativeTrainer:
         self.copy_stream = None
         self._feed = None
         self.feed_direct = os.environ.get("MI_FEED_DIRECT", "1") != "0"
+        # MI_WGRAD_SIDE=G (experiment, round 6; default off - profiles/r06_wgrad_cumask_ab.txt): the weight gradients as G
+        # grouped launches on a SIDE QUEUE beside the backward chain, each issued when the last out-gradient of its layers
+        # exists (PlanBuilder.wgrad_async cuts the groups), joined before the optimizer.  MI_WGRAD_CUMASK=n[x] confines
+        # the side queue to n compute units (hipExtStreamCreateWithCUMask; plain n: n / 8 CUs of every XCD, "nx": n / 32
+        # whole XCDs); MI_MAIN_CUMASK=1 gives the chain's stream the complement.  A captured hipGraph does not carry a
+        # stream's CU mask into its branches, so under use_graph the chain pieces and the groups are SEPARATE graphs
+        # launched on their own streams with event edges (_side_pieces).
+        self.side_groups = int(os.environ.get("MI_WGRAD_SIDE", "0") or 0) if self.world_is_one() else 0
+        self.side_stream = None
+        self.stream = None
+        if self.side_groups > 0:
+            os.environ["MI_WGRAD_ASYNC"] = str(self.side_groups)      # read by PlanBuilder when the plan is built
+            self._make_side_queue()
         model.train()
         self.params = model.ensure_params()
         self.world = dist.get_world_size() if dist.is_initialized() else 1
@@ -65,11 +78,82 @@ class NativeTrainer:
         self.momentum, self.n_buckets, self.use_graph = momentum, n_buckets, use_graph
         self.loss_weights = loss_weights
         self._states = {}
-        self.stream = torch.cuda.Stream()
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
         # optional on-device selection of the conv tile configurations before the graphs are captured (MI_CONV_TUNE=1).
         # Off by default: on the YOLOX-s step the launcher's cost model is within measurement noise of the tuned result.
         self.tune = (os.environ.get("MI_CONV_TUNE", "0") == "1") if tune is None else bool(tune)
         self.tune_report = None
+
+    @staticmethod
+    def world_is_one():
+        return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+    @staticmethod
+    def cu_mask_words(n, whole_xcds=False, total=256, xcds=8, invert=False):
+        """the 32-bit mask words for hipExtStreamCreateWithCUMask: logical CU i belongs to XCD i % xcds (the driver deals
+        the mask round-robin over the XCDs: tools/cu_mask_probe.py), so the low n bits are n / xcds CUs of every XCD and
+        the bits with i % xcds < n / (total / xcds) are whole XCDs"""
+        bits = [False] * total
+        per = total // xcds
+        for i in range(total):
+            bits[i] = (i % xcds) < max(1, n // per) if whole_xcds else i < n
+        if invert:
+            bits = [not b for b in bits]
+        words = [0] * (total // 32)
+        for i, b in enumerate(bits):
+            if b:
+                words[i // 32] |= 1 << (i % 32)
+        return words
+
+    def _masked_stream(self, words):
+        arr = (C.c_uint32 * len(words))(*words)
+        out = C.c_void_p()
+        L.check(L.lib().mi_stream_create_cu_mask(arr, len(words), C.byref(out)), "stream_create_cu_mask")
+        return torch.cuda.ExternalStream(out.value)
+
+    def _make_side_queue(self):
+        spec = os.environ.get("MI_WGRAD_CUMASK", "")
+        if spec:
+            whole = spec.endswith("x")
+            n = int(spec.rstrip("x"))
+            self.side_stream = self._masked_stream(self.cu_mask_words(n, whole))
+            if os.environ.get("MI_MAIN_CUMASK", "0") == "1":
+                self.stream = self._masked_stream(self.cu_mask_words(n, whole, invert=True))
+        else:
+            self.side_stream = torch.cuda.Stream(priority=0)       # torch: 0 = the low priority
+        # the executor's own FORK / STREAM / JOIN commands (eager replay, plan-time timing) use the same queue
+        L.check(L.lib().mi_aux_stream_set(L.MI_WGRAD_STREAM, self.side_stream.cuda_stream), "aux_stream_set")
+
+    def _side_pieces(self, barr, bn):
+        """the backward list cut at the side-queue markers the plan emitted (FORK, STREAM sid, <group>, STREAM 0 ... JOIN):
+        [("main", lo, hi) | ("side", lo, hi) | ("join", k, k + 1)]"""
+        sid, OP = L.MI_WGRAD_STREAM, L.OP
+        out, k, lo = [], 0, 0
+        while k < bn:
+            c = barr[k]
+            if c.op == OP["FORK"] and c.i[0] == sid:
+                if not (k + 3 < bn and barr[k + 1].op == OP["STREAM"] and barr[k + 1].i[0] == sid
+                        and barr[k + 3].op == OP["STREAM"] and barr[k + 3].i[0] == 0):
+                    raise L.MI355Error("side queue: unexpected command pattern after FORK")
+                if k > lo:
+                    out.append(("main", lo, k))
+                out.append(("side", k + 2, k + 3))
+                k += 4
+                lo = k
+            elif c.op == OP["JOIN"] and c.i[0] == sid:
+                if k > lo:
+                    out.append(("main", lo, k))
+                out.append(("join", k, k + 1))
+                k += 1
+                lo = k
+            else:
+                if c.op in (OP["FORK"], OP["JOIN"]) or (c.op == OP["STREAM"] and c.i[0] != 0):
+                    raise L.MI355Error("side queue: the backward list has other parallel regions (MI_MULTI_STREAM)")
+                k += 1
+        if bn > lo:
+            out.append(("main", lo, bn))
+        return out
 
     def set_lr(self, lr):
         # the lr table is read by the SGD graph on self.stream: update it on that stream (stream order = no race with
@@ -109,9 +193,18 @@ class NativeTrainer:
         farr, fn = plan.fwd_cmds
         barr, bn = plan.bwd_cmds
         gs = {"fwd": L.check(lib.mi_graph_capture(farr, fn, sp), "capture fwd"), "bwd": [], "fwd_stage": {}}
+        if self.side_groups > 0:
+            gs["side"] = []
+            for (kind, lo, hi) in self._side_pieces(barr, bn):
+                h = None
+                if kind != "join":
+                    ptr = C.cast(C.byref(barr, lo * C.sizeof(L.mi_cmd)), C.POINTER(L.mi_cmd))
+                    on = sp if kind == "main" else L.stream_ptr(self.side_stream)
+                    h = L.check(lib.mi_graph_capture(ptr, hi - lo, on), f"capture bwd {kind} piece")
+                gs["side"].append((kind, h, torch.cuda.Event()))
         for (lo, hi, bucket) in st["segs"]:
             h = None
-            if hi > lo:
+            if hi > lo and self.side_groups == 0:
                 ptr = C.cast(C.byref(barr, lo * C.sizeof(L.mi_cmd)), C.POINTER(L.mi_cmd))
                 h = L.check(lib.mi_graph_capture(ptr, hi - lo, sp), "capture bwd segment")
             gs["bwd"].append(h)
@@ -239,7 +332,21 @@ class NativeTrainer:
                 L.check(lib.mi_graph_launch(gs["fwd"], sp), "launch fwd")
             else:
                 self._run_cmds(farr, 0, fn, sp)
+            if gs and self.side_groups > 0:
+                ssp = L.stream_ptr(self.side_stream)
+                for (kind, h, ev) in gs["side"]:
+                    if kind == "main":
+                        L.check(lib.mi_graph_launch(h, sp), "launch bwd chain piece")
+                    elif kind == "side":
+                        ev.record(self.stream)
+                        self.side_stream.wait_event(ev)
+                        L.check(lib.mi_graph_launch(h, ssp), "launch wgrad group (side queue)")
+                    else:
+                        ev.record(self.side_stream)
+                        self.stream.wait_event(ev)
             for i, (lo, hi, bucket) in enumerate(st["segs"]):
+                if gs and self.side_groups > 0:
+                    continue
                 if gs:
                     if gs["bwd"][i] is not None:
                         L.check(lib.mi_graph_launch(gs["bwd"][i], sp), "launch bwd")
