@@ -85,3 +85,62 @@ def test_weight_images_only_takes_parameter_backed_weights():
     assert not ok(a.detach() * 2.0, a.numel())                          # a temporary
     calls = []
     assert reg.get(a.detach() * 2.0, 96, 64, 1, 64, 96, 96, 64, True, True, None, lambda wf, wd: calls.append(1)) is None and not calls
+
+
+class _Toy(torch.nn.Module):
+    """two 'stages' around a cut module; `share` re-uses the cut module's weight after the cut, `idle` adds an unused one"""
+
+    def __init__(self, share=False, idle=False):
+        super().__init__()
+        self.device = torch.device("cpu")
+        self.stage = torch.nn.Linear(4, 4)
+        self.head = torch.nn.Linear(4, 2)
+        self.share = share
+        if idle:
+            self.unused = torch.nn.Parameter(torch.zeros(3))
+
+    def grad_cut_modules(self):
+        return [self.stage]
+
+    def forward_prepared(self, static):
+        h = self.stage(static)
+        if self.share:
+            h = h @ self.stage.weight            # the SAME parameter on both sides of the cut
+        return {"total": self.head(h).square().sum()}
+
+
+def _staged(model):
+    from yolov7_d2_amd.graph_step import GraphedTrainStep
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    gs = GraphedTrainStep(model, opt, batch_packs=False, backward_stages=True)
+    try:
+        fns = gs._stage_fns(torch.ones(3, 4))
+        assert len(fns) == 2
+        out = fns[0]()
+        fns[1]()
+        return gs, out
+    finally:
+        gs.close()
+
+
+def test_staged_backward_assigns_every_parameter_to_one_stage():
+    """the stage a parameter belongs to is found from which gradients appear - a parameter that gains gradient in
+    two stages, or in none, must be refused (its first all-reduce would carry a partial sum / the one-launch AdamW would
+    update a stale slot), not trained on silently"""
+    import pytest
+    from yolov7_d2_amd import _lib as L
+    m = _Toy()
+    gs, out = _staged(m)
+    assert gs.stage_params == [[2, 3], [0, 1]]          # head in stage 0, the cut module in stage 1 (optimizer order)
+    ref = _Toy()
+    ref.load_state_dict(m.state_dict())
+    ref.forward_prepared(torch.ones(3, 4))["total"].backward()
+    for a, b in zip(m.parameters(), ref.parameters()):  # the cut changes nothing about the gradients
+        torch.testing.assert_close(a.grad, b.grad)
+    with pytest.raises(L.MI355Error, match="two backward stages"):
+        _staged(_Toy(share=True))
+    with pytest.raises(L.MI355Error, match="received no gradient"):
+        _staged(_Toy(idle=True))
+    frozen = _Toy(idle=True)
+    frozen.unused.requires_grad_(False)                  # explicitly frozen: fine
+    _staged(frozen)

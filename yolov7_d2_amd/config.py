@@ -120,6 +120,11 @@ def add_yolo_config(cfg):
     assert _C.SOLVER.REFERENCE_WORLD_SIZE == 0
     _C.SOLVER.REFERENCE_WORLD_SIZE = 8
     _C.SOLVER.OPTIMIZER = "sgd"
+    # yolov7/config.py:19: the reference's add_yolo_config itself calls add_sparse_inst_config, so train_inseg.py:42-49
+    # (get_cfg + add_yolo_config + merge_from_file) finds every MODEL.SPARSE_INST default the YAMLs do not spell out
+    # (ENCODER.NUM_CHANNELS, DECODER.*, LOSS.*, MATCHER.*).  Its side effects are the reference's too: MODEL.MASK_ON True and
+    # MODEL.DEVICE "cuda" until a YAML says otherwise (detr_256_6_6_torchvision.yaml sets MASK_ON False), SOLVER.AMSGRAD
+    add_sparse_inst_config(_C)
     _C.DATASETS.CLASS_NAMES = []
     _C.MODEL.NMS_TYPE = "normal"
     _C.MODEL.ONNX_EXPORT = False
@@ -153,12 +158,14 @@ def add_yolo_config(cfg):
     _C.MODEL.BACKBONE.SIMPLE = False
     _C.MODEL.BACKBONE.STRIDE = 1
     _C.MODEL.BACKBONE.CHANNEL = 0
+    _C.SOLVER.OPTIMIZER = "ADAMW"          # yolov7/config.py:243-244 (train_det.py's d2 build_optimizer does not read it)
     _C.SOLVER.BACKBONE_MULTIPLIER = 0.1
     return _C
 
 
 def add_sparse_inst_config(cfg):
     """yolov7/configs/config_sparseinst.py:6-68"""
+    cfg.MODEL.DEVICE = "cuda"
     cfg.MODEL.MASK_ON = True
     cfg.MODEL.SPARSE_INST = CN({
         "CLS_THRESHOLD": 0.005, "MASK_THRESHOLD": 0.45, "MAX_DETECTIONS": 100,
@@ -178,7 +185,7 @@ def add_sparse_inst_config(cfg):
 
 def sparse_inst_r50_giam_cfg(device="cuda", **over):
     """configs/coco/sparseinst/Base-SparseInst.yaml + sparse_inst_r50_giam.yaml without needing the files"""
-    cfg = add_sparse_inst_config(add_yolo_config(get_cfg()))
+    cfg = add_yolo_config(get_cfg())          # (includes add_sparse_inst_config, as the reference's does)
     cfg.MODEL.DEVICE = device
     cfg.MODEL.META_ARCHITECTURE = "SparseInst"
     cfg.MODEL.PIXEL_MEAN = [123.675, 116.280, 103.530]

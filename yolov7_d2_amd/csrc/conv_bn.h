@@ -21,6 +21,7 @@ __device__ __forceinline__ unsigned* bn_bar_cnt(unsigned* bar, int g) { return b
 // barrier by agent-scope atomic loads, which bypass the non-coherent caches.
 // *gave_up (LDS) = 1 when this block's wait timed out: its sums are incomplete and it must poison what it writes.
 __device__ __forceinline__ void bn_grid_barrier(unsigned* bar, const unsigned gen0, const int bid, const int nb, int* gave_up) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (see bn_bar_arrive)
   __syncthreads();
   if (threadIdx.x == 0) {
     *gave_up = 0;
@@ -56,6 +57,9 @@ __device__ __forceinline__ void bn_grid_barrier(unsigned* bar, const unsigned ge
 // others (bn_bwd_fused: it folds the accumulator slots into one total per channel - one block's worth of loads instead of
 // every block's; see bn_act.hip).  *is_last / *gave_up live in LDS.
 __device__ __forceinline__ void bn_bar_arrive(unsigned* bar, const int bid, const int nb, int* gave_up, int* is_last) {
+  // every thread's fp64 atomicAdds must have been acknowledged before thread 0 counts the arrival: stated explicitly - the
+  // memory model does not promise that a workgroup-scope barrier waits for vmcnt(0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     *gave_up = 0;
@@ -75,7 +79,8 @@ __device__ __forceinline__ void bn_bar_arrive(unsigned* bar, const int bid, cons
 }
 __device__ __forceinline__ void bn_bar_finish(unsigned* bar, const unsigned gen0, const int bid, const int nb, int* gave_up,
                                               const int* is_last) {
-  __syncthreads();   // (the last block's stores have been acknowledged: the barrier's s_waitcnt vmcnt(0))
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last block's agent-scope stores of the folded totals: acknowledged
+  __syncthreads();
   if (threadIdx.x == 0) {
     const int G = nb < BN_BAR_G ? nb : BN_BAR_G;
     const int g = bid % G;

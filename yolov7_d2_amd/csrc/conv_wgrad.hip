@@ -211,7 +211,12 @@ __device__ __forceinline__ void wg_fixup(const Wg2K& p, unsigned* const cnt, con
     int ok = 1, spins = 0;
     while (__hip_atomic_load(A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.nsplit) {
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > WG_FIX_SPIN_LIMIT) { ok = 0; break; }   // a block of this tile never became resident
+      if (++spins > WG_FIX_SPIN_LIMIT) {   // a block of this tile never became resident
+        ok = 0;
+        // sticky, never cleared by the device: the host finds it (Plan.check_bn_barriers reads word 33 of every tile record)
+        __hip_atomic_store(A + 33, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
     }
     *flag = ok;
   }
@@ -278,8 +283,9 @@ __device__ __forceinline__ void wg_fixup(const Wg2K& p, unsigned* const cnt, con
     __syncthreads();   // red is rewritten by the next pass
   }
   __syncthreads();
-  if (threadIdx.x == 0 && ok) {
-    // every block of the tile has passed its wait once it counts here: the last one re-arms the counters
+  if (threadIdx.x == 0) {
+    // every block of the tile has passed its wait (or given up: it still counts, so that a tile whose blocks all arrived
+    // late re-arms instead of growing without bound) once it counts here: the last one re-arms the counters
     if (__hip_atomic_fetch_add(A + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nsplit - 1u) {
       __hip_atomic_store(A + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(A, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1063,6 +1069,10 @@ extern "C" int mi_conv2d_wgrad(const mi_wgrad_desc* d, mi_stream_t st) {
   MI_REQUIRE(d->gw && d->ws, "wgrad: null gradient / workspace");
   MI_REQUIRE((uintptr_t)d->ws % 16 == 0 && (size_t)d->ws_bytes >= ws, "wgrad: workspace %lld < %zu bytes",
              (long long)d->ws_bytes, ws);
+  // (checked before anything is enqueued.  Note: with gbias the 3x3 layers take the generic reduce kernel, whose
+  // summation order differs from wgrad2_reduce9_kernel's: weight gradients with and without the fused bias gradient agree
+  // to fp32 rounding, not bit for bit - MI_WGRAD_BIAS_MAXPIX decides per layer)
+  MI_REQUIRE(!(d->gbias && d->accumulate), "wgrad: gbias is written, not accumulated");
   hipStream_t s = (hipStream_t)st;
   rc = MI_EINVAL;
 #define MI_WG(NTv, MIv, NJv, WCOv, WCIv, TPv)                                                          \
@@ -1083,7 +1093,6 @@ extern "C" int mi_conv2d_wgrad(const mi_wgrad_desc* d, mi_stream_t st) {
     const int outs = 256 / wg_redsl();
     unsigned nblk = (unsigned)((k.V + outs - 1) / outs);
     if (d->gbias) {
-      MI_REQUIRE(!d->accumulate, "wgrad: gbias is written, not accumulated");
       r.bpart = k.bpart; r.gbias = d->gbias; r.bld = k.bld; r.main_blocks = (int)nblk;
       nblk += (unsigned)((d->Cout + 255) / 256);
     }
@@ -1194,7 +1203,8 @@ extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, voi
     return (long)o;
   };
   // MI_WG_FIXUP=1: the tile counters of every job come first in the table (uploaded as zeros; they re-arm themselves), 64
-  // words per (cout, cin) output tile: [0] arrivals, [32] finished reductions, each on its own 128-byte line
+  // words per (cout, cin) output tile: [0] arrivals, [32] finished reductions, each on its own 128-byte line; [33] sticky
+  // "a wait of this tile timed out" flag (the blocks that gave up wrote NaN; read by the host, never cleared by the device)
   const bool fix = wg_fixup_on() != 0;
   std::vector<long> cnt_off(n, 0);
   if (fix) {

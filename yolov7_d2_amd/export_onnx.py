@@ -319,8 +319,15 @@ class _NetEmitter:
         x = self.conv(bb.stem.conv1, x, scope + ".stem.conv1", relu=True)
         x = g.node("MaxPool", [x], scope + ".stem", ceil_mode=0, dilations=[1, 1], kernel_shape=[3, 3], pads=[1, 1, 1, 1], strides=[2, 2])
         outs = {}
+        if g.opset != 11:       # Softmax(axis), ReduceSum / Split attributes below are the opset-11 forms
+            raise NotImplementedError(f"export_onnx: the SparseInst / Detr emitters write opset-11 nodes (graph opset {g.opset})")
         for name in bb.stage_names:
             for i, blk in enumerate(getattr(bb, name)):
+                if not all(hasattr(blk, a) for a in ("conv1", "conv2", "conv3", "shortcut")):
+                    # d2's BasicBlock (R18 / R34: two 3x3 convs) is not written here; the reference's Detr / SparseInst
+                    # configs all use the bottleneck depths
+                    raise NotImplementedError(f"export_onnx: {type(blk).__name__} in {name}: only bottleneck ResNet blocks "
+                                              "(conv1 / conv2 / conv3 + shortcut) are emitted")
                 sc = f"{scope}.{name}.{i}"
                 y = self.conv(blk.conv1, x, sc + ".conv1", relu=True)
                 y = self.conv(blk.conv2, y, sc + ".conv2", relu=True)

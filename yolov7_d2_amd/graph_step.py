@@ -116,10 +116,31 @@ class GraphedTrainStep:
             cuts.append((out, leaf))
             return leaf
 
+        marks = {}          # parameter index -> (address, version) of its .grad when its stage handed it over
+
         def finish(last):
+            # a parameter belongs to the FIRST stage that leaves it a gradient, and that stage's slice of the flat buffer
+            # goes on the wire at once: a later stage that adds to the same .grad (a weight shared across a cut) would
+            # train on a partial gradient without any error - refuse it instead
+            for k, mk in marks.items():
+                g = plist[k].grad
+                if g is None or (g.data_ptr(), g._version) != mk:
+                    raise L.MI355Error(f"GraphedTrainStep: parameter #{k} ({tuple(plist[k].shape)}) received gradient in two "
+                                       "backward stages (a weight shared across a grad_cut_modules() boundary): its first "
+                                       "stage's all-reduce would carry a partial sum; remove that cut")
             idx = [k for k, p in enumerate(plist) if p.grad is not None and k not in seen]
             seen.update(idx)
             found.append(idx)
+            for k in idx:
+                marks[k] = (plist[k].grad.data_ptr(), plist[k].grad._version)
+            if last:
+                missing = [k for k, p in enumerate(plist) if p.requires_grad and k not in seen]
+                if missing:
+                    # torch's optimizers skip parameters without a gradient; the one-launch AdamW reads every slot of its
+                    # table (weight decay and moment decay would run on a stale or zero slot): refuse rather than differ
+                    raise L.MI355Error(f"GraphedTrainStep: {len(missing)} optimizer parameter(s) received no gradient in any "
+                                       f"backward stage (first: #{missing[0]}, shape {tuple(plist[missing[0]].shape)}); freeze "
+                                       "them (requires_grad_(False)) or leave them out of the optimizer")
             if self.world > 1:
                 self.opt.gather_grads(only=None if (last and len(found) == 1) else idx)
             if last:

@@ -789,6 +789,12 @@ class Plan:
             if fl.value:
                 raise L.MI355Error(f"conv + BatchNorm grid barrier timed out (kernel families {fl.value:#x}): a block was not "
                                    "resident (another kernel holds CUs?); set MI_CONV_BN_FUSE=0")
+        for table, nbytes in getattr(self, "wgrad_fix_tables", []):
+            if nbytes >= 256 and torch.is_tensor(table):
+                words = table.view(torch.uint8)[:nbytes].view(torch.int32).view(-1, 64)
+                if int(words[:, 33].max()) != 0:
+                    raise L.MI355Error("weight-gradient fix-up (MI_WG_FIXUP=1): a tile's wait timed out - the blocks that "
+                                       "gave up wrote NaN into their share of the gradient; a block was not resident")
         bars = [bf for bf in self.b.bufs if bf.name.endswith(".bar")]
         if not bars:
             return
@@ -928,6 +934,12 @@ class Plan:
         L.check(L.lib().mi_conv2d_wgrad_group_plan(descs, len(wg), ws.ptr, host, meta.table_bytes, C.byref(meta)),
                 "wgrad_group_plan")
         table = self._upload_table(host, meta.table_bytes)
+        if meta.ngroups > 0 and meta.g[0].fixup:
+            # MI_WG_FIXUP=1: the table starts with the tile counters (64 words per tile, word 33 = sticky time-out flag)
+            nbytes = min(int(meta.g[k].job_off) for k in range(meta.ngroups)) // 256 * 256
+            if not hasattr(self, "wgrad_fix_tables"):
+                self.wgrad_fix_tables = []
+            self.wgrad_fix_tables.append((table, nbytes))
         self.descs += [meta, descs]
         self.wgrad_descs += list(descs)
         grp = _Cmd(L.OP["WGRAD_GROUP"], p=[_Ptr(C.addressof(meta)), _Ptr(table)], tag=tag)
