@@ -890,6 +890,9 @@ step WITH the host -> device copy of the batch: that is `value_incl_h2d` (fed fr
         # bus bandwidth of each bucket's all-reduce alone, the NCCL-tests convention: algbw * 2 (n - 1) / n
         busbw = [round(sz * 1e6 / (t * 1e-3) * 2 * (world - 1) / world / 1e9, 2) if t > 0 else None for sz, t in zip(sizes, alone)]
         ddp = dict(ranks=world, rccl_ranks=world if backend == "nccl" else 0, busbw_GBps=busbw,
+                   # which gradient-exchange schedule ran (engine.NativeTrainer: MI_DDP_OVERLAP=auto times both backward
+                   # schedules with their collectives at the first capture and keeps the faster)
+                   schedule=trainer.ddp_choice or dict(mode=trainer.ddp_mode, forced_by="MI_DDP_OVERLAP=" + os.environ.get("MI_DDP_OVERLAP", "")),
                    backend="nccl (RCCL over xGMI)" if backend == "nccl" else backend + " (rehearsal)", buckets_MB=sizes, bucket_allreduce_alone_ms=alone,
                    bwd_segments=len(st["segs"]), ms_per_step_without_allreduce=round(float(t_nocomm) / args.steps * 1e3, 3),
                    exposed_comm_ms=round(ms - float(t_nocomm) / args.steps * 1e3, 3))

@@ -45,6 +45,7 @@ res["single_segments"] = len(st["segs"])
 # (2) the data-parallel trainer: graphs on, lr 0 (parameters and hence gradients stay comparable over the three steps)
 dist.init_process_group("gloo", rank=rank, world_size=world)
 del os.environ["MI_BN_FUSED"]
+os.environ["MI_DDP_OVERLAP"] = "1"    # parts (2) / (3): the overlapped schedule, forced (the default "auto" is part (5))
 tr2 = NativeTrainer(fresh(), lr=0.0, use_graph=True)
 assert tr2.world == 2
 st2 = tr2.load_batch(imgs.cuda(), labels.cuda())
@@ -76,6 +77,34 @@ dist.all_gather(ps, p)
 res["params_equal"] = bool(torch.equal(ps[0], ps[1]))
 res["params_moved"] = float((p - p0).norm() / p0.norm())
 res["finite"] = bool(torch.isfinite(p).all())
+p_overlap = p
+
+
+def run_schedule(tag):
+    tr = NativeTrainer(fresh(), lr=0.01, use_graph=True)
+    s_ = tr.load_batch(imgs.cuda(), labels.cuda())
+    for it in range(3):
+        tr.step(s_)
+    tr.stream.synchronize()
+    q = tr.params.data.detach().cpu().clone()
+    qs = [torch.zeros_like(q) for _ in range(world)]
+    dist.all_gather(qs, q)
+    res[tag + "_params_equal"] = bool(torch.equal(qs[0], qs[1]))
+    res[tag + "_finite"] = bool(torch.isfinite(q).all())
+    res[tag + "_vs_overlap_rel"] = float((q - p_overlap).norm() / (p_overlap - p0).norm())     # relative to the update itself
+    res[tag + "_buckets"] = len(s_["red"].buckets)
+    res[tag + "_wgrad_groups"] = sum(1 for k in range(s_["plan"].bwd_cmds[1]) if L.OPS[s_["plan"].bwd_cmds[0][k].op] == "WGRAD_GROUP")
+    res[tag + "_mode"] = tr.ddp_mode
+    res[tag + "_choice"] = tr.ddp_choice
+    return tr
+
+
+# (4) the exposed schedule, forced: the single-GPU backward + ONE all-reduce after it lands on the same parameters
+os.environ["MI_DDP_OVERLAP"] = "0"
+run_schedule("exposed")
+# (5) auto: both schedules timed with their collectives at the first capture, the same one kept on both ranks
+os.environ["MI_DDP_OVERLAP"] = "auto"
+run_schedule("auto")
 dist.barrier()
 dist.destroy_process_group()
 json.dump(res, open(out_path, "w"))

@@ -120,30 +120,47 @@ def _step_worker(rank, world, port, q):
         return model
 
     B, H, W = 2, 64, 96
-    model = fresh(seed=rank)                     # different weights per rank ...
-    broadcast_params(model.params.data)          # ... until rank 0's are broadcast (DDP construction semantics)
     imgs, labels = O.synth_batch(B, H, W, seed=100 + rank, max_gt=4)      # a different batch per rank
-    ps = _PlanState(model, B, H, W, True, materialize=False)
-    b = ps.builder
-    assert b.wgrad_split                         # on by itself under torch.distributed with world_size > 1
-    plan = Plan(b, dry_run=True)
-    red, segs = ddp_schedule(plan, b, model.params, world, 3)
-    assert len(red.buckets) == 3 and len([s for s in segs if s[2] is not None]) == 3
-    ps.image.copy_(imgs); ps.labels.copy_(labels)
-    it = Interp(b, torch.float32)
-    it.run(b.prologue + b.fwd)
-    it.raw(ps.loss["gw"]).view(torch.float32)[:4] = 1.0
-    ran = set()
-    for (lo, hi, bucket) in segs:                # exactly NativeTrainer.step's loop
-        for k in range(lo, hi):
-            for c in _members(plan, b, k):
-                assert id(c) not in ran
-                ran.add(id(c))
-                it.run([c])
-        red.reduce_bucket(bucket)
-    red.wait()
-    assert ran == {id(c) for c in b.bwd if L.OPS[c.op] != "NOP"}   # every backward command ran exactly once
+
+    def scheduled_step(exposed):
+        """the overlapped schedule (staged weight-gradient groups, three buckets cut into the backward list) or the exposed
+        one (engine.NativeTrainer, MI_DDP_OVERLAP=0: the single-GPU backward list, ONE all-reduce after its last writer)"""
+        model = fresh(seed=rank)                     # different weights per rank ...
+        broadcast_params(model.params.data)          # ... until rank 0's are broadcast (DDP construction semantics)
+        if exposed:
+            os.environ["MI_WGRAD_SPLIT"] = "0"       # what NativeTrainer._ddp_build_env sets while the plan is built
+        try:
+            ps = _PlanState(model, B, H, W, True, materialize=False)
+        finally:
+            os.environ.pop("MI_WGRAD_SPLIT", None)
+        b = ps.builder
+        assert b.wgrad_split == (not exposed)        # on by itself under torch.distributed with world_size > 1
+        plan = Plan(b, dry_run=True)
+        red, segs = ddp_schedule(plan, b, model.params, world, 1 if exposed else 3)
+        nb = 1 if exposed else 3
+        assert len(red.buckets) == nb and len([s for s in segs if s[2] is not None]) == nb
+        ps.image.copy_(imgs); ps.labels.copy_(labels)
+        it = Interp(b, torch.float32)
+        it.run(b.prologue + b.fwd)
+        it.raw(ps.loss["gw"]).view(torch.float32)[:4] = 1.0
+        ran = set()
+        for (lo, hi, bucket) in segs:                # exactly NativeTrainer.step's loop
+            for k in range(lo, hi):
+                for c in _members(plan, b, k):
+                    assert id(c) not in ran
+                    ran.add(id(c))
+                    it.run([c])
+            red.reduce_bucket(bucket)
+        red.wait()
+        assert ran == {id(c) for c in b.bwd if L.OPS[c.op] != "NOP"}   # every backward command ran exactly once
+        return model, plan, segs
+
+    model_x, plan_x, segs_x = scheduled_step(exposed=True)
+    assert [plan_x.bwd_tags[s[1] - 1] for s in segs_x if s[2]] == ["wgrad_group"]      # the one bucket leaves after the last writer
+    G_exposed = model_x.params.grad.clone()
+    model, plan, segs = scheduled_step(exposed=False)
     G = model.params.grad.clone()                # sum over ranks of the local gradients
+    schedules_agree = bool(torch.equal(G, G_exposed))      # same commands, same two-rank sums: bit for bit
 
     # reference: every rank's LOCAL gradient from a plain (un-partitioned) run of the same plan, summed
     m2 = fresh(seed=0)                           # = the broadcast weights
@@ -168,7 +185,8 @@ def _step_worker(rank, world, port, q):
     same = all(torch.equal(allp[0], a) for a in allp[1:])
     moved = float((mine - p0).abs().max())
     if rank == 0:
-        q.put(dict(err=err, same=same, moved=moved, nseg=len(segs), tags=[plan.bwd_tags[s[1] - 1] for s in segs if s[2]]))
+        q.put(dict(err=err, same=same, moved=moved, nseg=len(segs), tags=[plan.bwd_tags[s[1] - 1] for s in segs if s[2]],
+                   schedules_agree=schedules_agree))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -188,3 +206,4 @@ def test_real_step_schedule_world2_gloo():
     assert r["err"] < 1e-6, r
     assert r["same"] and r["moved"] > 0, r
     assert r["tags"] == ["wgrad_group.early", "wgrad_group.stage1", "wgrad_group"], r
+    assert r["schedules_agree"], "the exposed and the overlapped schedule reduced different gradients"

@@ -47,6 +47,19 @@ def test_two_ranks_on_one_device(tmp_path):
         assert r["reduced_vs_sum_rel"] < 1e-5 and r["reduced_vs_sum_max"] < 1e-5, r
         assert r["sum_norm"] > r["local_norm"] * 0.5
         assert r["params_equal"] and r["finite"] and r["params_moved"] > 1e-6, r
+        # the exposed schedule (one bucket, one weight-gradient group, the single-GPU backward) and the automatic choice
+        # land on the overlapped schedule's parameters (to the BatchNorm backward's fp64 accumulation order: the exposed
+        # plan may take the one-launch form) - identically on both ranks
+        assert r["exposed_params_equal"] and r["exposed_finite"] and r["exposed_buckets"] == 1 and r["exposed_wgrad_groups"] == 1, r
+        assert r["exposed_mode"] == "exposed" and r["exposed_choice"] is None and r["exposed_vs_overlap_rel"] < 2e-2, r
+        assert r["auto_params_equal"] and r["auto_finite"] and r["auto_mode"] in ("overlap", "exposed"), r
+        ch = r["auto_choice"]
+        assert ch["mode"] == r["auto_mode"] and set(ch["selected_on_device"]) == {"overlap_backward_ms", "exposed_backward_ms"}
+        sel = ch["selected_on_device"]
+        assert (sel["overlap_backward_ms"] <= sel["exposed_backward_ms"]) == (ch["mode"] == "overlap")
+        assert r["auto_buckets"] == (3 if ch["mode"] == "overlap" else 1) and r["auto_vs_overlap_rel"] < 2e-2, r
+    a, b = (json.load(open(o)) for o in outs)
+    assert a["auto_choice"] == b["auto_choice"]                 # both ranks decided on the same two numbers
 
 
 def test_bench_starts_itself_for_n_gpus():
@@ -65,5 +78,8 @@ def test_bench_starts_itself_for_n_gpus():
     assert len(lines) == 1, p.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["global_batch"] == 32 and d["scaling"] == "weak"
-    assert d["value"] > 0 and d["ddp"]["ranks"] == 2 and d["ddp"]["rccl_ranks"] == 0 and len(d["ddp"]["buckets_MB"]) == 3
+    assert d["value"] > 0 and d["ddp"]["ranks"] == 2 and d["ddp"]["rccl_ranks"] == 0
+    sch = d["ddp"]["schedule"]
+    assert sch["mode"] in ("overlap", "exposed") and len(d["ddp"]["buckets_MB"]) == (3 if sch["mode"] == "overlap" else 1)
+    assert sch["selected_on_device"]["overlap_backward_ms"] > 0 and sch["selected_on_device"]["exposed_backward_ms"] > 0
     assert all(x == x for x in d["config"]["final_losses"])

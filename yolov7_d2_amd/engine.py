@@ -62,13 +62,23 @@ class NativeTrainer:
         model.train()
         self.params = model.ensure_params()
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        if self.world > 1:
-            # the one-launch BatchNorm backward needs every block of its grid resident at once, and under data parallelism
-            # RCCL's kernels share the device with the backward pass: how many CUs they take has not been measured on
-            # this pool (1-GPU boxes), so the plan defaults to the two-pass form there (plan.py: MI_BN_FUSED unset and
-            # world > 1 -> "0").  Forced on (MI_BN_FUSED=1 / auto) it leaves an eighth of the device to the collective.
-            full = L.lib().mi_bn_fused_set_capacity(0)
-            L.lib().mi_bn_fused_set_capacity(full - full // 8)
+        # Data parallel: which gradient-exchange schedule (train_det.py:73 -> d2 create_ddp_model).
+        #   "overlap": three staged weight-gradient groups, each bucket's all-reduce launched from its cut in the backward
+        #              list (ddp_schedule); RCCL's kernels then share the device with the rest of backward, so the plan takes
+        #              the two-pass BatchNorm backward (the one-launch form's grid barrier needs every block resident) - the
+        #              step itself is ~4 % longer than the single-GPU step, and a resident foreign kernel costs another 3 - 4 %
+        #              (profiles/r05_ddp_collective_footprint.txt);
+        #   "exposed": the single-GPU backward unchanged (fused BatchNorm backward selected on the device, one weight-gradient
+        #              group) and ONE all-reduce of the whole 35.9 MB arena after it: 0.06 - 0.41 ms on the xGMI mesh.
+        # Which is faster is a property of the node, not of this code: MI_DDP_OVERLAP=auto (default) times both backward
+        # schedules WITH their collectives on the device at the first capture, takes the maximum over ranks of each, and
+        # keeps the faster (every rank decides on the same two numbers, so all agree on the collective sequence);
+        # MI_DDP_OVERLAP=1 / 0 force one.  bench.py prints the choice and both times in its `ddp` block.
+        ov = os.environ.get("MI_DDP_OVERLAP", "auto")
+        self.ddp_mode = None if self.world == 1 else {"1": "overlap", "0": "exposed"}.get(ov)     # None: single GPU / undecided
+        self.ddp_auto = self.world > 1 and self.ddp_mode is None
+        self.ddp_choice = None
+        self._bn_capacity_full = L.lib().mi_bn_fused_set_capacity(0) if self.world > 1 else 0
         broadcast_params(self.params.data)
         norm_ids = set()
         for m in model.modules():
@@ -161,12 +171,35 @@ class NativeTrainer:
         with torch.cuda.stream(self.stream):
             self.params.set_lr(lr)
 
-    def _state(self, B, H, W):
-        key = (B, H, W)
+    def _ddp_build_env(self, mode):
+        """the build-time switches of a data-parallel schedule (PlanBuilder / Plan read them while the plan is built) and
+        the resident-block budget of the one-launch BatchNorm backward: an eighth of the device is left to the collective
+        while it runs beside backward"""
+        full = self._bn_capacity_full
+        if mode == "exposed":
+            L.lib().mi_bn_fused_set_capacity(0)
+            return {"MI_WGRAD_SPLIT": "0", "MI_BN_FUSED": os.environ.get("MI_BN_FUSED", "auto")}
+        L.lib().mi_bn_fused_set_capacity(full - full // 8)
+        return {}
+
+    def _state(self, B, H, W, mode=None):
+        primary = self.ddp_mode or ("overlap" if self.world > 1 else None)    # (undecided: the overlap candidate comes first)
+        mode = mode or primary
+        key = (B, H, W) if mode == primary else (B, H, W, mode)
         st = self._states.get(key)
         if st is not None:
             return st
-        ps = self.model.plan_for(B, H, W, True, input_u8=self.input_u8)
+        env = self._ddp_build_env(mode) if self.world > 1 else {}
+        prev = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            ps = self.model.plan_for(B, H, W, True, input_u8=self.input_u8, variant="ddp-exposed" if mode == "exposed" else "")
+        finally:
+            for k, v in prev.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         ps.gw().copy_(torch.tensor(self.loss_weights, dtype=torch.float32))
         plan = ps.plan
         # SGD command
@@ -176,10 +209,79 @@ class NativeTrainer:
                                                              self.params.mom.data_ptr(), self.segs.data_ptr())
         sgd[0].i[0], sgd[0].i[1] = self.nseg, 0
         sgd[0].f[0], sgd[0].f[1] = self.momentum, 1.0 / self.world
-        red, segs = ddp_schedule(plan, ps.builder, self.params, self.world, self.n_buckets)
-        st = dict(ps=ps, plan=plan, sgd=sgd, red=red, segs=segs, graphs=None)
+        red, segs = ddp_schedule(plan, ps.builder, self.params, self.world, 1 if mode == "exposed" else self.n_buckets)
+        st = dict(ps=ps, plan=plan, sgd=sgd, red=red, segs=segs, graphs=None, ddp_mode=mode)
         self._states[key] = st
         return st
+
+    def _run_backward(self, st):
+        """the backward of a step as step() issues it: segments (graphs when captured) with each bucket's all-reduce"""
+        lib, sp = L.lib(), L.stream_ptr(self.stream)
+        barr, bn = st["plan"].bwd_cmds
+        gs = st["graphs"] if self.use_graph else None
+        for i, (lo, hi, bucket) in enumerate(st["segs"]):
+            if gs:
+                if gs["bwd"][i] is not None:
+                    L.check(lib.mi_graph_launch(gs["bwd"][i], sp), "launch bwd")
+            else:
+                self._run_cmds(barr, lo, hi, sp)
+            st["red"].reduce_bucket(bucket)
+        st["red"].wait()
+
+    def _choose_ddp_schedule(self, st, rounds=3, reps=4):
+        """MI_DDP_OVERLAP=auto: `st` is the overlap candidate after its first (eager) step.  Builds the exposed candidate for
+        the same batch, runs its forward + backward once, captures both, then times `reps` backward passes WITH their
+        all-reduces per round, candidates alternating; each candidate's best round, maximum over ranks, decides.  Only
+        buffers every step overwrites are written (activations, gradients) plus the BatchNorm running statistics the extra
+        forward advances - saved and restored."""
+        lib, sp = L.lib(), L.stream_ptr(self.stream)
+        B, H, W = st["ps"].B, st["ps"].H, st["ps"].W
+        saved = [(t, t.clone()) for t in getattr(st["ps"].builder, "tune_restore", [])]
+        with torch.cuda.stream(self.stream):
+            st2 = self._state(B, H, W, mode="exposed")
+            st2["ps"].image.copy_(st["ps"].image)
+            st2["ps"].labels.copy_(st["ps"].labels)
+            farr, fn = st2["plan"].fwd_cmds
+            barr, bn = st2["plan"].bwd_cmds
+            self._run_cmds(farr, 0, fn, sp)
+            self._run_cmds(barr, 0, bn, sp)            # (eager once: kernel attributes, lazy initialisation)
+            cands = {"overlap": st, "exposed": st2}
+            best = {}
+            for mode, s_ in cands.items():
+                self._ddp_build_env(mode)              # the BatchNorm barrier budget the captured launches are sized with
+                if self.use_graph and s_["graphs"] is None:
+                    self._capture(s_)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for r in range(rounds):
+                for mode, s_ in cands.items():
+                    self._ddp_build_env(mode)
+                    self.stream.synchronize()
+                    dist.barrier()
+                    ev0.record(self.stream)
+                    for _ in range(reps):
+                        self._run_backward(s_)
+                    ev1.record(self.stream)
+                    ev1.synchronize()
+                    ms = ev0.elapsed_time(ev1) / reps
+                    best[mode] = ms if mode not in best else min(best[mode], ms)
+            t = torch.tensor([best["overlap"], best["exposed"]], device=self.params.data.device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_ov, t_ex = float(t[0]), float(t[1])
+            for tns, v in saved:
+                tns.copy_(v)
+        mode = "overlap" if t_ov <= t_ex else "exposed"
+        self.ddp_choice = dict(mode=mode, selected_on_device=dict(overlap_backward_ms=round(t_ov, 4), exposed_backward_ms=round(t_ex, 4)),
+                               rule="max over ranks of the best of %d rounds x %d backward passes incl. all-reduce" % (rounds, reps))
+        self.ddp_mode, self.ddp_auto = mode, False
+        self._ddp_build_env(mode)
+        # states are looked up by shape under the chosen mode from here on
+        for k in [k for k in self._states if len(k) == 4]:
+            self._states.pop(k)
+        if mode == "exposed":
+            st2["warm"] = True
+            st.clear()
+            st.update(st2)                             # the caller's handle now IS the chosen state
+        self._states[(B, H, W)] = st
 
     def _run_cmds(self, arr, lo, hi, sp):
         if hi > lo:
@@ -308,6 +410,9 @@ class NativeTrainer:
                     st["ps"].image.copy_(b["img"], non_blocking=True)
                     st["ps"].labels.copy_(b["lab"], non_blocking=True)
                     b["free"].record(self.stream)
+            if self.ddp_auto and st.get("warm"):
+                self._choose_ddp_schedule(st)          # (second call of the first shape: both schedules timed, one kept)
+                plan, red = st["plan"], st["red"]
             if self.use_graph and st["graphs"] is None:
                 # first call runs eagerly (sets kernel attributes, warms allocators), second call captures
                 if st.get("warm"):

@@ -183,10 +183,12 @@ class YOLOX(nn.Module):
             self.params = ParamArena(self, self.device)
         return self.params
 
-    def plan_for(self, B, H, W, training, input_u8=False):
+    def plan_for(self, B, H, W, training, input_u8=False, variant=""):
+        """variant: a second plan of the same shape built under other build-time switches (engine.NativeTrainer builds the
+        data-parallel step once with the all-reduce overlapped and once exposed, and keeps the faster)"""
         self.ensure_params()
         l1 = bool(training and self.use_l1)
-        key = (B, H, W, bool(training)) + (("u8",) if input_u8 else ()) + (("l1",) if l1 else ())
+        key = (B, H, W, bool(training)) + (("u8",) if input_u8 else ()) + (("l1",) if l1 else ()) + ((variant,) if variant else ())
         ps = self._plans.get(key)
         if ps is None:
             assert H % 32 == 0 and W % 32 == 0, (H, W)
