@@ -232,6 +232,12 @@ typedef struct mi_wgrad_group {
 int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, void* ws_base, void* table_host,
                                int64_t table_cap, mi_wgrad_group* meta);
 int mi_conv2d_wgrad_group_run(const mi_wgrad_group* meta, const void* table_dev, mi_stream_t s);
+/* (round 6) jobs of a group may carry gbias: the bias gradient (column sums of dy) then leaves with the group's launches -
+ * partial rows behind the job's split slabs, summed in a fixed order by extra blocks of the reduce grid.  Used by the
+ * per-layer grouped weight gradients of the transformer / ResNet blocks (yolov7_d2_amd/ops.py WgradBatch). */
+/* asynchronous host -> device copy of a job table on stream s (hipMemcpyAsync; `src_pinned` must be page-locked and must
+ * stay unchanged while a captured graph that recorded this copy can replay) */
+int mi_upload_async(void* dst_dev, const void* src_pinned, int64_t nbytes, mi_stream_t s);
 
 /* OIHW fp32 master -> packed bf16 images.  wf: forward [KH*KW][CinPad/8][CoutPad][8];
  * wd: dgrad  [KH*KW][CoutPadK/8][CinPadN][8] (roles swapped).  Either may be NULL. */

@@ -608,3 +608,62 @@ def test_colsum_wide_one_launch_equals_two_stage(T, C, extra, acc, monkeypatch):
         ws = torch.empty(L.lib().mi_colsum_wide_ws_bytes(C) // 4, device=DEV)
         L.check(L.lib().mi_colsum_bf16_wide(x.data_ptr(), C + extra, T, C, out.data_ptr(), acc, ws.data_ptr(), L.stream_ptr()), "colsum")
         assert torch.equal(out, outs[0])
+
+
+# ------------------------------------------------------------------------------------------ grouped weight gradients
+def _transformer_grads(monkeypatch, grouped, passes=1, keep_grad=False):
+    import sys
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle")
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    from gen_golden_inputs import synth_transformer_case, seeded_state_dict
+    from yolov7_d2_amd.modeling import Transformer
+    from yolov7_d2_amd.ops import WgradBatch
+    monkeypatch.setenv("MI_WGRAD_LAYER_GROUP", "1" if grouped else "0")
+    net = Transformer(256, 8, 2, 2, 512, 0.0, normalize_before=False, return_intermediate_dec=True)
+    net.load_state_dict(seeded_state_dict(net))
+    net.to(DEV).train()
+    src, mask, qe, pos = synth_transformer_case()
+    x = src.to(DEV, torch.bfloat16).requires_grad_(True)
+    q = qe.to(DEV, torch.bfloat16).requires_grad_(True)
+    gh = torch.randn(2, 2, 40, 256, generator=torch.Generator().manual_seed(73)).to(DEV)
+    before = dict(WgradBatch.stats)
+    for _ in range(passes):
+        hs, mem = net(x, mask.to(DEV), q, pos.to(DEV, torch.bfloat16))
+        (hs.float() * gh).sum().backward()
+        if not keep_grad:
+            break
+    torch.cuda.synchronize()
+    assert not WgradBatch.pending
+    done = {k: WgradBatch.stats[k] - before[k] for k in before}
+    return {k: p.grad.float().cpu() for k, p in net.named_parameters()}, x.grad.float().cpu(), done
+
+
+def test_layer_grouped_weight_gradients_equal_single_launches(monkeypatch):
+    """ops.WgradBatch (round 6): the Linears of a transformer layer register their weight-gradient jobs and ONE grouped
+    launch per layer (bias gradients included) writes them when the backward reaches the layer's input - every parameter
+    gradient equals the one-launch-per-Linear form to the split-K summation order (the group chooses its own split counts),
+    the data gradients bit for bit (they do not depend on it)"""
+    ref, dx_ref, n0 = _transformer_grads(monkeypatch, False)
+    got, dx_got, n1 = _transformer_grads(monkeypatch, True)
+    assert n0 == dict(flushes=0, jobs=0)
+    # 2 encoder layers x (q|k, v, out, linear1, linear2) + 2 decoder layers x (q|k, v, out, q, k, v, out, linear1, linear2)
+    # flush points: the inputs of encoder layers 0, 1 and decoder layer 1 (decoder layer 0 starts from tgt = 0, which carries no
+    # gradient: its jobs leave with the next group) + the end of the pass if anything is left
+    assert n1["jobs"] == 2 * 5 + 2 * 9 and 3 <= n1["flushes"] <= 5, n1
+    assert torch.equal(dx_ref, dx_got)
+    for k in ref:
+        scale = float(ref[k].abs().max()) + 1e-30
+        assert float((ref[k] - got[k]).abs().max()) <= 2e-5 * scale + 1e-9, (k, float((ref[k] - got[k]).abs().max()), scale)
+
+
+def test_deferred_weight_gradients_step_aside_when_grad_accumulates(monkeypatch):
+    """a parameter whose .grad already exists (gradient accumulation over micro-batches, zero_grad(set_to_none=False)) gets
+    its gradient from its own launch at its own node - autograd adds the returned tensor to .grad at once, a deferred write
+    would come too late: two accumulated passes = twice one pass"""
+    one, _, _ = _transformer_grads(monkeypatch, True)
+    two, _, n = _transformer_grads(monkeypatch, True, passes=2, keep_grad=True)
+    assert n["jobs"] == 2 * 5 + 2 * 9          # the first pass deferred, the second (grads present) did not
+    for k in one:
+        scale = float(one[k].abs().max()) + 1e-30
+        assert float((two[k] - 2 * one[k]).abs().max()) <= 1e-4 * scale + 1e-9, k

@@ -127,10 +127,13 @@ def test_post_norm_residual_as_one_node_equals_add_dropped_then_layernorm(p):
             assert torch.equal(a, c), (T, p, float((a.float() - c.float()).abs().max()))
 
 
-def test_in_projection_as_one_node_equals_three_sliced_linears():
+def test_in_projection_as_one_node_equals_three_sliced_linears(monkeypatch):
     """_InProjFn (q, k, v from the WHOLE in_proj_weight / in_proj_bias in one autograd node, the three weight-gradient
     launches writing their row blocks of one [3E, E] tensor) against three _LinearFn calls on parameter slices (autograd's
-    SliceBackward + accumulation): identical outputs, input gradients and parameter gradients"""
+    SliceBackward + accumulation): identical outputs, input gradients and parameter gradients.  (One launch per weight
+    gradient on both sides: the per-layer grouped form, ops.WgradBatch, picks other split-K counts - its own test is
+    test_gpu_detr.py::test_layer_grouped_weight_gradients_equal_single_launches.)"""
+    monkeypatch.setenv("MI_WGRAD_LAYER_GROUP", "0")
     from yolov7_d2_amd.modeling.transformer import _InProjFn, _LinearFn
     g = torch.Generator().manual_seed(6)
     E, Tq, Tk = 256, 400, 1040

@@ -495,9 +495,23 @@ def test_focus_pack_float_and_uint8_bit_exact(N, H, W):
     f32 = u8.float()
     ref = torch.cat([f32[..., ::2, ::2], f32[..., 1::2, ::2], f32[..., ::2, 1::2], f32[..., 1::2, 1::2]], 1)   # [N,12,H/2,W/2]
     ref = ref.permute(0, 2, 3, 1)
-    for src, fn in ((f32.to(DEV), lib.mi_focus_pack), (u8.to(DEV), lib.mi_focus_pack_u8)):
-        out = torch.full((N, H // 2, W // 2, 16), 5.0, dtype=torch.bfloat16, device=DEV)
-        L.check(fn(src.data_ptr(), N, H, W, out.data_ptr(), 16, sp()), "focus")
-        torch.cuda.synchronize()
-        o = out.float().cpu()
-        assert torch.equal(o[..., :12], ref) and torch.all(o[..., 12:] == 0)
+    import os
+    prev = os.environ.get("MI_FOCUS_ROWS")
+    try:
+        # uint8: the lane-pair-store kernel (round 6, the default), the row-staged kernel, the per-pixel kernel - forced
+        for src, fn, mode in ((f32.to(DEV), lib.mi_focus_pack, None), (u8.to(DEV), lib.mi_focus_pack_u8, "2"),
+                              (u8.to(DEV), lib.mi_focus_pack_u8, "1"), (u8.to(DEV), lib.mi_focus_pack_u8, "0")):
+            if mode is not None:
+                os.environ["MI_FOCUS_ROWS"] = mode
+            for ld in (16, 24):            # a contiguous output and a channel slice of a wider buffer
+                out = torch.full((N, H // 2, W // 2, ld), 5.0, dtype=torch.bfloat16, device=DEV)
+                L.check(fn(src.data_ptr(), N, H, W, out.data_ptr(), ld, sp()), "focus")
+                torch.cuda.synchronize()
+                o = out.float().cpu()
+                assert torch.equal(o[..., :12], ref) and torch.all(o[..., 12:16] == 0), (mode, ld)
+                assert torch.all(o[..., 16:] == 5.0)
+    finally:
+        if prev is None:
+            os.environ.pop("MI_FOCUS_ROWS", None)
+        else:
+            os.environ["MI_FOCUS_ROWS"] = prev

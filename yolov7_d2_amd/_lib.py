@@ -355,6 +355,7 @@ _PROTOS = {
     "mi_cmdlist_run": (C.c_int, [C.POINTER(mi_cmd), _i, _vp]),
     "mi_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_uint32), _i, C.POINTER(C.c_void_p)]),
     "mi_stream_destroy": (C.c_int, [_vp]),
+    "mi_upload_async": (C.c_int, [_vp, _vp, _i64, _vp]),
     "mi_aux_stream_set": (C.c_int, [_i, _vp]),
     "mi_graph_capture": (C.c_int64, [C.POINTER(mi_cmd), _i, _vp]),
     "mi_graph_launch": (C.c_int, [_i64, _vp]),

@@ -848,6 +848,10 @@ __global__ __launch_bounds__(256) void wgrad2_reduce_group_kernel(const Wg2R* __
     if (starts[mid] <= b) lo = mid; else hi = mid - 1;
   }
   const Wg2R p = jobs[lo];
+  if (p.bpart != nullptr && b - starts[lo] >= p.main_blocks) {   // (block-uniform)
+    wgrad2_reduce_bias(p, b - starts[lo]);
+    return;
+  }
   wgrad2_reduce_body<SL>(p, b - starts[lo]);
 }
 
@@ -1030,9 +1034,9 @@ static int wg_fill(const mi_wgrad_desc* d, Wg2K* k, Wg2Cfg* c, size_t* lds, size
   k->bpart = nullptr; k->bld = 0; k->pad_ = 0;
   k->fix = 0; k->g = d->gw; k->row_scale = d->row_scale; k->Cout = d->Cout; k->Cin = d->Cin; k->accumulate = d->accumulate;
   k->cnt_rel = 0;
-  if (d->gbias && !grouped) {     // the bias partials behind the slabs (single launches only)
+  if (d->gbias) {     // the bias partials behind the slabs (grouped: the group plan points bpart behind the job's slabs)
     k->bld = d->CoutPad;
-    k->bpart = d->ws ? (float*)((char*)d->ws + *ws) : (float*)(uintptr_t)16;   // (planning call without a workspace: non-null marker)
+    k->bpart = (d->ws && !grouped) ? (float*)((char*)d->ws + *ws) : (float*)(uintptr_t)16;   // (planning call without a workspace: non-null marker)
     *ws += (size_t)k->nsplit * (size_t)k->bld * 4;
   }
   return MI_OK;
@@ -1126,7 +1130,8 @@ extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, voi
   // pass 1: tile configuration + tile counts per layer
   for (int i = 0; i < n; ++i) {
     mi_wgrad_desc t = descs[i];
-    MI_REQUIRE(!t.gbias, "wgrad_group_plan: job %d carries a bias gradient (gbias): single launches only", i);
+    MI_REQUIRE(!(t.gbias && wg_fixup_on()), "wgrad_group_plan: job %d carries a bias gradient (gbias): not with MI_WG_FIXUP", i);
+    MI_REQUIRE(!(t.gbias && t.accumulate), "wgrad_group_plan: job %d: gbias is written, not accumulated", i);
     if (!t.x) t.x = (const void*)256;
     if (!t.dy) t.dy = (const void*)256;
     int rc = wg_fill(&t, &ks[i], &cs[i], &ldss[i], &wss[i], true);
@@ -1189,6 +1194,8 @@ extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, voi
     int rc = wg_fill(&t, &ks[i], &cs[i], &ldss[i], &wss[i], true);
     if (rc) return rc;
     ks[i].part = (float*)((char*)ws_base + ws_off);
+    if (descs[i].gbias)      // the bias partials [nsplit][bld] sit behind the job's split slabs (wss[i] counts them)
+      ks[i].bpart = (float*)((char*)ws_base + ws_off + (size_t)ks[i].nsplit * (size_t)ks[i].V * 16);
     ws_off += (wss[i] + 255) / 256 * 256;
   }
   meta->ws_bytes = (int64_t)ws_off;
@@ -1263,7 +1270,16 @@ extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, voi
     r.NT = cs[i].NT; r.MI = cs[i].MI; r.NJ = cs[i].NJ; r.WCO = cs[i].WCO; r.WCI = cs[i].WCI;
     r.nco = ks[i].nco; r.nci = ks[i].nci; r.Cout = descs[i].Cout; r.Cin = descs[i].Cin;
     r.accumulate = descs[i].accumulate; r.row_scale = descs[i].row_scale;
-    r.bpart = nullptr; r.gbias = nullptr; r.bld = 0; r.main_blocks = 0;     // (grouped launches carry no bias gradient)
+    r.bpart = nullptr; r.gbias = nullptr; r.bld = 0; r.main_blocks = 0;
+    if (descs[i].gbias) {      // bias gradient: extra blocks of the job in the generic reduce grid add up the split partials
+      const int outs = 256 / wg_redsl();
+      r.bpart = ks[i].bpart; r.gbias = descs[i].gbias; r.bld = ks[i].bld;
+      r.main_blocks = (int)((ks[i].V + outs - 1) / outs);
+      rj.push_back(r);
+      rs.push_back(rblocks);
+      rblocks += r.main_blocks + (descs[i].Cout + 255) / 256;
+      continue;
+    }
     if (cs[i].NT == 9 && wg_red9()) {
       rj9.push_back(r);
       rs9.push_back(rblocks9);

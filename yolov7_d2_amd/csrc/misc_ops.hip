@@ -125,12 +125,65 @@ __global__ __launch_bounds__(256) void focus_pack_u8_rows_kernel(const uint8_t* 
   }
 }
 
+// The same block geometry with the STORES laid out for whole lines (round 6): a lane PAIR writes one 32-byte output pixel,
+// even lane the first 16 bytes (TL c0..2, BL c0..2, TR c0..1), odd lane the second (TR c2, BR c0..2, four zero pads), so a
+// wave's store instruction covers 1 KB of consecutive addresses (ldo = 16) instead of 16 bytes out of every 32 twice
+// (focus_pack_u8_rows_kernel: 40 us for 52 MB of output in the captured step, 1.3 TB/s).  FOCUS_ROWS2 output rows per block.
+#define FOCUS_ROWS2 4
+__global__ __launch_bounds__(256) void focus_pack_u8_pairs_kernel(const uint8_t* __restrict__ img, int N, int H, int W,
+                                                                  __bf16* out, int ldo) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t srow[];      // [FOCUS_ROWS2][3 channels][2 parities][W]
+  const int Ho = H / 2, Wo = W / 2;
+  const int rb = (Ho + FOCUS_ROWS2 - 1) / FOCUS_ROWS2;
+  const int n = blockIdx.x / rb, oy0 = (blockIdx.x % rb) * FOCUS_ROWS2;
+  const int per = W / 16;
+  for (int i = threadIdx.x; i < FOCUS_ROWS2 * 6 * per; i += 256) {
+    const int piece = i % per, rowi = i / per;        // rowi = (r * 3 + c) * 2 + dy
+    const int dy = rowi & 1, c = (rowi >> 1) % 3, r = rowi / 6;
+    if (oy0 + r < Ho)
+      *(uint4*)(srow + (size_t)rowi * W + piece * 16) =
+          *(const uint4*)(img + (((int64_t)n * 3 + c) * H + 2 * (oy0 + r) + dy) * W + piece * 16);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < FOCUS_ROWS2 * Wo * 2; i += 256) {
+    const int half = i & 1, p = i >> 1;
+    const int r = p / Wo, ox = p - r * Wo;
+    if (oy0 + r >= Ho) break;
+    const uint8_t* base = srow + (size_t)(r * 6) * W + 2 * ox;        // row (c, dy) at base + (c * 2 + dy) * W
+    unsigned short v[3][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) v[c][dy] = *(const unsigned short*)(base + (size_t)(c * 2 + dy) * W);
+    float f[8];
+    if (half == 0) {      // q 0 TL (dx 0, dy 0), q 1 BL (dx 0, dy 1), first two of q 2 TR (dx 1, dy 0)  (wrappers.py:202-220)
+      f[0] = (float)(v[0][0] & 0xff); f[1] = (float)(v[1][0] & 0xff); f[2] = (float)(v[2][0] & 0xff);
+      f[3] = (float)(v[0][1] & 0xff); f[4] = (float)(v[1][1] & 0xff); f[5] = (float)(v[2][1] & 0xff);
+      f[6] = (float)(v[0][0] >> 8);   f[7] = (float)(v[1][0] >> 8);
+    } else {              // TR c2, q 3 BR (dx 1, dy 1), pads
+      f[0] = (float)(v[2][0] >> 8);
+      f[1] = (float)(v[0][1] >> 8);   f[2] = (float)(v[1][1] >> 8);   f[3] = (float)(v[2][1] >> 8);
+      f[4] = f[5] = f[6] = f[7] = 0.f;
+    }
+    *(bf16x8*)(out + ((size_t)(n * Ho + oy0 + r) * Wo + ox) * ldo + half * 8) = pack8(f);
+  }
+}
+
 extern "C" int mi_focus_pack_u8(const uint8_t* img, int N, int H, int W, void* out, int ldo, mi_stream_t st) {
   MI_REQUIRE(img && out && H % 2 == 0 && W % 2 == 0 && ldo % 8 == 0 && ldo >= 16 && ((uintptr_t)img & 1) == 0,
              "focus_pack_u8: args");
   const int64_t total = (int64_t)N * (H / 2) * (W / 2);
   MI_REQUIRE(total < (1LL << 31) - (1 << 24), "focus_pack_u8: %lld output pixels exceed the 32-bit index", (long long)total);
-  static const int rows_mode = getenv("MI_FOCUS_ROWS") ? atoi(getenv("MI_FOCUS_ROWS")) : 1;
+  // MI_FOCUS_ROWS: 2 (default) lane-pair stores, 1 the round-5 row kernel, 0 the per-pixel kernel (read per call: the
+  // equality test runs all three in one process)
+  const int rows_mode = getenv("MI_FOCUS_ROWS") ? atoi(getenv("MI_FOCUS_ROWS")) : 2;
+  if (rows_mode >= 2 && W % 16 == 0 && ((uintptr_t)img & 15) == 0 && W <= 4096) {
+    const int rb = (H / 2 + FOCUS_ROWS2 - 1) / FOCUS_ROWS2;
+    hipLaunchKernelGGL(focus_pack_u8_pairs_kernel, dim3((unsigned)(N * rb)), dim3(256), (size_t)FOCUS_ROWS2 * 6 * W, (hipStream_t)st,
+                       img, N, H, W, (__bf16*)out, ldo);
+    MI_CHECK_LAUNCH("focus_pack_u8 (pairs)");
+    return MI_OK;
+  }
   if (rows_mode && W % 16 == 0 && ((uintptr_t)img & 15) == 0 && W <= 4096) {
     const int rb = (H / 2 + FOCUS_ROWS - 1) / FOCUS_ROWS;
     hipLaunchKernelGGL(focus_pack_u8_rows_kernel, dim3((unsigned)(N * rb)), dim3(256), (size_t)FOCUS_ROWS * 6 * W, (hipStream_t)st, img,

@@ -174,6 +174,13 @@ extern "C" int mi_cmdlist_run(const mi_cmd* cmds, int n, mi_stream_t st) {
   return MI_OK;
 }
 
+extern "C" int mi_upload_async(void* dst_dev, const void* src_pinned, int64_t nbytes, mi_stream_t st) {
+  MI_REQUIRE(dst_dev && src_pinned && nbytes > 0, "upload_async: args");
+  const hipError_t e = hipMemcpyAsync(dst_dev, src_pinned, (size_t)nbytes, hipMemcpyHostToDevice, (hipStream_t)st);
+  if (e != hipSuccess) MI_FAIL(MI_ELAUNCH, "upload_async: %s", hipGetErrorString(e));
+  return MI_OK;
+}
+
 // ---- CU-masked streams (the weight-gradient side queue)
 extern "C" int mi_stream_create_cu_mask(const uint32_t* mask, int nwords, mi_stream_t* out) {
   if (mi_device_count() <= 0) MI_FAIL(MI_ENODEV, "no HIP device");

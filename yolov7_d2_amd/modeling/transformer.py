@@ -23,7 +23,7 @@ import torch
 from torch import nn
 
 from .. import _lib as L
-from ..ops import pack_images, wgrad_bias_fused
+from ..ops import WgradBatch, pack_images, wgrad_bias_fused, wgrad_flush_point
 from .attention import mha_core, mha_core_qk
 
 
@@ -75,7 +75,14 @@ def _linear_fwd(x, w32, bias, relu=False):
     return y, wd
 
 
-def _linear_bwd(x, wd, dy, Cout, need_dx=True, gw=None, gb=None):
+def _can_defer(*params):
+    """the weight gradient may be written later (ops.WgradBatch) only into a tensor autograd takes over untouched: every
+    parameter is a leaf whose .grad is None (else AccumulateGrad adds the returned tensor to .grad right away, and a
+    non-leaf weight's producer reads it right away)"""
+    return WgradBatch.enabled() and all(p is None or (p.is_leaf and p.grad is None) for p in params)
+
+
+def _linear_bwd(x, wd, dy, Cout, need_dx=True, gw=None, gb=None, defer_ok=False):
     """(dx or None); the weight gradient is WRITTEN to gw (fp32 [Cout, Cin] contiguous: a row block of a larger gradient
     is) and the bias gradient to gb (fp32 [Cout]) when they are given"""
     T, Cin = x.shape
@@ -90,7 +97,8 @@ def _linear_bwd(x, wd, dy, Cout, need_dx=True, gw=None, gb=None):
     if need_dx:
         dx = torch.empty(T, Cin, dtype=torch.bfloat16, device=dev)
         _conv1x1(dy, wd, dx, T, CoutP, Cin, Cin)
-    fused_gb = gb is not None and gw is not None and CoutP == Cout and wgrad_bias_fused(T)
+    defer = defer_ok and gw is not None and (gb is None or CoutP == Cout)
+    fused_gb = gb is not None and gw is not None and CoutP == Cout and (defer or wgrad_bias_fused(T))
     if gw is not None:
         H, W = _factor(T)
         d = L.mi_wgrad_desc()
@@ -99,6 +107,11 @@ def _linear_bwd(x, wd, dy, Cout, need_dx=True, gw=None, gb=None):
             d.gbias = gb.data_ptr()          # the bias gradient from the same two launches (mi_wgrad_desc.gbias)
         d.ldx, d.ldy, d.N, d.H, d.W, d.outH, d.outW, d.stride = Cin, CoutP, 1, H, W, H, W, 1
         d.Cin, d.Cout, d.CinPad, d.CoutPad, d.ntaps = Cin, Cout, Cin, CoutP, 1
+        if defer:
+            # one grouped launch per transformer layer (ops.WgradBatch): only the job is registered here; x and dy stay
+            # alive until the layer's flush point, gw / gb are written by the group's reduce grid
+            WgradBatch.add(d, (x, dy))
+            return dx
         need = L.lib().mi_conv2d_wgrad_plan(C.byref(d))
         L.check(need, "mi_conv2d_wgrad_plan")
         ws = torch.empty(max(int(need), 16), dtype=torch.uint8, device=dev)
@@ -128,6 +141,7 @@ class _LinearFn(torch.autograd.Function):
         out = y if y.shape[1] == Cout else y[:, :Cout]
         ctx.save_for_backward(x, wd, out if relu else None)
         ctx.dims = (Cout, bias is not None)
+        ctx.params = (weight, bias)
         return out
 
     @staticmethod
@@ -138,7 +152,7 @@ class _LinearFn(torch.autograd.Function):
             dy = _ew(dy.contiguous(), y.contiguous(), 2)       # dy * (y > 0)
         gw = torch.empty(Cout, x.shape[1], dtype=torch.float32, device=x.device)
         gb = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_bias else None
-        dx = _linear_bwd(x, wd, dy, Cout, True, gw, gb)
+        dx = _linear_bwd(x, wd, dy, Cout, True, gw, gb, defer_ok=_can_defer(*ctx.params))
         return dx, gw, gb, None
 
 
@@ -161,6 +175,7 @@ class _InProjFn(torch.autograd.Function):
             wds.append(wd)
         ctx.save_for_backward(xq, xk, xv, *wds)
         ctx.E = E
+        ctx.params = (w, b)
         return tuple(outs)
 
     @staticmethod
@@ -170,8 +185,10 @@ class _InProjFn(torch.autograd.Function):
         gw = torch.empty(3 * E, E, dtype=torch.float32, device=xq.device)
         gb = torch.empty(3 * E, dtype=torch.float32, device=xq.device)
         dxs = []
+        ok = _can_defer(*ctx.params)
         for i, (x, wd, dy) in enumerate(((xq, wq, dq), (xk, wk, dk), (xv, wv, dv))):
-            dxs.append(_linear_bwd(x, wd, dy, E, ctx.needs_input_grad[i], gw[i * E:(i + 1) * E], gb[i * E:(i + 1) * E]))
+            dxs.append(_linear_bwd(x, wd, dy, E, ctx.needs_input_grad[i], gw[i * E:(i + 1) * E], gb[i * E:(i + 1) * E],
+                                   defer_ok=ok))
         return dxs[0], dxs[1], dxs[2], gw, gb
 
 
@@ -189,6 +206,7 @@ class _InProjQKFn(torch.autograd.Function):
         yv, wdv = _linear_fwd(xv, w32[2 * E:], b32[2 * E:])
         ctx.save_for_backward(xqk, xv, wdqk, wdv)
         ctx.E = E
+        ctx.params = (w, b)
         return yqk, yv
 
     @staticmethod
@@ -197,8 +215,9 @@ class _InProjQKFn(torch.autograd.Function):
         E = ctx.E
         gw = torch.empty(3 * E, E, dtype=torch.float32, device=xqk.device)
         gb = torch.empty(3 * E, dtype=torch.float32, device=xqk.device)
-        dxqk = _linear_bwd(xqk, wdqk, dqk, 2 * E, ctx.needs_input_grad[0], gw[: 2 * E], gb[: 2 * E])
-        dxv = _linear_bwd(xv, wdv, dv, E, ctx.needs_input_grad[1], gw[2 * E:], gb[2 * E:])
+        ok = _can_defer(*ctx.params)
+        dxqk = _linear_bwd(xqk, wdqk, dqk, 2 * E, ctx.needs_input_grad[0], gw[: 2 * E], gb[: 2 * E], defer_ok=ok)
+        dxv = _linear_bwd(xv, wdv, dv, E, ctx.needs_input_grad[1], gw[2 * E:], gb[2 * E:], defer_ok=ok)
         return dxqk, dxv, gw, gb
 
 
@@ -438,7 +457,7 @@ class TransformerEncoderLayer(nn.Module):
         return _LinearFn.apply(h, self.linear2.weight, self.linear2.bias).view(Lx, B, E)
 
     def forward(self, src, src_mask=None, src_key_padding_mask=None, pos=None):
-        src = _tok(src)
+        src = wgrad_flush_point(_tok(src))      # this layer's weight gradients leave as one group when backward gets here
         if self.normalize_before:   # forward_pre (detr_backbone.py:170-182)
             src2 = self._ln(self.norm1, src)
             q = k = self.with_pos_embed(src2, pos)
@@ -478,7 +497,7 @@ class TransformerDecoderLayer(nn.Module):
 
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
                 memory_key_padding_mask=None, pos=None, query_pos=None):
-        tgt, memory = _tok(tgt), _tok(memory)
+        tgt, memory = wgrad_flush_point(_tok(tgt)), _tok(memory)
         mem_k = self.with_pos_embed(memory, pos)
         if self.normalize_before:   # forward_pre (detr_backbone.py:245-264)
             tgt2 = self._ln(self.norm1, tgt)

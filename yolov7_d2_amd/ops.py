@@ -118,6 +118,105 @@ class WeightImages:
             L.check(L.lib().mi_pack_conv_weights_batch(self.table.data_ptr(), n, nblk, kk, L.stream_ptr()), "mi_pack_conv_weights_batch")
 
 
+# ------------------------------------------------------------------------------------------------ grouped weight gradients
+class WgradBatch:
+    """Weight gradients of the eager module trees (transformer Linears, ResNet convolutions), deferred and issued ONE
+    GROUPED LAUNCH PER LAYER (round 6).  A captured DETR-R50 step ran 116 single weight-gradient launches of 18 us + 131
+    split-K reductions of 6.3 us - 20 % of the step - almost all of them on the launch floor (a 256 x 256 Linear over 4 368
+    rows is 0.6 GFLOP).  Here a backward node only REGISTERS its job (x, dy, the gradient's address); `flush()` - called from
+    an identity autograd node at every transformer layer / ResNet block input and once more when the backward pass ends -
+    plans the pending jobs as one group (mi_conv2d_wgrad_group_plan: one grid per tile configuration + one reduce grid,
+    bias gradients included), uploads the job table and launches it.  x / dy live one layer longer, not the whole step
+    (deferring to the END of backward was measured in round 4: -13 %, every activation kept alive and read cold).
+
+    The gradient tensor a node returns to autograd is written LATER by the group's reduce grid; autograd takes such a
+    tensor over as the parameter's .grad without touching it (AccumulateGrad steals a fresh contiguous gradient when .grad
+    is None - the trainers zero with set_to_none=True), so the job keeps only its ADDRESS: holding the tensor would make
+    autograd clone it before it is written.  A parameter that receives gradient twice in one backward would be accumulated
+    by a torch kernel before the deferred write - `add()` refuses to defer when .grad is already set.
+    MI_WGRAD_LAYER_GROUP=0: every weight gradient as its own launch at its own node (round 5's form)."""
+    pending = []        # (mi_wgrad_desc without workspace, keep-alive tensors)
+    armed = False       # an end-of-backward flush is queued for the running backward pass
+    _arena = None       # pinned host memory the job tables are copied from (a captured graph replays those copies)
+    _arena_off = 0
+    ARENA_BYTES = 8 << 20
+    stats = dict(flushes=0, jobs=0)
+
+    @staticmethod
+    def enabled():
+        import os
+        return os.environ.get("MI_WGRAD_LAYER_GROUP", "1") != "0"
+
+    @classmethod
+    def add(cls, desc, keep):
+        cls.pending.append((desc, keep))
+        if not cls.armed:
+            cls.armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(cls._end_of_backward)
+
+    @classmethod
+    def _end_of_backward(cls):
+        cls.armed = False
+        cls.flush()
+
+    @classmethod
+    def _pinned(cls, nbytes):
+        nbytes = _rup(nbytes, 256)
+        if cls._arena is None or cls._arena_off + nbytes > cls._arena.numel():
+            if torch.cuda.is_current_stream_capturing():
+                raise L.MI355Error("WgradBatch: the pinned table arena is exhausted inside a graph capture (raise ARENA_BYTES)")
+            cls._arena = torch.empty(max(cls.ARENA_BYTES, nbytes), dtype=torch.uint8).pin_memory()
+            cls._arena_off = 0
+        o = cls._arena_off
+        cls._arena_off += nbytes
+        return cls._arena[o:o + nbytes]
+
+    @classmethod
+    def flush(cls):
+        jobs, cls.pending = cls.pending, []
+        n = len(jobs)
+        if n == 0:
+            return
+        lib, dev = L.lib(), jobs[0][1][0].device
+        descs = (L.mi_wgrad_desc * n)()
+        for d, (src, _) in zip(descs, jobs):
+            C.memmove(C.byref(d), C.byref(src), C.sizeof(L.mi_wgrad_desc))
+        meta = L.mi_wgrad_group()
+        L.check(lib.mi_conv2d_wgrad_group_plan(descs, n, None, None, 0, C.byref(meta)), "wgrad_group_plan (sizes)")
+        ws = torch.empty(max(int(meta.ws_bytes), 256), dtype=torch.uint8, device=dev)
+        nb = int(meta.table_bytes)
+        host = cls._pinned(nb)
+        L.check(lib.mi_conv2d_wgrad_group_plan(descs, n, ws.data_ptr(), host.data_ptr(), nb, C.byref(meta)), "wgrad_group_plan")
+        table = torch.empty(_rup(nb, 256), dtype=torch.uint8, device=dev)
+        sp = L.stream_ptr()
+        L.check(lib.mi_upload_async(table.data_ptr(), host.data_ptr(), nb, sp), "upload_async")
+        L.check(lib.mi_conv2d_wgrad_group_run(C.byref(meta), table.data_ptr(), sp), "wgrad_group_run")
+        cls.stats["flushes"] += 1
+        cls.stats["jobs"] += n
+
+
+class _WgradFlushFn(torch.autograd.Function):
+    """identity; its backward runs when every consumer of the tensor inside the layer has produced its input gradient -
+    i.e. when the layer's weight-gradient jobs are all registered - and issues them as one group"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        WgradBatch.flush()
+        return g
+
+
+def wgrad_flush_point(x):
+    """mark a layer boundary: the weight gradients registered by the layer's backward are launched when the backward
+    pass reaches this tensor"""
+    if WgradBatch.enabled() and torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled():
+        return _WgradFlushFn.apply(x)
+    return x
+
+
 def pack_images(w32, Cout, Cin, kh, kw, CinP, CoutP, CoutPK, CinPN, fwd=True, dgrad=True, scale=None):
     """(forward image wf[tap][ci/8][co][ci%8] or None, data-gradient image wd[tap][co/8][ci][co%8] or None) of the fp32
     OIHW weight w32 (contiguous); scale: fp32 [Cout] folded in (W * scale[co], fp32 product then the bf16 rounding)"""
