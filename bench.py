@@ -460,6 +460,104 @@ def h2d_inclusive(model, args, world, rank, dev):
     return args.batch * world * args.steps / dt, dt / args.steps * 1e3
 
 
+def detr_algorithmic_flops(B, H, W, enc=6, dec=6, Q=100, E=256, ffn=2048, nh=8, freeze_at=2):
+    """ALGORITHMIC floating-point operations of one DETR-R50 training step on a padded B x 3 x H x W batch (2 per
+    multiply-add; forward + data gradient + weight gradient for trainable layers, forward only for the frozen stem + res2;
+    attention backward 2.5 x its forward): ResNet-50 (torchvision-style, stride in the 3x3: detr_256_6_6_torchvision.yaml),
+    input_proj, 6 + 6 transformer layers, the heads.  Returns (total, {part: flops})."""
+    parts = {}
+    h, w = (H + 1) // 2, (W + 1) // 2
+    stem = 2.0 * B * h * w * 64 * 3 * 49
+    h, w = (h + 1) // 2, (w + 1) // 2
+    res, cin = 0.0, 64
+    frozen = stem
+    for si, (nb, bc) in enumerate(((3, 64), (4, 128), (6, 256), (3, 512))):
+        cout = bc * 4
+        stage = 0.0
+        for k in range(nb):
+            stride = 2 if (k == 0 and si > 0) else 1
+            ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
+            f = 2.0 * B * (h * w * cin * bc + ho * wo * bc * bc * 9 + ho * wo * bc * cout)
+            if k == 0:
+                f += 2.0 * B * ho * wo * cin * cout
+            stage += f
+            h, w, cin = ho, wo, cout
+        if si + 2 <= freeze_at:
+            frozen += stage
+        else:
+            res += 3.0 * stage
+    parts["resnet50 (stem + res2 frozen: forward only)"] = frozen + res
+    L_ = h * w
+    T = B * L_
+    parts["input_proj"] = 3 * 2.0 * T * 2048 * E
+    lin_e = 2.0 * T * (4 * E * E + 2 * E * ffn)
+    att_e = 4.0 * B * L_ * L_ * E
+    parts["encoder"] = enc * (3 * lin_e + 3.5 * att_e)
+    TQ = B * Q
+    lin_d = 2.0 * (TQ * (4 * E * E) + TQ * 2 * E * E + T * 2 * E * E + TQ * 2 * E * ffn)
+    att_d = 4.0 * B * (Q * Q + Q * L_) * E
+    parts["decoder"] = dec * (3 * lin_d + 3.5 * att_d)
+    parts["heads"] = 3 * 2.0 * dec * TQ * (E * 81 + 2 * E * E + E * 4)
+    return sum(parts.values()), parts
+
+
+def cpu_baseline_detr(model, inputs, nimg=2, steps=2):
+    """the DETR-R50 training step on the host cores through the CPU restatements (oracle/resnet_oracle.py,
+    oracle/detr_net_oracle.py, oracle/detr_oracle.py - fp32 torch; the reference's own Detr needs the reference tree, which
+    the GPU box does not have): `nimg` images of the bench batch, forward + Hungarian matching + set criterion on all six
+    levels + backward + AdamW, median of `steps` timed steps after one warm-up.  kind "port"."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import detr_net_oracle as DN
+    import detr_oracle as DO
+    import resnet_oracle as R
+    import torch.nn.functional as F
+    torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("MI_CPU_BASELINE_THREADS", "32"))))
+    BP = "detr.backbone.0.backbone."
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    bsd = {k[len(BP):]: v for k, v in sd.items() if k.startswith(BP)}
+    train = [v.requires_grad_(True) for k, v in list(sd.items()) if v.is_floating_point() and "running" not in k and ".norm." not in k
+             and not k.startswith(BP + "stem") and not k.startswith(BP + "res2")]
+    opt = torch.optim.AdamW(train, lr=1e-4, weight_decay=1e-4)
+    ins = inputs[:nimg]
+    Hm = (max(i["image"].shape[1] for i in ins) + 31) // 32 * 32
+    Wm = (max(i["image"].shape[2] for i in ins) + 31) // 32 * 32
+    mean = model.pixel_mean.detach().float().cpu().reshape(3, 1, 1).clone()
+    std = model.pixel_std.detach().float().cpu().reshape(3, 1, 1).clone()
+    x = torch.zeros(nimg, 3, Hm, Wm)
+    mask = torch.ones(nimg, Hm, Wm, dtype=torch.bool)
+    targets = []
+    for b, i in enumerate(ins):
+        img = i["image"].detach().float().cpu()
+        _, h, w = img.shape
+        x[b, :, :h, :w] = (img - mean) / std
+        mask[b, :h, :w] = False
+        bx = i["instances"].gt_boxes.tensor.detach().float().cpu()
+        cxcywh = torch.stack([(bx[:, 0] + bx[:, 2]) / 2 / w, (bx[:, 1] + bx[:, 3]) / 2 / h, (bx[:, 2] - bx[:, 0]) / w, (bx[:, 3] - bx[:, 1]) / h], 1)
+        targets.append(dict(labels=i["instances"].gt_classes.detach().cpu().long(), boxes=cxcywh))
+    wd = dict(loss_ce=1.0, loss_bbox=5.0, loss_giou=2.0)
+    ts = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        feat = R.forward(bsd, x, stride_in_1x1=False)["res5"]
+        m = F.interpolate(mask[None].float(), size=feat.shape[-2:]).to(torch.bool)[0]
+        pos = DN.position_embedding_sine(m, 128)
+        o = DN.detr_after_backbone(sd, feat, m, pos, nhead=8, prefix="detr.")
+        lg, bxs = o["logits"], o["boxes"]
+        outputs = dict(pred_logits=lg[-1], pred_boxes=bxs[-1], aux_outputs=[dict(pred_logits=a, pred_boxes=b_) for a, b_ in zip(lg[:-1], bxs[:-1])])
+        losses = DO.set_criterion(outputs, targets, 80, 0.1)
+        total = sum(v * wd[k.rsplit("_", 1)[0] if k[-1].isdigit() else k] for k, v in losses.items()
+                    if (k.rsplit("_", 1)[0] if k[-1].isdigit() else k) in wd)
+        opt.zero_grad()
+        total.backward()
+        opt.step()
+        ts.append(time.perf_counter() - t0)
+    t = sorted(ts[1:])[len(ts[1:]) // 2]
+    return dict(value=round(nimg / t, 3), unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                sample=f"median of {steps} timed steps after 1 warm-up, {nimg} images of the bench batch (padded {Hm}x{Wm}), fp32 "
+                       "fwd + matching + criterion (6 levels) + bwd + AdamW through oracle/resnet_oracle.py + detr_net_oracle.py + "
+                       "detr_oracle.py (CPU restatements; the reference tree is not on this box)")
+
+
 def bench_detr(args):
     """--config detr: BASELINE.json configs[3] - DETR-R50 (6 + 6 layers, 100 queries, dropout 0.1) training step at
     800 x 1333 (the padded batch of the reference's MIN_SIZE_TRAIN 800 / MAX 1333), fwd + Hungarian matching + set
@@ -518,6 +616,28 @@ def bench_detr(args):
         last = step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the reference's own per-GPU batch: IMS_PER_BATCH 56 on 8 GPUs = 7 (configs/coco/detr/detr_256_6_6_torchvision.yaml:26)
+    bs7 = None
+    if graphed and args.batch == 16 and os.environ.get("MI_BENCH_DETR_BS7", "1") == "1":
+        g7 = torch.Generator().manual_seed(4321)
+        in7 = list(inputs)
+        for b in range(B, 7):
+            h, w = H_ - 32 * (b % 3), W_ - 64 * (b % 4)
+            n = int(torch.randint(1, 21, (1,), generator=g7))
+            wh = 16 + torch.rand(n, 2, generator=g7) * 256
+            xy = torch.rand(n, 2, generator=g7) * (torch.tensor([w, h]) - wh).clamp(min=1)
+            in7.append(dict(image=torch.randint(0, 256, (3, h, w), generator=g7).float().to(dev),
+                            instances=Instances((h, w), gt_boxes=Boxes(torch.cat([xy, xy + wh], 1)), gt_classes=torch.randint(0, 80, (n,), generator=g7))))
+        for _ in range(3):
+            gstep(in7)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            gstep(in7)
+        torch.cuda.synchronize()
+        d7 = time.perf_counter() - t1
+        bs7 = dict(batch=7, value=round(7 * args.steps / d7, 2), ms_per_step=round(d7 / args.steps * 1e3, 3),
+                   note="the reference's per-GPU batch (IMS_PER_BATCH 56 / 8 GPUs)")
     # attention kernels alone, encoder self-attention shape: 20 back-to-back launches through the C-ABI between HIP events
     # on the launch stream (the autograd wrapper's Python time - ~35 us per call - is not the kernel's)
     from yolov7_d2_amd import _lib as L
@@ -542,8 +662,30 @@ def bench_detr(args):
         torch.cuda.synchronize()
         times.append(e0.elapsed_time(e1) / 20)
     tf, tb = times
+    # the same forward as the step runs it: attention-weight dropout p = 0.1 (counter-based mask recomputed in the backward)
+    fwd_d = lambda: L.check(lib.mi_mha_fwd_dropout(q.data_ptr(), k.data_ptr(), v.data_ptr(), None, o.data_ptr(), lse.data_ptr(), B, nh, L_, L_, E,
+                                                   scl, 0.1, 12345, spx), "mha_fwd_dropout")
+    bwd_d = lambda: L.check(lib.mi_mha_bwd_dropout(q.data_ptr(), k.data_ptr(), v.data_ptr(), None, o.data_ptr(), lse.data_ptr(), go.data_ptr(),
+                                                   dws.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, nh, L_, L_, E, scl, 0.1, 12345, spx),
+                            "mha_bwd_dropout")
+    times_d = []
+    for fn in (fwd_d, bwd_d):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        times_d.append(e0.elapsed_time(e1) / 20)
+    tfd, tbd = times_d
     fl_f = 4.0 * L_ * L_ * 32 * B * nh
     fl_b = 2.5 * fl_f          # dP, dV, dS->dQ, dK + the recomputed scores (x2: dq and dkv kernels each recompute S)
+    Hp, Wp = (H_ + 63) // 64 * 64, (W_ + 63) // 64 * 64      # Detr.shape_bucket = 64: the padded tensor the step computes on
+    alg, alg_parts = detr_algorithmic_flops(B, Hp, Wp)
+    ms_step = dt / args.steps * 1e3
     out = {
         "metric": "images/sec training, DETR-R50 800x1333", "value": round(B * args.steps / dt, 2), "unit": "images/sec",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -553,13 +695,27 @@ def bench_detr(args):
                                + ("(one hipGraph per padded shape, host half outside)" if graphed else "(eager ops)"),
                    "hipgraph": graphed,
                    "final_loss": round(float(last), 4)},
-        "roofline": {"bound": "mfma", "kernel": "mha_fwd2_kernel (encoder self-attention, L=%d, B=%d, 8 heads x 32)" % (L_, B),
-                     "achieved": round(fl_f / (tf * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                     "frac": round(fl_f / (tf * 1e-3) / 1e12 / 2500.0, 4), "traffic": None, "avg_launch_ms": round(tf, 4),
+        "roofline": {"bound": "mfma", "kernel": "mha_fwd2_kernel WITH attention dropout p=0.1, as the step runs it (encoder self-attention, L=%d, B=%d, 8 heads x 32)" % (L_, B),
+                     "achieved": round(fl_f / (tfd * 1e-3) / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                     "frac": round(fl_f / (tfd * 1e-3) / 1e12 / 2500.0, 4), "traffic": None, "avg_launch_ms": round(tfd, 4),
+                     "without_dropout": {"achieved": round(fl_f / (tf * 1e-3) / 1e12, 1), "frac": round(fl_f / (tf * 1e-3) / 1e12 / 2500.0, 4),
+                                         "avg_launch_ms": round(tf, 4)},
+                     "mha_bwd_with_dropout": {"achieved": round(fl_b / (tbd * 1e-3) / 1e12, 1), "unit": "TFLOP/s",
+                                              "frac": round(fl_b / (tbd * 1e-3) / 1e12 / 2500.0, 4), "ms": round(tbd, 4)},
                      "mha_bwd": {"achieved": round(fl_b / (tb * 1e-3) / 1e12, 1), "unit": "TFLOP/s",
                                  "frac": round(fl_b / (tb * 1e-3) / 1e12 / 2500.0, 4), "ms": round(tb, 4),
-                                 "kernels": "mha_delta + mha_bwd_dq2 + mha_bwd_dkv2"}},
+                                 "kernels": "mha_delta + mha_bwd_dq2 + mha_bwd_dkv2"},
+                     "whole_step": {"algorithmic_flops": alg, "parts_GFLOP": {k_: round(v_ / 1e9, 1) for k_, v_ in alg_parts.items()},
+                                    "padded_batch": [B, 3, Hp, Wp], "ms_per_step": round(ms_step, 3),
+                                    "mfma_tflops": round(alg / (ms_step * 1e-3) / 1e12, 1),
+                                    "mfma_frac_of_2500": round(alg / (ms_step * 1e-3) / 1e12 / 2500.0, 4),
+                                    "note": "2 flops per multiply-add; fwd + dgrad + wgrad of the trainable layers, forward only for the "
+                                            "frozen stem + res2, attention backward 2.5 x forward (bench.detr_algorithmic_flops)"}},
     }
+    if bs7 is not None:
+        out["at_reference_batch"] = bs7
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_detr(model, inputs)
     print(json.dumps(out))
 
 

@@ -224,6 +224,7 @@ def test_bottleneck_as_one_node_equals_per_convolution_nodes(cin, cout, bc, stri
     """_BottleneckFn (the second path of the input gradient accumulated in the convolution epilogue, MI_CONV_ACCUM) against the
     per-convolution autograd nodes + autograd's own additions: same kernels and roundings -> identical output and weight gradients, the input gradient to a bf16 rounding"""
     from yolov7_d2_amd.modeling.resnet import BottleneckBlock
+    monkeypatch.setenv("MI_WGRAD_LAYER_GROUP", "0")     # one launch per weight gradient on both sides (the grouped form picks other split counts)
     torch.manual_seed(3)
     blk = BottleneckBlock(cin, cout, bc, stride=stride).cuda()
     for m in blk.modules():
@@ -246,6 +247,37 @@ def test_bottleneck_as_one_node_equals_per_convolution_nodes(cin, cout, bc, stri
             assert _rel(a, b) < 4e-3
         else:
             assert torch.equal(a, b), (i, float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("cin,cout,bc,stride", [(256, 512, 128, 2), (512, 512, 128, 1)], ids=["shortcut_s2", "identity"])
+def test_bottleneck_grouped_weight_gradients_equal_single_launches(cin, cout, bc, stride, monkeypatch):
+    """ops.WgradBatch inside _BottleneckFn.backward: the block's three or four weight gradients as ONE grouped launch, issued
+    before the input gradient is accumulated into the tensor two of the jobs read - equal to the one-launch-per-layer form to
+    the split-K summation order, input gradient and output bit for bit"""
+    from yolov7_d2_amd.modeling.resnet import BottleneckBlock
+    from yolov7_d2_amd.ops import WgradBatch
+    res = []
+    for grouped in ("0", "1"):
+        monkeypatch.setenv("MI_WGRAD_LAYER_GROUP", grouped)
+        torch.manual_seed(3)
+        blk = BottleneckBlock(cin, cout, bc, stride=stride).cuda()
+        for m in blk.modules():
+            if hasattr(m, "running_var"):
+                m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.1); m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+        g = torch.Generator().manual_seed(9)
+        x = torch.randn(2, cin, 24, 36, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        go = torch.randn(2, cout, 24 // stride, 36 // stride, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+        n0 = dict(WgradBatch.stats)
+        y = blk(x)
+        y.backward(go)
+        torch.cuda.synchronize()
+        assert WgradBatch.stats["flushes"] - n0["flushes"] == int(grouped) and not WgradBatch.pending
+        res.append((y.detach().float(), x.grad.float(), {k: p.grad.float() for k, p in blk.named_parameters() if p.grad is not None}))
+    (y0, dx0, g0), (y1, dx1, g1) = res
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1) and set(g0) == set(g1) and len(g0) >= 3
+    for k in g0:
+        scale = float(g0[k].abs().max()) + 1e-30
+        assert float((g0[k] - g1[k]).abs().max()) <= 2e-5 * scale, (k, float((g0[k] - g1[k]).abs().max()), scale)
 
 
 @pytest.mark.parametrize("k,stride,cin,cout", [(1, 1, 64, 256), (3, 2, 128, 128), (1, 2, 256, 512)])

@@ -26,7 +26,7 @@ from torch import nn
 
 from .. import _lib as L
 from ..d2shim import BACKBONE_REGISTRY, Backbone, ShapeSpec
-from ..ops import _ConvGeom, _conv_desc, _nchw, _nhwc, _pad_last, _run_conv
+from ..ops import WgradBatch, _ConvGeom, _conv_desc, _nchw, _nhwc, _pad_last, _run_conv, wgrad_can_defer
 
 
 class FrozenBatchNorm2d(nn.Module):
@@ -433,6 +433,7 @@ class _BottleneckFn(torch.autograd.Function):
             y = torch.empty_like(o)
             L.check(L.lib().mi_ew_bf16(o.data_ptr(), sc.data_ptr(), y.data_ptr(), o.numel(), 7, L.stream_ptr()), "mi_ew_bf16 add+relu")
         ctx.geoms, ctx.has_sc = geoms, bool(ssc)
+        ctx.params = ws
         ctx.save_for_backward(xh, a1, a2, y, *[im[1] for im in imgs], *scales)
         return y.permute(0, 3, 1, 2)
 
@@ -448,23 +449,28 @@ class _BottleneckFn(torch.autograd.Function):
         gm = torch.empty_like(gyh)          # (a fresh tensor: identity blocks accumulate the input gradient into it)
         L.check(L.lib().mi_ew_bf16(gyh.data_ptr(), y.data_ptr(), gm.data_ptr(), gm.numel(), 2, L.stream_ptr()), "mi_ew_bf16 relu'")
         gws = [None] * n
-        gws[2] = g3.wgrad_scaled(a2, gm, scales[2])
+        # the block's three or four weight gradients as ONE grouped launch (ops.WgradBatch), issued below - before the input
+        # gradient is accumulated INTO gm, which two of the jobs read
+        df = wgrad_can_defer(*ctx.params)
+        gws[2] = g3.wgrad_scaled(a2, gm, scales[2], defer=df)
         da2 = torch.empty_like(a2)
         if ctx.epi:
             g3.dgrad(gm, wds[2], da2, relu_mask=a2)
         else:
             g3.dgrad(gm, wds[2], da2)
             da2 = _relu_mask(da2, a2)
-        gws[1] = g2.wgrad_scaled(a1, da2, scales[1])
+        gws[1] = g2.wgrad_scaled(a1, da2, scales[1], defer=df)
         da1 = torch.empty_like(a1)
         if ctx.epi:
             g2.dgrad(da2, wds[1], da1, relu_mask=a1)
         else:
             g2.dgrad(da2, wds[1], da1)
             da1 = _relu_mask(da1, a1)
-        gws[0] = g1.wgrad_scaled(xh, da1, scales[0])
+        gws[0] = g1.wgrad_scaled(xh, da1, scales[0], defer=df)
         if gs is not None:
-            gws[3] = gs.wgrad_scaled(xh, gm, scales[3])
+            gws[3] = gs.wgrad_scaled(xh, gm, scales[3], defer=df)
+        if df:
+            WgradBatch.flush()
         dx = None
         if ctx.needs_input_grad[0]:
             if gs is None:

@@ -195,6 +195,13 @@ class WgradBatch:
         cls.stats["jobs"] += n
 
 
+def wgrad_can_defer(*params):
+    """the weight gradient may be written later only into a tensor autograd takes over untouched: every parameter is a leaf
+    whose .grad is None (else AccumulateGrad adds the returned tensor to .grad right away, and a non-leaf weight's producer
+    reads it right away)"""
+    return WgradBatch.enabled() and all(p is None or (p.is_leaf and p.grad is None) for p in params)
+
+
 class _WgradFlushFn(torch.autograd.Function):
     """identity; its backward runs when every consumer of the tensor inside the layer has produced its input gradient -
     i.e. when the layer's weight-gradient jobs are all registered - and issues them as one group"""
@@ -334,11 +341,11 @@ class _ConvGeom:
         return pack_images(weight.detach().float().contiguous(), self.Cout, self.Cin, self.k, self.k, self.CinP, self.CoutP,
                            self.CoutP, self.CinP, fwd, dgrad, scale)
 
-    def wgrad_scaled(self, xh, dyh, scale):
+    def wgrad_scaled(self, xh, dyh, scale, defer=False):
         """weight gradient of a layer whose image carried a folded per-Cout factor: scale[co] * dW' (the factor is applied
         to the fp32 sums in the split-K reduction: mi_wgrad_desc.row_scale)"""
         assert scale.dtype == torch.float32 and scale.is_contiguous() and scale.numel() == self.Cout
-        return self.wgrad(xh, dyh, row_scale=scale)
+        return self.wgrad(xh, dyh, row_scale=scale, defer=defer)
 
     def pad_in(self, x):
         """NCHW -> bf16 [N,H,W,CinP] (zero pad channels)"""
@@ -390,8 +397,10 @@ class _ConvGeom:
                                      self.CinP, self.H, self.W, self.Cin, self.CinP, taps, out_stride=2, oy=py, ox=px,
                                      gridH=gh, gridW=gw, flags=fl, aux=aux), "mi_conv2d (dgrad s2)")
 
-    def wgrad(self, xh, dyh, row_scale=None, gbias=None):
-        """gbias: fp32 [Cout] tensor that receives the bias gradient (column sums of dyh) from the same two launches"""
+    def wgrad(self, xh, dyh, row_scale=None, gbias=None, defer=False):
+        """gbias: fp32 [Cout] tensor that receives the bias gradient (column sums of dyh) from the same two launches.
+        defer: only register the job with WgradBatch (the caller flushes: one grouped launch for several layers); xh / dyh
+        must not be modified before that flush"""
         gw = torch.empty(self.Cout, self.Cin, self.k, self.k, dtype=torch.float32, device=xh.device)
         d = L.mi_wgrad_desc()
         d.x, d.dy, d.gw = xh.data_ptr(), dyh.data_ptr(), gw.data_ptr()
@@ -400,6 +409,9 @@ class _ConvGeom:
         d.Cin, d.Cout, d.CinPad, d.CoutPad, d.ntaps = self.Cin, self.Cout, self.CinP, self.CoutP, self.KK
         for t in range(self.KK):
             d.tap_dy[t], d.tap_dx[t] = t // self.k - self.pad, t % self.k - self.pad
+        if defer:
+            WgradBatch.add(d, (xh, dyh, row_scale))
+            return gw
         need = L.lib().mi_conv2d_wgrad_plan(C.byref(d))
         L.check(need, "mi_conv2d_wgrad_plan")
         ws = torch.empty(max(int(need), 16), dtype=torch.uint8, device=xh.device)
