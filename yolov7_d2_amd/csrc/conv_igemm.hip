@@ -561,6 +561,26 @@ __global__ __launch_bounds__(256) void pack_w_batch_kernel(const mi_pack_job* __
   int nci = j.Cin - ci0;
   nci = nci < 0 ? 0 : (nci > PK_CI ? PK_CI : nci);
   const int rowlen = PK_CI * KK;
+  // full tiles of 16-byte aligned rows (every tile of the YOLOX / ResNet / transformer weights but the ragged edges): a wave
+  // takes whole output-channel rows, a lane 4 consecutive floats per trip - one 16-byte load and no integer division per
+  // element (the scalar loop below spent ~25 instructions per 4-byte load: 44 us for the 36 MB of YOLOX-s masters)
+  const float* const wrow0 = j.w + ((size_t)co0 * j.Cin + ci0) * KK;
+  const bool fast = nci == PK_CI && co0 + PK_CO <= j.Cout && ((j.Cin * KK) & 3) == 0 && (((uintptr_t)wrow0) & 15) == 0 &&
+                    (rowlen & 3) == 0;
+  if (fast) {
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int co_l = wave; co_l < PK_CO; co_l += 4) {
+      const float4* src = (const float4*)(wrow0 + (size_t)co_l * j.Cin * KK);
+      const float sc = j.scale ? j.scale[co0 + co_l] : 1.f;      // (x * 1.f is exact: one code path)
+      unsigned* dst = (unsigned*)(pk_s + co_l * rs);             // rs even: 4-byte aligned rows
+      for (int q4 = lane; q4 < rowlen / 4; q4 += 64) {
+        const float4 v = src[q4];
+        const __bf16 b0 = (__bf16)(v.x * sc), b1 = (__bf16)(v.y * sc), b2 = (__bf16)(v.z * sc), b3 = (__bf16)(v.w * sc);
+        dst[2 * q4] = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
+        dst[2 * q4 + 1] = (unsigned)__builtin_bit_cast(unsigned short, b2) | ((unsigned)__builtin_bit_cast(unsigned short, b3) << 16);
+      }
+    }
+  } else
   for (int idx = tid; idx < PK_CO * rowlen; idx += 256) {
     const int co_l = idx / rowlen, q = idx - co_l * rowlen;
     const int row = co0 + co_l;

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void focus_pack_u8_rows_kernel(const uint8_t* 
 // even lane the first 16 bytes (TL c0..2, BL c0..2, TR c0..1), odd lane the second (TR c2, BR c0..2, four zero pads), so a
 // wave's store instruction covers 1 KB of consecutive addresses (ldo = 16) instead of 16 bytes out of every 32 twice
 // (focus_pack_u8_rows_kernel: 40 us for 52 MB of output in the captured step, 1.3 TB/s).  FOCUS_ROWS2 output rows per block.
-#define FOCUS_ROWS2 4
+template <int FOCUS_ROWS2>
 __global__ __launch_bounds__(256) void focus_pack_u8_pairs_kernel(const uint8_t* __restrict__ img, int N, int H, int W,
                                                                   __bf16* out, int ldo) {
   extern __shared__ __attribute__((aligned(16))) uint8_t srow[];      // [FOCUS_ROWS2][3 channels][2 parities][W]
@@ -178,9 +178,15 @@ extern "C" int mi_focus_pack_u8(const uint8_t* img, int N, int H, int W, void* o
   // equality test runs all three in one process)
   const int rows_mode = getenv("MI_FOCUS_ROWS") ? atoi(getenv("MI_FOCUS_ROWS")) : 2;
   if (rows_mode >= 2 && W % 16 == 0 && ((uintptr_t)img & 15) == 0 && W <= 4096) {
-    const int rb = (H / 2 + FOCUS_ROWS2 - 1) / FOCUS_ROWS2;
-    hipLaunchKernelGGL(focus_pack_u8_pairs_kernel, dim3((unsigned)(N * rb)), dim3(256), (size_t)FOCUS_ROWS2 * 6 * W, (hipStream_t)st,
-                       img, N, H, W, (__bf16*)out, ldo);
+    static const int th = getenv("MI_FOCUS_TH") ? atoi(getenv("MI_FOCUS_TH")) : 4;     // output rows per block (A/B knob: 1, 2, 4, 8)
+    const int R = th == 1 ? 1 : th == 2 ? 2 : th == 8 ? 8 : 4;
+    const int rb = (H / 2 + R - 1) / R;
+    const dim3 g((unsigned)(N * rb));
+    const size_t lds = (size_t)R * 6 * W;
+    if (R == 1) hipLaunchKernelGGL(focus_pack_u8_pairs_kernel<1>, g, dim3(256), lds, (hipStream_t)st, img, N, H, W, (__bf16*)out, ldo);
+    else if (R == 2) hipLaunchKernelGGL(focus_pack_u8_pairs_kernel<2>, g, dim3(256), lds, (hipStream_t)st, img, N, H, W, (__bf16*)out, ldo);
+    else if (R == 8) hipLaunchKernelGGL(focus_pack_u8_pairs_kernel<8>, g, dim3(256), lds, (hipStream_t)st, img, N, H, W, (__bf16*)out, ldo);
+    else hipLaunchKernelGGL(focus_pack_u8_pairs_kernel<4>, g, dim3(256), lds, (hipStream_t)st, img, N, H, W, (__bf16*)out, ldo);
     MI_CHECK_LAUNCH("focus_pack_u8 (pairs)");
     return MI_OK;
   }
