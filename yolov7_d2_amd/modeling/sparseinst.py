@@ -34,7 +34,7 @@ from torch import nn
 
 from .. import _lib as L
 from ..d2shim import META_ARCH_REGISTRY, ImageList, Instances, build_backbone
-from ..ops import ConvPaddedFn, _ld, nhwc_strided_ok
+from ..ops import ConvPaddedFn, WgradBatch, _ConvGeom, _conv_desc, _ld, _nhwc_v, _run_conv, nhwc_strided_ok, wgrad_can_defer
 from .transformer import _LinearFn, _factor
 
 # ------------------------------------------------------------------------------------------------ small op wrappers
@@ -364,6 +364,108 @@ def _aggregate(iam, features):
     return inst, _ColSumFn.apply(prob.reshape(B, H * W, N))           # normaliser [B, N] (fp32 accumulation, no fp32 copy of the map)
 
 
+IAM_GS = 128      # channel stride of one group in the padded IAM map: the kernels' output-channel tile (>= masks per group)
+
+
+class _GroupIamFn(torch.autograd.Function):
+    """GroupInstanceBranch's grouped 3x3 `iam_conv` (decoder_sparseinst.py:212-242: nn.Conv2d(dim, masks * G, 3, groups=G)) as
+    its G convolutions over channel slices of the feature map, each WRITING ITS SLICE of one bf16 NHWC map [B, H, W, G * 128]
+    (group g's `cout` masks at channels g * 128 .., the rest zero).  Round 5 ran G ops on NCHW slices and torch.cat'ed the
+    results (41 MB), `_aggregate` then made a zero-padded per-image copy of the sigmoid of that map (8 x (5.3 MB fill +
+    strided copy)), and the backward padded every out-gradient slice again (ops._pad_last: 4 x 52 MB): here the map IS the
+    operand of everything behind it, forward and backward, and nothing is copied.  Backward: the data gradients write their
+    64-channel slices of one feature gradient, the G weight gradients leave as ONE grouped launch (ops.WgradBatch), the bias
+    gradient is one column-sum launch over the whole map."""
+
+    @staticmethod
+    def forward(ctx, features, weight, bias, G):
+        fh = _nhwc_v(features)                                  # [B, H, W, C] (a view when the map is channels_last)
+        B, H, W, Cc = fh.shape
+        cin, cout = Cc // G, weight.shape[0] // G
+        if cin % 32 or cout > IAM_GS or cout % 4 or tuple(weight.shape[1:]) != (cin, 3, 3):
+            raise L.MI355Error(f"grouped IAM conv: {tuple(weight.shape)} over {Cc} channels in {G} groups is not served")
+        geo = _ConvGeom((B, cin, H, W), (cout, cin, 3, 3), 1, 1)
+        assert geo.CoutP == IAM_GS and geo.CinP == cin
+        out = torch.empty(B, H, W, G * IAM_GS, dtype=torch.bfloat16, device=fh.device)
+        if cout < IAM_GS:
+            out.view(B, H, W, G, IAM_GS)[..., cout:].zero_()
+        w32 = weight.detach().float().contiguous()
+        b32 = None if bias is None else bias.detach().float().contiguous()
+        taps = [(r - 1, s_ - 1, r * 3 + s_) for r in range(3) for s_ in range(3)]
+        ldx = _ld(fh)
+        wds = []
+        for g in range(G):
+            wf, wd = geo.pack(w32[g * cout:(g + 1) * cout])
+            wds.append(wd)
+            _run_conv(_conv_desc(fh.data_ptr() + g * cin * 2, ldx, B, H, W, wf, cin, out.data_ptr() + g * IAM_GS * 2, G * IAM_GS,
+                                 H, W, cout, IAM_GS, taps, bias=None if b32 is None else b32[g * cout:(g + 1) * cout]),
+                      "mi_conv2d (grouped IAM conv)")
+        ctx.geo, ctx.G, ctx.dims, ctx.has_bias = geo, G, (B, H, W, Cc, cin, cout), bias is not None
+        ctx.params = (weight, bias)
+        ctx.save_for_backward(fh, *wds)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        fh, *wds = ctx.saved_tensors
+        geo, G = ctx.geo, ctx.G
+        B, H, W, Cc, cin, cout = ctx.dims
+        gy = gy.contiguous()                                     # [B, H, W, G * 128]; its pad channels are zero (see _aggregate)
+        dev = gy.device
+        taps = [(1 - r, 1 - s_, r * 3 + s_) for r in range(3) for s_ in range(3)]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(B, H, W, Cc, dtype=torch.bfloat16, device=dev)
+            for g in range(G):
+                _run_conv(_conv_desc(gy.data_ptr() + g * IAM_GS * 2, G * IAM_GS, B, H, W, wds[g], IAM_GS, dx.data_ptr() + g * cin * 2,
+                                     Cc, H, W, cin, cin, taps), "mi_conv2d (grouped IAM dgrad)")
+            dx = dx.permute(0, 3, 1, 2)
+        gw = gb = None
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty(G * cout, cin, 3, 3, dtype=torch.float32, device=dev)
+            defer = wgrad_can_defer(*ctx.params)
+            for g in range(G):
+                d = L.mi_wgrad_desc()
+                d.x, d.dy, d.gw = fh.data_ptr() + g * cin * 2, gy.data_ptr() + g * IAM_GS * 2, gw.data_ptr() + g * cout * cin * 9 * 4
+                d.ldx, d.ldy, d.N, d.H, d.W, d.outH, d.outW, d.stride = _ld(fh), G * IAM_GS, B, H, W, H, W, 1
+                d.Cin, d.Cout, d.CinPad, d.CoutPad, d.ntaps = cin, cout, cin, IAM_GS, 9
+                for t in range(9):
+                    d.tap_dy[t], d.tap_dx[t] = t // 3 - 1, t % 3 - 1
+                if defer:
+                    WgradBatch.add(d, (fh, gy))
+                else:
+                    need = L.lib().mi_conv2d_wgrad_plan(C.byref(d))
+                    L.check(need, "mi_conv2d_wgrad_plan")
+                    ws = torch.empty(max(int(need), 16), dtype=torch.uint8, device=dev)
+                    d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
+                    L.check(L.lib().mi_conv2d_wgrad(C.byref(d), L.stream_ptr()), "mi_conv2d_wgrad (grouped IAM conv)")
+            if defer:
+                WgradBatch.flush()                               # the G jobs as one grouped launch
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            CP = G * IAM_GS
+            sums = torch.empty(CP, dtype=torch.float32, device=dev)
+            ws = torch.empty(128 * CP, dtype=torch.float32, device=dev)
+            L.check(L.lib().mi_colsum_bf16_wide(gy.data_ptr(), CP, B * H * W, CP, sums.data_ptr(), 0, ws.data_ptr(), L.stream_ptr()),
+                    "mi_colsum_bf16_wide")
+            gb = sums.view(G, IAM_GS)[:, :cout].reshape(G * cout)
+        return dx, gw, gb, None
+
+
+def _aggregate_padded(iam_h, features, G, cout):
+    """_aggregate on the padded IAM map of _GroupIamFn: iam_h bf16 [B, H, W, G * 128] -> inst fp32 [B, G * cout, C] and the
+    normaliser [B, G * cout].  The outer product and the column sums run over all G * 128 channels - the 0.5s the sigmoid makes
+    of the zero pad channels land in rows that are sliced off here, and the slices' backward hands those rows zero gradients,
+    so the pad channels of the map's gradient stay exactly zero for the convolution backward."""
+    B, H, W, CP = iam_h.shape
+    Cc = features.shape[1]
+    prob = _Ew1.apply(iam_h, "sigmoid")                                # [B, H, W, G * 128]
+    fh = _nhwc(features)
+    outs = [_PixelOuterFn.apply(prob[b].reshape(H * W, CP), fh[b].reshape(H * W, Cc)) for b in range(B)]
+    inst = torch.stack(outs).view(B, G, IAM_GS, Cc)[:, :, :cout].reshape(B, G * cout, Cc)
+    norm = _ColSumFn.apply(prob.reshape(B, H * W, CP)).view(B, G, IAM_GS)[:, :, :cout].reshape(B, G * cout)
+    return inst, norm
+
+
 class _ColSumFn(torch.autograd.Function):
     """[B, P, N] bf16 -> fp32 [B, N] sums over P (see _colsums); backward: the [B, N] gradient broadcast over the pixels"""
 
@@ -431,9 +533,16 @@ class GroupInstanceBranch(nn.Module):
         # grouped 3x3 conv = its `groups` independent convs over channel slices
         G = self.num_groups
         cin, cout = features.shape[1] // G, self.iam_conv.out_channels // G
-        iam = torch.cat([torch.ops.mi355.conv2d(features[:, g * cin:(g + 1) * cin], self.iam_conv.weight[g * cout:(g + 1) * cout],
-                                                self.iam_conv.bias[g * cout:(g + 1) * cout], 1, 1) for g in range(G)], 1)
-        inst, norm = _aggregate(iam, features)
+        if _IAM_PADDED() and cin % 32 == 0 and cout <= IAM_GS and cout % 4 == 0:
+            # one padded NHWC map written by the G convolutions in place and read in place by everything behind it
+            iam_h = _GroupIamFn.apply(features, self.iam_conv.weight, self.iam_conv.bias, G)
+            inst, norm = _aggregate_padded(iam_h, features, G, cout)
+            Bq, Hq, Wq = iam_h.shape[:3]
+            iam = lambda: iam_h.view(Bq, Hq, Wq, G, IAM_GS)[..., :cout].reshape(Bq, Hq, Wq, G * cout).permute(0, 3, 1, 2)   # (only OUTPUT_IAM reads it)
+        else:
+            iam = torch.cat([torch.ops.mi355.conv2d(features[:, g * cin:(g + 1) * cin], self.iam_conv.weight[g * cout:(g + 1) * cout],
+                                                    self.iam_conv.bias[g * cout:(g + 1) * cout], 1, 1) for g in range(G)], 1)
+            inst, norm = _aggregate(iam, features)
         inst = inst / norm.clamp(min=1e-6, max=1e5)[:, :, None]
         B, N = inst.shape[:2]
         d4 = N // 4
@@ -500,7 +609,7 @@ class BaseIAMDecoder(nn.Module):
         output = {"pred_logits": pred_logits.float(), "pred_masks": masks.permute(0, 3, 1, 2)[:, :N],
                   "pred_scores": pred_scores.float(), "_masks_nhwc": masks}
         if self.output_iam:
-            output["pred_iam"] = resize_bilinear(iam, (Ho, Wo))
+            output["pred_iam"] = resize_bilinear(iam() if callable(iam) else iam, (Ho, Wo))
         return output
 
 
@@ -515,6 +624,12 @@ class GroupIAMDecoder(BaseIAMDecoder):
         super().__init__(cfg)
         in_channels = cfg.MODEL.SPARSE_INST.ENCODER.NUM_CHANNELS + 2
         self.inst_branch = GroupInstanceBranch(cfg, in_channels)
+
+
+def _IAM_PADDED():
+    """MI_SI_IAM_PADDED=0: the grouped IAM conv as G ops + torch.cat and per-image padded copies (round 5's form; A/B, tests)"""
+    import os
+    return os.environ.get("MI_SI_IAM_PADDED", "1") != "0"
 
 
 def _PADDED_COORDS():
