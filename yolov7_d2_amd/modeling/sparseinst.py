@@ -35,7 +35,8 @@ from torch import nn
 from .. import _lib as L
 from ..d2shim import META_ARCH_REGISTRY, ImageList, Instances, build_backbone
 from ..ops import ConvPaddedFn, WgradBatch, _ConvGeom, _conv_desc, _ld, _nhwc_v, _run_conv, nhwc_strided_ok, wgrad_can_defer
-from .transformer import _LinearFn, _factor
+from ..ops import pack_images
+from .transformer import _LinearFn, _conv1x1, _factor
 
 # ------------------------------------------------------------------------------------------------ small op wrappers
 
@@ -167,6 +168,56 @@ def pixel_outer(a, b):
     d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
     L.check(L.lib().mi_conv2d_wgrad(C.byref(d), L.stream_ptr()), "mi_conv2d_wgrad (pixel_outer)")
     return out
+
+
+def pixel_outer_batch(a, b):
+    """pixel_outer for every image of a batch as ONE grouped launch (+ one reduce grid) instead of B pairs of launches:
+    a bf16 [B, P, Ca], b bf16 [B, P, Cb] (dense) -> fp32 [B, Ca, Cb].  MI_SI_OUTER_BATCH=0: the per-image launches."""
+    import os
+    B, P, Ca = a.shape
+    Cb = b.shape[2]
+    assert Ca % 32 == 0 and Cb % 32 == 0 and a.is_contiguous() and b.is_contiguous() and b.shape[:2] == a.shape[:2]
+    if os.environ.get("MI_SI_OUTER_BATCH", "1") == "0" or not WgradBatch.enabled():
+        return torch.stack([pixel_outer(a[i], b[i]) for i in range(B)])
+    H, W = _factor(P)
+    out = torch.empty(B, Ca, Cb, dtype=torch.float32, device=a.device)
+    jobs = []
+    for i in range(B):
+        d = L.mi_wgrad_desc()
+        d.x, d.dy, d.gw = b[i].data_ptr(), a[i].data_ptr(), out[i].data_ptr()
+        d.ldx, d.ldy, d.N, d.H, d.W, d.outH, d.outW, d.stride = Cb, Ca, 1, H, W, H, W, 1
+        d.Cin, d.Cout, d.CinPad, d.CoutPad, d.ntaps = Cb, Ca, Cb, Ca, 1
+        jobs.append((d, (a, b, out)))
+    WgradBatch.run_now(jobs)
+    return out
+
+
+class _PixelOuterBatchFn(torch.autograd.Function):
+    """differentiable pixel_outer_batch; backward per image as _PixelOuterFn's (two 1x1-conv launches with the image's own
+    gradient matrix as the weight)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return pixel_outer_batch(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        B, P, Ca = a.shape
+        Cb = b.shape[2]
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        g32 = g.float().contiguous()
+        gt = g32.transpose(1, 2).contiguous() if db is not None else None
+        for i in range(B):        # the 1x1-conv kernel writes each image's rows of the batch gradient in place
+            if da is not None:
+                wf, _ = pack_images(g32[i], Ca, Cb, 1, 1, Cb, Ca, Ca, Cb, dgrad=False)
+                _conv1x1(b[i], wf, da[i], P, Cb, Ca, Ca)
+            if db is not None:
+                wf, _ = pack_images(gt[i], Cb, Ca, 1, 1, Ca, Cb, Cb, Ca, dgrad=False)
+                _conv1x1(a[i], wf, db[i], P, Ca, Cb, Cb)
+        return da, db
 
 
 class _PixelOuterFn(torch.autograd.Function):
@@ -460,8 +511,8 @@ def _aggregate_padded(iam_h, features, G, cout):
     Cc = features.shape[1]
     prob = _Ew1.apply(iam_h, "sigmoid")                                # [B, H, W, G * 128]
     fh = _nhwc(features)
-    outs = [_PixelOuterFn.apply(prob[b].reshape(H * W, CP), fh[b].reshape(H * W, Cc)) for b in range(B)]
-    inst = torch.stack(outs).view(B, G, IAM_GS, Cc)[:, :, :cout].reshape(B, G * cout, Cc)
+    outer = _PixelOuterBatchFn.apply(prob.reshape(B, H * W, CP), fh.reshape(B, H * W, Cc))      # one grouped launch for the batch
+    inst = outer.view(B, G, IAM_GS, Cc)[:, :, :cout].reshape(B, G * cout, Cc)
     norm = _ColSumFn.apply(prob.reshape(B, H * W, CP)).view(B, G, IAM_GS)[:, :, :cout].reshape(B, G * cout)
     return inst, norm
 
@@ -720,11 +771,8 @@ def dice_score_packed(masks_nhwc, pk):
     sig = _Ew1.apply(masks_nhwc.contiguous(), "sigmoid").reshape(B, P, Np)
     s2 = _colsums(sig, square=True)                                                   # [B, Np]  sum_p sigmoid^2
     t2 = pk.t2                                                                        # [B, cap] sum_p t^2 (PackedMaskTargets.fill)
-    out = []
-    for b in range(B):
-        num = 2.0 * pixel_outer(sig[b], pk.tgtT[b])                                   # [Np, cap]; tgtT[b] = bf16 [P, cap]
-        out.append(num / (s2[b][:, None] + t2[b][None, :] + 1e-4))
-    return torch.stack(out)
+    num = pixel_outer_batch(sig, pk.tgtT)                                             # [B, Np, cap]; tgtT[b] = bf16 [P, cap]
+    return (2.0 * num) / (s2[:, :, None] + t2[:, None, :] + 1e-4)
 
 
 class SparseInstMatcher(nn.Module):

@@ -172,6 +172,16 @@ class WgradBatch:
         return cls._arena[o:o + nbytes]
 
     @classmethod
+    def run_now(cls, jobs):
+        """`jobs` [(mi_wgrad_desc, keep-alive tensors)] as one grouped launch, at once (forward-pass users of the
+        weight-gradient kernel: the per-image outer products of SparseInst)"""
+        saved, cls.pending = cls.pending, list(jobs)
+        try:
+            cls.flush()
+        finally:
+            cls.pending = saved + cls.pending
+
+    @classmethod
     def flush(cls):
         jobs, cls.pending = cls.pending, []
         n = len(jobs)
