@@ -46,6 +46,7 @@ class NativeTrainer:
         self.copy_stream = None
         self._feed = None
         self.feed_direct = os.environ.get("MI_FEED_DIRECT", "1") != "0"
+        self.one_graph = os.environ.get("MI_STEP_ONE_GRAPH", "1") != "0"
         # MI_WGRAD_SIDE=G (experiment, round 6; default off - profiles/r06_wgrad_cumask_ab.txt): the weight gradients as G
         # grouped launches on a SIDE QUEUE beside the backward chain, each issued when the last out-gradient of its layers
         # exists (PlanBuilder.wgrad_async cuts the groups), joined before the optimizer.  MI_WGRAD_CUMASK=n[x] confines
@@ -311,7 +312,24 @@ class NativeTrainer:
                 h = L.check(lib.mi_graph_capture(ptr, hi - lo, sp), "capture bwd segment")
             gs["bwd"].append(h)
         gs["sgd"] = L.check(lib.mi_graph_capture(st["sgd"], 1, sp), "capture sgd")
+        # single GPU: forward + backward + optimizer as ONE graph - the two graph-to-graph boundaries inside the step cost
+        # 8 - 14 us of idle device each (profiles/r06_h2d_where_the_gap_was.txt, the gaps after loss_final and the reduce grid)
+        gs["step"], gs["step_stage"] = None, {}
+        if self.one_graph and self.world == 1 and self.side_groups == 0:
+            arr, n = self._whole_step_cmds(st, farr, fn)
+            gs["step"] = L.check(lib.mi_graph_capture(arr, n, sp), "capture whole step")
         st["graphs"] = gs
+
+    def _whole_step_cmds(self, st, farr, fn):
+        """[forward list `farr`] + backward list + the SGD command as one array (kept alive in the state)"""
+        barr, bn = st["plan"].bwd_cmds
+        sz = C.sizeof(L.mi_cmd)
+        arr = (L.mi_cmd * (fn + bn + 1))()
+        C.memmove(arr, farr, fn * sz)
+        C.memmove(C.byref(arr, fn * sz), barr, bn * sz)
+        C.memmove(C.byref(arr, (fn + bn) * sz), st["sgd"], sz)
+        st.setdefault("_step_arrays", []).append(arr)
+        return arr, fn + bn + 1
 
     def load_batch(self, images, labels):
         """images float [B,3,H,W] (0..255, already padded to /32), labels [B,max_boxes,5] — device tensors"""
@@ -423,6 +441,20 @@ class NativeTrainer:
             gs = st["graphs"] if self.use_graph else None
             farr, fn = plan.fwd_cmds
             barr, bn = plan.bwd_cmds
+            if gs and gs.get("step") is not None:
+                # the whole step is one graph (of the staging buffer the batch sits in, when it was fed)
+                if staged is not None:
+                    h = gs["step_stage"].get(staged["k"])
+                    if h is None:
+                        sarr, sn = self._staged_fwd(st, staged["k"])
+                        arr, n = self._whole_step_cmds(st, sarr, sn)
+                        h = gs["step_stage"][staged["k"]] = L.check(lib.mi_graph_capture(arr, n, sp), "capture staged whole step")
+                        gs["fwd_stage"][staged["k"]] = h
+                    L.check(lib.mi_graph_launch(h, sp), "launch staged whole step")
+                    staged["free"].record(self.stream)
+                else:
+                    L.check(lib.mi_graph_launch(gs["step"], sp), "launch whole step")
+                return
             if staged is not None:
                 sarr, sn = self._staged_fwd(st, staged["k"])
                 if gs:
