@@ -667,3 +667,27 @@ def test_deferred_weight_gradients_step_aside_when_grad_accumulates(monkeypatch)
     for k in one:
         scale = float(one[k].abs().max()) + 1e-30
         assert float((two[k] - 2 * one[k]).abs().max()) <= 1e-4 * scale + 1e-9, k
+
+
+def test_deferred_weight_gradient_that_autograd_copies_is_reported(monkeypatch):
+    """the grouped form relies on autograd taking the returned gradient tensor over untouched; a tensor hook on the parameter
+    makes autograd hand a COPY to .grad before the group has written the original - that must fail loudly, not train on
+    uninitialised memory"""
+    from yolov7_d2_amd import _lib as L
+    from yolov7_d2_amd.modeling.transformer import _LinearFn
+    monkeypatch.setenv("MI_WGRAD_LAYER_GROUP", "1")
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(256, 64, generator=g).to(torch.bfloat16).to(DEV).requires_grad_(True)
+    w = (torch.randn(96, 64, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    b = torch.zeros(96, device=DEV, requires_grad=True)
+    y = _LinearFn.apply(x, w, b)
+    y.float().sum().backward()                       # the healthy case: deferred, written, taken over
+    torch.cuda.synchronize()
+    ref = x.detach().float().sum(0)[None, :].expand(96, 64)
+    torch.testing.assert_close(w.grad, ref, rtol=2e-2, atol=2e-2)
+    w2 = w.detach().clone().requires_grad_(True)
+    w2.register_hook(lambda gr: gr * 1.0)            # autograd now stores the hook's result, a different tensor
+    b2 = torch.zeros(96, device=DEV, requires_grad=True)      # (fresh: a parameter whose .grad exists is never deferred)
+    y = _LinearFn.apply(x, w2, b2)
+    with pytest.raises((L.MI355Error, RuntimeError), match="did not take a deferred weight gradient"):
+        y.float().sum().backward()

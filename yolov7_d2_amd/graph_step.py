@@ -309,6 +309,8 @@ class GraphedTrainStep:
             self.seed_word.copy_(sw)
 
     def _capture(self, fn):
+        from .ops import WgradBatch
+        WgradBatch.reserve_for_capture()        # (the job tables of the grouped weight gradients: pinned, allocated outside the capture)
         g = torch.cuda.CUDAGraph()
         if hasattr(self.opt, "begin_capture"):
             self.opt.begin_capture()        # a device table of its own for this graph (its pool has its own gradients)

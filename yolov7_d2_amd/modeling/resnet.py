@@ -452,23 +452,23 @@ class _BottleneckFn(torch.autograd.Function):
         # the block's three or four weight gradients as ONE grouped launch (ops.WgradBatch), issued below - before the input
         # gradient is accumulated INTO gm, which two of the jobs read
         df = wgrad_can_defer(*ctx.params)
-        gws[2] = g3.wgrad_scaled(a2, gm, scales[2], defer=df)
+        gws[2] = g3.wgrad_scaled(a2, gm, scales[2], defer=df, owner=ctx.params[2] if df else None)
         da2 = torch.empty_like(a2)
         if ctx.epi:
             g3.dgrad(gm, wds[2], da2, relu_mask=a2)
         else:
             g3.dgrad(gm, wds[2], da2)
             da2 = _relu_mask(da2, a2)
-        gws[1] = g2.wgrad_scaled(a1, da2, scales[1], defer=df)
+        gws[1] = g2.wgrad_scaled(a1, da2, scales[1], defer=df, owner=ctx.params[1] if df else None)
         da1 = torch.empty_like(a1)
         if ctx.epi:
             g2.dgrad(da2, wds[1], da1, relu_mask=a1)
         else:
             g2.dgrad(da2, wds[1], da1)
             da1 = _relu_mask(da1, a1)
-        gws[0] = g1.wgrad_scaled(xh, da1, scales[0], defer=df)
+        gws[0] = g1.wgrad_scaled(xh, da1, scales[0], defer=df, owner=ctx.params[0] if df else None)
         if gs is not None:
-            gws[3] = gs.wgrad_scaled(xh, gm, scales[3], defer=df)
+            gws[3] = gs.wgrad_scaled(xh, gm, scales[3], defer=df, owner=ctx.params[3] if df else None)
         if df:
             WgradBatch.flush()
         dx = None

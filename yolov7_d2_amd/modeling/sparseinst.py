@@ -483,7 +483,7 @@ class _GroupIamFn(torch.autograd.Function):
                 for t in range(9):
                     d.tap_dy[t], d.tap_dx[t] = t // 3 - 1, t % 3 - 1
                 if defer:
-                    WgradBatch.add(d, (fh, gy))
+                    WgradBatch.add(d, (fh, gy), ctx.params[0])
                 else:
                     need = L.lib().mi_conv2d_wgrad_plan(C.byref(d))
                     L.check(need, "mi_conv2d_wgrad_plan")

@@ -82,7 +82,7 @@ def _can_defer(*params):
     return WgradBatch.enabled() and all(p is None or (p.is_leaf and p.grad is None) for p in params)
 
 
-def _linear_bwd(x, wd, dy, Cout, need_dx=True, gw=None, gb=None, defer_ok=False):
+def _linear_bwd(x, wd, dy, Cout, need_dx=True, gw=None, gb=None, defer_ok=False, owner=None):
     """(dx or None); the weight gradient is WRITTEN to gw (fp32 [Cout, Cin] contiguous: a row block of a larger gradient
     is) and the bias gradient to gb (fp32 [Cout]) when they are given"""
     T, Cin = x.shape
@@ -110,7 +110,7 @@ def _linear_bwd(x, wd, dy, Cout, need_dx=True, gw=None, gb=None, defer_ok=False)
         if defer:
             # one grouped launch per transformer layer (ops.WgradBatch): only the job is registered here; x and dy stay
             # alive until the layer's flush point, gw / gb are written by the group's reduce grid
-            WgradBatch.add(d, (x, dy))
+            WgradBatch.add(d, (x, dy), owner)
             return dx
         need = L.lib().mi_conv2d_wgrad_plan(C.byref(d))
         L.check(need, "mi_conv2d_wgrad_plan")
@@ -152,7 +152,7 @@ class _LinearFn(torch.autograd.Function):
             dy = _ew(dy.contiguous(), y.contiguous(), 2)       # dy * (y > 0)
         gw = torch.empty(Cout, x.shape[1], dtype=torch.float32, device=x.device)
         gb = torch.empty(Cout, dtype=torch.float32, device=x.device) if has_bias else None
-        dx = _linear_bwd(x, wd, dy, Cout, True, gw, gb, defer_ok=_can_defer(*ctx.params))
+        dx = _linear_bwd(x, wd, dy, Cout, True, gw, gb, defer_ok=_can_defer(*ctx.params), owner=ctx.params[0])
         return dx, gw, gb, None
 
 
@@ -188,7 +188,7 @@ class _InProjFn(torch.autograd.Function):
         ok = _can_defer(*ctx.params)
         for i, (x, wd, dy) in enumerate(((xq, wq, dq), (xk, wk, dk), (xv, wv, dv))):
             dxs.append(_linear_bwd(x, wd, dy, E, ctx.needs_input_grad[i], gw[i * E:(i + 1) * E], gb[i * E:(i + 1) * E],
-                                   defer_ok=ok))
+                                   defer_ok=ok, owner=ctx.params[0]))
         return dxs[0], dxs[1], dxs[2], gw, gb
 
 
@@ -216,8 +216,8 @@ class _InProjQKFn(torch.autograd.Function):
         gw = torch.empty(3 * E, E, dtype=torch.float32, device=xqk.device)
         gb = torch.empty(3 * E, dtype=torch.float32, device=xqk.device)
         ok = _can_defer(*ctx.params)
-        dxqk = _linear_bwd(xqk, wdqk, dqk, 2 * E, ctx.needs_input_grad[0], gw[: 2 * E], gb[: 2 * E], defer_ok=ok)
-        dxv = _linear_bwd(xv, wdv, dv, E, ctx.needs_input_grad[1], gw[2 * E:], gb[2 * E:], defer_ok=ok)
+        dxqk = _linear_bwd(xqk, wdqk, dqk, 2 * E, ctx.needs_input_grad[0], gw[: 2 * E], gb[: 2 * E], defer_ok=ok, owner=ctx.params[0])
+        dxv = _linear_bwd(xv, wdv, dv, E, ctx.needs_input_grad[1], gw[2 * E:], gb[2 * E:], defer_ok=ok, owner=ctx.params[0])
         return dxqk, dxv, gw, gb
 
 

@@ -137,8 +137,12 @@ class WgradBatch:
     MI_WGRAD_LAYER_GROUP=0: every weight gradient as its own launch at its own node (round 5's form)."""
     pending = []        # (mi_wgrad_desc without workspace, keep-alive tensors)
     armed = False       # an end-of-backward flush is queued for the running backward pass
-    _arena = None       # pinned host memory the job tables are copied from (a captured graph replays those copies)
-    _arena_off = 0
+    owners = []         # (parameter, address of its deferred gradient): checked when the backward pass ends
+    # pinned host memory the job tables are copied from.  Eager steps use a RING (the stream is synchronised when it wraps:
+    # once per ~2 000 groups); a graph capture takes its tables from append-only blocks that live as long as the process -
+    # every replay of the graph copies from them again
+    _ring, _ring_off = None, 0
+    _graph_blocks, _graph_off = [], 0
     ARENA_BYTES = 8 << 20
     stats = dict(flushes=0, jobs=0)
 
@@ -148,8 +152,12 @@ class WgradBatch:
         return os.environ.get("MI_WGRAD_LAYER_GROUP", "1") != "0"
 
     @classmethod
-    def add(cls, desc, keep):
+    def add(cls, desc, keep, owner=None):
+        """owner: the parameter whose gradient this job writes (checked at the end of the backward pass: autograd must have
+        taken the returned tensor over as .grad, not copied it)"""
         cls.pending.append((desc, keep))
+        if owner is not None:
+            cls.owners.append((owner, int(desc.gw)))
         if not cls.armed:
             cls.armed = True
             torch.autograd.Variable._execution_engine.queue_callback(cls._end_of_backward)
@@ -158,18 +166,42 @@ class WgradBatch:
     def _end_of_backward(cls):
         cls.armed = False
         cls.flush()
+        owners, cls.owners = cls.owners, []
+        for p, ptr in owners:
+            g = p.grad
+            if g is None or not (g.data_ptr() <= ptr < g.data_ptr() + g.numel() * g.element_size()):
+                raise L.MI355Error("WgradBatch: autograd did not take a deferred weight gradient over as the parameter's .grad "
+                                   f"(parameter {tuple(p.shape)}: a hook or a second use copied it before it was written); "
+                                   "set MI_WGRAD_LAYER_GROUP=0")
 
     @classmethod
     def _pinned(cls, nbytes):
         nbytes = _rup(nbytes, 256)
-        if cls._arena is None or cls._arena_off + nbytes > cls._arena.numel():
-            if torch.cuda.is_current_stream_capturing():
-                raise L.MI355Error("WgradBatch: the pinned table arena is exhausted inside a graph capture (raise ARENA_BYTES)")
-            cls._arena = torch.empty(max(cls.ARENA_BYTES, nbytes), dtype=torch.uint8).pin_memory()
-            cls._arena_off = 0
-        o = cls._arena_off
-        cls._arena_off += nbytes
-        return cls._arena[o:o + nbytes]
+        if torch.cuda.is_current_stream_capturing():
+            if not cls._graph_blocks or cls._graph_off + nbytes > cls._graph_blocks[-1].numel():
+                # (page-locked allocation inside a capture is not a stream operation: thread-local capture mode allows it)
+                cls._graph_blocks.append(torch.empty(max(cls.ARENA_BYTES, nbytes), dtype=torch.uint8).pin_memory())
+                cls._graph_off = 0
+            o = cls._graph_off
+            cls._graph_off += nbytes
+            return cls._graph_blocks[-1][o:o + nbytes]
+        if cls._ring is None or nbytes > cls._ring.numel():
+            cls._ring = torch.empty(max(cls.ARENA_BYTES, nbytes), dtype=torch.uint8).pin_memory()
+            cls._ring_off = 0
+        if cls._ring_off + nbytes > cls._ring.numel():
+            torch.cuda.current_stream().synchronize()      # every copy issued from the ring has been executed
+            cls._ring_off = 0
+        o = cls._ring_off
+        cls._ring_off += nbytes
+        return cls._ring[o:o + nbytes]
+
+    @classmethod
+    def reserve_for_capture(cls):
+        """make sure a graph capture finds a pinned block (called from eager code before a capture starts: allocating
+        page-locked memory INSIDE a global-mode capture is an error)"""
+        if not cls._graph_blocks or cls._graph_off + (1 << 20) > cls._graph_blocks[-1].numel():
+            cls._graph_blocks.append(torch.empty(cls.ARENA_BYTES, dtype=torch.uint8).pin_memory())
+            cls._graph_off = 0
 
     @classmethod
     def run_now(cls, jobs):
@@ -351,11 +383,11 @@ class _ConvGeom:
         return pack_images(weight.detach().float().contiguous(), self.Cout, self.Cin, self.k, self.k, self.CinP, self.CoutP,
                            self.CoutP, self.CinP, fwd, dgrad, scale)
 
-    def wgrad_scaled(self, xh, dyh, scale, defer=False):
+    def wgrad_scaled(self, xh, dyh, scale, defer=False, owner=None):
         """weight gradient of a layer whose image carried a folded per-Cout factor: scale[co] * dW' (the factor is applied
         to the fp32 sums in the split-K reduction: mi_wgrad_desc.row_scale)"""
         assert scale.dtype == torch.float32 and scale.is_contiguous() and scale.numel() == self.Cout
-        return self.wgrad(xh, dyh, row_scale=scale, defer=defer)
+        return self.wgrad(xh, dyh, row_scale=scale, defer=defer, owner=owner)
 
     def pad_in(self, x):
         """NCHW -> bf16 [N,H,W,CinP] (zero pad channels)"""
@@ -407,7 +439,7 @@ class _ConvGeom:
                                      self.CinP, self.H, self.W, self.Cin, self.CinP, taps, out_stride=2, oy=py, ox=px,
                                      gridH=gh, gridW=gw, flags=fl, aux=aux), "mi_conv2d (dgrad s2)")
 
-    def wgrad(self, xh, dyh, row_scale=None, gbias=None, defer=False):
+    def wgrad(self, xh, dyh, row_scale=None, gbias=None, defer=False, owner=None):
         """gbias: fp32 [Cout] tensor that receives the bias gradient (column sums of dyh) from the same two launches.
         defer: only register the job with WgradBatch (the caller flushes: one grouped launch for several layers); xh / dyh
         must not be modified before that flush"""
@@ -420,7 +452,7 @@ class _ConvGeom:
         for t in range(self.KK):
             d.tap_dy[t], d.tap_dx[t] = t // self.k - self.pad, t % self.k - self.pad
         if defer:
-            WgradBatch.add(d, (xh, dyh, row_scale))
+            WgradBatch.add(d, (xh, dyh, row_scale), owner)
             return gw
         need = L.lib().mi_conv2d_wgrad_plan(C.byref(d))
         L.check(need, "mi_conv2d_wgrad_plan")
