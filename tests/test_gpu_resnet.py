@@ -424,3 +424,29 @@ def test_weight_images_one_launch_equals_the_per_layer_packs():
                 assert torch.equal(x.view(torch.int16), y.view(torch.int16))
     ref = ops.pack_images(late.detach(), 64, 64, 1, 1, 64, 64, 64, 64)
     assert torch.equal(unrec[0].view(torch.int16), ref[0].view(torch.int16))
+
+
+def test_frozen_bottleneck_add_relu_in_the_conv_epilogue_equals_the_separate_pass(monkeypatch):
+    """a frozen BottleneckBlock (the FREEZE_AT prefix; every block at inference): conv3 + shortcut + ReLU from conv3's epilogue
+    (MI_CONV_ADDRELU) against the separate add + ReLU pass (MI_RESNET_EPI_FUSE=0) - same roundings, bit for bit"""
+    from yolov7_d2_amd.modeling.resnet import BottleneckBlock
+    outs = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("MI_RESNET_EPI_FUSE", fuse)
+        for cin, cout, bc, stride in ((64, 256, 64, 1), (256, 256, 64, 1), (256, 512, 128, 2)):
+            torch.manual_seed(5)
+            blk = BottleneckBlock(cin, cout, bc, stride=stride).cuda()
+            for m in blk.modules():
+                if hasattr(m, "running_var"):
+                    m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.1); m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+            for p in blk.parameters():
+                p.requires_grad = False
+            g = torch.Generator().manual_seed(7)
+            x = torch.randn(2, cin, 40, 56, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+            y = blk(x)
+            torch.cuda.synchronize()
+            assert tuple(y.shape) == (2, cout, 40 // stride, 56 // stride)
+            outs.append(y.float().cpu())
+    n = len(outs) // 2
+    for a, b in zip(outs[:n], outs[n:]):
+        assert torch.equal(a, b) and float(a.abs().max()) > 0

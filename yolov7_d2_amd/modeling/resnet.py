@@ -26,7 +26,7 @@ from torch import nn
 
 from .. import _lib as L
 from ..d2shim import BACKBONE_REGISTRY, Backbone, ShapeSpec
-from ..ops import WgradBatch, _ConvGeom, _conv_desc, _nchw, _nhwc, _pad_last, _run_conv, wgrad_can_defer
+from ..ops import WgradBatch, _ConvGeom, _conv_desc, _nchw, _nhwc, _nhwc_v, _pad_last, _run_conv, wgrad_can_defer
 
 
 class FrozenBatchNorm2d(nn.Module):
@@ -157,10 +157,15 @@ class Conv2d(nn.Module):
         self.norm = FrozenBatchNorm2d(cout)
         self.stride, self.padding = stride, padding
 
-    def forward(self, x, relu=False):
+    def forward(self, x, relu=False, add_relu=None):
         """relu=True: the ReLU that follows runs in the convolution's epilogue (MI_CONV_RELU), one launch instead of two.
-        The frozen affine is folded into the packed weight image (scale) and the bias (shift)."""
+        The frozen affine is folded into the packed weight image (scale) and the bias (shift).
+        add_relu (no-autograd path only): an NCHW tensor of the output's shape; returns relu(bf16(conv + shift) + add_relu) from
+        the convolution's epilogue (MI_CONV_ADDRELU): conv3 + shortcut + ReLU of a frozen bottleneck as one launch"""
         scale, shift = self.norm.affine()
+        if add_relu is not None and (not _FOLDED_FN() or (self.weight.requires_grad and torch.is_grad_enabled())
+                                     or (x.requires_grad and torch.is_grad_enabled())):
+            raise L.MI355Error("Conv2d.forward(add_relu=...): only on the frozen / no-autograd path")
         if not _FOLDED_FN():
             w = self.weight * scale.view(-1, 1, 1, 1)
             op = torch.ops.mi355.conv2d_relu if relu else torch.ops.mi355.conv2d
@@ -186,7 +191,7 @@ class Conv2d(nn.Module):
                     if c is None or c[0] != key:
                         c = self.__dict__["_image"] = (key, _same_address(c, g.pack(self.weight, dgrad=False, scale=scale)[0]))
                     wf = c[1]
-                return _folded_forward(g, x, wf, shift, relu)[1]
+                return _folded_forward(g, x, wf, shift, relu, add_relu)[1]
         return _FoldedConvFn.apply(x, self.weight, scale, shift, self.stride, self.padding, relu)
 
 
@@ -205,14 +210,19 @@ def _FOLDED_FN():
     return os.environ.get("MI_RESNET_FOLDED_FN", "1") != "0"
 
 
-def _folded_forward(g, x, wf, shift, relu):
+def _folded_forward(g, x, wf, shift, relu, add_relu=None):
     xh = g.pad_in(x)
     y = torch.empty(g.N, g.Ho, g.Wo, g.CoutP, dtype=torch.bfloat16, device=x.device)
     b32 = shift
     if g.CoutP != g.Cout:
         b32 = torch.zeros(g.CoutP, dtype=torch.float32, device=x.device)
         b32[: g.Cout] = shift
-    g.fwd(xh, wf, y, bias=b32, relu=relu)
+    ar = None
+    if add_relu is not None:
+        if g.CoutP != g.Cout or relu:
+            raise L.MI355Error("conv + add + ReLU epilogue: channel count must be a multiple of 32 (and no second ReLU)")
+        ar = _nhwc_v(add_relu)
+    g.fwd(xh, wf, y, bias=b32, relu=relu, add_relu=ar)
     return xh, _nchw(y, g.Cout)
 
 
@@ -504,8 +514,14 @@ class BottleneckBlock(nn.Module):
             out = self.conv2(self.conv1(x, relu=True), relu=True)
         else:
             out = _relu(self.conv2(_relu(self.conv1(x))))
-        out = self.conv3(out)
         sc = self.shortcut(x) if self.shortcut is not None else x
+        no_grad_path = not (torch.is_grad_enabled() and (x.requires_grad or any(c.weight.requires_grad for c in convs)))
+        if no_grad_path and _EPI_FUSE() and _FOLDED_FN() and self.conv3.weight.shape[0] % 32 == 0:
+            # a frozen block (FREEZE_AT prefix) / inference: the residual add + ReLU in conv3's epilogue, as _BottleneckFn
+            # does for the trainable blocks - the separate pass was a read-read-write of the block's largest map
+            # (3 x 73 us per DETR-R50 step for res2 at 800 x 1333)
+            return self.conv3(out, add_relu=sc)
+        out = self.conv3(out)
         return _add_relu(out, sc)
 
 

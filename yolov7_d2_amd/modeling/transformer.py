@@ -496,9 +496,12 @@ class TransformerDecoderLayer(nn.Module):
     _ffn = TransformerEncoderLayer._ffn
 
     def forward(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None,
-                memory_key_padding_mask=None, pos=None, query_pos=None):
+                memory_key_padding_mask=None, pos=None, query_pos=None, mem_k=None):
+        """mem_k: memory + pos when the caller has formed it already (the decoder stack does, once for its six layers:
+        detr_backbone.py:226 adds the same two tensors in every layer)"""
         tgt, memory = wgrad_flush_point(_tok(tgt)), _tok(memory)
-        mem_k = self.with_pos_embed(memory, pos)
+        if mem_k is None:
+            mem_k = self.with_pos_embed(memory, pos)
         if self.normalize_before:   # forward_pre (detr_backbone.py:245-264)
             tgt2 = self._ln(self.norm1, tgt)
             q = k = self.with_pos_embed(tgt2, query_pos)
@@ -567,10 +570,11 @@ class TransformerDecoder(nn.Module):
         pos = None if pos is None else _tok(pos)
         query_pos = None if query_pos is None else _tok(query_pos)
         intermediate = []
+        mem_k = TransformerDecoderLayer.with_pos_embed(memory, pos)      # the same sum in every layer: formed once
         for layer in self.layers:
             output = layer(output, memory, tgt_mask=tgt_mask, memory_mask=memory_mask,
                            tgt_key_padding_mask=tgt_key_padding_mask, memory_key_padding_mask=memory_key_padding_mask,
-                           pos=pos, query_pos=query_pos)
+                           pos=pos, query_pos=query_pos, mem_k=mem_k)
             if self.return_intermediate:
                 intermediate.append(_norm_tokens(self.norm, output))
         if self.norm is not None:
