@@ -77,34 +77,51 @@ dist.all_gather(ps, p)
 res["params_equal"] = bool(torch.equal(ps[0], ps[1]))
 res["params_moved"] = float((p - p0).norm() / p0.norm())
 res["finite"] = bool(torch.isfinite(p).all())
-p_overlap = p
-
-
-def run_schedule(tag):
+def run_schedule(tag, steps=3, ref=None):
     tr = NativeTrainer(fresh(), lr=0.01, use_graph=True)
     s_ = tr.load_batch(imgs.cuda(), labels.cuda())
-    for it in range(3):
+    for it in range(steps):
         tr.step(s_)
     tr.stream.synchronize()
     q = tr.params.data.detach().cpu().clone()
+    p_overlap = p if ref is None else ref
     qs = [torch.zeros_like(q) for _ in range(world)]
     dist.all_gather(qs, q)
     res[tag + "_params_equal"] = bool(torch.equal(qs[0], qs[1]))
     res[tag + "_finite"] = bool(torch.isfinite(q).all())
-    res[tag + "_vs_overlap_rel"] = float((q - p_overlap).norm() / (p_overlap - p0).norm())     # relative to the update itself
+    res[tag + "_vs_overlap_rel"] = float((q - p_overlap).norm() / ((p_overlap - p0).norm() + 1e-30))     # relative to the update itself
     res[tag + "_buckets"] = len(s_["red"].buckets)
     res[tag + "_wgrad_groups"] = sum(1 for k in range(s_["plan"].bwd_cmds[1]) if L.OPS[s_["plan"].bwd_cmds[0][k].op] == "WGRAD_GROUP")
+    res[tag + "_bn_fused"] = bool(s_["plan"].bn_fused)
     res[tag + "_mode"] = tr.ddp_mode
     res[tag + "_choice"] = tr.ddp_choice
     return tr
 
 
-# (4) the exposed schedule, forced: the single-GPU backward + ONE all-reduce after it lands on the same parameters
+# (4) the exposed schedule, forced: the single-GPU backward + ONE all-reduce after it lands on the same parameters.  With
+# the SAME BatchNorm backward kernels as the overlapped run (two-pass) the schedules differ only in the split-K summation
+# order of the weight gradients (one group instead of three) and three steps stay together; with the BatchNorm form chosen
+# on the device (possibly the one-launch kernel: dy differs by bf16 roundings) the comparison is made after ONE step - a
+# randomly initialised YOLOX amplifies a rounding into other SimOTA assignments within a few updates
+os.environ["MI_DDP_OVERLAP"] = "1"
+tr_one = NativeTrainer(fresh(), lr=0.01, use_graph=True)
+st_one = tr_one.load_batch(imgs.cuda(), labels.cuda())
+tr_one.step(st_one)
+tr_one.stream.synchronize()
+p_overlap_1 = tr_one.params.data.detach().cpu().clone()
 os.environ["MI_DDP_OVERLAP"] = "0"
+run_schedule("exposed_bnauto_1step", steps=1, ref=p_overlap_1)
+os.environ["MI_BN_FUSED"] = "0"
 run_schedule("exposed")
+if os.environ.get("MI_REHEARSAL_PROBE") == "1":        # (diagnostic: the exposed schedule with each BatchNorm backward form forced)
+    for f in ("0", "1"):
+        os.environ["MI_BN_FUSED"] = f
+        run_schedule("exposed_bn" + f)
+    del os.environ["MI_BN_FUSED"]
 # (5) auto: both schedules timed with their collectives at the first capture, the same one kept on both ranks
 os.environ["MI_DDP_OVERLAP"] = "auto"
 run_schedule("auto")
+del os.environ["MI_BN_FUSED"]
 dist.barrier()
 dist.destroy_process_group()
 json.dump(res, open(out_path, "w"))

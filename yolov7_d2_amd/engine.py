@@ -58,8 +58,7 @@ class NativeTrainer:
         self.side_stream = None
         self.stream = None
         if self.side_groups > 0:
-            os.environ["MI_WGRAD_ASYNC"] = str(self.side_groups)      # read by PlanBuilder when the plan is built
-            self._make_side_queue()
+            self._make_side_queue()      # (MI_WGRAD_ASYNC is set around the plan build only: _state)
         model.train()
         self.params = model.ensure_params()
         self.world = dist.get_world_size() if dist.is_initialized() else 1
@@ -191,10 +190,13 @@ class NativeTrainer:
         if st is not None:
             return st
         env = self._ddp_build_env(mode) if self.world > 1 else {}
+        if self.side_groups > 0:
+            env = dict(env, MI_WGRAD_ASYNC=str(self.side_groups))      # PlanBuilder cuts the weight gradients into that many groups
         prev = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
-            ps = self.model.plan_for(B, H, W, True, input_u8=self.input_u8, variant="ddp-exposed" if mode == "exposed" else "")
+            variant = "ddp-exposed" if mode == "exposed" else (f"side{self.side_groups}" if self.side_groups > 0 else "")
+            ps = self.model.plan_for(B, H, W, True, input_u8=self.input_u8, variant=variant)
         finally:
             for k, v in prev.items():
                 if v is None:
@@ -229,7 +231,7 @@ class NativeTrainer:
             st["red"].reduce_bucket(bucket)
         st["red"].wait()
 
-    def _choose_ddp_schedule(self, st, rounds=3, reps=4):
+    def _choose_ddp_schedule(self, st, rounds=3, reps=3):
         """MI_DDP_OVERLAP=auto: `st` is the overlap candidate after its first (eager) step.  Builds the exposed candidate for
         the same batch, runs its forward + backward once, captures both, then times `reps` backward passes WITH their
         all-reduces per round, candidates alternating; each candidate's best round, maximum over ranks, decides.  Only
