@@ -133,3 +133,73 @@ def test_stream_rejects_what_it_cannot_do():
     d = _desc(x, 64, 0, 2, 13, 13, 64, w, y, 64, 0, 64)
     L.check(L.lib().mi_conv2d(C.byref(d), sp()), "conv2d")
     torch.cuda.synchronize()
+
+
+EPI_CASES = [
+    # N, H, W, K, Cout, x extra, y extra, aux extra
+    (4, 40, 56, 64, 256, 0, 0, 0),        # ResNet res2 conv3 / shortcut (K 64 -> 256), two cout tiles
+    (4, 40, 56, 256, 64, 0, 0, 0),        # res2 conv1 (256 -> 64)
+    (2, 40, 64, 128, 512, 128, 64, 32),   # res3 conv3 on channel-slice views, four cout tiles
+    (2, 40, 64, 512, 128, 0, 0, 0),       # res3 conv1 / data gradient of conv3 (K 512: 64-pixel tiles)
+    (2, 32, 32, 32, 32, 0, 0, 0),         # WM 1
+]
+
+
+@pytest.mark.parametrize("mode", ["bias", "bias_relu", "relu", "addrelu", "addrelu_nobias", "relumask"])
+@pytest.mark.parametrize("case", EPI_CASES, ids=[f"{c[0]}x{c[1]}x{c[2]}_K{c[3]}_Co{c[4]}" for c in EPI_CASES])
+def test_stream_epilogues_match_tile_kernel(case, mode, monkeypatch):
+    """MODE 4 / 5 (round 6): fp32 bias, ReLU, residual-add + ReLU (MI_CONV_ADDRELU) and the ReLU mask of a data gradient
+    (MI_CONV_RELUMASK) in the streaming kernel's epilogue - the detectron2 Conv2d + FrozenBatchNorm2d (+ ReLU / + shortcut)
+    layers of the ResNet bottlenecks (modeling/resnet.py) with K <= 512, Cout <= 512 - bit-identical to the tile kernel's
+    epilogues (same MFMA order over K, same roundings) and within bf16 tolerance of fp32 torch"""
+    N, H, W, K, Cout, xe, ye, ae = case
+    g = torch.Generator().manual_seed(hash((N, H, K, Cout)) & 0xFFFF)
+    npix = N * H * W
+    xbuf = torch.randn(npix, K + xe, generator=g).to(DEV, torch.bfloat16)
+    w = (torch.randn(Cout, K, 1, 1, generator=g) / K ** 0.5).to(DEV)
+    wf = _pack(w)
+    bias = torch.randn(Cout, generator=g).to(DEV) if "nobias" not in mode and mode not in ("relu", "relumask") else None
+    aux = torch.randn(npix, Cout + ae, generator=g).to(DEV, torch.bfloat16) if mode in ("addrelu", "addrelu_nobias", "relumask") else None
+    flags = {"bias": 0, "bias_relu": L.MI_CONV_RELU, "relu": L.MI_CONV_RELU, "addrelu": L.MI_CONV_ADDRELU,
+             "addrelu_nobias": L.MI_CONV_ADDRELU, "relumask": L.MI_CONV_RELUMASK}[mode]
+
+    def run(stream):
+        y = torch.full((npix, Cout + ye), 3.0, dtype=torch.bfloat16, device=DEV)
+        d = _desc(xbuf, K + xe, xe, N, H, W, K, wf, y, Cout + ye, ye, Cout, flags=flags)
+        if bias is not None:
+            d.bias = bias.data_ptr()
+        if aux is not None:
+            d.bn_y, d.bn_ldy = aux.data_ptr() + ae * 2, Cout + ae
+        if stream:
+            L.check(L.lib().mi_conv1x1_stream(C.byref(d), 1, sp()), "conv1x1_stream")
+        else:
+            monkeypatch.setenv("MI_CONV_STREAM", "0")
+            L.check(L.lib().mi_conv2d(C.byref(d), sp()), "conv2d")
+            monkeypatch.delenv("MI_CONV_STREAM")
+        torch.cuda.synchronize()
+        return y
+
+    a, b = run(True), run(False)
+    assert torch.equal(a[:, :ye], b[:, :ye]) and torch.all(a[:, :ye] == 3.0)
+    assert torch.equal(a[:, ye:], b[:, ye:]), float((a[:, ye:].float() - b[:, ye:].float()).abs().max())
+    ref = xbuf[:, xe:].float() @ w.view(Cout, K).to(torch.bfloat16).float().t()
+    if bias is not None:
+        ref = ref + bias
+    if flags & L.MI_CONV_RELU:
+        ref = ref.clamp(min=0)
+    if flags & L.MI_CONV_ADDRELU:
+        ref = (ref.to(torch.bfloat16).float() + aux[:, ae:].float()).clamp(min=0)
+    if flags & L.MI_CONV_RELUMASK:
+        ref = ref * (aux[:, ae:].float() > 0)
+    err = float((a[:, ye:].float() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-2, err
+    # and mi_conv2d routes such a descriptor to the streaming kernel by itself (MI_CONV_STREAM_EPI=0 would keep the tile kernel)
+    y2 = torch.full((npix, Cout + ye), 3.0, dtype=torch.bfloat16, device=DEV)
+    d = _desc(xbuf, K + xe, xe, N, H, W, K, wf, y2, Cout + ye, ye, Cout, flags=flags)
+    if bias is not None:
+        d.bias = bias.data_ptr()
+    if aux is not None:
+        d.bn_y, d.bn_ldy = aux.data_ptr() + ae * 2, Cout + ae
+    L.check(L.lib().mi_conv2d(C.byref(d), sp()), "conv2d (routed)")
+    torch.cuda.synchronize()
+    assert torch.equal(y2, a)

@@ -23,6 +23,11 @@
 // BatchNorm(train) + SiLU (+ residual) of the block's OWN output tiles (conv_bn.h): scale / shift come from the finished
 // fp64 sums, every lane re-reads the 16-byte pieces it stored itself (same CU, same L2: no cross-XCD coherence needed) and
 // writes the activation.  The whole BaseConv forward (layers/wrappers.py:76-83) in one launch.
+// MODE 4 (round 6): plain store with an fp32 bias and an optional ReLU in the epilogue (detectron2 Conv2d + FrozenBatchNorm2d
+// (+ ReLU) of the ResNet bottlenecks: the folded shift is the bias); MODE 5: MODE 4's bias, then the second tensor `aux` at
+// the output pixels - requested and waited for exactly like MODE 2's old values - as the residual under a ReLU
+// (MI_CONV_ADDRELU: conv3 + shortcut + ReLU) or as the ReLU mask of a data gradient (MI_CONV_RELUMASK).  Same arithmetic
+// and roundings as the tile kernel's epilogues (conv_igemm_kernel.h).
 // XF 1 (with MODE 1): x is the RAW output of the producing convolution; its BatchNorm(train) + SiLU runs here, on the x tile
 // in LDS, by the wave that fetched the piece (conv_bn.h, BnXf); the blocks of cout tile 0 store the activated tile.
 #pragma once
@@ -37,6 +42,9 @@ struct C1Slice {
   double* stats;    // fp64 accumulators of the slice's first channel, slot 0 ([slot][sld / 2][2]); MODE 1 only
   int wld, ldy, sld, nslots;
   int bnj, c0;      // MODE 3: the slice's convolution (index into C1K::bn) and its first channel inside that convolution
+  const float* bias;   // MODE 4 / 5: fp32 bias of the slice's first channel (NULL: none)
+  const __bf16* aux;   // MODE 5: second tensor at the output pixels, the slice's first channel (ReLU mask / residual)
+  int ldaux, pad2_;
 };
 struct C1K {
   const __bf16* x;
@@ -46,6 +54,7 @@ struct C1K {
   CBnFwd bn[C1_MAX_BN];       // MODE 3
   const BnXf* xf;             // XF launches: BatchNorm + activation of the input (device record)
   int xfw, pad_;              // xfw: store the activated input (cout tile 0's blocks do it)
+  int relu, epi;              // MODE 4: max(., 0) after the bias; MODE 5: 1 = relu(bf16(conv + bias) + aux), 2 = (aux > 0) ? conv : 0
 };
 struct C1Launch {
   int K, WM, PT, NBUF, MODE, grid, lds, XF;
@@ -77,7 +86,9 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
   constexpr int RBSH = K >= 128 ? 0 : (K == 64 ? 1 : 2);     // log2(pixel rows per 256-byte bank row)
   constexpr int SWM = KC8 - 1 < 15 ? KC8 - 1 : 15;           // swizzle mask (16-byte slots of a bank row)
   constexpr int S = 2 * PT;                                  // 16-byte stores per wave and tile
-  constexpr int L = MODE == 2 ? 2 * PT : 0;                  // old-value loads per wave and tile
+  constexpr bool AUXM = MODE == 2 || MODE == 5;              // a second tensor is read at the output pixels
+  constexpr bool BIASM = MODE >= 4;
+  constexpr int L = AUXM ? 2 * PT : 0;                       // old-value / aux loads per wave and tile
   // VMEM operations newer than tile i's DMA when iteration i waits for it (queue per iteration: OLD, DMA, ST)
   constexpr int W0 = (NBUF - 2) * D + L;
   constexpr int W1 = NBUF > 2 ? (NBUF - 2) * D + (S + L) + L : (S + L);
@@ -150,6 +161,20 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
 #pragma unroll
   for (int j = 0; j < PT; ++j) yoff[j] = (unsigned)(((wn * PT + j) * 32 + l31) * ldyb + h * 16);
   const size_t ytile = (size_t)TPIX * (size_t)ldyb;
+  // MODE 5: the second tensor, addressed like y with its own pixel stride
+  const int ldab5 = MODE == 5 ? sl.ldaux * 2 : 0;
+  unsigned aoff5[PT];
+#pragma unroll
+  for (int j = 0; j < PT; ++j) aoff5[j] = (unsigned)(((wn * PT + j) * 32 + l31) * ldab5 + h * 16);
+  const size_t atile5 = (size_t)TPIX * (size_t)ldab5;
+  float bs[BIASM ? 16 : 1];      // bias of this lane's channels 8 q + 4 h + e (accumulator order)
+  if constexpr (BIASM) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bs[4 * q + e] = sl.bias ? sl.bias[8 * q + 4 * h + e] : 0.f;
+  }
+  const bool relu4 = BIASM && p.relu != 0;
 
   float s1[16], s2[16];
   if constexpr (STATS) {
@@ -182,6 +207,14 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
       for (int j = 0; j < PT; ++j) {
         asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(old[j * 2]) : "v"(yoff[j]), "s"(yt) : "memory");
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=v"(old[j * 2 + 1]) : "v"(yoff[j]), "s"(yt) : "memory");
+      }
+    }
+    if constexpr (MODE == 5) {
+      const char* const at5 = (const char*)sl.aux + (size_t)(b + i * nb) * atile5;
+#pragma unroll
+      for (int j = 0; j < PT; ++j) {
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(old[j * 2]) : "v"(aoff5[j]), "s"(at5) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=v"(old[j * 2 + 1]) : "v"(aoff5[j]), "s"(at5) : "memory");
       }
     }
     if (XF && xf_a) {
@@ -229,7 +262,7 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
       for (int j = 0; j < PT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], bf[j], acc[j], 0, 0, 0);
     }
 
-    if constexpr (MODE == 2) {
+    if constexpr (AUXM) {
       // the old values were requested before this tile's DMA: D newer operations may stay in flight
       if constexpr (PT == 1)
         asm volatile("s_waitcnt vmcnt(%2)" : "+v"(old[0]), "+v"(old[1]) : "n"(D) : "memory");
@@ -243,7 +276,15 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
       for (int q = 0; q < 4; ++q) {
         bf16x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (__bf16)acc[j][4 * q + e];
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (BIASM) {
+            float v = acc[j][4 * q + e] + bs[4 * q + e];       // conv_igemm_kernel.h stage(): + bias, ReLU, then the bf16 rounding
+            if (relu4) v = fmaxf(v, 0.f);
+            o[e] = (__bf16)v;
+          } else {
+            o[e] = (__bf16)acc[j][4 * q + e];
+          }
+        }
         if constexpr (STATS) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -263,6 +304,18 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
         const auto w0 = __builtin_amdgcn_permlane32_swap(pk[2 * q0], pk[2 * q1], false, false);
         const auto w1 = __builtin_amdgcn_permlane32_swap(pk[2 * q0 + 1], pk[2 * q1 + 1], false, false);
         u32x4 v = {w0[0], w1[0], w0[1], w1[1]};
+        if constexpr (MODE == 5) {
+          const bf16x8 nv = __builtin_bit_cast(bf16x8, v), ov = __builtin_bit_cast(bf16x8, old[j * 2 + pr]);
+          bf16x8 rv;
+          if (p.epi == 1) {      // relu(bf16(conv + residual)): the rounding of mi_ew_bf16 op 7 / the tile kernel's MI_CONV_ADDRELU
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rv[e] = (__bf16)fmaxf((float)(__bf16)((float)nv[e] + (float)ov[e]), 0.f);
+          } else {               // dy * (a > 0): mi_ew_bf16 op 2 / MI_CONV_RELUMASK
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rv[e] = (float)ov[e] > 0.f ? nv[e] : (__bf16)0.f;
+          }
+          v = __builtin_bit_cast(u32x4, rv);
+        }
         if constexpr (MODE == 2) {
           // same double rounding as the tile kernel's accumulate path: bf16(result), then bf16(that + old)
           const bf16x8 nv = __builtin_bit_cast(bf16x8, v), ov = __builtin_bit_cast(bf16x8, old[j * 2 + pr]);

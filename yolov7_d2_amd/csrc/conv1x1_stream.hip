@@ -11,6 +11,8 @@ int c1s_launch_mode1(const C1Launch& l, hipStream_t s);
 int c1s_launch_mode1x(const C1Launch& l, hipStream_t s);
 int c1s_launch_mode2(const C1Launch& l, hipStream_t s);
 int c1s_launch_mode3(const C1Launch& l, hipStream_t s);
+int c1s_launch_mode4(const C1Launch& l, hipStream_t s);
+int c1s_launch_mode5(const C1Launch& l, hipStream_t s);
 int c1s_bar_status(unsigned* flag);
 
 static int c1s_cus() {
@@ -24,14 +26,23 @@ static int c1s_cus() {
   return cus;
 }
 
-// what the kernel cannot do stays on the tile kernel: taps, strides, fp32 outputs, bias, ragged channel counts
+// what the kernel cannot do stays on the tile kernel: taps, strides, fp32 outputs, ragged channel counts
 static bool c1s_desc_ok(const mi_conv_desc* d) {
   const int K = d->K8 * 8;
   if (d->ntaps != 1 || d->tap_dy[0] != 0 || d->tap_dx[0] != 0) return false;
   if (d->in_stride != 1 || d->out_stride != 1 || d->out_oy || d->out_ox) return false;
   if (d->gridH != d->outH || d->gridW != d->outW || d->outH != d->H || d->outW != d->W) return false;
-  if (d->flags & ~MI_CONV_ACCUM) return false;
-  if (d->bias) return false;
+  // round 6: bias / ReLU (MODE 4) and the aux-tensor epilogues (MODE 5) - MI_CONV_STREAM_EPI=0 keeps those on the tile kernel
+  static const int epi_ok = getenv("MI_CONV_STREAM_EPI") ? atoi(getenv("MI_CONV_STREAM_EPI")) : 1;
+  const int epf = MI_CONV_RELU | MI_CONV_ADDRELU | MI_CONV_RELUMASK;
+  if (d->flags & ~(MI_CONV_ACCUM | epf)) return false;
+  if ((d->flags & epf) || d->bias) {
+    if (!epi_ok || (d->flags & MI_CONV_ACCUM) || d->stats_acc || d->xf) return false;
+    const int aux = d->flags & (MI_CONV_ADDRELU | MI_CONV_RELUMASK);
+    if (aux == (MI_CONV_ADDRELU | MI_CONV_RELUMASK) || (aux && (d->flags & MI_CONV_RELU))) return false;
+    if (aux && (!d->bn_y || d->bn_ldy % 8 || ((uintptr_t)d->bn_y & 15) ||
+                (long long)d->N * d->H * d->W * d->bn_ldy * 2 >= (1LL << 31))) return false;
+  }
   if (!(K == 32 || K == 64 || K == 128 || K == 256 || K == 512)) return false;
   if (d->Cout != d->CoutPad || d->Cout % 32) return false;
   if (d->ldx % 8 || d->ldy % 8 || ((uintptr_t)d->x & 15) || ((uintptr_t)d->y & 15) || ((uintptr_t)d->w & 15)) return false;
@@ -74,7 +85,7 @@ static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l, const mi_bn_job
     const mi_conv_desc& d = ds[j];
     if (!c1s_desc_ok(&d)) return false;
     if (d.x != d0.x || d.ldx != d0.ldx || d.N != d0.N || d.H != d0.H || d.W != d0.W || d.K8 != d0.K8) return false;
-    if ((d.flags & MI_CONV_ACCUM) != (d0.flags & MI_CONV_ACCUM) || (d.stats_acc != nullptr) != (d0.stats_acc != nullptr)) return false;
+    if (d.flags != d0.flags || (d.stats_acc != nullptr) != (d0.stats_acc != nullptr)) return false;
     if (d.xf != d0.xf || (d.xf && (d.xf_C != d.K8 * 8 || ((uintptr_t)d.xf & 7)))) return false;   // one input tensor, one record
     ns += d.Cout / 32;
   }
@@ -95,6 +106,10 @@ static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l, const mi_bn_job
   memset(l, 0, sizeof(*l));
   l->K = K; l->WM = WM; l->PT = PT; l->NBUF = c1s_nbuf(K, tpix);
   l->MODE = (d0.flags & MI_CONV_ACCUM) ? 2 : (d0.stats_acc ? 1 : 0);
+  bool any_bias = false;
+  for (int j = 0; j < n; ++j) any_bias = any_bias || ds[j].bias != nullptr;
+  if (d0.flags & (MI_CONV_ADDRELU | MI_CONV_RELUMASK)) l->MODE = 5;
+  else if (any_bias || (d0.flags & MI_CONV_RELU)) l->MODE = 4;
   if (bn) {
     if (l->MODE != 1) return false;
     l->MODE = 3;
@@ -109,6 +124,8 @@ static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l, const mi_bn_job
   k.x = (const __bf16*)d0.x;
   k.ldx = d0.ldx;
   k.xf = (const BnXf*)d0.xf;
+  k.relu = (d0.flags & MI_CONV_RELU) ? 1 : 0;
+  k.epi = (d0.flags & MI_CONV_ADDRELU) ? 1 : ((d0.flags & MI_CONV_RELUMASK) ? 2 : 0);
   for (int j = 0; j < n; ++j) k.xfw |= (xf && ds[j].xf_write) ? 1 : 0;
   k.ntiles = (int)(npix / tpix);
   k.nco = nco;
@@ -142,6 +159,9 @@ static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l, const mi_bn_job
       s.nslots = nsl;
       s.bnj = j;
       s.c0 = c;
+      s.bias = d.bias ? d.bias + c : nullptr;
+      s.aux = (d.flags & (MI_CONV_ADDRELU | MI_CONV_RELUMASK)) ? (const __bf16*)d.bn_y + c : nullptr;
+      s.ldaux = d.bn_ldy;
     }
     if (bn && !cbn_from_job(d, bn[j], &k.bn[j])) return false;
   }
@@ -153,6 +173,8 @@ static int c1s_run(const C1Launch& l, hipStream_t s) {
     case 0: return c1s_launch_mode0(l, s);
     case 1: return l.XF ? c1s_launch_mode1x(l, s) : c1s_launch_mode1(l, s);
     case 3: return c1s_launch_mode3(l, s);
+    case 4: return c1s_launch_mode4(l, s);
+    case 5: return c1s_launch_mode5(l, s);
     default: return c1s_launch_mode2(l, s);
   }
 }
