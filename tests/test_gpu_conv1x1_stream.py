@@ -58,6 +58,8 @@ CASES = [
     (16, 40, 40, 256, [128, 128], 256, 0),
     (8, 80, 80, 64, [256], 0, 0),          # K 64 -> 256, two cout tiles
     (16, 20, 20, 256, [512], 0, 0),        # four cout tiles
+    (4, 50, 84, 256, [256], 0, 0),         # round 6: 16 800 pixels - a ragged last tile (plain / accumulate only)
+    (4, 50, 84, 128, [1024], 128, 0),      # ... and 1024 output channels: two launches of 512 over the same input
 ]
 
 
@@ -65,6 +67,8 @@ CASES = [
 @pytest.mark.parametrize("case", CASES, ids=[f"{c[0]}x{c[1]}x{c[2]}_K{c[3]}_Co{'+'.join(map(str, c[4]))}" for c in CASES])
 def test_stream_matches_tile_kernel(case, mode, monkeypatch):
     N, H, W, K, couts, xextra, yextra = case
+    if mode == "stats" and ((N * H * W) % 64 or sum(couts) > 512):
+        pytest.skip("statistics launches need whole pixel tiles and one slice table")
     g = torch.Generator().manual_seed(hash((N, H, K, sum(couts))) & 0xFFFF)
     npix = N * H * W
     ldx = K + xextra
@@ -125,8 +129,13 @@ def test_stream_rejects_what_it_cannot_do():
     w = _pack(torch.zeros(64, 64, 1, 1, device=DEV))
     y = torch.zeros(2 * 13 * 13, 64, dtype=torch.bfloat16, device=DEV)
     d = _desc(x, 64, 0, 2, 13, 13, 64, w, y, 64, 0, 64)
-    assert L.lib().mi_conv1x1_stream(C.byref(d), 1, sp()) < 0     # 338 pixels: not a multiple of 128
+    assert L.lib().mi_conv1x1_stream(C.byref(d), 1, sp()) < 0     # 338 pixels: a ragged map below MI_C1S_RAGGED_MINPIX
     assert b"conv1x1_stream" in L.lib().mi_last_error()
+    st = torch.zeros(8, 64, 2, dtype=torch.float64, device=DEV)
+    xr = torch.zeros(9797, 64, dtype=torch.bfloat16, device=DEV)
+    yr = torch.zeros(9797, 64, dtype=torch.bfloat16, device=DEV)
+    d = _desc(xr, 64, 0, 1, 97, 101, 64, w, yr, 64, 0, 64, st, 8)
+    assert L.lib().mi_conv1x1_stream(C.byref(d), 1, sp()) < 0     # statistics over a ragged map: not served
     d = _desc(x, 64, 0, 1, 16, 16, 64, w, y, 64, 0, 64, flags=L.MI_CONV_OUT_F32)
     assert L.lib().mi_conv1x1_stream(C.byref(d), 1, sp()) < 0
     # ... and mi_conv2d itself still serves such shapes on the tile kernel
@@ -142,6 +151,9 @@ EPI_CASES = [
     (2, 40, 64, 128, 512, 128, 64, 32),   # res3 conv3 on channel-slice views, four cout tiles
     (2, 40, 64, 512, 128, 0, 0, 0),       # res3 conv1 / data gradient of conv3 (K 512: 64-pixel tiles)
     (2, 32, 32, 32, 32, 0, 0, 0),         # WM 1
+    (4, 50, 84, 256, 1024, 0, 0, 0),      # res4 conv3 at 800 x 1333: 16 800 pixels (ragged last tile), 1024 channels = two launches
+    (4, 50, 84, 512, 256, 0, 0, 0),       # ragged, K 512
+    (1, 97, 101, 64, 2048, 64, 32, 0),    # 9 797 pixels, 2048 channels = four launches, slice views
 ]
 
 

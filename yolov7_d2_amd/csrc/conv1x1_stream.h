@@ -55,6 +55,7 @@ struct C1K {
   const BnXf* xf;             // XF launches: BatchNorm + activation of the input (device record)
   int xfw, pad_;              // xfw: store the activated input (cout tile 0's blocks do it)
   int relu, epi;              // MODE 4: max(., 0) after the bias; MODE 5: 1 = relu(bf16(conv + bias) + aux), 2 = (aux > 0) ? conv : 0
+  int npix, ragged;           // ragged 1 (MODE 0 / 2 / 4 / 5): the last pixel tile holds npix - (ntiles - 1) * TPIX < TPIX pixels
 };
 struct C1Launch {
   int K, WM, PT, NBUF, MODE, grid, lds, XF;
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
   constexpr int SWM = KC8 - 1 < 15 ? KC8 - 1 : 15;           // swizzle mask (16-byte slots of a bank row)
   constexpr int S = 2 * PT;                                  // 16-byte stores per wave and tile
   constexpr bool AUXM = MODE == 2 || MODE == 5;              // a second tensor is read at the output pixels
+  constexpr bool RAGGED_OK = (MODE == 0 || MODE == 2 || MODE == 4 || MODE == 5) && !XF;   // (no statistics over pad pixels)
   constexpr bool BIASM = MODE >= 4;
   constexpr int L = AUXM ? 2 * PT : 0;                       // old-value / aux loads per wave and tile
   // VMEM operations newer than tile i's DMA when iteration i waits for it (queue per iteration: OLD, DMA, ST)
@@ -143,6 +145,19 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
     // line for the whole wave), so that the counted waits keep their meaning
     const bool live = i < nt;
     const char* xt = live ? (const char*)p.x + (size_t)(b + i * nb) * xtile : (const char*)g_c1_zero_page;
+    if (RAGGED_OK && live && p.ragged && b + i * nb == p.ntiles - 1) {
+      // the partial last tile: rows past the end fetch the tile's row 0 instead (their results are never stored, and a
+      // pixel's output depends on its own row only)
+      const int lim = p.npix - (p.ntiles - 1) * TPIX;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int q = wave * D + d;
+        const int row = q * RPI + (KC8 >= 64 ? 0 : lane / KC8);
+        const int c = KC8 >= 64 ? lane : lane % KC8;
+        c1_glds16(xt, row < lim ? doff[d] : (unsigned)(c << 4), lds0 + buf * XB + (wave * D + d) * 1024);
+      }
+      return;
+    }
 #pragma unroll
     for (int d = 0; d < D; ++d) c1_glds16(xt, live ? doff[d] : 0u, lds0 + buf * XB + (wave * D + d) * 1024);
   };
@@ -201,20 +216,28 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
   int buf = 0, nbuf = NBUF - 1;   // ring slots of tile i / tile i + NBUF - 1
   for (int i = 0; i < nt; ++i) {
     char* const yt = (char*)sl.y + (size_t)(b + i * nb) * ytile;
+    // pixels of this tile that exist (TPIX except in a ragged launch's last tile); lanes past it read pixel 0's old / aux
+    // values (in bounds, discarded) and store nothing
+    int lim = TPIX;
+    if constexpr (RAGGED_OK) {
+      if (p.ragged && b + i * nb == p.ntiles - 1) lim = p.npix - (p.ntiles - 1) * TPIX;
+    }
     u32x4 old[2 * PT];
     if constexpr (MODE == 2) {
 #pragma unroll
       for (int j = 0; j < PT; ++j) {
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(old[j * 2]) : "v"(yoff[j]), "s"(yt) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=v"(old[j * 2 + 1]) : "v"(yoff[j]), "s"(yt) : "memory");
+        const unsigned yo = ((wn * PT + j) * 32 + l31) < lim ? yoff[j] : (unsigned)(h * 16);
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(old[j * 2]) : "v"(yo), "s"(yt) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=v"(old[j * 2 + 1]) : "v"(yo), "s"(yt) : "memory");
       }
     }
     if constexpr (MODE == 5) {
       const char* const at5 = (const char*)sl.aux + (size_t)(b + i * nb) * atile5;
 #pragma unroll
       for (int j = 0; j < PT; ++j) {
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(old[j * 2]) : "v"(aoff5[j]), "s"(at5) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=v"(old[j * 2 + 1]) : "v"(aoff5[j]), "s"(at5) : "memory");
+        const unsigned ao = ((wn * PT + j) * 32 + l31) < lim ? aoff5[j] : (unsigned)(h * 16);
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(old[j * 2]) : "v"(ao), "s"(at5) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=v"(old[j * 2 + 1]) : "v"(ao), "s"(at5) : "memory");
       }
     }
     if (XF && xf_a) {
@@ -324,7 +347,7 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
           for (int e = 0; e < 8; ++e) rv[e] = (__bf16)((float)nv[e] + (float)ov[e]);
           v = __builtin_bit_cast(u32x4, rv);
         }
-        *(u32x4*)(yt + yoff[j] + pr * 32) = v;
+        if (!RAGGED_OK || ((wn * PT + j) * 32 + l31) < lim) *(u32x4*)(yt + yoff[j] + pr * 32) = v;
       }
     }
     buf = buf + 1 == NBUF ? 0 : buf + 1;

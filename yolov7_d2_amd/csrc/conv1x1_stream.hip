@@ -76,9 +76,12 @@ bool cbn_from_job(const mi_conv_desc& d, const mi_bn_job& j, CBnFwd* o) {
 
 // n descriptors that read the same tensor -> one launch; returns false when the stream kernel does not apply.
 // bn (may be NULL): the BatchNorm jobs of the n convolutions -> MODE 3
-static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l, const mi_bn_job* bn = nullptr) {
+// c0 / cn (single descriptor only, cn > 0): the launch computes output channels [c0, c0 + cn) of the convolution - a layer
+// with more than 512 output channels runs as several launches over the same input (c1s_try_launch)
+static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l, const mi_bn_job* bn = nullptr, int c0 = 0, int cn = 0) {
   if (n < 1) return false;
   if (bn && n > C1_MAX_BN) return false;
+  if (cn > 0 && (n != 1 || bn || cn % 32 || c0 % 32 || c0 + cn > ds[0].Cout)) return false;
   const mi_conv_desc& d0 = ds[0];
   int ns = 0;
   for (int j = 0; j < n; ++j) {
@@ -87,7 +90,7 @@ static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l, const mi_bn_job
     if (d.x != d0.x || d.ldx != d0.ldx || d.N != d0.N || d.H != d0.H || d.W != d0.W || d.K8 != d0.K8) return false;
     if (d.flags != d0.flags || (d.stats_acc != nullptr) != (d0.stats_acc != nullptr)) return false;
     if (d.xf != d0.xf || (d.xf && (d.xf_C != d.K8 * 8 || ((uintptr_t)d.xf & 7)))) return false;   // one input tensor, one record
-    ns += d.Cout / 32;
+    ns += (cn > 0 ? cn : d.Cout) / 32;
   }
   if (ns > C1_MAX_SLICES) return false;
   const int K = d0.K8 * 8;
@@ -102,7 +105,7 @@ static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l, const mi_bn_job
     const bool fits = c1s_valid(K, 128), small = (npix / 128) * nco < 2 * c1s_cus();
     if (!fits || npix % 128 || (small && c1s_valid(K, 64))) { PT = 1; tpix = 64; }
   }
-  if (!c1s_valid(K, tpix) || npix % tpix) return false;
+  if (!c1s_valid(K, tpix)) return false;
   memset(l, 0, sizeof(*l));
   l->K = K; l->WM = WM; l->PT = PT; l->NBUF = c1s_nbuf(K, tpix);
   l->MODE = (d0.flags & MI_CONV_ACCUM) ? 2 : (d0.stats_acc ? 1 : 0);
@@ -110,6 +113,16 @@ static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l, const mi_bn_job
   for (int j = 0; j < n; ++j) any_bias = any_bias || ds[j].bias != nullptr;
   if (d0.flags & (MI_CONV_ADDRELU | MI_CONV_RELUMASK)) l->MODE = 5;
   else if (any_bias || (d0.flags & MI_CONV_RELU)) l->MODE = 4;
+  // a partial last pixel tile (round 6; the modes without statistics): maps whose pixel count is no multiple of the tile -
+  // detectron2's ResNet at 800 x 1333 (res4: 4 x 50 x 84 = 16 800 pixels).  Small ragged maps stay on the tile kernel
+  // (MI_C1S_RAGGED_MINPIX, default 8192: the transformer's token-row GEMMs, T = 4 368, measured no faster here)
+  bool ragged = false;
+  if (npix % tpix) {
+    static const long minpix = getenv("MI_C1S_RAGGED_MINPIX") ? atol(getenv("MI_C1S_RAGGED_MINPIX")) : 8192;
+    const bool mode_ok = l->MODE == 0 || l->MODE == 2 || l->MODE == 4 || l->MODE == 5;
+    if (!mode_ok || bn || d0.xf || minpix < 0 || npix < minpix || npix < tpix) return false;
+    ragged = true;
+  }
   if (bn) {
     if (l->MODE != 1) return false;
     l->MODE = 3;
@@ -127,7 +140,9 @@ static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l, const mi_bn_job
   k.relu = (d0.flags & MI_CONV_RELU) ? 1 : 0;
   k.epi = (d0.flags & MI_CONV_ADDRELU) ? 1 : ((d0.flags & MI_CONV_RELUMASK) ? 2 : 0);
   for (int j = 0; j < n; ++j) k.xfw |= (xf && ds[j].xf_write) ? 1 : 0;
-  k.ntiles = (int)(npix / tpix);
+  k.ntiles = (int)((npix + tpix - 1) / tpix);
+  k.npix = (int)npix;
+  k.ragged = ragged ? 1 : 0;
   k.nco = nco;
   // persistent grid: as many blocks as are resident at once (LDS-limited, at most 2 per CU), never more than tiles
   int per_cu = (160 * 1024) / l->lds;
@@ -148,7 +163,7 @@ static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l, const mi_bn_job
   for (int j = 0; j < n; ++j) {
     const mi_conv_desc& d = ds[j];
     const int nsl = (d.stats_slots >= 1 && d.stats_slots <= MI_BN_SLOTS) ? d.stats_slots : MI_BN_SLOTS;
-    for (int c = 0; c < d.Cout; c += 32, ++si) {
+    for (int c = c0; c < (cn > 0 ? c0 + cn : d.Cout); c += 32, ++si) {
       C1Slice& s = k.s[si];
       s.w = (const u32x4*)d.w + c;
       s.wld = d.CoutPad;
@@ -186,13 +201,25 @@ static bool c1s_enabled() {
 }
 
 // internal entry points for conv_igemm.hip
-bool c1s_try_launch(const mi_conv_desc* ds, int n, hipStream_t s, int* rc) {
-  if (!c1s_enabled()) return false;
+static bool c1s_launch_any(const mi_conv_desc* ds, int n, hipStream_t s, int* rc) {
   C1Launch l;
+  if (n == 1 && ds[0].Cout > 32 * C1_MAX_SLICES && ds[0].Cout % (32 * C1_MAX_SLICES) == 0 && !ds[0].stats_acc && !ds[0].xf) {
+    // more output channels than one launch's slice table holds (ResNet conv3 / shortcut: 1024, 2048): 512 at a time, each
+    // launch streaming the (4 - 16 x smaller) input again.  All or nothing: the first chunk decides
+    const int step = 32 * C1_MAX_SLICES;
+    if (!c1s_fill(ds, 1, &l, nullptr, 0, step)) return false;
+    *rc = c1s_run(l, s);
+    for (int c = step; c < ds[0].Cout && *rc == MI_OK; c += step) {
+      if (!c1s_fill(ds, 1, &l, nullptr, c, step)) { *rc = MI_EINVAL; break; }
+      *rc = c1s_run(l, s);
+    }
+    return true;
+  }
   if (!c1s_fill(ds, n, &l)) return false;
   *rc = c1s_run(l, s);
   return true;
 }
+bool c1s_try_launch(const mi_conv_desc* ds, int n, hipStream_t s, int* rc) { return c1s_enabled() && c1s_launch_any(ds, n, s, rc); }
 bool c1s_try_plan(const mi_conv_desc* ds, int n, C1Launch* l) { return c1s_enabled() && c1s_fill(ds, n, l); }
 bool c1s_try_plan_bn(const mi_conv_desc* ds, const mi_bn_job* bn, int n, C1Launch* l) { return c1s_enabled() && c1s_fill(ds, n, l, bn); }
 int c1s_barrier_status(unsigned* flag) { return c1s_bar_status(flag); }
@@ -200,9 +227,10 @@ int c1s_run_planned(const C1Launch* l, hipStream_t s) { return c1s_run(*l, s); }
 
 extern "C" int mi_conv1x1_stream(const mi_conv_desc* descs, int n, mi_stream_t st) {
   MI_REQUIRE(descs && n >= 1, "conv1x1_stream: null");
-  C1Launch l;
-  MI_REQUIRE(c1s_fill(descs, n, &l),
-             "conv1x1_stream: needs 1x1 stride-1 bf16 convs of one input with K in {32..512}, Cout %% 32 == 0, no bias, "
-             "N*H*W a multiple of the pixel tile");
-  return c1s_run(l, (hipStream_t)st);
+  int rc = MI_OK;
+  const bool ok = c1s_launch_any(descs, n, (hipStream_t)st, &rc);      // (the explicit entry does not honour the routing switch)
+  MI_REQUIRE(ok,
+             "conv1x1_stream: needs 1x1 stride-1 bf16 convs of one input with K in {32..512}, Cout %% 32 == 0 (at most 512 together, "
+             "or one convolution with a multiple of 512), statistics / BatchNorm modes with N*H*W a multiple of the pixel tile");
+  return rc;
 }
