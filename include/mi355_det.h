@@ -162,9 +162,12 @@ int mi_conv2d_bn_fwd(const mi_conv_desc* descs, const struct mi_bn_job* bn, int 
 int mi_conv_bn_barrier_status(uint32_t* flags);
 
 /* streaming 1x1 convolution (csrc/conv1x1_stream.h): n >= 1 bf16 1x1 stride-1 convolutions that read the SAME input
- * view (x, ldx, N, H, W, K8 equal; K in {32, 64, 128, 256, 512}; Cout == CoutPad, a multiple of 32; no bias; all with
- * stats_acc, all with MI_CONV_ACCUM, or all plain) as one persistent launch: weights stay in registers, the input is
- * read once, BatchNorm statistics leave as one set of atomics per block.  Replaces the 1x1 nn.Conv2d forward / data
+ * view (x, ldx, N, H, W, K8 equal; K in {32, 64, 128, 256, 512}; Cout == CoutPad, a multiple of 32; all with stats_acc,
+ * all with MI_CONV_ACCUM, or all plain) as one persistent launch: weights stay in registers, the input is read once,
+ * BatchNorm statistics leave as one set of atomics per block.  Round 6: descriptors with an fp32 bias, MI_CONV_RELU,
+ * MI_CONV_ADDRELU or MI_CONV_RELUMASK (the same flags for all n; bn_y / bn_ldy = the second tensor) are served too, and -
+ * for the launches without statistics - pixel counts N * H * W that are no multiple of the pixel tile (>= 8192 pixels) and
+ * ONE convolution with more than 512 output channels (a multiple of 512: 512 at a time).  Replaces the 1x1 nn.Conv2d forward / data
  * gradient of CSPLayer / Bottleneck / SPP / head stems (layers/wrappers.py:60-83,150-197).  mi_conv2d and
  * mi_conv2d_group_plan take this path by themselves for eligible descriptors (MI_CONV_STREAM=0 disables that);
  * this entry returns MI_EINVAL instead of falling back. */
