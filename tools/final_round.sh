@@ -1,7 +1,7 @@
 #!/bin/bash
 # on the GPU box: the round's evidence in one call -> gpurun_out/final_<tag>/   usage: tools/final_round.sh <tag> [skip-tests]
 set -u
-TAG=${1:-r05i}; SKIP=${2:-}
+TAG=${1:-r06}; SKIP=${2:-}
 O=$GRAFT_REPO_ROOT/gpurun_out/final_$TAG; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 if [ -z "$SKIP" ]; then timeout 1500 python -m pytest tests/ -q -m gpu --durations=8 > $O/pytest_gpu.txt 2>&1; tail -2 $O/pytest_gpu.txt; fi
