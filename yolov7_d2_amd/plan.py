@@ -769,6 +769,12 @@ class Plan:
         issues them as two branches of the captured graph, joined by the first convolution.  OPT-IN: measured SLOWER - 5.50 vs
         5.41 ms per step, four alternating pairs (profiles/r04_pack_async_ab.txt): one fork / join inside the hipGraph costs
         more than the ~45 us the overlap can save, like the head's branch experiment of round 1 (-3 %)."""
+        if os.environ.get("MI_PACK_LATE", "0") == "1" and len(pro) == 1 and pro[0].op == L.OP["PACK_W_BATCH"]:
+            # (A/B, round 6: the Focus packer takes 13 - 20 us alone and 41 us right behind the weight pack - does it matter who
+            #  follows the pack?  Order: Focus, pack, stem convolution)
+            k = next((i for i, c in enumerate(fwd) if c.op == L.OP["FOCUS"]), None)
+            if k is not None and all(c.op in (L.OP["MEMSET"], L.OP["FOCUS"]) for c in fwd[: k + 1]):
+                return fwd[: k + 1] + pro + fwd[k + 1:]
         if os.environ.get("MI_PACK_ASYNC", "0") != "1" or len(pro) != 1 or pro[0].op != L.OP["PACK_W_BATCH"]:
             return pro + fwd
         k = next((i for i, c in enumerate(fwd) if c.op == L.OP["FOCUS"]), None)
