@@ -691,3 +691,35 @@ def test_deferred_weight_gradient_that_autograd_copies_is_reported(monkeypatch):
     y = _LinearFn.apply(x, w2, b2)
     with pytest.raises((L.MI355Error, RuntimeError), match="did not take a deferred weight gradient"):
         y.float().sum().backward()
+
+
+def test_deferred_jobs_of_a_backward_pass_that_died_are_dropped(monkeypatch):
+    """a backward pass that raises between a node and its flush point leaves jobs pending; the next pass must neither write
+    them (their gradient tensors are gone) nor lose its own end-of-pass flush"""
+    from yolov7_d2_amd.modeling.transformer import _LinearFn
+    from yolov7_d2_amd.ops import WgradBatch
+    monkeypatch.setenv("MI_WGRAD_LAYER_GROUP", "1")
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(256, 64, generator=g).to(torch.bfloat16).to(DEV).requires_grad_(True)
+
+    class _Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, a):
+            return a.clone()
+
+        @staticmethod
+        def backward(ctx, gr):
+            raise RuntimeError("boom")
+
+    w = (torch.randn(96, 64, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    y = _LinearFn.apply(_Boom.apply(x), w, None)         # backward: the Linear registers its job, then the producer raises
+    with pytest.raises(RuntimeError, match="boom"):
+        y.float().sum().backward()
+    assert len(WgradBatch.pending) == 1 and WgradBatch.armed          # the dead pass left its job behind
+    w2 = (torch.randn(96, 64, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    y = _LinearFn.apply(x, w2, None)
+    y.float().sum().backward()
+    torch.cuda.synchronize()
+    assert not WgradBatch.pending and not WgradBatch.armed and not WgradBatch.owners
+    ref = x.detach().float().sum(0)[None, :].expand(96, 64)
+    torch.testing.assert_close(w2.grad, ref, rtol=2e-2, atol=2e-2)

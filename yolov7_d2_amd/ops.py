@@ -136,7 +136,8 @@ class WgradBatch:
     by a torch kernel before the deferred write - `add()` refuses to defer when .grad is already set.
     MI_WGRAD_LAYER_GROUP=0: every weight gradient as its own launch at its own node (round 5's form)."""
     pending = []        # (mi_wgrad_desc without workspace, keep-alive tensors)
-    armed = False       # an end-of-backward flush is queued for the running backward pass
+    armed = False       # an end-of-backward flush is queued for the running backward pass ...
+    armed_task = -1     # ... of this autograd graph task
     owners = []         # (parameter, address of its deferred gradient): checked when the backward pass ends
     # pinned host memory the job tables are copied from.  Eager steps use a RING (the stream is synchronised when it wraps:
     # once per ~2 000 groups); a graph capture takes its tables from append-only blocks that live as long as the process -
@@ -155,11 +156,17 @@ class WgradBatch:
     def add(cls, desc, keep, owner=None):
         """owner: the parameter whose gradient this job writes (checked at the end of the backward pass: autograd must have
         taken the returned tensor over as .grad, not copied it)"""
+        # one end-of-backward flush per autograd pass.  A pass that died with jobs pending (an exception between a node and
+        # its flush point) never ran its callback: its jobs point at gradients that no longer exist - dropped here, when the
+        # next pass registers its first job, instead of being written into whatever owns that memory now
+        task = torch._C._current_graph_task_id()
+        if cls.armed and task != cls.armed_task:
+            cls.pending, cls.owners, cls.armed = [], [], False
         cls.pending.append((desc, keep))
         if owner is not None:
             cls.owners.append((owner, int(desc.gw)))
         if not cls.armed:
-            cls.armed = True
+            cls.armed, cls.armed_task = True, task
             torch.autograd.Variable._execution_engine.queue_callback(cls._end_of_backward)
 
     @classmethod
