@@ -282,8 +282,12 @@ class NativeTrainer:
             self._states.pop(k)
         if mode == "exposed":
             st2["warm"] = True
+            # (the host-feed staging buffers are inputs, not plan state: they move over; the staged command lists, which
+            #  quote the other plan's forward list, are rebuilt on demand)
+            keep = {k: st[k] for k in ("stage", "stage_k") if k in st}
             st.clear()
             st.update(st2)                             # the caller's handle now IS the chosen state
+            st.update(keep)
         self._states[(B, H, W)] = st
 
     def _run_cmds(self, arr, lo, hi, sp):
