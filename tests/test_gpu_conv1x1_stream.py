@@ -157,7 +157,7 @@ EPI_CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", ["bias", "bias_relu", "relu", "addrelu", "addrelu_nobias", "relumask"])
+@pytest.mark.parametrize("mode", ["bias", "bias_relu", "relu", "addrelu", "addrelu_nobias", "relumask", "accum_relumask"])
 @pytest.mark.parametrize("case", EPI_CASES, ids=[f"{c[0]}x{c[1]}x{c[2]}_K{c[3]}_Co{c[4]}" for c in EPI_CASES])
 def test_stream_epilogues_match_tile_kernel(case, mode, monkeypatch):
     """MODE 4 / 5 (round 6): fp32 bias, ReLU, residual-add + ReLU (MI_CONV_ADDRELU) and the ReLU mask of a data gradient
@@ -170,10 +170,11 @@ def test_stream_epilogues_match_tile_kernel(case, mode, monkeypatch):
     xbuf = torch.randn(npix, K + xe, generator=g).to(DEV, torch.bfloat16)
     w = (torch.randn(Cout, K, 1, 1, generator=g) / K ** 0.5).to(DEV)
     wf = _pack(w)
-    bias = torch.randn(Cout, generator=g).to(DEV) if "nobias" not in mode and mode not in ("relu", "relumask") else None
-    aux = torch.randn(npix, Cout + ae, generator=g).to(DEV, torch.bfloat16) if mode in ("addrelu", "addrelu_nobias", "relumask") else None
+    bias = torch.randn(Cout, generator=g).to(DEV) if "nobias" not in mode and mode not in ("relu", "relumask", "accum_relumask") else None
+    aux = torch.randn(npix, Cout + ae, generator=g).to(DEV, torch.bfloat16) if mode in ("addrelu", "addrelu_nobias", "relumask", "accum_relumask") else None
     flags = {"bias": 0, "bias_relu": L.MI_CONV_RELU, "relu": L.MI_CONV_RELU, "addrelu": L.MI_CONV_ADDRELU,
-             "addrelu_nobias": L.MI_CONV_ADDRELU, "relumask": L.MI_CONV_RELUMASK}[mode]
+             "addrelu_nobias": L.MI_CONV_ADDRELU, "relumask": L.MI_CONV_RELUMASK,
+             "accum_relumask": L.MI_CONV_ACCUM | L.MI_CONV_RELUMASK}[mode]      # MODE 6: y = mask(bf16(bf16(conv) + y_old))
 
     def run(stream):
         y = torch.full((npix, Cout + ye), 3.0, dtype=torch.bfloat16, device=DEV)
@@ -201,6 +202,8 @@ def test_stream_epilogues_match_tile_kernel(case, mode, monkeypatch):
         ref = ref.clamp(min=0)
     if flags & L.MI_CONV_ADDRELU:
         ref = (ref.to(torch.bfloat16).float() + aux[:, ae:].float()).clamp(min=0)
+    if flags & L.MI_CONV_ACCUM:
+        ref = ref.to(torch.bfloat16).float() + 3.0                     # (the old values: y starts at 3.0 everywhere)
     if flags & L.MI_CONV_RELUMASK:
         ref = ref * (aux[:, ae:].float() > 0)
     err = float((a[:, ye:].float() - ref).abs().max() / ref.abs().max())

@@ -450,3 +450,38 @@ def test_frozen_bottleneck_add_relu_in_the_conv_epilogue_equals_the_separate_pas
     n = len(outs) // 2
     for a, b in zip(outs[:n], outs[n:]):
         assert torch.equal(a, b) and float(a.abs().max()) > 0
+
+
+def test_relu_mask_of_block_inputs_in_the_last_data_gradient_equals_the_separate_pass(monkeypatch):
+    """round 6: a bottleneck whose input is a ReLU output (every block of the ResNet) applies that ReLU's mask to its input
+    gradient in the epilogue of the last data gradient (MI_CONV_ACCUM | MI_CONV_RELUMASK: streaming kernel MODE 6 / tile kernel)
+    and the previous block skips its own mask pass - against the separate pass per block (MI_RESNET_MASK_FUSE=0): every
+    parameter gradient bit for bit, the chain's input gradient wherever the input is positive (where it is zero its producer
+    masks it anyway)"""
+    from yolov7_d2_amd.modeling.resnet import BottleneckBlock
+    from yolov7_d2_amd import modeling
+    res = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("MI_RESNET_MASK_FUSE", fuse)
+        torch.manual_seed(21)
+        chain = torch.nn.Sequential(BottleneckBlock(64, 256, 64, stride=1), BottleneckBlock(256, 256, 64), BottleneckBlock(256, 256, 64),
+                                    BottleneckBlock(256, 512, 128, stride=2), BottleneckBlock(512, 512, 128)).cuda()
+        for blk in chain:
+            blk.input_is_relu = True
+            for m in blk.modules():
+                if hasattr(m, "running_var"):
+                    m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.1); m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+        g = torch.Generator().manual_seed(13)
+        x = torch.randn(2, 64, 32, 64, generator=g).clamp(min=0).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        go = torch.randn(2, 512, 16, 32, generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+        y = chain(x)
+        y.backward(go)
+        torch.cuda.synchronize()
+        res.append((y.detach().float(), (x.grad.float() * (x.detach() > 0)), {k: p.grad.float() for k, p in chain.named_parameters() if p.grad is not None}))
+    (y0, dx0, g0), (y1, dx1, g1) = res
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1) and float(dx0.abs().max()) > 0
+    assert set(g0) == set(g1) and len(g0) == 17
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    from yolov7_d2_amd.modeling.resnet import _PREMASKED
+    assert len(_PREMASKED) <= 1          # (the chain input's entry: nothing consumed it; dropped by the next pass)

@@ -27,7 +27,8 @@
 // (+ ReLU) of the ResNet bottlenecks: the folded shift is the bias); MODE 5: MODE 4's bias, then the second tensor `aux` at
 // the output pixels - requested and waited for exactly like MODE 2's old values - as the residual under a ReLU
 // (MI_CONV_ADDRELU: conv3 + shortcut + ReLU) or as the ReLU mask of a data gradient (MI_CONV_RELUMASK).  Same arithmetic
-// and roundings as the tile kernel's epilogues (conv_igemm_kernel.h).
+// and roundings as the tile kernel's epilogues (conv_igemm_kernel.h).  MODE 6: MODE 2's accumulate, then the ReLU mask of the
+// sum from a third tensor (MI_CONV_ACCUM | MI_CONV_RELUMASK: the last data gradient of a ResNet bottleneck's input).
 // XF 1 (with MODE 1): x is the RAW output of the producing convolution; its BatchNorm(train) + SiLU runs here, on the x tile
 // in LDS, by the wave that fetched the piece (conv_bn.h, BnXf); the blocks of cout tile 0 store the activated tile.
 #pragma once
@@ -87,10 +88,10 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
   constexpr int RBSH = K >= 128 ? 0 : (K == 64 ? 1 : 2);     // log2(pixel rows per 256-byte bank row)
   constexpr int SWM = KC8 - 1 < 15 ? KC8 - 1 : 15;           // swizzle mask (16-byte slots of a bank row)
   constexpr int S = 2 * PT;                                  // 16-byte stores per wave and tile
-  constexpr bool AUXM = MODE == 2 || MODE == 5;              // a second tensor is read at the output pixels
-  constexpr bool RAGGED_OK = (MODE == 0 || MODE == 2 || MODE == 4 || MODE == 5) && !XF;   // (no statistics over pad pixels)
-  constexpr bool BIASM = MODE >= 4;
-  constexpr int L = AUXM ? 2 * PT : 0;                       // old-value / aux loads per wave and tile
+  constexpr bool AUXM = MODE == 2 || MODE == 5 || MODE == 6;  // a second (MODE 6: and a third) tensor is read at the output pixels
+  constexpr bool RAGGED_OK = (MODE == 0 || MODE == 2 || MODE >= 4) && !XF;   // (no statistics over pad pixels)
+  constexpr bool BIASM = MODE == 4 || MODE == 5;
+  constexpr int L = MODE == 6 ? 4 * PT : (AUXM ? 2 * PT : 0);   // old-value / aux loads per wave and tile
   // VMEM operations newer than tile i's DMA when iteration i waits for it (queue per iteration: OLD, DMA, ST)
   constexpr int W0 = (NBUF - 2) * D + L;
   constexpr int W1 = NBUF > 2 ? (NBUF - 2) * D + (S + L) + L : (S + L);
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
   for (int j = 0; j < PT; ++j) yoff[j] = (unsigned)(((wn * PT + j) * 32 + l31) * ldyb + h * 16);
   const size_t ytile = (size_t)TPIX * (size_t)ldyb;
   // MODE 5: the second tensor, addressed like y with its own pixel stride
-  const int ldab5 = MODE == 5 ? sl.ldaux * 2 : 0;
+  const int ldab5 = (MODE == 5 || MODE == 6) ? sl.ldaux * 2 : 0;
   unsigned aoff5[PT];
 #pragma unroll
   for (int j = 0; j < PT; ++j) aoff5[j] = (unsigned)(((wn * PT + j) * 32 + l31) * ldab5 + h * 16);
@@ -223,7 +224,8 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
       if (p.ragged && b + i * nb == p.ntiles - 1) lim = p.npix - (p.ntiles - 1) * TPIX;
     }
     u32x4 old[2 * PT];
-    if constexpr (MODE == 2) {
+    u32x4 aux6[MODE == 6 ? 2 * PT : 1];
+    if constexpr (MODE == 2 || MODE == 6) {
 #pragma unroll
       for (int j = 0; j < PT; ++j) {
         const unsigned yo = ((wn * PT + j) * 32 + l31) < lim ? yoff[j] : (unsigned)(h * 16);
@@ -238,6 +240,15 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
         const unsigned ao = ((wn * PT + j) * 32 + l31) < lim ? aoff5[j] : (unsigned)(h * 16);
         asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(old[j * 2]) : "v"(ao), "s"(at5) : "memory");
         asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=v"(old[j * 2 + 1]) : "v"(ao), "s"(at5) : "memory");
+      }
+    }
+    if constexpr (MODE == 6) {   // the ReLU mask of the accumulated sum, beside the old values
+      const char* const at5 = (const char*)sl.aux + (size_t)(b + i * nb) * atile5;
+#pragma unroll
+      for (int j = 0; j < PT; ++j) {
+        const unsigned ao = ((wn * PT + j) * 32 + l31) < lim ? aoff5[j] : (unsigned)(h * 16);
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(aux6[j * 2]) : "v"(ao), "s"(at5) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=v"(aux6[j * 2 + 1]) : "v"(ao), "s"(at5) : "memory");
       }
     }
     if (XF && xf_a) {
@@ -287,7 +298,14 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
 
     if constexpr (AUXM) {
       // the old values were requested before this tile's DMA: D newer operations may stay in flight
-      if constexpr (PT == 1)
+      if constexpr (MODE == 6) {
+        if constexpr (PT == 1)
+          asm volatile("s_waitcnt vmcnt(%4)" : "+v"(old[0]), "+v"(old[1]), "+v"(aux6[0]), "+v"(aux6[1]) : "n"(D) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(%8)"
+                       : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]), "+v"(aux6[0]), "+v"(aux6[1]), "+v"(aux6[2]), "+v"(aux6[3])
+                       : "n"(D) : "memory");
+      } else if constexpr (PT == 1)
         asm volatile("s_waitcnt vmcnt(%2)" : "+v"(old[0]), "+v"(old[1]) : "n"(D) : "memory");
       else
         asm volatile("s_waitcnt vmcnt(%4)" : "+v"(old[0]), "+v"(old[1]), "+v"(old[2]), "+v"(old[3]) : "n"(D) : "memory");
@@ -339,12 +357,17 @@ __global__ __launch_bounds__(WM* WN * 64) void c1s_kernel(const C1K p) {
           }
           v = __builtin_bit_cast(u32x4, rv);
         }
-        if constexpr (MODE == 2) {
+        if constexpr (MODE == 2 || MODE == 6) {
           // same double rounding as the tile kernel's accumulate path: bf16(result), then bf16(that + old)
           const bf16x8 nv = __builtin_bit_cast(bf16x8, v), ov = __builtin_bit_cast(bf16x8, old[j * 2 + pr]);
           bf16x8 rv;
 #pragma unroll
           for (int e = 0; e < 8; ++e) rv[e] = (__bf16)((float)nv[e] + (float)ov[e]);
+          if constexpr (MODE == 6) {   // ... then the ReLU mask (MI_CONV_ACCUM | MI_CONV_RELUMASK, the tile kernel's order)
+            const bf16x8 mv = __builtin_bit_cast(bf16x8, aux6[j * 2 + pr]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rv[e] = (float)mv[e] > 0.f ? rv[e] : (__bf16)0.f;
+          }
           v = __builtin_bit_cast(u32x4, rv);
         }
         if (!RAGGED_OK || ((wn * PT + j) * 32 + l31) < lim) *(u32x4*)(yt + yoff[j] + pr * 32) = v;

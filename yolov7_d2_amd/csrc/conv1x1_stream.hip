@@ -13,6 +13,7 @@ int c1s_launch_mode2(const C1Launch& l, hipStream_t s);
 int c1s_launch_mode3(const C1Launch& l, hipStream_t s);
 int c1s_launch_mode4(const C1Launch& l, hipStream_t s);
 int c1s_launch_mode5(const C1Launch& l, hipStream_t s);
+int c1s_launch_mode6(const C1Launch& l, hipStream_t s);
 int c1s_bar_status(unsigned* flag);
 
 static int c1s_cus() {
@@ -36,8 +37,9 @@ static bool c1s_desc_ok(const mi_conv_desc* d) {
   static const int epi_ok = getenv("MI_CONV_STREAM_EPI") ? atoi(getenv("MI_CONV_STREAM_EPI")) : 1;
   const int epf = MI_CONV_RELU | MI_CONV_ADDRELU | MI_CONV_RELUMASK;
   if (d->flags & ~(MI_CONV_ACCUM | epf)) return false;
+  const bool accmask = (d->flags & (MI_CONV_ACCUM | epf)) == (MI_CONV_ACCUM | MI_CONV_RELUMASK) && !d->bias;   // MODE 6
   if ((d->flags & epf) || d->bias) {
-    if (!epi_ok || (d->flags & MI_CONV_ACCUM) || d->stats_acc || d->xf) return false;
+    if (!epi_ok || ((d->flags & MI_CONV_ACCUM) && !accmask) || d->stats_acc || d->xf) return false;
     const int aux = d->flags & (MI_CONV_ADDRELU | MI_CONV_RELUMASK);
     if (aux == (MI_CONV_ADDRELU | MI_CONV_RELUMASK) || (aux && (d->flags & MI_CONV_RELU))) return false;
     if (aux && (!d->bn_y || d->bn_ldy % 8 || ((uintptr_t)d->bn_y & 15) ||
@@ -111,7 +113,8 @@ static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l, const mi_bn_job
   l->MODE = (d0.flags & MI_CONV_ACCUM) ? 2 : (d0.stats_acc ? 1 : 0);
   bool any_bias = false;
   for (int j = 0; j < n; ++j) any_bias = any_bias || ds[j].bias != nullptr;
-  if (d0.flags & (MI_CONV_ADDRELU | MI_CONV_RELUMASK)) l->MODE = 5;
+  if ((d0.flags & (MI_CONV_ACCUM | MI_CONV_RELUMASK)) == (MI_CONV_ACCUM | MI_CONV_RELUMASK)) l->MODE = 6;
+  else if (d0.flags & (MI_CONV_ADDRELU | MI_CONV_RELUMASK)) l->MODE = 5;
   else if (any_bias || (d0.flags & MI_CONV_RELU)) l->MODE = 4;
   // a partial last pixel tile (round 6; the modes without statistics): maps whose pixel count is no multiple of the tile -
   // detectron2's ResNet at 800 x 1333 (res4: 4 x 50 x 84 = 16 800 pixels).  Small ragged maps stay on the tile kernel
@@ -119,7 +122,7 @@ static bool c1s_fill(const mi_conv_desc* ds, int n, C1Launch* l, const mi_bn_job
   bool ragged = false;
   if (npix % tpix) {
     static const long minpix = getenv("MI_C1S_RAGGED_MINPIX") ? atol(getenv("MI_C1S_RAGGED_MINPIX")) : 8192;
-    const bool mode_ok = l->MODE == 0 || l->MODE == 2 || l->MODE == 4 || l->MODE == 5;
+    const bool mode_ok = l->MODE == 0 || l->MODE == 2 || l->MODE >= 4;
     if (!mode_ok || bn || d0.xf || minpix < 0 || npix < minpix || npix < tpix) return false;
     ragged = true;
   }
@@ -190,6 +193,7 @@ static int c1s_run(const C1Launch& l, hipStream_t s) {
     case 3: return c1s_launch_mode3(l, s);
     case 4: return c1s_launch_mode4(l, s);
     case 5: return c1s_launch_mode5(l, s);
+    case 6: return c1s_launch_mode6(l, s);
     default: return c1s_launch_mode2(l, s);
   }
 }

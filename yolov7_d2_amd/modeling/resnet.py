@@ -398,6 +398,31 @@ def _relu_mask(g, a):
     return out
 
 
+# Gradients that leave a bottleneck's backward ALREADY multiplied by the ReLU mask of the tensor they belong to (the block's
+# input is the previous block's ReLU output: the last data gradient into it applies (x > 0) in its epilogue, MI_CONV_ACCUM |
+# MI_CONV_RELUMASK), so that the previous block's backward skips its own mask pass - a read-read-write of the block's largest
+# map, 13 launches per DETR-R50 step.  Keyed by (address, autograd graph task): an entry is only believed inside the backward
+# pass that made it.  Correct for any consumer: the producer of a ReLU output multiplies its out-gradient by that mask anyway,
+# and the mask is idempotent; a gradient that autograd summed from several consumers is a new tensor and is masked as before.
+_PREMASKED = {}
+
+
+def _premask_note(t):
+    task = torch._C._current_graph_task_id()
+    for k in [k for k, v in _PREMASKED.items() if v != task]:
+        del _PREMASKED[k]
+    _PREMASKED[t.data_ptr()] = task
+
+
+def _premask_take(t):
+    return _PREMASKED.pop(t.data_ptr(), None) == torch._C._current_graph_task_id()
+
+
+def _MASK_FUSE():
+    """MI_RESNET_MASK_FUSE=0: every block masks its own out-gradient with a separate pass (round 5's form; A/B, tests)"""
+    return os.environ.get("MI_RESNET_MASK_FUSE", "1") == "1"
+
+
 class _BottleneckFn(torch.autograd.Function):
     """A trainable BottleneckBlock (detectron2 resnet.py BottleneckBlock: conv1 1x1 - conv2 3x3 - conv3 1x1, FrozenBN folded,
     + shortcut, ReLU) as ONE autograd node.  What the per-convolution nodes cannot do: the block input's gradient is the
@@ -408,9 +433,10 @@ class _BottleneckFn(torch.autograd.Function):
     roundings as the separate nodes (bf16 + bf16 -> bf16)."""
 
     @staticmethod
-    def forward(ctx, x, s2, ssc, *rest):
+    def forward(ctx, x, s2, ssc, in_relu, *rest):
         n = 4 if ssc else 3
         ws, aff = rest[:n], rest[n:]
+        ctx.in_relu = bool(in_relu)
         scales, shifts = aff[0::2], aff[1::2]
         need_dx = x.requires_grad
         N, Cin, H, W = x.shape
@@ -456,8 +482,11 @@ class _BottleneckFn(torch.autograd.Function):
         gs = ctx.geoms[3] if ctx.has_sc else None
         dev = xh.device
         gyh = _nhwc(gy)
-        gm = torch.empty_like(gyh)          # (a fresh tensor: identity blocks accumulate the input gradient into it)
-        L.check(L.lib().mi_ew_bf16(gyh.data_ptr(), y.data_ptr(), gm.data_ptr(), gm.numel(), 2, L.stream_ptr()), "mi_ew_bf16 relu'")
+        if _premask_take(gyh):
+            gm = gyh                        # the next block's backward masked it in its last epilogue (and owns no other use of it)
+        else:
+            gm = torch.empty_like(gyh)      # (a fresh tensor: identity blocks accumulate the input gradient into it)
+            L.check(L.lib().mi_ew_bf16(gyh.data_ptr(), y.data_ptr(), gm.data_ptr(), gm.numel(), 2, L.stream_ptr()), "mi_ew_bf16 relu'")
         gws = [None] * n
         # the block's three or four weight gradients as ONE grouped launch (ops.WgradBatch), issued below - before the input
         # gradient is accumulated INTO gm, which two of the jobs read
@@ -483,15 +512,20 @@ class _BottleneckFn(torch.autograd.Function):
             WgradBatch.flush()
         dx = None
         if ctx.needs_input_grad[0]:
+            # the block input is a ReLU output (ResNet sets in_relu): its mask goes into the LAST data gradient's epilogue
+            # (not for the stride-2 shortcut, whose accumulate visits only the even pixels)
+            fuse = ctx.in_relu and ctx.epi and _MASK_FUSE() and (gs is None or gs.s == 1)
             if gs is None:
                 dxh = gm
-                g1.dgrad(da1, wds[0], dxh, accum=True)
+                g1.dgrad(da1, wds[0], dxh, accum=True, relu_mask=xh if fuse else None)
             else:
                 dxh = torch.empty_like(xh)
                 g1.dgrad(da1, wds[0], dxh)
-                gs.dgrad(gm, wds[3], dxh, accum=True)
+                gs.dgrad(gm, wds[3], dxh, accum=True, relu_mask=xh if fuse else None)
+            if fuse:
+                _premask_note(dxh)
             dx = dxh.permute(0, 3, 1, 2)
-        return (dx, None, None, *gws, *([None] * (2 * n)))
+        return (dx, None, None, None, *gws, *([None] * (2 * n)))
 
 
 class BottleneckBlock(nn.Module):
@@ -509,7 +543,7 @@ class BottleneckBlock(nn.Module):
         if (_BLOCK_FN() and torch.is_grad_enabled() and all(c.weight.requires_grad for c in convs) and self.conv1.stride == 1):
             aff = [t for c in convs for t in c.norm.affine()]
             return _BottleneckFn.apply(x, self.conv2.stride, self.shortcut.stride if self.shortcut is not None else 0,
-                                       *[c.weight for c in convs], *aff)
+                                       getattr(self, "input_is_relu", False), *[c.weight for c in convs], *aff)
         if _conv_relu_fused():
             out = self.conv2(self.conv1(x, relu=True), relu=True)
         else:
@@ -539,6 +573,8 @@ class ResNet(Backbone):
             first = 1 if i == 0 else 2
             stage = nn.Sequential(*[BottleneckBlock(cin if k == 0 else cout, cout, bc, stride=first if k == 0 else 1,
                                                     stride_in_1x1=stride_in_1x1) for k in range(nb)])
+            for blk in stage:
+                blk.input_is_relu = True    # every block's input is a ReLU output (the stem's max-pooled ReLU, the previous block)
             self.add_module(name, stage)
             self.stage_names.append(name)
             stride *= first

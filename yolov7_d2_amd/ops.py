@@ -424,8 +424,10 @@ class _ConvGeom:
         fl = L.MI_CONV_ACCUM if accum else 0
         aux = None
         if relu_mask is not None:       # dx *= (relu_mask > 0) in the epilogue (MI_CONV_RELUMASK): relu_mask = the ReLU OUTPUT that was this conv's input
-            assert not accum and tuple(relu_mask.shape[:3]) == (self.N, self.H, self.W)
-            fl, aux = L.MI_CONV_RELUMASK, (relu_mask.data_ptr(), _ld(relu_mask))
+            # (with accum: the mask applies to the accumulated sum - the last data gradient into a block input; stride 1 only:
+            #  the strided forms visit only the pixels that receive a gradient)
+            assert tuple(relu_mask.shape[:3]) == (self.N, self.H, self.W) and not (accum and self.s != 1)
+            fl, aux = fl | L.MI_CONV_RELUMASK, (relu_mask.data_ptr(), _ld(relu_mask))
         ldy = _ld(dyh)
         if self.s == 1:
             taps = [(pad - r, pad - s, r * k + s) for r in range(k) for s in range(k)]
