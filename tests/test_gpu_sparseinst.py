@@ -557,3 +557,37 @@ def test_grouped_iam_conv_on_one_padded_map_equals_the_cat_form(monkeypatch):
         scale = float(a[k].abs().max()) + 1e-30
         tol = 2e-2 if k in ("dx",) or k.startswith("g:inst_convs") else 5e-3       # bf16 maps downstream of a re-ordered fp32 sum
         assert float((a[k] - b[k]).abs().max()) <= tol * scale, (k, float((a[k] - b[k]).abs().max()), scale)
+
+
+def test_masks_from_predicted_kernels_as_one_node_equal_the_per_image_nodes():
+    """decoder_sparseinst.py:141-147 (`torch.bmm(pred_kernel, mask_features.view(B, C, H * W))`): the batch's masks as ONE
+    autograd node (_MaskKernelFn: per-image convolutions into row blocks of one map, one grouped weight-gradient launch)
+    against round 5's B `_LinearFn` nodes + torch.stack - same kernels on the same operands: the masks and the feature
+    gradient bit for bit, the kernels' gradient to the split-K summation order of the grouped launch"""
+    from yolov7_d2_amd.modeling.sparseinst import _MaskKernelFn, _pad_rows
+    from yolov7_d2_amd.modeling.transformer import _LinearFn
+    g = torch.Generator().manual_seed(3)
+    B, P, Cc, N, Np = 3, 40 * 24, 128, 100, 128
+    mf0 = (torch.randn(B, P, Cc, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    k0 = (torch.randn(B, N, Cc, generator=g) * 0.2).to(torch.bfloat16).to(DEV)
+    gy = torch.randn(B, P, Np, generator=g).to(torch.bfloat16).to(DEV)
+    gy[:, :, N:] = 0                                  # (the pad instances receive no gradient: the model slices them off)
+    res = []
+    for one in (False, True):
+        mf, k = mf0.clone().requires_grad_(True), k0.clone().requires_grad_(True)
+        if one:
+            y = _MaskKernelFn.apply(mf, k, Np)
+        else:
+            y = torch.stack([_LinearFn.apply(mf[b], _pad_rows(k[b].float(), Np), None) for b in range(B)])
+        (y.float() * gy.float()).sum().backward()
+        torch.cuda.synchronize()
+        res.append((y.detach(), mf.grad, k.grad))
+    (ya, dma, dka), (yb, dmb, dkb) = res
+    assert torch.equal(ya, yb) and float(ya.float().abs().max()) > 0.5
+    assert torch.equal(dma, dmb)
+    assert dka.dtype == dkb.dtype == torch.bfloat16
+    assert float((dka.float() - dkb.float()).abs().max()) <= 1e-2 * float(dka.float().abs().max())
+    # ... and against fp32 torch
+    ref = torch.bmm(mf0.float(), k0.float().transpose(1, 2))
+    assert float((ya[:, :, :N].float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+    assert float(ya[:, :, N:].float().abs().max()) == 0.0

@@ -310,17 +310,19 @@ class GraphedTrainStep:
 
     def _capture(self, fn):
         from .ops import WgradBatch
-        WgradBatch.reserve_for_capture()        # (the job tables of the grouped weight gradients: pinned, allocated outside the capture)
         g = torch.cuda.CUDAGraph()
         if hasattr(self.opt, "begin_capture"):
             self.opt.begin_capture()        # a device table of its own for this graph (its pool has its own gradients)
-        if self.pool is None:
-            with torch.cuda.graph(g):
-                out = fn()
-            self.pool = g.pool()
-        else:
-            with torch.cuda.graph(g, pool=self.pool):
-                out = fn()
+        # (the job tables of the grouped weight gradients: pinned + device slots allocated outside the capture, the device
+        #  slots written once when it ends - no replay happens before this function returns)
+        with WgradBatch.step_capture():
+            if self.pool is None:
+                with torch.cuda.graph(g):
+                    out = fn()
+                self.pool = g.pool()
+            else:
+                with torch.cuda.graph(g, pool=self.pool):
+                    out = fn()
         handle = None
         if hasattr(self.opt, "finish_capture"):
             handle = self.opt.finish_capture()       # the gradient addresses of the graph's pool -> that table

@@ -35,10 +35,11 @@ class PackedTargets(list):
         if self.lv is None:
             return
         n, B, ntot = self.lv["n"], len(self), off[-1]
-        self.lv["off"].copy_(torch.tensor([l * ntot + off[b] for l in range(n) for b in range(B)] + [n * ntot], dtype=torch.int32))
+        from ..ops import HostRing
+        HostRing.upload(self.lv["off"], [l * ntot + off[b] for l in range(n) for b in range(B)] + [n * ntot])
         if ntot:
-            self.lv["labels"][:n * ntot].copy_(labels.repeat(n))
-            self.lv["boxes"][:n * ntot].copy_(boxes.repeat(n, 1))
+            HostRing.upload(self.lv["labels"][:n * ntot], labels.repeat(n))
+            HostRing.upload(self.lv["boxes"][:n * ntot], boxes.repeat(n, 1))
 
 
 class HungarianMatcher(nn.Module):

@@ -19,6 +19,7 @@ from torch import nn
 
 from .. import _lib as L
 from ..d2shim import META_ARCH_REGISTRY, Boxes, ImageList, Instances, build_backbone, detector_postprocess
+from ..ops import HostRing
 from .box_ops import box_cxcywh_to_xyxy, box_xyxy_to_cxcywh
 from .detr import DETR
 from .detr_criterion import SetCriterion
@@ -261,7 +262,8 @@ class Detr(nn.Module):
             images.tensor[b, :, :h, :w].copy_(self.normalizer(img))
             sizes.append((h, w))
         images.image_sizes = sizes
-        images.sizes_dev.copy_(torch.tensor(sizes, dtype=torch.int64), non_blocking=False)
+        # (host values through the page-locked ring: a blocking copy here waits for the previous step's graph, ops.HostRing)
+        HostRing.upload(images.sizes_dev, sizes)
         if self.training:
             cap = targets.cap
             labels, boxes, off = [], [], [0]
@@ -280,11 +282,11 @@ class Detr(nn.Module):
                 targets[b] = None      # (the per-image dicts are views of the packed tensors, rebuilt below)
             ntot = off[-1]
             if ntot:
-                targets.tgt_labels[:ntot].copy_(torch.cat(labels))
-                targets.tgt_boxes[:ntot].copy_(torch.cat(boxes))
-            targets.tgt_off.copy_(torch.tensor(off, dtype=torch.int32))
+                HostRing.upload(targets.tgt_labels[:ntot], torch.cat(labels))
+                HostRing.upload(targets.tgt_boxes[:ntot], torch.cat(boxes))
+            HostRing.upload(targets.tgt_off, off)
             targets.fill_levels(off, torch.cat(labels) if ntot else None, torch.cat(boxes) if ntot else None)
-            nb = torch.tensor([float(ntot)], device=dev)
+            nb = HostRing.upload(torch.empty(1, device=dev), [float(ntot)])
             world = 1
             if torch.distributed.is_available() and torch.distributed.is_initialized():      # detr.py:616-619
                 torch.distributed.all_reduce(nb)

@@ -34,7 +34,7 @@ from torch import nn
 
 from .. import _lib as L
 from ..d2shim import META_ARCH_REGISTRY, ImageList, Instances, build_backbone
-from ..ops import ConvPaddedFn, WgradBatch, _ConvGeom, _conv_desc, _ld, _nhwc_v, _run_conv, nhwc_strided_ok, wgrad_can_defer
+from ..ops import ConvPaddedFn, HostRing, WgradBatch, _ConvGeom, _conv_desc, _ld, _nhwc_v, _run_conv, nhwc_strided_ok, wgrad_can_defer
 from ..ops import pack_images
 from .transformer import _LinearFn, _conv1x1, _factor
 
@@ -653,8 +653,11 @@ class BaseIAMDecoder(nn.Module):
         Np = _rup(N, 32)
         mf = _nhwc(mask_features)
         # the predicted kernels ARE the weights of a per-image 1x1 conv over the mask features (padded to 32 instances)
-        masks = torch.stack([_LinearFn.apply(mf[b].reshape(H * W, Cc), _pad_rows(pred_kernel[b].float(), Np), None)
-                             for b in range(B)]).reshape(B, H, W, Np)
+        if _MASK_BATCH() and Cc % 32 == 0:
+            masks = _MaskKernelFn.apply(mf.reshape(B, H * W, Cc), pred_kernel, Np).reshape(B, H, W, Np)
+        else:
+            masks = torch.stack([_LinearFn.apply(mf[b].reshape(H * W, Cc), _pad_rows(pred_kernel[b].float(), Np), None)
+                                 for b in range(B)]).reshape(B, H, W, Np)
         Ho, Wo = int(H * self.scale_factor), int(W * self.scale_factor)
         masks = _Resize.apply(masks.contiguous(), Ho, Wo)                       # [B, Ho, Wo, Np] (NHWC, instance = channel)
         output = {"pred_logits": pred_logits.float(), "pred_masks": masks.permute(0, 3, 1, 2)[:, :N],
@@ -662,6 +665,56 @@ class BaseIAMDecoder(nn.Module):
         if self.output_iam:
             output["pred_iam"] = resize_bilinear(iam() if callable(iam) else iam, (Ho, Wo))
         return output
+
+
+def _MASK_BATCH():
+    """MI_SI_MASK_BATCH=0: the masks as B `_LinearFn` nodes + torch.stack (round 5's form; A/B, tests)"""
+    import os
+    return os.environ.get("MI_SI_MASK_BATCH", "1") != "0"
+
+
+class _MaskKernelFn(torch.autograd.Function):
+    """decoder_sparseinst.py:141-147 `pred_masks = torch.bmm(pred_kernel, mask_features.view(B, C, H * W))` as ONE autograd node:
+    image b's predicted kernels are the weight of a 1x1 convolution over its mask features, written straight into row block b
+    of the batch's mask map.  As B `_LinearFn` nodes (round 5) autograd indexed the two operands per image and stacked the
+    results: per image and step a zero fill + a slice copy + a full-size addition for EACH operand's gradient (SelectBackward
+    of a [B, P, C] map: 3 x 13 MB), a padded copy of the kernels, and a weight gradient of its own (launch + reduce) - 80 of the
+    ~890 launches of a captured step.  Here: forward one pack + one convolution per image (the pack also leaves the
+    data-gradient image), backward one convolution per image into its rows of the feature gradient and ONE grouped
+    weight-gradient launch for the batch (pixel_outer_batch).  mf bf16 [B, P, C] dense, kern [B, N, C] -> bf16 [B, P, Np]."""
+
+    @staticmethod
+    def forward(ctx, mf, kern, Np):
+        B, P, Cc = mf.shape
+        N = kern.shape[1]
+        if N == Np:
+            k32 = kern.detach().float().contiguous()
+        else:
+            k32 = torch.zeros(B, Np, Cc, dtype=torch.float32, device=mf.device)
+            k32[:, :N] = kern.detach()
+        out = torch.empty(B, P, Np, dtype=torch.bfloat16, device=mf.device)
+        wds = []
+        for b in range(B):
+            wf, wd = pack_images(k32[b], Np, Cc, 1, 1, Cc, Np, Np, Cc, dgrad=ctx.needs_input_grad[0])
+            wds.append(wd)
+            _conv1x1(mf[b], wf, out[b], P, Cc, Np, Np)
+        ctx.save_for_backward(mf, *[w for w in wds if w is not None])
+        ctx.dims, ctx.kdtype = (B, P, Cc, N, Np), kern.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mf, *wds = ctx.saved_tensors
+        B, P, Cc, N, Np = ctx.dims
+        g = g.contiguous()
+        dmf = dk = None
+        if ctx.needs_input_grad[0]:
+            dmf = torch.empty_like(mf)
+            for b in range(B):
+                _conv1x1(g[b], wds[b], dmf[b], P, Np, Cc, Cc)
+        if ctx.needs_input_grad[1]:
+            dk = pixel_outer_batch(g, mf)[:, :N].to(ctx.kdtype)          # [B, Np, C] = sum_p g[b, p, n] * mf[b, p, c]
+        return dmf, dk, None
 
 
 def _pad_rows(w, Np):
@@ -747,8 +800,9 @@ class PackedMaskTargets:
         self.sizes = sizes
         self.t2.copy_((self.tgt * self.tgt).sum(-1).view(self.B, self.cap))      # (eager, in the host half)
         self.tgtT.copy_(self.tgt.view(self.B, self.cap, -1).transpose(1, 2))
-        self.off.copy_(torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32))
-        num = torch.tensor([float(sum(sizes))], device=dev)
+        # (host values through the page-locked ring: a blocking copy here waits for the previous step's graph, ops.HostRing)
+        HostRing.upload(self.off, [0] + [sum(sizes[:i + 1]) for i in range(len(sizes))])
+        num = HostRing.upload(torch.empty(1, device=dev), [float(sum(sizes))])
         world = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():      # sparseinst_loss.py:210-212
             torch.distributed.all_reduce(num)

@@ -118,6 +118,49 @@ class WeightImages:
             L.check(L.lib().mi_pack_conv_weights_batch(self.table.data_ptr(), n, nblk, kk, L.stream_ptr()), "mi_pack_conv_weights_batch")
 
 
+# ------------------------------------------------------------------------------------------------ small host values
+class HostRing:
+    """Small host values on their way to the device (the `prepare_batch` halves of the DETR / SparseInst steps: image sizes,
+    packed labels / boxes, prefix offsets, 1 / num_boxes) WITHOUT blocking the host.  `t.copy_(torch.tensor(...))` from
+    pageable memory blocks until the stream has drained - i.e. until the PREVIOUS step's graph has finished - so the rest of
+    the host half and the graph launch ran with the device idle: 0.6 - 0.7 ms of every 12.5 ms step
+    (tools/host_step_probe.py).  Here the value is written into a slot of one page-locked ring and copied from there
+    asynchronously on the current stream; the host runs a step ahead, the device runs the host half's launches back to
+    back.  The ring is reused in order; when it wraps the stream is synchronised once (4 MB: every few thousand steps)."""
+    BYTES = 4 << 20
+    _buf, _off = None, 0
+
+    @classmethod
+    def _take(cls, nbytes):
+        nbytes = _rup(nbytes, 256)
+        if cls._buf is None or nbytes > cls._buf.numel():
+            cls._buf = torch.empty(max(cls.BYTES, nbytes), dtype=torch.uint8).pin_memory()
+            cls._off = 0
+        if cls._off + nbytes > cls._buf.numel():
+            torch.cuda.current_stream().synchronize()      # every copy issued from the ring has been executed
+            cls._off = 0
+        o = cls._off
+        cls._off += nbytes
+        return cls._buf[o:o + nbytes]
+
+    @classmethod
+    def upload(cls, dst, src):
+        """dst (device tensor, dense) <- src (CPU tensor or nested list of numbers of dst's shape), asynchronously"""
+        src = torch.as_tensor(src, dtype=dst.dtype, device="cpu").reshape(dst.shape).contiguous()
+        n = src.numel()
+        if n == 0:
+            return dst
+        if not dst.is_cuda:                 # (host-side unit tests of the packing logic)
+            dst.copy_(src)
+            return dst
+        if torch.cuda.is_current_stream_capturing():
+            raise L.MI355Error("HostRing.upload inside a graph capture: host values belong to the eager half (prepare_batch)")
+        slot = cls._take(n * src.element_size())[: n * src.element_size()].view(dst.dtype).view(dst.shape)
+        slot.copy_(src)
+        dst.copy_(slot, non_blocking=True)
+        return dst
+
+
 # ------------------------------------------------------------------------------------------------ grouped weight gradients
 class WgradBatch:
     """Weight gradients of the eager module trees (transformer Linears, ResNet convolutions), deferred and issued ONE
@@ -144,6 +187,8 @@ class WgradBatch:
     # every replay of the graph copies from them again
     _ring, _ring_off = None, 0
     _graph_blocks, _graph_off = [], 0
+    _graph_dev = []             # device twin of every capture block (None for a block that had to be allocated inside a capture)
+    _in_step_capture, _graph_pending = False, []
     ARENA_BYTES = 8 << 20
     stats = dict(flushes=0, jobs=0)
 
@@ -183,15 +228,21 @@ class WgradBatch:
 
     @classmethod
     def _pinned(cls, nbytes):
+        """(page-locked slot, device slot or None).  Device slots exist inside a `step_capture()` only: the table of a captured
+        group never changes between replays, so it is uploaded ONCE when the capture ends instead of by a memcpy node in every
+        replay (an in-graph copy from host memory: ~5 us of copy kernel + up to 10 us of idle device on either side, 24 per
+        DETR step)."""
         nbytes = _rup(nbytes, 256)
         if torch.cuda.is_current_stream_capturing():
             if not cls._graph_blocks or cls._graph_off + nbytes > cls._graph_blocks[-1].numel():
                 # (page-locked allocation inside a capture is not a stream operation: thread-local capture mode allows it)
                 cls._graph_blocks.append(torch.empty(max(cls.ARENA_BYTES, nbytes), dtype=torch.uint8).pin_memory())
+                cls._graph_dev.append(None)
                 cls._graph_off = 0
             o = cls._graph_off
             cls._graph_off += nbytes
-            return cls._graph_blocks[-1][o:o + nbytes]
+            dev = cls._graph_dev[-1]
+            return cls._graph_blocks[-1][o:o + nbytes], (dev[o:o + nbytes] if dev is not None and cls._in_step_capture else None)
         if cls._ring is None or nbytes > cls._ring.numel():
             cls._ring = torch.empty(max(cls.ARENA_BYTES, nbytes), dtype=torch.uint8).pin_memory()
             cls._ring_off = 0
@@ -200,15 +251,39 @@ class WgradBatch:
             cls._ring_off = 0
         o = cls._ring_off
         cls._ring_off += nbytes
-        return cls._ring[o:o + nbytes]
+        return cls._ring[o:o + nbytes], None
 
     @classmethod
     def reserve_for_capture(cls):
-        """make sure a graph capture finds a pinned block (called from eager code before a capture starts: allocating
-        page-locked memory INSIDE a global-mode capture is an error)"""
-        if not cls._graph_blocks or cls._graph_off + (1 << 20) > cls._graph_blocks[-1].numel():
+        """make sure a graph capture finds a pinned block and its device twin (called from eager code before a capture starts:
+        allocating page-locked memory INSIDE a global-mode capture is an error, and a device allocation in there would come
+        from the graph's private pool)"""
+        if not cls._graph_blocks or cls._graph_dev[-1] is None or cls._graph_off + (1 << 20) > cls._graph_blocks[-1].numel():
             cls._graph_blocks.append(torch.empty(cls.ARENA_BYTES, dtype=torch.uint8).pin_memory())
+            cls._graph_dev.append(torch.empty(cls.ARENA_BYTES, dtype=torch.uint8, device="cuda"))
             cls._graph_off = 0
+
+    @classmethod
+    def step_capture(cls):
+        """context manager around the capture of a training step whose owner promises to replay it only after the context has
+        ended (graph_step.GraphedTrainStep): the groups' job tables go to persistent device slots, written once on exit.  Any
+        other capture keeps the in-graph upload (a memcpy node per group), which needs no such promise."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            cls.reserve_for_capture()
+            cls._in_step_capture, cls._graph_pending = True, []
+            try:
+                yield
+            finally:
+                cls._in_step_capture = False
+                pend, cls._graph_pending = cls._graph_pending, []
+                for dev, host in pend:          # (eager, after the capture: ordinary stream-ordered copies, then one wait)
+                    dev.copy_(host, non_blocking=True)
+                if pend:
+                    torch.cuda.current_stream().synchronize()
+        return ctx()
 
     @classmethod
     def run_now(cls, jobs):
@@ -234,11 +309,14 @@ class WgradBatch:
         L.check(lib.mi_conv2d_wgrad_group_plan(descs, n, None, None, 0, C.byref(meta)), "wgrad_group_plan (sizes)")
         ws = torch.empty(max(int(meta.ws_bytes), 256), dtype=torch.uint8, device=dev)
         nb = int(meta.table_bytes)
-        host = cls._pinned(nb)
+        host, table = cls._pinned(nb)
         L.check(lib.mi_conv2d_wgrad_group_plan(descs, n, ws.data_ptr(), host.data_ptr(), nb, C.byref(meta)), "wgrad_group_plan")
-        table = torch.empty(_rup(nb, 256), dtype=torch.uint8, device=dev)
         sp = L.stream_ptr()
-        L.check(lib.mi_upload_async(table.data_ptr(), host.data_ptr(), nb, sp), "upload_async")
+        if table is None:
+            table = torch.empty(_rup(nb, 256), dtype=torch.uint8, device=dev)
+            L.check(lib.mi_upload_async(table.data_ptr(), host.data_ptr(), nb, sp), "upload_async")
+        else:
+            cls._graph_pending.append((table, host))      # written when the capture ends (step_capture)
         L.check(lib.mi_conv2d_wgrad_group_run(C.byref(meta), table.data_ptr(), sp), "wgrad_group_run")
         cls.stats["flushes"] += 1
         cls.stats["jobs"] += n
