@@ -961,6 +961,33 @@ int mi_graph_destroy(int64_t handle);
  * if per_cmd_ms != NULL (n floats) each command is additionally timed alone (event pair per cmd). */
 int mi_cmdlist_time(const mi_cmd* cmds, int n, int iters, float* ms, float* per_cmd_ms, mi_stream_t s);
 
+/* ---- the batch-building half of the DETR / SparseInst steps (csrc/host_feed.hip): one launch per batch where the reference
+ * runs a handful of torch calls per image.  The per-image records are passed BY VALUE inside the kernel arguments (`jobs` is
+ * a HOST array; nothing is uploaded, nothing has to stay alive), MI_FEED_MAX_IMAGES images per launch.
+ *
+ * mi_normalize_pad_batch: yolov7/modeling/meta_arch/detr.py:273-278 and meta_arch/sparseinst.py:95-98 -
+ *   dst[b][c][y][x] = (img_b[c][y][x] - mean[c]) / std[c] for y < h_b, x < w_b, else 0; dst fp32 [B][3][Hp][Wp] (16-byte
+ *   aligned, Wp % 4 == 0), images CHW dense on the device, dtype 0 = fp32, 1 = uint8.
+ * mi_mask_targets_batch: yolov7/utils/misc.py:148-170 (nested_masks_from_list) + yolov7/modeling/loss/sparseinst_loss.py:
+ *   149-151, 326-328 (F.interpolate bilinear, align_corners=False) - image b's M_b masks [M_b][h_b][w_b] (fp32, or 1-byte
+ *   bool / uint8 read as 0 / 1) zero-extended to (Hi, Wi), resized to (Ho, Wo), written as fp32 rows tgt[(b * cap + j)][Ho * Wo]
+ *   (rows j >= M_b zero), as their bf16 transpose tgtT[b][Ho * Wo][cap] (NULL: skipped) and labels[b][cap] (int64, 0 beyond
+ *   M_b; NULL: skipped; a job's `labels` may be NULL when M == 0).  cap % 8 == 0, 64 * cap * 2 bytes of LDS. */
+#define MI_FEED_MAX_IMAGES 32
+typedef struct mi_image_job {
+  const void* src;
+  int h, w, dtype, pad_;
+} mi_image_job;
+typedef struct mi_mask_job {
+  const void* masks;
+  const int64_t* labels;
+  int M, h, w, dtype;
+} mi_mask_job;
+int mi_normalize_pad_batch(const mi_image_job* jobs, int B, float* dst, int Hp, int Wp, const float* mean3, const float* std3,
+                           mi_stream_t s);
+int mi_mask_targets_batch(const mi_mask_job* jobs, int B, int cap, int Hi, int Wi, int Ho, int Wo, float* tgt, void* tgtT_bf16,
+                          int64_t* labels, mi_stream_t s);
+
 /* ---- hardware probes used by tests (lane layouts of MFMA / LDS transpose read) */
 int mi_probe_mfma32(const void* a_bf16_32x16, const void* b_bf16_16x32, float* d_32x32, mi_stream_t s);
 int mi_probe_mfma16(const void* a_bf16_16x32, const void* b_bf16_32x16, float* d_16x16, mi_stream_t s);

@@ -159,6 +159,14 @@ class mi_pack_job(C.Structure):
                 ("scale", C.c_void_p)]
 
 
+class mi_image_job(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("h", C.c_int32), ("w", C.c_int32), ("dtype", C.c_int32), ("pad_", C.c_int32)]
+
+
+class mi_mask_job(C.Structure):
+    _fields_ = [("masks", C.c_void_p), ("labels", C.c_void_p), ("M", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("dtype", C.c_int32)]
+
+
 class mi_mosaic_paste_job(C.Structure):
     _fields_ = [("src", C.c_void_p), ("canvas", C.c_void_p)] + [(n, C.c_int32) for n in
                 ("h0", "w0", "rh", "rw", "cw", "x1a", "y1a", "x2a", "y2a", "x1b", "y1b", "blk0", "fsrc", "pad_")]
@@ -356,6 +364,8 @@ _PROTOS = {
     "mi_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_uint32), _i, C.POINTER(C.c_void_p)]),
     "mi_stream_destroy": (C.c_int, [_vp]),
     "mi_upload_async": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "mi_normalize_pad_batch": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "mi_mask_targets_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "mi_aux_stream_set": (C.c_int, [_i, _vp]),
     "mi_graph_capture": (C.c_int64, [C.POINTER(mi_cmd), _i, _vp]),
     "mi_graph_launch": (C.c_int, [_i64, _vp]),

@@ -19,7 +19,7 @@ from torch import nn
 
 from .. import _lib as L
 from ..d2shim import META_ARCH_REGISTRY, Boxes, ImageList, Instances, build_backbone, detector_postprocess
-from ..ops import HostRing
+from ..ops import HostRing, feed_batch_enabled, normalize_pad_batch
 from .box_ops import box_cxcywh_to_xyxy, box_xyxy_to_cxcywh
 from .detr import DETR
 from .detr_criterion import SetCriterion
@@ -184,6 +184,7 @@ class Detr(nn.Module):
                                       eos_coef=d.NO_OBJECT_WEIGHT, losses=["labels", "boxes", "cardinality"])
         self.register_buffer("pixel_mean", torch.Tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1), persistent=False)
         self.register_buffer("pixel_std", torch.Tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1), persistent=False)
+        self.pixel_mean_host, self.pixel_std_host = [float(v) for v in cfg.MODEL.PIXEL_MEAN], [float(v) for v in cfg.MODEL.PIXEL_STD]
         self.normalizer = lambda x: (x - self.pixel_mean) / self.pixel_std
         self.iter = 0
         self.to(self.device)
@@ -254,13 +255,16 @@ class Detr(nn.Module):
             static = dict(images=images, targets=targets, key=(B, Hp, Wp))
         assert static["key"] == (B, Hp, Wp), (static["key"], (B, Hp, Wp))
         images, targets = static["images"], static["targets"]
-        images.tensor.zero_()
-        sizes = []
-        for b, x in enumerate(batched_inputs):
-            img = x["image"].to(dev).float()
-            h, w = int(img.shape[-2]), int(img.shape[-1])
-            images.tensor[b, :, :h, :w].copy_(self.normalizer(img))
-            sizes.append((h, w))
+        sizes = [(int(x["image"].shape[-2]), int(x["image"].shape[-1])) for x in batched_inputs]
+        if feed_batch_enabled():
+            # normalise + zero-pad the whole batch in one launch (the reference: two torch calls + a slice copy per image)
+            normalize_pad_batch([x["image"] for x in batched_inputs], images.tensor, self.pixel_mean_host, self.pixel_std_host)
+        else:
+            images.tensor.zero_()
+            for b, x in enumerate(batched_inputs):
+                img = x["image"].to(dev).float()
+                h, w = sizes[b]
+                images.tensor[b, :, :h, :w].copy_(self.normalizer(img))
         images.image_sizes = sizes
         # (host values through the page-locked ring: a blocking copy here waits for the previous step's graph, ops.HostRing)
         HostRing.upload(images.sizes_dev, sizes)

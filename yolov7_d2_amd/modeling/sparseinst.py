@@ -35,7 +35,7 @@ from torch import nn
 from .. import _lib as L
 from ..d2shim import META_ARCH_REGISTRY, ImageList, Instances, build_backbone
 from ..ops import ConvPaddedFn, HostRing, WgradBatch, _ConvGeom, _conv_desc, _ld, _nhwc_v, _run_conv, nhwc_strided_ok, wgrad_can_defer
-from ..ops import pack_images
+from ..ops import feed_batch_enabled, mask_targets_batch, normalize_pad_batch, pack_images
 from .transformer import _LinearFn, _conv1x1, _factor
 
 # ------------------------------------------------------------------------------------------------ small op wrappers
@@ -780,6 +780,16 @@ class PackedMaskTargets:
     def fill(self, targets, input_shape):
         """targets: per image {"labels": int64 [M], "masks": [M, h, w]} (prepare_targets); refilled IN PLACE"""
         dev = self.tgt.device
+        if feed_batch_enabled() and dev.type == "cuda" and self.cap * 128 <= 65536:
+            # pad + resize + pack of every image's masks, the bf16 transpose and the labels: one launch
+            ms = [t["masks"].tensor if hasattr(t["masks"], "tensor") else t["masks"] for t in targets]
+            sizes = [int(m.shape[0]) for m in ms]
+            if max(sizes + [0]) > self.cap:
+                raise ValueError(f"SparseInst: {max(sizes)} instances in one image, target capacity is {self.cap}")
+            mask_targets_batch(ms, [t["labels"] for t in targets], self.cap, input_shape, self.size, self.tgt, self.tgtT, self.labels)
+            self.sizes = sizes
+            self.t2.copy_((self.tgt * self.tgt).sum(-1).view(self.B, self.cap))
+            return self._fill_counts(sizes)
         self.tgt.zero_()
         self.labels.zero_()
         sizes = []
@@ -800,6 +810,10 @@ class PackedMaskTargets:
         self.sizes = sizes
         self.t2.copy_((self.tgt * self.tgt).sum(-1).view(self.B, self.cap))      # (eager, in the host half)
         self.tgtT.copy_(self.tgt.view(self.B, self.cap, -1).transpose(1, 2))
+        return self._fill_counts(sizes)
+
+    def _fill_counts(self, sizes):
+        dev = self.tgt.device
         # (host values through the page-locked ring: a blocking copy here waits for the previous step's graph, ops.HostRing)
         HostRing.upload(self.off, [0] + [sum(sizes[:i + 1]) for i in range(len(sizes))])
         num = HostRing.upload(torch.empty(1, device=dev), [float(sum(sizes))])
@@ -991,6 +1005,7 @@ class SparseInst(nn.Module):
         self.mask_format = cfg.INPUT.MASK_FORMAT
         self.register_buffer("pixel_mean", torch.Tensor(cfg.MODEL.PIXEL_MEAN).view(3, 1, 1), persistent=False)
         self.register_buffer("pixel_std", torch.Tensor(cfg.MODEL.PIXEL_STD).view(3, 1, 1), persistent=False)
+        self.pixel_mean_host, self.pixel_std_host = [float(v) for v in cfg.MODEL.PIXEL_MEAN], [float(v) for v in cfg.MODEL.PIXEL_STD]
         self.cls_threshold = cfg.MODEL.YOLO.CONF_THRESHOLD
         self.mask_threshold = cfg.MODEL.SPARSE_INST.MASK_THRESHOLD
         self.max_detections = cfg.MODEL.SPARSE_INST.MAX_DETECTIONS
@@ -1051,10 +1066,14 @@ class SparseInst(nn.Module):
                           targets=PackedMaskTargets(B, cap, (Hp // st, Wp // st), dev))
         assert static["key"] == (B, Hp, Wp, cap), (static["key"], (B, Hp, Wp, cap))
         img = static["images"]
-        img.zero_()
-        for b, x in enumerate(batched_inputs):
-            t = self.normalizer(x["image"].to(dev).float())
-            img[b, :, : t.shape[-2], : t.shape[-1]].copy_(t)
+        if feed_batch_enabled():
+            # normalise + zero-pad the whole batch in one launch (the reference: two torch calls + a slice copy per image)
+            normalize_pad_batch([x["image"] for x in batched_inputs], img, self.pixel_mean_host, self.pixel_std_host)
+        else:
+            img.zero_()
+            for b, x in enumerate(batched_inputs):
+                t = self.normalizer(x["image"].to(dev).float())
+                img[b, :, : t.shape[-2], : t.shape[-1]].copy_(t)
         gt = self.prepare_targets([x["instances"].to(dev) for x in batched_inputs])
         static["targets"].fill(gt, (Hp, Wp))
         return static

@@ -161,6 +161,68 @@ class HostRing:
         return dst
 
 
+def feed_batch_enabled():
+    """MI_FEED_BATCH=0: the per-image torch calls of the reference in prepare_batch (A/B, tests)"""
+    import os
+    return os.environ.get("MI_FEED_BATCH", "1") != "0"
+
+
+def _feed_dtype(t):
+    return 0 if t.dtype == torch.float32 else (1 if t.dtype in (torch.uint8, torch.bool) else -1)
+
+
+def normalize_pad_batch(images, dst, mean, std):
+    """dst[b] = zero-padded (images[b] - mean) / std for the whole batch in ONE launch (mi_normalize_pad_batch: detr.py:273-278 /
+    sparseinst.py:95-98 of the reference's meta architectures, which normalise every image and let ImageList.from_tensors
+    copy it into a zero-filled batch tensor).  images: CHW tensors (any device / dtype; moved to dst's device, anything but
+    fp32 / uint8 converted to fp32), dst fp32 [B, 3, Hp, Wp] dense, mean / std: three numbers each."""
+    B, _, Hp, Wp = dst.shape
+    assert dst.is_cuda and dst.dtype == torch.float32 and dst.is_contiguous() and len(images) == B
+    jobs = (L.mi_image_job * B)()
+    keep = []
+    for b, im in enumerate(images):
+        im = im.to(dst.device)
+        if _feed_dtype(im) < 0 or im.dtype == torch.bool:
+            im = im.float()
+        im = im.contiguous()
+        keep.append(im)
+        assert im.dim() == 3 and im.shape[0] == 3, "normalize_pad_batch: CHW images with three channels"
+        jobs[b].src, jobs[b].h, jobs[b].w, jobs[b].dtype = im.data_ptr(), int(im.shape[1]), int(im.shape[2]), _feed_dtype(im)
+    m3, s3 = (C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std])
+    L.check(L.lib().mi_normalize_pad_batch(jobs, B, dst.data_ptr(), Hp, Wp, m3, s3, L.stream_ptr()), "mi_normalize_pad_batch")
+    return dst
+
+
+def mask_targets_batch(masks, labels, cap, in_shape, out_shape, tgt, tgtT=None, labels_out=None):
+    """the batch's ground-truth masks zero-extended to `in_shape`, resized (bilinear, align_corners=False) to `out_shape` and
+    packed at fixed capacity in ONE launch (mi_mask_targets_batch: utils/misc.py:148-170 + sparseinst_loss.py:149-151 of the
+    reference, which pad, stack and F.interpolate per image).  masks: per image [M, h, w] (fp32 / bool / uint8, on any device),
+    labels: per image int64 [M] or None; tgt fp32 [B * cap, Ho * Wo], tgtT bf16 [B, Ho * Wo, cap] or None, labels_out int64
+    [B, cap] or None - all written completely (unused rows zero)."""
+    B = len(masks)
+    dev = tgt.device
+    jobs = (L.mi_mask_job * B)()
+    keep = []
+    for b, m in enumerate(masks):
+        M = int(m.shape[0])
+        jobs[b].M, jobs[b].dtype = M, 0
+        if M == 0:
+            continue
+        m = m.to(dev)
+        if _feed_dtype(m) < 0:
+            m = m.float()
+        m = m.contiguous()
+        lab = None
+        if labels_out is not None:
+            lab = labels[b].to(dev).to(torch.int64).contiguous()
+            assert lab.numel() == M
+        keep.append((m, lab))
+        jobs[b].masks, jobs[b].labels = m.data_ptr(), L.ptr(lab)
+        jobs[b].h, jobs[b].w, jobs[b].dtype = int(m.shape[1]), int(m.shape[2]), _feed_dtype(m)
+    L.check(L.lib().mi_mask_targets_batch(jobs, B, cap, int(in_shape[0]), int(in_shape[1]), int(out_shape[0]), int(out_shape[1]),
+                                          tgt.data_ptr(), L.ptr(tgtT), L.ptr(labels_out), L.stream_ptr()), "mi_mask_targets_batch")
+
+
 # ------------------------------------------------------------------------------------------------ grouped weight gradients
 class WgradBatch:
     """Weight gradients of the eager module trees (transformer Linears, ResNet convolutions), deferred and issued ONE
