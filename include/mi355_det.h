@@ -967,7 +967,7 @@ int mi_cmdlist_time(const mi_cmd* cmds, int n, int iters, float* ms, float* per_
  *
  * mi_normalize_pad_batch: yolov7/modeling/meta_arch/detr.py:273-278 and meta_arch/sparseinst.py:95-98 -
  *   dst[b][c][y][x] = (img_b[c][y][x] - mean[c]) / std[c] for y < h_b, x < w_b, else 0; dst fp32 [B][3][Hp][Wp] (16-byte
- *   aligned, Wp % 4 == 0), images CHW dense on the device, dtype 0 = fp32, 1 = uint8.
+ *   stores when Wp % 4 == 0 and dst is 16-byte aligned), images CHW dense on the device, dtype 0 = fp32, 1 = uint8.
  * mi_mask_targets_batch: yolov7/utils/misc.py:148-170 (nested_masks_from_list) + yolov7/modeling/loss/sparseinst_loss.py:
  *   149-151, 326-328 (F.interpolate bilinear, align_corners=False) - image b's M_b masks [M_b][h_b][w_b] (fp32, or 1-byte
  *   bool / uint8 read as 0 / 1) zero-extended to (Hi, Wi), resized to (Ho, Wo), written as fp32 rows tgt[(b * cap + j)][Ho * Wo]

@@ -23,14 +23,15 @@ def test_normalize_pad_batch_equals_the_per_image_torch_calls_bit_for_bit(dtype)
     if dtype == torch.float32:
         imgs = [im + torch.rand(im.shape, generator=g) for im in imgs]           # (not only integers)
     imgs = [im.to(DEV) if i % 2 == 0 else im for i, im in enumerate(imgs)]       # (host images are moved over)
-    dst = torch.full((len(sizes), 3, 96, 128), 7.0, device=DEV)                  # (stale values: every element is written)
-    ops.normalize_pad_batch(imgs, dst, MEAN, STD)
     mean, std = torch.tensor(MEAN, device=DEV).view(3, 1, 1), torch.tensor(STD, device=DEV).view(3, 1, 1)
-    ref = torch.zeros_like(dst)
-    for b, im in enumerate(imgs):
-        t = (im.to(DEV).float() - mean) / std
-        ref[b, :, :t.shape[1], :t.shape[2]] = t
-    assert torch.equal(dst, ref)
+    for Wp in (128, 130):                                                        # (130: DETR pads to the largest image, any width)
+        dst = torch.full((len(sizes), 3, 96, Wp), 7.0, device=DEV)               # (stale values: every element is written)
+        ops.normalize_pad_batch(imgs, dst, MEAN, STD)
+        ref = torch.zeros_like(dst)
+        for b, im in enumerate(imgs):
+            t = (im.to(DEV).float() - mean) / std
+            ref[b, :, :t.shape[1], :t.shape[2]] = t
+        assert torch.equal(dst, ref), Wp
 
 
 def test_normalize_pad_batch_beyond_one_launch_and_argument_checks():

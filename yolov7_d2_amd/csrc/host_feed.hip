@@ -36,7 +36,8 @@ __device__ __forceinline__ float feed_ld(const void* p, int64_t i) {
 __global__ __launch_bounds__(256) void normalize_pad_kernel(const FeedImgK p) {
   const int b = blockIdx.y;
   const mi_image_job jb = p.j[b];
-  const int W4 = p.Wp / 4;
+  const int W4 = (p.Wp + 3) / 4;
+  const bool vec = (p.Wp & 3) == 0;      // whole 16-byte stores (rows start 16-byte aligned); else element stores
   const int total = 3 * p.Hp * W4;
   float* const out = p.dst + (int64_t)(p.b0 + b) * 3 * p.Hp * p.Wp;
   for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
@@ -59,14 +60,20 @@ __global__ __launch_bounds__(256) void normalize_pad_kernel(const FeedImgK p) {
       }
       o = {v[0], v[1], v[2], v[3]};
     }
-    *(float4*)(out + ((int64_t)c * p.Hp + y) * p.Wp + x4 * 4) = o;
+    float* const q = out + ((int64_t)c * p.Hp + y) * p.Wp + x4 * 4;
+    if (vec) {
+      *(float4*)q = o;
+    } else {
+      const float ov[4] = {o.x, o.y, o.z, o.w};
+      for (int e = 0; e < 4 && x4 * 4 + e < p.Wp; ++e) q[e] = ov[e];
+    }
   }
 }
 
 extern "C" int mi_normalize_pad_batch(const mi_image_job* jobs, int B, float* dst, int Hp, int Wp, const float* mean3,
                                       const float* std3, mi_stream_t st) {
-  MI_REQUIRE(jobs && dst && mean3 && std3 && B >= 1 && Hp >= 1 && Wp >= 4 && Wp % 4 == 0, "normalize_pad_batch: args");
-  MI_REQUIRE(((uintptr_t)dst & 15) == 0 && (int64_t)3 * Hp * Wp < (1LL << 31), "normalize_pad_batch: dst alignment / size");
+  MI_REQUIRE(jobs && dst && mean3 && std3 && B >= 1 && Hp >= 1 && Wp >= 1, "normalize_pad_batch: args");
+  MI_REQUIRE((Wp % 4 != 0 || ((uintptr_t)dst & 15) == 0) && (int64_t)3 * Hp * (Wp + 3) < (1LL << 31), "normalize_pad_batch: dst alignment / size");
   for (int b = 0; b < B; ++b)
     MI_REQUIRE(jobs[b].src && jobs[b].h >= 1 && jobs[b].w >= 1 && jobs[b].h <= Hp && jobs[b].w <= Wp &&
                    (jobs[b].dtype == 0 || jobs[b].dtype == 1),
@@ -78,7 +85,7 @@ extern "C" int mi_normalize_pad_batch(const mi_image_job* jobs, int B, float* ds
     for (int b = 0; b < nb; ++b) k.j[b] = jobs[b0 + b];
     k.dst = dst; k.B = nb; k.Hp = Hp; k.Wp = Wp; k.b0 = b0;
     for (int c = 0; c < 3; ++c) { k.mean[c] = mean3[c]; k.std[c] = std3[c]; }
-    const int total = 3 * Hp * (Wp / 4);
+    const int total = 3 * Hp * ((Wp + 3) / 4);
     int gx = (total + 255) / 256;
     if (gx > 2048) gx = 2048;
     hipLaunchKernelGGL(normalize_pad_kernel, dim3(gx, nb), dim3(256), 0, (hipStream_t)st, k);

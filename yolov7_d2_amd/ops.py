@@ -645,7 +645,7 @@ def _pad_last(t, CP):
 
 # ------------------------------------------------------------------------------------------------ mi355::conv2d
 _LIBDEF.define("conv2d(Tensor x, Tensor weight, Tensor? bias, int stride, int padding) -> Tensor")
-_LIBDEF.define("conv2d_backward(Tensor grad, Tensor x, Tensor weight, bool has_bias, int stride, int padding) -> (Tensor, Tensor, Tensor)")
+_LIBDEF.define("conv2d_backward(Tensor grad, Tensor x, Tensor weight, bool has_bias, int stride, int padding, bool defer=False) -> (Tensor, Tensor, Tensor)")
 
 
 def _conv2d_cuda(x, weight, bias, stride, padding, relu=False):
@@ -663,7 +663,9 @@ def _conv2d_cuda(x, weight, bias, stride, padding, relu=False):
     return _nchw(y, g.Cout)
 
 
-def _conv2d_backward_cuda(grad, x, weight, has_bias, stride, padding):
+def _conv2d_backward_cuda(grad, x, weight, has_bias, stride, padding, defer=False):
+    """defer: the weight gradient only REGISTERS with WgradBatch (`weight` is the parameter that will own it) and leaves with
+    the next grouped launch - a later layer's flush point or the end of the backward pass"""
     g = _ConvGeom(x.shape, weight.shape, stride, padding)
     _, wd = g.pack(weight, fwd=False)
     dyh = _pad_last(_nhwc_v(grad), g.CoutP)
@@ -673,11 +675,12 @@ def _conv2d_backward_cuda(grad, x, weight, has_bias, stride, padding):
     full = g.CinP == g.Cin and not (g.k == 1 and g.s == 2)
     dx = (torch.empty if full else torch.zeros)(g.N, g.H, g.W, g.CinP, dtype=torch.bfloat16, device=x.device)
     g.dgrad(dyh, wd, dx)
+    own = weight if defer else None
     if has_bias and wgrad_bias_fused(g.N * g.Ho * g.Wo):
         gb = torch.empty(g.Cout, dtype=torch.float32, device=x.device)
-        gw = g.wgrad(xh, dyh, gbias=gb)       # (the bias gradient leaves with the weight gradient: no column-sum launch)
+        gw = g.wgrad(xh, dyh, gbias=gb, defer=defer, owner=own)       # (the bias gradient leaves with the weight gradient: no column-sum launch)
     else:
-        gw = g.wgrad(xh, dyh)
+        gw = g.wgrad(xh, dyh, defer=defer, owner=own)
         gb = _colsum(dyh, g.Cout) if has_bias else torch.zeros(0, device=x.device)
     return _nchw(dx, g.Cin), gw, gb
 
@@ -690,12 +693,24 @@ def _conv2d_setup(ctx, inputs, output):
     x, weight, bias, stride, padding = inputs
     ctx.save_for_backward(x, weight)
     ctx.has_bias, ctx.stride, ctx.padding = bias is not None, stride, padding
+    ctx.params = (weight, bias)        # (the parameter objects themselves: whether their .grad is still unset decides the deferral)
+
+
+def _conv_op_defer(weight, bias=None):
+    """the weight gradient of a mi355::conv2d(_relu) node may join the next grouped launch (WgradBatch) when autograd will
+    take the returned tensor over untouched: fp32 leaf parameter without a .grad yet (wgrad_can_defer).  MI_WGRAD_CONV_DEFER=0:
+    every convolution's weight gradient as its own launch + reduce (round 5's form)"""
+    import os
+    return (os.environ.get("MI_WGRAD_CONV_DEFER", "1") != "0" and weight.dtype == torch.float32 and weight.requires_grad
+            and wgrad_can_defer(weight, bias))
 
 
 def _conv2d_bwd(ctx, grad):
     x, weight = ctx.saved_tensors
     need_gb = ctx.has_bias and ctx.needs_input_grad[2]     # (a frozen-norm shift passed as bias has no gradient to compute)
-    dx, gw, gb = torch.ops.mi355.conv2d_backward(grad, x, weight, need_gb, ctx.stride, ctx.padding)
+    w_, b_ = ctx.params
+    dx, gw, gb = torch.ops.mi355.conv2d_backward(grad, x, w_, need_gb, ctx.stride, ctx.padding,
+                                                 ctx.needs_input_grad[1] and _conv_op_defer(w_, b_ if need_gb else None))
     return dx.to(x.dtype), gw.to(weight.dtype), (gb if need_gb else None), None, None
 
 
@@ -726,6 +741,7 @@ class ConvPaddedFn(torch.autograd.Function):
                 b32[: g.Cout] = bias.detach().float()
         g.fwd(xh, wf, y, bias=b32, relu=relu)
         ctx.g, ctx.relu, ctx.has_bias = g, relu, bias is not None
+        ctx.params = (weight, bias)
         ctx.save_for_backward(xh, wd, y if relu else None)
         return _nchw(y, g.Cout)
 
@@ -749,11 +765,13 @@ class ConvPaddedFn(torch.autograd.Function):
             g.dgrad(dyh, wd, dx)
         need_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
+            df = _conv_op_defer(ctx.params[0], ctx.params[1] if need_gb else None)
+            own = ctx.params[0] if df else None
             if need_gb and wgrad_bias_fused(g.N * g.Ho * g.Wo):
                 gb = torch.empty(g.Cout, dtype=torch.float32, device=xh.device)
-                gw = g.wgrad(xh, dyh, gbias=gb)
+                gw = g.wgrad(xh, dyh, gbias=gb, defer=df, owner=own)
             else:
-                gw = g.wgrad(xh, dyh)
+                gw = g.wgrad(xh, dyh, defer=df, owner=own)
         if need_gb and gb is None:
             gb = _colsum(dyh, g.Cout)
         return dx, gw, gb, None, None, None, None
@@ -770,6 +788,7 @@ def _conv2d_relu_setup(ctx, inputs, output):
     x, weight, bias, stride, padding = inputs
     ctx.save_for_backward(x, weight, output)
     ctx.has_bias, ctx.stride, ctx.padding = bias is not None, stride, padding
+    ctx.params = (weight, bias)
 
 
 def _conv2d_relu_bwd(ctx, grad):
@@ -778,7 +797,9 @@ def _conv2d_relu_bwd(ctx, grad):
     gm = torch.empty_like(gh)
     L.check(L.lib().mi_ew_bf16(gh.data_ptr(), oh.data_ptr(), gm.data_ptr(), gh.numel(), 2, L.stream_ptr()), "mi_ew_bf16 relu'")
     need_gb = ctx.has_bias and ctx.needs_input_grad[2]
-    dx, gw, gb = torch.ops.mi355.conv2d_backward(gm.permute(0, 3, 1, 2), x, weight, need_gb, ctx.stride, ctx.padding)
+    w_, b_ = ctx.params
+    dx, gw, gb = torch.ops.mi355.conv2d_backward(gm.permute(0, 3, 1, 2), x, w_, need_gb, ctx.stride, ctx.padding,
+                                                 ctx.needs_input_grad[1] and _conv_op_defer(w_, b_ if need_gb else None))
     return dx.to(x.dtype), gw.to(weight.dtype), (gb if need_gb else None), None, None
 
 
