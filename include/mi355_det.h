@@ -869,6 +869,46 @@ int mi_sparseinst_mask_grad(const void* masks, int ldm, int P, const float* targ
 int mi_sparseinst_mask_grad_dev(const void* masks, int ldm, int P, const float* targets, const int32_t* pairs, int K,
                                 const float* stats, const float* coef_dev, void* dmasks, mi_stream_t s);
 
+/* SparseInstCriterion's scalar half and SparseInstMatcher's cost matrix (csrc/sparseinst_loss.hip; loss/sparseinst_loss.py:
+ * 190-297, 300-354) - four launches for what the reference spells as ~150 small torch calls.
+ * mi_sparseinst_match_cost: cost[b][n][t] = -(dice^alpha * prob^beta), dice = 2 num[b][n][t] / (s2[b][n] + t2[b][t] + 1e-4),
+ *   prob = sigmoid(logits[b][n][labels[b][t]]); num fp32 [B][Np][cap], s2 [B][Np], t2 [B][cap], logits fp32 [B][N][C],
+ *   labels int64 [B][cap] -> cost fp32 [B][N][cap].
+ * The three criterion calls share one descriptor (all device pointers; fixed capacity `cap` pairs per image):
+ *   _pairs:        match_q / match_t int64 [B][cap], nmatch int32 [B] (mi_lsap), labels -> pairs int32 [B*cap][3] = (b or -1, q,
+ *                  b*cap+t), valid fp32 [B*cap], row_cls / row_pair int32 [B][N] (class / pair of the query's match or -1),
+ *                  kdev[0] = max(sum nmatch, 1)
+ *   _head_loss:    logits, scores fp32 [B][N] (objectness logits), stats fp32 [B*cap][8] (mi_sparseinst_mask_stats), inv_num[0]
+ *                  -> losses[4] = weighted loss_ce, loss_mask, loss_dice, loss_objectness
+ *   _head_loss_bwd: gup[4] upstream gradients -> dlogits [B][N][C], dscores [B][N], coef[2] (mi_sparseinst_mask_grad_dev's) */
+typedef struct mi_sparseinst_loss_desc {
+  const float* logits;
+  const float* scores;
+  const int64_t* labels;
+  const int64_t* match_q;
+  const int64_t* match_t;
+  const int32_t* nmatch;
+  const float* inv_num;
+  const float* stats;
+  const float* gup;
+  int32_t* pairs;
+  float* valid;
+  int32_t* row_cls;
+  int32_t* row_pair;
+  float* kdev;
+  float* losses;
+  float* dlogits;
+  float* dscores;
+  float* coef;
+  int B, N, C, cap, P, use_labels, use_masks, pad_;
+  float alpha, gamma, w_ce, w_mask, w_dice, w_obj;
+} mi_sparseinst_loss_desc;
+int mi_sparseinst_match_cost(const float* num, const float* s2, const float* t2, const float* logits, const int64_t* labels,
+                             int B, int N, int Np, int C, int cap, float alpha, float beta, float* cost, mi_stream_t s);
+int mi_sparseinst_pairs(const mi_sparseinst_loss_desc* d, mi_stream_t s);
+int mi_sparseinst_head_loss(const mi_sparseinst_loss_desc* d, mi_stream_t s);
+int mi_sparseinst_head_loss_bwd(const mi_sparseinst_loss_desc* d, mi_stream_t s);
+
 /* ---- box utilities of the DETR path (yolov7/utils/boxes.py:28-37,85-122) ------------------------------------------
  * mi_box_convert: n boxes [n][4] fp32; to_cxcywh 0 = box_cxcywh_to_xyxy, 1 = box_xyxy_to_cxcywh.
  * mi_box_iou_pairwise: box_iou (iou and union, [n][m]) and, when giou != NULL, generalized_box_iou of xyxy boxes in the

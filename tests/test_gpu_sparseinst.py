@@ -591,3 +591,47 @@ def test_masks_from_predicted_kernels_as_one_node_equal_the_per_image_nodes():
     ref = torch.bmm(mf0.float(), k0.float().transpose(1, 2))
     assert float((ya[:, :, :N].float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
     assert float(ya[:, :, N:].float().abs().max()) == 0.0
+
+
+def test_fused_matcher_cost_and_criterion_equal_the_torch_spelling(monkeypatch):
+    """SparseInstCriterion + SparseInstMatcher (loss/sparseinst_loss.py) with the cost matrix, the pair bookkeeping, the four
+    losses and their gradients in csrc/sparseinst_loss.hip (default) against the same module spelled in torch calls
+    (MI_SI_FUSED_LOSS=0, round 5's form, itself pinned to the reference's golden vectors above): the same assignment, losses
+    to 1e-5, gradients to 1e-4 of their scale - on a batch with an image without instances"""
+    cfg = M.sparse_inst_r50_giam_cfg(device=DEV)
+    crit = S.build_sparse_inst_criterion(cfg).to(DEV)
+    g = torch.Generator().manual_seed(21)
+    B, N, C_, Ho, Wo, Np, cap = 3, 100, 80, 40, 56, 128, 32
+    logits0 = (torch.randn(B, N, C_, generator=g) * 2 - 2).to(DEV)
+    scores0 = torch.randn(B, N, 1, generator=g).to(DEV)
+    masks0 = (torch.randn(B, Ho, Wo, Np, generator=g) * 2).to(torch.bfloat16).to(DEV)
+    tg = []
+    for b, n in enumerate((5, 0, 9)):
+        m = torch.zeros(n, Ho * 4, Wo * 4)
+        for k in range(n):
+            y0, x0 = int(torch.randint(0, Ho * 3, (1,), generator=g)), int(torch.randint(0, Wo * 3, (1,), generator=g))
+            m[k, y0:y0 + 30 + 7 * k, x0:x0 + 40 + 5 * k] = 1
+        tg.append({"labels": torch.randint(0, C_, (n,), generator=g).to(DEV), "masks": m.to(DEV)})
+    pk = S.PackedMaskTargets(B, cap, (Ho, Wo), DEV).fill(tg, (Ho * 4, Wo * 4))
+    res = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("MI_SI_FUSED_LOSS", fused)
+        logits, scores, masks = (t.clone().requires_grad_(True) for t in (logits0, scores0, masks0))
+        out = {"pred_logits": logits, "pred_scores": scores, "_masks_nhwc": masks}
+        with torch.no_grad():
+            mq, mt, nm = crit.matcher.match_packed(out, pk)
+        losses = crit(out, pk)
+        sum(w * losses[k] for w, k in zip((1.0, 0.7, 1.3, 0.9), ("loss_ce", "loss_mask", "loss_dice", "loss_objectness"))).backward()
+        torch.cuda.synchronize()
+        res.append(dict(mq=mq, mt=mt, nm=nm, losses={k: float(v) for k, v in losses.items()}, dl=logits.grad, ds=scores.grad, dm=masks.grad.float()))
+    a, b = res
+    assert torch.equal(a["nm"], b["nm"]) and a["nm"].tolist() == [5, 0, 9]
+    for i, n in enumerate(a["nm"].tolist()):
+        assert torch.equal(a["mq"][i, :n], b["mq"][i, :n]) and torch.equal(a["mt"][i, :n], b["mt"][i, :n])
+    assert set(a["losses"]) == set(b["losses"]) == {"loss_ce", "loss_mask", "loss_dice", "loss_objectness"}
+    for k in a["losses"]:
+        assert a["losses"][k] == pytest.approx(b["losses"][k], rel=1e-5), k
+        assert a["losses"][k] > 0
+    for k in ("dl", "ds", "dm"):
+        scale = float(a[k].abs().max())
+        assert scale > 0 and float((a[k] - b[k]).abs().max()) <= 1e-4 * scale, (k, float((a[k] - b[k]).abs().max()), scale)

@@ -159,6 +159,13 @@ class mi_pack_job(C.Structure):
                 ("scale", C.c_void_p)]
 
 
+class mi_sparseinst_loss_desc(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("logits", "scores", "labels", "match_q", "match_t", "nmatch", "inv_num", "stats", "gup",
+                                          "pairs", "valid", "row_cls", "row_pair", "kdev", "losses", "dlogits", "dscores", "coef")] + \
+               [(n, C.c_int32) for n in ("B", "N", "C", "cap", "P", "use_labels", "use_masks", "pad_")] + \
+               [(n, C.c_float) for n in ("alpha", "gamma", "w_ce", "w_mask", "w_dice", "w_obj")]
+
+
 class mi_image_job(C.Structure):
     _fields_ = [("src", C.c_void_p), ("h", C.c_int32), ("w", C.c_int32), ("dtype", C.c_int32), ("pad_", C.c_int32)]
 
@@ -364,6 +371,10 @@ _PROTOS = {
     "mi_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_uint32), _i, C.POINTER(C.c_void_p)]),
     "mi_stream_destroy": (C.c_int, [_vp]),
     "mi_upload_async": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "mi_sparseinst_match_cost": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _vp, _vp]),
+    "mi_sparseinst_pairs": (C.c_int, [_vp, _vp]),
+    "mi_sparseinst_head_loss": (C.c_int, [_vp, _vp]),
+    "mi_sparseinst_head_loss_bwd": (C.c_int, [_vp, _vp]),
     "mi_normalize_pad_batch": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "mi_mask_targets_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "mi_aux_stream_set": (C.c_int, [_i, _vp]),

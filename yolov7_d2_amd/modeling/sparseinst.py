@@ -831,6 +831,20 @@ def _pack_targets(targets, input_shape, size, device, cap=None):
     return PackedMaskTargets(len(targets), cap, size, device).fill(targets, input_shape)
 
 
+def _FUSED_LOSS():
+    """MI_SI_FUSED_LOSS=0: the matcher's cost matrix and the criterion's scalar half as torch calls (round 5's form; A/B, tests)"""
+    import os
+    return os.environ.get("MI_SI_FUSED_LOSS", "1") != "0"
+
+
+def dice_terms_packed(masks_nhwc, pk):
+    """the two device-heavy terms of dice_score_packed: num fp32 [B, Np, cap] = sum_p sigmoid * t and s2 fp32 [B, Np] =
+    sum_p sigmoid^2 (the target term is pk.t2)"""
+    B, Ho, Wo, Np = masks_nhwc.shape
+    sig = _Ew1.apply(masks_nhwc.contiguous(), "sigmoid").reshape(B, Ho * Wo, Np)
+    return pixel_outer_batch(sig, pk.tgtT), _colsums(sig, square=True)
+
+
 def dice_score_packed(masks_nhwc, pk):
     """dice_score (sparseinst_loss.py:31-36) of every prediction against the `cap` target rows OF ITS IMAGE: fp32 [B, Np, cap]
     (columns of unused rows are 0).  masks_nhwc: bf16 logits [B, Ho, Wo, Np]"""
@@ -860,12 +874,24 @@ class SparseInstMatcher(nn.Module):
         N = outputs["pred_logits"].shape[1]
         dev = masks.device
         cap = pk.cap
-        prob = outputs["pred_logits"].float().sigmoid()                                          # [B, N, C]
-        scores = dice_score_packed(masks, pk)[:, :N]                                             # [B, N, cap]
-        pl = prob.gather(2, pk.labels[:, None, :].expand(B, N, cap))
-        cost = (-((scores ** self.alpha) * (pl ** self.beta))).contiguous()
-        mq = torch.zeros(B, cap, dtype=torch.int64, device=dev)
-        mt = torch.zeros(B, cap, dtype=torch.int64, device=dev)
+        if _FUSED_LOSS():
+            # dice, class probability and the two powers in one launch (mi_sparseinst_match_cost) over the outer products
+            num, s2 = dice_terms_packed(masks, pk)
+            logits = outputs["pred_logits"].float().contiguous()
+            C_ = logits.shape[2]
+            cost = torch.empty(B, N, cap, dtype=torch.float32, device=dev)
+            L.check(L.lib().mi_sparseinst_match_cost(num.data_ptr(), s2.data_ptr(), pk.t2.data_ptr(), logits.data_ptr(),
+                                                     pk.labels.data_ptr(), B, N, num.shape[1], C_, cap, float(self.alpha),
+                                                     float(self.beta), cost.data_ptr(), L.stream_ptr()), "mi_sparseinst_match_cost")
+            mqt = torch.zeros(2, B, cap, dtype=torch.int64, device=dev)
+            mq, mt = mqt[0], mqt[1]
+        else:
+            prob = outputs["pred_logits"].float().sigmoid()                                          # [B, N, C]
+            scores = dice_score_packed(masks, pk)[:, :N]                                             # [B, N, cap]
+            pl = prob.gather(2, pk.labels[:, None, :].expand(B, N, cap))
+            cost = (-((scores ** self.alpha) * (pl ** self.beta))).contiguous()
+            mq = torch.zeros(B, cap, dtype=torch.int64, device=dev)
+            mt = torch.zeros(B, cap, dtype=torch.int64, device=dev)
         nm = torch.zeros(B, dtype=torch.int32, device=dev)
         L.check(L.lib().mi_lsap(cost.data_ptr(), pk.off.data_ptr(), B, N, cap, mq.data_ptr(), mt.data_ptr(), nm.data_ptr(),
                                 L.stream_ptr()), "mi_lsap")
@@ -916,6 +942,70 @@ class _MaskLossFn(torch.autograd.Function):
         return dm, None, None, None
 
 
+class _CriterionFn(torch.autograd.Function):
+    """SparseInstCriterion.forward behind the matcher as ONE autograd node: (class logits fp32 [B, N, C], objectness logits
+    fp32 [B, N, 1], mask logits bf16 NHWC, packed targets, the assignment) -> the four WEIGHTED losses fp32 [4] (loss_ce,
+    loss_mask, loss_dice, loss_objectness; sparseinst_loss.py:214-297).  Forward: pair table (mi_sparseinst_pairs), the
+    pairs' mask statistics (mi_sparseinst_mask_stats), the losses (mi_sparseinst_head_loss).  Backward: d logits, d scores
+    and the mask kernels' two coefficients from the four upstream gradients (mi_sparseinst_head_loss_bwd), then
+    mi_sparseinst_mask_grad_dev.  Focal loss alpha 0.25 / gamma 2 (sparseinst_loss.py:230-236)."""
+
+    @staticmethod
+    def forward(ctx, logits, scores, masks, tgt, labels, inv_num, mq, mt, nm, use, weights):
+        B, Ho, Wo, Np = masks.shape
+        N, C_ = logits.shape[1], logits.shape[2]
+        cap = mq.shape[1]
+        P, K = Ho * Wo, B * cap
+        dev = masks.device
+        logits, scores = logits.contiguous(), scores.contiguous()
+        mq, mt = mq.contiguous(), mt.contiguous()
+        ibuf = torch.empty(K * 3 + 2 * B * N, dtype=torch.int32, device=dev)
+        fbuf = torch.empty(K + 1 + 4, dtype=torch.float32, device=dev)
+        stats = torch.empty(K, 8, dtype=torch.float32, device=dev)
+        d = L.mi_sparseinst_loss_desc()
+        d.logits, d.scores, d.labels = logits.data_ptr(), scores.data_ptr(), labels.data_ptr()
+        d.match_q, d.match_t, d.nmatch, d.inv_num = mq.data_ptr(), mt.data_ptr(), nm.data_ptr(), inv_num.data_ptr()
+        d.pairs, d.row_cls, d.row_pair = ibuf.data_ptr(), ibuf[K * 3:].data_ptr(), ibuf[K * 3 + B * N:].data_ptr()
+        d.valid, d.kdev, d.losses = fbuf.data_ptr(), fbuf[K:].data_ptr(), fbuf[K + 1:].data_ptr()
+        d.stats = stats.data_ptr()
+        d.B, d.N, d.C, d.cap, d.P, d.use_labels, d.use_masks = B, N, C_, cap, P, use[0], use[1]
+        d.alpha, d.gamma = 0.25, 2.0
+        d.w_ce, d.w_mask, d.w_dice, d.w_obj = [float(w) for w in weights]
+        lib, sp = L.lib(), L.stream_ptr()
+        L.check(lib.mi_sparseinst_pairs(C.byref(d), sp), "mi_sparseinst_pairs")
+        if use[1]:
+            ws = torch.empty(int(lib.mi_sparseinst_mask_stats_ws_floats(K, P)), dtype=torch.float32, device=dev)
+            L.check(lib.mi_sparseinst_mask_stats(masks.data_ptr(), Np, P, tgt.data_ptr(), d.pairs, K, stats.data_ptr(), ws.data_ptr(), sp),
+                    "mi_sparseinst_mask_stats")
+        L.check(lib.mi_sparseinst_head_loss(C.byref(d), sp), "mi_sparseinst_head_loss")
+        ctx.desc, ctx.keep = d, (logits, scores, labels, inv_num, mq, mt, nm, ibuf, fbuf, stats)
+        ctx.save_for_backward(masks, tgt)
+        ctx.scores_shape = scores.shape
+        return fbuf[K + 1: K + 5]
+
+    @staticmethod
+    def backward(ctx, g):
+        masks, tgt = ctx.saved_tensors
+        d = ctx.desc
+        B, Ho, Wo, Np = masks.shape
+        dev = masks.device
+        gup = g.float().contiguous()
+        dlogits = torch.empty(d.B, d.N, d.C, dtype=torch.float32, device=dev)
+        dscores = torch.empty(ctx.scores_shape, dtype=torch.float32, device=dev)
+        coef = torch.empty(2, dtype=torch.float32, device=dev)
+        d.gup, d.dlogits, d.dscores, d.coef = gup.data_ptr(), dlogits.data_ptr(), dscores.data_ptr(), coef.data_ptr()
+        lib, sp = L.lib(), L.stream_ptr()
+        L.check(lib.mi_sparseinst_head_loss_bwd(C.byref(d), sp), "mi_sparseinst_head_loss_bwd")
+        dm = None
+        if ctx.needs_input_grad[2]:
+            dm = torch.zeros_like(masks)
+            if d.use_masks:
+                L.check(lib.mi_sparseinst_mask_grad_dev(masks.data_ptr(), Np, Ho * Wo, tgt.data_ptr(), d.pairs, d.B * d.cap,
+                                                        d.stats, coef.data_ptr(), dm.data_ptr(), sp), "mi_sparseinst_mask_grad_dev")
+        return (dlogits if ctx.needs_input_grad[0] else None, dscores if ctx.needs_input_grad[1] else None, dm,
+                None, None, None, None, None, None, None, None)
+
+
 def sigmoid_focal_loss(inputs, targets, alpha=0.25, gamma=2.0):
     """fvcore.nn.sigmoid_focal_loss_jit(reduction='sum') (un-vendored; published formula)"""
     p = torch.sigmoid(inputs)
@@ -952,6 +1042,18 @@ class SparseInstCriterion(nn.Module):
         mq, mt, nm = self.matcher.match_packed(outputs, pk)
         B, cap = mq.shape
         dev = masks.device
+        if _FUSED_LOSS() and outputs["pred_logits"].dtype == torch.float32 and outputs["pred_scores"].dtype == torch.float32:
+            # pair table, the four losses and their gradients: four launches + the two mask kernels (csrc/sparseinst_loss.hip)
+            use = (int("labels" in self.losses), int("masks" in self.losses))
+            wd = self.weight_dict
+            r = _CriterionFn.apply(outputs["pred_logits"], outputs["pred_scores"], masks.contiguous(), pk.tgt, pk.labels, pk.inv_num,
+                                   mq, mt, nm, use, (wd["loss_ce"], wd["loss_mask"], wd["loss_dice"], wd["loss_objectness"]))
+            losses = {}
+            if use[0]:
+                losses["loss_ce"] = r[0]
+            if use[1]:
+                losses.update(loss_mask=r[1], loss_dice=r[2], loss_objectness=r[3])
+            return losses
         nmc = nm.clamp(min=0)                       # (an invalid cost matrix - nmatch < 0 - contributes no pair; no host raise)
         valid = torch.arange(cap, device=dev)[None, :] < nmc[:, None]                           # [B, cap]
         vf = valid.float()
