@@ -1012,7 +1012,9 @@ int mi_cmdlist_time(const mi_cmd* cmds, int n, int iters, float* ms, float* per_
  *   149-151, 326-328 (F.interpolate bilinear, align_corners=False) - image b's M_b masks [M_b][h_b][w_b] (fp32, or 1-byte
  *   bool / uint8 read as 0 / 1) zero-extended to (Hi, Wi), resized to (Ho, Wo), written as fp32 rows tgt[(b * cap + j)][Ho * Wo]
  *   (rows j >= M_b zero), as their bf16 transpose tgtT[b][Ho * Wo][cap] (NULL: skipped) and labels[b][cap] (int64, 0 beyond
- *   M_b; NULL: skipped; a job's `labels` may be NULL when M == 0).  cap % 8 == 0, 64 * cap * 2 bytes of LDS. */
+ *   M_b; NULL: skipped; a job's `labels` may be NULL when M == 0).  cap % 8 == 0, 64 * cap * 2 bytes of LDS.
+ *   t2 (NULL: skipped): fp32 [B][cap] = sum over the pixels of tgt^2 per row, summed in a fixed order through t2_ws
+ *   (B * cap * ceil(Ho * Wo / 64) floats): wave sums of 64 pixels, then the chunks in sequence (a second small launch). */
 #define MI_FEED_MAX_IMAGES 32
 typedef struct mi_image_job {
   const void* src;
@@ -1026,7 +1028,7 @@ typedef struct mi_mask_job {
 int mi_normalize_pad_batch(const mi_image_job* jobs, int B, float* dst, int Hp, int Wp, const float* mean3, const float* std3,
                            mi_stream_t s);
 int mi_mask_targets_batch(const mi_mask_job* jobs, int B, int cap, int Hi, int Wi, int Ho, int Wo, float* tgt, void* tgtT_bf16,
-                          int64_t* labels, mi_stream_t s);
+                          int64_t* labels, float* t2, float* t2_ws, mi_stream_t s);
 
 /* ---- hardware probes used by tests (lane layouts of MFMA / LDS transpose read) */
 int mi_probe_mfma32(const void* a_bf16_32x16, const void* b_bf16_16x32, float* d_32x32, mi_stream_t s);

@@ -89,8 +89,14 @@ def test_mask_targets_batch_equals_pad_interpolate_stack(case):
     tgt = torch.full((B * cap, P), 3.0, device=DEV)
     tgtT = torch.full((B, P, cap), 3.0, dtype=torch.bfloat16, device=DEV)
     lab = torch.full((B, cap), 9, dtype=torch.int64, device=DEV)
-    ops.mask_targets_batch(masks, labels, cap, in_shape, out_shape, tgt, tgtT, lab)
+    t2 = torch.full((B, cap), 5.0, device=DEV)
+    ops.mask_targets_batch(masks, labels, cap, in_shape, out_shape, tgt, tgtT, lab, t2=t2)
     rt, rT, rl = _torch_targets(masks, labels, cap, in_shape, out_shape)
+    r2 = (rt.double() * rt.double()).sum(-1).view(B, cap)
+    assert float((t2.double() - r2).abs().max()) <= 1e-6 * float(r2.abs().max()) + 1e-12
+    t2b = torch.empty_like(t2)
+    ops.mask_targets_batch(masks, labels, cap, in_shape, out_shape, tgt, tgtT, lab, t2=t2b)
+    assert torch.equal(t2, t2b)                                  # (a fixed summation order: run-to-run identical)
     if case == "float_odd_ratio":    # (torch's kernel may contract a * b + c * d into an fma: one ulp)
         assert float((tgt - rt).abs().max()) <= 2e-7
         assert float((tgtT.float() - rT.float()).abs().max()) <= 1e-2

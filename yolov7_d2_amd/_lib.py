@@ -376,7 +376,7 @@ _PROTOS = {
     "mi_sparseinst_head_loss": (C.c_int, [_vp, _vp]),
     "mi_sparseinst_head_loss_bwd": (C.c_int, [_vp, _vp]),
     "mi_normalize_pad_batch": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
-    "mi_mask_targets_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "mi_mask_targets_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_aux_stream_set": (C.c_int, [_i, _vp]),
     "mi_graph_capture": (C.c_int64, [C.POINTER(mi_cmd), _i, _vp]),
     "mi_graph_launch": (C.c_int, [_i64, _vp]),

@@ -100,6 +100,8 @@ struct FeedMaskK {
   float* tgt;          // [B * cap][P]
   __bf16* tgtT;        // [B][P][cap] or NULL
   int64_t* labels;     // [B][cap] or NULL
+  float* t2ws;         // [B][cap][nchunk] or NULL: sum of squares of the block's 64 pixels of every row
+  int nchunk, pad_;
   int B, cap, Hi, Wi, Ho, Wo, b0;     // (Hi, Wi): the padded batch shape the masks are zero-extended to before the resize
   float sh, sw;
 };
@@ -151,6 +153,12 @@ __global__ __launch_bounds__(256) void mask_targets_kernel(const FeedMaskK p) {
     }
     if (live) trow[(int64_t)j * P + pix] = v;
     tile[px * p.cap + j] = (__bf16)v;
+    if (p.t2ws) {       // (a wave = the 64 pixels of one row: a fixed-order butterfly; pixels past the map contribute 0)
+      float q = v * v;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+      if (px == 0) p.t2ws[((int64_t)(p.b0 + b) * p.cap + j) * p.nchunk + blockIdx.x] = q;
+    }
   }
   if (p.labels && blockIdx.x == 0) {
     for (int j = threadIdx.x; j < p.cap; j += 256)
@@ -164,8 +172,17 @@ __global__ __launch_bounds__(256) void mask_targets_kernel(const FeedMaskK p) {
   for (int i = threadIdx.x; i < n16; i += 256) dst[i] = ((const uint4*)tile)[i];
 }
 
+__global__ __launch_bounds__(256) void mask_targets_t2_kernel(const float* __restrict__ ws, float* t2, int rows, int nchunk) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int c = 0; c < nchunk; ++c) s += ws[(int64_t)r * nchunk + c];
+  t2[r] = s;
+}
+
 extern "C" int mi_mask_targets_batch(const mi_mask_job* jobs, int B, int cap, int Hi, int Wi, int Ho, int Wo, float* tgt,
-                                     void* tgtT_bf16, int64_t* labels, mi_stream_t st) {
+                                     void* tgtT_bf16, int64_t* labels, float* t2, float* t2_ws, mi_stream_t st) {
+  MI_REQUIRE(!t2 || t2_ws, "mask_targets_batch: t2 needs its workspace");
   MI_REQUIRE(jobs && tgt && B >= 1 && cap >= 8 && cap % 8 == 0 && Hi >= 1 && Wi >= 1 && Ho >= 1 && Wo >= 1, "mask_targets_batch: args");
   MI_REQUIRE((size_t)FEED_TP * cap * 2 <= 64 * 1024, "mask_targets_batch: capacity %d exceeds the LDS tile", cap);
   MI_REQUIRE(!tgtT_bf16 || ((uintptr_t)tgtT_bf16 & 15) == 0, "mask_targets_batch: tgtT alignment");
@@ -183,10 +200,16 @@ extern "C" int mi_mask_targets_batch(const mi_mask_job* jobs, int B, int cap, in
     for (int b = 0; b < nb; ++b) k.j[b] = jobs[b0 + b];
     k.tgt = tgt; k.tgtT = (__bf16*)tgtT_bf16; k.labels = labels;
     k.B = nb; k.cap = cap; k.Hi = Hi; k.Wi = Wi; k.Ho = Ho; k.Wo = Wo; k.b0 = b0;
+    k.t2ws = t2 ? t2_ws : nullptr; k.nchunk = (P + FEED_TP - 1) / FEED_TP;
     k.sh = (float)Hi / (float)Ho; k.sw = (float)Wi / (float)Wo;        // area_pixel_compute_scale, no scale_factor given
     hipLaunchKernelGGL(mask_targets_kernel, dim3((P + FEED_TP - 1) / FEED_TP, nb), dim3(256), (size_t)FEED_TP * cap * 2,
                        (hipStream_t)st, k);
     MI_CHECK_LAUNCH("mask_targets_batch");
+  }
+  if (t2) {
+    hipLaunchKernelGGL(mask_targets_t2_kernel, dim3((B * cap + 255) / 256), dim3(256), 0, (hipStream_t)st, (const float*)t2_ws, t2,
+                       B * cap, (P + FEED_TP - 1) / FEED_TP);
+    MI_CHECK_LAUNCH("mask_targets_batch (t2)");
   }
   return MI_OK;
 }

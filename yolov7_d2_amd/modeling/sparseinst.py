@@ -786,9 +786,9 @@ class PackedMaskTargets:
             sizes = [int(m.shape[0]) for m in ms]
             if max(sizes + [0]) > self.cap:
                 raise ValueError(f"SparseInst: {max(sizes)} instances in one image, target capacity is {self.cap}")
-            mask_targets_batch(ms, [t["labels"] for t in targets], self.cap, input_shape, self.size, self.tgt, self.tgtT, self.labels)
+            mask_targets_batch(ms, [t["labels"] for t in targets], self.cap, input_shape, self.size, self.tgt, self.tgtT, self.labels,
+                               t2=self.t2)
             self.sizes = sizes
-            self.t2.copy_((self.tgt * self.tgt).sum(-1).view(self.B, self.cap))
             return self._fill_counts(sizes)
         self.tgt.zero_()
         self.labels.zero_()
@@ -816,11 +816,14 @@ class PackedMaskTargets:
         dev = self.tgt.device
         # (host values through the page-locked ring: a blocking copy here waits for the previous step's graph, ops.HostRing)
         HostRing.upload(self.off, [0] + [sum(sizes[:i + 1]) for i in range(len(sizes))])
+        if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            # one process: 1 / max(num_instances, 1) is a host value (the same fp32 division, done here)
+            import numpy as np
+            HostRing.upload(self.inv_num, [float(np.float32(1.0) / np.float32(max(float(sum(sizes)), 1.0)))])
+            return self
         num = HostRing.upload(torch.empty(1, device=dev), [float(sum(sizes))])
-        world = 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():      # sparseinst_loss.py:210-212
-            torch.distributed.all_reduce(num)
-            world = torch.distributed.get_world_size()
+        torch.distributed.all_reduce(num)                                                # sparseinst_loss.py:210-212
+        world = torch.distributed.get_world_size()
         self.inv_num.copy_(1.0 / torch.clamp(num / world, min=1.0))
         return self
 
@@ -981,15 +984,21 @@ class _CriterionFn(torch.autograd.Function):
         ctx.desc, ctx.keep = d, (logits, scores, labels, inv_num, mq, mt, nm, ibuf, fbuf, stats)
         ctx.save_for_backward(masks, tgt)
         ctx.scores_shape = scores.shape
-        return fbuf[K + 1: K + 5]
+        # four scalar outputs (views of one buffer), not one [4] tensor the caller indexes: every index is a select node whose
+        # backward is a zero fill + a copy, and the four of them meet in three additions
+        return tuple(fbuf[K + 1 + i] for i in range(4))
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         masks, tgt = ctx.saved_tensors
         d = ctx.desc
         B, Ho, Wo, Np = masks.shape
         dev = masks.device
-        gup = g.float().contiguous()
+        z = None
+        for g in gs:
+            if g is None and z is None:
+                z = torch.zeros((), dtype=torch.float32, device=dev)
+        gup = torch.stack([z if g is None else g.float() for g in gs])
         dlogits = torch.empty(d.B, d.N, d.C, dtype=torch.float32, device=dev)
         dscores = torch.empty(ctx.scores_shape, dtype=torch.float32, device=dev)
         coef = torch.empty(2, dtype=torch.float32, device=dev)

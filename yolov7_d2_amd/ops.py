@@ -193,14 +193,19 @@ def normalize_pad_batch(images, dst, mean, std):
     return dst
 
 
-def mask_targets_batch(masks, labels, cap, in_shape, out_shape, tgt, tgtT=None, labels_out=None):
+def mask_targets_batch(masks, labels, cap, in_shape, out_shape, tgt, tgtT=None, labels_out=None, t2=None):
     """the batch's ground-truth masks zero-extended to `in_shape`, resized (bilinear, align_corners=False) to `out_shape` and
     packed at fixed capacity in ONE launch (mi_mask_targets_batch: utils/misc.py:148-170 + sparseinst_loss.py:149-151 of the
     reference, which pad, stack and F.interpolate per image).  masks: per image [M, h, w] (fp32 / bool / uint8, on any device),
     labels: per image int64 [M] or None; tgt fp32 [B * cap, Ho * Wo], tgtT bf16 [B, Ho * Wo, cap] or None, labels_out int64
-    [B, cap] or None - all written completely (unused rows zero)."""
+    [B, cap] or None - all written completely (unused rows zero); t2 fp32 [B, cap] or None: every row's sum of squares over the
+    pixels (the dice denominators' target term), in a fixed order."""
     B = len(masks)
     dev = tgt.device
+    t2ws = None
+    if t2 is not None:
+        nchunk = (int(out_shape[0]) * int(out_shape[1]) + 63) // 64
+        t2ws = torch.empty(B * cap * nchunk, dtype=torch.float32, device=dev)
     jobs = (L.mi_mask_job * B)()
     keep = []
     for b, m in enumerate(masks):
@@ -220,7 +225,8 @@ def mask_targets_batch(masks, labels, cap, in_shape, out_shape, tgt, tgtT=None, 
         jobs[b].masks, jobs[b].labels = m.data_ptr(), L.ptr(lab)
         jobs[b].h, jobs[b].w, jobs[b].dtype = int(m.shape[1]), int(m.shape[2]), _feed_dtype(m)
     L.check(L.lib().mi_mask_targets_batch(jobs, B, cap, int(in_shape[0]), int(in_shape[1]), int(out_shape[0]), int(out_shape[1]),
-                                          tgt.data_ptr(), L.ptr(tgtT), L.ptr(labels_out), L.stream_ptr()), "mi_mask_targets_batch")
+                                          tgt.data_ptr(), L.ptr(tgtT), L.ptr(labels_out), L.ptr(t2), L.ptr(t2ws), L.stream_ptr()),
+            "mi_mask_targets_batch")
 
 
 # ------------------------------------------------------------------------------------------------ grouped weight gradients
