@@ -1016,6 +1016,7 @@ int mi_cmdlist_time(const mi_cmd* cmds, int n, int iters, float* ms, float* per_
  *   t2 (NULL: skipped): fp32 [B][cap] = sum over the pixels of tgt^2 per row, summed in a fixed order through t2_ws
  *   (B * cap * ceil(Ho * Wo / 64) floats): wave sums of 64 pixels, then the chunks in sequence (a second small launch). */
 #define MI_FEED_MAX_IMAGES 32
+#define MI_FEED_MAX_LEVELS 8
 typedef struct mi_image_job {
   const void* src;
   int h, w, dtype, pad_;
@@ -1027,6 +1028,11 @@ typedef struct mi_mask_job {
 } mi_mask_job;
 int mi_normalize_pad_batch(const mi_image_job* jobs, int B, float* dst, int Hp, int Wp, const float* mean3, const float* std3,
                            mi_stream_t s);
+/* mi_padding_masks: MaskedBackbone.mask_out_padding (yolov7/modeling/meta_arch/detr.py:385-403) for all feature levels in one
+ *   launch, from the device copy of the image sizes (int64 [B][2] = (h, w)): out[l] uint8 / bool [B][H[l]][W[l]] = 0 where
+ *   y < ceil(h / stride[l]) and x < ceil(w / stride[l]), else 1.  out / H / W / stride are HOST arrays of nlev entries. */
+int mi_padding_masks(const int64_t* sizes_dev, int B, int nlev, void* const* out, const int* H, const int* W, const int* stride,
+                     mi_stream_t s);
 int mi_mask_targets_batch(const mi_mask_job* jobs, int B, int cap, int Hi, int Wi, int Ho, int Wo, float* tgt, void* tgtT_bf16,
                           int64_t* labels, float* t2, float* t2_ws, mi_stream_t s);
 

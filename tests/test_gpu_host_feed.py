@@ -150,3 +150,22 @@ def test_prepare_batch_one_launch_forms_equal_the_per_image_forms(which, monkeyp
         assert set(first) == set(second) and len(first) >= 4
         for k in first:
             assert torch.equal(first[k], second[k]), (which, k)
+
+
+def test_padding_masks_of_all_levels_in_one_launch_equal_the_torch_spelling(monkeypatch):
+    """MaskedBackbone.mask_out_padding (meta_arch/detr.py:385-403) from the device copy of the image sizes: mi_padding_masks
+    against the host loop of the reference and against the per-level torch spelling (MI_FEED_BATCH=0)"""
+    from yolov7_d2_amd.modeling.detr_meta import MaskedBackbone
+    mb = MaskedBackbone.__new__(MaskedBackbone)
+    torch.nn.Module.__init__(mb)
+    mb.feature_strides = [4, 8, 16, 32]
+    sizes = [(250, 310), (224, 288), (1, 1), (256, 320)]
+    shapes = [(4, 8, 64, 80), (4, 8, 32, 40), (4, 8, 16, 20), (4, 8, 8, 10)]
+    sd = torch.tensor(sizes, dtype=torch.int64, device=DEV)
+    ref = mb.mask_out_padding(shapes, sizes, DEV)
+    got = mb.mask_out_padding_dev(shapes, sd)
+    monkeypatch.setenv("MI_FEED_BATCH", "0")
+    spelled = mb.mask_out_padding_dev(shapes, sd)
+    for r, g, s in zip(ref, got, spelled):
+        assert g.dtype == torch.bool and torch.equal(r, g) and torch.equal(r, s)
+    assert bool(ref[0].any()) and not bool(ref[0].all())

@@ -375,6 +375,7 @@ _PROTOS = {
     "mi_sparseinst_pairs": (C.c_int, [_vp, _vp]),
     "mi_sparseinst_head_loss": (C.c_int, [_vp, _vp]),
     "mi_sparseinst_head_loss_bwd": (C.c_int, [_vp, _vp]),
+    "mi_padding_masks": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "mi_normalize_pad_batch": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "mi_mask_targets_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_aux_stream_set": (C.c_int, [_i, _vp]),

@@ -213,3 +213,43 @@ extern "C" int mi_mask_targets_batch(const mi_mask_job* jobs, int B, int cap, in
   }
   return MI_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ padding masks
+// MaskedBackbone.mask_out_padding (yolov7/modeling/meta_arch/detr.py:385-403): per feature level a [B][H][W] mask that is 0
+// on the ceil(h / stride) x ceil(w / stride) corner the image covers and 1 on the padding - here from the DEVICE copy of the
+// image sizes (int64 [B][2] = (h, w)), all levels in one launch (the torch spelling was nine calls per level).
+struct FeedPadK {
+  uint8_t* out[MI_FEED_MAX_LEVELS];
+  int H[MI_FEED_MAX_LEVELS], W[MI_FEED_MAX_LEVELS], stride[MI_FEED_MAX_LEVELS];
+  const int64_t* sizes;
+  int B, nlev;
+};
+__global__ __launch_bounds__(256) void padding_masks_kernel(const FeedPadK p) {
+  const int lv = blockIdx.y;
+  const int H = p.H[lv], W = p.W[lv], st = p.stride[lv];
+  const int total = p.B * H * W;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int x = i % W, r = i / W;
+    const int y = r % H, b = r / H;
+    const int64_t hv = (p.sizes[b * 2] + (st - 1)) / st, wv = (p.sizes[b * 2 + 1] + (st - 1)) / st;      // ceil(size / stride)
+    p.out[lv][i] = (y >= hv || x >= wv) ? 1 : 0;
+  }
+}
+extern "C" int mi_padding_masks(const int64_t* sizes_dev, int B, int nlev, void* const* out, const int* H, const int* W,
+                                const int* stride, mi_stream_t st) {
+  MI_REQUIRE(sizes_dev && out && H && W && stride && B >= 1 && nlev >= 1 && nlev <= MI_FEED_MAX_LEVELS, "padding_masks: args");
+  FeedPadK k;
+  memset(&k, 0, sizeof(k));
+  int mx = 0;
+  for (int l = 0; l < nlev; ++l) {
+    MI_REQUIRE(out[l] && H[l] >= 1 && W[l] >= 1 && stride[l] >= 1, "padding_masks: level %d", l);
+    k.out[l] = (uint8_t*)out[l]; k.H[l] = H[l]; k.W[l] = W[l]; k.stride[l] = stride[l];
+    if (B * H[l] * W[l] > mx) mx = B * H[l] * W[l];
+  }
+  k.sizes = sizes_dev; k.B = B; k.nlev = nlev;
+  int gx = (mx + 255) / 256;
+  if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(padding_masks_kernel, dim3(gx, nlev), dim3(256), 0, (hipStream_t)st, k);
+  MI_CHECK_LAUNCH("padding_masks");
+  return MI_OK;
+}

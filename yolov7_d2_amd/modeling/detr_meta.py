@@ -103,6 +103,18 @@ class MaskedBackbone(nn.Module):
         as a hipGraph serves every batch of the same padded shape (Detr.prepare_batch)"""
         masks = []
         dev = sizes_dev.device
+        nlev = len(feature_shapes)
+        if feed_batch_enabled() and dev.type == "cuda" and nlev <= 8 and sizes_dev.dtype == torch.int64 and sizes_dev.is_contiguous():
+            # all levels in one launch (mi_padding_masks) instead of nine torch calls per level
+            import ctypes as C
+            masks = [torch.empty(s[0], s[2], s[3], dtype=torch.bool, device=dev) for s in feature_shapes]
+            ptrs = (C.c_void_p * nlev)(*[m.data_ptr() for m in masks])
+            Hs = (C.c_int * nlev)(*[int(s[2]) for s in feature_shapes])
+            Ws = (C.c_int * nlev)(*[int(s[3]) for s in feature_shapes])
+            sts = (C.c_int * nlev)(*[int(v) for v in self.feature_strides])
+            L.check(L.lib().mi_padding_masks(sizes_dev.data_ptr(), int(feature_shapes[0][0]), nlev, ptrs, Hs, Ws, sts, L.stream_ptr()),
+                    "mi_padding_masks")
+            return masks
         for idx, shape in enumerate(feature_shapes):
             N, _, H, W = shape
             st = self.feature_strides[idx]
