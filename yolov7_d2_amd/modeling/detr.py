@@ -78,7 +78,9 @@ class DETR(nn.Module):
             raise L.MI355Error("DETR: the MI355X path needs device tensors (no CPU fallback)")
         B, Cc, H, W = src.shape
         # input_proj: 1x1 conv with bias == a linear over the pixel rows
-        tok = _tok(src).permute(0, 2, 3, 1).reshape(B * H * W, Cc)
+        # (the backbone hands over NCHW-shaped channels_last memory: its NHWC view IS the token matrix - forming the NCHW copy
+        #  first and the NHWC one from it were two 18 MB passes per step)
+        tok = _tok(src.permute(0, 2, 3, 1)).reshape(B * H * W, Cc)
         w = self.input_proj.weight.view(self.input_proj.out_channels, Cc)
         proj = _LinearFn.apply(tok, w, self.input_proj.bias)
         proj = proj.reshape(B, H, W, -1).permute(0, 3, 1, 2)

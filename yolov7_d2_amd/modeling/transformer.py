@@ -605,6 +605,8 @@ class Transformer(nn.Module):
         bs, c, h, w = src.shape
         src = src.flatten(2).permute(2, 0, 1)
         pos_embed = pos_embed.flatten(2).permute(2, 0, 1)
+        if pos_embed.is_cuda and not pos_embed.requires_grad:
+            pos_embed = _tok(pos_embed)      # (a constant of the batch: its bf16 token layout once, not in every layer's _tok(pos))
         query_embed = query_embed.unsqueeze(1).repeat(1, bs, 1)
         mask = mask.flatten(1)
         tgt = torch.zeros_like(query_embed, dtype=torch.bfloat16)
