@@ -855,6 +855,15 @@ int mi_bilinear_resize_bf16(const void* x, int ldx, int N, int H, int W, int C, 
                             mi_stream_t s);
 int mi_bilinear_resize_bwd_bf16(const void* dy, int lddy, int N, int H, int W, int C, void* dx, int lddx, int Ho, int Wo,
                                 float* acc_ws_zeroed, mi_stream_t s);
+/* PyramidPoolingModule's pooling stages (transcoders/encoder_sparseinst.py:18-62: F.avg_pool2d(x, kernel = (kh, kw), stride =
+ * kernel, ceil_mode=False) per stage) of one bf16 NHWC map x [N][H][W][C] (ldx) in ONE launch: y[s] bf16 [N][H / kh[s]][W / kw[s]][C]
+ * dense; and the backward: dx = sum over the stages of dy[s] spread over its windows / (kh kw) (dy[s] NULL: no gradient).
+ * kh / kw / y / dy are HOST arrays of ns <= MI_PYR_MAX_STAGES entries. */
+#define MI_PYR_MAX_STAGES 8
+int mi_pyramid_pool_fwd(const void* x, int ldx, int N, int H, int W, int C, int ns, const int* kh, const int* kw, void* const* y,
+                        mi_stream_t s);
+int mi_pyramid_pool_bwd(void* const* dy, int N, int H, int W, int C, int ns, const int* kh, const int* kw, void* dx, int lddx,
+                        mi_stream_t s);
 /* masks bf16 logits [B][P][ldm] (instance = channel), targets fp32 [T][P], pairs int32 [K][3] = (b, n, t);
  * stats fp32 [K][8] = sum BCE, sum sig*t, sum sig^2, sum t^2, |sig>=.4 & t>.5|, |sig>=.4|, |t>.5|, 0 (rows with b < 0: zeros).
  * ws: mi_sparseinst_mask_stats_ws_floats(K, P) floats of block partials, summed in a fixed order (bit-reproducible; no

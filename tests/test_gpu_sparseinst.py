@@ -635,3 +635,38 @@ def test_fused_matcher_cost_and_criterion_equal_the_torch_spelling(monkeypatch):
     for k in ("dl", "ds", "dm"):
         scale = float(a[k].abs().max())
         assert scale > 0 and float((a[k] - b[k]).abs().max()) <= 1e-4 * scale, (k, float((a[k] - b[k]).abs().max()), scale)
+
+
+def test_pyramid_pooling_stages_in_one_launch_equal_the_torch_calls(monkeypatch):
+    """PyramidPoolingModule (encoder_sparseinst.py:18-62) with its four MyAdaptiveAvgPool2d stages as ONE launch forward and one
+    backward (mi_pyramid_pool_fwd / _bwd) against the same module spelled in torch calls (MI_SI_PPM_FUSED=0): the pooled maps to
+    one bf16 rounding, the module's output and gradients to bf16 accuracy - on a map whose size the windows do not divide"""
+    res = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("MI_SI_PPM_FUSED", fused)
+        torch.manual_seed(5)
+        ppm = S.PyramidPoolingModule(256, 64).to(DEV)
+        g = torch.Generator().manual_seed(6)
+        x = torch.randn(2, 256, 20, 23, generator=g).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = ppm(x)
+        gy = torch.randn(y.shape, generator=g).to(DEV)
+        (y.float() * gy).sum().backward()
+        torch.cuda.synchronize()
+        res.append(dict(y=y.detach().float(), dx=x.grad.float(), **{"g:" + k: p.grad.float() for k, p in ppm.named_parameters()}))
+    a, b = res
+    for k in a:
+        scale = float(a[k].abs().max()) + 1e-30
+        assert float((a[k] - b[k]).abs().max()) <= 2e-2 * scale, (k, float((a[k] - b[k]).abs().max()), scale)
+    # the pooling itself against torch, stage by stage
+    from yolov7_d2_amd.modeling.sparseinst import _PyramidPoolFn
+    x = torch.randn(2, 64, 20, 23, generator=torch.Generator().manual_seed(7)).to(torch.bfloat16).to(DEV).requires_grad_(True)
+    ks = ((20, 23), (10, 12), (7, 8), (4, 4))
+    outs = _PyramidPoolFn.apply(x, ks)
+    refs = [F.avg_pool2d(x.detach().float(), kernel_size=k, ceil_mode=False) for k in ks]
+    for o, r in zip(outs, refs):
+        assert o.shape == r.shape and float((o.float() - r).abs().max()) <= 2 ** -8 * float(r.abs().max())
+    gs = [torch.randn(r.shape, generator=torch.Generator().manual_seed(8)).to(torch.bfloat16).to(DEV) for r in refs]
+    torch.autograd.backward(outs, gs)
+    xr = x.detach().float().requires_grad_(True)
+    torch.autograd.backward([F.avg_pool2d(xr, kernel_size=k, ceil_mode=False) for k in ks], [g_.float() for g_ in gs])
+    assert float((x.grad.float() - xr.grad).abs().max()) <= 2 ** -7 * float(xr.grad.abs().max())

@@ -371,6 +371,8 @@ _PROTOS = {
     "mi_stream_create_cu_mask": (C.c_int, [C.POINTER(C.c_uint32), _i, C.POINTER(C.c_void_p)]),
     "mi_stream_destroy": (C.c_int, [_vp]),
     "mi_upload_async": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "mi_pyramid_pool_fwd": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "mi_pyramid_pool_bwd": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _vp]),
     "mi_sparseinst_match_cost": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _vp, _vp]),
     "mi_sparseinst_pairs": (C.c_int, [_vp, _vp]),
     "mi_sparseinst_head_loss": (C.c_int, [_vp, _vp]),

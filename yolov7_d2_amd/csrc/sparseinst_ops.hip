@@ -379,3 +379,116 @@ static int mask_grad_launch(const void* masks, int ldm, int P, const float* targ
   MI_CHECK_LAUNCH("sparseinst_mask_grad");
   return MI_OK;
 }
+
+// ---------------------------------------------------------------- pyramid pooling (encoder_sparseinst.py:18-62)
+// PyramidPoolingModule's MyAdaptiveAvgPool2d stages - F.avg_pool2d(x, kernel = (ceil(H / sz), ceil(W / sz)), stride = kernel,
+// ceil_mode=False) for sz in (1, 2, 3, 6) - of ONE bf16 NHWC map in one launch, and their backward (the sum of the four
+// stages' window-spread gradients) in one launch.  As torch calls each stage was float() + two avg_pool2d + to(bf16) forward
+// and the mirror image + an accumulation backward: ~35 launches of 4 - 12 us on a [8, 20, 20, 256] map.
+// fp32 window sums in a fixed order, one division by the window size (avg_pool2d's divisor with no padding).
+struct PyrPoolK {
+  const __bf16* x;      // [N][H][W][C] (ldx); backward: unused
+  __bf16* dx;           // backward: [N][H][W][C] (lddx)
+  __bf16* y[MI_PYR_MAX_STAGES];          // forward out / backward in: [N][oh][ow][C] dense
+  int kh[MI_PYR_MAX_STAGES], kw[MI_PYR_MAX_STAGES], oh[MI_PYR_MAX_STAGES], ow[MI_PYR_MAX_STAGES], first[MI_PYR_MAX_STAGES + 1];
+  int N, H, W, C8, ldx, ns;
+};
+// one BLOCK per (image, output pixel of any stage): thread (channel group c8 = tid % C8, part = tid / C8) sums every
+// (256 / C8)-th element of the window, the parts meet in LDS in a fixed order.  (One thread per output walks a 20 x 20
+// window alone: 400 dependent loads - the form torch's avg_pool2d has, 105 us for the 1-bin stage.)
+__global__ __launch_bounds__(256) void pyr_pool_fwd_kernel(const PyrPoolK p) {
+  __shared__ float red[256 * 8];
+  const int per_img = p.first[p.ns];
+  const int n = blockIdx.x / per_img, o = blockIdx.x - n * per_img;
+  int s = 0;
+  while (s + 1 < p.ns && o >= p.first[s + 1]) ++s;
+  const int oo = o - p.first[s], oy = oo / p.ow[s], ox = oo - oy * p.ow[s];
+  const int kh = p.kh[s], kw = p.kw[s], win = kh * kw;
+  const int C8 = p.C8, parts = 256 / C8;
+  const int tid = threadIdx.x, c8 = tid % C8, part = tid / C8;
+  float a[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a[e] = 0.f;
+  if (part < parts)
+    for (int w = part; w < win; w += parts) {
+      const int y = oy * kh + w / kw, x = ox * kw + w % kw;
+      const bf16x8 v = *(const bf16x8*)(p.x + (((int64_t)n * p.H + y) * p.W + x) * p.ldx + c8 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += (float)v[e];
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[tid * 8 + e] = a[e];
+  __syncthreads();
+  if (tid < C8) {
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = 0.f;
+    for (int q = 0; q < parts; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] += red[(q * C8 + tid) * 8 + e];
+    const float d = (float)win;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = t[e] / d;
+    *(bf16x8*)(p.y[s] + (((int64_t)n * p.oh[s] + oy) * p.ow[s] + ox) * (C8 * 8) + tid * 8) = pack8(t);
+  }
+}
+__global__ __launch_bounds__(256) void pyr_pool_bwd_kernel(const PyrPoolK p) {
+  const int64_t total = (int64_t)p.N * p.H * p.W * p.C8;
+  for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % p.C8);
+    int64_t r = i / p.C8;
+    const int x = (int)(r % p.W); r /= p.W;
+    const int y = (int)(r % p.H), n = (int)(r / p.H);
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    for (int s = 0; s < p.ns; ++s) {
+      const int oy = y / p.kh[s], ox = x / p.kw[s];
+      if (oy >= p.oh[s] || ox >= p.ow[s] || !p.y[s]) continue;      // (ceil_mode False: the remainder rows / columns feed no window)
+      const bf16x8 g = *(const bf16x8*)(p.y[s] + (((int64_t)n * p.oh[s] + oy) * p.ow[s] + ox) * (p.C8 * 8) + c8 * 8);
+      const float d = (float)(p.kh[s] * p.kw[s]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += (float)g[e] / d;
+    }
+    *(bf16x8*)(p.dx + (((int64_t)n * p.H + y) * p.W + x) * p.ldx + c8 * 8) = pack8(a);
+  }
+}
+static int pyr_fill(PyrPoolK* k, int N, int H, int W, int C, int ns, const int* kh, const int* kw, void* const* y) {
+  MI_REQUIRE(N >= 1 && H >= 1 && W >= 1 && C % 8 == 0 && ns >= 1 && ns <= MI_PYR_MAX_STAGES && kh && kw && y, "pyramid_pool: args");
+  memset(k, 0, sizeof(*k));
+  k->N = N; k->H = H; k->W = W; k->C8 = C / 8; k->ns = ns;
+  int off = 0;
+  for (int s = 0; s < ns; ++s) {
+    MI_REQUIRE(kh[s] >= 1 && kw[s] >= 1 && kh[s] <= H && kw[s] <= W, "pyramid_pool: stage %d window %d x %d on a %d x %d map", s, kh[s], kw[s], H, W);
+    k->kh[s] = kh[s]; k->kw[s] = kw[s]; k->oh[s] = H / kh[s]; k->ow[s] = W / kw[s];
+    k->y[s] = (__bf16*)y[s];
+    k->first[s] = off;
+    off += k->oh[s] * k->ow[s];
+  }
+  k->first[ns] = off;
+  return MI_OK;
+}
+extern "C" int mi_pyramid_pool_fwd(const void* x, int ldx, int N, int H, int W, int C, int ns, const int* kh, const int* kw,
+                                   void* const* y, mi_stream_t st) {
+  PyrPoolK k;
+  int rc = pyr_fill(&k, N, H, W, C, ns, kh, kw, y);
+  if (rc) return rc;
+  MI_REQUIRE(x && ldx % 8 == 0 && ldx >= C, "pyramid_pool_fwd: x");
+  for (int s = 0; s < ns; ++s) MI_REQUIRE(y[s], "pyramid_pool_fwd: output %d", s);
+  k.x = (const __bf16*)x; k.ldx = ldx;
+  MI_REQUIRE(k.C8 <= 256, "pyramid_pool_fwd: at most 2048 channels");
+  hipLaunchKernelGGL(pyr_pool_fwd_kernel, dim3((unsigned)(N * k.first[ns])), dim3(256), 0, (hipStream_t)st, k);
+  MI_CHECK_LAUNCH("pyramid_pool_fwd");
+  return MI_OK;
+}
+extern "C" int mi_pyramid_pool_bwd(void* const* dy, int N, int H, int W, int C, int ns, const int* kh, const int* kw, void* dx,
+                                   int lddx, mi_stream_t st) {
+  PyrPoolK k;
+  int rc = pyr_fill(&k, N, H, W, C, ns, kh, kw, dy);      // (a NULL dy[s]: that stage received no gradient)
+  if (rc) return rc;
+  MI_REQUIRE(dx && lddx % 8 == 0 && lddx >= C, "pyramid_pool_bwd: dx");
+  k.dx = (__bf16*)dx; k.ldx = lddx;
+  hipLaunchKernelGGL(pyr_pool_bwd_kernel, dim3(nblocks((int64_t)N * H * W * k.C8)), dim3(256), 0, (hipStream_t)st, k);
+  MI_CHECK_LAUNCH("pyramid_pool_bwd");
+  return MI_OK;
+}

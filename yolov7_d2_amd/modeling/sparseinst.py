@@ -309,6 +309,42 @@ class MyAdaptiveAvgPool2d(nn.Module):
         return F.avg_pool2d(xf, kernel_size=(kh, kw), ceil_mode=False).to(x.dtype)      # 1..36 output pixels
 
 
+class _PyramidPoolFn(torch.autograd.Function):
+    """the pooling stages of PyramidPoolingModule (MyAdaptiveAvgPool2d per stage, encoder_sparseinst.py:18-40) on one map as
+    ONE launch, their backward as one launch (mi_pyramid_pool_fwd / _bwd): x NCHW-shaped -> one NCHW-shaped (channels_last
+    memory) bf16 map per stage.  As torch calls: float() + two avg_pool2d + to(bf16) per stage, and the mirror image + the
+    accumulation of the four input gradients backward - ~35 launches on a [8, 256, 20, 20] map."""
+
+    @staticmethod
+    def forward(ctx, x, kernels):
+        xh = _nhwc_v(x)
+        N, H, W, Cc = xh.shape
+        ns = len(kernels)
+        ys = [torch.empty(N, H // kh, W // kw, Cc, dtype=torch.bfloat16, device=x.device) for kh, kw in kernels]
+        khs, kws = (C.c_int * ns)(*[k[0] for k in kernels]), (C.c_int * ns)(*[k[1] for k in kernels])
+        ptrs = (C.c_void_p * ns)(*[y.data_ptr() for y in ys])
+        L.check(L.lib().mi_pyramid_pool_fwd(xh.data_ptr(), _ld(xh), N, H, W, Cc, ns, khs, kws, ptrs, L.stream_ptr()), "mi_pyramid_pool_fwd")
+        ctx.kernels, ctx.shape, ctx.dtype = kernels, (N, H, W, Cc), x.dtype
+        return tuple(y.permute(0, 3, 1, 2) for y in ys)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        N, H, W, Cc = ctx.shape
+        ns = len(ctx.kernels)
+        ghs = [None if g is None else _nhwc(g) for g in gs]
+        dx = torch.empty(N, H, W, Cc, dtype=torch.bfloat16, device=next(g for g in ghs if g is not None).device)
+        khs, kws = (C.c_int * ns)(*[k[0] for k in ctx.kernels]), (C.c_int * ns)(*[k[1] for k in ctx.kernels])
+        ptrs = (C.c_void_p * ns)(*[None if g is None else g.data_ptr() for g in ghs])
+        L.check(L.lib().mi_pyramid_pool_bwd(ptrs, N, H, W, Cc, ns, khs, kws, dx.data_ptr(), Cc, L.stream_ptr()), "mi_pyramid_pool_bwd")
+        return dx.permute(0, 3, 1, 2).to(ctx.dtype), None
+
+
+def _PPM_FUSED():
+    """MI_SI_PPM_FUSED=0: the pooling stages as torch calls (round 5's form; A/B, tests)"""
+    import os
+    return os.environ.get("MI_SI_PPM_FUSED", "1") != "0"
+
+
 class PyramidPoolingModule(nn.Module):
     def __init__(self, in_channels, channels=512, sizes=(1, 2, 3, 6)):
         super().__init__()
@@ -318,7 +354,16 @@ class PyramidPoolingModule(nn.Module):
 
     def forward(self, feats):
         h, w = feats.shape[2], feats.shape[3]
-        priors = [resize_bilinear(_conv(st[0](feats), st[1], relu=True), (h, w)) for st in self.stages] + [feats]
+        if _PPM_FUSED() and feats.is_cuda and feats.shape[1] % 8 == 0 and len(self.stages) <= 8:
+            kernels = []
+            for st in self.stages:
+                sz = st[0].sz
+                sz = (sz, sz) if isinstance(sz, int) else sz
+                kernels.append((h, w) if sz is None else (math.ceil(h / sz[0]), math.ceil(w / sz[1])))
+            pooled = _PyramidPoolFn.apply(feats.to(torch.bfloat16), tuple(kernels))
+        else:
+            pooled = [st[0](feats) for st in self.stages]
+        priors = [resize_bilinear(_conv(pl, st[1], relu=True), (h, w)) for pl, st in zip(pooled, self.stages)] + [feats]
         return _conv(torch.cat(priors, 1), self.bottleneck, relu=True)
 
 

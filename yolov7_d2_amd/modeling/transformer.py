@@ -609,6 +609,8 @@ class Transformer(nn.Module):
             pos_embed = _tok(pos_embed)      # (a constant of the batch: its bf16 token layout once, not in every layer's _tok(pos))
         query_embed = query_embed.unsqueeze(1).repeat(1, bs, 1)
         mask = mask.flatten(1)
+        if mask.is_cuda:
+            mask = mask.to(torch.uint8).contiguous()     # (what the attention kernels read: once, not in each of the 18 attention calls)
         tgt = torch.zeros_like(query_embed, dtype=torch.bfloat16)
         memory = self.encoder(src, src_key_padding_mask=mask, pos=pos_embed)
         hs = self.decoder(tgt, memory, memory_key_padding_mask=mask, pos=pos_embed, query_pos=query_embed)
