@@ -506,7 +506,11 @@ __global__ __launch_bounds__(SPP_T) void spp_fwd_plane_kernel(const __bf16* __re
   const __bf16* xb = x + ((int64_t)n * HW) * ldx + c8 * 8;
   for (int p = threadIdx.x; p < HW; p += SPP_T) Xp[p] = *(const bf16x8*)(xb + (int64_t)p * ldx);
   __syncthreads();
-  for (int k = 0; k < 3; ++k) {
+  // gridDim.y == 3 (round 6): the three window sizes are three BLOCKS of the plane (each loads it: 3.3 MB in all) - the
+  // kernel is bound by the serial chain inside a block (window loads, barrier, window loads per size), and a third of the
+  // chain on three times as many resident blocks hides it better than one block walking all three
+  const int k_lo = gridDim.y == 3 ? (int)blockIdx.y : 0, k_hi = gridDim.y == 3 ? (int)blockIdx.y + 1 : 3;
+  for (int k = k_lo; k < k_hi; ++k) {
     const int r = 2 + 2 * k;
     for (int p = threadIdx.x; p < HW; p += SPP_T) {
       const int py = p / W, px = p - py * W;
@@ -658,7 +662,9 @@ extern "C" int mi_spp_pool_fwd(const void* x, int ldx, void* y5, void* y9, void*
     hipFuncSetAttribute((const void*)spp_bwd_plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL(spp_fwd_plane_kernel, dim3(N * (C / 8)), dim3(SPP_T), lds, (hipStream_t)st, (const __bf16*)x, ldx,
+  const char* sk = getenv("MI_SPP_SPLIT");        // (read per call: the tests compare the two forms in one process)
+  const int split = sk ? atoi(sk) : 1;
+  hipLaunchKernelGGL(spp_fwd_plane_kernel, dim3(N * (C / 8), split ? 3 : 1), dim3(SPP_T), lds, (hipStream_t)st, (const __bf16*)x, ldx,
                      (__bf16*)y5, (__bf16*)y9, (__bf16*)y13, ldy, idx, N, H, W, C / 8);
   MI_CHECK_LAUNCH("spp_fwd");
   return MI_OK;
