@@ -44,6 +44,7 @@ struct Wg2K {
   float* g;
   const float* row_scale;
   int Cout, Cin, accumulate, pad_;
+  int ra, rb;         // xmap 2: the splits that do not fill a group of 8 hand every XCD a compact ra x rb block of (cout, cin) tiles (0: off)
   long long cnt_rel;  // byte offset from the group's job array to this job's tile counters (64 words per output tile)
 };
 
@@ -293,6 +294,42 @@ __device__ __forceinline__ void wg_fixup(const Wg2K& p, unsigned* const cnt, con
   }
 }
 
+// block id -> (split s, output tile pair).  Workgroup b runs on XCD b % 8 (observed placement, speed only): with the
+// XCD-aware order the nco*nci blocks that read the SAME pixel range (dy re-read per cin block, x per cout block) sit
+// 8 ids apart - same XCD, dispatched together, so the second reader finds the tile in that XCD's L2 instead of HBM.
+// That covers the splits in whole groups of 8.  The remaining r < 8 splits (ALL of them for the layers of a per-block group:
+// 1 - 4 splits of 32 - 128 tile pairs) were dealt pair by pair over the XCDs - every XCD fetched every operand tile: counters
+// on the DETR-R50 step, 680 MB fetched by a launch whose operands are 125 MB (profiles/r06_wgrad_xcd_rect.txt).  xmap 2:
+// the r x npairs remaining items are ordered so that the 8 residue classes of the block id own CONTIGUOUS ranges of them,
+// and a range is a few ra x rb rectangles of the (cout, cin) tile grid: ra + rb operand tiles per ra * rb blocks.
+template <class PK>
+__device__ __forceinline__ void wg_decode(const PK& p, const int bid, int& s, int& pair) {
+  const int npairs = p.nco * p.nci;
+  const int s8 = p.xmap ? (p.nsplit & ~7) : 0;  // splits covered by full groups of 8
+  const int full = s8 * npairs;
+  if (bid < full) {
+    const int k = bid >> 3;
+    pair = k % npairs;
+    s = (k / npairs) * 8 + (bid & 7);
+    return;
+  }
+  const int rem = bid - full, r = p.nsplit - s8;
+  if (p.ra > 0) {
+    const int m = (r * npairs) >> 3;                   // items per XCD (host: r * npairs % 8 == 0, ra * rb | gcd(m, npairs))
+    const int idx = (rem & 7) * m + (rem >> 3);
+    const int so = idx / npairs, pi = idx - so * npairs;
+    const int rsz = p.ra * p.rb, c = pi / rsz, w = pi - c * rsz;
+    const int nca = p.nco / p.ra;
+    const int ca = c % nca, cb = c / nca;
+    const int da = w % p.ra, db = w / p.ra;
+    s = s8 + so;
+    pair = (ca * p.ra + da) + (cb * p.rb + db) * p.nco;
+    return;
+  }
+  s = s8 + rem % r;
+  pair = rem / r;
+}
+
 template <int NT, int MI, int NJ, int WCO, int WCI, int TP, bool FIX = false>
 __device__ __forceinline__ void wgrad2_body(const Wg2K& p, const int bid, unsigned* const cnt = nullptr) {
   constexpr int NW = WCO * WCI, BCO = 16 * MI * WCO, BCI = 16 * NJ * WCI;
@@ -310,24 +347,8 @@ __device__ __forceinline__ void wgrad2_body(const Wg2K& p, const int bid, unsign
   const int g = lane >> 4, t = lane & 15;
   const int wco = wave / WCI, wci = wave % WCI;
 
-  // block id -> (split s, output tile pair).  Workgroup b runs on XCD b % 8 (observed placement, speed only): with the
-  // XCD-aware order the nco*nci blocks that read the SAME pixel range (dy re-read per cin block, x per cout block) sit
-  // 8 ids apart - same XCD, dispatched together, so the second reader finds the tile in that XCD's L2 instead of HBM.
   int s, pair;
-  {
-    const int npairs = p.nco * p.nci;
-    const int s8 = p.xmap ? (p.nsplit & ~7) : 0;  // splits covered by full groups of 8
-    const int full = s8 * npairs;
-    if (bid < full) {
-      const int k = bid >> 3;
-      pair = k % npairs;
-      s = (k / npairs) * 8 + (bid & 7);
-    } else {
-      const int rem = bid - full, r = p.nsplit - s8;
-      s = s8 + rem % r;
-      pair = rem / r;
-    }
-  }
+  wg_decode(p, bid, s, pair);
   const int cob = pair % p.nco, cib = pair / p.nco;
   const int co0 = cob * BCO, ci0 = cib * BCI;
   const int TPv = p.TH * p.TW;
@@ -533,20 +554,7 @@ __device__ __forceinline__ void wgrad3_body(const Wg2K& p, const int bid, unsign
   const int wco = wave / WCI, wci = wave % WCI;
 
   int s, pair;
-  {
-    const int npairs = p.nco * p.nci;
-    const int s8 = p.xmap ? (p.nsplit & ~7) : 0;
-    const int full = s8 * npairs;
-    if (bid < full) {
-      const int k = bid >> 3;
-      pair = k % npairs;
-      s = (k / npairs) * 8 + (bid & 7);
-    } else {
-      const int rem = bid - full, r = p.nsplit - s8;
-      s = s8 + rem % r;
-      pair = rem / r;
-    }
-  }
+  wg_decode(p, bid, s, pair);
   const int cob = pair % p.nco, cib = pair / p.nco;
   const int co0 = cob * BCO, ci0 = cib * BCI;
   const int TPv = p.TH * p.TW;
@@ -878,7 +886,7 @@ static int wg_env(const char* name, int dflt) {
   const char* e = getenv(name);
   return (e && *e) ? atoi(e) : dflt;
 }
-static int wg_xmap() { static const int v = wg_env("MI_WG_XMAP", 1); return v; }
+static int wg_xmap() { return wg_env("MI_WG_XMAP", 1); }      // (read per plan: tests and A/B runs build both orders in one process)
 static int wg_units() { static const int v = wg_env("MI_WG_UNITS", 0); return v; }
 static int wg_red9() { static const int v = wg_env("MI_WG_RED9", 0); return v; }
 // threads per output float4 of the split-K reduction (1 or 4; see wgrad2_reduce_body)
@@ -1034,6 +1042,25 @@ static int wg_fill(const mi_wgrad_desc* d, Wg2K* k, Wg2Cfg* c, size_t* lds, size
   k->bpart = nullptr; k->bld = 0; k->pad_ = 0;
   k->fix = 0; k->g = d->gw; k->row_scale = d->row_scale; k->Cout = d->Cout; k->Cin = d->Cin; k->accumulate = d->accumulate;
   k->cnt_rel = 0;
+  k->ra = k->rb = 0;
+  if (k->xmap >= 2) {      // compact (cout, cin) rectangles per XCD for the splits outside the groups of 8 (wg_decode)
+    const int s8 = k->nsplit & ~7, r = k->nsplit - s8, np = k->nco * k->nci;
+    const long total = (long)r * np;
+    if (r > 0 && total % 8 == 0) {
+      long a = total / 8, b = np;
+      while (b) { const long t_ = a % b; a = b; b = t_; }      // a = gcd(items per XCD, pairs per split)
+      int ba = 0, bb = 0;
+      for (int ra = 1; ra <= k->nco; ++ra) {
+        if (k->nco % ra) continue;
+        for (int rb = 1; rb <= k->nci; ++rb) {
+          if (k->nci % rb || a % ((long)ra * rb)) continue;
+          const long cur = (long)ra * rb, best = (long)ba * bb;
+          if (cur > best || (cur == best && abs(ra - rb) < abs(ba - bb))) { ba = ra; bb = rb; }
+        }
+      }
+      if ((long)ba * bb >= 2) { k->ra = ba; k->rb = bb; }
+    }
+  }
   if (d->gbias) {     // the bias partials behind the slabs (grouped: the group plan points bpart behind the job's slabs)
     k->bld = d->CoutPad;
     k->bpart = (d->ws && !grouped) ? (float*)((char*)d->ws + *ws) : (float*)(uintptr_t)16;   // (planning call without a workspace: non-null marker)
