@@ -497,7 +497,8 @@ def test_wgrad_fixup_table_layout(monkeypatch):
                     [("toff", C.c_int32 * L.MI_MAX_TAPS), ("nco", C.c_int32), ("nci", C.c_int32), ("nrx", C.c_int32),
                      ("xmap", C.c_int32), ("mTW", C.c_uint32), ("mHW", C.c_uint32), ("V", C.c_longlong), ("bpart", C.c_void_p),
                      ("bld", C.c_int32), ("fix", C.c_int32), ("g", C.c_void_p), ("row_scale", C.c_void_p), ("Cout", C.c_int32),
-                     ("Cin", C.c_int32), ("accumulate", C.c_int32), ("pad_", C.c_int32), ("cnt_rel", C.c_longlong)])
+                     ("Cin", C.c_int32), ("accumulate", C.c_int32), ("pad_", C.c_int32), ("ra", C.c_int32), ("rb", C.c_int32),
+                         ("cnt_rel", C.c_longlong)])
 
     model, _ = _model()
     monkeypatch.setenv("MI_WG_FIXUP", "1")
