@@ -99,6 +99,50 @@ def test_simota_full_size_properties():
     assert abs(float(ws["out"][6]) - sum(a["num_fg"] for a in assigns)) == 0
 
 
+def _forms_equal(raw, labels, anchors, monkeypatch, **kw):
+    monkeypatch.setenv("MI_SIMOTA_COMPACT", "0")
+    monkeypatch.setenv("MI_SIMOTA_PREFILTER", "0")
+    ref = _loss_call(raw, labels, anchors, **kw)
+    for c, pf in (("1", "0"), ("0", "1"), ("1", "1")):
+        monkeypatch.setenv("MI_SIMOTA_COMPACT", c)
+        monkeypatch.setenv("MI_SIMOTA_PREFILTER", pf)
+        got = _loss_call(raw, labels, anchors, **kw)
+        for k in ("cost", "iou", "ngt", "fg", "matched_gt", "matched_iou", "out", "dpreds"):
+            assert torch.equal(ref[k], got[k]), (c, pf, k)
+    monkeypatch.delenv("MI_SIMOTA_COMPACT")
+    monkeypatch.delenv("MI_SIMOTA_PREFILTER")
+    return ref
+
+
+def test_simota_compacted_and_prefiltered_forms_are_bit_identical(monkeypatch):
+    """round 6: candidate compaction in the cost kernel and the pre-filtered dynamic-k selection against the round-5 kernels:
+    every output word equal - at the bench size, with exact ties (all logits equal: the orders fall back on the anchor index),
+    with lists that overflow the LDS capacity (the block-wide rounds take over), with <= 9 candidates, with 2 100 anchors"""
+    B, H, W = 16, 640, 640
+    _, labels = O.synth_batch(B, H, W, seed=1234, max_gt=20)
+    hw = [(H // s, W // s) for s in (8, 16, 32)]
+    raw, anchors = O.synth_raw(B, hw, 35, labels=labels)
+    ws = _forms_equal(raw, labels, anchors, monkeypatch)
+    assert int(ws["fg"].sum()) > 100
+    # exact ties everywhere: constant predictions (equal IoU along rows / columns of the grid, equal class terms), one huge
+    # box per image so that thousands of anchors are candidates of equal cost: the lists overflow -> fallback path
+    raw0 = torch.zeros(2, anchors.shape[0], 85)
+    lab0 = torch.zeros(2, 100, 5)
+    lab0[0, 0] = torch.tensor([3.0, 320, 320, 600, 600])
+    lab0[0, 1] = torch.tensor([7.0, 100, 100, 64, 64])
+    lab0[1, 0] = torch.tensor([1.0, 320, 320, 16, 16])
+    ws = _forms_equal(raw0, lab0, anchors, monkeypatch)
+    assert int(ws["fg"][0].sum()) >= 2 and int(ws["fg"][1].sum()) >= 1
+    # few candidates (a 4-pixel box: only its centre-radius anchors) and the small-map instantiation (NV = 9)
+    hw2 = [(40, 40), (20, 20), (10, 10)]
+    anchors2 = O.make_anchors(hw2)
+    _, lab2 = O.synth_batch(3, 320, 320, seed=5, max_gt=8)
+    lab2[2] = 0.0
+    lab2[2, 0] = torch.tensor([2.0, 7, 9, 4, 4])
+    raw2, _ = O.synth_raw(3, hw2, 36, labels=lab2)
+    _forms_equal(raw2, lab2, anchors2, monkeypatch, use_l1=True, gw=(1, 1, 1, 1, 1))
+
+
 def test_loss_edge_cases():
     hw = [(8, 8), (4, 4), (2, 2)]
     anchors = O.make_anchors(hw)

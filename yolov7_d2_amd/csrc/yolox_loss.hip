@@ -11,6 +11,7 @@
 // The reference loops over images and ground truths on the host with .item() syncs; here the
 // batch is processed by four launches.  Compile with -ffp-contract=off: the float expressions keep
 // the reference's operation order so near-ties resolve the same way.
+#include <stdlib.h>
 #include "common.h"
 #include "iou_v6.h"
 
@@ -63,52 +64,15 @@ __device__ int count_labels(const float* lab, int max_labels) {
 }
 
 // ---- kernel 1: candidates, pairwise IoU and cost
-__global__ __launch_bounds__(256) void simota_cost_kernel(const LossK p) {
-  extern __shared__ float slab[];  // [gmax][5]
-  __shared__ int s_ngt;
-  const int b = blockIdx.y;
-  const float* lab = p.labels + (size_t)b * p.max_labels * 5;
-  if (threadIdx.x == 0) {
-    int n = count_labels(lab, p.max_labels);
-    if (n > p.gmax) n = p.gmax;
-    s_ngt = n;
-    if (blockIdx.x == 0) p.ngt[b] = n;
-  }
-  for (int i = threadIdx.x; i < p.gmax * 5; i += 256) slab[i] = lab[i];
-  __syncthreads();
-  const int G = s_ngt;
-  const int a = blockIdx.x * 256 + threadIdx.x;
-  if (a >= p.A) return;
-  // per-anchor match counter / matched gt, filled by the dynamic-k kernels with atomics and consumed by the resolve
-  // kernel, which then stores the final values in the same words (the count lives in matched_iou's bits until then)
-  p.matched_gt[(size_t)b * p.A + a] = -1;
-  ((int32_t*)p.matched_iou)[(size_t)b * p.A + a] = 0;
+// one candidate anchor: decode, class term, its cost / IoU against the image's G ground truths
+__device__ __forceinline__ void simota_cost_candidate(const LossK& p, const float* slab, int G, int b, int a) {
   const float* pr = p.preds + ((size_t)b * p.A + a) * p.nch;
   const float gxs = p.anchors[a * 3 + 0], gys = p.anchors[a * 3 + 1], st = p.anchors[a * 3 + 2];
-  // anchor centre (yolox_head.py:558-570)
   const float xc = gxs * st + 0.5f * st;
   const float yc = gys * st + 0.5f * st;
-  bool cand = false;
-  for (int g = 0; g < G; ++g) {
-    const float gcx = slab[g * 5 + 1], gcy = slab[g * 5 + 2], gw = slab[g * 5 + 3], gh = slab[g * 5 + 4];
-    const float bl = xc - (gcx - 0.5f * gw), br = (gcx + 0.5f * gw) - xc;
-    const float bt = yc - (gcy - 0.5f * gh), bb = (gcy + 0.5f * gh) - yc;
-    const bool inb = fminf(fminf(bl, bt), fminf(br, bb)) > 0.0f;
-    const float cl = xc - (gcx - p.center_radius * st), cr = (gcx + p.center_radius * st) - xc;
-    const float ct = yc - (gcy - p.center_radius * st), cb = (gcy + p.center_radius * st) - yc;
-    const bool inc = fminf(fminf(cl, ct), fminf(cr, cb)) > 0.0f;
-    cand = cand || inb || inc;
-  }
   const size_t rowstride = (size_t)p.A;
   float* costp = p.cost + (size_t)b * p.gmax * rowstride + a;
   float* ioup = p.iou + (size_t)b * p.gmax * rowstride + a;
-  if (!cand) {
-    for (int g = 0; g < G; ++g) {
-      costp[g * rowstride] = SIMOTA_INF;
-      ioup[g * rowstride] = -1.0f;
-    }
-    return;
-  }
   // decode (yolox_head.py:243-244)
   const float px = (pr[0] + gxs) * st, py = (pr[1] + gys) * st;
   const float pw = expf(pr[2]) * st, ph = expf(pr[3]) * st;
@@ -154,6 +118,76 @@ __global__ __launch_bounds__(256) void simota_cost_kernel(const LossK p) {
     cost = cost + 100000.0f * ((inb && inc) ? 0.f : 1.f);
     costp[g * rowstride] = cost;
     ioup[g * rowstride] = iou;
+  }
+}
+
+// COMPACT: the block's candidate anchors (a third of the anchors with COCO-sized boxes, scattered over the lanes) are
+// gathered into a list and the first ncand threads take one each: the ~100 transcendentals per candidate run in full
+// waves instead of in every wave at a third of its lanes.  Same expressions per (anchor, gt): identical outputs.
+template <bool COMPACT>
+__global__ __launch_bounds__(256) void simota_cost_kernel(const LossK p) {
+  extern __shared__ float slab[];  // [gmax][5]
+  __shared__ int s_ngt;
+  __shared__ int s_wn[4];
+  __shared__ unsigned short s_list[256];
+  const int b = blockIdx.y;
+  const float* lab = p.labels + (size_t)b * p.max_labels * 5;
+  if (threadIdx.x == 0) {
+    int n = count_labels(lab, p.max_labels);
+    if (n > p.gmax) n = p.gmax;
+    s_ngt = n;
+    if (blockIdx.x == 0) p.ngt[b] = n;
+  }
+  for (int i = threadIdx.x; i < p.gmax * 5; i += 256) slab[i] = lab[i];
+  __syncthreads();
+  const int G = s_ngt;
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  bool cand = false;
+  if (a < p.A) {
+    // per-anchor match counter / matched gt, filled by the dynamic-k kernels with atomics and consumed by the resolve
+    // kernel, which then stores the final values in the same words (the count lives in matched_iou's bits until then)
+    p.matched_gt[(size_t)b * p.A + a] = -1;
+    ((int32_t*)p.matched_iou)[(size_t)b * p.A + a] = 0;
+    const float gxs = p.anchors[a * 3 + 0], gys = p.anchors[a * 3 + 1], st = p.anchors[a * 3 + 2];
+    // anchor centre (yolox_head.py:558-570)
+    const float xc = gxs * st + 0.5f * st;
+    const float yc = gys * st + 0.5f * st;
+    for (int g = 0; g < G; ++g) {
+      const float gcx = slab[g * 5 + 1], gcy = slab[g * 5 + 2], gw = slab[g * 5 + 3], gh = slab[g * 5 + 4];
+      const float bl = xc - (gcx - 0.5f * gw), br = (gcx + 0.5f * gw) - xc;
+      const float bt = yc - (gcy - 0.5f * gh), bb = (gcy + 0.5f * gh) - yc;
+      const bool inb = fminf(fminf(bl, bt), fminf(br, bb)) > 0.0f;
+      const float cl = xc - (gcx - p.center_radius * st), cr = (gcx + p.center_radius * st) - xc;
+      const float ct = yc - (gcy - p.center_radius * st), cb = (gcy + p.center_radius * st) - yc;
+      const bool inc = fminf(fminf(cl, ct), fminf(cr, cb)) > 0.0f;
+      cand = cand || inb || inc;
+    }
+    if (!cand) {
+      const size_t rowstride = (size_t)p.A;
+      float* costp = p.cost + (size_t)b * p.gmax * rowstride + a;
+      float* ioup = p.iou + (size_t)b * p.gmax * rowstride + a;
+      for (int g = 0; g < G; ++g) {
+        costp[g * rowstride] = SIMOTA_INF;
+        ioup[g * rowstride] = -1.0f;
+      }
+    }
+  }
+  if constexpr (!COMPACT) {
+    if (cand) simota_cost_candidate(p, slab, G, b, a);
+  } else {
+    const unsigned long long m = __ballot(cand);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_wn[wave] = __popcll(m);
+    __syncthreads();
+    int off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) off += s_wn[w];
+      total += s_wn[w];
+    }
+    if (cand) s_list[off + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)threadIdx.x;
+    __syncthreads();
+    if ((int)threadIdx.x < total) simota_cost_candidate(p, slab, G, b, blockIdx.x * 256 + s_list[threadIdx.x]);
   }
 }
 
@@ -268,6 +302,173 @@ __global__ __launch_bounds__(256) void simota_dynk_reg_kernel(const LossK p) {
     }
     lv = s.v;
     li = s.i;
+  }
+}
+
+// Pre-filtered variant of simota_dynk_reg_kernel: the ~20 block-wide selection rounds (each a scan of NV registers per
+// thread, a wave reduction and two barriers: ~2 us per round with one wave per SIMD) become two passes over the registers
+// and wave-level rounds over a short list.  The 10th best of the 256 per-thread bests bounds the 10th best element from
+// below, so every element of the top 10 is at or before it in the total order: those elements (typically 10 - 40) go to a
+// list in LDS and one wave takes the ordered selections from there.  k <= 10 (the sum of ten IoUs), so the same bound
+// serves the k smallest costs.  Same total order (ties -> smaller index), same descending summation order: identical
+// results; a list that overflows (or k > 10) falls back to the block-wide rounds.
+#define DYNK_CAP 512
+template <bool DESC>
+__device__ __forceinline__ bool kv_valid(float v) {
+  if (DESC) return !(v <= -0.5f || v >= INFINITY);
+  return !(v <= -INFINITY || v >= SIMOTA_INF);
+}
+template <bool DESC>
+__device__ __forceinline__ KV wave_select(const KV* list, int M, float lv, int li) {
+  float bv = 0.f;
+  int bi = -1;
+  for (int j = threadIdx.x & 63; j < M; j += 64) {
+    const KV e = list[j];
+    if (e.i < 0 || !kv_after<DESC>(e.v, e.i, lv, li)) continue;
+    if (kv_better<DESC>(e.v, e.i, bv, bi)) { bv = e.v; bi = e.i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (oi >= 0 && kv_better<DESC>(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+  }
+  KV r;
+  r.v = bv;
+  r.i = bi;
+  return r;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void simota_dynk_pre_kernel(const LossK p) {
+  __shared__ KV s_best[2][256];
+  __shared__ KV s_list[2][DYNK_CAP];
+  __shared__ KV s_thr[2];
+  __shared__ int s_cnt[2];
+  __shared__ int s_k;
+  __shared__ KV sred[4];
+  const int g = blockIdx.x, b = blockIdx.y;
+  if (g >= p.ngt[b]) return;
+  const float* iour = p.iou + ((size_t)b * p.gmax + g) * p.A;
+  const float* costr = p.cost + ((size_t)b * p.gmax + g) * p.A;
+  int32_t* cntr = (int32_t*)p.matched_iou + (size_t)b * p.A;
+  int32_t* gselr = p.matched_gt + (size_t)b * p.A;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  float vi[NV], vc[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int a = tid + 256 * j;
+    vi[j] = a < p.A ? iour[a] : -1.0f;
+    vc[j] = a < p.A ? costr[a] : SIMOTA_INF;
+  }
+  // ---- per-thread bests
+  {
+    float bvi = 0.f, bvc = 0.f;
+    int bii = -1, bic = -1;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int a = tid + 256 * j;
+      if (a < p.A && kv_valid<true>(vi[j]) && kv_better<true>(vi[j], a, bvi, bii)) { bvi = vi[j]; bii = a; }
+      if (a < p.A && kv_valid<false>(vc[j]) && kv_better<false>(vc[j], a, bvc, bic)) { bvc = vc[j]; bic = a; }
+    }
+    s_best[0][tid].v = bvi; s_best[0][tid].i = bii;
+    s_best[1][tid].v = bvc; s_best[1][tid].i = bic;
+    if (tid < 2) s_cnt[tid] = 0;
+  }
+  __syncthreads();
+  // ---- the bounds: wave 0 the 10th largest of the IoU bests, wave 1 the 10th smallest of the cost bests (i < 0: fewer than
+  // ten threads hold a valid element - then there are at most 9 NV of them and all are listed)
+  if (wave < 2) {
+    float lv = 0.f;
+    int li = -1, r = 0;
+    for (; r < 10; ++r) {
+      const KV s = wave == 0 ? wave_select<true>(s_best[0], 256, lv, li) : wave_select<false>(s_best[1], 256, lv, li);
+      if (s.i < 0) break;
+      lv = s.v;
+      li = s.i;
+    }
+    if ((tid & 63) == 0) {
+      s_thr[wave].v = lv;
+      s_thr[wave].i = r == 10 ? li : -1;
+    }
+  }
+  __syncthreads();
+  {
+    const KV ti = s_thr[0], tc = s_thr[1];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int a = tid + 256 * j;
+      if (a >= p.A) continue;
+      if (kv_valid<true>(vi[j]) && (ti.i < 0 || !kv_after<true>(vi[j], a, ti.v, ti.i))) {
+        const int pos = atomicAdd(&s_cnt[0], 1);
+        if (pos < DYNK_CAP) { s_list[0][pos].v = vi[j]; s_list[0][pos].i = a; }
+      }
+      if (kv_valid<false>(vc[j]) && (tc.i < 0 || !kv_after<false>(vc[j], a, tc.v, tc.i))) {
+        const int pos = atomicAdd(&s_cnt[1], 1);
+        if (pos < DYNK_CAP) { s_list[1][pos].v = vc[j]; s_list[1][pos].i = a; }
+      }
+    }
+  }
+  __syncthreads();
+  const int Mi = s_cnt[0], Mc = s_cnt[1];
+  // ---- top-10 IoU among candidates, summed in descending order
+  float sum = 0.f, lv = 0.f;
+  int li = -1;
+  if (Mi <= DYNK_CAP) {
+    if (wave == 0) {
+      for (int r = 0; r < 10; ++r) {
+        const KV s = wave_select<true>(s_list[0], Mi, lv, li);
+        if (s.i < 0) break;
+        sum += s.v;
+        lv = s.v;
+        li = s.i;
+      }
+      int k = (int)sum;
+      if (k < 1) k = 1;
+      if (tid == 0) s_k = k;
+    }
+    __syncthreads();
+  } else {
+    for (int r = 0; r < 10; ++r) {
+      const KV s = block_select_reg<true, NV>(vi, p.A, lv, li, -0.5f, INFINITY, sred);
+      if (s.i < 0) break;
+      sum += s.v;
+      lv = s.v;
+      li = s.i;
+    }
+    int k = (int)sum;
+    if (k < 1) k = 1;
+    __syncthreads();
+    if (tid == 0) s_k = k;
+    __syncthreads();
+  }
+  const int k = s_k;
+  lv = 0.f;
+  li = -1;
+  if (Mc <= DYNK_CAP && k <= 10) {
+    if (wave == 0) {
+      for (int r = 0; r < k; ++r) {
+        const KV s = wave_select<false>(s_list[1], Mc, lv, li);
+        if (s.i < 0) break;
+        if (tid == 0) {   // matching_matrix[g][s.i] = 1: count the anchor's matches, remember one of its gts
+          atomicAdd(cntr + s.i, 1);
+          atomicMax(gselr + s.i, g);
+        }
+        lv = s.v;
+        li = s.i;
+      }
+    }
+  } else {
+    for (int r = 0; r < k; ++r) {
+      const KV s = block_select_reg<false, NV>(vc, p.A, lv, li, -INFINITY, SIMOTA_INF, sred);
+      if (s.i < 0) break;
+      if (tid == 0) {
+        atomicAdd(cntr + s.i, 1);
+        atomicMax(gselr + s.i, g);
+      }
+      lv = s.v;
+      li = s.i;
+    }
   }
 }
 
@@ -465,14 +666,25 @@ extern "C" int mi_yolox_loss_fwd(const mi_yolox_loss_desc* d, mi_stream_t st) {
   if (rc) return rc;
   hipStream_t s = (hipStream_t)st;
   const int nb = mi_cdiv(d->A, 256);
-  hipLaunchKernelGGL(simota_cost_kernel, dim3(nb, d->B), dim3(256), d->gmax * 5 * sizeof(float), s, k);
-  MI_CHECK_LAUNCH("simota_cost");
-  if (d->A <= 256 * 9)
-    hipLaunchKernelGGL(simota_dynk_reg_kernel<9>, dim3(d->gmax, d->B), dim3(256), 0, s, k);
-  else if (d->A <= 256 * 33)
-    hipLaunchKernelGGL(simota_dynk_reg_kernel<33>, dim3(d->gmax, d->B), dim3(256), 0, s, k);
+  // MI_SIMOTA_COMPACT=0 / MI_SIMOTA_PREFILTER=0: the round-5 forms of the two kernels (read per call: the tests compare
+  // both forms in one process; identical outputs)
+  const char* e1 = getenv("MI_SIMOTA_COMPACT");
+  const char* e2 = getenv("MI_SIMOTA_PREFILTER");
+  const bool compact = !e1 || atoi(e1) != 0, pre = !e2 || atoi(e2) != 0;
+  if (compact)
+    hipLaunchKernelGGL(simota_cost_kernel<true>, dim3(nb, d->B), dim3(256), d->gmax * 5 * sizeof(float), s, k);
   else
+    hipLaunchKernelGGL(simota_cost_kernel<false>, dim3(nb, d->B), dim3(256), d->gmax * 5 * sizeof(float), s, k);
+  MI_CHECK_LAUNCH("simota_cost");
+  if (d->A <= 256 * 9) {
+    if (pre) hipLaunchKernelGGL(simota_dynk_pre_kernel<9>, dim3(d->gmax, d->B), dim3(256), 0, s, k);
+    else hipLaunchKernelGGL(simota_dynk_reg_kernel<9>, dim3(d->gmax, d->B), dim3(256), 0, s, k);
+  } else if (d->A <= 256 * 33) {
+    if (pre) hipLaunchKernelGGL(simota_dynk_pre_kernel<33>, dim3(d->gmax, d->B), dim3(256), 0, s, k);
+    else hipLaunchKernelGGL(simota_dynk_reg_kernel<33>, dim3(d->gmax, d->B), dim3(256), 0, s, k);
+  } else {
     hipLaunchKernelGGL(simota_dynk_kernel, dim3(d->gmax, d->B), dim3(256), 0, s, k);
+  }
   MI_CHECK_LAUNCH("simota_dynk");
   hipLaunchKernelGGL(simota_resolve_loss_kernel, dim3(nb, d->B), dim3(256), 0, s, k);
   MI_CHECK_LAUNCH("simota_resolve_loss");
