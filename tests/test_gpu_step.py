@@ -103,7 +103,7 @@ def _forms_equal(raw, labels, anchors, monkeypatch, **kw):
     monkeypatch.setenv("MI_SIMOTA_COMPACT", "0")
     monkeypatch.setenv("MI_SIMOTA_PREFILTER", "0")
     ref = _loss_call(raw, labels, anchors, **kw)
-    for c, pf in (("1", "0"), ("0", "1"), ("1", "1")):
+    for c, pf in (("1", "0"), ("0", "1"), ("2", "0"), ("2", "1")):
         monkeypatch.setenv("MI_SIMOTA_COMPACT", c)
         monkeypatch.setenv("MI_SIMOTA_PREFILTER", pf)
         got = _loss_call(raw, labels, anchors, **kw)
@@ -115,7 +115,7 @@ def _forms_equal(raw, labels, anchors, monkeypatch, **kw):
 
 
 def test_simota_compacted_and_prefiltered_forms_are_bit_identical(monkeypatch):
-    """round 6: candidate compaction in the cost kernel and the pre-filtered dynamic-k selection against the round-5 kernels:
+    """round 6: candidate compaction (1) + class terms across the lanes (2) in the cost kernel and the pre-filtered dynamic-k selection against the round-5 kernels:
     every output word equal - at the bench size, with exact ties (all logits equal: the orders fall back on the anchor index),
     with lists that overflow the LDS capacity (the block-wide rounds take over), with <= 9 candidates, with 2 100 anchors"""
     B, H, W = 16, 640, 640

@@ -22,8 +22,8 @@ for name, lab_for_raw in (("random head", None), ("half-trained head", labels)):
     d.preds, d.labels, d.anchors = rd.data_ptr(), ld.data_ptr(), ad.data_ptr()
     d.B, d.A, d.ncls, d.max_labels, d.gmax = B, A, nch - 5, 100, 100
     for k in ws: setattr(d, k, ws[k].data_ptr())
-    for c, pf in (("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")):
-        os.environ["MI_SIMOTA_COMPACT"], os.environ["MI_SIMOTA_PREFILTER"] = c, pf
+    for c, pf, dbg in (("0", "0", "0"), ("1", "0", "0"), ("2", "0", "0"), ("0", "1", "0"), ("1", "1", "0"), ("2", "1", "0"), ("2", "1", "1"), ("2", "1", "2"), ("2", "1", "3"), ("2", "1", "4"), ("2", "1", "5"), ("2", "1", "6")):
+        os.environ["MI_SIMOTA_COMPACT"], os.environ["MI_SIMOTA_PREFILTER"], os.environ["MI_SIMOTA_DBG"] = c, pf, dbg
         call = lambda: L.check(L.lib().mi_yolox_loss_fwd(C.byref(d), L.stream_ptr()), "loss")
         for _ in range(5): call()
         torch.cuda.synchronize()
@@ -31,4 +31,4 @@ for name, lab_for_raw in (("random head", None), ("half-trained head", labels)):
         e0.record()
         for _ in range(50): call()
         e1.record(); torch.cuda.synchronize()
-        print(f"{name:18s} compact={c} prefilter={pf}: {e0.elapsed_time(e1) * 20:7.1f} us per loss forward (4 launches), num_fg {float(ws['out'][6]):.0f}", flush=True)
+        print(f"{name:18s} compact={c} prefilter={pf} dbg={dbg}: {e0.elapsed_time(e1) * 20:7.1f} us per loss forward (4 launches), num_fg {float(ws['out'][6]):.0f}", flush=True)

@@ -36,6 +36,7 @@ struct LossK {
   // the YOLOv6 head's form of the same loss (ComputeLoss, head/yolov6_head.py:315-754): configurable SimOTA weights /
   // centre radius and an IOUlossV6 box loss; the YOLOX values are 2.5, 1, 3, 5 and box loss 1 - iou^2 (iou_type 0)
   float center_radius, cls_weight, iou_weight, reg_weight;
+  int dbg;             // timing experiments (MI_SIMOTA_DBG): early exits of the dynamic-k kernel
   int iou_type;        // 0: IOUloss "iou" of the YOLOX head; 1..4: IOUlossV6 giou / diou / ciou / siou (eps 1e-7)
 };
 
@@ -64,22 +65,25 @@ __device__ int count_labels(const float* lab, int max_labels) {
 }
 
 // ---- kernel 1: candidates, pairwise IoU and cost
-// one candidate anchor: decode, class term, its cost / IoU against the image's G ground truths
-__device__ __forceinline__ void simota_cost_candidate(const LossK& p, const float* slab, int G, int b, int a) {
-  const float* pr = p.preds + ((size_t)b * p.A + a) * p.nch;
+// what the cost of one (candidate anchor, gt) pair needs of the anchor
+struct CandRec { float xc, yc, st, px, py, pw, ph, so, S; const float* pr; };
+// decode (yolox_head.py:243-244) and anchor centre (yolox_head.py:558-570)
+__device__ __forceinline__ void simota_cand_decode(const LossK& p, int b, int a, CandRec& r) {
+  r.pr = p.preds + ((size_t)b * p.A + a) * p.nch;
   const float gxs = p.anchors[a * 3 + 0], gys = p.anchors[a * 3 + 1], st = p.anchors[a * 3 + 2];
-  const float xc = gxs * st + 0.5f * st;
-  const float yc = gys * st + 0.5f * st;
-  const size_t rowstride = (size_t)p.A;
-  float* costp = p.cost + (size_t)b * p.gmax * rowstride + a;
-  float* ioup = p.iou + (size_t)b * p.gmax * rowstride + a;
-  // decode (yolox_head.py:243-244)
-  const float px = (pr[0] + gxs) * st, py = (pr[1] + gys) * st;
-  const float pw = expf(pr[2]) * st, ph = expf(pr[3]) * st;
-  const float so = sigmoid_ref(pr[4]);
-  float S = 0.f;  // sum_c max(log(1 - p_c), -100)
-  // the row is read in batches of 16 logits issued together: one load per iteration is a chain of ncls dependent
-  // round trips for the lanes that own a candidate anchor, and the whole wave waits for them (same summation order)
+  r.st = st;
+  r.xc = gxs * st + 0.5f * st;
+  r.yc = gys * st + 0.5f * st;
+  r.px = (r.pr[0] + gxs) * st;
+  r.py = (r.pr[1] + gys) * st;
+  r.pw = expf(r.pr[2]) * st;
+  r.ph = expf(r.pr[3]) * st;
+  r.so = sigmoid_ref(r.pr[4]);
+}
+// sum_c max(log(1 - p_c), -100): the row is read in batches of 16 logits issued together (one load per iteration is a
+// chain of ncls dependent round trips), summed in class order
+__device__ __forceinline__ float simota_class_sum(const LossK& p, const float* pr, float so) {
+  float S = 0.f;
   for (int c0 = 0; c0 < p.ncls; c0 += 16) {
     float lg[16];
 #pragma unroll
@@ -92,56 +96,89 @@ __device__ __forceinline__ void simota_cost_candidate(const LossK& p, const floa
       }
     }
   }
+  return S;
+}
+// cost / IoU of one pair, stored at [g][a] (yolox_head.py:487-547)
+__device__ __forceinline__ void simota_cost_pair(const LossK& p, const float* slab, int g, const CandRec& r, float* costp, float* ioup) {
+  const float xc = r.xc, yc = r.yc, st = r.st, px = r.px, py = r.py, pw = r.pw, ph = r.ph;
   const float area_b = pw * ph;
-  for (int g = 0; g < G; ++g) {
-    const float gcls = slab[g * 5 + 0];
-    const float gcx = slab[g * 5 + 1], gcy = slab[g * 5 + 2], gw = slab[g * 5 + 3], gh = slab[g * 5 + 4];
-    const float bl = xc - (gcx - 0.5f * gw), br = (gcx + 0.5f * gw) - xc;
-    const float bt = yc - (gcy - 0.5f * gh), bb = (gcy + 0.5f * gh) - yc;
-    const bool inb = fminf(fminf(bl, bt), fminf(br, bb)) > 0.0f;
-    const float cl = xc - (gcx - p.center_radius * st), cr = (gcx + p.center_radius * st) - xc;
-    const float ct = yc - (gcy - p.center_radius * st), cb = (gcy + p.center_radius * st) - yc;
-    const bool inc = fminf(fminf(cl, ct), fminf(cr, cb)) > 0.0f;
-    // bboxes_iou(gt, pred, xyxy=False) boxes.py:66-81
-    const float tlx = fmaxf(gcx - gw / 2, px - pw / 2), tly = fmaxf(gcy - gh / 2, py - ph / 2);
-    const float brx = fminf(gcx + gw / 2, px + pw / 2), bry = fminf(gcy + gh / 2, py + ph / 2);
-    const float area_a = gw * gh;
-    const float en = (tlx < brx ? 1.f : 0.f) * (tly < bry ? 1.f : 0.f);
-    const float area_i = ((brx - tlx) * (bry - tly)) * en;
-    const float iou = area_i / (area_a + area_b - area_i);
-    const float iou_loss = -logf(iou + 1e-8f);
-    const int gc = (int)gcls;
-    const float pg = sqrtf(sigmoid_ref(pr[5 + gc]) * so);
-    const float lp = clamp_log(pg), l1p = clamp_log(1.0f - pg);
-    const float cls_loss = -lp - (S - l1p);
-    float cost = p.cls_weight * cls_loss + p.iou_weight * iou_loss;
-    cost = cost + 100000.0f * ((inb && inc) ? 0.f : 1.f);
-    costp[g * rowstride] = cost;
-    ioup[g * rowstride] = iou;
-  }
+  const float gcls = slab[g * 5 + 0];
+  const float gcx = slab[g * 5 + 1], gcy = slab[g * 5 + 2], gw = slab[g * 5 + 3], gh = slab[g * 5 + 4];
+  const float bl = xc - (gcx - 0.5f * gw), br = (gcx + 0.5f * gw) - xc;
+  const float bt = yc - (gcy - 0.5f * gh), bb = (gcy + 0.5f * gh) - yc;
+  const bool inb = fminf(fminf(bl, bt), fminf(br, bb)) > 0.0f;
+  const float cl = xc - (gcx - p.center_radius * st), cr = (gcx + p.center_radius * st) - xc;
+  const float ct = yc - (gcy - p.center_radius * st), cb = (gcy + p.center_radius * st) - yc;
+  const bool inc = fminf(fminf(cl, ct), fminf(cr, cb)) > 0.0f;
+  // bboxes_iou(gt, pred, xyxy=False) boxes.py:66-81
+  const float tlx = fmaxf(gcx - gw / 2, px - pw / 2), tly = fmaxf(gcy - gh / 2, py - ph / 2);
+  const float brx = fminf(gcx + gw / 2, px + pw / 2), bry = fminf(gcy + gh / 2, py + ph / 2);
+  const float area_a = gw * gh;
+  const float en = (tlx < brx ? 1.f : 0.f) * (tly < bry ? 1.f : 0.f);
+  const float area_i = ((brx - tlx) * (bry - tly)) * en;
+  const float iou = area_i / (area_a + area_b - area_i);
+  const float iou_loss = -logf(iou + 1e-8f);
+  const int gc = (int)gcls;
+  const float pg = sqrtf(sigmoid_ref(r.pr[5 + gc]) * r.so);
+  const float lp = clamp_log(pg), l1p = clamp_log(1.0f - pg);
+  const float cls_loss = -lp - (r.S - l1p);
+  float cost = p.cls_weight * cls_loss + p.iou_weight * iou_loss;
+  cost = cost + 100000.0f * ((inb && inc) ? 0.f : 1.f);
+  *costp = cost;
+  *ioup = iou;
+}
+// one candidate anchor, the round-5 way: everything by its own thread
+__device__ __forceinline__ void simota_cost_candidate(const LossK& p, const float* slab, int G, int b, int a) {
+  CandRec r;
+  simota_cand_decode(p, b, a, r);
+  r.S = simota_class_sum(p, r.pr, r.so);
+  const size_t rowstride = (size_t)p.A;
+  float* costp = p.cost + (size_t)b * p.gmax * rowstride + a;
+  float* ioup = p.iou + (size_t)b * p.gmax * rowstride + a;
+  for (int g = 0; g < G; ++g) simota_cost_pair(p, slab, g, r, costp + g * rowstride, ioup + g * rowstride);
 }
 
-// COMPACT: the block's candidate anchors (a third of the anchors with COCO-sized boxes, scattered over the lanes) are
-// gathered into a list and the first ncand threads take one each: the ~100 transcendentals per candidate run in full
-// waves instead of in every wave at a third of its lanes.  Same expressions per (anchor, gt): identical outputs.
-template <bool COMPACT>
+// FORM 0: the round-5 kernel (thread 0 counts the labels; a candidate's thread does all of its work - in waves a third
+// of whose lanes hold a candidate with COCO-sized boxes).
+// FORM 1: the label count across the threads; the block's candidates gathered into a list, the first ncand threads take
+// one each.
+// FORM 2: FORM 1, and (a) the class term is formed with the CLASSES across the lanes - 16 lanes take one candidate's row
+// (64 contiguous bytes per load instead of 64 lanes in 64 different rows 340 bytes apart), the terms go to LDS and the
+// candidate's thread adds them up in class order: the same float sum as the loop over its own row; (b) the (candidate, gt)
+// PAIRS are dealt to all 256 threads (an image's blocks hold 30 - 250 candidates and up to gmax ground truths).
+// Same expressions per class term / pair: identical outputs.
+#define SIMOTA_TERM_FLOATS 10240
+template <int FORM>
 __global__ __launch_bounds__(256) void simota_cost_kernel(const LossK p) {
-  extern __shared__ float slab[];  // [gmax][5]
+  extern __shared__ float slab[];  // [gmax][5] (FORM 2: + [SIMOTA_TERM_FLOATS] class terms)
   __shared__ int s_ngt;
+  __shared__ CandRec s_rec[FORM == 2 ? 256 : 1];
   __shared__ int s_wn[4];
   __shared__ unsigned short s_list[256];
-  const int b = blockIdx.y;
+  const int b = blockIdx.y, tid = threadIdx.x;
   const float* lab = p.labels + (size_t)b * p.max_labels * 5;
-  if (threadIdx.x == 0) {
-    int n = count_labels(lab, p.max_labels);
-    if (n > p.gmax) n = p.gmax;
-    s_ngt = n;
-    if (blockIdx.x == 0) p.ngt[b] = n;
+  if constexpr (FORM == 0) {
+    if (tid == 0) s_ngt = count_labels(lab, p.max_labels);
+  } else {
+    // number of valid labels: rows with sum > 0 (yolox_head.py:295; count_labels across the threads)
+    if (tid == 0) s_ngt = 0;
+    __syncthreads();
+    int n = 0;
+    for (int r = tid; r < p.max_labels; r += 256) {
+      float sm = lab[r * 5 + 0] + lab[r * 5 + 1];
+      sm = sm + lab[r * 5 + 2];
+      sm = sm + lab[r * 5 + 3];
+      sm = sm + lab[r * 5 + 4];
+      n += sm > 0.f ? 1 : 0;
+    }
+    if (n) atomicAdd(&s_ngt, n);
   }
-  for (int i = threadIdx.x; i < p.gmax * 5; i += 256) slab[i] = lab[i];
+  for (int i = tid; i < p.gmax * 5; i += 256) slab[i] = lab[i];
   __syncthreads();
-  const int G = s_ngt;
-  const int a = blockIdx.x * 256 + threadIdx.x;
+  const int G = s_ngt < p.gmax ? s_ngt : p.gmax;
+  if (tid == 0 && blockIdx.x == 0) p.ngt[b] = G;
+  if (p.dbg == 4) return;
+  const int a = blockIdx.x * 256 + tid;
   bool cand = false;
   if (a < p.A) {
     // per-anchor match counter / matched gt, filled by the dynamic-k kernels with atomics and consumed by the resolve
@@ -149,7 +186,6 @@ __global__ __launch_bounds__(256) void simota_cost_kernel(const LossK p) {
     p.matched_gt[(size_t)b * p.A + a] = -1;
     ((int32_t*)p.matched_iou)[(size_t)b * p.A + a] = 0;
     const float gxs = p.anchors[a * 3 + 0], gys = p.anchors[a * 3 + 1], st = p.anchors[a * 3 + 2];
-    // anchor centre (yolox_head.py:558-570)
     const float xc = gxs * st + 0.5f * st;
     const float yc = gys * st + 0.5f * st;
     for (int g = 0; g < G; ++g) {
@@ -172,11 +208,12 @@ __global__ __launch_bounds__(256) void simota_cost_kernel(const LossK p) {
       }
     }
   }
-  if constexpr (!COMPACT) {
+  if (p.dbg == 5) return;
+  if constexpr (FORM == 0) {
     if (cand) simota_cost_candidate(p, slab, G, b, a);
   } else {
     const unsigned long long m = __ballot(cand);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
     if (lane == 0) s_wn[wave] = __popcll(m);
     __syncthreads();
     int off = 0, total = 0;
@@ -185,9 +222,76 @@ __global__ __launch_bounds__(256) void simota_cost_kernel(const LossK p) {
       if (w < wave) off += s_wn[w];
       total += s_wn[w];
     }
-    if (cand) s_list[off + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)threadIdx.x;
+    if (cand) s_list[off + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)tid;
     __syncthreads();
-    if ((int)threadIdx.x < total) simota_cost_candidate(p, slab, G, b, blockIdx.x * 256 + s_list[threadIdx.x]);
+    if constexpr (FORM == 1) {
+      if (tid < total) simota_cost_candidate(p, slab, G, b, blockIdx.x * 256 + s_list[tid]);
+    } else {
+      float* const s_term = slab + p.gmax * 5;
+      const int ncls = p.ncls, ld = ncls + 1, CH = SIMOTA_TERM_FLOATS / ld;   // (host: CH >= 16)
+      CandRec rec;
+      if (tid < total) {
+        simota_cand_decode(p, b, blockIdx.x * 256 + s_list[tid], rec);
+        s_rec[tid].so = rec.so;
+        s_rec[tid].pr = rec.pr;
+      }
+      __syncthreads();
+      const int grp = tid >> 4, gl = tid & 15;
+      for (int c0 = 0; c0 < total; c0 += CH) {
+        const int n = total - c0 < CH ? total - c0 : CH;
+        // four candidates x eight logits per 16-lane group are loaded before the first is used: one load per iteration is a
+        // chain of dependent HBM round trips (a group walks ~8 candidates x 5 loads)
+        for (int ci0 = grp; ci0 < n; ci0 += 64) {
+          for (int cb = 0; cb < ncls; cb += 128) {
+            float lg[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int ci = ci0 + 16 * u;
+              const float* pr = s_rec[c0 + (ci < n ? ci : 0)].pr + 5;
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const int c = cb + gl + 16 * q;
+                lg[u][q] = (ci < n && c < ncls) ? pr[c] : 0.f;
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int ci = ci0 + 16 * u;
+              const float so = s_rec[c0 + (ci < n ? ci : 0)].so;
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const int c = cb + gl + 16 * q;
+                if (ci < n && c < ncls) {
+                  const float pc = sqrtf(sigmoid_ref(lg[u][q]) * so);
+                  s_term[ci * ld + c] = clamp_log(1.0f - pc);
+                }
+              }
+            }
+          }
+        }
+        __syncthreads();
+        if (tid >= c0 && tid < c0 + n) {
+          float S = 0.f;
+          for (int c = 0; c < ncls; ++c) S += s_term[(tid - c0) * ld + c];
+          rec.S = S;
+        }
+        __syncthreads();
+      }
+      if (p.dbg == 6) return;
+      if (tid < total) s_rec[tid] = rec;
+      __syncthreads();
+      // pairs: idx = g * total + ci (exact split: (idx + 0.5) / total is at least 0.5 / 256 away from an integer)
+      const float rt = 1.0f / (float)total;
+      const size_t rowstride = (size_t)p.A;
+      float* const cost0 = p.cost + (size_t)b * p.gmax * rowstride + (size_t)blockIdx.x * 256;
+      float* const iou0 = p.iou + (size_t)b * p.gmax * rowstride + (size_t)blockIdx.x * 256;
+      for (int idx = tid; idx < total * G; idx += 256) {
+        const int g = (int)(((float)idx + 0.5f) * rt);
+        const int ci = idx - g * total;
+        const size_t o = (size_t)g * rowstride + s_list[ci];
+        simota_cost_pair(p, slab, g, s_rec[ci], cost0 + o, iou0 + o);
+      }
+    }
   }
 }
 
@@ -305,47 +409,49 @@ __global__ __launch_bounds__(256) void simota_dynk_reg_kernel(const LossK p) {
   }
 }
 
-// Pre-filtered variant of simota_dynk_reg_kernel: the ~20 block-wide selection rounds (each a scan of NV registers per
-// thread, a wave reduction and two barriers: ~2 us per round with one wave per SIMD) become two passes over the registers
-// and wave-level rounds over a short list.  The 10th best of the 256 per-thread bests bounds the 10th best element from
-// below, so every element of the top 10 is at or before it in the total order: those elements (typically 10 - 40) go to a
-// list in LDS and one wave takes the ordered selections from there.  k <= 10 (the sum of ten IoUs), so the same bound
-// serves the k smallest costs.  Same total order (ties -> smaller index), same descending summation order: identical
-// results; a list that overflows (or k > 10) falls back to the block-wide rounds.
-#define DYNK_CAP 512
+// Pre-filtered, rank-sorted variant of simota_dynk_reg_kernel.  The ~20 block-wide selection rounds (each a scan of NV
+// registers per thread, a six-step shuffle chain and two barriers: ~2.4 us per round with one wave per SIMD) become:
+//  1. per-thread bests; their 10th best (per-wave rank sort of the 64 lane bests -> 4 x 10 entries -> rank sort of those)
+//     bounds the 10th best ELEMENT from below, so every element of the top 10 is at or before it in the total order;
+//  2. those elements (typically 10 - 40 per row) go to a list in LDS;
+//  3. every listed element finds its RANK (the number of listed elements before it: one loop of broadcast LDS reads, no
+//     dependent chain): ranks 0 .. 9 of the IoU list are the top 10 in order - summed in that order -, ranks 0 .. k - 1 of
+//     the cost list are the matches (k <= 10: the sum of ten IoUs), each written by its own thread.
+// Same total order (ties -> smaller index), same summation order: identical results; a list longer than the block (or
+// k > 10) falls back to the block-wide rounds.
+#define DYNK_CAP 256
+// (bitwise | and &: no short-circuit branches inside the rank loops)
 template <bool DESC>
 __device__ __forceinline__ bool kv_valid(float v) {
-  if (DESC) return !(v <= -0.5f || v >= INFINITY);
-  return !(v <= -INFINITY || v >= SIMOTA_INF);
+  if (DESC) return !((v <= -0.5f) | (v >= INFINITY));
+  return !((v <= -INFINITY) | (v >= SIMOTA_INF));
 }
+// strictly before (v, i) in the total order
 template <bool DESC>
-__device__ __forceinline__ KV wave_select(const KV* list, int M, float lv, int li) {
-  float bv = 0.f;
-  int bi = -1;
-  for (int j = threadIdx.x & 63; j < M; j += 64) {
-    const KV e = list[j];
-    if (e.i < 0 || !kv_after<DESC>(e.v, e.i, lv, li)) continue;
-    if (kv_better<DESC>(e.v, e.i, bv, bi)) { bv = e.v; bi = e.i; }
+__device__ __forceinline__ bool kv_before(float ov, int oi, float v, int i) {
+  if (DESC) return (ov > v) | ((ov == v) & (oi < i));
+  return (ov < v) | ((ov == v) & (oi < i));
+}
+// rank of (v, i) among the valid entries of list[0 .. M)
+template <bool DESC>
+__device__ __forceinline__ int kv_rank(const KV* list, int M, float v, int i) {
+  int r = 0;
+#pragma unroll 8
+  for (int m = 0; m < M; ++m) {   // (unrolled: the broadcast reads of eight entries are in flight together)
+    const KV e = list[m];
+    r += (int)((e.i >= 0) & kv_before<DESC>(e.v, e.i, v, i));
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(bv, o, 64);
-    const int oi = __shfl_xor(bi, o, 64);
-    if (oi >= 0 && kv_better<DESC>(ov, oi, bv, bi)) { bv = ov; bi = oi; }
-  }
-  KV r;
-  r.v = bv;
-  r.i = bi;
   return r;
 }
 
 template <int NV>
 __global__ __launch_bounds__(256) void simota_dynk_pre_kernel(const LossK p) {
   __shared__ KV s_best[2][256];
+  __shared__ KV s_wtop[2][40];
   __shared__ KV s_list[2][DYNK_CAP];
   __shared__ KV s_thr[2];
   __shared__ int s_cnt[2];
-  __shared__ int s_k;
+  __shared__ float s_top[10];
   __shared__ KV sred[4];
   const int g = blockIdx.x, b = blockIdx.y;
   if (g >= p.ngt[b]) return;
@@ -362,37 +468,40 @@ __global__ __launch_bounds__(256) void simota_dynk_pre_kernel(const LossK p) {
     vc[j] = a < p.A ? costr[a] : SIMOTA_INF;
   }
   // ---- per-thread bests
-  {
-    float bvi = 0.f, bvc = 0.f;
-    int bii = -1, bic = -1;
+  float bvi = 0.f, bvc = 0.f;
+  int bii = -1, bic = -1;
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int a = tid + 256 * j;
-      if (a < p.A && kv_valid<true>(vi[j]) && kv_better<true>(vi[j], a, bvi, bii)) { bvi = vi[j]; bii = a; }
-      if (a < p.A && kv_valid<false>(vc[j]) && kv_better<false>(vc[j], a, bvc, bic)) { bvc = vc[j]; bic = a; }
-    }
-    s_best[0][tid].v = bvi; s_best[0][tid].i = bii;
-    s_best[1][tid].v = bvc; s_best[1][tid].i = bic;
-    if (tid < 2) s_cnt[tid] = 0;
+  for (int j = 0; j < NV; ++j) {
+    const int a = tid + 256 * j;
+    const bool ti = (a < p.A) & kv_valid<true>(vi[j]) & ((bii < 0) | kv_before<true>(vi[j], a, bvi, bii));
+    const bool tc = (a < p.A) & kv_valid<false>(vc[j]) & ((bic < 0) | kv_before<false>(vc[j], a, bvc, bic));
+    bvi = ti ? vi[j] : bvi; bii = ti ? a : bii;
+    bvc = tc ? vc[j] : bvc; bic = tc ? a : bic;
+  }
+  s_best[0][tid].v = bvi; s_best[0][tid].i = bii;
+  s_best[1][tid].v = bvc; s_best[1][tid].i = bic;
+  if (tid < 80) s_wtop[tid / 40][tid % 40].i = -1;
+  if (tid < 2) { s_cnt[tid] = 0; s_thr[tid].i = -1; }
+  __syncthreads();
+  if (p.dbg == 1) return;
+  // ---- the bounds: the 10th largest of the IoU bests, the 10th smallest of the cost bests (i < 0: fewer than ten threads hold
+  // a valid element - then all valid elements are listed)
+  {
+    const int ri = bii >= 0 ? kv_rank<true>(s_best[0] + wave * 64, 64, bvi, bii) : 64;
+    const int rc = bic >= 0 ? kv_rank<false>(s_best[1] + wave * 64, 64, bvc, bic) : 64;
+    if (ri < 10) { s_wtop[0][wave * 10 + ri].v = bvi; s_wtop[0][wave * 10 + ri].i = bii; }
+    if (rc < 10) { s_wtop[1][wave * 10 + rc].v = bvc; s_wtop[1][wave * 10 + rc].i = bic; }
   }
   __syncthreads();
-  // ---- the bounds: wave 0 the 10th largest of the IoU bests, wave 1 the 10th smallest of the cost bests (i < 0: fewer than
-  // ten threads hold a valid element - then there are at most 9 NV of them and all are listed)
-  if (wave < 2) {
-    float lv = 0.f;
-    int li = -1, r = 0;
-    for (; r < 10; ++r) {
-      const KV s = wave == 0 ? wave_select<true>(s_best[0], 256, lv, li) : wave_select<false>(s_best[1], 256, lv, li);
-      if (s.i < 0) break;
-      lv = s.v;
-      li = s.i;
-    }
-    if ((tid & 63) == 0) {
-      s_thr[wave].v = lv;
-      s_thr[wave].i = r == 10 ? li : -1;
+  if (wave < 2 && (tid & 63) < 40) {
+    const KV e = s_wtop[wave][tid & 63];
+    if (e.i >= 0) {
+      const int r = wave == 0 ? kv_rank<true>(s_wtop[0], 40, e.v, e.i) : kv_rank<false>(s_wtop[1], 40, e.v, e.i);
+      if (r == 9) s_thr[wave] = e;
     }
   }
   __syncthreads();
+  if (p.dbg == 2) return;
   {
     const KV ti = s_thr[0], tc = s_thr[1];
 #pragma unroll
@@ -411,54 +520,40 @@ __global__ __launch_bounds__(256) void simota_dynk_pre_kernel(const LossK p) {
   }
   __syncthreads();
   const int Mi = s_cnt[0], Mc = s_cnt[1];
-  // ---- top-10 IoU among candidates, summed in descending order
-  float sum = 0.f, lv = 0.f;
-  int li = -1;
-  if (Mi <= DYNK_CAP) {
-    if (wave == 0) {
-      for (int r = 0; r < 10; ++r) {
-        const KV s = wave_select<true>(s_list[0], Mi, lv, li);
-        if (s.i < 0) break;
-        sum += s.v;
-        lv = s.v;
-        li = s.i;
-      }
-      int k = (int)sum;
-      if (k < 1) k = 1;
-      if (tid == 0) s_k = k;
+  if (p.dbg == 3) return;
+  if (Mi <= DYNK_CAP && Mc <= DYNK_CAP) {
+    KV ec;
+    ec.v = 0.f;
+    ec.i = -1;
+    int rc = DYNK_CAP;
+    if (tid < Mi) {
+      const KV e = s_list[0][tid];
+      const int r = kv_rank<true>(s_list[0], Mi, e.v, e.i);
+      if (r < 10) s_top[r] = e.v;
+    }
+    // (the cost list's ranks by the upper half of the block when it fits: the two rank loops then run on different SIMDs)
+    const int tc_ = Mc <= 128 ? tid - 128 : tid;
+    if (tc_ >= 0 && tc_ < Mc) {
+      ec = s_list[1][tc_];
+      rc = kv_rank<false>(s_list[1], Mc, ec.v, ec.i);
     }
     __syncthreads();
-  } else {
-    for (int r = 0; r < 10; ++r) {
-      const KV s = block_select_reg<true, NV>(vi, p.A, lv, li, -0.5f, INFINITY, sred);
-      if (s.i < 0) break;
-      sum += s.v;
-      lv = s.v;
-      li = s.i;
-    }
+    // top-10 IoU among candidates, summed in descending order (yolox_head.py:640-642)
+    float sum = 0.f;
+    const int ntop = Mi < 10 ? Mi : 10;
+    for (int r = 0; r < ntop; ++r) sum += s_top[r];
     int k = (int)sum;
     if (k < 1) k = 1;
-    __syncthreads();
-    if (tid == 0) s_k = k;
-    __syncthreads();
-  }
-  const int k = s_k;
-  lv = 0.f;
-  li = -1;
-  if (Mc <= DYNK_CAP && k <= 10) {
-    if (wave == 0) {
-      for (int r = 0; r < k; ++r) {
-        const KV s = wave_select<false>(s_list[1], Mc, lv, li);
-        if (s.i < 0) break;
-        if (tid == 0) {   // matching_matrix[g][s.i] = 1: count the anchor's matches, remember one of its gts
-          atomicAdd(cntr + s.i, 1);
-          atomicMax(gselr + s.i, g);
-        }
-        lv = s.v;
-        li = s.i;
+    if (k <= 10) {
+      if (rc < k) {   // matching_matrix[g][a] = 1: count the anchor's matches, remember one of its gts
+        atomicAdd(cntr + ec.i, 1);
+        atomicMax(gselr + ec.i, g);
       }
+      return;
     }
-  } else {
+    // (k > 10 cannot come out of ten IoUs <= 1; kept exact anyway)
+    float lv = 0.f;
+    int li = -1;
     for (int r = 0; r < k; ++r) {
       const KV s = block_select_reg<false, NV>(vc, p.A, lv, li, -INFINITY, SIMOTA_INF, sred);
       if (s.i < 0) break;
@@ -469,6 +564,31 @@ __global__ __launch_bounds__(256) void simota_dynk_pre_kernel(const LossK p) {
       lv = s.v;
       li = s.i;
     }
+    return;
+  }
+  // ---- a list overflowed: the block-wide rounds
+  float sum = 0.f, lv = 0.f;
+  int li = -1;
+  for (int r = 0; r < 10; ++r) {
+    const KV s = block_select_reg<true, NV>(vi, p.A, lv, li, -0.5f, INFINITY, sred);
+    if (s.i < 0) break;
+    sum += s.v;
+    lv = s.v;
+    li = s.i;
+  }
+  int k = (int)sum;
+  if (k < 1) k = 1;
+  lv = 0.f;
+  li = -1;
+  for (int r = 0; r < k; ++r) {
+    const KV s = block_select_reg<false, NV>(vc, p.A, lv, li, -INFINITY, SIMOTA_INF, sred);
+    if (s.i < 0) break;
+    if (tid == 0) {
+      atomicAdd(cntr + s.i, 1);
+      atomicMax(gselr + s.i, g);
+    }
+    lv = s.v;
+    li = s.i;
   }
 }
 
@@ -655,6 +775,7 @@ static int loss_fill(const mi_yolox_loss_desc* d, LossK* k) {
   k->iou_weight = d->iou_weight > 0.f ? d->iou_weight : 3.0f;
   k->reg_weight = d->reg_weight > 0.f ? d->reg_weight : 5.0f;
   k->iou_type = d->iou_type;
+  k->dbg = 0;
   MI_REQUIRE(d->iou_type >= 0 && d->iou_type <= 4, "yolox_loss: iou_type %d", d->iou_type);
   MI_REQUIRE(!k->use_l1 || d->partial_l1, "yolox_loss: use_l1 needs partial_l1");
   return MI_OK;
@@ -666,15 +787,22 @@ extern "C" int mi_yolox_loss_fwd(const mi_yolox_loss_desc* d, mi_stream_t st) {
   if (rc) return rc;
   hipStream_t s = (hipStream_t)st;
   const int nb = mi_cdiv(d->A, 256);
-  // MI_SIMOTA_COMPACT=0 / MI_SIMOTA_PREFILTER=0: the round-5 forms of the two kernels (read per call: the tests compare
+  // MI_SIMOTA_COMPACT=0 (1: compaction only) / MI_SIMOTA_PREFILTER=0: the round-5 forms of the two kernels (read per call: the tests compare
   // both forms in one process; identical outputs)
   const char* e1 = getenv("MI_SIMOTA_COMPACT");
   const char* e2 = getenv("MI_SIMOTA_PREFILTER");
-  const bool compact = !e1 || atoi(e1) != 0, pre = !e2 || atoi(e2) != 0;
-  if (compact)
-    hipLaunchKernelGGL(simota_cost_kernel<true>, dim3(nb, d->B), dim3(256), d->gmax * 5 * sizeof(float), s, k);
+  int form = e1 ? atoi(e1) : 2;
+  const bool pre = !e2 || atoi(e2) != 0;
+  if (form == 2 && SIMOTA_TERM_FLOATS / (d->ncls + 1) < 16) form = 1;   // (very many classes: the terms of 16 candidates do not fit)
+  const char* e3 = getenv("MI_SIMOTA_DBG");
+  k.dbg = e3 ? atoi(e3) : 0;
+  const size_t slab_bytes = d->gmax * 5 * sizeof(float);
+  if (form == 2)
+    hipLaunchKernelGGL(simota_cost_kernel<2>, dim3(nb, d->B), dim3(256), slab_bytes + SIMOTA_TERM_FLOATS * sizeof(float), s, k);
+  else if (form == 1)
+    hipLaunchKernelGGL(simota_cost_kernel<1>, dim3(nb, d->B), dim3(256), slab_bytes, s, k);
   else
-    hipLaunchKernelGGL(simota_cost_kernel<false>, dim3(nb, d->B), dim3(256), d->gmax * 5 * sizeof(float), s, k);
+    hipLaunchKernelGGL(simota_cost_kernel<0>, dim3(nb, d->B), dim3(256), slab_bytes, s, k);
   MI_CHECK_LAUNCH("simota_cost");
   if (d->A <= 256 * 9) {
     if (pre) hipLaunchKernelGGL(simota_dynk_pre_kernel<9>, dim3(d->gmax, d->B), dim3(256), 0, s, k);
