@@ -330,6 +330,18 @@ __device__ __forceinline__ void wg_decode(const PK& p, const int bid, int& s, in
   pair = rem / r;
 }
 
+#ifdef MI_WG_TIMELINE
+// diagnostic build (tools/build_variant.sh tl "-DMI_WG_TIMELINE" conv_wgrad; tools/wgrad_timeline.py): wave 0 of block 0 stamps
+// the phases of its first 200 steps: [step][0] loop top, [1] tile landed (counted wait), [2] barrier passed, [3] refill
+// issued, [4] multiplied
+__device__ long long g_wg_tl[200 * 5];
+extern "C" int mi_debug_wg_timeline(long long* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wg_tl), sizeof(g_wg_tl)) == hipSuccess ? MI_OK : MI_EINVAL;
+}
+#define WG_TL(k) do { if (bid == 0 && threadIdx.x == 0 && it < 200) g_wg_tl[it * 5 + (k)] = wall_clock64(); } while (0)
+#else
+#define WG_TL(k) do { } while (0)
+#endif
 template <int NT, int MI, int NJ, int WCO, int WCI, int TP, bool FIX = false>
 __device__ __forceinline__ void wgrad2_body(const Wg2K& p, const int bid, unsigned* const cnt = nullptr) {
   constexpr int NW = WCO * WCI, BCO = 16 * MI * WCO, BCI = 16 * NJ * WCI;
@@ -427,14 +439,18 @@ __device__ __forceinline__ void wgrad2_body(const Wg2K& p, const int bid, unsign
   int it = 0, cur = 0;  // cur = it % NS
   for (int tile = tbeg; tile < tend; ++tile, ++it) {
     const int ahead = min(NS - 2, tend - 1 - tile);
+    WG_TL(0);
     wait_vmcnt(ahead * nload);
+    WG_TL(1);
     __builtin_amdgcn_s_barrier();  // tile `tile` landed for every wave; the stage of tile-1 is no longer being read
+    WG_TL(2);
     {
       const int nxt = tile + NS - 1;
       int st = cur - 1;
       if (st < 0) st += NS;
       if (nxt < tend) issue(nxt, st);
     }
+    WG_TL(3);
     if (do_bias) {
       const int img = tile / tpi, rem = tile - img * tpi, tyq = rem / p.tilesX;
       bias.template tile<TP>(p, img, tyq * p.TH, (rem - tyq * p.tilesX) * p.TW, co0, TPv);
@@ -473,6 +489,10 @@ __device__ __forceinline__ void wgrad2_body(const Wg2K& p, const int bid, unsign
             acc[tap][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[tap][i][j], 0, 0, 0);
       }
     }
+#ifdef MI_WG_TIMELINE
+    asm volatile("s_nop 0" : "+v"(acc[0][0][0]) : : "memory");   // (the stamp follows the last MFMA's result)
+#endif
+    WG_TL(4);
   }
   // ---- split-K slab, fragment order: [split][cob][cib][wave][tap][i][j][lane] x float4
   f32x4* out = (f32x4*)p.part + (size_t)s * (size_t)p.V +
