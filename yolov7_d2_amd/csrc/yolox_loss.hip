@@ -983,6 +983,8 @@ __global__ __launch_bounds__(256) void yolox_loss_bwd_fused_kernel(const LossBwd
         for (int e = 0; e < 4; ++e)
           if (cb + e < 4 && j8 * 8 + e < j.nc) v[e] = dp[cb + e];
       }
+      // reg_preds + obj_preds as one 5-channel convolution (columns 0 .. 4 in one job): the objectness column rides along
+      if (cb == 0 && j.nc == 5) v[4] = w_obj * (sigmoid_ref(p.preds[o * p.nch + 4]) - (fg ? 1.f : 0.f));
     } else if (cb == 4 && j.nc == 1) {         // the objectness conv
       v[0] = w_obj * (sigmoid_ref(p.preds[o * p.nch + 4]) - (fg ? 1.f : 0.f));
     } else if (fg) {                           // the class conv (background rows: zero, their logits are not read)
@@ -1245,8 +1247,8 @@ extern "C" int mi_yolox_loss_bwd_fused(const mi_yolox_loss_desc* d, const float*
   for (int n = 0; n < nsplit; ++n) {
     const mi_split_job& j = split_jobs[n];
     MI_REQUIRE(j.dst && j.ld % 8 == 0 && j.ld >= j.nc && j.ld <= 2048 && j.nc >= 1 && j.c0 >= 0 && j.c0 + j.nc <= nch && j.a0 >= 0 &&
-                   j.a0 + j.HW <= d->A && (j.c0 >= 5 || j.c0 + j.nc <= 5) && (j.c0 >= 4 || j.c0 + j.nc <= 4),
-               "yolox_loss_bwd_fused: job %d (a job is the box columns, the objectness column or class columns)", n);
+                   j.a0 + j.HW <= d->A && (j.c0 >= 5 || j.c0 + j.nc <= 5) && (j.c0 >= 4 || j.c0 + j.nc <= 4 || (j.c0 == 0 && j.nc == 5)),
+               "yolox_loss_bwd_fused: job %d (a job is the box columns, the objectness column, both (0 .. 4) or class columns)", n);
     k.jobs[n] = j;
     k.bias_out[n] = nullptr;
     if (j.ld > k.ldmax) k.ldmax = j.ld;

@@ -4,6 +4,8 @@ yolov7/modeling/head/yolox_head.py:24-149) — parameter holders + plan emission
 """
 import math
 
+import os
+
 import torch
 from torch import nn
 
@@ -154,6 +156,48 @@ class YOLOXHead(_NoEager):
                                      torch.full((h * w,), float(s))), dim=1))
         return torch.cat(rows, 0).contiguous()
 
+    def arena_adjacent(self):
+        """ParamArena: obj_preds[k] right behind reg_preds[k] (weights and biases): see emit"""
+        out = []
+        for k in range(len(self.reg_preds)):
+            out += [(f"reg_preds.{k}.weight", f"obj_preds.{k}.weight"), (f"reg_preds.{k}.bias", f"obj_preds.{k}.bias")]
+        return out
+
+    def _reg_obj_views(self, ctx, k):
+        """([5, C, 1, 1] weight, [5] bias, their gradient views) when reg_preds[k] / obj_preds[k] are back to back in the
+        parameter and gradient arenas, else None (MI_HEAD_FUSE_REGOBJ=0: the two convolutions of round 5)"""
+        if os.environ.get("MI_HEAD_FUSE_REGOBJ", "1") == "0":
+            return None
+        reg, obj = self.reg_preds[k], self.obj_preds[k]
+        if reg.bias is None or obj.bias is None:
+            return None
+        C = reg.weight.shape[1]
+
+        def joined(a, b_, shape):
+            if a is None or b_ is None:
+                return None
+            if a.dtype != torch.float32 or not a.is_contiguous() or not b_.is_contiguous():
+                return None
+            if b_.data_ptr() != a.data_ptr() + a.numel() * 4 or a.untyped_storage().data_ptr() != b_.untyped_storage().data_ptr():
+                return None
+            st = [1] * len(shape)
+            st[0] = shape[1] if len(shape) > 1 else 1
+            if len(shape) > 1:
+                st[1] = 1
+            return torch.as_strided(a.detach(), shape, st)
+
+        w = joined(reg.weight.data, obj.weight.data, (5, C, 1, 1))
+        bi = joined(reg.bias.data, obj.bias.data, (5,))
+        if w is None or bi is None:
+            return None
+        if not ctx.b.training:
+            return w, bi, None, None
+        gw = joined(ctx.g(reg.weight), ctx.g(obj.weight), (5, C, 1, 1))
+        gb = joined(ctx.g(reg.bias), ctx.g(obj.bias), (5,))
+        if gw is None or gb is None:
+            return None
+        return w, bi, gw, gb
+
     def emit(self, ctx, fpn_outs, preds, A, tag="head"):
         nch = 5 + self.num_classes
         a0 = 0
@@ -178,9 +222,18 @@ class YOLOXHead(_NoEager):
             with b.on_stream(k), b.on_lane(2 * k + 1):
                 r = self.reg_convs[k][0].emit(ctx, t, f"{tag}.reg_convs.{k}.0")
                 r = self.reg_convs[k][1].emit(ctx, r, f"{tag}.reg_convs.{k}.1")
-                for name, mod, c0 in (("reg_preds", self.reg_preds[k], 0), ("obj_preds", self.obj_preds[k], 4)):
-                    b.pred_conv(f"{tag}.{name}.{k}", r, mod.weight, mod.bias, ctx.g(mod.weight), ctx.g(mod.bias),
-                                preds, A, a0, c0, nch)
+                fused = self._reg_obj_views(ctx, k)
+                if fused is not None:
+                    # reg_preds + obj_preds (yolox_head.py:166-168: two 1x1 convs over the same tower output, channels 0..3 and
+                    # 4 of the prediction row) as ONE convolution with 5 output channels: their parameters lie back to back
+                    # in the arena (arena_adjacent), so the weight / bias / gradients are [5, C] / [5] views.  One launch less
+                    # forward, one data gradient instead of a gradient + an accumulating one, one split map instead of two.
+                    w, bi, gw, gb = fused
+                    b.pred_conv(f"{tag}.reg_preds.{k}", r, w, bi, gw, gb, preds, A, a0, 0, nch)
+                else:
+                    for name, mod, c0 in (("reg_preds", self.reg_preds[k], 0), ("obj_preds", self.obj_preds[k], 4)):
+                        b.pred_conv(f"{tag}.{name}.{k}", r, mod.weight, mod.bias, ctx.g(mod.weight), ctx.g(mod.bias),
+                                    preds, A, a0, c0, nch)
             a0 += x.H * x.W
         b.par_end(tag + ".levels")
         assert a0 == A

@@ -17,7 +17,24 @@ class ParamArena:
         self.device = torch.device(device)
         self.entries = []  # (name, param, offset, numel)
         off = 0
-        for name, p in module.named_parameters():
+        named = list(module.named_parameters())
+        # a module may ask for pairs of its parameters to lie back to back (`arena_adjacent()` -> [(first, second)], names
+        # relative to the module): the YOLOX head's reg / obj prediction convs then read as ONE [5, C] weight / [5] bias (and
+        # gradient) view and run as one convolution (yolox_net.YOLOXHead.emit).  Names, shapes and state_dict keys are untouched.
+        order = [n for n, _ in named]
+        for mname, m in module.named_modules():
+            fn = getattr(m, "arena_adjacent", None)
+            if fn is None:
+                continue
+            pre = mname + "." if mname else ""
+            for a, b in fn():
+                a, b = pre + a, pre + b
+                if a in order and b in order:
+                    order.remove(b)
+                    order.insert(order.index(a) + 1, b)
+        byname = dict(named)
+        for name in order:
+            p = byname[name]
             n = p.numel()
             self.entries.append((name, p, off, n))
             off += (n + 3) // 4 * 4
