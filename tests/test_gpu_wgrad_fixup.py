@@ -50,10 +50,11 @@ def _descs(layers, gws):
     return descs
 
 
-def _run_group(layers, fixup, monkeypatch, runs=1):
+def _run_group(layers, fixup, monkeypatch, runs=1, multi="0"):
     """plan + upload + run the grouped launch `runs` times; returns the gradients after every run and the launch meta"""
     lib = L.lib()
     monkeypatch.setenv("MI_WG_FIXUP", "1" if fixup else "0")
+    monkeypatch.setenv("MI_WG_MULTI", multi)  # (default "0": the fix-up form keeps one grid per tile configuration - like with like, bit for bit)
     gws = [l["g0"].clone().to(DEV) for l in layers]
     descs = _descs(layers, gws)
     meta = L.mi_wgrad_group()
@@ -131,6 +132,25 @@ def test_fixup_single_split_and_tiny_layers(monkeypatch):
     for r in range(2):
         for s, a, b in zip(specs, ref[0], got[r]):
             assert torch.equal(a, b), (s, r)
+
+
+def test_mixed_grid_equals_one_grid_per_configuration(monkeypatch):
+    """MI_WG_MULTI (round 6: the 1x1 layers of a plan in ONE grid whatever their tile widths, wgrad2_multi_kernel; 4: the 3x3
+    layers' 256-thread configurations too) against one grid per tile configuration: fewer groups, the same gradients up to
+    the split-K summation order (the pooled slot count changes the splits), and both equal to the fp64 reference"""
+    layers = [_layer(*s, seed=300 + i) for i, s in enumerate(YOLOX_LAYERS)]
+    ref, meta0 = _run_group(layers, False, monkeypatch, multi="0")
+    for mode in ("3", "4"):                             # (3: forced for this 11-layer plan; the default needs >= 16 1x1 layers)
+        got, meta1 = _run_group(layers, False, monkeypatch, multi=mode)
+        assert meta1.ngroups < meta0.ngroups
+        assert any(meta1.g[i].cfg[0] == 1 and meta1.g[i].cfg[1] == 0 for i in range(meta1.ngroups))
+        for l, s, a, b in zip(layers, YOLOX_LAYERS, ref[0], got[0]):
+            xr = l["x"][..., :l["Cin"]].float().permute(0, 3, 1, 2).cpu()
+            dyr = l["dy"][..., :l["Cout"]].float().permute(0, 3, 1, 2).cpu()
+            w = torch.zeros(l["Cout"], l["Cin"], l["k"], l["k"], requires_grad=True)
+            torch.nn.functional.conv2d(xr, w, stride=l["stride"], padding=l["k"] // 2).backward(dyr)
+            assert float((b - w.grad).norm() / w.grad.norm()) < 2e-3, (s, mode)
+            assert float((a - b).abs().max()) <= 1e-5 * float(w.grad.abs().max()) + 1e-7, (s, mode)   # (fp32 sums in another order)
 
 
 def test_fixup_in_the_captured_step(monkeypatch):

@@ -474,6 +474,7 @@ def test_wgrad_fixup_plan_is_opt_in(monkeypatch):
     from yolov7_d2_amd.plan import Plan
     model, _ = _model()
     metas = {}
+    monkeypatch.setenv("MI_WG_MULTI", "0")     # (the fix-up form keeps one grid per tile configuration: compare like with like)
     for mode in ("0", "1"):
         monkeypatch.setenv("MI_WG_FIXUP", mode)
         ps = _PlanState(model, 2, 640, 640, True, materialize=False)

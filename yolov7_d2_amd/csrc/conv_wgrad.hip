@@ -535,6 +535,28 @@ __global__ __launch_bounds__(WCO* WCI * 64, 2) void wgrad2_group_kernel(const Wg
   const Wg2K p = jobs[j];
   wgrad2_body<NT, MI, NJ, WCO, WCI, TP>(p, b - starts[j]);
 }
+// MI_WG_MULTI (default 1): every 1x1 layer of the step in ONE grid, whatever its tile widths - the job carries them (Wg2K.pad_ =
+// 16 MI + NJ) and the block branches to that instantiation of the body.  One launch (its ~11 us of fixed cost once) and one
+// pool of resident slots for the split choice instead of up to nine grids of one tile configuration each.
+template <int TP>
+__global__ __launch_bounds__(256, 2) void wgrad2_multi_kernel(const Wg2K* __restrict__ jobs, const int* __restrict__ starts, int njobs) {
+  const int b = blockIdx.x;
+  int j = 0;
+  while (j + 1 < njobs && starts[j + 1] <= b) ++j;
+  const Wg2K p = jobs[j];
+  const int bid = b - starts[j];
+  switch (p.pad_) {
+    case 0x11: wgrad2_body<1, 1, 1, 2, 2, TP>(p, bid); break;
+    case 0x12: wgrad2_body<1, 1, 2, 2, 2, TP>(p, bid); break;
+    case 0x14: wgrad2_body<1, 1, 4, 2, 2, TP>(p, bid); break;
+    case 0x21: wgrad2_body<1, 2, 1, 2, 2, TP>(p, bid); break;
+    case 0x22: wgrad2_body<1, 2, 2, 2, 2, TP>(p, bid); break;
+    case 0x24: wgrad2_body<1, 2, 4, 2, 2, TP>(p, bid); break;
+    case 0x41: wgrad2_body<1, 4, 1, 2, 2, TP>(p, bid); break;
+    case 0x42: wgrad2_body<1, 4, 2, 2, 2, TP>(p, bid); break;
+    default: wgrad2_body<1, 4, 4, 2, 2, TP>(p, bid); break;
+  }
+}
 // the same grid with the split-K reduction inside (wg_fixup): every job of the group carries fix = 1
 template <int NT, int MI, int NJ, int WCO, int WCI, int TP>
 __global__ __launch_bounds__(WCO* WCI * 64, 2) void wgrad2_group_fix_kernel(const Wg2K* __restrict__ jobs,
@@ -736,6 +758,20 @@ __global__ __launch_bounds__(WCO* WCI * 64, 2) void wgrad3_group_kernel(const Wg
   wgrad3_body<NT, MI, NJ, WCO, WCI, TP>(p, b - starts[j]);
 }
 // the same grid with the split-K reduction inside (wg_fixup): every job of the group carries fix = 1
+// (MI_WG_MULTI=2, see wgrad2_multi_kernel: the 3x3 layers' three 256-thread tile configurations in one grid; pad_ = 16 MI + WCO)
+template <int TP>
+__global__ __launch_bounds__(256, 2) void wgrad3_multi_kernel(const Wg2K* __restrict__ jobs, const int* __restrict__ starts, int njobs) {
+  const int b = blockIdx.x;
+  int j = 0;
+  while (j + 1 < njobs && starts[j + 1] <= b) ++j;
+  const Wg2K p = jobs[j];
+  const int bid = b - starts[j];
+  switch (p.pad_) {
+    case 0x41: wgrad3_body<9, 4, 1, 1, 4, TP>(p, bid); break;
+    case 0x22: wgrad3_body<9, 2, 1, 2, 2, TP>(p, bid); break;
+    default: wgrad3_body<9, 1, 1, 2, 2, TP>(p, bid); break;
+  }
+}
 template <int NT, int MI, int NJ, int WCO, int WCI, int TP>
 __global__ __launch_bounds__(WCO* WCI * 64, 2) void wgrad3_group_fix_kernel(const Wg2K* __restrict__ jobs,
                                                                              const int* __restrict__ starts, int njobs) {
@@ -1165,6 +1201,29 @@ extern "C" int mi_conv2d_wgrad(const mi_wgrad_desc* d, mi_stream_t st) {
 // a YOLOX step collapse into one grid per tile configuration plus one reduce grid (thousands of blocks, no
 // per-layer ramp-up / tail, no per-layer launch latency).
 static int wg_cfg_id(const Wg2Cfg& c) { return ((((c.NT * 8 + c.MI) * 8 + c.NJ) * 8 + c.WCO) * 8 + c.WCI) * 256 + c.TP; }
+// MI_WG_MULTI: 1 (default) the 1x1 layers of a grouped plan share ONE grid whatever their tile widths (same box: 5.292 -> 5.266
+// ms per YOLOX-s step); 2: the 3x3 layers' three 256-thread configurations too (measured: 5.29 -> 5.44 ms, a loss - every block
+// of that grid takes the largest configuration's LDS and registers, and its ranges are as long as the cost model is wrong);
+// 0: one grid per tile configuration (round 5).  Read per plan.
+static int g_wg_multi_ok = 1;   // (set per plan: a mixed grid only for plans with many 1x1 layers, see mi_conv2d_wgrad_group_plan)
+static int wg_multi() { return g_wg_multi_ok ? wg_env("MI_WG_MULTI", 1) : 0; }
+static bool wg_is_multi(const Wg2Cfg& c) {
+  if (wg_multi() < 1 || wg_fixup_on()) return false;
+  if (c.NT == 1) return c.WCO == 2 && c.WCI == 2 && !wg_use_v3(1);
+  return (wg_multi() == 2 || wg_multi() == 4) && c.NT == 9 && wg_use_v3(9) && c.NJ == 1 && c.WCO * c.WCI == 4 &&
+         ((c.MI == 4 && c.WCO == 1) || (c.MI <= 2 && c.WCO == 2));
+}
+// launch group of a configuration: the 1x1 layers share one (MI_WG_MULTI=1), everything else one per tile configuration
+static int wg_gid(const Wg2Cfg& c) {
+  if (!wg_is_multi(c)) return wg_cfg_id(c);
+  Wg2Cfg t = c;
+  t.MI = 0; t.NJ = 0;
+  if (c.NT == 9) { t.WCO = 0; t.WCI = 0; }
+  return wg_cfg_id(t);
+}
+// relative time of one pixel-tile step of a configuration (profiles/r06_wgrad_xcd_rect.txt (6): 0.96 us for 1 x 1 fragments per
+// wave, 1.77 for 4 x 4): blocks of a mixed grid get pixel ranges of about equal duration
+static double wg_step_cost(const Wg2Cfg& c) { return 0.9 + 0.055 * c.NT * c.MI * c.NJ; }
 
 extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, void* ws_base, void* table_host,
                                           int64_t table_cap, mi_wgrad_group* meta) {
@@ -1174,6 +1233,14 @@ extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, voi
   std::vector<Wg2Cfg> cs(n);
   std::vector<size_t> ldss(n), wss(n);
   size_t ws_off = 0;
+  // the mixed 1x1 grid (MI_WG_MULTI) pays for the whole-step plans (YOLOX-s: 45 1x1 layers in five to nine configurations:
+  // -0.5 .. -0.75 % step time); the per-layer / per-block groups of the eager trees hold 4 - 10 jobs of one or two
+  // configurations and measured no gain (DETR-R50 346.4 -> 344.4 images/s): those keep one grid per configuration
+  {
+    int n1 = 0;
+    for (int i = 0; i < n; ++i) n1 += descs[i].ntaps == 1;
+    g_wg_multi_ok = n1 >= 16 || wg_env("MI_WG_MULTI", 1) >= 3;     // (3: force, for tests of small groups)
+  }
   // pass 1: tile configuration + tile counts per layer
   for (int i = 0; i < n; ++i) {
     mi_wgrad_desc t = descs[i];
@@ -1194,15 +1261,26 @@ extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, voi
     if (Tsel[i]) continue;
     long units = 0;
     size_t lds = 0;
+    const bool multi = wg_is_multi(cs[i]);
+    // (a mixed grid: T counts steps of the cheapest configuration; job j runs T / cost_j of its own)
+    double cmin = 1e30;
     for (int j = 0; j < n; ++j)
-      if (wg_cfg_id(cs[j]) == wg_cfg_id(cs[i])) {
+      if (wg_gid(cs[j]) == wg_gid(cs[i]) && wg_step_cost(cs[j]) < cmin) cmin = wg_step_cost(cs[j]);
+    auto Tj = [&](int j, long T) -> long {
+      if (!multi) return T;
+      long t = (long)((double)T * cmin / wg_step_cost(cs[j]) + 0.5);
+      return t < 4 ? 4 : t;
+    };
+    for (int j = 0; j < n; ++j)
+      if (wg_gid(cs[j]) == wg_gid(cs[i])) {
         units += (long)ks[j].ntiles * ks[j].nco * ks[j].nci;
         if (ldss[j] > lds) lds = ldss[j];
       }
-    auto blocks_for = [&](long T) {
+    auto blocks_for = [&](long T0) {
       long b = 0;
       for (int j = 0; j < n; ++j)
-        if (wg_cfg_id(cs[j]) == wg_cfg_id(cs[i])) {
+        if (wg_gid(cs[j]) == wg_gid(cs[i])) {
+          const long T = Tj(j, T0);
           long split = (ks[j].ntiles + T - 1) / T;
           if (split < 1) split = 1;
           const long tps = (ks[j].ntiles + split - 1) / split;
@@ -1224,10 +1302,19 @@ extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, voi
       const long slots = 256 * per_cu;
       T = (units + slots - 1) / slots;
       if (T < 4) T = 4;
-      while (blocks_for(T) > slots && T < (1 << 20)) ++T;   // per-layer rounding: first T whose grid fits
+      // per-layer rounding: first T whose grid fits.  (Past the longest layer's tile count every job is one split and the
+      // grid no longer shrinks: a group with more (cout, cin) pairs than slots - wide models in one mixed grid - stops there
+      // instead of counting to 2^20.)
+      long tmax = 4;
+      for (int j = 0; j < n; ++j)
+        if (wg_gid(cs[j]) == wg_gid(cs[i])) {
+          const long need = (long)((double)ks[j].ntiles * wg_step_cost(cs[j]) / cmin) + 2;
+          if (need > tmax) tmax = need;
+        }
+      while (blocks_for(T) > slots && T < tmax) ++T;
     }
     for (int j = 0; j < n; ++j)
-      if (wg_cfg_id(cs[j]) == wg_cfg_id(cs[i])) Tsel[j] = T;
+      if (wg_gid(cs[j]) == wg_gid(cs[i])) Tsel[j] = Tj(j, T);
   }
   for (int i = 0; i < n; ++i) {
     const long T = Tsel[i];
@@ -1279,15 +1366,17 @@ extern "C" int mi_conv2d_wgrad_group_plan(const mi_wgrad_desc* descs, int n, voi
     auto& g = meta->g[meta->ngroups++];
     g.cfg[0] = cs[i].NT; g.cfg[1] = cs[i].MI; g.cfg[2] = cs[i].NJ; g.cfg[3] = cs[i].WCO; g.cfg[4] = cs[i].WCI;
     g.cfg[5] = cs[i].TP;
+    if (wg_is_multi(cs[i])) g.cfg[1] = g.cfg[2] = 0;       // (a mixed group: wgrad2_multi_kernel / wgrad3_multi_kernel)
     std::vector<Wg2K> jobs;
     std::vector<int> starts;
     int blocks = 0;
     size_t lds = 0;
     const long job_off = (long)off;      // (what the put() below returns)
     for (int j = i; j < n; ++j)
-      if (!done[j] && wg_cfg_id(cs[j]) == wg_cfg_id(cs[i])) {
+      if (!done[j] && wg_gid(cs[j]) == wg_gid(cs[i])) {
         done[j] = 1;
         starts.push_back(blocks);
+        ks[j].pad_ = cs[j].NT == 9 ? cs[j].MI * 16 + cs[j].WCO : cs[j].MI * 16 + cs[j].NJ;
         if (fix) {
           ks[j].fix = 1;
           ks[j].cnt_rel = (long long)cnt_off[j] - (long long)job_off;
@@ -1384,6 +1473,34 @@ extern "C" int mi_conv2d_wgrad_group_run(const mi_wgrad_group* meta, const void*
     rc = wg_group_launch<NTv, MIv, NJv, WCOv, WCIv, TPv>(jobs, starts, g.njobs, g.nblocks, (size_t)g.lds_bytes, s, g.fixup == 1);
     MI_WG_ALL
 #undef MI_WG
+    if (g.cfg[0] == 1 && g.cfg[1] == 0 && g.cfg[2] == 0 && g.fixup != 1) {
+      static bool attr_done = false;
+      if (!attr_done) {
+        hipFuncSetAttribute((const void*)wgrad2_multi_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)wgrad2_multi_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+      }
+      if (g.cfg[5] == 64)
+        hipLaunchKernelGGL(wgrad2_multi_kernel<64>, dim3((unsigned)g.nblocks), dim3(256), (size_t)g.lds_bytes, s, jobs, starts, g.njobs);
+      else
+        hipLaunchKernelGGL(wgrad2_multi_kernel<128>, dim3((unsigned)g.nblocks), dim3(256), (size_t)g.lds_bytes, s, jobs, starts, g.njobs);
+      MI_CHECK_LAUNCH("conv_wgrad_multi");
+      rc = MI_OK;
+    }
+    if (g.cfg[0] == 9 && g.cfg[1] == 0 && g.cfg[2] == 0 && g.fixup != 1) {
+      static bool attr_done = false;
+      if (!attr_done) {
+        hipFuncSetAttribute((const void*)wgrad3_multi_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)wgrad3_multi_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+      }
+      if (g.cfg[5] == 64)
+        hipLaunchKernelGGL(wgrad3_multi_kernel<64>, dim3((unsigned)g.nblocks), dim3(256), (size_t)g.lds_bytes, s, jobs, starts, g.njobs);
+      else
+        hipLaunchKernelGGL(wgrad3_multi_kernel<128>, dim3((unsigned)g.nblocks), dim3(256), (size_t)g.lds_bytes, s, jobs, starts, g.njobs);
+      MI_CHECK_LAUNCH("conv_wgrad3_multi");
+      rc = MI_OK;
+    }
     if (rc == MI_EINVAL) MI_FAIL(MI_EINVAL, "wgrad_group: no kernel for group %d", gi);
     if (rc) return rc;
   }
