@@ -1163,13 +1163,16 @@ class Plan:
                     res += [g] if g is not None else part
                 return res
             if cs[0].op in BN_KIND:
-                # at most one bandwidth-sized job (> 512 blocks) per launch: two of them together were slower than apart
+                # bandwidth-sized jobs (> 512 blocks) per shared launch: round 3 measured two of them together slower than apart
+                # and kept one; re-measured at the end of round 6 (same box, three interleaved rounds): two 5.385 ms, one 5.411,
+                # all 5.391 - two it is (the head's level-0 cls / reg tower BatchNorms share their launch)
                 def bn_blocks(c):
                     npix, Cc = (c.l[1], c.i[3]) if cs[0].op == L.OP["BN_ACT_FWD"] else (c.l[0], c.i[3] if cs[0].op == L.OP["BN_BWD_REDUCE"] else c.i[5])
                     return npix * (Cc // 8) / 2048
                 big = [c for c in cs if bn_blocks(c) > 512]
                 small = [c for c in cs if bn_blocks(c) <= 512]
-                parts = [small + big[:1]] + [[c] for c in big[1:]]
+                nbig = int(os.environ.get("MI_BN_GROUP_BIG", "2"))
+                parts = [small + big[:nbig]] + [[c] for c in big[nbig:]]
                 res = []
                 for part in parts:
                     part = sorted(part, key=lambda c: order[id(c)])
